@@ -1,0 +1,571 @@
+// K9/K10 + dense optimizer: the elementwise / column-reduction work around the MLP GEMMs
+// (bias + BatchNorm(train) + ReLU, Dice), sigmoid cross-entropy, L2 terms, ApplyAdam over the
+// flat dense-parameter buffer.  HBM/L2-bound; fuses per layer what the reference issues as
+// BiasAdd + FusedBatchNorm/moments + Relu (layers/dnn.py:57-79).
+//
+// Reference call sites: layers/dnn.py:50-87, layers/keras/blocks.py:84-110,
+// layers/keras/activation.py:47-70, builders/loss_builder.py:35-39, compat/regularizers.py:76-108,
+// compat/optimizers.py:412-416 (apply_gradients -> tf.train.AdamOptimizer._apply_dense).
+#include "er_common.h"
+
+namespace er {
+
+// ------------------------------------------------------------------------------------------------
+// column statistics in row chunks.  block = 64 columns x 4 row lanes; grid = (col_blocks, chunks)
+// ------------------------------------------------------------------------------------------------
+constexpr int kColsPerBlock = 64;
+constexpr int kRowLanes = kBlock / kColsPerBlock;  // 4
+constexpr int kMaxChunks = 256;
+
+inline int choose_chunks(int B, int N) {
+  const int col_blocks = static_cast<int>(ceil_div(N, kColsPerBlock));
+  int chunks = 1024 / col_blocks;
+  const int max_by_rows = static_cast<int>(ceil_div(B, 32));
+  if (chunks > max_by_rows) chunks = max_by_rows;
+  if (chunks > kMaxChunks) chunks = kMaxChunks;
+  if (chunks < 1) chunks = 1;
+  return chunks;
+}
+
+struct Welford {
+  float n, mean, m2;
+};
+__device__ __forceinline__ Welford wf_merge(const Welford& a, const Welford& b) {
+  if (b.n == 0.f) return a;
+  if (a.n == 0.f) return b;
+  const float n = a.n + b.n;
+  const float delta = b.mean - a.mean;
+  Welford r;
+  r.n = n;
+  r.mean = a.mean + delta * (b.n / n);
+  r.m2 = a.m2 + b.m2 + delta * delta * (a.n * b.n / n);
+  return r;
+}
+
+// partial[(chunk*N + c)*3 + {0,1,2}] = (count, mean, M2) of z = x + bias over the chunk's rows
+__global__ void __launch_bounds__(kBlock)
+bn_stats_partial_kernel(const float* __restrict__ x, const float* __restrict__ bias, int B, int N, int chunks,
+                        float* __restrict__ partial) {
+  __shared__ Welford sm[kRowLanes][kColsPerBlock];
+  const int cl = threadIdx.x % kColsPerBlock;
+  const int rl = threadIdx.x / kColsPerBlock;
+  const int c = blockIdx.x * kColsPerBlock + cl;
+  const int chunk = blockIdx.y;
+  const int rows_per_chunk = static_cast<int>(ceil_div(B, chunks));
+  const int r0 = chunk * rows_per_chunk;
+  const int r1 = (r0 + rows_per_chunk < B) ? r0 + rows_per_chunk : B;
+  Welford w{0.f, 0.f, 0.f};
+  if (c < N) {
+    const float bv = bias ? bias[c] : 0.f;
+    for (int r = r0 + rl; r < r1; r += kRowLanes) {
+      const float v = x[static_cast<int64_t>(r) * N + c] + bv;
+      w.n += 1.f;
+      const float d = v - w.mean;
+      w.mean += d / w.n;
+      w.m2 += d * (v - w.mean);
+    }
+  }
+  sm[rl][cl] = w;
+  __syncthreads();
+  if (rl == 0 && c < N) {
+    Welford t = wf_merge(wf_merge(sm[0][cl], sm[1][cl]), wf_merge(sm[2][cl], sm[3][cl]));
+    float* p = partial + (static_cast<int64_t>(chunk) * N + c) * 3;
+    p[0] = t.n; p[1] = t.mean; p[2] = t.m2;
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+bn_finalize_kernel(const float* __restrict__ partial, int B, int N, int chunks, float eps, float momentum,
+                   float* __restrict__ moving_mean, float* __restrict__ moving_var, float* __restrict__ save_mean,
+                   float* __restrict__ save_invstd) {
+  const int c = blockIdx.x * kBlock + threadIdx.x;
+  if (c >= N) return;
+  Welford t{0.f, 0.f, 0.f};
+  for (int k = 0; k < chunks; ++k) {
+    const float* p = partial + (static_cast<int64_t>(k) * N + c) * 3;
+    t = wf_merge(t, Welford{p[0], p[1], p[2]});
+  }
+  const float mean = t.mean;
+  const float var = t.m2 / static_cast<float>(B);  // biased, as tf.nn.moments
+  save_mean[c] = mean;
+  save_invstd[c] = 1.f / sqrtf(var + eps);
+  if (moving_mean) {
+    // assign_moving_average: v -= (v - value) * (1 - momentum)
+    const float om = 1.f - momentum;
+    moving_mean[c] = moving_mean[c] - (moving_mean[c] - mean) * om;
+    moving_var[c] = moving_var[c] - (moving_var[c] - var) * om;
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ bias, const float* __restrict__ gamma,
+                const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ invstd,
+                int64_t n, int N, int use_bn, int act, float* __restrict__ y) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const int c = static_cast<int>(i % N);
+  float v = x[i] + (bias ? bias[c] : 0.f);
+  if (use_bn) {
+    v = (v - mean[c]) * invstd[c];
+    v = v * (gamma ? gamma[c] : 1.f) + (beta ? beta[c] : 0.f);
+  }
+  if (act == ER_ACT_RELU) v = v > 0.f ? v : 0.f;
+  y[i] = v;
+}
+
+// backward partials: p[(chunk*N + c)*2 + {0,1}] = (sum g, sum g*xhat), g = dy * act'(y)
+__global__ void __launch_bounds__(kBlock)
+bn_bwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ bias, const float* __restrict__ y,
+                      const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ dy,
+                      int B, int N, int chunks, int use_bn, int act, float* __restrict__ partial) {
+  __shared__ float sm[2][kRowLanes][kColsPerBlock];
+  const int cl = threadIdx.x % kColsPerBlock;
+  const int rl = threadIdx.x / kColsPerBlock;
+  const int c = blockIdx.x * kColsPerBlock + cl;
+  const int chunk = blockIdx.y;
+  const int rows_per_chunk = static_cast<int>(ceil_div(B, chunks));
+  const int r0 = chunk * rows_per_chunk;
+  const int r1 = (r0 + rows_per_chunk < B) ? r0 + rows_per_chunk : B;
+  float sg = 0.f, sgx = 0.f;
+  if (c < N) {
+    const float bv = bias ? bias[c] : 0.f;
+    const float mu = use_bn ? mean[c] : 0.f;
+    const float is = use_bn ? invstd[c] : 0.f;
+    for (int r = r0 + rl; r < r1; r += kRowLanes) {
+      const int64_t i = static_cast<int64_t>(r) * N + c;
+      float g = dy[i];
+      if (act == ER_ACT_RELU && !(y[i] > 0.f)) g = 0.f;
+      sg = sg + g;
+      if (use_bn) sgx = sgx + g * ((x[i] + bv - mu) * is);
+    }
+  }
+  sm[0][rl][cl] = sg;
+  sm[1][rl][cl] = sgx;
+  __syncthreads();
+  if (rl == 0 && c < N) {
+    float* p = partial + (static_cast<int64_t>(chunk) * N + c) * 2;
+    p[0] = (sm[0][0][cl] + sm[0][1][cl]) + (sm[0][2][cl] + sm[0][3][cl]);
+    p[1] = (sm[1][0][cl] + sm[1][1][cl]) + (sm[1][2][cl] + sm[1][3][cl]);
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+bn_bwd_finalize_kernel(const float* __restrict__ partial, int N, int chunks, int use_bn, float* __restrict__ sum_g,
+                       float* __restrict__ sum_gx, float* __restrict__ dbias, float* __restrict__ dgamma,
+                       float* __restrict__ dbeta) {
+  const int c = blockIdx.x * kBlock + threadIdx.x;
+  if (c >= N) return;
+  float a = 0.f, b = 0.f;
+  for (int k = 0; k < chunks; ++k) {
+    const float* p = partial + (static_cast<int64_t>(k) * N + c) * 2;
+    a = a + p[0];
+    b = b + p[1];
+  }
+  sum_g[c] = a;
+  sum_gx[c] = b;
+  if (use_bn) {
+    if (dbeta) dbeta[c] = a;
+    if (dgamma) dgamma[c] = b;
+    if (dbias) dbias[c] = 0.f;  // BatchNorm removes the column mean: d(loss)/d(bias) == 0
+  } else {
+    if (dbias) dbias[c] = a;
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ bias, const float* __restrict__ gamma,
+                    const float* __restrict__ y, const float* __restrict__ mean, const float* __restrict__ invstd,
+                    const float* __restrict__ dy, const float* __restrict__ sum_g, const float* __restrict__ sum_gx,
+                    int64_t n, int B, int N, int use_bn, int act, float* __restrict__ dx) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const int c = static_cast<int>(i % N);
+  float g = dy[i];
+  if (act == ER_ACT_RELU && !(y[i] > 0.f)) g = 0.f;
+  if (use_bn) {
+    const float xh = (x[i] + (bias ? bias[c] : 0.f) - mean[c]) * invstd[c];
+    const float invB = 1.f / static_cast<float>(B);
+    const float ga = gamma ? gamma[c] : 1.f;
+    g = ga * invstd[c] * (g - sum_g[c] * invB - xh * (sum_gx[c] * invB));
+  }
+  dx[i] = g;
+}
+
+// ------------------------------------------------------------------------------------------------
+// generic column sum (rows strided over chunks, deterministic)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+colsum_partial_kernel(const float* __restrict__ x, int rows, int cols, int x_stride, int chunks,
+                      float* __restrict__ partial) {
+  __shared__ float sm[kRowLanes][kColsPerBlock];
+  const int cl = threadIdx.x % kColsPerBlock;
+  const int rl = threadIdx.x / kColsPerBlock;
+  const int c = blockIdx.x * kColsPerBlock + cl;
+  const int chunk = blockIdx.y;
+  const int rows_per_chunk = static_cast<int>(ceil_div(rows, chunks));
+  const int r0 = chunk * rows_per_chunk;
+  const int r1 = (r0 + rows_per_chunk < rows) ? r0 + rows_per_chunk : rows;
+  float s = 0.f;
+  if (c < cols)
+    for (int r = r0 + rl; r < r1; r += kRowLanes) s = s + x[static_cast<int64_t>(r) * x_stride + c];
+  sm[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && c < cols)
+    partial[static_cast<int64_t>(chunk) * cols + c] = (sm[0][cl] + sm[1][cl]) + (sm[2][cl] + sm[3][cl]);
+}
+
+__global__ void __launch_bounds__(kBlock)
+colsum_finalize_kernel(const float* __restrict__ partial, int cols, int chunks, float* __restrict__ out) {
+  const int c = blockIdx.x * kBlock + threadIdx.x;
+  if (c >= cols) return;
+  float a = 0.f;
+  for (int k = 0; k < chunks; ++k) a = a + partial[static_cast<int64_t>(k) * cols + c];
+  out[c] = a;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Dice
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sigmoidf_(float z) { return 1.f / (1.f + expf(-z)); }
+
+__global__ void __launch_bounds__(kBlock)
+dice_apply_kernel(const float* __restrict__ x, const float* __restrict__ alpha, const float* __restrict__ mean,
+                  const float* __restrict__ invstd, int64_t n, int N, float* __restrict__ y) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const int c = static_cast<int>(i % N);
+  const float v = x[i];
+  const float p = sigmoidf_((v - mean[c]) * invstd[c]);
+  y[i] = alpha[c] * (1.f - p) * v + p * v;
+}
+
+// partials for dice backward: (sum q, sum q*xhat, sum dalpha) with q = dy * x*(1-alpha) * p*(1-p)
+__global__ void __launch_bounds__(kBlock)
+dice_bwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ alpha, const float* __restrict__ mean,
+                        const float* __restrict__ invstd, const float* __restrict__ dy, int B, int N, int chunks,
+                        float* __restrict__ partial) {
+  __shared__ float sm[3][kRowLanes][kColsPerBlock];
+  const int cl = threadIdx.x % kColsPerBlock;
+  const int rl = threadIdx.x / kColsPerBlock;
+  const int c = blockIdx.x * kColsPerBlock + cl;
+  const int chunk = blockIdx.y;
+  const int rows_per_chunk = static_cast<int>(ceil_div(B, chunks));
+  const int r0 = chunk * rows_per_chunk;
+  const int r1 = (r0 + rows_per_chunk < B) ? r0 + rows_per_chunk : B;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  if (c < N) {
+    const float al = alpha[c], mu = mean[c], is = invstd[c];
+    for (int r = r0 + rl; r < r1; r += kRowLanes) {
+      const int64_t i = static_cast<int64_t>(r) * N + c;
+      const float v = x[i];
+      const float xh = (v - mu) * is;
+      const float p = sigmoidf_(xh);
+      const float q = dy[i] * v * (1.f - al) * p * (1.f - p);
+      s0 = s0 + q;
+      s1 = s1 + q * xh;
+      s2 = s2 + dy[i] * (1.f - p) * v;
+    }
+  }
+  sm[0][rl][cl] = s0; sm[1][rl][cl] = s1; sm[2][rl][cl] = s2;
+  __syncthreads();
+  if (rl == 0 && c < N) {
+    float* p = partial + (static_cast<int64_t>(chunk) * N + c) * 3;
+    for (int k = 0; k < 3; ++k) p[k] = (sm[k][0][cl] + sm[k][1][cl]) + (sm[k][2][cl] + sm[k][3][cl]);
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+dice_bwd_finalize_kernel(const float* __restrict__ partial, int N, int chunks, float* __restrict__ sums,
+                         float* __restrict__ dalpha) {
+  const int c = blockIdx.x * kBlock + threadIdx.x;
+  if (c >= N) return;
+  float a = 0.f, b = 0.f, d = 0.f;
+  for (int k = 0; k < chunks; ++k) {
+    const float* p = partial + (static_cast<int64_t>(k) * N + c) * 3;
+    a = a + p[0]; b = b + p[1]; d = d + p[2];
+  }
+  sums[c] = a;
+  sums[N + c] = b;
+  if (dalpha) dalpha[c] = d;
+}
+
+__global__ void __launch_bounds__(kBlock)
+dice_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ alpha, const float* __restrict__ mean,
+                      const float* __restrict__ invstd, const float* __restrict__ dy, const float* __restrict__ sums,
+                      int64_t n, int B, int N, float* __restrict__ dx) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const int c = static_cast<int>(i % N);
+  const float v = x[i];
+  const float xh = (v - mean[c]) * invstd[c];
+  const float p = sigmoidf_(xh);
+  const float al = alpha[c];
+  const float g = dy[i];
+  // y = v*(al + (1-al)*p): direct term + the path through p = sigmoid(BN(x))
+  const float direct = g * (al + (1.f - al) * p);
+  const float q = g * v * (1.f - al) * p * (1.f - p);  // d loss / d xhat
+  const float invB = 1.f / static_cast<float>(B);
+  const float through_bn = invstd[c] * (q - sums[c] * invB - xh * (sums[N + c] * invB));
+  dx[i] = direct + through_bn;
+}
+
+// ------------------------------------------------------------------------------------------------
+// loss + scalar reductions (single block, fixed tree -> deterministic)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+sigmoid_ce_kernel(const float* __restrict__ z, const float* __restrict__ y, const float* __restrict__ w, int B,
+                  float loss_scale, float* __restrict__ loss_out, float* __restrict__ dz, float* __restrict__ probs) {
+  __shared__ float red[4];
+  __shared__ float s_nz;
+  float cnt = 0.f;
+  for (int i = threadIdx.x; i < B; i += kBlock) cnt += (w ? (w[i] != 0.f ? 1.f : 0.f) : 1.f);
+  const float tot = block_sum_256(cnt, red);
+  if (threadIdx.x == 0) s_nz = tot > 0.f ? tot : 1.f;
+  __syncthreads();
+  const float nz = s_nz;
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < B; i += kBlock) {
+    const float zi = z[i], yi = y[i];
+    const float wi = w ? w[i] : 1.f;
+    // tf.nn.sigmoid_cross_entropy_with_logits: max(z,0) - z*y + log1p(exp(-|z|))
+    const float ce = fmaxf(zi, 0.f) - zi * yi + log1pf(expf(-fabsf(zi)));
+    acc = acc + wi * ce;
+    const float p = 1.f / (1.f + expf(-zi));
+    if (probs) probs[i] = p;
+    if (dz) dz[i] = loss_scale * wi * (p - yi) / nz;
+  }
+  const float s = block_sum_256(acc, red);
+  if (threadIdx.x == 0 && loss_out) loss_out[0] = loss_scale * s / nz;
+}
+
+__global__ void __launch_bounds__(kBlock)
+reduce_sum_kernel(const float* __restrict__ p, int n, float scale, float* __restrict__ out, int accumulate) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += kBlock) acc = acc + p[i];
+  const float s = block_sum_256(acc, red);
+  if (threadIdx.x == 0) out[0] = accumulate ? (out[0] + scale * s) : scale * s;
+}
+
+__global__ void __launch_bounds__(kBlock)
+l2_loss_kernel(const float* __restrict__ w, const float* __restrict__ coef, int64_t n, float* __restrict__ out,
+               int accumulate) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += kBlock) {
+    const float c = coef[i];
+    if (c != 0.f) acc = acc + c * (0.5f * (w[i] * w[i]));
+  }
+  const float s = block_sum_256(acc, red);
+  if (threadIdx.x == 0) out[0] = accumulate ? (out[0] + s) : s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// dense-variable optimizer over the flat buffer
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+dense_opt_kernel(float* __restrict__ w, float* __restrict__ m, float* __restrict__ v, const float* __restrict__ grad,
+                 const float* __restrict__ l2coef, int64_t n, int opt_kind, const er_opt_hyper* __restrict__ hyper) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const er_opt_hyper h = *hyper;
+  float wi = w[i];
+  float g = grad[i] * h.grad_scale;
+  if (l2coef) {
+    const float c = l2coef[i];
+    if (c != 0.f) g = g + c * wi;
+  }
+  if (opt_kind == ER_OPT_ADAM || opt_kind == ER_OPT_LAZY_ADAM) {
+    // training_ops.apply_adam (dense): m += (g-m)*(1-b1); v += (g*g-v)*(1-b2); var -= m*alpha/(sqrt(v)+eps)
+    float mi = m[i], vi = v[i];
+    mi = mi + (g - mi) * h.one_minus_beta1;
+    vi = vi + (g * g - vi) * h.one_minus_beta2;
+    wi = wi - (mi * h.lr_t) / (sqrtf(vi) + h.eps);
+    m[i] = mi;
+    v[i] = vi;
+  } else if (opt_kind == ER_OPT_ADAGRAD) {
+    float vi = v[i] + g * g;
+    v[i] = vi;
+    wi = wi - (g * h.lr) / sqrtf(vi);
+  } else {
+    wi = wi - h.lr * g;
+  }
+  w[i] = wi;
+}
+
+inline int blocks_for(int64_t n) { return static_cast<int>(ceil_div(n, kBlock)); }
+
+// scratch for column-reduction partials: one buffer per stream would be the general answer; the
+// training loop is single-stream per process, so one lazily grown device buffer is used.
+static float* g_scratch = nullptr;
+static size_t g_scratch_floats = 0;
+int get_scratch(size_t floats, float** out) {
+  if (floats > g_scratch_floats) {
+    if (g_scratch) (void)hipFree(g_scratch);
+    size_t want = floats < (1u << 20) ? (1u << 20) : floats;
+    hipError_t e = hipMalloc(&g_scratch, want * sizeof(float));
+    if (e != hipSuccess) {
+      g_scratch = nullptr;
+      g_scratch_floats = 0;
+      set_error("scratch allocation of %zu floats failed: %s", want, hipGetErrorString(e));
+      return 1;
+    }
+    g_scratch_floats = want;
+  }
+  *out = g_scratch;
+  return 0;
+}
+
+}  // namespace er
+
+extern "C" {
+
+/* Pre-size the internal scratch (call once before hipGraph capture: allocation is not capturable). */
+int er_reserve_scratch(int64_t floats) {
+  float* p;
+  return er::get_scratch(static_cast<size_t>(floats), &p);
+}
+
+int er_bn_act_fwd(const float* x, const float* bias, const float* gamma, const float* beta, int32_t B, int32_t N,
+                  int use_bn, float eps, float momentum, float* moving_mean, float* moving_var, int act, float* y,
+                  float* save_mean, float* save_invstd, er_stream_t stream) {
+  ER_REQUIRE(x && y && B > 0 && N > 0, "er_bn_act_fwd: bad arguments");
+  hipStream_t s = er::as_stream(stream);
+  const int64_t n = static_cast<int64_t>(B) * N;
+  if (use_bn) {
+    ER_REQUIRE(save_mean && save_invstd, "er_bn_act_fwd: save_mean/save_invstd required with use_bn");
+    const int chunks = er::choose_chunks(B, N);
+    float* scratch;
+    if (er::get_scratch(static_cast<size_t>(chunks) * N * 3, &scratch)) return 1;
+    dim3 grid(static_cast<unsigned>(er::ceil_div(N, er::kColsPerBlock)), static_cast<unsigned>(chunks));
+    hipLaunchKernelGGL(er::bn_stats_partial_kernel, grid, dim3(er::kBlock), 0, s, x, bias, B, N, chunks, scratch);
+    ER_LAUNCH_CHECK();
+    hipLaunchKernelGGL(er::bn_finalize_kernel, dim3(er::blocks_for(N)), dim3(er::kBlock), 0, s, scratch, B, N, chunks,
+                       eps, momentum, moving_mean, moving_var, save_mean, save_invstd);
+    ER_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(er::bn_apply_kernel, dim3(er::blocks_for(n)), dim3(er::kBlock), 0, s, x, bias, gamma, beta,
+                     save_mean, save_invstd, n, N, use_bn, act, y);
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
+int er_bn_act_bwd(const float* x, const float* bias, const float* gamma, const float* y, const float* save_mean,
+                  const float* save_invstd, const float* dy, int32_t B, int32_t N, int use_bn, int act, float* dx,
+                  float* dbias, float* dgamma, float* dbeta, er_stream_t stream) {
+  ER_REQUIRE(x && y && dy && dx && B > 0 && N > 0, "er_bn_act_bwd: bad arguments");
+  hipStream_t s = er::as_stream(stream);
+  const int64_t n = static_cast<int64_t>(B) * N;
+  const int chunks = er::choose_chunks(B, N);
+  float* scratch;
+  if (er::get_scratch(static_cast<size_t>(chunks) * N * 2 + 2 * static_cast<size_t>(N), &scratch)) return 1;
+  float* sums = scratch + static_cast<size_t>(chunks) * N * 2;
+  dim3 grid(static_cast<unsigned>(er::ceil_div(N, er::kColsPerBlock)), static_cast<unsigned>(chunks));
+  hipLaunchKernelGGL(er::bn_bwd_partial_kernel, grid, dim3(er::kBlock), 0, s, x, bias, y, save_mean, save_invstd, dy, B,
+                     N, chunks, use_bn, act, scratch);
+  ER_LAUNCH_CHECK();
+  hipLaunchKernelGGL(er::bn_bwd_finalize_kernel, dim3(er::blocks_for(N)), dim3(er::kBlock), 0, s, scratch, N, chunks,
+                     use_bn, sums, sums + N, dbias, dgamma, dbeta);
+  ER_LAUNCH_CHECK();
+  hipLaunchKernelGGL(er::bn_bwd_apply_kernel, dim3(er::blocks_for(n)), dim3(er::kBlock), 0, s, x, bias, gamma, y,
+                     save_mean, save_invstd, dy, sums, sums + N, n, B, N, use_bn, act, dx);
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
+int er_colsum(const float* x, int32_t rows, int32_t cols, int32_t x_stride, float* out, er_stream_t stream) {
+  ER_REQUIRE(x && out && rows > 0 && cols > 0, "er_colsum: bad arguments");
+  hipStream_t s = er::as_stream(stream);
+  const int chunks = er::choose_chunks(rows, cols);
+  float* scratch;
+  if (er::get_scratch(static_cast<size_t>(chunks) * cols, &scratch)) return 1;
+  dim3 grid(static_cast<unsigned>(er::ceil_div(cols, er::kColsPerBlock)), static_cast<unsigned>(chunks));
+  hipLaunchKernelGGL(er::colsum_partial_kernel, grid, dim3(er::kBlock), 0, s, x, rows, cols, x_stride, chunks, scratch);
+  ER_LAUNCH_CHECK();
+  hipLaunchKernelGGL(er::colsum_finalize_kernel, dim3(er::blocks_for(cols)), dim3(er::kBlock), 0, s, scratch, cols,
+                     chunks, out);
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
+int er_dice_fwd(const float* x, const float* alpha, int32_t B, int32_t N, float eps, float momentum,
+                float* moving_mean, float* moving_var, float* y, float* save_mean, float* save_invstd,
+                er_stream_t stream) {
+  ER_REQUIRE(x && alpha && y && save_mean && save_invstd && B > 0 && N > 0, "er_dice_fwd: bad arguments");
+  hipStream_t s = er::as_stream(stream);
+  const int64_t n = static_cast<int64_t>(B) * N;
+  const int chunks = er::choose_chunks(B, N);
+  float* scratch;
+  if (er::get_scratch(static_cast<size_t>(chunks) * N * 3, &scratch)) return 1;
+  dim3 grid(static_cast<unsigned>(er::ceil_div(N, er::kColsPerBlock)), static_cast<unsigned>(chunks));
+  hipLaunchKernelGGL(er::bn_stats_partial_kernel, grid, dim3(er::kBlock), 0, s, x, static_cast<const float*>(nullptr), B,
+                     N, chunks, scratch);
+  ER_LAUNCH_CHECK();
+  hipLaunchKernelGGL(er::bn_finalize_kernel, dim3(er::blocks_for(N)), dim3(er::kBlock), 0, s, scratch, B, N, chunks, eps,
+                     momentum, moving_mean, moving_var, save_mean, save_invstd);
+  ER_LAUNCH_CHECK();
+  hipLaunchKernelGGL(er::dice_apply_kernel, dim3(er::blocks_for(n)), dim3(er::kBlock), 0, s, x, alpha, save_mean,
+                     save_invstd, n, N, y);
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
+int er_dice_bwd(const float* x, const float* alpha, const float* save_mean, const float* save_invstd, const float* dy,
+                int32_t B, int32_t N, float* dx, float* dalpha, er_stream_t stream) {
+  ER_REQUIRE(x && alpha && save_mean && save_invstd && dy && dx && B > 0 && N > 0, "er_dice_bwd: bad arguments");
+  hipStream_t s = er::as_stream(stream);
+  const int64_t n = static_cast<int64_t>(B) * N;
+  const int chunks = er::choose_chunks(B, N);
+  float* scratch;
+  if (er::get_scratch(static_cast<size_t>(chunks) * N * 3 + 2 * static_cast<size_t>(N), &scratch)) return 1;
+  float* sums = scratch + static_cast<size_t>(chunks) * N * 3;
+  dim3 grid(static_cast<unsigned>(er::ceil_div(N, er::kColsPerBlock)), static_cast<unsigned>(chunks));
+  hipLaunchKernelGGL(er::dice_bwd_partial_kernel, grid, dim3(er::kBlock), 0, s, x, alpha, save_mean, save_invstd, dy, B,
+                     N, chunks, scratch);
+  ER_LAUNCH_CHECK();
+  hipLaunchKernelGGL(er::dice_bwd_finalize_kernel, dim3(er::blocks_for(N)), dim3(er::kBlock), 0, s, scratch, N, chunks,
+                     sums, dalpha);
+  ER_LAUNCH_CHECK();
+  hipLaunchKernelGGL(er::dice_bwd_apply_kernel, dim3(er::blocks_for(n)), dim3(er::kBlock), 0, s, x, alpha, save_mean,
+                     save_invstd, dy, sums, n, B, N, dx);
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
+int er_sigmoid_ce_fwd_bwd(const float* logits, const float* labels, const float* weights, int32_t B,
+                          float loss_scale, float* loss_out, float* dlogits, float* probs_out, er_stream_t stream) {
+  ER_REQUIRE(logits && labels && B > 0, "er_sigmoid_ce_fwd_bwd: bad arguments");
+  hipLaunchKernelGGL(er::sigmoid_ce_kernel, dim3(1), dim3(er::kBlock), 0, er::as_stream(stream), logits, labels,
+                     weights, B, loss_scale, loss_out, dlogits, probs_out);
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
+int er_reduce_sum(const float* partials, int32_t n, float scale, float* out, int accumulate, er_stream_t stream) {
+  ER_REQUIRE(partials && out && n > 0, "er_reduce_sum: bad arguments");
+  hipLaunchKernelGGL(er::reduce_sum_kernel, dim3(1), dim3(er::kBlock), 0, er::as_stream(stream), partials, n, scale,
+                     out, accumulate);
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
+int er_l2_loss(const float* w, const float* coef, int64_t n, float* out, int accumulate, er_stream_t stream) {
+  ER_REQUIRE(w && coef && out && n > 0, "er_l2_loss: bad arguments");
+  hipLaunchKernelGGL(er::l2_loss_kernel, dim3(1), dim3(er::kBlock), 0, er::as_stream(stream), w, coef, n, out,
+                     accumulate);
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
+int er_dense_opt_step(float* w, float* m, float* v, const float* grad, const float* l2coef, int64_t n, int opt_kind,
+                      const er_opt_hyper* hyper, er_stream_t stream) {
+  ER_REQUIRE(w && grad && hyper && n > 0, "er_dense_opt_step: bad arguments");
+  if (opt_kind == ER_OPT_ADAM || opt_kind == ER_OPT_LAZY_ADAM) ER_REQUIRE(m && v, "er_dense_opt_step: Adam needs m, v");
+  if (opt_kind == ER_OPT_ADAGRAD) ER_REQUIRE(v, "er_dense_opt_step: Adagrad needs the accumulator in v");
+  hipLaunchKernelGGL(er::dense_opt_kernel, dim3(er::blocks_for(n)), dim3(er::kBlock), 0, er::as_stream(stream), w, m, v,
+                     grad, l2coef, n, opt_kind, hyper);
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,779 @@
+// K2/K3/K4: embedding lookup+combine forward, de-duplicated backward, row-wise optimizers.
+//
+// Replaces (reference, TF-op chains issued from Python):
+//   forward : feature_column_v2.py:3434-3462 (safe_embedding_lookup_sparse), compat/feature_column/
+//             feature_column.py:384-414 (reshape+concat), layers/input_layer.py:369-375 (L2 on outputs)
+//   backward: IndexedSlices gradient of the same chain + optimizer sparse apply
+//             (tf.train.AdamOptimizer._apply_sparse, compat/adam_s.py:185-213).
+//
+// MI355X design notes
+//   * all lookups of a model run in ONE launch: a block handles 256/G output rows of one lookup,
+//     G = lanes per row (dim/4 rounded up to a power of two, 128-bit loads: a D=16 row is one 64 B
+//     segment read by 4 lanes, 16 rows per wave instruction).  Outputs are written straight into
+//     the concatenated [B, sum(dim)] buffer - no concat pass.
+//   * backward is sort-based and deterministic: 32-bit keys (row inside the table group), stable
+//     radix sort (rocPRIM), then a two-level in-order segmented reduction; the head lane-group of
+//     every run applies the optimizer, so each touched row's var/m/v is read and written once.
+//   * TF's dense-decay Adam additionally streams every untouched row once per step
+//     (adam_decay_sweep_kernel): pure HBM streaming, float4, grid-stride, bitmap-skipped.
+//   * everything here is HBM/latency-bound integer+fp32 work; no MFMA on purpose.
+#include <cstring>
+#include <vector>
+
+#include <rocprim/rocprim.hpp>
+
+#include "er_common.h"
+
+namespace er {
+
+constexpr uint32_t kInvalidKey = 0xFFFFFFFFu;
+constexpr int kChunk = 32;  // positions per reduction piece
+
+__host__ __device__ __forceinline__ void lane_geom(int dim, int& V, int& G) {
+  V = (dim % 4 == 0) ? 4 : 1;
+  const int n = dim / V;
+  G = 1;
+  while (G < n) G <<= 1;
+}
+
+__device__ __forceinline__ int find_lookup(const int32_t* __restrict__ blk_start, int n, int bid) {
+  int lo = 0, hi = n;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (blk_start[mid] <= bid) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+struct Acc4 {
+  float x, y, z, w;
+};
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+emb_fwd_kernel(const er_lookup_desc* __restrict__ descs, const int32_t* __restrict__ blk_start, int n_lookups,
+               float* __restrict__ sumsq_partials) {
+  __shared__ float red[4];
+  const int l = find_lookup(blk_start, n_lookups, blockIdx.x);
+  const er_lookup_desc d = descs[l];
+  int V, G;
+  lane_geom(d.dim, V, G);
+  const int rows_per_block = kBlock / G;
+  const int r = (blockIdx.x - blk_start[l]) * rows_per_block + static_cast<int>(threadIdx.x) / G;
+  const int c = (static_cast<int>(threadIdx.x) % G) * V;
+  float ss = 0.f;
+  if (r < d.n_rows && c < d.dim) {
+    int64_t kb, ke;
+    if (d.offsets) {
+      kb = d.offsets[r];
+      ke = d.offsets[r + 1];
+    } else {
+      kb = r;
+      ke = r + 1;
+    }
+    const bool prune_nonpos = (d.weights != nullptr) && (d.combiner != ER_COMBINER_SUM);
+    Acc4 a{0.f, 0.f, 0.f, 0.f};
+    float wsum = 0.f, w2sum = 0.f;
+    for (int64_t k = kb; k < ke; ++k) {
+      const int64_t id = d.ids[k];
+      if (id < 0 || id >= d.rows) continue;
+      const float* row = d.table + id * d.dim + c;
+      if (d.weights) {
+        const float w = d.weights[k];
+        if (prune_nonpos && !(w > 0.f)) continue;
+        if (V == 4) {
+          const float4 e = *reinterpret_cast<const float4*>(row);
+          a.x = a.x + e.x * w; a.y = a.y + e.y * w; a.z = a.z + e.z * w; a.w = a.w + e.w * w;
+        } else {
+          a.x = a.x + row[0] * w;
+        }
+        wsum = wsum + w;
+        w2sum = w2sum + w * w;
+      } else {
+        if (V == 4) {
+          const float4 e = *reinterpret_cast<const float4*>(row);
+          a.x = a.x + e.x; a.y = a.y + e.y; a.z = a.z + e.z; a.w = a.w + e.w;
+        } else {
+          a.x = a.x + row[0];
+        }
+        wsum = wsum + 1.f;
+        w2sum = w2sum + 1.f;
+      }
+    }
+    if (d.combiner != ER_COMBINER_SUM && wsum != 0.f) {
+      const float den = (d.combiner == ER_COMBINER_MEAN) ? wsum : sqrtf(w2sum);
+      a.x = a.x / den; a.y = a.y / den; a.z = a.z / den; a.w = a.w / den;
+    }
+    float* o = d.out + static_cast<int64_t>(r) * d.out_stride + d.out_col + c;
+    if (V == 4) {
+      if (((d.out_stride | d.out_col) & 3) == 0 && (reinterpret_cast<uintptr_t>(d.out) & 15) == 0) {
+        *reinterpret_cast<float4*>(o) = make_float4(a.x, a.y, a.z, a.w);
+      } else {
+        o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w;
+      }
+      ss = (a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w);
+    } else {
+      o[0] = a.x;
+      ss = a.x * a.x;
+    }
+  }
+  if (sumsq_partials) {
+    const float tot = block_sum_256(ss, red);
+    if (threadIdx.x == 0) sumsq_partials[blockIdx.x] = tot;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward: entries, sort, reduce, apply
+// ------------------------------------------------------------------------------------------------
+// One thread per output row of one lookup: emits (key, grad pointer, scale) for every id of the row.
+__global__ void __launch_bounds__(kBlock)
+emb_bwd_build_kernel(const er_lookup_desc* __restrict__ descs, const int32_t* __restrict__ blk_start,
+                     const int64_t* __restrict__ ent_base, int n_lookups, uint32_t* __restrict__ keys,
+                     uint32_t* __restrict__ vals, const float** __restrict__ ent_gptr,
+                     float* __restrict__ ent_scale) {
+  const int l = find_lookup(blk_start, n_lookups, blockIdx.x);
+  const er_lookup_desc d = descs[l];
+  const int r = (blockIdx.x - blk_start[l]) * kBlock + static_cast<int>(threadIdx.x);
+  if (r >= d.n_rows) return;
+  int64_t kb, ke;
+  if (d.offsets) {
+    kb = d.offsets[r];
+    ke = d.offsets[r + 1];
+  } else {
+    kb = r;
+    ke = r + 1;
+  }
+  const bool prune_nonpos = (d.weights != nullptr) && (d.combiner != ER_COMBINER_SUM);
+  float den = 1.f;
+  if (d.combiner != ER_COMBINER_SUM) {
+    float wsum = 0.f, w2sum = 0.f;
+    for (int64_t k = kb; k < ke; ++k) {
+      const int64_t id = d.ids[k];
+      if (id < 0 || id >= d.rows) continue;
+      const float w = d.weights ? d.weights[k] : 1.f;
+      if (prune_nonpos && !(w > 0.f)) continue;
+      wsum = wsum + w;
+      w2sum = w2sum + w * w;
+    }
+    den = (d.combiner == ER_COMBINER_MEAN) ? wsum : sqrtf(w2sum);
+    if (wsum == 0.f) den = 1.f;
+  }
+  const float* gp = d.out + static_cast<int64_t>(r) * d.out_stride + d.out_col;
+  const int64_t base = ent_base[l];
+  for (int64_t k = kb; k < ke; ++k) {
+    const int64_t j = base + k;
+    const int64_t id = d.ids[k];
+    const float w = d.weights ? d.weights[k] : 1.f;
+    bool ok = !(id < 0 || id >= d.rows);
+    if (prune_nonpos && !(w > 0.f)) ok = false;
+    keys[j] = ok ? static_cast<uint32_t>(d.key_base + id) : kInvalidKey;
+    vals[j] = static_cast<uint32_t>(j);
+    ent_gptr[j] = gp;
+    ent_scale[j] = w / den;
+  }
+}
+
+template <int V>
+struct Vec;
+template <>
+struct Vec<4> {
+  float4 v;
+  __device__ __forceinline__ void zero() { v = make_float4(0.f, 0.f, 0.f, 0.f); }
+  __device__ __forceinline__ void load(const float* p) { v = *reinterpret_cast<const float4*>(p); }
+  __device__ __forceinline__ void loadu(const float* p) { v = make_float4(p[0], p[1], p[2], p[3]); }
+  __device__ __forceinline__ void store(float* p) const { *reinterpret_cast<float4*>(p) = v; }
+  __device__ __forceinline__ void add_scaled(const Vec& o, float s) {
+    v.x = v.x + o.v.x * s; v.y = v.y + o.v.y * s; v.z = v.z + o.v.z * s; v.w = v.w + o.v.w * s;
+  }
+  __device__ __forceinline__ void add(const Vec& o) {
+    v.x = v.x + o.v.x; v.y = v.y + o.v.y; v.z = v.z + o.v.z; v.w = v.w + o.v.w;
+  }
+};
+template <>
+struct Vec<1> {
+  float v;
+  __device__ __forceinline__ void zero() { v = 0.f; }
+  __device__ __forceinline__ void load(const float* p) { v = p[0]; }
+  __device__ __forceinline__ void loadu(const float* p) { v = p[0]; }
+  __device__ __forceinline__ void store(float* p) const { p[0] = v; }
+  __device__ __forceinline__ void add_scaled(const Vec& o, float s) { v = v + o.v * s; }
+  __device__ __forceinline__ void add(const Vec& o) { v = v + o.v; }
+};
+
+template <int V>
+__device__ __forceinline__ void gather_grad(Vec<V>& acc, const float* gp, int c, float scale) {
+  Vec<V> g;
+  if (V == 4 && (reinterpret_cast<uintptr_t>(gp + c) & 15) == 0) g.load(gp + c); else g.loadu(gp + c);
+  acc.add_scaled(g, scale);
+}
+
+// Level 1: one lane-group per chunk boundary q = c*kChunk.  When a run of equal keys continues
+// across q, sum its entries inside chunk c (in sorted = source order) into piece_sum[c].
+template <int V>
+__global__ void __launch_bounds__(kBlock)
+emb_bwd_piece_kernel(const uint32_t* __restrict__ skeys, const uint32_t* __restrict__ svals,
+                     const float* const* __restrict__ ent_gptr, const float* __restrict__ ent_scale,
+                     int64_t n, int dim, int G, float* __restrict__ piece_sum) {
+  const int64_t grp = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) / G;
+  const int c = (static_cast<int>(threadIdx.x) % G) * V;
+  const int64_t q = (grp + 1) * kChunk;
+  if (q >= n || c >= dim) return;
+  const uint32_t key = skeys[q];
+  if (key == kInvalidKey || skeys[q - 1] != key) return;
+  Vec<V> acc;
+  acc.zero();
+  const int64_t e = (q + kChunk < n) ? q + kChunk : n;
+  for (int64_t p = q; p < e && skeys[p] == key; ++p) {
+    const uint32_t j = svals[p];
+    gather_grad<V>(acc, ent_gptr[j], c, ent_scale[j]);
+  }
+  acc.store(piece_sum + (grp + 1) * dim + c);
+}
+
+struct RowUpdate {
+  float* var;
+  float* m;
+  float* v;
+  uint32_t* bitmap;
+};
+
+__device__ __forceinline__ float adam_elem(float& m, float& v, float var, float g, const er_opt_hyper& h) {
+  // tf.train.AdamOptimizer._apply_sparse_shared / compat/adam_s.py:193-213 (same row arithmetic):
+  //   m_t = m*beta1 + g*(1-beta1); v_t = v*beta2 + (g*g)*(1-beta2); var -= lr_t*m_t/(sqrt(v_t)+eps)
+  const float mt = m * h.beta1 + g * h.one_minus_beta1;
+  const float vt = v * h.beta2 + (g * g) * h.one_minus_beta2;
+  m = mt;
+  v = vt;
+  return var - (h.lr_t * mt) / (sqrtf(vt) + h.eps);
+}
+
+template <int V>
+__device__ __forceinline__ void ld_vec(float (&r)[V], const float* p) {
+  if constexpr (V == 4) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w;
+  } else {
+    r[0] = p[0];
+  }
+}
+template <int V>
+__device__ __forceinline__ void st_vec(float* p, const float (&r)[V]) {
+  if constexpr (V == 4) {
+    *reinterpret_cast<float4*>(p) = make_float4(r[0], r[1], r[2], r[3]);
+  } else {
+    p[0] = r[0];
+  }
+}
+
+template <int V>
+__device__ __forceinline__ void update_row(const RowUpdate& t, int opt_kind, const er_opt_hyper& h, int64_t off,
+                                           const float* g) {
+  float var[V], m[V], v[V];
+  ld_vec<V>(var, t.var + off);
+  if (opt_kind == ER_OPT_ADAM || opt_kind == ER_OPT_LAZY_ADAM) {
+    ld_vec<V>(m, t.m + off);
+    ld_vec<V>(v, t.v + off);
+#pragma unroll
+    for (int i = 0; i < V; ++i) var[i] = adam_elem(m[i], v[i], var[i], g[i], h);
+    st_vec<V>(t.m + off, m);
+    st_vec<V>(t.v + off, v);
+  } else if (opt_kind == ER_OPT_ADAGRAD) {
+    ld_vec<V>(v, t.v + off);
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      v[i] = v[i] + g[i] * g[i];
+      var[i] = var[i] - (g[i] * h.lr) / sqrtf(v[i]);
+    }
+    st_vec<V>(t.v + off, v);
+  } else {  // SGD
+#pragma unroll
+    for (int i = 0; i < V; ++i) var[i] = var[i] - h.lr * g[i];
+  }
+  st_vec<V>(t.var + off, var);
+}
+
+// Level 2: one lane-group per sorted position; the head of every run sums the run (its own chunk
+// tail in order, then the level-1 pieces in order) and either applies the optimizer to the row
+// (mode 0) or marks itself for compaction (mode 1: writes the summed gradient to run_grad[p]).
+template <int V>
+__global__ void __launch_bounds__(kBlock)
+emb_bwd_run_kernel(const uint32_t* __restrict__ skeys, const uint32_t* __restrict__ svals,
+                   const float* const* __restrict__ ent_gptr, const float* __restrict__ ent_scale, int64_t n,
+                   int dim, int G, const float* __restrict__ piece_sum, RowUpdate tab, int opt_kind,
+                   const er_opt_hyper* __restrict__ hyper, int mode, const uint32_t* __restrict__ head_index,
+                   uint32_t* __restrict__ out_keys, float* __restrict__ out_grads) {
+  const int64_t p = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) / G;
+  const int sub = static_cast<int>(threadIdx.x) % G;
+  const int c = sub * V;
+  if (p >= n || c >= dim) return;
+  const uint32_t key = skeys[p];
+  if (key == kInvalidKey) return;
+  if (p > 0 && skeys[p - 1] == key) return;
+  Vec<V> acc;
+  acc.zero();
+  const int64_t chunk_end = ((p / kChunk) + 1) * kChunk;
+  const int64_t e = chunk_end < n ? chunk_end : n;
+  int64_t q = p;
+  for (; q < e && skeys[q] == key; ++q) {
+    const uint32_t j = svals[q];
+    gather_grad<V>(acc, ent_gptr[j], c, ent_scale[j]);
+  }
+  if (q == chunk_end) {  // run may continue into following chunks
+    for (int64_t cb = chunk_end; cb < n && skeys[cb] == key; cb += kChunk) {
+      Vec<V> pc;
+      pc.load(piece_sum + (cb / kChunk) * dim + c);
+      acc.add(pc);
+    }
+  }
+  float g[V];
+  if constexpr (V == 4) { g[0] = acc.v.x; g[1] = acc.v.y; g[2] = acc.v.z; g[3] = acc.v.w; } else { g[0] = acc.v; }
+  if (mode == 0) {
+    const er_opt_hyper h = *hyper;
+#pragma unroll
+    for (int i = 0; i < V; ++i) g[i] = g[i] * h.grad_scale;
+    update_row<V>(tab, opt_kind, h, static_cast<int64_t>(key) * dim + c, g);
+    if (opt_kind == ER_OPT_ADAM && sub == 0) atomicOr(&tab.bitmap[key >> 5], 1u << (key & 31));
+  } else {
+    const uint32_t u = head_index[p];
+    if (sub == 0) out_keys[u] = key;
+#pragma unroll
+    for (int i = 0; i < V; ++i) out_grads[static_cast<int64_t>(u) * dim + c + i] = g[i];
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+emb_head_flag_kernel(const uint32_t* __restrict__ skeys, int64_t n, uint32_t* __restrict__ flags) {
+  const int64_t p = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (p >= n) return;
+  const uint32_t key = skeys[p];
+  flags[p] = (key != kInvalidKey && (p == 0 || skeys[p - 1] != key)) ? 1u : 0u;
+}
+
+__global__ void emb_count_unique_kernel(const uint32_t* __restrict__ flags, const uint32_t* __restrict__ head_index,
+                                        int64_t n, int32_t* __restrict__ n_unique) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *n_unique = static_cast<int32_t>(head_index[n - 1] + flags[n - 1]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// TF-exact Adam: rows not touched this step still decay (m*=b1, v*=b2) and move.
+// Pure streaming kernel: 3 arrays read + 3 written, float4, grid-stride, 4 units in flight per lane.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void decay_elem(float& var, float& m, float& v, const er_opt_hyper& h) {
+  const float mt = m * h.beta1;
+  const float vt = v * h.beta2;
+  m = mt;
+  v = vt;
+  var = var - (h.lr_t * mt) / (sqrtf(vt) + h.eps);
+}
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void decay_vec(f32x4& var, f32x4& m, f32x4& v, const er_opt_hyper& h, uint32_t skip) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (!((skip >> i) & 1u)) {
+      float a = var[i], b = m[i], c = v[i];
+      decay_elem(a, b, c, h);
+      var[i] = a; m[i] = b; v[i] = c;
+    }
+  }
+}
+
+template <int UNROLL>
+__global__ void __launch_bounds__(kBlock)
+adam_decay_sweep_vec4_kernel(float* __restrict__ var, float* __restrict__ m, float* __restrict__ v,
+                             const uint32_t* __restrict__ bitmap, int64_t n_units, int dim,
+                             const er_opt_hyper* __restrict__ hyper) {
+  const er_opt_hyper h = *hyper;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  f32x4* var4 = reinterpret_cast<f32x4*>(var);
+  f32x4* m4 = reinterpret_cast<f32x4*>(m);
+  f32x4* v4 = reinterpret_cast<f32x4*>(v);
+  const int upr = dim >> 2;  // float4 units per row
+  for (int64_t i0 = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i0 < n_units; i0 += stride * UNROLL) {
+    f32x4 a[UNROLL], b[UNROLL], c[UNROLL];
+    bool live[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const int64_t i = i0 + u * stride;
+      live[u] = false;
+      if (i < n_units) {
+        const int64_t row = i / upr;
+        const uint32_t word = bitmap ? bitmap[row >> 5] : 0u;
+        live[u] = ((word >> (row & 31)) & 1u) == 0u;
+        if (live[u]) {
+          a[u] = __builtin_nontemporal_load(&var4[i]);
+          b[u] = __builtin_nontemporal_load(&m4[i]);
+          c[u] = __builtin_nontemporal_load(&v4[i]);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      if (live[u]) {
+        const int64_t i = i0 + u * stride;
+        decay_vec(a[u], b[u], c[u], h, 0u);
+        __builtin_nontemporal_store(a[u], &var4[i]);
+        __builtin_nontemporal_store(b[u], &m4[i]);
+        __builtin_nontemporal_store(c[u], &v4[i]);
+      }
+    }
+  }
+}
+
+// dim == 1 tables (wide columns): a float4 covers 4 consecutive rows.
+template <int UNROLL>
+__global__ void __launch_bounds__(kBlock)
+adam_decay_sweep_dim1_kernel(float* __restrict__ var, float* __restrict__ m, float* __restrict__ v,
+                             const uint32_t* __restrict__ bitmap, int64_t n_rows,
+                             const er_opt_hyper* __restrict__ hyper) {
+  const er_opt_hyper h = *hyper;
+  const int64_t n_units = n_rows >> 2;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  f32x4* var4 = reinterpret_cast<f32x4*>(var);
+  f32x4* m4 = reinterpret_cast<f32x4*>(m);
+  f32x4* v4 = reinterpret_cast<f32x4*>(v);
+  for (int64_t i0 = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i0 < n_units; i0 += stride * UNROLL) {
+    f32x4 a[UNROLL], b[UNROLL], c[UNROLL];
+    uint32_t bits[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const int64_t i = i0 + u * stride;
+      bits[u] = 0xFu;
+      if (i < n_units) {
+        const int64_t row = i << 2;
+        const uint32_t word = bitmap ? bitmap[row >> 5] : 0u;
+        bits[u] = (word >> (row & 31)) & 0xFu;
+        a[u] = __builtin_nontemporal_load(&var4[i]);
+        b[u] = __builtin_nontemporal_load(&m4[i]);
+        c[u] = __builtin_nontemporal_load(&v4[i]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const int64_t i = i0 + u * stride;
+      if (i < n_units && bits[u] != 0xFu) {
+        decay_vec(a[u], b[u], c[u], h, bits[u]);
+        __builtin_nontemporal_store(a[u], &var4[i]);
+        __builtin_nontemporal_store(b[u], &m4[i]);
+        __builtin_nontemporal_store(c[u], &v4[i]);
+      }
+    }
+  }
+  // tail rows (n_rows % 4)
+  const int64_t t = (n_units << 2) + static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (t < n_rows) {
+    const uint32_t word = bitmap ? bitmap[t >> 5] : 0u;
+    if (((word >> (t & 31)) & 1u) == 0u) {
+      float a = var[t], b = m[t], c = v[t];
+      decay_elem(a, b, c, h);
+      var[t] = a; m[t] = b; v[t] = c;
+    }
+  }
+}
+
+// any other dim: scalar elements
+__global__ void __launch_bounds__(kBlock)
+adam_decay_sweep_scalar_kernel(float* __restrict__ var, float* __restrict__ m, float* __restrict__ v,
+                               const uint32_t* __restrict__ bitmap, int64_t n_elems, int dim,
+                               const er_opt_hyper* __restrict__ hyper) {
+  const er_opt_hyper h = *hyper;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n_elems; i += stride) {
+    const int64_t row = i / dim;
+    const uint32_t word = bitmap ? bitmap[row >> 5] : 0u;
+    if (((word >> (row & 31)) & 1u) == 0u) {
+      float a = var[i], b = m[i], c = v[i];
+      decay_elem(a, b, c, h);
+      var[i] = a; m[i] = b; v[i] = c;
+    }
+  }
+}
+
+}  // namespace er
+
+// ------------------------------------------------------------------------------------------------
+// host side: handles
+// ------------------------------------------------------------------------------------------------
+struct er_emb_plan {
+  int n = 0;
+  int n_blocks = 0;
+  er_lookup_desc* d_descs = nullptr;
+  int32_t* d_blk_start = nullptr;
+};
+
+struct er_emb_group {
+  int n = 0;
+  int32_t dim = 0;
+  int V = 4, G = 4;
+  int64_t total_rows = 0;
+  int64_t n_entries = 0;
+  int key_bits = 32;
+  bool has_ragged = false;
+  float *var = nullptr, *m = nullptr, *v = nullptr;
+  uint32_t* bitmap = nullptr;
+  int n_build_blocks = 0;
+  er_lookup_desc* d_descs = nullptr;
+  int32_t* d_blk_start = nullptr;
+  int64_t* d_ent_base = nullptr;
+  // workspace (owned)
+  uint32_t *keys_in = nullptr, *keys_out = nullptr, *vals_in = nullptr, *vals_out = nullptr;
+  const float** ent_gptr = nullptr;
+  float* ent_scale = nullptr;
+  float* piece_sum = nullptr;
+  uint32_t *head_flags = nullptr, *head_index = nullptr;
+  void* sort_temp = nullptr;
+  size_t sort_temp_bytes = 0;
+  void* scan_temp = nullptr;
+  size_t scan_temp_bytes = 0;
+};
+
+namespace {
+
+int validate_descs(const er_lookup_desc* descs, int n, const char* who) {
+  for (int i = 0; i < n; ++i) {
+    const er_lookup_desc& d = descs[i];
+    ER_REQUIRE(d.dim > 0 && d.dim <= 1024, "%s: lookup %d: dim %d out of range (1..1024)", who, i, d.dim);
+    ER_REQUIRE(d.dim % 4 == 0 || d.dim <= 64, "%s: lookup %d: dim %d must be a multiple of 4 or <= 64", who, i, d.dim);
+    ER_REQUIRE(d.n_rows >= 0 && d.rows > 0, "%s: lookup %d: bad n_rows/rows", who, i);
+    ER_REQUIRE(d.table && d.ids && d.out, "%s: lookup %d: null table/ids/out pointer", who, i);
+    ER_REQUIRE(d.combiner >= 0 && d.combiner <= 2, "%s: lookup %d: bad combiner %d", who, i, d.combiner);
+    if (d.dim % 4 == 0) {
+      ER_REQUIRE((reinterpret_cast<uintptr_t>(d.table) & 15) == 0, "%s: lookup %d: table must be 16-byte aligned", who, i);
+    }
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int er_emb_plan_create(const er_lookup_desc* descs, int n, er_emb_plan** out) {
+  ER_REQUIRE(descs && n > 0 && out, "er_emb_plan_create: bad arguments");
+  if (int rc = validate_descs(descs, n, "er_emb_plan_create")) return rc;
+  auto* p = new er_emb_plan();
+  p->n = n;
+  std::vector<int32_t> blk(n + 1, 0);
+  for (int i = 0; i < n; ++i) {
+    int V, G;
+    er::lane_geom(descs[i].dim, V, G);
+    const int rpb = er::kBlock / G;
+    blk[i + 1] = blk[i] + static_cast<int32_t>(er::ceil_div(descs[i].n_rows > 0 ? descs[i].n_rows : 1, rpb));
+  }
+  p->n_blocks = blk[n];
+  ER_CHECK_HIP(hipMalloc(&p->d_descs, sizeof(er_lookup_desc) * n));
+  ER_CHECK_HIP(hipMalloc(&p->d_blk_start, sizeof(int32_t) * (n + 1)));
+  ER_CHECK_HIP(hipMemcpy(p->d_descs, descs, sizeof(er_lookup_desc) * n, hipMemcpyHostToDevice));
+  ER_CHECK_HIP(hipMemcpy(p->d_blk_start, blk.data(), sizeof(int32_t) * (n + 1), hipMemcpyHostToDevice));
+  *out = p;
+  return 0;
+}
+
+int er_emb_plan_update(er_emb_plan* p, const er_lookup_desc* descs, int n) {
+  ER_REQUIRE(p && descs && n == p->n, "er_emb_plan_update: lookup count changed");
+  if (int rc = validate_descs(descs, n, "er_emb_plan_update")) return rc;
+  ER_CHECK_HIP(hipMemcpy(p->d_descs, descs, sizeof(er_lookup_desc) * n, hipMemcpyHostToDevice));
+  return 0;
+}
+
+int er_emb_plan_destroy(er_emb_plan* p) {
+  if (!p) return 0;
+  (void)hipFree(p->d_descs);
+  (void)hipFree(p->d_blk_start);
+  delete p;
+  return 0;
+}
+
+int er_emb_plan_num_blocks(const er_emb_plan* p) { return p ? p->n_blocks : -1; }
+
+int er_emb_fwd(const er_emb_plan* p, float* sumsq_partials, er_stream_t stream) {
+  ER_REQUIRE(p, "er_emb_fwd: null plan");
+  hipLaunchKernelGGL(er::emb_fwd_kernel, dim3(p->n_blocks), dim3(er::kBlock), 0, er::as_stream(stream), p->d_descs,
+                     p->d_blk_start, p->n, sumsq_partials);
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
+int er_emb_group_create(const er_lookup_desc* descs, int n, int32_t dim, int64_t total_rows, float* var, float* m,
+                        float* v, uint32_t* bitmap, er_emb_group** out) {
+  ER_REQUIRE(descs && n > 0 && out && var, "er_emb_group_create: bad arguments");
+  if (int rc = validate_descs(descs, n, "er_emb_group_create")) return rc;
+  ER_REQUIRE(total_rows > 0 && total_rows < 0xFFFFFFFFLL, "er_emb_group_create: total_rows %lld does not fit 32-bit keys",
+             (long long)total_rows);
+  auto* g = new er_emb_group();
+  g->n = n;
+  g->dim = dim;
+  er::lane_geom(dim, g->V, g->G);
+  g->total_rows = total_rows;
+  g->var = var; g->m = m; g->v = v; g->bitmap = bitmap;
+  g->key_bits = 1;
+  while ((1LL << g->key_bits) <= total_rows) ++g->key_bits;  // 2^bits > total_rows: invalid key sorts last
+  std::vector<int32_t> blk(n + 1, 0);
+  std::vector<int64_t> base(n + 1, 0);
+  for (int i = 0; i < n; ++i) {
+    ER_REQUIRE(descs[i].dim == dim, "er_emb_group_create: lookup %d has dim %d, group dim %d", i, descs[i].dim, dim);
+    ER_REQUIRE(descs[i].key_base >= 0 && descs[i].key_base + descs[i].rows <= total_rows,
+               "er_emb_group_create: lookup %d table outside the group", i);
+    blk[i + 1] = blk[i] + static_cast<int32_t>(er::ceil_div(descs[i].n_rows > 0 ? descs[i].n_rows : 1, er::kBlock));
+    const int64_t cap = descs[i].offsets ? descs[i].max_nnz : descs[i].n_rows;
+    ER_REQUIRE(cap >= 0, "er_emb_group_create: lookup %d: max_nnz not set", i);
+    base[i + 1] = base[i] + cap;
+    if (descs[i].offsets) g->has_ragged = true;
+  }
+  g->n_build_blocks = blk[n];
+  g->n_entries = base[n];
+  ER_REQUIRE(g->n_entries > 0 && g->n_entries < 0x7FFFFFFFLL, "er_emb_group_create: entry count %lld out of range",
+             (long long)g->n_entries);
+  const int64_t N = g->n_entries;
+  ER_CHECK_HIP(hipMalloc(&g->d_descs, sizeof(er_lookup_desc) * n));
+  ER_CHECK_HIP(hipMalloc(&g->d_blk_start, sizeof(int32_t) * (n + 1)));
+  ER_CHECK_HIP(hipMalloc(&g->d_ent_base, sizeof(int64_t) * (n + 1)));
+  ER_CHECK_HIP(hipMemcpy(g->d_descs, descs, sizeof(er_lookup_desc) * n, hipMemcpyHostToDevice));
+  ER_CHECK_HIP(hipMemcpy(g->d_blk_start, blk.data(), sizeof(int32_t) * (n + 1), hipMemcpyHostToDevice));
+  ER_CHECK_HIP(hipMemcpy(g->d_ent_base, base.data(), sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice));
+  ER_CHECK_HIP(hipMalloc(&g->keys_in, sizeof(uint32_t) * N));
+  ER_CHECK_HIP(hipMalloc(&g->keys_out, sizeof(uint32_t) * N));
+  ER_CHECK_HIP(hipMalloc(&g->vals_in, sizeof(uint32_t) * N));
+  ER_CHECK_HIP(hipMalloc(&g->vals_out, sizeof(uint32_t) * N));
+  ER_CHECK_HIP(hipMalloc(&g->ent_gptr, sizeof(float*) * N));
+  ER_CHECK_HIP(hipMalloc(&g->ent_scale, sizeof(float) * N));
+  ER_CHECK_HIP(hipMalloc(&g->piece_sum, sizeof(float) * (er::ceil_div(N, er::kChunk) + 1) * dim));
+  ER_CHECK_HIP(hipMalloc(&g->head_flags, sizeof(uint32_t) * N));
+  ER_CHECK_HIP(hipMalloc(&g->head_index, sizeof(uint32_t) * N));
+  ER_CHECK_HIP(hipMemset(g->keys_in, 0xFF, sizeof(uint32_t) * N));
+  ER_CHECK_HIP(rocprim::radix_sort_pairs(nullptr, g->sort_temp_bytes, g->keys_in, g->keys_out, g->vals_in, g->vals_out,
+                                         static_cast<size_t>(N), 0u, static_cast<unsigned>(g->key_bits)));
+  ER_CHECK_HIP(hipMalloc(&g->sort_temp, g->sort_temp_bytes > 0 ? g->sort_temp_bytes : 16));
+  ER_CHECK_HIP(rocprim::exclusive_scan(nullptr, g->scan_temp_bytes, g->head_flags, g->head_index, 0u,
+                                       static_cast<size_t>(N), rocprim::plus<uint32_t>()));
+  ER_CHECK_HIP(hipMalloc(&g->scan_temp, g->scan_temp_bytes > 0 ? g->scan_temp_bytes : 16));
+  *out = g;
+  return 0;
+}
+
+int er_emb_group_update(er_emb_group* g, const er_lookup_desc* descs, int n) {
+  ER_REQUIRE(g && descs && n == g->n, "er_emb_group_update: lookup count changed");
+  if (int rc = validate_descs(descs, n, "er_emb_group_update")) return rc;
+  ER_CHECK_HIP(hipMemcpy(g->d_descs, descs, sizeof(er_lookup_desc) * n, hipMemcpyHostToDevice));
+  return 0;
+}
+
+int er_emb_group_destroy(er_emb_group* g) {
+  if (!g) return 0;
+  void* ptrs[] = {g->d_descs, g->d_blk_start, g->d_ent_base, g->keys_in, g->keys_out, g->vals_in, g->vals_out,
+                  g->ent_gptr, g->ent_scale, g->piece_sum, g->head_flags, g->head_index, g->sort_temp, g->scan_temp};
+  for (void* q : ptrs) (void)hipFree(q);
+  delete g;
+  return 0;
+}
+
+int64_t er_emb_group_num_entries(const er_emb_group* g) { return g ? g->n_entries : -1; }
+
+static int emb_group_sort(er_emb_group* g, hipStream_t s) {
+  const int64_t N = g->n_entries;
+  if (g->has_ragged) ER_CHECK_HIP(hipMemsetAsync(g->keys_in, 0xFF, sizeof(uint32_t) * N, s));
+  hipLaunchKernelGGL(er::emb_bwd_build_kernel, dim3(g->n_build_blocks), dim3(er::kBlock), 0, s, g->d_descs,
+                     g->d_blk_start, g->d_ent_base, g->n, g->keys_in, g->vals_in, g->ent_gptr, g->ent_scale);
+  ER_LAUNCH_CHECK();
+  ER_CHECK_HIP(rocprim::radix_sort_pairs(g->sort_temp, g->sort_temp_bytes, g->keys_in, g->keys_out, g->vals_in,
+                                         g->vals_out, static_cast<size_t>(N), 0u, static_cast<unsigned>(g->key_bits), s));
+  const int64_t n_bound = er::ceil_div(N, er::kChunk) - 1;  // chunk boundaries
+  if (n_bound > 0) {
+    const int blocks = static_cast<int>(er::ceil_div(n_bound * g->G, er::kBlock));
+    if (g->V == 4) {
+      hipLaunchKernelGGL(er::emb_bwd_piece_kernel<4>, dim3(blocks), dim3(er::kBlock), 0, s, g->keys_out, g->vals_out,
+                         g->ent_gptr, g->ent_scale, N, g->dim, g->G, g->piece_sum);
+    } else {
+      hipLaunchKernelGGL(er::emb_bwd_piece_kernel<1>, dim3(blocks), dim3(er::kBlock), 0, s, g->keys_out, g->vals_out,
+                         g->ent_gptr, g->ent_scale, N, g->dim, g->G, g->piece_sum);
+    }
+    ER_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+static int emb_group_run(er_emb_group* g, int opt_kind, const er_opt_hyper* hyper, int mode, uint32_t* out_keys,
+                         float* out_grads, hipStream_t s) {
+  const int64_t N = g->n_entries;
+  const int blocks = static_cast<int>(er::ceil_div(N * g->G, er::kBlock));
+  er::RowUpdate tab{g->var, g->m, g->v, g->bitmap};
+  if (g->V == 4) {
+    hipLaunchKernelGGL(er::emb_bwd_run_kernel<4>, dim3(blocks), dim3(er::kBlock), 0, s, g->keys_out, g->vals_out,
+                       g->ent_gptr, g->ent_scale, N, g->dim, g->G, g->piece_sum, tab, opt_kind, hyper, mode,
+                       g->head_index, out_keys, out_grads);
+  } else {
+    hipLaunchKernelGGL(er::emb_bwd_run_kernel<1>, dim3(blocks), dim3(er::kBlock), 0, s, g->keys_out, g->vals_out,
+                       g->ent_gptr, g->ent_scale, N, g->dim, g->G, g->piece_sum, tab, opt_kind, hyper, mode,
+                       g->head_index, out_keys, out_grads);
+  }
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
+int er_adam_decay_sweep(float* var, float* m, float* v, uint32_t* bitmap, int64_t total_rows, int32_t dim,
+                        const er_opt_hyper* hyper, er_stream_t stream) {
+  ER_REQUIRE(var && m && v && hyper && total_rows > 0 && dim > 0, "er_adam_decay_sweep: bad arguments");
+  hipStream_t s = er::as_stream(stream);
+  constexpr int U = 4;
+  const int max_blocks = 256 * 8;
+  if (dim % 4 == 0) {
+    const int64_t units = total_rows * (dim / 4);
+    int64_t blocks = er::ceil_div(units, static_cast<int64_t>(er::kBlock) * U);
+    if (blocks > max_blocks) blocks = max_blocks;
+    hipLaunchKernelGGL(er::adam_decay_sweep_vec4_kernel<U>, dim3(static_cast<int>(blocks)), dim3(er::kBlock), 0, s, var,
+                       m, v, bitmap, units, dim, hyper);
+  } else if (dim == 1) {
+    const int64_t units = total_rows / 4;
+    int64_t blocks = er::ceil_div(units > 0 ? units : 1, static_cast<int64_t>(er::kBlock) * U);
+    if (blocks > max_blocks) blocks = max_blocks;
+    hipLaunchKernelGGL(er::adam_decay_sweep_dim1_kernel<U>, dim3(static_cast<int>(blocks)), dim3(er::kBlock), 0, s, var,
+                       m, v, bitmap, total_rows, hyper);
+  } else {
+    const int64_t elems = total_rows * dim;
+    int64_t blocks = er::ceil_div(elems, er::kBlock);
+    if (blocks > max_blocks) blocks = max_blocks;
+    hipLaunchKernelGGL(er::adam_decay_sweep_scalar_kernel, dim3(static_cast<int>(blocks)), dim3(er::kBlock), 0, s, var,
+                       m, v, bitmap, elems, dim, hyper);
+  }
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
+int er_emb_bwd_update(er_emb_group* g, int opt_kind, const er_opt_hyper* hyper, er_stream_t stream) {
+  ER_REQUIRE(g && hyper, "er_emb_bwd_update: null argument");
+  ER_REQUIRE(opt_kind >= ER_OPT_SGD && opt_kind <= ER_OPT_ADAGRAD, "er_emb_bwd_update: unknown optimizer %d", opt_kind);
+  if (opt_kind == ER_OPT_ADAM || opt_kind == ER_OPT_LAZY_ADAM)
+    ER_REQUIRE(g->m && g->v, "er_emb_bwd_update: Adam needs m and v");
+  if (opt_kind == ER_OPT_ADAGRAD) ER_REQUIRE(g->v, "er_emb_bwd_update: Adagrad needs the accumulator in v");
+  if (opt_kind == ER_OPT_ADAM) ER_REQUIRE(g->bitmap, "er_emb_bwd_update: ER_OPT_ADAM needs touched_bitmap");
+  hipStream_t s = er::as_stream(stream);
+  if (int rc = emb_group_sort(g, s)) return rc;
+  if (int rc = emb_group_run(g, opt_kind, hyper, 0, nullptr, nullptr, s)) return rc;
+  if (opt_kind == ER_OPT_ADAM) {
+    if (int rc = er_adam_decay_sweep(g->var, g->m, g->v, g->bitmap, g->total_rows, g->dim, hyper, stream)) return rc;
+    ER_CHECK_HIP(hipMemsetAsync(g->bitmap, 0, sizeof(uint32_t) * static_cast<size_t>(er::ceil_div(g->total_rows, 32)), s));
+  }
+  return 0;
+}
+
+int er_emb_bwd_reduce(er_emb_group* g, uint32_t* unique_keys, float* unique_grads, int32_t* n_unique,
+                      er_stream_t stream) {
+  ER_REQUIRE(g && unique_keys && unique_grads && n_unique, "er_emb_bwd_reduce: null argument");
+  hipStream_t s = er::as_stream(stream);
+  if (int rc = emb_group_sort(g, s)) return rc;
+  const int64_t N = g->n_entries;
+  hipLaunchKernelGGL(er::emb_head_flag_kernel, dim3(static_cast<int>(er::ceil_div(N, er::kBlock))), dim3(er::kBlock), 0,
+                     s, g->keys_out, N, g->head_flags);
+  ER_LAUNCH_CHECK();
+  ER_CHECK_HIP(rocprim::exclusive_scan(g->scan_temp, g->scan_temp_bytes, g->head_flags, g->head_index, 0u,
+                                       static_cast<size_t>(N), rocprim::plus<uint32_t>(), s));
+  hipLaunchKernelGGL(er::emb_count_unique_kernel, dim3(1), dim3(64), 0, s, g->head_flags, g->head_index, N, n_unique);
+  ER_LAUNCH_CHECK();
+  return emb_group_run(g, ER_OPT_SGD, nullptr, 1, unique_keys, unique_grads, s);
+}
+
+}  // extern "C"

@@ -1,0 +1,608 @@
+// K5-K8, K11: feature-interaction kernels (FM, wide sum, DCN cross v1 / v2 epilogue, DIN target
+// attention, MMoE mixing).  All are HBM/L2-bound elementwise + small-reduction work on [B, d]
+// activations that the embedding forward has just written; they are kept off the MFMA path on
+// purpose and fuse what the reference issues as 4-10 separate TF ops each.
+//
+// Reference call sites: layers/fm.py:20-26, model/deepfm.py:62-63, model/dcn.py:32-45,
+// layers/keras/interaction.py:276-286, model/multi_tower_din.py:62-97, layers/mmoe.py:73-82.
+#include "er_common.h"
+
+namespace er {
+
+// ------------------------------------------------------------------------------------------------
+// FM
+// ------------------------------------------------------------------------------------------------
+template <int V>
+__global__ void __launch_bounds__(kBlock)
+fm_fwd_kernel(const float* __restrict__ x, int B, int F, int D, int x_stride, float* __restrict__ fm_out,
+              float* __restrict__ sum_out) {
+  const int lanes = D / V;
+  const int64_t idx = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  const int64_t b = idx / lanes;
+  const int c = static_cast<int>(idx % lanes) * V;
+  if (b >= B) return;
+  const float* row = x + b * x_stride + c;
+  float s[V], q[V];
+#pragma unroll
+  for (int i = 0; i < V; ++i) { s[i] = 0.f; q[i] = 0.f; }
+#pragma unroll 4
+  for (int f = 0; f < F; ++f) {
+    float e[V];
+    if constexpr (V == 4) {
+      const float4 t = *reinterpret_cast<const float4*>(row + f * D);
+      e[0] = t.x; e[1] = t.y; e[2] = t.z; e[3] = t.w;
+    } else {
+      e[0] = row[f * D];
+    }
+#pragma unroll
+    for (int i = 0; i < V; ++i) { s[i] = s[i] + e[i]; q[i] = q[i] + e[i] * e[i]; }
+  }
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    fm_out[b * D + c + i] = 0.5f * (s[i] * s[i] - q[i]);
+    sum_out[b * D + c + i] = s[i];
+  }
+}
+
+template <int V>
+__global__ void __launch_bounds__(kBlock)
+fm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ S, const float* __restrict__ g, int B, int F,
+              int D, int x_stride, float* __restrict__ dx, int dx_stride, int accumulate) {
+  // one lane per (b, f, V columns): fully coalesced over the [B, F*D] activation
+  const int lanes_row = (F * D) / V;
+  const int64_t idx = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  const int64_t b = idx / lanes_row;
+  if (b >= B) return;
+  const int col = static_cast<int>(idx % lanes_row) * V;  // column in [0, F*D)
+  const int c = col % D;
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    const float e = x[b * x_stride + col + i];
+    const float v = g[b * D + c + i] * (S[b * D + c + i] - e);
+    float* o = dx + b * dx_stride + col + i;
+    *o = accumulate ? (*o + v) : v;
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+rowsum_fwd_kernel(const float* __restrict__ x, int B, int n, int x_stride, float* __restrict__ out) {
+  // 4 lanes per row, then a 4-lane tree: keeps loads semi-coalesced for n ~ 39
+  const int64_t idx = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  const int64_t b = idx >> 2;
+  const int sub = static_cast<int>(idx & 3);
+  float s = 0.f;
+  if (b < B) {
+    for (int j = sub; j < n; j += 4) s = s + x[b * x_stride + j];
+  }
+  s += __shfl_xor(s, 1, 64);
+  s += __shfl_xor(s, 2, 64);
+  if (b < B && sub == 0) out[b] = s;
+}
+
+__global__ void __launch_bounds__(kBlock)
+rowsum_bwd_kernel(const float* __restrict__ g, int B, int n, float* __restrict__ dx, int dx_stride, int accumulate) {
+  const int64_t idx = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  const int64_t b = idx / n;
+  if (b >= B) return;
+  const int j = static_cast<int>(idx % n);
+  float* o = dx + b * dx_stride + j;
+  *o = accumulate ? (*o + g[b]) : g[b];
+}
+
+__global__ void __launch_bounds__(kBlock)
+axpy2d_kernel(const float* __restrict__ x, int x_stride, float alpha, float* __restrict__ y, int y_stride, int rows,
+              int cols, int accumulate) {
+  const int64_t idx = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  const int64_t r = idx / cols;
+  if (r >= rows) return;
+  const int c = static_cast<int>(idx % cols);
+  const float v = alpha * x[r * x_stride + c];
+  float* o = y + r * y_stride + c;
+  *o = accumulate ? (*o + v) : v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// DCN-v1 cross: one wave per row, the row lives in registers (d <= 64*kCrossE)
+// ------------------------------------------------------------------------------------------------
+constexpr int kCrossE = 16;
+
+__global__ void __launch_bounds__(kBlock)
+cross_v1_fwd_kernel(const float* __restrict__ x0g, const float* __restrict__ w, const float* __restrict__ bias,
+                    int B, int d, int L, float* __restrict__ out, float* __restrict__ xl_dots) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = static_cast<int64_t>(blockIdx.x) * (kBlock / 64) + (threadIdx.x >> 6);
+  if (r >= B) return;
+  float x0[kCrossE], x[kCrossE];
+#pragma unroll
+  for (int i = 0; i < kCrossE; ++i) {
+    const int c = lane + i * 64;
+    x0[i] = (c < d) ? x0g[r * d + c] : 0.f;
+    x[i] = x0[i];
+  }
+  for (int l = 0; l < L; ++l) {
+    float part = 0.f;
+#pragma unroll
+    for (int i = 0; i < kCrossE; ++i) {
+      const int c = lane + i * 64;
+      if (c < d) part = part + x[i] * w[l * d + c];
+    }
+    const float dot = wave_sum(part);
+    if (lane == 0) xl_dots[r * L + l] = dot;
+#pragma unroll
+    for (int i = 0; i < kCrossE; ++i) {
+      const int c = lane + i * 64;
+      if (c < d) x[i] = (x0[i] * dot + bias[l * d + c]) + x[i];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < kCrossE; ++i) {
+    const int c = lane + i * 64;
+    if (c < d) out[r * d + c] = x[i];
+  }
+}
+
+// backward: one wave per block, rows strided over blocks; dw/db accumulated in LDS per block and
+// written as partials [gridDim.x, L, d] (reduced by er_colsum) -> deterministic.
+__global__ void __launch_bounds__(64)
+cross_v1_bwd_kernel(const float* __restrict__ x0g, const float* __restrict__ w, const float* __restrict__ bias,
+                    const float* __restrict__ xl_dots, const float* __restrict__ dout, int B, int d, int L,
+                    float* __restrict__ dx0g, float* __restrict__ dw_part, float* __restrict__ db_part) {
+  extern __shared__ float lds[];  // [2, L, d]
+  float* dw = lds;
+  float* db = lds + static_cast<size_t>(L) * d;
+  const int lane = threadIdx.x;
+  for (int i = lane; i < 2 * L * d; i += 64) lds[i] = 0.f;
+  __syncthreads();
+  for (int64_t r = blockIdx.x; r < B; r += gridDim.x) {
+    float x0[kCrossE], g[kCrossE], dx0[kCrossE];
+#pragma unroll
+    for (int i = 0; i < kCrossE; ++i) {
+      const int c = lane + i * 64;
+      x0[i] = (c < d) ? x0g[r * d + c] : 0.f;
+      g[i] = (c < d) ? dout[r * d + c] : 0.f;
+      dx0[i] = 0.f;
+    }
+    for (int l = L - 1; l >= 0; --l) {
+      // recompute x_l from x0 with the saved dots (x_{k+1} = x0*dot_k + b_k + x_k)
+      float xl[kCrossE];
+#pragma unroll
+      for (int i = 0; i < kCrossE; ++i) xl[i] = x0[i];
+      for (int k = 0; k < l; ++k) {
+        const float dk = xl_dots[r * L + k];
+#pragma unroll
+        for (int i = 0; i < kCrossE; ++i) {
+          const int c = lane + i * 64;
+          if (c < d) xl[i] = (x0[i] * dk + bias[k * d + c]) + xl[i];
+        }
+      }
+      const float dot = xl_dots[r * L + l];
+      float part = 0.f;
+#pragma unroll
+      for (int i = 0; i < kCrossE; ++i) part = part + g[i] * x0[i];
+      const float ddot = wave_sum(part);
+#pragma unroll
+      for (int i = 0; i < kCrossE; ++i) {
+        const int c = lane + i * 64;
+        if (c < d) {
+          dx0[i] = dx0[i] + g[i] * dot;
+          db[l * d + c] = db[l * d + c] + g[i];
+          dw[l * d + c] = dw[l * d + c] + ddot * xl[i];
+          g[i] = g[i] + ddot * w[l * d + c];  // gradient w.r.t. x_l
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < kCrossE; ++i) {
+      const int c = lane + i * 64;
+      if (c < d) dx0g[r * d + c] = dx0[i] + g[i];  // x_0 is also the first x_l
+    }
+  }
+  __syncthreads();
+  const size_t base = static_cast<size_t>(blockIdx.x) * L * d;
+  for (int i = lane; i < L * d; i += 64) {
+    dw_part[base + i] = dw[i];
+    db_part[base + i] = db[i];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// DCN-v2 cross epilogue
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+cross_v2_fwd_kernel(const float* __restrict__ x0, const float* __restrict__ x, const float* __restrict__ u,
+                    const float* __restrict__ bias, float diag, int64_t n, int d, float* __restrict__ out) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const int c = static_cast<int>(i % d);
+  float t = u[i] + (bias ? bias[c] : 0.f);
+  if (diag != 0.f) t = t + diag * x[i];
+  out[i] = x0[i] * t + x[i];
+}
+
+__global__ void __launch_bounds__(kBlock)
+cross_v2_bwd_kernel(const float* __restrict__ x0, const float* __restrict__ x, const float* __restrict__ u,
+                    const float* __restrict__ bias, float diag, const float* __restrict__ dout, int64_t n, int d,
+                    float* __restrict__ dx0, int acc_dx0, float* __restrict__ dx, float* __restrict__ du) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const int c = static_cast<int>(i % d);
+  float t = u[i] + (bias ? bias[c] : 0.f);
+  if (diag != 0.f) t = t + diag * x[i];
+  const float g = dout[i];
+  const float a = g * t;
+  dx0[i] = acc_dx0 ? (dx0[i] + a) : a;
+  du[i] = g * x0[i];
+  dx[i] = g + (diag != 0.f ? g * x0[i] * diag : 0.f);
+}
+
+// ------------------------------------------------------------------------------------------------
+// DIN
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+din_concat_fwd_kernel(const float* __restrict__ q, const float* __restrict__ h, int B, int L, int E,
+                      float* __restrict__ out) {
+  const int64_t n = static_cast<int64_t>(B) * L * E;
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const int e = static_cast<int>(i % E);
+  const int64_t bt = i / E;
+  const int64_t b = bt / L;
+  const float qv = q[b * E + e];
+  const float hv = h[i];
+  float* o = out + bt * (4 * E);
+  o[e] = qv;
+  o[E + e] = hv;
+  o[2 * E + e] = qv - hv;
+  o[3 * E + e] = qv * hv;
+}
+
+// dhist: elementwise.  dquery: sum over t -> one lane per (b, e) loops over L (coalesced over e).
+__global__ void __launch_bounds__(kBlock)
+din_concat_bwd_hist_kernel(const float* __restrict__ q, const float* __restrict__ dout, int B, int L, int E,
+                           float* __restrict__ dh, int acc_h) {
+  const int64_t n = static_cast<int64_t>(B) * L * E;
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const int e = static_cast<int>(i % E);
+  const int64_t bt = i / E;
+  const int64_t b = bt / L;
+  const float* g = dout + bt * (4 * E);
+  const float v = (g[E + e] - g[2 * E + e]) + g[3 * E + e] * q[b * E + e];
+  dh[i] = acc_h ? (dh[i] + v) : v;
+}
+
+__global__ void __launch_bounds__(kBlock)
+din_concat_bwd_query_kernel(const float* __restrict__ h, const float* __restrict__ dout, int B, int L, int E,
+                            float* __restrict__ dq, int acc_q) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i >= static_cast<int64_t>(B) * E) return;
+  const int e = static_cast<int>(i % E);
+  const int64_t b = i / E;
+  float s = 0.f;
+  for (int t = 0; t < L; ++t) {
+    const int64_t bt = b * L + t;
+    const float* g = dout + bt * (4 * E);
+    s = s + ((g[e] + g[2 * E + e]) + g[3 * E + e] * h[bt * E + e]);
+  }
+  dq[i] = acc_q ? (dq[i] + s) : s;
+}
+
+// one wave per example: masked softmax over L (any L, strided over lanes) then p @ hist
+__global__ void __launch_bounds__(kBlock)
+din_pool_fwd_kernel(const float* __restrict__ scores, const float* __restrict__ hist, const int32_t* __restrict__ len,
+                    int B, int L, int E, float scale, float* __restrict__ probs, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t b = static_cast<int64_t>(blockIdx.x) * (kBlock / 64) + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const float kPad = -4294967295.0f;  // -2**32 + 1 (reference model/multi_tower_din.py:88)
+  const int n = len[b];
+  float mx = -INFINITY;
+  for (int t = lane; t < L; t += 64) {
+    const float s = (t < n) ? scores[b * L + t] * scale : kPad;
+    mx = fmaxf(mx, s);
+  }
+  mx = wave_max(mx);
+  float den = 0.f;
+  for (int t = lane; t < L; t += 64) {
+    const float s = (t < n) ? scores[b * L + t] * scale : kPad;
+    den = den + expf(s - mx);
+  }
+  den = wave_sum(den);
+  for (int t = lane; t < L; t += 64) {
+    const float s = (t < n) ? scores[b * L + t] * scale : kPad;
+    probs[b * L + t] = expf(s - mx) / den;
+  }
+  // out[b, e] = sum_t p[t] * hist[b, t, e]; lanes over e.  p[t] is recomputed (wave-uniform
+  // score load) instead of re-reading probs[] written by other lanes.
+  for (int e = lane; e < E; e += 64) {
+    float acc = 0.f;
+    for (int t = 0; t < L; ++t) {
+      const float s = (t < n) ? scores[b * L + t] * scale : kPad;
+      acc = acc + (expf(s - mx) / den) * hist[(b * L + t) * E + e];
+    }
+    out[b * E + e] = acc;
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+din_pool_bwd_kernel(const float* __restrict__ probs, const float* __restrict__ hist, const int32_t* __restrict__ len,
+                    const float* __restrict__ dout, int B, int L, int E, float scale, float* __restrict__ dscores,
+                    float* __restrict__ dhist, int acc_h) {
+  const int lane = threadIdx.x & 63;
+  const int64_t b = static_cast<int64_t>(blockIdx.x) * (kBlock / 64) + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const int n = len[b];
+  // dp[t] = sum_e dout[e]*hist[t,e];  ds = p*(dp - sum_t p*dp); masked positions get no gradient
+  float dot_pd = 0.f;
+  for (int t = lane; t < L; t += 64) {
+    float dp = 0.f;
+    for (int e = 0; e < E; ++e) dp = dp + dout[b * E + e] * hist[(b * L + t) * E + e];
+    dot_pd = dot_pd + probs[b * L + t] * dp;
+  }
+  dot_pd = wave_sum(dot_pd);
+  for (int t = lane; t < L; t += 64) {
+    float dp = 0.f;
+    for (int e = 0; e < E; ++e) dp = dp + dout[b * E + e] * hist[(b * L + t) * E + e];
+    const float ds = probs[b * L + t] * (dp - dot_pd);
+    dscores[b * L + t] = (t < n) ? ds * scale : 0.f;
+  }
+  for (int64_t i = lane; i < static_cast<int64_t>(L) * E; i += 64) {
+    const int t = static_cast<int>(i / E), e = static_cast<int>(i % E);
+    const float v = probs[b * L + t] * dout[b * E + e];
+    float* o = dhist + (b * L + t) * E + e;
+    *o = acc_h ? (*o + v) : v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// MMoE mixing
+// ------------------------------------------------------------------------------------------------
+constexpr int kMaxExperts = 32;
+
+__global__ void __launch_bounds__(kBlock)
+mmoe_gate_softmax_kernel(const float* __restrict__ logits, int64_t rows, int E, float* __restrict__ gates) {
+  const int64_t r = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (r >= rows) return;
+  float mx = -INFINITY;
+  for (int e = 0; e < E; ++e) mx = fmaxf(mx, logits[r * E + e]);
+  float den = 0.f;
+  for (int e = 0; e < E; ++e) den = den + expf(logits[r * E + e] - mx);
+  for (int e = 0; e < E; ++e) gates[r * E + e] = expf(logits[r * E + e] - mx) / den;
+}
+
+__global__ void __launch_bounds__(kBlock)
+mmoe_mix_fwd_kernel(const float* __restrict__ experts, const float* __restrict__ gates, int T, int E, int B, int H,
+                    float* __restrict__ out) {
+  const int64_t n = static_cast<int64_t>(T) * B * H;
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const int h = static_cast<int>(i % H);
+  const int64_t tb = i / H;
+  const int64_t b = tb % B;
+  float acc = 0.f;
+  for (int e = 0; e < E; ++e) acc = acc + experts[(static_cast<int64_t>(e) * B + b) * H + h] * gates[tb * E + e];
+  out[i] = acc;
+}
+
+// dexperts[e,b,h] = sum_t gates[t,b,e]*dout[t,b,h]
+__global__ void __launch_bounds__(kBlock)
+mmoe_mix_bwd_experts_kernel(const float* __restrict__ gates, const float* __restrict__ dout, int T, int E, int B,
+                            int H, float* __restrict__ dexperts) {
+  const int64_t n = static_cast<int64_t>(E) * B * H;
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const int h = static_cast<int>(i % H);
+  const int64_t eb = i / H;
+  const int64_t b = eb % B;
+  const int e = static_cast<int>(eb / B);
+  float acc = 0.f;
+  for (int t = 0; t < T; ++t)
+    acc = acc + gates[(static_cast<int64_t>(t) * B + b) * E + e] * dout[(static_cast<int64_t>(t) * B + b) * H + h];
+  dexperts[i] = acc;
+}
+
+// one wave per (t, b): dgate[e] = sum_h dout[h]*experts[e,b,h]; dlogit = g*(dgate - sum_e g*dgate)
+__global__ void __launch_bounds__(kBlock)
+mmoe_mix_bwd_gate_kernel(const float* __restrict__ experts, const float* __restrict__ gates,
+                         const float* __restrict__ dout, int T, int E, int B, int H,
+                         float* __restrict__ dlogits) {
+  const int lane = threadIdx.x & 63;
+  const int64_t tb = static_cast<int64_t>(blockIdx.x) * (kBlock / 64) + (threadIdx.x >> 6);
+  if (tb >= static_cast<int64_t>(T) * B) return;
+  const int64_t b = tb % B;
+  float dg[kMaxExperts];
+  float dotg = 0.f;
+  for (int e = 0; e < E; ++e) {
+    float part = 0.f;
+    for (int h = lane; h < H; h += 64) part = part + dout[tb * H + h] * experts[(static_cast<int64_t>(e) * B + b) * H + h];
+    dg[e] = wave_sum(part);
+    dotg = dotg + gates[tb * E + e] * dg[e];
+  }
+  if (lane == 0) {
+    for (int e = 0; e < E; ++e) dlogits[tb * E + e] = gates[tb * E + e] * (dg[e] - dotg);
+  }
+}
+
+inline int blocks_for(int64_t n) { return static_cast<int>(ceil_div(n, kBlock)); }
+
+}  // namespace er
+
+extern "C" {
+
+int er_fm_fwd(const float* x, int32_t B, int32_t F, int32_t D, int32_t x_stride, float* fm_out, float* sum_out,
+              er_stream_t stream) {
+  ER_REQUIRE(x && fm_out && sum_out && B > 0 && F > 0 && D > 0, "er_fm_fwd: bad arguments");
+  hipStream_t s = er::as_stream(stream);
+  const bool vec = (D % 4 == 0) && (x_stride % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+  if (vec) {
+    hipLaunchKernelGGL(er::fm_fwd_kernel<4>, dim3(er::blocks_for(static_cast<int64_t>(B) * (D / 4))), dim3(er::kBlock),
+                       0, s, x, B, F, D, x_stride, fm_out, sum_out);
+  } else {
+    hipLaunchKernelGGL(er::fm_fwd_kernel<1>, dim3(er::blocks_for(static_cast<int64_t>(B) * D)), dim3(er::kBlock), 0, s,
+                       x, B, F, D, x_stride, fm_out, sum_out);
+  }
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
+int er_fm_bwd(const float* x, const float* sum_saved, const float* g, int32_t B, int32_t F, int32_t D,
+              int32_t x_stride, float* dx, int32_t dx_stride, int accumulate, er_stream_t stream) {
+  ER_REQUIRE(x && sum_saved && g && dx && B > 0 && F > 0 && D > 0, "er_fm_bwd: bad arguments");
+  hipLaunchKernelGGL(er::fm_bwd_kernel<1>, dim3(er::blocks_for(static_cast<int64_t>(B) * F * D)), dim3(er::kBlock), 0,
+                     er::as_stream(stream), x, sum_saved, g, B, F, D, x_stride, dx, dx_stride, accumulate);
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
+int er_rowsum_fwd(const float* x, int32_t B, int32_t n, int32_t x_stride, float* out, er_stream_t stream) {
+  ER_REQUIRE(x && out && B > 0 && n > 0, "er_rowsum_fwd: bad arguments");
+  hipLaunchKernelGGL(er::rowsum_fwd_kernel, dim3(er::blocks_for(static_cast<int64_t>(B) * 4)), dim3(er::kBlock), 0,
+                     er::as_stream(stream), x, B, n, x_stride, out);
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
+int er_rowsum_bwd(const float* g, int32_t B, int32_t n, float* dx, int32_t dx_stride, int accumulate,
+                  er_stream_t stream) {
+  ER_REQUIRE(g && dx && B > 0 && n > 0, "er_rowsum_bwd: bad arguments");
+  hipLaunchKernelGGL(er::rowsum_bwd_kernel, dim3(er::blocks_for(static_cast<int64_t>(B) * n)), dim3(er::kBlock), 0,
+                     er::as_stream(stream), g, B, n, dx, dx_stride, accumulate);
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
+int er_axpy2d(const float* x, int32_t x_stride, float alpha, float* y, int32_t y_stride, int32_t rows, int32_t cols,
+              int accumulate, er_stream_t stream) {
+  ER_REQUIRE(x && y && rows > 0 && cols > 0, "er_axpy2d: bad arguments");
+  hipLaunchKernelGGL(er::axpy2d_kernel, dim3(er::blocks_for(static_cast<int64_t>(rows) * cols)), dim3(er::kBlock), 0,
+                     er::as_stream(stream), x, x_stride, alpha, y, y_stride, rows, cols, accumulate);
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
+int er_cross_v1_fwd(const float* x0, const float* w, const float* b, int32_t B, int32_t d, int32_t L, float* out,
+                    float* xl_dots, er_stream_t stream) {
+  ER_REQUIRE(x0 && w && b && out && xl_dots && B > 0 && L > 0, "er_cross_v1_fwd: bad arguments");
+  ER_REQUIRE(d > 0 && d <= 64 * er::kCrossE, "er_cross_v1_fwd: d=%d exceeds %d", d, 64 * er::kCrossE);
+  hipLaunchKernelGGL(er::cross_v1_fwd_kernel, dim3(static_cast<int>(er::ceil_div(B, er::kBlock / 64))),
+                     dim3(er::kBlock), 0, er::as_stream(stream), x0, w, b, B, d, L, out, xl_dots);
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
+int er_cross_v1_bwd_partials(int32_t B) { return B < 512 ? B : 512; }
+
+int er_cross_v1_bwd(const float* x0, const float* w, const float* b, const float* xl_dots, const float* dout,
+                    int32_t B, int32_t d, int32_t L, float* dx0, float* dw_partials, float* db_partials,
+                    er_stream_t stream) {
+  ER_REQUIRE(x0 && w && b && xl_dots && dout && dx0 && dw_partials && db_partials, "er_cross_v1_bwd: null argument");
+  ER_REQUIRE(d > 0 && d <= 64 * er::kCrossE, "er_cross_v1_bwd: d=%d exceeds %d", d, 64 * er::kCrossE);
+  const size_t lds = sizeof(float) * 2 * static_cast<size_t>(L) * d;
+  ER_REQUIRE(lds <= 160 * 1024, "er_cross_v1_bwd: L*d too large for LDS accumulators");
+  if (lds > 64 * 1024) {
+    ER_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(er::cross_v1_bwd_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+  }
+  hipLaunchKernelGGL(er::cross_v1_bwd_kernel, dim3(er_cross_v1_bwd_partials(B)), dim3(64), lds, er::as_stream(stream),
+                     x0, w, b, xl_dots, dout, B, d, L, dx0, dw_partials, db_partials);
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
+int er_cross_v2_epilogue_fwd(const float* x0, const float* x, const float* u, const float* bias, float diag_scale,
+                             int32_t B, int32_t d, float* out, er_stream_t stream) {
+  ER_REQUIRE(x0 && x && u && out && B > 0 && d > 0, "er_cross_v2_epilogue_fwd: bad arguments");
+  const int64_t n = static_cast<int64_t>(B) * d;
+  hipLaunchKernelGGL(er::cross_v2_fwd_kernel, dim3(er::blocks_for(n)), dim3(er::kBlock), 0, er::as_stream(stream), x0,
+                     x, u, bias, diag_scale, n, d, out);
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
+int er_cross_v2_epilogue_bwd(const float* x0, const float* x, const float* u, const float* bias, float diag_scale,
+                             const float* dout, int32_t B, int32_t d, float* dx0, int accumulate_dx0, float* dx,
+                             float* du, er_stream_t stream) {
+  ER_REQUIRE(x0 && x && u && dout && dx0 && dx && du && B > 0 && d > 0, "er_cross_v2_epilogue_bwd: bad arguments");
+  const int64_t n = static_cast<int64_t>(B) * d;
+  hipLaunchKernelGGL(er::cross_v2_bwd_kernel, dim3(er::blocks_for(n)), dim3(er::kBlock), 0, er::as_stream(stream), x0,
+                     x, u, bias, diag_scale, dout, n, d, dx0, accumulate_dx0, dx, du);
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
+int er_din_concat_fwd(const float* query, const float* hist, int32_t B, int32_t L, int32_t E, float* out,
+                      er_stream_t stream) {
+  ER_REQUIRE(query && hist && out && B > 0 && L > 0 && E > 0, "er_din_concat_fwd: bad arguments");
+  hipLaunchKernelGGL(er::din_concat_fwd_kernel, dim3(er::blocks_for(static_cast<int64_t>(B) * L * E)),
+                     dim3(er::kBlock), 0, er::as_stream(stream), query, hist, B, L, E, out);
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
+int er_din_concat_bwd(const float* query, const float* hist, const float* dout, int32_t B, int32_t L, int32_t E,
+                      float* dquery, int acc_q, float* dhist, int acc_h, er_stream_t stream) {
+  ER_REQUIRE(query && hist && dout && B > 0 && L > 0 && E > 0, "er_din_concat_bwd: bad arguments");
+  hipStream_t s = er::as_stream(stream);
+  if (dhist) {
+    hipLaunchKernelGGL(er::din_concat_bwd_hist_kernel, dim3(er::blocks_for(static_cast<int64_t>(B) * L * E)),
+                       dim3(er::kBlock), 0, s, query, dout, B, L, E, dhist, acc_h);
+    ER_LAUNCH_CHECK();
+  }
+  if (dquery) {
+    hipLaunchKernelGGL(er::din_concat_bwd_query_kernel, dim3(er::blocks_for(static_cast<int64_t>(B) * E)),
+                       dim3(er::kBlock), 0, s, hist, dout, B, L, E, dquery, acc_q);
+    ER_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+int er_din_pool_fwd(const float* scores, const float* hist, const int32_t* seq_len, int32_t B, int32_t L, int32_t E,
+                    float scale, float* probs_out, float* out, er_stream_t stream) {
+  ER_REQUIRE(scores && hist && seq_len && probs_out && out && B > 0 && L > 0 && E > 0, "er_din_pool_fwd: bad arguments");
+  hipLaunchKernelGGL(er::din_pool_fwd_kernel, dim3(static_cast<int>(er::ceil_div(B, er::kBlock / 64))),
+                     dim3(er::kBlock), 0, er::as_stream(stream), scores, hist, seq_len, B, L, E, scale, probs_out, out);
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
+int er_din_pool_bwd(const float* probs, const float* hist, const int32_t* seq_len, const float* dout, int32_t B,
+                    int32_t L, int32_t E, float scale, float* dscores, float* dhist, int acc_h, er_stream_t stream) {
+  ER_REQUIRE(probs && hist && seq_len && dout && dscores && dhist, "er_din_pool_bwd: null argument");
+  hipLaunchKernelGGL(er::din_pool_bwd_kernel, dim3(static_cast<int>(er::ceil_div(B, er::kBlock / 64))),
+                     dim3(er::kBlock), 0, er::as_stream(stream), probs, hist, seq_len, dout, B, L, E, scale, dscores,
+                     dhist, acc_h);
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
+int er_mmoe_mix_fwd(const float* experts, const float* gate_logits, int32_t T, int32_t E, int32_t B, int32_t H,
+                    float* gates_out, float* out, er_stream_t stream) {
+  ER_REQUIRE(experts && gate_logits && gates_out && out && T > 0 && E > 0 && B > 0 && H > 0,
+             "er_mmoe_mix_fwd: bad arguments");
+  ER_REQUIRE(E <= er::kMaxExperts, "er_mmoe_mix_fwd: at most %d experts", er::kMaxExperts);
+  hipStream_t s = er::as_stream(stream);
+  hipLaunchKernelGGL(er::mmoe_gate_softmax_kernel, dim3(er::blocks_for(static_cast<int64_t>(T) * B)), dim3(er::kBlock),
+                     0, s, gate_logits, static_cast<int64_t>(T) * B, E, gates_out);
+  ER_LAUNCH_CHECK();
+  hipLaunchKernelGGL(er::mmoe_mix_fwd_kernel, dim3(er::blocks_for(static_cast<int64_t>(T) * B * H)), dim3(er::kBlock),
+                     0, s, experts, gates_out, T, E, B, H, out);
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
+int er_mmoe_mix_bwd(const float* experts, const float* gates, const float* dout, int32_t T, int32_t E, int32_t B,
+                    int32_t H, float* dexperts, float* dgate_logits, er_stream_t stream) {
+  ER_REQUIRE(experts && gates && dout && dexperts && dgate_logits, "er_mmoe_mix_bwd: null argument");
+  ER_REQUIRE(E <= er::kMaxExperts, "er_mmoe_mix_bwd: at most %d experts", er::kMaxExperts);
+  hipStream_t s = er::as_stream(stream);
+  hipLaunchKernelGGL(er::mmoe_mix_bwd_experts_kernel, dim3(er::blocks_for(static_cast<int64_t>(E) * B * H)),
+                     dim3(er::kBlock), 0, s, gates, dout, T, E, B, H, dexperts);
+  ER_LAUNCH_CHECK();
+  hipLaunchKernelGGL(er::mmoe_mix_bwd_gate_kernel,
+                     dim3(static_cast<int>(er::ceil_div(static_cast<int64_t>(T) * B, er::kBlock / 64))),
+                     dim3(er::kBlock), 0, s, experts, gates, dout, T, E, B, H, dgate_logits);
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,310 @@
+/*
+ * easyrec_hip.h - C ABI of libeasyrec_hip.so: hand-written gfx950 (MI355X / CDNA4) kernels for
+ * EasyRec's sparse-embedding + feature-interaction + MLP training hot path.
+ *
+ * The reference (alibaba/EasyRec v0.8.7) owns no device code: every kernel on this path is a
+ * TensorFlow op issued from Python.  Each entry point below therefore names the reference call
+ * site (file:line under /root/reference) whose TF-op chain it replaces - that is the "FFI" a
+ * maintainer would rebind (INTEGRATION.md shows the ctypes / tf.load_op_library stubs).
+ *
+ * Conventions:
+ *   - every function returns 0 on success, non-zero on error; er_last_error() gives the message
+ *     (thread-local).  Mirrors the OP_REQUIRES_OK status style of the reference's own C++ ops
+ *     (easy_rec/python/ops/src/load_dense_embed.cc:54,125-130).
+ *   - the caller owns every buffer.  Pointers are raw device pointers unless the name ends in
+ *     `_host`.  The library allocates only inside opaque handles (er_*_create / er_*_destroy).
+ *   - device work is asynchronous on the given stream (a hipStream_t passed as void*); no
+ *     function synchronises; all are safe to capture in a hipGraph after handle creation.
+ *   - fp32 arithmetic is compiled with -ffp-contract=off and IEEE div/sqrt so that results can
+ *     be compared bit-for-bit with the step-by-step CPU oracle where the order is defined.
+ *   - per-step scalars (learning rate, beta powers) are read from DEVICE memory (er_opt_hyper)
+ *     so that a captured graph can be replayed with new values.
+ */
+#ifndef EASYREC_HIP_H_
+#define EASYREC_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ER_ABI_VERSION 1
+
+typedef void* er_stream_t; /* hipStream_t */
+
+int er_abi_version(void);
+const char* er_last_error(void);
+/* Pre-size the library's internal column-reduction scratch (floats).  Call once before capturing
+ * a hipGraph: growing it calls hipMalloc, which is not capturable. */
+int er_reserve_scratch(int64_t floats);
+/* number of compute units / XCDs of the current device (launch sizing, reported by bench) */
+int er_device_info(int* cu_count, int* wave_size, char* arch_name, int arch_name_len);
+
+/* --------------------------------------------------------------------------------------------
+ * K1  id hashing.  Replaces StringToHashBucketFast issued at
+ *     easy_rec/python/compat/feature_column/feature_column_v2.py:3915-3921
+ *     (HashedCategoricalColumn._transform_input_tensor) and layers/input_layer.py:235,240.
+ *     bucket = FarmHash Fingerprint64(bytes) mod num_buckets.
+ * Strings are packed: string i = bytes[offsets[i], offsets[i+1]).  Strings are column-major:
+ * string i belongs to column i / n_per_col and uses num_buckets[column].
+ * drop_empty != 0: an empty string yields -1 (the reference drops '' cells of dense string inputs
+ * before hashing: compat/feature_column/feature_column.py:2599-2643; -1 ids are pruned by the
+ * lookup, giving the zero vector).  drop_empty == 0: '' is hashed like any other string (Tag /
+ * Sequence tokens, which arrive already sparse).
+ * -------------------------------------------------------------------------------------------- */
+int er_hash_bucket_fast_host(const uint8_t* bytes_host, const int64_t* offsets_host, int64_t n,
+                             int64_t n_per_col, const uint64_t* num_buckets_host, int drop_empty,
+                             int64_t* out_host);
+int er_hash_bucket_fast(const uint8_t* bytes, const int64_t* offsets, int64_t n, int64_t n_per_col,
+                        const uint64_t* num_buckets, int drop_empty, int64_t* out,
+                        er_stream_t stream);
+/* AsString for integer id columns (feature_column_v2.py:3918, input/input.py:356-376): decimal
+ * text of int64 -> hashed directly on device without materialising strings. */
+int er_hash_bucket_fast_int64(const int64_t* values, int64_t n, int64_t n_per_col,
+                              const uint64_t* num_buckets, int64_t* out, er_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
+ * K2  embedding lookup + combine, all lookups of a model in ONE launch.  Replaces, per embedding
+ *     column, the chain  Where/GatherNd -> SparseFillEmptyRows -> Unique -> GatherV2 ->
+ *     SparseSegmentSum/Mean/SqrtN | Mul+SegmentSum -> Select -> Reshape -> ConcatV2  issued by
+ *       EmbeddingColumn._get_dense_tensor_internal_helper  feature_column_v2.py:3434-3462
+ *       (safe_embedding_lookup_sparse, readable copy: compat/embedding_ops.py:37-162)
+ *       _internal_input_layer / _get_logits concat         compat/feature_column/feature_column.py:384-414
+ *     and the embedding-output L2 term of layers/input_layer.py:369-375 (sum of squares emitted
+ *     as per-block partials).
+ * -------------------------------------------------------------------------------------------- */
+enum { ER_COMBINER_SUM = 0, ER_COMBINER_MEAN = 1, ER_COMBINER_SQRTN = 2 };
+
+typedef struct er_lookup_desc {
+  const float* table;     /* row 0 of this lookup's table; [rows, dim] row-major fp32           */
+  const int64_t* ids;     /* dense mode: [n_rows]; ragged mode: [nnz]                            */
+  const int32_t* offsets; /* NULL = dense mode (one id per output row, id<0 = missing);
+                             else CSR row offsets [n_rows+1]                                     */
+  const float* weights;   /* NULL or one weight per id                                           */
+  float* out;             /* forward: output matrix base; backward: upstream-gradient base      */
+  int64_t rows;           /* table rows (ids outside [0, rows) are pruned)                       */
+  int64_t key_base;       /* index of table row 0 inside its table group (backward keys)        */
+  int32_t dim;            /* embedding dim                                                       */
+  int32_t out_stride;     /* floats between consecutive output rows                              */
+  int32_t out_col;        /* first output column of this lookup                                  */
+  int32_t combiner;       /* ER_COMBINER_*                                                       */
+  int32_t n_rows;         /* output rows: batch size, or batch*seq_len for sequence lookups      */
+  int32_t max_nnz;        /* capacity of ids[] (dense mode: == n_rows)                           */
+} er_lookup_desc;
+
+typedef struct er_emb_plan er_emb_plan;
+
+/* descs_host: n descriptors (copied).  Lookups may have different dims. */
+int er_emb_plan_create(const er_lookup_desc* descs_host, int n, er_emb_plan** plan);
+int er_emb_plan_update(er_emb_plan* plan, const er_lookup_desc* descs_host, int n);
+int er_emb_plan_destroy(er_emb_plan* plan);
+/* number of thread blocks (= number of sum-of-squares partials written by er_emb_fwd) */
+int er_emb_plan_num_blocks(const er_emb_plan* plan);
+/* sumsq_partials: NULL or [num_blocks] floats; partial b = sum of out^2 written by block b. */
+int er_emb_fwd(const er_emb_plan* plan, float* sumsq_partials, er_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
+ * K3+K4  embedding backward + row-wise optimizer for one table group (all tables of one dim
+ *     stored back to back: var/m/v are [total_rows, dim]).  Replaces the gradient of the chain
+ *     above (UnsortedSegmentSum -> IndexedSlices(unique ids), AddN for shared tables) and the
+ *     sparse apply of the optimizer:
+ *       tf.train.AdamOptimizer._apply_sparse   (builders/optimizer_builder.py:61-66): m and v of
+ *         EVERY row decay each step, every row's var moves        -> ER_OPT_ADAM
+ *       AdamOptimizerS._apply_sparse_shared    (compat/adam_s.py:185-213): touched rows only
+ *                                                                  -> ER_OPT_LAZY_ADAM
+ *       tf.train.AdagradOptimizer sparse apply (optimizer_builder.py:110-116) -> ER_OPT_ADAGRAD
+ *       tf.train.GradientDescent / Momentum(0)                     -> ER_OPT_SGD
+ *     Pipeline: build 32-bit keys (global row) -> stable radix sort -> two-level in-order
+ *     segmented reduction (deterministic) fused with the row update; ER_OPT_ADAM additionally
+ *     runs one streaming sweep over the untouched rows (bitmap-skipped).
+ * -------------------------------------------------------------------------------------------- */
+enum { ER_OPT_SGD = 0, ER_OPT_ADAM = 1, ER_OPT_LAZY_ADAM = 2, ER_OPT_ADAGRAD = 3 };
+
+/* Lives in DEVICE memory; the host refreshes it every step (fp32 scalars computed the way TF
+ * computes them, see easyrec_amd/builders/optimizer_builder.py). */
+typedef struct er_opt_hyper {
+  float lr;            /* scheduled learning rate for this step                                  */
+  float lr_t;          /* Adam: lr * sqrt(1 - beta2^t) / (1 - beta1^t)                           */
+  float beta1;
+  float beta2;
+  float one_minus_beta1;
+  float one_minus_beta2;
+  float eps;
+  float grad_scale;    /* multiplies summed row gradients (embedding lr multiplier, 1/world)     */
+  float reserved[8];
+} er_opt_hyper;
+
+typedef struct er_emb_group er_emb_group;
+
+/* descs_host: the group's lookups with `out` = gradient base of the matching forward output.
+ * var/m/v: [total_rows, dim]; m and/or v may be NULL when the optimizer does not use them
+ * (SGD: both; Adagrad: m).  touched_bitmap: [ceil(total_rows/32)] zero-initialised uint32 words,
+ * required for ER_OPT_ADAM only. */
+int er_emb_group_create(const er_lookup_desc* descs_host, int n, int32_t dim, int64_t total_rows,
+                        float* var, float* m, float* v, uint32_t* touched_bitmap,
+                        er_emb_group** group);
+int er_emb_group_update(er_emb_group* group, const er_lookup_desc* descs_host, int n);
+int er_emb_group_destroy(er_emb_group* group);
+/* total entries (sort length) of the group */
+int64_t er_emb_group_num_entries(const er_emb_group* group);
+/* backward + update.  opt_kind: ER_OPT_*; hyper: device pointer. */
+int er_emb_bwd_update(er_emb_group* group, int opt_kind, const er_opt_hyper* hyper,
+                      er_stream_t stream);
+/* backward only: writes the de-duplicated gradient: unique_keys [<= num_entries] (global rows,
+ * ascending), unique_grads [<= num_entries, dim], *n_unique (device int32).  Used by parity tests
+ * and by embedding-parallel training (grads are sent to the row owner instead of applied). */
+int er_emb_bwd_reduce(er_emb_group* group, uint32_t* unique_keys, float* unique_grads,
+                      int32_t* n_unique, er_stream_t stream);
+/* ER_OPT_ADAM's dense-decay sweep alone (exposed for benchmarking / roofline measurement). */
+int er_adam_decay_sweep(float* var, float* m, float* v, uint32_t* touched_bitmap,
+                        int64_t total_rows, int32_t dim, const er_opt_hyper* hyper,
+                        er_stream_t stream);
+/* --------------------------------------------------------------------------------------------
+ * K5  FM second-order interaction + wide sum.  Replaces Pack/Sum/Square/Sub/Mul of
+ *     FM.__call__ easy_rec/python/layers/fm.py:20-26 (keras variant layers/keras/interaction.py:24-44)
+ *     and reduce_sum of model/deepfm.py:62-63.
+ * x: [B, F*D] (row stride x_stride); fm_out [B, D] = 0.5*((sum_f e)^2 - sum_f e^2);
+ * sum_out [B, D] = sum_f e (saved for backward).
+ * -------------------------------------------------------------------------------------------- */
+int er_fm_fwd(const float* x, int32_t B, int32_t F, int32_t D, int32_t x_stride, float* fm_out,
+              float* sum_out, er_stream_t stream);
+/* dx[b,f,:] (+)= g[b,:] * (S[b,:] - x[b,f,:]).  accumulate != 0 adds into dx. */
+int er_fm_bwd(const float* x, const float* sum_saved, const float* g, int32_t B, int32_t F,
+              int32_t D, int32_t x_stride, float* dx, int32_t dx_stride, int accumulate,
+              er_stream_t stream);
+/* out[b] = sum_j x[b, j], j < n */
+int er_rowsum_fwd(const float* x, int32_t B, int32_t n, int32_t x_stride, float* out,
+                  er_stream_t stream);
+/* y[i] (+)= alpha * x[i]  over a strided 2-D view (used for the embedding L2 gradient
+ * lambda*out and for broadcasting d(wide_sum) back to the wide columns) */
+int er_axpy2d(const float* x, int32_t x_stride, float alpha, float* y, int32_t y_stride,
+              int32_t rows, int32_t cols, int accumulate, er_stream_t stream);
+/* y[b, j] (+)= g[b]  (gradient of the row sum) */
+int er_rowsum_bwd(const float* g, int32_t B, int32_t n, float* dx, int32_t dx_stride,
+                  int accumulate, er_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
+ * K6  DCN-v1 cross network.  Replaces Mul/Sum/Add x L of DCN._cross_net model/dcn.py:32-45:
+ *     x_{l+1} = x0 * (x_l . w_l) + b_l + x_l.   All L layers in one launch, one wave per row.
+ * x0 [B, d]; w, b [L, d]; out [B, d]; xl_dots [B, L] saves (x_l . w_l) for backward.
+ * -------------------------------------------------------------------------------------------- */
+int er_cross_v1_fwd(const float* x0, const float* w, const float* b, int32_t B, int32_t d,
+                    int32_t L, float* out, float* xl_dots, er_stream_t stream);
+/* dx0 [B, d]; dw_partials, db_partials [n_partial, L, d] (reduced by er_colsum);
+ * returns n_partial through er_cross_v1_bwd_partials(). Recomputes x_l from x0 and xl_dots. */
+int er_cross_v1_bwd_partials(int32_t B);
+int er_cross_v1_bwd(const float* x0, const float* w, const float* b, const float* xl_dots,
+                    const float* dout, int32_t B, int32_t d, int32_t L, float* dx0,
+                    float* dw_partials, float* db_partials, er_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
+ * K7  DCN-v2 cross epilogue.  Replaces BiasAdd/Mul/Add of Cross.call
+ *     layers/keras/interaction.py:276-286 after the  W x_l  GEMM:
+ *     out = x0 * (u + bias + diag_scale * x) + x          (u = x W, or (x U) V for low rank)
+ * -------------------------------------------------------------------------------------------- */
+int er_cross_v2_epilogue_fwd(const float* x0, const float* x, const float* u, const float* bias,
+                             float diag_scale, int32_t B, int32_t d, float* out,
+                             er_stream_t stream);
+/* given dout: dx0 (+)= dout * (u + bias + diag*x); du = dout * x0; dx (+)= dout*(1 + diag*x0);
+ * dbias via er_colsum(du). */
+int er_cross_v2_epilogue_bwd(const float* x0, const float* x, const float* u, const float* bias,
+                             float diag_scale, const float* dout, int32_t B, int32_t d,
+                             float* dx0, int accumulate_dx0, float* dx, float* du,
+                             er_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
+ * K8  DIN target attention.  Replaces Tile/ConcatV2 (input of the attention MLP) and
+ *     SequenceMask/Select/Softmax/BatchMatMul (pooling) of MultiTowerDIN.din
+ *     model/multi_tower_din.py:62-97 (same math: layers/sequence_feature_layer.py:123-189,
+ *     layers/keras/din.py:27-67).
+ * din_concat: a[b,t,:] = [q_b, h_bt, q_b - h_bt, q_b * h_bt]           ([B, L, 4E])
+ * din_pool  : scores [B, L] -> mask t >= len[b] with -2^32+1 -> softmax over L -> p @ hist
+ * -------------------------------------------------------------------------------------------- */
+int er_din_concat_fwd(const float* query, const float* hist, int32_t B, int32_t L, int32_t E,
+                      float* out, er_stream_t stream);
+/* dquery [B,E] (+)=, dhist [B,L,E] (+)= from dout [B,L,4E] */
+int er_din_concat_bwd(const float* query, const float* hist, const float* dout, int32_t B,
+                      int32_t L, int32_t E, float* dquery, int acc_q, float* dhist, int acc_h,
+                      er_stream_t stream);
+/* probs_out [B, L] saved for backward; out [B, E] */
+int er_din_pool_fwd(const float* scores, const float* hist, const int32_t* seq_len, int32_t B,
+                    int32_t L, int32_t E, float scale, float* probs_out, float* out,
+                    er_stream_t stream);
+int er_din_pool_bwd(const float* probs, const float* hist, const int32_t* seq_len,
+                    const float* dout, int32_t B, int32_t L, int32_t E, float scale,
+                    float* dscores, float* dhist, int acc_h, er_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
+ * K9  MLP layer pieces around the GEMM.  Replaces BiasAdd / FusedBatchNorm(train) / Relu of
+ *     DNN.__call__ layers/dnn.py:57-79 (keras MLP layers/keras/blocks.py:84-110) and Dice
+ *     layers/keras/activation.py:47-70.
+ * er_bn_act_fwd: y = act(gamma * (x + bias - mean) * rsqrt(var + eps) + beta), batch statistics
+ *   over the B rows (biased variance); updates moving stats with `momentum` when not NULL.
+ *   act: 0 = identity, 1 = relu.  bias/gamma/beta may be NULL (treated as 0/1/0).
+ *   use_bn == 0: y = act(x + bias).  save_mean/save_invstd: [N] (needed by backward).
+ * -------------------------------------------------------------------------------------------- */
+enum { ER_ACT_NONE = 0, ER_ACT_RELU = 1 };
+int er_bn_act_fwd(const float* x, const float* bias, const float* gamma, const float* beta,
+                  int32_t B, int32_t N, int use_bn, float eps, float momentum,
+                  float* moving_mean, float* moving_var, int act, float* y, float* save_mean,
+                  float* save_invstd, er_stream_t stream);
+/* dx [B,N]; dbias/dgamma/dbeta [N] (overwritten; NULL to skip). y is the forward output
+ * (relu mask); x the forward input. */
+int er_bn_act_bwd(const float* x, const float* bias, const float* gamma, const float* y,
+                  const float* save_mean, const float* save_invstd, const float* dy, int32_t B,
+                  int32_t N, int use_bn, int act, float* dx, float* dbias, float* dgamma,
+                  float* dbeta, er_stream_t stream);
+/* out[j] = sum_i x[i, j]  (bias gradients, partial reductions) */
+int er_colsum(const float* x, int32_t rows, int32_t cols, int32_t x_stride, float* out,
+              er_stream_t stream);
+/* Dice: p = sigmoid(BN_noaffine(x, eps)); y = alpha*(1-p)*x + p*x */
+int er_dice_fwd(const float* x, const float* alpha, int32_t B, int32_t N, float eps,
+                float momentum, float* moving_mean, float* moving_var, float* y,
+                float* save_mean, float* save_invstd, er_stream_t stream);
+int er_dice_bwd(const float* x, const float* alpha, const float* save_mean,
+                const float* save_invstd, const float* dy, int32_t B, int32_t N, float* dx,
+                float* dalpha, er_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
+ * K10 loss.  Replaces SigmoidCrossEntropyWithLogits + Mean of
+ *     loss_builder.build builders/loss_builder.py:35-39 (tf.losses.sigmoid_cross_entropy,
+ *     reduction SUM_BY_NONZERO_WEIGHTS) and its gradient.
+ * loss_out[0] = sum_i w_i * ce(z_i, y_i) / #(w_i != 0);  dlogits[i] = w_i*(sigmoid(z_i)-y_i)/#nz
+ * weights: NULL = all ones.  loss_scale multiplies both (task weight in multi-task models).
+ * -------------------------------------------------------------------------------------------- */
+int er_sigmoid_ce_fwd_bwd(const float* logits, const float* labels, const float* weights,
+                          int32_t B, float loss_scale, float* loss_out, float* dlogits,
+                          float* probs_out, er_stream_t stream);
+/* out[0] = scale * sum of all n partials (deterministic single-block tree) */
+int er_reduce_sum(const float* partials, int32_t n, float scale, float* out, int accumulate,
+                  er_stream_t stream);
+/* out[0] (+)= sum_i 0.5 * coef[i] * w[i]^2   (tf.nn.l2_loss terms, compat/regularizers.py:106) */
+int er_l2_loss(const float* w, const float* coef, int64_t n, float* out, int accumulate,
+               er_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
+ * K11 MMoE mixing.  Replaces Pack/Softmax/Mul/Sum of MMOE.__call__ layers/mmoe.py:73-82:
+ *     out[t][b,:] = sum_e softmax_e(gate_logits[t][b,:]) * experts[e][b,:]
+ * experts [E, B, H] ; gate_logits [T, B, E]; out [T, B, H]; gates_out [T, B, E] (softmax saved).
+ * -------------------------------------------------------------------------------------------- */
+int er_mmoe_mix_fwd(const float* experts, const float* gate_logits, int32_t T, int32_t E,
+                    int32_t B, int32_t H, float* gates_out, float* out, er_stream_t stream);
+int er_mmoe_mix_bwd(const float* experts, const float* gates, const float* dout, int32_t T,
+                    int32_t E, int32_t B, int32_t H, float* dexperts, float* dgate_logits,
+                    er_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
+ * Dense-variable optimizer: one launch over the flat parameter buffer.  Replaces ApplyAdam /
+ *     ApplyAdagrad / ApplyGradientDescent issued per variable by optimize_loss
+ *     compat/optimizers.py:412-416, plus the kernel L2 gradient l2*W
+ *     (kernel_regularizer of layers/dnn.py:57-62).   g = grad_scale*grad + l2coef*w
+ * -------------------------------------------------------------------------------------------- */
+int er_dense_opt_step(float* w, float* m, float* v, const float* grad, const float* l2coef,
+                      int64_t n, int opt_kind, const er_opt_hyper* hyper, er_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EASYREC_HIP_H_ */
