@@ -1,0 +1,36 @@
+"""Process-wide build context (the analogue of TF's default graph + variable scopes).
+
+The reference relies on TF's implicit global state: `tf.get_variable`, the REGULARIZATION_LOSSES
+and UPDATE_OPS collections (model/easy_rec_estimator.py:166-213).  Layers here fetch the dense
+`VarStore` and the `EmbeddingEngine` of the model being built/executed from this context.
+"""
+import contextlib
+
+_STACK = []
+
+
+class ModelContext(object):
+
+  def __init__(self, varstore, engine, is_training=True):
+    self.varstore = varstore
+    self.engine = engine
+    self.is_training = is_training
+    self.building = True  # build pass: variables are being created, moving statistics frozen
+
+
+@contextlib.contextmanager
+def use(ctx):
+  _STACK.append(ctx)
+  try:
+    yield ctx
+  finally:
+    _STACK.pop()
+
+
+def current():
+  assert _STACK, 'no active easyrec_amd ModelContext (wrap model calls in core.context.use(ctx))'
+  return _STACK[-1]
+
+
+def varstore():
+  return current().varstore

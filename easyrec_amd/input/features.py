@@ -1,0 +1,197 @@
+"""Device-resident feature "placeholders" and the host->device batch layout.
+
+The reference's model constructors take a `features` dict of TF tensors produced by
+`Input._preprocess` (easy_rec/python/input/input.py:806-939).  Here `features` is a
+`DeviceFeatures`: persistent HBM buffers with fixed addresses (so the whole training step can be
+captured in a hipGraph) that are refilled for every batch by `load()`.  The per-feature
+representation follows the reference's parsed dict:
+
+  IdFeature + hash_bucket_size : packed utf-8 bytes + offsets  -> hashed ON DEVICE (er_hash_bucket_fast)
+                                 or pre-hashed int64 ids (host hashing in data-loader threads)
+  IdFeature + num_buckets/vocab: int64 ids, out-of-range / OOV already mapped to default 0
+  RawFeature                   : fp32, min/max-normalised (input.py:638-640); with embedding_dim>0 the
+                                 value is the weight of projection id 0..raw_input_dim-1 (input.py:648-673)
+  TagFeature                   : CSR ids (+ weights)            (input.py:432-505)
+  SequenceFeature              : [B, L] ids padded with -1 + lengths (input.py:677-804)
+"""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from easyrec_amd.protos.feature_config_pb2 import FeatureConfig
+
+
+def feature_name_of(fc):
+  return fc.feature_name if fc.HasField('feature_name') else fc.input_names[0]
+
+
+class FeatureSchema(object):
+  """Static description of what a batch contains, derived from the config."""
+
+  def __init__(self, data_config, feature_configs, batch_size=None, max_tag_len=16,
+               max_seq_len=50, max_str_bytes=32):
+    self.batch_size = int(batch_size or data_config.batch_size)
+    self.label_fields = list(data_config.label_fields)
+    self.sample_weight = data_config.sample_weight if data_config.HasField('sample_weight') else None
+    self.raw = OrderedDict()      # name -> dict(dim, row)  rows of the raw block
+    self.hash_single = OrderedDict()   # name -> dict(buckets, col)
+    self.int_single = OrderedDict()    # name -> dict(col, num_buckets)
+    self.tags = OrderedDict()     # name -> dict(cap, weighted, hash_buckets | None)
+    self.seqs = OrderedDict()     # name -> dict(max_len, hash_buckets | None)
+    self.feature_configs = {}
+    self.max_str_bytes = max_str_bytes
+    n_raw_rows = 0
+    for fc in feature_configs:
+      name = feature_name_of(fc)
+      self.feature_configs[name] = fc
+      ft = fc.feature_type
+      if ft == FeatureConfig.RawFeature:
+        self.raw[name] = {'dim': fc.raw_input_dim, 'row': n_raw_rows}
+        n_raw_rows += fc.raw_input_dim
+      elif ft == FeatureConfig.IdFeature:
+        if fc.HasField('hash_bucket_size') and fc.hash_bucket_size > 0:
+          self.hash_single[name] = {'buckets': int(fc.hash_bucket_size), 'col': len(self.hash_single)}
+        else:
+          nb = len(fc.vocab_list) if fc.vocab_list else int(fc.num_buckets)
+          self.int_single[name] = {'col': len(self.int_single), 'num_buckets': nb}
+      elif ft == FeatureConfig.TagFeature:
+        hb = int(fc.hash_bucket_size) if fc.HasField('hash_bucket_size') and fc.hash_bucket_size > 0 else None
+        weighted = len(fc.input_names) > 1 or fc.HasField('kv_separator')
+        self.tags[name] = {'cap': self.batch_size * max_tag_len, 'weighted': weighted, 'hash_buckets': hb}
+      elif ft == FeatureConfig.SequenceFeature:
+        hb = int(fc.hash_bucket_size) if fc.HasField('hash_bucket_size') and fc.hash_bucket_size > 0 else None
+        ml = int(fc.max_seq_len) if fc.HasField('max_seq_len') and fc.max_seq_len > 0 else max_seq_len
+        self.seqs[name] = {'max_len': ml, 'hash_buckets': hb}
+      elif ft in (FeatureConfig.ComboFeature, FeatureConfig.LookupFeature):
+        if fc.HasField('hash_bucket_size') and fc.hash_bucket_size > 0:
+          self.hash_single[name] = {'buckets': int(fc.hash_bucket_size), 'col': len(self.hash_single)}
+      # Expr / PassThrough: handled by the Input class as raw values when used
+    self.n_raw_rows = n_raw_rows
+
+  @property
+  def hash_buckets_array(self):
+    return np.array([v['buckets'] for v in self.hash_single.values()], dtype=np.uint64)
+
+
+class DeviceFeatures(object):
+  """Persistent device buffers for one batch; dict-like access by feature name."""
+
+  def __init__(self, schema, device, backend=None):
+    self.schema = schema
+    self.device = torch.device(device)
+    self.version = 0
+    self._backend = backend
+    B = schema.batch_size
+    dev = self.device
+    self.labels = torch.zeros(max(len(schema.label_fields), 1), B, dtype=torch.float32, device=dev)
+    self.sample_weight = None
+    self.raw_block = torch.zeros(max(schema.n_raw_rows, 1), B, dtype=torch.float32, device=dev)
+    nh = len(schema.hash_single)
+    self.hash_ids = torch.full((max(nh, 1), B), -1, dtype=torch.int64, device=dev)
+    self.str_bytes = torch.zeros(max(nh * B * schema.max_str_bytes, 16), dtype=torch.uint8, device=dev)
+    self.str_offsets = torch.zeros(nh * B + 1, dtype=torch.int64, device=dev)
+    self.hash_buckets = torch.from_numpy(schema.hash_buckets_array.astype(np.int64)).to(dev) if nh else None
+    self.int_ids = torch.zeros(max(len(schema.int_single), 1), B, dtype=torch.int64, device=dev)
+    self.zero_ids = torch.zeros(B, dtype=torch.int64, device=dev)  # projection id 0 of raw features
+    self.tags = {}
+    for name, t in schema.tags.items():
+      self.tags[name] = {
+          'ids': torch.full((t['cap'],), -1, dtype=torch.int64, device=dev),
+          'offsets': torch.zeros(B + 1, dtype=torch.int32, device=dev),
+          'weights': torch.zeros(t['cap'], dtype=torch.float32, device=dev) if t['weighted'] else None,
+      }
+    self.seqs = {}
+    for name, s in schema.seqs.items():
+      self.seqs[name] = {
+          'ids': torch.full((B, s['max_len']), -1, dtype=torch.int64, device=dev),
+          'len': torch.zeros(B, dtype=torch.int32, device=dev),
+      }
+    self._use_device_hash = False
+
+  @property
+  def batch_size(self):
+    return self.schema.batch_size
+
+  # -- dict-like views (the reference's parsed feature dict)
+  def raw(self, name):
+    r = self.schema.raw[name]
+    blk = self.raw_block[r['row']:r['row'] + r['dim']]
+    return blk[0] if r['dim'] == 1 else blk  # [B] or [dim, B]
+
+  def ids_of(self, name):
+    if name in self.schema.hash_single:
+      return self.hash_ids[self.schema.hash_single[name]['col']]
+    if name in self.schema.int_single:
+      return self.int_ids[self.schema.int_single[name]['col']]
+    raise KeyError(name)
+
+  def label(self, name):
+    return self.labels[self.schema.label_fields.index(name)]
+
+  def __contains__(self, name):
+    s = self.schema
+    return (name in s.raw or name in s.hash_single or name in s.int_single or name in s.tags or
+            name in s.seqs)
+
+  # -- batch loading
+  def load(self, batch, non_blocking=True):
+    """Copy one batch (dict of numpy arrays or device tensors; see input/input.py) into the buffers.
+
+    Device-side transforms that belong to the training step (string hashing) are NOT run here;
+    call `transform()` inside the (possibly graph-captured) step.
+    """
+
+    def put(dst, src):
+      if src is None:
+        return
+      if isinstance(src, np.ndarray):
+        src = torch.from_numpy(src)
+      if src.device != dst.device and src.device.type == 'cpu' and non_blocking:
+        src = src.pin_memory() if torch.cuda.is_available() else src
+      dst.view(-1)[:src.numel()].copy_(src.reshape(-1), non_blocking=non_blocking)
+
+    put(self.labels, batch.get('labels'))
+    put(self.raw_block, batch.get('raw'))
+    if 'str_bytes' in batch:
+      nb = batch['str_bytes']
+      n = nb.numel() if torch.is_tensor(nb) else nb.size
+      assert n <= self.str_bytes.numel(), 'string block of %d bytes exceeds capacity %d' % (
+          n, self.str_bytes.numel())
+      put(self.str_bytes, nb)
+      put(self.str_offsets, batch['str_offsets'])
+      self._use_device_hash = True
+    elif 'hash_ids' in batch:
+      put(self.hash_ids, batch['hash_ids'])
+      self._use_device_hash = False
+    put(self.int_ids, batch.get('int_ids'))
+    if 'sample_weight' in batch:
+      if self.sample_weight is None:
+        self.sample_weight = torch.ones(self.batch_size, dtype=torch.float32, device=self.device)
+      put(self.sample_weight, batch['sample_weight'])
+    for name, bufs in self.tags.items():
+      ids = batch.get('tag/%s/ids' % name)
+      if ids is None:
+        continue
+      n = ids.numel() if torch.is_tensor(ids) else ids.size
+      assert n <= bufs['ids'].numel(), 'tag feature %s: %d ids exceed capacity %d' % (
+          name, n, bufs['ids'].numel())
+      put(bufs['ids'], ids)
+      put(bufs['offsets'], batch['tag/%s/offsets' % name])
+      if bufs['weights'] is not None:
+        put(bufs['weights'], batch['tag/%s/weights' % name])
+    for name, bufs in self.seqs.items():
+      ids = batch.get('seq/%s/ids' % name)
+      if ids is None:
+        continue
+      put(bufs['ids'], ids)
+      put(bufs['len'], batch['seq/%s/len' % name])
+    self.version += 1
+
+  def transform(self):
+    """Device-side part of `_preprocess`: hash the packed id strings (K1)."""
+    if self._use_device_hash and self.hash_buckets is not None:
+      from easyrec_amd import kernels
+      be = self._backend or kernels.hip()
+      be.hash_bucket_fast(self.str_bytes, self.str_offsets, self.batch_size, self.hash_buckets, True,
+                          out=self.hash_ids)

@@ -1,0 +1,255 @@
+"""Host-side input parsing: raw columns -> the batch dict consumed by DeviceFeatures.load().
+
+Mirror of the reference's `Input._preprocess` semantics (easy_rec/python/input/input.py) for the
+feature types on the hot path:
+  _parse_id_feature  :537-555   ids stay strings (hashed later) / string_to_number for num_buckets
+  _parse_raw_feature :557-673   string_to_number, (x - min_val) / (max_val - min_val) in fp32
+  _parse_tag_feature :432-505   tf.string_split(field, sep): sep is a SET of characters, empty
+                                tokens skipped; kv_separator / second input column give weights
+  _parse_seq_feature :677-804   tf.strings.split(field, sep): whole-string separator
+  get_type_defaults  utils/input_utils.py:11-36
+This is plumbing around the hot path (it runs in data-loader threads on the host); only the id
+hashing is done by the library (`er_hash_bucket_fast_host` here, or on device from packed bytes).
+"""
+import re
+from collections import OrderedDict
+
+import numpy as np
+
+from easyrec_amd.input.features import FeatureSchema, feature_name_of
+from easyrec_amd.protos.dataset_pb2 import DatasetConfig
+from easyrec_amd.protos.feature_config_pb2 import FeatureConfig
+from easyrec_amd.utils.load_class import get_register_class_meta
+
+_INPUT_CLASS_MAP = {}
+_meta_type = get_register_class_meta(_INPUT_CLASS_MAP, have_abstract_class=True)
+
+
+def get_type_defaults(field_type, default_val=''):
+  type_defaults = {
+      DatasetConfig.INT32: 0,
+      DatasetConfig.INT64: 0,
+      DatasetConfig.STRING: '',
+      DatasetConfig.BOOL: False,
+      DatasetConfig.FLOAT: 0.0,
+      DatasetConfig.DOUBLE: 0.0
+  }
+  assert field_type in type_defaults, 'invalid type: %s' % field_type
+  if default_val == '':
+    default_val = type_defaults[field_type]
+  if field_type in (DatasetConfig.INT32, DatasetConfig.INT64):
+    return int(default_val)
+  if field_type == DatasetConfig.STRING:
+    return default_val
+  if field_type == DatasetConfig.BOOL:
+    return str(default_val).lower() == 'true'
+  return float(default_val)
+
+
+def pack_strings(strings):
+  """list of str/bytes -> (uint8 bytes, int64 offsets[n+1])."""
+  enc = [s if isinstance(s, bytes) else str(s).encode('utf-8') for s in strings]
+  lens = np.fromiter((len(s) for s in enc), dtype=np.int64, count=len(enc))
+  offsets = np.zeros(len(enc) + 1, dtype=np.int64)
+  np.cumsum(lens, out=offsets[1:])
+  data = np.frombuffer(b''.join(enc), dtype=np.uint8) if offsets[-1] > 0 else np.zeros(0, dtype=np.uint8)
+  return data, offsets
+
+
+def as_string(values, field_type, precision=-1):
+  """`Input._as_string` (input.py:356-376): ints -> decimal, floats need an explicit precision."""
+  if field_type == DatasetConfig.STRING:
+    return [v if isinstance(v, str) else v.decode('utf-8') for v in values]
+  if field_type in (DatasetConfig.FLOAT, DatasetConfig.DOUBLE):
+    assert precision > 0, 'fc.precision not set: converting float to string is dangerous (input.py:361-367)'
+    return ['%.*f' % (precision, float(v)) for v in values]
+  return [str(int(v)) for v in values]
+
+
+class Input(object, metaclass=_meta_type):
+  """Base class: turns a dict {input_name: list/array of raw values} into a batch dict."""
+
+  def __init__(self, data_config, feature_configs, input_path=None, batch_size=None, hash_on_host=False,
+               schema_kwargs=None):
+    self._data_config = data_config
+    self._feature_configs = list(feature_configs)
+    self._input_path = input_path
+    self._batch_size = int(batch_size or data_config.batch_size)
+    self._input_fields = [x.input_name for x in data_config.input_fields]
+    self._input_field_types = [x.input_type for x in data_config.input_fields]
+    self._input_field_defaults = [x.default_val for x in data_config.input_fields]
+    self._label_fields = list(data_config.label_fields)
+    self._hash_on_host = hash_on_host
+    self.schema = FeatureSchema(data_config, self._feature_configs, batch_size=self._batch_size,
+                                **(schema_kwargs or {}))
+
+  def field_type(self, name):
+    return self._input_field_types[self._input_fields.index(name)]
+
+  # -- per-type parsers ---------------------------------------------------------------------
+  @staticmethod
+  def _to_float(col, default=0.0):
+    if isinstance(col, np.ndarray) and col.dtype.kind in 'fiu':
+      return col.astype(np.float32)
+    out = np.empty(len(col), dtype=np.float32)
+    for i, v in enumerate(col):
+      if isinstance(v, bytes):
+        v = v.decode('utf-8')
+      out[i] = np.float32(float(v)) if v not in ('', None) else np.float32(default)
+    return out
+
+  def _parse_raw(self, fc, columns):
+    x = self._to_float(columns[fc.input_names[0]])
+    if fc.max_val > fc.min_val:
+      # (x - min_val) / (max_val - min_val); TF casts the python floats to fp32 constants
+      x = (x - np.float32(fc.min_val)) / np.float32(fc.max_val - fc.min_val)
+    if fc.HasField('normalizer_fn'):
+      fn = fc.normalizer_fn
+      if fn in ('tf.math.log1p', 'tf.log1p'):
+        x = np.log1p(x).astype(np.float32)
+      else:
+        raise NotImplementedError('normalizer_fn %s' % fn)
+    return x.astype(np.float32)
+
+  @staticmethod
+  def _split_charset(s, seps):
+    """tf.string_split: every character of `seps` is a delimiter; empty tokens are skipped."""
+    if isinstance(s, bytes):
+      s = s.decode('utf-8')
+    if not seps:
+      return list(s)
+    if len(seps) == 1:
+      return [t for t in s.split(seps) if t != '']
+    return [t for t in re.split('[' + re.escape(seps) + ']', s) if t != '']
+
+  def _hash_tokens(self, tokens, buckets):
+    from easyrec_amd import kernels
+    data, offsets = pack_strings(tokens)
+    return kernels.hip().hash_bucket_fast_host(data, offsets, max(len(tokens), 1), [buckets], False)
+
+  def _parse_tag(self, fc, columns, out, name):
+    B = self._batch_size
+    col = columns[fc.input_names[0]]
+    toks, offs, wts = [], np.zeros(B + 1, dtype=np.int32), []
+    for i, s in enumerate(col):
+      parts = self._split_charset(s, fc.separator)
+      if fc.HasField('kv_separator'):
+        for p in parts:
+          k, v = p.split(fc.kv_separator)
+          toks.append(k)
+          wts.append(np.float32(float(v)))
+      else:
+        toks.extend(parts)
+      offs[i + 1] = len(toks)
+    if len(fc.input_names) > 1:
+      wcol = columns[fc.input_names[1]]
+      for s in wcol:
+        wts.extend(np.float32(float(p)) for p in self._split_charset(s, fc.separator))
+      assert len(wts) == len(toks), 'TagFeature Error: The size of %s not equal to the size of %s' % (
+          fc.input_names[0], fc.input_names[1])
+    if fc.HasField('hash_bucket_size') and fc.hash_bucket_size > 0:
+      ids = self._hash_tokens(toks, int(fc.hash_bucket_size)) if toks else np.zeros(0, dtype=np.int64)
+    elif fc.vocab_list:
+      vocab = {v: i for i, v in enumerate(fc.vocab_list)}
+      ids = np.array([vocab.get(t, 0) for t in toks], dtype=np.int64)
+    else:
+      ids = np.array([int(t) for t in toks], dtype=np.int64)
+      nb = int(fc.num_buckets)
+      ids = np.where((ids < 0) | (ids >= nb), 0, ids)  # IdentityCategoricalColumn default_value=0
+    out['tag/%s/ids' % name] = ids
+    out['tag/%s/offsets' % name] = offs
+    if wts:
+      out['tag/%s/weights' % name] = np.array(wts, dtype=np.float32)
+
+  def _parse_seq(self, fc, columns, out, name):
+    B = self._batch_size
+    L = self.schema.seqs[name]['max_len']
+    col = columns[fc.input_names[0]]
+    ids = np.full((B, L), -1, dtype=np.int64)
+    lens = np.zeros(B, dtype=np.int32)
+    for i, s in enumerate(col):
+      if isinstance(s, bytes):
+        s = s.decode('utf-8')
+      toks = s.split(fc.separator) if s != '' else []
+      toks = toks[:L]  # max_seq_len truncation (layers/input_layer.py:183-185)
+      if not toks:
+        continue
+      if fc.HasField('hash_bucket_size') and fc.hash_bucket_size > 0:
+        v = self._hash_tokens(toks, int(fc.hash_bucket_size))
+      elif fc.vocab_list:
+        vocab = {x: j for j, x in enumerate(fc.vocab_list)}
+        v = np.array([vocab.get(t, 0) for t in toks], dtype=np.int64)
+      else:
+        v = np.array([int(t) for t in toks], dtype=np.int64)
+        nb = int(fc.num_buckets)
+        v = np.where((v < 0) | (v >= nb), 0, v)
+      ids[i, :len(toks)] = v
+      lens[i] = len(toks)
+    out['seq/%s/ids' % name] = ids
+    out['seq/%s/len' % name] = lens
+
+  # -- batch assembly -----------------------------------------------------------------------
+  def preprocess(self, columns):
+    """columns: {input_name: sequence of B raw values (str / bytes / numbers)} -> batch dict."""
+    B = self._batch_size
+    sch = self.schema
+    out = OrderedDict()
+    labels = np.zeros((max(len(self._label_fields), 1), B), dtype=np.float32)
+    for i, name in enumerate(self._label_fields):
+      labels[i] = self._to_float(columns[name])
+    out['labels'] = labels
+    if sch.sample_weight:
+      out['sample_weight'] = self._to_float(columns[sch.sample_weight], 1.0)
+    raw = np.zeros((max(sch.n_raw_rows, 1), B), dtype=np.float32)
+    hash_strings = [None] * len(sch.hash_single)
+    int_ids = np.zeros((max(len(sch.int_single), 1), B), dtype=np.int64)
+    for fc in self._feature_configs:
+      name = feature_name_of(fc)
+      ft = fc.feature_type
+      if ft == FeatureConfig.RawFeature:
+        r = sch.raw[name]
+        assert r['dim'] == 1, 'raw_input_dim > 1 is not supported yet'
+        raw[r['row']] = self._parse_raw(fc, columns)
+      elif ft == FeatureConfig.IdFeature:
+        col = columns[fc.input_names[0]]
+        if name in sch.hash_single:
+          ftype = self.field_type(fc.input_names[0])
+          hash_strings[sch.hash_single[name]['col']] = as_string(col, ftype, fc.precision) \
+              if ftype != DatasetConfig.STRING else col
+        else:
+          c = sch.int_single[name]['col']
+          if fc.vocab_list:
+            vocab = {v: i for i, v in enumerate(fc.vocab_list)}
+            int_ids[c] = [vocab.get(v if isinstance(v, str) else str(v), 0) for v in col]
+          else:
+            v = np.array([int(x) if x not in ('', b'') else 0 for x in col], dtype=np.int64)
+            nb = sch.int_single[name]['num_buckets']
+            int_ids[c] = np.where((v < 0) | (v >= nb), 0, v)
+      elif ft == FeatureConfig.TagFeature:
+        self._parse_tag(fc, columns, out, name)
+      elif ft == FeatureConfig.SequenceFeature:
+        self._parse_seq(fc, columns, out, name)
+      elif ft == FeatureConfig.ComboFeature and name in sch.hash_single:
+        cols = [columns[n] for n in fc.input_names]
+        joined = [fc.combo_join_sep.join(str(c[i]) for c in cols) for i in range(B)]
+        hash_strings[sch.hash_single[name]['col']] = joined
+    out['raw'] = raw
+    out['int_ids'] = int_ids
+    if hash_strings:
+      flat = []
+      for s in hash_strings:
+        flat.extend(s if s is not None else [''] * B)
+      data, offsets = pack_strings(flat)
+      if self._hash_on_host:
+        from easyrec_amd import kernels
+        ids = kernels.hip().hash_bucket_fast_host(data, offsets, B, sch.hash_buckets_array, True)
+        out['hash_ids'] = ids.reshape(len(hash_strings), B)
+      else:
+        out['str_bytes'] = data
+        out['str_offsets'] = offsets
+    return out
+
+  @classmethod
+  def create(cls, data_config, feature_configs, input_path=None, **kwargs):
+    name = DatasetConfig.InputType.Name(data_config.input_type)
+    return cls.create_class(name)(data_config, feature_configs, input_path, **kwargs)

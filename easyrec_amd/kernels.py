@@ -1,0 +1,615 @@
+"""ctypes binding of libeasyrec_hip.so (include/easyrec_hip.h) at tensor level.
+
+The reference issues this work as TensorFlow ops from Python (file:line cited per entry point in
+include/easyrec_hip.h); here the same Python call sites call hand-written gfx950 kernels.
+
+`hip()` returns the singleton `HipBackend`.  It fails loudly (RuntimeError) when the shared
+library has not been built or no MI355X is visible - there is no CPU fallback in this package.
+"""
+import ctypes
+import os
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libeasyrec_hip.so')
+
+COMBINER_SUM, COMBINER_MEAN, COMBINER_SQRTN = 0, 1, 2
+COMBINERS = {'sum': COMBINER_SUM, 'mean': COMBINER_MEAN, 'sqrtn': COMBINER_SQRTN}
+OPT_SGD, OPT_ADAM, OPT_LAZY_ADAM, OPT_ADAGRAD = 0, 1, 2, 3
+ACT_NONE, ACT_RELU = 0, 1
+
+
+class LookupDesc(ctypes.Structure):
+  """Mirror of `er_lookup_desc` (include/easyrec_hip.h)."""
+  _fields_ = [
+      ('table', ctypes.c_void_p),
+      ('ids', ctypes.c_void_p),
+      ('offsets', ctypes.c_void_p),
+      ('weights', ctypes.c_void_p),
+      ('out', ctypes.c_void_p),
+      ('rows', ctypes.c_int64),
+      ('key_base', ctypes.c_int64),
+      ('dim', ctypes.c_int32),
+      ('out_stride', ctypes.c_int32),
+      ('out_col', ctypes.c_int32),
+      ('combiner', ctypes.c_int32),
+      ('n_rows', ctypes.c_int32),
+      ('max_nnz', ctypes.c_int32),
+  ]
+
+
+# er_opt_hyper: 16 floats
+HYPER_FLOATS = 16
+HYPER_LR, HYPER_LR_T, HYPER_BETA1, HYPER_BETA2, HYPER_OMB1, HYPER_OMB2, HYPER_EPS, HYPER_GSCALE = range(8)
+
+
+@dataclass
+class LookupSpec:
+  """One embedding lookup (tensor-level view of er_lookup_desc).
+
+  table:   [rows, dim] fp32 view of the lookup's table inside its table group
+  ids:     int64 [n_rows] (dense mode, id < 0 = missing) or [max_nnz] (ragged mode)
+  offsets: None or int32 [n_rows + 1]
+  weights: None or fp32, aligned with ids
+  out:     2-D fp32 base tensor [n_rows, out_stride]; forward output or upstream gradient
+  """
+  table: torch.Tensor
+  ids: torch.Tensor
+  offsets: Optional[torch.Tensor]
+  weights: Optional[torch.Tensor]
+  out: torch.Tensor
+  out_col: int
+  rows: int
+  key_base: int
+  dim: int
+  combiner: int
+  n_rows: int
+  max_nnz: int
+  name: str = ''
+
+  def with_out(self, out):
+    return LookupSpec(self.table, self.ids, self.offsets, self.weights, out, self.out_col,
+                      self.rows, self.key_base, self.dim, self.combiner, self.n_rows,
+                      self.max_nnz, self.name)
+
+
+def _p(t):
+  if t is None:
+    return ctypes.c_void_p(0)
+  return ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+  return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32c(t, name='tensor'):
+  assert t.dtype == torch.float32 and t.is_contiguous(), '%s must be contiguous fp32' % name
+  return t
+
+
+class HipBackend(object):
+  """Tensor-level wrappers.  Every method launches asynchronously on torch's current stream."""
+
+  name = 'hip'
+
+  def __init__(self):
+    if not os.path.exists(LIB_PATH):
+      raise RuntimeError(
+          'easyrec_amd: %s not found. Build it with `python -c "import __graft_entry__ as g; '
+          'g.build()"` or `make -C easyrec_amd/csrc`; there is no CPU fallback.' % LIB_PATH)
+    self.lib = ctypes.CDLL(LIB_PATH)
+    self.lib.er_last_error.restype = ctypes.c_char_p
+    self.lib.er_emb_group_num_entries.restype = ctypes.c_int64
+    if self.lib.er_abi_version() != 1:
+      raise RuntimeError('easyrec_amd: ABI version mismatch in %s' % LIB_PATH)
+
+  # -- plumbing
+  def _ck(self, rc, what):
+    if rc != 0:
+      msg = self.lib.er_last_error()
+      raise RuntimeError('%s failed (rc=%d): %s' % (what, rc, msg.decode() if msg else ''))
+
+  @staticmethod
+  def require_device():
+    if not torch.cuda.is_available():
+      raise RuntimeError('easyrec_amd: no HIP device visible; the training path needs an MI355X '
+                         '(there is no CPU fallback).')
+
+  def reserve_scratch(self, floats):
+    self._ck(self.lib.er_reserve_scratch(ctypes.c_int64(int(floats))), 'er_reserve_scratch')
+
+  def device_info(self):
+    cu, wave = ctypes.c_int(0), ctypes.c_int(0)
+    buf = ctypes.create_string_buffer(64)
+    self._ck(self.lib.er_device_info(ctypes.byref(cu), ctypes.byref(wave), buf, 64), 'er_device_info')
+    return {'cu_count': cu.value, 'wave_size': wave.value, 'arch': buf.value.decode()}
+
+  # -- K1 hashing
+  def hash_bucket_fast_host(self, bytes_np, offsets_np, n_per_col, num_buckets, drop_empty):
+    """numpy in / numpy out; runs on the host (data-loader threads)."""
+    bytes_np = np.ascontiguousarray(bytes_np, dtype=np.uint8)
+    offsets_np = np.ascontiguousarray(offsets_np, dtype=np.int64)
+    nb = np.ascontiguousarray(num_buckets, dtype=np.uint64)
+    n = len(offsets_np) - 1
+    out = np.empty(n, dtype=np.int64)
+    if bytes_np.size == 0:
+      bytes_np = np.zeros(1, dtype=np.uint8)
+    self._ck(
+        self.lib.er_hash_bucket_fast_host(
+            bytes_np.ctypes.data_as(ctypes.c_void_p), offsets_np.ctypes.data_as(ctypes.c_void_p),
+            ctypes.c_int64(n), ctypes.c_int64(int(n_per_col)), nb.ctypes.data_as(ctypes.c_void_p),
+            ctypes.c_int(int(drop_empty)), out.ctypes.data_as(ctypes.c_void_p)), 'er_hash_bucket_fast_host')
+    return out
+
+  def hash_bucket_fast(self, bytes_t, offsets_t, n_per_col, num_buckets_t, drop_empty, out=None):
+    n = offsets_t.numel() - 1
+    if out is None:
+      out = torch.empty(n, dtype=torch.int64, device=bytes_t.device)
+    self._ck(
+        self.lib.er_hash_bucket_fast(_p(bytes_t), _p(offsets_t), ctypes.c_int64(n),
+                                     ctypes.c_int64(int(n_per_col)), _p(num_buckets_t),
+                                     ctypes.c_int(int(drop_empty)), _p(out), _stream()), 'er_hash_bucket_fast')
+    return out
+
+  def hash_bucket_fast_int64(self, values_t, n_per_col, num_buckets_t, out=None):
+    n = values_t.numel()
+    if out is None:
+      out = torch.empty(n, dtype=torch.int64, device=values_t.device)
+    self._ck(
+        self.lib.er_hash_bucket_fast_int64(_p(values_t), ctypes.c_int64(n), ctypes.c_int64(int(n_per_col)),
+                                           _p(num_buckets_t), _p(out), _stream()), 'er_hash_bucket_fast_int64')
+    return out
+
+  # -- K2 / K3 / K4 embeddings
+  @staticmethod
+  def _descs(specs):
+    arr = (LookupDesc * len(specs))()
+    for i, s in enumerate(specs):
+      assert s.table.dtype == torch.float32 and s.ids.dtype == torch.int64
+      assert s.out.dim() == 2 and s.out.stride(1) == 1
+      d = arr[i]
+      d.table = s.table.data_ptr()
+      d.ids = s.ids.data_ptr()
+      d.offsets = s.offsets.data_ptr() if s.offsets is not None else None
+      d.weights = s.weights.data_ptr() if s.weights is not None else None
+      d.out = s.out.data_ptr()
+      d.rows, d.key_base, d.dim = s.rows, s.key_base, s.dim
+      d.out_stride, d.out_col, d.combiner = s.out.stride(0), s.out_col, s.combiner
+      d.n_rows, d.max_nnz = s.n_rows, s.max_nnz
+    return arr
+
+  def emb_plan_create(self, specs):
+    plan = ctypes.c_void_p(0)
+    self._ck(self.lib.er_emb_plan_create(self._descs(specs), len(specs), ctypes.byref(plan)),
+             'er_emb_plan_create')
+    nblk = self.lib.er_emb_plan_num_blocks(plan)
+    return {'handle': plan, 'specs': list(specs), 'num_blocks': nblk}
+
+  def emb_plan_destroy(self, plan):
+    self.lib.er_emb_plan_destroy(plan['handle'])
+
+  def emb_fwd(self, plan, sumsq_partials=None):
+    self._ck(self.lib.er_emb_fwd(plan['handle'], _p(sumsq_partials), _stream()), 'er_emb_fwd')
+
+  def emb_group_create(self, specs, dim, total_rows, var, m, v, bitmap):
+    grp = ctypes.c_void_p(0)
+    self._ck(
+        self.lib.er_emb_group_create(self._descs(specs), len(specs), ctypes.c_int32(dim),
+                                     ctypes.c_int64(total_rows), _p(var), _p(m), _p(v), _p(bitmap),
+                                     ctypes.byref(grp)), 'er_emb_group_create')
+    n_ent = self.lib.er_emb_group_num_entries(grp)
+    return {'handle': grp, 'specs': list(specs), 'dim': dim, 'total_rows': total_rows, 'var': var,
+            'm': m, 'v': v, 'bitmap': bitmap, 'num_entries': n_ent}
+
+  def emb_group_destroy(self, group):
+    self.lib.er_emb_group_destroy(group['handle'])
+
+  def emb_bwd_update(self, group, opt_kind, hyper):
+    self._ck(self.lib.er_emb_bwd_update(group['handle'], ctypes.c_int(opt_kind), _p(hyper), _stream()),
+             'er_emb_bwd_update')
+
+  def emb_bwd_reduce(self, group):
+    n = group['num_entries']
+    dev = group['var'].device
+    keys = torch.empty(n, dtype=torch.int32, device=dev)
+    grads = torch.empty(n, group['dim'], dtype=torch.float32, device=dev)
+    n_unique = torch.zeros(1, dtype=torch.int32, device=dev)
+    self._ck(self.lib.er_emb_bwd_reduce(group['handle'], _p(keys), _p(grads), _p(n_unique), _stream()),
+             'er_emb_bwd_reduce')
+    return keys, grads, n_unique
+
+  def adam_decay_sweep(self, var, m, v, bitmap, total_rows, dim, hyper):
+    self._ck(
+        self.lib.er_adam_decay_sweep(_p(var), _p(m), _p(v), _p(bitmap), ctypes.c_int64(total_rows),
+                                     ctypes.c_int32(dim), _p(hyper), _stream()), 'er_adam_decay_sweep')
+
+  # -- K5 FM / wide
+  def fm_fwd(self, x, F, D):
+    """x: [B, >=F*D] row-major (stride(0) = row stride).  Returns (fm [B,D], S [B,D])."""
+    B = x.shape[0]
+    fm = torch.empty(B, D, dtype=torch.float32, device=x.device)
+    S = torch.empty(B, D, dtype=torch.float32, device=x.device)
+    self._ck(self.lib.er_fm_fwd(_p(x), B, F, D, x.stride(0), _p(fm), _p(S), _stream()), 'er_fm_fwd')
+    return fm, S
+
+  def fm_bwd(self, x, S, g, F, D):
+    B = x.shape[0]
+    dx = torch.empty(B, F * D, dtype=torch.float32, device=x.device)
+    self._ck(
+        self.lib.er_fm_bwd(_p(x), _p(S), _p(_f32c(g)), B, F, D, x.stride(0), _p(dx), dx.stride(0), 0, _stream()),
+        'er_fm_bwd')
+    return dx
+
+  def rowsum_fwd(self, x, n):
+    B = x.shape[0]
+    out = torch.empty(B, 1, dtype=torch.float32, device=x.device)
+    self._ck(self.lib.er_rowsum_fwd(_p(x), B, n, x.stride(0), _p(out), _stream()), 'er_rowsum_fwd')
+    return out
+
+  def rowsum_bwd(self, g, n):
+    B = g.shape[0]
+    dx = torch.empty(B, n, dtype=torch.float32, device=g.device)
+    self._ck(self.lib.er_rowsum_bwd(_p(_f32c(g)), B, n, _p(dx), n, 0, _stream()), 'er_rowsum_bwd')
+    return dx
+
+  def axpy2d(self, x, alpha, y, accumulate=True):
+    """y (+)= alpha * x on 2-D views with unit inner stride."""
+    rows, cols = x.shape
+    assert x.stride(1) == 1 and y.stride(1) == 1 and y.shape == x.shape
+    self._ck(
+        self.lib.er_axpy2d(_p(x), x.stride(0), ctypes.c_float(alpha), _p(y), y.stride(0), rows, cols,
+                           int(accumulate), _stream()), 'er_axpy2d')
+
+  # -- K6 / K7 cross
+  def cross_v1_fwd(self, x0, w, b):
+    B, d = x0.shape
+    L = w.shape[0]
+    out = torch.empty_like(x0)
+    dots = torch.empty(B, L, dtype=torch.float32, device=x0.device)
+    self._ck(self.lib.er_cross_v1_fwd(_p(_f32c(x0)), _p(_f32c(w)), _p(_f32c(b)), B, d, L, _p(out), _p(dots),
+                                      _stream()), 'er_cross_v1_fwd')
+    return out, dots
+
+  def cross_v1_bwd(self, x0, w, b, dots, dout):
+    B, d = x0.shape
+    L = w.shape[0]
+    npart = self.lib.er_cross_v1_bwd_partials(B)
+    dx0 = torch.empty_like(x0)
+    dwp = torch.empty(npart, L * d, dtype=torch.float32, device=x0.device)
+    dbp = torch.empty(npart, L * d, dtype=torch.float32, device=x0.device)
+    self._ck(
+        self.lib.er_cross_v1_bwd(_p(x0), _p(w), _p(b), _p(dots), _p(_f32c(dout)), B, d, L, _p(dx0), _p(dwp),
+                                 _p(dbp), _stream()), 'er_cross_v1_bwd')
+    dw = self.colsum(dwp).view(L, d)
+    db = self.colsum(dbp).view(L, d)
+    return dx0, dw, db
+
+  def cross_v2_fwd(self, x0, x, u, bias, diag_scale):
+    B, d = x0.shape
+    out = torch.empty_like(x0)
+    self._ck(
+        self.lib.er_cross_v2_epilogue_fwd(_p(_f32c(x0)), _p(_f32c(x)), _p(_f32c(u)), _p(bias),
+                                          ctypes.c_float(diag_scale), B, d, _p(out), _stream()),
+        'er_cross_v2_epilogue_fwd')
+    return out
+
+  def cross_v2_bwd(self, x0, x, u, bias, diag_scale, dout):
+    B, d = x0.shape
+    dx0, dx, du = torch.empty_like(x0), torch.empty_like(x0), torch.empty_like(x0)
+    self._ck(
+        self.lib.er_cross_v2_epilogue_bwd(_p(x0), _p(x), _p(u), _p(bias), ctypes.c_float(diag_scale),
+                                          _p(_f32c(dout)), B, d, _p(dx0), 0, _p(dx), _p(du), _stream()),
+        'er_cross_v2_epilogue_bwd')
+    return dx0, dx, du
+
+  # -- K8 DIN
+  def din_concat_fwd(self, q, h):
+    B, L, E = h.shape
+    out = torch.empty(B, L, 4 * E, dtype=torch.float32, device=h.device)
+    self._ck(self.lib.er_din_concat_fwd(_p(_f32c(q)), _p(_f32c(h)), B, L, E, _p(out), _stream()),
+             'er_din_concat_fwd')
+    return out
+
+  def din_concat_bwd(self, q, h, dout):
+    B, L, E = h.shape
+    dq = torch.empty_like(q)
+    dh = torch.empty_like(h)
+    self._ck(
+        self.lib.er_din_concat_bwd(_p(q), _p(h), _p(_f32c(dout)), B, L, E, _p(dq), 0, _p(dh), 0, _stream()),
+        'er_din_concat_bwd')
+    return dq, dh
+
+  def din_pool_fwd(self, scores, hist, seq_len, scale=1.0):
+    B, L, E = hist.shape
+    probs = torch.empty(B, L, dtype=torch.float32, device=hist.device)
+    out = torch.empty(B, E, dtype=torch.float32, device=hist.device)
+    self._ck(
+        self.lib.er_din_pool_fwd(_p(_f32c(scores)), _p(_f32c(hist)), _p(seq_len), B, L, E, ctypes.c_float(scale),
+                                 _p(probs), _p(out), _stream()), 'er_din_pool_fwd')
+    return out, probs
+
+  def din_pool_bwd(self, probs, hist, seq_len, dout, scale=1.0):
+    B, L, E = hist.shape
+    dscores = torch.empty(B, L, dtype=torch.float32, device=hist.device)
+    dhist = torch.empty_like(hist)
+    self._ck(
+        self.lib.er_din_pool_bwd(_p(probs), _p(hist), _p(seq_len), _p(_f32c(dout)), B, L, E,
+                                 ctypes.c_float(scale), _p(dscores), _p(dhist), 0, _stream()), 'er_din_pool_bwd')
+    return dscores, dhist
+
+  # -- K9 MLP pieces
+  def bn_act_fwd(self, x, bias, gamma, beta, use_bn, eps, momentum, moving_mean, moving_var, act):
+    B, N = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(N, dtype=torch.float32, device=x.device) if use_bn else None
+    invstd = torch.empty(N, dtype=torch.float32, device=x.device) if use_bn else None
+    self._ck(
+        self.lib.er_bn_act_fwd(_p(_f32c(x)), _p(bias), _p(gamma), _p(beta), B, N, int(use_bn),
+                               ctypes.c_float(eps), ctypes.c_float(momentum), _p(moving_mean), _p(moving_var),
+                               int(act), _p(y), _p(mean), _p(invstd), _stream()), 'er_bn_act_fwd')
+    return y, mean, invstd
+
+  def bn_act_bwd(self, x, bias, gamma, y, mean, invstd, dy, use_bn, act, need_bias, need_affine):
+    B, N = x.shape
+    dx = torch.empty_like(x)
+    dev = x.device
+    dbias = torch.empty(N, dtype=torch.float32, device=dev) if need_bias else None
+    dgamma = torch.empty(N, dtype=torch.float32, device=dev) if need_affine else None
+    dbeta = torch.empty(N, dtype=torch.float32, device=dev) if need_affine else None
+    self._ck(
+        self.lib.er_bn_act_bwd(_p(x), _p(bias), _p(gamma), _p(y), _p(mean), _p(invstd), _p(_f32c(dy)), B, N,
+                               int(use_bn), int(act), _p(dx), _p(dbias), _p(dgamma), _p(dbeta), _stream()),
+        'er_bn_act_bwd')
+    return dx, dbias, dgamma, dbeta
+
+  def colsum(self, x):
+    rows, cols = x.shape
+    out = torch.empty(cols, dtype=torch.float32, device=x.device)
+    self._ck(self.lib.er_colsum(_p(x), rows, cols, x.stride(0), _p(out), _stream()), 'er_colsum')
+    return out
+
+  def dice_fwd(self, x, alpha, eps, momentum, moving_mean, moving_var):
+    B, N = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(N, dtype=torch.float32, device=x.device)
+    invstd = torch.empty(N, dtype=torch.float32, device=x.device)
+    self._ck(
+        self.lib.er_dice_fwd(_p(_f32c(x)), _p(alpha), B, N, ctypes.c_float(eps), ctypes.c_float(momentum),
+                             _p(moving_mean), _p(moving_var), _p(y), _p(mean), _p(invstd), _stream()),
+        'er_dice_fwd')
+    return y, mean, invstd
+
+  def dice_bwd(self, x, alpha, mean, invstd, dy):
+    B, N = x.shape
+    dx = torch.empty_like(x)
+    dalpha = torch.empty(N, dtype=torch.float32, device=x.device)
+    self._ck(
+        self.lib.er_dice_bwd(_p(x), _p(alpha), _p(mean), _p(invstd), _p(_f32c(dy)), B, N, _p(dx), _p(dalpha),
+                             _stream()), 'er_dice_bwd')
+    return dx, dalpha
+
+  # -- K10 loss / scalars
+  def sigmoid_ce(self, logits, labels, weights, loss_scale=1.0):
+    """Returns (loss [1], dlogits [B], probs [B])."""
+    B = logits.numel()
+    dev = logits.device
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    dlogits = torch.empty(B, dtype=torch.float32, device=dev)
+    probs = torch.empty(B, dtype=torch.float32, device=dev)
+    self._ck(
+        self.lib.er_sigmoid_ce_fwd_bwd(_p(_f32c(logits)), _p(_f32c(labels)), _p(weights), B,
+                                       ctypes.c_float(loss_scale), _p(loss), _p(dlogits), _p(probs), _stream()),
+        'er_sigmoid_ce_fwd_bwd')
+    return loss, dlogits, probs
+
+  def reduce_sum(self, partials, scale, out, accumulate=False):
+    self._ck(
+        self.lib.er_reduce_sum(_p(partials), partials.numel(), ctypes.c_float(scale), _p(out), int(accumulate),
+                               _stream()), 'er_reduce_sum')
+
+  def l2_loss(self, w, coef, out, accumulate=False):
+    self._ck(self.lib.er_l2_loss(_p(w), _p(coef), ctypes.c_int64(w.numel()), _p(out), int(accumulate), _stream()),
+             'er_l2_loss')
+
+  # -- K11 MMoE
+  def mmoe_mix_fwd(self, experts, gate_logits):
+    E, B, H = experts.shape
+    T = gate_logits.shape[0]
+    gates = torch.empty_like(gate_logits)
+    out = torch.empty(T, B, H, dtype=torch.float32, device=experts.device)
+    self._ck(
+        self.lib.er_mmoe_mix_fwd(_p(_f32c(experts)), _p(_f32c(gate_logits)), T, E, B, H, _p(gates), _p(out),
+                                 _stream()), 'er_mmoe_mix_fwd')
+    return out, gates
+
+  def mmoe_mix_bwd(self, experts, gates, dout):
+    E, B, H = experts.shape
+    T = gates.shape[0]
+    dexperts = torch.empty_like(experts)
+    dlogits = torch.empty_like(gates)
+    self._ck(
+        self.lib.er_mmoe_mix_bwd(_p(experts), _p(gates), _p(_f32c(dout)), T, E, B, H, _p(dexperts), _p(dlogits),
+                                 _stream()), 'er_mmoe_mix_bwd')
+    return dexperts, dlogits
+
+  # -- dense optimizer
+  def dense_opt_step(self, w, m, v, grad, l2coef, opt_kind, hyper):
+    self._ck(
+        self.lib.er_dense_opt_step(_p(w), _p(m), _p(v), _p(grad), _p(l2coef), ctypes.c_int64(w.numel()),
+                                   ctypes.c_int(opt_kind), _p(hyper), _stream()), 'er_dense_opt_step')
+
+
+_BACKEND = None
+
+
+def hip():
+  """The kernel backend used by every layer of this package."""
+  global _BACKEND
+  if _BACKEND is None:
+    _BACKEND = HipBackend()
+  return _BACKEND
+
+
+# ---------------------------------------------------------------------------------------------
+# autograd glue: dense activations flow through torch.autograd; each Function is one fused kernel
+# forward and one backward.
+# ---------------------------------------------------------------------------------------------
+class FMFn(torch.autograd.Function):
+  """reference layers/fm.py:20-26 over a [B, F*D] block of the input-layer output."""
+
+  @staticmethod
+  def forward(ctx, x, F, D):
+    fm, S = hip().fm_fwd(x, F, D)
+    ctx.save_for_backward(x, S)
+    ctx.F, ctx.D = F, D
+    return fm
+
+  @staticmethod
+  def backward(ctx, g):
+    x, S = ctx.saved_tensors
+    dx = hip().fm_bwd(x, S, g.contiguous(), ctx.F, ctx.D)
+    if x.shape[1] != ctx.F * ctx.D:
+      full = torch.zeros_like(x)
+      full[:, :ctx.F * ctx.D] = dx
+      dx = full
+    return dx, None, None
+
+
+class RowSumFn(torch.autograd.Function):
+  """reference model/deepfm.py:62-63 (reduce_sum(wide, axis=1, keepdims=True))."""
+
+  @staticmethod
+  def forward(ctx, x):
+    ctx.n = x.shape[1]
+    return hip().rowsum_fwd(x, x.shape[1])
+
+  @staticmethod
+  def backward(ctx, g):
+    return hip().rowsum_bwd(g.contiguous(), ctx.n)
+
+
+class BNActFn(torch.autograd.Function):
+  """bias + BatchNorm(train) + activation: reference layers/dnn.py:57-79."""
+
+  @staticmethod
+  def forward(ctx, x, bias, gamma, beta, moving_mean, moving_var, use_bn, eps, momentum, act, training):
+    if use_bn and not training:
+      # inference: normalise with the moving statistics (plain elementwise torch ops; not on the
+      # training hot path)
+      z = x if bias is None else x + bias
+      y = (z - moving_mean) * torch.rsqrt(moving_var + eps) * gamma + beta
+      return torch.relu(y) if act == ACT_RELU else y
+    y, mean, invstd = hip().bn_act_fwd(x, bias, gamma, beta, use_bn, eps, momentum, moving_mean, moving_var, act)
+    ctx.save_for_backward(x, bias, gamma, y, mean, invstd)
+    ctx.cfg = (use_bn, act)
+    return y
+
+  @staticmethod
+  def backward(ctx, dy):
+    x, bias, gamma, y, mean, invstd = ctx.saved_tensors
+    use_bn, act = ctx.cfg
+    dx, dbias, dgamma, dbeta = hip().bn_act_bwd(x, bias, gamma, y, mean, invstd, dy.contiguous(), use_bn, act,
+                                                bias is not None, gamma is not None)
+    return dx, dbias, dgamma, dbeta, None, None, None, None, None, None, None
+
+
+class DiceFn(torch.autograd.Function):
+  """reference layers/keras/activation.py:47-70 / utils/activation.py:14-44."""
+
+  @staticmethod
+  def forward(ctx, x, alpha, moving_mean, moving_var, eps, momentum):
+    y, mean, invstd = hip().dice_fwd(x, alpha, eps, momentum, moving_mean, moving_var)
+    ctx.save_for_backward(x, alpha, mean, invstd)
+    return y
+
+  @staticmethod
+  def backward(ctx, dy):
+    x, alpha, mean, invstd = ctx.saved_tensors
+    dx, dalpha = hip().dice_bwd(x, alpha, mean, invstd, dy.contiguous())
+    return dx, dalpha, None, None, None, None
+
+
+class CrossV1Fn(torch.autograd.Function):
+  """reference model/dcn.py:32-45, all layers in one launch."""
+
+  @staticmethod
+  def forward(ctx, x0, w, b):
+    out, dots = hip().cross_v1_fwd(x0.contiguous(), w, b)
+    ctx.save_for_backward(x0, w, b, dots)
+    return out
+
+  @staticmethod
+  def backward(ctx, dout):
+    x0, w, b, dots = ctx.saved_tensors
+    dx0, dw, db = hip().cross_v1_bwd(x0.contiguous(), w, b, dots, dout.contiguous())
+    return dx0, dw, db
+
+
+class CrossV2EpilogueFn(torch.autograd.Function):
+  """reference layers/keras/interaction.py:276-286: x0 * (u + bias + diag*x) + x."""
+
+  @staticmethod
+  def forward(ctx, x0, x, u, bias, diag_scale):
+    out = hip().cross_v2_fwd(x0.contiguous(), x.contiguous(), u.contiguous(), bias, diag_scale)
+    ctx.save_for_backward(x0, x, u, bias)
+    ctx.diag = diag_scale
+    return out
+
+  @staticmethod
+  def backward(ctx, dout):
+    x0, x, u, bias = ctx.saved_tensors
+    dx0, dx, du = hip().cross_v2_bwd(x0.contiguous(), x.contiguous(), u.contiguous(), bias, ctx.diag,
+                                     dout.contiguous())
+    dbias = hip().colsum(du) if bias is not None else None
+    return dx0, dx, du, dbias, None
+
+
+class DINConcatFn(torch.autograd.Function):
+  """reference model/multi_tower_din.py:69-75: [q, h, q-h, q*h]."""
+
+  @staticmethod
+  def forward(ctx, q, h):
+    ctx.save_for_backward(q, h)
+    return hip().din_concat_fwd(q.contiguous(), h.contiguous())
+
+  @staticmethod
+  def backward(ctx, dout):
+    q, h = ctx.saved_tensors
+    return hip().din_concat_bwd(q.contiguous(), h.contiguous(), dout.contiguous())
+
+
+class DINPoolFn(torch.autograd.Function):
+  """reference model/multi_tower_din.py:86-95: mask, softmax over time, scores @ hist."""
+
+  @staticmethod
+  def forward(ctx, scores, hist, seq_len, scale):
+    out, probs = hip().din_pool_fwd(scores.contiguous(), hist.contiguous(), seq_len, scale)
+    ctx.save_for_backward(probs, hist, seq_len)
+    ctx.scale = scale
+    return out
+
+  @staticmethod
+  def backward(ctx, dout):
+    probs, hist, seq_len = ctx.saved_tensors
+    dscores, dhist = hip().din_pool_bwd(probs, hist.contiguous(), seq_len, dout.contiguous(), ctx.scale)
+    return dscores, dhist, None, None
+
+
+class MMoEMixFn(torch.autograd.Function):
+  """reference layers/mmoe.py:73-82: softmax gates, weighted sum of experts, all tasks at once."""
+
+  @staticmethod
+  def forward(ctx, experts, gate_logits):
+    out, gates = hip().mmoe_mix_fwd(experts.contiguous(), gate_logits.contiguous())
+    ctx.save_for_backward(experts, gates)
+    return out
+
+  @staticmethod
+  def backward(ctx, dout):
+    experts, gates = ctx.saved_tensors
+    return hip().mmoe_mix_bwd(experts.contiguous(), gates, dout.contiguous())

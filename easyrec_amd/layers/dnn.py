@@ -1,0 +1,103 @@
+"""DNN: dense -> BatchNorm -> activation -> dropout per layer.
+
+Mirror of reference easy_rec/python/layers/dnn.py:13-87.  Per layer the reference issues
+MatMul, BiasAdd, FusedBatchNorm/moments, Relu; here: one GEMM + ONE fused HIP kernel pair
+(`er_bn_act_fwd` / `er_bn_act_bwd`: bias + batch statistics + affine + ReLU).
+TF defaults relied on: tf.layers.dense use_bias=True, glorot_uniform kernel,
+zeros bias; tf.layers.batch_normalization momentum 0.99, epsilon 1e-3, biased batch variance.
+"""
+import logging
+
+import torch
+
+from easyrec_amd import kernels
+from easyrec_amd.core import context
+from easyrec_amd.utils.activation import get_activation, is_relu
+
+BN_MOMENTUM = 0.99
+BN_EPSILON = 1e-3
+
+
+def dense(x, units, name, l2_reg=None, use_bias=True, kernel_initializer='glorot_uniform'):
+  """tf.layers.dense(activation=None): returns x @ kernel (+ bias).  Variables <name>/kernel, /bias."""
+  vs = context.varstore()
+  in_dim = x.shape[-1]
+  w = vs.get_variable(name + '/kernel', (in_dim, units), kernel_initializer, l2=l2_reg or 0.0)
+  b = vs.get_variable(name + '/bias', (units,), 'zeros') if use_bias else None
+  shape = x.shape
+  x2 = x.reshape(-1, in_dim)
+  y = torch.addmm(b, x2, w) if b is not None else torch.mm(x2, w)
+  return y.reshape(shape[:-1] + (units,))
+
+
+def dense_bn_act(x, units, name, l2_reg, use_bias, use_bn, act_relu, training, bn_name=None,
+                 kernel_initializer='glorot_uniform'):
+  """GEMM followed by the fused bias + BatchNorm(train) + ReLU kernel."""
+  ctx = context.current()
+  vs = ctx.varstore
+  in_dim = x.shape[-1]
+  w = vs.get_variable(name + '/kernel', (in_dim, units), kernel_initializer, l2=l2_reg or 0.0)
+  b = vs.get_variable(name + '/bias', (units,), 'zeros') if use_bias else None
+  gamma = beta = mm = mv = None
+  if use_bn:
+    bn = bn_name or (name + '/bn')
+    gamma = vs.get_variable(bn + '/gamma', (units,), 'ones')
+    beta = vs.get_variable(bn + '/beta', (units,), 'zeros')
+    mm = vs.get_variable(bn + '/moving_mean', (units,), 'zeros', trainable=False)
+    mv = vs.get_variable(bn + '/moving_variance', (units,), 'ones', trainable=False)
+  shape = x.shape
+  x2 = x.reshape(-1, in_dim)
+  z = torch.mm(x2, w)
+  act = kernels.ACT_RELU if act_relu else kernels.ACT_NONE
+  freeze = ctx.building and training  # build pass: do not touch the moving statistics
+  y = kernels.BNActFn.apply(z, b, gamma, beta, None if freeze else mm, None if freeze else mv, use_bn,
+                            BN_EPSILON, BN_MOMENTUM, act, training)
+  return y.reshape(shape[:-1] + (units,))
+
+
+class DNN(object):
+
+  def __init__(self, dnn_config, l2_reg, name='dnn', is_training=False, last_layer_no_activation=False,
+               last_layer_no_batch_norm=False):
+    self._config = dnn_config
+    self._l2_reg = l2_reg
+    self._name = name
+    self._is_training = is_training
+    logging.info('dnn activation function = %s' % self._config.activation)
+    self._act_string = self._config.activation
+    self.activation = get_activation(self._config.activation, training=is_training) \
+        if self._config.activation.lower() == 'dice' else get_activation(self._config.activation)
+    self._last_layer_no_activation = last_layer_no_activation
+    self._last_layer_no_batch_norm = last_layer_no_batch_norm
+
+  @property
+  def hidden_units(self):
+    return self._config.hidden_units
+
+  @property
+  def dropout_ratio(self):
+    return self._config.dropout_ratio
+
+  def __call__(self, deep_fea, hidden_layer_feature_output=False):
+    hidden_units_len = len(self.hidden_units)
+    if hidden_units_len == 1 and self.hidden_units[0] == 0:
+      return deep_fea
+    hidden_feature_dict = {}
+    for i, unit in enumerate(self.hidden_units):
+      layer = '%s/dnn_%d' % (self._name, i)
+      use_bn = self._config.use_bn and ((i + 1 < hidden_units_len) or not self._last_layer_no_batch_norm)
+      use_act = (i + 1 < hidden_units_len) or not self._last_layer_no_activation
+      fuse_relu = use_act and is_relu(self._act_string)
+      deep_fea = dense_bn_act(deep_fea, unit, layer, self._l2_reg, True, use_bn, fuse_relu, self._is_training)
+      if use_act and not fuse_relu and self.activation is not None:
+        deep_fea = self.activation(deep_fea, name='%s/dnn_%d/act' % (self._name, i))
+      if len(self.dropout_ratio) > 0 and self._is_training:
+        assert self.dropout_ratio[i] < 1, 'invalid dropout_ratio: %.3f' % self.dropout_ratio[i]
+        if self.dropout_ratio[i] > 0:
+          deep_fea = torch.nn.functional.dropout(deep_fea, p=self.dropout_ratio[i], training=True)
+      if hidden_layer_feature_output:
+        hidden_feature_dict['hidden_layer' + str(i)] = deep_fea
+        if i + 1 == hidden_units_len:
+          hidden_feature_dict['hidden_layer_end'] = deep_fea
+          return hidden_feature_dict
+    return deep_fea

@@ -1,0 +1,25 @@
+"""FM second-order interaction (reference easy_rec/python/layers/fm.py:9-26).
+
+`0.5 * ((sum_f e_f)^2 - sum_f e_f^2)` kept as [B, D].  The reference stacks the F field tensors
+([B,F,D] copy) and runs 4 elementwise/reduction ops; here one HIP kernel streams the fields straight
+out of the input-layer concat buffer (no stack), saving sum_f e_f for the backward.
+"""
+import torch
+
+from easyrec_amd import kernels
+
+
+class FM(object):
+
+  def __init__(self, name='fm'):
+    self._name = name
+
+  def __call__(self, fm_fea):
+    blk = fm_fea.uniform_block() if hasattr(fm_fea, 'uniform_block') else None
+    if blk is not None:
+      base, col0, F, D = blk
+      x = base if (col0 == 0 and base.shape[1] == F * D) else base[:, col0:col0 + F * D]
+    else:
+      F, D = len(fm_fea), fm_fea[0].shape[1]
+      x = torch.cat(list(fm_fea), dim=1)
+    return kernels.FMFn.apply(x, F, D)

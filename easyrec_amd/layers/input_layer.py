@@ -1,0 +1,424 @@
+"""InputLayer: the embedding stage of the hot path, one fused HIP launch per step.
+
+Host-side mirror of reference easy_rec/python/layers/input_layer.py:28-398 (`InputLayer`):
+  __call__(features, group_name) -> (concat [B, sum(dim)], [per-feature tensors])  (:245-278)
+  single_call_input_layer: columns in config order, concat on axis 1, L2 on the looked-up
+  outputs of every embedding column (:280-376, compat/regularizers.py:76-108,169-208).
+What the reference builds as ~6 TF ops per column (feature_column_v2.py:3434-3462) is compiled here
+into a static list of `LookupSpec`s executed by `er_emb_fwd` (all groups, one launch) and
+`er_emb_bwd_update` (one sort + reduce + row-wise optimizer per table dim).
+
+HBM layout: all tables of one embedding dim are stored back to back in one [total_rows, dim] fp32
+buffer (+ identical buffers for the optimizer slots), in creation order; a lookup addresses its
+table by `key_base` (first row).  Variable names follow TF's scoping
+(`input_layer[_k]/<column>_embedding/embedding_weights`, compat/feature_column/feature_column.py:
+384-414) so per-table views can be exported under the reference's names.
+"""
+import logging
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from easyrec_amd import kernels
+from easyrec_amd.feature_column.feature_column import (EmbeddingColumn, FeatureColumnParser, NumericColumn,
+                                                       SequenceNumericColumn)
+from easyrec_amd.feature_column.feature_group import FeatureGroup
+from easyrec_amd.protos.feature_config_pb2 import WideOrDeep
+
+
+class FeatureList(list):
+  """List of per-feature [B, dim] views that also remembers the concat block they live in, so that
+  consumers (FM, DIN) can read the block directly instead of re-stacking (layers/fm.py:22)."""
+
+  def __init__(self, views, base=None, col0=0, dims=None):
+    super(FeatureList, self).__init__(views)
+    self.base = base
+    self.col0 = col0
+    self.dims = list(dims) if dims is not None else None
+
+  def uniform_block(self):
+    """(base, col0, F, D) when all features have the same dim and are adjacent in `base`."""
+    if self.base is None or not self.dims or len(set(self.dims)) != 1:
+      return None
+    return self.base, self.col0, len(self.dims), self.dims[0]
+
+
+class _GroupOutFn(torch.autograd.Function):
+  """Makes a persistent group-output buffer a differentiable leaf-like tensor: backward deposits
+  (grad + lambda * out) into the group's static gradient buffer, which `er_emb_bwd_update` reads."""
+
+  @staticmethod
+  def forward(ctx, anchor, engine, gkey):
+    ctx.engine, ctx.gkey = engine, gkey
+    return engine.groups[gkey]['out'].view_as(engine.groups[gkey]['out'])
+
+  @staticmethod
+  def backward(ctx, g):
+    ctx.engine._deposit_grad(ctx.gkey, g)
+    return None, None, None
+
+
+class EmbeddingEngine(object):
+  """Owns tables, optimizer slots, lookup specs and the C handles."""
+
+  def __init__(self, device, batch_size, seed=0):
+    self.device = torch.device(device)
+    self.batch_size = batch_size
+    self.seed = seed
+    self.tables = OrderedDict()  # var name -> dict(dim, rows, key_base, init)
+    self.dim_rows = OrderedDict()  # dim -> total rows so far
+    self.groups = OrderedDict()  # gkey -> dict(out, dout, specs, reg, width)
+    self.finalized = False
+    self.plan = None
+    self.emb_groups = OrderedDict()  # dim -> C group handle
+    self.storage = {}  # dim -> dict(var, m, v, bitmap)
+    self._pending_tables = []
+    self._anchor = torch.zeros(1, device=self.device, requires_grad=True)
+    self.sumsq = None
+    self.reg_blocks = 0
+    self._ran_version = -1
+
+  # -- declaration (build pass)
+  def declare_table(self, var_name, rows, dim, initializer=None):
+    if var_name in self.tables:
+      t = self.tables[var_name]
+      assert t['rows'] == rows and t['dim'] == dim, 'shared table %s shape mismatch' % var_name
+      return t
+    assert not self.finalized, 'table %s declared after finalize()' % var_name
+    base = self.dim_rows.get(dim, 0)
+    self.dim_rows[dim] = base + rows
+    t = {'name': var_name, 'rows': int(rows), 'dim': int(dim), 'key_base': base, 'init': initializer}
+    self.tables[var_name] = t
+    return t
+
+  def declare_group(self, gkey, width, regularize):
+    assert gkey not in self.groups
+    B = self.batch_size
+    g = {
+        'out': torch.zeros(B, width, dtype=torch.float32, device=self.device),
+        'dout': torch.zeros(B, width, dtype=torch.float32, device=self.device),
+        'pending': [],  # (table name, ids, offsets, weights, col, combiner, n_rows, max_nnz, name)
+        'reg': float(regularize or 0.0),
+        'width': width,
+        'got_grad': False,
+    }
+    self.groups[gkey] = g
+    return g
+
+  def declare_seq_output(self, gkey, n_rows, width, regularize):
+    """Sequence lookups keep the time axis: output [B*L, width]."""
+    g = {
+        'out': torch.zeros(n_rows, width, dtype=torch.float32, device=self.device),
+        'dout': torch.zeros(n_rows, width, dtype=torch.float32, device=self.device),
+        'pending': [],
+        'reg': float(regularize or 0.0),
+        'width': width,
+        'got_grad': False,
+    }
+    self.groups[gkey] = g
+    return g
+
+  def add_lookup(self, gkey, table_name, ids, offsets, weights, col, combiner, n_rows, max_nnz, name):
+    self.groups[gkey]['pending'].append((table_name, ids, offsets, weights, col, combiner, n_rows, max_nnz, name))
+
+  # -- storage
+  def finalize(self, opt_kind):
+    """Allocate table groups, initialise tables, create the C handles."""
+    assert not self.finalized
+    be = kernels.hip()
+    gen = torch.Generator(device=self.device)
+    for dim, total in self.dim_rows.items():
+      var = torch.empty(total, dim, dtype=torch.float32, device=self.device)
+      st = {'var': var, 'm': None, 'v': None, 'bitmap': None, 'total_rows': total}
+      if opt_kind in (kernels.OPT_ADAM, kernels.OPT_LAZY_ADAM):
+        st['m'] = torch.zeros_like(var)
+        st['v'] = torch.zeros_like(var)
+      elif opt_kind == kernels.OPT_ADAGRAD:
+        st['v'] = torch.zeros_like(var)
+      if opt_kind == kernels.OPT_ADAM:
+        st['bitmap'] = torch.zeros((total + 31) // 32, dtype=torch.int32, device=self.device)
+      self.storage[dim] = st
+    for name, t in self.tables.items():
+      view = self.table_view(name)
+      init = t['init']
+      gen.manual_seed(_stable_seed(name, self.seed))
+      if init is not None and init.WhichOneof('initializer_oneof') == 'constant_initializer':
+        consts = list(init.constant_initializer.consts)
+        vals = torch.tensor(consts, dtype=torch.float32, device=self.device)
+        view.copy_(vals.view(-1)[:view.numel()].view_as(view) if vals.numel() >= view.numel() else
+                   vals.expand_as(view))
+      elif init is not None and init.WhichOneof('initializer_oneof') == 'random_normal_initializer':
+        view.normal_(init.random_normal_initializer.mean, init.random_normal_initializer.stddev, generator=gen)
+      elif init is not None and init.WhichOneof('initializer_oneof') == 'glorot_normal_initializer':
+        std = math.sqrt(2.0 / (t['rows'] + t['dim']))
+        torch.nn.init.trunc_normal_(view, 0.0, std, -2 * std, 2 * std, generator=gen)
+      else:
+        mean, std = 0.0, 0.01 / math.sqrt(t['dim'])  # feature_column_v2.py:908-912
+        if init is not None and init.WhichOneof('initializer_oneof') == 'truncated_normal_initializer':
+          mean = init.truncated_normal_initializer.mean
+          std = init.truncated_normal_initializer.stddev
+        torch.nn.init.trunc_normal_(view, mean, std, mean - 2 * std, mean + 2 * std, generator=gen)
+    # lookup specs: regularised groups first so their sum-of-squares partials form a prefix
+    ordered = sorted(self.groups.items(), key=lambda kv: 0 if kv[1]['reg'] > 0 else 1)
+    fwd_specs, reg_count = [], 0
+    for gkey, g in ordered:
+      g['specs'] = []
+      for (tname, ids, offsets, weights, col, combiner, n_rows, max_nnz, name) in g['pending']:
+        t = self.tables[tname]
+        spec = kernels.LookupSpec(
+            table=self.table_view(tname), ids=ids, offsets=offsets, weights=weights, out=g['out'],
+            out_col=col, rows=t['rows'], key_base=t['key_base'], dim=t['dim'],
+            combiner=kernels.COMBINERS[combiner], n_rows=n_rows, max_nnz=max_nnz, name=name)
+        g['specs'].append(spec)
+        fwd_specs.append(spec)
+        if g['reg'] > 0:
+          reg_count += 1
+    self.fwd_specs = fwd_specs
+    self.n_reg_specs = reg_count
+    if fwd_specs:
+      self.plan = be.emb_plan_create(fwd_specs)
+      self.sumsq = torch.zeros(max(self.plan['num_blocks'], 1), dtype=torch.float32, device=self.device)
+      self.reg_blocks = _blocks_of(fwd_specs[:reg_count])
+      assert len({g['reg'] for g in self.groups.values() if g['reg'] > 0}) <= 1, \
+          'one embedding_regularization value per model'
+    for dim, st in self.storage.items():
+      specs = [s.with_out(self._dout_of(s)) for s in fwd_specs if s.dim == dim]
+      if specs:
+        self.emb_groups[dim] = be.emb_group_create(specs, dim, st['total_rows'], st['var'], st['m'], st['v'],
+                                                   st['bitmap'])
+    self.reg_lambda = max([g['reg'] for g in self.groups.values()] + [0.0])
+    self.finalized = True
+
+  def _dout_of(self, spec):
+    for g in self.groups.values():
+      if g['out'] is spec.out:
+        return g['dout']
+    raise KeyError('spec output not registered')
+
+  def table_view(self, name):
+    t = self.tables[name]
+    var = self.storage[t['dim']]['var']
+    return var[t['key_base']:t['key_base'] + t['rows']]
+
+  def slot_view(self, name, slot):
+    t = self.tables[name]
+    buf = self.storage[t['dim']][slot]
+    return None if buf is None else buf[t['key_base']:t['key_base'] + t['rows']]
+
+  # -- per-step execution
+  def forward(self, version):
+    if version == self._ran_version:
+      return
+    be = kernels.hip()
+    for g in self.groups.values():
+      g['got_grad'] = False
+    if self.plan is not None:
+      be.emb_fwd(self.plan, self.sumsq if self.reg_lambda > 0 else None)
+    self._ran_version = version
+
+  def group_tensor(self, gkey, requires_grad=True):
+    if requires_grad and torch.is_grad_enabled():
+      return _GroupOutFn.apply(self._anchor, self, gkey)
+    return self.groups[gkey]['out']
+
+  def _deposit_grad(self, gkey, g):
+    be = kernels.hip()
+    grp = self.groups[gkey]
+    g2 = g.reshape(grp['dout'].shape)
+    if not g2.is_contiguous():
+      g2 = g2.contiguous()
+    be.axpy2d(g2, 1.0, grp['dout'], accumulate=grp['got_grad'])
+    if grp['reg'] > 0 and not grp['got_grad']:
+      # d/d(out) of lambda * 0.5 * ||out||^2 (layers/input_layer.py:369-375)
+      be.axpy2d(grp['out'], grp['reg'], grp['dout'], accumulate=True)
+    grp['got_grad'] = True
+
+  def regularization_loss(self, out):
+    """out[0] = lambda * 0.5 * sum(out^2) over regularised embedding outputs."""
+    if self.reg_lambda > 0 and self.reg_blocks > 0:
+      kernels.hip().reduce_sum(self.sumsq[:self.reg_blocks], 0.5 * self.reg_lambda, out, accumulate=False)
+    else:
+      out.zero_()
+
+  def backward_update(self, opt_kind, hyper):
+    be = kernels.hip()
+    for g in self.groups.values():
+      if not g['got_grad']:
+        g['dout'].zero_()
+    for dim, grp in self.emb_groups.items():
+      be.emb_bwd_update(grp, opt_kind, hyper)
+
+  # -- host exchange
+  def state_dict(self, slots=False):
+    out = OrderedDict()
+    for name in self.tables:
+      out[name] = self.table_view(name).detach().cpu().numpy().copy()
+      if slots:
+        for s in ('m', 'v'):
+          sv = self.slot_view(name, s)
+          if sv is not None:
+            out[name + '/' + s] = sv.detach().cpu().numpy().copy()
+    return out
+
+  def load_state_dict(self, state):
+    for name in self.tables:
+      if name in state:
+        self.table_view(name).copy_(torch.from_numpy(np.asarray(state[name], dtype=np.float32)).to(self.device))
+
+
+def _stable_seed(name, base):
+  import zlib
+  return (zlib.crc32(name.encode('utf-8')) ^ (base * 2654435761)) & 0x7FFFFFFF
+
+
+def _blocks_of(specs):
+  n = 0
+  for s in specs:
+    V = 4 if s.dim % 4 == 0 else 1
+    G = 1
+    while G < s.dim // V:
+      G <<= 1
+    rpb = 256 // G
+    n += (max(s.n_rows, 1) + rpb - 1) // rpb
+  return n
+
+
+class InputLayer(object):
+  """Same constructor and call contract as the reference's InputLayer (layers/input_layer.py:33-70)."""
+
+  def __init__(self, feature_configs, feature_groups_config, variational_dropout_config=None,
+               wide_output_dim=-1, ev_params=None, embedding_regularizer=None, kernel_regularizer=None,
+               is_training=False, is_predicting=False, engine=None):
+    self._feature_groups = OrderedDict((x.group_name, FeatureGroup(x)) for x in feature_groups_config)
+    self._group_name_to_seq_features = {
+        x.group_name: x.sequence_features for x in feature_groups_config if len(x.sequence_features) > 0
+    }
+    self._fc_parser = FeatureColumnParser(feature_configs, self.get_wide_deep_dict(), wide_output_dim,
+                                          ev_params=ev_params)
+    self._embedding_regularizer = embedding_regularizer  # lambda (float) or None
+    self._kernel_regularizer = kernel_regularizer
+    self._is_training = is_training
+    self._is_predicting = is_predicting
+    if variational_dropout_config is not None:
+      raise NotImplementedError('variational dropout is outside the hot-path scope')
+    assert engine is not None, 'InputLayer needs the EmbeddingEngine of the model'
+    self._engine = engine
+    self._group_plan = {}  # group name -> dict(gkey, columns, cols, dims)
+    self._scope_count = 0
+
+  @property
+  def engine(self):
+    return self._engine
+
+  def has_group(self, group_name):
+    return group_name in self._feature_groups
+
+  def get_wide_deep_dict(self):
+    """reference layers/input_layer.py:378-398."""
+    d = {}
+    for fg in self._feature_groups.values():
+      for k, v in fg.wide_and_deep_dict.items():
+        if k not in d:
+          d[k] = v
+        elif d[k] != v:
+          d[k] = WideOrDeep.WIDE_AND_DEEP
+    return d
+
+  def _next_scope(self):
+    s = 'input_layer' if self._scope_count == 0 else 'input_layer_%d' % self._scope_count
+    self._scope_count += 1
+    return s
+
+  def _declare(self, features, group_name):
+    """First call for a group: create tables + lookups (TF would create the variables here)."""
+    fg = self._feature_groups[group_name]
+    columns, seq_columns = fg.select_columns(self._fc_parser)
+    if seq_columns:
+      raise NotImplementedError(
+          'sequence_combiner columns inside a feature group are outside the hot-path scope; use '
+          'seq_att_groups (DIN) or TagFeature')
+    if group_name in self._group_name_to_seq_features:
+      raise NotImplementedError('feature_groups.sequence_features: use model-level seq_att_groups')
+    scope = self._next_scope()
+    eng = self._engine
+    B = eng.batch_size
+    width = sum(c.dimension for c in columns)
+    gkey = 'group:' + group_name
+    eng.declare_group(gkey, width, self._embedding_regularizer)
+    col, cols, dims, numeric = 0, [], [], []
+    for c in columns:
+      if isinstance(c, NumericColumn):
+        numeric.append((c, col))
+      elif isinstance(c, EmbeddingColumn):
+        declare_lookup(eng, features, c, scope, gkey, col, B)
+      else:
+        raise NotImplementedError('column type %s' % type(c).__name__)
+      cols.append(col)
+      dims.append(c.dimension)
+      col += c.dimension
+    self._group_plan[group_name] = {'gkey': gkey, 'columns': columns, 'cols': cols, 'dims': dims,
+                                    'numeric': numeric}
+
+  def __call__(self, features, group_name, is_combine=True, is_dict=False):
+    assert group_name in self._feature_groups, 'invalid group_name[%s], list: %s' % (
+        group_name, ','.join(self._feature_groups))
+    assert is_combine, 'is_combine=False (raw sequence output) is handled by SeqInputLayer'
+    eng = self._engine
+    if group_name not in self._group_plan:
+      self._declare(features, group_name)
+    plan = self._group_plan[group_name]
+    if not eng.finalized:
+      # build pass: shapes only (tables are allocated by engine.finalize() after all groups exist)
+      out = eng.groups[plan['gkey']]['out']
+    else:
+      eng.forward(features.version)
+      g = eng.groups[plan['gkey']]
+      for c, col in plan['numeric']:
+        src = features.raw(c.key)
+        src2 = src.view(1, -1).t() if src.dim() == 1 else src.t()
+        kernels.hip().axpy2d(src2.contiguous(), 1.0, g['out'][:, col:col + c.dimension], accumulate=False)
+      out = eng.group_tensor(plan['gkey'], requires_grad=self._is_training)
+    views = [out[:, c0:c0 + d] for c0, d in zip(plan['cols'], plan['dims'])]
+    flist = FeatureList(views, base=out, col0=0, dims=plan['dims'])
+    if is_dict:
+      return out, flist, {c.raw_name: v for c, v in zip(plan['columns'], views)}
+    return out, flist
+
+
+def declare_lookup(eng, features, column, scope, gkey, col, n_out_rows, seq=False):
+  """Create the table (or reuse a shared one) and the lookup spec of one embedding column."""
+  cat = column.categorical_column
+  rows = cat.num_buckets
+  table_name = '%s/%s/embedding_weights' % (scope, column.var_scope_name)
+  if column.shared_name:
+    table_name = '%s/embedding_weights' % column.var_scope_name  # shared across scopes/columns
+  eng.declare_table(table_name, rows, column.dimension, column.initializer)
+  fname = column.raw_name
+  schema = features.schema
+  B = features.batch_size
+  if cat.weight_key and cat.key.endswith('_raw_proj_id'):
+    # RawFeature projection: ids 0..k-1 weighted by the normalised values (input.py:648-673)
+    r = schema.raw[fname]
+    if r['dim'] == 1:
+      eng.add_lookup(gkey, table_name, features.zero_ids, None, features.raw(fname), col, column.combiner, B, B,
+                     fname)
+    else:
+      raise NotImplementedError('raw_input_dim > 1 projection')
+    return
+  if seq:
+    s = features.seqs[fname]
+    L = s['ids'].shape[1]
+    eng.add_lookup(gkey, table_name, s['ids'].view(-1), None, None, col, 'sum', B * L, B * L, fname)
+    return
+  if fname in schema.tags:
+    t = features.tags[fname]
+    eng.add_lookup(gkey, table_name, t['ids'], t['offsets'], t['weights'], col, column.combiner, B,
+                   t['ids'].numel(), fname)
+    return
+  if fname in schema.seqs:
+    # sequence feature used as a plain (combined) column: sum/mean over the time axis
+    s = features.seqs[fname]
+    raise NotImplementedError('sequence feature %s as combined column' % fname)
+  eng.add_lookup(gkey, table_name, features.ids_of(fname), None, None, col, column.combiner, B, B, fname)

@@ -1,0 +1,218 @@
+"""The training step: what `EasyRecEstimator._train_model_fn` + `optimize_loss` do per batch.
+
+Behaviour spec: reference easy_rec/python/model/easy_rec_estimator.py:155-353 and
+compat/optimizers.py:280-450:
+  total_loss = sum(loss_dict) + add_n(REGULARIZATION_LOSSES)           (estimator :166-184)
+    REGULARIZATION_LOSSES = embedding-output L2 (layers/input_layer.py:369-375)
+                          + l2 * 0.5*||kernel||^2 per regularised dense kernel (layers/dnn.py:57-62)
+  optimizer from train_config.optimizer_config (builders/optimizer_builder.py:28-144); with two
+    configs the first drives the embeddings, the second the dense variables (easy_rec_model.py:446-467)
+  embedding_learning_rate_multiplier -> gradient multiplier on embedding tables (estimator :308-317)
+  global step increments after the apply; the LR schedule sees the pre-increment step.
+
+The TF Estimator machinery (sessions, hooks, savers) is replaced by a plain Python loop around HIP
+launches; the whole step (hash -> lookup -> interactions/MLP -> loss -> backward -> sparse + dense
+optimizer) can be captured into one hipGraph (`capture()`), because every buffer has a fixed address
+and per-step scalars are read from device memory.
+"""
+import logging
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from easyrec_amd import kernels
+from easyrec_amd.builders import optimizer_builder
+from easyrec_amd.core import context
+from easyrec_amd.core.variables import VarStore
+from easyrec_amd.input.features import DeviceFeatures, FeatureSchema
+from easyrec_amd.layers.input_layer import EmbeddingEngine
+from easyrec_amd.model.easy_rec_model import EasyRecModel
+from easyrec_amd.utils import config_util
+from easyrec_amd.utils.load_class import import_all_models
+
+
+class EasyRecEstimator(object):
+
+  def __init__(self, pipeline_config, device='cuda', batch_size=None, seed=0, schema_kwargs=None,
+               is_training=True):
+    import_all_models()
+    self.pipeline_config = config_util.get_configs_from_pipeline_file(pipeline_config) \
+        if isinstance(pipeline_config, str) else pipeline_config
+    self.device = torch.device(device)
+    self.seed = seed
+    self.is_training = is_training
+    cfg = self.pipeline_config
+    self.feature_configs = config_util.get_compatible_feature_configs(cfg)
+    self.schema = FeatureSchema(cfg.data_config, self.feature_configs, batch_size=batch_size,
+                                **(schema_kwargs or {}))
+    self.batch_size = self.schema.batch_size
+    self.features = DeviceFeatures(self.schema, self.device)
+    self.varstore = VarStore(self.device, seed=seed)
+    self.engine = EmbeddingEngine(self.device, self.batch_size, seed=seed)
+    self.ctx = context.ModelContext(self.varstore, self.engine, is_training=is_training)
+    self.global_step = 0
+    self.graph = None
+    self._built = False
+
+    # optimizers (estimator :216-235)
+    oc = cfg.train_config.optimizer_config
+    assert 1 <= len(oc) <= 2, 'one optimizer, or two (embedding, dense)'
+    self.opt_emb = optimizer_builder.build(oc[0])
+    self.opt_dense = optimizer_builder.build(oc[1]) if len(oc) == 2 else self.opt_emb
+    self.emb_grad_scale = 1.0
+    if oc[0].HasField('embedding_learning_rate_multiplier'):
+      self.emb_grad_scale = float(oc[0].embedding_learning_rate_multiplier)
+    if cfg.train_config.gradient_clipping_by_norm > 0:
+      raise NotImplementedError('gradient_clipping_by_norm is not implemented on the MI355X path yet')
+
+    labels = OrderedDict((name, self.features.label(name)) for name in self.schema.label_fields)
+    with context.use(self.ctx):
+      model_cls = EasyRecModel.create_class(cfg.model_config.model_class)
+      self.model = model_cls(cfg.model_config, self.feature_configs, self.features, labels,
+                             is_training=is_training)
+
+    dev = self.device
+    self.hyper = torch.zeros(2, kernels.HYPER_FLOATS, dtype=torch.float32, device=dev)  # [emb, dense]
+    self._hyper_host = torch.zeros(2, kernels.HYPER_FLOATS, dtype=torch.float32)
+    if dev.type == 'cuda':
+      self._hyper_host = self._hyper_host.pin_memory()
+    self.losses = {
+        'regularization_loss': torch.zeros(1, dtype=torch.float32, device=dev),
+        'total_loss': torch.zeros(1, dtype=torch.float32, device=dev),
+    }
+    self._reg_emb = torch.zeros(1, dtype=torch.float32, device=dev)
+    self._reg_dense = torch.zeros(1, dtype=torch.float32, device=dev)
+
+  # -- construction
+  def build(self):
+    """Build pass (creates variables / declares tables), then allocate + pack everything."""
+    assert not self._built
+    kernels.hip().reserve_scratch(1 << 22)
+    self.ctx.building = True
+    with context.use(self.ctx):
+      self.model.begin_step()
+      with torch.no_grad():
+        self.model.build_predict_graph()
+    self.ctx.building = False
+    self.engine.finalize(self.opt_emb.kind)
+    if self.opt_emb.kind == kernels.OPT_ADAGRAD:
+      for st in self.engine.storage.values():
+        st['v'].fill_(getattr(self.opt_emb, 'initial_accumulator_value', 0.1))
+    self.varstore.pack()
+    if self.opt_dense.kind in (kernels.OPT_ADAM, kernels.OPT_LAZY_ADAM):
+      self.varstore.slot('m')
+      self.varstore.slot('v')
+    elif self.opt_dense.kind == kernels.OPT_ADAGRAD:
+      self.varstore.slot('v').fill_(getattr(self.opt_dense, 'initial_accumulator_value', 0.1))
+    self._built = True
+    return self
+
+  # -- one step
+  def _refresh_hyper(self):
+    """Per-step scalars -> pinned host -> device (a captured graph re-reads the pinned buffer)."""
+    h = self._hyper_host
+    h[0].copy_(torch.from_numpy(self.opt_emb.hyper_row(self.global_step, self.emb_grad_scale)))
+    h[1].copy_(torch.from_numpy(self.opt_dense.hyper_row(self.global_step, 1.0)))
+
+  def _device_step(self):
+    """Everything that runs on the GPU for one batch (graph-capturable)."""
+    be = kernels.hip()
+    self.hyper.copy_(self._hyper_host, non_blocking=True)
+    self.features.transform()
+    self.varstore.zero_grad()
+    with context.use(self.ctx):
+      self.model.begin_step()
+      self.model.build_predict_graph()
+      loss_dict = self.model.build_loss_graph()
+      # regularisation losses (estimator :166-184)
+      self.engine.regularization_loss(self._reg_emb)
+      if self.varstore.any_l2:
+        be.l2_loss(self.varstore.flat, self.varstore.l2coef, self._reg_dense)
+      torch.add(self._reg_emb, self._reg_dense, out=self.losses['regularization_loss'])
+      total = self.losses['total_loss']
+      total.copy_(self.losses['regularization_loss'])
+      for name, val in loss_dict.items():
+        if name not in self.losses:
+          self.losses[name] = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self.losses[name].copy_(val.reshape(1))
+        total.add_(val.reshape(1))
+      if self.is_training:
+        self.model.backward()
+        self.engine.backward_update(self.opt_emb.kind, self.hyper[0])
+        vs = self.varstore
+        be.dense_opt_step(vs.flat, vs.slots.get('m'), vs.slots.get('v'), vs.flat_grad,
+                          vs.l2coef if vs.any_l2 else None, self.opt_dense.kind, self.hyper[1])
+
+  def train_step(self, batch=None):
+    """Load `batch` (optional) and run one optimisation step.  Returns the dict of loss tensors."""
+    assert self._built, 'call build() first'
+    if batch is not None:
+      self.features.load(batch)
+    else:
+      self.features.version += 1
+    self._refresh_hyper()
+    if self.graph is not None:
+      self.graph.replay()
+    else:
+      self._device_step()
+    self.opt_emb.finish_step()
+    if self.opt_dense is not self.opt_emb:
+      self.opt_dense.finish_step()
+    self.global_step += 1
+    return self.losses
+
+  def predict(self, batch=None):
+    assert self._built
+    if batch is not None:
+      self.features.load(batch)
+    self.features.transform()
+    with context.use(self.ctx), torch.no_grad():
+      self.model.begin_step()
+      return self.model.build_predict_graph()
+
+  def capture(self, warmup=3):
+    """Capture the device part of the step into one hipGraph (replayed by train_step)."""
+    assert self._built and self.graph is None
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+      for _ in range(warmup):
+        self.features.version += 1
+        self._refresh_hyper()
+        self._device_step()
+        self.opt_emb.finish_step()
+        if self.opt_dense is not self.opt_emb:
+          self.opt_dense.finish_step()
+        self.global_step += 1
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    self.features.version += 1
+    self._refresh_hyper()
+    with torch.cuda.graph(g):
+      self._device_step()
+    # the capture itself does not execute: state (step, beta powers) is unchanged by it
+    self.graph = g
+    return g
+
+  # -- host exchange (parity tests / checkpoints)
+  def state_dict(self, slots=False):
+    sd = self.varstore.state_dict()
+    sd.update(self.engine.state_dict(slots=slots))
+    if slots:
+      for name in self.varstore.trainable_names():
+        o, n = self.varstore._offsets[name]
+        for s in ('m', 'v'):
+          if s in self.varstore.slots:
+            sd[name + '/' + s] = self.varstore.slots[s][o:o + n].view(
+                self.varstore._vars[name]['tensor'].shape).cpu().numpy().copy()
+    return sd
+
+  def load_state_dict(self, state):
+    self.varstore.load_state_dict(state, strict=False)
+    self.engine.load_state_dict(state)
+
+  def loss_values(self):
+    torch.cuda.synchronize() if self.device.type == 'cuda' else None
+    return {k: float(v.item()) for k, v in self.losses.items()}

@@ -1,0 +1,137 @@
+"""EasyRecModel base class: the model-level plugin surface.
+
+Mirror of reference easy_rec/python/model/easy_rec_model.py:41-183: constructor contract
+`(model_config, feature_configs, features, labels, is_training)`, `build_predict_graph()`,
+`build_loss_graph()`, `build_metric_graph()`, `get_outputs()`, regulariser resolution
+(`embedding_regularization`, `l2_regularization` incl. the deprecated `dense_regularization`,
+:129-155) and `build_input_layer` (:157-168).
+
+Execution model: `features` are persistent device buffers (input/features.py); the `build_*_graph`
+methods EXECUTE the forward on whatever batch is currently loaded (eager HIP launches that a hipGraph
+can capture), instead of building a TF graph once.  `backward()` seeds torch.autograd with the loss
+gradients produced by the fused loss kernels.
+"""
+import logging
+from abc import abstractmethod
+
+import six
+import torch
+
+from easyrec_amd.core import context
+from easyrec_amd.layers import input_layer
+from easyrec_amd.utils import constant
+from easyrec_amd.utils.load_class import get_register_class_meta
+
+_EASY_REC_MODEL_CLASS_MAP = {}
+_meta_type = get_register_class_meta(_EASY_REC_MODEL_CLASS_MAP, have_abstract_class=True)
+
+
+class EasyRecModel(six.with_metaclass(_meta_type, object)):
+
+  def __init__(self, model_config, feature_configs, features, labels=None, is_training=False):
+    self._base_model_config = model_config
+    self._model_config = model_config
+    self._is_training = is_training
+    self._is_predicting = labels is None
+    self._feature_dict = features
+
+    self._global_ev_params = model_config.ev_params if model_config.HasField('ev_params') else None
+    if self._global_ev_params is not None:
+      raise NotImplementedError('ev_params (hash-table embeddings) are outside the hot-path scope (SURVEY 8f)')
+
+    self._emb_reg = self.embedding_regularization if self.embedding_regularization > 0 else None
+    self._l2_reg = self.l2_regularization if self.l2_regularization > 0 else None
+
+    self._wide_output_dim = -1
+    self._feature_configs = feature_configs
+    self.build_input_layer(model_config, feature_configs)
+
+    self._labels = labels
+    self._prediction_dict = {}
+    self._loss_dict = {}
+    self._metric_dict = {}
+    self._backward_seeds = []
+
+    self._sample_weight = 1.0
+    if getattr(features, 'sample_weight', None) is not None:
+      self._sample_weight = features.sample_weight
+
+  @property
+  def has_backbone(self):
+    return self._base_model_config.HasField('backbone')
+
+  @property
+  def embedding_regularization(self):
+    return self._base_model_config.embedding_regularization
+
+  @property
+  def feature_groups(self):
+    return self._base_model_config.feature_groups
+
+  @property
+  def l2_regularization(self):
+    """reference easy_rec_model.py:143-155 (dense_regularization is a deprecated alias)."""
+    which = self._base_model_config.WhichOneof('model')
+    model_config = getattr(self._base_model_config, which)
+    l2 = 0.0
+    if hasattr(model_config, 'dense_regularization') and model_config.HasField('dense_regularization'):
+      logging.warning('dense_regularization is deprecated, please use l2_regularization')
+      l2 = model_config.dense_regularization
+    elif hasattr(model_config, 'l2_regularization'):
+      l2 = model_config.l2_regularization
+    return l2
+
+  def build_input_layer(self, model_config, feature_configs):
+    self._input_layer = input_layer.InputLayer(
+        feature_configs,
+        model_config.feature_groups,
+        wide_output_dim=self._wide_output_dim,
+        ev_params=self._global_ev_params,
+        embedding_regularizer=self._emb_reg,
+        kernel_regularizer=self._l2_reg,
+        variational_dropout_config=model_config.variational_dropout
+        if model_config.HasField('variational_dropout') else None,
+        is_training=self._is_training,
+        is_predicting=self._is_predicting,
+        engine=context.current().engine)
+
+  def begin_step(self):
+    """Reset per-step state; called by the estimator before build_predict_graph."""
+    self._prediction_dict = {}
+    self._loss_dict = {}
+    self._backward_seeds = []
+
+  @abstractmethod
+  def build_predict_graph(self):
+    pass
+
+  @abstractmethod
+  def build_loss_graph(self):
+    pass
+
+  def build_metric_graph(self, eval_config):
+    return self._metric_dict
+
+  @abstractmethod
+  def get_outputs(self):
+    pass
+
+  def build_output_dict(self):
+    outputs = {}
+    for name in self.get_outputs():
+      if name not in self._prediction_dict:
+        raise KeyError('output node {} not in prediction_dict, can not be exported'.format(name))
+      outputs[name] = self._prediction_dict[name]
+    return outputs
+
+  def backward(self):
+    """Back-propagate the loss gradients recorded by build_loss_graph through the dense graph."""
+    if not self._backward_seeds:
+      return
+    tensors = [t for t, _ in self._backward_seeds]
+    grads = [g.reshape(t.shape) for t, g in self._backward_seeds]
+    torch.autograd.backward(tensors, grads)
+
+  def get_grouped_vars(self, opt_num):
+    assert opt_num == 2, 'could only support 2 optimizers, one for embedding, one for the other layers'
+    return ['embedding', 'dense']

@@ -1,0 +1,107 @@
+"""RankModel: logits -> predictions -> loss (reference easy_rec/python/model/rank_model.py:20-332)."""
+import logging
+
+import torch
+
+from easyrec_amd.builders import loss_builder
+from easyrec_amd.layers.dnn import dense
+from easyrec_amd.model.easy_rec_model import EasyRecModel
+from easyrec_amd.protos.loss_pb2 import LossType
+
+
+class RankModel(EasyRecModel):
+
+  def __init__(self, model_config, feature_configs, features, labels=None, is_training=False):
+    super(RankModel, self).__init__(model_config, feature_configs, features, labels, is_training)
+    self._loss_type = self._model_config.loss_type
+    self._num_class = self._model_config.num_class
+    self._losses = self._model_config.losses
+    if self._labels is not None:
+      if model_config.HasField('label_name'):
+        self._label_name = model_config.label_name
+      else:
+        self._label_name = list(self._labels.keys())[0]
+    self._outputs = []
+
+  def build_predict_graph(self):
+    if not self.has_backbone:
+      raise NotImplementedError(
+          'method `build_predict_graph` must be implemented when backbone network do not exits')
+    raise NotImplementedError('backbone networks: see layers/backbone.py')
+
+  def _output_to_prediction_impl(self, output, loss_type, num_class=1, suffix='', **kwargs):
+    """reference rank_model.py:57-129 (binary / regression heads)."""
+    prediction_dict = {}
+    binary = {LossType.CLASSIFICATION, LossType.BINARY_CROSS_ENTROPY_LOSS, LossType.F1_REWEIGHTED_LOSS,
+              LossType.PAIR_WISE_LOSS, LossType.BINARY_FOCAL_LOSS}
+    if loss_type in binary:
+      assert num_class == 1, 'num_class > 1 (softmax heads) is outside the hot-path scope'
+      output = output.squeeze(1)
+      prediction_dict['logits' + suffix] = output
+      # probs are produced by the fused loss kernel during training; computed here otherwise
+      prediction_dict['probs' + suffix] = torch.sigmoid(output.detach()) if not self._is_training else None
+    elif loss_type == LossType.L2_LOSS:
+      prediction_dict['y' + suffix] = output.squeeze(1)
+    elif loss_type == LossType.SIGMOID_L2_LOSS:
+      prediction_dict['y' + suffix] = torch.sigmoid(output.squeeze(1))
+    else:
+      raise ValueError('unsupported loss type: %s' % LossType.Name(loss_type))
+    return prediction_dict
+
+  def _add_to_prediction_dict(self, output):
+    if len(self._losses) == 0:
+      self._prediction_dict.update(
+          self._output_to_prediction_impl(output, loss_type=self._loss_type, num_class=self._num_class))
+    else:
+      for loss in self._losses:
+        self._prediction_dict.update(
+            self._output_to_prediction_impl(output, loss_type=loss.loss_type, num_class=self._num_class))
+
+  def _build_loss_impl(self, loss_type, label_name, loss_weight=1.0, num_class=1, suffix='', loss_name='',
+                       loss_param=None, loss_scale=1.0):
+    """reference rank_model.py:213-268."""
+    loss_dict = {}
+    if loss_type in {LossType.CLASSIFICATION, LossType.BINARY_CROSS_ENTROPY_LOSS}:
+      loss_name = loss_name if loss_name else 'cross_entropy_loss' + suffix
+      pred = self._prediction_dict['logits' + suffix]
+    elif loss_type in [LossType.L2_LOSS, LossType.SIGMOID_L2_LOSS]:
+      loss_name = loss_name if loss_name else 'l2_loss' + suffix
+      pred = self._prediction_dict['y' + suffix]
+    else:
+      raise ValueError('invalid loss type: %s' % LossType.Name(loss_type))
+    loss, dpred = loss_builder.build(loss_type, self._labels[label_name], pred, loss_weight, num_class,
+                                     loss_scale=loss_scale)
+    loss_dict[loss_name] = loss
+    self._backward_seeds.append((pred, dpred))
+    return loss_dict
+
+  def build_loss_graph(self):
+    loss_dict = {}
+    if len(self._losses) == 0:
+      loss_dict = self._build_loss_impl(self._loss_type, label_name=self._label_name,
+                                        loss_weight=self._sample_weight, num_class=self._num_class)
+    else:
+      strategy = self._base_model_config.loss_weight_strategy
+      assert strategy == self._base_model_config.Fixed, 'only the Fixed loss weight strategy is supported'
+      for loss in self._losses:
+        loss_ops = self._build_loss_impl(loss.loss_type, label_name=self._label_name,
+                                         loss_weight=self._sample_weight, num_class=self._num_class,
+                                         loss_name=loss.loss_name, loss_scale=loss.weight)
+        loss_dict.update(loss_ops)
+    self._loss_dict.update(loss_dict)
+    return self._loss_dict
+
+  def get_outputs(self):
+    if len(self._losses) == 0:
+      return self._get_outputs_impl(self._loss_type, self._num_class)
+    all_outputs = []
+    for loss in self._losses:
+      all_outputs.extend(self._get_outputs_impl(loss.loss_type, self._num_class))
+    return list(set(all_outputs))
+
+  def _get_outputs_impl(self, loss_type, num_class=1, suffix=''):
+    if loss_type in {LossType.CLASSIFICATION, LossType.BINARY_CROSS_ENTROPY_LOSS}:
+      return ['probs' + suffix, 'logits' + suffix]
+    if loss_type in [LossType.L2_LOSS, LossType.SIGMOID_L2_LOSS]:
+      return ['y' + suffix]
+    raise ValueError('invalid loss type: %s' % LossType.Name(loss_type))

@@ -1,0 +1,498 @@
+"""ORACLE - TEST INFRASTRUCTURE ONLY (imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg; never by easyrec_amd/).
+
+Per-entry-point CPU restatement of the arithmetic behind include/easyrec_hip.h, written with plain
+numpy / torch-CPU ops in the order the reference's TF ops run.  `RefBackend` has the same
+tensor-level methods as `easyrec_amd.kernels.HipBackend`, so that
+  * `-m gpu` tests compare every HIP kernel with the matching method on the same seeded inputs;
+  * `-m "not gpu"` tests can drive the whole host logic (plan building, models, estimator) on CPU
+    by monkeypatching the backend - that checks the host code, not the kernels.
+
+Reference call sites restated (all under /root/reference/easy_rec/python):
+  lookup/combiner  compat/embedding_ops.py:37-162 (safe_embedding_lookup_sparse),
+                   compat/feature_column/feature_column.py:199-244 (sum / mean / sqrtn formulas)
+  sparse Adam      compat/adam_s.py:185-213 and tf.train.AdamOptimizer._apply_sparse_shared
+  dense Adam       training_ops.apply_adam (compat/adam_s.py:148-165 call site)
+  FM               layers/fm.py:20-26          wide sum  model/deepfm.py:62-63
+  cross v1 / v2    model/dcn.py:32-45 ; layers/keras/interaction.py:276-286
+  DIN              model/multi_tower_din.py:62-97
+  DNN / BN / Dice  layers/dnn.py:57-79 ; utils/activation.py:14-44
+  loss             builders/loss_builder.py:35-39 ; compat/regularizers.py:76-108
+  MMoE             layers/mmoe.py:62-83
+"""
+import numpy as np
+import torch
+
+from oracle import hashing
+
+OPT_SGD, OPT_ADAM, OPT_LAZY_ADAM, OPT_ADAGRAD = 0, 1, 2, 3
+ACT_NONE, ACT_RELU = 0, 1
+(HYPER_LR, HYPER_LR_T, HYPER_BETA1, HYPER_BETA2, HYPER_OMB1, HYPER_OMB2, HYPER_EPS, HYPER_GSCALE) = range(8)
+
+F32 = np.float32
+
+
+# ---------------------------------------------------------------------------------------------
+# embedding lookup
+# ---------------------------------------------------------------------------------------------
+def lookup_rows(table, ids, offsets, weights, combiner, n_rows):
+  """safe_embedding_lookup_sparse for one column.  numpy fp32, sequential in id order.
+
+  table [rows, dim]; ids int64 (dense mode: [n_rows]; ragged: [nnz] with offsets [n_rows+1]).
+  Pruning: id < 0 (or >= rows) dropped; weight <= 0 dropped unless combiner == sum
+  (compat/embedding_ops.py:95-110).  Empty rows -> zeros (:147-155).
+  """
+  rows, dim = table.shape
+  out = np.zeros((n_rows, dim), dtype=np.float32)
+  for r in range(n_rows):
+    kb, ke = (r, r + 1) if offsets is None else (int(offsets[r]), int(offsets[r + 1]))
+    acc = np.zeros(dim, dtype=np.float32)
+    wsum, w2sum = F32(0), F32(0)
+    for k in range(kb, ke):
+      i = int(ids[k])
+      if i < 0 or i >= rows:
+        continue
+      if weights is not None:
+        w = F32(weights[k])
+        if combiner != 0 and not (w > 0):
+          continue
+        acc = acc + table[i] * w  # embeddings *= weights ; segment_sum
+        wsum = F32(wsum + w)
+        w2sum = F32(w2sum + w * w)
+      else:
+        acc = acc + table[i]
+        wsum = F32(wsum + F32(1))
+        w2sum = F32(w2sum + F32(1))
+    if combiner != 0 and wsum != 0:
+      den = wsum if combiner == 1 else np.sqrt(w2sum, dtype=np.float32)
+      acc = acc / den
+    out[r] = acc
+  return out
+
+
+def lookup_rows_fast(table, ids, offsets, weights, combiner, n_rows):
+  """Vectorised equivalent of `lookup_rows` for dense-mode lookups (one id per row)."""
+  if offsets is not None:
+    return lookup_rows(table, ids, offsets, weights, combiner, n_rows)
+  rows, dim = table.shape
+  ids = np.asarray(ids[:n_rows])
+  ok = (ids >= 0) & (ids < rows)
+  w = None
+  if weights is not None:
+    w = np.asarray(weights[:n_rows], dtype=np.float32)
+    if combiner != 0:
+      ok = ok & (w > 0)
+  safe = np.where(ok, ids, 0)
+  e = table[safe].astype(np.float32)
+  if w is not None:
+    e = e * w[:, None]
+    if combiner == 1:
+      e = e / np.where(ok, w, F32(1))[:, None]
+    elif combiner == 2:
+      e = e / np.where(ok, np.sqrt(w * w, dtype=np.float32), F32(1))[:, None]
+  e[~ok] = 0
+  return e.astype(np.float32)
+
+
+def lookup_entries(spec):
+  """All (key, out_row, scale) entries of a lookup, in entry order (backward bookkeeping)."""
+  ids = spec.ids.cpu().numpy()
+  offsets = None if spec.offsets is None else spec.offsets.cpu().numpy()
+  weights = None if spec.weights is None else spec.weights.cpu().numpy()
+  ents = []
+  for r in range(spec.n_rows):
+    kb, ke = (r, r + 1) if offsets is None else (int(offsets[r]), int(offsets[r + 1]))
+    valid = []
+    for k in range(kb, ke):
+      i = int(ids[k])
+      w = F32(1) if weights is None else F32(weights[k])
+      if i < 0 or i >= spec.rows:
+        continue
+      if weights is not None and spec.combiner != 0 and not (w > 0):
+        continue
+      valid.append((i, w))
+    den = F32(1)
+    if spec.combiner != 0 and valid:
+      wsum = F32(0)
+      w2 = F32(0)
+      for _, w in valid:
+        wsum = F32(wsum + w)
+        w2 = F32(w2 + w * w)
+      den = wsum if spec.combiner == 1 else np.sqrt(w2, dtype=np.float32)
+    for i, w in valid:
+      ents.append((spec.key_base + i, r, F32(w / den)))
+  return ents
+
+
+def adam_row(var, m, v, g, h):
+  """Row arithmetic of the sparse Adam apply (fp32, op by op; compat/adam_s.py:193-213)."""
+  g = g.astype(np.float32)
+  m_t = m * F32(h[HYPER_BETA1]) + g * F32(h[HYPER_OMB1])
+  v_t = v * F32(h[HYPER_BETA2]) + (g * g) * F32(h[HYPER_OMB2])
+  var_t = var - (F32(h[HYPER_LR_T]) * m_t) / (np.sqrt(v_t, dtype=np.float32) + F32(h[HYPER_EPS]))
+  return var_t.astype(np.float32), m_t.astype(np.float32), v_t.astype(np.float32)
+
+
+def sparse_grads(specs, dim):
+  """De-duplicated gradient of a table group: {global_row: summed grad}, occurrences summed in
+  ascending entry order (TF: unsorted_segment_sum over positions)."""
+  acc = {}
+  order = []
+  for s in specs:
+    dout = s.out.detach().cpu().numpy()
+    for key, r, scale in lookup_entries(s):
+      g = dout[r, s.out_col:s.out_col + dim].astype(np.float32) * scale
+      if key in acc:
+        acc[key] = (acc[key] + g).astype(np.float32)
+      else:
+        acc[key] = g.astype(np.float32)
+        order.append(key)
+  return acc
+
+
+def apply_sparse(var, m, v, grads, opt_kind, h):
+  """var/m/v numpy [total_rows, dim] updated in place."""
+  gs = F32(h[HYPER_GSCALE])
+  touched = set()
+  for key, g in grads.items():
+    g = (g * gs).astype(np.float32)
+    touched.add(key)
+    if opt_kind in (OPT_ADAM, OPT_LAZY_ADAM):
+      var[key], m[key], v[key] = adam_row(var[key], m[key], v[key], g, h)
+    elif opt_kind == OPT_ADAGRAD:
+      v[key] = v[key] + g * g
+      var[key] = var[key] - (g * F32(h[HYPER_LR])) / np.sqrt(v[key], dtype=np.float32)
+    else:
+      var[key] = var[key] - F32(h[HYPER_LR]) * g
+  if opt_kind == OPT_ADAM:
+    # tf.train.AdamOptimizer._apply_sparse_shared: m, v of EVERY row decay, every row moves
+    mask = np.ones(var.shape[0], dtype=bool)
+    if touched:
+      mask[np.fromiter(touched, dtype=np.int64)] = False
+    m[mask] = m[mask] * F32(h[HYPER_BETA1])
+    v[mask] = v[mask] * F32(h[HYPER_BETA2])
+    var[mask] = var[mask] - (F32(h[HYPER_LR_T]) * m[mask]) / (np.sqrt(v[mask], dtype=np.float32) +
+                                                            F32(h[HYPER_EPS]))
+
+
+def dense_opt(w, m, v, grad, l2coef, opt_kind, h):
+  """training_ops.apply_adam: m += (g-m)*(1-b1); v += (g*g-v)*(1-b2); var -= m*alpha/(sqrt(v)+eps)."""
+  g = grad.astype(np.float32) * F32(h[HYPER_GSCALE])
+  if l2coef is not None:
+    g = np.where(l2coef != 0, g + l2coef * w, g).astype(np.float32)
+  if opt_kind in (OPT_ADAM, OPT_LAZY_ADAM):
+    m[:] = m + (g - m) * F32(h[HYPER_OMB1])
+    v[:] = v + (g * g - v) * F32(h[HYPER_OMB2])
+    w[:] = w - (m * F32(h[HYPER_LR_T])) / (np.sqrt(v, dtype=np.float32) + F32(h[HYPER_EPS]))
+  elif opt_kind == OPT_ADAGRAD:
+    v[:] = v + g * g
+    w[:] = w - (g * F32(h[HYPER_LR])) / np.sqrt(v, dtype=np.float32)
+  else:
+    w[:] = w - F32(h[HYPER_LR]) * g
+
+
+# ---------------------------------------------------------------------------------------------
+# backend with the HipBackend method surface (CPU tensors)
+# ---------------------------------------------------------------------------------------------
+class RefBackend(object):
+  name = 'oracle'
+
+  def reserve_scratch(self, floats):
+    pass
+
+  @staticmethod
+  def require_device():
+    pass
+
+  def device_info(self):
+    return {'cu_count': 0, 'wave_size': 0, 'arch': 'cpu-oracle'}
+
+  # -- hashing
+  def hash_bucket_fast_host(self, bytes_np, offsets_np, n_per_col, num_buckets, drop_empty):
+    return hashing.hash_bucket_fast(bytes_np, offsets_np, n_per_col, num_buckets, drop_empty)
+
+  def hash_bucket_fast(self, bytes_t, offsets_t, n_per_col, num_buckets_t, drop_empty, out=None):
+    r = hashing.hash_bucket_fast(bytes_t.cpu().numpy(), offsets_t.cpu().numpy(), n_per_col,
+                                 num_buckets_t.cpu().numpy().astype(np.uint64), drop_empty)
+    r = torch.from_numpy(r)
+    if out is None:
+      return r
+    out.view(-1)[:r.numel()].copy_(r)
+    return out
+
+  def hash_bucket_fast_int64(self, values_t, n_per_col, num_buckets_t, out=None):
+    vals = values_t.cpu().numpy().reshape(-1)
+    strs = [str(int(x)).encode() for x in vals]
+    data = np.frombuffer(b''.join(strs), dtype=np.uint8)
+    offs = np.cumsum([0] + [len(s) for s in strs]).astype(np.int64)
+    r = torch.from_numpy(
+        hashing.hash_bucket_fast(data, offs, n_per_col, num_buckets_t.cpu().numpy().astype(np.uint64), False))
+    if out is None:
+      return r
+    out.view(-1).copy_(r)
+    return out
+
+  # -- embeddings
+  def emb_plan_create(self, specs):
+    nblk = 0
+    for s in specs:
+      V = 4 if s.dim % 4 == 0 else 1
+      G = 1
+      while G < s.dim // V:
+        G <<= 1
+      nblk += (max(s.n_rows, 1) + 256 // G - 1) // (256 // G)
+    return {'specs': list(specs), 'num_blocks': nblk}
+
+  def emb_plan_destroy(self, plan):
+    pass
+
+  def emb_fwd(self, plan, sumsq_partials=None):
+    blk = 0
+    for s in plan['specs']:
+      table = s.table.detach().cpu().numpy()
+      ids = s.ids.cpu().numpy()
+      offsets = None if s.offsets is None else s.offsets.cpu().numpy()
+      weights = None if s.weights is None else s.weights.detach().cpu().numpy()
+      res = lookup_rows_fast(table, ids, offsets, weights, s.combiner, s.n_rows)
+      s.out[:s.n_rows, s.out_col:s.out_col + s.dim] = torch.from_numpy(res)
+      V = 4 if s.dim % 4 == 0 else 1
+      G = 1
+      while G < s.dim // V:
+        G <<= 1
+      rpb = 256 // G
+      nb = (max(s.n_rows, 1) + rpb - 1) // rpb
+      if sumsq_partials is not None:
+        sq = (res.astype(np.float64)**2).sum(axis=1)
+        for b in range(nb):
+          sumsq_partials[blk + b] = float(sq[b * rpb:(b + 1) * rpb].sum())
+      blk += nb
+
+  def emb_group_create(self, specs, dim, total_rows, var, m, v, bitmap):
+    n_ent = sum((s.max_nnz if s.offsets is not None else s.n_rows) for s in specs)
+    return {'specs': list(specs), 'dim': dim, 'total_rows': total_rows, 'var': var, 'm': m, 'v': v,
+            'bitmap': bitmap, 'num_entries': n_ent}
+
+  def emb_group_destroy(self, group):
+    pass
+
+  def emb_bwd_update(self, group, opt_kind, hyper):
+    h = hyper.detach().cpu().numpy().reshape(-1)
+    grads = sparse_grads(group['specs'], group['dim'])
+    var = group['var'].detach().numpy()
+    m = None if group['m'] is None else group['m'].numpy()
+    v = None if group['v'] is None else group['v'].numpy()
+    apply_sparse(var, m, v, grads, opt_kind, h)
+
+  def emb_bwd_reduce(self, group):
+    grads = sparse_grads(group['specs'], group['dim'])
+    keys = sorted(grads.keys())
+    n = group['num_entries']
+    k = torch.zeros(n, dtype=torch.int32)
+    g = torch.zeros(n, group['dim'], dtype=torch.float32)
+    for i, key in enumerate(keys):
+      k[i] = key
+      g[i] = torch.from_numpy(grads[key])
+    return k, g, torch.tensor([len(keys)], dtype=torch.int32)
+
+  def adam_decay_sweep(self, var, m, v, bitmap, total_rows, dim, hyper):
+    h = hyper.detach().cpu().numpy().reshape(-1)
+    bits = None if bitmap is None else bitmap.cpu().numpy().view(np.uint32)
+    rows = np.arange(total_rows)
+    live = np.ones(total_rows, dtype=bool)
+    if bits is not None:
+      live = ((bits[rows >> 5] >> (rows & 31).astype(np.uint32)) & 1) == 0
+    vn, mn, vv = var.numpy(), m.numpy(), v.numpy()
+    mn[live] = mn[live] * F32(h[HYPER_BETA1])
+    vv[live] = vv[live] * F32(h[HYPER_BETA2])
+    vn[live] = vn[live] - (F32(h[HYPER_LR_T]) * mn[live]) / (np.sqrt(vv[live], dtype=np.float32) +
+                                                          F32(h[HYPER_EPS]))
+
+  # -- FM / wide
+  def fm_fwd(self, x, F, D):
+    e = x[:, :F * D].reshape(x.shape[0], F, D)
+    S = e.sum(dim=1)
+    q = (e * e).sum(dim=1)
+    return 0.5 * (S * S - q), S
+
+  def fm_bwd(self, x, S, g, F, D):
+    e = x[:, :F * D].reshape(x.shape[0], F, D)
+    return (g[:, None, :] * (S[:, None, :] - e)).reshape(x.shape[0], F * D)
+
+  def rowsum_fwd(self, x, n):
+    return x[:, :n].sum(dim=1, keepdim=True)
+
+  def rowsum_bwd(self, g, n):
+    return g.reshape(-1, 1).expand(-1, n).contiguous()
+
+  def axpy2d(self, x, alpha, y, accumulate=True):
+    if accumulate:
+      y.add_(x, alpha=alpha)
+    else:
+      y.copy_(x * alpha)
+
+  # -- cross
+  def cross_v1_fwd(self, x0, w, b):
+    x = x0
+    dots = []
+    for l in range(w.shape[0]):
+      xw = (x * w[l]).sum(dim=1, keepdim=True)
+      dots.append(xw)
+      x = (x0 * xw + b[l]) + x
+    return x, torch.cat(dots, dim=1)
+
+  def cross_v1_bwd(self, x0, w, b, dots, dout):
+    x0_ = x0.detach().clone().requires_grad_(True)
+    w_ = w.detach().clone().requires_grad_(True)
+    b_ = b.detach().clone().requires_grad_(True)
+    with torch.enable_grad():
+      out, _ = self.cross_v1_fwd(x0_, w_, b_)
+      out.backward(dout)
+    return x0_.grad, w_.grad, b_.grad
+
+  def cross_v2_fwd(self, x0, x, u, bias, diag_scale):
+    t = u if bias is None else u + bias
+    if diag_scale != 0:
+      t = t + diag_scale * x
+    return x0 * t + x
+
+  def cross_v2_bwd(self, x0, x, u, bias, diag_scale, dout):
+    t = u if bias is None else u + bias
+    if diag_scale != 0:
+      t = t + diag_scale * x
+    dx = dout + (dout * x0 * diag_scale if diag_scale != 0 else 0)
+    return dout * t, dx, dout * x0
+
+  # -- DIN
+  def din_concat_fwd(self, q, h):
+    B, L, E = h.shape
+    qq = q[:, None, :].expand(B, L, E)
+    return torch.cat([qq, h, qq - h, qq * h], dim=-1)
+
+  def din_concat_bwd(self, q, h, dout):
+    B, L, E = h.shape
+    g0, g1, g2, g3 = dout[..., :E], dout[..., E:2 * E], dout[..., 2 * E:3 * E], dout[..., 3 * E:]
+    qq = q[:, None, :]
+    dq = (g0 + g2 + g3 * h).sum(dim=1)
+    dh = g1 - g2 + g3 * qq
+    return dq, dh
+
+  def din_pool_fwd(self, scores, hist, seq_len, scale=1.0):
+    B, L, E = hist.shape
+    mask = torch.arange(L)[None, :] < seq_len[:, None].to(torch.int64)
+    pad = torch.full_like(scores, float(-2**32 + 1))
+    s = torch.where(mask, scores * scale, pad)
+    p = torch.softmax(s, dim=1)
+    return torch.bmm(p[:, None, :], hist)[:, 0, :], p
+
+  def din_pool_bwd(self, probs, hist, seq_len, dout, scale=1.0):
+    B, L, E = hist.shape
+    dp = torch.bmm(hist, dout[:, :, None])[:, :, 0]
+    ds = probs * (dp - (probs * dp).sum(dim=1, keepdim=True))
+    mask = torch.arange(L)[None, :] < seq_len[:, None].to(torch.int64)
+    ds = torch.where(mask, ds * scale, torch.zeros_like(ds))
+    dh = probs[:, :, None] * dout[:, None, :]
+    return ds, dh
+
+  # -- MLP pieces
+  def bn_act_fwd(self, x, bias, gamma, beta, use_bn, eps, momentum, moving_mean, moving_var, act):
+    z = x if bias is None else x + bias
+    mean = invstd = None
+    if use_bn:
+      mean = z.mean(dim=0)
+      var = ((z - mean)**2).mean(dim=0)  # tf.nn.moments: biased
+      invstd = 1.0 / torch.sqrt(var + eps)
+      y = (z - mean) * invstd
+      y = y * (gamma if gamma is not None else 1.0) + (beta if beta is not None else 0.0)
+      if moving_mean is not None:
+        moving_mean.sub_((moving_mean - mean) * (1.0 - momentum))
+        moving_var.sub_((moving_var - var) * (1.0 - momentum))
+    else:
+      y = z
+    if act == ACT_RELU:
+      y = torch.relu(y)
+    return y, mean, invstd
+
+  def bn_act_bwd(self, x, bias, gamma, y, mean, invstd, dy, use_bn, act, need_bias, need_affine):
+    B = x.shape[0]
+    g = dy * (y > 0).to(dy.dtype) if act == ACT_RELU else dy
+    dbias = dgamma = dbeta = None
+    if use_bn:
+      z = x if bias is None else x + bias
+      xh = (z - mean) * invstd
+      sg, sgx = g.sum(dim=0), (g * xh).sum(dim=0)
+      ga = gamma if gamma is not None else 1.0
+      dx = ga * invstd * (g - sg / B - xh * (sgx / B))
+      if need_affine:
+        dgamma, dbeta = sgx, sg
+      if need_bias:
+        dbias = torch.zeros_like(sg)
+    else:
+      dx = g
+      if need_bias:
+        dbias = g.sum(dim=0)
+    return dx, dbias, dgamma, dbeta
+
+  def colsum(self, x):
+    return x.sum(dim=0)
+
+  def dice_fwd(self, x, alpha, eps, momentum, moving_mean, moving_var):
+    mean = x.mean(dim=0)
+    var = ((x - mean)**2).mean(dim=0)
+    invstd = 1.0 / torch.sqrt(var + eps)
+    p = torch.sigmoid((x - mean) * invstd)
+    if moving_mean is not None:
+      moving_mean.sub_((moving_mean - mean) * (1.0 - momentum))
+      moving_var.sub_((moving_var - var) * (1.0 - momentum))
+    return alpha * (1.0 - p) * x + p * x, mean, invstd
+
+  def dice_bwd(self, x, alpha, mean, invstd, dy):
+    B = x.shape[0]
+    xh = (x - mean) * invstd
+    p = torch.sigmoid(xh)
+    direct = dy * (alpha + (1.0 - alpha) * p)
+    q = dy * x * (1.0 - alpha) * p * (1.0 - p)
+    dx = direct + invstd * (q - q.sum(dim=0) / B - xh * ((q * xh).sum(dim=0) / B))
+    dalpha = (dy * (1.0 - p) * x).sum(dim=0)
+    return dx, dalpha
+
+  # -- loss
+  def sigmoid_ce(self, logits, labels, weights, loss_scale=1.0):
+    z, y = logits.to(torch.float32), labels.to(torch.float32)
+    ce = torch.clamp(z, min=0) - z * y + torch.log1p(torch.exp(-torch.abs(z)))
+    w = torch.ones_like(z) if weights is None else weights
+    nz = torch.clamp((w != 0).sum().to(torch.float32), min=1.0)
+    loss = (w * ce).sum().reshape(1) / nz * loss_scale
+    p = torch.sigmoid(z)
+    return loss, loss_scale * w * (p - y) / nz, p
+
+  def reduce_sum(self, partials, scale, out, accumulate=False):
+    s = partials.to(torch.float64).sum().to(torch.float32) * scale
+    if accumulate:
+      out.add_(s)
+    else:
+      out.fill_(float(s))
+
+  def l2_loss(self, w, coef, out, accumulate=False):
+    s = (coef.to(torch.float64) * 0.5 * w.detach().to(torch.float64)**2).sum().to(torch.float32)
+    if accumulate:
+      out.add_(s)
+    else:
+      out.fill_(float(s))
+
+  # -- MMoE
+  def mmoe_mix_fwd(self, experts, gate_logits):
+    gates = torch.softmax(gate_logits, dim=-1)  # [T,B,E]
+    out = torch.einsum('tbe,ebh->tbh', gates, experts)
+    return out, gates
+
+  def mmoe_mix_bwd(self, experts, gates, dout):
+    dexperts = torch.einsum('tbe,tbh->ebh', gates, dout)
+    dg = torch.einsum('tbh,ebh->tbe', dout, experts)
+    dlogits = gates * (dg - (gates * dg).sum(dim=-1, keepdim=True))
+    return dexperts, dlogits
+
+  # -- dense optimizer
+  def dense_opt_step(self, w, m, v, grad, l2coef, opt_kind, hyper):
+    h = hyper.detach().cpu().numpy().reshape(-1)
+    dense_opt(w.detach().numpy(), None if m is None else m.numpy(), None if v is None else v.numpy(),
+              grad.detach().numpy(), None if l2coef is None else l2coef.numpy(), opt_kind, h)
