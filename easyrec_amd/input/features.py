@@ -35,6 +35,7 @@ class FeatureSchema(object):
     self.label_fields = list(data_config.label_fields)
     self.sample_weight = data_config.sample_weight if data_config.HasField('sample_weight') else None
     self.raw = OrderedDict()      # name -> dict(dim, row)  rows of the raw block
+    self.raw_multi = OrderedDict()  # name -> k (raw_input_dim > 1)
     self.hash_single = OrderedDict()   # name -> dict(buckets, col)
     self.int_single = OrderedDict()    # name -> dict(col, num_buckets)
     self.tags = OrderedDict()     # name -> dict(cap, weighted, hash_buckets | None)
@@ -47,8 +48,11 @@ class FeatureSchema(object):
       self.feature_configs[name] = fc
       ft = fc.feature_type
       if ft == FeatureConfig.RawFeature:
-        self.raw[name] = {'dim': fc.raw_input_dim, 'row': n_raw_rows}
-        n_raw_rows += fc.raw_input_dim
+        if fc.raw_input_dim > 1:
+          self.raw_multi[name] = int(fc.raw_input_dim)  # stored example-major [B, k]
+        else:
+          self.raw[name] = {'dim': 1, 'row': n_raw_rows}
+          n_raw_rows += 1
       elif ft == FeatureConfig.IdFeature:
         if fc.HasField('hash_bucket_size') and fc.hash_bucket_size > 0:
           self.hash_single[name] = {'buckets': int(fc.hash_bucket_size), 'col': len(self.hash_single)}
@@ -94,6 +98,13 @@ class DeviceFeatures(object):
     self.hash_buckets = torch.from_numpy(schema.hash_buckets_array.astype(np.int64)).to(dev) if nh else None
     self.int_ids = torch.zeros(max(len(schema.int_single), 1), B, dtype=torch.int64, device=dev)
     self.zero_ids = torch.zeros(B, dtype=torch.int64, device=dev)  # projection id 0 of raw features
+    self.raw_multi = {}
+    for name, k in schema.raw_multi.items():
+      self.raw_multi[name] = {
+          'values': torch.zeros(B, k, dtype=torch.float32, device=dev),
+          'ids': torch.arange(k, dtype=torch.int64, device=dev).repeat(B),
+          'offsets': (torch.arange(B + 1, dtype=torch.int32, device=dev) * k),
+      }
     self.tags = {}
     for name, t in schema.tags.items():
       self.tags[name] = {
@@ -115,6 +126,8 @@ class DeviceFeatures(object):
 
   # -- dict-like views (the reference's parsed feature dict)
   def raw(self, name):
+    if name in self.raw_multi:
+      return self.raw_multi[name]['values']  # [B, k]
     r = self.schema.raw[name]
     blk = self.raw_block[r['row']:r['row'] + r['dim']]
     return blk[0] if r['dim'] == 1 else blk  # [B] or [dim, B]
@@ -131,7 +144,7 @@ class DeviceFeatures(object):
 
   def __contains__(self, name):
     s = self.schema
-    return (name in s.raw or name in s.hash_single or name in s.int_single or name in s.tags or
+    return (name in s.raw or name in s.raw_multi or name in s.hash_single or name in s.int_single or name in s.tags or
             name in s.seqs)
 
   # -- batch loading
@@ -165,6 +178,8 @@ class DeviceFeatures(object):
       put(self.hash_ids, batch['hash_ids'])
       self._use_device_hash = False
     put(self.int_ids, batch.get('int_ids'))
+    for name, bufs in self.raw_multi.items():
+      put(bufs['values'], batch.get('rawm/%s' % name))
     if 'sample_weight' in batch:
       if self.sample_weight is None:
         self.sample_weight = torch.ones(self.batch_size, dtype=torch.float32, device=self.device)

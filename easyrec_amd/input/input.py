@@ -111,6 +111,19 @@ class Input(object, metaclass=_meta_type):
         raise NotImplementedError('normalizer_fn %s' % fn)
     return x.astype(np.float32)
 
+  def _parse_raw_multi(self, fc, columns):
+    """raw_input_dim > 1: 'v0<sep>v1<sep>...' -> [B, k] (input.py:569-600), then min/max normalise."""
+    col = columns[fc.input_names[0]]
+    k = fc.raw_input_dim
+    x = np.zeros((len(col), k), dtype=np.float32)
+    for i, s in enumerate(col):
+      parts = self._split_charset(s, fc.separator)
+      assert len(parts) <= k, 'raw feature %s: %d values > raw_input_dim %d' % (fc.input_names[0], len(parts), k)
+      x[i, :len(parts)] = [np.float32(float(p)) for p in parts]
+    if fc.max_val > fc.min_val:
+      x = (x - np.float32(fc.min_val)) / np.float32(fc.max_val - fc.min_val)
+    return x.astype(np.float32)
+
   @staticmethod
   def _split_charset(s, seps):
     """tf.string_split: every character of `seps` is a delimiter; empty tokens are skipped."""
@@ -207,9 +220,10 @@ class Input(object, metaclass=_meta_type):
       name = feature_name_of(fc)
       ft = fc.feature_type
       if ft == FeatureConfig.RawFeature:
-        r = sch.raw[name]
-        assert r['dim'] == 1, 'raw_input_dim > 1 is not supported yet'
-        raw[r['row']] = self._parse_raw(fc, columns)
+        if name in sch.raw_multi:
+          out['rawm/%s' % name] = self._parse_raw_multi(fc, columns)
+        else:
+          raw[sch.raw[name]['row']] = self._parse_raw(fc, columns)
       elif ft == FeatureConfig.IdFeature:
         col = columns[fc.input_names[0]]
         if name in sch.hash_single:

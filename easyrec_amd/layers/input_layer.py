@@ -377,8 +377,8 @@ class InputLayer(object):
       g = eng.groups[plan['gkey']]
       for c, col in plan['numeric']:
         src = features.raw(c.key)
-        src2 = src.view(1, -1).t() if src.dim() == 1 else src.t()
-        kernels.hip().axpy2d(src2.contiguous(), 1.0, g['out'][:, col:col + c.dimension], accumulate=False)
+        src2 = src.view(-1, 1) if src.dim() == 1 else src
+        kernels.hip().axpy2d(src2, 1.0, g['out'][:, col:col + c.dimension], accumulate=False)
       out = eng.group_tensor(plan['gkey'], requires_grad=self._is_training)
     views = [out[:, c0:c0 + d] for c0, d in zip(plan['cols'], plan['dims'])]
     flist = FeatureList(views, base=out, col0=0, dims=plan['dims'])
@@ -400,12 +400,13 @@ def declare_lookup(eng, features, column, scope, gkey, col, n_out_rows, seq=Fals
   B = features.batch_size
   if cat.weight_key and cat.key.endswith('_raw_proj_id'):
     # RawFeature projection: ids 0..k-1 weighted by the normalised values (input.py:648-673)
-    r = schema.raw[fname]
-    if r['dim'] == 1:
+    if fname in schema.raw_multi:
+      rm = features.raw_multi[fname]
+      eng.add_lookup(gkey, table_name, rm['ids'], rm['offsets'], rm['values'].view(-1), col, column.combiner, B,
+                     rm['ids'].numel(), fname)
+    else:
       eng.add_lookup(gkey, table_name, features.zero_ids, None, features.raw(fname), col, column.combiner, B, B,
                      fname)
-    else:
-      raise NotImplementedError('raw_input_dim > 1 projection')
     return
   if seq:
     s = features.seqs[fname]

@@ -1,0 +1,420 @@
+"""ORACLE - TEST INFRASTRUCTURE ONLY.  Never imported by easyrec_amd/.
+
+CPU restatement (torch-CPU autograd + numpy fp32) of the reference's whole training step for the
+hot-path models, written from the cited reference source (alibaba/EasyRec v0.8.7, paths relative
+to /root/reference/easy_rec/python) and TF's documented op semantics:
+
+  preprocessing  input/input.py:537-555 (ids), :557-673 (raw: (x-min)/(max-min)),
+                 compat/feature_column/feature_column.py:2599-2643 ('' dropped), v2:3903-3926 (hash)
+  input layer    layers/input_layer.py:280-376, compat/feature_column/feature_column.py:384-414,
+                 lookup = safe_embedding_lookup_sparse (compat/embedding_ops.py:37-162)
+  DeepFM         model/deepfm.py:53-109; FM layers/fm.py:20-26; DNN layers/dnn.py:50-87
+  DCN            model/dcn.py:32-70
+  MultiTowerDIN  model/multi_tower_din.py:62-130, layers/seq_input_layer.py:34-124
+  MMoE           model/mmoe.py:35-70, layers/mmoe.py:62-83, model/multi_task_model.py:33-141
+  loss           model/rank_model.py:105-111,213-332, builders/loss_builder.py:35-39
+  regularisation model/easy_rec_estimator.py:166-184, compat/regularizers.py:76-108
+  optimizer      builders/optimizer_builder.py:61-66 (tf.train.AdamOptimizer, dense-decay sparse
+                 apply), compat/adam_s.py:185-213 (lazy), core/learning_schedules.py:25-73
+
+It shares with the product only the config schema (the drop-in boundary) and the host batch dict
+format; variables are taken BY NAME from the product's initial state, so a naming or layout
+disagreement fails loudly.
+
+Parity status: the reference's tests hold no numeric expectation for these graphs and TensorFlow
+cannot run here -> "parity unpinned" for everything except hashing and the embed_test vectors.
+"""
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from oracle import hashing
+
+F32 = np.float32
+BN_EPS, BN_MOMENTUM = 1e-3, 0.99
+
+
+def _fname(fc):
+  return fc.feature_name if fc.HasField('feature_name') else fc.input_names[0]
+
+
+class Vars(object):
+  """name -> torch leaf (requires_grad) created from the numpy state on first use."""
+
+  def __init__(self, state, dtype):
+    self.state = state
+    self.dtype = dtype
+    self.used = OrderedDict()
+    self.l2 = {}
+
+  def get(self, name, l2=0.0, trainable=True):
+    if name not in self.used:
+      if name not in self.state:
+        raise KeyError('oracle: variable %r not found in the product state (have e.g. %s)' %
+                       (name, list(self.state)[:5]))
+      t = torch.tensor(self.state[name], dtype=self.dtype)
+      if trainable:
+        t.requires_grad_(True)
+      self.used[name] = t
+      self.l2[name] = l2
+    return self.used[name]
+
+
+class OracleTrainer(object):
+
+  def __init__(self, cfg, state, batch_size, dtype=torch.float32):
+    self.cfg = cfg
+    self.B = batch_size
+    self.dtype = dtype
+    self.state = OrderedDict((k, np.array(v, dtype=np.float32)) for k, v in state.items())
+    self.features = list(cfg.feature_configs) if cfg.feature_configs else list(cfg.feature_config.features)
+    self.fc_by_name = OrderedDict((_fname(f), f) for f in self.features)
+    self.global_step = 0
+    oc = cfg.train_config.optimizer_config
+    self.opt = [self._opt_cfg(o) for o in oc]
+    self.beta_pow = [[F32(o['beta1']), F32(o['beta2'])] for o in self.opt]
+    self.slots = {}
+    self.emb_mult = float(oc[0].embedding_learning_rate_multiplier) \
+        if oc[0].HasField('embedding_learning_rate_multiplier') else 1.0
+    self.model_class = cfg.model_config.model_class
+
+  # ------------------------------------------------------------------ optimizer config
+  @staticmethod
+  def _opt_cfg(o):
+    kind = o.WhichOneof('optimizer')
+    c = getattr(o, kind)
+    d = {'kind': kind, 'beta1': getattr(c, 'beta1', 0.9), 'beta2': getattr(c, 'beta2', 0.999), 'lr_cfg': c.learning_rate}
+    return d
+
+  def _lr(self, lr_cfg, step):
+    kind = lr_cfg.WhichOneof('learning_rate')
+    if kind == 'constant_learning_rate':
+      return F32(lr_cfg.constant_learning_rate.learning_rate)
+    if kind == 'exponential_decay_learning_rate':
+      c = lr_cfg.exponential_decay_learning_rate
+      # core/learning_schedules.py:25-73 + tf.train.exponential_decay (staircase default true)
+      p = F32(step - c.burnin_steps) / F32(c.decay_steps)
+      if c.staircase:
+        p = np.floor(p)
+      post = F32(c.initial_learning_rate) * np.power(F32(c.decay_factor), F32(p), dtype=F32)
+      if c.burnin_learning_rate == 0:
+        burn = F32(c.initial_learning_rate)
+      else:
+        burn = F32((c.initial_learning_rate - c.burnin_learning_rate) / c.burnin_steps) * F32(step) + \
+            F32(c.burnin_learning_rate)
+      lr = burn if step < c.burnin_steps else post
+      return F32(max(F32(lr), F32(c.min_learning_rate)))
+    raise NotImplementedError(kind)
+
+  # ------------------------------------------------------------------ preprocessing
+  def _hashed_ids(self, batch):
+    """int64 [n_hash_features, B], -1 where the string is '' (dropped before hashing)."""
+    names = [n for n, f in self.fc_by_name.items()
+             if f.feature_type == f.IdFeature and f.HasField('hash_bucket_size') and f.hash_bucket_size > 0]
+    if not names:
+      return {}
+    if 'hash_ids' in batch:
+      ids = np.asarray(batch['hash_ids'])
+    else:
+      nb = np.array([self.fc_by_name[n].hash_bucket_size for n in names], dtype=np.uint64)
+      ids = hashing.hash_bucket_fast(np.asarray(batch['str_bytes']), np.asarray(batch['str_offsets']), self.B, nb,
+                                     True).reshape(len(names), self.B)
+    return {n: ids[i] for i, n in enumerate(names)}
+
+  def _raw_values(self, batch):
+    out, row = {}, 0
+    for n, f in self.fc_by_name.items():
+      if f.feature_type == f.RawFeature:
+        if f.raw_input_dim > 1:
+          out[n] = np.asarray(batch['rawm/%s' % n], dtype=np.float32)
+        else:
+          out[n] = np.asarray(batch['raw'], dtype=np.float32)[row]
+          row += 1
+    return out
+
+  def _int_ids(self, batch):
+    out, col = {}, 0
+    for n, f in self.fc_by_name.items():
+      if f.feature_type == f.IdFeature and not (f.HasField('hash_bucket_size') and f.hash_bucket_size > 0):
+        out[n] = np.asarray(batch['int_ids'])[col]
+        col += 1
+    return out
+
+  # ------------------------------------------------------------------ embedding columns
+  def _column_var_name(self, scope, fc, wide):
+    name = _fname(fc)
+    if fc.feature_type == fc.RawFeature and not fc.boundaries:
+      col = '%s_weighted_by_%s_raw_proj_val' % (name, name)
+    elif fc.feature_type == fc.TagFeature and (len(fc.input_names) > 1 or fc.HasField('kv_separator')):
+      col = '%s_weighted_by_%s_w' % (name, name)
+    else:
+      col = name
+    if fc.HasField('embedding_name') and self._is_shared(fc.embedding_name):
+      return '%s%s/embedding_weights' % (fc.embedding_name, '_wide' if wide else '')
+    return '%s/%s_embedding/embedding_weights' % (scope, col)
+
+  def _is_shared(self, embedding_name):
+    return sum(1 for f in self.features if f.HasField('embedding_name') and f.embedding_name == embedding_name) > 1
+
+  def _touch(self, table, ids):
+    key = id(table)
+    mask = self._touched.setdefault(key, np.zeros(table.shape[0], dtype=bool))
+    ids = np.asarray(ids).reshape(-1)
+    ok = (ids >= 0) & (ids < table.shape[0])
+    mask[ids[ok]] = True
+
+  def _lookup_dense(self, table, ids, weights=None):
+    """One id per example; id < 0 -> zero row; optional weight multiplies the row (combiner sum)."""
+    self._touch(table, ids)
+    idt = torch.as_tensor(np.asarray(ids), dtype=torch.int64)
+    ok = (idt >= 0) & (idt < table.shape[0])
+    e = table[torch.where(ok, idt, torch.zeros_like(idt))]
+    if weights is not None:
+      e = e * torch.as_tensor(np.asarray(weights), dtype=self.dtype)[:, None]
+    return e * ok.to(self.dtype)[:, None]
+
+  def _lookup_ragged(self, table, ids, offsets, weights, combiner):
+    rows = []
+    ids = np.asarray(ids)
+    self._touch(table, ids[int(offsets[0]):int(offsets[self.B])])
+    for r in range(self.B):
+      kb, ke = int(offsets[r]), int(offsets[r + 1])
+      acc = torch.zeros(table.shape[1], dtype=self.dtype)
+      wsum, w2 = 0.0, 0.0
+      for k in range(kb, ke):
+        i = int(ids[k])
+        if i < 0 or i >= table.shape[0]:
+          continue
+        w = 1.0 if weights is None else float(weights[k])
+        if weights is not None and combiner != 'sum' and not (w > 0):
+          continue
+        acc = acc + table[i] * w if weights is not None else acc + table[i]
+        wsum += w
+        w2 += w * w
+      if combiner == 'mean' and wsum != 0:
+        acc = acc / wsum
+      elif combiner == 'sqrtn' and wsum != 0:
+        acc = acc / math.sqrt(w2)
+      rows.append(acc)
+    return torch.stack(rows)
+
+  def input_layer(self, V, batch, group_name, scope, wide_dim=None):
+    """Returns (concat [B, sum dim], [per feature tensors]); adds the embedding L2 to self._reg."""
+    group = [g for g in self.cfg.model_config.feature_groups if g.group_name == group_name][0]
+    wide = (group.wide_deep == 1)
+    names = []
+    for n in group.feature_names:
+      m = __import__('re').match(r'([a-zA-Z_]+)\[([0-9]+)-([0-9]+)\]', n)
+      names.extend(['%s%d' % (m.group(1), t) for t in range(int(m.group(2)), int(m.group(3)) + 1)] if m else [n])
+    hashed, raws, ints = self._cache
+    outs = []
+    lam = self.cfg.model_config.embedding_regularization
+    for n in names:
+      fc = self.fc_by_name[n]
+      dim = wide_dim if wide else fc.embedding_dim
+      if fc.feature_type == fc.RawFeature:
+        if dim == 0:
+          v = torch.as_tensor(raws[n], dtype=self.dtype)
+          outs.append((v.reshape(self.B, -1), False))
+          continue
+        table = V.get(self._column_var_name(scope, fc, wide))
+        if fc.raw_input_dim > 1:
+          k = fc.raw_input_dim
+          ids = np.tile(np.arange(k), self.B)
+          e = self._lookup_ragged(table, ids, np.arange(self.B + 1) * k, raws[n].reshape(-1),
+                                  'sum' if wide else fc.combiner)
+        else:
+          e = self._lookup_dense(table, np.zeros(self.B, dtype=np.int64), raws[n])
+        outs.append((e, True))
+      elif fc.feature_type == fc.IdFeature:
+        table = V.get(self._column_var_name(scope, fc, wide))
+        ids = hashed[n] if n in hashed else ints[n]
+        outs.append((self._lookup_dense(table, ids), True))
+      elif fc.feature_type == fc.TagFeature:
+        table = V.get(self._column_var_name(scope, fc, wide))
+        w = batch.get('tag/%s/weights' % n)
+        e = self._lookup_ragged(table, batch['tag/%s/ids' % n], batch['tag/%s/offsets' % n], w,
+                                'sum' if wide else fc.combiner)
+        outs.append((e, True))
+      else:
+        raise NotImplementedError('oracle: feature type of %s' % n)
+    if lam > 0:
+      for e, is_emb in outs:
+        if is_emb:
+          self._reg = self._reg + lam * 0.5 * (e * e).sum()  # scale * tf.nn.l2_loss(out_f)
+    feats = [e for e, _ in outs]
+    return torch.cat(feats, dim=1), feats
+
+  # ------------------------------------------------------------------ dense layers
+  def dense(self, V, x, units, name, l2):
+    w = V.get(name + '/kernel', l2=l2)
+    b = V.get(name + '/bias')
+    assert w.shape == (x.shape[-1], units)
+    return x @ w + b
+
+  def batch_norm(self, V, x, name):
+    gamma, beta = V.get(name + '/gamma'), V.get(name + '/beta')
+    mm, mv = V.get(name + '/moving_mean', trainable=False), V.get(name + '/moving_variance', trainable=False)
+    axes = tuple(range(x.dim() - 1))
+    mean = x.mean(dim=axes)
+    var = ((x - mean)**2).mean(dim=axes)
+    y = (x - mean) / torch.sqrt(var + BN_EPS) * gamma + beta
+    with torch.no_grad():  # assign_moving_average, UPDATE_OPS forced before the loss (estimator :202-213)
+      self._moving[name + '/moving_mean'] = mm - (mm - mean) * (1 - BN_MOMENTUM)
+      self._moving[name + '/moving_variance'] = mv - (mv - var) * (1 - BN_MOMENTUM)
+    return y
+
+  def dice(self, V, x, name):
+    alpha = V.get('alpha_' + name)
+    mm = V.get(name + '/batch_normalization/moving_mean', trainable=False)
+    mv = V.get(name + '/batch_normalization/moving_variance', trainable=False)
+    axes = tuple(range(x.dim() - 1))
+    mean = x.mean(dim=axes)
+    var = ((x - mean)**2).mean(dim=axes)
+    p = torch.sigmoid((x - mean) / torch.sqrt(var + 1e-9))
+    with torch.no_grad():
+      self._moving[name + '/batch_normalization/moving_mean'] = mm - (mm - mean) * (1 - BN_MOMENTUM)
+      self._moving[name + '/batch_normalization/moving_variance'] = mv - (mv - var) * (1 - BN_MOMENTUM)
+    return alpha * (1.0 - p) * x + p * x
+
+  def dnn(self, V, x, dnn_cfg, name, l2, last_no_act=False, last_no_bn=False):
+    """layers/dnn.py:50-87."""
+    n = len(dnn_cfg.hidden_units)
+    for i, units in enumerate(dnn_cfg.hidden_units):
+      x = self.dense(V, x, units, '%s/dnn_%d' % (name, i), l2)
+      if dnn_cfg.use_bn and ((i + 1 < n) or not last_no_bn):
+        x = self.batch_norm(V, x, '%s/dnn_%d/bn' % (name, i))
+      if (i + 1 < n) or not last_no_act:
+        act = dnn_cfg.activation.lower()
+        if act in ('tf.nn.relu', 'relu', 'nn.relu'):
+          x = torch.relu(x)
+        elif act == 'dice':
+          x = self.dice(V, x, '%s/dnn_%d/act' % (name, i))
+        else:
+          raise NotImplementedError(act)
+      assert len(dnn_cfg.dropout_ratio) == 0 or all(r == 0 for r in dnn_cfg.dropout_ratio)
+    return x
+
+  def _l2_of(self, mc):
+    sub = getattr(mc, mc.WhichOneof('model'))
+    if hasattr(sub, 'dense_regularization') and sub.HasField('dense_regularization'):
+      return sub.dense_regularization
+    return getattr(sub, 'l2_regularization', 0.0)
+
+  # ------------------------------------------------------------------ models
+  def _deepfm(self, V, batch):
+    mc = self.cfg.model_config
+    c = mc.deepfm
+    l2 = self._l2_of(mc)
+    wide, _ = self.input_layer(V, batch, 'wide', 'input_layer', wide_dim=c.wide_output_dim)
+    deep, fm_list = self.input_layer(V, batch, 'deep', 'input_layer_1')
+    if any(g.group_name == 'fm' for g in mc.feature_groups):
+      _, fm_list = self.input_layer(V, batch, 'fm', 'input_layer_2')
+    wide_fea = wide.sum(dim=1, keepdim=True)
+    fm_feas = torch.stack(fm_list, dim=1)
+    fm_fea = 0.5 * (fm_feas.sum(dim=1)**2 - (fm_feas**2).sum(dim=1))
+    deep_fea = self.dnn(V, deep, c.dnn, 'deep_feature', l2)
+    if len(c.final_dnn.hidden_units) > 0:
+      all_fea = torch.cat([wide_fea, fm_fea, deep_fea], dim=1)
+      all_fea = self.dnn(V, all_fea, c.final_dnn, 'final_dnn', l2)
+      out = self.dense(V, all_fea, mc.num_class, 'output', l2)
+    else:
+      out = wide_fea + fm_fea.sum(dim=1, keepdim=True) + self.dense(V, deep_fea, mc.num_class, 'deep_logits', l2)
+    return {'logits': out.squeeze(1)}
+
+  def _dcn(self, V, batch):
+    mc = self.cfg.model_config
+    c = mc.dcn
+    l2 = self._l2_of(mc)
+    feats, _ = self.input_layer(V, batch, 'all', 'input_layer')
+    deep = self.dnn(V, feats, c.deep_tower.dnn, 'dnn', l2)
+    x0 = x = feats
+    for i in range(c.cross_tower.cross_num):
+      w = V.get('cross_layer_%d_w' % i)
+      b = V.get('cross_layer_%d_b' % i)
+      xw = (x * w).sum(dim=1, keepdim=True)
+      x = (x0 * xw + b) + x
+    all_fea = torch.cat([deep, x], dim=1)
+    all_fea = self.dnn(V, all_fea, c.final_dnn, 'final_dnn', l2)
+    out = self.dense(V, all_fea, mc.num_class, 'output', 0.0)  # no kernel_regularizer (dcn.py:66)
+    return {'logits': out.squeeze(1)}
+
+  # ------------------------------------------------------------------ one step
+  def forward(self, batch):
+    V = Vars(self.state, self.dtype)
+    self._reg = torch.zeros((), dtype=self.dtype)
+    self._moving = {}
+    self._touched = {}
+    self._cache = (self._hashed_ids(batch), self._raw_values(batch), self._int_ids(batch))
+    if self.model_class == 'DeepFM':
+      pred = self._deepfm(V, batch)
+    elif self.model_class == 'DCN':
+      pred = self._dcn(V, batch)
+    else:
+      raise NotImplementedError('oracle: model_class %s' % self.model_class)
+    labels = torch.as_tensor(np.asarray(batch['labels'], dtype=np.float32)[0], dtype=self.dtype)
+    z = pred['logits']
+    # tf.losses.sigmoid_cross_entropy (SUM_BY_NONZERO_WEIGHTS, weights = 1.0)
+    ce = (torch.clamp(z, min=0) - z * labels + torch.log1p(torch.exp(-torch.abs(z)))).mean()
+    reg = self._reg
+    for name, t in V.used.items():
+      if V.l2[name] > 0:
+        reg = reg + V.l2[name] * 0.5 * (t * t).sum()
+    losses = OrderedDict([('cross_entropy_loss', ce), ('regularization_loss', reg), ('total_loss', ce + reg)])
+    pred['probs'] = torch.sigmoid(z)
+    return V, pred, losses
+
+  def train_step(self, batch):
+    V, pred, losses = self.forward(batch)
+    losses['total_loss'].backward()
+    step = self.global_step
+    for name, t in V.used.items():
+      if not t.requires_grad:
+        continue
+      is_emb = name.endswith('/embedding_weights')
+      oi = 0 if (is_emb or len(self.opt) == 1) else 1
+      o = self.opt[oi]
+      g = np.zeros(t.shape, dtype=np.float32) if t.grad is None else t.grad.numpy().astype(np.float32)
+      if is_emb and self.emb_mult != 1.0:
+        g = (g * F32(self.emb_mult)).astype(np.float32)
+      lr = self._lr(o['lr_cfg'], step)
+      var = self.state[name]
+      if o['kind'] in ('adam_optimizer', 'lazy_adam_optimizer'):
+        b1, b2 = F32(o['beta1']), F32(o['beta2'])
+        b1p, b2p = self.beta_pow[oi]
+        one = F32(1.0)
+        lr_t = F32(lr * np.sqrt(one - b2p) / (one - b1p))
+        m = self.slots.setdefault(name + '/m', np.zeros_like(var))
+        v = self.slots.setdefault(name + '/v', np.zeros_like(var))
+        eps = F32(1e-8)
+        if is_emb:
+          # python-graph sparse apply (IndexedSlices): tf AdamOptimizer decays every row;
+          # AdamOptimizerS (lazy) only the rows present in the gradient.
+          if o['kind'] == 'lazy_adam_optimizer':
+            rows = self._touched.get(id(t), np.zeros(var.shape[0], dtype=bool))
+          else:
+            rows = np.ones(var.shape[0], dtype=bool)
+          m_t = m[rows] * b1 + g[rows] * (one - b1)
+          v_t = v[rows] * b2 + (g[rows] * g[rows]) * (one - b2)
+          var[rows] = var[rows] - (lr_t * m_t) / (np.sqrt(v_t, dtype=np.float32) + eps)
+          m[rows], v[rows] = m_t, v_t
+        else:
+          # training_ops.apply_adam
+          m[:] = m + (g - m) * (one - b1)
+          v[:] = v + (g * g - v) * (one - b2)
+          var[:] = var - (m * lr_t) / (np.sqrt(v, dtype=np.float32) + eps)
+      else:
+        raise NotImplementedError(o['kind'])
+    for oi, o in enumerate(self.opt):
+      if o['kind'] in ('adam_optimizer', 'lazy_adam_optimizer'):
+        self.beta_pow[oi][0] = F32(self.beta_pow[oi][0] * F32(o['beta1']))
+        self.beta_pow[oi][1] = F32(self.beta_pow[oi][1] * F32(o['beta2']))
+    for k, val in self._moving.items():
+      self.state[k] = val.numpy().astype(np.float32)
+    self.global_step += 1
+    self.last_pred = {k: v.detach().numpy() for k, v in pred.items()}
+    self.last_grads = {n: (None if t.grad is None else t.grad.numpy().copy()) for n, t in V.used.items()
+                       if t.requires_grad}
+    return {k: float(v.detach()) for k, v in losses.items()}

@@ -1,0 +1,159 @@
+"""-m gpu: the whole DeepFM training step on the MI355X (through the C ABI) against the
+independent model-level CPU oracle, plus size-independent properties at BASELINE.json's full size
+(B=4096, 26 x 1M-row tables, D=16)."""
+import logging
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from easyrec_amd import kernels  # noqa: E402
+from easyrec_amd.input.criteo_synthetic import SyntheticCriteo  # noqa: E402
+from easyrec_amd.model.easy_rec_estimator import EasyRecEstimator  # noqa: E402
+from easyrec_amd.utils import config_util  # noqa: E402
+from oracle.model_oracle import OracleTrainer  # noqa: E402
+
+logging.disable(logging.WARNING)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEV = 'cuda:0'
+
+
+def _cfg(name):
+  return config_util.get_configs_from_pipeline_file(os.path.join(ROOT, 'configs', name))
+
+
+def _compare_states(est_state, oracle_state, tol):
+  worst = ('', 0.0)
+  for k, v in oracle_state.items():
+    if k not in est_state or k.endswith('/bn/moving_mean'):
+      continue
+    if k.endswith('/bias') and (k[:-len('/bias')] + '/bn/gamma') in oracle_state:
+      continue  # d(loss)/d(bias) == 0 under BatchNorm: TF's value is rounding noise
+    d = float(np.max(np.abs(est_state[k] - v)) / (np.max(np.abs(v)) + 1e-12))
+    if d > worst[1]:
+      worst = (k, d)
+  assert worst[1] < tol, worst
+
+
+@pytest.mark.parametrize('config', ['deepfm_criteo_small.config'])
+@pytest.mark.parametrize('mode', ['zipf', 'uniform'])
+def test_train_steps_match_oracle(config, mode):
+  """logits / loss within 1e-4 relative (BASELINE.json north_star), parameters after 3 Adam steps
+  within 5e-4 of their scale."""
+  cfg = _cfg(config)
+  B = 256
+  est = EasyRecEstimator(cfg, device=DEV, batch_size=B, seed=11).build()
+  orc = OracleTrainer(cfg, est.state_dict(), batch_size=B)
+  gen = SyntheticCriteo(cfg.data_config, est.feature_configs, batch_size=B, mode=mode)
+  for step in range(3):
+    b = gen.next_batch()
+    est.train_step(b)
+    got, exp = est.loss_values(), orc.train_step(b)
+    for k in exp:
+      assert abs(got[k] - exp[k]) <= 1e-4 * max(1e-3, abs(exp[k])), (step, k, got[k], exp[k])
+    logits = est.model._prediction_dict['logits'].detach().cpu().numpy()
+    assert np.allclose(logits, orc.last_pred['logits'], rtol=1e-4, atol=1e-5), step
+  est.varstore.check_grad_views()
+  _compare_states(est.state_dict(), orc.state, 5e-4)
+
+
+def test_lazy_adam_matches_oracle():
+  cfg = _cfg('deepfm_criteo_small.config')
+  oc = cfg.train_config.optimizer_config[0]
+  lr = oc.adam_optimizer.learning_rate
+  oc.lazy_adam_optimizer.learning_rate.CopyFrom(lr)
+  assert oc.WhichOneof('optimizer') == 'lazy_adam_optimizer'
+  B = 128
+  est = EasyRecEstimator(cfg, device=DEV, batch_size=B, seed=5).build()
+  orc = OracleTrainer(cfg, est.state_dict(), batch_size=B)
+  gen = SyntheticCriteo(cfg.data_config, est.feature_configs, batch_size=B)
+  for step in range(3):
+    b = gen.next_batch()
+    est.train_step(b)
+    got, exp = est.loss_values(), orc.train_step(b)
+    assert abs(got['total_loss'] - exp['total_loss']) <= 1e-4 * abs(exp['total_loss'])
+  _compare_states(est.state_dict(), orc.state, 5e-4)
+
+
+def test_graph_replay_equals_eager():
+  """The captured hipGraph step must produce the same parameters as eager launches."""
+  cfg = _cfg('deepfm_criteo_small.config')
+  B = 256
+  gen = SyntheticCriteo(cfg.data_config, list(cfg.feature_config.features), batch_size=B)
+  batches = [gen.next_batch() for _ in range(6)]
+  a = EasyRecEstimator(cfg, device=DEV, batch_size=B, seed=2).build()
+  b = EasyRecEstimator(cfg, device=DEV, batch_size=B, seed=2).build()
+  b.load_state_dict(a.state_dict())
+  # warm both identically: capture() runs `warmup` eager steps on the batch currently loaded
+  a.features.load(batches[0])
+  b.features.load(batches[0])
+  for _ in range(3):
+    a.train_step()
+  b.capture(warmup=3)
+  for bt in batches[1:]:
+    a.train_step(bt)
+    b.train_step(bt)
+    la, lb = a.loss_values(), b.loss_values()
+    assert abs(la['total_loss'] - lb['total_loss']) <= 1e-6 * abs(la['total_loss']), (la, lb)
+  sa, sb = a.state_dict(), b.state_dict()
+  for k in sa:
+    assert np.allclose(sa[k], sb[k], rtol=1e-6, atol=1e-8), k
+
+
+def test_full_size_properties():
+  """BASELINE.json config 2 at full size: B=4096, 26 x (1M x 16) + 26 x (1M x 1) tables, TF-exact Adam.
+  Size-independent checks: (a) the fused lookup equals a plain torch gather of the hashed ids;
+  (b) ids on device == FarmHash oracle for a sample; (c) after one dense-decay Adam step with zero
+  initial moments, rows not touched by the batch are bit-identical, touched rows moved, and the
+  touched-row bitmap is clean again; (d) a second step keeps everything finite."""
+  cfg = _cfg('deepfm_criteo.config')
+  B = 4096
+  est = EasyRecEstimator(cfg, device=DEV, batch_size=B, seed=1).build()
+  gen = SyntheticCriteo(cfg.data_config, est.feature_configs, batch_size=B, mode='uniform')
+  batch = gen.next_batch()
+  var16_before = est.engine.storage[16]['var'].clone()
+  est.features.load(batch)
+  est.features.transform()
+  torch.cuda.synchronize()
+  ids = est.features.hash_ids.clone()  # [26, B]
+  # (b) device hash vs oracle on the first 64 strings of 3 columns
+  from oracle import hashing
+  raw, offs = batch['str_bytes'].tobytes(), batch['str_offsets']
+  for col in (0, 7, 25):
+    for i in range(64):
+      j = col * B + i
+      s = raw[int(offs[j]):int(offs[j + 1])]
+      exp = -1 if len(s) == 0 else hashing.fingerprint64(s) % 1000000
+      assert int(ids[col, i]) == exp
+  est.train_step()
+  torch.cuda.synchronize()
+  # (a) deep group output block of C1 (column 13*16) == gather of table rows (missing -> 0)
+  out = est.engine.groups['group:deep']['out']
+  t = est.engine.tables['input_layer_1/C1_embedding/embedding_weights']
+  rows = var16_before[t['key_base']:t['key_base'] + t['rows']]
+  idc = ids[0]
+  exp = rows[idc.clamp(min=0)] * (idc >= 0).float()[:, None]
+  assert torch.equal(out[:, 13 * 16:14 * 16], exp)
+  # (c) untouched rows unchanged, touched rows moved, bitmap clean
+  after = est.engine.storage[16]['var']
+  touched = torch.zeros(after.shape[0], dtype=torch.bool, device=DEV)
+  names = [n for n in est.schema.hash_single]
+  for c, n in enumerate(names):
+    tb = est.engine.tables['input_layer_1/%s_embedding/embedding_weights' % n]
+    v = ids[c][ids[c] >= 0] + tb['key_base']
+    touched[v] = True
+  for i in range(13):  # the 13 one-row projection tables are touched by every example
+    touched[est.engine.tables['input_layer_1/F%d_weighted_by_F%d_raw_proj_val_embedding/embedding_weights' %
+                              (i + 1, i + 1)]['key_base']] = True
+  assert torch.equal(after[~touched], var16_before[~touched])
+  moved = (after[touched] != var16_before[touched]).any(dim=1).float().mean()
+  assert float(moved) > 0.99
+  assert int(est.engine.storage[16]['bitmap'].abs().sum()) == 0
+  # (d)
+  est.train_step(gen.next_batch())
+  lv = est.loss_values()
+  assert all(np.isfinite(v) for v in lv.values()), lv
+  assert torch.isfinite(est.engine.storage[16]['var']).all()

@@ -1,0 +1,113 @@
+"""Host logic on CPU: the package's models/estimator driven through the per-kernel CPU oracle
+(monkeypatched backend) must reproduce the independent model-level oracle.  This checks the HOST
+code (plan building, variable naming, loss assembly, optimizer scalars) - the kernels are checked by
+the -m gpu tests."""
+import logging
+import os
+
+import numpy as np
+import pytest
+
+from easyrec_amd.builders import optimizer_builder
+from easyrec_amd.utils import config_util
+
+logging.disable(logging.WARNING)
+BN_BIAS = '/bias'  # biases followed by BatchNorm have an identically-zero gradient
+
+
+def _compare_states(est_state, oracle_state, skip_bn_bias=True, tol=3e-4):
+  worst = ('', 0.0)
+  for k, v in oracle_state.items():
+    if k not in est_state:
+      continue
+    if skip_bn_bias and k.endswith(BN_BIAS) and (k[:-len('/bias')] + '/bn/gamma') in oracle_state:
+      continue
+    a, b = est_state[k], v
+    if k.endswith('/bn/moving_mean'):
+      # the moving mean tracks mean(x @ W + bias): compare it net of the (noise-driven) bias
+      bias = k[:-len('/bn/moving_mean')] + '/bias'
+      a, b = a - 0.01 * est_state[bias], b - 0.01 * oracle_state[bias]
+      continue
+    d = float(np.max(np.abs(a - b)) / (np.max(np.abs(b)) + 1e-12))
+    if d > worst[1]:
+      worst = (k, d)
+  assert worst[1] < tol, worst
+
+
+@pytest.mark.parametrize('config', ['deepfm_criteo_small.config'])
+def test_estimator_matches_model_oracle(ref_backend, config):
+  from easyrec_amd.input.criteo_synthetic import SyntheticCriteo
+  from easyrec_amd.model.easy_rec_estimator import EasyRecEstimator
+  from oracle.model_oracle import OracleTrainer
+  cfg = config_util.get_configs_from_pipeline_file(os.path.join('configs', config))
+  B = 48
+  est = EasyRecEstimator(cfg, device='cpu', batch_size=B, seed=3).build()
+  orc = OracleTrainer(cfg, est.state_dict(), batch_size=B)
+  gen = SyntheticCriteo(cfg.data_config, est.feature_configs, batch_size=B)
+  for _ in range(3):
+    b = gen.next_batch()
+    est.train_step(b)
+    got, exp = est.loss_values(), orc.train_step(b)
+    for k in exp:
+      assert abs(got[k] - exp[k]) <= 1e-5 * max(1.0, abs(exp[k])), (k, got[k], exp[k])
+  est.varstore.check_grad_views()
+  _compare_states(est.state_dict(), orc.state)
+
+
+def test_variable_names_follow_tf_scopes(ref_backend):
+  from easyrec_amd.model.easy_rec_estimator import EasyRecEstimator
+  cfg = config_util.get_configs_from_pipeline_file('configs/deepfm_criteo_small.config')
+  est = EasyRecEstimator(cfg, device='cpu', batch_size=8).build()
+  names = set(est.state_dict())
+  for n in ('input_layer/C1_embedding/embedding_weights',  # wide group is called first
+            'input_layer_1/C1_embedding/embedding_weights',
+            'input_layer_1/F1_weighted_by_F1_raw_proj_val_embedding/embedding_weights',
+            'deep_feature/dnn_0/kernel', 'deep_feature/dnn_0/bn/moving_variance', 'final_dnn/dnn_2/bias',
+            'output/kernel'):
+    assert n in names, n
+  assert est.engine.tables['input_layer/C1_embedding/embedding_weights']['dim'] == 1
+  assert est.engine.tables['input_layer_1/C1_embedding/embedding_weights']['dim'] == 16
+  # dense_regularization (deprecated alias) is the kernels' L2, biases carry none
+  assert est.varstore.l2_of('deep_feature/dnn_0/kernel') == pytest.approx(1e-5)
+  assert est.varstore.l2_of('deep_feature/dnn_0/bias') == 0.0
+
+
+def test_adam_scalars_follow_tf():
+  cfg = config_util.get_configs_from_pipeline_file('configs/deepfm_criteo.config')
+  st = optimizer_builder.build(cfg.train_config.optimizer_config[0])
+  row = st.hyper_row(0)
+  f = np.float32
+  assert row[0] == f(0.001)
+  assert row[1] == f(0.001) * np.sqrt(f(1) - f(0.999)) / (f(1) - f(0.9))
+  for _ in range(1000):
+    st.finish_step()
+  assert st.hyper_row(999)[0] == f(0.001) and st.hyper_row(1000)[0] == f(0.0005)
+  assert st.hyper_row(10**6)[0] == f(1e-5)  # min_learning_rate
+
+
+def test_csv_input_roundtrip(tmp_path, built_lib):
+  from easyrec_amd.input.csv_input import CSVInput
+  cfg = config_util.get_configs_from_pipeline_file('configs/deepfm_criteo_small.config')
+  rows = []
+  rng = np.random.default_rng(0)
+  for i in range(4):
+    f = ['%d' % rng.integers(0, 50) if rng.random() > 0.2 else '' for _ in range(13)]
+    c = ['%08x' % rng.integers(0, 2**32) if rng.random() > 0.2 else '' for _ in range(26)]
+    rows.append('\t'.join(['%d' % (i % 2)] + f + c))
+  p = tmp_path / 'data.tsv'
+  p.write_text('\n'.join(rows) + '\n')
+  feats = list(cfg.feature_config.features)
+  inp = CSVInput(cfg.data_config, feats, str(p), batch_size=4, hash_on_host=True)
+  batch = next(inp.batches())
+  assert batch['labels'].tolist() == [[0.0, 1.0, 0.0, 1.0]]
+  assert batch['raw'].shape == (13, 4) and batch['hash_ids'].shape == (26, 4)
+  # '' -> dropped (-1); non-empty -> FarmHash bucket
+  from oracle import hashing
+  first = rows[0].split('\t')
+  for j in range(26):
+    s = first[14 + j]
+    exp = -1 if s == '' else hashing.fingerprint64(s) % 1000
+    assert batch['hash_ids'][j, 0] == exp
+  # F2: (x - (-3)) / (257675 + 3) in fp32; '' -> default 0
+  x = np.float32(float(first[2]) if first[2] else 0.0)
+  assert batch['raw'][1, 0] == (x - np.float32(-3.0)) / np.float32(257678.0)

@@ -1,0 +1,450 @@
+"""-m gpu: every HIP kernel, called through the C ABI (easyrec_amd.kernels.HipBackend -> ctypes ->
+libeasyrec_hip.so), against the CPU oracle (oracle/kernel_ref.py) on the same seeded inputs.
+
+Bars: bit-exact for integer/id work (hashing) and for the embedding forward (pure copies and fp32
+sums in a defined order); fp32 tolerances (stated per test) where the summation order differs.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from easyrec_amd import kernels  # noqa: E402
+from oracle import hashing, kernel_ref  # noqa: E402
+
+DEV = 'cuda:0'
+
+
+@pytest.fixture(scope='module')
+def hip():
+  assert torch.cuda.is_available(), 'gpu tests need an MI355X'
+  return kernels.hip()
+
+
+@pytest.fixture(scope='module')
+def ref():
+  return kernel_ref.RefBackend()
+
+
+def _hyper(lr=1e-3, t=1, b1=0.9, b2=0.999, gscale=1.0):
+  f = np.float32
+  row = np.zeros(kernels.HYPER_FLOATS, dtype=np.float32)
+  row[0] = f(lr)
+  row[1] = f(lr) * np.sqrt(f(1) - f(b2)**t) / (f(1) - f(b1)**t)
+  row[2], row[3], row[4], row[5], row[6], row[7] = f(b1), f(b2), f(1) - f(b1), f(1) - f(b2), f(1e-8), f(gscale)
+  return torch.from_numpy(row)
+
+
+# ------------------------------------------------------------------------------------------- K1
+def _random_strings(rng, n, maxlen):
+  return [bytes(rng.integers(0, 256, size=int(rng.integers(0, maxlen + 1)), dtype=np.uint8)) for _ in range(n)]
+
+
+def test_hash_device_bit_exact(hip):
+  from easyrec_amd.input.input import pack_strings
+  rng = np.random.default_rng(0)
+  strs = _random_strings(rng, 4000, 16) + _random_strings(rng, 2000, 300) + [b'', b'a', b'Hello', b'x' * 64,
+                                                                             b'y' * 65, b'z' * 129]
+  n = len(strs) // 3 * 3
+  strs = strs[:n]
+  data, offs = pack_strings(strs)
+  nb = np.array([1000000, 3, 2**40 + 7], dtype=np.uint64)
+  for drop in (0, 1):
+    exp = hashing.hash_bucket_fast(data, offs, n // 3, nb, drop)
+    got = hip.hash_bucket_fast(torch.from_numpy(data).to(DEV), torch.from_numpy(offs).to(DEV), n // 3,
+                               torch.from_numpy(nb.astype(np.int64)).to(DEV), drop).cpu().numpy()
+    assert np.array_equal(got, exp)
+
+
+def test_hash_tf_vectors_on_device(hip):
+  from easyrec_amd.input.input import pack_strings
+  data, offs = pack_strings([b'a', b'b', b'c', b'd'])
+  nb = torch.tensor([10], dtype=torch.int64, device=DEV)
+  got = hip.hash_bucket_fast(torch.from_numpy(data).to(DEV), torch.from_numpy(offs).to(DEV), 4, nb, 0)
+  assert got.cpu().tolist() == [9, 2, 2, 5]
+
+
+def test_hash_int64_as_string(hip):
+  vals = np.array([0, 7, -1, 123456789, -987654321, 2**62, -2**63 + 1, 42] * 4, dtype=np.int64)
+  nb = np.array([1000003], dtype=np.uint64)
+  got = hip.hash_bucket_fast_int64(torch.from_numpy(vals).to(DEV), len(vals),
+                                   torch.from_numpy(nb.astype(np.int64)).to(DEV)).cpu().numpy()
+  exp = np.array([hashing.fingerprint64(str(int(v))) % 1000003 for v in vals])
+  assert np.array_equal(got, exp)
+
+
+# ------------------------------------------------------------------------------------------- K2-K4
+def _make_lookup_problem(rng, B, dims, device, ragged=True):
+  """A model-like mix: dense single-id lookups (with missing ids), weighted dense, ragged
+  sum/mean/sqrtn with and without weights, different dims, a shared table."""
+  specs_cpu, specs_dev, tables = [], [], {}
+  outs = {}
+
+  def table(dim, rows):
+    key = (dim, len([k for k in tables if k[0] == dim]))
+    t = (rng.standard_normal((rows, dim)) * 0.1).astype(np.float32)
+    tables[key] = t
+    return key
+
+  layout = []
+  for dim in dims:
+    layout.append((dim, 'dense', None))
+    layout.append((dim, 'dense_w', None))
+    if ragged:
+      layout.append((dim, 'ragged', 'sum'))
+      layout.append((dim, 'ragged_w', 'mean'))
+      layout.append((dim, 'ragged_w', 'sqrtn'))
+      layout.append((dim, 'ragged', 'mean'))
+  width = sum(d for d, _, _ in layout)
+  out_cpu = torch.zeros(B, width)
+  out_dev = torch.zeros(B, width, device=device)
+  # tables of one dim back to back
+  group_rows = {}
+  metas = []
+  col = 0
+  for (dim, kind, comb) in layout:
+    rows = int(rng.integers(5, 60))
+    base = group_rows.get(dim, 0)
+    group_rows[dim] = base + rows
+    metas.append((dim, kind, comb, rows, base, col))
+    col += dim
+  storage_cpu = {d: torch.from_numpy((rng.standard_normal((n, d)) * 0.1).astype(np.float32))
+                 for d, n in group_rows.items()}
+  storage_dev = {d: t.to(device) for d, t in storage_cpu.items()}
+  for (dim, kind, comb, rows, base, col) in metas:
+    if kind.startswith('dense'):
+      ids = rng.integers(-1, rows, size=B).astype(np.int64)  # -1 = missing
+      ids[rng.random(B) < 0.1] = rows + 3  # out of range -> pruned
+      offsets, w = None, None
+      if kind == 'dense_w':
+        w = rng.standard_normal(B).astype(np.float32)
+      n_rows, max_nnz, combiner = B, B, 0
+    else:
+      lens = rng.integers(0, 5, size=B)
+      lens[rng.random(B) < 0.2] = 0
+      offsets = np.zeros(B + 1, dtype=np.int32)
+      offsets[1:] = np.cumsum(lens)
+      nnz = int(offsets[-1])
+      cap = nnz + 7
+      ids = np.full(cap, -1, dtype=np.int64)
+      ids[:nnz] = rng.integers(-1, rows, size=nnz)
+      w = None
+      if kind == 'ragged_w':
+        w = np.zeros(cap, dtype=np.float32)
+        w[:nnz] = rng.standard_normal(nnz).astype(np.float32)  # negatives get pruned for mean/sqrtn
+      n_rows, max_nnz, combiner = B, cap, kernels.COMBINERS[comb]
+    for store, out, lst, dv in ((storage_cpu, out_cpu, specs_cpu, 'cpu'), (storage_dev, out_dev, specs_dev, device)):
+      lst.append(
+          kernels.LookupSpec(
+              table=store[dim][base:base + rows], ids=torch.from_numpy(ids).to(dv),
+              offsets=None if offsets is None else torch.from_numpy(offsets).to(dv),
+              weights=None if w is None else torch.from_numpy(w).to(dv), out=out, out_col=col, rows=rows,
+              key_base=base, dim=dim, combiner=combiner, n_rows=n_rows, max_nnz=max_nnz))
+  return specs_cpu, specs_dev, storage_cpu, storage_dev, out_cpu, out_dev, group_rows
+
+
+@pytest.mark.parametrize('B,dims', [(257, (16, 1)), (64, (4, 8, 64, 3)), (1, (16,)), (1000, (32, 2))])
+def test_emb_fwd_bit_exact(hip, ref, B, dims):
+  rng = np.random.default_rng(B)
+  sc, sd, _, _, oc, od, _ = _make_lookup_problem(rng, B, dims, DEV)
+  pc, pd = ref.emb_plan_create(sc), hip.emb_plan_create(sd)
+  assert pc['num_blocks'] == pd['num_blocks']
+  ssq_c = torch.zeros(pc['num_blocks'])
+  ssq_d = torch.zeros(pd['num_blocks'], device=DEV)
+  # the oracle's lookup_rows (sequential, op by op) is the bit-exact reference
+  for s in sc:
+    res = kernel_ref.lookup_rows(s.table.numpy(), s.ids.numpy(), None if s.offsets is None else s.offsets.numpy(),
+                                 None if s.weights is None else s.weights.numpy(), s.combiner, s.n_rows)
+    oc[:, s.out_col:s.out_col + s.dim] = torch.from_numpy(res)
+  hip.emb_fwd(pd, ssq_d)
+  torch.cuda.synchronize()
+  assert torch.equal(od.cpu(), oc), 'embedding forward must be bit-exact'
+  ref.emb_fwd(pc, ssq_c)
+  assert torch.allclose(ssq_d.cpu().sum(), ssq_c.sum(), rtol=1e-5)
+  hip.emb_plan_destroy(pd)
+
+
+@pytest.mark.parametrize('opt', [kernels.OPT_SGD, kernels.OPT_ADAM, kernels.OPT_LAZY_ADAM, kernels.OPT_ADAGRAD])
+@pytest.mark.parametrize('B,dims', [(300, (16, 1)), (50, (8, 3))])
+def test_emb_bwd_update(hip, ref, opt, B, dims):
+  """sort + segmented reduce + row-wise optimizer (+ dense-decay sweep for ER_OPT_ADAM).
+  Runs that fit one 32-entry chunk are summed in source order (bit-exact vs the oracle); longer
+  runs are combined piece-wise -> 1e-6 relative."""
+  rng = np.random.default_rng(B + opt)
+  sc, sd, stc, std, oc, od, group_rows = _make_lookup_problem(rng, B, dims, DEV)
+  dout = (rng.standard_normal(tuple(oc.shape)) * 0.01).astype(np.float32)
+  dc, dd = torch.from_numpy(dout), torch.from_numpy(dout).to(DEV)
+  hyper = _hyper(lr=0.05, t=3, gscale=0.5)
+  for dim, total in group_rows.items():
+    mc = torch.from_numpy((rng.random((total, dim)) * 0.01).astype(np.float32))
+    vc = torch.from_numpy((rng.random((total, dim)) * 0.01 + 1e-4).astype(np.float32))
+    md, vd = mc.to(DEV), vc.to(DEV)
+    var_c, var_d = stc[dim], std[dim]
+    bitmap = torch.zeros((total + 31) // 32, dtype=torch.int32, device=DEV)
+    gc = ref.emb_group_create([s.with_out(dc) for s in sc if s.dim == dim], dim, total, var_c, mc, vc, None)
+    gd = hip.emb_group_create([s.with_out(dd) for s in sd if s.dim == dim], dim, total, var_d, md, vd, bitmap)
+    assert gd['num_entries'] == gc['num_entries']
+    for _ in range(2):  # twice: the bitmap must come back clean
+      ref.emb_bwd_update(gc, opt, hyper)
+      hip.emb_bwd_update(gd, opt, hyper.to(DEV))
+    torch.cuda.synchronize()
+    assert int(bitmap.abs().sum()) == 0
+    for a, b, what in ((var_d, var_c, 'var'), (md, mc, 'm'), (vd, vc, 'v')):
+      assert torch.allclose(a.cpu(), b, rtol=1e-5, atol=1e-8), (what, dim, opt, float((a.cpu() - b).abs().max()))
+    hip.emb_group_destroy(gd)
+
+
+def test_emb_bwd_long_runs_and_reduce(hip, ref):
+  """Hot ids: runs of thousands of equal keys cross many 32-entry chunks."""
+  rng = np.random.default_rng(5)
+  B, dim, rows = 5000, 16, 7
+  ids = rng.integers(0, rows, size=B).astype(np.int64)
+  ids[:3000] = 2  # one very hot row
+  table = torch.from_numpy(rng.standard_normal((rows, dim)).astype(np.float32))
+  dout = torch.from_numpy((rng.standard_normal((B, dim)) * 0.01).astype(np.float32))
+
+  def spec(dev):
+    return kernels.LookupSpec(table=table.to(dev), ids=torch.from_numpy(ids).to(dev), offsets=None, weights=None,
+                              out=dout.to(dev), out_col=0, rows=rows, key_base=0, dim=dim, combiner=0, n_rows=B,
+                              max_nnz=B)
+
+  gd = hip.emb_group_create([spec(DEV)], dim, rows, table.to(DEV), None, None, None)
+  keys, grads, n = hip.emb_bwd_reduce(gd)
+  torch.cuda.synchronize()
+  n = int(n.item())
+  assert n == len(np.unique(ids))
+  exp = np.zeros((rows, dim), dtype=np.float64)
+  np.add.at(exp, ids, dout.numpy().astype(np.float64))
+  got_keys = keys[:n].cpu().numpy()
+  assert np.array_equal(got_keys, np.unique(ids))
+  assert np.allclose(grads[:n].cpu().numpy(), exp[got_keys], rtol=1e-5, atol=1e-7)
+  # determinism: same bits on a second run
+  keys2, grads2, _ = hip.emb_bwd_reduce(gd)
+  torch.cuda.synchronize()
+  assert torch.equal(grads[:n], grads2[:n])
+  hip.emb_group_destroy(gd)
+
+
+@pytest.mark.parametrize('dim,rows', [(16, 100003), (1, 50001), (3, 1001), (64, 4097)])
+def test_adam_decay_sweep_bit_exact(hip, ref, dim, rows):
+  rng = np.random.default_rng(dim)
+  var = torch.from_numpy(rng.standard_normal((rows, dim)).astype(np.float32))
+  m = torch.from_numpy((rng.standard_normal((rows, dim)) * 0.01).astype(np.float32))
+  v = torch.from_numpy((rng.random((rows, dim)) * 0.01).astype(np.float32))
+  bits = rng.integers(0, 2**31, size=(rows + 31) // 32).astype(np.int32)
+  hyper = _hyper(t=5)
+  vd, md, sd = var.to(DEV), m.to(DEV), v.to(DEV)
+  hip.adam_decay_sweep(vd, md, sd, torch.from_numpy(bits).to(DEV), rows, dim, hyper.to(DEV))
+  ref.adam_decay_sweep(var, m, v, torch.from_numpy(bits), rows, dim, hyper)
+  torch.cuda.synchronize()
+  assert torch.equal(md.cpu(), m) and torch.equal(sd.cpu(), v)
+  assert torch.equal(vd.cpu(), var)
+
+
+# ------------------------------------------------------------------------------------------- K5
+@pytest.mark.parametrize('B,F,D', [(513, 39, 16), (7, 3, 5), (64, 8, 64)])
+def test_fm_and_rowsum(hip, ref, B, F, D):
+  rng = np.random.default_rng(F)
+  x = torch.from_numpy(rng.standard_normal((B, F * D)).astype(np.float32))
+  g = torch.from_numpy(rng.standard_normal((B, D)).astype(np.float32))
+  fm_d, S_d = hip.fm_fwd(x.to(DEV), F, D)
+  fm_c, S_c = ref.fm_fwd(x, F, D)
+  assert torch.allclose(fm_d.cpu(), fm_c, rtol=1e-5, atol=1e-5)
+  assert torch.allclose(S_d.cpu(), S_c, rtol=1e-5, atol=1e-6)
+  dx_d = hip.fm_bwd(x.to(DEV), S_d, g.to(DEV), F, D)
+  dx_c = ref.fm_bwd(x, S_c, g, F, D)
+  assert torch.allclose(dx_d.cpu(), dx_c, rtol=1e-5, atol=1e-5)
+  rs = hip.rowsum_fwd(x.to(DEV), F * D)
+  assert torch.allclose(rs.cpu(), x.sum(dim=1, keepdim=True), rtol=1e-5, atol=1e-5)
+  gb = hip.rowsum_bwd(g[:, :1].contiguous().to(DEV), 9)
+  assert torch.equal(gb.cpu(), g[:, :1].expand(-1, 9))
+
+
+def test_axpy2d_strided(hip):
+  x = torch.randn(33, 20)
+  y = torch.randn(33, 50)
+  yd = y.to(DEV)
+  hip.axpy2d(x.to(DEV), 0.5, yd[:, 7:27], accumulate=True)
+  y[:, 7:27] += 0.5 * x
+  assert torch.allclose(yd.cpu(), y, rtol=1e-6, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------- K6/K7
+@pytest.mark.parametrize('B,d,L', [(130, 624, 3), (5, 17, 1), (64, 1000, 5)])
+def test_cross_v1(hip, ref, B, d, L):
+  rng = np.random.default_rng(d)
+  x0 = torch.from_numpy((rng.standard_normal((B, d)) * 0.3).astype(np.float32))
+  w = torch.from_numpy((rng.standard_normal((L, d)) * 0.05).astype(np.float32))
+  b = torch.from_numpy((rng.standard_normal((L, d)) * 0.05).astype(np.float32))
+  dout = torch.from_numpy(rng.standard_normal((B, d)).astype(np.float32))
+  out_d, dots_d = hip.cross_v1_fwd(x0.to(DEV), w.to(DEV), b.to(DEV))
+  out_c, dots_c = ref.cross_v1_fwd(x0, w, b)
+  assert torch.allclose(out_d.cpu(), out_c, rtol=1e-4, atol=1e-5)
+  dx0_d, dw_d, db_d = hip.cross_v1_bwd(x0.to(DEV), w.to(DEV), b.to(DEV), dots_d, dout.to(DEV))
+  dx0_c, dw_c, db_c = ref.cross_v1_bwd(x0, w, b, dots_c, dout)
+  assert torch.allclose(dx0_d.cpu(), dx0_c, rtol=1e-3, atol=1e-4)
+  assert torch.allclose(dw_d.cpu(), dw_c, rtol=1e-3, atol=1e-3)
+  assert torch.allclose(db_d.cpu(), db_c, rtol=1e-3, atol=1e-3)
+
+
+def test_cross_v2_epilogue(hip, ref):
+  B, d = 77, 130
+  x0, x, u = torch.randn(B, d), torch.randn(B, d), torch.randn(B, d)
+  bias, dout = torch.randn(d), torch.randn(B, d)
+  for diag in (0.0, 0.3):
+    o_d = hip.cross_v2_fwd(x0.to(DEV), x.to(DEV), u.to(DEV), bias.to(DEV), diag)
+    assert torch.allclose(o_d.cpu(), ref.cross_v2_fwd(x0, x, u, bias, diag), rtol=1e-5, atol=1e-5)
+    got = hip.cross_v2_bwd(x0.to(DEV), x.to(DEV), u.to(DEV), bias.to(DEV), diag, dout.to(DEV))
+    exp = ref.cross_v2_bwd(x0, x, u, bias, diag, dout)
+    for a, e in zip(got, exp):
+      assert torch.allclose(a.cpu(), e, rtol=1e-5, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------- K8
+@pytest.mark.parametrize('B,L,E', [(33, 50, 32), (4, 70, 8), (9, 1, 16)])
+def test_din(hip, ref, B, L, E):
+  rng = np.random.default_rng(L)
+  q = torch.from_numpy(rng.standard_normal((B, E)).astype(np.float32))
+  h = torch.from_numpy(rng.standard_normal((B, L, E)).astype(np.float32))
+  lens = torch.from_numpy(rng.integers(1, L + 1, size=B).astype(np.int32))
+  c_d = hip.din_concat_fwd(q.to(DEV), h.to(DEV))
+  assert torch.equal(c_d.cpu(), ref.din_concat_fwd(q, h))
+  dout = torch.from_numpy(rng.standard_normal((B, L, 4 * E)).astype(np.float32))
+  dq_d, dh_d = hip.din_concat_bwd(q.to(DEV), h.to(DEV), dout.to(DEV))
+  dq_c, dh_c = ref.din_concat_bwd(q, h, dout)
+  assert torch.allclose(dq_d.cpu(), dq_c, rtol=1e-4, atol=1e-4) and torch.allclose(dh_d.cpu(), dh_c, rtol=1e-5, atol=1e-5)
+  scores = torch.from_numpy(rng.standard_normal((B, L)).astype(np.float32))
+  o_d, p_d = hip.din_pool_fwd(scores.to(DEV), h.to(DEV), lens.to(DEV))
+  o_c, p_c = ref.din_pool_fwd(scores, h, lens)
+  assert torch.allclose(p_d.cpu(), p_c, rtol=1e-5, atol=1e-6) and torch.allclose(o_d.cpu(), o_c, rtol=1e-4, atol=1e-5)
+  go = torch.from_numpy(rng.standard_normal((B, E)).astype(np.float32))
+  ds_d, dhh_d = hip.din_pool_bwd(p_d, h.to(DEV), lens.to(DEV), go.to(DEV))
+  ds_c, dhh_c = ref.din_pool_bwd(p_c, h, lens, go)
+  assert torch.allclose(ds_d.cpu(), ds_c, rtol=1e-4, atol=1e-5) and torch.allclose(dhh_d.cpu(), dhh_c, rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------- K9
+@pytest.mark.parametrize('B,N', [(4096, 256), (37, 5), (300, 64), (2, 1)])
+@pytest.mark.parametrize('use_bn,act', [(1, 1), (1, 0), (0, 1)])
+def test_bn_act(hip, ref, B, N, use_bn, act):
+  rng = np.random.default_rng(B + N)
+  x = torch.from_numpy((rng.standard_normal((B, N)) * 2 + 0.5).astype(np.float32))
+  bias = torch.from_numpy(rng.standard_normal(N).astype(np.float32))
+  gamma = torch.from_numpy((rng.random(N) + 0.5).astype(np.float32))
+  beta = torch.from_numpy(rng.standard_normal(N).astype(np.float32))
+  mm_c, mv_c = torch.zeros(N), torch.ones(N)
+  mm_d, mv_d = mm_c.to(DEV), mv_c.to(DEV)
+  dy = torch.from_numpy(rng.standard_normal((B, N)).astype(np.float32))
+  y_d, mean_d, inv_d = hip.bn_act_fwd(x.to(DEV), bias.to(DEV), gamma.to(DEV), beta.to(DEV), use_bn, 1e-3, 0.99, mm_d,
+                                      mv_d, act)
+  y_c, mean_c, inv_c = ref.bn_act_fwd(x, bias, gamma, beta, use_bn, 1e-3, 0.99, mm_c, mv_c, act)
+  assert torch.allclose(y_d.cpu(), y_c, rtol=1e-4, atol=2e-5)
+  if use_bn:
+    assert torch.allclose(mean_d.cpu(), mean_c, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(mm_d.cpu(), mm_c, rtol=1e-5, atol=1e-7) and torch.allclose(mv_d.cpu(), mv_c, rtol=1e-5)
+  got = hip.bn_act_bwd(x.to(DEV), bias.to(DEV), gamma.to(DEV), y_d, mean_d, inv_d, dy.to(DEV), use_bn, act, True,
+                       bool(use_bn))
+  exp = ref.bn_act_bwd(x, bias, gamma, y_c, mean_c, inv_c, dy, use_bn, act, True, bool(use_bn))
+  for a, e, tol in zip(got, exp, (1e-3, 1e-3, 1e-3, 1e-3)):
+    if e is None:
+      continue
+    scale = float(e.abs().max()) + 1e-6
+    assert float((a.cpu() - e).abs().max()) <= tol * scale + 1e-5, (B, N, use_bn, act)
+
+
+def test_bn_matches_autograd_of_the_formula(hip):
+  """independent check of the hand-written BN backward: torch autograd through the textbook formula."""
+  B, N = 512, 48
+  x = torch.randn(B, N, dtype=torch.float64, requires_grad=True)
+  gamma = (torch.rand(N, dtype=torch.float64) + 0.5).requires_grad_(True)
+  beta = torch.randn(N, dtype=torch.float64, requires_grad=True)
+  mean = x.mean(0)
+  var = ((x - mean)**2).mean(0)
+  y = torch.relu((x - mean) / torch.sqrt(var + 1e-3) * gamma + beta)
+  dy = torch.randn(B, N, dtype=torch.float64)
+  y.backward(dy)
+  xf, gf, bf = x.detach().float().to(DEV), gamma.detach().float().to(DEV), beta.detach().float().to(DEV)
+  y_d, mean_d, inv_d = hip.bn_act_fwd(xf, None, gf, bf, 1, 1e-3, 0.99, None, None, 1)
+  dx, _, dg, db = hip.bn_act_bwd(xf, None, gf, y_d, mean_d, inv_d, dy.float().to(DEV), 1, 1, False, True)
+  assert torch.allclose(dx.cpu().double(), x.grad, rtol=1e-3, atol=1e-4)
+  assert torch.allclose(dg.cpu().double(), gamma.grad, rtol=1e-3, atol=1e-3)
+  assert torch.allclose(db.cpu().double(), beta.grad, rtol=1e-3, atol=1e-3)
+
+
+def test_dice_matches_autograd(hip):
+  B, N = 600, 20
+  x = torch.randn(B, N, dtype=torch.float64, requires_grad=True)
+  alpha = (torch.randn(N, dtype=torch.float64) * 0.3).requires_grad_(True)
+  mean = x.mean(0)
+  var = ((x - mean)**2).mean(0)
+  p = torch.sigmoid((x - mean) / torch.sqrt(var + 1e-9))
+  y = alpha * (1 - p) * x + p * x
+  dy = torch.randn(B, N, dtype=torch.float64)
+  y.backward(dy)
+  xf, af = x.detach().float().to(DEV), alpha.detach().float().to(DEV)
+  y_d, mean_d, inv_d = hip.dice_fwd(xf, af, 1e-9, 0.99, None, None)
+  assert torch.allclose(y_d.cpu().double(), y.detach(), rtol=1e-4, atol=1e-5)
+  dx, da = hip.dice_bwd(xf, af, mean_d, inv_d, dy.float().to(DEV))
+  assert torch.allclose(dx.cpu().double(), x.grad, rtol=1e-3, atol=1e-4)
+  assert torch.allclose(da.cpu().double(), alpha.grad, rtol=1e-3, atol=1e-3)
+
+
+def test_colsum(hip):
+  x = torch.randn(1000, 70)
+  assert torch.allclose(hip.colsum(x.to(DEV)).cpu(), x.sum(0), rtol=1e-4, atol=1e-4)
+
+
+# ------------------------------------------------------------------------------------------- K10
+@pytest.mark.parametrize('B', [4096, 1, 300])
+def test_sigmoid_ce(hip, ref, B):
+  rng = np.random.default_rng(B)
+  z = torch.from_numpy((rng.standard_normal(B) * 3).astype(np.float32))
+  y = torch.from_numpy((rng.random(B) < 0.3).astype(np.float32))
+  w = torch.from_numpy((rng.random(B) < 0.8).astype(np.float32) * 2.0)
+  for weights in (None, w):
+    l_d, g_d, p_d = hip.sigmoid_ce(z.to(DEV), y.to(DEV), None if weights is None else weights.to(DEV), 0.7)
+    l_c, g_c, p_c = ref.sigmoid_ce(z, y, weights, 0.7)
+    assert torch.allclose(l_d.cpu(), l_c, rtol=1e-5)
+    assert torch.allclose(g_d.cpu(), g_c, rtol=1e-4, atol=1e-9) and torch.allclose(p_d.cpu(), p_c, rtol=1e-5)
+
+
+def test_reductions(hip):
+  p = torch.randn(1234)
+  out = torch.zeros(1, device=DEV)
+  hip.reduce_sum(p.to(DEV), 0.5, out)
+  assert abs(float(out.item()) - 0.5 * float(p.double().sum())) < 1e-3
+  w, c = torch.randn(5000), (torch.rand(5000) < 0.5).float() * 1e-2
+  hip.l2_loss(w.to(DEV), c.to(DEV), out)
+  assert abs(float(out.item()) - float((c.double() * 0.5 * w.double()**2).sum())) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------- K11
+def test_mmoe_mix(hip, ref):
+  T, E, B, H = 4, 5, 130, 64
+  experts, logits, dout = torch.randn(E, B, H), torch.randn(T, B, E), torch.randn(T, B, H)
+  o_d, g_d = hip.mmoe_mix_fwd(experts.to(DEV), logits.to(DEV))
+  o_c, g_c = ref.mmoe_mix_fwd(experts, logits)
+  assert torch.allclose(o_d.cpu(), o_c, rtol=1e-4, atol=1e-5) and torch.allclose(g_d.cpu(), g_c, rtol=1e-5, atol=1e-6)
+  de_d, dl_d = hip.mmoe_mix_bwd(experts.to(DEV), g_d, dout.to(DEV))
+  de_c, dl_c = ref.mmoe_mix_bwd(experts, g_c, dout)
+  assert torch.allclose(de_d.cpu(), de_c, rtol=1e-4, atol=1e-5) and torch.allclose(dl_d.cpu(), dl_c, rtol=1e-3, atol=1e-4)
+
+
+# ------------------------------------------------------------------------------------------- dense optimizer
+@pytest.mark.parametrize('opt', [kernels.OPT_SGD, kernels.OPT_ADAM, kernels.OPT_ADAGRAD])
+def test_dense_opt_bit_exact(hip, ref, opt):
+  n = 100003
+  rng = np.random.default_rng(opt)
+  w = torch.from_numpy(rng.standard_normal(n).astype(np.float32))
+  m = torch.from_numpy((rng.standard_normal(n) * 0.01).astype(np.float32))
+  v = torch.from_numpy((rng.random(n) * 0.01 + 1e-4).astype(np.float32))
+  g = torch.from_numpy(rng.standard_normal(n).astype(np.float32))
+  c = torch.from_numpy(((rng.random(n) < 0.5) * 1e-3).astype(np.float32))
+  hyper = _hyper(t=7)
+  wd, md, vd = w.to(DEV), m.to(DEV), v.to(DEV)
+  hip.dense_opt_step(wd, md, vd, g.to(DEV), c.to(DEV), opt, hyper.to(DEV))
+  ref.dense_opt_step(w, m, v, g, c, opt, hyper)
+  torch.cuda.synchronize()
+  assert torch.equal(md.cpu(), m) and torch.equal(vd.cpu(), v)
+  assert torch.equal(wd.cpu(), w)

@@ -1,0 +1,65 @@
+"""Pins the hashing oracle to TensorFlow's published vectors, then the library's host entry point
+(er_hash_bucket_fast_host) to the oracle."""
+import json
+import os
+
+import numpy as np
+
+from oracle import hashing
+
+GOLDEN = os.path.join(os.path.dirname(__file__), 'golden', 'hash_vectors.json')
+
+
+def test_tf_fingerprint64_vectors():
+  # quoted in tensorflow/python/kernel_tests/string_to_hash_bucket_op_test.py (testStringToHashBucketsFast)
+  known = {'a': 12917804110809363939, 'b': 11795596070477164822, 'c': 11430444447143000872,
+           'd': 4470636696479570465}
+  for s, h in known.items():
+    assert hashing.fingerprint64(s) == h
+    assert hashing.fingerprint64_py(s) == h
+  assert [hashing.fingerprint64(s) % 10 for s in 'abcd'] == [9, 2, 2, 5]
+
+
+def test_tf_docs_example():
+  # tf.strings.to_hash_bucket_fast(["Hello", "TensorFlow", "2.x"], 3) -> [0, 2, 2]
+  assert [hashing.fingerprint64(s) % 3 for s in ['Hello', 'TensorFlow', '2.x']] == [0, 2, 2]
+
+
+def test_c_matches_python_transcription():
+  rng = np.random.default_rng(0)
+  for n in list(range(0, 33)):
+    for _ in range(20):
+      s = bytes(rng.integers(0, 256, size=n, dtype=np.uint8))
+      assert hashing.fingerprint64(s) == hashing.fingerprint64_py(s)
+
+
+def test_golden_file_matches():
+  """tests/golden/hash_vectors.json (written by tests/golden/make_hash_vectors.py) is reproduced."""
+  with open(GOLDEN) as f:
+    vec = json.load(f)
+  for item in vec['vectors']:
+    assert hashing.fingerprint64(bytes.fromhex(item['hex'])) == int(item['fingerprint64'])
+
+
+def _random_strings(rng, n, maxlen):
+  out = []
+  for _ in range(n):
+    ln = int(rng.integers(0, maxlen + 1))
+    out.append(bytes(rng.integers(0, 256, size=ln, dtype=np.uint8)))
+  return out
+
+
+def test_library_host_hash_matches_oracle(built_lib):
+  from easyrec_amd import kernels
+  from easyrec_amd.input.input import pack_strings
+  be = kernels.HipBackend()
+  rng = np.random.default_rng(1)
+  strs = _random_strings(rng, 3000, 200) + [b'', b'a', b'x' * 64, b'y' * 65, b'z' * 128, b'w' * 129]
+  n = len(strs) // 2 * 2
+  strs = strs[:n]
+  data, offs = pack_strings(strs)
+  nb = np.array([1000000, 7], dtype=np.uint64)
+  for drop in (0, 1):
+    got = be.hash_bucket_fast_host(data, offs, n // 2, nb, drop)
+    exp = hashing.hash_bucket_fast(data, offs, n // 2, nb, drop)
+    assert np.array_equal(got, exp)
