@@ -1,0 +1,264 @@
+#!/usr/bin/env python
+"""Benchmark of the hot path: DeepFM training step on synthetic Criteo-shape input.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+
+A "step" = one pass of the hot path over one batch already resident in HBM: device-side id hashing
+-> fused embedding lookup (78 lookups, one launch) -> wide sum / FM / MLP(+BatchNorm) -> sigmoid CE
+-> backward -> sort-based de-duplicated embedding gradient + row-wise optimizer -> dense optimizer.
+Workload at N=1 = BASELINE.json configs[1]: configs/deepfm_criteo.config (39 features, 26 x 1M-row
+hashed tables, D=16, batch 4096, fp32, `adam_optimizer` with TF's dense-decay sparse apply).
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import logging
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s achievable by a float4 copy
+
+
+def parse_args():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--gpus', type=int, default=1)
+  ap.add_argument('--steps', type=int, default=100)
+  ap.add_argument('--warmup', type=int, default=10)
+  ap.add_argument('--config', default=os.path.join(ROOT, 'configs', 'deepfm_criteo.config'))
+  ap.add_argument('--batch_size', type=int, default=0, help='per-GPU batch (default: data_config.batch_size)')
+  ap.add_argument('--ids', default='zipf', choices=['zipf', 'uniform'])
+  ap.add_argument('--optimizer', default='config', choices=['config', 'adam', 'lazy_adam'])
+  ap.add_argument('--no_graph', action='store_true', help='eager launches instead of hipGraph replay')
+  ap.add_argument('--no_cpu_baseline', action='store_true')
+  ap.add_argument('--cpu_steps', type=int, default=2)
+  ap.add_argument('--ring', type=int, default=16, help='distinct pre-generated batches kept on device')
+  return ap.parse_args()
+
+
+def dist_setup(n_gpus):
+  import torch.distributed as dist
+  rank = int(os.environ.get('RANK', '0'))
+  world = int(os.environ.get('WORLD_SIZE', '1'))
+  local = int(os.environ.get('LOCAL_RANK', '0'))
+  assert world == n_gpus or world == 1 and n_gpus == 1, 'WORLD_SIZE %d != --gpus %d' % (world, n_gpus)
+  torch.cuda.set_device(local)
+  if world > 1:
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+  return rank, world, local
+
+
+def switch_optimizer(cfg, which):
+  oc = cfg.train_config.optimizer_config[0]
+  cur = oc.WhichOneof('optimizer')
+  want = {'adam': 'adam_optimizer', 'lazy_adam': 'lazy_adam_optimizer'}[which]
+  if cur == want:
+    return
+  lr = getattr(oc, cur).learning_rate
+  getattr(oc, want).learning_rate.CopyFrom(lr)
+
+
+def to_device_batch(batch, device):
+  return {k: torch.from_numpy(np.ascontiguousarray(v)).to(device) for k, v in batch.items()}
+
+
+def embedding_bytes_per_step(est, batches):
+  """Algorithmic bytes of the embedding stage per step:
+     per valid lookup fwd 8+8D, bwd 8+4D; per unique row update 8D*(1+S); dense-decay Adam adds the
+     sweep R*D*4*6 over every table."""
+  from easyrec_amd import kernels
+  lazy, n_steps = 0.0, 0
+  S = 2 if est.opt_emb.kind in (kernels.OPT_ADAM, kernels.OPT_LAZY_ADAM) else (1 if est.opt_emb.kind == kernels.OPT_ADAGRAD else 0)
+  for b in batches[:4]:
+    est.features.load(b)
+    est.features.transform()
+    torch.cuda.synchronize()
+    ids = est.features.hash_ids.cpu().numpy()
+    tot = 0.0
+    for dim in est.engine.storage:
+      n_valid = int((ids >= 0).sum())
+      uniq = sum(len(np.unique(r[r >= 0])) for r in ids)
+      tot += n_valid * (16 + 12 * dim) + uniq * 8 * dim * (1 + S)
+      n_proj = len(est.schema.raw)
+      tot += n_proj * est.batch_size * (4 + 8 * dim) + n_proj * 8 * dim * (1 + S)
+    lazy += tot
+    n_steps += 1
+  lazy /= max(n_steps, 1)
+  sweep = 0.0
+  if est.opt_emb.kind == kernels.OPT_ADAM:
+    sweep = sum(st['total_rows'] * dim * 4 * 6 for dim, st in est.engine.storage.items())
+  return lazy, sweep
+
+
+def time_dominant_kernel(est, launches):
+  """Average duration of the dominant kernel (the D=16 dense-decay sweep), HIP events on the launch
+  stream (torch's current stream is the stream the C ABI launches on)."""
+  from easyrec_amd import kernels
+  be = kernels.hip()
+  dim = max(est.engine.storage, key=lambda d: est.engine.storage[d]['total_rows'] * d)
+  st = est.engine.storage[dim]
+  if est.opt_emb.kind != kernels.OPT_ADAM:
+    return None
+  evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(launches)]
+  for _ in range(3):
+    be.adam_decay_sweep(st['var'], st['m'], st['v'], st['bitmap'], st['total_rows'], dim, est.hyper[0])
+  torch.cuda.synchronize()
+  for a, b in evs:
+    a.record()
+    be.adam_decay_sweep(st['var'], st['m'], st['v'], st['bitmap'], st['total_rows'], dim, est.hyper[0])
+    b.record()
+  torch.cuda.synchronize()
+  ms = [a.elapsed_time(b) for a, b in evs]
+  alg_bytes = st['total_rows'] * dim * 4 * 6
+  return {'kernel': 'adam_decay_sweep_vec4_kernel<4> (dim %d)' % dim, 'avg_ms': float(np.mean(ms)),
+          'min_ms': float(np.min(ms)), 'bytes': alg_bytes, 'launches': launches}
+
+
+def cpu_baseline(cfg, est_state, batches, batch_size, steps):
+  """The CPU restatement of the reference path (oracle/model_oracle.py) on the host cores."""
+  from oracle.model_oracle import OracleTrainer
+  torch.set_num_threads(os.cpu_count() or 1)
+  orc = OracleTrainer(cfg, est_state, batch_size=batch_size)
+  orc.train_step(batches[0])  # warm-up (first-touch of the numpy slots)
+  t0 = time.perf_counter()
+  for i in range(steps):
+    orc.train_step(batches[(i + 1) % len(batches)])
+  dt = time.perf_counter() - t0
+  return {
+      'value': steps * batch_size / dt,
+      'unit': 'examples/s',
+      'cores': torch.get_num_threads(),
+      'kind': 'port',
+      'sample': '%d steps of batch %d (same config, same synthetic batches, adam dense-decay semantics, fp32) in %.1f s; '
+                'torch-CPU ops use %d threads, numpy optimizer passes are single-threaded; CPU restatement of the '
+                'reference path - TensorFlow itself is not installable here' % (steps, batch_size, dt,
+                                                                                torch.get_num_threads()),
+  }
+
+
+def main():
+  args = parse_args()
+  logging.disable(logging.WARNING)
+  rank, world, local = dist_setup(args.gpus)
+  dev = torch.device('cuda', local)
+  from easyrec_amd import kernels
+  from easyrec_amd.input.criteo_synthetic import SyntheticCriteo
+  from easyrec_amd.model.easy_rec_estimator import EasyRecEstimator
+  from easyrec_amd.utils import config_util
+
+  cfg = config_util.get_configs_from_pipeline_file(args.config)
+  if args.optimizer != 'config':
+    switch_optimizer(cfg, args.optimizer)
+  B = args.batch_size or cfg.data_config.batch_size
+  if world > 1:
+    from easyrec_amd.model.embedding_parallel import EmbeddingParallelEstimator
+    est = EmbeddingParallelEstimator(cfg, device=dev, batch_size=B, seed=1, rank=rank, world=world).build()
+  else:
+    est = EasyRecEstimator(cfg, device=dev, batch_size=B, seed=1).build()
+  gen = SyntheticCriteo(cfg.data_config, est.feature_configs, batch_size=B, seed=20240607 + rank, mode=args.ids)
+  host_batches = [gen.next_batch() for _ in range(args.ring)]
+  ring = [to_device_batch(b, dev) for b in host_batches]
+  est.features.load(ring[0])
+  torch.cuda.synchronize()
+  if not args.no_graph:
+    est.capture(warmup=3)
+
+  def barrier():
+    if world > 1:
+      import torch.distributed as dist
+      dist.barrier()
+    torch.cuda.synchronize()
+
+  for i in range(args.warmup):
+    est.train_step(ring[i % len(ring)])
+  barrier()
+  t0 = time.perf_counter()
+  for i in range(args.steps):
+    est.train_step(ring[(args.warmup + i) % len(ring)])
+  barrier()
+  dt = time.perf_counter() - t0
+  if world > 1:
+    import torch.distributed as dist
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+  losses = est.loss_values()
+  assert all(np.isfinite(v) for v in losses.values()), losses
+
+  if rank != 0:
+    return
+  ms_per_step = dt / args.steps * 1e3
+  value = world * B * args.steps / dt
+  out = {
+      'metric': 'global examples/sec, DeepFM Criteo-shape b4096 (+ embedding-stage HBM GB/s in roofline)',
+      'value': value,
+      'unit': 'examples/s',
+      'n_gpus': world,
+      'steps': args.steps,
+      'warmup': args.warmup,
+      'ms_per_step': ms_per_step,
+      'higher_is_better': True,
+      'scaling': 'weak',
+      'vs_baseline': None,
+      'dtype': 'f32',
+      'data': 'synthetic',
+      'config': {
+          'workload': 'DeepFM synthetic Criteo: %s (39 features: 26 hashed x %d rows + 13 projected, D=16 deep + '
+                      'D=1 wide, batch %d per GPU, optimizer %s, ids %s, %s)' %
+                      (os.path.basename(args.config), cfg.feature_config.features[13].hash_bucket_size, B,
+                       est.opt_emb.name, args.ids, 'eager launches' if args.no_graph else 'hipGraph replay'),
+          'global_batch': world * B,
+          'parallelism': 'single GPU' if world == 1 else 'embedding-parallel x%d (row-sharded tables, RCCL all-to-all) + dense DP' % world,
+      },
+      'final_loss': losses.get('total_loss'),
+      'device': kernels.hip().device_info(),
+  }
+  if world == 1:
+    lazy_bytes, sweep_bytes = embedding_bytes_per_step(est, ring)
+    out['embedding_stage'] = {
+        'algorithmic_bytes_per_step': lazy_bytes + sweep_bytes,
+        'lookup_update_bytes_per_step': lazy_bytes,
+        'dense_decay_sweep_bytes_per_step': sweep_bytes,
+        'whole_step_GBps': (lazy_bytes + sweep_bytes) / (ms_per_step * 1e-3) / 1e9,
+        'note': 'whole_step_GBps divides the embedding stage\'s algorithmic bytes by the WHOLE step time',
+    }
+    dom = time_dominant_kernel(est, launches=max(10, min(args.steps, 50)))
+    if dom is not None:
+      ach = dom['bytes'] / (dom['avg_ms'] * 1e-3) / 1e9
+      traffic = None
+      pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+      if os.path.exists(pmc):
+        try:
+          traffic = json.load(open(pmc)).get('adam_decay_sweep_dim16_bytes_per_launch')
+        except Exception:
+          traffic = None
+      out['roofline'] = {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': ach / HBM_PEAK_GBS, 'traffic': traffic, 'kernel': dom['kernel'],
+                         'avg_kernel_ms': dom['avg_ms'], 'algorithmic_bytes_per_launch': dom['bytes'],
+                         'launches_timed': dom['launches']}
+    else:
+      # lazy optimizers: no HBM-streaming kernel dominates; report the fused lookup kernel
+      out['roofline'] = {'bound': 'hbm', 'achieved': lazy_bytes / (ms_per_step * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS,
+                         'unit': 'GB/s', 'frac': lazy_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         'traffic': None, 'kernel': 'whole step (launch/latency bound at B=4096)'}
+    if not args.no_cpu_baseline:
+      try:
+        # fresh state for the CPU run = the device state now (any state is as good for timing)
+        out['cpu_baseline'] = cpu_baseline(cfg, est.state_dict(), host_batches, B, args.cpu_steps)
+      except Exception as e:  # noqa: BLE001
+        out['cpu_baseline'] = {'value': None, 'unit': 'examples/s', 'cores': 0, 'kind': 'port',
+                               'sample': 'failed: %s' % str(e)[:200]}
+  print(json.dumps(out))
+
+
+if __name__ == '__main__':
+  main()

@@ -74,17 +74,26 @@ bn_stats_partial_kernel(const float* __restrict__ x, const float* __restrict__ b
   }
 }
 
+// one wave per column: lanes take chunks k, k+64, ..; then a fixed butterfly of Welford merges
 __global__ void __launch_bounds__(kBlock)
 bn_finalize_kernel(const float* __restrict__ partial, int B, int N, int chunks, float eps, float momentum,
                    float* __restrict__ moving_mean, float* __restrict__ moving_var, float* __restrict__ save_mean,
                    float* __restrict__ save_invstd) {
-  const int c = blockIdx.x * kBlock + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   if (c >= N) return;
   Welford t{0.f, 0.f, 0.f};
-  for (int k = 0; k < chunks; ++k) {
+  for (int k = lane; k < chunks; k += 64) {
     const float* p = partial + (static_cast<int64_t>(k) * N + c) * 3;
     t = wf_merge(t, Welford{p[0], p[1], p[2]});
   }
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    Welford o{__shfl_xor(t.n, off, 64), __shfl_xor(t.mean, off, 64), __shfl_xor(t.m2, off, 64)};
+    // merge in a lane-independent order (lower lane first) so that every lane holds the same bits
+    t = (lane & off) ? wf_merge(o, t) : wf_merge(t, o);
+  }
+  if (lane != 0) return;
   const float mean = t.mean;
   const float var = t.m2 / static_cast<float>(B);  // biased, as tf.nn.moments
   save_mean[c] = mean;
@@ -153,14 +162,18 @@ __global__ void __launch_bounds__(kBlock)
 bn_bwd_finalize_kernel(const float* __restrict__ partial, int N, int chunks, int use_bn, float* __restrict__ sum_g,
                        float* __restrict__ sum_gx, float* __restrict__ dbias, float* __restrict__ dgamma,
                        float* __restrict__ dbeta) {
-  const int c = blockIdx.x * kBlock + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   if (c >= N) return;
   float a = 0.f, b = 0.f;
-  for (int k = 0; k < chunks; ++k) {
+  for (int k = lane; k < chunks; k += 64) {
     const float* p = partial + (static_cast<int64_t>(k) * N + c) * 2;
     a = a + p[0];
     b = b + p[1];
   }
+  a = wave_sum(a);
+  b = wave_sum(b);
+  if (lane != 0) return;
   sum_g[c] = a;
   sum_gx[c] = b;
   if (use_bn) {
@@ -216,11 +229,13 @@ colsum_partial_kernel(const float* __restrict__ x, int rows, int cols, int x_str
 
 __global__ void __launch_bounds__(kBlock)
 colsum_finalize_kernel(const float* __restrict__ partial, int cols, int chunks, float* __restrict__ out) {
-  const int c = blockIdx.x * kBlock + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   if (c >= cols) return;
   float a = 0.f;
-  for (int k = 0; k < chunks; ++k) a = a + partial[static_cast<int64_t>(k) * cols + c];
-  out[c] = a;
+  for (int k = lane; k < chunks; k += 64) a = a + partial[static_cast<int64_t>(k) * cols + c];
+  a = wave_sum(a);
+  if (lane == 0) out[c] = a;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -277,13 +292,16 @@ dice_bwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ a
 __global__ void __launch_bounds__(kBlock)
 dice_bwd_finalize_kernel(const float* __restrict__ partial, int N, int chunks, float* __restrict__ sums,
                          float* __restrict__ dalpha) {
-  const int c = blockIdx.x * kBlock + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   if (c >= N) return;
   float a = 0.f, b = 0.f, d = 0.f;
-  for (int k = 0; k < chunks; ++k) {
+  for (int k = lane; k < chunks; k += 64) {
     const float* p = partial + (static_cast<int64_t>(k) * N + c) * 3;
     a = a + p[0]; b = b + p[1]; d = d + p[2];
   }
+  a = wave_sum(a); b = wave_sum(b); d = wave_sum(d);
+  if (lane != 0) return;
   sums[c] = a;
   sums[N + c] = b;
   if (dalpha) dalpha[c] = d;
@@ -348,16 +366,17 @@ reduce_sum_kernel(const float* __restrict__ p, int n, float scale, float* __rest
 }
 
 __global__ void __launch_bounds__(kBlock)
-l2_loss_kernel(const float* __restrict__ w, const float* __restrict__ coef, int64_t n, float* __restrict__ out,
-               int accumulate) {
+l2_loss_partial_kernel(const float* __restrict__ w, const float* __restrict__ coef, int64_t n,
+                       float* __restrict__ partial) {
   __shared__ float red[4];
   float acc = 0.f;
-  for (int64_t i = threadIdx.x; i < n; i += kBlock) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride) {
     const float c = coef[i];
     if (c != 0.f) acc = acc + c * (0.5f * (w[i] * w[i]));
   }
   const float s = block_sum_256(acc, red);
-  if (threadIdx.x == 0) out[0] = accumulate ? (out[0] + s) : s;
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -391,6 +410,16 @@ dense_opt_kernel(float* __restrict__ w, float* __restrict__ m, float* __restrict
     wi = wi - h.lr * g;
   }
   w[i] = wi;
+}
+
+// per-step scalars: out[:] = table[counter % n_slots][:]; counter += 1   (one block)
+__global__ void hyper_select_kernel(const float* __restrict__ table, int64_t* __restrict__ counter, int n_slots,
+                                    int floats_per_slot, float* __restrict__ out) {
+  const int64_t c = *counter;
+  const int64_t slot = c % n_slots;
+  for (int i = threadIdx.x; i < floats_per_slot; i += blockDim.x) out[i] = table[slot * floats_per_slot + i];
+  __syncthreads();
+  if (threadIdx.x == 0) *counter = c + 1;
 }
 
 inline int blocks_for(int64_t n) { return static_cast<int>(ceil_div(n, kBlock)); }
@@ -440,7 +469,7 @@ int er_bn_act_fwd(const float* x, const float* bias, const float* gamma, const f
     dim3 grid(static_cast<unsigned>(er::ceil_div(N, er::kColsPerBlock)), static_cast<unsigned>(chunks));
     hipLaunchKernelGGL(er::bn_stats_partial_kernel, grid, dim3(er::kBlock), 0, s, x, bias, B, N, chunks, scratch);
     ER_LAUNCH_CHECK();
-    hipLaunchKernelGGL(er::bn_finalize_kernel, dim3(er::blocks_for(N)), dim3(er::kBlock), 0, s, scratch, B, N, chunks,
+    hipLaunchKernelGGL(er::bn_finalize_kernel, dim3(er::blocks_for(static_cast<int64_t>(N) * 64)), dim3(er::kBlock), 0, s, scratch, B, N, chunks,
                        eps, momentum, moving_mean, moving_var, save_mean, save_invstd);
     ER_LAUNCH_CHECK();
   }
@@ -464,7 +493,7 @@ int er_bn_act_bwd(const float* x, const float* bias, const float* gamma, const f
   hipLaunchKernelGGL(er::bn_bwd_partial_kernel, grid, dim3(er::kBlock), 0, s, x, bias, y, save_mean, save_invstd, dy, B,
                      N, chunks, use_bn, act, scratch);
   ER_LAUNCH_CHECK();
-  hipLaunchKernelGGL(er::bn_bwd_finalize_kernel, dim3(er::blocks_for(N)), dim3(er::kBlock), 0, s, scratch, N, chunks,
+  hipLaunchKernelGGL(er::bn_bwd_finalize_kernel, dim3(er::blocks_for(static_cast<int64_t>(N) * 64)), dim3(er::kBlock), 0, s, scratch, N, chunks,
                      use_bn, sums, sums + N, dbias, dgamma, dbeta);
   ER_LAUNCH_CHECK();
   hipLaunchKernelGGL(er::bn_bwd_apply_kernel, dim3(er::blocks_for(n)), dim3(er::kBlock), 0, s, x, bias, gamma, y,
@@ -482,7 +511,7 @@ int er_colsum(const float* x, int32_t rows, int32_t cols, int32_t x_stride, floa
   dim3 grid(static_cast<unsigned>(er::ceil_div(cols, er::kColsPerBlock)), static_cast<unsigned>(chunks));
   hipLaunchKernelGGL(er::colsum_partial_kernel, grid, dim3(er::kBlock), 0, s, x, rows, cols, x_stride, chunks, scratch);
   ER_LAUNCH_CHECK();
-  hipLaunchKernelGGL(er::colsum_finalize_kernel, dim3(er::blocks_for(cols)), dim3(er::kBlock), 0, s, scratch, cols,
+  hipLaunchKernelGGL(er::colsum_finalize_kernel, dim3(er::blocks_for(static_cast<int64_t>(cols) * 64)), dim3(er::kBlock), 0, s, scratch, cols,
                      chunks, out);
   ER_LAUNCH_CHECK();
   return 0;
@@ -501,7 +530,7 @@ int er_dice_fwd(const float* x, const float* alpha, int32_t B, int32_t N, float 
   hipLaunchKernelGGL(er::bn_stats_partial_kernel, grid, dim3(er::kBlock), 0, s, x, static_cast<const float*>(nullptr), B,
                      N, chunks, scratch);
   ER_LAUNCH_CHECK();
-  hipLaunchKernelGGL(er::bn_finalize_kernel, dim3(er::blocks_for(N)), dim3(er::kBlock), 0, s, scratch, B, N, chunks, eps,
+  hipLaunchKernelGGL(er::bn_finalize_kernel, dim3(er::blocks_for(static_cast<int64_t>(N) * 64)), dim3(er::kBlock), 0, s, scratch, B, N, chunks, eps,
                      momentum, moving_mean, moving_var, save_mean, save_invstd);
   ER_LAUNCH_CHECK();
   hipLaunchKernelGGL(er::dice_apply_kernel, dim3(er::blocks_for(n)), dim3(er::kBlock), 0, s, x, alpha, save_mean,
@@ -523,7 +552,7 @@ int er_dice_bwd(const float* x, const float* alpha, const float* save_mean, cons
   hipLaunchKernelGGL(er::dice_bwd_partial_kernel, grid, dim3(er::kBlock), 0, s, x, alpha, save_mean, save_invstd, dy, B,
                      N, chunks, scratch);
   ER_LAUNCH_CHECK();
-  hipLaunchKernelGGL(er::dice_bwd_finalize_kernel, dim3(er::blocks_for(N)), dim3(er::kBlock), 0, s, scratch, N, chunks,
+  hipLaunchKernelGGL(er::dice_bwd_finalize_kernel, dim3(er::blocks_for(static_cast<int64_t>(N) * 64)), dim3(er::kBlock), 0, s, scratch, N, chunks,
                      sums, dalpha);
   ER_LAUNCH_CHECK();
   hipLaunchKernelGGL(er::dice_bwd_apply_kernel, dim3(er::blocks_for(n)), dim3(er::kBlock), 0, s, x, alpha, save_mean,
@@ -551,8 +580,25 @@ int er_reduce_sum(const float* partials, int32_t n, float scale, float* out, int
 
 int er_l2_loss(const float* w, const float* coef, int64_t n, float* out, int accumulate, er_stream_t stream) {
   ER_REQUIRE(w && coef && out && n > 0, "er_l2_loss: bad arguments");
-  hipLaunchKernelGGL(er::l2_loss_kernel, dim3(1), dim3(er::kBlock), 0, er::as_stream(stream), w, coef, n, out,
-                     accumulate);
+  hipStream_t s = er::as_stream(stream);
+  int64_t blocks = er::ceil_div(n, static_cast<int64_t>(er::kBlock) * 4);
+  if (blocks > 1024) blocks = 1024;
+  float* scratch;
+  if (er::get_scratch(static_cast<size_t>(blocks), &scratch)) return 1;
+  hipLaunchKernelGGL(er::l2_loss_partial_kernel, dim3(static_cast<int>(blocks)), dim3(er::kBlock), 0, s, w, coef, n,
+                     scratch);
+  ER_LAUNCH_CHECK();
+  hipLaunchKernelGGL(er::reduce_sum_kernel, dim3(1), dim3(er::kBlock), 0, s, scratch, static_cast<int>(blocks), 1.0f,
+                     out, accumulate);
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
+int er_hyper_select(const float* table, int64_t* counter, int32_t n_slots, int32_t floats_per_slot, float* out,
+                    er_stream_t stream) {
+  ER_REQUIRE(table && counter && out && n_slots > 0 && floats_per_slot > 0, "er_hyper_select: bad arguments");
+  hipLaunchKernelGGL(er::hyper_select_kernel, dim3(1), dim3(64), 0, er::as_stream(stream), table, counter, n_slots,
+                     floats_per_slot, out);
   ER_LAUNCH_CHECK();
   return 0;
 }

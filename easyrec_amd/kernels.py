@@ -437,6 +437,11 @@ class HipBackend(object):
                                  _stream()), 'er_mmoe_mix_bwd')
     return dexperts, dlogits
 
+  def hyper_select(self, table, counter, out):
+    n_slots = table.shape[0]
+    self._ck(self.lib.er_hyper_select(_p(table), _p(counter), n_slots, table[0].numel(), _p(out), _stream()),
+             'er_hyper_select')
+
   # -- dense optimizer
   def dense_opt_step(self, w, m, v, grad, l2coef, opt_kind, hyper):
     self._ck(

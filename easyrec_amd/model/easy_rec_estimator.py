@@ -34,6 +34,8 @@ from easyrec_amd.utils.load_class import import_all_models
 
 class EasyRecEstimator(object):
 
+  HYPER_SLOTS = 4096
+
   def __init__(self, pipeline_config, device='cuda', batch_size=None, seed=0, schema_kwargs=None,
                is_training=True):
     import_all_models()
@@ -73,10 +75,12 @@ class EasyRecEstimator(object):
                              is_training=is_training)
 
     dev = self.device
+    # per-step optimizer scalars: precomputed by the host for the next HYPER_SLOTS steps, selected on
+    # the device by a device-resident step counter (no host-written memory inside the captured graph)
     self.hyper = torch.zeros(2, kernels.HYPER_FLOATS, dtype=torch.float32, device=dev)  # [emb, dense]
-    self._hyper_host = torch.zeros(2, kernels.HYPER_FLOATS, dtype=torch.float32)
-    if dev.type == 'cuda':
-      self._hyper_host = self._hyper_host.pin_memory()
+    self.hyper_table = torch.zeros(self.HYPER_SLOTS, 2, kernels.HYPER_FLOATS, dtype=torch.float32, device=dev)
+    self.step_counter = torch.zeros(1, dtype=torch.int64, device=dev)
+    self._planned_until = 0
     self.losses = {
         'regularization_loss': torch.zeros(1, dtype=torch.float32, device=dev),
         'total_loss': torch.zeros(1, dtype=torch.float32, device=dev),
@@ -109,16 +113,34 @@ class EasyRecEstimator(object):
     return self
 
   # -- one step
+  def _plan_hyper(self, count):
+    """Generate the scalars of the next `count` steps and upload them to their table slots."""
+    rows = np.zeros((count, 2, kernels.HYPER_FLOATS), dtype=np.float32)
+    for i in range(count):
+      step = self._planned_until + i
+      rows[i, 0] = self.opt_emb.hyper_row(step, self.emb_grad_scale)
+      rows[i, 1] = self.opt_dense.hyper_row(step, 1.0)
+      self.opt_emb.finish_step()
+      if self.opt_dense is not self.opt_emb:
+        self.opt_dense.finish_step()
+    slots = (self._planned_until + np.arange(count)) % self.HYPER_SLOTS
+    self.hyper_table[torch.from_numpy(slots).to(self.device)] = torch.from_numpy(rows).to(self.device)
+    self._planned_until += count
+
   def _refresh_hyper(self):
-    """Per-step scalars -> pinned host -> device (a captured graph re-reads the pinned buffer)."""
-    h = self._hyper_host
-    h[0].copy_(torch.from_numpy(self.opt_emb.hyper_row(self.global_step, self.emb_grad_scale)))
-    h[1].copy_(torch.from_numpy(self.opt_dense.hyper_row(self.global_step, 1.0)))
+    """Keep the device table half a ring ahead of `global_step` (sync only once per half ring)."""
+    half = self.HYPER_SLOTS // 2
+    if self._planned_until == 0:
+      self._plan_hyper(self.HYPER_SLOTS)
+    elif self.global_step + half >= self._planned_until:
+      if self.device.type == 'cuda':
+        torch.cuda.current_stream().synchronize()  # the slots being rewritten were consumed long ago
+      self._plan_hyper(half)
 
   def _device_step(self):
     """Everything that runs on the GPU for one batch (graph-capturable)."""
     be = kernels.hip()
-    self.hyper.copy_(self._hyper_host, non_blocking=True)
+    be.hyper_select(self.hyper_table, self.step_counter, self.hyper)
     self.features.transform()
     self.varstore.zero_grad()
     with context.use(self.ctx):
@@ -156,9 +178,6 @@ class EasyRecEstimator(object):
       self.graph.replay()
     else:
       self._device_step()
-    self.opt_emb.finish_step()
-    if self.opt_dense is not self.opt_emb:
-      self.opt_dense.finish_step()
     self.global_step += 1
     return self.losses
 
@@ -181,9 +200,6 @@ class EasyRecEstimator(object):
         self.features.version += 1
         self._refresh_hyper()
         self._device_step()
-        self.opt_emb.finish_step()
-        if self.opt_dense is not self.opt_emb:
-          self.opt_dense.finish_step()
         self.global_step += 1
     torch.cuda.current_stream().wait_stream(s)
     torch.cuda.synchronize()
@@ -192,7 +208,7 @@ class EasyRecEstimator(object):
     self._refresh_hyper()
     with torch.cuda.graph(g):
       self._device_step()
-    # the capture itself does not execute: state (step, beta powers) is unchanged by it
+    # the capture itself does not execute: the device step counter is unchanged by it
     self.graph = g
     return g
 

@@ -142,6 +142,14 @@ typedef struct er_emb_group er_emb_group;
  * var/m/v: [total_rows, dim]; m and/or v may be NULL when the optimizer does not use them
  * (SGD: both; Adagrad: m).  touched_bitmap: [ceil(total_rows/32)] zero-initialised uint32 words,
  * required for ER_OPT_ADAM only. */
+/* Per-step scalars without a host round trip: `table` holds n_slots consecutive er_opt_hyper-sized
+ * records (floats_per_slot floats each, several optimizers may be packed in one slot) precomputed by
+ * the host for the coming steps; this copies slot (*counter % n_slots) to `out` and increments
+ * *counter.  Keeps a captured hipGraph free of host-written memory (no race with the host running
+ * ahead of the device). */
+int er_hyper_select(const float* table, int64_t* counter, int32_t n_slots, int32_t floats_per_slot,
+                    float* out, er_stream_t stream);
+
 int er_emb_group_create(const er_lookup_desc* descs_host, int n, int32_t dim, int64_t total_rows,
                         float* var, float* m, float* v, uint32_t* touched_bitmap,
                         er_emb_group** group);

@@ -491,6 +491,11 @@ class RefBackend(object):
     dlogits = gates * (dg - (gates * dg).sum(dim=-1, keepdim=True))
     return dexperts, dlogits
 
+  def hyper_select(self, table, counter, out):
+    c = int(counter.item())
+    out.copy_(table[c % table.shape[0]].reshape(out.shape))
+    counter.add_(1)
+
   # -- dense optimizer
   def dense_opt_step(self, w, m, v, grad, l2coef, opt_kind, hyper):
     h = hyper.detach().cpu().numpy().reshape(-1)
