@@ -38,7 +38,7 @@ def parse_args():
   ap.add_argument('--optimizer', default='config', choices=['config', 'adam', 'lazy_adam'])
   ap.add_argument('--no_graph', action='store_true', help='eager launches instead of hipGraph replay')
   ap.add_argument('--no_cpu_baseline', action='store_true')
-  ap.add_argument('--cpu_steps', type=int, default=2)
+  ap.add_argument('--cpu_seconds', type=float, default=12.0, help='time budget of the CPU baseline sample')
   ap.add_argument('--ring', type=int, default=16, help='distinct pre-generated batches kept on device')
   return ap.parse_args()
 
@@ -123,25 +123,28 @@ def time_dominant_kernel(est, launches):
           'min_ms': float(np.min(ms)), 'bytes': alg_bytes, 'launches': launches}
 
 
-def cpu_baseline(cfg, est_state, batches, batch_size, steps):
-  """The CPU restatement of the reference path (oracle/model_oracle.py) on the host cores."""
+def cpu_baseline(cfg, est_state, batches, batch_size, budget_s=12.0, max_steps=8):
+  """The CPU restatement of the reference path (oracle/model_oracle.py) on the host cores: a bounded
+  sample (about `budget_s` seconds) of the same workload."""
   from oracle.model_oracle import OracleTrainer
-  torch.set_num_threads(os.cpu_count() or 1)
+  threads = min(os.cpu_count() or 1, 64)
+  torch.set_num_threads(threads)
   orc = OracleTrainer(cfg, est_state, batch_size=batch_size)
-  orc.train_step(batches[0])  # warm-up (first-touch of the numpy slots)
+  orc.train_step(batches[0])  # warm-up (first-touch of the optimizer slots)
   t0 = time.perf_counter()
-  for i in range(steps):
-    orc.train_step(batches[(i + 1) % len(batches)])
+  steps = 0
+  while steps < max_steps and (steps == 0 or time.perf_counter() - t0 < budget_s):
+    orc.train_step(batches[(steps + 1) % len(batches)])
+    steps += 1
   dt = time.perf_counter() - t0
   return {
       'value': steps * batch_size / dt,
       'unit': 'examples/s',
-      'cores': torch.get_num_threads(),
+      'cores': threads,
       'kind': 'port',
-      'sample': '%d steps of batch %d (same config, same synthetic batches, adam dense-decay semantics, fp32) in %.1f s; '
-                'torch-CPU ops use %d threads, numpy optimizer passes are single-threaded; CPU restatement of the '
-                'reference path - TensorFlow itself is not installable here' % (steps, batch_size, dt,
-                                                                                torch.get_num_threads()),
+      'sample': '%d steps of batch %d in %.1f s (same config, same synthetic batches, same optimizer semantics, fp32); '
+                'torch-CPU ops on %d threads; CPU restatement of the reference path - TensorFlow itself is not '
+                'installable here' % (steps, batch_size, dt, threads),
   }
 
 
@@ -253,7 +256,7 @@ def main():
     if not args.no_cpu_baseline:
       try:
         # fresh state for the CPU run = the device state now (any state is as good for timing)
-        out['cpu_baseline'] = cpu_baseline(cfg, est.state_dict(), host_batches, B, args.cpu_steps)
+        out['cpu_baseline'] = cpu_baseline(cfg, est.state_dict(), host_batches, B, args.cpu_seconds)
       except Exception as e:  # noqa: BLE001
         out['cpu_baseline'] = {'value': None, 'unit': 'examples/s', 'cores': 0, 'kind': 'port',
                                'sample': 'failed: %s' % str(e)[:200]}

@@ -176,6 +176,34 @@ emb_bwd_build_kernel(const er_lookup_desc* __restrict__ descs, const int32_t* __
   }
 }
 
+// Marks the rows an upcoming step will touch (same validity rule as emb_bwd_build_kernel), so that the
+// dense-decay sweep over the UNTOUCHED rows can run concurrently with forward/backward on another
+// stream: untouched rows are neither read by this step's lookup nor written by its row updates.
+__global__ void __launch_bounds__(kBlock)
+emb_mark_kernel(const er_lookup_desc* __restrict__ descs, const int32_t* __restrict__ blk_start, int n_lookups,
+                uint32_t* __restrict__ bitmap) {
+  const int l = find_lookup(blk_start, n_lookups, blockIdx.x);
+  const er_lookup_desc d = descs[l];
+  const int r = (blockIdx.x - blk_start[l]) * kBlock + static_cast<int>(threadIdx.x);
+  if (r >= d.n_rows) return;
+  int64_t kb, ke;
+  if (d.offsets) {
+    kb = d.offsets[r];
+    ke = d.offsets[r + 1];
+  } else {
+    kb = r;
+    ke = r + 1;
+  }
+  const bool prune_nonpos = (d.weights != nullptr) && (d.combiner != ER_COMBINER_SUM);
+  for (int64_t k = kb; k < ke; ++k) {
+    const int64_t id = d.ids[k];
+    if (id < 0 || id >= d.rows) continue;
+    if (prune_nonpos && !(d.weights[k] > 0.f)) continue;
+    const uint32_t key = static_cast<uint32_t>(d.key_base + id);
+    atomicOr(&bitmap[key >> 5], 1u << (key & 31));
+  }
+}
+
 template <int V>
 struct Vec;
 template <>
@@ -493,6 +521,28 @@ adam_decay_sweep_scalar_kernel(float* __restrict__ var, float* __restrict__ m, f
   }
 }
 
+// Calibration / achievable-bandwidth probe: float4 copy with the sweep's access pattern (nontemporal,
+// grid-stride, 4 units in flight).  Moves exactly 2*bytes; used to calibrate rocprofv3's FETCH_SIZE /
+// WRITE_SIZE on a known byte count and to report the copy bandwidth next to the spec peak.
+template <int UNROLL>
+__global__ void __launch_bounds__(kBlock)
+stream_copy_kernel(const f32x4* __restrict__ src, f32x4* __restrict__ dst, int64_t n_units) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t i0 = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i0 < n_units; i0 += stride * UNROLL) {
+    f32x4 a[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const int64_t i = i0 + u * stride;
+      if (i < n_units) a[u] = __builtin_nontemporal_load(&src[i]);
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const int64_t i = i0 + u * stride;
+      if (i < n_units) __builtin_nontemporal_store(a[u], &dst[i]);
+    }
+  }
+}
+
 }  // namespace er
 
 // ------------------------------------------------------------------------------------------------
@@ -757,6 +807,36 @@ int er_emb_bwd_update(er_emb_group* g, int opt_kind, const er_opt_hyper* hyper, 
     if (int rc = er_adam_decay_sweep(g->var, g->m, g->v, g->bitmap, g->total_rows, g->dim, hyper, stream)) return rc;
     ER_CHECK_HIP(hipMemsetAsync(g->bitmap, 0, sizeof(uint32_t) * static_cast<size_t>(er::ceil_div(g->total_rows, 32)), s));
   }
+  return 0;
+}
+
+int er_stream_copy(const void* src, void* dst, int64_t bytes, er_stream_t stream) {
+  ER_REQUIRE(src && dst && bytes > 0 && bytes % 16 == 0, "er_stream_copy: bytes must be a positive multiple of 16");
+  ER_REQUIRE(((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0,
+             "er_stream_copy: pointers must be 16-byte aligned");
+  const int64_t units = bytes / 16;
+  int64_t blocks = er::ceil_div(units, static_cast<int64_t>(er::kBlock) * 4);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(er::stream_copy_kernel<4>, dim3(static_cast<int>(blocks)), dim3(er::kBlock), 0,
+                     er::as_stream(stream), reinterpret_cast<const er::f32x4*>(src), reinterpret_cast<er::f32x4*>(dst),
+                     units);
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
+int er_emb_mark_touched(er_emb_group* g, er_stream_t stream) {
+  ER_REQUIRE(g && g->bitmap, "er_emb_mark_touched: group has no touched bitmap");
+  hipLaunchKernelGGL(er::emb_mark_kernel, dim3(g->n_build_blocks), dim3(er::kBlock), 0, er::as_stream(stream),
+                     g->d_descs, g->d_blk_start, g->n, g->bitmap);
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
+int er_emb_sweep_untouched(er_emb_group* g, const er_opt_hyper* hyper, er_stream_t stream) {
+  ER_REQUIRE(g && hyper && g->bitmap && g->m && g->v, "er_emb_sweep_untouched: needs bitmap, m and v");
+  if (int rc = er_adam_decay_sweep(g->var, g->m, g->v, g->bitmap, g->total_rows, g->dim, hyper, stream)) return rc;
+  ER_CHECK_HIP(hipMemsetAsync(g->bitmap, 0, sizeof(uint32_t) * static_cast<size_t>(er::ceil_div(g->total_rows, 32)),
+                              er::as_stream(stream)));
   return 0;
 }
 

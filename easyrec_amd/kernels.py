@@ -223,6 +223,17 @@ class HipBackend(object):
              'er_emb_bwd_reduce')
     return keys, grads, n_unique
 
+  def emb_mark_touched(self, group):
+    self._ck(self.lib.er_emb_mark_touched(group['handle'], _stream()), 'er_emb_mark_touched')
+
+  def emb_sweep_untouched(self, group, hyper):
+    self._ck(self.lib.er_emb_sweep_untouched(group['handle'], _p(hyper), _stream()), 'er_emb_sweep_untouched')
+
+  def stream_copy(self, src, dst):
+    nbytes = src.numel() * src.element_size()
+    assert dst.numel() * dst.element_size() >= nbytes
+    self._ck(self.lib.er_stream_copy(_p(src), _p(dst), ctypes.c_int64(nbytes), _stream()), 'er_stream_copy')
+
   def adam_decay_sweep(self, var, m, v, bitmap, total_rows, dim, hyper):
     self._ck(
         self.lib.er_adam_decay_sweep(_p(var), _p(m), _p(v), _p(bitmap), ctypes.c_int64(total_rows),

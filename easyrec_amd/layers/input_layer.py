@@ -79,6 +79,8 @@ class EmbeddingEngine(object):
     self.sumsq = None
     self.reg_blocks = 0
     self._ran_version = -1
+    self._sweep_stream = None
+    self._sweep_pending = False
 
   # -- declaration (build pass)
   def declare_table(self, var_name, rows, dim, initializer=None):
@@ -242,13 +244,40 @@ class EmbeddingEngine(object):
     else:
       out.zero_()
 
+  # -- TF-exact Adam: the dense-decay sweep of the untouched rows, overlapped on a second stream
+  def start_decay_sweep(self, hyper):
+    """Call once the step's ids are on device (after DeviceFeatures.transform()).  Marks the rows the
+    step touches (main stream), then forks: the side stream sweeps every OTHER row of every table
+    group while the main stream runs forward/backward/row updates.  join_decay_sweep() joins."""
+    be = kernels.hip()
+    if self._sweep_stream is None:
+      self._sweep_stream = torch.cuda.Stream(device=self.device)
+    main = torch.cuda.current_stream()
+    for grp in self.emb_groups.values():
+      be.emb_mark_touched(grp)
+    self._sweep_stream.wait_stream(main)
+    with torch.cuda.stream(self._sweep_stream):
+      for grp in self.emb_groups.values():
+        be.emb_sweep_untouched(grp, hyper)
+    self._sweep_pending = True
+
+  def join_decay_sweep(self):
+    if self._sweep_pending:
+      torch.cuda.current_stream().wait_stream(self._sweep_stream)
+      self._sweep_pending = False
+
   def backward_update(self, opt_kind, hyper):
     be = kernels.hip()
     for g in self.groups.values():
       if not g['got_grad']:
         g['dout'].zero_()
+    if opt_kind == kernels.OPT_ADAM and self._sweep_pending:
+      # the sweep of the untouched rows is already in flight on the side stream; the touched rows
+      # get the same per-row arithmetic as TF's sparse apply (== the lazy row update)
+      opt_kind = kernels.OPT_LAZY_ADAM
     for dim, grp in self.emb_groups.items():
       be.emb_bwd_update(grp, opt_kind, hyper)
+    self.join_decay_sweep()
 
   # -- host exchange
   def state_dict(self, slots=False):

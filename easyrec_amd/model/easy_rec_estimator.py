@@ -37,13 +37,16 @@ class EasyRecEstimator(object):
   HYPER_SLOTS = 4096
 
   def __init__(self, pipeline_config, device='cuda', batch_size=None, seed=0, schema_kwargs=None,
-               is_training=True):
+               is_training=True, overlap_sweep=True):
     import_all_models()
     self.pipeline_config = config_util.get_configs_from_pipeline_file(pipeline_config) \
         if isinstance(pipeline_config, str) else pipeline_config
     self.device = torch.device(device)
     self.seed = seed
     self.is_training = is_training
+    # TF-exact Adam: run the dense-decay sweep of the untouched rows on a second stream (see
+    # EmbeddingEngine.start_decay_sweep); False = sequential sweep inside er_emb_bwd_update
+    self.overlap_sweep = overlap_sweep and torch.device(device).type == 'cuda'
     cfg = self.pipeline_config
     self.feature_configs = config_util.get_compatible_feature_configs(cfg)
     self.schema = FeatureSchema(cfg.data_config, self.feature_configs, batch_size=batch_size,
@@ -142,6 +145,8 @@ class EasyRecEstimator(object):
     be = kernels.hip()
     be.hyper_select(self.hyper_table, self.step_counter, self.hyper)
     self.features.transform()
+    if self.is_training and self.overlap_sweep and self.opt_emb.kind == kernels.OPT_ADAM:
+      self.engine.start_decay_sweep(self.hyper[0])
     self.varstore.zero_grad()
     with context.use(self.ctx):
       self.model.begin_step()

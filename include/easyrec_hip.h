@@ -165,10 +165,25 @@ int er_emb_bwd_update(er_emb_group* group, int opt_kind, const er_opt_hyper* hyp
  * and by embedding-parallel training (grads are sent to the row owner instead of applied). */
 int er_emb_bwd_reduce(er_emb_group* group, uint32_t* unique_keys, float* unique_grads,
                       int32_t* n_unique, er_stream_t stream);
+/* TF-exact Adam with the sweep OVERLAPPED (two streams).  The rows a step touches are known as soon as
+ * its ids are (before the forward): er_emb_mark_touched sets their bitmap bits; er_emb_sweep_untouched
+ * then decays every other row (m*=beta1, v*=beta2, var-=lr_t*m/(sqrt(v)+eps): what
+ * tf.train.AdamOptimizer._apply_sparse does to rows absent from the IndexedSlices) and clears the
+ * bitmap.  Untouched rows are neither read by this step's lookups nor written by its row updates, so
+ * the sweep may run on a second stream concurrently with forward/backward; the touched rows are then
+ * updated by er_emb_bwd_update(..., ER_OPT_LAZY_ADAM, ...) (identical per-row arithmetic).  Both must
+ * complete before the next step's lookups. */
+int er_emb_mark_touched(er_emb_group* group, er_stream_t stream);
+int er_emb_sweep_untouched(er_emb_group* group, const er_opt_hyper* hyper, er_stream_t stream);
 /* ER_OPT_ADAM's dense-decay sweep alone (exposed for benchmarking / roofline measurement). */
 int er_adam_decay_sweep(float* var, float* m, float* v, uint32_t* touched_bitmap,
                         int64_t total_rows, int32_t dim, const er_opt_hyper* hyper,
                         er_stream_t stream);
+/* Bandwidth probe: dst[0:bytes] = src[0:bytes] with the sweep's access pattern (16 B/lane, nontemporal,
+ * grid-stride).  Moves exactly 2*bytes of HBM traffic: calibrates rocprofv3 FETCH_SIZE/WRITE_SIZE and
+ * gives the achievable copy bandwidth quoted next to the 8 TB/s spec peak. */
+int er_stream_copy(const void* src, void* dst, int64_t bytes, er_stream_t stream);
+
 /* --------------------------------------------------------------------------------------------
  * K5  FM second-order interaction + wide sum.  Replaces Pack/Sum/Square/Sub/Mul of
  *     FM.__call__ easy_rec/python/layers/fm.py:20-26 (keras variant layers/keras/interaction.py:24-44)

@@ -393,13 +393,18 @@ class OracleTrainer(object):
           # python-graph sparse apply (IndexedSlices): tf AdamOptimizer decays every row;
           # AdamOptimizerS (lazy) only the rows present in the gradient.
           if o['kind'] == 'lazy_adam_optimizer':
-            rows = self._touched.get(id(t), np.zeros(var.shape[0], dtype=bool))
+            rows = np.flatnonzero(self._touched.get(id(t), np.zeros(var.shape[0], dtype=bool)))
+            m_t = m[rows] * b1 + g[rows] * (one - b1)
+            v_t = v[rows] * b2 + (g[rows] * g[rows]) * (one - b2)
+            var[rows] = var[rows] - (lr_t * m_t) / (np.sqrt(v_t, dtype=np.float32) + eps)
+            m[rows], v[rows] = m_t, v_t
           else:
-            rows = np.ones(var.shape[0], dtype=bool)
-          m_t = m[rows] * b1 + g[rows] * (one - b1)
-          v_t = v[rows] * b2 + (g[rows] * g[rows]) * (one - b2)
-          var[rows] = var[rows] - (lr_t * m_t) / (np.sqrt(v_t, dtype=np.float32) + eps)
-          m[rows], v[rows] = m_t, v_t
+            # every row: the same fp32 operations in the same order, as in-place multi-threaded torch-CPU
+            # passes over the numpy buffers (this is the timed CPU baseline of bench.py)
+            tm, tv, tvar, tg = (torch.from_numpy(a) for a in (m, v, var, g))
+            tm.mul_(float(b1)).add_(tg * float(one - b1))
+            tv.mul_(float(b2)).add_((tg * tg) * float(one - b2))
+            tvar.sub_((tm * float(lr_t)) / (tv.sqrt() + float(eps)))
         else:
           # training_ops.apply_adam
           m[:] = m + (g - m) * (one - b1)

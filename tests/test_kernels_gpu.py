@@ -226,6 +226,53 @@ def test_emb_bwd_long_runs_and_reduce(hip, ref):
   hip.emb_group_destroy(gd)
 
 
+def test_overlapped_sweep_equals_sequential_adam(hip):
+  """TF-exact Adam split over two streams (mark touched rows -> side stream sweeps the others while
+  the main stream updates the touched rows) must give the same bits as the sequential ER_OPT_ADAM."""
+  rng = np.random.default_rng(77)
+  B, dims = 300, (16, 1)
+  _, sd, _, std, _, od, group_rows = _make_lookup_problem(rng, B, dims, DEV)
+  dd = torch.from_numpy((rng.standard_normal(tuple(od.shape)) * 0.01).astype(np.float32)).to(DEV)
+  hyper = _hyper(lr=0.05, t=3, gscale=0.5).to(DEV)
+  side = torch.cuda.Stream()
+  for dim, total in group_rows.items():
+    m0 = torch.from_numpy((rng.random((total, dim)) * 0.01).astype(np.float32)).to(DEV)
+    v0 = torch.from_numpy((rng.random((total, dim)) * 0.01 + 1e-4).astype(np.float32)).to(DEV)
+    res = []
+    for mode in ('sequential', 'overlapped'):
+      var, m, v = std[dim].clone(), m0.clone(), v0.clone()
+      bitmap = torch.zeros((total + 31) // 32, dtype=torch.int32, device=DEV)
+      specs = [kernels.LookupSpec(table=var[s.key_base:s.key_base + s.rows], ids=s.ids, offsets=s.offsets,
+                                  weights=s.weights, out=dd, out_col=s.out_col, rows=s.rows, key_base=s.key_base,
+                                  dim=s.dim, combiner=s.combiner, n_rows=s.n_rows, max_nnz=s.max_nnz)
+               for s in sd if s.dim == dim]
+      g = hip.emb_group_create(specs, dim, total, var, m, v, bitmap)
+      for _ in range(3):
+        if mode == 'sequential':
+          hip.emb_bwd_update(g, kernels.OPT_ADAM, hyper)
+        else:
+          hip.emb_mark_touched(g)
+          side.wait_stream(torch.cuda.current_stream())
+          with torch.cuda.stream(side):
+            hip.emb_sweep_untouched(g, hyper)
+          hip.emb_bwd_update(g, kernels.OPT_LAZY_ADAM, hyper)
+          torch.cuda.current_stream().wait_stream(side)
+      torch.cuda.synchronize()
+      assert int(bitmap.abs().sum()) == 0
+      res.append((var, m, v))
+      hip.emb_group_destroy(g)
+    for a, b in zip(res[0], res[1]):
+      assert torch.equal(a, b)
+
+
+def test_stream_copy(hip):
+  src = torch.randn(1 << 20, device=DEV)
+  dst = torch.zeros_like(src)
+  hip.stream_copy(src, dst)
+  torch.cuda.synchronize()
+  assert torch.equal(src, dst)
+
+
 @pytest.mark.parametrize('dim,rows', [(16, 100003), (1, 50001), (3, 1001), (64, 4097)])
 def test_adam_decay_sweep_bit_exact(hip, ref, dim, rows):
   rng = np.random.default_rng(dim)
