@@ -38,6 +38,7 @@ def parse_args():
   ap.add_argument('--optimizer', default='config', choices=['config', 'adam', 'lazy_adam'])
   ap.add_argument('--no_graph', action='store_true', help='eager launches instead of hipGraph replay')
   ap.add_argument('--no_cpu_baseline', action='store_true')
+  ap.add_argument('--overlap', action='store_true', help='TF-exact Adam: dense-decay sweep on a second stream (measured slower)')
   ap.add_argument('--cpu_seconds', type=float, default=12.0, help='time budget of the CPU baseline sample')
   ap.add_argument('--ring', type=int, default=16, help='distinct pre-generated batches kept on device')
   return ap.parse_args()
@@ -166,7 +167,7 @@ def main():
     from easyrec_amd.model.embedding_parallel import EmbeddingParallelEstimator
     est = EmbeddingParallelEstimator(cfg, device=dev, batch_size=B, seed=1, rank=rank, world=world).build()
   else:
-    est = EasyRecEstimator(cfg, device=dev, batch_size=B, seed=1).build()
+    est = EasyRecEstimator(cfg, device=dev, batch_size=B, seed=1, overlap_sweep=args.overlap).build()
   gen = SyntheticCriteo(cfg.data_config, est.feature_configs, batch_size=B, seed=20240607 + rank, mode=args.ids)
   host_batches = [gen.next_batch() for _ in range(args.ring)]
   ring = [to_device_batch(b, dev) for b in host_batches]

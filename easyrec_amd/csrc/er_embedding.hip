@@ -764,12 +764,29 @@ static int emb_group_run(er_emb_group* g, int opt_kind, const er_opt_hyper* hype
   return 0;
 }
 
+// Workgroups per CU of the dense-decay sweep.  8 (the default) fills every wave slot and is right
+// when the sweep runs alone; when it is overlapped with the latency-bound forward/backward kernels on
+// another stream it must leave wave slots free or those kernels queue behind the sweep's
+// long-running grid-stride blocks (measured).
+static int g_sweep_blocks_per_cu = 8;
+
+int er_config_set(const char* key, int64_t value) {
+  ER_REQUIRE(key, "er_config_set: null key");
+  if (strcmp(key, "sweep_blocks_per_cu") == 0) {
+    ER_REQUIRE(value >= 1 && value <= 8, "er_config_set: sweep_blocks_per_cu must be in 1..8");
+    g_sweep_blocks_per_cu = static_cast<int>(value);
+    return 0;
+  }
+  ER_REQUIRE(false, "er_config_set: unknown key %s", key);
+  return 2;
+}
+
 int er_adam_decay_sweep(float* var, float* m, float* v, uint32_t* bitmap, int64_t total_rows, int32_t dim,
                         const er_opt_hyper* hyper, er_stream_t stream) {
   ER_REQUIRE(var && m && v && hyper && total_rows > 0 && dim > 0, "er_adam_decay_sweep: bad arguments");
   hipStream_t s = er::as_stream(stream);
   constexpr int U = 4;
-  const int max_blocks = 256 * 8;
+  const int max_blocks = 256 * g_sweep_blocks_per_cu;
   if (dim % 4 == 0) {
     const int64_t units = total_rows * (dim / 4);
     int64_t blocks = er::ceil_div(units, static_cast<int64_t>(er::kBlock) * U);

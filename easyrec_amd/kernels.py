@@ -123,6 +123,9 @@ class HipBackend(object):
   def reserve_scratch(self, floats):
     self._ck(self.lib.er_reserve_scratch(ctypes.c_int64(int(floats))), 'er_reserve_scratch')
 
+  def config_set(self, key, value):
+    self._ck(self.lib.er_config_set(key.encode(), ctypes.c_int64(int(value))), 'er_config_set')
+
   def device_info(self):
     cu, wave = ctypes.c_int(0), ctypes.c_int(0)
     buf = ctypes.create_string_buffer(64)

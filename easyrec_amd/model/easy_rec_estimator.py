@@ -16,6 +16,7 @@ optimizer) can be captured into one hipGraph (`capture()`), because every buffer
 and per-step scalars are read from device memory.
 """
 import logging
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -37,15 +38,18 @@ class EasyRecEstimator(object):
   HYPER_SLOTS = 4096
 
   def __init__(self, pipeline_config, device='cuda', batch_size=None, seed=0, schema_kwargs=None,
-               is_training=True, overlap_sweep=True):
+               is_training=True, overlap_sweep=False):
     import_all_models()
     self.pipeline_config = config_util.get_configs_from_pipeline_file(pipeline_config) \
         if isinstance(pipeline_config, str) else pipeline_config
     self.device = torch.device(device)
     self.seed = seed
     self.is_training = is_training
-    # TF-exact Adam: run the dense-decay sweep of the untouched rows on a second stream (see
-    # EmbeddingEngine.start_decay_sweep); False = sequential sweep inside er_emb_bwd_update
+    # TF-exact Adam: True = run the dense-decay sweep of the untouched rows on a second stream (see
+    # EmbeddingEngine.start_decay_sweep); False (default) = sequential sweep inside er_emb_bwd_update.
+    # Measured on MI355X (profiles/r01_overlap_knob.txt): the overlapped step is SLOWER (3.8 ms vs
+    # 2.74 ms) - the HBM-saturating sweep stretches the latency-bound forward/backward kernels more
+    # than it hides - so the sequential order is the default.
     self.overlap_sweep = overlap_sweep and torch.device(device).type == 'cuda'
     cfg = self.pipeline_config
     self.feature_configs = config_util.get_compatible_feature_configs(cfg)
@@ -96,6 +100,8 @@ class EasyRecEstimator(object):
     """Build pass (creates variables / declares tables), then allocate + pack everything."""
     assert not self._built
     kernels.hip().reserve_scratch(1 << 22)
+    if self.overlap_sweep and self.opt_emb.kind == kernels.OPT_ADAM:
+      kernels.hip().config_set('sweep_blocks_per_cu', int(os.environ.get('ER_SWEEP_BLOCKS_PER_CU', '3')))
     self.ctx.building = True
     with context.use(self.ctx):
       self.model.begin_step()

@@ -39,6 +39,9 @@ const char* er_last_error(void);
 /* Pre-size the library's internal column-reduction scratch (floats).  Call once before capturing
  * a hipGraph: growing it calls hipMalloc, which is not capturable. */
 int er_reserve_scratch(int64_t floats);
+/* Tuning knobs (process-wide).  Keys: "sweep_blocks_per_cu" (1..8, default 8): workgroups per CU of the
+ * dense-decay sweep; lower it when the sweep overlaps other kernels on a second stream. */
+int er_config_set(const char* key, int64_t value);
 /* number of compute units / XCDs of the current device (launch sizing, reported by bench) */
 int er_device_info(int* cu_count, int* wave_size, char* arch_name, int arch_name_len);
 
