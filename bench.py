@@ -38,6 +38,7 @@ def parse_args():
   ap.add_argument('--optimizer', default='config', choices=['config', 'adam', 'lazy_adam'])
   ap.add_argument('--no_graph', action='store_true', help='eager launches instead of hipGraph replay')
   ap.add_argument('--no_cpu_baseline', action='store_true')
+  ap.add_argument('--force_ep', action='store_true', help='run the embedding-parallel code path even at 1 GPU')
   ap.add_argument('--overlap', action='store_true', help='TF-exact Adam: dense-decay sweep on a second stream (measured slower)')
   ap.add_argument('--cpu_seconds', type=float, default=12.0, help='time budget of the CPU baseline sample')
   ap.add_argument('--ring', type=int, default=16, help='distinct pre-generated batches kept on device')
@@ -163,7 +164,7 @@ def main():
   if args.optimizer != 'config':
     switch_optimizer(cfg, args.optimizer)
   B = args.batch_size or cfg.data_config.batch_size
-  if world > 1:
+  if world > 1 or args.force_ep:
     from easyrec_amd.model.embedding_parallel import EmbeddingParallelEstimator
     est = EmbeddingParallelEstimator(cfg, device=dev, batch_size=B, seed=1, rank=rank, world=world).build()
   else:
@@ -173,7 +174,8 @@ def main():
   ring = [to_device_batch(b, dev) for b in host_batches]
   est.features.load(ring[0])
   torch.cuda.synchronize()
-  if not args.no_graph:
+  ep = world > 1 or args.force_ep
+  if not args.no_graph and not ep:
     est.capture(warmup=3)
 
   def barrier():
@@ -219,14 +221,14 @@ def main():
           'workload': 'DeepFM synthetic Criteo: %s (39 features: 26 hashed x %d rows + 13 projected, D=16 deep + '
                       'D=1 wide, batch %d per GPU, optimizer %s, ids %s, %s)' %
                       (os.path.basename(args.config), cfg.feature_config.features[13].hash_bucket_size, B,
-                       est.opt_emb.name, args.ids, 'eager launches' if args.no_graph else 'hipGraph replay'),
+                       est.opt_emb.name, args.ids, 'eager launches' if (args.no_graph or ep) else 'hipGraph replay'),
           'global_batch': world * B,
           'parallelism': 'single GPU' if world == 1 else 'embedding-parallel x%d (row-sharded tables, RCCL all-to-all) + dense DP' % world,
       },
       'final_loss': losses.get('total_loss'),
       'device': kernels.hip().device_info(),
   }
-  if world == 1:
+  if world == 1 and not ep:
     lazy_bytes, sweep_bytes = embedding_bytes_per_step(est, ring)
     out['embedding_stage'] = {
         'algorithmic_bytes_per_step': lazy_bytes + sweep_bytes,

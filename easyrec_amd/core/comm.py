@@ -1,0 +1,84 @@
+"""Collectives of the embedding-parallel path: one process per GPU, RCCL over xGMI.
+
+The reference issues these through Horovod (`hvd.alltoall(ids, splits)`, `hvd.alltoall(rows, ...)`,
+`hvd.allreduce(grad, op=Average)`; compat/feature_column/feature_column.py:296-357,
+compat/optimizers.py:285-345).  Here they are `torch.distributed` calls on device tensors: backend
+"nccl" IS RCCL on ROCm; the CPU tests use "gloo".  Only four operations exist:
+
+  exchange_counts   all-gather of a small [G, W] int32 matrix of per-owner unique-key counts ->
+                    host-side send/recv split lists (the ONE host synchronisation of a step)
+  all_to_all        variable-split exchange of keys (int32), rows and gradient rows (fp32, [n, dim])
+  all_reduce_sum    dense gradients / replicated small tables (scaled by 1/W in the optimizer kernels)
+  all_gather_rows   checkpoint/test only: collect the shards of a table
+
+Messages are small at B=4096 (<= 1 MB per peer), i.e. latency-bound on xGMI's point-to-point links;
+they are issued per embedding-dim group so that a step has 3 all-to-alls per group.
+"""
+import torch
+
+
+class LocalComm(object):
+  """world == 1: every exchange is a local copy (the single-GPU degenerate of the same code path)."""
+
+  rank = 0
+  world = 1
+
+  def exchange_counts(self, counts):
+    c = counts.cpu().tolist()
+    return c, c
+
+  def all_to_all(self, send, send_splits, recv, recv_splits):
+    n = int(send_splits[0])
+    assert n == int(recv_splits[0])
+    if n:
+      recv[:n].copy_(send[:n])
+
+  def all_reduce_sum(self, t):
+    return t
+
+  def all_gather_rows(self, t):
+    return [t]
+
+  def barrier(self):
+    pass
+
+
+class TorchDistComm(object):
+  """torch.distributed process group (nccl = RCCL on the MI355X node, gloo in the CPU tests)."""
+
+  def __init__(self, group=None):
+    import torch.distributed as dist
+    assert dist.is_initialized(), 'init_process_group first (bench.py / the launcher does it)'
+    self.dist = dist
+    self.group = group
+    self.rank = dist.get_rank(group)
+    self.world = dist.get_world_size(group)
+
+  def exchange_counts(self, counts):
+    """counts: int32 [G, W] on device: counts[g, w] = unique keys of dim-group g this rank sends to w.
+    Returns (send[g][w], recv[g][src]) as python ints."""
+    G, W = counts.shape
+    assert W == self.world
+    gathered = torch.empty(self.world, G, W, dtype=counts.dtype, device=counts.device)
+    self.dist.all_gather_into_tensor(gathered.view(-1), counts.contiguous().view(-1), group=self.group)
+    allc = gathered.cpu()  # host sync: the split sizes of the following all-to-alls
+    send = allc[self.rank].tolist()
+    recv = allc[:, :, self.rank].t().contiguous().tolist()
+    return send, recv
+
+  def all_to_all(self, send, send_splits, recv, recv_splits):
+    ns, nr = int(sum(send_splits)), int(sum(recv_splits))
+    self.dist.all_to_all_single(recv[:nr], send[:ns], output_split_sizes=[int(x) for x in recv_splits],
+                                input_split_sizes=[int(x) for x in send_splits], group=self.group)
+
+  def all_reduce_sum(self, t):
+    self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+    return t
+
+  def all_gather_rows(self, t):
+    out = [torch.empty_like(t) for _ in range(self.world)]
+    self.dist.all_gather(out, t.contiguous(), group=self.group)
+    return out
+
+  def barrier(self):
+    self.dist.barrier(group=self.group)

@@ -5,8 +5,16 @@ and UPDATE_OPS collections (model/easy_rec_estimator.py:166-213).  Layers here f
 `VarStore` and the `EmbeddingEngine` of the model being built/executed from this context.
 """
 import contextlib
+import threading
 
-_STACK = []
+_TLS = threading.local()  # one context stack per thread (tests run several ranks as threads)
+
+
+def _stack():
+  st = getattr(_TLS, 'stack', None)
+  if st is None:
+    st = _TLS.stack = []
+  return st
 
 
 class ModelContext(object):
@@ -20,16 +28,17 @@ class ModelContext(object):
 
 @contextlib.contextmanager
 def use(ctx):
-  _STACK.append(ctx)
+  _stack().append(ctx)
   try:
     yield ctx
   finally:
-    _STACK.pop()
+    _stack().pop()
 
 
 def current():
-  assert _STACK, 'no active easyrec_amd ModelContext (wrap model calls in core.context.use(ctx))'
-  return _STACK[-1]
+  st = _stack()
+  assert st, 'no active easyrec_amd ModelContext (wrap model calls in core.context.use(ctx))'
+  return st[-1]
 
 
 def varstore():

@@ -129,15 +129,32 @@ emb_fwd_kernel(const er_lookup_desc* __restrict__ descs, const int32_t* __restri
 // backward: entries, sort, reduce, apply
 // ------------------------------------------------------------------------------------------------
 // One thread per output row of one lookup: emits (key, grad pointer, scale) for every id of the row.
+// Row sharding of embedding-parallel training (reference compat/feature_column/feature_column.py:296,317,
+// 461-463): owner = id mod world, local row = id div world.  The routed key of an entry is
+// owner * shard_stride + local_base[lookup] + id div world, so that one ascending sort groups the
+// entries by owner and, inside an owner, by the row of the owner's shard storage.  world == 1 gives
+// key = key_base + id (local_base == key_base): the single-GPU layout.
+struct Route {
+  int32_t world;
+  int64_t shard_stride;
+  const int64_t* local_base;  // [n_lookups] (device) or nullptr when world == 1
+};
+
+__device__ __forceinline__ uint32_t routed_key(const er_lookup_desc& d, const Route& rt, int l, int64_t id) {
+  if (rt.local_base == nullptr) return static_cast<uint32_t>(d.key_base + id);
+  const int64_t owner = id % rt.world;
+  return static_cast<uint32_t>(owner * rt.shard_stride + rt.local_base[l] + id / rt.world);
+}
+
 __global__ void __launch_bounds__(kBlock)
 emb_bwd_build_kernel(const er_lookup_desc* __restrict__ descs, const int32_t* __restrict__ blk_start,
-                     const int64_t* __restrict__ ent_base, int n_lookups, uint32_t* __restrict__ keys,
-                     uint32_t* __restrict__ vals, const float** __restrict__ ent_gptr,
-                     float* __restrict__ ent_scale) {
+                     const int64_t* __restrict__ ent_base, int n_lookups, Route rt, int64_t n_active,
+                     uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                     const float** __restrict__ ent_gptr, float* __restrict__ ent_scale) {
   const int l = find_lookup(blk_start, n_lookups, blockIdx.x);
   const er_lookup_desc d = descs[l];
   const int r = (blockIdx.x - blk_start[l]) * kBlock + static_cast<int>(threadIdx.x);
-  if (r >= d.n_rows) return;
+  if (r >= d.n_rows || r >= n_active) return;
   int64_t kb, ke;
   if (d.offsets) {
     kb = d.offsets[r];
@@ -169,7 +186,7 @@ emb_bwd_build_kernel(const er_lookup_desc* __restrict__ descs, const int32_t* __
     const float w = d.weights ? d.weights[k] : 1.f;
     bool ok = !(id < 0 || id >= d.rows);
     if (prune_nonpos && !(w > 0.f)) ok = false;
-    keys[j] = ok ? static_cast<uint32_t>(d.key_base + id) : kInvalidKey;
+    keys[j] = ok ? routed_key(d, rt, l, id) : kInvalidKey;
     vals[j] = static_cast<uint32_t>(j);
     ent_gptr[j] = gp;
     ent_scale[j] = w / den;
@@ -181,11 +198,11 @@ emb_bwd_build_kernel(const er_lookup_desc* __restrict__ descs, const int32_t* __
 // stream: untouched rows are neither read by this step's lookup nor written by its row updates.
 __global__ void __launch_bounds__(kBlock)
 emb_mark_kernel(const er_lookup_desc* __restrict__ descs, const int32_t* __restrict__ blk_start, int n_lookups,
-                uint32_t* __restrict__ bitmap) {
+                int64_t n_active, uint32_t* __restrict__ bitmap) {
   const int l = find_lookup(blk_start, n_lookups, blockIdx.x);
   const er_lookup_desc d = descs[l];
   const int r = (blockIdx.x - blk_start[l]) * kBlock + static_cast<int>(threadIdx.x);
-  if (r >= d.n_rows) return;
+  if (r >= d.n_rows || r >= n_active) return;
   int64_t kb, ke;
   if (d.offsets) {
     kb = d.offsets[r];
@@ -385,6 +402,70 @@ __global__ void emb_count_unique_kernel(const uint32_t* __restrict__ flags, cons
   if (threadIdx.x == 0 && blockIdx.x == 0) *n_unique = static_cast<int32_t>(head_index[n - 1] + flags[n - 1]);
 }
 
+// Embedding-parallel routing: per sorted position p the index of its run among the valid runs
+// (= index into the de-duplicated key list) is head_index[p] + flags[p] - 1.  Writes the unique keys
+// (ascending = grouped by owner) and, per ENTRY (source order), the index of its unique key, or -1.
+__global__ void __launch_bounds__(kBlock)
+emb_route_kernel(const uint32_t* __restrict__ skeys, const uint32_t* __restrict__ svals,
+                 const uint32_t* __restrict__ flags, const uint32_t* __restrict__ head_index, int64_t n,
+                 uint32_t* __restrict__ unique_keys, int64_t* __restrict__ uidx) {
+  const int64_t p = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (p >= n) return;
+  const uint32_t key = skeys[p];
+  const uint32_t j = svals[p];
+  if (key == kInvalidKey) {
+    uidx[j] = -1;
+    return;
+  }
+  const uint32_t u = head_index[p] + flags[p] - 1u;
+  uidx[j] = static_cast<int64_t>(u);
+  if (flags[p]) unique_keys[u] = key;
+}
+
+// counts[w] = number of unique keys owned by rank w (keys in [w*stride, (w+1)*stride)).
+__global__ void emb_owner_counts_kernel(const uint32_t* __restrict__ unique_keys, const int32_t* __restrict__ n_unique,
+                                        int world, int64_t stride, int32_t* __restrict__ counts) {
+  const int w = threadIdx.x;
+  if (w >= world) return;
+  const int n = *n_unique;
+  auto lower = [&](int64_t v) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (static_cast<int64_t>(unique_keys[mid]) < v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+  };
+  counts[w] = lower((w + 1) * stride) - lower(w * stride);
+}
+
+// out[i, :] = table[keys[i] - key_sub, :]  (owner side of the lookup exchange)
+template <int V>
+__global__ void __launch_bounds__(kBlock)
+gather_rows_kernel(const float* __restrict__ table, const uint32_t* __restrict__ keys, int64_t n, int dim, int G,
+                   int64_t key_sub, int64_t table_rows, float* __restrict__ out) {
+  const int64_t i = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) / G;
+  const int c = (static_cast<int>(threadIdx.x) % G) * V;
+  if (i >= n || c >= dim) return;
+  const int64_t row = static_cast<int64_t>(keys[i]) - key_sub;
+  Vec<V> e;
+  if (row >= 0 && row < table_rows) e.load(table + row * dim + c); else e.zero();
+  e.store(out + i * dim + c);
+}
+
+// dense[key, 0:dim] = grads[i, :], dense[key, dim] = 1 for the n (device scalar) unique keys of a
+// replicated table group: the rows are then all-reduced across ranks like dense parameters.
+__global__ void __launch_bounds__(kBlock)
+scatter_unique_kernel(const uint32_t* __restrict__ keys, const float* __restrict__ grads,
+                      const int32_t* __restrict__ n_unique, int dim, float* __restrict__ dense, int dense_stride) {
+  const int64_t t = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  const int64_t i = t / (dim + 1);
+  const int c = static_cast<int>(t % (dim + 1));
+  if (i >= *n_unique) return;
+  const int64_t row = keys[i];
+  dense[row * dense_stride + c] = (c < dim) ? grads[i * dim + c] : 1.f;
+}
+
 // ------------------------------------------------------------------------------------------------
 // TF-exact Adam: rows not touched this step still decay (m*=b1, v*=b2) and move.
 // Pure streaming kernel: 3 arrays read + 3 written, float4, grid-stride, 4 units in flight per lane.
@@ -563,6 +644,13 @@ struct er_emb_group {
   int64_t n_entries = 0;
   int key_bits = 32;
   bool has_ragged = false;
+  // embedding-parallel routing (world == 1: plain single-GPU keys) and the active prefix of a
+  // single dense-mode lookup (owner-side groups whose entry count changes per step)
+  int32_t world = 1;
+  int64_t shard_stride = 0;
+  int64_t* d_local_base = nullptr;
+  int64_t n_active = -1;  // -1: all entries
+  bool sorted_valid = false;
   float *var = nullptr, *m = nullptr, *v = nullptr;
   uint32_t* bitmap = nullptr;
   int n_build_blocks = 0;
@@ -715,7 +803,8 @@ int er_emb_group_update(er_emb_group* g, const er_lookup_desc* descs, int n) {
 int er_emb_group_destroy(er_emb_group* g) {
   if (!g) return 0;
   void* ptrs[] = {g->d_descs, g->d_blk_start, g->d_ent_base, g->keys_in, g->keys_out, g->vals_in, g->vals_out,
-                  g->ent_gptr, g->ent_scale, g->piece_sum, g->head_flags, g->head_index, g->sort_temp, g->scan_temp};
+                  g->ent_gptr, g->ent_scale, g->piece_sum, g->head_flags, g->head_index, g->sort_temp, g->scan_temp,
+                  g->d_local_base};
   for (void* q : ptrs) (void)hipFree(q);
   delete g;
   return 0;
@@ -723,14 +812,26 @@ int er_emb_group_destroy(er_emb_group* g) {
 
 int64_t er_emb_group_num_entries(const er_emb_group* g) { return g ? g->n_entries : -1; }
 
-static int emb_group_sort(er_emb_group* g, hipStream_t s) {
-  const int64_t N = g->n_entries;
+static int64_t group_entries(const er_emb_group* g) { return g->n_active >= 0 ? g->n_active : g->n_entries; }
+
+// build keys (routed) + stable radix sort.  Leaves keys_out/vals_out valid for this step.
+static int emb_group_build_sort(er_emb_group* g, hipStream_t s) {
+  const int64_t N = group_entries(g);
+  if (N == 0) return 0;
   if (g->has_ragged) ER_CHECK_HIP(hipMemsetAsync(g->keys_in, 0xFF, sizeof(uint32_t) * N, s));
+  er::Route rt{g->world, g->shard_stride, g->d_local_base};
+  const int64_t n_act = g->n_active >= 0 ? g->n_active : INT64_MAX;
   hipLaunchKernelGGL(er::emb_bwd_build_kernel, dim3(g->n_build_blocks), dim3(er::kBlock), 0, s, g->d_descs,
-                     g->d_blk_start, g->d_ent_base, g->n, g->keys_in, g->vals_in, g->ent_gptr, g->ent_scale);
+                     g->d_blk_start, g->d_ent_base, g->n, rt, n_act, g->keys_in, g->vals_in, g->ent_gptr, g->ent_scale);
   ER_LAUNCH_CHECK();
   ER_CHECK_HIP(rocprim::radix_sort_pairs(g->sort_temp, g->sort_temp_bytes, g->keys_in, g->keys_out, g->vals_in,
                                          g->vals_out, static_cast<size_t>(N), 0u, static_cast<unsigned>(g->key_bits), s));
+  return 0;
+}
+
+// level-1 pieces of the in-order segmented reduction (reads the upstream gradients)
+static int emb_group_pieces(er_emb_group* g, hipStream_t s) {
+  const int64_t N = group_entries(g);
   const int64_t n_bound = er::ceil_div(N, er::kChunk) - 1;  // chunk boundaries
   if (n_bound > 0) {
     const int blocks = static_cast<int>(er::ceil_div(n_bound * g->G, er::kBlock));
@@ -746,9 +847,28 @@ static int emb_group_sort(er_emb_group* g, hipStream_t s) {
   return 0;
 }
 
+static int emb_group_sort(er_emb_group* g, hipStream_t s) {
+  if (int rc = emb_group_build_sort(g, s)) return rc;
+  return emb_group_pieces(g, s);
+}
+
+// head flags + exclusive scan + unique count over the sorted keys
+static int emb_group_heads(er_emb_group* g, int32_t* n_unique, hipStream_t s) {
+  const int64_t N = group_entries(g);
+  hipLaunchKernelGGL(er::emb_head_flag_kernel, dim3(static_cast<int>(er::ceil_div(N, er::kBlock))), dim3(er::kBlock), 0,
+                     s, g->keys_out, N, g->head_flags);
+  ER_LAUNCH_CHECK();
+  ER_CHECK_HIP(rocprim::exclusive_scan(g->scan_temp, g->scan_temp_bytes, g->head_flags, g->head_index, 0u,
+                                       static_cast<size_t>(N), rocprim::plus<uint32_t>(), s));
+  hipLaunchKernelGGL(er::emb_count_unique_kernel, dim3(1), dim3(64), 0, s, g->head_flags, g->head_index, N, n_unique);
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
 static int emb_group_run(er_emb_group* g, int opt_kind, const er_opt_hyper* hyper, int mode, uint32_t* out_keys,
                          float* out_grads, hipStream_t s) {
-  const int64_t N = g->n_entries;
+  const int64_t N = group_entries(g);
+  if (N == 0) return 0;
   const int blocks = static_cast<int>(er::ceil_div(N * g->G, er::kBlock));
   er::RowUpdate tab{g->var, g->m, g->v, g->bitmap};
   if (g->V == 4) {
@@ -843,8 +963,9 @@ int er_stream_copy(const void* src, void* dst, int64_t bytes, er_stream_t stream
 
 int er_emb_mark_touched(er_emb_group* g, er_stream_t stream) {
   ER_REQUIRE(g && g->bitmap, "er_emb_mark_touched: group has no touched bitmap");
+  const int64_t n_act = g->n_active >= 0 ? g->n_active : INT64_MAX;
   hipLaunchKernelGGL(er::emb_mark_kernel, dim3(g->n_build_blocks), dim3(er::kBlock), 0, er::as_stream(stream),
-                     g->d_descs, g->d_blk_start, g->n, g->bitmap);
+                     g->d_descs, g->d_blk_start, g->n, n_act, g->bitmap);
   ER_LAUNCH_CHECK();
   return 0;
 }
@@ -861,16 +982,97 @@ int er_emb_bwd_reduce(er_emb_group* g, uint32_t* unique_keys, float* unique_grad
                       er_stream_t stream) {
   ER_REQUIRE(g && unique_keys && unique_grads && n_unique, "er_emb_bwd_reduce: null argument");
   hipStream_t s = er::as_stream(stream);
+  if (group_entries(g) == 0) {
+    ER_CHECK_HIP(hipMemsetAsync(n_unique, 0, sizeof(int32_t), s));
+    return 0;
+  }
   if (int rc = emb_group_sort(g, s)) return rc;
-  const int64_t N = g->n_entries;
-  hipLaunchKernelGGL(er::emb_head_flag_kernel, dim3(static_cast<int>(er::ceil_div(N, er::kBlock))), dim3(er::kBlock), 0,
-                     s, g->keys_out, N, g->head_flags);
-  ER_LAUNCH_CHECK();
-  ER_CHECK_HIP(rocprim::exclusive_scan(g->scan_temp, g->scan_temp_bytes, g->head_flags, g->head_index, 0u,
-                                       static_cast<size_t>(N), rocprim::plus<uint32_t>(), s));
-  hipLaunchKernelGGL(er::emb_count_unique_kernel, dim3(1), dim3(64), 0, s, g->head_flags, g->head_index, N, n_unique);
-  ER_LAUNCH_CHECK();
+  if (int rc = emb_group_heads(g, n_unique, s)) return rc;
   return emb_group_run(g, ER_OPT_SGD, nullptr, 1, unique_keys, unique_grads, s);
+}
+
+int er_emb_group_set_routing(er_emb_group* g, int32_t world, int64_t shard_stride, const int64_t* local_base_host) {
+  ER_REQUIRE(g && world >= 1 && local_base_host, "er_emb_group_set_routing: bad arguments");
+  ER_REQUIRE(shard_stride > 0 && static_cast<int64_t>(world) * shard_stride < 0xFFFFFFFFLL,
+             "er_emb_group_set_routing: world * shard_stride = %lld does not fit 32-bit keys",
+             (long long)(world * shard_stride));
+  if (!g->d_local_base) ER_CHECK_HIP(hipMalloc(&g->d_local_base, sizeof(int64_t) * g->n));
+  ER_CHECK_HIP(hipMemcpy(g->d_local_base, local_base_host, sizeof(int64_t) * g->n, hipMemcpyHostToDevice));
+  g->world = world;
+  g->shard_stride = shard_stride;
+  const int64_t span = static_cast<int64_t>(world) * shard_stride;
+  g->key_bits = 1;
+  while ((1LL << g->key_bits) <= span) ++g->key_bits;
+  // the temporary storage of the radix sort does not depend on the bit range
+  return 0;
+}
+
+int er_emb_group_set_active(er_emb_group* g, int64_t n_rows) {
+  ER_REQUIRE(g, "er_emb_group_set_active: null group");
+  ER_REQUIRE(g->n == 1 && !g->has_ragged, "er_emb_group_set_active: needs a group of ONE dense-mode lookup");
+  ER_REQUIRE(n_rows >= 0 && n_rows <= g->n_entries, "er_emb_group_set_active: %lld rows exceed the capacity %lld",
+             (long long)n_rows, (long long)g->n_entries);
+  g->n_active = n_rows;
+  return 0;
+}
+
+int er_emb_route(er_emb_group* g, uint32_t* unique_keys, int32_t* n_unique, int64_t* entry_unique_index,
+                 int32_t* owner_counts, er_stream_t stream) {
+  ER_REQUIRE(g && unique_keys && n_unique && entry_unique_index && owner_counts, "er_emb_route: null argument");
+  ER_REQUIRE(g->world <= 64, "er_emb_route: world %d > 64", g->world);
+  hipStream_t s = er::as_stream(stream);
+  const int64_t N = group_entries(g);
+  ER_REQUIRE(N > 0, "er_emb_route: empty group");
+  if (int rc = emb_group_build_sort(g, s)) return rc;
+  if (int rc = emb_group_heads(g, n_unique, s)) return rc;
+  hipLaunchKernelGGL(er::emb_route_kernel, dim3(static_cast<int>(er::ceil_div(N, er::kBlock))), dim3(er::kBlock), 0, s,
+                     g->keys_out, g->vals_out, g->head_flags, g->head_index, N, unique_keys, entry_unique_index);
+  ER_LAUNCH_CHECK();
+  const int64_t stride = g->d_local_base ? g->shard_stride : g->total_rows;
+  hipLaunchKernelGGL(er::emb_owner_counts_kernel, dim3(1), dim3(64), 0, s, unique_keys, n_unique, g->world, stride,
+                     owner_counts);
+  ER_LAUNCH_CHECK();
+  g->sorted_valid = true;
+  return 0;
+}
+
+int er_emb_bwd_reduce_routed(er_emb_group* g, float* unique_grads, er_stream_t stream) {
+  ER_REQUIRE(g && unique_grads, "er_emb_bwd_reduce_routed: null argument");
+  ER_REQUIRE(g->sorted_valid, "er_emb_bwd_reduce_routed: call er_emb_route for this step first");
+  hipStream_t s = er::as_stream(stream);
+  if (int rc = emb_group_pieces(g, s)) return rc;
+  // unique keys were already written by er_emb_route: out_keys is a scratch sink here
+  return emb_group_run(g, ER_OPT_SGD, nullptr, 1, g->keys_in, unique_grads, s);
+}
+
+int er_gather_rows(const float* table, int64_t table_rows, int32_t dim, const uint32_t* keys, int64_t n,
+                   int64_t key_sub, float* out, er_stream_t stream) {
+  ER_REQUIRE(table && keys && out && dim > 0 && n >= 0, "er_gather_rows: bad arguments");
+  if (n == 0) return 0;
+  int V, G;
+  er::lane_geom(dim, V, G);
+  const int blocks = static_cast<int>(er::ceil_div(n * G, er::kBlock));
+  if (V == 4) {
+    hipLaunchKernelGGL(er::gather_rows_kernel<4>, dim3(blocks), dim3(er::kBlock), 0, er::as_stream(stream), table, keys, n,
+                       dim, G, key_sub, table_rows, out);
+  } else {
+    hipLaunchKernelGGL(er::gather_rows_kernel<1>, dim3(blocks), dim3(er::kBlock), 0, er::as_stream(stream), table, keys, n,
+                       dim, G, key_sub, table_rows, out);
+  }
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
+int er_scatter_unique(const uint32_t* keys, const float* grads, const int32_t* n_unique, int64_t capacity, int32_t dim,
+                      float* dense, int32_t dense_stride, er_stream_t stream) {
+  ER_REQUIRE(keys && grads && n_unique && dense && dim > 0 && dense_stride >= dim + 1 && capacity >= 0,
+             "er_scatter_unique: bad arguments");
+  if (capacity == 0) return 0;
+  const int blocks = static_cast<int>(er::ceil_div(capacity * (dim + 1), er::kBlock));
+  hipLaunchKernelGGL(er::scatter_unique_kernel, dim3(blocks), dim3(er::kBlock), 0, er::as_stream(stream), keys, grads,
+                     n_unique, dim, dense, dense_stride);
+  ER_LAUNCH_CHECK();
+  return 0;
 }
 
 }  // extern "C"

@@ -226,6 +226,39 @@ class HipBackend(object):
              'er_emb_bwd_reduce')
     return keys, grads, n_unique
 
+  # -- K12 embedding-parallel routing (include/easyrec_hip.h)
+  def emb_group_set_routing(self, group, world, shard_stride, local_base):
+    arr = (ctypes.c_int64 * len(local_base))(*[int(x) for x in local_base])
+    self._ck(self.lib.er_emb_group_set_routing(group['handle'], ctypes.c_int32(world), ctypes.c_int64(shard_stride), arr),
+             'er_emb_group_set_routing')
+    group['world'], group['shard_stride'], group['local_base'] = world, shard_stride, list(local_base)
+
+  def emb_group_set_active(self, group, n_rows):
+    self._ck(self.lib.er_emb_group_set_active(group['handle'], ctypes.c_int64(int(n_rows))), 'er_emb_group_set_active')
+    group['n_active'] = int(n_rows)
+
+  def emb_route(self, group, unique_keys, n_unique, entry_unique_index, owner_counts):
+    assert unique_keys.dtype == torch.int32 and entry_unique_index.dtype == torch.int64
+    assert n_unique.dtype == torch.int32 and owner_counts.dtype == torch.int32
+    self._ck(self.lib.er_emb_route(group['handle'], _p(unique_keys), _p(n_unique), _p(entry_unique_index),
+                                   _p(owner_counts), _stream()), 'er_emb_route')
+
+  def emb_bwd_reduce_routed(self, group, unique_grads):
+    self._ck(self.lib.er_emb_bwd_reduce_routed(group['handle'], _p(_f32c(unique_grads)), _stream()),
+             'er_emb_bwd_reduce_routed')
+
+  def gather_rows(self, table, keys, n, key_sub, out):
+    assert keys.dtype == torch.int32 and table.dim() == 2 and table.is_contiguous()
+    self._ck(self.lib.er_gather_rows(_p(table), ctypes.c_int64(table.shape[0]), ctypes.c_int32(table.shape[1]),
+                                     _p(keys), ctypes.c_int64(int(n)), ctypes.c_int64(int(key_sub)), _p(out),
+                                     _stream()), 'er_gather_rows')
+
+  def scatter_unique(self, keys, grads, n_unique, capacity, dim, dense):
+    assert dense.dim() == 2 and dense.stride(1) == 1
+    self._ck(self.lib.er_scatter_unique(_p(keys), _p(grads), _p(n_unique), ctypes.c_int64(int(capacity)),
+                                        ctypes.c_int32(dim), _p(dense), ctypes.c_int32(dense.stride(0)), _stream()),
+             'er_scatter_unique')
+
   def emb_mark_touched(self, group):
     self._ck(self.lib.er_emb_mark_touched(group['handle'], _stream()), 'er_emb_mark_touched')
 

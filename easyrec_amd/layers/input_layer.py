@@ -125,45 +125,57 @@ class EmbeddingEngine(object):
   def add_lookup(self, gkey, table_name, ids, offsets, weights, col, combiner, n_rows, max_nnz, name):
     self.groups[gkey]['pending'].append((table_name, ids, offsets, weights, col, combiner, n_rows, max_nnz, name))
 
+  def _alloc_storage(self, total, dim, opt_kind):
+    var = torch.empty(total, dim, dtype=torch.float32, device=self.device)
+    st = {'var': var, 'm': None, 'v': None, 'bitmap': None, 'total_rows': total}
+    if opt_kind in (kernels.OPT_ADAM, kernels.OPT_LAZY_ADAM):
+      st['m'] = torch.zeros_like(var)
+      st['v'] = torch.zeros_like(var)
+    elif opt_kind == kernels.OPT_ADAGRAD:
+      st['v'] = torch.zeros_like(var)
+    if opt_kind == kernels.OPT_ADAM:
+      st['bitmap'] = torch.zeros((total + 31) // 32, dtype=torch.int32, device=self.device)
+    return st
+
+  def init_table_values(self, name, view):
+    """Fill `view` ([rows, dim]) with the initial values of table `name` (seeded per table name, so the
+    single-GPU engine and every rank of the sharded engine draw the same table)."""
+    t = self.tables[name]
+    init = t['init']
+    gen = torch.Generator(device=self.device)
+    gen.manual_seed(_stable_seed(name, self.seed))
+    if init is not None and init.WhichOneof('initializer_oneof') == 'constant_initializer':
+      consts = list(init.constant_initializer.consts)
+      vals = torch.tensor(consts, dtype=torch.float32, device=self.device)
+      view.copy_(vals.view(-1)[:view.numel()].view_as(view) if vals.numel() >= view.numel() else
+                 vals.expand_as(view))
+    elif init is not None and init.WhichOneof('initializer_oneof') == 'random_normal_initializer':
+      view.normal_(init.random_normal_initializer.mean, init.random_normal_initializer.stddev, generator=gen)
+    elif init is not None and init.WhichOneof('initializer_oneof') == 'glorot_normal_initializer':
+      std = math.sqrt(2.0 / (t['rows'] + t['dim']))
+      torch.nn.init.trunc_normal_(view, 0.0, std, -2 * std, 2 * std, generator=gen)
+    else:
+      mean, std = 0.0, 0.01 / math.sqrt(t['dim'])  # feature_column_v2.py:908-912
+      if init is not None and init.WhichOneof('initializer_oneof') == 'truncated_normal_initializer':
+        mean = init.truncated_normal_initializer.mean
+        std = init.truncated_normal_initializer.stddev
+      torch.nn.init.trunc_normal_(view, mean, std, mean - 2 * std, mean + 2 * std, generator=gen)
+
+  def _ordered_groups(self):
+    """regularised groups first so their sum-of-squares partials form a prefix"""
+    return sorted(self.groups.items(), key=lambda kv: 0 if kv[1]['reg'] > 0 else 1)
+
   # -- storage
   def finalize(self, opt_kind):
     """Allocate table groups, initialise tables, create the C handles."""
     assert not self.finalized
     be = kernels.hip()
-    gen = torch.Generator(device=self.device)
     for dim, total in self.dim_rows.items():
-      var = torch.empty(total, dim, dtype=torch.float32, device=self.device)
-      st = {'var': var, 'm': None, 'v': None, 'bitmap': None, 'total_rows': total}
-      if opt_kind in (kernels.OPT_ADAM, kernels.OPT_LAZY_ADAM):
-        st['m'] = torch.zeros_like(var)
-        st['v'] = torch.zeros_like(var)
-      elif opt_kind == kernels.OPT_ADAGRAD:
-        st['v'] = torch.zeros_like(var)
-      if opt_kind == kernels.OPT_ADAM:
-        st['bitmap'] = torch.zeros((total + 31) // 32, dtype=torch.int32, device=self.device)
-      self.storage[dim] = st
+      self.storage[dim] = self._alloc_storage(total, dim, opt_kind)
     for name, t in self.tables.items():
-      view = self.table_view(name)
-      init = t['init']
-      gen.manual_seed(_stable_seed(name, self.seed))
-      if init is not None and init.WhichOneof('initializer_oneof') == 'constant_initializer':
-        consts = list(init.constant_initializer.consts)
-        vals = torch.tensor(consts, dtype=torch.float32, device=self.device)
-        view.copy_(vals.view(-1)[:view.numel()].view_as(view) if vals.numel() >= view.numel() else
-                   vals.expand_as(view))
-      elif init is not None and init.WhichOneof('initializer_oneof') == 'random_normal_initializer':
-        view.normal_(init.random_normal_initializer.mean, init.random_normal_initializer.stddev, generator=gen)
-      elif init is not None and init.WhichOneof('initializer_oneof') == 'glorot_normal_initializer':
-        std = math.sqrt(2.0 / (t['rows'] + t['dim']))
-        torch.nn.init.trunc_normal_(view, 0.0, std, -2 * std, 2 * std, generator=gen)
-      else:
-        mean, std = 0.0, 0.01 / math.sqrt(t['dim'])  # feature_column_v2.py:908-912
-        if init is not None and init.WhichOneof('initializer_oneof') == 'truncated_normal_initializer':
-          mean = init.truncated_normal_initializer.mean
-          std = init.truncated_normal_initializer.stddev
-        torch.nn.init.trunc_normal_(view, mean, std, mean - 2 * std, mean + 2 * std, generator=gen)
+      self.init_table_values(name, self.table_view(name))
     # lookup specs: regularised groups first so their sum-of-squares partials form a prefix
-    ordered = sorted(self.groups.items(), key=lambda kv: 0 if kv[1]['reg'] > 0 else 1)
+    ordered = self._ordered_groups()
     fwd_specs, reg_count = [], 0
     for gkey, g in ordered:
       g['specs'] = []

@@ -1,0 +1,296 @@
+"""Embedding-parallel input layer engine: tables row-sharded over the GPUs of one node.
+
+Mirror of the reference's EmbeddingParallelStrategy path
+(compat/feature_column/feature_column.py:248-357 `embedding_parallel_lookup`, :416-625
+`_get_logits_embedding_parallel`; compat/optimizers.py:285-345):
+  owner of id = id % world, local row = id // world, shard rows = ceil(rows / world)   (:296,317,461-463)
+  forward : unique ids -> all-to-all ids -> owner gathers rows -> all-to-all rows -> combine
+  backward: row gradients -> all-to-all to the owners -> owners reduce + apply the optimizer with the
+            gradient divided by the world size (optimizers.py:315-316)
+MI355X design: the de-duplication, the grouping by owner and the backward's segmented reduction all
+come out of ONE radix sort per embedding-dim group and step (`er_emb_route`: key = owner * stride +
+local row); the lookup itself stays the single fused `er_emb_fwd` launch, reading the received rows;
+the owner side is the same sort + in-order reduce + row-wise optimizer as single-GPU training
+(`er_emb_bwd_update` over the received keys).  Exchanges are RCCL all-to-alls (core/comm.py), three
+per dim group and step, with one host sync for the split sizes.
+
+Small tables (<= `replicate_bytes`, e.g. the 1-row RawFeature projection tables, which would all land
+on rank 0 under id % world) are replicated and trained data-parallel: their de-duplicated gradient is
+scattered into a dense buffer, all-reduced, and applied on every rank identically - the same math as
+sharding them (SURVEY.md 8e allows it).
+"""
+from collections import OrderedDict
+
+import torch
+
+from easyrec_amd import kernels
+from easyrec_amd.layers.input_layer import EmbeddingEngine
+
+
+class ShardedEmbeddingEngine(EmbeddingEngine):
+
+  def __init__(self, device, batch_size, comm, seed=0, replicate_bytes=256 * 1024, recv_slack=2.0):
+    super(ShardedEmbeddingEngine, self).__init__(device, batch_size, seed=seed)
+    self.comm = comm
+    self.rank, self.world = comm.rank, comm.world
+    self.replicate_bytes = replicate_bytes
+    self.recv_slack = recv_slack
+    self.shard = OrderedDict()  # dim -> dict of the sharded half of the dim group
+    self.rep = OrderedDict()    # dim -> dict of the replicated half
+    self.placement = {}         # table name -> ('shard' | 'rep', dim, local_base, local_rows)
+
+  def _is_replicated(self, t):
+    return t['rows'] * t['dim'] * 4 <= self.replicate_bytes
+
+  # -- storage
+  def finalize(self, opt_kind):
+    assert not self.finalized
+    be = kernels.hip()
+    W, rank, dev = self.world, self.rank, self.device
+    # 1. placement of every table
+    shard_rows, rep_rows = OrderedDict(), OrderedDict()
+    for name, t in self.tables.items():
+      dim = t['dim']
+      if self._is_replicated(t):
+        base = rep_rows.get(dim, 0)
+        rep_rows[dim] = base + t['rows']
+        self.placement[name] = ('rep', dim, base, t['rows'])
+      else:
+        n_local = (t['rows'] + W - 1) // W
+        base = shard_rows.get(dim, 0)
+        shard_rows[dim] = base + n_local
+        self.placement[name] = ('shard', dim, base, n_local)
+    # 2. storage + initial values (the same full table on every rank, then the rank's rows)
+    for dim, total in shard_rows.items():
+      self.shard[dim] = {'st': self._alloc_storage(total, dim, opt_kind), 'stride': total}
+    for dim, total in rep_rows.items():
+      self.rep[dim] = {'st': self._alloc_storage(total, dim, opt_kind)}
+    for name, t in self.tables.items():
+      kind, dim, base, n_local = self.placement[name]
+      if kind == 'rep':
+        self.init_table_values(name, self.rep[dim]['st']['var'][base:base + n_local])
+      else:
+        full = torch.empty(t['rows'], dim, dtype=torch.float32, device=dev)
+        self.init_table_values(name, full)
+        mine = full[rank::W]
+        var = self.shard[dim]['st']['var']
+        var[base:base + n_local].zero_()
+        var[base:base + mine.shape[0]].copy_(mine)
+        del full
+    self.storage = {}  # the base class' per-dim storage view: shard halves (bench / reporting)
+    for dim, sh in self.shard.items():
+      self.storage[dim] = sh['st']
+    # 3. lookups, split per dim into the sharded and the replicated half (entry order = spec order)
+    fwd_specs, reg_count = [], 0
+    per_dim = OrderedDict()
+    for gkey, g in self._ordered_groups():
+      g['specs'] = []
+      for (tname, ids, offsets, weights, col, combiner, n_rows, max_nnz, name) in g['pending']:
+        t = self.tables[tname]
+        kind, dim, base, n_local = self.placement[tname]
+        per_dim.setdefault(dim, {'shard': [], 'rep': []})[kind].append(
+            dict(tname=tname, ids=ids, offsets=offsets, weights=weights, col=col, combiner=kernels.COMBINERS[combiner],
+                 n_rows=n_rows, max_nnz=max_nnz, name=name, group=g, t=t, base=base, slot=len(fwd_specs)))
+        fwd_specs.append(None)
+        if g['reg'] > 0:
+          reg_count += 1
+    for dim, halves in per_dim.items():
+      if halves['shard']:
+        self._build_shard_half(dim, halves['shard'], fwd_specs, opt_kind)
+      if halves['rep']:
+        self._build_rep_half(dim, halves['rep'], fwd_specs, opt_kind)
+    assert all(s is not None for s in fwd_specs)
+    self.fwd_specs = fwd_specs
+    self.n_reg_specs = reg_count
+    if fwd_specs:
+      self.plan = be.emb_plan_create(fwd_specs)
+      self.sumsq = torch.zeros(max(self.plan['num_blocks'], 1), dtype=torch.float32, device=dev)
+      from easyrec_amd.layers.input_layer import _blocks_of
+      self.reg_blocks = _blocks_of(fwd_specs[:reg_count])
+    self.reg_lambda = max([g['reg'] for g in self.groups.values()] + [0.0])
+    # one flat buffer behind the replicated halves' dense gradients: ONE all-reduce per step
+    if self.rep:
+      sizes = [(dim, r['st']['total_rows'] * (dim + 1)) for dim, r in self.rep.items()]
+      self.rep_flat = torch.zeros(sum(n for _, n in sizes), dtype=torch.float32, device=dev)
+      off = 0
+      for dim, n in sizes:
+        r = self.rep[dim]
+        r['dense'] = self.rep_flat[off:off + n].view(r['st']['total_rows'], dim + 1)
+        off += n
+        self._build_rep_apply(dim, opt_kind)
+    self.counts_dev = torch.zeros(max(len(self.shard), 1), W, dtype=torch.int32, device=dev)
+    self.finalized = True
+
+  def _build_shard_half(self, dim, lookups, fwd_specs, opt_kind):
+    be = kernels.hip()
+    dev, W = self.device, self.world
+    sh = self.shard[dim]
+    caps = [(lk['max_nnz'] if lk['offsets'] is not None else lk['n_rows']) for lk in lookups]
+    n_ent = sum(caps)
+    m_cap = max(int(self.recv_slack * n_ent), 1024)
+    sh.update(
+        n_entries=n_ent, m_cap=m_cap,
+        ukeys=torch.zeros(n_ent, dtype=torch.int32, device=dev),
+        n_unique=torch.zeros(1, dtype=torch.int32, device=dev),
+        uidx=torch.full((n_ent,), -1, dtype=torch.int64, device=dev),
+        recv_rows=torch.zeros(n_ent, dim, dtype=torch.float32, device=dev),
+        ugrads=torch.zeros(n_ent, dim, dtype=torch.float32, device=dev),
+        recv_keys=torch.zeros(m_cap, dtype=torch.int32, device=dev),
+        recv_ids=torch.full((m_cap,), -1, dtype=torch.int64, device=dev),
+        rows_out=torch.zeros(m_cap, dim, dtype=torch.float32, device=dev),
+        recv_grads=torch.zeros(m_cap, dim, dtype=torch.float32, device=dev))
+    req_specs, off = [], 0
+    for lk, cap in zip(lookups, caps):
+      g = lk['group']
+      # requester group: the local lookups against their upstream-gradient buffers (routing + reduce)
+      req_specs.append(kernels.LookupSpec(
+          table=sh['recv_rows'], ids=lk['ids'], offsets=lk['offsets'], weights=lk['weights'], out=g['dout'],
+          out_col=lk['col'], rows=lk['t']['rows'], key_base=0, dim=dim, combiner=lk['combiner'], n_rows=lk['n_rows'],
+          max_nnz=lk['max_nnz'], name=lk['name']))
+      # forward: the same lookup, reading the rows received from the owners through the entry -> unique map
+      fwd_specs[lk['slot']] = kernels.LookupSpec(
+          table=sh['recv_rows'], ids=sh['uidx'][off:off + cap], offsets=lk['offsets'], weights=lk['weights'],
+          out=g['out'], out_col=lk['col'], rows=n_ent, key_base=0, dim=dim, combiner=lk['combiner'],
+          n_rows=lk['n_rows'], max_nnz=lk['max_nnz'], name=lk['name'])
+      g['specs'].append(fwd_specs[lk['slot']])
+      off += cap
+    span = max([lk['t']['rows'] for lk in lookups] + [n_ent, 1])  # validation bound only: keys are routed
+    sh['req'] = be.emb_group_create(req_specs, dim, span, sh['recv_rows'], None, None, None)
+    assert sh['req']['num_entries'] == n_ent
+    be.emb_group_set_routing(sh['req'], W, sh['stride'], [lk['base'] for lk in lookups])
+    st = sh['st']
+    owner_spec = kernels.LookupSpec(
+        table=st['var'], ids=sh['recv_ids'], offsets=None, weights=None, out=sh['recv_grads'], out_col=0,
+        rows=st['total_rows'], key_base=0, dim=dim, combiner=kernels.COMBINER_SUM, n_rows=m_cap, max_nnz=m_cap,
+        name='owner_dim%d' % dim)
+    sh['owner'] = be.emb_group_create([owner_spec], dim, st['total_rows'], st['var'], st['m'], st['v'], st['bitmap'])
+
+  def _build_rep_half(self, dim, lookups, fwd_specs, opt_kind):
+    be = kernels.hip()
+    r = self.rep[dim]
+    st = r['st']
+    specs = []
+    for lk in lookups:
+      g = lk['group']
+      view = st['var'][lk['base']:lk['base'] + lk['t']['rows']]
+      spec = kernels.LookupSpec(
+          table=view, ids=lk['ids'], offsets=lk['offsets'], weights=lk['weights'], out=g['out'], out_col=lk['col'],
+          rows=lk['t']['rows'], key_base=lk['base'], dim=dim, combiner=lk['combiner'], n_rows=lk['n_rows'],
+          max_nnz=lk['max_nnz'], name=lk['name'])
+      fwd_specs[lk['slot']] = spec
+      g['specs'].append(spec)
+      specs.append(spec.with_out(g['dout']))
+    r['group'] = be.emb_group_create(specs, dim, st['total_rows'], st['var'], None, None, None)
+
+  def _build_rep_apply(self, dim, opt_kind):
+    be = kernels.hip()
+    r = self.rep[dim]
+    st = r['st']
+    n = st['total_rows']
+    r['ids'] = torch.full((n,), -1, dtype=torch.int64, device=self.device)
+    r['arange'] = torch.arange(n, dtype=torch.int64, device=self.device)
+    r['minus1'] = torch.full((n,), -1, dtype=torch.int64, device=self.device)
+    spec = kernels.LookupSpec(
+        table=st['var'], ids=r['ids'], offsets=None, weights=None, out=r['dense'], out_col=0, rows=n, key_base=0,
+        dim=dim, combiner=kernels.COMBINER_SUM, n_rows=n, max_nnz=n, name='rep_apply_dim%d' % dim)
+    r['apply'] = be.emb_group_create([spec], dim, n, st['var'], st['m'], st['v'], st['bitmap'])
+
+  # -- per-step execution
+  def forward(self, version):
+    if version == self._ran_version:
+      return
+    be, comm = kernels.hip(), self.comm
+    for g in self.groups.values():
+      g['got_grad'] = False
+    for gi, (dim, sh) in enumerate(self.shard.items()):
+      be.emb_route(sh['req'], sh['ukeys'], sh['n_unique'], sh['uidx'], self.counts_dev[gi])
+    if self.shard:
+      send, recv = comm.exchange_counts(self.counts_dev)  # host sync: split sizes
+      for gi, (dim, sh) in enumerate(self.shard.items()):
+        sc, rc = send[gi], recv[gi]
+        m = int(sum(rc))
+        if m > sh['m_cap']:
+          raise RuntimeError('embedding-parallel: rank %d receives %d keys for dim %d, capacity %d; raise recv_slack' %
+                             (self.rank, m, dim, sh['m_cap']))
+        sh['send_counts'], sh['recv_counts'], sh['m'] = sc, rc, m
+        comm.all_to_all(sh['ukeys'], sc, sh['recv_keys'], rc)
+        st = sh['st']
+        key_sub = self.rank * sh['stride']
+        be.gather_rows(st['var'], sh['recv_keys'], m, key_sub, sh['rows_out'])
+        if m:
+          torch.sub(sh['recv_keys'][:m], key_sub, out=sh['recv_ids'][:m])
+        comm.all_to_all(sh['rows_out'], rc, sh['recv_rows'], sc)
+        be.emb_group_set_active(sh['owner'], m)
+    if self.plan is not None:
+      be.emb_fwd(self.plan, self.sumsq if self.reg_lambda > 0 else None)
+    self._ran_version = version
+
+  def backward_update(self, opt_kind, hyper):
+    be, comm = kernels.hip(), self.comm
+    for g in self.groups.values():
+      if not g['got_grad']:
+        g['dout'].zero_()
+    # replicated halves first: their all-reduce overlaps the sharded exchange below
+    for dim, r in self.rep.items():
+      r['reduced'] = be.emb_bwd_reduce(r['group'])
+    if self.rep:
+      self.rep_flat.zero_()
+      for dim, r in self.rep.items():
+        keys, grads, n_unique = r['reduced']
+        be.scatter_unique(keys, grads, n_unique, min(keys.numel(), r['st']['total_rows']), dim, r['dense'])
+      comm.all_reduce_sum(self.rep_flat)
+    for dim, sh in self.shard.items():
+      be.emb_bwd_reduce_routed(sh['req'], sh['ugrads'])
+      comm.all_to_all(sh['ugrads'], sh['send_counts'], sh['recv_grads'], sh['recv_counts'])
+      be.emb_bwd_update(sh['owner'], opt_kind, hyper)
+    for dim, r in self.rep.items():
+      torch.where(r['dense'][:, dim] > 0, r['arange'], r['minus1'], out=r['ids'])
+      be.emb_bwd_update(r['apply'], opt_kind, hyper)
+
+  # -- host exchange (collective: every rank must call)
+  def table_view(self, name):
+    kind, dim, base, n_local = self.placement[name]
+    st = self.rep[dim]['st'] if kind == 'rep' else self.shard[dim]['st']
+    return st['var'][base:base + n_local]
+
+  def slot_view(self, name, slot):
+    kind, dim, base, n_local = self.placement[name]
+    st = self.rep[dim]['st'] if kind == 'rep' else self.shard[dim]['st']
+    return None if st[slot] is None else st[slot][base:base + n_local]
+
+  def _gather_full(self, name, local):
+    kind, dim, base, n_local = self.placement[name]
+    if kind == 'rep':
+      return local.detach().clone()
+    rows = self.tables[name]['rows']
+    parts = self.comm.all_gather_rows(local.contiguous())
+    full = torch.empty(n_local * self.world, dim, dtype=local.dtype, device=local.device)
+    for w, p in enumerate(parts):
+      full[w::self.world] = p
+    return full[:rows]
+
+  def state_dict(self, slots=False):
+    out = OrderedDict()
+    for name in self.tables:
+      out[name] = self._gather_full(name, self.table_view(name)).cpu().numpy()
+      if slots:
+        for s in ('m', 'v'):
+          sv = self.slot_view(name, s)
+          if sv is not None:
+            out[name + '/' + s] = self._gather_full(name, sv).cpu().numpy()
+    return out
+
+  def load_state_dict(self, state):
+    import numpy as np
+    for name in self.tables:
+      if name not in state:
+        continue
+      kind, dim, base, n_local = self.placement[name]
+      full = torch.from_numpy(np.asarray(state[name], dtype=np.float32)).to(self.device)
+      view = self.table_view(name)
+      if kind == 'rep':
+        view.copy_(full)
+      else:
+        mine = full[self.rank::self.world]
+        view.zero_()
+        view[:mine.shape[0]].copy_(mine)

@@ -58,7 +58,7 @@ class EasyRecEstimator(object):
     self.batch_size = self.schema.batch_size
     self.features = DeviceFeatures(self.schema, self.device)
     self.varstore = VarStore(self.device, seed=seed)
-    self.engine = EmbeddingEngine(self.device, self.batch_size, seed=seed)
+    self.engine = self._make_engine()
     self.ctx = context.ModelContext(self.varstore, self.engine, is_training=is_training)
     self.global_step = 0
     self.graph = None
@@ -95,6 +95,16 @@ class EasyRecEstimator(object):
     self._reg_emb = torch.zeros(1, dtype=torch.float32, device=dev)
     self._reg_dense = torch.zeros(1, dtype=torch.float32, device=dev)
 
+  # -- hooks overridden by the embedding-parallel estimator (model/embedding_parallel.py)
+  def _make_engine(self):
+    return EmbeddingEngine(self.device, self.batch_size, seed=self.seed)
+
+  def _dense_grad_scale(self):
+    return 1.0
+
+  def _sync_dense_grads(self):
+    """Multi-GPU: all-reduce of the flat dense gradient buffer.  Single GPU: nothing."""
+
   # -- construction
   def build(self):
     """Build pass (creates variables / declares tables), then allocate + pack everything."""
@@ -128,7 +138,7 @@ class EasyRecEstimator(object):
     for i in range(count):
       step = self._planned_until + i
       rows[i, 0] = self.opt_emb.hyper_row(step, self.emb_grad_scale)
-      rows[i, 1] = self.opt_dense.hyper_row(step, 1.0)
+      rows[i, 1] = self.opt_dense.hyper_row(step, self._dense_grad_scale())
       self.opt_emb.finish_step()
       if self.opt_dense is not self.opt_emb:
         self.opt_dense.finish_step()
@@ -172,6 +182,7 @@ class EasyRecEstimator(object):
         total.add_(val.reshape(1))
       if self.is_training:
         self.model.backward()
+        self._sync_dense_grads()
         self.engine.backward_update(self.opt_emb.kind, self.hyper[0])
         vs = self.varstore
         be.dense_opt_step(vs.flat, vs.slots.get('m'), vs.slots.get('v'), vs.flat_grad,

@@ -322,6 +322,47 @@ int er_mmoe_mix_bwd(const float* experts, const float* gates, const float* dout,
                     er_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
+ * K12 embedding-parallel (row-sharded tables, one process per GPU).  Replaces
+ *     embedding_parallel_lookup / _get_logits_embedding_parallel
+ *       compat/feature_column/feature_column.py:248-357, 416-625
+ *     (Unique -> owner = id % world, local row = id // world (:296,317,461-463) -> hvd.alltoall of ids ->
+ *      owner-side gather -> hvd.alltoall of rows -> segment sums) and the hvd branch of optimize_loss
+ *     compat/optimizers.py:285-345 (embedding gradients divided by the world size :315-316).
+ *     The collectives themselves are RCCL all-to-alls issued by the host (torch.distributed); these
+ *     entry points are the device work on either side of them.
+ *
+ * Requester side (a group created from the rank's LOCAL lookups; var may be any [>=1, dim] buffer):
+ *   er_emb_group_set_routing: keys become owner * shard_stride + local_base[lookup] + id / world, so
+ *     ONE ascending sort groups a step's entries by owner rank and de-duplicates them.
+ *   er_emb_route: build + sort; writes the unique routed keys (ascending), *n_unique, for every entry
+ *     (source order; lookup l's entries start at the prefix sum of the lookups' capacities) the index
+ *     of its unique key or -1, and owner_counts[world] = unique keys per owner (the a2a send splits).
+ *     The lookup itself then runs through er_emb_fwd with table = the rows received from the owners
+ *     ([n_unique, dim]) and ids = entry_unique_index.
+ *   er_emb_bwd_reduce_routed: reuses the sort of this step's er_emb_route: unique_grads[u, :] = sum of
+ *     the upstream gradients of the entries of unique key u (in-order, deterministic).
+ * Owner side:
+ *   er_gather_rows: out[i, :] = table[keys[i] - key_sub, :] (key_sub = rank * shard_stride).
+ *   er_emb_group_set_active: a group of ONE dense-mode lookup (ids = received local rows, out =
+ *     received gradients) processes only its first n_rows entries in er_emb_bwd_update /
+ *     er_emb_mark_touched (the received count changes every step; capacity = the lookup's n_rows).
+ * Replicated (small) tables: er_scatter_unique writes the n_unique (device scalar) de-duplicated
+ *   gradient rows of er_emb_bwd_reduce into a dense zero-initialised [rows, dense_stride >= dim+1]
+ *   buffer (column `dim` = 1 marks a touched row) that is all-reduced like dense parameters.
+ * -------------------------------------------------------------------------------------------- */
+int er_emb_group_set_routing(er_emb_group* group, int32_t world, int64_t shard_stride,
+                             const int64_t* local_base_host);
+int er_emb_group_set_active(er_emb_group* group, int64_t n_rows);
+int er_emb_route(er_emb_group* group, uint32_t* unique_keys, int32_t* n_unique,
+                 int64_t* entry_unique_index, int32_t* owner_counts, er_stream_t stream);
+int er_emb_bwd_reduce_routed(er_emb_group* group, float* unique_grads, er_stream_t stream);
+int er_gather_rows(const float* table, int64_t table_rows, int32_t dim, const uint32_t* keys, int64_t n,
+                   int64_t key_sub, float* out, er_stream_t stream);
+int er_scatter_unique(const uint32_t* keys, const float* grads, const int32_t* n_unique,
+                      int64_t capacity, int32_t dim, float* dense, int32_t dense_stride,
+                      er_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
  * Dense-variable optimizer: one launch over the flat parameter buffer.  Replaces ApplyAdam /
  *     ApplyAdagrad / ApplyGradientDescent issued per variable by optimize_loss
  *     compat/optimizers.py:412-416, plus the kernel L2 gradient l2*W

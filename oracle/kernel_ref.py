@@ -277,7 +277,13 @@ class RefBackend(object):
 
   def emb_bwd_update(self, group, opt_kind, hyper):
     h = hyper.detach().cpu().numpy().reshape(-1)
-    grads = sparse_grads(group['specs'], group['dim'])
+    if group.get('n_active', -1) >= 0:
+      grads = {}
+      for key, _, s, r, scale in self._routed_entries(group):
+        g = s.out.detach().cpu().numpy()[r, s.out_col:s.out_col + group['dim']].astype(np.float32) * scale
+        grads[key] = (grads[key] + g).astype(np.float32) if key in grads else g.astype(np.float32)
+    else:
+      grads = sparse_grads(group['specs'], group['dim'])
     var = group['var'].detach().numpy()
     m = None if group['m'] is None else group['m'].numpy()
     v = None if group['v'] is None else group['v'].numpy()
@@ -293,6 +299,82 @@ class RefBackend(object):
       k[i] = key
       g[i] = torch.from_numpy(grads[key])
     return k, g, torch.tensor([len(keys)], dtype=torch.int32)
+
+  # -- embedding-parallel routing (reference compat/feature_column/feature_column.py:248-357:
+  #    owner = id % world, local row = id // world)
+  def emb_group_set_routing(self, group, world, shard_stride, local_base):
+    group['world'], group['shard_stride'], group['local_base'] = world, shard_stride, list(local_base)
+
+  def emb_group_set_active(self, group, n_rows):
+    group['n_active'] = int(n_rows)
+
+  def _routed_entries(self, group):
+    """[(routed key, entry index, spec, out row, scale)] in entry order."""
+    W = group.get('world', 1)
+    ents, base = [], 0
+    for li, s in enumerate(group['specs']):
+      ids = s.ids.cpu().numpy()
+      offsets = None if s.offsets is None else s.offsets.cpu().numpy()
+      weights = None if s.weights is None else s.weights.cpu().numpy()
+      n_rows = min(s.n_rows, group.get('n_active', s.n_rows)) if group.get('n_active', -1) >= 0 else s.n_rows
+      for r in range(n_rows):
+        kb, ke = (r, r + 1) if offsets is None else (int(offsets[r]), int(offsets[r + 1]))
+        valid = []
+        for k in range(kb, ke):
+          i = int(ids[k])
+          w = F32(1) if weights is None else F32(weights[k])
+          if i < 0 or i >= s.rows or (weights is not None and s.combiner != 0 and not (w > 0)):
+            continue
+          valid.append((k, i, w))
+        den = F32(1)
+        if s.combiner != 0 and valid:
+          wsum, w2 = F32(0), F32(0)
+          for _, _, w in valid:
+            wsum, w2 = F32(wsum + w), F32(w2 + w * w)
+          den = wsum if s.combiner == 1 else np.sqrt(w2, dtype=np.float32)
+        for k, i, w in valid:
+          key = (s.key_base + i) if 'local_base' not in group else \
+              ((i % W) * group['shard_stride'] + group['local_base'][li] + i // W)
+          ents.append((key, base + k, s, r, F32(w / den)))
+      base += s.max_nnz if s.offsets is not None else s.n_rows
+    return ents
+
+  def emb_route(self, group, unique_keys, n_unique, entry_unique_index, owner_counts):
+    ents = self._routed_entries(group)
+    keys = sorted(set(e[0] for e in ents))
+    pos = {k: i for i, k in enumerate(keys)}
+    entry_unique_index.fill_(-1)
+    for key, j, _, _, _ in ents:
+      entry_unique_index[j] = pos[key]
+    for i, k in enumerate(keys):
+      unique_keys[i] = k
+    n_unique[0] = len(keys)
+    W = group.get('world', 1)
+    stride = group['shard_stride'] if 'local_base' in group else group['total_rows']
+    for w in range(W):
+      owner_counts[w] = sum(1 for k in keys if w * stride <= k < (w + 1) * stride)
+    group['_route_keys'] = keys
+
+  def emb_bwd_reduce_routed(self, group, unique_grads):
+    acc = {}
+    for key, _, s, r, scale in self._routed_entries(group):
+      g = s.out.detach().cpu().numpy()[r, s.out_col:s.out_col + group['dim']].astype(np.float32) * scale
+      acc[key] = (acc[key] + g).astype(np.float32) if key in acc else g.astype(np.float32)
+    for i, key in enumerate(group['_route_keys']):
+      unique_grads[i] = torch.from_numpy(acc[key])
+
+  def gather_rows(self, table, keys, n, key_sub, out):
+    rows = keys[:n].to(torch.int64) - int(key_sub)
+    out[:n] = table[rows]
+
+  def scatter_unique(self, keys, grads, n_unique, capacity, dim, dense):
+    n = int(n_unique.item())
+    rows = keys[:n].to(torch.int64)
+    dense[rows, :dim] = grads[:n]
+    dense[rows, dim] = 1.0
+
+  def emb_mark_touched(self, group):
+    pass
 
   def adam_decay_sweep(self, var, m, v, bitmap, total_rows, dim, hyper):
     h = hyper.detach().cpu().numpy().reshape(-1)

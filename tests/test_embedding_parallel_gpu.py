@@ -1,0 +1,139 @@
+"""-m gpu: the embedding-parallel path through the real HIP kernels.  gpurun exposes ONE MI355X, so W
+ranks run as W threads on it with an in-process stand-in for the RCCL all-to-alls (tests/_sim_comm.py);
+everything else - er_emb_route, er_gather_rows, the fused lookup over received rows,
+er_emb_bwd_reduce_routed, owner-side er_emb_bwd_update, replicated small tables - is the product path."""
+import logging
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from easyrec_amd import kernels  # noqa: E402
+from easyrec_amd.input.criteo_synthetic import SyntheticCriteo  # noqa: E402
+from easyrec_amd.model.easy_rec_estimator import EasyRecEstimator  # noqa: E402
+from easyrec_amd.model.embedding_parallel import EmbeddingParallelEstimator  # noqa: E402
+from easyrec_amd.utils import config_util  # noqa: E402
+from _sim_comm import SimWorld  # noqa: E402  (tests/ is on sys.path under pytest)
+
+logging.disable(logging.WARNING)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEV = 'cuda:0'
+
+
+def _cfg(name, lazy=False):
+  cfg = config_util.get_configs_from_pipeline_file(os.path.join(ROOT, 'configs', name))
+  if lazy:
+    oc = cfg.train_config.optimizer_config[0]
+    oc.lazy_adam_optimizer.learning_rate.CopyFrom(oc.adam_optimizer.learning_rate)
+  return cfg
+
+
+def _worst(a, b):
+  worst = ('', 0.0)
+  for k in b:
+    if k.endswith('/bias') or k.endswith('/bias/m') or k.endswith('/bias/v'):
+      continue  # zero-gradient biases under BatchNorm: rounding noise through Adam
+    d = float(np.max(np.abs(a[k] - b[k]))) / (float(np.max(np.abs(b[k]))) + 1e-12)
+    if d > worst[1]:
+      worst = (k, d)
+  return worst
+
+
+def test_routing_kernels_against_numpy():
+  """er_emb_route / er_gather_rows / er_emb_bwd_reduce_routed on a group of two tables, world 4."""
+  hip = kernels.hip()
+  rng = np.random.default_rng(3)
+  W, B, dim = 4, 500, 16
+  rows = [1001, 37]
+  shard_rows = [(r + W - 1) // W for r in rows]
+  local_base = [0, shard_rows[0]]
+  stride = sum(shard_rows)
+  ids = [rng.integers(-1, r, size=B).astype(np.int64) for r in rows]
+  ids[0][:100] = 5  # a hot id
+  dout = torch.from_numpy((rng.standard_normal((B, 2 * dim)) * 0.1).astype(np.float32)).to(DEV)
+  dummy = torch.zeros(2 * B, dim, device=DEV)
+  specs = [kernels.LookupSpec(table=dummy, ids=torch.from_numpy(ids[t]).to(DEV), offsets=None, weights=None, out=dout,
+                              out_col=t * dim, rows=rows[t], key_base=0, dim=dim, combiner=0, n_rows=B, max_nnz=B)
+           for t in range(2)]
+  g = hip.emb_group_create(specs, dim, max(rows), dummy, None, None, None)
+  hip.emb_group_set_routing(g, W, stride, local_base)
+  n_ent = 2 * B
+  ukeys = torch.zeros(n_ent, dtype=torch.int32, device=DEV)
+  nu = torch.zeros(1, dtype=torch.int32, device=DEV)
+  uidx = torch.zeros(n_ent, dtype=torch.int64, device=DEV)
+  counts = torch.zeros(W, dtype=torch.int32, device=DEV)
+  hip.emb_route(g, ukeys, nu, uidx, counts)
+  ugrads = torch.zeros(n_ent, dim, device=DEV)
+  hip.emb_bwd_reduce_routed(g, ugrads)
+  torch.cuda.synchronize()
+  # numpy restatement
+  keys = np.full(n_ent, -1, dtype=np.int64)
+  for t in range(2):
+    ok = ids[t] >= 0
+    keys[t * B:(t + 1) * B][ok] = (ids[t][ok] % W) * stride + local_base[t] + ids[t][ok] // W
+  uniq = np.unique(keys[keys >= 0])
+  n = int(nu.item())
+  assert n == len(uniq)
+  assert np.array_equal(ukeys[:n].cpu().numpy().astype(np.int64), uniq)
+  exp_idx = np.where(keys >= 0, np.searchsorted(uniq, np.maximum(keys, 0)), -1)
+  assert np.array_equal(uidx.cpu().numpy(), exp_idx)
+  assert np.array_equal(counts.cpu().numpy(), [int(((uniq // stride) == w).sum()) for w in range(W)])
+  exp = np.zeros((n, dim), dtype=np.float64)
+  d = dout.cpu().numpy().astype(np.float64)
+  for t in range(2):
+    for r in range(B):
+      if keys[t * B + r] >= 0:
+        exp[exp_idx[t * B + r]] += d[r, t * dim:(t + 1) * dim]
+  assert np.allclose(ugrads[:n].cpu().numpy(), exp, rtol=1e-5, atol=1e-7)
+  # owner side: rank 2 gathers the rows of the keys it owns
+  table = torch.from_numpy(rng.standard_normal((stride, dim)).astype(np.float32)).to(DEV)
+  mine = uniq[(uniq // stride) == 2]
+  out = torch.zeros(len(mine) + 1, dim, device=DEV)
+  hip.gather_rows(table, torch.from_numpy(mine.astype(np.int32)).to(DEV), len(mine), 2 * stride, out)
+  torch.cuda.synchronize()
+  assert torch.equal(out[:len(mine)], table[torch.from_numpy(mine - 2 * stride).to(DEV)])
+  hip.emb_group_destroy(g)
+
+
+@pytest.mark.parametrize('world,lazy', [(1, False), (2, False), (4, True)])
+def test_sharded_ranks_with_the_same_batch_equal_single_gpu(world, lazy):
+  """Every rank sees the SAME batch: each embedding row gets world * g / world and each dense gradient
+  the average of identical gradients, so the W-rank run must follow the single-GPU run (to the fp32
+  noise of the GEMM library between runs)."""
+  cfg = _cfg('deepfm_criteo_small.config', lazy)
+  B, steps = 128, 2
+  gen = SyntheticCriteo(cfg.data_config, list(cfg.feature_config.features), batch_size=B, seed=9)
+  batches = [gen.next_batch() for _ in range(steps)]
+  ref = EasyRecEstimator(cfg, device=DEV, batch_size=B, seed=4).build()
+  ref_losses = []
+  for b in batches:
+    ref.train_step(b)
+    ref_losses.append(ref.loss_values())
+  ref_state = ref.state_dict(slots=True)
+  sim = SimWorld(world)
+
+  def rank_fn(rank, comm):
+    torch.cuda.set_device(0)
+    est = EmbeddingParallelEstimator(cfg, device=DEV, batch_size=B, seed=4, rank=rank, world=world, comm=comm,
+                                     replicate_bytes=1024).build()
+    losses = []
+    for b in batches:
+      est.train_step(b)
+      losses.append(est.loss_values())
+    return est.state_dict(slots=True), losses, dict(est.engine.placement)
+
+  results = sim.run(rank_fn)
+  for state, losses, placement in results:
+    assert any(p[0] == 'shard' for p in placement.values()) and any(p[0] == 'rep' for p in placement.values())
+    for got, exp in zip(losses, ref_losses):
+      assert abs(got['total_loss'] - exp['total_loss']) <= 2e-4 * abs(exp['total_loss']), (got, exp)
+    first = {k: v for k, v in state.items() if k.endswith('/m')}
+    k, d = _worst(first, {k: ref_state[k] for k in first})
+    assert d < 5e-3, (k, d)
+  # all ranks hold the same gathered tables
+  for k in results[0][0]:
+    if 'embedding_weights' in k:
+      assert np.array_equal(results[0][0][k], results[-1][0][k]), k
