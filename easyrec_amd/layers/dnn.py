@@ -55,6 +55,24 @@ def dense_bn_act(x, units, name, l2_reg, use_bias, use_bn, act_relu, training, b
   return y.reshape(shape[:-1] + (units,))
 
 
+def batch_norm(x, name, training):
+  """tf.layers.batch_normalization(x, training=..., name=name) on the last axis (TF defaults:
+  momentum 0.99, epsilon 1e-3, gamma ones, beta zeros): reference model/multi_tower_din.py:105-109."""
+  ctx = context.current()
+  vs = ctx.varstore
+  units = x.shape[-1]
+  gamma = vs.get_variable(name + '/gamma', (units,), 'ones')
+  beta = vs.get_variable(name + '/beta', (units,), 'zeros')
+  mm = vs.get_variable(name + '/moving_mean', (units,), 'zeros', trainable=False)
+  mv = vs.get_variable(name + '/moving_variance', (units,), 'ones', trainable=False)
+  shape = x.shape
+  x2 = x.reshape(-1, units)
+  freeze = ctx.building and training
+  y = kernels.BNActFn.apply(x2, None, gamma, beta, None if freeze else mm, None if freeze else mv, True,
+                            BN_EPSILON, BN_MOMENTUM, kernels.ACT_NONE, training)
+  return y.reshape(shape)
+
+
 class DNN(object):
 
   def __init__(self, dnn_config, l2_reg, name='dnn', is_training=False, last_layer_no_activation=False,

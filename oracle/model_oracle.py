@@ -247,6 +247,39 @@ class OracleTrainer(object):
     feats = [e for e, _ in outs]
     return torch.cat(feats, dim=1), feats
 
+  def _categorical_ids(self, batch, fc, name):
+    hashed, raws, ints = self._cache
+    return hashed[name] if name in hashed else ints[name]
+
+  def seq_input_layer(self, V, batch, group_name):
+    """layers/seq_input_layer.py:34-124: keys under variable_scope(group_name), history sequences keep the
+    time axis ([B, L, E], zero rows for padding); embedding L2 on key and history outputs
+    (:68-70, model/multi_tower_din.py:54-60)."""
+    grp = [g for g in self.cfg.model_config.seq_att_groups if g.group_name == group_name][0]
+    lam = self.cfg.model_config.embedding_regularization
+    keys, hists, seq_len = [], [], None
+    for m in grp.seq_att_map:
+      for k in m.key:
+        fc = self.fc_by_name[k]
+        table = V.get(self._column_var_name(group_name, fc, False))
+        keys.append(self._lookup_dense(table, self._categorical_ids(batch, fc, k)))
+      for h in m.hist_seq:
+        fc = self.fc_by_name[h]
+        table = V.get(self._column_var_name(group_name, fc, False))
+        ids = np.asarray(batch['seq/%s/ids' % h])  # [B, L], -1 padded
+        B, L = ids.shape
+        e = self._lookup_dense(table, ids.reshape(-1)).reshape(B, L, -1)
+        hists.append(e)
+        if seq_len is None:
+          seq_len = np.asarray(batch['seq/%s/len' % h]).astype(np.int64)
+    key = torch.cat(keys, dim=-1)
+    hist = torch.cat(hists, dim=-1)
+    if lam > 0:
+      for k in keys:
+        self._reg = self._reg + lam * 0.5 * (k * k).sum()
+      self._reg = self._reg + lam * 0.5 * (hist * hist).sum()
+    return {'key': key, 'hist_seq_emb': hist, 'hist_seq_len': seq_len}
+
   # ------------------------------------------------------------------ dense layers
   def dense(self, V, x, units, name, l2):
     w = V.get(name + '/kernel', l2=l2)
@@ -341,6 +374,62 @@ class OracleTrainer(object):
     out = self.dense(V, all_fea, mc.num_class, 'output', 0.0)  # no kernel_regularizer (dcn.py:66)
     return {'logits': out.squeeze(1)}
 
+  def _din(self, V, dnn_cfg, fea, name, l2):
+    """model/multi_tower_din.py:62-97."""
+    q, h, seq_len = fea['key'], fea['hist_seq_emb'], fea['hist_seq_len']
+    B, L, E = h.shape
+    cur = q[:, None, :].expand(B, L, E)
+    din_net = torch.cat([cur, h, cur - h, cur * h], dim=-1)
+    din_net = self.dnn(V, din_net, dnn_cfg, name, l2, last_no_act=True, last_no_bn=True)
+    scores = din_net.reshape(B, 1, L)
+    mask = (torch.arange(L)[None, :] < torch.as_tensor(seq_len)[:, None])[:, None, :]
+    scores = torch.where(mask, scores, torch.full_like(scores, float(-2**32 + 1)))
+    scores = torch.softmax(scores, dim=-1)
+    pooled = torch.matmul(scores, h).reshape(B, E)
+    return torch.cat([pooled, q], dim=1)
+
+  def _multi_tower_din(self, V, batch):
+    mc = self.cfg.model_config
+    c = mc.multi_tower
+    l2 = self._l2_of(mc)
+    feas, scope_id = [], 0
+    for tower in c.towers:
+      scope = 'input_layer' if scope_id == 0 else 'input_layer_%d' % scope_id
+      scope_id += 1
+      fea, _ = self.input_layer(V, batch, tower.input, scope)
+      feas.append(fea)
+    din_feas = [self.seq_input_layer(V, batch, t.input) for t in c.din_towers]
+    arr = []
+    for tower, fea in zip(c.towers, feas):
+      fea = self.batch_norm(V, fea, '%s_fea_bn' % tower.input)
+      arr.append(self.dnn(V, fea, tower.dnn, '%s_dnn' % tower.input, l2))
+    for tower, fea in zip(c.din_towers, din_feas):
+      arr.append(self._din(V, tower.dnn, fea, '%s_dnn' % tower.input, l2))
+    all_fea = self.dnn(V, torch.cat(arr, dim=1), c.final_dnn, 'final_dnn', l2)
+    out = self.dense(V, all_fea, mc.num_class, 'output', 0.0)
+    return {'logits': out.squeeze(1)}
+
+  def _mmoe(self, V, batch):
+    """model/mmoe.py:35-70, layers/mmoe.py:62-83."""
+    mc = self.cfg.model_config
+    c = mc.mmoe
+    l2 = self._l2_of(mc)
+    x, _ = self.input_layer(V, batch, 'all', 'input_layer')
+    if c.HasField('expert_dnn'):
+      cfgs = [c.expert_dnn] * c.num_expert
+    else:
+      cfgs = [e.dnn for e in c.experts]
+    experts = torch.stack([self.dnn(V, x, cfg, 'mmoe/expert_%d' % i, l2) for i, cfg in enumerate(cfgs)], dim=1)
+    pred = {}
+    for t, tower in enumerate(c.task_towers):
+      gate = torch.softmax(self.dense(V, x, len(cfgs), 'mmoe/gate_%d/dnn' % t, l2), dim=1)
+      task_in = (experts * gate[:, :, None]).sum(dim=1)
+      if tower.HasField('dnn'):
+        task_in = self.dnn(V, task_in, tower.dnn, tower.tower_name, l2)
+      out = self.dense(V, task_in, tower.num_class, 'dnn_output_%d' % t, l2)
+      pred['logits_%s' % tower.tower_name] = out.squeeze(1)
+    return pred
+
   # ------------------------------------------------------------------ one step
   def forward(self, batch):
     V = Vars(self.state, self.dtype)
@@ -348,22 +437,43 @@ class OracleTrainer(object):
     self._moving = {}
     self._touched = {}
     self._cache = (self._hashed_ids(batch), self._raw_values(batch), self._int_ids(batch))
-    if self.model_class == 'DeepFM':
-      pred = self._deepfm(V, batch)
-    elif self.model_class == 'DCN':
-      pred = self._dcn(V, batch)
+    labels_np = np.asarray(batch['labels'], dtype=np.float32)
+    ce_of = lambda z, y: (torch.clamp(z, min=0) - z * y + torch.log1p(torch.exp(-torch.abs(z)))).mean()  # noqa: E731
+    losses = OrderedDict()
+    if self.model_class == 'MMoE':
+      pred = self._mmoe(V, batch)
+      label_fields = list(self.cfg.data_config.label_fields)
+      ce = torch.zeros((), dtype=self.dtype)
+      for t, tower in enumerate(self.cfg.model_config.mmoe.task_towers):
+        lname = tower.label_name if tower.HasField('label_name') else label_fields[t]
+        y = torch.as_tensor(labels_np[label_fields.index(lname)], dtype=self.dtype)
+        z = pred['logits_%s' % tower.tower_name]
+        # tf.losses.sigmoid_cross_entropy (SUM_BY_NONZERO_WEIGHTS) x task weight (multi_task_model.py:229-240)
+        li = ce_of(z, y) * tower.weight
+        losses['cross_entropy_loss_%s' % tower.tower_name] = li
+        pred['probs_%s' % tower.tower_name] = torch.sigmoid(z)
+        ce = ce + li
     else:
-      raise NotImplementedError('oracle: model_class %s' % self.model_class)
-    labels = torch.as_tensor(np.asarray(batch['labels'], dtype=np.float32)[0], dtype=self.dtype)
-    z = pred['logits']
-    # tf.losses.sigmoid_cross_entropy (SUM_BY_NONZERO_WEIGHTS, weights = 1.0)
-    ce = (torch.clamp(z, min=0) - z * labels + torch.log1p(torch.exp(-torch.abs(z)))).mean()
+      if self.model_class == 'DeepFM':
+        pred = self._deepfm(V, batch)
+      elif self.model_class == 'DCN':
+        pred = self._dcn(V, batch)
+      elif self.model_class == 'MultiTowerDIN':
+        pred = self._multi_tower_din(V, batch)
+      else:
+        raise NotImplementedError('oracle: model_class %s' % self.model_class)
+      labels = torch.as_tensor(labels_np[0], dtype=self.dtype)
+      z = pred['logits']
+      # tf.losses.sigmoid_cross_entropy (SUM_BY_NONZERO_WEIGHTS, weights = 1.0)
+      ce = ce_of(z, labels)
+      losses['cross_entropy_loss'] = ce
+      pred['probs'] = torch.sigmoid(z)
     reg = self._reg
     for name, t in V.used.items():
       if V.l2[name] > 0:
         reg = reg + V.l2[name] * 0.5 * (t * t).sum()
-    losses = OrderedDict([('cross_entropy_loss', ce), ('regularization_loss', reg), ('total_loss', ce + reg)])
-    pred['probs'] = torch.sigmoid(z)
+    losses['regularization_loss'] = reg
+    losses['total_loss'] = ce + reg
     return V, pred, losses
 
   def train_step(self, batch):

@@ -111,3 +111,44 @@ def test_csv_input_roundtrip(tmp_path, built_lib):
   # F2: (x - (-3)) / (257675 + 3) in fp32; '' -> default 0
   x = np.float32(float(first[2]) if first[2] else 0.0)
   assert batch['raw'][1, 0] == (x - np.float32(-3.0)) / np.float32(257678.0)
+
+
+@pytest.mark.parametrize('config,B', [('dcn_criteo_small.config', 32), ('din_taobao_small.config', 24),
+                                      ('mmoe_taobao_small.config', 24)])
+def test_other_models_match_model_oracle(ref_backend, config, B):
+  """DCN / MultiTowerDIN / MMoE host logic (variable naming, layer wiring, multi-task losses, sequence and
+  tag lookups) against the independent model-level oracle, 2 optimisation steps."""
+  from easyrec_amd.input.synthetic import SyntheticBatches
+  from easyrec_amd.model.easy_rec_estimator import EasyRecEstimator
+  from oracle.model_oracle import OracleTrainer
+  cfg = config_util.get_configs_from_pipeline_file(os.path.join('configs', config))
+  est = EasyRecEstimator(cfg, device='cpu', batch_size=B, seed=3).build()
+  orc = OracleTrainer(cfg, est.state_dict(), batch_size=B)
+  gen = SyntheticBatches(cfg.data_config, est.feature_configs, batch_size=B, seed=11)
+  for step in range(2):
+    b = gen.next_batch()
+    est.train_step(b)
+    got, exp = est.loss_values(), orc.train_step(b)
+    for k in exp:
+      assert abs(got[k] - exp[k]) <= 2e-5 * max(1.0, abs(exp[k])), (k, got[k], exp[k])
+    if step == 0:
+      # gradients of every variable, read back as Adam's first moment m = (1 - beta1) * g (the parameters
+      # themselves go through Adam's normalisation, which amplifies rounding noise of near-zero gradients)
+      st = est.state_dict(slots=True)
+      names = set(orc.state)
+      n_cmp = 0
+      # tensors whose true gradient is zero (e.g. the last cross bias in front of a BatchNorm) carry only
+      # rounding noise: allow 1e-6 of the largest gradient scale in the model
+      gmax = max(float(np.max(np.abs(v))) for kk, v in orc.slots.items() if kk.endswith('/m'))
+      for k in orc.state:
+        key = k + '/m'
+        if key not in orc.slots or key not in st:
+          continue
+        if k.endswith('/bias') and (k[:-len('/bias')] + '/bn/gamma') in names:
+          continue  # d(loss)/d(bias) == 0 under BatchNorm
+        ref = orc.slots[key]
+        d, scale = float(np.max(np.abs(st[key] - ref))), float(np.max(np.abs(ref)))
+        assert d <= 2e-4 * scale + 1e-6 * gmax, (key, d, scale)
+        n_cmp += 1
+      assert n_cmp > 5
+  est.varstore.check_grad_views()

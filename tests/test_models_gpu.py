@@ -1,0 +1,108 @@
+"""-m gpu: DCN / MultiTowerDIN / MMoE training steps on the MI355X (through the C ABI) against the
+model-level CPU oracle: losses and logits within 1e-4 relative (north_star), gradients of every variable
+(read back as Adam's first moment after the first update) within 2e-4 of each tensor's gradient scale."""
+import logging
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from easyrec_amd.input.synthetic import SyntheticBatches  # noqa: E402
+from easyrec_amd.model.easy_rec_estimator import EasyRecEstimator  # noqa: E402
+from easyrec_amd.utils import config_util  # noqa: E402
+from oracle.model_oracle import OracleTrainer  # noqa: E402
+
+logging.disable(logging.WARNING)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEV = 'cuda:0'
+
+
+def _cfg(name, lazy=False):
+  cfg = config_util.get_configs_from_pipeline_file(os.path.join(ROOT, 'configs', name))
+  if lazy:
+    oc = cfg.train_config.optimizer_config[0]
+    oc.lazy_adam_optimizer.learning_rate.CopyFrom(oc.adam_optimizer.learning_rate)
+  return cfg
+
+
+def _first_steps(cfg, B, seed, steps=2):
+  est = EasyRecEstimator(cfg, device=DEV, batch_size=B, seed=seed).build()
+  orc = OracleTrainer(cfg, est.state_dict(), batch_size=B)
+  gen = SyntheticBatches(cfg.data_config, est.feature_configs, batch_size=B, seed=seed + 100)
+  for step in range(steps):
+    b = gen.next_batch()
+    est.train_step(b)
+    got, exp = est.loss_values(), orc.train_step(b)
+    for k in exp:
+      assert abs(got[k] - exp[k]) <= (1e-5 if step == 0 else 1e-4) * max(1e-3, abs(exp[k])), (step, k, got[k], exp[k])
+    if step > 0:
+      continue
+    for k, ref in orc.last_pred.items():
+      if k.startswith('logits'):
+        got_l = est.model._prediction_dict[k].detach().cpu().numpy()
+        assert np.allclose(got_l, ref, rtol=1e-4, atol=1e-5), k
+    est.varstore.check_grad_views()
+    st = est.state_dict(slots=True)
+    names = set(orc.state)
+    gmax = max(float(np.max(np.abs(v))) for kk, v in orc.slots.items() if kk.endswith('/m'))
+    n_cmp = 0
+    for k in orc.state:
+      key = k + '/m'
+      if key not in orc.slots or key not in st:
+        continue
+      if k.endswith('/bias') and (k[:-len('/bias')] + '/bn/gamma') in names:
+        continue  # d(loss)/d(bias) == 0 under BatchNorm: rounding noise
+      ref = orc.slots[key]
+      d, scale = float(np.max(np.abs(st[key] - ref))), float(np.max(np.abs(ref)))
+      assert d <= 2e-4 * scale + 2e-6 * gmax, (key, d, scale)
+      n_cmp += 1
+    assert n_cmp > 5
+  return est
+
+
+@pytest.mark.parametrize('lazy', [False, True])
+def test_dcn_matches_oracle(lazy):
+  _first_steps(_cfg('dcn_criteo_small.config', lazy), 128, 21)
+
+
+@pytest.mark.parametrize('lazy', [False, True])
+def test_multi_tower_din_matches_oracle(lazy):
+  _first_steps(_cfg('din_taobao_small.config', lazy), 128, 22)
+
+
+def test_mmoe_matches_oracle():
+  # seed chosen away from a ReLU tie: with seed 23 one pre-activation of expert_3 sits within rounding of 0, the
+  # GPU and the oracle take different sides and that one example's gradient (1/128 of the batch) differs by ~1%
+  # (tools/dbg_mmoe_gpu.py reproduces it; seeds 24-27 agree to 3e-6)
+  _first_steps(_cfg('mmoe_taobao_small.config'), 128, 24)
+
+
+@pytest.mark.parametrize('name,B', [('din_taobao.config', 4096), ('mmoe_taobao.config', 4096),
+                                    ('dcn_criteo.config', 4096)])
+def test_full_size_models_train_and_replay_as_graph(name, B):
+  """BASELINE shapes (B=4096; DIN with L=50): a few eager steps, then hipGraph replay; the loss must stay
+  finite and decrease on a repeated batch; ms/step is printed for the record."""
+  import time
+  cfg = _cfg(name, lazy=True)
+  est = EasyRecEstimator(cfg, device=DEV, batch_size=B, seed=1).build()
+  gen = SyntheticBatches(cfg.data_config, est.feature_configs, batch_size=B, seed=5)
+  batch = {k: torch.from_numpy(np.ascontiguousarray(v)).to(DEV) for k, v in gen.next_batch().items()}
+  est.features.load(batch)
+  est.train_step()
+  first = est.loss_values()['total_loss']
+  est.capture(warmup=2)
+  for _ in range(5):
+    est.train_step()
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  n = 30
+  for _ in range(n):
+    est.train_step()
+  torch.cuda.synchronize()
+  ms = (time.perf_counter() - t0) / n * 1e3
+  last = est.loss_values()['total_loss']
+  print('%s B=%d: %.3f ms/step (%.0f examples/s), loss %.4f -> %.4f' % (name, B, ms, B / ms * 1e3, first, last))
+  assert np.isfinite(last) and last < first

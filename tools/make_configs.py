@@ -115,6 +115,138 @@ def dcn_criteo(**kw):
   return cfg
 
 
+# ---------------------------------------------------------------------------------------------
+# Taobao-shaped configs (the feature set of the reference's samples/model_config/*_on_taobao.config)
+# ---------------------------------------------------------------------------------------------
+TAOBAO_ID_FEATURES = [  # (name, hash_bucket_size)
+    ('pid', 10), ('adgroup_id', 100000), ('cate_id', 10000), ('campaign_id', 100000), ('customer', 100000),
+    ('brand', 100000), ('user_id', 100000), ('cms_segid', 100), ('cms_group_id', 100), ('final_gender_code', 10),
+    ('age_level', 10), ('pvalue_level', 10), ('shopping_level', 10), ('occupation', 10),
+    ('new_user_class_level', 10)]
+TAOBAO_USER = ['user_id', 'cms_segid', 'cms_group_id', 'age_level', 'pvalue_level', 'shopping_level', 'occupation',
+               'new_user_class_level']
+TAOBAO_ITEM = ['adgroup_id', 'cate_id', 'campaign_id', 'customer', 'brand', 'price', 'pid']
+
+
+def taobao_base(list_type, batch_size=4096, scale=1.0, embedding_dim=16, seq_len=50, item_rows=None):
+  """list_type: 'tag' (TagFeature multi-hot lists, MMoE/DCN samples) or 'seq' (SequenceFeature, DIN sample)."""
+  cfg = pipeline_pb2.EasyRecConfig()
+  cfg.train_input_path = 'data/test/tb_data/taobao_train_data'
+  cfg.eval_input_path = 'data/test/tb_data/taobao_test_data'
+  tc = cfg.train_config
+  tc.log_step_count_steps = 100
+  oc = tc.optimizer_config.add()
+  lr = oc.adam_optimizer.learning_rate.exponential_decay_learning_rate
+  lr.initial_learning_rate, lr.decay_steps, lr.decay_factor, lr.min_learning_rate = 0.001, 1000, 0.5, 0.00001
+  oc.use_moving_average = False
+  tc.save_checkpoints_steps = 100
+  tc.sync_replicas = True
+  tc.num_steps = 2500
+  cfg.eval_config.metrics_set.add().auc.SetInParent()
+  dc = cfg.data_config
+  for name in ('clk', 'buy'):
+    f = dc.input_fields.add()
+    f.input_name, f.input_type = name, DatasetConfig.INT32
+  for name, _ in TAOBAO_ID_FEATURES:
+    f = dc.input_fields.add()
+    f.input_name, f.input_type = name, DatasetConfig.STRING
+  for name in ('tag_category_list', 'tag_brand_list'):
+    f = dc.input_fields.add()
+    f.input_name, f.input_type = name, DatasetConfig.STRING
+  f = dc.input_fields.add()
+  f.input_name, f.input_type = 'price', DatasetConfig.INT32
+  dc.batch_size = batch_size
+  dc.num_epochs = 10000
+  dc.prefetch_size = 32
+  dc.input_type = DatasetConfig.CSVInput
+  for name, buckets in TAOBAO_ID_FEATURES:
+    fc = cfg.feature_config.features.add()
+    fc.input_names.append(name)
+    fc.feature_type = FeatureConfig.IdFeature
+    fc.embedding_dim = embedding_dim
+    b = max(int(buckets * scale), 4) if buckets > 100 else buckets
+    if item_rows and name == 'adgroup_id':
+      b = item_rows
+    fc.hash_bucket_size = b
+  for name in ('tag_category_list', 'tag_brand_list'):
+    fc = cfg.feature_config.features.add()
+    fc.input_names.append(name)
+    fc.embedding_dim = embedding_dim
+    fc.hash_bucket_size = max(int(100000 * scale), 4)
+    fc.separator = '|'
+    if list_type == 'tag':
+      fc.feature_type = FeatureConfig.TagFeature
+    else:
+      fc.feature_type = FeatureConfig.SequenceFeature
+      fc.max_seq_len = seq_len
+  fc = cfg.feature_config.features.add()
+  fc.input_names.append('price')
+  fc.feature_type = FeatureConfig.IdFeature
+  fc.embedding_dim = embedding_dim
+  fc.num_buckets = 50
+  return cfg
+
+
+def din_taobao(**kw):
+  """MultiTowerDIN, the shape of samples/model_config/din_on_taobao.config (BASELINE config 4)."""
+  cfg = taobao_base('seq', **kw)
+  cfg.model_dir = 'experiments/din_taobao_ckpt'
+  cfg.data_config.label_fields.append('clk')
+  mc = cfg.model_config
+  mc.model_class = 'MultiTowerDIN'
+  for gname, names in (('user', TAOBAO_USER), ('item', TAOBAO_ITEM)):
+    g = mc.feature_groups.add()
+    g.group_name = gname
+    g.feature_names.extend(names)
+    g.wide_deep = WideOrDeep.DEEP
+  sg = mc.seq_att_groups.add()
+  sg.group_name = 'din'
+  for key, hist in (('brand', 'tag_brand_list'), ('cate_id', 'tag_category_list')):
+    m = sg.seq_att_map.add()
+    m.key.append(key)
+    m.hist_seq.append(hist)
+  mt = mc.multi_tower
+  for gname in ('user', 'item'):
+    t = mt.towers.add()
+    t.input = gname
+    t.dnn.hidden_units.extend([256, 128, 96, 64])
+  dt = mt.din_towers.add()
+  dt.input = 'din'
+  dt.dnn.hidden_units.extend([128, 64, 32, 1])
+  mt.final_dnn.hidden_units.extend([128, 96, 64, 32, 16])
+  mt.l2_regularization = 5e-7
+  mc.embedding_regularization = 5e-5
+  return cfg
+
+
+def mmoe_taobao(n_tasks=2, **kw):
+  """MMoE, the shape of samples/model_config/mmoe_on_taobao.config (BASELINE config 5 uses 4 tasks)."""
+  cfg = taobao_base('tag', **kw)
+  cfg.model_dir = 'experiments/mmoe_taobao_ckpt'
+  cfg.data_config.label_fields.extend(['clk', 'buy'])
+  mc = cfg.model_config
+  mc.model_class = 'MMoE'
+  g = mc.feature_groups.add()
+  g.group_name = 'all'
+  g.feature_names.extend(TAOBAO_USER + ['adgroup_id', 'cate_id', 'campaign_id', 'customer', 'brand', 'price', 'pid',
+                                        'tag_category_list', 'tag_brand_list'])
+  g.wide_deep = WideOrDeep.DEEP
+  mm = mc.mmoe
+  mm.expert_dnn.hidden_units.extend([256, 192, 128, 64])
+  mm.num_expert = 4
+  towers = [('ctr', 'clk'), ('cvr', 'buy'), ('ctr2', 'clk'), ('cvr2', 'buy')][:n_tasks]
+  for tname, label in towers:
+    t = mm.task_towers.add()
+    t.tower_name, t.label_name = tname, label
+    t.dnn.hidden_units.extend([256, 192, 128, 64])
+    t.num_class = 1
+    t.weight = 1.0
+    t.metrics_set.add().auc.SetInParent()
+  mm.l2_regularization = 1e-6
+  mc.embedding_regularization = 5e-5
+  return cfg
+
+
 def write(cfg, name):
   out = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'configs', name)
   with open(out, 'w') as f:
@@ -127,7 +259,11 @@ if __name__ == '__main__':
   write(deepfm_criteo(), 'deepfm_criteo.config')
   write(deepfm_criteo(optimizer='lazy_adam_optimizer'), 'deepfm_criteo_lazy_adam.config')
   write(deepfm_criteo(hash_bucket_size=1000, batch_size=256), 'deepfm_criteo_small.config')
-  try:
-    write(dcn_criteo(), 'dcn_criteo.config')
-  except Exception as e:  # pragma: no cover
-    print('dcn config skipped:', e)
+  write(dcn_criteo(), 'dcn_criteo.config')
+  write(dcn_criteo(hash_bucket_size=1000, batch_size=256), 'dcn_criteo_small.config')
+  write(din_taobao(), 'din_taobao.config')
+  write(din_taobao(item_rows=10000000), 'din_taobao_10m.config')
+  write(din_taobao(batch_size=128, scale=0.01, seq_len=12), 'din_taobao_small.config')
+  write(mmoe_taobao(), 'mmoe_taobao.config')
+  write(mmoe_taobao(n_tasks=4, embedding_dim=64, batch_size=8192), 'mmoe_taobao_4task_d64.config')
+  write(mmoe_taobao(batch_size=128, scale=0.01), 'mmoe_taobao_small.config')
