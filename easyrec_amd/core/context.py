@@ -24,6 +24,7 @@ class ModelContext(object):
     self.engine = engine
     self.is_training = is_training
     self.building = True  # build pass: variables are being created, moving statistics frozen
+    self.dense_dtype = 'f32'  # 'bf16': MLP / cross GEMMs on bf16 MFMA with fp32 accumulate (er_gemm_bf16)
 
 
 @contextlib.contextmanager

@@ -159,9 +159,9 @@ bn_bwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ bia
 }
 
 __global__ void __launch_bounds__(kBlock)
-bn_bwd_finalize_kernel(const float* __restrict__ partial, int N, int chunks, int use_bn, float* __restrict__ sum_g,
-                       float* __restrict__ sum_gx, float* __restrict__ dbias, float* __restrict__ dgamma,
-                       float* __restrict__ dbeta) {
+bn_bwd_finalize_kernel(const float* __restrict__ partial, int N, int chunks, int use_bn, int accumulate,
+                       float* __restrict__ sum_g, float* __restrict__ sum_gx, float* __restrict__ dbias,
+                       float* __restrict__ dgamma, float* __restrict__ dbeta) {
   const int lane = threadIdx.x & 63;
   const int c = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   if (c >= N) return;
@@ -177,11 +177,11 @@ bn_bwd_finalize_kernel(const float* __restrict__ partial, int N, int chunks, int
   sum_g[c] = a;
   sum_gx[c] = b;
   if (use_bn) {
-    if (dbeta) dbeta[c] = a;
-    if (dgamma) dgamma[c] = b;
-    if (dbias) dbias[c] = 0.f;  // BatchNorm removes the column mean: d(loss)/d(bias) == 0
+    if (dbeta) dbeta[c] = accumulate ? dbeta[c] + a : a;
+    if (dgamma) dgamma[c] = accumulate ? dgamma[c] + b : b;
+    if (dbias && !accumulate) dbias[c] = 0.f;  // BatchNorm removes the column mean: d(loss)/d(bias) == 0
   } else {
-    if (dbias) dbias[c] = a;
+    if (dbias) dbias[c] = accumulate ? dbias[c] + a : a;
   }
 }
 
@@ -481,7 +481,7 @@ int er_bn_act_fwd(const float* x, const float* bias, const float* gamma, const f
 
 int er_bn_act_bwd(const float* x, const float* bias, const float* gamma, const float* y, const float* save_mean,
                   const float* save_invstd, const float* dy, int32_t B, int32_t N, int use_bn, int act, float* dx,
-                  float* dbias, float* dgamma, float* dbeta, er_stream_t stream) {
+                  float* dbias, float* dgamma, float* dbeta, int accumulate, er_stream_t stream) {
   ER_REQUIRE(x && y && dy && dx && B > 0 && N > 0, "er_bn_act_bwd: bad arguments");
   hipStream_t s = er::as_stream(stream);
   const int64_t n = static_cast<int64_t>(B) * N;
@@ -494,7 +494,7 @@ int er_bn_act_bwd(const float* x, const float* bias, const float* gamma, const f
                      N, chunks, use_bn, act, scratch);
   ER_LAUNCH_CHECK();
   hipLaunchKernelGGL(er::bn_bwd_finalize_kernel, dim3(er::blocks_for(static_cast<int64_t>(N) * 64)), dim3(er::kBlock), 0, s, scratch, N, chunks,
-                     use_bn, sums, sums + N, dbias, dgamma, dbeta);
+                     use_bn, accumulate, sums, sums + N, dbias, dgamma, dbeta);
   ER_LAUNCH_CHECK();
   hipLaunchKernelGGL(er::bn_bwd_apply_kernel, dim3(er::blocks_for(n)), dim3(er::kBlock), 0, s, x, bias, gamma, y,
                      save_mean, save_invstd, dy, sums, sums + N, n, B, N, use_bn, act, dx);

@@ -27,7 +27,6 @@
 namespace er {
 
 constexpr uint32_t kInvalidKey = 0xFFFFFFFFu;
-constexpr int kChunk = 32;  // positions per reduction piece
 
 __host__ __device__ __forceinline__ void lane_geom(int dim, int& V, int& G) {
   V = (dim % 4 == 0) ? 4 : 1;
@@ -255,29 +254,6 @@ __device__ __forceinline__ void gather_grad(Vec<V>& acc, const float* gp, int c,
   acc.add_scaled(g, scale);
 }
 
-// Level 1: one lane-group per chunk boundary q = c*kChunk.  When a run of equal keys continues
-// across q, sum its entries inside chunk c (in sorted = source order) into piece_sum[c].
-template <int V>
-__global__ void __launch_bounds__(kBlock)
-emb_bwd_piece_kernel(const uint32_t* __restrict__ skeys, const uint32_t* __restrict__ svals,
-                     const float* const* __restrict__ ent_gptr, const float* __restrict__ ent_scale,
-                     int64_t n, int dim, int G, float* __restrict__ piece_sum) {
-  const int64_t grp = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) / G;
-  const int c = (static_cast<int>(threadIdx.x) % G) * V;
-  const int64_t q = (grp + 1) * kChunk;
-  if (q >= n || c >= dim) return;
-  const uint32_t key = skeys[q];
-  if (key == kInvalidKey || skeys[q - 1] != key) return;
-  Vec<V> acc;
-  acc.zero();
-  const int64_t e = (q + kChunk < n) ? q + kChunk : n;
-  for (int64_t p = q; p < e && skeys[p] == key; ++p) {
-    const uint32_t j = svals[p];
-    gather_grad<V>(acc, ent_gptr[j], c, ent_scale[j]);
-  }
-  acc.store(piece_sum + (grp + 1) * dim + c);
-}
-
 struct RowUpdate {
   float* var;
   float* m;
@@ -340,53 +316,162 @@ __device__ __forceinline__ void update_row(const RowUpdate& t, int opt_kind, con
   st_vec<V>(t.var + off, var);
 }
 
-// Level 2: one lane-group per sorted position; the head of every run sums the run (its own chunk
-// tail in order, then the level-1 pieces in order) and either applies the optimizer to the row
-// (mode 0) or marks itself for compaction (mode 1: writes the summed gradient to run_grad[p]).
+// ------------------------------------------------------------------------------------------------
+// De-duplicated gradient = segmented sum over the SORTED entries, then the row-wise optimizer.
+//
+// Tile kernel: a workgroup owns T = 4 * (256 / G) consecutive sorted entries (G lanes x 16 B per row).
+//   1. gather the entries' scaled upstream-gradient rows into LDS (random 64 B reads, 4 in flight/lane);
+//   2. in-LDS segmented inclusive scan over the tile (Hillis-Steele with key equality as the segment
+//      flag: log2(T) steps, fixed combination order -> deterministic, hot keys cost log T not run length);
+//   3. the last entry of every run that lies completely inside the tile applies the optimizer to its
+//      row (each touched row's var/m/v is read and written once) or, in reduce mode, emits the sum;
+//      runs that cross a tile boundary leave their partial in tile_first / tile_last.
+// Fix kernel: one lane group per tile whose LAST run starts in it and crosses into the next tile:
+//   sum = tile_last[s] + tile_last[whole tiles] + tile_first[end tile], then the same apply / emit.
+// ------------------------------------------------------------------------------------------------
+struct ReduceOut {
+  int mode;                      // 0: apply optimizer, 1: emit (out_grads[u], u = index of the run)
+  const uint32_t* flags;         // mode 1: head flags / exclusive scan of them over sorted positions
+  const uint32_t* head_index;
+  uint32_t* out_keys;
+  float* out_grads;
+};
+
 template <int V>
-__global__ void __launch_bounds__(kBlock)
-emb_bwd_run_kernel(const uint32_t* __restrict__ skeys, const uint32_t* __restrict__ svals,
-                   const float* const* __restrict__ ent_gptr, const float* __restrict__ ent_scale, int64_t n,
-                   int dim, int G, const float* __restrict__ piece_sum, RowUpdate tab, int opt_kind,
-                   const er_opt_hyper* __restrict__ hyper, int mode, const uint32_t* __restrict__ head_index,
-                   uint32_t* __restrict__ out_keys, float* __restrict__ out_grads) {
-  const int64_t p = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) / G;
-  const int sub = static_cast<int>(threadIdx.x) % G;
-  const int c = sub * V;
-  if (p >= n || c >= dim) return;
-  const uint32_t key = skeys[p];
-  if (key == kInvalidKey) return;
-  if (p > 0 && skeys[p - 1] == key) return;
-  Vec<V> acc;
-  acc.zero();
-  const int64_t chunk_end = ((p / kChunk) + 1) * kChunk;
-  const int64_t e = chunk_end < n ? chunk_end : n;
-  int64_t q = p;
-  for (; q < e && skeys[q] == key; ++q) {
-    const uint32_t j = svals[q];
-    gather_grad<V>(acc, ent_gptr[j], c, ent_scale[j]);
-  }
-  if (q == chunk_end) {  // run may continue into following chunks
-    for (int64_t cb = chunk_end; cb < n && skeys[cb] == key; cb += kChunk) {
-      Vec<V> pc;
-      pc.load(piece_sum + (cb / kChunk) * dim + c);
-      acc.add(pc);
-    }
-  }
+__device__ __forceinline__ void finish_run(const RowUpdate& tab, int opt_kind, const er_opt_hyper* hyper,
+                                           const ReduceOut& ro, uint32_t key, int64_t p, int sub, int c, int dim,
+                                           const float* gsum) {
   float g[V];
-  if constexpr (V == 4) { g[0] = acc.v.x; g[1] = acc.v.y; g[2] = acc.v.z; g[3] = acc.v.w; } else { g[0] = acc.v; }
-  if (mode == 0) {
+#pragma unroll
+  for (int i = 0; i < V; ++i) g[i] = gsum[i];
+  if (ro.mode == 0) {
     const er_opt_hyper h = *hyper;
 #pragma unroll
     for (int i = 0; i < V; ++i) g[i] = g[i] * h.grad_scale;
     update_row<V>(tab, opt_kind, h, static_cast<int64_t>(key) * dim + c, g);
     if (opt_kind == ER_OPT_ADAM && sub == 0) atomicOr(&tab.bitmap[key >> 5], 1u << (key & 31));
   } else {
-    const uint32_t u = head_index[p];
-    if (sub == 0) out_keys[u] = key;
+    const uint32_t u = ro.head_index[p] + ro.flags[p] - 1u;
+    if (sub == 0) ro.out_keys[u] = key;
 #pragma unroll
-    for (int i = 0; i < V; ++i) out_grads[static_cast<int64_t>(u) * dim + c + i] = g[i];
+    for (int i = 0; i < V; ++i) ro.out_grads[static_cast<int64_t>(u) * dim + c + i] = g[i];
   }
+}
+
+constexpr int kTilePasses = 4;
+
+template <int V>
+__global__ void __launch_bounds__(kBlock)
+emb_bwd_tile_kernel(const uint32_t* __restrict__ skeys, const uint32_t* __restrict__ svals,
+                    const float* const* __restrict__ ent_gptr, const float* __restrict__ ent_scale, int64_t n,
+                    int dim, int G, RowUpdate tab, int opt_kind, const er_opt_hyper* __restrict__ hyper,
+                    ReduceOut ro, float* __restrict__ tile_first, float* __restrict__ tile_last) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int epp = kBlock / G;            // entries per pass
+  const int T = kTilePasses * epp;       // entries per tile
+  float* vals = smem;                    // [T][dim]
+  uint32_t* keys = reinterpret_cast<uint32_t*>(smem + static_cast<size_t>(T) * dim);  // [T + 2]: prev, tile, next
+  const int tid = threadIdx.x;
+  const int sub = tid % G;
+  const int c = sub * V;
+  const int64_t t0 = static_cast<int64_t>(blockIdx.x) * T;
+  for (int i = tid; i < T + 2; i += kBlock) {
+    const int64_t p = t0 - 1 + i;
+    keys[i] = (p >= 0 && p < n) ? skeys[p] : kInvalidKey;
+  }
+  __syncthreads();
+  const bool col_ok = c < dim;
+  // 1. gather
+#pragma unroll
+  for (int ps = 0; ps < kTilePasses; ++ps) {
+    const int e = ps * epp + tid / G;
+    const int64_t p = t0 + e;
+    Vec<V> acc;
+    acc.zero();
+    if (col_ok && p < n && keys[e + 1] != kInvalidKey) {
+      const uint32_t j = svals[p];
+      gather_grad<V>(acc, ent_gptr[j], c, ent_scale[j]);
+    }
+    if (col_ok) acc.store(vals + static_cast<size_t>(e) * dim + c);
+  }
+  __syncthreads();
+  // 2. segmented inclusive scan (sorted keys: equal key at distance `off` => same run)
+  for (int off = 1; off < T; off <<= 1) {
+    Vec<V> add[kTilePasses];
+#pragma unroll
+    for (int ps = 0; ps < kTilePasses; ++ps) {
+      const int e = ps * epp + tid / G;
+      add[ps].zero();
+      if (col_ok && e >= off && keys[e + 1] != kInvalidKey && keys[e + 1 - off] == keys[e + 1])
+        add[ps].load(vals + static_cast<size_t>(e - off) * dim + c);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ps = 0; ps < kTilePasses; ++ps) {
+      const int e = ps * epp + tid / G;
+      if (col_ok && e >= off && keys[e + 1] != kInvalidKey && keys[e + 1 - off] == keys[e + 1]) {
+        Vec<V> cur;
+        cur.load(vals + static_cast<size_t>(e) * dim + c);
+        cur.add(add[ps]);
+        cur.store(vals + static_cast<size_t>(e) * dim + c);
+      }
+    }
+    __syncthreads();
+  }
+  // 3. run ends
+#pragma unroll
+  for (int ps = 0; ps < kTilePasses; ++ps) {
+    const int e = ps * epp + tid / G;
+    const int64_t p = t0 + e;
+    if (!col_ok || p >= n) continue;
+    const uint32_t key = keys[e + 1];
+    if (key == kInvalidKey) continue;
+    if (keys[e + 2] == key && e != T - 1) continue;           // not the last entry of its run in this tile
+    const bool from_prev = keys[0] == key;                    // sorted: then the run covers the tile up to e
+    const bool to_next = (e == T - 1) && keys[T + 1] == key;  // keys[T + 1] = first key of the next tile
+    const float* gs = vals + static_cast<size_t>(e) * dim + c;
+    if (!from_prev && !to_next) {
+      finish_run<V>(tab, opt_kind, hyper, ro, key, p, sub, c, dim, gs);
+    } else {
+      Vec<V> r;
+      r.load(gs);
+      if (from_prev) r.store(tile_first + static_cast<size_t>(blockIdx.x) * dim + c);
+      if (to_next) r.store(tile_last + static_cast<size_t>(blockIdx.x) * dim + c);
+    }
+  }
+}
+
+template <int V>
+__global__ void __launch_bounds__(kBlock)
+emb_bwd_fix_kernel(const uint32_t* __restrict__ skeys, int64_t n, int dim, int G, int T, int n_tiles,
+                   RowUpdate tab, int opt_kind, const er_opt_hyper* __restrict__ hyper, ReduceOut ro,
+                   const float* __restrict__ tile_first, const float* __restrict__ tile_last) {
+  const int64_t s = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) / G;  // start tile candidate
+  const int sub = static_cast<int>(threadIdx.x) % G;
+  const int c = sub * V;
+  if (s >= n_tiles || c >= dim) return;
+  const int64_t next0 = (s + 1) * T;
+  if (next0 >= n) return;                       // last tile: nothing to cross into
+  const uint32_t key = skeys[next0 - 1];
+  if (key == kInvalidKey || skeys[next0] != key) return;  // the tile's last run ends with the tile
+  if (s > 0 && skeys[s * T - 1] == key) return;            // the run came from an earlier tile: not its owner
+  Vec<V> acc;
+  acc.load(tile_last + s * dim + c);
+  for (int64_t m = s + 1; m < n_tiles; ++m) {
+    const int64_t mnext = (m + 1) * T;
+    Vec<V> part;
+    if (mnext < n && skeys[mnext - 1] == key && skeys[mnext] == key) {  // whole tile m, and it goes on
+      part.load(tile_last + m * dim + c);
+      acc.add(part);
+    } else {                                                            // the run ends inside tile m
+      part.load(tile_first + m * dim + c);
+      acc.add(part);
+      break;
+    }
+  }
+  float g[V];
+  if constexpr (V == 4) { g[0] = acc.v.x; g[1] = acc.v.y; g[2] = acc.v.z; g[3] = acc.v.w; } else { g[0] = acc.v; }
+  finish_run<V>(tab, opt_kind, hyper, ro, key, next0 - 1, sub, c, dim, g);
 }
 
 __global__ void __launch_bounds__(kBlock)
@@ -661,7 +746,8 @@ struct er_emb_group {
   uint32_t *keys_in = nullptr, *keys_out = nullptr, *vals_in = nullptr, *vals_out = nullptr;
   const float** ent_gptr = nullptr;
   float* ent_scale = nullptr;
-  float* piece_sum = nullptr;
+  float *tile_first = nullptr, *tile_last = nullptr;
+  int tile_entries = 0;
   uint32_t *head_flags = nullptr, *head_index = nullptr;
   void* sort_temp = nullptr;
   size_t sort_temp_bytes = 0;
@@ -779,7 +865,12 @@ int er_emb_group_create(const er_lookup_desc* descs, int n, int32_t dim, int64_t
   ER_CHECK_HIP(hipMalloc(&g->vals_out, sizeof(uint32_t) * N));
   ER_CHECK_HIP(hipMalloc(&g->ent_gptr, sizeof(float*) * N));
   ER_CHECK_HIP(hipMalloc(&g->ent_scale, sizeof(float) * N));
-  ER_CHECK_HIP(hipMalloc(&g->piece_sum, sizeof(float) * (er::ceil_div(N, er::kChunk) + 1) * dim));
+  g->tile_entries = er::kTilePasses * (er::kBlock / g->G);
+  {
+    const size_t nt = static_cast<size_t>(er::ceil_div(N, g->tile_entries)) + 1;
+    ER_CHECK_HIP(hipMalloc(&g->tile_first, sizeof(float) * nt * dim));
+    ER_CHECK_HIP(hipMalloc(&g->tile_last, sizeof(float) * nt * dim));
+  }
   ER_CHECK_HIP(hipMalloc(&g->head_flags, sizeof(uint32_t) * N));
   ER_CHECK_HIP(hipMalloc(&g->head_index, sizeof(uint32_t) * N));
   ER_CHECK_HIP(hipMemset(g->keys_in, 0xFF, sizeof(uint32_t) * N));
@@ -803,7 +894,7 @@ int er_emb_group_update(er_emb_group* g, const er_lookup_desc* descs, int n) {
 int er_emb_group_destroy(er_emb_group* g) {
   if (!g) return 0;
   void* ptrs[] = {g->d_descs, g->d_blk_start, g->d_ent_base, g->keys_in, g->keys_out, g->vals_in, g->vals_out,
-                  g->ent_gptr, g->ent_scale, g->piece_sum, g->head_flags, g->head_index, g->sort_temp, g->scan_temp,
+                  g->ent_gptr, g->ent_scale, g->tile_first, g->tile_last, g->head_flags, g->head_index, g->sort_temp, g->scan_temp,
                   g->d_local_base};
   for (void* q : ptrs) (void)hipFree(q);
   delete g;
@@ -829,28 +920,7 @@ static int emb_group_build_sort(er_emb_group* g, hipStream_t s) {
   return 0;
 }
 
-// level-1 pieces of the in-order segmented reduction (reads the upstream gradients)
-static int emb_group_pieces(er_emb_group* g, hipStream_t s) {
-  const int64_t N = group_entries(g);
-  const int64_t n_bound = er::ceil_div(N, er::kChunk) - 1;  // chunk boundaries
-  if (n_bound > 0) {
-    const int blocks = static_cast<int>(er::ceil_div(n_bound * g->G, er::kBlock));
-    if (g->V == 4) {
-      hipLaunchKernelGGL(er::emb_bwd_piece_kernel<4>, dim3(blocks), dim3(er::kBlock), 0, s, g->keys_out, g->vals_out,
-                         g->ent_gptr, g->ent_scale, N, g->dim, g->G, g->piece_sum);
-    } else {
-      hipLaunchKernelGGL(er::emb_bwd_piece_kernel<1>, dim3(blocks), dim3(er::kBlock), 0, s, g->keys_out, g->vals_out,
-                         g->ent_gptr, g->ent_scale, N, g->dim, g->G, g->piece_sum);
-    }
-    ER_LAUNCH_CHECK();
-  }
-  return 0;
-}
-
-static int emb_group_sort(er_emb_group* g, hipStream_t s) {
-  if (int rc = emb_group_build_sort(g, s)) return rc;
-  return emb_group_pieces(g, s);
-}
+static int emb_group_sort(er_emb_group* g, hipStream_t s) { return emb_group_build_sort(g, s); }
 
 // head flags + exclusive scan + unique count over the sorted keys
 static int emb_group_heads(er_emb_group* g, int32_t* n_unique, hipStream_t s) {
@@ -869,16 +939,26 @@ static int emb_group_run(er_emb_group* g, int opt_kind, const er_opt_hyper* hype
                          float* out_grads, hipStream_t s) {
   const int64_t N = group_entries(g);
   if (N == 0) return 0;
-  const int blocks = static_cast<int>(er::ceil_div(N * g->G, er::kBlock));
+  const int T = g->tile_entries;
+  const int n_tiles = static_cast<int>(er::ceil_div(N, T));
   er::RowUpdate tab{g->var, g->m, g->v, g->bitmap};
+  er::ReduceOut ro{mode, g->head_flags, g->head_index, out_keys, out_grads};
+  const size_t lds = sizeof(float) * static_cast<size_t>(T) * g->dim + sizeof(uint32_t) * (T + 2);
+  const int fix_blocks = static_cast<int>(er::ceil_div(static_cast<int64_t>(n_tiles) * g->G, er::kBlock));
   if (g->V == 4) {
-    hipLaunchKernelGGL(er::emb_bwd_run_kernel<4>, dim3(blocks), dim3(er::kBlock), 0, s, g->keys_out, g->vals_out,
-                       g->ent_gptr, g->ent_scale, N, g->dim, g->G, g->piece_sum, tab, opt_kind, hyper, mode,
-                       g->head_index, out_keys, out_grads);
+    hipLaunchKernelGGL(er::emb_bwd_tile_kernel<4>, dim3(n_tiles), dim3(er::kBlock), lds, s, g->keys_out, g->vals_out,
+                       g->ent_gptr, g->ent_scale, N, g->dim, g->G, tab, opt_kind, hyper, ro, g->tile_first, g->tile_last);
+    ER_LAUNCH_CHECK();
+    if (n_tiles > 1)
+      hipLaunchKernelGGL(er::emb_bwd_fix_kernel<4>, dim3(fix_blocks), dim3(er::kBlock), 0, s, g->keys_out, N, g->dim, g->G,
+                         T, n_tiles, tab, opt_kind, hyper, ro, g->tile_first, g->tile_last);
   } else {
-    hipLaunchKernelGGL(er::emb_bwd_run_kernel<1>, dim3(blocks), dim3(er::kBlock), 0, s, g->keys_out, g->vals_out,
-                       g->ent_gptr, g->ent_scale, N, g->dim, g->G, g->piece_sum, tab, opt_kind, hyper, mode,
-                       g->head_index, out_keys, out_grads);
+    hipLaunchKernelGGL(er::emb_bwd_tile_kernel<1>, dim3(n_tiles), dim3(er::kBlock), lds, s, g->keys_out, g->vals_out,
+                       g->ent_gptr, g->ent_scale, N, g->dim, g->G, tab, opt_kind, hyper, ro, g->tile_first, g->tile_last);
+    ER_LAUNCH_CHECK();
+    if (n_tiles > 1)
+      hipLaunchKernelGGL(er::emb_bwd_fix_kernel<1>, dim3(fix_blocks), dim3(er::kBlock), 0, s, g->keys_out, N, g->dim, g->G,
+                         T, n_tiles, tab, opt_kind, hyper, ro, g->tile_first, g->tile_last);
   }
   ER_LAUNCH_CHECK();
   return 0;
@@ -1040,7 +1120,6 @@ int er_emb_bwd_reduce_routed(er_emb_group* g, float* unique_grads, er_stream_t s
   ER_REQUIRE(g && unique_grads, "er_emb_bwd_reduce_routed: null argument");
   ER_REQUIRE(g->sorted_valid, "er_emb_bwd_reduce_routed: call er_emb_route for this step first");
   hipStream_t s = er::as_stream(stream);
-  if (int rc = emb_group_pieces(g, s)) return rc;
   // unique keys were already written by er_emb_route: out_keys is a scratch sink here
   return emb_group_run(g, ER_OPT_SGD, nullptr, 1, g->keys_in, unique_grads, s);
 }

@@ -1,0 +1,377 @@
+// K13: the dense contractions of the hot path on the gfx950 matrix cores.
+//
+// Replaces the MatMul ops of tf.layers.dense (reference layers/dnn.py:57-62, model/deepfm.py:84-104,
+// layers/mmoe.py:53-58, keras Dense in layers/keras/blocks.py:84-89, Cross layers/keras/interaction.py:
+// 249-286) and their two gradients.  Until now these went through torch.mm (rocBLAS picked fp32 tiles
+// that reach ~14 TFLOP/s on these skinny shapes and, with atomics allowed, are not run-to-run
+// deterministic).
+//
+// MI355X design
+//   * fp32 path: v_mfma_f32_32x32x2_f32 - exact f32 (bit-equal to an fmaf chain in k order), 64 FLOP/clk
+//     per SIMD = the chip's 157 TFLOP/s f32 peak; needed because the north-star bar is 1e-4 on fp32 logits.
+//   * bf16 path (config 3, "bf16 dense + fp32 emb"): fp32 operands in HBM are rounded to bf16 (RNE) while
+//     being staged into LDS - no separate cast pass, fp32 master weights - and contracted with
+//     v_mfma_f32_32x32x16_bf16 into fp32 accumulators.
+//   * one workgroup = 4 waves = a 64x64 output tile, each wave one 32x32 accumulator (16 VGPRs); operands
+//     staged through LDS in k-major layout so that the per-lane fragment reads are conflict-free
+//     (row strides 65 / 68 floats: MI355X_MICROARCH.md LDS banking); next tile's global loads are issued
+//     before the MFMAs of the current one (register double buffer).
+//   * three operand layouts without transposes in HBM: NN (forward x.W), NT (dx = dy.W^T), TN (dW = x^T.dy).
+//     TN contracts over the batch (K = 4096) into a small M x N: split-K over blockIdx.z into a
+//     workspace + a deterministic reduce (no atomics) keeps >= 512 workgroups in flight.
+//   * epilogue: + bias[col], optional accumulate into C (gradients land directly in the flat gradient
+//     buffer: no autograd add kernels), optional per-tile column statistics for BatchNorm.
+#include "er_common.h"
+
+namespace er {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 64, BN = 64;
+constexpr int BK32 = 32;   // k-tile of the f32 kernel
+constexpr int BK16 = 32;   // k-tile of the bf16 kernel (two 32x32x16 steps)
+
+struct GemmArgs {
+  const float* A;
+  const float* B;
+  float* C;           // output, or split-K workspace [splits][M][N] when splits > 1
+  const float* bias;  // [N] or nullptr (applied by the last stage only)
+  int M, N, K;
+  int lda, ldb, ldc;
+  int accumulate;
+  int k_per_split;    // multiple of the k-tile
+  int splits;
+};
+
+// Loads 4 consecutive elements along the CONTIGUOUS dimension of the operand tile.
+//   K_CONTIG : elements (mn, k..k+3);  else: elements (mn..mn+3, k)
+template <bool K_CONTIG>
+__device__ __forceinline__ f32x4v load4(const float* __restrict__ P, int ld, int mn, int k, int MN, int K,
+                                        bool vec_ok) {
+  f32x4v v = {0.f, 0.f, 0.f, 0.f};
+  if (K_CONTIG) {
+    if (mn >= MN) return v;
+    const float* p = P + static_cast<int64_t>(mn) * ld + k;
+    if (vec_ok && k + 3 < K) {
+      v = *reinterpret_cast<const f32x4v*>(p);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (k + j < K) v[j] = p[j];
+    }
+  } else {
+    if (k >= K) return v;
+    const float* p = P + static_cast<int64_t>(k) * ld + mn;
+    if (vec_ok && mn + 3 < MN) {
+      v = *reinterpret_cast<const f32x4v*>(p);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (mn + j < MN) v[j] = p[j];
+    }
+  }
+  return v;
+}
+
+__device__ __forceinline__ short f32_to_bf16_rne(float f) {
+  uint32_t u = __builtin_bit_cast(uint32_t, f);
+  if ((u & 0x7FFFFFFFu) > 0x7F800000u) return static_cast<short>((u >> 16) | 0x40);  // NaN stays NaN
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return static_cast<short>(u >> 16);
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp32: C tile 64x64, k-tile 32, LDS k-major: As[k][m], Bs[k][n]
+// ------------------------------------------------------------------------------------------------
+template <bool A_KC, bool B_KC>
+__global__ void __launch_bounds__(kBlock)
+gemm_f32_kernel(GemmArgs g) {
+  constexpr int SA = A_KC ? BM + 1 : BM + 4;  // transposed scatter stores want an odd stride, float4 stores 16 B
+  constexpr int SB = B_KC ? BN + 1 : BN + 4;
+  __shared__ __attribute__((aligned(16))) float As[BK32 * SA];
+  __shared__ __attribute__((aligned(16))) float Bs[BK32 * SB];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int kbeg = blockIdx.z * g.k_per_split;
+  int kend = kbeg + g.k_per_split;
+  if (kend > g.K) kend = g.K;
+  const bool a_vec = (g.lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0);
+  const bool b_vec = (g.ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0);
+
+  // staging assignment: 64 x 32 elements = 512 float4 per operand -> 2 per thread
+  //   K_CONTIG : unit u -> row mn = u / 8, k4 = (u % 8) * 4      else: unit u -> k = u / 16, mn4 = (u % 16) * 4
+  f32x4v ra[2], rb[2];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int u = tid + i * kBlock;
+      if (A_KC) ra[i] = load4<true>(g.A, g.lda, m0 + (u >> 3), k0 + (u & 7) * 4, g.M, kend, a_vec);
+      else ra[i] = load4<false>(g.A, g.lda, m0 + (u & 15) * 4, k0 + (u >> 4), g.M, kend, a_vec);
+      if (B_KC) rb[i] = load4<true>(g.B, g.ldb, n0 + (u >> 3), k0 + (u & 7) * 4, g.N, kend, b_vec);
+      else rb[i] = load4<false>(g.B, g.ldb, n0 + (u & 15) * 4, k0 + (u >> 4), g.N, kend, b_vec);
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int u = tid + i * kBlock;
+      if (A_KC) {
+        const int mn = u >> 3, k4 = (u & 7) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) As[(k4 + j) * SA + mn] = ra[i][j];
+      } else {
+        *reinterpret_cast<f32x4v*>(&As[(u >> 4) * SA + (u & 15) * 4]) = ra[i];
+      }
+      if (B_KC) {
+        const int mn = u >> 3, k4 = (u & 7) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Bs[(k4 + j) * SB + mn] = rb[i][j];
+      } else {
+        *reinterpret_cast<f32x4v*>(&Bs[(u >> 4) * SB + (u & 15) * 4]) = rb[i];
+      }
+    }
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  const int a_off = wm * 32 + (lane & 31);
+  const int b_off = wn * 32 + (lane & 31);
+  const int khalf = lane >> 5;
+  if (kbeg < kend) fetch(kbeg);
+  for (int k0 = kbeg; k0 < kend; k0 += BK32) {
+    __syncthreads();  // every wave is done reading the previous tile
+    stage();
+    __syncthreads();
+    if (k0 + BK32 < kend) fetch(k0 + BK32);  // in flight while the matrix cores run
+#pragma unroll
+    for (int kk = 0; kk < BK32; kk += 2) {
+      const float a = As[(kk + khalf) * SA + a_off];
+      const float b = Bs[(kk + khalf) * SB + b_off];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+  }
+  // epilogue.  C/D map of the 32x32 tile: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+  const int col = n0 + wn * 32 + (lane & 31);
+  if (col >= g.N) return;
+  float* Cz = g.C + (g.splits > 1 ? static_cast<int64_t>(blockIdx.z) * g.M * g.N : 0);
+  const int ldc = g.splits > 1 ? g.N : g.ldc;
+  const float bv = (g.bias && g.splits == 1) ? g.bias[col] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+    if (row < g.M) {
+      float* p = Cz + static_cast<int64_t>(row) * ldc + col;
+      float v = acc[r] + bv;
+      if (g.accumulate && g.splits == 1) v = *p + v;
+      *p = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// bf16 inputs (rounded from fp32 while staging), fp32 accumulate.  LDS: As[m][k], Bs[n][k] in bf16, row
+// stride 40 halves (80 B): the 16-byte fragment reads of a 16-lane group hit 16 distinct bank quads.
+// Fragment of v_mfma_f32_32x32x16_bf16: lane l holds A[i = l & 31][k = 8 * (l >> 5) + 0..7].
+// ------------------------------------------------------------------------------------------------
+template <bool A_KC, bool B_KC>
+__global__ void __launch_bounds__(kBlock)
+gemm_bf16_kernel(GemmArgs g) {
+  constexpr int SH = BK16 + 8;  // halves per row
+  __shared__ __attribute__((aligned(16))) short As[BM * SH];
+  __shared__ __attribute__((aligned(16))) short Bs[BN * SH];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int kbeg = blockIdx.z * g.k_per_split;
+  int kend = kbeg + g.k_per_split;
+  if (kend > g.K) kend = g.K;
+  const bool a_vec = (g.lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0);
+  const bool b_vec = (g.ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0);
+  f32x4v ra[2], rb[2];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int u = tid + i * kBlock;
+      if (A_KC) ra[i] = load4<true>(g.A, g.lda, m0 + (u >> 3), k0 + (u & 7) * 4, g.M, kend, a_vec);
+      else ra[i] = load4<false>(g.A, g.lda, m0 + (u & 15) * 4, k0 + (u >> 4), g.M, kend, a_vec);
+      if (B_KC) rb[i] = load4<true>(g.B, g.ldb, n0 + (u >> 3), k0 + (u & 7) * 4, g.N, kend, b_vec);
+      else rb[i] = load4<false>(g.B, g.ldb, n0 + (u & 15) * 4, k0 + (u >> 4), g.N, kend, b_vec);
+    }
+  };
+  auto put = [&](short* S, const f32x4v& v, int u, bool kc) {
+    if (kc) {  // 4 consecutive k of one row: one 8-byte store
+      bf16x4 h = {f32_to_bf16_rne(v[0]), f32_to_bf16_rne(v[1]), f32_to_bf16_rne(v[2]), f32_to_bf16_rne(v[3])};
+      *reinterpret_cast<bf16x4*>(&S[(u >> 3) * SH + (u & 7) * 4]) = h;
+    } else {   // one k of 4 consecutive rows
+      const int k = u >> 4, mn4 = (u & 15) * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) S[(mn4 + j) * SH + k] = f32_to_bf16_rne(v[j]);
+    }
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  const int a_row = wm * 32 + (lane & 31);
+  const int b_row = wn * 32 + (lane & 31);
+  const int kgrp = (lane >> 5) * 8;
+  if (kbeg < kend) fetch(kbeg);
+  for (int k0 = kbeg; k0 < kend; k0 += BK16) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      put(As, ra[i], tid + i * kBlock, A_KC);
+      put(Bs, rb[i], tid + i * kBlock, B_KC);
+    }
+    __syncthreads();
+    if (k0 + BK16 < kend) fetch(k0 + BK16);
+#pragma unroll
+    for (int kk = 0; kk < BK16; kk += 16) {
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(&As[a_row * SH + kk + kgrp]);
+      const bf16x8 b = *reinterpret_cast<const bf16x8*>(&Bs[b_row * SH + kk + kgrp]);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+    }
+  }
+  const int col = n0 + wn * 32 + (lane & 31);
+  if (col >= g.N) return;
+  float* Cz = g.C + (g.splits > 1 ? static_cast<int64_t>(blockIdx.z) * g.M * g.N : 0);
+  const int ldc = g.splits > 1 ? g.N : g.ldc;
+  const float bv = (g.bias && g.splits == 1) ? g.bias[col] : 0.f;
+  const int khalf = lane >> 5;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+    if (row < g.M) {
+      float* p = Cz + static_cast<int64_t>(row) * ldc + col;
+      float v = acc[r] + bv;
+      if (g.accumulate && g.splits == 1) v = *p + v;
+      *p = v;
+    }
+  }
+}
+
+// C[i, j] (+)= bias[j] + sum_s ws[s, i, j]   (split order fixed: deterministic)
+__global__ void __launch_bounds__(kBlock)
+gemm_splitk_reduce_kernel(const float* __restrict__ ws, int64_t mn, int N, int splits, const float* __restrict__ bias,
+                          float* __restrict__ C, int ldc, int accumulate) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i >= mn) return;
+  float s = 0.f;
+  for (int z = 0; z < splits; ++z) s = s + ws[z * mn + i];
+  const int64_t row = i / N;
+  const int col = static_cast<int>(i % N);
+  if (bias) s = s + bias[col];
+  float* p = C + row * ldc + col;
+  *p = accumulate ? *p + s : s;
+}
+
+}  // namespace er
+
+namespace {
+
+float* g_gemm_ws = nullptr;
+size_t g_gemm_ws_floats = 0;
+
+int ensure_ws(size_t floats, float** out) {
+  if (floats > g_gemm_ws_floats) {
+    // growing is a hipMalloc: not capturable.  er_gemm_reserve() pre-sizes it before graph capture.
+    if (g_gemm_ws) (void)hipFree(g_gemm_ws);
+    g_gemm_ws = nullptr;
+    g_gemm_ws_floats = 0;
+    ER_CHECK_HIP(hipMalloc(&g_gemm_ws, floats * sizeof(float)));
+    g_gemm_ws_floats = floats;
+  }
+  *out = g_gemm_ws;
+  return 0;
+}
+
+template <bool BF16>
+int launch_gemm(int layout, er::GemmArgs& a, hipStream_t s) {
+  dim3 grid(static_cast<unsigned>(er::ceil_div(a.N, er::BN)), static_cast<unsigned>(er::ceil_div(a.M, er::BM)),
+            static_cast<unsigned>(a.splits));
+  dim3 block(er::kBlock);
+#define ER_LAUNCH_GEMM(KERNEL)                                                   \
+  switch (layout) {                                                              \
+    case ER_GEMM_NN: hipLaunchKernelGGL((KERNEL<true, false>), grid, block, 0, s, a); break;  \
+    case ER_GEMM_NT: hipLaunchKernelGGL((KERNEL<true, true>), grid, block, 0, s, a); break;   \
+    case ER_GEMM_TN: hipLaunchKernelGGL((KERNEL<false, false>), grid, block, 0, s, a); break; \
+    default: er::set_error("er_gemm: unknown layout %d", layout); return 2;     \
+  }
+  if (BF16) {
+    ER_LAUNCH_GEMM(er::gemm_bf16_kernel)
+  } else {
+    ER_LAUNCH_GEMM(er::gemm_f32_kernel)
+  }
+#undef ER_LAUNCH_GEMM
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
+int choose_splits(int M, int N, int K, int ktile) {
+  const int64_t tiles = er::ceil_div(M, er::BM) * er::ceil_div(N, er::BN);
+  if (tiles >= 256 || K < 1024) return 1;  // split only the batch-long contractions (dW = x^T.dy)
+  int64_t s = 512 / tiles;
+  const int64_t max_by_k = K / (4 * ktile);  // at least 4 k-tiles per split
+  if (s > max_by_k) s = max_by_k;
+  if (s > 64) s = 64;
+  return s < 1 ? 1 : static_cast<int>(s);
+}
+
+template <bool BF16>
+int gemm_entry(int layout, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+               const float* bias, int accumulate, er_stream_t stream, const char* who) {
+  ER_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0, "%s: bad arguments", who);
+  ER_REQUIRE(layout >= ER_GEMM_NN && layout <= ER_GEMM_TN, "%s: unknown layout %d", who, layout);
+  const int min_lda = (layout == ER_GEMM_TN) ? M : K;
+  const int min_ldb = (layout == ER_GEMM_NT) ? K : N;
+  ER_REQUIRE(lda >= min_lda && ldb >= min_ldb && ldc >= N, "%s: leading dimension too small", who);
+  hipStream_t s = er::as_stream(stream);
+  constexpr int ktile = BF16 ? er::BK16 : er::BK32;
+  er::GemmArgs a;
+  a.A = A; a.B = B; a.C = C; a.bias = bias;
+  a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
+  a.accumulate = accumulate;
+  a.splits = choose_splits(M, N, K, ktile);
+  a.k_per_split = static_cast<int>(er::ceil_div(er::ceil_div(K, a.splits), ktile)) * ktile;
+  a.splits = static_cast<int>(er::ceil_div(K, a.k_per_split));
+  if (a.splits > 1) {
+    float* ws;
+    if (int rc = ensure_ws(static_cast<size_t>(a.splits) * M * N, &ws)) return rc;
+    a.C = ws;
+    if (int rc = launch_gemm<BF16>(layout, a, s)) return rc;
+    const int64_t mn = static_cast<int64_t>(M) * N;
+    hipLaunchKernelGGL(er::gemm_splitk_reduce_kernel, dim3(static_cast<unsigned>(er::ceil_div(mn, er::kBlock))),
+                       dim3(er::kBlock), 0, s, ws, mn, N, a.splits, bias, C, ldc, accumulate);
+    ER_LAUNCH_CHECK();
+    return 0;
+  }
+  return launch_gemm<BF16>(layout, a, s);
+}
+
+}  // namespace
+
+extern "C" {
+
+int er_gemm_reserve(int64_t floats) {
+  ER_REQUIRE(floats >= 0, "er_gemm_reserve: negative size");
+  float* p;
+  return ensure_ws(static_cast<size_t>(floats), &p);
+}
+
+int er_gemm_f32(int layout, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B, int32_t ldb,
+                float* C, int32_t ldc, const float* bias, int accumulate, er_stream_t stream) {
+  return gemm_entry<false>(layout, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, stream, "er_gemm_f32");
+}
+
+int er_gemm_bf16(int layout, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B, int32_t ldb,
+                 float* C, int32_t ldc, const float* bias, int accumulate, er_stream_t stream) {
+  return gemm_entry<true>(layout, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, stream, "er_gemm_bf16");
+}
+
+}  // extern "C"

@@ -21,6 +21,7 @@ COMBINER_SUM, COMBINER_MEAN, COMBINER_SQRTN = 0, 1, 2
 COMBINERS = {'sum': COMBINER_SUM, 'mean': COMBINER_MEAN, 'sqrtn': COMBINER_SQRTN}
 OPT_SGD, OPT_ADAM, OPT_LAZY_ADAM, OPT_ADAGRAD = 0, 1, 2, 3
 ACT_NONE, ACT_RELU = 0, 1
+GEMM_NN, GEMM_NT, GEMM_TN = 0, 1, 2
 
 
 class LookupDesc(ctypes.Structure):
@@ -226,6 +227,31 @@ class HipBackend(object):
              'er_emb_bwd_reduce')
     return keys, grads, n_unique
 
+  # -- K13 GEMM on the matrix cores
+  def gemm_reserve(self, floats):
+    self._ck(self.lib.er_gemm_reserve(ctypes.c_int64(int(floats))), 'er_gemm_reserve')
+
+  def gemm(self, layout, a, b, out=None, bias=None, accumulate=False, bf16=False):
+    """out (+)= op(a) . op(b) (+ bias).  2-D fp32 tensors with unit inner stride.
+    layout GEMM_NN: a[M,K] b[K,N]; GEMM_NT: a[M,K] b[N,K]; GEMM_TN: a[K,M] b[K,N]."""
+    assert a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1
+    assert a.dtype == torch.float32 and b.dtype == torch.float32
+    if layout == GEMM_NN:
+      (M, K), (K2, N) = a.shape, b.shape
+    elif layout == GEMM_NT:
+      (M, K), (N, K2) = a.shape, b.shape
+    else:
+      (K, M), (K2, N) = a.shape, b.shape
+    assert K == K2, 'gemm: inner dimensions %d vs %d' % (K, K2)
+    if out is None:
+      assert not accumulate
+      out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    assert out.shape == (M, N) and out.stride(1) == 1 and out.dtype == torch.float32
+    fn = self.lib.er_gemm_bf16 if bf16 else self.lib.er_gemm_f32
+    self._ck(fn(ctypes.c_int(layout), M, N, K, _p(a), ctypes.c_int32(a.stride(0)), _p(b), ctypes.c_int32(b.stride(0)),
+                _p(out), ctypes.c_int32(out.stride(0)), _p(bias), int(bool(accumulate)), _stream()), 'er_gemm')
+    return out
+
   # -- K12 embedding-parallel routing (include/easyrec_hip.h)
   def emb_group_set_routing(self, group, world, shard_stride, local_base):
     arr = (ctypes.c_int64 * len(local_base))(*[int(x) for x in local_base])
@@ -401,17 +427,25 @@ class HipBackend(object):
                                int(act), _p(y), _p(mean), _p(invstd), _stream()), 'er_bn_act_fwd')
     return y, mean, invstd
 
-  def bn_act_bwd(self, x, bias, gamma, y, mean, invstd, dy, use_bn, act, need_bias, need_affine):
+  def bn_act_bwd(self, x, bias, gamma, y, mean, invstd, dy, use_bn, act, need_bias, need_affine, into=None):
+    """into = (dbias_buf, dgamma_buf, dbeta_buf) (each may be None): accumulate the parameter gradients
+    into those buffers (slices of the flat gradient buffer) instead of returning new tensors."""
     B, N = x.shape
     dx = torch.empty_like(x)
     dev = x.device
-    dbias = torch.empty(N, dtype=torch.float32, device=dev) if need_bias else None
-    dgamma = torch.empty(N, dtype=torch.float32, device=dev) if need_affine else None
-    dbeta = torch.empty(N, dtype=torch.float32, device=dev) if need_affine else None
+    acc = into is not None
+    if acc:
+      dbias, dgamma, dbeta = into
+    else:
+      dbias = torch.empty(N, dtype=torch.float32, device=dev) if need_bias else None
+      dgamma = torch.empty(N, dtype=torch.float32, device=dev) if need_affine else None
+      dbeta = torch.empty(N, dtype=torch.float32, device=dev) if need_affine else None
     self._ck(
         self.lib.er_bn_act_bwd(_p(x), _p(bias), _p(gamma), _p(y), _p(mean), _p(invstd), _p(_f32c(dy)), B, N,
-                               int(use_bn), int(act), _p(dx), _p(dbias), _p(dgamma), _p(dbeta), _stream()),
+                               int(use_bn), int(act), _p(dx), _p(dbias), _p(dgamma), _p(dbeta), int(acc), _stream()),
         'er_bn_act_bwd')
+    if acc:
+      return dx, None, None, None
     return dx, dbias, dgamma, dbeta
 
   def colsum(self, x):
@@ -511,6 +545,45 @@ def hip():
 # autograd glue: dense activations flow through torch.autograd; each Function is one fused kernel
 # forward and one backward.
 # ---------------------------------------------------------------------------------------------
+class LinearFn(torch.autograd.Function):
+  """y = x . W (+ b): tf.layers.dense without activation (reference layers/dnn.py:57-62).  Forward and both
+  gradients are hand-written MFMA GEMMs (er_gemm_*).  The weight/bias gradients are accumulated straight
+  into the variables' slices of the flat gradient buffer (`w_grad`, `b_grad`; zeroed once per step by
+  VarStore.zero_grad), so autograd issues no per-variable add kernels; when no buffer is given they are
+  returned the normal way."""
+
+  @staticmethod
+  def forward(ctx, x, w, b, w_grad, b_grad, bf16):
+    be = hip()
+    x2 = x if x.stride(-1) == 1 else x.contiguous()
+    y = be.gemm(GEMM_NN, x2, w, bias=b, bf16=bf16)
+    ctx.save_for_backward(x2, w)
+    ctx.has_bias = b is not None
+    ctx.w_grad, ctx.b_grad, ctx.bf16 = w_grad, b_grad, bf16
+    return y
+
+  @staticmethod
+  def backward(ctx, dy):
+    be = hip()
+    x, w = ctx.saved_tensors
+    dy = dy if dy.stride(-1) == 1 and dy.dim() == 2 else dy.contiguous()
+    dx = dw = db = None
+    if ctx.needs_input_grad[0]:
+      dx = be.gemm(GEMM_NT, dy, w, bf16=ctx.bf16)
+    if ctx.needs_input_grad[1]:
+      if ctx.w_grad is not None:
+        be.gemm(GEMM_TN, x, dy, out=ctx.w_grad, accumulate=True, bf16=ctx.bf16)
+      else:
+        dw = be.gemm(GEMM_TN, x, dy, bf16=ctx.bf16)
+    if ctx.has_bias and ctx.needs_input_grad[2]:
+      s = be.colsum(dy)
+      if ctx.b_grad is not None:
+        ctx.b_grad.add_(s)
+      else:
+        db = s
+    return dx, dw, db, None, None, None
+
+
 class FMFn(torch.autograd.Function):
   """reference layers/fm.py:20-26 over a [B, F*D] block of the input-layer output."""
 
@@ -546,10 +619,13 @@ class RowSumFn(torch.autograd.Function):
 
 
 class BNActFn(torch.autograd.Function):
-  """bias + BatchNorm(train) + activation: reference layers/dnn.py:57-79."""
+  """bias + BatchNorm(train) + activation: reference layers/dnn.py:57-79.  `grad_bufs` = (bias.grad,
+  gamma.grad, beta.grad) slices of the flat gradient buffer: the backward kernel accumulates into them
+  directly (no autograd add kernels)."""
 
   @staticmethod
-  def forward(ctx, x, bias, gamma, beta, moving_mean, moving_var, use_bn, eps, momentum, act, training):
+  def forward(ctx, x, bias, gamma, beta, moving_mean, moving_var, use_bn, eps, momentum, act, training,
+              grad_bufs=None):
     if use_bn and not training:
       # inference: normalise with the moving statistics (plain elementwise torch ops; not on the
       # training hot path)
@@ -559,15 +635,22 @@ class BNActFn(torch.autograd.Function):
     y, mean, invstd = hip().bn_act_fwd(x, bias, gamma, beta, use_bn, eps, momentum, moving_mean, moving_var, act)
     ctx.save_for_backward(x, bias, gamma, y, mean, invstd)
     ctx.cfg = (use_bn, act)
+    ctx.grad_bufs = grad_bufs
     return y
 
   @staticmethod
   def backward(ctx, dy):
     x, bias, gamma, y, mean, invstd = ctx.saved_tensors
     use_bn, act = ctx.cfg
+    into = None
+    if ctx.grad_bufs is not None:
+      bg, gg, betag = ctx.grad_bufs
+      ok = (bias is None or bg is not None) and (gamma is None or (gg is not None and betag is not None))
+      if ok:
+        into = (bg, gg, betag)
     dx, dbias, dgamma, dbeta = hip().bn_act_bwd(x, bias, gamma, y, mean, invstd, dy.contiguous(), use_bn, act,
-                                                bias is not None, gamma is not None)
-    return dx, dbias, dgamma, dbeta, None, None, None, None, None, None, None
+                                                bias is not None, gamma is not None, into=into)
+    return dx, dbias, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
 class DiceFn(torch.autograd.Function):

@@ -18,6 +18,19 @@ BN_MOMENTUM = 0.99
 BN_EPSILON = 1e-3
 
 
+def _linear(x2, w, b):
+  """x2 [rows, in] . w [in, units] (+ b) through the hand-written MFMA GEMMs (kernels.LinearFn); weight and
+  bias gradients accumulate directly into the variables' slices of the flat gradient buffer."""
+  ctx = context.current()
+  bf16 = getattr(ctx, 'dense_dtype', 'f32') == 'bf16'
+  if not torch.is_grad_enabled() or not ctx.is_training:
+    return kernels.hip().gemm(kernels.GEMM_NN, x2 if x2.stride(-1) == 1 else x2.contiguous(), w.detach(),
+                              bias=None if b is None else b.detach(), bf16=bf16)
+  wg = w.grad if (w.requires_grad and w.grad is not None) else None
+  bg = b.grad if (b is not None and b.requires_grad and b.grad is not None) else None
+  return kernels.LinearFn.apply(x2, w, b, wg, bg, bf16)
+
+
 def dense(x, units, name, l2_reg=None, use_bias=True, kernel_initializer='glorot_uniform'):
   """tf.layers.dense(activation=None): returns x @ kernel (+ bias).  Variables <name>/kernel, /bias."""
   vs = context.varstore()
@@ -25,8 +38,7 @@ def dense(x, units, name, l2_reg=None, use_bias=True, kernel_initializer='glorot
   w = vs.get_variable(name + '/kernel', (in_dim, units), kernel_initializer, l2=l2_reg or 0.0)
   b = vs.get_variable(name + '/bias', (units,), 'zeros') if use_bias else None
   shape = x.shape
-  x2 = x.reshape(-1, in_dim)
-  y = torch.addmm(b, x2, w) if b is not None else torch.mm(x2, w)
+  y = _linear(x.reshape(-1, in_dim), w, b)
   return y.reshape(shape[:-1] + (units,))
 
 
@@ -46,13 +58,21 @@ def dense_bn_act(x, units, name, l2_reg, use_bias, use_bn, act_relu, training, b
     mm = vs.get_variable(bn + '/moving_mean', (units,), 'zeros', trainable=False)
     mv = vs.get_variable(bn + '/moving_variance', (units,), 'ones', trainable=False)
   shape = x.shape
-  x2 = x.reshape(-1, in_dim)
-  z = torch.mm(x2, w)
+  z = _linear(x.reshape(-1, in_dim), w, None)
   act = kernels.ACT_RELU if act_relu else kernels.ACT_NONE
   freeze = ctx.building and training  # build pass: do not touch the moving statistics
   y = kernels.BNActFn.apply(z, b, gamma, beta, None if freeze else mm, None if freeze else mv, use_bn,
-                            BN_EPSILON, BN_MOMENTUM, act, training)
+                            BN_EPSILON, BN_MOMENTUM, act, training, _grad_bufs(b, gamma, beta))
   return y.reshape(shape[:-1] + (units,))
+
+
+def _grad_bufs(b, gamma, beta):
+  """(bias.grad, gamma.grad, beta.grad) when the variables are packed into the flat gradient buffer."""
+  bufs = tuple(None if t is None else t.grad for t in (b, gamma, beta))
+  present = [t for t in (b, gamma, beta) if t is not None]
+  if not present or any(t.grad is None for t in present):
+    return None
+  return bufs
 
 
 def batch_norm(x, name, training):
@@ -69,7 +89,7 @@ def batch_norm(x, name, training):
   x2 = x.reshape(-1, units)
   freeze = ctx.building and training
   y = kernels.BNActFn.apply(x2, None, gamma, beta, None if freeze else mm, None if freeze else mv, True,
-                            BN_EPSILON, BN_MOMENTUM, kernels.ACT_NONE, training)
+                            BN_EPSILON, BN_MOMENTUM, kernels.ACT_NONE, training, _grad_bufs(None, gamma, beta))
   return y.reshape(shape)
 
 

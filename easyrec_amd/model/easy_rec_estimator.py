@@ -38,7 +38,7 @@ class EasyRecEstimator(object):
   HYPER_SLOTS = 4096
 
   def __init__(self, pipeline_config, device='cuda', batch_size=None, seed=0, schema_kwargs=None,
-               is_training=True, overlap_sweep=False):
+               is_training=True, overlap_sweep=False, dense_dtype=None):
     import_all_models()
     self.pipeline_config = config_util.get_configs_from_pipeline_file(pipeline_config) \
         if isinstance(pipeline_config, str) else pipeline_config
@@ -60,6 +60,9 @@ class EasyRecEstimator(object):
     self.varstore = VarStore(self.device, seed=seed)
     self.engine = self._make_engine()
     self.ctx = context.ModelContext(self.varstore, self.engine, is_training=is_training)
+    # 'f32' (default: exact-fp32 MFMA, the 1e-4 parity bar) or 'bf16' (BASELINE config 3: bf16 dense, fp32 embeddings)
+    self.ctx.dense_dtype = dense_dtype or os.environ.get('ER_DENSE_DTYPE', 'f32')
+    assert self.ctx.dense_dtype in ('f32', 'bf16')
     self.global_step = 0
     self.graph = None
     self._built = False
@@ -110,6 +113,7 @@ class EasyRecEstimator(object):
     """Build pass (creates variables / declares tables), then allocate + pack everything."""
     assert not self._built
     kernels.hip().reserve_scratch(1 << 22)
+    kernels.hip().gemm_reserve(1 << 24)  # split-K workspace (64 MB): sized before any hipGraph capture
     if self.overlap_sweep and self.opt_emb.kind == kernels.OPT_ADAM:
       kernels.hip().config_set('sweep_blocks_per_cu', int(os.environ.get('ER_SWEEP_BLOCKS_PER_CU', '3')))
     self.ctx.building = True

@@ -276,12 +276,12 @@ int er_bn_act_fwd(const float* x, const float* bias, const float* gamma, const f
                   int32_t B, int32_t N, int use_bn, float eps, float momentum,
                   float* moving_mean, float* moving_var, int act, float* y, float* save_mean,
                   float* save_invstd, er_stream_t stream);
-/* dx [B,N]; dbias/dgamma/dbeta [N] (overwritten; NULL to skip). y is the forward output
- * (relu mask); x the forward input. */
+/* dx [B,N]; dbias/dgamma/dbeta [N] (NULL to skip): overwritten, or += when accumulate != 0 (they then
+ * point into the flat gradient buffer).  y is the forward output (relu mask); x the forward input. */
 int er_bn_act_bwd(const float* x, const float* bias, const float* gamma, const float* y,
                   const float* save_mean, const float* save_invstd, const float* dy, int32_t B,
                   int32_t N, int use_bn, int act, float* dx, float* dbias, float* dgamma,
-                  float* dbeta, er_stream_t stream);
+                  float* dbeta, int accumulate, er_stream_t stream);
 /* out[j] = sum_i x[i, j]  (bias gradients, partial reductions) */
 int er_colsum(const float* x, int32_t rows, int32_t cols, int32_t x_stride, float* out,
               er_stream_t stream);
@@ -320,6 +320,27 @@ int er_mmoe_mix_fwd(const float* experts, const float* gate_logits, int32_t T, i
 int er_mmoe_mix_bwd(const float* experts, const float* gates, const float* dout, int32_t T,
                     int32_t E, int32_t B, int32_t H, float* dexperts, float* dgate_logits,
                     er_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
+ * K13 dense contractions on the matrix cores.  Replaces the MatMul of tf.layers.dense
+ *     (layers/dnn.py:57-62, model/deepfm.py:84-104, layers/mmoe.py:53-58, keras Dense
+ *     layers/keras/blocks.py:84-89, Cross W.x layers/keras/interaction.py:249-286) and its gradients.
+ *   C[M,N] (+)= op(A) . op(B) (+ bias[N]);  fp32 in HBM, row-major, leading dimensions in floats.
+ *     ER_GEMM_NN: A[M,K] B[K,N]   forward   y  = x . W
+ *     ER_GEMM_NT: A[M,K] B[N,K]   backward  dx = dy . W^T
+ *     ER_GEMM_TN: A[K,M] B[K,N]   backward  dW = x^T . dy   (split-K + deterministic reduce)
+ *   er_gemm_f32 : v_mfma_f32_32x32x2_f32, exact fp32 (an fmaf chain in k order).
+ *   er_gemm_bf16: operands rounded to bf16 (RNE) while staged into LDS, v_mfma_f32_32x32x16_bf16,
+ *                 fp32 accumulate (BASELINE config 3: bf16 dense, fp32 embeddings and master weights).
+ *   accumulate != 0: C += result (gradients accumulate straight into the flat gradient buffer).
+ *   er_gemm_reserve pre-sizes the split-K workspace (floats) before hipGraph capture.
+ * -------------------------------------------------------------------------------------------- */
+enum { ER_GEMM_NN = 0, ER_GEMM_NT = 1, ER_GEMM_TN = 2 };
+int er_gemm_reserve(int64_t floats);
+int er_gemm_f32(int layout, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B,
+                int32_t ldb, float* C, int32_t ldc, const float* bias, int accumulate, er_stream_t stream);
+int er_gemm_bf16(int layout, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B,
+                 int32_t ldb, float* C, int32_t ldc, const float* bias, int accumulate, er_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
  * K12 embedding-parallel (row-sharded tables, one process per GPU).  Replaces

@@ -300,6 +300,31 @@ class RefBackend(object):
       g[i] = torch.from_numpy(grads[key])
     return k, g, torch.tensor([len(keys)], dtype=torch.int32)
 
+  # -- GEMM: the same torch-CPU fp32 matmul calls the model oracle makes (x @ w, dy @ w.T, x.T @ dy), so the
+  #    host-logic tests stay bit-comparable; bf16=True rounds the operands to bfloat16 first, as the kernel does
+  def gemm_reserve(self, floats):
+    pass
+
+  def gemm(self, layout, a, b, out=None, bias=None, accumulate=False, bf16=False):
+    def rnd(t):
+      return t.to(torch.bfloat16).to(torch.float32) if bf16 else t
+    A, Bm = rnd(a.detach()), rnd(b.detach())
+    if layout == 0:
+      r = A @ Bm
+    elif layout == 1:
+      r = A @ Bm.t()
+    else:
+      r = A.t() @ Bm
+    if bias is not None:
+      r = r + bias.detach()
+    if out is None:
+      return r
+    if accumulate:
+      out.add_(r)
+    else:
+      out.copy_(r)
+    return out
+
   # -- embedding-parallel routing (reference compat/feature_column/feature_column.py:248-357:
   #    owner = id % world, local row = id // world)
   def emb_group_set_routing(self, group, world, shard_stride, local_base):
@@ -494,7 +519,17 @@ class RefBackend(object):
       y = torch.relu(y)
     return y, mean, invstd
 
-  def bn_act_bwd(self, x, bias, gamma, y, mean, invstd, dy, use_bn, act, need_bias, need_affine):
+  def bn_act_bwd(self, x, bias, gamma, y, mean, invstd, dy, use_bn, act, need_bias, need_affine, into=None):
+    res = self._bn_act_bwd(x, bias, gamma, y, mean, invstd, dy, use_bn, act, need_bias, need_affine)
+    if into is None:
+      return res
+    dx, dbias, dgamma, dbeta = res
+    for buf, g in zip(into, (dbias, dgamma, dbeta)):
+      if buf is not None and g is not None:
+        buf.add_(g)
+    return dx, None, None, None
+
+  def _bn_act_bwd(self, x, bias, gamma, y, mean, invstd, dy, use_bn, act, need_bias, need_affine):
     B = x.shape[0]
     g = dy * (y > 0).to(dy.dtype) if act == ACT_RELU else dy
     dbias = dgamma = dbeta = None

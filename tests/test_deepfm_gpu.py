@@ -63,6 +63,9 @@ def _first_step_check(cfg, B, mode, seed):
   names = set(orc.state)
   worst = {}
   for slot, tol in (('m', 2e-4), ('v', 4e-4)):
+    # tensors whose true gradient is (near) zero carry rounding noise only: allow 1e-6 of the largest
+    # gradient scale of the model on top of the per-tensor relative tolerance
+    gmax = max(float(np.max(np.abs(v))) for kk, v in orc.slots.items() if kk.endswith('/' + slot))
     for k in orc.state:
       key = k + '/' + slot
       if key not in orc.slots or key not in st or _skip_bias(k, names):
@@ -70,7 +73,7 @@ def _first_step_check(cfg, B, mode, seed):
       ref = orc.slots[key]
       d = float(np.max(np.abs(st[key] - ref)))
       scale = float(np.max(np.abs(ref)))
-      assert d <= tol * scale + 1e-12, (key, d, scale)
+      assert d <= tol * scale + 1e-6 * gmax, (key, d, scale)
       worst[slot] = max(worst.get(slot, 0.0), d / (scale + 1e-30))
   assert worst, 'no slots compared'
   return est, orc, gen

@@ -496,3 +496,73 @@ def test_dense_opt_bit_exact(hip, ref, opt):
   torch.cuda.synchronize()
   assert torch.equal(md.cpu(), m) and torch.equal(vd.cpu(), v)
   assert torch.equal(wd.cpu(), w)
+
+
+# ------------------------------------------------------------------------------------------- K13 GEMM
+_GEMM_SHAPES = [  # (M, N, K): DeepFM layers, odd sizes (81, 1), tiny, split-K (small MxN, long K)
+    (4096, 256, 624), (4096, 64, 128), (4096, 256, 81), (4096, 1, 64), (624, 256, 4096), (81, 256, 4096),
+    (64, 1, 4096), (33, 65, 97), (1, 1, 1), (130, 70, 1000)]
+
+
+@pytest.mark.parametrize('layout', [kernels.GEMM_NN, kernels.GEMM_NT, kernels.GEMM_TN])
+@pytest.mark.parametrize('M,N,K', _GEMM_SHAPES)
+def test_gemm_f32(hip, layout, M, N, K):
+  """fp32 MFMA GEMM against an fp64 matmul: every element within 1e-6 of sum |a||b| (an f32 fma chain)."""
+  g = torch.Generator().manual_seed(M * 131 + N * 17 + K + layout)
+  a_shape = (K, M) if layout == kernels.GEMM_TN else (M, K)
+  b_shape = (N, K) if layout == kernels.GEMM_NT else (K, N)
+  a = torch.randn(a_shape, generator=g)
+  b = torch.randn(b_shape, generator=g)
+  bias = torch.randn(N, generator=g)
+  A = a.t() if layout == kernels.GEMM_TN else a
+  Bm = b.t() if layout == kernels.GEMM_NT else b
+  ref = A.double() @ Bm.double()
+  bound = (A.double().abs() @ Bm.double().abs()) * 1e-6 + 1e-6
+  got = hip.gemm(layout, a.to(DEV), b.to(DEV))
+  assert ((got.cpu().double() - ref).abs() <= bound).all()
+  # bias + accumulate into a strided output view
+  base = torch.randn(M, N + 3, generator=g)
+  out = base.to(DEV)
+  hip.gemm(layout, a.to(DEV), b.to(DEV), out=out[:, 1:N + 1], bias=bias.to(DEV), accumulate=True)
+  exp = base.double()
+  exp[:, 1:N + 1] += ref + bias.double()
+  torch.cuda.synchronize()
+  assert ((out.cpu().double() - exp).abs() <= torch.nn.functional.pad(bound, (1, 2), value=0.0) + 1e-5).all()
+  # deterministic: same bits on a second launch
+  again = hip.gemm(layout, a.to(DEV), b.to(DEV))
+  assert torch.equal(got, again)
+
+
+@pytest.mark.parametrize('layout', [kernels.GEMM_NN, kernels.GEMM_NT, kernels.GEMM_TN])
+@pytest.mark.parametrize('M,N,K', [(4096, 256, 624), (624, 256, 4096), (33, 65, 97), (4096, 1, 64)])
+def test_gemm_bf16(hip, layout, M, N, K):
+  """bf16 MFMA GEMM: operands rounded to bfloat16 (RNE, checked against torch's cast), fp32 accumulate."""
+  g = torch.Generator().manual_seed(M + N + K + layout)
+  a_shape = (K, M) if layout == kernels.GEMM_TN else (M, K)
+  b_shape = (N, K) if layout == kernels.GEMM_NT else (K, N)
+  a, b = torch.randn(a_shape, generator=g), torch.randn(b_shape, generator=g)
+  ar, br = a.to(torch.bfloat16).double(), b.to(torch.bfloat16).double()
+  A = ar.t() if layout == kernels.GEMM_TN else ar
+  Bm = br.t() if layout == kernels.GEMM_NT else br
+  ref = A @ Bm
+  bound = (A.abs() @ Bm.abs()) * 2e-6 + 1e-6
+  got = hip.gemm(layout, a.to(DEV), b.to(DEV), bf16=True)
+  assert ((got.cpu().double() - ref).abs() <= bound).all()
+
+
+def test_linear_fn_matches_torch_autograd(hip):
+  x = torch.randn(300, 81, device=DEV, requires_grad=True)
+  w = torch.randn(81, 40, device=DEV, requires_grad=True)
+  b = torch.randn(40, device=DEV, requires_grad=True)
+  wg, bg = torch.zeros_like(w), torch.zeros_like(b)
+  y = kernels.LinearFn.apply(x, w, b, wg, bg, False)
+  dy = torch.randn_like(y)
+  y.backward(dy)
+  xr, wr, br = (t.detach().double().requires_grad_(True) for t in (x, w, b))
+  yr = xr @ wr + br
+  yr.backward(dy.double())
+  assert torch.allclose(y.double(), yr, rtol=1e-5, atol=1e-5)
+  assert torch.allclose(x.grad.double(), xr.grad, rtol=1e-5, atol=1e-5)
+  assert torch.allclose(wg.double(), wr.grad, rtol=1e-5, atol=1e-4)
+  assert torch.allclose(bg.double(), br.grad, rtol=1e-5, atol=1e-4)
+  assert w.grad is None and b.grad is None  # accumulated into the given buffers instead
