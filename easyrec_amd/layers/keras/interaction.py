@@ -1,0 +1,79 @@
+"""Feature-interaction layers of the backbone API (reference easy_rec/python/layers/keras/interaction.py).
+
+FM    (:24-44)   0.5 * ((sum_f e)^2 - sum_f e^2): [B, D] with `use_variant`, else summed over D -> [B, 1].
+Cross (:131-308) DCN-v2: x_{l+1} = x0 * (W x_l + b + diag_scale * x_l) + x_l; W full rank d x d or low rank
+                 U (d x r) V (r x d); kernel init truncated_normal (keras: stddev 0.05), bias zeros.
+                 W x_l is an MFMA GEMM (er_gemm, fp32 or bf16); bias, diag term, Hadamard product and residual
+                 are ONE fused epilogue kernel (er_cross_v2_epilogue) instead of BiasAdd/Mul/Mul/Add.
+"""
+import torch
+
+from easyrec_amd import kernels
+from easyrec_amd.core import context
+from easyrec_amd.layers import dnn
+from easyrec_amd.utils.activation import get_activation
+
+
+class FM(object):
+
+  def __init__(self, params, name='fm', reuse=None, **kwargs):
+    self.name = name
+    self.use_variant = params.get_or_default('use_variant', False)
+
+  def __call__(self, inputs, **kwargs):
+    blk = inputs.uniform_block() if hasattr(inputs, 'uniform_block') else None
+    if blk is not None:
+      base, col0, F, D = blk
+      x = base if (col0 == 0 and base.shape[1] == F * D) else base[:, col0:col0 + F * D]
+    elif isinstance(inputs, (list, tuple)):
+      dims = set(int(t.shape[-1]) for t in inputs)
+      if len(dims) != 1:
+        raise ValueError('all embedding dim must be equal in FM layer:' + ','.join(str(d) for d in dims))
+      F, D = len(inputs), inputs[0].shape[1]
+      x = torch.cat(list(inputs), dim=1)
+    else:
+      assert inputs.dim() == 3, 'input of FM layer must be a 3D tensor or a list of 2D tensors'
+      _, F, D = inputs.shape
+      x = inputs.reshape(inputs.shape[0], F * D)
+    cross = kernels.FMFn.apply(x, F, D)  # [B, D] = 0.5 * (square_of_sum - sum_of_square)
+    if self.use_variant:
+      return cross
+    return kernels.RowSumFn.apply(cross)
+
+
+class Cross(object):
+
+  def __init__(self, params, name='cross', reuse=None, **kwargs):
+    self.name = name
+    self._projection_dim = params.get_or_default('projection_dim', None)
+    self._diag_scale = float(params.get_or_default('diag_scale', 0.0))
+    self._use_bias = params.get_or_default('use_bias', True)
+    self._preactivation = get_activation(params.get_or_default('preactivation', None) or '')
+    self._kernel_initializer = params.get_or_default('kernel_initializer', 'truncated_normal')
+    self._bias_initializer = params.get_or_default('bias_initializer', 'zeros')
+    if self._diag_scale < 0:
+      raise ValueError('`diag_scale` should be non-negative. Got `diag_scale` = {}'.format(self._diag_scale))
+
+  def __call__(self, inputs, **kwargs):
+    if isinstance(inputs, (list, tuple)):
+      x0, x = inputs
+    else:
+      x0, x = inputs, inputs
+    if x0.shape[-1] != x.shape[-1]:
+      raise ValueError('`x0` and `x` dimension mismatch! Got `x0` dimension {}, and x dimension {}. This case '
+                       'is not supported yet.'.format(x0.shape[-1], x.shape[-1]))
+    vs = context.varstore()
+    d = x.shape[-1]
+    bias = vs.get_variable(self.name + '/dense/bias', (d,), self._bias_initializer) if self._use_bias else None
+    if self._projection_dim is None:
+      w = vs.get_variable(self.name + '/dense/kernel', (d, d), self._kernel_initializer)
+      u = dnn._linear(x, w, None)
+    else:
+      r = int(self._projection_dim)
+      wu = vs.get_variable(self.name + '/dense_u/kernel', (d, r), self._kernel_initializer)
+      wv = vs.get_variable(self.name + '/dense_v/kernel', (r, d), self._kernel_initializer)
+      u = dnn._linear(dnn._linear(x, wu, None), wv, None)
+    if self._preactivation is not None:
+      u = self._preactivation(u + bias if bias is not None else u)
+      bias = None
+    return kernels.CrossV2EpilogueFn.apply(x0, x, u, bias, self._diag_scale)

@@ -56,6 +56,30 @@ class EasyRecModel(six.with_metaclass(_meta_type, object)):
     if getattr(features, 'sample_weight', None) is not None:
       self._sample_weight = features.sample_weight
 
+    self._backbone_net = self.build_backbone_network()
+
+  def build_backbone_network(self):
+    """reference easy_rec_model.py:100-107"""
+    if self.has_backbone:
+      from easyrec_amd.layers.backbone import Backbone
+      return Backbone(self._base_model_config.backbone, self._feature_dict, input_layer=self._input_layer,
+                      l2_reg=self._l2_reg)
+    return None
+
+  @property
+  def backbone(self):
+    """Executes the backbone network on the batch currently loaded (reference easy_rec_model.py:113-127)."""
+    if self._backbone_net is None:
+      return None
+    kwargs = {
+        'loss_dict': self._loss_dict,
+        'metric_dict': self._metric_dict,
+        'prediction_dict': self._prediction_dict,
+        'labels': self._labels,
+        constant.SAMPLE_WEIGHT: self._sample_weight,
+    }
+    return self._backbone_net(self._is_training, **kwargs)
+
   @property
   def has_backbone(self):
     return self._base_model_config.HasField('backbone')

@@ -27,7 +27,17 @@ class RankModel(EasyRecModel):
     if not self.has_backbone:
       raise NotImplementedError(
           'method `build_predict_graph` must be implemented when backbone network do not exits')
-    raise NotImplementedError('backbone networks: see layers/backbone.py')
+    model = self._model_config.WhichOneof('model')
+    assert model == 'model_params', '`model_params` must be configured'
+    config = self._model_config.model_params
+    for out in config.outputs:
+      self._outputs.append(out)
+    output = self.backbone
+    if int(output.shape[-1]) != self._num_class:
+      logging.info('add head logits layer for rank model')
+      output = dense(output, self._num_class, 'output')
+    self._add_to_prediction_dict(output)
+    return self._prediction_dict
 
   def _output_to_prediction_impl(self, output, loss_type, num_class=1, suffix='', **kwargs):
     """reference rank_model.py:57-129 (binary / regression heads)."""

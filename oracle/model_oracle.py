@@ -430,6 +430,101 @@ class OracleTrainer(object):
       pred['logits_%s' % tower.tower_name] = out.squeeze(1)
     return pred
 
+  # ------------------------------------------------------------------ backbone (RankModel)
+  def _keras_mlp(self, V, x, p, name, l2):
+    """layers/keras/blocks.py:37-128: Dense(use_bias=False, he_uniform) -> BatchNorm -> activation per layer;
+    the LAST layer has BN too (use_final_bn default true) and `final_activation` (default none)."""
+    def opt(field, default):
+      return getattr(p, field) if p.HasField(field) else default
+    units = list(p.hidden_units)
+    use_bn, use_final_bn = opt('use_bn', True), opt('use_final_bn', True)
+    use_bias, use_final_bias = opt('use_bias', False), opt('use_final_bias', False)
+    act, final_act = opt('activation', 'relu'), opt('final_activation', None)
+    for i, u in enumerate(units):
+      last = i == len(units) - 1
+      lname = '%s/layer_%d' % (name, i)
+      w = V.get(lname + '/dense/kernel', l2=l2)
+      x = x @ w
+      if (use_final_bias if last else use_bias):
+        x = x + V.get(lname + '/dense/bias')
+      if (use_final_bn if last else use_bn):
+        x = self.batch_norm(V, x, lname + '/bn')
+      a = final_act if last else act
+      if a and a.lower() not in ('linear',):
+        assert a.lower() in ('relu', 'tf.nn.relu', 'nn.relu'), a
+        x = torch.relu(x)
+    return x
+
+  def _keras_cross(self, V, x0, x, st_params, name):
+    """layers/keras/interaction.py:249-286: x0 * (W x + b [+ diag_scale x]) + x; W = U V when projection_dim."""
+    proj = int(st_params['projection_dim']) if 'projection_dim' in st_params else None
+    diag = float(st_params['diag_scale']) if 'diag_scale' in st_params else 0.0
+    if proj is None:
+      prod = x @ V.get(name + '/dense/kernel') + V.get(name + '/dense/bias')
+    else:
+      prod = (x @ V.get(name + '/dense_u/kernel')) @ V.get(name + '/dense_v/kernel') + V.get(name + '/dense/bias')
+    if diag:
+      prod = prod + diag * x
+    return x0 * prod + x
+
+  def _rank_backbone(self, V, batch):
+    """model/rank_model.py:38-55 over layers/backbone.py: blocks in config order (the shipped configs list them
+    topologically), feature-group inputs -> input layer, `input_fn` lambdas, keras_layer MLP / Cross, recurrent
+    with a fixed input, concat_blocks, top_mlp, head `output` dense when the width != num_class."""
+    mc = self.cfg.model_config
+    bb = mc.backbone
+    l2 = mc.model_params.l2_regularization
+    outs, scope_id = {}, 0
+    groups = {g.group_name for g in mc.feature_groups}
+
+    def group_out(name):
+      nonlocal scope_id
+      if name not in outs:
+        scope = 'input_layer' if scope_id == 0 else 'input_layer_%d' % scope_id
+        scope_id += 1
+        outs[name] = self.input_layer(V, batch, name, scope)[0]
+      return outs[name]
+
+    # the input-layer calls happen in topological order with implicit group blocks first (backbone.py:160-186)
+    for blk in bb.blocks:
+      for node in blk.inputs:
+        if node.WhichOneof('name') == 'feature_group_name' and node.feature_group_name in groups:
+          group_out(node.feature_group_name)
+    for blk in bb.blocks:
+      ins = []
+      for node in blk.inputs:
+        fea = outs[getattr(node, node.WhichOneof('name'))]
+        if node.HasField('input_fn'):
+          fea = eval(node.input_fn)(fea)
+        ins.append(fea)
+      x = ins[0] if len(ins) == 1 else torch.cat(ins, dim=-1)
+      kind = blk.WhichOneof('layer')
+      if kind == 'keras_layer':
+        kl = blk.keras_layer
+        if kl.class_name == 'MLP':
+          x = self._keras_mlp(V, x, kl.mlp, blk.name, l2)
+        elif kl.class_name == 'Cross':
+          x = self._keras_cross(V, x[0], x[1], kl.st_params, blk.name)
+        else:
+          raise NotImplementedError(kl.class_name)
+      elif kind == 'recurrent':
+        rc = blk.recurrent
+        assert rc.keras_layer.class_name == 'Cross' and rc.fixed_input_index == 0
+        x0, xi = x
+        for i in range(rc.num_steps):
+          xi = self._keras_cross(V, x0, xi, rc.keras_layer.st_params, '%s_%d' % (blk.name, i))
+        x = xi
+      else:
+        raise NotImplementedError(kind)
+      outs[blk.name] = x
+    out = torch.cat([outs[n] for n in bb.concat_blocks], dim=-1) if len(bb.concat_blocks) > 1 \
+        else outs[bb.concat_blocks[0]]
+    if bb.HasField('top_mlp'):
+      out = self._keras_mlp(V, out, bb.top_mlp, 'backbone_top_mlp', l2)
+    if out.shape[-1] != mc.num_class:
+      out = self.dense(V, out, mc.num_class, 'output', 0.0)
+    return {'logits': out.squeeze(1)}
+
   # ------------------------------------------------------------------ one step
   def forward(self, batch):
     V = Vars(self.state, self.dtype)
@@ -460,6 +555,8 @@ class OracleTrainer(object):
         pred = self._dcn(V, batch)
       elif self.model_class == 'MultiTowerDIN':
         pred = self._multi_tower_din(V, batch)
+      elif self.model_class == 'RankModel':
+        pred = self._rank_backbone(V, batch)
       else:
         raise NotImplementedError('oracle: model_class %s' % self.model_class)
       labels = torch.as_tensor(labels_np[0], dtype=self.dtype)

@@ -114,7 +114,8 @@ def test_csv_input_roundtrip(tmp_path, built_lib):
 
 
 @pytest.mark.parametrize('config,B', [('dcn_criteo_small.config', 32), ('din_taobao_small.config', 24),
-                                      ('mmoe_taobao_small.config', 24)])
+                                      ('mmoe_taobao_small.config', 24), ('dcn_v2_criteo_small.config', 32),
+                                      ('dcn_v2_lowrank_criteo_small.config', 32)])
 def test_other_models_match_model_oracle(ref_backend, config, B):
   """DCN / MultiTowerDIN / MMoE host logic (variable naming, layer wiring, multi-task losses, sequence and
   tag lookups) against the independent model-level oracle, 2 optimisation steps."""

@@ -73,6 +73,31 @@ def test_multi_tower_din_matches_oracle(lazy):
   _first_steps(_cfg('din_taobao_small.config', lazy), 128, 22)
 
 
+@pytest.mark.parametrize('name', ['dcn_v2_criteo_small.config', 'dcn_v2_lowrank_criteo_small.config'])
+def test_dcn_v2_backbone_matches_oracle(name):
+  """RankModel + backbone {MLP || recurrent Cross} + top_mlp (layers/backbone.py, layers/keras/*)."""
+  _first_steps(_cfg(name), 128, 31)
+
+
+def test_dcn_v2_bf16_dense_tracks_the_fp32_oracle():
+  """BASELINE config 3: bf16 MFMA for the dense contractions (operands rounded to bf16, fp32 accumulate),
+  fp32 embeddings and master weights.  Against the fp32 oracle the loss must agree to bf16 resolution
+  (2^-8 relative per operand; tolerance 2e-2 on the loss, stated here) and training must progress."""
+  cfg = _cfg('dcn_v2_criteo_small.config', lazy=True)
+  B = 256
+  est = EasyRecEstimator(cfg, device=DEV, batch_size=B, seed=7, dense_dtype='bf16').build()
+  orc = OracleTrainer(cfg, est.state_dict(), batch_size=B)
+  gen = SyntheticBatches(cfg.data_config, est.feature_configs, batch_size=B, seed=77)
+  b = gen.next_batch()
+  est.train_step(b)
+  got, exp = est.loss_values(), orc.train_step(b)
+  assert abs(got['cross_entropy_loss'] - exp['cross_entropy_loss']) <= 2e-2 * exp['cross_entropy_loss'], (got, exp)
+  first = got['total_loss']
+  for _ in range(20):
+    est.train_step(b)
+  assert est.loss_values()['total_loss'] < first
+
+
 def test_mmoe_matches_oracle():
   # seed chosen away from a ReLU tie: with seed 23 one pre-activation of expert_3 sits within rounding of 0, the
   # GPU and the oracle take different sides and that one example's gradient (1/128 of the batch) differs by ~1%
@@ -80,14 +105,15 @@ def test_mmoe_matches_oracle():
   _first_steps(_cfg('mmoe_taobao_small.config'), 128, 24)
 
 
-@pytest.mark.parametrize('name,B', [('din_taobao.config', 4096), ('mmoe_taobao.config', 4096),
-                                    ('dcn_criteo.config', 4096)])
-def test_full_size_models_train_and_replay_as_graph(name, B):
+@pytest.mark.parametrize('name,B,dtype', [('din_taobao.config', 4096, 'f32'), ('mmoe_taobao.config', 4096, 'f32'),
+                                          ('dcn_criteo.config', 4096, 'f32'), ('dcn_v2_criteo.config', 4096, 'f32'),
+                                          ('dcn_v2_criteo.config', 4096, 'bf16')])
+def test_full_size_models_train_and_replay_as_graph(name, B, dtype):
   """BASELINE shapes (B=4096; DIN with L=50): a few eager steps, then hipGraph replay; the loss must stay
   finite and decrease on a repeated batch; ms/step is printed for the record."""
   import time
   cfg = _cfg(name, lazy=True)
-  est = EasyRecEstimator(cfg, device=DEV, batch_size=B, seed=1).build()
+  est = EasyRecEstimator(cfg, device=DEV, batch_size=B, seed=1, dense_dtype=dtype).build()
   gen = SyntheticBatches(cfg.data_config, est.feature_configs, batch_size=B, seed=5)
   batch = {k: torch.from_numpy(np.ascontiguousarray(v)).to(DEV) for k, v in gen.next_batch().items()}
   est.features.load(batch)
@@ -104,5 +130,6 @@ def test_full_size_models_train_and_replay_as_graph(name, B):
   torch.cuda.synchronize()
   ms = (time.perf_counter() - t0) / n * 1e3
   last = est.loss_values()['total_loss']
-  print('%s B=%d: %.3f ms/step (%.0f examples/s), loss %.4f -> %.4f' % (name, B, ms, B / ms * 1e3, first, last))
+  print('%s B=%d dense %s: %.3f ms/step (%.0f examples/s), loss %.4f -> %.4f' % (name, B, dtype, ms, B / ms * 1e3,
+                                                                                 first, last))
   assert np.isfinite(last) and last < first

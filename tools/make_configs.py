@@ -115,6 +115,41 @@ def dcn_criteo(**kw):
   return cfg
 
 
+def dcn_v2_criteo(cross_steps=3, projection_dim=0, **kw):
+  """DCN-v2 through the backbone API (model_class RankModel): deep MLP || `Cross` x cross_steps (recurrent,
+  x0 fixed), concat, top_mlp - the block structure of samples/model_config/dcn_backbone_on_taobao.config on
+  the 39 Criteo features (BASELINE config 3)."""
+  cfg = criteo_base(**kw)
+  cfg.model_dir = 'examples/ckpt/dcn_v2_criteo_ckpt'
+  mc = cfg.model_config
+  mc.model_class = 'RankModel'
+  g = mc.feature_groups.add()
+  g.group_name = 'all'
+  g.feature_names.extend(_all_names())
+  g.wide_deep = WideOrDeep.DEEP
+  bb = mc.backbone
+  b = bb.blocks.add()
+  b.name = 'deep'
+  b.inputs.add().feature_group_name = 'all'
+  b.keras_layer.class_name = 'MLP'
+  b.keras_layer.mlp.hidden_units.extend([256, 128, 64])
+  b = bb.blocks.add()
+  b.name = 'cross'
+  i = b.inputs.add()
+  i.feature_group_name = 'all'
+  i.input_fn = 'lambda x: [x, x]'
+  b.recurrent.num_steps = cross_steps
+  b.recurrent.fixed_input_index = 0
+  b.recurrent.keras_layer.class_name = 'Cross'
+  if projection_dim:
+    b.recurrent.keras_layer.st_params['projection_dim'] = projection_dim
+  bb.concat_blocks.extend(['deep', 'cross'])
+  bb.top_mlp.hidden_units.extend([64, 32, 16])
+  mc.model_params.l2_regularization = 1e-6
+  mc.embedding_regularization = 1e-5
+  return cfg
+
+
 # ---------------------------------------------------------------------------------------------
 # Taobao-shaped configs (the feature set of the reference's samples/model_config/*_on_taobao.config)
 # ---------------------------------------------------------------------------------------------
@@ -261,6 +296,10 @@ if __name__ == '__main__':
   write(deepfm_criteo(hash_bucket_size=1000, batch_size=256), 'deepfm_criteo_small.config')
   write(dcn_criteo(), 'dcn_criteo.config')
   write(dcn_criteo(hash_bucket_size=1000, batch_size=256), 'dcn_criteo_small.config')
+  write(dcn_v2_criteo(), 'dcn_v2_criteo.config')
+  write(dcn_v2_criteo(hash_bucket_size=1000, batch_size=256), 'dcn_v2_criteo_small.config')
+  write(dcn_v2_criteo(hash_bucket_size=1000, batch_size=256, projection_dim=32, cross_steps=2),
+        'dcn_v2_lowrank_criteo_small.config')
   write(din_taobao(), 'din_taobao.config')
   write(din_taobao(item_rows=10000000), 'din_taobao_10m.config')
   write(din_taobao(batch_size=128, scale=0.01, seq_len=12), 'din_taobao_small.config')
