@@ -657,42 +657,55 @@ class DiceFn(torch.autograd.Function):
   """reference layers/keras/activation.py:47-70 / utils/activation.py:14-44."""
 
   @staticmethod
-  def forward(ctx, x, alpha, moving_mean, moving_var, eps, momentum):
+  def forward(ctx, x, alpha, moving_mean, moving_var, eps, momentum, alpha_grad=None):
     y, mean, invstd = hip().dice_fwd(x, alpha, eps, momentum, moving_mean, moving_var)
     ctx.save_for_backward(x, alpha, mean, invstd)
+    ctx.alpha_grad = alpha_grad
     return y
 
   @staticmethod
   def backward(ctx, dy):
     x, alpha, mean, invstd = ctx.saved_tensors
     dx, dalpha = hip().dice_bwd(x, alpha, mean, invstd, dy.contiguous())
-    return dx, dalpha, None, None, None, None
+    if ctx.alpha_grad is not None:
+      ctx.alpha_grad.add_(dalpha)
+      dalpha = None
+    return dx, dalpha, None, None, None, None, None
 
 
 class CrossV1Fn(torch.autograd.Function):
-  """reference model/dcn.py:32-45, all layers in one launch."""
+  """reference model/dcn.py:32-45, all layers in one launch.  `grad_bufs` = ([w_l.grad], [b_l.grad]): the
+  per-layer slices of the flat gradient buffer (accumulated into directly; no AccumulateGrad nodes)."""
 
   @staticmethod
-  def forward(ctx, x0, w, b):
+  def forward(ctx, x0, w, b, grad_bufs=None):
     out, dots = hip().cross_v1_fwd(x0.contiguous(), w, b)
     ctx.save_for_backward(x0, w, b, dots)
+    ctx.grad_bufs = grad_bufs
     return out
 
   @staticmethod
   def backward(ctx, dout):
     x0, w, b, dots = ctx.saved_tensors
     dx0, dw, db = hip().cross_v1_bwd(x0.contiguous(), w, b, dots, dout.contiguous())
-    return dx0, dw, db
+    if ctx.grad_bufs is not None:
+      wg, bg = ctx.grad_bufs
+      for i in range(len(wg)):
+        wg[i].add_(dw[i])
+        bg[i].add_(db[i])
+      dw = db = None
+    return dx0, dw, db, None
 
 
 class CrossV2EpilogueFn(torch.autograd.Function):
   """reference layers/keras/interaction.py:276-286: x0 * (u + bias + diag*x) + x."""
 
   @staticmethod
-  def forward(ctx, x0, x, u, bias, diag_scale):
+  def forward(ctx, x0, x, u, bias, diag_scale, bias_grad=None):
     out = hip().cross_v2_fwd(x0.contiguous(), x.contiguous(), u.contiguous(), bias, diag_scale)
     ctx.save_for_backward(x0, x, u, bias)
     ctx.diag = diag_scale
+    ctx.bias_grad = bias_grad
     return out
 
   @staticmethod
@@ -701,7 +714,10 @@ class CrossV2EpilogueFn(torch.autograd.Function):
     dx0, dx, du = hip().cross_v2_bwd(x0.contiguous(), x.contiguous(), u.contiguous(), bias, ctx.diag,
                                      dout.contiguous())
     dbias = hip().colsum(du) if bias is not None else None
-    return dx0, dx, du, dbias, None
+    if dbias is not None and ctx.bias_grad is not None:
+      ctx.bias_grad.add_(dbias)
+      dbias = None
+    return dx0, dx, du, dbias, None, None
 
 
 class DINConcatFn(torch.autograd.Function):

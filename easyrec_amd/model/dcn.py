@@ -34,6 +34,12 @@ class DCN(RankModel):
       bs.append(vs.get_variable(name + '_b', (d,), 'glorot_uniform'))
     if num_cross_layers == 0:
       return tensor
+    bufs = None
+    if all(t.grad is not None for t in ws + bs):
+      bufs = ([t.grad for t in ws], [t.grad for t in bs])
+      # the stacks are detached copies: gradients go straight into the variables' gradient slices
+      return kernels.CrossV1Fn.apply(tensor, torch.stack([t.detach() for t in ws]),
+                                     torch.stack([t.detach() for t in bs]), bufs)
     return kernels.CrossV1Fn.apply(tensor, torch.stack(ws), torch.stack(bs))
 
   def build_predict_graph(self):

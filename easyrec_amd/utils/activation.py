@@ -21,7 +21,7 @@ def dice(x, name='dice', epsilon=1e-9, training=True, momentum=0.99):
     return (alpha * (1.0 - p) * x2 + p * x2).reshape(shape)
   frozen = context.current().building
   y = kernels.DiceFn.apply(x2.contiguous(), alpha, None if frozen else mm, None if frozen else mv, epsilon,
-                           momentum)
+                           momentum, alpha.grad)
   return y.reshape(shape)
 
 
