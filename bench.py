@@ -175,7 +175,7 @@ def main():
   est.features.load(ring[0])
   torch.cuda.synchronize()
   ep = world > 1 or args.force_ep
-  if not args.no_graph and not ep:
+  if not args.no_graph:
     est.capture(warmup=3)
 
   def barrier():
@@ -221,7 +221,7 @@ def main():
           'workload': 'DeepFM synthetic Criteo: %s (39 features: 26 hashed x %d rows + 13 projected, D=16 deep + '
                       'D=1 wide, batch %d per GPU, optimizer %s, ids %s, %s)' %
                       (os.path.basename(args.config), cfg.feature_config.features[13].hash_bucket_size, B,
-                       est.opt_emb.name, args.ids, 'eager launches' if (args.no_graph or ep) else 'hipGraph replay'),
+                       est.opt_emb.name, args.ids, 'eager launches' if args.no_graph else ('hipGraph segments + eager all-to-alls' if ep else 'hipGraph replay')),
           'global_batch': world * B,
           'parallelism': 'single GPU' if world == 1 else 'embedding-parallel x%d (row-sharded tables, RCCL all-to-all) + dense DP' % world,
       },

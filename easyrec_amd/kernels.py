@@ -217,12 +217,16 @@ class HipBackend(object):
     self._ck(self.lib.er_emb_bwd_update(group['handle'], ctypes.c_int(opt_kind), _p(hyper), _stream()),
              'er_emb_bwd_update')
 
-  def emb_bwd_reduce(self, group):
+  def emb_bwd_reduce(self, group, out=None):
+    """out: a (keys, grads, n_unique) triple from an earlier call to reuse (fixed addresses for hipGraphs)."""
     n = group['num_entries']
     dev = group['var'].device
-    keys = torch.empty(n, dtype=torch.int32, device=dev)
-    grads = torch.empty(n, group['dim'], dtype=torch.float32, device=dev)
-    n_unique = torch.zeros(1, dtype=torch.int32, device=dev)
+    if out is None:
+      keys = torch.empty(n, dtype=torch.int32, device=dev)
+      grads = torch.empty(n, group['dim'], dtype=torch.float32, device=dev)
+      n_unique = torch.zeros(1, dtype=torch.int32, device=dev)
+    else:
+      keys, grads, n_unique = out
     self._ck(self.lib.er_emb_bwd_reduce(group['handle'], _p(keys), _p(grads), _p(n_unique), _stream()),
              'er_emb_bwd_reduce')
     return keys, grads, n_unique

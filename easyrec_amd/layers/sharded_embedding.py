@@ -195,57 +195,83 @@ class ShardedEmbeddingEngine(EmbeddingEngine):
         dim=dim, combiner=kernels.COMBINER_SUM, n_rows=n, max_nnz=n, name='rep_apply_dim%d' % dim)
     r['apply'] = be.emb_group_create([spec], dim, n, st['var'], st['m'], st['v'], st['bitmap'])
 
-  # -- per-step execution
+  # -- per-step execution.  Three forward phases and three backward phases so that the static ones can be
+  #    replayed as hipGraphs around the data-dependent exchanges (model/embedding_parallel.py):
+  #      route()  [static]  -> exchange()  [host sync + all-to-alls] -> lookup() [static]
+  #      reduce_local() [static] -> exchange_grads_and_update() [all-to-all, variable counts] -> apply_replicated() [static]
+  def route(self):
+    be = kernels.hip()
+    for gi, (dim, sh) in enumerate(self.shard.items()):
+      be.emb_route(sh['req'], sh['ukeys'], sh['n_unique'], sh['uidx'], self.counts_dev[gi])
+
+  def exchange(self):
+    be, comm = kernels.hip(), self.comm
+    if not self.shard:
+      return
+    send, recv = comm.exchange_counts(self.counts_dev)  # host sync: split sizes
+    for gi, (dim, sh) in enumerate(self.shard.items()):
+      sc, rc = send[gi], recv[gi]
+      m = int(sum(rc))
+      if m > sh['m_cap']:
+        raise RuntimeError('embedding-parallel: rank %d receives %d keys for dim %d, capacity %d; raise recv_slack' %
+                           (self.rank, m, dim, sh['m_cap']))
+      sh['send_counts'], sh['recv_counts'], sh['m'] = sc, rc, m
+      comm.all_to_all(sh['ukeys'], sc, sh['recv_keys'], rc)
+      st = sh['st']
+      key_sub = self.rank * sh['stride']
+      be.gather_rows(st['var'], sh['recv_keys'], m, key_sub, sh['rows_out'])
+      if m:
+        torch.sub(sh['recv_keys'][:m], key_sub, out=sh['recv_ids'][:m])
+      comm.all_to_all(sh['rows_out'], rc, sh['recv_rows'], sc)
+      be.emb_group_set_active(sh['owner'], m)
+
+  def lookup(self):
+    for g in self.groups.values():
+      g['got_grad'] = False
+    if self.plan is not None:
+      kernels.hip().emb_fwd(self.plan, self.sumsq if self.reg_lambda > 0 else None)
+
   def forward(self, version):
     if version == self._ran_version:
       return
-    be, comm = kernels.hip(), self.comm
-    for g in self.groups.values():
-      g['got_grad'] = False
-    for gi, (dim, sh) in enumerate(self.shard.items()):
-      be.emb_route(sh['req'], sh['ukeys'], sh['n_unique'], sh['uidx'], self.counts_dev[gi])
-    if self.shard:
-      send, recv = comm.exchange_counts(self.counts_dev)  # host sync: split sizes
-      for gi, (dim, sh) in enumerate(self.shard.items()):
-        sc, rc = send[gi], recv[gi]
-        m = int(sum(rc))
-        if m > sh['m_cap']:
-          raise RuntimeError('embedding-parallel: rank %d receives %d keys for dim %d, capacity %d; raise recv_slack' %
-                             (self.rank, m, dim, sh['m_cap']))
-        sh['send_counts'], sh['recv_counts'], sh['m'] = sc, rc, m
-        comm.all_to_all(sh['ukeys'], sc, sh['recv_keys'], rc)
-        st = sh['st']
-        key_sub = self.rank * sh['stride']
-        be.gather_rows(st['var'], sh['recv_keys'], m, key_sub, sh['rows_out'])
-        if m:
-          torch.sub(sh['recv_keys'][:m], key_sub, out=sh['recv_ids'][:m])
-        comm.all_to_all(sh['rows_out'], rc, sh['recv_rows'], sc)
-        be.emb_group_set_active(sh['owner'], m)
-    if self.plan is not None:
-      be.emb_fwd(self.plan, self.sumsq if self.reg_lambda > 0 else None)
+    self.route()
+    self.exchange()
+    self.lookup()
     self._ran_version = version
 
-  def backward_update(self, opt_kind, hyper):
-    be, comm = kernels.hip(), self.comm
+  def reduce_local(self):
+    be = kernels.hip()
     for g in self.groups.values():
       if not g['got_grad']:
         g['dout'].zero_()
-    # replicated halves first: their all-reduce overlaps the sharded exchange below
     for dim, r in self.rep.items():
-      r['reduced'] = be.emb_bwd_reduce(r['group'])
+      r['reduced'] = be.emb_bwd_reduce(r['group'], out=r.get('reduced'))
     if self.rep:
       self.rep_flat.zero_()
       for dim, r in self.rep.items():
         keys, grads, n_unique = r['reduced']
         be.scatter_unique(keys, grads, n_unique, min(keys.numel(), r['st']['total_rows']), dim, r['dense'])
-      comm.all_reduce_sum(self.rep_flat)
     for dim, sh in self.shard.items():
       be.emb_bwd_reduce_routed(sh['req'], sh['ugrads'])
+
+  def exchange_grads_and_update(self, opt_kind, hyper):
+    be, comm = kernels.hip(), self.comm
+    if self.rep:
+      comm.all_reduce_sum(self.rep_flat)
+    for dim, sh in self.shard.items():
       comm.all_to_all(sh['ugrads'], sh['send_counts'], sh['recv_grads'], sh['recv_counts'])
       be.emb_bwd_update(sh['owner'], opt_kind, hyper)
+
+  def apply_replicated(self, opt_kind, hyper):
+    be = kernels.hip()
     for dim, r in self.rep.items():
       torch.where(r['dense'][:, dim] > 0, r['arange'], r['minus1'], out=r['ids'])
       be.emb_bwd_update(r['apply'], opt_kind, hyper)
+
+  def backward_update(self, opt_kind, hyper):
+    self.reduce_local()
+    self.exchange_grads_and_update(opt_kind, hyper)
+    self.apply_replicated(opt_kind, hyper)
 
   # -- host exchange (collective: every rank must call)
   def table_view(self, name):

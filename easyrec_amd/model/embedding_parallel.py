@@ -10,11 +10,14 @@ start identical on every rank (same seed; the reference broadcasts rank 0's, uti
 
 Per step: 1 small all-gather (split sizes, the one host sync) + 3 RCCL all-to-alls per embedding-dim
 group (keys, rows, row gradients) + 1 all-reduce of the flat dense-gradient buffer + 1 all-reduce of
-the replicated small tables' gradients.  The whole-step hipGraph of the single-GPU path does not apply
-(the all-to-all split sizes change every step), so launches are eager here.
+the replicated small tables' gradients.  The all-to-all split sizes change every step, so the step cannot
+be ONE hipGraph; instead its three static segments (route | lookup+forward+backward+local reduce | replicated
+apply + dense optimizer) are captured separately and the exchanges between them are issued eagerly.
 """
 import torch
 
+from easyrec_amd import kernels
+from easyrec_amd.core import context
 from easyrec_amd.core.comm import LocalComm, TorchDistComm
 from easyrec_amd.layers.sharded_embedding import ShardedEmbeddingEngine
 from easyrec_amd.model.easy_rec_estimator import EasyRecEstimator
@@ -31,6 +34,7 @@ class EmbeddingParallelEstimator(EasyRecEstimator):
     self.comm = comm
     self.rank, self.world = rank, world
     self._engine_kwargs = dict(replicate_bytes=replicate_bytes, recv_slack=recv_slack)
+    self._graphs = None
     super(EmbeddingParallelEstimator, self).__init__(pipeline_config, device=device, batch_size=batch_size, seed=seed,
                                                      schema_kwargs=schema_kwargs, is_training=is_training,
                                                      overlap_sweep=False)
@@ -47,9 +51,94 @@ class EmbeddingParallelEstimator(EasyRecEstimator):
     if self.world > 1:
       self.comm.all_reduce_sum(self.varstore.flat_grad)
 
+  # -- the step in phases: static device work (capturable) around the data-dependent exchanges
+  def _phase_route(self):
+    kernels.hip().hyper_select(self.hyper_table, self.step_counter, self.hyper)
+    self.features.transform()
+    self.engine.route()
+
+  def _phase_compute(self):
+    """lookup -> forward -> losses -> backward -> local gradient reduction (no collective inside)."""
+    be = kernels.hip()
+    self.engine.lookup()
+    self.engine._ran_version = self.features.version  # the model's input-layer calls find the lookup done
+    self.varstore.zero_grad()
+    with context.use(self.ctx):
+      self.model.begin_step()
+      self.model.build_predict_graph()
+      loss_dict = self.model.build_loss_graph()
+      self.engine.regularization_loss(self._reg_emb)
+      if self.varstore.any_l2:
+        be.l2_loss(self.varstore.flat, self.varstore.l2coef, self._reg_dense)
+      torch.add(self._reg_emb, self._reg_dense, out=self.losses['regularization_loss'])
+      total = self.losses['total_loss']
+      total.copy_(self.losses['regularization_loss'])
+      for name, val in loss_dict.items():
+        if name not in self.losses:
+          self.losses[name] = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self.losses[name].copy_(val.reshape(1))
+        total.add_(val.reshape(1))
+      if self.is_training:
+        self.model.backward()
+        self.engine.reduce_local()
+
+  def _phase_apply(self):
+    vs = self.varstore
+    self.engine.apply_replicated(self.opt_emb.kind, self.hyper[0])
+    kernels.hip().dense_opt_step(vs.flat, vs.slots.get('m'), vs.slots.get('v'), vs.flat_grad,
+                                 vs.l2coef if vs.any_l2 else None, self.opt_dense.kind, self.hyper[1])
+
+  def _device_step(self):
+    g = self._graphs
+    if g is None:
+      self._phase_route()
+    else:
+      g[0].replay()
+    self.engine.exchange()  # host sync (split sizes) + all-to-all keys / rows
+    if g is None:
+      self._phase_compute()
+    else:
+      g[1].replay()
+    if self.is_training:
+      self._sync_dense_grads()
+      self.engine.exchange_grads_and_update(self.opt_emb.kind, self.hyper[0])
+      if g is None:
+        self._phase_apply()
+      else:
+        g[2].replay()
+
+  def train_step(self, batch=None):
+    assert self._built, 'call build() first'
+    if batch is not None:
+      self.features.load(batch)
+    else:
+      self.features.version += 1
+    self._refresh_hyper()
+    self._device_step()
+    self.global_step += 1
+    return self.losses
+
   def capture(self, warmup=3):
-    raise NotImplementedError('the embedding-parallel step is not graph-capturable: its all-to-all split sizes '
-                              'are data dependent (one host sync per step)')
+    """Capture the three static segments of the step as hipGraphs (the all-to-alls between them have
+    data-dependent split sizes and stay eager).  Runs `warmup` eager steps on the loaded batch first."""
+    assert self._built and self._graphs is None
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+      for _ in range(warmup):
+        self.train_step()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    pool = torch.cuda.graph_pool_handle()
+    graphs = []
+    for phase in (self._phase_route, self._phase_compute, self._phase_apply):
+      g = torch.cuda.CUDAGraph()
+      with torch.cuda.graph(g, pool=pool):
+        phase()
+      graphs.append(g)
+    # captures do not execute: device state (tables, step counter) is exactly as after the warm-up steps
+    self._graphs = graphs
+    return graphs
 
   def loss_values(self, average=False):
     vals = super(EmbeddingParallelEstimator, self).loss_values()

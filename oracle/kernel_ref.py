@@ -289,7 +289,7 @@ class RefBackend(object):
     v = None if group['v'] is None else group['v'].numpy()
     apply_sparse(var, m, v, grads, opt_kind, h)
 
-  def emb_bwd_reduce(self, group):
+  def emb_bwd_reduce(self, group, out=None):
     grads = sparse_grads(group['specs'], group['dim'])
     keys = sorted(grads.keys())
     n = group['num_entries']

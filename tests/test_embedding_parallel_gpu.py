@@ -137,3 +137,28 @@ def test_sharded_ranks_with_the_same_batch_equal_single_gpu(world, lazy):
   for k in results[0][0]:
     if 'embedding_weights' in k:
       assert np.array_equal(results[0][0][k], results[-1][0][k]), k
+
+
+def test_graph_segments_equal_eager_embedding_parallel_step():
+  """The EP step replayed as three hipGraph segments (+ eager exchanges) must give the same bits as the
+  all-eager EP step (every kernel on the path is deterministic)."""
+  from easyrec_amd.core.comm import LocalComm
+  cfg = _cfg('deepfm_criteo_small.config')
+  B = 256
+  gen = SyntheticCriteo(cfg.data_config, list(cfg.feature_config.features), batch_size=B, seed=13)
+  batches = [gen.next_batch() for _ in range(5)]
+  ests = [EmbeddingParallelEstimator(cfg, device=DEV, batch_size=B, seed=6, rank=0, world=1, comm=LocalComm(),
+                                     replicate_bytes=1024).build() for _ in range(2)]
+  for e in ests:
+    e.features.load(batches[0])
+  for _ in range(3):
+    ests[0].train_step()
+  ests[1].capture(warmup=3)
+  for b in batches[1:]:
+    for e in ests:
+      e.train_step(b)
+    la, lb = ests[0].loss_values(), ests[1].loss_values()
+    assert la == lb, (la, lb)
+  sa, sb = ests[0].state_dict(slots=True), ests[1].state_dict(slots=True)
+  for k in sa:
+    assert np.array_equal(sa[k], sb[k]), k
