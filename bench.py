@@ -175,8 +175,17 @@ def main():
   est.features.load(ring[0])
   torch.cuda.synchronize()
   ep = world > 1 or args.force_ep
+  graph_note = 'eager launches'
   if not args.no_graph:
-    est.capture(warmup=3)
+    try:
+      est.capture(warmup=3)
+      graph_note = 'hipGraph segments + eager all-to-alls' if ep else 'hipGraph replay'
+    except Exception as e:  # noqa: BLE001  (multi-GPU only: keep the run alive, say so in the output)
+      if not ep:
+        raise
+      est._graphs = None
+      graph_note = 'eager launches (graph capture failed: %s)' % str(e)[:80]
+      torch.cuda.synchronize()
 
   def barrier():
     if world > 1:
@@ -221,7 +230,7 @@ def main():
           'workload': 'DeepFM synthetic Criteo: %s (39 features: 26 hashed x %d rows + 13 projected, D=16 deep + '
                       'D=1 wide, batch %d per GPU, optimizer %s, ids %s, %s)' %
                       (os.path.basename(args.config), cfg.feature_config.features[13].hash_bucket_size, B,
-                       est.opt_emb.name, args.ids, 'eager launches' if args.no_graph else ('hipGraph segments + eager all-to-alls' if ep else 'hipGraph replay')),
+                       est.opt_emb.name, args.ids, graph_note),
           'global_batch': world * B,
           'parallelism': 'single GPU' if world == 1 else 'embedding-parallel x%d (row-sharded tables, RCCL all-to-all) + dense DP' % world,
       },

@@ -122,6 +122,65 @@ bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ bias, con
   y[i] = v;
 }
 
+// Fused finalize + apply.  grid = (column blocks of 64, row blocks of kApplyRows); every workgroup first
+// merges the `chunks` Welford partials of ITS 64 columns (4 row-lanes x chunks/4 each, then a fixed merge:
+// identical bits in every workgroup), keeps mean / invstd in LDS, then normalises its [rows x 64] tile.
+// Row block 0 also writes save_mean / save_invstd and the moving statistics.  One launch instead of two.
+constexpr int kApplyRows = 64;
+
+__global__ void __launch_bounds__(kBlock)
+bn_finalize_apply_kernel(const float* __restrict__ partial, const float* __restrict__ x, const float* __restrict__ bias,
+                         const float* __restrict__ gamma, const float* __restrict__ beta, int B, int N, int chunks,
+                         float eps, float momentum, float* __restrict__ moving_mean, float* __restrict__ moving_var,
+                         int act, float* __restrict__ y, float* __restrict__ save_mean,
+                         float* __restrict__ save_invstd) {
+  __shared__ Welford sm[kRowLanes][kColsPerBlock];
+  __shared__ float s_mean[kColsPerBlock], s_inv[kColsPerBlock];
+  const int cl = threadIdx.x % kColsPerBlock;
+  const int rl = threadIdx.x / kColsPerBlock;
+  const int c = blockIdx.x * kColsPerBlock + cl;
+  Welford t{0.f, 0.f, 0.f};
+  if (c < N) {
+    for (int k = rl; k < chunks; k += kRowLanes) {
+      const float* p = partial + (static_cast<int64_t>(k) * N + c) * 3;
+      t = wf_merge(t, Welford{p[0], p[1], p[2]});
+    }
+  }
+  sm[rl][cl] = t;
+  __syncthreads();
+  if (rl == 0 && c < N) {
+    const Welford w = wf_merge(wf_merge(sm[0][cl], sm[1][cl]), wf_merge(sm[2][cl], sm[3][cl]));
+    const float mean = w.mean;
+    const float var = w.m2 / static_cast<float>(B);  // biased, as tf.nn.moments
+    const float inv = 1.f / sqrtf(var + eps);
+    s_mean[cl] = mean;
+    s_inv[cl] = inv;
+    if (blockIdx.y == 0) {
+      save_mean[c] = mean;
+      save_invstd[c] = inv;
+      if (moving_mean) {
+        const float om = 1.f - momentum;
+        moving_mean[c] = moving_mean[c] - (moving_mean[c] - mean) * om;
+        moving_var[c] = moving_var[c] - (moving_var[c] - var) * om;
+      }
+    }
+  }
+  __syncthreads();
+  if (c >= N) return;
+  const float mu = s_mean[cl], is = s_inv[cl];
+  const float bv = bias ? bias[c] : 0.f;
+  const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+  const int r0 = blockIdx.y * kApplyRows;
+  const int r1 = (r0 + kApplyRows < B) ? r0 + kApplyRows : B;
+  for (int r = r0 + rl; r < r1; r += kRowLanes) {
+    const int64_t i = static_cast<int64_t>(r) * N + c;
+    float v = ((x[i] + bv) - mu) * is;
+    v = v * ga + be;
+    if (act == ER_ACT_RELU) v = v > 0.f ? v : 0.f;
+    y[i] = v;
+  }
+}
+
 // backward partials: p[(chunk*N + c)*2 + {0,1}] = (sum g, sum g*xhat), g = dy * act'(y)
 __global__ void __launch_bounds__(kBlock)
 bn_bwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ bias, const float* __restrict__ y,
@@ -158,50 +217,65 @@ bn_bwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ bia
   }
 }
 
+// Fused finalize + apply of the backward: every workgroup reduces the partials of its 64 columns (fixed order),
+// row block 0 writes / accumulates dgamma, dbeta (dbias without BatchNorm), then dx for its [rows x 64] tile.
 __global__ void __launch_bounds__(kBlock)
-bn_bwd_finalize_kernel(const float* __restrict__ partial, int N, int chunks, int use_bn, int accumulate,
-                       float* __restrict__ sum_g, float* __restrict__ sum_gx, float* __restrict__ dbias,
-                       float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  const int lane = threadIdx.x & 63;
-  const int c = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-  if (c >= N) return;
+bn_bwd_finalize_apply_kernel(const float* __restrict__ partial, const float* __restrict__ x,
+                             const float* __restrict__ bias, const float* __restrict__ gamma,
+                             const float* __restrict__ y, const float* __restrict__ mean,
+                             const float* __restrict__ invstd, const float* __restrict__ dy, int B, int N,
+                             int chunks, int use_bn, int act, int accumulate, float* __restrict__ dx,
+                             float* __restrict__ dbias, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ float sm[2][kRowLanes][kColsPerBlock];
+  __shared__ float s_g[kColsPerBlock], s_gx[kColsPerBlock];
+  const int cl = threadIdx.x % kColsPerBlock;
+  const int rl = threadIdx.x / kColsPerBlock;
+  const int c = blockIdx.x * kColsPerBlock + cl;
   float a = 0.f, b = 0.f;
-  for (int k = lane; k < chunks; k += 64) {
-    const float* p = partial + (static_cast<int64_t>(k) * N + c) * 2;
-    a = a + p[0];
-    b = b + p[1];
+  if (c < N) {
+    for (int k = rl; k < chunks; k += kRowLanes) {
+      const float* p = partial + (static_cast<int64_t>(k) * N + c) * 2;
+      a = a + p[0];
+      b = b + p[1];
+    }
   }
-  a = wave_sum(a);
-  b = wave_sum(b);
-  if (lane != 0) return;
-  sum_g[c] = a;
-  sum_gx[c] = b;
-  if (use_bn) {
-    if (dbeta) dbeta[c] = accumulate ? dbeta[c] + a : a;
-    if (dgamma) dgamma[c] = accumulate ? dgamma[c] + b : b;
-    if (dbias && !accumulate) dbias[c] = 0.f;  // BatchNorm removes the column mean: d(loss)/d(bias) == 0
-  } else {
-    if (dbias) dbias[c] = accumulate ? dbias[c] + a : a;
+  sm[0][rl][cl] = a;
+  sm[1][rl][cl] = b;
+  __syncthreads();
+  if (rl == 0 && c < N) {
+    a = (sm[0][0][cl] + sm[0][1][cl]) + (sm[0][2][cl] + sm[0][3][cl]);
+    b = (sm[1][0][cl] + sm[1][1][cl]) + (sm[1][2][cl] + sm[1][3][cl]);
+    s_g[cl] = a;
+    s_gx[cl] = b;
+    if (blockIdx.y == 0) {
+      if (use_bn) {
+        if (dbeta) dbeta[c] = accumulate ? dbeta[c] + a : a;
+        if (dgamma) dgamma[c] = accumulate ? dgamma[c] + b : b;
+        if (dbias && !accumulate) dbias[c] = 0.f;  // BatchNorm removes the column mean: d(loss)/d(bias) == 0
+      } else {
+        if (dbias) dbias[c] = accumulate ? dbias[c] + a : a;
+      }
+    }
   }
-}
-
-__global__ void __launch_bounds__(kBlock)
-bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ bias, const float* __restrict__ gamma,
-                    const float* __restrict__ y, const float* __restrict__ mean, const float* __restrict__ invstd,
-                    const float* __restrict__ dy, const float* __restrict__ sum_g, const float* __restrict__ sum_gx,
-                    int64_t n, int B, int N, int use_bn, int act, float* __restrict__ dx) {
-  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
-  if (i >= n) return;
-  const int c = static_cast<int>(i % N);
-  float g = dy[i];
-  if (act == ER_ACT_RELU && !(y[i] > 0.f)) g = 0.f;
-  if (use_bn) {
-    const float xh = (x[i] + (bias ? bias[c] : 0.f) - mean[c]) * invstd[c];
-    const float invB = 1.f / static_cast<float>(B);
-    const float ga = gamma ? gamma[c] : 1.f;
-    g = ga * invstd[c] * (g - sum_g[c] * invB - xh * (sum_gx[c] * invB));
+  __syncthreads();
+  if (c >= N) return;
+  const float sg = s_g[cl], sgx = s_gx[cl];
+  const float bv = bias ? bias[c] : 0.f;
+  const float mu = use_bn ? mean[c] : 0.f, is = use_bn ? invstd[c] : 0.f;
+  const float ga = gamma ? gamma[c] : 1.f;
+  const float invB = 1.f / static_cast<float>(B);
+  const int r0 = blockIdx.y * kApplyRows;
+  const int r1 = (r0 + kApplyRows < B) ? r0 + kApplyRows : B;
+  for (int r = r0 + rl; r < r1; r += kRowLanes) {
+    const int64_t i = static_cast<int64_t>(r) * N + c;
+    float g = dy[i];
+    if (act == ER_ACT_RELU && !(y[i] > 0.f)) g = 0.f;
+    if (use_bn) {
+      const float xh = (x[i] + bv - mu) * is;
+      g = ga * is * (g - sg * invB - xh * (sgx * invB));
+    }
+    dx[i] = g;
   }
-  dx[i] = g;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -469,12 +543,25 @@ int er_bn_act_fwd(const float* x, const float* bias, const float* gamma, const f
     dim3 grid(static_cast<unsigned>(er::ceil_div(N, er::kColsPerBlock)), static_cast<unsigned>(chunks));
     hipLaunchKernelGGL(er::bn_stats_partial_kernel, grid, dim3(er::kBlock), 0, s, x, bias, B, N, chunks, scratch);
     ER_LAUNCH_CHECK();
-    hipLaunchKernelGGL(er::bn_finalize_kernel, dim3(er::blocks_for(static_cast<int64_t>(N) * 64)), dim3(er::kBlock), 0, s, scratch, B, N, chunks,
-                       eps, momentum, moving_mean, moving_var, save_mean, save_invstd);
-    ER_LAUNCH_CHECK();
+    return er_bn_apply_from_stats(x, bias, scratch, chunks, gamma, beta, B, N, eps, momentum, moving_mean, moving_var,
+                                  act, y, save_mean, save_invstd, stream);
   }
   hipLaunchKernelGGL(er::bn_apply_kernel, dim3(er::blocks_for(n)), dim3(er::kBlock), 0, s, x, bias, gamma, beta,
                      save_mean, save_invstd, n, N, use_bn, act, y);
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
+int er_bn_apply_from_stats(const float* x, const float* bias, const float* col_stats, int32_t chunks,
+                           const float* gamma, const float* beta, int32_t B, int32_t N, float eps, float momentum,
+                           float* moving_mean, float* moving_var, int act, float* y, float* save_mean,
+                           float* save_invstd, er_stream_t stream) {
+  ER_REQUIRE(x && y && col_stats && save_mean && save_invstd && B > 0 && N > 0 && chunks > 0,
+             "er_bn_apply_from_stats: bad arguments");
+  dim3 grid(static_cast<unsigned>(er::ceil_div(N, er::kColsPerBlock)),
+            static_cast<unsigned>(er::ceil_div(B, er::kApplyRows)));
+  hipLaunchKernelGGL(er::bn_finalize_apply_kernel, grid, dim3(er::kBlock), 0, er::as_stream(stream), col_stats, x, bias,
+                     gamma, beta, B, N, chunks, eps, momentum, moving_mean, moving_var, act, y, save_mean, save_invstd);
   ER_LAUNCH_CHECK();
   return 0;
 }
@@ -484,20 +571,17 @@ int er_bn_act_bwd(const float* x, const float* bias, const float* gamma, const f
                   float* dbias, float* dgamma, float* dbeta, int accumulate, er_stream_t stream) {
   ER_REQUIRE(x && y && dy && dx && B > 0 && N > 0, "er_bn_act_bwd: bad arguments");
   hipStream_t s = er::as_stream(stream);
-  const int64_t n = static_cast<int64_t>(B) * N;
   const int chunks = er::choose_chunks(B, N);
   float* scratch;
-  if (er::get_scratch(static_cast<size_t>(chunks) * N * 2 + 2 * static_cast<size_t>(N), &scratch)) return 1;
-  float* sums = scratch + static_cast<size_t>(chunks) * N * 2;
+  if (er::get_scratch(static_cast<size_t>(chunks) * N * 2, &scratch)) return 1;
   dim3 grid(static_cast<unsigned>(er::ceil_div(N, er::kColsPerBlock)), static_cast<unsigned>(chunks));
   hipLaunchKernelGGL(er::bn_bwd_partial_kernel, grid, dim3(er::kBlock), 0, s, x, bias, y, save_mean, save_invstd, dy, B,
                      N, chunks, use_bn, act, scratch);
   ER_LAUNCH_CHECK();
-  hipLaunchKernelGGL(er::bn_bwd_finalize_kernel, dim3(er::blocks_for(static_cast<int64_t>(N) * 64)), dim3(er::kBlock), 0, s, scratch, N, chunks,
-                     use_bn, accumulate, sums, sums + N, dbias, dgamma, dbeta);
-  ER_LAUNCH_CHECK();
-  hipLaunchKernelGGL(er::bn_bwd_apply_kernel, dim3(er::blocks_for(n)), dim3(er::kBlock), 0, s, x, bias, gamma, y,
-                     save_mean, save_invstd, dy, sums, sums + N, n, B, N, use_bn, act, dx);
+  dim3 grid2(static_cast<unsigned>(er::ceil_div(N, er::kColsPerBlock)),
+             static_cast<unsigned>(er::ceil_div(B, er::kApplyRows)));
+  hipLaunchKernelGGL(er::bn_bwd_finalize_apply_kernel, grid2, dim3(er::kBlock), 0, s, scratch, x, bias, gamma, y,
+                     save_mean, save_invstd, dy, B, N, chunks, use_bn, act, accumulate, dx, dbias, dgamma, dbeta);
   ER_LAUNCH_CHECK();
   return 0;
 }

@@ -687,6 +687,15 @@ adam_decay_sweep_scalar_kernel(float* __restrict__ var, float* __restrict__ m, f
   }
 }
 
+// Word fill used instead of hipMemsetAsync: inside a captured hipGraph a memset NODE was observed to lose its
+// ordering against the neighbouring kernel nodes on replay (the touched-row bitmap stayed dirty into the next
+// replay: eager and graph runs of TF-exact Adam diverged, tools/dbg_determinism.py); a kernel node keeps it.
+__global__ void __launch_bounds__(kBlock)
+fill_u32_kernel(uint32_t* __restrict__ p, uint32_t value, int64_t n) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride) p[i] = value;
+}
+
 // Calibration / achievable-bandwidth probe: float4 copy with the sweep's access pattern (nontemporal,
 // grid-stride, 4 units in flight).  Moves exactly 2*bytes; used to calibrate rocprofv3's FETCH_SIZE /
 // WRITE_SIZE on a known byte count and to report the copy bandwidth next to the spec peak.
@@ -903,13 +912,23 @@ int er_emb_group_destroy(er_emb_group* g) {
 
 int64_t er_emb_group_num_entries(const er_emb_group* g) { return g ? g->n_entries : -1; }
 
+static int fill_u32(uint32_t* p, uint32_t value, int64_t n, hipStream_t s) {
+  if (n <= 0) return 0;
+  int64_t blocks = er::ceil_div(n, er::kBlock);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(er::fill_u32_kernel, dim3(static_cast<int>(blocks)), dim3(er::kBlock), 0, s, p, value, n);
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
 static int64_t group_entries(const er_emb_group* g) { return g->n_active >= 0 ? g->n_active : g->n_entries; }
 
 // build keys (routed) + stable radix sort.  Leaves keys_out/vals_out valid for this step.
 static int emb_group_build_sort(er_emb_group* g, hipStream_t s) {
   const int64_t N = group_entries(g);
   if (N == 0) return 0;
-  if (g->has_ragged) ER_CHECK_HIP(hipMemsetAsync(g->keys_in, 0xFF, sizeof(uint32_t) * N, s));
+  if (g->has_ragged)
+    if (int rc = fill_u32(g->keys_in, 0xFFFFFFFFu, N, s)) return rc;
   er::Route rt{g->world, g->shard_stride, g->d_local_base};
   const int64_t n_act = g->n_active >= 0 ? g->n_active : INT64_MAX;
   hipLaunchKernelGGL(er::emb_bwd_build_kernel, dim3(g->n_build_blocks), dim3(er::kBlock), 0, s, g->d_descs,
@@ -1022,7 +1041,7 @@ int er_emb_bwd_update(er_emb_group* g, int opt_kind, const er_opt_hyper* hyper, 
   if (int rc = emb_group_run(g, opt_kind, hyper, 0, nullptr, nullptr, s)) return rc;
   if (opt_kind == ER_OPT_ADAM) {
     if (int rc = er_adam_decay_sweep(g->var, g->m, g->v, g->bitmap, g->total_rows, g->dim, hyper, stream)) return rc;
-    ER_CHECK_HIP(hipMemsetAsync(g->bitmap, 0, sizeof(uint32_t) * static_cast<size_t>(er::ceil_div(g->total_rows, 32)), s));
+    if (int rc = fill_u32(g->bitmap, 0u, er::ceil_div(g->total_rows, 32), s)) return rc;
   }
   return 0;
 }
@@ -1053,9 +1072,7 @@ int er_emb_mark_touched(er_emb_group* g, er_stream_t stream) {
 int er_emb_sweep_untouched(er_emb_group* g, const er_opt_hyper* hyper, er_stream_t stream) {
   ER_REQUIRE(g && hyper && g->bitmap && g->m && g->v, "er_emb_sweep_untouched: needs bitmap, m and v");
   if (int rc = er_adam_decay_sweep(g->var, g->m, g->v, g->bitmap, g->total_rows, g->dim, hyper, stream)) return rc;
-  ER_CHECK_HIP(hipMemsetAsync(g->bitmap, 0, sizeof(uint32_t) * static_cast<size_t>(er::ceil_div(g->total_rows, 32)),
-                              er::as_stream(stream)));
-  return 0;
+  return fill_u32(g->bitmap, 0u, er::ceil_div(g->total_rows, 32), er::as_stream(stream));
 }
 
 int er_emb_bwd_reduce(er_emb_group* g, uint32_t* unique_keys, float* unique_grads, int32_t* n_unique,
@@ -1063,8 +1080,7 @@ int er_emb_bwd_reduce(er_emb_group* g, uint32_t* unique_keys, float* unique_grad
   ER_REQUIRE(g && unique_keys && unique_grads && n_unique, "er_emb_bwd_reduce: null argument");
   hipStream_t s = er::as_stream(stream);
   if (group_entries(g) == 0) {
-    ER_CHECK_HIP(hipMemsetAsync(n_unique, 0, sizeof(int32_t), s));
-    return 0;
+    return fill_u32(reinterpret_cast<uint32_t*>(n_unique), 0u, 1, s);
   }
   if (int rc = emb_group_sort(g, s)) return rc;
   if (int rc = emb_group_heads(g, n_unique, s)) return rc;

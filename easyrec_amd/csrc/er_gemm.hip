@@ -44,6 +44,7 @@ struct GemmArgs {
   int accumulate;
   int k_per_split;    // multiple of the k-tile
   int splits;
+  float* col_stats;   // nullptr, or [gridDim.y][N][3] Welford (count, mean, M2) of the output columns per row tile
 };
 
 // Loads 4 consecutive elements along the CONTIGUOUS dimension of the operand tile.
@@ -81,6 +82,51 @@ __device__ __forceinline__ short f32_to_bf16_rne(float f) {
   if ((u & 0x7FFFFFFFu) > 0x7F800000u) return static_cast<short>((u >> 16) | 0x40);  // NaN stays NaN
   u += 0x7FFFu + ((u >> 16) & 1u);
   return static_cast<short>(u >> 16);
+}
+
+// Per-row-tile column statistics of the OUTPUT (value = acc + bias), for a following BatchNorm: removes the
+// separate statistics pass over the GEMM output.  A lane holds 16 rows of one column; lanes l and l^32 hold the
+// other 16 rows; the two waves with wm = 0 / 1 cover the tile's 64 rows.  Welford/Chan merges in a fixed order.
+__device__ __forceinline__ void chan_merge(float& n, float& mean, float& m2, float nb, float mb, float m2b) {
+  if (nb == 0.f) return;
+  if (n == 0.f) { n = nb; mean = mb; m2 = m2b; return; }
+  const float tot = n + nb;
+  const float delta = mb - mean;
+  mean = mean + delta * (nb / tot);
+  m2 = m2 + m2b + delta * delta * (n * nb / tot);
+  n = tot;
+}
+
+__device__ __forceinline__ void tile_col_stats(const f32x16& acc, float bv, int row_base, int M, int col, int N, int wm,
+                                               int wn, int lane, float* lds /* >= 2*32*3 floats */,
+                                               float* __restrict__ out_tile /* [N][3] of this row tile */) {
+  const int khalf = lane >> 5;
+  float n = 0.f, s = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = row_base + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+    if (row < M) { n += 1.f; s += acc[r] + bv; }
+  }
+  float mean = n > 0.f ? s / n : 0.f;
+  float m2 = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = row_base + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+    if (row < M) { const float d = (acc[r] + bv) - mean; m2 += d * d; }
+  }
+  // the other 16 rows of this column live in lane ^ 32: lower half first so both lanes compute the same bits
+  const float on = __shfl_xor(n, 32, 64), om = __shfl_xor(mean, 32, 64), o2 = __shfl_xor(m2, 32, 64);
+  float an = khalf ? on : n, am = khalf ? om : mean, a2 = khalf ? o2 : m2;
+  chan_merge(an, am, a2, khalf ? n : on, khalf ? mean : om, khalf ? m2 : o2);
+  __syncthreads();  // LDS operand tiles are dead
+  float* slot = lds + (wn * 32 + (lane & 31)) * 3;
+  if (wm == 1 && khalf == 0) { slot[0] = an; slot[1] = am; slot[2] = a2; }
+  __syncthreads();
+  if (wm == 0 && khalf == 0 && col < N) {
+    chan_merge(an, am, a2, slot[0], slot[1], slot[2]);
+    float* o = out_tile + static_cast<int64_t>(col) * 3;
+    o[0] = an; o[1] = am; o[2] = a2;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -158,10 +204,13 @@ gemm_f32_kernel(GemmArgs g) {
   }
   // epilogue.  C/D map of the 32x32 tile: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
   const int col = n0 + wn * 32 + (lane & 31);
+  const float bv = (g.bias && g.splits == 1 && col < g.N) ? g.bias[col] : 0.f;
+  if (g.col_stats)  // (host guarantees splits == 1) every thread takes part: it synchronises the workgroup
+    tile_col_stats(acc, bv, m0 + wm * 32, g.M, col, g.N, wm, wn, lane, As,
+                   g.col_stats + static_cast<int64_t>(blockIdx.y) * g.N * 3);
   if (col >= g.N) return;
   float* Cz = g.C + (g.splits > 1 ? static_cast<int64_t>(blockIdx.z) * g.M * g.N : 0);
   const int ldc = g.splits > 1 ? g.N : g.ldc;
-  const float bv = (g.bias && g.splits == 1) ? g.bias[col] : 0.f;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
@@ -239,11 +288,14 @@ gemm_bf16_kernel(GemmArgs g) {
     }
   }
   const int col = n0 + wn * 32 + (lane & 31);
+  const float bv = (g.bias && g.splits == 1 && col < g.N) ? g.bias[col] : 0.f;
+  const int khalf = lane >> 5;
+  if (g.col_stats)
+    tile_col_stats(acc, bv, m0 + wm * 32, g.M, col, g.N, wm, wn, lane, reinterpret_cast<float*>(As),
+                   g.col_stats + static_cast<int64_t>(blockIdx.y) * g.N * 3);
   if (col >= g.N) return;
   float* Cz = g.C + (g.splits > 1 ? static_cast<int64_t>(blockIdx.z) * g.M * g.N : 0);
   const int ldc = g.splits > 1 ? g.N : g.ldc;
-  const float bv = (g.bias && g.splits == 1) ? g.bias[col] : 0.f;
-  const int khalf = lane >> 5;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
@@ -325,7 +377,7 @@ int choose_splits(int M, int N, int K, int ktile) {
 
 template <bool BF16>
 int gemm_entry(int layout, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
-               const float* bias, int accumulate, er_stream_t stream, const char* who) {
+               const float* bias, int accumulate, float* col_stats, er_stream_t stream, const char* who) {
   ER_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0, "%s: bad arguments", who);
   ER_REQUIRE(layout >= ER_GEMM_NN && layout <= ER_GEMM_TN, "%s: unknown layout %d", who, layout);
   const int min_lda = (layout == ER_GEMM_TN) ? M : K;
@@ -337,7 +389,9 @@ int gemm_entry(int layout, int M, int N, int K, const float* A, int lda, const f
   a.A = A; a.B = B; a.C = C; a.bias = bias;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
   a.accumulate = accumulate;
-  a.splits = choose_splits(M, N, K, ktile);
+  a.col_stats = col_stats;
+  a.splits = col_stats ? 1 : choose_splits(M, N, K, ktile);
+  ER_REQUIRE(!(col_stats && accumulate), "%s: column statistics need a plain (non-accumulating) output", who);
   a.k_per_split = static_cast<int>(er::ceil_div(er::ceil_div(K, a.splits), ktile)) * ktile;
   a.splits = static_cast<int>(er::ceil_div(K, a.k_per_split));
   if (a.splits > 1) {
@@ -365,13 +419,15 @@ int er_gemm_reserve(int64_t floats) {
 }
 
 int er_gemm_f32(int layout, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B, int32_t ldb,
-                float* C, int32_t ldc, const float* bias, int accumulate, er_stream_t stream) {
-  return gemm_entry<false>(layout, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, stream, "er_gemm_f32");
+                float* C, int32_t ldc, const float* bias, int accumulate, float* col_stats, er_stream_t stream) {
+  return gemm_entry<false>(layout, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, col_stats, stream, "er_gemm_f32");
 }
 
 int er_gemm_bf16(int layout, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B, int32_t ldb,
-                 float* C, int32_t ldc, const float* bias, int accumulate, er_stream_t stream) {
-  return gemm_entry<true>(layout, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, stream, "er_gemm_bf16");
+                 float* C, int32_t ldc, const float* bias, int accumulate, float* col_stats, er_stream_t stream) {
+  return gemm_entry<true>(layout, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, col_stats, stream, "er_gemm_bf16");
 }
+
+int er_gemm_row_tiles(int32_t M) { return static_cast<int>(er::ceil_div(M, er::BM)); }
 
 }  // extern "C"

@@ -235,7 +235,23 @@ class HipBackend(object):
   def gemm_reserve(self, floats):
     self._ck(self.lib.er_gemm_reserve(ctypes.c_int64(int(floats))), 'er_gemm_reserve')
 
-  def gemm(self, layout, a, b, out=None, bias=None, accumulate=False, bf16=False):
+  def gemm_row_tiles(self, M):
+    return int(self.lib.er_gemm_row_tiles(ctypes.c_int32(int(M))))
+
+  def bn_apply_from_stats(self, x, bias, col_stats, chunks, gamma, beta, eps, momentum, moving_mean, moving_var, act):
+    """BatchNorm(train) + activation from ready-made column statistics (er_gemm's epilogue)."""
+    B, N = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(N, dtype=torch.float32, device=x.device)
+    invstd = torch.empty(N, dtype=torch.float32, device=x.device)
+    self._ck(
+        self.lib.er_bn_apply_from_stats(_p(_f32c(x)), _p(bias), _p(col_stats), ctypes.c_int32(int(chunks)), _p(gamma),
+                                        _p(beta), B, N, ctypes.c_float(eps), ctypes.c_float(momentum),
+                                        _p(moving_mean), _p(moving_var), int(act), _p(y), _p(mean), _p(invstd),
+                                        _stream()), 'er_bn_apply_from_stats')
+    return y, mean, invstd
+
+  def gemm(self, layout, a, b, out=None, bias=None, accumulate=False, bf16=False, col_stats=None):
     """out (+)= op(a) . op(b) (+ bias).  2-D fp32 tensors with unit inner stride.
     layout GEMM_NN: a[M,K] b[K,N]; GEMM_NT: a[M,K] b[N,K]; GEMM_TN: a[K,M] b[K,N]."""
     assert a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1
@@ -252,8 +268,11 @@ class HipBackend(object):
       out = torch.empty(M, N, dtype=torch.float32, device=a.device)
     assert out.shape == (M, N) and out.stride(1) == 1 and out.dtype == torch.float32
     fn = self.lib.er_gemm_bf16 if bf16 else self.lib.er_gemm_f32
+    if col_stats is not None:
+      assert col_stats.numel() >= self.gemm_row_tiles(M) * N * 3 and col_stats.dtype == torch.float32
     self._ck(fn(ctypes.c_int(layout), M, N, K, _p(a), ctypes.c_int32(a.stride(0)), _p(b), ctypes.c_int32(b.stride(0)),
-                _p(out), ctypes.c_int32(out.stride(0)), _p(bias), int(bool(accumulate)), _stream()), 'er_gemm')
+                _p(out), ctypes.c_int32(out.stride(0)), _p(bias), int(bool(accumulate)), _p(col_stats), _stream()),
+             'er_gemm')
     return out
 
   # -- K12 embedding-parallel routing (include/easyrec_hip.h)
@@ -586,6 +605,46 @@ class LinearFn(torch.autograd.Function):
       else:
         db = s
     return dx, dw, db, None, None, None
+
+
+class LinearBNActFn(torch.autograd.Function):
+  """dense (+ bias) -> BatchNorm(train) -> activation of one DNN layer (reference layers/dnn.py:57-79) as TWO
+  launches forward: the MFMA GEMM, whose epilogue adds the bias and emits per-row-tile column statistics, and
+  one fused finalize + normalise + ReLU kernel.  Backward: column sums, fused finalize + dz, then the two
+  gradient GEMMs; parameter gradients accumulate straight into the flat gradient buffer (`grad_bufs` =
+  (kernel.grad, gamma.grad, beta.grad)).  Under BatchNorm d(loss)/d(bias) == 0, so the bias gets none."""
+
+  @staticmethod
+  def forward(ctx, x, w, b, gamma, beta, moving_mean, moving_var, eps, momentum, act, bf16, grad_bufs):
+    be = hip()
+    x2 = x if x.stride(-1) == 1 else x.contiguous()
+    M, N = x2.shape[0], w.shape[1]
+    chunks = be.gemm_row_tiles(M)
+    stats = torch.empty(chunks * N * 3, dtype=torch.float32, device=x2.device)
+    z = be.gemm(GEMM_NN, x2, w, bias=b, bf16=bf16, col_stats=stats)
+    y, mean, invstd = be.bn_apply_from_stats(z, None, stats, chunks, gamma, beta, eps, momentum, moving_mean,
+                                             moving_var, act)
+    ctx.save_for_backward(x2, w, gamma, z, y, mean, invstd)
+    ctx.act, ctx.bf16, ctx.grad_bufs = act, bf16, grad_bufs
+    return y
+
+  @staticmethod
+  def backward(ctx, dy):
+    be = hip()
+    x, w, gamma, z, y, mean, invstd = ctx.saved_tensors
+    wg, gg, betag = ctx.grad_bufs if ctx.grad_bufs is not None else (None, None, None)
+    direct = gg is not None and betag is not None
+    dz, _, dgamma, dbeta = be.bn_act_bwd(z, None, gamma, y, mean, invstd, dy.contiguous(), 1, ctx.act, False, True,
+                                         into=(None, gg, betag) if direct else None)
+    dx = dw = None
+    if ctx.needs_input_grad[0]:
+      dx = be.gemm(GEMM_NT, dz, w, bf16=ctx.bf16)
+    if ctx.needs_input_grad[1]:
+      if wg is not None:
+        be.gemm(GEMM_TN, x, dz, out=wg, accumulate=True, bf16=ctx.bf16)
+      else:
+        dw = be.gemm(GEMM_TN, x, dz, bf16=ctx.bf16)
+    return dx, dw, None, dgamma, dbeta, None, None, None, None, None, None, None
 
 
 class FMFn(torch.autograd.Function):

@@ -58,9 +58,18 @@ def dense_bn_act(x, units, name, l2_reg, use_bias, use_bn, act_relu, training, b
     mm = vs.get_variable(bn + '/moving_mean', (units,), 'zeros', trainable=False)
     mv = vs.get_variable(bn + '/moving_variance', (units,), 'ones', trainable=False)
   shape = x.shape
-  z = _linear(x.reshape(-1, in_dim), w, None)
   act = kernels.ACT_RELU if act_relu else kernels.ACT_NONE
   freeze = ctx.building and training  # build pass: do not touch the moving statistics
+  if use_bn and training and torch.is_grad_enabled():
+    # GEMM (bias + column statistics in its epilogue) + ONE fused BatchNorm/ReLU launch
+    bufs = None
+    if w.grad is not None and gamma.grad is not None and beta.grad is not None:
+      bufs = (w.grad, gamma.grad, beta.grad)
+    bf16 = getattr(ctx, 'dense_dtype', 'f32') == 'bf16'
+    y = kernels.LinearBNActFn.apply(x.reshape(-1, in_dim), w, b, gamma, beta, None if freeze else mm,
+                                    None if freeze else mv, BN_EPSILON, BN_MOMENTUM, act, bf16, bufs)
+    return y.reshape(shape[:-1] + (units,))
+  z = _linear(x.reshape(-1, in_dim), w, None)
   y = kernels.BNActFn.apply(z, b, gamma, beta, None if freeze else mm, None if freeze else mv, use_bn,
                             BN_EPSILON, BN_MOMENTUM, act, training, _grad_bufs(b, gamma, beta))
   return y.reshape(shape[:-1] + (units,))

@@ -133,7 +133,8 @@ class EmbeddingParallelEstimator(EasyRecEstimator):
     graphs = []
     for phase in (self._phase_route, self._phase_compute, self._phase_apply):
       g = torch.cuda.CUDAGraph()
-      with torch.cuda.graph(g, pool=pool):
+      # thread_local: the RCCL watchdog thread of the process group may touch its own events meanwhile
+      with torch.cuda.graph(g, pool=pool, capture_error_mode='thread_local'):
         phase()
       graphs.append(g)
     # captures do not execute: device state (tables, step counter) is exactly as after the warm-up steps

@@ -276,6 +276,13 @@ int er_bn_act_fwd(const float* x, const float* bias, const float* gamma, const f
                   int32_t B, int32_t N, int use_bn, float eps, float momentum,
                   float* moving_mean, float* moving_var, int act, float* y, float* save_mean,
                   float* save_invstd, er_stream_t stream);
+/* The same normalisation from ready-made column statistics: col_stats = `chunks` Welford triples per column
+ * ([chunks][N][3]: count, mean, M2), e.g. written by er_gemm_*'s epilogue (chunks = er_gemm_row_tiles(B)).
+ * One launch: every workgroup merges the partials of its 64 columns, then normalises its tile. */
+int er_bn_apply_from_stats(const float* x, const float* bias, const float* col_stats, int32_t chunks,
+                           const float* gamma, const float* beta, int32_t B, int32_t N, float eps,
+                           float momentum, float* moving_mean, float* moving_var, int act, float* y,
+                           float* save_mean, float* save_invstd, er_stream_t stream);
 /* dx [B,N]; dbias/dgamma/dbeta [N] (NULL to skip): overwritten, or += when accumulate != 0 (they then
  * point into the flat gradient buffer).  y is the forward output (relu mask); x the forward input. */
 int er_bn_act_bwd(const float* x, const float* bias, const float* gamma, const float* y,
@@ -333,14 +340,21 @@ int er_mmoe_mix_bwd(const float* experts, const float* gates, const float* dout,
  *   er_gemm_bf16: operands rounded to bf16 (RNE) while staged into LDS, v_mfma_f32_32x32x16_bf16,
  *                 fp32 accumulate (BASELINE config 3: bf16 dense, fp32 embeddings and master weights).
  *   accumulate != 0: C += result (gradients accumulate straight into the flat gradient buffer).
+ *   col_stats != NULL: the epilogue also writes, per 64-row tile t (t < er_gemm_row_tiles(M)) and output
+ *     column j, the Welford triple (count, mean, M2) of C[64t : 64t+64, j] to col_stats[(t*N + j)*3 ..]:
+ *     the batch statistics of a following BatchNorm without another pass over C (er_bn_apply_from_stats
+ *     consumes them: FusedBatchNorm / moments of layers/dnn.py:63-69).
  *   er_gemm_reserve pre-sizes the split-K workspace (floats) before hipGraph capture.
  * -------------------------------------------------------------------------------------------- */
 enum { ER_GEMM_NN = 0, ER_GEMM_NT = 1, ER_GEMM_TN = 2 };
 int er_gemm_reserve(int64_t floats);
+int er_gemm_row_tiles(int32_t M);
 int er_gemm_f32(int layout, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B,
-                int32_t ldb, float* C, int32_t ldc, const float* bias, int accumulate, er_stream_t stream);
+                int32_t ldb, float* C, int32_t ldc, const float* bias, int accumulate, float* col_stats,
+                er_stream_t stream);
 int er_gemm_bf16(int layout, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B,
-                 int32_t ldb, float* C, int32_t ldc, const float* bias, int accumulate, er_stream_t stream);
+                 int32_t ldb, float* C, int32_t ldc, const float* bias, int accumulate, float* col_stats,
+                 er_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
  * K12 embedding-parallel (row-sharded tables, one process per GPU).  Replaces

@@ -305,7 +305,14 @@ class RefBackend(object):
   def gemm_reserve(self, floats):
     pass
 
-  def gemm(self, layout, a, b, out=None, bias=None, accumulate=False, bf16=False):
+  def gemm_row_tiles(self, M):
+    return (int(M) + 63) // 64
+
+  def bn_apply_from_stats(self, x, bias, col_stats, chunks, gamma, beta, eps, momentum, moving_mean, moving_var, act):
+    # the statistics are recomputed from x: same values as the Welford merge up to rounding
+    return self.bn_act_fwd(x, bias, gamma, beta, True, eps, momentum, moving_mean, moving_var, act)
+
+  def gemm(self, layout, a, b, out=None, bias=None, accumulate=False, bf16=False, col_stats=None):
     def rnd(t):
       return t.to(torch.bfloat16).to(torch.float32) if bf16 else t
     A, Bm = rnd(a.detach()), rnd(b.detach())

@@ -114,17 +114,23 @@ def test_lazy_adam_first_step_matches_oracle():
   assert np.isfinite(est.state_dict()[name]).all()
 
 
-def test_eager_runs_are_deterministic_and_graph_replay_agrees():
-  """Two eager estimators fed the same batches, and a third replaying a captured hipGraph."""
+@pytest.mark.parametrize('lazy', [False, True])
+def test_eager_runs_are_deterministic_and_graph_replay_agrees(lazy):
+  """Two eager estimators fed the same batches, and a third replaying a captured hipGraph, must agree BIT FOR
+  BIT: every kernel on the path (MFMA GEMMs, split-K reduce, radix sort, tile-scan reduction, BatchNorm
+  statistics) combines in a fixed order, and nothing in the graph depends on capture-time state.  (This test
+  caught a hipGraph memset node that lost its ordering on replay: the touched-row bitmap of TF-exact Adam is
+  now cleared by a kernel.)"""
   cfg = _cfg('deepfm_criteo_small.config')
+  if lazy:
+    oc = cfg.train_config.optimizer_config[0]
+    oc.lazy_adam_optimizer.learning_rate.CopyFrom(oc.adam_optimizer.learning_rate)
   B = 256
   gen = SyntheticCriteo(cfg.data_config, list(cfg.feature_config.features), batch_size=B)
   batches = [gen.next_batch() for _ in range(6)]
   a = EasyRecEstimator(cfg, device=DEV, batch_size=B, seed=2).build()
   b = EasyRecEstimator(cfg, device=DEV, batch_size=B, seed=2).build()
   c = EasyRecEstimator(cfg, device=DEV, batch_size=B, seed=2).build()
-  b.load_state_dict(a.state_dict())
-  c.load_state_dict(a.state_dict())
   for e in (a, b, c):
     e.features.load(batches[0])
   for _ in range(3):
@@ -136,11 +142,12 @@ def test_eager_runs_are_deterministic_and_graph_replay_agrees():
     for e in (a, b, c):
       e.train_step(bt)
     la, lb, lc = a.loss_values(), b.loss_values(), c.loss_values()
-    assert abs(la['total_loss'] - lb['total_loss']) <= 1e-3 * abs(la['total_loss']), (la, lb)
-    assert abs(la['total_loss'] - lc['total_loss']) <= 2e-3 * abs(la['total_loss']), (la, lc)
-  sa, sb = a.state_dict(), b.state_dict()
-  n_exact = sum(int(np.array_equal(sa[k], sb[k])) for k in sa)
-  print('bit-identical tensors between two eager runs: %d / %d' % (n_exact, len(sa)))
+    assert la == lb, (la, lb)
+    assert la == lc, (la, lc)
+  sa, sb, sc = a.state_dict(slots=True), b.state_dict(slots=True), c.state_dict(slots=True)
+  for k in sa:
+    assert np.array_equal(sa[k], sb[k]), ('eager vs eager', k)
+    assert np.array_equal(sa[k], sc[k]), ('eager vs graph', k)
 
 
 def test_full_size_properties():

@@ -566,3 +566,27 @@ def test_linear_fn_matches_torch_autograd(hip):
   assert torch.allclose(wg.double(), wr.grad, rtol=1e-5, atol=1e-4)
   assert torch.allclose(bg.double(), br.grad, rtol=1e-5, atol=1e-4)
   assert w.grad is None and b.grad is None  # accumulated into the given buffers instead
+
+
+@pytest.mark.parametrize('M,N,K', [(4096, 256, 624), (300, 40, 81), (130, 70, 33), (64, 1, 16)])
+@pytest.mark.parametrize('bf16', [False, True])
+def test_gemm_epilogue_statistics_feed_batchnorm(hip, M, N, K, bf16):
+  """er_gemm's column statistics + er_bn_apply_from_stats == BatchNorm(train)+ReLU of the GEMM output."""
+  g = torch.Generator().manual_seed(M + N + K)
+  x, w = torch.randn(M, K, generator=g), torch.randn(K, N, generator=g) * 0.1
+  bias, gamma, beta = torch.randn(N, generator=g), torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g)
+  mm, mv = torch.zeros(N, device=DEV), torch.ones(N, device=DEV)
+  chunks = hip.gemm_row_tiles(M)
+  stats = torch.zeros(chunks * N * 3, device=DEV)
+  z = hip.gemm(kernels.GEMM_NN, x.to(DEV), w.to(DEV), bias=bias.to(DEV), bf16=bf16, col_stats=stats)
+  y, mean, invstd = hip.bn_apply_from_stats(z, None, stats, chunks, gamma.to(DEV), beta.to(DEV), 1e-3, 0.99, mm, mv,
+                                            kernels.ACT_RELU)
+  torch.cuda.synchronize()
+  zr = z.cpu().double()
+  mu, var = zr.mean(dim=0), zr.var(dim=0, unbiased=False)
+  assert torch.allclose(mean.cpu().double(), mu, rtol=1e-5, atol=1e-5)
+  assert torch.allclose(invstd.cpu().double(), 1.0 / torch.sqrt(var + 1e-3), rtol=1e-5, atol=1e-6)
+  yr = torch.relu((zr - mu) / torch.sqrt(var + 1e-3) * gamma.double() + beta.double())
+  assert torch.allclose(y.cpu().double(), yr, rtol=1e-4, atol=1e-5)
+  assert torch.allclose(mm.cpu().double(), 0.01 * mu, rtol=1e-4, atol=1e-6)
+  assert torch.allclose(mv.cpu().double(), 0.99 + 0.01 * var, rtol=1e-4, atol=1e-6)
