@@ -141,9 +141,21 @@ bn_finalize_apply_kernel(const float* __restrict__ partial, const float* __restr
   const int c = blockIdx.x * kColsPerBlock + cl;
   Welford t{0.f, 0.f, 0.f};
   if (c < N) {
-    for (int k = rl; k < chunks; k += kRowLanes) {
-      const float* p = partial + (static_cast<int64_t>(k) * N + c) * 3;
-      t = wf_merge(t, Welford{p[0], p[1], p[2]});
+    // groups of 8 partials: the 24 loads of a group are issued together, then merged in order
+    for (int k0 = rl; k0 < chunks; k0 += 8 * kRowLanes) {
+      Welford w8[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = k0 + j * kRowLanes;
+        if (k < chunks) {
+          const float* p = partial + (static_cast<int64_t>(k) * N + c) * 3;
+          w8[j] = Welford{p[0], p[1], p[2]};
+        } else {
+          w8[j] = Welford{0.f, 0.f, 0.f};
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) t = wf_merge(t, w8[j]);
     }
   }
   sm[rl][cl] = t;
@@ -170,14 +182,23 @@ bn_finalize_apply_kernel(const float* __restrict__ partial, const float* __restr
   const float mu = s_mean[cl], is = s_inv[cl];
   const float bv = bias ? bias[c] : 0.f;
   const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
-  const int r0 = blockIdx.y * kApplyRows;
-  const int r1 = (r0 + kApplyRows < B) ? r0 + kApplyRows : B;
-  for (int r = r0 + rl; r < r1; r += kRowLanes) {
-    const int64_t i = static_cast<int64_t>(r) * N + c;
-    float v = ((x[i] + bv) - mu) * is;
-    v = v * ga + be;
-    if (act == ER_ACT_RELU) v = v > 0.f ? v : 0.f;
-    y[i] = v;
+  const int r0 = blockIdx.y * kApplyRows + rl;
+  // fixed trip count, fully unrolled: all the tile's loads of a lane are in flight together
+  float xv[kApplyRows / kRowLanes];
+#pragma unroll
+  for (int k = 0; k < kApplyRows / kRowLanes; ++k) {
+    const int r = r0 + k * kRowLanes;
+    xv[k] = (r < B) ? x[static_cast<int64_t>(r) * N + c] : 0.f;
+  }
+#pragma unroll
+  for (int k = 0; k < kApplyRows / kRowLanes; ++k) {
+    const int r = r0 + k * kRowLanes;
+    if (r < B) {
+      float v = ((xv[k] + bv) - mu) * is;
+      v = v * ga + be;
+      if (act == ER_ACT_RELU) v = v > 0.f ? v : 0.f;
+      y[static_cast<int64_t>(r) * N + c] = v;
+    }
   }
 }
 
@@ -233,6 +254,7 @@ bn_bwd_finalize_apply_kernel(const float* __restrict__ partial, const float* __r
   const int c = blockIdx.x * kColsPerBlock + cl;
   float a = 0.f, b = 0.f;
   if (c < N) {
+#pragma unroll 8
     for (int k = rl; k < chunks; k += kRowLanes) {
       const float* p = partial + (static_cast<int64_t>(k) * N + c) * 2;
       a = a + p[0];
@@ -264,17 +286,30 @@ bn_bwd_finalize_apply_kernel(const float* __restrict__ partial, const float* __r
   const float mu = use_bn ? mean[c] : 0.f, is = use_bn ? invstd[c] : 0.f;
   const float ga = gamma ? gamma[c] : 1.f;
   const float invB = 1.f / static_cast<float>(B);
-  const int r0 = blockIdx.y * kApplyRows;
-  const int r1 = (r0 + kApplyRows < B) ? r0 + kApplyRows : B;
-  for (int r = r0 + rl; r < r1; r += kRowLanes) {
+  const int r0 = blockIdx.y * kApplyRows + rl;
+  constexpr int kIter = kApplyRows / kRowLanes;
+  float gv[kIter], yv[kIter], xv[kIter];
+#pragma unroll
+  for (int k = 0; k < kIter; ++k) {
+    const int r = r0 + k * kRowLanes;
     const int64_t i = static_cast<int64_t>(r) * N + c;
-    float g = dy[i];
-    if (act == ER_ACT_RELU && !(y[i] > 0.f)) g = 0.f;
-    if (use_bn) {
-      const float xh = (x[i] + bv - mu) * is;
-      g = ga * is * (g - sg * invB - xh * (sgx * invB));
+    const bool ok = r < B;
+    gv[k] = ok ? dy[i] : 0.f;
+    yv[k] = (ok && act == ER_ACT_RELU) ? y[i] : 1.f;
+    xv[k] = (ok && use_bn) ? x[i] : 0.f;
+  }
+#pragma unroll
+  for (int k = 0; k < kIter; ++k) {
+    const int r = r0 + k * kRowLanes;
+    if (r < B) {
+      float g = gv[k];
+      if (act == ER_ACT_RELU && !(yv[k] > 0.f)) g = 0.f;
+      if (use_bn) {
+        const float xh = (xv[k] + bv - mu) * is;
+        g = ga * is * (g - sg * invB - xh * (sgx * invB));
+      }
+      dx[static_cast<int64_t>(r) * N + c] = g;
     }
-    dx[i] = g;
   }
 }
 
@@ -404,19 +439,38 @@ dice_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ alp
 // ------------------------------------------------------------------------------------------------
 // loss + scalar reductions (single block, fixed tree -> deterministic)
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock)
+// one workgroup of 1024 threads (16 waves): the batch is a few thousand logits; sums combine in a fixed order
+constexpr int kCeBlock = 1024;
+__device__ __forceinline__ float block_sum_1024(float v, float* smem16) {
+  v = wave_sum(v);
+  const int wid = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) smem16[wid] = v;
+  __syncthreads();
+  float r = 0.f;
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < kCeBlock / 64; ++i) r = r + smem16[i];
+  }
+  __syncthreads();
+  return r;
+}
+
+__global__ void __launch_bounds__(kCeBlock)
 sigmoid_ce_kernel(const float* __restrict__ z, const float* __restrict__ y, const float* __restrict__ w, int B,
                   float loss_scale, float* __restrict__ loss_out, float* __restrict__ dz, float* __restrict__ probs) {
-  __shared__ float red[4];
+  __shared__ float red[kCeBlock / 64];
   __shared__ float s_nz;
-  float cnt = 0.f;
-  for (int i = threadIdx.x; i < B; i += kBlock) cnt += (w ? (w[i] != 0.f ? 1.f : 0.f) : 1.f);
-  const float tot = block_sum_256(cnt, red);
-  if (threadIdx.x == 0) s_nz = tot > 0.f ? tot : 1.f;
-  __syncthreads();
-  const float nz = s_nz;
+  float nz = static_cast<float>(B);
+  if (w) {
+    float cnt = 0.f;
+    for (int i = threadIdx.x; i < B; i += kCeBlock) cnt += (w[i] != 0.f ? 1.f : 0.f);
+    const float tot = block_sum_1024(cnt, red);
+    if (threadIdx.x == 0) s_nz = tot > 0.f ? tot : 1.f;
+    __syncthreads();
+    nz = s_nz;
+  }
   float acc = 0.f;
-  for (int i = threadIdx.x; i < B; i += kBlock) {
+  for (int i = threadIdx.x; i < B; i += kCeBlock) {
     const float zi = z[i], yi = y[i];
     const float wi = w ? w[i] : 1.f;
     // tf.nn.sigmoid_cross_entropy_with_logits: max(z,0) - z*y + log1p(exp(-|z|))
@@ -426,8 +480,29 @@ sigmoid_ce_kernel(const float* __restrict__ z, const float* __restrict__ y, cons
     if (probs) probs[i] = p;
     if (dz) dz[i] = loss_scale * wi * (p - yi) / nz;
   }
-  const float s = block_sum_256(acc, red);
+  const float s = block_sum_1024(acc, red);
   if (threadIdx.x == 0 && loss_out) loss_out[0] = loss_scale * s / nz;
+}
+
+// regularization_loss = reg_emb + reg_dense; total_loss = regularization_loss + sum_i losses[i]; copies of the
+// individual losses into their report slots: the estimator's add_n over the loss dict + REGULARIZATION_LOSSES
+// (model/easy_rec_estimator.py:166-184) as ONE launch instead of ~6 scalar add / copy kernels.
+struct LossPtrs {
+  const float* src[8];
+  float* dst[8];
+};
+__global__ void total_loss_kernel(const float* __restrict__ reg_emb, const float* __restrict__ reg_dense, LossPtrs lp,
+                                  int n, float* __restrict__ reg_out, float* __restrict__ total_out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const float reg = reg_emb[0] + reg_dense[0];
+  reg_out[0] = reg;
+  float total = reg;
+  for (int i = 0; i < n; ++i) {
+    const float v = lp.src[i][0];
+    if (lp.dst[i]) lp.dst[i][0] = v;
+    total = total + v;
+  }
+  total_out[0] = total;
 }
 
 __global__ void __launch_bounds__(kBlock)
@@ -648,8 +723,22 @@ int er_dice_bwd(const float* x, const float* alpha, const float* save_mean, cons
 int er_sigmoid_ce_fwd_bwd(const float* logits, const float* labels, const float* weights, int32_t B,
                           float loss_scale, float* loss_out, float* dlogits, float* probs_out, er_stream_t stream) {
   ER_REQUIRE(logits && labels && B > 0, "er_sigmoid_ce_fwd_bwd: bad arguments");
-  hipLaunchKernelGGL(er::sigmoid_ce_kernel, dim3(1), dim3(er::kBlock), 0, er::as_stream(stream), logits, labels,
+  hipLaunchKernelGGL(er::sigmoid_ce_kernel, dim3(1), dim3(er::kCeBlock), 0, er::as_stream(stream), logits, labels,
                      weights, B, loss_scale, loss_out, dlogits, probs_out);
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
+int er_total_loss(const float* reg_emb, const float* reg_dense, const float* const* losses_host, float* const* report_host,
+                  int32_t n, float* reg_out, float* total_out, er_stream_t stream) {
+  ER_REQUIRE(reg_emb && reg_dense && reg_out && total_out && n >= 0 && n <= 8, "er_total_loss: bad arguments (n <= 8)");
+  er::LossPtrs lp;
+  for (int i = 0; i < 8; ++i) {
+    lp.src[i] = (i < n) ? losses_host[i] : nullptr;
+    lp.dst[i] = (i < n && report_host) ? report_host[i] : nullptr;
+  }
+  hipLaunchKernelGGL(er::total_loss_kernel, dim3(1), dim3(64), 0, er::as_stream(stream), reg_emb, reg_dense, lp, n,
+                     reg_out, total_out);
   ER_LAUNCH_CHECK();
   return 0;
 }

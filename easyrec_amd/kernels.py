@@ -511,6 +511,13 @@ class HipBackend(object):
         'er_sigmoid_ce_fwd_bwd')
     return loss, dlogits, probs
 
+  def total_loss(self, reg_emb, reg_dense, losses, reports, reg_out, total_out):
+    n = len(losses)
+    src = (ctypes.c_void_p * max(n, 1))(*[t.data_ptr() for t in losses])
+    dst = (ctypes.c_void_p * max(n, 1))(*[t.data_ptr() for t in reports])
+    self._ck(self.lib.er_total_loss(_p(reg_emb), _p(reg_dense), src, dst, n, _p(reg_out), _p(total_out), _stream()),
+             'er_total_loss')
+
   def reduce_sum(self, partials, scale, out, accumulate=False):
     self._ck(
         self.lib.er_reduce_sum(_p(partials), partials.numel(), ctypes.c_float(scale), _p(out), int(accumulate),

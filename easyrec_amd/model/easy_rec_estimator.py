@@ -176,14 +176,12 @@ class EasyRecEstimator(object):
       self.engine.regularization_loss(self._reg_emb)
       if self.varstore.any_l2:
         be.l2_loss(self.varstore.flat, self.varstore.l2coef, self._reg_dense)
-      torch.add(self._reg_emb, self._reg_dense, out=self.losses['regularization_loss'])
-      total = self.losses['total_loss']
-      total.copy_(self.losses['regularization_loss'])
-      for name, val in loss_dict.items():
+      names = list(loss_dict.keys())  # (_reg_dense stays 0 when no kernel carries an L2 coefficient)
+      for name in names:
         if name not in self.losses:
           self.losses[name] = torch.zeros(1, dtype=torch.float32, device=self.device)
-        self.losses[name].copy_(val.reshape(1))
-        total.add_(val.reshape(1))
+      be.total_loss(self._reg_emb, self._reg_dense, [loss_dict[n].reshape(1) for n in names],
+                    [self.losses[n] for n in names], self.losses['regularization_loss'], self.losses['total_loss'])
       if self.is_training:
         self.model.backward()
         self._sync_dense_grads()

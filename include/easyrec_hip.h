@@ -310,6 +310,11 @@ int er_dice_bwd(const float* x, const float* alpha, const float* save_mean,
 int er_sigmoid_ce_fwd_bwd(const float* logits, const float* labels, const float* weights,
                           int32_t B, float loss_scale, float* loss_out, float* dlogits,
                           float* probs_out, er_stream_t stream);
+/* reg_out[0] = reg_emb[0] + reg_dense[0]; total_out[0] = reg_out[0] + sum_i losses[i][0]; report[i][0] = losses[i][0]
+ * (report may be NULL).  losses_host / report_host: HOST arrays of n <= 8 DEVICE pointers.  The add_n over the
+ * loss dict and REGULARIZATION_LOSSES of model/easy_rec_estimator.py:166-184 in one launch. */
+int er_total_loss(const float* reg_emb, const float* reg_dense, const float* const* losses_host,
+                  float* const* report_host, int32_t n, float* reg_out, float* total_out, er_stream_t stream);
 /* out[0] = scale * sum of all n partials (deterministic single-block tree) */
 int er_reduce_sum(const float* partials, int32_t n, float scale, float* out, int accumulate,
                   er_stream_t stream);

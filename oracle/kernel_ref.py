@@ -589,6 +589,14 @@ class RefBackend(object):
     p = torch.sigmoid(z)
     return loss, loss_scale * w * (p - y) / nz, p
 
+  def total_loss(self, reg_emb, reg_dense, losses, reports, reg_out, total_out):
+    reg_out.copy_(reg_emb + reg_dense)
+    total = reg_out.clone()
+    for src, dst in zip(losses, reports):
+      dst.copy_(src.reshape(1))
+      total = total + src.reshape(1)
+    total_out.copy_(total)
+
   def reduce_sum(self, partials, scale, out, accumulate=False):
     s = partials.to(torch.float64).sum().to(torch.float32) * scale
     if accumulate:
