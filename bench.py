@@ -38,6 +38,7 @@ def parse_args():
   ap.add_argument('--optimizer', default='config', choices=['config', 'adam', 'lazy_adam'])
   ap.add_argument('--no_graph', action='store_true', help='eager launches instead of hipGraph replay')
   ap.add_argument('--no_cpu_baseline', action='store_true')
+  ap.add_argument('--dense_sweep', action='store_true', help='TF-exact Adam by streaming every row every step (default: lazy dense decay, bit-identical)')
   ap.add_argument('--force_ep', action='store_true', help='run the embedding-parallel code path even at 1 GPU')
   ap.add_argument('--overlap', action='store_true', help='TF-exact Adam: dense-decay sweep on a second stream (measured slower)')
   ap.add_argument('--cpu_seconds', type=float, default=12.0, help='time budget of the CPU baseline sample')
@@ -96,20 +97,21 @@ def embedding_bytes_per_step(est, batches):
     n_steps += 1
   lazy /= max(n_steps, 1)
   sweep = 0.0
-  if est.opt_emb.kind == kernels.OPT_ADAM:
+  if est.opt_emb.kind == kernels.OPT_ADAM and est.dense_sweep:
     sweep = sum(st['total_rows'] * dim * 4 * 6 for dim, st in est.engine.storage.items())
   return lazy, sweep
 
 
-def time_dominant_kernel(est, launches):
-  """Average duration of the dominant kernel (the D=16 dense-decay sweep), HIP events on the launch
-  stream (torch's current stream is the stream the C ABI launches on)."""
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X fp32 MFMA (= fp32 vector) peak, MI355X_MICROARCH.md
+
+
+def time_sweep_kernel(est, launches):
+  """--dense_sweep: average duration of the D=16 dense-decay sweep, HIP events on the launch stream (torch's
+  current stream is the stream the C ABI launches on)."""
   from easyrec_amd import kernels
   be = kernels.hip()
   dim = max(est.engine.storage, key=lambda d: est.engine.storage[d]['total_rows'] * d)
   st = est.engine.storage[dim]
-  if est.opt_emb.kind != kernels.OPT_ADAM:
-    return None
   evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(launches)]
   for _ in range(3):
     be.adam_decay_sweep(st['var'], st['m'], st['v'], st['bitmap'], st['total_rows'], dim, est.hyper[0])
@@ -121,8 +123,38 @@ def time_dominant_kernel(est, launches):
   torch.cuda.synchronize()
   ms = [a.elapsed_time(b) for a, b in evs]
   alg_bytes = st['total_rows'] * dim * 4 * 6
-  return {'kernel': 'adam_decay_sweep_vec4_kernel<4> (dim %d)' % dim, 'avg_ms': float(np.mean(ms)),
+  return {'kernel': 'er::adam_decay_sweep_vec4_kernel<4> (dim %d)' % dim, 'avg_ms': float(np.mean(ms)),
           'min_ms': float(np.min(ms)), 'bytes': alg_bytes, 'launches': launches}
+
+
+def time_gemm_kernel(est, launches):
+  """Default (lazy dense decay / lazy Adam): the largest share of the step is the forward GEMM kernel
+  er::gemm_f32_kernel<NN>; its biggest launch - the first deep layer, [B, 624] x [624, 256] with the bias and the
+  BatchNorm column statistics in the epilogue, exactly as the step issues it - is timed live with HIP events."""
+  from easyrec_amd import kernels
+  be = kernels.hip()
+  x = est.engine.groups['group:deep']['out']
+  vs = est.varstore
+  w = vs._vars['deep_feature/dnn_0/kernel']['tensor'].detach()
+  b = vs._vars['deep_feature/dnn_0/bias']['tensor'].detach()
+  M, K = x.shape
+  N = w.shape[1]
+  bf16 = est.ctx.dense_dtype == 'bf16'
+  stats = torch.empty(be.gemm_row_tiles(M) * N * 3, dtype=torch.float32, device=x.device)
+  out = torch.empty(M, N, dtype=torch.float32, device=x.device)
+  evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(launches)]
+  for _ in range(5):
+    be.gemm(kernels.GEMM_NN, x, w, out=out, bias=b, bf16=bf16, col_stats=stats)
+  torch.cuda.synchronize()
+  for a, e in evs:
+    a.record()
+    be.gemm(kernels.GEMM_NN, x, w, out=out, bias=b, bf16=bf16, col_stats=stats)
+    e.record()
+  torch.cuda.synchronize()
+  ms = [a.elapsed_time(e) for a, e in evs]
+  return {'kernel': 'er::gemm_%s_kernel<NN> %dx%dx%d (+bias, BatchNorm column statistics)' %
+                    ('bf16' if bf16 else 'f32', M, N, K), 'avg_ms': float(np.mean(ms)), 'min_ms': float(np.min(ms)),
+          'flops': 2.0 * M * N * K, 'launches': launches}
 
 
 def cpu_baseline(cfg, est_state, batches, batch_size, budget_s=12.0, max_steps=8):
@@ -166,9 +198,11 @@ def main():
   B = args.batch_size or cfg.data_config.batch_size
   if world > 1 or args.force_ep:
     from easyrec_amd.model.embedding_parallel import EmbeddingParallelEstimator
-    est = EmbeddingParallelEstimator(cfg, device=dev, batch_size=B, seed=1, rank=rank, world=world).build()
+    est = EmbeddingParallelEstimator(cfg, device=dev, batch_size=B, seed=1, rank=rank, world=world,
+                                     dense_sweep=args.dense_sweep).build()
   else:
-    est = EasyRecEstimator(cfg, device=dev, batch_size=B, seed=1, overlap_sweep=args.overlap).build()
+    est = EasyRecEstimator(cfg, device=dev, batch_size=B, seed=1, overlap_sweep=args.overlap,
+                           dense_sweep=args.dense_sweep).build()
   gen = SyntheticCriteo(cfg.data_config, est.feature_configs, batch_size=B, seed=20240607 + rank, mode=args.ids)
   host_batches = [gen.next_batch() for _ in range(args.ring)]
   ring = [to_device_batch(b, dev) for b in host_batches]
@@ -230,7 +264,9 @@ def main():
           'workload': 'DeepFM synthetic Criteo: %s (39 features: 26 hashed x %d rows + 13 projected, D=16 deep + '
                       'D=1 wide, batch %d per GPU, optimizer %s, ids %s, %s)' %
                       (os.path.basename(args.config), cfg.feature_config.features[13].hash_bucket_size, B,
-                       est.opt_emb.name, args.ids, graph_note),
+                       est.opt_emb.name + (' (dense sweep)' if getattr(est, 'dense_sweep', False) and est.opt_emb.name == 'adam_optimizer'
+                                           else ' (lazy dense decay, bit-identical)' if est.opt_emb.name == 'adam_optimizer' else ''),
+                       args.ids, graph_note),
           'global_batch': world * B,
           'parallelism': 'single GPU' if world == 1 else 'embedding-parallel x%d (row-sharded tables, RCCL all-to-all) + dense DP' % world,
       },
@@ -244,10 +280,12 @@ def main():
         'lookup_update_bytes_per_step': lazy_bytes,
         'dense_decay_sweep_bytes_per_step': sweep_bytes,
         'whole_step_GBps': (lazy_bytes + sweep_bytes) / (ms_per_step * 1e-3) / 1e9,
-        'note': 'whole_step_GBps divides the embedding stage\'s algorithmic bytes by the WHOLE step time',
+        'note': 'whole_step_GBps divides the embedding stage\'s algorithmic bytes by the WHOLE step time; '
+                'dense_decay_sweep_bytes_per_step is 0 unless --dense_sweep (default: lazy dense decay)',
     }
-    dom = time_dominant_kernel(est, launches=max(10, min(args.steps, 50)))
-    if dom is not None:
+    n_launch = max(10, min(args.steps, 50))
+    if sweep_bytes > 0 and est.dense_sweep:
+      dom = time_sweep_kernel(est, n_launch)
       ach = dom['bytes'] / (dom['avg_ms'] * 1e-3) / 1e9
       traffic = None
       pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
@@ -261,10 +299,12 @@ def main():
                          'avg_kernel_ms': dom['avg_ms'], 'algorithmic_bytes_per_launch': dom['bytes'],
                          'launches_timed': dom['launches']}
     else:
-      # lazy optimizers: no HBM-streaming kernel dominates; report the fused lookup kernel
-      out['roofline'] = {'bound': 'hbm', 'achieved': lazy_bytes / (ms_per_step * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS,
-                         'unit': 'GB/s', 'frac': lazy_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         'traffic': None, 'kernel': 'whole step (launch/latency bound at B=4096)'}
+      dom = time_gemm_kernel(est, n_launch)
+      ach = dom['flops'] / (dom['avg_ms'] * 1e-3) / 1e12
+      peak = 2500.0 if est.ctx.dense_dtype == 'bf16' else MFMA_F32_PEAK_TFLOPS
+      out['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
+                         'traffic': None, 'kernel': dom['kernel'], 'avg_kernel_ms': dom['avg_ms'],
+                         'algorithmic_flops_per_launch': dom['flops'], 'launches_timed': dom['launches']}
     if not args.no_cpu_baseline:
       try:
         # fresh state for the CPU run = the device state now (any state is as good for timing)

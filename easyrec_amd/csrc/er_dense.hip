@@ -563,12 +563,17 @@ dense_opt_kernel(float* __restrict__ w, float* __restrict__ m, float* __restrict
 
 // per-step scalars: out[:] = table[counter % n_slots][:]; counter += 1   (one block)
 __global__ void hyper_select_kernel(const float* __restrict__ table, int64_t* __restrict__ counter, int n_slots,
-                                    int floats_per_slot, float* __restrict__ out) {
+                                    int floats_per_slot, float* __restrict__ out, float* __restrict__ hist,
+                                    int64_t hist_capacity, int hist_index) {
   const int64_t c = *counter;
   const int64_t slot = c % n_slots;
   for (int i = threadIdx.x; i < floats_per_slot; i += blockDim.x) out[i] = table[slot * floats_per_slot + i];
   __syncthreads();
-  if (threadIdx.x == 0) *counter = c + 1;
+  if (threadIdx.x == 0) {
+    // per-step history of one scalar (Adam's lr_t): the lazy dense-decay catch-up replays past steps from it
+    if (hist && c < hist_capacity) hist[c] = table[slot * floats_per_slot + hist_index];
+    *counter = c + 1;
+  }
 }
 
 inline int blocks_for(int64_t n) { return static_cast<int>(ceil_div(n, kBlock)); }
@@ -768,10 +773,12 @@ int er_l2_loss(const float* w, const float* coef, int64_t n, float* out, int acc
 }
 
 int er_hyper_select(const float* table, int64_t* counter, int32_t n_slots, int32_t floats_per_slot, float* out,
-                    er_stream_t stream) {
+                    float* history, int64_t history_capacity, int32_t history_index, er_stream_t stream) {
   ER_REQUIRE(table && counter && out && n_slots > 0 && floats_per_slot > 0, "er_hyper_select: bad arguments");
+  ER_REQUIRE(!history || (history_index >= 0 && history_index < floats_per_slot && history_capacity > 0),
+             "er_hyper_select: bad history arguments");
   hipLaunchKernelGGL(er::hyper_select_kernel, dim3(1), dim3(64), 0, er::as_stream(stream), table, counter, n_slots,
-                     floats_per_slot, out);
+                     floats_per_slot, out, history, history_capacity, history_index);
   ER_LAUNCH_CHECK();
   return 0;
 }

@@ -259,6 +259,10 @@ struct RowUpdate {
   float* m;
   float* v;
   uint32_t* bitmap;
+  // lazy dense decay (ER_OPT_ADAM without the sweep): last step whose update each row has received, and the
+  // device step counter (== index of the current step + 1 once er_hyper_select has run)
+  int32_t* last_step;
+  const int64_t* step_counter;
 };
 
 __device__ __forceinline__ float adam_elem(float& m, float& v, float var, float g, const er_opt_hyper& h) {
@@ -317,6 +321,118 @@ __device__ __forceinline__ void update_row(const RowUpdate& t, int opt_kind, con
 }
 
 // ------------------------------------------------------------------------------------------------
+// TF-exact Adam WITHOUT the dense sweep ("lazy dense decay").  tf.train.AdamOptimizer._apply_sparse decays m, v
+// and moves var of EVERY row at EVERY step; a row that no lookup reads between two of its touches cannot
+// influence anything in between, so its decay-only steps can be replayed the next time it is touched - the same
+// fp32 operations in the same order (m*=b1; v*=b2; var -= lr_t(s)*m/(sqrt(v)+eps) for each missed step s, with
+// lr_t(s) read from the per-step history written by er_hyper_select), i.e. bit-identical to the sweep.  After
+// about 900 idle steps m has settled on a denormal fixed point of fl(m*b1) (|m| <= 5.6e-45) whose update var
+// absorbs: var and m no longer change, and the remaining decay of v is applied in closed form v *= b2^k (the
+// only deviation from step-by-step rounding: <= 1e-6 relative on v, on rows idle that long).
+// The rows of a step are caught up BEFORE the step's lookup reads them; er_emb_flush_decay brings every row
+// current (checkpoint / state_dict / evaluation).  HBM traffic per step drops from 24 B x every table element
+// to the touched rows.
+// ------------------------------------------------------------------------------------------------
+template <int V>
+__device__ __forceinline__ void replay_decay(float* var, float* m, float* v, const float* __restrict__ lr_hist,
+                                             int32_t s_begin, int32_t s_end, const er_opt_hyper& h) {
+  // steps s_begin .. s_end - 1 were decay-only for this row
+  for (int32_t s = s_begin; s < s_end; ++s) {
+    // m never reaches 0 in fp32: below 5 denormal units fl(m * 0.9) == m (3.6 -> 4, 2.7 -> 3, 1.8 -> 2, 0.9 -> 1), it
+    // sticks at |m| <= 5.6e-45 after ~900 idle steps.  From then on m is constant and the var update
+    // lr_t * m / (sqrt(v) + eps) <= |m| / eps (lr_t <= 1) is absorbed by var: nothing but v changes any more.
+    bool settled = true;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      const float bound = fabsf(m[i]) / h.eps;
+      settled = settled && (m[i] * h.beta1 == m[i]) && (var[i] - bound == var[i]) && (var[i] + bound == var[i]);
+    }
+    if (settled) {
+      const double f = pow(static_cast<double>(h.beta2), static_cast<double>(s_end - s));
+#pragma unroll
+      for (int i = 0; i < V; ++i) v[i] = static_cast<float>(static_cast<double>(v[i]) * f);
+      return;
+    }
+    const float lr_t = lr_hist[s];
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      const float mt = m[i] * h.beta1;
+      const float vt = v[i] * h.beta2;
+      m[i] = mt;
+      v[i] = vt;
+      var[i] = var[i] - (lr_t * mt) / (sqrtf(vt) + h.eps);
+    }
+  }
+}
+
+// one lane group per unique row touched by the coming step (keys from er_emb_route); brings the row to
+// "after step t-1" where t = *step_counter - 1 is the step being executed
+template <int V>
+__global__ void __launch_bounds__(kBlock)
+emb_catch_up_kernel(const uint32_t* __restrict__ ukeys, const int32_t* __restrict__ n_unique, int64_t capacity,
+                    RowUpdate tab, const float* __restrict__ lr_hist, const er_opt_hyper* __restrict__ hyper, int dim,
+                    int G) {
+  const int64_t i = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) / G;
+  const int c = (static_cast<int>(threadIdx.x) % G) * V;
+  if (i >= capacity || i >= *n_unique || c >= dim) return;
+  const uint32_t key = ukeys[i];
+  const int32_t t = static_cast<int32_t>(*tab.step_counter - 1);
+  const int32_t last = tab.last_step[key];
+  if (last + 1 >= t) return;  // nothing pending (touched at step t-1, or never decaying yet: see below)
+  const int64_t off = static_cast<int64_t>(key) * dim + c;
+  float var[V], m[V], v[V];
+  ld_vec<V>(var, tab.var + off);
+  ld_vec<V>(m, tab.m + off);
+  ld_vec<V>(v, tab.v + off);
+  bool live = false;
+#pragma unroll
+  for (int j = 0; j < V; ++j) live = live || (m[j] != 0.f) || (v[j] != 0.f);
+  if (!live) return;  // never touched: m = v = 0 is a fixed point of the decay
+  replay_decay<V>(var, m, v, lr_hist, last + 1, t, *hyper);
+  st_vec<V>(tab.var + off, var);
+  st_vec<V>(tab.m + off, m);
+  st_vec<V>(tab.v + off, v);
+  // last_step[key] is set to t by this step's row update (every caught-up row is touched by the step)
+}
+
+// every row: replay the pending decay steps up to and including step (*step_counter - 1); last_step = that
+template <int V>
+__global__ void __launch_bounds__(kBlock)
+emb_flush_decay_kernel(RowUpdate tab, int64_t total_rows, const float* __restrict__ lr_hist,
+                       const er_opt_hyper* __restrict__ hyper, int dim, int G) {
+  const int64_t row = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) / G;
+  const int sub = static_cast<int>(threadIdx.x) % G;
+  const int c = sub * V;
+  if (row >= total_rows || c >= dim) return;
+  const int32_t done = static_cast<int32_t>(*tab.step_counter);  // steps 0 .. done-1 have been executed
+  const int32_t last = tab.last_step[row];
+  if (last + 1 < done) {
+    const int64_t off = row * dim + c;
+    float var[V], m[V], v[V];
+    ld_vec<V>(var, tab.var + off);
+    ld_vec<V>(m, tab.m + off);
+    ld_vec<V>(v, tab.v + off);
+    bool live = false;
+#pragma unroll
+    for (int j = 0; j < V; ++j) live = live || (m[j] != 0.f) || (v[j] != 0.f);
+    if (live) {
+      replay_decay<V>(var, m, v, lr_hist, last + 1, done, *hyper);
+      st_vec<V>(tab.var + off, var);
+      st_vec<V>(tab.m + off, m);
+      st_vec<V>(tab.v + off, v);
+    }
+  }
+}
+
+// second pass of the flush (all lanes of a row must have read last_step before it changes)
+__global__ void __launch_bounds__(kBlock)
+emb_flush_mark_kernel(int32_t* __restrict__ last_step, int64_t total_rows, const int64_t* __restrict__ step_counter) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  const int32_t v = static_cast<int32_t>(*step_counter) - 1;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < total_rows; i += stride) last_step[i] = v;
+}
+
+// ------------------------------------------------------------------------------------------------
 // De-duplicated gradient = segmented sum over the SORTED entries, then the row-wise optimizer.
 //
 // Tile kernel: a workgroup owns T = 4 * (256 / G) consecutive sorted entries (G lanes x 16 B per row).
@@ -349,7 +465,10 @@ __device__ __forceinline__ void finish_run(const RowUpdate& tab, int opt_kind, c
 #pragma unroll
     for (int i = 0; i < V; ++i) g[i] = g[i] * h.grad_scale;
     update_row<V>(tab, opt_kind, h, static_cast<int64_t>(key) * dim + c, g);
-    if (opt_kind == ER_OPT_ADAM && sub == 0) atomicOr(&tab.bitmap[key >> 5], 1u << (key & 31));
+    if (opt_kind == ER_OPT_ADAM && sub == 0) {
+      if (tab.last_step) tab.last_step[key] = static_cast<int32_t>(*tab.step_counter - 1);
+      else atomicOr(&tab.bitmap[key >> 5], 1u << (key & 31));
+    }
   } else {
     const uint32_t u = ro.head_index[p] + ro.flags[p] - 1u;
     if (sub == 0) ro.out_keys[u] = key;
@@ -499,11 +618,11 @@ emb_route_kernel(const uint32_t* __restrict__ skeys, const uint32_t* __restrict_
   const uint32_t key = skeys[p];
   const uint32_t j = svals[p];
   if (key == kInvalidKey) {
-    uidx[j] = -1;
+    if (uidx) uidx[j] = -1;
     return;
   }
   const uint32_t u = head_index[p] + flags[p] - 1u;
-  uidx[j] = static_cast<int64_t>(u);
+  if (uidx) uidx[j] = static_cast<int64_t>(u);
   if (flags[p]) unique_keys[u] = key;
 }
 
@@ -740,6 +859,10 @@ struct er_emb_group {
   bool has_ragged = false;
   // embedding-parallel routing (world == 1: plain single-GPU keys) and the active prefix of a
   // single dense-mode lookup (owner-side groups whose entry count changes per step)
+  // lazy dense decay (er_emb_group_enable_lazy_decay)
+  int32_t* last_step = nullptr;
+  const float* lr_hist = nullptr;
+  const int64_t* step_counter = nullptr;
   int32_t world = 1;
   int64_t shard_stride = 0;
   int64_t* d_local_base = nullptr;
@@ -960,7 +1083,7 @@ static int emb_group_run(er_emb_group* g, int opt_kind, const er_opt_hyper* hype
   if (N == 0) return 0;
   const int T = g->tile_entries;
   const int n_tiles = static_cast<int>(er::ceil_div(N, T));
-  er::RowUpdate tab{g->var, g->m, g->v, g->bitmap};
+  er::RowUpdate tab{g->var, g->m, g->v, g->bitmap, g->last_step, g->step_counter};
   er::ReduceOut ro{mode, g->head_flags, g->head_index, out_keys, out_grads};
   const size_t lds = sizeof(float) * static_cast<size_t>(T) * g->dim + sizeof(uint32_t) * (T + 2);
   const int fix_blocks = static_cast<int>(er::ceil_div(static_cast<int64_t>(n_tiles) * g->G, er::kBlock));
@@ -1035,14 +1158,69 @@ int er_emb_bwd_update(er_emb_group* g, int opt_kind, const er_opt_hyper* hyper, 
   if (opt_kind == ER_OPT_ADAM || opt_kind == ER_OPT_LAZY_ADAM)
     ER_REQUIRE(g->m && g->v, "er_emb_bwd_update: Adam needs m and v");
   if (opt_kind == ER_OPT_ADAGRAD) ER_REQUIRE(g->v, "er_emb_bwd_update: Adagrad needs the accumulator in v");
-  if (opt_kind == ER_OPT_ADAM) ER_REQUIRE(g->bitmap, "er_emb_bwd_update: ER_OPT_ADAM needs touched_bitmap");
+  const bool lazy_decay = (opt_kind == ER_OPT_ADAM) && g->last_step;
+  if (opt_kind == ER_OPT_ADAM && !lazy_decay)
+    ER_REQUIRE(g->bitmap, "er_emb_bwd_update: ER_OPT_ADAM needs touched_bitmap (or er_emb_group_enable_lazy_decay)");
   hipStream_t s = er::as_stream(stream);
-  if (int rc = emb_group_sort(g, s)) return rc;
+  // a sort left by this step's er_emb_route (lazy dense decay, embedding-parallel requester) is reused
+  if (!g->sorted_valid)
+    if (int rc = emb_group_sort(g, s)) return rc;
+  g->sorted_valid = false;
   if (int rc = emb_group_run(g, opt_kind, hyper, 0, nullptr, nullptr, s)) return rc;
-  if (opt_kind == ER_OPT_ADAM) {
+  if (opt_kind == ER_OPT_ADAM && !lazy_decay) {
     if (int rc = er_adam_decay_sweep(g->var, g->m, g->v, g->bitmap, g->total_rows, g->dim, hyper, stream)) return rc;
     if (int rc = fill_u32(g->bitmap, 0u, er::ceil_div(g->total_rows, 32), s)) return rc;
   }
+  return 0;
+}
+
+int er_emb_group_enable_lazy_decay(er_emb_group* g, int32_t* last_step, const float* lr_t_history,
+                                   const int64_t* step_counter) {
+  ER_REQUIRE(g && last_step && lr_t_history && step_counter, "er_emb_group_enable_lazy_decay: null argument");
+  ER_REQUIRE(g->m && g->v, "er_emb_group_enable_lazy_decay: the group has no Adam slots");
+  g->last_step = last_step;
+  g->lr_hist = lr_t_history;
+  g->step_counter = step_counter;
+  return 0;
+}
+
+int er_emb_catch_up(er_emb_group* g, const uint32_t* unique_keys, const int32_t* n_unique, const er_opt_hyper* hyper,
+                    er_stream_t stream) {
+  ER_REQUIRE(g && unique_keys && n_unique && hyper, "er_emb_catch_up: null argument");
+  ER_REQUIRE(g->last_step, "er_emb_catch_up: call er_emb_group_enable_lazy_decay first");
+  const int64_t cap = group_entries(g);
+  if (cap == 0) return 0;
+  er::RowUpdate tab{g->var, g->m, g->v, g->bitmap, g->last_step, g->step_counter};
+  const int blocks = static_cast<int>(er::ceil_div(cap * g->G, er::kBlock));
+  if (g->V == 4) {
+    hipLaunchKernelGGL(er::emb_catch_up_kernel<4>, dim3(blocks), dim3(er::kBlock), 0, er::as_stream(stream), unique_keys,
+                       n_unique, cap, tab, g->lr_hist, hyper, g->dim, g->G);
+  } else {
+    hipLaunchKernelGGL(er::emb_catch_up_kernel<1>, dim3(blocks), dim3(er::kBlock), 0, er::as_stream(stream), unique_keys,
+                       n_unique, cap, tab, g->lr_hist, hyper, g->dim, g->G);
+  }
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
+int er_emb_flush_decay(er_emb_group* g, const er_opt_hyper* hyper, er_stream_t stream) {
+  ER_REQUIRE(g && hyper, "er_emb_flush_decay: null argument");
+  ER_REQUIRE(g->last_step, "er_emb_flush_decay: call er_emb_group_enable_lazy_decay first");
+  hipStream_t s = er::as_stream(stream);
+  er::RowUpdate tab{g->var, g->m, g->v, g->bitmap, g->last_step, g->step_counter};
+  const int64_t blocks = er::ceil_div(g->total_rows * g->G, er::kBlock);
+  ER_REQUIRE(blocks < 0x7FFFFFFFLL, "er_emb_flush_decay: table group too large for one launch");
+  if (g->V == 4) {
+    hipLaunchKernelGGL(er::emb_flush_decay_kernel<4>, dim3(static_cast<unsigned>(blocks)), dim3(er::kBlock), 0, s, tab,
+                       g->total_rows, g->lr_hist, hyper, g->dim, g->G);
+  } else {
+    hipLaunchKernelGGL(er::emb_flush_decay_kernel<1>, dim3(static_cast<unsigned>(blocks)), dim3(er::kBlock), 0, s, tab,
+                       g->total_rows, g->lr_hist, hyper, g->dim, g->G);
+  }
+  ER_LAUNCH_CHECK();
+  hipLaunchKernelGGL(er::emb_flush_mark_kernel, dim3(1024), dim3(er::kBlock), 0, s, g->last_step, g->total_rows,
+                     g->step_counter);
+  ER_LAUNCH_CHECK();
   return 0;
 }
 
@@ -1114,7 +1292,7 @@ int er_emb_group_set_active(er_emb_group* g, int64_t n_rows) {
 
 int er_emb_route(er_emb_group* g, uint32_t* unique_keys, int32_t* n_unique, int64_t* entry_unique_index,
                  int32_t* owner_counts, er_stream_t stream) {
-  ER_REQUIRE(g && unique_keys && n_unique && entry_unique_index && owner_counts, "er_emb_route: null argument");
+  ER_REQUIRE(g && unique_keys && n_unique, "er_emb_route: null argument");
   ER_REQUIRE(g->world <= 64, "er_emb_route: world %d > 64", g->world);
   hipStream_t s = er::as_stream(stream);
   const int64_t N = group_entries(g);
@@ -1124,10 +1302,12 @@ int er_emb_route(er_emb_group* g, uint32_t* unique_keys, int32_t* n_unique, int6
   hipLaunchKernelGGL(er::emb_route_kernel, dim3(static_cast<int>(er::ceil_div(N, er::kBlock))), dim3(er::kBlock), 0, s,
                      g->keys_out, g->vals_out, g->head_flags, g->head_index, N, unique_keys, entry_unique_index);
   ER_LAUNCH_CHECK();
-  const int64_t stride = g->d_local_base ? g->shard_stride : g->total_rows;
-  hipLaunchKernelGGL(er::emb_owner_counts_kernel, dim3(1), dim3(64), 0, s, unique_keys, n_unique, g->world, stride,
-                     owner_counts);
-  ER_LAUNCH_CHECK();
+  if (owner_counts) {
+    const int64_t stride = g->d_local_base ? g->shard_stride : g->total_rows;
+    hipLaunchKernelGGL(er::emb_owner_counts_kernel, dim3(1), dim3(64), 0, s, unique_keys, n_unique, g->world, stride,
+                       owner_counts);
+    ER_LAUNCH_CHECK();
+  }
   g->sorted_valid = true;
   return 0;
 }

@@ -84,6 +84,21 @@ __device__ __forceinline__ short f32_to_bf16_rne(float f) {
   return static_cast<short>(u >> 16);
 }
 
+// XCD-aware tile order.  Workgroup b is dispatched to XCD b % 8 and every XCD has its own L2
+// (MI355X_MICROARCH.md); the column tiles of one row of tiles all read the same 64 rows of A.  Tiles are
+// therefore numbered so that consecutive tiles (same tile row, x fastest) go to the SAME XCD: XCD c owns tiles
+// [c * per, (c + 1) * per), and A's rows are fetched into one L2 instead of up to N/64 of them.
+__device__ __forceinline__ bool tile_coords(int gx, int gy, int& tx, int& ty) {
+  const int nt = gx * gy;
+  const int per = (nt + 7) / 8;
+  const int b = blockIdx.x;
+  const int t = (b % 8) * per + b / 8;
+  if (t >= nt) return false;
+  tx = t % gx;
+  ty = t / gx;
+  return true;
+}
+
 // Per-row-tile column statistics of the OUTPUT (value = acc + bias), for a following BatchNorm: removes the
 // separate statistics pass over the GEMM output.  A lane holds 16 rows of one column; lanes l and l^32 hold the
 // other 16 rows; the two waves with wm = 0 / 1 cover the tile's 64 rows.  Welford/Chan merges in a fixed order.
@@ -142,7 +157,9 @@ gemm_f32_kernel(GemmArgs g) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  int tx, ty;
+  if (!tile_coords(static_cast<int>(ceil_div(g.N, BN)), static_cast<int>(ceil_div(g.M, BM)), tx, ty)) return;
+  const int m0 = ty * BM, n0 = tx * BN;
   const int kbeg = blockIdx.z * g.k_per_split;
   int kend = kbeg + g.k_per_split;
   if (kend > g.K) kend = g.K;
@@ -207,7 +224,7 @@ gemm_f32_kernel(GemmArgs g) {
   const float bv = (g.bias && g.splits == 1 && col < g.N) ? g.bias[col] : 0.f;
   if (g.col_stats)  // (host guarantees splits == 1) every thread takes part: it synchronises the workgroup
     tile_col_stats(acc, bv, m0 + wm * 32, g.M, col, g.N, wm, wn, lane, As,
-                   g.col_stats + static_cast<int64_t>(blockIdx.y) * g.N * 3);
+                   g.col_stats + static_cast<int64_t>(ty) * g.N * 3);
   if (col >= g.N) return;
   float* Cz = g.C + (g.splits > 1 ? static_cast<int64_t>(blockIdx.z) * g.M * g.N : 0);
   const int ldc = g.splits > 1 ? g.N : g.ldc;
@@ -237,7 +254,9 @@ gemm_bf16_kernel(GemmArgs g) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  int tx, ty;
+  if (!tile_coords(static_cast<int>(ceil_div(g.N, BN)), static_cast<int>(ceil_div(g.M, BM)), tx, ty)) return;
+  const int m0 = ty * BM, n0 = tx * BN;
   const int kbeg = blockIdx.z * g.k_per_split;
   int kend = kbeg + g.k_per_split;
   if (kend > g.K) kend = g.K;
@@ -292,7 +311,7 @@ gemm_bf16_kernel(GemmArgs g) {
   const int khalf = lane >> 5;
   if (g.col_stats)
     tile_col_stats(acc, bv, m0 + wm * 32, g.M, col, g.N, wm, wn, lane, reinterpret_cast<float*>(As),
-                   g.col_stats + static_cast<int64_t>(blockIdx.y) * g.N * 3);
+                   g.col_stats + static_cast<int64_t>(ty) * g.N * 3);
   if (col >= g.N) return;
   float* Cz = g.C + (g.splits > 1 ? static_cast<int64_t>(blockIdx.z) * g.M * g.N : 0);
   const int ldc = g.splits > 1 ? g.N : g.ldc;
@@ -362,8 +381,8 @@ int ensure_ws(size_t floats, float** out) {
 
 template <bool BF16>
 int launch_gemm(int layout, er::GemmArgs& a, hipStream_t s) {
-  dim3 grid(static_cast<unsigned>(er::ceil_div(a.N, er::BN)), static_cast<unsigned>(er::ceil_div(a.M, er::BM)),
-            static_cast<unsigned>(a.splits));
+  const int64_t n_tiles = er::ceil_div(a.N, er::BN) * er::ceil_div(a.M, er::BM);
+  dim3 grid(static_cast<unsigned>(8 * er::ceil_div(n_tiles, 8)), 1, static_cast<unsigned>(a.splits));  // tile_coords()
   dim3 block(er::kBlock);
 #define ER_LAUNCH_GEMM(KERNEL)                                                   \
   switch (layout) {                                                              \

@@ -287,8 +287,9 @@ class HipBackend(object):
     group['n_active'] = int(n_rows)
 
   def emb_route(self, group, unique_keys, n_unique, entry_unique_index, owner_counts):
-    assert unique_keys.dtype == torch.int32 and entry_unique_index.dtype == torch.int64
-    assert n_unique.dtype == torch.int32 and owner_counts.dtype == torch.int32
+    assert unique_keys.dtype == torch.int32 and n_unique.dtype == torch.int32
+    assert entry_unique_index is None or entry_unique_index.dtype == torch.int64
+    assert owner_counts is None or owner_counts.dtype == torch.int32
     self._ck(self.lib.er_emb_route(group['handle'], _p(unique_keys), _p(n_unique), _p(entry_unique_index),
                                    _p(owner_counts), _stream()), 'er_emb_route')
 
@@ -548,10 +549,26 @@ class HipBackend(object):
                                  _stream()), 'er_mmoe_mix_bwd')
     return dexperts, dlogits
 
-  def hyper_select(self, table, counter, out):
+  def hyper_select(self, table, counter, out, history=None, history_index=HYPER_LR_T):
     n_slots = table.shape[0]
-    self._ck(self.lib.er_hyper_select(_p(table), _p(counter), n_slots, table[0].numel(), _p(out), _stream()),
+    cap = 0 if history is None else history.numel()
+    self._ck(self.lib.er_hyper_select(_p(table), _p(counter), n_slots, table[0].numel(), _p(out), _p(history),
+                                      ctypes.c_int64(cap), ctypes.c_int32(history_index), _stream()),
              'er_hyper_select')
+
+  # -- TF-exact Adam without the sweep (lazy dense decay)
+  def emb_group_enable_lazy_decay(self, group, last_step, lr_hist, step_counter):
+    assert last_step.dtype == torch.int32 and lr_hist.dtype == torch.float32 and step_counter.dtype == torch.int64
+    self._ck(self.lib.er_emb_group_enable_lazy_decay(group['handle'], _p(last_step), _p(lr_hist), _p(step_counter)),
+             'er_emb_group_enable_lazy_decay')
+    group['last_step'], group['lr_hist'], group['step_counter'] = last_step, lr_hist, step_counter
+
+  def emb_catch_up(self, group, unique_keys, n_unique, hyper):
+    self._ck(self.lib.er_emb_catch_up(group['handle'], _p(unique_keys), _p(n_unique), _p(hyper), _stream()),
+             'er_emb_catch_up')
+
+  def emb_flush_decay(self, group, hyper):
+    self._ck(self.lib.er_emb_flush_decay(group['handle'], _p(hyper), _stream()), 'er_emb_flush_decay')
 
   # -- dense optimizer
   def dense_opt_step(self, w, m, v, grad, l2coef, opt_kind, hyper):

@@ -81,6 +81,10 @@ class EmbeddingEngine(object):
     self._ran_version = -1
     self._sweep_stream = None
     self._sweep_pending = False
+    # TF-exact Adam without the dense sweep (er_emb_catch_up): set by the estimator through set_step_clock()
+    self.lazy_decay = False
+    self._clock = None  # (step_counter int64[1], lr_t history fp32[capacity], hyper record of the embeddings)
+    self._lazy = OrderedDict()  # dim -> route buffers + last_step
 
   # -- declaration (build pass)
   def declare_table(self, var_name, rows, dim, initializer=None):
@@ -125,7 +129,33 @@ class EmbeddingEngine(object):
   def add_lookup(self, gkey, table_name, ids, offsets, weights, col, combiner, n_rows, max_nnz, name):
     self.groups[gkey]['pending'].append((table_name, ids, offsets, weights, col, combiner, n_rows, max_nnz, name))
 
-  def _alloc_storage(self, total, dim, opt_kind):
+  def set_step_clock(self, step_counter, lr_hist, hyper_emb, lazy_decay=True):
+    """Device step counter + per-step lr_t history + the embeddings' hyper record: what the lazy dense-decay
+    catch-up of TF-exact Adam reads.  Call before finalize()."""
+    self._clock = (step_counter, lr_hist, hyper_emb)
+    self.lazy_decay = bool(lazy_decay)
+
+  def _enable_lazy_decay(self, dim, grp, st, n_route):
+    """Per table group: the last-updated-step array and the buffers of er_emb_route (unique rows of a step)."""
+    be = kernels.hip()
+    dev = self.device
+    lz = {
+        'last_step': torch.full((st['total_rows'],), -1, dtype=torch.int32, device=dev),
+        'ukeys': torch.zeros(max(n_route, 1), dtype=torch.int32, device=dev),
+        'n_unique': torch.zeros(1, dtype=torch.int32, device=dev),
+    }
+    be.emb_group_enable_lazy_decay(grp, lz['last_step'], self._clock[1], self._clock[0])
+    return lz
+
+  def flush_decay(self):
+    """Bring every row current (lazy dense decay): before reading tables out (state_dict, evaluation)."""
+    if not self.lazy_decay:
+      return
+    be = kernels.hip()
+    for dim, grp in self.emb_groups.items():
+      be.emb_flush_decay(grp, self._clock[2])
+
+  def _alloc_storage(self, total, dim, opt_kind, force_bitmap=False):
     var = torch.empty(total, dim, dtype=torch.float32, device=self.device)
     st = {'var': var, 'm': None, 'v': None, 'bitmap': None, 'total_rows': total}
     if opt_kind in (kernels.OPT_ADAM, kernels.OPT_LAZY_ADAM):
@@ -133,7 +163,7 @@ class EmbeddingEngine(object):
       st['v'] = torch.zeros_like(var)
     elif opt_kind == kernels.OPT_ADAGRAD:
       st['v'] = torch.zeros_like(var)
-    if opt_kind == kernels.OPT_ADAM:
+    if opt_kind == kernels.OPT_ADAM and (force_bitmap or not self.lazy_decay):
       st['bitmap'] = torch.zeros((total + 31) // 32, dtype=torch.int32, device=self.device)
     return st
 
@@ -202,6 +232,9 @@ class EmbeddingEngine(object):
       if specs:
         self.emb_groups[dim] = be.emb_group_create(specs, dim, st['total_rows'], st['var'], st['m'], st['v'],
                                                    st['bitmap'])
+        if self.lazy_decay and opt_kind == kernels.OPT_ADAM:
+          self._lazy[dim] = self._enable_lazy_decay(dim, self.emb_groups[dim], st, self.emb_groups[dim]['num_entries'])
+    self.lazy_decay = self.lazy_decay and opt_kind == kernels.OPT_ADAM
     self.reg_lambda = max([g['reg'] for g in self.groups.values()] + [0.0])
     self.finalized = True
 
@@ -228,6 +261,12 @@ class EmbeddingEngine(object):
     be = kernels.hip()
     for g in self.groups.values():
       g['got_grad'] = False
+    if self.lazy_decay:
+      # sort the step's ids once (reused by the backward), bring the rows it touches up to date, then look up
+      for dim, grp in self.emb_groups.items():
+        lz = self._lazy[dim]
+        be.emb_route(grp, lz['ukeys'], lz['n_unique'], None, None)
+        be.emb_catch_up(grp, lz['ukeys'], lz['n_unique'], self._clock[2])
     if self.plan is not None:
       be.emb_fwd(self.plan, self.sumsq if self.reg_lambda > 0 else None)
     self._ran_version = version
@@ -294,6 +333,7 @@ class EmbeddingEngine(object):
   # -- host exchange
   def state_dict(self, slots=False):
     out = OrderedDict()
+    self.flush_decay()
     for name in self.tables:
       out[name] = self.table_view(name).detach().cpu().numpy().copy()
       if slots:

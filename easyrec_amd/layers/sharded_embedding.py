@@ -64,7 +64,8 @@ class ShardedEmbeddingEngine(EmbeddingEngine):
     for dim, total in shard_rows.items():
       self.shard[dim] = {'st': self._alloc_storage(total, dim, opt_kind), 'stride': total}
     for dim, total in rep_rows.items():
-      self.rep[dim] = {'st': self._alloc_storage(total, dim, opt_kind)}
+      # replicated (small) tables keep the streaming sweep of TF-exact Adam: a few KB per step
+      self.rep[dim] = {'st': self._alloc_storage(total, dim, opt_kind, force_bitmap=True)}
     for name, t in self.tables.items():
       kind, dim, base, n_local = self.placement[name]
       if kind == 'rep':
@@ -119,6 +120,7 @@ class ShardedEmbeddingEngine(EmbeddingEngine):
         off += n
         self._build_rep_apply(dim, opt_kind)
     self.counts_dev = torch.zeros(max(len(self.shard), 1), W, dtype=torch.int32, device=dev)
+    self.lazy_decay = self.lazy_decay and opt_kind == kernels.OPT_ADAM
     self.finalized = True
 
   def _build_shard_half(self, dim, lookups, fwd_specs, opt_kind):
@@ -164,6 +166,12 @@ class ShardedEmbeddingEngine(EmbeddingEngine):
         rows=st['total_rows'], key_base=0, dim=dim, combiner=kernels.COMBINER_SUM, n_rows=m_cap, max_nnz=m_cap,
         name='owner_dim%d' % dim)
     sh['owner'] = be.emb_group_create([owner_spec], dim, st['total_rows'], st['var'], st['m'], st['v'], st['bitmap'])
+    sh['lazy'] = None
+    if self.lazy_decay and opt_kind == kernels.OPT_ADAM:
+      # owner side of TF-exact Adam without the sweep: the received keys are sorted / de-duplicated once
+      # (er_emb_route on the owner group), caught up before the rows are gathered, and the same sort serves
+      # the owner-side update of the backward
+      sh['lazy'] = self._enable_lazy_decay(dim, sh['owner'], st, m_cap)
 
   def _build_rep_half(self, dim, lookups, fwd_specs, opt_kind):
     be = kernels.hip()
@@ -219,11 +227,15 @@ class ShardedEmbeddingEngine(EmbeddingEngine):
       comm.all_to_all(sh['ukeys'], sc, sh['recv_keys'], rc)
       st = sh['st']
       key_sub = self.rank * sh['stride']
-      be.gather_rows(st['var'], sh['recv_keys'], m, key_sub, sh['rows_out'])
       if m:
         torch.sub(sh['recv_keys'][:m], key_sub, out=sh['recv_ids'][:m])
-      comm.all_to_all(sh['rows_out'], rc, sh['recv_rows'], sc)
       be.emb_group_set_active(sh['owner'], m)
+      lz = sh['lazy']
+      if lz is not None and m:
+        be.emb_route(sh['owner'], lz['ukeys'], lz['n_unique'], None, None)
+        be.emb_catch_up(sh['owner'], lz['ukeys'], lz['n_unique'], self._clock[2])
+      be.gather_rows(st['var'], sh['recv_keys'], m, key_sub, sh['rows_out'])
+      comm.all_to_all(sh['rows_out'], rc, sh['recv_rows'], sc)
 
   def lookup(self):
     for g in self.groups.values():
@@ -273,6 +285,14 @@ class ShardedEmbeddingEngine(EmbeddingEngine):
     self.exchange_grads_and_update(opt_kind, hyper)
     self.apply_replicated(opt_kind, hyper)
 
+  def flush_decay(self):
+    if not self.lazy_decay:
+      return
+    be = kernels.hip()
+    for sh in self.shard.values():
+      if sh['lazy'] is not None:
+        be.emb_flush_decay(sh['owner'], self._clock[2])
+
   # -- host exchange (collective: every rank must call)
   def table_view(self, name):
     kind, dim, base, n_local = self.placement[name]
@@ -297,6 +317,7 @@ class ShardedEmbeddingEngine(EmbeddingEngine):
 
   def state_dict(self, slots=False):
     out = OrderedDict()
+    self.flush_decay()
     for name in self.tables:
       out[name] = self._gather_full(name, self.table_view(name)).cpu().numpy()
       if slots:

@@ -38,7 +38,7 @@ class EasyRecEstimator(object):
   HYPER_SLOTS = 4096
 
   def __init__(self, pipeline_config, device='cuda', batch_size=None, seed=0, schema_kwargs=None,
-               is_training=True, overlap_sweep=False, dense_dtype=None):
+               is_training=True, overlap_sweep=False, dense_dtype=None, dense_sweep=None):
     import_all_models()
     self.pipeline_config = config_util.get_configs_from_pipeline_file(pipeline_config) \
         if isinstance(pipeline_config, str) else pipeline_config
@@ -91,6 +91,15 @@ class EasyRecEstimator(object):
     self.hyper_table = torch.zeros(self.HYPER_SLOTS, 2, kernels.HYPER_FLOATS, dtype=torch.float32, device=dev)
     self.step_counter = torch.zeros(1, dtype=torch.int64, device=dev)
     self._planned_until = 0
+    # TF-exact Adam (`adam_optimizer`): by default the dense decay of untouched rows is applied lazily, bit-
+    # identically (er_emb_catch_up); dense_sweep=True (or ER_DENSE_SWEEP=1) streams every row every step instead
+    if dense_sweep is None:
+      dense_sweep = os.environ.get('ER_DENSE_SWEEP', '0') == '1'
+    self.dense_sweep = bool(dense_sweep)
+    n_hist = max(2 * int(cfg.train_config.num_steps or 0), 1 << 20)
+    self.lr_hist = torch.zeros(n_hist, dtype=torch.float32, device=dev)
+    self.engine.set_step_clock(self.step_counter, self.lr_hist, self.hyper[0],
+                               lazy_decay=not self.dense_sweep and not self.overlap_sweep)
     self.losses = {
         'regularization_loss': torch.zeros(1, dtype=torch.float32, device=dev),
         'total_loss': torch.zeros(1, dtype=torch.float32, device=dev),
@@ -163,7 +172,7 @@ class EasyRecEstimator(object):
   def _device_step(self):
     """Everything that runs on the GPU for one batch (graph-capturable)."""
     be = kernels.hip()
-    be.hyper_select(self.hyper_table, self.step_counter, self.hyper)
+    be.hyper_select(self.hyper_table, self.step_counter, self.hyper, history=self.lr_hist)
     self.features.transform()
     if self.is_training and self.overlap_sweep and self.opt_emb.kind == kernels.OPT_ADAM:
       self.engine.start_decay_sweep(self.hyper[0])

@@ -26,7 +26,8 @@ from easyrec_amd.model.easy_rec_estimator import EasyRecEstimator
 class EmbeddingParallelEstimator(EasyRecEstimator):
 
   def __init__(self, pipeline_config, device='cuda', batch_size=None, seed=0, rank=0, world=1, comm=None,
-               schema_kwargs=None, is_training=True, replicate_bytes=256 * 1024, recv_slack=2.0):
+               schema_kwargs=None, is_training=True, replicate_bytes=256 * 1024, recv_slack=2.0, dense_dtype=None,
+               dense_sweep=None):
     if comm is None:
       comm = TorchDistComm() if world > 1 else LocalComm()
     assert comm.rank == rank and comm.world == world, 'comm (%d/%d) does not match rank/world (%d/%d)' % (
@@ -37,7 +38,8 @@ class EmbeddingParallelEstimator(EasyRecEstimator):
     self._graphs = None
     super(EmbeddingParallelEstimator, self).__init__(pipeline_config, device=device, batch_size=batch_size, seed=seed,
                                                      schema_kwargs=schema_kwargs, is_training=is_training,
-                                                     overlap_sweep=False)
+                                                     overlap_sweep=False, dense_dtype=dense_dtype,
+                                                     dense_sweep=dense_sweep)
     # embedding gradients are divided by the world size (compat/optimizers.py:315-316)
     self.emb_grad_scale = self.emb_grad_scale / float(world)
 
@@ -53,7 +55,7 @@ class EmbeddingParallelEstimator(EasyRecEstimator):
 
   # -- the step in phases: static device work (capturable) around the data-dependent exchanges
   def _phase_route(self):
-    kernels.hip().hyper_select(self.hyper_table, self.step_counter, self.hyper)
+    kernels.hip().hyper_select(self.hyper_table, self.step_counter, self.hyper, history=self.lr_hist)
     self.features.transform()
     self.engine.route()
 

@@ -151,7 +151,10 @@ typedef struct er_emb_group er_emb_group;
  * *counter.  Keeps a captured hipGraph free of host-written memory (no race with the host running
  * ahead of the device). */
 int er_hyper_select(const float* table, int64_t* counter, int32_t n_slots, int32_t floats_per_slot,
-                    float* out, er_stream_t stream);
+                    float* out, float* history, int64_t history_capacity, int32_t history_index,
+                    er_stream_t stream);
+/* history != NULL: also history[*counter] = slot[history_index] (before the increment): the per-step record of
+ * Adam's lr_t that er_emb_catch_up / er_emb_flush_decay replay. */
 
 int er_emb_group_create(const er_lookup_desc* descs_host, int n, int32_t dim, int64_t total_rows,
                         float* var, float* m, float* v, uint32_t* touched_bitmap,
@@ -168,6 +171,23 @@ int er_emb_bwd_update(er_emb_group* group, int opt_kind, const er_opt_hyper* hyp
  * and by embedding-parallel training (grads are sent to the row owner instead of applied). */
 int er_emb_bwd_reduce(er_emb_group* group, uint32_t* unique_keys, float* unique_grads,
                       int32_t* n_unique, er_stream_t stream);
+/* TF-exact Adam WITHOUT the dense sweep ("lazy dense decay").  _apply_sparse decays m, v and moves var of every
+ * row at every step, but a row nobody looks up between two of its touches cannot influence anything meanwhile:
+ * its decay-only steps are replayed (same fp32 operations, same order, lr_t(s) from the history written by
+ * er_hyper_select) right before the next lookup that reads it - bit-identical to the sweep; only once m has
+ * settled on its denormal fixed point (~900 idle steps; var then absorbs the update) is the remaining decay of
+ * v applied in closed form (<= 1e-6 relative).  Assumes lr_t <= 1.
+ *   er_emb_group_enable_lazy_decay: last_step [total_rows] int32 initialised to -1 (device), lr_t_history
+ *     [capacity >= number of steps] (device), step_counter (device; the counter er_hyper_select increments).
+ *     Afterwards er_emb_bwd_update(ER_OPT_ADAM) updates the touched rows only (no bitmap, no sweep).
+ *   er_emb_catch_up: call after er_emb_route (whose unique keys / count it takes) and BEFORE the lookup of
+ *     the step; brings the rows the step touches to "after the previous step".
+ *   er_emb_flush_decay: brings EVERY row current (checkpoint, state_dict, evaluation of untouched rows). */
+int er_emb_group_enable_lazy_decay(er_emb_group* group, int32_t* last_step, const float* lr_t_history,
+                                   const int64_t* step_counter);
+int er_emb_catch_up(er_emb_group* group, const uint32_t* unique_keys, const int32_t* n_unique,
+                    const er_opt_hyper* hyper, er_stream_t stream);
+int er_emb_flush_decay(er_emb_group* group, const er_opt_hyper* hyper, er_stream_t stream);
 /* TF-exact Adam with the sweep OVERLAPPED (two streams).  The rows a step touches are known as soon as
  * its ids are (before the forward): er_emb_mark_touched sets their bitmap bits; er_emb_sweep_untouched
  * then decays every other row (m*=beta1, v*=beta2, var-=lr_t*m/(sqrt(v)+eps): what
@@ -376,7 +396,8 @@ int er_gemm_bf16(int layout, int32_t M, int32_t N, int32_t K, const float* A, in
  *     ONE ascending sort groups a step's entries by owner rank and de-duplicates them.
  *   er_emb_route: build + sort; writes the unique routed keys (ascending), *n_unique, for every entry
  *     (source order; lookup l's entries start at the prefix sum of the lookups' capacities) the index
- *     of its unique key or -1, and owner_counts[world] = unique keys per owner (the a2a send splits).
+ *     of its unique key or -1, and owner_counts[world] = unique keys per owner (the a2a send splits);
+ *     entry_unique_index and owner_counts may be NULL when only the unique keys are wanted.
  *     The lookup itself then runs through er_emb_fwd with table = the rows received from the owners
  *     ([n_unique, dim]) and ids = entry_unique_index.
  *   er_emb_bwd_reduce_routed: reuses the sort of this step's er_emb_route: unique_grads[u, :] = sum of

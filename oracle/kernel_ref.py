@@ -287,6 +287,12 @@ class RefBackend(object):
     var = group['var'].detach().numpy()
     m = None if group['m'] is None else group['m'].numpy()
     v = None if group['v'] is None else group['v'].numpy()
+    if opt_kind == OPT_ADAM and 'last_step' in group:
+      apply_sparse(var, m, v, grads, OPT_LAZY_ADAM, h)  # touched rows; the others decay lazily (emb_catch_up)
+      t = int(group['step_counter'].item()) - 1
+      for key in grads:
+        group['last_step'][int(key)] = t
+      return
     apply_sparse(var, m, v, grads, opt_kind, h)
 
   def emb_bwd_reduce(self, group, out=None):
@@ -375,16 +381,18 @@ class RefBackend(object):
     ents = self._routed_entries(group)
     keys = sorted(set(e[0] for e in ents))
     pos = {k: i for i, k in enumerate(keys)}
-    entry_unique_index.fill_(-1)
-    for key, j, _, _, _ in ents:
-      entry_unique_index[j] = pos[key]
+    if entry_unique_index is not None:
+      entry_unique_index.fill_(-1)
+      for key, j, _, _, _ in ents:
+        entry_unique_index[j] = pos[key]
     for i, k in enumerate(keys):
       unique_keys[i] = k
     n_unique[0] = len(keys)
     W = group.get('world', 1)
     stride = group['shard_stride'] if 'local_base' in group else group['total_rows']
-    for w in range(W):
-      owner_counts[w] = sum(1 for k in keys if w * stride <= k < (w + 1) * stride)
+    if owner_counts is not None:
+      for w in range(W):
+        owner_counts[w] = sum(1 for k in keys if w * stride <= k < (w + 1) * stride)
     group['_route_keys'] = keys
 
   def emb_bwd_reduce_routed(self, group, unique_grads):
@@ -623,12 +631,44 @@ class RefBackend(object):
     dlogits = gates * (dg - (gates * dg).sum(dim=-1, keepdim=True))
     return dexperts, dlogits
 
-  def hyper_select(self, table, counter, out):
+  def hyper_select(self, table, counter, out, history=None, history_index=HYPER_LR_T):
     c = int(counter.item())
-    out.copy_(table[c % table.shape[0]].reshape(out.shape))
-    counter.add_(1)
+    slot = table[c % table.shape[0]]
+    out.copy_(slot)
+    if history is not None and c < history.numel():
+      history[c] = slot.reshape(-1)[history_index]
+    counter += 1
 
-  # -- dense optimizer
+  # -- TF-exact Adam without the sweep: decay-only steps replayed when a row is next touched
+  def emb_group_enable_lazy_decay(self, group, last_step, lr_hist, step_counter):
+    group['last_step'], group['lr_hist'], group['step_counter'] = last_step, lr_hist, step_counter
+
+  @staticmethod
+  def _replay(group, rows, s_end, h):
+    var, m, v = group['var'].detach().numpy(), group['m'].numpy(), group['v'].numpy()
+    last, hist = group['last_step'].numpy(), group['lr_hist'].numpy()
+    b1, b2, eps = F32(h[HYPER_BETA1]), F32(h[HYPER_BETA2]), F32(h[HYPER_EPS])
+    for r in rows:
+      for sidx in range(int(last[r]) + 1, s_end):
+        if not (m[r].any() or v[r].any()):
+          break
+        lr_t = F32(hist[sidx])
+        m[r] = m[r] * b1
+        v[r] = v[r] * b2
+        var[r] = var[r] - (lr_t * m[r]) / (np.sqrt(v[r], dtype=np.float32) + eps)
+
+  def emb_catch_up(self, group, unique_keys, n_unique, hyper):
+    h = hyper.detach().cpu().numpy().reshape(-1)
+    t = int(group['step_counter'].item()) - 1
+    n = int(n_unique.item())
+    self._replay(group, [int(k) for k in unique_keys[:n].tolist()], t, h)
+
+  def emb_flush_decay(self, group, hyper):
+    h = hyper.detach().cpu().numpy().reshape(-1)
+    done = int(group['step_counter'].item())
+    self._replay(group, range(group['total_rows']), done, h)
+    group['last_step'].fill_(done - 1)
+
   def dense_opt_step(self, w, m, v, grad, l2coef, opt_kind, hyper):
     h = hyper.detach().cpu().numpy().reshape(-1)
     dense_opt(w.detach().numpy(), None if m is None else m.numpy(), None if v is None else v.numpy(),

@@ -150,7 +150,8 @@ def test_eager_runs_are_deterministic_and_graph_replay_agrees(lazy):
     assert np.array_equal(sa[k], sc[k]), ('eager vs graph', k)
 
 
-def test_full_size_properties():
+@pytest.mark.parametrize('dense_sweep', [True, False])
+def test_full_size_properties(dense_sweep):
   """BASELINE.json config 2 at full size: B=4096, 26 x (1M x 16) + 26 x (1M x 1) tables, TF-exact Adam.
   Size-independent checks: (a) the fused lookup equals a plain torch gather of the hashed ids;
   (b) ids on device == FarmHash oracle for a sample; (c) after one dense-decay Adam step with zero
@@ -158,7 +159,7 @@ def test_full_size_properties():
   touched-row bitmap is clean again; (d) a second step keeps everything finite."""
   cfg = _cfg('deepfm_criteo.config')
   B = 4096
-  est = EasyRecEstimator(cfg, device=DEV, batch_size=B, seed=1).build()
+  est = EasyRecEstimator(cfg, device=DEV, batch_size=B, seed=1, dense_sweep=dense_sweep).build()
   gen = SyntheticCriteo(cfg.data_config, est.feature_configs, batch_size=B, mode='uniform')
   batch = gen.next_batch()
   var16_before = est.engine.storage[16]['var'].clone()
@@ -198,7 +199,10 @@ def test_full_size_properties():
   assert torch.equal(after[~touched], var16_before[~touched])
   moved = (after[touched] != var16_before[touched]).any(dim=1).float().mean()
   assert float(moved) > 0.99
-  assert int(est.engine.storage[16]['bitmap'].abs().sum()) == 0
+  if dense_sweep:
+    assert int(est.engine.storage[16]['bitmap'].abs().sum()) == 0
+  else:
+    assert est.engine.storage[16]['bitmap'] is None and est.engine.lazy_decay
   # (d)
   est.train_step(gen.next_batch())
   lv = est.loss_values()

@@ -590,3 +590,61 @@ def test_gemm_epilogue_statistics_feed_batchnorm(hip, M, N, K, bf16):
   assert torch.allclose(y.cpu().double(), yr, rtol=1e-4, atol=1e-5)
   assert torch.allclose(mm.cpu().double(), 0.01 * mu, rtol=1e-4, atol=1e-6)
   assert torch.allclose(mv.cpu().double(), 0.99 + 0.01 * var, rtol=1e-4, atol=1e-6)
+
+
+def test_lazy_dense_decay_equals_the_sweep(hip):
+  """TF-exact Adam two ways over 1300 steps on one table: (A) the streaming sweep of every row every step,
+  (B) lazy dense decay (er_emb_route -> er_emb_catch_up -> touched-row update, er_emb_flush_decay at the end).
+  Rows touched early and never again sit idle for > 1000 steps (m settles on its denormal fixed point: the
+  closed-form tail of v is exercised).  var and m must agree bit for bit wherever no closed-form step happened, v to 1e-5."""
+  rng = np.random.default_rng(11)
+  rows, dim, B, T = 97, 16, 6, 1300
+  table0 = torch.from_numpy((rng.standard_normal((rows, dim)) * 0.05).astype(np.float32))
+  ids_all = rng.integers(0, rows, size=(T, B)).astype(np.int64)
+  ids_all[60:, :] = ids_all[60:, :] % 11            # after step 60 only rows 0..10 are ever touched again
+  dout_all = (rng.standard_normal((T, B, dim)) * 0.01).astype(np.float32)
+  state = {}
+  for mode in ('sweep', 'lazy'):
+    var, m, v = table0.clone().to(DEV), torch.zeros(rows, dim, device=DEV), torch.zeros(rows, dim, device=DEV)
+    ids = torch.zeros(B, dtype=torch.int64, device=DEV)
+    dout = torch.zeros(B, dim, device=DEV)
+    bitmap = torch.zeros((rows + 31) // 32, dtype=torch.int32, device=DEV) if mode == 'sweep' else None
+    spec = kernels.LookupSpec(table=var, ids=ids, offsets=None, weights=None, out=dout, out_col=0, rows=rows,
+                              key_base=0, dim=dim, combiner=0, n_rows=B, max_nnz=B)
+    g = hip.emb_group_create([spec], dim, rows, var, m, v, bitmap)
+    counter = torch.zeros(1, dtype=torch.int64, device=DEV)
+    hist = torch.zeros(T + 8, device=DEV)
+    hyper = torch.zeros(kernels.HYPER_FLOATS, device=DEV)
+    if mode == 'lazy':
+      last = torch.full((rows,), -1, dtype=torch.int32, device=DEV)
+      hip.emb_group_enable_lazy_decay(g, last, hist, counter)
+      ukeys = torch.zeros(B, dtype=torch.int32, device=DEV)
+      nu = torch.zeros(1, dtype=torch.int32, device=DEV)
+      uidx = torch.zeros(B, dtype=torch.int64, device=DEV)
+      cnt = torch.zeros(1, dtype=torch.int32, device=DEV)
+    rows_h = torch.stack([_hyper(lr=1e-2 * (0.5**(s // 400)), t=s + 1) for s in range(T)]).to(DEV)
+    hist[:T] = rows_h[:, kernels.HYPER_LR_T]
+    for s in range(T):
+      hyper.copy_(rows_h[s])
+      counter.fill_(s + 1)
+      ids.copy_(torch.from_numpy(ids_all[s]))
+      dout.copy_(torch.from_numpy(dout_all[s]))
+      if mode == 'lazy':
+        hip.emb_route(g, ukeys, nu, uidx, cnt)
+        hip.emb_catch_up(g, ukeys, nu, hyper)
+      hip.emb_bwd_update(g, kernels.OPT_ADAM, hyper)
+    if mode == 'lazy':
+      hip.emb_flush_decay(g, hyper)
+      torch.cuda.synchronize()
+      assert int(last.min()) == T - 1
+    torch.cuda.synchronize()
+    state[mode] = (var.cpu(), m.cpu(), v.cpu())
+    hip.emb_group_destroy(g)
+  (va, ma, sa), (vb, mb, sb) = state['sweep'], state['lazy']
+  assert torch.equal(ma, mb), 'first moments must be bit-identical'
+  hot = torch.arange(rows) < 11
+  assert torch.equal(va[hot], vb[hot]) and torch.equal(sa[hot], sb[hot]), 'recently touched rows: every bit'
+  # fp32 never reaches 0 by repeated * 0.9: it settles on a denormal fixed point (|m| <= 4 * 2^-149)
+  assert (ma[~hot].abs() <= 6e-45).all(), 'idle rows: m has settled (the closed-form tail of v was taken)'
+  assert torch.equal(va[~hot], vb[~hot]), 'var stops moving once m == 0'
+  assert torch.allclose(sa, sb, rtol=1e-5, atol=0.0)
