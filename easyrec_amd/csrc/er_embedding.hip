@@ -593,6 +593,108 @@ emb_bwd_fix_kernel(const uint32_t* __restrict__ skeys, int64_t n, int dim, int G
   finish_run<V>(tab, opt_kind, hyper, ro, key, next0 - 1, sub, c, dim, g);
 }
 
+// Segmented sort: when every lookup of a group owns its own table (disjoint, increasing key ranges - the normal
+// case: one embedding column per table) and has at most kSegSortMax entries, the global sort of the group's
+// entries is the concatenation of the per-lookup sorts.  One workgroup sorts one lookup's entries (bitonic network
+// over 64-bit (key << 32 | entry index) composites: ties broken by the entry index, i.e. exactly the result of
+// the stable radix sort), replacing the 8-kernel global rocPRIM radix sort of the group by ONE launch.
+//
+// Each thread keeps E consecutive composites in registers.  A compare-exchange stage of stride j runs
+//   j <  E        inside the thread,
+//   j <  64 E     between lanes of one wavefront (__shfl_xor, no barrier),
+//   j >= 64 E     through LDS, log2(E) stages per round trip: a thread gathers the E elements whose indices
+//                 differ in the log2(E) stride bits of those stages and finishes them in registers.
+// For P = 4096 that is 6 LDS round trips (12 barriers) instead of 78 barrier-separated passes.
+constexpr int kSegSortMax = 8192;
+constexpr int kSegSortMin = 256;
+
+__device__ __forceinline__ void seg_cmpx(unsigned long long& a, unsigned long long& b, bool up) {
+  const bool sw = (a > b) == up;
+  const unsigned long long lo = sw ? b : a, hi = sw ? a : b;
+  a = lo;
+  b = hi;
+}
+
+template <int E>
+__global__ void __launch_bounds__(kSegSortMax / 8)
+emb_segment_sort_kernel(const uint32_t* __restrict__ keys_in, const int64_t* __restrict__ ent_base, int P,
+                        uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long sk[];  // [P]
+  constexpr int L = E == 8 ? 3 : (E == 4 ? 2 : 1);
+  static_assert(E == 2 || E == 4 || E == 8, "E");
+  const int t = threadIdx.x;
+  const int i0 = t * E;
+  const int64_t base = ent_base[blockIdx.x];
+  const int cnt = static_cast<int>(ent_base[blockIdx.x + 1] - base);
+  unsigned long long x[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int i = i0 + e;
+    x[e] = i < cnt ? ((static_cast<unsigned long long>(keys_in[base + i]) << 32) | static_cast<unsigned>(base + i))
+                   : ~0ull;
+  }
+  for (int k = 2; k <= P; k <<= 1) {
+    int j = k >> 1;
+    bool in_lds = false;
+    while (j >= 64 * E) {
+      if (!in_lds) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) sk[i0 + e] = x[e];
+        __syncthreads();
+      }
+      const int b = __ffs(j) - 1, lb = b - L + 1;
+      const int bs = ((t >> lb) << (b + 1)) | (t & ((1 << lb) - 1));
+      const bool up = (bs & k) == 0;
+      unsigned long long y[E];
+#pragma unroll
+      for (int c = 0; c < E; ++c) y[c] = sk[bs + (c << lb)];
+#pragma unroll
+      for (int jj = E / 2; jj > 0; jj >>= 1)
+#pragma unroll
+        for (int c = 0; c < E; ++c)
+          if ((c & jj) == 0) seg_cmpx(y[c], y[c | jj], up);
+#pragma unroll
+      for (int c = 0; c < E; ++c) sk[bs + (c << lb)] = y[c];
+      __syncthreads();
+      in_lds = true;
+      j >>= L;
+    }
+    if (in_lds) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) x[e] = sk[i0 + e];
+    }
+    if (j >= E) {
+      const bool up = (i0 & k) == 0;  // k >= 2 j >= 2 E: bit k lies in the thread part of the index
+      for (; j >= E; j >>= 1) {
+        const int lj = j / E;
+        const bool keep_min = ((t & lj) == 0) == up;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const unsigned long long o = __shfl_xor(x[e], lj);
+          const unsigned long long mn = x[e] < o ? x[e] : o, mx = x[e] < o ? o : x[e];
+          x[e] = keep_min ? mn : mx;
+        }
+      }
+    }
+#pragma unroll
+    for (int jj = E / 2; jj > 0; jj >>= 1) {
+      if (jj <= j) {
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+          if ((e & jj) == 0) seg_cmpx(x[e], x[e | jj], ((i0 + e) & k) == 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int i = i0 + e;
+    if (i < cnt) {
+      keys_out[base + i] = static_cast<uint32_t>(x[e] >> 32);
+      vals_out[base + i] = static_cast<uint32_t>(x[e] & 0xFFFFFFFFu);
+    }
+  }
+}
+
 __global__ void __launch_bounds__(kBlock)
 emb_head_flag_kernel(const uint32_t* __restrict__ skeys, int64_t n, uint32_t* __restrict__ flags) {
   const int64_t p = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
@@ -867,7 +969,15 @@ struct er_emb_group {
   int64_t shard_stride = 0;
   int64_t* d_local_base = nullptr;
   int64_t n_active = -1;  // -1: all entries
+  int seg_sort_pow2 = 0;   // > 0: per-lookup LDS sort (emb_segment_sort_kernel) with this padded size
   bool sorted_valid = false;
+  // er_emb_group_share_sort: `src` owns the sorted keys / entry permutation / run heads this group reduces over
+  // (itself, or the leader whose keys are identical); the epochs tell a fresh leader sort from a stale one
+  er_emb_group* leader = nullptr;
+  er_emb_group* src = nullptr;
+  uint64_t sort_epoch = 0, adopted_epoch = 0, heads_epoch = 0;
+  std::vector<er_lookup_desc> h_descs;
+  std::vector<int64_t> h_local_base;
   float *var = nullptr, *m = nullptr, *v = nullptr;
   uint32_t* bitmap = nullptr;
   int n_build_blocks = 0;
@@ -982,6 +1092,24 @@ int er_emb_group_create(const er_lookup_desc* descs, int n, int32_t dim, int64_t
   }
   g->n_build_blocks = blk[n];
   g->n_entries = base[n];
+  g->src = g;
+  g->h_descs.assign(descs, descs + n);
+  {
+    // segmented-sort fast path: dense or small lookups, each on its own table, key ranges increasing in lookup order
+    bool ok = true;
+    int64_t max_cap = 0;
+    for (int i = 0; i < n && ok; ++i) {
+      const int64_t cap = base[i + 1] - base[i];
+      if (cap > max_cap) max_cap = cap;
+      if (cap > er::kSegSortMax) ok = false;
+      if (i + 1 < n && descs[i].key_base + descs[i].rows > descs[i + 1].key_base) ok = false;
+    }
+    if (ok && max_cap > 0) {
+      int p2 = er::kSegSortMin;
+      while (p2 < max_cap) p2 <<= 1;
+      g->seg_sort_pow2 = p2;
+    }
+  }
   ER_REQUIRE(g->n_entries > 0 && g->n_entries < 0x7FFFFFFFLL, "er_emb_group_create: entry count %lld out of range",
              (long long)g->n_entries);
   const int64_t N = g->n_entries;
@@ -1020,6 +1148,7 @@ int er_emb_group_update(er_emb_group* g, const er_lookup_desc* descs, int n) {
   ER_REQUIRE(g && descs && n == g->n, "er_emb_group_update: lookup count changed");
   if (int rc = validate_descs(descs, n, "er_emb_group_update")) return rc;
   ER_CHECK_HIP(hipMemcpy(g->d_descs, descs, sizeof(er_lookup_desc) * n, hipMemcpyHostToDevice));
+  g->h_descs.assign(descs, descs + n);
   return 0;
 }
 
@@ -1046,8 +1175,7 @@ static int fill_u32(uint32_t* p, uint32_t value, int64_t n, hipStream_t s) {
 
 static int64_t group_entries(const er_emb_group* g) { return g->n_active >= 0 ? g->n_active : g->n_entries; }
 
-// build keys (routed) + stable radix sort.  Leaves keys_out/vals_out valid for this step.
-static int emb_group_build_sort(er_emb_group* g, hipStream_t s) {
+static int emb_group_build(er_emb_group* g, hipStream_t s) {
   const int64_t N = group_entries(g);
   if (N == 0) return 0;
   if (g->has_ragged)
@@ -1057,6 +1185,59 @@ static int emb_group_build_sort(er_emb_group* g, hipStream_t s) {
   hipLaunchKernelGGL(er::emb_bwd_build_kernel, dim3(g->n_build_blocks), dim3(er::kBlock), 0, s, g->d_descs,
                      g->d_blk_start, g->d_ent_base, g->n, rt, n_act, g->keys_in, g->vals_in, g->ent_gptr, g->ent_scale);
   ER_LAUNCH_CHECK();
+  return 0;
+}
+
+// true when the keys of g are, by construction, those of its leader: every lookup reads the same ids with the same
+// table geometry and routing (re-checked on the host at every call: er_emb_group_update may have changed either)
+static bool emb_group_same_keys(const er_emb_group* g, const er_emb_group* l) {
+  if (!l || g->n != l->n || g->n_active >= 0 || l->n_active >= 0) return false;
+  if (g->world != l->world || g->shard_stride != l->shard_stride || g->h_local_base != l->h_local_base) return false;
+  if ((g->d_local_base == nullptr) != (l->d_local_base == nullptr)) return false;
+  for (int i = 0; i < g->n; ++i) {
+    const er_lookup_desc &a = g->h_descs[i], &b = l->h_descs[i];
+    if (a.ids != b.ids || a.offsets != b.offsets || a.rows != b.rows || a.key_base != b.key_base ||
+        a.n_rows != b.n_rows || a.max_nnz != b.max_nnz)
+      return false;
+  }
+  return true;
+}
+
+// Follower of a shared sort: only the per-entry gradient pointers / scales are built; the sorted keys, the entry
+// permutation and (after the leader's er_emb_route) the run heads are the leader's.
+static int emb_group_adopt(er_emb_group* g, hipStream_t s, bool* adopted) {
+  *adopted = false;
+  er_emb_group* l = g->leader;
+  if (!emb_group_same_keys(g, l)) return 0;
+  ER_REQUIRE(l->sort_epoch != g->adopted_epoch,
+             "shared sort: the leader group has not been processed since this group last used its sort "
+             "(call the leader first in every step)");
+  if (int rc = emb_group_build(g, s)) return rc;
+  g->adopted_epoch = l->sort_epoch;
+  g->src = l;
+  *adopted = true;
+  return 0;
+}
+
+// build keys (routed) + stable sort.  Leaves keys_out/vals_out valid for this step.
+static int emb_group_build_sort(er_emb_group* g, hipStream_t s) {
+  const int64_t N = group_entries(g);
+  if (N == 0) return 0;
+  if (int rc = emb_group_build(g, s)) return rc;
+  g->src = g;
+  ++g->sort_epoch;
+  if (g->seg_sort_pow2 > 0 && g->n_active < 0 && !g->d_local_base) {
+    const int P = g->seg_sort_pow2;
+    const size_t lds = sizeof(unsigned long long) * static_cast<size_t>(P);
+    if (P > 4096)
+      hipLaunchKernelGGL(er::emb_segment_sort_kernel<8>, dim3(g->n), dim3(P / 8), lds, s, g->keys_in, g->d_ent_base, P,
+                         g->keys_out, g->vals_out);
+    else
+      hipLaunchKernelGGL(er::emb_segment_sort_kernel<4>, dim3(g->n), dim3(P / 4), lds, s, g->keys_in, g->d_ent_base, P,
+                         g->keys_out, g->vals_out);
+    ER_LAUNCH_CHECK();
+    return 0;
+  }
   ER_CHECK_HIP(rocprim::radix_sort_pairs(g->sort_temp, g->sort_temp_bytes, g->keys_in, g->keys_out, g->vals_in,
                                          g->vals_out, static_cast<size_t>(N), 0u, static_cast<unsigned>(g->key_bits), s));
   return 0;
@@ -1068,7 +1249,7 @@ static int emb_group_sort(er_emb_group* g, hipStream_t s) { return emb_group_bui
 static int emb_group_heads(er_emb_group* g, int32_t* n_unique, hipStream_t s) {
   const int64_t N = group_entries(g);
   hipLaunchKernelGGL(er::emb_head_flag_kernel, dim3(static_cast<int>(er::ceil_div(N, er::kBlock))), dim3(er::kBlock), 0,
-                     s, g->keys_out, N, g->head_flags);
+                     s, g->src->keys_out, N, g->head_flags);
   ER_LAUNCH_CHECK();
   ER_CHECK_HIP(rocprim::exclusive_scan(g->scan_temp, g->scan_temp_bytes, g->head_flags, g->head_index, 0u,
                                        static_cast<size_t>(N), rocprim::plus<uint32_t>(), s));
@@ -1084,22 +1265,23 @@ static int emb_group_run(er_emb_group* g, int opt_kind, const er_opt_hyper* hype
   const int T = g->tile_entries;
   const int n_tiles = static_cast<int>(er::ceil_div(N, T));
   er::RowUpdate tab{g->var, g->m, g->v, g->bitmap, g->last_step, g->step_counter};
-  er::ReduceOut ro{mode, g->head_flags, g->head_index, out_keys, out_grads};
+  const er_emb_group* src = g->src;  // whose sort this group reduces over (itself unless er_emb_group_share_sort)
+  er::ReduceOut ro{mode, src->head_flags, src->head_index, out_keys, out_grads};
   const size_t lds = sizeof(float) * static_cast<size_t>(T) * g->dim + sizeof(uint32_t) * (T + 2);
   const int fix_blocks = static_cast<int>(er::ceil_div(static_cast<int64_t>(n_tiles) * g->G, er::kBlock));
   if (g->V == 4) {
-    hipLaunchKernelGGL(er::emb_bwd_tile_kernel<4>, dim3(n_tiles), dim3(er::kBlock), lds, s, g->keys_out, g->vals_out,
+    hipLaunchKernelGGL(er::emb_bwd_tile_kernel<4>, dim3(n_tiles), dim3(er::kBlock), lds, s, src->keys_out, src->vals_out,
                        g->ent_gptr, g->ent_scale, N, g->dim, g->G, tab, opt_kind, hyper, ro, g->tile_first, g->tile_last);
     ER_LAUNCH_CHECK();
     if (n_tiles > 1)
-      hipLaunchKernelGGL(er::emb_bwd_fix_kernel<4>, dim3(fix_blocks), dim3(er::kBlock), 0, s, g->keys_out, N, g->dim, g->G,
+      hipLaunchKernelGGL(er::emb_bwd_fix_kernel<4>, dim3(fix_blocks), dim3(er::kBlock), 0, s, src->keys_out, N, g->dim, g->G,
                          T, n_tiles, tab, opt_kind, hyper, ro, g->tile_first, g->tile_last);
   } else {
-    hipLaunchKernelGGL(er::emb_bwd_tile_kernel<1>, dim3(n_tiles), dim3(er::kBlock), lds, s, g->keys_out, g->vals_out,
+    hipLaunchKernelGGL(er::emb_bwd_tile_kernel<1>, dim3(n_tiles), dim3(er::kBlock), lds, s, src->keys_out, src->vals_out,
                        g->ent_gptr, g->ent_scale, N, g->dim, g->G, tab, opt_kind, hyper, ro, g->tile_first, g->tile_last);
     ER_LAUNCH_CHECK();
     if (n_tiles > 1)
-      hipLaunchKernelGGL(er::emb_bwd_fix_kernel<1>, dim3(fix_blocks), dim3(er::kBlock), 0, s, g->keys_out, N, g->dim, g->G,
+      hipLaunchKernelGGL(er::emb_bwd_fix_kernel<1>, dim3(fix_blocks), dim3(er::kBlock), 0, s, src->keys_out, N, g->dim, g->G,
                          T, n_tiles, tab, opt_kind, hyper, ro, g->tile_first, g->tile_last);
   }
   ER_LAUNCH_CHECK();
@@ -1163,8 +1345,13 @@ int er_emb_bwd_update(er_emb_group* g, int opt_kind, const er_opt_hyper* hyper, 
     ER_REQUIRE(g->bitmap, "er_emb_bwd_update: ER_OPT_ADAM needs touched_bitmap (or er_emb_group_enable_lazy_decay)");
   hipStream_t s = er::as_stream(stream);
   // a sort left by this step's er_emb_route (lazy dense decay, embedding-parallel requester) is reused
-  if (!g->sorted_valid)
-    if (int rc = emb_group_sort(g, s)) return rc;
+  if (!g->sorted_valid) {
+    bool adopted = false;
+    if (g->leader)
+      if (int rc = emb_group_adopt(g, s, &adopted)) return rc;
+    if (!adopted)
+      if (int rc = emb_group_sort(g, s)) return rc;
+  }
   g->sorted_valid = false;
   if (int rc = emb_group_run(g, opt_kind, hyper, 0, nullptr, nullptr, s)) return rc;
   if (opt_kind == ER_OPT_ADAM && !lazy_decay) {
@@ -1272,12 +1459,28 @@ int er_emb_group_set_routing(er_emb_group* g, int32_t world, int64_t shard_strid
              (long long)(world * shard_stride));
   if (!g->d_local_base) ER_CHECK_HIP(hipMalloc(&g->d_local_base, sizeof(int64_t) * g->n));
   ER_CHECK_HIP(hipMemcpy(g->d_local_base, local_base_host, sizeof(int64_t) * g->n, hipMemcpyHostToDevice));
+  g->h_local_base.assign(local_base_host, local_base_host + g->n);
   g->world = world;
   g->shard_stride = shard_stride;
   const int64_t span = static_cast<int64_t>(world) * shard_stride;
   g->key_bits = 1;
   while ((1LL << g->key_bits) <= span) ++g->key_bits;
   // the temporary storage of the radix sort does not depend on the bit range
+  return 0;
+}
+
+int er_emb_group_share_sort(er_emb_group* g, er_emb_group* leader) {
+  ER_REQUIRE(g && g != leader, "er_emb_group_share_sort: bad arguments");
+  if (!leader) {
+    g->leader = nullptr;
+    g->src = g;
+    return 0;
+  }
+  ER_REQUIRE(!leader->leader, "er_emb_group_share_sort: the leader itself follows another group");
+  ER_REQUIRE(emb_group_same_keys(g, leader),
+             "er_emb_group_share_sort: the groups do not read the same ids with the same table geometry");
+  g->leader = leader;
+  g->adopted_epoch = leader->sort_epoch;
   return 0;
 }
 
@@ -1292,16 +1495,38 @@ int er_emb_group_set_active(er_emb_group* g, int64_t n_rows) {
 
 int er_emb_route(er_emb_group* g, uint32_t* unique_keys, int32_t* n_unique, int64_t* entry_unique_index,
                  int32_t* owner_counts, er_stream_t stream) {
-  ER_REQUIRE(g && unique_keys && n_unique, "er_emb_route: null argument");
+  ER_REQUIRE(g, "er_emb_route: null argument");
   ER_REQUIRE(g->world <= 64, "er_emb_route: world %d > 64", g->world);
   hipStream_t s = er::as_stream(stream);
   const int64_t N = group_entries(g);
   ER_REQUIRE(N > 0, "er_emb_route: empty group");
-  if (int rc = emb_group_build_sort(g, s)) return rc;
-  if (int rc = emb_group_heads(g, n_unique, s)) return rc;
-  hipLaunchKernelGGL(er::emb_route_kernel, dim3(static_cast<int>(er::ceil_div(N, er::kBlock))), dim3(er::kBlock), 0, s,
-                     g->keys_out, g->vals_out, g->head_flags, g->head_index, N, unique_keys, entry_unique_index);
-  ER_LAUNCH_CHECK();
+  bool adopted = false;
+  if (g->leader)
+    if (int rc = emb_group_adopt(g, s, &adopted)) return rc;
+  if (adopted) {
+    // shared sort: the leader's er_emb_route already produced the run heads; the outputs are optional here
+    // (they equal the leader's)
+    const er_emb_group* l = g->src;
+    ER_REQUIRE(l->heads_epoch == l->sort_epoch, "er_emb_route: shared sort: call er_emb_route on the leader first");
+    ER_REQUIRE((unique_keys != nullptr) == (n_unique != nullptr) && (unique_keys || (!entry_unique_index && !owner_counts)),
+               "er_emb_route: shared sort: pass unique_keys AND n_unique, or neither (then no other output)");
+    if (unique_keys) {
+      hipLaunchKernelGGL(er::emb_count_unique_kernel, dim3(1), dim3(64), 0, s, l->head_flags, l->head_index, N, n_unique);
+      ER_LAUNCH_CHECK();
+    }
+  } else {
+    ER_REQUIRE(unique_keys && n_unique, "er_emb_route: null argument");
+    if (int rc = emb_group_build_sort(g, s)) return rc;
+    if (int rc = emb_group_heads(g, n_unique, s)) return rc;
+    g->heads_epoch = g->sort_epoch;
+  }
+  if (unique_keys) {
+    const er_emb_group* src = g->src;
+    hipLaunchKernelGGL(er::emb_route_kernel, dim3(static_cast<int>(er::ceil_div(N, er::kBlock))), dim3(er::kBlock), 0, s,
+                       src->keys_out, src->vals_out, src->head_flags, src->head_index, N, unique_keys,
+                       entry_unique_index);
+    ER_LAUNCH_CHECK();
+  }
   if (owner_counts) {
     const int64_t stride = g->d_local_base ? g->shard_stride : g->total_rows;
     hipLaunchKernelGGL(er::emb_owner_counts_kernel, dim3(1), dim3(64), 0, s, unique_keys, n_unique, g->world, stride,

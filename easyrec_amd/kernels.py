@@ -48,6 +48,27 @@ HYPER_FLOATS = 16
 HYPER_LR, HYPER_LR_T, HYPER_BETA1, HYPER_BETA2, HYPER_OMB1, HYPER_OMB2, HYPER_EPS, HYPER_GSCALE = range(8)
 
 
+def same_lookup_keys(group, leader):
+  """Do two table groups see the same keys every step (er_emb_group_share_sort's condition)?"""
+  if group is leader or leader.get('sort_leader') is not None:
+    return False
+  a, b = group['specs'], leader['specs']
+  if len(a) != len(b) or group.get('n_active', -1) >= 0 or leader.get('n_active', -1) >= 0:
+    return False
+  for k in ('world', 'shard_stride', 'local_base'):
+    if group.get(k) != leader.get(k):
+      return False
+
+  def ptr(t):
+    return None if t is None else t.data_ptr()
+
+  for x, y in zip(a, b):
+    if (ptr(x.ids), ptr(x.offsets), x.rows, x.key_base, x.n_rows, x.max_nnz) != \
+        (ptr(y.ids), ptr(y.offsets), y.rows, y.key_base, y.n_rows, y.max_nnz):
+      return False
+  return True
+
+
 @dataclass
 class LookupSpec:
   """One embedding lookup (tensor-level view of er_lookup_desc).
@@ -286,7 +307,19 @@ class HipBackend(object):
     self._ck(self.lib.er_emb_group_set_active(group['handle'], ctypes.c_int64(int(n_rows))), 'er_emb_group_set_active')
     group['n_active'] = int(n_rows)
 
+  def emb_group_share_sort(self, group, leader):
+    """True when `group` now reuses `leader`'s per-step sort (identical ids and table geometry), else False."""
+    if not same_lookup_keys(group, leader):
+      return False
+    self._ck(self.lib.er_emb_group_share_sort(group['handle'], leader['handle']), 'er_emb_group_share_sort')
+    group['sort_leader'] = leader
+    return True
+
   def emb_route(self, group, unique_keys, n_unique, entry_unique_index, owner_counts):
+    if unique_keys is None:  # follower of a shared sort: the outputs are the leader's
+      assert group.get('sort_leader') is not None and n_unique is None and entry_unique_index is None
+      self._ck(self.lib.er_emb_route(group['handle'], None, None, None, None, _stream()), 'er_emb_route')
+      return
     assert unique_keys.dtype == torch.int32 and n_unique.dtype == torch.int32
     assert entry_unique_index is None or entry_unique_index.dtype == torch.int64
     assert owner_counts is None or owner_counts.dtype == torch.int32

@@ -85,6 +85,8 @@ class EmbeddingEngine(object):
     self.lazy_decay = False
     self._clock = None  # (step_counter int64[1], lr_t history fp32[capacity], hyper record of the embeddings)
     self._lazy = OrderedDict()  # dim -> route buffers + last_step
+    self.share_sort = True  # er_emb_group_share_sort between table groups that read the same ids
+    self._sort_leader = {}  # dim -> dim of the group whose per-step sort it reuses
 
   # -- declaration (build pass)
   def declare_table(self, var_name, rows, dim, initializer=None):
@@ -235,6 +237,12 @@ class EmbeddingEngine(object):
         if self.lazy_decay and opt_kind == kernels.OPT_ADAM:
           self._lazy[dim] = self._enable_lazy_decay(dim, self.emb_groups[dim], st, self.emb_groups[dim]['num_entries'])
     self.lazy_decay = self.lazy_decay and opt_kind == kernels.OPT_ADAM
+    # wide and deep groups built from the same columns see the same keys: sort them once per step
+    self._sort_leader = {}
+    dims = list(self.emb_groups)
+    for dim in dims[1:]:
+      if self.share_sort and be.emb_group_share_sort(self.emb_groups[dim], self.emb_groups[dims[0]]):
+        self._sort_leader[dim] = dims[0]
     self.reg_lambda = max([g['reg'] for g in self.groups.values()] + [0.0])
     self.finalized = True
 
@@ -265,7 +273,11 @@ class EmbeddingEngine(object):
       # sort the step's ids once (reused by the backward), bring the rows it touches up to date, then look up
       for dim, grp in self.emb_groups.items():
         lz = self._lazy[dim]
-        be.emb_route(grp, lz['ukeys'], lz['n_unique'], None, None)
+        if dim in self._sort_leader:
+          lz = self._lazy[self._sort_leader[dim]]
+          be.emb_route(grp, None, None, None, None)
+        else:
+          be.emb_route(grp, lz['ukeys'], lz['n_unique'], None, None)
         be.emb_catch_up(grp, lz['ukeys'], lz['n_unique'], self._clock[2])
     if self.plan is not None:
       be.emb_fwd(self.plan, self.sumsq if self.reg_lambda > 0 else None)

@@ -414,6 +414,17 @@ int er_gemm_bf16(int layout, int32_t M, int32_t N, int32_t K, const float* A, in
 int er_emb_group_set_routing(er_emb_group* group, int32_t world, int64_t shard_stride,
                              const int64_t* local_base_host);
 int er_emb_group_set_active(er_emb_group* group, int64_t n_rows);
+/* Shared sort.  Wide and deep feature groups (DeepFM / WideAndDeep: model/deepfm.py:36-60,
+ * layers/input_layer.py:101-125 build both from the SAME input columns) look the same ids up in tables of
+ * different width, so the two table groups see identical keys every step.  After
+ * er_emb_group_share_sort(group, leader) - accepted only when every lookup i of both groups reads the same
+ * ids / offsets with the same rows, key_base, n_rows, max_nnz and routing - er_emb_route and er_emb_bwd_update
+ * on `group` reuse the sorted keys, entry permutation and run heads the same call on `leader` left for this
+ * step instead of sorting again (the leader must be processed first in every step and outlive the follower;
+ * a later er_emb_group_update that breaks the equality silently falls back to an own sort).  On a follower
+ * er_emb_route may be called with unique_keys = n_unique = NULL: they would equal the leader's.
+ * leader = NULL removes the link. */
+int er_emb_group_share_sort(er_emb_group* group, er_emb_group* leader);
 int er_emb_route(er_emb_group* group, uint32_t* unique_keys, int32_t* n_unique,
                  int64_t* entry_unique_index, int32_t* owner_counts, er_stream_t stream);
 int er_emb_bwd_reduce_routed(er_emb_group* group, float* unique_grads, er_stream_t stream);

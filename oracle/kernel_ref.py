@@ -377,9 +377,20 @@ class RefBackend(object):
       base += s.max_nnz if s.offsets is not None else s.n_rows
     return ents
 
+  def emb_group_share_sort(self, group, leader):
+    from easyrec_amd.kernels import same_lookup_keys
+    if not same_lookup_keys(group, leader):
+      return False
+    group['sort_leader'] = leader
+    return True
+
   def emb_route(self, group, unique_keys, n_unique, entry_unique_index, owner_counts):
     ents = self._routed_entries(group)
     keys = sorted(set(e[0] for e in ents))
+    if unique_keys is None:  # follower of a shared sort
+      assert group.get('sort_leader') is not None and group['sort_leader'].get('_route_keys') == keys
+      group['_route_keys'] = keys
+      return
     pos = {k: i for i, k in enumerate(keys)}
     if entry_unique_index is not None:
       entry_unique_index.fill_(-1)

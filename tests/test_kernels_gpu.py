@@ -648,3 +648,115 @@ def test_lazy_dense_decay_equals_the_sweep(hip):
   assert (ma[~hot].abs() <= 6e-45).all(), 'idle rows: m has settled (the closed-form tail of v was taken)'
   assert torch.equal(va[~hot], vb[~hot]), 'var stops moving once m == 0'
   assert torch.allclose(sa, sb, rtol=1e-5, atol=0.0)
+
+
+@pytest.mark.parametrize('sizes', [(100, 4096, 5000, 8192, 257), (1, 2, 3), (4097,), (8192, 8192), (9000, 50)])
+def test_segmented_sort_sizes(hip, sizes):
+  """One table per lookup -> one workgroup sorts one lookup's entries (emb_segment_sort_kernel; the last case has
+  a lookup above its capacity and takes the global radix sort).  The de-duplicated keys must come out ascending
+  and every row's gradient must be the source-order sum of its entries."""
+  rng = np.random.default_rng(sum(sizes))
+  dim = 4
+  specs, base, exp_keys, exp = [], 0, [], []
+  for n in sizes:
+    rows = int(rng.integers(1, 3 * n + 2))
+    ids = rng.integers(-1, rows, size=n).astype(np.int64)
+    if n > 64:
+      ids[:n // 3] = ids[0]  # one long run
+    dout = (rng.standard_normal((n, dim)) * 0.01).astype(np.float32)
+    specs.append(kernels.LookupSpec(table=torch.zeros(rows, dim, device=DEV), ids=torch.from_numpy(ids).to(DEV),
+                                    offsets=None, weights=None, out=torch.from_numpy(dout).to(DEV), out_col=0,
+                                    rows=rows, key_base=base, dim=dim, combiner=0, n_rows=n, max_nnz=n))
+    acc = np.zeros((rows, dim), dtype=np.float64)
+    ok = ids >= 0
+    np.add.at(acc, ids[ok], dout[ok].astype(np.float64))
+    u = np.unique(ids[ok])
+    exp_keys.append(u + base)
+    exp.append(acc[u])
+    base += rows
+  var = torch.zeros(base, dim, device=DEV)
+  g = hip.emb_group_create(specs, dim, base, var, None, None, None)
+  keys, grads, n = hip.emb_bwd_reduce(g)
+  torch.cuda.synchronize()
+  exp_keys, exp = np.concatenate(exp_keys), np.concatenate(exp)
+  assert int(n.item()) == len(exp_keys)
+  assert np.array_equal(keys[:len(exp_keys)].cpu().numpy(), exp_keys)
+  assert np.allclose(grads[:len(exp_keys)].cpu().numpy(), exp, rtol=1e-5, atol=1e-7)
+  keys2, grads2, _ = hip.emb_bwd_reduce(g)
+  torch.cuda.synchronize()
+  assert torch.equal(grads[:len(exp_keys)], grads2[:len(exp_keys)])
+  hip.emb_group_destroy(g)
+
+
+@pytest.mark.parametrize('lazy', [False, True])
+def test_shared_sort_between_wide_and_deep_groups(hip, lazy):
+  """A dim-1 (wide) and a dim-16 (deep) table group reading the same id columns: the follower reuses the leader's
+  sort (er_emb_group_share_sort).  Tables and Adam slots must equal, bit for bit, those of two independent groups."""
+  rng = np.random.default_rng(3)
+  B, n_feat, T = 700, 5, 4
+  rows = [int(rng.integers(3, 400)) for _ in range(n_feat)]
+  ids_steps = [[rng.integers(-1, r, size=B).astype(np.int64) for r in rows] for _ in range(T)]
+  results = {}
+  for share in (False, True):
+    ids = [torch.zeros(B, dtype=torch.int64, device=DEV) for _ in rows]
+    groups, state = {}, {}
+    counter = torch.zeros(1, dtype=torch.int64, device=DEV)
+    hist = torch.zeros(T + 8, device=DEV)
+    hyper = torch.zeros(kernels.HYPER_FLOATS, device=DEV)
+    rows_h = torch.stack([_hyper(lr=1e-2, t=s + 1) for s in range(T)]).to(DEV)
+    hist[:T] = rows_h[:, kernels.HYPER_LR_T]
+    total = sum(rows)
+    lz = {}
+    for dim in (1, 16):
+      g0 = torch.Generator().manual_seed(dim)
+      var = (torch.randn(total, dim, generator=g0) * 0.05).to(DEV)
+      m, v = torch.zeros(total, dim, device=DEV), torch.zeros(total, dim, device=DEV)
+      dout = torch.zeros(B, n_feat * dim, device=DEV)
+      specs, base = [], 0
+      for f, r in enumerate(rows):
+        specs.append(kernels.LookupSpec(table=var[base:base + r], ids=ids[f], offsets=None, weights=None, out=dout,
+                                        out_col=f * dim, rows=r, key_base=base, dim=dim, combiner=0, n_rows=B,
+                                        max_nnz=B))
+        base += r
+      bitmap = None if lazy else torch.zeros((total + 31) // 32, dtype=torch.int32, device=DEV)
+      groups[dim] = hip.emb_group_create(specs, dim, total, var, m, v, bitmap)
+      state[dim] = (var, m, v, dout)
+      if lazy:
+        lz[dim] = dict(last=torch.full((total,), -1, dtype=torch.int32, device=DEV),
+                       ukeys=torch.zeros(B * n_feat, dtype=torch.int32, device=DEV),
+                       nu=torch.zeros(1, dtype=torch.int32, device=DEV))
+        hip.emb_group_enable_lazy_decay(groups[dim], lz[dim]['last'], hist, counter)
+    if share:
+      assert hip.emb_group_share_sort(groups[16], groups[1])
+    for s in range(T):
+      hyper.copy_(rows_h[s])
+      counter.fill_(s + 1)
+      for f in range(n_feat):
+        ids[f].copy_(torch.from_numpy(ids_steps[s][f]))
+      for dim in (1, 16):
+        gd = torch.Generator().manual_seed(100 * s + dim)
+        state[dim][3].copy_((torch.randn(B, n_feat * dim, generator=gd) * 0.01).to(DEV))
+      if lazy:
+        for dim in (1, 16):
+          if share and dim == 16:
+            hip.emb_route(groups[16], None, None, None, None)
+            hip.emb_catch_up(groups[16], lz[1]['ukeys'], lz[1]['nu'], hyper)
+          else:
+            hip.emb_route(groups[dim], lz[dim]['ukeys'], lz[dim]['nu'], None, None)
+            hip.emb_catch_up(groups[dim], lz[dim]['ukeys'], lz[dim]['nu'], hyper)
+      for dim in (1, 16):
+        hip.emb_bwd_update(groups[dim], kernels.OPT_ADAM, hyper)
+    if lazy:
+      for dim in (1, 16):
+        hip.emb_flush_decay(groups[dim], hyper)
+    torch.cuda.synchronize()
+    results[share] = {dim: tuple(t.cpu() for t in state[dim][:3]) for dim in (1, 16)}
+    if share:  # the follower refuses a stale sort
+      with pytest.raises(RuntimeError):
+        hip.emb_bwd_update(groups[16], kernels.OPT_ADAM, hyper)
+    for dim in (16, 1):
+      hip.emb_group_destroy(groups[dim])
+  for dim in (1, 16):
+    for a, b, what in zip(results[False][dim], results[True][dim], ('var', 'm', 'v')):
+      assert torch.equal(a, b), (dim, what)
+  assert float(results[True][16][1].abs().max()) > 0
