@@ -145,15 +145,120 @@ __device__ __forceinline__ void tile_col_stats(const f32x16& acc, float bv, int 
 }
 
 // ------------------------------------------------------------------------------------------------
-// fp32: C tile 64x64, k-tile 32, LDS k-major: As[k][m], Bs[k][n]
+// fp32: C tile 64x64 per workgroup (4 waves, one 32x32 accumulator each), k-tile 32.
+//
+// LDS: both operand tiles as [mn][k] with a row stride of 36 floats, two stages.  A lane's MFMA fragment is then
+// 16 CONSECUTIVE k of one row = 4 ds_read_b128 per operand and k-tile (conflict-free for the b128 lane groups with
+// stride 36, and b128 reads reach the LDS rate from one wave per SIMD where the ds_read_b32 of a k-major layout get
+// a fifth of it - MI355X_MICROARCH.md, LDS): all 8 reads of a tile are issued up front and the 16 MFMAs run back to
+// back.  Lane (i = lane & 31, h = lane >> 5) holds k = 16 h + s for MFMA step s, for A and B alike: each step
+// contracts the pair (s, 16 + s) - a fixed order, the same for every launch.
+//
+// Staging: a thread owns 2 units (4 consecutive k of one row) per operand and k-tile.  An operand whose k runs
+// contiguously in HBM fetches a unit with one 16-byte load; the other kind (B of NN, both of TN) with 4 dword loads
+// that are each coalesced along mn across the wave - the transpose happens in registers, not as scattered LDS
+// stores.  Either way a unit is ONE ds_write_b128 (8 consecutive lanes cover 32 distinct banks).
+//
+// Pipeline: two register sets hold the global loads of k-tiles t+1 and t+2 while tile t is contracted; tile t+1
+// is written to the other LDS stage during the MFMAs of tile t: one barrier per k-tile, global latency has two
+// k-tiles to hide in.  Interior tiles take branch-free loads; edge tiles (uniform test) masked scalar loads.
 // ------------------------------------------------------------------------------------------------
+constexpr int SK = BK32 + 4;      // floats per LDS row
+constexpr int kOpTile = BM * SK;  // floats per operand tile (BM == BN)
+
+// A thread's unit i (0 / 1) of an operand tile: 4 elements that are consecutive in HBM.
+//   K_CONTIG : row = u >> 3, k = (u & 7) * 4 + 0..3, u = tid + 256 i            -> one ds_write_b128 at [row][k]
+//   else     : rows (tid >> 4) * 4 + 0..3, k = (tid & 15) + 16 i                -> four ds_write_b32 at [row + j][k]
+//              (32 consecutive lanes cover 16 k x 2 row groups = 32 distinct banks with the row stride 36)
+template <bool KC>
+__device__ __forceinline__ void unit_pos(int tid, int i, int& row, int& k) {
+  if (KC) {
+    const int u = tid + i * kBlock;
+    row = u >> 3;
+    k = (u & 7) * 4;
+  } else {
+    row = (tid >> 4) * 4;
+    k = (tid & 15) + 16 * i;
+  }
+}
+
+// Branch-free 16-byte loads of a thread's 2 units: indices outside the operand are clamped to a valid address and
+// the values zeroed later, in stage_tile (NOT here: a use of the loaded value would wait for the load).  Needs
+// ld % 4 == 0 and a 16-byte aligned base; the extent along the contiguous dimension rounded up to 4 is <= ld.
+template <bool KC>
+__device__ __forceinline__ void fetch_tile(const float* __restrict__ P, int ld, int mn0, int MN, int k0, int kend,
+                                           int K, int tid, f32x4v (&r)[2]) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int row, k;
+    unit_pos<KC>(tid, i, row, k);
+    int mn = mn0 + row;
+    k += k0;
+    if (KC) {
+      const int kpad = (K + 3) & ~3;
+      mn = mn < MN ? mn : MN - 1;
+      k = k < kpad - 4 ? k : kpad - 4;
+      r[i] = *reinterpret_cast<const f32x4v*>(P + static_cast<int64_t>(mn) * ld + k);
+    } else {
+      const int mnpad = (MN + 3) & ~3;
+      mn = mn < mnpad - 4 ? mn : mnpad - 4;
+      k = k < kend ? k : kend - 1;
+      r[i] = *reinterpret_cast<const f32x4v*>(P + static_cast<int64_t>(k) * ld + mn);
+    }
+  }
+}
+
+// Generic loads (any alignment): masked scalar loads, used by the non-pipelined loop only.
+template <bool KC>
+__device__ __forceinline__ void fetch_tile_generic(const float* __restrict__ P, int ld, int mn0, int MN, int k0,
+                                                   int kend, int tid, f32x4v (&r)[2]) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int row, k;
+    unit_pos<KC>(tid, i, row, k);
+    const int mn = mn0 + row;
+    k += k0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v = 0.f;
+      if (KC) {
+        if (mn < MN && k + j < kend) v = P[static_cast<int64_t>(mn) * ld + k + j];
+      } else {
+        if (mn + j < MN && k < kend) v = P[static_cast<int64_t>(k) * ld + mn + j];
+      }
+      r[i][j] = v;
+    }
+  }
+}
+
+template <bool KC>
+__device__ __forceinline__ void stage_tile(float* __restrict__ S, int tid, const f32x4v (&r)[2], bool interior, int mn0,
+                                           int MN, int k0, int kend) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int row, k;
+    unit_pos<KC>(tid, i, row, k);
+    f32x4v v = r[i];
+    if (!interior) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool ok = KC ? (mn0 + row < MN && k0 + k + j < kend) : (mn0 + row + j < MN && k0 + k < kend);
+        if (!ok) v[j] = 0.f;
+      }
+    }
+    if (KC) {
+      *reinterpret_cast<f32x4v*>(&S[row * SK + k]) = v;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) S[(row + j) * SK + k] = v[j];
+    }
+  }
+}
+
 template <bool A_KC, bool B_KC>
 __global__ void __launch_bounds__(kBlock)
 gemm_f32_kernel(GemmArgs g) {
-  constexpr int SA = A_KC ? BM + 1 : BM + 4;  // transposed scatter stores want an odd stride, float4 stores 16 B
-  constexpr int SB = B_KC ? BN + 1 : BN + 4;
-  __shared__ __attribute__((aligned(16))) float As[BK32 * SA];
-  __shared__ __attribute__((aligned(16))) float Bs[BK32 * SB];
+  __shared__ __attribute__((aligned(16))) float lds[2 * 2 * kOpTile];  // [stage][A | B][64][SK]
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -163,67 +268,98 @@ gemm_f32_kernel(GemmArgs g) {
   const int kbeg = blockIdx.z * g.k_per_split;
   int kend = kbeg + g.k_per_split;
   if (kend > g.K) kend = g.K;
+  const int T = (kend - kbeg + BK32 - 1) / BK32;
   const bool a_vec = (g.lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0);
   const bool b_vec = (g.ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0);
-
-  // staging assignment: 64 x 32 elements = 512 float4 per operand -> 2 per thread
-  //   K_CONTIG : unit u -> row mn = u / 8, k4 = (u % 8) * 4      else: unit u -> k = u / 16, mn4 = (u % 16) * 4
-  f32x4v ra[2], rb[2];
-  auto fetch = [&](int k0) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int u = tid + i * kBlock;
-      if (A_KC) ra[i] = load4<true>(g.A, g.lda, m0 + (u >> 3), k0 + (u & 7) * 4, g.M, kend, a_vec);
-      else ra[i] = load4<false>(g.A, g.lda, m0 + (u & 15) * 4, k0 + (u >> 4), g.M, kend, a_vec);
-      if (B_KC) rb[i] = load4<true>(g.B, g.ldb, n0 + (u >> 3), k0 + (u & 7) * 4, g.N, kend, b_vec);
-      else rb[i] = load4<false>(g.B, g.ldb, n0 + (u & 15) * 4, k0 + (u >> 4), g.N, kend, b_vec);
-    }
-  };
-  auto stage = [&]() {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int u = tid + i * kBlock;
-      if (A_KC) {
-        const int mn = u >> 3, k4 = (u & 7) * 4;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) As[(k4 + j) * SA + mn] = ra[i][j];
-      } else {
-        *reinterpret_cast<f32x4v*>(&As[(u >> 4) * SA + (u & 15) * 4]) = ra[i];
-      }
-      if (B_KC) {
-        const int mn = u >> 3, k4 = (u & 7) * 4;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) Bs[(k4 + j) * SB + mn] = rb[i][j];
-      } else {
-        *reinterpret_cast<f32x4v*>(&Bs[(u >> 4) * SB + (u & 15) * 4]) = rb[i];
-      }
-    }
-  };
+  const bool rows_full = (m0 + BM <= g.M) && (n0 + BN <= g.N);
 
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-  const int a_off = wm * 32 + (lane & 31);
-  const int b_off = wn * 32 + (lane & 31);
   const int khalf = lane >> 5;
-  if (kbeg < kend) fetch(kbeg);
-  for (int k0 = kbeg; k0 < kend; k0 += BK32) {
-    __syncthreads();  // every wave is done reading the previous tile
-    stage();
-    __syncthreads();
-    if (k0 + BK32 < kend) fetch(k0 + BK32);  // in flight while the matrix cores run
+  const int fa = (wm * 32 + (lane & 31)) * SK + khalf * 16;
+  const int fb = kOpTile + (wn * 32 + (lane & 31)) * SK + khalf * 16;
+  auto contract = [&](const float* base, f32x4v (&a)[4], f32x4v (&b)[4]) {
 #pragma unroll
-    for (int kk = 0; kk < BK32; kk += 2) {
-      const float a = As[(kk + khalf) * SA + a_off];
-      const float b = Bs[(kk + khalf) * SB + b_off];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][i], b[q][i], acc, 0, 0, 0);
+  };
+  auto read_frags = [&](const float* base, f32x4v (&a)[4], f32x4v (&b)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      a[q] = *reinterpret_cast<const f32x4v*>(base + fa + 4 * q);
+      b[q] = *reinterpret_cast<const f32x4v*>(base + fb + 4 * q);
+    }
+  };
+
+  if (a_vec && b_vec) {
+    f32x4v ra0[2], rb0[2], ra1[2], rb1[2];
+    // k-tile indices past the end are clamped to the last tile: the loop body has the same loads every
+    // iteration (the compiler can then wait for exactly the older register set), the duplicate tile is never used
+    auto fetch = [&](f32x4v (&ra)[2], f32x4v (&rb)[2], int t) {
+      const int k0 = kbeg + (t < T ? t : T - 1) * BK32;
+      fetch_tile<A_KC>(g.A, g.lda, m0, g.M, k0, kend, g.K, tid, ra);
+      fetch_tile<B_KC>(g.B, g.ldb, n0, g.N, k0, kend, g.K, tid, rb);
+    };
+    auto stage = [&](int buf, const f32x4v (&ra)[2], const f32x4v (&rb)[2], int t) {
+      const int k0 = kbeg + t * BK32;  // unclamped: a tile past the end is masked to zero
+      const bool interior = rows_full && (k0 + BK32 <= kend);
+      stage_tile<A_KC>(lds + buf * 2 * kOpTile, tid, ra, interior, m0, g.M, k0, kend);
+      stage_tile<B_KC>(lds + buf * 2 * kOpTile + kOpTile, tid, rb, interior, n0, g.N, k0, kend);
+    };
+    // One step = one k-tile: read its fragments from LDS stage `buf`, issue the global loads of k-tile t + 2 into
+    // the register set that was written to LDS at the end of the previous step, contract, and - after three
+    // quarters of the MFMAs - write the OTHER register set (k-tile t + 1, loaded during the previous step) to the
+    // other LDS stage.  A global load has almost two k-tiles of matrix work to arrive.  Two steps per loop
+    // iteration so that each register set keeps its registers; an odd k-tile count is rounded up with an
+    // all-zero tile (masked in stage_tile).
+    auto step = [&](int buf, f32x4v (&fa_)[2], f32x4v (&fb_)[2], f32x4v (&sa)[2], f32x4v (&sb)[2], int t) {
+      const float* base = lds + buf * 2 * kOpTile;
+      f32x4v a[4], b[4];
+      read_frags(base, a, b);
+      fetch(fa_, fb_, t + 2);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][i], b[q][i], acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      stage(buf ^ 1, sa, sb, t + 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3][i], b[3][i], acc, 0, 0, 0);
+      __syncthreads();
+    };
+    fetch(ra0, rb0, 0);
+    fetch(ra1, rb1, 1);
+    stage(0, ra0, rb0, 0);
+    __syncthreads();
+    for (int t = 0; t < T; t += 2) {
+      step(0, ra0, rb0, ra1, rb1, t);
+      step(1, ra1, rb1, ra0, rb0, t + 1);
+    }
+  } else {
+    // unaligned operands (e.g. lda = 81): masked scalar loads, one k-tile at a time
+    f32x4v ra[2], rb[2];
+    for (int t = 0; t < T; ++t) {
+      const int k0 = kbeg + t * BK32;
+      fetch_tile_generic<A_KC>(g.A, g.lda, m0, g.M, k0, kend, tid, ra);
+      fetch_tile_generic<B_KC>(g.B, g.ldb, n0, g.N, k0, kend, tid, rb);
+      stage_tile<A_KC>(lds, tid, ra, true, m0, g.M, k0, kend);
+      stage_tile<B_KC>(lds + kOpTile, tid, rb, true, n0, g.N, k0, kend);
+      __syncthreads();
+      f32x4v a[4], b[4];
+      read_frags(lds, a, b);
+      contract(lds, a, b);
+      __syncthreads();
     }
   }
   // epilogue.  C/D map of the 32x32 tile: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
   const int col = n0 + wn * 32 + (lane & 31);
   const float bv = (g.bias && g.splits == 1 && col < g.N) ? g.bias[col] : 0.f;
   if (g.col_stats)  // (host guarantees splits == 1) every thread takes part: it synchronises the workgroup
-    tile_col_stats(acc, bv, m0 + wm * 32, g.M, col, g.N, wm, wn, lane, As,
+    tile_col_stats(acc, bv, m0 + wm * 32, g.M, col, g.N, wm, wn, lane, lds,
                    g.col_stats + static_cast<int64_t>(ty) * g.N * 3);
   if (col >= g.N) return;
   float* Cz = g.C + (g.splits > 1 ? static_cast<int64_t>(blockIdx.z) * g.M * g.N : 0);

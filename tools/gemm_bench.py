@@ -18,8 +18,12 @@ for k, n in layers:
   shapes.append(('NN fwd', kernels.GEMM_NN, (B, k), (k, n)))
   shapes.append(('NT dx ', kernels.GEMM_NT, (B, n), (k, n)))
   shapes.append(('TN dW ', kernels.GEMM_TN, (B, k), (B, n)))
+only = [int(x) for x in sys.argv[1].split(',')] if len(sys.argv) > 1 else None  # indices into the shape list
+f32_only = len(sys.argv) > 2
 tot = {False: 0.0, True: 0.0}
-for name, layout, sa, sb in shapes:
+for si, (name, layout, sa, sb) in enumerate(shapes):
+  if only is not None and si not in only:
+    continue
   a, b = torch.randn(sa, device=dev), torch.randn(sb, device=dev)
   if layout == kernels.GEMM_NN:
     M, N, K = sa[0], sb[1], sa[1]
@@ -28,7 +32,7 @@ for name, layout, sa, sb in shapes:
   else:
     M, N, K = sa[1], sb[1], sa[0]
   line = '%s M=%5d N=%4d K=%5d ' % (name, M, N, K)
-  for bf16 in (False, True):
+  for bf16 in ((False,) if f32_only else (False, True)):
     for _ in range(5):
       be.gemm(layout, a, b, bf16=bf16)
     torch.cuda.synchronize()
