@@ -88,10 +88,9 @@ __device__ __forceinline__ short f32_to_bf16_rne(float f) {
 // (MI355X_MICROARCH.md); the column tiles of one row of tiles all read the same 64 rows of A.  Tiles are
 // therefore numbered so that consecutive tiles (same tile row, x fastest) go to the SAME XCD: XCD c owns tiles
 // [c * per, (c + 1) * per), and A's rows are fetched into one L2 instead of up to N/64 of them.
-__device__ __forceinline__ bool tile_coords(int gx, int gy, int& tx, int& ty) {
+__device__ __forceinline__ bool tile_coords(int b, int gx, int gy, int& tx, int& ty) {
   const int nt = gx * gy;
   const int per = (nt + 7) / 8;
-  const int b = blockIdx.x;
   const int t = (b % 8) * per + b / 8;
   if (t >= nt) return false;
   tx = t % gx;
@@ -255,17 +254,16 @@ __device__ __forceinline__ void stage_tile(float* __restrict__ S, int tid, const
   }
 }
 
+// bx: index of the workgroup among the problem's (8-rounded) tiles, bz: its k-split
 template <bool A_KC, bool B_KC>
-__global__ void __launch_bounds__(kBlock)
-gemm_f32_kernel(GemmArgs g) {
-  __shared__ __attribute__((aligned(16))) float lds[2 * 2 * kOpTile];  // [stage][A | B][64][SK]
+__device__ __forceinline__ void gemm_f32_block(const GemmArgs& g, int bx, int bz, float* __restrict__ lds) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   int tx, ty;
-  if (!tile_coords(static_cast<int>(ceil_div(g.N, BN)), static_cast<int>(ceil_div(g.M, BM)), tx, ty)) return;
+  if (!tile_coords(bx, static_cast<int>(ceil_div(g.N, BN)), static_cast<int>(ceil_div(g.M, BM)), tx, ty)) return;
   const int m0 = ty * BM, n0 = tx * BN;
-  const int kbeg = blockIdx.z * g.k_per_split;
+  const int kbeg = bz * g.k_per_split;
   int kend = kbeg + g.k_per_split;
   if (kend > g.K) kend = g.K;
   const int T = (kend - kbeg + BK32 - 1) / BK32;
@@ -362,7 +360,7 @@ gemm_f32_kernel(GemmArgs g) {
     tile_col_stats(acc, bv, m0 + wm * 32, g.M, col, g.N, wm, wn, lane, lds,
                    g.col_stats + static_cast<int64_t>(ty) * g.N * 3);
   if (col >= g.N) return;
-  float* Cz = g.C + (g.splits > 1 ? static_cast<int64_t>(blockIdx.z) * g.M * g.N : 0);
+  float* Cz = g.C + (g.splits > 1 ? static_cast<int64_t>(bz) * g.M * g.N : 0);
   const int ldc = g.splits > 1 ? g.N : g.ldc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -374,6 +372,36 @@ gemm_f32_kernel(GemmArgs g) {
       *p = v;
     }
   }
+}
+
+template <bool A_KC, bool B_KC>
+__global__ void __launch_bounds__(kBlock)
+gemm_f32_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * 2 * kOpTile];  // [stage][A | B][64][SK]
+  gemm_f32_block<A_KC, B_KC>(g, blockIdx.x, blockIdx.z, lds);
+}
+
+// Grouped launch: up to kMaxGroup independent problems of one layout in ONE grid (the weight gradients of all
+// layers of a step: each is a small M x N with K = batch, far too few tiles to fill 256 CUs on its own).
+// Workgroups [start[p], start[p+1]) belong to problem p: tile = local % tiles8, k-split = local / tiles8
+// (tiles8 is a multiple of 8, so the XCD a tile lands on is the same as in a single launch).
+constexpr int kMaxGroup = 16;
+struct GroupedArgs {
+  int n;
+  int start[kMaxGroup + 1];
+  int tiles8[kMaxGroup];
+  GemmArgs p[kMaxGroup];
+};
+
+template <bool A_KC, bool B_KC>
+__global__ void __launch_bounds__(kBlock)
+gemm_f32_grouped_kernel(GroupedArgs ga) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * 2 * kOpTile];
+  const int b = blockIdx.x;
+  int p = 0;
+  while (p + 1 < ga.n && b >= ga.start[p + 1]) ++p;
+  const int local = b - ga.start[p];
+  gemm_f32_block<A_KC, B_KC>(ga.p[p], local % ga.tiles8[p], local / ga.tiles8[p], lds);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -391,7 +419,7 @@ gemm_bf16_kernel(GemmArgs g) {
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   int tx, ty;
-  if (!tile_coords(static_cast<int>(ceil_div(g.N, BN)), static_cast<int>(ceil_div(g.M, BM)), tx, ty)) return;
+  if (!tile_coords(blockIdx.x, static_cast<int>(ceil_div(g.N, BN)), static_cast<int>(ceil_div(g.M, BM)), tx, ty)) return;
   const int m0 = ty * BM, n0 = tx * BN;
   const int kbeg = blockIdx.z * g.k_per_split;
   int kend = kbeg + g.k_per_split;
@@ -466,10 +494,9 @@ gemm_bf16_kernel(GemmArgs g) {
 // C[i, j] (+)= bias[j] + sum_s ws[s, i, j]   (split order fixed: deterministic).  VEC = 4: float4 per lane, the
 // `splits` loads of a lane are independent and unrolled by 4.
 template <int VEC>
-__global__ void __launch_bounds__(kBlock)
-gemm_splitk_reduce_kernel(const float* __restrict__ ws, int64_t mn, int N, int splits, const float* __restrict__ bias,
-                          float* __restrict__ C, int ldc, int accumulate) {
-  const int64_t i = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) * VEC;
+__device__ __forceinline__ void splitk_reduce_elems(const float* __restrict__ ws, int64_t mn, int N, int splits,
+                                                    const float* __restrict__ bias, float* __restrict__ C, int ldc,
+                                                    int accumulate, int64_t i) {
   if (i >= mn) return;
   float s[VEC];
 #pragma unroll
@@ -493,6 +520,40 @@ gemm_splitk_reduce_kernel(const float* __restrict__ ws, int64_t mn, int N, int s
     if (bias) v = v + bias[col + j];
     p[j] = accumulate ? p[j] + v : v;
   }
+}
+
+template <int VEC>
+__global__ void __launch_bounds__(kBlock)
+gemm_splitk_reduce_kernel(const float* __restrict__ ws, int64_t mn, int N, int splits, const float* __restrict__ bias,
+                          float* __restrict__ C, int ldc, int accumulate) {
+  splitk_reduce_elems<VEC>(ws, mn, N, splits, bias, C, ldc, accumulate,
+                           (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) * VEC);
+}
+
+// the reduces of a grouped launch in one grid: workgroups [start[p], start[p+1]) own the output of item p
+struct ReduceItem {
+  const float* ws;
+  int64_t mn;
+  int N, splits;
+  const float* bias;
+  float* C;
+  int ldc, accumulate;
+};
+struct GroupedReduceArgs {
+  int n;
+  int start[kMaxGroup + 1];
+  ReduceItem r[kMaxGroup];
+};
+
+template <int VEC>
+__global__ void __launch_bounds__(kBlock)
+gemm_splitk_reduce_grouped_kernel(GroupedReduceArgs ra) {
+  const int b = blockIdx.x;
+  int p = 0;
+  while (p + 1 < ra.n && b >= ra.start[p + 1]) ++p;
+  const ReduceItem& r = ra.r[p];
+  splitk_reduce_elems<VEC>(r.ws, r.mn, r.N, r.splits, r.bias, r.C, r.ldc, r.accumulate,
+                           (static_cast<int64_t>(b - ra.start[p]) * kBlock + threadIdx.x) * VEC);
 }
 
 }  // namespace er
@@ -585,6 +646,91 @@ int gemm_entry(int layout, int M, int N, int K, const float* A, int lda, const f
   return launch_gemm<BF16>(layout, a, s);
 }
 
+int gemm_grouped_f32(int layout, const er_gemm_problem* pr, int n, er_stream_t stream) {
+  hipStream_t s = er::as_stream(stream);
+  int64_t total_tiles = 0;
+  for (int i = 0; i < n; ++i) {
+    const er_gemm_problem& q = pr[i];
+    ER_REQUIRE(q.A && q.B && q.C && q.M > 0 && q.N > 0 && q.K > 0, "er_gemm_grouped_f32: problem %d: bad arguments", i);
+    const int min_lda = (layout == ER_GEMM_TN) ? q.M : q.K;
+    const int min_ldb = (layout == ER_GEMM_NT) ? q.K : q.N;
+    ER_REQUIRE(q.lda >= min_lda && q.ldb >= min_ldb && q.ldc >= q.N,
+               "er_gemm_grouped_f32: problem %d: leading dimension too small", i);
+    total_tiles += er::ceil_div(q.M, er::BM) * er::ceil_div(q.N, er::BN);
+  }
+  // k-splits: enough workgroups for ~4 per CU over the whole group, at least 4 k-tiles per split
+  int64_t want = total_tiles >= 1024 ? 1 : er::ceil_div(1024, total_tiles);
+  if (want > 64) want = 64;
+  er::GroupedArgs ga;
+  er::GroupedReduceArgs ra;
+  ga.n = n;
+  ga.start[0] = 0;
+  ra.n = 0;
+  ra.start[0] = 0;
+  size_t ws_floats = 0;
+  bool vec_ok = true;
+  for (int i = 0; i < n; ++i) {
+    const er_gemm_problem& q = pr[i];
+    er::GemmArgs& a = ga.p[i];
+    a.A = q.A; a.B = q.B; a.C = q.C; a.bias = q.bias;
+    a.M = q.M; a.N = q.N; a.K = q.K; a.lda = q.lda; a.ldb = q.ldb; a.ldc = q.ldc;
+    a.accumulate = q.accumulate;
+    a.col_stats = nullptr;
+    int64_t sp = want;
+    const int64_t max_by_k = q.K / (4 * er::BK32);
+    if (sp > max_by_k) sp = max_by_k;
+    if (sp < 1) sp = 1;
+    a.k_per_split = static_cast<int>(er::ceil_div(er::ceil_div(q.K, sp), er::BK32)) * er::BK32;
+    a.splits = static_cast<int>(er::ceil_div(q.K, a.k_per_split));
+    const int64_t tiles = er::ceil_div(q.M, er::BM) * er::ceil_div(q.N, er::BN);
+    ga.tiles8[i] = static_cast<int>(8 * er::ceil_div(tiles, 8));
+    ga.start[i + 1] = ga.start[i] + ga.tiles8[i] * a.splits;
+    if (a.splits > 1) {
+      const int64_t mn = static_cast<int64_t>(q.M) * q.N;
+      er::ReduceItem& r = ra.r[ra.n];
+      r.ws = reinterpret_cast<const float*>(ws_floats);  // offset for now: the base is known after ensure_ws
+      r.mn = mn; r.N = q.N; r.splits = a.splits; r.bias = q.bias; r.C = q.C; r.ldc = q.ldc; r.accumulate = q.accumulate;
+      if (!(q.N % 4 == 0 && q.ldc % 4 == 0 && (reinterpret_cast<uintptr_t>(q.C) & 15) == 0)) vec_ok = false;
+      a.C = reinterpret_cast<float*>(ws_floats);
+      ws_floats += static_cast<size_t>(a.splits) * mn;
+      ws_floats = (ws_floats + 3) & ~static_cast<size_t>(3);
+      ++ra.n;
+    }
+  }
+  if (ra.n > 0) {
+    float* ws;
+    if (int rc = ensure_ws(ws_floats, &ws)) return rc;
+    int k = 0;
+    for (int i = 0; i < n; ++i) {
+      if (ga.p[i].splits > 1) {
+        const size_t off = reinterpret_cast<size_t>(ga.p[i].C);
+        ga.p[i].C = ws + off;
+        ra.r[k].ws = ws + off;
+        ++k;
+      }
+    }
+    for (int j = 0; j < ra.n; ++j) {
+      const int64_t units = vec_ok ? ra.r[j].mn / 4 : ra.r[j].mn;
+      ra.start[j + 1] = ra.start[j] + static_cast<int>(er::ceil_div(units, er::kBlock));
+    }
+  }
+  dim3 grid(static_cast<unsigned>(ga.start[n])), block(er::kBlock);
+  switch (layout) {
+    case ER_GEMM_NN: hipLaunchKernelGGL((er::gemm_f32_grouped_kernel<true, false>), grid, block, 0, s, ga); break;
+    case ER_GEMM_NT: hipLaunchKernelGGL((er::gemm_f32_grouped_kernel<true, true>), grid, block, 0, s, ga); break;
+    case ER_GEMM_TN: hipLaunchKernelGGL((er::gemm_f32_grouped_kernel<false, false>), grid, block, 0, s, ga); break;
+    default: er::set_error("er_gemm_grouped_f32: unknown layout %d", layout); return 2;
+  }
+  ER_LAUNCH_CHECK();
+  if (ra.n > 0) {
+    dim3 rgrid(static_cast<unsigned>(ra.start[ra.n]));
+    if (vec_ok) hipLaunchKernelGGL(er::gemm_splitk_reduce_grouped_kernel<4>, rgrid, block, 0, s, ra);
+    else hipLaunchKernelGGL(er::gemm_splitk_reduce_grouped_kernel<1>, rgrid, block, 0, s, ra);
+    ER_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -603,6 +749,16 @@ int er_gemm_f32(int layout, int32_t M, int32_t N, int32_t K, const float* A, int
 int er_gemm_bf16(int layout, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B, int32_t ldb,
                  float* C, int32_t ldc, const float* bias, int accumulate, float* col_stats, er_stream_t stream) {
   return gemm_entry<true>(layout, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, col_stats, stream, "er_gemm_bf16");
+}
+
+int er_gemm_grouped_f32(int layout, const er_gemm_problem* problems, int n, er_stream_t stream) {
+  ER_REQUIRE(problems && n > 0, "er_gemm_grouped_f32: bad arguments");
+  ER_REQUIRE(layout >= ER_GEMM_NN && layout <= ER_GEMM_TN, "er_gemm_grouped_f32: unknown layout %d", layout);
+  for (int i = 0; i < n; i += er::kMaxGroup) {
+    const int m = n - i < er::kMaxGroup ? n - i : er::kMaxGroup;
+    if (int rc = gemm_grouped_f32(layout, problems + i, m, stream)) return rc;
+  }
+  return 0;
 }
 
 int er_gemm_row_tiles(int32_t M) { return static_cast<int>(er::ceil_div(M, er::BM)); }

@@ -7,6 +7,7 @@ include/easyrec_hip.h); here the same Python call sites call hand-written gfx950
 library has not been built or no MI355X is visible - there is no CPU fallback in this package.
 """
 import ctypes
+import threading
 import os
 from dataclasses import dataclass
 from typing import Optional
@@ -46,6 +47,29 @@ class LookupDesc(ctypes.Structure):
 # er_opt_hyper: 16 floats
 HYPER_FLOATS = 16
 HYPER_LR, HYPER_LR_T, HYPER_BETA1, HYPER_BETA2, HYPER_OMB1, HYPER_OMB2, HYPER_EPS, HYPER_GSCALE = range(8)
+
+
+_wgrad_tls = threading.local()
+
+
+class WgradSink(object):
+  """Weight gradients queued during one backward pass (HipBackend.defer_wgrads / flush_wgrads)."""
+
+  def __init__(self):
+    self.active = False
+    self.queue = []
+
+  def put(self, x, dy, out, bf16):
+    if not self.active or bf16:
+      return False
+    self.queue.append((x, dy, out, None, True))
+    return True
+
+
+class GemmProblem(ctypes.Structure):  # = er_gemm_problem
+  _fields_ = [('M', ctypes.c_int32), ('N', ctypes.c_int32), ('K', ctypes.c_int32), ('A', ctypes.c_void_p),
+              ('lda', ctypes.c_int32), ('B', ctypes.c_void_p), ('ldb', ctypes.c_int32), ('C', ctypes.c_void_p),
+              ('ldc', ctypes.c_int32), ('bias', ctypes.c_void_p), ('accumulate', ctypes.c_int32)]
 
 
 def same_lookup_keys(group, leader):
@@ -295,6 +319,46 @@ class HipBackend(object):
                 _p(out), ctypes.c_int32(out.stride(0)), _p(bias), int(bool(accumulate)), _p(col_stats), _stream()),
              'er_gemm')
     return out
+
+  def gemm_grouped(self, layout, problems):
+    """problems: [(a, b, out, bias, accumulate)] fp32, one layout: ONE launch (+ one for the split-K reduces)."""
+    arr = (GemmProblem * len(problems))()
+    for q, (a, b, out, bias, accumulate) in zip(arr, problems):
+      assert a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1 and out.stride(1) == 1
+      assert a.dtype == torch.float32 and b.dtype == torch.float32 and out.dtype == torch.float32
+      if layout == GEMM_NN:
+        (M, K), (K2, N) = a.shape, b.shape
+      elif layout == GEMM_NT:
+        (M, K), (N, K2) = a.shape, b.shape
+      else:
+        (K, M), (K2, N) = a.shape, b.shape
+      assert K == K2 and out.shape == (M, N)
+      q.M, q.N, q.K = M, N, K
+      q.A, q.lda, q.B, q.ldb = a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0)
+      q.C, q.ldc = out.data_ptr(), out.stride(0)
+      q.bias = bias.data_ptr() if bias is not None else None
+      q.accumulate = int(bool(accumulate))
+    self._ck(self.lib.er_gemm_grouped_f32(ctypes.c_int(layout), arr, len(problems), _stream()), 'er_gemm_grouped_f32')
+
+  # weight gradients of a backward pass: queued by LinearFn / LinearBNActFn, contracted together by flush_wgrads()
+  def wgrad_sink(self):
+    """The calling thread's queue object.  Functions fetch it in forward() (the caller's thread: the simulated ranks
+    of the embedding-parallel tests are threads) because backward() runs on an autograd engine thread."""
+    sink = getattr(_wgrad_tls, 'sink', None)
+    if sink is None:
+      sink = _wgrad_tls.sink = WgradSink()
+    return sink
+
+  def defer_wgrads(self):
+    sink = self.wgrad_sink()
+    assert not sink.queue, 'flush_wgrads() was not called for the previous backward pass'
+    sink.active = True
+
+  def flush_wgrads(self):
+    sink = self.wgrad_sink()
+    q, sink.queue, sink.active = sink.queue, [], False
+    if q:
+      self.gemm_grouped(GEMM_TN, q)
 
   # -- K12 embedding-parallel routing (include/easyrec_hip.h)
   def emb_group_set_routing(self, group, world, shard_stride, local_base):
@@ -640,6 +704,7 @@ class LinearFn(torch.autograd.Function):
     ctx.save_for_backward(x2, w)
     ctx.has_bias = b is not None
     ctx.w_grad, ctx.b_grad, ctx.bf16 = w_grad, b_grad, bf16
+    ctx.sink = be.wgrad_sink()
     return y
 
   @staticmethod
@@ -652,7 +717,8 @@ class LinearFn(torch.autograd.Function):
       dx = be.gemm(GEMM_NT, dy, w, bf16=ctx.bf16)
     if ctx.needs_input_grad[1]:
       if ctx.w_grad is not None:
-        be.gemm(GEMM_TN, x, dy, out=ctx.w_grad, accumulate=True, bf16=ctx.bf16)
+        if not ctx.sink.put(x, dy, ctx.w_grad, ctx.bf16):
+          be.gemm(GEMM_TN, x, dy, out=ctx.w_grad, accumulate=True, bf16=ctx.bf16)
       else:
         dw = be.gemm(GEMM_TN, x, dy, bf16=ctx.bf16)
     if ctx.has_bias and ctx.needs_input_grad[2]:
@@ -683,6 +749,7 @@ class LinearBNActFn(torch.autograd.Function):
                                              moving_var, act)
     ctx.save_for_backward(x2, w, gamma, z, y, mean, invstd)
     ctx.act, ctx.bf16, ctx.grad_bufs = act, bf16, grad_bufs
+    ctx.sink = be.wgrad_sink()
     return y
 
   @staticmethod
@@ -698,7 +765,8 @@ class LinearBNActFn(torch.autograd.Function):
       dx = be.gemm(GEMM_NT, dz, w, bf16=ctx.bf16)
     if ctx.needs_input_grad[1]:
       if wg is not None:
-        be.gemm(GEMM_TN, x, dz, out=wg, accumulate=True, bf16=ctx.bf16)
+        if not ctx.sink.put(x, dz, wg, ctx.bf16):
+          be.gemm(GEMM_TN, x, dz, out=wg, accumulate=True, bf16=ctx.bf16)
       else:
         dw = be.gemm(GEMM_TN, x, dz, bf16=ctx.bf16)
     return dx, dw, None, dgamma, dbeta, None, None, None, None, None, None, None

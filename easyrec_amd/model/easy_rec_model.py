@@ -17,6 +17,7 @@ from abc import abstractmethod
 import six
 import torch
 
+from easyrec_amd import kernels
 from easyrec_amd.core import context
 from easyrec_amd.layers import input_layer
 from easyrec_amd.utils import constant
@@ -154,7 +155,12 @@ class EasyRecModel(six.with_metaclass(_meta_type, object)):
       return
     tensors = [t for t, _ in self._backward_seeds]
     grads = [g.reshape(t.shape) for t, g in self._backward_seeds]
-    torch.autograd.backward(tensors, grads)
+    be = kernels.hip()
+    be.defer_wgrads()  # the layers' weight gradients (x^T . dz, K = batch) are contracted in one grouped launch
+    try:
+      torch.autograd.backward(tensors, grads)
+    finally:
+      be.flush_wgrads()
 
   def get_grouped_vars(self, opt_num):
     assert opt_num == 2, 'could only support 2 optimizers, one for embedding, one for the other layers'

@@ -374,6 +374,21 @@ int er_mmoe_mix_bwd(const float* experts, const float* gates, const float* dout,
 enum { ER_GEMM_NN = 0, ER_GEMM_NT = 1, ER_GEMM_TN = 2 };
 int er_gemm_reserve(int64_t floats);
 int er_gemm_row_tiles(int32_t M);
+/* Grouped launch: n independent fp32 problems of ONE layout in one grid (+ one grid for their split-K reduces).
+ * The use: the weight gradients dW_l = x_l^T . dz_l of every dense layer of a step (reference: the MatMul
+ * gradients TF schedules for layers/dnn.py:57-62, one per layer) - each a small M x N with K = batch - queued
+ * during the backward pass and contracted together once it is over.  Same kernel body as er_gemm_f32; the
+ * k-split of a problem (hence its summation order) is a fixed function of the group's shapes; no column
+ * statistics. */
+typedef struct er_gemm_problem {
+  int32_t M, N, K;
+  const float* A; int32_t lda;
+  const float* B; int32_t ldb;
+  float* C; int32_t ldc;
+  const float* bias;
+  int32_t accumulate;
+} er_gemm_problem;
+int er_gemm_grouped_f32(int layout, const er_gemm_problem* problems_host, int n, er_stream_t stream);
 int er_gemm_f32(int layout, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B,
                 int32_t ldb, float* C, int32_t ldc, const float* bias, int accumulate, float* col_stats,
                 er_stream_t stream);

@@ -377,6 +377,17 @@ class RefBackend(object):
       base += s.max_nnz if s.offsets is not None else s.n_rows
     return ents
 
+  # grouped weight-gradient launch of the HIP backend: the reference contracts every layer on its own
+  def defer_wgrads(self):
+    pass
+
+  def wgrad_sink(self):
+    from easyrec_amd.kernels import WgradSink
+    return WgradSink()  # never active: every gradient is computed where it arises
+
+  def flush_wgrads(self):
+    pass
+
   def emb_group_share_sort(self, group, leader):
     from easyrec_amd.kernels import same_lookup_keys
     if not same_lookup_keys(group, leader):

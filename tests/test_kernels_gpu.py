@@ -760,3 +760,30 @@ def test_shared_sort_between_wide_and_deep_groups(hip, lazy):
     for a, b, what in zip(results[False][dim], results[True][dim], ('var', 'm', 'v')):
       assert torch.equal(a, b), (dim, what)
   assert float(results[True][16][1].abs().max()) > 0
+
+
+def test_gemm_grouped_matches_single_launches(hip):
+  """The weight gradients of a step in ONE grouped launch (er_gemm_grouped_f32): every problem within the f32 bound of
+  an fp64 matmul, accumulate honoured, bit-identical across launches; > 16 problems are chunked."""
+  g = torch.Generator().manual_seed(7)
+  shapes = [(624, 256, 4096), (256, 128, 4096), (128, 64, 4096), (81, 256, 4096), (64, 1, 4096), (33, 65, 97),
+            (1, 1, 1), (130, 72, 1000)] * 3  # 24 problems
+  probs, refs, bases = [], [], []
+  for (M, N, K) in shapes:
+    a, b = torch.randn(K, M, generator=g), torch.randn(K, N, generator=g)
+    base = torch.randn(M, N, generator=g)
+    out = base.to(DEV)
+    probs.append((a.to(DEV), b.to(DEV), out, None, True))
+    refs.append(((a.double().t() @ b.double()), (a.double().abs().t() @ b.double().abs()) * 1e-6 + 1e-5))
+    bases.append(base)
+  hip.gemm_grouped(kernels.GEMM_TN, probs)
+  torch.cuda.synchronize()
+  first = [p[2].clone() for p in probs]
+  for (ref, bound), base, got in zip(refs, bases, first):
+    assert ((got.cpu().double() - (base.double() + ref)).abs() <= bound).all()
+  for p, base in zip(probs, bases):
+    p[2].copy_(base.to(DEV))
+  hip.gemm_grouped(kernels.GEMM_TN, probs)
+  torch.cuda.synchronize()
+  for p, f in zip(probs, first):
+    assert torch.equal(p[2], f)
