@@ -666,6 +666,19 @@ int er_bn_act_bwd(const float* x, const float* bias, const float* gamma, const f
   return 0;
 }
 
+int er_bn_act_bwd_from_partials(const float* x, const float* bias, const float* gamma, const float* y,
+                                const float* save_mean, const float* save_invstd, const float* dy, int32_t B, int32_t N,
+                                int use_bn, int act, const float* partial, int32_t chunks, float* dx, float* dbias,
+                                float* dgamma, float* dbeta, int accumulate, er_stream_t stream) {
+  ER_REQUIRE(x && y && dy && dx && partial && B > 0 && N > 0 && chunks > 0, "er_bn_act_bwd_from_partials: bad arguments");
+  dim3 grid2(static_cast<unsigned>(er::ceil_div(N, er::kColsPerBlock)),
+             static_cast<unsigned>(er::ceil_div(B, er::kApplyRows)));
+  hipLaunchKernelGGL(er::bn_bwd_finalize_apply_kernel, grid2, dim3(er::kBlock), 0, er::as_stream(stream), partial, x, bias,
+                     gamma, y, save_mean, save_invstd, dy, B, N, chunks, use_bn, act, accumulate, dx, dbias, dgamma, dbeta);
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
 int er_colsum(const float* x, int32_t rows, int32_t cols, int32_t x_stride, float* out, er_stream_t stream) {
   ER_REQUIRE(x && out && rows > 0 && cols > 0, "er_colsum: bad arguments");
   hipStream_t s = er::as_stream(stream);

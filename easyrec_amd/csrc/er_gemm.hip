@@ -34,6 +34,19 @@ constexpr int BM = 64, BN = 64;
 constexpr int BK32 = 32;   // k-tile of the f32 kernel
 constexpr int BK16 = 32;   // k-tile of the bf16 kernel (two 32x32x16 steps)
 
+// Optional epilogue of the dgrad GEMM dy = dz_next . W_next^T: the per-row-tile column sums the BatchNorm
+// backward of the layer that produced y needs (sum g, sum g * xhat with g = dy masked by the activation), i.e.
+// the output of bn_bwd_partial_kernel without another pass over dy / y / z.
+struct BnBwdEpi {
+  const float* z = nullptr;       // pre-normalisation values of the producing layer [M][ld] (its GEMM output)
+  const float* zbias = nullptr;   // bias added to z (nullptr: already included)
+  const float* y = nullptr;       // its activation output [M][ld]
+  const float* mean = nullptr;
+  const float* invstd = nullptr;
+  int ld = 0, use_bn = 0, act = 0;
+  float* partial = nullptr;       // [row tiles][N][2]
+};
+
 struct GemmArgs {
   const float* A;
   const float* B;
@@ -45,6 +58,7 @@ struct GemmArgs {
   int k_per_split;    // multiple of the k-tile
   int splits;
   float* col_stats;   // nullptr, or [gridDim.y][N][3] Welford (count, mean, M2) of the output columns per row tile
+  BnBwdEpi bn;        // bn.partial != nullptr: emit the BatchNorm-backward column sums of the output tile
 };
 
 // Loads 4 consecutive elements along the CONTIGUOUS dimension of the operand tile.
@@ -140,6 +154,42 @@ __device__ __forceinline__ void tile_col_stats(const f32x16& acc, float bv, int 
     chan_merge(an, am, a2, slot[0], slot[1], slot[2]);
     float* o = out_tile + static_cast<int64_t>(col) * 3;
     o[0] = an; o[1] = am; o[2] = a2;
+  }
+}
+
+// BatchNorm-backward column sums of a 64-row output tile (see BnBwdEpi).  Fixed order: a lane's 16 rows in
+// register order, then the lane pair (l, l ^ 32), then the two waves that share the columns.
+__device__ __forceinline__ void tile_bn_bwd_partial(const f32x16& acc, const BnBwdEpi& e, const float (&py)[16],
+                                                    const float (&pz)[16], int row_base, int M, int col, int N, int wm,
+                                                    int wn, int lane, float* lds, int ty) {
+  const int khalf = lane >> 5;
+  float sg = 0.f, sgx = 0.f;
+  if (col < N) {
+    const float bv = e.zbias ? e.zbias[col] : 0.f;
+    const float mu = e.use_bn ? e.mean[col] : 0.f;
+    const float is = e.use_bn ? e.invstd[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = row_base + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+      if (row < M) {
+        float g = acc[r];
+        if (e.act == ER_ACT_RELU && !(py[r] > 0.f)) g = 0.f;
+        sg = sg + g;
+        if (e.use_bn) sgx = sgx + g * ((pz[r] + bv - mu) * is);
+      }
+    }
+  }
+  const float og = __shfl_xor(sg, 32, 64), ogx = __shfl_xor(sgx, 32, 64);
+  const float a = (khalf ? og : sg) + (khalf ? sg : og);
+  const float ax = (khalf ? ogx : sgx) + (khalf ? sgx : ogx);
+  __syncthreads();  // LDS operand tiles are dead
+  float* slot = lds + (wn * 32 + (lane & 31)) * 2;
+  if (wm == 1 && khalf == 0) { slot[0] = a; slot[1] = ax; }
+  __syncthreads();
+  if (wm == 0 && khalf == 0 && col < N) {
+    float* p = e.partial + (static_cast<int64_t>(ty) * N + col) * 2;
+    p[0] = a + slot[0];
+    p[1] = ax + slot[1];
   }
 }
 
@@ -254,8 +304,10 @@ __device__ __forceinline__ void stage_tile(float* __restrict__ S, int tid, const
   }
 }
 
-// bx: index of the workgroup among the problem's (8-rounded) tiles, bz: its k-split
-template <bool A_KC, bool B_KC>
+// bx: index of the workgroup among the problem's (8-rounded) tiles, bz: its k-split.  BN_EPI: with the BnBwdEpi
+// epilogue - the y / z values of the lane's 16 output positions are requested BEFORE the k loop so that their
+// latency hides behind it (32 more VGPRs: a separate instantiation).
+template <bool A_KC, bool B_KC, bool BN_EPI = false>
 __device__ __forceinline__ void gemm_f32_block(const GemmArgs& g, int bx, int bz, float* __restrict__ lds) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -267,6 +319,19 @@ __device__ __forceinline__ void gemm_f32_block(const GemmArgs& g, int bx, int bz
   int kend = kbeg + g.k_per_split;
   if (kend > g.K) kend = g.K;
   const int T = (kend - kbeg + BK32 - 1) / BK32;
+  float py[16], pz[16];
+  if (BN_EPI) {
+    int c = n0 + wn * 32 + (lane & 31);
+    c = c < g.N ? c : g.N - 1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      row = row < g.M ? row : g.M - 1;
+      const int64_t i = static_cast<int64_t>(row) * g.bn.ld + c;
+      py[r] = g.bn.y[i];
+      pz[r] = g.bn.z[i];
+    }
+  }
   const bool a_vec = (g.lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0);
   const bool b_vec = (g.ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0);
   const bool rows_full = (m0 + BM <= g.M) && (n0 + BN <= g.N);
@@ -359,6 +424,7 @@ __device__ __forceinline__ void gemm_f32_block(const GemmArgs& g, int bx, int bz
   if (g.col_stats)  // (host guarantees splits == 1) every thread takes part: it synchronises the workgroup
     tile_col_stats(acc, bv, m0 + wm * 32, g.M, col, g.N, wm, wn, lane, lds,
                    g.col_stats + static_cast<int64_t>(ty) * g.N * 3);
+  if (BN_EPI) tile_bn_bwd_partial(acc, g.bn, py, pz, m0 + wm * 32, g.M, col, g.N, wm, wn, lane, lds, ty);
   if (col >= g.N) return;
   float* Cz = g.C + (g.splits > 1 ? static_cast<int64_t>(bz) * g.M * g.N : 0);
   const int ldc = g.splits > 1 ? g.N : g.ldc;
@@ -379,6 +445,13 @@ __global__ void __launch_bounds__(kBlock)
 gemm_f32_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) float lds[2 * 2 * kOpTile];  // [stage][A | B][64][SK]
   gemm_f32_block<A_KC, B_KC>(g, blockIdx.x, blockIdx.z, lds);
+}
+
+template <bool A_KC, bool B_KC>
+__global__ void __launch_bounds__(kBlock)
+gemm_f32_bn_bwd_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * 2 * kOpTile];
+  gemm_f32_block<A_KC, B_KC, true>(g, blockIdx.x, 0, lds);
 }
 
 // Grouped launch: up to kMaxGroup independent problems of one layout in ONE grid (the weight gradients of all
@@ -590,6 +663,8 @@ int launch_gemm(int layout, er::GemmArgs& a, hipStream_t s) {
   }
   if (BF16) {
     ER_LAUNCH_GEMM(er::gemm_bf16_kernel)
+  } else if (a.bn.partial) {
+    ER_LAUNCH_GEMM(er::gemm_f32_bn_bwd_kernel)
   } else {
     ER_LAUNCH_GEMM(er::gemm_f32_kernel)
   }
@@ -610,7 +685,8 @@ int choose_splits(int M, int N, int K, int ktile) {
 
 template <bool BF16>
 int gemm_entry(int layout, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
-               const float* bias, int accumulate, float* col_stats, er_stream_t stream, const char* who) {
+               const float* bias, int accumulate, float* col_stats, er_stream_t stream, const char* who,
+               const er::BnBwdEpi* bn = nullptr) {
   ER_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0, "%s: bad arguments", who);
   ER_REQUIRE(layout >= ER_GEMM_NN && layout <= ER_GEMM_TN, "%s: unknown layout %d", who, layout);
   const int min_lda = (layout == ER_GEMM_TN) ? M : K;
@@ -623,7 +699,8 @@ int gemm_entry(int layout, int M, int N, int K, const float* A, int lda, const f
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
   a.accumulate = accumulate;
   a.col_stats = col_stats;
-  a.splits = col_stats ? 1 : choose_splits(M, N, K, ktile);
+  if (bn) a.bn = *bn;
+  a.splits = (col_stats || bn) ? 1 : choose_splits(M, N, K, ktile);
   ER_REQUIRE(!(col_stats && accumulate), "%s: column statistics need a plain (non-accumulating) output", who);
   a.k_per_split = static_cast<int>(er::ceil_div(er::ceil_div(K, a.splits), ktile)) * ktile;
   a.splits = static_cast<int>(er::ceil_div(K, a.k_per_split));
@@ -749,6 +826,18 @@ int er_gemm_f32(int layout, int32_t M, int32_t N, int32_t K, const float* A, int
 int er_gemm_bf16(int layout, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B, int32_t ldb,
                  float* C, int32_t ldc, const float* bias, int accumulate, float* col_stats, er_stream_t stream) {
   return gemm_entry<true>(layout, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, col_stats, stream, "er_gemm_bf16");
+}
+
+int er_gemm_f32_bn_bwd(int layout, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B,
+                       int32_t ldb, float* C, int32_t ldc, const float* z, const float* z_bias, const float* y,
+                       const float* save_mean, const float* save_invstd, int32_t ld_zy, int use_bn, int act,
+                       float* partial, er_stream_t stream) {
+  ER_REQUIRE(z && y && partial && ld_zy >= N, "er_gemm_f32_bn_bwd: bad epilogue arguments");
+  ER_REQUIRE(!use_bn || (save_mean && save_invstd), "er_gemm_f32_bn_bwd: BatchNorm statistics missing");
+  er::BnBwdEpi e;
+  e.z = z; e.zbias = z_bias; e.y = y; e.mean = save_mean; e.invstd = save_invstd;
+  e.ld = ld_zy; e.use_bn = use_bn; e.act = act; e.partial = partial;
+  return gemm_entry<false>(layout, M, N, K, A, lda, B, ldb, C, ldc, nullptr, 0, nullptr, stream, "er_gemm_f32_bn_bwd", &e);
 }
 
 int er_gemm_grouped_f32(int layout, const er_gemm_problem* problems, int n, er_stream_t stream) {

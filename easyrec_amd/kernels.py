@@ -50,6 +50,13 @@ HYPER_LR, HYPER_LR_T, HYPER_BETA1, HYPER_BETA2, HYPER_OMB1, HYPER_OMB2, HYPER_EP
 
 
 _wgrad_tls = threading.local()
+_bn_tls = threading.local()
+
+
+def take_last_bn_source():
+  """The BnSource of the LinearBNActFn that just ran on this thread (None when the fused path is off)."""
+  src, _bn_tls.last = getattr(_bn_tls, 'last', None), None
+  return src
 
 
 class WgradSink(object):
@@ -64,6 +71,31 @@ class WgradSink(object):
       return False
     self.queue.append((x, dy, out, None, True))
     return True
+
+
+class BnSource(object):
+  """What the dgrad GEMM of a consumer needs in order to emit, in its epilogue, the BatchNorm-backward column sums
+  of the layer that produced its input (HipBackend.gemm_bn_bwd): that layer's z, y and batch statistics."""
+  __slots__ = ('z', 'zbias', 'y', 'mean', 'invstd', 'act', 'partial', 'dx_ptr')
+
+  def __init__(self, z, zbias, y, mean, invstd, act):
+    self.z, self.zbias, self.y, self.mean, self.invstd, self.act = z, zbias, y, mean, invstd, act
+    self.partial, self.dx_ptr = None, 0
+
+
+def tag_bn_source(y, src):
+  """Mark `y` (what the layer function returns) as the output described by src."""
+  y._er_bn_src = src
+  return y
+
+
+def bn_source_of(x):
+  """The BnSource of x if x IS the untouched 2-D output of a fused dense + BatchNorm + activation layer."""
+  src = getattr(x, '_er_bn_src', None)
+  if src is None or x.dim() != 2 or x.data_ptr() != src.y.data_ptr() or x.shape != src.y.shape or \
+      x.stride() != src.y.stride():
+    return None
+  return src
 
 
 class GemmProblem(ctypes.Structure):  # = er_gemm_problem
@@ -320,6 +352,30 @@ class HipBackend(object):
              'er_gemm')
     return out
 
+  # er_gemm_f32_bn_bwd / er_bn_act_bwd_from_partials are used (A/B switch: EASYREC_AMD_FUSED_BN_BWD=0)
+  fused_bn_bwd = os.environ.get('EASYREC_AMD_FUSED_BN_BWD', '1') != '0'
+
+  def gemm_bn_bwd(self, layout, a, b, src, partial):
+    """dgrad GEMM whose epilogue also emits the BatchNorm-backward column sums of the layer described by `src`
+    (a BnSource: the producer of this GEMM's input) into partial [row tiles][N][2]."""
+    assert a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1
+    if layout == GEMM_NN:
+      (M, K), (K2, N) = a.shape, b.shape
+    elif layout == GEMM_NT:
+      (M, K), (N, K2) = a.shape, b.shape
+    else:
+      (K, M), (K2, N) = a.shape, b.shape
+    assert K == K2 and src.y.shape == (M, N) and src.z.shape == (M, N) and src.y.stride() == src.z.stride()
+    assert partial.numel() >= self.gemm_row_tiles(M) * N * 2
+    out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    use_bn = src.mean is not None
+    self._ck(self.lib.er_gemm_f32_bn_bwd(ctypes.c_int(layout), M, N, K, _p(a), ctypes.c_int32(a.stride(0)), _p(b),
+                                         ctypes.c_int32(b.stride(0)), _p(out), ctypes.c_int32(out.stride(0)),
+                                         _p(src.z), _p(src.zbias), _p(src.y), _p(src.mean), _p(src.invstd),
+                                         ctypes.c_int32(src.y.stride(0)), int(use_bn), int(src.act), _p(partial),
+                                         _stream()), 'er_gemm_f32_bn_bwd')
+    return out
+
   def gemm_grouped(self, layout, problems):
     """problems: [(a, b, out, bias, accumulate)] fp32, one layout: ONE launch (+ one for the split-K reduces)."""
     arr = (GemmProblem * len(problems))()
@@ -352,7 +408,7 @@ class HipBackend(object):
   def defer_wgrads(self):
     sink = self.wgrad_sink()
     assert not sink.queue, 'flush_wgrads() was not called for the previous backward pass'
-    sink.active = True
+    sink.active = os.environ.get('EASYREC_AMD_GROUPED_WGRAD', '1') != '0'  # A/B switch
 
   def flush_wgrads(self):
     sink = self.wgrad_sink()
@@ -548,9 +604,11 @@ class HipBackend(object):
                                int(act), _p(y), _p(mean), _p(invstd), _stream()), 'er_bn_act_fwd')
     return y, mean, invstd
 
-  def bn_act_bwd(self, x, bias, gamma, y, mean, invstd, dy, use_bn, act, need_bias, need_affine, into=None):
+  def bn_act_bwd(self, x, bias, gamma, y, mean, invstd, dy, use_bn, act, need_bias, need_affine, into=None,
+                 partial=None):
     """into = (dbias_buf, dgamma_buf, dbeta_buf) (each may be None): accumulate the parameter gradients
-    into those buffers (slices of the flat gradient buffer) instead of returning new tensors."""
+    into those buffers (slices of the flat gradient buffer) instead of returning new tensors.
+    partial: column sums [gemm_row_tiles(B)][N][2] already produced by gemm_bn_bwd (skips that pass)."""
     B, N = x.shape
     dx = torch.empty_like(x)
     dev = x.device
@@ -561,10 +619,17 @@ class HipBackend(object):
       dbias = torch.empty(N, dtype=torch.float32, device=dev) if need_bias else None
       dgamma = torch.empty(N, dtype=torch.float32, device=dev) if need_affine else None
       dbeta = torch.empty(N, dtype=torch.float32, device=dev) if need_affine else None
-    self._ck(
-        self.lib.er_bn_act_bwd(_p(x), _p(bias), _p(gamma), _p(y), _p(mean), _p(invstd), _p(_f32c(dy)), B, N,
-                               int(use_bn), int(act), _p(dx), _p(dbias), _p(dgamma), _p(dbeta), int(acc), _stream()),
-        'er_bn_act_bwd')
+    if partial is not None:
+      self._ck(
+          self.lib.er_bn_act_bwd_from_partials(_p(x), _p(bias), _p(gamma), _p(y), _p(mean), _p(invstd), _p(_f32c(dy)),
+                                               B, N, int(use_bn), int(act), _p(partial),
+                                               ctypes.c_int32(self.gemm_row_tiles(B)), _p(dx), _p(dbias), _p(dgamma),
+                                               _p(dbeta), int(acc), _stream()), 'er_bn_act_bwd_from_partials')
+    else:
+      self._ck(
+          self.lib.er_bn_act_bwd(_p(x), _p(bias), _p(gamma), _p(y), _p(mean), _p(invstd), _p(_f32c(dy)), B, N,
+                                 int(use_bn), int(act), _p(dx), _p(dbias), _p(dgamma), _p(dbeta), int(acc),
+                                 _stream()), 'er_bn_act_bwd')
     if acc:
       return dx, None, None, None
     return dx, dbias, dgamma, dbeta
@@ -697,7 +762,7 @@ class LinearFn(torch.autograd.Function):
   returned the normal way."""
 
   @staticmethod
-  def forward(ctx, x, w, b, w_grad, b_grad, bf16):
+  def forward(ctx, x, w, b, w_grad, b_grad, bf16, src=None):
     be = hip()
     x2 = x if x.stride(-1) == 1 else x.contiguous()
     y = be.gemm(GEMM_NN, x2, w, bias=b, bf16=bf16)
@@ -705,6 +770,7 @@ class LinearFn(torch.autograd.Function):
     ctx.has_bias = b is not None
     ctx.w_grad, ctx.b_grad, ctx.bf16 = w_grad, b_grad, bf16
     ctx.sink = be.wgrad_sink()
+    ctx.src = src if (src is not None and x2 is x and not bf16 and getattr(be, 'fused_bn_bwd', False)) else None
     return y
 
   @staticmethod
@@ -714,7 +780,7 @@ class LinearFn(torch.autograd.Function):
     dy = dy if dy.stride(-1) == 1 and dy.dim() == 2 else dy.contiguous()
     dx = dw = db = None
     if ctx.needs_input_grad[0]:
-      dx = be.gemm(GEMM_NT, dy, w, bf16=ctx.bf16)
+      dx = _dgrad(be, dy, w, ctx.src, ctx.bf16)
     if ctx.needs_input_grad[1]:
       if ctx.w_grad is not None:
         if not ctx.sink.put(x, dy, ctx.w_grad, ctx.bf16):
@@ -727,7 +793,19 @@ class LinearFn(torch.autograd.Function):
         ctx.b_grad.add_(s)
       else:
         db = s
-    return dx, dw, db, None, None, None
+    return dx, dw, db, None, None, None, None
+
+
+def _dgrad(be, dz, w, src, bf16):
+  """dx = dz . W^T; when the input was the output of a fused dense + BatchNorm layer (src), the GEMM's epilogue also
+  leaves that layer's BatchNorm-backward column sums in src.partial."""
+  if src is None:
+    return be.gemm(GEMM_NT, dz, w, bf16=bf16)
+  M, N = dz.shape[0], w.shape[0]
+  partial = torch.empty(be.gemm_row_tiles(M) * N * 2, dtype=torch.float32, device=dz.device)
+  dx = be.gemm_bn_bwd(GEMM_NT, dz, w, src, partial)
+  src.partial, src.dx_ptr = partial, dx.data_ptr()
+  return dx
 
 
 class LinearBNActFn(torch.autograd.Function):
@@ -738,7 +816,7 @@ class LinearBNActFn(torch.autograd.Function):
   (kernel.grad, gamma.grad, beta.grad)).  Under BatchNorm d(loss)/d(bias) == 0, so the bias gets none."""
 
   @staticmethod
-  def forward(ctx, x, w, b, gamma, beta, moving_mean, moving_var, eps, momentum, act, bf16, grad_bufs):
+  def forward(ctx, x, w, b, gamma, beta, moving_mean, moving_var, eps, momentum, act, bf16, grad_bufs, src=None):
     be = hip()
     x2 = x if x.stride(-1) == 1 else x.contiguous()
     M, N = x2.shape[0], w.shape[1]
@@ -750,6 +828,10 @@ class LinearBNActFn(torch.autograd.Function):
     ctx.save_for_backward(x2, w, gamma, z, y, mean, invstd)
     ctx.act, ctx.bf16, ctx.grad_bufs = act, bf16, grad_bufs
     ctx.sink = be.wgrad_sink()
+    fused = not bf16 and getattr(be, 'fused_bn_bwd', False)
+    ctx.src = src if (src is not None and x2 is x and fused) else None
+    ctx.own = BnSource(z, None, y, mean, invstd, act) if fused else None  # z already carries the bias
+    _bn_tls.last = ctx.own
     return y
 
   @staticmethod
@@ -758,18 +840,25 @@ class LinearBNActFn(torch.autograd.Function):
     x, w, gamma, z, y, mean, invstd = ctx.saved_tensors
     wg, gg, betag = ctx.grad_bufs if ctx.grad_bufs is not None else (None, None, None)
     direct = gg is not None and betag is not None
-    dz, _, dgamma, dbeta = be.bn_act_bwd(z, None, gamma, y, mean, invstd, dy.contiguous(), 1, ctx.act, False, True,
-                                         into=(None, gg, betag) if direct else None)
+    dyc = dy.contiguous()
+    own, partial = ctx.own, None
+    if own is not None:
+      # the consumer's dgrad GEMM already reduced the column sums, provided dy is exactly its output
+      if own.partial is not None and dyc.data_ptr() == own.dx_ptr:
+        partial = own.partial
+      own.partial = None
+    dz, _, dgamma, dbeta = be.bn_act_bwd(z, None, gamma, y, mean, invstd, dyc, 1, ctx.act, False, True,
+                                         into=(None, gg, betag) if direct else None, partial=partial)
     dx = dw = None
     if ctx.needs_input_grad[0]:
-      dx = be.gemm(GEMM_NT, dz, w, bf16=ctx.bf16)
+      dx = _dgrad(be, dz, w, ctx.src, ctx.bf16)
     if ctx.needs_input_grad[1]:
       if wg is not None:
         if not ctx.sink.put(x, dz, wg, ctx.bf16):
           be.gemm(GEMM_TN, x, dz, out=wg, accumulate=True, bf16=ctx.bf16)
       else:
         dw = be.gemm(GEMM_TN, x, dz, bf16=ctx.bf16)
-    return dx, dw, None, dgamma, dbeta, None, None, None, None, None, None, None
+    return dx, dw, None, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
 class FMFn(torch.autograd.Function):

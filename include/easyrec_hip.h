@@ -309,6 +309,13 @@ int er_bn_act_bwd(const float* x, const float* bias, const float* gamma, const f
                   const float* save_mean, const float* save_invstd, const float* dy, int32_t B,
                   int32_t N, int use_bn, int act, float* dx, float* dbias, float* dgamma,
                   float* dbeta, int accumulate, er_stream_t stream);
+/* The second half of er_bn_act_bwd, fed with column-sum partials [chunks][N][2] that the dgrad GEMM's epilogue
+ * already produced (er_gemm_f32_bn_bwd). */
+int er_bn_act_bwd_from_partials(const float* x, const float* bias, const float* gamma, const float* y,
+                                const float* save_mean, const float* save_invstd, const float* dy,
+                                int32_t B, int32_t N, int use_bn, int act, const float* partial,
+                                int32_t chunks, float* dx, float* dbias, float* dgamma, float* dbeta,
+                                int accumulate, er_stream_t stream);
 /* out[j] = sum_i x[i, j]  (bias gradients, partial reductions) */
 int er_colsum(const float* x, int32_t rows, int32_t cols, int32_t x_stride, float* out,
               er_stream_t stream);
@@ -374,6 +381,16 @@ int er_mmoe_mix_bwd(const float* experts, const float* gates, const float* dout,
 enum { ER_GEMM_NN = 0, ER_GEMM_NT = 1, ER_GEMM_TN = 2 };
 int er_gemm_reserve(int64_t floats);
 int er_gemm_row_tiles(int32_t M);
+/* dgrad GEMM with the BatchNorm-backward column sums in its epilogue.  C = op(A).op(B) is the gradient dy of the
+ * activations y = act(BN(z + z_bias)) of the layer below (reference layers/dnn.py:57-79, its tf.layers.dense ->
+ * batch_normalization -> relu chain); per 64-row tile of C the epilogue writes partial[tile][col][0..1] =
+ * (sum g, sum g * xhat), g = dy masked by the activation - what er_bn_act_bwd otherwise computes in a pass of its
+ * own over dy, y and z.  er_bn_act_bwd_from_partials(partial, chunks = er_gemm_row_tiles(M)) then finishes the
+ * BatchNorm backward in one launch.  No split-K, bias or accumulate. */
+int er_gemm_f32_bn_bwd(int layout, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B,
+                       int32_t ldb, float* C, int32_t ldc, const float* z, const float* z_bias, const float* y,
+                       const float* save_mean, const float* save_invstd, int32_t ld_zy, int use_bn, int act,
+                       float* partial, er_stream_t stream);
 /* Grouped launch: n independent fp32 problems of ONE layout in one grid (+ one grid for their split-K reduces).
  * The use: the weight gradients dW_l = x_l^T . dz_l of every dense layer of a step (reference: the MatMul
  * gradients TF schedules for layers/dnn.py:57-62, one per layer) - each a small M x N with K = batch - queued

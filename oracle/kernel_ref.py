@@ -556,7 +556,9 @@ class RefBackend(object):
       y = torch.relu(y)
     return y, mean, invstd
 
-  def bn_act_bwd(self, x, bias, gamma, y, mean, invstd, dy, use_bn, act, need_bias, need_affine, into=None):
+  def bn_act_bwd(self, x, bias, gamma, y, mean, invstd, dy, use_bn, act, need_bias, need_affine, into=None,
+                 partial=None):
+    assert partial is None  # only the HIP backend fuses the column sums into the dgrad GEMM
     res = self._bn_act_bwd(x, bias, gamma, y, mean, invstd, dy, use_bn, act, need_bias, need_affine)
     if into is None:
       return res

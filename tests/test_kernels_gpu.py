@@ -787,3 +787,31 @@ def test_gemm_grouped_matches_single_launches(hip):
   torch.cuda.synchronize()
   for p, f in zip(probs, first):
     assert torch.equal(p[2], f)
+
+
+@pytest.mark.parametrize('B,N,K', [(4096, 256, 128), (300, 70, 33), (64, 1, 16), (130, 128, 64)])
+@pytest.mark.parametrize('act', [kernels.ACT_RELU, kernels.ACT_NONE])
+def test_dgrad_gemm_emits_batchnorm_backward_sums(hip, B, N, K, act):
+  """er_gemm_f32_bn_bwd: the dgrad GEMM dy = dz_next . W^T also leaves the (sum g, sum g xhat) column partials of the
+  layer below; er_bn_act_bwd_from_partials must then give what the two-pass er_bn_act_bwd gives from the same dy."""
+  g = torch.Generator().manual_seed(B + N + K + act)
+  z = torch.randn(B, N, generator=g).to(DEV)
+  gamma = (torch.rand(N, generator=g) + 0.5).to(DEV)
+  beta = (torch.randn(N, generator=g) * 0.1).to(DEV)
+  mm, mv = torch.zeros(N, device=DEV), torch.ones(N, device=DEV)
+  y, mean, invstd = hip.bn_act_fwd(z, None, gamma, beta, 1, 1e-3, 0.99, mm, mv, act)
+  dz_next = (torch.randn(B, K, generator=g) * 0.1).to(DEV)
+  w = torch.randn(N, K, generator=g).to(DEV)
+  src = kernels.BnSource(z, None, y, mean, invstd, act)
+  partial = torch.empty(hip.gemm_row_tiles(B) * N * 2, device=DEV)
+  dy = hip.gemm_bn_bwd(kernels.GEMM_NT, dz_next, w, src, partial)
+  assert torch.equal(dy, hip.gemm(kernels.GEMM_NT, dz_next, w))
+  ref = hip.bn_act_bwd(z, None, gamma, y, mean, invstd, dy, 1, act, False, True)
+  got = hip.bn_act_bwd(z, None, gamma, y, mean, invstd, dy, 1, act, False, True, partial=partial)
+  torch.cuda.synchronize()
+  for a, b, what in zip(got, ref, ('dz', 'dbias', 'dgamma', 'dbeta')):
+    if a is None:
+      assert b is None
+      continue
+    scale = float(b.abs().max()) + 1e-12
+    assert float((a - b).abs().max()) <= 2e-5 * scale, (what, float((a - b).abs().max()), scale)
