@@ -88,15 +88,26 @@ class DeviceFeatures(object):
     self._backend = backend
     B = schema.batch_size
     dev = self.device
-    self.labels = torch.zeros(max(len(schema.label_fields), 1), B, dtype=torch.float32, device=dev)
-    self.sample_weight = None
-    self.raw_block = torch.zeros(max(schema.n_raw_rows, 1), B, dtype=torch.float32, device=dev)
     nh = len(schema.hash_single)
-    self.hash_ids = torch.full((max(nh, 1), B), -1, dtype=torch.int64, device=dev)
-    self.str_bytes = torch.zeros(max(nh * B * schema.max_str_bytes, 16), dtype=torch.uint8, device=dev)
-    self.str_offsets = torch.zeros(nh * B + 1, dtype=torch.int64, device=dev)
+    # the fixed-size inputs live back to back in ONE arena so that a packed batch (pack()) is loaded with a single
+    # copy: labels | raw | int ids | hash ids | string offsets | string bytes, each section 256-byte aligned
+    sections = [('labels', (max(len(schema.label_fields), 1), B), torch.float32),
+                ('raw_block', (max(schema.n_raw_rows, 1), B), torch.float32),
+                ('int_ids', (max(len(schema.int_single), 1), B), torch.int64),
+                ('hash_ids', (max(nh, 1), B), torch.int64),
+                ('str_offsets', (nh * B + 1,), torch.int64),
+                ('str_bytes', (max(nh * B * schema.max_str_bytes, 16),), torch.uint8)]
+    self._layout, off = {}, 0
+    for name, shape, dt in sections:
+      nbytes = int(np.prod(shape)) * torch.empty(0, dtype=dt).element_size()
+      self._layout[name] = (off, nbytes, shape, dt)
+      off += (nbytes + 255) // 256 * 256
+    self.arena = torch.zeros(off, dtype=torch.uint8, device=dev)
+    for name, (o, nbytes, shape, dt) in self._layout.items():
+      setattr(self, name, self.arena[o:o + nbytes].view(dt).view(shape))
+    self.hash_ids.fill_(-1)
+    self.sample_weight = None
     self.hash_buckets = torch.from_numpy(schema.hash_buckets_array.astype(np.int64)).to(dev) if nh else None
-    self.int_ids = torch.zeros(max(len(schema.int_single), 1), B, dtype=torch.int64, device=dev)
     self.zero_ids = torch.zeros(B, dtype=torch.int64, device=dev)  # projection id 0 of raw features
     self.raw_multi = {}
     for name, k in schema.raw_multi.items():
@@ -164,6 +175,10 @@ class DeviceFeatures(object):
         src = src.pin_memory() if torch.cuda.is_available() else src
       dst.view(-1)[:src.numel()].copy_(src.reshape(-1), non_blocking=non_blocking)
 
+    if 'packed' in batch:  # pack(): one copy for labels, raw values, ids and strings
+      src = batch['packed']
+      self.arena[:src.numel()].copy_(src, non_blocking=non_blocking)
+      self._use_device_hash = bool(batch['packed_has_strings'])
     put(self.labels, batch.get('labels'))
     put(self.raw_block, batch.get('raw'))
     if 'str_bytes' in batch:
@@ -202,6 +217,36 @@ class DeviceFeatures(object):
       put(bufs['ids'], ids)
       put(bufs['len'], batch['seq/%s/len' % name])
     self.version += 1
+
+  _PACKED_KEYS = {'labels': 'labels', 'raw': 'raw_block', 'int_ids': 'int_ids', 'hash_ids': 'hash_ids',
+                  'str_offsets': 'str_offsets', 'str_bytes': 'str_bytes'}
+
+  def pack(self, batch, device=None):
+    """Batch dict (input/input.py) -> the same batch with its fixed-size parts laid out as ONE byte image of the
+    input arena ('packed'): what a native loader would hand over, and a single host-to-device / device-to-device copy
+    per step instead of one per array.  Ragged parts (tags, sequences, multi-valued raws) stay separate entries."""
+    has_str = 'str_bytes' in batch
+    last = 'str_bytes' if has_str else 'hash_ids'
+    end = self._layout[last][0] + self._layout[last][1]
+    img = np.zeros(end, dtype=np.uint8)
+    out = {}
+    for key, val in batch.items():
+      name = self._PACKED_KEYS.get(key)
+      if name is None:
+        out[key] = val
+        continue
+      o, nbytes, shape, dt = self._layout[name]
+      a = np.ascontiguousarray(val.cpu().numpy() if torch.is_tensor(val) else val)
+      a = a.astype({torch.float32: np.float32, torch.int64: np.int64, torch.uint8: np.uint8}[dt], copy=False).reshape(-1)
+      assert a.nbytes <= nbytes, '%s: %d bytes exceed the capacity %d' % (key, a.nbytes, nbytes)
+      img[o:o + a.nbytes] = a.view(np.uint8)
+    if not has_str and 'hash_ids' not in batch:
+      o, nbytes, _, _ = self._layout['hash_ids']
+      img[o:o + nbytes] = 0xFF  # -1: missing
+    t = torch.from_numpy(img)
+    out['packed'] = t.to(device) if device is not None else t
+    out['packed_has_strings'] = has_str
+    return out
 
   def transform(self):
     """Device-side part of `_preprocess`: hash the packed id strings (K1)."""

@@ -153,3 +153,33 @@ def test_other_models_match_model_oracle(ref_backend, config, B):
         n_cmp += 1
       assert n_cmp > 5
   est.varstore.check_grad_views()
+
+
+@pytest.mark.parametrize('config', ['deepfm_criteo_small.config', 'mmoe_taobao_small.config'])
+def test_packed_batch_loads_like_the_plain_one(ref_backend, config):
+  """DeviceFeatures.pack(): the fixed-size inputs as ONE byte image of the input arena (a single copy per step);
+  loading it must leave every buffer exactly as the per-array load does, ragged parts included."""
+  import torch
+  from easyrec_amd.input.synthetic import SyntheticBatches
+  from easyrec_amd.model.easy_rec_estimator import EasyRecEstimator
+  cfg = config_util.get_configs_from_pipeline_file(os.path.join('configs', config))
+  B = 24
+  est = EasyRecEstimator(cfg, device='cpu', batch_size=B, seed=1).build()
+  gen = SyntheticBatches(cfg.data_config, est.feature_configs, batch_size=B, seed=5)
+  f = est.features
+  for _ in range(2):
+    batch = gen.next_batch()
+    f.load(batch)
+    plain = f.arena.clone()
+    tags = {k: {n: (None if t is None else t.clone()) for n, t in v.items()} for k, v in f.tags.items()}
+    f.arena.zero_()
+    packed = f.pack(batch)
+    assert set(packed) & {'labels', 'raw', 'str_bytes', 'str_offsets', 'hash_ids', 'int_ids'} == set()
+    f.load(packed)
+    for name, (o, nbytes, _, _) in f._layout.items():
+      if name == 'hash_ids' and packed['packed_has_strings']:
+        continue  # produced on the device by transform()
+      assert torch.equal(f.arena[o:o + nbytes], plain[o:o + nbytes]), name
+    for k, v in f.tags.items():
+      for n, t in v.items():
+        assert t is None or torch.equal(t, tags[k][n]), (k, n)
