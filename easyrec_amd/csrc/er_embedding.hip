@@ -477,7 +477,10 @@ __device__ __forceinline__ void finish_run(const RowUpdate& tab, int opt_kind, c
   }
 }
 
-constexpr int kTilePasses = 4;
+// entries per lane of a tile: 4 for 16-byte lanes (dim 16: 64 entries per pass -> tiles of 256), 1 for scalar lanes
+// (dim 1: 256 entries per pass) - a tile is 256 sorted entries either way, and a group of 100 k entries spreads over
+// > 400 workgroups (the kernel is latency-bound: dependent random reads, so parallelism is what matters)
+__host__ __device__ constexpr int tile_passes(int V) { return V == 4 ? 4 : 1; }
 
 template <int V>
 __global__ void __launch_bounds__(kBlock)
@@ -487,6 +490,7 @@ emb_bwd_tile_kernel(const uint32_t* __restrict__ skeys, const uint32_t* __restri
                     ReduceOut ro, float* __restrict__ tile_first, float* __restrict__ tile_last) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int epp = kBlock / G;            // entries per pass
+  constexpr int kTilePasses = tile_passes(V);
   const int T = kTilePasses * epp;       // entries per tile
   float* vals = smem;                    // [T][dim]
   uint32_t* keys = reinterpret_cast<uint32_t*>(smem + static_cast<size_t>(T) * dim);  // [T + 2]: prev, tile, next
@@ -517,14 +521,19 @@ emb_bwd_tile_kernel(const uint32_t* __restrict__ skeys, const uint32_t* __restri
   // 2. segmented inclusive scan (sorted keys: equal key at distance `off` => same run)
   for (int off = 1; off < T; off <<= 1) {
     Vec<V> add[kTilePasses];
+    int any = 0;
 #pragma unroll
     for (int ps = 0; ps < kTilePasses; ++ps) {
       const int e = ps * epp + tid / G;
       add[ps].zero();
-      if (col_ok && e >= off && keys[e + 1] != kInvalidKey && keys[e + 1 - off] == keys[e + 1])
+      if (col_ok && e >= off && keys[e + 1] != kInvalidKey && keys[e + 1 - off] == keys[e + 1]) {
         add[ps].load(vals + static_cast<size_t>(e - off) * dim + c);
+        any = 1;
+      }
     }
-    __syncthreads();
+    // sorted keys: no equal pair at distance `off` means no run of the tile is longer than `off` - the scan is done
+    // (the barrier doubles as the one that separates the reads above from the writes below)
+    if (!__syncthreads_or(any)) break;
 #pragma unroll
     for (int ps = 0; ps < kTilePasses; ++ps) {
       const int e = ps * epp + tid / G;
@@ -615,10 +624,15 @@ __device__ __forceinline__ void seg_cmpx(unsigned long long& a, unsigned long lo
   b = hi;
 }
 
-template <int E>
+// HEADS: also emit, per sorted position, the run-head flag and the number of heads before it INSIDE the lookup, and
+// the lookup's number of distinct valid keys (emb_route_seg_kernel adds the lookups before it): the head-flag /
+// exclusive-scan / count launches of the generic path disappear.
+template <int E, bool HEADS>
 __global__ void __launch_bounds__(kSegSortMax / 8)
 emb_segment_sort_kernel(const uint32_t* __restrict__ keys_in, const int64_t* __restrict__ ent_base, int P,
-                        uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
+                        uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+                        uint32_t* __restrict__ flags_out, uint32_t* __restrict__ hidx_out,
+                        uint32_t* __restrict__ seg_count) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long sk[];  // [P]
   constexpr int L = E == 8 ? 3 : (E == 4 ? 2 : 1);
   static_assert(E == 2 || E == 4 || E == 8, "E");
@@ -693,6 +707,88 @@ emb_segment_sort_kernel(const uint32_t* __restrict__ keys_in, const int64_t* __r
       vals_out[base + i] = static_cast<uint32_t>(x[e] & 0xFFFFFFFFu);
     }
   }
+  if (HEADS) {
+    __shared__ uint32_t wave_sum[kSegSortMax / 8 / 64];
+    uint32_t* k32 = reinterpret_cast<uint32_t*>(sk);  // [P] sorted keys, to look one position back
+    __syncthreads();                                  // every thread has taken its composites out of sk
+#pragma unroll
+    for (int e = 0; e < E; ++e) k32[i0 + e] = static_cast<uint32_t>(x[e] >> 32);
+    __syncthreads();
+    uint32_t prev = i0 > 0 ? k32[i0 - 1] : kInvalidKey;
+    uint32_t f[E], c = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const uint32_t key = static_cast<uint32_t>(x[e] >> 32);
+      f[e] = (key != kInvalidKey && (i0 + e == 0 || prev != key)) ? 1u : 0u;
+      c += f[e];
+      prev = key;
+    }
+    // exclusive scan of c over the workgroup: inclusive scan inside the wave, then the wave totals
+    const int lane = t & 63, wave = t >> 6, n_waves = blockDim.x >> 6;
+    uint32_t inc = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t o = __shfl_up(inc, d, 64);
+      if (lane >= d) inc += o;
+    }
+    if (lane == 63) wave_sum[wave] = inc;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+    for (int w = 0; w < n_waves; ++w) {
+      const uint32_t ws = wave_sum[w];
+      if (w < wave) before += ws;
+      total += ws;
+    }
+    uint32_t run = before + inc - c;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int i = i0 + e;
+      if (i < cnt) {
+        flags_out[base + i] = f[e];
+        hidx_out[base + i] = run;
+      }
+      run += f[e];
+    }
+    if (t == 0) seg_count[blockIdx.x] = total;
+  }
+}
+
+// Second half of the fused route of the segmented path: add the distinct-key counts of the lookups before this one
+// (head_index becomes the global exclusive scan), write the de-duplicated key list, the per-entry index into it and
+// the total.  grid = (ceil(P / 256), lookups).
+__global__ void __launch_bounds__(kBlock)
+emb_route_seg_kernel(const uint32_t* __restrict__ skeys, const uint32_t* __restrict__ svals,
+                     const uint32_t* __restrict__ flags, uint32_t* __restrict__ head_index,
+                     const int64_t* __restrict__ ent_base, const uint32_t* __restrict__ seg_count, int n_lookups,
+                     uint32_t* __restrict__ unique_keys, int64_t* __restrict__ uidx, int32_t* __restrict__ n_unique) {
+  __shared__ uint32_t red[kBlock / 64];
+  const int l = blockIdx.y;
+  uint32_t acc = 0;
+  for (int j = threadIdx.x; j < l; j += kBlock) acc += seg_count[j];
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  uint32_t prefix = 0;
+#pragma unroll
+  for (int w = 0; w < kBlock / 64; ++w) prefix += red[w];
+  if (l == n_lookups - 1 && blockIdx.x == 0 && threadIdx.x == 0) *n_unique = static_cast<int32_t>(prefix + seg_count[l]);
+  const int64_t base = ent_base[l];
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i >= ent_base[l + 1] - base) return;
+  const int64_t p = base + i;
+  const uint32_t h = head_index[p] + prefix;
+  head_index[p] = h;
+  const uint32_t key = skeys[p];
+  const uint32_t j = svals[p];
+  if (key == kInvalidKey) {
+    if (uidx) uidx[j] = -1;
+    return;
+  }
+  const uint32_t f = flags[p];
+  const uint32_t u = h + f - 1u;
+  if (uidx) uidx[j] = static_cast<int64_t>(u);
+  if (f) unique_keys[u] = key;
 }
 
 __global__ void __launch_bounds__(kBlock)
@@ -970,6 +1066,7 @@ struct er_emb_group {
   int64_t* d_local_base = nullptr;
   int64_t n_active = -1;  // -1: all entries
   int seg_sort_pow2 = 0;   // > 0: per-lookup LDS sort (emb_segment_sort_kernel) with this padded size
+  uint32_t* seg_count = nullptr;  // [n] distinct valid keys per lookup (fused heads of the segmented path)
   bool sorted_valid = false;
   // er_emb_group_share_sort: `src` owns the sorted keys / entry permutation / run heads this group reduces over
   // (itself, or the leader whose keys are identical); the epochs tell a fresh leader sort from a stale one
@@ -1125,7 +1222,7 @@ int er_emb_group_create(const er_lookup_desc* descs, int n, int32_t dim, int64_t
   ER_CHECK_HIP(hipMalloc(&g->vals_out, sizeof(uint32_t) * N));
   ER_CHECK_HIP(hipMalloc(&g->ent_gptr, sizeof(float*) * N));
   ER_CHECK_HIP(hipMalloc(&g->ent_scale, sizeof(float) * N));
-  g->tile_entries = er::kTilePasses * (er::kBlock / g->G);
+  g->tile_entries = er::tile_passes(g->V) * (er::kBlock / g->G);
   {
     const size_t nt = static_cast<size_t>(er::ceil_div(N, g->tile_entries)) + 1;
     ER_CHECK_HIP(hipMalloc(&g->tile_first, sizeof(float) * nt * dim));
@@ -1133,6 +1230,7 @@ int er_emb_group_create(const er_lookup_desc* descs, int n, int32_t dim, int64_t
   }
   ER_CHECK_HIP(hipMalloc(&g->head_flags, sizeof(uint32_t) * N));
   ER_CHECK_HIP(hipMalloc(&g->head_index, sizeof(uint32_t) * N));
+  ER_CHECK_HIP(hipMalloc(&g->seg_count, sizeof(uint32_t) * (n + 1)));
   ER_CHECK_HIP(hipMemset(g->keys_in, 0xFF, sizeof(uint32_t) * N));
   ER_CHECK_HIP(rocprim::radix_sort_pairs(nullptr, g->sort_temp_bytes, g->keys_in, g->keys_out, g->vals_in, g->vals_out,
                                          static_cast<size_t>(N), 0u, static_cast<unsigned>(g->key_bits)));
@@ -1156,7 +1254,7 @@ int er_emb_group_destroy(er_emb_group* g) {
   if (!g) return 0;
   void* ptrs[] = {g->d_descs, g->d_blk_start, g->d_ent_base, g->keys_in, g->keys_out, g->vals_in, g->vals_out,
                   g->ent_gptr, g->ent_scale, g->tile_first, g->tile_last, g->head_flags, g->head_index, g->sort_temp, g->scan_temp,
-                  g->d_local_base};
+                  g->d_local_base, g->seg_count};
   for (void* q : ptrs) (void)hipFree(q);
   delete g;
   return 0;
@@ -1220,21 +1318,29 @@ static int emb_group_adopt(er_emb_group* g, hipStream_t s, bool* adopted) {
 }
 
 // build keys (routed) + stable sort.  Leaves keys_out/vals_out valid for this step.
-static int emb_group_build_sort(er_emb_group* g, hipStream_t s) {
+static bool emb_group_segmented(const er_emb_group* g) {
+  return g->seg_sort_pow2 > 0 && g->n_active < 0 && !g->d_local_base;
+}
+
+// with_heads (segmented path only): the sort kernel also leaves head flags, per-lookup head indices and counts
+static int emb_group_build_sort(er_emb_group* g, hipStream_t s, bool with_heads = false) {
   const int64_t N = group_entries(g);
   if (N == 0) return 0;
   if (int rc = emb_group_build(g, s)) return rc;
   g->src = g;
   ++g->sort_epoch;
-  if (g->seg_sort_pow2 > 0 && g->n_active < 0 && !g->d_local_base) {
+  if (emb_group_segmented(g)) {
     const int P = g->seg_sort_pow2;
     const size_t lds = sizeof(unsigned long long) * static_cast<size_t>(P);
-    if (P > 4096)
-      hipLaunchKernelGGL(er::emb_segment_sort_kernel<8>, dim3(g->n), dim3(P / 8), lds, s, g->keys_in, g->d_ent_base, P,
-                         g->keys_out, g->vals_out);
-    else
-      hipLaunchKernelGGL(er::emb_segment_sort_kernel<4>, dim3(g->n), dim3(P / 4), lds, s, g->keys_in, g->d_ent_base, P,
-                         g->keys_out, g->vals_out);
+#define ER_SEG_SORT(E, H)                                                                                            \
+  hipLaunchKernelGGL((er::emb_segment_sort_kernel<E, H>), dim3(g->n), dim3(P / E), lds, s, g->keys_in, g->d_ent_base, P, \
+                     g->keys_out, g->vals_out, g->head_flags, g->head_index, g->seg_count)
+    if (P > 4096) {
+      if (with_heads) ER_SEG_SORT(8, true); else ER_SEG_SORT(8, false);
+    } else {
+      if (with_heads) ER_SEG_SORT(4, true); else ER_SEG_SORT(4, false);
+    }
+#undef ER_SEG_SORT
     ER_LAUNCH_CHECK();
     return 0;
   }
@@ -1500,7 +1606,7 @@ int er_emb_route(er_emb_group* g, uint32_t* unique_keys, int32_t* n_unique, int6
   hipStream_t s = er::as_stream(stream);
   const int64_t N = group_entries(g);
   ER_REQUIRE(N > 0, "er_emb_route: empty group");
-  bool adopted = false;
+  bool adopted = false, fused_route = false;
   if (g->leader)
     if (int rc = emb_group_adopt(g, s, &adopted)) return rc;
   if (adopted) {
@@ -1516,11 +1622,22 @@ int er_emb_route(er_emb_group* g, uint32_t* unique_keys, int32_t* n_unique, int6
     }
   } else {
     ER_REQUIRE(unique_keys && n_unique, "er_emb_route: null argument");
-    if (int rc = emb_group_build_sort(g, s)) return rc;
-    if (int rc = emb_group_heads(g, n_unique, s)) return rc;
-    g->heads_epoch = g->sort_epoch;
+    if (emb_group_segmented(g)) {
+      // two launches: sort + in-lookup heads, then the cross-lookup offsets + key list + per-entry index
+      if (int rc = emb_group_build_sort(g, s, true)) return rc;
+      dim3 grid(static_cast<unsigned>(er::ceil_div(g->seg_sort_pow2, er::kBlock)), static_cast<unsigned>(g->n));
+      hipLaunchKernelGGL(er::emb_route_seg_kernel, grid, dim3(er::kBlock), 0, s, g->keys_out, g->vals_out, g->head_flags,
+                         g->head_index, g->d_ent_base, g->seg_count, g->n, unique_keys, entry_unique_index, n_unique);
+      ER_LAUNCH_CHECK();
+      g->heads_epoch = g->sort_epoch;
+      fused_route = true;
+    } else {
+      if (int rc = emb_group_build_sort(g, s)) return rc;
+      if (int rc = emb_group_heads(g, n_unique, s)) return rc;
+      g->heads_epoch = g->sort_epoch;
+    }
   }
-  if (unique_keys) {
+  if (unique_keys && !fused_route) {
     const er_emb_group* src = g->src;
     hipLaunchKernelGGL(er::emb_route_kernel, dim3(static_cast<int>(er::ceil_div(N, er::kBlock))), dim3(er::kBlock), 0, s,
                        src->keys_out, src->vals_out, src->head_flags, src->head_index, N, unique_keys,

@@ -815,3 +815,26 @@ def test_dgrad_gemm_emits_batchnorm_backward_sums(hip, B, N, K, act):
       continue
     scale = float(b.abs().max()) + 1e-12
     assert float((a - b).abs().max()) <= 2e-5 * scale, (what, float((a - b).abs().max()), scale)
+
+
+@pytest.mark.parametrize('B,dims', [(300, (16, 1)), (5000, (4,)), (7, (8,))])
+def test_route_outputs_of_the_segmented_path(hip, ref, B, dims):
+  """er_emb_route without routing tables (one table per lookup -> fused sort + heads + route launches): the
+  de-duplicated key list, its length and every entry's index into it must equal the oracle's."""
+  rng = np.random.default_rng(B)
+  sc, sd, stc, std, oc, od, group_rows = _make_lookup_problem(rng, B, dims, DEV)
+  for dim, total in group_rows.items():
+    gc = ref.emb_group_create([s for s in sc if s.dim == dim], dim, total, stc[dim], None, None, None)
+    gd = hip.emb_group_create([s for s in sd if s.dim == dim], dim, total, std[dim], None, None, None)
+    n = gd['num_entries']
+    uk_c, nu_c, ui_c = torch.zeros(n, dtype=torch.int32), torch.zeros(1, dtype=torch.int32), torch.zeros(n, dtype=torch.int64)
+    uk_d, nu_d, ui_d = uk_c.to(DEV), nu_c.to(DEV), ui_c.to(DEV)
+    ref.emb_route(gc, uk_c, nu_c, ui_c, None)
+    for _ in range(2):
+      hip.emb_route(gd, uk_d, nu_d, ui_d, None)
+    torch.cuda.synchronize()
+    k = int(nu_c.item())
+    assert int(nu_d.item()) == k
+    assert torch.equal(uk_d[:k].cpu(), uk_c[:k])
+    assert torch.equal(ui_d.cpu(), ui_c)
+    hip.emb_group_destroy(gd)
