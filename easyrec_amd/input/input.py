@@ -236,7 +236,10 @@ class Input(object, metaclass=_meta_type):
             vocab = {v: i for i, v in enumerate(fc.vocab_list)}
             int_ids[c] = [vocab.get(v if isinstance(v, str) else str(v), 0) for v in col]
           else:
-            v = np.array([int(x) if x not in ('', b'') else 0 for x in col], dtype=np.int64)
+            if isinstance(col, np.ndarray) and col.dtype.kind in 'iu':
+              v = col.astype(np.int64)
+            else:
+              v = np.array([int(x) if x not in ('', b'') else 0 for x in col], dtype=np.int64)
             nb = sch.int_single[name]['num_buckets']
             int_ids[c] = np.where((v < 0) | (v >= nb), 0, v)
       elif ft == FeatureConfig.TagFeature:
@@ -266,4 +269,9 @@ class Input(object, metaclass=_meta_type):
   @classmethod
   def create(cls, data_config, feature_configs, input_path=None, **kwargs):
     name = DatasetConfig.InputType.Name(data_config.input_type)
+    # the reader classes register themselves on import (reference: input/__init__ + utils/load_class.py)
+    import importlib
+    module = {'CSVInput': 'csv_input', 'ParquetInput': 'parquet_input', 'CriteoInput': 'criteo_input'}.get(name)
+    if module is not None:
+      importlib.import_module('easyrec_amd.input.' + module)
     return cls.create_class(name)(data_config, feature_configs, input_path, **kwargs)
