@@ -115,6 +115,14 @@ class OptimizerState(object):
     row[kernels.HYPER_GSCALE] = F32(grad_scale)
     return row
 
+  def reset_to_step(self, step):
+    """State after `step` applies, e.g. when a checkpoint is restored: TF keeps beta1_power / beta2_power as fp32
+    variables multiplied once per apply, so they are re-derived by the same sequence of fp32 multiplications."""
+    if self.kind in (kernels.OPT_ADAM, kernels.OPT_LAZY_ADAM):
+      self.beta1_power, self.beta2_power = F32(self.beta1), F32(self.beta2)
+      for _ in range(int(step)):
+        self.finish_step()
+
   def finish_step(self):
     """AdamOptimizer._finish: beta powers advance after the apply."""
     if self.kind in (kernels.OPT_ADAM, kernels.OPT_LAZY_ADAM):

@@ -210,6 +210,35 @@ class HipBackend(object):
     self._ck(self.lib.er_device_info(ctypes.byref(cu), ctypes.byref(wave), buf, 64), 'er_device_info')
     return {'cu_count': cu.value, 'wave_size': wave.value, 'arch': buf.value.decode()}
 
+  # -- K14 sharded embedding checkpoint files (host code)
+  def save_dense_embed(self, ckpt_path, var_name, task_index, task_num, vals_np):
+    vals_np = np.ascontiguousarray(vals_np, dtype=np.float32)
+    rows, dim = vals_np.shape
+    self._ck(self.lib.er_save_dense_embed(ckpt_path.encode(), var_name.encode(), ctypes.c_int32(task_index),
+                                          ctypes.c_int32(task_num), vals_np.ctypes.data_as(ctypes.c_void_p),
+                                          ctypes.c_int64(rows), ctypes.c_int32(dim)), 'er_save_dense_embed')
+
+  def load_dense_embed(self, ckpt_path, var_name, task_index, task_num, embed_dim, embed_part_size):
+    out = np.empty((embed_part_size, embed_dim), dtype=np.float32)
+    n = ctypes.c_int64(0)
+    self._ck(self.lib.er_load_dense_embed(ckpt_path.encode(), var_name.encode(), ctypes.c_int32(task_index),
+                                          ctypes.c_int32(task_num), ctypes.c_int32(embed_dim),
+                                          ctypes.c_int64(embed_part_size), out.ctypes.data_as(ctypes.c_void_p),
+                                          ctypes.byref(n)), 'er_load_dense_embed')
+    return out
+
+  def load_kv_embed(self, ckpt_path, var_name, task_index, task_num, embed_dim):
+    n = ctypes.c_int64(0)
+    args = (ckpt_path.encode(), var_name.encode(), ctypes.c_int32(task_index), ctypes.c_int32(task_num),
+            ctypes.c_int32(embed_dim))
+    self._ck(self.lib.er_load_kv_embed(*args, ctypes.c_int64(0), None, None, ctypes.byref(n)), 'er_load_kv_embed')
+    keys = np.empty(n.value, dtype=np.int64)
+    vals = np.empty((n.value, embed_dim), dtype=np.float32)
+    if n.value:
+      self._ck(self.lib.er_load_kv_embed(*args, ctypes.c_int64(n.value), keys.ctypes.data_as(ctypes.c_void_p),
+                                         vals.ctypes.data_as(ctypes.c_void_p), ctypes.byref(n)), 'er_load_kv_embed')
+    return keys, vals
+
   # -- K1 hashing
   def hash_bucket_fast_host(self, bytes_np, offsets_np, n_per_col, num_buckets, drop_empty):
     """numpy in / numpy out; runs on the host (data-loader threads)."""

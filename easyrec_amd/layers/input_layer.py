@@ -157,6 +157,14 @@ class EmbeddingEngine(object):
     for dim, grp in self.emb_groups.items():
       be.emb_flush_decay(grp, self._clock[2])
 
+  def mark_restored(self, step):
+    """Tables were loaded as of `step` finished steps: no decay is pending on any row."""
+    for lz in self._lazy_states():
+      lz['last_step'].fill_(int(step) - 1)
+
+  def _lazy_states(self):
+    return list(self._lazy.values())
+
   def _alloc_storage(self, total, dim, opt_kind, force_bitmap=False):
     var = torch.empty(total, dim, dtype=torch.float32, device=self.device)
     st = {'var': var, 'm': None, 'v': None, 'bitmap': None, 'total_rows': total}

@@ -293,6 +293,9 @@ class ShardedEmbeddingEngine(EmbeddingEngine):
       if sh['lazy'] is not None:
         be.emb_flush_decay(sh['owner'], self._clock[2])
 
+  def _lazy_states(self):
+    return [sh['lazy'] for sh in self.shard.values() if sh.get('lazy')]
+
   # -- host exchange (collective: every rank must call)
   def table_view(self, name):
     kind, dim, base, n_local = self.placement[name]

@@ -258,6 +258,20 @@ class EasyRecEstimator(object):
                 self.varstore._vars[name]['tensor'].shape).cpu().numpy().copy()
     return sd
 
+  def set_global_step(self, step):
+    """Continue from `step` optimisation steps (checkpoint restore): host and device step counters, the optimizers'
+    beta powers and the pre-planned per-step scalars restart there; the tables are taken to be current."""
+    assert self.graph is None or step == self.global_step, 'restore before capture()'
+    if self.device.type == 'cuda':
+      torch.cuda.synchronize()
+    self.global_step = int(step)
+    self.step_counter.fill_(int(step))
+    for opt in {id(o): o for o in (self.opt_emb, self.opt_dense)}.values():
+      opt.reset_to_step(step)
+    self._planned_until = int(step)
+    self._plan_hyper(self.HYPER_SLOTS)
+    self.engine.mark_restored(int(step))
+
   def load_state_dict(self, state):
     self.varstore.load_state_dict(state, strict=False)
     self.engine.load_state_dict(state)

@@ -1,0 +1,108 @@
+"""Checkpoints with the reference's sharded embedding files.
+
+Reference: easy_rec/python/compat/embedding_parallel_saver.py:99-190 - under embedding parallelism every worker
+writes its shard of every embedding variable to `<ckpt>-embedding/embed-<var name, '/' -> '__'>-part-<rank>.bin`
+(raw float32 rows; row i of worker k is table row i * W + k) and on restore re-shards whatever parts it finds by
+`row % world` (native op ops/src/load_dense_embed.cc -> er_load_dense_embed).  The optimizer's slot variables are
+sharded the same way and use TF's slot names (`<var>/Adam`, `<var>/Adam_1`, `<var>/Adagrad`).
+
+Everything else - dense variables, their slots, the step - goes through the TF Saver in the reference (tensor-bundle
+files); that format is not written here: `<ckpt>.dense.npz` holds the same arrays under the same TF variable names.
+
+A checkpoint written by W workers loads on any other number (1 GPU <-> 8 GPUs): that is what the re-shard is for.
+"""
+import os
+
+import numpy as np
+import torch
+
+from easyrec_amd import kernels
+
+_SLOT_NAMES = {  # estimator slot -> TF slot variable suffix, per optimizer kind
+    kernels.OPT_ADAM: {'m': 'Adam', 'v': 'Adam_1'},
+    kernels.OPT_LAZY_ADAM: {'m': 'Adam', 'v': 'Adam_1'},
+    kernels.OPT_ADAGRAD: {'v': 'Adagrad'},
+    kernels.OPT_SGD: {},
+}
+
+
+def embed_file_var_name(tf_var_name):
+  """embedding_parallel_saver.py:103-111: 'embed-' + embed_var.name with '/' -> '__' (TF names end in ':0')."""
+  return 'embed-' + (tf_var_name + ':0').replace('/', '__')
+
+
+def _host_backend():
+  # file I/O entry points of libeasyrec_hip.so: usable without a GPU, whatever backend the layers run on
+  return kernels.HipBackend()
+
+
+def _engine_tables(engine):
+  """[(table name, sharded?, local rows tensor getter)]"""
+  sharded = hasattr(engine, 'placement')
+  for name in engine.tables:
+    is_shard = sharded and engine.placement[name][0] != 'rep'
+    yield name, is_shard
+
+
+def save(est, ckpt_path):
+  """Every rank calls it.  Rank 0 writes the dense file; every rank its embedding shards (replicated and
+  single-GPU tables: rank 0 alone, as a one-part table)."""
+  be = _host_backend()
+  engine = est.engine
+  rank, world = getattr(engine, 'rank', 0), getattr(engine, 'world', 1)
+  engine.flush_decay()
+  if est.device.type == 'cuda':
+    torch.cuda.synchronize()
+  os.makedirs(os.path.dirname(os.path.abspath(ckpt_path)) or '.', exist_ok=True)
+  slots = _SLOT_NAMES[est.opt_emb.kind]
+  for name, is_shard in _engine_tables(engine):
+    if not is_shard and rank != 0:
+      continue
+    t_idx, t_num = (rank, world) if is_shard else (0, 1)
+    be.save_dense_embed(ckpt_path, embed_file_var_name(name), t_idx, t_num, engine.table_view(name).cpu().numpy())
+    for s, suffix in slots.items():
+      sv = engine.slot_view(name, s)
+      if sv is not None:
+        be.save_dense_embed(ckpt_path, embed_file_var_name(name + '/' + suffix), t_idx, t_num, sv.cpu().numpy())
+  if rank == 0:
+    dense = {}
+    vs = est.varstore
+    for k, v in vs.state_dict().items():
+      dense[k] = np.asarray(v)
+    dslots = _SLOT_NAMES[est.opt_dense.kind]
+    for name in vs.trainable_names():
+      o, n = vs._offsets[name]
+      for s, suffix in dslots.items():
+        if s in vs.slots:
+          dense[name + '/' + suffix] = vs.slots[s][o:o + n].view(vs._vars[name]['tensor'].shape).cpu().numpy().copy()
+    dense['global_step'] = np.asarray(int(est.global_step), dtype=np.int64)
+    np.savez(ckpt_path + '.dense.npz', **dense)
+
+
+def restore(est, ckpt_path):
+  """Every rank calls it; the embedding parts may have been written by a different number of workers."""
+  be = _host_backend()
+  engine = est.engine
+  rank, world = getattr(engine, 'rank', 0), getattr(engine, 'world', 1)
+  slots = _SLOT_NAMES[est.opt_emb.kind]
+  for name, is_shard in _engine_tables(engine):
+    t_idx, t_num = (rank, world) if is_shard else (0, 1)
+    view = engine.table_view(name)
+    n_local, dim = view.shape
+    view.copy_(torch.from_numpy(be.load_dense_embed(ckpt_path, embed_file_var_name(name), t_idx, t_num, dim, n_local)))
+    for s, suffix in slots.items():
+      sv = engine.slot_view(name, s)
+      if sv is not None:
+        sv.copy_(torch.from_numpy(
+            be.load_dense_embed(ckpt_path, embed_file_var_name(name + '/' + suffix), t_idx, t_num, dim, n_local)))
+  z = np.load(ckpt_path + '.dense.npz')
+  vs = est.varstore
+  vs.load_state_dict({k: z[k] for k in z.files}, strict=False)
+  dslots = _SLOT_NAMES[est.opt_dense.kind]
+  for name in vs.trainable_names():
+    o, n = vs._offsets[name]
+    for s, suffix in dslots.items():
+      key = name + '/' + suffix
+      if s in vs.slots and key in z.files:
+        vs.slots[s][o:o + n].copy_(torch.from_numpy(z[key].reshape(-1)).to(vs.slots[s].device))
+  est.set_global_step(int(z['global_step']))

@@ -475,6 +475,32 @@ int er_scatter_unique(const uint32_t* keys, const float* grads, const int32_t* n
 int er_dense_opt_step(float* w, float* m, float* v, const float* grad, const float* l2coef,
                       int64_t n, int opt_kind, const er_opt_hyper* hyper, er_stream_t stream);
 
+/* ----------------------------------------------------------------------------------------------
+ * K14  Sharded embedding checkpoint files (host code, no device work).
+ * Replaces the reference's two native TF ops and the python writer around them:
+ *   ops/src/load_dense_embed.cc:54-135 (LoadEmbedOp), ops/src/load_kv_embed.cc:60-163 (LoadKVEmbedOp),
+ *   compat/embedding_parallel_saver.py:99-127 (_save_dense_embedding).
+ * Files live in "<ckpt_path>-embedding/": "<var_name>-part-<k>.bin" = raw float32 rows of worker k's shard
+ * (rows k, k + P, k + 2P, ... of the table, P = number of parts); var_name is "embed-" + the TF variable
+ * name with '/' replaced by "__" (e.g. "embed-input_layer__user_id_embedding__embedding_weights:0").
+ *   er_save_dense_embed : write this worker's shard; worker 0 deletes parts of workers >= task_num.
+ *   er_load_dense_embed : fill out_vals [embed_part_size, embed_dim] (host) with the rows id % task_num ==
+ *     task_index at local position id / task_num, from parts written by ANY number of workers; rows the files
+ *     do not hold are zero.  Fails unless embed_part_size or embed_part_size - 1 rows were found (the check of
+ *     load_dense_embed.cc:121-126).
+ *   er_load_kv_embed    : key/value tables ("-part-<k>.key" int64, ".val" float32 [n, embed_dim]): the keys
+ *     with key mod task_num == task_index.  Call with out_keys = NULL to get the count in *n_keys, then with
+ *     buffers of that capacity.  (The reference shuffles the result; here it is in file order.)
+ * -------------------------------------------------------------------------------------------- */
+int er_save_dense_embed(const char* ckpt_path, const char* var_name, int32_t task_index, int32_t task_num,
+                        const float* vals_host, int64_t rows, int32_t embed_dim);
+int er_load_dense_embed(const char* ckpt_path, const char* var_name, int32_t task_index, int32_t task_num,
+                        int32_t embed_dim, int64_t embed_part_size, float* out_vals_host,
+                        int64_t* rows_loaded);
+int er_load_kv_embed(const char* ckpt_path, const char* var_name, int32_t task_index, int32_t task_num,
+                     int32_t embed_dim, int64_t capacity, int64_t* out_keys_host, float* out_vals_host,
+                     int64_t* n_keys);
+
 #ifdef __cplusplus
 }
 #endif

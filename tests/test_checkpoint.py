@@ -1,0 +1,166 @@
+"""Sharded embedding checkpoints: the file format and re-sharding of
+compat/embedding_parallel_saver.py + ops/src/load_dense_embed.cc / load_kv_embed.cc."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+CFG = os.path.join(ROOT, 'configs', 'deepfm_criteo_small.config')
+
+
+def _ref_load_embed(folder, var_name, embed_dim, embed_part_size, part_id, part_num):
+  """Restatement of the reference's python fallback `_load_embed` (embedding_parallel_saver.py:140-168)."""
+  import glob
+  files = glob.glob(os.path.join(folder, var_name + '-part-*.bin'))
+  files.sort(key=lambda p: int(p.split('-')[-1].replace('.bin', '')))
+  out = np.zeros([embed_part_size, embed_dim], dtype=np.float32)
+  for f in files:
+    part_id_o = int(f.split('-')[-1].replace('.bin', ''))
+    val = np.frombuffer(open(f, 'rb').read(), np.float32).reshape([-1, embed_dim])
+    ids_o = part_id_o + np.arange(len(val)) * len(files)
+    sel = np.where(np.logical_and((ids_o % part_num) == part_id, ids_o < embed_part_size * part_num))[0]
+    out[np.array(ids_o[sel] / part_num, dtype=np.int64)] = val[sel]
+  return out
+
+
+@pytest.mark.parametrize('rows,dim,w_old,w_new', [(103, 8, 3, 2), (64, 1, 1, 4), (1000, 16, 8, 1), (17, 4, 2, 5)])
+def test_dense_embed_files_reshard_like_the_reference(tmp_path, built_lib, rows, dim, w_old, w_new):
+  from easyrec_amd import kernels
+  be = kernels.HipBackend()
+  rng = np.random.default_rng(rows)
+  table = rng.standard_normal((rows, dim)).astype(np.float32)
+  ckpt = os.path.join(str(tmp_path), 'model.ckpt-7')
+  var = 'embed-input_layer__c1_embedding__embedding_weights:0'
+  n_old = (rows + w_old - 1) // w_old
+  # a stale part of a larger previous world must disappear when worker 0 saves
+  os.makedirs(ckpt + '-embedding')
+  open(os.path.join(ckpt + '-embedding', var + '-part-%d.bin' % (w_old + 2)), 'wb').write(b'junk')
+  for k in range(w_old - 1, -1, -1):
+    shard = np.zeros((n_old, dim), dtype=np.float32)
+    mine = table[k::w_old]
+    shard[:len(mine)] = mine
+    be.save_dense_embed(ckpt, var, k, w_old, shard)
+  names = sorted(os.listdir(ckpt + '-embedding'))
+  assert names == sorted(var + '-part-%d.bin' % k for k in range(w_old))
+  n_new = (rows + w_new - 1) // w_new
+  full = np.zeros((n_new * w_new, dim), dtype=np.float32)
+  for r in range(w_new):
+    got = be.load_dense_embed(ckpt, var, r, w_new, dim, n_new)
+    assert np.array_equal(got, _ref_load_embed(ckpt + '-embedding', var, dim, n_new, r, w_new))
+    full[r::w_new] = got
+  assert np.array_equal(full[:rows], table) and not full[rows:].any()
+  with pytest.raises(RuntimeError):  # a shard size the files cannot fill: the reference op's consistency check
+    be.load_dense_embed(ckpt, var, 0, w_new, dim, n_new + 5)
+
+
+def test_kv_embed_files(tmp_path, built_lib):
+  from easyrec_amd import kernels
+  be = kernels.HipBackend()
+  rng = np.random.default_rng(0)
+  ckpt = os.path.join(str(tmp_path), 'model.ckpt-1')
+  os.makedirs(ckpt + '-embedding')
+  var, dim = 'embed-kv_table:0', 4
+  all_k, all_v = [], []
+  for part in range(3):
+    k = rng.integers(-10**12, 10**12, size=50 + part).astype(np.int64)
+    v = rng.standard_normal((len(k), dim)).astype(np.float32)
+    k.tofile(os.path.join(ckpt + '-embedding', '%s-part-%d.key' % (var, part)))
+    v.tofile(os.path.join(ckpt + '-embedding', '%s-part-%d.val' % (var, part)))
+    all_k.append(k)
+    all_v.append(v)
+  all_k, all_v = np.concatenate(all_k), np.concatenate(all_v)
+  seen = 0
+  for r in range(4):
+    keys, vals = be.load_kv_embed(ckpt, var, r, 4, dim)
+    sel = (all_k % 4) == r  # numpy's % is non-negative like the op's fixed-up remainder (load_kv_embed.cc:123-127)
+    assert np.array_equal(keys, all_k[sel]) and np.array_equal(vals, all_v[sel])
+    seen += len(keys)
+  assert seen == len(all_k)
+
+
+def _train(est, batches):
+  out = []
+  for b in batches:
+    est.train_step(b)
+    out.append(est.loss_values())
+  return out
+
+
+@pytest.mark.parametrize('optimizer', [None, 'lazy'])
+def test_save_restore_continues_bit_identically(ref_backend, built_lib, tmp_path, optimizer):
+  """3 steps, save, restore into a freshly built estimator (other seed), 2 more steps == 5 uninterrupted steps."""
+  from test_embedding_parallel import _cfg_and_batches
+  from easyrec_amd.model.easy_rec_estimator import EasyRecEstimator
+  from easyrec_amd.utils import checkpoint
+  B = 16
+  cfg, batches = _cfg_and_batches(B, 5, optimizer)
+  a = EasyRecEstimator(cfg, device='cpu', batch_size=B, seed=3).build()
+  _train(a, batches[:3])
+  ckpt = os.path.join(str(tmp_path), 'model.ckpt-3')
+  checkpoint.save(a, ckpt)
+  files = os.listdir(ckpt + '-embedding')
+  assert 'embed-input_layer__C1_embedding__embedding_weights:0-part-0.bin' in files, files[:4]
+  assert any(f.endswith('embedding_weights__Adam_1:0-part-0.bin') for f in files)
+  rest_a = _train(a, batches[3:])
+  b = EasyRecEstimator(cfg, device='cpu', batch_size=B, seed=99).build()
+  checkpoint.restore(b, ckpt)
+  assert b.global_step == 3
+  rest_b = _train(b, batches[3:])
+  assert rest_a == rest_b
+  sa, sb = a.state_dict(slots=True), b.state_dict(slots=True)
+  assert set(sa) == set(sb)
+  for k in sa:
+    assert np.array_equal(sa[k], sb[k]), k
+
+
+def _gloo_ckpt_worker(rank, world, port, B, out_dir):
+  sys.path.insert(0, ROOT)
+  sys.path.insert(0, os.path.join(ROOT, 'tests'))
+  os.environ['MASTER_ADDR'] = '127.0.0.1'
+  os.environ['MASTER_PORT'] = str(port)
+  import torch.distributed as dist
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  torch.set_num_threads(1)
+  from easyrec_amd import kernels
+  from oracle.kernel_ref import RefBackend
+  kernels._BACKEND = RefBackend()
+  from test_embedding_parallel import _cfg_and_batches
+  from easyrec_amd.model.embedding_parallel import EmbeddingParallelEstimator
+  from easyrec_amd.utils import checkpoint
+  cfg, batches = _cfg_and_batches(B, 2)
+  est = EmbeddingParallelEstimator(cfg, device='cpu', batch_size=B, seed=3, rank=rank, world=world,
+                                   replicate_bytes=1024).build()
+  for b in batches:
+    est.train_step(b)
+  checkpoint.save(est, os.path.join(out_dir, 'model.ckpt-2'))
+  state = est.state_dict(slots=True)
+  if rank == 0:
+    np.savez(os.path.join(out_dir, 'state.npz'), **{k.replace('/', '|'): v for k, v in state.items()})
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+def test_two_rank_checkpoint_restores_on_one_rank(ref_backend, built_lib, tmp_path):
+  """World 2 (gloo) trains and saves part-0 / part-1 files; a single-GPU estimator restores them: every table,
+  slot and dense variable equals the two-rank run's gathered state (the re-shard by row % world)."""
+  import torch.multiprocessing as mp
+  from test_embedding_parallel import _cfg_and_batches
+  from easyrec_amd.model.easy_rec_estimator import EasyRecEstimator
+  from easyrec_amd.utils import checkpoint
+  B, world = 24, 2
+  port = 31500 + (os.getpid() % 2000)
+  mp.spawn(_gloo_ckpt_worker, args=(world, port, B, str(tmp_path)), nprocs=world, join=True)
+  names = os.listdir(os.path.join(str(tmp_path), 'model.ckpt-2-embedding'))
+  assert any(n.endswith('-part-1.bin') for n in names) and any(n.endswith('-part-0.bin') for n in names)
+  cfg, _ = _cfg_and_batches(B, 2)
+  est = EasyRecEstimator(cfg, device='cpu', batch_size=B, seed=42).build()
+  checkpoint.restore(est, os.path.join(str(tmp_path), 'model.ckpt-2'))
+  want = {k.replace('|', '/'): v for k, v in np.load(os.path.join(str(tmp_path), 'state.npz')).items()}
+  got = est.state_dict(slots=True)
+  assert set(got) == set(want)
+  for k in want:
+    assert np.array_equal(got[k], want[k]), k
