@@ -425,6 +425,68 @@ mmoe_mix_bwd_gate_kernel(const float* __restrict__ experts, const float* __restr
 
 inline int blocks_for(int64_t n) { return static_cast<int>(ceil_div(n, kBlock)); }
 
+// ------------------------------------------------------------------------------------------------
+// K15 DLRM dot interaction: all pairwise dot products of the F feature vectors of an example.
+// One workgroup per example: the [F][D] block is staged in LDS (row stride D + 1: lanes of a wave read
+// different rows), thread t owns pairs t, t + 256, ... (forward) or elements (f, d) (backward).
+// Pair order = the reference's: for i in 0..F-1: for j in i + offset .. F-1 (model/dlrm.py:51-57).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int dot_pair_index(int i, int j, int F, int offset) {
+  // pairs before row i: sum_{r < i} (F - r - offset) = i * (F - offset) - i (i - 1) / 2
+  return i * (F - offset) - (i * (i - 1)) / 2 + (j - i - offset);
+}
+
+__global__ void __launch_bounds__(kBlock)
+dot_interaction_fwd_kernel(const float* __restrict__ x, int F, int D, int x_stride, int offset, int P,
+                           float* __restrict__ out, int out_stride) {
+  extern __shared__ float xs[];  // [F][D + 1]
+  const int b = blockIdx.x;
+  const float* xb = x + static_cast<int64_t>(b) * x_stride;
+  const int SD = D + 1;
+  for (int e = threadIdx.x; e < F * D; e += kBlock) xs[(e / D) * SD + e % D] = xb[e];
+  __syncthreads();
+  for (int p = threadIdx.x; p < P; p += kBlock) {
+    // invert the pair index: rows are short (F <= 128), walk them
+    int i = 0, rem = p;
+    while (rem >= F - i - offset) { rem -= F - i - offset; ++i; }
+    const int j = i + offset + rem;
+    const float* a = xs + i * SD;
+    const float* c = xs + j * SD;
+    float acc = 0.f;
+    for (int d = 0; d < D; ++d) acc = acc + a[d] * c[d];
+    out[static_cast<int64_t>(b) * out_stride + p] = acc;
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+dot_interaction_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g, int F, int D, int x_stride,
+                           int offset, int P, int g_stride, float* __restrict__ dx, int dx_stride, int accumulate) {
+  extern __shared__ float sm[];  // xs [F][D + 1], then gs [P]
+  const int b = blockIdx.x;
+  const int SD = D + 1;
+  float* xs = sm;
+  float* gs = sm + F * SD;
+  const float* xb = x + static_cast<int64_t>(b) * x_stride;
+  for (int e = threadIdx.x; e < F * D; e += kBlock) xs[(e / D) * SD + e % D] = xb[e];
+  for (int p = threadIdx.x; p < P; p += kBlock) gs[p] = g[static_cast<int64_t>(b) * g_stride + p];
+  __syncthreads();
+  for (int e = threadIdx.x; e < F * D; e += kBlock) {
+    const int f = e / D, d = e % D;
+    float acc = 0.f;
+    // d out(i, j) / d x_f = x_j (i == f) + x_i (j == f): partners in ascending order
+    for (int o = 0; o < F; ++o) {
+      if (o == f) {
+        if (offset == 0) acc = acc + 2.f * gs[dot_pair_index(f, f, F, 0)] * xs[f * SD + d];
+        continue;
+      }
+      const int i = o < f ? o : f, j = o < f ? f : o;
+      acc = acc + gs[dot_pair_index(i, j, F, offset)] * xs[o * SD + d];
+    }
+    float* p = dx + static_cast<int64_t>(b) * dx_stride + e;
+    *p = accumulate ? *p + acc : acc;
+  }
+}
+
 }  // namespace er
 
 extern "C" {
@@ -601,6 +663,36 @@ int er_mmoe_mix_bwd(const float* experts, const float* gates, const float* dout,
   hipLaunchKernelGGL(er::mmoe_mix_bwd_gate_kernel,
                      dim3(static_cast<int>(er::ceil_div(static_cast<int64_t>(T) * B, er::kBlock / 64))),
                      dim3(er::kBlock), 0, s, experts, gates, dout, T, E, B, H, dgate_logits);
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
+int er_dot_interaction_fwd(const float* x, int32_t B, int32_t F, int32_t D, int32_t x_stride, int self_interaction,
+                           float* out, int32_t out_stride, er_stream_t stream) {
+  ER_REQUIRE(x && out && B > 0 && F > 1 && D > 0 && x_stride >= F * D, "er_dot_interaction_fwd: bad arguments");
+  const int offset = self_interaction ? 0 : 1;
+  const int P = F * (F - 1) / 2 + (self_interaction ? F : 0);
+  ER_REQUIRE(out_stride >= P, "er_dot_interaction_fwd: out_stride %d < %d pairs", out_stride, P);
+  const size_t lds = sizeof(float) * static_cast<size_t>(F) * (D + 1);
+  ER_REQUIRE(lds <= 60 * 1024, "er_dot_interaction_fwd: F * (D + 1) = %d floats exceed the LDS budget", F * (D + 1));
+  hipLaunchKernelGGL(er::dot_interaction_fwd_kernel, dim3(B), dim3(er::kBlock), lds, er::as_stream(stream), x, F, D,
+                     x_stride, offset, P, out, out_stride);
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
+int er_dot_interaction_bwd(const float* x, const float* g, int32_t B, int32_t F, int32_t D, int32_t x_stride,
+                           int self_interaction, int32_t g_stride, float* dx, int32_t dx_stride, int accumulate,
+                           er_stream_t stream) {
+  ER_REQUIRE(x && g && dx && B > 0 && F > 1 && D > 0 && x_stride >= F * D && dx_stride >= F * D,
+             "er_dot_interaction_bwd: bad arguments");
+  const int offset = self_interaction ? 0 : 1;
+  const int P = F * (F - 1) / 2 + (self_interaction ? F : 0);
+  ER_REQUIRE(g_stride >= P, "er_dot_interaction_bwd: g_stride %d < %d pairs", g_stride, P);
+  const size_t lds = sizeof(float) * (static_cast<size_t>(F) * (D + 1) + P);
+  ER_REQUIRE(lds <= 60 * 1024, "er_dot_interaction_bwd: %zu bytes exceed the LDS budget", lds);
+  hipLaunchKernelGGL(er::dot_interaction_bwd_kernel, dim3(B), dim3(er::kBlock), lds, er::as_stream(stream), x, g, F, D,
+                     x_stride, offset, P, g_stride, dx, dx_stride, accumulate);
   ER_LAUNCH_CHECK();
   return 0;
 }

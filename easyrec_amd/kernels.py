@@ -524,6 +524,24 @@ class HipBackend(object):
         'er_fm_bwd')
     return dx
 
+  def dot_interaction_fwd(self, x, F, D, self_interaction):
+    """x [B, F*D] -> [B, P] pairwise dot products in the order of model/dlrm.py:51-57."""
+    B = x.shape[0]
+    P = F * (F - 1) // 2 + (F if self_interaction else 0)
+    out = torch.empty(B, P, dtype=torch.float32, device=x.device)
+    self._ck(self.lib.er_dot_interaction_fwd(_p(x), B, F, D, x.stride(0), int(bool(self_interaction)), _p(out),
+                                             out.stride(0), _stream()), 'er_dot_interaction_fwd')
+    return out
+
+  def dot_interaction_bwd(self, x, g, F, D, self_interaction):
+    B = x.shape[0]
+    dx = torch.empty(B, F * D, dtype=torch.float32, device=x.device)
+    g = _f32c(g)
+    self._ck(self.lib.er_dot_interaction_bwd(_p(x), _p(g), B, F, D, x.stride(0), int(bool(self_interaction)),
+                                             g.stride(0), _p(dx), dx.stride(0), 0, _stream()),
+             'er_dot_interaction_bwd')
+    return dx
+
   def rowsum_fwd(self, x, n):
     B = x.shape[0]
     out = torch.empty(B, 1, dtype=torch.float32, device=x.device)
@@ -909,6 +927,24 @@ class FMFn(torch.autograd.Function):
       full[:, :ctx.F * ctx.D] = dx
       dx = full
     return dx, None, None
+
+
+class DotInteractionFn(torch.autograd.Function):
+  """DLRM's pairwise feature interaction (reference model/dlrm.py:44-57) over a contiguous [B, F*D] block."""
+
+  @staticmethod
+  def forward(ctx, x, F, D, self_interaction):
+    x = x if (x.stride(-1) == 1 and x.dim() == 2) else x.contiguous()
+    out = hip().dot_interaction_fwd(x, F, D, self_interaction)
+    ctx.save_for_backward(x)
+    ctx.F, ctx.D, ctx.self_interaction = F, D, self_interaction
+    return out
+
+  @staticmethod
+  def backward(ctx, g):
+    x, = ctx.saved_tensors
+    dx = hip().dot_interaction_bwd(x, g.contiguous(), ctx.F, ctx.D, ctx.self_interaction)
+    return dx, None, None, None
 
 
 class RowSumFn(torch.autograd.Function):

@@ -476,6 +476,20 @@ int er_dense_opt_step(float* w, float* m, float* v, const float* grad, const flo
                       int64_t n, int opt_kind, const er_opt_hyper* hyper, er_stream_t stream);
 
 /* ----------------------------------------------------------------------------------------------
+ * K15 DLRM dot interaction.  Replaces einsum('bne,bme->bnm') + the upper-triangle slicing / concat of
+ *     DLRM.build_predict_graph easy_rec/python/model/dlrm.py:44-57.
+ * x: [B, F*D] (row stride x_stride), the F feature vectors of an example back to back;
+ * out[b, p] = <x[b,i,:], x[b,j,:]> for the pairs in the reference's order: i = 0..F-1, j = i + offset..F-1,
+ * offset = 0 with self_interaction (arch_interaction_itself), else 1; P = F(F-1)/2 (+ F).
+ * bwd: dx[b,f,:] (+)= sum over pairs containing f of g[b,p] * the partner vector (twice for a self pair).
+ * -------------------------------------------------------------------------------------------- */
+int er_dot_interaction_fwd(const float* x, int32_t B, int32_t F, int32_t D, int32_t x_stride,
+                           int self_interaction, float* out, int32_t out_stride, er_stream_t stream);
+int er_dot_interaction_bwd(const float* x, const float* g, int32_t B, int32_t F, int32_t D,
+                           int32_t x_stride, int self_interaction, int32_t g_stride, float* dx,
+                           int32_t dx_stride, int accumulate, er_stream_t stream);
+
+/* ----------------------------------------------------------------------------------------------
  * K14  Sharded embedding checkpoint files (host code, no device work).
  * Replaces the reference's two native TF ops and the python writer around them:
  *   ops/src/load_dense_embed.cc:54-135 (LoadEmbedOp), ops/src/load_kv_embed.cc:60-163 (LoadKVEmbedOp),

@@ -462,6 +462,24 @@ class RefBackend(object):
     e = x[:, :F * D].reshape(x.shape[0], F, D)
     return (g[:, None, :] * (S[:, None, :] - e)).reshape(x.shape[0], F * D)
 
+  @staticmethod
+  def _dot_pairs(F, self_interaction):
+    off = 0 if self_interaction else 1
+    return [(i, j) for i in range(F) for j in range(i + off, F)]  # model/dlrm.py:51-57
+
+  def dot_interaction_fwd(self, x, F, D, self_interaction):
+    e = x[:, :F * D].reshape(x.shape[0], F, D)
+    inter = torch.einsum('bne,bme->bnm', e, e)
+    return torch.stack([inter[:, i, j] for i, j in self._dot_pairs(F, self_interaction)], dim=1)
+
+  def dot_interaction_bwd(self, x, g, F, D, self_interaction):
+    e = x[:, :F * D].reshape(x.shape[0], F, D)
+    de = torch.zeros_like(e)
+    for p, (i, j) in enumerate(self._dot_pairs(F, self_interaction)):
+      de[:, i] += g[:, p:p + 1] * e[:, j]
+      de[:, j] += g[:, p:p + 1] * e[:, i]
+    return de.reshape(x.shape[0], F * D)
+
   def rowsum_fwd(self, x, n):
     return x[:, :n].sum(dim=1, keepdim=True)
 

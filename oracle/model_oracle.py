@@ -374,6 +374,75 @@ class OracleTrainer(object):
     out = self.dense(V, all_fea, mc.num_class, 'output', 0.0)  # no kernel_regularizer (dcn.py:66)
     return {'logits': out.squeeze(1)}
 
+  def _wide_and_deep(self, V, batch):
+    """easy_rec/python/model/wide_and_deep.py:38-86"""
+    mc = self.cfg.model_config
+    c = mc.wide_and_deep
+    l2 = self._l2_of(mc)
+    has_final = len(c.final_dnn.hidden_units) > 0
+    wd = c.wide_output_dim if has_final else mc.num_class
+    _, wide_list = self.input_layer(V, batch, 'wide', 'input_layer', wide_dim=wd)
+    deep, _ = self.input_layer(V, batch, 'deep', 'input_layer_1')
+    wide_fea = torch.stack(wide_list, dim=0).sum(dim=0)  # add_n
+    deep_fea = self.dnn(V, deep, c.dnn, 'deep_feature', l2)
+    if has_final:
+      all_fea = self.dnn(V, torch.cat([wide_fea, deep_fea], dim=1), c.final_dnn, 'final_dnn', l2)
+      out = self.dense(V, all_fea, mc.num_class, 'output', l2)
+    else:
+      out = self.dense(V, deep_fea, mc.num_class, 'deep_out', l2) + wide_fea
+    return {'logits': out.squeeze(1)}
+
+  def _fm(self, V, batch):
+    """easy_rec/python/model/fm.py:35-63"""
+    mc = self.cfg.model_config
+    wide, _ = self.input_layer(V, batch, 'wide', 'input_layer', wide_dim=mc.num_class)
+    _, fm_list = self.input_layer(V, batch, 'deep', 'input_layer_1')
+    wide_fea = wide.sum(dim=1, keepdim=True)
+    e = torch.stack(fm_list, dim=1)
+    fm_fea = 0.5 * (e.sum(dim=1)**2 - (e**2).sum(dim=1))
+    assert mc.num_class == 1
+    out = (wide_fea + fm_fea.sum(dim=1, keepdim=True)) + V.get('fm_bias')
+    return {'logits': out.squeeze(1)}
+
+  def _multi_tower(self, V, batch):
+    """easy_rec/python/model/multi_tower.py:37-62"""
+    mc = self.cfg.model_config
+    c = mc.multi_tower
+    l2 = self._l2_of(mc)
+    feats = [self.input_layer(V, batch, t.input, 'input_layer' if i == 0 else 'input_layer_%d' % i)[0]
+             for i, t in enumerate(c.towers)]
+    outs = []
+    for t, fea in zip(c.towers, feats):
+      fea = self.batch_norm(V, fea, '%s_fea_bn' % t.input)
+      outs.append(self.dnn(V, fea, t.dnn, '%s_dnn' % t.input, l2))
+    all_fea = self.dnn(V, torch.cat(outs, dim=1), c.final_dnn, 'final_dnn', l2)
+    out = self.dense(V, all_fea, mc.num_class, 'output', 0.0)  # no kernel_regularizer (multi_tower.py:58)
+    return {'logits': out.squeeze(1)}
+
+  def _dlrm(self, V, batch):
+    """easy_rec/python/model/dlrm.py:36-73"""
+    mc = self.cfg.model_config
+    c = mc.dlrm
+    l2 = self._l2_of(mc)
+    _, sparse = self.input_layer(V, batch, 'sparse', 'input_layer')
+    dense, _ = self.input_layer(V, batch, 'dense', 'input_layer_1')
+    dense_fea = self.dnn(V, dense, c.bot_dnn, 'bot_dnn', l2)
+    if c.arch_interaction_op == 'cat':
+      all_fea = torch.cat([dense_fea] + sparse, dim=1)
+    else:
+      feas = torch.stack([dense_fea] + sparse, dim=1)
+      inter = torch.einsum('bne,bme->bnm', feas, feas)
+      off = 0 if c.arch_interaction_itself else 1
+      n = feas.shape[1]
+      upper = torch.cat([inter[:, i, i + off:n] for i in range(n)], dim=1)
+      parts = [upper] + sparse
+      if c.arch_with_dense_feature:
+        parts.append(dense_fea)
+      all_fea = torch.cat(parts, dim=1)
+    all_fea = self.dnn(V, all_fea, c.top_dnn, 'top_dnn', l2)
+    out = self.dense(V, all_fea, 1, 'output', l2)
+    return {'logits': out.squeeze(1)}
+
   def _din(self, V, dnn_cfg, fea, name, l2):
     """model/multi_tower_din.py:62-97."""
     q, h, seq_len = fea['key'], fea['hist_seq_emb'], fea['hist_seq_len']
@@ -557,6 +626,14 @@ class OracleTrainer(object):
         pred = self._multi_tower_din(V, batch)
       elif self.model_class == 'RankModel':
         pred = self._rank_backbone(V, batch)
+      elif self.model_class == 'WideAndDeep':
+        pred = self._wide_and_deep(V, batch)
+      elif self.model_class == 'FM':
+        pred = self._fm(V, batch)
+      elif self.model_class == 'MultiTower':
+        pred = self._multi_tower(V, batch)
+      elif self.model_class == 'DLRM':
+        pred = self._dlrm(V, batch)
       else:
         raise NotImplementedError('oracle: model_class %s' % self.model_class)
       labels = torch.as_tensor(labels_np[0], dtype=self.dtype)

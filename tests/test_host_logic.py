@@ -115,7 +115,11 @@ def test_csv_input_roundtrip(tmp_path, built_lib):
 
 @pytest.mark.parametrize('config,B', [('dcn_criteo_small.config', 32), ('din_taobao_small.config', 24),
                                       ('mmoe_taobao_small.config', 24), ('dcn_v2_criteo_small.config', 32),
-                                      ('dcn_v2_lowrank_criteo_small.config', 32)])
+                                      ('dcn_v2_lowrank_criteo_small.config', 32),
+                                      ('wide_and_deep_criteo_small.config', 24),
+                                      ('wide_and_deep_nofinal_criteo_small.config', 24), ('fm_criteo_small.config', 24),
+                                      ('multi_tower_criteo_small.config', 24), ('dlrm_criteo_small.config', 24),
+                                      ('dlrm_itself_criteo_small.config', 24), ('dlrm_cat_criteo_small.config', 24)])
 def test_other_models_match_model_oracle(ref_backend, config, B):
   """DCN / MultiTowerDIN / MMoE host logic (variable naming, layer wiring, multi-task losses, sequence and
   tag lookups) against the independent model-level oracle, 2 optimisation steps."""

@@ -838,3 +838,25 @@ def test_route_outputs_of_the_segmented_path(hip, ref, B, dims):
     assert torch.equal(uk_d[:k].cpu(), uk_c[:k])
     assert torch.equal(ui_d.cpu(), ui_c)
     hip.emb_group_destroy(gd)
+
+
+@pytest.mark.parametrize('B,F,D', [(300, 27, 16), (5, 2, 3), (64, 9, 64), (1, 40, 8)])
+@pytest.mark.parametrize('itself', [False, True])
+def test_dot_interaction(hip, ref, B, F, D, itself):
+  """er_dot_interaction_fwd / _bwd against the einsum + upper-triangle restatement of model/dlrm.py:44-57 and
+  against autograd of that formula."""
+  g = torch.Generator().manual_seed(B * 7 + F + D)
+  x = torch.randn(B, F * D, generator=g)
+  out = hip.dot_interaction_fwd(x.to(DEV), F, D, itself)
+  exp = ref.dot_interaction_fwd(x, F, D, itself)
+  assert out.shape == exp.shape == (B, F * (F - 1) // 2 + (F if itself else 0))
+  assert torch.allclose(out.cpu(), exp, rtol=1e-5, atol=1e-5)
+  go = torch.randn(exp.shape, generator=g)
+  dx = hip.dot_interaction_bwd(x.to(DEV), go.to(DEV), F, D, itself)
+  xr = x.clone().requires_grad_(True)
+  e = xr.reshape(B, F, D)
+  inter = torch.einsum('bne,bme->bnm', e, e)
+  off = 0 if itself else 1
+  torch.cat([inter[:, i, i + off:F] for i in range(F)], dim=1).backward(go)
+  assert torch.allclose(dx.cpu(), xr.grad, rtol=1e-5, atol=1e-5)
+  assert torch.allclose(ref.dot_interaction_bwd(x, go, F, D, itself), xr.grad, rtol=1e-5, atol=1e-5)
