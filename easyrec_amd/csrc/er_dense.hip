@@ -599,6 +599,27 @@ int get_scratch(size_t floats, float** out) {
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// K16 streaming AUC (tf.metrics.auc, used by RankModel.build_metric_graph, model/rank_model.py:358-373).
+// TF keeps, per threshold t, tp/fn/tn/fp = counts of (label, prediction > t).  With sorted thresholds that is a
+// histogram over bucket(p) = #{t : p > t}: counts[label][bucket], integer atomics (order-independent, exact).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+auc_hist_kernel(const float* __restrict__ probs, const float* __restrict__ labels, const float* __restrict__ weights,
+                int64_t n, const float* __restrict__ thresholds, int T, unsigned long long* __restrict__ counts) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i >= n) return;
+  if (weights && !(weights[i] > 0.f)) return;
+  const float p = probs[i];
+  int lo = 0, hi = T;  // first index with !(p > thresholds[idx]) == number of thresholds below p
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (p > thresholds[mid]) lo = mid + 1; else hi = mid;
+  }
+  const int pos = labels[i] != 0.f ? 1 : 0;  // tf.cast(labels, bool)
+  atomicAdd(&counts[static_cast<size_t>(pos) * (T + 1) + lo], 1ull);
+}
+
 }  // namespace er
 
 extern "C" {
@@ -803,6 +824,16 @@ int er_dense_opt_step(float* w, float* m, float* v, const float* grad, const flo
   if (opt_kind == ER_OPT_ADAGRAD) ER_REQUIRE(v, "er_dense_opt_step: Adagrad needs the accumulator in v");
   hipLaunchKernelGGL(er::dense_opt_kernel, dim3(er::blocks_for(n)), dim3(er::kBlock), 0, er::as_stream(stream), w, m, v,
                      grad, l2coef, n, opt_kind, hyper);
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
+int er_auc_update(const float* probs, const float* labels, const float* weights, int64_t n, const float* thresholds,
+                  int32_t num_thresholds, uint64_t* counts, er_stream_t stream) {
+  ER_REQUIRE(probs && labels && thresholds && counts && n >= 0 && num_thresholds >= 2, "er_auc_update: bad arguments");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(er::auc_hist_kernel, dim3(er::blocks_for(n)), dim3(er::kBlock), 0, er::as_stream(stream), probs, labels,
+                     weights, n, thresholds, num_thresholds, reinterpret_cast<unsigned long long*>(counts));
   ER_LAUNCH_CHECK();
   return 0;
 }

@@ -524,6 +524,15 @@ class HipBackend(object):
         'er_fm_bwd')
     return dx
 
+  def auc_update(self, probs, labels, weights, thresholds, counts):
+    """counts int64 [2, T + 1] += histogram of (label != 0, #thresholds below the prediction); see core/metrics.py."""
+    probs, labels = _f32c(probs.reshape(-1)), _f32c(labels.reshape(-1))
+    assert probs.numel() == labels.numel() and counts.dtype == torch.int64 and counts.is_contiguous()
+    assert counts.numel() == 2 * (thresholds.numel() + 1)
+    w = None if weights is None else _f32c(weights.reshape(-1))
+    self._ck(self.lib.er_auc_update(_p(probs), _p(labels), _p(w), ctypes.c_int64(probs.numel()), _p(thresholds),
+                                    ctypes.c_int32(thresholds.numel()), _p(counts), _stream()), 'er_auc_update')
+
   def dot_interaction_fwd(self, x, F, D, self_interaction):
     """x [B, F*D] -> [B, P] pairwise dot products in the order of model/dlrm.py:51-57."""
     B = x.shape[0]

@@ -223,6 +223,37 @@ class EasyRecEstimator(object):
       self.model.begin_step()
       return self.model.build_predict_graph()
 
+  def evaluate(self, batches, eval_config=None):
+    """The evaluation pass of the reference (`EasyRecEstimator._eval_model_fn` -> `build_metric_graph`,
+    model/easy_rec_estimator.py:355-420, model/rank_model.py:334-470) for the metric every shipped rank config
+    asks for: `metrics_set { auc {} }`.  The model runs with is_training=False (BatchNorm moving statistics, no
+    dropout) over `batches`; returns {'auc'[+ '_<tower>']: value}."""
+    from easyrec_amd.core import metrics as metrics_lib
+    assert self._built
+    ec = eval_config if eval_config is not None else self.pipeline_config.eval_config
+    specs = []
+    for m in ec.metrics_set:
+      kind = m.WhichOneof('metric')
+      if kind != 'auc':
+        raise NotImplementedError('metric %s is outside the hot-path scope (auc only)' % kind)
+      specs.append(int(m.auc.num_thresholds))
+    if not specs:
+      specs = [200]  # eval.proto: auc is the default metric of a rank model
+    towers = getattr(self.model, '_label_name_dict', None)
+    heads = [('', self.model._label_name)] if not towers else [('_' + t, l) for t, l in towers.items()]
+    aucs = {(suf, nt): metrics_lib.AUC(nt, self.device) for suf, _ in heads for nt in specs}
+    was = (self.model._is_training, self.ctx.is_training)
+    self.model._is_training, self.ctx.is_training = False, False
+    try:
+      for batch in batches:
+        pred = self.predict(batch)
+        for suf, label_name in heads:
+          for nt in specs:
+            aucs[(suf, nt)].update(self.features.label(label_name), pred['probs' + suf], self.features.sample_weight)
+    finally:
+      self.model._is_training, self.ctx.is_training = was
+    return {'auc' + suf: aucs[(suf, specs[0])].result() for suf, _ in heads}
+
   def capture(self, warmup=3):
     """Capture the device part of the step into one hipGraph (replayed by train_step)."""
     assert self._built and self.graph is None

@@ -476,6 +476,17 @@ int er_dense_opt_step(float* w, float* m, float* v, const float* grad, const flo
                       int64_t n, int opt_kind, const er_opt_hyper* hyper, er_stream_t stream);
 
 /* ----------------------------------------------------------------------------------------------
+ * K16 Streaming AUC.  Replaces the per-threshold confusion-matrix update of tf.metrics.auc
+ *     (RankModel.build_metric_graph, easy_rec/python/model/rank_model.py:358-373; default 200 thresholds).
+ * counts: uint64 [2][num_thresholds + 1], zero before the first batch; counts[label][k] += 1 for every example
+ * whose prediction is greater than exactly k of the (ascending) thresholds; examples with weight <= 0 are
+ * skipped (weights may be NULL).  tp(t) = sum_{k > t} counts[1][k], fp(t) likewise from counts[0]; the area is
+ * finished on the host (easyrec_amd/core/metrics.py).
+ * -------------------------------------------------------------------------------------------- */
+int er_auc_update(const float* probs, const float* labels, const float* weights, int64_t n,
+                  const float* thresholds, int32_t num_thresholds, uint64_t* counts, er_stream_t stream);
+
+/* ----------------------------------------------------------------------------------------------
  * K15 DLRM dot interaction.  Replaces einsum('bne,bme->bnm') + the upper-triangle slicing / concat of
  *     DLRM.build_predict_graph easy_rec/python/model/dlrm.py:44-57.
  * x: [B, F*D] (row stride x_stride), the F feature vectors of an example back to back;

@@ -462,6 +462,17 @@ class RefBackend(object):
     e = x[:, :F * D].reshape(x.shape[0], F, D)
     return (g[:, None, :] * (S[:, None, :] - e)).reshape(x.shape[0], F * D)
 
+  def auc_update(self, probs, labels, weights, thresholds, counts):
+    """tf.metrics.auc's per-threshold `prediction > threshold` counts, as a histogram (core/metrics.py)."""
+    p = probs.detach().reshape(-1).cpu().numpy().astype(np.float32)
+    y = labels.detach().reshape(-1).cpu().numpy() != 0
+    t = thresholds.cpu().numpy().astype(np.float32)
+    keep = np.ones(len(p), dtype=bool) if weights is None else (weights.reshape(-1).cpu().numpy() > 0)
+    bucket = (p[:, None] > t[None, :]).sum(axis=1)
+    for b, pos, k in zip(bucket, y, keep):
+      if k:
+        counts[int(pos), int(b)] += 1
+
   @staticmethod
   def _dot_pairs(F, self_interaction):
     off = 0 if self_interaction else 1

@@ -860,3 +860,31 @@ def test_dot_interaction(hip, ref, B, F, D, itself):
   torch.cat([inter[:, i, i + off:F] for i in range(F)], dim=1).backward(go)
   assert torch.allclose(dx.cpu(), xr.grad, rtol=1e-5, atol=1e-5)
   assert torch.allclose(ref.dot_interaction_bwd(x, go, F, D, itself), xr.grad, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('n,nt', [(4096, 200), (100000, 200), (5, 3)])
+def test_auc_update_counts_bit_exact(hip, ref, n, nt):
+  """er_auc_update: the (label, #thresholds below the prediction) histogram, integer-exact and order-independent."""
+  from easyrec_amd.core.metrics import auc_thresholds, auc_from_counts
+  rng = np.random.default_rng(n + nt)
+  y = torch.from_numpy((rng.random(n) < 0.25).astype(np.float32))
+  p = torch.from_numpy(np.clip(rng.normal(0.5, 0.3, size=n), 0, 1).astype(np.float32))
+  p[::5] = torch.from_numpy(auc_thresholds(nt)[rng.integers(0, nt, size=len(p[::5]))])  # exactly on thresholds
+  w = torch.from_numpy((rng.random(n) < 0.9).astype(np.float32))
+  t = torch.from_numpy(auc_thresholds(nt))
+  cc = torch.zeros(2, nt + 1, dtype=torch.int64)
+  cd = torch.zeros(2, nt + 1, dtype=torch.int64, device=DEV)
+  ref.auc_update(p[:min(n, 3000)], y[:min(n, 3000)], w[:min(n, 3000)], t, cc)
+  hip.auc_update(p[:min(n, 3000)].to(DEV), y[:min(n, 3000)].to(DEV), w[:min(n, 3000)].to(DEV), t.to(DEV), cd)
+  torch.cuda.synchronize()
+  assert torch.equal(cd.cpu(), cc)
+  # streaming the whole set in two calls == one numpy pass
+  cd.zero_()
+  h = n // 2
+  hip.auc_update(p[:h].to(DEV), y[:h].to(DEV), None, t.to(DEV), cd)
+  hip.auc_update(p[h:].to(DEV), y[h:].to(DEV), None, t.to(DEV), cd)
+  bucket = (p.numpy()[:, None] > t.numpy()[None, :]).sum(axis=1)
+  exp = np.zeros((2, nt + 1), dtype=np.int64)
+  np.add.at(exp, ((y.numpy() != 0).astype(np.int64), bucket), 1)
+  assert np.array_equal(cd.cpu().numpy(), exp)
+  assert 0.0 <= auc_from_counts(exp) <= 1.0
