@@ -89,6 +89,15 @@ def tag_bn_source(y, src):
   return y
 
 
+def grad_sink_of(x, col0=0, width=None):
+  """The GradSink of x if x IS a group output of the embedding engine (layers/input_layer.py) and a deposit into
+  columns [col0, col0 + width) is allowed now, else None."""
+  sink = getattr(x, '_er_sink', None)
+  if sink is None or x.dim() != 2 or os.environ.get('EASYREC_AMD_GRAD_SINK', '1') == '0':  # A/B switch
+    return None
+  return sink
+
+
 def bn_source_of(x):
   """The BnSource of x if x IS the untouched 2-D output of a fused dense + BatchNorm + activation layer."""
   src = getattr(x, '_er_bn_src', None)
@@ -516,12 +525,13 @@ class HipBackend(object):
     self._ck(self.lib.er_fm_fwd(_p(x), B, F, D, x.stride(0), _p(fm), _p(S), _stream()), 'er_fm_fwd')
     return fm, S
 
-  def fm_bwd(self, x, S, g, F, D):
+  def fm_bwd(self, x, S, g, F, D, into=None, accumulate=False):
     B = x.shape[0]
-    dx = torch.empty(B, F * D, dtype=torch.float32, device=x.device)
+    dx = torch.empty(B, F * D, dtype=torch.float32, device=x.device) if into is None else into
+    assert dx.shape == (B, F * D) and dx.stride(1) == 1
     self._ck(
-        self.lib.er_fm_bwd(_p(x), _p(S), _p(_f32c(g)), B, F, D, x.stride(0), _p(dx), dx.stride(0), 0, _stream()),
-        'er_fm_bwd')
+        self.lib.er_fm_bwd(_p(x), _p(S), _p(_f32c(g)), B, F, D, x.stride(0), _p(dx), dx.stride(0), int(accumulate),
+                           _stream()), 'er_fm_bwd')
     return dx
 
   def auc_update(self, probs, labels, weights, thresholds, counts):
@@ -557,10 +567,12 @@ class HipBackend(object):
     self._ck(self.lib.er_rowsum_fwd(_p(x), B, n, x.stride(0), _p(out), _stream()), 'er_rowsum_fwd')
     return out
 
-  def rowsum_bwd(self, g, n):
+  def rowsum_bwd(self, g, n, into=None, accumulate=False):
     B = g.shape[0]
-    dx = torch.empty(B, n, dtype=torch.float32, device=g.device)
-    self._ck(self.lib.er_rowsum_bwd(_p(_f32c(g)), B, n, _p(dx), n, 0, _stream()), 'er_rowsum_bwd')
+    dx = torch.empty(B, n, dtype=torch.float32, device=g.device) if into is None else into
+    assert dx.shape == (B, n) and dx.stride(1) == 1
+    self._ck(self.lib.er_rowsum_bwd(_p(_f32c(g)), B, n, _p(dx), dx.stride(0), int(accumulate), _stream()),
+             'er_rowsum_bwd')
     return dx
 
   def axpy2d(self, x, alpha, y, accumulate=True):
@@ -818,7 +830,7 @@ class LinearFn(torch.autograd.Function):
   returned the normal way."""
 
   @staticmethod
-  def forward(ctx, x, w, b, w_grad, b_grad, bf16, src=None):
+  def forward(ctx, x, w, b, w_grad, b_grad, bf16, src=None, sink=None):
     be = hip()
     x2 = x if x.stride(-1) == 1 else x.contiguous()
     y = be.gemm(GEMM_NN, x2, w, bias=b, bf16=bf16)
@@ -827,6 +839,7 @@ class LinearFn(torch.autograd.Function):
     ctx.w_grad, ctx.b_grad, ctx.bf16 = w_grad, b_grad, bf16
     ctx.sink = be.wgrad_sink()
     ctx.src = src if (src is not None and x2 is x and not bf16 and getattr(be, 'fused_bn_bwd', False)) else None
+    ctx.gsink = sink if x2 is x else None
     return y
 
   @staticmethod
@@ -836,7 +849,7 @@ class LinearFn(torch.autograd.Function):
     dy = dy if dy.stride(-1) == 1 and dy.dim() == 2 else dy.contiguous()
     dx = dw = db = None
     if ctx.needs_input_grad[0]:
-      dx = _dgrad(be, dy, w, ctx.src, ctx.bf16)
+      dx = _dgrad(be, dy, w, ctx.src, ctx.bf16, ctx.gsink)
     if ctx.needs_input_grad[1]:
       if ctx.w_grad is not None:
         if not ctx.sink.put(x, dy, ctx.w_grad, ctx.bf16):
@@ -849,12 +862,18 @@ class LinearFn(torch.autograd.Function):
         ctx.b_grad.add_(s)
       else:
         db = s
-    return dx, dw, db, None, None, None, None
+    return dx, dw, db, None, None, None, None, None
 
 
-def _dgrad(be, dz, w, src, bf16):
+def _dgrad(be, dz, w, src, bf16, sink=None):
   """dx = dz . W^T; when the input was the output of a fused dense + BatchNorm layer (src), the GEMM's epilogue also
-  leaves that layer's BatchNorm-backward column sums in src.partial."""
+  leaves that layer's BatchNorm-backward column sums in src.partial; when it was an embedding group output (sink),
+  the GEMM accumulates straight into the group's gradient buffer and nothing is returned to autograd."""
+  if sink is not None and sink.covers(0, w.shape[0]):
+    dst, acc = sink.target(0, w.shape[0])
+    be.gemm(GEMM_NT, dz, w, out=dst, accumulate=acc, bf16=bf16)
+    sink.done()
+    return None
   if src is None:
     return be.gemm(GEMM_NT, dz, w, bf16=bf16)
   M, N = dz.shape[0], w.shape[0]
@@ -872,7 +891,8 @@ class LinearBNActFn(torch.autograd.Function):
   (kernel.grad, gamma.grad, beta.grad)).  Under BatchNorm d(loss)/d(bias) == 0, so the bias gets none."""
 
   @staticmethod
-  def forward(ctx, x, w, b, gamma, beta, moving_mean, moving_var, eps, momentum, act, bf16, grad_bufs, src=None):
+  def forward(ctx, x, w, b, gamma, beta, moving_mean, moving_var, eps, momentum, act, bf16, grad_bufs, src=None,
+              sink=None):
     be = hip()
     x2 = x if x.stride(-1) == 1 else x.contiguous()
     M, N = x2.shape[0], w.shape[1]
@@ -886,6 +906,7 @@ class LinearBNActFn(torch.autograd.Function):
     ctx.sink = be.wgrad_sink()
     fused = not bf16 and getattr(be, 'fused_bn_bwd', False)
     ctx.src = src if (src is not None and x2 is x and fused) else None
+    ctx.gsink = sink if x2 is x else None
     ctx.own = BnSource(z, None, y, mean, invstd, act) if fused else None  # z already carries the bias
     _bn_tls.last = ctx.own
     return y
@@ -907,35 +928,42 @@ class LinearBNActFn(torch.autograd.Function):
                                          into=(None, gg, betag) if direct else None, partial=partial)
     dx = dw = None
     if ctx.needs_input_grad[0]:
-      dx = _dgrad(be, dz, w, ctx.src, ctx.bf16)
+      dx = _dgrad(be, dz, w, ctx.src, ctx.bf16, ctx.gsink)
     if ctx.needs_input_grad[1]:
       if wg is not None:
         if not ctx.sink.put(x, dz, wg, ctx.bf16):
           be.gemm(GEMM_TN, x, dz, out=wg, accumulate=True, bf16=ctx.bf16)
       else:
         dw = be.gemm(GEMM_TN, x, dz, bf16=ctx.bf16)
-    return dx, dw, None, dgamma, dbeta, None, None, None, None, None, None, None, None
+    return dx, dw, None, dgamma, dbeta, None, None, None, None, None, None, None, None, None
 
 
 class FMFn(torch.autograd.Function):
   """reference layers/fm.py:20-26 over a [B, F*D] block of the input-layer output."""
 
   @staticmethod
-  def forward(ctx, x, F, D):
+  def forward(ctx, x, F, D, sink=None, col0=0):
     fm, S = hip().fm_fwd(x, F, D)
     ctx.save_for_backward(x, S)
     ctx.F, ctx.D = F, D
+    ctx.sink, ctx.col0 = sink, col0
     return fm
 
   @staticmethod
   def backward(ctx, g):
     x, S = ctx.saved_tensors
+    if ctx.sink is not None and ctx.sink.covers(ctx.col0, ctx.F * ctx.D):
+      # x is (a column block of) an embedding group output: the gradient goes straight into its gradient buffer
+      dst, acc = ctx.sink.target(ctx.col0, ctx.F * ctx.D)
+      hip().fm_bwd(x, S, g.contiguous(), ctx.F, ctx.D, into=dst, accumulate=acc)
+      ctx.sink.done()
+      return None, None, None, None, None
     dx = hip().fm_bwd(x, S, g.contiguous(), ctx.F, ctx.D)
     if x.shape[1] != ctx.F * ctx.D:
       full = torch.zeros_like(x)
       full[:, :ctx.F * ctx.D] = dx
       dx = full
-    return dx, None, None
+    return dx, None, None, None, None
 
 
 class DotInteractionFn(torch.autograd.Function):
@@ -960,13 +988,19 @@ class RowSumFn(torch.autograd.Function):
   """reference model/deepfm.py:62-63 (reduce_sum(wide, axis=1, keepdims=True))."""
 
   @staticmethod
-  def forward(ctx, x):
+  def forward(ctx, x, sink=None):
     ctx.n = x.shape[1]
+    ctx.sink = sink
     return hip().rowsum_fwd(x, x.shape[1])
 
   @staticmethod
   def backward(ctx, g):
-    return hip().rowsum_bwd(g.contiguous(), ctx.n)
+    if ctx.sink is not None and ctx.sink.covers(0, ctx.n):
+      dst, acc = ctx.sink.target(0, ctx.n)
+      hip().rowsum_bwd(g.contiguous(), ctx.n, into=dst, accumulate=acc)
+      ctx.sink.done()
+      return None, None
+    return hip().rowsum_bwd(g.contiguous(), ctx.n), None
 
 
 class BNActFn(torch.autograd.Function):

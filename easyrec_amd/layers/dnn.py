@@ -18,7 +18,7 @@ BN_MOMENTUM = 0.99
 BN_EPSILON = 1e-3
 
 
-def _linear(x2, w, b, src=None):
+def _linear(x2, w, b, src=None, sink=None):
   """x2 [rows, in] . w [in, units] (+ b) through the hand-written MFMA GEMMs (kernels.LinearFn); weight and
   bias gradients accumulate directly into the variables' slices of the flat gradient buffer."""
   ctx = context.current()
@@ -28,7 +28,7 @@ def _linear(x2, w, b, src=None):
                               bias=None if b is None else b.detach(), bf16=bf16)
   wg = w.grad if (w.requires_grad and w.grad is not None) else None
   bg = b.grad if (b is not None and b.requires_grad and b.grad is not None) else None
-  return kernels.LinearFn.apply(x2, w, b, wg, bg, bf16, src)
+  return kernels.LinearFn.apply(x2, w, b, wg, bg, bf16, src, sink)
 
 
 def dense(x, units, name, l2_reg=None, use_bias=True, kernel_initializer='glorot_uniform'):
@@ -38,7 +38,7 @@ def dense(x, units, name, l2_reg=None, use_bias=True, kernel_initializer='glorot
   w = vs.get_variable(name + '/kernel', (in_dim, units), kernel_initializer, l2=l2_reg or 0.0)
   b = vs.get_variable(name + '/bias', (units,), 'zeros') if use_bias else None
   shape = x.shape
-  y = _linear(x if x.dim() == 2 else x.reshape(-1, in_dim), w, b, kernels.bn_source_of(x))
+  y = _linear(x if x.dim() == 2 else x.reshape(-1, in_dim), w, b, kernels.bn_source_of(x), kernels.grad_sink_of(x))
   return y.reshape(shape[:-1] + (units,))
 
 
@@ -68,7 +68,7 @@ def dense_bn_act(x, units, name, l2_reg, use_bias, use_bn, act_relu, training, b
     bf16 = getattr(ctx, 'dense_dtype', 'f32') == 'bf16'
     y = kernels.LinearBNActFn.apply(x if x.dim() == 2 else x.reshape(-1, in_dim), w, b, gamma, beta,
                                     None if freeze else mm, None if freeze else mv, BN_EPSILON, BN_MOMENTUM, act, bf16,
-                                    bufs, kernels.bn_source_of(x))
+                                    bufs, kernels.bn_source_of(x), kernels.grad_sink_of(x))
     src = kernels.take_last_bn_source()
     y = y.reshape(shape[:-1] + (units,))
     return kernels.tag_bn_source(y, src) if src is not None else y

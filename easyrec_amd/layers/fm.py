@@ -16,10 +16,12 @@ class FM(object):
 
   def __call__(self, fm_fea):
     blk = fm_fea.uniform_block() if hasattr(fm_fea, 'uniform_block') else None
+    sink, col0 = None, 0
     if blk is not None:
       base, col0, F, D = blk
       x = base if (col0 == 0 and base.shape[1] == F * D) else base[:, col0:col0 + F * D]
+      sink = kernels.grad_sink_of(base)  # the block lives in an embedding group output: deposit its gradient there
     else:
       F, D = len(fm_fea), fm_fea[0].shape[1]
       x = torch.cat(list(fm_fea), dim=1)
-    return kernels.FMFn.apply(x, F, D)
+    return kernels.FMFn.apply(x, F, D, sink, col0)

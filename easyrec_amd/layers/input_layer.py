@@ -60,6 +60,31 @@ class _GroupOutFn(torch.autograd.Function):
     return None, None, None
 
 
+class GradSink(object):
+  """Lets the backward kernel of a group output's consumer write d(loss)/d(out) straight into the group's gradient
+  buffer (the one er_emb_bwd_update reads) instead of returning a tensor that autograd would add to the other
+  consumers' and that _GroupOutFn.backward would then copy: `target()` gives (view of dout, accumulate flag) for the
+  column block, `done()` records the deposit (and adds the output-L2 term once)."""
+
+  def __init__(self, engine, gkey):
+    self.engine, self.gkey = engine, gkey
+
+  def target(self, col0=0, width=None):
+    grp = self.engine.groups[self.gkey]
+    dout = grp['dout']
+    if width is None:
+      width = dout.shape[1] - col0
+    return dout[:, col0:col0 + width], grp['got_grad']
+
+  def covers(self, col0, width):
+    """A first deposit must initialise the WHOLE buffer: partial blocks may only accumulate."""
+    grp = self.engine.groups[self.gkey]
+    return grp['got_grad'] or (col0 == 0 and width == grp['dout'].shape[1])
+
+  def done(self):
+    self.engine._after_deposit(self.gkey)
+
+
 class EmbeddingEngine(object):
   """Owns tables, optimizer slots, lookup specs and the C handles."""
 
@@ -293,7 +318,9 @@ class EmbeddingEngine(object):
 
   def group_tensor(self, gkey, requires_grad=True):
     if requires_grad and torch.is_grad_enabled():
-      return _GroupOutFn.apply(self._anchor, self, gkey)
+      t = _GroupOutFn.apply(self._anchor, self, gkey)
+      t._er_sink = GradSink(self, gkey)
+      return t
     return self.groups[gkey]['out']
 
   def _deposit_grad(self, gkey, g):
@@ -303,9 +330,13 @@ class EmbeddingEngine(object):
     if not g2.is_contiguous():
       g2 = g2.contiguous()
     be.axpy2d(g2, 1.0, grp['dout'], accumulate=grp['got_grad'])
+    self._after_deposit(gkey)
+
+  def _after_deposit(self, gkey):
+    grp = self.groups[gkey]
     if grp['reg'] > 0 and not grp['got_grad']:
       # d/d(out) of lambda * 0.5 * ||out||^2 (layers/input_layer.py:369-375)
-      be.axpy2d(grp['out'], grp['reg'], grp['dout'], accumulate=True)
+      kernels.hip().axpy2d(grp['out'], grp['reg'], grp['dout'], accumulate=True)
     grp['got_grad'] = True
 
   def regularization_loss(self, out):

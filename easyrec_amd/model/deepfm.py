@@ -45,7 +45,7 @@ class DeepFM(RankModel):
     # Wide
     assert not (self._num_class > 1 and self._wide_output_dim == self._num_class), \
         'multi-class wide output is outside the hot-path scope'
-    wide_fea = kernels.RowSumFn.apply(self._wide_features)
+    wide_fea = kernels.RowSumFn.apply(self._wide_features, kernels.grad_sink_of(self._wide_features))
 
     # FM
     fm_fea = fm.FM(name='fm_feature')(self._fm_features)

@@ -29,7 +29,7 @@ class FM(RankModel):
     wide_features, _ = self._input_layer(self._feature_dict, 'wide')
     _, fm_features = self._input_layer(self._feature_dict, 'deep')
     assert self._num_class == 1 or self._wide_output_dim == 1, 'multi-class wide sum: outside the hot-path scope'
-    wide_fea = kernels.RowSumFn.apply(wide_features)
+    wide_fea = kernels.RowSumFn.apply(wide_features, kernels.grad_sink_of(wide_features))
     fm_fea = fm.FM(name='fm_feature')(fm_features)
     if self._num_class > 1:
       fm_fea = dnn.dense(fm_fea, self._num_class, 'fm_logits', l2_reg=self._l2_reg)

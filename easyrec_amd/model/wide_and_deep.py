@@ -38,7 +38,7 @@ class WideAndDeep(RankModel):
     deep_features, _ = self._input_layer(self._feature_dict, 'deep')
     wd = self._wide_output_dim
     if wd == 1:
-      wide_fea = kernels.RowSumFn.apply(wide_cat)  # add_n of [B, 1] columns
+      wide_fea = kernels.RowSumFn.apply(wide_cat, kernels.grad_sink_of(wide_cat))  # add_n of [B, 1] columns
     else:
       wide_fea = wide_cat.reshape(wide_cat.shape[0], len(wide_features), wd).sum(dim=1)
 

@@ -458,9 +458,21 @@ class RefBackend(object):
     q = (e * e).sum(dim=1)
     return 0.5 * (S * S - q), S
 
-  def fm_bwd(self, x, S, g, F, D):
+  def fm_bwd(self, x, S, g, F, D, into=None, accumulate=False):
     e = x[:, :F * D].reshape(x.shape[0], F, D)
-    return (g[:, None, :] * (S[:, None, :] - e)).reshape(x.shape[0], F * D)
+    dx = (g[:, None, :] * (S[:, None, :] - e)).reshape(x.shape[0], F * D)
+    return self._into(dx, into, accumulate)
+
+  @staticmethod
+  def _into(val, into, accumulate):
+    if into is None:
+      return val
+    with torch.no_grad():
+      if accumulate:
+        into.add_(val)
+      else:
+        into.copy_(val)
+    return into
 
   def auc_update(self, probs, labels, weights, thresholds, counts):
     """tf.metrics.auc's per-threshold `prediction > threshold` counts, as a histogram (core/metrics.py)."""
@@ -494,8 +506,8 @@ class RefBackend(object):
   def rowsum_fwd(self, x, n):
     return x[:, :n].sum(dim=1, keepdim=True)
 
-  def rowsum_bwd(self, g, n):
-    return g.reshape(-1, 1).expand(-1, n).contiguous()
+  def rowsum_bwd(self, g, n, into=None, accumulate=False):
+    return self._into(g.reshape(-1, 1).expand(-1, n).contiguous(), into, accumulate)
 
   def axpy2d(self, x, alpha, y, accumulate=True):
     if accumulate:
