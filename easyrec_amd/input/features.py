@@ -26,6 +26,23 @@ def feature_name_of(fc):
   return fc.feature_name if fc.HasField('feature_name') else fc.input_names[0]
 
 
+def raw_boundaries(fc):
+  """Sorted float32 bucket boundaries of a RawFeature, or None (reference feature_column/feature_column.py:365-376:
+  explicit `boundaries`, or `num_buckets` equal-width buckets of the [0, 1]-normalised value)."""
+  if fc.raw_input_dim > 1:
+    return None
+  if len(fc.boundaries) > 0:
+    return np.sort(np.asarray(list(fc.boundaries), dtype=np.float32))
+  if fc.num_buckets > 1 and fc.max_val > fc.min_val:
+    return np.asarray([x / float(fc.num_buckets) for x in range(0, fc.num_buckets)], dtype=np.float32)
+  return None
+
+
+def bucketize(x, bounds):
+  """tf bucketize (BucketizedColumn, feature_column_v2.py:2762-2916): index = number of boundaries <= x."""
+  return np.searchsorted(bounds, np.asarray(x, dtype=np.float32), side='right').astype(np.int64)
+
+
 class FeatureSchema(object):
   """Static description of what a batch contains, derived from the config."""
 
@@ -53,6 +70,11 @@ class FeatureSchema(object):
         else:
           self.raw[name] = {'dim': 1, 'row': n_raw_rows}
           n_raw_rows += 1
+          bounds = raw_boundaries(fc)
+          if bounds is not None:
+            # bucketized raw feature (feature_column.py:365-386): the value stays in the raw block, the bucket index
+            # it falls into is an id column like any other
+            self.int_single[name] = {'col': len(self.int_single), 'num_buckets': len(bounds) + 1, 'bounds': bounds}
       elif ft == FeatureConfig.IdFeature:
         if fc.HasField('hash_bucket_size') and fc.hash_bucket_size > 0:
           self.hash_single[name] = {'buckets': int(fc.hash_bucket_size), 'col': len(self.hash_single)}

@@ -16,7 +16,7 @@ from collections import OrderedDict
 
 import numpy as np
 
-from easyrec_amd.input.features import FeatureSchema, feature_name_of
+from easyrec_amd.input.features import FeatureSchema, bucketize, feature_name_of
 from easyrec_amd.protos.dataset_pb2 import DatasetConfig
 from easyrec_amd.protos.feature_config_pb2 import FeatureConfig
 from easyrec_amd.utils.load_class import get_register_class_meta
@@ -224,6 +224,8 @@ class Input(object, metaclass=_meta_type):
           out['rawm/%s' % name] = self._parse_raw_multi(fc, columns)
         else:
           raw[sch.raw[name]['row']] = self._parse_raw(fc, columns)
+          if name in sch.int_single:  # bucketized: the id is the bucket of the normalised value
+            int_ids[sch.int_single[name]['col']] = bucketize(raw[sch.raw[name]['row']], sch.int_single[name]['bounds'])
       elif ft == FeatureConfig.IdFeature:
         col = columns[fc.input_names[0]]
         if name in sch.hash_single:

@@ -9,6 +9,8 @@ Produces the packed batch dict of DeviceFeatures.load directly (no CSV round tri
 """
 import numpy as np
 
+from easyrec_amd.input.features import bucketize
+
 from easyrec_amd.input.features import FeatureSchema, feature_name_of
 from easyrec_amd.protos.feature_config_pb2 import FeatureConfig
 
@@ -59,7 +61,10 @@ class SyntheticBatches(object):
       out['hash_ids'] = h
     ints = np.zeros((max(len(sch.int_single), 1), B), dtype=np.int64)
     for name, info in sch.int_single.items():
-      ints[info['col']] = rng.integers(0, max(info['num_buckets'], 1), size=B)
+      if 'bounds' in info:  # bucketized raw feature: derived from the value drawn above
+        ints[info['col']] = bucketize(raw[sch.raw[name]['row']], info['bounds'])
+      else:
+        ints[info['col']] = rng.integers(0, max(info['num_buckets'], 1), size=B)
     out['int_ids'] = ints
     for name, t in sch.tags.items():
       lens = rng.integers(0, self.max_tag + 1, size=B)

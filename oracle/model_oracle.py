@@ -134,18 +134,33 @@ class OracleTrainer(object):
           row += 1
     return out
 
+  @staticmethod
+  def _bounds(f):
+    """feature_column/feature_column.py:365-376"""
+    if f.feature_type != f.RawFeature or f.raw_input_dim > 1:
+      return None
+    if len(f.boundaries) > 0:
+      return sorted(np.float32(b) for b in f.boundaries)
+    if f.num_buckets > 1 and f.max_val > f.min_val:
+      return [np.float32(x / float(f.num_buckets)) for x in range(f.num_buckets)]
+    return None
+
   def _int_ids(self, batch):
     out, col = {}, 0
     for n, f in self.fc_by_name.items():
       if f.feature_type == f.IdFeature and not (f.HasField('hash_bucket_size') and f.hash_bucket_size > 0):
         out[n] = np.asarray(batch['int_ids'])[col]
         col += 1
+      elif self._bounds(f) is not None:
+        col += 1  # the batch carries the bucket index too; the oracle re-derives it from the raw value
     return out
 
   # ------------------------------------------------------------------ embedding columns
   def _column_var_name(self, scope, fc, wide):
     name = _fname(fc)
-    if fc.feature_type == fc.RawFeature and not fc.boundaries:
+    if fc.feature_type == fc.RawFeature and self._bounds(fc) is not None:
+      col = '%s_bucketized' % name  # BucketizedColumn.name (feature_column_v2.py:2777-2779)
+    elif fc.feature_type == fc.RawFeature:
       col = '%s_weighted_by_%s_raw_proj_val' % (name, name)
     elif fc.feature_type == fc.TagFeature and (len(fc.input_names) > 1 or fc.HasField('kv_separator')):
       col = '%s_weighted_by_%s_w' % (name, name)
@@ -214,7 +229,12 @@ class OracleTrainer(object):
     for n in names:
       fc = self.fc_by_name[n]
       dim = wide_dim if wide else fc.embedding_dim
-      if fc.feature_type == fc.RawFeature:
+      if fc.feature_type == fc.RawFeature and self._bounds(fc) is not None:
+        # BucketizedColumn: id = number of boundaries <= value (feature_column_v2.py:2762-2916)
+        bounds = self._bounds(fc)
+        ids = np.array([sum(1 for b in bounds if b <= np.float32(v)) for v in raws[n]], dtype=np.int64)
+        outs.append((self._lookup_dense(V.get(self._column_var_name(scope, fc, wide)), ids), True))
+      elif fc.feature_type == fc.RawFeature:
         if dim == 0:
           v = torch.as_tensor(raws[n], dtype=self.dtype)
           outs.append((v.reshape(self.B, -1), False))

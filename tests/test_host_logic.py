@@ -119,7 +119,8 @@ def test_csv_input_roundtrip(tmp_path, built_lib):
                                       ('wide_and_deep_criteo_small.config', 24),
                                       ('wide_and_deep_nofinal_criteo_small.config', 24), ('fm_criteo_small.config', 24),
                                       ('multi_tower_criteo_small.config', 24), ('dlrm_criteo_small.config', 24),
-                                      ('dlrm_itself_criteo_small.config', 24), ('dlrm_cat_criteo_small.config', 24)])
+                                      ('dlrm_itself_criteo_small.config', 24), ('dlrm_cat_criteo_small.config', 24),
+                                      ('deepfm_bucketized_criteo_small.config', 24)])
 def test_other_models_match_model_oracle(ref_backend, config, B):
   """DCN / MultiTowerDIN / MMoE host logic (variable naming, layer wiring, multi-task losses, sequence and
   tag lookups) against the independent model-level oracle, 2 optimisation steps."""
@@ -187,3 +188,26 @@ def test_packed_batch_loads_like_the_plain_one(ref_backend, config):
     for k, v in f.tags.items():
       for n, t in v.items():
         assert t is None or torch.equal(t, tags[k][n]), (k, n)
+
+
+def test_bucketized_raw_feature_ids():
+  """RawFeature with boundaries / num_buckets -> BucketizedColumn ids (reference feature_column/feature_column.py:
+  365-386, compat/feature_column/feature_column_v2.py:2762-2916): bucket = number of boundaries <= the NORMALISED
+  value; a value equal to a boundary belongs to the upper bucket."""
+  from easyrec_amd.input.csv_input import CSVInput
+  cfg = config_util.get_configs_from_pipeline_file('configs/deepfm_bucketized_criteo_small.config')
+  B = 6
+  reader = CSVInput(cfg.data_config, cfg.feature_config.features, None, batch_size=B)
+  sch = reader.schema
+  names = [x.input_name for x in cfg.data_config.input_fields]
+  cols = {n: (['0'] * B if not n.startswith('C') else ['ab'] * B) for n in names}
+  f1 = {f.input_names[0]: f for f in cfg.feature_config.features}['F1']
+  span = f1.max_val - f1.min_val
+  # normalised 0.0, 0.05 (on a boundary), 0.1, 0.5 (boundary), 0.79, 1.0 -> buckets 0, 1, 1, 3, 3, 4
+  cols['F1'] = [str(f1.min_val + v * span) for v in (0.0, 0.05, 0.1, 0.5, 0.79, 1.0)]
+  batch = reader.preprocess(cols)
+  got = batch['int_ids'][sch.int_single['F1']['col']]
+  x = batch['raw'][sch.raw['F1']['row']]
+  exp = [sum(1 for b in (0.05, 0.2, 0.5, 0.8) if np.float32(b) <= v) for v in x]
+  assert list(got) == exp and exp[0] == 0 and exp[3] == 3 and exp[5] == 4, (list(got), exp, list(x))
+  assert sch.int_single['F3']['num_buckets'] == 11 and sch.int_single['F1']['num_buckets'] == 5
