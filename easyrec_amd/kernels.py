@@ -16,7 +16,8 @@ import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libeasyrec_hip.so')
+# EASYREC_AMD_LIB: another build of the same ABI (same-box A/B of a kernel change, tools/gpu_ab.sh)
+LIB_PATH = os.environ.get('EASYREC_AMD_LIB') or os.path.join(_HERE, 'csrc', 'libeasyrec_hip.so')
 
 COMBINER_SUM, COMBINER_MEAN, COMBINER_SQRTN = 0, 1, 2
 COMBINERS = {'sum': COMBINER_SUM, 'mean': COMBINER_MEAN, 'sqrtn': COMBINER_SQRTN}
