@@ -735,8 +735,8 @@ int gemm_grouped_f32(int layout, const er_gemm_problem* pr, int n, er_stream_t s
                "er_gemm_grouped_f32: problem %d: leading dimension too small", i);
     total_tiles += er::ceil_div(q.M, er::BM) * er::ceil_div(q.N, er::BN);
   }
-  // k-splits: enough workgroups for ~4 per CU over the whole group, at least 4 k-tiles per split
-  int64_t want = total_tiles >= 1024 ? 1 : er::ceil_div(1024, total_tiles);
+  // k-splits: enough workgroups for ~2 per CU over the whole group (A/B: 512 beat 1024 and 2048), >= 4 k-tiles per split
+  int64_t want = total_tiles >= 512 ? 1 : er::ceil_div(512, total_tiles);
   if (want > 64) want = 64;
   er::GroupedArgs ga;
   er::GroupedReduceArgs ra;
