@@ -304,8 +304,15 @@ def main():
       dom = time_gemm_kernel(est, n_launch)
       ach = dom['flops'] / (dom['avg_ms'] * 1e-3) / 1e12
       peak = 2500.0 if est.ctx.dense_dtype == 'bf16' else MFMA_F32_PEAK_TFLOPS
+      traffic = None  # HBM-side bytes of this launch from the PMC passes of tools/gpu_gemm_traffic.sh
+      pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+      if os.path.exists(pmc) and est.ctx.dense_dtype != 'bf16' and dom['flops'] == 2.0 * 4096 * 256 * 624:
+        try:
+          traffic = json.load(open(pmc)).get('gemm_f32_nn_4096x256x624_bytes_per_launch')
+        except Exception:
+          traffic = None
       out['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
-                         'traffic': None, 'kernel': dom['kernel'], 'avg_kernel_ms': dom['avg_ms'],
+                         'traffic': traffic, 'kernel': dom['kernel'], 'avg_kernel_ms': dom['avg_ms'],
                          'algorithmic_flops_per_launch': dom['flops'], 'launches_timed': dom['launches']}
     if not args.no_cpu_baseline:
       try:
@@ -314,6 +321,17 @@ def main():
       except Exception as e:  # noqa: BLE001
         out['cpu_baseline'] = {'value': None, 'unit': 'examples/s', 'cores': 0, 'kind': 'port',
                                'sample': 'failed: %s' % str(e)[:200]}
+  if 'roofline' not in out and not getattr(est, 'dense_sweep', False):
+    # embedding-parallel runs (N > 1, --force_ep): the dense part is the same per rank; time the same GEMM on rank 0
+    try:
+      dom = time_gemm_kernel(est, max(10, min(args.steps, 50)))
+      ach = dom['flops'] / (dom['avg_ms'] * 1e-3) / 1e12
+      out['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': ach / MFMA_F32_PEAK_TFLOPS, 'traffic': None, 'kernel': dom['kernel'],
+                         'avg_kernel_ms': dom['avg_ms'], 'algorithmic_flops_per_launch': dom['flops'],
+                         'launches_timed': dom['launches'], 'note': 'rank 0'}
+    except Exception as e:  # noqa: BLE001
+      out['roofline_error'] = str(e)[:200]
   print(json.dumps(out))
 
 
