@@ -450,10 +450,13 @@ class HipBackend(object):
     sink.active = os.environ.get('EASYREC_AMD_GROUPED_WGRAD', '1') != '0'  # A/B switch
 
   def flush_wgrads(self):
+    """Launch the queued weight gradients on the current stream.  Returns the queue: when that stream is not the one
+    the operands were produced on, the caller keeps it alive until the streams have joined."""
     sink = self.wgrad_sink()
     q, sink.queue, sink.active = sink.queue, [], False
     if q:
       self.gemm_grouped(GEMM_TN, q)
+    return q
 
   # -- K12 embedding-parallel routing (include/easyrec_hip.h)
   def emb_group_set_routing(self, group, world, shard_stride, local_base):

@@ -149,18 +149,23 @@ class EasyRecModel(six.with_metaclass(_meta_type, object)):
       outputs[name] = self._prediction_dict[name]
     return outputs
 
-  def backward(self):
-    """Back-propagate the loss gradients recorded by build_loss_graph through the dense graph."""
+  def backward(self, flush=True):
+    """Back-propagate the loss gradients recorded by build_loss_graph through the dense graph.  flush=False leaves
+    the queued weight gradients to the caller (`kernels.hip().flush_wgrads()`), which may contract them on another
+    stream while the embedding backward runs."""
     if not self._backward_seeds:
       return
     tensors = [t for t, _ in self._backward_seeds]
     grads = [g.reshape(t.shape) for t, g in self._backward_seeds]
     be = kernels.hip()
     be.defer_wgrads()  # the layers' weight gradients (x^T . dz, K = batch) are contracted in one grouped launch
+    ok = False
     try:
       torch.autograd.backward(tensors, grads)
+      ok = True
     finally:
-      be.flush_wgrads()
+      if flush or not ok:
+        be.flush_wgrads()
 
   def get_grouped_vars(self, opt_num):
     assert opt_num == 2, 'could only support 2 optimizers, one for embedding, one for the other layers'
