@@ -617,9 +617,10 @@ emb_bwd_fix_kernel(const uint32_t* __restrict__ skeys, int64_t n, int dim, int G
 constexpr int kSegSortMax = 8192;
 constexpr int kSegSortMin = 256;
 
-__device__ __forceinline__ void seg_cmpx(unsigned long long& a, unsigned long long& b, bool up) {
+template <typename C>
+__device__ __forceinline__ void seg_cmpx(C& a, C& b, bool up) {
   const bool sw = (a > b) == up;
-  const unsigned long long lo = sw ? b : a, hi = sw ? a : b;
+  const C lo = sw ? b : a, hi = sw ? a : b;
   a = lo;
   b = hi;
 }
@@ -627,25 +628,47 @@ __device__ __forceinline__ void seg_cmpx(unsigned long long& a, unsigned long lo
 // HEADS: also emit, per sorted position, the run-head flag and the number of heads before it INSIDE the lookup, and
 // the lookup's number of distinct valid keys (emb_route_seg_kernel adds the lookups before it): the head-flag /
 // exclusive-scan / count launches of the generic path disappear.
-template <int E, bool HEADS>
+// NARROW: 32-bit composites (row inside the lookup's table << log2 P | position inside the lookup; a missing id
+// sorts as row == rows) when (rows + 2) * P <= 2^32 for every lookup of the group - e.g. 1 M-row tables at P = 4096:
+// half the shuffles, LDS traffic and registers of the 64-bit (group key << 32 | group entry) form.
+template <int E, bool HEADS, bool NARROW>
 __global__ void __launch_bounds__(kSegSortMax / 8)
-emb_segment_sort_kernel(const uint32_t* __restrict__ keys_in, const int64_t* __restrict__ ent_base, int P,
-                        uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
-                        uint32_t* __restrict__ flags_out, uint32_t* __restrict__ hidx_out,
-                        uint32_t* __restrict__ seg_count) {
-  extern __shared__ __attribute__((aligned(16))) unsigned long long sk[];  // [P]
+emb_segment_sort_kernel(const uint32_t* __restrict__ keys_in, const int64_t* __restrict__ ent_base,
+                        const er_lookup_desc* __restrict__ descs, int P, uint32_t* __restrict__ keys_out,
+                        uint32_t* __restrict__ vals_out, uint32_t* __restrict__ flags_out,
+                        uint32_t* __restrict__ hidx_out, uint32_t* __restrict__ seg_count) {
+  typedef typename std::conditional<NARROW, uint32_t, unsigned long long>::type C;
+  extern __shared__ __attribute__((aligned(16))) unsigned long long sk_raw[];  // [P] composites
+  C* sk = reinterpret_cast<C*>(sk_raw);
   constexpr int L = E == 8 ? 3 : (E == 4 ? 2 : 1);
   static_assert(E == 2 || E == 4 || E == 8, "E");
   const int t = threadIdx.x;
   const int i0 = t * E;
   const int64_t base = ent_base[blockIdx.x];
   const int cnt = static_cast<int>(ent_base[blockIdx.x + 1] - base);
-  unsigned long long x[E];
+  const int logP = __ffs(P) - 1;
+  const uint32_t key_base = NARROW ? static_cast<uint32_t>(descs[blockIdx.x].key_base) : 0u;
+  const uint32_t rows = NARROW ? static_cast<uint32_t>(descs[blockIdx.x].rows) : 0u;
+  auto key_of = [&](C c) -> uint32_t {
+    if (NARROW) {
+      const uint32_t rel = static_cast<uint32_t>(c >> logP);
+      return rel >= rows ? kInvalidKey : rel + key_base;  // (padding decodes as invalid too)
+    }
+    return static_cast<uint32_t>(static_cast<unsigned long long>(c) >> 32);
+  };
+  C x[E];
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     const int i = i0 + e;
-    x[e] = i < cnt ? ((static_cast<unsigned long long>(keys_in[base + i]) << 32) | static_cast<unsigned>(base + i))
-                   : ~0ull;
+    if (i >= cnt) {
+      x[e] = static_cast<C>(~0ull);
+    } else if (NARROW) {
+      const uint32_t key = keys_in[base + i];
+      const uint32_t rel = key == kInvalidKey ? rows : key - key_base;
+      x[e] = static_cast<C>((rel << logP) | static_cast<uint32_t>(i));
+    } else {
+      x[e] = static_cast<C>((static_cast<unsigned long long>(keys_in[base + i]) << 32) | static_cast<unsigned>(base + i));
+    }
   }
   for (int k = 2; k <= P; k <<= 1) {
     int j = k >> 1;
@@ -659,7 +682,7 @@ emb_segment_sort_kernel(const uint32_t* __restrict__ keys_in, const int64_t* __r
       const int b = __ffs(j) - 1, lb = b - L + 1;
       const int bs = ((t >> lb) << (b + 1)) | (t & ((1 << lb) - 1));
       const bool up = (bs & k) == 0;
-      unsigned long long y[E];
+      C y[E];
 #pragma unroll
       for (int c = 0; c < E; ++c) y[c] = sk[bs + (c << lb)];
 #pragma unroll
@@ -684,8 +707,8 @@ emb_segment_sort_kernel(const uint32_t* __restrict__ keys_in, const int64_t* __r
         const bool keep_min = ((t & lj) == 0) == up;
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-          const unsigned long long o = __shfl_xor(x[e], lj);
-          const unsigned long long mn = x[e] < o ? x[e] : o, mx = x[e] < o ? o : x[e];
+          const C o = __shfl_xor(x[e], lj);
+          const C mn = x[e] < o ? x[e] : o, mx = x[e] < o ? o : x[e];
           x[e] = keep_min ? mn : mx;
         }
       }
@@ -703,22 +726,23 @@ emb_segment_sort_kernel(const uint32_t* __restrict__ keys_in, const int64_t* __r
   for (int e = 0; e < E; ++e) {
     const int i = i0 + e;
     if (i < cnt) {
-      keys_out[base + i] = static_cast<uint32_t>(x[e] >> 32);
-      vals_out[base + i] = static_cast<uint32_t>(x[e] & 0xFFFFFFFFu);
+      keys_out[base + i] = key_of(x[e]);
+      vals_out[base + i] = NARROW ? static_cast<uint32_t>(base) + (static_cast<uint32_t>(x[e]) & static_cast<uint32_t>(P - 1))
+                                  : static_cast<uint32_t>(static_cast<unsigned long long>(x[e]) & 0xFFFFFFFFu);
     }
   }
   if (HEADS) {
     __shared__ uint32_t wave_sum[kSegSortMax / 8 / 64];
-    uint32_t* k32 = reinterpret_cast<uint32_t*>(sk);  // [P] sorted keys, to look one position back
-    __syncthreads();                                  // every thread has taken its composites out of sk
+    uint32_t* k32 = reinterpret_cast<uint32_t*>(sk_raw);  // [P] sorted keys, to look one position back
+    __syncthreads();                                      // every thread has taken its composites out of sk
 #pragma unroll
-    for (int e = 0; e < E; ++e) k32[i0 + e] = static_cast<uint32_t>(x[e] >> 32);
+    for (int e = 0; e < E; ++e) k32[i0 + e] = key_of(x[e]);
     __syncthreads();
     uint32_t prev = i0 > 0 ? k32[i0 - 1] : kInvalidKey;
     uint32_t f[E], c = 0;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-      const uint32_t key = static_cast<uint32_t>(x[e] >> 32);
+      const uint32_t key = key_of(x[e]);
       f[e] = (key != kInvalidKey && (i0 + e == 0 || prev != key)) ? 1u : 0u;
       c += f[e];
       prev = key;
@@ -1067,6 +1091,7 @@ struct er_emb_group {
   int64_t n_active = -1;  // -1: all entries
   int seg_sort_pow2 = 0;   // > 0: per-lookup LDS sort (emb_segment_sort_kernel) with this padded size
   uint32_t* seg_count = nullptr;  // [n] distinct valid keys per lookup (fused heads of the segmented path)
+  bool seg_narrow = false;        // 32-bit sort composites: (rows + 2) * P <= 2^32 for every lookup
   bool sorted_valid = false;
   // er_emb_group_share_sort: `src` owns the sorted keys / entry permutation / run heads this group reduces over
   // (itself, or the leader whose keys are identical); the epochs tell a fresh leader sort from a stale one
@@ -1205,6 +1230,9 @@ int er_emb_group_create(const er_lookup_desc* descs, int n, int32_t dim, int64_t
       int p2 = er::kSegSortMin;
       while (p2 < max_cap) p2 <<= 1;
       g->seg_sort_pow2 = p2;
+      g->seg_narrow = true;
+      for (int i = 0; i < n; ++i)
+        if ((static_cast<uint64_t>(descs[i].rows) + 2) * static_cast<uint64_t>(p2) > (1ull << 32)) g->seg_narrow = false;
     }
   }
   ER_REQUIRE(g->n_entries > 0 && g->n_entries < 0x7FFFFFFFLL, "er_emb_group_create: entry count %lld out of range",
@@ -1245,6 +1273,10 @@ int er_emb_group_create(const er_lookup_desc* descs, int n, int32_t dim, int64_t
 int er_emb_group_update(er_emb_group* g, const er_lookup_desc* descs, int n) {
   ER_REQUIRE(g && descs && n == g->n, "er_emb_group_update: lookup count changed");
   if (int rc = validate_descs(descs, n, "er_emb_group_update")) return rc;
+  for (int i = 0; i < n; ++i)
+    ER_REQUIRE(descs[i].rows == g->h_descs[i].rows && descs[i].key_base == g->h_descs[i].key_base &&
+                   descs[i].dim == g->h_descs[i].dim,
+               "er_emb_group_update: lookup %d: the table geometry (rows, key_base, dim) cannot change", i);
   ER_CHECK_HIP(hipMemcpy(g->d_descs, descs, sizeof(er_lookup_desc) * n, hipMemcpyHostToDevice));
   g->h_descs.assign(descs, descs + n);
   return 0;
@@ -1332,14 +1364,17 @@ static int emb_group_build_sort(er_emb_group* g, hipStream_t s, bool with_heads 
   if (emb_group_segmented(g)) {
     const int P = g->seg_sort_pow2;
     const size_t lds = sizeof(unsigned long long) * static_cast<size_t>(P);
-#define ER_SEG_SORT(E, H)                                                                                            \
-  hipLaunchKernelGGL((er::emb_segment_sort_kernel<E, H>), dim3(g->n), dim3(P / E), lds, s, g->keys_in, g->d_ent_base, P, \
-                     g->keys_out, g->vals_out, g->head_flags, g->head_index, g->seg_count)
-    if (P > 4096) {
-      if (with_heads) ER_SEG_SORT(8, true); else ER_SEG_SORT(8, false);
-    } else {
-      if (with_heads) ER_SEG_SORT(4, true); else ER_SEG_SORT(4, false);
-    }
+#define ER_SEG_SORT(E, H, NRW)                                                                                     \
+  hipLaunchKernelGGL((er::emb_segment_sort_kernel<E, H, NRW>), dim3(g->n), dim3(P / E), lds, s, g->keys_in,        \
+                     g->d_ent_base, g->d_descs, P, g->keys_out, g->vals_out, g->head_flags, g->head_index, g->seg_count)
+#define ER_SEG_SORT_E(E)                                                       \
+  if (g->seg_narrow) {                                                         \
+    if (with_heads) ER_SEG_SORT(E, true, true); else ER_SEG_SORT(E, false, true);   \
+  } else {                                                                     \
+    if (with_heads) ER_SEG_SORT(E, true, false); else ER_SEG_SORT(E, false, false); \
+  }
+    if (P > 4096) { ER_SEG_SORT_E(8) } else { ER_SEG_SORT_E(4) }
+#undef ER_SEG_SORT_E
 #undef ER_SEG_SORT
     ER_LAUNCH_CHECK();
     return 0;

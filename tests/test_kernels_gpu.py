@@ -650,17 +650,22 @@ def test_lazy_dense_decay_equals_the_sweep(hip):
   assert torch.allclose(sa, sb, rtol=1e-5, atol=0.0)
 
 
-@pytest.mark.parametrize('sizes', [(100, 4096, 5000, 8192, 257), (1, 2, 3), (4097,), (8192, 8192), (9000, 50)])
+@pytest.mark.parametrize('sizes', [(100, 4096, 5000, 8192, 257), (1, 2, 3), (4097,), (8192, 8192), (9000, 50),
+                                   (-3000000, 4096), (-600000, 8192, 77)])
 def test_segmented_sort_sizes(hip, sizes):
   """One table per lookup -> one workgroup sorts one lookup's entries (emb_segment_sort_kernel; the last case has
   a lookup above its capacity and takes the global radix sort).  The de-duplicated keys must come out ascending
   and every row's gradient must be the source-order sum of its entries."""
-  rng = np.random.default_rng(sum(sizes))
+  rng = np.random.default_rng(abs(sum(sizes)))
   dim = 4
   specs, base, exp_keys, exp = [], 0, [], []
-  for n in sizes:
-    rows = int(rng.integers(1, 3 * n + 2))
+  big_rows = -sizes[0] if sizes[0] < 0 else None  # a table too large for 32-bit sort composites -> 64-bit path
+  sizes = sizes[1:] if big_rows else sizes
+  for li, n in enumerate(sizes):
+    rows = big_rows if (big_rows and li == 0) else int(rng.integers(1, 3 * n + 2))
     ids = rng.integers(-1, rows, size=n).astype(np.int64)
+    if big_rows and li == 0:
+      ids[-1] = rows - 1
     if n > 64:
       ids[:n // 3] = ids[0]  # one long run
     dout = (rng.standard_normal((n, dim)) * 0.01).astype(np.float32)
