@@ -19,6 +19,10 @@
  *     be compared bit-for-bit with the step-by-step CPU oracle where the order is defined.
  *   - per-step scalars (learning rate, beta powers) are read from DEVICE memory (er_opt_hyper)
  *     so that a captured graph can be replayed with new values.
+ *   - two pieces of library-owned device scratch are shared by all calls of a process: the column-
+ *     reduction scratch (er_reserve_scratch) and the split-K workspace (er_gemm_reserve).  Calls that
+ *     use them (BatchNorm / colsum / loss reductions; split-K and grouped GEMMs) must therefore be
+ *     ordered on ONE stream (or by events); everything else may run on any stream.
  */
 #ifndef EASYREC_HIP_H_
 #define EASYREC_HIP_H_
