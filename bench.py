@@ -127,6 +127,36 @@ def time_sweep_kernel(est, launches):
           'min_ms': float(np.min(ms)), 'bytes': alg_bytes, 'launches': launches}
 
 
+def time_embedding_stage(est, alg_bytes, reps=20):
+  """The embedding stage alone: id sort + catch-up + fused lookup, then segmented reduction + row
+  update, launched eagerly on the bench stream and timed with HIP events after the timed region (the extra optimizer
+  applications reuse the last step's gradients; nothing is reported from the state afterwards)."""
+  eng = est.engine
+  kind, hyper = est.opt_emb.kind, est.hyper[0]
+  ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
+  f0, f1, b0, b1 = ev(), ev(), ev(), ev()
+  fwd = bwd = 0.0
+  for i in range(reps + 3):
+    est.features.version += 1
+    f0.record()
+    eng.forward(est.features.version)
+    f1.record()
+    for g in eng.groups.values():
+      g['got_grad'] = True  # keep last step's upstream gradients
+    b0.record()
+    eng.backward_update(kind, hyper)
+    b1.record()
+    torch.cuda.synchronize()
+    if i >= 3:
+      fwd += f0.elapsed_time(f1)
+      bwd += b0.elapsed_time(b1)
+  fwd, bwd = fwd / reps, bwd / reps
+  gbps = alg_bytes / ((fwd + bwd) * 1e-3) / 1e9
+  return {'stage_forward_ms': fwd, 'stage_backward_ms': bwd, 'stage_GBps': gbps, 'stage_frac_of_hbm_peak': gbps / HBM_PEAK_GBS,
+          'stage_note': 'eager launches timed with HIP events (launch gaps included): sort + catch-up + lookup | '
+                        'segmented reduction + row update; latency-bound at these sizes (SURVEY.md 8d)'}
+
+
 def time_gemm_kernel(est, launches):
   """Default (lazy dense decay / lazy Adam): the largest share of the step is the forward GEMM kernel
   er::gemm_f32_kernel<NN>; its biggest launch - the first deep layer, [B, 624] x [624, 256] with the bias and the
@@ -285,6 +315,10 @@ def main():
         'note': 'whole_step_GBps divides the embedding stage\'s algorithmic bytes by the WHOLE step time; '
                 'dense_decay_sweep_bytes_per_step is 0 unless --dense_sweep (default: lazy dense decay)',
     }
+    try:
+      out['embedding_stage'].update(time_embedding_stage(est, lazy_bytes + sweep_bytes))
+    except Exception as e:  # noqa: BLE001
+      out['embedding_stage']['stage_error'] = str(e)[:200]
     n_launch = max(10, min(args.steps, 50))
     if sweep_bytes > 0 and est.dense_sweep:
       dom = time_sweep_kernel(est, n_launch)
