@@ -17,6 +17,7 @@
 //   * TF's dense-decay Adam additionally streams every untouched row once per step
 //     (adam_decay_sweep_kernel): pure HBM streaming, float4, grid-stride, bitmap-skipped.
 //   * everything here is HBM/latency-bound integer+fp32 work; no MFMA on purpose.
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -145,14 +146,14 @@ __device__ __forceinline__ uint32_t routed_key(const er_lookup_desc& d, const Ro
   return static_cast<uint32_t>(owner * rt.shard_stride + rt.local_base[l] + id / rt.world);
 }
 
-__global__ void __launch_bounds__(kBlock)
-emb_bwd_build_kernel(const er_lookup_desc* __restrict__ descs, const int32_t* __restrict__ blk_start,
-                     const int64_t* __restrict__ ent_base, int n_lookups, Route rt, int64_t n_active,
-                     uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                     const float** __restrict__ ent_gptr, float* __restrict__ ent_scale) {
-  const int l = find_lookup(blk_start, n_lookups, blockIdx.x);
+__device__ __forceinline__ void build_body(int bid, const er_lookup_desc* __restrict__ descs,
+                                           const int32_t* __restrict__ blk_start, const int64_t* __restrict__ ent_base,
+                                           int n_lookups, const Route& rt, int64_t n_active, uint32_t* __restrict__ keys,
+                                           uint32_t* __restrict__ vals, const float** __restrict__ ent_gptr,
+                                           float* __restrict__ ent_scale) {
+  const int l = find_lookup(blk_start, n_lookups, bid);
   const er_lookup_desc d = descs[l];
-  const int r = (blockIdx.x - blk_start[l]) * kBlock + static_cast<int>(threadIdx.x);
+  const int r = (bid - blk_start[l]) * kBlock + static_cast<int>(threadIdx.x);
   if (r >= d.n_rows || r >= n_active) return;
   int64_t kb, ke;
   if (d.offsets) {
@@ -190,6 +191,41 @@ emb_bwd_build_kernel(const er_lookup_desc* __restrict__ descs, const int32_t* __
     ent_gptr[j] = gp;
     ent_scale[j] = w / den;
   }
+}
+
+__global__ void __launch_bounds__(kBlock)
+emb_bwd_build_kernel(const er_lookup_desc* __restrict__ descs, const int32_t* __restrict__ blk_start,
+                     const int64_t* __restrict__ ent_base, int n_lookups, Route rt, int64_t n_active,
+                     uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                     const float** __restrict__ ent_gptr, float* __restrict__ ent_scale) {
+  build_body(blockIdx.x, descs, blk_start, ent_base, n_lookups, rt, n_active, keys, vals, ent_gptr, ent_scale);
+}
+
+struct BuildArgs {
+  const er_lookup_desc* descs;
+  const int32_t* blk_start;
+  const int64_t* ent_base;
+  int n_lookups;
+  Route rt;
+  int64_t n_active;
+  uint32_t* keys;
+  uint32_t* vals;
+  const float** ent_gptr;
+  float* ent_scale;
+};
+struct BuildMulti {
+  int n;
+  int start[4 + 1];
+  BuildArgs a[4];
+};
+
+__global__ void __launch_bounds__(kBlock)
+emb_bwd_build_multi_kernel(BuildMulti ma) {
+  int i = 0;
+  while (i + 1 < ma.n && static_cast<int>(blockIdx.x) >= ma.start[i + 1]) ++i;
+  const BuildArgs& a = ma.a[i];
+  build_body(blockIdx.x - ma.start[i], a.descs, a.blk_start, a.ent_base, a.n_lookups, a.rt, a.n_active, a.keys, a.vals,
+             a.ent_gptr, a.ent_scale);
 }
 
 // Marks the rows an upcoming step will touch (same validity rule as emb_bwd_build_kernel), so that the
@@ -368,11 +404,11 @@ __device__ __forceinline__ void replay_decay(float* var, float* m, float* v, con
 // one lane group per unique row touched by the coming step (keys from er_emb_route); brings the row to
 // "after step t-1" where t = *step_counter - 1 is the step being executed
 template <int V>
-__global__ void __launch_bounds__(kBlock)
-emb_catch_up_kernel(const uint32_t* __restrict__ ukeys, const int32_t* __restrict__ n_unique, int64_t capacity,
-                    RowUpdate tab, const float* __restrict__ lr_hist, const er_opt_hyper* __restrict__ hyper, int dim,
-                    int G) {
-  const int64_t i = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) / G;
+__device__ __forceinline__ void catch_up_body(int bid, const uint32_t* __restrict__ ukeys,
+                                              const int32_t* __restrict__ n_unique, int64_t capacity, const RowUpdate& tab,
+                                              const float* __restrict__ lr_hist, const er_opt_hyper* __restrict__ hyper,
+                                              int dim, int G) {
+  const int64_t i = (static_cast<int64_t>(bid) * kBlock + threadIdx.x) / G;
   const int c = (static_cast<int>(threadIdx.x) % G) * V;
   if (i >= capacity || i >= *n_unique || c >= dim) return;
   const uint32_t key = ukeys[i];
@@ -393,6 +429,45 @@ emb_catch_up_kernel(const uint32_t* __restrict__ ukeys, const int32_t* __restric
   st_vec<V>(tab.m + off, m);
   st_vec<V>(tab.v + off, v);
   // last_step[key] is set to t by this step's row update (every caught-up row is touched by the step)
+}
+
+template <int V>
+__global__ void __launch_bounds__(kBlock)
+emb_catch_up_kernel(const uint32_t* __restrict__ ukeys, const int32_t* __restrict__ n_unique, int64_t capacity,
+                    RowUpdate tab, const float* __restrict__ lr_hist, const er_opt_hyper* __restrict__ hyper, int dim,
+                    int G) {
+  catch_up_body<V>(blockIdx.x, ukeys, n_unique, capacity, tab, lr_hist, hyper, dim, G);
+}
+
+// Horizontal fusion: the same per-group work of up to kMaxMulti table groups in ONE grid - workgroups
+// [start[i], start[i + 1]) run group i's body (a wave-uniform dispatch on its lane width V).  The groups' kernels are
+// independent chains of dependent random accesses that leave most CUs idle: side by side they overlap, and the step
+// has one launch instead of one per group.
+constexpr int kMaxMulti = 4;
+
+struct CatchUpArgs {
+  const uint32_t* ukeys;
+  const int32_t* n_unique;
+  int64_t capacity;
+  RowUpdate tab;
+  const float* lr_hist;
+  int dim, G, V;
+};
+struct CatchUpMulti {
+  int n;
+  int start[kMaxMulti + 1];
+  const er_opt_hyper* hyper;
+  CatchUpArgs a[kMaxMulti];
+};
+
+__global__ void __launch_bounds__(kBlock)
+emb_catch_up_multi_kernel(CatchUpMulti ma) {
+  int i = 0;
+  while (i + 1 < ma.n && static_cast<int>(blockIdx.x) >= ma.start[i + 1]) ++i;
+  const CatchUpArgs& a = ma.a[i];
+  const int bid = blockIdx.x - ma.start[i];
+  if (a.V == 4) catch_up_body<4>(bid, a.ukeys, a.n_unique, a.capacity, a.tab, a.lr_hist, ma.hyper, a.dim, a.G);
+  else catch_up_body<1>(bid, a.ukeys, a.n_unique, a.capacity, a.tab, a.lr_hist, ma.hyper, a.dim, a.G);
 }
 
 // every row: replay the pending decay steps up to and including step (*step_counter - 1); last_step = that
@@ -483,12 +558,12 @@ __device__ __forceinline__ void finish_run(const RowUpdate& tab, int opt_kind, c
 __host__ __device__ constexpr int tile_passes(int V) { return V == 4 ? 4 : 1; }
 
 template <int V>
-__global__ void __launch_bounds__(kBlock)
-emb_bwd_tile_kernel(const uint32_t* __restrict__ skeys, const uint32_t* __restrict__ svals,
-                    const float* const* __restrict__ ent_gptr, const float* __restrict__ ent_scale, int64_t n,
-                    int dim, int G, RowUpdate tab, int opt_kind, const er_opt_hyper* __restrict__ hyper,
-                    ReduceOut ro, float* __restrict__ tile_first, float* __restrict__ tile_last) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+__device__ __forceinline__ void tile_body(int bid, float* __restrict__ smem, const uint32_t* __restrict__ skeys,
+                                          const uint32_t* __restrict__ svals, const float* const* __restrict__ ent_gptr,
+                                          const float* __restrict__ ent_scale, int64_t n, int dim, int G,
+                                          const RowUpdate& tab, int opt_kind, const er_opt_hyper* __restrict__ hyper,
+                                          const ReduceOut& ro, float* __restrict__ tile_first,
+                                          float* __restrict__ tile_last) {
   const int epp = kBlock / G;            // entries per pass
   constexpr int kTilePasses = tile_passes(V);
   const int T = kTilePasses * epp;       // entries per tile
@@ -497,7 +572,7 @@ emb_bwd_tile_kernel(const uint32_t* __restrict__ skeys, const uint32_t* __restri
   const int tid = threadIdx.x;
   const int sub = tid % G;
   const int c = sub * V;
-  const int64_t t0 = static_cast<int64_t>(blockIdx.x) * T;
+  const int64_t t0 = static_cast<int64_t>(bid) * T;
   for (int i = tid; i < T + 2; i += kBlock) {
     const int64_t p = t0 - 1 + i;
     keys[i] = (p >= 0 && p < n) ? skeys[p] : kInvalidKey;
@@ -563,18 +638,29 @@ emb_bwd_tile_kernel(const uint32_t* __restrict__ skeys, const uint32_t* __restri
     } else {
       Vec<V> r;
       r.load(gs);
-      if (from_prev) r.store(tile_first + static_cast<size_t>(blockIdx.x) * dim + c);
-      if (to_next) r.store(tile_last + static_cast<size_t>(blockIdx.x) * dim + c);
+      if (from_prev) r.store(tile_first + static_cast<size_t>(bid) * dim + c);
+      if (to_next) r.store(tile_last + static_cast<size_t>(bid) * dim + c);
     }
   }
 }
 
 template <int V>
 __global__ void __launch_bounds__(kBlock)
-emb_bwd_fix_kernel(const uint32_t* __restrict__ skeys, int64_t n, int dim, int G, int T, int n_tiles,
-                   RowUpdate tab, int opt_kind, const er_opt_hyper* __restrict__ hyper, ReduceOut ro,
-                   const float* __restrict__ tile_first, const float* __restrict__ tile_last) {
-  const int64_t s = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) / G;  // start tile candidate
+emb_bwd_tile_kernel(const uint32_t* __restrict__ skeys, const uint32_t* __restrict__ svals,
+                    const float* const* __restrict__ ent_gptr, const float* __restrict__ ent_scale, int64_t n,
+                    int dim, int G, RowUpdate tab, int opt_kind, const er_opt_hyper* __restrict__ hyper,
+                    ReduceOut ro, float* __restrict__ tile_first, float* __restrict__ tile_last) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  tile_body<V>(blockIdx.x, smem, skeys, svals, ent_gptr, ent_scale, n, dim, G, tab, opt_kind, hyper, ro, tile_first,
+               tile_last);
+}
+
+template <int V>
+__device__ __forceinline__ void fix_body(int bid, const uint32_t* __restrict__ skeys, int64_t n, int dim, int G, int T,
+                                         int n_tiles, const RowUpdate& tab, int opt_kind,
+                                         const er_opt_hyper* __restrict__ hyper, const ReduceOut& ro,
+                                         const float* __restrict__ tile_first, const float* __restrict__ tile_last) {
+  const int64_t s = (static_cast<int64_t>(bid) * kBlock + threadIdx.x) / G;  // start tile candidate
   const int sub = static_cast<int>(threadIdx.x) % G;
   const int c = sub * V;
   if (s >= n_tiles || c >= dim) return;
@@ -600,6 +686,64 @@ emb_bwd_fix_kernel(const uint32_t* __restrict__ skeys, int64_t n, int dim, int G
   float g[V];
   if constexpr (V == 4) { g[0] = acc.v.x; g[1] = acc.v.y; g[2] = acc.v.z; g[3] = acc.v.w; } else { g[0] = acc.v; }
   finish_run<V>(tab, opt_kind, hyper, ro, key, next0 - 1, sub, c, dim, g);
+}
+
+template <int V>
+__global__ void __launch_bounds__(kBlock)
+emb_bwd_fix_kernel(const uint32_t* __restrict__ skeys, int64_t n, int dim, int G, int T, int n_tiles,
+                   RowUpdate tab, int opt_kind, const er_opt_hyper* __restrict__ hyper, ReduceOut ro,
+                   const float* __restrict__ tile_first, const float* __restrict__ tile_last) {
+  fix_body<V>(blockIdx.x, skeys, n, dim, G, T, n_tiles, tab, opt_kind, hyper, ro, tile_first, tile_last);
+}
+
+// the tile / fix kernels of several table groups in one grid each (see emb_catch_up_multi_kernel)
+struct RunArgs {
+  const uint32_t* skeys;
+  const uint32_t* svals;
+  const float* const* ent_gptr;
+  const float* ent_scale;
+  int64_t n;
+  int dim, G, V, T, n_tiles;
+  RowUpdate tab;
+  ReduceOut ro;
+  float* tile_first;
+  float* tile_last;
+};
+struct RunMulti {
+  int n;
+  int start[kMaxMulti + 1];
+  int opt_kind;
+  const er_opt_hyper* hyper;
+  RunArgs a[kMaxMulti];
+};
+
+__global__ void __launch_bounds__(kBlock)
+emb_bwd_tile_multi_kernel(RunMulti ma) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  int i = 0;
+  while (i + 1 < ma.n && static_cast<int>(blockIdx.x) >= ma.start[i + 1]) ++i;
+  const RunArgs& a = ma.a[i];
+  const int bid = blockIdx.x - ma.start[i];
+  if (a.V == 4)
+    tile_body<4>(bid, smem, a.skeys, a.svals, a.ent_gptr, a.ent_scale, a.n, a.dim, a.G, a.tab, ma.opt_kind, ma.hyper, a.ro,
+                 a.tile_first, a.tile_last);
+  else
+    tile_body<1>(bid, smem, a.skeys, a.svals, a.ent_gptr, a.ent_scale, a.n, a.dim, a.G, a.tab, ma.opt_kind, ma.hyper, a.ro,
+                 a.tile_first, a.tile_last);
+}
+
+__global__ void __launch_bounds__(kBlock)
+emb_bwd_fix_multi_kernel(RunMulti ma) {
+  int i = 0;
+  while (i + 1 < ma.n && static_cast<int>(blockIdx.x) >= ma.start[i + 1]) ++i;
+  const RunArgs& a = ma.a[i];
+  const int bid = blockIdx.x - ma.start[i];
+  if (a.V == 4)
+    fix_body<4>(bid, a.skeys, a.n, a.dim, a.G, a.T, a.n_tiles, a.tab, ma.opt_kind, ma.hyper, a.ro, a.tile_first,
+                a.tile_last);
+  else
+    fix_body<1>(bid, a.skeys, a.n, a.dim, a.G, a.T, a.n_tiles, a.tab, ma.opt_kind, ma.hyper, a.ro, a.tile_first,
+                a.tile_last);
 }
 
 // Segmented sort: when every lookup of a group owns its own table (disjoint, increasing key ranges - the normal
@@ -1098,6 +1242,8 @@ struct er_emb_group {
   er_emb_group* leader = nullptr;
   er_emb_group* src = nullptr;
   uint64_t sort_epoch = 0, adopted_epoch = 0, heads_epoch = 0;
+  std::vector<er_emb_group*> followers;  // groups that share this group's sort: their entries are built with ours
+  uint64_t built_epoch = ~0ull;          // follower: leader sort epoch its entry arrays were built for
   std::vector<er_lookup_desc> h_descs;
   std::vector<int64_t> h_local_base;
   float *var = nullptr, *m = nullptr, *v = nullptr;
@@ -1284,6 +1430,14 @@ int er_emb_group_update(er_emb_group* g, const er_lookup_desc* descs, int n) {
 
 int er_emb_group_destroy(er_emb_group* g) {
   if (!g) return 0;
+  if (g->leader) {
+    auto& fl = g->leader->followers;
+    fl.erase(std::remove(fl.begin(), fl.end(), g), fl.end());
+  }
+  for (er_emb_group* f : g->followers) {  // followers fall back to their own sort
+    f->leader = nullptr;
+    f->src = f;
+  }
   void* ptrs[] = {g->d_descs, g->d_blk_start, g->d_ent_base, g->keys_in, g->keys_out, g->vals_in, g->vals_out,
                   g->ent_gptr, g->ent_scale, g->tile_first, g->tile_last, g->head_flags, g->head_index, g->sort_temp, g->scan_temp,
                   g->d_local_base, g->seg_count};
@@ -1305,16 +1459,38 @@ static int fill_u32(uint32_t* p, uint32_t value, int64_t n, hipStream_t s) {
 
 static int64_t group_entries(const er_emb_group* g) { return g->n_active >= 0 ? g->n_active : g->n_entries; }
 
+static bool emb_group_same_keys(const er_emb_group* g, const er_emb_group* l);
+
+// Entry arrays (keys, gradient pointers, scales) of g - and, in the same launch, of the groups that share its sort
+// (they are about to adopt it: er_emb_group_share_sort).
 static int emb_group_build(er_emb_group* g, hipStream_t s) {
   const int64_t N = group_entries(g);
   if (N == 0) return 0;
-  if (g->has_ragged)
-    if (int rc = fill_u32(g->keys_in, 0xFFFFFFFFu, N, s)) return rc;
-  er::Route rt{g->world, g->shard_stride, g->d_local_base};
-  const int64_t n_act = g->n_active >= 0 ? g->n_active : INT64_MAX;
-  hipLaunchKernelGGL(er::emb_bwd_build_kernel, dim3(g->n_build_blocks), dim3(er::kBlock), 0, s, g->d_descs,
-                     g->d_blk_start, g->d_ent_base, g->n, rt, n_act, g->keys_in, g->vals_in, g->ent_gptr, g->ent_scale);
+  er_emb_group* gs[er::kMaxMulti] = {g};
+  int n = 1;
+  for (er_emb_group* f : g->followers)
+    if (n < er::kMaxMulti && group_entries(f) > 0 && emb_group_same_keys(f, g)) gs[n++] = f;
+  er::BuildMulti ma;
+  ma.n = n;
+  ma.start[0] = 0;
+  for (int i = 0; i < n; ++i) {
+    er_emb_group* q = gs[i];
+    if (q->has_ragged)
+      if (int rc = fill_u32(q->keys_in, 0xFFFFFFFFu, group_entries(q), s)) return rc;
+    ma.a[i] = er::BuildArgs{q->d_descs, q->d_blk_start, q->d_ent_base, q->n,
+                            er::Route{q->world, q->shard_stride, q->d_local_base},
+                            q->n_active >= 0 ? q->n_active : INT64_MAX, q->keys_in, q->vals_in, q->ent_gptr, q->ent_scale};
+    ma.start[i + 1] = ma.start[i] + q->n_build_blocks;
+  }
+  if (n == 1) {
+    hipLaunchKernelGGL(er::emb_bwd_build_kernel, dim3(g->n_build_blocks), dim3(er::kBlock), 0, s, ma.a[0].descs,
+                       ma.a[0].blk_start, ma.a[0].ent_base, ma.a[0].n_lookups, ma.a[0].rt, ma.a[0].n_active, ma.a[0].keys,
+                       ma.a[0].vals, ma.a[0].ent_gptr, ma.a[0].ent_scale);
+  } else {
+    hipLaunchKernelGGL(er::emb_bwd_build_multi_kernel, dim3(ma.start[n]), dim3(er::kBlock), 0, s, ma);
+  }
   ER_LAUNCH_CHECK();
+  for (int i = 1; i < n; ++i) gs[i]->built_epoch = g->sort_epoch + 1;  // the sort that follows bumps the epoch
   return 0;
 }
 
@@ -1342,7 +1518,8 @@ static int emb_group_adopt(er_emb_group* g, hipStream_t s, bool* adopted) {
   ER_REQUIRE(l->sort_epoch != g->adopted_epoch,
              "shared sort: the leader group has not been processed since this group last used its sort "
              "(call the leader first in every step)");
-  if (int rc = emb_group_build(g, s)) return rc;
+  if (g->built_epoch != l->sort_epoch)  // normally built together with the leader's entries (emb_group_build)
+    if (int rc = emb_group_build(g, s)) return rc;
   g->adopted_epoch = l->sort_epoch;
   g->src = l;
   *adopted = true;
@@ -1502,6 +1679,75 @@ int er_emb_bwd_update(er_emb_group* g, int opt_kind, const er_opt_hyper* hyper, 
   return 0;
 }
 
+int er_emb_bwd_update_multi(er_emb_group* const* groups, int n, int opt_kind, const er_opt_hyper* hyper,
+                            er_stream_t stream) {
+  ER_REQUIRE(groups && hyper && n >= 1 && n <= er::kMaxMulti, "er_emb_bwd_update_multi: bad arguments (1 <= n <= %d)",
+             er::kMaxMulti);
+  if (n == 1) return er_emb_bwd_update(groups[0], opt_kind, hyper, stream);
+  ER_REQUIRE(opt_kind >= ER_OPT_SGD && opt_kind <= ER_OPT_ADAGRAD, "er_emb_bwd_update_multi: unknown optimizer %d", opt_kind);
+  hipStream_t s = er::as_stream(stream);
+  er::RunMulti ma;
+  ma.n = 0;
+  ma.start[0] = 0;
+  ma.opt_kind = opt_kind;
+  ma.hyper = hyper;
+  int fix_start[er::kMaxMulti + 1] = {0};
+  size_t lds = 0;
+  bool any_fix = false;
+  for (int i = 0; i < n; ++i) {
+    er_emb_group* g = groups[i];
+    ER_REQUIRE(g, "er_emb_bwd_update_multi: null group %d", i);
+    if (opt_kind == ER_OPT_ADAM || opt_kind == ER_OPT_LAZY_ADAM)
+      ER_REQUIRE(g->m && g->v, "er_emb_bwd_update_multi: Adam needs m and v (group %d)", i);
+    if (opt_kind == ER_OPT_ADAGRAD) ER_REQUIRE(g->v, "er_emb_bwd_update_multi: Adagrad needs the accumulator in v");
+    const bool lazy_decay = (opt_kind == ER_OPT_ADAM) && g->last_step;
+    if (opt_kind == ER_OPT_ADAM && !lazy_decay)
+      ER_REQUIRE(g->bitmap, "er_emb_bwd_update_multi: ER_OPT_ADAM needs touched_bitmap or lazy decay (group %d)", i);
+    if (!g->sorted_valid) {  // as er_emb_bwd_update: reuse this step's er_emb_route, adopt the leader's sort, or sort
+      bool adopted = false;
+      if (g->leader)
+        if (int rc = emb_group_adopt(g, s, &adopted)) return rc;
+      if (!adopted)
+        if (int rc = emb_group_sort(g, s)) return rc;
+    }
+    g->sorted_valid = false;
+    const int64_t N = group_entries(g);
+    if (N == 0) continue;
+    const er_emb_group* src = g->src;
+    er::RunArgs& a = ma.a[ma.n];
+    a.skeys = src->keys_out; a.svals = src->vals_out; a.ent_gptr = g->ent_gptr; a.ent_scale = g->ent_scale;
+    a.n = N; a.dim = g->dim; a.G = g->G; a.V = g->V; a.T = g->tile_entries;
+    a.n_tiles = static_cast<int>(er::ceil_div(N, a.T));
+    a.tab = er::RowUpdate{g->var, g->m, g->v, g->bitmap, g->last_step, g->step_counter};
+    a.ro = er::ReduceOut{0, src->head_flags, src->head_index, nullptr, nullptr};
+    a.tile_first = g->tile_first; a.tile_last = g->tile_last;
+    ma.start[ma.n + 1] = ma.start[ma.n] + a.n_tiles;
+    const int fb = a.n_tiles > 1 ? static_cast<int>(er::ceil_div(static_cast<int64_t>(a.n_tiles) * g->G, er::kBlock)) : 0;
+    fix_start[ma.n + 1] = fix_start[ma.n] + fb;
+    any_fix = any_fix || fb > 0;
+    const size_t need = sizeof(float) * static_cast<size_t>(a.T) * g->dim + sizeof(uint32_t) * (a.T + 2);
+    if (need > lds) lds = need;
+    ++ma.n;
+  }
+  if (ma.n > 0) {
+    hipLaunchKernelGGL(er::emb_bwd_tile_multi_kernel, dim3(ma.start[ma.n]), dim3(er::kBlock), lds, s, ma);
+    ER_LAUNCH_CHECK();
+    if (any_fix) {
+      for (int i = 0; i <= ma.n; ++i) ma.start[i] = fix_start[i];
+      hipLaunchKernelGGL(er::emb_bwd_fix_multi_kernel, dim3(ma.start[ma.n]), dim3(er::kBlock), 0, s, ma);
+      ER_LAUNCH_CHECK();
+    }
+  }
+  for (int i = 0; i < n; ++i) {  // TF-exact Adam with the streaming sweep: per group, as er_emb_bwd_update
+    er_emb_group* g = groups[i];
+    if (opt_kind == ER_OPT_ADAM && !g->last_step) {
+      if (int rc = er_adam_decay_sweep(g->var, g->m, g->v, g->bitmap, g->total_rows, g->dim, hyper, stream)) return rc;
+      if (int rc = fill_u32(g->bitmap, 0u, er::ceil_div(g->total_rows, 32), s)) return rc;
+    }
+  }
+  return 0;
+}
+
 int er_emb_group_enable_lazy_decay(er_emb_group* g, int32_t* last_step, const float* lr_t_history,
                                    const int64_t* step_counter) {
   ER_REQUIRE(g && last_step && lr_t_history && step_counter, "er_emb_group_enable_lazy_decay: null argument");
@@ -1527,6 +1773,34 @@ int er_emb_catch_up(er_emb_group* g, const uint32_t* unique_keys, const int32_t*
     hipLaunchKernelGGL(er::emb_catch_up_kernel<1>, dim3(blocks), dim3(er::kBlock), 0, er::as_stream(stream), unique_keys,
                        n_unique, cap, tab, g->lr_hist, hyper, g->dim, g->G);
   }
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
+int er_emb_catch_up_multi(er_emb_group* const* groups, const uint32_t* const* unique_keys,
+                          const int32_t* const* n_unique, int n, const er_opt_hyper* hyper, er_stream_t stream) {
+  ER_REQUIRE(groups && unique_keys && n_unique && hyper && n >= 1 && n <= er::kMaxMulti,
+             "er_emb_catch_up_multi: bad arguments (1 <= n <= %d)", er::kMaxMulti);
+  if (n == 1) return er_emb_catch_up(groups[0], unique_keys[0], n_unique[0], hyper, stream);
+  er::CatchUpMulti ma;
+  ma.n = 0;
+  ma.start[0] = 0;
+  ma.hyper = hyper;
+  for (int i = 0; i < n; ++i) {
+    er_emb_group* g = groups[i];
+    ER_REQUIRE(g && unique_keys[i] && n_unique[i], "er_emb_catch_up_multi: null argument (group %d)", i);
+    ER_REQUIRE(g->last_step, "er_emb_catch_up_multi: call er_emb_group_enable_lazy_decay first (group %d)", i);
+    const int64_t cap = group_entries(g);
+    if (cap == 0) continue;
+    er::CatchUpArgs& a = ma.a[ma.n];
+    a.ukeys = unique_keys[i]; a.n_unique = n_unique[i]; a.capacity = cap;
+    a.tab = er::RowUpdate{g->var, g->m, g->v, g->bitmap, g->last_step, g->step_counter};
+    a.lr_hist = g->lr_hist; a.dim = g->dim; a.G = g->G; a.V = g->V;
+    ma.start[ma.n + 1] = ma.start[ma.n] + static_cast<int>(er::ceil_div(cap * g->G, er::kBlock));
+    ++ma.n;
+  }
+  if (ma.n == 0) return 0;
+  hipLaunchKernelGGL(er::emb_catch_up_multi_kernel, dim3(ma.start[ma.n]), dim3(er::kBlock), 0, er::as_stream(stream), ma);
   ER_LAUNCH_CHECK();
   return 0;
 }
@@ -1613,6 +1887,10 @@ int er_emb_group_set_routing(er_emb_group* g, int32_t world, int64_t shard_strid
 int er_emb_group_share_sort(er_emb_group* g, er_emb_group* leader) {
   ER_REQUIRE(g && g != leader, "er_emb_group_share_sort: bad arguments");
   if (!leader) {
+    if (g->leader) {
+      auto& fl = g->leader->followers;
+      fl.erase(std::remove(fl.begin(), fl.end(), g), fl.end());
+    }
     g->leader = nullptr;
     g->src = g;
     return 0;
@@ -1620,8 +1898,14 @@ int er_emb_group_share_sort(er_emb_group* g, er_emb_group* leader) {
   ER_REQUIRE(!leader->leader, "er_emb_group_share_sort: the leader itself follows another group");
   ER_REQUIRE(emb_group_same_keys(g, leader),
              "er_emb_group_share_sort: the groups do not read the same ids with the same table geometry");
+  if (g->leader && g->leader != leader) {
+    auto& fl = g->leader->followers;
+    fl.erase(std::remove(fl.begin(), fl.end(), g), fl.end());
+  }
   g->leader = leader;
   g->adopted_epoch = leader->sort_epoch;
+  if (std::find(leader->followers.begin(), leader->followers.end(), g) == leader->followers.end())
+    leader->followers.push_back(g);
   return 0;
 }
 

@@ -801,6 +801,21 @@ class HipBackend(object):
     self._ck(self.lib.er_emb_catch_up(group['handle'], _p(unique_keys), _p(n_unique), _p(hyper), _stream()),
              'er_emb_catch_up')
 
+  def emb_catch_up_multi(self, groups, unique_keys, n_unique, hyper):
+    """er_emb_catch_up for several table groups in one launch (same results)."""
+    n = len(groups)
+    gh = (ctypes.c_void_p * n)(*[g['handle'] for g in groups])
+    uk = (ctypes.c_void_p * n)(*[t.data_ptr() for t in unique_keys])
+    nu = (ctypes.c_void_p * n)(*[t.data_ptr() for t in n_unique])
+    self._ck(self.lib.er_emb_catch_up_multi(gh, uk, nu, n, _p(hyper), _stream()), 'er_emb_catch_up_multi')
+
+  def emb_bwd_update_multi(self, groups, opt_kind, hyper):
+    """er_emb_bwd_update for several table groups: one tile launch and one fix launch for all (same results)."""
+    n = len(groups)
+    gh = (ctypes.c_void_p * n)(*[g['handle'] for g in groups])
+    self._ck(self.lib.er_emb_bwd_update_multi(gh, n, ctypes.c_int(opt_kind), _p(hyper), _stream()),
+             'er_emb_bwd_update_multi')
+
   def emb_flush_decay(self, group, hyper):
     self._ck(self.lib.er_emb_flush_decay(group['handle'], _p(hyper), _stream()), 'er_emb_flush_decay')
 

@@ -15,6 +15,7 @@ table by `key_base` (first row).  Variable names follow TF's scoping
 384-414) so per-table views can be exported under the reference's names.
 """
 import logging
+import os
 import math
 from collections import OrderedDict
 
@@ -304,6 +305,7 @@ class EmbeddingEngine(object):
       g['got_grad'] = False
     if self.lazy_decay:
       # sort the step's ids once (reused by the backward), bring the rows it touches up to date, then look up
+      grps, uks, nus = [], [], []
       for dim, grp in self.emb_groups.items():
         lz = self._lazy[dim]
         if dim in self._sort_leader:
@@ -311,7 +313,12 @@ class EmbeddingEngine(object):
           be.emb_route(grp, None, None, None, None)
         else:
           be.emb_route(grp, lz['ukeys'], lz['n_unique'], None, None)
-        be.emb_catch_up(grp, lz['ukeys'], lz['n_unique'], self._clock[2])
+        grps.append(grp)
+        uks.append(lz['ukeys'])
+        nus.append(lz['n_unique'])
+      step = 4 if os.environ.get('EASYREC_AMD_MULTI', '1') != '0' else 1  # A/B switch
+      for i in range(0, len(grps), step):  # the table groups' catch-up kernels side by side in one launch
+        be.emb_catch_up_multi(grps[i:i + step], uks[i:i + step], nus[i:i + step], self._clock[2])
     if self.plan is not None:
       be.emb_fwd(self.plan, self.sumsq if self.reg_lambda > 0 else None)
     self._ran_version = version
@@ -377,8 +384,10 @@ class EmbeddingEngine(object):
       # the sweep of the untouched rows is already in flight on the side stream; the touched rows
       # get the same per-row arithmetic as TF's sparse apply (== the lazy row update)
       opt_kind = kernels.OPT_LAZY_ADAM
-    for dim, grp in self.emb_groups.items():
-      be.emb_bwd_update(grp, opt_kind, hyper)
+    grps = list(self.emb_groups.values())
+    step = 4 if os.environ.get('EASYREC_AMD_MULTI', '1') != '0' else 1
+    for i in range(0, len(grps), step):  # one tile launch + one fix launch for (up to 4) table groups
+      be.emb_bwd_update_multi(grps[i:i + step], opt_kind, hyper)
     self.join_decay_sweep()
 
   # -- host exchange

@@ -461,6 +461,16 @@ int er_emb_group_set_active(er_emb_group* group, int64_t n_rows);
  * er_emb_route may be called with unique_keys = n_unique = NULL: they would equal the leader's.
  * leader = NULL removes the link. */
 int er_emb_group_share_sort(er_emb_group* group, er_emb_group* leader);
+/* The same work for up to 4 table groups in ONE launch each ("horizontal fusion": workgroup ranges of one grid run
+ * the groups' kernels side by side).  The per-group arithmetic - and every bit of the result - is that of n separate
+ * er_emb_catch_up / er_emb_bwd_update calls in the given order of the groups; what changes is that the groups'
+ * latency-bound kernels (dependent random accesses that leave most CUs idle) overlap, and the launch count.
+ * Groups that share a sort (er_emb_group_share_sort) must come after their leader. */
+int er_emb_catch_up_multi(er_emb_group* const* groups_host, const uint32_t* const* unique_keys_host,
+                          const int32_t* const* n_unique_host, int n, const er_opt_hyper* hyper,
+                          er_stream_t stream);
+int er_emb_bwd_update_multi(er_emb_group* const* groups_host, int n, int opt_kind, const er_opt_hyper* hyper,
+                            er_stream_t stream);
 int er_emb_route(er_emb_group* group, uint32_t* unique_keys, int32_t* n_unique,
                  int64_t* entry_unique_index, int32_t* owner_counts, er_stream_t stream);
 int er_emb_bwd_reduce_routed(er_emb_group* group, float* unique_grads, er_stream_t stream);

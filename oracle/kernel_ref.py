@@ -388,6 +388,14 @@ class RefBackend(object):
   def flush_wgrads(self):
     pass
 
+  def emb_catch_up_multi(self, groups, unique_keys, n_unique, hyper):
+    for g, uk, nu in zip(groups, unique_keys, n_unique):
+      self.emb_catch_up(g, uk, nu, hyper)
+
+  def emb_bwd_update_multi(self, groups, opt_kind, hyper):
+    for g in groups:
+      self.emb_bwd_update(g, opt_kind, hyper)
+
   def emb_group_share_sort(self, group, leader):
     from easyrec_amd.kernels import same_lookup_keys
     if not same_lookup_keys(group, leader):

@@ -702,7 +702,7 @@ def test_shared_sort_between_wide_and_deep_groups(hip, lazy):
   rows = [int(rng.integers(3, 400)) for _ in range(n_feat)]
   ids_steps = [[rng.integers(-1, r, size=B).astype(np.int64) for r in rows] for _ in range(T)]
   results = {}
-  for share in (False, True):
+  for share in (False, True, 'multi'):  # 'multi': shared sort + the groups' kernels fused into one launch each
     ids = [torch.zeros(B, dtype=torch.int64, device=DEV) for _ in rows]
     groups, state = {}, {}
     counter = torch.zeros(1, dtype=torch.int64, device=DEV)
@@ -741,7 +741,11 @@ def test_shared_sort_between_wide_and_deep_groups(hip, lazy):
       for dim in (1, 16):
         gd = torch.Generator().manual_seed(100 * s + dim)
         state[dim][3].copy_((torch.randn(B, n_feat * dim, generator=gd) * 0.01).to(DEV))
-      if lazy:
+      if lazy and share == 'multi':
+        hip.emb_route(groups[1], lz[1]['ukeys'], lz[1]['nu'], None, None)
+        hip.emb_route(groups[16], None, None, None, None)
+        hip.emb_catch_up_multi([groups[1], groups[16]], [lz[1]['ukeys']] * 2, [lz[1]['nu']] * 2, hyper)
+      elif lazy:
         for dim in (1, 16):
           if share and dim == 16:
             hip.emb_route(groups[16], None, None, None, None)
@@ -749,8 +753,11 @@ def test_shared_sort_between_wide_and_deep_groups(hip, lazy):
           else:
             hip.emb_route(groups[dim], lz[dim]['ukeys'], lz[dim]['nu'], None, None)
             hip.emb_catch_up(groups[dim], lz[dim]['ukeys'], lz[dim]['nu'], hyper)
-      for dim in (1, 16):
-        hip.emb_bwd_update(groups[dim], kernels.OPT_ADAM, hyper)
+      if share == 'multi':
+        hip.emb_bwd_update_multi([groups[1], groups[16]], kernels.OPT_ADAM, hyper)
+      else:
+        for dim in (1, 16):
+          hip.emb_bwd_update(groups[dim], kernels.OPT_ADAM, hyper)
     if lazy:
       for dim in (1, 16):
         hip.emb_flush_decay(groups[dim], hyper)
@@ -762,8 +769,9 @@ def test_shared_sort_between_wide_and_deep_groups(hip, lazy):
     for dim in (16, 1):
       hip.emb_group_destroy(groups[dim])
   for dim in (1, 16):
-    for a, b, what in zip(results[False][dim], results[True][dim], ('var', 'm', 'v')):
-      assert torch.equal(a, b), (dim, what)
+    for variant in (True, 'multi'):
+      for a, b, what in zip(results[False][dim], results[variant][dim], ('var', 'm', 'v')):
+        assert torch.equal(a, b), (dim, what, variant)
   assert float(results[True][16][1].abs().max()) > 0
 
 
