@@ -775,10 +775,14 @@ __device__ __forceinline__ void seg_cmpx(C& a, C& b, bool up) {
 // NARROW: 32-bit composites (row inside the lookup's table << log2 P | position inside the lookup; a missing id
 // sorts as row == rows) when (rows + 2) * P <= 2^32 for every lookup of the group - e.g. 1 M-row tables at P = 4096:
 // half the shuffles, LDS traffic and registers of the 64-bit (group key << 32 | group entry) form.
+// Routed keys (embedding-parallel requester: key = owner * stride + local_base[lookup] + id / W, rt.local_base != 0):
+// inside one lookup that order is (owner, local row), which is all the all-to-all needs; NARROW then packs
+// owner * shard_rows + local row, and with HEADS the kernel also counts the distinct keys per (lookup, owner)
+// (seg_count[lookup * 64 + owner]) for emb_route_seg_routed_kernel.
 template <int E, bool HEADS, bool NARROW>
 __global__ void __launch_bounds__(kSegSortMax / 8)
 emb_segment_sort_kernel(const uint32_t* __restrict__ keys_in, const int64_t* __restrict__ ent_base,
-                        const er_lookup_desc* __restrict__ descs, int P, uint32_t* __restrict__ keys_out,
+                        const er_lookup_desc* __restrict__ descs, int P, Route rt, uint32_t* __restrict__ keys_out,
                         uint32_t* __restrict__ vals_out, uint32_t* __restrict__ flags_out,
                         uint32_t* __restrict__ hidx_out, uint32_t* __restrict__ seg_count) {
   typedef typename std::conditional<NARROW, uint32_t, unsigned long long>::type C;
@@ -791,12 +795,28 @@ emb_segment_sort_kernel(const uint32_t* __restrict__ keys_in, const int64_t* __r
   const int64_t base = ent_base[blockIdx.x];
   const int cnt = static_cast<int>(ent_base[blockIdx.x + 1] - base);
   const int logP = __ffs(P) - 1;
-  const uint32_t key_base = NARROW ? static_cast<uint32_t>(descs[blockIdx.x].key_base) : 0u;
-  const uint32_t rows = NARROW ? static_cast<uint32_t>(descs[blockIdx.x].rows) : 0u;
+  const bool routed = rt.local_base != nullptr;
+  const uint32_t stride = static_cast<uint32_t>(rt.shard_stride);
+  // NARROW: `rel` in [0, rows) enumerates the lookup's keys in key order; rel == rows is a missing id
+  uint32_t key_base = 0u, rows = 0u, srows = 1u;
+  if (NARROW) {
+    const er_lookup_desc& d = descs[blockIdx.x];
+    if (routed) {
+      srows = static_cast<uint32_t>((d.rows + rt.world - 1) / rt.world);  // rows of one rank's shard of this table
+      rows = srows * static_cast<uint32_t>(rt.world);
+      key_base = static_cast<uint32_t>(rt.local_base[blockIdx.x]);
+    } else {
+      rows = static_cast<uint32_t>(d.rows);
+      key_base = static_cast<uint32_t>(d.key_base);
+    }
+  }
   auto key_of = [&](C c) -> uint32_t {
     if (NARROW) {
       const uint32_t rel = static_cast<uint32_t>(c >> logP);
-      return rel >= rows ? kInvalidKey : rel + key_base;  // (padding decodes as invalid too)
+      if (rel >= rows) return kInvalidKey;  // (padding decodes as invalid too)
+      if (!routed) return rel + key_base;
+      const uint32_t owner = rel / srows;
+      return owner * stride + key_base + (rel - owner * srows);
     }
     return static_cast<uint32_t>(static_cast<unsigned long long>(c) >> 32);
   };
@@ -808,7 +828,15 @@ emb_segment_sort_kernel(const uint32_t* __restrict__ keys_in, const int64_t* __r
       x[e] = static_cast<C>(~0ull);
     } else if (NARROW) {
       const uint32_t key = keys_in[base + i];
-      const uint32_t rel = key == kInvalidKey ? rows : key - key_base;
+      uint32_t rel = rows;
+      if (key != kInvalidKey) {
+        if (routed) {
+          const uint32_t owner = key / stride;
+          rel = owner * srows + (key - owner * stride - key_base);
+        } else {
+          rel = key - key_base;
+        }
+      }
       x[e] = static_cast<C>((rel << logP) | static_cast<uint32_t>(i));
     } else {
       x[e] = static_cast<C>((static_cast<unsigned long long>(keys_in[base + i]) << 32) | static_cast<unsigned>(base + i));
@@ -917,8 +945,78 @@ emb_segment_sort_kernel(const uint32_t* __restrict__ keys_in, const int64_t* __r
       }
       run += f[e];
     }
-    if (t == 0) seg_count[blockIdx.x] = total;
+    if (!routed) {
+      if (t == 0) seg_count[blockIdx.x] = total;
+    } else {
+      __shared__ uint32_t owner_cnt[64];
+      if (t < 64) owner_cnt[t] = 0u;
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < E; ++e)
+        if (f[e]) atomicAdd(&owner_cnt[key_of(x[e]) / stride], 1u);  // integer: exact, order-independent
+      __syncthreads();
+      if (t < 64) seg_count[blockIdx.x * 64 + t] = owner_cnt[t];
+    }
   }
+}
+
+// Routed counterpart of emb_route_seg_kernel.  The de-duplicated keys must come out grouped by owner (the
+// all-to-all send order) and, inside an owner, by lookup then row - which is the ascending order of the routed
+// key.  A run of lookup l owned by w gets the index
+//   u = (keys of owners < w) + (keys of owner w in lookups < l) + (its rank among lookup l's keys of owner w),
+// all from the 64-column count matrix the sort kernel left.  head_index[p] is stored as u + 1 - flag[p] so that the
+// reduction kernels' `head_index + flag - 1` yields u at every entry of the run.
+__global__ void __launch_bounds__(kBlock)
+emb_route_seg_routed_kernel(const uint32_t* __restrict__ skeys, const uint32_t* __restrict__ svals,
+                            const uint32_t* __restrict__ flags, uint32_t* __restrict__ head_index,
+                            const int64_t* __restrict__ ent_base, const uint32_t* __restrict__ seg_count, int n_lookups,
+                            int world, uint32_t stride, uint32_t* __restrict__ unique_keys, int64_t* __restrict__ uidx,
+                            int32_t* __restrict__ n_unique, int32_t* __restrict__ owner_counts) {
+  __shared__ uint32_t s_total[64], s_before[64], s_row[64], s_obase[64], s_lbase[64];
+  const int l = blockIdx.y;
+  const int tid = threadIdx.x;
+  if (tid < 64) {
+    uint32_t tot = 0, before = 0;
+    if (tid < world)
+      for (int j = 0; j < n_lookups; ++j) {
+        const uint32_t c = seg_count[j * 64 + tid];
+        if (j < l) before += c;
+        tot += c;
+      }
+    s_total[tid] = tot;
+    s_before[tid] = before;
+    s_row[tid] = tid < world ? seg_count[l * 64 + tid] : 0u;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t a = 0, b = 0;
+    for (int w = 0; w < world; ++w) {
+      s_obase[w] = a;
+      s_lbase[w] = b;
+      a += s_total[w];
+      b += s_row[w];
+    }
+    if (l == n_lookups - 1 && blockIdx.x == 0) *n_unique = static_cast<int32_t>(a);
+  }
+  __syncthreads();
+  if (l == n_lookups - 1 && blockIdx.x == 0 && owner_counts && tid < world) owner_counts[tid] = static_cast<int32_t>(s_total[tid]);
+  const int64_t base = ent_base[l];
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + tid;
+  if (i >= ent_base[l + 1] - base) return;
+  const int64_t p = base + i;
+  const uint32_t key = skeys[p];
+  const uint32_t j = svals[p];
+  if (key == kInvalidKey) {
+    if (uidx) uidx[j] = -1;
+    return;
+  }
+  const uint32_t f = flags[p];
+  const uint32_t w = key / stride;
+  const uint32_t run = head_index[p] + f - 1u;  // index of the run among the lookup's runs
+  const uint32_t u = s_obase[w] + s_before[w] + (run - s_lbase[w]);
+  head_index[p] = u + 1u - f;
+  if (uidx) uidx[j] = static_cast<int64_t>(u);
+  if (f) unique_keys[u] = key;
 }
 
 // Second half of the fused route of the segmented path: add the distinct-key counts of the lookups before this one
@@ -1236,6 +1334,9 @@ struct er_emb_group {
   int seg_sort_pow2 = 0;   // > 0: per-lookup LDS sort (emb_segment_sort_kernel) with this padded size
   uint32_t* seg_count = nullptr;  // [n] distinct valid keys per lookup (fused heads of the segmented path)
   bool seg_narrow = false;        // 32-bit sort composites: (rows + 2) * P <= 2^32 for every lookup
+  int seg_caps_pow2 = 0;          // padded per-lookup size if every lookup has at most kSegSortMax entries
+  bool seg_routed = false;        // routed keys (er_emb_group_set_routing) keep per-lookup disjoint, increasing ranges
+  bool seg_routed_narrow = false;
   bool sorted_valid = false;
   // er_emb_group_share_sort: `src` owns the sorted keys / entry permutation / run heads this group reduces over
   // (itself, or the leader whose keys are identical); the epochs tell a fresh leader sort from a stale one
@@ -1363,6 +1464,15 @@ int er_emb_group_create(const er_lookup_desc* descs, int n, int32_t dim, int64_t
   g->src = g;
   g->h_descs.assign(descs, descs + n);
   {
+    int64_t mc = 0;
+    for (int i = 0; i < n; ++i) mc = std::max<int64_t>(mc, base[i + 1] - base[i]);
+    if (mc > 0 && mc <= er::kSegSortMax) {
+      int p2 = er::kSegSortMin;
+      while (p2 < mc) p2 <<= 1;
+      g->seg_caps_pow2 = p2;
+    }
+  }
+  {
     // segmented-sort fast path: dense or small lookups, each on its own table, key ranges increasing in lookup order
     bool ok = true;
     int64_t max_cap = 0;
@@ -1404,7 +1514,7 @@ int er_emb_group_create(const er_lookup_desc* descs, int n, int32_t dim, int64_t
   }
   ER_CHECK_HIP(hipMalloc(&g->head_flags, sizeof(uint32_t) * N));
   ER_CHECK_HIP(hipMalloc(&g->head_index, sizeof(uint32_t) * N));
-  ER_CHECK_HIP(hipMalloc(&g->seg_count, sizeof(uint32_t) * (n + 1)));
+  ER_CHECK_HIP(hipMalloc(&g->seg_count, sizeof(uint32_t) * (static_cast<size_t>(n) * 64 + 1)));  // [n][64 owners]
   ER_CHECK_HIP(hipMemset(g->keys_in, 0xFF, sizeof(uint32_t) * N));
   ER_CHECK_HIP(rocprim::radix_sort_pairs(nullptr, g->sort_temp_bytes, g->keys_in, g->keys_out, g->vals_in, g->vals_out,
                                          static_cast<size_t>(N), 0u, static_cast<unsigned>(g->key_bits)));
@@ -1515,6 +1625,7 @@ static int emb_group_adopt(er_emb_group* g, hipStream_t s, bool* adopted) {
   *adopted = false;
   er_emb_group* l = g->leader;
   if (!emb_group_same_keys(g, l)) return 0;
+  if (l->d_local_base) return 0;  // routed keys: the leader's head indices are in the requester's send order
   ER_REQUIRE(l->sort_epoch != g->adopted_epoch,
              "shared sort: the leader group has not been processed since this group last used its sort "
              "(call the leader first in every step)");
@@ -1528,7 +1639,8 @@ static int emb_group_adopt(er_emb_group* g, hipStream_t s, bool* adopted) {
 
 // build keys (routed) + stable sort.  Leaves keys_out/vals_out valid for this step.
 static bool emb_group_segmented(const er_emb_group* g) {
-  return g->seg_sort_pow2 > 0 && g->n_active < 0 && !g->d_local_base;
+  if (g->n_active >= 0) return false;
+  return g->d_local_base ? g->seg_routed : g->seg_sort_pow2 > 0;
 }
 
 // with_heads (segmented path only): the sort kernel also leaves head flags, per-lookup head indices and counts
@@ -1539,13 +1651,17 @@ static int emb_group_build_sort(er_emb_group* g, hipStream_t s, bool with_heads 
   g->src = g;
   ++g->sort_epoch;
   if (emb_group_segmented(g)) {
-    const int P = g->seg_sort_pow2;
+    const bool routed = g->d_local_base != nullptr;
+    const int P = routed ? g->seg_caps_pow2 : g->seg_sort_pow2;
+    const bool narrow = routed ? g->seg_routed_narrow : g->seg_narrow;
+    const er::Route srt{g->world, g->shard_stride, g->d_local_base};
     const size_t lds = sizeof(unsigned long long) * static_cast<size_t>(P);
 #define ER_SEG_SORT(E, H, NRW)                                                                                     \
   hipLaunchKernelGGL((er::emb_segment_sort_kernel<E, H, NRW>), dim3(g->n), dim3(P / E), lds, s, g->keys_in,        \
-                     g->d_ent_base, g->d_descs, P, g->keys_out, g->vals_out, g->head_flags, g->head_index, g->seg_count)
+                     g->d_ent_base, g->d_descs, P, srt, g->keys_out, g->vals_out, g->head_flags, g->head_index,     \
+                     g->seg_count)
 #define ER_SEG_SORT_E(E)                                                       \
-  if (g->seg_narrow) {                                                         \
+  if (narrow) {                                                                \
     if (with_heads) ER_SEG_SORT(E, true, true); else ER_SEG_SORT(E, false, true);   \
   } else {                                                                     \
     if (with_heads) ER_SEG_SORT(E, true, false); else ER_SEG_SORT(E, false, false); \
@@ -1875,6 +1991,17 @@ int er_emb_group_set_routing(er_emb_group* g, int32_t world, int64_t shard_strid
   if (!g->d_local_base) ER_CHECK_HIP(hipMalloc(&g->d_local_base, sizeof(int64_t) * g->n));
   ER_CHECK_HIP(hipMemcpy(g->d_local_base, local_base_host, sizeof(int64_t) * g->n, hipMemcpyHostToDevice));
   g->h_local_base.assign(local_base_host, local_base_host + g->n);
+  // segmented sort of routed keys: every lookup's shard range [local_base, local_base + ceil(rows / world)) must be
+  // its own and the ranges increasing with the lookup (one table per lookup), world <= 64 owners
+  g->seg_routed = g->seg_caps_pow2 > 0 && world <= 64;
+  g->seg_routed_narrow = g->seg_routed;
+  for (int i = 0; i < g->n && g->seg_routed; ++i) {
+    const int64_t srows = (g->h_descs[i].rows + world - 1) / world;
+    if (local_base_host[i] < 0 || local_base_host[i] + srows > shard_stride) g->seg_routed = false;
+    if (i + 1 < g->n && local_base_host[i] + srows > local_base_host[i + 1]) g->seg_routed = false;
+    if ((static_cast<uint64_t>(srows) * world + 2) * static_cast<uint64_t>(g->seg_caps_pow2) > (1ull << 32))
+      g->seg_routed_narrow = false;
+  }
   g->world = world;
   g->shard_stride = shard_stride;
   const int64_t span = static_cast<int64_t>(world) * shard_stride;
@@ -1925,7 +2052,7 @@ int er_emb_route(er_emb_group* g, uint32_t* unique_keys, int32_t* n_unique, int6
   hipStream_t s = er::as_stream(stream);
   const int64_t N = group_entries(g);
   ER_REQUIRE(N > 0, "er_emb_route: empty group");
-  bool adopted = false, fused_route = false;
+  bool adopted = false, fused_route = false, counts_done = false;
   if (g->leader)
     if (int rc = emb_group_adopt(g, s, &adopted)) return rc;
   if (adopted) {
@@ -1944,9 +2071,18 @@ int er_emb_route(er_emb_group* g, uint32_t* unique_keys, int32_t* n_unique, int6
     if (emb_group_segmented(g)) {
       // two launches: sort + in-lookup heads, then the cross-lookup offsets + key list + per-entry index
       if (int rc = emb_group_build_sort(g, s, true)) return rc;
-      dim3 grid(static_cast<unsigned>(er::ceil_div(g->seg_sort_pow2, er::kBlock)), static_cast<unsigned>(g->n));
-      hipLaunchKernelGGL(er::emb_route_seg_kernel, grid, dim3(er::kBlock), 0, s, g->keys_out, g->vals_out, g->head_flags,
-                         g->head_index, g->d_ent_base, g->seg_count, g->n, unique_keys, entry_unique_index, n_unique);
+      if (g->d_local_base) {
+        dim3 grid(static_cast<unsigned>(er::ceil_div(g->seg_caps_pow2, er::kBlock)), static_cast<unsigned>(g->n));
+        hipLaunchKernelGGL(er::emb_route_seg_routed_kernel, grid, dim3(er::kBlock), 0, s, g->keys_out, g->vals_out,
+                           g->head_flags, g->head_index, g->d_ent_base, g->seg_count, g->n, g->world,
+                           static_cast<uint32_t>(g->shard_stride), unique_keys, entry_unique_index, n_unique,
+                           owner_counts);
+        counts_done = true;
+      } else {
+        dim3 grid(static_cast<unsigned>(er::ceil_div(g->seg_sort_pow2, er::kBlock)), static_cast<unsigned>(g->n));
+        hipLaunchKernelGGL(er::emb_route_seg_kernel, grid, dim3(er::kBlock), 0, s, g->keys_out, g->vals_out, g->head_flags,
+                           g->head_index, g->d_ent_base, g->seg_count, g->n, unique_keys, entry_unique_index, n_unique);
+      }
       ER_LAUNCH_CHECK();
       g->heads_epoch = g->sort_epoch;
       fused_route = true;
@@ -1963,7 +2099,7 @@ int er_emb_route(er_emb_group* g, uint32_t* unique_keys, int32_t* n_unique, int6
                        entry_unique_index);
     ER_LAUNCH_CHECK();
   }
-  if (owner_counts) {
+  if (owner_counts && !counts_done) {
     const int64_t stride = g->d_local_base ? g->shard_stride : g->total_rows;
     hipLaunchKernelGGL(er::emb_owner_counts_kernel, dim3(1), dim3(64), 0, s, unique_keys, n_unique, g->world, stride,
                        owner_counts);
