@@ -1607,7 +1607,7 @@ static int emb_group_build(er_emb_group* g, hipStream_t s) {
 // true when the keys of g are, by construction, those of its leader: every lookup reads the same ids with the same
 // table geometry and routing (re-checked on the host at every call: er_emb_group_update may have changed either)
 static bool emb_group_same_keys(const er_emb_group* g, const er_emb_group* l) {
-  if (!l || g->n != l->n || g->n_active >= 0 || l->n_active >= 0) return false;
+  if (!l || g->n != l->n || g->n_active != l->n_active) return false;  // (owner groups: the same rows received)
   if (g->world != l->world || g->shard_stride != l->shard_stride || g->h_local_base != l->h_local_base) return false;
   if ((g->d_local_base == nullptr) != (l->d_local_base == nullptr)) return false;
   for (int i = 0; i < g->n; ++i) {
@@ -1625,7 +1625,6 @@ static int emb_group_adopt(er_emb_group* g, hipStream_t s, bool* adopted) {
   *adopted = false;
   er_emb_group* l = g->leader;
   if (!emb_group_same_keys(g, l)) return 0;
-  if (l->d_local_base) return 0;  // routed keys: the leader's head indices are in the requester's send order
   ER_REQUIRE(l->sort_epoch != g->adopted_epoch,
              "shared sort: the leader group has not been processed since this group last used its sort "
              "(call the leader first in every step)");
@@ -2063,6 +2062,9 @@ int er_emb_route(er_emb_group* g, uint32_t* unique_keys, int32_t* n_unique, int6
     ER_REQUIRE((unique_keys != nullptr) == (n_unique != nullptr) && (unique_keys || (!entry_unique_index && !owner_counts)),
                "er_emb_route: shared sort: pass unique_keys AND n_unique, or neither (then no other output)");
     if (unique_keys) {
+      // (routed per-lookup sort: the leader's head indices are in send order, not a running count)
+      ER_REQUIRE(!(l->d_local_base && emb_group_segmented(l)),
+                 "er_emb_route: shared sort of routed keys: the de-duplicated keys are the leader's outputs, pass none");
       hipLaunchKernelGGL(er::emb_count_unique_kernel, dim3(1), dim3(64), 0, s, l->head_flags, l->head_index, N, n_unique);
       ER_LAUNCH_CHECK();
     }

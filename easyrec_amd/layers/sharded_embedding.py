@@ -19,6 +19,7 @@ on rank 0 under id % world) are replicated and trained data-parallel: their de-d
 scattered into a dense buffer, all-reduced, and applied on every rank identically - the same math as
 sharding them (SURVEY.md 8e allows it).
 """
+import os
 from collections import OrderedDict
 
 import torch
@@ -34,6 +35,7 @@ class ShardedEmbeddingEngine(EmbeddingEngine):
     self.comm = comm
     self.rank, self.world = comm.rank, comm.world
     self.replicate_bytes = replicate_bytes
+    self.share_route = os.environ.get('EASYREC_AMD_SHARE_ROUTE', '1') != '0'  # A/B switch
     self.recv_slack = recv_slack
     self.shard = OrderedDict()  # dim -> dict of the sharded half of the dim group
     self.rep = OrderedDict()    # dim -> dict of the replicated half
@@ -130,17 +132,40 @@ class ShardedEmbeddingEngine(EmbeddingEngine):
     caps = [(lk['max_nnz'] if lk['offsets'] is not None else lk['n_rows']) for lk in lookups]
     n_ent = sum(caps)
     m_cap = max(int(self.recv_slack * n_ent), 1024)
+
+    def ptr(t):
+      return None if t is None else t.data_ptr()
+
+    # A dim group whose sharded lookups read the same ids against tables of the same geometry as an earlier group's
+    # (DeepFM's wide dim-1 and deep dim-16 tables of one feature set) has the SAME routed keys: it follows that
+    # group's route - one sort, one de-duplication, one key all-to-all and one owner-side sort serve both; only the
+    # rows and the row gradients (which differ) are exchanged per group.
+    sh['sig'] = (sh['stride'], tuple((ptr(lk['ids']), ptr(lk['offsets']), ptr(lk['weights']), lk['t']['rows'], lk['base'],
+                                      lk['n_rows'], lk['max_nnz'], lk['combiner']) for lk in lookups))
+    lead_dim = None
+    if self.share_route:
+      for d0, s0 in self.shard.items():
+        if d0 != dim and s0.get('sig') == sh['sig'] and s0.get('leader') is None and 'req' in s0:
+          lead_dim = d0
+          break
+    sh['leader'] = lead_dim
+    lead = self.shard[lead_dim] if lead_dim is not None else None
     sh.update(
         n_entries=n_ent, m_cap=m_cap,
-        ukeys=torch.zeros(n_ent, dtype=torch.int32, device=dev),
-        n_unique=torch.zeros(1, dtype=torch.int32, device=dev),
-        uidx=torch.full((n_ent,), -1, dtype=torch.int64, device=dev),
         recv_rows=torch.zeros(n_ent, dim, dtype=torch.float32, device=dev),
         ugrads=torch.zeros(n_ent, dim, dtype=torch.float32, device=dev),
-        recv_keys=torch.zeros(m_cap, dtype=torch.int32, device=dev),
-        recv_ids=torch.full((m_cap,), -1, dtype=torch.int64, device=dev),
         rows_out=torch.zeros(m_cap, dim, dtype=torch.float32, device=dev),
         recv_grads=torch.zeros(m_cap, dim, dtype=torch.float32, device=dev))
+    if lead is not None:
+      for k in ('ukeys', 'n_unique', 'uidx', 'recv_keys', 'recv_ids'):
+        sh[k] = lead[k]
+    else:
+      sh.update(
+          ukeys=torch.zeros(n_ent, dtype=torch.int32, device=dev),
+          n_unique=torch.zeros(1, dtype=torch.int32, device=dev),
+          uidx=torch.full((n_ent,), -1, dtype=torch.int64, device=dev),
+          recv_keys=torch.zeros(m_cap, dtype=torch.int32, device=dev),
+          recv_ids=torch.full((m_cap,), -1, dtype=torch.int64, device=dev))
     req_specs, off = [], 0
     for lk, cap in zip(lookups, caps):
       g = lk['group']
@@ -160,12 +185,16 @@ class ShardedEmbeddingEngine(EmbeddingEngine):
     sh['req'] = be.emb_group_create(req_specs, dim, span, sh['recv_rows'], None, None, None)
     assert sh['req']['num_entries'] == n_ent
     be.emb_group_set_routing(sh['req'], W, sh['stride'], [lk['base'] for lk in lookups])
+    if lead is not None:
+      assert be.emb_group_share_sort(sh['req'], lead['req']), 'dim %d: cannot follow the route of dim %d' % (dim, lead_dim)
     st = sh['st']
     owner_spec = kernels.LookupSpec(
         table=st['var'], ids=sh['recv_ids'], offsets=None, weights=None, out=sh['recv_grads'], out_col=0,
         rows=st['total_rows'], key_base=0, dim=dim, combiner=kernels.COMBINER_SUM, n_rows=m_cap, max_nnz=m_cap,
         name='owner_dim%d' % dim)
     sh['owner'] = be.emb_group_create([owner_spec], dim, st['total_rows'], st['var'], st['m'], st['v'], st['bitmap'])
+    if lead is not None:  # the same received keys: the owner-side sort is shared too
+      assert be.emb_group_share_sort(sh['owner'], lead['owner'])
     sh['lazy'] = None
     if self.lazy_decay and opt_kind == kernels.OPT_ADAM:
       # owner side of TF-exact Adam without the sweep: the received keys are sorted / de-duplicated once
@@ -210,32 +239,45 @@ class ShardedEmbeddingEngine(EmbeddingEngine):
   def route(self):
     be = kernels.hip()
     for gi, (dim, sh) in enumerate(self.shard.items()):
-      be.emb_route(sh['req'], sh['ukeys'], sh['n_unique'], sh['uidx'], self.counts_dev[gi])
+      if sh['leader'] is None:
+        be.emb_route(sh['req'], sh['ukeys'], sh['n_unique'], sh['uidx'], self.counts_dev[gi])
+      else:  # adopts the leader's sort and run heads (no launch: its entries were built with the leader's)
+        be.emb_route(sh['req'], None, None, None, None)
 
   def exchange(self):
     be, comm = kernels.hip(), self.comm
     if not self.shard:
       return
     send, recv = comm.exchange_counts(self.counts_dev)  # host sync: split sizes
+    # keys: one all-to-all per route (a follower group receives what its leader receives)
     for gi, (dim, sh) in enumerate(self.shard.items()):
-      sc, rc = send[gi], recv[gi]
-      m = int(sum(rc))
-      if m > sh['m_cap']:
-        raise RuntimeError('embedding-parallel: rank %d receives %d keys for dim %d, capacity %d; raise recv_slack' %
-                           (self.rank, m, dim, sh['m_cap']))
-      sh['send_counts'], sh['recv_counts'], sh['m'] = sc, rc, m
-      comm.all_to_all(sh['ukeys'], sc, sh['recv_keys'], rc)
-      st = sh['st']
-      key_sub = self.rank * sh['stride']
-      if m:
-        torch.sub(sh['recv_keys'][:m], key_sub, out=sh['recv_ids'][:m])
-      be.emb_group_set_active(sh['owner'], m)
+      if sh['leader'] is not None:
+        lead = self.shard[sh['leader']]
+        sh['send_counts'], sh['recv_counts'], sh['m'] = lead['send_counts'], lead['recv_counts'], lead['m']
+      else:
+        sc, rc = send[gi], recv[gi]
+        m = int(sum(rc))
+        if m > sh['m_cap']:
+          raise RuntimeError('embedding-parallel: rank %d receives %d keys for dim %d, capacity %d; raise recv_slack' %
+                             (self.rank, m, dim, sh['m_cap']))
+        sh['send_counts'], sh['recv_counts'], sh['m'] = sc, rc, m
+        comm.all_to_all(sh['ukeys'], sc, sh['recv_keys'], rc)
+        if m:
+          torch.sub(sh['recv_keys'][:m], self.rank * sh['stride'], out=sh['recv_ids'][:m])
+      be.emb_group_set_active(sh['owner'], sh['m'])
+    # rows: per group (the tables differ)
+    for dim, sh in self.shard.items():
+      m, st = sh['m'], sh['st']
       lz = sh['lazy']
       if lz is not None and m:
-        be.emb_route(sh['owner'], lz['ukeys'], lz['n_unique'], None, None)
+        if sh['leader'] is None:
+          be.emb_route(sh['owner'], lz['ukeys'], lz['n_unique'], None, None)
+        else:
+          be.emb_route(sh['owner'], None, None, None, None)
+          lz = self.shard[sh['leader']]['lazy']
         be.emb_catch_up(sh['owner'], lz['ukeys'], lz['n_unique'], self._clock[2])
-      be.gather_rows(st['var'], sh['recv_keys'], m, key_sub, sh['rows_out'])
-      comm.all_to_all(sh['rows_out'], rc, sh['recv_rows'], sc)
+      be.gather_rows(st['var'], sh['recv_keys'], m, self.rank * sh['stride'], sh['rows_out'])
+      comm.all_to_all(sh['rows_out'], sh['recv_counts'], sh['recv_rows'], sh['send_counts'])
 
   def lookup(self):
     for g in self.groups.values():
@@ -272,7 +314,9 @@ class ShardedEmbeddingEngine(EmbeddingEngine):
       comm.all_reduce_sum(self.rep_flat)
     for dim, sh in self.shard.items():
       comm.all_to_all(sh['ugrads'], sh['send_counts'], sh['recv_grads'], sh['recv_counts'])
-      be.emb_bwd_update(sh['owner'], opt_kind, hyper)
+    owners = [sh['owner'] for sh in self.shard.values()]
+    for i in range(0, len(owners), 4):  # the groups' reduce + optimizer kernels side by side in one launch
+      be.emb_bwd_update_multi(owners[i:i + 4], opt_kind, hyper)
 
   def apply_replicated(self, opt_kind, hyper):
     be = kernels.hip()
