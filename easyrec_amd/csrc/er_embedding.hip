@@ -521,11 +521,13 @@ emb_flush_mark_kernel(int32_t* __restrict__ last_step, int64_t total_rows, const
 //   sum = tile_last[s] + tile_last[whole tiles] + tile_first[end tile], then the same apply / emit.
 // ------------------------------------------------------------------------------------------------
 struct ReduceOut {
-  int mode;                      // 0: apply optimizer, 1: emit (out_grads[u], u = index of the run)
+  int mode;                      // 0: apply optimizer, 1: emit (out_grads[u], u = index of the run),
+                                 // 2: emit into a dense row-indexed buffer (out_grads[key * ld + 0 .. dim), 1 at + dim)
   const uint32_t* flags;         // mode 1: head flags / exclusive scan of them over sorted positions
   const uint32_t* head_index;
   uint32_t* out_keys;
   float* out_grads;
+  int ld;                        // mode 2: floats per row of out_grads (>= dim + 1)
 };
 
 template <int V>
@@ -544,6 +546,11 @@ __device__ __forceinline__ void finish_run(const RowUpdate& tab, int opt_kind, c
       if (tab.last_step) tab.last_step[key] = static_cast<int32_t>(*tab.step_counter - 1);
       else atomicOr(&tab.bitmap[key >> 5], 1u << (key & 31));
     }
+  } else if (ro.mode == 2) {
+    float* d = ro.out_grads + static_cast<int64_t>(key) * ro.ld;
+#pragma unroll
+    for (int i = 0; i < V; ++i) d[c + i] = g[i];
+    if (sub == 0) d[dim] = 1.f;  // "this row has a gradient" (summed over ranks by the all-reduce that follows)
   } else {
     const uint32_t u = ro.head_index[p] + ro.flags[p] - 1u;
     if (sub == 0) ro.out_keys[u] = key;
@@ -1270,6 +1277,62 @@ adam_decay_sweep_scalar_kernel(float* __restrict__ var, float* __restrict__ m, f
   }
 }
 
+// Replicated (small, data-parallel) tables of the embedding-parallel path: after the all-reduce of the dense
+// gradient buffer every rank applies the same update.  Row r of `dense` holds [grad (dim floats), count]; count > 0
+// means some rank had a gradient for the row.  Touched rows take the optimizer step on grad * grad_scale; under
+// TF-exact Adam the untouched rows take the decay-only step (what er_adam_decay_sweep does) - one pass over the
+// table instead of build + sort + reduce + sweep + bitmap clear.  Up to kMaxMulti tables side by side.
+struct DenseApplyArgs {
+  float *var, *m, *v;
+  const float* dense;
+  int ld, dim, V, G;
+  int64_t rows;
+};
+struct DenseApplyMulti {
+  int n;
+  int start[kMaxMulti + 1];
+  int opt_kind;
+  const er_opt_hyper* hyper;
+  DenseApplyArgs a[kMaxMulti];
+};
+
+template <int V>
+__device__ __forceinline__ void dense_apply_body(int bid, const DenseApplyArgs& a, int opt_kind,
+                                                 const er_opt_hyper* __restrict__ hyper) {
+  const int64_t t = static_cast<int64_t>(bid) * kBlock + threadIdx.x;
+  const int64_t row = t / a.G;
+  const int c = static_cast<int>(t % a.G) * V;
+  if (row >= a.rows || c >= a.dim) return;
+  const er_opt_hyper h = *hyper;
+  const float* d = a.dense + row * a.ld;
+  const int64_t off = row * a.dim + c;
+  if (d[a.dim] > 0.f) {
+    float g[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) g[i] = d[c + i] * h.grad_scale;
+    update_row<V>(RowUpdate{a.var, a.m, a.v, nullptr, nullptr, nullptr}, opt_kind, h, off, g);
+  } else if (opt_kind == ER_OPT_ADAM) {
+    float var[V], m[V], v[V];
+    ld_vec<V>(var, a.var + off);
+    ld_vec<V>(m, a.m + off);
+    ld_vec<V>(v, a.v + off);
+#pragma unroll
+    for (int i = 0; i < V; ++i) decay_elem(var[i], m[i], v[i], h);
+    st_vec<V>(a.var + off, var);
+    st_vec<V>(a.m + off, m);
+    st_vec<V>(a.v + off, v);
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+emb_dense_apply_kernel(DenseApplyMulti ma) {
+  int i = 0;
+  while (i + 1 < ma.n && static_cast<int>(blockIdx.x) >= ma.start[i + 1]) ++i;
+  const DenseApplyArgs& a = ma.a[i];
+  if (a.V == 4) dense_apply_body<4>(blockIdx.x - ma.start[i], a, ma.opt_kind, ma.hyper);
+  else dense_apply_body<1>(blockIdx.x - ma.start[i], a, ma.opt_kind, ma.hyper);
+}
+
 // Word fill used instead of hipMemsetAsync: inside a captured hipGraph a memset NODE was observed to lose its
 // ordering against the neighbouring kernel nodes on replay (the touched-row bitmap stayed dirty into the next
 // replay: eager and graph runs of TF-exact Adam diverged, tools/dbg_determinism.py); a kernel node keeps it.
@@ -1699,7 +1762,7 @@ static int emb_group_run(er_emb_group* g, int opt_kind, const er_opt_hyper* hype
   const int n_tiles = static_cast<int>(er::ceil_div(N, T));
   er::RowUpdate tab{g->var, g->m, g->v, g->bitmap, g->last_step, g->step_counter};
   const er_emb_group* src = g->src;  // whose sort this group reduces over (itself unless er_emb_group_share_sort)
-  er::ReduceOut ro{mode, src->head_flags, src->head_index, out_keys, out_grads};
+  er::ReduceOut ro{mode, src->head_flags, src->head_index, out_keys, out_grads, 0};
   const size_t lds = sizeof(float) * static_cast<size_t>(T) * g->dim + sizeof(uint32_t) * (T + 2);
   const int fix_blocks = static_cast<int>(er::ceil_div(static_cast<int64_t>(n_tiles) * g->G, er::kBlock));
   if (g->V == 4) {
@@ -1794,12 +1857,10 @@ int er_emb_bwd_update(er_emb_group* g, int opt_kind, const er_opt_hyper* hyper, 
   return 0;
 }
 
-int er_emb_bwd_update_multi(er_emb_group* const* groups, int n, int opt_kind, const er_opt_hyper* hyper,
-                            er_stream_t stream) {
-  ER_REQUIRE(groups && hyper && n >= 1 && n <= er::kMaxMulti, "er_emb_bwd_update_multi: bad arguments (1 <= n <= %d)",
-             er::kMaxMulti);
-  if (n == 1) return er_emb_bwd_update(groups[0], opt_kind, hyper, stream);
-  ER_REQUIRE(opt_kind >= ER_OPT_SGD && opt_kind <= ER_OPT_ADAGRAD, "er_emb_bwd_update_multi: unknown optimizer %d", opt_kind);
+// The reduce kernels of up to kMaxMulti groups side by side in one launch.  dense == nullptr: apply the optimizer
+// (er_emb_bwd_update_multi); else: the row sums go to dense[i][key * ld[i] ...] (er_emb_bwd_reduce_dense).
+static int emb_groups_run_multi(er_emb_group* const* groups, int n, int opt_kind, const er_opt_hyper* hyper,
+                                float* const* dense, const int32_t* ld, er_stream_t stream) {
   hipStream_t s = er::as_stream(stream);
   er::RunMulti ma;
   ma.n = 0;
@@ -1812,12 +1873,16 @@ int er_emb_bwd_update_multi(er_emb_group* const* groups, int n, int opt_kind, co
   for (int i = 0; i < n; ++i) {
     er_emb_group* g = groups[i];
     ER_REQUIRE(g, "er_emb_bwd_update_multi: null group %d", i);
-    if (opt_kind == ER_OPT_ADAM || opt_kind == ER_OPT_LAZY_ADAM)
-      ER_REQUIRE(g->m && g->v, "er_emb_bwd_update_multi: Adam needs m and v (group %d)", i);
-    if (opt_kind == ER_OPT_ADAGRAD) ER_REQUIRE(g->v, "er_emb_bwd_update_multi: Adagrad needs the accumulator in v");
-    const bool lazy_decay = (opt_kind == ER_OPT_ADAM) && g->last_step;
-    if (opt_kind == ER_OPT_ADAM && !lazy_decay)
-      ER_REQUIRE(g->bitmap, "er_emb_bwd_update_multi: ER_OPT_ADAM needs touched_bitmap or lazy decay (group %d)", i);
+    if (!dense) {
+      if (opt_kind == ER_OPT_ADAM || opt_kind == ER_OPT_LAZY_ADAM)
+        ER_REQUIRE(g->m && g->v, "er_emb_bwd_update_multi: Adam needs m and v (group %d)", i);
+      if (opt_kind == ER_OPT_ADAGRAD) ER_REQUIRE(g->v, "er_emb_bwd_update_multi: Adagrad needs the accumulator in v");
+      const bool lazy_decay = (opt_kind == ER_OPT_ADAM) && g->last_step;
+      if (opt_kind == ER_OPT_ADAM && !lazy_decay)
+        ER_REQUIRE(g->bitmap, "er_emb_bwd_update_multi: ER_OPT_ADAM needs touched_bitmap or lazy decay (group %d)", i);
+    } else {
+      ER_REQUIRE(dense[i] && ld[i] > g->dim, "er_emb_bwd_reduce_dense: group %d: null buffer or ld <= dim", i);
+    }
     if (!g->sorted_valid) {  // as er_emb_bwd_update: reuse this step's er_emb_route, adopt the leader's sort, or sort
       bool adopted = false;
       if (g->leader)
@@ -1834,7 +1899,8 @@ int er_emb_bwd_update_multi(er_emb_group* const* groups, int n, int opt_kind, co
     a.n = N; a.dim = g->dim; a.G = g->G; a.V = g->V; a.T = g->tile_entries;
     a.n_tiles = static_cast<int>(er::ceil_div(N, a.T));
     a.tab = er::RowUpdate{g->var, g->m, g->v, g->bitmap, g->last_step, g->step_counter};
-    a.ro = er::ReduceOut{0, src->head_flags, src->head_index, nullptr, nullptr};
+    a.ro = dense ? er::ReduceOut{2, nullptr, nullptr, nullptr, dense[i], ld[i]}
+                 : er::ReduceOut{0, src->head_flags, src->head_index, nullptr, nullptr, 0};
     a.tile_first = g->tile_first; a.tile_last = g->tile_last;
     ma.start[ma.n + 1] = ma.start[ma.n] + a.n_tiles;
     const int fb = a.n_tiles > 1 ? static_cast<int>(er::ceil_div(static_cast<int64_t>(a.n_tiles) * g->G, er::kBlock)) : 0;
@@ -1853,7 +1919,7 @@ int er_emb_bwd_update_multi(er_emb_group* const* groups, int n, int opt_kind, co
       ER_LAUNCH_CHECK();
     }
   }
-  for (int i = 0; i < n; ++i) {  // TF-exact Adam with the streaming sweep: per group, as er_emb_bwd_update
+  for (int i = 0; i < n && !dense; ++i) {  // TF-exact Adam with the streaming sweep: per group, as er_emb_bwd_update
     er_emb_group* g = groups[i];
     if (opt_kind == ER_OPT_ADAM && !g->last_step) {
       if (int rc = er_adam_decay_sweep(g->var, g->m, g->v, g->bitmap, g->total_rows, g->dim, hyper, stream)) return rc;
@@ -1861,6 +1927,22 @@ int er_emb_bwd_update_multi(er_emb_group* const* groups, int n, int opt_kind, co
     }
   }
   return 0;
+}
+
+int er_emb_bwd_update_multi(er_emb_group* const* groups, int n, int opt_kind, const er_opt_hyper* hyper,
+                            er_stream_t stream) {
+  ER_REQUIRE(groups && hyper && n >= 1 && n <= er::kMaxMulti, "er_emb_bwd_update_multi: bad arguments (1 <= n <= %d)",
+             er::kMaxMulti);
+  if (n == 1) return er_emb_bwd_update(groups[0], opt_kind, hyper, stream);
+  ER_REQUIRE(opt_kind >= ER_OPT_SGD && opt_kind <= ER_OPT_ADAGRAD, "er_emb_bwd_update_multi: unknown optimizer %d", opt_kind);
+  return emb_groups_run_multi(groups, n, opt_kind, hyper, nullptr, nullptr, stream);
+}
+
+int er_emb_bwd_reduce_dense(er_emb_group* const* groups, float* const* dense, const int32_t* ld, int n,
+                            er_stream_t stream) {
+  ER_REQUIRE(groups && dense && ld && n >= 1 && n <= er::kMaxMulti, "er_emb_bwd_reduce_dense: bad arguments (1 <= n <= %d)",
+             er::kMaxMulti);
+  return emb_groups_run_multi(groups, n, ER_OPT_SGD, nullptr, dense, ld, stream);
 }
 
 int er_emb_group_enable_lazy_decay(er_emb_group* g, int32_t* last_step, const float* lr_t_history,
@@ -2133,6 +2215,35 @@ int er_gather_rows(const float* table, int64_t table_rows, int32_t dim, const ui
     hipLaunchKernelGGL(er::gather_rows_kernel<1>, dim3(blocks), dim3(er::kBlock), 0, er::as_stream(stream), table, keys, n,
                        dim, G, key_sub, table_rows, out);
   }
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
+int er_emb_dense_apply(const er_dense_apply_desc* descs, int n, int opt_kind, const er_opt_hyper* hyper,
+                       er_stream_t stream) {
+  ER_REQUIRE(descs && hyper && n >= 1 && n <= er::kMaxMulti, "er_emb_dense_apply: bad arguments (1 <= n <= %d)",
+             er::kMaxMulti);
+  ER_REQUIRE(opt_kind >= ER_OPT_SGD && opt_kind <= ER_OPT_ADAGRAD, "er_emb_dense_apply: unknown optimizer %d", opt_kind);
+  er::DenseApplyMulti ma;
+  ma.n = 0;
+  ma.start[0] = 0;
+  ma.opt_kind = opt_kind;
+  ma.hyper = hyper;
+  for (int i = 0; i < n; ++i) {
+    const er_dense_apply_desc& d = descs[i];
+    ER_REQUIRE(d.var && d.dense && d.dim > 0 && d.ld > d.dim && d.rows >= 0, "er_emb_dense_apply: table %d: bad arguments", i);
+    if (opt_kind == ER_OPT_ADAM || opt_kind == ER_OPT_LAZY_ADAM)
+      ER_REQUIRE(d.m && d.v, "er_emb_dense_apply: Adam needs m and v (table %d)", i);
+    if (opt_kind == ER_OPT_ADAGRAD) ER_REQUIRE(d.v, "er_emb_dense_apply: Adagrad needs the accumulator in v (table %d)", i);
+    if (d.rows == 0) continue;
+    er::DenseApplyArgs& a = ma.a[ma.n];
+    a.var = d.var; a.m = d.m; a.v = d.v; a.dense = d.dense; a.ld = d.ld; a.dim = d.dim; a.rows = d.rows;
+    er::lane_geom(d.dim, a.V, a.G);
+    ma.start[ma.n + 1] = ma.start[ma.n] + static_cast<int>(er::ceil_div(d.rows * a.G, er::kBlock));
+    ++ma.n;
+  }
+  if (ma.n == 0) return 0;
+  hipLaunchKernelGGL(er::emb_dense_apply_kernel, dim3(ma.start[ma.n]), dim3(er::kBlock), 0, er::as_stream(stream), ma);
   ER_LAUNCH_CHECK();
   return 0;
 }

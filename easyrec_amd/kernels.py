@@ -114,6 +114,11 @@ class GemmProblem(ctypes.Structure):  # = er_gemm_problem
               ('ldc', ctypes.c_int32), ('bias', ctypes.c_void_p), ('accumulate', ctypes.c_int32)]
 
 
+class DenseApplyDesc(ctypes.Structure):  # = er_dense_apply_desc
+  _fields_ = [('var', ctypes.c_void_p), ('m', ctypes.c_void_p), ('v', ctypes.c_void_p), ('dense', ctypes.c_void_p),
+              ('ld', ctypes.c_int32), ('dim', ctypes.c_int32), ('rows', ctypes.c_int64)]
+
+
 def same_lookup_keys(group, leader):
   """Do two table groups see the same keys every step (er_emb_group_share_sort's condition)?"""
   if group is leader or leader.get('sort_leader') is not None:
@@ -503,6 +508,27 @@ class HipBackend(object):
     self._ck(self.lib.er_scatter_unique(_p(keys), _p(grads), _p(n_unique), ctypes.c_int64(int(capacity)),
                                         ctypes.c_int32(dim), _p(dense), ctypes.c_int32(dense.stride(0)), _stream()),
              'er_scatter_unique')
+
+  def emb_bwd_reduce_dense(self, groups, dense):
+    """Per-row gradient sums of the groups straight into their dense [rows, dim + 1] buffers (count in the last
+    column); one launch for all groups."""
+    n = len(groups)
+    for d in dense:
+      assert d.dim() == 2 and d.stride(1) == 1 and d.dtype == torch.float32
+    gh = (ctypes.c_void_p * n)(*[g['handle'] for g in groups])
+    dp = (ctypes.c_void_p * n)(*[d.data_ptr() for d in dense])
+    ld = (ctypes.c_int32 * n)(*[d.stride(0) for d in dense])
+    self._ck(self.lib.er_emb_bwd_reduce_dense(gh, dp, ld, n, _stream()), 'er_emb_bwd_reduce_dense')
+
+  def emb_dense_apply(self, tables, opt_kind, hyper):
+    """tables: [(var, m, v, dense)] - one pass over each replicated table after the all-reduce of `dense`."""
+    n = len(tables)
+    descs = (DenseApplyDesc * n)()
+    for i, (var, m, v, dense) in enumerate(tables):
+      assert var.is_contiguous() and dense.stride(1) == 1 and dense.shape[0] == var.shape[0]
+      descs[i] = DenseApplyDesc(var.data_ptr(), None if m is None else m.data_ptr(), None if v is None else v.data_ptr(),
+                                dense.data_ptr(), dense.stride(0), var.shape[1], var.shape[0])
+    self._ck(self.lib.er_emb_dense_apply(descs, n, ctypes.c_int(opt_kind), _p(hyper), _stream()), 'er_emb_dense_apply')
 
   def emb_mark_touched(self, group):
     self._ck(self.lib.er_emb_mark_touched(group['handle'], _stream()), 'er_emb_mark_touched')

@@ -120,7 +120,6 @@ class ShardedEmbeddingEngine(EmbeddingEngine):
         r = self.rep[dim]
         r['dense'] = self.rep_flat[off:off + n].view(r['st']['total_rows'], dim + 1)
         off += n
-        self._build_rep_apply(dim, opt_kind)
     self.counts_dev = torch.zeros(max(len(self.shard), 1), W, dtype=torch.int32, device=dev)
     self.lazy_decay = self.lazy_decay and opt_kind == kernels.OPT_ADAM
     self.finalized = True
@@ -218,19 +217,9 @@ class ShardedEmbeddingEngine(EmbeddingEngine):
       g['specs'].append(spec)
       specs.append(spec.with_out(g['dout']))
     r['group'] = be.emb_group_create(specs, dim, st['total_rows'], st['var'], None, None, None)
-
-  def _build_rep_apply(self, dim, opt_kind):
-    be = kernels.hip()
-    r = self.rep[dim]
-    st = r['st']
-    n = st['total_rows']
-    r['ids'] = torch.full((n,), -1, dtype=torch.int64, device=self.device)
-    r['arange'] = torch.arange(n, dtype=torch.int64, device=self.device)
-    r['minus1'] = torch.full((n,), -1, dtype=torch.int64, device=self.device)
-    spec = kernels.LookupSpec(
-        table=st['var'], ids=r['ids'], offsets=None, weights=None, out=r['dense'], out_col=0, rows=n, key_base=0,
-        dim=dim, combiner=kernels.COMBINER_SUM, n_rows=n, max_nnz=n, name='rep_apply_dim%d' % dim)
-    r['apply'] = be.emb_group_create([spec], dim, n, st['var'], st['m'], st['v'], st['bitmap'])
+    for d0, r0 in self.rep.items():  # the same ids against tables of the same geometry: one sort per step for both
+      if d0 != dim and 'group' in r0 and be.emb_group_share_sort(r['group'], r0['group']):
+        break
 
   # -- per-step execution.  Three forward phases and three backward phases so that the static ones can be
   #    replayed as hipGraphs around the data-dependent exchanges (model/embedding_parallel.py):
@@ -298,13 +287,12 @@ class ShardedEmbeddingEngine(EmbeddingEngine):
     for g in self.groups.values():
       if not g['got_grad']:
         g['dout'].zero_()
-    for dim, r in self.rep.items():
-      r['reduced'] = be.emb_bwd_reduce(r['group'], out=r.get('reduced'))
     if self.rep:
+      # replicated tables: the per-row gradient sums go straight into the dense buffer that is all-reduced
       self.rep_flat.zero_()
-      for dim, r in self.rep.items():
-        keys, grads, n_unique = r['reduced']
-        be.scatter_unique(keys, grads, n_unique, min(keys.numel(), r['st']['total_rows']), dim, r['dense'])
+      reps = list(self.rep.values())
+      for i in range(0, len(reps), 4):
+        be.emb_bwd_reduce_dense([r['group'] for r in reps[i:i + 4]], [r['dense'] for r in reps[i:i + 4]])
     for dim, sh in self.shard.items():
       be.emb_bwd_reduce_routed(sh['req'], sh['ugrads'])
 
@@ -320,9 +308,9 @@ class ShardedEmbeddingEngine(EmbeddingEngine):
 
   def apply_replicated(self, opt_kind, hyper):
     be = kernels.hip()
-    for dim, r in self.rep.items():
-      torch.where(r['dense'][:, dim] > 0, r['arange'], r['minus1'], out=r['ids'])
-      be.emb_bwd_update(r['apply'], opt_kind, hyper)
+    tables = [(r['st']['var'], r['st']['m'], r['st']['v'], r['dense']) for r in self.rep.values()]
+    for i in range(0, len(tables), 4):  # one pass over every replicated table: optimizer step or (TF-exact Adam) decay
+      be.emb_dense_apply(tables[i:i + 4], opt_kind, hyper)
 
   def backward_update(self, opt_kind, hyper):
     self.reduce_local()

@@ -443,10 +443,26 @@ int er_gemm_bf16(int layout, int32_t M, int32_t N, int32_t K, const float* A, in
  *   er_emb_group_set_active: a group of ONE dense-mode lookup (ids = received local rows, out =
  *     received gradients) processes only its first n_rows entries in er_emb_bwd_update /
  *     er_emb_mark_touched (the received count changes every step; capacity = the lookup's n_rows).
- * Replicated (small) tables: er_scatter_unique writes the n_unique (device scalar) de-duplicated
- *   gradient rows of er_emb_bwd_reduce into a dense zero-initialised [rows, dense_stride >= dim+1]
- *   buffer (column `dim` = 1 marks a touched row) that is all-reduced like dense parameters.
+ * Replicated (small) tables, trained data-parallel (their gradient is summed over the ranks like a dense
+ *   parameter's - the same math as sharding them):
+ *   er_emb_bwd_reduce_dense: the per-row gradient sums of up to 4 groups (one launch; followers of a shared
+ *     sort after their leader) go straight into zero-initialised dense buffers dense[i][key * ld[i] + 0..dim),
+ *     with dense[i][key * ld[i] + dim] = 1 marking a touched row (ld >= dim + 1) - no run heads or unique list.
+ *   er_emb_dense_apply: after the all-reduce of that buffer, one pass over each table: rows with a count > 0
+ *     take the optimizer step on grad * grad_scale; under ER_OPT_ADAM (TF-exact) the other rows take the
+ *     decay-only step of er_adam_decay_sweep.  Same arithmetic as er_emb_bwd_update over ids = touched rows.
+ *   er_scatter_unique (the two-step form): writes the n_unique (device scalar) de-duplicated gradient rows of
+ *     er_emb_bwd_reduce into the same kind of buffer.
  * -------------------------------------------------------------------------------------------- */
+typedef struct er_dense_apply_desc {
+  float* var;         /* [rows, dim] */
+  float* m;           /* Adam first moment, or NULL */
+  float* v;           /* Adam second moment / Adagrad accumulator, or NULL */
+  const float* dense; /* [rows, ld]: gradient (dim floats), count */
+  int32_t ld;
+  int32_t dim;
+  int64_t rows;
+} er_dense_apply_desc;
 int er_emb_group_set_routing(er_emb_group* group, int32_t world, int64_t shard_stride,
                              const int64_t* local_base_host);
 int er_emb_group_set_active(er_emb_group* group, int64_t n_rows);
@@ -479,6 +495,10 @@ int er_gather_rows(const float* table, int64_t table_rows, int32_t dim, const ui
 int er_scatter_unique(const uint32_t* keys, const float* grads, const int32_t* n_unique,
                       int64_t capacity, int32_t dim, float* dense, int32_t dense_stride,
                       er_stream_t stream);
+int er_emb_bwd_reduce_dense(er_emb_group* const* groups_host, float* const* dense_host, const int32_t* ld_host,
+                            int n, er_stream_t stream);
+int er_emb_dense_apply(const er_dense_apply_desc* descs_host, int n, int opt_kind, const er_opt_hyper* hyper,
+                       er_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
  * Dense-variable optimizer: one launch over the flat parameter buffer.  Replaces ApplyAdam /

@@ -443,6 +443,24 @@ class RefBackend(object):
     dense[rows, :dim] = grads[:n]
     dense[rows, dim] = 1.0
 
+  def emb_bwd_reduce_dense(self, groups, dense):
+    for g, d in zip(groups, dense):  # the two-step form: de-duplicated rows, then the scatter
+      keys, grads, n_unique = self.emb_bwd_reduce(g)
+      self.scatter_unique(keys, grads, n_unique, keys.numel(), g['dim'], d)
+
+  def emb_dense_apply(self, tables, opt_kind, hyper):
+    """Restated through the sparse path: the rows with a count are the ids of one lookup whose upstream gradient is
+    the dense buffer; TF-exact Adam then sweeps the others."""
+    from easyrec_amd import kernels as K
+    for var, m, v, dense in tables:
+      n, dim = var.shape
+      ids = torch.where(dense[:, dim] > 0, torch.arange(n, dtype=torch.int64), torch.full((n,), -1, dtype=torch.int64))
+      bitmap = torch.zeros((n + 31) // 32, dtype=torch.int32) if opt_kind == K.OPT_ADAM else None
+      spec = K.LookupSpec(table=var, ids=ids, offsets=None, weights=None, out=dense, out_col=0, rows=n, key_base=0,
+                          dim=dim, combiner=K.COMBINER_SUM, n_rows=n, max_nnz=n, name='dense_apply')
+      grp = self.emb_group_create([spec], dim, n, var, m, v, bitmap)
+      self.emb_bwd_update(grp, opt_kind, hyper)
+
   def emb_mark_touched(self, group):
     pass
 

@@ -901,3 +901,59 @@ def test_auc_update_counts_bit_exact(hip, ref, n, nt):
   np.add.at(exp, ((y.numpy() != 0).astype(np.int64), bucket), 1)
   assert np.array_equal(cd.cpu().numpy(), exp)
   assert 0.0 <= auc_from_counts(exp) <= 1.0
+
+
+@pytest.mark.parametrize('opt', [kernels.OPT_SGD, kernels.OPT_ADAM, kernels.OPT_LAZY_ADAM, kernels.OPT_ADAGRAD])
+def test_replicated_tables_dense_reduce_and_apply(hip, ref, opt):
+  """er_emb_bwd_reduce_dense (two groups in one launch, the second sharing the first's sort) must write what
+  er_emb_bwd_reduce + er_scatter_unique write, bit for bit; er_emb_dense_apply must equal er_emb_bwd_update over the
+  rows with a count (+ the dense-decay sweep of TF-exact Adam), which is how the oracle restates it."""
+  rng = np.random.default_rng(11 + opt)
+  B, n_feat = 700, 5
+  rows = [int(rng.integers(3, 90)) for _ in range(n_feat)]
+  rows[2] = 1
+  ids = [rng.integers(-1, r, size=B).astype(np.int64) for r in rows]
+  ids[0][:300] = 1  # a hot row: runs across tiles
+  base = np.concatenate([[0], np.cumsum(rows)]).astype(int)
+  total = int(base[-1])
+  groups_d, groups_c, dense_d, dense_c, tabs = [], [], [], [], []
+  ids_on = {dev: [torch.from_numpy(i).to(dev) for i in ids] for dev in (DEV, 'cpu')}  # one ids tensor per feature
+  for dim in (1, 16):
+    dout = torch.from_numpy((rng.standard_normal((B, n_feat * dim)) * 0.01).astype(np.float32))
+    var = torch.from_numpy((rng.standard_normal((total, dim)) * 0.1).astype(np.float32))
+    m = torch.from_numpy((rng.random((total, dim)) * 0.01).astype(np.float32))
+    v = torch.from_numpy((rng.random((total, dim)) * 0.01 + 1e-4).astype(np.float32))
+    tabs.append((var, m, v))
+    for dev, groups, be in ((DEV, groups_d, hip), ('cpu', groups_c, ref)):
+      vd, od = var.to(dev), dout.to(dev)
+      specs = [kernels.LookupSpec(table=vd[base[f]:base[f + 1]], ids=ids_on[dev][f], offsets=None, weights=None, out=od,
+                                  out_col=f * dim, rows=rows[f], key_base=int(base[f]), dim=dim, combiner=0, n_rows=B,
+                                  max_nnz=B) for f in range(n_feat)]
+      groups.append(be.emb_group_create(specs, dim, total, var.to(dev), None, None, None))
+    dense_d.append(torch.zeros(total, dim + 1, device=DEV))
+    dense_c.append(torch.zeros(total, dim + 1))
+  assert hip.emb_group_share_sort(groups_d[1], groups_d[0])
+  hip.emb_bwd_reduce_dense(groups_d, dense_d)
+  # the two-step form on the device, and the oracle
+  for g, dd, dc, gc in zip(groups_d, dense_d, dense_c, groups_c):
+    two = torch.zeros_like(dd)
+    keys, grads, n = hip.emb_bwd_reduce(g)
+    hip.scatter_unique(keys, grads, n, keys.numel(), g['dim'], two)
+    torch.cuda.synchronize()
+    assert torch.equal(dd, two), g['dim']
+    ref.emb_bwd_reduce_dense([gc], [dc])
+    assert torch.allclose(dd.cpu(), dc, rtol=1e-5, atol=1e-7)  # runs of 300+ terms are summed piece-wise
+    assert torch.equal(dd.cpu()[:, -1], dc[:, -1])
+  # apply: both tables in one launch, twice (untouched rows keep decaying under TF-exact Adam)
+  hyper = _hyper(lr=0.05, t=3, gscale=0.5)
+  dev_t = [(var.to(DEV), m.to(DEV), v.to(DEV), dd) for (var, m, v), dd in zip(tabs, dense_d)]
+  cpu_t = [(var.clone(), m.clone(), v.clone(), dd.cpu()) for (var, m, v), dd in zip(tabs, dense_d)]
+  for _ in range(2):
+    hip.emb_dense_apply(dev_t, opt, hyper.to(DEV))
+    ref.emb_dense_apply(cpu_t, opt, hyper)
+  torch.cuda.synchronize()
+  for a, b in zip(dev_t, cpu_t):
+    for x, y, what in zip(a[:3], b[:3], ('var', 'm', 'v')):
+      assert torch.allclose(x.cpu(), y, rtol=1e-6, atol=1e-9), (what, float((x.cpu() - y).abs().max()))
+  for g in groups_d:
+    hip.emb_group_destroy(g)
