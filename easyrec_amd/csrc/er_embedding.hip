@@ -1128,6 +1128,111 @@ gather_rows_kernel(const float* __restrict__ table, const uint32_t* __restrict__
   e.store(out + i * dim + c);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Owner side of the embedding-parallel exchange.  What a rank receives is `world` runs (one per requester), each
+// ascending and free of duplicates (the requesters' er_emb_route wrote them), so the stable sort by key the
+// reduction needs is a MERGE: an entry's sorted position is the number of received keys below its own in every
+// run (a binary search per run, all L2-resident) plus the equal keys of earlier runs.  One launch instead of the
+// device-wide radix sort's seven, and the run-head flags fall out of the same searches.
+// ------------------------------------------------------------------------------------------------
+constexpr int kMaxRuns = 64;
+struct MergeRuns {
+  int n;
+  int off[kMaxRuns + 1];
+};
+
+__global__ void __launch_bounds__(kBlock)
+emb_owner_merge_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, MergeRuns r,
+                       uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint32_t* __restrict__ flags) {
+  // (the run offsets are read with wave-uniform indices only: scalar loads from the kernarg segment - a per-lane
+  // read of it goes to host memory over PCIe, ~1 us per workgroup and serialised: measured 140 us per launch)
+  const int N = r.off[r.n];
+  const int i = static_cast<int>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i >= N) return;
+  const uint32_t k = keys_in[i];
+  int own = 0;  // the run of entry i: the last one starting at or before i (empty runs share their offset)
+  for (int q = 1; q < r.n; ++q) own += (r.off[q] <= i) ? 1 : 0;
+  uint32_t pos = 0;
+  bool first = true;
+  for (int q = 0; q < r.n; ++q) {
+    const int b = r.off[q], e = r.off[q + 1];
+    int lo = b, hi = e;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (keys_in[mid] < k) lo = mid + 1; else hi = mid;
+    }
+    pos += static_cast<uint32_t>(lo - b);
+    if (q < own && lo < e && keys_in[lo] == k) {
+      ++pos;
+      first = false;
+    }
+  }
+  keys_out[pos] = k;
+  vals_out[pos] = vals_in[i];
+  flags[pos] = first ? 1u : 0u;
+}
+
+// Serve the received keys: one lane group per sorted position that heads a run brings the row up to date (lazy
+// dense decay of TF-exact Adam: the catch-up of catch_up_body) and writes it to the reply slot of EVERY entry of
+// the run (at most one per requester), so each distinct row is read once.
+struct ServeArgs {
+  const uint32_t* skeys;
+  const uint32_t* svals;
+  const uint32_t* flags;
+  int64_t n;
+  RowUpdate tab;         // last_step == nullptr: no catch-up
+  const float* lr_hist;
+  float* out;            // [n, dim] reply rows in entry order
+  int dim, G, V;
+};
+struct ServeMulti {
+  int n;
+  int start[kMaxMulti + 1];
+  const er_opt_hyper* hyper;
+  ServeArgs a[kMaxMulti];
+};
+
+template <int V>
+__device__ __forceinline__ void serve_body(int bid, const ServeArgs& a, const er_opt_hyper* __restrict__ hyper) {
+  const int64_t p = (static_cast<int64_t>(bid) * kBlock + threadIdx.x) / a.G;
+  const int c = (static_cast<int>(threadIdx.x) % a.G) * V;
+  if (p >= a.n || c >= a.dim || !a.flags[p]) return;
+  const uint32_t key = a.skeys[p];
+  if (key == kInvalidKey) return;
+  const int64_t off = static_cast<int64_t>(key) * a.dim + c;
+  float var[V];
+  ld_vec<V>(var, a.tab.var + off);
+  if (a.tab.last_step) {
+    const int32_t t = static_cast<int32_t>(*a.tab.step_counter - 1);
+    const int32_t last = a.tab.last_step[key];
+    if (last + 1 < t) {
+      float m[V], v[V];
+      ld_vec<V>(m, a.tab.m + off);
+      ld_vec<V>(v, a.tab.v + off);
+      bool live = false;
+#pragma unroll
+      for (int j = 0; j < V; ++j) live = live || (m[j] != 0.f) || (v[j] != 0.f);
+      if (live) {
+        replay_decay<V>(var, m, v, a.lr_hist, last + 1, t, *hyper);
+        st_vec<V>(a.tab.var + off, var);
+        st_vec<V>(a.tab.m + off, m);
+        st_vec<V>(a.tab.v + off, v);
+      }
+    }
+  }
+  for (int64_t q = p; q < a.n && a.skeys[q] == key; ++q)
+    st_vec<V>(a.out + static_cast<int64_t>(a.svals[q]) * a.dim + c, var);
+}
+
+__global__ void __launch_bounds__(kBlock)
+emb_owner_serve_kernel(ServeMulti ma) {
+  int i = 0;
+  while (i + 1 < ma.n && static_cast<int>(blockIdx.x) >= ma.start[i + 1]) ++i;
+  const ServeArgs& a = ma.a[i];
+  if (a.V == 4) serve_body<4>(blockIdx.x - ma.start[i], a, ma.hyper);
+  else serve_body<1>(blockIdx.x - ma.start[i], a, ma.hyper);
+}
+
 // dense[key, 0:dim] = grads[i, :], dense[key, dim] = 1 for the n (device scalar) unique keys of a
 // replicated table group: the rows are then all-reduced across ranks like dense parameters.
 __global__ void __launch_bounds__(kBlock)
@@ -1400,6 +1505,7 @@ struct er_emb_group {
   int seg_caps_pow2 = 0;          // padded per-lookup size if every lookup has at most kSegSortMax entries
   bool seg_routed = false;        // routed keys (er_emb_group_set_routing) keep per-lookup disjoint, increasing ranges
   bool seg_routed_narrow = false;
+  uint64_t merged_epoch = ~0ull;  // sort_epoch of the last er_emb_owner_merge (head_flags hold its run heads)
   bool sorted_valid = false;
   // er_emb_group_share_sort: `src` owns the sorted keys / entry permutation / run heads this group reduces over
   // (itself, or the leader whose keys are identical); the epochs tell a fresh leader sort from a stale one
@@ -2215,6 +2321,71 @@ int er_gather_rows(const float* table, int64_t table_rows, int32_t dim, const ui
     hipLaunchKernelGGL(er::gather_rows_kernel<1>, dim3(blocks), dim3(er::kBlock), 0, er::as_stream(stream), table, keys, n,
                        dim, G, key_sub, table_rows, out);
   }
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
+int er_emb_owner_merge(er_emb_group* g, const int32_t* run_counts, int n_runs, er_stream_t stream) {
+  ER_REQUIRE(g && run_counts && n_runs >= 1 && n_runs <= er::kMaxRuns, "er_emb_owner_merge: bad arguments (1 <= runs <= %d)",
+             er::kMaxRuns);
+  ER_REQUIRE(g->n == 1 && !g->has_ragged && !g->d_local_base && !g->leader,
+             "er_emb_owner_merge: needs a group of ONE dense-mode lookup that follows no other group");
+  hipStream_t s = er::as_stream(stream);
+  const int64_t N = group_entries(g);
+  er::MergeRuns r;
+  r.n = n_runs;
+  r.off[0] = 0;
+  for (int i = 0; i < n_runs; ++i) {
+    ER_REQUIRE(run_counts[i] >= 0, "er_emb_owner_merge: negative run length");
+    r.off[i + 1] = r.off[i] + run_counts[i];
+  }
+  ER_REQUIRE(r.off[n_runs] == N, "er_emb_owner_merge: the runs hold %d keys, the group's active rows are %lld",
+             r.off[n_runs], (long long)N);
+  if (N == 0) return 0;
+  if (int rc = emb_group_build(g, s)) return rc;
+  g->src = g;
+  ++g->sort_epoch;
+  hipLaunchKernelGGL(er::emb_owner_merge_kernel, dim3(static_cast<unsigned>(er::ceil_div(N, er::kBlock))), dim3(er::kBlock),
+                     0, s, g->keys_in, g->vals_in, r, g->keys_out, g->vals_out, g->head_flags);
+  ER_LAUNCH_CHECK();
+  g->merged_epoch = g->sort_epoch;
+  g->sorted_valid = true;
+  return 0;
+}
+
+int er_emb_owner_serve(er_emb_group* const* groups, float* const* rows_out, int n, const er_opt_hyper* hyper,
+                       er_stream_t stream) {
+  ER_REQUIRE(groups && rows_out && n >= 1 && n <= er::kMaxMulti, "er_emb_owner_serve: bad arguments (1 <= n <= %d)",
+             er::kMaxMulti);
+  hipStream_t s = er::as_stream(stream);
+  er::ServeMulti ma;
+  ma.n = 0;
+  ma.start[0] = 0;
+  ma.hyper = hyper;
+  for (int i = 0; i < n; ++i) {
+    er_emb_group* g = groups[i];
+    ER_REQUIRE(g && rows_out[i], "er_emb_owner_serve: null argument (group %d)", i);
+    ER_REQUIRE(hyper || !g->last_step, "er_emb_owner_serve: group %d decays lazily: hyper is needed", i);
+    const int64_t N = group_entries(g);
+    if (N == 0) continue;
+    if (g->leader && !g->sorted_valid) {  // follower of a shared sort: take the leader's merge of this step
+      bool adopted = false;
+      if (int rc = emb_group_adopt(g, s, &adopted)) return rc;
+      ER_REQUIRE(adopted, "er_emb_owner_serve: group %d no longer sees its leader's keys", i);
+      g->sorted_valid = true;
+    }
+    const er_emb_group* src = g->src;
+    ER_REQUIRE(g->sorted_valid && src->merged_epoch == src->sort_epoch,
+               "er_emb_owner_serve: call er_emb_owner_merge (on the group or its leader) for this step first");
+    er::ServeArgs& a = ma.a[ma.n];
+    a.skeys = src->keys_out; a.svals = src->vals_out; a.flags = src->head_flags; a.n = N;
+    a.tab = er::RowUpdate{g->var, g->m, g->v, g->bitmap, g->last_step, g->step_counter};
+    a.lr_hist = g->lr_hist; a.out = rows_out[i]; a.dim = g->dim; a.G = g->G; a.V = g->V;
+    ma.start[ma.n + 1] = ma.start[ma.n] + static_cast<int>(er::ceil_div(N * g->G, er::kBlock));
+    ++ma.n;
+  }
+  if (ma.n == 0) return 0;
+  hipLaunchKernelGGL(er::emb_owner_serve_kernel, dim3(ma.start[ma.n]), dim3(er::kBlock), 0, s, ma);
   ER_LAUNCH_CHECK();
   return 0;
 }

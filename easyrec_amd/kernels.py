@@ -124,7 +124,7 @@ def same_lookup_keys(group, leader):
   if group is leader or leader.get('sort_leader') is not None:
     return False
   a, b = group['specs'], leader['specs']
-  if len(a) != len(b) or group.get('n_active', -1) >= 0 or leader.get('n_active', -1) >= 0:
+  if len(a) != len(b) or group.get('n_active', -1) != leader.get('n_active', -1):
     return False
   for k in ('world', 'shard_stride', 'local_base'):
     if group.get(k) != leader.get(k):
@@ -508,6 +508,21 @@ class HipBackend(object):
     self._ck(self.lib.er_scatter_unique(_p(keys), _p(grads), _p(n_unique), ctypes.c_int64(int(capacity)),
                                         ctypes.c_int32(dim), _p(dense), ctypes.c_int32(dense.stride(0)), _stream()),
              'er_scatter_unique')
+
+  def emb_owner_merge(self, group, run_counts):
+    """Owner side: the received keys are len(run_counts) ascending duplicate-free runs; merge instead of sort."""
+    n = len(run_counts)
+    rc = (ctypes.c_int32 * n)(*[int(x) for x in run_counts])
+    self._ck(self.lib.er_emb_owner_merge(group['handle'], rc, n, _stream()), 'er_emb_owner_merge')
+
+  def emb_owner_serve(self, groups, rows_out, hyper):
+    """Catch up (lazy dense decay) and reply the received rows of up to 4 owner groups in one launch."""
+    n = len(groups)
+    gh = (ctypes.c_void_p * n)(*[g['handle'] for g in groups])
+    for g, o in zip(groups, rows_out):
+      assert o.is_contiguous() and o.dtype == torch.float32 and o.shape[1] == g['dim']
+    op = (ctypes.c_void_p * n)(*[o.data_ptr() for o in rows_out])
+    self._ck(self.lib.er_emb_owner_serve(gh, op, n, None if hyper is None else _p(hyper), _stream()), 'er_emb_owner_serve')
 
   def emb_bwd_reduce_dense(self, groups, dense):
     """Per-row gradient sums of the groups straight into their dense [rows, dim + 1] buffers (count in the last

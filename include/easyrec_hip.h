@@ -495,6 +495,19 @@ int er_gather_rows(const float* table, int64_t table_rows, int32_t dim, const ui
 int er_scatter_unique(const uint32_t* keys, const float* grads, const int32_t* n_unique,
                       int64_t capacity, int32_t dim, float* dense, int32_t dense_stride,
                       er_stream_t stream);
+/* Owner side without a sort.  The keys a rank receives are `n_runs` runs (one per requester, lengths
+ * run_counts_host, in rank order), each ascending and duplicate-free - what the requesters' er_emb_route sent.
+ *   er_emb_owner_merge: on a group of ONE dense-mode lookup over the received rows (er_emb_group_set_active = the
+ *     received count): builds the entries and MERGES the runs into the stable by-key order the reduction needs
+ *     (one launch; the following er_emb_bwd_update(_multi) of the group - and of the groups sharing its sort -
+ *     reuses it, as after er_emb_route).
+ *   er_emb_owner_serve: for up to 4 such groups (a leader before its followers) in one launch: every distinct
+ *     received row is caught up (lazy dense decay, if enabled on the group; hyper may be NULL otherwise) and
+ *     written to rows_out[i][entry, :] of every entry that asked for it - er_emb_route + er_emb_catch_up +
+ *     er_gather_rows of the sorted form. */
+int er_emb_owner_merge(er_emb_group* group, const int32_t* run_counts_host, int n_runs, er_stream_t stream);
+int er_emb_owner_serve(er_emb_group* const* groups_host, float* const* rows_out_host, int n,
+                       const er_opt_hyper* hyper, er_stream_t stream);
 int er_emb_bwd_reduce_dense(er_emb_group* const* groups_host, float* const* dense_host, const int32_t* ld_host,
                             int n, er_stream_t stream);
 int er_emb_dense_apply(const er_dense_apply_desc* descs_host, int n, int opt_kind, const er_opt_hyper* hyper,

@@ -443,6 +443,23 @@ class RefBackend(object):
     dense[rows, :dim] = grads[:n]
     dense[rows, dim] = 1.0
 
+  def emb_owner_merge(self, group, run_counts):
+    assert sum(int(x) for x in run_counts) == group['n_active']
+
+  def emb_owner_serve(self, groups, rows_out, hyper):
+    """The sorted form: de-duplicate the received rows, catch them up, gather."""
+    for g, out in zip(groups, rows_out):
+      n = g['n_active']
+      if n == 0:
+        continue
+      if g.get('last_step') is not None:
+        uk = torch.zeros(g['num_entries'], dtype=torch.int32)
+        nu = torch.zeros(1, dtype=torch.int32)
+        self.emb_route(g, uk, nu, None, None)
+        self.emb_catch_up(g, uk, nu, hyper)
+      spec = g['specs'][0]
+      out[:n] = g['var'][spec.key_base + spec.ids[:n]]
+
   def emb_bwd_reduce_dense(self, groups, dense):
     for g, d in zip(groups, dense):  # the two-step form: de-duplicated rows, then the scatter
       keys, grads, n_unique = self.emb_bwd_reduce(g)

@@ -165,3 +165,56 @@ def test_graph_segments_equal_eager_embedding_parallel_step():
   sa, sb = ests[0].state_dict(slots=True), ests[1].state_dict(slots=True)
   for k in sa:
     assert np.array_equal(sa[k], sb[k]), k
+
+
+@pytest.mark.parametrize('counts', [[700], [300, 0, 450, 1, 0], [2000, 1500, 1800, 1700, 1600, 1900, 1400, 1300]])
+def test_owner_merge_and_serve_against_the_sorted_form(counts):
+  """er_emb_owner_merge + er_emb_owner_serve + er_emb_bwd_update on runs of ascending duplicate-free keys (one per
+  requester, some empty) against the sorted form (er_gather_rows, er_emb_bwd_update's own radix sort) on a copy -
+  bit for bit: the merge yields the stable by-key order the sort yields.  Two groups (dim 16 and 1) share the merge."""
+  hip = kernels.hip()
+  rng = np.random.default_rng(len(counts))
+  rows, cap = 5000, sum(counts) + 100
+  runs = [np.sort(rng.choice(rows, size=c, replace=False)) for c in counts]
+  ids = np.full(cap, -1, dtype=np.int64)
+  m = sum(counts)
+  ids[:m] = np.concatenate(runs)
+  ids_dev = torch.from_numpy(ids).to(DEV)
+  hyper = torch.zeros(16, dtype=torch.float32)
+  hyper[kernels.HYPER_LR], hyper[kernels.HYPER_GSCALE] = 0.1, 0.5
+  hyper = hyper.to(DEV)
+  made = []
+  for dim in (16, 1):
+    table = torch.from_numpy(rng.standard_normal((rows, dim)).astype(np.float32)).to(DEV)
+    grads = torch.from_numpy(rng.standard_normal((cap, dim)).astype(np.float32)).to(DEV)
+    if dim == 16:  # numpy: a row asked for by several requesters moves by the sum of their gradients
+      want = table.cpu().numpy().astype(np.float64)
+      np.subtract.at(want, ids[:m], 0.1 * 0.5 * grads[:m].cpu().numpy().astype(np.float64))
+    pair = []
+    for _ in range(2):  # [merged form, sorted form]
+      var = table.clone()
+      spec = kernels.LookupSpec(table=var, ids=ids_dev, offsets=None, weights=None, out=grads, out_col=0, rows=rows,
+                                key_base=0, dim=dim, combiner=0, n_rows=cap, max_nnz=cap)
+      g = hip.emb_group_create([spec], dim, rows, var, None, None, None)
+      hip.emb_group_set_active(g, m)
+      pair.append((g, var))
+    made.append(pair)
+  (g16, v16), (s16, sv16) = made[0]
+  (g1, v1), (s1, sv1) = made[1]
+  assert hip.emb_group_share_sort(g1, g16)
+  out16, out1 = torch.zeros(cap, 16, device=DEV), torch.zeros(cap, 1, device=DEV)
+  hip.emb_owner_merge(g16, counts)
+  hip.emb_owner_serve([g16, g1], [out16, out1], None)
+  hip.emb_bwd_update_multi([g16, g1], kernels.OPT_SGD, hyper)
+  exp16, exp1 = torch.zeros(cap, 16, device=DEV), torch.zeros(cap, 1, device=DEV)
+  keys32 = ids_dev[:m].to(torch.int32)
+  hip.gather_rows(sv16, keys32, m, 0, exp16)
+  hip.gather_rows(sv1, keys32, m, 0, exp1)
+  hip.emb_bwd_update(s16, kernels.OPT_SGD, hyper)
+  hip.emb_bwd_update(s1, kernels.OPT_SGD, hyper)
+  torch.cuda.synchronize()
+  assert torch.equal(out16[:m], exp16[:m]) and torch.equal(out1[:m], exp1[:m])
+  assert torch.equal(v16, sv16) and torch.equal(v1, sv1)
+  assert np.allclose(v16.cpu().numpy(), want, rtol=1e-5, atol=1e-6)
+  for g, _ in made[0] + made[1]:
+    hip.emb_group_destroy(g)
