@@ -8,6 +8,8 @@ compat/optimizers.py:285-345).  Here they are `torch.distributed` calls on devic
   exchange_counts   all-gather of a small [G, W] int32 matrix of per-owner unique-key counts ->
                     host-side send/recv split lists (the ONE host synchronisation of a step)
   all_to_all        variable-split exchange of keys (int32), rows and gradient rows (fp32, [n, dim])
+  all_to_all_equal  the same with a fixed capacity per peer (padded): no host-side sizes, so no exchange_counts
+                    and no host synchronisation - the default (layers/sharded_embedding.py)
   all_reduce_sum    dense gradients / replicated small tables (scaled by 1/W in the optimizer kernels)
   all_gather_rows   checkpoint/test only: collect the shards of a table
 
@@ -32,6 +34,9 @@ class LocalComm(object):
     assert n == int(recv_splits[0])
     if n:
       recv[:n].copy_(send[:n])
+
+  def all_to_all_equal(self, send, recv):
+    recv.copy_(send)
 
   def all_reduce_sum(self, t):
     return t
@@ -70,6 +75,10 @@ class TorchDistComm(object):
     ns, nr = int(sum(send_splits)), int(sum(recv_splits))
     self.dist.all_to_all_single(recv[:nr], send[:ns], output_split_sizes=[int(x) for x in recv_splits],
                                 input_split_sizes=[int(x) for x in send_splits], group=self.group)
+
+  def all_to_all_equal(self, send, recv):
+    """Equal splits (numel / world elements per peer): no host-side sizes, nothing to synchronise on."""
+    self.dist.all_to_all_single(recv, send, group=self.group)
 
   def all_reduce_sum(self, t):
     self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)

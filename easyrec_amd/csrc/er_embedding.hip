@@ -553,7 +553,7 @@ __device__ __forceinline__ void finish_run(const RowUpdate& tab, int opt_kind, c
     if (sub == 0) d[dim] = 1.f;  // "this row has a gradient" (summed over ranks by the all-reduce that follows)
   } else {
     const uint32_t u = ro.head_index[p] + ro.flags[p] - 1u;
-    if (sub == 0) ro.out_keys[u] = key;
+    if (sub == 0 && ro.out_keys) ro.out_keys[u] = key;
 #pragma unroll
     for (int i = 0; i < V; ++i) ro.out_grads[static_cast<int64_t>(u) * dim + c + i] = g[i];
   }
@@ -978,7 +978,8 @@ emb_route_seg_routed_kernel(const uint32_t* __restrict__ skeys, const uint32_t* 
                             const uint32_t* __restrict__ flags, uint32_t* __restrict__ head_index,
                             const int64_t* __restrict__ ent_base, const uint32_t* __restrict__ seg_count, int n_lookups,
                             int world, uint32_t stride, uint32_t* __restrict__ unique_keys, int64_t* __restrict__ uidx,
-                            int32_t* __restrict__ n_unique, int32_t* __restrict__ owner_counts) {
+                            int32_t* __restrict__ n_unique, int32_t* __restrict__ owner_counts, uint32_t peer_cap,
+                            int32_t* __restrict__ overflow) {
   __shared__ uint32_t s_total[64], s_before[64], s_row[64], s_obase[64], s_lbase[64];
   const int l = blockIdx.y;
   const int tid = threadIdx.x;
@@ -997,13 +998,18 @@ emb_route_seg_routed_kernel(const uint32_t* __restrict__ skeys, const uint32_t* 
   __syncthreads();
   if (tid == 0) {
     uint32_t a = 0, b = 0;
+    bool over = false;
     for (int w = 0; w < world; ++w) {
-      s_obase[w] = a;
+      s_obase[w] = peer_cap ? static_cast<uint32_t>(w) * peer_cap : a;  // padded: owner w's keys start at w * peer_cap
       s_lbase[w] = b;
       a += s_total[w];
       b += s_row[w];
+      over = over || (peer_cap && s_total[w] > peer_cap);
     }
-    if (l == n_lookups - 1 && blockIdx.x == 0) *n_unique = static_cast<int32_t>(a);
+    if (l == n_lookups - 1 && blockIdx.x == 0) {
+      *n_unique = static_cast<int32_t>(a);
+      if (over) *overflow = 1;
+    }
   }
   __syncthreads();
   if (l == n_lookups - 1 && blockIdx.x == 0 && owner_counts && tid < world) owner_counts[tid] = static_cast<int32_t>(s_total[tid]);
@@ -1020,10 +1026,13 @@ emb_route_seg_routed_kernel(const uint32_t* __restrict__ skeys, const uint32_t* 
   const uint32_t f = flags[p];
   const uint32_t w = key / stride;
   const uint32_t run = head_index[p] + f - 1u;  // index of the run among the lookup's runs
-  const uint32_t u = s_obase[w] + s_before[w] + (run - s_lbase[w]);
+  uint32_t r = s_before[w] + (run - s_lbase[w]);  // index of the key among owner w's keys
+  const bool fits = !peer_cap || r < peer_cap;
+  if (!fits) r = peer_cap - 1u;                    // (*overflow is set: the step's results are void, stay in bounds)
+  const uint32_t u = s_obase[w] + r;
   head_index[p] = u + 1u - f;
-  if (uidx) uidx[j] = static_cast<int64_t>(u);
-  if (f) unique_keys[u] = key;
+  if (uidx) uidx[j] = fits ? static_cast<int64_t>(u) : -1;
+  if (f && fits) unique_keys[u] = key;
 }
 
 // Second half of the fused route of the segmented path: add the distinct-key counts of the lookups before this one
@@ -1168,6 +1177,59 @@ emb_owner_merge_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __r
     }
   }
   keys_out[pos] = k;
+  vals_out[pos] = vals_in[i];
+  flags[pos] = first ? 1u : 0u;
+}
+
+// Padded form (no host-visible counts: the exchange has fixed per-peer capacity `cap`, so the step needs no host
+// synchronisation): run q occupies [q * cap, q * cap + counts[q]) of the received buffer, counts on the device.
+// Entries past a run's count are padding: they get the invalid key and the positions after the N real ones.
+__global__ void __launch_bounds__(kBlock)
+emb_owner_ids_kernel(const uint32_t* __restrict__ keys, const int32_t* __restrict__ counts, int n_runs, int cap,
+                     int64_t key_sub, int64_t* __restrict__ ids) {
+  const int i = static_cast<int>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i >= n_runs * cap) return;
+  const int q = i / cap;
+  ids[i] = (i - q * cap) < counts[q] ? static_cast<int64_t>(keys[i]) - key_sub : -1;
+}
+
+__global__ void __launch_bounds__(kBlock)
+emb_owner_merge_padded_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                              const int32_t* __restrict__ counts, int n_runs, int cap, uint32_t* __restrict__ keys_out,
+                              uint32_t* __restrict__ vals_out, uint32_t* __restrict__ flags) {
+  const int i = static_cast<int>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i >= n_runs * cap) return;
+  const int own = i / cap;
+  const int j = i - own * cap;
+  uint32_t pos = 0;
+  bool first = true;
+  const uint32_t k = keys_in[i];
+  const bool valid = j < min(counts[own], cap);
+  if (valid) {
+    for (int q = 0; q < n_runs; ++q) {  // (q and counts[q] are wave-uniform: scalar loads)
+      const int b = q * cap, e = b + min(counts[q], cap);
+      int lo = b, hi = e;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (keys_in[mid] < k) lo = mid + 1; else hi = mid;
+      }
+      pos += static_cast<uint32_t>(lo - b);
+      if (q < own && lo < e && keys_in[lo] == k) {
+        ++pos;
+        first = false;
+      }
+    }
+  } else {
+    int n_valid = 0, pad_before = 0;
+    for (int q = 0; q < n_runs; ++q) {
+      const int c = min(counts[q], cap);
+      n_valid += c;
+      if (q < own) pad_before += cap - c;
+    }
+    pos = static_cast<uint32_t>(n_valid + pad_before + (j - min(counts[own], cap)));
+    first = false;
+  }
+  keys_out[pos] = valid ? k : kInvalidKey;
   vals_out[pos] = vals_in[i];
   flags[pos] = first ? 1u : 0u;
 }
@@ -1505,6 +1567,8 @@ struct er_emb_group {
   int seg_caps_pow2 = 0;          // padded per-lookup size if every lookup has at most kSegSortMax entries
   bool seg_routed = false;        // routed keys (er_emb_group_set_routing) keep per-lookup disjoint, increasing ranges
   bool seg_routed_narrow = false;
+  int64_t peer_cap = 0;           // > 0: er_emb_route writes owner w's keys at [w * peer_cap, ...) (padded exchange)
+  int32_t* d_overflow = nullptr;  // set to 1 by er_emb_route when an owner's keys exceed peer_cap
   uint64_t merged_epoch = ~0ull;  // sort_epoch of the last er_emb_owner_merge (head_flags hold its run heads)
   bool sorted_valid = false;
   // er_emb_group_share_sort: `src` owns the sorted keys / entry permutation / run heads this group reduces over
@@ -1719,7 +1783,7 @@ int er_emb_group_destroy(er_emb_group* g) {
   }
   void* ptrs[] = {g->d_descs, g->d_blk_start, g->d_ent_base, g->keys_in, g->keys_out, g->vals_in, g->vals_out,
                   g->ent_gptr, g->ent_scale, g->tile_first, g->tile_last, g->head_flags, g->head_index, g->sort_temp, g->scan_temp,
-                  g->d_local_base, g->seg_count};
+                  g->d_local_base, g->seg_count, g->d_overflow};
   for (void* q : ptrs) (void)hipFree(q);
   delete g;
   return 0;
@@ -2258,6 +2322,8 @@ int er_emb_route(er_emb_group* g, uint32_t* unique_keys, int32_t* n_unique, int6
     }
   } else {
     ER_REQUIRE(unique_keys && n_unique, "er_emb_route: null argument");
+    ER_REQUIRE(g->peer_cap == 0 || (g->d_local_base && emb_group_segmented(g)),
+               "er_emb_route: a per-peer capacity needs routed keys on the per-lookup sort path");
     if (emb_group_segmented(g)) {
       // two launches: sort + in-lookup heads, then the cross-lookup offsets + key list + per-entry index
       if (int rc = emb_group_build_sort(g, s, true)) return rc;
@@ -2266,7 +2332,7 @@ int er_emb_route(er_emb_group* g, uint32_t* unique_keys, int32_t* n_unique, int6
         hipLaunchKernelGGL(er::emb_route_seg_routed_kernel, grid, dim3(er::kBlock), 0, s, g->keys_out, g->vals_out,
                            g->head_flags, g->head_index, g->d_ent_base, g->seg_count, g->n, g->world,
                            static_cast<uint32_t>(g->shard_stride), unique_keys, entry_unique_index, n_unique,
-                           owner_counts);
+                           owner_counts, static_cast<uint32_t>(g->peer_cap), g->d_overflow);
         counts_done = true;
       } else {
         dim3 grid(static_cast<unsigned>(er::ceil_div(g->seg_sort_pow2, er::kBlock)), static_cast<unsigned>(g->n));
@@ -2303,8 +2369,8 @@ int er_emb_bwd_reduce_routed(er_emb_group* g, float* unique_grads, er_stream_t s
   ER_REQUIRE(g && unique_grads, "er_emb_bwd_reduce_routed: null argument");
   ER_REQUIRE(g->sorted_valid, "er_emb_bwd_reduce_routed: call er_emb_route for this step first");
   hipStream_t s = er::as_stream(stream);
-  // unique keys were already written by er_emb_route: out_keys is a scratch sink here
-  return emb_group_run(g, ER_OPT_SGD, nullptr, 1, g->keys_in, unique_grads, s);
+  // unique keys were already written by er_emb_route (and with a per-peer capacity the run index exceeds the entries)
+  return emb_group_run(g, ER_OPT_SGD, nullptr, 1, nullptr, unique_grads, s);
 }
 
 int er_gather_rows(const float* table, int64_t table_rows, int32_t dim, const uint32_t* keys, int64_t n,
@@ -2347,6 +2413,58 @@ int er_emb_owner_merge(er_emb_group* g, const int32_t* run_counts, int n_runs, e
   ++g->sort_epoch;
   hipLaunchKernelGGL(er::emb_owner_merge_kernel, dim3(static_cast<unsigned>(er::ceil_div(N, er::kBlock))), dim3(er::kBlock),
                      0, s, g->keys_in, g->vals_in, r, g->keys_out, g->vals_out, g->head_flags);
+  ER_LAUNCH_CHECK();
+  g->merged_epoch = g->sort_epoch;
+  g->sorted_valid = true;
+  return 0;
+}
+
+int er_emb_group_set_peer_capacity(er_emb_group* g, int64_t peer_cap) {
+  ER_REQUIRE(g && peer_cap >= 0, "er_emb_group_set_peer_capacity: bad arguments");
+  if (peer_cap > 0) {
+    ER_REQUIRE(g->d_local_base && g->seg_routed, "er_emb_group_set_peer_capacity: needs er_emb_group_set_routing with "
+               "lookups the per-lookup sort covers (one table per lookup, <= %d entries each)", er::kSegSortMax);
+    ER_REQUIRE(peer_cap * g->world < 0x7FFFFFFFLL, "er_emb_group_set_peer_capacity: world * capacity too large");
+    if (!g->d_overflow) {
+      ER_CHECK_HIP(hipMalloc(&g->d_overflow, sizeof(int32_t)));
+      ER_CHECK_HIP(hipMemset(g->d_overflow, 0, sizeof(int32_t)));
+    }
+  }
+  g->peer_cap = peer_cap;
+  return 0;
+}
+
+int er_emb_route_overflow(er_emb_group* g, int32_t* overflow_host) {
+  ER_REQUIRE(g && overflow_host, "er_emb_route_overflow: null argument");
+  *overflow_host = 0;
+  if (g->d_overflow) ER_CHECK_HIP(hipMemcpy(overflow_host, g->d_overflow, sizeof(int32_t), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int er_emb_owner_ids(const uint32_t* recv_keys, const int32_t* counts, int n_runs, int64_t peer_cap, int64_t key_sub,
+                     int64_t* ids, er_stream_t stream) {
+  ER_REQUIRE(recv_keys && counts && ids && n_runs >= 1 && peer_cap > 0 && n_runs * peer_cap < 0x7FFFFFFFLL,
+             "er_emb_owner_ids: bad arguments");
+  const int64_t n = n_runs * peer_cap;
+  hipLaunchKernelGGL(er::emb_owner_ids_kernel, dim3(static_cast<unsigned>(er::ceil_div(n, er::kBlock))), dim3(er::kBlock), 0,
+                     er::as_stream(stream), recv_keys, counts, n_runs, static_cast<int>(peer_cap), key_sub, ids);
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
+int er_emb_owner_merge_padded(er_emb_group* g, const int32_t* counts, int n_runs, int64_t peer_cap, er_stream_t stream) {
+  ER_REQUIRE(g && counts && n_runs >= 1 && peer_cap > 0, "er_emb_owner_merge_padded: bad arguments");
+  ER_REQUIRE(g->n == 1 && !g->has_ragged && !g->d_local_base && !g->leader && g->n_active < 0,
+             "er_emb_owner_merge_padded: needs a group of ONE dense-mode lookup, all rows active, following no group");
+  ER_REQUIRE(g->n_entries == n_runs * peer_cap, "er_emb_owner_merge_padded: the group holds %lld rows, not %d x %lld",
+             (long long)g->n_entries, n_runs, (long long)peer_cap);
+  hipStream_t s = er::as_stream(stream);
+  if (int rc = emb_group_build(g, s)) return rc;
+  g->src = g;
+  ++g->sort_epoch;
+  hipLaunchKernelGGL(er::emb_owner_merge_padded_kernel, dim3(static_cast<unsigned>(er::ceil_div(g->n_entries, er::kBlock))),
+                     dim3(er::kBlock), 0, s, g->keys_in, g->vals_in, counts, n_runs, static_cast<int>(peer_cap), g->keys_out,
+                     g->vals_out, g->head_flags);
   ER_LAUNCH_CHECK();
   g->merged_epoch = g->sort_epoch;
   g->sorted_valid = true;

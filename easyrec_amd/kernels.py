@@ -515,6 +515,27 @@ class HipBackend(object):
     rc = (ctypes.c_int32 * n)(*[int(x) for x in run_counts])
     self._ck(self.lib.er_emb_owner_merge(group['handle'], rc, n, _stream()), 'er_emb_owner_merge')
 
+  def emb_group_set_peer_capacity(self, group, peer_cap):
+    self._ck(self.lib.er_emb_group_set_peer_capacity(group['handle'], ctypes.c_int64(int(peer_cap))),
+             'er_emb_group_set_peer_capacity')
+    group['peer_cap'] = int(peer_cap)
+
+  def emb_route_overflow(self, group):
+    out = ctypes.c_int32(0)
+    self._ck(self.lib.er_emb_route_overflow(group['handle'], ctypes.byref(out)), 'er_emb_route_overflow')
+    return bool(out.value)
+
+  def emb_owner_ids(self, recv_keys, counts, n_runs, peer_cap, key_sub, ids):
+    assert recv_keys.dtype == torch.int32 and counts.dtype == torch.int32 and ids.dtype == torch.int64
+    assert recv_keys.numel() >= n_runs * peer_cap and ids.numel() >= n_runs * peer_cap and counts.numel() >= n_runs
+    self._ck(self.lib.er_emb_owner_ids(_p(recv_keys), _p(counts), ctypes.c_int(n_runs), ctypes.c_int64(int(peer_cap)),
+                                       ctypes.c_int64(int(key_sub)), _p(ids), _stream()), 'er_emb_owner_ids')
+
+  def emb_owner_merge_padded(self, group, counts, n_runs, peer_cap):
+    assert counts.dtype == torch.int32 and counts.numel() >= n_runs
+    self._ck(self.lib.er_emb_owner_merge_padded(group['handle'], _p(counts), ctypes.c_int(n_runs),
+                                                ctypes.c_int64(int(peer_cap)), _stream()), 'er_emb_owner_merge_padded')
+
   def emb_owner_serve(self, groups, rows_out, hyper):
     """Catch up (lazy dense decay) and reply the received rows of up to 4 owner groups in one launch."""
     n = len(groups)

@@ -39,6 +39,8 @@ class ShardedEmbeddingEngine(EmbeddingEngine):
     # the owner merges the runs it receives instead of sorting them: 10 us against 52 us at world 1, 24 us at world 8
     # (45 k keys); one binary search per run and key, so beyond 16 runs the radix sort wins again (117 us at 64)
     self.owner_merge = os.environ.get('EASYREC_AMD_OWNER_MERGE', '1') != '0' and self.world <= 16
+    self.padded_exchange = os.environ.get('EASYREC_AMD_PADDED_EXCHANGE', '1') != '0'  # A/B switch
+    self.padded = False  # set by finalize(): every sharded dim group uses the fixed-capacity exchange
     self.recv_slack = recv_slack
     self.shard = OrderedDict()  # dim -> dict of the sharded half of the dim group
     self.rep = OrderedDict()    # dim -> dict of the replicated half
@@ -100,6 +102,8 @@ class ShardedEmbeddingEngine(EmbeddingEngine):
         fwd_specs.append(None)
         if g['reg'] > 0:
           reg_count += 1
+    self.padded = bool(self.shard) and self.padded_exchange and self.owner_merge and all(
+        self._can_pad(h['shard']) for h in per_dim.values() if h['shard'])
     for dim, halves in per_dim.items():
       if halves['shard']:
         self._build_shard_half(dim, halves['shard'], fwd_specs, opt_kind)
@@ -127,6 +131,14 @@ class ShardedEmbeddingEngine(EmbeddingEngine):
     self.lazy_decay = self.lazy_decay and opt_kind == kernels.OPT_ADAM
     self.finalized = True
 
+  @staticmethod
+  def _can_pad(lookups):
+    """The fixed-capacity exchange needs er_emb_route's per-lookup sort of routed keys: one table per lookup, in
+    table order, at most 8192 entries per lookup."""
+    caps = [(lk['max_nnz'] if lk['offsets'] is not None else lk['n_rows']) for lk in lookups]
+    bases = [lk['base'] for lk in lookups]
+    return max(caps) <= 8192 and len(set(lk['tname'] for lk in lookups)) == len(lookups) and bases == sorted(bases)
+
   def _build_shard_half(self, dim, lookups, fwd_specs, opt_kind):
     be = kernels.hip()
     dev, W = self.device, self.world
@@ -152,22 +164,33 @@ class ShardedEmbeddingEngine(EmbeddingEngine):
           break
     sh['leader'] = lead_dim
     lead = self.shard[lead_dim] if lead_dim is not None else None
+    # Fixed-capacity ("padded") exchange: owner w's keys sit at [w * C, w * C + count[w]) of every buffer, so the
+    # all-to-alls have equal splits known at build time: no count all-gather, no host synchronisation, every launch
+    # static (hipGraph segments; the host runs ahead of the device).  C = slack x the even share, at most all entries.
+    # It needs the per-lookup routed sort (one table per lookup, in table order, <= 8192 entries each) and the
+    # owner-side merge (world <= 16); otherwise the compact exchange with host-side split sizes is used.
+    padded = self.padded
+    peer_cap = min(n_ent, -(-int(self.recv_slack * n_ent) // W)) if padded else 0
+    n_slots = W * peer_cap if padded else n_ent  # rows of the requester-side buffers
+    if padded:
+      m_cap = W * peer_cap
     sh.update(
-        n_entries=n_ent, m_cap=m_cap,
-        recv_rows=torch.zeros(n_ent, dim, dtype=torch.float32, device=dev),
-        ugrads=torch.zeros(n_ent, dim, dtype=torch.float32, device=dev),
+        n_entries=n_ent, m_cap=m_cap, peer_cap=peer_cap,
+        recv_rows=torch.zeros(n_slots, dim, dtype=torch.float32, device=dev),
+        ugrads=torch.zeros(n_slots, dim, dtype=torch.float32, device=dev),
         rows_out=torch.zeros(m_cap, dim, dtype=torch.float32, device=dev),
         recv_grads=torch.zeros(m_cap, dim, dtype=torch.float32, device=dev))
     if lead is not None:
-      for k in ('ukeys', 'n_unique', 'uidx', 'recv_keys', 'recv_ids'):
+      for k in ('ukeys', 'n_unique', 'uidx', 'recv_keys', 'recv_ids', 'recv_cnt'):
         sh[k] = lead[k]
     else:
       sh.update(
-          ukeys=torch.zeros(n_ent, dtype=torch.int32, device=dev),
+          ukeys=torch.zeros(n_slots, dtype=torch.int32, device=dev),
           n_unique=torch.zeros(1, dtype=torch.int32, device=dev),
           uidx=torch.full((n_ent,), -1, dtype=torch.int64, device=dev),
           recv_keys=torch.zeros(m_cap, dtype=torch.int32, device=dev),
-          recv_ids=torch.full((m_cap,), -1, dtype=torch.int64, device=dev))
+          recv_ids=torch.full((m_cap,), -1, dtype=torch.int64, device=dev),
+          recv_cnt=torch.zeros(W, dtype=torch.int32, device=dev))
     req_specs, off = [], 0
     for lk, cap in zip(lookups, caps):
       g = lk['group']
@@ -179,14 +202,16 @@ class ShardedEmbeddingEngine(EmbeddingEngine):
       # forward: the same lookup, reading the rows received from the owners through the entry -> unique map
       fwd_specs[lk['slot']] = kernels.LookupSpec(
           table=sh['recv_rows'], ids=sh['uidx'][off:off + cap], offsets=lk['offsets'], weights=lk['weights'],
-          out=g['out'], out_col=lk['col'], rows=n_ent, key_base=0, dim=dim, combiner=lk['combiner'],
+          out=g['out'], out_col=lk['col'], rows=n_slots, key_base=0, dim=dim, combiner=lk['combiner'],
           n_rows=lk['n_rows'], max_nnz=lk['max_nnz'], name=lk['name'])
       g['specs'].append(fwd_specs[lk['slot']])
       off += cap
-    span = max([lk['t']['rows'] for lk in lookups] + [n_ent, 1])  # validation bound only: keys are routed
+    span = max([lk['t']['rows'] for lk in lookups] + [n_slots, 1])  # validation bound only: keys are routed
     sh['req'] = be.emb_group_create(req_specs, dim, span, sh['recv_rows'], None, None, None)
     assert sh['req']['num_entries'] == n_ent
     be.emb_group_set_routing(sh['req'], W, sh['stride'], [lk['base'] for lk in lookups])
+    if padded and lead is None:
+      be.emb_group_set_peer_capacity(sh['req'], peer_cap)
     if lead is not None:
       assert be.emb_group_share_sort(sh['req'], lead['req']), 'dim %d: cannot follow the route of dim %d' % (dim, lead_dim)
     st = sh['st']
@@ -237,6 +262,59 @@ class ShardedEmbeddingEngine(EmbeddingEngine):
         be.emb_route(sh['req'], None, None, None, None)
 
   def exchange(self):
+    if self.shard and self.padded:
+      self.exchange_keys()
+      self.owner_serve()
+      self.exchange_rows()
+    else:
+      self._exchange_compact()
+
+  # -- fixed-capacity exchange: collectives with build-time sizes around static device work
+  def exchange_keys(self):
+    comm = self.comm
+    for gi, (dim, sh) in enumerate(self.shard.items()):
+      if sh['leader'] is None:
+        comm.all_to_all_equal(self.counts_dev[gi], sh['recv_cnt'])
+        comm.all_to_all_equal(sh['ukeys'], sh['recv_keys'])
+
+  def owner_serve(self):
+    """Received keys -> local rows, merged order, caught-up rows written to the reply buffers (static launches)."""
+    be, W = kernels.hip(), self.world
+    shs = list(self.shard.values())
+    for sh in shs:
+      if sh['leader'] is None:
+        be.emb_owner_ids(sh['recv_keys'], sh['recv_cnt'], W, sh['peer_cap'], self.rank * sh['stride'], sh['recv_ids'])
+        be.emb_owner_merge_padded(sh['owner'], sh['recv_cnt'], W, sh['peer_cap'])
+    hyper = self._clock[2] if any(sh['lazy'] is not None for sh in shs) else None
+    for i in range(0, len(shs), 4):
+      be.emb_owner_serve([sh['owner'] for sh in shs[i:i + 4]], [sh['rows_out'] for sh in shs[i:i + 4]], hyper)
+
+  def exchange_rows(self):
+    for sh in self.shard.values():
+      self.comm.all_to_all_equal(sh['rows_out'], sh['recv_rows'])
+
+  def exchange_grads(self):
+    if self.rep:
+      self.comm.all_reduce_sum(self.rep_flat)
+    for sh in self.shard.values():
+      self.comm.all_to_all_equal(sh['ugrads'], sh['recv_grads'])
+
+  def owner_update(self, opt_kind, hyper):
+    be = kernels.hip()
+    owners = [sh['owner'] for sh in self.shard.values()]
+    for i in range(0, len(owners), 4):  # the groups' reduce + optimizer kernels side by side in one launch
+      be.emb_bwd_update_multi(owners[i:i + 4], opt_kind, hyper)
+
+  def check_overflow(self):
+    """Blocking: did any step since the last check route more keys to one owner than the exchange's capacity?"""
+    be = kernels.hip()
+    for dim, sh in self.shard.items():
+      if sh['peer_cap'] and sh['leader'] is None and be.emb_route_overflow(sh['req']):
+        raise RuntimeError('embedding-parallel: rank %d routed more than %d keys of dim %d to one owner; raise recv_slack'
+                           % (self.rank, sh['peer_cap'], dim))
+
+  # -- compact exchange: split sizes through the host (one synchronisation per step)
+  def _exchange_compact(self):
     be, comm = kernels.hip(), self.comm
     if not self.shard:
       return
@@ -314,6 +392,10 @@ class ShardedEmbeddingEngine(EmbeddingEngine):
 
   def exchange_grads_and_update(self, opt_kind, hyper):
     be, comm = kernels.hip(), self.comm
+    if self.shard and self.padded:
+      self.exchange_grads()
+      self.owner_update(opt_kind, hyper)
+      return
     if self.rep:
       comm.all_reduce_sum(self.rep_flat)
     for dim, sh in self.shard.items():

@@ -8,11 +8,15 @@ AVERAGED (compat/optimizers.py:328-331); embedding gradients are divided by the 
 (:315-316); BatchNorm statistics stay per-rank (the reference does not sync them); dense variables
 start identical on every rank (same seed; the reference broadcasts rank 0's, utils/hvd_utils.py:43-56).
 
-Per step: 1 small all-gather (split sizes, the one host sync) + 3 RCCL all-to-alls per embedding-dim
-group (keys, rows, row gradients) + 1 all-reduce of the flat dense-gradient buffer + 1 all-reduce of
-the replicated small tables' gradients.  The all-to-all split sizes change every step, so the step cannot
-be ONE hipGraph; instead its three static segments (route | lookup+forward+backward+local reduce | replicated
-apply + dense optimizer) are captured separately and the exchanges between them are issued eagerly.
+Per step (fixed-capacity exchange, the default: layers/sharded_embedding.py): per route (dim groups with the
+same routed keys share one) an all-to-all of the per-owner counts and one of the keys; per dim group an
+all-to-all of rows and one of row gradients - all with equal, build-time split sizes, so there is NO host
+synchronisation in the step; + 1 all-reduce of the flat dense-gradient buffer + 1 all-reduce of the replicated
+small tables' gradients.  The static device work between the collectives (route | owner merge + serve |
+lookup+forward+backward+local reduce | owner update + replicated apply + dense optimizer) is captured as four
+hipGraphs; the collectives are issued eagerly between them and the host runs ahead of the device.
+The compact exchange (variable split sizes through one host sync per step, three segments) remains for lookups
+the per-lookup routed sort does not cover.
 """
 import torch
 
@@ -88,24 +92,42 @@ class EmbeddingParallelEstimator(EasyRecEstimator):
     kernels.hip().dense_opt_step(vs.flat, vs.slots.get('m'), vs.slots.get('v'), vs.flat_grad,
                                  vs.l2coef if vs.any_l2 else None, self.opt_dense.kind, self.hyper[1])
 
+  def _phase_owner_serve(self):
+    self.engine.owner_serve()
+
+  def _phase_update(self):
+    self.engine.owner_update(self.opt_emb.kind, self.hyper[0])
+    self._phase_apply()
+
+  def _phases(self):
+    """[(static device work, the collectives that follow it)]: the static parts replay as hipGraphs."""
+    eng = self.engine
+    if eng.padded:
+      # fixed-capacity exchange: no host-side sizes anywhere, the host never waits for the device
+      seq = [(self._phase_route, eng.exchange_keys), (self._phase_owner_serve, eng.exchange_rows)]
+      if self.is_training:
+        seq += [(self._phase_compute, lambda: (self._sync_dense_grads(), eng.exchange_grads())), (self._phase_update, None)]
+      else:
+        seq += [(self._phase_compute, None)]
+      return seq
+    seq = [(self._phase_route, eng.exchange)]  # host sync (split sizes) + all-to-all keys / rows
+    if self.is_training:
+      seq += [(self._phase_compute,
+               lambda: (self._sync_dense_grads(), eng.exchange_grads_and_update(self.opt_emb.kind, self.hyper[0]))),
+              (self._phase_apply, None)]
+    else:
+      seq += [(self._phase_compute, None)]
+    return seq
+
   def _device_step(self):
     g = self._graphs
-    if g is None:
-      self._phase_route()
-    else:
-      g[0].replay()
-    self.engine.exchange()  # host sync (split sizes) + all-to-all keys / rows
-    if g is None:
-      self._phase_compute()
-    else:
-      g[1].replay()
-    if self.is_training:
-      self._sync_dense_grads()
-      self.engine.exchange_grads_and_update(self.opt_emb.kind, self.hyper[0])
+    for i, (static, collectives) in enumerate(self._phases()):
       if g is None:
-        self._phase_apply()
+        static()
       else:
-        g[2].replay()
+        g[i].replay()
+      if collectives is not None:
+        collectives()
 
   def train_step(self, batch=None):
     assert self._built, 'call build() first'
@@ -131,7 +153,7 @@ class EmbeddingParallelEstimator(EasyRecEstimator):
     torch.cuda.synchronize()
     pool = torch.cuda.graph_pool_handle()
     graphs = []
-    for phase in (self._phase_route, self._phase_compute, self._phase_apply):
+    for phase, _ in self._phases():
       g = torch.cuda.CUDAGraph()
       # thread_local: the RCCL watchdog thread of the process group may touch its own events meanwhile
       with torch.cuda.graph(g, pool=pool, capture_error_mode='thread_local'):
@@ -143,6 +165,7 @@ class EmbeddingParallelEstimator(EasyRecEstimator):
 
   def loss_values(self, average=False):
     vals = super(EmbeddingParallelEstimator, self).loss_values()
+    self.engine.check_overflow()  # (the losses were just read back: the device is idle anyway)
     if average and self.world > 1:
       keys = sorted(vals)
       t = torch.tensor([vals[k] for k in keys], dtype=torch.float64, device=self.device)

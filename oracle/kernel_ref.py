@@ -403,35 +403,62 @@ class RefBackend(object):
     group['sort_leader'] = leader
     return True
 
+  def emb_group_set_peer_capacity(self, group, peer_cap):
+    group['peer_cap'], group['overflow'] = int(peer_cap), False
+
+  def emb_route_overflow(self, group):
+    return bool(group.get('overflow', False))
+
   def emb_route(self, group, unique_keys, n_unique, entry_unique_index, owner_counts):
     ents = self._routed_entries(group)
     keys = sorted(set(e[0] for e in ents))
     if unique_keys is None:  # follower of a shared sort
       assert group.get('sort_leader') is not None and group['sort_leader'].get('_route_keys') == keys
-      group['_route_keys'] = keys
+      group['_route_keys'], group['_route_pos'] = keys, group['sort_leader']['_route_pos']
       return
-    pos = {k: i for i, k in enumerate(keys)}
+    W = group.get('world', 1)
+    stride = group['shard_stride'] if 'local_base' in group else group['total_rows']
+    cap = group.get('peer_cap', 0)
+    if cap:  # padded layout: owner w's keys at [w * cap, ...)
+      pos, seen = {}, [0] * W
+      for k in keys:
+        w = k // stride
+        if seen[w] < cap:
+          pos[k] = w * cap + seen[w]
+        else:
+          group['overflow'] = True
+        seen[w] += 1
+    else:
+      pos = {k: i for i, k in enumerate(keys)}
     if entry_unique_index is not None:
       entry_unique_index.fill_(-1)
       for key, j, _, _, _ in ents:
-        entry_unique_index[j] = pos[key]
-    for i, k in enumerate(keys):
+        entry_unique_index[j] = pos.get(key, -1)
+    for k, i in pos.items():
       unique_keys[i] = k
     n_unique[0] = len(keys)
-    W = group.get('world', 1)
-    stride = group['shard_stride'] if 'local_base' in group else group['total_rows']
     if owner_counts is not None:
       for w in range(W):
         owner_counts[w] = sum(1 for k in keys if w * stride <= k < (w + 1) * stride)
-    group['_route_keys'] = keys
+    group['_route_keys'], group['_route_pos'] = keys, pos
 
   def emb_bwd_reduce_routed(self, group, unique_grads):
     acc = {}
     for key, _, s, r, scale in self._routed_entries(group):
       g = s.out.detach().cpu().numpy()[r, s.out_col:s.out_col + group['dim']].astype(np.float32) * scale
       acc[key] = (acc[key] + g).astype(np.float32) if key in acc else g.astype(np.float32)
-    for i, key in enumerate(group['_route_keys']):
+    for key, i in group['_route_pos'].items():
       unique_grads[i] = torch.from_numpy(acc[key])
+
+  def emb_owner_ids(self, recv_keys, counts, n_runs, peer_cap, key_sub, ids):
+    for q in range(n_runs):
+      c = int(counts[q])
+      seg = slice(q * peer_cap, (q + 1) * peer_cap)
+      ids[seg] = -1
+      ids[q * peer_cap:q * peer_cap + c] = recv_keys[q * peer_cap:q * peer_cap + c].to(torch.int64) - int(key_sub)
+
+  def emb_owner_merge_padded(self, group, counts, n_runs, peer_cap):
+    assert group['num_entries'] == n_runs * peer_cap and group.get('n_active', -1) < 0
 
   def gather_rows(self, table, keys, n, key_sub, out):
     rows = keys[:n].to(torch.int64) - int(key_sub)
@@ -449,7 +476,7 @@ class RefBackend(object):
   def emb_owner_serve(self, groups, rows_out, hyper):
     """The sorted form: de-duplicate the received rows, catch them up, gather."""
     for g, out in zip(groups, rows_out):
-      n = g['n_active']
+      n = g['n_active'] if g.get('n_active', -1) >= 0 else g['num_entries']
       if n == 0:
         continue
       if g.get('last_step') is not None:
@@ -458,7 +485,8 @@ class RefBackend(object):
         self.emb_route(g, uk, nu, None, None)
         self.emb_catch_up(g, uk, nu, hyper)
       spec = g['specs'][0]
-      out[:n] = g['var'][spec.key_base + spec.ids[:n]]
+      ok = spec.ids[:n] >= 0  # (padding of the fixed-capacity exchange)
+      out[:n][ok] = g['var'].detach()[spec.key_base + spec.ids[:n][ok]]
 
   def emb_bwd_reduce_dense(self, groups, dense):
     for g, d in zip(groups, dense):  # the two-step form: de-duplicated rows, then the scatter

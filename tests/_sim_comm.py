@@ -71,6 +71,13 @@ class ThreadSimComm(object):
       pos += n
     self.sim.barrier.wait()
 
+  def all_to_all_equal(self, send, recv):
+    n = send.shape[0] // self.world
+    allp = self._publish(send)
+    for src in range(self.world):
+      recv[src * n:(src + 1) * n].copy_(allp[src][self.rank * n:(self.rank + 1) * n])
+    self.sim.barrier.wait()
+
   def all_reduce_sum(self, t):
     allt = self._publish(t)
     total = allt[0].clone()

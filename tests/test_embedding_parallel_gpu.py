@@ -101,11 +101,14 @@ def test_routing_kernels_against_numpy(W, B, rows):
   hip.emb_group_destroy(g)
 
 
-@pytest.mark.parametrize('world,lazy', [(1, False), (2, False), (4, True)])
-def test_sharded_ranks_with_the_same_batch_equal_single_gpu(world, lazy):
+@pytest.mark.parametrize('world,lazy,padded', [(1, False, True), (2, False, True), (4, True, True), (2, True, False),
+                                               (3, False, False)])
+def test_sharded_ranks_with_the_same_batch_equal_single_gpu(world, lazy, padded, monkeypatch):
   """Every rank sees the SAME batch: each embedding row gets world * g / world and each dense gradient
   the average of identical gradients, so the W-rank run must follow the single-GPU run (to the fp32
   noise of the GEMM library between runs)."""
+  # padded: the fixed-capacity exchange (no host sync); else the compact one with host-side split sizes
+  monkeypatch.setenv('EASYREC_AMD_PADDED_EXCHANGE', '1' if padded else '0')
   cfg = _cfg('deepfm_criteo_small.config', lazy)
   B, steps = 128, 2
   gen = SyntheticCriteo(cfg.data_config, list(cfg.feature_config.features), batch_size=B, seed=9)
@@ -126,6 +129,7 @@ def test_sharded_ranks_with_the_same_batch_equal_single_gpu(world, lazy):
     for b in batches:
       est.train_step(b)
       losses.append(est.loss_values())
+    assert est.engine.padded == padded
     return est.state_dict(slots=True), losses, dict(est.engine.placement)
 
   results = sim.run(rank_fn)
