@@ -42,20 +42,23 @@ def parse_args():
   ap.add_argument('--force_ep', action='store_true', help='run the embedding-parallel code path even at 1 GPU')
   ap.add_argument('--overlap', action='store_true', help='TF-exact Adam: dense-decay sweep on a second stream (measured slower)')
   ap.add_argument('--cpu_seconds', type=float, default=12.0, help='time budget of the CPU baseline sample')
+  ap.add_argument('--rccl', action='store_true',
+                  help='with --force_ep at 1 GPU: issue the collectives through a world-1 RCCL process group (not local copies)')
   ap.add_argument('--ring', type=int, default=16, help='distinct pre-generated batches kept on device')
   return ap.parse_args()
 
 
-def dist_setup(n_gpus):
+def dist_setup(n_gpus, rccl_world1=False):
   import torch.distributed as dist
   rank = int(os.environ.get('RANK', '0'))
   world = int(os.environ.get('WORLD_SIZE', '1'))
   local = int(os.environ.get('LOCAL_RANK', '0'))
   assert world == n_gpus or world == 1 and n_gpus == 1, 'WORLD_SIZE %d != --gpus %d' % (world, n_gpus)
   torch.cuda.set_device(local)
-  if world > 1:
+  if world > 1 or rccl_world1:
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29533')
     dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
   return rank, world, local
 
@@ -215,7 +218,7 @@ def cpu_baseline(cfg, est_state, batches, batch_size, budget_s=12.0, max_steps=8
 def main():
   args = parse_args()
   logging.disable(logging.WARNING)
-  rank, world, local = dist_setup(args.gpus)
+  rank, world, local = dist_setup(args.gpus, args.rccl and args.force_ep)
   dev = torch.device('cuda', local)
   from easyrec_amd import kernels
   from easyrec_amd.input.criteo_synthetic import SyntheticCriteo
@@ -228,7 +231,11 @@ def main():
   B = args.batch_size or cfg.data_config.batch_size
   if world > 1 or args.force_ep:
     from easyrec_amd.model.embedding_parallel import EmbeddingParallelEstimator
-    est = EmbeddingParallelEstimator(cfg, device=dev, batch_size=B, seed=1, rank=rank, world=world,
+    comm = None
+    if args.rccl and world == 1:
+      from easyrec_amd.core.comm import TorchDistComm
+      comm = TorchDistComm()
+    est = EmbeddingParallelEstimator(cfg, device=dev, batch_size=B, seed=1, rank=rank, world=world, comm=comm,
                                      dense_sweep=args.dense_sweep).build()
   else:
     est = EasyRecEstimator(cfg, device=dev, batch_size=B, seed=1, overlap_sweep=args.overlap,
@@ -300,7 +307,9 @@ def main():
                                            else ' (lazy dense decay, bit-identical)' if est.opt_emb.name == 'adam_optimizer' else ''),
                        args.ids, graph_note),
           'global_batch': world * B,
-          'parallelism': 'single GPU' if world == 1 else 'embedding-parallel x%d (row-sharded tables, RCCL all-to-all) + dense DP' % world,
+          'parallelism': ('embedding-parallel x%d (row-sharded tables, RCCL all-to-all) + dense DP' % world if world > 1 else
+                          'single GPU' if not ep else 'single GPU through the embedding-parallel code path (%s)' %
+                          ('world-1 RCCL process group' if args.rccl else 'local copies for the collectives')),
       },
       'final_loss': losses.get('total_loss'),
       'device': kernels.hip().device_info(),

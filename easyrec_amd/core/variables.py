@@ -125,8 +125,9 @@ class VarStore(object):
   def trainable_names(self):
     return [n for n, r in self._vars.items() if r['trainable']]
 
-  def pack(self):
-    """Move every trainable variable into one flat buffer (+ grads + L2 coefficients)."""
+  def pack(self, extra_grad_floats=0):
+    """Move every trainable variable into one flat buffer (+ grads + L2 coefficients).  extra_grad_floats: room
+    behind the gradients (`grad_tail`) for gradients that are zeroed and all-reduced with them (`flat_grad_all`)."""
     assert not self.packed
     names = self.trainable_names()
     total, off = 0, {}
@@ -136,7 +137,9 @@ class VarStore(object):
       total += (numel + 3) // 4 * 4  # keep every view 16-byte aligned
     total = max(total, 4)
     self.flat = torch.zeros(total, dtype=torch.float32, device=self.device)
-    self.flat_grad = torch.zeros(total, dtype=torch.float32, device=self.device)
+    self.flat_grad_all = torch.zeros(total + int(extra_grad_floats), dtype=torch.float32, device=self.device)
+    self.flat_grad = self.flat_grad_all[:total]
+    self.grad_tail = self.flat_grad_all[total:]
     self.l2coef = torch.zeros(total, dtype=torch.float32, device=self.device)
     for n in names:
       rec = self._vars[n]
@@ -158,7 +161,7 @@ class VarStore(object):
     return self.slots[name]
 
   def zero_grad(self):
-    self.flat_grad.zero_()
+    self.flat_grad_all.zero_()
 
   def check_grad_views(self):
     """Autograd must have accumulated in place into the flat gradient buffer."""

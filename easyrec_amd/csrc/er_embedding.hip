@@ -979,7 +979,7 @@ emb_route_seg_routed_kernel(const uint32_t* __restrict__ skeys, const uint32_t* 
                             const int64_t* __restrict__ ent_base, const uint32_t* __restrict__ seg_count, int n_lookups,
                             int world, uint32_t stride, uint32_t* __restrict__ unique_keys, int64_t* __restrict__ uidx,
                             int32_t* __restrict__ n_unique, int32_t* __restrict__ owner_counts, uint32_t peer_cap,
-                            int32_t* __restrict__ overflow) {
+                            uint32_t peer_hdr, int32_t* __restrict__ overflow) {
   __shared__ uint32_t s_total[64], s_before[64], s_row[64], s_obase[64], s_lbase[64];
   const int l = blockIdx.y;
   const int tid = threadIdx.x;
@@ -1012,7 +1012,11 @@ emb_route_seg_routed_kernel(const uint32_t* __restrict__ skeys, const uint32_t* 
     }
   }
   __syncthreads();
-  if (l == n_lookups - 1 && blockIdx.x == 0 && owner_counts && tid < world) owner_counts[tid] = static_cast<int32_t>(s_total[tid]);
+  if (l == n_lookups - 1 && blockIdx.x == 0 && tid < world) {
+    if (owner_counts) owner_counts[tid] = static_cast<int32_t>(s_total[tid]);
+    // padded with a header: the count travels in front of the owner's keys (one all-to-all for both)
+    if (peer_hdr) unique_keys[static_cast<uint32_t>(tid) * (peer_cap + 1u)] = s_total[tid];
+  }
   const int64_t base = ent_base[l];
   const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + tid;
   if (i >= ent_base[l + 1] - base) return;
@@ -1032,7 +1036,7 @@ emb_route_seg_routed_kernel(const uint32_t* __restrict__ skeys, const uint32_t* 
   const uint32_t u = s_obase[w] + r;
   head_index[p] = u + 1u - f;
   if (uidx) uidx[j] = fits ? static_cast<int64_t>(u) : -1;
-  if (f && fits) unique_keys[u] = key;
+  if (f && fits) unique_keys[peer_hdr ? w * (peer_cap + 1u) + 1u + r : u] = key;
 }
 
 // Second half of the fused route of the segmented path: add the distinct-key counts of the lookups before this one
@@ -1185,12 +1189,16 @@ emb_owner_merge_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __r
 // synchronisation): run q occupies [q * cap, q * cap + counts[q]) of the received buffer, counts on the device.
 // Entries past a run's count are padding: they get the invalid key and the positions after the N real ones.
 __global__ void __launch_bounds__(kBlock)
-emb_owner_ids_kernel(const uint32_t* __restrict__ keys, const int32_t* __restrict__ counts, int n_runs, int cap,
-                     int64_t key_sub, int64_t* __restrict__ ids) {
+emb_owner_ids_kernel(const uint32_t* __restrict__ keys, const int32_t* __restrict__ counts, int n_runs, int cap, int hdr,
+                     int64_t key_sub, int64_t* __restrict__ ids, int32_t* __restrict__ counts_out) {
   const int i = static_cast<int>(blockIdx.x) * kBlock + threadIdx.x;
   if (i >= n_runs * cap) return;
-  const int q = i / cap;
-  ids[i] = (i - q * cap) < counts[q] ? static_cast<int64_t>(keys[i]) - key_sub : -1;
+  const int q = i / cap, j = i - q * cap;
+  // hdr: run q arrives as [count, keys ...] in cap + 1 slots; else the counts came in their own array
+  const uint32_t* run = keys + static_cast<int64_t>(q) * (cap + hdr);
+  const int cnt = hdr ? static_cast<int>(run[0]) : counts[q];
+  ids[i] = j < cnt ? static_cast<int64_t>(run[hdr + j]) - key_sub : -1;
+  if (j == 0 && counts_out) counts_out[q] = cnt;
 }
 
 __global__ void __launch_bounds__(kBlock)
@@ -1567,6 +1575,7 @@ struct er_emb_group {
   int seg_caps_pow2 = 0;          // padded per-lookup size if every lookup has at most kSegSortMax entries
   bool seg_routed = false;        // routed keys (er_emb_group_set_routing) keep per-lookup disjoint, increasing ranges
   bool seg_routed_narrow = false;
+  int peer_hdr = 0;               // 1: the keys of owner w are preceded by their count, in peer_cap + 1 slots
   int64_t peer_cap = 0;           // > 0: er_emb_route writes owner w's keys at [w * peer_cap, ...) (padded exchange)
   int32_t* d_overflow = nullptr;  // set to 1 by er_emb_route when an owner's keys exceed peer_cap
   uint64_t merged_epoch = ~0ull;  // sort_epoch of the last er_emb_owner_merge (head_flags hold its run heads)
@@ -2332,7 +2341,8 @@ int er_emb_route(er_emb_group* g, uint32_t* unique_keys, int32_t* n_unique, int6
         hipLaunchKernelGGL(er::emb_route_seg_routed_kernel, grid, dim3(er::kBlock), 0, s, g->keys_out, g->vals_out,
                            g->head_flags, g->head_index, g->d_ent_base, g->seg_count, g->n, g->world,
                            static_cast<uint32_t>(g->shard_stride), unique_keys, entry_unique_index, n_unique,
-                           owner_counts, static_cast<uint32_t>(g->peer_cap), g->d_overflow);
+                           owner_counts, static_cast<uint32_t>(g->peer_cap), static_cast<uint32_t>(g->peer_hdr),
+                           g->d_overflow);
         counts_done = true;
       } else {
         dim3 grid(static_cast<unsigned>(er::ceil_div(g->seg_sort_pow2, er::kBlock)), static_cast<unsigned>(g->n));
@@ -2419,8 +2429,8 @@ int er_emb_owner_merge(er_emb_group* g, const int32_t* run_counts, int n_runs, e
   return 0;
 }
 
-int er_emb_group_set_peer_capacity(er_emb_group* g, int64_t peer_cap) {
-  ER_REQUIRE(g && peer_cap >= 0, "er_emb_group_set_peer_capacity: bad arguments");
+int er_emb_group_set_peer_capacity(er_emb_group* g, int64_t peer_cap, int32_t count_header) {
+  ER_REQUIRE(g && peer_cap >= 0 && (count_header == 0 || count_header == 1), "er_emb_group_set_peer_capacity: bad arguments");
   if (peer_cap > 0) {
     ER_REQUIRE(g->d_local_base && g->seg_routed, "er_emb_group_set_peer_capacity: needs er_emb_group_set_routing with "
                "lookups the per-lookup sort covers (one table per lookup, <= %d entries each)", er::kSegSortMax);
@@ -2431,6 +2441,7 @@ int er_emb_group_set_peer_capacity(er_emb_group* g, int64_t peer_cap) {
     }
   }
   g->peer_cap = peer_cap;
+  g->peer_hdr = peer_cap > 0 ? count_header : 0;
   return 0;
 }
 
@@ -2442,12 +2453,13 @@ int er_emb_route_overflow(er_emb_group* g, int32_t* overflow_host) {
 }
 
 int er_emb_owner_ids(const uint32_t* recv_keys, const int32_t* counts, int n_runs, int64_t peer_cap, int64_t key_sub,
-                     int64_t* ids, er_stream_t stream) {
-  ER_REQUIRE(recv_keys && counts && ids && n_runs >= 1 && peer_cap > 0 && n_runs * peer_cap < 0x7FFFFFFFLL,
-             "er_emb_owner_ids: bad arguments");
+                     int64_t* ids, int32_t* counts_out, er_stream_t stream) {
+  ER_REQUIRE(recv_keys && ids && (counts || counts_out) && n_runs >= 1 && peer_cap > 0 &&
+             n_runs * (peer_cap + 1) < 0x7FFFFFFFLL, "er_emb_owner_ids: bad arguments");
   const int64_t n = n_runs * peer_cap;
   hipLaunchKernelGGL(er::emb_owner_ids_kernel, dim3(static_cast<unsigned>(er::ceil_div(n, er::kBlock))), dim3(er::kBlock), 0,
-                     er::as_stream(stream), recv_keys, counts, n_runs, static_cast<int>(peer_cap), key_sub, ids);
+                     er::as_stream(stream), recv_keys, counts, n_runs, static_cast<int>(peer_cap), counts ? 0 : 1, key_sub,
+                     ids, counts_out);
   ER_LAUNCH_CHECK();
   return 0;
 }

@@ -515,21 +515,26 @@ class HipBackend(object):
     rc = (ctypes.c_int32 * n)(*[int(x) for x in run_counts])
     self._ck(self.lib.er_emb_owner_merge(group['handle'], rc, n, _stream()), 'er_emb_owner_merge')
 
-  def emb_group_set_peer_capacity(self, group, peer_cap):
-    self._ck(self.lib.er_emb_group_set_peer_capacity(group['handle'], ctypes.c_int64(int(peer_cap))),
+  def emb_group_set_peer_capacity(self, group, peer_cap, count_header=True):
+    self._ck(self.lib.er_emb_group_set_peer_capacity(group['handle'], ctypes.c_int64(int(peer_cap)),
+                                                     ctypes.c_int32(1 if count_header else 0)),
              'er_emb_group_set_peer_capacity')
-    group['peer_cap'] = int(peer_cap)
+    group['peer_cap'], group['peer_hdr'] = int(peer_cap), bool(count_header)
 
   def emb_route_overflow(self, group):
     out = ctypes.c_int32(0)
     self._ck(self.lib.er_emb_route_overflow(group['handle'], ctypes.byref(out)), 'er_emb_route_overflow')
     return bool(out.value)
 
-  def emb_owner_ids(self, recv_keys, counts, n_runs, peer_cap, key_sub, ids):
-    assert recv_keys.dtype == torch.int32 and counts.dtype == torch.int32 and ids.dtype == torch.int64
-    assert recv_keys.numel() >= n_runs * peer_cap and ids.numel() >= n_runs * peer_cap and counts.numel() >= n_runs
-    self._ck(self.lib.er_emb_owner_ids(_p(recv_keys), _p(counts), ctypes.c_int(n_runs), ctypes.c_int64(int(peer_cap)),
-                                       ctypes.c_int64(int(key_sub)), _p(ids), _stream()), 'er_emb_owner_ids')
+  def emb_owner_ids(self, recv_keys, counts, n_runs, peer_cap, key_sub, ids, counts_out):
+    """counts None: the received runs carry their count in front ([count, keys ...], peer_cap + 1 slots each)."""
+    hdr = 1 if counts is None else 0
+    assert recv_keys.dtype == torch.int32 and ids.dtype == torch.int64 and counts_out.dtype == torch.int32
+    assert recv_keys.numel() >= n_runs * (peer_cap + hdr) and ids.numel() >= n_runs * peer_cap and counts_out.numel() >= n_runs
+    assert counts is None or (counts.dtype == torch.int32 and counts.numel() >= n_runs)
+    self._ck(self.lib.er_emb_owner_ids(_p(recv_keys), None if counts is None else _p(counts), ctypes.c_int(n_runs),
+                                       ctypes.c_int64(int(peer_cap)), ctypes.c_int64(int(key_sub)), _p(ids), _p(counts_out),
+                                       _stream()), 'er_emb_owner_ids')
 
   def emb_owner_merge_padded(self, group, counts, n_runs, peer_cap):
     assert counts.dtype == torch.int32 and counts.numel() >= n_runs

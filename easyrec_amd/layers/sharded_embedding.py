@@ -121,12 +121,8 @@ class ShardedEmbeddingEngine(EmbeddingEngine):
     # one flat buffer behind the replicated halves' dense gradients: ONE all-reduce per step
     if self.rep:
       sizes = [(dim, r['st']['total_rows'] * (dim + 1)) for dim, r in self.rep.items()]
-      self.rep_flat = torch.zeros(sum(n for _, n in sizes), dtype=torch.float32, device=dev)
-      off = 0
-      for dim, n in sizes:
-        r = self.rep[dim]
-        r['dense'] = self.rep_flat[off:off + n].view(r['st']['total_rows'], dim + 1)
-        off += n
+      self._rep_sizes = sizes
+      self.set_rep_flat(torch.zeros(sum(n for _, n in sizes), dtype=torch.float32, device=dev), own=True)
     self.counts_dev = torch.zeros(max(len(self.shard), 1), W, dtype=torch.int32, device=dev)
     self.lazy_decay = self.lazy_decay and opt_kind == kernels.OPT_ADAM
     self.finalized = True
@@ -138,6 +134,17 @@ class ShardedEmbeddingEngine(EmbeddingEngine):
     caps = [(lk['max_nnz'] if lk['offsets'] is not None else lk['n_rows']) for lk in lookups]
     bases = [lk['base'] for lk in lookups]
     return max(caps) <= 8192 and len(set(lk['tname'] for lk in lookups)) == len(lookups) and bases == sorted(bases)
+
+  def set_rep_flat(self, buf, own=False):
+    """The dense gradient buffer of the replicated tables.  own=False: it is the tail of the dense variables' flat
+    gradient buffer - zeroed and all-reduced together with it (one collective instead of two)."""
+    assert buf.numel() == sum(n for _, n in self._rep_sizes) and buf.is_contiguous()
+    self.rep_flat, self.rep_flat_own = buf, own
+    off = 0
+    for dim, n in self._rep_sizes:
+      r = self.rep[dim]
+      r['dense'] = buf[off:off + n].view(r['st']['total_rows'], dim + 1)
+      off += n
 
   def _build_shard_half(self, dim, lookups, fwd_specs, opt_kind):
     be = kernels.hip()
@@ -185,10 +192,10 @@ class ShardedEmbeddingEngine(EmbeddingEngine):
         sh[k] = lead[k]
     else:
       sh.update(
-          ukeys=torch.zeros(n_slots, dtype=torch.int32, device=dev),
+          ukeys=torch.zeros(n_slots + (W if padded else 0), dtype=torch.int32, device=dev),  # padded: [count, keys] x W
           n_unique=torch.zeros(1, dtype=torch.int32, device=dev),
           uidx=torch.full((n_ent,), -1, dtype=torch.int64, device=dev),
-          recv_keys=torch.zeros(m_cap, dtype=torch.int32, device=dev),
+          recv_keys=torch.zeros(m_cap + (W if padded else 0), dtype=torch.int32, device=dev),
           recv_ids=torch.full((m_cap,), -1, dtype=torch.int64, device=dev),
           recv_cnt=torch.zeros(W, dtype=torch.int32, device=dev))
     req_specs, off = [], 0
@@ -211,7 +218,7 @@ class ShardedEmbeddingEngine(EmbeddingEngine):
     assert sh['req']['num_entries'] == n_ent
     be.emb_group_set_routing(sh['req'], W, sh['stride'], [lk['base'] for lk in lookups])
     if padded and lead is None:
-      be.emb_group_set_peer_capacity(sh['req'], peer_cap)
+      be.emb_group_set_peer_capacity(sh['req'], peer_cap, count_header=True)
     if lead is not None:
       assert be.emb_group_share_sort(sh['req'], lead['req']), 'dim %d: cannot follow the route of dim %d' % (dim, lead_dim)
     st = sh['st']
@@ -273,8 +280,7 @@ class ShardedEmbeddingEngine(EmbeddingEngine):
   def exchange_keys(self):
     comm = self.comm
     for gi, (dim, sh) in enumerate(self.shard.items()):
-      if sh['leader'] is None:
-        comm.all_to_all_equal(self.counts_dev[gi], sh['recv_cnt'])
+      if sh['leader'] is None:  # per owner [count, keys ...]: the counts ride with the keys
         comm.all_to_all_equal(sh['ukeys'], sh['recv_keys'])
 
   def owner_serve(self):
@@ -283,7 +289,7 @@ class ShardedEmbeddingEngine(EmbeddingEngine):
     shs = list(self.shard.values())
     for sh in shs:
       if sh['leader'] is None:
-        be.emb_owner_ids(sh['recv_keys'], sh['recv_cnt'], W, sh['peer_cap'], self.rank * sh['stride'], sh['recv_ids'])
+        be.emb_owner_ids(sh['recv_keys'], None, W, sh['peer_cap'], self.rank * sh['stride'], sh['recv_ids'], sh['recv_cnt'])
         be.emb_owner_merge_padded(sh['owner'], sh['recv_cnt'], W, sh['peer_cap'])
     hyper = self._clock[2] if any(sh['lazy'] is not None for sh in shs) else None
     for i in range(0, len(shs), 4):
@@ -294,7 +300,7 @@ class ShardedEmbeddingEngine(EmbeddingEngine):
       self.comm.all_to_all_equal(sh['rows_out'], sh['recv_rows'])
 
   def exchange_grads(self):
-    if self.rep:
+    if self.rep and self.rep_flat_own:
       self.comm.all_reduce_sum(self.rep_flat)
     for sh in self.shard.values():
       self.comm.all_to_all_equal(sh['ugrads'], sh['recv_grads'])
@@ -383,7 +389,8 @@ class ShardedEmbeddingEngine(EmbeddingEngine):
         g['dout'].zero_()
     if self.rep:
       # replicated tables: the per-row gradient sums go straight into the dense buffer that is all-reduced
-      self.rep_flat.zero_()
+      if self.rep_flat_own:
+        self.rep_flat.zero_()
       reps = list(self.rep.values())
       for i in range(0, len(reps), 4):
         be.emb_bwd_reduce_dense([r['group'] for r in reps[i:i + 4]], [r['dense'] for r in reps[i:i + 4]])
@@ -396,7 +403,7 @@ class ShardedEmbeddingEngine(EmbeddingEngine):
       self.exchange_grads()
       self.owner_update(opt_kind, hyper)
       return
-    if self.rep:
+    if self.rep and self.rep_flat_own:
       comm.all_reduce_sum(self.rep_flat)
     for dim, sh in self.shard.items():
       comm.all_to_all(sh['ugrads'], sh['send_counts'], sh['recv_grads'], sh['recv_counts'])

@@ -140,7 +140,8 @@ class EasyRecEstimator(object):
     if self.opt_emb.kind == kernels.OPT_ADAGRAD:
       for st in self.engine.storage.values():
         st['v'].fill_(getattr(self.opt_emb, 'initial_accumulator_value', 0.1))
-    self.varstore.pack()
+    self.varstore.pack(self._extra_grad_floats())
+    self._after_pack()
     if self.opt_dense.kind in (kernels.OPT_ADAM, kernels.OPT_LAZY_ADAM):
       self.varstore.slot('m')
       self.varstore.slot('v')
@@ -148,6 +149,12 @@ class EasyRecEstimator(object):
       self.varstore.slot('v').fill_(getattr(self.opt_dense, 'initial_accumulator_value', 0.1))
     self._built = True
     return self
+
+  def _extra_grad_floats(self):
+    return 0
+
+  def _after_pack(self):
+    pass
 
   # -- one step
   def _plan_hyper(self, count):

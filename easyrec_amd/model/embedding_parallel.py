@@ -53,9 +53,18 @@ class EmbeddingParallelEstimator(EasyRecEstimator):
   def _dense_grad_scale(self):
     return 1.0 / float(self.world)  # hvd.allreduce(op=Average)
 
+  # the replicated small tables' dense gradient buffer lives behind the dense variables' gradients: zeroed by the
+  # same fill and summed over the ranks by the same all-reduce
+  def _extra_grad_floats(self):
+    return self.engine.rep_flat.numel() if self.engine.rep else 0
+
+  def _after_pack(self):
+    if self.engine.rep:
+      self.engine.set_rep_flat(self.varstore.grad_tail)
+
   def _sync_dense_grads(self):
-    if self.world > 1:
-      self.comm.all_reduce_sum(self.varstore.flat_grad)
+    if self.world > 1 or not isinstance(self.comm, LocalComm):
+      self.comm.all_reduce_sum(self.varstore.flat_grad_all)
 
   # -- the step in phases: static device work (capturable) around the data-dependent exchanges
   def _phase_route(self):

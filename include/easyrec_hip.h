@@ -509,17 +509,21 @@ int er_emb_owner_merge(er_emb_group* group, const int32_t* run_counts_host, int 
 /* The same exchange with NO host-visible sizes (no host synchronisation in the step; every launch is static, so
  * the segments between the collectives replay as hipGraphs and the host runs ahead of the device):
  *   er_emb_group_set_peer_capacity: on a routed requester group: er_emb_route then writes the keys of owner w at
- *     unique_keys[w * peer_cap ...] (entry_unique_index points into that padded layout), so keys, rows and row
- *     gradients travel in equal-split all-to-alls of peer_cap elements per peer; the counts travel as their own
- *     [world] int32 all-to-all.  An owner with more than peer_cap keys sets a device flag read back by
- *     er_emb_route_overflow (a blocking copy: poll it off the critical path); that step's results are void.
- *   er_emb_owner_ids: ids[q * peer_cap + j] = recv_keys[...] - key_sub for j < counts[q], else -1 (padding).
+ *     unique_keys[w * peer_cap ...] and entry_unique_index points into that padded layout (rows and row gradients
+ *     of owner w at [w * peer_cap, ...)), so keys, rows and row gradients travel in equal-split all-to-alls.
+ *     count_header = 1: owner w's segment of unique_keys is peer_cap + 1 slots, [count, keys ...] - the counts ride
+ *     in the key all-to-all; 0: they travel as their own [world] int32 all-to-all (owner_counts).  An owner with
+ *     more than peer_cap keys sets a device flag read back by er_emb_route_overflow (a blocking copy: poll it off
+ *     the critical path); that step's results are void.
+ *   er_emb_owner_ids: ids[q * peer_cap + j] = key j of run q - key_sub for j < count[q], else -1 (padding).
+ *     counts != NULL: keys at recv_keys[q * peer_cap + j]; counts == NULL: the header form, run q =
+ *     recv_keys[q * (peer_cap + 1)] = count, then keys.  counts_out (may be NULL) receives the counts either way.
  *   er_emb_owner_merge_padded: er_emb_owner_merge for runs at q * peer_cap with device-side lengths, on a group
  *     whose lookup spans all n_runs * peer_cap received slots; padding sorts behind the real keys. */
-int er_emb_group_set_peer_capacity(er_emb_group* group, int64_t peer_cap);
+int er_emb_group_set_peer_capacity(er_emb_group* group, int64_t peer_cap, int32_t count_header);
 int er_emb_route_overflow(er_emb_group* group, int32_t* overflow_host);
 int er_emb_owner_ids(const uint32_t* recv_keys, const int32_t* counts, int n_runs, int64_t peer_cap, int64_t key_sub,
-                     int64_t* ids, er_stream_t stream);
+                     int64_t* ids, int32_t* counts_out, er_stream_t stream);
 int er_emb_owner_merge_padded(er_emb_group* group, const int32_t* counts, int n_runs, int64_t peer_cap,
                               er_stream_t stream);
 int er_emb_owner_serve(er_emb_group* const* groups_host, float* const* rows_out_host, int n,

@@ -403,8 +403,8 @@ class RefBackend(object):
     group['sort_leader'] = leader
     return True
 
-  def emb_group_set_peer_capacity(self, group, peer_cap):
-    group['peer_cap'], group['overflow'] = int(peer_cap), False
+  def emb_group_set_peer_capacity(self, group, peer_cap, count_header=True):
+    group['peer_cap'], group['peer_hdr'], group['overflow'] = int(peer_cap), bool(count_header), False
 
   def emb_route_overflow(self, group):
     return bool(group.get('overflow', False))
@@ -434,12 +434,17 @@ class RefBackend(object):
       entry_unique_index.fill_(-1)
       for key, j, _, _, _ in ents:
         entry_unique_index[j] = pos.get(key, -1)
-    for k, i in pos.items():
-      unique_keys[i] = k
+    hdr = 1 if (cap and group.get('peer_hdr')) else 0
+    per_owner = [sum(1 for k in keys if w * stride <= k < (w + 1) * stride) for w in range(W)]
+    for k, i in pos.items():  # (i = the row slot; with a header the key sits 1 + owner slots further)
+      unique_keys[i + (i // cap + 1 if hdr else 0)] = k
+    if hdr:
+      for w in range(W):
+        unique_keys[w * (cap + 1)] = per_owner[w]
     n_unique[0] = len(keys)
     if owner_counts is not None:
       for w in range(W):
-        owner_counts[w] = sum(1 for k in keys if w * stride <= k < (w + 1) * stride)
+        owner_counts[w] = per_owner[w]
     group['_route_keys'], group['_route_pos'] = keys, pos
 
   def emb_bwd_reduce_routed(self, group, unique_grads):
@@ -450,12 +455,14 @@ class RefBackend(object):
     for key, i in group['_route_pos'].items():
       unique_grads[i] = torch.from_numpy(acc[key])
 
-  def emb_owner_ids(self, recv_keys, counts, n_runs, peer_cap, key_sub, ids):
+  def emb_owner_ids(self, recv_keys, counts, n_runs, peer_cap, key_sub, ids, counts_out):
+    hdr = 1 if counts is None else 0
     for q in range(n_runs):
-      c = int(counts[q])
-      seg = slice(q * peer_cap, (q + 1) * peer_cap)
-      ids[seg] = -1
-      ids[q * peer_cap:q * peer_cap + c] = recv_keys[q * peer_cap:q * peer_cap + c].to(torch.int64) - int(key_sub)
+      b = q * (peer_cap + hdr)
+      c = int(recv_keys[b]) if hdr else int(counts[q])
+      ids[q * peer_cap:(q + 1) * peer_cap] = -1
+      ids[q * peer_cap:q * peer_cap + c] = recv_keys[b + hdr:b + hdr + c].to(torch.int64) - int(key_sub)
+      counts_out[q] = c
 
   def emb_owner_merge_padded(self, group, counts, n_runs, peer_cap):
     assert group['num_entries'] == n_runs * peer_cap and group.get('n_active', -1) < 0

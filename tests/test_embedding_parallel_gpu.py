@@ -222,3 +222,105 @@ def test_owner_merge_and_serve_against_the_sorted_form(counts):
   assert np.allclose(v16.cpu().numpy(), want, rtol=1e-5, atol=1e-6)
   for g, _ in made[0] + made[1]:
     hip.emb_group_destroy(g)
+
+
+@pytest.mark.parametrize('header', [True, False])
+def test_fixed_capacity_route_and_owner_side_against_numpy(header):
+  """er_emb_group_set_peer_capacity: owner w's keys at [w * C, ...) (behind their count with a header), the entry
+  index and the reduced gradients in the same padded row layout; er_emb_owner_ids + er_emb_owner_merge_padded +
+  er_emb_owner_serve on such a buffer (as if every peer had sent this rank's buffer) against numpy; an owner with more
+  keys than C raises the overflow flag."""
+  hip = kernels.hip()
+  rng = np.random.default_rng(17)
+  W, B, dim, rows = 4, 600, 16, [3001, 37, 1]
+  T = len(rows)
+  shard_rows = [(r + W - 1) // W for r in rows]
+  local_base = [int(x) for x in np.concatenate([[0], np.cumsum(shard_rows)[:-1]])]
+  stride = sum(shard_rows)
+  ids = [rng.integers(-1, r, size=B).astype(np.int64) for r in rows]
+  dout = torch.from_numpy((rng.standard_normal((B, T * dim)) * 0.1).astype(np.float32)).to(DEV)
+  dummy = torch.zeros(T * B, dim, device=DEV)
+  specs = [kernels.LookupSpec(table=dummy, ids=torch.from_numpy(ids[t]).to(DEV), offsets=None, weights=None, out=dout,
+                              out_col=t * dim, rows=rows[t], key_base=0, dim=dim, combiner=0, n_rows=B, max_nnz=B)
+           for t in range(T)]
+  keys = np.full(T * B, -1, dtype=np.int64)
+  for t in range(T):
+    ok = ids[t] >= 0
+    keys[t * B:(t + 1) * B][ok] = (ids[t][ok] % W) * stride + local_base[t] + ids[t][ok] // W
+  uniq = np.unique(keys[keys >= 0])
+  per_owner = [uniq[(uniq // stride) == w] for w in range(W)]
+  C = max(len(p) for p in per_owner) + 5
+  hdr = 1 if header else 0
+  g = hip.emb_group_create(specs, dim, max(rows + [W * C]), dummy, None, None, None)
+  hip.emb_group_set_routing(g, W, stride, local_base)
+  hip.emb_group_set_peer_capacity(g, C, count_header=header)
+  ukeys = torch.full((W * (C + hdr),), -7, dtype=torch.int32, device=DEV)
+  nu = torch.zeros(1, dtype=torch.int32, device=DEV)
+  uidx = torch.zeros(T * B, dtype=torch.int64, device=DEV)
+  counts = torch.zeros(W, dtype=torch.int32, device=DEV)
+  hip.emb_route(g, ukeys, nu, uidx, counts)
+  ugrads = torch.zeros(W * C, dim, device=DEV)
+  hip.emb_bwd_reduce_routed(g, ugrads)
+  torch.cuda.synchronize()
+  assert not hip.emb_route_overflow(g)
+  uk = ukeys.cpu().numpy().astype(np.int64)
+  slot = {}
+  for w in range(W):
+    seg = uk[w * (C + hdr):(w + 1) * (C + hdr)]
+    if header:
+      assert seg[0] == len(per_owner[w])
+    assert np.array_equal(seg[hdr:hdr + len(per_owner[w])], per_owner[w])
+    for r, k in enumerate(per_owner[w]):
+      slot[int(k)] = w * C + r
+  assert np.array_equal(counts.cpu().numpy(), [len(p) for p in per_owner]) and int(nu.item()) == len(uniq)
+  exp_idx = np.array([slot[int(k)] if k >= 0 else -1 for k in keys])
+  assert np.array_equal(uidx.cpu().numpy(), exp_idx)
+  exp = np.zeros((W * C, dim), dtype=np.float64)
+  d = dout.cpu().numpy().astype(np.float64)
+  for t in range(T):
+    ok = keys[t * B:(t + 1) * B] >= 0
+    np.add.at(exp, exp_idx[t * B:(t + 1) * B][ok], d[ok, t * dim:(t + 1) * dim])
+  got = ugrads.cpu().numpy()
+  used = sorted(slot.values())
+  assert np.allclose(got[used], exp[used], rtol=1e-5, atol=1e-6)
+  # owner side: pretend every peer sent this buffer's segment of owner 2 (so every key arrives W times)
+  me = 2
+  seg = ukeys[me * (C + hdr):(me + 1) * (C + hdr)]
+  recv = seg.repeat(W).contiguous()
+  cnt_in = None if header else torch.full((W,), len(per_owner[me]), dtype=torch.int32, device=DEV)
+  rids = torch.zeros(W * C, dtype=torch.int64, device=DEV)
+  rcnt = torch.zeros(W, dtype=torch.int32, device=DEV)
+  hip.emb_owner_ids(recv, cnt_in, W, C, me * stride, rids, rcnt)
+  table = torch.from_numpy(rng.standard_normal((stride, dim)).astype(np.float32)).to(DEV)
+  rgrads = torch.from_numpy(rng.standard_normal((W * C, dim)).astype(np.float32)).to(DEV)
+  var = table.clone()
+  ospec = kernels.LookupSpec(table=var, ids=rids, offsets=None, weights=None, out=rgrads, out_col=0, rows=stride, key_base=0,
+                             dim=dim, combiner=0, n_rows=W * C, max_nnz=W * C)
+  og = hip.emb_group_create([ospec], dim, stride, var, None, None, None)
+  hip.emb_owner_merge_padded(og, rcnt, W, C)
+  rows_out = torch.full((W * C, dim), 7.0, device=DEV)
+  hip.emb_owner_serve([og], [rows_out], None)
+  hyper = torch.zeros(16, dtype=torch.float32)
+  hyper[kernels.HYPER_LR], hyper[kernels.HYPER_GSCALE] = 0.1, 1.0
+  hip.emb_bwd_update(og, kernels.OPT_SGD, hyper.to(DEV))
+  torch.cuda.synchronize()
+  n_me = len(per_owner[me])
+  assert np.array_equal(rcnt.cpu().numpy(), [n_me] * W)
+  local = per_owner[me] - me * stride
+  exp_ids = np.full((W, C), -1, dtype=np.int64)
+  exp_ids[:, :n_me] = local
+  assert np.array_equal(rids.cpu().numpy().reshape(W, C), exp_ids)
+  ro = rows_out.cpu().numpy().reshape(W, C, dim)
+  assert np.array_equal(ro[:, :n_me], np.broadcast_to(table.cpu().numpy()[local], (W, n_me, dim)))
+  assert np.all(ro[:, n_me:] == 7.0)  # padding slots are not written
+  want = table.cpu().numpy().astype(np.float64)
+  gsum = rgrads.cpu().numpy().astype(np.float64).reshape(W, C, dim)[:, :n_me].sum(axis=0)
+  want[local] -= 0.1 * gsum
+  assert np.allclose(var.cpu().numpy(), want, rtol=1e-5, atol=1e-6)
+  # overflow: a capacity below the largest owner's count
+  hip.emb_group_set_peer_capacity(g, max(len(p) for p in per_owner) - 1, count_header=header)
+  hip.emb_route(g, ukeys, nu, uidx, counts)
+  torch.cuda.synchronize()
+  assert hip.emb_route_overflow(g)
+  hip.emb_group_destroy(g)
+  hip.emb_group_destroy(og)

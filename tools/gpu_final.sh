@@ -10,6 +10,7 @@ timeout 600 python bench.py --dense_sweep --no_cpu_baseline > $O/bench_sweep.log
 timeout 600 python bench.py --optimizer lazy_adam --no_cpu_baseline > $O/bench_lazy.log 2>&1; tail -1 $O/bench_lazy.log | cut -c1-300
 timeout 600 python bench.py --ids uniform --no_cpu_baseline > $O/bench_uniform.log 2>&1; tail -1 $O/bench_uniform.log | cut -c1-300
 timeout 600 python bench.py --force_ep --no_cpu_baseline > $O/bench_ep1.log 2>&1; tail -1 $O/bench_ep1.log | cut -c1-300
+timeout 600 python bench.py --force_ep --rccl --no_cpu_baseline > $O/bench_ep1_rccl.log 2>&1; tail -1 $O/bench_ep1_rccl.log | cut -c1-400
 timeout 900 rocprofv3 --kernel-trace --stats -f csv -d $O/prof -o bench -- python bench.py --steps 50 --warmup 10 --no_cpu_baseline > $O/prof.log 2>&1
 timeout 900 rocprofv3 --kernel-trace --stats -f csv -d $O/prof_sweep -o bench -- python bench.py --steps 50 --warmup 10 --no_cpu_baseline --dense_sweep > $O/prof_sweep.log 2>&1
 timeout 900 rocprofv3 --kernel-trace --stats -f csv -d $O/prof_ep1 -o bench -- python bench.py --steps 50 --warmup 10 --no_cpu_baseline --force_ep > $O/prof_ep1.log 2>&1
