@@ -79,7 +79,7 @@ emb_fwd_kernel(const er_lookup_desc* __restrict__ descs, const int32_t* __restri
     for (int64_t k = kb; k < ke; ++k) {
       const int64_t id = d.ids[k];
       if (id < 0 || id >= d.rows) continue;
-      const float* row = d.table + id * d.dim + c;
+      const float* row = d.table + id * (d.table_ld ? d.table_ld : d.dim) + c;
       if (d.weights) {
         const float w = d.weights[k];
         if (prune_nonpos && !(w > 0.f)) continue;
@@ -555,7 +555,7 @@ __device__ __forceinline__ void finish_run(const RowUpdate& tab, int opt_kind, c
     const uint32_t u = ro.head_index[p] + ro.flags[p] - 1u;
     if (sub == 0 && ro.out_keys) ro.out_keys[u] = key;
 #pragma unroll
-    for (int i = 0; i < V; ++i) ro.out_grads[static_cast<int64_t>(u) * dim + c + i] = g[i];
+    for (int i = 0; i < V; ++i) ro.out_grads[static_cast<int64_t>(u) * (ro.ld ? ro.ld : dim) + c + i] = g[i];
   }
 }
 
@@ -1252,8 +1252,8 @@ struct ServeArgs {
   int64_t n;
   RowUpdate tab;         // last_step == nullptr: no catch-up
   const float* lr_hist;
-  float* out;            // [n, dim] reply rows in entry order
-  int dim, G, V;
+  float* out;            // [n, ld] reply rows in entry order (ld >= dim: several groups' rows side by side)
+  int dim, G, V, ld;
 };
 struct ServeMulti {
   int n;
@@ -1291,7 +1291,7 @@ __device__ __forceinline__ void serve_body(int bid, const ServeArgs& a, const er
     }
   }
   for (int64_t q = p; q < a.n && a.skeys[q] == key; ++q)
-    st_vec<V>(a.out + static_cast<int64_t>(a.svals[q]) * a.dim + c, var);
+    st_vec<V>(a.out + static_cast<int64_t>(a.svals[q]) * a.ld + c, var);
 }
 
 __global__ void __launch_bounds__(kBlock)
@@ -1934,14 +1934,14 @@ static int emb_group_heads(er_emb_group* g, int32_t* n_unique, hipStream_t s) {
 }
 
 static int emb_group_run(er_emb_group* g, int opt_kind, const er_opt_hyper* hyper, int mode, uint32_t* out_keys,
-                         float* out_grads, hipStream_t s) {
+                         float* out_grads, hipStream_t s, int out_ld = 0) {
   const int64_t N = group_entries(g);
   if (N == 0) return 0;
   const int T = g->tile_entries;
   const int n_tiles = static_cast<int>(er::ceil_div(N, T));
   er::RowUpdate tab{g->var, g->m, g->v, g->bitmap, g->last_step, g->step_counter};
   const er_emb_group* src = g->src;  // whose sort this group reduces over (itself unless er_emb_group_share_sort)
-  er::ReduceOut ro{mode, src->head_flags, src->head_index, out_keys, out_grads, 0};
+  er::ReduceOut ro{mode, src->head_flags, src->head_index, out_keys, out_grads, out_ld};
   const size_t lds = sizeof(float) * static_cast<size_t>(T) * g->dim + sizeof(uint32_t) * (T + 2);
   const int fix_blocks = static_cast<int>(er::ceil_div(static_cast<int64_t>(n_tiles) * g->G, er::kBlock));
   if (g->V == 4) {
@@ -2375,12 +2375,12 @@ int er_emb_route(er_emb_group* g, uint32_t* unique_keys, int32_t* n_unique, int6
   return 0;
 }
 
-int er_emb_bwd_reduce_routed(er_emb_group* g, float* unique_grads, er_stream_t stream) {
-  ER_REQUIRE(g && unique_grads, "er_emb_bwd_reduce_routed: null argument");
+int er_emb_bwd_reduce_routed(er_emb_group* g, float* unique_grads, int32_t ld, er_stream_t stream) {
+  ER_REQUIRE(g && unique_grads && (ld == 0 || ld >= g->dim), "er_emb_bwd_reduce_routed: null argument or ld < dim");
   ER_REQUIRE(g->sorted_valid, "er_emb_bwd_reduce_routed: call er_emb_route for this step first");
   hipStream_t s = er::as_stream(stream);
   // unique keys were already written by er_emb_route (and with a per-peer capacity the run index exceeds the entries)
-  return emb_group_run(g, ER_OPT_SGD, nullptr, 1, nullptr, unique_grads, s);
+  return emb_group_run(g, ER_OPT_SGD, nullptr, 1, nullptr, unique_grads, s, ld);
 }
 
 int er_gather_rows(const float* table, int64_t table_rows, int32_t dim, const uint32_t* keys, int64_t n,
@@ -2483,8 +2483,8 @@ int er_emb_owner_merge_padded(er_emb_group* g, const int32_t* counts, int n_runs
   return 0;
 }
 
-int er_emb_owner_serve(er_emb_group* const* groups, float* const* rows_out, int n, const er_opt_hyper* hyper,
-                       er_stream_t stream) {
+int er_emb_owner_serve(er_emb_group* const* groups, float* const* rows_out, const int32_t* ld, int n,
+                       const er_opt_hyper* hyper, er_stream_t stream) {
   ER_REQUIRE(groups && rows_out && n >= 1 && n <= er::kMaxMulti, "er_emb_owner_serve: bad arguments (1 <= n <= %d)",
              er::kMaxMulti);
   hipStream_t s = er::as_stream(stream);
@@ -2511,6 +2511,9 @@ int er_emb_owner_serve(er_emb_group* const* groups, float* const* rows_out, int 
     a.skeys = src->keys_out; a.svals = src->vals_out; a.flags = src->head_flags; a.n = N;
     a.tab = er::RowUpdate{g->var, g->m, g->v, g->bitmap, g->last_step, g->step_counter};
     a.lr_hist = g->lr_hist; a.out = rows_out[i]; a.dim = g->dim; a.G = g->G; a.V = g->V;
+    a.ld = ld && ld[i] ? ld[i] : g->dim;
+    ER_REQUIRE(a.ld >= g->dim && (g->V == 1 || (a.ld % 4 == 0 && (reinterpret_cast<uintptr_t>(rows_out[i]) & 15) == 0)),
+               "er_emb_owner_serve: group %d: ld %d < dim, or 16-byte lanes on rows that are not 16-byte aligned", i, a.ld);
     ma.start[ma.n + 1] = ma.start[ma.n] + static_cast<int>(er::ceil_div(N * g->G, er::kBlock));
     ++ma.n;
   }

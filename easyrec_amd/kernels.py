@@ -42,6 +42,7 @@ class LookupDesc(ctypes.Structure):
       ('combiner', ctypes.c_int32),
       ('n_rows', ctypes.c_int32),
       ('max_nnz', ctypes.c_int32),
+      ('table_ld', ctypes.c_int32),
   ]
 
 
@@ -306,6 +307,9 @@ class HipBackend(object):
       d.rows, d.key_base, d.dim = s.rows, s.key_base, s.dim
       d.out_stride, d.out_col, d.combiner = s.out.stride(0), s.out_col, s.combiner
       d.n_rows, d.max_nnz = s.n_rows, s.max_nnz
+      # a column block of a wider buffer as the table (er_emb_fwd only: rows received side by side with another group's)
+      assert s.table.dim() != 2 or s.table.stride(1) == 1
+      d.table_ld = s.table.stride(0) if (s.table.dim() == 2 and s.table.stride(0) != s.dim) else 0
     return arr
 
   def emb_plan_create(self, specs):
@@ -494,8 +498,9 @@ class HipBackend(object):
                                    _p(owner_counts), _stream()), 'er_emb_route')
 
   def emb_bwd_reduce_routed(self, group, unique_grads):
-    self._ck(self.lib.er_emb_bwd_reduce_routed(group['handle'], _p(_f32c(unique_grads)), _stream()),
-             'er_emb_bwd_reduce_routed')
+    assert unique_grads.dtype == torch.float32 and unique_grads.dim() == 2 and unique_grads.stride(1) == 1
+    self._ck(self.lib.er_emb_bwd_reduce_routed(group['handle'], _p(unique_grads), ctypes.c_int32(unique_grads.stride(0)),
+                                               _stream()), 'er_emb_bwd_reduce_routed')
 
   def gather_rows(self, table, keys, n, key_sub, out):
     assert keys.dtype == torch.int32 and table.dim() == 2 and table.is_contiguous()
@@ -545,10 +550,12 @@ class HipBackend(object):
     """Catch up (lazy dense decay) and reply the received rows of up to 4 owner groups in one launch."""
     n = len(groups)
     gh = (ctypes.c_void_p * n)(*[g['handle'] for g in groups])
-    for g, o in zip(groups, rows_out):
-      assert o.is_contiguous() and o.dtype == torch.float32 and o.shape[1] == g['dim']
+    for g, o in zip(groups, rows_out):  # (a column block of a wider buffer is fine: ld = its row stride)
+      assert o.stride(1) == 1 and o.dtype == torch.float32 and o.shape[1] == g['dim']
     op = (ctypes.c_void_p * n)(*[o.data_ptr() for o in rows_out])
-    self._ck(self.lib.er_emb_owner_serve(gh, op, n, None if hyper is None else _p(hyper), _stream()), 'er_emb_owner_serve')
+    ld = (ctypes.c_int32 * n)(*[o.stride(0) for o in rows_out])
+    self._ck(self.lib.er_emb_owner_serve(gh, op, ld, n, None if hyper is None else _p(hyper), _stream()),
+             'er_emb_owner_serve')
 
   def emb_bwd_reduce_dense(self, groups, dense):
     """Per-row gradient sums of the groups straight into their dense [rows, dim + 1] buffers (count in the last

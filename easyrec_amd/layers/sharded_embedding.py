@@ -104,6 +104,24 @@ class ShardedEmbeddingEngine(EmbeddingEngine):
           reg_count += 1
     self.padded = bool(self.shard) and self.padded_exchange and self.owner_merge and all(
         self._can_pad(h['shard']) for h in per_dim.values() if h['shard'])
+    # routes: dim groups whose sharded lookups read the same ids against tables of the same geometry (DeepFM's wide
+    # dim-1 and deep dim-16 tables of one feature set) have the SAME routed keys: the later one follows the first
+    # one's route - one sort, one de-duplication, one key all-to-all and one owner-side merge serve both - and, in
+    # the fixed-capacity exchange, their rows (and row gradients) lie side by side in ONE buffer, [slots, 16 | 1 | pad]:
+    # one all-to-all of rows and one of gradients per ROUTE instead of per dim group.
+    classes = OrderedDict()
+    for dim, halves in per_dim.items():
+      if halves['shard']:
+        sig = self._route_sig(self.shard[dim]['stride'], halves['shard'])
+        classes.setdefault(sig if self.share_route else (sig, dim), []).append(dim)
+    self._route_plan = {}
+    for dims in classes.values():
+      col, cols = 0, []
+      for d in dims:
+        cols.append(col)
+        col += (d + 3) // 4 * 4  # 16-byte aligned column blocks
+      for d, c in zip(dims, cols):
+        self._route_plan[d] = (dims[0], c, col) if self.padded else (dims[0], 0, d)
     for dim, halves in per_dim.items():
       if halves['shard']:
         self._build_shard_half(dim, halves['shard'], fwd_specs, opt_kind)
@@ -126,6 +144,14 @@ class ShardedEmbeddingEngine(EmbeddingEngine):
     self.counts_dev = torch.zeros(max(len(self.shard), 1), W, dtype=torch.int32, device=dev)
     self.lazy_decay = self.lazy_decay and opt_kind == kernels.OPT_ADAM
     self.finalized = True
+
+  @staticmethod
+  def _route_sig(stride, lookups):
+    def ptr(t):
+      return None if t is None else t.data_ptr()
+
+    return (stride, tuple((ptr(lk['ids']), ptr(lk['offsets']), ptr(lk['weights']), lk['t']['rows'], lk['base'],
+                           lk['n_rows'], lk['max_nnz'], lk['combiner']) for lk in lookups))
 
   @staticmethod
   def _can_pad(lookups):
@@ -154,21 +180,8 @@ class ShardedEmbeddingEngine(EmbeddingEngine):
     n_ent = sum(caps)
     m_cap = max(int(self.recv_slack * n_ent), 1024)
 
-    def ptr(t):
-      return None if t is None else t.data_ptr()
-
-    # A dim group whose sharded lookups read the same ids against tables of the same geometry as an earlier group's
-    # (DeepFM's wide dim-1 and deep dim-16 tables of one feature set) has the SAME routed keys: it follows that
-    # group's route - one sort, one de-duplication, one key all-to-all and one owner-side sort serve both; only the
-    # rows and the row gradients (which differ) are exchanged per group.
-    sh['sig'] = (sh['stride'], tuple((ptr(lk['ids']), ptr(lk['offsets']), ptr(lk['weights']), lk['t']['rows'], lk['base'],
-                                      lk['n_rows'], lk['max_nnz'], lk['combiner']) for lk in lookups))
-    lead_dim = None
-    if self.share_route:
-      for d0, s0 in self.shard.items():
-        if d0 != dim and s0.get('sig') == sh['sig'] and s0.get('leader') is None and 'req' in s0:
-          lead_dim = d0
-          break
+    lead_dim, col, ld = self._route_plan[dim]
+    lead_dim = None if lead_dim == dim else lead_dim
     sh['leader'] = lead_dim
     lead = self.shard[lead_dim] if lead_dim is not None else None
     # Fixed-capacity ("padded") exchange: owner w's keys sit at [w * C, w * C + count[w]) of every buffer, so the
@@ -181,12 +194,12 @@ class ShardedEmbeddingEngine(EmbeddingEngine):
     n_slots = W * peer_cap if padded else n_ent  # rows of the requester-side buffers
     if padded:
       m_cap = W * peer_cap
-    sh.update(
-        n_entries=n_ent, m_cap=m_cap, peer_cap=peer_cap,
-        recv_rows=torch.zeros(n_slots, dim, dtype=torch.float32, device=dev),
-        ugrads=torch.zeros(n_slots, dim, dtype=torch.float32, device=dev),
-        rows_out=torch.zeros(m_cap, dim, dtype=torch.float32, device=dev),
-        recv_grads=torch.zeros(m_cap, dim, dtype=torch.float32, device=dev))
+    sh.update(n_entries=n_ent, m_cap=m_cap, peer_cap=peer_cap)
+    for k, n in (('recv_rows', n_slots), ('ugrads', n_slots), ('rows_out', m_cap), ('recv_grads', m_cap)):
+      own = lead is None or not padded  # (the compact exchange moves every dim group's rows on their own)
+      if own:  # [slots, ld]: this group's columns first, its followers' after (ld == dim without followers)
+        sh[k + '_all'] = torch.zeros(n, ld, dtype=torch.float32, device=dev)
+      sh[k] = (sh if own else lead)[k + '_all'][:, col:col + dim]
     if lead is not None:
       for k in ('ukeys', 'n_unique', 'uidx', 'recv_keys', 'recv_ids', 'recv_cnt'):
         sh[k] = lead[k]
@@ -214,7 +227,7 @@ class ShardedEmbeddingEngine(EmbeddingEngine):
       g['specs'].append(fwd_specs[lk['slot']])
       off += cap
     span = max([lk['t']['rows'] for lk in lookups] + [n_slots, 1])  # validation bound only: keys are routed
-    sh['req'] = be.emb_group_create(req_specs, dim, span, sh['recv_rows'], None, None, None)
+    sh['req'] = be.emb_group_create(req_specs, dim, span, sh['recv_rows'], None, None, None)  # (updates no table)
     assert sh['req']['num_entries'] == n_ent
     be.emb_group_set_routing(sh['req'], W, sh['stride'], [lk['base'] for lk in lookups])
     if padded and lead is None:
@@ -297,13 +310,15 @@ class ShardedEmbeddingEngine(EmbeddingEngine):
 
   def exchange_rows(self):
     for sh in self.shard.values():
-      self.comm.all_to_all_equal(sh['rows_out'], sh['recv_rows'])
+      if sh['leader'] is None:  # the rows of every dim group of the route in one buffer
+        self.comm.all_to_all_equal(sh['rows_out_all'], sh['recv_rows_all'])
 
   def exchange_grads(self):
     if self.rep and self.rep_flat_own:
       self.comm.all_reduce_sum(self.rep_flat)
     for sh in self.shard.values():
-      self.comm.all_to_all_equal(sh['ugrads'], sh['recv_grads'])
+      if sh['leader'] is None:
+        self.comm.all_to_all_equal(sh['ugrads_all'], sh['recv_grads_all'])
 
   def owner_update(self, opt_kind, hyper):
     be = kernels.hip()

@@ -99,6 +99,8 @@ typedef struct er_lookup_desc {
   int32_t combiner;       /* ER_COMBINER_*                                                       */
   int32_t n_rows;         /* output rows: batch size, or batch*seq_len for sequence lookups      */
   int32_t max_nnz;        /* capacity of ids[] (dense mode: == n_rows)                           */
+  int32_t table_ld;       /* er_emb_fwd only: floats between consecutive table rows, 0 = dim (the rows
+                             received from the owners lie side by side with another dim group's)    */
 } er_lookup_desc;
 
 typedef struct er_emb_plan er_emb_plan;
@@ -436,7 +438,8 @@ int er_gemm_bf16(int layout, int32_t M, int32_t N, int32_t K, const float* A, in
  *     entry_unique_index and owner_counts may be NULL when only the unique keys are wanted.
  *     The lookup itself then runs through er_emb_fwd with table = the rows received from the owners
  *     ([n_unique, dim]) and ids = entry_unique_index.
- *   er_emb_bwd_reduce_routed: reuses the sort of this step's er_emb_route: unique_grads[u, :] = sum of
+ *   er_emb_bwd_reduce_routed: reuses the sort of this step's er_emb_route: unique_grads[u * ld + 0..dim) (ld = 0:
+ *     dim; larger: dim groups that share a route keep their rows side by side in one exchange buffer) = sum of
  *     the upstream gradients of the entries of unique key u (in-order, deterministic).
  * Owner side:
  *   er_gather_rows: out[i, :] = table[keys[i] - key_sub, :] (key_sub = rank * shard_stride).
@@ -489,7 +492,7 @@ int er_emb_bwd_update_multi(er_emb_group* const* groups_host, int n, int opt_kin
                             er_stream_t stream);
 int er_emb_route(er_emb_group* group, uint32_t* unique_keys, int32_t* n_unique,
                  int64_t* entry_unique_index, int32_t* owner_counts, er_stream_t stream);
-int er_emb_bwd_reduce_routed(er_emb_group* group, float* unique_grads, er_stream_t stream);
+int er_emb_bwd_reduce_routed(er_emb_group* group, float* unique_grads, int32_t ld, er_stream_t stream);
 int er_gather_rows(const float* table, int64_t table_rows, int32_t dim, const uint32_t* keys, int64_t n,
                    int64_t key_sub, float* out, er_stream_t stream);
 int er_scatter_unique(const uint32_t* keys, const float* grads, const int32_t* n_unique,
@@ -503,8 +506,8 @@ int er_scatter_unique(const uint32_t* keys, const float* grads, const int32_t* n
  *     reuses it, as after er_emb_route).
  *   er_emb_owner_serve: for up to 4 such groups (a leader before its followers) in one launch: every distinct
  *     received row is caught up (lazy dense decay, if enabled on the group; hyper may be NULL otherwise) and
- *     written to rows_out[i][entry, :] of every entry that asked for it - er_emb_route + er_emb_catch_up +
- *     er_gather_rows of the sorted form. */
+ *     written to rows_out[i][entry * ld[i] + 0..dim) of every entry that asked for it (ld_host NULL or 0: dim) -
+ *     er_emb_route + er_emb_catch_up + er_gather_rows of the sorted form. */
 int er_emb_owner_merge(er_emb_group* group, const int32_t* run_counts_host, int n_runs, er_stream_t stream);
 /* The same exchange with NO host-visible sizes (no host synchronisation in the step; every launch is static, so
  * the segments between the collectives replay as hipGraphs and the host runs ahead of the device):
@@ -526,8 +529,8 @@ int er_emb_owner_ids(const uint32_t* recv_keys, const int32_t* counts, int n_run
                      int64_t* ids, int32_t* counts_out, er_stream_t stream);
 int er_emb_owner_merge_padded(er_emb_group* group, const int32_t* counts, int n_runs, int64_t peer_cap,
                               er_stream_t stream);
-int er_emb_owner_serve(er_emb_group* const* groups_host, float* const* rows_out_host, int n,
-                       const er_opt_hyper* hyper, er_stream_t stream);
+int er_emb_owner_serve(er_emb_group* const* groups_host, float* const* rows_out_host, const int32_t* ld_host,
+                       int n, const er_opt_hyper* hyper, er_stream_t stream);
 int er_emb_bwd_reduce_dense(er_emb_group* const* groups_host, float* const* dense_host, const int32_t* ld_host,
                             int n, er_stream_t stream);
 int er_emb_dense_apply(const er_dense_apply_desc* descs_host, int n, int opt_kind, const er_opt_hyper* hyper,

@@ -30,8 +30,8 @@ def test_library_exports_every_declared_symbol(built_lib):
 
 def test_struct_layout_matches_header(built_lib):
   from easyrec_amd import kernels
-  # er_lookup_desc: 5 pointers + 2 int64 + 6 int32 = 40 + 16 + 24 = 80 bytes
-  assert ctypes.sizeof(kernels.LookupDesc) == 80
+  # er_lookup_desc: 5 pointers + 2 int64 + 7 int32 = 40 + 16 + 28 = 84, padded to the 8-byte alignment: 88 bytes
+  assert ctypes.sizeof(kernels.LookupDesc) == 88
   assert kernels.HYPER_FLOATS == 16
 
 

@@ -50,9 +50,11 @@ def _cfg_and_batches(B, n, optimizer=None):
   return cfg, [gen.next_batch() for _ in range(n)]
 
 
-@pytest.mark.parametrize('optimizer', [None, 'lazy'])
-def test_world1_sharded_engine_equals_single_gpu_engine(ref_backend, optimizer):
+@pytest.mark.parametrize('optimizer,padded', [(None, True), ('lazy', True), ('lazy', False)])
+def test_world1_sharded_engine_equals_single_gpu_engine(ref_backend, optimizer, padded, monkeypatch):
+  """padded: the fixed-capacity exchange (equal-split all-to-alls, no host sync); else the compact one."""
   from easyrec_amd.model.embedding_parallel import EmbeddingParallelEstimator
+  monkeypatch.setenv('EASYREC_AMD_PADDED_EXCHANGE', '1' if padded else '0')
   B = 32
   cfg, batches = _cfg_and_batches(B, 2, optimizer)
   ref_state, ref_losses = _run_single(cfg, batches, B, seed=3)
@@ -60,6 +62,7 @@ def test_world1_sharded_engine_equals_single_gpu_engine(ref_backend, optimizer):
                                    replicate_bytes=1024).build()
   assert any(p[0] == 'rep' for p in est.engine.placement.values())
   assert any(p[0] == 'shard' for p in est.engine.placement.values())
+  assert est.engine.padded == padded
   for b, rl in zip(batches, ref_losses):
     est.train_step(b)
     got = est.loss_values()
@@ -93,11 +96,12 @@ def _gloo_worker(rank, world, port, B, optimizer, out_dir):
   dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('optimizer', [None, 'lazy'])
-def test_world2_gloo_same_batch_equals_single_process(ref_backend, tmp_path, optimizer):
+@pytest.mark.parametrize('optimizer,padded', [(None, True), ('lazy', True), (None, False)])
+def test_world2_gloo_same_batch_equals_single_process(ref_backend, tmp_path, optimizer, padded, monkeypatch):
   import torch.multiprocessing as mp
+  monkeypatch.setenv('EASYREC_AMD_PADDED_EXCHANGE', '1' if padded else '0')  # (inherited by the spawned ranks)
   B, world = 24, 2
-  port = 29500 + (os.getpid() % 2000) + (7 if optimizer else 0)
+  port = 29500 + (os.getpid() % 2000) + (7 if optimizer else 0) + (13 if padded else 0)
   mp.spawn(_gloo_worker, args=(world, port, B, optimizer, str(tmp_path)), nprocs=world, join=True)
   cfg, batches = _cfg_and_batches(B, 2, optimizer)
   ref_state, ref_losses = _run_single(cfg, batches, B, seed=3)
