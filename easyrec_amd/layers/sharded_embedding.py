@@ -7,16 +7,18 @@ Mirror of the reference's EmbeddingParallelStrategy path
   forward : unique ids -> all-to-all ids -> owner gathers rows -> all-to-all rows -> combine
   backward: row gradients -> all-to-all to the owners -> owners reduce + apply the optimizer with the
             gradient divided by the world size (optimizers.py:315-316)
-MI355X design: the de-duplication, the grouping by owner and the backward's segmented reduction all
-come out of ONE radix sort per embedding-dim group and step (`er_emb_route`: key = owner * stride +
-local row); the lookup itself stays the single fused `er_emb_fwd` launch, reading the received rows;
-the owner side is the same sort + in-order reduce + row-wise optimizer as single-GPU training
-(`er_emb_bwd_update` over the received keys).  Exchanges are RCCL all-to-alls (core/comm.py), three
-per dim group and step, with one host sync for the split sizes.
+MI355X design: the de-duplication, the grouping by owner and the backward's segmented
+reduction all come out of ONE per-lookup LDS sort per route and step (`er_emb_route`: key = owner * stride + local
+row); dim groups that read the same ids share the route.  The exchange has a fixed capacity per peer, so its
+all-to-alls (keys with their counts in front, rows, row gradients - the route's dim groups side by side) have
+equal build-time splits: no host synchronisation, static launches that replay as hipGraphs.  The lookup itself stays
+the single fused `er_emb_fwd` launch, reading the received rows; the owner MERGES the sorted runs it receives
+(`er_emb_owner_merge_padded`), catches the rows up and replies in one launch (`er_emb_owner_serve`), and applies
+the same in-order reduce + row-wise optimizer as single-GPU training (`er_emb_bwd_update_multi`).
 
-Small tables (<= `replicate_bytes`, e.g. the 1-row RawFeature projection tables, which would all land
-on rank 0 under id % world) are replicated and trained data-parallel: their de-duplicated gradient is
-scattered into a dense buffer, all-reduced, and applied on every rank identically - the same math as
+Small tables (<= `replicate_bytes`) are replicated and trained data-parallel: their per-row gradient sums go
+straight into a dense buffer behind the dense variables' gradients (`er_emb_bwd_reduce_dense`), are summed by the
+same all-reduce, and applied on every rank identically in one pass (`er_emb_dense_apply`) - the same math as
 sharding them (SURVEY.md 8e allows it).
 """
 import os

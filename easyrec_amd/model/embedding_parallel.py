@@ -8,11 +8,11 @@ AVERAGED (compat/optimizers.py:328-331); embedding gradients are divided by the 
 (:315-316); BatchNorm statistics stay per-rank (the reference does not sync them); dense variables
 start identical on every rank (same seed; the reference broadcasts rank 0's, utils/hvd_utils.py:43-56).
 
-Per step (fixed-capacity exchange, the default: layers/sharded_embedding.py): per route (dim groups with the
-same routed keys share one) an all-to-all of the per-owner counts and one of the keys; per dim group an
-all-to-all of rows and one of row gradients - all with equal, build-time split sizes, so there is NO host
-synchronisation in the step; + 1 all-reduce of the flat dense-gradient buffer + 1 all-reduce of the replicated
-small tables' gradients.  The static device work between the collectives (route | owner merge + serve |
+Per step (fixed-capacity exchange, the default: layers/sharded_embedding.py), per route (dim groups with the same
+routed keys share one): an all-to-all of [count, keys] per owner, one of the rows and one of the row gradients
+of all the route's dim groups side by side - all with equal, build-time split sizes, so there is NO host
+synchronisation in the step; + ONE all-reduce (dense gradients, with the replicated small tables' gradients
+behind them in the same buffer).  The static device work between the collectives (route | owner merge + serve |
 lookup+forward+backward+local reduce | owner update + replicated apply + dense optimizer) is captured as four
 hipGraphs; the collectives are issued eagerly between them and the host runs ahead of the device.
 The compact exchange (variable split sizes through one host sync per step, three segments) remains for lookups
