@@ -1110,6 +1110,39 @@ emb_route_kernel(const uint32_t* __restrict__ skeys, const uint32_t* __restrict_
   if (flags[p]) unique_keys[u] = key;
 }
 
+// Fixed-capacity layout after the device-wide sort (lookups that share a table, or > 8192 entries: the per-lookup
+// sort does not apply): the ascending unique keys are already grouped by owner, so key number u of owner w moves to
+// slot w * cap + (u - keys of the owners before w); head_index and the per-entry index follow.  compact_keys is the
+// de-duplicated list emb_route_kernel wrote (a scratch buffer), counts[w] come from emb_owner_counts_kernel.
+__global__ void __launch_bounds__(kBlock)
+emb_route_pad_kernel(const uint32_t* __restrict__ skeys, const uint32_t* __restrict__ svals,
+                     const uint32_t* __restrict__ flags, uint32_t* __restrict__ head_index, int64_t n,
+                     const int32_t* __restrict__ counts, int world, uint32_t stride, uint32_t cap, uint32_t hdr,
+                     uint32_t* __restrict__ unique_keys, int64_t* __restrict__ uidx, int32_t* __restrict__ owner_counts,
+                     int32_t* __restrict__ overflow) {
+  const int64_t p = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (p < world) {
+    const int32_t c = counts[p];
+    if (hdr) unique_keys[static_cast<uint32_t>(p) * (cap + 1u)] = static_cast<uint32_t>(c);
+    if (owner_counts) owner_counts[p] = c;
+    if (static_cast<uint32_t>(c) > cap) *overflow = 1;
+  }
+  if (p >= n) return;
+  const uint32_t key = skeys[p];
+  if (key == kInvalidKey) return;  // (emb_route_kernel left uidx = -1)
+  const uint32_t w = key / stride;
+  uint32_t obase = 0;
+  for (uint32_t q = 0; q < w; ++q) obase += static_cast<uint32_t>(counts[q]);
+  const uint32_t f = flags[p];
+  uint32_t r = head_index[p] + f - 1u - obase;
+  const bool fits = r < cap;
+  if (!fits) r = cap - 1u;
+  const uint32_t u = w * cap + r;
+  head_index[p] = u + 1u - f;
+  if (uidx) uidx[svals[p]] = fits ? static_cast<int64_t>(u) : -1;
+  if (f && fits) unique_keys[w * (cap + hdr) + hdr + r] = key;
+}
+
 // counts[w] = number of unique keys owned by rank w (keys in [w*stride, (w+1)*stride)).
 __global__ void emb_owner_counts_kernel(const uint32_t* __restrict__ unique_keys, const int32_t* __restrict__ n_unique,
                                         int world, int64_t stride, int32_t* __restrict__ counts) {
@@ -2331,8 +2364,7 @@ int er_emb_route(er_emb_group* g, uint32_t* unique_keys, int32_t* n_unique, int6
     }
   } else {
     ER_REQUIRE(unique_keys && n_unique, "er_emb_route: null argument");
-    ER_REQUIRE(g->peer_cap == 0 || (g->d_local_base && emb_group_segmented(g)),
-               "er_emb_route: a per-peer capacity needs routed keys on the per-lookup sort path");
+    ER_REQUIRE(g->peer_cap == 0 || g->d_local_base, "er_emb_route: a per-peer capacity needs routed keys");
     if (emb_group_segmented(g)) {
       // two launches: sort + in-lookup heads, then the cross-lookup offsets + key list + per-entry index
       if (int rc = emb_group_build_sort(g, s, true)) return rc;
@@ -2358,7 +2390,22 @@ int er_emb_route(er_emb_group* g, uint32_t* unique_keys, int32_t* n_unique, int6
       g->heads_epoch = g->sort_epoch;
     }
   }
-  if (unique_keys && !fused_route) {
+  if (unique_keys && !fused_route && !adopted && g->peer_cap > 0) {
+    // device-wide sort + fixed-capacity layout: compact list into scratch, counts per owner, then the padded layout
+    uint32_t* compact = g->keys_in;  // (the unsorted keys are no longer needed)
+    int32_t* cnt = reinterpret_cast<int32_t*>(g->seg_count);
+    const int blocks = static_cast<int>(er::ceil_div(N, er::kBlock));
+    hipLaunchKernelGGL(er::emb_route_kernel, dim3(blocks), dim3(er::kBlock), 0, s, g->keys_out, g->vals_out, g->head_flags,
+                       g->head_index, N, compact, entry_unique_index);
+    hipLaunchKernelGGL(er::emb_owner_counts_kernel, dim3(1), dim3(64), 0, s, compact, n_unique, g->world, g->shard_stride,
+                       cnt);
+    hipLaunchKernelGGL(er::emb_route_pad_kernel, dim3(blocks), dim3(er::kBlock), 0, s, g->keys_out, g->vals_out,
+                       g->head_flags, g->head_index, N, cnt, g->world, static_cast<uint32_t>(g->shard_stride),
+                       static_cast<uint32_t>(g->peer_cap), static_cast<uint32_t>(g->peer_hdr), unique_keys,
+                       entry_unique_index, owner_counts, g->d_overflow);
+    ER_LAUNCH_CHECK();
+    counts_done = true;
+  } else if (unique_keys && !fused_route) {
     const er_emb_group* src = g->src;
     hipLaunchKernelGGL(er::emb_route_kernel, dim3(static_cast<int>(er::ceil_div(N, er::kBlock))), dim3(er::kBlock), 0, s,
                        src->keys_out, src->vals_out, src->head_flags, src->head_index, N, unique_keys,
@@ -2432,8 +2479,7 @@ int er_emb_owner_merge(er_emb_group* g, const int32_t* run_counts, int n_runs, e
 int er_emb_group_set_peer_capacity(er_emb_group* g, int64_t peer_cap, int32_t count_header) {
   ER_REQUIRE(g && peer_cap >= 0 && (count_header == 0 || count_header == 1), "er_emb_group_set_peer_capacity: bad arguments");
   if (peer_cap > 0) {
-    ER_REQUIRE(g->d_local_base && g->seg_routed, "er_emb_group_set_peer_capacity: needs er_emb_group_set_routing with "
-               "lookups the per-lookup sort covers (one table per lookup, <= %d entries each)", er::kSegSortMax);
+    ER_REQUIRE(g->d_local_base && g->world <= 64, "er_emb_group_set_peer_capacity: needs er_emb_group_set_routing, world <= 64");
     ER_REQUIRE(peer_cap * g->world < 0x7FFFFFFFLL, "er_emb_group_set_peer_capacity: world * capacity too large");
     if (!g->d_overflow) {
       ER_CHECK_HIP(hipMalloc(&g->d_overflow, sizeof(int32_t)));

@@ -104,8 +104,7 @@ class ShardedEmbeddingEngine(EmbeddingEngine):
         fwd_specs.append(None)
         if g['reg'] > 0:
           reg_count += 1
-    self.padded = bool(self.shard) and self.padded_exchange and self.owner_merge and all(
-        self._can_pad(h['shard']) for h in per_dim.values() if h['shard'])
+    self.padded = bool(self.shard) and self.padded_exchange and self.owner_merge
     # routes: dim groups whose sharded lookups read the same ids against tables of the same geometry (DeepFM's wide
     # dim-1 and deep dim-16 tables of one feature set) have the SAME routed keys: the later one follows the first
     # one's route - one sort, one de-duplication, one key all-to-all and one owner-side merge serve both - and, in
@@ -155,14 +154,6 @@ class ShardedEmbeddingEngine(EmbeddingEngine):
     return (stride, tuple((ptr(lk['ids']), ptr(lk['offsets']), ptr(lk['weights']), lk['t']['rows'], lk['base'],
                            lk['n_rows'], lk['max_nnz'], lk['combiner']) for lk in lookups))
 
-  @staticmethod
-  def _can_pad(lookups):
-    """The fixed-capacity exchange needs er_emb_route's per-lookup sort of routed keys: one table per lookup, in
-    table order, at most 8192 entries per lookup."""
-    caps = [(lk['max_nnz'] if lk['offsets'] is not None else lk['n_rows']) for lk in lookups]
-    bases = [lk['base'] for lk in lookups]
-    return max(caps) <= 8192 and len(set(lk['tname'] for lk in lookups)) == len(lookups) and bases == sorted(bases)
-
   def set_rep_flat(self, buf, own=False):
     """The dense gradient buffer of the replicated tables.  own=False: it is the tail of the dense variables' flat
     gradient buffer - zeroed and all-reduced together with it (one collective instead of two)."""
@@ -189,8 +180,7 @@ class ShardedEmbeddingEngine(EmbeddingEngine):
     # Fixed-capacity ("padded") exchange: owner w's keys sit at [w * C, w * C + count[w]) of every buffer, so the
     # all-to-alls have equal splits known at build time: no count all-gather, no host synchronisation, every launch
     # static (hipGraph segments; the host runs ahead of the device).  C = slack x the even share, at most all entries.
-    # It needs the per-lookup routed sort (one table per lookup, in table order, <= 8192 entries each) and the
-    # owner-side merge (world <= 16); otherwise the compact exchange with host-side split sizes is used.
+    # It needs the owner-side merge (world <= 16); otherwise the compact exchange with host-side split sizes is used.
     padded = self.padded
     peer_cap = min(n_ent, -(-int(self.recv_slack * n_ent) // W)) if padded else 0
     n_slots = W * peer_cap if padded else n_ent  # rows of the requester-side buffers

@@ -511,7 +511,9 @@ int er_scatter_unique(const uint32_t* keys, const float* grads, const int32_t* n
 int er_emb_owner_merge(er_emb_group* group, const int32_t* run_counts_host, int n_runs, er_stream_t stream);
 /* The same exchange with NO host-visible sizes (no host synchronisation in the step; every launch is static, so
  * the segments between the collectives replay as hipGraphs and the host runs ahead of the device):
- *   er_emb_group_set_peer_capacity: on a routed requester group: er_emb_route then writes the keys of owner w at
+ *   er_emb_group_set_peer_capacity: on a routed requester group (any lookups: the per-lookup sort places the keys
+ *     directly, the device-wide sort re-lays its ascending key list out in one more launch): er_emb_route then
+ *     writes the keys of owner w at
  *     unique_keys[w * peer_cap ...] and entry_unique_index points into that padded layout (rows and row gradients
  *     of owner w at [w * peer_cap, ...)), so keys, rows and row gradients travel in equal-split all-to-alls.
  *     count_header = 1: owner w's segment of unique_keys is peer_cap + 1 slots, [count, keys ...] - the counts ride

@@ -101,15 +101,20 @@ def test_routing_kernels_against_numpy(W, B, rows):
   hip.emb_group_destroy(g)
 
 
-@pytest.mark.parametrize('world,lazy,padded', [(1, False, True), (2, False, True), (4, True, True), (2, True, False),
-                                               (3, False, False)])
-def test_sharded_ranks_with_the_same_batch_equal_single_gpu(world, lazy, padded, monkeypatch):
+@pytest.mark.parametrize('world,lazy,padded,config', [
+    (1, False, True, 'deepfm_criteo_small.config'), (2, False, True, 'deepfm_criteo_small.config'),
+    (4, True, True, 'deepfm_criteo_small.config'), (2, True, False, 'deepfm_criteo_small.config'),
+    (3, False, False, 'deepfm_criteo_small.config'),
+    # ONE table behind all 26 categorical features (the reference's own embedding-parallel Criteo config): the
+    # device-wide sort + the fixed-capacity layout pass instead of the per-lookup sort
+    (2, True, True, 'deepfm_shared_criteo_small.config'), (4, False, True, 'deepfm_shared_criteo_small.config')])
+def test_sharded_ranks_with_the_same_batch_equal_single_gpu(world, lazy, padded, config, monkeypatch):
   """Every rank sees the SAME batch: each embedding row gets world * g / world and each dense gradient
   the average of identical gradients, so the W-rank run must follow the single-GPU run (to the fp32
   noise of the GEMM library between runs)."""
   # padded: the fixed-capacity exchange (no host sync); else the compact one with host-side split sizes
   monkeypatch.setenv('EASYREC_AMD_PADDED_EXCHANGE', '1' if padded else '0')
-  cfg = _cfg('deepfm_criteo_small.config', lazy)
+  cfg = _cfg(config, lazy)
   B, steps = 128, 2
   gen = SyntheticCriteo(cfg.data_config, list(cfg.feature_config.features), batch_size=B, seed=9)
   batches = [gen.next_batch() for _ in range(steps)]

@@ -290,6 +290,22 @@ def write(cfg, name):
   print('wrote', out)
 
 
+def shared_embedding_variant(src_name, dst_name, embedding_name='embedding'):
+  """The reference's own embedding-parallel Criteo config keeps ONE table for all categorical features
+  (samples/model_config/dlrm_on_criteo_parquet_ep_v2.config: `embedding_name: "embedding"` on all 26): the same edit on
+  one of the small fixtures."""
+  from easyrec_amd.protos import pipeline_pb2
+  from easyrec_amd.protos.feature_config_pb2 import FeatureConfig
+  here = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'configs')
+  cfg = pipeline_pb2.EasyRecConfig()
+  with open(os.path.join(here, src_name)) as f:
+    text_format.Merge(f.read(), cfg)
+  for fc in cfg.feature_config.features:
+    if fc.feature_type == FeatureConfig.IdFeature and fc.hash_bucket_size > 0:
+      fc.embedding_name = embedding_name
+  write(cfg, dst_name)
+
+
 if __name__ == '__main__':
   write(deepfm_criteo(), 'deepfm_criteo.config')
   write(deepfm_criteo(optimizer='lazy_adam_optimizer'), 'deepfm_criteo_lazy_adam.config')
@@ -306,3 +322,5 @@ if __name__ == '__main__':
   write(mmoe_taobao(), 'mmoe_taobao.config')
   write(mmoe_taobao(n_tasks=4, embedding_dim=64, batch_size=8192), 'mmoe_taobao_4task_d64.config')
   write(mmoe_taobao(batch_size=128, scale=0.01), 'mmoe_taobao_small.config')
+  shared_embedding_variant('dlrm_criteo_small.config', 'dlrm_shared_criteo_small.config')
+  shared_embedding_variant('deepfm_criteo_small.config', 'deepfm_shared_criteo_small.config')
