@@ -1,5 +1,7 @@
 """Evaluation metrics on the hot path's predictions.
 
+Also: gAUC / session AUC (`SeparatedAUC`) and max F1 (`MaxF1`), host-side as in the reference (see below).
+
 AUC = `tf.metrics.auc(labels, predictions, num_thresholds=200)` as called by `RankModel.build_metric_graph`
 (reference easy_rec/python/model/rank_model.py:358-373; `eval_config.metrics_set { auc {} }`).  TensorFlow's
 published algorithm (tf.metrics.auc, curve='ROC', summation_method='trapezoidal'; TF is third-party and absent
@@ -54,3 +56,109 @@ class AUC(object):
 
   def result(self):
     return auc_from_counts(self.counts.cpu().numpy())
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Grouped AUCs (reference easy_rec/python/core/metrics.py:59-108 `_separated_auc_impl`, :260-297 `gauc` /
+# `session_auc`; wired by model/rank_model.py:376-420).  The reference accumulates (label, prediction, key) in Python
+# dictionaries inside a tf.py_func and, at read-out, averages `sklearn.metrics.roc_auc_score` over the keys that have
+# both classes - host work there, host work here: the rows are kept as arrays and grouped once with a sort.
+# ------------------------------------------------------------------------------------------------------------------
+def roc_auc(labels, predictions):
+  """Area under the ROC curve of binary `labels` = the Mann-Whitney statistic with tied predictions counted half
+  (what sklearn.metrics.roc_auc_score returns for a binary target).  Needs both classes."""
+  labels = np.asarray(labels).reshape(-1) != 0
+  predictions = np.asarray(predictions, dtype=np.float64).reshape(-1)
+  n_pos = int(labels.sum())
+  n_neg = labels.size - n_pos
+  assert n_pos > 0 and n_neg > 0, 'roc_auc: only one class present'
+  order = np.argsort(predictions, kind='mergesort')
+  p = predictions[order]
+  # average rank (1-based) of every run of equal predictions
+  starts = np.flatnonzero(np.concatenate([[True], p[1:] != p[:-1]]))
+  ends = np.concatenate([starts[1:], [p.size]])
+  run_rank = (starts + 1 + ends) / 2.0
+  ranks = np.repeat(run_rank, ends - starts)
+  pos_rank_sum = ranks[labels[order]].sum()
+  return float((pos_rank_sum - n_pos * (n_pos + 1) / 2.0) / (n_pos * float(n_neg)))
+
+
+class SeparatedAUC(object):
+  """AUC per key (user, session), reduced by 'mean' | 'mean_by_sample_num' | 'mean_by_positive_num'."""
+
+  REDUCTIONS = ('mean', 'mean_by_sample_num', 'mean_by_positive_num')
+
+  def __init__(self, reduction='mean'):
+    assert reduction in self.REDUCTIONS, 'reduction method must in mean | mean_by_sample_num | mean_by_positive_num'
+    self.reduction = reduction
+    self.reset()
+
+  def reset(self):
+    self._labels, self._preds, self._keys = [], [], []
+
+  def update(self, labels, predictions, keys):
+    def host(x):
+      return x.detach().cpu().numpy() if torch.is_tensor(x) else np.asarray(x)
+    labels, predictions, keys = host(labels).reshape(-1), host(predictions).reshape(-1), host(keys).reshape(-1)
+    assert labels.size == predictions.size == keys.size
+    self._labels.append(labels.astype(np.int64))
+    self._preds.append(predictions.astype(np.float64))
+    self._keys.append(keys)
+
+  def result(self):
+    if not self._labels:
+      return 0.0
+    labels, preds = np.concatenate(self._labels), np.concatenate(self._preds)
+    keys = np.concatenate([k.astype(object) for k in self._keys]) if any(k.dtype == object for k in self._keys) \
+        else np.concatenate(self._keys)
+    _, inv = np.unique(keys, return_inverse=True)
+    order = np.argsort(inv, kind='mergesort')
+    bounds = np.flatnonzero(np.concatenate([[True], inv[order][1:] != inv[order][:-1], [True]]))
+    metrics, weights = [], []
+    for b, e in zip(bounds[:-1], bounds[1:]):
+      idx = order[b:e]
+      lab = labels[idx]
+      n_pos = int((lab != 0).sum())
+      if n_pos == 0 or n_pos == lab.size:  # (metrics.py:93-94: keys with one class are skipped)
+        continue
+      metrics.append(roc_auc(lab, preds[idx]))
+      weights.append(1 if self.reduction == 'mean' else lab.size if self.reduction == 'mean_by_sample_num' else lab.sum())
+    if not metrics:
+      return 0.0
+    return float(np.average(metrics, weights=weights).astype(np.float32))
+
+
+def gauc(reduction='mean'):
+  return SeparatedAUC(reduction)
+
+
+def session_auc(reduction='mean'):
+  return SeparatedAUC(reduction)
+
+
+class MaxF1(object):
+  """Largest F1 over 200 thresholds (reference core/metrics.py:25-56): streaming tp / fp / fn per threshold
+  (tf.metrics.precision / recall: 0 when their denominator is 0), f1 = 2 p r / (p + r + 1e-12)."""
+
+  def __init__(self, num_thresholds=200):
+    self.thresholds = auc_thresholds(num_thresholds)  # float32, like the predictions they are compared with
+    self.reset()
+
+  def reset(self):
+    n = self.thresholds.size
+    self.tp, self.fp, self.fn = np.zeros(n), np.zeros(n), np.zeros(n)
+
+  def update(self, labels, predictions):
+    def host(x):
+      return x.detach().cpu().numpy() if torch.is_tensor(x) else np.asarray(x)
+    lab = host(labels).reshape(-1) != 0
+    pred = host(predictions).reshape(-1).astype(np.float32)[None, :] > self.thresholds[:, None]
+    self.tp += (pred & lab[None, :]).sum(axis=1)
+    self.fp += (pred & ~lab[None, :]).sum(axis=1)
+    self.fn += (~pred & lab[None, :]).sum(axis=1)
+
+  def result(self):
+    with np.errstate(divide='ignore', invalid='ignore'):
+      p = np.where(self.tp + self.fp > 0, self.tp / (self.tp + self.fp), 0.0)
+      r = np.where(self.tp + self.fn > 0, self.tp / (self.tp + self.fn), 0.0)
+    return float(np.max(2 * p * r / (p + r + 1e-12)))

@@ -100,6 +100,25 @@ class FeatureSchema(object):
     return np.array([v['buckets'] for v in self.hash_single.values()], dtype=np.uint64)
 
 
+def host_key_column(schema, batch, name):
+  """The values of input feature `name` in a HOST batch (numpy arrays, before pack()), one per example, as grouping
+  keys for gAUC / session AUC (the reference groups by `feature_dict[uid_field]`, model/rank_model.py:380): the raw
+  strings of a hashed id feature, the integers of an identity one."""
+  B = schema.batch_size
+  if name in schema.hash_single:
+    j = schema.hash_single[name]['col']
+    if 'str_bytes' in batch:
+      data = np.asarray(batch['str_bytes'], dtype=np.uint8).tobytes()
+      off = np.asarray(batch['str_offsets']).astype(np.int64)
+      return np.array([data[off[j * B + r]:off[j * B + r + 1]] for r in range(B)], dtype=object)
+    if 'hash_ids' in batch:  # already hashed on the host: the bucket is all that is left of the value
+      return np.asarray(batch['hash_ids'])[j].astype(np.int64)
+  if name in schema.int_single and 'int_ids' in batch:
+    return np.asarray(batch['int_ids'])[schema.int_single[name]['col']].astype(np.int64)
+  raise KeyError('no per-example key column for feature %r in this batch (need a host batch with str_bytes / hash_ids / '
+                 'int_ids; a packed batch has left the host)' % name)
+
+
 class DeviceFeatures(object):
   """Persistent device buffers for one batch; dict-like access by feature name."""
 

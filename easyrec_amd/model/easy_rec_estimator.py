@@ -256,34 +256,58 @@ class EasyRecEstimator(object):
 
   def evaluate(self, batches, eval_config=None):
     """The evaluation pass of the reference (`EasyRecEstimator._eval_model_fn` -> `build_metric_graph`,
-    model/easy_rec_estimator.py:355-420, model/rank_model.py:334-470) for the metric every shipped rank config
-    asks for: `metrics_set { auc {} }`.  The model runs with is_training=False (BatchNorm moving statistics, no
-    dropout) over `batches`; returns {'auc'[+ '_<tower>']: value}."""
+    model/easy_rec_estimator.py:355-420, model/rank_model.py:334-470) for `metrics_set { auc | gauc | session_auc |
+    max_f1 }`.  The model runs with is_training=False (BatchNorm moving statistics, no dropout) over `batches` (host
+    batches when a grouped AUC needs its key column); returns {'<metric>'[+ '_<tower>']: value}."""
     from easyrec_amd.core import metrics as metrics_lib
     assert self._built
     ec = eval_config if eval_config is not None else self.pipeline_config.eval_config
-    specs = []
+    from easyrec_amd.input.features import host_key_column
+    specs = []  # (output name, metric kind, argument)
     for m in ec.metrics_set:
       kind = m.WhichOneof('metric')
-      if kind != 'auc':
-        raise NotImplementedError('metric %s is outside the hot-path scope (auc only)' % kind)
-      specs.append(int(m.auc.num_thresholds))
+      if kind == 'auc':
+        specs.append(('auc', 'auc', int(m.auc.num_thresholds)))
+      elif kind == 'gauc':  # rank_model.py:376-399
+        specs.append(('gauc', 'grouped', (m.gauc.uid_field, m.gauc.reduction)))
+      elif kind == 'session_auc':  # rank_model.py:401-420
+        specs.append(('session_auc', 'grouped', (m.session_auc.session_id_field, m.session_auc.reduction)))
+      elif kind == 'max_f1':
+        specs.append(('max_f1', 'max_f1', None))
+      else:
+        raise NotImplementedError('metric %s is outside the hot-path scope (auc, gauc, session_auc, max_f1)' % kind)
     if not specs:
-      specs = [200]  # eval.proto: auc is the default metric of a rank model
+      specs = [('auc', 'auc', 200)]  # eval.proto: auc is the default metric of a rank model
     towers = getattr(self.model, '_label_name_dict', None)
     heads = [('', self.model._label_name)] if not towers else [('_' + t, l) for t, l in towers.items()]
-    aucs = {(suf, nt): metrics_lib.AUC(nt, self.device) for suf, _ in heads for nt in specs}
+
+    def make(kind, arg):
+      if kind == 'auc':
+        return metrics_lib.AUC(arg, self.device)
+      if kind == 'grouped':
+        return metrics_lib.SeparatedAUC(arg[1])
+      return metrics_lib.MaxF1()
+
+    acc = {}
+    for suf, _ in heads:
+      for name, kind, arg in specs:
+        acc.setdefault((name, suf), (kind, arg, make(kind, arg)))  # (a metric named twice keeps its first settings)
     was = (self.model._is_training, self.ctx.is_training)
     self.model._is_training, self.ctx.is_training = False, False
     try:
       for batch in batches:
         pred = self.predict(batch)
-        for suf, label_name in heads:
-          for nt in specs:
-            aucs[(suf, nt)].update(self.features.label(label_name), pred['probs' + suf], self.features.sample_weight)
+        for (name, suf), (kind, arg, m) in acc.items():
+          label = self.features.label(dict(heads)[suf])
+          if kind == 'auc':
+            m.update(label, pred['probs' + suf], self.features.sample_weight)
+          elif kind == 'grouped':  # host-side, as the reference's py_func
+            m.update(label, pred['probs' + suf], host_key_column(self.features.schema, batch, arg[0]))
+          else:
+            m.update(label, pred['probs' + suf])
     finally:
       self.model._is_training, self.ctx.is_training = was
-    return {'auc' + suf: aucs[(suf, specs[0])].result() for suf, _ in heads}
+    return {name + suf: m.result() for (name, suf), (_, _, m) in acc.items()}
 
   def capture(self, warmup=3):
     """Capture the device part of the step into one hipGraph (replayed by train_step)."""

@@ -77,3 +77,104 @@ def test_evaluate_returns_auc(ref_backend):
     for k in before:  # evaluation leaves every variable (moving statistics included) untouched
       assert np.array_equal(before[k], after[k]), k
     est.train_step(batches[0])  # and training continues
+
+
+def _separated_auc_like_the_reference(labels, preds, keys, reduction):
+  """The reference's `_separated_auc_impl` (core/metrics.py:59-108) restated: python dictionaries keyed by the
+  group, sklearn.metrics.roc_auc_score per group with both classes (sklearn IS what the reference calls)."""
+  from collections import defaultdict
+  from sklearn import metrics as sk
+  lab, pr, w = defaultdict(list), defaultdict(list), defaultdict(int)
+  for y, p, k in zip(labels, preds, keys):
+    lab[k].append(y)
+    pr[k].append(p)
+    w[k] = 1 if reduction == 'mean' else w[k] + (1 if reduction == 'mean_by_sample_num' else y)
+  ms, ws = [], []
+  for k in lab:
+    y = np.asarray(lab[k])
+    if np.all(y == 1) or np.all(y == 0):
+      continue
+    ms.append(sk.roc_auc_score(y, np.asarray(pr[k])))
+    ws.append(w[k])
+  return np.float32(np.average(ms, weights=ws)) if ms else np.float32(0.0)
+
+
+@pytest.mark.parametrize('reduction', ['mean', 'mean_by_sample_num', 'mean_by_positive_num'])
+@pytest.mark.parametrize('string_keys', [False, True])
+def test_grouped_auc_equals_the_reference_algorithm(reduction, string_keys):
+  from easyrec_amd.core.metrics import SeparatedAUC, roc_auc
+  from sklearn import metrics as sk
+  rng = np.random.default_rng(7)
+  n = 3000
+  users = rng.integers(0, 120, size=n)  # some users end up with one class only, some with a single row
+  users[:40] = 1000 + np.arange(40)
+  y = (rng.random(n) < 0.3).astype(np.int64)
+  p = np.round(np.clip(rng.normal(0.4 + 0.15 * y, 0.2), 0, 1), 2).astype(np.float32)  # rounded: ties inside groups
+  keys = np.array([b'u%d' % u for u in users], dtype=object) if string_keys else users
+  m = SeparatedAUC(reduction)
+  for lo in range(0, n, 700):  # streaming
+    m.update(torch.from_numpy(y[lo:lo + 700]), torch.from_numpy(p[lo:lo + 700]), keys[lo:lo + 700])
+  exp = _separated_auc_like_the_reference(y, p, [k for k in keys], reduction)
+  assert abs(m.result() - float(exp)) < 1e-6, (m.result(), exp)
+  assert abs(roc_auc(y, p) - sk.roc_auc_score(y, p)) < 1e-12
+  empty = SeparatedAUC(reduction)
+  empty.update(np.ones(5), np.linspace(0, 1, 5), np.arange(5))  # no key has both classes
+  assert empty.result() == 0.0
+
+
+def test_max_f1_follows_the_restatement():
+  """core/metrics.py:25-56: tf.metrics.precision / recall of (prediction > threshold) at 200 thresholds."""
+  from easyrec_amd.core.metrics import MaxF1, auc_thresholds
+  rng = np.random.default_rng(3)
+  n = 4000
+  y = (rng.random(n) < 0.2).astype(np.float32)
+  p = np.clip(rng.normal(0.3 + 0.3 * y, 0.15), 0, 1).astype(np.float32)
+  m = MaxF1()
+  for lo in range(0, n, 1500):
+    m.update(y[lo:lo + 1500], torch.from_numpy(p[lo:lo + 1500]))
+  best = 0.0
+  for t in auc_thresholds(200):
+    pred = p > t
+    tp, fp, fn = float((pred & (y > 0)).sum()), float((pred & (y == 0)).sum()), float((~pred & (y > 0)).sum())
+    prec = tp / (tp + fp) if tp + fp > 0 else 0.0
+    rec = tp / (tp + fn) if tp + fn > 0 else 0.0
+    best = max(best, 2 * prec * rec / (prec + rec + 1e-12))
+  assert abs(m.result() - best) < 1e-9 and 0.3 < best < 1.0
+
+
+def test_evaluate_with_grouped_metrics(ref_backend):
+  """metrics_set { gauc } / { session_auc } / { max_f1 } through EasyRecEstimator.evaluate(): the key column is the
+  RAW value of the named feature (its strings for a hashed id feature), as `feature_dict[uid_field]` in the
+  reference; the result must equal the metric recomputed from the predictions by the reference's algorithm."""
+  from google.protobuf import text_format
+  from easyrec_amd.input.features import host_key_column
+  from easyrec_amd.input.synthetic import SyntheticBatches
+  from easyrec_amd.model.easy_rec_estimator import EasyRecEstimator
+  from easyrec_amd.utils import config_util
+  cfg = config_util.get_configs_from_pipeline_file(os.path.join(ROOT, 'configs', 'deepfm_criteo_small.config'))
+  text_format.Merge('metrics_set { gauc { uid_field: "C1" reduction: "mean_by_sample_num" } } '
+                    'metrics_set { session_auc { session_id_field: "C2" } } metrics_set { max_f1 {} }', cfg.eval_config)
+  B = 64
+  from easyrec_amd.input.criteo_synthetic import SyntheticCriteo
+  est = EasyRecEstimator(cfg, device='cpu', batch_size=B, seed=1).build()
+  gen = SyntheticCriteo(cfg.data_config, est.feature_configs, batch_size=B, seed=5)  # id features as raw strings
+  batches = [gen.next_batch() for _ in range(4)]
+  est.train_step(batches[0])
+  out = est.evaluate(batches)
+  assert sorted(out) == ['auc', 'gauc', 'max_f1', 'session_auc']
+  # recompute from the predictions
+  labels, probs, k1, k2 = [], [], [], []
+  est.model._is_training, est.ctx.is_training = False, False
+  for b in batches:
+    pred = est.predict(b)
+    probs.append(pred['probs'].detach().cpu().numpy().reshape(-1).copy())
+    labels.append(est.features.label(est.model._label_name).cpu().numpy().reshape(-1).copy())
+    k1.append(host_key_column(est.features.schema, b, 'C1'))
+    k2.append(host_key_column(est.features.schema, b, 'C2'))
+  est.model._is_training, est.ctx.is_training = True, True
+  labels, probs = np.concatenate(labels).astype(np.int64), np.concatenate(probs)
+  k1, k2 = np.concatenate(k1), np.concatenate(k2)
+  assert k1.dtype == object and len(set(k1.tolist())) > 3  # raw strings, several users
+  assert abs(out['gauc'] - float(_separated_auc_like_the_reference(labels, probs, k1.tolist(), 'mean_by_sample_num'))) < 1e-6
+  assert abs(out['session_auc'] - float(_separated_auc_like_the_reference(labels, probs, k2.tolist(), 'mean'))) < 1e-6
+  assert 0.0 <= out['max_f1'] <= 1.0
