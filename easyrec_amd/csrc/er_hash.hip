@@ -221,6 +221,38 @@ int er_hash_bucket_fast_host(const uint8_t* bytes, const int64_t* offsets, int64
   return 0;
 }
 
+// TensorFlow's FingerprintCat64 (tensorflow/core/platform/fingerprint.h): the order-dependent mix SparseCross folds
+// the columns' fingerprints with.
+static inline uint64_t fingerprint_cat64(uint64_t fp1, uint64_t fp2) {
+  const uint64_t k = 0xc6a4a7935bd1e995ULL;
+  uint64_t r = fp1 ^ k;
+  r ^= er::fh::smix(fp2 * k) * k;
+  r *= k;
+  r = er::fh::smix(r) * k;
+  return er::fh::smix(r);
+}
+
+int er_sparse_cross_hashed_host(const uint8_t* bytes, const int64_t* offsets, int64_t n_rows, int32_t n_cols,
+                                uint64_t num_buckets, uint64_t hash_key, int64_t* out) {
+  ER_REQUIRE(bytes && offsets && out && n_rows >= 0 && n_cols >= 1 && num_buckets > 0,
+             "er_sparse_cross_hashed_host: bad arguments");
+  for (int64_t r = 0; r < n_rows; ++r) {
+    uint64_t h = hash_key;
+    bool missing = false;
+    for (int32_t c = 0; c < n_cols && !missing; ++c) {
+      const int64_t i = static_cast<int64_t>(c) * n_rows + r;
+      const int64_t b = offsets[i], e = offsets[i + 1];
+      if (e == b) {
+        missing = true;  // '' is dropped from a dense string input: no combination left for this row
+      } else {
+        h = fingerprint_cat64(h, er::fh::fingerprint64(bytes + b, static_cast<uint64_t>(e - b)));
+      }
+    }
+    out[r] = missing ? -1 : static_cast<int64_t>(h % num_buckets);
+  }
+  return 0;
+}
+
 int er_hash_bucket_fast(const uint8_t* bytes, const int64_t* offsets, int64_t n, int64_t n_per_col,
                         const uint64_t* num_buckets, int drop_empty, int64_t* out, er_stream_t stream) {
   ER_REQUIRE(n >= 0 && n_per_col > 0, "er_hash_bucket_fast: bad sizes");

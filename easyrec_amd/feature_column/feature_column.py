@@ -292,14 +292,17 @@ class FeatureColumnParser(object):
       self._deep_columns[feature_name] = fc
 
   def parse_combo_feature(self, config):
-    """reference feature_column.py:424-455 (join-separator variant = one hashed column)."""
+    """reference feature_column.py:424-455: crossed_column, or with combo_join_sep one hashed column."""
     feature_name = config.feature_name if config.HasField('feature_name') else None
     assert len(config.input_names) >= 2
     if len(config.combo_join_sep) == 0:
-      raise NotImplementedError(
-          'ComboFeature via crossed_column (sparse_cross_hashed) is outside the hot-path scope '
-          '(SURVEY.md 8f rank 3); set combo_join_sep to use the hashed-join variant')
-    fc = CategoricalColumn(feature_name, 'hash', self._get_hash_bucket_size(config), feature_name)
+      # crossed_column(input names, hash_bucket_size, hash_key=None, feature_name) (:434-445): the crossed id comes
+      # out of the input pipeline (input/input.py, er_sparse_cross_hashed_host); from here on an identity column
+      # named feature_name (CrossedColumn.name, compat/feature_column/feature_column_v2.py:4501-4504)
+      assert feature_name, 'ComboFeature needs feature_name'
+      fc = CategoricalColumn(feature_name, 'identity', self._get_hash_bucket_size(config), feature_name)
+    else:
+      fc = CategoricalColumn(feature_name, 'hash', self._get_hash_bucket_size(config), feature_name)
     if self.is_wide(config):
       self._add_wide_embedding_column(fc, config)
     if self.is_deep(config):

@@ -248,6 +248,19 @@ class Input(object, metaclass=_meta_type):
         self._parse_tag(fc, columns, out, name)
       elif ft == FeatureConfig.SequenceFeature:
         self._parse_seq(fc, columns, out, name)
+      elif ft == FeatureConfig.ComboFeature and name in sch.int_single:
+        # crossed_column: every input as a string (input.py:407 `_as_string`), one combination per row
+        assert len(fc.combo_input_seps) == 0 or all(s == '' for s in fc.combo_input_seps), \
+            'ComboFeature %s: multi-valued inputs (combo_input_seps) are not supported' % name
+        strs = []
+        for n in fc.input_names:
+          ftype = self.field_type(n)
+          col = columns[n]
+          strs.extend(as_string(col, ftype, fc.precision) if ftype != DatasetConfig.STRING else col)
+        data, offsets = pack_strings(strs)
+        from easyrec_amd import kernels
+        int_ids[sch.int_single[name]['col']] = kernels.hip().sparse_cross_hashed_host(
+            data, offsets, B, len(fc.input_names), sch.int_single[name]['num_buckets'])
       elif ft == FeatureConfig.ComboFeature and name in sch.hash_single:
         cols = [columns[n] for n in fc.input_names]
         joined = [fc.combo_join_sep.join(str(c[i]) for c in cols) for i in range(B)]

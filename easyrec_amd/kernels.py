@@ -115,6 +115,9 @@ class GemmProblem(ctypes.Structure):  # = er_gemm_problem
               ('ldc', ctypes.c_int32), ('bias', ctypes.c_void_p), ('accumulate', ctypes.c_int32)]
 
 
+CROSS_HASH_KEY = 0xDECAFCAFFE  # tf.sparse.cross_hashed's default hash_key (crossed_column(hash_key=None))
+
+
 class DenseApplyDesc(ctypes.Structure):  # = er_dense_apply_desc
   _fields_ = [('var', ctypes.c_void_p), ('m', ctypes.c_void_p), ('v', ctypes.c_void_p), ('dense', ctypes.c_void_p),
               ('ld', ctypes.c_int32), ('dim', ctypes.c_int32), ('rows', ctypes.c_int64)]
@@ -256,6 +259,22 @@ class HipBackend(object):
     return keys, vals
 
   # -- K1 hashing
+  def sparse_cross_hashed_host(self, bytes_np, offsets_np, n_rows, n_cols, num_buckets, hash_key=None):
+    """ComboFeature through crossed_column: column-major strings -> int64 [n_rows] bucket ids (-1: a '' in the row)."""
+    bytes_np = np.ascontiguousarray(bytes_np, dtype=np.uint8)
+    offsets_np = np.ascontiguousarray(offsets_np, dtype=np.int64)
+    assert len(offsets_np) == n_rows * n_cols + 1
+    out = np.empty(n_rows, dtype=np.int64)
+    if bytes_np.size == 0:
+      bytes_np = np.zeros(1, dtype=np.uint8)
+    key = CROSS_HASH_KEY if hash_key is None else int(hash_key)
+    self._ck(
+        self.lib.er_sparse_cross_hashed_host(
+            bytes_np.ctypes.data_as(ctypes.c_void_p), offsets_np.ctypes.data_as(ctypes.c_void_p),
+            ctypes.c_int64(int(n_rows)), ctypes.c_int32(int(n_cols)), ctypes.c_uint64(int(num_buckets)),
+            ctypes.c_uint64(key), out.ctypes.data_as(ctypes.c_void_p)), 'er_sparse_cross_hashed_host')
+    return out
+
   def hash_bucket_fast_host(self, bytes_np, offsets_np, n_per_col, num_buckets, drop_empty):
     """numpy in / numpy out; runs on the host (data-loader threads)."""
     bytes_np = np.ascontiguousarray(bytes_np, dtype=np.uint8)

@@ -67,6 +67,15 @@ int er_hash_bucket_fast_host(const uint8_t* bytes_host, const int64_t* offsets_h
 int er_hash_bucket_fast(const uint8_t* bytes, const int64_t* offsets, int64_t n, int64_t n_per_col,
                         const uint64_t* num_buckets, int drop_empty, int64_t* out,
                         er_stream_t stream);
+/* ComboFeature through `crossed_column` (reference feature_column/feature_column.py:434-445 ->
+ * CrossedColumn._transform_feature, compat/feature_column/feature_column_v2.py:4527-4560 -> TF's
+ * sparse_cross_hashed): one string per (column, row), column-major (string i = c * n_rows + r);
+ *   out[r] = Fold_c FingerprintCat64(h, Fingerprint64(string[c][r])) mod num_buckets, h0 = hash_key
+ * (TF's default 0xDECAFCAFFE when the config gives none), -1 when any of the row's strings is '' (dropped before
+ * the cross: no combination, zero embedding).  Host-side: it belongs to the input pipeline, the ids then go
+ * through the lookup like any identity column.  Pinned by the example in the Keras `HashedCrossing` docs. */
+int er_sparse_cross_hashed_host(const uint8_t* bytes_host, const int64_t* offsets_host, int64_t n_rows,
+                                int32_t n_cols, uint64_t num_buckets, uint64_t hash_key, int64_t* out_host);
 /* AsString for integer id columns (feature_column_v2.py:3918, input/input.py:356-376): decimal
  * text of int64 -> hashed directly on device without materialising strings. */
 int er_hash_bucket_fast_int64(const int64_t* values, int64_t n, int64_t n_per_col,

@@ -52,6 +52,51 @@ def hash_bucket_fast(bytes_np, offsets_np, n_per_col, num_buckets, drop_empty):
   return out
 
 
+# ---- ComboFeature through crossed_column: TF's sparse_cross_hashed (hashed_output=True) --------------------------
+# reference call site: CrossedColumn._transform_feature, compat/feature_column/feature_column_v2.py:4527-4560
+# (`sparse_ops.sparse_cross_hashed(inputs, num_buckets=hash_bucket_size, hash_key=self.hash_key)`), reached from
+# FeatureColumnParser.parse_combo_feature (feature_column/feature_column.py:434-445, hash_key=None).  TensorFlow is
+# third-party and absent from /root/reference; its published algorithm (sparse_cross_op.cc HashCrosser +
+# platform/fingerprint.h FingerprintCat64): start from hash_key (default 0xDECAFCAFFE), fold every column's value -
+# Fingerprint64 of a string, an int64 as it is - with FingerprintCat64, then mod num_buckets.  Pinned by the example
+# in the Keras `HashedCrossing` docs (tests/test_oracle_hash.py).
+DEFAULT_CROSS_HASH_KEY = 0xDECAFCAFFE
+
+
+def fingerprint_cat64(fp1, fp2):
+  m, k = (1 << 64) - 1, 0xc6a4a7935bd1e995
+
+  def shift_mix(x):
+    return x ^ (x >> 47)
+
+  r = fp1 ^ k
+  r ^= (shift_mix((fp2 * k) & m) * k) & m
+  r = (r * k) & m
+  r = (shift_mix(r) * k) & m
+  return shift_mix(r)
+
+
+def sparse_cross_hashed(values, num_buckets, hash_key=DEFAULT_CROSS_HASH_KEY):
+  """values: one entry per crossed column (bytes / str -> Fingerprint64, int -> itself).  One combination."""
+  h = hash_key
+  for v in values:
+    fp = (v & ((1 << 64) - 1)) if isinstance(v, (int, np.integer)) else fingerprint64(v)
+    h = fingerprint_cat64(h, fp)
+  return h % int(num_buckets)
+
+
+def sparse_cross_hashed_columns(bytes_np, offsets_np, n_rows, n_cols, num_buckets, hash_key=DEFAULT_CROSS_HASH_KEY):
+  """Column-major packed strings (string i = c * n_rows + r) -> int64 [n_rows]; -1 where any string of the row is ''
+  (dropped from a dense string input before the cross: feature_column.py:2599-2643)."""
+  raw = np.ascontiguousarray(bytes_np, dtype=np.uint8).tobytes()
+  off = np.ascontiguousarray(offsets_np, dtype=np.int64)
+  out = np.empty(n_rows, dtype=np.int64)
+  for r in range(n_rows):
+    vals = [raw[int(off[c * n_rows + r]):int(off[c * n_rows + r + 1])] for c in range(n_cols)]
+    out[r] = -1 if any(len(v) == 0 for v in vals) else sparse_cross_hashed(vals, num_buckets, hash_key)
+  return out
+
+
 # ---- pure-python transcription (small cases; independent of the C file's compiler) -------------
 _M = (1 << 64) - 1
 _K0, _K1, _K2 = 0xc3a5c85c97cb3127, 0xb492b66fbe98f273, 0x9ae16a3b2f90404f

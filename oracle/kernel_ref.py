@@ -211,6 +211,10 @@ class RefBackend(object):
   def hash_bucket_fast_host(self, bytes_np, offsets_np, n_per_col, num_buckets, drop_empty):
     return hashing.hash_bucket_fast(bytes_np, offsets_np, n_per_col, num_buckets, drop_empty)
 
+  def sparse_cross_hashed_host(self, bytes_np, offsets_np, n_rows, n_cols, num_buckets, hash_key=None):
+    key = hashing.DEFAULT_CROSS_HASH_KEY if hash_key is None else hash_key
+    return hashing.sparse_cross_hashed_columns(bytes_np, offsets_np, n_rows, n_cols, num_buckets, key)
+
   def hash_bucket_fast(self, bytes_t, offsets_t, n_per_col, num_buckets_t, drop_empty, out=None):
     r = hashing.hash_bucket_fast(bytes_t.cpu().numpy(), offsets_t.cpu().numpy(), n_per_col,
                                  num_buckets_t.cpu().numpy().astype(np.uint64), drop_empty)

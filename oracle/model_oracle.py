@@ -153,6 +153,9 @@ class OracleTrainer(object):
         col += 1
       elif self._bounds(f) is not None:
         col += 1  # the batch carries the bucket index too; the oracle re-derives it from the raw value
+      elif f.feature_type == f.ComboFeature and len(f.combo_join_sep) == 0:
+        out[n] = np.asarray(batch['int_ids'])[col]  # crossed id from the input stage (oracle/hashing.py pins it)
+        col += 1
     return out
 
   # ------------------------------------------------------------------ embedding columns
@@ -248,7 +251,8 @@ class OracleTrainer(object):
         else:
           e = self._lookup_dense(table, np.zeros(self.B, dtype=np.int64), raws[n])
         outs.append((e, True))
-      elif fc.feature_type == fc.IdFeature:
+      elif fc.feature_type == fc.IdFeature or (fc.feature_type == fc.ComboFeature and n in ints):
+        # (crossed ComboFeature: CrossedColumn under an EmbeddingColumn, the id comes from the input stage)
         table = V.get(self._column_var_name(scope, fc, wide))
         ids = hashed[n] if n in hashed else ints[n]
         outs.append((self._lookup_dense(table, ids), True))

@@ -121,7 +121,8 @@ def test_csv_input_roundtrip(tmp_path, built_lib):
                                       ('multi_tower_criteo_small.config', 24), ('dlrm_criteo_small.config', 24),
                                       ('dlrm_itself_criteo_small.config', 24), ('dlrm_cat_criteo_small.config', 24),
                                       ('deepfm_bucketized_criteo_small.config', 24),
-                                      ('dlrm_shared_criteo_small.config', 24), ('deepfm_shared_criteo_small.config', 24)])
+                                      ('dlrm_shared_criteo_small.config', 24), ('deepfm_shared_criteo_small.config', 24),
+                                      ('deepfm_combo_criteo_small.config', 24)])
 def test_other_models_match_model_oracle(ref_backend, config, B):
   """DCN / MultiTowerDIN / MMoE host logic (variable naming, layer wiring, multi-task losses, sequence and
   tag lookups) against the independent model-level oracle, 2 optimisation steps."""
@@ -212,3 +213,44 @@ def test_bucketized_raw_feature_ids():
   exp = [sum(1 for b in (0.05, 0.2, 0.5, 0.8) if np.float32(b) <= v) for v in x]
   assert list(got) == exp and exp[0] == 0 and exp[3] == 3 and exp[5] == 4, (list(got), exp, list(x))
   assert sch.int_single['F3']['num_buckets'] == 11 and sch.int_single['F1']['num_buckets'] == 5
+
+
+def test_combo_feature_crossed_column_through_the_input_and_the_model(ref_backend, tmp_path):
+  """ComboFeature without combo_join_sep = crossed_column (reference feature_column.py:434-445): CSVInput computes the
+  crossed id (sparse_cross_hashed of the two inputs' strings, '' drops the row) and the model looks it up like any id
+  column; ids against the pinned restatement, two training steps against the model oracle."""
+  from easyrec_amd.input.csv_input import CSVInput
+  from easyrec_amd.model.easy_rec_estimator import EasyRecEstimator
+  from oracle import hashing
+  from oracle.model_oracle import OracleTrainer
+  cfg = config_util.get_configs_from_pipeline_file('configs/deepfm_combo_criteo_small.config')
+  B, rows = 24, []
+  rng = np.random.default_rng(2)
+  for i in range(2 * B):
+    f = ['%d' % rng.integers(0, 50) if rng.random() > 0.2 else '' for _ in range(13)]
+    c = ['%02x' % rng.integers(0, 40) if rng.random() > 0.15 else '' for _ in range(26)]
+    rows.append('\t'.join(['%d' % (i % 3 == 0)] + f + c))
+  p = tmp_path / 'data.tsv'
+  p.write_text('\n'.join(rows) + '\n')
+  feats = list(cfg.feature_config.features)
+  inp = CSVInput(cfg.data_config, feats, str(p), batch_size=B, hash_on_host=True)
+  batches = list(inp.batches())[:2]
+  est = EasyRecEstimator(cfg, device='cpu', batch_size=B, seed=3).build()
+  col = est.features.schema.int_single['C1_C2_cross']['col']
+  got = batches[0]['int_ids'][col]
+  for r in range(B):
+    c1, c2 = rows[r].split('\t')[14], rows[r].split('\t')[15]
+    exp = -1 if (c1 == '' or c2 == '') else hashing.sparse_cross_hashed([c1, c2], 1000)
+    assert got[r] == exp, (r, c1, c2)
+  assert (got == -1).any() and (got >= 0).sum() > B // 2
+  assert any('C1_C2_cross' in n for n in est.state_dict())  # its own embedding tables (deep and wide)
+  orc = OracleTrainer(cfg, est.state_dict(), batch_size=B)
+  for b in batches:
+    est.train_step(b)
+    res, exp = est.loss_values(), orc.train_step(b)
+    for k in exp:
+      assert abs(res[k] - exp[k]) <= 2e-5 * max(1.0, abs(exp[k])), (k, res[k], exp[k])
+  st = est.state_dict()
+  for k, v in orc.state.items():
+    if 'C1_C2_cross' in k:
+      assert np.allclose(st[k], v, rtol=1e-4, atol=1e-6), k

@@ -1,5 +1,6 @@
 """Pins the hashing oracle to TensorFlow's published vectors, then the library's host entry point
 (er_hash_bucket_fast_host) to the oracle."""
+import ctypes
 import json
 import os
 
@@ -63,3 +64,40 @@ def test_library_host_hash_matches_oracle(built_lib):
     got = be.hash_bucket_fast_host(data, offs, n // 2, nb, drop)
     exp = hashing.hash_bucket_fast(data, offs, n // 2, nb, drop)
     assert np.array_equal(got, exp)
+
+
+def test_sparse_cross_hashed_known_answer_from_the_keras_docs():
+  """tf.keras.layers.HashedCrossing(num_bins=5) on (['A','B','A','B','A'], [101,101,101,102,102]) -> [1, 4, 1, 1, 3]
+  (TF API docs; the layer calls tf.sparse.cross_hashed(inputs, num_bins): strings are fingerprinted, int64 values go
+  in as they are, folded with FingerprintCat64 from the default hash_key 0xDECAFCAFFE).  This pins the restatement
+  behind ComboFeature / crossed_column (reference feature_column/feature_column.py:434-445)."""
+  from oracle import hashing
+  f1, f2 = ['A', 'B', 'A', 'B', 'A'], [101, 101, 101, 102, 102]
+  assert [hashing.sparse_cross_hashed([a, b], 5) for a, b in zip(f1, f2)] == [1, 4, 1, 1, 3]
+  # order matters (the fold is not symmetric), and the key is part of the hash
+  assert hashing.sparse_cross_hashed(['A', 'B'], 1 << 40) != hashing.sparse_cross_hashed(['B', 'A'], 1 << 40)
+  assert hashing.sparse_cross_hashed(['A', 'B'], 1 << 40) != hashing.sparse_cross_hashed(['A', 'B'], 1 << 40, hash_key=1)
+
+
+def test_sparse_cross_hashed_host_entry_equals_the_oracle(built_lib):
+  """er_sparse_cross_hashed_host (the product's input-stage entry point) against the restatement: random strings of
+  0..40 bytes in 2 and 3 columns, '' anywhere in a row drops the row (-1)."""
+  from easyrec_amd.input.input import pack_strings
+  rng = np.random.default_rng(5)
+  for n_cols, n_rows, buckets in ((2, 300, 1000), (3, 257, 1 << 33)):
+    strs = []
+    for _ in range(n_cols * n_rows):
+      n = int(rng.integers(0, 41)) if rng.random() > 0.1 else 0
+      strs.append(bytes(rng.integers(1, 256, size=n, dtype=np.uint8)))
+    data, offsets = pack_strings(strs)
+    exp = hashing.sparse_cross_hashed_columns(data, offsets, n_rows, n_cols, buckets)
+    lib = ctypes.CDLL(built_lib)
+    out = np.empty(n_rows, dtype=np.int64)
+    d = np.ascontiguousarray(data, dtype=np.uint8)
+    o = np.ascontiguousarray(offsets, dtype=np.int64)
+    rc = lib.er_sparse_cross_hashed_host(d.ctypes.data_as(ctypes.c_void_p), o.ctypes.data_as(ctypes.c_void_p),
+                                         ctypes.c_int64(n_rows), ctypes.c_int32(n_cols), ctypes.c_uint64(buckets),
+                                         ctypes.c_uint64(hashing.DEFAULT_CROSS_HASH_KEY), out.ctypes.data_as(ctypes.c_void_p))
+    assert rc == 0
+    assert np.array_equal(out, exp)
+    assert (out == -1).sum() > 0 and (out >= 0).sum() > 0

@@ -306,6 +306,28 @@ def shared_embedding_variant(src_name, dst_name, embedding_name='embedding'):
   write(cfg, dst_name)
 
 
+def combo_feature_variant(src_name, dst_name):
+  """+ one ComboFeature (crossed_column of two categorical inputs, reference feature_column.py:434-445) in every
+  feature group that holds both inputs."""
+  from easyrec_amd.protos import pipeline_pb2
+  from easyrec_amd.protos.feature_config_pb2 import FeatureConfig
+  here = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'configs')
+  cfg = pipeline_pb2.EasyRecConfig()
+  with open(os.path.join(here, src_name)) as f:
+    text_format.Merge(f.read(), cfg)
+  fc = cfg.feature_config.features.add()
+  fc.input_names.extend(['C1', 'C2'])
+  fc.feature_name = 'C1_C2_cross'
+  fc.feature_type = FeatureConfig.ComboFeature
+  fc.hash_bucket_size = 1000
+  fc.embedding_dim = 16
+  for g in cfg.model_config.feature_groups:
+    names = list(g.feature_names)
+    if 'C1' in names or any(n.startswith('C[') for n in names):
+      g.feature_names.append('C1_C2_cross')
+  write(cfg, dst_name)
+
+
 if __name__ == '__main__':
   write(deepfm_criteo(), 'deepfm_criteo.config')
   write(deepfm_criteo(optimizer='lazy_adam_optimizer'), 'deepfm_criteo_lazy_adam.config')
@@ -324,3 +346,4 @@ if __name__ == '__main__':
   write(mmoe_taobao(batch_size=128, scale=0.01), 'mmoe_taobao_small.config')
   shared_embedding_variant('dlrm_criteo_small.config', 'dlrm_shared_criteo_small.config')
   shared_embedding_variant('deepfm_criteo_small.config', 'deepfm_shared_criteo_small.config')
+  combo_feature_variant('deepfm_criteo_small.config', 'deepfm_combo_criteo_small.config')
