@@ -94,7 +94,13 @@ class FeatureSchema(object):
         # inputs' strings, er_sparse_cross_hashed_host) and looked up like any identity column
         assert fc.HasField('hash_bucket_size') and fc.hash_bucket_size > 0, 'ComboFeature %s needs hash_bucket_size' % name
         self.int_single[name] = {'col': len(self.int_single), 'num_buckets': int(fc.hash_bucket_size), 'cross': True}
-      elif ft in (FeatureConfig.ComboFeature, FeatureConfig.LookupFeature):
+      elif ft == FeatureConfig.LookupFeature:
+        # the values of the row's map whose key equals the row's key (input.py:941-1000): a ragged lookup of hashed
+        # strings, at most lookup_max_sel_elem_num per row - the TagFeature machinery
+        assert fc.HasField('hash_bucket_size') and fc.hash_bucket_size > 0, 'LookupFeature %s needs hash_bucket_size' % name
+        self.tags[name] = {'cap': self.batch_size * max(int(fc.lookup_max_sel_elem_num), 1), 'weighted': False,
+                           'hash_buckets': int(fc.hash_bucket_size)}
+      elif ft == FeatureConfig.ComboFeature:
         if fc.HasField('hash_bucket_size') and fc.hash_bucket_size > 0:
           self.hash_single[name] = {'buckets': int(fc.hash_bucket_size), 'col': len(self.hash_single)}
       # Expr / PassThrough: handled by the Input class as raw values when used

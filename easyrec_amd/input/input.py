@@ -174,6 +174,30 @@ class Input(object, metaclass=_meta_type):
     if wts:
       out['tag/%s/weights' % name] = np.array(wts, dtype=np.float32)
 
+  def _parse_lookup(self, fc, columns, out, name):
+    """`Input._lookup_preprocess` (input.py:941-1000): input 0 = one key per row, input 1 = a map
+    'k<kv_separator>v' joined by `separator` (character-set split, empty tokens skipped); the feature's values are the
+    v of every pair whose k equals the key, in map order; they are hashed as they are ('' included: the tensor is
+    already sparse when it reaches categorical_column_with_hash_bucket)."""
+    B = self._batch_size
+    keys, maps = columns[fc.input_names[0]], columns[fc.input_names[1]]
+    max_sel = max(int(fc.lookup_max_sel_elem_num), 1)
+    toks, offs = [], np.zeros(B + 1, dtype=np.int32)
+    for i in range(B):
+      key = keys[i].decode('utf-8') if isinstance(keys[i], bytes) else str(keys[i])
+      sel = []
+      for kv in self._split_charset(maps[i], fc.separator):
+        parts = self._split_charset(kv, fc.kv_separator)
+        assert len(parts) == 2, 'LookupFeature %s: %r is not key%svalue' % (name, kv, fc.kv_separator)
+        if parts[0] == key:
+          sel.append(parts[1])
+      assert len(sel) <= max_sel, 'LookupFeature %s: %d values selected, lookup_max_sel_elem_num = %d' % (
+          name, len(sel), max_sel)
+      toks.extend(sel)
+      offs[i + 1] = len(toks)
+    out['tag/%s/ids' % name] = self._hash_tokens(toks, int(fc.hash_bucket_size)) if toks else np.zeros(0, dtype=np.int64)
+    out['tag/%s/offsets' % name] = offs
+
   def _parse_seq(self, fc, columns, out, name):
     B = self._batch_size
     L = self.schema.seqs[name]['max_len']
@@ -248,6 +272,8 @@ class Input(object, metaclass=_meta_type):
         self._parse_tag(fc, columns, out, name)
       elif ft == FeatureConfig.SequenceFeature:
         self._parse_seq(fc, columns, out, name)
+      elif ft == FeatureConfig.LookupFeature:
+        self._parse_lookup(fc, columns, out, name)
       elif ft == FeatureConfig.ComboFeature and name in sch.int_single:
         # crossed_column: every input as a string (input.py:407 `_as_string`), one combination per row
         assert len(fc.combo_input_seps) == 0 or all(s == '' for s in fc.combo_input_seps), \

@@ -256,7 +256,8 @@ class OracleTrainer(object):
         table = V.get(self._column_var_name(scope, fc, wide))
         ids = hashed[n] if n in hashed else ints[n]
         outs.append((self._lookup_dense(table, ids), True))
-      elif fc.feature_type == fc.TagFeature:
+      elif fc.feature_type in (fc.TagFeature, fc.LookupFeature):
+        # (LookupFeature: the selected map values arrive from the input stage as a ragged id list, input.py:941-1000)
         table = V.get(self._column_var_name(scope, fc, wide))
         w = batch.get('tag/%s/weights' % n)
         e = self._lookup_ragged(table, batch['tag/%s/ids' % n], batch['tag/%s/offsets' % n], w,

@@ -122,7 +122,7 @@ def test_csv_input_roundtrip(tmp_path, built_lib):
                                       ('dlrm_itself_criteo_small.config', 24), ('dlrm_cat_criteo_small.config', 24),
                                       ('deepfm_bucketized_criteo_small.config', 24),
                                       ('dlrm_shared_criteo_small.config', 24), ('deepfm_shared_criteo_small.config', 24),
-                                      ('deepfm_combo_criteo_small.config', 24)])
+                                      ('deepfm_combo_criteo_small.config', 24), ('deepfm_lookup_criteo_small.config', 24)])
 def test_other_models_match_model_oracle(ref_backend, config, B):
   """DCN / MultiTowerDIN / MMoE host logic (variable naming, layer wiring, multi-task losses, sequence and
   tag lookups) against the independent model-level oracle, 2 optimisation steps."""
@@ -253,4 +253,45 @@ def test_combo_feature_crossed_column_through_the_input_and_the_model(ref_backen
   st = est.state_dict()
   for k, v in orc.state.items():
     if 'C1_C2_cross' in k:
+      assert np.allclose(st[k], v, rtol=1e-4, atol=1e-6), k
+
+
+def test_lookup_feature_through_the_input_and_the_model(ref_backend, tmp_path):
+  """LookupFeature (reference input/input.py:941-1000): the values of the row's map whose key equals the row's key,
+  hashed, combined ('mean' here) - ids against a direct restatement, two training steps against the model oracle."""
+  from easyrec_amd.input.csv_input import CSVInput
+  from easyrec_amd.model.easy_rec_estimator import EasyRecEstimator
+  from oracle import hashing
+  from oracle.model_oracle import OracleTrainer
+  cfg = config_util.get_configs_from_pipeline_file('configs/deepfm_lookup_criteo_small.config')
+  B, rows, want = 24, [], []
+  rng = np.random.default_rng(4)
+  for i in range(2 * B):
+    f = ['%d' % rng.integers(0, 50) if rng.random() > 0.2 else '' for _ in range(13)]
+    c = ['k%d' % rng.integers(0, 4) for _ in range(26)]
+    pairs = [('k%d' % rng.integers(0, 4), 'v%d' % rng.integers(0, 30)) for _ in range(int(rng.integers(0, 7)))]
+    while sum(1 for k, _ in pairs if k == c[2]) > 4:  # lookup_max_sel_elem_num
+      pairs.pop()
+    kv = '|'.join('%s:%s' % p for p in pairs)
+    want.append([v for k, v in pairs if k == c[2]])
+    rows.append('\t'.join(['%d' % (i % 3 == 0)] + f + c + [kv]))
+  p = tmp_path / 'data.tsv'
+  p.write_text('\n'.join(rows) + '\n')
+  inp = CSVInput(cfg.data_config, list(cfg.feature_config.features), str(p), batch_size=B, hash_on_host=True)
+  batches = list(inp.batches())[:2]
+  ids, offs = batches[0]['tag/C3_lookup/ids'], batches[0]['tag/C3_lookup/offsets']
+  assert offs[-1] == len(ids) and len(ids) > B // 4
+  for r in range(B):
+    got = ids[offs[r]:offs[r + 1]].tolist()
+    assert got == [hashing.fingerprint64(v) % 500 for v in want[r]], r
+  est = EasyRecEstimator(cfg, device='cpu', batch_size=B, seed=3).build()
+  orc = OracleTrainer(cfg, est.state_dict(), batch_size=B)
+  for b in batches:
+    est.train_step(b)
+    res, exp = est.loss_values(), orc.train_step(b)
+    for k in exp:
+      assert abs(res[k] - exp[k]) <= 2e-5 * max(1.0, abs(exp[k])), (k, res[k], exp[k])
+  st = est.state_dict()
+  for k, v in orc.state.items():
+    if 'C3_lookup' in k:
       assert np.allclose(st[k], v, rtol=1e-4, atol=1e-6), k

@@ -328,6 +328,35 @@ def combo_feature_variant(src_name, dst_name):
   write(cfg, dst_name)
 
 
+def lookup_feature_variant(src_name, dst_name):
+  """+ one LookupFeature (reference input/input.py:941-1000, feature_column.py:457-476): key = C3, map = a new
+  string field 'KV' of 'key:value' pairs joined by '|'."""
+  from easyrec_amd.protos import pipeline_pb2
+  from easyrec_amd.protos.dataset_pb2 import DatasetConfig
+  from easyrec_amd.protos.feature_config_pb2 import FeatureConfig
+  here = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'configs')
+  cfg = pipeline_pb2.EasyRecConfig()
+  with open(os.path.join(here, src_name)) as f:
+    text_format.Merge(f.read(), cfg)
+  fld = cfg.data_config.input_fields.add()
+  fld.input_name = 'KV'
+  fld.input_type = DatasetConfig.STRING
+  fc = cfg.feature_config.features.add()
+  fc.input_names.extend(['C3', 'KV'])
+  fc.feature_name = 'C3_lookup'
+  fc.feature_type = FeatureConfig.LookupFeature
+  fc.hash_bucket_size = 500
+  fc.embedding_dim = 16
+  fc.separator = '|'
+  fc.kv_separator = ':'
+  fc.lookup_max_sel_elem_num = 4
+  fc.combiner = 'mean'
+  for g in cfg.model_config.feature_groups:
+    if 'C3' in list(g.feature_names):
+      g.feature_names.append('C3_lookup')
+  write(cfg, dst_name)
+
+
 if __name__ == '__main__':
   write(deepfm_criteo(), 'deepfm_criteo.config')
   write(deepfm_criteo(optimizer='lazy_adam_optimizer'), 'deepfm_criteo_lazy_adam.config')
@@ -347,3 +376,4 @@ if __name__ == '__main__':
   shared_embedding_variant('dlrm_criteo_small.config', 'dlrm_shared_criteo_small.config')
   shared_embedding_variant('deepfm_criteo_small.config', 'deepfm_shared_criteo_small.config')
   combo_feature_variant('deepfm_criteo_small.config', 'deepfm_combo_criteo_small.config')
+  lookup_feature_variant('deepfm_criteo_small.config', 'deepfm_lookup_criteo_small.config')
