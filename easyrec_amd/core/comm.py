@@ -3,18 +3,20 @@
 The reference issues these through Horovod (`hvd.alltoall(ids, splits)`, `hvd.alltoall(rows, ...)`,
 `hvd.allreduce(grad, op=Average)`; compat/feature_column/feature_column.py:296-357,
 compat/optimizers.py:285-345).  Here they are `torch.distributed` calls on device tensors: backend
-"nccl" IS RCCL on ROCm; the CPU tests use "gloo".  Only four operations exist:
+"nccl" IS RCCL on ROCm; the CPU tests use "gloo".
 
-  exchange_counts   all-gather of a small [G, W] int32 matrix of per-owner unique-key counts ->
-                    host-side send/recv split lists (the ONE host synchronisation of a step)
-  all_to_all        variable-split exchange of keys (int32), rows and gradient rows (fp32, [n, dim])
-  all_to_all_equal  the same with a fixed capacity per peer (padded): no host-side sizes, so no exchange_counts
-                    and no host synchronisation - the default (layers/sharded_embedding.py)
-  all_reduce_sum    dense gradients / replicated small tables (scaled by 1/W in the optimizer kernels)
-  all_gather_rows   checkpoint/test only: collect the shards of a table
+  all_to_all_equal  fixed capacity per peer (padded buffers): numel / world elements to and from every peer, no
+                    host-side sizes, nothing to synchronise on - the default exchange (layers/sharded_embedding.py):
+                    per route one for [count, keys], one for rows, one for row gradients
+  all_reduce_sum    dense gradients with the replicated small tables' gradients behind them (scaled by 1 / W in the
+                    optimizer kernels)
+  exchange_counts   compact exchange only (more than 16 ranks): all-gather of a small [G, W] int32 matrix of
+                    per-owner unique-key counts -> host-side send / recv split lists (one host synchronisation a step)
+  all_to_all        compact exchange only: variable-split exchange of keys (int32), rows and gradient rows
+  all_gather_rows   checkpoint / test only: collect the shards of a table
 
-Messages are small at B=4096 (<= 1 MB per peer), i.e. latency-bound on xGMI's point-to-point links;
-they are issued per embedding-dim group so that a step has 3 all-to-alls per group.
+Messages are small at B=4096 (<= 1 MB per peer), i.e. latency-bound on xGMI's point-to-point links: what counts is
+how many collectives a step issues (4 for DeepFM), not their bytes.
 """
 import torch
 
