@@ -36,6 +36,8 @@ def _worst(a, b):
   for k in b:
     if k.endswith('/bias') or k.endswith('/bias/m') or k.endswith('/bias/v'):
       continue  # zero-gradient biases under BatchNorm: rounding noise through Adam
+    if float(np.max(np.abs(b[k]))) < 1e-6:
+      continue  # a shift in front of a BatchNorm (MultiTowerDIN's feature-BN beta) has a zero gradient too: noise only
     d = float(np.max(np.abs(a[k] - b[k]))) / (float(np.max(np.abs(b[k]))) + 1e-12)
     if d > worst[1]:
       worst = (k, d)
@@ -107,7 +109,9 @@ def test_routing_kernels_against_numpy(W, B, rows):
     (3, False, False, 'deepfm_criteo_small.config'),
     # ONE table behind all 26 categorical features (the reference's own embedding-parallel Criteo config): the
     # device-wide sort + the fixed-capacity layout pass instead of the per-lookup sort
-    (2, True, True, 'deepfm_shared_criteo_small.config'), (4, False, True, 'deepfm_shared_criteo_small.config')])
+    (2, True, True, 'deepfm_shared_criteo_small.config'), (4, False, True, 'deepfm_shared_criteo_small.config'),
+    # sequence + key lookups of MultiTowerDIN, ragged TagFeature lookups of MMoE through the same exchange
+    (2, True, True, 'din_taobao_small.config'), (2, False, True, 'mmoe_taobao_small.config')])
 def test_sharded_ranks_with_the_same_batch_equal_single_gpu(world, lazy, padded, config, monkeypatch):
   """Every rank sees the SAME batch: each embedding row gets world * g / world and each dense gradient
   the average of identical gradients, so the W-rank run must follow the single-GPU run (to the fp32
@@ -116,9 +120,13 @@ def test_sharded_ranks_with_the_same_batch_equal_single_gpu(world, lazy, padded,
   monkeypatch.setenv('EASYREC_AMD_PADDED_EXCHANGE', '1' if padded else '0')
   cfg = _cfg(config, lazy)
   B, steps = 128, 2
-  gen = SyntheticCriteo(cfg.data_config, list(cfg.feature_config.features), batch_size=B, seed=9)
-  batches = [gen.next_batch() for _ in range(steps)]
   ref = EasyRecEstimator(cfg, device=DEV, batch_size=B, seed=4).build()
+  if 'criteo' in config:
+    gen = SyntheticCriteo(cfg.data_config, list(cfg.feature_config.features), batch_size=B, seed=9)
+  else:
+    from easyrec_amd.input.synthetic import SyntheticBatches
+    gen = SyntheticBatches(cfg.data_config, ref.feature_configs, batch_size=B, seed=9)
+  batches = [gen.next_batch() for _ in range(steps)]
   ref_losses = []
   for b in batches:
     ref.train_step(b)
@@ -139,7 +147,8 @@ def test_sharded_ranks_with_the_same_batch_equal_single_gpu(world, lazy, padded,
 
   results = sim.run(rank_fn)
   for state, losses, placement in results:
-    assert any(p[0] == 'shard' for p in placement.values()) and any(p[0] == 'rep' for p in placement.values())
+    assert any(p[0] == 'shard' for p in placement.values())
+    assert 'criteo' not in config or any(p[0] == 'rep' for p in placement.values())
     for got, exp in zip(losses, ref_losses):
       assert abs(got['total_loss'] - exp['total_loss']) <= 2e-4 * abs(exp['total_loss']), (got, exp)
     first = {k: v for k, v in state.items() if k.endswith('/m')}
