@@ -148,3 +148,40 @@ def test_model_trains_from_parquet_batches(tmp_path, ref_backend):
     if n == 2:
       break
   assert n == 2
+
+
+def test_reference_ep_scenario_parquet_shared_table_lazy_adam(tmp_path, ref_backend):
+  """The shape of the reference's own embedding-parallel config (samples/model_config/
+  dlrm_on_criteo_parquet_ep_v2.config): ParquetInput, ONE table behind every id feature (`embedding_name`),
+  `lazy_adam_optimizer`, EmbeddingParallelStrategy - here on the small parquet fixture: the embedding-parallel
+  estimator (world 1, fixed-capacity exchange after the device-wide sort) must follow the plain one exactly."""
+  from easyrec_amd.model.easy_rec_estimator import EasyRecEstimator
+  from easyrec_amd.model.embedding_parallel import EmbeddingParallelEstimator
+  cfg, reader = _parquet_reader(tmp_path)
+  for fc in cfg.feature_config.features:
+    if fc.num_buckets > 0:
+      fc.embedding_name = 'embedding'
+  oc = cfg.train_config.optimizer_config[0]
+  if oc.WhichOneof('optimizer') == 'adam_optimizer':
+    oc.lazy_adam_optimizer.learning_rate.CopyFrom(oc.adam_optimizer.learning_rate)
+  B = cfg.data_config.batch_size
+  batches = []
+  for b in reader.batches():
+    batches.append(b)
+    if len(batches) == 3:
+      break
+  ref = EasyRecEstimator(cfg, device='cpu', batch_size=B, seed=2).build()
+  est = EmbeddingParallelEstimator(cfg, device='cpu', batch_size=B, seed=2, rank=0, world=1, replicate_bytes=64).build()
+  assert est.engine.padded and any(p[0] == 'shard' for p in est.engine.placement.values())
+  shared = [n for n in est.engine.tables if n.startswith('embedding')]
+  assert shared and len(est.engine.tables) < len(list(cfg.feature_config.features)) + 2  # one table for the id features
+  for b in batches:
+    ref.train_step(b)
+    est.train_step(b)
+    a, c = ref.loss_values(), est.loss_values()
+    for k in a:
+      assert abs(a[k] - c[k]) <= 1e-6 * max(1.0, abs(a[k])), (k, a[k], c[k])
+  sa, sc = ref.state_dict(slots=True), est.state_dict(slots=True)
+  assert set(sa) == set(sc)
+  for k in sa:
+    assert np.allclose(sa[k], sc[k], rtol=1e-6, atol=1e-8), k
