@@ -238,17 +238,13 @@ int er_sparse_cross_hashed_host(const uint8_t* bytes, const int64_t* offsets, in
              "er_sparse_cross_hashed_host: bad arguments");
   for (int64_t r = 0; r < n_rows; ++r) {
     uint64_t h = hash_key;
-    bool missing = false;
-    for (int32_t c = 0; c < n_cols && !missing; ++c) {
+    for (int32_t c = 0; c < n_cols; ++c) {
+      // ('' is a value like any other here: CrossedColumn hands the dense string tensors to the op as they are)
       const int64_t i = static_cast<int64_t>(c) * n_rows + r;
       const int64_t b = offsets[i], e = offsets[i + 1];
-      if (e == b) {
-        missing = true;  // '' is dropped from a dense string input: no combination left for this row
-      } else {
-        h = fingerprint_cat64(h, er::fh::fingerprint64(bytes + b, static_cast<uint64_t>(e - b)));
-      }
+      h = fingerprint_cat64(h, er::fh::fingerprint64(bytes + b, static_cast<uint64_t>(e - b)));
     }
-    out[r] = missing ? -1 : static_cast<int64_t>(h % num_buckets);
+    out[r] = static_cast<int64_t>(h % num_buckets);
   }
   return 0;
 }

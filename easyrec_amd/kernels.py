@@ -260,7 +260,7 @@ class HipBackend(object):
 
   # -- K1 hashing
   def sparse_cross_hashed_host(self, bytes_np, offsets_np, n_rows, n_cols, num_buckets, hash_key=None):
-    """ComboFeature through crossed_column: column-major strings -> int64 [n_rows] bucket ids (-1: a '' in the row)."""
+    """ComboFeature through crossed_column: column-major strings -> int64 [n_rows] bucket ids ('' is a value too)."""
     bytes_np = np.ascontiguousarray(bytes_np, dtype=np.uint8)
     offsets_np = np.ascontiguousarray(offsets_np, dtype=np.int64)
     assert len(offsets_np) == n_rows * n_cols + 1

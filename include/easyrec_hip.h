@@ -71,8 +71,8 @@ int er_hash_bucket_fast(const uint8_t* bytes, const int64_t* offsets, int64_t n,
  * CrossedColumn._transform_feature, compat/feature_column/feature_column_v2.py:4527-4560 -> TF's
  * sparse_cross_hashed): one string per (column, row), column-major (string i = c * n_rows + r);
  *   out[r] = Fold_c FingerprintCat64(h, Fingerprint64(string[c][r])) mod num_buckets, h0 = hash_key
- * (TF's default 0xDECAFCAFFE when the config gives none), -1 when any of the row's strings is '' (dropped before
- * the cross: no combination, zero embedding).  Host-side: it belongs to the input pipeline, the ids then go
+ * (TF's default 0xDECAFCAFFE when the config gives none).  '' is crossed like any other value: the column passes
+ * the dense string tensors to the op unfiltered (:4556-4558), unlike the hashed id columns.  Host-side: it belongs to the input pipeline, the ids then go
  * through the lookup like any identity column.  Pinned by the example in the Keras `HashedCrossing` docs. */
 int er_sparse_cross_hashed_host(const uint8_t* bytes_host, const int64_t* offsets_host, int64_t n_rows,
                                 int32_t n_cols, uint64_t num_buckets, uint64_t hash_key, int64_t* out_host);

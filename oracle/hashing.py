@@ -86,14 +86,15 @@ def sparse_cross_hashed(values, num_buckets, hash_key=DEFAULT_CROSS_HASH_KEY):
 
 
 def sparse_cross_hashed_columns(bytes_np, offsets_np, n_rows, n_cols, num_buckets, hash_key=DEFAULT_CROSS_HASH_KEY):
-  """Column-major packed strings (string i = c * n_rows + r) -> int64 [n_rows]; -1 where any string of the row is ''
-  (dropped from a dense string input before the cross: feature_column.py:2599-2643)."""
+  """Column-major packed strings (string i = c * n_rows + r) -> int64 [n_rows].  '' is crossed like any value:
+  CrossedColumn._transform_feature appends `inputs.get(key)` - the dense string tensor - unfiltered
+  (feature_column_v2.py:4556-4558); only the hashed id columns drop '' first."""
   raw = np.ascontiguousarray(bytes_np, dtype=np.uint8).tobytes()
   off = np.ascontiguousarray(offsets_np, dtype=np.int64)
   out = np.empty(n_rows, dtype=np.int64)
   for r in range(n_rows):
     vals = [raw[int(off[c * n_rows + r]):int(off[c * n_rows + r + 1])] for c in range(n_cols)]
-    out[r] = -1 if any(len(v) == 0 for v in vals) else sparse_cross_hashed(vals, num_buckets, hash_key)
+    out[r] = sparse_cross_hashed(vals, num_buckets, hash_key)
   return out
 
 
