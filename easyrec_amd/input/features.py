@@ -89,6 +89,12 @@ class FeatureSchema(object):
         hb = int(fc.hash_bucket_size) if fc.HasField('hash_bucket_size') and fc.hash_bucket_size > 0 else None
         ml = int(fc.max_seq_len) if fc.HasField('max_seq_len') and fc.max_seq_len > 0 else max_seq_len
         self.seqs[name] = {'max_len': ml, 'hash_buckets': hb}
+      elif ft == FeatureConfig.ComboFeature and len(fc.combo_join_sep) == 0 and any(len(x) > 0 for x in fc.combo_input_seps):
+        # crossed_column over multi-valued inputs (input.py:400-405: tf.string_split by combo_input_seps[i]): every
+        # combination of one token per input is an id - a ragged lookup like a TagFeature, ids from the host
+        assert fc.HasField('hash_bucket_size') and fc.hash_bucket_size > 0, 'ComboFeature %s needs hash_bucket_size' % name
+        self.tags[name] = {'cap': self.batch_size * max_tag_len, 'weighted': False, 'hash_buckets': None,
+                           'num_buckets': int(fc.hash_bucket_size), 'cross': True}
       elif ft == FeatureConfig.ComboFeature and len(fc.combo_join_sep) == 0:
         # crossed_column (feature_column.py:434-445): the id is computed on the host (sparse_cross_hashed of the
         # inputs' strings, er_sparse_cross_hashed_host) and looked up like any identity column

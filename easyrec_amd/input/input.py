@@ -174,6 +174,38 @@ class Input(object, metaclass=_meta_type):
     if wts:
       out['tag/%s/weights' % name] = np.array(wts, dtype=np.float32)
 
+  def _parse_combo_multi(self, fc, columns, out, name):
+    """ComboFeature with combo_input_seps (input.py:383-407): input i is split by combo_input_seps[i] (character-set
+    split, empty tokens skipped; '' = not split: the whole string, '' included, is its one value); the crossed column
+    then emits one id per combination of one value from every input (no values in one input: no id for the row)."""
+    from easyrec_amd import kernels
+    import itertools
+    B = self._batch_size
+    n_in = len(fc.input_names)
+    assert len(fc.combo_input_seps) == n_in, 'len(combo_separator)[%d] != len(fc.input_names)[%d]' % (
+        len(fc.combo_input_seps), n_in)
+    per_input = []
+    for i, n in enumerate(fc.input_names):
+      col, sep = columns[n], fc.combo_input_seps[i]
+      if sep != '':
+        per_input.append([self._split_charset(s, sep) for s in col])
+      else:
+        ftype = self.field_type(n)
+        vals = as_string(col, ftype, fc.precision) if ftype != DatasetConfig.STRING else col
+        per_input.append([[v.decode('utf-8') if isinstance(v, bytes) else v] for v in vals])
+    combos, offs = [], np.zeros(B + 1, dtype=np.int32)
+    for r in range(B):
+      combos.extend(itertools.product(*[per_input[i][r] for i in range(n_in)]))
+      offs[r + 1] = len(combos)
+    n = len(combos)
+    if n:
+      data, offsets = pack_strings([c[i] for i in range(n_in) for c in combos])  # column-major: input i, combination k
+      ids = kernels.hip().sparse_cross_hashed_host(data, offsets, n, n_in, int(fc.hash_bucket_size))
+    else:
+      ids = np.zeros(0, dtype=np.int64)
+    out['tag/%s/ids' % name] = ids
+    out['tag/%s/offsets' % name] = offs
+
   def _parse_lookup(self, fc, columns, out, name):
     """`Input._lookup_preprocess` (input.py:941-1000): input 0 = one key per row, input 1 = a map
     'k<kv_separator>v' joined by `separator` (character-set split, empty tokens skipped); the feature's values are the
@@ -274,10 +306,10 @@ class Input(object, metaclass=_meta_type):
         self._parse_seq(fc, columns, out, name)
       elif ft == FeatureConfig.LookupFeature:
         self._parse_lookup(fc, columns, out, name)
+      elif ft == FeatureConfig.ComboFeature and name in sch.tags:
+        self._parse_combo_multi(fc, columns, out, name)
       elif ft == FeatureConfig.ComboFeature and name in sch.int_single:
         # crossed_column: every input as a string (input.py:407 `_as_string`), one combination per row
-        assert len(fc.combo_input_seps) == 0 or all(s == '' for s in fc.combo_input_seps), \
-            'ComboFeature %s: multi-valued inputs (combo_input_seps) are not supported' % name
         strs = []
         for n in fc.input_names:
           ftype = self.field_type(n)

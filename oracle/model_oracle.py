@@ -153,7 +153,7 @@ class OracleTrainer(object):
         col += 1
       elif self._bounds(f) is not None:
         col += 1  # the batch carries the bucket index too; the oracle re-derives it from the raw value
-      elif f.feature_type == f.ComboFeature and len(f.combo_join_sep) == 0:
+      elif f.feature_type == f.ComboFeature and len(f.combo_join_sep) == 0 and not any(len(x) for x in f.combo_input_seps):
         out[n] = np.asarray(batch['int_ids'])[col]  # crossed id from the input stage (oracle/hashing.py pins it)
         col += 1
     return out
@@ -256,7 +256,8 @@ class OracleTrainer(object):
         table = V.get(self._column_var_name(scope, fc, wide))
         ids = hashed[n] if n in hashed else ints[n]
         outs.append((self._lookup_dense(table, ids), True))
-      elif fc.feature_type in (fc.TagFeature, fc.LookupFeature):
+      elif fc.feature_type in (fc.TagFeature, fc.LookupFeature) or (
+          fc.feature_type == fc.ComboFeature and ('tag/%s/ids' % n) in batch):
         # (LookupFeature: the selected map values arrive from the input stage as a ragged id list, input.py:941-1000)
         table = V.get(self._column_var_name(scope, fc, wide))
         w = batch.get('tag/%s/weights' % n)

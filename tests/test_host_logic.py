@@ -294,3 +294,46 @@ def test_lookup_feature_through_the_input_and_the_model(ref_backend, tmp_path):
   for k, v in orc.state.items():
     if 'C3_lookup' in k:
       assert np.allclose(st[k], v, rtol=1e-4, atol=1e-6), k
+
+
+def test_combo_feature_with_multi_valued_inputs(ref_backend, tmp_path):
+  """ComboFeature + combo_input_seps (input.py:383-407): the second input is split by '|'; every (C1 value, C4 token)
+  pair is one crossed id - a ragged lookup.  Ids against the pinned restatement, two steps against the model oracle."""
+  import itertools
+  from easyrec_amd.input.csv_input import CSVInput
+  from easyrec_amd.model.easy_rec_estimator import EasyRecEstimator
+  from easyrec_amd.protos.feature_config_pb2 import FeatureConfig
+  from oracle import hashing
+  from oracle.model_oracle import OracleTrainer
+  cfg = config_util.get_configs_from_pipeline_file('configs/deepfm_criteo_small.config')
+  fc = cfg.feature_config.features.add()
+  fc.input_names.extend(['C1', 'C4'])
+  fc.combo_input_seps.extend(['', '|'])
+  fc.feature_name, fc.feature_type, fc.hash_bucket_size, fc.embedding_dim = 'C1_C4_cross', FeatureConfig.ComboFeature, 700, 16
+  fc.combiner = 'mean'
+  for g in cfg.model_config.feature_groups:
+    g.feature_names.append('C1_C4_cross')
+  B, rows, want = 24, [], []
+  rng = np.random.default_rng(6)
+  for i in range(2 * B):
+    f = ['%d' % rng.integers(0, 50) if rng.random() > 0.2 else '' for _ in range(13)]
+    c = ['%02x' % rng.integers(0, 40) if rng.random() > 0.15 else '' for _ in range(26)]
+    toks = ['t%d' % rng.integers(0, 9) for _ in range(int(rng.integers(0, 4)))]
+    c[3] = '|'.join(toks)
+    want.append(list(itertools.product([c[0]], toks)))
+    rows.append('\t'.join(['%d' % (i % 3 == 0)] + f + c))
+  p = tmp_path / 'data.tsv'
+  p.write_text('\n'.join(rows) + '\n')
+  inp = CSVInput(cfg.data_config, list(cfg.feature_config.features), str(p), batch_size=B, hash_on_host=True)
+  batches = list(inp.batches())[:2]
+  ids, offs = batches[0]['tag/C1_C4_cross/ids'], batches[0]['tag/C1_C4_cross/offsets']
+  for r in range(B):
+    assert ids[offs[r]:offs[r + 1]].tolist() == [hashing.sparse_cross_hashed(list(cb), 700) for cb in want[r]], r
+  assert any(len(w) == 0 for w in want[:B]) and any(len(w) > 1 for w in want[:B])
+  est = EasyRecEstimator(cfg, device='cpu', batch_size=B, seed=3).build()
+  orc = OracleTrainer(cfg, est.state_dict(), batch_size=B)
+  for b in batches:
+    est.train_step(b)
+    res, exp = est.loss_values(), orc.train_step(b)
+    for k in exp:
+      assert abs(res[k] - exp[k]) <= 2e-5 * max(1.0, abs(exp[k])), (k, res[k], exp[k])
