@@ -525,6 +525,17 @@ class OracleTrainer(object):
       pred['logits_%s' % tower.tower_name] = out.squeeze(1)
     return pred
 
+  def _simple_multi_task(self, V, batch):
+    """model/simple_multi_task.py:36-54: one tower DNN per task on the shared input."""
+    mc = self.cfg.model_config
+    l2 = self._l2_of(mc)
+    x, _ = self.input_layer(V, batch, 'all', 'input_layer')
+    pred = {}
+    for t, tower in enumerate(mc.simple_multi_task.task_towers):
+      h = self.dnn(V, x, tower.dnn, tower.tower_name, l2)
+      pred['logits_%s' % tower.tower_name] = self.dense(V, h, tower.num_class, 'dnn_output_%d' % t, l2).squeeze(1)
+    return pred
+
   # ------------------------------------------------------------------ backbone (RankModel)
   def _keras_mlp(self, V, x, p, name, l2):
     """layers/keras/blocks.py:37-128: Dense(use_bias=False, he_uniform) -> BatchNorm -> activation per layer;
@@ -630,11 +641,13 @@ class OracleTrainer(object):
     labels_np = np.asarray(batch['labels'], dtype=np.float32)
     ce_of = lambda z, y: (torch.clamp(z, min=0) - z * y + torch.log1p(torch.exp(-torch.abs(z)))).mean()  # noqa: E731
     losses = OrderedDict()
-    if self.model_class == 'MMoE':
-      pred = self._mmoe(V, batch)
+    if self.model_class in ('MMoE', 'SimpleMultiTask'):
+      pred = self._mmoe(V, batch) if self.model_class == 'MMoE' else self._simple_multi_task(V, batch)
+      towers = (self.cfg.model_config.mmoe if self.model_class == 'MMoE'
+                else self.cfg.model_config.simple_multi_task).task_towers
       label_fields = list(self.cfg.data_config.label_fields)
       ce = torch.zeros((), dtype=self.dtype)
-      for t, tower in enumerate(self.cfg.model_config.mmoe.task_towers):
+      for t, tower in enumerate(towers):
         lname = tower.label_name if tower.HasField('label_name') else label_fields[t]
         y = torch.as_tensor(labels_np[label_fields.index(lname)], dtype=self.dtype)
         z = pred['logits_%s' % tower.tower_name]

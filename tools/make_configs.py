@@ -357,6 +357,26 @@ def lookup_feature_variant(src_name, dst_name):
   write(cfg, dst_name)
 
 
+def simple_multi_task_variant(src_name, dst_name):
+  """The MMoE fixture with `simple_multi_task { task_towers ... }` instead of the expert / gate layer
+  (reference model/simple_multi_task.py)."""
+  from easyrec_amd.protos import pipeline_pb2
+  here = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'configs')
+  cfg = pipeline_pb2.EasyRecConfig()
+  with open(os.path.join(here, src_name)) as f:
+    text_format.Merge(f.read(), cfg)
+  mm = cfg.model_config.mmoe
+  towers = [t for t in mm.task_towers]
+  l2 = mm.l2_regularization
+  cfg.model_config.ClearField('mmoe')
+  cfg.model_config.model_class = 'SimpleMultiTask'
+  smt = cfg.model_config.simple_multi_task
+  smt.l2_regularization = l2
+  for t in towers:
+    smt.task_towers.add().CopyFrom(t)
+  write(cfg, dst_name)
+
+
 if __name__ == '__main__':
   write(deepfm_criteo(), 'deepfm_criteo.config')
   write(deepfm_criteo(optimizer='lazy_adam_optimizer'), 'deepfm_criteo_lazy_adam.config')
@@ -377,3 +397,4 @@ if __name__ == '__main__':
   shared_embedding_variant('deepfm_criteo_small.config', 'deepfm_shared_criteo_small.config')
   combo_feature_variant('deepfm_criteo_small.config', 'deepfm_combo_criteo_small.config')
   lookup_feature_variant('deepfm_criteo_small.config', 'deepfm_lookup_criteo_small.config')
+  simple_multi_task_variant('mmoe_taobao_small.config', 'simple_multi_task_taobao_small.config')
