@@ -1,6 +1,5 @@
 """MMoE (reference easy_rec/python/model/mmoe.py:14-70): shared `all` group -> MMOE layer -> per-task
 tower DNN -> dense(num_class) named `dnn_output_<i>`."""
-from easyrec_amd.layers import dnn
 from easyrec_amd.layers import mmoe
 from easyrec_amd.model.multi_task_model import MultiTaskModel
 from easyrec_amd.protos.mmoe_pb2 import MMoE as MMoEConfig
@@ -25,16 +24,4 @@ class MMoE(MultiTaskModel):
     else:
       mmoe_layer = mmoe.MMOE([x.dnn for x in self._model_config.experts], l2_reg=self._l2_reg,
                              num_task=self._task_num, is_training=self._is_training)
-    task_input_list = mmoe_layer(self._features)
-    tower_outputs = {}
-    for i, task_tower_cfg in enumerate(self._model_config.task_towers):
-      tower_name = task_tower_cfg.tower_name
-      if task_tower_cfg.HasField('dnn'):
-        tower_dnn = dnn.DNN(task_tower_cfg.dnn, self._l2_reg, name=tower_name, is_training=self._is_training)
-        tower_output = tower_dnn(task_input_list[i])
-      else:
-        tower_output = task_input_list[i]
-      tower_outputs[tower_name] = dnn.dense(tower_output, task_tower_cfg.num_class, 'dnn_output_%d' % i,
-                                            l2_reg=self._l2_reg)
-    self._add_to_prediction_dict(tower_outputs)
-    return self._prediction_dict
+    return self._tower_heads(mmoe_layer(self._features))

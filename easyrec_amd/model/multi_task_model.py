@@ -34,6 +34,20 @@ class MultiTaskModel(RankModel):
         assert label_name in self._labels, 'label [%s] must exists in labels' % label_name
         self._label_name_dict[tower_name] = label_name
 
+  def _tower_heads(self, inputs_per_task):
+    """Shared tail of the multi-task models here (MMoE, SimpleMultiTask): task t's input goes through the tower's
+    DNN when it has one, then the `dnn_output_<t>` projection to num_class (reference model/mmoe.py:56-68,
+    model/simple_multi_task.py:38-52); fills the prediction dict."""
+    from easyrec_amd.layers import dnn
+    heads = {}
+    for t, tower in enumerate(self._task_towers):
+      h = inputs_per_task[t]
+      if tower.HasField('dnn'):
+        h = dnn.DNN(tower.dnn, self._l2_reg, name=tower.tower_name, is_training=self._is_training)(h)
+      heads[tower.tower_name] = dnn.dense(h, tower.num_class, 'dnn_output_%d' % t, l2_reg=self._l2_reg)
+    self._add_to_prediction_dict(heads)
+    return self._prediction_dict
+
   def _add_to_prediction_dict(self, output):
     for task_tower_cfg in self._task_towers:
       tower_name = task_tower_cfg.tower_name
