@@ -536,6 +536,40 @@ class OracleTrainer(object):
       pred['logits_%s' % tower.tower_name] = self.dense(V, h, tower.num_class, 'dnn_output_%d' % t, l2).squeeze(1)
     return pred
 
+  def _ple(self, V, batch):
+    """model/ple.py:36-118: CGC layers (task experts + shared experts, one softmax gate per task and one for the
+    shared path except in the last layer), then the towers."""
+    mc = self.cfg.model_config
+    c = mc.ple
+    l2 = self._l2_of(mc)
+    x, _ = self.input_layer(V, batch, 'all', 'input_layer')
+    T = len(c.task_towers)
+
+    def gate(sel, cands, name):
+      g = torch.softmax(self.dense(V, sel, len(cands), name + '_gate/dnn', l2), dim=1)
+      return (torch.stack(cands, dim=1) * g[:, :, None]).sum(dim=1)
+
+    task_in, shared_in = [x] * T, x
+    nets = list(c.extraction_networks)
+    for li, net in enumerate(nets):
+      nm = net.network_name
+      shared = [self.dnn(V, shared_in, net.share_expert_net, '%s_share/dnn_expert_%d/dnn' % (nm, e), l2)
+                for e in range(net.share_num)]
+      all_task, outs = [], []
+      for t in range(T):
+        tn = '%s_task_%d' % (nm, t)
+        mine = [self.dnn(V, task_in[t], net.task_expert_net, '%s_expert_%d/dnn' % (tn, e), l2)
+                for e in range(net.expert_num_per_task)]
+        outs.append(gate(task_in[t], mine + shared, tn))
+        all_task.extend(mine)
+      new_shared = None if li == len(nets) - 1 else gate(shared_in, all_task + shared, nm + '_share')
+      task_in, shared_in = outs, new_shared
+    pred = {}
+    for t, tower in enumerate(c.task_towers):
+      h = self.dnn(V, task_in[t], tower.dnn, tower.tower_name, l2) if tower.HasField('dnn') else task_in[t]
+      pred['logits_%s' % tower.tower_name] = self.dense(V, h, tower.num_class, 'dnn_output_%d' % t, l2).squeeze(1)
+    return pred
+
   # ------------------------------------------------------------------ backbone (RankModel)
   def _keras_mlp(self, V, x, p, name, l2):
     """layers/keras/blocks.py:37-128: Dense(use_bias=False, he_uniform) -> BatchNorm -> activation per layer;
@@ -641,10 +675,11 @@ class OracleTrainer(object):
     labels_np = np.asarray(batch['labels'], dtype=np.float32)
     ce_of = lambda z, y: (torch.clamp(z, min=0) - z * y + torch.log1p(torch.exp(-torch.abs(z)))).mean()  # noqa: E731
     losses = OrderedDict()
-    if self.model_class in ('MMoE', 'SimpleMultiTask'):
-      pred = self._mmoe(V, batch) if self.model_class == 'MMoE' else self._simple_multi_task(V, batch)
-      towers = (self.cfg.model_config.mmoe if self.model_class == 'MMoE'
-                else self.cfg.model_config.simple_multi_task).task_towers
+    if self.model_class in ('MMoE', 'SimpleMultiTask', 'PLE'):
+      fn, sub = {'MMoE': (self._mmoe, 'mmoe'), 'SimpleMultiTask': (self._simple_multi_task, 'simple_multi_task'),
+                 'PLE': (self._ple, 'ple')}[self.model_class]
+      pred = fn(V, batch)
+      towers = getattr(self.cfg.model_config, sub).task_towers
       label_fields = list(self.cfg.data_config.label_fields)
       ce = torch.zeros((), dtype=self.dtype)
       for t, tower in enumerate(towers):

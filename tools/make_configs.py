@@ -377,6 +377,32 @@ def simple_multi_task_variant(src_name, dst_name):
   write(cfg, dst_name)
 
 
+def ple_variant(src_name, dst_name):
+  """The MMoE fixture as PLE (reference model/ple.py): two extraction networks, 2 experts per task + 2 shared."""
+  from easyrec_amd.protos import pipeline_pb2
+  here = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'configs')
+  cfg = pipeline_pb2.EasyRecConfig()
+  with open(os.path.join(here, src_name)) as f:
+    text_format.Merge(f.read(), cfg)
+  mm = cfg.model_config.mmoe
+  towers = [t for t in mm.task_towers]
+  l2 = mm.l2_regularization
+  cfg.model_config.ClearField('mmoe')
+  cfg.model_config.model_class = 'PLE'
+  ple = cfg.model_config.ple
+  ple.l2_regularization = l2
+  for i, units in enumerate(([64, 32], [32, 16])):
+    net = ple.extraction_networks.add()
+    net.network_name = 'network_%d' % i
+    net.expert_num_per_task = 2
+    net.share_num = 2
+    net.task_expert_net.hidden_units.extend(units)
+    net.share_expert_net.hidden_units.extend(units)
+  for t in towers:
+    ple.task_towers.add().CopyFrom(t)
+  write(cfg, dst_name)
+
+
 if __name__ == '__main__':
   write(deepfm_criteo(), 'deepfm_criteo.config')
   write(deepfm_criteo(optimizer='lazy_adam_optimizer'), 'deepfm_criteo_lazy_adam.config')
@@ -398,3 +424,4 @@ if __name__ == '__main__':
   combo_feature_variant('deepfm_criteo_small.config', 'deepfm_combo_criteo_small.config')
   lookup_feature_variant('deepfm_criteo_small.config', 'deepfm_lookup_criteo_small.config')
   simple_multi_task_variant('mmoe_taobao_small.config', 'simple_multi_task_taobao_small.config')
+  ple_variant('mmoe_taobao_small.config', 'ple_taobao_small.config')
