@@ -51,7 +51,7 @@ def load_keras_layer(name):
 def import_all_models():
   """Import every model module so that the registry is populated."""
   for mod in ('deepfm', 'dcn', 'multi_tower_din', 'mmoe', 'rank_model', 'multi_task_model', 'wide_and_deep', 'fm',
-              'multi_tower', 'dlrm', 'simple_multi_task', 'ple'):
+              'multi_tower', 'dlrm', 'simple_multi_task', 'ple', 'dbmtl'):
     try:
       importlib.import_module('easyrec_amd.model.' + mod)
     except ImportError as e:  # pragma: no cover

@@ -570,6 +570,24 @@ class OracleTrainer(object):
       pred['logits_%s' % tower.tower_name] = self.dense(V, h, tower.num_class, 'dnn_output_%d' % t, l2).squeeze(1)
     return pred
 
+  def _dbmtl(self, V, batch):
+    """model/dbmtl.py:46-116 without the optional MMoE block: bottom (dnn) -> tower dnn -> relation dnn over
+    [own features, earlier towers' relation features] -> output."""
+    mc = self.cfg.model_config
+    c = mc.dbmtl
+    l2 = self._l2_of(mc)
+    x, _ = self.input_layer(V, batch, 'all', 'input_layer')
+    if c.HasField('bottom_dnn'):
+      x = self.dnn(V, x, c.bottom_dnn, 'bottom_dnn', l2)
+    rel, pred = {}, {}
+    for tower in c.task_towers:
+      nm = tower.tower_name
+      own = self.dnn(V, x, tower.dnn, nm + '/dnn', l2) if tower.HasField('dnn') else x
+      inp = torch.cat([own] + [rel[r] for r in tower.relation_tower_names], dim=-1)
+      rel[nm] = self.dnn(V, inp, tower.relation_dnn, nm + '/relation_dnn', l2)
+      pred['logits_%s' % nm] = self.dense(V, rel[nm], tower.num_class, nm + '/output', l2).squeeze(1)
+    return pred
+
   # ------------------------------------------------------------------ backbone (RankModel)
   def _keras_mlp(self, V, x, p, name, l2):
     """layers/keras/blocks.py:37-128: Dense(use_bias=False, he_uniform) -> BatchNorm -> activation per layer;
@@ -675,9 +693,9 @@ class OracleTrainer(object):
     labels_np = np.asarray(batch['labels'], dtype=np.float32)
     ce_of = lambda z, y: (torch.clamp(z, min=0) - z * y + torch.log1p(torch.exp(-torch.abs(z)))).mean()  # noqa: E731
     losses = OrderedDict()
-    if self.model_class in ('MMoE', 'SimpleMultiTask', 'PLE'):
+    if self.model_class in ('MMoE', 'SimpleMultiTask', 'PLE', 'DBMTL'):
       fn, sub = {'MMoE': (self._mmoe, 'mmoe'), 'SimpleMultiTask': (self._simple_multi_task, 'simple_multi_task'),
-                 'PLE': (self._ple, 'ple')}[self.model_class]
+                 'PLE': (self._ple, 'ple'), 'DBMTL': (self._dbmtl, 'dbmtl')}[self.model_class]
       pred = fn(V, batch)
       towers = getattr(self.cfg.model_config, sub).task_towers
       label_fields = list(self.cfg.data_config.label_fields)

@@ -79,7 +79,8 @@ def test_multi_tower_din_matches_oracle(lazy):
                                   'dlrm_cat_criteo_small.config', 'deepfm_bucketized_criteo_small.config',
                                   'dlrm_shared_criteo_small.config', 'deepfm_shared_criteo_small.config',
                                   'deepfm_combo_criteo_small.config', 'deepfm_lookup_criteo_small.config',
-                                  'simple_multi_task_taobao_small.config', 'ple_taobao_small.config'])
+                                  'simple_multi_task_taobao_small.config', 'ple_taobao_small.config',
+                                  'dbmtl_taobao_small.config'])
 def test_neighbouring_models_match_oracle(name):
   """WideAndDeep / FM / MultiTower / DLRM on the HIP kernels against the model oracle."""
   _first_steps(_cfg(name), 128, 41)

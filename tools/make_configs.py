@@ -403,6 +403,34 @@ def ple_variant(src_name, dst_name):
   write(cfg, dst_name)
 
 
+def dbmtl_variant(src_name, dst_name):
+  """The MMoE fixture as DBMTL (reference model/dbmtl.py): bottom_dnn, per-task towers, cvr's relation network also
+  reads ctr's relation features."""
+  from easyrec_amd.protos import pipeline_pb2
+  here = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'configs')
+  cfg = pipeline_pb2.EasyRecConfig()
+  with open(os.path.join(here, src_name)) as f:
+    text_format.Merge(f.read(), cfg)
+  mm = cfg.model_config.mmoe
+  towers = [t for t in mm.task_towers]
+  l2 = mm.l2_regularization
+  cfg.model_config.ClearField('mmoe')
+  cfg.model_config.model_class = 'DBMTL'
+  db = cfg.model_config.dbmtl
+  db.l2_regularization = l2
+  db.bottom_dnn.hidden_units.extend([128, 64])
+  for i, t in enumerate(towers):
+    bt = db.task_towers.add()
+    bt.tower_name, bt.label_name, bt.num_class, bt.weight = t.tower_name, t.label_name, t.num_class, t.weight
+    for m in t.metrics_set:
+      bt.metrics_set.add().CopyFrom(m)
+    bt.dnn.hidden_units.extend([64, 32])
+    bt.relation_dnn.hidden_units.extend([32])
+    if i > 0:
+      bt.relation_tower_names.append(towers[0].tower_name)
+  write(cfg, dst_name)
+
+
 if __name__ == '__main__':
   write(deepfm_criteo(), 'deepfm_criteo.config')
   write(deepfm_criteo(optimizer='lazy_adam_optimizer'), 'deepfm_criteo_lazy_adam.config')
@@ -425,3 +453,4 @@ if __name__ == '__main__':
   lookup_feature_variant('deepfm_criteo_small.config', 'deepfm_lookup_criteo_small.config')
   simple_multi_task_variant('mmoe_taobao_small.config', 'simple_multi_task_taobao_small.config')
   ple_variant('mmoe_taobao_small.config', 'ple_taobao_small.config')
+  dbmtl_variant('mmoe_taobao_small.config', 'dbmtl_taobao_small.config')
