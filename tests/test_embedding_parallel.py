@@ -109,3 +109,23 @@ def test_world2_gloo_same_batch_equals_single_process(ref_backend, tmp_path, opt
   _compare(got, ref_state, 2e-5)
   loss = float(np.load(os.path.join(str(tmp_path), 'loss.npy'))[0])
   assert abs(loss - ref_losses[-1]['total_loss']) <= 1e-5 * abs(ref_losses[-1]['total_loss'])
+
+
+def test_evaluate_through_the_sharded_engine(ref_backend):
+  """EasyRecEstimator.evaluate() on the embedding-parallel estimator: the eval-mode forward goes through the same
+  route / exchange / lookup, gives the single-process metrics, and training continues identically afterwards."""
+  from easyrec_amd.model.embedding_parallel import EmbeddingParallelEstimator
+  from easyrec_amd.model.easy_rec_estimator import EasyRecEstimator
+  B = 32
+  cfg, batches = _cfg_and_batches(B, 3)
+  ref = EasyRecEstimator(cfg, device='cpu', batch_size=B, seed=3).build()
+  est = EmbeddingParallelEstimator(cfg, device='cpu', batch_size=B, seed=3, rank=0, world=1, replicate_bytes=1024).build()
+  for b in batches[:2]:
+    ref.train_step(b)
+    est.train_step(b)
+  a, c = ref.evaluate(batches), est.evaluate(batches)
+  assert a.keys() == c.keys() and all(abs(a[k] - c[k]) < 1e-6 for k in a), (a, c)
+  ref.train_step(batches[2])
+  est.train_step(batches[2])
+  ra, rc = ref.loss_values(), est.loss_values()
+  assert all(abs(ra[k] - rc[k]) <= 1e-6 * max(1.0, abs(ra[k])) for k in ra), (ra, rc)
