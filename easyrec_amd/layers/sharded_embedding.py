@@ -319,7 +319,7 @@ class ShardedEmbeddingEngine(EmbeddingEngine):
       be.emb_bwd_update_multi(owners[i:i + 4], opt_kind, hyper)
 
   def check_overflow(self):
-    """Blocking: did any step since the last check route more keys to one owner than the exchange's capacity?"""
+    """Blocking: has any step so far routed more keys to one owner than the exchange's capacity (the flag is sticky)?"""
     be = kernels.hip()
     for dim, sh in self.shard.items():
       if sh['peer_cap'] and sh['leader'] is None and be.emb_route_overflow(sh['req']):
