@@ -178,3 +178,29 @@ def test_evaluate_with_grouped_metrics(ref_backend):
   assert abs(out['gauc'] - float(_separated_auc_like_the_reference(labels, probs, k1.tolist(), 'mean_by_sample_num'))) < 1e-6
   assert abs(out['session_auc'] - float(_separated_auc_like_the_reference(labels, probs, k2.tolist(), 'mean'))) < 1e-6
   assert 0.0 <= out['max_f1'] <= 1.0
+
+
+def test_host_key_column_variants():
+  """The grouping keys of gAUC / session AUC come from the HOST batch: raw strings of a hashed id feature, the bucket
+  when the batch was hashed on the host, the integer of an identity feature; a packed (device) batch has none."""
+  from easyrec_amd.input.criteo_synthetic import SyntheticCriteo
+  from easyrec_amd.input.features import FeatureSchema, host_key_column
+  from easyrec_amd.utils import config_util
+  cfg = config_util.get_configs_from_pipeline_file(os.path.join(ROOT, 'configs', 'deepfm_criteo_small.config'))
+  feats = list(cfg.feature_config.features)
+  B = 16
+  gen = SyntheticCriteo(cfg.data_config, feats, batch_size=B, seed=1)
+  b = gen.next_batch()
+  sch = FeatureSchema(cfg.data_config, feats, batch_size=B)
+  k = host_key_column(sch, b, 'C5')
+  assert k.dtype == object and len(k) == B
+  j = sch.hash_single['C5']['col']
+  off = np.asarray(b['str_offsets'])
+  raw = np.asarray(b['str_bytes'], dtype=np.uint8).tobytes()
+  assert k[3] == raw[off[j * B + 3]:off[j * B + 4]]
+  hashed = {'hash_ids': np.arange(len(sch.hash_single) * B, dtype=np.int64).reshape(len(sch.hash_single), B)}
+  assert np.array_equal(host_key_column(sch, hashed, 'C5'), hashed['hash_ids'][j])
+  with pytest.raises(KeyError):
+    host_key_column(sch, {'packed': None}, 'C5')
+  with pytest.raises(KeyError):
+    host_key_column(sch, b, 'F1')  # a raw feature has no key column
