@@ -38,10 +38,10 @@ def _compare(a, b, tol):
     assert d <= tol * max(scale, 1e-3), (k, d, scale)
 
 
-def _cfg_and_batches(B, n, optimizer=None):
+def _cfg_and_batches(B, n, optimizer=None, config=None):
   from easyrec_amd.input.criteo_synthetic import SyntheticCriteo
   from easyrec_amd.utils import config_util
-  cfg = config_util.get_configs_from_pipeline_file(CFG)
+  cfg = config_util.get_configs_from_pipeline_file(os.path.join(ROOT, 'configs', config) if config else CFG)
   if optimizer == 'lazy':
     oc = cfg.train_config.optimizer_config[0]
     oc.lazy_adam_optimizer.learning_rate.CopyFrom(oc.adam_optimizer.learning_rate)
@@ -71,7 +71,7 @@ def test_world1_sharded_engine_equals_single_gpu_engine(ref_backend, optimizer, 
   _compare(est.state_dict(slots=True), ref_state, 1e-6)
 
 
-def _gloo_worker(rank, world, port, B, optimizer, out_dir):
+def _gloo_worker(rank, world, port, B, optimizer, out_dir, config=None):
   sys.path.insert(0, ROOT)
   os.environ['MASTER_ADDR'] = '127.0.0.1'
   os.environ['MASTER_PORT'] = str(port)
@@ -82,7 +82,7 @@ def _gloo_worker(rank, world, port, B, optimizer, out_dir):
   from oracle.kernel_ref import RefBackend
   kernels._BACKEND = RefBackend()  # CPU stand-in for the HIP kernels (tests only)
   from easyrec_amd.model.embedding_parallel import EmbeddingParallelEstimator
-  cfg, batches = _cfg_and_batches(B, 2, optimizer)
+  cfg, batches = _cfg_and_batches(B, 2, optimizer, config)
   est = EmbeddingParallelEstimator(cfg, device='cpu', batch_size=B, seed=3, rank=rank, world=world,
                                    replicate_bytes=1024).build()
   for b in batches:  # the SAME batch on every rank
@@ -96,14 +96,16 @@ def _gloo_worker(rank, world, port, B, optimizer, out_dir):
   dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('optimizer,padded', [(None, True), ('lazy', True), (None, False)])
-def test_world2_gloo_same_batch_equals_single_process(ref_backend, tmp_path, optimizer, padded, monkeypatch):
+@pytest.mark.parametrize('optimizer,padded,config', [
+    (None, True, None), ('lazy', True, None), (None, False, None),
+    ('lazy', True, 'deepfm_shared_criteo_small.config')])  # ONE table behind all categorical features
+def test_world2_gloo_same_batch_equals_single_process(ref_backend, tmp_path, optimizer, padded, config, monkeypatch):
   import torch.multiprocessing as mp
   monkeypatch.setenv('EASYREC_AMD_PADDED_EXCHANGE', '1' if padded else '0')  # (inherited by the spawned ranks)
   B, world = 24, 2
-  port = 29500 + (os.getpid() % 2000) + (7 if optimizer else 0) + (13 if padded else 0)
-  mp.spawn(_gloo_worker, args=(world, port, B, optimizer, str(tmp_path)), nprocs=world, join=True)
-  cfg, batches = _cfg_and_batches(B, 2, optimizer)
+  port = 29500 + (os.getpid() % 2000) + (7 if optimizer else 0) + (13 if padded else 0) + (29 if config else 0)
+  mp.spawn(_gloo_worker, args=(world, port, B, optimizer, str(tmp_path), config), nprocs=world, join=True)
+  cfg, batches = _cfg_and_batches(B, 2, optimizer, config)
   ref_state, ref_losses = _run_single(cfg, batches, B, seed=3)
   got = {k.replace('|', '/'): v for k, v in np.load(os.path.join(str(tmp_path), 'state.npz')).items()}
   _compare(got, ref_state, 2e-5)
