@@ -1,8 +1,10 @@
 """CSVInput: separator-delimited text -> batches (reference easy_rec/python/input/csv_input.py:17-175).
 
 `decode_csv` semantics used by the hot-path configs: split each line on `data_config.separator`,
-empty cells take the field's default (utils/input_utils.py:11-36).  Plumbing for config 1 (the
-reference's own CPU-runnable case); the MI355X benchmark feeds device-resident synthetic batches.
+empty cells take the field's default (utils/input_utils.py:11-36).  The decode itself is native, as in the
+reference (tf.decode_csv is a C++ kernel): `er_decode_csv_host` splits and parses a whole batch in one pass, string
+cells stay (begin, length) views of the file's bytes until they are packed for hashing (input.py PackedCol) - no
+per-cell Python work on the Criteo layout.  The MI355X benchmark feeds device-resident synthetic batches.
 """
 import numpy as np
 
@@ -15,6 +17,8 @@ class CSVInput(Input):
   def __init__(self, data_config, feature_configs, input_path=None, **kwargs):
     super(CSVInput, self).__init__(data_config, feature_configs, input_path, **kwargs)
     self._with_header = data_config.with_header
+    import os
+    self.native_decode = os.environ.get('EASYREC_AMD_NATIVE_CSV', '1') != '0'  # else the line-by-line Python path
 
   def _parse_lines(self, lines):
     sep = self._data_config.separator
@@ -33,8 +37,76 @@ class CSVInput(Input):
         cols[i].append(p)
     return {name: cols[i] for i, name in enumerate(self._input_fields)}
 
+  # -- native decode: one pass of er_decode_csv_host per batch ---------------------------------------------------
+  def _native_ok(self):
+    sep = self._data_config.separator
+    return self.native_decode and len(sep.encode('utf-8')) == 1 and sep not in ('\n', '\r')
+
+  def _columns_from_decoded(self, text, n, ints, flts, empty, begin, length):
+    """Decoded arrays of n rows -> the {input_name: column} dict `preprocess` takes: numpy arrays for numeric fields
+    (defaults filled in), PackedCol views of the text for string fields."""
+    from easyrec_amd.input.input import PackedCol
+    cols = {}
+    for f, name in enumerate(self._input_fields):
+      t = self._input_field_types[f]
+      miss = empty[f, :n] != 0
+      default = get_type_defaults(t, self._input_field_defaults[f])
+      if t == DatasetConfig.STRING:
+        if miss.any() and default not in ('', b''):
+          col = PackedCol(text, begin[f, :n], length[f, :n])
+          cols[name] = [default if miss[i] else col[i] for i in range(n)]
+        else:
+          cols[name] = PackedCol(text, begin[f, :n].copy(), length[f, :n].copy())
+      elif t in (DatasetConfig.INT32, DatasetConfig.INT64):
+        cols[name] = np.where(miss, np.int64(default), ints[f, :n])
+      else:
+        cols[name] = np.where(miss, np.float64(default), flts[f, :n])
+    return cols
+
+  def _native_batches(self, paths, drop_remainder):
+    from easyrec_amd import kernels
+    be = kernels.hip()
+    B = self._batch_size
+    kinds = [0 if t == DatasetConfig.STRING else 1 if t in (DatasetConfig.INT32, DatasetConfig.INT64) else 2
+             for t in self._input_field_types]
+    sep = self._data_config.separator
+    carry = None  # decoded rows of a batch that straddles two files: per-field python lists
+    for path in paths:
+      with open(path, 'rb') as f:
+        data = f.read()
+      if not data.endswith(b'\n'):
+        data += b'\n'
+      text = np.frombuffer(data, dtype=np.uint8)
+      pos = data.index(b'\n') + 1 if self._with_header else 0
+      while pos < len(text):
+        want = B - (len(next(iter(carry.values()))) if carry else 0)
+        n, used, ints, flts, empty, begin, length = be.decode_csv_host(text[pos:], sep, kinds, want)
+        if n == 0:
+          break
+        chunk = text[pos:]
+        pos += used
+        cols = self._columns_from_decoded(chunk, n, ints, flts, empty, begin, length)
+        if carry is None and n == B:
+          yield self.preprocess(cols)
+          continue
+        # a partial batch (file end) or its completion: fall back to plain lists for the few rows involved
+        lists = {k: [v[i] for i in range(n)] for k, v in cols.items()}
+        carry = lists if carry is None else {k: carry[k] + lists[k] for k in lists}
+        if len(next(iter(carry.values()))) == B:
+          yield self.preprocess(carry)
+          carry = None
+    if carry is not None and not drop_remainder:
+      n = len(next(iter(carry.values())))
+      yield self.preprocess({k: v + [v[-1]] * (B - n) for k, v in carry.items()})
+
   def batches(self, num_epochs=None, drop_remainder=True):
     """Yield batch dicts from the input file(s)."""
+    if self._native_ok():
+      paths = self._input_path if isinstance(self._input_path, list) else self._input_path.split(',')
+      for _ in range(num_epochs or self._data_config.num_epochs or 1):
+        for b in self._native_batches(paths, drop_remainder):
+          yield b
+      return
     paths = self._input_path if isinstance(self._input_path, list) else self._input_path.split(',')
     epochs = num_epochs or self._data_config.num_epochs or 1
     B = self._batch_size

@@ -46,6 +46,41 @@ def get_type_defaults(field_type, default_val=''):
   return float(default_val)
 
 
+class PackedCol(object):
+  """One string column of a decoded text batch: cells are (begin, length) slices of the batch's text buffer
+  (er_decode_csv_host) - nothing is copied until the strings are packed for hashing.  Behaves like a sequence of
+  `bytes` for the generic per-row code."""
+
+  def __init__(self, buf, begin, length):
+    self.buf, self.begin, self.length = buf, begin, length
+
+  def __len__(self):
+    return len(self.begin)
+
+  def __getitem__(self, i):
+    b = int(self.begin[i])
+    return self.buf[b:b + int(self.length[i])].tobytes()
+
+  def __iter__(self):
+    for i in range(len(self.begin)):
+      yield self[i]
+
+
+def pack_columns(cols):
+  """[PackedCol ...] over ONE text buffer -> (uint8 bytes, int64 offsets) of all their cells, column after column:
+  one vectorised gather instead of a Python loop over every cell."""
+  begin = np.concatenate([c.begin for c in cols]).astype(np.int64)
+  length = np.concatenate([c.length for c in cols]).astype(np.int64)
+  offsets = np.zeros(len(begin) + 1, dtype=np.int64)
+  np.cumsum(length, out=offsets[1:])
+  total = int(offsets[-1])
+  if total == 0:
+    return np.zeros(0, dtype=np.uint8), offsets
+  # byte k of the packed output comes from text[begin[cell] + (k - offsets[cell])]
+  src = np.repeat(begin - offsets[:-1], length) + np.arange(total, dtype=np.int64)
+  return cols[0].buf[src], offsets
+
+
 def pack_strings(strings):
   """list of str/bytes -> (uint8 bytes, int64 offsets[n+1])."""
   enc = [s if isinstance(s, bytes) else str(s).encode('utf-8') for s in strings]
@@ -326,10 +361,13 @@ class Input(object, metaclass=_meta_type):
     out['raw'] = raw
     out['int_ids'] = int_ids
     if hash_strings:
-      flat = []
-      for s in hash_strings:
-        flat.extend(s if s is not None else [''] * B)
-      data, offsets = pack_strings(flat)
+      if all(isinstance(s, PackedCol) for s in hash_strings) and len({id(s.buf) for s in hash_strings}) == 1:
+        data, offsets = pack_columns(hash_strings)  # cells of the decoded text batch: no per-cell Python work
+      else:
+        flat = []
+        for s in hash_strings:
+          flat.extend(s if s is not None else [''] * B)
+        data, offsets = pack_strings(flat)
       if self._hash_on_host:
         from easyrec_amd import kernels
         ids = kernels.hip().hash_bucket_fast_host(data, offsets, B, sch.hash_buckets_array, True)

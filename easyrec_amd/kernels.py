@@ -259,6 +259,32 @@ class HipBackend(object):
     return keys, vals
 
   # -- K1 hashing
+  def decode_csv_host(self, text, sep, kinds, max_rows):
+    """CSVInput's decode step on the host (er_decode_csv_host).  text: uint8 array; kinds: 0 string / 1 int / 2 float
+    per field.  Returns (n_rows, consumed bytes, ints [F, max_rows], floats, empty mask, str_begin, str_len)."""
+    text = np.ascontiguousarray(text, dtype=np.uint8)
+    kinds = np.ascontiguousarray(kinds, dtype=np.int32)
+    F = len(kinds)
+    ints = np.empty((F, max_rows), dtype=np.int64)
+    flts = np.empty((F, max_rows), dtype=np.float64)
+    empty = np.empty((F, max_rows), dtype=np.uint8)
+    begin = np.empty((F, max_rows), dtype=np.int64)
+    length = np.empty((F, max_rows), dtype=np.int32)
+    n_rows, consumed = ctypes.c_int64(0), ctypes.c_int64(0)
+    sep_b = sep.encode('utf-8') if isinstance(sep, str) else bytes(sep)
+    assert len(sep_b) == 1, 'separator must be one byte: %r' % sep
+
+    if text.size == 0:
+      return 0, 0, ints, flts, empty, begin, length
+
+    def ptr(a):
+      return a.ctypes.data_as(ctypes.c_void_p)
+    self._ck(self.lib.er_decode_csv_host(ptr(text), ctypes.c_int64(text.size), ctypes.c_uint8(sep_b[0]), ctypes.c_int32(F),
+                                         ptr(kinds), ctypes.c_int64(int(max_rows)), ptr(ints), ptr(flts), ptr(empty),
+                                         ptr(begin), ptr(length), ctypes.byref(n_rows), ctypes.byref(consumed)),
+             'er_decode_csv_host')
+    return n_rows.value, consumed.value, ints, flts, empty, begin, length
+
   def sparse_cross_hashed_host(self, bytes_np, offsets_np, n_rows, n_cols, num_buckets, hash_key=None):
     """ComboFeature through crossed_column: column-major strings -> int64 [n_rows] bucket ids ('' is a value too)."""
     bytes_np = np.ascontiguousarray(bytes_np, dtype=np.uint8)

@@ -67,6 +67,17 @@ int er_hash_bucket_fast_host(const uint8_t* bytes_host, const int64_t* offsets_h
 int er_hash_bucket_fast(const uint8_t* bytes, const int64_t* offsets, int64_t n, int64_t n_per_col,
                         const uint64_t* num_buckets, int drop_empty, int64_t* out,
                         er_stream_t stream);
+/* CSVInput's decode step (reference input/csv_input.py:33-76: tf.decode_csv, a TensorFlow C++ kernel), host-side:
+ * up to max_rows newline-terminated lines of `text` (blank lines skipped, a trailing "\r" dropped) are split on the ONE
+ * separator byte into exactly n_fields cells.  kinds[f]: 0 string, 1 integer, 2 floating point.  Column-major outputs
+ * (index f * max_rows + row): int_out / flt_out = the parsed number of a numeric field (0 for an empty cell),
+ * empty_out = 1 for an empty cell (the caller substitutes the field's default), str_begin / str_len = the cell's
+ * bytes inside `text` (no copy).  n_rows_out = lines decoded, consumed_out = bytes of text they took (an unterminated
+ * last line is not consumed).  A wrong field count or a malformed number fails with the line number. */
+int er_decode_csv_host(const uint8_t* text_host, int64_t n_bytes, uint8_t separator, int32_t n_fields,
+                       const int32_t* kinds_host, int64_t max_rows, int64_t* int_out, double* flt_out,
+                       uint8_t* empty_out, int64_t* str_begin, int32_t* str_len, int64_t* n_rows_out,
+                       int64_t* consumed_out);
 /* ComboFeature through `crossed_column` (reference feature_column/feature_column.py:434-445 ->
  * CrossedColumn._transform_feature, compat/feature_column/feature_column_v2.py:4527-4560 -> TF's
  * sparse_cross_hashed): one string per (column, row), column-major (string i = c * n_rows + r);

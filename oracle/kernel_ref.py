@@ -211,6 +211,36 @@ class RefBackend(object):
   def hash_bucket_fast_host(self, bytes_np, offsets_np, n_per_col, num_buckets, drop_empty):
     return hashing.hash_bucket_fast(bytes_np, offsets_np, n_per_col, num_buckets, drop_empty)
 
+  def decode_csv_host(self, text, sep, kinds, max_rows):
+    """Line by line in Python (what tf.decode_csv does per record, input/csv_input.py:33-76)."""
+    raw = np.ascontiguousarray(text, dtype=np.uint8).tobytes()
+    sep_b = sep.encode('utf-8') if isinstance(sep, str) else bytes(sep)
+    F = len(kinds)
+    ints, flts = np.zeros((F, max_rows), dtype=np.int64), np.zeros((F, max_rows), dtype=np.float64)
+    empty, begin = np.zeros((F, max_rows), dtype=np.uint8), np.zeros((F, max_rows), dtype=np.int64)
+    length = np.zeros((F, max_rows), dtype=np.int32)
+    pos = row = 0
+    while pos < len(raw) and row < max_rows:
+      nl = raw.find(b'\n', pos)
+      if nl < 0:
+        break
+      eol = nl - 1 if nl > pos and raw[nl - 1:nl] == b'\r' else nl
+      if eol > pos:
+        cells = raw[pos:eol].split(sep_b)
+        assert len(cells) == F, 'line %d has %d fields, expected %d' % (row, len(cells), F)
+        b = pos
+        for f, c in enumerate(cells):
+          empty[f, row], begin[f, row], length[f, row] = len(c) == 0, b, len(c)
+          if c and kinds[f] == 1:
+            ints[f, row] = int(c)
+            flts[f, row] = float(int(c))
+          elif c and kinds[f] == 2:
+            flts[f, row] = float(c)
+          b += len(c) + 1
+        row += 1
+      pos = nl + 1
+    return row, pos, ints, flts, empty, begin, length
+
   def sparse_cross_hashed_host(self, bytes_np, offsets_np, n_rows, n_cols, num_buckets, hash_key=None):
     key = hashing.DEFAULT_CROSS_HASH_KEY if hash_key is None else hash_key
     return hashing.sparse_cross_hashed_columns(bytes_np, offsets_np, n_rows, n_cols, num_buckets, key)

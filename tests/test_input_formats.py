@@ -185,3 +185,43 @@ def test_reference_ep_scenario_parquet_shared_table_lazy_adam(tmp_path, ref_back
   assert set(sa) == set(sc)
   for k in sa:
     assert np.allclose(sa[k], sc[k], rtol=1e-6, atol=1e-8), k
+
+
+@pytest.mark.parametrize('drop', [True, False])
+def test_native_csv_decode_equals_the_line_by_line_path(tmp_path, built_lib, drop, monkeypatch):
+  """er_decode_csv_host (one pass per batch, string cells as views of the file bytes) against the Python
+  line-by-line decode: CRLF and blank lines, empty cells -> defaults, negative / exponent numbers, a batch that
+  straddles two files, the padded remainder."""
+  import time
+  from easyrec_amd.input.csv_input import CSVInput
+  cfg = config_util.get_configs_from_pipeline_file(os.path.join(ROOT, 'configs', 'deepfm_criteo_small.config'))
+  feats = list(cfg.feature_config.features)
+  rng = np.random.default_rng(8)
+  B = 64
+
+  def line(i):
+    f = [rng.choice(['%d' % rng.integers(-5, 500), '%.3f' % rng.normal(), '1e2', '']) for _ in range(13)]
+    c = ['%08x' % rng.integers(0, 2**32) if rng.random() > 0.2 else '' for _ in range(26)]
+    return '\t'.join(['%d' % (i % 2)] + list(f) + c)
+
+  paths = []
+  for k, (n, eol) in enumerate(((150, '\n'), (77, '\r\n'))):
+    p = tmp_path / ('part%d.tsv' % k)
+    rows = [line(i) for i in range(n)]
+    rows.insert(10, '')  # a blank line
+    p.write_text(eol.join(rows) + (eol if k == 0 else ''))  # the second file does not end with a newline
+    paths.append(str(p))
+  got = {}
+  for native in ('1', '0'):
+    monkeypatch.setenv('EASYREC_AMD_NATIVE_CSV', native)
+    inp = CSVInput(cfg.data_config, feats, ','.join(paths), batch_size=B, hash_on_host=False)
+    assert inp._native_ok() == (native == '1')
+    t0 = time.perf_counter()
+    got[native] = list(inp.batches(drop_remainder=drop))
+    dt = time.perf_counter() - t0
+    print('native=%s: %d batches of %d in %.1f ms' % (native, len(got[native]), B, dt * 1e3))
+  assert len(got['1']) == len(got['0']) == (3 if drop else 4)
+  for a, b in zip(got['1'], got['0']):
+    assert set(a) == set(b)
+    for k in a:
+      assert np.array_equal(np.asarray(a[k]), np.asarray(b[k])), k
