@@ -14,9 +14,15 @@ from easyrec_amd.protos.dataset_pb2 import DatasetConfig
 
 class CSVInput(Input):
 
-  def __init__(self, data_config, feature_configs, input_path=None, **kwargs):
+  def __init__(self, data_config, feature_configs, input_path=None, task_index=0, task_num=1, **kwargs):
     super(CSVInput, self).__init__(data_config, feature_configs, input_path, **kwargs)
     self._with_header = data_config.with_header
+    # one process per GPU: every worker reads its own part of the data (csv_input.py:109-127, input.py:1018-1023
+    # `_safe_shard`): whole files when data_config.file_shard, else every task_num-th line
+    if data_config.chief_redundant:
+      task_index, task_num = max(task_index - 1, 0), max(task_num - 1, 1)
+    self._task_index, self._task_num = int(task_index), int(task_num)
+    self._line_no = 0  # data lines seen so far (line sharding runs over the concatenation of the files)
     import os
     self.native_decode = os.environ.get('EASYREC_AMD_NATIVE_CSV', '1') != '0'  # else the line-by-line Python path
 
@@ -36,6 +42,44 @@ class CSVInput(Input):
           p = int(p) if t in (DatasetConfig.INT32, DatasetConfig.INT64) else float(p)
         cols[i].append(p)
     return {name: cols[i] for i, name in enumerate(self._input_fields)}
+
+  # -- worker sharding -------------------------------------------------------------------------------------------
+  def _my_paths(self):
+    paths = self._input_path if isinstance(self._input_path, list) else self._input_path.split(',')
+    if self._task_num > 1 and self._data_config.file_shard:
+      paths = [p for i, p in enumerate(paths) if i % self._task_num == self._task_index]
+    return paths
+
+  def _my_lines(self, data):
+    """bytes of one file (header already removed) -> the bytes of this worker's lines, newline-terminated.  Blank
+    lines are dropped; with line sharding line k of the data set belongs to worker k % task_num."""
+    if not data.endswith(b'\n'):
+      data += b'\n'
+    if self._task_num == 1 or self._data_config.file_shard:
+      return data
+    text = np.frombuffer(data, dtype=np.uint8)
+    ends = np.flatnonzero(text == 10) + 1            # one past every newline
+    starts = np.concatenate([[0], ends[:-1]])
+    body = ends - starts - 1 - (text[np.maximum(ends - 2, 0)] == 13)  # length without "\n" / "\r\n"
+    keep = body > 0
+    starts, ends = starts[keep], ends[keep]
+    mine = (self._line_no + np.arange(len(starts))) % self._task_num == self._task_index
+    self._line_no += len(starts)
+    starts, ends = starts[mine], ends[mine]
+    if len(starts) == 0:
+      return b''
+    length = ends - starts
+    offs = np.zeros(len(length) + 1, dtype=np.int64)
+    np.cumsum(length, out=offs[1:])
+    src = np.repeat(starts - offs[:-1], length) + np.arange(int(offs[-1]), dtype=np.int64)
+    return text[src].tobytes()
+
+  def _read(self, path):
+    with open(path, 'rb') as f:
+      data = f.read()
+    if self._with_header:
+      data = data[data.index(b'\n') + 1:] if b'\n' in data else b''
+    return self._my_lines(data)
 
   # -- native decode: one pass of er_decode_csv_host per batch ---------------------------------------------------
   def _native_ok(self):
@@ -72,12 +116,8 @@ class CSVInput(Input):
     sep = self._data_config.separator
     carry = None  # decoded rows of a batch that straddles two files: per-field python lists
     for path in paths:
-      with open(path, 'rb') as f:
-        data = f.read()
-      if not data.endswith(b'\n'):
-        data += b'\n'
-      text = np.frombuffer(data, dtype=np.uint8)
-      pos = data.index(b'\n') + 1 if self._with_header else 0
+      text = np.frombuffer(self._read(path), dtype=np.uint8)
+      pos = 0
       while pos < len(text):
         want = B - (len(next(iter(carry.values()))) if carry else 0)
         n, used, ints, flts, empty, begin, length = be.decode_csv_host(text[pos:], sep, kinds, want)
@@ -102,27 +142,24 @@ class CSVInput(Input):
   def batches(self, num_epochs=None, drop_remainder=True):
     """Yield batch dicts from the input file(s)."""
     if self._native_ok():
-      paths = self._input_path if isinstance(self._input_path, list) else self._input_path.split(',')
       for _ in range(num_epochs or self._data_config.num_epochs or 1):
-        for b in self._native_batches(paths, drop_remainder):
+        self._line_no = 0
+        for b in self._native_batches(self._my_paths(), drop_remainder):
           yield b
       return
-    paths = self._input_path if isinstance(self._input_path, list) else self._input_path.split(',')
     epochs = num_epochs or self._data_config.num_epochs or 1
     B = self._batch_size
     for _ in range(epochs):
       buf = []
-      for path in paths:
-        with open(path, 'r') as f:
-          if self._with_header:
-            next(f)
-          for line in f:
-            if not line.strip('\r\n'):
-              continue
-            buf.append(line)
-            if len(buf) == B:
-              yield self.preprocess(self._parse_lines(buf))
-              buf = []
+      self._line_no = 0
+      for path in self._my_paths():
+        for line in self._read(path).decode('utf-8').split('\n'):
+          if not line.strip('\r'):
+            continue
+          buf.append(line)
+          if len(buf) == B:
+            yield self.preprocess(self._parse_lines(buf))
+            buf = []
       if buf and not drop_remainder:
         while len(buf) < B:
           buf.append(buf[-1])

@@ -225,3 +225,43 @@ def test_native_csv_decode_equals_the_line_by_line_path(tmp_path, built_lib, dro
     assert set(a) == set(b)
     for k in a:
       assert np.array_equal(np.asarray(a[k]), np.asarray(b[k])), k
+
+
+@pytest.mark.parametrize('file_shard', [False, True])
+def test_csv_workers_read_disjoint_parts_of_the_data(tmp_path, built_lib, file_shard, monkeypatch):
+  """One process per GPU: worker r of W takes line k of the data set when k % W == r (reference
+  `_safe_shard`, input/input.py:1018-1023 after csv_input.py:126-127), or whole files with data_config.file_shard
+  (:109-110).  Both decode paths; the workers' rows together are the data set, in order, without overlap."""
+  from easyrec_amd.input.csv_input import CSVInput
+  cfg = config_util.get_configs_from_pipeline_file(os.path.join(ROOT, 'configs', 'deepfm_criteo_small.config'))
+  cfg.data_config.file_shard = file_shard
+  feats = list(cfg.feature_config.features)
+  W, B, n_files, per_file = 3, 8, 3, 40
+  rng = np.random.default_rng(1)
+  paths, labels_of_file = [], []
+  for k in range(n_files):
+    rows, labs = [], []
+    for i in range(per_file):
+      lab = int(rng.integers(0, 1000))  # the label column doubles as a row id
+      labs.append(lab)
+      f = ['%d' % rng.integers(0, 50) for _ in range(13)]
+      c = ['%04x' % rng.integers(0, 2**16) for _ in range(26)]
+      rows.append('\t'.join(['%d' % lab] + f + c))
+    p = tmp_path / ('p%d.tsv' % k)
+    p.write_text('\n'.join(rows) + '\n')
+    paths.append(str(p))
+    labels_of_file.append(labs)
+  whole = [lab for labs in labels_of_file for lab in labs]
+  for native in ('1', '0'):
+    monkeypatch.setenv('EASYREC_AMD_NATIVE_CSV', native)
+    seen = []
+    for r in range(W):
+      inp = CSVInput(cfg.data_config, feats, ','.join(paths), batch_size=B, hash_on_host=True, task_index=r, task_num=W)
+      got = [int(x) for b in inp.batches(drop_remainder=True) for x in b['labels'][0]]
+      if file_shard:
+        exp = [lab for k in range(n_files) if k % W == r for lab in labels_of_file[k]]
+      else:
+        exp = whole[r::W]
+      assert got == exp[:len(exp) // B * B], (native, r)
+      seen.append(got)
+    assert sum(len(g) for g in seen) == sum(len(whole[r::W]) // B * B for r in range(W)) or file_shard
