@@ -265,3 +265,36 @@ def test_csv_workers_read_disjoint_parts_of_the_data(tmp_path, built_lib, file_s
       assert got == exp[:len(exp) // B * B], (native, r)
       seen.append(got)
     assert sum(len(g) for g in seen) == sum(len(whole[r::W]) // B * B for r in range(W)) or file_shard
+
+
+def test_prefetcher_keeps_order_and_hands_over_errors():
+  import threading
+  import time
+  from easyrec_amd.input.prefetch import Prefetcher
+  assert list(Prefetcher(range(50), depth=3)) == list(range(50))
+  assert list(Prefetcher(range(5), depth=1, transform=lambda x: x * x)) == [0, 1, 4, 9, 16]
+
+  def bad():
+    yield 1
+    yield 2
+    raise ValueError('boom')
+
+  p = Prefetcher(bad(), depth=2)
+  assert next(p) == 1 and next(p) == 2
+  with pytest.raises(ValueError):
+    next(p)
+  # the producer runs ahead of a slow consumer, but no further than `depth`
+  produced = []
+
+  def src():
+    for i in range(10):
+      produced.append(i)
+      yield i
+
+  p = Prefetcher(src(), depth=2)
+  time.sleep(0.3)
+  assert 2 <= len(produced) <= 4  # depth items queued + one in hand (+ one being offered)
+  assert next(p) == 0
+  p.close()
+  time.sleep(0.3)
+  assert len(produced) < 10 and threading.active_count() < 10
