@@ -73,4 +73,22 @@ int er_decode_csv_host(const uint8_t* text, int64_t n_bytes, uint8_t sep, int32_
   return 0;
 }
 
+// The cells (begin, length) of a decoded text batch, in the order given, as one packed byte string + offsets[n + 1]:
+// what er_hash_bucket_fast(_host) takes.  out_bytes must hold sum(length) bytes.
+int er_pack_cells_host(const uint8_t* text, const int64_t* begin, const int32_t* length, int64_t n, uint8_t* out_bytes,
+                       int64_t* out_offsets) {
+  ER_REQUIRE(text && begin && length && out_offsets && n >= 0, "er_pack_cells_host: bad arguments");
+  int64_t o = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    out_offsets[i] = o;
+    if (length[i] > 0) {
+      ER_REQUIRE(out_bytes, "er_pack_cells_host: null output");
+      memcpy(out_bytes + o, text + begin[i], static_cast<size_t>(length[i]));
+      o += length[i];
+    }
+  }
+  out_offsets[n] = o;
+  return 0;
+}
+
 }  // extern "C"

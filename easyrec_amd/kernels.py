@@ -285,6 +285,21 @@ class HipBackend(object):
              'er_decode_csv_host')
     return n_rows.value, consumed.value, ints, flts, empty, begin, length
 
+  def pack_cells_host(self, text, begin, length):
+    """Cells (begin, length) of `text` -> (packed uint8 bytes, int64 offsets[n + 1])."""
+    text = np.ascontiguousarray(text, dtype=np.uint8)
+    begin = np.ascontiguousarray(begin, dtype=np.int64)
+    length = np.ascontiguousarray(length, dtype=np.int32)
+    n = len(begin)
+    out = np.empty(max(int(length.sum(dtype=np.int64)), 1), dtype=np.uint8)
+    offsets = np.empty(n + 1, dtype=np.int64)
+
+    def ptr(a):
+      return a.ctypes.data_as(ctypes.c_void_p)
+    self._ck(self.lib.er_pack_cells_host(ptr(text) if text.size else ptr(out), ptr(begin), ptr(length), ctypes.c_int64(n),
+                                         ptr(out), ptr(offsets)), 'er_pack_cells_host')
+    return out[:int(offsets[-1])], offsets
+
   def sparse_cross_hashed_host(self, bytes_np, offsets_np, n_rows, n_cols, num_buckets, hash_key=None):
     """ComboFeature through crossed_column: column-major strings -> int64 [n_rows] bucket ids ('' is a value too)."""
     bytes_np = np.ascontiguousarray(bytes_np, dtype=np.uint8)

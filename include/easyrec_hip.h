@@ -78,6 +78,10 @@ int er_decode_csv_host(const uint8_t* text_host, int64_t n_bytes, uint8_t separa
                        const int32_t* kinds_host, int64_t max_rows, int64_t* int_out, double* flt_out,
                        uint8_t* empty_out, int64_t* str_begin, int32_t* str_len, int64_t* n_rows_out,
                        int64_t* consumed_out);
+/* The string cells of a decoded batch (any order, e.g. feature-major) -> packed bytes + offsets[n + 1], the input of
+ * er_hash_bucket_fast(_host).  out_bytes holds sum(length) bytes. */
+int er_pack_cells_host(const uint8_t* text_host, const int64_t* begin, const int32_t* length, int64_t n,
+                       uint8_t* out_bytes, int64_t* out_offsets);
 /* ComboFeature through `crossed_column` (reference feature_column/feature_column.py:434-445 ->
  * CrossedColumn._transform_feature, compat/feature_column/feature_column_v2.py:4527-4560 -> TF's
  * sparse_cross_hashed): one string per (column, row), column-major (string i = c * n_rows + r);

@@ -241,6 +241,13 @@ class RefBackend(object):
       pos = nl + 1
     return row, pos, ints, flts, empty, begin, length
 
+  def pack_cells_host(self, text, begin, length):
+    raw = np.ascontiguousarray(text, dtype=np.uint8).tobytes()
+    cells = [raw[int(b):int(b) + int(n)] for b, n in zip(begin, length)]
+    offsets = np.zeros(len(cells) + 1, dtype=np.int64)
+    np.cumsum([len(c) for c in cells], out=offsets[1:])
+    return np.frombuffer(b''.join(cells), dtype=np.uint8) if offsets[-1] else np.zeros(0, dtype=np.uint8), offsets
+
   def sparse_cross_hashed_host(self, bytes_np, offsets_np, n_rows, n_cols, num_buckets, hash_key=None):
     key = hashing.DEFAULT_CROSS_HASH_KEY if hash_key is None else hash_key
     return hashing.sparse_cross_hashed_columns(bytes_np, offsets_np, n_rows, n_cols, num_buckets, key)
