@@ -1,0 +1,132 @@
+// Gradient clipping by global norm: train_config.gradient_clipping_by_norm.
+//
+// Reference: compat/optimizers.py:365-376 (`_get_grad_norm` + `clip_ops.clip_by_global_norm(grads, clip, use_norm)`)
+// and :453-481 (the norm: sqrt(2 * sum of tf.nn.l2_loss over every gradient; IndexedSlices contribute their `values`
+// rows - one row per distinct id of a lookup; sharded tables' partial sums are all-reduced).  Every gradient is then
+// multiplied by  clip_norm * min(1 / norm, 1 / clip_norm).
+//
+// Here the gradients never exist as separate tensors at that point: the dense ones sit in the flat gradient buffer
+// (the kernel-L2 term l2 * w is added by the optimizer kernel), the embedding ones are the de-duplicated row sums
+// of er_emb_bwd_reduce(_routed).  So: squared-norm partials of both (fixed order -> deterministic), one scalar kernel
+// that turns the total into the multiplier and stores it in the er_opt_hyper records of the step (`clip_scale`),
+// and the optimizer kernels (dense_opt_kernel, the embedding row updates) multiply by it.  All HBM-streaming fp32.
+#include "er_common.h"
+
+namespace er {
+
+int get_scratch(size_t floats, float** out);  // er_dense.hip
+
+// partial[b] = sum over block b's strided share of x[r * ld + c]^2, r a valid row, c < cols
+__global__ void __launch_bounds__(kBlock)
+gradsq_rows_partial_kernel(const float* __restrict__ x, int64_t max_rows, int cols, int ld,
+                           const int32_t* __restrict__ seg_counts, int n_seg, int64_t seg_stride,
+                           float* __restrict__ partial) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  const int64_t total = max_rows * cols;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < total; i += stride) {
+    const int64_t r = i / cols;
+    const int c = static_cast<int>(i - r * cols);
+    if (seg_counts) {
+      const int64_t sg = r / seg_stride;
+      if (sg >= n_seg || (r - sg * seg_stride) >= seg_counts[sg]) continue;
+    }
+    const float v = x[r * ld + c];
+    acc = acc + v * v;
+  }
+  const float s = block_sum_256(acc, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+// the dense variables' gradient as the optimizer will see it: grad_scale * grad + l2coef * w
+__global__ void __launch_bounds__(kBlock)
+gradsq_dense_partial_kernel(const float* __restrict__ w, const float* __restrict__ grad,
+                            const float* __restrict__ l2coef, int64_t n, const er_opt_hyper* __restrict__ hyper,
+                            float* __restrict__ partial) {
+  __shared__ float red[4];
+  const float gs = hyper->grad_scale;
+  float acc = 0.f;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride) {
+    float g = grad[i] * gs;
+    if (l2coef) {
+      const float c = l2coef[i];
+      if (c != 0.f) g = g + c * w[i];
+    }
+    acc = acc + g * g;
+  }
+  const float s = block_sum_256(acc, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+__global__ void __launch_bounds__(kBlock)
+gradsq_finish_kernel(const float* __restrict__ partial, int n, float weight, float* __restrict__ acc, int accumulate) {
+  __shared__ float red[4];
+  float a = 0.f;
+  for (int i = threadIdx.x; i < n; i += kBlock) a = a + partial[i];
+  const float s = block_sum_256(a, red);
+  if (threadIdx.x == 0) acc[0] = accumulate ? (acc[0] + weight * s) : weight * s;
+}
+
+__global__ void clip_scale_kernel(const float* __restrict__ normsq, float clip_norm, er_opt_hyper* __restrict__ records,
+                                  int n_records, float* __restrict__ norm_out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const float norm = sqrtf(normsq[0]);
+  // clip_ops.clip_by_global_norm: scale = clip_norm * min(1 / norm, 1 / clip_norm)
+  const float a = 1.0f / norm, b = 1.0f / clip_norm;
+  const float scale = clip_norm * (a < b ? a : b);
+  for (int i = 0; i < n_records; ++i) records[i].clip_scale = scale;
+  if (norm_out) norm_out[0] = norm;
+}
+
+}  // namespace er
+
+extern "C" {
+
+int er_gradsq_rows(const float* x, int64_t max_rows, int32_t cols, int32_t ld, const int32_t* seg_counts, int32_t n_seg,
+                   int64_t seg_stride, float weight, float* acc, int accumulate, er_stream_t stream) {
+  ER_REQUIRE(x && acc && max_rows >= 0 && cols > 0 && ld >= cols, "er_gradsq_rows: bad arguments");
+  ER_REQUIRE(!seg_counts || (n_seg > 0 && seg_stride > 0), "er_gradsq_rows: seg_counts needs n_seg and seg_stride");
+  hipStream_t s = er::as_stream(stream);
+  int64_t blocks = er::ceil_div(max_rows * cols, static_cast<int64_t>(er::kBlock) * 4);
+  if (blocks > 512) blocks = 512;
+  if (blocks < 1) blocks = 1;
+  float* scratch;
+  if (er::get_scratch(static_cast<size_t>(blocks), &scratch)) return 1;
+  hipLaunchKernelGGL(er::gradsq_rows_partial_kernel, dim3(static_cast<int>(blocks)), dim3(er::kBlock), 0, s, x, max_rows,
+                     cols, ld, seg_counts, n_seg, seg_stride, scratch);
+  ER_LAUNCH_CHECK();
+  hipLaunchKernelGGL(er::gradsq_finish_kernel, dim3(1), dim3(er::kBlock), 0, s, scratch, static_cast<int>(blocks), weight,
+                     acc, accumulate);
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
+int er_gradsq_dense(const float* w, const float* grad, const float* l2coef, int64_t n, const er_opt_hyper* hyper,
+                    float* acc, int accumulate, er_stream_t stream) {
+  ER_REQUIRE(w && grad && hyper && acc && n > 0, "er_gradsq_dense: bad arguments");
+  hipStream_t s = er::as_stream(stream);
+  int64_t blocks = er::ceil_div(n, static_cast<int64_t>(er::kBlock) * 4);
+  if (blocks > 512) blocks = 512;
+  float* scratch;
+  if (er::get_scratch(static_cast<size_t>(blocks), &scratch)) return 1;
+  hipLaunchKernelGGL(er::gradsq_dense_partial_kernel, dim3(static_cast<int>(blocks)), dim3(er::kBlock), 0, s, w, grad,
+                     l2coef, n, hyper, scratch);
+  ER_LAUNCH_CHECK();
+  hipLaunchKernelGGL(er::gradsq_finish_kernel, dim3(1), dim3(er::kBlock), 0, s, scratch, static_cast<int>(blocks), 1.0f,
+                     acc, accumulate);
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
+int er_clip_scale(const float* normsq, float clip_norm, er_opt_hyper* records, int32_t n_records, float* norm_out,
+                  er_stream_t stream) {
+  ER_REQUIRE(normsq && records && n_records > 0 && clip_norm > 0.f, "er_clip_scale: bad arguments");
+  hipLaunchKernelGGL(er::clip_scale_kernel, dim3(1), dim3(64), 0, er::as_stream(stream), normsq, clip_norm, records,
+                     n_records, norm_out);
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // extern "C"

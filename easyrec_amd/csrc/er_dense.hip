@@ -546,6 +546,7 @@ dense_opt_kernel(float* __restrict__ w, float* __restrict__ m, float* __restrict
     const float c = l2coef[i];
     if (c != 0.f) g = g + c * wi;
   }
+  if (h.clip_scale != 0.f) g = g * h.clip_scale;  // clip_by_global_norm (er_clip_scale); 0 = no clipping
   if (opt_kind == ER_OPT_ADAM || opt_kind == ER_OPT_LAZY_ADAM) {
     // training_ops.apply_adam (dense): m += (g-m)*(1-b1); v += (g*g-v)*(1-b2); var -= m*alpha/(sqrt(v)+eps)
     float mi = m[i], vi = v[i];

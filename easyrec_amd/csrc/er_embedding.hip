@@ -541,6 +541,10 @@ __device__ __forceinline__ void finish_run(const RowUpdate& tab, int opt_kind, c
     const er_opt_hyper h = *hyper;
 #pragma unroll
     for (int i = 0; i < V; ++i) g[i] = g[i] * h.grad_scale;
+    if (h.clip_scale != 0.f) {  // clip_by_global_norm (er_clip_scale); 0 = no clipping
+#pragma unroll
+      for (int i = 0; i < V; ++i) g[i] = g[i] * h.clip_scale;
+    }
     update_row<V>(tab, opt_kind, h, static_cast<int64_t>(key) * dim + c, g);
     if (opt_kind == ER_OPT_ADAM && sub == 0) {
       if (tab.last_step) tab.last_step[key] = static_cast<int32_t>(*tab.step_counter - 1);
@@ -701,6 +705,26 @@ emb_bwd_fix_kernel(const uint32_t* __restrict__ skeys, int64_t n, int dim, int G
                    RowUpdate tab, int opt_kind, const er_opt_hyper* __restrict__ hyper, ReduceOut ro,
                    const float* __restrict__ tile_first, const float* __restrict__ tile_last) {
   fix_body<V>(blockIdx.x, skeys, n, dim, G, T, n_tiles, tab, opt_kind, hyper, ro, tile_first, tile_last);
+}
+
+// Row-wise optimizer on ready-made row sums (er_emb_apply_unique): one lane group per de-duplicated key.
+template <int V>
+__global__ void __launch_bounds__(kBlock)
+emb_apply_unique_kernel(const uint32_t* __restrict__ ukeys, const float* __restrict__ ugrads, int ld,
+                        const int32_t* __restrict__ n_unique, int64_t capacity, RowUpdate tab, int opt_kind,
+                        const er_opt_hyper* __restrict__ hyper, int dim, int G) {
+  const int64_t i = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) / G;
+  const int sub = static_cast<int>(threadIdx.x) % G;
+  const int c = sub * V;
+  if (i >= capacity || i >= *n_unique || c >= dim) return;
+  const uint32_t key = ukeys[i];
+  if (key == kInvalidKey) return;
+  const float* gp = ugrads + i * ld + c;
+  float g[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) g[j] = gp[j];
+  const ReduceOut ro{0, nullptr, nullptr, nullptr, nullptr, 0};
+  finish_run<V>(tab, opt_kind, hyper, ro, key, 0, sub, c, dim, g);
 }
 
 // the tile / fix kernels of several table groups in one grid each (see emb_catch_up_multi_kernel)
@@ -1518,6 +1542,10 @@ __device__ __forceinline__ void dense_apply_body(int bid, const DenseApplyArgs& 
     float g[V];
 #pragma unroll
     for (int i = 0; i < V; ++i) g[i] = d[c + i] * h.grad_scale;
+    if (h.clip_scale != 0.f) {
+#pragma unroll
+      for (int i = 0; i < V; ++i) g[i] = g[i] * h.clip_scale;
+    }
     update_row<V>(RowUpdate{a.var, a.m, a.v, nullptr, nullptr, nullptr}, opt_kind, h, off, g);
   } else if (opt_kind == ER_OPT_ADAM) {
     float var[V], m[V], v[V];
@@ -2274,6 +2302,39 @@ int er_emb_bwd_reduce(er_emb_group* g, uint32_t* unique_keys, float* unique_grad
   if (int rc = emb_group_sort(g, s)) return rc;
   if (int rc = emb_group_heads(g, n_unique, s)) return rc;
   return emb_group_run(g, ER_OPT_SGD, nullptr, 1, unique_keys, unique_grads, s);
+}
+
+int er_emb_apply_unique(er_emb_group* g, const uint32_t* unique_keys, const float* unique_grads, int32_t ld,
+                        const int32_t* n_unique, int opt_kind, const er_opt_hyper* hyper, er_stream_t stream) {
+  ER_REQUIRE(g && unique_keys && unique_grads && n_unique && hyper, "er_emb_apply_unique: null argument");
+  ER_REQUIRE(opt_kind >= ER_OPT_SGD && opt_kind <= ER_OPT_ADAGRAD, "er_emb_apply_unique: unknown optimizer %d", opt_kind);
+  ER_REQUIRE(ld == 0 || ld >= g->dim, "er_emb_apply_unique: ld < dim");
+  if (opt_kind == ER_OPT_ADAM || opt_kind == ER_OPT_LAZY_ADAM) ER_REQUIRE(g->m && g->v, "er_emb_apply_unique: Adam needs m and v");
+  if (opt_kind == ER_OPT_ADAGRAD) ER_REQUIRE(g->v, "er_emb_apply_unique: Adagrad needs the accumulator in v");
+  const bool lazy_decay = (opt_kind == ER_OPT_ADAM) && g->last_step;
+  if (opt_kind == ER_OPT_ADAM && !lazy_decay)
+    ER_REQUIRE(g->bitmap, "er_emb_apply_unique: ER_OPT_ADAM needs touched_bitmap (or er_emb_group_enable_lazy_decay)");
+  hipStream_t s = er::as_stream(stream);
+  const int64_t cap = group_entries(g);
+  if (cap > 0) {
+    er::RowUpdate tab{g->var, g->m, g->v, g->bitmap, g->last_step, g->step_counter};
+    const int blocks = static_cast<int>(er::ceil_div(cap * g->G, er::kBlock));
+    const int row_ld = ld ? ld : g->dim;
+    if (g->V == 4) {
+      hipLaunchKernelGGL(er::emb_apply_unique_kernel<4>, dim3(blocks), dim3(er::kBlock), 0, s, unique_keys, unique_grads,
+                         row_ld, n_unique, cap, tab, opt_kind, hyper, g->dim, g->G);
+    } else {
+      hipLaunchKernelGGL(er::emb_apply_unique_kernel<1>, dim3(blocks), dim3(er::kBlock), 0, s, unique_keys, unique_grads,
+                         row_ld, n_unique, cap, tab, opt_kind, hyper, g->dim, g->G);
+    }
+    ER_LAUNCH_CHECK();
+  }
+  g->sorted_valid = false;  // (a sort left by this step's er_emb_route has served its purpose)
+  if (opt_kind == ER_OPT_ADAM && !lazy_decay) {  // TF-exact Adam with the streaming sweep, as er_emb_bwd_update
+    if (int rc = er_adam_decay_sweep(g->var, g->m, g->v, g->bitmap, g->total_rows, g->dim, hyper, stream)) return rc;
+    if (int rc = fill_u32(g->bitmap, 0u, er::ceil_div(g->total_rows, 32), s)) return rc;
+  }
+  return 0;
 }
 
 int er_emb_group_set_routing(er_emb_group* g, int32_t world, int64_t shard_stride, const int64_t* local_base_host) {

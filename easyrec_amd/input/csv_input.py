@@ -26,13 +26,51 @@ class CSVInput(Input):
     import os
     self.native_decode = os.environ.get('EASYREC_AMD_NATIVE_CSV', '1') != '0'  # else the line-by-line Python path
 
+  @staticmethod
+  def _split_quoted(line, sep):
+    """tf.decode_csv(use_quote_delim=True) on one line that contains '"': a cell that STARTS with a quote runs to its
+    closing quote (separators inside are data, '""' is one quote character); a quote inside an unquoted cell is an
+    error, as in TensorFlow ("Unquoted fields cannot have quotes/CRLFs inside")."""
+    parts, i, n = [], 0, len(line)
+    while True:
+      if i < n and line[i] == '"':
+        cell, i = [], i + 1
+        while True:
+          j = line.find('"', i)
+          if j < 0:
+            raise ValueError('Quoted field has to end with quote followed by delim or end: %r' % line[:80])
+          cell.append(line[i:j])
+          if j + 1 < n and line[j + 1] == '"':  # escaped quote
+            cell.append('"')
+            i = j + 2
+            continue
+          i = j + 1
+          break
+        if i < n and not line.startswith(sep, i):
+          raise ValueError('Quoted field has to end with quote followed by delim or end: %r' % line[:80])
+        parts.append(''.join(cell))
+      else:
+        j = line.find(sep, i)
+        cell = line[i:] if j < 0 else line[i:j]
+        if '"' in cell:
+          raise ValueError('Unquoted fields cannot have quotes/CRLFs inside: %r' % line[:80])
+        parts.append(cell)
+        i = n if j < 0 else j
+      if i >= n:
+        return parts
+      i += len(sep)
+      if i >= n:  # the line ends with a separator: one more, empty, cell
+        parts.append('')
+        return parts
+
   def _parse_lines(self, lines):
     sep = self._data_config.separator
     n_fields = len(self._input_fields)
     cols = [[] for _ in range(n_fields)]
     defaults = [get_type_defaults(t, v) for t, v in zip(self._input_field_types, self._input_field_defaults)]
     for line in lines:
-      parts = line.rstrip('\n').rstrip('\r').split(sep)
+      line = line.rstrip('\n').rstrip('\r')
+      parts = self._split_quoted(line, sep) if '"' in line else line.split(sep)
       assert len(parts) == n_fields, 'expected %d fields, got %d: %r' % (n_fields, len(parts), line[:80])
       for i, p in enumerate(parts):
         if p == '':
@@ -116,7 +154,23 @@ class CSVInput(Input):
     sep = self._data_config.separator
     carry = None  # decoded rows of a batch that straddles two files: per-field python lists
     for path in paths:
-      text = np.frombuffer(self._read(path), dtype=np.uint8)
+      data = self._read(path)
+      if b'"' in data:
+        # quoted cells (tf.decode_csv's use_quote_delim): the zero-copy (begin, length) cells of the native decoder
+        # cannot express an un-escaped '""'; such files take the line-by-line path (not the Criteo / Taobao layouts)
+        lines = [ln for ln in data.decode('utf-8').split('\n') if ln.strip('\r')]
+        for i in range(0, len(lines), B):
+          part = self._parse_lines(lines[i:i + B])
+          if carry is None and len(lines[i:i + B]) == B:
+            yield self.preprocess(part)
+            continue
+          carry = part if carry is None else {k: list(carry[k]) + list(part[k]) for k in part}
+          n_have = len(next(iter(carry.values())))
+          if n_have >= B:
+            yield self.preprocess({k: v[:B] for k, v in carry.items()})
+            carry = {k: v[B:] for k, v in carry.items()} if n_have > B else None
+        continue
+      text = np.frombuffer(data, dtype=np.uint8)
       pos = 0
       while pos < len(text):
         want = B - (len(next(iter(carry.values()))) if carry else 0)

@@ -17,6 +17,7 @@ class Prefetcher(object):
     assert depth >= 1
     self._q = queue.Queue(maxsize=int(depth))
     self._stop = threading.Event()
+    self._final = None  # terminal state seen by the consumer: ('end', None) or ('error', exception)
     self._thread = threading.Thread(target=self._run, args=(iter(source), transform), daemon=True)
     self._thread.start()
 
@@ -42,18 +43,25 @@ class Prefetcher(object):
     return self
 
   def __next__(self):
+    if self._final is not None:  # the producer is gone: repeat its last word instead of waiting on an empty queue
+      if self._final[0] == 'error':
+        raise self._final[1]
+      raise StopIteration
     err, item = self._q.get()
     if err is not None:
+      self._final = ('error', err)
       self.close()
       raise err
     if item is self._END:
-      self._q.put((None, self._END))  # stay exhausted
+      self._final = ('end', None)
       raise StopIteration
     return item
 
   def close(self):
     """Stop the producer (e.g. when the consumer leaves the loop early)."""
     self._stop.set()
+    if self._final is None:
+      self._final = ('end', None)  # closed early: later __next__ calls stop instead of blocking
     while True:
       try:
         self._q.get_nowait()

@@ -49,6 +49,7 @@ class LookupDesc(ctypes.Structure):
 # er_opt_hyper: 16 floats
 HYPER_FLOATS = 16
 HYPER_LR, HYPER_LR_T, HYPER_BETA1, HYPER_BETA2, HYPER_OMB1, HYPER_OMB2, HYPER_EPS, HYPER_GSCALE = range(8)
+HYPER_CLIP = 8  # er_opt_hyper.clip_scale: 0 = no clipping
 
 
 _wgrad_tls = threading.local()
@@ -952,6 +953,36 @@ class HipBackend(object):
 
   def emb_flush_decay(self, group, hyper):
     self._ck(self.lib.er_emb_flush_decay(group['handle'], _p(hyper), _stream()), 'er_emb_flush_decay')
+
+  # -- gradient clipping by global norm (compat/optimizers.py:365-376, 453-481)
+  def gradsq_rows(self, x, cols, weight, acc, accumulate, counts=None, seg_stride=None):
+    """acc[0] (+)= weight * sum of x[r, :cols]^2 over the valid rows: all of them, or (counts int32 [n_seg]) the rows
+    with (r % seg_stride) < counts[r // seg_stride]; seg_stride None = the whole buffer is one segment."""
+    assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == torch.float32 and acc.dtype == torch.float32
+    rows = x.shape[0]
+    n_seg = 0 if counts is None else counts.numel()
+    assert counts is None or counts.dtype == torch.int32
+    stride = rows if seg_stride is None else int(seg_stride)
+    self._ck(self.lib.er_gradsq_rows(_p(x), ctypes.c_int64(rows), ctypes.c_int32(int(cols)), ctypes.c_int32(x.stride(0)),
+                                     _p(counts), ctypes.c_int32(n_seg), ctypes.c_int64(max(stride, 1)),
+                                     ctypes.c_float(weight), _p(acc), int(bool(accumulate)), _stream()), 'er_gradsq_rows')
+
+  def gradsq_dense(self, w, grad, l2coef, hyper, acc, accumulate=False):
+    """acc[0] (+)= sum (hyper.grad_scale * grad + l2coef * w)^2: the dense gradient as er_dense_opt_step sees it."""
+    self._ck(self.lib.er_gradsq_dense(_p(w), _p(grad), _p(l2coef), ctypes.c_int64(w.numel()), _p(hyper), _p(acc),
+                                      int(bool(accumulate)), _stream()), 'er_gradsq_dense')
+
+  def clip_scale(self, normsq, clip_norm, records, norm_out=None):
+    """records [n, HYPER_FLOATS] (device): records[:, HYPER_CLIP] = clip_norm * min(1 / norm, 1 / clip_norm)."""
+    assert records.dim() == 2 and records.shape[1] == HYPER_FLOATS and records.is_contiguous()
+    self._ck(self.lib.er_clip_scale(_p(normsq), ctypes.c_float(clip_norm), _p(records), ctypes.c_int32(records.shape[0]),
+                                    _p(norm_out), _stream()), 'er_clip_scale')
+
+  def emb_apply_unique(self, group, keys, grads, n_unique, opt_kind, hyper):
+    """The row-wise optimizer of emb_bwd_update on ready-made de-duplicated row sums (emb_bwd_reduce[_routed])."""
+    assert keys.dtype == torch.int32 and n_unique.dtype == torch.int32 and grads.dim() == 2 and grads.stride(1) == 1
+    self._ck(self.lib.er_emb_apply_unique(group['handle'], _p(keys), _p(grads), ctypes.c_int32(grads.stride(0)),
+                                          _p(n_unique), ctypes.c_int(opt_kind), _p(hyper), _stream()), 'er_emb_apply_unique')
 
   # -- dense optimizer
   def dense_opt_step(self, w, m, v, grad, l2coef, opt_kind, hyper):

@@ -112,6 +112,10 @@ class EmbeddingEngine(object):
     self._clock = None  # (step_counter int64[1], lr_t history fp32[capacity], hyper record of the embeddings)
     self._lazy = OrderedDict()  # dim -> route buffers + last_step
     self.share_sort = True  # er_emb_group_share_sort between table groups that read the same ids
+    # lazy dense decay: rows carry pending decay steps after a training step (backward_update) until flush_decay();
+    # inference lookups (predict / evaluate) must read current rows WITHOUT replaying anything twice
+    self._decay_pending = False
+    self.inference = False
     self._sort_leader = {}  # dim -> dim of the group whose per-step sort it reuses
 
   # -- declaration (build pass)
@@ -175,6 +179,19 @@ class EmbeddingEngine(object):
     be.emb_group_enable_lazy_decay(grp, lz['last_step'], self._clock[1], self._clock[0])
     return lz
 
+  def _lazy_groups(self):
+    """[(C group handle, its lazy-decay state)] of the table groups whose rows carry pending decay."""
+    return [(self.emb_groups[dim], lz) for dim, lz in self._lazy.items()]
+
+  def rebind_lr_history(self, lr_hist):
+    """The estimator re-allocated the per-step lr_t history (it grew): point the table groups at the new buffer."""
+    if self._clock is None:
+      return
+    self._clock = (self._clock[0], lr_hist, self._clock[2])
+    be = kernels.hip()
+    for grp, lz in self._lazy_groups():
+      be.emb_group_enable_lazy_decay(grp, lz['last_step'], lr_hist, self._clock[0])
+
   def flush_decay(self):
     """Bring every row current (lazy dense decay): before reading tables out (state_dict, evaluation)."""
     if not self.lazy_decay:
@@ -182,6 +199,18 @@ class EmbeddingEngine(object):
     be = kernels.hip()
     for dim, grp in self.emb_groups.items():
       be.emb_flush_decay(grp, self._clock[2])
+    self._decay_pending = False
+
+  def begin_inference(self):
+    """Lookups that no row update follows (predict / evaluate).  The catch-up kernel leaves `last_step` to the row
+    update of the same step, so running it without one would replay the same pending decay on every call: instead every
+    row is brought current once (only if a training step ran since the last flush) and the lookups skip the catch-up."""
+    if self.lazy_decay and self._decay_pending:
+      self.flush_decay()
+    self.inference = True
+
+  def end_inference(self):
+    self.inference = False
 
   def mark_restored(self, step):
     """Tables were loaded as of `step` finished steps: no decay is pending on any row."""
@@ -303,7 +332,7 @@ class EmbeddingEngine(object):
     be = kernels.hip()
     for g in self.groups.values():
       g['got_grad'] = False
-    if self.lazy_decay:
+    if self.lazy_decay and not self.inference:
       # sort the step's ids once (reused by the backward), bring the rows it touches up to date, then look up
       grps, uks, nus = [], [], []
       for dim, grp in self.emb_groups.items():
@@ -389,6 +418,43 @@ class EmbeddingEngine(object):
     for i in range(0, len(grps), step):  # one tile launch + one fix launch for (up to 4) table groups
       be.emb_bwd_update_multi(grps[i:i + step], opt_kind, hyper)
     self.join_decay_sweep()
+    self._decay_pending = True
+
+  # -- gradient clipping by global norm: the reduce and the row update as two steps, the norm in between
+  def backward_reduce(self, normsq, weight):
+    """First half of backward_update when gradients are clipped by their global norm (compat/optimizers.py:365-376):
+    the de-duplicated row sums of every table group go to buffers instead of straight into the optimizer, and
+    normsq[0] += weight * sum of their squares (weight = grad_scale^2: `values` of the IndexedSlices after the gradient
+    multipliers).  apply_reduced() finishes the step once the multiplier is known."""
+    be = kernels.hip()
+    for g in self.groups.values():
+      if not g['got_grad']:
+        g['dout'].zero_()
+    self._reduced = []
+    for dim, grp in self.emb_groups.items():
+      bufs = self._clip_bufs.get(dim) if hasattr(self, '_clip_bufs') else None
+      if bufs is None:
+        if not hasattr(self, '_clip_bufs'):
+          self._clip_bufs = {}
+        n = grp['num_entries']
+        bufs = self._clip_bufs[dim] = (torch.zeros(n, dtype=torch.int32, device=self.device),
+                                       torch.zeros(n, dim, dtype=torch.float32, device=self.device),
+                                       torch.zeros(1, dtype=torch.int32, device=self.device))
+      if self.lazy_decay:  # this step's er_emb_route (forward) left the sort and the key list
+        lz = self._lazy[self._sort_leader.get(dim, dim)]
+        keys, n_unique, grads = lz['ukeys'], lz['n_unique'], bufs[1]
+        be.emb_bwd_reduce_routed(grp, grads)
+      else:
+        keys, grads, n_unique = be.emb_bwd_reduce(grp, out=bufs)
+      be.gradsq_rows(grads, dim, weight, normsq, True, counts=n_unique)
+      self._reduced.append((grp, keys, grads, n_unique))
+
+  def apply_reduced(self, opt_kind, hyper):
+    be = kernels.hip()
+    for grp, keys, grads, n_unique in self._reduced:
+      be.emb_apply_unique(grp, keys, grads, n_unique, opt_kind, hyper)
+    self._reduced = []
+    self._decay_pending = True
 
   # -- host exchange
   def state_dict(self, slots=False):

@@ -296,7 +296,8 @@ class ShardedEmbeddingEngine(EmbeddingEngine):
       if sh['leader'] is None:
         be.emb_owner_ids(sh['recv_keys'], None, W, sh['peer_cap'], self.rank * sh['stride'], sh['recv_ids'], sh['recv_cnt'])
         be.emb_owner_merge_padded(sh['owner'], sh['recv_cnt'], W, sh['peer_cap'])
-    hyper = self._clock[2] if any(sh['lazy'] is not None for sh in shs) else None
+    # (inference: the rows were flushed by begin_inference(); serving them must not replay anything)
+    hyper = self._clock[2] if (any(sh['lazy'] is not None for sh in shs) and not self.inference) else None
     for i in range(0, len(shs), 4):
       be.emb_owner_serve([sh['owner'] for sh in shs[i:i + 4]], [sh['rows_out'] for sh in shs[i:i + 4]], hyper)
 
@@ -356,7 +357,7 @@ class ShardedEmbeddingEngine(EmbeddingEngine):
       for sh in live:
         if sh['leader'] is None:
           be.emb_owner_merge(sh['owner'], sh['recv_counts'])
-      hyper = self._clock[2] if any(sh['lazy'] is not None for sh in live) else None
+      hyper = self._clock[2] if (any(sh['lazy'] is not None for sh in live) and not self.inference) else None
       for i in range(0, len(live), 4):
         be.emb_owner_serve([sh['owner'] for sh in live[i:i + 4]], [sh['rows_out'] for sh in live[i:i + 4]], hyper)
       for sh in self.shard.values():
@@ -365,7 +366,7 @@ class ShardedEmbeddingEngine(EmbeddingEngine):
     for dim, sh in self.shard.items():
       m, st = sh['m'], sh['st']
       lz = sh['lazy']
-      if lz is not None and m:
+      if lz is not None and m and not self.inference:
         if sh['leader'] is None:
           be.emb_route(sh['owner'], lz['ukeys'], lz['n_unique'], None, None)
         else:
@@ -428,6 +429,7 @@ class ShardedEmbeddingEngine(EmbeddingEngine):
     self.reduce_local()
     self.exchange_grads_and_update(opt_kind, hyper)
     self.apply_replicated(opt_kind, hyper)
+    self._decay_pending = True
 
   def flush_decay(self):
     if not self.lazy_decay:
@@ -436,9 +438,13 @@ class ShardedEmbeddingEngine(EmbeddingEngine):
     for sh in self.shard.values():
       if sh['lazy'] is not None:
         be.emb_flush_decay(sh['owner'], self._clock[2])
+    self._decay_pending = False
 
   def _lazy_states(self):
     return [sh['lazy'] for sh in self.shard.values() if sh.get('lazy')]
+
+  def _lazy_groups(self):
+    return [(sh['owner'], sh['lazy']) for sh in self.shard.values() if sh.get('lazy')]
 
   # -- host exchange (collective: every rank must call)
   def table_view(self, name):

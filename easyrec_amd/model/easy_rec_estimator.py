@@ -80,8 +80,11 @@ class EasyRecEstimator(object):
     self.emb_grad_scale = 1.0
     if oc[0].HasField('embedding_learning_rate_multiplier'):
       self.emb_grad_scale = float(oc[0].embedding_learning_rate_multiplier)
-    if cfg.train_config.gradient_clipping_by_norm > 0:
-      raise NotImplementedError('gradient_clipping_by_norm is not implemented on the MI355X path yet')
+    # gradient clipping by global norm (estimator :339-353 -> optimize_loss(clip_gradients=...), compat/optimizers.py:
+    # 365-376): 0 = off.  The norm covers every gradient after the multipliers, so the embedding backward runs as
+    # reduce -> norm -> apply instead of the fused reduce+apply (layers/input_layer.py backward_reduce).
+    self.clip_norm = float(cfg.train_config.gradient_clipping_by_norm) \
+        if cfg.train_config.gradient_clipping_by_norm > 0 else 0.0
 
     labels = OrderedDict((name, self.features.label(name)) for name in self.schema.label_fields)
     with context.use(self.ctx):
@@ -101,6 +104,8 @@ class EasyRecEstimator(object):
     if dense_sweep is None:
       dense_sweep = os.environ.get('ER_DENSE_SWEEP', '0') == '1'
     self.dense_sweep = bool(dense_sweep)
+    # per-step lr_t history read by the lazy dense decay's replay: step s lives at lr_hist[s]; train_step / set_global_step
+    # refuse to run past its capacity (er_hyper_select stops recording there and a replay would read out of bounds)
     n_hist = max(2 * int(cfg.train_config.num_steps or 0), 1 << 20)
     self.lr_hist = torch.zeros(n_hist, dtype=torch.float32, device=dev)
     self.engine.set_step_clock(self.step_counter, self.lr_hist, self.hyper[0],
@@ -111,6 +116,8 @@ class EasyRecEstimator(object):
     }
     self._reg_emb = torch.zeros(1, dtype=torch.float32, device=dev)
     self._reg_dense = torch.zeros(1, dtype=torch.float32, device=dev)
+    self._normsq = torch.zeros(1, dtype=torch.float32, device=dev)   # clipping: sum of squares of all gradients
+    self.grad_norm = torch.zeros(1, dtype=torch.float32, device=dev)  # clipping: the step's global gradient norm
 
   # -- hooks overridden by the embedding-parallel estimator (model/embedding_parallel.py)
   def _make_engine(self):
@@ -171,8 +178,26 @@ class EasyRecEstimator(object):
     self.hyper_table[torch.from_numpy(slots).to(self.device)] = torch.from_numpy(rows).to(self.device)
     self._planned_until += count
 
+  def _grow_lr_history(self, need):
+    """Make room for step indices < need in the lr_t history (lazy dense decay).  Outside a captured graph the buffer
+    is re-allocated (doubling) and re-registered with the table groups; inside one its address is baked in, so every
+    row is brought current first (nothing older than the flush is ever replayed) - then the run must stop."""
+    cap = self.lr_hist.numel()
+    if need <= cap:
+      return
+    if self.graph is not None or getattr(self, '_graphs', None) is not None:
+      raise RuntimeError('easyrec_amd: step %d exceeds the lr_t history capacity %d baked into the captured hipGraph; '
+                         'set train_config.num_steps (the history is sized 2x num_steps) before capture()' % (need, cap))
+    if self.device.type == 'cuda':
+      torch.cuda.synchronize()
+    grown = torch.zeros(max(2 * cap, need), dtype=torch.float32, device=self.device)
+    grown[:cap].copy_(self.lr_hist)
+    self.lr_hist = grown
+    self.engine.rebind_lr_history(grown)
+
   def _refresh_hyper(self):
     """Keep the device table half a ring ahead of `global_step` (sync only once per half ring)."""
+    self._grow_lr_history(self.global_step + 1)
     half = self.HYPER_SLOTS // 2
     if self._planned_until == 0:
       self._plan_hyper(self.HYPER_SLOTS)
@@ -205,7 +230,7 @@ class EasyRecEstimator(object):
                     [self.losses[n] for n in names], self.losses['regularization_loss'], self.losses['total_loss'])
       if self.is_training:
         vs = self.varstore
-        if self.overlap_dense_update and self.device.type == 'cuda':
+        if self.overlap_dense_update and self.device.type == 'cuda' and self.clip_norm <= 0:
           # Two independent tails of the step: (a) the grouped weight-gradient GEMM + the dense optimizer, (b) the
           # embedding backward (segmented reduction + row updates: chains of dependent random accesses that leave
           # most CUs idle).  They run on two streams - parallel branches of the captured hipGraph.
@@ -223,12 +248,32 @@ class EasyRecEstimator(object):
           self.engine.backward_update(self.opt_emb.kind, self.hyper[0])
           main.wait_stream(side)
           del keep  # the queued operands stayed referenced until the streams joined
+        elif self.clip_norm > 0:
+          self.model.backward()
+          self._sync_dense_grads()
+          self._clipped_update()
         else:
           self.model.backward()
           self._sync_dense_grads()
           self.engine.backward_update(self.opt_emb.kind, self.hyper[0])
           be.dense_opt_step(vs.flat, vs.slots.get('m'), vs.slots.get('v'), vs.flat_grad,
                             vs.l2coef if vs.any_l2 else None, self.opt_dense.kind, self.hyper[1])
+
+  def _emb_gradsq_weight(self):
+    """What the squared embedding row sums are multiplied by in the norm: grad_scale^2 (fp32, as the kernels apply it)."""
+    gs = np.float32(self.emb_grad_scale)
+    return float(gs * gs)
+
+  def _clipped_update(self):
+    """norm over (dense gradients as the optimizer sees them, de-duplicated embedding row sums) -> multiplier in the
+    step's er_opt_hyper records -> both optimizers."""
+    be, vs = kernels.hip(), self.varstore
+    l2 = vs.l2coef if vs.any_l2 else None
+    be.gradsq_dense(vs.flat, vs.flat_grad, l2, self.hyper[1], self._normsq, accumulate=False)
+    self.engine.backward_reduce(self._normsq, self._emb_gradsq_weight())
+    be.clip_scale(self._normsq, self.clip_norm, self.hyper, self.grad_norm)
+    self.engine.apply_reduced(self.opt_emb.kind, self.hyper[0])
+    be.dense_opt_step(vs.flat, vs.slots.get('m'), vs.slots.get('v'), vs.flat_grad, l2, self.opt_dense.kind, self.hyper[1])
 
   def train_step(self, batch=None):
     """Load `batch` (optional) and run one optimisation step.  Returns the dict of loss tensors."""
@@ -250,9 +295,15 @@ class EasyRecEstimator(object):
     if batch is not None:
       self.features.load(batch)
     self.features.transform()
-    with context.use(self.ctx), torch.no_grad():
-      self.model.begin_step()
-      return self.model.build_predict_graph()
+    # no row update follows these lookups: bring the tables current once, then look up without the catch-up
+    # (running it here would re-apply the pending Adam decay on every call)
+    self.engine.begin_inference()
+    try:
+      with context.use(self.ctx), torch.no_grad():
+        self.model.begin_step()
+        return self.model.build_predict_graph()
+    finally:
+      self.engine.end_inference()
 
   def evaluate(self, batches, eval_config=None):
     """The evaluation pass of the reference (`EasyRecEstimator._eval_model_fn` -> `build_metric_graph`,
@@ -299,8 +350,10 @@ class EasyRecEstimator(object):
         pred = self.predict(batch)
         for (name, suf), (kind, arg, m) in acc.items():
           label = self.features.label(dict(heads)[suf])
-          if kind == 'auc':
-            m.update(label, pred['probs' + suf], self.features.sample_weight)
+          if label.dtype.is_floating_point:  # tf.to_int64(label) in front of the metrics (rank_model.py:352): truncation
+            label = torch.trunc(label)
+          if kind == 'auc':  # metrics_tf.auc(label, probs, num_thresholds): no weights (rank_model.py:362)
+            m.update(label, pred['probs' + suf], None)
           elif kind == 'grouped':  # host-side, as the reference's py_func
             m.update(label, pred['probs' + suf], host_key_column(self.features.schema, batch, arg[0]))
           else:
@@ -350,6 +403,7 @@ class EasyRecEstimator(object):
     assert self.graph is None or step == self.global_step, 'restore before capture()'
     if self.device.type == 'cuda':
       torch.cuda.synchronize()
+    self._grow_lr_history(int(step) + 1)
     self.global_step = int(step)
     self.step_counter.fill_(int(step))
     for opt in {id(o): o for o in (self.opt_emb, self.opt_dense)}.values():

@@ -138,6 +138,8 @@ class EmbeddingParallelEstimator(EasyRecEstimator):
       if collectives is not None:
         collectives()
 
+  OVERFLOW_CHECK_EVERY = 256  # steps between blocking reads of the exchange's sticky overflow flag
+
   def train_step(self, batch=None):
     assert self._built, 'call build() first'
     if batch is not None:
@@ -147,7 +149,20 @@ class EmbeddingParallelEstimator(EasyRecEstimator):
     self._refresh_hyper()
     self._device_step()
     self.global_step += 1
+    # An owner that receives more keys than the exchange's capacity voids the step (keys are clamped): the flag is
+    # sticky, so a periodic blocking read bounds how long a skewed id distribution can go unnoticed; evaluate(),
+    # state_dict(), checkpoint.save() and loss_values() check it too.
+    if self.global_step % self.OVERFLOW_CHECK_EVERY == 0:
+      self.engine.check_overflow()
     return self.losses
+
+  def evaluate(self, batches, eval_config=None):
+    self.engine.check_overflow()
+    return super(EmbeddingParallelEstimator, self).evaluate(batches, eval_config)
+
+  def state_dict(self, slots=False):
+    self.engine.check_overflow()
+    return super(EmbeddingParallelEstimator, self).state_dict(slots=slots)
 
   def capture(self, warmup=3):
     """Capture the three static segments of the step as hipGraphs (the all-to-alls between them have

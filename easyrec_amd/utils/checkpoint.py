@@ -53,6 +53,9 @@ def save(est, ckpt_path):
   engine.flush_decay()
   if est.device.type == 'cuda':
     torch.cuda.synchronize()
+  # an overflowed fixed-capacity exchange voids the steps since: never persist tables it may have touched
+  if hasattr(engine, 'check_overflow'):
+    engine.check_overflow()
   os.makedirs(os.path.dirname(os.path.abspath(ckpt_path)) or '.', exist_ok=True)
   slots = _SLOT_NAMES[est.opt_emb.kind]
   for name, is_shard in _engine_tables(engine):

@@ -1,7 +1,8 @@
 """Load EasyRec pipeline configs unchanged (the drop-in boundary).
 
-Mirrors reference easy_rec/python/utils/config_util.py:46-136 (get_configs_from_pipeline_file,
-auto_expand_share_feature_configs, auto_expand_names) and :583-610 (get_compatible_feature_configs).
+Behaviour spec: reference easy_rec/python/utils/config_util.py:46-136 (`get_configs_from_pipeline_file`: `.config` =
+protobuf text, `.json` = protobuf JSON; `shared_names` expansion; `name[a-b]` range expansion) and :583-590
+(`get_compatible_feature_configs`: the deprecated repeated `feature_configs` wins over `feature_config.features`).
 """
 import os
 import re
@@ -9,77 +10,68 @@ import re
 from google.protobuf import json_format
 from google.protobuf import text_format
 
-from easyrec_amd.protos import feature_config_pb2
 from easyrec_amd.protos import pipeline_pb2
+
+_RANGE_NAME = re.compile(r'([a-zA-Z_]+)\[([0-9]+)-([0-9]+)\]')
+_PARSERS = {
+    '.config': lambda text, msg: text_format.Merge(text, msg),
+    '.json': lambda text, msg: json_format.Parse(text, msg),
+}
 
 
 def get_configs_from_pipeline_file(pipeline_config_path, auto_expand=True):
-  """Read a `.config` (prototxt) or `.json` EasyRecConfig (reference config_util.py:46-78)."""
+  """An EasyRecConfig from a `.config` (prototxt) or `.json` file; an EasyRecConfig passes through."""
   if isinstance(pipeline_config_path, pipeline_pb2.EasyRecConfig):
     return pipeline_config_path
-  assert os.path.exists(pipeline_config_path), \
-      'pipeline_config_path [%s] not exists' % pipeline_config_path
-  pipeline_config = pipeline_pb2.EasyRecConfig()
-  with open(pipeline_config_path, 'r') as f:
-    config_str = f.read()
-  if pipeline_config_path.endswith('.config'):
-    text_format.Merge(config_str, pipeline_config)
-  elif pipeline_config_path.endswith('.json'):
-    json_format.Parse(config_str, pipeline_config)
-  else:
-    assert False, 'invalid file format(%s), currently support formats: .config(prototxt) .json' % \
-        pipeline_config_path
-  if auto_expand:
-    return auto_expand_share_feature_configs(pipeline_config)
-  return pipeline_config
+  path = pipeline_config_path
+  if not os.path.exists(path):
+    raise AssertionError('pipeline_config_path [%s] not exists' % path)
+  parse = _PARSERS.get(os.path.splitext(path)[1])
+  if parse is None:
+    raise AssertionError('invalid file format(%s), currently support formats: .config(prototxt) .json' % path)
+  config = pipeline_pb2.EasyRecConfig()
+  with open(path, 'r') as f:
+    parse(f.read(), config)
+  return auto_expand_share_feature_configs(config) if auto_expand else config
 
 
 def parse_pipeline_text(config_str, auto_expand=True):
-  pipeline_config = pipeline_pb2.EasyRecConfig()
-  text_format.Merge(config_str, pipeline_config)
-  return auto_expand_share_feature_configs(pipeline_config) if auto_expand else pipeline_config
+  config = pipeline_pb2.EasyRecConfig()
+  text_format.Merge(config_str, config)
+  return auto_expand_share_feature_configs(config) if auto_expand else config
 
 
 def get_compatible_feature_configs(pipeline_config):
-  """`feature_configs` (deprecated, repeated) or `feature_config.features` (config_util.py:583-590)."""
-  if pipeline_config.feature_configs:
-    return pipeline_config.feature_configs
-  return pipeline_config.feature_config.features
+  """The feature list in use: `feature_configs` (deprecated) when non-empty, else `feature_config.features`."""
+  old_style = pipeline_config.feature_configs
+  return old_style if len(old_style) > 0 else pipeline_config.feature_config.features
 
 
 def auto_expand_names(input_name):
-  """field[1-3] -> field1, field2, field3 (reference config_util.py:114-133)."""
-  m = re.match(r'([a-zA-Z_]+)\[([0-9]+)-([0-9]+)\]', input_name)
-  if m:
-    prefix, sid, eid = m.group(1), int(m.group(2)), int(m.group(3)) + 1
-    return ['%s%d' % (prefix, t) for t in range(sid, eid)]
-  return [input_name]
+  """`field[1-3]` -> [field1, field2, field3]; any other name -> [name]."""
+  m = _RANGE_NAME.match(input_name)
+  if m is None:
+    return [input_name]
+  stem, first, last = m.group(1), int(m.group(2)), int(m.group(3))
+  return [stem + str(k) for k in range(first, last + 1)]
 
 
 def auto_expand_share_feature_configs(pipeline_config):
-  """Expand `shared_names` into one FeatureConfig per name (reference config_util.py:81-111)."""
-  feature_configs = get_compatible_feature_configs(pipeline_config)
-  for share_config in list(feature_configs):
-    if len(share_config.shared_names) == 0:
-      continue
-    input_names = []
-    for input_name in share_config.shared_names:
-      if pipeline_config.data_config.auto_expand_input_fields:
-        input_names.extend(auto_expand_names(input_name))
-      else:
-        input_names.append(input_name)
-    del share_config.shared_names[:]
-    fea_config = feature_config_pb2.FeatureConfig()
-    fea_config.CopyFrom(share_config)
-    del fea_config.input_names[:]
-    for tmp_name in input_names:
-      tmp_config = feature_config_pb2.FeatureConfig()
-      tmp_config.CopyFrom(fea_config)
-      tmp_config.input_names.append(tmp_name)
-      if pipeline_config.feature_configs:
-        pipeline_config.feature_configs.append(tmp_config)
-      else:
-        pipeline_config.feature_config.features.append(tmp_config)
+  """A FeatureConfig with `shared_names` stands for one more FeatureConfig per shared name (same settings, that name
+  as its only input); the clones are appended to the list in use and `shared_names` is cleared on the template."""
+  features = get_compatible_feature_configs(pipeline_config)
+  expand_ranges = pipeline_config.data_config.auto_expand_input_fields
+  templates = [fc for fc in features if len(fc.shared_names) > 0]  # snapshot: clones carry no shared_names
+  for template in templates:
+    names = []
+    for shared in template.shared_names:
+      names.extend(auto_expand_names(shared) if expand_ranges else [shared])
+    template.ClearField('shared_names')
+    for name in names:
+      clone = features.add()
+      clone.CopyFrom(template)
+      clone.ClearField('input_names')
+      clone.input_names.append(name)
   return pipeline_config
 
 

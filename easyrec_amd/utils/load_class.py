@@ -1,57 +1,72 @@
 """Class registries: the plugin lookups the kernels sit behind.
 
-Mirror of reference easy_rec/python/utils/load_class.py:203-249: `get_register_class_meta` (models
-and inputs register themselves by class name; `EasyRecModel.create_class('DeepFM')`) and
-`load_keras_layer(name)` (backbone `keras_layer.class_name` -> easyrec_amd.layers.keras.<name>).
+API of reference easy_rec/python/utils/load_class.py:193-249: `get_register_class_meta(class_map)` gives the metaclass
+through which models register themselves under their class name and gain `create_class(name)`
+(`EasyRecModel.create_class('DeepFM')`); `load_keras_layer(name)` resolves a backbone `keras_layer.class_name`.
+
+Here the registry is a small object (`ClassRegistry`) and the metaclass is a thin hook that records each new class
+in it; duplicates are rejected unless the very same class object registers twice (module re-import).
 """
 import importlib
 import logging
-import pydoc
 from abc import ABCMeta
 
 
+class ClassRegistry(object):
+  """name -> class, backed by the caller's dict so existing references to the map keep working."""
+
+  def __init__(self, backing):
+    self._map = backing
+
+  def add(self, name, cls):
+    known = self._map.get(name)
+    if known is not None and known is not cls:
+      raise AssertionError('class name %s is taken: %r is registered, %r tried to register' % (name, known, cls))
+    self._map[name] = cls
+    logging.debug('registered %s -> %r', name, cls)
+
+  def find(self, name):
+    try:
+      return self._map[name]
+    except KeyError:
+      raise Exception('Class %s is not registered. Available ones are %s' % (name, sorted(self._map)))
+
+
 def register_class(class_map, class_name, cls):
-  assert class_name not in class_map or class_map[class_name] == cls, \
-      'confilict class %s , %s is already register to be %s' % (cls, class_name, str(class_map[class_name]))
-  logging.debug('register class %s' % class_name)
-  class_map[class_name] = cls
+  ClassRegistry(class_map).add(class_name, cls)
 
 
 def get_register_class_meta(class_map, have_abstract_class=True):
+  """A metaclass (ABCMeta-derived, so `@abstractmethod` works on the bases) that files every class created with it
+  in `class_map` and gives it a `create_class(name)` classmethod looking names up in the same map."""
+  registry = ClassRegistry(class_map)
 
-  class RegisterABCMeta(ABCMeta):
+  def _init(cls, name, bases, attrs):
+    ABCMeta.__init__(cls, name, bases, attrs)
+    registry.add(name, cls)
+    cls.create_class = classmethod(lambda _cls, wanted: registry.find(wanted))
 
-    def __new__(mcs, name, bases, attrs):
-      newclass = super(RegisterABCMeta, mcs).__new__(mcs, name, bases, attrs)
-      register_class(class_map, name, newclass)
-
-      @classmethod
-      def create_class(cls, name):
-        if name in class_map:
-          return class_map[name]
-        raise Exception('Class %s is not registered. Available ones are %s' % (name, list(class_map.keys())))
-
-      setattr(newclass, 'create_class', create_class)
-      return newclass
-
-  return RegisterABCMeta
+  return type('RegisterABCMeta', (ABCMeta,), {'__init__': _init})
 
 
 def load_keras_layer(name):
-  """(layer_class, is_customize).  Only this package's layers exist (no tf.keras fallback)."""
+  """(layer_class, is_customize) for a backbone `keras_layer.class_name`.  Only this package's layers exist (there is
+  no tf.keras to fall back to): unknown names give (None, False)."""
   name = (name or '').strip()
   if not name:
     return None
-  cls = pydoc.locate('easyrec_amd.layers.keras.' + name)
-  if cls is not None:
-    return cls, True
-  return None, False
+  module = importlib.import_module('easyrec_amd.layers.keras')
+  cls = getattr(module, name, None)
+  return (cls, True) if isinstance(cls, type) else (None, False)
+
+
+MODEL_MODULES = ('deepfm', 'dcn', 'multi_tower_din', 'mmoe', 'rank_model', 'multi_task_model', 'wide_and_deep', 'fm',
+                 'multi_tower', 'dlrm', 'simple_multi_task', 'ple', 'dbmtl')
 
 
 def import_all_models():
   """Import every model module so that the registry is populated."""
-  for mod in ('deepfm', 'dcn', 'multi_tower_din', 'mmoe', 'rank_model', 'multi_task_model', 'wide_and_deep', 'fm',
-              'multi_tower', 'dlrm', 'simple_multi_task', 'ple', 'dbmtl'):
+  for mod in MODEL_MODULES:
     try:
       importlib.import_module('easyrec_amd.model.' + mod)
     except ImportError as e:  # pragma: no cover

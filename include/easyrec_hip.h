@@ -166,7 +166,9 @@ typedef struct er_opt_hyper {
   float one_minus_beta2;
   float eps;
   float grad_scale;    /* multiplies summed row gradients (embedding lr multiplier, 1/world)     */
-  float reserved[8];
+  float clip_scale;    /* gradient clipping by global norm: multiplies the whole gradient (after grad_scale and
+                          the kernel-L2 term); 0 = no clipping.  Written per step by er_clip_scale.              */
+  float reserved[7];
 } er_opt_hyper;
 
 typedef struct er_emb_group er_emb_group;
@@ -570,6 +572,30 @@ int er_emb_dense_apply(const er_dense_apply_desc* descs_host, int n, int opt_kin
  * -------------------------------------------------------------------------------------------- */
 int er_dense_opt_step(float* w, float* m, float* v, const float* grad, const float* l2coef,
                       int64_t n, int opt_kind, const er_opt_hyper* hyper, er_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
+ * Gradient clipping by global norm (train_config.gradient_clipping_by_norm).  Replaces `_get_grad_norm` +
+ *     clip_ops.clip_by_global_norm of optimize_loss, compat/optimizers.py:365-376 and :453-481: norm = sqrt of the
+ *     sum of squares of every gradient (dense: as the optimizer sees it, grad_scale*grad + l2coef*w; embeddings: the
+ *     de-duplicated row sums of a lookup, times grad_scale), multiplier = clip_norm * min(1/norm, 1/clip_norm).
+ * er_gradsq_rows : acc[0] (+)= weight * sum of x[r*ld + c]^2 over c < cols and the valid rows r < max_rows; with
+ *     seg_counts (device int32 [n_seg]) row r is valid iff (r % seg_stride) < seg_counts[r / seg_stride] (a prefix
+ *     count: n_seg = 1, seg_stride = max_rows; the fixed-capacity exchange: per-owner counts, seg_stride = capacity).
+ * er_gradsq_dense: acc[0] (+)= sum_i (hyper->grad_scale * grad[i] + l2coef[i] * w[i])^2   (l2coef may be NULL)
+ * er_clip_scale  : norm = sqrt(normsq[0]); records[i].clip_scale = multiplier for i < n_records (records: DEVICE
+ *     er_opt_hyper array, e.g. the step's [embedding, dense] pair written by er_hyper_select); norm_out optional.
+ * er_emb_apply_unique: the row-wise optimizer of er_emb_bwd_update applied to ready-made row sums (keys / grads /
+ *     n_unique as produced by er_emb_bwd_reduce or er_emb_route + er_emb_bwd_reduce_routed; ld = floats per grads
+ *     row, 0 = dim): what the fused reduce+apply does once the norm of ALL gradients is known.
+ * Fixed summation order: deterministic. */
+int er_gradsq_rows(const float* x, int64_t max_rows, int32_t cols, int32_t ld, const int32_t* seg_counts,
+                   int32_t n_seg, int64_t seg_stride, float weight, float* acc, int accumulate, er_stream_t stream);
+int er_gradsq_dense(const float* w, const float* grad, const float* l2coef, int64_t n, const er_opt_hyper* hyper,
+                    float* acc, int accumulate, er_stream_t stream);
+int er_clip_scale(const float* normsq, float clip_norm, er_opt_hyper* records, int32_t n_records, float* norm_out,
+                  er_stream_t stream);
+int er_emb_apply_unique(er_emb_group* g, const uint32_t* unique_keys, const float* unique_grads, int32_t ld,
+                        const int32_t* n_unique, int opt_kind, const er_opt_hyper* hyper, er_stream_t stream);
 
 /* ----------------------------------------------------------------------------------------------
  * K16 Streaming AUC.  Replaces the per-threshold confusion-matrix update of tf.metrics.auc

@@ -28,6 +28,11 @@ from oracle import hashing
 OPT_SGD, OPT_ADAM, OPT_LAZY_ADAM, OPT_ADAGRAD = 0, 1, 2, 3
 ACT_NONE, ACT_RELU = 0, 1
 (HYPER_LR, HYPER_LR_T, HYPER_BETA1, HYPER_BETA2, HYPER_OMB1, HYPER_OMB2, HYPER_EPS, HYPER_GSCALE) = range(8)
+HYPER_CLIP = 8  # er_opt_hyper.clip_scale (0 = no clipping)
+
+
+def _clip_of(h):
+  return F32(h[HYPER_CLIP]) if (len(h) > HYPER_CLIP and h[HYPER_CLIP] != 0) else None
 
 F32 = np.float32
 
@@ -153,9 +158,12 @@ def sparse_grads(specs, dim):
 def apply_sparse(var, m, v, grads, opt_kind, h):
   """var/m/v numpy [total_rows, dim] updated in place."""
   gs = F32(h[HYPER_GSCALE])
+  clip = _clip_of(h)
   touched = set()
   for key, g in grads.items():
     g = (g * gs).astype(np.float32)
+    if clip is not None:
+      g = (g * clip).astype(np.float32)
     touched.add(key)
     if opt_kind in (OPT_ADAM, OPT_LAZY_ADAM):
       var[key], m[key], v[key] = adam_row(var[key], m[key], v[key], g, h)
@@ -180,6 +188,8 @@ def dense_opt(w, m, v, grad, l2coef, opt_kind, h):
   g = grad.astype(np.float32) * F32(h[HYPER_GSCALE])
   if l2coef is not None:
     g = np.where(l2coef != 0, g + l2coef * w, g).astype(np.float32)
+  if _clip_of(h) is not None:
+    g = (g * _clip_of(h)).astype(np.float32)
   if opt_kind in (OPT_ADAM, OPT_LAZY_ADAM):
     m[:] = m + (g - m) * F32(h[HYPER_OMB1])
     v[:] = v + (g * g - v) * F32(h[HYPER_OMB2])
@@ -194,6 +204,36 @@ def dense_opt(w, m, v, grad, l2coef, opt_kind, h):
 # ---------------------------------------------------------------------------------------------
 # backend with the HipBackend method surface (CPU tensors)
 # ---------------------------------------------------------------------------------------------
+class _NoWgradSink(object):
+  """The queue object LinearFn asks its backend for; this backend never defers a weight gradient."""
+  active = False
+  queue = ()
+
+  def put(self, x, dy, out, bf16):
+    return False
+
+
+class _Spec(object):
+  """The attributes of a lookup this file reads (duck-typed stand-in for the product's LookupSpec)."""
+
+  def __init__(self, **kw):
+    self.__dict__.update(kw)
+
+
+def _same_lookup_keys(group, leader):
+  """Do two table groups see the same keys every step: same id / offset buffers, table geometry and routing?"""
+  if group is leader or leader.get('sort_leader') is not None:
+    return False
+  a, b = group['specs'], leader['specs']
+  if len(a) != len(b) or group.get('n_active', -1) != leader.get('n_active', -1):
+    return False
+  if any(group.get(k) != leader.get(k) for k in ('world', 'shard_stride', 'local_base')):
+    return False
+  addr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+  return all((addr(x.ids), addr(x.offsets), x.rows, x.key_base, x.n_rows, x.max_nnz) ==
+             (addr(y.ids), addr(y.offsets), y.rows, y.key_base, y.n_rows, y.max_nnz) for x, y in zip(a, b))
+
+
 class RefBackend(object):
   name = 'oracle'
 
@@ -423,8 +463,7 @@ class RefBackend(object):
     pass
 
   def wgrad_sink(self):
-    from easyrec_amd.kernels import WgradSink
-    return WgradSink()  # never active: every gradient is computed where it arises
+    return _NoWgradSink()  # never active: every gradient is computed where it arises
 
   def flush_wgrads(self):
     pass
@@ -438,8 +477,7 @@ class RefBackend(object):
       self.emb_bwd_update(g, opt_kind, hyper)
 
   def emb_group_share_sort(self, group, leader):
-    from easyrec_amd.kernels import same_lookup_keys
-    if not same_lookup_keys(group, leader):
+    if not _same_lookup_keys(group, leader):
       return False
     group['sort_leader'] = leader
     return True
@@ -544,13 +582,12 @@ class RefBackend(object):
   def emb_dense_apply(self, tables, opt_kind, hyper):
     """Restated through the sparse path: the rows with a count are the ids of one lookup whose upstream gradient is
     the dense buffer; TF-exact Adam then sweeps the others."""
-    from easyrec_amd import kernels as K
     for var, m, v, dense in tables:
       n, dim = var.shape
       ids = torch.where(dense[:, dim] > 0, torch.arange(n, dtype=torch.int64), torch.full((n,), -1, dtype=torch.int64))
-      bitmap = torch.zeros((n + 31) // 32, dtype=torch.int32) if opt_kind == K.OPT_ADAM else None
-      spec = K.LookupSpec(table=var, ids=ids, offsets=None, weights=None, out=dense, out_col=0, rows=n, key_base=0,
-                          dim=dim, combiner=K.COMBINER_SUM, n_rows=n, max_nnz=n, name='dense_apply')
+      bitmap = torch.zeros((n + 31) // 32, dtype=torch.int32) if opt_kind == OPT_ADAM else None
+      spec = _Spec(table=var, ids=ids, offsets=None, weights=None, out=dense, out_col=0, rows=n, key_base=0,
+                   dim=dim, combiner=0, n_rows=n, max_nnz=n, name='dense_apply')
       grp = self.emb_group_create([spec], dim, n, var, m, v, bitmap)
       self.emb_bwd_update(grp, opt_kind, hyper)
 
@@ -852,6 +889,53 @@ class RefBackend(object):
     done = int(group['step_counter'].item())
     self._replay(group, range(group['total_rows']), done, h)
     group['last_step'].fill_(done - 1)
+
+  # -- gradient clipping by global norm (compat/optimizers.py:365-376, 453-481)
+  def gradsq_rows(self, x, cols, weight, acc, accumulate, counts=None, seg_stride=None):
+    rows = x.shape[0]
+    valid = np.ones(rows, dtype=bool)
+    if counts is not None:
+      stride = rows if seg_stride is None else int(seg_stride)
+      r = np.arange(rows)
+      seg = r // max(stride, 1)
+      cnt = counts.cpu().numpy()
+      valid = (seg < len(cnt)) & ((r - seg * stride) < cnt[np.minimum(seg, len(cnt) - 1)])
+    xs = x.detach().cpu().numpy()[valid, :cols].astype(np.float32)
+    s = F32(weight) * F32((xs * xs).sum(dtype=np.float32))
+    acc[0] = float(F32(acc[0].item()) + s) if accumulate else float(s)
+
+  def gradsq_dense(self, w, grad, l2coef, hyper, acc, accumulate=False):
+    h = hyper.detach().cpu().numpy().reshape(-1)
+    g = grad.detach().numpy().astype(np.float32) * F32(h[HYPER_GSCALE])
+    if l2coef is not None:
+      c = l2coef.numpy()
+      g = np.where(c != 0, g + c * w.detach().numpy(), g).astype(np.float32)
+    s = F32((g * g).sum(dtype=np.float32))
+    acc[0] = float(F32(acc[0].item()) + s) if accumulate else float(s)
+
+  def clip_scale(self, normsq, clip_norm, records, norm_out=None):
+    norm = np.sqrt(F32(normsq[0].item()), dtype=np.float32)
+    with np.errstate(divide='ignore'):
+      scale = F32(clip_norm) * min(F32(1.0) / norm, F32(1.0) / F32(clip_norm))
+    records[:, HYPER_CLIP] = float(scale)
+    if norm_out is not None:
+      norm_out[0] = float(norm)
+
+  def emb_apply_unique(self, group, keys, grads, n_unique, opt_kind, hyper):
+    h = hyper.detach().cpu().numpy().reshape(-1)
+    n = int(n_unique[0].item())
+    ks, gs = keys.cpu().numpy(), grads.detach().cpu().numpy()
+    sums = {int(ks[i]): gs[i, :group['dim']].astype(np.float32) for i in range(n) if ks[i] >= 0}
+    var = group['var'].detach().numpy()
+    m = None if group['m'] is None else group['m'].numpy()
+    v = None if group['v'] is None else group['v'].numpy()
+    if opt_kind == OPT_ADAM and 'last_step' in group:
+      apply_sparse(var, m, v, sums, OPT_LAZY_ADAM, h)
+      t = int(group['step_counter'].item()) - 1
+      for key in sums:
+        group['last_step'][key] = t
+      return
+    apply_sparse(var, m, v, sums, opt_kind, h)
 
   def dense_opt_step(self, w, m, v, grad, l2coef, opt_kind, hyper):
     h = hyper.detach().cpu().numpy().reshape(-1)

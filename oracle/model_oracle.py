@@ -746,15 +746,34 @@ class OracleTrainer(object):
     V, pred, losses = self.forward(batch)
     losses['total_loss'].backward()
     step = self.global_step
+    # gradients after the multipliers (compat/optimizers.py:347-356), then clip_by_global_norm (:365-376, 453-481):
+    # norm = sqrt(2 * sum of tf.nn.l2_loss(g)); a table's IndexedSlices carry one row per distinct id of a lookup, so
+    # (one lookup per table) the dense gradient has the same sum of squares.  Tables shared by several lookups keep
+    # per-lookup rows in TF; the dense gradient merges them - configs with shared tables and clipping are not covered.
+    grads = OrderedDict()
+    for name, t in V.used.items():
+      if not t.requires_grad:
+        continue
+      g = np.zeros(t.shape, dtype=np.float32) if t.grad is None else t.grad.numpy().astype(np.float32)
+      if name.endswith('/embedding_weights') and self.emb_mult != 1.0:
+        g = (g * F32(self.emb_mult)).astype(np.float32)
+      grads[name] = g
+    clip = float(self.cfg.train_config.gradient_clipping_by_norm)
+    self.last_grad_norm = None
+    if clip > 0:
+      half = [F32(0.5) * F32((g.astype(np.float64) ** 2).sum()) for g in grads.values()]
+      norm = F32(np.sqrt(F32(2.0) * F32(np.sum(np.asarray(half, dtype=np.float64)))))
+      with np.errstate(divide='ignore'):
+        scale = F32(clip) * min(F32(1.0) / norm, F32(1.0) / F32(clip))
+      grads = OrderedDict((n, (g * scale).astype(np.float32)) for n, g in grads.items())
+      self.last_grad_norm = float(norm)
     for name, t in V.used.items():
       if not t.requires_grad:
         continue
       is_emb = name.endswith('/embedding_weights')
       oi = 0 if (is_emb or len(self.opt) == 1) else 1
       o = self.opt[oi]
-      g = np.zeros(t.shape, dtype=np.float32) if t.grad is None else t.grad.numpy().astype(np.float32)
-      if is_emb and self.emb_mult != 1.0:
-        g = (g * F32(self.emb_mult)).astype(np.float32)
+      g = grads[name]
       lr = self._lr(o['lr_cfg'], step)
       var = self.state[name]
       if o['kind'] in ('adam_optimizer', 'lazy_adam_optimizer'):
