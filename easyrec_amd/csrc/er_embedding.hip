@@ -2602,7 +2602,6 @@ int er_emb_owner_serve(er_emb_group* const* groups, float* const* rows_out, cons
   for (int i = 0; i < n; ++i) {
     er_emb_group* g = groups[i];
     ER_REQUIRE(g && rows_out[i], "er_emb_owner_serve: null argument (group %d)", i);
-    ER_REQUIRE(hyper || !g->last_step, "er_emb_owner_serve: group %d decays lazily: hyper is needed", i);
     const int64_t N = group_entries(g);
     if (N == 0) continue;
     if (g->leader && !g->sorted_valid) {  // follower of a shared sort: take the leader's merge of this step
@@ -2616,7 +2615,9 @@ int er_emb_owner_serve(er_emb_group* const* groups, float* const* rows_out, cons
                "er_emb_owner_serve: call er_emb_owner_merge (on the group or its leader) for this step first");
     er::ServeArgs& a = ma.a[ma.n];
     a.skeys = src->keys_out; a.svals = src->vals_out; a.flags = src->head_flags; a.n = N;
-    a.tab = er::RowUpdate{g->var, g->m, g->v, g->bitmap, g->last_step, g->step_counter};
+    // hyper == NULL: serve the rows as they are (inference after er_emb_flush_decay: nothing is pending and nothing
+    // may be replayed, because no row update follows that would advance last_step)
+    a.tab = er::RowUpdate{g->var, g->m, g->v, g->bitmap, hyper ? g->last_step : nullptr, g->step_counter};
     a.lr_hist = g->lr_hist; a.out = rows_out[i]; a.dim = g->dim; a.G = g->G; a.V = g->V;
     a.ld = ld && ld[i] ? ld[i] : g->dim;
     ER_REQUIRE(a.ld >= g->dim && (g->V == 1 || (a.ld % 4 == 0 && (reinterpret_cast<uintptr_t>(rows_out[i]) & 15) == 0)),

@@ -405,6 +405,23 @@ class ShardedEmbeddingEngine(EmbeddingEngine):
     for dim, sh in self.shard.items():
       be.emb_bwd_reduce_routed(sh['req'], sh['ugrads'])
 
+  def local_gradsq(self, acc, weight):
+    """Gradient clipping (compat/optimizers.py:453-481): acc[0] += weight * sum of squares of THIS rank's de-duplicated
+    row gradients - the rows it is about to send to the owners (what arrives there is `values` of the owner's
+    IndexedSlices: one row per (requester, distinct id), un-merged across requesters) and its share of the replicated
+    tables' rows.  The all-reduce of the dense gradients carries the sum over the ranks (model/embedding_parallel.py).
+    Call after reduce_local()."""
+    be = kernels.hip()
+    for gi, (dim, sh) in enumerate(self.shard.items()):
+      if self.padded:
+        if sh['leader'] is None:  # the route's dim groups side by side; pad columns stay zero
+          be.gradsq_rows(sh['ugrads_all'], sh['ugrads_all'].shape[1], weight, acc, True, counts=self.counts_dev[gi],
+                         seg_stride=sh['peer_cap'])
+      else:
+        be.gradsq_rows(sh['ugrads'], dim, weight, acc, True, counts=sh['n_unique'])
+    for dim, r in self.rep.items():
+      be.gradsq_rows(r['dense'], dim, weight, acc, True)  # [rows, dim | count]: zero where the rank had no gradient
+
   def exchange_grads_and_update(self, opt_kind, hyper):
     be, comm = kernels.hip(), self.comm
     if self.shard and self.padded:

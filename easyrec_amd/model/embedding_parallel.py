@@ -55,12 +55,24 @@ class EmbeddingParallelEstimator(EasyRecEstimator):
 
   # the replicated small tables' dense gradient buffer lives behind the dense variables' gradients: zeroed by the
   # same fill and summed over the ranks by the same all-reduce
+  # (+ with gradient clipping, 4 floats whose first holds this rank's share of the embedding gradients' squared norm)
   def _extra_grad_floats(self):
-    return self.engine.rep_flat.numel() if self.engine.rep else 0
+    return (self.engine.rep_flat.numel() if self.engine.rep else 0) + (4 if self.clip_norm > 0 else 0)
 
   def _after_pack(self):
+    n_rep = self.engine.rep_flat.numel() if self.engine.rep else 0
     if self.engine.rep:
-      self.engine.set_rep_flat(self.varstore.grad_tail)
+      self.engine.set_rep_flat(self.varstore.grad_tail[:n_rep])
+    if self.clip_norm > 0:
+      self._norm_slot = self.varstore.grad_tail[n_rep:n_rep + 1]
+
+  def _clip_from_reduced(self):
+    """After the all-reduce: norm^2 = dense part (identical on every rank) + the summed per-rank embedding shares
+    (compat/optimizers.py:453-481: hvd.grouped_allreduce of the sharded tables' l2 sums) -> the step's multiplier."""
+    be, vs = kernels.hip(), self.varstore
+    be.gradsq_dense(vs.flat, vs.flat_grad, vs.l2coef if vs.any_l2 else None, self.hyper[1], self._normsq, accumulate=False)
+    be.reduce_sum(self._norm_slot, 1.0, self._normsq, accumulate=True)
+    be.clip_scale(self._normsq, self.clip_norm, self.hyper, self.grad_norm)
 
   def _sync_dense_grads(self):
     if self.world > 1 or not isinstance(self.comm, LocalComm):
@@ -94,6 +106,8 @@ class EmbeddingParallelEstimator(EasyRecEstimator):
       if self.is_training:
         self.model.backward()
         self.engine.reduce_local()
+        if self.clip_norm > 0:
+          self.engine.local_gradsq(self._norm_slot, self._emb_gradsq_weight())
 
   def _phase_apply(self):
     vs = self.varstore
@@ -105,8 +119,16 @@ class EmbeddingParallelEstimator(EasyRecEstimator):
     self.engine.owner_serve()
 
   def _phase_update(self):
+    if self.clip_norm > 0:
+      self._clip_from_reduced()
     self.engine.owner_update(self.opt_emb.kind, self.hyper[0])
     self._phase_apply()
+
+  def _compact_exchange_and_update(self):
+    self._sync_dense_grads()
+    if self.clip_norm > 0:
+      self._clip_from_reduced()
+    self.engine.exchange_grads_and_update(self.opt_emb.kind, self.hyper[0])
 
   def _phases(self):
     """[(static device work, the collectives that follow it)]: the static parts replay as hipGraphs."""
@@ -121,9 +143,7 @@ class EmbeddingParallelEstimator(EasyRecEstimator):
       return seq
     seq = [(self._phase_route, eng.exchange)]  # host sync (split sizes) + all-to-all keys / rows
     if self.is_training:
-      seq += [(self._phase_compute,
-               lambda: (self._sync_dense_grads(), eng.exchange_grads_and_update(self.opt_emb.kind, self.hyper[0]))),
-              (self._phase_apply, None)]
+      seq += [(self._phase_compute, self._compact_exchange_and_update), (self._phase_apply, None)]
     else:
       seq += [(self._phase_compute, None)]
     return seq

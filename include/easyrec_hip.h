@@ -531,7 +531,8 @@ int er_scatter_unique(const uint32_t* keys, const float* grads, const int32_t* n
  *     (one launch; the following er_emb_bwd_update(_multi) of the group - and of the groups sharing its sort -
  *     reuses it, as after er_emb_route).
  *   er_emb_owner_serve: for up to 4 such groups (a leader before its followers) in one launch: every distinct
- *     received row is caught up (lazy dense decay, if enabled on the group; hyper may be NULL otherwise) and
+ *     received row is caught up (lazy dense decay, if enabled on the group) and - hyper == NULL: no catch-up, the
+ *     rows are served as they are (inference after er_emb_flush_decay: no row update follows to advance last_step) -
  *     written to rows_out[i][entry * ld[i] + 0..dim) of every entry that asked for it (ld_host NULL or 0: dim) -
  *     er_emb_route + er_emb_catch_up + er_gather_rows of the sorted form. */
 int er_emb_owner_merge(er_emb_group* group, const int32_t* run_counts_host, int n_runs, er_stream_t stream);

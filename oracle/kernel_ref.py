@@ -565,7 +565,7 @@ class RefBackend(object):
       n = g['n_active'] if g.get('n_active', -1) >= 0 else g['num_entries']
       if n == 0:
         continue
-      if g.get('last_step') is not None:
+      if g.get('last_step') is not None and hyper is not None:  # (hyper None: inference, the rows were flushed)
         uk = torch.zeros(g['num_entries'], dtype=torch.int32)
         nu = torch.zeros(1, dtype=torch.int32)
         self.emb_route(g, uk, nu, None, None)

@@ -743,33 +743,70 @@ class OracleTrainer(object):
     return V, pred, losses
 
   def train_step(self, batch):
-    V, pred, losses = self.forward(batch)
-    losses['total_loss'].backward()
+    return self.train_step_world([batch])[0]
+
+  def train_step_world(self, batches):
+    """One optimisation step of W = len(batches) data-parallel workers with row-sharded embedding tables, the
+    reference's EmbeddingParallelStrategy (compat/optimizers.py:285-345): every worker runs forward / backward on ITS
+    batch (BatchNorm statistics per worker: the reference does not synchronise them), dense gradients are averaged
+    (hvd.allreduce(op=Average), :328-331), the row gradients of all workers meet at the rows' owners through the
+    all-to-all's backward, summed, and are divided by the world size (:315-316) - i.e. every gradient is the mean over
+    the workers - and ONE optimizer step is applied to the (logically single) set of variables.  Returns the list of
+    per-worker loss dicts.  W = 1 is plain single-GPU training."""
+    W = len(batches)
+    per_rank, losses_out, touched = [], [], {}
+    self.rank_moving = []
+    for batch in batches:
+      V, pred, losses = self.forward(batch)
+      losses['total_loss'].backward()
+      gr = OrderedDict()
+      for name, t in V.used.items():
+        if t.requires_grad:
+          gr[name] = np.zeros(t.shape, dtype=np.float32) if t.grad is None else t.grad.numpy().astype(np.float32)
+      per_rank.append(gr)
+      for name, t in V.used.items():
+        mask = self._touched.get(id(t))
+        if mask is not None:
+          touched[name] = mask if name not in touched else (touched[name] | mask)
+      self.rank_moving.append({k: val.numpy().astype(np.float32) for k, val in self._moving.items()})
+      losses_out.append({k: float(v.detach()) for k, v in losses.items()})
+      self.last_pred = {k: v.detach().numpy() for k, v in pred.items()}
+    names = list(per_rank[0].keys())
     step = self.global_step
-    # gradients after the multipliers (compat/optimizers.py:347-356), then clip_by_global_norm (:365-376, 453-481):
-    # norm = sqrt(2 * sum of tf.nn.l2_loss(g)); a table's IndexedSlices carry one row per distinct id of a lookup, so
-    # (one lookup per table) the dense gradient has the same sum of squares.  Tables shared by several lookups keep
-    # per-lookup rows in TF; the dense gradient merges them - configs with shared tables and clipping are not covered.
+    # gradients after the multipliers (compat/optimizers.py:347-356); mean over the workers
     grads = OrderedDict()
-    for name, t in V.used.items():
-      if not t.requires_grad:
-        continue
-      g = np.zeros(t.shape, dtype=np.float32) if t.grad is None else t.grad.numpy().astype(np.float32)
+    for name in names:
+      g = per_rank[0][name]
+      for r in range(1, W):
+        g = (g + per_rank[r][name]).astype(np.float32)
+      if W > 1:
+        g = (g * F32(1.0 / W)).astype(np.float32)
       if name.endswith('/embedding_weights') and self.emb_mult != 1.0:
         g = (g * F32(self.emb_mult)).astype(np.float32)
       grads[name] = g
+    self.last_grads = OrderedDict((n, g.copy()) for n, g in grads.items())
+    # clip_by_global_norm (:365-376, 453-481): norm = sqrt(2 * sum of tf.nn.l2_loss(g)); a table's IndexedSlices carry
+    # one row per distinct id of a lookup, so (one lookup per table) the dense gradient has the same sum of squares; with
+    # sharded tables the rows of different workers stay separate rows of `values` (each divided by W), their l2 sums are
+    # all-reduced.  Tables shared by several lookups keep per-lookup rows in TF; the dense gradient merges them -
+    # configs with shared tables AND clipping are not covered here.
     clip = float(self.cfg.train_config.gradient_clipping_by_norm)
     self.last_grad_norm = None
     if clip > 0:
-      half = [F32(0.5) * F32((g.astype(np.float64) ** 2).sum()) for g in grads.values()]
-      norm = F32(np.sqrt(F32(2.0) * F32(np.sum(np.asarray(half, dtype=np.float64)))))
+      sq = 0.0
+      for name in names:
+        if name.endswith('/embedding_weights') and W > 1:
+          for r in range(W):
+            gr = per_rank[r][name].astype(np.float64) * (self.emb_mult / W)
+            sq += float((gr ** 2).sum())
+        else:
+          sq += float((grads[name].astype(np.float64) ** 2).sum())
+      norm = F32(np.sqrt(sq))
       with np.errstate(divide='ignore'):
         scale = F32(clip) * min(F32(1.0) / norm, F32(1.0) / F32(clip))
       grads = OrderedDict((n, (g * scale).astype(np.float32)) for n, g in grads.items())
       self.last_grad_norm = float(norm)
-    for name, t in V.used.items():
-      if not t.requires_grad:
-        continue
+    for name in names:
       is_emb = name.endswith('/embedding_weights')
       oi = 0 if (is_emb or len(self.opt) == 1) else 1
       o = self.opt[oi]
@@ -788,7 +825,7 @@ class OracleTrainer(object):
           # python-graph sparse apply (IndexedSlices): tf AdamOptimizer decays every row;
           # AdamOptimizerS (lazy) only the rows present in the gradient.
           if o['kind'] == 'lazy_adam_optimizer':
-            rows = np.flatnonzero(self._touched.get(id(t), np.zeros(var.shape[0], dtype=bool)))
+            rows = np.flatnonzero(touched.get(name, np.zeros(var.shape[0], dtype=bool)))
             m_t = m[rows] * b1 + g[rows] * (one - b1)
             v_t = v[rows] * b2 + (g[rows] * g[rows]) * (one - b2)
             var[rows] = var[rows] - (lr_t * m_t) / (np.sqrt(v_t, dtype=np.float32) + eps)
@@ -811,10 +848,8 @@ class OracleTrainer(object):
       if o['kind'] in ('adam_optimizer', 'lazy_adam_optimizer'):
         self.beta_pow[oi][0] = F32(self.beta_pow[oi][0] * F32(o['beta1']))
         self.beta_pow[oi][1] = F32(self.beta_pow[oi][1] * F32(o['beta2']))
-    for k, val in self._moving.items():
-      self.state[k] = val.numpy().astype(np.float32)
+    # BatchNorm moving statistics live per worker; `state` follows worker 0 (rank_moving has all of them)
+    for k, val in self.rank_moving[0].items():
+      self.state[k] = val
     self.global_step += 1
-    self.last_pred = {k: v.detach().numpy() for k, v in pred.items()}
-    self.last_grads = {n: (None if t.grad is None else t.grad.numpy().copy()) for n, t in V.used.items()
-                       if t.requires_grad}
-    return {k: float(v.detach()) for k, v in losses.items()}
+    return losses_out

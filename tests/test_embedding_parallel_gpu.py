@@ -338,3 +338,30 @@ def test_fixed_capacity_route_and_owner_side_against_numpy(header):
   assert hip.emb_route_overflow(g)
   hip.emb_group_destroy(g)
   hip.emb_group_destroy(og)
+
+
+def test_lazy_decay_equals_sweep_through_two_sharded_ranks():
+  """The model-level lazy-dense-decay == sweep check of tests/test_deepfm_gpu.py through EmbeddingParallelEstimator,
+  W = 2 ranks as threads with their own batches: the owner side's er_emb_owner_serve catches rows up, the owner's
+  er_emb_bwd_update_multi stamps them, er_emb_flush_decay finishes - against the same two ranks streaming every row."""
+  from test_deepfm_gpu import _assert_lazy_equals_sweep, _idle_schedule
+  cfg = _cfg('deepfm_criteo_small.config')
+  B, world = 64, 2
+  feats = list(cfg.feature_config.features)
+  scheds = [_idle_schedule(cfg, feats, B, 1000)]
+  gen = SyntheticCriteo(cfg.data_config, feats, batch_size=B, seed=77)
+  scheds.append([gen.next_batch() for _ in range(len(scheds[0]))])  # rank 1: fresh batches throughout
+  states = {}
+  for sweep in (False, True):
+    sim = SimWorld(world)
+
+    def rank_fn(rank, comm):
+      torch.cuda.set_device(0)
+      est = EmbeddingParallelEstimator(cfg, device=DEV, batch_size=B, seed=4, rank=rank, world=world, comm=comm,
+                                       replicate_bytes=1024, dense_sweep=sweep).build()
+      for b in scheds[rank]:
+        est.train_step(b)
+      return est.state_dict(slots=True)
+
+    states[sweep] = sim.run(rank_fn)[0]
+  _assert_lazy_equals_sweep(states[False], states[True])
