@@ -44,7 +44,16 @@ def parse_args():
   ap.add_argument('--cpu_seconds', type=float, default=12.0, help='time budget of the CPU baseline sample')
   ap.add_argument('--rccl', action='store_true',
                   help='with --force_ep at 1 GPU: issue the collectives through a world-1 RCCL process group (not local copies)')
-  ap.add_argument('--ring', type=int, default=16, help='distinct pre-generated batches kept on device')
+  ap.add_argument('--ring', type=int, default=256, help='distinct device-generated batches the timed loop cycles over')
+  ap.add_argument('--precondition', type=int, default=1024,
+                  help='untimed steps over as many further distinct batches BEFORE the warm-up, so that the timed steps '
+                       'see tables in their steady state (rows with Adam history and realistic idle lengths) instead of '
+                       'freshly initialised ones, whose lazy dense decay is trivially cheap; 0 = skip')
+  ap.add_argument('--steady_steps', type=int, default=2048,
+                  help='N=1: after the timed region, this many further steps over as many DISTINCT device-generated '
+                       'batches (realistic idle lengths for the lazy dense decay); 0 = skip')
+  ap.add_argument('--parity_steps', type=int, default=2,
+                  help='N=1: steps of the full-size GPU-vs-oracle loss comparison (0 = skip; needs the CPU baseline)')
   return ap.parse_args()
 
 
@@ -198,14 +207,139 @@ def time_gemm_kernel(est, launches):
           'flops': 2.0 * M * N * K, 'launches': launches}
 
 
-def cpu_baseline(cfg, est_state, batches, batch_size, budget_s=12.0, max_steps=8):
+class DeviceCriteo(object):
+  """SyntheticCriteo's distribution (Zipf(1.05) ids over per-feature vocabularies, 8-hex-digit strings,
+  2 % empty, labels ~ Bernoulli(0.25), raw = u^3 scaled) generated ON THE DEVICE straight into the packed arena image
+  DeviceFeatures.load takes: thousands of distinct batches cost milliseconds instead of 20 ms of host time each."""
+
+  def __init__(self, host_gen, features, device, seed):
+    self.f, self.dev = features, device
+    self.B = host_gen.B
+    self.g = torch.Generator(device=device)
+    self.g.manual_seed(seed)
+    self.n_hash = host_gen.n_hash
+    self.mix = torch.from_numpy(host_gen.mix.astype(np.int64)).to(device)
+    self.mode, self.empty_frac = host_gen.mode, host_gen.empty_frac
+    self.cdf = {}
+    for V in sorted(set(host_gen.vocab)):
+      p = torch.arange(1, V + 1, dtype=torch.float64, device=device) ** (-1.05)
+      self.cdf[V] = torch.cumsum(p / p.sum(), 0)
+    self.vocab = list(host_gen.vocab)
+    self.raw_rows = [(host_gen.schema.raw[n]['row'], float(fc.min_val), float(fc.max_val)) for n, fc in host_gen.raw_cfg]
+    self.hex = torch.tensor(list(b'0123456789abcdef'), dtype=torch.uint8, device=device)
+    self.shifts = torch.arange(28, -4, -4, dtype=torch.int64, device=device)
+
+  def next_packed(self):
+    f, B, dev, g = self.f, self.B, self.dev, self.g
+    end = f._layout['str_bytes'][0] + f._layout['str_bytes'][1]
+    img = torch.zeros(end, dtype=torch.uint8, device=dev)
+
+    def section(name):
+      o, nbytes, shape, dt = f._layout[name]
+      return img[o:o + nbytes].view(dt).view(shape)
+
+    section('labels')[0] = (torch.rand(B, device=dev, generator=g) < 0.25).float()
+    raw = section('raw_block')
+    for row, lo, hi in self.raw_rows:
+      u = torch.rand(B, device=dev, generator=g, dtype=torch.float64)
+      x = (lo + (hi - lo) * u ** 3).float()
+      raw[row] = (x - lo) / (hi - lo) if hi > lo else x
+    vals = torch.empty(self.n_hash, B, dtype=torch.int64, device=dev)
+    for i in range(self.n_hash):
+      if self.mode == 'uniform':
+        vals[i] = torch.randint(0, 2 ** 32, (B,), device=dev, generator=g, dtype=torch.int64)
+      else:
+        r = torch.searchsorted(self.cdf[self.vocab[i]], torch.rand(B, device=dev, generator=g, dtype=torch.float64))
+        vals[i] = (r * self.mix[i]) & 0xFFFFFFFF
+    n = self.n_hash * B
+    nib = (vals.view(-1, 1) >> self.shifts.view(1, -1)) & 0xF
+    chars = self.hex[nib]  # [n, 8]
+    empty = torch.rand(n, device=dev, generator=g) < self.empty_frac
+    offs = section('str_offsets')
+    offs[1:] = torch.cumsum(torch.where(empty, 0, 8), 0)
+    body = chars[~empty].reshape(-1)
+    section('str_bytes')[:body.numel()] = body
+    return {'packed': img, 'packed_has_strings': True}
+
+
+def steady_state(est, gen, n_steps):
+  """n_steps further training steps over n_steps DISTINCT batches (a real epoch: most rows of a 1M-row table stay idle
+  for hundreds to thousands of steps, so the lazy dense decay's catch-up replays long histories), per-step wall time
+  from HIP events between graph replays, the catch-up launches alone over an eager tail, and one er_emb_flush_decay
+  (what a checkpoint / evaluation owes)."""
+  t0 = time.perf_counter()
+  batches = [gen.next_packed() for _ in range(n_steps)]
+  torch.cuda.synchronize()
+  gen_s = time.perf_counter() - t0
+  evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_steps + 1)]
+  evs[0].record()
+  for i, b in enumerate(batches):
+    est.train_step(b)
+    evs[i + 1].record()
+  torch.cuda.synchronize()
+  ms = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(n_steps)])
+  out = {'steps': n_steps, 'distinct_batches': n_steps, 'batch_generation_s': gen_s,
+         'ms_per_step_mean': float(ms.mean()), 'ms_per_step_p50': float(np.percentile(ms, 50)),
+         'ms_per_step_p99': float(np.percentile(ms, 99)), 'ms_per_step_last_256_mean': float(ms[-256:].mean()),
+         'examples_per_s': float(est.batch_size / (ms.mean() * 1e-3))}
+  eng = est.engine
+  if getattr(eng, 'lazy_decay', False):
+    # the catch-up launches alone: eager forward passes over a tail of further distinct batches
+    tail = [gen.next_packed() for _ in range(64)]
+    cu = []
+    saved_graph, est.graph = est.graph, None
+    try:
+      for b in tail:
+        probe = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        eng.catch_up_probe = probe
+        est.train_step(b)
+        torch.cuda.synchronize()
+        cu.append(probe[0].elapsed_time(probe[1]))
+    finally:
+      eng.catch_up_probe = None
+      est.graph = saved_graph
+    out['catch_up_ms_p50'] = float(np.percentile(cu, 50))
+    out['catch_up_ms_p99'] = float(np.percentile(cu, 99))
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    eng.flush_decay()
+    b.record()
+    torch.cuda.synchronize()
+    out['flush_decay_ms'] = float(a.elapsed_time(b))
+    out['flush_decay_note'] = 'one er_emb_flush_decay over every table group: owed once per checkpoint / evaluation'
+  return out
+
+
+def parity_full_size(cfg, est, ring, host_batches, batch_size, n_steps):
+  """The GPU path and the CPU oracle from the SAME full-size training state (weights, Adam slots, step), the same
+  batches: relative loss differences over n_steps steps (north_star: 1e-4)."""
+  from oracle.model_oracle import OracleTrainer
+  state = est.state_dict(slots=True)
+  weights = {k: v for k, v in state.items() if not (k.endswith('/m') or k.endswith('/v'))}
+  orc = OracleTrainer(cfg, weights, batch_size=batch_size)
+  orc.resume(est.global_step, {k: v for k, v in state.items() if k.endswith('/m') or k.endswith('/v')})
+  del state, weights
+  worst, per_step = 0.0, []
+  for k in range(n_steps):
+    est.train_step(ring[k % len(ring)])
+    got = est.loss_values()
+    exp = orc.train_step(host_batches[k % len(host_batches)])
+    d = max(abs(got[n] - exp[n]) / max(abs(exp[n]), 1e-3) for n in exp)
+    per_step.append({'gpu_total_loss': got['total_loss'], 'oracle_total_loss': exp['total_loss'], 'max_rel_diff': d})
+    worst = max(worst, d)
+  return {'max_rel_loss_diff': worst, 'steps': n_steps, 'tolerance': 1e-4, 'ok': bool(worst <= 1e-4),
+          'per_step': per_step, 'from_global_step': int(est.global_step - n_steps)}, orc
+
+
+def cpu_baseline(cfg, est_state, batches, batch_size, budget_s=12.0, max_steps=8, orc=None):
   """The CPU restatement of the reference path (oracle/model_oracle.py) on the host cores: a bounded
   sample (about `budget_s` seconds) of the same workload."""
   from oracle.model_oracle import OracleTrainer
   threads = min(os.cpu_count() or 1, 64)
   torch.set_num_threads(threads)
-  orc = OracleTrainer(cfg, est_state, batch_size=batch_size)
-  orc.train_step(batches[0])  # warm-up (first-touch of the optimizer slots)
+  if orc is None:
+    orc = OracleTrainer(cfg, est_state, batch_size=batch_size)
+    orc.train_step(batches[0])  # warm-up (first-touch of the optimizer slots)
   t0 = time.perf_counter()
   steps = 0
   while steps < max_steps and (steps == 0 or time.perf_counter() - t0 < budget_s):
@@ -249,10 +383,14 @@ def main():
     est = EasyRecEstimator(cfg, device=dev, batch_size=B, seed=1, overlap_sweep=args.overlap,
                            dense_sweep=args.dense_sweep).build()
   gen = SyntheticCriteo(cfg.data_config, est.feature_configs, batch_size=B, seed=20240607 + rank, mode=args.ids)
-  host_batches = [gen.next_batch() for _ in range(args.ring)]
-  # resident batches in the packed layout of the input arena: loading one is a single device-to-device copy
-  ring = [{k: (torch.from_numpy(np.ascontiguousarray(v)).to(dev) if isinstance(v, np.ndarray) else v)
-           for k, v in est.features.pack(b, device=dev).items()} for b in host_batches]
+  # a few host batches (the CPU baseline and the full-size parity check need the same batch on both sides) ...
+  host_batches = [gen.next_batch() for _ in range(4)]
+  host_ring = [{k: (torch.from_numpy(np.ascontiguousarray(v)).to(dev) if isinstance(v, np.ndarray) else v)
+                for k, v in est.features.pack(b, device=dev).items()} for b in host_batches]
+  # ... and the timed loop's batches: the same distribution generated on the device, resident in the packed layout of
+  # the input arena (loading one is a single device-to-device copy)
+  dgen = DeviceCriteo(gen, est.features, dev, seed=977 + rank)
+  ring = [dgen.next_packed() for _ in range(max(args.ring, 1))]
   est.features.load(ring[0])
   torch.cuda.synchronize()
   ep = world > 1 or args.force_ep
@@ -274,6 +412,8 @@ def main():
       dist.barrier()
     torch.cuda.synchronize()
 
+  for _ in range(args.precondition):  # untimed: bring the tables into their steady state (see --precondition)
+    est.train_step(dgen.next_packed())
   for i in range(args.warmup):
     est.train_step(ring[i % len(ring)])
   barrier()
@@ -313,7 +453,8 @@ def main():
                       (os.path.basename(args.config), cfg.feature_config.features[13].hash_bucket_size, B,
                        est.opt_emb.name + (' (dense sweep)' if getattr(est, 'dense_sweep', False) and est.opt_emb.name == 'adam_optimizer'
                                            else ' (lazy dense decay, bit-identical)' if est.opt_emb.name == 'adam_optimizer' else ''),
-                       args.ids, graph_note),
+                       args.ids, graph_note) + '; timed steps cycle over %d distinct device-generated batches after %d '
+                      'untimed pre-conditioning steps over further distinct batches' % (len(ring), args.precondition),
           'global_batch': world * B,
           'parallelism': ('embedding-parallel x%d (row-sharded tables, RCCL all-to-all) + dense DP' % world if world > 1 else
                           'single GPU' if not ep else 'single GPU through the embedding-parallel code path (%s)' %
@@ -323,7 +464,7 @@ def main():
       'device': kernels.hip().device_info(),
   }
   if world == 1 and not ep:
-    lazy_bytes, sweep_bytes = embedding_bytes_per_step(est, ring)
+    lazy_bytes, sweep_bytes = embedding_bytes_per_step(est, host_ring)
     out['embedding_stage'] = {
         'algorithmic_bytes_per_step': lazy_bytes + sweep_bytes,
         'lookup_update_bytes_per_step': lazy_bytes,
@@ -365,10 +506,24 @@ def main():
       out['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
                          'traffic': traffic, 'kernel': dom['kernel'], 'avg_kernel_ms': dom['avg_ms'],
                          'algorithmic_flops_per_launch': dom['flops'], 'launches_timed': dom['launches']}
+    if args.steady_steps > 0 and not args.no_graph:
+      try:
+        out['steady_state'] = steady_state(est, dgen, args.steady_steps)
+      except Exception as e:  # noqa: BLE001
+        out['steady_state'] = {'error': str(e)[:300]}
     if not args.no_cpu_baseline:
+      orc = None
+      torch.set_num_threads(min(os.cpu_count() or 1, 64))
+      if args.parity_steps > 0:
+        try:
+          # the oracle continues from the device's state: its steps double as the CPU baseline's warm-up
+          out['parity_full_size'], orc = parity_full_size(cfg, est, host_ring, host_batches, B, args.parity_steps)
+        except Exception as e:  # noqa: BLE001
+          out['parity_full_size'] = {'error': str(e)[:300]}
       try:
         # fresh state for the CPU run = the device state now (any state is as good for timing)
-        out['cpu_baseline'] = cpu_baseline(cfg, est.state_dict(), host_batches, B, args.cpu_seconds)
+        out['cpu_baseline'] = cpu_baseline(cfg, None if orc is not None else est.state_dict(), host_batches, B,
+                                           args.cpu_seconds, orc=orc)
       except Exception as e:  # noqa: BLE001
         out['cpu_baseline'] = {'value': None, 'unit': 'examples/s', 'cores': 0, 'kind': 'port',
                                'sample': 'failed: %s' % str(e)[:200]}

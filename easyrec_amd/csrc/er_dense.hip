@@ -575,7 +575,14 @@ __global__ void hyper_select_kernel(const float* __restrict__ table, int64_t* __
   __syncthreads();
   if (threadIdx.x == 0) {
     // per-step history of one scalar (Adam's lr_t): the lazy dense-decay catch-up replays past steps from it
-    if (hist && c < hist_capacity) hist[c] = table[slot * floats_per_slot + hist_index];
+    // hist holds 2 * hist_capacity floats: [value per step | running maximum of the values up to that step] (the
+    // absorbed regime of the replay bounds every later update with the largest lr_t so far)
+    if (hist && c < hist_capacity) {
+      const float val = table[slot * floats_per_slot + hist_index];
+      hist[c] = val;
+      const float before = c > 0 ? hist[hist_capacity + c - 1] : 0.f;
+      hist[hist_capacity + c] = val > before ? val : before;
+    }
     *counter = c + 1;
   }
 }

@@ -371,12 +371,27 @@ __device__ __forceinline__ void update_row(const RowUpdate& t, int opt_kind, con
 // ------------------------------------------------------------------------------------------------
 template <int V>
 __device__ __forceinline__ void replay_decay(float* var, float* m, float* v, const float* __restrict__ lr_hist,
-                                             int32_t s_begin, int32_t s_end, const er_opt_hyper& h) {
-  // steps s_begin .. s_end - 1 were decay-only for this row
-  for (int32_t s = s_begin; s < s_end; ++s) {
-    // m never reaches 0 in fp32: below 5 denormal units fl(m * 0.9) == m (3.6 -> 4, 2.7 -> 3, 1.8 -> 2, 0.9 -> 1), it
-    // sticks at |m| <= 5.6e-45 after ~900 idle steps.  From then on m is constant and the var update
-    // lr_t * m / (sqrt(v) + eps) <= |m| / eps (lr_t <= 1) is absorbed by var: nothing but v changes any more.
+                                             int32_t s_begin, int32_t s_end, const er_opt_hyper& h,
+                                             const float* __restrict__ lr_max_hist = nullptr) {
+  // steps s_begin .. s_end - 1 were decay-only for this row.  Three regimes, the first two bit-identical to the
+  // step-by-step sweep:
+  //  (1) full step: m *= b1; v *= b2; var -= lr_t(s) * m / (sqrt(v) + eps)                  (~20 instructions/element)
+  //  (2) ABSORBED: the update has fallen below a quarter ulp of var and can only shrink from here, so var no longer
+  //      changes and only the two decays remain (2 multiplications/element/step).  Why it can only shrink: in exact
+  //      arithmetic q(s) = lr_t(s) |m_s| / (sqrt(v_s) + eps) obeys q(s+1) / q(s) <= (lr_t(s+1) / lr_t(s)) * b1 / sqrt(b2)
+  //      (+ rounding of 2^-23 per step); with L = max lr_t over the whole history so far (lr_max_hist, written next to
+  //      lr_hist by er_hyper_select) every later update is <= (L / lr_t(s)) * q(s) as long as b1 < sqrt(b2).  The
+  //      test below is on the COMPUTED update with a 2x margin: |upd| * L / lr_t(s) * 2 < |var| * 2^-25 <= ulp(var) / 2
+  //      ... conservatively a quarter ulp, which also covers var at a power of two (half-sized ulp below).
+  //      Typically reached ~150 steps after a row's last touch (0.9^150 = 1e-7).
+  //  (3) settled (the documented deviation): fp32 m never reaches 0 under m *= b1 - below 5 denormal units
+  //      fl(m * 0.9) == m - so ~900 steps after the touch m is constant, and the remaining decay of v is applied in
+  //      closed form v *= b2^k (<= 1e-6 relative on v of rows idle that long).
+  const bool can_absorb = lr_max_hist != nullptr && h.beta1 < 0.999f * sqrtf(h.beta2) && s_end > s_begin;
+  const float lr_cap = can_absorb ? lr_max_hist[s_end - 1] : 0.f;
+  int32_t s = s_begin;
+  bool absorbed = false;
+  for (; s < s_end && !absorbed; ++s) {
     bool settled = true;
 #pragma unroll
     for (int i = 0; i < V; ++i) {
@@ -390,13 +405,36 @@ __device__ __forceinline__ void replay_decay(float* var, float* m, float* v, con
       return;
     }
     const float lr_t = lr_hist[s];
+    const float amp = can_absorb ? 2.0f * (lr_cap / lr_t) : 0.f;  // (lr_t > 0: the schedules have a positive floor)
+    bool all_small = can_absorb;
 #pragma unroll
     for (int i = 0; i < V; ++i) {
       const float mt = m[i] * h.beta1;
       const float vt = v[i] * h.beta2;
+      const float upd = (lr_t * mt) / (sqrtf(vt) + h.eps);
       m[i] = mt;
       v[i] = vt;
-      var[i] = var[i] - (lr_t * mt) / (sqrtf(vt) + h.eps);
+      var[i] = var[i] - upd;
+      all_small = all_small && (fabsf(upd) * amp < fabsf(var[i]) * 1.4901161193847656e-08f);  // 2^-26 |var|
+    }
+    absorbed = all_small;
+  }
+  // (2) var is fixed from here on (every lane element absorbed; lanes of a row decide independently - each owns its
+  // elements).  m and v keep their step-by-step rounding.
+  for (; s < s_end; ++s) {
+    bool m_fixed = true;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      const float mt = m[i] * h.beta1;
+      m_fixed = m_fixed && (mt == m[i]);
+      m[i] = mt;
+      v[i] = v[i] * h.beta2;
+    }
+    if (m_fixed && s + 1 < s_end) {  // m sits on its fixed point: only v is left, in closed form (regime 3)
+      const double f = pow(static_cast<double>(h.beta2), static_cast<double>(s_end - s - 1));
+#pragma unroll
+      for (int i = 0; i < V; ++i) v[i] = static_cast<float>(static_cast<double>(v[i]) * f);
+      return;
     }
   }
 }
@@ -407,7 +445,7 @@ template <int V>
 __device__ __forceinline__ void catch_up_body(int bid, const uint32_t* __restrict__ ukeys,
                                               const int32_t* __restrict__ n_unique, int64_t capacity, const RowUpdate& tab,
                                               const float* __restrict__ lr_hist, const er_opt_hyper* __restrict__ hyper,
-                                              int dim, int G) {
+                                              int dim, int G, const float* __restrict__ lr_max = nullptr) {
   const int64_t i = (static_cast<int64_t>(bid) * kBlock + threadIdx.x) / G;
   const int c = (static_cast<int>(threadIdx.x) % G) * V;
   if (i >= capacity || i >= *n_unique || c >= dim) return;
@@ -424,7 +462,7 @@ __device__ __forceinline__ void catch_up_body(int bid, const uint32_t* __restric
 #pragma unroll
   for (int j = 0; j < V; ++j) live = live || (m[j] != 0.f) || (v[j] != 0.f);
   if (!live) return;  // never touched: m = v = 0 is a fixed point of the decay
-  replay_decay<V>(var, m, v, lr_hist, last + 1, t, *hyper);
+  replay_decay<V>(var, m, v, lr_hist, last + 1, t, *hyper, lr_max);
   st_vec<V>(tab.var + off, var);
   st_vec<V>(tab.m + off, m);
   st_vec<V>(tab.v + off, v);
@@ -435,8 +473,8 @@ template <int V>
 __global__ void __launch_bounds__(kBlock)
 emb_catch_up_kernel(const uint32_t* __restrict__ ukeys, const int32_t* __restrict__ n_unique, int64_t capacity,
                     RowUpdate tab, const float* __restrict__ lr_hist, const er_opt_hyper* __restrict__ hyper, int dim,
-                    int G) {
-  catch_up_body<V>(blockIdx.x, ukeys, n_unique, capacity, tab, lr_hist, hyper, dim, G);
+                    int G, const float* __restrict__ lr_max) {
+  catch_up_body<V>(blockIdx.x, ukeys, n_unique, capacity, tab, lr_hist, hyper, dim, G, lr_max);
 }
 
 // Horizontal fusion: the same per-group work of up to kMaxMulti table groups in ONE grid - workgroups
@@ -451,6 +489,7 @@ struct CatchUpArgs {
   int64_t capacity;
   RowUpdate tab;
   const float* lr_hist;
+  const float* lr_max;
   int dim, G, V;
 };
 struct CatchUpMulti {
@@ -466,15 +505,15 @@ emb_catch_up_multi_kernel(CatchUpMulti ma) {
   while (i + 1 < ma.n && static_cast<int>(blockIdx.x) >= ma.start[i + 1]) ++i;
   const CatchUpArgs& a = ma.a[i];
   const int bid = blockIdx.x - ma.start[i];
-  if (a.V == 4) catch_up_body<4>(bid, a.ukeys, a.n_unique, a.capacity, a.tab, a.lr_hist, ma.hyper, a.dim, a.G);
-  else catch_up_body<1>(bid, a.ukeys, a.n_unique, a.capacity, a.tab, a.lr_hist, ma.hyper, a.dim, a.G);
+  if (a.V == 4) catch_up_body<4>(bid, a.ukeys, a.n_unique, a.capacity, a.tab, a.lr_hist, ma.hyper, a.dim, a.G, a.lr_max);
+  else catch_up_body<1>(bid, a.ukeys, a.n_unique, a.capacity, a.tab, a.lr_hist, ma.hyper, a.dim, a.G, a.lr_max);
 }
 
 // every row: replay the pending decay steps up to and including step (*step_counter - 1); last_step = that
 template <int V>
 __global__ void __launch_bounds__(kBlock)
 emb_flush_decay_kernel(RowUpdate tab, int64_t total_rows, const float* __restrict__ lr_hist,
-                       const er_opt_hyper* __restrict__ hyper, int dim, int G) {
+                       const er_opt_hyper* __restrict__ hyper, int dim, int G, const float* __restrict__ lr_max) {
   const int64_t row = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) / G;
   const int sub = static_cast<int>(threadIdx.x) % G;
   const int c = sub * V;
@@ -491,12 +530,75 @@ emb_flush_decay_kernel(RowUpdate tab, int64_t total_rows, const float* __restric
 #pragma unroll
     for (int j = 0; j < V; ++j) live = live || (m[j] != 0.f) || (v[j] != 0.f);
     if (live) {
-      replay_decay<V>(var, m, v, lr_hist, last + 1, done, *hyper);
+      replay_decay<V>(var, m, v, lr_hist, last + 1, done, *hyper, lr_max);
       st_vec<V>(tab.var + off, var);
       st_vec<V>(tab.m + off, m);
       st_vec<V>(tab.v + off, v);
     }
   }
+}
+
+// ROLLING flush (er_emb_flush_window): step t brings the rows of window (t mod n_windows) - rows
+// [w * chunk, (w + 1) * chunk) - current.  Every row is visited once per n_windows steps, so no row is ever more
+// than n_windows steps behind: the catch-up of a touched row replays at most that many steps (instead of the
+// thousands a cold row of a 1 M-row table accumulates in a real epoch), at a cost of one pass over 1 / n_windows of
+// the tables per step (10.6 GB / 256 = 41 MB for DeepFM-Criteo).  Same arithmetic as the full flush -> still
+// bit-identical to the every-row sweep.  The G lanes of a row sit in one wavefront: all of them have read last_step
+// (one instruction) before lane 0 stores it.
+template <int V>
+__device__ __forceinline__ void flush_window_body(int bid, const RowUpdate& tab, int64_t total_rows, int64_t chunk,
+                                                  int n_windows, const float* __restrict__ lr_hist,
+                                                  const float* __restrict__ lr_max,
+                                                  const er_opt_hyper* __restrict__ hyper, int dim, int G) {
+  const int32_t done = static_cast<int32_t>(*tab.step_counter);
+  const int64_t w = static_cast<int64_t>(done) % n_windows;
+  const int64_t row = w * chunk + (static_cast<int64_t>(bid) * kBlock + threadIdx.x) / G;
+  const int sub = static_cast<int>(threadIdx.x) % G;
+  const int c = sub * V;
+  const int64_t end = (w + 1) * chunk < total_rows ? (w + 1) * chunk : total_rows;
+  if (row >= end || c >= dim) return;
+  const int32_t last = tab.last_step[row];
+  if (last + 1 >= done) return;
+  const int64_t off = row * dim + c;
+  float m[V], v[V];
+  ld_vec<V>(m, tab.m + off);
+  ld_vec<V>(v, tab.v + off);
+  bool live = false;
+#pragma unroll
+  for (int j = 0; j < V; ++j) live = live || (m[j] != 0.f) || (v[j] != 0.f);
+  if (live) {  // (a lane whose elements never moved skips; m = v = 0 is a fixed point of the decay)
+    float var[V];
+    ld_vec<V>(var, tab.var + off);
+    replay_decay<V>(var, m, v, lr_hist, last + 1, done, *hyper, lr_max);
+    st_vec<V>(tab.var + off, var);
+    st_vec<V>(tab.m + off, m);
+    st_vec<V>(tab.v + off, v);
+  }
+  if (sub == 0) tab.last_step[row] = done - 1;
+}
+
+struct FlushWindowArgs {
+  RowUpdate tab;
+  int64_t total_rows, chunk;
+  const float* lr_hist;
+  const float* lr_max;
+  int dim, G, V;
+};
+struct FlushWindowMulti {
+  int n, n_windows;
+  int start[4 + 1];
+  const er_opt_hyper* hyper;
+  FlushWindowArgs a[4];
+};
+
+__global__ void __launch_bounds__(kBlock)
+emb_flush_window_kernel(FlushWindowMulti ma) {
+  int i = 0;
+  while (i + 1 < ma.n && static_cast<int>(blockIdx.x) >= ma.start[i + 1]) ++i;
+  const FlushWindowArgs& a = ma.a[i];
+  const int bid = blockIdx.x - ma.start[i];
+  if (a.V == 4) flush_window_body<4>(bid, a.tab, a.total_rows, a.chunk, ma.n_windows, a.lr_hist, a.lr_max, ma.hyper, a.dim, a.G);
+  else flush_window_body<1>(bid, a.tab, a.total_rows, a.chunk, ma.n_windows, a.lr_hist, a.lr_max, ma.hyper, a.dim, a.G);
 }
 
 // second pass of the flush (all lanes of a row must have read last_step before it changes)
@@ -1309,6 +1411,7 @@ struct ServeArgs {
   int64_t n;
   RowUpdate tab;         // last_step == nullptr: no catch-up
   const float* lr_hist;
+  const float* lr_max;
   float* out;            // [n, ld] reply rows in entry order (ld >= dim: several groups' rows side by side)
   int dim, G, V, ld;
 };
@@ -1340,7 +1443,7 @@ __device__ __forceinline__ void serve_body(int bid, const ServeArgs& a, const er
 #pragma unroll
       for (int j = 0; j < V; ++j) live = live || (m[j] != 0.f) || (v[j] != 0.f);
       if (live) {
-        replay_decay<V>(var, m, v, a.lr_hist, last + 1, t, *hyper);
+        replay_decay<V>(var, m, v, a.lr_hist, last + 1, t, *hyper, a.lr_max);
         st_vec<V>(a.tab.var + off, var);
         st_vec<V>(a.tab.m + off, m);
         st_vec<V>(a.tab.v + off, v);
@@ -1625,6 +1728,7 @@ struct er_emb_group {
   // lazy dense decay (er_emb_group_enable_lazy_decay)
   int32_t* last_step = nullptr;
   const float* lr_hist = nullptr;
+  const float* lr_max = nullptr;  // prefix maximum of lr_hist (er_emb_group_set_lr_max): enables the absorbed regime
   const int64_t* step_counter = nullptr;
   int32_t world = 1;
   int64_t shard_stride = 0;
@@ -2205,10 +2309,10 @@ int er_emb_catch_up(er_emb_group* g, const uint32_t* unique_keys, const int32_t*
   const int blocks = static_cast<int>(er::ceil_div(cap * g->G, er::kBlock));
   if (g->V == 4) {
     hipLaunchKernelGGL(er::emb_catch_up_kernel<4>, dim3(blocks), dim3(er::kBlock), 0, er::as_stream(stream), unique_keys,
-                       n_unique, cap, tab, g->lr_hist, hyper, g->dim, g->G);
+                       n_unique, cap, tab, g->lr_hist, hyper, g->dim, g->G, g->lr_max);
   } else {
     hipLaunchKernelGGL(er::emb_catch_up_kernel<1>, dim3(blocks), dim3(er::kBlock), 0, er::as_stream(stream), unique_keys,
-                       n_unique, cap, tab, g->lr_hist, hyper, g->dim, g->G);
+                       n_unique, cap, tab, g->lr_hist, hyper, g->dim, g->G, g->lr_max);
   }
   ER_LAUNCH_CHECK();
   return 0;
@@ -2232,7 +2336,7 @@ int er_emb_catch_up_multi(er_emb_group* const* groups, const uint32_t* const* un
     er::CatchUpArgs& a = ma.a[ma.n];
     a.ukeys = unique_keys[i]; a.n_unique = n_unique[i]; a.capacity = cap;
     a.tab = er::RowUpdate{g->var, g->m, g->v, g->bitmap, g->last_step, g->step_counter};
-    a.lr_hist = g->lr_hist; a.dim = g->dim; a.G = g->G; a.V = g->V;
+    a.lr_hist = g->lr_hist; a.lr_max = g->lr_max; a.dim = g->dim; a.G = g->G; a.V = g->V;
     ma.start[ma.n + 1] = ma.start[ma.n] + static_cast<int>(er::ceil_div(cap * g->G, er::kBlock));
     ++ma.n;
   }
@@ -2251,14 +2355,46 @@ int er_emb_flush_decay(er_emb_group* g, const er_opt_hyper* hyper, er_stream_t s
   ER_REQUIRE(blocks < 0x7FFFFFFFLL, "er_emb_flush_decay: table group too large for one launch");
   if (g->V == 4) {
     hipLaunchKernelGGL(er::emb_flush_decay_kernel<4>, dim3(static_cast<unsigned>(blocks)), dim3(er::kBlock), 0, s, tab,
-                       g->total_rows, g->lr_hist, hyper, g->dim, g->G);
+                       g->total_rows, g->lr_hist, hyper, g->dim, g->G, g->lr_max);
   } else {
     hipLaunchKernelGGL(er::emb_flush_decay_kernel<1>, dim3(static_cast<unsigned>(blocks)), dim3(er::kBlock), 0, s, tab,
-                       g->total_rows, g->lr_hist, hyper, g->dim, g->G);
+                       g->total_rows, g->lr_hist, hyper, g->dim, g->G, g->lr_max);
   }
   ER_LAUNCH_CHECK();
   hipLaunchKernelGGL(er::emb_flush_mark_kernel, dim3(1024), dim3(er::kBlock), 0, s, g->last_step, g->total_rows,
                      g->step_counter);
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
+int er_emb_group_set_lr_max(er_emb_group* g, const float* lr_max_history) {
+  ER_REQUIRE(g, "er_emb_group_set_lr_max: null group");
+  g->lr_max = lr_max_history;
+  return 0;
+}
+
+int er_emb_flush_window(er_emb_group* const* groups, int n, int32_t n_windows, const er_opt_hyper* hyper,
+                        er_stream_t stream) {
+  ER_REQUIRE(groups && hyper && n >= 1 && n <= er::kMaxMulti && n_windows >= 1,
+             "er_emb_flush_window: bad arguments (1 <= n <= %d, n_windows >= 1)", er::kMaxMulti);
+  er::FlushWindowMulti ma;
+  ma.n = 0;
+  ma.n_windows = n_windows;
+  ma.start[0] = 0;
+  ma.hyper = hyper;
+  for (int i = 0; i < n; ++i) {
+    er_emb_group* g = groups[i];
+    ER_REQUIRE(g && g->last_step, "er_emb_flush_window: call er_emb_group_enable_lazy_decay first (group %d)", i);
+    ER_REQUIRE(g->G <= er::kWave, "er_emb_flush_window: a row must fit one wavefront");
+    er::FlushWindowArgs& a = ma.a[ma.n];
+    a.tab = er::RowUpdate{g->var, g->m, g->v, g->bitmap, g->last_step, g->step_counter};
+    a.total_rows = g->total_rows;
+    a.chunk = er::ceil_div(g->total_rows, n_windows);
+    a.lr_hist = g->lr_hist; a.lr_max = g->lr_max; a.dim = g->dim; a.G = g->G; a.V = g->V;
+    ma.start[ma.n + 1] = ma.start[ma.n] + static_cast<int>(er::ceil_div(a.chunk * g->G, er::kBlock));
+    ++ma.n;
+  }
+  hipLaunchKernelGGL(er::emb_flush_window_kernel, dim3(ma.start[ma.n]), dim3(er::kBlock), 0, er::as_stream(stream), ma);
   ER_LAUNCH_CHECK();
   return 0;
 }
@@ -2618,7 +2754,7 @@ int er_emb_owner_serve(er_emb_group* const* groups, float* const* rows_out, cons
     // hyper == NULL: serve the rows as they are (inference after er_emb_flush_decay: nothing is pending and nothing
     // may be replayed, because no row update follows that would advance last_step)
     a.tab = er::RowUpdate{g->var, g->m, g->v, g->bitmap, hyper ? g->last_step : nullptr, g->step_counter};
-    a.lr_hist = g->lr_hist; a.out = rows_out[i]; a.dim = g->dim; a.G = g->G; a.V = g->V;
+    a.lr_hist = g->lr_hist; a.lr_max = g->lr_max; a.out = rows_out[i]; a.dim = g->dim; a.G = g->G; a.V = g->V;
     a.ld = ld && ld[i] ? ld[i] : g->dim;
     ER_REQUIRE(a.ld >= g->dim && (g->V == 1 || (a.ld % 4 == 0 && (reinterpret_cast<uintptr_t>(rows_out[i]) & 15) == 0)),
                "er_emb_owner_serve: group %d: ld %d < dim, or 16-byte lanes on rows that are not 16-byte aligned", i, a.ld);

@@ -919,18 +919,30 @@ class HipBackend(object):
     return dexperts, dlogits
 
   def hyper_select(self, table, counter, out, history=None, history_index=HYPER_LR_T):
+    """history: fp32 [2 * capacity]: value of step s at [s], the running maximum of the values at [capacity + s]."""
     n_slots = table.shape[0]
-    cap = 0 if history is None else history.numel()
+    cap = 0 if history is None else history.numel() // 2
     self._ck(self.lib.er_hyper_select(_p(table), _p(counter), n_slots, table[0].numel(), _p(out), _p(history),
                                       ctypes.c_int64(cap), ctypes.c_int32(history_index), _stream()),
              'er_hyper_select')
 
   # -- TF-exact Adam without the sweep (lazy dense decay)
   def emb_group_enable_lazy_decay(self, group, last_step, lr_hist, step_counter):
+    """lr_hist: the [2 * capacity] history buffer of hyper_select (values | running maxima)."""
     assert last_step.dtype == torch.int32 and lr_hist.dtype == torch.float32 and step_counter.dtype == torch.int64
     self._ck(self.lib.er_emb_group_enable_lazy_decay(group['handle'], _p(last_step), _p(lr_hist), _p(step_counter)),
              'er_emb_group_enable_lazy_decay')
+    cap = lr_hist.numel() // 2
+    if os.environ.get('EASYREC_AMD_ABSORB', '1') != '0':  # A/B switch: the absorbed regime of the replay
+      self._ck(self.lib.er_emb_group_set_lr_max(group['handle'], _p(lr_hist[cap:])), 'er_emb_group_set_lr_max')
     group['last_step'], group['lr_hist'], group['step_counter'] = last_step, lr_hist, step_counter
+
+  def emb_flush_window(self, groups, n_windows, hyper):
+    """Rolling flush: this step's window (step mod n_windows) of up to 4 table groups, one launch."""
+    n = len(groups)
+    gh = (ctypes.c_void_p * n)(*[g['handle'] for g in groups])
+    self._ck(self.lib.er_emb_flush_window(gh, n, ctypes.c_int32(int(n_windows)), _p(hyper), _stream()),
+             'er_emb_flush_window')
 
   def emb_catch_up(self, group, unique_keys, n_unique, hyper):
     self._ck(self.lib.er_emb_catch_up(group['handle'], _p(unique_keys), _p(n_unique), _p(hyper), _stream()),

@@ -285,6 +285,19 @@ class Backbone(object):
       params.l2_regularizer = l2_reg
       self._top_mlp = MLP(params, name='backbone_top_mlp')
 
+  @classmethod
+  def wide_embed_dim(cls, config):
+    """The `wide_output_dim` the backbone's input-layer blocks declare (None when none does; they must agree):
+    reference layers/backbone.py:512-530."""
+    found = None
+    for blocks in [pkg.blocks for pkg in config.packages] + [config.blocks]:
+      for block in blocks:
+        if block.WhichOneof('layer') == 'input_layer' and block.input_layer.HasField('wide_output_dim'):
+          dim = block.input_layer.wide_output_dim
+          assert not found or found == dim, 'wide_output_dim must be consistent'
+          found = found or dim
+    return found
+
   def __call__(self, is_training, **kwargs):
     output = self._main_pkg(is_training, **kwargs)
     if self._top_mlp is not None:

@@ -116,6 +116,9 @@ class EmbeddingEngine(object):
     # inference lookups (predict / evaluate) must read current rows WITHOUT replaying anything twice
     self._decay_pending = False
     self.inference = False
+    # rolling flush: every step one window of every table group is brought current, so no row is ever more than
+    # this many steps behind (er_emb_flush_window); 0 = off (rows wait for their next touch or a full flush)
+    self.flush_windows = int(os.environ.get('EASYREC_AMD_FLUSH_WINDOWS', '256'))
     self._sort_leader = {}  # dim -> dim of the group whose per-step sort it reuses
 
   # -- declaration (build pass)
@@ -346,8 +349,13 @@ class EmbeddingEngine(object):
         uks.append(lz['ukeys'])
         nus.append(lz['n_unique'])
       step = 4 if os.environ.get('EASYREC_AMD_MULTI', '1') != '0' else 1  # A/B switch
+      probe = getattr(self, 'catch_up_probe', None)  # bench.py: (start event, end event) around the catch-up launches
+      if probe is not None:
+        probe[0].record()
       for i in range(0, len(grps), step):  # the table groups' catch-up kernels side by side in one launch
         be.emb_catch_up_multi(grps[i:i + step], uks[i:i + step], nus[i:i + step], self._clock[2])
+      if probe is not None:
+        probe[1].record()
     if self.plan is not None:
       be.emb_fwd(self.plan, self.sumsq if self.reg_lambda > 0 else None)
     self._ran_version = version
@@ -418,7 +426,16 @@ class EmbeddingEngine(object):
     for i in range(0, len(grps), step):  # one tile launch + one fix launch for (up to 4) table groups
       be.emb_bwd_update_multi(grps[i:i + step], opt_kind, hyper)
     self.join_decay_sweep()
+    self._roll_flush(hyper)
     self._decay_pending = True
+
+  def _roll_flush(self, hyper):
+    """After the step's row updates: this step's window of every lazily decaying table group (one launch per 4)."""
+    if not self.lazy_decay or self.flush_windows <= 0:
+      return
+    lazy = [grp for grp, _ in self._lazy_groups()]
+    for i in range(0, len(lazy), 4):
+      kernels.hip().emb_flush_window(lazy[i:i + 4], self.flush_windows, hyper)
 
   # -- gradient clipping by global norm: the reduce and the row update as two steps, the norm in between
   def backward_reduce(self, normsq, weight):
@@ -454,6 +471,7 @@ class EmbeddingEngine(object):
     for grp, keys, grads, n_unique in self._reduced:
       be.emb_apply_unique(grp, keys, grads, n_unique, opt_kind, hyper)
     self._reduced = []
+    self._roll_flush(hyper)
     self._decay_pending = True
 
   # -- host exchange

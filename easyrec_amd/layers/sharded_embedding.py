@@ -318,6 +318,7 @@ class ShardedEmbeddingEngine(EmbeddingEngine):
     owners = [sh['owner'] for sh in self.shard.values()]
     for i in range(0, len(owners), 4):  # the groups' reduce + optimizer kernels side by side in one launch
       be.emb_bwd_update_multi(owners[i:i + 4], opt_kind, hyper)
+    self._roll_flush(hyper)
 
   def check_overflow(self):
     """Blocking: has any step so far routed more keys to one owner than the exchange's capacity (the flag is sticky)?"""
@@ -435,6 +436,7 @@ class ShardedEmbeddingEngine(EmbeddingEngine):
     owners = [sh['owner'] for sh in self.shard.values()]
     for i in range(0, len(owners), 4):  # the groups' reduce + optimizer kernels side by side in one launch
       be.emb_bwd_update_multi(owners[i:i + 4], opt_kind, hyper)
+    self._roll_flush(hyper)
 
   def apply_replicated(self, opt_kind, hyper):
     be = kernels.hip()

@@ -106,8 +106,9 @@ class EasyRecEstimator(object):
     self.dense_sweep = bool(dense_sweep)
     # per-step lr_t history read by the lazy dense decay's replay: step s lives at lr_hist[s]; train_step / set_global_step
     # refuse to run past its capacity (er_hyper_select stops recording there and a replay would read out of bounds)
+    # layout [2 * capacity]: lr_t per step | running maximum of lr_t (the replay's absorbed regime bounds with it)
     n_hist = max(2 * int(cfg.train_config.num_steps or 0), 1 << 20)
-    self.lr_hist = torch.zeros(n_hist, dtype=torch.float32, device=dev)
+    self.lr_hist = torch.zeros(2 * n_hist, dtype=torch.float32, device=dev)
     self.engine.set_step_clock(self.step_counter, self.lr_hist, self.hyper[0],
                                lazy_decay=not self.dense_sweep and not self.overlap_sweep)
     self.losses = {
@@ -182,7 +183,7 @@ class EasyRecEstimator(object):
     """Make room for step indices < need in the lr_t history (lazy dense decay).  Outside a captured graph the buffer
     is re-allocated (doubling) and re-registered with the table groups; inside one its address is baked in, so every
     row is brought current first (nothing older than the flush is ever replayed) - then the run must stop."""
-    cap = self.lr_hist.numel()
+    cap = self.lr_hist.numel() // 2
     if need <= cap:
       return
     if self.graph is not None or getattr(self, '_graphs', None) is not None:
@@ -190,8 +191,10 @@ class EasyRecEstimator(object):
                          'set train_config.num_steps (the history is sized 2x num_steps) before capture()' % (need, cap))
     if self.device.type == 'cuda':
       torch.cuda.synchronize()
-    grown = torch.zeros(max(2 * cap, need), dtype=torch.float32, device=self.device)
-    grown[:cap].copy_(self.lr_hist)
+    new_cap = max(2 * cap, need)
+    grown = torch.zeros(2 * new_cap, dtype=torch.float32, device=self.device)
+    grown[:cap].copy_(self.lr_hist[:cap])
+    grown[new_cap:new_cap + cap].copy_(self.lr_hist[cap:])
     self.lr_hist = grown
     self.engine.rebind_lr_history(grown)
 

@@ -43,7 +43,15 @@ class EasyRecModel(six.with_metaclass(_meta_type, object)):
     self._emb_reg = self.embedding_regularization if self.embedding_regularization > 0 else None
     self._l2_reg = self.l2_regularization if self.l2_regularization > 0 else None
 
+    # wide feature groups are embeddings of dimension wide_output_dim: set by WideAndDeep / DeepFM from their own
+    # config, by backbone models from the `input_layer { wide_output_dim }` of their blocks (easy_rec_model.py:79-84)
     self._wide_output_dim = -1
+    if self.has_backbone:
+      from easyrec_amd.layers.backbone import Backbone
+      declared = Backbone.wide_embed_dim(model_config.backbone)
+      if declared:
+        self._wide_output_dim = declared
+        logging.info('set `wide_output_dim` to %d' % declared)
     self._feature_configs = feature_configs
     self.build_input_layer(model_config, feature_configs)
 

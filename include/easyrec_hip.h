@@ -185,8 +185,9 @@ typedef struct er_emb_group er_emb_group;
 int er_hyper_select(const float* table, int64_t* counter, int32_t n_slots, int32_t floats_per_slot,
                     float* out, float* history, int64_t history_capacity, int32_t history_index,
                     er_stream_t stream);
-/* history != NULL: also history[*counter] = slot[history_index] (before the increment): the per-step record of
- * Adam's lr_t that er_emb_catch_up / er_emb_flush_decay replay. */
+/* history != NULL (2 * history_capacity floats): also history[*counter] = slot[history_index] (before the increment):
+ * the per-step record of Adam's lr_t that er_emb_catch_up / er_emb_flush_decay replay; and
+ * history[history_capacity + *counter] = the largest such value so far (er_emb_group_set_lr_max). */
 
 int er_emb_group_create(const er_lookup_desc* descs_host, int n, int32_t dim, int64_t total_rows,
                         float* var, float* m, float* v, uint32_t* touched_bitmap,
@@ -214,9 +215,22 @@ int er_emb_bwd_reduce(er_emb_group* group, uint32_t* unique_keys, float* unique_
  *     Afterwards er_emb_bwd_update(ER_OPT_ADAM) updates the touched rows only (no bitmap, no sweep).
  *   er_emb_catch_up: call after er_emb_route (whose unique keys / count it takes) and BEFORE the lookup of
  *     the step; brings the rows the step touches to "after the previous step".
- *   er_emb_flush_decay: brings EVERY row current (checkpoint, state_dict, evaluation of untouched rows). */
+ *   er_emb_flush_decay: brings EVERY row current (checkpoint, state_dict, evaluation of untouched rows).
+ *   er_emb_group_set_lr_max: lr_max_history[s] = max of lr_t_history[0..s] (the second half of the buffer
+ *     er_hyper_select fills).  Enables the ABSORBED regime of the replay: once a row's update has fallen below a
+ *     quarter ulp of var - and, bounded with the largest lr_t so far, can only fall further (beta1 < sqrt(beta2)) -
+ *     var stops changing and only m *= beta1, v *= beta2 are replayed: still bit-identical to the sweep, ~10x fewer
+ *     instructions per idle step (reached ~150 steps after a row's last touch).
+ *   er_emb_flush_window: the ROLLING flush of up to 4 table groups in one launch: step t brings the rows
+ *     [w * chunk, (w + 1) * chunk), w = t mod n_windows, chunk = ceil(total_rows / n_windows), current.  Called once
+ *     per step (after the row update) it bounds how far behind any row can be to n_windows steps, so the catch-up of a
+ *     cold row replays <= n_windows steps instead of its whole idle time, for one pass over 1 / n_windows of the
+ *     tables per step.  Same arithmetic as er_emb_flush_decay. */
 int er_emb_group_enable_lazy_decay(er_emb_group* group, int32_t* last_step, const float* lr_t_history,
                                    const int64_t* step_counter);
+int er_emb_group_set_lr_max(er_emb_group* group, const float* lr_max_history);
+int er_emb_flush_window(er_emb_group* const* groups_host, int n, int32_t n_windows, const er_opt_hyper* hyper,
+                        er_stream_t stream);
 int er_emb_catch_up(er_emb_group* group, const uint32_t* unique_keys, const int32_t* n_unique,
                     const er_opt_hyper* hyper, er_stream_t stream);
 int er_emb_flush_decay(er_emb_group* group, const er_opt_hyper* hyper, er_stream_t stream);

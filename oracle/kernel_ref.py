@@ -852,12 +852,15 @@ class RefBackend(object):
     dlogits = gates * (dg - (gates * dg).sum(dim=-1, keepdim=True))
     return dexperts, dlogits
 
-  def hyper_select(self, table, counter, out, history=None, history_index=HYPER_LR_T):
+  def hyper_select(self, table, counter, out, history=None, history_index=HYPER_LR_T):  # history: [values | maxima]
     c = int(counter.item())
     slot = table[c % table.shape[0]]
     out.copy_(slot)
-    if history is not None and c < history.numel():
-      history[c] = slot.reshape(-1)[history_index]
+    if history is not None and c < history.numel() // 2:
+      cap = history.numel() // 2
+      val = slot.reshape(-1)[history_index]
+      history[c] = val
+      history[cap + c] = max(float(val), float(history[cap + c - 1]) if c > 0 else 0.0)
     counter += 1
 
   # -- TF-exact Adam without the sweep: decay-only steps replayed when a row is next touched
@@ -883,6 +886,17 @@ class RefBackend(object):
     t = int(group['step_counter'].item()) - 1
     n = int(n_unique.item())
     self._replay(group, [int(k) for k in unique_keys[:n].tolist()], t, h)
+
+  def emb_flush_window(self, groups, n_windows, hyper):
+    h = hyper.detach().cpu().numpy().reshape(-1)
+    for group in groups:
+      done = int(group['step_counter'].item())
+      chunk = -(-group['total_rows'] // n_windows)
+      w = done % n_windows
+      rows = range(w * chunk, min((w + 1) * chunk, group['total_rows']))
+      self._replay(group, rows, done, h)
+      for r in rows:
+        group['last_step'][r] = max(int(group['last_step'][r]), done - 1)
 
   def emb_flush_decay(self, group, hyper):
     h = hyper.detach().cpu().numpy().reshape(-1)

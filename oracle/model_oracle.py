@@ -80,6 +80,18 @@ class OracleTrainer(object):
         if oc[0].HasField('embedding_learning_rate_multiplier') else 1.0
     self.model_class = cfg.model_config.model_class
 
+  def resume(self, global_step, slots):
+    """Continue from a training state taken elsewhere: `global_step` finished steps (LR schedule position, Adam's beta
+    powers = beta^(step + 1), computed by repeated fp32 multiplication as TF's update op does) and the optimizer slots
+    {'<var>/m', '<var>/v'}."""
+    self.global_step = int(global_step)
+    self.slots = {k: np.array(v, dtype=np.float32) for k, v in slots.items()}
+    for oi, o in enumerate(self.opt):
+      b1p, b2p = F32(o['beta1']), F32(o['beta2'])
+      for _ in range(self.global_step):
+        b1p, b2p = F32(b1p * F32(o['beta1'])), F32(b2p * F32(o['beta2']))
+      self.beta_pow[oi] = [b1p, b2p]
+
   # ------------------------------------------------------------------ optimizer config
   @staticmethod
   def _opt_cfg(o):

@@ -604,7 +604,7 @@ def test_lazy_dense_decay_equals_the_sweep(hip):
   ids_all[60:, :] = ids_all[60:, :] % 11            # after step 60 only rows 0..10 are ever touched again
   dout_all = (rng.standard_normal((T, B, dim)) * 0.01).astype(np.float32)
   state = {}
-  for mode in ('sweep', 'lazy'):
+  for mode in ('sweep', 'lazy', 'lazy_roll'):  # lazy_roll: + the rolling flush (er_emb_flush_window, 16 windows)
     var, m, v = table0.clone().to(DEV), torch.zeros(rows, dim, device=DEV), torch.zeros(rows, dim, device=DEV)
     ids = torch.zeros(B, dtype=torch.int64, device=DEV)
     dout = torch.zeros(B, dim, device=DEV)
@@ -613,9 +613,10 @@ def test_lazy_dense_decay_equals_the_sweep(hip):
                               key_base=0, dim=dim, combiner=0, n_rows=B, max_nnz=B)
     g = hip.emb_group_create([spec], dim, rows, var, m, v, bitmap)
     counter = torch.zeros(1, dtype=torch.int64, device=DEV)
-    hist = torch.zeros(T + 8, device=DEV)
+    cap = T + 8
+    hist = torch.zeros(2 * cap, device=DEV)  # [lr_t per step | running maximum] as er_hyper_select lays it out
     hyper = torch.zeros(kernels.HYPER_FLOATS, device=DEV)
-    if mode == 'lazy':
+    if mode != 'sweep':
       last = torch.full((rows,), -1, dtype=torch.int32, device=DEV)
       hip.emb_group_enable_lazy_decay(g, last, hist, counter)
       ukeys = torch.zeros(B, dtype=torch.int32, device=DEV)
@@ -624,30 +625,35 @@ def test_lazy_dense_decay_equals_the_sweep(hip):
       cnt = torch.zeros(1, dtype=torch.int32, device=DEV)
     rows_h = torch.stack([_hyper(lr=1e-2 * (0.5**(s // 400)), t=s + 1) for s in range(T)]).to(DEV)
     hist[:T] = rows_h[:, kernels.HYPER_LR_T]
+    hist[cap:cap + T] = torch.cummax(rows_h[:, kernels.HYPER_LR_T], 0).values
     for s in range(T):
       hyper.copy_(rows_h[s])
       counter.fill_(s + 1)
       ids.copy_(torch.from_numpy(ids_all[s]))
       dout.copy_(torch.from_numpy(dout_all[s]))
-      if mode == 'lazy':
+      if mode != 'sweep':
         hip.emb_route(g, ukeys, nu, uidx, cnt)
         hip.emb_catch_up(g, ukeys, nu, hyper)
       hip.emb_bwd_update(g, kernels.OPT_ADAM, hyper)
-    if mode == 'lazy':
+      if mode == 'lazy_roll':
+        hip.emb_flush_window([g], 16, hyper)
+    if mode != 'sweep':
       hip.emb_flush_decay(g, hyper)
       torch.cuda.synchronize()
       assert int(last.min()) == T - 1
     torch.cuda.synchronize()
     state[mode] = (var.cpu(), m.cpu(), v.cpu())
     hip.emb_group_destroy(g)
-  (va, ma, sa), (vb, mb, sb) = state['sweep'], state['lazy']
-  assert torch.equal(ma, mb), 'first moments must be bit-identical'
+  (va, ma, sa) = state['sweep']
   hot = torch.arange(rows) < 11
-  assert torch.equal(va[hot], vb[hot]) and torch.equal(sa[hot], sb[hot]), 'recently touched rows: every bit'
   # fp32 never reaches 0 by repeated * 0.9: it settles on a denormal fixed point (|m| <= 4 * 2^-149)
   assert (ma[~hot].abs() <= 6e-45).all(), 'idle rows: m has settled (the closed-form tail of v was taken)'
-  assert torch.equal(va[~hot], vb[~hot]), 'var stops moving once m == 0'
-  assert torch.allclose(sa, sb, rtol=1e-5, atol=0.0)
+  for mode in ('lazy', 'lazy_roll'):
+    vb, mb, sb = state[mode]
+    assert torch.equal(ma, mb), (mode, 'first moments must be bit-identical')
+    assert torch.equal(va[hot], vb[hot]) and torch.equal(sa[hot], sb[hot]), (mode, 'recently touched rows: every bit')
+    assert torch.equal(va, vb), (mode, 'var: every bit, through the full, the absorbed and the settled regime')
+    assert torch.allclose(sa, sb, rtol=1e-5, atol=0.0), mode
 
 
 @pytest.mark.parametrize('sizes', [(100, 4096, 5000, 8192, 257), (1, 2, 3), (4097,), (8192, 8192), (9000, 50),
@@ -706,10 +712,11 @@ def test_shared_sort_between_wide_and_deep_groups(hip, lazy):
     ids = [torch.zeros(B, dtype=torch.int64, device=DEV) for _ in rows]
     groups, state = {}, {}
     counter = torch.zeros(1, dtype=torch.int64, device=DEV)
-    hist = torch.zeros(T + 8, device=DEV)
+    hist = torch.zeros(2 * (T + 8), device=DEV)  # [lr_t per step | running maximum]
     hyper = torch.zeros(kernels.HYPER_FLOATS, device=DEV)
     rows_h = torch.stack([_hyper(lr=1e-2, t=s + 1) for s in range(T)]).to(DEV)
     hist[:T] = rows_h[:, kernels.HYPER_LR_T]
+    hist[T + 8:2 * T + 8] = torch.cummax(rows_h[:, kernels.HYPER_LR_T], 0).values
     total = sum(rows)
     lz = {}
     for dim in (1, 16):
