@@ -7,25 +7,40 @@
 //
 // Here the gradients never exist as separate tensors at that point: the dense ones sit in the flat gradient buffer
 // (the kernel-L2 term l2 * w is added by the optimizer kernel), the embedding ones are the de-duplicated row sums
-// of er_emb_bwd_reduce(_routed).  So: squared-norm partials of both (fixed order -> deterministic), one scalar kernel
+// of er_emb_bwd_reduce(_routed).  So: squared norms of both (one workgroup each, fixed order -> deterministic), one scalar kernel
 // that turns the total into the multiplier and stores it in the er_opt_hyper records of the step (`clip_scale`),
 // and the optimizer kernels (dense_opt_kernel, the embedding row updates) multiply by it.  All HBM-streaming fp32.
 #include "er_common.h"
 
 namespace er {
 
-int get_scratch(size_t floats, float** out);  // er_dense.hip
+constexpr int kNormBlock = 1024;
 
-// partial[b] = sum over block b's strided share of x[r * ld + c]^2, r a valid row, c < cols
-__global__ void __launch_bounds__(kBlock)
-gradsq_rows_partial_kernel(const float* __restrict__ x, int64_t max_rows, int cols, int ld,
-                           const int32_t* __restrict__ seg_counts, int n_seg, int64_t seg_stride,
-                           float* __restrict__ partial) {
-  __shared__ float red[4];
-  float acc = 0.f;
+// block-wide sum for kNormBlock threads (16 waves), fixed combination order; result valid in thread 0
+__device__ __forceinline__ float block_sum_1024(float v, float* smem16) {
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) smem16[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float r = 0.f;
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < kNormBlock / 64; ++i) r = r + smem16[i];
+  }
+  return r;
+}
+
+// ONE workgroup per buffer, no library scratch: the sums are a few MB at most and clipping is an optional path; a
+// single block keeps the order fixed (deterministic) and the call free of shared state (ranks simulated as threads of
+// one process - the tests - would otherwise race on the reduction scratch between the partial and the final pass).
+// acc[0] (+)= weight * sum of x[r * ld + c]^2 over the valid rows r, c < cols
+__global__ void __launch_bounds__(kNormBlock)
+gradsq_rows_kernel(const float* __restrict__ x, int64_t max_rows, int cols, int ld,
+                   const int32_t* __restrict__ seg_counts, int n_seg, int64_t seg_stride, float weight,
+                   float* __restrict__ acc, int accumulate) {
+  __shared__ float red[kNormBlock / 64];
+  float a = 0.f;
   const int64_t total = max_rows * cols;
-  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
-  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < total; i += stride) {
+  for (int64_t i = threadIdx.x; i < total; i += kNormBlock) {
     const int64_t r = i / cols;
     const int c = static_cast<int>(i - r * cols);
     if (seg_counts) {
@@ -33,40 +48,29 @@ gradsq_rows_partial_kernel(const float* __restrict__ x, int64_t max_rows, int co
       if (sg >= n_seg || (r - sg * seg_stride) >= seg_counts[sg]) continue;
     }
     const float v = x[r * ld + c];
-    acc = acc + v * v;
+    a = a + v * v;
   }
-  const float s = block_sum_256(acc, red);
-  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+  const float s = block_sum_1024(a, red);
+  if (threadIdx.x == 0) acc[0] = accumulate ? (acc[0] + weight * s) : weight * s;
 }
 
 // the dense variables' gradient as the optimizer will see it: grad_scale * grad + l2coef * w
-__global__ void __launch_bounds__(kBlock)
-gradsq_dense_partial_kernel(const float* __restrict__ w, const float* __restrict__ grad,
-                            const float* __restrict__ l2coef, int64_t n, const er_opt_hyper* __restrict__ hyper,
-                            float* __restrict__ partial) {
-  __shared__ float red[4];
+__global__ void __launch_bounds__(kNormBlock)
+gradsq_dense_kernel(const float* __restrict__ w, const float* __restrict__ grad, const float* __restrict__ l2coef,
+                    int64_t n, const er_opt_hyper* __restrict__ hyper, float* __restrict__ acc, int accumulate) {
+  __shared__ float red[kNormBlock / 64];
   const float gs = hyper->grad_scale;
-  float acc = 0.f;
-  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
-  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride) {
+  float a = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += kNormBlock) {
     float g = grad[i] * gs;
     if (l2coef) {
       const float c = l2coef[i];
       if (c != 0.f) g = g + c * w[i];
     }
-    acc = acc + g * g;
+    a = a + g * g;
   }
-  const float s = block_sum_256(acc, red);
-  if (threadIdx.x == 0) partial[blockIdx.x] = s;
-}
-
-__global__ void __launch_bounds__(kBlock)
-gradsq_finish_kernel(const float* __restrict__ partial, int n, float weight, float* __restrict__ acc, int accumulate) {
-  __shared__ float red[4];
-  float a = 0.f;
-  for (int i = threadIdx.x; i < n; i += kBlock) a = a + partial[i];
-  const float s = block_sum_256(a, red);
-  if (threadIdx.x == 0) acc[0] = accumulate ? (acc[0] + weight * s) : weight * s;
+  const float s = block_sum_1024(a, red);
+  if (threadIdx.x == 0) acc[0] = accumulate ? (acc[0] + s) : s;
 }
 
 __global__ void clip_scale_kernel(const float* __restrict__ normsq, float clip_norm, er_opt_hyper* __restrict__ records,
@@ -88,17 +92,8 @@ int er_gradsq_rows(const float* x, int64_t max_rows, int32_t cols, int32_t ld, c
                    int64_t seg_stride, float weight, float* acc, int accumulate, er_stream_t stream) {
   ER_REQUIRE(x && acc && max_rows >= 0 && cols > 0 && ld >= cols, "er_gradsq_rows: bad arguments");
   ER_REQUIRE(!seg_counts || (n_seg > 0 && seg_stride > 0), "er_gradsq_rows: seg_counts needs n_seg and seg_stride");
-  hipStream_t s = er::as_stream(stream);
-  int64_t blocks = er::ceil_div(max_rows * cols, static_cast<int64_t>(er::kBlock) * 4);
-  if (blocks > 512) blocks = 512;
-  if (blocks < 1) blocks = 1;
-  float* scratch;
-  if (er::get_scratch(static_cast<size_t>(blocks), &scratch)) return 1;
-  hipLaunchKernelGGL(er::gradsq_rows_partial_kernel, dim3(static_cast<int>(blocks)), dim3(er::kBlock), 0, s, x, max_rows,
-                     cols, ld, seg_counts, n_seg, seg_stride, scratch);
-  ER_LAUNCH_CHECK();
-  hipLaunchKernelGGL(er::gradsq_finish_kernel, dim3(1), dim3(er::kBlock), 0, s, scratch, static_cast<int>(blocks), weight,
-                     acc, accumulate);
+  hipLaunchKernelGGL(er::gradsq_rows_kernel, dim3(1), dim3(er::kNormBlock), 0, er::as_stream(stream), x, max_rows, cols,
+                     ld, seg_counts, n_seg, seg_stride, weight, acc, accumulate);
   ER_LAUNCH_CHECK();
   return 0;
 }
@@ -106,16 +101,8 @@ int er_gradsq_rows(const float* x, int64_t max_rows, int32_t cols, int32_t ld, c
 int er_gradsq_dense(const float* w, const float* grad, const float* l2coef, int64_t n, const er_opt_hyper* hyper,
                     float* acc, int accumulate, er_stream_t stream) {
   ER_REQUIRE(w && grad && hyper && acc && n > 0, "er_gradsq_dense: bad arguments");
-  hipStream_t s = er::as_stream(stream);
-  int64_t blocks = er::ceil_div(n, static_cast<int64_t>(er::kBlock) * 4);
-  if (blocks > 512) blocks = 512;
-  float* scratch;
-  if (er::get_scratch(static_cast<size_t>(blocks), &scratch)) return 1;
-  hipLaunchKernelGGL(er::gradsq_dense_partial_kernel, dim3(static_cast<int>(blocks)), dim3(er::kBlock), 0, s, w, grad,
-                     l2coef, n, hyper, scratch);
-  ER_LAUNCH_CHECK();
-  hipLaunchKernelGGL(er::gradsq_finish_kernel, dim3(1), dim3(er::kBlock), 0, s, scratch, static_cast<int>(blocks), 1.0f,
-                     acc, accumulate);
+  hipLaunchKernelGGL(er::gradsq_dense_kernel, dim3(1), dim3(er::kNormBlock), 0, er::as_stream(stream), w, grad, l2coef, n,
+                     hyper, acc, accumulate);
   ER_LAUNCH_CHECK();
   return 0;
 }

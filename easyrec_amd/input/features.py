@@ -187,6 +187,11 @@ class DeviceFeatures(object):
           'ids': torch.full((B, s['max_len']), -1, dtype=torch.int64, device=dev),
           'len': torch.zeros(B, dtype=torch.int32, device=dev),
       }
+    # longest sequence of the loaded batch, per sequence feature: the reference pads a batch's sequences to ITS longest
+    # one (the sparse tensor's dense shape), and BatchNorm inside an attention MLP sees exactly those positions
+    # (SURVEY.md App. B.2); the buffers here have the static max_seq_len, consumers slice [:, :seq_pad_len(name)]
+    self.seq_batch_max = {name: s['max_len'] for name, s in schema.seqs.items()}
+    self.pad_to_batch_max = True
     self._use_device_hash = False
 
   @property
@@ -210,6 +215,16 @@ class DeviceFeatures(object):
 
   def label(self, name):
     return self.labels[self.schema.label_fields.index(name)]
+
+  def seq_pad_len(self, name):
+    """Time steps of sequence feature `name` the model sees this step: the loaded batch's longest sequence (at least
+    1), or the static max_seq_len when pad_to_batch_max is off."""
+    L = self.schema.seqs[name]['max_len']
+    return max(1, min(L, self.seq_batch_max.get(name, L))) if self.pad_to_batch_max else L
+
+  def shape_signature(self):
+    """What a captured hipGraph depends on besides buffer addresses: the padded lengths of the sequence features."""
+    return tuple(self.seq_pad_len(n) for n in self.schema.seqs)
 
   def __contains__(self, name):
     s = self.schema
@@ -273,7 +288,9 @@ class DeviceFeatures(object):
       if ids is None:
         continue
       put(bufs['ids'], ids)
-      put(bufs['len'], batch['seq/%s/len' % name])
+      lens = batch['seq/%s/len' % name]
+      put(bufs['len'], lens)
+      self.seq_batch_max[name] = int(lens.max()) if len(lens) else 0  # (a device tensor synchronises here)
     self.version += 1
 
   _PACKED_KEYS = {'labels': 'labels', 'raw': 'raw_block', 'int_ids': 'int_ids', 'hash_ids': 'hash_ids',

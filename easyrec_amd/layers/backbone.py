@@ -232,11 +232,21 @@ class Package(object):
     return output
 
   def _input_layer_output(self, group, cfg):
+    if cfg is not None and cfg.output_seq_and_normal_feature:
+      # sequence blocks (layers/common_layers.py:119-131): ([B, L, E] history, [B] lengths, [B, E'] target features)
+      seq_and_len, _, targets = self._input_layer(self._features, group, is_combine=False)
+      seq_len = seq_and_len[0][1]
+      seqs = [fea for fea, _ in seq_and_len]
+      if cfg.concat_seq_feature:
+        assert len(seqs) > 0, '[input_%s] sequence feature is empty' % group
+        seqs = seqs[0] if len(seqs) == 1 else torch.cat(seqs, dim=-1)
+        targets = (targets[0] if len(targets) == 1 else torch.cat(list(targets), dim=-1)) if targets else None
+      return seqs, seq_len, targets
     out, feature_list = self._input_layer(self._features, group)
     if cfg is not None:
       assert not (cfg.do_batch_norm or cfg.do_layer_norm or cfg.dropout_rate or cfg.feature_dropout_rate or
-                  cfg.only_output_3d_tensor or cfg.output_seq_and_normal_feature), \
-          'input_layer block options other than the feature-list outputs are outside the hot-path scope'
+                  cfg.only_output_3d_tensor), \
+          'input_layer block options other than the feature-list / sequence outputs are outside the hot-path scope'
       if cfg.only_output_feature_list:
         return feature_list
       if cfg.output_2d_tensor_and_feature_list:

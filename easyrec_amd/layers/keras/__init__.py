@@ -3,3 +3,5 @@
 from .blocks import MLP  # noqa: F401
 from .interaction import FM, Cross  # noqa: F401
 from .multi_task import MMoE  # noqa: F401
+from .din import DIN  # noqa: F401
+from .fibinet import SENet  # noqa: F401

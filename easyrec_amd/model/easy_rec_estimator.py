@@ -70,6 +70,7 @@ class EasyRecEstimator(object):
     assert self.ctx.dense_dtype in ('f32', 'bf16')
     self.global_step = 0
     self.graph = None
+    self._graph_signature = None
     self._built = False
 
     # optimizers (estimator :216-235)
@@ -286,9 +287,11 @@ class EasyRecEstimator(object):
     else:
       self.features.version += 1
     self._refresh_hyper()
-    if self.graph is not None:
+    if self.graph is not None and self.features.shape_signature() == self._graph_signature:
       self.graph.replay()
     else:
+      # eager: no graph yet, or this batch's sequences are padded to another length than the captured one's (the
+      # reference pads to the batch's longest sequence: tensor shapes follow the batch)
       self._device_step()
     self.global_step += 1
     return self.losses
@@ -385,6 +388,7 @@ class EasyRecEstimator(object):
       self._device_step()
     # the capture itself does not execute: the device step counter is unchanged by it
     self.graph = g
+    self._graph_signature = self.features.shape_signature()
     return g
 
   # -- host exchange (parity tests / checkpoints)

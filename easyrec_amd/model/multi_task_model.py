@@ -48,6 +48,43 @@ class MultiTaskModel(RankModel):
       assert label in self._labels, 'label [%s] must exists in labels' % label
       self._label_name_dict[cfg.tower_name] = label
 
+  def build_predict_graph(self):
+    """Backbone multi-task models (`model_class: "MultiTaskModel"` + `model_params { task_towers }`, reference
+    multi_task_model.py:33-100): the backbone yields one input per tower (or one shared input); tower DNN
+    `<tower_name>`, optional Bayes `relation_dnn` over [own features, the relation towers' features], then the
+    `<tower_name>/output` projection."""
+    if not self.has_backbone:
+      raise NotImplementedError('method `build_predict_graph` must be implemented when backbone network do not exists')
+    assert self._model_config.WhichOneof('model') == 'model_params', '`model_params` must be configured'
+    config = self._model_config.model_params
+    if not self._towers:  # (this method runs once per step: the towers are parsed on the first call)
+      self._outputs.extend(config.outputs)
+      self._init_towers(config.task_towers)
+    from easyrec_amd.layers import dnn
+    import torch
+    shared = self.backbone
+    if isinstance(shared, (list, tuple)):
+      if len(shared) != len(self._towers):
+        raise ValueError('The number of backbone outputs and task towers must be equal')
+      inputs = list(shared)
+    else:
+      inputs = [shared] * len(self._towers)
+    features, relation, logits = {}, {}, {}
+    for tower, x in zip(self._towers, inputs):
+      if tower.config.HasField('dnn'):
+        x = dnn.DNN(tower.config.dnn, self._l2_reg, name=tower.name, is_training=self._is_training)(x)
+      features[tower.name] = x
+    for tower in self._towers:
+      x = features[tower.name]
+      if tower.config.HasField('relation_dnn'):
+        parts = [x] + [relation[r] for r in tower.config.relation_tower_names]
+        x = dnn.DNN(tower.config.relation_dnn, self._l2_reg, name=tower.name + '/relation_dnn',
+                    is_training=self._is_training)(torch.cat(parts, dim=-1))
+        relation[tower.name] = x
+      logits[tower.name] = dnn.dense(x, tower.num_class, tower.name + '/output', l2_reg=self._l2_reg)
+    self._add_to_prediction_dict(logits)
+    return self._prediction_dict
+
   def _tower_heads(self, inputs_per_task):
     """Shared tail of the multi-task models here (MMoE, SimpleMultiTask, PLE): task t's input goes through the
     tower's DNN when it has one, then the `dnn_output_<t>` projection to num_class (reference model/mmoe.py:56-68,

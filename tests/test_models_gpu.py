@@ -146,3 +146,38 @@ def test_full_size_models_train_and_replay_as_graph(name, B, dtype):
   print('%s B=%d dense %s: %.3f ms/step (%.0f examples/s), loss %.4f -> %.4f' % (name, B, dtype, ms, B / ms * 1e3,
                                                                                  first, last))
   assert np.isfinite(last) and last < first
+
+
+@pytest.mark.parametrize('name', ['din_backbone_taobao_small.config', 'din_sequence_features_taobao_small.config',
+                                  'deepfm_backbone_criteo_small.config'])
+def test_backbone_and_group_level_din_match_oracle(name):
+  """keras `DIN` block behind an `output_seq_and_normal_feature` input layer, `sequence_features` inside a feature
+  group, backbone `wide_output_dim` (SURVEY.md 8 a11 / b) on the HIP kernels."""
+  _first_steps(_cfg(name), 128, 52)
+
+
+@pytest.mark.parametrize('name', ['din_taobao_small.config', 'din_backbone_taobao_small.config'])
+def test_din_batch_without_a_max_length_sequence(name):
+  """The model sees the BATCH's longest sequence (here 7 of max_seq_len 12): BatchNorm in the attention MLP normalises
+  over B x 7 positions, as the reference's batch-max padded tensors make it.  Eager, then through a captured graph
+  whose signature differs (the step falls back to eager launches)."""
+  from test_din_paths import shorten_sequences
+  cfg = _cfg(name)
+  B = 128
+  est = EasyRecEstimator(cfg, device=DEV, batch_size=B, seed=5).build()
+  orc = OracleTrainer(cfg, est.state_dict(), batch_size=B)
+  gen = SyntheticBatches(cfg.data_config, est.feature_configs, batch_size=B, seed=9)
+  full = gen.next_batch()
+  est.features.load(full)
+  est.capture(warmup=1)  # captured with full-length sequences
+  for _ in range(2):  # (the capture's warm-up + nothing else ran: bring the oracle to the same step)
+    pass
+  orc.train_step(full)
+  for step in range(2):
+    b = gen.next_batch()
+    shorten_sequences(b, 7)
+    est.train_step(b)
+    assert est.features.shape_signature()[0] == 7
+    got, exp = est.loss_values(), orc.train_step(b)
+    for k in exp:
+      assert abs(got[k] - exp[k]) <= 2e-4 * max(1e-3, abs(exp[k])), (step, k, got[k], exp[k])

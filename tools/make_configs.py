@@ -282,6 +282,91 @@ def mmoe_taobao(n_tasks=2, **kw):
   return cfg
 
 
+def _model_text(cfg, text):
+  cfg.ClearField('model_config')
+  text_format.Merge(text, cfg.model_config)
+  return cfg
+
+
+def din_backbone_taobao(**kw):
+  """The shape of samples/model_config/din_backbone_on_taobao.config: RankModel over a backbone whose `seq_input`
+  block hands (history [B, L, E], lengths, target features) to the keras `DIN` layer; MLP tower beside it."""
+  cfg = taobao_base('seq', **kw)
+  cfg.model_dir = 'experiments/din_backbone_taobao_ckpt'
+  cfg.data_config.label_fields.append('clk')
+  normal = TAOBAO_USER + ['adgroup_id', 'cate_id', 'campaign_id', 'customer', 'brand', 'price', 'pid']
+  return _model_text(cfg, '''
+    model_name: 'DIN'  model_class: 'RankModel'
+    feature_groups { group_name: 'normal' %s wide_deep: DEEP }
+    feature_groups { group_name: 'sequence' feature_names: 'cate_id' feature_names: 'brand'
+                     feature_names: 'tag_category_list' feature_names: 'tag_brand_list' wide_deep: DEEP }
+    backbone {
+      blocks { name: 'deep' inputs { feature_group_name: 'normal' }
+               keras_layer { class_name: 'MLP' mlp { hidden_units: [256, 128, 64] } } }
+      blocks { name: 'seq_input' inputs { feature_group_name: 'sequence' }
+               input_layer { output_seq_and_normal_feature: true } }
+      blocks { name: 'DIN' inputs { block_name: 'seq_input' }
+               keras_layer { class_name: 'DIN'
+                             din { attention_dnn { hidden_units: 32 hidden_units: 1 activation: "dice" }
+                                   need_target_feature: true } } }
+      top_mlp { hidden_units: [256, 128, 64] }
+    }
+    model_params { l2_regularization: 0 }
+    embedding_regularization: 0
+  ''' % ' '.join("feature_names: '%s'" % n for n in normal))
+
+
+def din_sequence_features_taobao(**kw):
+  """MultiTower whose `item` group carries `sequence_features` (target attention inside the input layer,
+  layers/input_layer.py:96-111): keys `brand` / `cate_id` are the group's own outputs (allow_key_search false)."""
+  cfg = taobao_base('seq', **kw)
+  cfg.model_dir = 'experiments/din_sequence_features_taobao_ckpt'
+  cfg.data_config.label_fields.append('clk')
+  return _model_text(cfg, '''
+    model_class: 'MultiTower'
+    feature_groups { group_name: 'user' %s wide_deep: DEEP }
+    feature_groups { group_name: 'item' %s wide_deep: DEEP
+      sequence_features { group_name: 'seq_fea' allow_key_search: false need_key_feature: true
+        seq_att_map { key: 'brand' hist_seq: 'tag_brand_list' }
+        seq_att_map { key: 'cate_id' hist_seq: 'tag_category_list' }
+        seq_dnn { hidden_units: [32, 16, 1] } } }
+    multi_tower {
+      towers { input: 'user' dnn { hidden_units: [64, 32] } }
+      towers { input: 'item' dnn { hidden_units: [64, 32] } }
+      final_dnn { hidden_units: [32, 16] }
+      l2_regularization: 1e-6
+    }
+    embedding_regularization: 5e-5
+  ''' % (' '.join("feature_names: '%s'" % n for n in TAOBAO_USER), ' '.join("feature_names: '%s'" % n for n in TAOBAO_ITEM)))
+
+
+def deepfm_backbone_criteo(**kw):
+  """The shape of examples/configs/deepfm_backbone_on_criteo.config: the wide group's width comes from the backbone's
+  `input_layer { wide_output_dim }`, wide logit through a config lambda, keras FM + MLP, top_mlp."""
+  cfg = deepfm_criteo(**kw)
+  names = ' '.join("feature_names: '%s'" % n for n in _all_names())
+  return _model_text(cfg, '''
+    model_name: 'DeepFM'  model_class: 'RankModel'
+    feature_groups { group_name: 'deep_features' %s wide_deep: DEEP }
+    feature_groups { group_name: 'wide_features' %s wide_deep: WIDE }
+    backbone {
+      blocks { name: 'wide_features' inputs { feature_group_name: 'wide_features' } input_layer { wide_output_dim: 1 } }
+      blocks { name: 'wide_logit' inputs { block_name: 'wide_features' }
+               lambda { expression: 'lambda x: tf.reduce_sum(x, axis=1, keepdims=True)' } }
+      blocks { name: 'deep_features' inputs { feature_group_name: 'deep_features' }
+               input_layer { output_2d_tensor_and_feature_list: true } }
+      blocks { name: 'fm' inputs { block_name: 'deep_features' input_slice: '[1]' }
+               keras_layer { class_name: 'FM' st_params { fields { key: 'use_variant' value { bool_value: true } } } } }
+      blocks { name: 'deep' inputs { block_name: 'deep_features' input_slice: '[0]' }
+               keras_layer { class_name: 'MLP' mlp { hidden_units: [256, 128, 64] } } }
+      concat_blocks: ['wide_logit', 'fm', 'deep']
+      top_mlp { hidden_units: [256, 128, 64] }
+    }
+    model_params { l2_regularization: 1e-5 }
+    embedding_regularization: 1e-5
+  ''' % (names, names))
+
+
 def write(cfg, name):
   out = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'configs', name)
   with open(out, 'w') as f:
@@ -447,6 +532,10 @@ if __name__ == '__main__':
   write(mmoe_taobao(), 'mmoe_taobao.config')
   write(mmoe_taobao(n_tasks=4, embedding_dim=64, batch_size=8192), 'mmoe_taobao_4task_d64.config')
   write(mmoe_taobao(batch_size=128, scale=0.01), 'mmoe_taobao_small.config')
+  write(din_backbone_taobao(), 'din_backbone_taobao.config')
+  write(din_backbone_taobao(batch_size=128, scale=0.01, seq_len=12), 'din_backbone_taobao_small.config')
+  write(din_sequence_features_taobao(batch_size=128, scale=0.01, seq_len=12), 'din_sequence_features_taobao_small.config')
+  write(deepfm_backbone_criteo(hash_bucket_size=1000, batch_size=256), 'deepfm_backbone_criteo_small.config')
   shared_embedding_variant('dlrm_criteo_small.config', 'dlrm_shared_criteo_small.config')
   shared_embedding_variant('deepfm_criteo_small.config', 'deepfm_shared_criteo_small.config')
   combo_feature_variant('deepfm_criteo_small.config', 'deepfm_combo_criteo_small.config')
