@@ -369,6 +369,23 @@ __device__ __forceinline__ void update_row(const RowUpdate& t, int opt_kind, con
 // current (checkpoint / state_dict / evaluation).  HBM traffic per step drops from 24 B x every table element
 // to the touched rows.
 // ------------------------------------------------------------------------------------------------
+constexpr int32_t kClosedFormMin = 2048;
+
+// k more decay-only steps of a row whose m no longer moves and whose update var absorbs: v *= b2, k times.
+template <int V>
+__device__ __forceinline__ void decay_v_only(float* v, int32_t k, const er_opt_hyper& h) {
+  if (k > kClosedFormMin) {
+    const double f = pow(static_cast<double>(h.beta2), static_cast<double>(k));
+#pragma unroll
+    for (int i = 0; i < V; ++i) v[i] = static_cast<float>(static_cast<double>(v[i]) * f);
+    return;
+  }
+  for (int32_t j = 0; j < k; ++j) {
+#pragma unroll
+    for (int i = 0; i < V; ++i) v[i] = v[i] * h.beta2;
+  }
+}
+
 template <int V>
 __device__ __forceinline__ void replay_decay(float* var, float* m, float* v, const float* __restrict__ lr_hist,
                                              int32_t s_begin, int32_t s_end, const er_opt_hyper& h,
@@ -384,9 +401,11 @@ __device__ __forceinline__ void replay_decay(float* var, float* m, float* v, con
   //      test below is on the COMPUTED update with a 2x margin: |upd| * L / lr_t(s) * 2 < |var| * 2^-25 <= ulp(var) / 2
   //      ... conservatively a quarter ulp, which also covers var at a power of two (half-sized ulp below).
   //      Typically reached ~150 steps after a row's last touch (0.9^150 = 1e-7).
-  //  (3) settled (the documented deviation): fp32 m never reaches 0 under m *= b1 - below 5 denormal units
-  //      fl(m * 0.9) == m - so ~900 steps after the touch m is constant, and the remaining decay of v is applied in
-  //      closed form v *= b2^k (<= 1e-6 relative on v of rows idle that long).
+  //  (3) settled: fp32 m never reaches 0 under m *= b1 - below 5 denormal units fl(m * 0.9) == m - so ~900 steps
+  //      after the touch m is constant and only v *= b2 is left: replayed step by step (1 multiplication/element/step,
+  //      still bit-identical) as long as at most kClosedFormMin steps are pending - always, when the rolling flush
+  //      (er_emb_flush_window) bounds the idle time; a longer backlog (a flush after thousands of steps without the
+  //      rolling flush) takes the closed form v *= b2^k, the one documented deviation (<= 1e-6 relative on v).
   const bool can_absorb = lr_max_hist != nullptr && h.beta1 < 0.999f * sqrtf(h.beta2) && s_end > s_begin;
   const float lr_cap = can_absorb ? lr_max_hist[s_end - 1] : 0.f;
   int32_t s = s_begin;
@@ -399,9 +418,7 @@ __device__ __forceinline__ void replay_decay(float* var, float* m, float* v, con
       settled = settled && (m[i] * h.beta1 == m[i]) && (var[i] - bound == var[i]) && (var[i] + bound == var[i]);
     }
     if (settled) {
-      const double f = pow(static_cast<double>(h.beta2), static_cast<double>(s_end - s));
-#pragma unroll
-      for (int i = 0; i < V; ++i) v[i] = static_cast<float>(static_cast<double>(v[i]) * f);
+      decay_v_only<V>(v, s_end - s, h);
       return;
     }
     const float lr_t = lr_hist[s];
@@ -430,10 +447,8 @@ __device__ __forceinline__ void replay_decay(float* var, float* m, float* v, con
       m[i] = mt;
       v[i] = v[i] * h.beta2;
     }
-    if (m_fixed && s + 1 < s_end) {  // m sits on its fixed point: only v is left, in closed form (regime 3)
-      const double f = pow(static_cast<double>(h.beta2), static_cast<double>(s_end - s - 1));
-#pragma unroll
-      for (int i = 0; i < V; ++i) v[i] = static_cast<float>(static_cast<double>(v[i]) * f);
+    if (m_fixed && s + 1 < s_end) {  // m sits on its fixed point: only v is left (regime 3)
+      decay_v_only<V>(v, s_end - s - 1, h);
       return;
     }
   }

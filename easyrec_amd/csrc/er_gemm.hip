@@ -47,6 +47,31 @@ struct BnBwdEpi {
   float* partial = nullptr;       // [row tiles][N][2]
 };
 
+// BatchNorm fused INTO the epilogue (forward: normalise + activation; backward: the dz of the producing layer) needs
+// the column statistics of ALL row tiles before any output can be written: the workgroups of one column of tiles meet
+// at a barrier (arrive counter + spin; the whole grid is co-resident: er_gemm_fused_bn_ok), each then finalises the
+// statistics of its 64 columns redundantly - in exactly the order bn_finalize_apply_kernel /
+// bn_bwd_finalize_apply_kernel use, so the results are bit-identical to the two-launch form - and transforms its
+// accumulator tile in registers.  One launch per dense + BatchNorm + ReLU layer instead of two, and no second pass over
+// the layer's output.
+struct BnFused {
+  int mode = 0;                    // 0: off; 1: forward (needs col_stats); 2: backward (needs bn.partial)
+  const float* gamma = nullptr;
+  const float* beta = nullptr;     // forward
+  float eps = 0.f, momentum = 0.f;
+  float* moving_mean = nullptr;    // forward, may be nullptr (build pass)
+  float* moving_var = nullptr;
+  float* save_mean = nullptr;      // forward: [N] outputs
+  float* save_invstd = nullptr;
+  float* y = nullptr;              // forward: activation output [M][ldy]
+  int ldy = 0, act = 0;
+  float* dgamma = nullptr;         // backward: parameter gradients (accumulated when accumulate != 0), may be nullptr
+  float* dbeta = nullptr;
+  float* dbias = nullptr;          // backward without BatchNorm: the bias gradient
+  int accumulate = 0;
+  unsigned* counters = nullptr;    // [column tiles][2], all zero between launches (the barrier resets itself)
+};
+
 struct GemmArgs {
   const float* A;
   const float* B;
@@ -59,6 +84,7 @@ struct GemmArgs {
   int splits;
   float* col_stats;   // nullptr, or [gridDim.y][N][3] Welford (count, mean, M2) of the output columns per row tile
   BnBwdEpi bn;        // bn.partial != nullptr: emit the BatchNorm-backward column sums of the output tile
+  BnFused fu;         // fu.mode != 0: finish the BatchNorm in this launch (see BnFused)
 };
 
 // Loads 4 consecutive elements along the CONTIGUOUS dimension of the operand tile.
@@ -191,6 +217,124 @@ __device__ __forceinline__ void tile_bn_bwd_partial(const f32x16& acc, const BnB
     p[0] = a + slot[0];
     p[1] = ax + slot[1];
   }
+}
+
+// Barrier among the `n` workgroups that share a column of tiles.  c[0]: arrivals, c[1]: departures; the last workgroup
+// to leave zeroes both (every other one has left the spin by then), so the words are zero again for the next launch.
+// Release / acquire at agent scope: the partial statistics cross XCDs (separate L2s).
+__device__ __forceinline__ void tile_column_barrier(unsigned* c, unsigned n) {
+  __threadfence();  // this thread's stores to the partial buffer
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    while (__hip_atomic_load(c, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < n) __builtin_amdgcn_s_sleep(1);
+    const unsigned gone = __hip_atomic_fetch_add(c + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (gone == n - 1) {
+      __hip_atomic_store(c + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(c, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  __syncthreads();
+  __threadfence();  // every wave: later loads must not be served from lines cached before the barrier
+}
+
+// Forward: finalise the statistics of the tile's 64 columns from the per-row-tile Welford partials (thread (cl, rl)
+// merges row tiles rl, rl + 4, ... in ascending order, eight loads in flight; then ((0 + 1) + (2 + 3)): the order of
+// bn_finalize_apply_kernel), leave mean / invstd in LDS; the ty == 0 workgroup records them and moves the moving
+// statistics.  lds: >= 256 + 768 + 128 floats.
+__device__ __forceinline__ void fused_bn_fwd_finalize(const GemmArgs& g, int n0, int ty, int gy, float* lds,
+                                                      float*& s_mu, float*& s_is) {
+  float* sm = lds + 256;  // [4][64][3]
+  s_mu = lds + 256 + 768;
+  s_is = s_mu + 64;
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = n0 + cl;
+  float tn = 0.f, tm = 0.f, t2 = 0.f;
+  if (c < g.N) {
+    for (int k0 = rl; k0 < gy; k0 += 32) {
+      float w[8][3];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = k0 + j * 4;
+        if (k < gy) {
+          const float* p = g.col_stats + (static_cast<int64_t>(k) * g.N + c) * 3;
+          w[j][0] = p[0]; w[j][1] = p[1]; w[j][2] = p[2];
+        } else {
+          w[j][0] = 0.f; w[j][1] = 0.f; w[j][2] = 0.f;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) chan_merge(tn, tm, t2, w[j][0], w[j][1], w[j][2]);
+    }
+  }
+  float* mine = sm + (rl * 64 + cl) * 3;
+  mine[0] = tn; mine[1] = tm; mine[2] = t2;
+  __syncthreads();
+  if (rl == 0 && c < g.N) {
+    const float* q0 = sm + (0 * 64 + cl) * 3;
+    const float* q1 = sm + (1 * 64 + cl) * 3;
+    const float* q2 = sm + (2 * 64 + cl) * 3;
+    const float* q3 = sm + (3 * 64 + cl) * 3;
+    float an = q0[0], am = q0[1], a2 = q0[2];
+    chan_merge(an, am, a2, q1[0], q1[1], q1[2]);
+    float bn = q2[0], bm = q2[1], b2 = q2[2];
+    chan_merge(bn, bm, b2, q3[0], q3[1], q3[2]);
+    chan_merge(an, am, a2, bn, bm, b2);
+    const float mean = am;
+    const float var = a2 / static_cast<float>(g.M);  // biased, as tf.nn.moments
+    const float inv = 1.f / sqrtf(var + g.fu.eps);
+    s_mu[cl] = mean;
+    s_is[cl] = inv;
+    if (ty == 0) {
+      g.fu.save_mean[c] = mean;
+      g.fu.save_invstd[c] = inv;
+      if (g.fu.moving_mean) {
+        const float om = 1.f - g.fu.momentum;
+        g.fu.moving_mean[c] = g.fu.moving_mean[c] - (g.fu.moving_mean[c] - mean) * om;
+        g.fu.moving_var[c] = g.fu.moving_var[c] - (g.fu.moving_var[c] - var) * om;
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// Backward: the two column sums (sum g, sum g * xhat) of the tile's 64 columns from the per-row-tile partials, in the
+// order of bn_bwd_finalize_apply_kernel; the ty == 0 workgroup writes / accumulates the parameter gradients.
+__device__ __forceinline__ void fused_bn_bwd_finalize(const GemmArgs& g, int n0, int ty, int gy, float* lds,
+                                                      float*& s_g, float*& s_gx) {
+  float* sm = lds + 256;  // [2][4][64]
+  s_g = lds + 256 + 512;
+  s_gx = s_g + 64;
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = n0 + cl;
+  float a = 0.f, b = 0.f;
+  if (c < g.N) {
+#pragma unroll 8
+    for (int k = rl; k < gy; k += 4) {
+      const float* p = g.bn.partial + (static_cast<int64_t>(k) * g.N + c) * 2;
+      a = a + p[0];
+      b = b + p[1];
+    }
+  }
+  sm[rl * 64 + cl] = a;
+  sm[256 + rl * 64 + cl] = b;
+  __syncthreads();
+  if (rl == 0 && c < g.N) {
+    a = (sm[cl] + sm[64 + cl]) + (sm[128 + cl] + sm[192 + cl]);
+    b = (sm[256 + cl] + sm[256 + 64 + cl]) + (sm[256 + 128 + cl] + sm[256 + 192 + cl]);
+    s_g[cl] = a;
+    s_gx[cl] = b;
+    if (ty == 0) {
+      const int acc = g.fu.accumulate;
+      if (g.bn.use_bn) {
+        if (g.fu.dbeta) g.fu.dbeta[c] = acc ? g.fu.dbeta[c] + a : a;
+        if (g.fu.dgamma) g.fu.dgamma[c] = acc ? g.fu.dgamma[c] + b : b;
+      } else if (g.fu.dbias) {
+        g.fu.dbias[c] = acc ? g.fu.dbias[c] + a : a;
+      }
+    }
+  }
+  __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -425,6 +569,55 @@ __device__ __forceinline__ void gemm_f32_block(const GemmArgs& g, int bx, int bz
     tile_col_stats(acc, bv, m0 + wm * 32, g.M, col, g.N, wm, wn, lane, lds,
                    g.col_stats + static_cast<int64_t>(ty) * g.N * 3);
   if (BN_EPI) tile_bn_bwd_partial(acc, g.bn, py, pz, m0 + wm * 32, g.M, col, g.N, wm, wn, lane, lds, ty);
+  if (g.fu.mode != 0) {  // (uniform over the grid; host guarantees splits == 1 and a co-resident grid)
+    const int gy = static_cast<int>(ceil_div(g.M, BM));
+    tile_column_barrier(g.fu.counters + 2 * tx, static_cast<unsigned>(gy));
+    const int cl = wn * 32 + (lane & 31);
+    if (g.fu.mode == 1) {
+      float *s_mu, *s_is;
+      fused_bn_fwd_finalize(g, n0, ty, gy, lds, s_mu, s_is);
+      if (col >= g.N) return;
+      const float mu = s_mu[cl], is = s_is[cl];
+      const float ga = g.fu.gamma ? g.fu.gamma[col] : 1.f, be = g.fu.beta ? g.fu.beta[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+        if (row < g.M) {
+          const float z = acc[r] + bv;
+          g.C[static_cast<int64_t>(row) * g.ldc + col] = z;
+          float v = (z - mu) * is;
+          v = v * ga + be;
+          if (g.fu.act == ER_ACT_RELU) v = v > 0.f ? v : 0.f;
+          g.fu.y[static_cast<int64_t>(row) * g.fu.ldy + col] = v;
+        }
+      }
+      return;
+    }
+    if (BN_EPI) {  // mode 2: dz of the producing layer instead of dy
+      float *s_g, *s_gx;
+      fused_bn_bwd_finalize(g, n0, ty, gy, lds, s_g, s_gx);
+      if (col >= g.N) return;
+      const float sg = s_g[cl], sgx = s_gx[cl];
+      const float zb = g.bn.zbias ? g.bn.zbias[col] : 0.f;
+      const float mu = g.bn.use_bn ? g.bn.mean[col] : 0.f, is = g.bn.use_bn ? g.bn.invstd[col] : 0.f;
+      const float ga = g.fu.gamma ? g.fu.gamma[col] : 1.f;
+      const float invB = 1.f / static_cast<float>(g.M);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+        if (row < g.M) {
+          float gr = acc[r];
+          if (g.bn.act == ER_ACT_RELU && !(py[r] > 0.f)) gr = 0.f;
+          if (g.bn.use_bn) {
+            const float xh = (pz[r] + zb - mu) * is;
+            gr = ga * is * (gr - sg * invB - xh * (sgx * invB));
+          }
+          g.C[static_cast<int64_t>(row) * g.ldc + col] = gr;
+        }
+      }
+      return;
+    }
+  }
   if (col >= g.N) return;
   float* Cz = g.C + (g.splits > 1 ? static_cast<int64_t>(bz) * g.M * g.N : 0);
   const int ldc = g.splits > 1 ? g.N : g.ldc;
@@ -649,6 +842,32 @@ int ensure_ws(size_t floats, float** out) {
   return 0;
 }
 
+// barrier words of the fused-BatchNorm epilogues: [kMaxColTiles][2], zero between launches
+constexpr int kMaxColTiles = 256;
+unsigned* g_bn_counters = nullptr;
+int g_num_cus = 0;
+
+int ensure_counters() {
+  if (!g_bn_counters) {
+    ER_CHECK_HIP(hipMalloc(&g_bn_counters, sizeof(unsigned) * 2 * kMaxColTiles));
+    ER_CHECK_HIP(hipMemset(g_bn_counters, 0, sizeof(unsigned) * 2 * kMaxColTiles));
+    int dev = 0;
+    hipDeviceProp_t prop;
+    ER_CHECK_HIP(hipGetDevice(&dev));
+    ER_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
+    g_num_cus = prop.multiProcessorCount;
+  }
+  return 0;
+}
+
+// The barrier needs every workgroup of the grid resident at once: 36 KB of LDS and 256 threads per workgroup leave
+// room for at least 2 per CU; stay at that.
+bool fused_bn_fits(int M, int N) {
+  if (!g_bn_counters || g_num_cus <= 0) return false;
+  const int64_t gx = er::ceil_div(N, er::BN), gy = er::ceil_div(M, er::BM);
+  return gx <= kMaxColTiles && 8 * er::ceil_div(gx * gy, 8) <= 2LL * g_num_cus;
+}
+
 template <bool BF16>
 int launch_gemm(int layout, er::GemmArgs& a, hipStream_t s) {
   const int64_t n_tiles = er::ceil_div(a.N, er::BN) * er::ceil_div(a.M, er::BM);
@@ -814,8 +1033,65 @@ extern "C" {
 
 int er_gemm_reserve(int64_t floats) {
   ER_REQUIRE(floats >= 0, "er_gemm_reserve: negative size");
+  if (int rc = ensure_counters()) return rc;  // (allocations are not capturable: both happen here)
   float* p;
   return ensure_ws(static_cast<size_t>(floats), &p);
+}
+
+int er_gemm_fused_bn_ok(int32_t M, int32_t N) { return fused_bn_fits(M, N) ? 1 : 0; }
+
+int er_gemm_f32_bn_fwd(int layout, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B,
+                       int32_t ldb, float* Z, int32_t ldz, const float* bias, float* col_stats, const float* gamma,
+                       const float* beta, float eps, float momentum, float* moving_mean, float* moving_var, int act,
+                       float* Y, int32_t ldy, float* save_mean, float* save_invstd, er_stream_t stream) {
+  ER_REQUIRE(A && B && Z && Y && col_stats && save_mean && save_invstd && ldy >= N, "er_gemm_f32_bn_fwd: bad arguments");
+  ER_REQUIRE(fused_bn_fits(M, N), "er_gemm_f32_bn_fwd: %d x %d outputs do not fit one co-resident grid (er_gemm_fused_bn_ok); "
+             "call er_gemm_reserve first", M, N);
+  ER_REQUIRE(layout >= ER_GEMM_NN && layout <= ER_GEMM_TN, "er_gemm_f32_bn_fwd: unknown layout %d", layout);
+  const int min_lda = (layout == ER_GEMM_TN) ? M : K;
+  const int min_ldb = (layout == ER_GEMM_NT) ? K : N;
+  ER_REQUIRE(lda >= min_lda && ldb >= min_ldb && ldz >= N, "er_gemm_f32_bn_fwd: leading dimension too small");
+  er::GemmArgs a;
+  a.A = A; a.B = B; a.C = Z; a.bias = bias;
+  a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldz;
+  a.accumulate = 0;
+  a.col_stats = col_stats;
+  a.splits = 1;
+  a.k_per_split = static_cast<int>(er::ceil_div(K, er::BK32)) * er::BK32;
+  a.fu.mode = 1;
+  a.fu.gamma = gamma; a.fu.beta = beta; a.fu.eps = eps; a.fu.momentum = momentum;
+  a.fu.moving_mean = moving_mean; a.fu.moving_var = moving_var;
+  a.fu.save_mean = save_mean; a.fu.save_invstd = save_invstd;
+  a.fu.y = Y; a.fu.ldy = ldy; a.fu.act = act;
+  a.fu.counters = g_bn_counters;
+  return launch_gemm<false>(layout, a, er::as_stream(stream));
+}
+
+int er_gemm_f32_bn_bwd_apply(int layout, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B,
+                             int32_t ldb, float* DZ, int32_t ldc, const float* z, const float* z_bias, const float* y,
+                             const float* save_mean, const float* save_invstd, int32_t ld_zy, int use_bn, int act,
+                             const float* gamma, float* partial, float* dgamma, float* dbeta, float* dbias,
+                             int accumulate, er_stream_t stream) {
+  ER_REQUIRE(A && B && DZ && z && y && partial && ld_zy >= N && ldc >= N, "er_gemm_f32_bn_bwd_apply: bad arguments");
+  ER_REQUIRE(!use_bn || (save_mean && save_invstd), "er_gemm_f32_bn_bwd_apply: BatchNorm statistics missing");
+  ER_REQUIRE(fused_bn_fits(M, N), "er_gemm_f32_bn_bwd_apply: %d x %d outputs do not fit one co-resident grid", M, N);
+  ER_REQUIRE(layout >= ER_GEMM_NN && layout <= ER_GEMM_TN, "er_gemm_f32_bn_bwd_apply: unknown layout %d", layout);
+  const int min_lda = (layout == ER_GEMM_TN) ? M : K;
+  const int min_ldb = (layout == ER_GEMM_NT) ? K : N;
+  ER_REQUIRE(lda >= min_lda && ldb >= min_ldb, "er_gemm_f32_bn_bwd_apply: leading dimension too small");
+  er::GemmArgs a;
+  a.A = A; a.B = B; a.C = DZ; a.bias = nullptr;
+  a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
+  a.accumulate = 0;
+  a.col_stats = nullptr;
+  a.splits = 1;
+  a.k_per_split = static_cast<int>(er::ceil_div(K, er::BK32)) * er::BK32;
+  a.bn.z = z; a.bn.zbias = z_bias; a.bn.y = y; a.bn.mean = save_mean; a.bn.invstd = save_invstd;
+  a.bn.ld = ld_zy; a.bn.use_bn = use_bn; a.bn.act = act; a.bn.partial = partial;
+  a.fu.mode = 2;
+  a.fu.gamma = gamma; a.fu.dgamma = dgamma; a.fu.dbeta = dbeta; a.fu.dbias = dbias; a.fu.accumulate = accumulate;
+  a.fu.counters = g_bn_counters;
+  return launch_gemm<false>(layout, a, er::as_stream(stream));
 }
 
 int er_gemm_f32(int layout, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B, int32_t ldb,

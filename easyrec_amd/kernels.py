@@ -78,12 +78,26 @@ class WgradSink(object):
 
 class BnSource(object):
   """What the dgrad GEMM of a consumer needs in order to emit, in its epilogue, the BatchNorm-backward column sums
-  of the layer that produced its input (HipBackend.gemm_bn_bwd): that layer's z, y and batch statistics."""
-  __slots__ = ('z', 'zbias', 'y', 'mean', 'invstd', 'act', 'partial', 'dx_ptr')
+  of the layer that produced its input (HipBackend.gemm_bn_bwd): that layer's z, y and batch statistics - or, when the
+  consumer is the ONLY reader of y (`exclusive`, set by the layer stacks for their inner layers), to finish that
+  layer's BatchNorm backward itself (HipBackend.gemm_bn_bwd_apply): then also gamma and the gradient buffers."""
+  __slots__ = ('z', 'zbias', 'y', 'mean', 'invstd', 'act', 'partial', 'dx_ptr', 'gamma', 'grad_bufs', 'exclusive',
+               'dz_ptr')
 
-  def __init__(self, z, zbias, y, mean, invstd, act):
+  def __init__(self, z, zbias, y, mean, invstd, act, gamma=None, grad_bufs=None):
     self.z, self.zbias, self.y, self.mean, self.invstd, self.act = z, zbias, y, mean, invstd, act
     self.partial, self.dx_ptr = None, 0
+    self.gamma, self.grad_bufs = gamma, grad_bufs  # grad_bufs = (gamma.grad, beta.grad) slices of the flat buffer
+    self.exclusive, self.dz_ptr = False, 0
+
+
+def mark_single_consumer(y):
+  """Promise that the NEXT dense layer is the only reader of y (the output of a fused dense + BatchNorm layer): its
+  dgrad GEMM may then finish this layer's BatchNorm backward in its epilogue and hand dz, not dy, to autograd."""
+  src = bn_source_of(y)
+  if src is not None:
+    src.exclusive = True
+  return y
 
 
 def tag_bn_source(y, src):
@@ -463,6 +477,51 @@ class HipBackend(object):
 
   # er_gemm_f32_bn_bwd / er_bn_act_bwd_from_partials are used (A/B switch: EASYREC_AMD_FUSED_BN_BWD=0)
   fused_bn_bwd = os.environ.get('EASYREC_AMD_FUSED_BN_BWD', '1') != '0'
+  # BatchNorm finished INSIDE the GEMM launch (er_gemm_f32_bn_fwd / er_gemm_f32_bn_bwd_apply); A/B switch
+  fused_bn_gemm = os.environ.get('EASYREC_AMD_FUSED_BN_GEMM', '1') != '0'
+
+  def gemm_fused_bn_ok(self, M, N):
+    return self.fused_bn_gemm and bool(self.lib.er_gemm_fused_bn_ok(ctypes.c_int32(int(M)), ctypes.c_int32(int(N))))
+
+  def gemm_bn_fwd(self, x, w, b, gamma, beta, eps, momentum, moving_mean, moving_var, act, y_out=None):
+    """One launch: z = x . w (+ b), batch statistics, y = act(BatchNorm(z)).  Returns (z, y, mean, invstd).
+    y_out: a [M, N] view (unit inner stride) to write y into, e.g. a column block of a wider buffer."""
+    (M, K), (K2, N) = x.shape, w.shape
+    assert K == K2 and x.stride(1) == 1 and w.stride(1) == 1
+    dev = x.device
+    z = torch.empty(M, N, dtype=torch.float32, device=dev)
+    y = torch.empty(M, N, dtype=torch.float32, device=dev) if y_out is None else y_out
+    assert y.shape == (M, N) and y.stride(1) == 1
+    stats = torch.empty(self.gemm_row_tiles(M) * N * 3, dtype=torch.float32, device=dev)
+    mean = torch.empty(N, dtype=torch.float32, device=dev)
+    invstd = torch.empty(N, dtype=torch.float32, device=dev)
+    self._ck(self.lib.er_gemm_f32_bn_fwd(ctypes.c_int(GEMM_NN), M, N, K, _p(x), ctypes.c_int32(x.stride(0)), _p(w),
+                                         ctypes.c_int32(w.stride(0)), _p(z), ctypes.c_int32(z.stride(0)), _p(b), _p(stats),
+                                         _p(gamma), _p(beta), ctypes.c_float(eps), ctypes.c_float(momentum),
+                                         _p(moving_mean), _p(moving_var), int(act), _p(y), ctypes.c_int32(y.stride(0)),
+                                         _p(mean), _p(invstd), _stream()), 'er_gemm_f32_bn_fwd')
+    return z, y, mean, invstd
+
+  def gemm_bn_bwd_apply(self, layout, a, b, src, accumulate=True):
+    """dgrad GEMM whose epilogue finishes the BatchNorm / activation backward of the layer described by `src`: returns
+    dz of THAT layer; its gamma / beta gradients go to src.grad_bufs."""
+    if layout == GEMM_NN:
+      (M, K), (K2, N) = a.shape, b.shape
+    elif layout == GEMM_NT:
+      (M, K), (N, K2) = a.shape, b.shape
+    else:
+      (K, M), (K2, N) = a.shape, b.shape
+    assert K == K2 and src.y.shape == (M, N) and src.z.shape == (M, N) and src.y.stride() == src.z.stride()
+    use_bn = src.mean is not None
+    dg, dbt = src.grad_bufs if src.grad_bufs is not None else (None, None)
+    partial = torch.empty(self.gemm_row_tiles(M) * N * 2, dtype=torch.float32, device=a.device)
+    out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    self._ck(self.lib.er_gemm_f32_bn_bwd_apply(
+        ctypes.c_int(layout), M, N, K, _p(a), ctypes.c_int32(a.stride(0)), _p(b), ctypes.c_int32(b.stride(0)), _p(out),
+        ctypes.c_int32(out.stride(0)), _p(src.z), _p(src.zbias), _p(src.y), _p(src.mean), _p(src.invstd),
+        ctypes.c_int32(src.y.stride(0)), int(use_bn), int(src.act), _p(src.gamma), _p(partial), _p(dg), _p(dbt), None,
+        int(bool(accumulate)), _stream()), 'er_gemm_f32_bn_bwd_apply')
+    return out
 
   def gemm_bn_bwd(self, layout, a, b, src, partial):
     """dgrad GEMM whose epilogue also emits the BatchNorm-backward column sums of the layer described by `src`
@@ -1073,6 +1132,11 @@ def _dgrad(be, dz, w, src, bf16, sink=None):
   if src is None:
     return be.gemm(GEMM_NT, dz, w, bf16=bf16)
   M, N = dz.shape[0], w.shape[0]
+  if src.exclusive and src.grad_bufs is not None and getattr(be, 'gemm_fused_bn_ok', None) and be.gemm_fused_bn_ok(M, N):
+    # this GEMM is the only reader of the producing layer's output: finish that layer's BatchNorm backward here
+    dx = be.gemm_bn_bwd_apply(GEMM_NT, dz, w, src)
+    src.dz_ptr = dx.data_ptr()
+    return dx
   partial = torch.empty(be.gemm_row_tiles(M) * N * 2, dtype=torch.float32, device=dz.device)
   dx = be.gemm_bn_bwd(GEMM_NT, dz, w, src, partial)
   src.partial, src.dx_ptr = partial, dx.data_ptr()
@@ -1092,18 +1156,23 @@ class LinearBNActFn(torch.autograd.Function):
     be = hip()
     x2 = x if x.stride(-1) == 1 else x.contiguous()
     M, N = x2.shape[0], w.shape[1]
-    chunks = be.gemm_row_tiles(M)
-    stats = torch.empty(chunks * N * 3, dtype=torch.float32, device=x2.device)
-    z = be.gemm(GEMM_NN, x2, w, bias=b, bf16=bf16, col_stats=stats)
-    y, mean, invstd = be.bn_apply_from_stats(z, None, stats, chunks, gamma, beta, eps, momentum, moving_mean,
-                                             moving_var, act)
+    if not bf16 and getattr(be, 'gemm_fused_bn_ok', None) and be.gemm_fused_bn_ok(M, N):
+      # ONE launch: GEMM, statistics, barrier, normalise + activation from registers
+      z, y, mean, invstd = be.gemm_bn_fwd(x2, w, b, gamma, beta, eps, momentum, moving_mean, moving_var, act)
+    else:
+      chunks = be.gemm_row_tiles(M)
+      stats = torch.empty(chunks * N * 3, dtype=torch.float32, device=x2.device)
+      z = be.gemm(GEMM_NN, x2, w, bias=b, bf16=bf16, col_stats=stats)
+      y, mean, invstd = be.bn_apply_from_stats(z, None, stats, chunks, gamma, beta, eps, momentum, moving_mean,
+                                               moving_var, act)
     ctx.save_for_backward(x2, w, gamma, z, y, mean, invstd)
     ctx.act, ctx.bf16, ctx.grad_bufs = act, bf16, grad_bufs
     ctx.sink = be.wgrad_sink()
     fused = not bf16 and getattr(be, 'fused_bn_bwd', False)
     ctx.src = src if (src is not None and x2 is x and fused) else None
     ctx.gsink = sink if x2 is x else None
-    ctx.own = BnSource(z, None, y, mean, invstd, act) if fused else None  # z already carries the bias
+    gb = None if grad_bufs is None else (grad_bufs[1], grad_bufs[2])
+    ctx.own = BnSource(z, None, y, mean, invstd, act, gamma, gb) if fused else None  # z already carries the bias
     _bn_tls.last = ctx.own
     return y
 
@@ -1115,13 +1184,22 @@ class LinearBNActFn(torch.autograd.Function):
     direct = gg is not None and betag is not None
     dyc = dy.contiguous()
     own, partial = ctx.own, None
-    if own is not None:
-      # the consumer's dgrad GEMM already reduced the column sums, provided dy is exactly its output
-      if own.partial is not None and dyc.data_ptr() == own.dx_ptr:
-        partial = own.partial
-      own.partial = None
-    dz, _, dgamma, dbeta = be.bn_act_bwd(z, None, gamma, y, mean, invstd, dyc, 1, ctx.act, False, True,
-                                         into=(None, gg, betag) if direct else None, partial=partial)
+    dgamma = dbeta = None
+    if own is not None and own.dz_ptr:
+      # the (single) consumer's dgrad GEMM finished this layer's BatchNorm backward: what arrives is dz
+      if dyc.data_ptr() != own.dz_ptr:
+        raise RuntimeError('easyrec_amd: the output of a fused dense + BatchNorm layer marked single-consumer '
+                           '(kernels.mark_single_consumer) reached a second consumer; set EASYREC_AMD_FUSED_BN_GEMM=0')
+      own.dz_ptr = 0
+      dz = dyc
+    else:
+      if own is not None:
+        # the consumer's dgrad GEMM already reduced the column sums, provided dy is exactly its output
+        if own.partial is not None and dyc.data_ptr() == own.dx_ptr:
+          partial = own.partial
+        own.partial = None
+      dz, _, dgamma, dbeta = be.bn_act_bwd(z, None, gamma, y, mean, invstd, dyc, 1, ctx.act, False, True,
+                                           into=(None, gg, betag) if direct else None, partial=partial)
     dx = dw = None
     if ctx.needs_input_grad[0]:
       dx = _dgrad(be, dz, w, ctx.src, ctx.bf16, ctx.gsink)

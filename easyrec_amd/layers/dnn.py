@@ -139,6 +139,8 @@ class DNN(object):
       use_act = (i + 1 < hidden_units_len) or not self._last_layer_no_activation
       fuse_relu = use_act and is_relu(self._act_string)
       deep_fea = dense_bn_act(deep_fea, unit, layer, self._l2_reg, True, use_bn, fuse_relu, self._is_training)
+      if i + 1 < hidden_units_len and not hidden_layer_feature_output:
+        kernels.mark_single_consumer(deep_fea)  # (the next layer's GEMM is its only reader, unless replaced below)
       if use_act and not fuse_relu and self.activation is not None:
         deep_fea = self.activation(deep_fea, name='%s/dnn_%d/act' % (self._name, i))
       if len(self.dropout_ratio) > 0 and self._is_training:

@@ -59,7 +59,7 @@ class DeepFM(RankModel):
     if len(self._model_config.final_dnn.hidden_units) > 0:
       all_fea = torch.cat([wide_fea, fm_fea, deep_fea], dim=1)
       final_dnn_layer = dnn.DNN(self._model_config.final_dnn, self._l2_reg, 'final_dnn', self._is_training)
-      all_fea = final_dnn_layer(all_fea)
+      all_fea = kernels.mark_single_consumer(final_dnn_layer(all_fea))  # read by the `output` projection alone
       output = dnn.dense(all_fea, self._num_class, 'output', l2_reg=self._l2_reg)
     else:
       fm_sum = fm_fea.sum(dim=1, keepdim=True)

@@ -437,6 +437,27 @@ int er_gemm_f32_bn_bwd(int layout, int32_t M, int32_t N, int32_t K, const float*
                        int32_t ldb, float* C, int32_t ldc, const float* z, const float* z_bias, const float* y,
                        const float* save_mean, const float* save_invstd, int32_t ld_zy, int use_bn, int act,
                        float* partial, er_stream_t stream);
+/* dense + BatchNorm(train) + activation of one DNN layer in ONE launch (reference layers/dnn.py:57-79: MatMul, BiasAdd,
+ * FusedBatchNorm / moments, Relu): the GEMM's workgroups publish per-row-tile column statistics (col_stats scratch,
+ * er_gemm_row_tiles(M) * N * 3 floats), meet at a barrier per column of tiles, finalise the statistics (same order
+ * as er_bn_apply_from_stats: bit-identical results) and write Z = A.B + bias (kept for the backward) and
+ * Y = act(gamma * (Z - mean) * invstd + beta) from registers; save_mean / save_invstd [N] and the moving statistics
+ * (NULL: untouched) as er_bn_act_fwd.  The grid must be co-resident: er_gemm_fused_bn_ok(M, N) != 0 (after
+ * er_gemm_reserve), else use er_gemm_f32 + er_bn_apply_from_stats.
+ * er_gemm_f32_bn_bwd_apply: the dgrad GEMM DY = A.B (as er_gemm_f32_bn_bwd) that goes on, after the same kind of
+ * barrier, to the BatchNorm / activation backward of the layer that produced its output's forward value (z, y, mean,
+ * invstd, gamma): DZ is written instead of DY, dgamma / dbeta (or dbias without BatchNorm; any may be NULL) are
+ * written or accumulated.  Replaces er_gemm_f32_bn_bwd + er_bn_act_bwd_from_partials, bit-identically. */
+int er_gemm_fused_bn_ok(int32_t M, int32_t N);
+int er_gemm_f32_bn_fwd(int layout, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B,
+                       int32_t ldb, float* Z, int32_t ldz, const float* bias, float* col_stats, const float* gamma,
+                       const float* beta, float eps, float momentum, float* moving_mean, float* moving_var, int act,
+                       float* Y, int32_t ldy, float* save_mean, float* save_invstd, er_stream_t stream);
+int er_gemm_f32_bn_bwd_apply(int layout, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B,
+                             int32_t ldb, float* DZ, int32_t ldc, const float* z, const float* z_bias, const float* y,
+                             const float* save_mean, const float* save_invstd, int32_t ld_zy, int use_bn, int act,
+                             const float* gamma, float* partial, float* dgamma, float* dbeta, float* dbias,
+                             int accumulate, er_stream_t stream);
 /* Grouped launch: n independent fp32 problems of ONE layout in one grid (+ one grid for their split-K reduces).
  * The use: the weight gradients dW_l = x_l^T . dz_l of every dense layer of a step (reference: the MatMul
  * gradients TF schedules for layers/dnn.py:57-62, one per layer) - each a small M x N with K = batch - queued

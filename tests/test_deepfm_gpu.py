@@ -230,9 +230,9 @@ def test_full_size_losses_match_oracle():
     tol = 1e-4 if step < 2 else 5e-4
     for k in exp:
       assert abs(got[k] - exp[k]) <= tol * max(1e-3, abs(exp[k])), (step, k, got[k], exp[k])
-    if step == 1:
+    if step == 0:  # from identical parameters
       logits = est.model._prediction_dict['logits'].detach().cpu().numpy()
-      assert np.allclose(logits, orc.last_pred['logits'], rtol=1e-4, atol=2e-5)
+      assert np.allclose(logits, orc.last_pred['logits'], rtol=1e-4, atol=1e-5)
 
 
 def _idle_schedule(cfg, feature_configs, B, n_idle):
@@ -247,14 +247,11 @@ def _idle_schedule(cfg, feature_configs, B, n_idle):
 
 
 def _assert_lazy_equals_sweep(lazy_state, sweep_state):
+  """EVERY bit of every variable and slot: with the rolling flush no row is ever behind by more than its window, so
+  the closed-form tail of v (the one documented deviation, for backlogs > 2048 steps) is never taken."""
   n = 0
   for k, ref in sweep_state.items():
-    got = lazy_state[k]
-    if k.endswith('/v') and 'embedding_weights' in k:
-      # rows idle for > ~900 steps: v *= beta2^k in closed form instead of k roundings (<= 1e-6 relative, documented)
-      assert np.allclose(got, ref, rtol=2e-6, atol=0.0), k
-    else:
-      assert np.array_equal(got, ref), k
+    assert np.array_equal(lazy_state[k], ref), k
     n += 1
   assert n > 100
 
@@ -263,7 +260,7 @@ def test_lazy_decay_equals_sweep_model_level():
   """EasyRecEstimator(dense_sweep=False) (the default: TF-exact Adam's every-row decay replayed lazily, the headline
   path) against dense_sweep=True (every row streamed every step) over 1300 steps with rows idle for > 1200 steps,
   through the whole model (shared sort of the wide / deep groups, er_emb_catch_up_multi, er_emb_flush_decay): after the
-  flush var and m of every table are BIT-equal, v within 1e-6 relative, and so is every dense variable."""
+  flush var, m and v of every table and every dense variable are BIT-equal, and so are the losses on the way."""
   cfg = _cfg('deepfm_criteo_small.config')
   B = 64
   ests = [EasyRecEstimator(cfg, device=DEV, batch_size=B, seed=9, dense_sweep=ds).build() for ds in (False, True)]
@@ -297,7 +294,37 @@ def test_evaluate_does_not_disturb_training():
       assert m1 == m2, (m1, m2)
   sa, sb = a.state_dict(slots=True), b.state_dict(slots=True)
   for k in sa:
-    if k.endswith('/v') and 'embedding_weights' in k:
-      assert np.allclose(sa[k], sb[k], rtol=2e-6, atol=0.0), k
-    else:
-      assert np.array_equal(sa[k], sb[k]), k
+    assert np.array_equal(sa[k], sb[k]), k
+
+
+def test_fused_batchnorm_gemms_change_no_bit():
+  """The whole DeepFM step with BatchNorm finished inside the GEMM launches (forward normalise + ReLU, backward dz of
+  the producing layer) against the two-launch forms: states and losses bit for bit, eager and as a replayed graph."""
+  cfg = _cfg('deepfm_criteo_small.config')
+  B = 512
+  be = kernels.hip()
+  gen = SyntheticCriteo(cfg.data_config, list(cfg.feature_config.features), batch_size=B, seed=6)
+  batches = [gen.next_batch() for _ in range(5)]
+  states = []
+  saved = be.fused_bn_gemm
+  try:
+    for fused, graph in ((False, False), (True, False), (True, True)):
+      be.fused_bn_gemm = fused
+      est = EasyRecEstimator(cfg, device=DEV, batch_size=B, seed=2).build()
+      assert be.gemm_fused_bn_ok(B, 256) == fused
+      est.features.load(batches[0])
+      if graph:
+        est.capture(warmup=1)
+      else:
+        est.train_step()
+      losses = []
+      for bt in batches[1:]:
+        est.train_step(bt)
+        losses.append(est.loss_values())
+      states.append((est.state_dict(slots=True), losses))
+  finally:
+    be.fused_bn_gemm = saved
+  for st, losses in states[1:]:
+    assert losses == states[0][1]
+    for k in states[0][0]:
+      assert np.array_equal(st[k], states[0][0][k]), k

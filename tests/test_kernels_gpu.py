@@ -592,6 +592,47 @@ def test_gemm_epilogue_statistics_feed_batchnorm(hip, M, N, K, bf16):
   assert torch.allclose(mv.cpu().double(), 0.99 + 0.01 * var, rtol=1e-4, atol=1e-6)
 
 
+@pytest.mark.parametrize('M,N,K', [(4096, 256, 624), (4096, 128, 256), (4096, 64, 128), (1000, 70, 33), (8192, 256, 81)])
+def test_batchnorm_fused_into_the_gemm_launch(hip, M, N, K):
+  """er_gemm_f32_bn_fwd / er_gemm_f32_bn_bwd_apply (statistics, a barrier among the row tiles of a column of tiles,
+  BatchNorm from registers - ONE launch) against the two-launch forms they replace: every output bit for bit,
+  repeated launches included (the barrier words reset themselves)."""
+  hip.gemm_reserve(1 << 20)
+  assert hip.gemm_fused_bn_ok(M, N)
+  g = torch.Generator().manual_seed(M + N + K)
+  x, w = torch.randn(M, K, generator=g).to(DEV), (torch.randn(K, N, generator=g) * 0.1).to(DEV)
+  bias, gamma, beta = torch.randn(N, generator=g).to(DEV), (torch.rand(N, generator=g) + 0.5).to(DEV), torch.randn(N, generator=g).to(DEV)
+  chunks = hip.gemm_row_tiles(M)
+  for rep in range(3):
+    mm_a, mv_a = torch.zeros(N, device=DEV), torch.ones(N, device=DEV)
+    mm_b, mv_b = torch.zeros(N, device=DEV), torch.ones(N, device=DEV)
+    stats = torch.zeros(chunks * N * 3, device=DEV)
+    z_a = hip.gemm(kernels.GEMM_NN, x, w, bias=bias, col_stats=stats)
+    y_a, mean_a, inv_a = hip.bn_apply_from_stats(z_a, None, stats, chunks, gamma, beta, 1e-3, 0.99, mm_a, mv_a, kernels.ACT_RELU)
+    z_b, y_b, mean_b, inv_b = hip.gemm_bn_fwd(x, w, bias, gamma, beta, 1e-3, 0.99, mm_b, mv_b, kernels.ACT_RELU)
+    torch.cuda.synchronize()
+    for a, b, what in ((z_a, z_b, 'z'), (y_a, y_b, 'y'), (mean_a, mean_b, 'mean'), (inv_a, inv_b, 'invstd'),
+                       (mm_a, mm_b, 'moving_mean'), (mv_a, mv_b, 'moving_variance')):
+      assert torch.equal(a, b), (rep, what)
+  # backward: the dgrad GEMM of a consumer layer [M, N] <- dz_next [M, K2] . w_next^T [K2, N] finishing THIS layer's BatchNorm
+  K2 = 96
+  dz_next = (torch.randn(M, K2, generator=g) * 0.01).to(DEV)
+  w_next = (torch.randn(N, K2, generator=g) * 0.1).to(DEV)
+  src = kernels.BnSource(z_b, None, y_b, mean_b, inv_b, kernels.ACT_RELU, gamma, None)
+  for rep in range(2):
+    dg_a, db_a = torch.full((N,), 0.25, device=DEV), torch.full((N,), -0.5, device=DEV)
+    dg_b, db_b = dg_a.clone(), db_a.clone()
+    partial = torch.zeros(chunks * N * 2, device=DEV)
+    dy = hip.gemm_bn_bwd(kernels.GEMM_NT, dz_next, w_next, src, partial)
+    dz_a, _, _, _ = hip.bn_act_bwd(z_b, None, gamma, y_b, mean_b, inv_b, dy, 1, kernels.ACT_RELU, False, True,
+                                   into=(None, dg_a, db_a), partial=partial)
+    src.grad_bufs = (dg_b, db_b)
+    dz_b = hip.gemm_bn_bwd_apply(kernels.GEMM_NT, dz_next, w_next, src)
+    torch.cuda.synchronize()
+    assert torch.equal(dz_a, dz_b), rep
+    assert torch.equal(dg_a, dg_b) and torch.equal(db_a, db_b), rep
+
+
 def test_lazy_dense_decay_equals_the_sweep(hip):
   """TF-exact Adam two ways over 1300 steps on one table: (A) the streaming sweep of every row every step,
   (B) lazy dense decay (er_emb_route -> er_emb_catch_up -> touched-row update, er_emb_flush_decay at the end).
@@ -653,7 +694,10 @@ def test_lazy_dense_decay_equals_the_sweep(hip):
     assert torch.equal(ma, mb), (mode, 'first moments must be bit-identical')
     assert torch.equal(va[hot], vb[hot]) and torch.equal(sa[hot], sb[hot]), (mode, 'recently touched rows: every bit')
     assert torch.equal(va, vb), (mode, 'var: every bit, through the full, the absorbed and the settled regime')
-    assert torch.allclose(sa, sb, rtol=1e-5, atol=0.0), mode
+    if mode == 'lazy_roll':  # never more than 16 steps behind: v decays step by step too
+      assert torch.equal(sa, sb), mode
+    else:  # one catch-up of > 1200 steps at the flush: the closed-form tail of v (backlog > 2048: no; <= 2048: exact)
+      assert torch.equal(sa, sb), mode
 
 
 @pytest.mark.parametrize('sizes', [(100, 4096, 5000, 8192, 257), (1, 2, 3), (4097,), (8192, 8192), (9000, 50),
