@@ -508,6 +508,38 @@ __global__ void total_loss_kernel(const float* __restrict__ reg_emb, const float
   total_out[0] = total;
 }
 
+// The scalar tail of the loss in ONE launch (one workgroup of 1024): regularization_loss = emb_scale * sum(partials)
+// [the embedding-output L2: per-block sums of squares left by er_emb_fwd] + sum_i 0.5 * coef[i] * w[i]^2 [the kernels'
+// L2], total_loss = regularization_loss + sum of the task losses, and the copies of the task losses into their report
+// slots.  Replaces er_reduce_sum + er_l2_loss (two launches) + er_total_loss.  Fixed order: deterministic.
+__global__ void __launch_bounds__(kCeBlock)
+reg_total_loss_kernel(const float* __restrict__ emb_partials, int n_partials, float emb_scale,
+                      const float* __restrict__ w, const float* __restrict__ coef, int64_t n, LossPtrs lp, int n_losses,
+                      float* __restrict__ reg_out, float* __restrict__ total_out) {
+  __shared__ float red[kCeBlock / 64];
+  float a = 0.f;
+  for (int i = threadIdx.x; i < n_partials; i += kCeBlock) a = a + emb_partials[i];
+  const float emb = block_sum_1024(a, red);
+  float b = 0.f;
+  if (w && coef) {
+    for (int64_t i = threadIdx.x; i < n; i += kCeBlock) {
+      const float c = coef[i];
+      if (c != 0.f) b = b + c * (0.5f * (w[i] * w[i]));
+    }
+  }
+  const float dense = block_sum_1024(b, red);
+  if (threadIdx.x != 0) return;
+  const float reg = emb_scale * emb + dense;
+  reg_out[0] = reg;
+  float total = reg;
+  for (int i = 0; i < n_losses; ++i) {
+    const float v = lp.src[i][0];
+    if (lp.dst[i]) lp.dst[i][0] = v;
+    total = total + v;
+  }
+  total_out[0] = total;
+}
+
 __global__ void __launch_bounds__(kBlock)
 reduce_sum_kernel(const float* __restrict__ p, int n, float scale, float* __restrict__ out, int accumulate) {
   __shared__ float red[4];
@@ -566,9 +598,16 @@ dense_opt_kernel(float* __restrict__ w, float* __restrict__ m, float* __restrict
 }
 
 // per-step scalars: out[:] = table[counter % n_slots][:]; counter += 1   (one block)
+// (+ blocks > 0, and block 0 after its own work: zero `zero_n` floats at `zero` - the flat gradient buffer of the dense
+// variables - so that the step's prologue is one launch instead of this one plus a fill)
 __global__ void hyper_select_kernel(const float* __restrict__ table, int64_t* __restrict__ counter, int n_slots,
                                     int floats_per_slot, float* __restrict__ out, float* __restrict__ hist,
-                                    int64_t hist_capacity, int hist_index) {
+                                    int64_t hist_capacity, int hist_index, float* __restrict__ zero, int64_t zero_n) {
+  if (zero) {
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < zero_n; i += stride) zero[i] = 0.f;
+  }
+  if (blockIdx.x != 0) return;
   const int64_t c = *counter;
   const int64_t slot = c % n_slots;
   for (int i = threadIdx.x; i < floats_per_slot; i += blockDim.x) out[i] = table[slot * floats_per_slot + i];
@@ -819,11 +858,38 @@ int er_l2_loss(const float* w, const float* coef, int64_t n, float* out, int acc
 
 int er_hyper_select(const float* table, int64_t* counter, int32_t n_slots, int32_t floats_per_slot, float* out,
                     float* history, int64_t history_capacity, int32_t history_index, er_stream_t stream) {
-  ER_REQUIRE(table && counter && out && n_slots > 0 && floats_per_slot > 0, "er_hyper_select: bad arguments");
+  return er_step_prologue(table, counter, n_slots, floats_per_slot, out, history, history_capacity, history_index, nullptr,
+                          0, stream);
+}
+
+int er_step_prologue(const float* table, int64_t* counter, int32_t n_slots, int32_t floats_per_slot, float* out,
+                     float* history, int64_t history_capacity, int32_t history_index, float* zero, int64_t zero_floats,
+                     er_stream_t stream) {
+  ER_REQUIRE(table && counter && out && n_slots > 0 && floats_per_slot > 0, "er_step_prologue: bad arguments");
   ER_REQUIRE(!history || (history_index >= 0 && history_index < floats_per_slot && history_capacity > 0),
-             "er_hyper_select: bad history arguments");
-  hipLaunchKernelGGL(er::hyper_select_kernel, dim3(1), dim3(64), 0, er::as_stream(stream), table, counter, n_slots,
-                     floats_per_slot, out, history, history_capacity, history_index);
+             "er_step_prologue: bad history arguments");
+  ER_REQUIRE(zero_floats >= 0 && (zero || zero_floats == 0), "er_step_prologue: bad zero arguments");
+  int64_t blocks = zero ? er::ceil_div(zero_floats, 256 * 8) : 1;
+  if (blocks > 512) blocks = 512;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(er::hyper_select_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, er::as_stream(stream), table,
+                     counter, n_slots, floats_per_slot, out, history, history_capacity, history_index, zero, zero_floats);
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
+int er_reg_total_loss(const float* emb_partials, int32_t n_partials, float emb_scale, const float* w, const float* coef,
+                      int64_t n, const float* const* losses, float* const* report, int32_t n_losses, float* reg_out,
+                      float* total_out, er_stream_t stream) {
+  ER_REQUIRE(reg_out && total_out && n_losses >= 0 && n_losses <= 8 && n_partials >= 0 && (emb_partials || n_partials == 0),
+             "er_reg_total_loss: bad arguments (at most 8 losses)");
+  er::LossPtrs lp;
+  for (int i = 0; i < 8; ++i) {
+    lp.src[i] = i < n_losses ? losses[i] : nullptr;
+    lp.dst[i] = (i < n_losses && report) ? report[i] : nullptr;
+  }
+  hipLaunchKernelGGL(er::reg_total_loss_kernel, dim3(1), dim3(er::kCeBlock), 0, er::as_stream(stream), emb_partials,
+                     n_partials, emb_scale, w, coef, n, lp, n_losses, reg_out, total_out);
   ER_LAUNCH_CHECK();
   return 0;
 }

@@ -138,6 +138,17 @@ __device__ __forceinline__ bool tile_coords(int b, int gx, int gy, int& tx, int&
   return true;
 }
 
+// Values that cross workgroups INSIDE a launch (the per-row-tile partials of the fused epilogues) are stored and
+// loaded as relaxed agent-scope atomics: on gfx950 these go through to the memory side (sc1) instead of sitting in
+// the issuing XCD's L2, so no cache-wide writeback / invalidate (a release / acquire FENCE at agent scope costs about
+// as much as the kernel boundary the fusion is meant to save - measured: 27 us per fused launch with fences).
+__device__ __forceinline__ void st_agent(float* p, float v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float ld_agent(const float* p) {
+  return __hip_atomic_load(const_cast<float*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // Per-row-tile column statistics of the OUTPUT (value = acc + bias), for a following BatchNorm: removes the
 // separate statistics pass over the GEMM output.  A lane holds 16 rows of one column; lanes l and l^32 hold the
 // other 16 rows; the two waves with wm = 0 / 1 cover the tile's 64 rows.  Welford/Chan merges in a fixed order.
@@ -153,7 +164,8 @@ __device__ __forceinline__ void chan_merge(float& n, float& mean, float& m2, flo
 
 __device__ __forceinline__ void tile_col_stats(const f32x16& acc, float bv, int row_base, int M, int col, int N, int wm,
                                                int wn, int lane, float* lds /* >= 2*32*3 floats */,
-                                               float* __restrict__ out_tile /* [N][3] of this row tile */) {
+                                               float* __restrict__ out_tile /* [N][3] of this row tile */,
+                                               bool coherent = false /* read by other workgroups of THIS launch */) {
   const int khalf = lane >> 5;
   float n = 0.f, s = 0.f;
 #pragma unroll
@@ -179,7 +191,8 @@ __device__ __forceinline__ void tile_col_stats(const f32x16& acc, float bv, int 
   if (wm == 0 && khalf == 0 && col < N) {
     chan_merge(an, am, a2, slot[0], slot[1], slot[2]);
     float* o = out_tile + static_cast<int64_t>(col) * 3;
-    o[0] = an; o[1] = am; o[2] = a2;
+    if (coherent) { st_agent(o, an); st_agent(o + 1, am); st_agent(o + 2, a2); }
+    else { o[0] = an; o[1] = am; o[2] = a2; }
   }
 }
 
@@ -187,7 +200,7 @@ __device__ __forceinline__ void tile_col_stats(const f32x16& acc, float bv, int 
 // register order, then the lane pair (l, l ^ 32), then the two waves that share the columns.
 __device__ __forceinline__ void tile_bn_bwd_partial(const f32x16& acc, const BnBwdEpi& e, const float (&py)[16],
                                                     const float (&pz)[16], int row_base, int M, int col, int N, int wm,
-                                                    int wn, int lane, float* lds, int ty) {
+                                                    int wn, int lane, float* lds, int ty, bool coherent = false) {
   const int khalf = lane >> 5;
   float sg = 0.f, sgx = 0.f;
   if (col < N) {
@@ -214,28 +227,29 @@ __device__ __forceinline__ void tile_bn_bwd_partial(const f32x16& acc, const BnB
   __syncthreads();
   if (wm == 0 && khalf == 0 && col < N) {
     float* p = e.partial + (static_cast<int64_t>(ty) * N + col) * 2;
-    p[0] = a + slot[0];
-    p[1] = ax + slot[1];
+    if (coherent) { st_agent(p, a + slot[0]); st_agent(p + 1, ax + slot[1]); }
+    else { p[0] = a + slot[0]; p[1] = ax + slot[1]; }
   }
 }
 
 // Barrier among the `n` workgroups that share a column of tiles.  c[0]: arrivals, c[1]: departures; the last workgroup
 // to leave zeroes both (every other one has left the spin by then), so the words are zero again for the next launch.
-// Release / acquire at agent scope: the partial statistics cross XCDs (separate L2s).
+// No fences: the data the barrier orders is written with st_agent and read with ld_agent only; a writer waits for
+// its stores to be acknowledged (s_waitcnt vmcnt(0): stores count in vmcnt on gfx9) before the workgroup's arrival
+// is counted, a reader issues its loads after the spin has seen every arrival (in-order issue + the barrier).
 __device__ __forceinline__ void tile_column_barrier(unsigned* c, unsigned n) {
-  __threadfence();  // this thread's stores to the partial buffer
+  __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) expcnt(0) lgkmcnt(0): this wave's partial stores have completed
   __syncthreads();
   if (threadIdx.x == 0) {
-    __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    while (__hip_atomic_load(c, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < n) __builtin_amdgcn_s_sleep(1);
-    const unsigned gone = __hip_atomic_fetch_add(c + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    if (gone == n - 1) {
+    __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n) __builtin_amdgcn_s_sleep(1);
+    const unsigned gone = __hip_atomic_fetch_add(c + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (gone == n - 1) {  // everyone has left the spin: zero the words for the next launch
       __hip_atomic_store(c + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(c, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
   __syncthreads();
-  __threadfence();  // every wave: later loads must not be served from lines cached before the barrier
 }
 
 // Forward: finalise the statistics of the tile's 64 columns from the per-row-tile Welford partials (thread (cl, rl)
@@ -258,7 +272,7 @@ __device__ __forceinline__ void fused_bn_fwd_finalize(const GemmArgs& g, int n0,
         const int k = k0 + j * 4;
         if (k < gy) {
           const float* p = g.col_stats + (static_cast<int64_t>(k) * g.N + c) * 3;
-          w[j][0] = p[0]; w[j][1] = p[1]; w[j][2] = p[2];
+          w[j][0] = ld_agent(p); w[j][1] = ld_agent(p + 1); w[j][2] = ld_agent(p + 2);
         } else {
           w[j][0] = 0.f; w[j][1] = 0.f; w[j][2] = 0.f;
         }
@@ -312,8 +326,8 @@ __device__ __forceinline__ void fused_bn_bwd_finalize(const GemmArgs& g, int n0,
 #pragma unroll 8
     for (int k = rl; k < gy; k += 4) {
       const float* p = g.bn.partial + (static_cast<int64_t>(k) * g.N + c) * 2;
-      a = a + p[0];
-      b = b + p[1];
+      a = a + ld_agent(p);
+      b = b + ld_agent(p + 1);
     }
   }
   sm[rl * 64 + cl] = a;
@@ -567,8 +581,8 @@ __device__ __forceinline__ void gemm_f32_block(const GemmArgs& g, int bx, int bz
   const float bv = (g.bias && g.splits == 1 && col < g.N) ? g.bias[col] : 0.f;
   if (g.col_stats)  // (host guarantees splits == 1) every thread takes part: it synchronises the workgroup
     tile_col_stats(acc, bv, m0 + wm * 32, g.M, col, g.N, wm, wn, lane, lds,
-                   g.col_stats + static_cast<int64_t>(ty) * g.N * 3);
-  if (BN_EPI) tile_bn_bwd_partial(acc, g.bn, py, pz, m0 + wm * 32, g.M, col, g.N, wm, wn, lane, lds, ty);
+                   g.col_stats + static_cast<int64_t>(ty) * g.N * 3, g.fu.mode == 1);
+  if (BN_EPI) tile_bn_bwd_partial(acc, g.bn, py, pz, m0 + wm * 32, g.M, col, g.N, wm, wn, lane, lds, ty, g.fu.mode == 2);
   if (g.fu.mode != 0) {  // (uniform over the grid; host guarantees splits == 1 and a co-resident grid)
     const int gy = static_cast<int>(ceil_div(g.M, BM));
     tile_column_barrier(g.fu.counters + 2 * tx, static_cast<unsigned>(gy));

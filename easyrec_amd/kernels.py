@@ -477,8 +477,12 @@ class HipBackend(object):
 
   # er_gemm_f32_bn_bwd / er_bn_act_bwd_from_partials are used (A/B switch: EASYREC_AMD_FUSED_BN_BWD=0)
   fused_bn_bwd = os.environ.get('EASYREC_AMD_FUSED_BN_BWD', '1') != '0'
-  # BatchNorm finished INSIDE the GEMM launch (er_gemm_f32_bn_fwd / er_gemm_f32_bn_bwd_apply); A/B switch
-  fused_bn_gemm = os.environ.get('EASYREC_AMD_FUSED_BN_GEMM', '1') != '0'
+  # BatchNorm finished INSIDE the GEMM launch (er_gemm_f32_bn_fwd / er_gemm_f32_bn_bwd_apply): bit-identical, 10 launches
+  # fewer per DeepFM step - and SLOWER: the barrier among a column's row tiles crosses XCDs, i.e. goes through
+  # memory-side atomics at ~2 us a hop (stats out, arrive, spin, partials back in), which costs what the kernel
+  # boundary it replaces costs.  Same box, 300 steps: 0.592 / 0.597 ms fused vs 0.561 / 0.565 two-launch (with
+  # agent-scope fences instead of sc1 atomics: 0.788).  OFF by default; kept as an A/B switch and for its tests.
+  fused_bn_gemm = os.environ.get('EASYREC_AMD_FUSED_BN_GEMM', '0') != '0'
 
   def gemm_fused_bn_ok(self, M, N):
     return self.fused_bn_gemm and bool(self.lib.er_gemm_fused_bn_ok(ctypes.c_int32(int(M)), ctypes.c_int32(int(N))))
@@ -947,6 +951,19 @@ class HipBackend(object):
     self._ck(self.lib.er_total_loss(_p(reg_emb), _p(reg_dense), src, dst, n, _p(reg_out), _p(total_out), _stream()),
              'er_total_loss')
 
+  def reg_total_loss(self, emb_partials, emb_scale, w, coef, losses, reports, reg_out, total_out):
+    """reg_out = emb_scale * sum(emb_partials) + sum 0.5 * coef * w^2; total_out = reg_out + sum(losses); reports[i] =
+    losses[i].  emb_partials / (w, coef) may be None.  One launch (er_reg_total_loss)."""
+    n = len(losses)
+    assert n <= 8
+    src = (ctypes.c_void_p * max(n, 1))(*[t.data_ptr() for t in losses])
+    dst = (ctypes.c_void_p * max(n, 1))(*[t.data_ptr() for t in reports])
+    n_part = 0 if emb_partials is None else emb_partials.numel()
+    n_w = 0 if (w is None or coef is None) else w.numel()
+    self._ck(self.lib.er_reg_total_loss(_p(emb_partials), ctypes.c_int32(n_part), ctypes.c_float(emb_scale),
+                                        _p(w) if n_w else None, _p(coef) if n_w else None, ctypes.c_int64(n_w), src, dst,
+                                        ctypes.c_int32(n), _p(reg_out), _p(total_out), _stream()), 'er_reg_total_loss')
+
   def reduce_sum(self, partials, scale, out, accumulate=False):
     self._ck(
         self.lib.er_reduce_sum(_p(partials), partials.numel(), ctypes.c_float(scale), _p(out), int(accumulate),
@@ -984,6 +1001,16 @@ class HipBackend(object):
     self._ck(self.lib.er_hyper_select(_p(table), _p(counter), n_slots, table[0].numel(), _p(out), _p(history),
                                       ctypes.c_int64(cap), ctypes.c_int32(history_index), _stream()),
              'er_hyper_select')
+
+  def step_prologue(self, table, counter, out, history=None, zero=None, history_index=HYPER_LR_T):
+    """hyper_select + zeroing of `zero` (the flat gradient buffer) in one launch."""
+    n_slots = table.shape[0]
+    cap = 0 if history is None else history.numel() // 2
+    nz = 0 if zero is None else zero.numel()
+    assert zero is None or (zero.dtype == torch.float32 and zero.is_contiguous())
+    self._ck(self.lib.er_step_prologue(_p(table), _p(counter), n_slots, table[0].numel(), _p(out), _p(history),
+                                       ctypes.c_int64(cap), ctypes.c_int32(history_index), _p(zero), ctypes.c_int64(nz),
+                                       _stream()), 'er_step_prologue')
 
   # -- TF-exact Adam without the sweep (lazy dense decay)
   def emb_group_enable_lazy_decay(self, group, last_step, lr_hist, step_counter):

@@ -213,25 +213,17 @@ class EasyRecEstimator(object):
   def _device_step(self):
     """Everything that runs on the GPU for one batch (graph-capturable)."""
     be = kernels.hip()
-    be.hyper_select(self.hyper_table, self.step_counter, self.hyper, history=self.lr_hist)
+    # prologue, one launch: this step's optimizer scalars (device-side step counter) + the flat gradient buffer zeroed
+    be.step_prologue(self.hyper_table, self.step_counter, self.hyper, history=self.lr_hist,
+                     zero=self.varstore.flat_grad_all)
     self.features.transform()
     if self.is_training and self.overlap_sweep and self.opt_emb.kind == kernels.OPT_ADAM:
       self.engine.start_decay_sweep(self.hyper[0])
-    self.varstore.zero_grad()
     with context.use(self.ctx):
       self.model.begin_step()
       self.model.build_predict_graph()
       loss_dict = self.model.build_loss_graph()
-      # regularisation losses (estimator :166-184)
-      self.engine.regularization_loss(self._reg_emb)
-      if self.varstore.any_l2:
-        be.l2_loss(self.varstore.flat, self.varstore.l2coef, self._reg_dense)
-      names = list(loss_dict.keys())  # (_reg_dense stays 0 when no kernel carries an L2 coefficient)
-      for name in names:
-        if name not in self.losses:
-          self.losses[name] = torch.zeros(1, dtype=torch.float32, device=self.device)
-      be.total_loss(self._reg_emb, self._reg_dense, [loss_dict[n].reshape(1) for n in names],
-                    [self.losses[n] for n in names], self.losses['regularization_loss'], self.losses['total_loss'])
+      self._loss_tail(loss_dict)
       if self.is_training:
         vs = self.varstore
         if self.overlap_dense_update and self.device.type == 'cuda' and self.clip_norm <= 0:
@@ -278,6 +270,19 @@ class EasyRecEstimator(object):
     be.clip_scale(self._normsq, self.clip_norm, self.hyper, self.grad_norm)
     self.engine.apply_reduced(self.opt_emb.kind, self.hyper[0])
     be.dense_opt_step(vs.flat, vs.slots.get('m'), vs.slots.get('v'), vs.flat_grad, l2, self.opt_dense.kind, self.hyper[1])
+
+  def _loss_tail(self, loss_dict):
+    """regularization_loss = embedding-output L2 + kernel L2, total_loss = that + the task losses (estimator :166-184);
+    one launch."""
+    be, eng, vs = kernels.hip(), self.engine, self.varstore
+    names = list(loss_dict.keys())
+    for name in names:
+      if name not in self.losses:
+        self.losses[name] = torch.zeros(1, dtype=torch.float32, device=self.device)
+    partials = eng.sumsq[:eng.reg_blocks] if (eng.reg_lambda > 0 and eng.reg_blocks > 0) else None
+    be.reg_total_loss(partials, 0.5 * eng.reg_lambda, vs.flat if vs.any_l2 else None, vs.l2coef if vs.any_l2 else None,
+                      [loss_dict[n].reshape(1) for n in names], [self.losses[n] for n in names],
+                      self.losses['regularization_loss'], self.losses['total_loss'])
 
   def train_step(self, batch=None):
     """Load `batch` (optional) and run one optimisation step.  Returns the dict of loss tensors."""

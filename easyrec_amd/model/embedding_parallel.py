@@ -80,7 +80,8 @@ class EmbeddingParallelEstimator(EasyRecEstimator):
 
   # -- the step in phases: static device work (capturable) around the data-dependent exchanges
   def _phase_route(self):
-    kernels.hip().hyper_select(self.hyper_table, self.step_counter, self.hyper, history=self.lr_hist)
+    kernels.hip().step_prologue(self.hyper_table, self.step_counter, self.hyper, history=self.lr_hist,
+                                zero=self.varstore.flat_grad_all)
     self.features.transform()
     self.engine.route()
 
@@ -89,20 +90,11 @@ class EmbeddingParallelEstimator(EasyRecEstimator):
     be = kernels.hip()
     self.engine.lookup()
     self.engine._ran_version = self.features.version  # the model's input-layer calls find the lookup done
-    self.varstore.zero_grad()
     with context.use(self.ctx):
       self.model.begin_step()
       self.model.build_predict_graph()
       loss_dict = self.model.build_loss_graph()
-      self.engine.regularization_loss(self._reg_emb)
-      if self.varstore.any_l2:
-        be.l2_loss(self.varstore.flat, self.varstore.l2coef, self._reg_dense)
-      names = list(loss_dict.keys())  # (_reg_dense stays 0 when no kernel carries an L2 coefficient)
-      for name in names:
-        if name not in self.losses:
-          self.losses[name] = torch.zeros(1, dtype=torch.float32, device=self.device)
-      be.total_loss(self._reg_emb, self._reg_dense, [loss_dict[n].reshape(1) for n in names],
-                    [self.losses[n] for n in names], self.losses['regularization_loss'], self.losses['total_loss'])
+      self._loss_tail(loss_dict)
       if self.is_training:
         self.model.backward()
         self.engine.reduce_local()

@@ -388,6 +388,18 @@ int er_sigmoid_ce_fwd_bwd(const float* logits, const float* labels, const float*
  * loss dict and REGULARIZATION_LOSSES of model/easy_rec_estimator.py:166-184 in one launch. */
 int er_total_loss(const float* reg_emb, const float* reg_dense, const float* const* losses_host,
                   float* const* report_host, int32_t n, float* reg_out, float* total_out, er_stream_t stream);
+/* The scalar tail of the loss in ONE launch: reg_out[0] = emb_scale * sum(emb_partials[0..n_partials)) [embedding-output
+ * L2 from er_emb_fwd's per-block sums of squares; n_partials may be 0] + sum_i 0.5 * coef[i] * w[i]^2 [w / coef may be
+ * NULL]; total_out[0] = reg_out[0] + sum_i losses[i][0]; report[i][0] = losses[i][0] (report may be NULL).  losses /
+ * report: HOST arrays of n_losses <= 8 DEVICE pointers.  = er_reduce_sum + er_l2_loss + er_total_loss. */
+int er_reg_total_loss(const float* emb_partials, int32_t n_partials, float emb_scale, const float* w, const float* coef,
+                      int64_t n, const float* const* losses_host, float* const* report_host, int32_t n_losses,
+                      float* reg_out, float* total_out, er_stream_t stream);
+/* er_hyper_select that also zeroes zero_floats floats at `zero` (the dense variables' flat gradient buffer): the
+ * step's prologue as one launch. */
+int er_step_prologue(const float* table, int64_t* counter, int32_t n_slots, int32_t floats_per_slot, float* out,
+                     float* history, int64_t history_capacity, int32_t history_index, float* zero, int64_t zero_floats,
+                     er_stream_t stream);
 /* out[0] = scale * sum of all n partials (deterministic single-block tree) */
 int er_reduce_sum(const float* partials, int32_t n, float scale, float* out, int accumulate,
                   er_stream_t stream);

@@ -826,6 +826,25 @@ class RefBackend(object):
       total = total + src.reshape(1)
     total_out.copy_(total)
 
+  def reg_total_loss(self, emb_partials, emb_scale, w, coef, losses, reports, reg_out, total_out):
+    reg = F32(0)
+    if emb_partials is not None and emb_partials.numel():
+      reg = F32(emb_scale) * F32(emb_partials.detach().cpu().numpy().astype(np.float64).sum())
+    if w is not None and coef is not None:
+      c, ww = coef.numpy().astype(np.float64), w.detach().numpy().astype(np.float64)
+      reg = F32(reg + F32((0.5 * c * ww * ww).sum()))
+    reg_out[0] = float(reg)
+    total = F32(reg)
+    for src, dst in zip(losses, reports):
+      dst[0] = float(src.reshape(-1)[0])
+      total = F32(total + F32(src.reshape(-1)[0].item()))
+    total_out[0] = float(total)
+
+  def step_prologue(self, table, counter, out, history=None, zero=None, history_index=HYPER_LR_T):
+    self.hyper_select(table, counter, out, history=history, history_index=history_index)
+    if zero is not None:
+      zero.zero_()
+
   def reduce_sum(self, partials, scale, out, accumulate=False):
     s = partials.to(torch.float64).sum().to(torch.float32) * scale
     if accumulate:

@@ -598,7 +598,7 @@ def test_batchnorm_fused_into_the_gemm_launch(hip, M, N, K):
   BatchNorm from registers - ONE launch) against the two-launch forms they replace: every output bit for bit,
   repeated launches included (the barrier words reset themselves)."""
   hip.gemm_reserve(1 << 20)
-  assert hip.gemm_fused_bn_ok(M, N)
+  assert hip.lib.er_gemm_fused_bn_ok(M, N) == 1  # (the path is off by default: kernels.HipBackend.fused_bn_gemm)
   g = torch.Generator().manual_seed(M + N + K)
   x, w = torch.randn(M, K, generator=g).to(DEV), (torch.randn(K, N, generator=g) * 0.1).to(DEV)
   bias, gamma, beta = torch.randn(N, generator=g).to(DEV), (torch.rand(N, generator=g) + 0.5).to(DEV), torch.randn(N, generator=g).to(DEV)
