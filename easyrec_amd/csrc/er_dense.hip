@@ -209,7 +209,7 @@ bn_finalize_apply_kernel(const float* __restrict__ partial, const float* __restr
 __global__ void __launch_bounds__(kBlock)
 bn_bwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ bias, const float* __restrict__ y,
                       const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ dy,
-                      int B, int N, int chunks, int use_bn, int act, float* __restrict__ partial) {
+                      int B, int N, int chunks, int use_bn, int act, float* __restrict__ partial, int dy_ld) {
   __shared__ float sm[2][kRowLanes][kColsPerBlock];
   const int cl = threadIdx.x % kColsPerBlock;
   const int rl = threadIdx.x / kColsPerBlock;
@@ -225,7 +225,7 @@ bn_bwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ bia
     const float is = use_bn ? invstd[c] : 0.f;
     for (int r = r0 + rl; r < r1; r += kRowLanes) {
       const int64_t i = static_cast<int64_t>(r) * N + c;
-      float g = dy[i];
+      float g = dy[static_cast<int64_t>(r) * dy_ld + c];
       if (act == ER_ACT_RELU && !(y[i] > 0.f)) g = 0.f;
       sg = sg + g;
       if (use_bn) sgx = sgx + g * ((x[i] + bv - mu) * is);
@@ -249,7 +249,8 @@ bn_bwd_finalize_apply_kernel(const float* __restrict__ partial, const float* __r
                              const float* __restrict__ y, const float* __restrict__ mean,
                              const float* __restrict__ invstd, const float* __restrict__ dy, int B, int N,
                              int chunks, int use_bn, int act, int accumulate, float* __restrict__ dx,
-                             float* __restrict__ dbias, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                             float* __restrict__ dbias, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                             int dy_ld) {
   __shared__ float sm[2][kRowLanes][kColsPerBlock];
   __shared__ float s_g[kColsPerBlock], s_gx[kColsPerBlock];
   const int cl = threadIdx.x % kColsPerBlock;
@@ -297,7 +298,7 @@ bn_bwd_finalize_apply_kernel(const float* __restrict__ partial, const float* __r
     const int r = r0 + k * kRowLanes;
     const int64_t i = static_cast<int64_t>(r) * N + c;
     const bool ok = r < B;
-    gv[k] = ok ? dy[i] : 0.f;
+    gv[k] = ok ? dy[static_cast<int64_t>(r) * dy_ld + c] : 0.f;
     yv[k] = (ok && act == ER_ACT_RELU) ? y[i] : 1.f;
     xv[k] = (ok && use_bn) ? x[i] : 0.f;
   }
@@ -340,14 +341,26 @@ colsum_partial_kernel(const float* __restrict__ x, int rows, int cols, int x_str
 }
 
 __global__ void __launch_bounds__(kBlock)
-colsum_finalize_kernel(const float* __restrict__ partial, int cols, int chunks, float* __restrict__ out) {
+colsum_finalize_kernel(const float* __restrict__ partial, int cols, int chunks, float* __restrict__ out, int accumulate) {
   const int lane = threadIdx.x & 63;
   const int c = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   if (c >= cols) return;
   float a = 0.f;
   for (int k = lane; k < chunks; k += 64) a = a + partial[static_cast<int64_t>(k) * cols + c];
   a = wave_sum(a);
-  if (lane == 0) out[c] = a;
+  if (lane == 0) out[c] = accumulate ? out[c] + a : a;
+}
+
+// few columns (the bias gradient of a narrow head: dy [B, 1]): one workgroup per column, one launch
+__global__ void __launch_bounds__(kBlock)
+colsum_narrow_kernel(const float* __restrict__ x, int rows, int cols, int x_stride, float* __restrict__ out,
+                     int accumulate) {
+  __shared__ float red[4];
+  const int c = blockIdx.x;
+  float a = 0.f;
+  for (int r = threadIdx.x; r < rows; r += kBlock) a = a + x[static_cast<int64_t>(r) * x_stride + c];
+  const float s = block_sum_256(a, red);
+  if (threadIdx.x == 0) out[c] = accumulate ? out[c] + s : s;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -720,19 +733,26 @@ int er_bn_apply_from_stats(const float* x, const float* bias, const float* col_s
 int er_bn_act_bwd(const float* x, const float* bias, const float* gamma, const float* y, const float* save_mean,
                   const float* save_invstd, const float* dy, int32_t B, int32_t N, int use_bn, int act, float* dx,
                   float* dbias, float* dgamma, float* dbeta, int accumulate, er_stream_t stream) {
-  ER_REQUIRE(x && y && dy && dx && B > 0 && N > 0, "er_bn_act_bwd: bad arguments");
+  return er_bn_act_bwd_ld(x, bias, gamma, y, save_mean, save_invstd, dy, N, B, N, use_bn, act, dx, dbias, dgamma, dbeta,
+                          accumulate, stream);
+}
+
+int er_bn_act_bwd_ld(const float* x, const float* bias, const float* gamma, const float* y, const float* save_mean,
+                     const float* save_invstd, const float* dy, int32_t dy_ld, int32_t B, int32_t N, int use_bn, int act,
+                     float* dx, float* dbias, float* dgamma, float* dbeta, int accumulate, er_stream_t stream) {
+  ER_REQUIRE(x && y && dy && dx && B > 0 && N > 0 && dy_ld >= N, "er_bn_act_bwd: bad arguments");
   hipStream_t s = er::as_stream(stream);
   const int chunks = er::choose_chunks(B, N);
   float* scratch;
   if (er::get_scratch(static_cast<size_t>(chunks) * N * 2, &scratch)) return 1;
   dim3 grid(static_cast<unsigned>(er::ceil_div(N, er::kColsPerBlock)), static_cast<unsigned>(chunks));
   hipLaunchKernelGGL(er::bn_bwd_partial_kernel, grid, dim3(er::kBlock), 0, s, x, bias, y, save_mean, save_invstd, dy, B,
-                     N, chunks, use_bn, act, scratch);
+                     N, chunks, use_bn, act, scratch, dy_ld);
   ER_LAUNCH_CHECK();
   dim3 grid2(static_cast<unsigned>(er::ceil_div(N, er::kColsPerBlock)),
              static_cast<unsigned>(er::ceil_div(B, er::kApplyRows)));
   hipLaunchKernelGGL(er::bn_bwd_finalize_apply_kernel, grid2, dim3(er::kBlock), 0, s, scratch, x, bias, gamma, y,
-                     save_mean, save_invstd, dy, B, N, chunks, use_bn, act, accumulate, dx, dbias, dgamma, dbeta);
+                     save_mean, save_invstd, dy, B, N, chunks, use_bn, act, accumulate, dx, dbias, dgamma, dbeta, dy_ld);
   ER_LAUNCH_CHECK();
   return 0;
 }
@@ -745,14 +765,25 @@ int er_bn_act_bwd_from_partials(const float* x, const float* bias, const float* 
   dim3 grid2(static_cast<unsigned>(er::ceil_div(N, er::kColsPerBlock)),
              static_cast<unsigned>(er::ceil_div(B, er::kApplyRows)));
   hipLaunchKernelGGL(er::bn_bwd_finalize_apply_kernel, grid2, dim3(er::kBlock), 0, er::as_stream(stream), partial, x, bias,
-                     gamma, y, save_mean, save_invstd, dy, B, N, chunks, use_bn, act, accumulate, dx, dbias, dgamma, dbeta);
+                     gamma, y, save_mean, save_invstd, dy, B, N, chunks, use_bn, act, accumulate, dx, dbias, dgamma, dbeta, N);
   ER_LAUNCH_CHECK();
   return 0;
 }
 
 int er_colsum(const float* x, int32_t rows, int32_t cols, int32_t x_stride, float* out, er_stream_t stream) {
+  return er_colsum_acc(x, rows, cols, x_stride, out, 0, stream);
+}
+
+int er_colsum_acc(const float* x, int32_t rows, int32_t cols, int32_t x_stride, float* out, int accumulate,
+                  er_stream_t stream) {
   ER_REQUIRE(x && out && rows > 0 && cols > 0, "er_colsum: bad arguments");
   hipStream_t s = er::as_stream(stream);
+  if (cols <= 8 && static_cast<int64_t>(rows) * cols <= (1 << 17)) {
+    hipLaunchKernelGGL(er::colsum_narrow_kernel, dim3(static_cast<unsigned>(cols)), dim3(er::kBlock), 0, s, x, rows, cols,
+                       x_stride, out, accumulate);
+    ER_LAUNCH_CHECK();
+    return 0;
+  }
   const int chunks = er::choose_chunks(rows, cols);
   float* scratch;
   if (er::get_scratch(static_cast<size_t>(chunks) * cols, &scratch)) return 1;
@@ -760,7 +791,7 @@ int er_colsum(const float* x, int32_t rows, int32_t cols, int32_t x_stride, floa
   hipLaunchKernelGGL(er::colsum_partial_kernel, grid, dim3(er::kBlock), 0, s, x, rows, cols, x_stride, chunks, scratch);
   ER_LAUNCH_CHECK();
   hipLaunchKernelGGL(er::colsum_finalize_kernel, dim3(er::blocks_for(static_cast<int64_t>(cols) * 64)), dim3(er::kBlock), 0, s, scratch, cols,
-                     chunks, out);
+                     chunks, out, accumulate);
   ER_LAUNCH_CHECK();
   return 0;
 }

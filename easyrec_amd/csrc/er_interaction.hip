@@ -487,6 +487,68 @@ dot_interaction_bwd_kernel(const float* __restrict__ x, const float* __restrict_
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The gradient of an embedding group's output, finished in ONE launch for all groups of a model:
+//   dout[b, c] = (has_base ? dout[b, c] : 0)            what the consumers' GEMMs deposited (er_gemm accumulate)
+//              + deferred terms, in the order recorded    row-sum broadcast (the wide logit), FM (g * (S - x))
+//              + lambda * out[b, c]                       d/d(out) of the embedding-output L2 (layers/input_layer.py:369-375)
+// instead of er_rowsum_bwd + er_fm_bwd + one er_axpy2d per regularised group (+ a zero fill for groups nobody
+// differentiated).  Elementwise, HBM-bound: B * W * (2 or 3) floats.
+// ------------------------------------------------------------------------------------------------
+struct GradFinishMulti {
+  int n;
+  int start[8 + 1];
+  er_grad_group g[8];
+};
+
+__global__ void __launch_bounds__(kBlock)
+group_grad_finish_kernel(GradFinishMulti ma) {
+  int i = 0;
+  while (i + 1 < ma.n && static_cast<int>(blockIdx.x) >= ma.start[i + 1]) ++i;
+  const er_grad_group& g = ma.g[i];
+  const int64_t idx = (static_cast<int64_t>(blockIdx.x) - ma.start[i]) * kBlock + threadIdx.x;
+  const int64_t b = idx / g.width;
+  if (b >= g.batch) return;
+  const int c = static_cast<int>(idx - b * g.width);
+  float* o = g.dout + b * g.ld + c;
+  float v = g.has_base ? *o : 0.f;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    if (t >= g.n_terms) break;
+    const er_grad_term& q = g.terms[t];
+    if (c < q.col0 || c >= q.col0 + q.width) continue;
+    if (q.kind == ER_GRAD_TERM_ROWSUM) {
+      v = v + q.g[b * q.g_ld];
+    } else {  // ER_GRAD_TERM_FM
+      const int d = (c - q.col0) % q.dim;
+      v = v + q.g[b * q.g_ld + d] * (q.saved[b * q.dim + d] - g.out[b * g.ld + c]);
+    }
+  }
+  if (g.lambda != 0.f) v = v + g.lambda * g.out[b * g.ld + c];
+  *o = v;
+}
+
+// out[b, col0_p + j] = part_p[b * ld_p + j]: tf.concat(axis=1) of up to 8 row-major blocks (model/deepfm.py:75-83) in one
+// launch; pure copy, HBM-bound.
+struct ConcatArgs {
+  int n, batch, out_ld;
+  float* out;
+  const float* src[8];
+  int ld[8], col0[8 + 1];
+};
+
+__global__ void __launch_bounds__(kBlock)
+concat_cols_kernel(ConcatArgs a) {
+  const int width = a.col0[a.n];
+  const int64_t idx = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  const int64_t b = idx / width;
+  if (b >= a.batch) return;
+  const int c = static_cast<int>(idx - b * width);
+  int p = 0;
+  while (p + 1 < a.n && c >= a.col0[p + 1]) ++p;
+  a.out[b * a.out_ld + c] = a.src[p][b * a.ld[p] + (c - a.col0[p])];
+}
+
 }  // namespace er
 
 extern "C" {
@@ -693,6 +755,50 @@ int er_dot_interaction_bwd(const float* x, const float* g, int32_t B, int32_t F,
   ER_REQUIRE(lds <= 60 * 1024, "er_dot_interaction_bwd: %zu bytes exceed the LDS budget", lds);
   hipLaunchKernelGGL(er::dot_interaction_bwd_kernel, dim3(B), dim3(er::kBlock), lds, er::as_stream(stream), x, g, F, D,
                      x_stride, offset, P, g_stride, dx, dx_stride, accumulate);
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
+int er_group_grad_finish(const er_grad_group* groups, int n, er_stream_t stream) {
+  ER_REQUIRE(groups && n >= 1, "er_group_grad_finish: bad arguments");
+  for (int i0 = 0; i0 < n; i0 += 8) {
+    er::GradFinishMulti ma;
+    ma.n = n - i0 < 8 ? n - i0 : 8;
+    ma.start[0] = 0;
+    for (int i = 0; i < ma.n; ++i) {
+      const er_grad_group& g = groups[i0 + i];
+      ER_REQUIRE(g.dout && g.out && g.batch > 0 && g.width > 0 && g.ld >= g.width && g.n_terms >= 0 && g.n_terms <= 4,
+                 "er_group_grad_finish: group %d: bad descriptor", i0 + i);
+      for (int t = 0; t < g.n_terms; ++t)
+        ER_REQUIRE(g.terms[t].g && g.terms[t].width > 0 && g.terms[t].col0 >= 0 &&
+                       g.terms[t].col0 + g.terms[t].width <= g.width &&
+                       (g.terms[t].kind == ER_GRAD_TERM_ROWSUM ||
+                        (g.terms[t].kind == ER_GRAD_TERM_FM && g.terms[t].saved && g.terms[t].dim > 0)),
+                   "er_group_grad_finish: group %d term %d: bad descriptor", i0 + i, t);
+      ma.g[i] = g;
+      ma.start[i + 1] = ma.start[i] + static_cast<int>(er::ceil_div(static_cast<int64_t>(g.batch) * g.width, er::kBlock));
+    }
+    hipLaunchKernelGGL(er::group_grad_finish_kernel, dim3(static_cast<unsigned>(ma.start[ma.n])), dim3(er::kBlock), 0,
+                       er::as_stream(stream), ma);
+    ER_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+int er_concat_cols(const float* const* parts, const int32_t* widths, const int32_t* lds, int n, int32_t batch, float* out,
+                   int32_t out_ld, er_stream_t stream) {
+  ER_REQUIRE(parts && widths && lds && out && n >= 1 && n <= 8 && batch > 0, "er_concat_cols: bad arguments (n <= 8)");
+  er::ConcatArgs a;
+  a.n = n; a.batch = batch; a.out_ld = out_ld; a.out = out;
+  a.col0[0] = 0;
+  for (int i = 0; i < n; ++i) {
+    ER_REQUIRE(parts[i] && widths[i] > 0 && lds[i] >= widths[i], "er_concat_cols: part %d: bad descriptor", i);
+    a.src[i] = parts[i]; a.ld[i] = lds[i];
+    a.col0[i + 1] = a.col0[i] + widths[i];
+  }
+  ER_REQUIRE(out_ld >= a.col0[n], "er_concat_cols: out_ld too small");
+  hipLaunchKernelGGL(er::concat_cols_kernel, dim3(er::blocks_for(static_cast<int64_t>(batch) * a.col0[n])), dim3(er::kBlock), 0,
+                     er::as_stream(stream), a);
   ER_LAUNCH_CHECK();
   return 0;
 }

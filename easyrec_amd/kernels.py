@@ -133,6 +133,20 @@ class GemmProblem(ctypes.Structure):  # = er_gemm_problem
 CROSS_HASH_KEY = 0xDECAFCAFFE  # tf.sparse.cross_hashed's default hash_key (crossed_column(hash_key=None))
 
 
+class GradTerm(ctypes.Structure):  # = er_grad_term
+  _fields_ = [('kind', ctypes.c_int32), ('col0', ctypes.c_int32), ('width', ctypes.c_int32), ('dim', ctypes.c_int32),
+              ('g', ctypes.c_void_p), ('g_ld', ctypes.c_int32), ('pad_', ctypes.c_int32), ('saved', ctypes.c_void_p)]
+
+
+class GradGroup(ctypes.Structure):  # = er_grad_group
+  _fields_ = [('dout', ctypes.c_void_p), ('out', ctypes.c_void_p), ('ld', ctypes.c_int32), ('batch', ctypes.c_int32),
+              ('width', ctypes.c_int32), ('has_base', ctypes.c_int32), ('n_terms', ctypes.c_int32),
+              ('lam', ctypes.c_float), ('terms', GradTerm * 4)]
+
+
+GRAD_TERM_ROWSUM, GRAD_TERM_FM = 0, 1
+
+
 class DenseApplyDesc(ctypes.Structure):  # = er_dense_apply_desc
   _fields_ = [('var', ctypes.c_void_p), ('m', ctypes.c_void_p), ('v', ctypes.c_void_p), ('dense', ctypes.c_void_p),
               ('ld', ctypes.c_int32), ('dim', ctypes.c_int32), ('rows', ctypes.c_int64)]
@@ -777,6 +791,25 @@ class HipBackend(object):
              'er_rowsum_bwd')
     return dx
 
+  def group_grad_finish(self, groups):
+    """groups: [(dout, out, lambda, has_base, [terms])], term = ('rowsum', g, col0, width) | ('fm', g, saved, col0,
+    width, dim); g: [B] / [B, 1] / [B, dim] with unit inner stride.  One launch (er_group_grad_finish)."""
+    arr = (GradGroup * len(groups))()
+    for q, (dout, out, lam, has_base, terms) in zip(arr, groups):
+      assert dout.shape == out.shape and dout.stride() == out.stride() and dout.stride(1) == 1 and len(terms) <= 4
+      q.dout, q.out, q.ld = dout.data_ptr(), out.data_ptr(), dout.stride(0)
+      q.batch, q.width, q.has_base, q.n_terms, q.lam = dout.shape[0], dout.shape[1], int(bool(has_base)), len(terms), lam
+      for t, term in zip(q.terms, terms):
+        g = term[1]
+        assert g.dtype == torch.float32 and (g.dim() == 1 or g.stride(-1) == 1)
+        t.g, t.g_ld = g.data_ptr(), (g.stride(0) if g.dim() >= 1 else 1)
+        if term[0] == 'rowsum':
+          t.kind, t.col0, t.width, t.dim = GRAD_TERM_ROWSUM, term[2], term[3], 1
+        else:
+          saved = _f32c(term[2])
+          t.kind, t.col0, t.width, t.dim, t.saved = GRAD_TERM_FM, term[3], term[4], term[5], saved.data_ptr()
+    self._ck(self.lib.er_group_grad_finish(arr, len(groups), _stream()), 'er_group_grad_finish')
+
   def axpy2d(self, x, alpha, y, accumulate=True):
     """y (+)= alpha * x on 2-D views with unit inner stride."""
     rows, cols = x.shape
@@ -874,6 +907,24 @@ class HipBackend(object):
                                int(act), _p(y), _p(mean), _p(invstd), _stream()), 'er_bn_act_fwd')
     return y, mean, invstd
 
+  def concat_cols(self, parts):
+    """torch.cat(parts, dim=1) of 2-D fp32 blocks (unit inner stride) as one library launch."""
+    n = len(parts)
+    B = parts[0].shape[0]
+    for t in parts:
+      assert t.dim() == 2 and t.shape[0] == B and t.stride(1) == 1 and t.dtype == torch.float32
+    out = torch.empty(B, sum(t.shape[1] for t in parts), dtype=torch.float32, device=parts[0].device)
+    for i in range(0, n, 8):  # (more than 8 parts: several launches into column blocks of `out`)
+      chunk = parts[i:i + 8]
+      col0 = sum(t.shape[1] for t in parts[:i])
+      dst = out[:, col0:]
+      pp = (ctypes.c_void_p * len(chunk))(*[t.data_ptr() for t in chunk])
+      ww = (ctypes.c_int32 * len(chunk))(*[t.shape[1] for t in chunk])
+      ll = (ctypes.c_int32 * len(chunk))(*[t.stride(0) for t in chunk])
+      self._ck(self.lib.er_concat_cols(pp, ww, ll, len(chunk), B, _p(dst), ctypes.c_int32(out.stride(0)), _stream()),
+               'er_concat_cols')
+    return out
+
   def bn_act_bwd(self, x, bias, gamma, y, mean, invstd, dy, use_bn, act, need_bias, need_affine, into=None,
                  partial=None):
     """into = (dbias_buf, dgamma_buf, dbeta_buf) (each may be None): accumulate the parameter gradients
@@ -889,7 +940,13 @@ class HipBackend(object):
       dbias = torch.empty(N, dtype=torch.float32, device=dev) if need_bias else None
       dgamma = torch.empty(N, dtype=torch.float32, device=dev) if need_affine else None
       dbeta = torch.empty(N, dtype=torch.float32, device=dev) if need_affine else None
-    if partial is not None:
+    assert dy.dim() == 2 and dy.stride(1) == 1 and dy.dtype == torch.float32
+    if partial is None and dy.stride(0) != N:  # a column block of a wider gradient (ConcatFn's backward): read in place
+      self._ck(
+          self.lib.er_bn_act_bwd_ld(_p(x), _p(bias), _p(gamma), _p(y), _p(mean), _p(invstd), _p(dy),
+                                    ctypes.c_int32(dy.stride(0)), B, N, int(use_bn), int(act), _p(dx), _p(dbias),
+                                    _p(dgamma), _p(dbeta), int(acc), _stream()), 'er_bn_act_bwd_ld')
+    elif partial is not None:
       self._ck(
           self.lib.er_bn_act_bwd_from_partials(_p(x), _p(bias), _p(gamma), _p(y), _p(mean), _p(invstd), _p(_f32c(dy)),
                                                B, N, int(use_bn), int(act), _p(partial),
@@ -904,10 +961,14 @@ class HipBackend(object):
       return dx, None, None, None
     return dx, dbias, dgamma, dbeta
 
-  def colsum(self, x):
+  def colsum(self, x, out=None, accumulate=False):
+    """out[j] (+)= sum_i x[i, j]; out: e.g. a bias' slice of the flat gradient buffer."""
     rows, cols = x.shape
-    out = torch.empty(cols, dtype=torch.float32, device=x.device)
-    self._ck(self.lib.er_colsum(_p(x), rows, cols, x.stride(0), _p(out), _stream()), 'er_colsum')
+    if out is None:
+      assert not accumulate
+      out = torch.empty(cols, dtype=torch.float32, device=x.device)
+    self._ck(self.lib.er_colsum_acc(_p(x), rows, cols, x.stride(0), _p(out), int(bool(accumulate)), _stream()),
+             'er_colsum_acc')
     return out
 
   def dice_fwd(self, x, alpha, eps, momentum, moving_mean, moving_var):
@@ -1139,11 +1200,10 @@ class LinearFn(torch.autograd.Function):
       else:
         dw = be.gemm(GEMM_TN, x, dy, bf16=ctx.bf16)
     if ctx.has_bias and ctx.needs_input_grad[2]:
-      s = be.colsum(dy)
       if ctx.b_grad is not None:
-        ctx.b_grad.add_(s)
+        be.colsum(dy, out=ctx.b_grad, accumulate=True)  # straight into the flat gradient buffer
       else:
-        db = s
+        db = be.colsum(dy)
     return dx, dw, db, None, None, None, None, None
 
 
@@ -1209,7 +1269,8 @@ class LinearBNActFn(torch.autograd.Function):
     x, w, gamma, z, y, mean, invstd = ctx.saved_tensors
     wg, gg, betag = ctx.grad_bufs if ctx.grad_bufs is not None else (None, None, None)
     direct = gg is not None and betag is not None
-    dyc = dy.contiguous()
+    # (a column block of a wider gradient - ConcatFn's backward - is read in place by the BatchNorm backward)
+    dyc = dy if (dy.dim() == 2 and dy.stride(1) == 1) else dy.contiguous()
     own, partial = ctx.own, None
     dgamma = dbeta = None
     if own is not None and own.dz_ptr:
@@ -1253,11 +1314,10 @@ class FMFn(torch.autograd.Function):
   @staticmethod
   def backward(ctx, g):
     x, S = ctx.saved_tensors
-    if ctx.sink is not None and ctx.sink.covers(ctx.col0, ctx.F * ctx.D):
-      # x is (a column block of) an embedding group output: the gradient goes straight into its gradient buffer
-      dst, acc = ctx.sink.target(ctx.col0, ctx.F * ctx.D)
-      hip().fm_bwd(x, S, g.contiguous(), ctx.F, ctx.D, into=dst, accumulate=acc)
-      ctx.sink.done()
+    if ctx.sink is not None:
+      # x is (a column block of) an embedding group output: its gradient g * (S - x) is added when the group's gradient
+      # buffer is finished (er_group_grad_finish: one launch for all groups and terms)
+      ctx.sink.defer(('fm', g if g.stride(-1) == 1 else g.contiguous(), S, ctx.col0, ctx.F * ctx.D, ctx.D))
       return None, None, None, None, None
     dx = hip().fm_bwd(x, S, g.contiguous(), ctx.F, ctx.D)
     if x.shape[1] != ctx.F * ctx.D:
@@ -1265,6 +1325,35 @@ class FMFn(torch.autograd.Function):
       full[:, :ctx.F * ctx.D] = dx
       dx = full
     return dx, None, None, None, None
+
+
+class ConcatFn(torch.autograd.Function):
+  """tf.concat(parts, axis=1) (model/deepfm.py:75-83 and the towers' joins): ONE library launch forward; the backward
+  hands every producer the column block of the incoming gradient as a VIEW - the fused backward kernels read strided
+  gradients in place (no copies)."""
+
+  @staticmethod
+  def forward(ctx, *parts):
+    ctx.widths = [int(t.shape[1]) for t in parts]
+    return hip().concat_cols([t if t.stride(-1) == 1 else t.contiguous() for t in parts])
+
+  @staticmethod
+  def backward(ctx, g):
+    out, c = [], 0
+    for w in ctx.widths:
+      out.append(g[:, c:c + w])
+      c += w
+    return tuple(out)
+
+
+def concat_cols(parts):
+  """Differentiable concat along dim 1 through the library (2-D fp32 tensors)."""
+  parts = list(parts)
+  if len(parts) == 1:
+    return parts[0]
+  if any(t.requires_grad for t in parts) and torch.is_grad_enabled():
+    return ConcatFn.apply(*parts)
+  return hip().concat_cols([t if t.stride(-1) == 1 else t.contiguous() for t in parts])
 
 
 class DotInteractionFn(torch.autograd.Function):
@@ -1296,10 +1385,8 @@ class RowSumFn(torch.autograd.Function):
 
   @staticmethod
   def backward(ctx, g):
-    if ctx.sink is not None and ctx.sink.covers(0, ctx.n):
-      dst, acc = ctx.sink.target(0, ctx.n)
-      hip().rowsum_bwd(g.contiguous(), ctx.n, into=dst, accumulate=acc)
-      ctx.sink.done()
+    if ctx.sink is not None:
+      ctx.sink.defer(('rowsum', g if g.stride(-1) == 1 else g.contiguous(), 0, ctx.n))
       return None, None
     return hip().rowsum_bwd(g.contiguous(), ctx.n), None
 

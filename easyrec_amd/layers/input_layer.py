@@ -53,11 +53,15 @@ class _GroupOutFn(torch.autograd.Function):
   @staticmethod
   def forward(ctx, anchor, engine, gkey):
     ctx.engine, ctx.gkey = engine, gkey
+    # consumers that deposit their gradient through the GradSink return None to autograd: without this autograd would
+    # hand backward() a zero tensor (one fill + one add per group and step for nothing)
+    ctx.set_materialize_grads(False)
     return engine.groups[gkey]['out'].view_as(engine.groups[gkey]['out'])
 
   @staticmethod
   def backward(ctx, g):
-    ctx.engine._deposit_grad(ctx.gkey, g)
+    if g is not None:
+      ctx.engine._deposit_grad(ctx.gkey, g)
     return None, None, None
 
 
@@ -84,6 +88,11 @@ class GradSink(object):
 
   def done(self):
     self.engine._after_deposit(self.gkey)
+
+  def defer(self, term):
+    """A contribution that is cheap to add elementwise (`kernels.HipBackend.group_grad_finish` terms): recorded now,
+    added when the engine finishes the group's gradient buffer - one launch for all groups of the model."""
+    self.engine.groups[self.gkey]['terms'].append(term)
 
 
 class EmbeddingEngine(object):
@@ -144,6 +153,7 @@ class EmbeddingEngine(object):
         'reg': float(regularize or 0.0),
         'width': width,
         'got_grad': False,
+        'terms': [],
     }
     self.groups[gkey] = g
     return g
@@ -157,6 +167,7 @@ class EmbeddingEngine(object):
         'reg': float(regularize or 0.0),
         'width': width,
         'got_grad': False,
+        'terms': [],
     }
     self.groups[gkey] = g
     return g
@@ -335,6 +346,7 @@ class EmbeddingEngine(object):
     be = kernels.hip()
     for g in self.groups.values():
       g['got_grad'] = False
+      g['terms'] = []
     if self.lazy_decay and not self.inference:
       # sort the step's ids once (reused by the backward), bring the rows it touches up to date, then look up
       grps, uks, nus = [], [], []
@@ -377,11 +389,29 @@ class EmbeddingEngine(object):
     self._after_deposit(gkey)
 
   def _after_deposit(self, gkey):
-    grp = self.groups[gkey]
-    if grp['reg'] > 0 and not grp['got_grad']:
-      # d/d(out) of lambda * 0.5 * ||out||^2 (layers/input_layer.py:369-375)
-      kernels.hip().axpy2d(grp['out'], grp['reg'], grp['dout'], accumulate=True)
-    grp['got_grad'] = True
+    self.groups[gkey]['got_grad'] = True  # (dout holds a base; lambda * out and the deferred terms come at the finish)
+
+  def finish_group_grads(self):
+    """Every group's gradient buffer complete, in ONE launch: base (what GEMMs / autograd deposited, else zero) +
+    deferred terms (row-sum broadcast, FM) + lambda * out, the gradient of the embedding-output L2
+    (layers/input_layer.py:369-375).  Called first thing by the embedding backward."""
+    descs = []
+    for g in self.groups.values():
+      lam = g['reg'] if g['reg'] > 0 else 0.0
+      if g['got_grad'] and not g['terms'] and lam == 0.0:
+        continue  # already complete
+      terms = g['terms']
+      while len(terms) > 4:  # (more than 4 deferred terms on one group: finish in rounds)
+        descs.append((g['dout'], g['out'], 0.0, g['got_grad'], terms[:4]))
+        terms, g['got_grad'] = terms[4:], True
+        kernels.hip().group_grad_finish(descs[-1:])
+        descs.pop()
+      descs.append((g['dout'], g['out'], lam, g['got_grad'], terms))
+    if descs:
+      kernels.hip().group_grad_finish(descs)
+    for g in self.groups.values():
+      g['terms'] = []
+      g['got_grad'] = True
 
   def regularization_loss(self, out):
     """out[0] = lambda * 0.5 * sum(out^2) over regularised embedding outputs."""
@@ -414,9 +444,7 @@ class EmbeddingEngine(object):
 
   def backward_update(self, opt_kind, hyper):
     be = kernels.hip()
-    for g in self.groups.values():
-      if not g['got_grad']:
-        g['dout'].zero_()
+    self.finish_group_grads()
     if opt_kind == kernels.OPT_ADAM and self._sweep_pending:
       # the sweep of the untouched rows is already in flight on the side stream; the touched rows
       # get the same per-row arithmetic as TF's sparse apply (== the lazy row update)
@@ -444,9 +472,7 @@ class EmbeddingEngine(object):
     normsq[0] += weight * sum of their squares (weight = grad_scale^2: `values` of the IndexedSlices after the gradient
     multipliers).  apply_reduced() finishes the step once the multiplier is known."""
     be = kernels.hip()
-    for g in self.groups.values():
-      if not g['got_grad']:
-        g['dout'].zero_()
+    self.finish_group_grads()
     self._reduced = []
     for dim, grp in self.emb_groups.items():
       bufs = self._clip_bufs.get(dim) if hasattr(self, '_clip_bufs') else None

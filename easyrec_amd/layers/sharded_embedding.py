@@ -380,6 +380,7 @@ class ShardedEmbeddingEngine(EmbeddingEngine):
   def lookup(self):
     for g in self.groups.values():
       g['got_grad'] = False
+      g['terms'] = []
     if self.plan is not None:
       kernels.hip().emb_fwd(self.plan, self.sumsq if self.reg_lambda > 0 else None)
 
@@ -393,9 +394,7 @@ class ShardedEmbeddingEngine(EmbeddingEngine):
 
   def reduce_local(self):
     be = kernels.hip()
-    for g in self.groups.values():
-      if not g['got_grad']:
-        g['dout'].zero_()
+    self.finish_group_grads()
     if self.rep:
       # replicated tables: the per-row gradient sums go straight into the dense buffer that is all-reduced
       if self.rep_flat_own:

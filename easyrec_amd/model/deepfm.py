@@ -57,7 +57,7 @@ class DeepFM(RankModel):
 
     # Final
     if len(self._model_config.final_dnn.hidden_units) > 0:
-      all_fea = torch.cat([wide_fea, fm_fea, deep_fea], dim=1)
+      all_fea = kernels.concat_cols([wide_fea, fm_fea, deep_fea])
       final_dnn_layer = dnn.DNN(self._model_config.final_dnn, self._l2_reg, 'final_dnn', self._is_training)
       all_fea = kernels.mark_single_consumer(final_dnn_layer(all_fea))  # read by the `output` projection alone
       output = dnn.dense(all_fea, self._num_class, 'output', l2_reg=self._l2_reg)

@@ -10,6 +10,8 @@ import logging
 
 import torch
 
+from easyrec_amd import kernels
+
 from easyrec_amd.core import context
 from easyrec_amd.layers import dnn
 from easyrec_amd.layers import seq_input_layer
@@ -59,7 +61,7 @@ class MultiTowerDIN(RankModel):
     for tower, tower_fea in zip(self._model_config.din_towers, din_features):
       tower_fea_arr.append(self.din(tower.dnn, tower_fea, name='%s_dnn' % tower.input))
 
-    all_fea = torch.cat(tower_fea_arr, dim=1)
+    all_fea = kernels.concat_cols(tower_fea_arr)
     final_dnn_layer = dnn.DNN(self._model_config.final_dnn, self._l2_reg, 'final_dnn', self._is_training)
     all_fea = final_dnn_layer(all_fea)
     output = dnn.dense(all_fea, self._num_class, 'output')

@@ -46,7 +46,7 @@ class WideAndDeep(RankModel):
     deep_fea = deep_layer(deep_features)
 
     if len(self._model_config.final_dnn.hidden_units) > 0:
-      all_fea = torch.cat([wide_fea, deep_fea], dim=1)
+      all_fea = kernels.concat_cols([wide_fea, deep_fea])
       final_layer = dnn.DNN(self._model_config.final_dnn, self._l2_reg, 'final_dnn', self._is_training)
       all_fea = final_layer(all_fea)
       output = dnn.dense(all_fea, self._num_class, 'output', l2_reg=self._l2_reg)

@@ -269,6 +269,33 @@ int er_fm_bwd(const float* x, const float* sum_saved, const float* g, int32_t B,
 /* out[b] = sum_j x[b, j], j < n */
 int er_rowsum_fwd(const float* x, int32_t B, int32_t n, int32_t x_stride, float* out,
                   er_stream_t stream);
+/* The gradient buffers of a model's embedding group outputs, finished in ONE launch (instead of er_rowsum_bwd +
+ * er_fm_bwd + er_axpy2d per regularised group + zero fills).  Per group: dout[b, c] = (has_base ? dout[b, c] : 0)
+ * [what dgrad GEMMs accumulated there] + the deferred terms in order + lambda * out[b, c] [gradient of the
+ * embedding-output L2, layers/input_layer.py:369-375].  Terms: ER_GRAD_TERM_ROWSUM: + g[b * g_ld] for columns
+ * [col0, col0 + width) (gradient of reduce_sum over the wide columns, model/deepfm.py:62-63); ER_GRAD_TERM_FM:
+ * + g[b * g_ld + d] * (saved[b * dim + d] - out[b, c]), d = (c - col0) % dim (gradient of layers/fm.py:20-26; saved =
+ * the field sums er_fm_fwd kept).  groups: HOST array; all pointers DEVICE. */
+#define ER_GRAD_TERM_ROWSUM 0
+#define ER_GRAD_TERM_FM 1
+typedef struct er_grad_term {
+  int32_t kind, col0, width, dim;
+  const float* g;      /* upstream gradient: [B] (row sum) or [B, dim] (FM), row stride g_ld */
+  int32_t g_ld, pad_;
+  const float* saved;  /* FM: field sums [B, dim] */
+} er_grad_term;
+typedef struct er_grad_group {
+  float* dout;         /* [batch, width] gradient buffer, row stride ld */
+  const float* out;    /* the group's forward output, same layout */
+  int32_t ld, batch, width, has_base, n_terms;
+  float lambda;
+  er_grad_term terms[4];
+} er_grad_group;
+int er_group_grad_finish(const er_grad_group* groups_host, int n, er_stream_t stream);
+/* out[b, sum(widths[<p]) + j] = parts[p][b * lds[p] + j]: tf.concat(values, axis=1) of n <= 8 row-major blocks
+ * (model/deepfm.py:75-83, model/multi_tower_din.py:96,117) in one launch.  parts / widths / lds: HOST arrays. */
+int er_concat_cols(const float* const* parts_host, const int32_t* widths_host, const int32_t* lds_host, int n,
+                   int32_t batch, float* out, int32_t out_ld, er_stream_t stream);
 /* y[i] (+)= alpha * x[i]  over a strided 2-D view (used for the embedding L2 gradient
  * lambda*out and for broadcasting d(wide_sum) back to the wide columns) */
 int er_axpy2d(const float* x, int32_t x_stride, float alpha, float* y, int32_t y_stride,
@@ -355,6 +382,12 @@ int er_bn_act_bwd(const float* x, const float* bias, const float* gamma, const f
                   const float* save_mean, const float* save_invstd, const float* dy, int32_t B,
                   int32_t N, int use_bn, int act, float* dx, float* dbias, float* dgamma,
                   float* dbeta, int accumulate, er_stream_t stream);
+/* er_bn_act_bwd with dy as a column block of a wider buffer (row stride dy_ld >= N): the gradient slice a concat's
+ * backward hands over, read in place. */
+int er_bn_act_bwd_ld(const float* x, const float* bias, const float* gamma, const float* y,
+                     const float* save_mean, const float* save_invstd, const float* dy, int32_t dy_ld,
+                     int32_t B, int32_t N, int use_bn, int act, float* dx, float* dbias, float* dgamma,
+                     float* dbeta, int accumulate, er_stream_t stream);
 /* The second half of er_bn_act_bwd, fed with column-sum partials [chunks][N][2] that the dgrad GEMM's epilogue
  * already produced (er_gemm_f32_bn_bwd). */
 int er_bn_act_bwd_from_partials(const float* x, const float* bias, const float* gamma, const float* y,
@@ -362,7 +395,10 @@ int er_bn_act_bwd_from_partials(const float* x, const float* bias, const float* 
                                 int32_t B, int32_t N, int use_bn, int act, const float* partial,
                                 int32_t chunks, float* dx, float* dbias, float* dgamma, float* dbeta,
                                 int accumulate, er_stream_t stream);
-/* out[j] = sum_i x[i, j]  (bias gradients, partial reductions) */
+/* out[j] = sum_i x[i, j]  (bias gradients, partial reductions); er_colsum_acc: out[j] += ... when accumulate
+ * (straight into the variable's slice of the flat gradient buffer) */
+int er_colsum_acc(const float* x, int32_t rows, int32_t cols, int32_t x_stride, float* out, int accumulate,
+                  er_stream_t stream);
 int er_colsum(const float* x, int32_t rows, int32_t cols, int32_t x_stride, float* out,
               er_stream_t stream);
 /* Dice: p = sigmoid(BN_noaffine(x, eps)); y = alpha*(1-p)*x + p*x */

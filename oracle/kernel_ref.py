@@ -665,6 +665,26 @@ class RefBackend(object):
   def rowsum_bwd(self, g, n, into=None, accumulate=False):
     return self._into(g.reshape(-1, 1).expand(-1, n).contiguous(), into, accumulate)
 
+  def concat_cols(self, parts):
+    return torch.cat([t.detach() for t in parts], dim=1)
+
+  def group_grad_finish(self, groups):
+    for dout, out, lam, has_base, terms in groups:
+      v = dout.detach().clone() if has_base else torch.zeros_like(dout)
+      o = out.detach()
+      for term in terms:
+        if term[0] == 'rowsum':
+          _, g, col0, width = term
+          v[:, col0:col0 + width] += g.detach().reshape(-1, 1)
+        else:
+          _, g, saved, col0, width, dim = term
+          F = width // dim
+          x3 = o[:, col0:col0 + width].reshape(o.shape[0], F, dim)
+          v[:, col0:col0 + width] += (g.detach().reshape(-1, 1, dim) * (saved.reshape(-1, 1, dim) - x3)).reshape(o.shape[0], width)
+      if lam:
+        v += F32(lam) * o
+      dout.copy_(v)
+
   def axpy2d(self, x, alpha, y, accumulate=True):
     if accumulate:
       y.add_(x, alpha=alpha)
@@ -785,8 +805,15 @@ class RefBackend(object):
         dbias = g.sum(dim=0)
     return dx, dbias, dgamma, dbeta
 
-  def colsum(self, x):
-    return x.sum(dim=0)
+  def colsum(self, x, out=None, accumulate=False):
+    r = x.detach().sum(dim=0)
+    if out is None:
+      return r
+    if accumulate:
+      out += r
+    else:
+      out.copy_(r)
+    return out
 
   def dice_fwd(self, x, alpha, eps, momentum, moving_mean, moving_var):
     mean = x.mean(dim=0)
