@@ -154,6 +154,15 @@ class VarStore(object):
     self._offsets = off
     self.packed = True
     self.any_l2 = any(self._vars[n]['l2'] != 0.0 for n in names)
+    # per-256-weight sums of 0.5 * l2 * w^2: the kernel-L2 term of the loss without a pass over the weights - the dense
+    # optimizer leaves them behind for the next step (er_dense_opt_step_l2); refreshed here and after every load
+    self.l2_partials = torch.zeros((total + 255) // 256, dtype=torch.float32, device=self.device) if self.any_l2 else None
+    self.refresh_l2_partials()
+
+  def refresh_l2_partials(self):
+    if getattr(self, 'l2_partials', None) is not None:
+      from easyrec_amd import kernels
+      kernels.hip().l2_partials(self.flat, self.l2coef, self.l2_partials)
 
   def slot(self, name):
     if name not in self.slots:
@@ -182,6 +191,8 @@ class VarStore(object):
           r['tensor'].copy_(torch.from_numpy(np.asarray(state[n], dtype=np.float32)).to(self.device))
       elif strict:
         raise KeyError('missing variable %s' % n)
+    if self.packed:
+      self.refresh_l2_partials()
 
   def grad_dict(self):
     out = OrderedDict()

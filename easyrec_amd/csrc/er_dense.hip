@@ -522,24 +522,21 @@ __global__ void total_loss_kernel(const float* __restrict__ reg_emb, const float
 }
 
 // The scalar tail of the loss in ONE launch (one workgroup of 1024): regularization_loss = emb_scale * sum(partials)
-// [the embedding-output L2: per-block sums of squares left by er_emb_fwd] + sum_i 0.5 * coef[i] * w[i]^2 [the kernels'
-// L2], total_loss = regularization_loss + sum of the task losses, and the copies of the task losses into their report
-// slots.  Replaces er_reduce_sum + er_l2_loss (two launches) + er_total_loss.  Fixed order: deterministic.
+// [the embedding-output L2: per-block sums of squares left by er_emb_fwd] + sum(dense_partials) [the kernels' L2: per-
+// block sums of 0.5 * coef * w^2 that the dense optimizer leaves behind for the NEXT step while it has every weight in
+// registers anyway - er_dense_opt_step_l2 / er_l2_partials; a single workgroup walking 0.28 M weights itself took
+// 150 us], total_loss = regularization_loss + sum of the task losses, and the copies of the task losses into their
+// report slots.  Replaces er_reduce_sum + er_l2_loss (two launches) + er_total_loss.  Fixed order: deterministic.
 __global__ void __launch_bounds__(kCeBlock)
 reg_total_loss_kernel(const float* __restrict__ emb_partials, int n_partials, float emb_scale,
-                      const float* __restrict__ w, const float* __restrict__ coef, int64_t n, LossPtrs lp, int n_losses,
+                      const float* __restrict__ dense_partials, int n_dense, LossPtrs lp, int n_losses,
                       float* __restrict__ reg_out, float* __restrict__ total_out) {
   __shared__ float red[kCeBlock / 64];
   float a = 0.f;
   for (int i = threadIdx.x; i < n_partials; i += kCeBlock) a = a + emb_partials[i];
   const float emb = block_sum_1024(a, red);
   float b = 0.f;
-  if (w && coef) {
-    for (int64_t i = threadIdx.x; i < n; i += kCeBlock) {
-      const float c = coef[i];
-      if (c != 0.f) b = b + c * (0.5f * (w[i] * w[i]));
-    }
-  }
+  for (int i = threadIdx.x; i < n_dense; i += kCeBlock) b = b + dense_partials[i];
   const float dense = block_sum_1024(b, red);
   if (threadIdx.x != 0) return;
   const float reg = emb_scale * emb + dense;
@@ -579,12 +576,10 @@ l2_loss_partial_kernel(const float* __restrict__ w, const float* __restrict__ co
 // ------------------------------------------------------------------------------------------------
 // dense-variable optimizer over the flat buffer
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock)
-dense_opt_kernel(float* __restrict__ w, float* __restrict__ m, float* __restrict__ v, const float* __restrict__ grad,
-                 const float* __restrict__ l2coef, int64_t n, int opt_kind, const er_opt_hyper* __restrict__ hyper) {
-  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
-  if (i >= n) return;
-  const er_opt_hyper h = *hyper;
+// one element of the dense optimizer; returns 0.5 * coef * w_new^2 (its share of the next step's kernel-L2 loss)
+__device__ __forceinline__ float dense_opt_elem(float* __restrict__ w, float* __restrict__ m, float* __restrict__ v,
+                                                const float* __restrict__ grad, const float* __restrict__ l2coef,
+                                                int64_t i, int opt_kind, const er_opt_hyper& h) {
   float wi = w[i];
   float g = grad[i] * h.grad_scale;
   if (l2coef) {
@@ -608,7 +603,43 @@ dense_opt_kernel(float* __restrict__ w, float* __restrict__ m, float* __restrict
     wi = wi - h.lr * g;
   }
   w[i] = wi;
+  float l2 = 0.f;
+  if (l2coef) {
+    const float c = l2coef[i];
+    if (c != 0.f) l2 = c * (0.5f * (wi * wi));
+  }
+  return l2;
 }
+
+__global__ void __launch_bounds__(kBlock)
+dense_opt_kernel(float* __restrict__ w, float* __restrict__ m, float* __restrict__ v, const float* __restrict__ grad,
+                 const float* __restrict__ l2coef, int64_t n, int opt_kind, const er_opt_hyper* __restrict__ hyper,
+                 float* __restrict__ l2_partial) {
+  __shared__ float red[4];
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  float l2 = 0.f;
+  if (i < n) l2 = dense_opt_elem(w, m, v, grad, l2coef, i, opt_kind, *hyper);
+  if (l2_partial) {  // (uniform) sum over the block of 0.5 * coef * w_new^2: the next step's kernel-L2 loss term
+    const float sum = block_sum_256(l2, red);
+    if (threadIdx.x == 0) l2_partial[blockIdx.x] = sum;
+  }
+}
+
+// partial[b] = sum over block b's 256 weights of 0.5 * coef * w^2, the block mapping and order of dense_opt_kernel
+__global__ void __launch_bounds__(kBlock)
+l2_partials_kernel(const float* __restrict__ w, const float* __restrict__ coef, int64_t n, float* __restrict__ partial) {
+  __shared__ float red[4];
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  float l2 = 0.f;
+  if (i < n) {
+    const float c = coef[i];
+    if (c != 0.f) l2 = c * (0.5f * (w[i] * w[i]));
+  }
+  const float sum = block_sum_256(l2, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = sum;
+}
+
+
 
 // per-step scalars: out[:] = table[counter % n_slots][:]; counter += 1   (one block)
 // (+ blocks > 0, and block 0 after its own work: zero `zero_n` floats at `zero` - the flat gradient buffer of the dense
@@ -909,10 +940,11 @@ int er_step_prologue(const float* table, int64_t* counter, int32_t n_slots, int3
   return 0;
 }
 
-int er_reg_total_loss(const float* emb_partials, int32_t n_partials, float emb_scale, const float* w, const float* coef,
-                      int64_t n, const float* const* losses, float* const* report, int32_t n_losses, float* reg_out,
+int er_reg_total_loss(const float* emb_partials, int32_t n_partials, float emb_scale, const float* dense_partials,
+                      int32_t n_dense, const float* const* losses, float* const* report, int32_t n_losses, float* reg_out,
                       float* total_out, er_stream_t stream) {
-  ER_REQUIRE(reg_out && total_out && n_losses >= 0 && n_losses <= 8 && n_partials >= 0 && (emb_partials || n_partials == 0),
+  ER_REQUIRE(reg_out && total_out && n_losses >= 0 && n_losses <= 8 && n_partials >= 0 && (emb_partials || n_partials == 0) &&
+                 n_dense >= 0 && (dense_partials || n_dense == 0),
              "er_reg_total_loss: bad arguments (at most 8 losses)");
   er::LossPtrs lp;
   for (int i = 0; i < 8; ++i) {
@@ -920,18 +952,31 @@ int er_reg_total_loss(const float* emb_partials, int32_t n_partials, float emb_s
     lp.dst[i] = (i < n_losses && report) ? report[i] : nullptr;
   }
   hipLaunchKernelGGL(er::reg_total_loss_kernel, dim3(1), dim3(er::kCeBlock), 0, er::as_stream(stream), emb_partials,
-                     n_partials, emb_scale, w, coef, n, lp, n_losses, reg_out, total_out);
+                     n_partials, emb_scale, dense_partials, n_dense, lp, n_losses, reg_out, total_out);
   ER_LAUNCH_CHECK();
   return 0;
 }
 
 int er_dense_opt_step(float* w, float* m, float* v, const float* grad, const float* l2coef, int64_t n, int opt_kind,
                       const er_opt_hyper* hyper, er_stream_t stream) {
+  return er_dense_opt_step_l2(w, m, v, grad, l2coef, n, opt_kind, hyper, nullptr, stream);
+}
+
+int er_l2_partials(const float* w, const float* coef, int64_t n, float* partials, er_stream_t stream) {
+  ER_REQUIRE(w && coef && partials && n > 0, "er_l2_partials: bad arguments");
+  hipLaunchKernelGGL(er::l2_partials_kernel, dim3(er::blocks_for(n)), dim3(er::kBlock), 0, er::as_stream(stream), w, coef, n,
+                     partials);
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
+int er_dense_opt_step_l2(float* w, float* m, float* v, const float* grad, const float* l2coef, int64_t n, int opt_kind,
+                         const er_opt_hyper* hyper, float* l2_partials, er_stream_t stream) {
   ER_REQUIRE(w && grad && hyper && n > 0, "er_dense_opt_step: bad arguments");
   if (opt_kind == ER_OPT_ADAM || opt_kind == ER_OPT_LAZY_ADAM) ER_REQUIRE(m && v, "er_dense_opt_step: Adam needs m, v");
   if (opt_kind == ER_OPT_ADAGRAD) ER_REQUIRE(v, "er_dense_opt_step: Adagrad needs the accumulator in v");
   hipLaunchKernelGGL(er::dense_opt_kernel, dim3(er::blocks_for(n)), dim3(er::kBlock), 0, er::as_stream(stream), w, m, v,
-                     grad, l2coef, n, opt_kind, hyper);
+                     grad, l2coef, n, opt_kind, hyper, l2_partials);
   ER_LAUNCH_CHECK();
   return 0;
 }

@@ -389,8 +389,10 @@ __device__ __forceinline__ void decay_v_only(float* v, int32_t k, const er_opt_h
 template <int V>
 __device__ __forceinline__ void replay_decay(float* var, float* m, float* v, const float* __restrict__ lr_hist,
                                              int32_t s_begin, int32_t s_end, const er_opt_hyper& h,
-                                             const float* __restrict__ lr_max_hist = nullptr) {
-  // steps s_begin .. s_end - 1 were decay-only for this row.  Three regimes, the first two bit-identical to the
+                                             const float* __restrict__ lr_max_hist = nullptr,
+                                             bool* cheap_from_here = nullptr) {
+  // steps s_begin .. s_end - 1 were decay-only for this row.  cheap_from_here (optional): did the row leave the full
+  // regime by the end of this call (replay_block sorts its tasks by it).  Three regimes, the first two bit-identical to the
   // step-by-step sweep:
   //  (1) full step: m *= b1; v *= b2; var -= lr_t(s) * m / (sqrt(v) + eps)                  (~20 instructions/element)
   //  (2) ABSORBED: the update has fallen below a quarter ulp of var and can only shrink from here, so var no longer
@@ -407,22 +409,31 @@ __device__ __forceinline__ void replay_decay(float* var, float* m, float* v, con
   //      (er_emb_flush_window) bounds the idle time; a longer backlog (a flush after thousands of steps without the
   //      rolling flush) takes the closed form v *= b2^k, the one documented deviation (<= 1e-6 relative on v).
   const bool can_absorb = lr_max_hist != nullptr && h.beta1 < 0.999f * sqrtf(h.beta2) && s_end > s_begin;
-  const float lr_cap = can_absorb ? lr_max_hist[s_end - 1] : 0.f;
+  const float lr_cap2 = can_absorb ? 2.0f * lr_max_hist[s_end - 1] : 0.f;
   int32_t s = s_begin;
   bool absorbed = false;
   for (; s < s_end && !absorbed; ++s) {
-    bool settled = true;
+    // settled needs m on the fixed point of fl(m * b1), i.e. a handful of denormal units: the (division-heavy) test is
+    // only evaluated once every m of the lane is that small
+    bool tiny = true;
 #pragma unroll
-    for (int i = 0; i < V; ++i) {
-      const float bound = fabsf(m[i]) / h.eps;
-      settled = settled && (m[i] * h.beta1 == m[i]) && (var[i] - bound == var[i]) && (var[i] + bound == var[i]);
-    }
-    if (settled) {
-      decay_v_only<V>(v, s_end - s, h);
-      return;
+    for (int i = 0; i < V; ++i) tiny = tiny && (fabsf(m[i]) < 1.0e-37f);
+    if (tiny) {
+      bool settled = true;
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        const float bound = fabsf(m[i]) / h.eps;
+        settled = settled && (m[i] * h.beta1 == m[i]) && (var[i] - bound == var[i]) && (var[i] + bound == var[i]);
+      }
+      if (settled) {
+        decay_v_only<V>(v, s_end - s, h);
+        if (cheap_from_here) *cheap_from_here = true;
+        return;
+      }
     }
     const float lr_t = lr_hist[s];
-    const float amp = can_absorb ? 2.0f * (lr_cap / lr_t) : 0.f;  // (lr_t > 0: the schedules have a positive floor)
+    // absorbed test without a division: |upd| * 2 L / lr_t < 2^-26 |var|  <=>  |upd| * 2 L < 2^-26 |var| * lr_t
+    const float thr = 1.4901161193847656e-08f * lr_t;  // (lr_t > 0: the schedules have a positive floor)
     bool all_small = can_absorb;
 #pragma unroll
     for (int i = 0; i < V; ++i) {
@@ -432,10 +443,11 @@ __device__ __forceinline__ void replay_decay(float* var, float* m, float* v, con
       m[i] = mt;
       v[i] = vt;
       var[i] = var[i] - upd;
-      all_small = all_small && (fabsf(upd) * amp < fabsf(var[i]) * 1.4901161193847656e-08f);  // 2^-26 |var|
+      all_small = all_small && (fabsf(upd) * lr_cap2 < fabsf(var[i]) * thr);
     }
     absorbed = all_small;
   }
+  if (cheap_from_here) *cheap_from_here = absorbed;
   // (2) var is fixed from here on (every lane element absorbed; lanes of a row decide independently - each owns its
   // elements).  m and v keep their step-by-step rounding.
   for (; s < s_end; ++s) {
@@ -454,33 +466,98 @@ __device__ __forceinline__ void replay_decay(float* var, float* m, float* v, con
   }
 }
 
+// Block-cooperative replay.  A lane's task = the V elements it owns of one row with pending decay steps
+// [s_begin, s_end) (s_end uniform over the workgroup).  The cost of a task is dominated by its steps in the FULL regime
+// (sqrt + IEEE division per element and step) - ~150 of them after a touch, none for a row that has long been idle -
+// and rows of both kinds sit side by side in a table: lanes replaying in place would idle while one lane of their wave
+// grinds through full steps (measured: two thirds of the lane-cycles).  So: every task runs ONE step in place, which
+// also classifies it (still full / cheap from here); unfinished tasks are compacted into two LDS queues - registers
+// and all - and the workgroup's lanes take them densely, the full ones first.  Results do not depend on the order
+// the queues fill in.  All threads of the workgroup must call this (it synchronises); smem: kReplaySmemWords words.
+constexpr int kReplayEntry = 3 * 4 + 3;                        // var, m, v (V <= 4) + element offset (2) + next step
+constexpr int kReplaySmemWords = 2 * kBlock * kReplayEntry + 4;
+
+template <int V>
+__device__ __forceinline__ void replay_block(bool has, int64_t off, int32_t s_begin, int32_t s_end, const RowUpdate& tab,
+                                             const float* __restrict__ lr_hist, const float* __restrict__ lr_max,
+                                             const er_opt_hyper* __restrict__ hyper, uint32_t* __restrict__ smem) {
+  int* cnt = reinterpret_cast<int*>(smem);  // [2]
+  uint32_t* queue = smem + 4;               // [2][kBlock][kReplayEntry]
+  if (threadIdx.x < 2) cnt[threadIdx.x] = 0;
+  __syncthreads();
+  float var[V], m[V], v[V];
+  bool task = false;
+  int32_t s = s_begin;
+  if (has && s_begin < s_end) {
+    ld_vec<V>(m, tab.m + off);
+    ld_vec<V>(v, tab.v + off);
+#pragma unroll
+    for (int j = 0; j < V; ++j) task = task || (m[j] != 0.f) || (v[j] != 0.f);  // never touched: a fixed point of the decay
+  }
+  if (task) {
+    const er_opt_hyper h = *hyper;
+    ld_vec<V>(var, tab.var + off);
+    bool cheap = false;
+    replay_decay<V>(var, m, v, lr_hist, s, s + 1, h, lr_max, &cheap);
+    ++s;
+    if (s >= s_end) {
+      st_vec<V>(tab.var + off, var);
+      st_vec<V>(tab.m + off, m);
+      st_vec<V>(tab.v + off, v);
+    } else {
+      const int k = cheap ? 1 : 0;
+      uint32_t* e = queue + (static_cast<size_t>(k) * kBlock + atomicAdd(&cnt[k], 1)) * kReplayEntry;
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        e[j] = __builtin_bit_cast(uint32_t, var[j]);
+        e[4 + j] = __builtin_bit_cast(uint32_t, m[j]);
+        e[8 + j] = __builtin_bit_cast(uint32_t, v[j]);
+      }
+      e[12] = static_cast<uint32_t>(static_cast<uint64_t>(off) & 0xFFFFFFFFu);
+      e[13] = static_cast<uint32_t>(static_cast<uint64_t>(off) >> 32);
+      e[14] = static_cast<uint32_t>(s);
+    }
+  }
+  __syncthreads();
+#pragma unroll 1
+  for (int k = 0; k < 2; ++k) {
+    const int n = cnt[k];
+    for (int t = threadIdx.x; t < n; t += kBlock) {
+      const uint32_t* e = queue + (static_cast<size_t>(k) * kBlock + t) * kReplayEntry;
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        var[j] = __builtin_bit_cast(float, e[j]);
+        m[j] = __builtin_bit_cast(float, e[4 + j]);
+        v[j] = __builtin_bit_cast(float, e[8 + j]);
+      }
+      const int64_t o = static_cast<int64_t>(static_cast<uint64_t>(e[12]) | (static_cast<uint64_t>(e[13]) << 32));
+      replay_decay<V>(var, m, v, lr_hist, static_cast<int32_t>(e[14]), s_end, *hyper, lr_max);
+      st_vec<V>(tab.var + o, var);
+      st_vec<V>(tab.m + o, m);
+      st_vec<V>(tab.v + o, v);
+    }
+  }
+}
+
 // one lane group per unique row touched by the coming step (keys from er_emb_route); brings the row to
 // "after step t-1" where t = *step_counter - 1 is the step being executed
 template <int V>
 __device__ __forceinline__ void catch_up_body(int bid, const uint32_t* __restrict__ ukeys,
                                               const int32_t* __restrict__ n_unique, int64_t capacity, const RowUpdate& tab,
                                               const float* __restrict__ lr_hist, const er_opt_hyper* __restrict__ hyper,
-                                              int dim, int G, const float* __restrict__ lr_max = nullptr) {
+                                              int dim, int G, const float* __restrict__ lr_max, uint32_t* __restrict__ smem) {
   const int64_t i = (static_cast<int64_t>(bid) * kBlock + threadIdx.x) / G;
   const int c = (static_cast<int>(threadIdx.x) % G) * V;
-  if (i >= capacity || i >= *n_unique || c >= dim) return;
-  const uint32_t key = ukeys[i];
   const int32_t t = static_cast<int32_t>(*tab.step_counter - 1);
-  const int32_t last = tab.last_step[key];
-  if (last + 1 >= t) return;  // nothing pending (touched at step t-1, or never decaying yet: see below)
-  const int64_t off = static_cast<int64_t>(key) * dim + c;
-  float var[V], m[V], v[V];
-  ld_vec<V>(var, tab.var + off);
-  ld_vec<V>(m, tab.m + off);
-  ld_vec<V>(v, tab.v + off);
-  bool live = false;
-#pragma unroll
-  for (int j = 0; j < V; ++j) live = live || (m[j] != 0.f) || (v[j] != 0.f);
-  if (!live) return;  // never touched: m = v = 0 is a fixed point of the decay
-  replay_decay<V>(var, m, v, lr_hist, last + 1, t, *hyper, lr_max);
-  st_vec<V>(tab.var + off, var);
-  st_vec<V>(tab.m + off, m);
-  st_vec<V>(tab.v + off, v);
+  bool has = i < capacity && i < *n_unique && c < dim;
+  int64_t off = 0;
+  int32_t s_begin = t;
+  if (has) {
+    const uint32_t key = ukeys[i];
+    s_begin = tab.last_step[key] + 1;  // (touched at step t-1, or never updated yet and current: nothing pending)
+    off = static_cast<int64_t>(key) * dim + c;
+  }
+  replay_block<V>(has, off, s_begin, t, tab, lr_hist, lr_max, hyper, smem);
   // last_step[key] is set to t by this step's row update (every caught-up row is touched by the step)
 }
 
@@ -489,7 +566,8 @@ __global__ void __launch_bounds__(kBlock)
 emb_catch_up_kernel(const uint32_t* __restrict__ ukeys, const int32_t* __restrict__ n_unique, int64_t capacity,
                     RowUpdate tab, const float* __restrict__ lr_hist, const er_opt_hyper* __restrict__ hyper, int dim,
                     int G, const float* __restrict__ lr_max) {
-  catch_up_body<V>(blockIdx.x, ukeys, n_unique, capacity, tab, lr_hist, hyper, dim, G, lr_max);
+  __shared__ uint32_t smem[kReplaySmemWords];
+  catch_up_body<V>(blockIdx.x, ukeys, n_unique, capacity, tab, lr_hist, hyper, dim, G, lr_max, smem);
 }
 
 // Horizontal fusion: the same per-group work of up to kMaxMulti table groups in ONE grid - workgroups
@@ -518,10 +596,11 @@ __global__ void __launch_bounds__(kBlock)
 emb_catch_up_multi_kernel(CatchUpMulti ma) {
   int i = 0;
   while (i + 1 < ma.n && static_cast<int>(blockIdx.x) >= ma.start[i + 1]) ++i;
+  __shared__ uint32_t smem[kReplaySmemWords];
   const CatchUpArgs& a = ma.a[i];
   const int bid = blockIdx.x - ma.start[i];
-  if (a.V == 4) catch_up_body<4>(bid, a.ukeys, a.n_unique, a.capacity, a.tab, a.lr_hist, ma.hyper, a.dim, a.G, a.lr_max);
-  else catch_up_body<1>(bid, a.ukeys, a.n_unique, a.capacity, a.tab, a.lr_hist, ma.hyper, a.dim, a.G, a.lr_max);
+  if (a.V == 4) catch_up_body<4>(bid, a.ukeys, a.n_unique, a.capacity, a.tab, a.lr_hist, ma.hyper, a.dim, a.G, a.lr_max, smem);
+  else catch_up_body<1>(bid, a.ukeys, a.n_unique, a.capacity, a.tab, a.lr_hist, ma.hyper, a.dim, a.G, a.lr_max, smem);
 }
 
 // every row: replay the pending decay steps up to and including step (*step_counter - 1); last_step = that
@@ -564,32 +643,19 @@ template <int V>
 __device__ __forceinline__ void flush_window_body(int bid, const RowUpdate& tab, int64_t total_rows, int64_t chunk,
                                                   int n_windows, const float* __restrict__ lr_hist,
                                                   const float* __restrict__ lr_max,
-                                                  const er_opt_hyper* __restrict__ hyper, int dim, int G) {
+                                                  const er_opt_hyper* __restrict__ hyper, int dim, int G,
+                                                  uint32_t* __restrict__ smem) {
   const int32_t done = static_cast<int32_t>(*tab.step_counter);
   const int64_t w = static_cast<int64_t>(done) % n_windows;
   const int64_t row = w * chunk + (static_cast<int64_t>(bid) * kBlock + threadIdx.x) / G;
   const int sub = static_cast<int>(threadIdx.x) % G;
   const int c = sub * V;
   const int64_t end = (w + 1) * chunk < total_rows ? (w + 1) * chunk : total_rows;
-  if (row >= end || c >= dim) return;
-  const int32_t last = tab.last_step[row];
-  if (last + 1 >= done) return;
-  const int64_t off = row * dim + c;
-  float m[V], v[V];
-  ld_vec<V>(m, tab.m + off);
-  ld_vec<V>(v, tab.v + off);
-  bool live = false;
-#pragma unroll
-  for (int j = 0; j < V; ++j) live = live || (m[j] != 0.f) || (v[j] != 0.f);
-  if (live) {  // (a lane whose elements never moved skips; m = v = 0 is a fixed point of the decay)
-    float var[V];
-    ld_vec<V>(var, tab.var + off);
-    replay_decay<V>(var, m, v, lr_hist, last + 1, done, *hyper, lr_max);
-    st_vec<V>(tab.var + off, var);
-    st_vec<V>(tab.m + off, m);
-    st_vec<V>(tab.v + off, v);
-  }
-  if (sub == 0) tab.last_step[row] = done - 1;
+  const bool in_window = row < end;
+  const bool has = in_window && c < dim;
+  const int32_t s_begin = in_window ? tab.last_step[row] + 1 : done;
+  replay_block<V>(has, row * dim + c, s_begin, done, tab, lr_hist, lr_max, hyper, smem);  // (synchronises first)
+  if (in_window && sub == 0 && s_begin < done) tab.last_step[row] = done - 1;
 }
 
 struct FlushWindowArgs {
@@ -610,10 +676,11 @@ __global__ void __launch_bounds__(kBlock)
 emb_flush_window_kernel(FlushWindowMulti ma) {
   int i = 0;
   while (i + 1 < ma.n && static_cast<int>(blockIdx.x) >= ma.start[i + 1]) ++i;
+  __shared__ uint32_t smem[kReplaySmemWords];
   const FlushWindowArgs& a = ma.a[i];
   const int bid = blockIdx.x - ma.start[i];
-  if (a.V == 4) flush_window_body<4>(bid, a.tab, a.total_rows, a.chunk, ma.n_windows, a.lr_hist, a.lr_max, ma.hyper, a.dim, a.G);
-  else flush_window_body<1>(bid, a.tab, a.total_rows, a.chunk, ma.n_windows, a.lr_hist, a.lr_max, ma.hyper, a.dim, a.G);
+  if (a.V == 4) flush_window_body<4>(bid, a.tab, a.total_rows, a.chunk, ma.n_windows, a.lr_hist, a.lr_max, ma.hyper, a.dim, a.G, smem);
+  else flush_window_body<1>(bid, a.tab, a.total_rows, a.chunk, ma.n_windows, a.lr_hist, a.lr_max, ma.hyper, a.dim, a.G, smem);
 }
 
 // second pass of the flush (all lanes of a row must have read last_step before it changes)

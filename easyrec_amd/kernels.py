@@ -1012,18 +1012,25 @@ class HipBackend(object):
     self._ck(self.lib.er_total_loss(_p(reg_emb), _p(reg_dense), src, dst, n, _p(reg_out), _p(total_out), _stream()),
              'er_total_loss')
 
-  def reg_total_loss(self, emb_partials, emb_scale, w, coef, losses, reports, reg_out, total_out):
-    """reg_out = emb_scale * sum(emb_partials) + sum 0.5 * coef * w^2; total_out = reg_out + sum(losses); reports[i] =
-    losses[i].  emb_partials / (w, coef) may be None.  One launch (er_reg_total_loss)."""
+  def reg_total_loss(self, emb_partials, emb_scale, dense_partials, losses, reports, reg_out, total_out):
+    """reg_out = emb_scale * sum(emb_partials) + sum(dense_partials); total_out = reg_out + sum(losses); reports[i] =
+    losses[i].  Either partial array may be None.  One launch (er_reg_total_loss)."""
     n = len(losses)
     assert n <= 8
     src = (ctypes.c_void_p * max(n, 1))(*[t.data_ptr() for t in losses])
     dst = (ctypes.c_void_p * max(n, 1))(*[t.data_ptr() for t in reports])
     n_part = 0 if emb_partials is None else emb_partials.numel()
-    n_w = 0 if (w is None or coef is None) else w.numel()
+    n_dense = 0 if dense_partials is None else dense_partials.numel()
     self._ck(self.lib.er_reg_total_loss(_p(emb_partials), ctypes.c_int32(n_part), ctypes.c_float(emb_scale),
-                                        _p(w) if n_w else None, _p(coef) if n_w else None, ctypes.c_int64(n_w), src, dst,
-                                        ctypes.c_int32(n), _p(reg_out), _p(total_out), _stream()), 'er_reg_total_loss')
+                                        _p(dense_partials), ctypes.c_int32(n_dense), src, dst, ctypes.c_int32(n),
+                                        _p(reg_out), _p(total_out), _stream()), 'er_reg_total_loss')
+
+  def l2_partials(self, w, coef, partials):
+    """partials[b] = sum over weights [256 b, 256 b + 256) of 0.5 * coef * w^2 (what dense_opt_step(l2_partials=) keeps
+    current from then on)."""
+    assert partials.numel() == (w.numel() + 255) // 256
+    self._ck(self.lib.er_l2_partials(_p(w), _p(coef), ctypes.c_int64(w.numel()), _p(partials), _stream()),
+             'er_l2_partials')
 
   def reduce_sum(self, partials, scale, out, accumulate=False):
     self._ck(
@@ -1144,10 +1151,12 @@ class HipBackend(object):
                                           _p(n_unique), ctypes.c_int(opt_kind), _p(hyper), _stream()), 'er_emb_apply_unique')
 
   # -- dense optimizer
-  def dense_opt_step(self, w, m, v, grad, l2coef, opt_kind, hyper):
+  def dense_opt_step(self, w, m, v, grad, l2coef, opt_kind, hyper, l2_partials=None):
+    """l2_partials: left holding the per-256-weight sums of 0.5 * l2coef * w_new^2 (the next step's kernel-L2 loss)."""
     self._ck(
-        self.lib.er_dense_opt_step(_p(w), _p(m), _p(v), _p(grad), _p(l2coef), ctypes.c_int64(w.numel()),
-                                   ctypes.c_int(opt_kind), _p(hyper), _stream()), 'er_dense_opt_step')
+        self.lib.er_dense_opt_step_l2(_p(w), _p(m), _p(v), _p(grad), _p(l2coef), ctypes.c_int64(w.numel()),
+                                      ctypes.c_int(opt_kind), _p(hyper), _p(l2_partials), _stream()),
+        'er_dense_opt_step_l2')
 
 
 _BACKEND = None

@@ -240,7 +240,8 @@ class EasyRecEstimator(object):
             keep = be.flush_wgrads()
             self._sync_dense_grads()
             be.dense_opt_step(vs.flat, vs.slots.get('m'), vs.slots.get('v'), vs.flat_grad,
-                              vs.l2coef if vs.any_l2 else None, self.opt_dense.kind, self.hyper[1])
+                              vs.l2coef if vs.any_l2 else None, self.opt_dense.kind, self.hyper[1],
+                              l2_partials=vs.l2_partials)
           self.engine.backward_update(self.opt_emb.kind, self.hyper[0])
           main.wait_stream(side)
           del keep  # the queued operands stayed referenced until the streams joined
@@ -253,7 +254,8 @@ class EasyRecEstimator(object):
           self._sync_dense_grads()
           self.engine.backward_update(self.opt_emb.kind, self.hyper[0])
           be.dense_opt_step(vs.flat, vs.slots.get('m'), vs.slots.get('v'), vs.flat_grad,
-                            vs.l2coef if vs.any_l2 else None, self.opt_dense.kind, self.hyper[1])
+                            vs.l2coef if vs.any_l2 else None, self.opt_dense.kind, self.hyper[1],
+                            l2_partials=vs.l2_partials)
 
   def _emb_gradsq_weight(self):
     """What the squared embedding row sums are multiplied by in the norm: grad_scale^2 (fp32, as the kernels apply it)."""
@@ -269,7 +271,8 @@ class EasyRecEstimator(object):
     self.engine.backward_reduce(self._normsq, self._emb_gradsq_weight())
     be.clip_scale(self._normsq, self.clip_norm, self.hyper, self.grad_norm)
     self.engine.apply_reduced(self.opt_emb.kind, self.hyper[0])
-    be.dense_opt_step(vs.flat, vs.slots.get('m'), vs.slots.get('v'), vs.flat_grad, l2, self.opt_dense.kind, self.hyper[1])
+    be.dense_opt_step(vs.flat, vs.slots.get('m'), vs.slots.get('v'), vs.flat_grad, l2, self.opt_dense.kind, self.hyper[1],
+                      l2_partials=vs.l2_partials)
 
   def _loss_tail(self, loss_dict):
     """regularization_loss = embedding-output L2 + kernel L2, total_loss = that + the task losses (estimator :166-184);
@@ -280,7 +283,7 @@ class EasyRecEstimator(object):
       if name not in self.losses:
         self.losses[name] = torch.zeros(1, dtype=torch.float32, device=self.device)
     partials = eng.sumsq[:eng.reg_blocks] if (eng.reg_lambda > 0 and eng.reg_blocks > 0) else None
-    be.reg_total_loss(partials, 0.5 * eng.reg_lambda, vs.flat if vs.any_l2 else None, vs.l2coef if vs.any_l2 else None,
+    be.reg_total_loss(partials, 0.5 * eng.reg_lambda, vs.l2_partials if vs.any_l2 else None,
                       [loss_dict[n].reshape(1) for n in names], [self.losses[n] for n in names],
                       self.losses['regularization_loss'], self.losses['total_loss'])
 

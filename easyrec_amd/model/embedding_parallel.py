@@ -105,7 +105,8 @@ class EmbeddingParallelEstimator(EasyRecEstimator):
     vs = self.varstore
     self.engine.apply_replicated(self.opt_emb.kind, self.hyper[0])
     kernels.hip().dense_opt_step(vs.flat, vs.slots.get('m'), vs.slots.get('v'), vs.flat_grad,
-                                 vs.l2coef if vs.any_l2 else None, self.opt_dense.kind, self.hyper[1])
+                                 vs.l2coef if vs.any_l2 else None, self.opt_dense.kind, self.hyper[1],
+                                 l2_partials=vs.l2_partials)
 
   def _phase_owner_serve(self):
     self.engine.owner_serve()

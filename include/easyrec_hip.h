@@ -425,12 +425,20 @@ int er_sigmoid_ce_fwd_bwd(const float* logits, const float* labels, const float*
 int er_total_loss(const float* reg_emb, const float* reg_dense, const float* const* losses_host,
                   float* const* report_host, int32_t n, float* reg_out, float* total_out, er_stream_t stream);
 /* The scalar tail of the loss in ONE launch: reg_out[0] = emb_scale * sum(emb_partials[0..n_partials)) [embedding-output
- * L2 from er_emb_fwd's per-block sums of squares; n_partials may be 0] + sum_i 0.5 * coef[i] * w[i]^2 [w / coef may be
- * NULL]; total_out[0] = reg_out[0] + sum_i losses[i][0]; report[i][0] = losses[i][0] (report may be NULL).  losses /
- * report: HOST arrays of n_losses <= 8 DEVICE pointers.  = er_reduce_sum + er_l2_loss + er_total_loss. */
-int er_reg_total_loss(const float* emb_partials, int32_t n_partials, float emb_scale, const float* w, const float* coef,
-                      int64_t n, const float* const* losses_host, float* const* report_host, int32_t n_losses,
+ * L2 from er_emb_fwd's per-block sums of squares; n_partials may be 0] + sum(dense_partials[0..n_dense)) [the kernels'
+ * L2, sum_i 0.5 * coef[i] * w[i]^2, as per-256-weight block sums: er_l2_partials once, then kept current by
+ * er_dense_opt_step_l2; n_dense may be 0]; total_out[0] = reg_out[0] + sum_i losses[i][0]; report[i][0] = losses[i][0]
+ * (report may be NULL).  losses / report: HOST arrays of n_losses <= 8 DEVICE pointers.
+ * = er_reduce_sum + er_l2_loss + er_total_loss. */
+int er_reg_total_loss(const float* emb_partials, int32_t n_partials, float emb_scale, const float* dense_partials,
+                      int32_t n_dense, const float* const* losses_host, float* const* report_host, int32_t n_losses,
                       float* reg_out, float* total_out, er_stream_t stream);
+/* partials[b] = sum over weights [256 b, 256 b + 256) of 0.5 * coef * w^2 (ceil(n / 256) floats); er_dense_opt_step_l2 =
+ * er_dense_opt_step that also leaves these sums of the UPDATED weights (l2_partials may be NULL): the next step's
+ * kernel-L2 term costs no pass over the weights. */
+int er_l2_partials(const float* w, const float* coef, int64_t n, float* partials, er_stream_t stream);
+int er_dense_opt_step_l2(float* w, float* m, float* v, const float* grad, const float* l2coef, int64_t n,
+                         int opt_kind, const er_opt_hyper* hyper, float* l2_partials, er_stream_t stream);
 /* er_hyper_select that also zeroes zero_floats floats at `zero` (the dense variables' flat gradient buffer): the
  * step's prologue as one launch. */
 int er_step_prologue(const float* table, int64_t* counter, int32_t n_slots, int32_t floats_per_slot, float* out,

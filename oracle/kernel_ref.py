@@ -853,13 +853,18 @@ class RefBackend(object):
       total = total + src.reshape(1)
     total_out.copy_(total)
 
-  def reg_total_loss(self, emb_partials, emb_scale, w, coef, losses, reports, reg_out, total_out):
+  def l2_partials(self, w, coef, partials):
+    c, ww = coef.numpy().astype(np.float64), w.detach().numpy().astype(np.float64)
+    t = np.zeros(partials.numel() * 256)
+    t[:ww.size] = 0.5 * c * ww * ww
+    partials.copy_(torch.from_numpy(t.reshape(-1, 256).sum(axis=1).astype(np.float32)))
+
+  def reg_total_loss(self, emb_partials, emb_scale, dense_partials, losses, reports, reg_out, total_out):
     reg = F32(0)
     if emb_partials is not None and emb_partials.numel():
       reg = F32(emb_scale) * F32(emb_partials.detach().cpu().numpy().astype(np.float64).sum())
-    if w is not None and coef is not None:
-      c, ww = coef.numpy().astype(np.float64), w.detach().numpy().astype(np.float64)
-      reg = F32(reg + F32((0.5 * c * ww * ww).sum()))
+    if dense_partials is not None and dense_partials.numel():
+      reg = F32(reg + F32(dense_partials.detach().numpy().astype(np.float64).sum()))
     reg_out[0] = float(reg)
     total = F32(reg)
     for src, dst in zip(losses, reports):
@@ -997,7 +1002,9 @@ class RefBackend(object):
       return
     apply_sparse(var, m, v, sums, opt_kind, h)
 
-  def dense_opt_step(self, w, m, v, grad, l2coef, opt_kind, hyper):
+  def dense_opt_step(self, w, m, v, grad, l2coef, opt_kind, hyper, l2_partials=None):
     h = hyper.detach().cpu().numpy().reshape(-1)
     dense_opt(w.detach().numpy(), None if m is None else m.numpy(), None if v is None else v.numpy(),
               grad.detach().numpy(), None if l2coef is None else l2coef.numpy(), opt_kind, h)
+    if l2_partials is not None and l2coef is not None:
+      self.l2_partials(w, l2coef, l2_partials)
