@@ -413,23 +413,20 @@ __device__ __forceinline__ void replay_decay(float* var, float* m, float* v, con
   int32_t s = s_begin;
   bool absorbed = false;
   for (; s < s_end && !absorbed; ++s) {
-    // settled needs m on the fixed point of fl(m * b1), i.e. a handful of denormal units: the (division-heavy) test is
-    // only evaluated once every m of the lane is that small
-    bool tiny = true;
+    // settled: m on the fixed point of fl(m * b1) (a handful of denormal units) AND its largest possible update
+    // |m| / eps (lr_t < 1) below a quarter ulp of var.  Written without a division - |m| * 2^26 < |var| * eps; the
+    // scaling by 2^26 is exact and lifts the denormal m into the normal range - so it is cheap enough to evaluate at
+    // every step.  (A version that guarded a division-based test behind `|m| < 1e-37` produced garbage m on gfx950
+    // although the same source is exact on the host; tools/dbg_lazy_roll.py is the reproducer.)
+    bool settled = true;
 #pragma unroll
-    for (int i = 0; i < V; ++i) tiny = tiny && (fabsf(m[i]) < 1.0e-37f);
-    if (tiny) {
-      bool settled = true;
-#pragma unroll
-      for (int i = 0; i < V; ++i) {
-        const float bound = fabsf(m[i]) / h.eps;
-        settled = settled && (m[i] * h.beta1 == m[i]) && (var[i] - bound == var[i]) && (var[i] + bound == var[i]);
-      }
-      if (settled) {
-        decay_v_only<V>(v, s_end - s, h);
-        if (cheap_from_here) *cheap_from_here = true;
-        return;
-      }
+    for (int i = 0; i < V; ++i) {
+      settled = settled && (m[i] * h.beta1 == m[i]) && (fabsf(m[i]) * 67108864.0f < fabsf(var[i]) * h.eps);
+    }
+    if (settled) {
+      decay_v_only<V>(v, s_end - s, h);
+      if (cheap_from_here) *cheap_from_here = true;
+      return;
     }
     const float lr_t = lr_hist[s];
     // absorbed test without a division: |upd| * 2 L / lr_t < 2^-26 |var|  <=>  |upd| * 2 L < 2^-26 |var| * lr_t
