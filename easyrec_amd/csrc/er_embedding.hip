@@ -370,73 +370,88 @@ __device__ __forceinline__ void update_row(const RowUpdate& t, int opt_kind, con
 // to the touched rows.
 // ------------------------------------------------------------------------------------------------
 constexpr int32_t kClosedFormMin = 2048;
+constexpr int kLrStage = 512;  // the last kLrStage entries of the lr_t history are staged in LDS by replay_block
+
+// The scalars of the replay, pinned in SGPRs (readfirstlane: the compiler otherwise re-loads the fields of the
+// er_opt_hyper record from memory inside the per-step loop, a dependent scalar load per iteration).
+struct DecayConsts {
+  float b1, b2, eps;
+  bool can_absorb;  // b1 < sqrt(b2): the update of a decay-only row shrinks from step to step
+};
+__device__ __forceinline__ float pin_scalar(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x)));
+}
+__device__ __forceinline__ DecayConsts pin_decay_consts(const er_opt_hyper& h) {
+  DecayConsts k;
+  k.b1 = pin_scalar(h.beta1);
+  k.b2 = pin_scalar(h.beta2);
+  k.eps = pin_scalar(h.eps);
+  k.can_absorb = k.b1 < 0.999f * sqrtf(k.b2);
+  return k;
+}
+
+// lr_t(s): the newest kLrStage steps from LDS (staged once per workgroup), anything older from HBM.  The replay's
+// per-step loop is a chain of dependent operations; a global load per iteration (per-lane address: the lanes of a
+// wave replay different steps) made it latency-bound.
+struct LrHist {
+  const float* __restrict__ global;
+  const float* staged;  // [kLrStage] = global[base .. base + kLrStage), or nullptr
+  int32_t base;
+  __device__ __forceinline__ float at(int32_t s) const {
+    return (staged != nullptr && s >= base) ? staged[s - base] : global[s];
+  }
+};
 
 // k more decay-only steps of a row whose m no longer moves and whose update var absorbs: v *= b2, k times.
 template <int V>
-__device__ __forceinline__ void decay_v_only(float* v, int32_t k, const er_opt_hyper& h) {
+__device__ __forceinline__ void decay_v_only(float* v, int32_t k, float b2) {
   if (k > kClosedFormMin) {
-    const double f = pow(static_cast<double>(h.beta2), static_cast<double>(k));
+    const double f = pow(static_cast<double>(b2), static_cast<double>(k));
 #pragma unroll
     for (int i = 0; i < V; ++i) v[i] = static_cast<float>(static_cast<double>(v[i]) * f);
     return;
   }
   for (int32_t j = 0; j < k; ++j) {
 #pragma unroll
-    for (int i = 0; i < V; ++i) v[i] = v[i] * h.beta2;
+    for (int i = 0; i < V; ++i) v[i] = v[i] * b2;
   }
 }
 
 template <int V>
-__device__ __forceinline__ void replay_decay(float* var, float* m, float* v, const float* __restrict__ lr_hist,
-                                             int32_t s_begin, int32_t s_end, const er_opt_hyper& h,
-                                             const float* __restrict__ lr_max_hist = nullptr,
+__device__ __forceinline__ void replay_decay(float* var, float* m, float* v, const LrHist& lr, int32_t s_begin,
+                                             int32_t s_end, const DecayConsts& k, float lr_cap2,
                                              bool* cheap_from_here = nullptr) {
   // steps s_begin .. s_end - 1 were decay-only for this row.  cheap_from_here (optional): did the row leave the full
-  // regime by the end of this call (replay_block sorts its tasks by it).  Three regimes, the first two bit-identical to the
-  // step-by-step sweep:
-  //  (1) full step: m *= b1; v *= b2; var -= lr_t(s) * m / (sqrt(v) + eps)                  (~20 instructions/element)
+  // regime by the end of this call (replay_block sorts its tasks by it).  lr_cap2 = 2 * max lr_t over the history so
+  // far (0: no absorbed regime).  Three regimes, the first two bit-identical to the step-by-step sweep:
+  //  (1) full step: m *= b1; v *= b2; var -= lr_t(s) * m / (sqrt(v) + eps)      (~45 instructions/element: IEEE sqrt, division)
   //  (2) ABSORBED: the update has fallen below a quarter ulp of var and can only shrink from here, so var no longer
   //      changes and only the two decays remain (2 multiplications/element/step).  Why it can only shrink: in exact
   //      arithmetic q(s) = lr_t(s) |m_s| / (sqrt(v_s) + eps) obeys q(s+1) / q(s) <= (lr_t(s+1) / lr_t(s)) * b1 / sqrt(b2)
-  //      (+ rounding of 2^-23 per step); with L = max lr_t over the whole history so far (lr_max_hist, written next to
-  //      lr_hist by er_hyper_select) every later update is <= (L / lr_t(s)) * q(s) as long as b1 < sqrt(b2).  The
-  //      test below is on the COMPUTED update with a 2x margin: |upd| * L / lr_t(s) * 2 < |var| * 2^-25 <= ulp(var) / 2
-  //      ... conservatively a quarter ulp, which also covers var at a power of two (half-sized ulp below).
-  //      Typically reached ~150 steps after a row's last touch (0.9^150 = 1e-7).
+  //      (+ rounding of 2^-23 per step); with L = max lr_t over the whole history so far (written next to the history
+  //      by er_hyper_select) every later update is <= (L / lr_t(s)) * q(s) as long as b1 < sqrt(b2).  The test is on
+  //      the COMPUTED update with a 2x margin and without a division:
+  //      |upd| * 2 L < 2^-26 |var| * lr_t(s)  =>  every later |upd| < 2^-26 |var| <= ulp(var) / 4, which also covers
+  //      var at a power of two (half-sized ulp below).  Typically reached ~130 steps after a row's last touch.
   //  (3) settled: fp32 m never reaches 0 under m *= b1 - below 5 denormal units fl(m * 0.9) == m - so ~900 steps
-  //      after the touch m is constant and only v *= b2 is left: replayed step by step (1 multiplication/element/step,
-  //      still bit-identical) as long as at most kClosedFormMin steps are pending - always, when the rolling flush
-  //      (er_emb_flush_window) bounds the idle time; a longer backlog (a flush after thousands of steps without the
-  //      rolling flush) takes the closed form v *= b2^k, the one documented deviation (<= 1e-6 relative on v).
-  const bool can_absorb = lr_max_hist != nullptr && h.beta1 < 0.999f * sqrtf(h.beta2) && s_end > s_begin;
-  const float lr_cap2 = can_absorb ? 2.0f * lr_max_hist[s_end - 1] : 0.f;
+  //      after the touch m is constant and only v *= b2 is left (found by regime 2: m stops changing): replayed step
+  //      by step (1 multiplication/element/step, still bit-identical) as long as at most kClosedFormMin steps are
+  //      pending - always, when the rolling flush (er_emb_flush_window) bounds the idle time; a longer backlog (a
+  //      flush after thousands of steps without the rolling flush) takes the closed form v *= b2^k, the one
+  //      documented deviation (<= 1e-6 relative on v).
+  //  A row whose var is 0 (or so small that no update is ever absorbed) stays in regime 1: correct, merely slower.
+  const bool can_absorb = k.can_absorb && lr_cap2 > 0.f;
   int32_t s = s_begin;
   bool absorbed = false;
   for (; s < s_end && !absorbed; ++s) {
-    // settled: m on the fixed point of fl(m * b1) (a handful of denormal units) AND its largest possible update
-    // |m| / eps (lr_t < 1) below a quarter ulp of var.  Written without a division - |m| * 2^26 < |var| * eps; the
-    // scaling by 2^26 is exact and lifts the denormal m into the normal range - so it is cheap enough to evaluate at
-    // every step.  (A version that guarded a division-based test behind `|m| < 1e-37` produced garbage m on gfx950
-    // although the same source is exact on the host; tools/dbg_lazy_roll.py is the reproducer.)
-    bool settled = true;
-#pragma unroll
-    for (int i = 0; i < V; ++i) {
-      settled = settled && (m[i] * h.beta1 == m[i]) && (fabsf(m[i]) * 67108864.0f < fabsf(var[i]) * h.eps);
-    }
-    if (settled) {
-      decay_v_only<V>(v, s_end - s, h);
-      if (cheap_from_here) *cheap_from_here = true;
-      return;
-    }
-    const float lr_t = lr_hist[s];
-    // absorbed test without a division: |upd| * 2 L / lr_t < 2^-26 |var|  <=>  |upd| * 2 L < 2^-26 |var| * lr_t
-    const float thr = 1.4901161193847656e-08f * lr_t;  // (lr_t > 0: the schedules have a positive floor)
+    const float lr_t = lr.at(s);
+    const float thr = 1.4901161193847656e-08f * lr_t;  // 2^-26 lr_t  (lr_t > 0: the schedules have a positive floor)
     bool all_small = can_absorb;
 #pragma unroll
     for (int i = 0; i < V; ++i) {
-      const float mt = m[i] * h.beta1;
-      const float vt = v[i] * h.beta2;
-      const float upd = (lr_t * mt) / (sqrtf(vt) + h.eps);
+      const float mt = m[i] * k.b1;
+      const float vt = v[i] * k.b2;
+      const float upd = (lr_t * mt) / (sqrtf(vt) + k.eps);
       m[i] = mt;
       v[i] = vt;
       var[i] = var[i] - upd;
@@ -451,28 +466,33 @@ __device__ __forceinline__ void replay_decay(float* var, float* m, float* v, con
     bool m_fixed = true;
 #pragma unroll
     for (int i = 0; i < V; ++i) {
-      const float mt = m[i] * h.beta1;
+      const float mt = m[i] * k.b1;
       m_fixed = m_fixed && (mt == m[i]);
       m[i] = mt;
-      v[i] = v[i] * h.beta2;
+      v[i] = v[i] * k.b2;
     }
     if (m_fixed && s + 1 < s_end) {  // m sits on its fixed point: only v is left (regime 3)
-      decay_v_only<V>(v, s_end - s - 1, h);
+      decay_v_only<V>(v, s_end - s - 1, k.b2);
       return;
     }
   }
 }
 
+// 2 * (largest lr_t of steps 0 .. s_end-1), or 0 when the running maxima are not kept (no absorbed regime)
+__device__ __forceinline__ float lr_cap_twice(const float* __restrict__ lr_max, int32_t s_end) {
+  return (lr_max != nullptr && s_end > 0) ? 2.0f * lr_max[s_end - 1] : 0.f;
+}
+
 // Block-cooperative replay.  A lane's task = the V elements it owns of one row with pending decay steps
 // [s_begin, s_end) (s_end uniform over the workgroup).  The cost of a task is dominated by its steps in the FULL regime
-// (sqrt + IEEE division per element and step) - ~150 of them after a touch, none for a row that has long been idle -
+// (sqrt + IEEE division per element and step) - ~130 of them after a touch, none for a row that has long been idle -
 // and rows of both kinds sit side by side in a table: lanes replaying in place would idle while one lane of their wave
 // grinds through full steps (measured: two thirds of the lane-cycles).  So: every task runs ONE step in place, which
 // also classifies it (still full / cheap from here); unfinished tasks are compacted into two LDS queues - registers
 // and all - and the workgroup's lanes take them densely, the full ones first.  Results do not depend on the order
 // the queues fill in.  All threads of the workgroup must call this (it synchronises); smem: kReplaySmemWords words.
 constexpr int kReplayEntry = 3 * 4 + 3;                        // var, m, v (V <= 4) + element offset (2) + next step
-constexpr int kReplaySmemWords = 2 * kBlock * kReplayEntry + 4;
+constexpr int kReplaySmemWords = 2 * kBlock * kReplayEntry + 4 + kLrStage;
 
 template <int V>
 __device__ __forceinline__ void replay_block(bool has, int64_t off, int32_t s_begin, int32_t s_end, const RowUpdate& tab,
@@ -480,8 +500,17 @@ __device__ __forceinline__ void replay_block(bool has, int64_t off, int32_t s_be
                                              const er_opt_hyper* __restrict__ hyper, uint32_t* __restrict__ smem) {
   int* cnt = reinterpret_cast<int*>(smem);  // [2]
   uint32_t* queue = smem + 4;               // [2][kBlock][kReplayEntry]
+  float* lr_staged = reinterpret_cast<float*>(smem + 4 + 2 * kBlock * kReplayEntry);  // [kLrStage]
   if (threadIdx.x < 2) cnt[threadIdx.x] = 0;
+  const int32_t stage_base = s_end - kLrStage;
+  for (int i = threadIdx.x; i < kLrStage; i += kBlock) {
+    const int32_t si = stage_base + i;
+    lr_staged[i] = si >= 0 ? lr_hist[si] : 0.f;
+  }
   __syncthreads();
+  const LrHist lr{lr_hist, lr_staged, stage_base};
+  const DecayConsts k = pin_decay_consts(*hyper);
+  const float lr_cap2 = lr_cap_twice(lr_max, s_end);
   float var[V], m[V], v[V];
   bool task = false;
   int32_t s = s_begin;
@@ -492,18 +521,17 @@ __device__ __forceinline__ void replay_block(bool has, int64_t off, int32_t s_be
     for (int j = 0; j < V; ++j) task = task || (m[j] != 0.f) || (v[j] != 0.f);  // never touched: a fixed point of the decay
   }
   if (task) {
-    const er_opt_hyper h = *hyper;
     ld_vec<V>(var, tab.var + off);
     bool cheap = false;
-    replay_decay<V>(var, m, v, lr_hist, s, s + 1, h, lr_max, &cheap);
+    replay_decay<V>(var, m, v, lr, s, s + 1, k, lr_cap2, &cheap);
     ++s;
     if (s >= s_end) {
       st_vec<V>(tab.var + off, var);
       st_vec<V>(tab.m + off, m);
       st_vec<V>(tab.v + off, v);
     } else {
-      const int k = cheap ? 1 : 0;
-      uint32_t* e = queue + (static_cast<size_t>(k) * kBlock + atomicAdd(&cnt[k], 1)) * kReplayEntry;
+      const int q = cheap ? 1 : 0;
+      uint32_t* e = queue + (static_cast<size_t>(q) * kBlock + atomicAdd(&cnt[q], 1)) * kReplayEntry;
 #pragma unroll
       for (int j = 0; j < V; ++j) {
         e[j] = __builtin_bit_cast(uint32_t, var[j]);
@@ -517,10 +545,10 @@ __device__ __forceinline__ void replay_block(bool has, int64_t off, int32_t s_be
   }
   __syncthreads();
 #pragma unroll 1
-  for (int k = 0; k < 2; ++k) {
-    const int n = cnt[k];
+  for (int q = 0; q < 2; ++q) {
+    const int n = cnt[q];
     for (int t = threadIdx.x; t < n; t += kBlock) {
-      const uint32_t* e = queue + (static_cast<size_t>(k) * kBlock + t) * kReplayEntry;
+      const uint32_t* e = queue + (static_cast<size_t>(q) * kBlock + t) * kReplayEntry;
 #pragma unroll
       for (int j = 0; j < V; ++j) {
         var[j] = __builtin_bit_cast(float, e[j]);
@@ -528,7 +556,7 @@ __device__ __forceinline__ void replay_block(bool has, int64_t off, int32_t s_be
         v[j] = __builtin_bit_cast(float, e[8 + j]);
       }
       const int64_t o = static_cast<int64_t>(static_cast<uint64_t>(e[12]) | (static_cast<uint64_t>(e[13]) << 32));
-      replay_decay<V>(var, m, v, lr_hist, static_cast<int32_t>(e[14]), s_end, *hyper, lr_max);
+      replay_decay<V>(var, m, v, lr, static_cast<int32_t>(e[14]), s_end, k, lr_cap2);
       st_vec<V>(tab.var + o, var);
       st_vec<V>(tab.m + o, m);
       st_vec<V>(tab.v + o, v);
@@ -554,8 +582,11 @@ __device__ __forceinline__ void catch_up_body(int bid, const uint32_t* __restric
     s_begin = tab.last_step[key] + 1;  // (touched at step t-1, or never updated yet and current: nothing pending)
     off = static_cast<int64_t>(key) * dim + c;
   }
-  replay_block<V>(has, off, s_begin, t, tab, lr_hist, lr_max, hyper, smem);
-  // last_step[key] is set to t by this step's row update (every caught-up row is touched by the step)
+  replay_block<V>(has, off, s_begin, t, tab, lr_hist, lr_max, hyper, smem);  // (synchronises first: every lane has read last_step)
+  // The row is current up to step t-1 now.  This step's row update will set last_step = t; until then the record must
+  // already say t-1, because the rolling flush of the step may run CONCURRENTLY (er_emb_flush_window with lag 1 on a
+  // second stream) and has to find nothing pending on the rows the step touches.
+  if (has && c == 0 && s_begin < t) tab.last_step[ukeys[i]] = t - 1;
 }
 
 template <int V>
@@ -621,7 +652,7 @@ emb_flush_decay_kernel(RowUpdate tab, int64_t total_rows, const float* __restric
 #pragma unroll
     for (int j = 0; j < V; ++j) live = live || (m[j] != 0.f) || (v[j] != 0.f);
     if (live) {
-      replay_decay<V>(var, m, v, lr_hist, last + 1, done, *hyper, lr_max);
+      replay_decay<V>(var, m, v, LrHist{lr_hist, nullptr, 0}, last + 1, done, pin_decay_consts(*hyper), lr_cap_twice(lr_max, done));
       st_vec<V>(tab.var + off, var);
       st_vec<V>(tab.m + off, m);
       st_vec<V>(tab.v + off, v);
@@ -638,11 +669,14 @@ emb_flush_decay_kernel(RowUpdate tab, int64_t total_rows, const float* __restric
 // (one instruction) before lane 0 stores it.
 template <int V>
 __device__ __forceinline__ void flush_window_body(int bid, const RowUpdate& tab, int64_t total_rows, int64_t chunk,
-                                                  int n_windows, const float* __restrict__ lr_hist,
+                                                  int n_windows, int lag, const float* __restrict__ lr_hist,
                                                   const float* __restrict__ lr_max,
                                                   const er_opt_hyper* __restrict__ hyper, int dim, int G,
                                                   uint32_t* __restrict__ smem) {
-  const int32_t done = static_cast<int32_t>(*tab.step_counter);
+  // lag 0: called after the step's row updates, rows brought to the step just executed.  lag 1: called DURING step t
+  // (after its catch-up), rows brought to step t-1 - the state the catch-up leaves the touched rows in, so the launch
+  // has no work on them and can overlap the step's lookup / dense part / row update on another stream.
+  const int32_t done = static_cast<int32_t>(*tab.step_counter) - lag;
   const int64_t w = static_cast<int64_t>(done) % n_windows;
   const int64_t row = w * chunk + (static_cast<int64_t>(bid) * kBlock + threadIdx.x) / G;
   const int sub = static_cast<int>(threadIdx.x) % G;
@@ -663,21 +697,31 @@ struct FlushWindowArgs {
   int dim, G, V;
 };
 struct FlushWindowMulti {
-  int n, n_windows;
+  int n, n_windows, lag;
   int start[4 + 1];
   const er_opt_hyper* hyper;
   FlushWindowArgs a[4];
 };
 
+// The grid may be smaller than the number of tiles (er_emb_flush_window's max_blocks): each workgroup then walks the
+// tiles b, b + gridDim.x, ...  That is the form that runs NEXT TO the step on a second stream: the replay is VALU-bound
+// (IEEE sqrt + division per element and pending step), the dense part it overlaps is latency-bound, and a full grid
+// (tens of thousands of workgroups, 30 KB of LDS each) would fill every CU and make the step's own kernels queue
+// behind it (measured: GEMMs 12 -> 31 us, no net gain); a couple of resident workgroups per CU leave the rest of the
+// CU's wave slots and LDS to the step.
 __global__ void __launch_bounds__(kBlock)
 emb_flush_window_kernel(FlushWindowMulti ma) {
-  int i = 0;
-  while (i + 1 < ma.n && static_cast<int>(blockIdx.x) >= ma.start[i + 1]) ++i;
   __shared__ uint32_t smem[kReplaySmemWords];
-  const FlushWindowArgs& a = ma.a[i];
-  const int bid = blockIdx.x - ma.start[i];
-  if (a.V == 4) flush_window_body<4>(bid, a.tab, a.total_rows, a.chunk, ma.n_windows, a.lr_hist, a.lr_max, ma.hyper, a.dim, a.G, smem);
-  else flush_window_body<1>(bid, a.tab, a.total_rows, a.chunk, ma.n_windows, a.lr_hist, a.lr_max, ma.hyper, a.dim, a.G, smem);
+  const int total = ma.start[ma.n];
+  for (int b = blockIdx.x; b < total; b += gridDim.x) {
+    int i = 0;
+    while (i + 1 < ma.n && b >= ma.start[i + 1]) ++i;
+    const FlushWindowArgs& a = ma.a[i];
+    const int bid = b - ma.start[i];
+    if (a.V == 4) flush_window_body<4>(bid, a.tab, a.total_rows, a.chunk, ma.n_windows, ma.lag, a.lr_hist, a.lr_max, ma.hyper, a.dim, a.G, smem);
+    else flush_window_body<1>(bid, a.tab, a.total_rows, a.chunk, ma.n_windows, ma.lag, a.lr_hist, a.lr_max, ma.hyper, a.dim, a.G, smem);
+    __syncthreads();  // (the next tile resets the queues' counters)
+  }
 }
 
 // second pass of the flush (all lanes of a row must have read last_step before it changes)
@@ -1522,11 +1566,14 @@ __device__ __forceinline__ void serve_body(int bid, const ServeArgs& a, const er
 #pragma unroll
       for (int j = 0; j < V; ++j) live = live || (m[j] != 0.f) || (v[j] != 0.f);
       if (live) {
-        replay_decay<V>(var, m, v, a.lr_hist, last + 1, t, *hyper, a.lr_max);
+        replay_decay<V>(var, m, v, LrHist{a.lr_hist, nullptr, 0}, last + 1, t, pin_decay_consts(*hyper), lr_cap_twice(a.lr_max, t));
         st_vec<V>(a.tab.var + off, var);
         st_vec<V>(a.tab.m + off, m);
         st_vec<V>(a.tab.v + off, v);
       }
+      // current up to t-1 from here on (see catch_up_body: the rolling flush of the step may run next to the step).
+      // The G lanes of the row sit in one wavefront (G <= 64, a power of two): all have read last_step above.
+      if (c == 0) a.tab.last_step[key] = t - 1;
     }
   }
   for (int64_t q = p; q < a.n && a.skeys[q] == key; ++q)
@@ -2452,13 +2499,14 @@ int er_emb_group_set_lr_max(er_emb_group* g, const float* lr_max_history) {
   return 0;
 }
 
-int er_emb_flush_window(er_emb_group* const* groups, int n, int32_t n_windows, const er_opt_hyper* hyper,
-                        er_stream_t stream) {
-  ER_REQUIRE(groups && hyper && n >= 1 && n <= er::kMaxMulti && n_windows >= 1,
-             "er_emb_flush_window: bad arguments (1 <= n <= %d, n_windows >= 1)", er::kMaxMulti);
+int er_emb_flush_window(er_emb_group* const* groups, int n, int32_t n_windows, int32_t lag, int32_t max_blocks,
+                        const er_opt_hyper* hyper, er_stream_t stream) {
+  ER_REQUIRE(groups && hyper && n >= 1 && n <= er::kMaxMulti && n_windows >= 1 && (lag == 0 || lag == 1),
+             "er_emb_flush_window: bad arguments (1 <= n <= %d, n_windows >= 1, lag 0 or 1)", er::kMaxMulti);
   er::FlushWindowMulti ma;
   ma.n = 0;
   ma.n_windows = n_windows;
+  ma.lag = lag;
   ma.start[0] = 0;
   ma.hyper = hyper;
   for (int i = 0; i < n; ++i) {
@@ -2473,7 +2521,9 @@ int er_emb_flush_window(er_emb_group* const* groups, int n, int32_t n_windows, c
     ma.start[ma.n + 1] = ma.start[ma.n] + static_cast<int>(er::ceil_div(a.chunk * g->G, er::kBlock));
     ++ma.n;
   }
-  hipLaunchKernelGGL(er::emb_flush_window_kernel, dim3(ma.start[ma.n]), dim3(er::kBlock), 0, er::as_stream(stream), ma);
+  if (ma.start[ma.n] == 0) return 0;
+  const int grid = max_blocks > 0 && max_blocks < ma.start[ma.n] ? max_blocks : ma.start[ma.n];
+  hipLaunchKernelGGL(er::emb_flush_window_kernel, dim3(grid), dim3(er::kBlock), 0, er::as_stream(stream), ma);
   ER_LAUNCH_CHECK();
   return 0;
 }
@@ -2833,6 +2883,7 @@ int er_emb_owner_serve(er_emb_group* const* groups, float* const* rows_out, cons
     // hyper == NULL: serve the rows as they are (inference after er_emb_flush_decay: nothing is pending and nothing
     // may be replayed, because no row update follows that would advance last_step)
     a.tab = er::RowUpdate{g->var, g->m, g->v, g->bitmap, hyper ? g->last_step : nullptr, g->step_counter};
+    ER_REQUIRE(a.tab.last_step == nullptr || g->G <= er::kWave, "er_emb_owner_serve: a lazily decayed row must fit one wavefront");
     a.lr_hist = g->lr_hist; a.lr_max = g->lr_max; a.out = rows_out[i]; a.dim = g->dim; a.G = g->G; a.V = g->V;
     a.ld = ld && ld[i] ? ld[i] : g->dim;
     ER_REQUIRE(a.ld >= g->dim && (g->V == 1 || (a.ld % 4 == 0 && (reinterpret_cast<uintptr_t>(rows_out[i]) & 15) == 0)),

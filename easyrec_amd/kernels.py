@@ -1091,11 +1091,13 @@ class HipBackend(object):
       self._ck(self.lib.er_emb_group_set_lr_max(group['handle'], _p(lr_hist[cap:])), 'er_emb_group_set_lr_max')
     group['last_step'], group['lr_hist'], group['step_counter'] = last_step, lr_hist, step_counter
 
-  def emb_flush_window(self, groups, n_windows, hyper):
-    """Rolling flush: this step's window (step mod n_windows) of up to 4 table groups, one launch."""
+  def emb_flush_window(self, groups, n_windows, hyper, lag=0, max_blocks=0):
+    """Rolling flush: this step's window (step mod n_windows) of up to 4 table groups, one launch.  lag 1: the
+    variant that runs concurrently with the step (after its catch-up, on another stream)."""
     n = len(groups)
     gh = (ctypes.c_void_p * n)(*[g['handle'] for g in groups])
-    self._ck(self.lib.er_emb_flush_window(gh, n, ctypes.c_int32(int(n_windows)), _p(hyper), _stream()),
+    self._ck(self.lib.er_emb_flush_window(gh, n, ctypes.c_int32(int(n_windows)), ctypes.c_int32(int(lag)),
+                                          ctypes.c_int32(int(max_blocks)), _p(hyper), _stream()),
              'er_emb_flush_window')
 
   def emb_catch_up(self, group, unique_keys, n_unique, hyper):

@@ -127,7 +127,16 @@ class EmbeddingEngine(object):
     self.inference = False
     # rolling flush: every step one window of every table group is brought current, so no row is ever more than
     # this many steps behind (er_emb_flush_window); 0 = off (rows wait for their next touch or a full flush)
-    self.flush_windows = int(os.environ.get('EASYREC_AMD_FLUSH_WINDOWS', '256'))
+    self.flush_windows = int(os.environ.get('EASYREC_AMD_FLUSH_WINDOWS', '64'))
+    # '1': the window's launch runs on a second stream, concurrently with the step (lag 1: see er_emb_flush_window), joined
+    # after the step's row update; default: after the row update on the main stream (lag 0).  Measured on DeepFM-Criteo
+    # (profiles/r02_overlap_flush.md): no gain - the steady-state step is bound by the SUM of its kernels' durations
+    # (graph replay leaves no gaps) and the replay is VALU-bound, so running it next to the GEMMs only slows those down.
+    self.overlap_flush = os.environ.get('EASYREC_AMD_OVERLAP_FLUSH', '0') != '0'
+    self.flush_blocks = int(os.environ.get('EASYREC_AMD_FLUSH_BLOCKS', '1024'))  # grid of the concurrent launch (4 / CU)
+    self._flush_stream = None
+    self._window_pending = False  # launched on the second stream, not joined yet
+    self._window_started = False  # this step's window has been launched (the row update must not launch it again)
     self._sort_leader = {}  # dim -> dim of the group whose per-step sort it reuses
 
   # -- declaration (build pass)
@@ -211,6 +220,7 @@ class EmbeddingEngine(object):
     if not self.lazy_decay:
       return
     be = kernels.hip()
+    self._join_window_flush()
     for dim, grp in self.emb_groups.items():
       be.emb_flush_decay(grp, self._clock[2])
     self._decay_pending = False
@@ -347,6 +357,7 @@ class EmbeddingEngine(object):
     for g in self.groups.values():
       g['got_grad'] = False
       g['terms'] = []
+    self._join_window_flush()  # (a forward that no row update followed)
     if self.lazy_decay and not self.inference:
       # sort the step's ids once (reused by the backward), bring the rows it touches up to date, then look up
       grps, uks, nus = [], [], []
@@ -368,6 +379,7 @@ class EmbeddingEngine(object):
         be.emb_catch_up_multi(grps[i:i + step], uks[i:i + step], nus[i:i + step], self._clock[2])
       if probe is not None:
         probe[1].record()
+      self._start_window_flush()
     if self.plan is not None:
       be.emb_fwd(self.plan, self.sumsq if self.reg_lambda > 0 else None)
     self._ran_version = version
@@ -458,12 +470,45 @@ class EmbeddingEngine(object):
     self._decay_pending = True
 
   def _roll_flush(self, hyper):
-    """After the step's row updates: this step's window of every lazily decaying table group (one launch per 4)."""
+    """After the step's row updates: this step's window of every lazily decaying table group (one launch per 4) - or,
+    when the window was started next to the step (_start_window_flush), the join with it."""
     if not self.lazy_decay or self.flush_windows <= 0:
+      return
+    if self._window_started:  # (this step's window ran next to the step)
+      self._join_window_flush()
+      self._window_started = False
       return
     lazy = [grp for grp, _ in self._lazy_groups()]
     for i in range(0, len(lazy), 4):
       kernels.hip().emb_flush_window(lazy[i:i + 4], self.flush_windows, hyper)
+
+  def _start_window_flush(self):
+    """Right after the step's catch-up: the step's window on the second stream, bringing its rows to the step BEFORE
+    this one (lag 1) - exactly where the catch-up left the rows the step touches, so the launch skips those and is
+    independent of the lookup, the dense part and the row update it runs next to."""
+    if not (self.lazy_decay and self.overlap_flush and self.flush_windows > 0):
+      return
+    lazy = [grp for grp, _ in self._lazy_groups()]
+    if not lazy:
+      return
+    be, hyper = kernels.hip(), self._clock[2]
+    if self.device.type == 'cuda':
+      if self._flush_stream is None:
+        self._flush_stream = torch.cuda.Stream(device=self.device)
+      self._flush_stream.wait_stream(torch.cuda.current_stream())
+      with torch.cuda.stream(self._flush_stream):
+        for i in range(0, len(lazy), 4):
+          be.emb_flush_window(lazy[i:i + 4], self.flush_windows, hyper, lag=1, max_blocks=self.flush_blocks)
+    else:
+      for i in range(0, len(lazy), 4):
+        be.emb_flush_window(lazy[i:i + 4], self.flush_windows, hyper, lag=1, max_blocks=self.flush_blocks)
+    self._window_pending = self._window_started = True
+
+  def _join_window_flush(self):
+    if self._window_pending:
+      if self.device.type == 'cuda':
+        torch.cuda.current_stream().wait_stream(self._flush_stream)
+      self._window_pending = False
 
   # -- gradient clipping by global norm: the reduce and the row update as two steps, the norm in between
   def backward_reduce(self, normsq, weight):

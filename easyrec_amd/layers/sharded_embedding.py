@@ -387,6 +387,7 @@ class ShardedEmbeddingEngine(EmbeddingEngine):
   def forward(self, version):
     if version == self._ran_version:
       return
+    self._join_window_flush()  # (a forward that no row update followed)
     self.route()
     self.exchange()
     self.lookup()
@@ -453,6 +454,7 @@ class ShardedEmbeddingEngine(EmbeddingEngine):
     if not self.lazy_decay:
       return
     be = kernels.hip()
+    self._join_window_flush()
     for sh in self.shard.values():
       if sh['lazy'] is not None:
         be.emb_flush_decay(sh['owner'], self._clock[2])

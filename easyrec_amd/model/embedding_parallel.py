@@ -88,6 +88,10 @@ class EmbeddingParallelEstimator(EasyRecEstimator):
   def _phase_compute(self):
     """lookup -> forward -> losses -> backward -> local gradient reduction (no collective inside)."""
     be = kernels.hip()
+    if self.is_training and not self.engine.inference:
+      # the owned rows' rolling flush next to the lookup and the dense part (the owners' catch-up ran in an earlier
+      # phase, their row update comes in a later one); fork and join inside this phase: one hipGraph holds both
+      self.engine._start_window_flush()
     self.engine.lookup()
     self.engine._ran_version = self.features.version  # the model's input-layer calls find the lookup done
     with context.use(self.ctx):
@@ -100,6 +104,7 @@ class EmbeddingParallelEstimator(EasyRecEstimator):
         self.engine.reduce_local()
         if self.clip_norm > 0:
           self.engine.local_gradsq(self._norm_slot, self._emb_gradsq_weight())
+    self.engine._join_window_flush()
 
   def _phase_apply(self):
     vs = self.varstore

@@ -225,11 +225,17 @@ int er_emb_bwd_reduce(er_emb_group* group, uint32_t* unique_keys, float* unique_
  *     [w * chunk, (w + 1) * chunk), w = t mod n_windows, chunk = ceil(total_rows / n_windows), current.  Called once
  *     per step (after the row update) it bounds how far behind any row can be to n_windows steps, so the catch-up of a
  *     cold row replays <= n_windows steps instead of its whole idle time, for one pass over 1 / n_windows of the
- *     tables per step.  Same arithmetic as er_emb_flush_decay. */
+ *     tables per step.  Same arithmetic as er_emb_flush_decay.  lag 0: call after the step's row update (rows brought
+ *     to the step just executed).  lag 1: call DURING step t, after er_emb_catch_up, on ANOTHER stream: rows are
+ *     brought to step t-1, which is where the catch-up left the rows the step touches (it records that in last_step),
+ *     so the launch has nothing to do on them and overlaps the lookup, the dense part and the row update; join the
+ *     stream before the next step's er_emb_route.  max_blocks > 0 caps the grid (workgroups walk the tiles): the
+ *     form for the concurrent launch - ~2 workgroups per CU leave the CUs' wave slots and LDS to the step. */
 int er_emb_group_enable_lazy_decay(er_emb_group* group, int32_t* last_step, const float* lr_t_history,
                                    const int64_t* step_counter);
 int er_emb_group_set_lr_max(er_emb_group* group, const float* lr_max_history);
-int er_emb_flush_window(er_emb_group* const* groups_host, int n, int32_t n_windows, const er_opt_hyper* hyper,
+int er_emb_flush_window(er_emb_group* const* groups_host, int n, int32_t n_windows, int32_t lag, int32_t max_blocks,
+                        const er_opt_hyper* hyper,
                         er_stream_t stream);
 int er_emb_catch_up(er_emb_group* group, const uint32_t* unique_keys, const int32_t* n_unique,
                     const er_opt_hyper* hyper, er_stream_t stream);

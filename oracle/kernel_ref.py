@@ -936,12 +936,15 @@ class RefBackend(object):
     h = hyper.detach().cpu().numpy().reshape(-1)
     t = int(group['step_counter'].item()) - 1
     n = int(n_unique.item())
-    self._replay(group, [int(k) for k in unique_keys[:n].tolist()], t, h)
+    rows = [int(k) for k in unique_keys[:n].tolist()]
+    self._replay(group, rows, t, h)
+    for r in rows:
+      group['last_step'][r] = max(int(group['last_step'][r]), t - 1)
 
-  def emb_flush_window(self, groups, n_windows, hyper):
+  def emb_flush_window(self, groups, n_windows, hyper, lag=0, max_blocks=0):
     h = hyper.detach().cpu().numpy().reshape(-1)
     for group in groups:
-      done = int(group['step_counter'].item())
+      done = int(group['step_counter'].item()) - int(lag)
       chunk = -(-group['total_rows'] // n_windows)
       w = done % n_windows
       rows = range(w * chunk, min((w + 1) * chunk, group['total_rows']))

@@ -256,15 +256,22 @@ def _assert_lazy_equals_sweep(lazy_state, sweep_state):
   assert n > 100
 
 
-def test_lazy_decay_equals_sweep_model_level():
-  """EasyRecEstimator(dense_sweep=False) (the default: TF-exact Adam's every-row decay replayed lazily, the headline
+@pytest.mark.parametrize('flush_blocks', [0, 1])
+def test_lazy_decay_equals_sweep_model_level(monkeypatch, flush_blocks):
+  """flush_blocks 0: the default (rolling flush after the row update); 1: the concurrent rolling flush (second stream,
+  lag 1) as ONE workgroup walking all the window's tiles.
+  EasyRecEstimator(dense_sweep=False) (the default: TF-exact Adam's every-row decay replayed lazily, the headline
   path) against dense_sweep=True (every row streamed every step) over 1300 steps with rows idle for > 1200 steps,
   through the whole model (shared sort of the wide / deep groups, er_emb_catch_up_multi, er_emb_flush_decay): after the
   flush var, m and v of every table and every dense variable are BIT-equal, and so are the losses on the way."""
+  if flush_blocks:
+    monkeypatch.setenv('EASYREC_AMD_OVERLAP_FLUSH', '1')
+    monkeypatch.setenv('EASYREC_AMD_FLUSH_BLOCKS', str(flush_blocks))
   cfg = _cfg('deepfm_criteo_small.config')
   B = 64
   ests = [EasyRecEstimator(cfg, device=DEV, batch_size=B, seed=9, dense_sweep=ds).build() for ds in (False, True)]
   assert ests[0].engine.lazy_decay and not ests[1].engine.lazy_decay
+  assert ests[0].engine.overlap_flush == bool(flush_blocks)
   sched = _idle_schedule(cfg, ests[0].feature_configs, B, 1250)
   for i, b in enumerate(sched):
     for e in ests:

@@ -340,11 +340,14 @@ def test_fixed_capacity_route_and_owner_side_against_numpy(header):
   hip.emb_group_destroy(og)
 
 
-def test_lazy_decay_equals_sweep_through_two_sharded_ranks():
-  """The model-level lazy-dense-decay == sweep check of tests/test_deepfm_gpu.py through EmbeddingParallelEstimator,
+@pytest.mark.parametrize('overlap', ['0', '1'])
+def test_lazy_decay_equals_sweep_through_two_sharded_ranks(monkeypatch, overlap):
+  """overlap '1': the owners' rolling flush on a second stream next to the compute phase (lag 1).
+  The model-level lazy-dense-decay == sweep check of tests/test_deepfm_gpu.py through EmbeddingParallelEstimator,
   W = 2 ranks as threads with their own batches: the owner side's er_emb_owner_serve catches rows up, the owner's
   er_emb_bwd_update_multi stamps them, er_emb_flush_decay finishes - against the same two ranks streaming every row."""
   from test_deepfm_gpu import _assert_lazy_equals_sweep, _idle_schedule
+  monkeypatch.setenv('EASYREC_AMD_OVERLAP_FLUSH', overlap)
   cfg = _cfg('deepfm_criteo_small.config')
   B, world = 64, 2
   feats = list(cfg.feature_config.features)

@@ -645,7 +645,10 @@ def test_lazy_dense_decay_equals_the_sweep(hip):
   ids_all[60:, :] = ids_all[60:, :] % 11            # after step 60 only rows 0..10 are ever touched again
   dout_all = (rng.standard_normal((T, B, dim)) * 0.01).astype(np.float32)
   state = {}
-  for mode in ('sweep', 'lazy', 'lazy_roll'):  # lazy_roll: + the rolling flush (er_emb_flush_window, 16 windows)
+  # lazy_roll: + the rolling flush (er_emb_flush_window, 16 windows) after the row update; lazy_roll_side: the flush
+  # with lag 1 on a second stream, concurrent with the row update of the same step
+  side = torch.cuda.Stream()
+  for mode in ('sweep', 'lazy', 'lazy_roll', 'lazy_roll_side'):
     var, m, v = table0.clone().to(DEV), torch.zeros(rows, dim, device=DEV), torch.zeros(rows, dim, device=DEV)
     ids = torch.zeros(B, dtype=torch.int64, device=DEV)
     dout = torch.zeros(B, dim, device=DEV)
@@ -675,9 +678,15 @@ def test_lazy_dense_decay_equals_the_sweep(hip):
       if mode != 'sweep':
         hip.emb_route(g, ukeys, nu, uidx, cnt)
         hip.emb_catch_up(g, ukeys, nu, hyper)
+      if mode == 'lazy_roll_side':
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+          hip.emb_flush_window([g], 16, hyper, lag=1, max_blocks=1)
       hip.emb_bwd_update(g, kernels.OPT_ADAM, hyper)
       if mode == 'lazy_roll':
         hip.emb_flush_window([g], 16, hyper)
+      if mode == 'lazy_roll_side':
+        torch.cuda.current_stream().wait_stream(side)
     if mode != 'sweep':
       hip.emb_flush_decay(g, hyper)
       torch.cuda.synchronize()
@@ -689,12 +698,12 @@ def test_lazy_dense_decay_equals_the_sweep(hip):
   hot = torch.arange(rows) < 11
   # fp32 never reaches 0 by repeated * 0.9: it settles on a denormal fixed point (|m| <= 4 * 2^-149)
   assert (ma[~hot].abs() <= 6e-45).all(), 'idle rows: m has settled (the closed-form tail of v was taken)'
-  for mode in ('lazy', 'lazy_roll'):
+  for mode in ('lazy', 'lazy_roll', 'lazy_roll_side'):
     vb, mb, sb = state[mode]
     assert torch.equal(ma, mb), (mode, 'first moments must be bit-identical')
     assert torch.equal(va[hot], vb[hot]) and torch.equal(sa[hot], sb[hot]), (mode, 'recently touched rows: every bit')
     assert torch.equal(va, vb), (mode, 'var: every bit, through the full, the absorbed and the settled regime')
-    if mode == 'lazy_roll':  # never more than 16 steps behind: v decays step by step too
+    if mode != 'lazy':  # never more than 16 steps behind: v decays step by step too
       assert torch.equal(sa, sb), mode
     else:  # one catch-up of > 1200 steps at the flush: the closed-form tail of v (backlog > 2048: no; <= 2048: exact)
       assert torch.equal(sa, sb), mode
