@@ -37,6 +37,8 @@ def parse_args():
   ap.add_argument('--ids', default='zipf', choices=['zipf', 'uniform'])
   ap.add_argument('--optimizer', default='config', choices=['config', 'adam', 'lazy_adam'])
   ap.add_argument('--no_graph', action='store_true', help='eager launches instead of hipGraph replay')
+  ap.add_argument('--dense_dtype', default='f32', choices=['f32', 'bf16'],
+                  help="bf16: BASELINE config 3 (bf16 dense contractions with fp32 accumulate, fp32 embeddings and master weights)")
   ap.add_argument('--no_cpu_baseline', action='store_true')
   ap.add_argument('--dense_sweep', action='store_true', help='TF-exact Adam by streaming every row every step (default: lazy dense decay, bit-identical)')
   ap.add_argument('--force_ep', action='store_true', help='run the embedding-parallel code path even at 1 GPU')
@@ -55,6 +57,12 @@ def parse_args():
   ap.add_argument('--parity_steps', type=int, default=2,
                   help='N=1: steps of the full-size GPU-vs-oracle loss comparison (0 = skip; needs the CPU baseline)')
   return ap.parse_args()
+
+
+def workload_name(cfg, args):
+  base = os.path.basename(args.config)
+  name = 'DeepFM' if 'deepfm' in base else 'DCN-v2' if 'dcn_v2' in base else cfg.model_config.model_class or base
+  return name + (' (bf16 dense, fp32 embeddings)' if args.dense_dtype == 'bf16' else '')
 
 
 def baseline_metric():
@@ -183,28 +191,49 @@ def time_gemm_kernel(est, launches):
   BatchNorm column statistics in the epilogue, exactly as the step issues it - is timed live with HIP events."""
   from easyrec_amd import kernels
   be = kernels.hip()
-  x = est.engine.groups['group:deep']['out']
   vs = est.varstore
-  w = vs._vars['deep_feature/dnn_0/kernel']['tensor'].detach()
-  b = vs._vars['deep_feature/dnn_0/bias']['tensor'].detach()
-  M, K = x.shape
-  N = w.shape[1]
   bf16 = est.ctx.dense_dtype == 'bf16'
-  stats = torch.empty(be.gemm_row_tiles(M) * N * 3, dtype=torch.float32, device=x.device)
-  out = torch.empty(M, N, dtype=torch.float32, device=x.device)
   evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(launches)]
-  for _ in range(5):
-    be.gemm(kernels.GEMM_NN, x, w, out=out, bias=b, bf16=bf16, col_stats=stats)
-  torch.cuda.synchronize()
-  for a, e in evs:
-    a.record()
-    be.gemm(kernels.GEMM_NN, x, w, out=out, bias=b, bf16=bf16, col_stats=stats)
-    e.record()
-  torch.cuda.synchronize()
-  ms = [a.elapsed_time(e) for a, e in evs]
-  return {'kernel': 'er::gemm_%s_kernel<NN> %dx%dx%d (+bias, BatchNorm column statistics)' %
-                    ('bf16' if bf16 else 'f32', M, N, K), 'avg_ms': float(np.mean(ms)), 'min_ms': float(np.min(ms)),
-          'flops': 2.0 * M * N * K, 'launches': launches}
+
+  def timed(fn):
+    for _ in range(5):
+      fn()
+    torch.cuda.synchronize()
+    for a, e in evs:
+      a.record()
+      fn()
+      e.record()
+    torch.cuda.synchronize()
+    return [a.elapsed_time(e) for a, e in evs]
+
+  if not bf16 and 'deep_feature/dnn_0/kernel' in vs._vars and 'group:deep' in est.engine.groups:
+    x = est.engine.groups['group:deep']['out']
+    w = vs._vars['deep_feature/dnn_0/kernel']['tensor'].detach()
+    b = vs._vars['deep_feature/dnn_0/bias']['tensor'].detach()
+    M, K = x.shape
+    N = w.shape[1]
+    stats = torch.empty(be.gemm_row_tiles(M) * N * 3, dtype=torch.float32, device=x.device)
+    out = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    ms = timed(lambda: be.gemm(kernels.GEMM_NN, x, w, out=out, bias=b, col_stats=stats))
+    name = 'er::gemm_f32_kernel<NN> %dx%dx%d (+bias, BatchNorm column statistics)' % (M, N, K)
+  else:
+    # the largest weight matrix of the dense part (DCN-v2: a 624 x 624 cross kernel), on a batch-sized activation
+    wname, w = max(((n, r['tensor'].detach()) for n, r in vs._vars.items() if r['tensor'].dim() == 2),
+                   key=lambda nw: nw[1].numel())
+    K, N = w.shape
+    M = est.batch_size
+    x = torch.randn(M, K, device=w.device)
+    out = torch.empty(M, N, dtype=torch.float32, device=w.device)
+    if bf16 and getattr(est, '_bf16', None) is not None and be.bf16_nt:
+      x16 = est._bf16.act(x)
+      wt = est._bf16.weight(w)[2]
+      ms = timed(lambda: be.gemm_bf16_nt(x16, wt, M, N, K, out=out))
+      name = 'er::gemm_bf16_nt_kernel<4> %dx%dx%d (%s: bf16 operands in HBM, fp32 out)' % (M, N, K, wname)
+    else:
+      ms = timed(lambda: be.gemm(kernels.GEMM_NN, x, w, out=out, bf16=bf16))
+      name = 'er::gemm_%s_kernel<NN> %dx%dx%d (%s)' % ('bf16' if bf16 else 'f32', M, N, K, wname)
+  return {'kernel': name, 'avg_ms': float(np.mean(ms)), 'min_ms': float(np.min(ms)), 'flops': 2.0 * M * N * K,
+          'launches': launches}
 
 
 class DeviceCriteo(object):
@@ -378,10 +407,10 @@ def main():
       from easyrec_amd.core.comm import TorchDistComm
       comm = TorchDistComm()
     est = EmbeddingParallelEstimator(cfg, device=dev, batch_size=B, seed=1, rank=rank, world=world, comm=comm,
-                                     dense_sweep=args.dense_sweep).build()
+                                     dense_sweep=args.dense_sweep, dense_dtype=args.dense_dtype).build()
   else:
     est = EasyRecEstimator(cfg, device=dev, batch_size=B, seed=1, overlap_sweep=args.overlap,
-                           dense_sweep=args.dense_sweep).build()
+                           dense_sweep=args.dense_sweep, dense_dtype=args.dense_dtype).build()
   gen = SyntheticCriteo(cfg.data_config, est.feature_configs, batch_size=B, seed=20240607 + rank, mode=args.ids)
   # a few host batches (the CPU baseline and the full-size parity check need the same batch on both sides) ...
   host_batches = [gen.next_batch() for _ in range(4)]
@@ -445,12 +474,13 @@ def main():
       'higher_is_better': True,
       'scaling': 'weak',
       'vs_baseline': None,
-      'dtype': 'f32',
+      'dtype': args.dense_dtype,
       'data': 'synthetic',
       'config': {
-          'workload': 'DeepFM synthetic Criteo: %s (39 features: 26 hashed x %d rows + 13 projected, D=16 deep + '
-                      'D=1 wide, batch %d per GPU, optimizer %s, ids %s, %s)' %
-                      (os.path.basename(args.config), cfg.feature_config.features[13].hash_bucket_size, B,
+          'workload': '%s synthetic Criteo: %s (39 features: 26 hashed x %d rows + 13 projected, D=16%s, '
+                      'batch %d per GPU, optimizer %s, ids %s, %s)' %
+                      (workload_name(cfg, args), os.path.basename(args.config), cfg.feature_config.features[13].hash_bucket_size,
+                       ' deep + D=1 wide' if 'deepfm' in os.path.basename(args.config) else '', B,
                        est.opt_emb.name + (' (dense sweep)' if getattr(est, 'dense_sweep', False) and est.opt_emb.name == 'adam_optimizer'
                                            else ' (lazy dense decay, bit-identical)' if est.opt_emb.name == 'adam_optimizer' else ''),
                        args.ids, graph_note) + '; timed steps cycle over %d distinct device-generated batches after %d '

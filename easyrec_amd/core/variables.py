@@ -160,6 +160,8 @@ class VarStore(object):
     self.refresh_l2_partials()
 
   def refresh_l2_partials(self):
+    # (called whenever the weights were written from outside the optimizer: pack, load_state_dict)
+    self.version = getattr(self, 'version', 0) + 1  # kernels.Bf16Shadows re-casts the weights' bf16 shadows
     if getattr(self, 'l2_partials', None) is not None:
       from easyrec_amd import kernels
       kernels.hip().l2_partials(self.flat, self.l2coef, self.l2_partials)

@@ -15,6 +15,12 @@ from typing import Optional
 import numpy as np
 import torch
 
+
+class CastDesc(ctypes.Structure):
+  """er_cast_desc (include/easyrec_hip.h)"""
+  _fields_ = [('src', ctypes.c_void_p), ('dst', ctypes.c_void_p), ('rows', ctypes.c_int64), ('cols', ctypes.c_int32),
+              ('ld_src', ctypes.c_int32), ('ld_dst', ctypes.c_int32), ('transpose', ctypes.c_int32)]
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # EASYREC_AMD_LIB: another build of the same ABI (same-box A/B of a kernel change, tools/gpu_ab.sh)
 LIB_PATH = os.environ.get('EASYREC_AMD_LIB') or os.path.join(_HERE, 'csrc', 'libeasyrec_hip.so')
@@ -216,6 +222,66 @@ def _stream():
 def _f32c(t, name='tensor'):
   assert t.dtype == torch.float32 and t.is_contiguous(), '%s must be contiguous fp32' % name
   return t
+
+
+class Bf16Shadows(object):
+  """dense_dtype 'bf16' (BASELINE config 3): the bf16 operands the contractions read from HBM.
+
+  Weights: two bf16 shadows per fp32 master in `varstore.flat` - `plain` [K, pad8(N)] (the k-contiguous operand of the
+  input-gradient product dx = dy . W^T) and `t` [N, pad8(K)] (of the forward product x . W) - written by ONE er_cast_bf16
+  launch after every dense optimizer step (HipBackend.dense_opt_step) and whenever the store's weights were replaced
+  (VarStore.version).  Activations: cast by act() when a contraction needs them (their producers write fp32)."""
+
+  def __init__(self, be, varstore):
+    import weakref
+    self.be = be
+    self.vs = weakref.ref(varstore)
+    flat = varstore.flat
+    self.lo, self.hi = flat.data_ptr(), flat.data_ptr() + flat.numel() * 4
+    self.device = flat.device
+    self.weights = {}  # data_ptr -> (master view [K, N], plain, t)
+    self.seen_version = getattr(varstore, 'version', 0)
+
+  @staticmethod
+  def pad8(n):
+    return (int(n) + 7) // 8 * 8
+
+  def owns(self, t):
+    return self.lo <= t.data_ptr() < self.hi
+
+  def alive(self):
+    return self.vs() is not None
+
+  def _descs(self, entries):
+    return [d for w, plain, t in entries for d in ((w, plain, False), (w, t, True))]
+
+  def weight(self, w):
+    vs = self.vs()
+    if vs is not None and getattr(vs, 'version', 0) != self.seen_version:
+      self.refresh()
+    e = self.weights.get(w.data_ptr())
+    if e is None or e[0].shape != w.shape:
+      K, N = w.shape
+      plain = torch.zeros(K, self.pad8(N), dtype=torch.bfloat16, device=self.device)
+      t = torch.zeros(N, self.pad8(K), dtype=torch.bfloat16, device=self.device)
+      e = self.weights[w.data_ptr()] = (w.detach(), plain, t)
+      self.be.cast_bf16(self._descs([e]))
+    return e
+
+  def refresh(self):
+    vs = self.vs()
+    if vs is not None:
+      self.seen_version = getattr(vs, 'version', 0)
+    if self.weights:
+      self.be.cast_bf16(self._descs(self.weights.values()))
+
+  def act(self, x, transpose=False):
+    """A bf16 copy of the fp32 matrix x ([rows, pad8(cols)], or its transpose [cols, pad8(rows)])."""
+    rows, cols = x.shape
+    dst = torch.empty((cols, self.pad8(rows)) if transpose else (rows, self.pad8(cols)), dtype=torch.bfloat16,
+                      device=x.device)
+    self.be.cast_bf16([(x, dst, transpose)])
+    return dst
 
 
 class HipBackend(object):
@@ -481,6 +547,8 @@ class HipBackend(object):
       assert not accumulate
       out = torch.empty(M, N, dtype=torch.float32, device=a.device)
     assert out.shape == (M, N) and out.stride(1) == 1 and out.dtype == torch.float32
+    if bf16 and col_stats is None and self._gemm_bf16_fast(layout, a, b, out, bias, accumulate, M, N, K):
+      return out
     fn = self.lib.er_gemm_bf16 if bf16 else self.lib.er_gemm_f32
     if col_stats is not None:
       assert col_stats.numel() >= self.gemm_row_tiles(M) * N * 3 and col_stats.dtype == torch.float32
@@ -488,6 +556,65 @@ class HipBackend(object):
                 _p(out), ctypes.c_int32(out.stride(0)), _p(bias), int(bool(accumulate)), _p(col_stats), _stream()),
              'er_gemm')
     return out
+
+  # -- bf16 operands in HBM (dense_dtype 'bf16'): er_gemm_bf16_nt
+  bf16_nt = os.environ.get('EASYREC_AMD_BF16_NT', '1') != '0'  # A/B switch: '0' = er_gemm_bf16 (converts while staging)
+
+  def bf16_enable(self, varstore):
+    """Called by the estimator (dense_dtype 'bf16') once the dense variables are packed; outside graph capture."""
+    self._ck(self.lib.er_gemm_bf16_nt_prepare(), 'er_gemm_bf16_nt_prepare')
+    states = [s for s in getattr(self, '_bf16_states', []) if s.alive()]
+    st = Bf16Shadows(self, varstore)
+    states.append(st)
+    self._bf16_states = states
+    return st
+
+  def _bf16_state_of(self, t):
+    for st in getattr(self, '_bf16_states', ()):
+      if st.owns(t) and st.alive():
+        return st
+    return None
+
+  def cast_bf16(self, items):
+    """items: [(src fp32 [rows, cols] (unit inner stride), dst bf16, transpose)]: dst[r, c] = src[r, c] or
+    dst[c, r] = src[r, c], padding columns of dst zeroed; ceil(n / 16) launches."""
+    n = len(items)
+    arr = (CastDesc * n)()
+    for i, (src, dst, tr) in enumerate(items):
+      assert src.dim() == 2 and src.stride(1) == 1 and src.dtype == torch.float32
+      assert dst.dim() == 2 and dst.stride(1) == 1 and dst.dtype == torch.bfloat16
+      rows, cols = src.shape
+      assert dst.shape[0] == (cols if tr else rows) and dst.stride(0) >= (rows if tr else cols)
+      arr[i] = CastDesc(src.data_ptr(), dst.data_ptr(), rows, cols, src.stride(0), dst.stride(0), 1 if tr else 0)
+    self._ck(self.lib.er_cast_bf16(arr, n, _stream()), 'er_cast_bf16')
+
+  def gemm_bf16_nt(self, a, bt, M, N, K, out=None, out_bf16=None, bias=None, accumulate=False):
+    """out[M, N] (+)= a[M, K] . bt[N, K]^T (+ bias): bf16 operands with leading dimensions that are multiples of 8,
+    fp32 accumulate; out fp32 and / or out_bf16."""
+    assert a.dtype == torch.bfloat16 and bt.dtype == torch.bfloat16 and a.stride(1) == 1 and bt.stride(1) == 1
+    assert a.shape[0] >= M and bt.shape[0] >= N
+    Kp = (K + 7) // 8 * 8  # (the k-tail up to the padded width reads zeros: Bf16Shadows pads with zeros)
+    assert a.stride(0) >= Kp and bt.stride(0) >= Kp and a.stride(0) % 8 == 0 and bt.stride(0) % 8 == 0
+    self._ck(self.lib.er_gemm_bf16_nt(M, N, Kp, ctypes.c_void_p(a.data_ptr()), ctypes.c_int32(a.stride(0)),
+                                      ctypes.c_void_p(bt.data_ptr()), ctypes.c_int32(bt.stride(0)), _p(out),
+                                      ctypes.c_int32(0 if out is None else out.stride(0)),
+                                      ctypes.c_void_p(0 if out_bf16 is None else out_bf16.data_ptr()),
+                                      ctypes.c_int32(0 if out_bf16 is None else out_bf16.stride(0)), _p(bias),
+                                      int(bool(accumulate)), _stream()), 'er_gemm_bf16_nt')
+    return out
+
+  def _gemm_bf16_fast(self, layout, a, b, out, bias, accumulate, M, N, K):
+    """The bf16 contraction through er_gemm_bf16_nt when one operand is a weight of a bf16-enabled store (forward
+    x . W, input gradient dy . W^T); False = not applicable."""
+    if not self.bf16_nt or layout == GEMM_TN:
+      return False
+    st = self._bf16_state_of(b)
+    if st is None:
+      return False
+    w, plain, t = st.weight(b)
+    a16 = st.act(a)
+    self.gemm_bf16_nt(a16, t if layout == GEMM_NN else plain, M, N, K, out=out, bias=bias, accumulate=accumulate)
+    return True
 
   # er_gemm_f32_bn_bwd / er_bn_act_bwd_from_partials are used (A/B switch: EASYREC_AMD_FUSED_BN_BWD=0)
   fused_bn_bwd = os.environ.get('EASYREC_AMD_FUSED_BN_BWD', '1') != '0'
@@ -1159,6 +1286,9 @@ class HipBackend(object):
         self.lib.er_dense_opt_step_l2(_p(w), _p(m), _p(v), _p(grad), _p(l2coef), ctypes.c_int64(w.numel()),
                                       ctypes.c_int(opt_kind), _p(hyper), _p(l2_partials), _stream()),
         'er_dense_opt_step_l2')
+    st = self._bf16_state_of(w)
+    if st is not None:
+      st.refresh()  # the weights' bf16 shadows follow the masters (one launch)
 
 
 _BACKEND = None

@@ -150,6 +150,8 @@ class EasyRecEstimator(object):
       for st in self.engine.storage.values():
         st['v'].fill_(getattr(self.opt_emb, 'initial_accumulator_value', 0.1))
     self.varstore.pack(self._extra_grad_floats())
+    if self.ctx.dense_dtype == 'bf16' and self.device.type == 'cuda':
+      self._bf16 = kernels.hip().bf16_enable(self.varstore)  # bf16 weight shadows for er_gemm_bf16_nt
     self._after_pack()
     if self.opt_dense.kind in (kernels.OPT_ADAM, kernels.OPT_LAZY_ADAM):
       self.varstore.slot('m')

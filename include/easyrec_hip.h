@@ -541,6 +541,30 @@ int er_gemm_f32(int layout, int32_t M, int32_t N, int32_t K, const float* A, int
 int er_gemm_bf16(int layout, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B,
                  int32_t ldb, float* C, int32_t ldc, const float* bias, int accumulate, float* col_stats,
                  er_stream_t stream);
+/* bf16 operands IN HBM (BASELINE config 3), both k-contiguous: C[M,N] (+)= A[M,K] . Bt[N,K]^T (+ bias[N]), fp32
+ * accumulate on v_mfma_f32_32x32x16_bf16.  Replaces the MatMul of the DCN-v2 cross layer (layers/keras/interaction.py:
+ * 249-286) / tf.layers.dense (layers/dnn.py:57-62) and their input gradient (dx = dy . W^T: A = dy, Bt = W [K_in][N_out])
+ * when the dense part runs in bf16: 128 x 128 tiles, operands DMA'd HBM -> LDS (global_load_lds, 16 B per lane) in a
+ * ring of 4 k-tiles kept in flight across the workgroup barrier.  K, lda, ldb: multiples of 8 (16-byte chunks), A / Bt
+ * 16-byte aligned.  C (fp32, optional C +=) and / or C_bf16 (the next layer's operand) are written in one epilogue.
+ * er_gemm_bf16_nt_prepare allocates the zero chunk and raises the kernel's LDS limit: call once, outside graph capture.
+ * er_cast_bf16: fp32 -> bf16 (round to nearest even) copies of up to any number of matrices in ceil(n / 16) launches:
+ * dst[r][c] = src[r][c], or transposed dst[c][r] = src[r][c]; the padding columns of dst up to ld_dst are zeroed
+ * (they are read as the k-tail).  Used for the weights' shadows after an optimizer step and for an fp32 activation
+ * matrix whose producer does not write bf16 itself. */
+typedef struct {
+  const float* src;
+  uint16_t* dst;
+  int64_t rows;      /* of src */
+  int32_t cols;      /* of src */
+  int32_t ld_src, ld_dst;
+  int32_t transpose;
+} er_cast_desc;
+int er_gemm_bf16_nt_prepare(void);
+int er_gemm_bf16_nt(int32_t M, int32_t N, int32_t K, const uint16_t* A, int32_t lda, const uint16_t* Bt, int32_t ldb,
+                    float* C, int32_t ldc, uint16_t* C_bf16, int32_t ldc_bf16, const float* bias, int accumulate,
+                    er_stream_t stream);
+int er_cast_bf16(const er_cast_desc* descs_host, int n, er_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
  * K12 embedding-parallel (row-sharded tables, one process per GPU).  Replaces

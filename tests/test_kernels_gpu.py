@@ -1017,3 +1017,61 @@ def test_replicated_tables_dense_reduce_and_apply(hip, ref, opt):
       assert torch.allclose(x.cpu(), y, rtol=1e-6, atol=1e-9), (what, float((x.cpu() - y).abs().max()))
   for g in groups_d:
     hip.emb_group_destroy(g)
+
+
+def _bf16_round(x):
+  return x.to(torch.bfloat16).to(torch.float32)
+
+
+@pytest.mark.parametrize('rows,cols', [(4096, 624), (130, 70), (7, 3), (624, 624)])
+def test_cast_bf16_plain_and_transposed(hip, rows, cols):
+  """er_cast_bf16 against torch's own round-to-nearest-even cast; the padding up to the leading dimension is zero."""
+  g = torch.Generator().manual_seed(rows * 7 + cols)
+  x = (torch.randn(rows, cols, generator=g) * 3).to(DEV)
+  x[0, 0] = float('inf')
+  x[rows - 1, cols - 1] = 1.00390625  # a tie: rounds to even
+  pad = kernels.Bf16Shadows.pad8
+  plain = torch.full((rows, pad(cols)), 7.0, dtype=torch.bfloat16, device=DEV)
+  tr = torch.full((cols, pad(rows)), 7.0, dtype=torch.bfloat16, device=DEV)
+  hip.cast_bf16([(x, plain, False), (x, tr, True)])
+  torch.cuda.synchronize()
+  want = x.to(torch.bfloat16)
+  assert torch.equal(plain[:, :cols], want)
+  assert torch.equal(tr[:, :rows], want.t())
+  assert (plain[:, cols:] == 0).all() and (tr[:, rows:] == 0).all()
+
+
+@pytest.mark.parametrize('M,N,K', [(4096, 624, 624), (4096, 256, 624), (130, 70, 40), (128, 128, 64), (257, 129, 520),
+                                   (64, 8, 8)])
+@pytest.mark.parametrize('mode', ['plain', 'bias_accumulate', 'bf16_out'])
+def test_gemm_bf16_nt(hip, M, N, K, mode):
+  """er_gemm_bf16_nt: bf16 operands in HBM, fp32 accumulate.  The products of bf16 values are exact in fp32, so the
+  reference (fp64 sum of the same bf16-rounded operands) differs only by fp32 summation order: 2e-5 of sum |a||b|."""
+  hip._ck(hip.lib.er_gemm_bf16_nt_prepare(), 'prepare')
+  g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
+  a = torch.randn(M, K, generator=g).to(DEV)
+  b = torch.randn(N, K, generator=g).to(DEV)  # Bt: asymmetric by construction
+  pad = kernels.Bf16Shadows.pad8
+  a16 = torch.empty(M, pad(K), dtype=torch.bfloat16, device=DEV)
+  b16 = torch.empty(N, pad(K), dtype=torch.bfloat16, device=DEV)
+  hip.cast_bf16([(a, a16, False), (b, b16, False)])
+  ref = _bf16_round(a).double() @ _bf16_round(b).double().t()
+  scale = _bf16_round(a).abs().double() @ _bf16_round(b).abs().double().t()
+  if mode == 'plain':
+    out = torch.full((M, N), 3.0, device=DEV)
+    hip.gemm_bf16_nt(a16, b16, M, N, K, out=out)
+  elif mode == 'bias_accumulate':
+    bias = torch.randn(N, generator=g).to(DEV)
+    base = torch.randn(M, N, generator=g).to(DEV)
+    out = base.clone()
+    hip.gemm_bf16_nt(a16, b16, M, N, K, out=out, bias=bias, accumulate=True)
+    ref = ref + bias.double()[None, :] + base.double()
+  else:
+    out16 = torch.zeros(M, pad(N), dtype=torch.bfloat16, device=DEV)
+    out = torch.zeros(M, N, device=DEV)
+    hip.gemm_bf16_nt(a16, b16, M, N, K, out=out, out_bf16=out16)
+    torch.cuda.synchronize()
+    assert torch.equal(out16[:, :N], out.to(torch.bfloat16)), 'the bf16 copy is the RNE rounding of the fp32 output'
+  torch.cuda.synchronize()
+  err = (out.double() - ref).abs()
+  assert bool((err <= 2e-5 * scale + 1e-6).all()), float((err / (scale + 1e-9)).max())
