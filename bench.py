@@ -65,6 +65,44 @@ def workload_name(cfg, args):
   return name + (' (bf16 dense, fp32 embeddings)' if args.dense_dtype == 'bf16' else '')
 
 
+def workload_text(cfg, args, est, criteo, B, graph_note, n_ring):
+  base = os.path.basename(args.config)
+  opt = est.opt_emb.name + (' (dense sweep)' if getattr(est, 'dense_sweep', False) and est.opt_emb.name == 'adam_optimizer'
+                            else ' (lazy dense decay, bit-identical)' if est.opt_emb.name == 'adam_optimizer' else '')
+  if criteo:
+    head = '%s synthetic Criteo: %s (39 features: 26 hashed x %d rows + 13 projected, D=16%s, ' % (
+        workload_name(cfg, args), base, cfg.feature_config.features[13].hash_bucket_size,
+        ' deep + D=1 wide' if 'deepfm' in base else '')
+    src = 'distinct device-generated batches'
+  else:
+    feats = cfg.feature_config.features
+    rows = sum((f.hash_bucket_size or f.num_buckets) for f in feats)
+    seqs = [f.max_seq_len for f in feats if f.HasField('max_seq_len')]
+    head = '%s synthetic Taobao-shaped: %s (%d features, %.1f M embedding rows, D=%d%s, ' % (
+        workload_name(cfg, args), base, len(feats), rows / 1e6, feats[0].embedding_dim,
+        ', %d sequences of max length %d' % (len(seqs), max(seqs)) if seqs else '')
+    src = 'distinct host-generated, device-resident batches (pre-conditioning cycles over the same ring)'
+  return head + 'batch %d per GPU, optimizer %s, ids %s, %s); timed steps cycle over %d %s after %d untimed ' \
+      'pre-conditioning steps' % (B, opt, args.ids, graph_note, n_ring, src, args.precondition)
+
+
+def is_criteo_shaped(cfg):
+  names = [f.input_names[0] for f in cfg.feature_config.features if len(f.input_names)]
+  return 'C1' in names and 'C26' in names and not any(f.HasField('max_seq_len') or f.feature_type == f.TagFeature
+                                                      for f in cfg.feature_config.features)
+
+
+class RingSource(object):
+  """next_packed() over a fixed ring of device-resident batches (schemas DeviceCriteo does not generate)."""
+
+  def __init__(self, ring):
+    self.ring, self.i = ring, 0
+
+  def next_packed(self):
+    self.i += 1
+    return self.ring[self.i % len(self.ring)]
+
+
 def baseline_metric():
   """BASELINE.json's metric string (the embedding-stage GB/s half of it is reported under `embedding_stage`)."""
   try:
@@ -411,15 +449,27 @@ def main():
   else:
     est = EasyRecEstimator(cfg, device=dev, batch_size=B, seed=1, overlap_sweep=args.overlap,
                            dense_sweep=args.dense_sweep, dense_dtype=args.dense_dtype).build()
-  gen = SyntheticCriteo(cfg.data_config, est.feature_configs, batch_size=B, seed=20240607 + rank, mode=args.ids)
-  # a few host batches (the CPU baseline and the full-size parity check need the same batch on both sides) ...
-  host_batches = [gen.next_batch() for _ in range(4)]
-  host_ring = [{k: (torch.from_numpy(np.ascontiguousarray(v)).to(dev) if isinstance(v, np.ndarray) else v)
-                for k, v in est.features.pack(b, device=dev).items()} for b in host_batches]
-  # ... and the timed loop's batches: the same distribution generated on the device, resident in the packed layout of
-  # the input arena (loading one is a single device-to-device copy)
-  dgen = DeviceCriteo(gen, est.features, dev, seed=977 + rank)
-  ring = [dgen.next_packed() for _ in range(max(args.ring, 1))]
+  criteo = is_criteo_shaped(cfg)
+  pack = lambda b: {k: (torch.from_numpy(np.ascontiguousarray(v)).to(dev) if isinstance(v, np.ndarray) else v)  # noqa: E731
+                    for k, v in est.features.pack(b, device=dev).items()}
+  if criteo:
+    gen = SyntheticCriteo(cfg.data_config, est.feature_configs, batch_size=B, seed=20240607 + rank, mode=args.ids)
+    # a few host batches (the CPU baseline and the full-size parity check need the same batch on both sides) ...
+    host_batches = [gen.next_batch() for _ in range(4)]
+    host_ring = [pack(b) for b in host_batches]
+    # ... and the timed loop's batches: the same distribution generated on the device, resident in the packed layout of
+    # the input arena (loading one is a single device-to-device copy)
+    dgen = DeviceCriteo(gen, est.features, dev, seed=977 + rank)
+    ring = [dgen.next_packed() for _ in range(max(args.ring, 1))]
+  else:
+    # any other schema (Taobao-shaped DIN / MMoE: sequences, tag lists): schema-driven host generator, a ring of
+    # distinct batches made resident on the device; pre-conditioning and the steady-state pass cycle over the ring
+    from easyrec_amd.input.synthetic import SyntheticBatches
+    gen = SyntheticBatches(cfg.data_config, est.feature_configs, batch_size=B, seed=20240607 + rank, mode=args.ids)
+    host_batches = [gen.next_batch() for _ in range(4)]
+    host_ring = [pack(b) for b in host_batches]
+    ring = host_ring + [pack(gen.next_batch()) for _ in range(max(min(args.ring, 64), 4) - 4)]
+    dgen = RingSource(ring)
   est.features.load(ring[0])
   torch.cuda.synchronize()
   ep = world > 1 or args.force_ep
@@ -477,14 +527,7 @@ def main():
       'dtype': args.dense_dtype,
       'data': 'synthetic',
       'config': {
-          'workload': '%s synthetic Criteo: %s (39 features: 26 hashed x %d rows + 13 projected, D=16%s, '
-                      'batch %d per GPU, optimizer %s, ids %s, %s)' %
-                      (workload_name(cfg, args), os.path.basename(args.config), cfg.feature_config.features[13].hash_bucket_size,
-                       ' deep + D=1 wide' if 'deepfm' in os.path.basename(args.config) else '', B,
-                       est.opt_emb.name + (' (dense sweep)' if getattr(est, 'dense_sweep', False) and est.opt_emb.name == 'adam_optimizer'
-                                           else ' (lazy dense decay, bit-identical)' if est.opt_emb.name == 'adam_optimizer' else ''),
-                       args.ids, graph_note) + '; timed steps cycle over %d distinct device-generated batches after %d '
-                      'untimed pre-conditioning steps over further distinct batches' % (len(ring), args.precondition),
+          'workload': workload_text(cfg, args, est, criteo, B, graph_note, len(ring)),
           'global_batch': world * B,
           'parallelism': ('embedding-parallel x%d (row-sharded tables, RCCL all-to-all) + dense DP' % world if world > 1 else
                           'single GPU' if not ep else 'single GPU through the embedding-parallel code path (%s)' %
@@ -494,19 +537,20 @@ def main():
       'device': kernels.hip().device_info(),
   }
   if world == 1 and not ep:
-    lazy_bytes, sweep_bytes = embedding_bytes_per_step(est, host_ring)
-    out['embedding_stage'] = {
-        'algorithmic_bytes_per_step': lazy_bytes + sweep_bytes,
-        'lookup_update_bytes_per_step': lazy_bytes,
-        'dense_decay_sweep_bytes_per_step': sweep_bytes,
-        'whole_step_GBps': (lazy_bytes + sweep_bytes) / (ms_per_step * 1e-3) / 1e9,
-        'note': 'whole_step_GBps divides the embedding stage\'s algorithmic bytes by the WHOLE step time; '
-                'dense_decay_sweep_bytes_per_step is 0 unless --dense_sweep (default: lazy dense decay)',
-    }
-    try:
-      out['embedding_stage'].update(time_embedding_stage(est, lazy_bytes + sweep_bytes))
-    except Exception as e:  # noqa: BLE001
-      out['embedding_stage']['stage_error'] = str(e)[:200]
+    lazy_bytes, sweep_bytes = embedding_bytes_per_step(est, host_ring) if criteo else (0.0, 0.0)
+    if criteo:  # (the byte accounting of SURVEY.md 8d is written for the Criteo schema)
+      out['embedding_stage'] = {
+          'algorithmic_bytes_per_step': lazy_bytes + sweep_bytes,
+          'lookup_update_bytes_per_step': lazy_bytes,
+          'dense_decay_sweep_bytes_per_step': sweep_bytes,
+          'whole_step_GBps': (lazy_bytes + sweep_bytes) / (ms_per_step * 1e-3) / 1e9,
+          'note': 'whole_step_GBps divides the embedding stage\'s algorithmic bytes by the WHOLE step time; '
+                  'dense_decay_sweep_bytes_per_step is 0 unless --dense_sweep (default: lazy dense decay)',
+      }
+      try:
+        out['embedding_stage'].update(time_embedding_stage(est, lazy_bytes + sweep_bytes))
+      except Exception as e:  # noqa: BLE001
+        out['embedding_stage']['stage_error'] = str(e)[:200]
     n_launch = max(10, min(args.steps, 50))
     if sweep_bytes > 0 and est.dense_sweep:
       dom = time_sweep_kernel(est, n_launch)

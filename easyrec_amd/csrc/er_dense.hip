@@ -6,6 +6,8 @@
 // Reference call sites: layers/dnn.py:50-87, layers/keras/blocks.py:84-110,
 // layers/keras/activation.py:47-70, builders/loss_builder.py:35-39, compat/regularizers.py:76-108,
 // compat/optimizers.py:412-416 (apply_gradients -> tf.train.AdamOptimizer._apply_dense).
+#include <mutex>
+
 #include "er_common.h"
 
 namespace er {
@@ -15,7 +17,7 @@ namespace er {
 // ------------------------------------------------------------------------------------------------
 constexpr int kColsPerBlock = 64;
 constexpr int kRowLanes = kBlock / kColsPerBlock;  // 4
-constexpr int kMaxChunks = 256;
+constexpr int kMaxChunks = 1024;  // (B = 4096 layers stay at <= 128: rows / 32; tall activations get more workgroups)
 
 inline int choose_chunks(int B, int N) {
   const int col_blocks = static_cast<int>(ceil_div(N, kColsPerBlock));
@@ -130,6 +132,64 @@ bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ bias, con
 // matters is workgroups in flight - measured on one box, whole DeepFM step: 64 rows 0.591 ms, 32 0.562, 16 0.553,
 // 8 0.569, 4 0.605 (the redundant partial merges start to cost).
 constexpr int kApplyRows = 16;
+
+// Tall activations (DIN's attention MLP: B x L = 204,800 rows -> 3,200 row-tile partials per column): the fused
+// finalize + apply kernels below re-merge ALL partials in every 16-row workgroup (cheap for the 64 partials of a
+// B = 4096 layer, 2.4 MB per workgroup here: bn_finalize_apply took 0.58 ms on average in the DIN step).  Above
+// kInlineChunks partials they are merged ONCE per column by these kernels (same lane layout and merge order as the
+// fused kernels' first phase) into kMergeSlices records by as many workgroups per 64 columns, and the fused kernel merges
+// those.
+constexpr int kInlineChunks = 256;
+constexpr int kMergeSlices = 64;
+
+__global__ void __launch_bounds__(kBlock)
+bn_stats_merge_kernel(const float* __restrict__ partial, int N, int chunks, int per_slice, float* __restrict__ merged) {
+  // workgroup (x, y): columns x * 64 .., partials [y * per_slice, (y + 1) * per_slice) -> merged[y][column]
+  __shared__ Welford sm[kRowLanes][kColsPerBlock];
+  const int cl = threadIdx.x % kColsPerBlock;
+  const int rl = threadIdx.x / kColsPerBlock;
+  const int c = blockIdx.x * kColsPerBlock + cl;
+  const int k_end = min(chunks, static_cast<int>(blockIdx.y + 1) * per_slice);
+  Welford t{0.f, 0.f, 0.f};
+  if (c < N) {
+    for (int k = blockIdx.y * per_slice + rl; k < k_end; k += kRowLanes) {
+      const float* p = partial + (static_cast<int64_t>(k) * N + c) * 3;
+      t = wf_merge(t, Welford{p[0], p[1], p[2]});
+    }
+  }
+  sm[rl][cl] = t;
+  __syncthreads();
+  if (rl == 0 && c < N) {
+    const Welford w = wf_merge(wf_merge(sm[0][cl], sm[1][cl]), wf_merge(sm[2][cl], sm[3][cl]));
+    float* o = merged + (static_cast<int64_t>(blockIdx.y) * N + c) * 3;
+    o[0] = w.n; o[1] = w.mean; o[2] = w.m2;
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+bn_bwd_merge_kernel(const float* __restrict__ partial, int N, int chunks, int per_slice, float* __restrict__ merged) {
+  __shared__ float sm[2][kRowLanes][kColsPerBlock];
+  const int cl = threadIdx.x % kColsPerBlock;
+  const int rl = threadIdx.x / kColsPerBlock;
+  const int c = blockIdx.x * kColsPerBlock + cl;
+  const int k_end = min(chunks, static_cast<int>(blockIdx.y + 1) * per_slice);
+  float a = 0.f, b = 0.f;
+  if (c < N) {
+    for (int k = blockIdx.y * per_slice + rl; k < k_end; k += kRowLanes) {
+      const float* p = partial + (static_cast<int64_t>(k) * N + c) * 2;
+      a = a + p[0];
+      b = b + p[1];
+    }
+  }
+  sm[0][rl][cl] = a;
+  sm[1][rl][cl] = b;
+  __syncthreads();
+  if (rl == 0 && c < N) {
+    float* o = merged + (static_cast<int64_t>(blockIdx.y) * N + c) * 2;
+    o[0] = (sm[0][0][cl] + sm[0][1][cl]) + (sm[0][2][cl] + sm[0][3][cl]);
+    o[1] = (sm[1][0][cl] + sm[1][1][cl]) + (sm[1][2][cl] + sm[1][3][cl]);
+  }
+}
 
 __global__ void __launch_bounds__(kBlock)
 bn_finalize_apply_kernel(const float* __restrict__ partial, const float* __restrict__ x, const float* __restrict__ bias,
@@ -676,6 +736,28 @@ inline int blocks_for(int64_t n) { return static_cast<int>(ceil_div(n, kBlock));
 // training loop is single-stream per process, so one lazily grown device buffer is used.
 static float* g_scratch = nullptr;
 static size_t g_scratch_floats = 0;
+// Host functions that launch a producer and a consumer of the shared scratch take this lock: ranks simulated as
+// threads (tests) call concurrently with the GIL released, and a launch of another thread between the two would
+// overwrite the scratch in stream order.
+static std::mutex g_scratch_mu;
+static std::mutex g_merge_mu;  // the merged-partials buffer (taken after g_scratch_mu where both are held)
+
+// merged BatchNorm partials of tall activations (bn_stats_merge_kernel / bn_bwd_merge_kernel): 3 floats x 64 K columns
+static float* g_merged = nullptr;
+constexpr size_t kMergedFloats = (3u << 12) * 64;  // kMergeSlices records x 3 floats x 4 K columns
+int get_merged(float** out) {
+  if (!g_merged) {
+    hipError_t e = hipMalloc(&g_merged, kMergedFloats * sizeof(float));
+    if (e != hipSuccess) {
+      g_merged = nullptr;
+      set_error("merge buffer allocation failed: %s", hipGetErrorString(e));
+      return 1;
+    }
+  }
+  *out = g_merged;
+  return 0;
+}
+
 int get_scratch(size_t floats, float** out) {
   if (floats > g_scratch_floats) {
     if (g_scratch) (void)hipFree(g_scratch);
@@ -730,7 +812,9 @@ int er_bn_act_fwd(const float* x, const float* bias, const float* gamma, const f
   ER_REQUIRE(x && y && B > 0 && N > 0, "er_bn_act_fwd: bad arguments");
   hipStream_t s = er::as_stream(stream);
   const int64_t n = static_cast<int64_t>(B) * N;
+  std::unique_lock<std::mutex> lock(er::g_scratch_mu, std::defer_lock);
   if (use_bn) {
+    lock.lock();
     ER_REQUIRE(save_mean && save_invstd, "er_bn_act_fwd: save_mean/save_invstd required with use_bn");
     const int chunks = er::choose_chunks(B, N);
     float* scratch;
@@ -753,6 +837,20 @@ int er_bn_apply_from_stats(const float* x, const float* bias, const float* col_s
                            float* save_invstd, er_stream_t stream) {
   ER_REQUIRE(x && y && col_stats && save_mean && save_invstd && B > 0 && N > 0 && chunks > 0,
              "er_bn_apply_from_stats: bad arguments");
+  std::unique_lock<std::mutex> merge_lock(er::g_merge_mu, std::defer_lock);
+  if (chunks > er::kInlineChunks && static_cast<size_t>(N) * 3 * er::kMergeSlices <= er::kMergedFloats) {
+    float* merged;
+    if (er::get_merged(&merged)) return 1;
+    merge_lock.lock();  // (held until the consumer below is launched)
+    const int per_slice = static_cast<int>(er::ceil_div(chunks, er::kMergeSlices));
+    const int slices = static_cast<int>(er::ceil_div(chunks, per_slice));
+    hipLaunchKernelGGL(er::bn_stats_merge_kernel,
+                       dim3(static_cast<unsigned>(er::ceil_div(N, er::kColsPerBlock)), static_cast<unsigned>(slices)),
+                       dim3(er::kBlock), 0, er::as_stream(stream), col_stats, N, chunks, per_slice, merged);
+    ER_LAUNCH_CHECK();
+    col_stats = merged;
+    chunks = slices;
+  }
   dim3 grid(static_cast<unsigned>(er::ceil_div(N, er::kColsPerBlock)),
             static_cast<unsigned>(er::ceil_div(B, er::kApplyRows)));
   hipLaunchKernelGGL(er::bn_finalize_apply_kernel, grid, dim3(er::kBlock), 0, er::as_stream(stream), col_stats, x, bias,
@@ -760,6 +858,27 @@ int er_bn_apply_from_stats(const float* x, const float* bias, const float* col_s
   ER_LAUNCH_CHECK();
   return 0;
 }
+
+
+namespace {
+// > kInlineChunks partial sums per column: merged into kMergeSlices records first (the lock stays held until the
+// caller has launched the consumer)
+int merge_bwd_partials(const float** partial, int* chunks, int N, hipStream_t s, std::unique_lock<std::mutex>* lock) {
+  if (*chunks <= er::kInlineChunks || static_cast<size_t>(N) * 2 * er::kMergeSlices > er::kMergedFloats) return 0;
+  float* merged;
+  if (er::get_merged(&merged)) return 1;
+  lock->lock();
+  const int per_slice = static_cast<int>(er::ceil_div(*chunks, er::kMergeSlices));
+  const int slices = static_cast<int>(er::ceil_div(*chunks, per_slice));
+  hipLaunchKernelGGL(er::bn_bwd_merge_kernel,
+                     dim3(static_cast<unsigned>(er::ceil_div(N, er::kColsPerBlock)), static_cast<unsigned>(slices)),
+                     dim3(er::kBlock), 0, s, *partial, N, *chunks, per_slice, merged);
+  ER_LAUNCH_CHECK();
+  *partial = merged;
+  *chunks = slices;
+  return 0;
+}
+}  // namespace
 
 int er_bn_act_bwd(const float* x, const float* bias, const float* gamma, const float* y, const float* save_mean,
                   const float* save_invstd, const float* dy, int32_t B, int32_t N, int use_bn, int act, float* dx,
@@ -774,16 +893,21 @@ int er_bn_act_bwd_ld(const float* x, const float* bias, const float* gamma, cons
   ER_REQUIRE(x && y && dy && dx && B > 0 && N > 0 && dy_ld >= N, "er_bn_act_bwd: bad arguments");
   hipStream_t s = er::as_stream(stream);
   const int chunks = er::choose_chunks(B, N);
+  std::lock_guard<std::mutex> lock(er::g_scratch_mu);
   float* scratch;
   if (er::get_scratch(static_cast<size_t>(chunks) * N * 2, &scratch)) return 1;
   dim3 grid(static_cast<unsigned>(er::ceil_div(N, er::kColsPerBlock)), static_cast<unsigned>(chunks));
   hipLaunchKernelGGL(er::bn_bwd_partial_kernel, grid, dim3(er::kBlock), 0, s, x, bias, y, save_mean, save_invstd, dy, B,
                      N, chunks, use_bn, act, scratch, dy_ld);
   ER_LAUNCH_CHECK();
+  const float* partial = scratch;
+  int n_partial = chunks;
+  std::unique_lock<std::mutex> merge_lock(er::g_merge_mu, std::defer_lock);
+  if (int rc = merge_bwd_partials(&partial, &n_partial, N, s, &merge_lock)) return rc;
   dim3 grid2(static_cast<unsigned>(er::ceil_div(N, er::kColsPerBlock)),
              static_cast<unsigned>(er::ceil_div(B, er::kApplyRows)));
-  hipLaunchKernelGGL(er::bn_bwd_finalize_apply_kernel, grid2, dim3(er::kBlock), 0, s, scratch, x, bias, gamma, y,
-                     save_mean, save_invstd, dy, B, N, chunks, use_bn, act, accumulate, dx, dbias, dgamma, dbeta, dy_ld);
+  hipLaunchKernelGGL(er::bn_bwd_finalize_apply_kernel, grid2, dim3(er::kBlock), 0, s, partial, x, bias, gamma, y,
+                     save_mean, save_invstd, dy, B, N, n_partial, use_bn, act, accumulate, dx, dbias, dgamma, dbeta, dy_ld);
   ER_LAUNCH_CHECK();
   return 0;
 }
@@ -793,6 +917,8 @@ int er_bn_act_bwd_from_partials(const float* x, const float* bias, const float* 
                                 int use_bn, int act, const float* partial, int32_t chunks, float* dx, float* dbias,
                                 float* dgamma, float* dbeta, int accumulate, er_stream_t stream) {
   ER_REQUIRE(x && y && dy && dx && partial && B > 0 && N > 0 && chunks > 0, "er_bn_act_bwd_from_partials: bad arguments");
+  std::unique_lock<std::mutex> merge_lock(er::g_merge_mu, std::defer_lock);
+  if (int rc = merge_bwd_partials(&partial, &chunks, N, er::as_stream(stream), &merge_lock)) return rc;
   dim3 grid2(static_cast<unsigned>(er::ceil_div(N, er::kColsPerBlock)),
              static_cast<unsigned>(er::ceil_div(B, er::kApplyRows)));
   hipLaunchKernelGGL(er::bn_bwd_finalize_apply_kernel, grid2, dim3(er::kBlock), 0, er::as_stream(stream), partial, x, bias,

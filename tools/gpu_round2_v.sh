@@ -1,0 +1,24 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
+O=gpurun_out/r02v; mkdir -p $O
+timeout 120 python -m pytest tests/test_kernels_gpu.py -m gpu -q -x -k 'gemm_bf16_nt or lazy_dense' 2>&1 | tail -2 | tee $O/canary.txt
+if ! grep -q passed $O/canary.txt || grep -q failed $O/canary.txt; then echo 'canary failed: bad box?'; exit 0; fi
+line() { python -c "
+import sys,json
+try:
+  d=json.loads(sys.stdin.read())
+except Exception as e:
+  print('NO JSON', e); sys.exit(0)
+s=d.get('steady_state') or {}; r=d.get('roofline') or {}
+print(round(d['ms_per_step'],4), 'ms/step', round(d['value']), 'ex/s', 'steady', round(s.get('ms_per_step_mean',0),4), d['dtype'], '|', r.get('kernel'), round(r.get('achieved',0),1), r.get('unit'), 'frac', round(r.get('frac',0),3), '| loss', d.get('final_loss'))"; }
+run() { name=$1; shift; echo "--- $name: $*" | tee -a $O/lines.log; timeout 420 python bench.py --no_cpu_baseline --steps 100 --precondition 128 --steady_steps 128 "$@" > $O/$name.out 2>&1; grep '^{' $O/$name.out | tail -1 | tee -a $O/bench_lines.jsonl | line | tee -a $O/lines.log; grep -E "Error|error|Traceback" $O/$name.out | head -3; }
+run din10m --config configs/din_taobao_10m.config
+run din10m_ep --config configs/din_taobao_10m.config --force_ep
+run mmoe25m --config configs/mmoe_taobao_4task_d64_25m.config
+run mmoe25m_ep --config configs/mmoe_taobao_4task_d64_25m.config --force_ep
+run dcnv2_bf16 --config configs/dcn_v2_criteo.config --dense_dtype bf16
+prof() { name=$1; shift; cd /tmp && timeout 420 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$O/prof_$name -o step -- python $GRAFT_REPO_ROOT/bench.py --no_cpu_baseline --steps 300 --warmup 20 --steady_steps 0 --precondition 128 "$@" > $GRAFT_REPO_ROOT/$O/prof_$name.log 2>&1; cd $GRAFT_REPO_ROOT; DB=$(find $O/prof_$name -name "*.db" | head -1); python tools/rocpd_stats.py $DB $O/kernel_stats_$name.csv --steps 448 | tail -45 > $O/stats_$name.txt; rm -rf $O/prof_$name; tail -1 $O/stats_$name.txt; }
+prof din10m --config $GRAFT_REPO_ROOT/configs/din_taobao_10m.config
+prof mmoe25m --config $GRAFT_REPO_ROOT/configs/mmoe_taobao_4task_d64_25m.config
+( time timeout 1500 python -m pytest tests -m gpu -q --tb=short 2>&1 | grep -v "^$" | cut -c1-300 | tail -40 ) > $O/pytest.log 2>&1
+grep -E "^(FAILED|ERROR)|passed|failed|^E |^real" $O/pytest.log | head -30

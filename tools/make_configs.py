@@ -531,6 +531,10 @@ if __name__ == '__main__':
   write(din_taobao(batch_size=128, scale=0.01, seq_len=12), 'din_taobao_small.config')
   write(mmoe_taobao(), 'mmoe_taobao.config')
   write(mmoe_taobao(n_tasks=4, embedding_dim=64, batch_size=8192), 'mmoe_taobao_4task_d64.config')
+  # BASELINE config 5 at full size (200 M embedding rows of 64 floats: 51 GB + Adam slots, row-sharded over 8 GPUs) and
+  # the share one GPU owns of it (25 M rows) for single-GPU runs
+  write(mmoe_taobao(n_tasks=4, embedding_dim=64, batch_size=8192, item_rows=200000000), 'mmoe_taobao_4task_d64_200m.config')
+  write(mmoe_taobao(n_tasks=4, embedding_dim=64, batch_size=8192, item_rows=25000000), 'mmoe_taobao_4task_d64_25m.config')
   write(mmoe_taobao(batch_size=128, scale=0.01), 'mmoe_taobao_small.config')
   write(din_backbone_taobao(), 'din_backbone_taobao.config')
   write(din_backbone_taobao(batch_size=128, scale=0.01, seq_len=12), 'din_backbone_taobao_small.config')
