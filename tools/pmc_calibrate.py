@@ -28,3 +28,14 @@ for _ in range(5):
   be.adam_decay_sweep(var, m, v, bitmap, rows, dim, hyper)
 torch.cuda.synchronize()
 print('copy bytes each way', n * 4, 'sweep bytes each way', rows * dim * 4 * 3)
+
+# random 64-byte rows (the embedding kernels' access pattern): er_gather_rows of `g_rows` DISTINCT rows of a table far
+# larger than the Infinity Cache (4 M x 16 floats = 256 MB per table; three tables cycled so nothing is resident)
+g_rows = 1 << 20
+tables = [torch.randn(rows, dim, device=dev) for _ in range(3)]
+perm = torch.randperm(rows, device=dev)[:g_rows].to(torch.int32)
+out = torch.empty(g_rows, dim, device=dev)
+for i in range(6):
+  be.gather_rows(tables[i % 3], perm, g_rows, 0, out)
+torch.cuda.synchronize()
+print('gather rows', g_rows, 'bytes read', g_rows * dim * 4, 'written', g_rows * dim * 4)
