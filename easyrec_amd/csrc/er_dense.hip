@@ -132,6 +132,7 @@ bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ bias, con
 // matters is workgroups in flight - measured on one box, whole DeepFM step: 64 rows 0.591 ms, 32 0.562, 16 0.553,
 // 8 0.569, 4 0.605 (the redundant partial merges start to cost).
 constexpr int kApplyRows = 16;
+inline int apply_tiles_per_block(int B) { return B > 32768 ? 16 : 1; }
 
 // Tall activations (DIN's attention MLP: B x L = 204,800 rows -> 3,200 row-tile partials per column): the fused
 // finalize + apply kernels below re-merge ALL partials in every 16-row workgroup (cheap for the 64 partials of a
@@ -196,7 +197,7 @@ bn_finalize_apply_kernel(const float* __restrict__ partial, const float* __restr
                          const float* __restrict__ gamma, const float* __restrict__ beta, int B, int N, int chunks,
                          float eps, float momentum, float* __restrict__ moving_mean, float* __restrict__ moving_var,
                          int act, float* __restrict__ y, float* __restrict__ save_mean,
-                         float* __restrict__ save_invstd) {
+                         float* __restrict__ save_invstd, int tiles_per_block) {
   __shared__ Welford sm[kRowLanes][kColsPerBlock];
   __shared__ float s_mean[kColsPerBlock], s_inv[kColsPerBlock];
   const int cl = threadIdx.x % kColsPerBlock;
@@ -245,22 +246,27 @@ bn_finalize_apply_kernel(const float* __restrict__ partial, const float* __restr
   const float mu = s_mean[cl], is = s_inv[cl];
   const float bv = bias ? bias[c] : 0.f;
   const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
-  const int r0 = blockIdx.y * kApplyRows + rl;
-  // fixed trip count, fully unrolled: all the tile's loads of a lane are in flight together
-  float xv[kApplyRows / kRowLanes];
+  // tiles_per_block row tiles per workgroup (1 for batch-sized layers; tall activations - DIN's B x L rows - amortise
+  // the partial merge above over 16 tiles)
+  for (int tile = 0; tile < tiles_per_block; ++tile) {
+    const int r0 = (blockIdx.y * tiles_per_block + tile) * kApplyRows + rl;
+    if (r0 - rl >= B) break;
+    // fixed trip count, fully unrolled: all the tile's loads of a lane are in flight together
+    float xv[kApplyRows / kRowLanes];
 #pragma unroll
-  for (int k = 0; k < kApplyRows / kRowLanes; ++k) {
-    const int r = r0 + k * kRowLanes;
-    xv[k] = (r < B) ? x[static_cast<int64_t>(r) * N + c] : 0.f;
-  }
+    for (int k = 0; k < kApplyRows / kRowLanes; ++k) {
+      const int r = r0 + k * kRowLanes;
+      xv[k] = (r < B) ? x[static_cast<int64_t>(r) * N + c] : 0.f;
+    }
 #pragma unroll
-  for (int k = 0; k < kApplyRows / kRowLanes; ++k) {
-    const int r = r0 + k * kRowLanes;
-    if (r < B) {
-      float v = ((xv[k] + bv) - mu) * is;
-      v = v * ga + be;
-      if (act == ER_ACT_RELU) v = v > 0.f ? v : 0.f;
-      y[static_cast<int64_t>(r) * N + c] = v;
+    for (int k = 0; k < kApplyRows / kRowLanes; ++k) {
+      const int r = r0 + k * kRowLanes;
+      if (r < B) {
+        float v = ((xv[k] + bv) - mu) * is;
+        v = v * ga + be;
+        if (act == ER_ACT_RELU) v = v > 0.f ? v : 0.f;
+        y[static_cast<int64_t>(r) * N + c] = v;
+      }
     }
   }
 }
@@ -310,7 +316,7 @@ bn_bwd_finalize_apply_kernel(const float* __restrict__ partial, const float* __r
                              const float* __restrict__ invstd, const float* __restrict__ dy, int B, int N,
                              int chunks, int use_bn, int act, int accumulate, float* __restrict__ dx,
                              float* __restrict__ dbias, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                             int dy_ld) {
+                             int dy_ld, int tiles_per_block) {
   __shared__ float sm[2][kRowLanes][kColsPerBlock];
   __shared__ float s_g[kColsPerBlock], s_gx[kColsPerBlock];
   const int cl = threadIdx.x % kColsPerBlock;
@@ -350,29 +356,32 @@ bn_bwd_finalize_apply_kernel(const float* __restrict__ partial, const float* __r
   const float mu = use_bn ? mean[c] : 0.f, is = use_bn ? invstd[c] : 0.f;
   const float ga = gamma ? gamma[c] : 1.f;
   const float invB = 1.f / static_cast<float>(B);
-  const int r0 = blockIdx.y * kApplyRows + rl;
   constexpr int kIter = kApplyRows / kRowLanes;
-  float gv[kIter], yv[kIter], xv[kIter];
+  for (int tile = 0; tile < tiles_per_block; ++tile) {
+    const int r0 = (blockIdx.y * tiles_per_block + tile) * kApplyRows + rl;
+    if (r0 - rl >= B) break;
+    float gv[kIter], yv[kIter], xv[kIter];
 #pragma unroll
-  for (int k = 0; k < kIter; ++k) {
-    const int r = r0 + k * kRowLanes;
-    const int64_t i = static_cast<int64_t>(r) * N + c;
-    const bool ok = r < B;
-    gv[k] = ok ? dy[static_cast<int64_t>(r) * dy_ld + c] : 0.f;
-    yv[k] = (ok && act == ER_ACT_RELU) ? y[i] : 1.f;
-    xv[k] = (ok && use_bn) ? x[i] : 0.f;
-  }
+    for (int k = 0; k < kIter; ++k) {
+      const int r = r0 + k * kRowLanes;
+      const int64_t i = static_cast<int64_t>(r) * N + c;
+      const bool ok = r < B;
+      gv[k] = ok ? dy[static_cast<int64_t>(r) * dy_ld + c] : 0.f;
+      yv[k] = (ok && act == ER_ACT_RELU) ? y[i] : 1.f;
+      xv[k] = (ok && use_bn) ? x[i] : 0.f;
+    }
 #pragma unroll
-  for (int k = 0; k < kIter; ++k) {
-    const int r = r0 + k * kRowLanes;
-    if (r < B) {
-      float g = gv[k];
-      if (act == ER_ACT_RELU && !(yv[k] > 0.f)) g = 0.f;
-      if (use_bn) {
-        const float xh = (xv[k] + bv - mu) * is;
-        g = ga * is * (g - sg * invB - xh * (sgx * invB));
+    for (int k = 0; k < kIter; ++k) {
+      const int r = r0 + k * kRowLanes;
+      if (r < B) {
+        float g = gv[k];
+        if (act == ER_ACT_RELU && !(yv[k] > 0.f)) g = 0.f;
+        if (use_bn) {
+          const float xh = (xv[k] + bv - mu) * is;
+          g = ga * is * (g - sg * invB - xh * (sgx * invB));
+        }
+        dx[static_cast<int64_t>(r) * N + c] = g;
       }
-      dx[static_cast<int64_t>(r) * N + c] = g;
     }
   }
 }
@@ -851,10 +860,11 @@ int er_bn_apply_from_stats(const float* x, const float* bias, const float* col_s
     col_stats = merged;
     chunks = slices;
   }
+  const int tpb = er::apply_tiles_per_block(B);
   dim3 grid(static_cast<unsigned>(er::ceil_div(N, er::kColsPerBlock)),
-            static_cast<unsigned>(er::ceil_div(B, er::kApplyRows)));
+            static_cast<unsigned>(er::ceil_div(B, er::kApplyRows * tpb)));
   hipLaunchKernelGGL(er::bn_finalize_apply_kernel, grid, dim3(er::kBlock), 0, er::as_stream(stream), col_stats, x, bias,
-                     gamma, beta, B, N, chunks, eps, momentum, moving_mean, moving_var, act, y, save_mean, save_invstd);
+                     gamma, beta, B, N, chunks, eps, momentum, moving_mean, moving_var, act, y, save_mean, save_invstd, tpb);
   ER_LAUNCH_CHECK();
   return 0;
 }
@@ -904,10 +914,11 @@ int er_bn_act_bwd_ld(const float* x, const float* bias, const float* gamma, cons
   int n_partial = chunks;
   std::unique_lock<std::mutex> merge_lock(er::g_merge_mu, std::defer_lock);
   if (int rc = merge_bwd_partials(&partial, &n_partial, N, s, &merge_lock)) return rc;
+  const int tpb = er::apply_tiles_per_block(B);
   dim3 grid2(static_cast<unsigned>(er::ceil_div(N, er::kColsPerBlock)),
-             static_cast<unsigned>(er::ceil_div(B, er::kApplyRows)));
+             static_cast<unsigned>(er::ceil_div(B, er::kApplyRows * tpb)));
   hipLaunchKernelGGL(er::bn_bwd_finalize_apply_kernel, grid2, dim3(er::kBlock), 0, s, partial, x, bias, gamma, y,
-                     save_mean, save_invstd, dy, B, N, n_partial, use_bn, act, accumulate, dx, dbias, dgamma, dbeta, dy_ld);
+                     save_mean, save_invstd, dy, B, N, n_partial, use_bn, act, accumulate, dx, dbias, dgamma, dbeta, dy_ld, tpb);
   ER_LAUNCH_CHECK();
   return 0;
 }
@@ -919,10 +930,11 @@ int er_bn_act_bwd_from_partials(const float* x, const float* bias, const float* 
   ER_REQUIRE(x && y && dy && dx && partial && B > 0 && N > 0 && chunks > 0, "er_bn_act_bwd_from_partials: bad arguments");
   std::unique_lock<std::mutex> merge_lock(er::g_merge_mu, std::defer_lock);
   if (int rc = merge_bwd_partials(&partial, &chunks, N, er::as_stream(stream), &merge_lock)) return rc;
+  const int tpb = er::apply_tiles_per_block(B);
   dim3 grid2(static_cast<unsigned>(er::ceil_div(N, er::kColsPerBlock)),
-             static_cast<unsigned>(er::ceil_div(B, er::kApplyRows)));
+             static_cast<unsigned>(er::ceil_div(B, er::kApplyRows * tpb)));
   hipLaunchKernelGGL(er::bn_bwd_finalize_apply_kernel, grid2, dim3(er::kBlock), 0, er::as_stream(stream), partial, x, bias,
-                     gamma, y, save_mean, save_invstd, dy, B, N, chunks, use_bn, act, accumulate, dx, dbias, dgamma, dbeta, N);
+                     gamma, y, save_mean, save_invstd, dy, B, N, chunks, use_bn, act, accumulate, dx, dbias, dgamma, dbeta, N, tpb);
   ER_LAUNCH_CHECK();
   return 0;
 }
