@@ -200,9 +200,8 @@ def time_embedding_stage(est, alg_bytes, reps=20):
   eng = est.engine
   kind, hyper = est.opt_emb.kind, est.hyper[0]
   ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
-  f0, f1, b0, b1, w0, w1 = ev(), ev(), ev(), ev(), ev(), ev()
-  fwd = bwd = win = 0.0
-  windows = getattr(eng, 'flush_windows', 0) if getattr(eng, 'lazy_decay', False) else 0
+  f0, f1, b0, b1 = ev(), ev(), ev(), ev()
+  fwd = bwd = 0.0
   for i in range(reps + 3):
     est.features.version += 1
     f0.record()
@@ -210,30 +209,18 @@ def time_embedding_stage(est, alg_bytes, reps=20):
     f1.record()
     for g in eng.groups.values():
       g['got_grad'] = True  # keep last step's upstream gradients
-    saved, eng.flush_windows = getattr(eng, 'flush_windows', 0), 0  # the rolling flush is timed on its own below
+    saved, eng.flush_windows = getattr(eng, 'flush_windows', 0), 0  # (without the rolling flush: its kernel is in the kernel stats)
     b0.record()
     eng.backward_update(kind, hyper)
     b1.record()
     eng.flush_windows = saved
-    w0.record()
-    if windows:
-      eng._roll_flush(hyper)
-    w1.record()
     torch.cuda.synchronize()
     if i >= 3:
       fwd += f0.elapsed_time(f1)
       bwd += b0.elapsed_time(b1)
-      win += w0.elapsed_time(w1)
-  fwd, bwd, win = fwd / reps, bwd / reps, win / reps
+  fwd, bwd = fwd / reps, bwd / reps
   gbps = alg_bytes / ((fwd + bwd) * 1e-3) / 1e9
-  out_win = {}
-  if windows:
-    # the rolling flush of TF-exact Adam's pending decay: 1 / windows of every table group's var, m, v read and written
-    wbytes = 2.0 * sum(st['total_rows'] * dim * 4 * 3 for dim, st in eng.storage.items()) / windows
-    out_win = {'window_flush_ms': win, 'window_flush_bytes': wbytes, 'window_flush_GBps': wbytes / (win * 1e-3) / 1e9,
-               'window_flush_note': 'er_emb_flush_window, 1/%d of the tables per step (streamed; VALU-bound: DESIGN.md 3.1); '
-                                    'not part of stage_GBps' % windows}
-  return {**out_win, 'stage_forward_ms': fwd, 'stage_backward_ms': bwd, 'stage_GBps': gbps, 'stage_frac_of_hbm_peak': gbps / HBM_PEAK_GBS,
+  return {'stage_forward_ms': fwd, 'stage_backward_ms': bwd, 'stage_GBps': gbps, 'stage_frac_of_hbm_peak': gbps / HBM_PEAK_GBS,
           'stage_note': 'eager launches timed with HIP events (launch gaps included): sort + catch-up + lookup | '
                         'segmented reduction + row update; latency-bound at these sizes (SURVEY.md 8d)'}
 

@@ -242,7 +242,10 @@ __device__ __forceinline__ void tile_column_barrier(unsigned* c, unsigned n) {
   __syncthreads();
   if (threadIdx.x == 0) {
     __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n) __builtin_amdgcn_s_sleep(1);
+    // (bounded: ~50 ms.  The host only launches a co-resident grid; should that ever not hold, the launch produces wrong
+    // statistics - which the tests catch - instead of hanging the device)
+    for (unsigned spins = 0; __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n && spins < (1u << 21); ++spins)
+      __builtin_amdgcn_s_sleep(1);
     const unsigned gone = __hip_atomic_fetch_add(c + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (gone == n - 1) {  // everyone has left the spin: zero the words for the next launch
       __hip_atomic_store(c + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
