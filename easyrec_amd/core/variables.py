@@ -47,6 +47,16 @@ def truncated_normal(shape, rng, mean=0.0, stddev=1.0):
   return (out * stddev + mean).astype(np.float32)
 
 
+def he_normal(shape, rng):
+  """tf.initializers.he_normal = VarianceScaling(2.0, 'fan_in', 'truncated_normal'): stddev sqrt(2 / fan_in) with the
+  correction 0.8796 for the truncation at 2 sigma; fan_in of an [.., a, b] kernel = a * prod(leading dims)."""
+  if len(shape) == 1:
+    fan_in = shape[0]
+  else:
+    fan_in = shape[-2] * int(np.prod(shape[:-2])) if len(shape) > 2 else shape[-2]
+  return truncated_normal(shape, rng, 0.0, math.sqrt(2.0 / fan_in) / 0.87962566103423978)
+
+
 def zeros(shape, rng=None):
   return np.zeros(shape, dtype=np.float32)
 
@@ -58,6 +68,7 @@ def ones(shape, rng=None):
 INITIALIZERS = {
     'glorot_uniform': glorot_uniform,
     'he_uniform': he_uniform,
+    'he_normal': he_normal,
     'zeros': zeros,
     'ones': ones,
     'truncated_normal': lambda shape, rng: truncated_normal(shape, rng, 0.0, 0.05),

@@ -549,6 +549,100 @@ concat_cols_kernel(ConcatArgs a) {
   a.out[b * a.out_ld + c] = a.src[p][b * a.ld[p] + (c - a.col0[p])];
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// K9b: CIN, the compressed interaction network of xDeepFM (reference layers/keras/interaction.py:370-409):
+//   x_{k+1}[b, n, d] = relu( sum_{h, m} W_k[n, h, m] * x_k[b, h, d] * x_0[b, m, d] + bias_k[n] ),
+//   output = concat_k sum_d x_{k+1}[b, :, d].
+// The reference materialises [B, H_k+1, H_k, H_0, D] (tile + multiply + two reduce_sums).  Here the outer product
+// z[(b, d), (h, m)] = x_k[b, h, d] * x_0[b, m, d] is written once, k-contiguous, and the contraction over (h, m) is an
+// MFMA GEMM (er_gemm_f32 NT against W_k viewed as [H_k+1, H_k * H_0]) whose output rows are (b, d): the layers after
+// the first keep x_k as [B, D, H_k] (h innermost), which is exactly that output - no transposes.  x_0 is [B, H_0, D].
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+cin_outer_fwd_kernel(const float* __restrict__ xi, int64_t xi_sb, int xi_sh, int xi_sd, int H,
+                     const float* __restrict__ x0, int H0, int D, int64_t rows, float* __restrict__ z) {
+  // one thread per element of z: row = b * D + d, col = h * H0 + m
+  const int64_t K = static_cast<int64_t>(H) * H0;
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i >= rows * K) return;
+  const int64_t row = i / K;
+  const int col = static_cast<int>(i - row * K);
+  const int64_t b = row / D;
+  const int d = static_cast<int>(row - b * D);
+  const int h = col / H0, m = col - h * H0;
+  z[i] = xi[b * xi_sb + static_cast<int64_t>(h) * xi_sh + static_cast<int64_t>(d) * xi_sd] *
+         x0[(b * H0 + m) * D + d];
+}
+
+// fm = relu(c + bias) in place ([B * D, N]); pooled[b, col0 + n] = sum_d fm[(b, d), n] (d ascending)
+__global__ void __launch_bounds__(kBlock)
+cin_act_pool_fwd_kernel(float* __restrict__ c, const float* __restrict__ bias, int64_t B, int D, int N,
+                        float* __restrict__ pooled, int pooled_ld, int col0) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i >= B * N) return;
+  const int64_t b = i / N;
+  const int n = static_cast<int>(i - b * N);
+  const float bv = bias[n];
+  float s = 0.f;
+  for (int d = 0; d < D; ++d) {
+    float* p = c + (b * D + d) * N + n;
+    float v = *p + bv;
+    v = v > 0.f ? v : 0.f;
+    *p = v;
+    s = s + v;
+  }
+  pooled[b * pooled_ld + col0 + n] = s;
+}
+
+// dc[(b, d), n] = (dpooled[b, col0 + n] + dnext[(b, d), n]) * (fm > 0)      (dnext may be nullptr; dc may alias dnext)
+__global__ void __launch_bounds__(kBlock)
+cin_act_pool_bwd_kernel(const float* __restrict__ fm, const float* __restrict__ dpooled, int dpooled_ld, int col0,
+                        const float* dnext, int64_t B, int D, int N, float* dc) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i >= B * D * N) return;
+  const int64_t row = i / N;
+  const int n = static_cast<int>(i - row * N);
+  const int64_t b = row / D;
+  float g = dpooled[b * dpooled_ld + col0 + n];
+  if (dnext) g = g + dnext[i];
+  dc[i] = fm[i] > 0.f ? g : 0.f;
+}
+
+// One workgroup per row (b, d) of dz [rows, H * H0]:
+//   dxi[b, h, d]  = sum_m dz[row, h * H0 + m] * x0[b, m, d]       (m ascending; written, or added when add_xi)
+//   dx0[b, m, d] += sum_h dz[row, h * H0 + m] * xi[b, h, d]       (h ascending)
+// The first layer has xi == x0: both terms land in dx0 (dxi == dx0, add_xi set).
+__global__ void __launch_bounds__(kBlock)
+cin_outer_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ xi, int64_t xi_sb, int xi_sh, int xi_sd,
+                     int H, const float* __restrict__ x0, int H0, int D, float* dxi, int add_xi, float* dx0) {
+  extern __shared__ float sh[];  // [H] xi column, [H0] x0 column
+  float* s_xi = sh;
+  float* s_x0 = sh + H;
+  const int64_t row = blockIdx.x;
+  const int64_t b = row / D;
+  const int d = static_cast<int>(row - b * D);
+  for (int h = threadIdx.x; h < H; h += kBlock) s_xi[h] = xi[b * xi_sb + static_cast<int64_t>(h) * xi_sh + static_cast<int64_t>(d) * xi_sd];
+  for (int m = threadIdx.x; m < H0; m += kBlock) s_x0[m] = x0[(b * H0 + m) * D + d];
+  __syncthreads();
+  const float* r = dz + row * (static_cast<int64_t>(H) * H0);
+  // the x0 term first (it reads dx0 += ...), then the xi term: when dxi aliases dx0 both updates of one element are
+  // made by different threads at different times - keep them in two phases separated by a barrier
+  for (int m = threadIdx.x; m < H0; m += kBlock) {
+    float s = 0.f;
+    for (int h = 0; h < H; ++h) s = s + r[h * H0 + m] * s_xi[h];
+    float* o = dx0 + (b * H0 + m) * D + d;
+    *o = *o + s;
+  }
+  __syncthreads();
+  for (int h = threadIdx.x; h < H; h += kBlock) {
+    float s = 0.f;
+    for (int m = 0; m < H0; ++m) s = s + r[h * H0 + m] * s_x0[m];
+    float* o = dxi + b * xi_sb + static_cast<int64_t>(h) * xi_sh + static_cast<int64_t>(d) * xi_sd;
+    *o = add_xi ? *o + s : s;
+  }
+}
+
 }  // namespace er
 
 extern "C" {
@@ -755,6 +849,47 @@ int er_dot_interaction_bwd(const float* x, const float* g, int32_t B, int32_t F,
   ER_REQUIRE(lds <= 60 * 1024, "er_dot_interaction_bwd: %zu bytes exceed the LDS budget", lds);
   hipLaunchKernelGGL(er::dot_interaction_bwd_kernel, dim3(B), dim3(er::kBlock), lds, er::as_stream(stream), x, g, F, D,
                      x_stride, offset, P, g_stride, dx, dx_stride, accumulate);
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
+int er_cin_outer_fwd(const float* xi, int64_t xi_stride_b, int32_t xi_stride_h, int32_t xi_stride_d, int32_t H,
+                     const float* x0, int32_t H0, int32_t D, int64_t B, float* z, er_stream_t stream) {
+  ER_REQUIRE(xi && x0 && z && B > 0 && H > 0 && H0 > 0 && D > 0, "er_cin_outer_fwd: bad arguments");
+  const int64_t n = B * D * H * H0;
+  hipLaunchKernelGGL(er::cin_outer_fwd_kernel, dim3(er::blocks_for(n)), dim3(er::kBlock), 0, er::as_stream(stream), xi,
+                     xi_stride_b, xi_stride_h, xi_stride_d, H, x0, H0, D, B * D, z);
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
+int er_cin_act_pool_fwd(float* c, const float* bias, int64_t B, int32_t D, int32_t N, float* pooled, int32_t pooled_ld,
+                        int32_t col0, er_stream_t stream) {
+  ER_REQUIRE(c && bias && pooled && B > 0 && D > 0 && N > 0 && pooled_ld >= col0 + N, "er_cin_act_pool_fwd: bad arguments");
+  hipLaunchKernelGGL(er::cin_act_pool_fwd_kernel, dim3(er::blocks_for(B * N)), dim3(er::kBlock), 0, er::as_stream(stream),
+                     c, bias, B, D, N, pooled, pooled_ld, col0);
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
+int er_cin_act_pool_bwd(const float* fm, const float* dpooled, int32_t dpooled_ld, int32_t col0, const float* dnext,
+                        int64_t B, int32_t D, int32_t N, float* dc, er_stream_t stream) {
+  ER_REQUIRE(fm && dpooled && dc && B > 0 && D > 0 && N > 0 && dpooled_ld >= col0 + N, "er_cin_act_pool_bwd: bad arguments");
+  hipLaunchKernelGGL(er::cin_act_pool_bwd_kernel, dim3(er::blocks_for(B * D * N)), dim3(er::kBlock), 0,
+                     er::as_stream(stream), fm, dpooled, dpooled_ld, col0, dnext, B, D, N, dc);
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
+int er_cin_outer_bwd(const float* dz, const float* xi, int64_t xi_stride_b, int32_t xi_stride_h, int32_t xi_stride_d,
+                     int32_t H, const float* x0, int32_t H0, int32_t D, int64_t B, float* dxi, int add_xi, float* dx0,
+                     er_stream_t stream) {
+  ER_REQUIRE(dz && xi && x0 && dxi && dx0 && B > 0 && H > 0 && H0 > 0 && D > 0, "er_cin_outer_bwd: bad arguments");
+  ER_REQUIRE(B * D < 0x7FFFFFFFLL && (H + H0) * 4 <= 48 * 1024, "er_cin_outer_bwd: too many rows / features");
+  ER_REQUIRE(dxi != dx0 || add_xi, "er_cin_outer_bwd: dxi aliasing dx0 must add");
+  hipLaunchKernelGGL(er::cin_outer_bwd_kernel, dim3(static_cast<unsigned>(B * D)), dim3(er::kBlock),
+                     static_cast<size_t>(H + H0) * sizeof(float), er::as_stream(stream), dz, xi, xi_stride_b, xi_stride_h,
+                     xi_stride_d, H, x0, H0, D, dxi, add_xi, dx0);
   ER_LAUNCH_CHECK();
   return 0;
 }

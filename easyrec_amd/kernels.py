@@ -1022,6 +1022,38 @@ class HipBackend(object):
                                  ctypes.c_float(scale), _p(dscores), _p(dhist), 0, _stream()), 'er_din_pool_bwd')
     return dscores, dhist
 
+  # -- K9b CIN (xDeepFM)
+  def cin_outer_fwd(self, xi, strides, H, x0, z):
+    """z[(b, d), h * H0 + m] = xi[b, h, d] * x0[b, m, d]; xi addressed by strides = (stride_b, stride_h, stride_d)."""
+    B, H0, D = x0.shape
+    assert z.shape == (B * D, H * H0) and z.is_contiguous() and x0.is_contiguous()
+    self._ck(self.lib.er_cin_outer_fwd(_p(xi), ctypes.c_int64(strides[0]), ctypes.c_int32(strides[1]),
+                                       ctypes.c_int32(strides[2]), ctypes.c_int32(H), _p(x0), ctypes.c_int32(H0),
+                                       ctypes.c_int32(D), ctypes.c_int64(B), _p(z), _stream()), 'er_cin_outer_fwd')
+
+  def cin_act_pool_fwd(self, c, bias, B, D, pooled, col0):
+    """c [B * D, N] <- relu(c + bias) in place; pooled[:, col0 : col0 + N] = its sum over d."""
+    N = c.shape[1]
+    assert c.is_contiguous() and pooled.stride(1) == 1
+    self._ck(self.lib.er_cin_act_pool_fwd(_p(c), _p(bias), ctypes.c_int64(B), ctypes.c_int32(D), ctypes.c_int32(N),
+                                          _p(pooled), ctypes.c_int32(pooled.stride(0)), ctypes.c_int32(col0), _stream()),
+             'er_cin_act_pool_fwd')
+
+  def cin_act_pool_bwd(self, fm, dpooled, col0, dnext, B, D, dc):
+    N = fm.shape[1]
+    assert fm.is_contiguous() and dc.is_contiguous() and dpooled.stride(1) == 1 and (dnext is None or dnext.is_contiguous())
+    self._ck(self.lib.er_cin_act_pool_bwd(_p(fm), _p(dpooled), ctypes.c_int32(dpooled.stride(0)), ctypes.c_int32(col0),
+                                          _p(dnext), ctypes.c_int64(B), ctypes.c_int32(D), ctypes.c_int32(N), _p(dc),
+                                          _stream()), 'er_cin_act_pool_bwd')
+
+  def cin_outer_bwd(self, dz, xi, strides, H, x0, dxi, add_xi, dx0):
+    B, H0, D = x0.shape
+    assert dz.shape == (B * D, H * H0) and dz.is_contiguous() and dx0.is_contiguous()
+    self._ck(self.lib.er_cin_outer_bwd(_p(dz), _p(xi), ctypes.c_int64(strides[0]), ctypes.c_int32(strides[1]),
+                                       ctypes.c_int32(strides[2]), ctypes.c_int32(H), _p(x0), ctypes.c_int32(H0),
+                                       ctypes.c_int32(D), ctypes.c_int64(B), _p(dxi), int(bool(add_xi)), _p(dx0),
+                                       _stream()), 'er_cin_outer_bwd')
+
   # -- K9 MLP pieces
   def bn_act_fwd(self, x, bias, gamma, beta, use_bn, eps, momentum, moving_mean, moving_var, act):
     B, N = x.shape
@@ -1632,6 +1664,70 @@ class CrossV2EpilogueFn(torch.autograd.Function):
       ctx.bias_grad.add_(dbias)
       dbias = None
     return dx0, dx, du, dbias, None, None
+
+
+class CINFn(torch.autograd.Function):
+  """xDeepFM's compressed interaction network, all layers (reference layers/keras/interaction.py:370-409).
+  x0 [B, H0, D]; kernels[k] [H_k+1, H_k, H0], biases[k] [H_k+1]; returns [B, sum_k H_k+1].  The parameter gradients are
+  accumulated into kernel_grads / bias_grads (the flat gradient buffer's views)."""
+
+  @staticmethod
+  def forward(ctx, x0, n_layers, *params):
+    be = hip()
+    kernels, biases = params[:n_layers], params[n_layers:2 * n_layers]
+    ctx.kernel_grads, ctx.bias_grads = params[2 * n_layers:3 * n_layers], params[3 * n_layers:4 * n_layers]
+    x0 = x0.contiguous()
+    B, H0, D = x0.shape
+    sizes = [int(w.shape[0]) for w in kernels]
+    out = torch.empty(B, sum(sizes), dtype=torch.float32, device=x0.device)
+    xi, strides, H = x0, (H0 * D, D, 1), H0
+    zs, fms = [], []
+    col = 0
+    for w, b in zip(kernels, biases):
+      N = int(w.shape[0])
+      assert w.shape == (N, H, H0), 'cin kernel %s for a [%d x %d] interaction' % (tuple(w.shape), H, H0)
+      z = torch.empty(B * D, H * H0, dtype=torch.float32, device=x0.device)
+      be.cin_outer_fwd(xi, strides, H, x0, z)
+      fm = be.gemm(GEMM_NT, z, w.detach().reshape(N, H * H0))  # [B * D, N] = x_{k+1} as [B, D, N]
+      be.cin_act_pool_fwd(fm, b.detach(), B, D, out, col)
+      zs.append(z)
+      fms.append(fm)
+      xi, strides, H = fm, (D * N, 1, N), N
+      col += N
+    ctx.save_for_backward(x0, *kernels, *zs, *fms)
+    ctx.n_layers, ctx.sizes = n_layers, sizes
+    return out
+
+  @staticmethod
+  def backward(ctx, dout):
+    be = hip()
+    n = ctx.n_layers
+    saved = ctx.saved_tensors
+    x0, kernels, zs, fms = saved[0], saved[1:1 + n], saved[1 + n:1 + 2 * n], saved[1 + 2 * n:1 + 3 * n]
+    B, H0, D = x0.shape
+    dout = dout.contiguous()
+    dx0 = torch.zeros_like(x0)
+    cols = [sum(ctx.sizes[:k]) for k in range(n)]
+    dnext = None  # gradient of x_{k+1} from the layer above ([B * D, N])
+    for k in reversed(range(n)):
+      w, z, fm = kernels[k].detach(), zs[k], fms[k]
+      N = ctx.sizes[k]
+      H = H0 if k == 0 else ctx.sizes[k - 1]
+      dc = torch.empty_like(fm)
+      be.cin_act_pool_bwd(fm, dout, cols[k], dnext, B, D, dc)
+      if ctx.bias_grads[k] is not None:
+        be.colsum(dc, out=ctx.bias_grads[k], accumulate=True)
+      be.gemm(GEMM_TN, dc, z, out=ctx.kernel_grads[k].view(N, H * H0), accumulate=True)  # dW = dc^T . z
+      dz = be.gemm(GEMM_NN, dc, w.reshape(N, H * H0))
+      if k == 0:
+        be.cin_outer_bwd(dz, x0, (H0 * D, D, 1), H, x0, dx0, True, dx0)
+        dnext = None
+      else:
+        prev = fms[k - 1]
+        dprev = torch.empty_like(prev)
+        be.cin_outer_bwd(dz, prev, (D * H, 1, H), H, x0, dprev, False, dx0)
+        dnext = dprev
+    return (dx0, None) + (None,) * (4 * n)
 
 
 class DINConcatFn(torch.autograd.Function):

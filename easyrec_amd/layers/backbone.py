@@ -36,6 +36,19 @@ class _TFShim(object):
     return torch.stack(list(values), dim=axis)
 
   @staticmethod
+  def add_n(values):
+    """tf.add_n; a list of [B, 1] columns (xDeepFM's wide block: `lambda x: tf.add_n(x)` over width-1 embeddings) is one
+    library concat + row sum instead of a chain of adds."""
+    values = list(values)
+    if len(values) > 1 and all(v.dim() == 2 and v.shape[1] == 1 and v.dtype == torch.float32 for v in values):
+      from easyrec_amd import kernels
+      return kernels.RowSumFn.apply(kernels.concat_cols(values))
+    out = values[0]
+    for v in values[1:]:
+      out = out + v
+    return out
+
+  @staticmethod
   def reduce_sum(x, axis=None, keepdims=False):
     return x.sum() if axis is None else x.sum(dim=axis, keepdim=keepdims)
 

@@ -5,6 +5,11 @@ Cross (:131-308) DCN-v2: x_{l+1} = x0 * (W x_l + b + diag_scale * x_l) + x_l; W 
                  U (d x r) V (r x d); kernel init truncated_normal (keras: stddev 0.05), bias zeros.
                  W x_l is an MFMA GEMM (er_gemm, fp32 or bf16); bias, diag term, Hadamard product and residual
                  are ONE fused epilogue kernel (er_cross_v2_epilogue) instead of BiasAdd/Mul/Mul/Add.
+CIN   (:311-409) xDeepFM's compressed interaction network over a [B, H0, D] stack of field embeddings: per layer
+                 x_{k+1}[b,n,d] = relu(sum_{h,m} W[n,h,m] x_k[b,h,d] x_0[b,m,d] + bias[n]); output = the feature maps
+                 summed over d, concatenated over the layers.  Kernels `cin_kernel_<k>` [H_k+1, H_k, H0] he_normal,
+                 `cin_bias_<k>` zeros.  The outer product is written once and contracted on the matrix cores
+                 (kernels.CINFn: er_cin_outer_fwd + er_gemm_f32 + er_cin_act_pool_fwd per layer).
 """
 import torch
 
@@ -77,3 +82,28 @@ class Cross(object):
       u = self._preactivation(u + bias if bias is not None else u)
       bias = None
     return kernels.CrossV2EpilogueFn.apply(x0, x, u, bias, self._diag_scale, None if bias is None else bias.grad)
+
+
+class CIN(object):
+
+  def __init__(self, params, name='cin', reuse=None, **kwargs):
+    self.name = name
+    self._hidden_feature_sizes = [int(h) for h in params.get_or_default('hidden_feature_sizes', [])]
+    assert len(self._hidden_feature_sizes) > 0, \
+        'parameter hidden_feature_sizes must be a list of int with length greater than 0'
+    assert not params.get_or_default('kernel_regularizer', None) and not params.get_or_default('bias_regularizer', None), \
+        'CIN kernel / bias regularizers are outside the hot-path scope'
+
+  def __call__(self, inputs, **kwargs):
+    if isinstance(inputs, (list, tuple)):  # a feature list: stacked along a new field axis
+      inputs = torch.stack(list(inputs), dim=1)
+    if inputs.dim() != 3:
+      raise ValueError('Unexpected inputs dimensions %d, expect to be 3 dimensions' % inputs.dim())
+    vs = context.varstore()
+    sizes = [int(inputs.shape[1])] + self._hidden_feature_sizes
+    ws, bs = [], []
+    for i in range(len(self._hidden_feature_sizes)):
+      ws.append(vs.get_variable('%s/cin_kernel_%d' % (self.name, i), (sizes[i + 1], sizes[i], sizes[0]), 'he_normal'))
+      bs.append(vs.get_variable('%s/cin_bias_%d' % (self.name, i), (sizes[i + 1],), 'zeros'))
+    n = len(ws)
+    return kernels.CINFn.apply(inputs, n, *ws, *bs, *[w.grad for w in ws], *[b.grad for b in bs])

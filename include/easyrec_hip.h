@@ -339,6 +339,25 @@ int er_cross_v2_epilogue_bwd(const float* x0, const float* x, const float* u, co
                              float* dx0, int accumulate_dx0, float* dx, float* du,
                              er_stream_t stream);
 
+/* ---- K9b: CIN, xDeepFM's compressed interaction network (reference layers/keras/interaction.py:370-409) ----
+ *   x_{k+1}[b, n, d] = relu(sum_{h, m} W_k[n, h, m] * x_k[b, h, d] * x_0[b, m, d] + bias_k[n]);
+ *   output = concat over the layers of sum_d x_{k+1}[b, :, d].
+ * The reference materialises [B, H_k+1, H_k, H_0, D].  Here: er_cin_outer_fwd writes the outer product
+ * z[(b, d), h * H0 + m] = x_k[b, h, d] * x_0[b, m, d] ([B * D, H * H0], k-contiguous); er_gemm_f32(ER_GEMM_NT, z, W_k
+ * viewed as [H_k+1, H * H0]) contracts it into c [B * D, H_k+1]; er_cin_act_pool_fwd turns c into the feature map
+ * relu(c + bias) in place and writes its sum over d into columns [col0, col0 + N) of the layer's output block.  c IS
+ * x_{k+1} in [B, D, H_k+1] layout: x_k is addressed through (stride_b, stride_h, stride_d) - x_0 is [B, H_0, D].
+ * Backward: er_cin_act_pool_bwd -> dc; dW_k = dc^T . z (ER_GEMM_TN), dz = dc . W_k (ER_GEMM_NN); er_cin_outer_bwd:
+ * dx_k[b, h, d] (=|+=) sum_m dz * x_0, dx_0[b, m, d] += sum_h dz * x_k (the first layer has x_k == x_0: dxi == dx0, add). */
+int er_cin_outer_fwd(const float* xi, int64_t xi_stride_b, int32_t xi_stride_h, int32_t xi_stride_d, int32_t H,
+                     const float* x0, int32_t H0, int32_t D, int64_t B, float* z, er_stream_t stream);
+int er_cin_act_pool_fwd(float* c, const float* bias, int64_t B, int32_t D, int32_t N, float* pooled, int32_t pooled_ld,
+                        int32_t col0, er_stream_t stream);
+int er_cin_act_pool_bwd(const float* fm, const float* dpooled, int32_t dpooled_ld, int32_t col0, const float* dnext,
+                        int64_t B, int32_t D, int32_t N, float* dc, er_stream_t stream);
+int er_cin_outer_bwd(const float* dz, const float* xi, int64_t xi_stride_b, int32_t xi_stride_h, int32_t xi_stride_d,
+                     int32_t H, const float* x0, int32_t H0, int32_t D, int64_t B, float* dxi, int add_xi, float* dx0,
+                     er_stream_t stream);
 /* --------------------------------------------------------------------------------------------
  * K8  DIN target attention.  Replaces Tile/ConcatV2 (input of the attention MLP) and
  *     SequenceMask/Select/Softmax/BatchMatMul (pooling) of MultiTowerDIN.din

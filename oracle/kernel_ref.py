@@ -754,6 +754,41 @@ class RefBackend(object):
     dh = probs[:, :, None] * dout[:, None, :]
     return ds, dh
 
+  # -- CIN (xDeepFM): strided views of the operands, plain torch arithmetic
+  @staticmethod
+  def _cin_view(x, strides, B, H, D):
+    return torch.as_strided(x, (B, H, D), strides)
+
+  def cin_outer_fwd(self, xi, strides, H, x0, z):
+    B, H0, D = x0.shape
+    xv = self._cin_view(xi, strides, B, H, D)
+    z.copy_((xv.permute(0, 2, 1)[:, :, :, None] * x0.permute(0, 2, 1)[:, :, None, :]).reshape(B * D, H * H0))
+
+  def cin_act_pool_fwd(self, c, bias, B, D, pooled, col0):
+    N = c.shape[1]
+    c.copy_(torch.relu(c + bias))
+    pooled[:, col0:col0 + N] = c.reshape(B, D, N).sum(dim=1)
+
+  def cin_act_pool_bwd(self, fm, dpooled, col0, dnext, B, D, dc):
+    N = fm.shape[1]
+    g = dpooled[:, col0:col0 + N][:, None, :].expand(B, D, N).reshape(B * D, N)
+    if dnext is not None:
+      g = g + dnext
+    dc.copy_(torch.where(fm > 0, g, torch.zeros_like(g)))
+
+  def cin_outer_bwd(self, dz, xi, strides, H, x0, dxi, add_xi, dx0):
+    B, H0, D = x0.shape
+    xv = self._cin_view(xi, strides, B, H, D).clone()
+    dzv = dz.reshape(B, D, H, H0)
+    d0 = torch.einsum('bdhm,bhd->bmd', dzv, xv)
+    di = torch.einsum('bdhm,bmd->bhd', dzv, x0)
+    dx0.add_(d0)
+    out = self._cin_view(dxi, strides, B, H, D)
+    if add_xi:
+      out.add_(di)
+    else:
+      out.copy_(di)
+
   # -- MLP pieces
   def bn_act_fwd(self, x, bias, gamma, beta, use_bn, eps, momentum, moving_mean, moving_var, act):
     z = x if bias is None else x + bias

@@ -47,6 +47,17 @@ class _TF(object):
   def concat(values, axis=-1):
     return torch.cat(list(values), dim=axis)
 
+  @staticmethod
+  def stack(values, axis=0):
+    return torch.stack(list(values), dim=axis)
+
+  @staticmethod
+  def add_n(values):
+    out = values[0]
+    for v in values[1:]:
+      out = out + v
+    return out
+
 
 tf = _TF
 
@@ -740,6 +751,23 @@ class OracleTrainer(object):
       target, _ = self.input_layer(V, batch, group_name, scope, only=plain_names)
     return torch.cat(seqs, dim=-1), seq_len, target
 
+  def _keras_cin(self, V, x0, hidden_sizes, name):
+    """keras CIN (layers/keras/interaction.py:370-409): per layer the outer product of x_k and x_0 along the field
+    axes, weighted by cin_kernel_k [H_k+1, H_k, H_0] and summed over both, + bias, relu; the feature maps summed over the
+    embedding axis and concatenated."""
+    if isinstance(x0, (list, tuple)):
+      x0 = torch.stack(list(x0), dim=1)
+    xi, pooled = x0, []
+    for k, hk in enumerate(hidden_sizes):
+      w = V.get('%s/cin_kernel_%d' % (name, k))
+      b = V.get('%s/cin_bias_%d' % (name, k))
+      inter = x0[:, None, :, :] * xi[:, :, None, :]                      # [B, H_k, H_0, D]
+      fm = (inter[:, None, :, :, :] * w[None, :, :, :, None]).sum(dim=3).sum(dim=2)  # [B, H_k+1, D]
+      fm = torch.relu(fm + b[None, :, None])
+      pooled.append(fm.sum(dim=-1))
+      xi = fm
+    return torch.cat(pooled, dim=-1)
+
   def _keras_cross(self, V, x0, x, st_params, name):
     """layers/keras/interaction.py:249-286: x0 * (W x + b [+ diag_scale x]) + x; W = U V when projection_dim."""
     proj = int(st_params['projection_dim']) if 'projection_dim' in st_params else None
@@ -804,6 +832,8 @@ class OracleTrainer(object):
           fea = eval(node.input_fn)(fea)
         ins.append(fea)
       x = ins[0] if len(ins) == 1 else torch.cat(ins, dim=-1)
+      if blk.HasField('extra_input_fn'):  # (backbone.py:424-441: applied to the merged input)
+        x = eval(blk.extra_input_fn)(x)
       kind = blk.WhichOneof('layer')
       if kind == 'keras_layer':
         kl = blk.keras_layer
@@ -813,6 +843,8 @@ class OracleTrainer(object):
           x = self._keras_cross(V, x[0], x[1], kl.st_params, blk.name)
         elif kl.class_name == 'DIN':
           x = self._keras_din(V, x[0], x[1], x[2], kl.din, l2)
+        elif kl.class_name == 'CIN':
+          x = self._keras_cin(V, x, [int(h) for h in kl.cin.hidden_feature_sizes], blk.name)
         elif kl.class_name == 'FM':
           fl = torch.stack(list(x), dim=1)  # [B, F, D]
           x = 0.5 * (fl.sum(dim=1) ** 2 - (fl ** 2).sum(dim=1))

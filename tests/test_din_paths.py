@@ -67,7 +67,7 @@ def shorten_sequences(batch, max_len):
 
 
 @pytest.mark.parametrize('config', ['din_backbone_taobao_small.config', 'din_sequence_features_taobao_small.config',
-                                    'deepfm_backbone_criteo_small.config'])
+                                    'deepfm_backbone_criteo_small.config', 'xdeepfm_taobao_small.config'])
 def test_backbone_and_group_level_din_match_the_oracle(ref_backend, config):
   _run(config, 24)
 

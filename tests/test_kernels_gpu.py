@@ -1075,3 +1075,41 @@ def test_gemm_bf16_nt(hip, M, N, K, mode):
   torch.cuda.synchronize()
   err = (out.double() - ref).abs()
   assert bool((err <= 2e-5 * scale + 1e-6).all()), float((err / (scale + 1e-9)).max())
+
+
+@pytest.mark.parametrize('B,H0,D,sizes', [(37, 5, 8, (6, 4)), (128, 17, 16, (64, 64, 64)), (3, 2, 4, (1,))])
+def test_cin_layers_against_einsum(hip, B, H0, D, sizes):
+  """kernels.CINFn (er_cin_outer_fwd + er_gemm_f32 + er_cin_act_pool_fwd per layer, and their backward) against the
+  formula of layers/keras/interaction.py:385-409 written with einsum in fp64."""
+  g = torch.Generator().manual_seed(B * 131 + H0)
+  x0 = torch.randn(B, H0, D, generator=g)
+  hs = [H0] + list(sizes)
+  ws = [torch.randn(hs[k + 1], hs[k], H0, generator=g) * 0.3 for k in range(len(sizes))]
+  bs = [torch.randn(hs[k + 1], generator=g) * 0.1 for k in range(len(sizes))]
+  dout = torch.randn(B, sum(sizes), generator=g)
+  # reference
+  xr = x0.double().requires_grad_(True)
+  wr = [w.double().requires_grad_(True) for w in ws]
+  br = [b.double().requires_grad_(True) for b in bs]
+  xi, pooled = xr, []
+  for w, b in zip(wr, br):
+    fm = torch.relu(torch.einsum('bhd,bmd,nhm->bnd', xi, xr, w) + b[None, :, None])
+    pooled.append(fm.sum(-1))
+    xi = fm
+  ref = torch.cat(pooled, dim=-1)
+  ref.backward(dout.double())
+  # device
+  xd = x0.to(DEV).requires_grad_(True)
+  wd = [w.to(DEV).requires_grad_(True) for w in ws]
+  bd = [b.to(DEV).requires_grad_(True) for b in bs]
+  wg = [torch.zeros_like(w) for w in wd]
+  bg = [torch.zeros_like(b) for b in bd]
+  out = kernels.CINFn.apply(xd, len(sizes), *wd, *bd, *wg, *bg)
+  out.backward(dout.to(DEV))
+  torch.cuda.synchronize()
+  tol = dict(rtol=2e-4, atol=2e-4)
+  assert torch.allclose(out.detach().cpu().double(), ref.detach(), **tol)
+  assert torch.allclose(xd.grad.cpu().double(), xr.grad, **tol)
+  for k in range(len(sizes)):
+    assert torch.allclose(wg[k].cpu().double(), wr[k].grad, **tol), k
+    assert torch.allclose(bg[k].cpu().double(), br[k].grad, **tol), k

@@ -92,6 +92,12 @@ def test_dcn_v2_backbone_matches_oracle(name):
   _first_steps(_cfg(name), 128, 31)
 
 
+def test_xdeepfm_backbone_matches_oracle():
+  """xDeepFM as a backbone (the shape of samples/model_config/xdeepfm_on_taobao_backbone.config): wide feature list
+  summed by `tf.add_n`, CIN over the stacked field embeddings (layers/keras/interaction.py:311-409), MLP, final MLP."""
+  _first_steps(_cfg('xdeepfm_taobao_small.config'), 128, 51)
+
+
 def test_dcn_v2_bf16_dense_tracks_the_fp32_oracle():
   """BASELINE config 3: bf16 MFMA for the dense contractions (operands rounded to bf16, fp32 accumulate),
   fp32 embeddings and master weights.  Against the fp32 oracle the loss must agree to bf16 resolution

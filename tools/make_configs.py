@@ -340,6 +340,43 @@ def din_sequence_features_taobao(**kw):
   ''' % (' '.join("feature_names: '%s'" % n for n in TAOBAO_USER), ' '.join("feature_names: '%s'" % n for n in TAOBAO_ITEM)))
 
 
+def xdeepfm_backbone_taobao(hidden=(64, 64, 64), mlp=(128, 64), final=(32, 1), **kw):
+  """The shape of samples/model_config/xdeepfm_on_taobao_backbone.config: RankModel over a backbone with a wide block
+  (feature list of width-1 embeddings, summed by `tf.add_n`), a CIN block over the stacked field embeddings
+  (`input_slice: '[1]'` + `extra_input_fn: tf.stack(x, axis=1)`), an MLP over the concatenated embeddings, and a final
+  MLP over [wide, cin, dnn]."""
+  cfg = taobao_base('tag', **kw)
+  cfg.model_dir = 'experiments/xdeepfm_taobao_ckpt'
+  cfg.data_config.label_fields.append('clk')
+  feats = TAOBAO_USER + ['tag_category_list', 'tag_brand_list'] + TAOBAO_ITEM
+  names = ' '.join("feature_names: '%s'" % n for n in feats)
+  return _model_text(cfg, '''
+    model_name: 'xDeepFM'  model_class: 'RankModel'
+    feature_groups { group_name: 'features' %s wide_deep: DEEP }
+    feature_groups { group_name: 'wide' %s wide_deep: WIDE }
+    backbone {
+      blocks { name: 'wide' inputs { feature_group_name: 'wide' }
+               input_layer { only_output_feature_list: true wide_output_dim: 1 } }
+      blocks { name: 'features' inputs { feature_group_name: 'features' }
+               input_layer { output_2d_tensor_and_feature_list: true } }
+      blocks { name: 'cin' inputs { block_name: 'features' input_slice: '[1]' }
+               extra_input_fn: 'lambda x: tf.stack(x, axis=1)'
+               keras_layer { class_name: 'CIN' cin { hidden_feature_sizes: %s } } }
+      blocks { name: 'dnn' inputs { block_name: 'features' input_slice: '[0]' }
+               keras_layer { class_name: 'MLP' mlp { hidden_units: %s } } }
+      blocks { name: 'final_logit'
+               inputs { block_name: 'wide' input_fn: 'lambda x: tf.add_n(x)' }
+               inputs { block_name: 'cin' }
+               inputs { block_name: 'dnn' }
+               keras_layer { class_name: 'MLP'
+                             mlp { hidden_units: %s use_final_bn: false final_activation: 'linear' } } }
+      concat_blocks: 'final_logit'
+    }
+    model_params { l2_regularization: 1e-4 }
+    embedding_regularization: 1e-4
+  ''' % (names, names, list(hidden), list(mlp), list(final)))
+
+
 def deepfm_backbone_criteo(**kw):
   """The shape of examples/configs/deepfm_backbone_on_criteo.config: the wide group's width comes from the backbone's
   `input_layer { wide_output_dim }`, wide logit through a config lambda, keras FM + MLP, top_mlp."""
@@ -540,6 +577,9 @@ if __name__ == '__main__':
   write(din_backbone_taobao(batch_size=128, scale=0.01, seq_len=12), 'din_backbone_taobao_small.config')
   write(din_sequence_features_taobao(batch_size=128, scale=0.01, seq_len=12), 'din_sequence_features_taobao_small.config')
   write(deepfm_backbone_criteo(hash_bucket_size=1000, batch_size=256), 'deepfm_backbone_criteo_small.config')
+  write(xdeepfm_backbone_taobao(), 'xdeepfm_taobao.config')
+  write(xdeepfm_backbone_taobao(hidden=(8, 6), mlp=(32, 16), final=(16, 1), batch_size=128, scale=0.01, embedding_dim=8),
+        'xdeepfm_taobao_small.config')
   shared_embedding_variant('dlrm_criteo_small.config', 'dlrm_shared_criteo_small.config')
   shared_embedding_variant('deepfm_criteo_small.config', 'deepfm_shared_criteo_small.config')
   combo_feature_variant('deepfm_criteo_small.config', 'deepfm_combo_criteo_small.config')
