@@ -562,17 +562,16 @@ concat_cols_kernel(ConcatArgs a) {
 __global__ void __launch_bounds__(kBlock)
 cin_outer_fwd_kernel(const float* __restrict__ xi, int64_t xi_sb, int xi_sh, int xi_sd, int H,
                      const float* __restrict__ x0, int H0, int D, int64_t rows, float* __restrict__ z) {
-  // one thread per element of z: row = b * D + d, col = h * H0 + m
-  const int64_t K = static_cast<int64_t>(H) * H0;
-  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
-  if (i >= rows * K) return;
-  const int64_t row = i / K;
-  const int col = static_cast<int>(i - row * K);
+  // workgroup (x, y): row x = b * D + d, columns y * 256 .. of z; col = h * H0 + m  (32-bit index arithmetic only)
+  const int K = H * H0;
+  const int64_t row = blockIdx.x;
+  const int col = blockIdx.y * kBlock + threadIdx.x;
+  if (col >= K) return;
   const int64_t b = row / D;
   const int d = static_cast<int>(row - b * D);
   const int h = col / H0, m = col - h * H0;
-  z[i] = xi[b * xi_sb + static_cast<int64_t>(h) * xi_sh + static_cast<int64_t>(d) * xi_sd] *
-         x0[(b * H0 + m) * D + d];
+  z[row * K + col] = xi[b * xi_sb + static_cast<int64_t>(h) * xi_sh + static_cast<int64_t>(d) * xi_sd] *
+                     x0[(b * H0 + m) * D + d];
 }
 
 // fm = relu(c + bias) in place ([B * D, N]); pooled[b, col0 + n] = sum_d fm[(b, d), n] (d ascending)
@@ -856,9 +855,10 @@ int er_dot_interaction_bwd(const float* x, const float* g, int32_t B, int32_t F,
 int er_cin_outer_fwd(const float* xi, int64_t xi_stride_b, int32_t xi_stride_h, int32_t xi_stride_d, int32_t H,
                      const float* x0, int32_t H0, int32_t D, int64_t B, float* z, er_stream_t stream) {
   ER_REQUIRE(xi && x0 && z && B > 0 && H > 0 && H0 > 0 && D > 0, "er_cin_outer_fwd: bad arguments");
-  const int64_t n = B * D * H * H0;
-  hipLaunchKernelGGL(er::cin_outer_fwd_kernel, dim3(er::blocks_for(n)), dim3(er::kBlock), 0, er::as_stream(stream), xi,
-                     xi_stride_b, xi_stride_h, xi_stride_d, H, x0, H0, D, B * D, z);
+  ER_REQUIRE(B * D < 0x7FFFFFFFLL && static_cast<int64_t>(H) * H0 < (1 << 24), "er_cin_outer_fwd: too many rows / columns");
+  dim3 grid(static_cast<unsigned>(B * D), static_cast<unsigned>(er::ceil_div(static_cast<int64_t>(H) * H0, er::kBlock)));
+  hipLaunchKernelGGL(er::cin_outer_fwd_kernel, grid, dim3(er::kBlock), 0, er::as_stream(stream), xi, xi_stride_b,
+                     xi_stride_h, xi_stride_d, H, x0, H0, D, B * D, z);
   ER_LAUNCH_CHECK();
   return 0;
 }

@@ -33,15 +33,26 @@ class _TFShim(object):
 
   @staticmethod
   def stack(values, axis=0):
+    # a feature list whose [B, D] views lie side by side in one group buffer (xDeepFM: `tf.stack(x, axis=1)` in front
+    # of CIN) is a VIEW of that buffer: no copies forward, one dense gradient backward
+    blk = values.uniform_block() if hasattr(values, 'uniform_block') else None
+    if blk is not None and axis == 1:
+      base, col0, F, D = blk
+      x = base if (col0 == 0 and base.shape[1] == F * D) else base[:, col0:col0 + F * D]
+      return x.reshape(x.shape[0], F, D)
     return torch.stack(list(values), dim=axis)
 
   @staticmethod
   def add_n(values):
     """tf.add_n; a list of [B, 1] columns (xDeepFM's wide block: `lambda x: tf.add_n(x)` over width-1 embeddings) is one
     library concat + row sum instead of a chain of adds."""
+    blk = values.uniform_block() if hasattr(values, 'uniform_block') else None
     values = list(values)
+    from easyrec_amd import kernels
+    if blk is not None and blk[3] == 1:  # width-1 columns side by side in one buffer: a row sum of that block
+      base, col0, F, _ = blk
+      return kernels.RowSumFn.apply(base if (col0 == 0 and base.shape[1] == F) else base[:, col0:col0 + F])
     if len(values) > 1 and all(v.dim() == 2 and v.shape[1] == 1 and v.dtype == torch.float32 for v in values):
-      from easyrec_amd import kernels
       return kernels.RowSumFn.apply(kernels.concat_cols(values))
     out = values[0]
     for v in values[1:]:

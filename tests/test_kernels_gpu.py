@@ -1107,9 +1107,12 @@ def test_cin_layers_against_einsum(hip, B, H0, D, sizes):
   out = kernels.CINFn.apply(xd, len(sizes), *wd, *bd, *wg, *bg)
   out.backward(dout.to(DEV))
   torch.cuda.synchronize()
-  tol = dict(rtol=2e-4, atol=2e-4)
-  assert torch.allclose(out.detach().cpu().double(), ref.detach(), **tol)
-  assert torch.allclose(xd.grad.cpu().double(), xr.grad, **tol)
+  def close(got, want):  # fp32 sums of up to B * D * H * H0 terms: 2e-5 of the tensor's scale
+    want = want.detach()
+    return float((got.detach().cpu().double() - want).abs().max()) <= 2e-5 * float(want.abs().max()) + 1e-6
+
+  assert close(out, ref)
+  assert close(xd.grad, xr.grad)
   for k in range(len(sizes)):
-    assert torch.allclose(wg[k].cpu().double(), wr[k].grad, **tol), k
-    assert torch.allclose(bg[k].cpu().double(), br[k].grad, **tol), k
+    assert close(wg[k], wr[k].grad), k
+    assert close(bg[k], br[k].grad), k
