@@ -339,3 +339,27 @@ def test_combo_feature_with_multi_valued_inputs(ref_backend, tmp_path):
     res, exp = est.loss_values(), orc.train_step(b)
     for k in exp:
       assert abs(res[k] - exp[k]) <= 2e-5 * max(1.0, abs(exp[k])), (k, res[k], exp[k])
+
+
+def test_bench_helpers_describe_every_baseline_config(ref_backend):
+  """bench.py's host-side helpers (no GPU): which generator a config gets, the workload text of the JSON line, the ring
+  source, and that a packed generic batch round-trips through DeviceFeatures on the stand-in backend."""
+  import importlib.util
+  import types
+  ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  spec = importlib.util.spec_from_file_location('bench_module', os.path.join(ROOT, 'bench.py'))
+  bench = importlib.util.module_from_spec(spec)
+  spec.loader.exec_module(bench)
+  criteo = {'deepfm_criteo.config': True, 'dcn_v2_criteo.config': True, 'din_taobao_10m.config': False,
+            'mmoe_taobao_4task_d64_25m.config': False, 'xdeepfm_taobao.config': False}
+  for name, want in criteo.items():
+    cfg = config_util.get_configs_from_pipeline_file(os.path.join(ROOT, 'configs', name))
+    assert bench.is_criteo_shaped(cfg) == want, name
+    args = types.SimpleNamespace(config=os.path.join(ROOT, 'configs', name), dense_dtype='f32', ids='zipf', precondition=8)
+    est = types.SimpleNamespace(opt_emb=types.SimpleNamespace(name='adam_optimizer'), dense_sweep=False)
+    text = bench.workload_text(cfg, args, est, want, cfg.data_config.batch_size, 'hipGraph replay', 4)
+    assert name in text and 'batch %d' % cfg.data_config.batch_size in text
+    assert ('Criteo' in text) == want and ('Taobao' in text) == (not want)
+  ring = bench.RingSource(['a', 'b', 'c'])
+  assert [ring.next_packed() for _ in range(4)] == ['b', 'c', 'a', 'b']
+  assert 'examples/sec' in bench.baseline_metric()
