@@ -21,8 +21,15 @@ It shares with the product only the config schema (the drop-in boundary) and the
 format; variables are taken BY NAME from the product's initial state, so a naming or layout
 disagreement fails loudly.
 
-Parity status: the reference's tests hold no numeric expectation for these graphs and TensorFlow
-cannot run here -> "parity unpinned" for everything except hashing and the embed_test vectors.
+Parity status.  PINNED by outputs of the reference's own code (tests/golden/reference_layer_vectors.npz, produced by
+tests/golden/make_reference_layer_vectors.py executing the reference's functions unmodified on a numpy stand-in for
+the tensorflow module; tests/test_reference_layers.py): layers/fm.py FM, keras FM / Cross (full, diag_scale, low rank,
+no bias) / CIN / DotInteraction (layers/keras/interaction.py), layers/dnn.py DNN, model/multi_tower_din.py din(),
+layers/mmoe.py MMOE, model/dcn.py _cross_net, core/learning_schedules.py exponential_decay_with_burnin; hashing by
+TensorFlow's documented vectors; the embedding lookup by embed_test's vectors.  "Parity unpinned" (the reference's
+tests hold no numeric expectation, the code is TensorFlow's own and TensorFlow cannot run here): the loss
+(tf.losses.sigmoid_cross_entropy), the optimizers' update rules (tf.train.AdamOptimizer / AdamOptimizerS), the
+regularisation terms, BatchNorm's moving-average bookkeeping and the assembly of the model classes around the layers.
 """
 import math
 from collections import OrderedDict
@@ -473,18 +480,23 @@ class OracleTrainer(object):
       out = wide_fea + fm_fea.sum(dim=1, keepdim=True) + self.dense(V, deep_fea, mc.num_class, 'deep_logits', l2)
     return {'logits': out.squeeze(1)}
 
+  def _cross_net(self, V, x0, num_layers):
+    """model/dcn.py:32-45: x_{l+1} = x0 * (x_l . w_l) + b_l + x_l."""
+    x = x0
+    for i in range(num_layers):
+      w = V.get('cross_layer_%d_w' % i)
+      b = V.get('cross_layer_%d_b' % i)
+      xw = (x * w).sum(dim=1, keepdim=True)
+      x = (x0 * xw + b) + x
+    return x
+
   def _dcn(self, V, batch):
     mc = self.cfg.model_config
     c = mc.dcn
     l2 = self._l2_of(mc)
     feats, _ = self.input_layer(V, batch, 'all', 'input_layer')
     deep = self.dnn(V, feats, c.deep_tower.dnn, 'dnn', l2)
-    x0 = x = feats
-    for i in range(c.cross_tower.cross_num):
-      w = V.get('cross_layer_%d_w' % i)
-      b = V.get('cross_layer_%d_b' % i)
-      xw = (x * w).sum(dim=1, keepdim=True)
-      x = (x0 * xw + b) + x
+    x = self._cross_net(V, feats, c.cross_tower.cross_num)
     all_fea = torch.cat([deep, x], dim=1)
     all_fea = self.dnn(V, all_fea, c.final_dnn, 'final_dnn', l2)
     out = self.dense(V, all_fea, mc.num_class, 'output', 0.0)  # no kernel_regularizer (dcn.py:66)
@@ -594,6 +606,15 @@ class OracleTrainer(object):
     out = self.dense(V, all_fea, mc.num_class, 'output', 0.0)
     return {'logits': out.squeeze(1)}
 
+  def _mmoe_layer(self, V, x, expert_cfgs, num_task, l2, name='mmoe'):
+    """layers/mmoe.py:62-83: expert DNNs stacked on axis 1, per task a softmax gate over the experts, the mixture."""
+    experts = torch.stack([self.dnn(V, x, cfg, '%s/expert_%d' % (name, i), l2) for i, cfg in enumerate(expert_cfgs)], dim=1)
+    out = []
+    for t in range(num_task):
+      gate = torch.softmax(self.dense(V, x, len(expert_cfgs), '%s/gate_%d/dnn' % (name, t), l2), dim=1)
+      out.append((experts * gate[:, :, None]).sum(dim=1))
+    return out
+
   def _mmoe(self, V, batch):
     """model/mmoe.py:35-70, layers/mmoe.py:62-83."""
     mc = self.cfg.model_config
@@ -604,11 +625,10 @@ class OracleTrainer(object):
       cfgs = [c.expert_dnn] * c.num_expert
     else:
       cfgs = [e.dnn for e in c.experts]
-    experts = torch.stack([self.dnn(V, x, cfg, 'mmoe/expert_%d' % i, l2) for i, cfg in enumerate(cfgs)], dim=1)
+    task_inputs = self._mmoe_layer(V, x, cfgs, len(c.task_towers), l2)
     pred = {}
     for t, tower in enumerate(c.task_towers):
-      gate = torch.softmax(self.dense(V, x, len(cfgs), 'mmoe/gate_%d/dnn' % t, l2), dim=1)
-      task_in = (experts * gate[:, :, None]).sum(dim=1)
+      task_in = task_inputs[t]
       if tower.HasField('dnn'):
         task_in = self.dnn(V, task_in, tower.dnn, tower.tower_name, l2)
       out = self.dense(V, task_in, tower.num_class, 'dnn_output_%d' % t, l2)

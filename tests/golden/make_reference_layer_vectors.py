@@ -1,0 +1,324 @@
+#!/usr/bin/env python
+"""Golden vectors from the REFERENCE'S OWN layer code (run in the build container, where /root/reference exists).
+
+TensorFlow cannot be installed here, but several of the reference's layers are a few lines of plain tensor algebra:
+  easy_rec/python/layers/fm.py                 FM.__call__            (DeepFM's pairwise term)
+  easy_rec/python/layers/keras/interaction.py  FM.call, DotInteraction.call, Cross.call (DCN-v2), CIN.call (xDeepFM)
+  easy_rec/python/core/learning_schedules.py   exponential_decay_with_burnin
+  easy_rec/python/layers/dnn.py                DNN.__call__           (dense -> batch_normalization -> activation)
+  easy_rec/python/model/multi_tower_din.py     MultiTowerDIN.din      (target attention over a padded history)
+  easy_rec/python/layers/mmoe.py               MMOE.__call__          (experts, softmax gates, mixture per task)
+  easy_rec/python/model/dcn.py                 DCN._cross_net         (DCN-v1 cross layers)
+This script executes THOSE FUNCTIONS, unmodified, against a small stand-in for the `tensorflow` module (numpy, fp64)
+that implements the documented semantics of the ~25 ops they call (stack, reduce_sum, matmul(transpose_b), band_part,
+boolean_mask, tile, sequence_mask, ...), a `keras.layers.Dense` whose kernel / bias are set by this script, and
+`tf.layers.dense` / `tf.layers.batch_normalization` (training mode: batch statistics over all axes but the last, epsilon
+1e-3, the documented defaults) over seeded variables recorded under their TF names, and stores seeded inputs, those
+variables and the outputs in tests/golden/reference_layer_vectors.npz.  tests/test_reference_layers.py then holds the oracle's
+restatements (and, on the GPU, the HIP kernels) to those outputs: the index conventions of the reference code (which
+axis is summed, kernel[n, h, m] against x_k[h] and x_0[m], lower-triangle order of the dot interaction, diag_scale
+placement, staircase flooring) are pinned by the reference itself rather than by a reading of it.
+
+usage: python tests/golden/make_reference_layer_vectors.py [/root/reference]
+"""
+import contextlib
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+
+REF = sys.argv[1] if len(sys.argv) > 1 else '/root/reference'
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+# ------------------------------------------------------------------------------------------------ the tf stand-in
+def _arr(x):
+  return np.asarray(x, dtype=np.float64) if not isinstance(x, np.ndarray) or x.dtype != np.bool_ else x
+
+
+class _Layer(object):
+
+  def __init__(self, name=None, **kwargs):
+    self.name = name
+    self.built = False
+    self.dtype = 'float64'
+
+  def build(self, input_shape):
+    self.built = True
+
+  def __call__(self, inputs, **kwargs):
+    return self.call(inputs, **kwargs)
+
+
+class _Dense(_Layer):
+  """keras Dense: y = activation(x @ kernel + bias); this script assigns `kernel` / `bias` before the first call."""
+
+  def __init__(self, units, use_bias=True, activation=None, **kwargs):
+    super(_Dense, self).__init__(name=kwargs.get('name'))
+    self.units, self.use_bias, self.activation = units, use_bias, activation
+    self.kernel = self.bias = None
+
+  def call(self, x, **kwargs):
+    y = _arr(x) @ self.kernel
+    if self.use_bias:
+      y = y + self.bias
+    return self.activation(y) if self.activation is not None else y
+
+
+class _Initializer(object):
+
+  def __init__(self, name='x'):
+    self.name = name
+
+  def get_config(self):
+    return {'name': self.name}
+
+  @classmethod
+  def from_config(cls, cfg):
+    return cls(**cfg)
+
+
+def _reduce_sum(x, axis=None, keepdims=False):
+  return np.sum(_arr(x), axis=axis, keepdims=keepdims)
+
+
+def _band_part(x, num_lower, num_upper):
+  x = _arr(x)
+  m, n = x.shape[-2], x.shape[-1]
+  i, j = np.arange(m)[:, None], np.arange(n)[None, :]
+  keep = ((num_lower < 0) | ((i - j) <= num_lower)) & ((num_upper < 0) | ((j - i) <= num_upper))
+  return x * keep
+
+
+VARS = {}  # TF variable name -> value, filled by tf.layers.* below (the consumers feed the same values to the oracle)
+_VAR_RNG = np.random.default_rng(77)
+
+
+def _layers_dense(inputs, units, kernel_regularizer=None, activation=None, name=None, **kw):
+  x = _arr(inputs)
+  k = VARS.setdefault(name + '/kernel', _VAR_RNG.standard_normal((x.shape[-1], units)) * 0.4)
+  b = VARS.setdefault(name + '/bias', _VAR_RNG.standard_normal(units) * 0.1)
+  y = x @ k + b
+  return activation(y) if activation is not None else y
+
+
+def _layers_batch_normalization(inputs, training=False, trainable=True, name=None, epsilon=1e-3, **kw):
+  assert training, 'only the training-mode formula is exercised'
+  x = _arr(inputs)
+  gamma = VARS.setdefault(name + '/gamma', _VAR_RNG.random(x.shape[-1]) + 0.5)
+  beta = VARS.setdefault(name + '/beta', _VAR_RNG.standard_normal(x.shape[-1]) * 0.2)
+  axes = tuple(range(x.ndim - 1))
+  mean, var = x.mean(axis=axes), x.var(axis=axes)
+  return (x - mean) / np.sqrt(var + epsilon) * gamma + beta
+
+
+def _softmax(x, axis=-1):
+  x = _arr(x)
+  e = np.exp(x - x.max(axis=axis, keepdims=True))
+  return e / e.sum(axis=axis, keepdims=True)
+
+
+def _sequence_mask(lengths, maxlen=None):
+  lengths = np.asarray(lengths)
+  maxlen = int(lengths.max()) if maxlen is None else int(maxlen)
+  return np.arange(maxlen) < lengths[..., None]
+
+
+def make_tf():
+  tf = types.ModuleType('tensorflow')
+  tf.__version__ = '1.15.0'
+  tf.float32, tf.int32, tf.bool = np.float64, np.int64, np.bool_  # (fp64 throughout: the consumers compare with tolerances)
+  tf.name_scope = lambda *a, **k: contextlib.nullcontext()
+  tf.stack = lambda xs, axis=0: np.stack([_arr(x) for x in xs], axis=axis)
+  tf.concat = lambda xs, axis=-1: np.concatenate([_arr(x) for x in xs], axis=axis)
+  tf.square = lambda x: _arr(x) ** 2
+  tf.reduce_sum = _reduce_sum
+  tf.subtract = lambda a, b: _arr(a) - _arr(b)
+  tf.add = lambda a, b: _arr(a) + _arr(b)
+  tf.multiply = lambda a, b: _arr(a) * _arr(b)
+  tf.maximum = lambda a, b, name=None: np.maximum(_arr(a), _arr(b))
+  tf.less = lambda a, b: np.asarray(a) < np.asarray(b)
+  tf.constant = lambda v, *a, **k: np.asarray(v)
+  tf.expand_dims = lambda x, axis: np.expand_dims(_arr(x), axis)
+  tf.tile = lambda x, multiples: np.tile(_arr(x), multiples)
+  tf.reshape = lambda x, shape: np.reshape(_arr(x), [int(s) for s in shape])
+  tf.shape = lambda x: np.asarray(_arr(x).shape)
+  tf.ones_like = lambda x: np.ones_like(_arr(x))
+  tf.zeros_like = lambda x: np.zeros_like(_arr(x))
+  tf.matmul = lambda a, b, transpose_b=False: _arr(a) @ (np.swapaxes(_arr(b), -1, -2) if transpose_b else _arr(b))
+  tf.where = lambda condition=None, x=None, y=None: np.where(condition, x, y)
+  tf.cast = lambda x, dtype: np.asarray(x).astype(dtype)
+  tf.boolean_mask = lambda t, mask: _arr(t)[np.asarray(mask).astype(bool)]  # row-major order of the kept elements
+  tf.linalg = types.SimpleNamespace(band_part=_band_part)
+  tf.nn = types.SimpleNamespace(relu=lambda x, name=None: np.maximum(_arr(x), 0.0), softmax=_softmax)
+  tf.layers = types.SimpleNamespace(dense=_layers_dense, batch_normalization=_layers_batch_normalization)
+  tf.sequence_mask = _sequence_mask
+  tf.math = types.SimpleNamespace(add=lambda a, b: _arr(a) + _arr(b))
+
+  def get_variable(name=None, dtype=None, shape=None, **kw):
+    shape = (shape,) if isinstance(shape, (int, np.integer)) else tuple(shape)
+    return VARS.setdefault(name, _VAR_RNG.standard_normal(shape) * 0.3)
+
+  tf.get_variable = get_variable
+  tf.sigmoid = lambda x: 1.0 / (1.0 + np.exp(-_arr(x)))
+  tf.errors = types.SimpleNamespace(InvalidArgumentError=ValueError)
+
+  def exponential_decay(lr, step, decay_steps, decay_rate, staircase=False, name=None):  # tf.train.exponential_decay
+    p = np.asarray(step, dtype=np.float64) / float(decay_steps)
+    if staircase:
+      p = np.floor(p)
+    return float(lr) * np.power(float(decay_rate), p)
+
+  tf.train = types.SimpleNamespace(exponential_decay=exponential_decay)
+  tf.keras = types.SimpleNamespace(
+      layers=types.SimpleNamespace(Layer=_Layer, Dense=_Dense),
+      activations=types.SimpleNamespace(get=lambda a: a, serialize=lambda a: a),
+      initializers=types.SimpleNamespace(get=lambda n: _Initializer(str(n)), serialize=lambda a: a, Zeros=_Initializer),
+      regularizers=types.SimpleNamespace(get=lambda r: None, serialize=lambda a: a))
+  tf.compat = types.SimpleNamespace(v1=tf)
+  tf.initializers = types.SimpleNamespace(he_normal=lambda: _Initializer('he_normal'))
+  return tf
+
+
+def load_reference(rel_path, name):
+  spec = importlib.util.spec_from_file_location(name, os.path.join(REF, rel_path))
+  mod = importlib.util.module_from_spec(spec)
+  spec.loader.exec_module(mod)
+  return mod
+
+
+class Params(object):
+  """what the reference's layers read their settings from (layers/utils.py Parameter.get_or_default)"""
+
+  def __init__(self, **kw):
+    self.kw = kw
+
+  def get_or_default(self, key, default):
+    return self.kw.get(key, default)
+
+
+def main():
+  sys.modules['tensorflow'] = make_tf()
+  for pkg in ('easy_rec', 'easy_rec.python', 'easy_rec.python.utils'):
+    sys.modules.setdefault(pkg, types.ModuleType(pkg))
+  act = types.ModuleType('easy_rec.python.utils.activation')
+  relu = sys.modules['tensorflow'].nn.relu
+  act.get_activation = lambda name, **kw: relu if name in ('relu', 'tf.nn.relu', 'nn.relu') else None
+  sys.modules['easy_rec.python.utils.activation'] = act
+  fm_mod = load_reference('easy_rec/python/layers/fm.py', 'ref_layers_fm')
+  inter = load_reference('easy_rec/python/layers/keras/interaction.py', 'ref_keras_interaction')
+  sched = load_reference('easy_rec/python/core/learning_schedules.py', 'ref_learning_schedules')
+  dnn_mod = load_reference('easy_rec/python/layers/dnn.py', 'easy_rec.python.layers.dnn')
+  layers_pkg = types.ModuleType('easy_rec.python.layers')
+  layers_pkg.dnn = dnn_mod
+  layers_pkg.seq_input_layer = types.ModuleType('easy_rec.python.layers.seq_input_layer')
+  sys.modules['easy_rec.python.layers'] = layers_pkg
+  sys.modules['easy_rec.python.layers.dnn'] = dnn_mod
+  sys.modules['easy_rec.python.layers.seq_input_layer'] = layers_pkg.seq_input_layer
+  for name, attrs in (('easy_rec.python.compat', {}), ('easy_rec.python.compat.regularizers', {}),
+                      ('easy_rec.python.model', {}), ('easy_rec.python.model.rank_model', {'RankModel': object}),
+                      ('easy_rec.python.protos', {}), ('easy_rec.python.protos.multi_tower_pb2', {'MultiTower': object}),
+                      ('easy_rec.python.protos.dcn_pb2', {'DCN': object})):
+    m = types.ModuleType(name)
+    for k, v in attrs.items():
+      setattr(m, k, v)
+    sys.modules[name] = m
+  sys.modules['easy_rec.python.compat'].regularizers = sys.modules['easy_rec.python.compat.regularizers']
+  din_mod = load_reference('easy_rec/python/model/multi_tower_din.py', 'ref_multi_tower_din')
+  mmoe_mod = load_reference('easy_rec/python/layers/mmoe.py', 'ref_layers_mmoe')
+  dcn_mod = load_reference('easy_rec/python/model/dcn.py', 'ref_model_dcn')
+
+  rng = np.random.default_rng(20240923)
+  out = {}
+  B, F, D = 7, 5, 4
+  feats = [rng.standard_normal((B, D)) for _ in range(F)]
+  out['fm_inputs'] = np.stack(feats, axis=1)
+  out['fm_layers_fm'] = fm_mod.FM()(feats)                                            # [B, D]
+  out['fm_keras'] = inter.FM(Params(), name='fm').call(feats)                          # [B, 1]
+  out['fm_keras_variant'] = inter.FM(Params(use_variant=True), name='fm').call(feats)  # [B, D]
+  for self_inter in (False, True):
+    for skip in (False, True):
+      layer = inter.DotInteraction(Params(self_interaction=self_inter, skip_gather=skip), name='dot')
+      out['dot_self%d_skip%d' % (self_inter, skip)] = layer.call(feats)
+
+  d = 6
+  x0, x = rng.standard_normal((B, d)), rng.standard_normal((B, d))
+  out['cross_x0'], out['cross_x'] = x0, x
+  for tag, kw in (('full', {}), ('diag', {'diag_scale': 0.25}), ('nobias', {'use_bias': False}),
+                  ('lowrank', {'projection_dim': 3})):
+    layer = inter.Cross(Params(**kw), name='cross')
+    layer.build((x0.shape, x.shape))
+    layer.built = True
+    if 'projection_dim' in kw:
+      layer._dense_u.kernel = rng.standard_normal((d, 3)) * 0.5
+      layer._dense_v.kernel = rng.standard_normal((3, d)) * 0.5
+      layer._dense_v.bias = rng.standard_normal(d) * 0.1
+      out['cross_%s_u' % tag], out['cross_%s_v' % tag], out['cross_%s_bias' % tag] = \
+          layer._dense_u.kernel, layer._dense_v.kernel, layer._dense_v.bias
+    else:
+      layer._dense.kernel = rng.standard_normal((d, d)) * 0.5
+      layer._dense.bias = rng.standard_normal(d) * 0.1 if kw.get('use_bias', True) else None
+      out['cross_%s_kernel' % tag] = layer._dense.kernel
+      if layer._dense.bias is not None:
+        out['cross_%s_bias' % tag] = layer._dense.bias
+    out['cross_%s_out' % tag] = layer.call((x0, x))
+
+  H0, Dc, sizes = 4, 3, [5, 2]
+  cin_x = rng.standard_normal((B, H0, Dc))
+  cin = inter.CIN(Params(hidden_feature_sizes=sizes), name='cin')
+  hs = [H0] + sizes
+  cin.kernel_list = [rng.standard_normal((hs[i + 1], hs[i], H0)) * 0.4 for i in range(len(sizes))]
+  cin.bias_list = [rng.standard_normal(hs[i + 1]) * 0.2 for i in range(len(sizes))]
+  out['cin_x'] = cin_x
+  for i in range(len(sizes)):
+    out['cin_kernel_%d' % i], out['cin_bias_%d' % i] = cin.kernel_list[i], cin.bias_list[i]
+  out['cin_out'] = cin.call(cin_x)
+
+  steps = np.array([0, 1, 5, 9, 10, 11, 999, 1000, 1001, 2500, 25000, 100000], dtype=np.int64)
+  out['lr_steps'] = steps
+  for tag, kw in (('plain', dict(learning_rate_base=0.001, learning_rate_decay_steps=1000, learning_rate_decay_factor=0.5,
+                                 min_learning_rate=1e-5)),
+                  ('burnin', dict(learning_rate_base=0.01, learning_rate_decay_steps=500, learning_rate_decay_factor=0.7,
+                                  burnin_learning_rate=0.001, burnin_steps=10, min_learning_rate=1e-6)),
+                  ('smooth', dict(learning_rate_base=0.002, learning_rate_decay_steps=300, learning_rate_decay_factor=0.9,
+                                  staircase=False))):
+    out['lr_%s' % tag] = np.array([float(sched.exponential_decay_with_burnin(int(s), **kw)) for s in steps])
+    out['lr_%s_args' % tag] = np.array([kw.get(k, d) for k, d in (('learning_rate_base', 0), ('learning_rate_decay_steps', 0),
+                                                                 ('learning_rate_decay_factor', 0), ('burnin_learning_rate', 0.0),
+                                                                 ('burnin_steps', 0), ('min_learning_rate', 0.0),
+                                                                 ('staircase', True))], dtype=np.float64)
+
+  # DNN / DIN / MMoE: tf.layers.dense + batch_normalization over seeded variables recorded in VARS
+  dnn_cfg = types.SimpleNamespace(hidden_units=[6, 3], use_bn=True, activation='tf.nn.relu', dropout_ratio=[])
+  x_dnn = rng.standard_normal((9, 5))
+  out['dnn_x'] = x_dnn
+  out['dnn_out'] = dnn_mod.DNN(dnn_cfg, None, 'tower', True)(x_dnn)
+  out['dnn_out_last_plain'] = dnn_mod.DNN(dnn_cfg, None, 'tower2', True, last_layer_no_activation=True,
+                                          last_layer_no_batch_norm=True)(x_dnn)
+  Bd, L, E = 6, 5, 4
+  din_cfg = types.SimpleNamespace(hidden_units=[8, 4, 1], use_bn=True, activation='tf.nn.relu', dropout_ratio=[])
+  key, hist = rng.standard_normal((Bd, E)), rng.standard_normal((Bd, L, E))
+  lens = np.array([5, 1, 3, 2, 5, 4], dtype=np.int64)
+  out['din_key'], out['din_hist'], out['din_len'] = key, hist, lens
+  fake_self = types.SimpleNamespace(_l2_reg=None, _is_training=True)
+  out['din_out'] = din_mod.MultiTowerDIN.din(fake_self, din_cfg, {'key': key, 'hist_seq_emb': hist, 'hist_seq_len': lens},
+                                             'din')
+  exp_cfg = types.SimpleNamespace(hidden_units=[5, 3], use_bn=True, activation='relu', dropout_ratio=[])
+  x_mm = rng.standard_normal((8, 6))
+  out['mmoe_x'] = x_mm
+  tasks = mmoe_mod.MMOE(exp_cfg, None, num_task=2, num_expert=3, name='mmoe', is_training=True)(x_mm)
+  out['mmoe_task_0'], out['mmoe_task_1'] = tasks
+  x_dcn = rng.standard_normal((7, 5))
+  out['dcn_x'] = x_dcn
+  out['dcn_cross_out'] = dcn_mod.DCN._cross_net(None, x_dcn, 3)
+  for k, v in VARS.items():
+    out['var:' + k] = v
+  path = os.path.join(HERE, 'reference_layer_vectors.npz')
+  np.savez(path, **{k: np.asarray(v) for k, v in out.items()})
+  print('wrote %s: %d arrays' % (path, len(out)))
+
+
+if __name__ == '__main__':
+  main()

@@ -1,0 +1,174 @@
+"""The oracle's restatements (and, on the GPU, the HIP kernels) against tests/golden/reference_layer_vectors.npz:
+outputs of the REFERENCE'S OWN layer code - layers/fm.py FM, keras FM / DotInteraction / Cross / CIN
+(layers/keras/interaction.py), core/learning_schedules.py exponential_decay_with_burnin - executed unmodified on a numpy
+stand-in for the tensorflow module (tests/golden/make_reference_layer_vectors.py, run where /root/reference exists).
+What this pins: index conventions of the reference code (summed axes, CIN's kernel[n, h, m] against x_k[h] and x_0[m],
+the lower-triangle order of the dot interaction, diag_scale placement, staircase flooring) - not TensorFlow's rounding."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+G = np.load(os.path.join(HERE, 'golden', 'reference_layer_vectors.npz'))
+
+
+def _t(name, dtype=torch.float64):
+  return torch.from_numpy(np.asarray(G[name])).to(dtype)
+
+
+def _close(got, want, tol=1e-9):
+  got, want = torch.as_tensor(got).double().cpu(), torch.as_tensor(want).double()
+  assert got.shape == want.shape, (tuple(got.shape), tuple(want.shape))
+  assert float((got.detach() - want).abs().max()) <= tol * max(1.0, float(want.abs().max()))
+
+
+def test_fm_restatements():
+  from oracle.kernel_ref import RefBackend
+  x = _t('fm_inputs')  # [B, F, D]
+  B, F, D = x.shape
+  fm, _ = RefBackend().fm_fwd(x.reshape(B, F * D), F, D)
+  _close(fm, _t('fm_layers_fm'))
+  _close(fm, _t('fm_keras_variant'))
+  _close(fm.sum(dim=1, keepdim=True), _t('fm_keras'))
+
+
+def _keras_dot_index(F, self_interaction):
+  """position of pair (i, j), i >= j, in the keras DotInteraction output (lower triangle, row-major: boolean_mask)"""
+  order = [(i, j) for i in range(F) for j in range(i + 1 if self_interaction else i)]
+  return {p: k for k, p in enumerate(order)}
+
+
+@pytest.mark.parametrize('self_interaction', [False, True])
+def test_dot_interaction_restatement(self_interaction):
+  """The DLRM model class lists the pairs of the UPPER triangle row by row (model/dlrm.py:51-57, what this package's
+  DLRM and er_dot_interaction implement); the keras DotInteraction layer (not exported here) lists the lower triangle.
+  Same products: pair (i, j) of the one is pair (j, i) of the other."""
+  from oracle.kernel_ref import RefBackend
+  x = _t('fm_inputs')
+  B, F, D = x.shape
+  ref = RefBackend()
+  got = ref.dot_interaction_fwd(x.reshape(B, F * D), F, D, self_interaction)
+  keras = _t('dot_self%d_skip0' % int(self_interaction))
+  where = _keras_dot_index(F, self_interaction)
+  pairs = ref._dot_pairs(F, self_interaction)
+  assert len(pairs) == keras.shape[1]
+  _close(got, torch.stack([keras[:, where[(j, i)]] for i, j in pairs], dim=1))
+  # skip_gather: the full F x F matrix with the other triangle zeroed - the same numbers in place
+  full = _t('dot_self%d_skip1' % int(self_interaction)).reshape(B, F, F)
+  keep = torch.tril(torch.ones(F, F), 0 if self_interaction else -1).bool()
+  _close(full[:, keep], keras)
+
+
+def _vars(state):
+  from oracle.model_oracle import Vars
+  return Vars({k: np.asarray(v, dtype=np.float64) for k, v in state.items()}, torch.float64)
+
+
+@pytest.mark.parametrize('tag', ['full', 'diag', 'lowrank'])
+def test_cross_v2_restatement(tag):
+  from google.protobuf import struct_pb2
+
+  from oracle.model_oracle import OracleTrainer
+  st = struct_pb2.Struct()
+  state = {}
+  if tag == 'lowrank':
+    st['projection_dim'] = 3
+    state['c/dense_u/kernel'], state['c/dense_v/kernel'] = G['cross_lowrank_u'], G['cross_lowrank_v']
+    state['c/dense/bias'] = G['cross_lowrank_bias']
+  else:
+    state['c/dense/kernel'], state['c/dense/bias'] = G['cross_%s_kernel' % tag], G['cross_%s_bias' % tag]
+    if tag == 'diag':
+      st['diag_scale'] = 0.25
+  got = OracleTrainer._keras_cross(None, _vars(state), _t('cross_x0'), _t('cross_x'), st, 'c')
+  _close(got, _t('cross_%s_out' % tag))
+
+
+def test_cross_v2_kernel_ref_without_bias():
+  from oracle.kernel_ref import RefBackend
+  x0, x = _t('cross_x0'), _t('cross_x')
+  _close(RefBackend().cross_v2_fwd(x0, x, x @ _t('cross_nobias_kernel'), None, 0.0), _t('cross_nobias_out'))
+  _close(RefBackend().cross_v2_fwd(x0, x, x @ _t('cross_diag_kernel'), _t('cross_diag_bias'), 0.25), _t('cross_diag_out'))
+
+
+def test_cin_restatement():
+  from oracle.model_oracle import OracleTrainer
+  state = {'cin/cin_kernel_%d' % i: G['cin_kernel_%d' % i] for i in range(2)}
+  state.update({'cin/cin_bias_%d' % i: G['cin_bias_%d' % i] for i in range(2)})
+  got = OracleTrainer._keras_cin(None, _vars(state), _t('cin_x'), [5, 2], 'cin')
+  _close(got, _t('cin_out'))
+
+
+@pytest.mark.parametrize('tag', ['plain', 'burnin', 'smooth'])
+def test_learning_rate_schedule(tag):
+  from easyrec_amd.builders.optimizer_builder import exponential_decay_with_burnin
+  base, decay_steps, factor, burn_lr, burn_steps, min_lr, staircase = [float(v) for v in G['lr_%s_args' % tag]]
+  for step, want in zip(G['lr_steps'], G['lr_%s' % tag]):
+    got = exponential_decay_with_burnin(int(step), base, int(decay_steps), factor, burnin_learning_rate=burn_lr,
+                                        burnin_steps=int(burn_steps), min_learning_rate=min_lr, staircase=bool(staircase))
+    assert abs(float(got) - float(want)) <= 2e-6 * float(want) + 1e-12, (tag, int(step), float(got), float(want))
+
+
+def _layer_vars():
+  """the variables the reference's tf.layers.* calls created, + the moving statistics the oracle's BatchNorm reads"""
+  state = {k[len('var:'):]: G[k] for k in G.files if k.startswith('var:')}
+  for k in list(state):
+    if k.endswith('/bn/gamma'):
+      n = state[k].shape[0]
+      state[k[:-len('gamma')] + 'moving_mean'] = np.zeros(n)
+      state[k[:-len('gamma')] + 'moving_variance'] = np.ones(n)
+  return _vars(state)
+
+
+def _oracle():
+  from oracle.model_oracle import OracleTrainer
+  orc = OracleTrainer.__new__(OracleTrainer)
+  orc._moving = {}
+  return orc
+
+
+class _DnnCfg(object):  # the fields of dnn_pb2.DNN the oracle reads
+
+  def __init__(self, hidden_units, activation='tf.nn.relu'):
+    self.hidden_units, self.use_bn, self.activation, self.dropout_ratio = hidden_units, True, activation, []
+
+
+def test_dnn_din_mmoe_restatements():
+  """layers/dnn.py DNN (dense -> BatchNorm over every axis but the last -> relu; the last layer optionally plain),
+  model/multi_tower_din.py din() (concat order [q, h, q-h, q*h], mask value, softmax over time, output [pooled, q]) and
+  layers/mmoe.py MMOE (experts stacked on axis 1, softmax gate over experts) - the reference's code on the stand-in."""
+  orc, V = _oracle(), _layer_vars()
+  _close(orc.dnn(V, _t('dnn_x'), _DnnCfg([6, 3]), 'tower', 0.0), _t('dnn_out'))
+  _close(orc.dnn(V, _t('dnn_x'), _DnnCfg([6, 3]), 'tower2', 0.0, last_no_act=True, last_no_bn=True), _t('dnn_out_last_plain'))
+  fea = {'key': _t('din_key'), 'hist_seq_emb': _t('din_hist'), 'hist_seq_len': torch.from_numpy(np.asarray(G['din_len']))}
+  _close(orc._din(V, _DnnCfg([8, 4, 1]), fea, 'din', 0.0), _t('din_out'))
+  tasks = orc._mmoe_layer(V, _t('mmoe_x'), [_DnnCfg([5, 3], 'relu')] * 3, 2, 0.0)
+  _close(tasks[0], _t('mmoe_task_0'))
+  _close(tasks[1], _t('mmoe_task_1'))
+  _close(orc._cross_net(V, _t('dcn_x'), 3), _t('dcn_cross_out'))  # model/dcn.py _cross_net
+
+
+# ------------------------------------------------------------------------------------------------ the HIP kernels
+@pytest.mark.gpu
+def test_hip_kernels_against_the_reference_layers():
+  from easyrec_amd import kernels
+  hip, dev = kernels.hip(), 'cuda:0'
+  x = _t('fm_inputs', torch.float32).to(dev)
+  B, F, D = x.shape
+  fm = kernels.FMFn.apply(x.reshape(B, F * D).contiguous(), F, D)
+  _close(fm, _t('fm_layers_fm'), 1e-5)
+  _close(kernels.RowSumFn.apply(fm), _t('fm_keras'), 1e-5)
+  from oracle.kernel_ref import RefBackend
+  for si in (False, True):
+    keras, where = _t('dot_self%d_skip0' % int(si)), _keras_dot_index(F, si)
+    want = torch.stack([keras[:, where[(j, i)]] for i, j in RefBackend._dot_pairs(F, si)], dim=1)
+    _close(hip.dot_interaction_fwd(x.reshape(B, F * D).contiguous(), F, D, si), want, 1e-5)
+  x0, xx = _t('cross_x0', torch.float32).to(dev), _t('cross_x', torch.float32).to(dev)
+  w, b = _t('cross_diag_kernel', torch.float32).to(dev), _t('cross_diag_bias', torch.float32).to(dev)
+  u = hip.gemm(kernels.GEMM_NN, xx, w)
+  _close(hip.cross_v2_fwd(x0, xx, u, b, 0.25), _t('cross_diag_out'), 1e-5)
+  cx = _t('cin_x', torch.float32).to(dev)
+  ws = [_t('cin_kernel_%d' % i, torch.float32).to(dev) for i in range(2)]
+  bs = [_t('cin_bias_%d' % i, torch.float32).to(dev) for i in range(2)]
+  _close(kernels.CINFn.apply(cx, 2, *ws, *bs, None, None, None, None), _t('cin_out'), 1e-5)
