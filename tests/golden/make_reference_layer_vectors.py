@@ -9,6 +9,7 @@ TensorFlow cannot be installed here, but several of the reference's layers are a
   easy_rec/python/model/multi_tower_din.py     MultiTowerDIN.din      (target attention over a padded history)
   easy_rec/python/layers/mmoe.py               MMOE.__call__          (experts, softmax gates, mixture per task)
   easy_rec/python/model/dcn.py                 DCN._cross_net         (DCN-v1 cross layers)
+  easy_rec/python/layers/keras/blocks.py       MLP.__init__ / call    (which sub-layers a backbone MLP consists of)
 This script executes THOSE FUNCTIONS, unmodified, against a small stand-in for the `tensorflow` module (numpy, fp64)
 that implements the documented semantics of the ~25 ops they call (stack, reduce_sum, matmul(transpose_b), band_part,
 boolean_mask, tile, sequence_mask, ...), a `keras.layers.Dense` whose kernel / bias are set by this script, and
@@ -65,6 +66,54 @@ class _Dense(_Layer):
     if self.use_bias:
       y = y + self.bias
     return self.activation(y) if self.activation is not None else y
+
+
+
+class Dense(_Layer):  # (class names matter: blocks.MLP.call dispatches on layer.__class__.__name__)
+  """keras Dense over seeded variables recorded under <scope>/<name>/kernel|bias"""
+  scope = ''
+
+  def __init__(self, units, use_bias=True, name=None, **kwargs):
+    super(Dense, self).__init__(name=name)
+    self.units, self.use_bias = units, use_bias
+
+  def call(self, x, **kwargs):
+    x = _arr(x)
+    full = Dense.scope + self.name
+    y = x @ VARS.setdefault(full + '/kernel', _VAR_RNG.standard_normal((x.shape[-1], self.units)) * 0.4)
+    return y + VARS.setdefault(full + '/bias', _VAR_RNG.standard_normal(self.units) * 0.1) if self.use_bias else y
+
+
+class BatchNormalization(_Layer):
+
+  def __init__(self, name=None, trainable=True, **kwargs):
+    super(BatchNormalization, self).__init__(name=name)
+    self.updates = []
+
+  def __call__(self, x, training=None, **kwargs):
+    return _layers_batch_normalization(x, training=training, name=Dense.scope + self.name)
+
+
+class Dropout(_Layer):
+
+  def __init__(self, rate, name=None, **kwargs):
+    super(Dropout, self).__init__(name=name)
+
+  def __call__(self, x, training=None, **kwargs):
+    raise AssertionError('dropout is not exercised')
+
+
+class _Activation(_Layer):
+
+  def __init__(self, kind, name=None):
+    super(_Activation, self).__init__(name=name)
+    self.kind = kind
+
+  def call(self, x, **kwargs):
+    if self.kind in (None, 'linear'):
+      return _arr(x)
+    assert self.kind == 'relu', self.kind
+    return np.maximum(_arr(x), 0.0)
 
 
 class _Initializer(object):
@@ -229,6 +278,23 @@ def main():
   din_mod = load_reference('easy_rec/python/model/multi_tower_din.py', 'ref_multi_tower_din')
   mmoe_mod = load_reference('easy_rec/python/layers/mmoe.py', 'ref_layers_mmoe')
   dcn_mod = load_reference('easy_rec/python/model/dcn.py', 'ref_model_dcn')
+  # keras MLP block: its imports of keras classes / helpers resolve to the stand-ins above
+  tf = sys.modules['tensorflow']
+  tf.GraphKeys = types.SimpleNamespace(UPDATE_OPS='update_ops')
+  tf.keras.layers.BatchNormalization = BatchNormalization
+  for name, attrs in (('tensorflow.python', {}), ('tensorflow.python.keras', {}),
+                      ('tensorflow.python.keras.initializers', {'Constant': _Initializer}),
+                      ('tensorflow.python.keras.layers', {'Dense': Dense, 'Dropout': Dropout, 'Lambda': _Layer, 'Layer': _Layer}),
+                      ('easy_rec.python.layers.keras', {}),
+                      ('easy_rec.python.layers.keras.activation', {'activation_layer': lambda a, name=None: _Activation(a, name)}),
+                      ('easy_rec.python.layers.utils', {'Parameter': object}),
+                      ('easy_rec.python.utils.shape_utils', {'pad_or_truncate_sequence': None}),
+                      ('easy_rec.python.utils.tf_utils', {'add_elements_to_collection': lambda *a, **k: None})):
+    m = types.ModuleType(name)
+    for k, v in attrs.items():
+      setattr(m, k, v)
+    sys.modules[name] = m
+  blocks = load_reference('easy_rec/python/layers/keras/blocks.py', 'ref_keras_blocks')
 
   rng = np.random.default_rng(20240923)
   out = {}
@@ -310,6 +376,25 @@ def main():
   out['mmoe_x'] = x_mm
   tasks = mmoe_mod.MMOE(exp_cfg, None, num_task=2, num_expert=3, name='mmoe', is_training=True)(x_mm)
   out['mmoe_task_0'], out['mmoe_task_1'] = tasks
+  # keras MLP (backbone blocks): default settings, and the settings of xDeepFM's final block
+  class MlpParams(Params):
+    l2_regularizer = None
+
+    def check_required(self, key):
+      assert key in self.kw
+
+    @property
+    def hidden_units(self):
+      return self.kw['hidden_units']
+
+  x_mlp = rng.standard_normal((9, 5))
+  out['mlp_x'] = x_mlp
+  for tag, kw in (('default', dict(hidden_units=[6, 3])),
+                  ('final_linear', dict(hidden_units=[4, 1], use_final_bn=False, final_activation='linear')),
+                  ('biased', dict(hidden_units=[4, 2], use_bias=True, use_final_bias=True, use_bn=False))):
+    Dense.scope = 'mlp_%s/' % tag
+    out['mlp_%s_out' % tag] = blocks.MLP(MlpParams(**kw), name='mlp_%s' % tag).call(x_mlp, training=True)
+  Dense.scope = ''
   x_dcn = rng.standard_normal((7, 5))
   out['dcn_x'] = x_dcn
   out['dcn_cross_out'] = dcn_mod.DCN._cross_net(None, x_dcn, 3)

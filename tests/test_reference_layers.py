@@ -149,6 +149,20 @@ def test_dnn_din_mmoe_restatements():
   _close(orc._cross_net(V, _t('dcn_x'), 3), _t('dcn_cross_out'))  # model/dcn.py _cross_net
 
 
+@pytest.mark.parametrize('tag,text', [('default', 'hidden_units: [6, 3]'),
+                                      ('final_linear', "hidden_units: [4, 1] use_final_bn: false final_activation: 'linear'"),
+                                      ('biased', 'hidden_units: [4, 2] use_bias: true use_final_bias: true use_bn: false')])
+def test_keras_mlp_restatement(tag, text):
+  """layers/keras/blocks.py MLP: Dense without bias -> BatchNorm -> activation per layer by default, the LAST layer with
+  BatchNorm too and no activation; use_final_bn / final_activation / use_bias / use_final_bias / use_bn as configured."""
+  from google.protobuf import text_format
+
+  from easyrec_amd.protos import dnn_pb2
+  cfg = dnn_pb2.MLP()
+  text_format.Merge(text, cfg)
+  _close(_oracle()._keras_mlp(_layer_vars(), _t('mlp_x'), cfg, 'mlp_%s' % tag, 0.0), _t('mlp_%s_out' % tag))
+
+
 # ------------------------------------------------------------------------------------------------ the HIP kernels
 @pytest.mark.gpu
 def test_hip_kernels_against_the_reference_layers():
