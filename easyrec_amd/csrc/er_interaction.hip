@@ -608,35 +608,39 @@ cin_act_pool_bwd_kernel(const float* __restrict__ fm, const float* __restrict__ 
   dc[i] = fm[i] > 0.f ? g : 0.f;
 }
 
-// One workgroup per row (b, d) of dz [rows, H * H0]:
+// One workgroup per row (b, d) of dz [rows, H * H0]; the row is staged in LDS (coalesced 16-byte reads by all lanes),
+// then reduced from there:
 //   dxi[b, h, d]  = sum_m dz[row, h * H0 + m] * x0[b, m, d]       (m ascending; written, or added when add_xi)
 //   dx0[b, m, d] += sum_h dz[row, h * H0 + m] * xi[b, h, d]       (h ascending)
 // The first layer has xi == x0: both terms land in dx0 (dxi == dx0, add_xi set).
 __global__ void __launch_bounds__(kBlock)
 cin_outer_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ xi, int64_t xi_sb, int xi_sh, int xi_sd,
                      int H, const float* __restrict__ x0, int H0, int D, float* dxi, int add_xi, float* dx0) {
-  extern __shared__ float sh[];  // [H] xi column, [H0] x0 column
+  extern __shared__ float sh[];  // [H] xi column, [H0] x0 column, [H * H0] the dz row
   float* s_xi = sh;
   float* s_x0 = sh + H;
+  float* s_dz = sh + H + H0;
   const int64_t row = blockIdx.x;
   const int64_t b = row / D;
   const int d = static_cast<int>(row - b * D);
+  const int K = H * H0;
+  const float* r = dz + row * static_cast<int64_t>(K);
   for (int h = threadIdx.x; h < H; h += kBlock) s_xi[h] = xi[b * xi_sb + static_cast<int64_t>(h) * xi_sh + static_cast<int64_t>(d) * xi_sd];
   for (int m = threadIdx.x; m < H0; m += kBlock) s_x0[m] = x0[(b * H0 + m) * D + d];
+  for (int k = threadIdx.x; k < K; k += kBlock) s_dz[k] = r[k];
   __syncthreads();
-  const float* r = dz + row * (static_cast<int64_t>(H) * H0);
-  // the x0 term first (it reads dx0 += ...), then the xi term: when dxi aliases dx0 both updates of one element are
-  // made by different threads at different times - keep them in two phases separated by a barrier
+  // the x0 term first, then the xi term: when dxi aliases dx0 both updates of one element are made by different
+  // threads - keep them in two phases separated by a barrier
   for (int m = threadIdx.x; m < H0; m += kBlock) {
     float s = 0.f;
-    for (int h = 0; h < H; ++h) s = s + r[h * H0 + m] * s_xi[h];
+    for (int h = 0; h < H; ++h) s = s + s_dz[h * H0 + m] * s_xi[h];
     float* o = dx0 + (b * H0 + m) * D + d;
     *o = *o + s;
   }
   __syncthreads();
   for (int h = threadIdx.x; h < H; h += kBlock) {
     float s = 0.f;
-    for (int m = 0; m < H0; ++m) s = s + r[h * H0 + m] * s_x0[m];
+    for (int m = 0; m < H0; ++m) s = s + s_dz[h * H0 + m] * s_x0[m];
     float* o = dxi + b * xi_sb + static_cast<int64_t>(h) * xi_sh + static_cast<int64_t>(d) * xi_sd;
     *o = add_xi ? *o + s : s;
   }
@@ -885,10 +889,11 @@ int er_cin_outer_bwd(const float* dz, const float* xi, int64_t xi_stride_b, int3
                      int32_t H, const float* x0, int32_t H0, int32_t D, int64_t B, float* dxi, int add_xi, float* dx0,
                      er_stream_t stream) {
   ER_REQUIRE(dz && xi && x0 && dxi && dx0 && B > 0 && H > 0 && H0 > 0 && D > 0, "er_cin_outer_bwd: bad arguments");
-  ER_REQUIRE(B * D < 0x7FFFFFFFLL && (H + H0) * 4 <= 48 * 1024, "er_cin_outer_bwd: too many rows / features");
+  const size_t lds_bytes = (static_cast<size_t>(H) + H0 + static_cast<size_t>(H) * H0) * sizeof(float);
+  ER_REQUIRE(B * D < 0x7FFFFFFFLL && lds_bytes <= 60 * 1024, "er_cin_outer_bwd: too many rows / features");
   ER_REQUIRE(dxi != dx0 || add_xi, "er_cin_outer_bwd: dxi aliasing dx0 must add");
-  hipLaunchKernelGGL(er::cin_outer_bwd_kernel, dim3(static_cast<unsigned>(B * D)), dim3(er::kBlock),
-                     static_cast<size_t>(H + H0) * sizeof(float), er::as_stream(stream), dz, xi, xi_stride_b, xi_stride_h,
+  hipLaunchKernelGGL(er::cin_outer_bwd_kernel, dim3(static_cast<unsigned>(B * D)), dim3(er::kBlock), lds_bytes,
+                     er::as_stream(stream), dz, xi, xi_stride_b, xi_stride_h,
                      xi_stride_d, H, x0, H0, D, dxi, add_xi, dx0);
   ER_LAUNCH_CHECK();
   return 0;
