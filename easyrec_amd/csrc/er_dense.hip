@@ -132,7 +132,14 @@ bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ bias, con
 // matters is workgroups in flight - measured on one box, whole DeepFM step: 64 rows 0.591 ms, 32 0.562, 16 0.553,
 // 8 0.569, 4 0.605 (the redundant partial merges start to cost).
 constexpr int kApplyRows = 16;
-inline int apply_tiles_per_block(int B) { return B > 32768 ? 16 : (B >= 8192 ? 2 : 1); }  // (workgroups in flight ~ constant)
+inline int apply_tiles_per_block(int B) {  // (workgroups in flight ~ constant)
+  static const int mid = [] {  // (A/B knob: row tiles per workgroup for 8192 <= B <= 32768)
+    const char* e = getenv("ER_BN_TILES_MID");
+    const int v = e ? atoi(e) : 0;
+    return v >= 1 ? v : 2;
+  }();
+  return B > 32768 ? 16 : (B >= 8192 ? mid : 1);
+}
 
 // Tall activations (DIN's attention MLP: B x L = 204,800 rows -> 3,200 row-tile partials per column): the fused
 // finalize + apply kernels below re-merge ALL partials in every 16-row workgroup (cheap for the 64 partials of a

@@ -992,7 +992,12 @@ int gemm_grouped_f32(int layout, const er_gemm_problem* pr, int n, er_stream_t s
     int64_t sp = want;
     // a long contraction (DIN's attention MLP contracts over B x L = 204,800 rows into an 80-column output) gets
     // splits of at most 2048 rows whatever the group's tile count asks for: 13 splits of 15,753 rows took 0.52 ms
-    const int64_t by_len = er::ceil_div(q.K, 2048);
+    static const int64_t split_rows = [] {  // (A/B knob for tools/gpu_round2_cc.sh)
+      const char* e = getenv("ER_WGRAD_SPLIT_ROWS");
+      const int64_t v = e ? atoll(e) : 0;
+      return v >= 256 ? v : 2048;
+    }();
+    const int64_t by_len = er::ceil_div(q.K, split_rows);
     if (by_len > sp) sp = by_len;
     if (sp > 128) sp = 128;
     const int64_t max_by_k = q.K / (4 * er::BK32);
