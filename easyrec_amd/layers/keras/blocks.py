@@ -66,3 +66,19 @@ class MLP(object):
     if self.add_to_outputs and 'prediction_dict' in kwargs:
       kwargs['prediction_dict'][self.layer_name] = x.squeeze(1)
     return x
+
+
+class Add(object):
+  """tf.keras.layers.Add, which backbone configs name directly (`class_name: 'Add'` with `merge_inputs_into_list`,
+  e.g. the final logit of examples/configs/wide_and_deep_backbone_on_movielens.config): the sum of a list of tensors."""
+
+  def __init__(self, params=None, name=None, reuse=None, **kwargs):
+    self.name = name
+
+  def __call__(self, inputs, **kwargs):
+    inputs = list(inputs)
+    assert len(inputs) >= 2, 'A merge layer should be called on a list of at least 2 inputs'
+    out = inputs[0]
+    for t in inputs[1:]:
+      out = out + t
+    return out

@@ -107,3 +107,40 @@ class CIN(object):
       bs.append(vs.get_variable('%s/cin_bias_%d' % (self.name, i), (sizes[i + 1],), 'zeros'))
     n = len(ws)
     return kernels.CINFn.apply(inputs, n, *ws, *bs, *[w.grad for w in ws], *[b.grad for b in bs])
+
+
+class DotInteraction(object):
+  """DLRM's dot interaction as a backbone block (reference layers/keras/interaction.py:47-127): all pairwise dot
+  products of a list of [B, D] features, listed in the order of the LOWER triangle of the F x F matrix row by row
+  (`tf.boolean_mask`), with the diagonal when `self_interaction`.  er_dot_interaction produces the same products in the
+  order of the DLRM model class (upper triangle, model/dlrm.py:51-57): pair (i, j) there is pair (j, i) here, so the
+  output is a column permutation of the kernel's."""
+
+  def __init__(self, params, name=None, reuse=None, **kwargs):
+    self.name = name
+    self._self_interaction = bool(params.get_or_default('self_interaction', False))
+    assert not params.get_or_default('skip_gather', False), 'DotInteraction.skip_gather is outside the hot-path scope'
+    self._perm = {}
+
+  def _permutation(self, F, device):
+    key = (F, str(device))
+    if key not in self._perm:
+      off = 0 if self._self_interaction else 1
+      mine = {p: k for k, p in enumerate((i, j) for i in range(F) for j in range(i + off, F))}
+      order = [(i, j) for i in range(F) for j in range(i + 1 if self._self_interaction else i)]
+      self._perm[key] = torch.tensor([mine[(j, i)] for i, j in order], dtype=torch.int64, device=device)
+    return self._perm[key]
+
+  def __call__(self, inputs, **kwargs):
+    if isinstance(inputs, (list, tuple)):
+      dims = set(int(t.shape[-1]) for t in inputs)
+      if len(dims) != 1:
+        raise ValueError('Input tensors` dimensions must be equal, got: %s' % sorted(dims))
+      F, D = len(inputs), int(inputs[0].shape[-1])
+      x = kernels.concat_cols(list(inputs))
+    else:
+      assert inputs.dim() == 3, 'input of dot func must be a 3D tensor or a list of 2D tensors'
+      _, F, D = inputs.shape
+      x = inputs.reshape(inputs.shape[0], F * D)
+    out = kernels.DotInteractionFn.apply(x, F, D, self._self_interaction)
+    return out.index_select(1, self._permutation(F, out.device))

@@ -851,7 +851,14 @@ class OracleTrainer(object):
         if node.HasField('input_fn'):
           fea = eval(node.input_fn)(fea)
         ins.append(fea)
-      x = ins[0] if len(ins) == 1 else torch.cat(ins, dim=-1)
+      if blk.merge_inputs_into_list:
+        x = ins
+      elif len(ins) == 1:
+        x = ins[0]
+      elif any(isinstance(v, list) for v in ins):  # (backbone.py merge_inputs: lists are merged into one list)
+        x = [e for v in ins for e in (v if isinstance(v, list) else [v])]
+      else:
+        x = torch.cat(ins, dim=-1)
       if blk.HasField('extra_input_fn'):  # (backbone.py:424-441: applied to the merged input)
         x = eval(blk.extra_input_fn)(x)
       kind = blk.WhichOneof('layer')
@@ -863,6 +870,15 @@ class OracleTrainer(object):
           x = self._keras_cross(V, x[0], x[1], kl.st_params, blk.name)
         elif kl.class_name == 'DIN':
           x = self._keras_din(V, x[0], x[1], x[2], kl.din, l2)
+        elif kl.class_name == 'Add':
+          x = _TF.add_n(list(x))
+        elif kl.class_name == 'DotInteraction':
+          # layers/keras/interaction.py:90-127: lower triangle of the F x F dot products, row by row
+          fl = torch.stack(list(x), dim=1)
+          inter = fl @ fl.transpose(1, 2)
+          self_inter = 'self_interaction' in kl.st_params and bool(kl.st_params['self_interaction'])
+          F = fl.shape[1]
+          x = torch.stack([inter[:, i, j] for i in range(F) for j in range(i + 1 if self_inter else i)], dim=1)
         elif kl.class_name == 'CIN':
           x = self._keras_cin(V, x, [int(h) for h in kl.cin.hidden_feature_sizes], blk.name)
         elif kl.class_name == 'FM':
@@ -882,6 +898,8 @@ class OracleTrainer(object):
         for i in range(rc.num_steps):
           xi = self._keras_cross(V, x0, xi, rc.keras_layer.st_params, '%s_%d' % (blk.name, i))
         x = xi
+      elif kind is None:
+        pass  # a block without a layer hands its (merged, transformed) input on (backbone.py:262-268)
       else:
         raise NotImplementedError(kind)
       outs[blk.name] = x

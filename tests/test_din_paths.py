@@ -67,7 +67,8 @@ def shorten_sequences(batch, max_len):
 
 
 @pytest.mark.parametrize('config', ['din_backbone_taobao_small.config', 'din_sequence_features_taobao_small.config',
-                                    'deepfm_backbone_criteo_small.config', 'xdeepfm_taobao_small.config'])
+                                    'deepfm_backbone_criteo_small.config', 'xdeepfm_taobao_small.config',
+                                    'dlrm_backbone_criteo_small.config', 'wide_and_deep_backbone_criteo_small.config'])
 def test_backbone_and_group_level_din_match_the_oracle(ref_backend, config):
   _run(config, 24)
 
@@ -102,6 +103,9 @@ def test_reference_fixture_configs_build_and_step(ref_backend):
       ['samples/model_config/%s.config' % n for n in ('dcn_on_taobao', 'dcn_backbone_on_taobao', 'din_on_taobao',
                                                         'din_backbone_on_taobao', 'mmoe_on_taobao',
                                                         'mmoe_backbone_on_taobao')]
+  # + neighbours built on the same blocks: xDeepFM (CIN), DLRM as a backbone (DotInteraction), wide & deep with `Add`
+  fixtures += ['samples/model_config/xdeepfm_on_taobao_backbone.config', 'examples/configs/dlrm_backbone_on_criteo.config',
+               'examples/configs/wide_and_deep_backbone_on_movielens.config']
   for rel in fixtures:
     est = EasyRecEstimator(os.path.join(REFERENCE, rel), device='cpu', batch_size=8, seed=1).build()
     gen = SyntheticBatches(est.pipeline_config.data_config, est.feature_configs, batch_size=8, seed=3)

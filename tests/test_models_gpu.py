@@ -92,6 +92,13 @@ def test_dcn_v2_backbone_matches_oracle(name):
   _first_steps(_cfg(name), 128, 31)
 
 
+@pytest.mark.parametrize('name', ['dlrm_backbone_criteo_small.config', 'wide_and_deep_backbone_criteo_small.config'])
+def test_dlrm_and_wide_and_deep_as_backbones_match_oracle(name):
+  """examples/configs/dlrm_backbone_on_criteo.config (keras DotInteraction over a merged input list) and
+  wide_and_deep_backbone_on_movielens.config (`tf.add_n` + the standard keras `Add`)."""
+  _first_steps(_cfg(name), 128, 61)
+
+
 def test_xdeepfm_backbone_matches_oracle():
   """xDeepFM as a backbone (the shape of samples/model_config/xdeepfm_on_taobao_backbone.config): wide feature list
   summed by `tf.add_n`, CIN over the stacked field embeddings (layers/keras/interaction.py:311-409), MLP, final MLP."""

@@ -61,6 +61,25 @@ def test_dot_interaction_restatement(self_interaction):
   _close(full[:, keep], keras)
 
 
+def test_keras_dot_interaction_layer_on_the_stand_in_backend(ref_backend):
+  """the product's keras DotInteraction block (a column permutation of er_dot_interaction's output) in the reference
+  layer's own order"""
+  from easyrec_amd.layers.keras import DotInteraction
+
+  class P(object):
+    def __init__(self, **kw):
+      self.kw = kw
+
+    def get_or_default(self, k, d):
+      return self.kw.get(k, d)
+
+  x = _t('fm_inputs', torch.float32)
+  feats = [x[:, i, :].contiguous() for i in range(x.shape[1])]
+  for si in (False, True):
+    got = DotInteraction(P(self_interaction=si), name='dot')(feats)
+    _close(got, _t('dot_self%d_skip0' % int(si)), 1e-5)
+
+
 def _vars(state):
   from oracle.model_oracle import Vars
   return Vars({k: np.asarray(v, dtype=np.float64) for k, v in state.items()}, torch.float64)

@@ -404,6 +404,63 @@ def deepfm_backbone_criteo(**kw):
   ''' % (names, names))
 
 
+def dlrm_backbone_criteo(bottom=(64, 32, 16), top=(256, 128, 64), **kw):
+  """The shape of examples/configs/dlrm_backbone_on_criteo.config: bottom MLP over the dense group, the keras
+  DotInteraction over [bottom output] + the sparse group's feature list (inputs merged into one list), concatenated with
+  the sparse embeddings, top_mlp."""
+  cfg = deepfm_criteo(**kw)
+  names = _all_names()
+  dense = ' '.join("feature_names: '%s'" % n for n in names[:13])
+  sparse = ' '.join("feature_names: '%s'" % n for n in names[13:])
+  return _model_text(cfg, '''
+    model_name: 'DLRM'  model_class: 'RankModel'
+    feature_groups { group_name: 'dense' %s wide_deep: DEEP }
+    feature_groups { group_name: 'sparse' %s wide_deep: DEEP }
+    backbone {
+      blocks { name: 'bottom_mlp' inputs { feature_group_name: 'dense' }
+               keras_layer { class_name: 'MLP' mlp { hidden_units: %s } } }
+      blocks { name: 'sparse' inputs { feature_group_name: 'sparse' }
+               input_layer { output_2d_tensor_and_feature_list: true } }
+      blocks { name: 'dot'
+               inputs { block_name: 'bottom_mlp' input_fn: 'lambda x: [x]' }
+               inputs { block_name: 'sparse' input_fn: 'lambda x: x[1]' }
+               keras_layer { class_name: 'DotInteraction' } }
+      blocks { name: 'sparse_2d' inputs { block_name: 'sparse' input_fn: 'lambda x: x[0]' } }
+      concat_blocks: ['sparse_2d', 'dot']
+      top_mlp { hidden_units: %s }
+    }
+    model_params { l2_regularization: 1e-5 }
+    embedding_regularization: 1e-5
+  ''' % (dense, sparse, list(bottom), list(top)))
+
+
+def wide_and_deep_backbone_criteo(hidden=(256, 256, 256, 1), **kw):
+  """The shape of examples/configs/wide_and_deep_backbone_on_movielens.config: the wide feature list summed by
+  `tf.add_n`, a deep MLP down to one logit (no final BatchNorm, linear), the two merged into a list and summed by the
+  standard keras `Add` layer."""
+  cfg = deepfm_criteo(**kw)
+  names = ' '.join("feature_names: '%s'" % n for n in _all_names())
+  return _model_text(cfg, '''
+    model_name: 'WideAndDeep'  model_class: 'RankModel'
+    feature_groups { group_name: 'wide' %s wide_deep: WIDE }
+    feature_groups { group_name: 'deep' %s wide_deep: DEEP }
+    backbone {
+      blocks { name: 'wide' inputs { feature_group_name: 'wide' }
+               input_layer { wide_output_dim: 1 only_output_feature_list: true } }
+      blocks { name: 'deep_logit' inputs { feature_group_name: 'deep' }
+               keras_layer { class_name: 'MLP' mlp { hidden_units: %s use_final_bn: false final_activation: 'linear' } } }
+      blocks { name: 'final_logit'
+               inputs { block_name: 'wide' input_fn: 'lambda x: tf.add_n(x)' }
+               inputs { block_name: 'deep_logit' }
+               merge_inputs_into_list: true
+               keras_layer { class_name: 'Add' } }
+      concat_blocks: 'final_logit'
+    }
+    model_params { l2_regularization: 1e-4 }
+    embedding_regularization: 1e-4
+  ''' % (names, names, list(hidden)))
+
+
 def write(cfg, name):
   out = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'configs', name)
   with open(out, 'w') as f:
@@ -578,6 +635,9 @@ if __name__ == '__main__':
   write(din_sequence_features_taobao(batch_size=128, scale=0.01, seq_len=12), 'din_sequence_features_taobao_small.config')
   write(deepfm_backbone_criteo(hash_bucket_size=1000, batch_size=256), 'deepfm_backbone_criteo_small.config')
   write(xdeepfm_backbone_taobao(), 'xdeepfm_taobao.config')
+  write(dlrm_backbone_criteo(bottom=(32, 16), top=(64, 32), hash_bucket_size=1000, batch_size=256), 'dlrm_backbone_criteo_small.config')
+  write(wide_and_deep_backbone_criteo(hidden=(64, 32, 1), hash_bucket_size=1000, batch_size=256),
+        'wide_and_deep_backbone_criteo_small.config')
   write(xdeepfm_backbone_taobao(hidden=(8, 6), mlp=(32, 16), final=(16, 1), batch_size=128, scale=0.01, embedding_dim=8),
         'xdeepfm_taobao_small.config')
   shared_embedding_variant('dlrm_criteo_small.config', 'dlrm_shared_criteo_small.config')
