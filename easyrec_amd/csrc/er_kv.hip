@@ -1,0 +1,146 @@
+// K1b: hash-table ("KV") embedding tables: rows exist only for the ids that have been looked up in training.
+//
+// Replaces what `ev_params` turns an embedding column into in the reference: PAI-TF's `get_embedding_variable`
+// (compat/feature_column/feature_column_v2.py:3478-3513) / SOK's `DynamicVariable` under embedding parallelism
+// (compat/feature_column/feature_column.py:470-503, compat/dynamic_variable.py) - a key -> row map that creates a row,
+// drawn from the column's initializer, the first time a key is looked up in training and serves zeros for unseen keys
+// at evaluation (feature_column_v2.py:3487-3493).  Both are closed dependencies that are absent from /root/reference;
+// what is restated here is the behaviour the reference's call sites rely on.
+//
+// MI355X design: the table's rows are an ARENA inside the ordinary table-group storage ([capacity, dim] var / m / v), so
+// everything after the id translation - sort, catch-up, lookup, segmented reduction, row optimizer, lazy decay,
+// checkpoints - is the dense-table path unchanged.  The translation id -> arena row is an open-addressing hash map in
+// HBM (linear probing, 64-bit keys, load factor <= 0.5) in TWO launches per lookup array:
+//   insert: every id claims its key with one 64-bit CAS; the winner of a new key takes the next arena row (one atomic
+//           counter), initialises the row and publishes the row index;
+//   find  : every id probes to its key and reads the row index (all published: the launch boundary orders it).
+// Two launches instead of a spin on the winner: lanes of one wavefront may hold the same new key, and a lane spinning
+// for another lane of its own wave never sees it progress.  Which key gets which arena row depends on the atomics'
+// order and differs from run to run; nothing computed from the rows does (a row's value is a pure function of its
+// key: rows are initialised from a counter-based generator keyed by (seed, key, column)).
+#include "er_common.h"
+
+namespace er {
+
+constexpr int64_t kKvEmpty = -1;
+inline int blocks_for(int64_t n) { return static_cast<int>(ceil_div(n, kBlock)); }
+
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {  // splitmix64 finaliser
+  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+  x ^= x >> 27; x *= 0x94D049BB133111EBull;
+  x ^= x >> 31;
+  return x;
+}
+
+// value of column c of the row of `key`: mean + stddev * z, z = ((u0 + u1) + (u2 + u3) - 2) * sqrt(3) with four
+// 24-bit uniforms (sum of four U(0,1): variance 1/3 -> unit variance, support +-3.46 sigma; fp32, this operation order:
+// oracle/kernel_ref.py kv_init_value restates it bit for bit)
+__device__ __forceinline__ float kv_init_value(uint64_t seed, int64_t key, int c, float mean, float stddev) {
+  const uint64_t base = mix64(seed ^ mix64(static_cast<uint64_t>(key))) + static_cast<uint64_t>(c) * 0x9E3779B97F4A7C15ull;
+  float u[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    u[k] = static_cast<float>(mix64(base + static_cast<uint64_t>(k) * 0xD1B54A32D192ED03ull) >> 40) * 5.9604644775390625e-08f;
+  const float z = (((u[0] + u[1]) + (u[2] + u[3])) - 2.0f) * 1.7320508075688772f;
+  return mean + stddev * z;
+}
+
+__device__ __forceinline__ uint64_t kv_home(int64_t key, uint64_t mask) { return mix64(static_cast<uint64_t>(key)) & mask; }
+
+__global__ void __launch_bounds__(kBlock)
+kv_insert_kernel(const int64_t* __restrict__ ids, int64_t n, int64_t* keys, int32_t* rows, uint64_t mask,
+                 int32_t* next_row, int32_t capacity, float* __restrict__ var, int dim, uint64_t seed, float mean,
+                 float stddev, int32_t* overflow) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const int64_t key = ids[i];
+  if (key < 0) return;  // ('' / padding: no row)
+  uint64_t pos = kv_home(key, mask);
+  for (uint64_t probes = 0; probes <= mask; ++probes, pos = (pos + 1) & mask) {
+    const unsigned long long prev = atomicCAS(reinterpret_cast<unsigned long long*>(keys + pos),
+                                              static_cast<unsigned long long>(kKvEmpty), static_cast<unsigned long long>(key));
+    if (static_cast<int64_t>(prev) == key) return;  // present (or being created by its winner)
+    if (static_cast<int64_t>(prev) == kKvEmpty) {    // this lane created the key
+      const int32_t r = atomicAdd(next_row, 1);
+      if (r >= capacity) {
+        atomicExch(overflow, 1);  // the key stays without a row (find returns -1 for it: a zero embedding)
+        return;
+      }
+      float* dst = var + static_cast<int64_t>(r) * dim;
+      for (int c = 0; c < dim; ++c) dst[c] = kv_init_value(seed, key, c, mean, stddev);
+      __hip_atomic_store(rows + pos, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+  }
+  atomicExch(overflow, 1);
+}
+
+__global__ void __launch_bounds__(kBlock)
+kv_find_kernel(const int64_t* __restrict__ ids, int64_t n, const int64_t* __restrict__ keys,
+               const int32_t* __restrict__ rows, uint64_t mask, int64_t* __restrict__ out) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const int64_t key = ids[i];
+  int64_t r = -1;
+  if (key >= 0) {
+    uint64_t pos = kv_home(key, mask);
+    for (uint64_t probes = 0; probes <= mask; ++probes, pos = (pos + 1) & mask) {
+      const int64_t k = keys[pos];
+      if (k == key) {
+        r = rows[pos];  // (-1: created past the capacity)
+        break;
+      }
+      if (k == kKvEmpty) break;  // never seen: zero embedding (evaluation, or an id first met outside training)
+    }
+  }
+  out[i] = r;
+}
+
+// export: (key, row) of every occupied slot, compacted in slot order (the host sorts by key)
+__global__ void __launch_bounds__(kBlock)
+kv_export_kernel(const int64_t* __restrict__ keys, const int32_t* __restrict__ rows, int64_t slots,
+                 int64_t* __restrict__ out_keys, int32_t* __restrict__ out_rows, int32_t* count) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i >= slots) return;
+  if (keys[i] != kKvEmpty && rows[i] >= 0) {
+    const int32_t p = atomicAdd(count, 1);
+    out_keys[p] = keys[i];
+    out_rows[p] = rows[i];
+  }
+}
+
+}  // namespace er
+
+extern "C" {
+
+int er_kv_translate(const int64_t* ids, int64_t n, int64_t* map_keys, int32_t* map_rows, int64_t map_slots,
+                    int32_t* next_row, int32_t capacity, float* var, int32_t dim, uint64_t seed, float init_mean,
+                    float init_stddev, int insert, int64_t* rows_out, int32_t* overflow, er_stream_t stream) {
+  ER_REQUIRE(ids && map_keys && map_rows && next_row && rows_out && overflow && n >= 0, "er_kv_translate: null argument");
+  ER_REQUIRE(map_slots >= 2 && (map_slots & (map_slots - 1)) == 0, "er_kv_translate: map_slots must be a power of two");
+  ER_REQUIRE(capacity > 0 && static_cast<int64_t>(capacity) * 2 <= map_slots && dim > 0 && (var || !insert),
+             "er_kv_translate: capacity must be <= map_slots / 2");
+  if (n == 0) return 0;
+  hipStream_t s = er::as_stream(stream);
+  const uint64_t mask = static_cast<uint64_t>(map_slots - 1);
+  if (insert) {
+    hipLaunchKernelGGL(er::kv_insert_kernel, dim3(er::blocks_for(n)), dim3(er::kBlock), 0, s, ids, n, map_keys, map_rows,
+                       mask, next_row, capacity, var, dim, seed, init_mean, init_stddev, overflow);
+    ER_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(er::kv_find_kernel, dim3(er::blocks_for(n)), dim3(er::kBlock), 0, s, ids, n, map_keys, map_rows, mask,
+                     rows_out);
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
+int er_kv_export(const int64_t* map_keys, const int32_t* map_rows, int64_t map_slots, int64_t* out_keys,
+                 int32_t* out_rows, int32_t* count, er_stream_t stream) {
+  ER_REQUIRE(map_keys && map_rows && out_keys && out_rows && count && map_slots > 0, "er_kv_export: null argument");
+  hipLaunchKernelGGL(er::kv_export_kernel, dim3(er::blocks_for(map_slots)), dim3(er::kBlock), 0, er::as_stream(stream),
+                     map_keys, map_rows, map_slots, out_keys, out_rows, count);
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // extern "C"

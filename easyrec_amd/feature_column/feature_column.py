@@ -345,6 +345,12 @@ class FeatureColumnParser(object):
     else:
       self._sequence_columns[feature_name] = fc
 
+  def _ev_params_of(self, config):
+    """The feature's own `ev_params`, else the model-level ones (feature_column.py:212-219)."""
+    if config.HasField('ev_params'):
+      return config.ev_params
+    return self._global_ev_params
+
   def _add_wide_embedding_column(self, fc, config):
     """Wide column = dim-`wide_output_dim` embedding with `sum` combiner (feature_column.py:596-623)."""
     feature_name = self._feature_name(config)
@@ -355,7 +361,7 @@ class FeatureColumnParser(object):
     self._wide_columns[feature_name] = EmbeddingColumn(
         fc, self._wide_output_dim, 'sum', feature_name,
         initializer=config.initializer if config.HasField('initializer') else None,
-        shared_name=shared, max_partitions=config.max_partitions)
+        shared_name=shared, max_partitions=config.max_partitions, ev_params=self._ev_params_of(config))
 
   def _add_deep_embedding_column(self, fc, config):
     """reference feature_column.py:625-656."""
@@ -375,7 +381,7 @@ class FeatureColumnParser(object):
           fc, config.embedding_dim, config.combiner, feature_name,
           initializer=config.initializer if config.HasField('initializer') else None,
           max_seq_length=config.max_seq_len if config.HasField('max_seq_len') else -1,
-          max_partitions=config.max_partitions)
+          max_partitions=config.max_partitions, ev_params=self._ev_params_of(config))
     if config.feature_type != config.SequenceFeature:
       self._deep_columns[feature_name] = col
     else:

@@ -43,6 +43,9 @@ def bucketize(x, bounds):
   return np.searchsorted(bounds, np.asarray(x, dtype=np.float32), side='right').astype(np.int64)
 
 
+MAX_HASH_BUCKET_SIZE = 9223372036854775807  # (feature_column/feature_column.py:19)
+
+
 class FeatureSchema(object):
   """Static description of what a batch contains, derived from the config."""
 
@@ -77,8 +80,12 @@ class FeatureSchema(object):
             self.int_single[name] = {'col': len(self.int_single), 'num_buckets': len(bounds) + 1, 'bounds': bounds}
       elif ft == FeatureConfig.IdFeature:
         if fc.HasField('hash_bucket_size') and fc.hash_bucket_size > 0:
-          self.hash_single[name] = {'buckets': int(fc.hash_bucket_size), 'col': len(self.hash_single)}
+          # `ev_params` (hash-table embedding): the id is the hash into the whole int64 range, not into a bucket count
+          # (feature_column.py:222-226: MAX_HASH_BUCKET_SIZE), the table holds a row per id actually seen
+          buckets = MAX_HASH_BUCKET_SIZE if fc.HasField('ev_params') else int(fc.hash_bucket_size)
+          self.hash_single[name] = {'buckets': buckets, 'col': len(self.hash_single)}
         else:
+          assert not fc.HasField('ev_params'), 'ev_params on %s: only hashed IdFeatures are hash-table backed here' % name
           nb = len(fc.vocab_list) if fc.vocab_list else int(fc.num_buckets)
           self.int_single[name] = {'col': len(self.int_single), 'num_buckets': nb}
       elif ft == FeatureConfig.TagFeature:

@@ -1022,6 +1022,43 @@ class HipBackend(object):
                                  ctypes.c_float(scale), _p(dscores), _p(dhist), 0, _stream()), 'er_din_pool_bwd')
     return dscores, dhist
 
+  # -- K1b hash-table (KV) embedding tables
+  def kv_create(self, var_rows, capacity, seed, init_mean, init_stddev):
+    """The map of one KV table whose arena is `var_rows` ([capacity, dim] view of the table group's storage)."""
+    dev = var_rows.device
+    slots = 1
+    while slots < 2 * int(capacity):
+      slots *= 2
+    return {'keys': torch.full((slots,), -1, dtype=torch.int64, device=dev),
+            'rows': torch.full((slots,), -1, dtype=torch.int32, device=dev),
+            'next_row': torch.zeros(1, dtype=torch.int32, device=dev),
+            'overflow': torch.zeros(1, dtype=torch.int32, device=dev),
+            'capacity': int(capacity), 'var': var_rows, 'dim': int(var_rows.shape[1]), 'seed': int(seed) & ((1 << 63) - 1),
+            'mean': float(init_mean), 'stddev': float(init_stddev)}
+
+  def kv_translate(self, kv, ids, rows_out, insert):
+    """rows_out[i] = arena row of ids[i] (-1: no row); insert: unseen ids get a row (training)."""
+    assert ids.dtype == torch.int64 and rows_out.dtype == torch.int64 and ids.is_contiguous() and rows_out.is_contiguous()
+    assert ids.numel() == rows_out.numel()
+    self._ck(self.lib.er_kv_translate(_p(ids), ctypes.c_int64(ids.numel()), _p(kv['keys']), _p(kv['rows']),
+                                      ctypes.c_int64(kv['keys'].numel()), _p(kv['next_row']), ctypes.c_int32(kv['capacity']),
+                                      _p(kv['var']), ctypes.c_int32(kv['dim']), ctypes.c_uint64(kv['seed']),
+                                      ctypes.c_float(kv['mean']), ctypes.c_float(kv['stddev']), int(bool(insert)),
+                                      _p(rows_out), _p(kv['overflow']), _stream()), 'er_kv_translate')
+
+  def kv_export(self, kv):
+    """(keys ascending, arena rows) of the table's materialised ids (host sync)."""
+    n_max = kv['capacity']
+    keys = torch.empty(n_max, dtype=torch.int64, device=kv['keys'].device)
+    rows = torch.empty(n_max, dtype=torch.int32, device=kv['keys'].device)
+    count = torch.zeros(1, dtype=torch.int32, device=kv['keys'].device)
+    self._ck(self.lib.er_kv_export(_p(kv['keys']), _p(kv['rows']), ctypes.c_int64(kv['keys'].numel()), _p(keys), _p(rows),
+                                   _p(count), _stream()), 'er_kv_export')
+    n = int(count.item())
+    keys, rows = keys[:n], rows[:n]
+    order = torch.argsort(keys)
+    return keys[order], rows[order].to(torch.int64)
+
   # -- K9b CIN (xDeepFM)
   def cin_outer_fwd(self, xi, strides, H, x0, z):
     """z[(b, d), h * H0 + m] = xi[b, h, d] * x0[b, m, d]; xi addressed by strides = (stride_b, stride_h, stride_d)."""

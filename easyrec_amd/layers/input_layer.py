@@ -135,12 +135,19 @@ class EmbeddingEngine(object):
     self.overlap_flush = os.environ.get('EASYREC_AMD_OVERLAP_FLUSH', '0') != '0'
     self.flush_blocks = int(os.environ.get('EASYREC_AMD_FLUSH_BLOCKS', '1024'))  # grid of the concurrent launch (4 / CU)
     self._flush_stream = None
+    self.train_mode = True  # (the estimator clears it for is_training=False: no hash-table rows are created then)
+    self.kv_tables = {}  # table name -> map state (kernels.kv_create) of the hash-table backed tables
+    self.kv_jobs = []    # (table name, id array, arena-row array) translated before every lookup
     self._window_pending = False  # launched on the second stream, not joined yet
     self._window_started = False  # this step's window has been launched (the row update must not launch it again)
     self._sort_leader = {}  # dim -> dim of the group whose per-step sort it reuses
 
   # -- declaration (build pass)
-  def declare_table(self, var_name, rows, dim, initializer=None):
+  def declare_table(self, var_name, rows, dim, initializer=None, kv_capacity=None):
+    """kv_capacity: a hash-table (`ev_params`) table - `rows` is then the capacity of its arena, ids are translated to
+    arena rows before every lookup (er_kv_translate) and rows are created on first sight."""
+    if kv_capacity is not None:
+      rows = int(kv_capacity)
     if var_name in self.tables:
       t = self.tables[var_name]
       assert t['rows'] == rows and t['dim'] == dim, 'shared table %s shape mismatch' % var_name
@@ -148,7 +155,8 @@ class EmbeddingEngine(object):
     assert not self.finalized, 'table %s declared after finalize()' % var_name
     base = self.dim_rows.get(dim, 0)
     self.dim_rows[dim] = base + rows
-    t = {'name': var_name, 'rows': int(rows), 'dim': int(dim), 'key_base': base, 'init': initializer}
+    t = {'name': var_name, 'rows': int(rows), 'dim': int(dim), 'key_base': base, 'init': initializer,
+         'kv': kv_capacity is not None}
     self.tables[var_name] = t
     return t
 
@@ -256,6 +264,33 @@ class EmbeddingEngine(object):
       st['bitmap'] = torch.zeros((total + 31) // 32, dtype=torch.int32, device=self.device)
     return st
 
+  @staticmethod
+  def _init_mean_std(t):
+    """(mean, stddev) of a hash-table row's initial values: the column's (truncated) normal initializer, else the
+    default of an embedding column (feature_column_v2.py:908-912)."""
+    init = t['init']
+    kind = init.WhichOneof('initializer_oneof') if init is not None else None
+    if kind == 'truncated_normal_initializer':
+      return init.truncated_normal_initializer.mean, init.truncated_normal_initializer.stddev
+    if kind == 'random_normal_initializer':
+      return init.random_normal_initializer.mean, init.random_normal_initializer.stddev
+    assert kind is None, 'hash-table embedding %s: initializer %s is not supported' % (t['name'], kind)
+    return 0.0, 0.01 / math.sqrt(t['dim'])
+
+  def translate_kv_ids(self):
+    """ids -> arena rows for every lookup of a hash-table backed table; unseen ids get a row while training and read
+    zeros (row -1) in predict() / evaluate() (feature_column_v2.py:3487-3493)."""
+    be = kernels.hip()
+    insert = self.train_mode and not self.inference
+    for name, ids, rows in self.kv_jobs:
+      be.kv_translate(self.kv_tables[name], ids, rows, insert)
+
+  def check_kv_overflow(self):
+    for name, kv in self.kv_tables.items():
+      if int(kv['overflow'].item()):
+        raise RuntimeError('hash-table embedding %s: more than %d distinct ids (raise ev_params.max_capacity)'
+                           % (name, kv['capacity']))
+
   def init_table_values(self, name, view):
     """Fill `view` ([rows, dim]) with the initial values of table `name` (seeded per table name, so the
     single-GPU engine and every rank of the sharded engine draw the same table)."""
@@ -292,7 +327,14 @@ class EmbeddingEngine(object):
     for dim, total in self.dim_rows.items():
       self.storage[dim] = self._alloc_storage(total, dim, opt_kind)
     for name, t in self.tables.items():
-      self.init_table_values(name, self.table_view(name))
+      if t['kv']:
+        # rows are created on first sight by er_kv_translate (a pure function of seed, id and column); the arena
+        # starts as zeros (a row that no id owns is never read)
+        self.table_view(name).zero_()
+        mean, std = self._init_mean_std(t)
+        self.kv_tables[name] = be.kv_create(self.table_view(name), t['rows'], _stable_seed(name, self.seed), mean, std)
+      else:
+        self.init_table_values(name, self.table_view(name))
     # lookup specs: regularised groups first so their sum-of-squares partials form a prefix
     ordered = self._ordered_groups()
     fwd_specs, reg_count = [], 0
@@ -358,6 +400,8 @@ class EmbeddingEngine(object):
       g['got_grad'] = False
       g['terms'] = []
     self._join_window_flush()  # (a forward that no row update followed)
+    if self.kv_jobs:
+      self.translate_kv_ids()
     if self.lazy_decay and not self.inference:
       # sort the step's ids once (reused by the backward), bring the rows it touches up to date, then look up
       grps, uks, nus = [], [], []
@@ -549,19 +593,42 @@ class EmbeddingEngine(object):
   def state_dict(self, slots=False):
     out = OrderedDict()
     self.flush_decay()
+    self.check_kv_overflow()
     for name in self.tables:
-      out[name] = self.table_view(name).detach().cpu().numpy().copy()
+      rows = None
+      if self.tables[name]['kv']:
+        # the materialised ids in ascending order and their rows (arena positions are run-dependent, keys are not)
+        kv = self.kv_tables[name]
+        keys, rows = kernels.hip().kv_export(kv)
+        out[name + '/keys'] = keys.cpu().numpy().copy()
+        out[name + '/kv_meta'] = np.array([kv['seed'], kv['mean'], kv['stddev'], kv['capacity']], dtype=np.float64)
+      pick = (lambda v: v) if rows is None else (lambda v: v[rows.to(v.device)])
+      out[name] = pick(self.table_view(name).detach()).cpu().numpy().copy()
       if slots:
         for s in ('m', 'v'):
           sv = self.slot_view(name, s)
           if sv is not None:
-            out[name + '/' + s] = sv.detach().cpu().numpy().copy()
+            out[name + '/' + s] = pick(sv.detach()).cpu().numpy().copy()
     return out
 
   def load_state_dict(self, state):
     for name in self.tables:
-      if name in state:
-        self.table_view(name).copy_(torch.from_numpy(np.asarray(state[name], dtype=np.float32)).to(self.device))
+      if name not in state:
+        continue
+      values = torch.from_numpy(np.asarray(state[name], dtype=np.float32)).to(self.device)
+      if self.tables[name]['kv']:
+        # re-create the rows of the saved ids (any arena order), then overwrite them with the saved values
+        keys = torch.from_numpy(np.asarray(state[name + '/keys'], dtype=np.int64)).to(self.device)
+        rows = torch.empty_like(keys)
+        kernels.hip().kv_translate(self.kv_tables[name], keys, rows, True)
+        self.check_kv_overflow()
+        self.table_view(name)[rows] = values
+        for s in ('m', 'v'):
+          sv = self.slot_view(name, s)
+          if sv is not None and (name + '/' + s) in state:
+            sv[rows] = torch.from_numpy(np.asarray(state[name + '/' + s], dtype=np.float32)).to(self.device)
+      else:
+        self.table_view(name).copy_(values)
 
 
 def _stable_seed(name, base):
@@ -764,7 +831,14 @@ def declare_lookup(eng, features, column, scope, gkey, col, n_out_rows, seq=Fals
     table_name = '%s/embedding_weights' % column.var_scope_name  # shared across scopes/columns
   elif table_name is None:
     table_name = '%s/%s/embedding_weights' % (scope, column.var_scope_name)
-  eng.declare_table(table_name, rows, column.dimension, column.initializer)
+  ev = getattr(column, 'ev_params', None)
+  kv_capacity = None
+  if ev is not None:
+    assert cat.kind == 'hash' and not seq and not column.shared_name, \
+        'ev_params on %s: hash-table embeddings cover single-valued hashed IdFeatures' % column.raw_name
+    kv_capacity = int(ev.max_capacity) if ev.HasField('max_capacity') else int(os.environ.get('EASYREC_AMD_KV_CAPACITY', 1 << 22))
+    assert ev.filter_freq == 0 and ev.steps_to_live == 0, 'ev_params.filter_freq / steps_to_live are not supported'
+  eng.declare_table(table_name, rows, column.dimension, column.initializer, kv_capacity=kv_capacity)
   fname = column.raw_name
   schema = features.schema
   B = features.batch_size
@@ -792,4 +866,10 @@ def declare_lookup(eng, features, column, scope, gkey, col, n_out_rows, seq=Fals
     # sequence feature used as a plain (combined) column: sum/mean over the time axis
     s = features.seqs[fname]
     raise NotImplementedError('sequence feature %s as combined column' % fname)
-  eng.add_lookup(gkey, table_name, features.ids_of(fname), None, None, col, column.combiner, B, B, fname)
+  ids = features.ids_of(fname)
+  if kv_capacity is not None:
+    assert fname in schema.hash_single, 'ev_params on %s: hash-table embeddings cover single-valued hashed IdFeatures' % fname
+    rows_buf = torch.full((B,), -1, dtype=torch.int64, device=eng.device)  # arena rows of this step's ids
+    eng.kv_jobs.append((table_name, ids, rows_buf))
+    ids = rows_buf
+  eng.add_lookup(gkey, table_name, ids, None, None, col, column.combiner, B, B, fname)

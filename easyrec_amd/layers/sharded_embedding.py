@@ -54,6 +54,8 @@ class ShardedEmbeddingEngine(EmbeddingEngine):
   # -- storage
   def finalize(self, opt_kind):
     assert not self.finalized
+    assert not any(t.get('kv') for t in self.tables.values()), \
+        'hash-table (ev_params) embeddings are single-GPU only for now (the owner side would translate the received ids)'
     be = kernels.hip()
     W, rank, dev = self.world, self.rank, self.device
     # 1. placement of every table

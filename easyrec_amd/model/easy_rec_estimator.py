@@ -58,12 +58,19 @@ class EasyRecEstimator(object):
     self.overlap_sweep = overlap_sweep and torch.device(device).type == 'cuda'
     cfg = self.pipeline_config
     self.feature_configs = config_util.get_compatible_feature_configs(cfg)
+    if cfg.model_config.HasField('ev_params'):
+      # model-level ev_params apply to every feature (model/easy_rec_model.py:64-66): written into the hashed
+      # IdFeatures' own configs so that the schema, the generators and the oracle all read one place
+      for fc in self.feature_configs:
+        if fc.feature_type == fc.IdFeature and fc.HasField('hash_bucket_size') and not fc.HasField('ev_params'):
+          fc.ev_params.CopyFrom(cfg.model_config.ev_params)
     self.schema = FeatureSchema(cfg.data_config, self.feature_configs, batch_size=batch_size,
                                 **(schema_kwargs or {}))
     self.batch_size = self.schema.batch_size
     self.features = DeviceFeatures(self.schema, self.device)
     self.varstore = VarStore(self.device, seed=seed)
     self.engine = self._make_engine()
+    self.engine.train_mode = bool(is_training)
     self.ctx = context.ModelContext(self.varstore, self.engine, is_training=is_training)
     # 'f32' (default: exact-fp32 MFMA, the 1e-4 parity bar) or 'bf16' (BASELINE config 3: bf16 dense, fp32 embeddings)
     self.ctx.dense_dtype = dense_dtype or os.environ.get('ER_DENSE_DTYPE', 'f32')

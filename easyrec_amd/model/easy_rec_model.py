@@ -37,8 +37,6 @@ class EasyRecModel(six.with_metaclass(_meta_type, object)):
     self._feature_dict = features
 
     self._global_ev_params = model_config.ev_params if model_config.HasField('ev_params') else None
-    if self._global_ev_params is not None:
-      raise NotImplementedError('ev_params (hash-table embeddings) are outside the hot-path scope (SURVEY 8f)')
 
     self._emb_reg = self.embedding_regularization if self.embedding_regularization > 0 else None
     self._l2_reg = self.l2_regularization if self.l2_regularization > 0 else None

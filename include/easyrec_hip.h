@@ -339,6 +339,25 @@ int er_cross_v2_epilogue_bwd(const float* x0, const float* x, const float* u, co
                              float* dx0, int accumulate_dx0, float* dx, float* du,
                              er_stream_t stream);
 
+/* ---- K1b: hash-table ("KV") embedding tables: `ev_params` on a feature / model config ---------------------------
+ * In the reference an embedding column with ev_params is backed by PAI-TF's get_embedding_variable
+ * (compat/feature_column/feature_column_v2.py:3478-3513) or, under embedding parallelism, SOK's DynamicVariable
+ * (compat/feature_column/feature_column.py:470-503): rows exist only for ids that have been looked up in training, a new
+ * row is drawn from the column's initializer, unseen ids read zeros at evaluation (:3487-3493).  Both are closed
+ * dependencies absent from /root/reference; their call-site behaviour is what is reproduced.
+ * Here the rows live in an arena of `capacity` rows inside the ordinary table-group storage; er_kv_translate turns an id
+ * array into arena rows (open-addressing map in HBM: map_keys int64[map_slots] initialised to -1, map_rows
+ * int32[map_slots], map_slots a power of two >= 2 * capacity, *next_row = rows in use) and everything downstream is the
+ * dense-table path.  insert != 0 (training): ids not in the map get the next arena row, var[row] = init_mean +
+ * init_stddev * z(seed, id, column) from a counter-based generator (a row is a pure function of its key: which arena row
+ * a key gets is run-dependent, nothing computed from it is).  insert == 0 (evaluation / prediction): unseen ids map to -1
+ * = a zero embedding and no gradient.  ids < 0 ('' / padding) map to -1.  *overflow is set when the arena is full (the
+ * ids beyond it read zeros).  er_kv_export compacts the (key, row) pairs for checkpoints / state_dict. */
+int er_kv_translate(const int64_t* ids, int64_t n, int64_t* map_keys, int32_t* map_rows, int64_t map_slots,
+                    int32_t* next_row, int32_t capacity, float* var, int32_t dim, uint64_t seed, float init_mean,
+                    float init_stddev, int insert, int64_t* rows_out, int32_t* overflow, er_stream_t stream);
+int er_kv_export(const int64_t* map_keys, const int32_t* map_rows, int64_t map_slots, int64_t* out_keys,
+                 int32_t* out_rows, int32_t* count, er_stream_t stream);
 /* ---- K9b: CIN, xDeepFM's compressed interaction network (reference layers/keras/interaction.py:370-409) ----
  *   x_{k+1}[b, n, d] = relu(sum_{h, m} W_k[n, h, m] * x_k[b, h, d] * x_0[b, m, d] + bias_k[n]);
  *   output = concat over the layers of sum_d x_{k+1}[b, :, d].

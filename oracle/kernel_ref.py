@@ -754,6 +754,55 @@ class RefBackend(object):
     dh = probs[:, :, None] * dout[:, None, :]
     return ds, dh
 
+  # -- hash-table (KV) embedding tables: a python dict for the map, the same counter-based row initialiser in numpy
+  @staticmethod
+  def _mix64(x):
+    x = np.asarray(x, dtype=np.uint64)
+    with np.errstate(over='ignore'):
+      x = x ^ (x >> np.uint64(30)); x = x * np.uint64(0xBF58476D1CE4E5B9)
+      x = x ^ (x >> np.uint64(27)); x = x * np.uint64(0x94D049BB133111EB)
+      x = x ^ (x >> np.uint64(31))
+    return x
+
+  @classmethod
+  def kv_init_value(cls, seed, keys, dim, mean, stddev):
+    """er_kv.hip kv_init_value, restated: [len(keys), dim] fp32."""
+    keys = np.asarray(keys, dtype=np.int64).astype(np.uint64)
+    with np.errstate(over='ignore'):
+      base = cls._mix64(np.uint64(seed) ^ cls._mix64(keys))[:, None] + \
+          np.arange(dim, dtype=np.uint64)[None, :] * np.uint64(0x9E3779B97F4A7C15)
+      u = [(cls._mix64(base + np.uint64(k) * np.uint64(0xD1B54A32D192ED03)) >> np.uint64(40)).astype(np.float32) *
+           np.float32(5.9604644775390625e-08) for k in range(4)]
+    z = (((u[0] + u[1]) + (u[2] + u[3])) - np.float32(2.0)) * np.float32(1.7320508075688772)
+    return (np.float32(mean) + np.float32(stddev) * z).astype(np.float32)
+
+  def kv_create(self, var_rows, capacity, seed, init_mean, init_stddev):
+    return {'map': {}, 'capacity': int(capacity), 'var': var_rows, 'dim': int(var_rows.shape[1]),
+            'seed': int(seed) & ((1 << 63) - 1), 'mean': float(init_mean), 'stddev': float(init_stddev),
+            'overflow': torch.zeros(1, dtype=torch.int32)}
+
+  def kv_translate(self, kv, ids, rows_out, insert):
+    out = []
+    for k in ids.view(-1).tolist():
+      if k < 0:
+        out.append(-1)
+        continue
+      r = kv['map'].get(k)
+      if r is None and insert:
+        if len(kv['map']) >= kv['capacity']:
+          kv['overflow'][0] = 1
+          r = -1
+        else:
+          r = len(kv['map'])
+          kv['var'].detach()[r] = torch.from_numpy(self.kv_init_value(kv['seed'], [k], kv['dim'], kv['mean'], kv['stddev'])[0])
+        kv['map'][k] = r
+      out.append(-1 if r is None else r)
+    rows_out.view(-1).copy_(torch.tensor(out, dtype=torch.int64))
+
+  def kv_export(self, kv):
+    items = sorted((k, r) for k, r in kv['map'].items() if r >= 0)
+    return (torch.tensor([k for k, _ in items], dtype=torch.int64), torch.tensor([r for _, r in items], dtype=torch.int64))
+
   # -- CIN (xDeepFM): strided views of the operands, plain torch arithmetic
   @staticmethod
   def _cin_view(x, strides, B, H, D):

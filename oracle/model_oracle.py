@@ -101,6 +101,20 @@ class OracleTrainer(object):
     self.cfg = cfg
     self.B = batch_size
     self.dtype = dtype
+    # hash-table (ev_params) tables arrive as (ids ascending, rows, meta): kept here as a dense arena of `capacity` rows
+    # + an id -> row dict; rows are created on first sight from the same counter-based generator as the product
+    # (oracle/kernel_ref.py kv_init_value), so a row's value does not depend on which arena position it gets
+    self.kv = {}
+    state = OrderedDict(state)
+    for k in [k for k in state if k.endswith('/kv_meta')]:
+      name = k[:-len('/kv_meta')]
+      seed, mean, std, cap = [float(x) for x in state.pop(k)]
+      keys = np.asarray(state.pop(name + '/keys'), dtype=np.int64)
+      vals = np.asarray(state[name], dtype=np.float32)
+      arena = np.zeros((int(cap), vals.shape[1]), dtype=np.float32)
+      arena[:len(keys)] = vals
+      state[name] = arena
+      self.kv[name] = {'map': {int(key): i for i, key in enumerate(keys)}, 'seed': int(seed), 'mean': mean, 'stddev': std}
     self.state = OrderedDict((k, np.array(v, dtype=np.float32)) for k, v in state.items())
     self.features = list(cfg.feature_configs) if cfg.feature_configs else list(cfg.feature_config.features)
     self.fc_by_name = OrderedDict((_fname(f), f) for f in self.features)
@@ -117,6 +131,7 @@ class OracleTrainer(object):
     """Continue from a training state taken elsewhere: `global_step` finished steps (LR schedule position, Adam's beta
     powers = beta^(step + 1), computed by repeated fp32 multiplication as TF's update op does) and the optimizer slots
     {'<var>/m', '<var>/v'}."""
+    assert not self.kv, 'resume() with hash-table tables is not restated'
     self.global_step = int(global_step)
     self.slots = {k: np.array(v, dtype=np.float32) for k, v in slots.items()}
     for oi, o in enumerate(self.opt):
@@ -163,7 +178,9 @@ class OracleTrainer(object):
     if 'hash_ids' in batch:
       ids = np.asarray(batch['hash_ids'])
     else:
-      nb = np.array([self.fc_by_name[n].hash_bucket_size for n in names], dtype=np.uint64)
+      # (ev_params: the id is the hash into the whole int64 range, feature_column/feature_column.py:19, 222-226)
+      nb = np.array([(2**63 - 1) if self.fc_by_name[n].HasField('ev_params') else self.fc_by_name[n].hash_bucket_size
+                     for n in names], dtype=np.uint64)
       ids = hashing.hash_bucket_fast(np.asarray(batch['str_bytes']), np.asarray(batch['str_offsets']), self.B, nb,
                                      True).reshape(len(names), self.B)
     return {n: ids[i] for i, n in enumerate(names)}
@@ -227,6 +244,29 @@ class OracleTrainer(object):
     ids = np.asarray(ids).reshape(-1)
     ok = (ids >= 0) & (ids < table.shape[0])
     mask[ids[ok]] = True
+
+  def _kv_rows(self, name, ids):
+    """ids -> arena rows of a hash-table table (training: unseen ids get the next row, initialised from the generator)"""
+    from oracle.kernel_ref import RefBackend
+    kv, arena = self.kv[name], self.state[name]
+    out = np.full(len(ids), -1, dtype=np.int64)
+    for i, key in enumerate(np.asarray(ids, dtype=np.int64).tolist()):
+      if key < 0:
+        continue
+      r = kv['map'].get(key)
+      if r is None:
+        r = len(kv['map'])
+        assert r < arena.shape[0], 'oracle: hash-table %s is full' % name
+        arena[r] = RefBackend.kv_init_value(kv['seed'], [key], arena.shape[1], kv['mean'], kv['stddev'])[0]
+        kv['map'][key] = r
+      out[i] = r
+    return out
+
+  def kv_state(self, name, array=None):
+    """(ids ascending, their rows of `array` - default the table itself) of a hash-table table"""
+    items = sorted(self.kv[name]['map'].items())
+    src = self.state[name] if array is None else array
+    return np.array([k for k, _ in items], dtype=np.int64), np.stack([src[r] for _, r in items]) if items else src[:0]
 
   def _lookup_dense(self, table, ids, weights=None):
     """One id per example; id < 0 -> zero row; optional weight multiplies the row (combiner sum)."""
@@ -301,8 +341,11 @@ class OracleTrainer(object):
         outs.append((e, True))
       elif fc.feature_type == fc.IdFeature or (fc.feature_type == fc.ComboFeature and n in ints):
         # (crossed ComboFeature: CrossedColumn under an EmbeddingColumn, the id comes from the input stage)
-        table = V.get(self._column_var_name(scope, fc, wide))
+        var_name = self._column_var_name(scope, fc, wide)
         ids = hashed[n] if n in hashed else ints[n]
+        if var_name in self.kv:  # (before V.get: new rows are written into the state the leaf is made from)
+          ids = self._kv_rows(var_name, ids)
+        table = V.get(var_name)
         outs.append((self._lookup_dense(table, ids), True))
       elif fc.feature_type in (fc.TagFeature, fc.LookupFeature) or (
           fc.feature_type == fc.ComboFeature and ('tag/%s/ids' % n) in batch):

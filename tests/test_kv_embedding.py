@@ -1,0 +1,122 @@
+"""Hash-table (`ev_params`) embedding tables: rows exist only for the ids seen in training, a new
+row is a pure function of (seed, id, column), unseen ids read zeros at evaluation.  The product on the oracle's stand-in
+backend against the oracle (which keeps a dict + arena of its own and assigns arena rows in its own order): losses,
+the set of materialised ids, and every row by id."""
+import os
+
+import numpy as np
+import pytest
+
+from easyrec_amd.utils import config_util
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(device, steps=3, B=64):
+  from easyrec_amd.input.criteo_synthetic import SyntheticCriteo
+  from easyrec_amd.model.easy_rec_estimator import EasyRecEstimator
+  from oracle.model_oracle import OracleTrainer
+  cfg = config_util.get_configs_from_pipeline_file(os.path.join(ROOT, 'configs', 'deepfm_kv_criteo_small.config'))
+  est = EasyRecEstimator(cfg, device=device, batch_size=B, seed=4).build()
+  kv_names = sorted(est.engine.kv_tables)
+  assert len(kv_names) == 8, kv_names  # C1..C4, deep and wide
+  state0 = est.state_dict()
+  assert all(state0[n + '/keys'].size == 0 and state0[n].shape[0] == 0 for n in kv_names)
+  orc = OracleTrainer(cfg, state0, batch_size=B)
+  gen = SyntheticCriteo(cfg.data_config, est.feature_configs, batch_size=B, seed=12)
+  batches = [gen.next_batch() for _ in range(steps)]
+  for step, b in enumerate(batches):
+    est.train_step(b)
+    got, exp = est.loss_values(), orc.train_step(b)
+    for k in exp:
+      assert abs(got[k] - exp[k]) <= 1e-4 * max(1.0, abs(exp[k])), (step, k, got[k], exp[k])
+  st = est.state_dict(slots=True)
+  for n in kv_names:
+    keys, rows = orc.kv_state(n)
+    assert np.array_equal(st[n + '/keys'], keys), n
+    assert keys.size > 10 and st[n].shape == rows.shape
+    assert np.allclose(st[n], rows, rtol=2e-4, atol=2e-6), n
+    _, m_rows = orc.kv_state(n, orc.slots[n + '/m'])
+    assert float(np.abs(st[n + '/m'] - m_rows).max()) <= 2e-4 * float(np.abs(m_rows).max()) + 1e-9, n
+  return est, cfg, batches, st
+
+
+def _evaluate_and_reload(est, cfg, batches, st, device):
+  from easyrec_amd.model.easy_rec_estimator import EasyRecEstimator
+  # evaluation creates no rows: ids never seen in training read zeros
+  n_before = {n: st[n + '/keys'].size for n in est.engine.kv_tables}
+  from easyrec_amd.input.criteo_synthetic import SyntheticCriteo
+  fresh = SyntheticCriteo(cfg.data_config, est.feature_configs, batch_size=est.batch_size, seed=99).next_batch()
+  est.evaluate([fresh])
+  after = est.state_dict()
+  assert all(after[n + '/keys'].size == n_before[n] for n in n_before)
+  # a restored estimator continues exactly like the original
+  twin = EasyRecEstimator(cfg, device=device, batch_size=est.batch_size, seed=4).build()
+  twin.load_state_dict(est.state_dict(slots=True))
+  est.train_step(batches[0])
+  twin.train_step(batches[0])
+  a, b = est.loss_values(), twin.loss_values()
+  assert all(abs(a[k] - b[k]) <= 1e-6 * max(1.0, abs(a[k])) for k in a), (a, b)
+
+
+def test_kv_embeddings_match_the_oracle_on_the_stand_in_backend(ref_backend):
+  est, cfg, batches, st = _run('cpu')
+  _evaluate_and_reload(est, cfg, batches, st, 'cpu')
+
+
+def test_row_initialiser_is_a_pure_function_of_its_key():
+  from oracle.kernel_ref import RefBackend
+  a = RefBackend.kv_init_value(5, [3, 10**15, 7], 4, 0.0, 0.5)
+  b = RefBackend.kv_init_value(5, [7, 3], 4, 0.0, 0.5)
+  assert np.array_equal(a[0], b[1]) and np.array_equal(a[2], b[0])
+  big = RefBackend.kv_init_value(1, np.arange(50000), 4, 0.25, 2.0)
+  assert abs(float(big.mean()) - 0.25) < 0.02 and abs(float(big.std()) - 2.0) < 0.02
+  assert float(np.abs(big - 0.25).max()) <= 2.0 * 3.4642  # the sum of four uniforms has bounded support
+
+
+@pytest.mark.gpu
+def test_kv_translate_kernel():
+  """er_kv_translate: every id gets ONE row however often and wherever it occurs in the launch, rows are the generator's
+  values, ids < 0 and (without insert) unseen ids map to -1, the arena's end sets the overflow flag."""
+  import torch
+
+  from easyrec_amd import kernels
+  from oracle.kernel_ref import RefBackend
+  hip, dev = kernels.hip(), 'cuda:0'
+  cap, dim = 5000, 8
+  var = torch.zeros(cap, dim, device=dev)
+  kv = hip.kv_create(var, cap, 1234, 0.1, 0.7)
+  g = torch.Generator().manual_seed(3)
+  ids = torch.randint(0, 3000, (20000,), generator=g, dtype=torch.int64) * 982451653 + 17
+  ids[::7] = -1
+  ids_d, rows = ids.to(dev), torch.empty(20000, dtype=torch.int64, device=dev)
+  hip.kv_translate(kv, ids_d, rows, True)
+  torch.cuda.synchronize()
+  r = rows.cpu()
+  assert bool((r[ids < 0] == -1).all()) and bool((r[ids >= 0] >= 0).all())
+  uniq = torch.unique(ids[ids >= 0])
+  assert int(kv['next_row'].item()) == uniq.numel() and int(kv['overflow'].item()) == 0
+  by_id = {}
+  for k, row in zip(ids.tolist(), r.tolist()):
+    if k >= 0:
+      assert by_id.setdefault(k, row) == row
+  assert len(set(by_id.values())) == len(by_id)
+  keys, krows = hip.kv_export(kv)
+  assert torch.equal(keys.cpu(), uniq)
+  want = RefBackend.kv_init_value(1234, keys.cpu().numpy(), dim, 0.1, 0.7)
+  assert np.array_equal(var[krows].cpu().numpy(), want), 'rows are bit-identical to the numpy restatement of the generator'
+  # without insert: known ids find their rows, unknown ones read -1
+  probe = torch.cat([ids[:100], torch.tensor([5, 6, 7], dtype=torch.int64)]).to(dev)
+  out = torch.empty(103, dtype=torch.int64, device=dev)
+  hip.kv_translate(kv, probe, out, False)
+  assert torch.equal(out[:100].cpu(), r[:100]) and bool((out[100:] == -1).all())
+  # overflow
+  more = (torch.arange(10000, dtype=torch.int64) + 10**12).to(dev)
+  hip.kv_translate(kv, more, torch.empty(10000, dtype=torch.int64, device=dev), True)
+  assert int(kv['overflow'].item()) == 1
+
+
+@pytest.mark.gpu
+def test_kv_embeddings_match_the_oracle_on_the_gpu():
+  est, cfg, batches, st = _run('cuda:0')
+  _evaluate_and_reload(est, cfg, batches, st, 'cuda:0')

@@ -635,6 +635,12 @@ if __name__ == '__main__':
   write(din_sequence_features_taobao(batch_size=128, scale=0.01, seq_len=12), 'din_sequence_features_taobao_small.config')
   write(deepfm_backbone_criteo(hash_bucket_size=1000, batch_size=256), 'deepfm_backbone_criteo_small.config')
   write(xdeepfm_backbone_taobao(), 'xdeepfm_taobao.config')
+  # hash-table (ev_params) embeddings: C1..C4 keyed by the full 63-bit hash, rows created on first sight
+  cfg = deepfm_criteo(hash_bucket_size=1000, batch_size=256)
+  for fc in cfg.feature_config.features:
+    if fc.input_names[0] in ('C1', 'C2', 'C3', 'C4'):
+      fc.ev_params.max_capacity = 4096
+  write(cfg, 'deepfm_kv_criteo_small.config')
   write(dlrm_backbone_criteo(bottom=(32, 16), top=(64, 32), hash_bucket_size=1000, batch_size=256), 'dlrm_backbone_criteo_small.config')
   write(wide_and_deep_backbone_criteo(hidden=(64, 32, 1), hash_bucket_size=1000, batch_size=256),
         'wide_and_deep_backbone_criteo_small.config')
