@@ -47,11 +47,10 @@ __device__ __forceinline__ float kv_init_value(uint64_t seed, int64_t key, int c
 
 __device__ __forceinline__ uint64_t kv_home(int64_t key, uint64_t mask) { return mix64(static_cast<uint64_t>(key)) & mask; }
 
-__global__ void __launch_bounds__(kBlock)
-kv_insert_kernel(const int64_t* __restrict__ ids, int64_t n, int64_t* keys, int32_t* rows, uint64_t mask,
-                 int32_t* next_row, int32_t capacity, float* __restrict__ var, int dim, uint64_t seed, float mean,
-                 float stddev, int32_t* overflow) {
-  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+__device__ __forceinline__ void kv_insert_one(int64_t i, const int64_t* __restrict__ ids, int64_t n, int64_t* keys,
+                                              int32_t* rows, uint64_t mask, int32_t* next_row, int32_t capacity,
+                                              float* __restrict__ var, int dim, uint64_t seed, float mean, float stddev,
+                                              int32_t* overflow) {
   if (i >= n) return;
   const int64_t key = ids[i];
   if (key < 0) return;  // ('' / padding: no row)
@@ -76,9 +75,16 @@ kv_insert_kernel(const int64_t* __restrict__ ids, int64_t n, int64_t* keys, int3
 }
 
 __global__ void __launch_bounds__(kBlock)
-kv_find_kernel(const int64_t* __restrict__ ids, int64_t n, const int64_t* __restrict__ keys,
-               const int32_t* __restrict__ rows, uint64_t mask, int64_t* __restrict__ out) {
-  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+kv_insert_kernel(const int64_t* __restrict__ ids, int64_t n, int64_t* keys, int32_t* rows, uint64_t mask,
+                 int32_t* next_row, int32_t capacity, float* __restrict__ var, int dim, uint64_t seed, float mean,
+                 float stddev, int32_t* overflow) {
+  kv_insert_one(static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x, ids, n, keys, rows, mask, next_row, capacity, var,
+                dim, seed, mean, stddev, overflow);
+}
+
+__device__ __forceinline__ void kv_find_one(int64_t i, const int64_t* __restrict__ ids, int64_t n,
+                                            const int64_t* __restrict__ keys, const int32_t* __restrict__ rows,
+                                            uint64_t mask, int64_t* __restrict__ out) {
   if (i >= n) return;
   const int64_t key = ids[i];
   int64_t r = -1;
@@ -94,6 +100,40 @@ kv_find_kernel(const int64_t* __restrict__ ids, int64_t n, const int64_t* __rest
     }
   }
   out[i] = r;
+}
+
+__global__ void __launch_bounds__(kBlock)
+kv_find_kernel(const int64_t* __restrict__ ids, int64_t n, const int64_t* __restrict__ keys,
+               const int32_t* __restrict__ rows, uint64_t mask, int64_t* __restrict__ out) {
+  kv_find_one(static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x, ids, n, keys, rows, mask, out);
+}
+
+// All hash-table lookups of a model in one grid (a model with 26 hash-table features would otherwise pay 52 launches
+// per step): workgroup b serves job j with blk_start[j] <= b < blk_start[j + 1] (descriptors in device memory).
+__device__ __forceinline__ int kv_job_of(const int32_t* __restrict__ blk_start, int n_jobs, int b) {
+  int lo = 0, hi = n_jobs - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (blk_start[mid] <= b) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+__global__ void __launch_bounds__(kBlock)
+kv_insert_multi_kernel(const er_kv_job* __restrict__ jobs, const int32_t* __restrict__ blk_start, int n_jobs) {
+  const int j = kv_job_of(blk_start, n_jobs, blockIdx.x);
+  const er_kv_job q = jobs[j];
+  kv_insert_one(static_cast<int64_t>(blockIdx.x - blk_start[j]) * kBlock + threadIdx.x, q.ids, q.n, q.map_keys, q.map_rows,
+                static_cast<uint64_t>(q.map_slots - 1), q.next_row, q.capacity, q.var, q.dim, q.seed, q.init_mean,
+                q.init_stddev, q.overflow);
+}
+
+__global__ void __launch_bounds__(kBlock)
+kv_find_multi_kernel(const er_kv_job* __restrict__ jobs, const int32_t* __restrict__ blk_start, int n_jobs) {
+  const int j = kv_job_of(blk_start, n_jobs, blockIdx.x);
+  const er_kv_job q = jobs[j];
+  kv_find_one(static_cast<int64_t>(blockIdx.x - blk_start[j]) * kBlock + threadIdx.x, q.ids, q.n, q.map_keys, q.map_rows,
+              static_cast<uint64_t>(q.map_slots - 1), q.rows_out);
 }
 
 // export: (key, row) of every occupied slot, compacted in slot order (the host sorts by key)
@@ -130,6 +170,19 @@ int er_kv_translate(const int64_t* ids, int64_t n, int64_t* map_keys, int32_t* m
   }
   hipLaunchKernelGGL(er::kv_find_kernel, dim3(er::blocks_for(n)), dim3(er::kBlock), 0, s, ids, n, map_keys, map_rows, mask,
                      rows_out);
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
+int er_kv_translate_multi(const er_kv_job* jobs_dev, const int32_t* blk_start_dev, int n_jobs, int total_blocks, int insert,
+                          er_stream_t stream) {
+  ER_REQUIRE(jobs_dev && blk_start_dev && n_jobs >= 1 && total_blocks >= 1, "er_kv_translate_multi: bad arguments");
+  hipStream_t s = er::as_stream(stream);
+  if (insert) {
+    hipLaunchKernelGGL(er::kv_insert_multi_kernel, dim3(total_blocks), dim3(er::kBlock), 0, s, jobs_dev, blk_start_dev, n_jobs);
+    ER_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(er::kv_find_multi_kernel, dim3(total_blocks), dim3(er::kBlock), 0, s, jobs_dev, blk_start_dev, n_jobs);
   ER_LAUNCH_CHECK();
   return 0;
 }

@@ -346,10 +346,10 @@ class FeatureColumnParser(object):
       self._sequence_columns[feature_name] = fc
 
   def _ev_params_of(self, config):
-    """The feature's own `ev_params`, else the model-level ones (feature_column.py:212-219)."""
-    if config.HasField('ev_params'):
-      return config.ev_params
-    return self._global_ev_params
+    """The feature's own `ev_params`.  Model-level ev_params (feature_column.py:212-219) have been written into the
+    hashed IdFeatures' configs by the estimator - the columns they turn into hash tables here; the other column kinds
+    (raw-feature projections, vocab / identity ids, tags, sequences) keep dense tables."""
+    return config.ev_params if config.HasField('ev_params') else None
 
   def _add_wide_embedding_column(self, fc, config):
     """Wide column = dim-`wide_output_dim` embedding with `sum` combiner (feature_column.py:596-623)."""

@@ -16,6 +16,14 @@ import numpy as np
 import torch
 
 
+class KvJob(ctypes.Structure):
+  """er_kv_job (include/easyrec_hip.h)"""
+  _fields_ = [('ids', ctypes.c_void_p), ('n', ctypes.c_int64), ('map_keys', ctypes.c_void_p), ('map_rows', ctypes.c_void_p),
+              ('map_slots', ctypes.c_int64), ('next_row', ctypes.c_void_p), ('var', ctypes.c_void_p), ('seed', ctypes.c_uint64),
+              ('rows_out', ctypes.c_void_p), ('overflow', ctypes.c_void_p), ('capacity', ctypes.c_int32), ('dim', ctypes.c_int32),
+              ('init_mean', ctypes.c_float), ('init_stddev', ctypes.c_float)]
+
+
 class CastDesc(ctypes.Structure):
   """er_cast_desc (include/easyrec_hip.h)"""
   _fields_ = [('src', ctypes.c_void_p), ('dst', ctypes.c_void_p), ('rows', ctypes.c_int64), ('cols', ctypes.c_int32),
@@ -1045,6 +1053,28 @@ class HipBackend(object):
                                       _p(kv['var']), ctypes.c_int32(kv['dim']), ctypes.c_uint64(kv['seed']),
                                       ctypes.c_float(kv['mean']), ctypes.c_float(kv['stddev']), int(bool(insert)),
                                       _p(rows_out), _p(kv['overflow']), _stream()), 'er_kv_translate')
+
+  def kv_jobs_create(self, jobs):
+    """jobs: [(kv, ids, rows_out)] -> the device-resident descriptor table of er_kv_translate_multi (built once)."""
+    n = len(jobs)
+    arr = (KvJob * n)()
+    starts = [0]
+    for i, (kv, ids, rows_out) in enumerate(jobs):
+      assert ids.dtype == torch.int64 and rows_out.dtype == torch.int64 and ids.is_contiguous() and rows_out.is_contiguous()
+      arr[i] = KvJob(ids.data_ptr(), ids.numel(), kv['keys'].data_ptr(), kv['rows'].data_ptr(), kv['keys'].numel(),
+                     kv['next_row'].data_ptr(), kv['var'].data_ptr(), kv['seed'], rows_out.data_ptr(),
+                     kv['overflow'].data_ptr(), kv['capacity'], kv['dim'], kv['mean'], kv['stddev'])
+      starts.append(starts[-1] + (ids.numel() + 255) // 256)
+    dev = jobs[0][1].device
+    table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+    blk = torch.tensor(starts, dtype=torch.int32, device=dev)
+    return {'table': table, 'blk_start': blk, 'n': n, 'blocks': starts[-1], 'jobs': jobs}
+
+  def kv_translate_multi(self, handle, insert):
+    if handle['blocks'] == 0:
+      return
+    self._ck(self.lib.er_kv_translate_multi(_p(handle['table']), _p(handle['blk_start']), handle['n'], handle['blocks'],
+                                            int(bool(insert)), _stream()), 'er_kv_translate_multi')
 
   def kv_export(self, kv):
     """(keys ascending, arena rows) of the table's materialised ids (host sync)."""

@@ -137,6 +137,7 @@ class EmbeddingEngine(object):
     self._flush_stream = None
     self.train_mode = True  # (the estimator clears it for is_training=False: no hash-table rows are created then)
     self.kv_tables = {}  # table name -> map state (kernels.kv_create) of the hash-table backed tables
+    self._kv_handle = None
     self.kv_jobs = []    # (table name, id array, arena-row array) translated before every lookup
     self._window_pending = False  # launched on the second stream, not joined yet
     self._window_started = False  # this step's window has been launched (the row update must not launch it again)
@@ -282,8 +283,9 @@ class EmbeddingEngine(object):
     zeros (row -1) in predict() / evaluate() (feature_column_v2.py:3487-3493)."""
     be = kernels.hip()
     insert = self.train_mode and not self.inference
-    for name, ids, rows in self.kv_jobs:
-      be.kv_translate(self.kv_tables[name], ids, rows, insert)
+    if self._kv_handle is None:  # every lookup of every hash-table table in one pair of launches
+      self._kv_handle = be.kv_jobs_create([(self.kv_tables[name], ids, rows) for name, ids, rows in self.kv_jobs])
+    be.kv_translate_multi(self._kv_handle, insert)
 
   def check_kv_overflow(self):
     for name, kv in self.kv_tables.items():

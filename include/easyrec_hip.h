@@ -356,6 +356,24 @@ int er_cross_v2_epilogue_bwd(const float* x0, const float* x, const float* u, co
 int er_kv_translate(const int64_t* ids, int64_t n, int64_t* map_keys, int32_t* map_rows, int64_t map_slots,
                     int32_t* next_row, int32_t capacity, float* var, int32_t dim, uint64_t seed, float init_mean,
                     float init_stddev, int insert, int64_t* rows_out, int32_t* overflow, er_stream_t stream);
+/* every hash-table lookup of a model in two launches: jobs_dev / blk_start_dev are DEVICE arrays (n_jobs descriptors and
+ * n_jobs + 1 workgroup offsets, job j owning ceil(n_j / 256) workgroups), written once when the model is built */
+typedef struct {
+  const int64_t* ids;
+  int64_t n;
+  int64_t* map_keys;
+  int32_t* map_rows;
+  int64_t map_slots;
+  int32_t* next_row;
+  float* var;
+  uint64_t seed;
+  int64_t* rows_out;
+  int32_t* overflow;
+  int32_t capacity, dim;
+  float init_mean, init_stddev;
+} er_kv_job;
+int er_kv_translate_multi(const er_kv_job* jobs_dev, const int32_t* blk_start_dev, int n_jobs, int total_blocks, int insert,
+                          er_stream_t stream);
 int er_kv_export(const int64_t* map_keys, const int32_t* map_rows, int64_t map_slots, int64_t* out_keys,
                  int32_t* out_rows, int32_t* count, er_stream_t stream);
 /* ---- K9b: CIN, xDeepFM's compressed interaction network (reference layers/keras/interaction.py:370-409) ----

@@ -799,6 +799,13 @@ class RefBackend(object):
       out.append(-1 if r is None else r)
     rows_out.view(-1).copy_(torch.tensor(out, dtype=torch.int64))
 
+  def kv_jobs_create(self, jobs):
+    return {'jobs': jobs}
+
+  def kv_translate_multi(self, handle, insert):
+    for kv, ids, rows_out in handle['jobs']:
+      self.kv_translate(kv, ids, rows_out, insert)
+
   def kv_export(self, kv):
     items = sorted((k, r) for k, r in kv['map'].items() if r >= 0)
     return (torch.tensor([k for k, _ in items], dtype=torch.int64), torch.tensor([r for _, r in items], dtype=torch.int64))
