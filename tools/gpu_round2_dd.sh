@@ -1,10 +1,10 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
-O=gpurun_out/r02dd; mkdir -p $O
+O=gpurun_out/r02ee; mkdir -p $O
 timeout 60 python -c "import torch; x=torch.ones(1<<20,device='cuda'); print('canary', float(x.sum()))" 2>&1 | tail -1 | tee $O/canary0.txt
 if ! grep -q 'canary 1048576' $O/canary0.txt; then echo 'bad box'; exit 0; fi
 timeout 300 python -m pytest tests/test_kv_embedding.py tests/test_reference_layers.py tests/test_models_gpu.py -m gpu -q --tb=short --timeout 150 2>&1 | grep -E "passed|failed|^E  |FAILED" | head -20
-( time timeout 900 python -m pytest tests -m gpu -q --tb=line --timeout 200 2>&1 | tail -4 ) 2>&1 | grep -E "passed|failed|real|FAILED" | tee $O/suite.log
+( time timeout 900 python -m pytest tests/test_kv_embedding.py tests/test_deepfm_gpu.py -m gpu -q --tb=line --timeout 200 2>&1 | tail -4 ) 2>&1 | grep -E "passed|failed|real|FAILED" | tee $O/suite.log
 line() { python -c "
 import sys,json
 try:
@@ -19,7 +19,7 @@ import sys; sys.path.insert(0, '.')
 from easyrec_amd.utils import config_util
 cfg = config_util.get_configs_from_pipeline_file('configs/deepfm_criteo.config')
 cfg.model_config.ev_params.max_capacity = 1 << 20
-config_util.save_pipeline_config(cfg, 'gpurun_out/r02dd/deepfm_criteo_kv.config')
+config_util.save_pipeline_config(cfg, 'gpurun_out/r02ee/deepfm_criteo_kv.config')
 PY
 echo "--- deepfm kv (1 M-row arenas)" | tee -a $O/lines.log
 timeout 300 python bench.py --no_cpu_baseline --config $O/deepfm_criteo_kv.config --steady_steps 256 --precondition 256 > $O/kv.out 2>&1; grep '^{' $O/kv.out | tail -1 | tee -a $O/bench_lines.jsonl | line | tee -a $O/lines.log; grep -E "Error|Traceback" -A3 $O/kv.out | head -8
