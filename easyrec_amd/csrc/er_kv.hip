@@ -123,7 +123,8 @@ __global__ void __launch_bounds__(kBlock)
 kv_insert_multi_kernel(const er_kv_job* __restrict__ jobs, const int32_t* __restrict__ blk_start, int n_jobs) {
   const int j = kv_job_of(blk_start, n_jobs, blockIdx.x);
   const er_kv_job q = jobs[j];
-  kv_insert_one(static_cast<int64_t>(blockIdx.x - blk_start[j]) * kBlock + threadIdx.x, q.ids, q.n, q.map_keys, q.map_rows,
+  const int64_t n = q.n_limit ? (static_cast<int64_t>(*q.n_limit) < q.n ? static_cast<int64_t>(*q.n_limit) : q.n) : q.n;
+  kv_insert_one(static_cast<int64_t>(blockIdx.x - blk_start[j]) * kBlock + threadIdx.x, q.ids, n, q.map_keys, q.map_rows,
                 static_cast<uint64_t>(q.map_slots - 1), q.next_row, q.capacity, q.var, q.dim, q.seed, q.init_mean,
                 q.init_stddev, q.overflow);
 }
@@ -132,7 +133,8 @@ __global__ void __launch_bounds__(kBlock)
 kv_find_multi_kernel(const er_kv_job* __restrict__ jobs, const int32_t* __restrict__ blk_start, int n_jobs) {
   const int j = kv_job_of(blk_start, n_jobs, blockIdx.x);
   const er_kv_job q = jobs[j];
-  kv_find_one(static_cast<int64_t>(blockIdx.x - blk_start[j]) * kBlock + threadIdx.x, q.ids, q.n, q.map_keys, q.map_rows,
+  const int64_t n = q.n_limit ? (static_cast<int64_t>(*q.n_limit) < q.n ? static_cast<int64_t>(*q.n_limit) : q.n) : q.n;
+  kv_find_one(static_cast<int64_t>(blockIdx.x - blk_start[j]) * kBlock + threadIdx.x, q.ids, n, q.map_keys, q.map_rows,
               static_cast<uint64_t>(q.map_slots - 1), q.rows_out);
 }
 

@@ -90,6 +90,9 @@ class FeatureSchema(object):
           self.int_single[name] = {'col': len(self.int_single), 'num_buckets': nb}
       elif ft == FeatureConfig.TagFeature:
         hb = int(fc.hash_bucket_size) if fc.HasField('hash_bucket_size') and fc.hash_bucket_size > 0 else None
+        if fc.HasField('ev_params'):
+          assert hb is not None, 'ev_params on %s: only hashed TagFeatures are hash-table backed here' % name
+          hb = MAX_HASH_BUCKET_SIZE
         weighted = len(fc.input_names) > 1 or fc.HasField('kv_separator')
         self.tags[name] = {'cap': self.batch_size * max_tag_len, 'weighted': weighted, 'hash_buckets': hb}
       elif ft == FeatureConfig.SequenceFeature:

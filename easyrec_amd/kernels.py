@@ -21,7 +21,7 @@ class KvJob(ctypes.Structure):
   _fields_ = [('ids', ctypes.c_void_p), ('n', ctypes.c_int64), ('map_keys', ctypes.c_void_p), ('map_rows', ctypes.c_void_p),
               ('map_slots', ctypes.c_int64), ('next_row', ctypes.c_void_p), ('var', ctypes.c_void_p), ('seed', ctypes.c_uint64),
               ('rows_out', ctypes.c_void_p), ('overflow', ctypes.c_void_p), ('capacity', ctypes.c_int32), ('dim', ctypes.c_int32),
-              ('init_mean', ctypes.c_float), ('init_stddev', ctypes.c_float)]
+              ('init_mean', ctypes.c_float), ('init_stddev', ctypes.c_float), ('n_limit', ctypes.c_void_p)]
 
 
 class CastDesc(ctypes.Structure):
@@ -1055,15 +1055,20 @@ class HipBackend(object):
                                       _p(rows_out), _p(kv['overflow']), _stream()), 'er_kv_translate')
 
   def kv_jobs_create(self, jobs):
-    """jobs: [(kv, ids, rows_out)] -> the device-resident descriptor table of er_kv_translate_multi (built once)."""
+    """jobs: [(kv, ids, rows_out[, n_limit])] -> the device-resident descriptor table of er_kv_translate_multi (built
+    once).  n_limit: int32 device scalar = the number of valid ids of the step (ragged lists in fixed buffers)."""
     n = len(jobs)
     arr = (KvJob * n)()
     starts = [0]
-    for i, (kv, ids, rows_out) in enumerate(jobs):
+    for i, job in enumerate(jobs):
+      kv, ids, rows_out = job[:3]
+      limit = job[3] if len(job) > 3 else None
+      assert limit is None or (limit.dtype == torch.int32 and limit.numel() == 1)
       assert ids.dtype == torch.int64 and rows_out.dtype == torch.int64 and ids.is_contiguous() and rows_out.is_contiguous()
       arr[i] = KvJob(ids.data_ptr(), ids.numel(), kv['keys'].data_ptr(), kv['rows'].data_ptr(), kv['keys'].numel(),
                      kv['next_row'].data_ptr(), kv['var'].data_ptr(), kv['seed'], rows_out.data_ptr(),
-                     kv['overflow'].data_ptr(), kv['capacity'], kv['dim'], kv['mean'], kv['stddev'])
+                     kv['overflow'].data_ptr(), kv['capacity'], kv['dim'], kv['mean'], kv['stddev'],
+                     0 if limit is None else limit.data_ptr())
       starts.append(starts[-1] + (ids.numel() + 255) // 256)
     dev = jobs[0][1].device
     table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)

@@ -284,7 +284,7 @@ class EmbeddingEngine(object):
     be = kernels.hip()
     insert = self.train_mode and not self.inference
     if self._kv_handle is None:  # every lookup of every hash-table table in one pair of launches
-      self._kv_handle = be.kv_jobs_create([(self.kv_tables[name], ids, rows) for name, ids, rows in self.kv_jobs])
+      self._kv_handle = be.kv_jobs_create([(self.kv_tables[job[0]],) + tuple(job[1:]) for job in self.kv_jobs])
     be.kv_translate_multi(self._kv_handle, insert)
 
   def check_kv_overflow(self):
@@ -837,7 +837,7 @@ def declare_lookup(eng, features, column, scope, gkey, col, n_out_rows, seq=Fals
   kv_capacity = None
   if ev is not None:
     assert cat.kind == 'hash' and not seq and not column.shared_name, \
-        'ev_params on %s: hash-table embeddings cover single-valued hashed IdFeatures' % column.raw_name
+        'ev_params on %s: hash-table embeddings cover hashed IdFeatures and TagFeatures' % column.raw_name
     kv_capacity = int(ev.max_capacity) if ev.HasField('max_capacity') else int(os.environ.get('EASYREC_AMD_KV_CAPACITY', 1 << 22))
     assert ev.filter_freq == 0 and ev.steps_to_live == 0, 'ev_params.filter_freq / steps_to_live are not supported'
   eng.declare_table(table_name, rows, column.dimension, column.initializer, kv_capacity=kv_capacity)
@@ -861,7 +861,13 @@ def declare_lookup(eng, features, column, scope, gkey, col, n_out_rows, seq=Fals
     return
   if fname in schema.tags:
     t = features.tags[fname]
-    eng.add_lookup(gkey, table_name, t['ids'], t['offsets'], t['weights'], col, column.combiner, B,
+    tag_ids = t['ids']
+    if kv_capacity is not None:
+      # the buffer holds offsets[B] ids of this step (the tail is stale): only those are translated
+      rows_buf = torch.full_like(tag_ids, -1)
+      eng.kv_jobs.append((table_name, tag_ids, rows_buf, t['offsets'][B:B + 1]))
+      tag_ids = rows_buf
+    eng.add_lookup(gkey, table_name, tag_ids, t['offsets'], t['weights'], col, column.combiner, B,
                    t['ids'].numel(), fname)
     return
   if fname in schema.seqs:
@@ -870,7 +876,7 @@ def declare_lookup(eng, features, column, scope, gkey, col, n_out_rows, seq=Fals
     raise NotImplementedError('sequence feature %s as combined column' % fname)
   ids = features.ids_of(fname)
   if kv_capacity is not None:
-    assert fname in schema.hash_single, 'ev_params on %s: hash-table embeddings cover single-valued hashed IdFeatures' % fname
+    assert fname in schema.hash_single, 'ev_params on %s: hash-table embeddings cover hashed IdFeatures and TagFeatures' % fname
     rows_buf = torch.full((B,), -1, dtype=torch.int64, device=eng.device)  # arena rows of this step's ids
     eng.kv_jobs.append((table_name, ids, rows_buf))
     ids = rows_buf

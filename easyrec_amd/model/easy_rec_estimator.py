@@ -62,7 +62,8 @@ class EasyRecEstimator(object):
       # model-level ev_params apply to every feature (model/easy_rec_model.py:64-66): written into the hashed
       # IdFeatures' own configs so that the schema, the generators and the oracle all read one place
       for fc in self.feature_configs:
-        if fc.feature_type == fc.IdFeature and fc.HasField('hash_bucket_size') and not fc.HasField('ev_params'):
+        if fc.feature_type in (fc.IdFeature, fc.TagFeature) and fc.HasField('hash_bucket_size') and \
+            fc.hash_bucket_size > 0 and not fc.HasField('ev_params'):
           fc.ev_params.CopyFrom(cfg.model_config.ev_params)
     self.schema = FeatureSchema(cfg.data_config, self.feature_configs, batch_size=batch_size,
                                 **(schema_kwargs or {}))

@@ -371,6 +371,8 @@ typedef struct {
   int32_t* overflow;
   int32_t capacity, dim;
   float init_mean, init_stddev;
+  const int32_t* n_limit; /* NULL, or a device count: only the first min(n, *n_limit) ids are valid (a ragged id list
+                             in a fixed-capacity buffer: the number of ids of this step) */
 } er_kv_job;
 int er_kv_translate_multi(const er_kv_job* jobs_dev, const int32_t* blk_start_dev, int n_jobs, int total_blocks, int insert,
                           er_stream_t stream);

@@ -803,8 +803,10 @@ class RefBackend(object):
     return {'jobs': jobs}
 
   def kv_translate_multi(self, handle, insert):
-    for kv, ids, rows_out in handle['jobs']:
-      self.kv_translate(kv, ids, rows_out, insert)
+    for job in handle['jobs']:
+      kv, ids, rows_out = job[:3]
+      n = ids.numel() if len(job) < 4 or job[3] is None else min(ids.numel(), int(job[3].item()))
+      self.kv_translate(kv, ids.view(-1)[:n], rows_out.view(-1)[:n], insert)
 
   def kv_export(self, kv):
     items = sorted((k, r) for k, r in kv['map'].items() if r >= 0)

@@ -350,9 +350,13 @@ class OracleTrainer(object):
       elif fc.feature_type in (fc.TagFeature, fc.LookupFeature) or (
           fc.feature_type == fc.ComboFeature and ('tag/%s/ids' % n) in batch):
         # (LookupFeature: the selected map values arrive from the input stage as a ragged id list, input.py:941-1000)
-        table = V.get(self._column_var_name(scope, fc, wide))
+        var_name = self._column_var_name(scope, fc, wide)
+        tag_ids = batch['tag/%s/ids' % n]
+        if var_name in self.kv:
+          tag_ids = self._kv_rows(var_name, tag_ids)
+        table = V.get(var_name)
         w = batch.get('tag/%s/weights' % n)
-        e = self._lookup_ragged(table, batch['tag/%s/ids' % n], batch['tag/%s/offsets' % n], w,
+        e = self._lookup_ragged(table, tag_ids, batch['tag/%s/offsets' % n], w,
                                 'sum' if wide else fc.combiner)
         outs.append((e, True))
       else:

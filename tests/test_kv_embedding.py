@@ -12,14 +12,17 @@ from easyrec_amd.utils import config_util
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(device, steps=3, B=64):
+def _run(device, steps=3, B=64, config='deepfm_kv_criteo_small.config', n_kv=8, row_tol=2e-4):
   from easyrec_amd.input.criteo_synthetic import SyntheticCriteo
+  from easyrec_amd.input.synthetic import SyntheticBatches
   from easyrec_amd.model.easy_rec_estimator import EasyRecEstimator
   from oracle.model_oracle import OracleTrainer
-  cfg = config_util.get_configs_from_pipeline_file(os.path.join(ROOT, 'configs', 'deepfm_kv_criteo_small.config'))
+  cfg = config_util.get_configs_from_pipeline_file(os.path.join(ROOT, 'configs', config))
   est = EasyRecEstimator(cfg, device=device, batch_size=B, seed=4).build()
   kv_names = sorted(est.engine.kv_tables)
-  assert len(kv_names) == 8, kv_names  # C1..C4, deep and wide
+  assert len(kv_names) == n_kv, kv_names  # (deepfm: C1..C4, deep and wide)
+  if 'criteo' not in config:
+    SyntheticCriteo = SyntheticBatches  # noqa: N806  (schema-driven generator: tag lists)
   state0 = est.state_dict()
   assert all(state0[n + '/keys'].size == 0 and state0[n].shape[0] == 0 for n in kv_names)
   orc = OracleTrainer(cfg, state0, batch_size=B)
@@ -35,9 +38,10 @@ def _run(device, steps=3, B=64):
     keys, rows = orc.kv_state(n)
     assert np.array_equal(st[n + '/keys'], keys), n
     assert keys.size > 10 and st[n].shape == rows.shape
-    assert np.allclose(st[n], rows, rtol=2e-4, atol=2e-6), n
+    # (after a few Adam steps: 2e-4 of the table's scale - elements whose gradient is rounding noise move by O(lr))
+    assert float(np.abs(st[n] - rows).max()) <= row_tol * float(np.abs(rows).max()) + 1e-7, (n, float(np.abs(st[n] - rows).max()))
     _, m_rows = orc.kv_state(n, orc.slots[n + '/m'])
-    assert float(np.abs(st[n + '/m'] - m_rows).max()) <= 2e-4 * float(np.abs(m_rows).max()) + 1e-9, n
+    assert float(np.abs(st[n + '/m'] - m_rows).max()) <= row_tol * float(np.abs(m_rows).max()) + 1e-9, n
   return est, cfg, batches, st
 
 
@@ -62,6 +66,14 @@ def _evaluate_and_reload(est, cfg, batches, st, device):
 def test_kv_embeddings_match_the_oracle_on_the_stand_in_backend(ref_backend):
   est, cfg, batches, st = _run('cpu')
   _evaluate_and_reload(est, cfg, batches, st, 'cpu')
+
+
+def test_kv_tag_features_match_the_oracle_on_the_stand_in_backend(ref_backend):
+  """MMoE over the Taobao schema with hash-table backed IdFeatures AND TagFeatures (ragged id lists in fixed-capacity
+  buffers: only the step's ids are translated)."""
+  # (row tolerance 2e-3 of the table's scale: MMoE's gates make some row gradients rounding noise, which Adam turns
+  # into O(lr) moves - the same allowance as the MMoE model tests)
+  _run('cpu', config='mmoe_kv_taobao_small.config', n_kv=4, row_tol=2e-3)
 
 
 def test_row_initialiser_is_a_pure_function_of_its_key():
@@ -120,3 +132,8 @@ def test_kv_translate_kernel():
 def test_kv_embeddings_match_the_oracle_on_the_gpu():
   est, cfg, batches, st = _run('cuda:0')
   _evaluate_and_reload(est, cfg, batches, st, 'cuda:0')
+
+
+@pytest.mark.gpu
+def test_kv_tag_features_match_the_oracle_on_the_gpu():
+  _run('cuda:0', config='mmoe_kv_taobao_small.config', n_kv=4, row_tol=2e-3)

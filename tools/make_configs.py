@@ -641,6 +641,11 @@ if __name__ == '__main__':
     if fc.input_names[0] in ('C1', 'C2', 'C3', 'C4'):
       fc.ev_params.max_capacity = 4096
   write(cfg, 'deepfm_kv_criteo_small.config')
+  cfg = mmoe_taobao(batch_size=128, scale=0.01)
+  for fc in cfg.feature_config.features:
+    if fc.input_names[0] in ('adgroup_id', 'user_id', 'tag_category_list', 'tag_brand_list'):
+      fc.ev_params.max_capacity = 2048
+  write(cfg, 'mmoe_kv_taobao_small.config')
   write(dlrm_backbone_criteo(bottom=(32, 16), top=(64, 32), hash_bucket_size=1000, batch_size=256), 'dlrm_backbone_criteo_small.config')
   write(wide_and_deep_backbone_criteo(hidden=(64, 32, 1), hash_bucket_size=1000, batch_size=256),
         'wide_and_deep_backbone_criteo_small.config')
