@@ -4,7 +4,8 @@ Input: (history [B, L, E], lengths [B], target [B, E']) - an `input_layer { outp
 block.  Attention scores = MLP `din_attention` over [q, h, q - h, q * h] with the last layer forced to bias / no
 BatchNorm / linear (:19-22); padded positions get -2^32 + 1; `attention_normalizer` softmax (default) or sigmoid of
 score / sqrt(E); output = scores @ history (+ the target when `need_target_feature`).  A target narrower than the
-history is zero-padded for the attention and the pooled history is cut back to the target's width (:31-40, 60-61).
+history is zero-padded for the attention (and appended in that padded form) and the pooled history is cut back to the
+target's width (:31-40, 60-64).
 
 Kernels: `er_din_concat` builds the MLP input in one pass, `er_din_pool` does mask + softmax + pooling (forward and
 backward); the sigmoid normaliser (no shipped hot-path config uses it) is plain elementwise torch.
@@ -57,5 +58,7 @@ class DIN(object):
     if q_dim < E:
       pooled = pooled[:, :q_dim]
     if self.config.need_target_feature:
-      pooled = torch.cat([pooled, query], dim=-1)
+      # (the reference re-binds `query` to its zero-padded form at :36, so a narrower target is appended PADDED to the
+      # history's width - pinned by tests/test_reference_layers.py against the reference's own DIN.call)
+      pooled = torch.cat([pooled, q_att], dim=-1)
     return pooled

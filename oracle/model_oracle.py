@@ -793,7 +793,7 @@ class OracleTrainer(object):
       assert cfg.attention_normalizer == 'sigmoid'
       scores = torch.sigmoid(scores / (E ** 0.5))
     out = torch.matmul(scores, keys[:, :, :qd] if qd < E else keys).reshape(B, qd)
-    return torch.cat([out, query], dim=-1) if cfg.need_target_feature else out
+    return torch.cat([out, q], dim=-1) if cfg.need_target_feature else out  # (q: the PADDED target, din.py:36, 63)
 
   def _seq_block(self, V, batch, group_name, scope):
     """input_layer { output_seq_and_normal_feature } (layers/common_layers.py:119-131, layers/input_layer.py:164-200):

@@ -10,6 +10,7 @@ TensorFlow cannot be installed here, but several of the reference's layers are a
   easy_rec/python/layers/mmoe.py               MMOE.__call__          (experts, softmax gates, mixture per task)
   easy_rec/python/model/dcn.py                 DCN._cross_net         (DCN-v1 cross layers)
   easy_rec/python/layers/keras/blocks.py       MLP.__init__ / call    (which sub-layers a backbone MLP consists of)
+  easy_rec/python/layers/keras/din.py          DIN.__init__ / call    (target attention block: softmax and sigmoid)
 This script executes THOSE FUNCTIONS, unmodified, against a small stand-in for the `tensorflow` module (numpy, fp64)
 that implements the documented semantics of the ~25 ops they call (stack, reduce_sum, matmul(transpose_b), band_part,
 boolean_mask, tile, sequence_mask, ...), a `keras.layers.Dense` whose kernel / bias are set by this script, and
@@ -39,6 +40,29 @@ def _arr(x):
   return np.asarray(x, dtype=np.float64) if not isinstance(x, np.ndarray) or x.dtype != np.bool_ else x
 
 
+class _Shape(tuple):
+  """tf.TensorShape's `as_list()` / `ndims` on top of a numpy shape"""
+
+  def as_list(self):
+    return list(self)
+
+  @property
+  def ndims(self):
+    return len(self)
+
+
+class _Tensor(np.ndarray):
+  """a numpy array whose `.shape` also answers TensorShape calls (the reference reads `keys.shape.as_list()`)"""
+
+  @property
+  def shape(self):
+    return _Shape(np.ndarray.shape.__get__(self))
+
+
+def _tensor(x):
+  return np.asarray(x, dtype=np.float64).view(_Tensor)
+
+
 class _Layer(object):
 
   def __init__(self, name=None, **kwargs):
@@ -49,8 +73,8 @@ class _Layer(object):
   def build(self, input_shape):
     self.built = True
 
-  def __call__(self, inputs, **kwargs):
-    return self.call(inputs, **kwargs)
+  def __call__(self, inputs, *args, **kwargs):  # (keras passes `training` positionally: din.py:45)
+    return self.call(inputs, *args, **kwargs)
 
 
 class _Dense(_Layer):
@@ -201,9 +225,13 @@ def make_tf():
   tf.cast = lambda x, dtype: np.asarray(x).astype(dtype)
   tf.boolean_mask = lambda t, mask: _arr(t)[np.asarray(mask).astype(bool)]  # row-major order of the kept elements
   tf.linalg = types.SimpleNamespace(band_part=_band_part)
-  tf.nn = types.SimpleNamespace(relu=lambda x, name=None: np.maximum(_arr(x), 0.0), softmax=_softmax)
+  tf.nn = types.SimpleNamespace(relu=lambda x, name=None: np.maximum(_arr(x), 0.0), softmax=_softmax,
+                                sigmoid=lambda x: 1.0 / (1.0 + np.exp(-_arr(x))))
   tf.layers = types.SimpleNamespace(dense=_layers_dense, batch_normalization=_layers_batch_normalization)
-  tf.sequence_mask = _sequence_mask
+  tf.sequence_mask = lambda lengths, maxlen=None, dtype=None: _sequence_mask(lengths, maxlen)
+  tf.pad = lambda x, paddings: np.pad(_arr(x), [tuple(p) for p in paddings])
+  tf.transpose = lambda x, perm: np.transpose(_arr(x), perm)
+  tf.squeeze = lambda x, axis=None: np.squeeze(_arr(x), axis=tuple(axis) if isinstance(axis, (list, tuple)) else axis)
   tf.math = types.SimpleNamespace(add=lambda a, b: _arr(a) + _arr(b))
 
   def get_variable(name=None, dtype=None, shape=None, **kw):
@@ -394,6 +422,41 @@ def main():
                   ('biased', dict(hidden_units=[4, 2], use_bias=True, use_final_bias=True, use_bn=False))):
     Dense.scope = 'mlp_%s/' % tag
     out['mlp_%s_out' % tag] = blocks.MLP(MlpParams(**kw), name='mlp_%s' % tag).call(x_mlp, training=True)
+  Dense.scope = ''
+  # keras DIN block: its attention MLP is the reference's own blocks.MLP (loaded above) under the name `din_attention`
+  class MlpPb(MlpParams):  # Parameter.make_from_pb(config.attention_dnn): the fields MLP reads, from the pb-like object
+
+    def __init__(self, pb):
+      kw = {k: getattr(pb, k) for k in ('hidden_units', 'activation', 'use_final_bn', 'use_final_bias', 'final_activation')
+            if getattr(pb, k, None) is not None}
+      MlpParams.__init__(self, **kw)
+
+  utils_mod = sys.modules['easy_rec.python.layers.utils']
+  utils_mod.Parameter = types.SimpleNamespace(make_from_pb=lambda pb: MlpPb(pb))
+  keras_pkg = sys.modules['easy_rec.python.layers.keras']
+  keras_pkg.MLP = blocks.MLP
+  sys.modules['easy_rec.python.utils.shape_utils'].get_shape_list = lambda t, rank=None: list(_arr(t).shape)
+  din_keras = load_reference('easy_rec/python/layers/keras/din.py', 'ref_keras_din')
+  Bk, Lk, Ek = 6, 5, 4
+  keys_k, query_k = rng.standard_normal((Bk, Lk, Ek)), rng.standard_normal((Bk, Ek))
+  query_small = rng.standard_normal((Bk, 3))  # a target narrower than the sequence embedding: padded with zeros
+  lens_k = np.array([5, 2, 4, 1, 5, 3], dtype=np.int64)
+  out['kdin_keys'], out['kdin_query'], out['kdin_query_small'], out['kdin_len'] = keys_k, query_k, query_small, lens_k
+  for tag, normalizer, need_target, q in (('softmax', 'softmax', True, query_k), ('sigmoid', 'sigmoid', False, query_k),
+                                          ('narrow', 'softmax', True, query_small)):
+    att = types.SimpleNamespace(hidden_units=[6, 1], activation='relu', use_final_bn=None, use_final_bias=None,
+                                final_activation=None)
+    pb = types.SimpleNamespace(attention_dnn=att, attention_normalizer=normalizer, need_target_feature=need_target)
+
+    class DinParams(object):
+      l2_regularizer = None
+
+      def get_pb_config(self):
+        return pb
+
+    Dense.scope = 'kdin_%s/' % tag
+    layer = din_keras.DIN(DinParams(), name='din')
+    out['kdin_%s_out' % tag] = np.asarray(layer.call((_tensor(keys_k), lens_k, _tensor(q)), training=True))
   Dense.scope = ''
   x_dcn = rng.standard_normal((7, 5))
   out['dcn_x'] = x_dcn

@@ -182,6 +182,29 @@ def test_keras_mlp_restatement(tag, text):
   _close(_oracle()._keras_mlp(_layer_vars(), _t('mlp_x'), cfg, 'mlp_%s' % tag, 0.0), _t('mlp_%s_out' % tag))
 
 
+@pytest.mark.parametrize('tag,normalizer,need_target,query', [('softmax', 'softmax', True, 'kdin_query'),
+                                                              ('sigmoid', 'sigmoid', False, 'kdin_query'),
+                                                              ('narrow', 'softmax', True, 'kdin_query_small')])
+def test_keras_din_restatement(tag, normalizer, need_target, query):
+  """layers/keras/din.py DIN: the attention MLP forced to (no final BatchNorm, final bias, linear), softmax or
+  sigmoid(score / sqrt(E)) normaliser, a target narrower than the sequence embedding zero-padded for the scores and
+  the keys cut back for the output, the target appended when need_target_feature."""
+  from google.protobuf import text_format
+
+  from easyrec_amd.protos import seq_encoder_pb2
+  cfg = seq_encoder_pb2.DINEncoder()
+  text_format.Merge("attention_dnn { hidden_units: [6, 1] activation: 'relu' } attention_normalizer: '%s' "
+                    'need_target_feature: %s' % (normalizer, 'true' if need_target else 'false'), cfg)
+  state = {k[len('var:kdin_%s/' % tag):]: G[k] for k in G.files if k.startswith('var:kdin_%s/' % tag)}
+  state = {'din_attention/' + k: v for k, v in state.items()}
+  for k in list(state):
+    if k.endswith('/bn/gamma'):
+      n = state[k].shape[0]
+      state[k[:-len('gamma')] + 'moving_mean'], state[k[:-len('gamma')] + 'moving_variance'] = np.zeros(n), np.ones(n)
+  got = _oracle()._keras_din(_vars(state), _t('kdin_keys'), torch.from_numpy(np.asarray(G['kdin_len'])), _t(query), cfg, 0.0)
+  _close(got, _t('kdin_%s_out' % tag))
+
+
 # ------------------------------------------------------------------------------------------------ the HIP kernels
 @pytest.mark.gpu
 def test_hip_kernels_against_the_reference_layers():
