@@ -25,6 +25,7 @@ Parity status.  PINNED by outputs of the reference's own code (tests/golden/refe
 tests/golden/make_reference_layer_vectors.py executing the reference's functions unmodified on a numpy stand-in for
 the tensorflow module; tests/test_reference_layers.py): layers/fm.py FM, keras FM / Cross (full, diag_scale, low rank,
 no bias) / CIN / DotInteraction (layers/keras/interaction.py), layers/dnn.py DNN, model/multi_tower_din.py din(),
+keras MLP (layers/keras/blocks.py), keras DIN (layers/keras/din.py), layers/sequence_feature_layer.py target_attention,
 layers/mmoe.py MMOE, model/dcn.py _cross_net, core/learning_schedules.py exponential_decay_with_burnin; hashing by
 TensorFlow's documented vectors; the embedding lookup by embed_test's vectors.  "Parity unpinned" (the reference's
 tests hold no numeric expectation, the code is TensorFlow's own and TensorFlow cannot run here): the loss

@@ -11,6 +11,8 @@ TensorFlow cannot be installed here, but several of the reference's layers are a
   easy_rec/python/model/dcn.py                 DCN._cross_net         (DCN-v1 cross layers)
   easy_rec/python/layers/keras/blocks.py       MLP.__init__ / call    (which sub-layers a backbone MLP consists of)
   easy_rec/python/layers/keras/din.py          DIN.__init__ / call    (target attention block: softmax and sigmoid)
+  easy_rec/python/layers/sequence_feature_layer.py  SequenceFeatureLayer.target_attention (with / without the key,
+                                                a key narrower than the history under allow_key_transform)
 This script executes THOSE FUNCTIONS, unmodified, against a small stand-in for the `tensorflow` module (numpy, fp64)
 that implements the documented semantics of the ~25 ops they call (stack, reduce_sum, matmul(transpose_b), band_part,
 boolean_mask, tile, sequence_mask, ...), a `keras.layers.Dense` whose kernel / bias are set by this script, and
@@ -458,11 +460,31 @@ def main():
     layer = din_keras.DIN(DinParams(), name='din')
     out['kdin_%s_out' % tag] = np.asarray(layer.call((_tensor(keys_k), lens_k, _tensor(q)), training=True))
   Dense.scope = ''
+  # SequenceFeatureLayer.target_attention (sequence_features inside a feature group)
+  for name, attrs in (('tensorflow.python.framework', {}), ('tensorflow.python.framework.ops', {}),
+                      ('easy_rec.python.utils.conditional', {})):
+    m = types.ModuleType(name)
+    sys.modules[name] = m
+  sys.modules['tensorflow.python.framework'].ops = sys.modules['tensorflow.python.framework.ops']
+  sys.modules['easy_rec.python.utils'].conditional = sys.modules['easy_rec.python.utils.conditional']
+  sfl = load_reference('easy_rec/python/layers/sequence_feature_layer.py', 'ref_sequence_feature_layer')
+  fake_layer = types.SimpleNamespace(_kernel_regularizer=None, _is_training=True)
+  ta_cfg = types.SimpleNamespace(hidden_units=[6, 3, 1], use_bn=True, activation='tf.nn.relu', dropout_ratio=[])
+  ta_key, ta_hist = rng.standard_normal((Bd, E)), rng.standard_normal((Bd, L, E))
+  ta_key_narrow = rng.standard_normal((Bd, 3))
+  out['ta_key'], out['ta_hist'], out['ta_key_narrow'] = ta_key, ta_hist, ta_key_narrow
+  for tag, key, kw in (('with_key', ta_key, {}), ('no_key', ta_key, {'need_key_feature': False}),
+                       ('narrow_key', ta_key_narrow, {'allow_key_transform': True})):
+    fea = {'key': key, 'hist_seq_emb': ta_hist, 'hist_seq_len': lens, 'aux_hist_seq_emb_list': []}
+    out['ta_%s_out' % tag] = sfl.SequenceFeatureLayer.target_attention(fake_layer, ta_cfg, fea, 'ta_' + tag, **kw)
   x_dcn = rng.standard_normal((7, 5))
   out['dcn_x'] = x_dcn
   out['dcn_cross_out'] = dcn_mod.DCN._cross_net(None, x_dcn, 3)
   for k, v in VARS.items():
     out['var:' + k] = v
+  for k in [k for k in out if k.startswith('cross_') and (k.endswith('_kernel') or k.endswith('_bias'))] + \
+      [k for k in out if k.startswith('cin_kernel_') or k.startswith('cin_bias_')]:
+    out['var:' + k] = out[k]
   path = os.path.join(HERE, 'reference_layer_vectors.npz')
   np.savez(path, **{k: np.asarray(v) for k, v in out.items()})
   print('wrote %s: %d arrays' % (path, len(out)))

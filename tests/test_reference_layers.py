@@ -205,6 +205,112 @@ def test_keras_din_restatement(tag, normalizer, need_target, query):
   _close(got, _t('kdin_%s_out' % tag))
 
 
+@pytest.mark.parametrize('tag,key,kw', [('with_key', 'ta_key', {}), ('no_key', 'ta_key', {'need_key_feature': False}),
+                                        ('narrow_key', 'ta_key_narrow', {'allow_key_transform': True})])
+def test_product_target_attention_on_the_stand_in_backend(ref_backend, tag, key, kw):
+  """THE PRODUCT's layers/sequence_feature_layer.target_attention (sequence_features of a feature group) on the oracle's
+  stand-in backend, fed the variables the reference's SequenceFeatureLayer.target_attention created, against that
+  function's output: with / without the key in the output, a key narrower than the history zero-padded
+  (allow_key_transform) and appended in its padded form."""
+  from easyrec_amd.core import context
+  from easyrec_amd.core.variables import VarStore
+  from easyrec_amd.layers.sequence_feature_layer import target_attention
+  from easyrec_amd.protos import dnn_pb2
+  cfg = dnn_pb2.DNN()
+  cfg.hidden_units.extend([6, 3, 1])
+  name = 'ta_' + tag
+  fea = {'key': _t(key, torch.float32), 'hist_seq_emb': _t('ta_hist', torch.float32),
+         'hist_seq_len': torch.from_numpy(np.asarray(G['din_len'])).to(torch.int32), 'aux_hist_seq_emb_list': []}
+  vs = VarStore('cpu', seed=0)
+  ctx = context.ModelContext(vs, None, is_training=True)
+  with context.use(ctx), torch.no_grad():
+    target_attention(cfg, fea, name, None, True, **kw)  # build pass: creates the variables
+    ctx.building = False
+    state = {k[len('var:'):]: np.asarray(G[k], dtype=np.float32) for k in G.files if k.startswith('var:' + name + '/')}
+    vs.load_state_dict(state, strict=False)
+    got = target_attention(cfg, fea, name, None, True, **kw)
+  _close(got, _t('ta_%s_out' % tag), 2e-5)
+
+
+def _product(fn, var_prefixes, rename=None):
+  """Run a PRODUCT layer (host code of easyrec_amd/layers on the stand-in kernels) with the variables the reference's code
+  created: build pass (creates the variables under the product's names), load the recorded values, run."""
+  from easyrec_amd.core import context
+  from easyrec_amd.core.variables import VarStore
+  vs = VarStore('cpu', seed=0)
+  ctx = context.ModelContext(vs, None, is_training=True)
+  with context.use(ctx), torch.no_grad():
+    fn()
+    ctx.building = False
+    state = {}
+    for k in G.files:
+      if k.startswith('var:') and any(k[4:].startswith(p) for p in var_prefixes):
+        name = k[4:]
+        state[rename(name) if rename else name] = np.asarray(G[k], dtype=np.float32)
+    missing = [n for n in vs.trainable_names() if n not in state]
+    assert not missing, 'the product creates variables the reference did not: %s' % missing
+    vs.load_state_dict(state, strict=False)
+    return fn()
+
+
+class _P(object):  # keras-layer parameters from keyword arguments (layers/utils.py Parameter's accessors)
+  l2_regularizer = None
+
+  def __init__(self, **kw):
+    self.kw = kw
+
+  def get_or_default(self, k, d):
+    return self.kw.get(k, d)
+
+  def check_required(self, k):
+    assert k in self.kw
+
+  def __getattr__(self, k):
+    try:
+      return self.__dict__['kw'][k]
+    except KeyError:
+      raise AttributeError(k)
+
+
+def test_product_layers_on_the_stand_in_backend(ref_backend):
+  """easyrec_amd's own DNN, MMOE, keras MLP / Cross / CIN layers, fed the reference's variables BY NAME (so the variable
+  naming - the checkpoint-compatibility contract - is checked too), against the reference code's outputs."""
+  from easyrec_amd.layers import dnn, mmoe
+  from easyrec_amd.layers.keras import CIN, MLP, Cross
+  from easyrec_amd.protos import dnn_pb2
+
+  def dnn_cfg(units, act=None):
+    c = dnn_pb2.DNN()
+    c.hidden_units.extend(units)
+    if act:
+      c.activation = act
+    return c
+
+  x = _t('dnn_x', torch.float32)
+  _close(_product(lambda: dnn.DNN(dnn_cfg([6, 3]), None, 'tower', True)(x), ['tower/']), _t('dnn_out'), 2e-5)
+  _close(_product(lambda: dnn.DNN(dnn_cfg([6, 3]), None, 'tower2', True, last_layer_no_activation=True,
+                                  last_layer_no_batch_norm=True)(x), ['tower2/']), _t('dnn_out_last_plain'), 2e-5)
+  xm = _t('mmoe_x', torch.float32)
+  tasks = _product(lambda: mmoe.MMOE(dnn_cfg([5, 3], 'relu'), None, num_task=2, num_expert=3, name='mmoe',
+                                     is_training=True)(xm), ['mmoe/'])
+  _close(tasks[0], _t('mmoe_task_0'), 2e-5)
+  _close(tasks[1], _t('mmoe_task_1'), 2e-5)
+  xl = _t('mlp_x', torch.float32)
+  for tag, kw in (('default', dict(hidden_units=[6, 3])),
+                  ('final_linear', dict(hidden_units=[4, 1], use_final_bn=False, final_activation='linear')),
+                  ('biased', dict(hidden_units=[4, 2], use_bias=True, use_final_bias=True, use_bn=False))):
+    got = _product(lambda: MLP(_P(**kw), name='mlp_%s' % tag)(xl, training=True), ['mlp_%s/' % tag])
+    _close(got, _t('mlp_%s_out' % tag), 2e-5)
+  x0, xx = _t('cross_x0', torch.float32), _t('cross_x', torch.float32)
+  for tag, kw in (('full', {}), ('diag', {'diag_scale': 0.25})):
+    got = _product(lambda: Cross(_P(**kw), name='cross')((x0, xx)), ['cross_%s_' % tag],
+                   rename=lambda n: {'cross_%s_kernel' % tag: 'cross/dense/kernel', 'cross_%s_bias' % tag: 'cross/dense/bias'}[n])
+    _close(got, _t('cross_%s_out' % tag), 2e-5)
+  got = _product(lambda: CIN(_P(hidden_feature_sizes=[5, 2]), name='cin')(_t('cin_x', torch.float32)), ['cin_kernel', 'cin_bias'],
+                 rename=lambda n: 'cin/' + n)
+  _close(got, _t('cin_out'), 2e-5)
+
+
 # ------------------------------------------------------------------------------------------------ the HIP kernels
 @pytest.mark.gpu
 def test_hip_kernels_against_the_reference_layers():
