@@ -124,6 +124,30 @@ bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ bias, con
   y[i] = v;
 }
 
+// use_bn == ER_BN_FROZEN: batch_normalization(training=False) inside a training graph.  The reference's MMoE and
+// DBMTL models build their experts that way (model/mmoe.py:37-47, model/dbmtl.py:66-70 call layers/mmoe.py MMOE
+// without is_training, whose default is False): the MOVING statistics normalise, nothing updates them, gamma / beta /
+// the bias and the input still receive gradients.  save_mean / save_invstd are written for the backward.
+__global__ void __launch_bounds__(kBlock)
+bn_frozen_apply_kernel(const float* __restrict__ x, const float* __restrict__ bias, const float* __restrict__ gamma,
+                       const float* __restrict__ beta, const float* __restrict__ moving_mean,
+                       const float* __restrict__ moving_var, int64_t n, int N, float eps, int act,
+                       float* __restrict__ y, float* __restrict__ save_mean, float* __restrict__ save_invstd) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const int c = static_cast<int>(i % N);
+  const float mu = moving_mean[c];
+  const float is = 1.f / sqrtf(moving_var[c] + eps);
+  if (i < N) {  // (row 0: one writer per column)
+    save_mean[c] = mu;
+    save_invstd[c] = is;
+  }
+  float v = ((x[i] + (bias ? bias[c] : 0.f)) - mu) * is;
+  v = v * (gamma ? gamma[c] : 1.f) + (beta ? beta[c] : 0.f);
+  if (act == ER_ACT_RELU) v = v > 0.f ? v : 0.f;
+  y[i] = v;
+}
+
 // Fused finalize + apply.  grid = (column blocks of 64, row blocks of kApplyRows); every workgroup first
 // merges the `chunks` Welford partials of ITS 64 columns (4 row-lanes x chunks/4 each, then a fixed merge:
 // identical bits in every workgroup), keeps mean / invstd in LDS, then normalises its [rows x 64] tile.
@@ -350,7 +374,14 @@ bn_bwd_finalize_apply_kernel(const float* __restrict__ partial, const float* __r
       if (use_bn) {
         if (dbeta) dbeta[c] = accumulate ? dbeta[c] + a : a;
         if (dgamma) dgamma[c] = accumulate ? dgamma[c] + b : b;
-        if (dbias && !accumulate) dbias[c] = 0.f;  // BatchNorm removes the column mean: d(loss)/d(bias) == 0
+        if (use_bn == ER_BN_FROZEN) {  // fixed statistics: the bias sees the column sum of dx
+          if (dbias) {
+            const float d = (gamma ? gamma[c] : 1.f) * invstd[c] * a;
+            dbias[c] = accumulate ? dbias[c] + d : d;
+          }
+        } else if (dbias && !accumulate) {
+          dbias[c] = 0.f;  // BatchNorm removes the column mean: d(loss)/d(bias) == 0
+        }
       } else {
         if (dbias) dbias[c] = accumulate ? dbias[c] + a : a;
       }
@@ -385,7 +416,7 @@ bn_bwd_finalize_apply_kernel(const float* __restrict__ partial, const float* __r
         if (act == ER_ACT_RELU && !(yv[k] > 0.f)) g = 0.f;
         if (use_bn) {
           const float xh = (xv[k] + bv - mu) * is;
-          g = ga * is * (g - sg * invB - xh * (sgx * invB));
+          g = (use_bn == ER_BN_FROZEN) ? ga * is * g : ga * is * (g - sg * invB - xh * (sgx * invB));
         }
         dx[static_cast<int64_t>(r) * N + c] = g;
       }
@@ -829,6 +860,14 @@ int er_bn_act_fwd(const float* x, const float* bias, const float* gamma, const f
   hipStream_t s = er::as_stream(stream);
   const int64_t n = static_cast<int64_t>(B) * N;
   std::unique_lock<std::mutex> lock(er::g_scratch_mu, std::defer_lock);
+  if (use_bn == ER_BN_FROZEN) {
+    ER_REQUIRE(moving_mean && moving_var && save_mean && save_invstd,
+               "er_bn_act_fwd: the moving statistics and save_mean/save_invstd are required with ER_BN_FROZEN");
+    hipLaunchKernelGGL(er::bn_frozen_apply_kernel, dim3(er::blocks_for(n)), dim3(er::kBlock), 0, s, x, bias, gamma, beta,
+                       moving_mean, moving_var, n, N, eps, act, y, save_mean, save_invstd);
+    ER_LAUNCH_CHECK();
+    return 0;
+  }
   if (use_bn) {
     lock.lock();
     ER_REQUIRE(save_mean && save_invstd, "er_bn_act_fwd: save_mean/save_invstd required with use_bn");

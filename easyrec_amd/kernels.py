@@ -37,6 +37,7 @@ COMBINER_SUM, COMBINER_MEAN, COMBINER_SQRTN = 0, 1, 2
 COMBINERS = {'sum': COMBINER_SUM, 'mean': COMBINER_MEAN, 'sqrtn': COMBINER_SQRTN}
 OPT_SGD, OPT_ADAM, OPT_LAZY_ADAM, OPT_ADAGRAD = 0, 1, 2, 3
 ACT_NONE, ACT_RELU = 0, 1
+BN_NONE, BN_BATCH, BN_FROZEN = 0, 1, 2  # er_bn_act_fwd / _bwd use_bn (include/easyrec_hip.h)
 GEMM_NN, GEMM_NT, GEMM_TN = 0, 1, 2
 
 
@@ -1644,15 +1645,16 @@ class BNActFn(torch.autograd.Function):
   @staticmethod
   def forward(ctx, x, bias, gamma, beta, moving_mean, moving_var, use_bn, eps, momentum, act, training,
               grad_bufs=None):
-    if use_bn and not training:
-      # inference: normalise with the moving statistics (plain elementwise torch ops; not on the
-      # training hot path)
-      z = x if bias is None else x + bias
-      y = (z - moving_mean) * torch.rsqrt(moving_var + eps) * gamma + beta
-      return torch.relu(y) if act == ACT_RELU else y
-    y, mean, invstd = hip().bn_act_fwd(x, bias, gamma, beta, use_bn, eps, momentum, moving_mean, moving_var, act)
+    mode = BN_NONE
+    if use_bn:
+      # training=False: the moving statistics normalise and stay as they are - evaluation, and the experts of the
+      # reference's MMoE / DBMTL models in TRAINING too (model/mmoe.py:37-47 builds layers/mmoe.py MMOE without
+      # is_training); gamma, beta, the bias and the input still receive gradients (er_bn_act_bwd, ER_BN_FROZEN)
+      mode = BN_BATCH if training else BN_FROZEN
+      assert training or (moving_mean is not None and moving_var is not None)
+    y, mean, invstd = hip().bn_act_fwd(x, bias, gamma, beta, mode, eps, momentum, moving_mean, moving_var, act)
     ctx.save_for_backward(x, bias, gamma, y, mean, invstd)
-    ctx.cfg = (use_bn, act)
+    ctx.cfg = (mode, act)
     ctx.grad_bufs = grad_bufs
     return y
 

@@ -72,7 +72,12 @@ def dense_bn_act(x, units, name, l2_reg, use_bias, use_bn, act_relu, training, b
     src = kernels.take_last_bn_source()
     y = y.reshape(shape[:-1] + (units,))
     return kernels.tag_bn_source(y, src) if src is not None else y
-  z = _linear(x.reshape(-1, in_dim), w, None)
+  # no BatchNorm, or BatchNorm on the moving statistics (evaluation; in training the experts of the reference's MMoE /
+  # DBMTL, whose MMOE layer is built without is_training): plain GEMM, then ONE bias + normalise + activation launch
+  if x.dim() == 2:
+    z = _linear(x, w, None, kernels.bn_source_of(x), kernels.grad_sink_of(x))
+  else:
+    z = _linear(x.reshape(-1, in_dim), w, None)
   y = kernels.BNActFn.apply(z, b, gamma, beta, None if freeze else mm, None if freeze else mv, use_bn,
                             BN_EPSILON, BN_MOMENTUM, act, training, _grad_bufs(b, gamma, beta))
   return y.reshape(shape[:-1] + (units,))

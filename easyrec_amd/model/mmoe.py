@@ -18,10 +18,14 @@ class MMoE(MultiTaskModel):
 
   def build_predict_graph(self):
     self._features, _ = self._input_layer(self._feature_dict, 'all')
+    # The reference builds the layer WITHOUT is_training (model/mmoe.py:37-47; layers/mmoe.py:14-20 defaults it to
+    # False): the experts' BatchNorm normalises with the moving statistics - zeros / ones unless a checkpoint says
+    # otherwise, never updated - and their dropout is off, in training as in evaluation.  Kept, so that losses,
+    # gradients and checkpoints match the reference's (pinned by tests/test_reference_layers.py's model assemblies).
     if self._model_config.HasField('expert_dnn'):
       mmoe_layer = mmoe.MMOE(self._model_config.expert_dnn, l2_reg=self._l2_reg, num_task=self._task_num,
-                             num_expert=self._model_config.num_expert, is_training=self._is_training)
+                             num_expert=self._model_config.num_expert)
     else:
       mmoe_layer = mmoe.MMOE([x.dnn for x in self._model_config.experts], l2_reg=self._l2_reg,
-                             num_task=self._task_num, is_training=self._is_training)
+                             num_task=self._task_num)
     return self._tower_heads(mmoe_layer(self._features))

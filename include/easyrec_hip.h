@@ -427,8 +427,14 @@ int er_din_pool_bwd(const float* probs, const float* hist, const int32_t* seq_le
  *   over the B rows (biased variance); updates moving stats with `momentum` when not NULL.
  *   act: 0 = identity, 1 = relu.  bias/gamma/beta may be NULL (treated as 0/1/0).
  *   use_bn == 0: y = act(x + bias).  save_mean/save_invstd: [N] (needed by backward).
+ *   use_bn == ER_BN_FROZEN: tf.layers.batch_normalization(training=False) inside a training graph - what the
+ *   experts of the reference's MMoE / DBMTL models run (model/mmoe.py:37-47 and model/dbmtl.py:66-70 build
+ *   layers/mmoe.py:14-20 MMOE without is_training, default False): the MOVING statistics normalise and are not
+ *   updated; save_mean / save_invstd receive them for er_bn_act_bwd*, which with the same flag drops the two
+ *   batch-statistics terms of dx (dx = gamma * invstd * g) and gives the bias its gradient (column sum of dx).
  * -------------------------------------------------------------------------------------------- */
 enum { ER_ACT_NONE = 0, ER_ACT_RELU = 1 };
+enum { ER_BN_NONE = 0, ER_BN_BATCH = 1, ER_BN_FROZEN = 2 };
 int er_bn_act_fwd(const float* x, const float* bias, const float* gamma, const float* beta,
                   int32_t B, int32_t N, int use_bn, float eps, float momentum,
                   float* moving_mean, float* moving_var, int act, float* y, float* save_mean,

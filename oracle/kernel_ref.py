@@ -27,6 +27,7 @@ from oracle import hashing
 
 OPT_SGD, OPT_ADAM, OPT_LAZY_ADAM, OPT_ADAGRAD = 0, 1, 2, 3
 ACT_NONE, ACT_RELU = 0, 1
+BN_FROZEN = 2  # use_bn value: normalise with the moving statistics (include/easyrec_hip.h ER_BN_FROZEN)
 (HYPER_LR, HYPER_LR_T, HYPER_BETA1, HYPER_BETA2, HYPER_OMB1, HYPER_OMB2, HYPER_EPS, HYPER_GSCALE) = range(8)
 HYPER_CLIP = 8  # er_opt_hyper.clip_scale (0 = no clipping)
 
@@ -851,7 +852,12 @@ class RefBackend(object):
   def bn_act_fwd(self, x, bias, gamma, beta, use_bn, eps, momentum, moving_mean, moving_var, act):
     z = x if bias is None else x + bias
     mean = invstd = None
-    if use_bn:
+    if use_bn == BN_FROZEN:  # batch_normalization(training=False): the moving statistics, untouched
+      mean = moving_mean.clone()
+      invstd = 1.0 / torch.sqrt(moving_var + eps)
+      y = (z - mean) * invstd
+      y = y * (gamma if gamma is not None else 1.0) + (beta if beta is not None else 0.0)
+    elif use_bn:
       mean = z.mean(dim=0)
       var = ((z - mean)**2).mean(dim=0)  # tf.nn.moments: biased
       invstd = 1.0 / torch.sqrt(var + eps)
@@ -887,11 +893,14 @@ class RefBackend(object):
       xh = (z - mean) * invstd
       sg, sgx = g.sum(dim=0), (g * xh).sum(dim=0)
       ga = gamma if gamma is not None else 1.0
-      dx = ga * invstd * (g - sg / B - xh * (sgx / B))
+      if use_bn == BN_FROZEN:
+        dx = ga * invstd * g
+      else:
+        dx = ga * invstd * (g - sg / B - xh * (sgx / B))
       if need_affine:
         dgamma, dbeta = sgx, sg
       if need_bias:
-        dbias = torch.zeros_like(sg)
+        dbias = ga * invstd * sg if use_bn == BN_FROZEN else torch.zeros_like(sg)
     else:
       dx = g
       if need_bias:

@@ -458,9 +458,11 @@ class OracleTrainer(object):
     assert w.shape == (x.shape[-1], units)
     return x @ w + b
 
-  def batch_norm(self, V, x, name):
+  def batch_norm(self, V, x, name, training=True):
     gamma, beta = V.get(name + '/gamma'), V.get(name + '/beta')
     mm, mv = V.get(name + '/moving_mean', trainable=False), V.get(name + '/moving_variance', trainable=False)
+    if not training:  # tf.layers.batch_normalization(training=False): the moving statistics, no update op
+      return (x - mm) / torch.sqrt(mv + BN_EPS) * gamma + beta
     axes = tuple(range(x.dim() - 1))
     mean = x.mean(dim=axes)
     var = ((x - mean)**2).mean(dim=axes)
@@ -483,18 +485,19 @@ class OracleTrainer(object):
       self._moving[name + '/batch_normalization/moving_variance'] = mv - (mv - var) * (1 - BN_MOMENTUM)
     return alpha * (1.0 - p) * x + p * x
 
-  def dnn(self, V, x, dnn_cfg, name, l2, last_no_act=False, last_no_bn=False):
-    """layers/dnn.py:50-87."""
+  def dnn(self, V, x, dnn_cfg, name, l2, last_no_act=False, last_no_bn=False, training=True):
+    """layers/dnn.py:50-87.  training = the layer's is_training (BatchNorm's mode)."""
     n = len(dnn_cfg.hidden_units)
     for i, units in enumerate(dnn_cfg.hidden_units):
       x = self.dense(V, x, units, '%s/dnn_%d' % (name, i), l2)
       if dnn_cfg.use_bn and ((i + 1 < n) or not last_no_bn):
-        x = self.batch_norm(V, x, '%s/dnn_%d/bn' % (name, i))
+        x = self.batch_norm(V, x, '%s/dnn_%d/bn' % (name, i), training=training)
       if (i + 1 < n) or not last_no_act:
         act = dnn_cfg.activation.lower()
         if act in ('tf.nn.relu', 'relu', 'nn.relu'):
           x = torch.relu(x)
         elif act == 'dice':
+          assert training, 'dice inside an is_training=False DNN is not restated'
           x = self.dice(V, x, '%s/dnn_%d/act' % (name, i))
         else:
           raise NotImplementedError(act)
@@ -654,9 +657,12 @@ class OracleTrainer(object):
     out = self.dense(V, all_fea, mc.num_class, 'output', 0.0)
     return {'logits': out.squeeze(1)}
 
-  def _mmoe_layer(self, V, x, expert_cfgs, num_task, l2, name='mmoe'):
-    """layers/mmoe.py:62-83: expert DNNs stacked on axis 1, per task a softmax gate over the experts, the mixture."""
-    experts = torch.stack([self.dnn(V, x, cfg, '%s/expert_%d' % (name, i), l2) for i, cfg in enumerate(expert_cfgs)], dim=1)
+  def _mmoe_layer(self, V, x, expert_cfgs, num_task, l2, name='mmoe', training=False):
+    """layers/mmoe.py:62-83: expert DNNs stacked on axis 1, per task a softmax gate over the experts, the mixture.
+    The model classes build the layer without is_training (model/mmoe.py:37-47, model/dbmtl.py:66-70; the layer's
+    default is False, layers/mmoe.py:20): the experts' BatchNorm normalises with the moving statistics."""
+    experts = torch.stack([self.dnn(V, x, cfg, '%s/expert_%d' % (name, i), l2, training=training)
+                           for i, cfg in enumerate(expert_cfgs)], dim=1)
     out = []
     for t in range(num_task):
       gate = torch.softmax(self.dense(V, x, len(expert_cfgs), '%s/gate_%d/dnn' % (name, t), l2), dim=1)
@@ -729,7 +735,7 @@ class OracleTrainer(object):
     return pred
 
   def _dbmtl(self, V, batch):
-    """model/dbmtl.py:46-116 without the optional MMoE block: bottom (dnn) -> tower dnn -> relation dnn over
+    """model/dbmtl.py:46-116: bottom (dnn) -> optional MMoE block -> tower dnn -> relation dnn over
     [own features, earlier towers' relation features] -> output."""
     mc = self.cfg.model_config
     c = mc.dbmtl
@@ -737,10 +743,14 @@ class OracleTrainer(object):
     x, _ = self.input_layer(V, batch, 'all', 'input_layer')
     if c.HasField('bottom_dnn'):
       x = self.dnn(V, x, c.bottom_dnn, 'bottom_dnn', l2)
+    if c.HasField('expert_dnn'):
+      task_in = self._mmoe_layer(V, x, [c.expert_dnn] * c.num_expert, len(c.task_towers), l2)
+    else:
+      task_in = [x] * len(c.task_towers)
     rel, pred = {}, {}
-    for tower in c.task_towers:
+    for tower, x_t in zip(c.task_towers, task_in):
       nm = tower.tower_name
-      own = self.dnn(V, x, tower.dnn, nm + '/dnn', l2) if tower.HasField('dnn') else x
+      own = self.dnn(V, x_t, tower.dnn, nm + '/dnn', l2) if tower.HasField('dnn') else x_t
       inp = torch.cat([own] + [rel[r] for r in tower.relation_tower_names], dim=-1)
       rel[nm] = self.dnn(V, inp, tower.relation_dnn, nm + '/relation_dnn', l2)
       pred['logits_%s' % nm] = self.dense(V, rel[nm], tower.num_class, nm + '/output', l2).squeeze(1)

@@ -13,6 +13,9 @@ TensorFlow cannot be installed here, but several of the reference's layers are a
   easy_rec/python/layers/keras/din.py          DIN.__init__ / call    (target attention block: softmax and sigmoid)
   easy_rec/python/layers/sequence_feature_layer.py  SequenceFeatureLayer.target_attention (with / without the key,
                                                 a key narrower than the history under allow_key_transform)
+  easy_rec/python/model/{deepfm,fm,dcn,wide_and_deep,dlrm,multi_tower,multi_tower_din,simple_multi_task,mmoe,ple,dbmtl}.py
+                                                build_predict_graph   (the model classes' assembly of those layers, on
+                                                seeded group features: tests/golden/model_assembly_cases.py)
 This script executes THOSE FUNCTIONS, unmodified, against a small stand-in for the `tensorflow` module (numpy, fp64)
 that implements the documented semantics of the ~25 ops they call (stack, reduce_sum, matmul(transpose_b), band_part,
 boolean_mask, tile, sequence_mask, ...), a `keras.layers.Dense` whose kernel / bias are set by this script, and
@@ -59,6 +62,9 @@ class _Tensor(np.ndarray):
   @property
   def shape(self):
     return _Shape(np.ndarray.shape.__get__(self))
+
+  def get_shape(self):
+    return self.shape
 
 
 def _tensor(x):
@@ -169,10 +175,12 @@ def _band_part(x, num_lower, num_upper):
 
 VARS = {}  # TF variable name -> value, filled by tf.layers.* below (the consumers feed the same values to the oracle)
 _VAR_RNG = np.random.default_rng(77)
+MODEL_SCOPE = ['']  # key prefix of the variables a model assembly creates ('<case tag>::'): several cases reuse TF names
 
 
 def _layers_dense(inputs, units, kernel_regularizer=None, activation=None, name=None, **kw):
   x = _arr(inputs)
+  name = MODEL_SCOPE[0] + name
   k = VARS.setdefault(name + '/kernel', _VAR_RNG.standard_normal((x.shape[-1], units)) * 0.4)
   b = VARS.setdefault(name + '/bias', _VAR_RNG.standard_normal(units) * 0.1)
   y = x @ k + b
@@ -180,10 +188,16 @@ def _layers_dense(inputs, units, kernel_regularizer=None, activation=None, name=
 
 
 def _layers_batch_normalization(inputs, training=False, trainable=True, name=None, epsilon=1e-3, **kw):
-  assert training, 'only the training-mode formula is exercised'
   x = _arr(inputs)
+  name = MODEL_SCOPE[0] + name
   gamma = VARS.setdefault(name + '/gamma', _VAR_RNG.random(x.shape[-1]) + 0.5)
   beta = VARS.setdefault(name + '/beta', _VAR_RNG.standard_normal(x.shape[-1]) * 0.2)
+  if not training:
+    # training=False: the moving statistics normalise (TF initialises them to zeros / ones and, with no update op in
+    # the graph, they stay there; seeded values here so that the consumers must read them)
+    mm = VARS.setdefault(name + '/moving_mean', _VAR_RNG.standard_normal(x.shape[-1]) * 0.3)
+    mv = VARS.setdefault(name + '/moving_variance', _VAR_RNG.random(x.shape[-1]) + 0.5)
+    return (x - mm) / np.sqrt(mv + epsilon) * gamma + beta
   axes = tuple(range(x.ndim - 1))
   mean, var = x.mean(axis=axes), x.var(axis=axes)
   return (x - mean) / np.sqrt(var + epsilon) * gamma + beta
@@ -236,9 +250,9 @@ def make_tf():
   tf.squeeze = lambda x, axis=None: np.squeeze(_arr(x), axis=tuple(axis) if isinstance(axis, (list, tuple)) else axis)
   tf.math = types.SimpleNamespace(add=lambda a, b: _arr(a) + _arr(b))
 
-  def get_variable(name=None, dtype=None, shape=None, **kw):
+  def get_variable(name=None, shape=None, dtype=None, **kw):
     shape = (shape,) if isinstance(shape, (int, np.integer)) else tuple(shape)
-    return VARS.setdefault(name, _VAR_RNG.standard_normal(shape) * 0.3)
+    return VARS.setdefault(MODEL_SCOPE[0] + name, _VAR_RNG.standard_normal(shape) * 0.3)
 
   tf.get_variable = get_variable
   tf.sigmoid = lambda x: 1.0 / (1.0 + np.exp(-_arr(x)))
@@ -256,8 +270,32 @@ def make_tf():
       activations=types.SimpleNamespace(get=lambda a: a, serialize=lambda a: a),
       initializers=types.SimpleNamespace(get=lambda n: _Initializer(str(n)), serialize=lambda a: a, Zeros=_Initializer),
       regularizers=types.SimpleNamespace(get=lambda r: None, serialize=lambda a: a))
-  tf.compat = types.SimpleNamespace(v1=tf)
   tf.initializers = types.SimpleNamespace(he_normal=lambda: _Initializer('he_normal'))
+  tf.einsum = lambda eq, *ops: np.einsum(eq, *[_arr(o) for o in ops])
+  tf.add_n = lambda xs: sum(_arr(x) for x in xs)
+  tf.nn.bias_add = lambda x, b: _arr(x) + _arr(b)
+  tf.zeros_initializer = lambda: _Initializer('zeros')
+  tf.logging = types.SimpleNamespace(info=lambda *a, **k: None, warn=lambda *a, **k: None)
+
+  def as_tensor(fn):  # results answer .shape.as_list() / .get_shape() like tf.Tensor does; op names are dropped
+    import inspect
+    named = 'name' in inspect.signature(fn).parameters or any(
+        p.kind == p.VAR_KEYWORD for p in inspect.signature(fn).parameters.values())
+
+    def wrapped(*a, **k):
+      if not named:
+        k.pop('name', None)
+      r = fn(*a, **k)
+      if isinstance(r, np.ndarray) and not isinstance(r, _Tensor):
+        r = r.view(_Tensor)
+      return r
+    return wrapped
+
+  for ns in (tf, tf.nn, tf.layers, tf.math, tf.linalg):
+    for k, v in list(vars(ns).items()):
+      if isinstance(v, types.FunctionType) and k not in ('name_scope',):
+        setattr(ns, k, as_tensor(v))
+  tf.compat = types.SimpleNamespace(v1=tf)
   return tf
 
 
@@ -276,6 +314,86 @@ class Params(object):
 
   def get_or_default(self, key, default):
     return self.kw.get(key, default)
+
+
+def model_assemblies(out, rng, loaded):
+  """build_predict_graph of the reference's model classes, on bare instances (no constructor: the input layer, the
+  estimator and the loss are not what is pinned here) holding seeded group features and the model's config message
+  (easyrec_amd.protos is the reference's schema: the drop-in boundary)."""
+  sys.path.insert(0, HERE)
+  sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+  import model_assembly_cases as mac
+  from easyrec_amd import protos
+  for base in ('deepfm', 'fm', 'dcn', 'wide_and_deep', 'dlrm', 'multi_tower', 'simple_multi_task', 'mmoe', 'ple', 'dbmtl'):
+    sys.modules['easy_rec.python.protos.%s_pb2' % base] = getattr(protos, base + '_pb2')
+  sys.modules['easy_rec.python.model.multi_task_model'] = types.ModuleType('easy_rec.python.model.multi_task_model')
+  sys.modules['easy_rec.python.model.multi_task_model'].MultiTaskModel = object
+  for name in ('cmbf', 'uniter'):
+    m = types.ModuleType('easy_rec.python.layers.' + name)
+    sys.modules[m.__name__] = m
+    setattr(sys.modules['easy_rec.python.layers'], name, m)
+  classes = {'deepfm': 'DeepFM', 'fm': 'FM', 'dcn': 'DCN', 'wide_and_deep': 'WideAndDeep', 'dlrm': 'DLRM',
+             'multi_tower': 'MultiTower', 'multi_tower_din': 'MultiTowerDIN', 'simple_multi_task': 'SimpleMultiTask',
+             'mmoe': 'MMoE', 'ple': 'PLE', 'dbmtl': 'DBMTL'}
+  mods = dict(loaded)
+  for tag, (model, text, groups) in mac.CASES.items():
+    if model not in mods:
+      mods[model] = load_reference('easy_rec/python/model/%s.py' % model, 'ref_model_' + model)
+    cls = getattr(mods[model], classes[model])
+    cfg = mac.sub_config(model, text)
+    # seeded group features
+    g = {}
+    for gname, spec in groups.items():
+      if spec[0] == 'cat':
+        g[gname] = [_tensor(rng.standard_normal((mac.B, w))) for w in spec[1]]
+        for i, f in enumerate(g[gname]):
+          out['m:%s:%s:%d' % (tag, gname, i)] = np.asarray(f)
+      else:
+        _, E, L = spec
+        lens = rng.integers(1, L + 1, mac.B).astype(np.int64)
+        lens[0] = L  # (tf.sequence_mask(lengths) takes its width from the longest)
+        g[gname] = {'key': _tensor(rng.standard_normal((mac.B, E))), 'hist_seq_emb': _tensor(rng.standard_normal((mac.B, L, E))),
+                    'hist_seq_len': lens}
+        for k, v in g[gname].items():
+          out['m:%s:%s:%s' % (tag, gname, k)] = np.asarray(v)
+    cat = lambda name: _tensor(np.concatenate([np.asarray(f) for f in g[name]], axis=1))
+    got = {}
+    obj = object.__new__(cls)
+    obj._model_config, obj._l2_reg, obj._is_training, obj._num_class = cfg, None, True, 1
+    obj._prediction_dict = {}
+    obj._add_to_prediction_dict = lambda o: got.__setitem__('out', o)
+    if model in ('deepfm', 'fm'):
+      obj._wide_output_dim = 1
+      obj._wide_features, obj._deep_features = cat('wide'), cat('deep')
+      obj._fm_features = list(g['fm'] if 'fm' in g else g['deep'])
+    elif model == 'dcn':
+      obj._features = cat('all')
+    elif model == 'wide_and_deep':
+      obj._wide_features, obj._deep_features = list(g['wide']), list(g['deep'])
+    elif model == 'dlrm':
+      obj._sparse_features, obj._dense_feature = list(g['sparse']), cat('dense')
+    elif model in ('multi_tower', 'multi_tower_din'):
+      obj._tower_num = len(cfg.towers)
+      obj._tower_features = [cat(t.input) for t in cfg.towers]
+      if model == 'multi_tower_din':
+        obj._din_tower_num = len(cfg.din_towers)
+        obj._din_tower_features = [g[t.input] for t in cfg.din_towers]
+    else:  # the multi-task models
+      obj._features = cat('all')
+      obj._task_towers = cfg.task_towers
+      obj._task_num = obj._task_nums = len(cfg.task_towers)
+      obj.backbone = None
+    MODEL_SCOPE[0] = tag + '::'
+    try:
+      cls.build_predict_graph(obj)
+    finally:
+      MODEL_SCOPE[0] = ''
+    res = got['out']
+    if isinstance(res, dict):
+      for k, v in res.items():
+        out['m:%s:out:%s' % (tag, k)] = np.asarray(v)
+    else:
+      out['m:%s:out' % tag] = np.asarray(res)
 
 
 def main():
@@ -480,6 +598,8 @@ def main():
   x_dcn = rng.standard_normal((7, 5))
   out['dcn_x'] = x_dcn
   out['dcn_cross_out'] = dcn_mod.DCN._cross_net(None, x_dcn, 3)
+  layers_pkg.fm, layers_pkg.mmoe = fm_mod, mmoe_mod
+  model_assemblies(out, np.random.default_rng(20240924), {'dcn': dcn_mod, 'multi_tower_din': din_mod})
   for k, v in VARS.items():
     out['var:' + k] = v
   for k in [k for k in out if k.startswith('cross_') and (k.endswith('_kernel') or k.endswith('_bias'))] + \

@@ -1,0 +1,148 @@
+"""The model configs of the model-assembly pins: read by make_reference_layer_vectors.py (which runs the REFERENCE's model
+classes' build_predict_graph on them) and by tests/test_reference_layers.py (which runs THE PRODUCT's model classes on
+them).  Each case: tag -> (model, the model's config in protobuf text (the `model` oneof member's body), group inputs).
+
+Group inputs are descriptions, not data: `('cat', [widths])` = a group whose per-feature outputs have those widths (the
+group output is their concatenation); `('seq', E, L)` = a DIN tower's key [B, E] / history [B, L, E] / lengths.
+The data itself is drawn by the generator and stored in the fixture.
+"""
+from collections import OrderedDict
+
+B = 9
+
+CASES = OrderedDict()
+
+CASES['deepfm_final'] = ('deepfm', """
+  dnn { hidden_units: [8, 4] }
+  final_dnn { hidden_units: [6] }
+  wide_output_dim: 1
+""", OrderedDict(wide=('cat', [1, 1, 1, 1, 1]), deep=('cat', [3, 3, 3, 3, 3])))
+
+CASES['deepfm_plain'] = ('deepfm', """
+  dnn { hidden_units: [8, 4] }
+  wide_output_dim: 1
+""", OrderedDict(wide=('cat', [1, 1, 1, 1]), deep=('cat', [4, 4, 4, 4])))
+
+CASES['deepfm_fm_group'] = ('deepfm', """
+  dnn { hidden_units: [5] }
+  final_dnn { hidden_units: [4, 2] }
+  wide_output_dim: 1
+""", OrderedDict(wide=('cat', [1, 1, 1]), deep=('cat', [4, 2, 3]), fm=('cat', [4, 4])))
+
+CASES['fm'] = ('fm', "", OrderedDict(wide=('cat', [1, 1, 1, 1]), deep=('cat', [3, 3, 3, 3])))
+
+CASES['dcn'] = ('dcn', """
+  deep_tower { input: "all" dnn { hidden_units: [6, 4] } }
+  cross_tower { input: "all" cross_num: 3 }
+  final_dnn { hidden_units: [5] }
+""", OrderedDict(all=('cat', [2, 3, 2])))
+
+CASES['wide_and_deep_final'] = ('wide_and_deep', """
+  dnn { hidden_units: [6, 3] }
+  final_dnn { hidden_units: [4] }
+  wide_output_dim: 2
+""", OrderedDict(wide=('cat', [2, 2, 2]), deep=('cat', [3, 4, 2])))
+
+CASES['wide_and_deep_plain'] = ('wide_and_deep', """
+  dnn { hidden_units: [6, 3] }
+  wide_output_dim: 1
+""", OrderedDict(wide=('cat', [1, 1, 1, 1]), deep=('cat', [3, 4, 2])))
+
+CASES['dlrm_dot'] = ('dlrm', """
+  bot_dnn { hidden_units: [6, 4] }
+  top_dnn { hidden_units: [7, 3] }
+""", OrderedDict(sparse=('cat', [4, 4, 4]), dense=('cat', [1, 1, 1, 1, 1])))
+
+CASES['dlrm_dot_itself_nodense'] = ('dlrm', """
+  bot_dnn { hidden_units: [4] }
+  top_dnn { hidden_units: [5] }
+  arch_interaction_itself: true
+  arch_with_dense_feature: false
+""", OrderedDict(sparse=('cat', [4, 4]), dense=('cat', [1, 1, 1])))
+
+CASES['dlrm_cat'] = ('dlrm', """
+  bot_dnn { hidden_units: [5] }
+  top_dnn { hidden_units: [6] }
+  arch_interaction_op: "cat"
+""", OrderedDict(sparse=('cat', [3, 3]), dense=('cat', [1, 1, 1])))
+
+CASES['multi_tower'] = ('multi_tower', """
+  towers { input: "user" dnn { hidden_units: [6, 3] } }
+  towers { input: "item" dnn { hidden_units: [4] } }
+  final_dnn { hidden_units: [5, 2] }
+""", OrderedDict(user=('cat', [3, 2, 2]), item=('cat', [4, 1])))
+
+CASES['multi_tower_din'] = ('multi_tower_din', """
+  towers { input: "user" dnn { hidden_units: [6, 3] } }
+  din_towers { input: "click_seq" dnn { hidden_units: [8, 4, 1] } }
+  din_towers { input: "buy_seq" dnn { hidden_units: [5, 1] } }
+  final_dnn { hidden_units: [6] }
+""", OrderedDict(user=('cat', [3, 2]), click_seq=('seq', 4, 5), buy_seq=('seq', 6, 3)))
+
+_TWO_TOWERS = """
+  task_towers { tower_name: "ctr" label_name: "clk" dnn { hidden_units: [5, 3] } }
+  task_towers { tower_name: "cvr" label_name: "buy" dnn { hidden_units: [4] } }
+"""
+
+CASES['simple_multi_task'] = ('simple_multi_task', _TWO_TOWERS, OrderedDict(all=('cat', [3, 3, 2])))
+
+CASES['mmoe'] = ('mmoe', """
+  expert_dnn { hidden_units: [6, 4] }
+  num_expert: 3
+""" + _TWO_TOWERS, OrderedDict(all=('cat', [3, 3, 2])))
+
+CASES['mmoe_no_tower_dnn'] = ('mmoe', """
+  expert_dnn { hidden_units: [5] }
+  num_expert: 2
+  task_towers { tower_name: "ctr" label_name: "clk" }
+  task_towers { tower_name: "cvr" label_name: "buy" }
+  task_towers { tower_name: "fav" label_name: "fav" dnn { hidden_units: [3] } }
+""", OrderedDict(all=('cat', [4, 3])))
+
+CASES['mmoe_experts_list'] = ('mmoe', """
+  experts { expert_name: "e0" dnn { hidden_units: [5, 3] } }
+  experts { expert_name: "e1" dnn { hidden_units: [5, 3] } }
+""" + _TWO_TOWERS, OrderedDict(all=('cat', [4, 3])))
+
+CASES['ple'] = ('ple', """
+  extraction_networks {
+    network_name: "layer1" expert_num_per_task: 2 share_num: 2
+    task_expert_net { hidden_units: [6, 4] }
+    share_expert_net { hidden_units: [6, 4] }
+  }
+  extraction_networks {
+    network_name: "layer2" expert_num_per_task: 1 share_num: 2
+    task_expert_net { hidden_units: [5] }
+    share_expert_net { hidden_units: [5] }
+  }
+""" + _TWO_TOWERS, OrderedDict(all=('cat', [3, 3, 2])))
+
+CASES['dbmtl'] = ('dbmtl', """
+  bottom_dnn { hidden_units: [7] }
+  expert_dnn { hidden_units: [6, 4] }
+  num_expert: 3
+  task_towers { tower_name: "ctr" label_name: "clk" dnn { hidden_units: [5] } relation_dnn { hidden_units: [3] } }
+  task_towers { tower_name: "cvr" label_name: "buy" dnn { hidden_units: [4] } relation_tower_names: "ctr"
+                relation_dnn { hidden_units: [3, 2] } }
+""", OrderedDict(all=('cat', [3, 3, 2])))
+
+CASES['dbmtl_no_mmoe'] = ('dbmtl', """
+  task_towers { tower_name: "ctr" label_name: "clk" relation_dnn { hidden_units: [4] } }
+  task_towers { tower_name: "cvr" label_name: "buy" dnn { hidden_units: [4] } relation_tower_names: "ctr"
+                relation_dnn { hidden_units: [3] } }
+  task_towers { tower_name: "fav" label_name: "fav" relation_tower_names: "ctr" relation_tower_names: "cvr"
+                relation_dnn { hidden_units: [2] } }
+""", OrderedDict(all=('cat', [4, 3])))
+
+
+def sub_config(model, text):
+  """the model's config message (easyrec_amd.protos = the reference's schema) parsed from `text`"""
+  from google.protobuf import text_format
+
+  from easyrec_amd.protos import easy_rec_model_pb2
+  field = 'multi_tower' if model == 'multi_tower_din' else model
+  cfg = easy_rec_model_pb2.EasyRecModel()
+  sub = getattr(cfg, field)
+  sub.SetInParent()
+  text_format.Merge(text, sub)
+  return sub

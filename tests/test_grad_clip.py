@@ -54,14 +54,18 @@ def _run(cfg, B, steps, device, gen_cls, data_seed=11, **est_kw):
 #  every step (checked); over several steps of this B=24 fixture the two trajectories drift apart by ~2e-3 in single
 #  gradient tensors - with or without clipping - because Adam turns the rounding-noise gradients of the biases in
 #  front of BatchNorm (exactly 0 in the product, ~1e-10 in autograd) into O(lr) moves: DESIGN.md section 4.  A norm
-#  compared to 1e-4 needs a trajectory on which that drift stays below it.)
-@pytest.mark.parametrize('config,clip,steps', [('deepfm_criteo_small.config', 0.05, 3),
-                                               ('deepfm_criteo_small.config', 1e4, 3),
-                                               ('dcn_criteo_small.config', 0.05, 3),
-                                               ('mmoe_taobao_small.config', 5.0, 3)])
-def test_clipped_step_matches_the_oracle(ref_backend, config, clip, steps):
+#  compared to 1e-4 needs a trajectory on which that drift stays below it.  With the experts' BatchNorm on the moving
+#  statistics (the reference's MMoE) nothing re-normalises the four expert layers, and an ACTIVE clip makes the first
+#  Adam step depend on the gradients' low bits (scaled elements near epsilon): the oracle ALONE, its weights perturbed
+#  by 1e-6 after the first step, moves its second-step norm by 6e-4 on data seed 11.  Data seed 13 is a trajectory
+#  where product and oracle stay within 2e-6 for three steps.)
+@pytest.mark.parametrize('config,clip,steps,data_seed', [('deepfm_criteo_small.config', 0.05, 3, 11),
+                                                         ('deepfm_criteo_small.config', 1e4, 3, 11),
+                                                         ('dcn_criteo_small.config', 0.05, 3, 11),
+                                                         ('mmoe_taobao_small.config', 5.0, 3, 13)])
+def test_clipped_step_matches_the_oracle(ref_backend, config, clip, steps, data_seed):
   from easyrec_amd.input.synthetic import SyntheticBatches
-  norms = _run(_cfg(config, clip), 24, steps, 'cpu', SyntheticBatches)
+  norms = _run(_cfg(config, clip), 24, steps, 'cpu', SyntheticBatches, data_seed=data_seed)
   for got, exp in norms:
     assert abs(got - exp) <= 1e-4 * exp, (got, exp)
   if clip < 10:

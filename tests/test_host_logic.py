@@ -124,7 +124,7 @@ def test_csv_input_roundtrip(tmp_path, built_lib):
                                       ('dlrm_shared_criteo_small.config', 24), ('deepfm_shared_criteo_small.config', 24),
                                       ('deepfm_combo_criteo_small.config', 24), ('deepfm_lookup_criteo_small.config', 24),
                                       ('simple_multi_task_taobao_small.config', 24), ('ple_taobao_small.config', 24),
-                                      ('dbmtl_taobao_small.config', 24)])
+                                      ('dbmtl_taobao_small.config', 24), ('dbmtl_mmoe_taobao_small.config', 24)])
 def test_other_models_match_model_oracle(ref_backend, config, B):
   """DCN / MultiTowerDIN / MMoE host logic (variable naming, layer wiring, multi-task losses, sequence and
   tag lookups) against the independent model-level oracle, 2 optimisation steps."""

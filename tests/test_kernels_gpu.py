@@ -376,7 +376,7 @@ def test_din(hip, ref, B, L, E):
 # (40000 x 80: a tall activation like DIN's attention MLP - > 256 partial chunks are merged by bn_*_merge_kernel first and
 # every workgroup of the apply kernels walks 16 row tiles)
 @pytest.mark.parametrize('B,N', [(4096, 256), (37, 5), (300, 64), (2, 1), (40000, 80)])
-@pytest.mark.parametrize('use_bn,act', [(1, 1), (1, 0), (0, 1)])
+@pytest.mark.parametrize('use_bn,act', [(1, 1), (1, 0), (0, 1), (2, 1), (2, 0)])  # 2 = ER_BN_FROZEN (moving statistics)
 def test_bn_act(hip, ref, B, N, use_bn, act):
   rng = np.random.default_rng(B + N)
   x = torch.from_numpy((rng.standard_normal((B, N)) * 2 + 0.5).astype(np.float32))
@@ -384,6 +384,9 @@ def test_bn_act(hip, ref, B, N, use_bn, act):
   gamma = torch.from_numpy((rng.random(N) + 0.5).astype(np.float32))
   beta = torch.from_numpy(rng.standard_normal(N).astype(np.float32))
   mm_c, mv_c = torch.zeros(N), torch.ones(N)
+  if use_bn == 2:
+    mm_c = torch.from_numpy((rng.standard_normal(N) * 0.5).astype(np.float32))
+    mv_c = torch.from_numpy((rng.random(N) * 2 + 0.25).astype(np.float32))
   mm_d, mv_d = mm_c.to(DEV), mv_c.to(DEV)
   dy = torch.from_numpy(rng.standard_normal((B, N)).astype(np.float32))
   y_d, mean_d, inv_d = hip.bn_act_fwd(x.to(DEV), bias.to(DEV), gamma.to(DEV), beta.to(DEV), use_bn, 1e-3, 0.99, mm_d,
@@ -403,6 +406,35 @@ def test_bn_act(hip, ref, B, N, use_bn, act):
       continue
     scale = float(e.abs().max()) + 1e-6
     assert float((a.cpu() - e).abs().max()) <= tol * scale + 1e-5, (B, N, use_bn, act)
+
+
+def test_frozen_bn_matches_autograd_of_the_formula(hip):
+  """use_bn = ER_BN_FROZEN (tf.layers.batch_normalization(training=False) inside the training graph: the experts of the
+  reference's MMoE / DBMTL): forward and every gradient - the bias's too - against torch autograd in fp64."""
+  B, N = 700, 70
+  g = torch.Generator().manual_seed(5)
+  x = torch.randn(B, N, dtype=torch.float64, generator=g, requires_grad=True)
+  bias = torch.randn(N, dtype=torch.float64, generator=g, requires_grad=True)
+  gamma = (torch.rand(N, dtype=torch.float64, generator=g) + 0.5).requires_grad_(True)
+  beta = torch.randn(N, dtype=torch.float64, generator=g, requires_grad=True)
+  mm = torch.randn(N, dtype=torch.float64, generator=g) * 0.4
+  mv = torch.rand(N, dtype=torch.float64, generator=g) + 0.3
+  y = torch.relu((x + bias - mm) / torch.sqrt(mv + 1e-3) * gamma + beta)
+  dy = torch.randn(B, N, dtype=torch.float64, generator=g)
+  y.backward(dy)
+  f = lambda t: t.detach().float().to(DEV)
+  mm_d, mv_d = f(mm), f(mv)
+  y_d, mean_d, inv_d = hip.bn_act_fwd(f(x), f(bias), f(gamma), f(beta), 2, 1e-3, 0.99, mm_d, mv_d, 1)
+  assert torch.equal(mm_d.cpu(), mm.float()) and torch.equal(mv_d.cpu(), mv.float()), 'the moving statistics must stay'
+  assert torch.allclose(y_d.cpu().double(), y.detach(), rtol=1e-5, atol=1e-5)
+  dx, dbias, dgamma, dbeta = hip.bn_act_bwd(f(x), f(bias), f(gamma), y_d, mean_d, inv_d, f(dy), 2, 1, True, True)
+  for got, want in ((dx, x.grad), (dbias, bias.grad), (dgamma, gamma.grad), (dbeta, beta.grad)):
+    assert float((got.cpu().double() - want).abs().max()) <= 2e-5 * float(want.abs().max()) + 1e-6
+  # accumulating into existing buffers (slices of the flat gradient buffer)
+  into = tuple(torch.full((N,), 0.5, device=DEV) for _ in range(3))
+  hip.bn_act_bwd(f(x), f(bias), f(gamma), y_d, mean_d, inv_d, f(dy), 2, 1, True, True, into=into)
+  for got, want in zip(into, (bias.grad, gamma.grad, beta.grad)):
+    assert float((got.cpu().double() - 0.5 - want).abs().max()) <= 2e-5 * float(want.abs().max()) + 1e-5
 
 
 def test_bn_matches_autograd_of_the_formula(hip):

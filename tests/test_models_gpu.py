@@ -80,7 +80,7 @@ def test_multi_tower_din_matches_oracle(lazy):
                                   'dlrm_shared_criteo_small.config', 'deepfm_shared_criteo_small.config',
                                   'deepfm_combo_criteo_small.config', 'deepfm_lookup_criteo_small.config',
                                   'simple_multi_task_taobao_small.config', 'ple_taobao_small.config',
-                                  'dbmtl_taobao_small.config'])
+                                  'dbmtl_taobao_small.config', 'dbmtl_mmoe_taobao_small.config'])
 def test_neighbouring_models_match_oracle(name):
   """WideAndDeep / FM / MultiTower / DLRM on the HIP kernels against the model oracle."""
   _first_steps(_cfg(name), 128, 41)
@@ -127,8 +127,8 @@ def test_dcn_v2_bf16_dense_tracks_the_fp32_oracle():
 def test_mmoe_matches_oracle():
   # seed chosen away from a ReLU tie: with seed 23 one pre-activation of expert_3 sits within rounding of 0, the
   # GPU and the oracle take different sides and that one example's gradient (1/128 of the batch) differs by ~1%
-  # (tools/dbg_mmoe_gpu.py reproduces it; seeds 24-27 agree to 3e-6)
-  _first_steps(_cfg('mmoe_taobao_small.config'), 128, 24)
+  # (tools/dbg_mmoe_gpu.py reproduces it).  Seed 25: no ReLU input of the two steps within 1e-6 of its column's scale
+  _first_steps(_cfg('mmoe_taobao_small.config'), 128, 25)
 
 
 @pytest.mark.parametrize('name,B,dtype', [('din_taobao.config', 4096, 'f32'), ('mmoe_taobao.config', 4096, 'f32'),

@@ -162,7 +162,7 @@ def test_dnn_din_mmoe_restatements():
   _close(orc.dnn(V, _t('dnn_x'), _DnnCfg([6, 3]), 'tower2', 0.0, last_no_act=True, last_no_bn=True), _t('dnn_out_last_plain'))
   fea = {'key': _t('din_key'), 'hist_seq_emb': _t('din_hist'), 'hist_seq_len': torch.from_numpy(np.asarray(G['din_len']))}
   _close(orc._din(V, _DnnCfg([8, 4, 1]), fea, 'din', 0.0), _t('din_out'))
-  tasks = orc._mmoe_layer(V, _t('mmoe_x'), [_DnnCfg([5, 3], 'relu')] * 3, 2, 0.0)
+  tasks = orc._mmoe_layer(V, _t('mmoe_x'), [_DnnCfg([5, 3], 'relu')] * 3, 2, 0.0, training=True)  # (as generated)
   _close(tasks[0], _t('mmoe_task_0'))
   _close(tasks[1], _t('mmoe_task_1'))
   _close(orc._cross_net(V, _t('dcn_x'), 3), _t('dcn_cross_out'))  # model/dcn.py _cross_net
@@ -309,6 +309,78 @@ def test_product_layers_on_the_stand_in_backend(ref_backend):
   got = _product(lambda: CIN(_P(hidden_feature_sizes=[5, 2]), name='cin')(_t('cin_x', torch.float32)), ['cin_kernel', 'cin_bias'],
                  rename=lambda n: 'cin/' + n)
   _close(got, _t('cin_out'), 2e-5)
+
+
+# ------------------------------------------------------------------------------------------------ model assemblies
+import sys  # noqa: E402
+sys.path.insert(0, os.path.join(HERE, 'golden'))
+import model_assembly_cases as mac  # noqa: E402
+
+
+class _Groups(object):
+  """stands in for the product's InputLayer / SeqInputLayer: `layer(features, group)` -> (concatenation, feature list)
+  or the DIN tower's dict, from the fixture"""
+
+  def __init__(self, tag, groups):
+    self.data = {}
+    for gname, spec in groups.items():
+      if spec[0] == 'cat':
+        feats = [_t('m:%s:%s:%d' % (tag, gname, i), torch.float32) for i in range(len(spec[1]))]
+        self.data[gname] = (torch.cat(feats, dim=1), feats)
+      else:
+        self.data[gname] = {'key': _t('m:%s:%s:key' % (tag, gname), torch.float32),
+                            'hist_seq_emb': _t('m:%s:%s:hist_seq_emb' % (tag, gname), torch.float32),
+                            'hist_seq_len': torch.from_numpy(np.asarray(G['m:%s:%s:hist_seq_len' % (tag, gname)])).to(torch.int32),
+                            'aux_hist_seq_emb_list': []}
+
+  def has_group(self, name):
+    return name in self.data
+
+  def __call__(self, features, group, **kwargs):
+    return self.data[group]
+
+
+@pytest.mark.parametrize('tag', list(mac.CASES))
+def test_product_model_assemblies(ref_backend, tag):
+  """build_predict_graph of THE PRODUCT's model classes (easyrec_amd/model/*.py, host code over the stand-in kernels)
+  against build_predict_graph of the reference's model classes (run by the generator on the same group features): the
+  order of the concatenations, which DNN gets which input, variable names (the reference's variables are loaded BY
+  NAME) - and the modes: the experts of MMoE / DBMTL normalise with the moving statistics, as the reference's do."""
+  from easyrec_amd.model import (dbmtl, dcn, deepfm, dlrm, fm, mmoe, multi_tower, multi_tower_din, ple,
+                                 simple_multi_task, wide_and_deep)
+  model, text, groups = mac.CASES[tag]
+  cls = {'deepfm': deepfm.DeepFM, 'fm': fm.FM, 'dcn': dcn.DCN, 'wide_and_deep': wide_and_deep.WideAndDeep,
+         'dlrm': dlrm.DLRM, 'multi_tower': multi_tower.MultiTower, 'multi_tower_din': multi_tower_din.MultiTowerDIN,
+         'simple_multi_task': simple_multi_task.SimpleMultiTask, 'mmoe': mmoe.MMoE, 'ple': ple.PLE,
+         'dbmtl': dbmtl.DBMTL}[model]
+  cfg = mac.sub_config(model, text)
+  layer = _Groups(tag, groups)
+  got = {}
+
+  def run():
+    obj = object.__new__(cls)  # (the constructor builds the input layer, which is not what is compared here)
+    obj._model_config, obj._l2_reg, obj._is_training, obj._num_class = cfg, None, True, 1
+    obj._prediction_dict, obj._feature_dict, obj._input_layer, obj._seq_input_layer = {}, None, layer, layer
+    obj._labels, obj._label_name_dict = None, {}
+    if model in ('deepfm', 'fm', 'wide_and_deep'):
+      obj._wide_output_dim = cfg.wide_output_dim if model == 'wide_and_deep' else 1
+    if model in ('multi_tower', 'multi_tower_din'):
+      obj._tower_num, obj._din_tower_num = len(cfg.towers), len(cfg.din_towers)
+    if hasattr(cfg, 'task_towers'):
+      obj._init_towers(cfg.task_towers)
+    obj._add_to_prediction_dict = lambda o: got.__setitem__('out', o)
+    obj.build_predict_graph()
+    return got['out']
+
+  prefix = tag + '::'
+  out = _product(run, [prefix], rename=lambda n: n[len(prefix):])
+  if isinstance(out, dict):
+    want = {k[len('m:%s:out:' % tag):]: k for k in G.files if k.startswith('m:%s:out:' % tag)}
+    assert sorted(out) == sorted(want)
+    for name, key in want.items():
+      _close(out[name], _t(key), 5e-5)
+  else:
+    _close(out, _t('m:%s:out' % tag), 5e-5)
 
 
 # ------------------------------------------------------------------------------------------------ the HIP kernels

@@ -582,9 +582,10 @@ def ple_variant(src_name, dst_name):
   write(cfg, dst_name)
 
 
-def dbmtl_variant(src_name, dst_name):
+def dbmtl_variant(src_name, dst_name, experts=0):
   """The MMoE fixture as DBMTL (reference model/dbmtl.py): bottom_dnn, per-task towers, cvr's relation network also
-  reads ctr's relation features."""
+  reads ctr's relation features.  experts > 0: + the MMoE block between the bottom and the towers (the shape of the
+  reference's samples/model_config/dbmtl_mmoe_on_taobao.config)."""
   from easyrec_amd.protos import pipeline_pb2
   here = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'configs')
   cfg = pipeline_pb2.EasyRecConfig()
@@ -598,6 +599,9 @@ def dbmtl_variant(src_name, dst_name):
   db = cfg.model_config.dbmtl
   db.l2_regularization = l2
   db.bottom_dnn.hidden_units.extend([128, 64])
+  if experts > 0:
+    db.expert_dnn.hidden_units.extend([64, 32])
+    db.num_expert = experts
   for i, t in enumerate(towers):
     bt = db.task_towers.add()
     bt.tower_name, bt.label_name, bt.num_class, bt.weight = t.tower_name, t.label_name, t.num_class, t.weight
@@ -658,3 +662,4 @@ if __name__ == '__main__':
   simple_multi_task_variant('mmoe_taobao_small.config', 'simple_multi_task_taobao_small.config')
   ple_variant('mmoe_taobao_small.config', 'ple_taobao_small.config')
   dbmtl_variant('mmoe_taobao_small.config', 'dbmtl_taobao_small.config')
+  dbmtl_variant('mmoe_taobao_small.config', 'dbmtl_mmoe_taobao_small.config', experts=3)
