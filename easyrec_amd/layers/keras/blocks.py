@@ -30,7 +30,7 @@ class MLP(object):
     self.final_activation = params.get_or_default('final_activation', None)
     assert not params.get_or_default('use_bn_after_activation', False), \
         'use_bn_after_activation is outside the hot-path scope'
-    self.units = list(params.hidden_units)
+    self.units = [int(u) for u in params.hidden_units]  # (st_params hold doubles; keras Dense takes int(units))
     assert len(self.units) > 0, 'MLP(%s) takes at least one hidden units' % name
     self.l2_reg = params.l2_regularizer
     self.add_to_outputs = params.get_or_default('add_to_outputs', False)

@@ -31,7 +31,9 @@ class DIN(object):
     att.use_final_bn, att.use_final_bias, att.final_activation = False, True, 'linear'
     mlp_params = Parameter.make_from_pb(att)
     mlp_params.l2_regularizer = self.l2_reg
-    self.din_layer = MLP(mlp_params, 'din_attention', reuse=reuse)
+    # a layer called inside another layer's call() creates its variables under BOTH name scopes (keras): two DIN
+    # blocks of one backbone keep separate attention MLPs, `<block>/din_attention/layer_i/...`
+    self.din_layer = MLP(mlp_params, name + '/din_attention', reuse=reuse)
 
   def __call__(self, inputs, training=None, **kwargs):
     keys, seq_len, query = inputs

@@ -20,7 +20,8 @@ class MMoE(object):
     if params.has_field('expert_mlp'):
       expert_params = params.expert_mlp
       expert_params.l2_regularizer = self._l2_reg
-      self._experts = [MLP(expert_params, 'expert_%d' % i, reuse) for i in range(self._num_expert)]
+      # (variables of the nested layers carry this layer's name scope too: `<block>/expert_i/...`, `<block>/gate_t/...`)
+      self._experts = [MLP(expert_params, '%s/expert_%d' % (name, i), reuse) for i in range(self._num_expert)]
 
   def __call__(self, inputs, training=None, **kwargs):
     if self._num_expert == 0:
@@ -33,7 +34,8 @@ class MMoE(object):
     # without built-in expert MLPs the gate reads the extra last input (multi_task.py:57-58)
     gate_input = inputs if self._experts else inputs[self._num_expert]
     gate_logits = torch.stack([
-        dnn.dense(gate_input, self._num_expert, 'gate_%d' % t, l2_reg=self._l2_reg) for t in range(self._num_task)
+        dnn.dense(gate_input, self._num_expert, '%s/gate_%d' % (self.name, t), l2_reg=self._l2_reg)
+        for t in range(self._num_task)
     ], dim=0)
     mixed = kernels.MMoEMixFn.apply(experts, gate_logits)
     return [mixed[t] for t in range(self._num_task)]

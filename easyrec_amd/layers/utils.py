@@ -56,8 +56,13 @@ class _MessageSource(object):
     value = getattr(self.raw, key, _MISSING)
     if value is _MISSING:
       return False
-    if hasattr(value, '__len__') and not isinstance(value, (str, bytes)):
-      return len(value) > 0  # repeated field: present when non-empty
+    if hasattr(value, '__len__'):
+      # repeated field: present when non-empty.  STRINGS have a length too, and the reference's test is exactly this
+      # one (layers/utils.py:226-229): an unset string field whose proto default is non-empty counts as present and
+      # yields that default - e.g. `mlp { hidden_units: ... }` gets final_activation 'relu' (protos/dnn.proto:26), where
+      # the same MLP configured through st_params gets the layer's default None.  Pinned by
+      # tests/test_reference_layers.py::test_product_keras_mmoe against the reference's own Parameter.
+      return len(value) > 0
     try:
       return self.raw.HasField(key)
     except ValueError:  # proto3-style scalar without presence: treat as unset
@@ -123,7 +128,8 @@ class Parameter(object):
 
   def get_or_default(self, key, def_val):
     """The configured value of `key`, or `def_val` when the config does not set it (an unset proto field does NOT
-    fall back to the proto's own default: the layer's default wins)."""
+    fall back to the proto's own default: the layer's default wins - except for string fields, see
+    _MessageSource.present)."""
     if not self._src.present(key):
       return def_val
     return self._src.coerce(self._src.fetch(key), def_val)

@@ -759,9 +759,16 @@ class OracleTrainer(object):
   # ------------------------------------------------------------------ backbone (RankModel)
   def _keras_mlp(self, V, x, p, name, l2):
     """layers/keras/blocks.py:37-128: Dense(use_bias=False, he_uniform) -> BatchNorm -> activation per layer;
-    the LAST layer has BN too (use_final_bn default true) and `final_activation` (default none)."""
+    the LAST layer has BN too (use_final_bn default true) and `final_activation` (the layer's default is none; a
+    proto-configured MLP that leaves it unset gets the proto default 'relu', see opt below)."""
     def opt(field, default):
-      return getattr(p, field) if p.HasField(field) else default
+      # Parameter.get_or_default on a proto message (layers/utils.py:222-236): anything with a length - repeated
+      # fields AND strings - is taken when non-empty, so an unset string field yields its non-empty PROTO default
+      # (final_activation 'relu', protos/dnn.proto:26); other scalars only when set
+      value = getattr(p, field)
+      if hasattr(value, '__len__'):
+        return value if len(value) > 0 else default
+      return value if p.HasField(field) else default
     units = list(p.hidden_units)
     use_bn, use_final_bn = opt('use_bn', True), opt('use_final_bn', True)
     use_bias, use_final_bias = opt('use_bias', False), opt('use_final_bias', False)
@@ -784,7 +791,7 @@ class OracleTrainer(object):
           x = torch.relu(x)
     return x
 
-  def _keras_din(self, V, keys, seq_len, query, cfg, l2):
+  def _keras_din(self, V, keys, seq_len, query, cfg, l2, name='din'):
     """layers/keras/din.py:13-67: attention MLP `din_attention` (last layer: bias, no BN, linear) over
     [q, h, q - h, q * h]; -2^32 + 1 on padding; softmax | sigmoid(score / sqrt(E)); scores @ h (+ the target)."""
     import copy
@@ -795,7 +802,7 @@ class OracleTrainer(object):
     din_all = torch.cat([cur, keys, cur - keys, cur * keys], dim=-1)
     att = copy.deepcopy(cfg.attention_dnn)
     att.use_final_bn, att.use_final_bias, att.final_activation = False, True, 'linear'
-    scores = self._keras_mlp(V, din_all, att, 'din_attention', l2).reshape(B, 1, L)
+    scores = self._keras_mlp(V, din_all, att, name + '/din_attention', l2).reshape(B, 1, L)
     mask = (torch.arange(L)[None, :] < torch.as_tensor(seq_len)[:, None])[:, None, :]
     scores = torch.where(mask, scores, torch.full_like(scores, float(-2**32 + 1)))
     if cfg.attention_normalizer == 'softmax':
@@ -858,10 +865,86 @@ class OracleTrainer(object):
       prod = prod + diag * x
     return x0 * prod + x
 
+  def _keras_mmoe(self, V, x, cfg, name, l2):
+    """layers/keras/multi_task.py:18-68: `num_expert` keras MLPs `expert_i` over the input (or, without expert_mlp, the
+    first num_expert entries of the input list as experts and the entry after them as the gates' input); per task a
+    Dense(num_expert, softmax) gate `gate_t`; the list of the tasks' mixtures."""
+    E, T = cfg.num_expert, cfg.num_task
+    if E == 0:
+      return x
+    if cfg.HasField('expert_mlp'):
+      experts = [self._keras_mlp(V, x, cfg.expert_mlp, '%s/expert_%d' % (name, i), l2) for i in range(E)]
+      gate_in = x
+    else:
+      experts, gate_in = list(x)[:E], x[E]
+    stacked = torch.stack(experts, dim=1)
+    out = []
+    for t in range(T):
+      gate = torch.softmax(self.dense(V, gate_in, E, '%s/gate_%d' % (name, t), l2), dim=-1)
+      out.append((stacked * gate[:, :, None]).sum(dim=1))
+    return out
+
+  def _keras_senet(self, V, inputs, cfg, name):
+    """layers/keras/fibinet.py:15-92: per field and squeeze group the max and the mean over the group's columns ->
+    Dense W1 (relu, with bias) -> Dense W2 (sum of the dims) -> re-weight the concatenated embeddings (+ skip
+    connection, + LayerNormalization `output_ln`, epsilon 1e-3)."""
+    g = int(cfg.num_squeeze_group)
+    inputs = list(inputs)
+    sq = []
+    for emb in inputs:
+      grouped = emb.reshape(emb.shape[0], g, -1)
+      sq.append(grouped.max(dim=-1).values)
+      sq.append(grouped.mean(dim=-1))
+    z = torch.cat(sq, dim=1)
+    emb_size = sum(int(e.shape[-1]) for e in inputs)
+    red = max(1, len(inputs) * g * 2 // int(cfg.reduction_ratio))
+    a1 = torch.relu(self.dense(V, z, red, name + '/W1', 0.0))
+    w = self.dense(V, a1, emb_size, name + '/W2', 0.0)
+    x = torch.cat(inputs, dim=-1)
+    out = x * w
+    if cfg.use_skip_connection:
+      out = out + x
+    if cfg.use_output_layer_norm:
+      mean = out.mean(dim=-1, keepdim=True)
+      var = ((out - mean) ** 2).mean(dim=-1, keepdim=True)
+      out = (out - mean) / torch.sqrt(var + 1e-3) * V.get(name + '/output_ln/gamma') + V.get(name + '/output_ln/beta')
+    return out
+
   def _rank_backbone(self, V, batch):
-    """model/rank_model.py:38-55 over layers/backbone.py: blocks in config order (the shipped configs list them
+    """model/rank_model.py:38-55: the backbone's output, top_mlp aside, + the head `output` dense when its width is
+    not num_class."""
+    mc = self.cfg.model_config
+    out = self._backbone(V, batch)
+    if out.shape[-1] != mc.num_class:
+      out = self.dense(V, out, mc.num_class, 'output', 0.0)
+    return {'logits': out.squeeze(1)}
+
+  def _multi_task_backbone(self, V, batch):
+    """model/multi_task_model.py:33-100 (model_class MultiTaskModel): the backbone yields one input per tower or one
+    shared input; tower DNN `<tower>`, Bayes relation DNN `<tower>/relation_dnn` over [own features, the named
+    earlier towers' relation features], `<tower>/output`."""
+    mc = self.cfg.model_config
+    l2 = mc.model_params.l2_regularization
+    towers = list(mc.model_params.task_towers)
+    shared = self._backbone(V, batch)
+    inputs = list(shared) if isinstance(shared, (list, tuple)) else [shared] * len(towers)
+    assert len(inputs) == len(towers), 'The number of backbone outputs and task towers must be equal'
+    feats, rel, pred = {}, {}, {}
+    for tower, x in zip(towers, inputs):
+      feats[tower.tower_name] = self.dnn(V, x, tower.dnn, tower.tower_name, l2) if tower.HasField('dnn') else x
+    for tower in towers:
+      nm = tower.tower_name
+      x = feats[nm]
+      if tower.HasField('relation_dnn'):
+        x = torch.cat([x] + [rel[r] for r in tower.relation_tower_names], dim=-1)
+        x = rel[nm] = self.dnn(V, x, tower.relation_dnn, nm + '/relation_dnn', l2)
+      pred['logits_%s' % nm] = self.dense(V, x, tower.num_class, nm + '/output', l2).squeeze(1)
+    return pred
+
+  def _backbone(self, V, batch):
+    """layers/backbone.py: blocks in config order (the shipped configs list them
     topologically), feature-group inputs -> input layer, `input_fn` lambdas, keras_layer MLP / Cross, recurrent
-    with a fixed input, concat_blocks, top_mlp, head `output` dense when the width != num_class."""
+    with a fixed input, concat_blocks, top_mlp."""
     mc = self.cfg.model_config
     bb = mc.backbone
     l2 = mc.model_params.l2_regularization
@@ -927,7 +1010,7 @@ class OracleTrainer(object):
         elif kl.class_name == 'Cross':
           x = self._keras_cross(V, x[0], x[1], kl.st_params, blk.name)
         elif kl.class_name == 'DIN':
-          x = self._keras_din(V, x[0], x[1], x[2], kl.din, l2)
+          x = self._keras_din(V, x[0], x[1], x[2], kl.din, l2, blk.name)
         elif kl.class_name == 'Add':
           x = _TF.add_n(list(x))
         elif kl.class_name == 'DotInteraction':
@@ -939,6 +1022,10 @@ class OracleTrainer(object):
           x = torch.stack([inter[:, i, j] for i in range(F) for j in range(i + 1 if self_inter else i)], dim=1)
         elif kl.class_name == 'CIN':
           x = self._keras_cin(V, x, [int(h) for h in kl.cin.hidden_feature_sizes], blk.name)
+        elif kl.class_name == 'MMoE':
+          x = self._keras_mmoe(V, x, kl.mmoe, blk.name, l2)
+        elif kl.class_name == 'SENet':
+          x = self._keras_senet(V, x, kl.senet, blk.name)
         elif kl.class_name == 'FM':
           fl = torch.stack(list(x), dim=1)  # [B, F, D]
           x = 0.5 * (fl.sum(dim=1) ** 2 - (fl ** 2).sum(dim=1))
@@ -965,12 +1052,11 @@ class OracleTrainer(object):
     if not concat:  # no concat_blocks / output_blocks: every leaf block, in config order (backbone.py:187-196)
       used = {getattr(node, node.WhichOneof('name')) for blk in bb.blocks for node in blk.inputs}
       concat = [blk.name for blk in bb.blocks if blk.name not in used]
+    # merge_inputs (backbone.py:532-550): one output is handed on as it is (a list stays a list)
     out = torch.cat([outs[n] for n in concat], dim=-1) if len(concat) > 1 else outs[concat[0]]
     if bb.HasField('top_mlp'):
       out = self._keras_mlp(V, out, bb.top_mlp, 'backbone_top_mlp', l2)
-    if out.shape[-1] != mc.num_class:
-      out = self.dense(V, out, mc.num_class, 'output', 0.0)
-    return {'logits': out.squeeze(1)}
+    return out
 
   # ------------------------------------------------------------------ one step
   def forward(self, batch):
@@ -982,9 +1068,10 @@ class OracleTrainer(object):
     labels_np = np.asarray(batch['labels'], dtype=np.float32)
     ce_of = lambda z, y: (torch.clamp(z, min=0) - z * y + torch.log1p(torch.exp(-torch.abs(z)))).mean()  # noqa: E731
     losses = OrderedDict()
-    if self.model_class in ('MMoE', 'SimpleMultiTask', 'PLE', 'DBMTL'):
+    if self.model_class in ('MMoE', 'SimpleMultiTask', 'PLE', 'DBMTL', 'MultiTaskModel'):
       fn, sub = {'MMoE': (self._mmoe, 'mmoe'), 'SimpleMultiTask': (self._simple_multi_task, 'simple_multi_task'),
-                 'PLE': (self._ple, 'ple'), 'DBMTL': (self._dbmtl, 'dbmtl')}[self.model_class]
+                 'PLE': (self._ple, 'ple'), 'DBMTL': (self._dbmtl, 'dbmtl'),
+                 'MultiTaskModel': (self._multi_task_backbone, 'model_params')}[self.model_class]
       pred = fn(V, batch)
       towers = getattr(self.cfg.model_config, sub).task_towers
       label_fields = list(self.cfg.data_config.label_fields)

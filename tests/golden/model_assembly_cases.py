@@ -134,6 +134,26 @@ CASES['dbmtl_no_mmoe'] = ('dbmtl', """
                 relation_dnn { hidden_units: [2] } }
 """, OrderedDict(all=('cat', [4, 3])))
 
+# model_class: "MultiTaskModel" over a backbone (model/multi_task_model.py:33-100): `text` is the body of model_params;
+# the backbone's output is the group `backbone` (one shared tensor) or the groups `backbone_<i>` (one per tower)
+CASES['multi_task_backbone_shared'] = ('multi_task_model', """
+  task_towers { tower_name: "ctr" label_name: "clk" dnn { hidden_units: [5, 3] } }
+  task_towers { tower_name: "cvr" label_name: "buy" dnn { hidden_units: [4] } relation_dnn { hidden_units: [3] } }
+  task_towers { tower_name: "fav" label_name: "fav" relation_tower_names: "cvr" relation_dnn { hidden_units: [4, 2] } }
+""", OrderedDict(backbone=('cat', [7])))
+
+CASES['multi_task_backbone_chain'] = ('multi_task_model', """
+  task_towers { tower_name: "ctr" label_name: "clk" dnn { hidden_units: [5, 3] } relation_dnn { hidden_units: [4, 2] } }
+  task_towers { tower_name: "cvr" label_name: "buy" relation_tower_names: "ctr" dnn { hidden_units: [4] }
+                relation_dnn { hidden_units: [3] } }
+  task_towers { tower_name: "fav" label_name: "fav" }
+""", OrderedDict(backbone=('cat', [7])))
+
+CASES['multi_task_backbone_list'] = ('multi_task_model', """
+  task_towers { tower_name: "ctr" label_name: "clk" dnn { hidden_units: [5] } relation_dnn { hidden_units: [2] } }
+  task_towers { tower_name: "cvr" label_name: "buy" relation_tower_names: "ctr" relation_dnn { hidden_units: [3] } }
+""", OrderedDict(backbone_0=('cat', [6]), backbone_1=('cat', [4])))
+
 
 def sub_config(model, text):
   """the model's config message (easyrec_amd.protos = the reference's schema) parsed from `text`"""
@@ -142,6 +162,10 @@ def sub_config(model, text):
   from easyrec_amd.protos import easy_rec_model_pb2
   field = 'multi_tower' if model == 'multi_tower_din' else model
   cfg = easy_rec_model_pb2.EasyRecModel()
+  if model == 'multi_task_model':  # the model class reads model_params off the whole model config
+    cfg.model_class = 'MultiTaskModel'
+    text_format.Merge(text, cfg.model_params)
+    return cfg
   sub = getattr(cfg, field)
   sub.SetInParent()
   text_format.Merge(text, sub)

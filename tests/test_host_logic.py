@@ -124,7 +124,10 @@ def test_csv_input_roundtrip(tmp_path, built_lib):
                                       ('dlrm_shared_criteo_small.config', 24), ('deepfm_shared_criteo_small.config', 24),
                                       ('deepfm_combo_criteo_small.config', 24), ('deepfm_lookup_criteo_small.config', 24),
                                       ('simple_multi_task_taobao_small.config', 24), ('ple_taobao_small.config', 24),
-                                      ('dbmtl_taobao_small.config', 24), ('dbmtl_mmoe_taobao_small.config', 24)])
+                                      ('dbmtl_taobao_small.config', 24), ('dbmtl_mmoe_taobao_small.config', 24),
+                                      ('mmoe_backbone_taobao_small.config', 24),
+                                      # (B = 24 with this data seed puts one example of cvr/dnn_0 on a ReLU tie: B = 32)
+                                      ('mmoe_backbone_bayes_taobao_small.config', 32)])
 def test_other_models_match_model_oracle(ref_backend, config, B):
   """DCN / MultiTowerDIN / MMoE host logic (variable naming, layer wiring, multi-task losses, sequence and
   tag lookups) against the independent model-level oracle, 2 optimisation steps."""

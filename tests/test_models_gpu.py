@@ -86,6 +86,13 @@ def test_neighbouring_models_match_oracle(name):
   _first_steps(_cfg(name), 128, 41)
 
 
+@pytest.mark.parametrize('name', ['mmoe_backbone_taobao_small.config', 'mmoe_backbone_bayes_taobao_small.config'])
+def test_multi_task_model_over_a_backbone_matches_oracle(name):
+  """`model_class: "MultiTaskModel"` over a backbone of SENet -> keras MMoE (the reference's
+  samples/model_config/mmoe_backbone_on_taobao.config), and with Bayes relation towers."""
+  _first_steps(_cfg(name), 128, 71)
+
+
 @pytest.mark.parametrize('name', ['dcn_v2_criteo_small.config', 'dcn_v2_lowrank_criteo_small.config'])
 def test_dcn_v2_backbone_matches_oracle(name):
   """RankModel + backbone {MLP || recurrent Cross} + top_mlp (layers/backbone.py, layers/keras/*)."""
@@ -125,10 +132,12 @@ def test_dcn_v2_bf16_dense_tracks_the_fp32_oracle():
 
 
 def test_mmoe_matches_oracle():
-  # seed chosen away from a ReLU tie: with seed 23 one pre-activation of expert_3 sits within rounding of 0, the
-  # GPU and the oracle take different sides and that one example's gradient (1/128 of the batch) differs by ~1%
-  # (tools/dbg_mmoe_gpu.py reproduces it).  Seed 25: no ReLU input of the two steps within 1e-6 of its column's scale
-  _first_steps(_cfg('mmoe_taobao_small.config'), 128, 25)
+  # Seed chosen away from a ReLU tie.  The experts run BatchNorm on the moving statistics (the reference's MMoE), so
+  # nothing brings their pre-activations to O(1): among the ~250 K ReLU inputs of a step some lie within 1e-6 of their
+  # column's scale of zero, where the GPU GEMM's summation order decides the side and that one example's gradient
+  # (1/128 of the batch) moves a column by ~1%.  tools/scan_mmoe_seeds_gpu.py: seeds 24, 26, 27, 33, 41, 44, 46, 52
+  # agree within the tolerances below, 25 and 28 hit a tie (one column of one first-layer tensor).
+  _first_steps(_cfg('mmoe_taobao_small.config'), 128, 46)
 
 
 @pytest.mark.parametrize('name,B,dtype', [('din_taobao.config', 4096, 'f32'), ('mmoe_taobao.config', 4096, 'f32'),

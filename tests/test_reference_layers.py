@@ -170,10 +170,13 @@ def test_dnn_din_mmoe_restatements():
 
 @pytest.mark.parametrize('tag,text', [('default', 'hidden_units: [6, 3]'),
                                       ('final_linear', "hidden_units: [4, 1] use_final_bn: false final_activation: 'linear'"),
-                                      ('biased', 'hidden_units: [4, 2] use_bias: true use_final_bias: true use_bn: false')])
+                                      ('biased', 'hidden_units: [4, 2] use_bias: true use_final_bias: true use_bn: false'),
+                                      ('final_none', "hidden_units: [5, 2] final_activation: ''")])
 def test_keras_mlp_restatement(tag, text):
-  """layers/keras/blocks.py MLP: Dense without bias -> BatchNorm -> activation per layer by default, the LAST layer with
-  BatchNorm too and no activation; use_final_bn / final_activation / use_bias / use_final_bias / use_bn as configured."""
+  """layers/keras/blocks.py MLP configured as a backbone block is (the reference's Parameter over dnn_pb2.MLP): Dense
+  without bias -> BatchNorm -> activation per layer by default, the LAST layer with BatchNorm too and - the proto
+  default of the string field coming through Parameter.get_or_default - ReLU, unless final_activation says otherwise
+  ('' = none); use_final_bn / use_bias / use_final_bias / use_bn as configured."""
   from google.protobuf import text_format
 
   from easyrec_amd.protos import dnn_pb2
@@ -196,7 +199,7 @@ def test_keras_din_restatement(tag, normalizer, need_target, query):
   text_format.Merge("attention_dnn { hidden_units: [6, 1] activation: 'relu' } attention_normalizer: '%s' "
                     'need_target_feature: %s' % (normalizer, 'true' if need_target else 'false'), cfg)
   state = {k[len('var:kdin_%s/' % tag):]: G[k] for k in G.files if k.startswith('var:kdin_%s/' % tag)}
-  state = {'din_attention/' + k: v for k, v in state.items()}
+  state = {'din/din_attention/' + k: v for k, v in state.items()}
   for k in list(state):
     if k.endswith('/bn/gamma'):
       n = state[k].shape[0]
@@ -296,11 +299,24 @@ def test_product_layers_on_the_stand_in_backend(ref_backend):
   _close(tasks[0], _t('mmoe_task_0'), 2e-5)
   _close(tasks[1], _t('mmoe_task_1'), 2e-5)
   xl = _t('mlp_x', torch.float32)
-  for tag, kw in (('default', dict(hidden_units=[6, 3])),
-                  ('final_linear', dict(hidden_units=[4, 1], use_final_bn=False, final_activation='linear')),
-                  ('biased', dict(hidden_units=[4, 2], use_bias=True, use_final_bias=True, use_bn=False))):
-    got = _product(lambda: MLP(_P(**kw), name='mlp_%s' % tag)(xl, training=True), ['mlp_%s/' % tag])
+  from google.protobuf import struct_pb2, text_format
+
+  from easyrec_amd.layers.utils import Parameter
+  from easyrec_amd.protos import dnn_pb2 as _dnn_pb2
+  for tag, text in (('default', 'hidden_units: [6, 3]'),
+                    ('final_linear', "hidden_units: [4, 1] use_final_bn: false final_activation: 'linear'"),
+                    ('biased', 'hidden_units: [4, 2] use_bias: true use_final_bias: true use_bn: false'),
+                    ('final_none', "hidden_units: [5, 2] final_activation: ''")):
+    pb = _dnn_pb2.MLP()
+    text_format.Merge(text, pb)
+    got = _product(lambda: MLP(Parameter.make_from_pb(pb), name='mlp_%s' % tag)(xl, training=True), ['mlp_%s/' % tag])
     _close(got, _t('mlp_%s_out' % tag), 2e-5)
+  # the same block through st_params: an unset final_activation is the layer's default (none) there
+  st = struct_pb2.Struct()
+  st.update({'hidden_units': [6, 3]})
+  got = _product(lambda: MLP(Parameter(st, True), name='mlp_struct')(xl, training=True), ['mlp_struct/'])
+  _close(got, _t('mlp_struct_out'), 2e-5)
+  assert float((_t('mlp_struct_out') < 0).sum()) > 0 and float((_t('mlp_default_out') < 0).sum()) == 0
   x0, xx = _t('cross_x0', torch.float32), _t('cross_x', torch.float32)
   for tag, kw in (('full', {}), ('diag', {'diag_scale': 0.25})):
     got = _product(lambda: Cross(_P(**kw), name='cross')((x0, xx)), ['cross_%s_' % tag],
@@ -346,16 +362,23 @@ def test_product_model_assemblies(ref_backend, tag):
   against build_predict_graph of the reference's model classes (run by the generator on the same group features): the
   order of the concatenations, which DNN gets which input, variable names (the reference's variables are loaded BY
   NAME) - and the modes: the experts of MMoE / DBMTL normalise with the moving statistics, as the reference's do."""
-  from easyrec_amd.model import (dbmtl, dcn, deepfm, dlrm, fm, mmoe, multi_tower, multi_tower_din, ple,
-                                 simple_multi_task, wide_and_deep)
+  from easyrec_amd.model import (dbmtl, dcn, deepfm, dlrm, fm, mmoe, multi_task_model, multi_tower, multi_tower_din,
+                                 ple, simple_multi_task, wide_and_deep)
   model, text, groups = mac.CASES[tag]
   cls = {'deepfm': deepfm.DeepFM, 'fm': fm.FM, 'dcn': dcn.DCN, 'wide_and_deep': wide_and_deep.WideAndDeep,
          'dlrm': dlrm.DLRM, 'multi_tower': multi_tower.MultiTower, 'multi_tower_din': multi_tower_din.MultiTowerDIN,
          'simple_multi_task': simple_multi_task.SimpleMultiTask, 'mmoe': mmoe.MMoE, 'ple': ple.PLE,
-         'dbmtl': dbmtl.DBMTL}[model]
+         'dbmtl': dbmtl.DBMTL, 'multi_task_model': multi_task_model.MultiTaskModel}[model]
   cfg = mac.sub_config(model, text)
   layer = _Groups(tag, groups)
   got = {}
+  if model == 'multi_task_model':  # towers over a backbone: its output(s) come from the fixture
+
+    def backbone(self):
+      return layer.data['backbone'][0] if 'backbone' in layer.data else [layer.data[n][0] for n in groups]
+
+    # (model classes register themselves by name: one name per case)
+    cls = type(cls)('MultiTaskOver_' + tag, (cls,), {'has_backbone': True, 'backbone': property(backbone)})
 
   def run():
     obj = object.__new__(cls)  # (the constructor builds the input layer, which is not what is compared here)
@@ -366,6 +389,7 @@ def test_product_model_assemblies(ref_backend, tag):
       obj._wide_output_dim = cfg.wide_output_dim if model == 'wide_and_deep' else 1
     if model in ('multi_tower', 'multi_tower_din'):
       obj._tower_num, obj._din_tower_num = len(cfg.towers), len(cfg.din_towers)
+    obj._outputs, obj._towers = [], []
     if hasattr(cfg, 'task_towers'):
       obj._init_towers(cfg.task_towers)
     obj._add_to_prediction_dict = lambda o: got.__setitem__('out', o)
@@ -381,6 +405,46 @@ def test_product_model_assemblies(ref_backend, tag):
       _close(out[name], _t(key), 5e-5)
   else:
     _close(out, _t('m:%s:out' % tag), 5e-5)
+
+
+@pytest.mark.parametrize('tag,text', [('mlp', 'num_task: 2 num_expert: 3 expert_mlp { hidden_units: [5, 3] }'),
+                                      ('plain_final', "num_task: 3 num_expert: 2 expert_mlp { hidden_units: [4] use_final_bn: false "
+                                       "final_activation: 'linear' use_final_bias: true }")])
+def test_product_keras_mmoe(ref_backend, tag, text):
+  """easyrec_amd's keras MMoE block, configured by ITS Parameter over the layer_pb2 message, against the reference's
+  layers/keras/multi_task.py MMoE configured by the reference's Parameter over the same message (what an unset
+  `final_activation` means - None, not the proto default 'relu' - comes out of Parameter.get_or_default)."""
+  from google.protobuf import text_format
+
+  from easyrec_amd.layers.keras import MMoE
+  from easyrec_amd.layers.utils import Parameter
+  from easyrec_amd.protos import layer_pb2
+  pb = layer_pb2.MMoELayer()
+  text_format.Merge(text, pb)
+  name = 'kmmoe_' + tag
+  tasks = _product(lambda: MMoE(Parameter.make_from_pb(pb), name=name)(_t('kmmoe_x', torch.float32), training=True),
+                   [name + '/'])
+  assert len(tasks) == pb.num_task
+  for t, got in enumerate(tasks):
+    _close(got, _t('kmmoe_%s_task_%d' % (tag, t)), 2e-5)
+
+
+@pytest.mark.parametrize('tag,text', [('default', 'reduction_ratio: 4'),
+                                      ('bare', 'reduction_ratio: 2 num_squeeze_group: 1 use_skip_connection: false '
+                                       'use_output_layer_norm: false')])
+def test_product_senet(ref_backend, tag, text):
+  """the SENet block in front of MMoE in the reference's mmoe_backbone_on_taobao.config (layers/keras/fibinet.py)"""
+  from google.protobuf import text_format
+
+  from easyrec_amd.layers.keras import SENet
+  from easyrec_amd.layers.utils import Parameter
+  from easyrec_amd.protos import layer_pb2
+  pb = layer_pb2.SENet()
+  text_format.Merge(text, pb)
+  name = 'senet_' + tag
+  fields = [_t('senet_in_%d' % i, torch.float32) for i in range(3)]
+  got = _product(lambda: SENet(Parameter.make_from_pb(pb), name=name)(fields, training=True), [name + '/'])
+  _close(got, _t('senet_%s_out' % tag), 2e-5)
 
 
 # ------------------------------------------------------------------------------------------------ the HIP kernels

@@ -556,6 +556,43 @@ def simple_multi_task_variant(src_name, dst_name):
   write(cfg, dst_name)
 
 
+def mmoe_backbone_variant(src_name, dst_name, senet=True, bayes=False):
+  """The MMoE fixture in the shape of the reference's samples/model_config/mmoe_backbone_on_taobao.config:
+  `model_class: "MultiTaskModel"` over a backbone of the feature list -> SENet -> keras MMoE (3 expert MLPs), the task
+  towers in model_params.  bayes: cvr's relation network also reads ctr's relation features."""
+  from easyrec_amd.protos import pipeline_pb2
+  here = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'configs')
+  cfg = pipeline_pb2.EasyRecConfig()
+  with open(os.path.join(here, src_name)) as f:
+    text_format.Merge(f.read(), cfg)
+  mc = cfg.model_config
+  towers = [t for t in mc.mmoe.task_towers]
+  l2 = mc.mmoe.l2_regularization
+  mc.ClearField('mmoe')
+  mc.model_class = 'MultiTaskModel'
+  mc.model_name = 'MMoE'
+  text_format.Merge("""
+    blocks { name: 'all' inputs { feature_group_name: 'all' } input_layer { only_output_feature_list: true } }
+    %s
+    blocks { name: 'mmoe' inputs { block_name: '%s' }
+             keras_layer { class_name: 'MMoE' mmoe { num_task: %d num_expert: 3 expert_mlp { hidden_units: [64, 32] } } } }
+  """ % ("blocks { name: 'senet' inputs { block_name: 'all' } keras_layer { class_name: 'SENet' senet { reduction_ratio: 4 } } }"
+         if senet else "blocks { name: 'flat' inputs { block_name: 'all' input_fn: 'lambda x: tf.concat(x, axis=-1)' } }",
+         'senet' if senet else 'flat', len(towers)), mc.backbone)
+  mc.model_params.l2_regularization = l2
+  for i, t in enumerate(towers):
+    bt = mc.model_params.task_towers.add()
+    bt.tower_name, bt.label_name, bt.num_class, bt.weight = t.tower_name, t.label_name, t.num_class, t.weight
+    for m in t.metrics_set:
+      bt.metrics_set.add().CopyFrom(m)
+    bt.dnn.CopyFrom(t.dnn)
+    if bayes:
+      bt.relation_dnn.hidden_units.extend([16])
+      if i > 0:
+        bt.relation_tower_names.append(towers[0].tower_name)
+  write(cfg, dst_name)
+
+
 def ple_variant(src_name, dst_name):
   """The MMoE fixture as PLE (reference model/ple.py): two extraction networks, 2 experts per task + 2 shared."""
   from easyrec_amd.protos import pipeline_pb2
@@ -663,3 +700,5 @@ if __name__ == '__main__':
   ple_variant('mmoe_taobao_small.config', 'ple_taobao_small.config')
   dbmtl_variant('mmoe_taobao_small.config', 'dbmtl_taobao_small.config')
   dbmtl_variant('mmoe_taobao_small.config', 'dbmtl_mmoe_taobao_small.config', experts=3)
+  mmoe_backbone_variant('mmoe_taobao_small.config', 'mmoe_backbone_taobao_small.config')
+  mmoe_backbone_variant('mmoe_taobao_small.config', 'mmoe_backbone_bayes_taobao_small.config', senet=False, bayes=True)
