@@ -447,6 +447,67 @@ def test_product_senet(ref_backend, tag, text):
   _close(got, _t('senet_%s_out' % tag), 2e-5)
 
 
+import backbone_cases as bbc  # noqa: E402
+
+
+class _BackboneGroups(object):
+  """stands in for the product's InputLayer under a backbone: `layer(features, group, is_combine)`"""
+
+  def __init__(self, tag, groups):
+    self.data = {}
+    for gname, spec in groups.items():
+      if spec[0] == 'cat':
+        self.data[gname] = [_t('b:%s:%s:%d' % (tag, gname, i), torch.float32) for i in range(len(spec[1]))]
+      else:
+        self.data[gname] = {'seq': _t('b:%s:%s:seq' % (tag, gname), torch.float32),
+                            'len': torch.from_numpy(np.asarray(G['b:%s:%s:len' % (tag, gname)])).to(torch.int32),
+                            'targets': [_t('b:%s:%s:target:%d' % (tag, gname, i), torch.float32) for i in range(len(spec[3]))]}
+
+  def has_group(self, name):
+    return name in self.data
+
+  def __call__(self, features, group, is_combine=True):
+    d = self.data[group]
+    if isinstance(d, dict):
+      assert not is_combine
+      return [(d['seq'], d['len'])], None, list(d['targets'])
+    return torch.cat(d, dim=1), list(d)
+
+
+def _lowrank_cross_names(name):
+  # keras numbers the unnamed Dense sub-layers of a low-rank Cross (dense, dense_1 per graph: no stable names); this
+  # package calls them dense_u / dense_v and keeps the bias under `dense`
+  import re
+  m = re.match(r'(cross_\d+)/(dense|dense_1)/(kernel|bias)$', name)
+  if not m:
+    return name
+  layer, sub, what = m.groups()
+  if what == 'bias':
+    return '%s/dense/bias' % layer
+  return '%s/%s/kernel' % (layer, 'dense_u' if sub == 'dense' else 'dense_v')
+
+
+@pytest.mark.parametrize('tag', list(bbc.CASES))
+def test_product_backbone(ref_backend, tag):
+  """THE PRODUCT's layers/backbone.py (Backbone / Package and the keras layers it loads) on the configs of
+  tests/golden/backbone_cases.py against the REFERENCE's layers/backbone.py run by the generator on the same features
+  and variables: block order, input_fn / input_slice / extra_input_fn / ignore_input, merges, implicit input blocks,
+  keras / lambda / recurrent / repeat / sequential layers, concat_blocks or the leaves, top_mlp, list outputs."""
+  from easyrec_amd.layers.backbone import Backbone
+  text, groups = bbc.CASES[tag]
+  cfg = bbc.backbone_config(text)
+  layer = _BackboneGroups(tag, groups)
+  prefix = tag + '::'
+  rename = (lambda n: _lowrank_cross_names(n[len(prefix):])) if tag == 'bb_dcn_v2_lowrank' else (lambda n: n[len(prefix):])
+  out = _product(lambda: Backbone(cfg, None, layer, l2_reg=None)(True), [prefix], rename=rename)
+  if isinstance(out, (list, tuple)):
+    assert len(out) == len([k for k in G.files if k.startswith('b:%s:out:' % tag)])
+    for i, o in enumerate(out):
+      _close(o, _t('b:%s:out:%d' % (tag, i)), 5e-5)
+  else:
+    _close(out, _t('b:%s:out' % tag), 5e-5)
+
+
 # ------------------------------------------------------------------------------------------------ the HIP kernels
 @pytest.mark.gpu
 def test_hip_kernels_against_the_reference_layers():
