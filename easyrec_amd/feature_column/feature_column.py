@@ -355,13 +355,16 @@ class FeatureColumnParser(object):
     """Wide column = dim-`wide_output_dim` embedding with `sum` combiner (feature_column.py:596-623)."""
     feature_name = self._feature_name(config)
     assert self._wide_output_dim > 0, 'wide_output_dim is not set'
-    shared = None
+    shared, max_seq_length = None, -1
     if config.embedding_name in self._share_embed_infos:
       shared = config.embedding_name + '_wide'
+      info = self._share_embed_infos[config.embedding_name]  # (the shared columns all carry the shared info's max_seq_len)
+      max_seq_length = info.max_seq_len if info.HasField('max_seq_len') else -1
     self._wide_columns[feature_name] = EmbeddingColumn(
         fc, self._wide_output_dim, 'sum', feature_name,
         initializer=config.initializer if config.HasField('initializer') else None,
-        shared_name=shared, max_partitions=config.max_partitions, ev_params=self._ev_params_of(config))
+        shared_name=shared, max_seq_length=max_seq_length, max_partitions=config.max_partitions,
+        ev_params=self._ev_params_of(config))
 
   def _add_deep_embedding_column(self, fc, config):
     """reference feature_column.py:625-656."""

@@ -1,0 +1,191 @@
+#!/usr/bin/env python
+"""What the REFERENCE'S OWN FeatureColumnParser (easy_rec/python/feature_column/feature_column.py:41-664) builds from
+feature configs - run in the build container, where /root/reference exists.
+
+The parser is plain Python over the feature-column constructor API (categorical_column_with_hash_bucket,
+weighted_categorical_column, bucketized_column, embedding_column, shared_embedding_columns, sequence_* ...).  This script
+executes it, unmodified, against a RECORDING stand-in for that API (each constructor returns a record of its arguments;
+`num_buckets` of a record follows the documented rule of the column it stands for) and stores, per case, the feature
+configs (protobuf text), the wide / deep dictionary and a canonical description of every wide / deep / sequence column the
+parser produced.  tests/test_feature_column_pins.py builds the same description from easyrec_amd's FeatureColumnParser
+and compares: which features get which table shape, combiner, weight input, boundaries, shared-embedding name,
+max_seq_length, sequence_combiner - the static lookup plan of the embedding stage.
+
+usage: python tests/golden/make_feature_column_vectors.py [/root/reference]
+"""
+import importlib.util
+import json
+import os
+import sys
+import types
+
+REF = sys.argv[1] if len(sys.argv) > 1 else '/root/reference'
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+sys.path.insert(0, HERE)
+
+
+class Rec(object):
+  """a recorded feature column: constructor kind + arguments; the parser may set attributes on it"""
+
+  def __init__(self, kind, **kw):
+    self.kind = kind
+    self.__dict__.update(kw)
+
+  @property
+  def name(self):
+    return getattr(self, 'key', self.kind)
+
+
+def recording_api():
+  m = types.ModuleType('feature_column_v2')
+
+  def cat(kind, sequence=False):
+    def make(key, *args, **kw):
+      names = {'hash': ['hash_bucket_size'], 'identity': ['num_buckets'], 'vocab_list': ['vocabulary_list'],
+               'vocab_file': ['vocabulary_file', 'vocabulary_size']}[kind]
+      kw.update(dict(zip(names, args)))
+      if kind == 'hash':
+        n = kw['hash_bucket_size']
+      elif kind == 'identity':
+        n = kw['num_buckets']
+      elif kind == 'vocab_list':
+        n = len(kw['vocabulary_list'])  # + num_oov_buckets (0 with default_value)
+      else:
+        n = kw['vocabulary_size']
+      return Rec(kind, key=key, num_buckets=n, sequence=sequence, vocabulary=list(kw.get('vocabulary_list', [])),
+                 default_value=kw.get('default_value'), feature_name=kw.get('feature_name'))
+    return make
+
+  m.categorical_column_with_hash_bucket = cat('hash')
+  m.categorical_column_with_identity = cat('identity')
+  m.categorical_column_with_vocabulary_list = cat('vocab_list')
+  m.categorical_column_with_vocabulary_file = cat('vocab_file')
+  m.numeric_column = lambda key, shape=(1,), feature_name=None, **kw: Rec('numeric', key=key, shape=tuple(shape),
+                                                                          feature_name=feature_name)
+  m.bucketized_column = lambda source, boundaries: Rec('bucketized', key=source.key, source=source,
+                                                       boundaries=list(boundaries), num_buckets=len(boundaries) + 1,
+                                                       sequence=False)
+  m.weighted_categorical_column = lambda col, weight_feature_key, dtype=None: Rec(
+      'weighted', key=col.key, inner=col, weight_key=weight_feature_key, num_buckets=col.num_buckets, sequence=col.sequence)
+  m.crossed_column = lambda keys, hash_bucket_size, hash_key=None, feature_name=None: Rec(
+      'crossed', key=feature_name, keys=list(keys), num_buckets=hash_bucket_size, sequence=False)
+
+  def embedding_column(col, dimension, combiner='mean', initializer=None, partitioner=None, ev_params=None, **kw):
+    return Rec('embedding', col=col, dimension=dimension, combiner=combiner, initializer=initializer,
+               partitioner=partitioner, ev_params=ev_params, shared_name=None, max_seq_length=-1, sequence_combiner=None)
+
+  def shared_embedding_columns(cols, dimension, combiner='mean', initializer=None, shared_embedding_collection_name=None,
+                               partitioner=None, ev_params=None, **kw):
+    return [Rec('embedding', col=c, dimension=dimension, combiner=combiner, initializer=initializer,
+                partitioner=partitioner, ev_params=ev_params, shared_name=shared_embedding_collection_name,
+                max_seq_length=-1, sequence_combiner=None) for c in cols]
+
+  m.embedding_column, m.shared_embedding_columns = embedding_column, shared_embedding_columns
+  s = types.ModuleType('sequence_feature_column')
+  s.sequence_categorical_column_with_hash_bucket = cat('hash', True)
+  s.sequence_categorical_column_with_identity = cat('identity', True)
+  s.sequence_categorical_column_with_vocabulary_list = cat('vocab_list', True)
+  s.sequence_categorical_column_with_vocabulary_file = cat('vocab_file', True)
+  s.sequence_numeric_column = lambda key, shape=(1,), feature_name=None, **kw: Rec('seq_numeric', key=key, shape=tuple(shape),
+                                                                                   feature_name=feature_name)
+  s.sequence_numeric_column_with_bucketized_column = lambda source, boundaries: Rec(
+      'bucketized', key=source.key, source=source, boundaries=list(boundaries), num_buckets=len(boundaries) + 1, sequence=True)
+  s.sequence_numeric_column_with_raw_column = lambda source, sequence_length: Rec(
+      'seq_raw', key=source.key, sequence_length=sequence_length)
+  s.sequence_weighted_categorical_column = lambda col, weight_feature_key, dtype=None: Rec(
+      'weighted', key=col.key, inner=col, weight_key=weight_feature_key, num_buckets=col.num_buckets, sequence=True)
+  return m, s
+
+
+def describe_reference(col):
+  """canonical description (the same shape tests/test_feature_column_pins.py derives from the product's columns)"""
+  if col.kind == 'numeric':
+    return {'type': 'numeric', 'key': col.key, 'shape': int(col.shape[0])}
+  if col.kind == 'seq_raw':
+    return {'type': 'seq_numeric', 'key': col.key, 'sequence_length': int(col.sequence_length)}
+  assert col.kind == 'embedding', col.kind
+  c, weight_key = col.col, None
+  if c.kind == 'weighted':
+    weight_key, c = c.weight_key, c.inner
+  if c.kind == 'numeric':  # ExprFeature in a wide group: an embedding column over a numeric column (as the reference builds it)
+    cat = {'kind': 'numeric', 'key': c.key}
+  else:
+    kind = {'hash': 'hash', 'identity': 'identity', 'vocab_list': 'vocab', 'vocab_file': 'vocab', 'bucketized': 'bucketized',
+            # the crossed ids are computed by the input pipeline; downstream a column of ids in [0, hash_bucket_size)
+            'crossed': 'identity'}[c.kind]
+    cat = {'kind': kind, 'key': c.key, 'num_buckets': int(c.num_buckets), 'weight_key': weight_key,
+           'boundaries': [float(b) for b in getattr(c, 'boundaries', [])], 'is_sequence': bool(c.sequence),
+           'vocabulary': list(getattr(c, 'vocabulary', []))}
+  return {'type': 'embedding', 'column': cat, 'dimension': int(col.dimension), 'combiner': col.combiner,
+          'shared_name': col.shared_name, 'max_seq_length': int(col.max_seq_length),
+          'sequence_combiner': None if col.sequence_combiner is None else str(col.sequence_combiner).strip(),
+          'has_initializer': col.initializer is not None, 'partitioned': col.partitioner is not None}
+
+
+def main():
+  from google.protobuf import text_format
+
+  from easyrec_amd import protos
+  import feature_column_cases as fcc
+  tf = types.ModuleType('tensorflow')
+  tf.__version__ = '1.15.0'
+  tf.string, tf.float32 = 'string', 'float32'
+  sys.modules['tensorflow'] = tf
+  api, seq_api = recording_api()
+  for name in ('tensorflow.python', 'tensorflow.python.ops', 'tensorflow.python.ops.partitioned_variables',
+               'tensorflow.python.platform', 'tensorflow.python.platform.gfile', 'easy_rec', 'easy_rec.python',
+               'easy_rec.python.builders', 'easy_rec.python.builders.hyperparams_builder', 'easy_rec.python.compat',
+               'easy_rec.python.compat.feature_column', 'easy_rec.python.protos', 'easy_rec.python.utils'):
+    sys.modules[name] = types.ModuleType(name)
+  pv = sys.modules['tensorflow.python.ops.partitioned_variables']
+  pv.min_max_variable_partitioner = lambda max_partitions: ('min_max', max_partitions)
+  pv.fixed_size_partitioner = lambda num_shards: ('fixed', num_shards)
+  sys.modules['tensorflow.python.ops'].partitioned_variables = pv
+  sys.modules['tensorflow.python.platform'].gfile = sys.modules['tensorflow.python.platform.gfile']
+  sys.modules['tensorflow.python.platform.gfile'].GFile = open
+  hb = sys.modules['easy_rec.python.builders.hyperparams_builder']
+  hb.build_initializer = lambda cfg: ('initializer', text_format.MessageToString(cfg, as_one_line=True))
+  sys.modules['easy_rec.python.builders'].hyperparams_builder = hb
+  cf = sys.modules['easy_rec.python.compat.feature_column']
+  cf.feature_column_v2, cf.sequence_feature_column = api, seq_api
+  sys.modules['easy_rec.python.compat.feature_column.feature_column_v2'] = api
+  sys.modules['easy_rec.python.compat.feature_column.sequence_feature_column'] = seq_api
+  sys.modules['easy_rec.python.protos.feature_config_pb2'] = protos.feature_config_pb2
+  spec = importlib.util.spec_from_file_location('easy_rec.python.utils.proto_util',
+                                                os.path.join(REF, 'easy_rec/python/utils/proto_util.py'))
+  pu = importlib.util.module_from_spec(spec)
+  spec.loader.exec_module(pu)
+  sys.modules['easy_rec.python.utils.proto_util'] = pu
+  spec = importlib.util.spec_from_file_location('ref_feature_column',
+                                                os.path.join(REF, 'easy_rec/python/feature_column/feature_column.py'))
+  ref = importlib.util.module_from_spec(spec)
+  spec.loader.exec_module(ref)
+
+  cases = []
+  for tag, features_text, wide_deep, wide_output_dim, ev_text in fcc.cases():
+    fcfg = protos.feature_config_pb2.FeatureConfigV2()
+    text_format.Merge(features_text, fcfg)
+    ev = None
+    if ev_text:
+      ev = protos.feature_config_pb2.EVParams()
+      text_format.Merge(ev_text, ev)
+    wd = {k: getattr(protos.feature_config_pb2.WideOrDeep, v) if hasattr(protos.feature_config_pb2, 'WideOrDeep')
+          else v for k, v in wide_deep.items()}
+    parser = ref.FeatureColumnParser(list(fcfg.features), wd, wide_output_dim, ev_params=ev)
+    cases.append({'tag': tag, 'features': features_text, 'wide_deep': wide_deep, 'wide_output_dim': wide_output_dim,
+                  'ev_params': ev_text,
+                  'wide': {k: describe_reference(v) for k, v in parser.wide_columns.items()},
+                  'deep': {k: describe_reference(v) for k, v in parser.deep_columns.items()},
+                  'sequence': {k: describe_reference(v) for k, v in parser.sequence_columns.items()},
+                  'vocab_size': {k: int(parser.get_feature_vocab_size(k)) for k in list(parser.deep_columns) +
+                                 list(parser.sequence_columns)}})
+  path = os.path.join(HERE, 'feature_column_vectors.json')
+  with open(path, 'w') as f:
+    json.dump({'generator': 'tests/golden/make_feature_column_vectors.py', 'cases': cases}, f, indent=1, sort_keys=True)
+  print('wrote %s: %d cases, %d columns' % (path, len(cases), sum(len(c['wide']) + len(c['deep']) + len(c['sequence'])
+                                                                for c in cases)))
+
+
+if __name__ == '__main__':
+  main()
