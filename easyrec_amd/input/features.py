@@ -99,6 +99,13 @@ class FeatureSchema(object):
         hb = int(fc.hash_bucket_size) if fc.HasField('hash_bucket_size') and fc.hash_bucket_size > 0 else None
         ml = int(fc.max_seq_len) if fc.HasField('max_seq_len') and fc.max_seq_len > 0 else max_seq_len
         self.seqs[name] = {'max_len': ml, 'hash_buckets': hb}
+        if fc.sub_feature_type == FeatureConfig.RawFeature:
+          # a sequence of numbers (feature_column.py:521-545): with `boundaries` / `num_buckets` every element is
+          # bucketized into an id (sequence_numeric_column_with_bucketized_column) and embedded like an id sequence
+          bounds = raw_boundaries(fc)
+          assert bounds is not None and hb is None, \
+              'SequenceFeature %s: numeric sequences without boundaries / num_buckets are outside the hot-path scope' % name
+          self.seqs[name]['bounds'] = bounds
       elif ft == FeatureConfig.ComboFeature and len(fc.combo_join_sep) == 0 and any(len(x) > 0 for x in fc.combo_input_seps):
         # crossed_column over multi-valued inputs (input.py:400-405: tf.string_split by combo_input_seps[i]): every
         # combination of one token per input is an id - a ragged lookup like a TagFeature, ids from the host

@@ -272,7 +272,13 @@ class Input(object, metaclass=_meta_type):
       toks = toks[:L]  # max_seq_len truncation (layers/input_layer.py:183-185)
       if not toks:
         continue
-      if fc.HasField('hash_bucket_size') and fc.hash_bucket_size > 0:
+      if 'bounds' in self.schema.seqs[name]:
+        # numbers (input.py:714-734: string_to_number float32, (x - min) / (max - min) with num_buckets), bucketized
+        x = np.array([float(t) for t in toks], dtype=np.float32)
+        if fc.num_buckets > 1 and fc.max_val > fc.min_val:
+          x = (x - np.float32(fc.min_val)) / np.float32(fc.max_val - fc.min_val)
+        v = bucketize(x, self.schema.seqs[name]['bounds'])
+      elif fc.HasField('hash_bucket_size') and fc.hash_bucket_size > 0:
         v = self._hash_tokens(toks, int(fc.hash_bucket_size))
       elif fc.vocab_list:
         vocab = {x: j for j, x in enumerate(fc.vocab_list)}

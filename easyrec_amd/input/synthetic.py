@@ -83,8 +83,13 @@ class SyntheticBatches(object):
       lens = rng.integers(1, L + 1, size=B).astype(np.int32)
       lens[0] = L
       fc = self.fcs[name]
-      buckets = s['hash_buckets'] or (len(fc.vocab_list) if fc.vocab_list else int(fc.num_buckets))
-      ids = self._ids(buckets, B * L).reshape(B, L)
+      if 'bounds' in s:  # a sequence of numbers, bucketized (values around the boundaries' range)
+        lo, hi = float(s['bounds'][0]), float(s['bounds'][-1])
+        span = (hi - lo) or 1.0
+        ids = bucketize((lo - 0.1 * span + 1.2 * span * rng.random(B * L)).astype(np.float32), s['bounds']).reshape(B, L)
+      else:
+        buckets = s['hash_buckets'] or (len(fc.vocab_list) if fc.vocab_list else int(fc.num_buckets))
+        ids = self._ids(buckets, B * L).reshape(B, L)
       ids[np.arange(L)[None, :] >= lens[:, None]] = -1
       out['seq/%s/ids' % name] = ids
       out['seq/%s/len' % name] = lens

@@ -25,12 +25,16 @@ Parity status.  PINNED by outputs of the reference's own code (tests/golden/refe
 tests/golden/make_reference_layer_vectors.py executing the reference's functions unmodified on a numpy stand-in for
 the tensorflow module; tests/test_reference_layers.py): layers/fm.py FM, keras FM / Cross (full, diag_scale, low rank,
 no bias) / CIN / DotInteraction (layers/keras/interaction.py), layers/dnn.py DNN, model/multi_tower_din.py din(),
-keras MLP (layers/keras/blocks.py), keras DIN (layers/keras/din.py), layers/sequence_feature_layer.py target_attention,
-layers/mmoe.py MMOE, model/dcn.py _cross_net, core/learning_schedules.py exponential_decay_with_burnin; hashing by
-TensorFlow's documented vectors; the embedding lookup by embed_test's vectors.  "Parity unpinned" (the reference's
-tests hold no numeric expectation, the code is TensorFlow's own and TensorFlow cannot run here): the loss
-(tf.losses.sigmoid_cross_entropy), the optimizers' update rules (tf.train.AdamOptimizer / AdamOptimizerS), the
-regularisation terms, BatchNorm's moving-average bookkeeping and the assembly of the model classes around the layers.
+keras MLP (layers/keras/blocks.py, configured through the reference's Parameter), keras DIN (layers/keras/din.py),
+layers/sequence_feature_layer.py target_attention, layers/mmoe.py MMOE, model/dcn.py _cross_net,
+core/learning_schedules.py exponential_decay_with_burnin; hashing by TensorFlow's documented vectors; the embedding
+lookup by embed_test's vectors.  The assembly of the model classes (build_predict_graph of eleven classes), the
+backbone DAG, keras MMoE / SENet and the FeatureColumnParser are pinned THROUGH THE PRODUCT (its model classes,
+backbone, layers and parser are held to the reference's outputs; this oracle is held to the product by
+tests/test_host_logic.py).  "Parity unpinned" (the reference's tests hold no numeric expectation, the code is
+TensorFlow's own and TensorFlow cannot run here): the loss (tf.losses.sigmoid_cross_entropy), the optimizers' update
+rules (tf.train.AdamOptimizer / AdamOptimizerS), the regularisation terms, BatchNorm's moving-average bookkeeping, the
+evaluation of the feature columns (compat/feature_column/*).
 """
 import math
 from collections import OrderedDict
@@ -200,7 +204,8 @@ class OracleTrainer(object):
   @staticmethod
   def _bounds(f):
     """feature_column/feature_column.py:365-376"""
-    if f.feature_type != f.RawFeature or f.raw_input_dim > 1:
+    numeric = f.feature_type == f.RawFeature or (f.feature_type == f.SequenceFeature and f.sub_feature_type == f.RawFeature)
+    if not numeric or f.raw_input_dim > 1:
       return None
     if len(f.boundaries) > 0:
       return sorted(np.float32(b) for b in f.boundaries)
@@ -214,7 +219,7 @@ class OracleTrainer(object):
       if f.feature_type == f.IdFeature and not (f.HasField('hash_bucket_size') and f.hash_bucket_size > 0):
         out[n] = np.asarray(batch['int_ids'])[col]
         col += 1
-      elif self._bounds(f) is not None:
+      elif f.feature_type == f.RawFeature and self._bounds(f) is not None:
         col += 1  # the batch carries the bucket index too; the oracle re-derives it from the raw value
       elif f.feature_type == f.ComboFeature and len(f.combo_join_sep) == 0 and not any(len(x) for x in f.combo_input_seps):
         out[n] = np.asarray(batch['int_ids'])[col]  # crossed id from the input stage (oracle/hashing.py pins it)
@@ -224,8 +229,9 @@ class OracleTrainer(object):
   # ------------------------------------------------------------------ embedding columns
   def _column_var_name(self, scope, fc, wide):
     name = _fname(fc)
-    if fc.feature_type == fc.RawFeature and self._bounds(fc) is not None:
-      col = '%s_bucketized' % name  # BucketizedColumn.name (feature_column_v2.py:2777-2779)
+    if (fc.feature_type == fc.RawFeature or (fc.feature_type == fc.SequenceFeature and fc.sub_feature_type == fc.RawFeature)) \
+        and self._bounds(fc) is not None:
+      col = '%s_bucketized' % name  # BucketizedColumn.name (feature_column_v2.py:2777-2779; Sequence-: :2934-2936)
     elif fc.feature_type == fc.RawFeature:
       col = '%s_weighted_by_%s_raw_proj_val' % (name, name)
     elif fc.feature_type == fc.TagFeature and (len(fc.input_names) > 1 or fc.HasField('kv_separator')):
@@ -403,7 +409,7 @@ class OracleTrainer(object):
           from easyrec_amd.protos.dnn_pb2 import DNN  # (the config schema is the shared boundary)
           dnn_cfg = DNN()
           dnn_cfg.hidden_units.extend([128, 64, 32, 1])
-        att = self._din(V, dnn_cfg, fea, 'seq_dnn' + sc.group_name, l2)
+        att = self._din(V, dnn_cfg, fea, 'seq_dnn' + sc.group_name, l2, sc.allow_key_transform, sc.transform_dnn)
         if not sc.need_key_feature:
           att = att[:, :hist.shape[-1]]
         feats = feats + [att]
@@ -622,10 +628,18 @@ class OracleTrainer(object):
     out = self.dense(V, all_fea, 1, 'output', l2)
     return {'logits': out.squeeze(1)}
 
-  def _din(self, V, dnn_cfg, fea, name, l2):
-    """model/multi_tower_din.py:62-97."""
+  def _din(self, V, dnn_cfg, fea, name, l2, allow_key_transform=False, transform_dnn=False):
+    """model/multi_tower_din.py:62-97; layers/sequence_feature_layer.py:123-189 with its key transform (:138-147: a key
+    of another width than the history is zero-padded up to it, or - transform_dnn, or a wider key - both go through a
+    dense layer of the history's width)."""
     q, h, seq_len = fea['key'], fea['hist_seq_emb'], fea['hist_seq_len']
     B, L, E = h.shape
+    if allow_key_transform and q.shape[-1] != E:
+      if E > q.shape[-1] and not transform_dnn:
+        q = torch.nn.functional.pad(q, (0, E - q.shape[-1]))
+      else:
+        q = self.dense(V, q, E, 'sequence_key_transform_layer_' + name, 0.0)
+        h = self.dense(V, h, E, 'sequence_fea_transform_layer_' + name, 0.0)
     cur = q[:, None, :].expand(B, L, E)
     din_net = torch.cat([cur, h, cur - h, cur * h], dim=-1)
     din_net = self.dnn(V, din_net, dnn_cfg, name, l2, last_no_act=True, last_no_bn=True)
@@ -1066,7 +1080,14 @@ class OracleTrainer(object):
     self._touched = {}
     self._cache = (self._hashed_ids(batch), self._raw_values(batch), self._int_ids(batch))
     labels_np = np.asarray(batch['labels'], dtype=np.float32)
-    ce_of = lambda z, y: (torch.clamp(z, min=0) - z * y + torch.log1p(torch.exp(-torch.abs(z)))).mean()  # noqa: E731
+    def ce_of(z, y):
+      # tf.nn.sigmoid_cross_entropy_with_logits as TensorFlow writes it - relu and -|z| through `where(z >= 0, ...)` - so
+      # that autograd gives sigmoid(z) - y at z == 0 exactly too (clamp / abs have subgradient 1 / 0 there: a logit that is
+      # exactly 0 - a row whose last hidden layer is all-dead under a zero bias - would get 0 - y instead of 0.5 - y)
+      pos = z >= 0
+      relu_z = torch.where(pos, z, torch.zeros_like(z))
+      neg_abs = torch.where(pos, -z, z)
+      return (relu_z - z * y + torch.log1p(torch.exp(neg_abs))).mean()
     losses = OrderedDict()
     if self.model_class in ('MMoE', 'SimpleMultiTask', 'PLE', 'DBMTL', 'MultiTaskModel'):
       fn, sub = {'MMoE': (self._mmoe, 'mmoe'), 'SimpleMultiTask': (self._simple_multi_task, 'simple_multi_task'),

@@ -340,6 +340,37 @@ def din_sequence_features_taobao(**kw):
   ''' % (' '.join("feature_names: '%s'" % n for n in TAOBAO_USER), ' '.join("feature_names: '%s'" % n for n in TAOBAO_ITEM)))
 
 
+def dbmtl_numeric_sequences_taobao(transform_dnn=False, **kw):
+  """The shape of the reference's samples/model_config/dbmtl_on_multi_numeric_boundary_allow_key_transform(_dnn).config:
+  DBMTL whose `all` group carries `sequence_features` over two sequences of NUMBERS bucketized by `boundaries`
+  (SequenceFeature, sub_feature_type RawFeature), attended by one key narrower than the two histories together
+  (allow_key_transform: zero-padded, or with transform_dnn a dense layer on key and history)."""
+  cfg = taobao_base('seq', **kw)
+  cfg.model_dir = 'experiments/dbmtl_numeric_sequences_taobao_ckpt'
+  cfg.data_config.label_fields.extend(['clk', 'buy'])
+  for fc in cfg.feature_config.features:
+    if fc.feature_type == FeatureConfig.SequenceFeature:
+      fc.sub_feature_type = FeatureConfig.RawFeature
+      fc.ClearField('hash_bucket_size')
+      fc.boundaries.extend([15.0, 20.0, 21.0, 23.0, 30.0, 32.0, 40.0, 47.0, 66.0, 70.0])
+  names = [n for n, _ in TAOBAO_ID_FEATURES] + ['price']
+  return _model_text(cfg, '''
+    model_class: 'DBMTL'
+    feature_groups { group_name: 'all' %s wide_deep: DEEP
+      sequence_features { group_name: 'seq_fea' allow_key_transform: true %s
+        seq_att_map { key: 'brand' hist_seq: 'tag_brand_list' hist_seq: 'tag_category_list' } } }
+    dbmtl {
+      bottom_dnn { hidden_units: [64, 32] }
+      task_towers { tower_name: 'ctr' label_name: 'clk' loss_type: CLASSIFICATION metrics_set { auc {} }
+                    dnn { hidden_units: [32, 16] } relation_dnn { hidden_units: [8] } weight: 1.0 }
+      task_towers { tower_name: 'cvr' label_name: 'buy' loss_type: CLASSIFICATION metrics_set { auc {} }
+                    dnn { hidden_units: [32, 16] } relation_tower_names: 'ctr' relation_dnn { hidden_units: [8] } weight: 1.0 }
+      l2_regularization: 1e-6
+    }
+    embedding_regularization: 5e-6
+  ''' % (' '.join("feature_names: '%s'" % n for n in names), 'transform_dnn: true' if transform_dnn else ''))
+
+
 def xdeepfm_backbone_taobao(hidden=(64, 64, 64), mlp=(128, 64), final=(32, 1), **kw):
   """The shape of samples/model_config/xdeepfm_on_taobao_backbone.config: RankModel over a backbone with a wide block
   (feature list of width-1 embeddings, summed by `tf.add_n`), a CIN block over the stacked field embeddings
@@ -701,4 +732,7 @@ if __name__ == '__main__':
   dbmtl_variant('mmoe_taobao_small.config', 'dbmtl_taobao_small.config')
   dbmtl_variant('mmoe_taobao_small.config', 'dbmtl_mmoe_taobao_small.config', experts=3)
   mmoe_backbone_variant('mmoe_taobao_small.config', 'mmoe_backbone_taobao_small.config')
+  write(dbmtl_numeric_sequences_taobao(batch_size=128, scale=0.01, seq_len=12), 'dbmtl_numeric_sequences_taobao_small.config')
+  write(dbmtl_numeric_sequences_taobao(transform_dnn=True, batch_size=128, scale=0.01, seq_len=12),
+        'dbmtl_numeric_sequences_dnn_taobao_small.config')
   mmoe_backbone_variant('mmoe_taobao_small.config', 'mmoe_backbone_bayes_taobao_small.config', senet=False, bayes=True)
