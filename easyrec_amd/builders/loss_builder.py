@@ -10,8 +10,72 @@ from easyrec_amd import kernels
 from easyrec_amd.protos.loss_pb2 import LossType
 
 
-def build(loss_type, label, pred, loss_weight=1.0, num_class=1, loss_scale=1.0, **kwargs):
+def f1_reweight_sigmoid_cross_entropy(labels, logits, beta_square, weights=None):
+  """reference easy_rec/python/loss/f1_reweight_loss.py:10-39 ("Adaptive Scaling for Sparse Detection"): sigmoid cross
+  entropy with weight 1 on the positives and tp / (beta^2 * #pos + #neg - tn + 1e-8) on the negatives, tp = sum of the
+  batch's probabilities, tn = B - tp; reduction SUM_BY_NONZERO_WEIGHTS.  The negatives' weight is a function of the
+  logits and the reference does not stop its gradient: plain autograd ops here (a loss variant, not the hot path), so
+  that d(loss)/d(logits) carries that term as TensorFlow's does."""
+  y = labels.to(torch.float32)
+  probs = torch.sigmoid(logits)
+  batch = float(y.shape[0])
+  num_pos = y.sum()
+  tp = probs.sum()
+  neg_weight = tp / (beta_square * num_pos + (batch - num_pos) - (batch - tp) + 1e-8)
+  w = torch.where(y == 1.0, torch.ones_like(y), neg_weight.expand_as(y))
+  if weights is not None:
+    w = w * weights
+  pos = logits >= 0  # tf.nn.sigmoid_cross_entropy_with_logits' own form (exact derivative at a zero logit)
+  ce = torch.where(pos, logits, torch.zeros_like(logits)) - logits * y + \
+      torch.log1p(torch.exp(torch.where(pos, -logits, logits)))
+  present = (w != 0).sum().clamp(min=1).to(torch.float32)
+  return (w * ce).sum() / present
+
+
+def pairwise_loss(labels, logits, margin=0.0, temperature=1.0, weights=None):
+  """reference easy_rec/python/loss/pairwise_loss.py:15-70 (the deprecated `pairwise_loss`, without session ids): over
+  the ordered pairs (i, j) with label_i > label_j, sigmoid cross entropy of z_i - z_j - margin against 1, i.e. the mean of
+  softplus(-(z_i - z_j - margin)); per-example weights weigh the pairs of their FIRST member.  No pair: the mean of
+  nothing - 0 with SUM_BY_NONZERO_WEIGHTS' safe division."""
+  y = labels.to(torch.float32)
+  z = logits / temperature if temperature != 1.0 else logits
+  diff = z[:, None] - z[None, :] - margin
+  mask = y[:, None] > y[None, :]
+  x = diff[mask]
+  per = torch.where(x >= 0, x, torch.zeros_like(x)) - x + torch.log1p(torch.exp(torch.where(x >= 0, -x, x)))
+  if weights is None:
+    return per.sum() / max(int(x.numel()), 1)
+  w = weights[:, None].expand_as(diff)[mask]
+  return (w * per).sum() / (w != 0).sum().clamp(min=1).to(torch.float32)
+
+
+def build(loss_type, label, pred, loss_weight=1.0, num_class=1, loss_scale=1.0, loss_param=None, **kwargs):
   """Returns (loss [1] tensor, d loss / d pred).  `loss_weight`: scalar or per-example tensor."""
+  if loss_type == LossType.PAIR_WISE_LOSS:
+    assert num_class == 1, 'num_class must be 1 when loss type is PAIR_WISE_LOSS'
+    assert loss_param is None or not loss_param.session_name, 'session ids in pairwise losses are outside the hot-path scope'
+    margin = 0.0 if loss_param is None else float(loss_param.margin)
+    temperature = 1.0 if loss_param is None else float(loss_param.temperature)
+    z = pred.detach().clone().requires_grad_(True)
+    with torch.enable_grad():
+      # (a python float weight is not a "numeric tensor" for the reference: it multiplies the mean as a scalar)
+      loss = pairwise_loss(label, z, margin, temperature, loss_weight if torch.is_tensor(loss_weight) else None)
+      loss = loss * (loss_scale if torch.is_tensor(loss_weight) else loss_scale * float(loss_weight))
+      if loss.requires_grad:
+        dz, = torch.autograd.grad(loss, z)
+      else:  # no (positive, negative) pair in the batch
+        dz = torch.zeros_like(z)
+    return loss.detach().reshape(1), dz
+  if loss_type == LossType.F1_REWEIGHTED_LOSS:
+    assert num_class == 1, 'num_class must be 1 when loss type is F1_REWEIGHTED_LOSS'
+    beta_square = 1.0 if loss_param is None else float(loss_param.f1_beta_square)
+    assert loss_param is None or not loss_param.label_smoothing, 'label smoothing is outside the hot-path scope'
+    z = pred.detach().clone().requires_grad_(True)
+    with torch.enable_grad():
+      weights = loss_weight if torch.is_tensor(loss_weight) else torch.full_like(z, float(loss_weight))
+      loss = f1_reweight_sigmoid_cross_entropy(label, z, beta_square, weights) * loss_scale
+      dz, = torch.autograd.grad(loss, z)
+    return loss.detach().reshape(1), dz
   if loss_type in (LossType.CLASSIFICATION, LossType.BINARY_CROSS_ENTROPY_LOSS):
     assert num_class == 1, 'multi-class softmax cross entropy is outside the hot-path scope'
     weights = loss_weight if torch.is_tensor(loss_weight) else None

@@ -26,14 +26,21 @@ _BINARY = _Head('binary', ('probs', 'logits'), 'logits', 'cross_entropy_loss')
 _REGRESSION = _Head('regression', ('y',), 'y', 'l2_loss')
 _SIGMOID_REGRESSION = _Head('sigmoid_regression', ('y',), 'y', 'l2_loss')
 
+# (the other binary loss types name their loss after the type: rank_model.py:241-246)
+_F1_REWEIGHTED = _Head('binary', ('probs', 'logits'), 'logits', 'f1_reweighted_loss')
+
+_PAIR_WISE = _Head('binary', ('probs', 'logits'), 'logits', 'pair_wise_loss')
+
 _HEADS = {
+    LossType.PAIR_WISE_LOSS: _PAIR_WISE,
     LossType.CLASSIFICATION: _BINARY,
     LossType.BINARY_CROSS_ENTROPY_LOSS: _BINARY,
+    LossType.F1_REWEIGHTED_LOSS: _F1_REWEIGHTED,
     LossType.L2_LOSS: _REGRESSION,
     LossType.SIGMOID_L2_LOSS: _SIGMOID_REGRESSION,
 }
 # loss types whose PREDICTIONS are those of a binary head but whose loss is not built on this path
-_BINARY_PREDICTION_ONLY = (LossType.F1_REWEIGHTED_LOSS, LossType.PAIR_WISE_LOSS, LossType.BINARY_FOCAL_LOSS)
+_BINARY_PREDICTION_ONLY = (LossType.BINARY_FOCAL_LOSS,)
 
 
 def _head_of(loss_type, for_loss=True):
@@ -74,7 +81,7 @@ class RankModel(EasyRecModel):
   def _output_to_prediction_impl(self, output, loss_type, num_class=1, suffix='', **kwargs):
     head = _head_of(loss_type, for_loss=False)
     column = output.squeeze(1)
-    if head is _BINARY:
+    if head.kind == 'binary':
       assert num_class == 1, 'num_class > 1 (softmax heads) is outside the hot-path scope'
       # while training, the fused loss kernel produces the probabilities; otherwise they are computed here
       probs = None if self._is_training else torch.sigmoid(column.detach())
@@ -97,7 +104,7 @@ class RankModel(EasyRecModel):
     head = _head_of(loss_type)
     pred = self._prediction_dict[head.loss_input + suffix]
     value, dpred = loss_builder.build(loss_type, self._labels[label_name], pred, loss_weight, num_class,
-                                      loss_scale=loss_scale)
+                                      loss_scale=loss_scale, loss_param=loss_param)
     self._backward_seeds.append((pred, dpred))
     return {loss_name or (head.loss_key + suffix): value}
 
@@ -109,8 +116,9 @@ class RankModel(EasyRecModel):
     base = self._base_model_config
     assert base.loss_weight_strategy == base.Fixed, 'only the Fixed loss weight strategy is supported'
     for entry in self._losses:
-      self._loss_dict.update(self._build_loss_impl(entry.loss_type, loss_name=entry.loss_name,
-                                                   loss_scale=entry.weight, **common))
+      which = entry.WhichOneof('loss_param')
+      self._loss_dict.update(self._build_loss_impl(entry.loss_type, loss_name=entry.loss_name, loss_scale=entry.weight,
+                                                   loss_param=getattr(entry, which) if which else None, **common))
     return self._loss_dict
 
   # -- exported outputs

@@ -624,6 +624,21 @@ def mmoe_backbone_variant(src_name, dst_name, senet=True, bayes=False):
   write(cfg, dst_name)
 
 
+def losses_variant(src_name, dst_name):
+  """A single-task fixture with the `losses` list of the reference's samples/model_config/multi_tower_on_taobao.config:
+  F1_REWEIGHTED_LOSS (f1_beta_square 2.25) + PAIR_WISE_LOSS, each with weight 1."""
+  from easyrec_amd.protos import pipeline_pb2
+  here = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'configs')
+  cfg = pipeline_pb2.EasyRecConfig()
+  with open(os.path.join(here, src_name)) as f:
+    text_format.Merge(f.read(), cfg)
+  text_format.Merge("""
+    losses { loss_type: F1_REWEIGHTED_LOSS weight: 1.0 f1_reweighted_loss { f1_beta_square: 2.25 } }
+    losses { loss_type: PAIR_WISE_LOSS weight: 1.0 }
+  """, cfg.model_config)
+  write(cfg, dst_name)
+
+
 def ple_variant(src_name, dst_name):
   """The MMoE fixture as PLE (reference model/ple.py): two extraction networks, 2 experts per task + 2 shared."""
   from easyrec_amd.protos import pipeline_pb2
@@ -732,6 +747,7 @@ if __name__ == '__main__':
   dbmtl_variant('mmoe_taobao_small.config', 'dbmtl_taobao_small.config')
   dbmtl_variant('mmoe_taobao_small.config', 'dbmtl_mmoe_taobao_small.config', experts=3)
   mmoe_backbone_variant('mmoe_taobao_small.config', 'mmoe_backbone_taobao_small.config')
+  losses_variant('multi_tower_criteo_small.config', 'multi_tower_f1_pairwise_criteo_small.config')
   write(dbmtl_numeric_sequences_taobao(batch_size=128, scale=0.01, seq_len=12), 'dbmtl_numeric_sequences_taobao_small.config')
   write(dbmtl_numeric_sequences_taobao(transform_dnn=True, batch_size=128, scale=0.01, seq_len=12),
         'dbmtl_numeric_sequences_dnn_taobao_small.config')
