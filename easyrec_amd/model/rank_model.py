@@ -106,6 +106,10 @@ class RankModel(EasyRecModel):
     value, dpred = loss_builder.build(loss_type, self._labels[label_name], pred, loss_weight, num_class,
                                       loss_scale=loss_scale, loss_param=loss_param)
     self._backward_seeds.append((pred, dpred))
+    # rank_model.py:236-250: a given loss_name stands as it is for the cross-entropy / L2 losses and gets the suffix for
+    # the other binary loss types
+    if loss_name and head not in (_BINARY, _REGRESSION, _SIGMOID_REGRESSION):
+      loss_name = loss_name + suffix
     return {loss_name or (head.loss_key + suffix): value}
 
   def build_loss_graph(self):

@@ -82,6 +82,7 @@ def test_multi_tower_din_matches_oracle(lazy):
                                   'simple_multi_task_taobao_small.config', 'ple_taobao_small.config',
                                   'dbmtl_taobao_small.config', 'dbmtl_mmoe_taobao_small.config',
                                   'dbmtl_numeric_sequences_taobao_small.config', 'multi_tower_f1_pairwise_criteo_small.config',
+                                  'mmoe_tower_losses_taobao_small.config',
                                   'dbmtl_numeric_sequences_dnn_taobao_small.config'])
 def test_neighbouring_models_match_oracle(name):
   """WideAndDeep / FM / MultiTower / DLRM on the HIP kernels against the model oracle."""

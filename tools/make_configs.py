@@ -639,6 +639,22 @@ def losses_variant(src_name, dst_name):
   write(cfg, dst_name)
 
 
+def tower_losses_variant(src_name, dst_name):
+  """The MMoE fixture with a `losses` list on its first tower (the shape of the reference's
+  samples/model_config/mmoe_on_taobao_with_multi_loss.config; the second weight differs from the first on purpose:
+  the reference multiplies every loss of the list by the FIRST weight, model/multi_task_model.py:263-269)."""
+  from easyrec_amd.protos import pipeline_pb2
+  here = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'configs')
+  cfg = pipeline_pb2.EasyRecConfig()
+  with open(os.path.join(here, src_name)) as f:
+    text_format.Merge(f.read(), cfg)
+  text_format.Merge("""
+    losses { loss_type: CLASSIFICATION weight: 0.8 }
+    losses { loss_type: PAIR_WISE_LOSS weight: 0.25 loss_name: 'rank' pairwise_loss { margin: 0.1 temperature: 2.0 } }
+  """, cfg.model_config.mmoe.task_towers[0])
+  write(cfg, dst_name)
+
+
 def ple_variant(src_name, dst_name):
   """The MMoE fixture as PLE (reference model/ple.py): two extraction networks, 2 experts per task + 2 shared."""
   from easyrec_amd.protos import pipeline_pb2
@@ -748,6 +764,7 @@ if __name__ == '__main__':
   dbmtl_variant('mmoe_taobao_small.config', 'dbmtl_mmoe_taobao_small.config', experts=3)
   mmoe_backbone_variant('mmoe_taobao_small.config', 'mmoe_backbone_taobao_small.config')
   losses_variant('multi_tower_criteo_small.config', 'multi_tower_f1_pairwise_criteo_small.config')
+  tower_losses_variant('mmoe_taobao_small.config', 'mmoe_tower_losses_taobao_small.config')
   write(dbmtl_numeric_sequences_taobao(batch_size=128, scale=0.01, seq_len=12), 'dbmtl_numeric_sequences_taobao_small.config')
   write(dbmtl_numeric_sequences_taobao(transform_dnn=True, batch_size=128, scale=0.01, seq_len=12),
         'dbmtl_numeric_sequences_dnn_taobao_small.config')
