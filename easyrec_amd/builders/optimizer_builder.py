@@ -65,14 +65,16 @@ def _make_schedule(lr_config):
     c = lr_config.cosine_decay_learning_rate
 
     def cosine(step):
-      lr = 0.5 * c.learning_rate_base * (1 + math.cos(
-          math.pi * (float(step) - c.warmup_steps - c.hold_base_rate_steps) /
-          float(c.total_steps - c.warmup_steps - c.hold_base_rate_steps)))
+      # fp32 throughout, in the graph's order (core/learning_schedules.py:113-127: python floats are constants of the
+      # tensor's type): near the end of the decay 1 + cos(x) keeps only a few bits, and they should be the same bits
+      x = F32(math.pi) * (F32(step) - F32(c.warmup_steps) - F32(c.hold_base_rate_steps)) / \
+          F32(float(c.total_steps - c.warmup_steps - c.hold_base_rate_steps))
+      lr = F32(0.5 * c.learning_rate_base) * (F32(1.0) + np.cos(x, dtype=np.float32))
       if c.hold_base_rate_steps > 0 and step <= c.warmup_steps + c.hold_base_rate_steps:
-        lr = c.learning_rate_base
+        lr = F32(c.learning_rate_base)
       if c.warmup_steps > 0 and step < c.warmup_steps:
         slope = (c.learning_rate_base - c.warmup_learning_rate) / c.warmup_steps
-        lr = slope * step + c.warmup_learning_rate
+        lr = F32(slope) * F32(step) + F32(c.warmup_learning_rate)
       return F32(0.0 if step > c.total_steps else lr)
 
     return cosine
