@@ -10,44 +10,33 @@ import torch
 from easyrec_amd import kernels
 from easyrec_amd.layers import dnn
 from easyrec_amd.model.rank_model import RankModel
-from easyrec_amd.protos.dlrm_pb2 import DLRM as DLRMConfig
 
 
 class DLRM(RankModel):
 
   def __init__(self, model_config, feature_configs, features, labels=None, is_training=False):
     super(DLRM, self).__init__(model_config, feature_configs, features, labels, is_training)
-    assert model_config.WhichOneof('model') == 'dlrm', 'invalid model config: %s' % model_config.WhichOneof('model')
-    self._model_config = model_config.dlrm
-    assert isinstance(self._model_config, DLRMConfig)
-    assert self._input_layer.has_group('sparse'), 'sparse group is not specified'
-    assert self._input_layer.has_group('dense'), 'dense group is not specified'
+    self._take_config('dlrm')
+    for needed in ('sparse', 'dense'):
+      assert self._input_layer.has_group(needed), needed + ' group is not specified'
+
+  def _interact(self, bottom, sparse_block, sparse_list):
+    own = self._model_config
+    if own.arch_interaction_op == 'cat':
+      return torch.cat([bottom, sparse_block], dim=1)
+    if own.arch_interaction_op != 'dot':
+      raise ValueError('invalid arch_interaction_op: %s' % own.arch_interaction_op)
+    width = sparse_list[0].shape[1]
+    assert bottom.shape[1] == width, 'bot_dnn last hidden[%d] != sparse feature embedding_dim[%d]' % (bottom.shape[1], width)
+    assert all(f.shape[1] == width for f in sparse_list)
+    fields = torch.cat([bottom, sparse_block], dim=1)  # [B, (1 + n_sparse) * width], the bottom output first
+    pairs = kernels.DotInteractionFn.apply(fields, 1 + len(sparse_list), width, bool(own.arch_interaction_itself))
+    parts = [pairs, sparse_block] + ([bottom] if own.arch_with_dense_feature else [])
+    return torch.cat(parts, dim=1)
 
   def build_predict_graph(self):
-    sparse_cat, sparse_features = self._input_layer(self._feature_dict, 'sparse')
-    dense_feature, _ = self._input_layer(self._feature_dict, 'dense')
-    bot_dnn = dnn.DNN(self._model_config.bot_dnn, self._l2_reg, 'bot_dnn', self._is_training)
-    dense_fea = bot_dnn(dense_feature)
-    op = self._model_config.arch_interaction_op
-    if op == 'cat':
-      all_fea = torch.cat([dense_fea, sparse_cat], dim=1)
-    elif op == 'dot':
-      E = sparse_features[0].shape[1]
-      assert dense_fea.shape[1] == E, 'bot_dnn last hidden[%d] != sparse feature embedding_dim[%d]' % (
-          dense_fea.shape[1], E)
-      assert all(f.shape[1] == E for f in sparse_features)
-      all_feas = torch.cat([dense_fea, sparse_cat], dim=1)  # [B, (1 + n_sparse) * E]
-      num_fea = 1 + len(sparse_features)
-      upper_tri = kernels.DotInteractionFn.apply(all_feas, num_fea, E,
-                                                 bool(self._model_config.arch_interaction_itself))
-      concat_feas = [upper_tri, sparse_cat]
-      if self._model_config.arch_with_dense_feature:
-        concat_feas.append(dense_fea)
-      all_fea = torch.cat(concat_feas, dim=1)
-    else:
-      raise ValueError('invalid arch_interaction_op: %s' % op)
-    top_dnn = dnn.DNN(self._model_config.top_dnn, self._l2_reg, 'top_dnn', self._is_training)
-    all_fea = top_dnn(all_fea)
-    logits = dnn.dense(all_fea, 1, 'output', l2_reg=self._l2_reg)
-    self._add_to_prediction_dict(logits)
-    return self._prediction_dict
+    sparse_block, sparse_list = self._group('sparse')
+    dense_block = self._group('dense')[0]
+    bottom = self._dnn(dense_block, self._model_config.bot_dnn, 'bot_dnn')
+    top = self._dnn(self._interact(bottom, sparse_block, sparse_list), self._model_config.top_dnn, 'top_dnn')
+    return self._emit(dnn.dense(top, 1, 'output', l2_reg=self._l2_reg))

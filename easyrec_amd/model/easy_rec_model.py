@@ -65,6 +65,28 @@ class EasyRecModel(six.with_metaclass(_meta_type, object)):
 
     self._backbone_net = self.build_backbone_network()
 
+  # -- what every model class of this package does around its own wiring
+  def _take_config(self, member):
+    """Narrow `_model_config` to the class's own member of the `model` oneof; a config for another class is refused."""
+    chosen = self._model_config.WhichOneof('model')
+    if chosen != member:
+      raise AssertionError('invalid model config: %s' % chosen)
+    self._model_config = getattr(self._model_config, member)
+    return self._model_config
+
+  def _group(self, name):
+    """(concatenated output, per-feature outputs) of a feature group, through the input layer"""
+    return self._input_layer(self._feature_dict, name)
+
+  def _dnn(self, x, config, name):
+    """a layers/dnn.py DNN with this model's kernel regulariser and training flag"""
+    from easyrec_amd.layers import dnn
+    return dnn.DNN(config, self._l2_reg, name, self._is_training)(x)
+
+  def _emit(self, output):
+    self._add_to_prediction_dict(output)
+    return self._prediction_dict
+
   def build_backbone_network(self):
     """reference easy_rec_model.py:100-107"""
     if self.has_backbone:

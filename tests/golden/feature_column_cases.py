@@ -80,13 +80,19 @@ def _fixture_cases():
     wide_dim = 1 if any(v != 'DEEP' for v in wd.values()) else -1
     text = text_format.MessageToString(cfg.feature_config) if len(cfg.feature_config.features) else \
         ''.join('features { %s }\n' % text_format.MessageToString(f, as_one_line=True) for f in cfg.feature_configs)
-    yield name[:-len('.config')], text, wd, wide_dim, ''
+    groups = [text_format.MessageToString(g, as_one_line=True) for g in cfg.model_config.feature_groups]
+    yield name[:-len('.config')], text, wd, wide_dim, '', groups
 
 
 def cases():
-  yield 'zoo', ZOO, ZOO_GROUPS, 1, ''
-  yield 'zoo_wide4', ZOO, ZOO_GROUPS, 4, ''
-  yield 'feature_ev_params', EV_FEATURES, {k: 'DEEP' for k in ('uid', 'city', 'tags', 'click_seq', 'price')}, -1, ''
-  yield 'global_ev_params', EV_FEATURES, {k: 'DEEP' for k in ('uid', 'city', 'tags', 'click_seq', 'price')}, -1, 'filter_freq: 3'
+  zoo_groups = ["group_name: 'deep' wide_deep: DEEP " + ' '.join("feature_names: '%s'" % k for k in ZOO_GROUPS if ZOO_GROUPS[k] != 'WIDE'),
+                "group_name: 'wide' wide_deep: WIDE " + ' '.join("feature_names: '%s'" % k for k in ZOO_GROUPS
+                                                                 if ZOO_GROUPS[k] != 'DEEP' and 'seq' not in k),
+                "group_name: 'ranged' wide_deep: DEEP feature_names: 'tags' feature_names: 'item_[a-b]' feature_names: 'uid'"]
+  # (`item_[a-b]` does not match the digits-only range syntax: kept as a literal name and not selected below)
+  yield 'zoo', ZOO, ZOO_GROUPS, 1, '', zoo_groups[:2]
+  yield 'zoo_wide4', ZOO, ZOO_GROUPS, 4, '', zoo_groups[:2]
+  yield 'feature_ev_params', EV_FEATURES, {k: 'DEEP' for k in ('uid', 'city', 'tags', 'click_seq', 'price')}, -1, '', []
+  yield 'global_ev_params', EV_FEATURES, {k: 'DEEP' for k in ('uid', 'city', 'tags', 'click_seq', 'price')}, -1, 'filter_freq: 3', []
   for c in _fixture_cases():
     yield c

@@ -163,7 +163,11 @@ def main():
   spec.loader.exec_module(ref)
 
   cases = []
-  for tag, features_text, wide_deep, wide_output_dim, ev_text in fcc.cases():
+  spec = importlib.util.spec_from_file_location('ref_feature_group',
+                                                os.path.join(REF, 'easy_rec/python/feature_column/feature_group.py'))
+  ref_group = importlib.util.module_from_spec(spec)
+  spec.loader.exec_module(ref_group)
+  for tag, features_text, wide_deep, wide_output_dim, ev_text, groups in fcc.cases():
     fcfg = protos.feature_config_pb2.FeatureConfigV2()
     text_format.Merge(features_text, fcfg)
     ev = None
@@ -173,7 +177,15 @@ def main():
     wd = {k: getattr(protos.feature_config_pb2.WideOrDeep, v) if hasattr(protos.feature_config_pb2, 'WideOrDeep')
           else v for k, v in wide_deep.items()}
     parser = ref.FeatureColumnParser(list(fcfg.features), wd, wide_output_dim, ev_params=ev)
-    cases.append({'tag': tag, 'features': features_text, 'wide_deep': wide_deep, 'wide_output_dim': wide_output_dim,
+    selected = {}
+    for gtext in groups:  # FeatureGroup.select_columns: which columns, in which order, make up a group's output
+      gcfg = protos.feature_config_pb2.FeatureGroupConfig()
+      text_format.Merge(gtext, gcfg)
+      gcfg.ClearField('sequence_features')
+      plain, seqs = ref_group.FeatureGroup(gcfg).select_columns(parser)
+      names = {id(v): k for d in (parser.wide_columns, parser.deep_columns, parser.sequence_columns) for k, v in d.items()}
+      selected[gcfg.group_name] = {'text': gtext, 'plain': [names[id(c)] for c in plain], 'sequence': [names[id(c)] for c in seqs]}
+    cases.append({'tag': tag, 'features': features_text, 'groups': selected, 'wide_deep': wide_deep, 'wide_output_dim': wide_output_dim,
                   'ev_params': ev_text,
                   'wide': {k: describe_reference(v) for k, v in parser.wide_columns.items()},
                   'deep': {k: describe_reference(v) for k, v in parser.deep_columns.items()},

@@ -54,5 +54,12 @@ def test_parser_builds_what_the_reference_parser_builds(tag):
     assert list(cols) == list(want) or sorted(cols) == sorted(want), (part, sorted(cols), sorted(want))
     for name in want:
       assert _describe(cols[name]) == want[name], (part, name, _describe(cols[name]), want[name])
+  from easyrec_amd.feature_column.feature_group import FeatureGroup
+  by_id = {id(v): k for d in (parser.wide_columns, parser.deep_columns, parser.sequence_columns) for k, v in d.items()}
+  for gname, want in case['groups'].items():  # the columns a group selects, in the order of its output
+    gcfg = feature_config_pb2.FeatureGroupConfig()
+    text_format.Merge(want['text'], gcfg)
+    plain, seqs = FeatureGroup(gcfg).select_columns(parser)
+    assert [by_id[id(c)] for c in plain] == want['plain'] and [by_id[id(c)] for c in seqs] == want['sequence'], gname
   for name, n in case['vocab_size'].items():
     assert parser.get_feature_vocab_size(name) == n, (name, parser.get_feature_vocab_size(name), n)
