@@ -245,8 +245,13 @@ def _layers_dense(inputs, units, kernel_regularizer=None, activation=None, name=
   return activation(y) if activation is not None else y
 
 
-def _layers_batch_normalization(inputs, training=False, trainable=True, name=None, epsilon=1e-3, prescoped=False, **kw):
+def _layers_batch_normalization(inputs, training=False, trainable=True, name=None, epsilon=1e-3, prescoped=False,
+                                center=True, scale=True, axis=-1, **kw):
   x = _arr(inputs)
+  if not (center or scale):  # Dice's statistics-only normalisation (utils/activation.py:36-42): no gamma / beta
+    assert training and axis == -1
+    axes = tuple(range(x.ndim - 1))
+    return (x - x.mean(axis=axes)) / np.sqrt(x.var(axis=axes) + epsilon)
   name = name if prescoped else MODEL_SCOPE[0] + name
   gamma = VARS.setdefault(name + '/gamma', _VAR_RNG.random(x.shape[-1]) + 0.5)
   beta = VARS.setdefault(name + '/beta', _VAR_RNG.standard_normal(x.shape[-1]) * 0.2)
@@ -815,6 +820,20 @@ def main():
             {'MLP': (blocks.MLP, True), 'Cross': (inter.Cross, True), 'FM': (inter.FM, True), 'CIN': (inter.CIN, True),
              'DotInteraction': (inter.DotInteraction, True), 'DIN': (din_keras.DIN, True), 'MMoE': (mt.MMoE, True),
              'SENet': (fib.SENet, True), 'Add': (Add, False)})
+  # Dice / gelu of utils/activation.py (the DNN's `activation: "dice"`: DIN's attention MLP in the reference's samples)
+  sys.modules['easy_rec.python.utils.load_class'] = types.ModuleType('easy_rec.python.utils.load_class')
+  sys.modules['easy_rec.python.utils.load_class'].load_by_path = None
+  tf.constant_initializer = lambda v: _Initializer('constant')
+  tf.tanh = lambda x: np.tanh(_arr(x))
+  tf.pow = lambda x, p: np.power(_arr(x), p)
+  act_ref = load_reference('easy_rec/python/utils/activation.py', 'ref_utils_activation')
+  x_act = rng_act = None
+  rng_act = np.random.default_rng(20240929)
+  x_act = rng_act.standard_normal((11, 6)) * 1.7 + 0.3
+  out['act_x'] = x_act
+  out['dice_out'] = np.asarray(act_ref.dice(_tensor(x_act), name='tower/dnn_0/act', training=True))
+  out['dice_3d_out'] = np.asarray(act_ref.dice(_tensor(x_act.reshape(11, 2, 3)), name='att/dnn_1/act', training=True))
+  out['gelu_out'] = np.asarray(act_ref.gelu(_tensor(x_act)))
   for k, v in VARS.items():
     out['var:' + k] = v
   for k in [k for k in out if k.startswith('cross_') and (k.endswith('_kernel') or k.endswith('_bias'))] + \
