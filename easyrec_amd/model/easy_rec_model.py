@@ -30,40 +30,33 @@ _meta_type = get_register_class_meta(_EASY_REC_MODEL_CLASS_MAP, have_abstract_cl
 class EasyRecModel(six.with_metaclass(_meta_type, object)):
 
   def __init__(self, model_config, feature_configs, features, labels=None, is_training=False):
-    self._base_model_config = model_config
-    self._model_config = model_config
-    self._is_training = is_training
-    self._is_predicting = labels is None
-    self._feature_dict = features
-
+    # the whole model config stays reachable; `_model_config` is narrowed to the class's own member by _take_config
+    self._base_model_config = self._model_config = model_config
+    self._feature_configs, self._feature_dict, self._labels = feature_configs, features, labels
+    self._is_training, self._is_predicting = is_training, labels is None
     self._global_ev_params = model_config.ev_params if model_config.HasField('ev_params') else None
+    # regularisers: a coefficient of 0 means "none" (easy_rec_model.py:66-77)
+    self._emb_reg = self.embedding_regularization or None
+    self._l2_reg = self.l2_regularization or None
+    self._wide_output_dim = self._declared_wide_output_dim()
+    self.build_input_layer(model_config, feature_configs)
+    self._metric_dict = {}
+    self.begin_step()
+    weight = getattr(features, 'sample_weight', None)
+    self._sample_weight = 1.0 if weight is None else weight
+    self._backbone_net = self.build_backbone_network()
 
-    self._emb_reg = self.embedding_regularization if self.embedding_regularization > 0 else None
-    self._l2_reg = self.l2_regularization if self.l2_regularization > 0 else None
-
-    # wide feature groups are embeddings of dimension wide_output_dim: set by WideAndDeep / DeepFM from their own
-    # config, by backbone models from the `input_layer { wide_output_dim }` of their blocks (easy_rec_model.py:79-84)
-    self._wide_output_dim = -1
+  def _declared_wide_output_dim(self):
+    """Wide feature groups are embeddings of dimension wide_output_dim.  WideAndDeep / DeepFM / FM set it from their own
+    config (in their build_input_layer); a backbone model takes it from the `input_layer { wide_output_dim }` of its
+    blocks (easy_rec_model.py:79-84); otherwise -1: no wide group may be used."""
     if self.has_backbone:
       from easyrec_amd.layers.backbone import Backbone
-      declared = Backbone.wide_embed_dim(model_config.backbone)
+      declared = Backbone.wide_embed_dim(self._base_model_config.backbone)
       if declared:
-        self._wide_output_dim = declared
         logging.info('set `wide_output_dim` to %d' % declared)
-    self._feature_configs = feature_configs
-    self.build_input_layer(model_config, feature_configs)
-
-    self._labels = labels
-    self._prediction_dict = {}
-    self._loss_dict = {}
-    self._metric_dict = {}
-    self._backward_seeds = []
-
-    self._sample_weight = 1.0
-    if getattr(features, 'sample_weight', None) is not None:
-      self._sample_weight = features.sample_weight
-
-    self._backbone_net = self.build_backbone_network()
+        return declared
+    return -1
 
   # -- what every model class of this package does around its own wiring
   def _take_config(self, member):
@@ -123,36 +116,26 @@ class EasyRecModel(six.with_metaclass(_meta_type, object)):
 
   @property
   def l2_regularization(self):
-    """reference easy_rec_model.py:143-155 (dense_regularization is a deprecated alias)."""
-    which = self._base_model_config.WhichOneof('model')
-    model_config = getattr(self._base_model_config, which)
-    l2 = 0.0
-    if hasattr(model_config, 'dense_regularization') and model_config.HasField('dense_regularization'):
+    """The kernel regulariser's coefficient of the model's own config: `l2_regularization`, or its deprecated alias
+    `dense_regularization` when that one is set (easy_rec_model.py:143-155); 0 when the config has neither."""
+    own = getattr(self._base_model_config, self._base_model_config.WhichOneof('model'))
+    fields = own.DESCRIPTOR.fields_by_name
+    if 'dense_regularization' in fields and own.HasField('dense_regularization'):
       logging.warning('dense_regularization is deprecated, please use l2_regularization')
-      l2 = model_config.dense_regularization
-    elif hasattr(model_config, 'l2_regularization'):
-      l2 = model_config.l2_regularization
-    return l2
+      return own.dense_regularization
+    return own.l2_regularization if 'l2_regularization' in fields else 0.0
 
   def build_input_layer(self, model_config, feature_configs):
+    dropout = model_config.variational_dropout if model_config.HasField('variational_dropout') else None
     self._input_layer = input_layer.InputLayer(
-        feature_configs,
-        model_config.feature_groups,
-        wide_output_dim=self._wide_output_dim,
-        ev_params=self._global_ev_params,
-        embedding_regularizer=self._emb_reg,
-        kernel_regularizer=self._l2_reg,
-        variational_dropout_config=model_config.variational_dropout
-        if model_config.HasField('variational_dropout') else None,
-        is_training=self._is_training,
-        is_predicting=self._is_predicting,
+        feature_configs, model_config.feature_groups, wide_output_dim=self._wide_output_dim,
+        ev_params=self._global_ev_params, embedding_regularizer=self._emb_reg, kernel_regularizer=self._l2_reg,
+        variational_dropout_config=dropout, is_training=self._is_training, is_predicting=self._is_predicting,
         engine=context.current().engine)
 
   def begin_step(self):
-    """Reset per-step state; called by the estimator before build_predict_graph."""
-    self._prediction_dict = {}
-    self._loss_dict = {}
-    self._backward_seeds = []
+    """Per-step state, emptied by the estimator before build_predict_graph (and once by the constructor)."""
+    self._prediction_dict, self._loss_dict, self._backward_seeds = {}, {}, []
 
   @abstractmethod
   def build_predict_graph(self):
@@ -170,12 +153,11 @@ class EasyRecModel(six.with_metaclass(_meta_type, object)):
     pass
 
   def build_output_dict(self):
-    outputs = {}
-    for name in self.get_outputs():
-      if name not in self._prediction_dict:
-        raise KeyError('output node {} not in prediction_dict, can not be exported'.format(name))
-      outputs[name] = self._prediction_dict[name]
-    return outputs
+    """name -> tensor for every exported output (easy_rec_model.py:175-183)"""
+    missing = [n for n in self.get_outputs() if n not in self._prediction_dict]
+    if missing:
+      raise KeyError('output node {} not in prediction_dict, can not be exported'.format(missing[0]))
+    return {n: self._prediction_dict[n] for n in self.get_outputs()}
 
   def backward(self, flush=True):
     """Back-propagate the loss gradients recorded by build_loss_graph through the dense graph.  flush=False leaves
