@@ -268,7 +268,14 @@ class Input(object, metaclass=_meta_type):
     for i, s in enumerate(col):
       if isinstance(s, bytes):
         s = s.decode('utf-8')
-      toks = s.split(fc.separator) if s != '' else []
+      # tf.strings.split (input.py:685) is python's str.split with the whole separator: empty tokens stay, and an EMPTY
+      # cell is one empty token.  The column takes the sparse result as it is (no ignore-value dropping for inputs
+      # that are already sparse), so a hashed / vocabulary sequence embeds the empty string like any other token - an
+      # empty cell is a sequence of length 1.  Number sequences cannot convert '' (TensorFlow raises): no token here.
+      toks = s.split(fc.separator)
+      embeds_strings = (fc.HasField('hash_bucket_size') and fc.hash_bucket_size > 0) or len(fc.vocab_list) > 0
+      if toks == [''] and ('bounds' in self.schema.seqs[name] or not embeds_strings):
+        toks = []
       toks = toks[:L]  # max_seq_len truncation (layers/input_layer.py:183-185)
       if not toks:
         continue
