@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """What the REFERENCE'S OWN input preprocessing (easy_rec/python/input/input.py: Input._parse_id_feature :537-555,
-_parse_raw_feature :557-673, _parse_tag_feature :432-505, _parse_seq_feature :677-760, _as_string :356-376) makes of raw
+_parse_raw_feature :557-673, _parse_tag_feature :432-505, _parse_seq_feature :677-760, _parse_combo_feature :378-430,
+_lookup_preprocess :941-1003, _as_string :356-376) makes of raw
 columns - run in the build container where /root/reference exists.
 
 Those methods are Python over a dozen TensorFlow string / sparse ops.  This script executes them, unmodified, on a numpy
@@ -64,7 +65,19 @@ class Str(object):
 
   def __getitem__(self, i):
     r = self.a[i]
-    return Str(r) if isinstance(r, np.ndarray) else r
+    return Str(r) if isinstance(r, np.ndarray) else Scalar(r)
+
+
+class Scalar(str):
+  """one string of a string tensor, as tf.map_fn hands it to its function"""
+  dtype = 'string'
+
+  def get_shape(self):
+    return Shape(())
+
+  @property
+  def a(self):
+    return np.asarray(str(self), dtype=object)
 
 
 class Sparse(object):
@@ -141,7 +154,7 @@ def make_tf():
   tf.expand_dims = lambda x, axis=0: Str(np.expand_dims(x.a, axis)) if isinstance(x, Str) else num(np.expand_dims(x, axis))
   tf.squeeze = lambda x, axis=None: Str(np.squeeze(x.a, axis)) if isinstance(x, Str) else num(np.squeeze(x, axis))
 
-  def reshape(x, shape):
+  def reshape(x, shape, name=None):
     shape = [int(s) for s in shape]
     return Str(x.a.reshape(shape)) if isinstance(x, Str) else num(np.reshape(x, shape))
 
@@ -166,6 +179,25 @@ def make_tf():
     return num(out)
 
   tf.sparse_to_dense = sparse_to_dense
+  # the ops of Input._lookup_preprocess (input.py:941-1003) and _parse_combo_feature (:378-430)
+  tf.equal = lambda a, b: (a.a if isinstance(a, Str) else np.asarray(a)) == (b.a if isinstance(b, Str) else b)
+  tf.where = lambda cond: num(np.argwhere(np.asarray(cond)), np.int64)
+  tf.gather = lambda x, i: Str(x.a[np.asarray(i, dtype=np.int64)]) if isinstance(x, Str) else num(np.asarray(x)[np.asarray(i)])
+  tf.pad = lambda x, paddings: Str(np.concatenate([x.a, np.array([''] * int(paddings[0][1]), dtype=object)])) \
+      if isinstance(x, Str) else num(np.pad(np.asarray(x), [tuple(int(v) for v in p) for p in paddings]))
+  tf.sequence_mask = lambda n, maxlen: np.arange(int(maxlen)) < int(n)
+  tf.zeros = lambda shape, dtype=np.float32: num(np.zeros([int(v) for v in shape], dtype=dtype))
+  tf.stack = lambda xs: num([int(v) for v in xs], np.int64)
+  tf.reduce_max = lambda x: np.max(np.asarray(x))
+
+  def map_fn(fn, elems, dtype=None):
+    outs = [fn([e[i] if isinstance(e, Str) else np.asarray(e)[i] for e in elems]) for i in range(len(elems[0].a))]
+    cols = list(zip(*outs))
+    return tuple(Str(np.stack([c.a for c in col])) if isinstance(col[0], Str) else num(np.stack([np.asarray(c) for c in col]))
+                 for col in cols)
+
+  tf.map_fn = map_fn
+  tf.boolean_mask = lambda x, m: Str(x.a[np.asarray(m)]) if isinstance(x, Str) else num(np.asarray(x)[np.asarray(m)])
   tf.compat = types.SimpleNamespace(v1=tf)
   return tf
 
@@ -201,6 +233,8 @@ def main():
                         ('easy_rec.python.utils', 'constant')):
     setattr(sys.modules[parent], child, sys.modules[parent + '.' + child])
   sys.modules['easy_rec.python.protos.dataset_pb2'] = protos.dataset_pb2
+  sys.modules['tensorflow.python.ops.string_ops'].string_join = lambda inputs, separator='': Str(
+      [separator.join(str(i.a.reshape(-1)[r]) for i in inputs) for r in range(inputs[0].a.size)])
   sys.modules['easy_rec.python.utils.check_utils'].check_split = None
   sys.modules['easy_rec.python.utils.check_utils'].check_string_to_number = None
   sys.modules['easy_rec.python.utils.expr_util'].get_expression = None
@@ -231,8 +265,11 @@ def main():
   FC = protos.feature_config_pb2.FeatureConfig
   parsed = {}
   for fc in features.features:
+    if fc.feature_type == FC.LookupFeature:  # (as Input._preprocess dispatches it: input.py:851-855)
+      parsed[fc.feature_name] = inp._lookup_preprocess(fc, field_dict)
+      continue
     {FC.IdFeature: inp._parse_id_feature, FC.RawFeature: inp._parse_raw_feature, FC.TagFeature: inp._parse_tag_feature,
-     FC.SequenceFeature: inp._parse_seq_feature}[fc.feature_type](fc, parsed, field_dict)
+     FC.SequenceFeature: inp._parse_seq_feature, FC.ComboFeature: inp._parse_combo_feature}[fc.feature_type](fc, parsed, field_dict)
   out = {'generator': 'tests/golden/make_preprocess_vectors.py', 'parsed': {k: canonical(v) for k, v in parsed.items()}}
   path = os.path.join(HERE, 'preprocess_vectors.json')
   with open(path, 'w') as f:

@@ -18,6 +18,7 @@ DATA_CONFIG = """
   input_fields { input_name: 'clicks' input_type: STRING }
   input_fields { input_name: 'cates' input_type: STRING }
   input_fields { input_name: 'prices' input_type: STRING }
+  input_fields { input_name: 'kv_map' input_type: STRING }
   label_fields: 'label'
   batch_size: 6
 """
@@ -40,6 +41,12 @@ FEATURES = """
              separator: ';' }
   features { input_names: 'prices' feature_type: SequenceFeature sub_feature_type: RawFeature boundaries: [1, 5, 10] embedding_dim: 4
              separator: '|' }
+  features { feature_name: 'city_value' input_names: 'city' input_names: 'kv_map' feature_type: LookupFeature hash_bucket_size: 300
+             embedding_dim: 4 separator: '|' kv_separator: ':' lookup_max_sel_elem_num: 4 }
+  features { feature_name: 'uid_x_level' input_names: 'uid' input_names: 'level' feature_type: ComboFeature hash_bucket_size: 400
+             embedding_dim: 4 }
+  features { feature_name: 'city_level' input_names: 'city' input_names: 'level' feature_type: ComboFeature hash_bucket_size: 400
+             embedding_dim: 4 combo_join_sep: '_' }
 """
 
 COLUMNS = {
@@ -59,4 +66,5 @@ COLUMNS = {
     'clicks': ['c1|c2|c3', 'c9', 'c1||c2', '', 'c5|c6', 'c7|c8|c9|c1'],
     'cates': ['1;2;3', '29', '0;0', '5', '7;8', '10;11;12;13'],
     'prices': ['0.5|3|12', '5', '10|1', '7.5', '0|100', '4.9|5.1'],
+    'kv_map': ['3:a|4:b|3:c', '19:x', '1:no', '7:p|7:q|7:r|8:s', '', '11:z|12:y'],
 }

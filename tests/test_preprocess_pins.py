@@ -45,7 +45,7 @@ def _batch():
     cols[name] = list(col) if t == dataset_pb2.DatasetConfig.STRING else np.asarray(
         col, dtype={dataset_pb2.DatasetConfig.INT32: np.int32, dataset_pb2.DatasetConfig.INT64: np.int64,
                     dataset_pb2.DatasetConfig.FLOAT: np.float32, dataset_pb2.DatasetConfig.DOUBLE: np.float64}[t])
-  return inp, inp.preprocess(cols), {f.input_names[0]: f for f in fcs.features}
+  return inp, inp.preprocess(cols), {(f.feature_name or f.input_names[0]): f for f in fcs.features}
 
 
 def _ragged(batch, kind, name):
@@ -102,3 +102,20 @@ def test_sequence_features(ref_backend):
   got = _ragged(batch, 'seq', 'prices')[0]
   assert got == [bucketize(np.asarray(r, dtype=np.float32), np.asarray([1, 5, 10], dtype=np.float32)).tolist()
                  for r in REF['prices']['sparse_rows']]
+
+
+def test_lookup_and_combo_features(ref_backend):
+  from oracle import hashing
+  inp, batch, fcs = _batch()
+  sch = inp.schema
+  # LookupFeature: the values of the map's pairs whose key is the row's key, in map order, hashed
+  rows, _ = _ragged(batch, 'tag', 'city_value')
+  assert rows == [_hash(r, 300).tolist() if r else [] for r in REF['city_value']['sparse_rows']]
+  # ComboFeature with combo_join_sep: ONE hashed string per row, the inputs joined
+  assert np.array_equal(np.asarray(batch['hash_ids'])[sch.hash_single['city_level']['col']],
+                        _hash(REF['city_level']['strings'], 400))
+  # ComboFeature without it: crossed_column over the inputs as strings (integers through as_string) - the input stage
+  # computes the crossed id; the strings the reference hands to the cross are what was crossed
+  a, b = REF['uid_x_level']['strings'], REF['uid_x_level_1']['strings']
+  want = [int(hashing.sparse_cross_hashed([x.encode('utf-8'), y.encode('utf-8')], 400)) for x, y in zip(a, b)]
+  assert np.asarray(batch['int_ids'])[sch.int_single['uid_x_level']['col']].tolist() == want
