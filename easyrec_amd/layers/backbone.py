@@ -60,6 +60,10 @@ class _TFShim(object):
     return out
 
   @staticmethod
+  def unstack(x, num=None, axis=0):
+    return list(torch.unbind(x, dim=axis))
+
+  @staticmethod
   def reduce_sum(x, axis=None, keepdims=False):
     return x.sum() if axis is None else x.sum(dim=axis, keepdim=keepdims)
 

@@ -52,6 +52,14 @@ class _TF(object):
   """the tf.* calls config lambdas make, over torch (test infrastructure)"""
 
   @staticmethod
+  def unstack(x, num=None, axis=0):
+    return list(torch.unbind(x, dim=axis))
+
+  @staticmethod
+  def reshape(x, shape):
+    return x.reshape(tuple(int(s) for s in shape))
+
+  @staticmethod
   def reduce_sum(x, axis=None, keepdims=False):
     return x.sum() if axis is None else x.sum(dim=axis, keepdim=keepdims)
 
