@@ -101,3 +101,14 @@ def test_sparse_cross_hashed_host_entry_equals_the_oracle(built_lib):
     assert rc == 0
     assert np.array_equal(out, exp)
     assert (out >= 0).all()  # '' is crossed like any other value
+
+
+def test_fingerprint64_bigquery_documentation_vectors():
+  """FARM_FINGERPRINT is farmhash Fingerprint64 (as a signed int64); the example in BigQuery's function reference
+  fingerprints CONCAT(x, y, z) of the rows (1, "foo", true), (2, "apple", false), (3, "", true): full 64-bit known
+  answers for inputs of 8, 11 and 5 bytes."""
+  from oracle import hashing
+  for s, want in ((b'1footrue', -1541654101129638711), (b'2applefalse', 2794438866806483259), (b'3true', -4880158226897771312)):
+    for fn in (hashing.fingerprint64, hashing.fingerprint64_py):
+      v = int(fn(s))
+      assert (v - (1 << 64) if v >= (1 << 63) else v) == want, (s, fn.__name__)
