@@ -185,6 +185,10 @@ class Package(object):
     if layer_cls is None:
       raise ValueError('Invalid keras layer class name: ' + layer_conf.class_name)
     param_type = layer_conf.WhichOneof('params')
+    if not customize:
+      # a standard Keras layer: its st_params are the constructor's keyword arguments (backbone.py:381-397)
+      assert param_type in (None, 'st_params'), 'internal keras layer only support st_params'
+      return layer_cls(name=name, **(convert_to_dict(layer_conf.st_params) if param_type else {}))
     if param_type is None or param_type == 'st_params':
       params = Parameter(layer_conf.st_params, True, l2_reg=self._l2_reg)
     else:
@@ -366,3 +370,20 @@ def merge_inputs(inputs, axis=-1, msg=''):
     logging.warning('%s: try to merge inputs into list' % msg)
     return [e for x in inputs for e in (x if isinstance(x, list) else [x])]
   return torch.cat(list(inputs), dim=axis)
+
+
+def convert_to_dict(struct):
+  """A Struct of constructor arguments as python values (reference backbone.py:553-571): whole numbers arrive as
+  doubles and are handed on as ints, nested structs as dicts, lists as lists."""
+  from google.protobuf import struct_pb2
+
+  def plain(value):
+    if isinstance(value, float):
+      return int(value) if int(value) == value else value
+    if isinstance(value, struct_pb2.ListValue):
+      return [plain(v) for v in value]
+    if isinstance(value, struct_pb2.Struct):
+      return convert_to_dict(value)
+    return value
+
+  return {str(key): plain(value) for key, value in struct.items()}

@@ -5,3 +5,4 @@ from .interaction import CIN, FM, Cross, DotInteraction  # noqa: F401
 from .multi_task import MMoE  # noqa: F401
 from .din import DIN  # noqa: F401
 from .fibinet import SENet  # noqa: F401
+from .standard import Activation, Dense, Dropout  # noqa: F401

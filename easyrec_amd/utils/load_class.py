@@ -57,7 +57,10 @@ def load_keras_layer(name):
     return None
   module = importlib.import_module('easyrec_amd.layers.keras')
   cls = getattr(module, name, None)
-  return (cls, True) if isinstance(cls, type) else (None, False)
+  if not isinstance(cls, type):
+    return None, False
+  # (False: a standard Keras layer, constructed from keyword arguments - layers/keras/standard.py)
+  return cls, not getattr(cls, 'standard', False)
 
 
 MODEL_MODULES = ('deepfm', 'dcn', 'multi_tower_din', 'mmoe', 'rank_model', 'multi_task_model', 'wide_and_deep', 'fm',

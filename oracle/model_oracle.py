@@ -906,6 +906,21 @@ class OracleTrainer(object):
       out.append((stacked * gate[:, :, None]).sum(dim=1))
     return out
 
+  def _standard_keras(self, V, x, kl, name):
+    """tensorflow.keras.layers.Dense / Activation / Dropout named directly in a backbone (st_params = constructor
+    keyword arguments, backbone.py:381-397)"""
+    p = kl.st_params
+    act = p['activation'] if 'activation' in p else None
+    if kl.class_name == 'Dense':
+      x = self.dense(V, x, int(p['units']), name, 0.0)  # (no kernel regulariser: none is passed)
+    elif kl.class_name == 'Dropout':
+      assert float(p['rate']) == 0.0, 'the oracle has no random dropout'
+      return x
+    if act in (None, 'linear'):
+      return x
+    return {'relu': torch.relu, 'sigmoid': torch.sigmoid, 'tanh': torch.tanh,
+            'softmax': lambda t: torch.softmax(t, dim=-1)}[act](x)
+
   def _keras_senet(self, V, inputs, cfg, name):
     """layers/keras/fibinet.py:15-92: per field and squeeze group the max and the mean over the group's columns ->
     Dense W1 (relu, with bias) -> Dense W2 (sum of the dims) -> re-weight the concatenated embeddings (+ skip
@@ -1046,6 +1061,8 @@ class OracleTrainer(object):
           x = self._keras_cin(V, x, [int(h) for h in kl.cin.hidden_feature_sizes], blk.name)
         elif kl.class_name == 'MMoE':
           x = self._keras_mmoe(V, x, kl.mmoe, blk.name, l2)
+        elif kl.class_name in ('Dense', 'Activation', 'Dropout'):
+          x = self._standard_keras(V, x, kl, blk.name)
         elif kl.class_name == 'SENet':
           x = self._keras_senet(V, x, kl.senet, blk.name)
         elif kl.class_name == 'FM':

@@ -117,6 +117,22 @@ CASES['bb_mechanics'] = ("""
   blocks { name: 'side' inputs { block_name: 'heads' input_slice: '[:, 1:4]' } }
 """, OrderedDict(user=('cat', [3, 2]), item=('cat', [2, 3])))
 
+# standard Keras layers named directly (tensorflow.keras.layers.Dense: constructed from the st_params as keyword
+# arguments, backbone.py:381-397; the shape of examples/configs/mlp_on_movielens.config without its Dropout layers)
+CASES['bb_standard_keras'] = ("""
+  blocks { name: 'mlp' inputs { feature_group_name: 'features' }
+           layers { keras_layer { class_name: 'Dense' st_params { fields { key: 'units' value { number_value: 6 } }
+                                                                 fields { key: 'activation' value { string_value: 'relu' } } } } }
+           layers { keras_layer { class_name: 'Dense' st_params { fields { key: 'units' value { number_value: 4 } }
+                                                                 fields { key: 'activation' value { string_value: 'sigmoid' } }
+                                                                 fields { key: 'use_bias' value { bool_value: false } } } } }
+           layers { keras_layer { class_name: 'Dense' st_params { fields { key: 'units' value { number_value: 1 } } } } } }
+  blocks { name: 'side' inputs { feature_group_name: 'features' input_fn: 'lambda x: x[:, :3]' }
+           keras_layer { class_name: 'Dense' st_params { fields { key: 'units' value { number_value: 2 } }
+                                                         fields { key: 'activation' value { string_value: 'tanh' } } } } }
+  concat_blocks: ['mlp', 'side']
+""", OrderedDict(features=('cat', [3, 2, 2])))
+
 
 def backbone_config(text):
   from google.protobuf import text_format
