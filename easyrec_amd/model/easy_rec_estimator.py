@@ -381,7 +381,9 @@ class EasyRecEstimator(object):
           elif kind == 'grouped':  # host-side, as the reference's py_func
             m.update(label, pred['probs' + suf], host_key_column(self.features.schema, batch, arg[0]))
           else:
-            m.update(label, pred['probs' + suf])
+            # max_f1 is fed the LOGITS (rank_model.py:424-427: `metrics_lib.max_f1(label, prediction_dict['logits'])`),
+            # against its 200 thresholds in [0, 1] - the reference's choice, kept so that the numbers agree
+            m.update(label, pred['logits' + suf])
     finally:
       self.model._is_training, self.ctx.is_training = was
     return {name + suf: m.result() for (name, suf), (_, _, m) in acc.items()}

@@ -163,11 +163,12 @@ def test_evaluate_with_grouped_metrics(ref_backend):
   out = est.evaluate(batches)
   assert sorted(out) == ['auc', 'gauc', 'max_f1', 'session_auc']
   # recompute from the predictions
-  labels, probs, k1, k2 = [], [], [], []
+  labels, probs, k1, k2, logits = [], [], [], [], []
   est.model._is_training, est.ctx.is_training = False, False
   for b in batches:
     pred = est.predict(b)
     probs.append(pred['probs'].detach().cpu().numpy().reshape(-1).copy())
+    logits.append(pred['logits'].detach().cpu().numpy().reshape(-1).copy())
     labels.append(est.features.label(est.model._label_name).cpu().numpy().reshape(-1).copy())
     k1.append(host_key_column(est.features.schema, b, 'C1'))
     k2.append(host_key_column(est.features.schema, b, 'C2'))
@@ -177,7 +178,13 @@ def test_evaluate_with_grouped_metrics(ref_backend):
   assert k1.dtype == object and len(set(k1.tolist())) > 3  # raw strings, several users
   assert abs(out['gauc'] - float(_separated_auc_like_the_reference(labels, probs, k1.tolist(), 'mean_by_sample_num'))) < 1e-6
   assert abs(out['session_auc'] - float(_separated_auc_like_the_reference(labels, probs, k2.tolist(), 'mean'))) < 1e-6
-  assert 0.0 <= out['max_f1'] <= 1.0
+  # max_f1 reads the LOGITS (rank_model.py:424-427), not the probabilities
+  from easyrec_amd.core.metrics import MaxF1
+  on_logits, on_probs = MaxF1(), MaxF1()
+  on_logits.update(labels, np.concatenate(logits))
+  on_probs.update(labels, probs)
+  assert abs(out['max_f1'] - on_logits.result()) < 1e-9 and 0.0 <= out['max_f1'] <= 1.0
+  assert on_logits.result() != on_probs.result()
 
 
 def test_host_key_column_variants():
