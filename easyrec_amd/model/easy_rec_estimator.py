@@ -338,23 +338,32 @@ class EasyRecEstimator(object):
     assert self._built
     ec = eval_config if eval_config is not None else self.pipeline_config.eval_config
     from easyrec_amd.input.features import host_key_column
-    specs = []  # (output name, metric kind, argument)
-    for m in ec.metrics_set:
-      kind = m.WhichOneof('metric')
-      if kind == 'auc':
-        specs.append(('auc', 'auc', int(m.auc.num_thresholds)))
-      elif kind == 'gauc':  # rank_model.py:376-399
-        specs.append(('gauc', 'grouped', (m.gauc.uid_field, m.gauc.reduction)))
-      elif kind == 'session_auc':  # rank_model.py:401-420
-        specs.append(('session_auc', 'grouped', (m.session_auc.session_id_field, m.session_auc.reduction)))
-      elif kind == 'max_f1':
-        specs.append(('max_f1', 'max_f1', None))
-      else:
-        raise NotImplementedError('metric %s is outside the hot-path scope (auc, gauc, session_auc, max_f1)' % kind)
-    if not specs:
-      specs = [('auc', 'auc', 200)]  # eval.proto: auc is the default metric of a rank model
+    def specs_of(metrics_set):  # [(output name, metric kind, argument)]
+      specs = []
+      for m in metrics_set:
+        kind = m.WhichOneof('metric')
+        if kind == 'auc':
+          specs.append(('auc', 'auc', int(m.auc.num_thresholds)))
+        elif kind == 'gauc':  # rank_model.py:376-399
+          specs.append(('gauc', 'grouped', (m.gauc.uid_field, m.gauc.reduction)))
+        elif kind == 'session_auc':  # rank_model.py:401-420
+          specs.append(('session_auc', 'grouped', (m.session_auc.session_id_field, m.session_auc.reduction)))
+        elif kind == 'max_f1':
+          specs.append(('max_f1', 'max_f1', None))
+        else:
+          raise NotImplementedError('metric %s is outside the hot-path scope (auc, gauc, session_auc, max_f1)' % kind)
+      return specs
+
     towers = getattr(self.model, '_label_name_dict', None)
-    heads = [('', self.model._label_name)] if not towers else [('_' + t, l) for t, l in towers.items()]
+    if not towers:
+      # a rank model: eval_config.metrics_set (rank_model.py build_metric_graph); auc when it is empty (eval.proto)
+      heads = [('', self.model._label_name)]
+      head_specs = {'': specs_of(ec.metrics_set) or [('auc', 'auc', 200)]}
+    else:
+      # a multi-task model: every tower's OWN metrics_set (multi_task_model.py:143-158); a passed eval_config overrides
+      heads = [('_' + t, l) for t, l in towers.items()]
+      by_name = {t.name: t.config.metrics_set for t in self.model._towers}
+      head_specs = {'_' + t: specs_of(ec.metrics_set if eval_config is not None else by_name[t]) for t in towers}
 
     def make(kind, arg):
       if kind == 'auc':
@@ -365,7 +374,7 @@ class EasyRecEstimator(object):
 
     acc = {}
     for suf, _ in heads:
-      for name, kind, arg in specs:
+      for name, kind, arg in head_specs[suf]:
         acc.setdefault((name, suf), (kind, arg, make(kind, arg)))  # (a metric named twice keeps its first settings)
     was = (self.model._is_training, self.ctx.is_training)
     self.model._is_training, self.ctx.is_training = False, False

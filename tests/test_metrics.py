@@ -142,6 +142,25 @@ def test_max_f1_follows_the_restatement():
   assert abs(m.result() - best) < 1e-9 and 0.3 < best < 1.0
 
 
+def test_multi_task_metrics_are_each_tower_s_own(ref_backend):
+  """A multi-task model evaluates every tower with the tower's OWN metrics_set (multi_task_model.py:143-158), not with
+  eval_config.metrics_set: a tower without one reports nothing, a tower may ask for max_f1 beside auc."""
+  from google.protobuf import text_format
+  from easyrec_amd.input.synthetic import SyntheticBatches
+  from easyrec_amd.model.easy_rec_estimator import EasyRecEstimator
+  from easyrec_amd.utils import config_util
+  cfg = config_util.get_configs_from_pipeline_file(os.path.join(ROOT, 'configs', 'mmoe_taobao_small.config'))
+  towers = cfg.model_config.mmoe.task_towers
+  towers[1].ClearField('metrics_set')
+  text_format.Merge('metrics_set { max_f1 {} }', towers[0])
+  est = EasyRecEstimator(cfg, device='cpu', batch_size=32, seed=1).build()
+  gen = SyntheticBatches(cfg.data_config, est.feature_configs, batch_size=32, seed=5)
+  batches = [gen.next_batch() for _ in range(2)]
+  est.train_step(batches[0])
+  out = est.evaluate(batches)
+  assert sorted(out) == ['auc_%s' % towers[0].tower_name, 'max_f1_%s' % towers[0].tower_name], out
+
+
 def test_evaluate_with_grouped_metrics(ref_backend):
   """metrics_set { gauc } / { session_auc } / { max_f1 } through EasyRecEstimator.evaluate(): the key column is the
   RAW value of the named feature (its strings for a hashed id feature), as `feature_dict[uid_field]` in the
