@@ -158,7 +158,8 @@ class OracleTrainer(object):
   def _opt_cfg(o):
     kind = o.WhichOneof('optimizer')
     c = getattr(o, kind)
-    d = {'kind': kind, 'beta1': getattr(c, 'beta1', 0.9), 'beta2': getattr(c, 'beta2', 0.999), 'lr_cfg': c.learning_rate}
+    d = {'kind': kind, 'beta1': getattr(c, 'beta1', 0.9), 'beta2': getattr(c, 'beta2', 0.999), 'lr_cfg': c.learning_rate,
+         'initial_accumulator_value': getattr(c, 'initial_accumulator_value', 0.1)}
     return d
 
   def _lr(self, lr_cfg, step):
@@ -1314,6 +1315,13 @@ class OracleTrainer(object):
           m[:] = m + (g - m) * (one - b1)
           v[:] = v + (g * g - v) * (one - b2)
           var[:] = var - (m * lr_t) / (np.sqrt(v, dtype=np.float32) + eps)
+      elif o['kind'] == 'adagrad_optimizer':
+        # tf.train.AdagradOptimizer (builders/optimizer_builder.py:110-116): accumulator starts at
+        # initial_accumulator_value; accum += g^2; var -= lr * g / sqrt(accum).  A table's sparse apply touches the rows
+        # of the gradient only - the same arithmetic, since untouched rows have g = 0.
+        acc = self.slots.setdefault(name + '/v', np.full_like(var, F32(o['initial_accumulator_value'])))
+        acc[:] = acc + g * g
+        var[:] = var - (F32(lr) * g) / np.sqrt(acc, dtype=np.float32)
       else:
         raise NotImplementedError(o['kind'])
     for oi, o in enumerate(self.opt):

@@ -127,6 +127,7 @@ def test_csv_input_roundtrip(tmp_path, built_lib):
                                       ('dbmtl_taobao_small.config', 24), ('dbmtl_mmoe_taobao_small.config', 24),
                                       ('mmoe_backbone_taobao_small.config', 24),
                                       ('multi_tower_f1_pairwise_criteo_small.config', 24),
+                                      ('deepfm_adagrad_criteo_small.config', 24),
                                       ('mmoe_tower_losses_taobao_small.config', 24),
                                       ('dbmtl_numeric_sequences_taobao_small.config', 24),
                                       ('dbmtl_numeric_sequences_dnn_taobao_small.config', 24),

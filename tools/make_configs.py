@@ -655,6 +655,24 @@ def tower_losses_variant(src_name, dst_name):
   write(cfg, dst_name)
 
 
+def adagrad_embedding_variant(src_name, dst_name):
+  """Two optimizers, as the reference's samples/model_config/deepfm_combo_on_avazu_embed_adagrad.config: Adagrad for
+  the embedding tables (initial accumulator 0.2), the fixture's Adam for the dense variables."""
+  from easyrec_amd.protos import pipeline_pb2
+  here = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'configs')
+  cfg = pipeline_pb2.EasyRecConfig()
+  with open(os.path.join(here, src_name)) as f:
+    text_format.Merge(f.read(), cfg)
+  dense = pipeline_pb2.EasyRecConfig().train_config.optimizer_config.add()
+  dense.CopyFrom(cfg.train_config.optimizer_config[0])
+  emb = cfg.train_config.optimizer_config[0]
+  emb.Clear()
+  text_format.Merge("adagrad_optimizer { learning_rate { constant_learning_rate { learning_rate: 0.05 } } "
+                    "initial_accumulator_value: 0.2 }", emb)
+  cfg.train_config.optimizer_config.add().CopyFrom(dense)
+  write(cfg, dst_name)
+
+
 def ple_variant(src_name, dst_name):
   """The MMoE fixture as PLE (reference model/ple.py): two extraction networks, 2 experts per task + 2 shared."""
   from easyrec_amd.protos import pipeline_pb2
@@ -764,6 +782,7 @@ if __name__ == '__main__':
   dbmtl_variant('mmoe_taobao_small.config', 'dbmtl_mmoe_taobao_small.config', experts=3)
   mmoe_backbone_variant('mmoe_taobao_small.config', 'mmoe_backbone_taobao_small.config')
   losses_variant('multi_tower_criteo_small.config', 'multi_tower_f1_pairwise_criteo_small.config')
+  adagrad_embedding_variant('deepfm_criteo_small.config', 'deepfm_adagrad_criteo_small.config')
   tower_losses_variant('mmoe_taobao_small.config', 'mmoe_tower_losses_taobao_small.config')
   write(dbmtl_numeric_sequences_taobao(batch_size=128, scale=0.01, seq_len=12), 'dbmtl_numeric_sequences_taobao_small.config')
   write(dbmtl_numeric_sequences_taobao(transform_dnn=True, batch_size=128, scale=0.01, seq_len=12),
