@@ -84,8 +84,9 @@ def build(loss_type, label, pred, loss_weight=1.0, num_class=1, loss_scale=1.0, 
     loss, dlogits, _ = kernels.hip().sigmoid_ce(pred.detach().contiguous(), labels.contiguous(), weights,
                                                 scale)
     return loss, dlogits
-  if loss_type == LossType.L2_LOSS:
-    # tf.losses.mean_squared_error: mean((label - pred)^2) (elementwise torch ops; not the hot path)
+  if loss_type in (LossType.L2_LOSS, LossType.SIGMOID_L2_LOSS):
+    # tf.losses.mean_squared_error: mean((label - pred)^2) (elementwise torch ops; not the hot path).  For
+    # SIGMOID_L2_LOSS `pred` is already sigmoid(output) (rank_model.py:126-128) and autograd carries dz through it
     labels = label.to(torch.float32)
     p = pred.detach()
     diff = p - labels

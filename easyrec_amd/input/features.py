@@ -219,6 +219,10 @@ class DeviceFeatures(object):
   def raw(self, name):
     if name in self.raw_multi:
       return self.raw_multi[name]['values']  # [B, k]
+    if name not in self.schema.raw:
+      # (ExprFeature columns: the reference evaluates the expression in the input pipeline, input.py:507-530)
+      raise NotImplementedError('feature %s: ExprFeature / PassThroughFeature values are outside the hot-path scope '
+                                '(no numeric input of that name in the batch)' % name)
     r = self.schema.raw[name]
     blk = self.raw_block[r['row']:r['row'] + r['dim']]
     return blk[0] if r['dim'] == 1 else blk  # [B] or [dim, B]

@@ -362,8 +362,9 @@ class Input(object, metaclass=_meta_type):
         int_ids[sch.int_single[name]['col']] = kernels.hip().sparse_cross_hashed_host(
             data, offsets, B, len(fc.input_names), sch.int_single[name]['num_buckets'])
       elif ft == FeatureConfig.ComboFeature and name in sch.hash_single:
-        cols = [columns[n] for n in fc.input_names]
-        joined = [fc.combo_join_sep.join(str(c[i]) for c in cols) for i in range(B)]
+        # string_join of every input as a string (input.py:425-430, `_as_string`: ints in decimal, floats at fc.precision)
+        cols = [as_string(columns[n], self.field_type(n), fc.precision) for n in fc.input_names]
+        joined = [fc.combo_join_sep.join(c[i] for c in cols) for i in range(B)]
         hash_strings[sch.hash_single[name]['col']] = joined
     out['raw'] = raw
     out['int_ids'] = int_ids

@@ -23,5 +23,8 @@ class FM(object):
       sink = kernels.grad_sink_of(base)  # the block lives in an embedding group output: deposit its gradient there
     else:
       F, D = len(fm_fea), fm_fea[0].shape[1]
+      if any(t.shape[1] != D for t in fm_fea):  # (the reference's tf.stack rejects it when the graph is built)
+        raise ValueError('FM %s: every field must have the same embedding_dim, got %s' %
+                         (self._name, [int(t.shape[1]) for t in fm_fea]))
       x = torch.cat(list(fm_fea), dim=1)
     return kernels.FMFn.apply(x, F, D, sink, col0)

@@ -185,8 +185,11 @@ class OracleTrainer(object):
   # ------------------------------------------------------------------ preprocessing
   def _hashed_ids(self, batch):
     """int64 [n_hash_features, B], -1 where the string is '' (dropped before hashing)."""
+    # (a ComboFeature with combo_join_sep is ONE hashed column over the inputs' strings joined by the separator,
+    # feature_column/feature_column.py:446-455, input/input.py:408-430: the joined string arrives from the input stage)
     names = [n for n, f in self.fc_by_name.items()
-             if f.feature_type == f.IdFeature and f.HasField('hash_bucket_size') and f.hash_bucket_size > 0]
+             if (f.feature_type == f.IdFeature or (f.feature_type == f.ComboFeature and len(f.combo_join_sep) > 0))
+             and f.HasField('hash_bucket_size') and f.hash_bucket_size > 0]
     if not names:
       return {}
     if 'hash_ids' in batch:
@@ -355,7 +358,7 @@ class OracleTrainer(object):
         else:
           e = self._lookup_dense(table, np.zeros(self.B, dtype=np.int64), raws[n])
         outs.append((e, True))
-      elif fc.feature_type == fc.IdFeature or (fc.feature_type == fc.ComboFeature and n in ints):
+      elif fc.feature_type == fc.IdFeature or (fc.feature_type == fc.ComboFeature and (n in ints or n in hashed)):
         # (crossed ComboFeature: CrossedColumn under an EmbeddingColumn, the id comes from the input stage)
         var_name = self._column_var_name(scope, fc, wide)
         ids = hashed[n] if n in hashed else ints[n]
@@ -1138,6 +1141,11 @@ class OracleTrainer(object):
         x = (zz[:, None] - zz[None, :] - margin)[labels[:, None] > labels[None, :]]
         per = torch.where(x >= 0, x, torch.zeros_like(x)) - x + torch.log1p(torch.exp(torch.where(x >= 0, -x, x)))
         return 'pair_wise_loss', per.sum() / max(int(x.numel()), 1)
+      if loss_type in (LossType.L2_LOSS, LossType.SIGMOID_L2_LOSS):
+        # rank_model.py:123-128 (y = the output column, through a sigmoid for SIGMOID_L2_LOSS) and
+        # builders/loss_builder.py:52-56: tf.losses.mean_squared_error of y against the float label
+        y = torch.sigmoid(z) if loss_type == LossType.SIGMOID_L2_LOSS else z
+        return 'l2_loss', ((y - labels) ** 2).mean()
       assert loss_type in (LossType.CLASSIFICATION, LossType.BINARY_CROSS_ENTROPY_LOSS), loss_type
       # tf.losses.sigmoid_cross_entropy (SUM_BY_NONZERO_WEIGHTS, weights = 1.0)
       return 'cross_entropy_loss', ce_of(z, labels)

@@ -265,6 +265,80 @@ def test_combo_feature_crossed_column_through_the_input_and_the_model(ref_backen
       assert np.allclose(st[k], v, rtol=1e-4, atol=1e-6), k
 
 
+def test_joined_combo_feature_through_the_input_and_the_model(ref_backend, tmp_path):
+  """ComboFeature WITH combo_join_sep = one hashed column over the inputs' strings joined by the separator (reference
+  input/input.py:425-430 string_join, feature_column/feature_column.py:446-455; the shape of
+  samples/model_config/deepfm_combo_v2_on_avazu_ctr.config): CSVInput joins and hashes, ids against the pinned hash
+  restatement, two training steps against the model oracle."""
+  from easyrec_amd.input.csv_input import CSVInput
+  from easyrec_amd.model.easy_rec_estimator import EasyRecEstimator
+  from oracle import hashing
+  from oracle.model_oracle import OracleTrainer
+  cfg = config_util.get_configs_from_pipeline_file('configs/deepfm_combo_criteo_small.config')
+  combo = [f for f in cfg.feature_config.features if f.feature_name == 'C1_C2_cross'][0]
+  combo.combo_join_sep = 'X'
+  B, rows = 24, []
+  rng = np.random.default_rng(5)
+  for i in range(2 * B):
+    f = ['%d' % rng.integers(0, 50) if rng.random() > 0.2 else '' for _ in range(13)]
+    c = ['%02x' % rng.integers(0, 40) if rng.random() > 0.15 else '' for _ in range(26)]
+    rows.append('\t'.join(['%d' % (i % 3 == 0)] + f + c))
+  p = tmp_path / 'data.tsv'
+  p.write_text('\n'.join(rows) + '\n')
+  inp = CSVInput(cfg.data_config, list(cfg.feature_config.features), str(p), batch_size=B, hash_on_host=True)
+  batches = list(inp.batches())[:2]
+  est = EasyRecEstimator(cfg, device='cpu', batch_size=B, seed=3).build()
+  assert 'C1_C2_cross' not in est.features.schema.int_single
+  col = est.features.schema.hash_single['C1_C2_cross']['col']
+  got = batches[0]['hash_ids'][col]
+  for r in range(B):
+    joined = (rows[r].split('\t')[14] + 'X' + rows[r].split('\t')[15]).encode()
+    want = hashing.hash_bucket_fast(np.frombuffer(joined, dtype=np.uint8), np.array([0, len(joined)]), 1, [1000], True)
+    assert got[r] == want[0], (r, joined)  # (both inputs empty is still the string 'X': never dropped)
+  orc = OracleTrainer(cfg, est.state_dict(), batch_size=B)
+  for b in batches:
+    est.train_step(b)
+    res, exp = est.loss_values(), orc.train_step(b)
+    for k in exp:
+      assert abs(res[k] - exp[k]) <= 2e-5 * max(1.0, abs(exp[k])), (k, res[k], exp[k])
+  st = est.state_dict()
+  for k, v in orc.state.items():
+    if 'C1_C2_cross' in k:
+      assert np.allclose(st[k], v, rtol=1e-4, atol=1e-6), k
+
+
+@pytest.mark.parametrize('loss_type', ['L2_LOSS', 'SIGMOID_L2_LOSS'])
+def test_regression_heads_match_model_oracle(ref_backend, loss_type):
+  """loss_type L2_LOSS / SIGMOID_L2_LOSS (reference model/rank_model.py:123-128: y = the output column, through a sigmoid
+  for the latter; builders/loss_builder.py:52-55 mean_squared_error; the shape of
+  samples/model_config/deepfm_combo_on_avazu_reg.config): losses, predictions' key and the updated variables of two
+  steps against the model oracle."""
+  from easyrec_amd.input.synthetic import SyntheticBatches
+  from easyrec_amd.model.easy_rec_estimator import EasyRecEstimator
+  from easyrec_amd.protos.loss_pb2 import LossType
+  from oracle.model_oracle import OracleTrainer
+  cfg = config_util.get_configs_from_pipeline_file('configs/deepfm_criteo_small.config')
+  cfg.model_config.loss_type = LossType.Value(loss_type)
+  B = 24
+  est = EasyRecEstimator(cfg, device='cpu', batch_size=B, seed=3).build()
+  orc = OracleTrainer(cfg, est.state_dict(), batch_size=B)
+  gen = SyntheticBatches(cfg.data_config, est.feature_configs, batch_size=B, seed=11)
+  for _ in range(2):
+    b = gen.next_batch()
+    est.train_step(b)
+    got, exp = est.loss_values(), orc.train_step(b)
+    assert sorted(got) == sorted(exp) and 'l2_loss' in exp
+    for k in exp:
+      assert abs(got[k] - exp[k]) <= 2e-5 * max(1.0, abs(exp[k])), (k, got[k], exp[k])
+  st = est.state_dict()
+  for k, v in orc.state.items():
+    if not k.endswith(('kernel', 'embedding_weights', 'gamma', 'beta')):
+      continue  # (a bias under BatchNorm has d(loss)/d(bias) == 0: Adam normalises pure rounding noise, and the moving
+      # mean follows that bias)
+    d = float(np.max(np.abs(st[k] - v)))
+    assert d <= 1e-4, (k, d)  # (a tenth of one Adam step: Adam's normalisation amplifies the rounding of small gradients)
+
+
 def test_lookup_feature_through_the_input_and_the_model(ref_backend, tmp_path):
   """LookupFeature (reference input/input.py:941-1000): the values of the row's map whose key equals the row's key,
   hashed, combined ('mean' here) - ids against a direct restatement, two training steps against the model oracle."""
@@ -371,3 +445,14 @@ def test_bench_helpers_describe_every_baseline_config(ref_backend):
   ring = bench.RingSource(['a', 'b', 'c'])
   assert [ring.next_packed() for _ in range(4)] == ['b', 'c', 'a', 'b']
   assert 'examples/sec' in bench.baseline_metric()
+
+
+def test_fm_over_fields_of_unequal_widths_is_rejected(ref_backend):
+  """layers/fm.py:20 stacks the fields (tf.stack): fields of different embedding_dim fail when the reference builds the
+  graph (the shape of examples/configs/fm_on_criteo.config: embedding_dim 10 beside 16).  The product raises too instead
+  of reading the concatenation as F fields of the first width."""
+  import torch
+
+  from easyrec_amd.layers.fm import FM
+  with pytest.raises(ValueError, match='same embedding_dim'):
+    FM('fm')([torch.zeros(4, 10), torch.zeros(4, 16), torch.zeros(4, 10)])

@@ -51,6 +51,8 @@ def main():
       (agree if worst <= 1e-4 else differ).append((name, worst))
     except BaseException as e:  # noqa
       no_oracle['%s: %s' % (type(e).__name__, str(e).split('\n')[0][:90])] += 1
+      if '-v' in sys.argv:
+        print('  (oracle) %s: %s: %s' % (name, type(e).__name__, str(e).split('\n')[0][:120]))
   print('%d configs; %d do not build in the product; of the %d that do: %d agree with the oracle over 2 steps (1e-4), '
         '%d differ, %d the oracle does not restate' % (len(files), no_product, len(files) - no_product, len(agree), len(differ),
                                                        sum(no_oracle.values())))
