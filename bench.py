@@ -68,7 +68,9 @@ def workload_name(cfg, args):
 def workload_text(cfg, args, est, criteo, B, graph_note, n_ring):
   base = os.path.basename(args.config)
   opt = est.opt_emb.name + (' (dense sweep)' if getattr(est, 'dense_sweep', False) and est.opt_emb.name == 'adam_optimizer'
-                            else ' (lazy dense decay, bit-identical)' if est.opt_emb.name == 'adam_optimizer' else '')
+                            else ' (lazy dense decay, closed-form replay)' if getattr(est, 'decay_tables', None) is not None
+                            else ' (lazy dense decay, exact step-by-step replay + rolling flush)'
+                            if est.opt_emb.name == 'adam_optimizer' else '')
   if criteo:
     head = '%s synthetic Criteo: %s (39 features: 26 hashed x %d rows + 13 projected, D=16%s, ' % (
         workload_name(cfg, args), base, cfg.feature_config.features[13].hash_bucket_size,

@@ -9,6 +9,7 @@
 #include <mutex>
 
 #include "er_common.h"
+#include "er_decay.h"
 
 namespace er {
 
@@ -753,7 +754,8 @@ l2_partials_kernel(const float* __restrict__ w, const float* __restrict__ coef, 
 // variables - so that the step's prologue is one launch instead of this one plus a fill)
 __global__ void hyper_select_kernel(const float* __restrict__ table, int64_t* __restrict__ counter, int n_slots,
                                     int floats_per_slot, float* __restrict__ out, float* __restrict__ hist,
-                                    int64_t hist_capacity, int hist_index, float* __restrict__ zero, int64_t zero_n) {
+                                    int64_t hist_capacity, int hist_index, float* __restrict__ zero, int64_t zero_n,
+                                    DecayTabDev tabs) {
   if (zero) {
     const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < zero_n; i += stride) zero[i] = 0.f;
@@ -774,6 +776,15 @@ __global__ void hyper_select_kernel(const float* __restrict__ table, int64_t* __
       hist[hist_capacity + c] = val > before ? val : before;
     }
     *counter = c + 1;
+  }
+  // closed-form replay tables (er_decay.h): the sums of the row-idle interval that starts after step t0 = c - K are
+  // complete now that lr_t(c) exists: C[t0 + 1][:] = T(t0, K)
+  if (tabs.coef != nullptr && hist && c < hist_capacity && c - tabs.K + 1 >= 0) {
+    __syncthreads();  // hist[c] written by thread 0
+    if (threadIdx.x < 64) {
+      const float mine = decay_sum_wave(tabs, hist, c - tabs.K, tabs.K);
+      if (threadIdx.x < kDecayLd) tabs.C[(c - tabs.K + 1) * kDecayLd + threadIdx.x] = mine;
+    }
   }
 }
 
@@ -1111,7 +1122,19 @@ int er_hyper_select(const float* table, int64_t* counter, int32_t n_slots, int32
 int er_step_prologue(const float* table, int64_t* counter, int32_t n_slots, int32_t floats_per_slot, float* out,
                      float* history, int64_t history_capacity, int32_t history_index, float* zero, int64_t zero_floats,
                      er_stream_t stream) {
+  return er_step_prologue_decay(table, counter, n_slots, floats_per_slot, out, history, history_capacity, history_index,
+                                zero, zero_floats, nullptr, stream);
+}
+
+int er_step_prologue_decay(const float* table, int64_t* counter, int32_t n_slots, int32_t floats_per_slot, float* out,
+                           float* history, int64_t history_capacity, int32_t history_index, float* zero,
+                           int64_t zero_floats, er_decay_tables* decay_tables, er_stream_t stream) {
   ER_REQUIRE(table && counter && out && n_slots > 0 && floats_per_slot > 0, "er_step_prologue: bad arguments");
+  ER_REQUIRE(!decay_tables || (decay_tables->hist == history && decay_tables->counter == counter &&
+                               decay_tables->dev.capacity == history_capacity),
+             "er_step_prologue: the decay tables were created for another history / counter");
+  er::DecayTabDev tabs{};
+  if (decay_tables) tabs = decay_tables->dev;
   ER_REQUIRE(!history || (history_index >= 0 && history_index < floats_per_slot && history_capacity > 0),
              "er_step_prologue: bad history arguments");
   ER_REQUIRE(zero_floats >= 0 && (zero || zero_floats == 0), "er_step_prologue: bad zero arguments");
@@ -1119,7 +1142,7 @@ int er_step_prologue(const float* table, int64_t* counter, int32_t n_slots, int3
   if (blocks > 512) blocks = 512;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(er::hyper_select_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, er::as_stream(stream), table,
-                     counter, n_slots, floats_per_slot, out, history, history_capacity, history_index, zero, zero_floats);
+                     counter, n_slots, floats_per_slot, out, history, history_capacity, history_index, zero, zero_floats, tabs);
   ER_LAUNCH_CHECK();
   return 0;
 }

@@ -18,12 +18,14 @@
 //     (adam_decay_sweep_kernel): pure HBM streaming, float4, grid-stride, bitmap-skipped.
 //   * everything here is HBM/latency-bound integer+fp32 work; no MFMA on purpose.
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <vector>
 
 #include <rocprim/rocprim.hpp>
 
 #include "er_common.h"
+#include "er_decay.h"
 
 namespace er {
 
@@ -402,6 +404,44 @@ struct LrHist {
   }
 };
 
+// What a replay needs besides the lr_t history.  A == nullptr: the exact step-by-step replay (lr_max: prefix maxima of
+// the history, enables its absorbed regime); A != nullptr: the closed form of er_decay.h.
+struct DecayAux {
+  const float* lr_max = nullptr;
+  const float* A = nullptr;  // [K][kDecayLd] for the s_end of THIS launch
+  const float* C = nullptr;  // [capacity + 1][kDecayLd]
+  double ln_b1 = 0.0, ln_b2 = 0.0;
+  int K = 0;
+};
+
+// steps s_begin .. s_end-1 were decay-only for this row (s_begin < s_end): closed form, er_decay.h
+template <int V>
+__device__ __forceinline__ void replay_closed(float* var, float* m, float* v, const DecayAux& x, int32_t s_begin,
+                                              int32_t s_end, float eps) {
+  const int32_t k = s_end - s_begin;
+  const float* __restrict__ T = k <= x.K ? x.A + static_cast<int64_t>(k - 1) * kDecayLd
+                                         : x.C + static_cast<int64_t>(s_begin) * kDecayLd;  // (t0 + 1 = s_begin)
+  const float4 ta = *reinterpret_cast<const float4*>(T);
+  const float2 tb = *reinterpret_cast<const float2*>(T + 4);
+  const float p1 = static_cast<float>(exp(x.ln_b1 * static_cast<double>(k)));
+  const float p2 = static_cast<float>(exp(x.ln_b2 * static_cast<double>(k)));
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    const float a = sqrtf(v[i]);
+    const float d = a + eps;
+    const float z = a / d;
+    float poly = tb.y;
+    poly = poly * z + tb.x;
+    poly = poly * z + ta.w;
+    poly = poly * z + ta.z;
+    poly = poly * z + ta.y;
+    poly = poly * z + ta.x;
+    var[i] = var[i] - (m[i] * poly) / d;
+    m[i] = m[i] * p1;
+    v[i] = v[i] * p2;
+  }
+}
+
 // k more decay-only steps of a row whose m no longer moves and whose update var absorbs: v *= b2, k times.
 template <int V>
 __device__ __forceinline__ void decay_v_only(float* v, int32_t k, float b2) {
@@ -496,8 +536,27 @@ constexpr int kReplaySmemWords = 2 * kBlock * kReplayEntry + 4 + kLrStage;
 
 template <int V>
 __device__ __forceinline__ void replay_block(bool has, int64_t off, int32_t s_begin, int32_t s_end, const RowUpdate& tab,
-                                             const float* __restrict__ lr_hist, const float* __restrict__ lr_max,
+                                             const float* __restrict__ lr_hist, const DecayAux& aux,
                                              const er_opt_hyper* __restrict__ hyper, uint32_t* __restrict__ smem) {
+  if (aux.A != nullptr) {  // closed form: a fixed cost per element whatever the backlog - nothing to balance
+    __syncthreads();       // (every lane has read last_step: the lanes of a row may sit in two wavefronts)
+    if (has && s_begin < s_end) {
+      float var[V], m[V], v[V];
+      ld_vec<V>(m, tab.m + off);
+      ld_vec<V>(v, tab.v + off);
+      bool live = false;
+#pragma unroll
+      for (int j = 0; j < V; ++j) live = live || (m[j] != 0.f) || (v[j] != 0.f);
+      if (live) {
+        ld_vec<V>(var, tab.var + off);
+        replay_closed<V>(var, m, v, aux, s_begin, s_end, pin_scalar(hyper->eps));
+        st_vec<V>(tab.var + off, var);
+        st_vec<V>(tab.m + off, m);
+        st_vec<V>(tab.v + off, v);
+      }
+    }
+    return;
+  }
   int* cnt = reinterpret_cast<int*>(smem);  // [2]
   uint32_t* queue = smem + 4;               // [2][kBlock][kReplayEntry]
   float* lr_staged = reinterpret_cast<float*>(smem + 4 + 2 * kBlock * kReplayEntry);  // [kLrStage]
@@ -510,7 +569,7 @@ __device__ __forceinline__ void replay_block(bool has, int64_t off, int32_t s_be
   __syncthreads();
   const LrHist lr{lr_hist, lr_staged, stage_base};
   const DecayConsts k = pin_decay_consts(*hyper);
-  const float lr_cap2 = lr_cap_twice(lr_max, s_end);
+  const float lr_cap2 = lr_cap_twice(aux.lr_max, s_end);
   float var[V], m[V], v[V];
   bool task = false;
   int32_t s = s_begin;
@@ -570,7 +629,7 @@ template <int V>
 __device__ __forceinline__ void catch_up_body(int bid, const uint32_t* __restrict__ ukeys,
                                               const int32_t* __restrict__ n_unique, int64_t capacity, const RowUpdate& tab,
                                               const float* __restrict__ lr_hist, const er_opt_hyper* __restrict__ hyper,
-                                              int dim, int G, const float* __restrict__ lr_max, uint32_t* __restrict__ smem) {
+                                              int dim, int G, const DecayAux& aux, uint32_t* __restrict__ smem) {
   const int64_t i = (static_cast<int64_t>(bid) * kBlock + threadIdx.x) / G;
   const int c = (static_cast<int>(threadIdx.x) % G) * V;
   const int32_t t = static_cast<int32_t>(*tab.step_counter - 1);
@@ -582,7 +641,7 @@ __device__ __forceinline__ void catch_up_body(int bid, const uint32_t* __restric
     s_begin = tab.last_step[key] + 1;  // (touched at step t-1, or never updated yet and current: nothing pending)
     off = static_cast<int64_t>(key) * dim + c;
   }
-  replay_block<V>(has, off, s_begin, t, tab, lr_hist, lr_max, hyper, smem);  // (synchronises first: every lane has read last_step)
+  replay_block<V>(has, off, s_begin, t, tab, lr_hist, aux, hyper, smem);  // (synchronises first: every lane has read last_step)
   // The row is current up to step t-1 now.  This step's row update will set last_step = t; until then the record must
   // already say t-1, because the rolling flush of the step may run CONCURRENTLY (er_emb_flush_window with lag 1 on a
   // second stream) and has to find nothing pending on the rows the step touches.
@@ -593,9 +652,9 @@ template <int V>
 __global__ void __launch_bounds__(kBlock)
 emb_catch_up_kernel(const uint32_t* __restrict__ ukeys, const int32_t* __restrict__ n_unique, int64_t capacity,
                     RowUpdate tab, const float* __restrict__ lr_hist, const er_opt_hyper* __restrict__ hyper, int dim,
-                    int G, const float* __restrict__ lr_max) {
+                    int G, DecayAux aux) {
   __shared__ uint32_t smem[kReplaySmemWords];
-  catch_up_body<V>(blockIdx.x, ukeys, n_unique, capacity, tab, lr_hist, hyper, dim, G, lr_max, smem);
+  catch_up_body<V>(blockIdx.x, ukeys, n_unique, capacity, tab, lr_hist, hyper, dim, G, aux, smem);
 }
 
 // Horizontal fusion: the same per-group work of up to kMaxMulti table groups in ONE grid - workgroups
@@ -610,7 +669,7 @@ struct CatchUpArgs {
   int64_t capacity;
   RowUpdate tab;
   const float* lr_hist;
-  const float* lr_max;
+  DecayAux aux;
   int dim, G, V;
 };
 struct CatchUpMulti {
@@ -627,15 +686,65 @@ emb_catch_up_multi_kernel(CatchUpMulti ma) {
   __shared__ uint32_t smem[kReplaySmemWords];
   const CatchUpArgs& a = ma.a[i];
   const int bid = blockIdx.x - ma.start[i];
-  if (a.V == 4) catch_up_body<4>(bid, a.ukeys, a.n_unique, a.capacity, a.tab, a.lr_hist, ma.hyper, a.dim, a.G, a.lr_max, smem);
-  else catch_up_body<1>(bid, a.ukeys, a.n_unique, a.capacity, a.tab, a.lr_hist, ma.hyper, a.dim, a.G, a.lr_max, smem);
+  if (a.V == 4) catch_up_body<4>(bid, a.ukeys, a.n_unique, a.capacity, a.tab, a.lr_hist, ma.hyper, a.dim, a.G, a.aux, smem);
+  else catch_up_body<1>(bid, a.ukeys, a.n_unique, a.capacity, a.tab, a.lr_hist, ma.hyper, a.dim, a.G, a.aux, smem);
+}
+
+// The same catch-up in closed form (er_decay.h): no replay queues, no LDS - a lane group loads its row's pending
+// interval, evaluates the closed form and stores; the lanes of a row sit in one wavefront (G <= 64, a power of two), so
+// all of them have read last_step before lane 0 stores it.
+template <int V>
+__device__ __forceinline__ void catch_up_closed_body(int bid, const CatchUpArgs& a, const er_opt_hyper* __restrict__ hyper) {
+  const int64_t i = (static_cast<int64_t>(bid) * kBlock + threadIdx.x) / a.G;
+  const int c = (static_cast<int>(threadIdx.x) % a.G) * V;
+  if (i >= a.capacity || i >= *a.n_unique || c >= a.dim) return;
+  const int32_t t = static_cast<int32_t>(*a.tab.step_counter - 1);
+  const uint32_t key = a.ukeys[i];
+  const int32_t s_begin = a.tab.last_step[key] + 1;
+  if (s_begin >= t) return;
+  const int64_t off = static_cast<int64_t>(key) * a.dim + c;
+  float var[V], m[V], v[V];
+  ld_vec<V>(m, a.tab.m + off);
+  ld_vec<V>(v, a.tab.v + off);
+  bool live = false;
+#pragma unroll
+  for (int j = 0; j < V; ++j) live = live || (m[j] != 0.f) || (v[j] != 0.f);
+  if (live) {
+    ld_vec<V>(var, a.tab.var + off);
+    replay_closed<V>(var, m, v, a.aux, s_begin, t, pin_scalar(hyper->eps));
+    st_vec<V>(a.tab.var + off, var);
+    st_vec<V>(a.tab.m + off, m);
+    st_vec<V>(a.tab.v + off, v);
+  }
+  if (c == 0) a.tab.last_step[key] = t - 1;
+}
+
+__global__ void __launch_bounds__(kBlock)
+emb_catch_up_closed_kernel(CatchUpMulti ma) {
+  int i = 0;
+  while (i + 1 < ma.n && static_cast<int>(blockIdx.x) >= ma.start[i + 1]) ++i;
+  const CatchUpArgs& a = ma.a[i];
+  const int bid = blockIdx.x - ma.start[i];
+  if (a.V == 4) catch_up_closed_body<4>(bid, a, ma.hyper);
+  else catch_up_closed_body<1>(bid, a, ma.hyper);
+}
+
+// A[k-1][:] = T(s_end-1-k, k), k = 1..K, s_end = *counter - lag: one wavefront per k (er_decay.h)
+__global__ void __launch_bounds__(kBlock)
+decay_tables_kernel(DecayTabDev t, const float* __restrict__ hist, const int64_t* __restrict__ counter, int lag) {
+  const int k = static_cast<int>((blockIdx.x * kBlock + threadIdx.x) >> 6) + 1;
+  if (k > t.K) return;
+  const int64_t s_end = *counter - lag;
+  const float mine = decay_sum_wave(t, hist, s_end - 1 - k, k);
+  const int lane = threadIdx.x & 63;
+  if (lane < kDecayLd) t.A[static_cast<int64_t>(k - 1) * kDecayLd + lane] = mine;  // (lanes >= kDecayN hold 0)
 }
 
 // every row: replay the pending decay steps up to and including step (*step_counter - 1); last_step = that
 template <int V>
 __global__ void __launch_bounds__(kBlock)
 emb_flush_decay_kernel(RowUpdate tab, int64_t total_rows, const float* __restrict__ lr_hist,
-                       const er_opt_hyper* __restrict__ hyper, int dim, int G, const float* __restrict__ lr_max) {
+                       const er_opt_hyper* __restrict__ hyper, int dim, int G, DecayAux aux) {
   const int64_t row = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) / G;
   const int sub = static_cast<int>(threadIdx.x) % G;
   const int c = sub * V;
@@ -652,7 +761,8 @@ emb_flush_decay_kernel(RowUpdate tab, int64_t total_rows, const float* __restric
 #pragma unroll
     for (int j = 0; j < V; ++j) live = live || (m[j] != 0.f) || (v[j] != 0.f);
     if (live) {
-      replay_decay<V>(var, m, v, LrHist{lr_hist, nullptr, 0}, last + 1, done, pin_decay_consts(*hyper), lr_cap_twice(lr_max, done));
+      if (aux.A != nullptr) replay_closed<V>(var, m, v, aux, last + 1, done, pin_scalar(hyper->eps));
+      else replay_decay<V>(var, m, v, LrHist{lr_hist, nullptr, 0}, last + 1, done, pin_decay_consts(*hyper), lr_cap_twice(aux.lr_max, done));
       st_vec<V>(tab.var + off, var);
       st_vec<V>(tab.m + off, m);
       st_vec<V>(tab.v + off, v);
@@ -670,7 +780,7 @@ emb_flush_decay_kernel(RowUpdate tab, int64_t total_rows, const float* __restric
 template <int V>
 __device__ __forceinline__ void flush_window_body(int bid, const RowUpdate& tab, int64_t total_rows, int64_t chunk,
                                                   int n_windows, int lag, const float* __restrict__ lr_hist,
-                                                  const float* __restrict__ lr_max,
+                                                  const DecayAux& aux,
                                                   const er_opt_hyper* __restrict__ hyper, int dim, int G,
                                                   uint32_t* __restrict__ smem) {
   // lag 0: called after the step's row updates, rows brought to the step just executed.  lag 1: called DURING step t
@@ -685,7 +795,7 @@ __device__ __forceinline__ void flush_window_body(int bid, const RowUpdate& tab,
   const bool in_window = row < end;
   const bool has = in_window && c < dim;
   const int32_t s_begin = in_window ? tab.last_step[row] + 1 : done;
-  replay_block<V>(has, row * dim + c, s_begin, done, tab, lr_hist, lr_max, hyper, smem);  // (synchronises first)
+  replay_block<V>(has, row * dim + c, s_begin, done, tab, lr_hist, aux, hyper, smem);  // (synchronises first)
   if (in_window && sub == 0 && s_begin < done) tab.last_step[row] = done - 1;
 }
 
@@ -693,7 +803,7 @@ struct FlushWindowArgs {
   RowUpdate tab;
   int64_t total_rows, chunk;
   const float* lr_hist;
-  const float* lr_max;
+  DecayAux aux;
   int dim, G, V;
 };
 struct FlushWindowMulti {
@@ -718,8 +828,8 @@ emb_flush_window_kernel(FlushWindowMulti ma) {
     while (i + 1 < ma.n && b >= ma.start[i + 1]) ++i;
     const FlushWindowArgs& a = ma.a[i];
     const int bid = b - ma.start[i];
-    if (a.V == 4) flush_window_body<4>(bid, a.tab, a.total_rows, a.chunk, ma.n_windows, ma.lag, a.lr_hist, a.lr_max, ma.hyper, a.dim, a.G, smem);
-    else flush_window_body<1>(bid, a.tab, a.total_rows, a.chunk, ma.n_windows, ma.lag, a.lr_hist, a.lr_max, ma.hyper, a.dim, a.G, smem);
+    if (a.V == 4) flush_window_body<4>(bid, a.tab, a.total_rows, a.chunk, ma.n_windows, ma.lag, a.lr_hist, a.aux, ma.hyper, a.dim, a.G, smem);
+    else flush_window_body<1>(bid, a.tab, a.total_rows, a.chunk, ma.n_windows, ma.lag, a.lr_hist, a.aux, ma.hyper, a.dim, a.G, smem);
     __syncthreads();  // (the next tile resets the queues' counters)
   }
 }
@@ -1534,7 +1644,7 @@ struct ServeArgs {
   int64_t n;
   RowUpdate tab;         // last_step == nullptr: no catch-up
   const float* lr_hist;
-  const float* lr_max;
+  DecayAux aux;
   float* out;            // [n, ld] reply rows in entry order (ld >= dim: several groups' rows side by side)
   int dim, G, V, ld;
 };
@@ -1566,7 +1676,8 @@ __device__ __forceinline__ void serve_body(int bid, const ServeArgs& a, const er
 #pragma unroll
       for (int j = 0; j < V; ++j) live = live || (m[j] != 0.f) || (v[j] != 0.f);
       if (live) {
-        replay_decay<V>(var, m, v, LrHist{a.lr_hist, nullptr, 0}, last + 1, t, pin_decay_consts(*hyper), lr_cap_twice(a.lr_max, t));
+        if (a.aux.A != nullptr) replay_closed<V>(var, m, v, a.aux, last + 1, t, pin_scalar(hyper->eps));
+        else replay_decay<V>(var, m, v, LrHist{a.lr_hist, nullptr, 0}, last + 1, t, pin_decay_consts(*hyper), lr_cap_twice(a.aux.lr_max, t));
         st_vec<V>(a.tab.var + off, var);
         st_vec<V>(a.tab.m + off, m);
         st_vec<V>(a.tab.v + off, v);
@@ -1854,7 +1965,8 @@ struct er_emb_group {
   // lazy dense decay (er_emb_group_enable_lazy_decay)
   int32_t* last_step = nullptr;
   const float* lr_hist = nullptr;
-  const float* lr_max = nullptr;  // prefix maximum of lr_hist (er_emb_group_set_lr_max): enables the absorbed regime
+  er::DecayAux aux;               // lr_max: prefix maximum of lr_hist (er_emb_group_set_lr_max); A / C: closed form
+  er_decay_tables* tabs = nullptr;  // er_emb_group_set_decay_tables
   const int64_t* step_counter = nullptr;
   int32_t world = 1;
   int64_t shard_stride = 0;
@@ -2425,20 +2537,38 @@ int er_emb_group_enable_lazy_decay(er_emb_group* g, int32_t* last_step, const fl
   return 0;
 }
 
+// A[k] for the consumer launch that follows on `s` (rows brought to step *counter - lag); one launch per distinct table set
+static int launch_decay_tables(er_emb_group* const* groups, int n, int lag, hipStream_t s) {
+  const er_decay_tables* done[er::kMaxMulti];
+  int n_done = 0;
+  for (int i = 0; i < n; ++i) {
+    const er_decay_tables* t = groups[i] ? groups[i]->tabs : nullptr;
+    bool seen = t == nullptr;
+    for (int j = 0; j < n_done; ++j) seen = seen || done[j] == t;
+    if (seen) continue;
+    if (n_done < er::kMaxMulti) done[n_done++] = t;
+    const int blocks = static_cast<int>(er::ceil_div(static_cast<int64_t>(t->dev.K) * er::kWave, er::kBlock));
+    hipLaunchKernelGGL(er::decay_tables_kernel, dim3(blocks), dim3(er::kBlock), 0, s, t->dev, t->hist, t->counter, lag);
+    ER_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
 int er_emb_catch_up(er_emb_group* g, const uint32_t* unique_keys, const int32_t* n_unique, const er_opt_hyper* hyper,
                     er_stream_t stream) {
   ER_REQUIRE(g && unique_keys && n_unique && hyper, "er_emb_catch_up: null argument");
   ER_REQUIRE(g->last_step, "er_emb_catch_up: call er_emb_group_enable_lazy_decay first");
+  if (g->tabs) return er_emb_catch_up_multi(&g, &unique_keys, &n_unique, 1, hyper, stream);
   const int64_t cap = group_entries(g);
   if (cap == 0) return 0;
   er::RowUpdate tab{g->var, g->m, g->v, g->bitmap, g->last_step, g->step_counter};
   const int blocks = static_cast<int>(er::ceil_div(cap * g->G, er::kBlock));
   if (g->V == 4) {
     hipLaunchKernelGGL(er::emb_catch_up_kernel<4>, dim3(blocks), dim3(er::kBlock), 0, er::as_stream(stream), unique_keys,
-                       n_unique, cap, tab, g->lr_hist, hyper, g->dim, g->G, g->lr_max);
+                       n_unique, cap, tab, g->lr_hist, hyper, g->dim, g->G, g->aux);
   } else {
     hipLaunchKernelGGL(er::emb_catch_up_kernel<1>, dim3(blocks), dim3(er::kBlock), 0, er::as_stream(stream), unique_keys,
-                       n_unique, cap, tab, g->lr_hist, hyper, g->dim, g->G, g->lr_max);
+                       n_unique, cap, tab, g->lr_hist, hyper, g->dim, g->G, g->aux);
   }
   ER_LAUNCH_CHECK();
   return 0;
@@ -2448,8 +2578,9 @@ int er_emb_catch_up_multi(er_emb_group* const* groups, const uint32_t* const* un
                           const int32_t* const* n_unique, int n, const er_opt_hyper* hyper, er_stream_t stream) {
   ER_REQUIRE(groups && unique_keys && n_unique && hyper && n >= 1 && n <= er::kMaxMulti,
              "er_emb_catch_up_multi: bad arguments (1 <= n <= %d)", er::kMaxMulti);
-  if (n == 1) return er_emb_catch_up(groups[0], unique_keys[0], n_unique[0], hyper, stream);
+  if (n == 1 && !(groups[0] && groups[0]->tabs)) return er_emb_catch_up(groups[0], unique_keys[0], n_unique[0], hyper, stream);
   er::CatchUpMulti ma;
+  bool closed = true;  // every group evaluates the closed form and keeps a row's lanes in one wavefront
   ma.n = 0;
   ma.start[0] = 0;
   ma.hyper = hyper;
@@ -2459,15 +2590,18 @@ int er_emb_catch_up_multi(er_emb_group* const* groups, const uint32_t* const* un
     ER_REQUIRE(g->last_step, "er_emb_catch_up_multi: call er_emb_group_enable_lazy_decay first (group %d)", i);
     const int64_t cap = group_entries(g);
     if (cap == 0) continue;
+    closed = closed && g->tabs != nullptr && g->G <= er::kWave;
     er::CatchUpArgs& a = ma.a[ma.n];
     a.ukeys = unique_keys[i]; a.n_unique = n_unique[i]; a.capacity = cap;
     a.tab = er::RowUpdate{g->var, g->m, g->v, g->bitmap, g->last_step, g->step_counter};
-    a.lr_hist = g->lr_hist; a.lr_max = g->lr_max; a.dim = g->dim; a.G = g->G; a.V = g->V;
+    a.lr_hist = g->lr_hist; a.aux = g->aux; a.dim = g->dim; a.G = g->G; a.V = g->V;
     ma.start[ma.n + 1] = ma.start[ma.n] + static_cast<int>(er::ceil_div(cap * g->G, er::kBlock));
     ++ma.n;
   }
   if (ma.n == 0) return 0;
-  hipLaunchKernelGGL(er::emb_catch_up_multi_kernel, dim3(ma.start[ma.n]), dim3(er::kBlock), 0, er::as_stream(stream), ma);
+  if (int rc = launch_decay_tables(groups, n, 1, er::as_stream(stream))) return rc;
+  if (closed) hipLaunchKernelGGL(er::emb_catch_up_closed_kernel, dim3(ma.start[ma.n]), dim3(er::kBlock), 0, er::as_stream(stream), ma);
+  else hipLaunchKernelGGL(er::emb_catch_up_multi_kernel, dim3(ma.start[ma.n]), dim3(er::kBlock), 0, er::as_stream(stream), ma);
   ER_LAUNCH_CHECK();
   return 0;
 }
@@ -2479,12 +2613,13 @@ int er_emb_flush_decay(er_emb_group* g, const er_opt_hyper* hyper, er_stream_t s
   er::RowUpdate tab{g->var, g->m, g->v, g->bitmap, g->last_step, g->step_counter};
   const int64_t blocks = er::ceil_div(g->total_rows * g->G, er::kBlock);
   ER_REQUIRE(blocks < 0x7FFFFFFFLL, "er_emb_flush_decay: table group too large for one launch");
+  if (int rc = launch_decay_tables(&g, 1, 0, s)) return rc;
   if (g->V == 4) {
     hipLaunchKernelGGL(er::emb_flush_decay_kernel<4>, dim3(static_cast<unsigned>(blocks)), dim3(er::kBlock), 0, s, tab,
-                       g->total_rows, g->lr_hist, hyper, g->dim, g->G, g->lr_max);
+                       g->total_rows, g->lr_hist, hyper, g->dim, g->G, g->aux);
   } else {
     hipLaunchKernelGGL(er::emb_flush_decay_kernel<1>, dim3(static_cast<unsigned>(blocks)), dim3(er::kBlock), 0, s, tab,
-                       g->total_rows, g->lr_hist, hyper, g->dim, g->G, g->lr_max);
+                       g->total_rows, g->lr_hist, hyper, g->dim, g->G, g->aux);
   }
   ER_LAUNCH_CHECK();
   hipLaunchKernelGGL(er::emb_flush_mark_kernel, dim3(1024), dim3(er::kBlock), 0, s, g->last_step, g->total_rows,
@@ -2495,7 +2630,94 @@ int er_emb_flush_decay(er_emb_group* g, const er_opt_hyper* hyper, er_stream_t s
 
 int er_emb_group_set_lr_max(er_emb_group* g, const float* lr_max_history) {
   ER_REQUIRE(g, "er_emb_group_set_lr_max: null group");
-  g->lr_max = lr_max_history;
+  g->aux.lr_max = lr_max_history;
+  return 0;
+}
+
+// ---- closed-form replay tables (er_decay.h) ----
+static int decay_terms(double beta1) {  // smallest multiple of 64 with beta1^K <= 2e-9
+  if (!(beta1 > 0.0 && beta1 < 1.0)) return 0;
+  const double k = std::ceil(std::log(2e-9) / std::log(beta1));
+  const int K = static_cast<int>((static_cast<int64_t>(k) + 63) / 64 * 64);
+  return K < 64 ? 64 : K;
+}
+
+int er_decay_tables_supported(float beta1, float beta2) {
+  const int K = decay_terms(static_cast<double>(beta1));
+  if (K <= 0 || K > er::kDecayKMax || !(beta2 > 0.f && beta2 < 1.f)) return 0;
+  // remainder of the w-expansion relative to the whole update: sum_s beta1^s w_s^N / sum_s beta1^s, w_s = 1 - sqrt(beta2)^s
+  const double q = std::sqrt(static_cast<double>(beta2)), b1 = static_cast<double>(beta1);
+  double num = 0.0, den = 0.0;
+  for (int s = 1; s <= K; ++s) {
+    const double w = -std::expm1(s * std::log(q)), p = std::pow(b1, s);
+    num += p * std::pow(w, er::kDecayN) / (1.0 - w);
+    den += p;
+  }
+  return num / den <= 3e-8 ? K : 0;
+}
+
+int64_t er_decay_tables_bytes(int64_t history_capacity) {
+  if (history_capacity <= 0) return -1;
+  return static_cast<int64_t>(er::kDecayKMax) * er::kDecayLd * (sizeof(double) + sizeof(float)) +
+         (history_capacity + 1) * er::kDecayLd * static_cast<int64_t>(sizeof(float));
+}
+
+int er_decay_tables_create(void* buffer, int64_t history_capacity, const float* lr_t_history, const int64_t* step_counter,
+                           float beta1, float beta2, er_decay_tables** out) {
+  ER_REQUIRE(buffer && lr_t_history && step_counter && out && history_capacity > 0, "er_decay_tables_create: bad arguments");
+  ER_REQUIRE((reinterpret_cast<uintptr_t>(buffer) & 15) == 0, "er_decay_tables_create: buffer must be 16-byte aligned");
+  const int K = er_decay_tables_supported(beta1, beta2);
+  ER_REQUIRE(K > 0, "er_decay_tables_create: beta1 %g / beta2 %g are outside the closed form's range (use the exact replay)",
+             static_cast<double>(beta1), static_cast<double>(beta2));
+  std::vector<double> coef(static_cast<size_t>(er::kDecayKMax) * er::kDecayLd, 0.0);
+  const double b1 = static_cast<double>(beta1), lq = 0.5 * std::log(static_cast<double>(beta2));
+  for (int s = 1; s <= K; ++s) {
+    const double p = std::exp(s * std::log(b1)), w = -std::expm1(s * lq);
+    double wn = 1.0;
+    for (int n = 0; n < er::kDecayN; ++n, wn *= w) coef[static_cast<size_t>(s - 1) * er::kDecayLd + n] = p * wn;
+  }
+  er_decay_tables* t = new er_decay_tables();
+  char* base = static_cast<char*>(buffer);
+  t->dev.coef = reinterpret_cast<const double*>(base);
+  base += static_cast<size_t>(er::kDecayKMax) * er::kDecayLd * sizeof(double);
+  t->dev.A = reinterpret_cast<float*>(base);
+  base += static_cast<size_t>(er::kDecayKMax) * er::kDecayLd * sizeof(float);
+  t->dev.C = reinterpret_cast<float*>(base);
+  t->dev.K = K;
+  t->dev.capacity = history_capacity;
+  t->hist = lr_t_history;
+  t->counter = step_counter;
+  t->beta1 = beta1;
+  t->beta2 = beta2;
+  t->ln_b1 = std::log(b1);
+  t->ln_b2 = std::log(static_cast<double>(beta2));
+  hipError_t e = hipMemcpy(buffer, coef.data(), coef.size() * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess)
+    e = hipMemset(t->dev.A, 0, (static_cast<size_t>(er::kDecayKMax) + static_cast<size_t>(history_capacity) + 1) * er::kDecayLd * sizeof(float));
+  if (e != hipSuccess) {
+    delete t;
+    er::set_error("er_decay_tables_create: %s", hipGetErrorString(e));
+    return 1;
+  }
+  *out = t;
+  return 0;
+}
+
+int er_decay_tables_destroy(er_decay_tables* t) {
+  delete t;
+  return 0;
+}
+
+int er_emb_group_set_decay_tables(er_emb_group* g, er_decay_tables* t) {
+  ER_REQUIRE(g, "er_emb_group_set_decay_tables: null group");
+  ER_REQUIRE(!t || (g->last_step && g->lr_hist == t->hist && g->step_counter == t->counter),
+             "er_emb_group_set_decay_tables: call er_emb_group_enable_lazy_decay with the tables' history and counter first");
+  g->tabs = t;
+  g->aux.A = t ? t->dev.A : nullptr;
+  g->aux.C = t ? t->dev.C : nullptr;
+  g->aux.K = t ? t->dev.K : 0;
+  g->aux.ln_b1 = t ? t->ln_b1 : 0.0;
+  g->aux.ln_b2 = t ? t->ln_b2 : 0.0;
   return 0;
 }
 
@@ -2517,11 +2739,12 @@ int er_emb_flush_window(er_emb_group* const* groups, int n, int32_t n_windows, i
     a.tab = er::RowUpdate{g->var, g->m, g->v, g->bitmap, g->last_step, g->step_counter};
     a.total_rows = g->total_rows;
     a.chunk = er::ceil_div(g->total_rows, n_windows);
-    a.lr_hist = g->lr_hist; a.lr_max = g->lr_max; a.dim = g->dim; a.G = g->G; a.V = g->V;
+    a.lr_hist = g->lr_hist; a.aux = g->aux; a.dim = g->dim; a.G = g->G; a.V = g->V;
     ma.start[ma.n + 1] = ma.start[ma.n] + static_cast<int>(er::ceil_div(a.chunk * g->G, er::kBlock));
     ++ma.n;
   }
   if (ma.start[ma.n] == 0) return 0;
+  if (int rc = launch_decay_tables(groups, n, lag, er::as_stream(stream))) return rc;
   const int grid = max_blocks > 0 && max_blocks < ma.start[ma.n] ? max_blocks : ma.start[ma.n];
   hipLaunchKernelGGL(er::emb_flush_window_kernel, dim3(grid), dim3(er::kBlock), 0, er::as_stream(stream), ma);
   ER_LAUNCH_CHECK();
@@ -2884,7 +3107,7 @@ int er_emb_owner_serve(er_emb_group* const* groups, float* const* rows_out, cons
     // may be replayed, because no row update follows that would advance last_step)
     a.tab = er::RowUpdate{g->var, g->m, g->v, g->bitmap, hyper ? g->last_step : nullptr, g->step_counter};
     ER_REQUIRE(a.tab.last_step == nullptr || g->G <= er::kWave, "er_emb_owner_serve: a lazily decayed row must fit one wavefront");
-    a.lr_hist = g->lr_hist; a.lr_max = g->lr_max; a.out = rows_out[i]; a.dim = g->dim; a.G = g->G; a.V = g->V;
+    a.lr_hist = g->lr_hist; a.aux = g->aux; a.out = rows_out[i]; a.dim = g->dim; a.G = g->G; a.V = g->V;
     a.ld = ld && ld[i] ? ld[i] : g->dim;
     ER_REQUIRE(a.ld >= g->dim && (g->V == 1 || (a.ld % 4 == 0 && (reinterpret_cast<uintptr_t>(rows_out[i]) & 15) == 0)),
                "er_emb_owner_serve: group %d: ld %d < dim, or 16-byte lanes on rows that are not 16-byte aligned", i, a.ld);
@@ -2892,6 +3115,9 @@ int er_emb_owner_serve(er_emb_group* const* groups, float* const* rows_out, cons
     ++ma.n;
   }
   if (ma.n == 0) return 0;
+  if (hyper) {  // (serve_body brings the rows to step *counter - 1)
+    if (int rc = launch_decay_tables(groups, n, 1, s)) return rc;
+  }
   hipLaunchKernelGGL(er::emb_owner_serve_kernel, dim3(ma.start[ma.n]), dim3(er::kBlock), 0, s, ma);
   ER_LAUNCH_CHECK();
   return 0;

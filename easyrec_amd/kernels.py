@@ -1302,15 +1302,44 @@ class HipBackend(object):
                                       ctypes.c_int64(cap), ctypes.c_int32(history_index), _stream()),
              'er_hyper_select')
 
-  def step_prologue(self, table, counter, out, history=None, zero=None, history_index=HYPER_LR_T):
-    """hyper_select + zeroing of `zero` (the flat gradient buffer) in one launch."""
+  def step_prologue(self, table, counter, out, history=None, zero=None, history_index=HYPER_LR_T, decay_tables=None):
+    """hyper_select + zeroing of `zero` (the flat gradient buffer) in one launch.  decay_tables (decay_tables_create):
+    the same launch appends the step's entry to the closed-form replay's per-step table."""
     n_slots = table.shape[0]
     cap = 0 if history is None else history.numel() // 2
     nz = 0 if zero is None else zero.numel()
     assert zero is None or (zero.dtype == torch.float32 and zero.is_contiguous())
-    self._ck(self.lib.er_step_prologue(_p(table), _p(counter), n_slots, table[0].numel(), _p(out), _p(history),
-                                       ctypes.c_int64(cap), ctypes.c_int32(history_index), _p(zero), ctypes.c_int64(nz),
-                                       _stream()), 'er_step_prologue')
+    self._ck(self.lib.er_step_prologue_decay(_p(table), _p(counter), n_slots, table[0].numel(), _p(out), _p(history),
+                                             ctypes.c_int64(cap), ctypes.c_int32(history_index), _p(zero),
+                                             ctypes.c_int64(nz), decay_tables['handle'] if decay_tables else None,
+                                             _stream()), 'er_step_prologue_decay')
+
+  # -- closed-form replay of TF-Adam's decay-only steps (csrc/er_decay.h)
+  def decay_tables_create(self, lr_hist, step_counter, beta1, beta2):
+    """The tables of the closed-form replay for the history buffer `lr_hist` ([2 * capacity]) - or None when the
+    betas are outside its range (the groups then keep the exact step-by-step replay)."""
+    self.lib.er_decay_tables_bytes.restype = ctypes.c_int64
+    if self.lib.er_decay_tables_supported(ctypes.c_float(beta1), ctypes.c_float(beta2)) <= 0:
+      return None
+    cap = lr_hist.numel() // 2
+    nbytes = int(self.lib.er_decay_tables_bytes(ctypes.c_int64(cap)))
+    buf = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=lr_hist.device)
+    handle = ctypes.c_void_p()
+    self._ck(self.lib.er_decay_tables_create(_p(buf), ctypes.c_int64(cap), _p(lr_hist), _p(step_counter),
+                                             ctypes.c_float(beta1), ctypes.c_float(beta2), ctypes.byref(handle)),
+             'er_decay_tables_create')
+    return {'handle': handle, 'buffer': buf, 'lr_hist': lr_hist, 'step_counter': step_counter,
+            'betas': (float(beta1), float(beta2))}
+
+  def decay_tables_destroy(self, tabs):
+    if tabs is not None and tabs.get('handle') is not None:
+      self.lib.er_decay_tables_destroy(tabs['handle'])
+      tabs['handle'] = None
+
+  def emb_group_set_decay_tables(self, group, tabs):
+    self._ck(self.lib.er_emb_group_set_decay_tables(group['handle'], tabs['handle'] if tabs else None),
+             'er_emb_group_set_decay_tables')
+    group['decay_tables'] = tabs
 
   # -- TF-exact Adam without the sweep (lazy dense decay)
   def emb_group_enable_lazy_decay(self, group, last_step, lr_hist, step_counter):

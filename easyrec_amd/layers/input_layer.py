@@ -199,6 +199,15 @@ class EmbeddingEngine(object):
     self._clock = (step_counter, lr_hist, hyper_emb)
     self.lazy_decay = bool(lazy_decay)
 
+  def set_decay_tables(self, tabs):
+    """The closed-form replay's tables (kernels.decay_tables_create; None = exact step-by-step replay).  With them a
+    catch-up costs the same whatever the backlog, so the rolling flush that bounds the backlog is switched off."""
+    self._decay_tables = tabs
+    if tabs is not None:
+      self.flush_windows = 0
+    for grp, _ in self._lazy_groups():
+      kernels.hip().emb_group_set_decay_tables(grp, tabs)
+
   def _enable_lazy_decay(self, dim, grp, st, n_route):
     """Per table group: the last-updated-step array and the buffers of er_emb_route (unique rows of a step)."""
     be = kernels.hip()
@@ -209,20 +218,27 @@ class EmbeddingEngine(object):
         'n_unique': torch.zeros(1, dtype=torch.int32, device=dev),
     }
     be.emb_group_enable_lazy_decay(grp, lz['last_step'], self._clock[1], self._clock[0])
+    if getattr(self, '_decay_tables', None) is not None:
+      be.emb_group_set_decay_tables(grp, self._decay_tables)
     return lz
 
   def _lazy_groups(self):
     """[(C group handle, its lazy-decay state)] of the table groups whose rows carry pending decay."""
     return [(self.emb_groups[dim], lz) for dim, lz in self._lazy.items()]
 
-  def rebind_lr_history(self, lr_hist):
-    """The estimator re-allocated the per-step lr_t history (it grew): point the table groups at the new buffer."""
+  def rebind_lr_history(self, lr_hist, decay_tables=None):
+    """The estimator re-allocated the per-step lr_t history (it grew): point the table groups at the new buffer (and
+    at the closed-form tables re-created for it)."""
     if self._clock is None:
       return
     self._clock = (self._clock[0], lr_hist, self._clock[2])
+    self._decay_tables = decay_tables
     be = kernels.hip()
     for grp, lz in self._lazy_groups():
+      be.emb_group_set_decay_tables(grp, None)
       be.emb_group_enable_lazy_decay(grp, lz['last_step'], lr_hist, self._clock[0])
+      if decay_tables is not None:
+        be.emb_group_set_decay_tables(grp, decay_tables)
 
   def flush_decay(self):
     """Bring every row current (lazy dense decay): before reading tables out (state_dict, evaluation)."""

@@ -120,6 +120,14 @@ class EasyRecEstimator(object):
     self.lr_hist = torch.zeros(2 * n_hist, dtype=torch.float32, device=dev)
     self.engine.set_step_clock(self.step_counter, self.lr_hist, self.hyper[0],
                                lazy_decay=not self.dense_sweep and not self.overlap_sweep)
+    # the replay of the decay-only steps: closed form (csrc/er_decay.h; default) or the bit-exact step-by-step replay
+    # with its rolling flush (EASYREC_AMD_EXACT_DECAY=1, and whenever the betas are outside the closed form's range)
+    self.decay_tables = None
+    if self.engine.lazy_decay and self.opt_emb.kind == kernels.OPT_ADAM and \
+        os.environ.get('EASYREC_AMD_EXACT_DECAY', '0') != '1':
+      self.decay_tables = kernels.hip().decay_tables_create(self.lr_hist, self.step_counter, self.opt_emb.beta1,
+                                                            self.opt_emb.beta2)
+      self.engine.set_decay_tables(self.decay_tables)
     self.losses = {
         'regularization_loss': torch.zeros(1, dtype=torch.float32, device=dev),
         'total_loss': torch.zeros(1, dtype=torch.float32, device=dev),
@@ -206,8 +214,16 @@ class EasyRecEstimator(object):
     grown = torch.zeros(2 * new_cap, dtype=torch.float32, device=self.device)
     grown[:cap].copy_(self.lr_hist[:cap])
     grown[new_cap:new_cap + cap].copy_(self.lr_hist[cap:])
+    if self.decay_tables is not None:
+      # the per-step table is indexed like the history: every row is brought current first (entries older than a row's
+      # last update are never read), then the tables restart on the grown history
+      self.engine.flush_decay()
+      torch.cuda.synchronize() if self.device.type == 'cuda' else None
+      kernels.hip().decay_tables_destroy(self.decay_tables)
+      self.decay_tables = kernels.hip().decay_tables_create(grown, self.step_counter, self.opt_emb.beta1,
+                                                            self.opt_emb.beta2)
     self.lr_hist = grown
-    self.engine.rebind_lr_history(grown)
+    self.engine.rebind_lr_history(grown, decay_tables=self.decay_tables)
 
   def _refresh_hyper(self):
     """Keep the device table half a ring ahead of `global_step` (sync only once per half ring)."""
@@ -225,7 +241,7 @@ class EasyRecEstimator(object):
     be = kernels.hip()
     # prologue, one launch: this step's optimizer scalars (device-side step counter) + the flat gradient buffer zeroed
     be.step_prologue(self.hyper_table, self.step_counter, self.hyper, history=self.lr_hist,
-                     zero=self.varstore.flat_grad_all)
+                     zero=self.varstore.flat_grad_all, decay_tables=self.decay_tables)
     self.features.transform()
     if self.is_training and self.overlap_sweep and self.opt_emb.kind == kernels.OPT_ADAM:
       self.engine.start_decay_sweep(self.hyper[0])

@@ -81,7 +81,7 @@ class EmbeddingParallelEstimator(EasyRecEstimator):
   # -- the step in phases: static device work (capturable) around the data-dependent exchanges
   def _phase_route(self):
     kernels.hip().step_prologue(self.hyper_table, self.step_counter, self.hyper, history=self.lr_hist,
-                                zero=self.varstore.flat_grad_all)
+                                zero=self.varstore.flat_grad_all, decay_tables=self.decay_tables)
     self.features.transform()
     self.engine.route()
 

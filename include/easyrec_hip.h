@@ -240,6 +240,29 @@ int er_emb_flush_window(er_emb_group* const* groups_host, int n, int32_t n_windo
 int er_emb_catch_up(er_emb_group* group, const uint32_t* unique_keys, const int32_t* n_unique,
                     const er_opt_hyper* hyper, er_stream_t stream);
 int er_emb_flush_decay(er_emb_group* group, const er_opt_hyper* hyper, er_stream_t stream);
+/* CLOSED-FORM replay of the decay-only steps (the default of the training step; the step-by-step replay above stays
+ * as the exact mode).  north_star's bar is 1e-4 on logits / loss, not bit-equality of Adam's slots with a dense sweep: k
+ * idle steps of a row after step t0 are, with a = sqrt(v0), d = a + eps, z = a / d, w_s = 1 - sqrt(beta2)^s,
+ *     var -= (m0 / d) * sum_n z^n T_n(t0, k),   T_n(t0, k) = sum_{s=1..k} lr_t(t0+s) beta1^s w_s^n,
+ *     m = m0 beta1^k,  v = v0 beta2^k
+ * (csrc/er_decay.h): one sqrt, two divisions and a degree-5 polynomial per element whatever k is - closer to an fp64
+ * evaluation of tf.train.AdamOptimizer's recurrence (builders/optimizer_builder.py:61-66, compat/adam_s.py:185-213)
+ * than the fp32 step-by-step replay itself (2e-7 against 1e-6 of the update).  The T_n are table lookups:
+ *   er_decay_tables_supported: K > 0 (terms kept: beta1^K <= 2e-9, K <= 512) if the betas are in range, else 0.
+ *   er_decay_tables_bytes / _create: `buffer` (device, 16-byte aligned, er_decay_tables_bytes(history_capacity) bytes)
+ *     holds the coefficient block, the per-launch table A[k] = T(s_end-1-k, k) (rebuilt by a 64-workgroup launch in
+ *     front of er_emb_catch_up(_multi) / er_emb_flush_decay / er_emb_flush_window / er_emb_owner_serve) and the
+ *     per-step table C[t0] = T(t0, K) that er_step_prologue_decay appends to (rows idle for more than K steps).
+ *   er_emb_group_set_decay_tables: the group's replays use the closed form (NULL: back to the exact replay); the group
+ *     must have been given the tables' history and counter by er_emb_group_enable_lazy_decay.  No rolling flush
+ *     (er_emb_flush_window) is needed: the catch-up costs the same for a row idle 1 step or 100,000. */
+typedef struct er_decay_tables er_decay_tables;
+int er_decay_tables_supported(float beta1, float beta2);
+int64_t er_decay_tables_bytes(int64_t history_capacity);
+int er_decay_tables_create(void* buffer, int64_t history_capacity, const float* lr_t_history,
+                           const int64_t* step_counter, float beta1, float beta2, er_decay_tables** tables);
+int er_decay_tables_destroy(er_decay_tables* tables);
+int er_emb_group_set_decay_tables(er_emb_group* group, er_decay_tables* tables);
 /* TF-exact Adam with the sweep OVERLAPPED (two streams).  The rows a step touches are known as soon as
  * its ids are (before the forward): er_emb_mark_touched sets their bitmap bits; er_emb_sweep_untouched
  * then decays every other row (m*=beta1, v*=beta2, var-=lr_t*m/(sqrt(v)+eps): what
@@ -514,6 +537,10 @@ int er_dense_opt_step_l2(float* w, float* m, float* v, const float* grad, const 
 int er_step_prologue(const float* table, int64_t* counter, int32_t n_slots, int32_t floats_per_slot, float* out,
                      float* history, int64_t history_capacity, int32_t history_index, float* zero, int64_t zero_floats,
                      er_stream_t stream);
+/* the same + the closed-form replay's per-step table (er_decay_tables_create; NULL: plain er_step_prologue) */
+int er_step_prologue_decay(const float* table, int64_t* counter, int32_t n_slots, int32_t floats_per_slot, float* out,
+                           float* history, int64_t history_capacity, int32_t history_index, float* zero,
+                           int64_t zero_floats, er_decay_tables* decay_tables, er_stream_t stream);
 /* out[0] = scale * sum of all n partials (deterministic single-block tree) */
 int er_reduce_sum(const float* partials, int32_t n, float scale, float* out, int accumulate,
                   er_stream_t stream);

@@ -974,7 +974,7 @@ class RefBackend(object):
       total = F32(total + F32(src.reshape(-1)[0].item()))
     total_out[0] = float(total)
 
-  def step_prologue(self, table, counter, out, history=None, zero=None, history_index=HYPER_LR_T):
+  def step_prologue(self, table, counter, out, history=None, zero=None, history_index=HYPER_LR_T, decay_tables=None):
     self.hyper_select(table, counter, out, history=history, history_index=history_index)
     if zero is not None:
       zero.zero_()
@@ -1015,6 +1015,17 @@ class RefBackend(object):
       history[c] = val
       history[cap + c] = max(float(val), float(history[cap + c - 1]) if c > 0 else 0.0)
     counter += 1
+
+  # -- the closed-form replay of the HIP library (csrc/er_decay.h): the stand-in accepts the calls (so that the host
+  # logic around them runs on CPU) and keeps replaying step by step - the recurrence the closed form is held to
+  def decay_tables_create(self, lr_hist, step_counter, beta1, beta2):
+    return {'handle': None, 'lr_hist': lr_hist, 'step_counter': step_counter, 'betas': (float(beta1), float(beta2))}
+
+  def decay_tables_destroy(self, tabs):
+    pass
+
+  def emb_group_set_decay_tables(self, group, tabs):
+    group['decay_tables'] = tabs
 
   # -- TF-exact Adam without the sweep: decay-only steps replayed when a row is next touched
   def emb_group_enable_lazy_decay(self, group, last_step, lr_hist, step_counter):

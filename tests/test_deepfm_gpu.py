@@ -256,14 +256,55 @@ def _assert_lazy_equals_sweep(lazy_state, sweep_state):
   assert n > 100
 
 
+def _assert_closed_tracks_sweep(closed_state, sweep_state, tol=2e-5):
+  """The closed-form replay against the every-row sweep: every variable and slot within `tol` of the tensor's scale
+  (max |value|).  Not bit-equal by construction: the closed form evaluates the exact recurrence to ~2e-7 of an update,
+  fp32 step-by-step arithmetic to ~1e-6; what the bound leaves room for is the training dynamics amplifying that."""
+  n, worst = 0, (0.0, None)
+  for k, ref in sweep_state.items():
+    ref = np.asarray(ref, dtype=np.float64)
+    if ref.dtype.kind != 'f' or ref.size == 0:
+      continue
+    scale = max(float(np.abs(ref).max()), 1e-30)
+    err = float(np.abs(np.asarray(closed_state[k], dtype=np.float64) - ref).max()) / scale
+    worst = max(worst, (err, k))
+    n += 1
+  assert worst[0] <= tol, worst
+  assert n > 100
+  return worst
+
+
+def test_closed_form_decay_tracks_sweep_model_level():
+  """The DEFAULT training step (closed-form replay of the decay-only steps, csrc/er_decay.h; no rolling flush) against
+  dense_sweep=True (every row streamed every step) over 1300 steps with rows idle for > 1200 steps: losses within 1e-5
+  on the way, every variable and Adam slot of every table within 2e-5 of its scale at the end."""
+  cfg = _cfg('deepfm_criteo_small.config')
+  B = 64
+  ests = [EasyRecEstimator(cfg, device=DEV, batch_size=B, seed=9, dense_sweep=ds).build() for ds in (False, True)]
+  assert ests[0].engine.lazy_decay and ests[0].decay_tables is not None and ests[0].engine.flush_windows == 0
+  assert not ests[1].engine.lazy_decay
+  sched = _idle_schedule(cfg, ests[0].feature_configs, B, 1250)
+  for i, b in enumerate(sched):
+    for e in ests:
+      e.train_step(b)
+    if i in (0, 600, len(sched) - 1):
+      la, lb = ests[0].loss_values(), ests[1].loss_values()
+      for k in lb:
+        assert abs(la[k] - lb[k]) <= 1e-5 * max(1e-3, abs(lb[k])), (i, k, la[k], lb[k])
+  worst = _assert_closed_tracks_sweep(ests[0].state_dict(slots=True), ests[1].state_dict(slots=True))
+  print('closed form vs sweep after %d steps: worst relative deviation %.3g (%s)' % (len(sched), worst[0], worst[1]))
+
+
 @pytest.mark.parametrize('flush_blocks', [0, 1])
 def test_lazy_decay_equals_sweep_model_level(monkeypatch, flush_blocks):
   """flush_blocks 0: the default (rolling flush after the row update); 1: the concurrent rolling flush (second stream,
   lag 1) as ONE workgroup walking all the window's tiles.
-  EasyRecEstimator(dense_sweep=False) (the default: TF-exact Adam's every-row decay replayed lazily, the headline
-  path) against dense_sweep=True (every row streamed every step) over 1300 steps with rows idle for > 1200 steps,
+  The EXACT mode (EASYREC_AMD_EXACT_DECAY=1: the step-by-step replay with its rolling flush).
+  EasyRecEstimator(dense_sweep=False) (TF-exact Adam's every-row decay replayed lazily)
+  against dense_sweep=True (every row streamed every step) over 1300 steps with rows idle for > 1200 steps,
   through the whole model (shared sort of the wide / deep groups, er_emb_catch_up_multi, er_emb_flush_decay): after the
   flush var, m and v of every table and every dense variable are BIT-equal, and so are the losses on the way."""
+  monkeypatch.setenv('EASYREC_AMD_EXACT_DECAY', '1')
   if flush_blocks:
     monkeypatch.setenv('EASYREC_AMD_OVERLAP_FLUSH', '1')
     monkeypatch.setenv('EASYREC_AMD_FLUSH_BLOCKS', str(flush_blocks))
@@ -282,10 +323,15 @@ def test_lazy_decay_equals_sweep_model_level(monkeypatch, flush_blocks):
   _assert_lazy_equals_sweep(ests[0].state_dict(slots=True), ests[1].state_dict(slots=True))
 
 
-def test_evaluate_does_not_disturb_training():
+@pytest.mark.parametrize('exact', [True, False])
+def test_evaluate_does_not_disturb_training(monkeypatch, exact):
   """predict() / evaluate() between training steps (no state_dict() in between, so nothing flushes on the side):
   the tables must end up exactly where an uninterrupted twin run leaves them - the lookups of an evaluation must not
-  replay pending Adam decay more than once (they flush once, then read)."""
+  replay pending Adam decay more than once (they flush once, then read).  exact: the step-by-step replay - every bit;
+  else the default closed form, where an evaluation's flush splits a row's idle interval into two closed-form pieces:
+  equal to 1e-6 of each tensor's scale."""
+  if exact:
+    monkeypatch.setenv('EASYREC_AMD_EXACT_DECAY', '1')
   cfg = _cfg('deepfm_criteo_small.config')
   B = 64
   a = EasyRecEstimator(cfg, device=DEV, batch_size=B, seed=5).build()
@@ -301,7 +347,11 @@ def test_evaluate_does_not_disturb_training():
       assert m1 == m2, (m1, m2)
   sa, sb = a.state_dict(slots=True), b.state_dict(slots=True)
   for k in sa:
-    assert np.array_equal(sa[k], sb[k]), k
+    if exact:
+      assert np.array_equal(sa[k], sb[k]), k
+    else:
+      scale = max(float(np.abs(sa[k]).max()), 1e-30) if sa[k].size else 1.0
+      assert float(np.abs(sa[k].astype(np.float64) - sb[k]).max()) <= 1e-6 * scale if sa[k].size else True, k
 
 
 def test_fused_batchnorm_gemms_change_no_bit():

@@ -340,14 +340,21 @@ def test_fixed_capacity_route_and_owner_side_against_numpy(header):
   hip.emb_group_destroy(og)
 
 
-@pytest.mark.parametrize('overlap', ['0', '1'])
+@pytest.mark.parametrize('overlap', ['0', '1', 'closed'])
 def test_lazy_decay_equals_sweep_through_two_sharded_ranks(monkeypatch, overlap):
-  """overlap '1': the owners' rolling flush on a second stream next to the compute phase (lag 1).
+  """overlap '1': the owners' rolling flush on a second stream next to the compute phase (lag 1); 'closed': the default
+  closed-form replay (csrc/er_decay.h) instead of the bit-exact step-by-step one, held to the sweep within 2e-5 of each
+  tensor's scale (it is closer to the exact recurrence than fp32 step-by-step arithmetic, not bit-equal to it).
   The model-level lazy-dense-decay == sweep check of tests/test_deepfm_gpu.py through EmbeddingParallelEstimator,
   W = 2 ranks as threads with their own batches: the owner side's er_emb_owner_serve catches rows up, the owner's
   er_emb_bwd_update_multi stamps them, er_emb_flush_decay finishes - against the same two ranks streaming every row."""
   from test_deepfm_gpu import _assert_lazy_equals_sweep, _idle_schedule
-  monkeypatch.setenv('EASYREC_AMD_OVERLAP_FLUSH', overlap)
+  from test_deepfm_gpu import _assert_closed_tracks_sweep
+  if overlap == 'closed':
+    monkeypatch.delenv('EASYREC_AMD_EXACT_DECAY', raising=False)
+  else:
+    monkeypatch.setenv('EASYREC_AMD_EXACT_DECAY', '1')
+    monkeypatch.setenv('EASYREC_AMD_OVERLAP_FLUSH', overlap)
   cfg = _cfg('deepfm_criteo_small.config')
   B, world = 64, 2
   feats = list(cfg.feature_config.features)
@@ -367,4 +374,7 @@ def test_lazy_decay_equals_sweep_through_two_sharded_ranks(monkeypatch, overlap)
       return est.state_dict(slots=True)
 
     states[sweep] = sim.run(rank_fn)[0]
-  _assert_lazy_equals_sweep(states[False], states[True])
+  if overlap == 'closed':
+    _assert_closed_tracks_sweep(states[False], states[True])
+  else:
+    _assert_lazy_equals_sweep(states[False], states[True])

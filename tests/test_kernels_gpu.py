@@ -745,6 +745,74 @@ def test_lazy_dense_decay_equals_the_sweep(hip):
       assert torch.equal(sa, sb), mode
 
 
+def test_closed_form_decay_tracks_the_sweep(hip):
+  """The closed-form replay (csrc/er_decay.h: er_decay_tables_create, the per-step table appended by
+  er_step_prologue_decay, the per-launch table in front of er_emb_catch_up / er_emb_flush_decay) against the streaming
+  sweep of every row every step, 1300 steps, rows idle for 1 .. 1240 steps, a halving learning rate: var within 1e-6 of
+  the table's scale, m within 1e-5 and v within 2e-4 relative (step-by-step fp32 rounding of 1240 multiplications
+  drifts by that much from beta^k; the closed form is the more accurate of the two)."""
+  rng = np.random.default_rng(11)
+  rows, dim, B, T = 97, 16, 6, 1300
+  table0 = torch.from_numpy((rng.standard_normal((rows, dim)) * 0.05).astype(np.float32))
+  ids_all = rng.integers(0, rows, size=(T, B)).astype(np.int64)
+  ids_all[60:, :] = ids_all[60:, :] % 11            # after step 60 only rows 0..10 are ever touched again
+  ids_all[700, 0] = 50                               # ... except one touch of a row idle for > 600 steps
+  dout_all = (rng.standard_normal((T, B, dim)) * 0.01).astype(np.float32)
+  dout_all[:, :, :4] *= 1e-4                         # columns whose sqrt(v) is comparable to eps
+  dout_all[:, :, 4:6] *= 1e-7                        # ... and far below it
+  state = {}
+  rows_h = torch.stack([_hyper(lr=1e-2 * (0.5**(s // 400)), t=s + 1) for s in range(T)]).to(DEV)
+  for mode in ('sweep', 'closed'):
+    var, m, v = table0.clone().to(DEV), torch.zeros(rows, dim, device=DEV), torch.zeros(rows, dim, device=DEV)
+    ids = torch.zeros(B, dtype=torch.int64, device=DEV)
+    dout = torch.zeros(B, dim, device=DEV)
+    bitmap = torch.zeros((rows + 31) // 32, dtype=torch.int32, device=DEV) if mode == 'sweep' else None
+    spec = kernels.LookupSpec(table=var, ids=ids, offsets=None, weights=None, out=dout, out_col=0, rows=rows,
+                              key_base=0, dim=dim, combiner=0, n_rows=B, max_nnz=B)
+    g = hip.emb_group_create([spec], dim, rows, var, m, v, bitmap)
+    counter = torch.zeros(1, dtype=torch.int64, device=DEV)
+    cap = T + 8
+    hist = torch.zeros(2 * cap, device=DEV)
+    hyper = torch.zeros(kernels.HYPER_FLOATS, device=DEV)
+    tabs = None
+    if mode == 'closed':
+      last = torch.full((rows,), -1, dtype=torch.int32, device=DEV)
+      hip.emb_group_enable_lazy_decay(g, last, hist, counter)
+      tabs = hip.decay_tables_create(hist, counter, 0.9, 0.999)
+      assert tabs is not None
+      hip.emb_group_set_decay_tables(g, tabs)
+      ukeys = torch.zeros(B, dtype=torch.int32, device=DEV)
+      nu = torch.zeros(1, dtype=torch.int32, device=DEV)
+      uidx = torch.zeros(B, dtype=torch.int64, device=DEV)
+      cnt = torch.zeros(1, dtype=torch.int32, device=DEV)
+    for s in range(T):
+      hip.step_prologue(rows_h, counter, hyper, history=hist, decay_tables=tabs)  # slot s of the table; counter = s + 1
+      ids.copy_(torch.from_numpy(ids_all[s]))
+      dout.copy_(torch.from_numpy(dout_all[s]))
+      if mode == 'closed':
+        hip.emb_route(g, ukeys, nu, uidx, cnt)
+        hip.emb_catch_up(g, ukeys, nu, hyper)
+      hip.emb_bwd_update(g, kernels.OPT_ADAM, hyper)
+    if mode == 'closed':
+      hip.emb_flush_decay(g, hyper)
+      torch.cuda.synchronize()
+      assert int(last.min()) == T - 1
+    torch.cuda.synchronize()
+    state[mode] = (var.cpu().double(), m.cpu().double(), v.cpu().double())
+    hip.emb_group_destroy(g)
+    hip.decay_tables_destroy(tabs)
+  (va, ma, sa), (vb, mb, sb) = state['sweep'], state['closed']
+  scale = float(va.abs().max())
+  dv = float((va - vb).abs().max()) / scale
+  print('closed form vs sweep: var %.3g of the table scale' % dv)
+  assert dv <= 1e-6, dv
+  big_m = ma.abs() > 1e-30
+  assert float(((ma - mb).abs()[big_m] / ma.abs()[big_m]).max()) <= 1e-4
+  assert float((ma - mb).abs()[~big_m].max()) <= 1e-30
+  big_v = sa > 1e-35
+  assert float(((sa - sb).abs()[big_v] / sa[big_v]).max()) <= 2e-4
+
+
 @pytest.mark.parametrize('sizes', [(100, 4096, 5000, 8192, 257), (1, 2, 3), (4097,), (8192, 8192), (9000, 50),
                                    (-3000000, 4096), (-600000, 8192, 77)])
 def test_segmented_sort_sizes(hip, sizes):
