@@ -113,8 +113,25 @@ def baseline_metric():
     return 'global examples/sec + emb HBM GB/s, DeepFM Criteo-shape b4096 @1/2/4/8 GPU'
 
 
+def self_spawn(n_gpus):
+  """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (what the driver's
+  `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ...` does) and hand their output through."""
+  import socket
+  import subprocess
+  with socket.socket() as sk:
+    sk.bind(('127.0.0.1', 0))
+    port = sk.getsockname()[1]
+  env = dict(os.environ)
+  env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n_gpus), '--master-addr',
+         '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+  sys.exit(subprocess.call(cmd, env=env))
+
+
 def dist_setup(n_gpus, rccl_world1=False):
   import torch.distributed as dist
+  if n_gpus > 1 and 'WORLD_SIZE' not in os.environ:
+    self_spawn(n_gpus)
   rank = int(os.environ.get('RANK', '0'))
   world = int(os.environ.get('WORLD_SIZE', '1'))
   local = int(os.environ.get('LOCAL_RANK', '0'))
@@ -145,9 +162,12 @@ def to_device_batch(batch, device):
 def embedding_bytes_per_step(est, batches):
   """Algorithmic bytes of the embedding stage per step:
      per valid lookup fwd 8+8D, bwd 8+4D; per unique row update 8D*(1+S); dense-decay Adam adds the
-     sweep R*D*4*6 over every table."""
+     sweep R*D*4*6 over every table.  -> (lookup + update bytes, sweep bytes, {kernel: its share per launch}): the
+     lookup kernel reads id + row and writes the row; the segmented reduction reads id + upstream gradient per lookup
+     and reads + writes var, m, v of every distinct row; the catch-up reads + writes var, m, v of every distinct row;
+     the sort reads the id and writes key + permutation entry."""
   from easyrec_amd import kernels
-  lazy, n_steps = 0.0, 0
+  lazy, n_steps, per = 0.0, 0, {}
   S = 2 if est.opt_emb.kind in (kernels.OPT_ADAM, kernels.OPT_LAZY_ADAM) else (1 if est.opt_emb.kind == kernels.OPT_ADAGRAD else 0)
   for b in batches[:4]:
     est.features.load(b)
@@ -161,13 +181,20 @@ def embedding_bytes_per_step(est, batches):
       tot += n_valid * (16 + 12 * dim) + uniq * 8 * dim * (1 + S)
       n_proj = len(est.schema.raw)
       tot += n_proj * est.batch_size * (4 + 8 * dim) + n_proj * 8 * dim * (1 + S)
+      per['emb_fwd_kernel'] = per.get('emb_fwd_kernel', 0.0) + n_valid * (8 + 8 * dim) + n_proj * est.batch_size * (4 + 4 * dim)
+      per['emb_bwd_tile_multi_kernel'] = per.get('emb_bwd_tile_multi_kernel', 0.0) + n_valid * (8 + 4 * dim) + \
+          uniq * 8 * dim * (1 + S) + n_proj * est.batch_size * 4 * dim + n_proj * 8 * dim * (1 + S)
+      per['emb_catch_up_closed_kernel'] = per.get('emb_catch_up_closed_kernel', 0.0) + (uniq + n_proj) * 8 * dim * (1 + S)
+    per['emb_segment_sort_kernel'] = per.get('emb_segment_sort_kernel', 0.0) + (n_valid + n_proj * est.batch_size) * 16
     lazy += tot
     n_steps += 1
   lazy /= max(n_steps, 1)
   sweep = 0.0
   if est.opt_emb.kind == kernels.OPT_ADAM and est.dense_sweep:
     sweep = sum(st['total_rows'] * dim * 4 * 6 for dim, st in est.engine.storage.items())
-  return lazy, sweep
+  per = {k: v / max(n_steps, 1) for k, v in per.items()}
+  per['emb_catch_up_multi_kernel'] = per['emb_catch_up_closed_kernel']
+  return lazy, sweep, per
 
 
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X fp32 MFMA (= fp32 vector) peak, MI355X_MICROARCH.md
@@ -193,38 +220,6 @@ def time_sweep_kernel(est, launches):
   alg_bytes = st['total_rows'] * dim * 4 * 6
   return {'kernel': 'er::adam_decay_sweep_vec4_kernel<4> (dim %d)' % dim, 'avg_ms': float(np.mean(ms)),
           'min_ms': float(np.min(ms)), 'bytes': alg_bytes, 'launches': launches}
-
-
-def time_embedding_stage(est, alg_bytes, reps=20):
-  """The embedding stage alone: id sort + catch-up + fused lookup, then segmented reduction + row
-  update, launched eagerly on the bench stream and timed with HIP events after the timed region (the extra optimizer
-  applications reuse the last step's gradients; nothing is reported from the state afterwards)."""
-  eng = est.engine
-  kind, hyper = est.opt_emb.kind, est.hyper[0]
-  ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
-  f0, f1, b0, b1 = ev(), ev(), ev(), ev()
-  fwd = bwd = 0.0
-  for i in range(reps + 3):
-    est.features.version += 1
-    f0.record()
-    eng.forward(est.features.version)
-    f1.record()
-    for g in eng.groups.values():
-      g['got_grad'] = True  # keep last step's upstream gradients
-    saved, eng.flush_windows = getattr(eng, 'flush_windows', 0), 0  # (without the rolling flush: its kernel is in the kernel stats)
-    b0.record()
-    eng.backward_update(kind, hyper)
-    b1.record()
-    eng.flush_windows = saved
-    torch.cuda.synchronize()
-    if i >= 3:
-      fwd += f0.elapsed_time(f1)
-      bwd += b0.elapsed_time(b1)
-  fwd, bwd = fwd / reps, bwd / reps
-  gbps = alg_bytes / ((fwd + bwd) * 1e-3) / 1e9
-  return {'stage_forward_ms': fwd, 'stage_backward_ms': bwd, 'stage_GBps': gbps, 'stage_frac_of_hbm_peak': gbps / HBM_PEAK_GBS,
-          'stage_note': 'eager launches timed with HIP events (launch gaps included): sort + catch-up + lookup | '
-                        'segmented reduction + row update; latency-bound at these sizes (SURVEY.md 8d)'}
 
 
 def time_gemm_kernel(est, launches):
@@ -276,6 +271,134 @@ def time_gemm_kernel(est, launches):
       name = 'er::gemm_%s_kernel<NN> %dx%dx%d (%s)' % ('bf16' if bf16 else 'f32', M, N, K, wname)
   return {'kernel': name, 'avg_ms': float(np.mean(ms)), 'min_ms': float(np.min(ms)), 'flops': 2.0 * M * N * K,
           'launches': launches}
+
+
+FAMILIES = (  # first match wins; names as rocprofv3 / the profiler print them
+    ('decay replay', ('catch_up', 'flush_window', 'flush_decay', 'flush_mark', 'decay_tables', 'adam_decay_sweep')),
+    ('gemm', ('gemm_',)),
+    ('batchnorm', ('er::bn_', 'dice', 'colsum')),
+    ('embedding', ('er::emb_', 'hash_bucket', 'group_grad_finish', 'er::kv_', 'gather_rows', 'scatter_unique', 'rocprim')),
+    ('interaction', ('fm_', 'cross_', 'din_', 'mmoe_', 'cin_', 'dot_interaction', 'rowsum', 'concat_cols', 'cast_bf16')),
+    ('loss / optimizer / prologue', ('er::',)),
+    ('input copy', ('Memcpy', 'copyBuffer')),
+)
+
+
+def family_of(name):
+  for fam, pats in FAMILIES:
+    if any(p in name for p in pats):
+      return fam
+  return 'other'
+
+
+def kernel_breakdown(est, ring, n_steps=32):
+  """Per-kernel device time of the STEP AS BENCHMARKED (hipGraph replays over ring batches), from torch.profiler's
+  device activity records (roctracer kernel timestamps - what rocprofv3 --kernel-trace reports), plus the
+  algorithmic flops behind every GEMM kernel from one eager step with the backend's op log on.
+  -> ({kernel name: (launches per step, us per step)}, {kernel name: flops per step})"""
+  from torch.profiler import ProfilerActivity, profile
+  from easyrec_amd import kernels
+  for i in range(4):
+    est.train_step(ring[i % len(ring)])
+  torch.cuda.synchronize()
+  with profile(activities=[ProfilerActivity.CUDA]) as prof:
+    for i in range(n_steps):
+      est.train_step(ring[(4 + i) % len(ring)])
+    torch.cuda.synchronize()
+  agg = {}
+  for e in prof.events():
+    if 'cuda' not in str(getattr(e, 'device_type', '')).lower():
+      continue
+    us = getattr(e, 'device_time', None)
+    if us is None:
+      us = getattr(e, 'cuda_time', 0.0)
+    a = agg.setdefault(e.name, [0, 0.0])
+    a[0] += 1
+    a[1] += float(us)
+  per_kernel = {k: (v[0] / n_steps, v[1] / n_steps) for k, v in agg.items()}
+  be = kernels.hip()
+  saved_graph, saved_graphs = est.graph, getattr(est, '_graphs', None)
+  est.graph = None
+  if saved_graphs is not None:
+    est._graphs = None
+  be.op_log = []
+  try:
+    est.train_step(ring[0])
+    torch.cuda.synchronize()
+    flops = {}
+    for name, f in be.op_log:
+      flops[name] = flops.get(name, 0.0) + f
+  finally:
+    be.op_log = None
+    est.graph = saved_graph
+    if saved_graphs is not None:
+      est._graphs = saved_graphs
+  return per_kernel, flops
+
+
+def short_name(name):
+  return name if len(name) <= 96 else name[:93] + '...'
+
+
+def step_roofline(est, per_kernel, flops, emb_bytes, pmc):
+  """The bench line's `roofline`: the kernel with the largest total duration per step (chosen from the step's own
+  per-kernel timings), its algorithmic work and counter traffic, the kernel families, and the embedding stage (the
+  second half of BASELINE.json's metric) as a fraction of the HBM peak."""
+  total = sum(us for _, us in per_kernel.values())
+  fams = {}
+  for name, (n, us) in per_kernel.items():
+    f = fams.setdefault(family_of(name), [0.0, 0.0])
+    f[0] += n
+    f[1] += us
+  compute = {k: v for k, v in per_kernel.items() if family_of(k) not in ('input copy', 'other')}
+  dom = max(compute, key=lambda k: compute[k][1])
+  n, us = per_kernel[dom]
+  avg_ms = us / max(n, 1e-9) * 1e-3
+  peak_tf = 2500.0 if 'bf16' in dom else MFMA_F32_PEAK_TFLOPS
+  # flops of a logged name: exact kernel-name prefix match (the profiler prints `void er::gemm_f32_kernel<true, false>(...)`)
+  f_dom = sum(f for k, f in flops.items() if k in dom)
+  out = {'kernel': short_name(dom), 'launches_per_step': n, 'us_per_step': us, 'share_of_step_kernel_time': us / total,
+         'avg_kernel_ms': avg_ms,
+         'selection': 'largest total device time per step among the step\'s kernels; durations from the profiler\'s '
+                      'device activity records (roctracer kernel timestamps, = rocprofv3 --kernel-trace) over graph '
+                      'replays of the benchmarked step'}
+  if f_dom > 0:
+    ach = f_dom / (us * 1e-6) / 1e12
+    out.update({'bound': 'mfma', 'achieved': ach, 'peak': peak_tf, 'unit': 'TFLOP/s', 'frac': ach / peak_tf,
+                'algorithmic_flops_per_launch': f_dom / max(n, 1e-9), 'algorithmic_flops_per_step': f_dom})
+  else:
+    b = emb_bytes.get(dom_key(dom)) if emb_bytes else None
+    ach = (b / (us * 1e-6) / 1e9) if b else None
+    out.update({'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': (ach / HBM_PEAK_GBS) if ach else None, 'algorithmic_bytes_per_launch': (b / max(n, 1e-9)) if b else None})
+  t = (pmc or {}).get('by_kernel', {}).get(dom_key(dom))
+  out['traffic'] = t.get('bytes_per_launch') if t else None
+  if t:
+    out['traffic_source'] = t.get('source')
+  out['families'] = [{'family': k, 'us_per_step': v[1], 'share': v[1] / total, 'launches_per_step': v[0]}
+                     for k, v in sorted(fams.items(), key=lambda kv: -kv[1][1])]
+  out['kernels'] = [{'kernel': short_name(k), 'launches_per_step': v[0], 'us_per_step': v[1]}
+                    for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1][1])[:14]]
+  out['kernel_time_us_per_step'] = total
+  gemm_flops = sum(flops.values())
+  gemm_us = fams.get('gemm', [0, 0.0])[1]
+  if gemm_flops > 0 and gemm_us > 0:
+    out['gemm_family'] = {'flops_per_step': gemm_flops, 'us_per_step': gemm_us, 'TFLOPs': gemm_flops / (gemm_us * 1e-6) / 1e12,
+                          'frac_of_mfma_peak': gemm_flops / (gemm_us * 1e-6) / 1e12 / peak_tf}
+  if emb_bytes and emb_bytes.get('stage'):
+    stage_us = fams.get('embedding', [0, 0.0])[1] + fams.get('decay replay', [0, 0.0])[1]
+    gbps = emb_bytes['stage'] / (stage_us * 1e-6) / 1e9
+    out['embedding_stage'] = {'algorithmic_bytes_per_step': emb_bytes['stage'], 'us_per_step': stage_us, 'GBps': gbps,
+                              'frac_of_hbm_peak': gbps / HBM_PEAK_GBS,
+                              'note': 'hash + sort + catch-up + lookup + gradient finish + segmented reduction + row '
+                                      'update: the sum of those kernels\' durations INSIDE the replayed graph'}
+  return out
+
+
+def dom_key(name):
+  """`er::emb_bwd_tile_multi_kernel(er::RunMulti)` -> `emb_bwd_tile_multi_kernel`"""
+  n = name.split('(')[0].split('<')[0]
+  return n.replace('void ', '').replace('er::', '').strip()
 
 
 class DeviceCriteo(object):
@@ -517,6 +640,10 @@ def main():
     return
   ms_per_step = dt / args.steps * 1e3
   value = world * B * args.steps / dt
+  rccl_world = None
+  if world > 1 or (args.rccl and args.force_ep):
+    import torch.distributed as dist
+    rccl_world = dist.get_world_size()
   out = {
       'metric': baseline_metric(),
       'value': value,
@@ -533,6 +660,7 @@ def main():
       'config': {
           'workload': workload_text(cfg, args, est, criteo, B, graph_note, len(ring)),
           'global_batch': world * B,
+          'rccl_world_size': rccl_world,
           'parallelism': ('embedding-parallel x%d (row-sharded tables, RCCL all-to-all) + dense DP' % world if world > 1 else
                           'single GPU' if not ep else 'single GPU through the embedding-parallel code path (%s)' %
                           ('world-1 RCCL process group' if args.rccl else 'local copies for the collectives')),
@@ -541,49 +669,51 @@ def main():
       'device': kernels.hip().device_info(),
   }
   if world == 1 and not ep:
-    lazy_bytes, sweep_bytes = embedding_bytes_per_step(est, host_ring) if criteo else (0.0, 0.0)
+    lazy_bytes, sweep_bytes, per_kernel_bytes = embedding_bytes_per_step(est, host_ring) if criteo else (0.0, 0.0, {})
     if criteo:  # (the byte accounting of SURVEY.md 8d is written for the Criteo schema)
       out['embedding_stage'] = {
           'algorithmic_bytes_per_step': lazy_bytes + sweep_bytes,
           'lookup_update_bytes_per_step': lazy_bytes,
           'dense_decay_sweep_bytes_per_step': sweep_bytes,
           'whole_step_GBps': (lazy_bytes + sweep_bytes) / (ms_per_step * 1e-3) / 1e9,
-          'note': 'whole_step_GBps divides the embedding stage\'s algorithmic bytes by the WHOLE step time; '
-                  'dense_decay_sweep_bytes_per_step is 0 unless --dense_sweep (default: lazy dense decay)',
+          'note': 'whole_step_GBps divides the embedding stage\'s algorithmic bytes by the WHOLE step time; the stage '
+                  'inside the replayed graph is roofline.embedding_stage; dense_decay_sweep_bytes_per_step is 0 unless '
+                  '--dense_sweep (default: lazy dense decay)',
       }
-      try:
-        out['embedding_stage'].update(time_embedding_stage(est, lazy_bytes + sweep_bytes))
-      except Exception as e:  # noqa: BLE001
-        out['embedding_stage']['stage_error'] = str(e)[:200]
     n_launch = max(10, min(args.steps, 50))
+    pmc = None
+    try:
+      pmc = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
+    except Exception:  # noqa: BLE001
+      pmc = None
     if sweep_bytes > 0 and est.dense_sweep:
       dom = time_sweep_kernel(est, n_launch)
       ach = dom['bytes'] / (dom['avg_ms'] * 1e-3) / 1e9
-      traffic = None
-      pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-      if os.path.exists(pmc):
-        try:
-          traffic = json.load(open(pmc)).get('adam_decay_sweep_dim16_bytes_per_launch')
-        except Exception:
-          traffic = None
       out['roofline'] = {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': ach / HBM_PEAK_GBS, 'traffic': traffic, 'kernel': dom['kernel'],
-                         'avg_kernel_ms': dom['avg_ms'], 'algorithmic_bytes_per_launch': dom['bytes'],
-                         'launches_timed': dom['launches']}
-    else:
-      dom = time_gemm_kernel(est, n_launch)
-      ach = dom['flops'] / (dom['avg_ms'] * 1e-3) / 1e12
-      peak = 2500.0 if est.ctx.dense_dtype == 'bf16' else MFMA_F32_PEAK_TFLOPS
-      traffic = None  # HBM-side bytes of this launch from the PMC passes of tools/gpu_gemm_traffic.sh
-      pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-      if os.path.exists(pmc) and est.ctx.dense_dtype != 'bf16' and dom['flops'] == 2.0 * 4096 * 256 * 624:
-        try:
-          traffic = json.load(open(pmc)).get('gemm_f32_nn_4096x256x624_bytes_per_launch')
-        except Exception:
-          traffic = None
-      out['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
-                         'traffic': traffic, 'kernel': dom['kernel'], 'avg_kernel_ms': dom['avg_ms'],
-                         'algorithmic_flops_per_launch': dom['flops'], 'launches_timed': dom['launches']}
+                         'frac': ach / HBM_PEAK_GBS, 'traffic': (pmc or {}).get('adam_decay_sweep_dim16_bytes_per_launch'),
+                         'kernel': dom['kernel'], 'avg_kernel_ms': dom['avg_ms'],
+                         'algorithmic_bytes_per_launch': dom['bytes'], 'launches_timed': dom['launches']}
+    elif not args.no_graph:
+      try:
+        per_kernel, flops = kernel_breakdown(est, ring)
+        emb_bytes = dict(per_kernel_bytes)
+        if criteo:
+          emb_bytes['stage'] = lazy_bytes
+        out['roofline'] = step_roofline(est, per_kernel, flops, emb_bytes, pmc)
+      except Exception as e:  # noqa: BLE001
+        out['roofline_error'] = str(e)[:300]
+      try:  # cross-check of the profiler's durations: the largest GEMM launch alone, HIP events on the launch stream
+        dom = time_gemm_kernel(est, n_launch)
+        ach = dom['flops'] / (dom['avg_ms'] * 1e-3) / 1e12
+        peak = 2500.0 if est.ctx.dense_dtype == 'bf16' else MFMA_F32_PEAK_TFLOPS
+        out.setdefault('roofline', {})['largest_gemm_launch'] = {
+            'kernel': dom['kernel'], 'avg_kernel_ms': dom['avg_ms'], 'achieved': ach, 'unit': 'TFLOP/s', 'frac': ach / peak,
+            'algorithmic_flops_per_launch': dom['flops'], 'launches_timed': dom['launches'],
+            'timed_with': 'HIP events on the launch stream, one launch per event pair',
+            'traffic': (pmc or {}).get('gemm_f32_nn_4096x256x624_bytes_per_launch')
+            if dom['flops'] == 2.0 * 4096 * 256 * 624 and est.ctx.dense_dtype != 'bf16' else None}
+      except Exception as e:  # noqa: BLE001
+        out.setdefault('roofline', {})['largest_gemm_launch'] = {'error': str(e)[:200]}
     if args.steady_steps > 0 and not args.no_graph:
       try:
         out['steady_state'] = steady_state(est, dgen, args.steady_steps)

@@ -309,6 +309,16 @@ class HipBackend(object):
     if self.lib.er_abi_version() != 1:
       raise RuntimeError('easyrec_amd: ABI version mismatch in %s' % LIB_PATH)
 
+  # -- measurement hook (bench.py): with `op_log` a list, every contraction appends (kernel name as rocprof prints it,
+  # flops): one eager step gives the algorithmic work behind each GEMM kernel of the step's profile
+  op_log = None
+  _LAYOUT_TPL = {0: '<true, false>', 1: '<true, true>', 2: '<false, false>'}
+
+  def _log_gemm(self, kernel, layout, M, N, K):
+    if self.op_log is not None:
+      self.op_log.append(('er::' + kernel + (self._LAYOUT_TPL[int(layout)] if layout is not None else ''),
+                          2.0 * M * N * K))
+
   # -- plumbing
   def _ck(self, rc, what):
     if rc != 0:
@@ -558,6 +568,7 @@ class HipBackend(object):
     assert out.shape == (M, N) and out.stride(1) == 1 and out.dtype == torch.float32
     if bf16 and col_stats is None and self._gemm_bf16_fast(layout, a, b, out, bias, accumulate, M, N, K):
       return out
+    self._log_gemm('gemm_bf16_kernel' if bf16 else 'gemm_f32_kernel', layout, M, N, K)
     fn = self.lib.er_gemm_bf16 if bf16 else self.lib.er_gemm_f32
     if col_stats is not None:
       assert col_stats.numel() >= self.gemm_row_tiles(M) * N * 3 and col_stats.dtype == torch.float32
@@ -604,6 +615,7 @@ class HipBackend(object):
     assert a.shape[0] >= M and bt.shape[0] >= N
     Kp = (K + 7) // 8 * 8  # (the k-tail up to the padded width reads zeros: Bf16Shadows pads with zeros)
     assert a.stride(0) >= Kp and bt.stride(0) >= Kp and a.stride(0) % 8 == 0 and bt.stride(0) % 8 == 0
+    self._log_gemm('gemm_bf16_nt_kernel', None, M, N, K)
     self._ck(self.lib.er_gemm_bf16_nt(M, N, Kp, ctypes.c_void_p(a.data_ptr()), ctypes.c_int32(a.stride(0)),
                                       ctypes.c_void_p(bt.data_ptr()), ctypes.c_int32(bt.stride(0)), _p(out),
                                       ctypes.c_int32(0 if out is None else out.stride(0)),
@@ -667,6 +679,7 @@ class HipBackend(object):
       (K, M), (K2, N) = a.shape, b.shape
     assert K == K2 and src.y.shape == (M, N) and src.z.shape == (M, N) and src.y.stride() == src.z.stride()
     use_bn = src.mean is not None
+    self._log_gemm('gemm_f32_bn_bwd_apply_kernel', layout, M, N, K)
     dg, dbt = src.grad_bufs if src.grad_bufs is not None else (None, None)
     partial = torch.empty(self.gemm_row_tiles(M) * N * 2, dtype=torch.float32, device=a.device)
     out = torch.empty(M, N, dtype=torch.float32, device=a.device)
@@ -689,6 +702,7 @@ class HipBackend(object):
       (K, M), (K2, N) = a.shape, b.shape
     assert K == K2 and src.y.shape == (M, N) and src.z.shape == (M, N) and src.y.stride() == src.z.stride()
     assert partial.numel() >= self.gemm_row_tiles(M) * N * 2
+    self._log_gemm('gemm_f32_bn_bwd_kernel', layout, M, N, K)
     out = torch.empty(M, N, dtype=torch.float32, device=a.device)
     use_bn = src.mean is not None
     self._ck(self.lib.er_gemm_f32_bn_bwd(ctypes.c_int(layout), M, N, K, _p(a), ctypes.c_int32(a.stride(0)), _p(b),
@@ -711,6 +725,7 @@ class HipBackend(object):
       else:
         (K, M), (K2, N) = a.shape, b.shape
       assert K == K2 and out.shape == (M, N)
+      self._log_gemm('gemm_f32_grouped_kernel', layout, M, N, K)
       q.M, q.N, q.K = M, N, K
       q.A, q.lda, q.B, q.ldb = a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0)
       q.C, q.ldc = out.data_ptr(), out.stride(0)

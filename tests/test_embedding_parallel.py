@@ -113,6 +113,64 @@ def test_world2_gloo_same_batch_equals_single_process(ref_backend, tmp_path, opt
   assert abs(loss - ref_losses[-1]['total_loss']) <= 1e-5 * abs(ref_losses[-1]['total_loss'])
 
 
+def _gloo_worker_own_batches(rank, world, port, B, steps, lazy, clip, out_dir):
+  """like _gloo_worker, but every rank trains on ITS OWN batches (tests/_multi_rank.py rank_batches)"""
+  sys.path.insert(0, ROOT)
+  sys.path.insert(0, os.path.join(ROOT, 'tests'))
+  os.environ['MASTER_ADDR'] = '127.0.0.1'
+  os.environ['MASTER_PORT'] = str(port)
+  import pickle
+  import torch.distributed as dist
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  torch.set_num_threads(1)
+  from easyrec_amd import kernels
+  from oracle.kernel_ref import RefBackend
+  kernels._BACKEND = RefBackend()  # CPU stand-in for the HIP kernels (tests only)
+  from _multi_rank import make_cfg, rank_batches
+  from easyrec_amd.model.embedding_parallel import EmbeddingParallelEstimator
+  cfg = make_cfg('deepfm_criteo_small.config', lazy=lazy, clip=clip)
+  batches = rank_batches(cfg, list(cfg.feature_config.features), B, world, steps)
+  est = EmbeddingParallelEstimator(cfg, device='cpu', batch_size=B, seed=4, rank=rank, world=world,
+                                   replicate_bytes=1024).build()
+  init = est.state_dict()  # collective: rank 0's copy seeds the oracle
+  losses, norms = [], []
+  for step_batches in batches:
+    est.train_step(step_batches[rank])
+    losses.append(est.loss_values())
+    norms.append(float(est.grad_norm.item()))
+  state = est.state_dict(slots=True)
+  with open(os.path.join(out_dir, 'rank%d.pkl' % rank), 'wb') as f:
+    pickle.dump({'init': init if rank == 0 else None, 'state': state, 'losses': losses, 'norms': norms}, f)
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('lazy,clip,steps', [(False, 0.0, 1), (True, 0.05, 1), (True, 0.0, 3)])
+def test_world2_gloo_own_batches_match_the_w_worker_oracle(ref_backend, tmp_path, lazy, clip, steps):
+  """Two PROCESSES over gloo (torch.distributed all-to-alls and all-reduce, not the in-process SimWorld), each rank on
+  its own batches, against the oracle's W-worker step: per-rank losses, Adam's first moments after the first update,
+  per-rank BatchNorm statistics, the clipped global norm (tests/_multi_rank.py check_against_oracle)."""
+  import pickle
+  import torch.multiprocessing as mp
+  sys.path.insert(0, os.path.join(ROOT, 'tests'))
+  from _multi_rank import check_against_oracle, make_cfg, rank_batches
+  from oracle.model_oracle import OracleTrainer
+  B, world = 24, 2
+  port = 33500 + (os.getpid() % 2000) + (3 if lazy else 0) + (5 if clip else 0) + steps
+  mp.spawn(_gloo_worker_own_batches, args=(world, port, B, steps, lazy, clip, str(tmp_path)), nprocs=world, join=True)
+  ranks = [pickle.load(open(os.path.join(str(tmp_path), 'rank%d.pkl' % r), 'rb')) for r in range(world)]
+  cfg = make_cfg('deepfm_criteo_small.config', lazy=lazy, clip=clip)
+  batches = rank_batches(cfg, list(cfg.feature_config.features), B, world, steps)
+  orc = OracleTrainer(cfg, ranks[0]['init'], batch_size=B)
+  exp_losses = [orc.train_step_world(batches[0])]
+  orc_first = {k: v.copy() for k, v in orc.slots.items()}
+  orc_norm0, moving0 = orc.last_grad_norm, [dict(m) for m in orc.rank_moving]
+  for step_batches in batches[1:]:
+    exp_losses.append(orc.train_step_world(step_batches))
+  results = [(r['state'], r['losses'], r['norms']) for r in ranks]
+  check_against_oracle(results, orc, exp_losses, orc_first, orc_norm0, moving0, steps_checked=steps, clip=clip > 0)
+
+
 def test_evaluate_through_the_sharded_engine(ref_backend):
   """EasyRecEstimator.evaluate() on the embedding-parallel estimator: the eval-mode forward goes through the same
   route / exchange / lookup, gives the single-process metrics, and training continues identically afterwards."""
