@@ -45,7 +45,37 @@ struct BnBwdEpi {
   const float* invstd = nullptr;
   int ld = 0, use_bn = 0, act = 0;
   float* partial = nullptr;       // [row tiles][N][2]
+  // y == nullptr (the producing layer's activation output was never materialised: ATransform below): the ReLU mask is
+  // recomputed from z with the producing layer's affine parameters
+  const float* gamma = nullptr;
+  const float* beta = nullptr;
 };
+
+// y of a dense + BatchNorm + activation layer from its pre-normalisation value: the operation sequence of
+// bn_finalize_apply_kernel (er_dense.hip), so a recomputed y has the bits of a materialised one
+__device__ __forceinline__ float bn_act_value(float z, float mu, float is, float ga, float be, int use_bn, int act) {
+  float v = z;
+  if (use_bn) {
+    v = (z - mu) * is;
+    v = v * ga + be;
+  }
+  if (act == ER_ACT_RELU) v = v > 0.f ? v : 0.f;
+  return v;
+}
+
+// Operand A as the output of a dense + BatchNorm(train) + activation layer that was NEVER WRITTEN: A points at that
+// layer's pre-normalisation values z (bias included) and the staging applies bn_act_value with the layer's batch
+// statistics and affine parameters per FEATURE - A is [batch, features] row-major both as the forward operand (NN:
+// features = k) and as the weight-gradient operand (TN: features = m), so a staging unit's 4 contiguous elements are 4
+// consecutive features either way.  Saves the separate normalise + activate pass and the write + re-reads of y.
+struct ATransform {
+  const float* mean = nullptr;  // nullptr: A is used as it is
+  const float* invstd = nullptr;
+  const float* gamma = nullptr;  // nullptr: 1
+  const float* beta = nullptr;   // nullptr: 0
+  int act = 0;
+};
+constexpr int kTrMaxK = 1024;  // forward operand: the whole feature axis (= K) sits in the LDS parameter table
 
 // BatchNorm fused INTO the epilogue (forward: normalise + activation; backward: the dz of the producing layer) needs
 // the column statistics of ALL row tiles before any output can be written: the workgroups of one column of tiles meet
@@ -55,7 +85,10 @@ struct BnBwdEpi {
 // accumulator tile in registers.  One launch per dense + BatchNorm + ReLU layer instead of two, and no second pass over
 // the layer's output.
 struct BnFused {
-  int mode = 0;                    // 0: off; 1: forward (needs col_stats); 2: backward (needs bn.partial)
+  int mode = 0;                    // 0: off; 1: forward (needs col_stats); 2: backward (needs bn.partial);
+                                   // 3: forward statistics only, WITHOUT a barrier: the workgroup that is last to add
+                                   //    its partial to a column of tiles (arrival counter) finalises mean / invstd /
+                                   //    moving statistics of those 64 columns; nobody waits, z is written as usual
   const float* gamma = nullptr;
   const float* beta = nullptr;     // forward
   float eps = 0.f, momentum = 0.f;
@@ -85,6 +118,7 @@ struct GemmArgs {
   float* col_stats;   // nullptr, or [gridDim.y][N][3] Welford (count, mean, M2) of the output columns per row tile
   BnBwdEpi bn;        // bn.partial != nullptr: emit the BatchNorm-backward column sums of the output tile
   BnFused fu;         // fu.mode != 0: finish the BatchNorm in this launch (see BnFused)
+  ATransform at;      // at.mean != nullptr: A is transformed while staged (kernels instantiated with A_TR)
 };
 
 // Loads 4 consecutive elements along the CONTIGUOUS dimension of the operand tile.
@@ -207,12 +241,16 @@ __device__ __forceinline__ void tile_bn_bwd_partial(const f32x16& acc, const BnB
     const float bv = e.zbias ? e.zbias[col] : 0.f;
     const float mu = e.use_bn ? e.mean[col] : 0.f;
     const float is = e.use_bn ? e.invstd[col] : 0.f;
+    const float ga = e.gamma ? e.gamma[col] : 1.f, be = e.beta ? e.beta[col] : 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = row_base + (r & 3) + 8 * (r >> 2) + 4 * khalf;
       if (row < M) {
         float g = acc[r];
-        if (e.act == ER_ACT_RELU && !(py[r] > 0.f)) g = 0.f;
+        if (e.act == ER_ACT_RELU) {
+          const float yv = e.y ? py[r] : bn_act_value(pz[r] + bv, mu, is, ga, be, e.use_bn, ER_ACT_NONE);
+          if (!(yv > 0.f)) g = 0.f;
+        }
         sg = sg + g;
         if (e.use_bn) sgx = sgx + g * ((pz[r] + bv - mu) * is);
       }
@@ -441,14 +479,26 @@ __device__ __forceinline__ void fetch_tile_generic(const float* __restrict__ P, 
   }
 }
 
+// tr (LDS, A_TR only): [4][kTrMaxK] = mean | invstd | gamma | beta, indexed by the absolute k (KC) or by the feature's
+// offset inside the tile (non-KC); tr_off = what to add to the unit's own coordinate to get that index
 template <bool KC>
 __device__ __forceinline__ void stage_tile(float* __restrict__ S, int tid, const f32x4v (&r)[2], bool interior, int mn0,
-                                           int MN, int k0, int kend) {
+                                           int MN, int k0, int kend, const float* __restrict__ tr = nullptr,
+                                           int tr_off = 0, int tr_act = 0) {
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     int row, k;
     unit_pos<KC>(tid, i, row, k);
     f32x4v v = r[i];
+    if (tr != nullptr) {
+      const int f = (KC ? k : row) + tr_off;  // (a multiple of 4)
+      const f32x4v mu = *reinterpret_cast<const f32x4v*>(tr + f);
+      const f32x4v is = *reinterpret_cast<const f32x4v*>(tr + kTrMaxK + f);
+      const f32x4v ga = *reinterpret_cast<const f32x4v*>(tr + 2 * kTrMaxK + f);
+      const f32x4v be = *reinterpret_cast<const f32x4v*>(tr + 3 * kTrMaxK + f);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = bn_act_value(v[j], mu[j], is[j], ga[j], be[j], 1, tr_act);
+    }
     if (!interior) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -468,7 +518,7 @@ __device__ __forceinline__ void stage_tile(float* __restrict__ S, int tid, const
 // bx: index of the workgroup among the problem's (8-rounded) tiles, bz: its k-split.  BN_EPI: with the BnBwdEpi
 // epilogue - the y / z values of the lane's 16 output positions are requested BEFORE the k loop so that their
 // latency hides behind it (32 more VGPRs: a separate instantiation).
-template <bool A_KC, bool B_KC, bool BN_EPI = false>
+template <bool A_KC, bool B_KC, bool BN_EPI = false, bool A_TR = false>
 __device__ __forceinline__ void gemm_f32_block(const GemmArgs& g, int bx, int bz, float* __restrict__ lds) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -489,10 +539,30 @@ __device__ __forceinline__ void gemm_f32_block(const GemmArgs& g, int bx, int bz
       int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
       row = row < g.M ? row : g.M - 1;
       const int64_t i = static_cast<int64_t>(row) * g.bn.ld + c;
-      py[r] = g.bn.y[i];
+      py[r] = g.bn.y ? g.bn.y[i] : 0.f;
       pz[r] = g.bn.z[i];
     }
   }
+  // A_TR: the parameter table of the A transform, behind the operand stages
+  const float* tr = nullptr;
+  if (A_TR && g.at.mean != nullptr) {
+    float* t = lds + 2 * 2 * kOpTile;
+    const int n_feat = A_KC ? ((g.K + 3) & ~3) : BM;
+    const int f0 = A_KC ? 0 : m0;
+    const int f_end = A_KC ? g.K : g.M;
+    for (int i = tid; i < n_feat; i += kBlock) {
+      const int f = f0 + i;
+      const bool ok = f < f_end;
+      t[i] = ok ? g.at.mean[f] : 0.f;
+      t[kTrMaxK + i] = ok ? g.at.invstd[f] : 0.f;
+      t[2 * kTrMaxK + i] = (ok && g.at.gamma) ? g.at.gamma[f] : 1.f;
+      t[3 * kTrMaxK + i] = (ok && g.at.beta) ? g.at.beta[f] : 0.f;
+    }
+    tr = t;  // (visible after the __syncthreads() that precedes the first use of a staged tile ... and the first stage
+             // itself reads it: synchronise here)
+    __syncthreads();
+  }
+  const int tr_act = g.at.act;
   const bool a_vec = (g.lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0);
   const bool b_vec = (g.ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0);
   const bool rows_full = (m0 + BM <= g.M) && (n0 + BN <= g.N);
@@ -529,7 +599,7 @@ __device__ __forceinline__ void gemm_f32_block(const GemmArgs& g, int bx, int bz
     auto stage = [&](int buf, const f32x4v (&ra)[2], const f32x4v (&rb)[2], int t) {
       const int k0 = kbeg + t * BK32;  // unclamped: a tile past the end is masked to zero
       const bool interior = rows_full && (k0 + BK32 <= kend);
-      stage_tile<A_KC>(lds + buf * 2 * kOpTile, tid, ra, interior, m0, g.M, k0, kend);
+      stage_tile<A_KC>(lds + buf * 2 * kOpTile, tid, ra, interior, m0, g.M, k0, kend, tr, A_KC ? k0 : 0, tr_act);
       stage_tile<B_KC>(lds + buf * 2 * kOpTile + kOpTile, tid, rb, interior, n0, g.N, k0, kend);
     };
     // One step = one k-tile: read its fragments from LDS stage `buf`, issue the global loads of k-tile t + 2 into
@@ -570,7 +640,8 @@ __device__ __forceinline__ void gemm_f32_block(const GemmArgs& g, int bx, int bz
       const int k0 = kbeg + t * BK32;
       fetch_tile_generic<A_KC>(g.A, g.lda, m0, g.M, k0, kend, tid, ra);
       fetch_tile_generic<B_KC>(g.B, g.ldb, n0, g.N, k0, kend, tid, rb);
-      stage_tile<A_KC>(lds, tid, ra, true, m0, g.M, k0, kend);
+      stage_tile<A_KC>(lds, tid, ra, tr == nullptr, m0, g.M, k0, kend, tr, A_KC ? k0 : 0, tr_act);  // (a transformed
+      // out-of-range element is not zero: masked again after the transform)
       stage_tile<B_KC>(lds + kOpTile, tid, rb, true, n0, g.N, k0, kend);
       __syncthreads();
       f32x4v a[4], b[4];
@@ -584,9 +655,33 @@ __device__ __forceinline__ void gemm_f32_block(const GemmArgs& g, int bx, int bz
   const float bv = (g.bias && g.splits == 1 && col < g.N) ? g.bias[col] : 0.f;
   if (g.col_stats)  // (host guarantees splits == 1) every thread takes part: it synchronises the workgroup
     tile_col_stats(acc, bv, m0 + wm * 32, g.M, col, g.N, wm, wn, lane, lds,
-                   g.col_stats + static_cast<int64_t>(ty) * g.N * 3, g.fu.mode == 1);
+                   g.col_stats + static_cast<int64_t>(ty) * g.N * 3, g.fu.mode == 1 || g.fu.mode == 3);
+  if (g.fu.mode == 3) {
+    // No barrier: a workgroup adds itself to its column's arrival counter once its partial is at the memory side
+    // (st_agent + s_waitcnt, as in tile_column_barrier); the one that completes the count - whichever it is - merges
+    // all partials of the 64 columns in bn_finalize_apply_kernel's fixed order and writes mean / invstd / the moving
+    // statistics.  The consumer of those is the NEXT launch.
+    const int gy = static_cast<int>(ceil_div(g.M, BM));
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    unsigned* flag = reinterpret_cast<unsigned*>(lds);
+    if (tid == 0) {
+      unsigned* c = g.fu.counters + 2 * tx;
+      const unsigned before = __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const bool last = before + 1u == static_cast<unsigned>(gy);
+      if (last) __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // zero again for the next launch
+      *flag = last ? 1u : 0u;
+    }
+    __syncthreads();
+    const bool last = *flag != 0u;
+    __syncthreads();
+    if (last) {
+      float *s_mu, *s_is;
+      fused_bn_fwd_finalize(g, n0, 0, gy, lds, s_mu, s_is);
+    }
+  }
   if (BN_EPI) tile_bn_bwd_partial(acc, g.bn, py, pz, m0 + wm * 32, g.M, col, g.N, wm, wn, lane, lds, ty, g.fu.mode == 2);
-  if (g.fu.mode != 0) {  // (uniform over the grid; host guarantees splits == 1 and a co-resident grid)
+  if (g.fu.mode == 1 || g.fu.mode == 2) {  // (uniform over the grid; host guarantees splits == 1 and a co-resident grid)
     const int gy = static_cast<int>(ceil_div(g.M, BM));
     tile_column_barrier(g.fu.counters + 2 * tx, static_cast<unsigned>(gy));
     const int cl = wn * 32 + (lane & 31);
@@ -664,6 +759,15 @@ gemm_f32_bn_bwd_kernel(GemmArgs g) {
   gemm_f32_block<A_KC, B_KC, true>(g, blockIdx.x, 0, lds);
 }
 
+// the same with the A transform: the LDS parameter table behind the operand stages
+constexpr int kTrLds = 2 * 2 * kOpTile + 4 * kTrMaxK;
+template <bool A_KC, bool B_KC>
+__global__ void __launch_bounds__(kBlock)
+gemm_f32_tr_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) float lds[kTrLds];
+  gemm_f32_block<A_KC, B_KC, false, true>(g, blockIdx.x, blockIdx.z, lds);
+}
+
 // Grouped launch: up to kMaxGroup independent problems of one layout in ONE grid (the weight gradients of all
 // layers of a step: each is a small M x N with K = batch, far too few tiles to fill 256 CUs on its own).
 // Workgroups [start[p], start[p+1]) belong to problem p: tile = local % tiles8, k-split = local / tiles8
@@ -685,6 +789,17 @@ gemm_f32_grouped_kernel(GroupedArgs ga) {
   while (p + 1 < ga.n && b >= ga.start[p + 1]) ++p;
   const int local = b - ga.start[p];
   gemm_f32_block<A_KC, B_KC>(ga.p[p], local % ga.tiles8[p], local / ga.tiles8[p], lds);
+}
+
+template <bool A_KC, bool B_KC>
+__global__ void __launch_bounds__(kBlock)
+gemm_f32_grouped_tr_kernel(GroupedArgs ga) {
+  __shared__ __attribute__((aligned(16))) float lds[kTrLds];
+  const int b = blockIdx.x;
+  int p = 0;
+  while (p + 1 < ga.n && b >= ga.start[p + 1]) ++p;
+  const int local = b - ga.start[p];
+  gemm_f32_block<A_KC, B_KC, false, true>(ga.p[p], local % ga.tiles8[p], local / ga.tiles8[p], lds);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -901,6 +1016,8 @@ int launch_gemm(int layout, er::GemmArgs& a, hipStream_t s) {
     ER_LAUNCH_GEMM(er::gemm_bf16_kernel)
   } else if (a.bn.partial) {
     ER_LAUNCH_GEMM(er::gemm_f32_bn_bwd_kernel)
+  } else if (a.at.mean) {
+    ER_LAUNCH_GEMM(er::gemm_f32_tr_kernel)
   } else {
     ER_LAUNCH_GEMM(er::gemm_f32_kernel)
   }
@@ -982,6 +1099,7 @@ int gemm_grouped_f32(int layout, const er_gemm_problem* pr, int n, er_stream_t s
   ra.start[0] = 0;
   size_t ws_floats = 0;
   bool vec_ok = true;
+  bool any_tr = false;
   for (int i = 0; i < n; ++i) {
     const er_gemm_problem& q = pr[i];
     er::GemmArgs& a = ga.p[i];
@@ -989,6 +1107,13 @@ int gemm_grouped_f32(int layout, const er_gemm_problem* pr, int n, er_stream_t s
     a.M = q.M; a.N = q.N; a.K = q.K; a.lda = q.lda; a.ldb = q.ldb; a.ldc = q.ldc;
     a.accumulate = q.accumulate;
     a.col_stats = nullptr;
+    if (q.a_mean) {
+      ER_REQUIRE(q.a_invstd, "er_gemm_grouped_f32: problem %d: A transform without invstd", i);
+      ER_REQUIRE(layout == ER_GEMM_TN || q.K <= er::kTrMaxK - 64,
+                 "er_gemm_grouped_f32: problem %d: A transform over K = %d features (limit %d)", i, q.K, er::kTrMaxK - 64);
+      a.at.mean = q.a_mean; a.at.invstd = q.a_invstd; a.at.gamma = q.a_gamma; a.at.beta = q.a_beta; a.at.act = q.a_act;
+      any_tr = true;
+    }
     int64_t sp = want;
     // a long contraction (DIN's attention MLP contracts over B x L = 204,800 rows into an 80-column output) gets
     // splits of at most 2048 rows whatever the group's tile count asks for: 13 splits of 15,753 rows took 0.52 ms
@@ -1038,11 +1163,20 @@ int gemm_grouped_f32(int layout, const er_gemm_problem* pr, int n, er_stream_t s
     }
   }
   dim3 grid(static_cast<unsigned>(ga.start[n])), block(er::kBlock);
-  switch (layout) {
-    case ER_GEMM_NN: hipLaunchKernelGGL((er::gemm_f32_grouped_kernel<true, false>), grid, block, 0, s, ga); break;
-    case ER_GEMM_NT: hipLaunchKernelGGL((er::gemm_f32_grouped_kernel<true, true>), grid, block, 0, s, ga); break;
-    case ER_GEMM_TN: hipLaunchKernelGGL((er::gemm_f32_grouped_kernel<false, false>), grid, block, 0, s, ga); break;
-    default: er::set_error("er_gemm_grouped_f32: unknown layout %d", layout); return 2;
+  if (any_tr) {
+    switch (layout) {
+      case ER_GEMM_NN: hipLaunchKernelGGL((er::gemm_f32_grouped_tr_kernel<true, false>), grid, block, 0, s, ga); break;
+      case ER_GEMM_NT: hipLaunchKernelGGL((er::gemm_f32_grouped_tr_kernel<true, true>), grid, block, 0, s, ga); break;
+      case ER_GEMM_TN: hipLaunchKernelGGL((er::gemm_f32_grouped_tr_kernel<false, false>), grid, block, 0, s, ga); break;
+      default: er::set_error("er_gemm_grouped_f32: unknown layout %d", layout); return 2;
+    }
+  } else {
+    switch (layout) {
+      case ER_GEMM_NN: hipLaunchKernelGGL((er::gemm_f32_grouped_kernel<true, false>), grid, block, 0, s, ga); break;
+      case ER_GEMM_NT: hipLaunchKernelGGL((er::gemm_f32_grouped_kernel<true, true>), grid, block, 0, s, ga); break;
+      case ER_GEMM_TN: hipLaunchKernelGGL((er::gemm_f32_grouped_kernel<false, false>), grid, block, 0, s, ga); break;
+      default: er::set_error("er_gemm_grouped_f32: unknown layout %d", layout); return 2;
+    }
   }
   ER_LAUNCH_CHECK();
   if (ra.n > 0) {
@@ -1119,6 +1253,56 @@ int er_gemm_f32_bn_bwd_apply(int layout, int32_t M, int32_t N, int32_t K, const 
   a.fu.gamma = gamma; a.fu.dgamma = dgamma; a.fu.dbeta = dbeta; a.fu.dbias = dbias; a.fu.accumulate = accumulate;
   a.fu.counters = g_bn_counters;
   return launch_gemm<false>(layout, a, er::as_stream(stream));
+}
+
+int er_gemm_f32_deferred(int layout, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const er_a_transform* at,
+                         const float* B, int32_t ldb, float* C, int32_t ldc, const float* bias, int accumulate,
+                         float* col_stats, const er_bn_finalize* fin, er_stream_t stream) {
+  ER_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0, "er_gemm_f32_deferred: bad arguments");
+  ER_REQUIRE(layout >= ER_GEMM_NN && layout <= ER_GEMM_TN, "er_gemm_f32_deferred: unknown layout %d", layout);
+  const int min_lda = (layout == ER_GEMM_TN) ? M : K;
+  const int min_ldb = (layout == ER_GEMM_NT) ? K : N;
+  ER_REQUIRE(lda >= min_lda && ldb >= min_ldb && ldc >= N, "er_gemm_f32_deferred: leading dimension too small");
+  ER_REQUIRE(!fin || (col_stats && fin->save_mean && fin->save_invstd && fin->counters && !accumulate),
+             "er_gemm_f32_deferred: finalising the statistics needs col_stats, save_mean, save_invstd, counters and a plain output");
+  ER_REQUIRE(!fin || er::ceil_div(N, er::BN) <= fin->n_counters / 2,
+             "er_gemm_f32_deferred: %d column tiles need %d counter words", static_cast<int>(er::ceil_div(N, er::BN)),
+             static_cast<int>(2 * er::ceil_div(N, er::BN)));
+  er::GemmArgs a;
+  a.A = A; a.B = B; a.C = C; a.bias = bias;
+  a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
+  a.accumulate = accumulate;
+  a.col_stats = col_stats;
+  a.splits = 1;
+  a.k_per_split = static_cast<int>(er::ceil_div(K, er::BK32)) * er::BK32;
+  if (at && at->mean) {
+    ER_REQUIRE(at->invstd, "er_gemm_f32_deferred: A transform without invstd");
+    ER_REQUIRE(layout != ER_GEMM_NT, "er_gemm_f32_deferred: the A transform is defined for [batch, features] operands (NN, TN)");
+    ER_REQUIRE(layout == ER_GEMM_TN || K <= er::kTrMaxK - 64, "er_gemm_f32_deferred: A transform over K = %d features (limit %d)",
+               K, er::kTrMaxK - 64);
+    a.at.mean = at->mean; a.at.invstd = at->invstd; a.at.gamma = at->gamma; a.at.beta = at->beta; a.at.act = at->act;
+  }
+  if (fin) {
+    a.fu.mode = 3;
+    a.fu.eps = fin->eps; a.fu.momentum = fin->momentum;
+    a.fu.moving_mean = fin->moving_mean; a.fu.moving_var = fin->moving_var;
+    a.fu.save_mean = fin->save_mean; a.fu.save_invstd = fin->save_invstd;
+    a.fu.counters = reinterpret_cast<unsigned*>(fin->counters);
+  }
+  return launch_gemm<false>(layout, a, er::as_stream(stream));
+}
+
+int er_gemm_f32_bn_bwd_z(int layout, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B,
+                         int32_t ldb, float* C, int32_t ldc, const float* z, const float* z_bias, const float* gamma,
+                         const float* beta, const float* save_mean, const float* save_invstd, int32_t ld_z, int use_bn,
+                         int act, float* partial, er_stream_t stream) {
+  ER_REQUIRE(z && partial && ld_z >= N, "er_gemm_f32_bn_bwd_z: bad epilogue arguments");
+  ER_REQUIRE(!use_bn || (save_mean && save_invstd), "er_gemm_f32_bn_bwd_z: BatchNorm statistics missing");
+  er::BnBwdEpi e;
+  e.z = z; e.zbias = z_bias; e.y = nullptr; e.mean = save_mean; e.invstd = save_invstd;
+  e.gamma = gamma; e.beta = beta;
+  e.ld = ld_z; e.use_bn = use_bn; e.act = act; e.partial = partial;
+  return gemm_entry<false>(layout, M, N, K, A, lda, B, ldb, C, ldc, nullptr, 0, nullptr, stream, "er_gemm_f32_bn_bwd_z", &e);
 }
 
 int er_gemm_f32(int layout, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B, int32_t ldb,

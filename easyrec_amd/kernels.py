@@ -84,10 +84,11 @@ class WgradSink(object):
     self.active = False
     self.queue = []
 
-  def put(self, x, dy, out, bf16):
+  def put(self, x, dy, out, bf16, at=None):
+    """at: the BnSource of a DEFERRED producer of x (x holds its pre-normalisation values: the GEMM transforms them)"""
     if not self.active or bf16:
       return False
-    self.queue.append((x, dy, out, None, True))
+    self.queue.append((x, dy, out, None, True, at))
     return True
 
 
@@ -97,13 +98,21 @@ class BnSource(object):
   consumer is the ONLY reader of y (`exclusive`, set by the layer stacks for their inner layers), to finish that
   layer's BatchNorm backward itself (HipBackend.gemm_bn_bwd_apply): then also gamma and the gradient buffers."""
   __slots__ = ('z', 'zbias', 'y', 'mean', 'invstd', 'act', 'partial', 'dx_ptr', 'gamma', 'grad_bufs', 'exclusive',
-               'dz_ptr')
+               'dz_ptr', 'beta', 'fused')
 
-  def __init__(self, z, zbias, y, mean, invstd, act, gamma=None, grad_bufs=None):
+  def __init__(self, z, zbias, y, mean, invstd, act, gamma=None, grad_bufs=None, beta=None, fused=True):
     self.z, self.zbias, self.y, self.mean, self.invstd, self.act = z, zbias, y, mean, invstd, act
     self.partial, self.dx_ptr = None, 0
     self.gamma, self.grad_bufs = gamma, grad_bufs  # grad_bufs = (gamma.grad, beta.grad) slices of the flat buffer
     self.exclusive, self.dz_ptr = False, 0
+    # DEFERRED layer (y is None): the activation output was never written; the tensor handed to the next layer holds z and
+    # every reader applies act(BN(z)) itself (include/easyrec_hip.h er_a_transform) - which needs beta as well.
+    # fused: the consumer's dgrad GEMM may emit this layer's BatchNorm-backward column sums (HipBackend.fused_bn_bwd)
+    self.beta, self.fused = beta, fused
+
+  @property
+  def deferred(self):
+    return self.y is None
 
 
 def mark_single_consumer(y):
@@ -133,16 +142,44 @@ def grad_sink_of(x, col0=0, width=None):
 def bn_source_of(x):
   """The BnSource of x if x IS the untouched 2-D output of a fused dense + BatchNorm + activation layer."""
   src = getattr(x, '_er_bn_src', None)
-  if src is None or x.dim() != 2 or x.data_ptr() != src.y.data_ptr() or x.shape != src.y.shape or \
-      x.stride() != src.y.stride():
+  if src is None:
+    return None
+  ref = src.y if src.y is not None else src.z
+  if x.dim() != 2 or x.data_ptr() != ref.data_ptr() or x.shape != ref.shape or x.stride() != ref.stride():
+    assert src.y is not None, 'easyrec_amd: a view of a deferred dense + BatchNorm output reached a layer (it holds ' \
+        'pre-normalisation values: only the untouched tensor may be consumed)'
     return None
   return src
+
+
+class ATransform(ctypes.Structure):  # = er_a_transform
+  _fields_ = [('mean', ctypes.c_void_p), ('invstd', ctypes.c_void_p), ('gamma', ctypes.c_void_p), ('beta', ctypes.c_void_p),
+              ('act', ctypes.c_int32)]
+
+
+class BnFinalize(ctypes.Structure):  # = er_bn_finalize
+  _fields_ = [('save_mean', ctypes.c_void_p), ('save_invstd', ctypes.c_void_p), ('moving_mean', ctypes.c_void_p),
+              ('moving_var', ctypes.c_void_p), ('eps', ctypes.c_float), ('momentum', ctypes.c_float),
+              ('counters', ctypes.c_void_p), ('n_counters', ctypes.c_int32)]
+
+
+def _ptr(t):
+  return None if t is None else t.data_ptr()
+
+
+def _a_transform(at):
+  """er_a_transform of a deferred BnSource (or None)"""
+  if at is None:
+    return None
+  return ATransform(_ptr(at.mean), _ptr(at.invstd), _ptr(at.gamma), _ptr(at.beta), int(at.act))
 
 
 class GemmProblem(ctypes.Structure):  # = er_gemm_problem
   _fields_ = [('M', ctypes.c_int32), ('N', ctypes.c_int32), ('K', ctypes.c_int32), ('A', ctypes.c_void_p),
               ('lda', ctypes.c_int32), ('B', ctypes.c_void_p), ('ldb', ctypes.c_int32), ('C', ctypes.c_void_p),
-              ('ldc', ctypes.c_int32), ('bias', ctypes.c_void_p), ('accumulate', ctypes.c_int32)]
+              ('ldc', ctypes.c_int32), ('bias', ctypes.c_void_p), ('accumulate', ctypes.c_int32),
+              ('a_mean', ctypes.c_void_p), ('a_invstd', ctypes.c_void_p), ('a_gamma', ctypes.c_void_p),
+              ('a_beta', ctypes.c_void_p), ('a_act', ctypes.c_int32)]
 
 
 CROSS_HASH_KEY = 0xDECAFCAFFE  # tf.sparse.cross_hashed's default hash_key (crossed_column(hash_key=None))
@@ -700,11 +737,18 @@ class HipBackend(object):
       (M, K), (N, K2) = a.shape, b.shape
     else:
       (K, M), (K2, N) = a.shape, b.shape
-    assert K == K2 and src.y.shape == (M, N) and src.z.shape == (M, N) and src.y.stride() == src.z.stride()
+    assert K == K2 and src.z.shape == (M, N) and (src.y is None or (src.y.shape == (M, N) and src.y.stride() == src.z.stride()))
     assert partial.numel() >= self.gemm_row_tiles(M) * N * 2
     self._log_gemm('gemm_f32_bn_bwd_kernel', layout, M, N, K)
     out = torch.empty(M, N, dtype=torch.float32, device=a.device)
     use_bn = src.mean is not None
+    if src.y is None:  # deferred producer: the ReLU mask is recomputed from z
+      self._ck(self.lib.er_gemm_f32_bn_bwd_z(ctypes.c_int(layout), M, N, K, _p(a), ctypes.c_int32(a.stride(0)), _p(b),
+                                             ctypes.c_int32(b.stride(0)), _p(out), ctypes.c_int32(out.stride(0)),
+                                             _p(src.z), _p(src.zbias), _p(src.gamma), _p(src.beta), _p(src.mean),
+                                             _p(src.invstd), ctypes.c_int32(src.z.stride(0)), int(use_bn), int(src.act),
+                                             _p(partial), _stream()), 'er_gemm_f32_bn_bwd_z')
+      return out
     self._ck(self.lib.er_gemm_f32_bn_bwd(ctypes.c_int(layout), M, N, K, _p(a), ctypes.c_int32(a.stride(0)), _p(b),
                                          ctypes.c_int32(b.stride(0)), _p(out), ctypes.c_int32(out.stride(0)),
                                          _p(src.z), _p(src.zbias), _p(src.y), _p(src.mean), _p(src.invstd),
@@ -712,10 +756,62 @@ class HipBackend(object):
                                          _stream()), 'er_gemm_f32_bn_bwd')
     return out
 
+  # -- deferred BatchNorm + activation (include/easyrec_hip.h er_a_transform / er_bn_finalize)
+  deferred_bn = os.environ.get('EASYREC_AMD_DEFER_BN', '1') != '0'  # A/B switch
+
+  def _bn_counters(self, device):
+    """arrival counters of er_bn_finalize: one zero-initialised buffer per calling thread and device (the launches of one
+    thread are stream-ordered; the simulated ranks of the tests are threads)"""
+    bufs = getattr(_bn_tls, 'counters', None)
+    if bufs is None:
+      bufs = _bn_tls.counters = {}
+    key = str(device)
+    if key not in bufs:
+      bufs[key] = torch.zeros(512, dtype=torch.int32, device=device)
+    return bufs[key]
+
+  def gemm_deferred(self, layout, a, b, at=None, out=None, bias=None, accumulate=False, col_stats=None, fin=None):
+    """gemm() with the A operand transformed while staged (at: the BnSource of a deferred layer whose z `a` holds) and /
+    or the output's batch statistics finalised by the launch (fin = (save_mean, save_invstd, moving_mean, moving_var, eps,
+    momentum); needs col_stats)."""
+    assert a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1
+    assert a.dtype == torch.float32 and b.dtype == torch.float32
+    if layout == GEMM_NN:
+      (M, K), (K2, N) = a.shape, b.shape
+    elif layout == GEMM_NT:
+      (M, K), (N, K2) = a.shape, b.shape
+    else:
+      (K, M), (K2, N) = a.shape, b.shape
+    assert K == K2, 'gemm: inner dimensions %d vs %d' % (K, K2)
+    if out is None:
+      assert not accumulate
+      out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    assert out.shape == (M, N) and out.stride(1) == 1 and out.dtype == torch.float32
+    self._log_gemm('gemm_f32_tr_kernel' if at is not None else 'gemm_f32_kernel', layout, M, N, K)
+    tr = _a_transform(at)
+    fz = None
+    if fin is not None:
+      mean, invstd, mm, mv, eps, momentum = fin
+      assert col_stats is not None and col_stats.numel() >= self.gemm_row_tiles(M) * N * 3
+      cnt = self._bn_counters(a.device)
+      fz = BnFinalize(_ptr(mean), _ptr(invstd), _ptr(mm), _ptr(mv), float(eps), float(momentum), cnt.data_ptr(), cnt.numel())
+    self._ck(self.lib.er_gemm_f32_deferred(ctypes.c_int(layout), M, N, K, _p(a), ctypes.c_int32(a.stride(0)),
+                                           ctypes.byref(tr) if tr is not None else None, _p(b), ctypes.c_int32(b.stride(0)),
+                                           _p(out), ctypes.c_int32(out.stride(0)), _p(bias), int(bool(accumulate)),
+                                           _p(col_stats), ctypes.byref(fz) if fz is not None else None, _stream()),
+             'er_gemm_f32_deferred')
+    return out
+
   def gemm_grouped(self, layout, problems):
     """problems: [(a, b, out, bias, accumulate)] fp32, one layout: ONE launch (+ one for the split-K reduces)."""
     arr = (GemmProblem * len(problems))()
-    for q, (a, b, out, bias, accumulate) in zip(arr, problems):
+    for q, pr in zip(arr, problems):
+      a, b, out, bias, accumulate = pr[:5]
+      at = pr[5] if len(pr) > 5 else None
+      if at is not None:
+        assert layout != GEMM_NT and at.deferred
+        q.a_mean, q.a_invstd, q.a_gamma, q.a_beta, q.a_act = _ptr(at.mean), _ptr(at.invstd), _ptr(at.gamma), \
+            _ptr(at.beta), int(at.act)
       assert a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1 and out.stride(1) == 1
       assert a.dtype == torch.float32 and b.dtype == torch.float32 and out.dtype == torch.float32
       if layout == GEMM_NN:
@@ -1173,10 +1269,11 @@ class HipBackend(object):
     return out
 
   def bn_act_bwd(self, x, bias, gamma, y, mean, invstd, dy, use_bn, act, need_bias, need_affine, into=None,
-                 partial=None):
+                 partial=None, beta=None):
     """into = (dbias_buf, dgamma_buf, dbeta_buf) (each may be None): accumulate the parameter gradients
     into those buffers (slices of the flat gradient buffer) instead of returning new tensors.
-    partial: column sums [gemm_row_tiles(B)][N][2] already produced by gemm_bn_bwd (skips that pass)."""
+    partial: column sums [gemm_row_tiles(B)][N][2] already produced by gemm_bn_bwd (skips that pass).
+    y None (a deferred layer: never written): the activation's mask is recomputed from x with gamma / beta."""
     B, N = x.shape
     dx = torch.empty_like(x)
     dev = x.device
@@ -1188,7 +1285,14 @@ class HipBackend(object):
       dgamma = torch.empty(N, dtype=torch.float32, device=dev) if need_affine else None
       dbeta = torch.empty(N, dtype=torch.float32, device=dev) if need_affine else None
     assert dy.dim() == 2 and dy.stride(1) == 1 and dy.dtype == torch.float32
-    if partial is None and dy.stride(0) != N:  # a column block of a wider gradient (ConcatFn's backward): read in place
+    if y is None:
+      dyl = dy if partial is None else _f32c(dy)
+      self._ck(
+          self.lib.er_bn_act_bwd_z(_p(x), _p(bias), _p(gamma), _p(beta), _p(mean), _p(invstd), _p(dyl),
+                                   ctypes.c_int32(dyl.stride(0)), B, N, int(use_bn), int(act), _p(partial),
+                                   ctypes.c_int32(self.gemm_row_tiles(B) if partial is not None else 0), _p(dx),
+                                   _p(dbias), _p(dgamma), _p(dbeta), int(acc), _stream()), 'er_bn_act_bwd_z')
+    elif partial is None and dy.stride(0) != N:  # a column block of a wider gradient (ConcatFn's backward): read in place
       self._ck(
           self.lib.er_bn_act_bwd_ld(_p(x), _p(bias), _p(gamma), _p(y), _p(mean), _p(invstd), _p(dy),
                                     ctypes.c_int32(dy.stride(0)), B, N, int(use_bn), int(act), _p(dx), _p(dbias),
@@ -1466,12 +1570,17 @@ class LinearFn(torch.autograd.Function):
   def forward(ctx, x, w, b, w_grad, b_grad, bf16, src=None, sink=None):
     be = hip()
     x2 = x if x.stride(-1) == 1 else x.contiguous()
-    y = be.gemm(GEMM_NN, x2, w, bias=b, bf16=bf16)
+    at = src if (src is not None and src.deferred) else None  # x holds a deferred layer's z: transformed by the GEMM
+    assert at is None or (x2 is x and not bf16)
+    if at is not None:
+      y = be.gemm_deferred(GEMM_NN, x2, w, at=at, bias=b)
+    else:
+      y = be.gemm(GEMM_NN, x2, w, bias=b, bf16=bf16)
     ctx.save_for_backward(x2, w)
     ctx.has_bias = b is not None
-    ctx.w_grad, ctx.b_grad, ctx.bf16 = w_grad, b_grad, bf16
+    ctx.w_grad, ctx.b_grad, ctx.bf16, ctx.at = w_grad, b_grad, bf16, at
     ctx.sink = be.wgrad_sink()
-    ctx.src = src if (src is not None and x2 is x and not bf16 and getattr(be, 'fused_bn_bwd', False)) else None
+    ctx.src = src if (src is not None and x2 is x and not bf16 and src.fused and getattr(be, 'fused_bn_bwd', False)) else None
     ctx.gsink = sink if x2 is x else None
     return y
 
@@ -1484,17 +1593,28 @@ class LinearFn(torch.autograd.Function):
     if ctx.needs_input_grad[0]:
       dx = _dgrad(be, dy, w, ctx.src, ctx.bf16, ctx.gsink)
     if ctx.needs_input_grad[1]:
-      if ctx.w_grad is not None:
-        if not ctx.sink.put(x, dy, ctx.w_grad, ctx.bf16):
-          be.gemm(GEMM_TN, x, dy, out=ctx.w_grad, accumulate=True, bf16=ctx.bf16)
-      else:
-        dw = be.gemm(GEMM_TN, x, dy, bf16=ctx.bf16)
+      dw = _wgrad(be, x, dy, ctx.w_grad, ctx.bf16, ctx.at, ctx.sink)
     if ctx.has_bias and ctx.needs_input_grad[2]:
       if ctx.b_grad is not None:
         be.colsum(dy, out=ctx.b_grad, accumulate=True)  # straight into the flat gradient buffer
       else:
         db = be.colsum(dy)
     return dx, dw, db, None, None, None, None, None
+
+
+def _wgrad(be, x, dz, w_grad, bf16, at, sink):
+  """dW = x^T . dz: queued for the grouped launch (accumulating into w_grad, a slice of the flat gradient buffer), else
+  launched here; `at`: x holds a deferred layer's z and is transformed while staged.  Returns dW only without w_grad."""
+  if w_grad is not None:
+    if not sink.put(x, dz, w_grad, bf16, at):
+      if at is not None:
+        be.gemm_deferred(GEMM_TN, x, dz, at=at, out=w_grad, accumulate=True)
+      else:
+        be.gemm(GEMM_TN, x, dz, out=w_grad, accumulate=True, bf16=bf16)
+    return None
+  if at is not None:
+    return be.gemm_deferred(GEMM_TN, x, dz, at=at)
+  return be.gemm(GEMM_TN, x, dz, bf16=bf16)
 
 
 def _dgrad(be, dz, w, src, bf16, sink=None):
@@ -1509,7 +1629,8 @@ def _dgrad(be, dz, w, src, bf16, sink=None):
   if src is None:
     return be.gemm(GEMM_NT, dz, w, bf16=bf16)
   M, N = dz.shape[0], w.shape[0]
-  if src.exclusive and src.grad_bufs is not None and getattr(be, 'gemm_fused_bn_ok', None) and be.gemm_fused_bn_ok(M, N):
+  if src.exclusive and src.y is not None and src.grad_bufs is not None and getattr(be, 'gemm_fused_bn_ok', None) and \
+      be.gemm_fused_bn_ok(M, N):
     # this GEMM is the only reader of the producing layer's output: finish that layer's BatchNorm backward here
     dx = be.gemm_bn_bwd_apply(GEMM_NT, dz, w, src)
     src.dz_ptr = dx.data_ptr()
@@ -1529,11 +1650,31 @@ class LinearBNActFn(torch.autograd.Function):
 
   @staticmethod
   def forward(ctx, x, w, b, gamma, beta, moving_mean, moving_var, eps, momentum, act, bf16, grad_bufs, src=None,
-              sink=None):
+              sink=None, defer=False):
+    """defer: do not write y - return z tagged as a DEFERRED output (BnSource.deferred); the caller guarantees that
+    every reader is a dense layer of this package (layers/dnn.py: the inner layers of a stack)."""
     be = hip()
     x2 = x if x.stride(-1) == 1 else x.contiguous()
     M, N = x2.shape[0], w.shape[1]
-    if not bf16 and getattr(be, 'gemm_fused_bn_ok', None) and be.gemm_fused_bn_ok(M, N):
+    at = src if (src is not None and src.deferred) else None  # x holds a deferred layer's z: transformed by the GEMM
+    assert at is None or (x2 is x and not bf16)
+    defer = bool(defer) and not bf16 and getattr(be, 'deferred_bn', False)
+    y = None
+    if defer or at is not None:
+      chunks = be.gemm_row_tiles(M)
+      stats = torch.empty(chunks * N * 3, dtype=torch.float32, device=x2.device)
+      if defer:
+        # ONE launch: GEMM (+ the producer's BatchNorm / ReLU on its A operand) + bias + column statistics, finalised by
+        # the last workgroup of each column of tiles; y is never written
+        mean = torch.empty(N, dtype=torch.float32, device=x2.device)
+        invstd = torch.empty(N, dtype=torch.float32, device=x2.device)
+        z = be.gemm_deferred(GEMM_NN, x2, w, at=at, bias=b, col_stats=stats,
+                             fin=(mean, invstd, moving_mean, moving_var, eps, momentum))
+      else:
+        z = be.gemm_deferred(GEMM_NN, x2, w, at=at, bias=b, col_stats=stats)
+        y, mean, invstd = be.bn_apply_from_stats(z, None, stats, chunks, gamma, beta, eps, momentum, moving_mean,
+                                                 moving_var, act)
+    elif not bf16 and getattr(be, 'gemm_fused_bn_ok', None) and be.gemm_fused_bn_ok(M, N):
       # ONE launch: GEMM, statistics, barrier, normalise + activation from registers
       z, y, mean, invstd = be.gemm_bn_fwd(x2, w, b, gamma, beta, eps, momentum, moving_mean, moving_var, act)
     else:
@@ -1542,21 +1683,22 @@ class LinearBNActFn(torch.autograd.Function):
       z = be.gemm(GEMM_NN, x2, w, bias=b, bf16=bf16, col_stats=stats)
       y, mean, invstd = be.bn_apply_from_stats(z, None, stats, chunks, gamma, beta, eps, momentum, moving_mean,
                                                moving_var, act)
-    ctx.save_for_backward(x2, w, gamma, z, y, mean, invstd)
-    ctx.act, ctx.bf16, ctx.grad_bufs = act, bf16, grad_bufs
+    ctx.save_for_backward(x2, w, gamma, beta, z, y, mean, invstd)
+    ctx.act, ctx.bf16, ctx.grad_bufs, ctx.at = act, bf16, grad_bufs, at
     ctx.sink = be.wgrad_sink()
     fused = not bf16 and getattr(be, 'fused_bn_bwd', False)
-    ctx.src = src if (src is not None and x2 is x and fused) else None
+    ctx.src = src if (src is not None and x2 is x and fused and src.fused) else None
     ctx.gsink = sink if x2 is x else None
     gb = None if grad_bufs is None else (grad_bufs[1], grad_bufs[2])
-    ctx.own = BnSource(z, None, y, mean, invstd, act, gamma, gb) if fused else None  # z already carries the bias
+    # (z already carries the bias)
+    ctx.own = BnSource(z, None, y, mean, invstd, act, gamma, gb, beta=beta, fused=fused) if (fused or defer) else None
     _bn_tls.last = ctx.own
-    return y
+    return z if defer else y
 
   @staticmethod
   def backward(ctx, dy):
     be = hip()
-    x, w, gamma, z, y, mean, invstd = ctx.saved_tensors
+    x, w, gamma, beta, z, y, mean, invstd = ctx.saved_tensors
     wg, gg, betag = ctx.grad_bufs if ctx.grad_bufs is not None else (None, None, None)
     direct = gg is not None and betag is not None
     # (a column block of a wider gradient - ConcatFn's backward - is read in place by the BatchNorm backward)
@@ -1577,17 +1719,13 @@ class LinearBNActFn(torch.autograd.Function):
           partial = own.partial
         own.partial = None
       dz, _, dgamma, dbeta = be.bn_act_bwd(z, None, gamma, y, mean, invstd, dyc, 1, ctx.act, False, True,
-                                           into=(None, gg, betag) if direct else None, partial=partial)
+                                           into=(None, gg, betag) if direct else None, partial=partial, beta=beta)
     dx = dw = None
     if ctx.needs_input_grad[0]:
       dx = _dgrad(be, dz, w, ctx.src, ctx.bf16, ctx.gsink)
     if ctx.needs_input_grad[1]:
-      if wg is not None:
-        if not ctx.sink.put(x, dz, wg, ctx.bf16):
-          be.gemm(GEMM_TN, x, dz, out=wg, accumulate=True, bf16=ctx.bf16)
-      else:
-        dw = be.gemm(GEMM_TN, x, dz, bf16=ctx.bf16)
-    return dx, dw, None, dgamma, dbeta, None, None, None, None, None, None, None, None, None
+      dw = _wgrad(be, x, dz, wg, ctx.bf16, ctx.at, ctx.sink)
+    return dx, dw, None, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
 
 
 class FMFn(torch.autograd.Function):

@@ -624,8 +624,49 @@ typedef struct er_gemm_problem {
   float* C; int32_t ldc;
   const float* bias;
   int32_t accumulate;
+  /* a_mean != NULL: A is the never-written output of a dense + BatchNorm + activation layer (er_a_transform below) */
+  const float* a_mean; const float* a_invstd; const float* a_gamma; const float* a_beta;
+  int32_t a_act;
 } er_gemm_problem;
 int er_gemm_grouped_f32(int layout, const er_gemm_problem* problems_host, int n, er_stream_t stream);
+/* DEFERRED BatchNorm + activation (reference layers/dnn.py:57-79: dense -> batch_normalization -> relu per layer).
+ * The reference materialises every intermediate; here a hidden layer of a stack writes only its pre-normalisation
+ * values z (bias included) and its batch statistics, and every reader of its activation output y = act(BN(z)) -
+ * the next layer's forward GEMM, the next layer's weight-gradient GEMM, the ReLU mask of its own backward - applies
+ *     y = act(((z - mean[f]) * invstd[f]) * gamma[f] + beta[f])
+ * itself (the operation sequence of er_bn_apply_from_stats: a recomputed y has the bits of a materialised one):
+ *   er_a_transform: operand A ([batch, features] row-major: layouts NN and TN) is transformed while the GEMM stages
+ *     it into LDS (parameter table of the features in LDS; NN: K <= 960).  mean == NULL: A as it is.
+ *   er_bn_finalize: the GEMM emits per-row-tile column statistics of its output (col_stats: [er_gemm_row_tiles(M)][N]
+ *     [3]) and the workgroup that is LAST to deliver a partial for a column of tiles (arrival counter, no barrier, no
+ *     spinning) merges them in er_bn_apply_from_stats' order into save_mean / save_invstd and moves the moving
+ *     statistics (NULL: not touched).  counters: device int32 [n_counters >= 2 * ceil(N / 64)], zero before the first
+ *     launch; every launch leaves them zero.  One buffer per stream (launches of one stream are ordered).
+ *   er_gemm_f32_deferred: C (+)= op(A') . op(B) (+ bias) with either or both (`at`, `fin` may be NULL).
+ *   er_gemm_f32_bn_bwd_z: er_gemm_f32_bn_bwd for a producing layer whose y was never written: the mask is recomputed
+ *     from z, z_bias, the statistics and gamma / beta.
+ *   er_bn_act_bwd_z: er_bn_act_bwd(_ld / _from_partials) likewise (partial NULL: the column sums are computed first). */
+typedef struct er_a_transform {
+  const float* mean; const float* invstd; const float* gamma; const float* beta;
+  int32_t act;
+} er_a_transform;
+typedef struct er_bn_finalize {
+  float* save_mean; float* save_invstd; float* moving_mean; float* moving_var;
+  float eps, momentum;
+  int32_t* counters; int32_t n_counters;
+} er_bn_finalize;
+int er_gemm_f32_deferred(int layout, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda,
+                         const er_a_transform* at, const float* B, int32_t ldb, float* C, int32_t ldc,
+                         const float* bias, int accumulate, float* col_stats, const er_bn_finalize* fin,
+                         er_stream_t stream);
+int er_gemm_f32_bn_bwd_z(int layout, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B,
+                         int32_t ldb, float* C, int32_t ldc, const float* z, const float* z_bias, const float* gamma,
+                         const float* beta, const float* save_mean, const float* save_invstd, int32_t ld_z, int use_bn,
+                         int act, float* partial, er_stream_t stream);
+int er_bn_act_bwd_z(const float* z, const float* bias, const float* gamma, const float* beta, const float* save_mean,
+                    const float* save_invstd, const float* dy, int32_t dy_ld, int32_t B, int32_t N, int use_bn, int act,
+                    const float* partial, int32_t chunks, float* dx, float* dbias, float* dgamma, float* dbeta,
+                    int accumulate, er_stream_t stream);
 int er_gemm_f32(int layout, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B,
                 int32_t ldb, float* C, int32_t ldc, const float* bias, int accumulate, float* col_stats,
                 er_stream_t stream);

@@ -669,6 +669,72 @@ def test_batchnorm_fused_into_the_gemm_launch(hip, M, N, K):
     assert torch.equal(dg_a, dg_b) and torch.equal(db_a, db_b), rep
 
 
+@pytest.mark.parametrize('M,N,K,N2', [(4096, 256, 624, 128), (4096, 128, 256, 64), (1000, 70, 33, 40), (8192, 64, 81, 1),
+                                      (20000, 40, 24, 32)])
+def test_deferred_batchnorm_changes_no_bit(hip, M, N, K, N2):
+  """A hidden dense + BatchNorm + ReLU layer WITHOUT its activation output (er_gemm_f32_deferred: statistics finalised
+  by the last workgroup of a column of tiles; the readers transform z while staging it) against the materialised form
+  (er_gemm_f32 + er_bn_apply_from_stats, then plain GEMMs over y), bit for bit:
+    forward of the next layer  y . W2          (NN, A transformed; also with its own statistics finalised)
+    weight gradient            y^T . dz2       (TN, A transformed; single launch and grouped with split-K)
+    dgrad + BatchNorm sums     dz2 . W2^T      (er_gemm_f32_bn_bwd_z: mask recomputed from z)
+    the layer's own backward   er_bn_act_bwd_z (with and without the column sums handed over)
+  repeated (the arrival counters reset themselves)."""
+  g = torch.Generator().manual_seed(M + N + K)
+  x, w = torch.randn(M, K, generator=g).to(DEV), (torch.randn(K, N, generator=g) * 0.1).to(DEV)
+  bias, gamma, beta = torch.randn(N, generator=g).to(DEV), (torch.rand(N, generator=g) + 0.5).to(DEV), torch.randn(N, generator=g).to(DEV)
+  w2 = (torch.randn(N, N2, generator=g) * 0.1).to(DEV)
+  b2 = torch.randn(N2, generator=g).to(DEV)
+  dz2 = (torch.randn(M, N2, generator=g) * 0.01).to(DEV)
+  chunks = hip.gemm_row_tiles(M)
+  for rep in range(3):
+    mm_a, mv_a = torch.zeros(N, device=DEV), torch.ones(N, device=DEV)
+    mm_b, mv_b = torch.zeros(N, device=DEV), torch.ones(N, device=DEV)
+    stats = torch.zeros(chunks * N * 3, device=DEV)
+    z_a = hip.gemm(kernels.GEMM_NN, x, w, bias=bias, col_stats=stats)
+    y_a, mean_a, inv_a = hip.bn_apply_from_stats(z_a, None, stats, chunks, gamma, beta, 1e-3, 0.99, mm_a, mv_a, kernels.ACT_RELU)
+    stats_b = torch.zeros(chunks * N * 3, device=DEV)
+    mean_b, inv_b = torch.empty(N, device=DEV), torch.empty(N, device=DEV)
+    z_b = hip.gemm_deferred(kernels.GEMM_NN, x, w, bias=bias, col_stats=stats_b, fin=(mean_b, inv_b, mm_b, mv_b, 1e-3, 0.99))
+    torch.cuda.synchronize()
+    for a, b, what in ((z_a, z_b, 'z'), (mean_a, mean_b, 'mean'), (inv_a, inv_b, 'invstd'), (mm_a, mm_b, 'moving_mean'),
+                       (mv_a, mv_b, 'moving_variance')):
+      assert torch.equal(a, b), (rep, what)
+    src = kernels.BnSource(z_b, None, None, mean_b, inv_b, kernels.ACT_RELU, gamma, None, beta=beta)
+    assert src.deferred
+    # next layer forward, plain and with its own statistics
+    o_a = hip.gemm(kernels.GEMM_NN, y_a, w2, bias=b2)
+    o_b = hip.gemm_deferred(kernels.GEMM_NN, z_b, w2, at=src, bias=b2)
+    st2_a, st2_b = torch.zeros(chunks * N2 * 3, device=DEV), torch.zeros(chunks * N2 * 3, device=DEV)
+    m2, i2 = torch.empty(N2, device=DEV), torch.empty(N2, device=DEV)
+    p_a = hip.gemm(kernels.GEMM_NN, y_a, w2, bias=b2, col_stats=st2_a)
+    p_b = hip.gemm_deferred(kernels.GEMM_NN, z_b, w2, at=src, bias=b2, col_stats=st2_b, fin=(m2, i2, None, None, 1e-3, 0.99))
+    # weight gradient: single launch, and grouped (split-K over the batch)
+    dw_a = hip.gemm(kernels.GEMM_TN, y_a, dz2)
+    dw_b = hip.gemm_deferred(kernels.GEMM_TN, z_b, dz2, at=src)
+    gw_a, gw_b = torch.full((N, N2), 0.5, device=DEV), torch.full((N, N2), 0.5, device=DEV)
+    hip.gemm_grouped(kernels.GEMM_TN, [(y_a, dz2, gw_a, None, True)])
+    hip.gemm_grouped(kernels.GEMM_TN, [(z_b, dz2, gw_b, None, True, src)])
+    # dgrad with the BatchNorm-backward column sums of the producing layer, then that layer's own backward
+    src_a = kernels.BnSource(z_a, None, y_a, mean_a, inv_a, kernels.ACT_RELU, gamma, None)
+    part_a, part_b = torch.zeros(chunks * N * 2, device=DEV), torch.zeros(chunks * N * 2, device=DEV)
+    dy_a = hip.gemm_bn_bwd(kernels.GEMM_NT, dz2, w2, src_a, part_a)
+    dy_b = hip.gemm_bn_bwd(kernels.GEMM_NT, dz2, w2, src, part_b)
+    r_a = hip.bn_act_bwd(z_a, None, gamma, y_a, mean_a, inv_a, dy_a, 1, kernels.ACT_RELU, False, True, partial=part_a)
+    r_b = hip.bn_act_bwd(z_b, None, gamma, None, mean_b, inv_b, dy_b, 1, kernels.ACT_RELU, False, True, partial=part_b, beta=beta)
+    q_a = hip.bn_act_bwd(z_a, None, gamma, y_a, mean_a, inv_a, dy_a, 1, kernels.ACT_RELU, False, True)
+    q_b = hip.bn_act_bwd(z_b, None, gamma, None, mean_b, inv_b, dy_b, 1, kernels.ACT_RELU, False, True, beta=beta)
+    torch.cuda.synchronize()
+    for a, b, what in ((o_a, o_b, 'next forward'), (p_a, p_b, 'next forward + statistics'), (st2_a, st2_b, 'next statistics'),
+                       (dw_a, dw_b, 'dW'), (gw_a, gw_b, 'grouped dW'), (dy_a, dy_b, 'dgrad'), (part_a, part_b, 'column sums'),
+                       (r_a[0], r_b[0], 'dz from partials'), (r_a[2], r_b[2], 'dgamma'), (r_a[3], r_b[3], 'dbeta'),
+                       (q_a[0], q_b[0], 'dz'), (q_a[2], q_b[2], 'dgamma (own sums)')):
+      assert torch.equal(a, b), (rep, what, float((a - b).abs().max()))
+    zr = p_b.cpu().double()
+    assert torch.allclose(m2.cpu().double(), zr.mean(dim=0), rtol=1e-5, atol=1e-5)
+    assert torch.allclose(i2.cpu().double(), 1.0 / torch.sqrt(zr.var(dim=0, unbiased=False) + 1e-3), rtol=1e-5, atol=1e-6)
+
+
 def test_lazy_dense_decay_equals_the_sweep(hip):
   """TF-exact Adam two ways over 1300 steps on one table: (A) the streaming sweep of every row every step,
   (B) lazy dense decay (er_emb_route -> er_emb_catch_up -> touched-row update, er_emb_flush_decay at the end).
