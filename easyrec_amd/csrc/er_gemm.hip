@@ -803,6 +803,162 @@ gemm_f32_grouped_tr_kernel(GroupedArgs ga) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// TN with a 128 x 128 tile: the weight gradients dW = x^T . dz contract over the BATCH (K = 4,096 ... 204,800) into a
+// small M x N, so the launch is bound by operand delivery, not by the matrix cores: a 64 x 64 tile moves (64 + 64) * 4 B
+// per k for 8,192 flops (16 flop / B: x is re-read by every column tile, dz by every row tile), a 128 x 128 tile 32
+// flop / B.  Same LDS layout ([mn][k], row stride 36), same staging of the two mn-contiguous operands (a unit = 4
+// consecutive mn at one k, four conflict-free ds_write_b32), same two-register-set pipeline and the same fixed
+// contraction order per accumulator as gemm_f32_block; a wave owns 64 x 64 = 2 x 2 accumulators, so each pair of
+// fragment reads feeds two MFMAs instead of one.  73.7 KB of LDS (dynamic: er_gemm_reserve raises the limit).
+// Plain epilogue only (split-K workspace or C (+)=): what the grouped weight-gradient launch needs.
+// ------------------------------------------------------------------------------------------------
+constexpr int BM2 = 128;
+constexpr int kOpTile2 = BM2 * SK;
+constexpr int kTn128LdsBytes = 2 * 2 * kOpTile2 * static_cast<int>(sizeof(float));
+
+__device__ __forceinline__ void unit_pos128(int tid, int i, int& row, int& k) {
+  row = (tid >> 4) * 4 + 64 * (i >> 1);
+  k = (tid & 15) + 16 * (i & 1);
+}
+
+__device__ __forceinline__ void fetch_tile128(const float* __restrict__ P, int ld, int mn0, int MN, int k0, int kend, int tid,
+                                              f32x4v (&r)[4]) {
+  const int mnpad = (MN + 3) & ~3;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int row, k;
+    unit_pos128(tid, i, row, k);
+    int mn = mn0 + row;
+    k += k0;
+    mn = mn < mnpad - 4 ? mn : mnpad - 4;
+    k = k < kend ? k : kend - 1;
+    r[i] = *reinterpret_cast<const f32x4v*>(P + static_cast<int64_t>(k) * ld + mn);
+  }
+}
+
+__device__ __forceinline__ void stage_tile128(float* __restrict__ S, int tid, const f32x4v (&r)[4], bool interior, int mn0,
+                                              int MN, int k0, int kend) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int row, k;
+    unit_pos128(tid, i, row, k);
+    f32x4v v = r[i];
+    if (!interior) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (!(mn0 + row + j < MN && k0 + k < kend)) v[j] = 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) S[(row + j) * SK + k] = v[j];
+  }
+}
+
+__device__ __forceinline__ void gemm_f32_tn128_block(const GemmArgs& g, int bx, int bz, float* __restrict__ lds) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  int tx, ty;
+  if (!tile_coords(bx, static_cast<int>(ceil_div(g.N, BM2)), static_cast<int>(ceil_div(g.M, BM2)), tx, ty)) return;
+  const int m0 = ty * BM2, n0 = tx * BM2;
+  const int kbeg = bz * g.k_per_split;
+  int kend = kbeg + g.k_per_split;
+  if (kend > g.K) kend = g.K;
+  const int T = (kend - kbeg + BK32 - 1) / BK32;
+  const bool rows_full = (m0 + BM2 <= g.M) && (n0 + BM2 <= g.N);
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+  const int khalf = lane >> 5;
+  const int fa = (wm * 64 + (lane & 31)) * SK + khalf * 16;
+  const int fb = kOpTile2 + (wn * 64 + (lane & 31)) * SK + khalf * 16;
+  f32x4v ra0[4], rb0[4], ra1[4], rb1[4];
+  auto fetch = [&](f32x4v (&ra)[4], f32x4v (&rb)[4], int t) {
+    const int k0 = kbeg + (t < T ? t : T - 1) * BK32;
+    fetch_tile128(g.A, g.lda, m0, g.M, k0, kend, tid, ra);
+    fetch_tile128(g.B, g.ldb, n0, g.N, k0, kend, tid, rb);
+  };
+  auto stage = [&](int buf, const f32x4v (&ra)[4], const f32x4v (&rb)[4], int t) {
+    const int k0 = kbeg + t * BK32;  // unclamped: a tile past the end is masked to zero
+    const bool interior = rows_full && (k0 + BK32 <= kend);
+    stage_tile128(lds + buf * 2 * kOpTile2, tid, ra, interior, m0, g.M, k0, kend);
+    stage_tile128(lds + buf * 2 * kOpTile2 + kOpTile2, tid, rb, interior, n0, g.N, k0, kend);
+  };
+  auto step = [&](int buf, f32x4v (&fa_)[4], f32x4v (&fb_)[4], f32x4v (&sa)[4], f32x4v (&sb)[4], int t) {
+    const float* base = lds + buf * 2 * kOpTile2;
+    f32x4v a[2][4], b[2][4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        a[h][q] = *reinterpret_cast<const f32x4v*>(base + fa + h * 32 * SK + 4 * q);
+        b[h][q] = *reinterpret_cast<const f32x4v*>(base + fb + h * 32 * SK + 4 * q);
+      }
+    fetch(fa_, fb_, t + 2);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int c = 0; c < 2; ++c) acc[h][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[h][q][i], b[c][q][i], acc[h][c], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    stage(buf ^ 1, sa, sb, t + 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) acc[h][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[h][3][i], b[c][3][i], acc[h][c], 0, 0, 0);
+    __syncthreads();
+  };
+  fetch(ra0, rb0, 0);
+  fetch(ra1, rb1, 1);
+  stage(0, ra0, rb0, 0);
+  __syncthreads();
+  for (int t = 0; t < T; t += 2) {
+    step(0, ra0, rb0, ra1, rb1, t);
+    step(1, ra1, rb1, ra0, rb0, t + 1);
+  }
+  float* Cz = g.C + (g.splits > 1 ? static_cast<int64_t>(bz) * g.M * g.N : 0);
+  const int ldc = g.splits > 1 ? g.N : g.ldc;
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int col = n0 + wn * 64 + c * 32 + (lane & 31);
+      if (col >= g.N) continue;
+      const float bv = (g.bias && g.splits == 1) ? g.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + h * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+        if (row < g.M) {
+          float* p = Cz + static_cast<int64_t>(row) * ldc + col;
+          float v = acc[h][c][r] + bv;
+          if (g.accumulate && g.splits == 1) v = *p + v;
+          *p = v;
+        }
+      }
+    }
+}
+
+__global__ void __launch_bounds__(kBlock)
+gemm_f32_grouped_tn128_kernel(GroupedArgs ga) {
+  extern __shared__ __attribute__((aligned(16))) float lds128[];
+  const int b = blockIdx.x;
+  int p = 0;
+  while (p + 1 < ga.n && b >= ga.start[p + 1]) ++p;
+  const int local = b - ga.start[p];
+  gemm_f32_tn128_block(ga.p[p], local % ga.tiles8[p], local / ga.tiles8[p], lds128);
+}
+
+// ------------------------------------------------------------------------------------------------
 // bf16 inputs (rounded from fp32 while staging), fp32 accumulate.  LDS: As[m][k], Bs[n][k] in bf16, row
 // stride 40 halves (80 B): the 16-byte fragment reads of a 16-lane group hit 16 distinct bank quads.
 // Fragment of v_mfma_f32_32x32x16_bf16: lane l holds A[i = l & 31][k = 8 * (l >> 5) + 0..7].
@@ -1039,7 +1195,7 @@ int choose_splits(int M, int N, int K, int ktile) {
 template <bool BF16>
 int gemm_entry(int layout, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                const float* bias, int accumulate, float* col_stats, er_stream_t stream, const char* who,
-               const er::BnBwdEpi* bn = nullptr) {
+               const er::BnBwdEpi* bn = nullptr, const er::ATransform* at = nullptr, const er::BnFused* fu = nullptr) {
   ER_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0, "%s: bad arguments", who);
   ER_REQUIRE(layout >= ER_GEMM_NN && layout <= ER_GEMM_TN, "%s: unknown layout %d", who, layout);
   const int min_lda = (layout == ER_GEMM_TN) ? M : K;
@@ -1053,6 +1209,8 @@ int gemm_entry(int layout, int M, int N, int K, const float* A, int lda, const f
   a.accumulate = accumulate;
   a.col_stats = col_stats;
   if (bn) a.bn = *bn;
+  if (at) a.at = *at;
+  if (fu) a.fu = *fu;
   a.splits = (col_stats || bn) ? 1 : choose_splits(M, N, K, ktile);
   ER_REQUIRE(!(col_stats && accumulate), "%s: column statistics need a plain (non-accumulating) output", who);
   a.k_per_split = static_cast<int>(er::ceil_div(er::ceil_div(K, a.splits), ktile)) * ktile;
@@ -1076,9 +1234,24 @@ int gemm_entry(int layout, int M, int N, int K, const float* A, int lda, const f
   return launch_gemm<BF16>(layout, a, s);
 }
 
+bool g_tn128_ready = false;  // er_gemm_reserve raised the 128 x 128 kernel's LDS limit
+
+// A TN problem takes 128 x 128 tiles when both operands allow the 16-byte loads, neither dimension fits one 64-tile and
+// padding to 128 wastes no more than a third over padding to 64 (624 x 256, 256 x 128, 81 x 256: none; 320 x 128: 20 %)
+bool tn128_fits(int layout, const er_gemm_problem& q) {
+  static const bool off = [] { const char* e = getenv("ER_GEMM_TN128"); return e && atoi(e) == 0; }();  // A/B switch
+  if (off || !g_tn128_ready || layout != ER_GEMM_TN || q.a_mean || q.M <= er::BM || q.N <= er::BN) return false;
+  if (q.lda % 4 != 0 || q.ldb % 4 != 0 || ((reinterpret_cast<uintptr_t>(q.A) | reinterpret_cast<uintptr_t>(q.B)) & 15) != 0)
+    return false;
+  const int64_t a128 = er::ceil_div(q.M, er::BM2) * er::ceil_div(q.N, er::BM2) * 4;
+  const int64_t a64 = er::ceil_div(q.M, er::BM) * er::ceil_div(q.N, er::BN);
+  return 3 * a128 <= 4 * a64;
+}
+
 int gemm_grouped_f32(int layout, const er_gemm_problem* pr, int n, er_stream_t stream) {
   hipStream_t s = er::as_stream(stream);
   int64_t total_tiles = 0;
+  bool big[er::kMaxGroup];
   for (int i = 0; i < n; ++i) {
     const er_gemm_problem& q = pr[i];
     ER_REQUIRE(q.A && q.B && q.C && q.M > 0 && q.N > 0 && q.K > 0, "er_gemm_grouped_f32: problem %d: bad arguments", i);
@@ -1086,15 +1259,20 @@ int gemm_grouped_f32(int layout, const er_gemm_problem* pr, int n, er_stream_t s
     const int min_ldb = (layout == ER_GEMM_NT) ? q.K : q.N;
     ER_REQUIRE(q.lda >= min_lda && q.ldb >= min_ldb && q.ldc >= q.N,
                "er_gemm_grouped_f32: problem %d: leading dimension too small", i);
-    total_tiles += er::ceil_div(q.M, er::BM) * er::ceil_div(q.N, er::BN);
+    big[i] = tn128_fits(layout, q);
+    const int tile = big[i] ? er::BM2 : er::BM;
+    total_tiles += er::ceil_div(q.M, tile) * er::ceil_div(q.N, tile);
   }
   // k-splits: enough workgroups for ~2 per CU over the whole group (A/B: 512 beat 1024 and 2048), >= 4 k-tiles per split
   int64_t want = total_tiles >= 512 ? 1 : er::ceil_div(512, total_tiles);
   if (want > 64) want = 64;
-  er::GroupedArgs ga;
+  er::GroupedArgs ga, gb;  // the 64 x 64 problems | the 128 x 128 ones
   er::GroupedReduceArgs ra;
-  ga.n = n;
+  ga.n = 0;
   ga.start[0] = 0;
+  gb.n = 0;
+  gb.start[0] = 0;
+  er::GemmArgs* slot[er::kMaxGroup];  // where problem i's arguments live (the workspace base is patched in below)
   ra.n = 0;
   ra.start[0] = 0;
   size_t ws_floats = 0;
@@ -1102,7 +1280,10 @@ int gemm_grouped_f32(int layout, const er_gemm_problem* pr, int n, er_stream_t s
   bool any_tr = false;
   for (int i = 0; i < n; ++i) {
     const er_gemm_problem& q = pr[i];
-    er::GemmArgs& a = ga.p[i];
+    er::GroupedArgs& grp = big[i] ? gb : ga;
+    er::GemmArgs& a = grp.p[grp.n];
+    slot[i] = &a;
+    a = er::GemmArgs();
     a.A = q.A; a.B = q.B; a.C = q.C; a.bias = q.bias;
     a.M = q.M; a.N = q.N; a.K = q.K; a.lda = q.lda; a.ldb = q.ldb; a.ldc = q.ldc;
     a.accumulate = q.accumulate;
@@ -1130,9 +1311,11 @@ int gemm_grouped_f32(int layout, const er_gemm_problem* pr, int n, er_stream_t s
     if (sp < 1) sp = 1;
     a.k_per_split = static_cast<int>(er::ceil_div(er::ceil_div(q.K, sp), er::BK32)) * er::BK32;
     a.splits = static_cast<int>(er::ceil_div(q.K, a.k_per_split));
-    const int64_t tiles = er::ceil_div(q.M, er::BM) * er::ceil_div(q.N, er::BN);
-    ga.tiles8[i] = static_cast<int>(8 * er::ceil_div(tiles, 8));
-    ga.start[i + 1] = ga.start[i] + ga.tiles8[i] * a.splits;
+    const int tile = big[i] ? er::BM2 : er::BM;
+    const int64_t tiles = er::ceil_div(q.M, tile) * er::ceil_div(q.N, tile);
+    grp.tiles8[grp.n] = static_cast<int>(8 * er::ceil_div(tiles, 8));
+    grp.start[grp.n + 1] = grp.start[grp.n] + grp.tiles8[grp.n] * a.splits;
+    ++grp.n;
     if (a.splits > 1) {
       const int64_t mn = static_cast<int64_t>(q.M) * q.N;
       er::ReduceItem& r = ra.r[ra.n];
@@ -1150,9 +1333,9 @@ int gemm_grouped_f32(int layout, const er_gemm_problem* pr, int n, er_stream_t s
     if (int rc = ensure_ws(ws_floats, &ws)) return rc;
     int k = 0;
     for (int i = 0; i < n; ++i) {
-      if (ga.p[i].splits > 1) {
-        const size_t off = reinterpret_cast<size_t>(ga.p[i].C);
-        ga.p[i].C = ws + off;
+      if (slot[i]->splits > 1) {
+        const size_t off = reinterpret_cast<size_t>(slot[i]->C);
+        slot[i]->C = ws + off;
         ra.r[k].ws = ws + off;
         ++k;
       }
@@ -1162,8 +1345,15 @@ int gemm_grouped_f32(int layout, const er_gemm_problem* pr, int n, er_stream_t s
       ra.start[j + 1] = ra.start[j] + static_cast<int>(er::ceil_div(units, er::kBlock));
     }
   }
-  dim3 grid(static_cast<unsigned>(ga.start[n])), block(er::kBlock);
-  if (any_tr) {
+  dim3 grid(static_cast<unsigned>(ga.start[ga.n])), block(er::kBlock);
+  if (gb.n > 0) {
+    hipLaunchKernelGGL(er::gemm_f32_grouped_tn128_kernel, dim3(static_cast<unsigned>(gb.start[gb.n])), block,
+                       er::kTn128LdsBytes, s, gb);
+    ER_LAUNCH_CHECK();
+  }
+  if (ga.n == 0) {
+    // (every problem took the 128 x 128 kernel)
+  } else if (any_tr) {
     switch (layout) {
       case ER_GEMM_NN: hipLaunchKernelGGL((er::gemm_f32_grouped_tr_kernel<true, false>), grid, block, 0, s, ga); break;
       case ER_GEMM_NT: hipLaunchKernelGGL((er::gemm_f32_grouped_tr_kernel<true, true>), grid, block, 0, s, ga); break;
@@ -1195,6 +1385,11 @@ extern "C" {
 int er_gemm_reserve(int64_t floats) {
   ER_REQUIRE(floats >= 0, "er_gemm_reserve: negative size");
   if (int rc = ensure_counters()) return rc;  // (allocations are not capturable: both happen here)
+  if (!g_tn128_ready) {
+    ER_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&er::gemm_f32_grouped_tn128_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, er::kTn128LdsBytes));
+    g_tn128_ready = true;
+  }
   float* p;
   return ensure_ws(static_cast<size_t>(floats), &p);
 }
@@ -1268,28 +1463,25 @@ int er_gemm_f32_deferred(int layout, int32_t M, int32_t N, int32_t K, const floa
   ER_REQUIRE(!fin || er::ceil_div(N, er::BN) <= fin->n_counters / 2,
              "er_gemm_f32_deferred: %d column tiles need %d counter words", static_cast<int>(er::ceil_div(N, er::BN)),
              static_cast<int>(2 * er::ceil_div(N, er::BN)));
-  er::GemmArgs a;
-  a.A = A; a.B = B; a.C = C; a.bias = bias;
-  a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
-  a.accumulate = accumulate;
-  a.col_stats = col_stats;
-  a.splits = 1;
-  a.k_per_split = static_cast<int>(er::ceil_div(K, er::BK32)) * er::BK32;
+  er::ATransform tr;
   if (at && at->mean) {
     ER_REQUIRE(at->invstd, "er_gemm_f32_deferred: A transform without invstd");
     ER_REQUIRE(layout != ER_GEMM_NT, "er_gemm_f32_deferred: the A transform is defined for [batch, features] operands (NN, TN)");
     ER_REQUIRE(layout == ER_GEMM_TN || K <= er::kTrMaxK - 64, "er_gemm_f32_deferred: A transform over K = %d features (limit %d)",
                K, er::kTrMaxK - 64);
-    a.at.mean = at->mean; a.at.invstd = at->invstd; a.at.gamma = at->gamma; a.at.beta = at->beta; a.at.act = at->act;
+    tr.mean = at->mean; tr.invstd = at->invstd; tr.gamma = at->gamma; tr.beta = at->beta; tr.act = at->act;
   }
+  er::BnFused fu;
   if (fin) {
-    a.fu.mode = 3;
-    a.fu.eps = fin->eps; a.fu.momentum = fin->momentum;
-    a.fu.moving_mean = fin->moving_mean; a.fu.moving_var = fin->moving_var;
-    a.fu.save_mean = fin->save_mean; a.fu.save_invstd = fin->save_invstd;
-    a.fu.counters = reinterpret_cast<unsigned*>(fin->counters);
+    fu.mode = 3;
+    fu.eps = fin->eps; fu.momentum = fin->momentum;
+    fu.moving_mean = fin->moving_mean; fu.moving_var = fin->moving_var;
+    fu.save_mean = fin->save_mean; fu.save_invstd = fin->save_invstd;
+    fu.counters = reinterpret_cast<unsigned*>(fin->counters);
   }
-  return launch_gemm<false>(layout, a, er::as_stream(stream));
+  // (the k-split of a plain contraction - hence its summation order - is er_gemm_f32's)
+  return gemm_entry<false>(layout, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, col_stats, stream, "er_gemm_f32_deferred",
+                           nullptr, tr.mean ? &tr : nullptr, fin ? &fu : nullptr);
 }
 
 int er_gemm_f32_bn_bwd_z(int layout, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B,

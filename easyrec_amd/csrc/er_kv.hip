@@ -55,6 +55,19 @@ __device__ __forceinline__ void kv_insert_one(int64_t i, const int64_t* __restri
   const int64_t key = ids[i];
   if (key < 0) return;  // ('' / padding: no row)
   uint64_t pos = kv_home(key, mask);
+  // A full arena claims no further key slots: ids that have a row are found, new ones only raise the (sticky) overflow
+  // flag.  Otherwise every unseen id of every later step would occupy a slot for good (with row -1), the map's load
+  // factor would pass 0.5 and probe sequences would grow towards the size of the map.  (The arena filling up between
+  // this read and the CAS below leaves at most one launch's worth of such slots.)
+  if (__hip_atomic_load(next_row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= capacity) {
+    for (uint64_t probes = 0; probes <= mask; ++probes, pos = (pos + 1) & mask) {
+      const int64_t k = __hip_atomic_load(keys + pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (k == key) return;
+      if (k == kKvEmpty) break;
+    }
+    atomicExch(overflow, 1);
+    return;
+  }
   for (uint64_t probes = 0; probes <= mask; ++probes, pos = (pos + 1) & mask) {
     const unsigned long long prev = atomicCAS(reinterpret_cast<unsigned long long*>(keys + pos),
                                               static_cast<unsigned long long>(kKvEmpty), static_cast<unsigned long long>(key));

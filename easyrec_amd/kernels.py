@@ -757,7 +757,14 @@ class HipBackend(object):
     return out
 
   # -- deferred BatchNorm + activation (include/easyrec_hip.h er_a_transform / er_bn_finalize)
-  deferred_bn = os.environ.get('EASYREC_AMD_DEFER_BN', '1') != '0'  # A/B switch
+  # OFF by default - built, bit-identical to the materialised form (tests), and SLOWER on MI355X at these sizes: what the
+  # deferred form removes is one normalise + activate launch per hidden layer (7.8 us for a batch-sized layer), what it
+  # adds is the statistics' finalisation inside the GEMM launch - partial stores, an arrival counter and the last
+  # workgroup's loads all cross XCDs through memory-side (sc1) accesses at ~2 us a hop, the same wall the in-GEMM barrier
+  # of fused_bn_gemm hit - plus a parameter-table prologue in every reader: DeepFM-Criteo 0.524 ms deferred against 0.488
+  # (GEMM family 282 us against 222, BatchNorm 69 against 95); DIN 10 M 3.21 ms against 2.66 (one workgroup merging the
+  # 3,200 row-tile partials of a [B x L]-row layer is a 50 us serial tail).  profiles/r03_deferred_bn.md.
+  deferred_bn = os.environ.get('EASYREC_AMD_DEFER_BN', '0') != '0'  # A/B switch
 
   def _bn_counters(self, device):
     """arrival counters of er_bn_finalize: one zero-initialised buffer per calling thread and device (the launches of one
@@ -821,7 +828,14 @@ class HipBackend(object):
       else:
         (K, M), (K2, N) = a.shape, b.shape
       assert K == K2 and out.shape == (M, N)
-      self._log_gemm('gemm_f32_grouped_kernel', layout, M, N, K)
+      if self.op_log is not None:  # (which of the two grouped kernels takes the problem: er_gemm.hip tn128_fits)
+        c = lambda x, t: (x + t - 1) // t  # noqa: E731
+        big = layout == GEMM_TN and at is None and M > 64 and N > 64 and a.stride(0) % 4 == 0 and b.stride(0) % 4 == 0 and \
+            3 * c(M, 128) * c(N, 128) * 4 <= 4 * c(M, 64) * c(N, 64) and os.environ.get('ER_GEMM_TN128', '1') != '0'
+        if big:
+          self._log_gemm('gemm_f32_grouped_tn128_kernel', None, M, N, K)
+        else:
+          self._log_gemm('gemm_f32_grouped_tr_kernel' if at is not None else 'gemm_f32_grouped_kernel', layout, M, N, K)
       q.M, q.N, q.K = M, N, K
       q.A, q.lda, q.B, q.ldb = a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0)
       q.C, q.ldc = out.data_ptr(), out.stride(0)

@@ -303,6 +303,12 @@ class EmbeddingEngine(object):
       self._kv_handle = be.kv_jobs_create([(self.kv_tables[job[0]],) + tuple(job[1:]) for job in self.kv_jobs])
     be.kv_translate_multi(self._kv_handle, insert)
 
+  def check_overflow(self):
+    """Sticky device flags that void the steps since they were set (read back: a host sync): here the hash-table arenas;
+    the sharded engine adds its exchange capacity.  Called every OVERFLOW_CHECK_EVERY steps by the estimator, by
+    evaluate(), state_dict() and checkpoint.save()."""
+    self.check_kv_overflow()
+
   def check_kv_overflow(self):
     for name, kv in self.kv_tables.items():
       if int(kv['overflow'].item()):

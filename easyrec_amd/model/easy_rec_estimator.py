@@ -328,7 +328,14 @@ class EasyRecEstimator(object):
       # reference pads to the batch's longest sequence: tensor shapes follow the batch)
       self._device_step()
     self.global_step += 1
+    # hash-table embeddings: an arena that ran out of rows serves zeros for every new id from then on (a sticky device
+    # flag): a periodic blocking read bounds how long that can go unnoticed; evaluate(), state_dict() and
+    # checkpoint.save() check it too
+    if self.engine.kv_tables and self.global_step % self.OVERFLOW_CHECK_EVERY == 0:
+      self.engine.check_overflow()
     return self.losses
+
+  OVERFLOW_CHECK_EVERY = 256
 
   def predict(self, batch=None):
     assert self._built
@@ -352,6 +359,8 @@ class EasyRecEstimator(object):
     batches when a grouped AUC needs its key column); returns {'<metric>'[+ '_<tower>']: value}."""
     from easyrec_amd.core import metrics as metrics_lib
     assert self._built
+    if getattr(self.engine, 'kv_tables', None):
+      self.engine.check_overflow()
     ec = eval_config if eval_config is not None else self.pipeline_config.eval_config
     from easyrec_amd.input.features import host_key_column
     def specs_of(metrics_set):  # [(output name, metric kind, argument)]

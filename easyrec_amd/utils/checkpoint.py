@@ -6,6 +6,12 @@ writes its shard of every embedding variable to `<ckpt>-embedding/embed-<var nam
 `row % world` (native op ops/src/load_dense_embed.cc -> er_load_dense_embed).  The optimizer's slot variables are
 sharded the same way and use TF's slot names (`<var>/Adam`, `<var>/Adam_1`, `<var>/Adagrad`).
 
+Hash-table (`ev_params`) tables are written the way the saver writes SOK dynamic variables (:187-222): the ids that have
+a row as `embed-<var>-part-<rank>.key` (int64) and their rows as `...-part-<rank>.val` (float32 [n, dim]) - never the
+arena, whose row order is an accident of the run - and restored through er_load_kv_embed (ops/src/load_kv_embed.cc:
+115-163: keys with `key % world == rank`), re-inserted into the map (any arena order), values and slots scattered to
+the rows they got.
+
 Everything else - dense variables, their slots, the step - goes through the TF Saver in the reference (tensor-bundle
 files); that format is not written here: `<ckpt>.dense.npz` holds the same arrays under the same TF variable names.
 
@@ -44,6 +50,45 @@ def _engine_tables(engine):
     yield name, is_shard
 
 
+def _kv_file(ckpt_path, var_name, rank, ext):
+  return '%s-embedding/%s-part-%d.%s' % (ckpt_path, var_name, rank, ext)
+
+
+def _save_kv_table(engine, ckpt_path, name, slots, rank):
+  """keys / rows of the ids that have a row, and the same rows of every slot (the slots share the table's keys)"""
+  kv = engine.kv_tables[name]
+  keys, rows = kernels.hip().kv_export(kv)
+  os.makedirs(ckpt_path + '-embedding', exist_ok=True)
+  keys_np = keys.cpu().numpy().astype(np.int64)
+  pairs = [(name, engine.table_view(name))] + [(name + '/' + suffix, engine.slot_view(name, s)) for s, suffix in slots.items()]
+  for var, view in pairs:
+    if view is None:
+      continue
+    fv = embed_file_var_name(var)
+    keys_np.tofile(_kv_file(ckpt_path, fv, rank, 'key'))
+    view[rows.to(view.device)].detach().cpu().numpy().astype(np.float32).tofile(_kv_file(ckpt_path, fv, rank, 'val'))
+
+
+def _restore_kv_table(be, engine, ckpt_path, name, slots, rank, world):
+  kv = engine.kv_tables[name]
+  dev = engine.table_view(name).device
+  dim = engine.table_view(name).shape[1]
+  pairs = [(name, engine.table_view(name))] + [(name + '/' + suffix, engine.slot_view(name, s)) for s, suffix in slots.items()]
+  for i, (var, view) in enumerate(pairs):
+    if view is None:
+      continue
+    keys, vals = be.load_kv_embed(ckpt_path, embed_file_var_name(var), rank, world, dim)
+    keys_t = torch.from_numpy(np.ascontiguousarray(keys, dtype=np.int64)).to(dev)
+    rows = torch.empty_like(keys_t)
+    # the table's own file creates the rows; a slot's file finds them (its keys are the table's, in its own order)
+    kernels.hip().kv_translate(kv, keys_t, rows, i == 0)
+    if i == 0:
+      engine.check_kv_overflow()
+    else:
+      assert bool((rows >= 0).all()), 'checkpoint %s: slot file %s names ids the table file does not' % (ckpt_path, var)
+    view[rows] = torch.from_numpy(np.ascontiguousarray(vals, dtype=np.float32)).to(dev)
+
+
 def save(est, ckpt_path):
   """Every rank calls it.  Rank 0 writes the dense file; every rank its embedding shards (replicated and
   single-GPU tables: rank 0 alone, as a one-part table)."""
@@ -62,6 +107,9 @@ def save(est, ckpt_path):
     if not is_shard and rank != 0:
       continue
     t_idx, t_num = (rank, world) if is_shard else (0, 1)
+    if engine.tables[name].get('kv'):
+      _save_kv_table(engine, ckpt_path, name, slots, t_idx)
+      continue
     be.save_dense_embed(ckpt_path, embed_file_var_name(name), t_idx, t_num, engine.table_view(name).cpu().numpy())
     for s, suffix in slots.items():
       sv = engine.slot_view(name, s)
@@ -78,6 +126,10 @@ def save(est, ckpt_path):
       for s, suffix in dslots.items():
         if s in vs.slots:
           dense[name + '/' + suffix] = vs.slots[s][o:o + n].view(vs._vars[name]['tensor'].shape).cpu().numpy().copy()
+    # hash-table tables: the generator of rows created AFTER the restore (seed, mean, stddev), so that a resumed run draws
+    # the rows an uninterrupted one would
+    for name, kv in getattr(engine, 'kv_tables', {}).items():
+      dense[name + '/kv_meta'] = np.array([kv['seed'], kv['mean'], kv['stddev'], kv['capacity']], dtype=np.float64)
     dense['global_step'] = np.asarray(int(est.global_step), dtype=np.int64)
     np.savez(ckpt_path + '.dense.npz', **dense)
 
@@ -90,6 +142,9 @@ def restore(est, ckpt_path):
   slots = _SLOT_NAMES[est.opt_emb.kind]
   for name, is_shard in _engine_tables(engine):
     t_idx, t_num = (rank, world) if is_shard else (0, 1)
+    if engine.tables[name].get('kv'):
+      _restore_kv_table(be, engine, ckpt_path, name, slots, t_idx, t_num)
+      continue
     view = engine.table_view(name)
     n_local, dim = view.shape
     view.copy_(torch.from_numpy(be.load_dense_embed(ckpt_path, embed_file_var_name(name), t_idx, t_num, dim, n_local)))
@@ -99,6 +154,11 @@ def restore(est, ckpt_path):
         sv.copy_(torch.from_numpy(
             be.load_dense_embed(ckpt_path, embed_file_var_name(name + '/' + suffix), t_idx, t_num, dim, n_local)))
   z = np.load(ckpt_path + '.dense.npz')
+  for name, kv in getattr(engine, 'kv_tables', {}).items():
+    if name + '/kv_meta' in z.files:
+      meta = z[name + '/kv_meta']
+      kv['seed'], kv['mean'], kv['stddev'] = int(meta[0]), float(meta[1]), float(meta[2])
+      engine._kv_handle = None  # (the device-resident job table carries the generator's parameters: rebuilt on next use)
   vs = est.varstore
   vs.load_state_dict({k: z[k] for k in z.files}, strict=False)
   dslots = _SLOT_NAMES[est.opt_dense.kind]

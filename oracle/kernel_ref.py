@@ -422,7 +422,7 @@ class RefBackend(object):
 
   # -- deferred BatchNorm + activation (include/easyrec_hip.h er_a_transform / er_bn_finalize): the stand-in applies the
   # producer's normalisation to the operand, then contracts; statistics straight from the output
-  deferred_bn = True
+  deferred_bn = True  # (on for the stand-in: the host logic of the deferred path stays covered by the CPU tests)
 
   @staticmethod
   def _deferred_value(at, a):
@@ -816,12 +816,12 @@ class RefBackend(object):
       r = kv['map'].get(k)
       if r is None and insert:
         if len(kv['map']) >= kv['capacity']:
-          kv['overflow'][0] = 1
+          kv['overflow'][0] = 1  # (a full arena claims no further key: the id reads zeros, the flag is sticky)
           r = -1
         else:
           r = len(kv['map'])
           kv['var'].detach()[r] = torch.from_numpy(self.kv_init_value(kv['seed'], [k], kv['dim'], kv['mean'], kv['stddev'])[0])
-        kv['map'][k] = r
+          kv['map'][k] = r
       out.append(-1 if r is None else r)
     rows_out.view(-1).copy_(torch.tensor(out, dtype=torch.int64))
 

@@ -117,6 +117,68 @@ def test_save_restore_continues_bit_identically(ref_backend, built_lib, tmp_path
     assert np.array_equal(sa[k], sb[k]), k
 
 
+def test_hash_table_tables_save_restore_continue(ref_backend, built_lib, tmp_path):
+  """`ev_params` tables: 3 steps, save (key / value files per table and slot, as the saver writes SOK variables:
+  compat/embedding_parallel_saver.py:187-222), restore into a freshly built estimator with another seed (the ids get
+  OTHER arena rows), 2 more steps == 5 uninterrupted steps: losses, and every id's row and slots."""
+  from easyrec_amd.input.criteo_synthetic import SyntheticCriteo
+  from easyrec_amd.model.easy_rec_estimator import EasyRecEstimator
+  from easyrec_amd.utils import checkpoint, config_util
+  B = 16
+  cfg = config_util.get_configs_from_pipeline_file(os.path.join(ROOT, 'configs', 'deepfm_kv_criteo_small.config'))
+  gen = SyntheticCriteo(cfg.data_config, list(cfg.feature_config.features), batch_size=B, seed=5)
+  batches = [gen.next_batch() for _ in range(5)]
+  a = EasyRecEstimator(cfg, device='cpu', batch_size=B, seed=3).build()
+  assert a.engine.kv_tables
+  _train(a, batches[:3])
+  ckpt = os.path.join(str(tmp_path), 'model.ckpt-3')
+  checkpoint.save(a, ckpt)
+  files = os.listdir(ckpt + '-embedding')
+  kv_name = next(iter(a.engine.kv_tables))
+  stem = checkpoint.embed_file_var_name(kv_name)
+  assert stem + '-part-0.key' in files and stem + '-part-0.val' in files, files[:6]
+  assert checkpoint.embed_file_var_name(kv_name + '/Adam_1') + '-part-0.val' in files
+  assert not any(f.startswith(stem) and f.endswith('.bin') for f in files), 'the arena itself must not be written'
+  n_keys = os.path.getsize(os.path.join(ckpt + '-embedding', stem + '-part-0.key')) // 8
+  assert 0 < n_keys <= 3 * B
+  rest_a = _train(a, batches[3:])
+  b = EasyRecEstimator(cfg, device='cpu', batch_size=B, seed=99).build()
+  # a few ids before the restore: the restored ids land on other arena rows than in `a`
+  checkpoint.restore(b, ckpt)
+  assert b.global_step == 3
+  rest_b = _train(b, batches[3:])
+  assert rest_a == rest_b
+  sa, sb = a.state_dict(slots=True), b.state_dict(slots=True)
+  assert set(sa) == set(sb)
+  for k in sa:
+    assert np.array_equal(sa[k], sb[k]), k
+
+
+def test_full_hash_table_arena_is_noticed_and_claims_no_slots(ref_backend):
+  """More distinct ids than ev_params.max_capacity: new ids read zeros, the sticky flag raises at the estimator's
+  periodic check / evaluate / state_dict, and the ids that found no row do not occupy map slots."""
+  from easyrec_amd.input.criteo_synthetic import SyntheticCriteo
+  from easyrec_amd.model.easy_rec_estimator import EasyRecEstimator
+  from easyrec_amd.utils import config_util
+  B = 16
+  cfg = config_util.get_configs_from_pipeline_file(os.path.join(ROOT, 'configs', 'deepfm_kv_criteo_small.config'))
+  for f in cfg.feature_config.features:
+    if f.HasField('ev_params'):
+      f.ev_params.max_capacity = 8
+  if cfg.model_config.HasField('ev_params'):
+    cfg.model_config.ev_params.max_capacity = 8
+  gen = SyntheticCriteo(cfg.data_config, list(cfg.feature_config.features), batch_size=B, seed=5, mode='uniform')
+  est = EasyRecEstimator(cfg, device='cpu', batch_size=B, seed=3).build()
+  est.OVERFLOW_CHECK_EVERY = 2
+  est.train_step(gen.next_batch())
+  with pytest.raises(RuntimeError, match='max_capacity'):
+    est.train_step(gen.next_batch())
+  with pytest.raises(RuntimeError, match='max_capacity'):
+    est.evaluate([gen.next_batch()])
+  kv = next(iter(est.engine.kv_tables.values()))
+  assert len(kv['map']) <= kv['capacity']
+
+
 def _gloo_ckpt_worker(rank, world, port, B, out_dir):
   sys.path.insert(0, ROOT)
   sys.path.insert(0, os.path.join(ROOT, 'tests'))
