@@ -39,16 +39,25 @@ gradsq_rows_kernel(const float* __restrict__ x, int64_t max_rows, int cols, int 
                    float* __restrict__ acc, int accumulate) {
   __shared__ float red[kNormBlock / 64];
   float a = 0.f;
-  const int64_t total = max_rows * cols;
-  for (int64_t i = threadIdx.x; i < total; i += kNormBlock) {
-    const int64_t r = i / cols;
-    const int c = static_cast<int>(i - r * cols);
-    if (seg_counts) {
-      const int64_t sg = r / seg_stride;
-      if (sg >= n_seg || (r - sg * seg_stride) >= seg_counts[sg]) continue;
+  // a thread owns a column slot and walks rows (no division per element: DIN's sequence groups have 204,800 rows): with
+  // cols <= kNormBlock, kNormBlock / cols rows are in flight per pass; wider rows are walked in column chunks
+  const int per_pass = cols <= kNormBlock ? kNormBlock / cols : 1;
+  const int my_row = cols <= kNormBlock ? static_cast<int>(threadIdx.x) / cols : 0;
+  const int my_col = cols <= kNormBlock ? static_cast<int>(threadIdx.x) % cols : static_cast<int>(threadIdx.x);
+  const bool active = cols > kNormBlock || my_row < per_pass;
+  if (active) {
+    // (rows of one segment are consecutive: the segment cursor only moves forward)
+    for (int64_t r = my_row; r < max_rows; r += per_pass) {
+      if (seg_counts) {
+        const int64_t sg = r / seg_stride;
+        if (sg >= n_seg) break;
+        if ((r - sg * seg_stride) >= seg_counts[sg]) continue;
+      }
+      for (int c = my_col; c < cols; c += kNormBlock) {
+        const float v = x[r * ld + c];
+        a = a + v * v;
+      }
     }
-    const float v = x[r * ld + c];
-    a = a + v * v;
   }
   const float s = block_sum_1024(a, red);
   if (threadIdx.x == 0) acc[0] = accumulate ? (acc[0] + weight * s) : weight * s;
@@ -77,9 +86,12 @@ __global__ void clip_scale_kernel(const float* __restrict__ normsq, float clip_n
                                   int n_records, float* __restrict__ norm_out) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const float norm = sqrtf(normsq[0]);
-  // clip_ops.clip_by_global_norm: scale = clip_norm * min(1 / norm, 1 / clip_norm)
+  // clip_ops.clip_by_global_norm: scale = clip_norm * min(1 / norm, 1 / clip_norm).  A non-finite norm must not pass for
+  // "no clipping" (0 in the record means that; inf would give it, and NaN compares false into 1.0): like TensorFlow,
+  // which propagates NaN into every clipped gradient, the multiplier becomes NaN and the divergence shows at once.
   const float a = 1.0f / norm, b = 1.0f / clip_norm;
-  const float scale = clip_norm * (a < b ? a : b);
+  float scale = clip_norm * (a < b ? a : b);
+  if (!(norm <= 3.0e38f)) scale = __builtin_nanf("");
   for (int i = 0; i < n_records; ++i) records[i].clip_scale = scale;
   if (norm_out) norm_out[0] = norm;
 }

@@ -6,6 +6,8 @@ reference (tf.decode_csv is a C++ kernel): `er_decode_csv_host` splits and parse
 cells stay (begin, length) views of the file's bytes until they are packed for hashing (input.py PackedCol) - no
 per-cell Python work on the Criteo layout.  The MI355X benchmark feeds device-resident synthetic batches.
 """
+import logging
+
 import numpy as np
 
 from easyrec_amd.input.input import Input, get_type_defaults
@@ -158,7 +160,15 @@ class CSVInput(Input):
       if b'"' in data:
         # quoted cells (tf.decode_csv's use_quote_delim): the zero-copy (begin, length) cells of the native decoder
         # cannot express an un-escaped '""'; such files take the line-by-line path (not the Criteo / Taobao layouts)
+        if not getattr(self, '_warned_quoted', False):
+          self._warned_quoted = True
+          logging.warning('%s contains quote characters: read line by line in Python (~13x slower than the native decoder); '
+                          'a quoted cell may not contain a line break', path)
         lines = [ln for ln in data.decode('utf-8').split('\n') if ln.strip('\r')]
+        for ln in lines:
+          if ln.count('"') % 2:
+            raise ValueError('%s: a line with an unbalanced quote - quoted cells that span several lines are not '
+                             'supported (tf.data.TextLineDataset splits on line breaks first as well): %r' % (path, ln[:80]))
         for i in range(0, len(lines), B):
           part = self._parse_lines(lines[i:i + B])
           if carry is None and len(lines[i:i + B]) == B:

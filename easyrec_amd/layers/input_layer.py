@@ -602,8 +602,41 @@ class EmbeddingEngine(object):
         be.emb_bwd_reduce_routed(grp, grads)
       else:
         keys, grads, n_unique = be.emb_bwd_reduce(grp, out=bufs)
-      be.gradsq_rows(grads, dim, weight, normsq, True, counts=n_unique)
+      ng = self._norm_group(dim)
+      if ng is None:
+        be.gradsq_rows(grads, dim, weight, normsq, True, counts=n_unique)
+      else:
+        # a table read by several lookups: TensorFlow's norm sees each lookup's IndexedSlices on its own (merged within
+        # a lookup only: compat/optimizers.py:453-481) - a second reduction over keys that keep the lookups apart
+        _, ngrads, nn = be.emb_bwd_reduce(ng['group'], out=ng['bufs'])
+        be.gradsq_rows(ngrads, dim, weight, normsq, True, counts=nn)
       self._reduced.append((grp, keys, grads, n_unique))
+
+  def _norm_group(self, dim):
+    """None unless a table of this dim is read by more than one lookup; else a reduce-only twin of the table group whose
+    lookups own disjoint key ranges (key bases spread), built once."""
+    if not hasattr(self, '_norm_groups'):
+      self._norm_groups = {}
+    if dim not in self._norm_groups:
+      specs = [s for s in self.fwd_specs if s.dim == dim]
+      bases = [s.key_base for s in specs]
+      ng = None
+      if len(set(bases)) < len(bases):
+        be = kernels.hip()
+        spread, base = [], 0
+        for s in specs:
+          t = s.with_out(self._dout_of(s))
+          t.key_base = base
+          spread.append(t)
+          base += s.rows
+        st = self.storage[dim]
+        grp = be.emb_group_create(spread, dim, base, st['var'], st['m'], st['v'], None)
+        n = grp['num_entries']
+        ng = {'group': grp, 'bufs': (torch.zeros(n, dtype=torch.int32, device=self.device),
+                                     torch.zeros(n, dim, dtype=torch.float32, device=self.device),
+                                     torch.zeros(1, dtype=torch.int32, device=self.device))}
+      self._norm_groups[dim] = ng
+    return self._norm_groups[dim]
 
   def apply_reduced(self, opt_kind, hyper):
     be = kernels.hip()

@@ -1129,6 +1129,8 @@ class RefBackend(object):
     norm = np.sqrt(F32(normsq[0].item()), dtype=np.float32)
     with np.errstate(divide='ignore'):
       scale = F32(clip_norm) * min(F32(1.0) / norm, F32(1.0) / F32(clip_norm))
+    if not np.isfinite(norm):  # (TensorFlow propagates a non-finite norm into every clipped gradient)
+      scale = F32(np.nan)
     records[:, HYPER_CLIP] = float(scale)
     if norm_out is not None:
       norm_out[0] = float(norm)

@@ -287,9 +287,22 @@ class OracleTrainer(object):
     src = self.state[name] if array is None else array
     return np.array([k for k, _ in items], dtype=np.int64), np.stack([src[r] for _, r in items]) if items else src[:0]
 
+  def _per_lookup(self, table):
+    """When gradients are clipped: the table as THIS lookup sees it (an identity op whose gradient is kept), so that the
+    gradient each lookup sends to a shared table can be told apart afterwards - TensorFlow keeps the IndexedSlices of
+    the lookups of one variable side by side (merged within a lookup: embedding_lookup_sparse gathers unique ids) and
+    `_get_grad_norm` takes l2_loss of their concatenated values (compat/optimizers.py:453-481)."""
+    if not getattr(self, '_track_lookups', False) or not table.requires_grad:
+      return table
+    t = table + 0
+    t.retain_grad()
+    self._lookup_leaves.setdefault(id(table), []).append(t)
+    return t
+
   def _lookup_dense(self, table, ids, weights=None):
     """One id per example; id < 0 -> zero row; optional weight multiplies the row (combiner sum)."""
     self._touch(table, ids)
+    table = self._per_lookup(table)
     idt = torch.as_tensor(np.asarray(ids), dtype=torch.int64)
     ok = (idt >= 0) & (idt < table.shape[0])
     e = table[torch.where(ok, idt, torch.zeros_like(idt))]
@@ -301,6 +314,7 @@ class OracleTrainer(object):
     rows = []
     ids = np.asarray(ids)
     self._touch(table, ids[int(offsets[0]):int(offsets[self.B])])
+    table = self._per_lookup(table)
     for r in range(self.B):
       kb, ke = int(offsets[r]), int(offsets[r + 1])
       acc = torch.zeros(table.shape[1], dtype=self.dtype)
@@ -1237,9 +1251,17 @@ class OracleTrainer(object):
     W = len(batches)
     per_rank, losses_out, touched = [], [], {}
     self.rank_moving = []
+    clip_on = float(self.cfg.train_config.gradient_clipping_by_norm) > 0
+    lookup_sq = {}  # W == 1: variable name -> sum over its lookups of the squared per-lookup gradient (shared tables)
     for batch in batches:
+      self._track_lookups, self._lookup_leaves = clip_on and W == 1, {}
       V, pred, losses = self.forward(batch)
       losses['total_loss'].backward()
+      for name, t in V.used.items():
+        leaves = self._lookup_leaves.get(id(t), [])
+        if len(leaves) > 1:
+          lookup_sq[name] = sum(float((lf.grad.double() ** 2).sum()) for lf in leaves if lf.grad is not None)
+      self._track_lookups = False
       gr = OrderedDict()
       for name, t in V.used.items():
         if t.requires_grad:
@@ -1269,8 +1291,9 @@ class OracleTrainer(object):
     # clip_by_global_norm (:365-376, 453-481): norm = sqrt(2 * sum of tf.nn.l2_loss(g)); a table's IndexedSlices carry
     # one row per distinct id of a lookup, so (one lookup per table) the dense gradient has the same sum of squares; with
     # sharded tables the rows of different workers stay separate rows of `values` (each divided by W), their l2 sums are
-    # all-reduced.  Tables shared by several lookups keep per-lookup rows in TF; the dense gradient merges them -
-    # configs with shared tables AND clipping are not covered here.
+    # all-reduced.  Tables shared by several lookups keep per-lookup rows in TF (W == 1: `lookup_sq`, the sum over the
+    # lookups of their own squared gradients; under embedding parallelism the ids of all features of a table are
+    # de-duplicated together before the exchange, feature_column.py:259-289, so a rank's rows ARE merged).
     clip = float(self.cfg.train_config.gradient_clipping_by_norm)
     self.last_grad_norm = None
     if clip > 0:
@@ -1280,6 +1303,8 @@ class OracleTrainer(object):
           for r in range(W):
             gr = per_rank[r][name].astype(np.float64) * (self.emb_mult / W)
             sq += float((gr ** 2).sum())
+        elif name in lookup_sq:
+          sq += lookup_sq[name] * float(self.emb_mult) ** 2
         else:
           sq += float((grads[name].astype(np.float64) ** 2).sum())
       norm = F32(np.sqrt(sq))

@@ -60,6 +60,12 @@ def _run(cfg, B, steps, device, gen_cls, data_seed=11, **est_kw):
 #  by 1e-6 after the first step, moves its second-step norm by 6e-4 on data seed 11.  Data seed 13 is a trajectory
 #  where product and oracle stay within 2e-6 for three steps.)
 @pytest.mark.parametrize('config,clip,steps,data_seed', [('deepfm_criteo_small.config', 0.05, 3, 11),
+                                                         # ONE table behind every categorical feature, and DIN's item /
+                                                         # category tables read by the target AND the history lookups: the
+                                                         # norm keeps the lookups' IndexedSlices apart (a^2 + b^2 on a row
+                                                         # two lookups hit, not (a + b)^2)
+                                                         ('deepfm_shared_criteo_small.config', 0.05, 2, 11),
+                                                         ('din_taobao_small.config', 0.5, 2, 11),
                                                          ('deepfm_criteo_small.config', 1e4, 3, 11),
                                                          ('dcn_criteo_small.config', 0.05, 3, 11),
                                                          ('mmoe_taobao_small.config', 5.0, 3, 13)])
