@@ -1239,7 +1239,12 @@ bool g_tn128_ready = false;  // er_gemm_reserve raised the 128 x 128 kernel's LD
 // A TN problem takes 128 x 128 tiles when both operands allow the 16-byte loads, neither dimension fits one 64-tile and
 // padding to 128 wastes no more than a third over padding to 64 (624 x 256, 256 x 128, 81 x 256: none; 320 x 128: 20 %)
 bool tn128_fits(int layout, const er_gemm_problem& q) {
-  static const bool off = [] { const char* e = getenv("ER_GEMM_TN128"); return e && atoi(e) == 0; }();  // A/B switch
+  // OFF by default: measured SLOWER than the 64 x 64 kernel on every config (same box, profiles/r03_tn128.md) - the
+  // grouped weight-gradient launch of DeepFM-Criteo 87 us against 48, DIN 10 M 658 against 581, MMoE 775 against 584.
+  // Half the operand traffic does not pay for what the bigger tile costs here: 32 ds_write_b32 per thread and k-tile
+  // for the two mn-contiguous operands (the transpose into the [mn][k] fragment layout), one barrier per k-tile with
+  // only 2 workgroups (8 waves) per CU to hide it, and 4x fewer tiles for the split-K to spread.  ER_GEMM_TN128=1 enables.
+  static const bool off = [] { const char* e = getenv("ER_GEMM_TN128"); return !(e && atoi(e) == 1); }();  // A/B switch
   if (off || !g_tn128_ready || layout != ER_GEMM_TN || q.a_mean || q.M <= er::BM || q.N <= er::BN) return false;
   if (q.lda % 4 != 0 || q.ldb % 4 != 0 || ((reinterpret_cast<uintptr_t>(q.A) | reinterpret_cast<uintptr_t>(q.B)) & 15) != 0)
     return false;

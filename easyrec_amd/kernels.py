@@ -831,7 +831,7 @@ class HipBackend(object):
       if self.op_log is not None:  # (which of the two grouped kernels takes the problem: er_gemm.hip tn128_fits)
         c = lambda x, t: (x + t - 1) // t  # noqa: E731
         big = layout == GEMM_TN and at is None and M > 64 and N > 64 and a.stride(0) % 4 == 0 and b.stride(0) % 4 == 0 and \
-            3 * c(M, 128) * c(N, 128) * 4 <= 4 * c(M, 64) * c(N, 64) and os.environ.get('ER_GEMM_TN128', '1') != '0'
+            3 * c(M, 128) * c(N, 128) * 4 <= 4 * c(M, 64) * c(N, 64) and os.environ.get('ER_GEMM_TN128', '0') == '1'
         if big:
           self._log_gemm('gemm_f32_grouped_tn128_kernel', None, M, N, K)
         else:

@@ -1009,7 +1009,7 @@ def test_gemm_grouped_matches_single_launches(hip):
   """The weight gradients of a step in ONE grouped launch (er_gemm_grouped_f32): every problem within the f32 bound of
   an fp64 matmul, accumulate honoured, bit-identical across launches; > 16 problems are chunked."""
   g = torch.Generator().manual_seed(7)
-  hip.gemm_reserve(1 << 22)  # (also enables the 128 x 128 TN kernel: the first, second, fourth and last shapes take it)
+  hip.gemm_reserve(1 << 22)  # (with ER_GEMM_TN128=1 the first, second, fourth and ninth shapes take the 128 x 128 kernel)
   shapes = [(624, 256, 4096), (256, 128, 4096), (128, 64, 4096), (81, 256, 4096), (64, 1, 4096), (33, 65, 97),
             (1, 1, 1), (130, 72, 1000), (320, 128, 20000), (129, 129, 131)] * 3  # 30 problems
   probs, refs, bases = [], [], []
