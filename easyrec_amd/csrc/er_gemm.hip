@@ -1245,7 +1245,7 @@ bool tn128_fits(int layout, const er_gemm_problem& q) {
   // for the two mn-contiguous operands (the transpose into the [mn][k] fragment layout), one barrier per k-tile with
   // only 2 workgroups (8 waves) per CU to hide it, and 4x fewer tiles for the split-K to spread.  ER_GEMM_TN128=1 enables.
   static const bool off = [] { const char* e = getenv("ER_GEMM_TN128"); return !(e && atoi(e) == 1); }();  // A/B switch
-  if (off || !g_tn128_ready || layout != ER_GEMM_TN || q.a_mean || q.M <= er::BM || q.N <= er::BN) return false;
+  if (off || !g_tn128_ready || layout != ER_GEMM_TN || q.a_mean || q.col_stats || q.M <= er::BM || q.N <= er::BN) return false;
   if (q.lda % 4 != 0 || q.ldb % 4 != 0 || ((reinterpret_cast<uintptr_t>(q.A) | reinterpret_cast<uintptr_t>(q.B)) & 15) != 0)
     return false;
   const int64_t a128 = er::ceil_div(q.M, er::BM2) * er::ceil_div(q.N, er::BM2) * 4;
@@ -1292,7 +1292,8 @@ int gemm_grouped_f32(int layout, const er_gemm_problem* pr, int n, er_stream_t s
     a.A = q.A; a.B = q.B; a.C = q.C; a.bias = q.bias;
     a.M = q.M; a.N = q.N; a.K = q.K; a.lda = q.lda; a.ldb = q.ldb; a.ldc = q.ldc;
     a.accumulate = q.accumulate;
-    a.col_stats = nullptr;
+    a.col_stats = q.col_stats;
+    ER_REQUIRE(!(q.col_stats && q.accumulate), "er_gemm_grouped_f32: problem %d: column statistics need a plain output", i);
     if (q.a_mean) {
       ER_REQUIRE(q.a_invstd, "er_gemm_grouped_f32: problem %d: A transform without invstd", i);
       ER_REQUIRE(layout == ER_GEMM_TN || q.K <= er::kTrMaxK - 64,
@@ -1313,7 +1314,7 @@ int gemm_grouped_f32(int layout, const er_gemm_problem* pr, int n, er_stream_t s
     if (sp > 128) sp = 128;
     const int64_t max_by_k = q.K / (4 * er::BK32);
     if (sp > max_by_k) sp = max_by_k;
-    if (sp < 1) sp = 1;
+    if (sp < 1 || q.col_stats) sp = 1;
     a.k_per_split = static_cast<int>(er::ceil_div(er::ceil_div(q.K, sp), er::BK32)) * er::BK32;
     a.splits = static_cast<int>(er::ceil_div(q.K, a.k_per_split));
     const int tile = big[i] ? er::BM2 : er::BM;

@@ -179,7 +179,7 @@ class GemmProblem(ctypes.Structure):  # = er_gemm_problem
               ('lda', ctypes.c_int32), ('B', ctypes.c_void_p), ('ldb', ctypes.c_int32), ('C', ctypes.c_void_p),
               ('ldc', ctypes.c_int32), ('bias', ctypes.c_void_p), ('accumulate', ctypes.c_int32),
               ('a_mean', ctypes.c_void_p), ('a_invstd', ctypes.c_void_p), ('a_gamma', ctypes.c_void_p),
-              ('a_beta', ctypes.c_void_p), ('a_act', ctypes.c_int32)]
+              ('a_beta', ctypes.c_void_p), ('a_act', ctypes.c_int32), ('col_stats', ctypes.c_void_p)]
 
 
 CROSS_HASH_KEY = 0xDECAFCAFFE  # tf.sparse.cross_hashed's default hash_key (crossed_column(hash_key=None))
@@ -756,6 +756,9 @@ class HipBackend(object):
                                          _stream()), 'er_gemm_f32_bn_bwd')
     return out
 
+  # the same-depth layers of parallel stacks (MMoE's experts, task towers) as one grouped launch: layers/dnn.py run_parallel
+  grouped_stacks = os.environ.get('EASYREC_AMD_GROUPED_STACKS', '1') != '0'  # A/B switch
+
   # -- deferred BatchNorm + activation (include/easyrec_hip.h er_a_transform / er_bn_finalize)
   # OFF by default - built, bit-identical to the materialised form (tests), and SLOWER on MI355X at these sizes: what the
   # deferred form removes is one normalise + activate launch per hidden layer (7.8 us for a batch-sized layer), what it
@@ -815,6 +818,7 @@ class HipBackend(object):
     for q, pr in zip(arr, problems):
       a, b, out, bias, accumulate = pr[:5]
       at = pr[5] if len(pr) > 5 else None
+      stats = pr[6] if len(pr) > 6 else None
       if at is not None:
         assert layout != GEMM_NT and at.deferred
         q.a_mean, q.a_invstd, q.a_gamma, q.a_beta, q.a_act = _ptr(at.mean), _ptr(at.invstd), _ptr(at.gamma), \
@@ -841,6 +845,9 @@ class HipBackend(object):
       q.C, q.ldc = out.data_ptr(), out.stride(0)
       q.bias = bias.data_ptr() if bias is not None else None
       q.accumulate = int(bool(accumulate))
+      if stats is not None:
+        assert stats.dtype == torch.float32 and stats.numel() >= self.gemm_row_tiles(M) * N * 3 and not accumulate
+        q.col_stats = stats.data_ptr()
     self._ck(self.lib.er_gemm_grouped_f32(ctypes.c_int(layout), arr, len(problems), _stream()), 'er_gemm_grouped_f32')
 
   # weight gradients of a backward pass: queued by LinearFn / LinearBNActFn, contracted together by flush_wgrads()
@@ -1740,6 +1747,106 @@ class LinearBNActFn(torch.autograd.Function):
     if ctx.needs_input_grad[1]:
       dw = _wgrad(be, x, dz, wg, ctx.bf16, ctx.at, ctx.sink)
     return dx, dw, None, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
+
+
+class GroupedLinearFn(torch.autograd.Function):
+  """The same-depth dense layers z_e = x_e . W_e (+ b_e) of E PARALLEL stacks - MMoE's experts, the task towers, the
+  gates (reference layers/mmoe.py:62-83, model/multi_task_model.py:33-100, which issue them one after the other) - as ONE
+  grouped launch forward (er_gemm_grouped_f32: bias in the epilogue, optionally the column statistics a BatchNorm needs)
+  and ONE grouped launch for the input gradients; weight gradients join the step's grouped weight-gradient launch, bias
+  gradients are column sums into the flat gradient buffer.  Layers that read the SAME input (the first depth of MMoE:
+  every expert and gate reads the shared features) accumulate their input gradients into one buffer - or straight into the
+  embedding group's gradient buffer (`sinks`) - one GEMM after the other, as the sequential form does.
+  apply(E, stats_mask, sinks, x_0..x_{E-1}, W_0.., b_0.. (None ok)) -> (z_0 .. z_{E-1}, stats_0 .. stats_{E-1}) (stats_e:
+  an empty tensor unless stats_mask[e])."""
+
+  @staticmethod
+  def forward(ctx, E, stats_mask, sinks, *args):
+    be = hip()
+    xs, ws, bs = args[:E], args[E:2 * E], args[2 * E:3 * E]
+    ctx.gsinks = [sk if (sk is not None and x.stride(-1) == 1) else None for sk, x in zip(sinks, xs)]
+    xs = [x if x.stride(-1) == 1 else x.contiguous() for x in xs]
+    zs, stats, problems = [], [], []
+    for e in range(E):
+      M, N = xs[e].shape[0], ws[e].shape[1]
+      z = torch.empty(M, N, dtype=torch.float32, device=xs[e].device)
+      st = torch.empty(be.gemm_row_tiles(M) * N * 3, dtype=torch.float32, device=z.device) if stats_mask[e] else None
+      zs.append(z)
+      stats.append(st if st is not None else torch.empty(0, device=z.device))
+      problems.append((xs[e], ws[e].detach(), z, None if bs[e] is None else bs[e].detach(), False, None, st))
+    be.gemm_grouped(GEMM_NN, problems)
+    ctx.save_for_backward(*xs, *ws)
+    ctx.E, ctx.bs = E, bs
+    ctx.wgrads = [w.grad if (w.requires_grad and w.grad is not None) else None for w in ws]  # slices of the flat buffer
+    ctx.sink = be.wgrad_sink()
+    ctx.mark_non_differentiable(*stats)
+    return tuple(zs) + tuple(stats)
+
+  @staticmethod
+  def backward(ctx, *grads):
+    be = hip()
+    E = ctx.E
+    saved = ctx.saved_tensors
+    xs, ws = saved[:E], saved[E:2 * E]
+    dzs = [g if (g.dim() == 2 and g.stride(1) == 1) else g.contiguous() for g in grads[:E]]
+    dxs = [None] * E
+    need = [e for e in range(E) if ctx.needs_input_grad[3 + e]]
+    by_input = {}
+    for e in need:
+      by_input.setdefault(xs[e].data_ptr(), []).append(e)
+    solo = [es[0] for es in by_input.values() if len(es) == 1 and ctx.gsinks[es[0]] is None]
+    if solo:
+      for e in solo:
+        dxs[e] = torch.empty_like(xs[e])
+      be.gemm_grouped(GEMM_NT, [(dzs[e], ws[e], dxs[e], None, False) for e in solo])
+    for es in by_input.values():
+      if len(es) == 1 and ctx.gsinks[es[0]] is None:
+        continue
+      sink = ctx.gsinks[es[0]]
+      if sink is not None and sink.covers(0, ws[es[0]].shape[0]):  # an embedding group output: into its gradient buffer
+        for e in es:
+          _dgrad(be, dzs[e], ws[e], None, False, sink)
+        continue
+      acc = torch.empty_like(xs[es[0]])  # readers of one input: one buffer, accumulated GEMM by GEMM; the sum is returned
+      for j, e in enumerate(es):         # for the first of them, the others contribute nothing more
+        be.gemm(GEMM_NT, dzs[e], ws[e], out=acc, accumulate=j > 0)
+      dxs[es[0]] = acc
+    dws, dbs = [None] * E, [None] * E
+    for e in range(E):
+      if ctx.needs_input_grad[3 + E + e]:
+        dws[e] = _wgrad(be, xs[e], dzs[e], ctx.wgrads[e], False, None, ctx.sink)
+      b = ctx.bs[e]
+      if b is not None and ctx.needs_input_grad[3 + 2 * E + e]:
+        if b.grad is not None:
+          be.colsum(dzs[e], out=b.grad, accumulate=True)
+        else:
+          dbs[e] = be.colsum(dzs[e])
+    return (None, None, None) + tuple(dxs) + tuple(dws) + tuple(dbs)
+
+
+class BNFromStatsFn(torch.autograd.Function):
+  """BatchNorm(train) + activation of a GEMM output whose per-row-tile column statistics its launch already produced
+  (GroupedLinearFn): er_bn_apply_from_stats forward, er_bn_act_bwd backward (parameter gradients into the flat buffer)."""
+
+  @staticmethod
+  def forward(ctx, z, stats, gamma, beta, moving_mean, moving_var, eps, momentum, act, grad_bufs):
+    be = hip()
+    y, mean, invstd = be.bn_apply_from_stats(z, None, stats, be.gemm_row_tiles(z.shape[0]), gamma, beta, eps, momentum,
+                                             moving_mean, moving_var, act)
+    ctx.save_for_backward(z, gamma, y, mean, invstd)
+    ctx.act, ctx.grad_bufs = act, grad_bufs
+    return y
+
+  @staticmethod
+  def backward(ctx, dy):
+    be = hip()
+    z, gamma, y, mean, invstd = ctx.saved_tensors
+    gg, betag = ctx.grad_bufs if ctx.grad_bufs is not None else (None, None)
+    direct = gg is not None and betag is not None
+    dyc = dy if (dy.dim() == 2 and dy.stride(1) == 1) else dy.contiguous()
+    dz, _, dgamma, dbeta = be.bn_act_bwd(z, None, gamma, y, mean, invstd, dyc, 1, ctx.act, False, True,
+                                         into=(None, gg, betag) if direct else None)
+    return dz, None, dgamma, dbeta, None, None, None, None, None, None
 
 
 class FMFn(torch.autograd.Function):

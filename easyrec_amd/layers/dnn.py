@@ -112,6 +112,80 @@ def batch_norm(x, name, training):
   return y.reshape(shape)
 
 
+def run_parallel(stacks, inputs, extra_dense=()):
+  """E DNN stacks over (possibly the same) 2-D inputs, LAYER BY LAYER: the same-depth dense layers of all stacks run as
+  one grouped launch (kernels.GroupedLinearFn), each followed by its own bias / BatchNorm / activation kernel - the
+  variables, the arithmetic and the results are those of calling the stacks one after the other (the reference's order:
+  layers/mmoe.py:62-83, model/multi_task_model.py:33-100), only the launch count differs (MMoE 4 tasks: 40 forward GEMM
+  launches -> 8).  extra_dense: [(x, units, name, l2_reg)] plain dense layers that join the first depth's launch (MMoE's
+  gates).  Returns ([stack outputs], [extra outputs]).  Anything the lock-step form does not cover (dropout, non-ReLU
+  activations, per-layer outputs, unequal depths, evaluation) falls back to the sequential calls."""
+  ctx = context.current()
+  ok = torch.is_grad_enabled() and getattr(ctx, 'dense_dtype', 'f32') == 'f32' and \
+      getattr(kernels.hip(), 'grouped_stacks', False) and len(stacks) > 1
+  depth = len(stacks[0].hidden_units) if stacks else 0
+  for d, x in zip(stacks, inputs):
+    ok = ok and x.dim() == 2 and len(d.hidden_units) == depth and not (depth == 1 and d.hidden_units[0] == 0) and \
+        not (len(d.dropout_ratio) > 0 and d._is_training and any(r > 0 for r in d.dropout_ratio)) and \
+        (is_relu(d._act_string) or d.activation is None)
+  if not ok:
+    return [d(x) for d, x in zip(stacks, inputs)], [dense(x, units, name, l2_reg=l2) for x, units, name, l2 in extra_dense]
+  vs = ctx.varstore
+  cur = list(inputs)
+  extras = []
+  for i in range(depth):
+    xs, ws, bs, metas = [], [], [], []
+    for d, x in zip(stacks, cur):
+      unit, layer = d.hidden_units[i], '%s/dnn_%d' % (d._name, i)
+      use_bn = d._config.use_bn and ((i + 1 < depth) or not d._last_layer_no_batch_norm)
+      use_act = (i + 1 < depth) or not d._last_layer_no_activation
+      w = vs.get_variable(layer + '/kernel', (x.shape[-1], unit), 'glorot_uniform', l2=d._l2_reg or 0.0)
+      b = vs.get_variable(layer + '/bias', (unit,), 'zeros')
+      gamma = beta = mm = mv = None
+      if use_bn:
+        gamma = vs.get_variable(layer + '/bn/gamma', (unit,), 'ones')
+        beta = vs.get_variable(layer + '/bn/beta', (unit,), 'zeros')
+        mm = vs.get_variable(layer + '/bn/moving_mean', (unit,), 'zeros', trainable=False)
+        mv = vs.get_variable(layer + '/bn/moving_variance', (unit,), 'ones', trainable=False)
+      xs.append(x)
+      ws.append(w)
+      bs.append(b)
+      metas.append((use_bn, use_act and is_relu(d._act_string), d._is_training, gamma, beta, mm, mv))
+    if i == 0:
+      for x, units, name, l2 in extra_dense:
+        xs.append(x)
+        ws.append(vs.get_variable(name + '/kernel', (x.shape[-1], units), 'glorot_uniform', l2=l2 or 0.0))
+        bs.append(vs.get_variable(name + '/bias', (units,), 'zeros'))
+        metas.append(None)
+    E = len(xs)
+    train_bn = [m is not None and bool(m[0]) and m[2] for m in metas]  # batch statistics: from the GEMM's epilogue
+    sinks = tuple(kernels.grad_sink_of(x) for x in xs)
+    out = kernels.GroupedLinearFn.apply(E, tuple(train_bn), sinks, *xs, *ws, *bs)
+    zs, stats = out[:E], out[E:]
+    nxt = []
+    for e, m in enumerate(metas):
+      if m is None:
+        extras.append(zs[e])
+        continue
+      use_bn, relu, training, gamma, beta, mm, mv = m
+      act = kernels.ACT_RELU if relu else kernels.ACT_NONE
+      freeze = ctx.building and training  # build pass: do not touch the moving statistics
+      if train_bn[e]:
+        gb = (gamma.grad, beta.grad) if (gamma.grad is not None and beta.grad is not None) else None
+        y = kernels.BNFromStatsFn.apply(zs[e], stats[e], gamma, beta, None if freeze else mm, None if freeze else mv,
+                                        BN_EPSILON, BN_MOMENTUM, act, gb)
+      elif use_bn or relu:
+        # BatchNorm on the moving statistics (the experts of the reference's MMoE) and / or ReLU: one launch; the bias is
+        # already in z
+        y = kernels.BNActFn.apply(zs[e], None, gamma, beta, None if freeze else mm, None if freeze else mv, use_bn,
+                                  BN_EPSILON, BN_MOMENTUM, act, training, _grad_bufs(None, gamma, beta))
+      else:
+        y = zs[e]
+      nxt.append(y)
+    cur = nxt
+  return cur, extras
+
+
 class DNN(object):
 
   def __init__(self, dnn_config, l2_reg, name='dnn', is_training=False, last_layer_no_activation=False,

@@ -30,9 +30,13 @@ class MMOE(object):
 
   def __call__(self, deep_fea):
     scope, n = self._name, len(self._expert_configs)
-    experts = torch.stack([dnn.DNN(cfg, self._l2_reg, name='%s/expert_%d' % (scope, e), is_training=self._is_training)(deep_fea)
-                           for e, cfg in enumerate(self._expert_configs)], dim=0)  # [E, B, H]
-    gates = torch.stack([dnn.dense(deep_fea, n, '%s/gate_%d/dnn' % (scope, t), l2_reg=self._l2_reg)
-                         for t in range(self._num_task)], dim=0)  # [T, B, E] logits
+    stacks = [dnn.DNN(cfg, self._l2_reg, name='%s/expert_%d' % (scope, e), is_training=self._is_training)
+              for e, cfg in enumerate(self._expert_configs)]
+    # experts layer by layer (one grouped launch per depth), the gates' projections in the first depth's launch
+    outs, gate_logits = dnn.run_parallel(
+        stacks, [deep_fea] * n,
+        extra_dense=[(deep_fea, n, '%s/gate_%d/dnn' % (scope, t), self._l2_reg) for t in range(self._num_task)])
+    experts = torch.stack(outs, dim=0)  # [E, B, H]
+    gates = torch.stack(gate_logits, dim=0)  # [T, B, E] logits
     mixed = kernels.MMoEMixFn.apply(experts, gates)  # [T, B, H]
     return [mixed[t] for t in range(self._num_task)]

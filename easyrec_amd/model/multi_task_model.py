@@ -93,11 +93,15 @@ class MultiTaskModel(RankModel):
     model/simple_multi_task.py:38-52); fills the prediction dict."""
     from easyrec_amd.layers import dnn
     heads = {}
+    hs = list(inputs_per_task)
+    with_dnn = [t for t, tower in enumerate(self._towers) if tower.config.HasField('dnn')]
+    if with_dnn:  # the towers layer by layer: one grouped launch per depth (dnn.run_parallel)
+      outs, _ = dnn.run_parallel([dnn.DNN(self._towers[t].config.dnn, self._l2_reg, name=self._towers[t].name,
+                                          is_training=self._is_training) for t in with_dnn], [hs[t] for t in with_dnn])
+      for t, o in zip(with_dnn, outs):
+        hs[t] = o
     for t, tower in enumerate(self._towers):
-      h = inputs_per_task[t]
-      if tower.config.HasField('dnn'):
-        h = dnn.DNN(tower.config.dnn, self._l2_reg, name=tower.name, is_training=self._is_training)(h)
-      heads[tower.name] = dnn.dense(h, tower.num_class, 'dnn_output_%d' % t, l2_reg=self._l2_reg)
+      heads[tower.name] = dnn.dense(hs[t], tower.num_class, 'dnn_output_%d' % t, l2_reg=self._l2_reg)
     self._add_to_prediction_dict(heads)
     return self._prediction_dict
 

@@ -627,6 +627,11 @@ typedef struct er_gemm_problem {
   /* a_mean != NULL: A is the never-written output of a dense + BatchNorm + activation layer (er_a_transform below) */
   const float* a_mean; const float* a_invstd; const float* a_gamma; const float* a_beta;
   int32_t a_act;
+  /* col_stats != NULL: per-row-tile Welford statistics of this problem's output columns, as er_gemm_f32's col_stats
+   * ([er_gemm_row_tiles(M)][N][3]; the problem is then not k-split and must not accumulate): the same-depth layers of
+   * parallel stacks (MMoE's experts, the task towers: layers/mmoe.py:62-83, model/multi_task_model.py:33-100) run as ONE
+   * launch and still feed their BatchNorms */
+  float* col_stats;
 } er_gemm_problem;
 int er_gemm_grouped_f32(int layout, const er_gemm_problem* problems_host, int n, er_stream_t stream);
 /* DEFERRED BatchNorm + activation (reference layers/dnn.py:57-79: dense -> batch_normalization -> relu per layer).

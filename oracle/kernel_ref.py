@@ -420,6 +420,15 @@ class RefBackend(object):
       out.copy_(r)
     return out
 
+  grouped_stacks = True  # layers/dnn.py run_parallel: the lock-step host logic runs on the stand-in too
+
+  def gemm_grouped(self, layout, problems):
+    for pr in problems:
+      a, b, out, bias, accumulate = pr[:5]
+      at = pr[5] if len(pr) > 5 else None
+      A = self._deferred_value(at, a) if at is not None else a
+      self.gemm(layout, A, b, out=out, bias=bias, accumulate=accumulate)  # (column statistics: recomputed by bn_apply_from_stats)
+
   # -- deferred BatchNorm + activation (include/easyrec_hip.h er_a_transform / er_bn_finalize): the stand-in applies the
   # producer's normalisation to the operand, then contracts; statistics straight from the output
   deferred_bn = True  # (on for the stand-in: the host logic of the deferred path stays covered by the CPU tests)
