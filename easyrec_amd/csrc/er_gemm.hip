@@ -531,7 +531,7 @@ __device__ __forceinline__ void gemm_f32_block(const GemmArgs& g, int bx, int bz
   if (kend > g.K) kend = g.K;
   const int T = (kend - kbeg + BK32 - 1) / BK32;
   float py[16], pz[16];
-  if (BN_EPI) {
+  if (BN_EPI && g.bn.partial != nullptr) {  // (a grouped launch may mix problems with and without the epilogue)
     int c = n0 + wn * 32 + (lane & 31);
     c = c < g.N ? c : g.N - 1;
 #pragma unroll
@@ -680,7 +680,8 @@ __device__ __forceinline__ void gemm_f32_block(const GemmArgs& g, int bx, int bz
       fused_bn_fwd_finalize(g, n0, 0, gy, lds, s_mu, s_is);
     }
   }
-  if (BN_EPI) tile_bn_bwd_partial(acc, g.bn, py, pz, m0 + wm * 32, g.M, col, g.N, wm, wn, lane, lds, ty, g.fu.mode == 2);
+  if (BN_EPI && g.bn.partial != nullptr)
+    tile_bn_bwd_partial(acc, g.bn, py, pz, m0 + wm * 32, g.M, col, g.N, wm, wn, lane, lds, ty, g.fu.mode == 2);
   if (g.fu.mode == 1 || g.fu.mode == 2) {  // (uniform over the grid; host guarantees splits == 1 and a co-resident grid)
     const int gy = static_cast<int>(ceil_div(g.M, BM));
     tile_column_barrier(g.fu.counters + 2 * tx, static_cast<unsigned>(gy));
@@ -789,6 +790,18 @@ gemm_f32_grouped_kernel(GroupedArgs ga) {
   while (p + 1 < ga.n && b >= ga.start[p + 1]) ++p;
   const int local = b - ga.start[p];
   gemm_f32_block<A_KC, B_KC>(ga.p[p], local % ga.tiles8[p], local / ga.tiles8[p], lds);
+}
+
+// ... with the BatchNorm-backward column sums of each problem's producing layer in the epilogue (BnBwdEpi per problem)
+template <bool A_KC, bool B_KC>
+__global__ void __launch_bounds__(kBlock)
+gemm_f32_grouped_bn_bwd_kernel(GroupedArgs ga) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * 2 * kOpTile];
+  const int b = blockIdx.x;
+  int p = 0;
+  while (p + 1 < ga.n && b >= ga.start[p + 1]) ++p;
+  const int local = b - ga.start[p];
+  gemm_f32_block<A_KC, B_KC, true>(ga.p[p], local % ga.tiles8[p], local / ga.tiles8[p], lds);
 }
 
 template <bool A_KC, bool B_KC>
@@ -1245,7 +1258,9 @@ bool tn128_fits(int layout, const er_gemm_problem& q) {
   // for the two mn-contiguous operands (the transpose into the [mn][k] fragment layout), one barrier per k-tile with
   // only 2 workgroups (8 waves) per CU to hide it, and 4x fewer tiles for the split-K to spread.  ER_GEMM_TN128=1 enables.
   static const bool off = [] { const char* e = getenv("ER_GEMM_TN128"); return !(e && atoi(e) == 1); }();  // A/B switch
-  if (off || !g_tn128_ready || layout != ER_GEMM_TN || q.a_mean || q.col_stats || q.M <= er::BM || q.N <= er::BN) return false;
+  if (off || !g_tn128_ready || layout != ER_GEMM_TN || q.a_mean || q.col_stats || q.bn_partial || q.M <= er::BM ||
+      q.N <= er::BN)
+    return false;
   if (q.lda % 4 != 0 || q.ldb % 4 != 0 || ((reinterpret_cast<uintptr_t>(q.A) | reinterpret_cast<uintptr_t>(q.B)) & 15) != 0)
     return false;
   const int64_t a128 = er::ceil_div(q.M, er::BM2) * er::ceil_div(q.N, er::BM2) * 4;
@@ -1282,7 +1297,7 @@ int gemm_grouped_f32(int layout, const er_gemm_problem* pr, int n, er_stream_t s
   ra.start[0] = 0;
   size_t ws_floats = 0;
   bool vec_ok = true;
-  bool any_tr = false;
+  bool any_tr = false, any_bn = false;
   for (int i = 0; i < n; ++i) {
     const er_gemm_problem& q = pr[i];
     er::GroupedArgs& grp = big[i] ? gb : ga;
@@ -1294,6 +1309,14 @@ int gemm_grouped_f32(int layout, const er_gemm_problem* pr, int n, er_stream_t s
     a.accumulate = q.accumulate;
     a.col_stats = q.col_stats;
     ER_REQUIRE(!(q.col_stats && q.accumulate), "er_gemm_grouped_f32: problem %d: column statistics need a plain output", i);
+    if (q.bn_partial) {
+      ER_REQUIRE(q.bn_z && q.bn_ld >= q.N && !q.accumulate && (!q.bn_use_bn || (q.bn_mean && q.bn_invstd)),
+                 "er_gemm_grouped_f32: problem %d: bad BatchNorm-backward epilogue arguments", i);
+      a.bn.z = q.bn_z; a.bn.zbias = q.bn_zbias; a.bn.y = q.bn_y; a.bn.mean = q.bn_mean; a.bn.invstd = q.bn_invstd;
+      a.bn.gamma = q.bn_gamma; a.bn.beta = q.bn_beta; a.bn.ld = q.bn_ld; a.bn.use_bn = q.bn_use_bn; a.bn.act = q.bn_act;
+      a.bn.partial = q.bn_partial;
+      any_bn = true;
+    }
     if (q.a_mean) {
       ER_REQUIRE(q.a_invstd, "er_gemm_grouped_f32: problem %d: A transform without invstd", i);
       ER_REQUIRE(layout == ER_GEMM_TN || q.K <= er::kTrMaxK - 64,
@@ -1314,7 +1337,7 @@ int gemm_grouped_f32(int layout, const er_gemm_problem* pr, int n, er_stream_t s
     if (sp > 128) sp = 128;
     const int64_t max_by_k = q.K / (4 * er::BK32);
     if (sp > max_by_k) sp = max_by_k;
-    if (sp < 1 || q.col_stats) sp = 1;
+    if (sp < 1 || q.col_stats || q.bn_partial) sp = 1;
     a.k_per_split = static_cast<int>(er::ceil_div(er::ceil_div(q.K, sp), er::BK32)) * er::BK32;
     a.splits = static_cast<int>(er::ceil_div(q.K, a.k_per_split));
     const int tile = big[i] ? er::BM2 : er::BM;
@@ -1359,6 +1382,14 @@ int gemm_grouped_f32(int layout, const er_gemm_problem* pr, int n, er_stream_t s
   }
   if (ga.n == 0) {
     // (every problem took the 128 x 128 kernel)
+  } else if (any_bn) {
+    ER_REQUIRE(!any_tr, "er_gemm_grouped_f32: the A transform and the BatchNorm-backward epilogue in one launch");
+    switch (layout) {
+      case ER_GEMM_NN: hipLaunchKernelGGL((er::gemm_f32_grouped_bn_bwd_kernel<true, false>), grid, block, 0, s, ga); break;
+      case ER_GEMM_NT: hipLaunchKernelGGL((er::gemm_f32_grouped_bn_bwd_kernel<true, true>), grid, block, 0, s, ga); break;
+      case ER_GEMM_TN: hipLaunchKernelGGL((er::gemm_f32_grouped_bn_bwd_kernel<false, false>), grid, block, 0, s, ga); break;
+      default: er::set_error("er_gemm_grouped_f32: unknown layout %d", layout); return 2;
+    }
   } else if (any_tr) {
     switch (layout) {
       case ER_GEMM_NN: hipLaunchKernelGGL((er::gemm_f32_grouped_tr_kernel<true, false>), grid, block, 0, s, ga); break;

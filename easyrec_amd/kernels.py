@@ -179,7 +179,11 @@ class GemmProblem(ctypes.Structure):  # = er_gemm_problem
               ('lda', ctypes.c_int32), ('B', ctypes.c_void_p), ('ldb', ctypes.c_int32), ('C', ctypes.c_void_p),
               ('ldc', ctypes.c_int32), ('bias', ctypes.c_void_p), ('accumulate', ctypes.c_int32),
               ('a_mean', ctypes.c_void_p), ('a_invstd', ctypes.c_void_p), ('a_gamma', ctypes.c_void_p),
-              ('a_beta', ctypes.c_void_p), ('a_act', ctypes.c_int32), ('col_stats', ctypes.c_void_p)]
+              ('a_beta', ctypes.c_void_p), ('a_act', ctypes.c_int32), ('col_stats', ctypes.c_void_p),
+              ('bn_z', ctypes.c_void_p), ('bn_zbias', ctypes.c_void_p), ('bn_y', ctypes.c_void_p),
+              ('bn_mean', ctypes.c_void_p), ('bn_invstd', ctypes.c_void_p), ('bn_gamma', ctypes.c_void_p),
+              ('bn_beta', ctypes.c_void_p), ('bn_ld', ctypes.c_int32), ('bn_use_bn', ctypes.c_int32),
+              ('bn_act', ctypes.c_int32), ('bn_partial', ctypes.c_void_p)]
 
 
 CROSS_HASH_KEY = 0xDECAFCAFFE  # tf.sparse.cross_hashed's default hash_key (crossed_column(hash_key=None))
@@ -819,6 +823,7 @@ class HipBackend(object):
       a, b, out, bias, accumulate = pr[:5]
       at = pr[5] if len(pr) > 5 else None
       stats = pr[6] if len(pr) > 6 else None
+      bn = pr[7] if len(pr) > 7 else None  # (BnSource of the layer that produced this problem's output position, partial)
       if at is not None:
         assert layout != GEMM_NT and at.deferred
         q.a_mean, q.a_invstd, q.a_gamma, q.a_beta, q.a_act = _ptr(at.mean), _ptr(at.invstd), _ptr(at.gamma), \
@@ -848,6 +853,13 @@ class HipBackend(object):
       if stats is not None:
         assert stats.dtype == torch.float32 and stats.numel() >= self.gemm_row_tiles(M) * N * 3 and not accumulate
         q.col_stats = stats.data_ptr()
+      if bn is not None:
+        src, partial = bn
+        assert src.z.shape == (M, N) and partial.numel() >= self.gemm_row_tiles(M) * N * 2 and not accumulate
+        q.bn_z, q.bn_zbias, q.bn_y = _ptr(src.z), _ptr(src.zbias), _ptr(src.y)
+        q.bn_mean, q.bn_invstd, q.bn_gamma, q.bn_beta = _ptr(src.mean), _ptr(src.invstd), _ptr(src.gamma), _ptr(src.beta)
+        q.bn_ld, q.bn_use_bn, q.bn_act = src.z.stride(0), int(src.mean is not None), int(src.act)
+        q.bn_partial = partial.data_ptr()
     self._ck(self.lib.er_gemm_grouped_f32(ctypes.c_int(layout), arr, len(problems), _stream()), 'er_gemm_grouped_f32')
 
   # weight gradients of a backward pass: queued by LinearFn / LinearBNActFn, contracted together by flush_wgrads()
@@ -1761,10 +1773,15 @@ class GroupedLinearFn(torch.autograd.Function):
   an empty tensor unless stats_mask[e])."""
 
   @staticmethod
-  def forward(ctx, E, stats_mask, sinks, *args):
+  def forward(ctx, E, stats_mask, sinks, srcs, *args):
     be = hip()
     xs, ws, bs = args[:E], args[E:2 * E], args[2 * E:3 * E]
     ctx.gsinks = [sk if (sk is not None and x.stride(-1) == 1) else None for sk, x in zip(sinks, xs)]
+    # srcs[e]: the BnSource of x_e when it IS the output of a dense + BatchNorm(train) layer: the input-gradient launch
+    # then also emits that layer's BatchNorm-backward column sums (er_gemm_problem.bn_*)
+    fused = getattr(be, 'fused_bn_bwd', False)
+    ctx.srcs = [sc if (fused and sc is not None and sc.fused and not sc.deferred and x.stride(-1) == 1) else None
+                for sc, x in zip(srcs, xs)]
     xs = [x if x.stride(-1) == 1 else x.contiguous() for x in xs]
     zs, stats, problems = [], [], []
     for e in range(E):
@@ -1790,15 +1807,24 @@ class GroupedLinearFn(torch.autograd.Function):
     xs, ws = saved[:E], saved[E:2 * E]
     dzs = [g if (g.dim() == 2 and g.stride(1) == 1) else g.contiguous() for g in grads[:E]]
     dxs = [None] * E
-    need = [e for e in range(E) if ctx.needs_input_grad[3 + e]]
+    need = [e for e in range(E) if ctx.needs_input_grad[4 + e]]
     by_input = {}
     for e in need:
       by_input.setdefault(xs[e].data_ptr(), []).append(e)
     solo = [es[0] for es in by_input.values() if len(es) == 1 and ctx.gsinks[es[0]] is None]
     if solo:
+      problems = []
       for e in solo:
         dxs[e] = torch.empty_like(xs[e])
-      be.gemm_grouped(GEMM_NT, [(dzs[e], ws[e], dxs[e], None, False) for e in solo])
+        src = ctx.srcs[e]
+        if src is None:
+          problems.append((dzs[e], ws[e], dxs[e], None, False))
+        else:
+          M, N = dxs[e].shape
+          partial = torch.empty(be.gemm_row_tiles(M) * N * 2, dtype=torch.float32, device=dxs[e].device)
+          problems.append((dzs[e], ws[e], dxs[e], None, False, None, None, (src, partial)))
+          src.partial, src.dx_ptr = partial, dxs[e].data_ptr()
+      be.gemm_grouped(GEMM_NT, problems)
     for es in by_input.values():
       if len(es) == 1 and ctx.gsinks[es[0]] is None:
         continue
@@ -1813,15 +1839,15 @@ class GroupedLinearFn(torch.autograd.Function):
       dxs[es[0]] = acc
     dws, dbs = [None] * E, [None] * E
     for e in range(E):
-      if ctx.needs_input_grad[3 + E + e]:
+      if ctx.needs_input_grad[4 + E + e]:
         dws[e] = _wgrad(be, xs[e], dzs[e], ctx.wgrads[e], False, None, ctx.sink)
       b = ctx.bs[e]
-      if b is not None and ctx.needs_input_grad[3 + 2 * E + e]:
+      if b is not None and ctx.needs_input_grad[4 + 2 * E + e]:
         if b.grad is not None:
           be.colsum(dzs[e], out=b.grad, accumulate=True)
         else:
           dbs[e] = be.colsum(dzs[e])
-    return (None, None, None) + tuple(dxs) + tuple(dws) + tuple(dbs)
+    return (None, None, None, None) + tuple(dxs) + tuple(dws) + tuple(dbs)
 
 
 class BNFromStatsFn(torch.autograd.Function):
@@ -1835,6 +1861,9 @@ class BNFromStatsFn(torch.autograd.Function):
                                              moving_mean, moving_var, act)
     ctx.save_for_backward(z, gamma, y, mean, invstd)
     ctx.act, ctx.grad_bufs = act, grad_bufs
+    fused = getattr(be, 'fused_bn_bwd', False)
+    ctx.own = BnSource(z, None, y, mean, invstd, act, gamma, grad_bufs, beta=beta, fused=fused) if fused else None
+    _bn_tls.last = ctx.own
     return y
 
   @staticmethod
@@ -1844,8 +1873,14 @@ class BNFromStatsFn(torch.autograd.Function):
     gg, betag = ctx.grad_bufs if ctx.grad_bufs is not None else (None, None)
     direct = gg is not None and betag is not None
     dyc = dy if (dy.dim() == 2 and dy.stride(1) == 1) else dy.contiguous()
+    own, partial = ctx.own, None
+    if own is not None:
+      # the consumer's input-gradient launch already reduced the column sums, provided dy is exactly its output
+      if own.partial is not None and dyc.data_ptr() == own.dx_ptr:
+        partial = own.partial
+      own.partial = None
     dz, _, dgamma, dbeta = be.bn_act_bwd(z, None, gamma, y, mean, invstd, dyc, 1, ctx.act, False, True,
-                                         into=(None, gg, betag) if direct else None)
+                                         into=(None, gg, betag) if direct else None, partial=partial)
     return dz, None, dgamma, dbeta, None, None, None, None, None, None
 
 

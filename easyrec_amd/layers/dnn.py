@@ -149,8 +149,11 @@ def run_parallel(stacks, inputs, extra_dense=()):
         mv = vs.get_variable(layer + '/bn/moving_variance', (unit,), 'ones', trainable=False)
       xs.append(x)
       ws.append(w)
-      bs.append(b)
-      metas.append((use_bn, use_act and is_relu(d._act_string), d._is_training, gamma, beta, mm, mv))
+      # the bias: in the GEMM's epilogue where batch statistics follow (they must see it; its gradient is zero under
+      # BatchNorm), else left to the bias + normalise + activate kernel, whose backward also yields the bias gradient -
+      # no separate column sums either way
+      bs.append(b if (use_bn and d._is_training) else None)
+      metas.append((use_bn, use_act and is_relu(d._act_string), d._is_training, gamma, beta, mm, mv, b))
     if i == 0:
       for x, units, name, l2 in extra_dense:
         xs.append(x)
@@ -160,27 +163,31 @@ def run_parallel(stacks, inputs, extra_dense=()):
     E = len(xs)
     train_bn = [m is not None and bool(m[0]) and m[2] for m in metas]  # batch statistics: from the GEMM's epilogue
     sinks = tuple(kernels.grad_sink_of(x) for x in xs)
-    out = kernels.GroupedLinearFn.apply(E, tuple(train_bn), sinks, *xs, *ws, *bs)
+    srcs = tuple(kernels.bn_source_of(x) for x in xs)
+    out = kernels.GroupedLinearFn.apply(E, tuple(train_bn), sinks, srcs, *xs, *ws, *bs)
     zs, stats = out[:E], out[E:]
     nxt = []
     for e, m in enumerate(metas):
       if m is None:
         extras.append(zs[e])
         continue
-      use_bn, relu, training, gamma, beta, mm, mv = m
+      use_bn, relu, training, gamma, beta, mm, mv, bias = m
       act = kernels.ACT_RELU if relu else kernels.ACT_NONE
       freeze = ctx.building and training  # build pass: do not touch the moving statistics
       if train_bn[e]:
         gb = (gamma.grad, beta.grad) if (gamma.grad is not None and beta.grad is not None) else None
         y = kernels.BNFromStatsFn.apply(zs[e], stats[e], gamma, beta, None if freeze else mm, None if freeze else mv,
                                         BN_EPSILON, BN_MOMENTUM, act, gb)
+        src = kernels.take_last_bn_source()
+        if src is not None:
+          y = kernels.tag_bn_source(y, src)
       elif use_bn or relu:
-        # BatchNorm on the moving statistics (the experts of the reference's MMoE) and / or ReLU: one launch; the bias is
-        # already in z
-        y = kernels.BNActFn.apply(zs[e], None, gamma, beta, None if freeze else mm, None if freeze else mv, use_bn,
-                                  BN_EPSILON, BN_MOMENTUM, act, training, _grad_bufs(None, gamma, beta))
+        # BatchNorm on the moving statistics (the experts of the reference's MMoE) and / or ReLU: one launch
+        y = kernels.BNActFn.apply(zs[e], bias, gamma, beta, None if freeze else mm, None if freeze else mv, use_bn,
+                                  BN_EPSILON, BN_MOMENTUM, act, training, _grad_bufs(bias, gamma, beta))
       else:
-        y = zs[e]
+        y = kernels.BNActFn.apply(zs[e], bias, None, None, None, None, 0, BN_EPSILON, BN_MOMENTUM, kernels.ACT_NONE,
+                                  training, _grad_bufs(bias, None, None))
       nxt.append(y)
     cur = nxt
   return cur, extras

@@ -632,6 +632,13 @@ typedef struct er_gemm_problem {
    * parallel stacks (MMoE's experts, the task towers: layers/mmoe.py:62-83, model/multi_task_model.py:33-100) run as ONE
    * launch and still feed their BatchNorms */
   float* col_stats;
+  /* bn_partial != NULL: the epilogue of er_gemm_f32_bn_bwd(_z) for this problem - the BatchNorm-backward column sums of
+   * the layer that produced the problem's OUTPUT position (z, y (NULL: recomputed from z with gamma / beta), statistics,
+   * leading dimension of z / y, partial [er_gemm_row_tiles(M)][N][2]); not k-split, no accumulate */
+  const float* bn_z; const float* bn_zbias; const float* bn_y; const float* bn_mean; const float* bn_invstd;
+  const float* bn_gamma; const float* bn_beta;
+  int32_t bn_ld, bn_use_bn, bn_act;
+  float* bn_partial;
 } er_gemm_problem;
 int er_gemm_grouped_f32(int layout, const er_gemm_problem* problems_host, int n, er_stream_t stream);
 /* DEFERRED BatchNorm + activation (reference layers/dnn.py:57-79: dense -> batch_normalization -> relu per layer).

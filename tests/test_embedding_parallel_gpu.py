@@ -359,7 +359,10 @@ def test_lazy_decay_equals_sweep_through_two_sharded_ranks(monkeypatch, overlap)
   cfg = _cfg('deepfm_criteo_small.config')
   B, world = 64, 2
   feats = list(cfg.feature_config.features)
-  scheds = [_idle_schedule(cfg, feats, B, 1000)]
+  # ('closed': a short horizon - two whole-model runs that differ in rounding separate under this config's training
+  #  dynamics, test_deepfm_gpu._assert_closed_tracks_sweep; the long idle times are held on the single-GPU rows that
+  #  nothing but the replay acts on, here the owners' closed-form catch-up of er_emb_owner_serve is what is exercised)
+  scheds = [_idle_schedule(cfg, feats, B, 20 if overlap == 'closed' else 1000)]
   gen = SyntheticCriteo(cfg.data_config, feats, batch_size=B, seed=77)
   scheds.append([gen.next_batch() for _ in range(len(scheds[0]))])  # rank 1: fresh batches throughout
   states = {}

@@ -1040,6 +1040,62 @@ def test_gemm_grouped_matches_single_launches(hip):
     assert torch.equal(p[2], f)
 
 
+def test_grouped_launch_epilogues_match_single_launches(hip):
+  """What kernels.GroupedLinearFn relies on: problems of ONE grouped launch with their own epilogues - bias + per-row-tile
+  column statistics forward (er_gemm_problem.col_stats), the BatchNorm-backward column sums of the producing layer on the
+  input-gradient side (er_gemm_problem.bn_*) - give the bits of the single launches er_gemm_f32(col_stats) /
+  er_gemm_f32_bn_bwd, next to problems without any epilogue."""
+  g = torch.Generator().manual_seed(3)
+  shapes = [(8192, 256, 64), (8192, 192, 256), (300, 70, 33), (8192, 4, 64)]
+  xs = [torch.randn(M, K, generator=g).to(DEV) for (M, N, K) in shapes]
+  ws = [(torch.randn(K, N, generator=g) * 0.1).to(DEV) for (M, N, K) in shapes]
+  bs = [torch.randn(N, generator=g).to(DEV) for (M, N, K) in shapes]
+  want_stats = [True, True, True, False]
+  single_z, single_st = [], []
+  for x, w, b, ws_ in zip(xs, ws, bs, want_stats):
+    st = torch.zeros(hip.gemm_row_tiles(x.shape[0]) * w.shape[1] * 3, device=DEV) if ws_ else None
+    single_z.append(hip.gemm(kernels.GEMM_NN, x, w, bias=b, col_stats=st))
+    single_st.append(st)
+  zs = [torch.empty_like(z) for z in single_z]
+  sts = [torch.zeros_like(st) if st is not None else None for st in single_st]
+  hip.gemm_grouped(kernels.GEMM_NN, [(x, w, z, b, False, None, st) for x, w, z, b, st in zip(xs, ws, zs, bs, sts)])
+  torch.cuda.synchronize()
+  for i in range(len(shapes)):
+    assert torch.equal(zs[i], single_z[i]), i
+    if sts[i] is not None:
+      assert torch.equal(sts[i], single_st[i]), i
+  # input gradients: dx_e = dz_e . W_e^T, two of the four with the BatchNorm-backward sums of the layer that produced x_e
+  srcs, dzs = [], []
+  for i, (M, N, K) in enumerate(shapes):
+    dzs.append((torch.randn(M, N, generator=g) * 0.01).to(DEV))
+    if i in (0, 2):  # x_i as the output of a dense + BatchNorm + ReLU layer
+      zprev = torch.randn(M, K, generator=g).to(DEV)
+      gamma, beta = (torch.rand(K, generator=g) + 0.5).to(DEV), (torch.randn(K, generator=g) * 0.1).to(DEV)
+      y, mean, invstd = hip.bn_act_fwd(zprev, None, gamma, beta, 1, 1e-3, 0.99, torch.zeros(K, device=DEV),
+                                       torch.ones(K, device=DEV), kernels.ACT_RELU)
+      srcs.append(kernels.BnSource(zprev, None, y, mean, invstd, kernels.ACT_RELU, gamma, None, beta=beta))
+    else:
+      srcs.append(None)
+  single_dx, single_part = [], []
+  for i, (M, N, K) in enumerate(shapes):
+    if srcs[i] is not None:
+      part = torch.zeros(hip.gemm_row_tiles(M) * K * 2, device=DEV)
+      single_dx.append(hip.gemm_bn_bwd(kernels.GEMM_NT, dzs[i], ws[i], srcs[i], part))
+      single_part.append(part)
+    else:
+      single_dx.append(hip.gemm(kernels.GEMM_NT, dzs[i], ws[i]))
+      single_part.append(None)
+  dxs = [torch.empty_like(d) for d in single_dx]
+  parts = [torch.zeros_like(p) if p is not None else None for p in single_part]
+  hip.gemm_grouped(kernels.GEMM_NT, [(dzs[i], ws[i], dxs[i], None, False) + ((None, None, (srcs[i], parts[i])) if srcs[i] is not None else ())
+                                     for i in range(len(shapes))])
+  torch.cuda.synchronize()
+  for i in range(len(shapes)):
+    assert torch.equal(dxs[i], single_dx[i]), i
+    if parts[i] is not None:
+      assert torch.equal(parts[i], single_part[i]), i
+
+
 @pytest.mark.parametrize('B,N,K', [(4096, 256, 128), (300, 70, 33), (64, 1, 16), (130, 128, 64)])
 @pytest.mark.parametrize('act', [kernels.ACT_RELU, kernels.ACT_NONE])
 def test_dgrad_gemm_emits_batchnorm_backward_sums(hip, B, N, K, act):

@@ -15,5 +15,5 @@ for f in r.get('families', []): print('   ', f['family'], round(f['us_per_step']
 for k in r.get('kernels', [])[:14]: print('      ', round(k['us_per_step'],1), k['launches_per_step'], k['kernel'][:80])
 "; }
 run() { name=$1; shift; echo "--- $name: $*" | tee -a $O/lines.log; ( time timeout 1200 python bench.py "$@" ) > $O/$name.out 2>&1; grep '^{' $O/$name.out | tail -1 | tee -a $O/bench_lines.jsonl | line | tee -a $O/lines.log; grep -E "^real|Error|Traceback" $O/$name.out | head -3; }
-run mmoe25m_grouped --config configs/mmoe_taobao_4task_d64_25m.config --steady_steps 128 --precondition 128 --cpu_seconds 2
+run mmoe25m_grouped --config configs/mmoe_taobao_4task_d64_25m.config --no_cpu_baseline --steady_steps 128 --precondition 128
 EASYREC_AMD_GROUPED_STACKS=0 run mmoe25m_sequential --config configs/mmoe_taobao_4task_d64_25m.config --no_cpu_baseline --steady_steps 128 --precondition 128
