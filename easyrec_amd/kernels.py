@@ -1795,6 +1795,8 @@ class GroupedLinearFn(torch.autograd.Function):
     ctx.save_for_backward(*xs, *ws)
     ctx.E, ctx.bs = E, bs
     ctx.wgrads = [w.grad if (w.requires_grad and w.grad is not None) else None for w in ws]  # slices of the flat buffer
+    ctx.stats_mask = tuple(stats_mask)
+    ctx.set_materialize_grads(False)  # (the statistics outputs get no gradient: no zero tensors to be filled for them)
     ctx.sink = be.wgrad_sink()
     ctx.mark_non_differentiable(*stats)
     return tuple(zs) + tuple(stats)
@@ -1805,7 +1807,8 @@ class GroupedLinearFn(torch.autograd.Function):
     E = ctx.E
     saved = ctx.saved_tensors
     xs, ws = saved[:E], saved[E:2 * E]
-    dzs = [g if (g.dim() == 2 and g.stride(1) == 1) else g.contiguous() for g in grads[:E]]
+    dzs = [None if g is None else (g if (g.dim() == 2 and g.stride(1) == 1) else g.contiguous()) for g in grads[:E]]
+    assert all(g is not None for g in dzs), 'an output of GroupedLinearFn was left out of the loss'  
     dxs = [None] * E
     need = [e for e in range(E) if ctx.needs_input_grad[4 + e]]
     by_input = {}
@@ -1842,7 +1845,8 @@ class GroupedLinearFn(torch.autograd.Function):
       if ctx.needs_input_grad[4 + E + e]:
         dws[e] = _wgrad(be, xs[e], dzs[e], ctx.wgrads[e], False, None, ctx.sink)
       b = ctx.bs[e]
-      if b is not None and ctx.needs_input_grad[4 + 2 * E + e]:
+      # (a layer whose output feeds BatchNorm on batch statistics - stats_mask - has a bias gradient of exactly zero)
+      if b is not None and not ctx.stats_mask[e] and ctx.needs_input_grad[4 + 2 * E + e]:
         if b.grad is not None:
           be.colsum(dzs[e], out=b.grad, accumulate=True)
         else:

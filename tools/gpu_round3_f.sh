@@ -1,0 +1,4 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
+O=gpurun_out/r03f; mkdir -p $O
+timeout 600 python -m pytest tests/test_embedding_parallel_gpu.py -m gpu -q -x -k "closed_form" 2>&1 | tail -30 | tee $O/serve_test.txt
