@@ -367,7 +367,7 @@ def step_roofline(est, per_kernel, flops, emb_bytes, pmc):
     out.update({'bound': 'mfma', 'achieved': ach, 'peak': peak_tf, 'unit': 'TFLOP/s', 'frac': ach / peak_tf,
                 'algorithmic_flops_per_launch': f_dom / max(n, 1e-9), 'algorithmic_flops_per_step': f_dom})
   else:
-    b = emb_bytes.get(dom_key(dom)) if emb_bytes else None
+    b = (emb_bytes.get(dom_key(dom)) or emb_bytes.get(dom_key(dom).split('<')[0])) if emb_bytes else None
     ach = (b / (us * 1e-6) / 1e9) if b else None
     out.update({'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': (ach / HBM_PEAK_GBS) if ach else None, 'algorithmic_bytes_per_launch': (b / max(n, 1e-9)) if b else None})
@@ -396,9 +396,9 @@ def step_roofline(est, per_kernel, flops, emb_bytes, pmc):
 
 
 def dom_key(name):
-  """`er::emb_bwd_tile_multi_kernel(er::RunMulti)` -> `emb_bwd_tile_multi_kernel`"""
-  n = name.split('(')[0].split('<')[0]
-  return n.replace('void ', '').replace('er::', '').strip()
+  """`void er::gemm_f32_kernel<true, false>(er::GemmArgs)` -> `gemm_f32_kernel<true, false>` (the keys of
+  profiles/pmc_traffic.json `by_kernel` and of embedding_bytes_per_step)"""
+  return name.split('(')[0].replace('void ', '').replace('er::', '').strip()
 
 
 class DeviceCriteo(object):
