@@ -129,12 +129,11 @@ bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ bias, con
 // DBMTL models build their experts that way (model/mmoe.py:37-47, model/dbmtl.py:66-70 call layers/mmoe.py MMOE
 // without is_training, whose default is False): the MOVING statistics normalise, nothing updates them, gamma / beta /
 // the bias and the input still receive gradients.  save_mean / save_invstd are written for the backward.
-__global__ void __launch_bounds__(kBlock)
-bn_frozen_apply_kernel(const float* __restrict__ x, const float* __restrict__ bias, const float* __restrict__ gamma,
+__device__ __forceinline__ void bn_frozen_apply_body(const float* __restrict__ x, const float* __restrict__ bias, const float* __restrict__ gamma,
                        const float* __restrict__ beta, const float* __restrict__ moving_mean,
                        const float* __restrict__ moving_var, int64_t n, int N, float eps, int act,
-                       float* __restrict__ y, float* __restrict__ save_mean, float* __restrict__ save_invstd) {
-  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+                       float* __restrict__ y, float* __restrict__ save_mean, float* __restrict__ save_invstd, int bx, int by) {
+  const int64_t i = static_cast<int64_t>(bx) * kBlock + threadIdx.x;
   if (i >= n) return;
   const int c = static_cast<int>(i % N);
   const float mu = moving_mean[c];
@@ -148,6 +147,15 @@ bn_frozen_apply_kernel(const float* __restrict__ x, const float* __restrict__ bi
   if (act == ER_ACT_RELU) v = v > 0.f ? v : 0.f;
   y[i] = v;
 }
+
+__global__ void __launch_bounds__(kBlock)
+bn_frozen_apply_kernel(const float* __restrict__ x, const float* __restrict__ bias, const float* __restrict__ gamma,
+                       const float* __restrict__ beta, const float* __restrict__ moving_mean,
+                       const float* __restrict__ moving_var, int64_t n, int N, float eps, int act,
+                       float* __restrict__ y, float* __restrict__ save_mean, float* __restrict__ save_invstd) {
+  bn_frozen_apply_body(x, bias, gamma, beta, moving_mean, moving_var, n, N, eps, act, y, save_mean, save_invstd, static_cast<int>(blockIdx.x), static_cast<int>(blockIdx.y));
+}
+
 
 // Fused finalize + apply.  grid = (column blocks of 64, row blocks of kApplyRows); every workgroup first
 // merges the `chunks` Welford partials of ITS 64 columns (4 row-lanes x chunks/4 each, then a fixed merge:
@@ -224,17 +232,16 @@ bn_bwd_merge_kernel(const float* __restrict__ partial, int N, int chunks, int pe
   }
 }
 
-__global__ void __launch_bounds__(kBlock)
-bn_finalize_apply_kernel(const float* __restrict__ partial, const float* __restrict__ x, const float* __restrict__ bias,
+__device__ __forceinline__ void bn_finalize_apply_body(const float* __restrict__ partial, const float* __restrict__ x, const float* __restrict__ bias,
                          const float* __restrict__ gamma, const float* __restrict__ beta, int B, int N, int chunks,
                          float eps, float momentum, float* __restrict__ moving_mean, float* __restrict__ moving_var,
                          int act, float* __restrict__ y, float* __restrict__ save_mean,
-                         float* __restrict__ save_invstd, int tiles_per_block) {
+                         float* __restrict__ save_invstd, int tiles_per_block, int bx, int by) {
   __shared__ Welford sm[kRowLanes][kColsPerBlock];
   __shared__ float s_mean[kColsPerBlock], s_inv[kColsPerBlock];
   const int cl = threadIdx.x % kColsPerBlock;
   const int rl = threadIdx.x / kColsPerBlock;
-  const int c = blockIdx.x * kColsPerBlock + cl;
+  const int c = bx * kColsPerBlock + cl;
   Welford t{0.f, 0.f, 0.f};
   if (c < N) {
     // groups of 8 partials: the 24 loads of a group are issued together, then merged in order
@@ -263,7 +270,7 @@ bn_finalize_apply_kernel(const float* __restrict__ partial, const float* __restr
     const float inv = 1.f / sqrtf(var + eps);
     s_mean[cl] = mean;
     s_inv[cl] = inv;
-    if (blockIdx.y == 0) {
+    if (by == 0) {
       save_mean[c] = mean;
       save_invstd[c] = inv;
       if (moving_mean) {
@@ -281,7 +288,7 @@ bn_finalize_apply_kernel(const float* __restrict__ partial, const float* __restr
   // tiles_per_block row tiles per workgroup (1 for batch-sized layers; tall activations - DIN's B x L rows - amortise
   // the partial merge above over 16 tiles)
   for (int tile = 0; tile < tiles_per_block; ++tile) {
-    const int r0 = (blockIdx.y * tiles_per_block + tile) * kApplyRows + rl;
+    const int r0 = (by * tiles_per_block + tile) * kApplyRows + rl;
     if (r0 - rl >= B) break;
     // fixed trip count, fully unrolled: all the tile's loads of a lane are in flight together
     float xv[kApplyRows / kRowLanes];
@@ -303,6 +310,16 @@ bn_finalize_apply_kernel(const float* __restrict__ partial, const float* __restr
   }
 }
 
+__global__ void __launch_bounds__(kBlock)
+bn_finalize_apply_kernel(const float* __restrict__ partial, const float* __restrict__ x, const float* __restrict__ bias,
+                         const float* __restrict__ gamma, const float* __restrict__ beta, int B, int N, int chunks,
+                         float eps, float momentum, float* __restrict__ moving_mean, float* __restrict__ moving_var,
+                         int act, float* __restrict__ y, float* __restrict__ save_mean,
+                         float* __restrict__ save_invstd, int tiles_per_block) {
+  bn_finalize_apply_body(partial, x, bias, gamma, beta, B, N, chunks, eps, momentum, moving_mean, moving_var, act, y, save_mean, save_invstd, tiles_per_block, static_cast<int>(blockIdx.x), static_cast<int>(blockIdx.y));
+}
+
+
 __device__ __forceinline__ float recomputed_y(float z, float mu, float is, float ga, float be, int use_bn) {
   if (!use_bn) return z;
   const float v = (z - mu) * is;
@@ -310,16 +327,15 @@ __device__ __forceinline__ float recomputed_y(float z, float mu, float is, float
 }
 
 // backward partials: p[(chunk*N + c)*2 + {0,1}] = (sum g, sum g*xhat), g = dy * act'(y)
-__global__ void __launch_bounds__(kBlock)
-bn_bwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ bias, const float* __restrict__ y,
+__device__ __forceinline__ void bn_bwd_partial_body(const float* __restrict__ x, const float* __restrict__ bias, const float* __restrict__ y,
                       const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ dy,
                       int B, int N, int chunks, int use_bn, int act, float* __restrict__ partial, int dy_ld,
-                      const float* __restrict__ gamma = nullptr, const float* __restrict__ beta = nullptr) {
+                      const float* __restrict__ gamma, const float* __restrict__ beta, int bx, int by) {
   __shared__ float sm[2][kRowLanes][kColsPerBlock];
   const int cl = threadIdx.x % kColsPerBlock;
   const int rl = threadIdx.x / kColsPerBlock;
-  const int c = blockIdx.x * kColsPerBlock + cl;
-  const int chunk = blockIdx.y;
+  const int c = bx * kColsPerBlock + cl;
+  const int chunk = by;
   const int rows_per_chunk = static_cast<int>(ceil_div(B, chunks));
   const int r0 = chunk * rows_per_chunk;
   const int r1 = (r0 + rows_per_chunk < B) ? r0 + rows_per_chunk : B;
@@ -348,21 +364,29 @@ bn_bwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ bia
   }
 }
 
+__global__ void __launch_bounds__(kBlock)
+bn_bwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ bias, const float* __restrict__ y,
+                      const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ dy,
+                      int B, int N, int chunks, int use_bn, int act, float* __restrict__ partial, int dy_ld,
+                      const float* __restrict__ gamma = nullptr, const float* __restrict__ beta = nullptr) {
+  bn_bwd_partial_body(x, bias, y, mean, invstd, dy, B, N, chunks, use_bn, act, partial, dy_ld, gamma, beta, static_cast<int>(blockIdx.x), static_cast<int>(blockIdx.y));
+}
+
+
 // Fused finalize + apply of the backward: every workgroup reduces the partials of its 64 columns (fixed order),
 // row block 0 writes / accumulates dgamma, dbeta (dbias without BatchNorm), then dx for its [rows x 64] tile.
-__global__ void __launch_bounds__(kBlock)
-bn_bwd_finalize_apply_kernel(const float* __restrict__ partial, const float* __restrict__ x,
+__device__ __forceinline__ void bn_bwd_finalize_apply_body(const float* __restrict__ partial, const float* __restrict__ x,
                              const float* __restrict__ bias, const float* __restrict__ gamma,
                              const float* __restrict__ y, const float* __restrict__ mean,
                              const float* __restrict__ invstd, const float* __restrict__ dy, int B, int N,
                              int chunks, int use_bn, int act, int accumulate, float* __restrict__ dx,
                              float* __restrict__ dbias, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                             int dy_ld, int tiles_per_block, const float* __restrict__ beta = nullptr) {
+                             int dy_ld, int tiles_per_block, const float* __restrict__ beta, int bx, int by) {
   __shared__ float sm[2][kRowLanes][kColsPerBlock];
   __shared__ float s_g[kColsPerBlock], s_gx[kColsPerBlock];
   const int cl = threadIdx.x % kColsPerBlock;
   const int rl = threadIdx.x / kColsPerBlock;
-  const int c = blockIdx.x * kColsPerBlock + cl;
+  const int c = bx * kColsPerBlock + cl;
   float a = 0.f, b = 0.f;
   if (c < N) {
 #pragma unroll 8
@@ -380,7 +404,7 @@ bn_bwd_finalize_apply_kernel(const float* __restrict__ partial, const float* __r
     b = (sm[1][0][cl] + sm[1][1][cl]) + (sm[1][2][cl] + sm[1][3][cl]);
     s_g[cl] = a;
     s_gx[cl] = b;
-    if (blockIdx.y == 0) {
+    if (by == 0) {
       if (use_bn) {
         if (dbeta) dbeta[c] = accumulate ? dbeta[c] + a : a;
         if (dgamma) dgamma[c] = accumulate ? dgamma[c] + b : b;
@@ -406,7 +430,7 @@ bn_bwd_finalize_apply_kernel(const float* __restrict__ partial, const float* __r
   const float invB = 1.f / static_cast<float>(B);
   constexpr int kIter = kApplyRows / kRowLanes;
   for (int tile = 0; tile < tiles_per_block; ++tile) {
-    const int r0 = (blockIdx.y * tiles_per_block + tile) * kApplyRows + rl;
+    const int r0 = (by * tiles_per_block + tile) * kApplyRows + rl;
     if (r0 - rl >= B) break;
     float gv[kIter], yv[kIter], xv[kIter];
 #pragma unroll
@@ -432,6 +456,88 @@ bn_bwd_finalize_apply_kernel(const float* __restrict__ partial, const float* __r
       }
     }
   }
+}
+
+__global__ void __launch_bounds__(kBlock)
+bn_bwd_finalize_apply_kernel(const float* __restrict__ partial, const float* __restrict__ x,
+                             const float* __restrict__ bias, const float* __restrict__ gamma,
+                             const float* __restrict__ y, const float* __restrict__ mean,
+                             const float* __restrict__ invstd, const float* __restrict__ dy, int B, int N,
+                             int chunks, int use_bn, int act, int accumulate, float* __restrict__ dx,
+                             float* __restrict__ dbias, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                             int dy_ld, int tiles_per_block, const float* __restrict__ beta = nullptr) {
+  bn_bwd_finalize_apply_body(partial, x, bias, gamma, y, mean, invstd, dy, B, N, chunks, use_bn, act, accumulate, dx, dbias, dgamma, dbeta, dy_ld, tiles_per_block, beta, static_cast<int>(blockIdx.x), static_cast<int>(blockIdx.y));
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// The bias / BatchNorm / activation kernels of SEVERAL layer outputs in ONE launch (er_bn_fwd_multi / er_bn_bwd_multi):
+// the same-depth layers of parallel stacks (MMoE's experts and task towers) each own a few-microsecond launch that fills
+// a fraction of the chip; workgroups [start[i], start[i + 1]) run layer i's body - the bodies of the single-layer
+// kernels above, same arithmetic, same bits.
+// ------------------------------------------------------------------------------------------------
+constexpr int kBnMulti = 8;
+struct BnItem {
+  const float* x; const float* bias; const float* gamma; const float* beta;
+  float* moving_mean; float* moving_var;
+  const float* partial;   // forward: Welford column statistics [chunks][N][3]; backward: column sums [chunks][N][2]
+  float* y; float* save_mean; float* save_invstd;
+  const float* yin;       // backward: the layer's activation output
+  const float* dy; float* dx; float* dbias; float* dgamma; float* dbeta;
+  float* scratch;         // backward phase 1 output (when the sums are computed here)
+  int B, N, chunks, mode, act, dy_ld, accumulate, tpb, gx;
+  float eps, momentum;
+};
+struct BnMultiArgs {
+  int n;
+  int start[kBnMulti + 1];
+  BnItem d[kBnMulti];
+};
+
+__device__ __forceinline__ int bn_multi_find(const BnMultiArgs& a, int b) {
+  int i = 0;
+  while (i + 1 < a.n && b >= a.start[i + 1]) ++i;
+  return i;
+}
+
+__global__ void __launch_bounds__(kBlock)
+bn_fwd_multi_kernel(BnMultiArgs a) {
+  const int i = bn_multi_find(a, blockIdx.x);
+  const BnItem& d = a.d[i];
+  const int local = blockIdx.x - a.start[i];
+  if (d.mode == 1) {  // batch statistics from the GEMM's epilogue: finalise + normalise + activate
+    bn_finalize_apply_body(d.partial, d.x, d.bias, d.gamma, d.beta, d.B, d.N, d.chunks, d.eps, d.momentum, d.moving_mean,
+                           d.moving_var, d.act, d.y, d.save_mean, d.save_invstd, d.tpb, local % d.gx, local / d.gx);
+  } else if (d.mode == ER_BN_FROZEN) {
+    bn_frozen_apply_body(d.x, d.bias, d.gamma, d.beta, d.moving_mean, d.moving_var, static_cast<int64_t>(d.B) * d.N, d.N,
+                         d.eps, d.act, d.y, d.save_mean, d.save_invstd, local, 0);
+  } else {  // bias + activation only
+    const int64_t idx = static_cast<int64_t>(local) * kBlock + threadIdx.x;
+    if (idx < static_cast<int64_t>(d.B) * d.N) {
+      float v = d.x[idx] + (d.bias ? d.bias[idx % d.N] : 0.f);
+      if (d.act == ER_ACT_RELU) v = v > 0.f ? v : 0.f;
+      d.y[idx] = v;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+bn_bwd_partial_multi_kernel(BnMultiArgs a) {
+  const int i = bn_multi_find(a, blockIdx.x);
+  const BnItem& d = a.d[i];
+  const int local = blockIdx.x - a.start[i];
+  bn_bwd_partial_body(d.x, d.bias, d.yin, d.save_mean, d.save_invstd, d.dy, d.B, d.N, d.chunks, d.mode, d.act, d.scratch,
+                      d.dy_ld, d.gamma, d.beta, local % d.gx, local / d.gx);
+}
+
+__global__ void __launch_bounds__(kBlock)
+bn_bwd_finalize_apply_multi_kernel(BnMultiArgs a) {
+  const int i = bn_multi_find(a, blockIdx.x);
+  const BnItem& d = a.d[i];
+  const int local = blockIdx.x - a.start[i];
+  bn_bwd_finalize_apply_body(d.partial, d.x, d.bias, d.gamma, d.yin, d.save_mean, d.save_invstd, d.dy, d.B, d.N, d.chunks,
+                             d.mode, d.act, d.accumulate, d.dx, d.dbias, d.dgamma, d.dbeta, d.dy_ld, d.tpb, d.beta,
+                             local % d.gx, local / d.gx);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1033,6 +1139,101 @@ int er_bn_act_bwd_z(const float* z, const float* bias, const float* gamma, const
                      static_cast<const float*>(nullptr), save_mean, save_invstd, dy, B, N, chunks, use_bn, act, accumulate,
                      dx, dbias, dgamma, dbeta, dy_ld, tpb, beta);
   ER_LAUNCH_CHECK();
+  return 0;
+}
+
+int er_bn_fwd_multi(const er_bn_layer* layers, int n, er_stream_t stream) {
+  ER_REQUIRE(layers && n >= 1, "er_bn_fwd_multi: bad arguments");
+  for (int base = 0; base < n; base += er::kBnMulti) {
+    er::BnMultiArgs a;
+    a.n = 0;
+    a.start[0] = 0;
+    for (int i = base; i < n && i < base + er::kBnMulti; ++i) {
+      const er_bn_layer& q = layers[i];
+      ER_REQUIRE(q.x && q.y && q.B > 0 && q.N > 0, "er_bn_fwd_multi: layer %d: bad arguments", i);
+      er::BnItem& d = a.d[a.n];
+      d = er::BnItem();
+      d.x = q.x; d.bias = q.bias; d.gamma = q.gamma; d.beta = q.beta; d.moving_mean = q.moving_mean; d.moving_var = q.moving_var;
+      d.y = q.y; d.save_mean = q.save_mean; d.save_invstd = q.save_invstd;
+      d.B = q.B; d.N = q.N; d.mode = q.use_bn; d.act = q.act; d.eps = q.eps; d.momentum = q.momentum;
+      int blocks;
+      if (q.use_bn == 1) {
+        ER_REQUIRE(q.col_stats && q.chunks > 0 && q.chunks <= er::kInlineChunks && q.save_mean && q.save_invstd,
+                   "er_bn_fwd_multi: layer %d: batch statistics need col_stats of at most %d row tiles, save_mean, save_invstd",
+                   i, er::kInlineChunks);
+        d.partial = q.col_stats; d.chunks = q.chunks;
+        d.tpb = er::apply_tiles_per_block(q.B);
+        d.gx = static_cast<int>(er::ceil_div(q.N, er::kColsPerBlock));
+        blocks = d.gx * static_cast<int>(er::ceil_div(q.B, er::kApplyRows * d.tpb));
+      } else {
+        ER_REQUIRE(q.use_bn != ER_BN_FROZEN || (q.moving_mean && q.moving_var && q.save_mean && q.save_invstd),
+                   "er_bn_fwd_multi: layer %d: ER_BN_FROZEN needs the moving statistics and save_mean / save_invstd", i);
+        d.gx = 1;
+        blocks = er::blocks_for(static_cast<int64_t>(q.B) * q.N);
+      }
+      a.start[a.n + 1] = a.start[a.n] + blocks;
+      ++a.n;
+    }
+    hipLaunchKernelGGL(er::bn_fwd_multi_kernel, dim3(static_cast<unsigned>(a.start[a.n])), dim3(er::kBlock), 0,
+                       er::as_stream(stream), a);
+    ER_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+int er_bn_bwd_multi(const er_bn_layer* layers, int n, er_stream_t stream) {
+  ER_REQUIRE(layers && n >= 1, "er_bn_bwd_multi: bad arguments");
+  hipStream_t s = er::as_stream(stream);
+  std::lock_guard<std::mutex> lock(er::g_scratch_mu);
+  for (int base = 0; base < n; base += er::kBnMulti) {
+    er::BnMultiArgs p1, p2;
+    p1.n = p2.n = 0;
+    p1.start[0] = p2.start[0] = 0;
+    size_t need = 0;
+    const int m = (n - base < er::kBnMulti) ? n - base : er::kBnMulti;
+    for (int i = base; i < base + m; ++i) {  // scratch for the layers whose column sums are computed here
+      const er_bn_layer& q = layers[i];
+      if (!q.partial) need += static_cast<size_t>(er::choose_chunks(q.B, q.N)) * q.N * 2;
+    }
+    float* scratch = nullptr;
+    if (need && er::get_scratch(need, &scratch)) return 1;
+    size_t off = 0;
+    for (int i = base; i < base + m; ++i) {
+      const er_bn_layer& q = layers[i];
+      ER_REQUIRE(q.x && q.dy && q.dx && q.B > 0 && q.N > 0 && q.dy_ld >= q.N, "er_bn_bwd_multi: layer %d: bad arguments", i);
+      ER_REQUIRE(!q.use_bn || (q.save_mean && q.save_invstd), "er_bn_bwd_multi: layer %d: BatchNorm statistics missing", i);
+      er::BnItem d = er::BnItem();
+      d.x = q.x; d.bias = q.bias; d.gamma = q.gamma; d.beta = q.beta; d.yin = q.y_in; d.save_mean = q.save_mean;
+      d.save_invstd = q.save_invstd; d.dy = q.dy; d.dy_ld = q.dy_ld; d.dx = q.dx; d.dbias = q.dbias; d.dgamma = q.dgamma;
+      d.dbeta = q.dbeta; d.accumulate = q.accumulate; d.B = q.B; d.N = q.N; d.mode = q.use_bn; d.act = q.act;
+      d.gx = static_cast<int>(er::ceil_div(q.N, er::kColsPerBlock));
+      d.tpb = er::apply_tiles_per_block(q.B);
+      if (q.partial) {
+        ER_REQUIRE(q.chunks > 0 && q.chunks <= er::kInlineChunks, "er_bn_bwd_multi: layer %d: at most %d partials", i,
+                   er::kInlineChunks);
+        d.partial = q.partial; d.chunks = q.chunks;
+      } else {
+        d.chunks = er::choose_chunks(q.B, q.N);
+        ER_REQUIRE(d.chunks <= er::kInlineChunks, "er_bn_bwd_multi: layer %d: too tall for the grouped form", i);
+        d.scratch = scratch + off;
+        d.partial = d.scratch;
+        off += static_cast<size_t>(d.chunks) * q.N * 2;
+        p1.d[p1.n] = d;
+        p1.start[p1.n + 1] = p1.start[p1.n] + d.gx * d.chunks;
+        ++p1.n;
+      }
+      p2.d[p2.n] = d;
+      p2.start[p2.n + 1] = p2.start[p2.n] + d.gx * static_cast<int>(er::ceil_div(q.B, er::kApplyRows * d.tpb));
+      ++p2.n;
+    }
+    if (p1.n > 0) {
+      hipLaunchKernelGGL(er::bn_bwd_partial_multi_kernel, dim3(static_cast<unsigned>(p1.start[p1.n])), dim3(er::kBlock), 0, s, p1);
+      ER_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(er::bn_bwd_finalize_apply_multi_kernel, dim3(static_cast<unsigned>(p2.start[p2.n])), dim3(er::kBlock),
+                       0, s, p2);
+    ER_LAUNCH_CHECK();
+  }
   return 0;
 }
 

@@ -186,6 +186,17 @@ class GemmProblem(ctypes.Structure):  # = er_gemm_problem
               ('bn_act', ctypes.c_int32), ('bn_partial', ctypes.c_void_p)]
 
 
+class BnLayer(ctypes.Structure):  # = er_bn_layer
+  _fields_ = [('x', ctypes.c_void_p), ('bias', ctypes.c_void_p), ('gamma', ctypes.c_void_p), ('beta', ctypes.c_void_p),
+              ('moving_mean', ctypes.c_void_p), ('moving_var', ctypes.c_void_p), ('col_stats', ctypes.c_void_p),
+              ('chunks', ctypes.c_int32), ('B', ctypes.c_int32), ('N', ctypes.c_int32), ('use_bn', ctypes.c_int32),
+              ('act', ctypes.c_int32), ('eps', ctypes.c_float), ('momentum', ctypes.c_float), ('y', ctypes.c_void_p),
+              ('save_mean', ctypes.c_void_p), ('save_invstd', ctypes.c_void_p), ('y_in', ctypes.c_void_p),
+              ('dy', ctypes.c_void_p), ('dy_ld', ctypes.c_int32), ('partial', ctypes.c_void_p), ('dx', ctypes.c_void_p),
+              ('dbias', ctypes.c_void_p), ('dgamma', ctypes.c_void_p), ('dbeta', ctypes.c_void_p),
+              ('accumulate', ctypes.c_int32)]
+
+
 CROSS_HASH_KEY = 0xDECAFCAFFE  # tf.sparse.cross_hashed's default hash_key (crossed_column(hash_key=None))
 
 
@@ -762,6 +773,69 @@ class HipBackend(object):
 
   # the same-depth layers of parallel stacks (MMoE's experts, task towers) as one grouped launch: layers/dnn.py run_parallel
   grouped_stacks = os.environ.get('EASYREC_AMD_GROUPED_STACKS', '1') != '0'  # A/B switch
+
+  # the bias / BatchNorm / activation launches of those layers as one launch forward, two backward (er_bn_fwd_multi /
+  # er_bn_bwd_multi)
+  grouped_bn = os.environ.get('EASYREC_AMD_GROUPED_BN', '1') != '0'  # A/B switch
+  BN_MULTI_MAX_ROWS = 8192  # (taller layers reduce their partial sums in a merge launch of their own: single launches)
+
+  def bn_fwd_multi(self, layers):
+    """layers: [dict(x, bias, gamma, beta, moving_mean, moving_var, col_stats, use_bn, act, eps, momentum)] -> [(y, mean,
+    invstd)]: the forward of BNFromStatsFn (use_bn 1: batch statistics from the GEMM's epilogue) / BNActFn (0, BN_FROZEN)
+    for all of them in ONE launch."""
+    arr = (BnLayer * len(layers))()
+    outs = []
+    for q, l in zip(arr, layers):
+      x = l['x']
+      assert x.dim() == 2 and x.is_contiguous() and x.dtype == torch.float32 and x.shape[0] <= self.BN_MULTI_MAX_ROWS
+      B, N = x.shape
+      y = torch.empty_like(x)
+      mean = torch.empty(N, dtype=torch.float32, device=x.device) if l['use_bn'] else None
+      invstd = torch.empty(N, dtype=torch.float32, device=x.device) if l['use_bn'] else None
+      q.x, q.bias, q.gamma, q.beta = x.data_ptr(), _ptr(l.get('bias')), _ptr(l.get('gamma')), _ptr(l.get('beta'))
+      q.moving_mean, q.moving_var = _ptr(l.get('moving_mean')), _ptr(l.get('moving_var'))
+      q.B, q.N, q.use_bn, q.act = B, N, int(l['use_bn']), int(l['act'])
+      q.eps, q.momentum = float(l.get('eps', 0.0)), float(l.get('momentum', 0.0))
+      if int(l['use_bn']) == BN_BATCH:
+        q.col_stats, q.chunks = l['col_stats'].data_ptr(), self.gemm_row_tiles(B)
+      q.y, q.save_mean, q.save_invstd = y.data_ptr(), _ptr(mean), _ptr(invstd)
+      outs.append((y, mean, invstd))
+    self._ck(self.lib.er_bn_fwd_multi(arr, len(layers), _stream()), 'er_bn_fwd_multi')
+    return outs
+
+  def bn_bwd_multi(self, layers):
+    """layers: [dict(x, bias, gamma, beta, y, mean, invstd, dy, use_bn, act, partial, into)] -> [(dx, dbias, dgamma, dbeta)]
+    (bn_act_bwd's arguments and results, layer by layer) in two launches: column sums (of the layers without `partial`),
+    finalize + apply."""
+    arr = (BnLayer * len(layers))()
+    outs = []
+    for q, l in zip(arr, layers):
+      x, dy = l['x'], l['dy']
+      B, N = x.shape
+      assert dy.dim() == 2 and dy.stride(1) == 1 and dy.dtype == torch.float32 and B <= self.BN_MULTI_MAX_ROWS
+      dev = x.device
+      dx = torch.empty_like(x)
+      into = l.get('into')
+      if into is not None:
+        dbias, dgamma, dbeta = into
+      else:
+        dbias = torch.empty(N, dtype=torch.float32, device=dev) if l.get('bias') is not None else None
+        dgamma = torch.empty(N, dtype=torch.float32, device=dev) if l.get('gamma') is not None else None
+        dbeta = torch.empty(N, dtype=torch.float32, device=dev) if l.get('gamma') is not None else None
+      partial = l.get('partial')
+      if partial is not None and dy.stride(0) != N:
+        partial = None
+      q.x, q.bias, q.gamma, q.beta = x.data_ptr(), _ptr(l.get('bias')), _ptr(l.get('gamma')), _ptr(l.get('beta'))
+      q.B, q.N, q.use_bn, q.act = B, N, int(l['use_bn']), int(l['act'])
+      q.save_mean, q.save_invstd, q.y_in = _ptr(l.get('mean')), _ptr(l.get('invstd')), _ptr(l['y'])
+      q.dy, q.dy_ld = dy.data_ptr(), dy.stride(0)
+      if partial is not None:
+        q.partial, q.chunks = partial.data_ptr(), self.gemm_row_tiles(B)
+      q.dx, q.dbias, q.dgamma, q.dbeta = dx.data_ptr(), _ptr(dbias), _ptr(dgamma), _ptr(dbeta)
+      q.accumulate = int(into is not None)
+      outs.append((dx, None, None, None) if into is not None else (dx, dbias, dgamma, dbeta))
+    self._ck(self.lib.er_bn_bwd_multi(arr, len(layers), _stream()), 'er_bn_bwd_multi')
+    return outs
 
   # -- deferred BatchNorm + activation (include/easyrec_hip.h er_a_transform / er_bn_finalize)
   # OFF by default - built, bit-identical to the materialised form (tests), and SLOWER on MI355X at these sizes: what the
@@ -1886,6 +1960,70 @@ class BNFromStatsFn(torch.autograd.Function):
     dz, _, dgamma, dbeta = be.bn_act_bwd(z, None, gamma, y, mean, invstd, dyc, 1, ctx.act, False, True,
                                          into=(None, gg, betag) if direct else None, partial=partial)
     return dz, None, dgamma, dbeta, None, None, None, None, None, None
+
+
+class GroupedBNActFn(torch.autograd.Function):
+  """The bias / BatchNorm / activation kernels that follow the same-depth dense layers of E parallel stacks
+  (GroupedLinearFn) as ONE launch forward and two backward: layer e is BNFromStatsFn (cfg mode BN_BATCH: the statistics its
+  GEMM's epilogue produced) or BNActFn (BN_NONE, BN_FROZEN) - same kernels' bodies, same bits, E times fewer launches.
+  apply(E, cfgs, z_0.., stats_0.., bias_0.., gamma_0.., beta_0..) -> y_0 .. y_{E-1}; cfgs[e] = (mode, act, moving_mean,
+  moving_var, eps, momentum, grad_bufs) with grad_bufs = (bias.grad, gamma.grad, beta.grad) slices of the flat gradient
+  buffer or None."""
+
+  @staticmethod
+  def forward(ctx, E, cfgs, *args):
+    be = hip()
+    zs, stats, biases, gammas, betas = (args[i * E:(i + 1) * E] for i in range(5))
+    layers = []
+    for e in range(E):
+      mode, act, mm, mv, eps, momentum, _ = cfgs[e]
+      layers.append(dict(x=zs[e], bias=biases[e], gamma=gammas[e], beta=betas[e], moving_mean=mm, moving_var=mv,
+                         col_stats=stats[e], use_bn=mode, act=act, eps=eps, momentum=momentum))
+    outs = be.bn_fwd_multi(layers)
+    fused = getattr(be, 'fused_bn_bwd', False)
+    ctx.owns, saved = [], []
+    for e in range(E):
+      y, mean, invstd = outs[e]
+      mode, act = cfgs[e][0], cfgs[e][1]
+      gb = cfgs[e][6]
+      own = None
+      if fused and mode == BN_BATCH:
+        own = BnSource(zs[e], None, y, mean, invstd, act, gammas[e], None if gb is None else (gb[1], gb[2]), beta=betas[e],
+                       fused=True)
+      ctx.owns.append(own)
+      saved += [zs[e], biases[e], gammas[e], betas[e], y, mean, invstd]
+    ctx.save_for_backward(*saved)
+    ctx.E, ctx.cfgs = E, cfgs
+    _bn_tls.last = ctx.owns if any(o is not None for o in ctx.owns) else None  # (the caller tags the outputs)
+    return tuple(o[0] for o in outs)
+
+  @staticmethod
+  def backward(ctx, *dys):
+    be = hip()
+    E = ctx.E
+    saved = ctx.saved_tensors
+    layers = []
+    for e in range(E):
+      z, bias, gamma, beta, y, mean, invstd = saved[7 * e:7 * e + 7]
+      mode, act, gb = ctx.cfgs[e][0], ctx.cfgs[e][1], ctx.cfgs[e][6]
+      dy = dys[e] if (dys[e].dim() == 2 and dys[e].stride(1) == 1) else dys[e].contiguous()
+      own, partial = ctx.owns[e], None
+      if own is not None:
+        # the consumer's input-gradient launch already reduced the column sums, provided dy is exactly its output
+        if own.partial is not None and dy.data_ptr() == own.dx_ptr:
+          partial = own.partial
+        own.partial = None
+      into = None
+      if gb is not None:
+        bg, gg, betag = gb
+        if (bias is None or bg is not None) and (gamma is None or (gg is not None and betag is not None)):
+          into = (bg if bias is not None else None, gg, betag)
+      layers.append(dict(x=z, bias=bias, gamma=gamma, beta=beta, y=y, mean=mean, invstd=invstd, dy=dy, use_bn=mode, act=act,
+                         partial=partial, into=into))
+    outs = be.bn_bwd_multi(layers)
+    dzs = tuple(o[0] for o in outs)
+    none = (None,) * E
+    return (None, None) + dzs + none + tuple(o[1] for o in outs) + tuple(o[2] for o in outs) + tuple(o[3] for o in outs)
 
 
 class FMFn(torch.autograd.Function):

@@ -166,6 +166,32 @@ def run_parallel(stacks, inputs, extra_dense=()):
     srcs = tuple(kernels.bn_source_of(x) for x in xs)
     out = kernels.GroupedLinearFn.apply(E, tuple(train_bn), sinks, srcs, *xs, *ws, *bs)
     zs, stats = out[:E], out[E:]
+    be = kernels.hip()
+    lay = [e for e, m in enumerate(metas) if m is not None]
+    if getattr(be, 'grouped_bn', False) and len(lay) > 1 and all(zs[e].shape[0] <= be.BN_MULTI_MAX_ROWS for e in lay):
+      # the bias / BatchNorm / activation kernels of the depth as one launch (kernels.GroupedBNActFn)
+      cfgs, a_b, a_g, a_be = [], [], [], []
+      for e in lay:
+        use_bn, relu, training, gamma, beta, mm, mv, bias = metas[e]
+        freeze = ctx.building and training  # build pass: do not touch the moving statistics
+        mode = kernels.BN_NONE if not use_bn else (kernels.BN_BATCH if training else kernels.BN_FROZEN)
+        eb = None if train_bn[e] else bias  # (batch statistics: the bias went into the GEMM's epilogue)
+        gb = tuple(None if t is None else t.grad for t in (eb, gamma, beta))
+        if any(t is not None and t.grad is None for t in (eb, gamma, beta)):
+          gb = None
+        cfgs.append((mode, kernels.ACT_RELU if relu else kernels.ACT_NONE, None if freeze else mm, None if freeze else mv,
+                     BN_EPSILON, BN_MOMENTUM, gb))
+        a_b.append(eb)
+        a_g.append(gamma)
+        a_be.append(beta)
+      ys = kernels.GroupedBNActFn.apply(len(lay), tuple(cfgs), *[zs[e] for e in lay],
+                                        *[stats[e] if train_bn[e] else None for e in lay], *a_b, *a_g, *a_be)
+      owns = kernels.take_last_bn_source() or [None] * len(lay)
+      for e in range(E):
+        if metas[e] is None:
+          extras.append(zs[e])
+      cur = [kernels.tag_bn_source(y, o) if o is not None else y for y, o in zip(ys, owns)]
+      continue
     nxt = []
     for e, m in enumerate(metas):
       if m is None:

@@ -675,6 +675,26 @@ int er_gemm_f32_bn_bwd_z(int layout, int32_t M, int32_t N, int32_t K, const floa
                          int32_t ldb, float* C, int32_t ldc, const float* z, const float* z_bias, const float* gamma,
                          const float* beta, const float* save_mean, const float* save_invstd, int32_t ld_z, int use_bn,
                          int act, float* partial, er_stream_t stream);
+/* The bias / BatchNorm / activation kernels of SEVERAL layer outputs in one launch (forward) or two (backward: column
+ * sums, then finalize + apply): the same-depth layers of parallel stacks - MMoE's experts and task towers
+ * (layers/mmoe.py:62-83, model/multi_task_model.py:33-100) - each own launches of a few microseconds otherwise.  Same
+ * arithmetic as er_bn_apply_from_stats / er_bn_act_fwd / er_bn_act_bwd(_from_partials), layer by layer.
+ *   use_bn 0: y = act(x + bias); 1: batch statistics from `col_stats` ([chunks][N][3], chunks = er_gemm_row_tiles(B) <=
+ *   256; moving statistics updated when given); ER_BN_FROZEN: the moving statistics normalise.
+ *   backward: dy (leading dimension dy_ld), y_in = the forward's y, `partial` ([chunks][N][2] from er_gemm_f32_bn_bwd /
+ *   er_gemm_problem.bn_partial) or NULL (computed here); dx, and dbias / dgamma / dbeta written or accumulated. */
+typedef struct er_bn_layer {
+  const float* x; const float* bias; const float* gamma; const float* beta;
+  float* moving_mean; float* moving_var;
+  const float* col_stats; int32_t chunks;
+  int32_t B, N, use_bn, act;
+  float eps, momentum;
+  float* y; float* save_mean; float* save_invstd;
+  const float* y_in; const float* dy; int32_t dy_ld; const float* partial;
+  float* dx; float* dbias; float* dgamma; float* dbeta; int32_t accumulate;
+} er_bn_layer;
+int er_bn_fwd_multi(const er_bn_layer* layers_host, int n, er_stream_t stream);
+int er_bn_bwd_multi(const er_bn_layer* layers_host, int n, er_stream_t stream);
 int er_bn_act_bwd_z(const float* z, const float* bias, const float* gamma, const float* beta, const float* save_mean,
                     const float* save_invstd, const float* dy, int32_t dy_ld, int32_t B, int32_t N, int use_bn, int act,
                     const float* partial, int32_t chunks, float* dx, float* dbias, float* dgamma, float* dbeta,

@@ -422,6 +422,18 @@ class RefBackend(object):
 
   grouped_stacks = True  # layers/dnn.py run_parallel: the lock-step host logic runs on the stand-in too
 
+  grouped_bn = True
+  BN_MULTI_MAX_ROWS = 8192
+
+  def bn_fwd_multi(self, layers):
+    return [self.bn_act_fwd(l['x'], l.get('bias'), l.get('gamma'), l.get('beta'), l['use_bn'], l.get('eps', 0.0),
+                            l.get('momentum', 0.0), l.get('moving_mean'), l.get('moving_var'), l['act']) for l in layers]
+
+  def bn_bwd_multi(self, layers):
+    return [self.bn_act_bwd(l['x'], l.get('bias'), l.get('gamma'), l['y'], l.get('mean'), l.get('invstd'), l['dy'],
+                            l['use_bn'], l['act'], l.get('bias') is not None, l.get('gamma') is not None,
+                            into=l.get('into')) for l in layers]
+
   def gemm_grouped(self, layout, problems):
     for pr in problems:
       a, b, out, bias, accumulate = pr[:5]

@@ -1096,6 +1096,87 @@ def test_grouped_launch_epilogues_match_single_launches(hip):
       assert torch.equal(parts[i], single_part[i]), i
 
 
+def test_multi_layer_batchnorm_launches_match_single_launches(hip):
+  """er_bn_fwd_multi / er_bn_bwd_multi (kernels.GroupedBNActFn): the bias / BatchNorm / activation kernels of several
+  layers in one launch run the bodies of the single-layer kernels - every output bit for bit what er_bn_apply_from_stats /
+  er_bn_act_fwd and er_bn_act_bwd(_from_partials, _ld) give: batch statistics from a GEMM epilogue, the moving statistics
+  (ER_BN_FROZEN), bias + ReLU alone, bias alone; gradients from a column block of a wider tensor, from ready-made
+  partial sums, and accumulated into buffers.  More than 8 layers: several launches."""
+  g = torch.Generator().manual_seed(11)
+  eps, mom = 1e-3, 0.99
+  # (rows, cols, mode, act, bias?)
+  spec = [(8192, 256, kernels.BN_BATCH, kernels.ACT_RELU, False), (8192, 192, kernels.BN_FROZEN, kernels.ACT_RELU, True),
+          (300, 70, kernels.BN_BATCH, kernels.ACT_NONE, False), (8192, 64, kernels.BN_NONE, kernels.ACT_RELU, True),
+          (130, 1, kernels.BN_NONE, kernels.ACT_NONE, True), (4096, 33, kernels.BN_FROZEN, kernels.ACT_NONE, False),
+          (8192, 128, kernels.BN_BATCH, kernels.ACT_RELU, False), (64, 5, kernels.BN_NONE, kernels.ACT_RELU, False),
+          (1000, 130, kernels.BN_BATCH, kernels.ACT_RELU, False), (8192, 256, kernels.BN_FROZEN, kernels.ACT_RELU, True)]
+  layers, single = [], []
+  for (B, N, mode, act, has_bias) in spec:
+    K = 48
+    x, w = torch.randn(B, K, generator=g).to(DEV), (torch.randn(K, N, generator=g) * 0.2).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV) if has_bias else None
+    gamma = (torch.rand(N, generator=g) + 0.5).to(DEV) if mode else None
+    beta = (torch.randn(N, generator=g) * 0.1).to(DEV) if mode else None
+    mm = (torch.randn(N, generator=g) * 0.1).to(DEV) if mode else None
+    mv = (torch.rand(N, generator=g) + 0.5).to(DEV) if mode else None
+    stats = torch.zeros(hip.gemm_row_tiles(B) * N * 3, device=DEV) if mode == kernels.BN_BATCH else None
+    z = hip.gemm(kernels.GEMM_NN, x, w, col_stats=stats)
+    mm1, mv1 = (mm.clone(), mv.clone()) if mode else (None, None)
+    if mode == kernels.BN_BATCH:
+      ref = hip.bn_apply_from_stats(z, bias, stats, hip.gemm_row_tiles(B), gamma, beta, eps, mom, mm1, mv1, act)
+    else:
+      ref = hip.bn_act_fwd(z, bias, gamma, beta, mode, eps, mom, mm1, mv1, act)
+    single.append(ref + (mm1, mv1))
+    layers.append(dict(x=z, bias=bias, gamma=gamma, beta=beta, moving_mean=mm, moving_var=mv, col_stats=stats, use_bn=mode,
+                       act=act, eps=eps, momentum=mom))
+  outs = hip.bn_fwd_multi(layers)
+  torch.cuda.synchronize()
+  for i, (l, o, r) in enumerate(zip(layers, outs, single)):
+    assert torch.equal(o[0], r[0]), i
+    if l['use_bn']:
+      assert torch.equal(o[1], r[1]) and torch.equal(o[2], r[2]), i
+      assert torch.equal(l['moving_mean'], r[3]) and torch.equal(l['moving_var'], r[4]), i
+  # backward
+  blayers, bsingle = [], []
+  for i, (l, o) in enumerate(zip(layers, outs)):
+    B, N = l['x'].shape
+    y, mean, invstd = o
+    kind = i % 4  # 0: plain dy; 1: a column block of a wider gradient; 2: ready-made partial sums; 3: accumulate into buffers
+    mode, act = l['use_bn'], l['act']
+    if kind == 1:
+      wide = (torch.randn(B, N + 7, generator=g) * 0.1).to(DEV)
+      dy = wide[:, 3:3 + N]
+    else:
+      dy = (torch.randn(B, N, generator=g) * 0.1).to(DEV)
+    partial = None
+    if kind == 2 and mode == kernels.BN_BATCH:
+      K2 = 40
+      dzn, wn = (torch.randn(B, K2, generator=g) * 0.1).to(DEV), torch.randn(N, K2, generator=g).to(DEV)
+      partial = torch.empty(hip.gemm_row_tiles(B) * N * 2, device=DEV)
+      dy = hip.gemm_bn_bwd(kernels.GEMM_NT, dzn, wn, kernels.BnSource(l['x'], None, y, mean, invstd, act), partial)
+    into_a = into_b = None
+    if kind == 3:
+      base = [None if t is None else torch.randn(N, generator=g).to(DEV) for t in (l['bias'], l['gamma'], l['gamma'])]
+      into_a = tuple(None if t is None else t.clone() for t in base)
+      into_b = tuple(None if t is None else t.clone() for t in base)
+    ref = hip.bn_act_bwd(l['x'], l['bias'], l['gamma'], y, mean, invstd, dy, mode, act, l['bias'] is not None,
+                         l['gamma'] is not None, into=into_a, partial=partial)
+    bsingle.append((ref, into_a))
+    blayers.append(dict(x=l['x'], bias=l['bias'], gamma=l['gamma'], beta=l['beta'], y=y, mean=mean, invstd=invstd, dy=dy,
+                        use_bn=mode, act=act, partial=partial, into=into_b))
+  bouts = hip.bn_bwd_multi(blayers)
+  torch.cuda.synchronize()
+  for i, (l, o, (r, into_a)) in enumerate(zip(blayers, bouts, bsingle)):
+    for a, b_ in zip(o, r):
+      assert (a is None) == (b_ is None), i
+      if a is not None:
+        assert torch.equal(a, b_), i
+    if into_a is not None:
+      for a, b_ in zip(l['into'], into_a):
+        if a is not None:
+          assert torch.equal(a, b_), i
+
+
 @pytest.mark.parametrize('B,N,K', [(4096, 256, 128), (300, 70, 33), (64, 1, 16), (130, 128, 64)])
 @pytest.mark.parametrize('act', [kernels.ACT_RELU, kernels.ACT_NONE])
 def test_dgrad_gemm_emits_batchnorm_backward_sums(hip, B, N, K, act):

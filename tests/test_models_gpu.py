@@ -143,6 +143,31 @@ def test_mmoe_matches_oracle():
   _first_steps(_cfg('mmoe_taobao_small.config'), 128, 46)
 
 
+@pytest.mark.parametrize('name', ['mmoe_taobao_small.config', 'mmoe_backbone_taobao_small.config'])
+def test_grouped_batchnorm_launches_change_no_bit_model_level(name):
+  """The multi-layer BatchNorm launches of the parallel stacks (kernels.GroupedBNActFn: experts / task towers, one launch
+  per depth) against the layer-by-layer launches: every variable and slot after 3 steps, bit for bit."""
+  from easyrec_amd import kernels
+  cfg = _cfg(name)
+  B = 256
+  states = []
+  prev = kernels.HipBackend.grouped_bn
+  try:
+    for on in (True, False):
+      kernels.HipBackend.grouped_bn = on
+      est = EasyRecEstimator(cfg, device=DEV, batch_size=B, seed=46).build()
+      gen = SyntheticBatches(cfg.data_config, est.feature_configs, batch_size=B, seed=146)
+      for _ in range(3):
+        est.train_step(gen.next_batch())
+      states.append((est.state_dict(slots=True), est.loss_values()))
+  finally:
+    kernels.HipBackend.grouped_bn = prev
+  (sa, la), (sb, lb) = states
+  assert la == lb
+  for k in sb:
+    assert np.array_equal(np.asarray(sa[k]), np.asarray(sb[k])), k
+
+
 @pytest.mark.parametrize('name,B,dtype', [('din_taobao.config', 4096, 'f32'), ('mmoe_taobao.config', 4096, 'f32'),
                                           ('dcn_criteo.config', 4096, 'f32'), ('dcn_v2_criteo.config', 4096, 'f32'),
                                           ('dcn_v2_criteo.config', 4096, 'bf16')])
