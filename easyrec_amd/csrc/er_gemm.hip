@@ -119,6 +119,7 @@ struct GemmArgs {
   BnBwdEpi bn;        // bn.partial != nullptr: emit the BatchNorm-backward column sums of the output tile
   BnFused fu;         // fu.mode != 0: finish the BatchNorm in this launch (see BnFused)
   ATransform at;      // at.mean != nullptr: A is transformed while staged (kernels instantiated with A_TR)
+  int xcd_rot = 0;    // tile_coords(): where this problem's XCD slots start (grouped launches: problems take turns)
 };
 
 // Loads 4 consecutive elements along the CONTIGUOUS dimension of the operand tile.
@@ -162,10 +163,19 @@ __device__ __forceinline__ short f32_to_bf16_rne(float f) {
 // (MI355X_MICROARCH.md); the column tiles of one row of tiles all read the same 64 rows of A.  Tiles are
 // therefore numbered so that consecutive tiles (same tile row, x fastest) go to the SAME XCD: XCD c owns tiles
 // [c * per, (c + 1) * per), and A's rows are fetched into one L2 instead of up to N/64 of them.
-__device__ __forceinline__ bool tile_coords(int b, int gx, int gy, int& tx, int& ty) {
+//
+// Fewer tiles than 8 * per leave XCDs without work (4 tiles: XCDs 4-7 idle; ONE tile: seven of eight) - and a split-K
+// problem repeats that pattern once per split (grid x = 8-rounded tiles, so a workgroup's XCD is its x % 8 whatever its
+// split): the weight gradients of DIN's attention MLP (128 x 128 ... 32 x 1 outputs contracted over 204,800 rows in
+// 100 splits) ran on XCDs 0-3, half of their workgroups on XCD 0 alone.  `rot` (xcd_rot + split * XCDs used) rotates
+// the assignment per split - and per problem of a grouped launch - so that the used slots walk around the chip.  Which
+// workgroup computes a tile changes, what it computes does not.
+__device__ __forceinline__ bool tile_coords(int b, int gx, int gy, int rot0, int bz, int& tx, int& ty) {
   const int nt = gx * gy;
   const int per = (nt + 7) / 8;
-  const int t = (b % 8) * per + b / 8;
+  const int used = (nt + per - 1) / per;  // XCDs that own at least one tile
+  const int c = rot0 < 0 ? b % 8 : (b % 8 + 8 - (rot0 + bz * used) % 8) % 8;  // (rot0 < 0: the A/B switch's "off")
+  const int t = c * per + b / 8;
   if (t >= nt) return false;
   tx = t % gx;
   ty = t / gx;
@@ -524,7 +534,7 @@ __device__ __forceinline__ void gemm_f32_block(const GemmArgs& g, int bx, int bz
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   int tx, ty;
-  if (!tile_coords(bx, static_cast<int>(ceil_div(g.N, BN)), static_cast<int>(ceil_div(g.M, BM)), tx, ty)) return;
+  if (!tile_coords(bx, static_cast<int>(ceil_div(g.N, BN)), static_cast<int>(ceil_div(g.M, BM)), g.xcd_rot, bz, tx, ty)) return;
   const int m0 = ty * BM, n0 = tx * BN;
   const int kbeg = bz * g.k_per_split;
   int kend = kbeg + g.k_per_split;
@@ -871,7 +881,7 @@ __device__ __forceinline__ void gemm_f32_tn128_block(const GemmArgs& g, int bx, 
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   int tx, ty;
-  if (!tile_coords(bx, static_cast<int>(ceil_div(g.N, BM2)), static_cast<int>(ceil_div(g.M, BM2)), tx, ty)) return;
+  if (!tile_coords(bx, static_cast<int>(ceil_div(g.N, BM2)), static_cast<int>(ceil_div(g.M, BM2)), g.xcd_rot, bz, tx, ty)) return;
   const int m0 = ty * BM2, n0 = tx * BM2;
   const int kbeg = bz * g.k_per_split;
   int kend = kbeg + g.k_per_split;
@@ -986,7 +996,9 @@ gemm_bf16_kernel(GemmArgs g) {
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   int tx, ty;
-  if (!tile_coords(blockIdx.x, static_cast<int>(ceil_div(g.N, BN)), static_cast<int>(ceil_div(g.M, BM)), tx, ty)) return;
+  if (!tile_coords(blockIdx.x, static_cast<int>(ceil_div(g.N, BN)), static_cast<int>(ceil_div(g.M, BM)), g.xcd_rot, blockIdx.z, tx,
+                   ty))
+    return;
   const int m0 = ty * BM, n0 = tx * BN;
   const int kbeg = blockIdx.z * g.k_per_split;
   int kend = kbeg + g.k_per_split;
@@ -1195,6 +1207,11 @@ int launch_gemm(int layout, er::GemmArgs& a, hipStream_t s) {
   return 0;
 }
 
+bool xcd_rotate_on() {  // A/B switch of tile_coords()'s per-split / per-problem rotation
+  static const bool on = [] { const char* e = getenv("ER_GEMM_XCD_ROTATE"); return !(e && atoi(e) == 0); }();
+  return on;
+}
+
 int choose_splits(int M, int N, int K, int ktile) {
   const int64_t tiles = er::ceil_div(M, er::BM) * er::ceil_div(N, er::BN);
   if (tiles >= 256 || K < 1024) return 1;  // split only the batch-long contractions (dW = x^T.dy)
@@ -1224,6 +1241,7 @@ int gemm_entry(int layout, int M, int N, int K, const float* A, int lda, const f
   if (bn) a.bn = *bn;
   if (at) a.at = *at;
   if (fu) a.fu = *fu;
+  a.xcd_rot = xcd_rotate_on() ? 0 : -1;
   a.splits = (col_stats || bn) ? 1 : choose_splits(M, N, K, ktile);
   ER_REQUIRE(!(col_stats && accumulate), "%s: column statistics need a plain (non-accumulating) output", who);
   a.k_per_split = static_cast<int>(er::ceil_div(er::ceil_div(K, a.splits), ktile)) * ktile;
@@ -1298,6 +1316,7 @@ int gemm_grouped_f32(int layout, const er_gemm_problem* pr, int n, er_stream_t s
   size_t ws_floats = 0;
   bool vec_ok = true;
   bool any_tr = false, any_bn = false;
+  int xcd_rot = 0;
   for (int i = 0; i < n; ++i) {
     const er_gemm_problem& q = pr[i];
     er::GroupedArgs& grp = big[i] ? gb : ga;
@@ -1345,6 +1364,13 @@ int gemm_grouped_f32(int layout, const er_gemm_problem* pr, int n, er_stream_t s
     grp.tiles8[grp.n] = static_cast<int>(8 * er::ceil_div(tiles, 8));
     grp.start[grp.n + 1] = grp.start[grp.n] + grp.tiles8[grp.n] * a.splits;
     ++grp.n;
+    {  // tile_coords(): the next problem's XCD slots start where this one's stop
+      const bool rotate = xcd_rotate_on();
+      const int64_t per = er::ceil_div(tiles, 8);
+      const int64_t used = er::ceil_div(tiles, per);
+      a.xcd_rot = rotate ? xcd_rot : -1;
+      xcd_rot = static_cast<int>((xcd_rot + used * a.splits) % 8);
+    }
     if (a.splits > 1) {
       const int64_t mn = static_cast<int64_t>(q.M) * q.N;
       er::ReduceItem& r = ra.r[ra.n];
