@@ -120,6 +120,7 @@ struct GemmArgs {
   BnFused fu;         // fu.mode != 0: finish the BatchNorm in this launch (see BnFused)
   ATransform at;      // at.mean != nullptr: A is transformed while staged (kernels instantiated with A_TR)
   int xcd_rot = 0;    // tile_coords(): where this problem's XCD slots start (grouped launches: problems take turns)
+  int tile_shape = 0; // gemm_f32_grouped_tnn_kernel: 2 * (128-row tile) + (128-column tile)
 };
 
 // Loads 4 consecutive elements along the CONTIGUOUS dimension of the operand tile.
@@ -826,141 +827,169 @@ gemm_f32_grouped_tr_kernel(GroupedArgs ga) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// TN with a 128 x 128 tile: the weight gradients dW = x^T . dz contract over the BATCH (K = 4,096 ... 204,800) into a
-// small M x N, so the launch is bound by operand delivery, not by the matrix cores: a 64 x 64 tile moves (64 + 64) * 4 B
-// per k for 8,192 flops (16 flop / B: x is re-read by every column tile, dz by every row tile), a 128 x 128 tile 32
-// flop / B.  Same LDS layout ([mn][k], row stride 36), same staging of the two mn-contiguous operands (a unit = 4
-// consecutive mn at one k, four conflict-free ds_write_b32), same two-register-set pipeline and the same fixed
-// contraction order per accumulator as gemm_f32_block; a wave owns 64 x 64 = 2 x 2 accumulators, so each pair of
-// fragment reads feeds two MFMAs instead of one.  73.7 KB of LDS (dynamic: er_gemm_reserve raises the limit).
-// Plain epilogue only (split-K workspace or C (+)=): what the grouped weight-gradient launch needs.
+// TN in the operands' NATURAL layout.  The weight gradients dW = x^T . dz contract over the batch (K = 4,096 ... 204,800
+// rows) into a small M x N; both operands are k-major in HBM ([K][M], [K][N]), and so is the fragment of
+// v_mfma_f32_32x32x2f32: lane l supplies A[k = l >> 5][i = l & 31].  gemm_f32_block transposes both operands on their way
+// into its [mn][k] LDS tiles (4 dword stores per 16-byte load, and global loads that touch 16 rows x 64 B per wave
+// instruction); here a k-tile sits in LDS the way it sits in HBM - As[k][m], Bs[k][n], 16-byte loads along full rows,
+// 16-byte LDS stores - and a fragment is ONE ds_read_b32 per operand and MFMA (lanes 0-31: 32 consecutive floats of
+// row k, lanes 32-63: of the row its pair sits in; row stride = tile + 32 floats, so the halves use different banks).
+// Tile per problem: 128 or 64 along each of m and n (4 waves of (tile / 2) x (tile / 2): 2 x 2 ... 1 x 1 accumulators),
+// so that a 128 x 128 output reads x and dz exactly once per split.
+// Same contraction order per accumulator as gemm_f32_block (MFMA j of a 32-row k-tile takes rows j and 16 + j; a stage
+// here = 8 of the 16 MFMAs = rows {8 s + 0..7} and {16 + 8 s + 0..7}), same split-K workspace: the bits do not change.
 // ------------------------------------------------------------------------------------------------
-constexpr int BM2 = 128;
-constexpr int kOpTile2 = BM2 * SK;
-constexpr int kTn128LdsBytes = 2 * 2 * kOpTile2 * static_cast<int>(sizeof(float));
+constexpr int kTnnRows = 16;                         // k rows per LDS stage
+constexpr int kTnnLdMax = 128 + 32;
+constexpr int kTnnLds = 2 * 2 * kTnnRows * kTnnLdMax;  // floats: [stage][A | B][16][160]
 
-__device__ __forceinline__ void unit_pos128(int tid, int i, int& row, int& k) {
-  row = (tid >> 4) * 4 + 64 * (i >> 1);
-  k = (tid & 15) + 16 * (i & 1);
-}
-
-__device__ __forceinline__ void fetch_tile128(const float* __restrict__ P, int ld, int mn0, int MN, int k0, int kend, int tid,
-                                              f32x4v (&r)[4]) {
-  const int mnpad = (MN + 3) & ~3;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int row, k;
-    unit_pos128(tid, i, row, k);
-    int mn = mn0 + row;
-    k += k0;
-    mn = mn < mnpad - 4 ? mn : mnpad - 4;
-    k = k < kend ? k : kend - 1;
-    r[i] = *reinterpret_cast<const f32x4v*>(P + static_cast<int64_t>(k) * ld + mn);
-  }
-}
-
-__device__ __forceinline__ void stage_tile128(float* __restrict__ S, int tid, const f32x4v (&r)[4], bool interior, int mn0,
-                                              int MN, int k0, int kend) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int row, k;
-    unit_pos128(tid, i, row, k);
-    f32x4v v = r[i];
-    if (!interior) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (!(mn0 + row + j < MN && k0 + k < kend)) v[j] = 0.f;
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) S[(row + j) * SK + k] = v[j];
-  }
-}
-
-__device__ __forceinline__ void gemm_f32_tn128_block(const GemmArgs& g, int bx, int bz, float* __restrict__ lds) {
+template <int WM, int WN>
+__device__ __forceinline__ void gemm_f32_tnn_block(const GemmArgs& g, int bx, int bz, float* __restrict__ lds) {
+  constexpr int TM = 64 * WM, TN = 64 * WN;     // block tile
+  constexpr int LDA = TM + 32, LDB = TN + 32;   // LDS row strides
+  constexpr int UA = TM / 64, UB = TN / 64;     // 16-byte units per thread and stage
+  constexpr int kStage = kTnnRows * (LDA + LDB);
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   int tx, ty;
-  if (!tile_coords(bx, static_cast<int>(ceil_div(g.N, BM2)), static_cast<int>(ceil_div(g.M, BM2)), g.xcd_rot, bz, tx, ty)) return;
-  const int m0 = ty * BM2, n0 = tx * BM2;
+  if (!tile_coords(bx, static_cast<int>(ceil_div(g.N, TN)), static_cast<int>(ceil_div(g.M, TM)), g.xcd_rot, bz, tx, ty)) return;
+  const int m0 = ty * TM, n0 = tx * TN;
   const int kbeg = bz * g.k_per_split;
   int kend = kbeg + g.k_per_split;
   if (kend > g.K) kend = g.K;
-  const int T = (kend - kbeg + BK32 - 1) / BK32;
-  const bool rows_full = (m0 + BM2 <= g.M) && (n0 + BM2 <= g.N);
-  f32x16 acc[2][2];
+  const int S = 2 * ((kend - kbeg + BK32 - 1) / BK32);  // stages (two per 32-row k-tile)
+  const bool a_vec = (g.lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0);
+  const bool b_vec = (g.ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0);
+  f32x16 acc[WM][WN];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < WM; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < WN; ++b)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
-  const int khalf = lane >> 5;
-  const int fa = (wm * 64 + (lane & 31)) * SK + khalf * 16;
-  const int fb = kOpTile2 + (wn * 64 + (lane & 31)) * SK + khalf * 16;
-  f32x4v ra0[4], rb0[4], ra1[4], rb1[4];
-  auto fetch = [&](f32x4v (&ra)[4], f32x4v (&rb)[4], int t) {
-    const int k0 = kbeg + (t < T ? t : T - 1) * BK32;
-    fetch_tile128(g.A, g.lda, m0, g.M, k0, kend, tid, ra);
-    fetch_tile128(g.B, g.ldb, n0, g.N, k0, kend, tid, rb);
-  };
-  auto stage = [&](int buf, const f32x4v (&ra)[4], const f32x4v (&rb)[4], int t) {
-    const int k0 = kbeg + t * BK32;  // unclamped: a tile past the end is masked to zero
-    const bool interior = rows_full && (k0 + BK32 <= kend);
-    stage_tile128(lds + buf * 2 * kOpTile2, tid, ra, interior, m0, g.M, k0, kend);
-    stage_tile128(lds + buf * 2 * kOpTile2 + kOpTile2, tid, rb, interior, n0, g.N, k0, kend);
-  };
-  auto step = [&](int buf, f32x4v (&fa_)[4], f32x4v (&fb_)[4], f32x4v (&sa)[4], f32x4v (&sb)[4], int t) {
-    const float* base = lds + buf * 2 * kOpTile2;
-    f32x4v a[2][4], b[2][4];
+  // a wave whose whole tile lies outside the output (a 64 x 32 problem under a 64 x 64 tile: wn = 1) only stages
+  const bool live = (m0 + wm * 32 * WM < g.M) && (n0 + wn * 32 * WN < g.N);
+
+  // stage s, stage row sr -> global k (see the header: rows j and 16 + j of a 32-row tile pair up in MFMA j)
+  auto k_of = [&](int s, int sr) { return kbeg + (s >> 1) * BK32 + (s & 1) * 8 + (sr & 7) + 16 * (sr >> 3); };
+  const bool tile_full = (m0 + TM <= g.M) && (n0 + TN <= g.N);
+  // Branch-free 16-byte loads (both operands 16-byte aligned with ld % 4 == 0): coordinates outside the operand are
+  // clamped to a valid address and the values zeroed later, in stage() - a use of the loaded value here would wait for it
+  auto fetch_op = [&](const float* __restrict__ P, int ld, int mn0, int MN, int upr, int s, f32x4v* r, int U) {
+    const int mnpad = (MN + 3) & ~3;
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+    for (int i = 0; i < 2; ++i) {
+      if (i >= U) break;
+      const int u = tid + i * kBlock;
+      int k = k_of(s, u / upr);
+      int mn = mn0 + (u % upr) * 4;
+      k = k < kend ? k : kend - 1;
+      mn = mn < mnpad - 4 ? mn : mnpad - 4;
+      r[i] = *reinterpret_cast<const f32x4v*>(P + static_cast<int64_t>(k) * ld + mn);
+    }
+  };
+  auto fetch_op_generic = [&](const float* __restrict__ P, int ld, int mn0, int MN, int upr, int s, f32x4v* r, int U) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        a[h][q] = *reinterpret_cast<const f32x4v*>(base + fa + h * 32 * SK + 4 * q);
-        b[h][q] = *reinterpret_cast<const f32x4v*>(base + fb + h * 32 * SK + 4 * q);
+    for (int i = 0; i < 2; ++i) {
+      if (i >= U) break;
+      const int u = tid + i * kBlock;
+      const int k = k_of(s, u / upr);
+      const int mn = mn0 + (u % upr) * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) r[i][j] = (k < kend && mn + j < MN) ? P[static_cast<int64_t>(k) * ld + mn + j] : 0.f;
+    }
+  };
+  auto fetch = [&](f32x4v (&ra)[2], f32x4v (&rb)[2], int s) {
+    s = s < S ? s : S - 1;  // (past the end: the same loads again, never staged)
+    fetch_op(g.A, g.lda, m0, g.M, TM / 4, s, ra, UA);
+    fetch_op(g.B, g.ldb, n0, g.N, TN / 4, s, rb, UB);
+  };
+  auto stage_op = [&](float* __restrict__ dst, int LD, const f32x4v* r, int mn0, int MN, int upr, int s, bool interior, int U) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (i >= U) break;
+      const int u = tid + i * kBlock;
+      const int sr = u / upr, c4 = (u % upr) * 4;
+      f32x4v v = r[i];
+      if (!interior) {
+        const int k = k_of(s, sr);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (!(k < kend && mn0 + c4 + j < MN)) v[j] = 0.f;
       }
-    fetch(fa_, fb_, t + 2);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int q = 0; q < 3; ++q)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-          for (int c = 0; c < 2; ++c) acc[h][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[h][q][i], b[c][q][i], acc[h][c], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    stage(buf ^ 1, sa, sb, t + 1);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int c = 0; c < 2; ++c) acc[h][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[h][3][i], b[c][3][i], acc[h][c], 0, 0, 0);
-    __syncthreads();
+      *reinterpret_cast<f32x4v*>(&dst[sr * LD + c4]) = v;
+    }
   };
-  fetch(ra0, rb0, 0);
-  fetch(ra1, rb1, 1);
-  stage(0, ra0, rb0, 0);
-  __syncthreads();
-  for (int t = 0; t < T; t += 2) {
-    step(0, ra0, rb0, ra1, rb1, t);
-    step(1, ra1, rb1, ra0, rb0, t + 1);
+  auto stage = [&](int buf, const f32x4v (&ra)[2], const f32x4v (&rb)[2], int s, bool masked) {
+    if (s >= S) return;  // (uniform)
+    const bool interior = !masked || (tile_full && (kbeg + (s >> 1) * BK32 + BK32 <= kend));
+    float* As = lds + buf * kStage;
+    stage_op(As, LDA, ra, m0, g.M, TM / 4, s, interior, UA);
+    stage_op(As + kTnnRows * LDA, LDB, rb, n0, g.N, TN / 4, s, interior, UB);
+  };
+  const int khalf = lane >> 5, l31 = lane & 31;
+  auto compute = [&](int buf) {
+    if (!live) return;
+    const float* As = lds + buf * kStage + khalf * 8 * LDA + wm * 32 * WM + l31;
+    const float* Bs = lds + buf * kStage + kTnnRows * LDA + khalf * 8 * LDB + wn * 32 * WN + l31;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float a[WM], b[WN];
+#pragma unroll
+      for (int h = 0; h < WM; ++h) a[h] = As[j * LDA + h * 32];
+#pragma unroll
+      for (int c = 0; c < WN; ++c) b[c] = Bs[j * LDB + c * 32];
+#pragma unroll
+      for (int h = 0; h < WM; ++h)
+#pragma unroll
+        for (int c = 0; c < WN; ++c) acc[h][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[h], b[c], acc[h][c], 0, 0, 0);
+    }
+  };
+  // two register sets: the loads of stage s + 2 are issued before stage s is contracted, stage s + 1 goes to the other LDS
+  // buffer after it; one barrier per stage
+  f32x4v ra0[2], rb0[2], ra1[2], rb1[2];
+  if (a_vec && b_vec) {
+    auto step = [&](int buf, f32x4v (&fa_)[2], f32x4v (&fb_)[2], f32x4v (&sa)[2], f32x4v (&sb)[2], int s) {
+      fetch(fa_, fb_, s + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(buf);
+      __builtin_amdgcn_sched_barrier(0);
+      stage(buf ^ 1, sa, sb, s + 1, true);
+      __syncthreads();
+    };
+    fetch(ra0, rb0, 0);
+    fetch(ra1, rb1, 1);
+    stage(0, ra0, rb0, 0, true);
+    __syncthreads();
+    for (int s = 0; s < S; s += 2) {
+      step(0, ra0, rb0, ra1, rb1, s);
+      step(1, ra1, rb1, ra0, rb0, s + 1);
+    }
+  } else {
+    // unaligned operands (a [K x 1] gradient, a column block at an odd offset): masked scalar loads, a stage at a time
+    for (int s = 0; s < S; ++s) {
+      fetch_op_generic(g.A, g.lda, m0, g.M, TM / 4, s, ra0, UA);
+      fetch_op_generic(g.B, g.ldb, n0, g.N, TN / 4, s, rb0, UB);
+      stage(0, ra0, rb0, s, false);
+      __syncthreads();
+      compute(0);
+      __syncthreads();
+    }
   }
+  if (!live) return;
   float* Cz = g.C + (g.splits > 1 ? static_cast<int64_t>(bz) * g.M * g.N : 0);
   const int ldc = g.splits > 1 ? g.N : g.ldc;
 #pragma unroll
-  for (int h = 0; h < 2; ++h)
+  for (int h = 0; h < WM; ++h)
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const int col = n0 + wn * 64 + c * 32 + (lane & 31);
+    for (int c = 0; c < WN; ++c) {
+      const int col = n0 + wn * 32 * WN + c * 32 + l31;
       if (col >= g.N) continue;
       const float bv = (g.bias && g.splits == 1) ? g.bias[col] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 64 + h * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+        const int row = m0 + wm * 32 * WM + h * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
         if (row < g.M) {
           float* p = Cz + static_cast<int64_t>(row) * ldc + col;
           float v = acc[h][c][r] + bv;
@@ -972,13 +1001,20 @@ __device__ __forceinline__ void gemm_f32_tn128_block(const GemmArgs& g, int bx, 
 }
 
 __global__ void __launch_bounds__(kBlock)
-gemm_f32_grouped_tn128_kernel(GroupedArgs ga) {
-  extern __shared__ __attribute__((aligned(16))) float lds128[];
+gemm_f32_grouped_tnn_kernel(GroupedArgs ga) {
+  __shared__ __attribute__((aligned(16))) float lds[kTnnLds];
   const int b = blockIdx.x;
   int p = 0;
   while (p + 1 < ga.n && b >= ga.start[p + 1]) ++p;
   const int local = b - ga.start[p];
-  gemm_f32_tn128_block(ga.p[p], local % ga.tiles8[p], local / ga.tiles8[p], lds128);
+  const GemmArgs& g = ga.p[p];
+  const int bx = local % ga.tiles8[p], bz = local / ga.tiles8[p];
+  switch (g.tile_shape) {  // (uniform over the workgroup)
+    case 3: gemm_f32_tnn_block<2, 2>(g, bx, bz, lds); break;
+    case 2: gemm_f32_tnn_block<2, 1>(g, bx, bz, lds); break;
+    case 1: gemm_f32_tnn_block<1, 2>(g, bx, bz, lds); break;
+    default: gemm_f32_tnn_block<1, 1>(g, bx, bz, lds); break;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1265,31 +1301,31 @@ int gemm_entry(int layout, int M, int N, int K, const float* A, int lda, const f
   return launch_gemm<BF16>(layout, a, s);
 }
 
-bool g_tn128_ready = false;  // er_gemm_reserve raised the 128 x 128 kernel's LDS limit
+// Which TN problems of a grouped launch take the natural-layout kernel (gemm_f32_grouped_tnn_kernel).  ER_GEMM_TNN:
+// 0 = none, 1 = the batch-long contractions into one or a few tiles (M, N <= 128: every operand byte is then read once
+// per split), 2 = every TN problem without an epilogue.
+int g_tnn_mode = -1;  // (er_gemm_tn_natural_mode)
+int tnn_mode() {
+  if (g_tnn_mode < 0) {
+    const char* e = getenv("ER_GEMM_TNN");  // A/B switch
+    g_tnn_mode = e ? atoi(e) : 1;
+    if (g_tnn_mode < 0) g_tnn_mode = 0;
+  }
+  return g_tnn_mode;
+}
 
-// A TN problem takes 128 x 128 tiles when both operands allow the 16-byte loads, neither dimension fits one 64-tile and
-// padding to 128 wastes no more than a third over padding to 64 (624 x 256, 256 x 128, 81 x 256: none; 320 x 128: 20 %)
-bool tn128_fits(int layout, const er_gemm_problem& q) {
-  // OFF by default: measured SLOWER than the 64 x 64 kernel on every config (same box, profiles/r03_tn128.md) - the
-  // grouped weight-gradient launch of DeepFM-Criteo 87 us against 48, DIN 10 M 658 against 581, MMoE 775 against 584.
-  // Half the operand traffic does not pay for what the bigger tile costs here: 32 ds_write_b32 per thread and k-tile
-  // for the two mn-contiguous operands (the transpose into the [mn][k] fragment layout), one barrier per k-tile with
-  // only 2 workgroups (8 waves) per CU to hide it, and 4x fewer tiles for the split-K to spread.  ER_GEMM_TN128=1 enables.
-  static const bool off = [] { const char* e = getenv("ER_GEMM_TN128"); return !(e && atoi(e) == 1); }();  // A/B switch
-  if (off || !g_tn128_ready || layout != ER_GEMM_TN || q.a_mean || q.col_stats || q.bn_partial || q.M <= er::BM ||
-      q.N <= er::BN)
-    return false;
-  if (q.lda % 4 != 0 || q.ldb % 4 != 0 || ((reinterpret_cast<uintptr_t>(q.A) | reinterpret_cast<uintptr_t>(q.B)) & 15) != 0)
-    return false;
-  const int64_t a128 = er::ceil_div(q.M, er::BM2) * er::ceil_div(q.N, er::BM2) * 4;
-  const int64_t a64 = er::ceil_div(q.M, er::BM) * er::ceil_div(q.N, er::BN);
-  return 3 * a128 <= 4 * a64;
+bool tnn_fits(int layout, const er_gemm_problem& q) {
+  const int mode = tnn_mode();
+  if (mode <= 0 || layout != ER_GEMM_TN || q.a_mean || q.col_stats || q.bn_partial) return false;
+  if (mode >= 2) return true;
+  return q.M <= 128 && q.N <= 128 && q.K >= 2048;
 }
 
 int gemm_grouped_f32(int layout, const er_gemm_problem* pr, int n, er_stream_t stream) {
   hipStream_t s = er::as_stream(stream);
   int64_t total_tiles = 0;
-  bool big[er::kMaxGroup];
+  bool big[er::kMaxGroup];  // the problem takes the natural-layout TN kernel
+  int tm[er::kMaxGroup], tn[er::kMaxGroup];  // its tile
   for (int i = 0; i < n; ++i) {
     const er_gemm_problem& q = pr[i];
     ER_REQUIRE(q.A && q.B && q.C && q.M > 0 && q.N > 0 && q.K > 0, "er_gemm_grouped_f32: problem %d: bad arguments", i);
@@ -1297,14 +1333,16 @@ int gemm_grouped_f32(int layout, const er_gemm_problem* pr, int n, er_stream_t s
     const int min_ldb = (layout == ER_GEMM_NT) ? q.K : q.N;
     ER_REQUIRE(q.lda >= min_lda && q.ldb >= min_ldb && q.ldc >= q.N,
                "er_gemm_grouped_f32: problem %d: leading dimension too small", i);
-    big[i] = tn128_fits(layout, q);
-    const int tile = big[i] ? er::BM2 : er::BM;
-    total_tiles += er::ceil_div(q.M, tile) * er::ceil_div(q.N, tile);
+    big[i] = tnn_fits(layout, q);
+    tm[i] = (big[i] && q.M > 64) ? 128 : 64;
+    tn[i] = (big[i] && q.N > 64) ? 128 : 64;
+    total_tiles += er::ceil_div(q.M, er::BM) * er::ceil_div(q.N, er::BN);  // (in 64 x 64 units whatever the kernel: the
+    // splits - and with them the bits - do not depend on which kernel takes a problem)
   }
   // k-splits: enough workgroups for ~2 per CU over the whole group (A/B: 512 beat 1024 and 2048), >= 4 k-tiles per split
   int64_t want = total_tiles >= 512 ? 1 : er::ceil_div(512, total_tiles);
   if (want > 64) want = 64;
-  er::GroupedArgs ga, gb;  // the 64 x 64 problems | the 128 x 128 ones
+  er::GroupedArgs ga, gb;  // the problems of gemm_f32_block | of the natural-layout TN kernel
   er::GroupedReduceArgs ra;
   ga.n = 0;
   ga.start[0] = 0;
@@ -1359,8 +1397,8 @@ int gemm_grouped_f32(int layout, const er_gemm_problem* pr, int n, er_stream_t s
     if (sp < 1 || q.col_stats || q.bn_partial) sp = 1;
     a.k_per_split = static_cast<int>(er::ceil_div(er::ceil_div(q.K, sp), er::BK32)) * er::BK32;
     a.splits = static_cast<int>(er::ceil_div(q.K, a.k_per_split));
-    const int tile = big[i] ? er::BM2 : er::BM;
-    const int64_t tiles = er::ceil_div(q.M, tile) * er::ceil_div(q.N, tile);
+    const int64_t tiles = er::ceil_div(q.M, tm[i]) * er::ceil_div(q.N, tn[i]);
+    a.tile_shape = 2 * (tm[i] == 128) + (tn[i] == 128);
     grp.tiles8[grp.n] = static_cast<int>(8 * er::ceil_div(tiles, 8));
     grp.start[grp.n + 1] = grp.start[grp.n] + grp.tiles8[grp.n] * a.splits;
     ++grp.n;
@@ -1402,12 +1440,11 @@ int gemm_grouped_f32(int layout, const er_gemm_problem* pr, int n, er_stream_t s
   }
   dim3 grid(static_cast<unsigned>(ga.start[ga.n])), block(er::kBlock);
   if (gb.n > 0) {
-    hipLaunchKernelGGL(er::gemm_f32_grouped_tn128_kernel, dim3(static_cast<unsigned>(gb.start[gb.n])), block,
-                       er::kTn128LdsBytes, s, gb);
+    hipLaunchKernelGGL(er::gemm_f32_grouped_tnn_kernel, dim3(static_cast<unsigned>(gb.start[gb.n])), block, 0, s, gb);
     ER_LAUNCH_CHECK();
   }
   if (ga.n == 0) {
-    // (every problem took the 128 x 128 kernel)
+    // (every problem took the natural-layout kernel)
   } else if (any_bn) {
     ER_REQUIRE(!any_tr, "er_gemm_grouped_f32: the A transform and the BatchNorm-backward epilogue in one launch");
     switch (layout) {
@@ -1448,13 +1485,14 @@ extern "C" {
 int er_gemm_reserve(int64_t floats) {
   ER_REQUIRE(floats >= 0, "er_gemm_reserve: negative size");
   if (int rc = ensure_counters()) return rc;  // (allocations are not capturable: both happen here)
-  if (!g_tn128_ready) {
-    ER_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&er::gemm_f32_grouped_tn128_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, er::kTn128LdsBytes));
-    g_tn128_ready = true;
-  }
   float* p;
   return ensure_ws(static_cast<size_t>(floats), &p);
+}
+
+int er_gemm_tn_natural_mode(int mode) {
+  const int prev = tnn_mode();
+  if (mode >= 0) g_tnn_mode = mode;
+  return prev;
 }
 
 int er_gemm_fused_bn_ok(int32_t M, int32_t N) { return fused_bn_fits(M, N) ? 1 : 0; }

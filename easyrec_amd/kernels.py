@@ -586,6 +586,10 @@ class HipBackend(object):
   def gemm_reserve(self, floats):
     self._ck(self.lib.er_gemm_reserve(ctypes.c_int64(int(floats))), 'er_gemm_reserve')
 
+  def gemm_tn_natural_mode(self, mode=-1):
+    """er_gemm_tn_natural_mode: which TN problems of gemm_grouped take the natural-layout kernel; returns the previous."""
+    return int(self.lib.er_gemm_tn_natural_mode(ctypes.c_int(int(mode))))
+
   def gemm_row_tiles(self, M):
     return int(self.lib.er_gemm_row_tiles(ctypes.c_int32(int(M))))
 
@@ -911,12 +915,12 @@ class HipBackend(object):
       else:
         (K, M), (K2, N) = a.shape, b.shape
       assert K == K2 and out.shape == (M, N)
-      if self.op_log is not None:  # (which of the two grouped kernels takes the problem: er_gemm.hip tn128_fits)
-        c = lambda x, t: (x + t - 1) // t  # noqa: E731
-        big = layout == GEMM_TN and at is None and M > 64 and N > 64 and a.stride(0) % 4 == 0 and b.stride(0) % 4 == 0 and \
-            3 * c(M, 128) * c(N, 128) * 4 <= 4 * c(M, 64) * c(N, 64) and os.environ.get('ER_GEMM_TN128', '0') == '1'
-        if big:
-          self._log_gemm('gemm_f32_grouped_tn128_kernel', None, M, N, K)
+      if self.op_log is not None:  # (which of the two grouped kernels takes the problem: er_gemm.hip tnn_fits)
+        mode = self.gemm_tn_natural_mode()
+        natural = layout == GEMM_TN and at is None and stats is None and bn is None and \
+            (mode >= 2 or (mode == 1 and M <= 128 and N <= 128 and K >= 2048))
+        if natural:
+          self._log_gemm('gemm_f32_grouped_tnn_kernel', None, M, N, K)
         else:
           self._log_gemm('gemm_f32_grouped_tr_kernel' if at is not None else 'gemm_f32_grouped_kernel', layout, M, N, K)
       q.M, q.N, q.K = M, N, K

@@ -1016,7 +1016,7 @@ def test_gemm_grouped_matches_single_launches(hip):
   """The weight gradients of a step in ONE grouped launch (er_gemm_grouped_f32): every problem within the f32 bound of
   an fp64 matmul, accumulate honoured, bit-identical across launches; > 16 problems are chunked."""
   g = torch.Generator().manual_seed(7)
-  hip.gemm_reserve(1 << 22)  # (with ER_GEMM_TN128=1 the first, second, fourth and ninth shapes take the 128 x 128 kernel)
+  hip.gemm_reserve(1 << 22)
   shapes = [(624, 256, 4096), (256, 128, 4096), (128, 64, 4096), (81, 256, 4096), (64, 1, 4096), (33, 65, 97),
             (1, 1, 1), (130, 72, 1000), (320, 128, 20000), (129, 129, 131)] * 3  # 30 problems
   probs, refs, bases = [], [], []
@@ -1038,6 +1038,48 @@ def test_gemm_grouped_matches_single_launches(hip):
   torch.cuda.synchronize()
   for p, f in zip(probs, first):
     assert torch.equal(p[2], f)
+
+
+def test_natural_layout_weight_gradient_kernel_changes_no_bit(hip):
+  """gemm_f32_grouped_tnn_kernel (TN problems staged k-major, 128- / 64-wide tiles) against the default 64 x 64 kernel:
+  the same contraction order per accumulator and the same splits, so every output bit agrees - aligned and unaligned
+  operands, ragged edges, K that is no multiple of the k-tile, accumulate, column blocks of wider tensors."""
+  g = torch.Generator().manual_seed(17)
+  hip.gemm_reserve(1 << 23)
+  shapes = [(128, 128, 20480), (128, 64, 20480), (64, 32, 20480), (32, 1, 20480), (128, 128, 4100), (100, 36, 3001),
+            (624, 256, 4096), (81, 256, 4096), (129, 129, 131), (1, 1, 1), (64, 1, 4096), (320, 128, 20000),
+            (130, 72, 1000), (256, 192, 8192)]
+  probs, bases = [], []
+  for i, (M, N, K) in enumerate(shapes):
+    if i % 5 == 4:  # column blocks of wider tensors (aligned: offset 8; ld a multiple of 4)
+      wa, wb = torch.randn(K, M + 20, generator=g).to(DEV), torch.randn(K, N + 12, generator=g).to(DEV)
+      a, b = wa[:, 8:8 + M], wb[:, 8:8 + N]
+    elif i % 5 == 3:  # unaligned views
+      wa, wb = torch.randn(K, M + 5, generator=g).to(DEV), torch.randn(K, N + 3, generator=g).to(DEV)
+      a, b = wa[:, 1:1 + M], wb[:, 2:2 + N]
+    else:
+      a, b = torch.randn(K, M, generator=g).to(DEV), torch.randn(K, N, generator=g).to(DEV)
+    base = torch.randn(M, N, generator=g).to(DEV)
+    probs.append((a, b, base.clone(), None, i % 2 == 0))
+    bases.append(base)
+  prev = hip.gemm_tn_natural_mode()
+  try:
+    results = {}
+    for mode in (0, 1, 2):
+      hip.gemm_tn_natural_mode(mode)
+      for p, base in zip(probs, bases):
+        p[2].copy_(base)
+      hip.gemm_grouped(kernels.GEMM_TN, probs)
+      torch.cuda.synchronize()
+      results[mode] = [p[2].clone() for p in probs]
+  finally:
+    hip.gemm_tn_natural_mode(prev)
+  for i, (M, N, K) in enumerate(shapes):
+    ref = probs[i][0].double().t() @ probs[i][1].double() + (bases[i].double() if i % 2 == 0 else 0)
+    bound = (probs[i][0].double().abs().t() @ probs[i][1].double().abs()) * 1e-6 + 1e-5
+    assert ((results[0][i].double() - ref).abs() <= bound).all(), (i, M, N, K)
+    for mode in (1, 2):
+      assert torch.equal(results[mode][i], results[0][i]), (mode, i, M, N, K)
 
 
 def test_grouped_launch_epilogues_match_single_launches(hip):
