@@ -119,7 +119,6 @@ struct GemmArgs {
   BnBwdEpi bn;        // bn.partial != nullptr: emit the BatchNorm-backward column sums of the output tile
   BnFused fu;         // fu.mode != 0: finish the BatchNorm in this launch (see BnFused)
   ATransform at;      // at.mean != nullptr: A is transformed while staged (kernels instantiated with A_TR)
-  int xcd_rot = 0;    // tile_coords(): where this problem's XCD slots start (grouped launches: problems take turns)
   int tile_shape = 0; // gemm_f32_grouped_tnn_kernel: 2 * (128-row tile) + (128-column tile)
 };
 
@@ -160,27 +159,24 @@ __device__ __forceinline__ short f32_to_bf16_rne(float f) {
   return static_cast<short>(u >> 16);
 }
 
-// XCD-aware tile order.  Workgroup b is dispatched to XCD b % 8 and every XCD has its own L2
-// (MI355X_MICROARCH.md); the column tiles of one row of tiles all read the same 64 rows of A.  Tiles are
-// therefore numbered so that consecutive tiles (same tile row, x fastest) go to the SAME XCD: XCD c owns tiles
-// [c * per, (c + 1) * per), and A's rows are fetched into one L2 instead of up to N/64 of them.
+// XCD-aware tile order.  Workgroup b of a launch is dispatched to XCD b % 8 and every XCD has its own L2
+// (MI355X_MICROARCH.md); the column tiles of one row of tiles all read the same 64 rows of A.  Tiles are therefore
+// numbered so that consecutive tiles (same tile row, x fastest) go to the SAME XCD: of the first 8 * per tiles
+// (per = tiles / 8) slot i takes tile (i % 8) * per + i / 8 - XCD c owns tiles [c * per, (c + 1) * per) - and the
+// remaining tiles % 8 keep their slot's number.
 //
-// Fewer tiles than 8 * per leave XCDs without work (4 tiles: XCDs 4-7 idle; ONE tile: seven of eight) - and a split-K
-// problem repeats that pattern once per split (grid x = 8-rounded tiles, so a workgroup's XCD is its x % 8 whatever its
-// split): the weight gradients of DIN's attention MLP (128 x 128 ... 32 x 1 outputs contracted over 204,800 rows in
-// 100 splits) ran on XCDs 0-3, half of their workgroups on XCD 0 alone.  `rot` (xcd_rot + split * XCDs used) rotates
-// the assignment per split - and per problem of a grouped launch - so that the used slots walk around the chip.  Which
-// workgroup computes a tile changes, what it computes does not.
-__device__ __forceinline__ bool tile_coords(int b, int gx, int gy, int rot0, int bz, int& tx, int& ty) {
+// The grid holds EXACTLY tiles x splits workgroups (per problem, in a grouped launch).  Rounds 1 - 2 rounded the tile
+// count up to a multiple of 8 and let the surplus workgroups return at once: within an XCD workgroups are handed to the
+// CUs round robin, so the live workgroups of a few-tile split-K problem landed on every 8th / 2nd CU only - the
+// 128 x 128 weight gradient of DIN's attention MLP (1 - 4 tiles x 100 splits) ran three workgroups deep on 4 CUs per
+// XCD while 28 idled (tools/micro/tn_stream.hip reproduces the kernel at 2.9x the speed with the same decomposition
+// and no idle workgroups; profiles/r03_wgrad_probe.md).
+__device__ __forceinline__ void tile_coords(int i, int gx, int gy, int& tx, int& ty) {
   const int nt = gx * gy;
-  const int per = (nt + 7) / 8;
-  const int used = (nt + per - 1) / per;  // XCDs that own at least one tile
-  const int c = rot0 < 0 ? b % 8 : (b % 8 + 8 - (rot0 + bz * used) % 8) % 8;  // (rot0 < 0: the A/B switch's "off")
-  const int t = c * per + b / 8;
-  if (t >= nt) return false;
+  const int per = nt / 8;
+  const int t = i < 8 * per ? (i % 8) * per + i / 8 : i;
   tx = t % gx;
   ty = t / gx;
-  return true;
 }
 
 // Values that cross workgroups INSIDE a launch (the per-row-tile partials of the fused epilogues) are stored and
@@ -535,7 +531,7 @@ __device__ __forceinline__ void gemm_f32_block(const GemmArgs& g, int bx, int bz
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   int tx, ty;
-  if (!tile_coords(bx, static_cast<int>(ceil_div(g.N, BN)), static_cast<int>(ceil_div(g.M, BM)), g.xcd_rot, bz, tx, ty)) return;
+  tile_coords(bx, static_cast<int>(ceil_div(g.N, BN)), static_cast<int>(ceil_div(g.M, BM)), tx, ty);
   const int m0 = ty * BM, n0 = tx * BN;
   const int kbeg = bz * g.k_per_split;
   int kend = kbeg + g.k_per_split;
@@ -782,13 +778,12 @@ gemm_f32_tr_kernel(GemmArgs g) {
 
 // Grouped launch: up to kMaxGroup independent problems of one layout in ONE grid (the weight gradients of all
 // layers of a step: each is a small M x N with K = batch, far too few tiles to fill 256 CUs on its own).
-// Workgroups [start[p], start[p+1]) belong to problem p: tile = local % tiles8, k-split = local / tiles8
-// (tiles8 is a multiple of 8, so the XCD a tile lands on is the same as in a single launch).
+// Workgroups [start[p], start[p+1]) belong to problem p: tile slot = local % tiles, k-split = local / tiles
 constexpr int kMaxGroup = 16;
 struct GroupedArgs {
   int n;
   int start[kMaxGroup + 1];
-  int tiles8[kMaxGroup];
+  int tiles[kMaxGroup];
   GemmArgs p[kMaxGroup];
 };
 
@@ -800,7 +795,7 @@ gemm_f32_grouped_kernel(GroupedArgs ga) {
   int p = 0;
   while (p + 1 < ga.n && b >= ga.start[p + 1]) ++p;
   const int local = b - ga.start[p];
-  gemm_f32_block<A_KC, B_KC>(ga.p[p], local % ga.tiles8[p], local / ga.tiles8[p], lds);
+  gemm_f32_block<A_KC, B_KC>(ga.p[p], local % ga.tiles[p], local / ga.tiles[p], lds);
 }
 
 // ... with the BatchNorm-backward column sums of each problem's producing layer in the epilogue (BnBwdEpi per problem)
@@ -812,7 +807,7 @@ gemm_f32_grouped_bn_bwd_kernel(GroupedArgs ga) {
   int p = 0;
   while (p + 1 < ga.n && b >= ga.start[p + 1]) ++p;
   const int local = b - ga.start[p];
-  gemm_f32_block<A_KC, B_KC, true>(ga.p[p], local % ga.tiles8[p], local / ga.tiles8[p], lds);
+  gemm_f32_block<A_KC, B_KC, true>(ga.p[p], local % ga.tiles[p], local / ga.tiles[p], lds);
 }
 
 template <bool A_KC, bool B_KC>
@@ -823,7 +818,7 @@ gemm_f32_grouped_tr_kernel(GroupedArgs ga) {
   int p = 0;
   while (p + 1 < ga.n && b >= ga.start[p + 1]) ++p;
   const int local = b - ga.start[p];
-  gemm_f32_block<A_KC, B_KC, false, true>(ga.p[p], local % ga.tiles8[p], local / ga.tiles8[p], lds);
+  gemm_f32_block<A_KC, B_KC, false, true>(ga.p[p], local % ga.tiles[p], local / ga.tiles[p], lds);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -841,19 +836,22 @@ gemm_f32_grouped_tr_kernel(GroupedArgs ga) {
 // ------------------------------------------------------------------------------------------------
 constexpr int kTnnRows = 16;                         // k rows per LDS stage
 constexpr int kTnnLdMax = 128 + 32;
-constexpr int kTnnLds = 2 * 2 * kTnnRows * kTnnLdMax;  // floats: [stage][A | B][16][160]
+constexpr int kTnnLds = 2 * 2 * (kTnnRows * kTnnLdMax + 32);  // floats: [stage][A | B][16][160] (+ the half offset)
 
 template <int WM, int WN>
 __device__ __forceinline__ void gemm_f32_tnn_block(const GemmArgs& g, int bx, int bz, float* __restrict__ lds) {
   constexpr int TM = 64 * WM, TN = 64 * WN;     // block tile
   constexpr int LDA = TM + 32, LDB = TN + 32;   // LDS row strides
   constexpr int UA = TM / 64, UB = TN / 64;     // 16-byte units per thread and stage
-  constexpr int kStage = kTnnRows * (LDA + LDB);
+  // rows 8-15 of a stage (the k of lanes 32-63) start 32 floats later than 8 row strides: 8 * LD is a multiple of 64 and
+  // lanes l, l + 32 of a fragment read would otherwise share a bank
+  constexpr int kOpA = kTnnRows * LDA + 32, kOpB = kTnnRows * LDB + 32;
+  constexpr int kStage = kOpA + kOpB;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   int tx, ty;
-  if (!tile_coords(bx, static_cast<int>(ceil_div(g.N, TN)), static_cast<int>(ceil_div(g.M, TM)), g.xcd_rot, bz, tx, ty)) return;
+  tile_coords(bx, static_cast<int>(ceil_div(g.N, TN)), static_cast<int>(ceil_div(g.M, TM)), tx, ty);
   const int m0 = ty * TM, n0 = tx * TN;
   const int kbeg = bz * g.k_per_split;
   int kend = kbeg + g.k_per_split;
@@ -918,7 +916,7 @@ __device__ __forceinline__ void gemm_f32_tnn_block(const GemmArgs& g, int bx, in
         for (int j = 0; j < 4; ++j)
           if (!(k < kend && mn0 + c4 + j < MN)) v[j] = 0.f;
       }
-      *reinterpret_cast<f32x4v*>(&dst[sr * LD + c4]) = v;
+      *reinterpret_cast<f32x4v*>(&dst[sr * LD + (sr >> 3) * 32 + c4]) = v;
     }
   };
   auto stage = [&](int buf, const f32x4v (&ra)[2], const f32x4v (&rb)[2], int s, bool masked) {
@@ -926,13 +924,13 @@ __device__ __forceinline__ void gemm_f32_tnn_block(const GemmArgs& g, int bx, in
     const bool interior = !masked || (tile_full && (kbeg + (s >> 1) * BK32 + BK32 <= kend));
     float* As = lds + buf * kStage;
     stage_op(As, LDA, ra, m0, g.M, TM / 4, s, interior, UA);
-    stage_op(As + kTnnRows * LDA, LDB, rb, n0, g.N, TN / 4, s, interior, UB);
+    stage_op(As + kOpA, LDB, rb, n0, g.N, TN / 4, s, interior, UB);
   };
   const int khalf = lane >> 5, l31 = lane & 31;
   auto compute = [&](int buf) {
     if (!live) return;
-    const float* As = lds + buf * kStage + khalf * 8 * LDA + wm * 32 * WM + l31;
-    const float* Bs = lds + buf * kStage + kTnnRows * LDA + khalf * 8 * LDB + wn * 32 * WN + l31;
+    const float* As = lds + buf * kStage + khalf * (8 * LDA + 32) + wm * 32 * WM + l31;
+    const float* Bs = lds + buf * kStage + kOpA + khalf * (8 * LDB + 32) + wn * 32 * WN + l31;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       float a[WM], b[WN];
@@ -1008,7 +1006,7 @@ gemm_f32_grouped_tnn_kernel(GroupedArgs ga) {
   while (p + 1 < ga.n && b >= ga.start[p + 1]) ++p;
   const int local = b - ga.start[p];
   const GemmArgs& g = ga.p[p];
-  const int bx = local % ga.tiles8[p], bz = local / ga.tiles8[p];
+  const int bx = local % ga.tiles[p], bz = local / ga.tiles[p];
   switch (g.tile_shape) {  // (uniform over the workgroup)
     case 3: gemm_f32_tnn_block<2, 2>(g, bx, bz, lds); break;
     case 2: gemm_f32_tnn_block<2, 1>(g, bx, bz, lds); break;
@@ -1032,9 +1030,7 @@ gemm_bf16_kernel(GemmArgs g) {
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   int tx, ty;
-  if (!tile_coords(blockIdx.x, static_cast<int>(ceil_div(g.N, BN)), static_cast<int>(ceil_div(g.M, BM)), g.xcd_rot, blockIdx.z, tx,
-                   ty))
-    return;
+  tile_coords(blockIdx.x, static_cast<int>(ceil_div(g.N, BN)), static_cast<int>(ceil_div(g.M, BM)), tx, ty);
   const int m0 = ty * BM, n0 = tx * BN;
   const int kbeg = blockIdx.z * g.k_per_split;
   int kend = kbeg + g.k_per_split;
@@ -1214,13 +1210,13 @@ int ensure_counters() {
 bool fused_bn_fits(int M, int N) {
   if (!g_bn_counters || g_num_cus <= 0) return false;
   const int64_t gx = er::ceil_div(N, er::BN), gy = er::ceil_div(M, er::BM);
-  return gx <= kMaxColTiles && 8 * er::ceil_div(gx * gy, 8) <= 2LL * g_num_cus;
+  return gx <= kMaxColTiles && gx * gy <= 2LL * g_num_cus;
 }
 
 template <bool BF16>
 int launch_gemm(int layout, er::GemmArgs& a, hipStream_t s) {
   const int64_t n_tiles = er::ceil_div(a.N, er::BN) * er::ceil_div(a.M, er::BM);
-  dim3 grid(static_cast<unsigned>(8 * er::ceil_div(n_tiles, 8)), 1, static_cast<unsigned>(a.splits));  // tile_coords()
+  dim3 grid(static_cast<unsigned>(n_tiles), 1, static_cast<unsigned>(a.splits));  // (x fastest: split z's tiles are consecutive)
   dim3 block(er::kBlock);
 #define ER_LAUNCH_GEMM(KERNEL)                                                   \
   switch (layout) {                                                              \
@@ -1241,11 +1237,6 @@ int launch_gemm(int layout, er::GemmArgs& a, hipStream_t s) {
 #undef ER_LAUNCH_GEMM
   ER_LAUNCH_CHECK();
   return 0;
-}
-
-bool xcd_rotate_on() {  // A/B switch of tile_coords()'s per-split / per-problem rotation
-  static const bool on = [] { const char* e = getenv("ER_GEMM_XCD_ROTATE"); return !(e && atoi(e) == 0); }();
-  return on;
 }
 
 int choose_splits(int M, int N, int K, int ktile) {
@@ -1277,7 +1268,6 @@ int gemm_entry(int layout, int M, int N, int K, const float* A, int lda, const f
   if (bn) a.bn = *bn;
   if (at) a.at = *at;
   if (fu) a.fu = *fu;
-  a.xcd_rot = xcd_rotate_on() ? 0 : -1;
   a.splits = (col_stats || bn) ? 1 : choose_splits(M, N, K, ktile);
   ER_REQUIRE(!(col_stats && accumulate), "%s: column statistics need a plain (non-accumulating) output", who);
   a.k_per_split = static_cast<int>(er::ceil_div(er::ceil_div(K, a.splits), ktile)) * ktile;
@@ -1302,13 +1292,17 @@ int gemm_entry(int layout, int M, int N, int K, const float* A, int lda, const f
 }
 
 // Which TN problems of a grouped launch take the natural-layout kernel (gemm_f32_grouped_tnn_kernel).  ER_GEMM_TNN:
-// 0 = none, 1 = the batch-long contractions into one or a few tiles (M, N <= 128: every operand byte is then read once
-// per split), 2 = every TN problem without an epilogue.
+// 0 = none (DEFAULT), 1 = the batch-long contractions into one or a few tiles (M, N <= 128: every operand byte is then
+// read once per split), 2 = every TN problem without an epilogue.
+// Measured on MI355X once the grids were exact (profiles/r03_wgrad_probe.md): no faster than gemm_f32_block on the
+// shapes it was built for (128 x 128 x 204,800: 117 us against 121 at 512 rows per split, 167 against 106 at 2,048) and
+// 20 - 30 % slower on the batch-8,192 problems (1152 x 256: 86 us against 71) - the transposing stores it avoids were
+// never what the launch waited for.  Kept as a tested (bit-identical) alternative, off.
 int g_tnn_mode = -1;  // (er_gemm_tn_natural_mode)
 int tnn_mode() {
   if (g_tnn_mode < 0) {
     const char* e = getenv("ER_GEMM_TNN");  // A/B switch
-    g_tnn_mode = e ? atoi(e) : 1;
+    g_tnn_mode = e ? atoi(e) : 0;
     if (g_tnn_mode < 0) g_tnn_mode = 0;
   }
   return g_tnn_mode;
@@ -1340,7 +1334,12 @@ int gemm_grouped_f32(int layout, const er_gemm_problem* pr, int n, er_stream_t s
     // splits - and with them the bits - do not depend on which kernel takes a problem)
   }
   // k-splits: enough workgroups for ~2 per CU over the whole group (A/B: 512 beat 1024 and 2048), >= 4 k-tiles per split
-  int64_t want = total_tiles >= 512 ? 1 : er::ceil_div(512, total_tiles);
+  static const int64_t target_blocks = [] {  // (A/B knob)
+    const char* e = getenv("ER_WGRAD_TARGET_BLOCKS");
+    const int64_t v = e ? atoll(e) : 0;
+    return v >= 1 ? v : 512;
+  }();
+  int64_t want = total_tiles >= target_blocks ? 1 : er::ceil_div(target_blocks, total_tiles);
   if (want > 64) want = 64;
   er::GroupedArgs ga, gb;  // the problems of gemm_f32_block | of the natural-layout TN kernel
   er::GroupedReduceArgs ra;
@@ -1354,7 +1353,6 @@ int gemm_grouped_f32(int layout, const er_gemm_problem* pr, int n, er_stream_t s
   size_t ws_floats = 0;
   bool vec_ok = true;
   bool any_tr = false, any_bn = false;
-  int xcd_rot = 0;
   for (int i = 0; i < n; ++i) {
     const er_gemm_problem& q = pr[i];
     er::GroupedArgs& grp = big[i] ? gb : ga;
@@ -1391,7 +1389,12 @@ int gemm_grouped_f32(int layout, const er_gemm_problem* pr, int n, er_stream_t s
     }();
     const int64_t by_len = er::ceil_div(q.K, split_rows);
     if (by_len > sp) sp = by_len;
-    if (sp > 128) sp = 128;
+    static const int64_t max_splits = [] {  // (A/B knob)
+      const char* e = getenv("ER_WGRAD_MAX_SPLITS");
+      const int64_t v = e ? atoll(e) : 0;
+      return v >= 1 ? v : 128;
+    }();
+    if (sp > max_splits) sp = max_splits;
     const int64_t max_by_k = q.K / (4 * er::BK32);
     if (sp > max_by_k) sp = max_by_k;
     if (sp < 1 || q.col_stats || q.bn_partial) sp = 1;
@@ -1399,16 +1402,9 @@ int gemm_grouped_f32(int layout, const er_gemm_problem* pr, int n, er_stream_t s
     a.splits = static_cast<int>(er::ceil_div(q.K, a.k_per_split));
     const int64_t tiles = er::ceil_div(q.M, tm[i]) * er::ceil_div(q.N, tn[i]);
     a.tile_shape = 2 * (tm[i] == 128) + (tn[i] == 128);
-    grp.tiles8[grp.n] = static_cast<int>(8 * er::ceil_div(tiles, 8));
-    grp.start[grp.n + 1] = grp.start[grp.n] + grp.tiles8[grp.n] * a.splits;
+    grp.tiles[grp.n] = static_cast<int>(tiles);
+    grp.start[grp.n + 1] = grp.start[grp.n] + grp.tiles[grp.n] * a.splits;
     ++grp.n;
-    {  // tile_coords(): the next problem's XCD slots start where this one's stop
-      const bool rotate = xcd_rotate_on();
-      const int64_t per = er::ceil_div(tiles, 8);
-      const int64_t used = er::ceil_div(tiles, per);
-      a.xcd_rot = rotate ? xcd_rot : -1;
-      xcd_rot = static_cast<int>((xcd_rot + used * a.splits) % 8);
-    }
     if (a.splits > 1) {
       const int64_t mn = static_cast<int64_t>(q.M) * q.N;
       er::ReduceItem& r = ra.r[ra.n];

@@ -560,8 +560,8 @@ int er_mmoe_mix_bwd(const float* experts, const float* gates, const float* dout,
                     er_stream_t stream);
 
 /* Which TN problems of er_gemm_grouped_f32 (the weight gradients dW = x^T . dz) run in the operands' natural k-major
- * layout (128- or 64-wide tiles, no transposition on the way into LDS; same bits as the default kernel): 0 none, 1 the
- * batch-long contractions into M, N <= 128 (default; env ER_GEMM_TNN), 2 every TN problem without an epilogue.
+ * layout (128- or 64-wide tiles, no transposition on the way into LDS; same bits as the default kernel): 0 none (default;
+ * env ER_GEMM_TNN), 1 the batch-long contractions into M, N <= 128, 2 every TN problem without an epilogue.
  * mode < 0 only queries.  Returns the previous mode. */
 int er_gemm_tn_natural_mode(int mode);
 
