@@ -125,6 +125,16 @@ bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ bias, con
   y[i] = v;
 }
 
+typedef float f32x4d __attribute__((ext_vector_type(4)));
+
+// one element of bias + BatchNorm + activation
+__device__ __forceinline__ float bn_act_one(float x, float bv, float mu, float is, float ga, float be, int act) {
+  float v = ((x + bv) - mu) * is;
+  v = v * ga + be;
+  if (act == ER_ACT_RELU) v = v > 0.f ? v : 0.f;
+  return v;
+}
+
 // use_bn == ER_BN_FROZEN: batch_normalization(training=False) inside a training graph.  The reference's MMoE and
 // DBMTL models build their experts that way (model/mmoe.py:37-47, model/dbmtl.py:66-70 call layers/mmoe.py MMOE
 // without is_training, whose default is False): the MOVING statistics normalise, nothing updates them, gamma / beta /
@@ -281,6 +291,46 @@ __device__ __forceinline__ void bn_finalize_apply_body(const float* __restrict__
     }
   }
   __syncthreads();
+  if (tiles_per_block >= 4 && N % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0) {
+    // tall activations (DIN's [B x L]-row layers: 16 row tiles per workgroup): 16-byte lanes - 16 column lanes x 16 row
+    // lanes, one load per lane and tile, four tiles in flight.  Measured (profiles/r03_bn_lanes.md): 250 -> 210 us per DIN
+    // step for this kernel; for batch-sized layers (1 - 2 tiles per workgroup) the wider lanes were SLOWER (MMoE 205 ->
+    // 233 us, DeepFM 46 -> 47) - those workgroups live on the latency of their three dependent round trips, not on
+    // request width - and the backward and frozen kernels gained nothing: they keep 4-byte lanes.
+    const int cl4 = (threadIdx.x & 15) * 4, rl16 = threadIdx.x >> 4;
+    const int c4 = bx * kColsPerBlock + cl4;
+    if (c4 >= N) return;
+    float mu[4], is[4], bv[4], ga[4], be[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      mu[j] = s_mean[cl4 + j];
+      is[j] = s_inv[cl4 + j];
+      bv[j] = bias ? bias[c4 + j] : 0.f;
+      ga[j] = gamma ? gamma[c4 + j] : 1.f;
+      be[j] = beta ? beta[c4 + j] : 0.f;
+    }
+    const int row_base = by * tiles_per_block * kApplyRows + rl16;
+    for (int tile0 = 0; tile0 < tiles_per_block; tile0 += 4) {
+      f32x4d xv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int r = row_base + (tile0 + u) * kApplyRows;
+        const bool ok = tile0 + u < tiles_per_block && r < B;
+        xv[u] = ok ? *reinterpret_cast<const f32x4d*>(x + static_cast<int64_t>(r) * N + c4) : f32x4d{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int r = row_base + (tile0 + u) * kApplyRows;
+        if (tile0 + u < tiles_per_block && r < B) {
+          f32x4d out;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) out[j] = bn_act_one(xv[u][j], bv[j], mu[j], is[j], ga[j], be[j], act);
+          *reinterpret_cast<f32x4d*>(y + static_cast<int64_t>(r) * N + c4) = out;
+        }
+      }
+    }
+    return;
+  }
   if (c >= N) return;
   const float mu = s_mean[cl], is = s_inv[cl];
   const float bv = bias ? bias[c] : 0.f;
@@ -300,12 +350,7 @@ __device__ __forceinline__ void bn_finalize_apply_body(const float* __restrict__
 #pragma unroll
     for (int k = 0; k < kApplyRows / kRowLanes; ++k) {
       const int r = r0 + k * kRowLanes;
-      if (r < B) {
-        float v = ((xv[k] + bv) - mu) * is;
-        v = v * ga + be;
-        if (act == ER_ACT_RELU) v = v > 0.f ? v : 0.f;
-        y[static_cast<int64_t>(r) * N + c] = v;
-      }
+      if (r < B) y[static_cast<int64_t>(r) * N + c] = bn_act_one(xv[k], bv, mu, is, ga, be, act);
     }
   }
 }
