@@ -1025,19 +1025,17 @@ gemm_f32_grouped_tnn_kernel(GroupedArgs ga) {
 // stride 40 halves (80 B): the 16-byte fragment reads of a 16-lane group hit 16 distinct bank quads.
 // Fragment of v_mfma_f32_32x32x16_bf16: lane l holds A[i = l & 31][k = 8 * (l >> 5) + 0..7].
 // ------------------------------------------------------------------------------------------------
+constexpr int kBf16SH = BK16 + 8;  // halves per LDS row
 template <bool A_KC, bool B_KC>
-__global__ void __launch_bounds__(kBlock)
-gemm_bf16_kernel(GemmArgs g) {
-  constexpr int SH = BK16 + 8;  // halves per row
-  __shared__ __attribute__((aligned(16))) short As[BM * SH];
-  __shared__ __attribute__((aligned(16))) short Bs[BN * SH];
+__device__ __forceinline__ void gemm_bf16_block(const GemmArgs& g, int bx, int bz, short* __restrict__ As, short* __restrict__ Bs) {
+  constexpr int SH = kBf16SH;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   int tx, ty;
-  tile_coords(blockIdx.x, static_cast<int>(ceil_div(g.N, BN)), static_cast<int>(ceil_div(g.M, BM)), tx, ty);
+  tile_coords(bx, static_cast<int>(ceil_div(g.N, BN)), static_cast<int>(ceil_div(g.M, BM)), tx, ty);
   const int m0 = ty * BM, n0 = tx * BN;
-  const int kbeg = blockIdx.z * g.k_per_split;
+  const int kbeg = bz * g.k_per_split;
   int kend = kbeg + g.k_per_split;
   if (kend > g.K) kend = g.K;
   const bool a_vec = (g.lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0);
@@ -1093,7 +1091,7 @@ gemm_bf16_kernel(GemmArgs g) {
     tile_col_stats(acc, bv, m0 + wm * 32, g.M, col, g.N, wm, wn, lane, reinterpret_cast<float*>(As),
                    g.col_stats + static_cast<int64_t>(ty) * g.N * 3);
   if (col >= g.N) return;
-  float* Cz = g.C + (g.splits > 1 ? static_cast<int64_t>(blockIdx.z) * g.M * g.N : 0);
+  float* Cz = g.C + (g.splits > 1 ? static_cast<int64_t>(bz) * g.M * g.N : 0);
   const int ldc = g.splits > 1 ? g.N : g.ldc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -1105,6 +1103,27 @@ gemm_bf16_kernel(GemmArgs g) {
       *p = v;
     }
   }
+}
+
+template <bool A_KC, bool B_KC>
+__global__ void __launch_bounds__(kBlock)
+gemm_bf16_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) short As[BM * kBf16SH];
+  __shared__ __attribute__((aligned(16))) short Bs[BN * kBf16SH];
+  gemm_bf16_block<A_KC, B_KC>(g, blockIdx.x, blockIdx.z, As, Bs);
+}
+
+// several bf16 problems in ONE launch (the weight gradients of a bf16 step: er_gemm_grouped_bf16)
+template <bool A_KC, bool B_KC>
+__global__ void __launch_bounds__(kBlock)
+gemm_bf16_grouped_kernel(GroupedArgs ga) {
+  __shared__ __attribute__((aligned(16))) short As[BM * kBf16SH];
+  __shared__ __attribute__((aligned(16))) short Bs[BN * kBf16SH];
+  const int b = blockIdx.x;
+  int p = 0;
+  while (p + 1 < ga.n && b >= ga.start[p + 1]) ++p;
+  const int local = b - ga.start[p];
+  gemm_bf16_block<A_KC, B_KC>(ga.p[p], local % ga.tiles[p], local / ga.tiles[p], As, Bs);
 }
 
 // C[i, j] (+)= bias[j] + sum_s ws[s, i, j]   (split order fixed: deterministic).  VEC = 4: float4 per lane, the
@@ -1320,7 +1339,7 @@ bool tnn_fits(int layout, const er_gemm_problem& q) {
   return q.M <= 128 && q.N <= 128 && q.K >= 2048;
 }
 
-int gemm_grouped_f32(int layout, const er_gemm_problem* pr, int n, er_stream_t stream) {
+int gemm_grouped_f32(int layout, const er_gemm_problem* pr, int n, er_stream_t stream, bool bf16 = false) {
   hipStream_t s = er::as_stream(stream);
   int64_t total_tiles = 0;
   bool big[er::kMaxGroup];  // the problem takes the natural-layout TN kernel
@@ -1332,7 +1351,8 @@ int gemm_grouped_f32(int layout, const er_gemm_problem* pr, int n, er_stream_t s
     const int min_ldb = (layout == ER_GEMM_NT) ? q.K : q.N;
     ER_REQUIRE(q.lda >= min_lda && q.ldb >= min_ldb && q.ldc >= q.N,
                "er_gemm_grouped_f32: problem %d: leading dimension too small", i);
-    big[i] = tnn_fits(layout, q);
+    ER_REQUIRE(!bf16 || !(q.a_mean || q.bn_partial), "er_gemm_grouped_bf16: problem %d: epilogues / transforms are fp32 only", i);
+    big[i] = !bf16 && tnn_fits(layout, q);
     tm[i] = (big[i] && q.M > 64) ? 128 : 64;
     tn[i] = (big[i] && q.N > 64) ? 128 : 64;
     total_tiles += er::ceil_div(q.M, er::BM) * er::ceil_div(q.N, er::BN);  // (in 64 x 64 units whatever the kernel: the
@@ -1446,6 +1466,13 @@ int gemm_grouped_f32(int layout, const er_gemm_problem* pr, int n, er_stream_t s
   }
   if (ga.n == 0) {
     // (every problem took the natural-layout kernel)
+  } else if (bf16) {
+    switch (layout) {
+      case ER_GEMM_NN: hipLaunchKernelGGL((er::gemm_bf16_grouped_kernel<true, false>), grid, block, 0, s, ga); break;
+      case ER_GEMM_NT: hipLaunchKernelGGL((er::gemm_bf16_grouped_kernel<true, true>), grid, block, 0, s, ga); break;
+      case ER_GEMM_TN: hipLaunchKernelGGL((er::gemm_bf16_grouped_kernel<false, false>), grid, block, 0, s, ga); break;
+      default: er::set_error("er_gemm_grouped_bf16: unknown layout %d", layout); return 2;
+    }
   } else if (any_bn) {
     ER_REQUIRE(!any_tr, "er_gemm_grouped_f32: the A transform and the BatchNorm-backward epilogue in one launch");
     switch (layout) {
@@ -1627,6 +1654,16 @@ int er_gemm_grouped_f32(int layout, const er_gemm_problem* problems, int n, er_s
   for (int i = 0; i < n; i += er::kMaxGroup) {
     const int m = n - i < er::kMaxGroup ? n - i : er::kMaxGroup;
     if (int rc = gemm_grouped_f32(layout, problems + i, m, stream)) return rc;
+  }
+  return 0;
+}
+
+int er_gemm_grouped_bf16(int layout, const er_gemm_problem* problems, int n, er_stream_t stream) {
+  ER_REQUIRE(problems && n > 0, "er_gemm_grouped_bf16: bad arguments");
+  ER_REQUIRE(layout >= ER_GEMM_NN && layout <= ER_GEMM_TN, "er_gemm_grouped_bf16: unknown layout %d", layout);
+  for (int i = 0; i < n; i += er::kMaxGroup) {
+    const int m = n - i < er::kMaxGroup ? n - i : er::kMaxGroup;
+    if (int rc = gemm_grouped_f32(layout, problems + i, m, stream, true)) return rc;
   }
   return 0;
 }

@@ -83,12 +83,13 @@ class WgradSink(object):
   def __init__(self):
     self.active = False
     self.queue = []
+    self.queue_bf16 = []  # (a bf16 step's weight gradients: er_gemm_grouped_bf16)
 
   def put(self, x, dy, out, bf16, at=None):
     """at: the BnSource of a DEFERRED producer of x (x holds its pre-normalisation values: the GEMM transforms them)"""
-    if not self.active or bf16:
+    if not self.active or (bf16 and at is not None):
       return False
-    self.queue.append((x, dy, out, None, True, at))
+    (self.queue_bf16 if bf16 else self.queue).append((x, dy, out, None, True, at))
     return True
 
 
@@ -894,8 +895,9 @@ class HipBackend(object):
              'er_gemm_f32_deferred')
     return out
 
-  def gemm_grouped(self, layout, problems):
-    """problems: [(a, b, out, bias, accumulate)] fp32, one layout: ONE launch (+ one for the split-K reduces)."""
+  def gemm_grouped(self, layout, problems, bf16=False):
+    """problems: [(a, b, out, bias, accumulate)] fp32, one layout: ONE launch (+ one for the split-K reduces).
+    bf16: operands rounded to bf16 while staged (er_gemm_grouped_bf16)."""
     arr = (GemmProblem * len(problems))()
     for q, pr in zip(arr, problems):
       a, b, out, bias, accumulate = pr[:5]
@@ -917,9 +919,11 @@ class HipBackend(object):
       assert K == K2 and out.shape == (M, N)
       if self.op_log is not None:  # (which of the two grouped kernels takes the problem: er_gemm.hip tnn_fits)
         mode = self.gemm_tn_natural_mode()
-        natural = layout == GEMM_TN and at is None and stats is None and bn is None and \
+        natural = not bf16 and layout == GEMM_TN and at is None and stats is None and bn is None and \
             (mode >= 2 or (mode == 1 and M <= 128 and N <= 128 and K >= 2048))
-        if natural:
+        if bf16:
+          self._log_gemm('gemm_bf16_grouped_kernel', layout, M, N, K)
+        elif natural:
           self._log_gemm('gemm_f32_grouped_tnn_kernel', None, M, N, K)
         else:
           self._log_gemm('gemm_f32_grouped_tr_kernel' if at is not None else 'gemm_f32_grouped_kernel', layout, M, N, K)
@@ -938,7 +942,10 @@ class HipBackend(object):
         q.bn_mean, q.bn_invstd, q.bn_gamma, q.bn_beta = _ptr(src.mean), _ptr(src.invstd), _ptr(src.gamma), _ptr(src.beta)
         q.bn_ld, q.bn_use_bn, q.bn_act = src.z.stride(0), int(src.mean is not None), int(src.act)
         q.bn_partial = partial.data_ptr()
-    self._ck(self.lib.er_gemm_grouped_f32(ctypes.c_int(layout), arr, len(problems), _stream()), 'er_gemm_grouped_f32')
+    if bf16:
+      self._ck(self.lib.er_gemm_grouped_bf16(ctypes.c_int(layout), arr, len(problems), _stream()), 'er_gemm_grouped_bf16')
+    else:
+      self._ck(self.lib.er_gemm_grouped_f32(ctypes.c_int(layout), arr, len(problems), _stream()), 'er_gemm_grouped_f32')
 
   # weight gradients of a backward pass: queued by LinearFn / LinearBNActFn, contracted together by flush_wgrads()
   def wgrad_sink(self):
@@ -951,7 +958,7 @@ class HipBackend(object):
 
   def defer_wgrads(self):
     sink = self.wgrad_sink()
-    assert not sink.queue, 'flush_wgrads() was not called for the previous backward pass'
+    assert not sink.queue and not sink.queue_bf16, 'flush_wgrads() was not called for the previous backward pass'
     sink.active = os.environ.get('EASYREC_AMD_GROUPED_WGRAD', '1') != '0'  # A/B switch
 
   def flush_wgrads(self):
@@ -959,9 +966,12 @@ class HipBackend(object):
     the operands were produced on, the caller keeps it alive until the streams have joined."""
     sink = self.wgrad_sink()
     q, sink.queue, sink.active = sink.queue, [], False
+    qb, sink.queue_bf16 = sink.queue_bf16, []
     if q:
       self.gemm_grouped(GEMM_TN, q)
-    return q
+    if qb:
+      self.gemm_grouped(GEMM_TN, qb, bf16=True)
+    return q + qb
 
   # -- K12 embedding-parallel routing (include/easyrec_hip.h)
   def emb_group_set_routing(self, group, world, shard_stride, local_base):

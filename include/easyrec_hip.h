@@ -647,6 +647,9 @@ typedef struct er_gemm_problem {
   float* bn_partial;
 } er_gemm_problem;
 int er_gemm_grouped_f32(int layout, const er_gemm_problem* problems_host, int n, er_stream_t stream);
+/* ... with the operands rounded to bf16 while staged (er_gemm_bf16's arithmetic: v_mfma_f32_32x32x16_bf16, fp32
+ * accumulation; the weight gradients of a bf16 step in one launch).  No A transform, no BatchNorm-backward epilogue. */
+int er_gemm_grouped_bf16(int layout, const er_gemm_problem* problems_host, int n, er_stream_t stream);
 /* DEFERRED BatchNorm + activation (reference layers/dnn.py:57-79: dense -> batch_normalization -> relu per layer).
  * The reference materialises every intermediate; here a hidden layer of a stack writes only its pre-normalisation
  * values z (bias included) and its batch statistics, and every reader of its activation output y = act(BN(z)) -

@@ -434,12 +434,12 @@ class RefBackend(object):
                             l['use_bn'], l['act'], l.get('bias') is not None, l.get('gamma') is not None,
                             into=l.get('into')) for l in layers]
 
-  def gemm_grouped(self, layout, problems):
+  def gemm_grouped(self, layout, problems, bf16=False):
     for pr in problems:
       a, b, out, bias, accumulate = pr[:5]
       at = pr[5] if len(pr) > 5 else None
       A = self._deferred_value(at, a) if at is not None else a
-      self.gemm(layout, A, b, out=out, bias=bias, accumulate=accumulate)  # (column statistics: recomputed by bn_apply_from_stats)
+      self.gemm(layout, A, b, out=out, bias=bias, accumulate=accumulate, bf16=bf16)  # (column statistics: recomputed by bn_apply_from_stats)
 
   # -- deferred BatchNorm + activation (include/easyrec_hip.h er_a_transform / er_bn_finalize): the stand-in applies the
   # producer's normalisation to the operand, then contracts; statistics straight from the output

@@ -1040,6 +1040,34 @@ def test_gemm_grouped_matches_single_launches(hip):
     assert torch.equal(p[2], f)
 
 
+def test_gemm_grouped_bf16_matches_rounded_operands(hip):
+  """er_gemm_grouped_bf16 (the weight gradients of a bf16 step in one launch): every problem = the fp32-accumulated
+  product of the operands rounded to bf16 (fp64 reference of the ROUNDED operands within the fp32 summation bound),
+  accumulate honoured, bit-identical across launches."""
+  g = torch.Generator().manual_seed(23)
+  hip.gemm_reserve(1 << 22)
+  shapes = [(429, 256, 4096), (256, 128, 4096), (128, 64, 4096), (64, 1, 4096), (33, 65, 97), (130, 72, 1000)] * 3
+  probs, refs, bases = [], [], []
+  for (M, N, K) in shapes:
+    a, b = torch.randn(K, M, generator=g), torch.randn(K, N, generator=g)
+    base = torch.randn(M, N, generator=g)
+    probs.append((a.to(DEV), b.to(DEV), base.to(DEV), None, True))
+    ar, br = a.to(torch.bfloat16).double(), b.to(torch.bfloat16).double()
+    refs.append((ar.t() @ br, (ar.abs().t() @ br.abs()) * 1e-6 + 1e-5))
+    bases.append(base)
+  hip.gemm_grouped(kernels.GEMM_TN, probs, bf16=True)
+  torch.cuda.synchronize()
+  first = [p[2].clone() for p in probs]
+  for (ref, bound), base, got in zip(refs, bases, first):
+    assert ((got.cpu().double() - (base.double() + ref)).abs() <= bound).all()
+  for p, base in zip(probs, bases):
+    p[2].copy_(base.to(DEV))
+  hip.gemm_grouped(kernels.GEMM_TN, probs, bf16=True)
+  torch.cuda.synchronize()
+  for p, f in zip(probs, first):
+    assert torch.equal(p[2], f)
+
+
 def test_natural_layout_weight_gradient_kernel_changes_no_bit(hip):
   """gemm_f32_grouped_tnn_kernel (TN problems staged k-major, 128- / 64-wide tiles) against the default 64 x 64 kernel:
   the same contraction order per accumulator and the same splits, so every output bit agrees - aligned and unaligned
