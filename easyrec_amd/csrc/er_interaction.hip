@@ -287,6 +287,150 @@ din_concat_bwd_query_kernel(const float* __restrict__ h, const float* __restrict
   dq[i] = acc_q ? (dq[i] + s) : s;
 }
 
+// ------------------------------------------------------------------------------------------------
+// DIN, one wave per example with 16-byte lanes: lane = (row r = lane / C, chunk c = lane % C), C = E / 4 chunks per
+// history row, 64 / C rows per pass; a [L x E] history block is read ONCE, coalesced, and sums over t finish with
+// xor-shuffles across the row lanes.  Needs L <= 64 (a lane holds position `lane`'s probability), E % 4 == 0 and
+// E / 4 a power of two <= 64, 16-byte aligned tensors: DIN's L = 50, E = 32.  Anything else: the kernels below (one
+// lane per position / per output column, 4-byte lanes).  Round 3: the four kernels were 1/11 of the DIN step.
+// ------------------------------------------------------------------------------------------------
+typedef float f32x4i __attribute__((ext_vector_type(4)));
+
+__host__ __device__ inline bool din_fast_ok(int L, int E, const void* a, const void* b = nullptr, const void* c = nullptr) {
+  const int C = E / 4;
+  return L <= 64 && E % 4 == 0 && C >= 1 && C <= 64 && (C & (C - 1)) == 0 &&
+         ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c)) & 15) == 0;
+}
+
+// sum over the lanes that share `lane % C` (C a power of two): xor-shuffles over the row bits
+__device__ __forceinline__ float row_lanes_sum(float v, int C) {
+  for (int m = C; m < 64; m <<= 1) v = v + __shfl_xor(v, m, 64);
+  return v;
+}
+
+__global__ void __launch_bounds__(kBlock)
+din_pool_fwd_fast_kernel(const float* __restrict__ scores, const float* __restrict__ hist, const int32_t* __restrict__ len,
+                         int B, int L, int E, float scale, float* __restrict__ probs, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t b = static_cast<int64_t>(blockIdx.x) * (kBlock / 64) + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const float kPad = -4294967295.0f;  // -2**32 + 1 (reference model/multi_tower_din.py:88)
+  const int n = len[b];
+  const float s = (lane < L) ? ((lane < n) ? scores[b * L + lane] * scale : kPad) : -INFINITY;
+  const float mx = wave_max(s);
+  const float ex = (lane < L) ? expf(s - mx) : 0.f;
+  const float den = wave_sum(ex);
+  const float p = ex / den;
+  if (lane < L) probs[b * L + lane] = p;
+  const int C = E / 4, c = lane % C, r0 = lane / C, R = 64 / C;
+  f32x4i acc = {0.f, 0.f, 0.f, 0.f};
+  const f32x4i* h4 = reinterpret_cast<const f32x4i*>(hist + b * L * E);
+  for (int t0 = 0; t0 < L; t0 += R) {
+    const int t = t0 + r0;
+    const float pt = __shfl(p, t < L ? t : 0, 64);
+    if (t < L) {
+      const f32x4i v = h4[t * C + c];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = acc[j] + pt * v[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc[j] = row_lanes_sum(acc[j], C);
+  if (r0 == 0) *reinterpret_cast<f32x4i*>(out + b * E + c * 4) = acc;
+}
+
+__global__ void __launch_bounds__(kBlock)
+din_pool_bwd_fast_kernel(const float* __restrict__ probs, const float* __restrict__ hist, const int32_t* __restrict__ len,
+                         const float* __restrict__ dout, int B, int L, int E, float scale, float* __restrict__ dscores,
+                         float* __restrict__ dhist, int acc_h) {
+  const int lane = threadIdx.x & 63;
+  const int64_t b = static_cast<int64_t>(blockIdx.x) * (kBlock / 64) + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const int n = len[b];
+  const int C = E / 4, c = lane % C, r0 = lane / C, R = 64 / C;
+  const float p = (lane < L) ? probs[b * L + lane] : 0.f;
+  const f32x4i g = *reinterpret_cast<const f32x4i*>(dout + b * E + c * 4);
+  const f32x4i* h4 = reinterpret_cast<const f32x4i*>(hist + b * L * E);
+  f32x4i* dh4 = reinterpret_cast<f32x4i*>(dhist + b * L * E);
+  // dp[t] = sum_e dout[e] * hist[t, e] lands in lane t (the probabilities' layout); dhist[t, e] = p[t] * dout[e]
+  float dp = 0.f;
+  for (int t0 = 0; t0 < L; t0 += R) {
+    const int t = t0 + r0;
+    const float pt = __shfl(p, t < L ? t : 0, 64);
+    float part = 0.f;
+    if (t < L) {
+      const f32x4i v = h4[t * C + c];
+      part = (g[0] * v[0] + g[1] * v[1]) + (g[2] * v[2] + g[3] * v[3]);
+      f32x4i o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = pt * g[j];
+      if (acc_h) {
+        const f32x4i old = dh4[t * C + c];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = old[j] + o[j];
+      }
+      dh4[t * C + c] = o;
+    }
+    for (int m = 1; m < C; m <<= 1) part = part + __shfl_xor(part, m, 64);  // over the row's chunks
+    // row t0 + r of this pass sits in lanes r * C ..: hand it to lane t0 + r
+    const int src_row = lane - t0;
+    const float got = __shfl(part, (src_row >= 0 && src_row < R) ? src_row * C : 0, 64);
+    if (src_row >= 0 && src_row < R && lane < L) dp = got;
+  }
+  const float dot_pd = wave_sum(p * dp);
+  // ds = p * (dp - sum_t p * dp); masked positions get no gradient
+  if (lane < L) dscores[b * L + lane] = (lane < n) ? p * (dp - dot_pd) * scale : 0.f;
+}
+
+// dhist and dquery of the [q, h, q - h, q * h] concat in one pass over dout (one wave per example)
+__global__ void __launch_bounds__(kBlock)
+din_concat_bwd_fast_kernel(const float* __restrict__ q, const float* __restrict__ h, const float* __restrict__ dout, int B,
+                           int L, int E, float* __restrict__ dq, int acc_q, float* __restrict__ dh, int acc_h) {
+  const int lane = threadIdx.x & 63;
+  const int64_t b = static_cast<int64_t>(blockIdx.x) * (kBlock / 64) + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const int C = E / 4, c = lane % C, r0 = lane / C, R = 64 / C;
+  const f32x4i qv = *reinterpret_cast<const f32x4i*>(q + b * E + c * 4);
+  const f32x4i* h4 = reinterpret_cast<const f32x4i*>(h + b * L * E);
+  const f32x4i* g4 = reinterpret_cast<const f32x4i*>(dout + b * L * 4 * E);
+  f32x4i* dh4 = dh ? reinterpret_cast<f32x4i*>(dh + b * L * E) : nullptr;
+  f32x4i s = {0.f, 0.f, 0.f, 0.f};
+  for (int t0 = 0; t0 < L; t0 += R) {
+    const int t = t0 + r0;
+    if (t < L) {
+      const f32x4i g0 = g4[(t * 4 + 0) * C + c], g1 = g4[(t * 4 + 1) * C + c], g2 = g4[(t * 4 + 2) * C + c],
+                   g3 = g4[(t * 4 + 3) * C + c];
+      const f32x4i hv = h4[t * C + c];
+      if (dh4) {
+        f32x4i o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (g1[j] - g2[j]) + g3[j] * qv[j];
+        if (acc_h) {
+          const f32x4i old = dh4[t * C + c];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = old[j] + o[j];
+        }
+        dh4[t * C + c] = o;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s[j] = s[j] + ((g0[j] + g2[j]) + g3[j] * hv[j]);
+    }
+  }
+  if (dq) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s[j] = row_lanes_sum(s[j], C);
+    if (r0 == 0) {
+      f32x4i* o = reinterpret_cast<f32x4i*>(dq + b * E + c * 4);
+      if (acc_q) {
+        const f32x4i old = *o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s[j] = old[j] + s[j];
+      }
+      *o = s;
+    }
+  }
+}
+
 // one wave per example: masked softmax over L (any L, strided over lanes) then p @ hist
 __global__ void __launch_bounds__(kBlock)
 din_pool_fwd_kernel(const float* __restrict__ scores, const float* __restrict__ hist, const int32_t* __restrict__ len,
@@ -764,6 +908,12 @@ int er_din_concat_bwd(const float* query, const float* hist, const float* dout, 
                       float* dquery, int acc_q, float* dhist, int acc_h, er_stream_t stream) {
   ER_REQUIRE(query && hist && dout && B > 0 && L > 0 && E > 0, "er_din_concat_bwd: bad arguments");
   hipStream_t s = er::as_stream(stream);
+  if (er::din_fast_ok(L, E, query, hist, dout) && er::din_fast_ok(L, E, dquery, dhist)) {
+    hipLaunchKernelGGL(er::din_concat_bwd_fast_kernel, dim3(static_cast<int>(er::ceil_div(B, er::kBlock / 64))),
+                       dim3(er::kBlock), 0, s, query, hist, dout, B, L, E, dquery, acc_q, dhist, acc_h);
+    ER_LAUNCH_CHECK();
+    return 0;
+  }
   if (dhist) {
     hipLaunchKernelGGL(er::din_concat_bwd_hist_kernel, dim3(er::blocks_for(static_cast<int64_t>(B) * L * E)),
                        dim3(er::kBlock), 0, s, query, dout, B, L, E, dhist, acc_h);
@@ -780,6 +930,12 @@ int er_din_concat_bwd(const float* query, const float* hist, const float* dout, 
 int er_din_pool_fwd(const float* scores, const float* hist, const int32_t* seq_len, int32_t B, int32_t L, int32_t E,
                     float scale, float* probs_out, float* out, er_stream_t stream) {
   ER_REQUIRE(scores && hist && seq_len && probs_out && out && B > 0 && L > 0 && E > 0, "er_din_pool_fwd: bad arguments");
+  if (er::din_fast_ok(L, E, hist, out)) {
+    hipLaunchKernelGGL(er::din_pool_fwd_fast_kernel, dim3(static_cast<int>(er::ceil_div(B, er::kBlock / 64))),
+                       dim3(er::kBlock), 0, er::as_stream(stream), scores, hist, seq_len, B, L, E, scale, probs_out, out);
+    ER_LAUNCH_CHECK();
+    return 0;
+  }
   hipLaunchKernelGGL(er::din_pool_fwd_kernel, dim3(static_cast<int>(er::ceil_div(B, er::kBlock / 64))),
                      dim3(er::kBlock), 0, er::as_stream(stream), scores, hist, seq_len, B, L, E, scale, probs_out, out);
   ER_LAUNCH_CHECK();
@@ -789,6 +945,13 @@ int er_din_pool_fwd(const float* scores, const float* hist, const int32_t* seq_l
 int er_din_pool_bwd(const float* probs, const float* hist, const int32_t* seq_len, const float* dout, int32_t B,
                     int32_t L, int32_t E, float scale, float* dscores, float* dhist, int acc_h, er_stream_t stream) {
   ER_REQUIRE(probs && hist && seq_len && dout && dscores && dhist, "er_din_pool_bwd: null argument");
+  if (er::din_fast_ok(L, E, hist, dout, dhist)) {
+    hipLaunchKernelGGL(er::din_pool_bwd_fast_kernel, dim3(static_cast<int>(er::ceil_div(B, er::kBlock / 64))),
+                       dim3(er::kBlock), 0, er::as_stream(stream), probs, hist, seq_len, dout, B, L, E, scale, dscores,
+                       dhist, acc_h);
+    ER_LAUNCH_CHECK();
+    return 0;
+  }
   hipLaunchKernelGGL(er::din_pool_bwd_kernel, dim3(static_cast<int>(er::ceil_div(B, er::kBlock / 64))),
                      dim3(er::kBlock), 0, er::as_stream(stream), probs, hist, seq_len, dout, B, L, E, scale, dscores,
                      dhist, acc_h);

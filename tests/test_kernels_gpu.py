@@ -350,7 +350,8 @@ def test_cross_v2_epilogue(hip, ref):
 
 
 # ------------------------------------------------------------------------------------------- K8
-@pytest.mark.parametrize('B,L,E', [(33, 50, 32), (4, 70, 8), (9, 1, 16)])
+# (L <= 64 with E / 4 a power of two: the one-pass 16-byte-lane kernels; (4, 70, 8) and (5, 13, 12): the general ones)
+@pytest.mark.parametrize('B,L,E', [(33, 50, 32), (4, 70, 8), (9, 1, 16), (7, 64, 64), (5, 13, 12), (130, 50, 4)])
 def test_din(hip, ref, B, L, E):
   rng = np.random.default_rng(L)
   q = torch.from_numpy(rng.standard_normal((B, E)).astype(np.float32))
