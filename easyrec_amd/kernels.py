@@ -762,7 +762,7 @@ class HipBackend(object):
     self._log_gemm('gemm_f32_bn_bwd_kernel', layout, M, N, K)
     out = torch.empty(M, N, dtype=torch.float32, device=a.device)
     use_bn = src.mean is not None
-    if src.y is None:  # deferred producer: the ReLU mask is recomputed from z
+    if src.y is None or self._mask_from_z(use_bn, src.act, src.gamma, src.beta):  # the ReLU mask is recomputed from z
       self._ck(self.lib.er_gemm_f32_bn_bwd_z(ctypes.c_int(layout), M, N, K, _p(a), ctypes.c_int32(a.stride(0)), _p(b),
                                              ctypes.c_int32(b.stride(0)), _p(out), ctypes.c_int32(out.stride(0)),
                                              _p(src.z), _p(src.zbias), _p(src.gamma), _p(src.beta), _p(src.mean),
@@ -783,6 +783,16 @@ class HipBackend(object):
   # er_bn_bwd_multi)
   grouped_bn = os.environ.get('EASYREC_AMD_GROUPED_BN', '1') != '0'  # A/B switch
   BN_MULTI_MAX_ROWS = 8192  # (taller layers reduce their partial sums in a merge launch of their own: single launches)
+
+  # BatchNorm + ReLU layers: the backward kernels can recompute the ReLU mask from z (one multiply-add chain, the forward's
+  # own operation sequence: the same bits as y > 0, tests) instead of reading y - a quarter of their traffic.  OFF:
+  # measured no faster (same box, BatchNorm family per step: MMoE 500 us against 504, DeepFM 91.5 against 90.0) and slower
+  # on DIN's tall layers (591 against 557) - these kernels wait on their dependent round trips, not on bytes.
+  recompute_relu_mask = os.environ.get('EASYREC_AMD_BN_RECOMPUTE_MASK', '0') != '0'  # A/B switch
+
+  def _mask_from_z(self, use_bn, act, gamma, beta):
+    return self.recompute_relu_mask and int(use_bn) != BN_NONE and int(act) == ACT_RELU and gamma is not None and \
+        beta is not None
 
   def bn_fwd_multi(self, layers):
     """layers: [dict(x, bias, gamma, beta, moving_mean, moving_var, col_stats, use_bn, act, eps, momentum)] -> [(y, mean,
@@ -832,7 +842,8 @@ class HipBackend(object):
         partial = None
       q.x, q.bias, q.gamma, q.beta = x.data_ptr(), _ptr(l.get('bias')), _ptr(l.get('gamma')), _ptr(l.get('beta'))
       q.B, q.N, q.use_bn, q.act = B, N, int(l['use_bn']), int(l['act'])
-      q.save_mean, q.save_invstd, q.y_in = _ptr(l.get('mean')), _ptr(l.get('invstd')), _ptr(l['y'])
+      q.save_mean, q.save_invstd = _ptr(l.get('mean')), _ptr(l.get('invstd'))
+      q.y_in = None if self._mask_from_z(l['use_bn'], l['act'], l.get('gamma'), l.get('beta')) else _ptr(l['y'])
       q.dy, q.dy_ld = dy.data_ptr(), dy.stride(0)
       if partial is not None:
         q.partial, q.chunks = partial.data_ptr(), self.gemm_row_tiles(B)
@@ -938,7 +949,8 @@ class HipBackend(object):
       if bn is not None:
         src, partial = bn
         assert src.z.shape == (M, N) and partial.numel() >= self.gemm_row_tiles(M) * N * 2 and not accumulate
-        q.bn_z, q.bn_zbias, q.bn_y = _ptr(src.z), _ptr(src.zbias), _ptr(src.y)
+        q.bn_z, q.bn_zbias = _ptr(src.z), _ptr(src.zbias)
+        q.bn_y = None if self._mask_from_z(src.mean is not None, src.act, src.gamma, src.beta) else _ptr(src.y)
         q.bn_mean, q.bn_invstd, q.bn_gamma, q.bn_beta = _ptr(src.mean), _ptr(src.invstd), _ptr(src.gamma), _ptr(src.beta)
         q.bn_ld, q.bn_use_bn, q.bn_act = src.z.stride(0), int(src.mean is not None), int(src.act)
         q.bn_partial = partial.data_ptr()
@@ -1406,6 +1418,8 @@ class HipBackend(object):
       dgamma = torch.empty(N, dtype=torch.float32, device=dev) if need_affine else None
       dbeta = torch.empty(N, dtype=torch.float32, device=dev) if need_affine else None
     assert dy.dim() == 2 and dy.stride(1) == 1 and dy.dtype == torch.float32
+    if y is not None and self._mask_from_z(use_bn, act, gamma, beta):
+      y = None
     if y is None:
       dyl = dy if partial is None else _f32c(dy)
       self._ck(
@@ -1953,6 +1967,7 @@ class BNFromStatsFn(torch.autograd.Function):
                                              moving_mean, moving_var, act)
     ctx.save_for_backward(z, gamma, y, mean, invstd)
     ctx.act, ctx.grad_bufs = act, grad_bufs
+    ctx.beta = None if beta is None else beta.detach()  # (read by the backward's mask recomputation only)
     fused = getattr(be, 'fused_bn_bwd', False)
     ctx.own = BnSource(z, None, y, mean, invstd, act, gamma, grad_bufs, beta=beta, fused=fused) if fused else None
     _bn_tls.last = ctx.own
@@ -1972,7 +1987,7 @@ class BNFromStatsFn(torch.autograd.Function):
         partial = own.partial
       own.partial = None
     dz, _, dgamma, dbeta = be.bn_act_bwd(z, None, gamma, y, mean, invstd, dyc, 1, ctx.act, False, True,
-                                         into=(None, gg, betag) if direct else None, partial=partial)
+                                         into=(None, gg, betag) if direct else None, partial=partial, beta=ctx.beta)
     return dz, None, dgamma, dbeta, None, None, None, None, None, None
 
 
@@ -2150,6 +2165,7 @@ class BNActFn(torch.autograd.Function):
     ctx.save_for_backward(x, bias, gamma, y, mean, invstd)
     ctx.cfg = (mode, act)
     ctx.grad_bufs = grad_bufs
+    ctx.beta = None if beta is None else beta.detach()  # (read by the backward's mask recomputation only)
     return y
 
   @staticmethod
@@ -2163,7 +2179,7 @@ class BNActFn(torch.autograd.Function):
       if ok:
         into = (bg, gg, betag)
     dx, dbias, dgamma, dbeta = hip().bn_act_bwd(x, bias, gamma, y, mean, invstd, dy.contiguous(), use_bn, act,
-                                                bias is not None, gamma is not None, into=into)
+                                                bias is not None, gamma is not None, into=into, beta=ctx.beta)
     return dx, dbias, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 

@@ -1167,6 +1167,46 @@ def test_grouped_launch_epilogues_match_single_launches(hip):
       assert torch.equal(parts[i], single_part[i]), i
 
 
+@pytest.mark.parametrize('B,N', [(4096, 256), (300, 70), (20000, 40)])
+@pytest.mark.parametrize('mode', [kernels.BN_BATCH, kernels.BN_FROZEN])
+def test_relu_mask_recomputed_from_z_changes_no_bit(hip, B, N, mode):
+  """BatchNorm + ReLU backward with the mask recomputed from z (HipBackend.recompute_relu_mask: y is not read) against
+  the kernels reading y: the forward's operation sequence gives the forward's bits, so every gradient bit agrees - the
+  two-pass kernels, the sums from a dgrad GEMM's epilogue, and the multi-layer launch."""
+  g = torch.Generator().manual_seed(B + N + mode)
+  z = torch.randn(B, N, generator=g).to(DEV)
+  bias = torch.randn(N, generator=g).to(DEV) if mode == kernels.BN_FROZEN else None
+  gamma, beta = (torch.rand(N, generator=g) + 0.5).to(DEV), (torch.randn(N, generator=g) * 0.1).to(DEV)
+  mm, mv = (torch.randn(N, generator=g) * 0.1).to(DEV), (torch.rand(N, generator=g) + 0.5).to(DEV)
+  y, mean, invstd = hip.bn_act_fwd(z, bias, gamma, beta, mode, 1e-3, 0.99, mm, mv, kernels.ACT_RELU)
+  dy = (torch.randn(B, N, generator=g) * 0.1).to(DEV)
+  dzn, wn = (torch.randn(B, 24, generator=g) * 0.1).to(DEV), torch.randn(N, 24, generator=g).to(DEV)
+  prev = hip.recompute_relu_mask
+  res = {}
+  try:
+    for on in (True, False):
+      hip.recompute_relu_mask = on
+      a = hip.bn_act_bwd(z, bias, gamma, y, mean, invstd, dy, mode, kernels.ACT_RELU, bias is not None, True, beta=beta)
+      out = list(a)
+      if mode == kernels.BN_BATCH:
+        part = torch.empty(hip.gemm_row_tiles(B) * N * 2, device=DEV)
+        src = kernels.BnSource(z, None, y, mean, invstd, kernels.ACT_RELU, gamma, None, beta=beta)
+        dy2 = hip.gemm_bn_bwd(kernels.GEMM_NT, dzn, wn, src, part)
+        out += [dy2, part] + list(hip.bn_act_bwd(z, None, gamma, y, mean, invstd, dy2, mode, kernels.ACT_RELU, False, True,
+                                                 partial=part, beta=beta))
+      if B <= hip.BN_MULTI_MAX_ROWS:
+        out += list(hip.bn_bwd_multi([dict(x=z, bias=bias, gamma=gamma, beta=beta, y=y, mean=mean, invstd=invstd, dy=dy,
+                                            use_bn=mode, act=kernels.ACT_RELU)] * 2)[1])
+      res[on] = out
+  finally:
+    hip.recompute_relu_mask = prev
+  torch.cuda.synchronize()
+  for i, (a, b_) in enumerate(zip(res[True], res[False])):
+    assert (a is None) == (b_ is None), i
+    if a is not None:
+      assert torch.equal(a, b_), i
+
+
 def test_multi_layer_batchnorm_launches_match_single_launches(hip):
   """er_bn_fwd_multi / er_bn_bwd_multi (kernels.GroupedBNActFn): the bias / BatchNorm / activation kernels of several
   layers in one launch run the bodies of the single-layer kernels - every output bit for bit what er_bn_apply_from_stats /
