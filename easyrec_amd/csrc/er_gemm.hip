@@ -1173,6 +1173,7 @@ struct ReduceItem {
   const float* bias;
   float* C;
   int ldc, accumulate;
+  int vec;  // 16-byte lanes (N % 4 == 0, ldc % 4 == 0, C 16-byte aligned: decided per problem)
 };
 struct GroupedReduceArgs {
   int n;
@@ -1187,8 +1188,9 @@ gemm_splitk_reduce_grouped_kernel(GroupedReduceArgs ra) {
   int p = 0;
   while (p + 1 < ra.n && b >= ra.start[p + 1]) ++p;
   const ReduceItem& r = ra.r[p];
-  splitk_reduce_elems<VEC>(r.ws, r.mn, r.N, r.splits, r.bias, r.C, r.ldc, r.accumulate,
-                           (static_cast<int64_t>(b - ra.start[p]) * kBlock + threadIdx.x) * VEC);
+  const int64_t lane = static_cast<int64_t>(b - ra.start[p]) * kBlock + threadIdx.x;
+  if (VEC == 4 && r.vec) splitk_reduce_elems<4>(r.ws, r.mn, r.N, r.splits, r.bias, r.C, r.ldc, r.accumulate, lane * 4);
+  else splitk_reduce_elems<1>(r.ws, r.mn, r.N, r.splits, r.bias, r.C, r.ldc, r.accumulate, lane);
 }
 
 }  // namespace er
@@ -1376,7 +1378,6 @@ int gemm_grouped_f32(int layout, const er_gemm_problem* pr, int n, er_stream_t s
   ra.n = 0;
   ra.start[0] = 0;
   size_t ws_floats = 0;
-  bool vec_ok = true;
   bool any_tr = false, any_bn = false;
   for (int i = 0; i < n; ++i) {
     const er_gemm_problem& q = pr[i];
@@ -1435,7 +1436,7 @@ int gemm_grouped_f32(int layout, const er_gemm_problem* pr, int n, er_stream_t s
       er::ReduceItem& r = ra.r[ra.n];
       r.ws = reinterpret_cast<const float*>(ws_floats);  // offset for now: the base is known after ensure_ws
       r.mn = mn; r.N = q.N; r.splits = a.splits; r.bias = q.bias; r.C = q.C; r.ldc = q.ldc; r.accumulate = q.accumulate;
-      if (!(q.N % 4 == 0 && q.ldc % 4 == 0 && (reinterpret_cast<uintptr_t>(q.C) & 15) == 0)) vec_ok = false;
+      r.vec = (q.N % 4 == 0 && q.ldc % 4 == 0 && (reinterpret_cast<uintptr_t>(q.C) & 15) == 0) ? 1 : 0;
       a.C = reinterpret_cast<float*>(ws_floats);
       ws_floats += static_cast<size_t>(a.splits) * mn;
       ws_floats = (ws_floats + 3) & ~static_cast<size_t>(3);
@@ -1455,7 +1456,7 @@ int gemm_grouped_f32(int layout, const er_gemm_problem* pr, int n, er_stream_t s
       }
     }
     for (int j = 0; j < ra.n; ++j) {
-      const int64_t units = vec_ok ? ra.r[j].mn / 4 : ra.r[j].mn;
+      const int64_t units = ra.r[j].vec ? ra.r[j].mn / 4 : ra.r[j].mn;
       ra.start[j + 1] = ra.start[j] + static_cast<int>(er::ceil_div(units, er::kBlock));
     }
   }
@@ -1499,8 +1500,7 @@ int gemm_grouped_f32(int layout, const er_gemm_problem* pr, int n, er_stream_t s
   ER_LAUNCH_CHECK();
   if (ra.n > 0) {
     dim3 rgrid(static_cast<unsigned>(ra.start[ra.n]));
-    if (vec_ok) hipLaunchKernelGGL(er::gemm_splitk_reduce_grouped_kernel<4>, rgrid, block, 0, s, ra);
-    else hipLaunchKernelGGL(er::gemm_splitk_reduce_grouped_kernel<1>, rgrid, block, 0, s, ra);
+    hipLaunchKernelGGL(er::gemm_splitk_reduce_grouped_kernel<4>, rgrid, block, 0, s, ra);  // (16-byte lanes per problem: r.vec)
     ER_LAUNCH_CHECK();
   }
   return 0;

@@ -672,6 +672,45 @@ group_grad_finish_kernel(GradFinishMulti ma) {
   *o = v;
 }
 
+// Several device-to-device copies in ONE launch (the parts of a device-resident batch that go into the step's static
+// input buffers: labels / ids / tag lists / sequences were 7 - 9 hipMemcpyAsync of a few microseconds each per step).
+// Item i: workgroups [start[i], start[i + 1]), 16 bytes per lane when both ends and the size allow, else 4 / 1.
+constexpr int kCopyMulti = 16;
+struct CopyMultiArgs {
+  int n;
+  int start[kCopyMulti + 1];
+  const unsigned char* src[kCopyMulti];
+  unsigned char* dst[kCopyMulti];
+  long long bytes[kCopyMulti];
+};
+
+__global__ void __launch_bounds__(kBlock)
+copy_multi_kernel(CopyMultiArgs a) {
+  int i = 0;
+  while (i + 1 < a.n && static_cast<int>(blockIdx.x) >= a.start[i + 1]) ++i;
+  const long long lane = static_cast<long long>(blockIdx.x - a.start[i]) * kBlock + threadIdx.x;
+  const unsigned char* s = a.src[i];
+  unsigned char* d = a.dst[i];
+  const long long n = a.bytes[i];
+  const unsigned long long align = reinterpret_cast<unsigned long long>(s) | reinterpret_cast<unsigned long long>(d) |
+                                   static_cast<unsigned long long>(n);
+  if ((align & 15) == 0) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    if (lane * 16 < n) reinterpret_cast<u32x4*>(d)[lane] = reinterpret_cast<const u32x4*>(s)[lane];
+  } else if ((align & 3) == 0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long long k = lane * 4 + j;
+      if (k * 4 < n) reinterpret_cast<unsigned int*>(d)[k] = reinterpret_cast<const unsigned int*>(s)[k];
+    }
+  } else {
+    for (int j = 0; j < 16; ++j) {
+      const long long k = lane * 16 + j;
+      if (k < n) d[k] = s[k];
+    }
+  }
+}
+
 // out[b, col0_p + j] = part_p[b * ld_p + j]: tf.concat(axis=1) of up to 8 row-major blocks (model/deepfm.py:75-83) in one
 // launch; pure copy, HBM-bound.
 struct ConcatArgs {
@@ -1083,6 +1122,29 @@ int er_group_grad_finish(const er_grad_group* groups, int n, er_stream_t stream)
     }
     hipLaunchKernelGGL(er::group_grad_finish_kernel, dim3(static_cast<unsigned>(ma.start[ma.n])), dim3(er::kBlock), 0,
                        er::as_stream(stream), ma);
+    ER_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+int er_copy_multi(const void* const* src, void* const* dst, const int64_t* bytes, int n, er_stream_t stream) {
+  ER_REQUIRE(src && dst && bytes && n >= 1, "er_copy_multi: bad arguments");
+  for (int base = 0; base < n; base += er::kCopyMulti) {
+    er::CopyMultiArgs a;
+    a.n = 0;
+    a.start[0] = 0;
+    for (int i = base; i < n && i < base + er::kCopyMulti; ++i) {
+      ER_REQUIRE(bytes[i] >= 0 && (bytes[i] == 0 || (src[i] && dst[i])), "er_copy_multi: item %d: bad descriptor", i);
+      if (bytes[i] == 0) continue;
+      a.src[a.n] = static_cast<const unsigned char*>(src[i]);
+      a.dst[a.n] = static_cast<unsigned char*>(dst[i]);
+      a.bytes[a.n] = bytes[i];
+      a.start[a.n + 1] = a.start[a.n] + static_cast<int>(er::ceil_div(er::ceil_div(bytes[i], 16), er::kBlock));  // 16 B per lane
+      ++a.n;
+    }
+    if (a.n == 0) continue;
+    hipLaunchKernelGGL(er::copy_multi_kernel, dim3(static_cast<unsigned>(a.start[a.n])), dim3(er::kBlock), 0,
+                       er::as_stream(stream), a);
     ER_LAUNCH_CHECK();
   }
   return 0;

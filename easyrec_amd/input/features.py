@@ -260,18 +260,26 @@ class DeviceFeatures(object):
     call `transform()` inside the (possibly graph-captured) step.
     """
 
+    # device-resident parts (a batch ring in HBM) are gathered and copied by ONE launch at the end (er_copy_multi)
+    dev_pairs = []
+    multi = self.device.type == 'cuda'
+
     def put(dst, src):
       if src is None:
         return
       if isinstance(src, np.ndarray):
         src = torch.from_numpy(src)
+      if multi and src.device == dst.device and src.dtype == dst.dtype and src.is_contiguous() and dst.is_contiguous():
+        if src.numel():
+          dev_pairs.append((dst.view(-1)[:src.numel()], src))
+        return
       if src.device != dst.device and src.device.type == 'cpu' and non_blocking:
         src = src.pin_memory() if torch.cuda.is_available() else src
       dst.view(-1)[:src.numel()].copy_(src.reshape(-1), non_blocking=non_blocking)
 
     if 'packed' in batch:  # pack(): one copy for labels, raw values, ids and strings
       src = batch['packed']
-      self.arena[:src.numel()].copy_(src, non_blocking=non_blocking)
+      put(self.arena, src)
       self._use_device_hash = bool(batch['packed_has_strings'])
     put(self.labels, batch.get('labels'))
     put(self.raw_block, batch.get('raw'))
@@ -311,7 +319,14 @@ class DeviceFeatures(object):
       put(bufs['ids'], ids)
       lens = batch['seq/%s/len' % name]
       put(bufs['len'], lens)
-      self.seq_batch_max[name] = int(lens.max()) if len(lens) else 0  # (a device tensor synchronises here)
+      mx = batch.get('seq/%s/max' % name)  # (pack() leaves it: asking a device tensor for it would synchronise)
+      self.seq_batch_max[name] = int(mx) if mx is not None else (int(lens.max()) if len(lens) else 0)
+    if dev_pairs:
+      from easyrec_amd import kernels
+      if len(dev_pairs) == 1:
+        dev_pairs[0][0].copy_(dev_pairs[0][1], non_blocking=non_blocking)
+      else:
+        (self._backend or kernels.hip()).copy_multi(dev_pairs)
     self.version += 1
 
   _PACKED_KEYS = {'labels': 'labels', 'raw': 'raw_block', 'int_ids': 'int_ids', 'hash_ids': 'hash_ids',
@@ -336,6 +351,10 @@ class DeviceFeatures(object):
       a = a.astype({torch.float32: np.float32, torch.int64: np.int64, torch.uint8: np.uint8}[dt], copy=False).reshape(-1)
       assert a.nbytes <= nbytes, '%s: %d bytes exceed the capacity %d' % (key, a.nbytes, nbytes)
       img[o:o + a.nbytes] = a.view(np.uint8)
+    for name in self.schema.seqs:  # the longest sequence of the batch, while the lengths are still on the host (load())
+      lens = batch.get('seq/%s/len' % name)
+      if lens is not None and 'seq/%s/max' % name not in batch:
+        out['seq/%s/max' % name] = int(lens.max()) if len(lens) else 0
     if not has_str and 'hash_ids' not in batch:
       o, nbytes, _, _ = self._layout['hash_ids']
       img[o:o + nbytes] = 0xFF  # -1: missing

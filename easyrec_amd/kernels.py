@@ -1383,6 +1383,16 @@ class HipBackend(object):
                                int(act), _p(y), _p(mean), _p(invstd), _stream()), 'er_bn_act_fwd')
     return y, mean, invstd
 
+  def copy_multi(self, pairs):
+    """[(dst, src)] device tensors (same byte size, contiguous) -> all copies in one launch (er_copy_multi)."""
+    n = len(pairs)
+    if n == 0:
+      return
+    srcs = (ctypes.c_void_p * n)(*[s_.data_ptr() for _, s_ in pairs])
+    dsts = (ctypes.c_void_p * n)(*[d.data_ptr() for d, _ in pairs])
+    nb = (ctypes.c_int64 * n)(*[s_.numel() * s_.element_size() for _, s_ in pairs])
+    self._ck(self.lib.er_copy_multi(srcs, dsts, nb, n, _stream()), 'er_copy_multi')
+
   def concat_cols(self, parts):
     """torch.cat(parts, dim=1) of 2-D fp32 blocks (unit inner stride) as one library launch."""
     n = len(parts)

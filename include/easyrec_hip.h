@@ -282,6 +282,10 @@ int er_adam_decay_sweep(float* var, float* m, float* v, uint32_t* touched_bitmap
  * gives the achievable copy bandwidth quoted next to the 8 TB/s spec peak. */
 int er_stream_copy(const void* src, void* dst, int64_t bytes, er_stream_t stream);
 
+/* n device-to-device copies (src[i] -> dst[i], bytes[i] each; non-overlapping) in one launch: the parts of a
+ * device-resident batch that a step copies into its static input buffers (input/features.py load()). */
+int er_copy_multi(const void* const* src_host, void* const* dst_host, const int64_t* bytes_host, int n, er_stream_t stream);
+
 /* --------------------------------------------------------------------------------------------
  * K5  FM second-order interaction + wide sum.  Replaces Pack/Sum/Square/Sub/Mul of
  *     FM.__call__ easy_rec/python/layers/fm.py:20-26 (keras variant layers/keras/interaction.py:24-44)

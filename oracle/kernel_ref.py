@@ -712,6 +712,10 @@ class RefBackend(object):
   def rowsum_bwd(self, g, n, into=None, accumulate=False):
     return self._into(g.reshape(-1, 1).expand(-1, n).contiguous(), into, accumulate)
 
+  def copy_multi(self, pairs):
+    for dst, src in pairs:
+      dst.copy_(src)
+
   def concat_cols(self, parts):
     return torch.cat([t.detach() for t in parts], dim=1)
 

@@ -1041,6 +1041,27 @@ def test_gemm_grouped_matches_single_launches(hip):
     assert torch.equal(p[2], f)
 
 
+def test_copy_multi(hip):
+  """er_copy_multi: any mix of sizes / alignments / dtypes, more items than one launch holds."""
+  g = torch.Generator().manual_seed(5)
+  pairs, refs = [], []
+  for i in range(37):
+    n = [1, 3, 4, 16, 1000, 4096 * 50, 12345, 7][i % 8]
+    dt = [torch.float32, torch.int64, torch.int32, torch.uint8][i % 4]
+    src = torch.randint(0, 100, (n + 3,), generator=g).to(dt).to(DEV)
+    off = i % 3  # odd element offsets: unaligned byte addresses for the narrow types
+    s_ = src[off:off + n]
+    dst = torch.zeros(n + 5, dtype=dt, device=DEV)
+    d = dst[1:1 + n] if i % 2 else dst[:n]
+    pairs.append((d, s_))
+    refs.append((dst, d, s_.clone()))
+  hip.copy_multi(pairs)
+  torch.cuda.synchronize()
+  for dst, d, want in refs:
+    assert torch.equal(d, want)
+    assert int(dst.sum()) == int(want.sum())  # nothing written outside the destination
+
+
 def test_gemm_grouped_bf16_matches_rounded_operands(hip):
   """er_gemm_grouped_bf16 (the weight gradients of a bf16 step in one launch): every problem = the fp32-accumulated
   product of the operands rounded to bf16 (fp64 reference of the ROUNDED operands within the fp32 summation bound),
