@@ -49,6 +49,35 @@ def pairwise_loss(labels, logits, margin=0.0, temperature=1.0, weights=None):
   return (w * per).sum() / (w != 0).sum().clamp(min=1).to(torch.float32)
 
 
+_SIGMOID_CE = (LossType.CLASSIFICATION, LossType.BINARY_CROSS_ENTROPY_LOSS)
+
+
+def build_many(specs):
+  """[dict(loss_type, label, pred, loss_weight, num_class, loss_scale, loss_param)] -> [(loss, d loss / d pred)], one per
+  entry, in order.  The sigmoid cross-entropy heads among them (the towers of a multi-task model: the reference calls
+  tf.losses once per tower, model/multi_task_model.py:228-275) share ONE launch (er_sigmoid_ce_multi: each head's own
+  workgroup runs the single-head kernel's body - same values); everything else goes through build()."""
+  out = [None] * len(specs)
+  fused = [i for i, sp in enumerate(specs) if sp['loss_type'] in _SIGMOID_CE and sp.get('num_class', 1) == 1]
+  be = kernels.hip()
+  if len(fused) >= 2 and hasattr(be, 'sigmoid_ce_multi'):
+    heads = []
+    for i in fused:
+      sp = specs[i]
+      lw = sp.get('loss_weight', 1.0)
+      label = sp['label']
+      heads.append((sp['pred'].detach().contiguous(), (label if label.dtype == torch.float32 else label.to(torch.float32)).contiguous(),
+                    lw if torch.is_tensor(lw) else None,
+                    sp.get('loss_scale', 1.0) * (1.0 if torch.is_tensor(lw) else float(lw))))
+    for i, res in zip(fused, be.sigmoid_ce_multi(heads)):
+      out[i] = res
+  for i, sp in enumerate(specs):
+    if out[i] is None:
+      out[i] = build(sp['loss_type'], sp['label'], sp['pred'], sp.get('loss_weight', 1.0), sp.get('num_class', 1),
+                     loss_scale=sp.get('loss_scale', 1.0), loss_param=sp.get('loss_param'))
+  return out
+
+
 def build(loss_type, label, pred, loss_weight=1.0, num_class=1, loss_scale=1.0, loss_param=None, **kwargs):
   """Returns (loss [1] tensor, d loss / d pred).  `loss_weight`: scalar or per-example tensor."""
   if loss_type == LossType.PAIR_WISE_LOSS:

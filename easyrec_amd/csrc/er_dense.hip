@@ -748,8 +748,7 @@ __device__ __forceinline__ float block_sum_1024(float v, float* smem16) {
   return r;
 }
 
-__global__ void __launch_bounds__(kCeBlock)
-sigmoid_ce_kernel(const float* __restrict__ z, const float* __restrict__ y, const float* __restrict__ w, int B,
+__device__ __forceinline__ void sigmoid_ce_body(const float* __restrict__ z, const float* __restrict__ y, const float* __restrict__ w, int B,
                   float loss_scale, float* __restrict__ loss_out, float* __restrict__ dz, float* __restrict__ probs) {
   __shared__ float red[kCeBlock / 64];
   __shared__ float s_nz;
@@ -777,6 +776,26 @@ sigmoid_ce_kernel(const float* __restrict__ z, const float* __restrict__ y, cons
   }
   const float s = block_sum_1024(acc, red);
   if (threadIdx.x == 0 && loss_out) loss_out[0] = loss_scale * s / nz;
+}
+
+__global__ void __launch_bounds__(kCeBlock)
+sigmoid_ce_kernel(const float* __restrict__ z, const float* __restrict__ y, const float* __restrict__ w, int B,
+                  float loss_scale, float* __restrict__ loss_out, float* __restrict__ dz, float* __restrict__ probs) {
+  sigmoid_ce_body(z, y, w, B, loss_scale, loss_out, dz, probs);
+}
+
+// the losses of several heads (the towers of a multi-task model) in one launch: workgroup t runs head t's body
+constexpr int kCeMulti = 8;
+struct CeMultiArgs {
+  const float* z[kCeMulti]; const float* y[kCeMulti]; const float* w[kCeMulti];
+  float* loss[kCeMulti]; float* dz[kCeMulti]; float* probs[kCeMulti];
+  int B[kCeMulti];
+  float scale[kCeMulti];
+};
+__global__ void __launch_bounds__(kCeBlock)
+sigmoid_ce_multi_kernel(CeMultiArgs a) {
+  const int t = blockIdx.x;
+  sigmoid_ce_body(a.z[t], a.y[t], a.w[t], a.B[t], a.scale[t], a.loss[t], a.dz[t], a.probs[t]);
 }
 
 // regularization_loss = reg_emb + reg_dense; total_loss = regularization_loss + sum_i losses[i]; copies of the
@@ -1369,6 +1388,24 @@ int er_sigmoid_ce_fwd_bwd(const float* logits, const float* labels, const float*
   hipLaunchKernelGGL(er::sigmoid_ce_kernel, dim3(1), dim3(er::kCeBlock), 0, er::as_stream(stream), logits, labels,
                      weights, B, loss_scale, loss_out, dlogits, probs_out);
   ER_LAUNCH_CHECK();
+  return 0;
+}
+
+int er_sigmoid_ce_multi(const er_ce_head* heads, int n, er_stream_t stream) {
+  ER_REQUIRE(heads && n >= 1, "er_sigmoid_ce_multi: bad arguments");
+  for (int base = 0; base < n; base += er::kCeMulti) {
+    er::CeMultiArgs a;
+    const int m = n - base < er::kCeMulti ? n - base : er::kCeMulti;
+    for (int i = 0; i < m; ++i) {
+      const er_ce_head& h = heads[base + i];
+      ER_REQUIRE(h.logits && h.labels && h.B > 0, "er_sigmoid_ce_multi: head %d: bad arguments", base + i);
+      a.z[i] = h.logits; a.y[i] = h.labels; a.w[i] = h.weights; a.loss[i] = h.loss_out; a.dz[i] = h.dlogits;
+      a.probs[i] = h.probs_out; a.B[i] = h.B; a.scale[i] = h.loss_scale;
+    }
+    hipLaunchKernelGGL(er::sigmoid_ce_multi_kernel, dim3(static_cast<unsigned>(m)), dim3(er::kCeBlock), 0,
+                       er::as_stream(stream), a);
+    ER_LAUNCH_CHECK();
+  }
   return 0;
 }
 

@@ -198,6 +198,12 @@ class BnLayer(ctypes.Structure):  # = er_bn_layer
               ('accumulate', ctypes.c_int32)]
 
 
+class CeHead(ctypes.Structure):  # = er_ce_head
+  _fields_ = [('logits', ctypes.c_void_p), ('labels', ctypes.c_void_p), ('weights', ctypes.c_void_p), ('B', ctypes.c_int32),
+              ('loss_scale', ctypes.c_float), ('loss_out', ctypes.c_void_p), ('dlogits', ctypes.c_void_p),
+              ('probs_out', ctypes.c_void_p)]
+
+
 CROSS_HASH_KEY = 0xDECAFCAFFE  # tf.sparse.cross_hashed's default hash_key (crossed_column(hash_key=None))
 
 
@@ -1500,6 +1506,23 @@ class HipBackend(object):
                                        ctypes.c_float(loss_scale), _p(loss), _p(dlogits), _p(probs), _stream()),
         'er_sigmoid_ce_fwd_bwd')
     return loss, dlogits, probs
+
+  def sigmoid_ce_multi(self, heads):
+    """heads: [(logits, labels, weights or None, loss_scale)] -> [(loss [1], dlogits [B])] in one launch."""
+    arr = (CeHead * len(heads))()
+    outs, keep = [], []
+    for q, (logits, labels, weights, scale) in zip(arr, heads):
+      z, y = _f32c(logits), _f32c(labels)
+      B = z.numel()
+      loss = torch.empty(1, dtype=torch.float32, device=z.device)
+      dz = torch.empty(B, dtype=torch.float32, device=z.device)
+      q.logits, q.labels, q.weights = z.data_ptr(), y.data_ptr(), _ptr(weights)
+      q.B, q.loss_scale = B, float(scale)
+      q.loss_out, q.dlogits, q.probs_out = loss.data_ptr(), dz.data_ptr(), None
+      outs.append((loss, dz))
+      keep.append((z, y))
+    self._ck(self.lib.er_sigmoid_ce_multi(arr, len(heads), _stream()), 'er_sigmoid_ce_multi')
+    return outs
 
   def total_loss(self, reg_emb, reg_dense, losses, reports, reg_out, total_out):
     n = len(losses)

@@ -125,22 +125,23 @@ class MultiTaskModel(RankModel):
 
   def build_loss_graph(self):
     weights = self.build_loss_weight()
+    entries = []  # every tower's losses, then ONE pass over them: the sigmoid cross-entropy heads share a launch
     for tower in self._towers:
       common = dict(label_name=self._label_name_dict[tower.name],
                     loss_weight=self._sample_weight if tower.use_sample_weight else 1.0,
                     num_class=tower.num_class, suffix=tower.suffix)
       # the weight multiplies the loss AND its gradient inside the loss (loss_scale)
       if len(tower.config.losses) == 0:
-        self._loss_dict.update(self._build_loss_impl(tower.loss_type, loss_scale=weights[tower.name][0], **common))
+        entries.append(dict(loss_type=tower.loss_type, loss_scale=weights[tower.name][0], **common))
         continue
       for loss in tower.config.losses:
         which = loss.WhichOneof('loss_param')
         # Every loss of the list is multiplied by the tower's FIRST weight: the reference indexes the weights by the
         # position inside the one-entry dict `_build_loss_impl` returns (multi_task_model.py:263-269:
         # `for i, loss_name in enumerate(loss_ops): ... task_loss_weight[i]`), which is always 0.  Kept.
-        self._loss_dict.update(
-            self._build_loss_impl(loss.loss_type, loss_name=loss.loss_name, loss_scale=weights[tower.name][0],
-                                  loss_param=getattr(loss, which) if which else None, **common))
+        entries.append(dict(loss_type=loss.loss_type, loss_name=loss.loss_name, loss_scale=weights[tower.name][0],
+                            loss_param=getattr(loss, which) if which else None, **common))
+    self._loss_dict.update(self._build_losses_impl(entries))
     return self._loss_dict
 
   def get_outputs(self):

@@ -112,6 +112,26 @@ class RankModel(EasyRecModel):
       loss_name = loss_name + suffix
     return {loss_name or (head.loss_key + suffix): value}
 
+  def _build_losses_impl(self, entries):
+    """Several _build_loss_impl calls ([kwargs]) whose sigmoid cross-entropy heads share one launch
+    (loss_builder.build_many); loss dict entries and backward seeds in the entries' order."""
+    specs, metas = [], []
+    for kw in entries:
+      head = _head_of(kw['loss_type'])
+      suffix = kw.get('suffix', '')
+      pred = self._prediction_dict[head.loss_input + suffix]
+      specs.append(dict(loss_type=kw['loss_type'], label=self._labels[kw['label_name']], pred=pred,
+                        loss_weight=kw.get('loss_weight', 1.0), num_class=kw.get('num_class', 1),
+                        loss_scale=kw.get('loss_scale', 1.0), loss_param=kw.get('loss_param')))
+      metas.append((head, suffix, kw.get('loss_name', ''), pred))
+    out = {}
+    for (head, suffix, loss_name, pred), (value, dpred) in zip(metas, loss_builder.build_many(specs)):
+      self._backward_seeds.append((pred, dpred))
+      if loss_name and head not in (_BINARY, _REGRESSION, _SIGMOID_REGRESSION):
+        loss_name = loss_name + suffix
+      out[loss_name or (head.loss_key + suffix)] = value
+    return out
+
   def build_loss_graph(self):
     common = dict(label_name=self._label_name, loss_weight=self._sample_weight, num_class=self._num_class)
     if len(self._losses) == 0:

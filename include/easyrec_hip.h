@@ -516,6 +516,13 @@ int er_dice_bwd(const float* x, const float* alpha, const float* save_mean,
 int er_sigmoid_ce_fwd_bwd(const float* logits, const float* labels, const float* weights,
                           int32_t B, float loss_scale, float* loss_out, float* dlogits,
                           float* probs_out, er_stream_t stream);
+/* ... of several heads (the towers of model/multi_task_model.py:228-275, one tf.losses call each) in one launch. */
+typedef struct er_ce_head {
+  const float* logits; const float* labels; const float* weights; /* weights may be NULL */
+  int32_t B; float loss_scale;
+  float* loss_out; float* dlogits; float* probs_out;              /* any of them may be NULL */
+} er_ce_head;
+int er_sigmoid_ce_multi(const er_ce_head* heads_host, int n, er_stream_t stream);
 /* reg_out[0] = reg_emb[0] + reg_dense[0]; total_out[0] = reg_out[0] + sum_i losses[i][0]; report[i][0] = losses[i][0]
  * (report may be NULL).  losses_host / report_host: HOST arrays of n <= 8 DEVICE pointers.  The add_n over the
  * loss dict and REGULARIZATION_LOSSES of model/easy_rec_estimator.py:166-184 in one launch. */

@@ -1003,6 +1003,9 @@ class RefBackend(object):
     p = torch.sigmoid(z)
     return loss, loss_scale * w * (p - y) / nz, p
 
+  def sigmoid_ce_multi(self, heads):
+    return [self.sigmoid_ce(z.reshape(-1), y.reshape(-1), w, s)[:2] for z, y, w, s in heads]
+
   def total_loss(self, reg_emb, reg_dense, losses, reports, reg_out, total_out):
     reg_out.copy_(reg_emb + reg_dense)
     total = reg_out.clone()

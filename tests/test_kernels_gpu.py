@@ -1041,6 +1041,24 @@ def test_gemm_grouped_matches_single_launches(hip):
     assert torch.equal(p[2], f)
 
 
+def test_sigmoid_ce_multi_matches_single_launches(hip):
+  """er_sigmoid_ce_multi (the towers' losses of a multi-task model in one launch): head by head the bits of
+  er_sigmoid_ce_fwd_bwd - with and without example weights, different batch sizes and scales, more heads than a launch."""
+  g = torch.Generator().manual_seed(31)
+  heads = []
+  for i in range(11):
+    B = [8192, 4096, 1, 777][i % 4]
+    z = (torch.randn(B, generator=g) * 3).to(DEV)
+    y = (torch.rand(B, generator=g) > 0.7).float().to(DEV)
+    w = None if i % 3 == 0 else (torch.rand(B, generator=g) * (torch.rand(B, generator=g) > 0.2).float()).to(DEV)
+    heads.append((z, y, w, 0.5 + 0.25 * i))
+  single = [hip.sigmoid_ce(z, y, w, s)[:2] for z, y, w, s in heads]
+  multi = hip.sigmoid_ce_multi(heads)
+  torch.cuda.synchronize()
+  for i, ((l1, d1), (l2, d2)) in enumerate(zip(single, multi)):
+    assert torch.equal(l1, l2) and torch.equal(d1, d2), i
+
+
 def test_copy_multi(hip):
   """er_copy_multi: any mix of sizes / alignments / dtypes, more items than one launch holds."""
   g = torch.Generator().manual_seed(5)
