@@ -2378,6 +2378,39 @@ class DINPoolFn(torch.autograd.Function):
     return dscores, dhist, None, None
 
 
+class MMoEMixManyFn(torch.autograd.Function):
+  """MMoEMixFn over E + T separate tensors: apply(E, T, expert_0 .. expert_{E-1} [B, H], gate_logits_0 .. [B, E]) -> T
+  mixtures [B, H].  The inputs are gathered into the kernels' [E, B, H] / [T, B, E] operands by ONE copy launch
+  (er_copy_multi) and so are the T output gradients on the way back; the input gradients are views of the backward
+  kernels' outputs (torch.stack / select through autograd was ~9 launches of zero-fill and slice copies per step)."""
+
+  @staticmethod
+  def forward(ctx, E, T, *args):
+    be = hip()
+    outs, gate_logits = args[:E], args[E:E + T]
+    B, H = outs[0].shape
+    dev = outs[0].device
+    experts = torch.empty(E, B, H, dtype=torch.float32, device=dev)
+    logits = torch.empty(T, B, E, dtype=torch.float32, device=dev)
+    be.copy_multi([(experts[e], outs[e] if outs[e].is_contiguous() else outs[e].contiguous()) for e in range(E)] +
+                  [(logits[t], gate_logits[t] if gate_logits[t].is_contiguous() else gate_logits[t].contiguous())
+                   for t in range(T)])
+    out, gates = be.mmoe_mix_fwd(experts, logits)
+    ctx.save_for_backward(experts, gates)
+    ctx.E, ctx.T = E, T
+    return tuple(out[t] for t in range(T))
+
+  @staticmethod
+  def backward(ctx, *douts):
+    be = hip()
+    experts, gates = ctx.saved_tensors
+    E, T = ctx.E, ctx.T
+    dout = torch.empty(T, experts.shape[1], experts.shape[2], dtype=torch.float32, device=experts.device)
+    be.copy_multi([(dout[t], douts[t] if douts[t].is_contiguous() else douts[t].contiguous()) for t in range(T)])
+    dexperts, dlogits = be.mmoe_mix_bwd(experts, gates, dout)
+    return (None, None) + tuple(dexperts[e] for e in range(E)) + tuple(dlogits[t] for t in range(T))
+
+
 class MMoEMixFn(torch.autograd.Function):
   """reference layers/mmoe.py:73-82: softmax gates, weighted sum of experts, all tasks at once."""
 

@@ -36,6 +36,8 @@ class MMOE(object):
     outs, gate_logits = dnn.run_parallel(
         stacks, [deep_fea] * n,
         extra_dense=[(deep_fea, n, '%s/gate_%d/dnn' % (scope, t), self._l2_reg) for t in range(self._num_task)])
+    if torch.is_grad_enabled() and hasattr(kernels.hip(), 'copy_multi'):
+      return list(kernels.MMoEMixManyFn.apply(n, self._num_task, *outs, *gate_logits))  # T mixtures [B, H]
     experts = torch.stack(outs, dim=0)  # [E, B, H]
     gates = torch.stack(gate_logits, dim=0)  # [T, B, E] logits
     mixed = kernels.MMoEMixFn.apply(experts, gates)  # [T, B, H]
