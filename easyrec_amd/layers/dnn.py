@@ -112,6 +112,25 @@ def batch_norm(x, name, training):
   return y.reshape(shape)
 
 
+def dense_parallel(items):
+  """[(x, units, name, l2_reg)] plain dense layers (bias, no activation) over 2-D inputs - the towers' output projections
+  of a multi-task model (reference model/mmoe.py:56-68: one tf.layers.dense per tower) - as ONE grouped launch forward and
+  ONE for the input gradients (kernels.GroupedLinearFn); anything the grouped form does not cover: dense() one by one."""
+  ctx = context.current()
+  ok = torch.is_grad_enabled() and ctx.is_training and getattr(ctx, 'dense_dtype', 'f32') == 'f32' and \
+      getattr(kernels.hip(), 'grouped_stacks', False) and len(items) > 1 and all(x.dim() == 2 for x, _, _, _ in items)
+  if not ok:
+    return [dense(x, units, name, l2_reg=l2) for x, units, name, l2 in items]
+  vs = ctx.varstore
+  xs = [x for x, _, _, _ in items]
+  ws = [vs.get_variable(name + '/kernel', (x.shape[-1], units), 'glorot_uniform', l2=l2 or 0.0) for x, units, name, l2 in items]
+  bs = [vs.get_variable(name + '/bias', (units,), 'zeros') for _, units, name, _ in items]
+  E = len(items)
+  out = kernels.GroupedLinearFn.apply(E, (False,) * E, tuple(kernels.grad_sink_of(x) for x in xs),
+                                      tuple(kernels.bn_source_of(x) for x in xs), *xs, *ws, *bs)
+  return list(out[:E])
+
+
 def run_parallel(stacks, inputs, extra_dense=()):
   """E DNN stacks over (possibly the same) 2-D inputs, LAYER BY LAYER: the same-depth dense layers of all stacks run as
   one grouped launch (kernels.GroupedLinearFn), each followed by its own bias / BatchNorm / activation kernel - the

@@ -100,8 +100,10 @@ class MultiTaskModel(RankModel):
                                           is_training=self._is_training) for t in with_dnn], [hs[t] for t in with_dnn])
       for t, o in zip(with_dnn, outs):
         hs[t] = o
-    for t, tower in enumerate(self._towers):
-      heads[tower.name] = dnn.dense(hs[t], tower.num_class, 'dnn_output_%d' % t, l2_reg=self._l2_reg)
+    outs = dnn.dense_parallel([(hs[t], tower.num_class, 'dnn_output_%d' % t, self._l2_reg)
+                               for t, tower in enumerate(self._towers)])  # (one grouped launch for the T projections)
+    for tower, o in zip(self._towers, outs):
+      heads[tower.name] = o
     self._add_to_prediction_dict(heads)
     return self._prediction_dict
 
