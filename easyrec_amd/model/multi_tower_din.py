@@ -52,12 +52,14 @@ class MultiTowerDIN(RankModel):
     for tower in self._model_config.din_towers:
       din_features.append(self._seq_input_layer(self._feature_dict, tower.input, requires_grad=self._is_training))
 
-    tower_fea_arr = []
+    # the plain towers are independent stacks: layer by layer in grouped launches when their depths agree
+    # (dnn.run_parallel; the reference's order - one tower after the other - otherwise)
+    stacks, inputs = [], []
     for tower, tower_fea in zip(self._model_config.towers, tower_features):
       tower_name = tower.input
-      tower_fea = dnn.batch_norm(tower_fea, '%s_fea_bn' % tower_name, self._is_training)
-      dnn_layer = dnn.DNN(tower.dnn, self._l2_reg, '%s_dnn' % tower_name, self._is_training)
-      tower_fea_arr.append(dnn_layer(tower_fea))
+      inputs.append(dnn.batch_norm(tower_fea, '%s_fea_bn' % tower_name, self._is_training))
+      stacks.append(dnn.DNN(tower.dnn, self._l2_reg, '%s_dnn' % tower_name, self._is_training))
+    tower_fea_arr, _ = dnn.run_parallel(stacks, inputs) if stacks else ([], [])
     for tower, tower_fea in zip(self._model_config.din_towers, din_features):
       tower_fea_arr.append(self.din(tower.dnn, tower_fea, name='%s_dnn' % tower.input))
 
