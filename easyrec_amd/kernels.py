@@ -2276,10 +2276,12 @@ class CrossV2EpilogueFn(torch.autograd.Function):
     x0, x, u, bias = ctx.saved_tensors
     dx0, dx, du = hip().cross_v2_bwd(x0.contiguous(), x.contiguous(), u.contiguous(), bias, ctx.diag,
                                      dout.contiguous())
-    dbias = hip().colsum(du) if bias is not None else None
-    if dbias is not None and ctx.bias_grad is not None:
-      ctx.bias_grad.add_(dbias)
-      dbias = None
+    dbias = None
+    if bias is not None:
+      if ctx.bias_grad is not None:  # the column sums straight into the bias' slice of the flat gradient buffer
+        hip().colsum(du, out=ctx.bias_grad, accumulate=True)
+      else:
+        dbias = hip().colsum(du)
     return dx0, dx, du, dbias, None, None
 
 
