@@ -1,4 +1,5 @@
 #!/bin/bash
+# round 3: dense tail on a second stream (EASYREC_AMD_OVERLAP_DENSE) re-measured against the default, same box
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 O=gpurun_out/r03h; mkdir -p $O
 line() { python -c "
