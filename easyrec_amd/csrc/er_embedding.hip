@@ -737,7 +737,8 @@ decay_tables_kernel(DecayTabDev t, const float* __restrict__ hist, const int64_t
   const int64_t s_end = *counter - lag;
   const float mine = decay_sum_wave(t, hist, s_end - 1 - k, k);
   const int lane = threadIdx.x & 63;
-  if (lane < kDecayLd) t.A[static_cast<int64_t>(k - 1) * kDecayLd + lane] = mine;  // (lanes >= kDecayN hold 0)
+  float* A = t.A + static_cast<int64_t>(lag) * kDecayKMax * kDecayLd;  // (one table per lag: see decay_aux_for)
+  if (lane < kDecayLd) A[static_cast<int64_t>(k - 1) * kDecayLd + lane] = mine;  // (lanes >= kDecayN hold 0)
 }
 
 // every row: replay the pending decay steps up to and including step (*step_counter - 1); last_step = that
@@ -2537,6 +2538,16 @@ int er_emb_group_enable_lazy_decay(er_emb_group* g, int32_t* last_step, const fl
   return 0;
 }
 
+// The closed form's per-launch table A depends on the step the launch brings its rows to (*counter - lag).  Consumers with
+// DIFFERENT lags may run on different streams (er_emb_flush_decay: lag 0; catch-up, owner serve: lag 1; the rolling window:
+// either), so each lag owns a table; concurrent consumers of ONE lag rebuild identical contents (same counter, same
+// history), which is benign.  lag is 0 or 1 everywhere (checked by the callers).
+static er::DecayAux decay_aux_for(const er_emb_group* g, int lag) {
+  er::DecayAux a = g->aux;
+  if (a.A != nullptr) a.A += static_cast<int64_t>(lag) * er::kDecayKMax * er::kDecayLd;
+  return a;
+}
+
 // A[k] for the consumer launch that follows on `s` (rows brought to step *counter - lag); one launch per distinct table set
 static int launch_decay_tables(er_emb_group* const* groups, int n, int lag, hipStream_t s) {
   const er_decay_tables* done[er::kMaxMulti];
@@ -2565,10 +2576,10 @@ int er_emb_catch_up(er_emb_group* g, const uint32_t* unique_keys, const int32_t*
   const int blocks = static_cast<int>(er::ceil_div(cap * g->G, er::kBlock));
   if (g->V == 4) {
     hipLaunchKernelGGL(er::emb_catch_up_kernel<4>, dim3(blocks), dim3(er::kBlock), 0, er::as_stream(stream), unique_keys,
-                       n_unique, cap, tab, g->lr_hist, hyper, g->dim, g->G, g->aux);
+                       n_unique, cap, tab, g->lr_hist, hyper, g->dim, g->G, decay_aux_for(g, 1));
   } else {
     hipLaunchKernelGGL(er::emb_catch_up_kernel<1>, dim3(blocks), dim3(er::kBlock), 0, er::as_stream(stream), unique_keys,
-                       n_unique, cap, tab, g->lr_hist, hyper, g->dim, g->G, g->aux);
+                       n_unique, cap, tab, g->lr_hist, hyper, g->dim, g->G, decay_aux_for(g, 1));
   }
   ER_LAUNCH_CHECK();
   return 0;
@@ -2594,7 +2605,7 @@ int er_emb_catch_up_multi(er_emb_group* const* groups, const uint32_t* const* un
     er::CatchUpArgs& a = ma.a[ma.n];
     a.ukeys = unique_keys[i]; a.n_unique = n_unique[i]; a.capacity = cap;
     a.tab = er::RowUpdate{g->var, g->m, g->v, g->bitmap, g->last_step, g->step_counter};
-    a.lr_hist = g->lr_hist; a.aux = g->aux; a.dim = g->dim; a.G = g->G; a.V = g->V;
+    a.lr_hist = g->lr_hist; a.aux = decay_aux_for(g, 1); a.dim = g->dim; a.G = g->G; a.V = g->V;
     ma.start[ma.n + 1] = ma.start[ma.n] + static_cast<int>(er::ceil_div(cap * g->G, er::kBlock));
     ++ma.n;
   }
@@ -2658,7 +2669,7 @@ int er_decay_tables_supported(float beta1, float beta2) {
 
 int64_t er_decay_tables_bytes(int64_t history_capacity) {
   if (history_capacity <= 0) return -1;
-  return static_cast<int64_t>(er::kDecayKMax) * er::kDecayLd * (sizeof(double) + sizeof(float)) +
+  return static_cast<int64_t>(er::kDecayKMax) * er::kDecayLd * (sizeof(double) + 2 * sizeof(float)) +  // coef, A[lag 0 | 1]
          (history_capacity + 1) * er::kDecayLd * static_cast<int64_t>(sizeof(float));
 }
 
@@ -2680,8 +2691,8 @@ int er_decay_tables_create(void* buffer, int64_t history_capacity, const float* 
   char* base = static_cast<char*>(buffer);
   t->dev.coef = reinterpret_cast<const double*>(base);
   base += static_cast<size_t>(er::kDecayKMax) * er::kDecayLd * sizeof(double);
-  t->dev.A = reinterpret_cast<float*>(base);
-  base += static_cast<size_t>(er::kDecayKMax) * er::kDecayLd * sizeof(float);
+  t->dev.A = reinterpret_cast<float*>(base);  // two tables back to back: lag 0, lag 1 (er::decay_aux_for)
+  base += 2 * static_cast<size_t>(er::kDecayKMax) * er::kDecayLd * sizeof(float);
   t->dev.C = reinterpret_cast<float*>(base);
   t->dev.K = K;
   t->dev.capacity = history_capacity;
@@ -2693,7 +2704,7 @@ int er_decay_tables_create(void* buffer, int64_t history_capacity, const float* 
   t->ln_b2 = std::log(static_cast<double>(beta2));
   hipError_t e = hipMemcpy(buffer, coef.data(), coef.size() * sizeof(double), hipMemcpyHostToDevice);
   if (e == hipSuccess)
-    e = hipMemset(t->dev.A, 0, (static_cast<size_t>(er::kDecayKMax) + static_cast<size_t>(history_capacity) + 1) * er::kDecayLd * sizeof(float));
+    e = hipMemset(t->dev.A, 0, (2 * static_cast<size_t>(er::kDecayKMax) + static_cast<size_t>(history_capacity) + 1) * er::kDecayLd * sizeof(float));
   if (e != hipSuccess) {
     delete t;
     er::set_error("er_decay_tables_create: %s", hipGetErrorString(e));
@@ -2739,7 +2750,7 @@ int er_emb_flush_window(er_emb_group* const* groups, int n, int32_t n_windows, i
     a.tab = er::RowUpdate{g->var, g->m, g->v, g->bitmap, g->last_step, g->step_counter};
     a.total_rows = g->total_rows;
     a.chunk = er::ceil_div(g->total_rows, n_windows);
-    a.lr_hist = g->lr_hist; a.aux = g->aux; a.dim = g->dim; a.G = g->G; a.V = g->V;
+    a.lr_hist = g->lr_hist; a.aux = decay_aux_for(g, lag); a.dim = g->dim; a.G = g->G; a.V = g->V;
     ma.start[ma.n + 1] = ma.start[ma.n] + static_cast<int>(er::ceil_div(a.chunk * g->G, er::kBlock));
     ++ma.n;
   }
@@ -3107,7 +3118,7 @@ int er_emb_owner_serve(er_emb_group* const* groups, float* const* rows_out, cons
     // may be replayed, because no row update follows that would advance last_step)
     a.tab = er::RowUpdate{g->var, g->m, g->v, g->bitmap, hyper ? g->last_step : nullptr, g->step_counter};
     ER_REQUIRE(a.tab.last_step == nullptr || g->G <= er::kWave, "er_emb_owner_serve: a lazily decayed row must fit one wavefront");
-    a.lr_hist = g->lr_hist; a.aux = g->aux; a.out = rows_out[i]; a.dim = g->dim; a.G = g->G; a.V = g->V;
+    a.lr_hist = g->lr_hist; a.aux = decay_aux_for(g, 1); a.out = rows_out[i]; a.dim = g->dim; a.G = g->G; a.V = g->V;
     a.ld = ld && ld[i] ? ld[i] : g->dim;
     ER_REQUIRE(a.ld >= g->dim && (g->V == 1 || (a.ld % 4 == 0 && (reinterpret_cast<uintptr_t>(rows_out[i]) & 15) == 0)),
                "er_emb_owner_serve: group %d: ld %d < dim, or 16-byte lanes on rows that are not 16-byte aligned", i, a.ld);

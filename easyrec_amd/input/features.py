@@ -269,9 +269,13 @@ class DeviceFeatures(object):
         return
       if isinstance(src, np.ndarray):
         src = torch.from_numpy(src)
+      # every path below copies src.numel() elements into the FRONT of dst: a source larger than the buffer must fail
+      # here (the one-launch device copy moves bytes and would overrun the buffer silently)
+      if src.numel() > dst.numel():
+        raise ValueError('batch array of %d elements exceeds the device buffer of %d' % (src.numel(), dst.numel()))
       if multi and src.device == dst.device and src.dtype == dst.dtype and src.is_contiguous() and dst.is_contiguous():
         if src.numel():
-          dev_pairs.append((dst.view(-1)[:src.numel()], src))
+          dev_pairs.append((dst.view(-1)[:src.numel()], src.reshape(-1)))
         return
       if src.device != dst.device and src.device.type == 'cpu' and non_blocking:
         src = src.pin_memory() if torch.cuda.is_available() else src

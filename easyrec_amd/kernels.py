@@ -1943,12 +1943,15 @@ class GroupedLinearFn(torch.autograd.Function):
     saved = ctx.saved_tensors
     xs, ws = saved[:E], saved[E:2 * E]
     dzs = [None if g is None else (g if (g.dim() == 2 and g.stride(1) == 1) else g.contiguous()) for g in grads[:E]]
-    assert all(g is not None for g in dzs), 'an output of GroupedLinearFn was left out of the loss'  
+    # a stack output left out of the loss (a tower no loss reads) arrives as None (set_materialize_grads(False)): that
+    # layer contributes nothing - no input gradient, no weight gradient, no bias gradient - as in the one-by-one form
     dxs = [None] * E
-    need = [e for e in range(E) if ctx.needs_input_grad[4 + e]]
+    need = [e for e in range(E) if ctx.needs_input_grad[4 + e] and dzs[e] is not None]
     by_input = {}
     for e in need:
-      by_input.setdefault(xs[e].data_ptr(), []).append(e)
+      # readers of ONE input share an accumulation buffer: same storage start AND same shape / strides (a row prefix
+      # x[:k] of x shares its base pointer and is a different input)
+      by_input.setdefault((xs[e].data_ptr(), tuple(xs[e].shape), tuple(xs[e].stride())), []).append(e)
     solo = [es[0] for es in by_input.values() if len(es) == 1 and ctx.gsinks[es[0]] is None]
     if solo:
       problems = []
@@ -1977,6 +1980,8 @@ class GroupedLinearFn(torch.autograd.Function):
       dxs[es[0]] = acc
     dws, dbs = [None] * E, [None] * E
     for e in range(E):
+      if dzs[e] is None:
+        continue
       if ctx.needs_input_grad[4 + E + e]:
         dws[e] = _wgrad(be, xs[e], dzs[e], ctx.wgrads[e], False, None, ctx.sink)
       b = ctx.bs[e]

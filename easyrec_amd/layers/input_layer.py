@@ -265,6 +265,7 @@ class EmbeddingEngine(object):
     """Tables were loaded as of `step` finished steps: no decay is pending on any row."""
     for lz in self._lazy_states():
       lz['last_step'].fill_(int(step) - 1)
+    self._decay_pending = False
 
   def _lazy_states(self):
     return list(self._lazy.values())

@@ -198,10 +198,12 @@ class EasyRecEstimator(object):
     self.hyper_table[torch.from_numpy(slots).to(self.device)] = torch.from_numpy(rows).to(self.device)
     self._planned_until += count
 
-  def _grow_lr_history(self, need):
+  def _grow_lr_history(self, need, flush=True):
     """Make room for step indices < need in the lr_t history (lazy dense decay).  Outside a captured graph the buffer
     is re-allocated (doubling) and re-registered with the table groups; inside one its address is baked in, so every
-    row is brought current first (nothing older than the flush is ever replayed) - then the run must stop."""
+    row is brought current first (nothing older than the flush is ever replayed) - then the run must stop.
+    flush=False (checkpoint restore): the tables were just loaded and are current by definition - replaying whatever
+    decay the PREVIOUS run of this estimator left pending would corrupt the restored rows."""
     cap = self.lr_hist.numel() // 2
     if need <= cap:
       return
@@ -217,7 +219,8 @@ class EasyRecEstimator(object):
     if self.decay_tables is not None:
       # the per-step table is indexed like the history: every row is brought current first (entries older than a row's
       # last update are never read), then the tables restart on the grown history
-      self.engine.flush_decay()
+      if flush:
+        self.engine.flush_decay()
       torch.cuda.synchronize() if self.device.type == 'cuda' else None
       kernels.hip().decay_tables_destroy(self.decay_tables)
       self.decay_tables = kernels.hip().decay_tables_create(grown, self.step_counter, self.opt_emb.beta1,
@@ -464,14 +467,15 @@ class EasyRecEstimator(object):
     assert self.graph is None or step == self.global_step, 'restore before capture()'
     if self.device.type == 'cuda':
       torch.cuda.synchronize()
-    self._grow_lr_history(int(step) + 1)
+    # counters and "nothing pending" first: growing the history must not replay stale decay onto restored rows
     self.global_step = int(step)
     self.step_counter.fill_(int(step))
+    self.engine.mark_restored(int(step))
+    self._grow_lr_history(int(step) + 1, flush=False)
     for opt in {id(o): o for o in (self.opt_emb, self.opt_dense)}.values():
       opt.reset_to_step(step)
     self._planned_until = int(step)
     self._plan_hyper(self.HYPER_SLOTS)
-    self.engine.mark_restored(int(step))
 
   def load_state_dict(self, state):
     self.varstore.load_state_dict(state, strict=False)

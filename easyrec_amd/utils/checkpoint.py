@@ -54,7 +54,20 @@ def _kv_file(ckpt_path, var_name, rank, ext):
   return '%s-embedding/%s-part-%d.%s' % (ckpt_path, var_name, rank, ext)
 
 
-def _save_kv_table(engine, ckpt_path, name, slots, rank):
+def _remove_stale_kv_parts(ckpt_path, var_name, world):
+  """embedding_parallel_saver.py:207-216: worker 0 deletes `part-<id>.key/.val` of workers that no longer exist (id >=
+  world) - a loader reads EVERY part it finds, so parts left by a larger previous world would come back as stale or
+  duplicate keys."""
+  import glob
+  import re
+  for ext in ('key', 'val'):
+    for path in glob.glob(glob.escape('%s-embedding/%s-part-' % (ckpt_path, var_name)) + '*.' + ext):
+      m = re.search(r'-part-(\d+)\.%s$' % ext, path)
+      if m and int(m.group(1)) >= world:
+        os.remove(path)
+
+
+def _save_kv_table(engine, ckpt_path, name, slots, rank, world=1):
   """keys / rows of the ids that have a row, and the same rows of every slot (the slots share the table's keys)"""
   kv = engine.kv_tables[name]
   keys, rows = kernels.hip().kv_export(kv)
@@ -67,6 +80,8 @@ def _save_kv_table(engine, ckpt_path, name, slots, rank):
     fv = embed_file_var_name(var)
     keys_np.tofile(_kv_file(ckpt_path, fv, rank, 'key'))
     view[rows.to(view.device)].detach().cpu().numpy().astype(np.float32).tofile(_kv_file(ckpt_path, fv, rank, 'val'))
+    if rank == 0:
+      _remove_stale_kv_parts(ckpt_path, fv, world)
 
 
 def _restore_kv_table(be, engine, ckpt_path, name, slots, rank, world):
@@ -108,7 +123,7 @@ def save(est, ckpt_path):
       continue
     t_idx, t_num = (rank, world) if is_shard else (0, 1)
     if engine.tables[name].get('kv'):
-      _save_kv_table(engine, ckpt_path, name, slots, t_idx)
+      _save_kv_table(engine, ckpt_path, name, slots, t_idx, t_num)
       continue
     be.save_dense_embed(ckpt_path, embed_file_var_name(name), t_idx, t_num, engine.table_view(name).cpu().numpy())
     for s, suffix in slots.items():
@@ -130,6 +145,7 @@ def save(est, ckpt_path):
     # the rows an uninterrupted one would
     for name, kv in getattr(engine, 'kv_tables', {}).items():
       dense[name + '/kv_meta'] = np.array([kv['seed'], kv['mean'], kv['stddev'], kv['capacity']], dtype=np.float64)
+      dense[name + '/kv_seed'] = np.asarray(int(kv['seed']), dtype=np.uint64)  # (float64 loses seeds >= 2^53)
     dense['global_step'] = np.asarray(int(est.global_step), dtype=np.int64)
     np.savez(ckpt_path + '.dense.npz', **dense)
 
@@ -158,6 +174,8 @@ def restore(est, ckpt_path):
     if name + '/kv_meta' in z.files:
       meta = z[name + '/kv_meta']
       kv['seed'], kv['mean'], kv['stddev'] = int(meta[0]), float(meta[1]), float(meta[2])
+      if name + '/kv_seed' in z.files:
+        kv['seed'] = int(z[name + '/kv_seed'])
       engine._kv_handle = None  # (the device-resident job table carries the generator's parameters: rebuilt on next use)
   vs = est.varstore
   vs.load_state_dict({k: z[k] for k in z.files}, strict=False)

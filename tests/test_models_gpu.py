@@ -252,10 +252,8 @@ def test_din_batch_without_a_max_length_sequence(name):
   gen = SyntheticBatches(cfg.data_config, est.feature_configs, batch_size=B, seed=9)
   full = gen.next_batch()
   est.features.load(full)
-  est.capture(warmup=1)  # captured with full-length sequences
-  for _ in range(2):  # (the capture's warm-up + nothing else ran: bring the oracle to the same step)
-    pass
-  orc.train_step(full)
+  est.capture(warmup=1)  # captured with full-length sequences: the warm-up ran ONE real step on `full` (the capture
+  orc.train_step(full)   # itself executes nothing), so the oracle takes the same one step
   for step in range(2):
     b = gen.next_batch()
     shorten_sequences(b, 7)
