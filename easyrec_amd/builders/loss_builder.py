@@ -78,8 +78,37 @@ def build_many(specs):
   return out
 
 
+def _fused_head(head, label, scale):
+  """The pending logit head of a rank model (layers/dnn.py dense(head=True)) under plain sigmoid cross entropy: ONE launch
+  computes the projection, the loss, d loss / d logits and the projection's backward (kernels.HipBackend.head_sigmoid_ce);
+  the loss value and the head's dW / db are finished by the loss tail's launch (EasyRecEstimator._loss_tail)."""
+  from easyrec_amd.core import context
+  be = kernels.hip()
+  labels = label if label.dtype == torch.float32 else label.to(torch.float32)
+  res = be.head_sigmoid_ce(head.x, head.w, head.b, labels.contiguous(), scale, src=head.src, logits=head.logits)
+  B, K = head.x.shape
+  head.state, head.dx, head.dz = 'fused', res['dx'], res['dlogits']
+  if head.src is not None:  # the producing layer's BatchNorm backward finds its column sums ready (kernels.LinearBNActFn)
+    head.src.partial, head.src.dx_ptr = res['bn_partials'].view(-1), res['dx'].data_ptr()
+  ctx = context.current()
+  wb = res['wb_partials']
+  ctx.tail_jobs.append((wb, head.w_grad.view(-1), K))
+  if head.b is not None:
+    ctx.tail_jobs.append((wb[:, K:], head.b_grad.view(-1), 1))
+  loss = torch.empty(1, dtype=torch.float32, device=head.x.device)
+  loss._er_partials = (res['loss_partials'], float(scale), float(B))  # loss = scale * sum / B (the loss tail's launch)
+  return loss, res['dlogits'], res['probs']
+
+
 def build(loss_type, label, pred, loss_weight=1.0, num_class=1, loss_scale=1.0, loss_param=None, **kwargs):
   """Returns (loss [1] tensor, d loss / d pred).  `loss_weight`: scalar or per-example tensor."""
+  head = kernels.pending_head(pred)
+  if head is not None:
+    if loss_type in _SIGMOID_CE and num_class == 1 and not torch.is_tensor(loss_weight) and head.fusable and \
+        kwargs.get('fuse_head', True):
+      loss, dlogits, _ = _fused_head(head, label, loss_scale * float(loss_weight))
+      return loss, dlogits
+    kernels.materialize_head(head)  # any other loss reads the logits
   if loss_type == LossType.PAIR_WISE_LOSS:
     assert num_class == 1, 'num_class must be 1 when loss type is PAIR_WISE_LOSS'
     assert loss_param is None or not loss_param.session_name, 'session ids in pairwise losses are outside the hot-path scope'

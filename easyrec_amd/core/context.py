@@ -25,6 +25,10 @@ class ModelContext(object):
     self.is_training = is_training
     self.building = True  # build pass: variables are being created, moving statistics frozen
     self.dense_dtype = 'f32'  # 'bf16': MLP / cross GEMMs on bf16 MFMA with fp32 accumulate (er_gemm_bf16)
+    # per step (EasyRecModel.begin_step): logit heads waiting for the loss builder (kernels.HeadState, keyed by the logits'
+    # data pointer) and the column-sum jobs their fused launch leaves to the loss tail [(partial [P, ld], dst, n_cols)]
+    self.heads = {}
+    self.tail_jobs = []
 
 
 @contextlib.contextmanager

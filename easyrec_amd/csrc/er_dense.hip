@@ -848,6 +848,240 @@ reg_total_loss_kernel(const float* __restrict__ emb_partials, int n_partials, fl
   total_out[0] = total;
 }
 
+// ------------------------------------------------------------------------------------------------
+// The binary head of a rank model in ONE launch (er_head_sigmoid_ce): logits = x . w + b (the `output` projection of
+// model/deepfm.py:84-88, dcn.py:66, ...: tf.layers.dense(units = 1)), tf.losses.sigmoid_cross_entropy of them
+// (builders/loss_builder.py:35-39, no sample weights: mean over the batch), AND the head's own backward - d loss / d
+// logits, dx = dz (x) w, per-workgroup partial sums of dW = x^T dz and db = sum dz, and (when x is the output of a dense
+// + BatchNorm + ReLU layer) that layer's BatchNorm-backward column sums in the layout er_gemm_f32_bn_bwd leaves them.
+// What the step issued before: a 64 x 64-tile GEMM for one output column, the loss kernel (one workgroup), a column
+// sum, a K = 1 dgrad GEMM, a BatchNorm-backward partial pass and a share of the grouped weight-gradient launch.
+// A workgroup owns 64 rows (= one row tile of the GEMMs: the BatchNorm partials line up); a row's K values are spread
+// over G = K / 4 lanes (16-byte loads), dot products finish with a fixed xor-shuffle tree: deterministic.
+// ------------------------------------------------------------------------------------------------
+constexpr int kHeadRows = 64;
+struct HeadArgs {
+  const float* x; int ldx;
+  const float* w; const float* b; const float* y;
+  int B, K, G;
+  float scale, nz;  // loss_scale, B as a float: dz = scale * (p - y) / nz, the loss kernel's own expression
+  float* logits; float* probs; float* dz; float* dx;
+  float* loss_part;   // [tiles]
+  float* wb_part;     // [tiles][K + 1]: sum_rows x[r][c] * dz[r] | sum_rows dz[r]
+  const float* src_z; const float* src_mean; const float* src_invstd; int src_ld, src_act, src_bn;
+  float* bn_part;     // [tiles][K][2] or nullptr
+};
+
+template <int PASSES>
+__device__ __forceinline__ void head_body(const HeadArgs& a, float* smem) {
+  const int G = a.G, K = a.K;
+  const int rpp = kBlock / G;                 // rows per pass (PASSES * rpp == kHeadRows unless G < 4)
+  const int sub = threadIdx.x % G, rl = threadIdx.x / G;
+  const int c = sub * 4;
+  const bool col_ok = c < K;
+  const int r0 = blockIdx.x * kHeadRows;
+  const bool bn = a.bn_part != nullptr;
+  __shared__ float s_z[kHeadRows], s_dzr[kHeadRows];
+  // every load of the workgroup is issued before the first use: one round trip to memory, not one per pass
+  float4 xv[PASSES], zv[PASSES];
+#pragma unroll
+  for (int ps = 0; ps < PASSES; ++ps) {
+    const int r = r0 + ps * rpp + rl;
+    const bool ok = r < a.B && col_ok && ps * rpp + rl < kHeadRows;  // (G < 4: more row lanes than the tile has rows)
+    xv[ps] = ok ? *reinterpret_cast<const float4*>(a.x + static_cast<int64_t>(r) * a.ldx + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    zv[ps] = (ok && bn) ? *reinterpret_cast<const float4*>(a.src_z + static_cast<int64_t>(r) * a.src_ld + c)
+                        : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const int myrow = r0 + static_cast<int>(threadIdx.x);  // phase 2: thread t < 64 owns row t of the tile
+  const float yrow = (threadIdx.x < kHeadRows && myrow < a.B) ? a.y[myrow] : 0.f;
+  float4 wv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (col_ok) wv = *reinterpret_cast<const float4*>(a.w + c);
+  const float bias = a.b ? a.b[0] : 0.f;
+  float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), is = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (bn && a.src_bn && col_ok) {
+    mu = *reinterpret_cast<const float4*>(a.src_mean + c);
+    is = *reinterpret_cast<const float4*>(a.src_invstd + c);
+  }
+  const float mus[4] = {mu.x, mu.y, mu.z, mu.w}, iss[4] = {is.x, is.y, is.z, is.w};
+  // phase 1: the rows' dot products (G lanes per row, fixed xor-shuffle tree) -> LDS
+#pragma unroll
+  for (int ps = 0; ps < PASSES; ++ps) {
+    float dot = (xv[ps].x * wv.x + xv[ps].y * wv.y) + (xv[ps].z * wv.z + xv[ps].w * wv.w);
+    // G = 4 * PASSES lanes per row (one pass: G = 1, 2 or 4)
+    dot = PASSES > 1 ? group_sum<(kBlock / kHeadRows) * PASSES>(dot) : group_sum_rt(dot, G);
+    if (sub == 0 && ps * rpp + rl < kHeadRows) s_z[ps * rpp + rl] = dot + bias;
+  }
+  __syncthreads();
+  // phase 2: ONE wavefront evaluates the loss of the tile's 64 rows (exp / log1p / two divisions per row are ~350 wave
+  // instructions: every lane group repeating them for its own row was 2 us per workgroup)
+  if (threadIdx.x < kHeadRows) {
+    const bool ok = myrow < a.B;
+    const float z = s_z[threadIdx.x];
+    // tf.nn.sigmoid_cross_entropy_with_logits: max(z,0) - z*y + log1p(exp(-|z|))
+    float ce = fmaxf(z, 0.f) - z * yrow + log1pf(expf(-fabsf(z)));
+    const float p = 1.f / (1.f + expf(-z));
+    float dzr = a.scale * (p - yrow) / a.nz;
+    if (!ok) { ce = 0.f; dzr = 0.f; }
+    s_dzr[threadIdx.x] = dzr;
+    if (ok) {
+      a.logits[myrow] = z;
+      if (a.probs) a.probs[myrow] = p;
+      if (a.dz) a.dz[myrow] = dzr;
+    }
+    const float cs = wave_sum(ce), ds = wave_sum(dzr);
+    if (threadIdx.x == 0) {
+      a.loss_part[blockIdx.x] = cs;
+      a.wb_part[static_cast<int64_t>(blockIdx.x) * (K + 1) + K] = ds;
+    }
+  }
+  __syncthreads();
+  // phase 3: dx = dz (x) w, and the per-column partial sums of dW and of the producing layer's BatchNorm backward
+  float dw[4] = {0.f, 0.f, 0.f, 0.f}, sg[4] = {0.f, 0.f, 0.f, 0.f}, sgx[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ps = 0; ps < PASSES; ++ps) {
+    const int lr = ps * rpp + rl;
+    const int r = r0 + lr;
+    if (!(r < a.B && lr < kHeadRows && col_ok)) continue;
+    const float dzr = s_dzr[lr];
+    const float g[4] = {dzr * wv.x, dzr * wv.y, dzr * wv.z, dzr * wv.w};
+    *reinterpret_cast<float4*>(a.dx + static_cast<int64_t>(r) * K + c) = make_float4(g[0], g[1], g[2], g[3]);
+    const float xs[4] = {xv[ps].x, xv[ps].y, xv[ps].z, xv[ps].w};
+    const float zs[4] = {zv[ps].x, zv[ps].y, zv[ps].z, zv[ps].w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      dw[j] = dw[j] + xs[j] * dzr;
+      if (bn) {
+        float gj = g[j];
+        if (a.src_act == ER_ACT_RELU && !(xs[j] > 0.f)) gj = 0.f;  // (x IS the layer's activation output y)
+        sg[j] = sg[j] + gj;
+        if (a.src_bn) sgx[j] = sgx[j] + gj * ((zs[j] - mus[j]) * iss[j]);
+      }
+    }
+  }
+  // combine the rpp row lanes of every column in a fixed order
+  float* s_dw = smem;                         // [rpp][K]
+  float* s_g = smem + rpp * K;                // [rpp][K]
+  float* s_gx = smem + 2 * rpp * K;           // [rpp][K]
+  if (col_ok) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      s_dw[rl * K + c + j] = dw[j];
+      s_g[rl * K + c + j] = sg[j];
+      s_gx[rl * K + c + j] = sgx[j];
+    }
+  }
+  __syncthreads();
+  const int t = threadIdx.x;
+  if (t < K) {
+    float d = 0.f, g1 = 0.f, g2 = 0.f;
+    for (int q = 0; q < rpp; ++q) {
+      d = d + s_dw[q * K + t];
+      g1 = g1 + s_g[q * K + t];
+      g2 = g2 + s_gx[q * K + t];
+    }
+    a.wb_part[static_cast<int64_t>(blockIdx.x) * (K + 1) + t] = d;
+    if (bn) {
+      float* pp = a.bn_part + (static_cast<int64_t>(blockIdx.x) * K + t) * 2;
+      pp[0] = g1;
+      pp[1] = g2;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+head_sigmoid_ce_kernel(HeadArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [3][rows_per_pass][K] + 2 * [rows_per_pass]
+  switch (a.G) {  // passes = 64 rows / (256 / G) rows per pass
+    case 64: head_body<16>(a, smem); break;
+    case 32: head_body<8>(a, smem); break;
+    case 16: head_body<4>(a, smem); break;
+    case 8: head_body<2>(a, smem); break;
+    default: head_body<1>(a, smem); break;  // G <= 4: one pass covers the 64 rows (the surplus row lanes idle)
+  }
+}
+
+// The scalar tail of the loss (reg_total_loss_kernel) for steps whose head ran as er_head_sigmoid_ce: a task loss may
+// arrive as per-workgroup partial sums (loss = scale * sum of them, fixed order), and small column-sum jobs (the head's
+// dW / db partials: dst[j] += sum_p partial[p][j]) ride along, so that the head costs no launch of its own for them.
+constexpr int kTailJobs = 4;
+struct TailJob { const float* partial; float* dst; int n_parts, n_cols, ld; };
+struct LossTailArgs {
+  const float* emb_partials; int n_partials; float emb_scale;
+  const float* dense_partials; int n_dense;
+  LossPtrs lp; int n_losses;
+  int loss_parts[8];       // > 0: lp.src[i] holds that many partial sums ...
+  float loss_scale[8];     // ... and the loss is loss_scale[i] * their sum / loss_div[i] (sigmoid_ce_kernel's expression),
+  float loss_div[8];       //     also written back to loss_value[i]
+  float* loss_value[8];
+  float* reg_out; float* total_out;
+  int n_jobs; TailJob jobs[kTailJobs];
+};
+
+__global__ void __launch_bounds__(kCeBlock)
+loss_tail_kernel(LossTailArgs a) {
+  __shared__ float red[kCeBlock / 64];
+  __shared__ float s_loss[8];
+  // column-sum jobs: 16 part lanes x 64 columns per round (every partial's load is in flight at once: a thread per column
+  // walking its partials one after the other was a 20 us chain of dependent L2 round trips), lanes combined in a fixed order
+  __shared__ float s_job[16][64];
+  for (int j = 0; j < a.n_jobs; ++j) {
+    const TailJob& jb = a.jobs[j];
+    const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+    for (int c0 = 0; c0 < jb.n_cols; c0 += 64) {
+      const int col = c0 + cl;
+      float s = 0.f;
+      if (col < jb.n_cols) {
+        float v[8];
+        for (int p0 = pl; p0 < jb.n_parts; p0 += 16 * 8) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int p = p0 + u * 16;
+            v[u] = p < jb.n_parts ? jb.partial[static_cast<int64_t>(p) * jb.ld + col] : 0.f;
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) s = s + v[u];
+        }
+      }
+      s_job[pl][cl] = s;
+      __syncthreads();
+      if (pl == 0 && col < jb.n_cols) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t = t + s_job[q][cl];
+        jb.dst[col] = jb.dst[col] + t;
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = 0; i < a.n_losses; ++i) {
+    if (a.loss_parts[i] <= 0) continue;  // (uniform)
+    float v = 0.f;
+    for (int p = threadIdx.x; p < a.loss_parts[i]; p += kCeBlock) v = v + a.lp.src[i][p];
+    const float tot = block_sum_1024(v, red);
+    if (threadIdx.x == 0) {
+      const float l = a.loss_scale[i] * tot / a.loss_div[i];
+      s_loss[i] = l;
+      if (a.loss_value[i]) a.loss_value[i][0] = l;
+    }
+  }
+  float e = 0.f;
+  for (int i = threadIdx.x; i < a.n_partials; i += kCeBlock) e = e + a.emb_partials[i];
+  const float emb = block_sum_1024(e, red);
+  float b = 0.f;
+  for (int i = threadIdx.x; i < a.n_dense; i += kCeBlock) b = b + a.dense_partials[i];
+  const float dense = block_sum_1024(b, red);
+  if (threadIdx.x != 0) return;
+  const float reg = a.emb_scale * emb + dense;
+  a.reg_out[0] = reg;
+  float total = reg;
+  for (int i = 0; i < a.n_losses; ++i) {
+    const float v = a.loss_parts[i] > 0 ? s_loss[i] : a.lp.src[i][0];
+    if (a.lp.dst[i]) a.lp.dst[i][0] = v;
+    total = total + v;
+  }
+  a.total_out[0] = total;
+}
+
 __global__ void __launch_bounds__(kBlock)
 reduce_sum_kernel(const float* __restrict__ p, int n, float scale, float* __restrict__ out, int accumulate) {
   __shared__ float red[4];
@@ -1494,6 +1728,65 @@ int er_reg_total_loss(const float* emb_partials, int32_t n_partials, float emb_s
   }
   hipLaunchKernelGGL(er::reg_total_loss_kernel, dim3(1), dim3(er::kCeBlock), 0, er::as_stream(stream), emb_partials,
                      n_partials, emb_scale, dense_partials, n_dense, lp, n_losses, reg_out, total_out);
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
+int er_head_sigmoid_ce(const float* x, int32_t ldx, const float* w, const float* b, const float* labels, int32_t B, int32_t K,
+                       float loss_scale, float* logits, float* probs, float* dlogits, float* dx, float* loss_partials,
+                       float* wb_partials, const float* src_z, int32_t src_ld, const float* src_mean, const float* src_invstd,
+                       int32_t src_act, float* bn_partials, er_stream_t stream) {
+  ER_REQUIRE(x && w && labels && logits && dx && loss_partials && wb_partials && B > 0 && K > 0,
+             "er_head_sigmoid_ce: bad arguments");
+  ER_REQUIRE(K % 4 == 0 && K <= 256 && ldx >= K && ldx % 4 == 0, "er_head_sigmoid_ce: K must be a multiple of 4, at most 256 (K = %d, ldx = %d)", K, ldx);
+  ER_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0,
+             "er_head_sigmoid_ce: x, w and dx must be 16-byte aligned");
+  ER_REQUIRE(!bn_partials || (src_z && src_ld >= K && src_ld % 4 == 0 && (reinterpret_cast<uintptr_t>(src_z) & 15) == 0 &&
+                              (!src_mean == !src_invstd)),
+             "er_head_sigmoid_ce: the BatchNorm source needs z (16-byte aligned rows) and mean / invstd together");
+  er::HeadArgs a;
+  int G = 1;
+  while (G < K / 4) G <<= 1;
+  a.x = x; a.ldx = ldx; a.w = w; a.b = b; a.y = labels; a.B = B; a.K = K; a.G = G;
+  a.scale = loss_scale;
+  a.nz = static_cast<float>(B);
+  a.logits = logits; a.probs = probs; a.dz = dlogits; a.dx = dx; a.loss_part = loss_partials; a.wb_part = wb_partials;
+  a.src_z = src_z; a.src_mean = src_mean; a.src_invstd = src_invstd; a.src_ld = src_ld; a.src_act = src_act;
+  a.src_bn = src_mean != nullptr; a.bn_part = bn_partials;
+  const int tiles = static_cast<int>(er::ceil_div(B, er::kHeadRows));
+  const int rpp = er::kBlock / G;
+  const size_t smem = (static_cast<size_t>(3) * rpp * K + 2 * rpp) * sizeof(float);
+  hipLaunchKernelGGL(er::head_sigmoid_ce_kernel, dim3(tiles), dim3(er::kBlock), smem, er::as_stream(stream), a);
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
+int er_loss_tail(const float* emb_partials, int32_t n_partials, float emb_scale, const float* dense_partials, int32_t n_dense,
+                 const float* const* losses, float* const* report, const int32_t* loss_parts, const float* loss_scales,
+                 const float* loss_divs, float* const* loss_values, int32_t n_losses, const er_tail_job* jobs, int32_t n_jobs, float* reg_out,
+                 float* total_out, er_stream_t stream) {
+  ER_REQUIRE(reg_out && total_out && n_losses >= 0 && n_losses <= 8 && n_partials >= 0 && (emb_partials || n_partials == 0) &&
+                 n_dense >= 0 && (dense_partials || n_dense == 0) && n_jobs >= 0 && n_jobs <= er::kTailJobs && (jobs || n_jobs == 0),
+             "er_loss_tail: bad arguments (at most 8 losses, %d column-sum jobs)", er::kTailJobs);
+  er::LossTailArgs a;
+  a.emb_partials = emb_partials; a.n_partials = n_partials; a.emb_scale = emb_scale;
+  a.dense_partials = dense_partials; a.n_dense = n_dense; a.n_losses = n_losses;
+  for (int i = 0; i < 8; ++i) {
+    a.lp.src[i] = i < n_losses ? losses[i] : nullptr;
+    a.lp.dst[i] = (i < n_losses && report) ? report[i] : nullptr;
+    a.loss_parts[i] = (i < n_losses && loss_parts) ? loss_parts[i] : 0;
+    a.loss_scale[i] = (i < n_losses && loss_scales) ? loss_scales[i] : 1.f;
+    a.loss_div[i] = (i < n_losses && loss_divs) ? loss_divs[i] : 1.f;
+    a.loss_value[i] = (i < n_losses && loss_values) ? loss_values[i] : nullptr;
+    ER_REQUIRE(i >= n_losses || losses[i], "er_loss_tail: loss %d is null", i);
+  }
+  a.reg_out = reg_out; a.total_out = total_out; a.n_jobs = n_jobs;
+  for (int j = 0; j < n_jobs; ++j) {
+    ER_REQUIRE(jobs[j].partial && jobs[j].dst && jobs[j].n_parts > 0 && jobs[j].n_cols > 0 && jobs[j].ld >= jobs[j].n_cols,
+               "er_loss_tail: job %d: bad arguments", j);
+    a.jobs[j] = er::TailJob{jobs[j].partial, jobs[j].dst, jobs[j].n_parts, jobs[j].n_cols, jobs[j].ld};
+  }
+  hipLaunchKernelGGL(er::loss_tail_kernel, dim3(1), dim3(er::kCeBlock), 0, er::as_stream(stream), a);
   ER_LAUNCH_CHECK();
   return 0;
 }

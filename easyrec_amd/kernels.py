@@ -207,6 +207,11 @@ class CeHead(ctypes.Structure):  # = er_ce_head
 CROSS_HASH_KEY = 0xDECAFCAFFE  # tf.sparse.cross_hashed's default hash_key (crossed_column(hash_key=None))
 
 
+class TailJob(ctypes.Structure):  # = er_tail_job
+  _fields_ = [('partial', ctypes.c_void_p), ('dst', ctypes.c_void_p), ('n_parts', ctypes.c_int32), ('n_cols', ctypes.c_int32),
+              ('ld', ctypes.c_int32)]
+
+
 class GradTerm(ctypes.Structure):  # = er_grad_term
   _fields_ = [('kind', ctypes.c_int32), ('col0', ctypes.c_int32), ('width', ctypes.c_int32), ('dim', ctypes.c_int32),
               ('g', ctypes.c_void_p), ('g_ld', ctypes.c_int32), ('pad_', ctypes.c_int32), ('saved', ctypes.c_void_p)]
@@ -1544,6 +1549,60 @@ class HipBackend(object):
                                         _p(dense_partials), ctypes.c_int32(n_dense), src, dst, ctypes.c_int32(n),
                                         _p(reg_out), _p(total_out), _stream()), 'er_reg_total_loss')
 
+  # the binary head of a rank model (dense(K -> 1) + sigmoid cross entropy + their gradients) as ONE launch, its dW / db
+  # partial sums folded into the loss tail's launch: layers/dnn.py dense(head=True), builders/loss_builder.py
+  fused_head = os.environ.get('EASYREC_AMD_FUSED_HEAD', '1') != '0'  # A/B switch
+
+  def head_sigmoid_ce(self, x, w, b, labels, loss_scale, src=None, logits=None):
+    """er_head_sigmoid_ce: x [B, K] (row stride >= K), w [K, 1], b [1] or None, labels [B] -> dict(logits [B, 1], probs [B],
+    dlogits [B], dx [B, K], loss_partials [T], wb_partials [T, K + 1], bn_partials [T, K, 2] or None); the loss is
+    loss_scale * sum(loss_partials) / B (loss_tail).  src: the BnSource of x (x is its activation output)."""
+    B, K = x.shape
+    dev = x.device
+    T = (B + 63) // 64
+    f = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)  # noqa: E731
+    out = {'logits': logits if logits is not None else f(B, 1), 'probs': f(B), 'dlogits': f(B), 'dx': f(B, K), 'loss_partials': f(T), 'wb_partials': f(T, K + 1),
+           'bn_partials': None}
+    sz = smean = sinv = None
+    sld, sact = 0, ACT_NONE
+    if src is not None:
+      assert src.y is not None and src.y.data_ptr() == x.data_ptr() and src.zbias is None
+      out['bn_partials'] = f(T, K, 2)
+      sz, smean, sinv, sld, sact = src.z, src.mean, src.invstd, src.z.stride(0), src.act
+    self._ck(self.lib.er_head_sigmoid_ce(_p(x), ctypes.c_int32(x.stride(0)), _p(w), _p(b), _p(_f32c(labels)), ctypes.c_int32(B),
+                                         ctypes.c_int32(K), ctypes.c_float(loss_scale), _p(out['logits']), _p(out['probs']),
+                                         _p(out['dlogits']), _p(out['dx']), _p(out['loss_partials']), _p(out['wb_partials']),
+                                         _p(sz), ctypes.c_int32(sld), _p(smean), _p(sinv), ctypes.c_int32(int(sact)),
+                                         _p(out['bn_partials']), _stream()), 'er_head_sigmoid_ce')
+    return out
+
+  def loss_tail(self, emb_partials, emb_scale, dense_partials, losses, reports, reg_out, total_out, jobs=()):
+    """reg_total_loss whose task losses may be PartialLoss records (per-workgroup partial sums left by head_sigmoid_ce)
+    and which also runs small column-sum jobs [(partial [P, ld], dst [n_cols], n_cols)]: dst[j] += sum_p partial[p, j]."""
+    n = len(losses)
+    assert n <= 8 and len(jobs) <= 4
+    src = (ctypes.c_void_p * max(n, 1))()
+    dst = (ctypes.c_void_p * max(n, 1))(*[t.data_ptr() for t in reports])
+    parts = (ctypes.c_int32 * max(n, 1))()
+    scales = (ctypes.c_float * max(n, 1))()
+    divs = (ctypes.c_float * max(n, 1))()
+    values = (ctypes.c_void_p * max(n, 1))()
+    for i, t in enumerate(losses):
+      pl = getattr(t, '_er_partials', None)
+      if pl is not None:
+        src[i], parts[i], scales[i], divs[i], values[i] = pl[0].data_ptr(), pl[0].numel(), float(pl[1]), float(pl[2]), t.data_ptr()
+      else:
+        src[i], parts[i], scales[i], divs[i], values[i] = t.data_ptr(), 0, 1.0, 1.0, None
+    arr = (TailJob * max(len(jobs), 1))()
+    for q, (partial, d, n_cols) in zip(arr, jobs):
+      assert partial.dim() == 2 and partial.stride(1) == 1 and d.is_contiguous() and d.numel() == n_cols
+      q.partial, q.dst, q.n_parts, q.n_cols, q.ld = partial.data_ptr(), d.data_ptr(), partial.shape[0], int(n_cols), partial.stride(0)
+    n_part = 0 if emb_partials is None else emb_partials.numel()
+    n_dense = 0 if dense_partials is None else dense_partials.numel()
+    self._ck(self.lib.er_loss_tail(_p(emb_partials), ctypes.c_int32(n_part), ctypes.c_float(emb_scale), _p(dense_partials),
+                                   ctypes.c_int32(n_dense), src, dst, parts, scales, divs, values, ctypes.c_int32(n), arr,
+                                   ctypes.c_int32(len(jobs)), _p(reg_out), _p(total_out), _stream()), 'er_loss_tail')
+
   def l2_partials(self, w, coef, partials):
     """partials[b] = sum over weights [256 b, 256 b + 256) of 0.5 * coef * w^2 (what dense_opt_step(l2_partials=) keeps
     current from then on)."""
@@ -1765,6 +1824,93 @@ class LinearFn(torch.autograd.Function):
     if ctx.has_bias and ctx.needs_input_grad[2]:
       if ctx.b_grad is not None:
         be.colsum(dy, out=ctx.b_grad, accumulate=True)  # straight into the flat gradient buffer
+      else:
+        db = be.colsum(dy)
+    return dx, dw, db, None, None, None, None, None
+
+
+class HeadState(object):
+  """A rank model's `output` projection (dense(K -> 1)) whose logits have not been computed yet: layers/dnn.py dense(head=True)
+  registers it; builders/loss_builder.py either runs the fused head launch on it (HipBackend.head_sigmoid_ce: logits, loss,
+  and the projection's whole backward) or materialises the logits with an ordinary GEMM (materialize_head)."""
+  __slots__ = ('x', 'w', 'b', 'w_grad', 'b_grad', 'src', 'logits', 'state', 'dx', 'dz', 'bf16')
+
+  def __init__(self, x, w, b, w_grad, b_grad, src, logits, bf16):
+    self.x, self.w, self.b, self.w_grad, self.b_grad, self.src, self.logits, self.bf16 = x, w, b, w_grad, b_grad, src, logits, bf16
+    self.state, self.dx, self.dz = 'pending', None, None
+
+  @property
+  def fusable(self):
+    K = self.x.shape[1]
+    return (self.state == 'pending' and self.w_grad is not None and (self.b is None or self.b_grad is not None) and
+            K % 4 == 0 and K <= 256 and self.x.stride(0) % 4 == 0 and self.x.data_ptr() % 16 == 0 and self.w.data_ptr() % 16 == 0)
+
+
+def pending_head(pred):
+  """The HeadState whose logits buffer `pred` views (same storage start), while it is still pending; else None."""
+  from easyrec_amd.core import context
+  stack = context._stack()
+  heads = getattr(stack[-1], 'heads', None) if stack else None
+  if not heads:
+    return None
+  st = heads.get(pred.data_ptr())
+  return st if (st is not None and st.state == 'pending' and pred.numel() == st.logits.numel()) else None
+
+
+def materialize_head(st):
+  """logits = x . w + b by the ordinary GEMM (the loss is not the fused sigmoid cross entropy)."""
+  if st.state == 'pending':
+    hip().gemm(GEMM_NN, st.x, st.w.detach(), out=st.logits, bias=None if st.b is None else st.b.detach(), bf16=st.bf16)
+    st.state = 'materialized'
+
+
+def materialize_pending_heads():
+  from easyrec_amd.core import context
+  stack = context._stack()
+  for st in list(getattr(stack[-1], 'heads', {}).values()) if stack else []:
+    materialize_head(st)
+
+
+class HeadFn(torch.autograd.Function):
+  """LinearFn for the logit head of a rank model (units = 1): the forward only RESERVES the logits; the loss builder fills
+  them - together with the loss and this layer's complete backward (HeadState / HipBackend.head_sigmoid_ce) - or falls back
+  to the GEMMs of LinearFn."""
+
+  @staticmethod
+  def forward(ctx, x, w, b, w_grad, b_grad, bf16, src, heads):
+    x2 = x if x.stride(-1) == 1 else x.contiguous()
+    logits = torch.empty(x2.shape[0], 1, dtype=torch.float32, device=x2.device)
+    be = hip()
+    fused = src is not None and x2 is x and not bf16 and src.fused and getattr(be, 'fused_bn_bwd', False)
+    # (the state keeps a DETACHED alias of the logits: they are written after this forward returned, outside autograd's view)
+    st = HeadState(x2, w.detach(), None if b is None else b.detach(), w_grad, b_grad, src if fused else None, logits.detach(), bf16)
+    heads[logits.data_ptr()] = st
+    ctx.st = st
+    ctx.save_for_backward(x2, w)
+    ctx.has_bias = b is not None
+    ctx.sink = be.wgrad_sink()
+    return logits
+
+  @staticmethod
+  def backward(ctx, dy):
+    be = hip()
+    st = ctx.st
+    x, w = ctx.saved_tensors
+    if st.state == 'fused':
+      # the loss launch already produced dx and queued dW / db for the loss tail: dy must be the gradient it computed
+      # (autograd may hand over a copy of the seed; build_loss_graph seeds exactly one gradient per logits tensor)
+      assert dy.numel() == st.dz.numel()
+      return st.dx, None, None, None, None, None, None, None
+    assert st.state == 'materialized', 'the logits of a rank model\'s head were never computed (kernels.materialize_head)'
+    dy = dy if dy.stride(-1) == 1 and dy.dim() == 2 else dy.contiguous()
+    dx = dw = db = None
+    if ctx.needs_input_grad[0]:
+      dx = _dgrad(be, dy, w, st.src, st.bf16, None)
+    if ctx.needs_input_grad[1]:
+      dw = _wgrad(be, x, dy, st.w_grad, st.bf16, None, ctx.sink)
+    if ctx.has_bias and ctx.needs_input_grad[2]:
+      if st.b_grad is not None:
+        be.colsum(dy, out=st.b_grad, accumulate=True)
       else:
         db = be.colsum(dy)
     return dx, dw, db, None, None, None, None, None

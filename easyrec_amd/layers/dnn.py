@@ -31,13 +31,23 @@ def _linear(x2, w, b, src=None, sink=None):
   return kernels.LinearFn.apply(x2, w, b, wg, bg, bf16, src, sink)
 
 
-def dense(x, units, name, l2_reg=None, use_bias=True, kernel_initializer='glorot_uniform'):
-  """tf.layers.dense(activation=None): returns x @ kernel (+ bias).  Variables <name>/kernel, /bias."""
+def dense(x, units, name, l2_reg=None, use_bias=True, kernel_initializer='glorot_uniform', head=False):
+  """tf.layers.dense(activation=None): returns x @ kernel (+ bias).  Variables <name>/kernel, /bias.
+  head: the caller hands the result UNCHANGED to the prediction dict as a rank model's logits (units == 1): while training
+  the projection is then computed by the loss builder's fused head launch (kernels.HeadFn) - nothing may read the returned
+  tensor before the loss graph is built (the estimator materialises whatever is still pending after it)."""
   vs = context.varstore()
   in_dim = x.shape[-1]
   w = vs.get_variable(name + '/kernel', (in_dim, units), kernel_initializer, l2=l2_reg or 0.0)
   b = vs.get_variable(name + '/bias', (units,), 'zeros') if use_bias else None
   shape = x.shape
+  ctx = context.current()
+  if head and units == 1 and x.dim() == 2 and torch.is_grad_enabled() and ctx.is_training and not ctx.building and \
+      getattr(kernels.hip(), 'fused_head', False) and hasattr(ctx, 'heads'):
+    wg = w.grad if (w.requires_grad and w.grad is not None) else None
+    bg = b.grad if (b is not None and b.requires_grad and b.grad is not None) else None
+    bf16 = getattr(ctx, 'dense_dtype', 'f32') == 'bf16'
+    return kernels.HeadFn.apply(x, w, b, wg, bg, bf16, kernels.bn_source_of(x), ctx.heads)
   y = _linear(x if x.dim() == 2 else x.reshape(-1, in_dim), w, b, kernels.bn_source_of(x), kernels.grad_sink_of(x))
   return y.reshape(shape[:-1] + (units,))
 

@@ -40,4 +40,4 @@ class DCN(RankModel):
     deep = self._dnn(self._features, own.deep_tower.dnn, 'dnn')
     crossed = self._cross_net(self._features, own.cross_tower.cross_num)
     top = self._dnn(torch.cat([deep, crossed], dim=1), own.final_dnn, 'final_dnn')
-    return self._emit(dnn.dense(top, self._num_class, 'output'))  # (no kernel regulariser on `output`: dcn.py:66)
+    return self._emit(dnn.dense(top, self._num_class, 'output', head=True))  # (no kernel regulariser on `output`: dcn.py:66)

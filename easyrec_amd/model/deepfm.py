@@ -42,7 +42,7 @@ class DeepFM(RankModel):
     if len(own.final_dnn.hidden_units) > 0:
       top = self._dnn(kernels.concat_cols([wide, pairwise, deep]), own.final_dnn, 'final_dnn')
       kernels.mark_single_consumer(top)  # read by the `output` projection alone
-      return self._emit(dnn.dense(top, self._num_class, 'output', l2_reg=self._l2_reg))
+      return self._emit(dnn.dense(top, self._num_class, 'output', l2_reg=self._l2_reg, head=True))
     # without a final_dnn the three parts ARE logits and add up (deepfm.py:90-105)
     deep_logit = dnn.dense(deep, self._num_class, 'deep_logits', l2_reg=self._l2_reg)
     return self._emit(wide + pairwise.sum(dim=1, keepdim=True) + deep_logit)

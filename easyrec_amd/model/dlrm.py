@@ -39,4 +39,4 @@ class DLRM(RankModel):
     dense_block = self._group('dense')[0]
     bottom = self._dnn(dense_block, self._model_config.bot_dnn, 'bot_dnn')
     top = self._dnn(self._interact(bottom, sparse_block, sparse_list), self._model_config.top_dnn, 'top_dnn')
-    return self._emit(dnn.dense(top, 1, 'output', l2_reg=self._l2_reg))
+    return self._emit(dnn.dense(top, 1, 'output', l2_reg=self._l2_reg, head=True))

@@ -312,8 +312,17 @@ class EasyRecEstimator(object):
       if name not in self.losses:
         self.losses[name] = torch.zeros(1, dtype=torch.float32, device=self.device)
     partials = eng.sumsq[:eng.reg_blocks] if (eng.reg_lambda > 0 and eng.reg_blocks > 0) else None
+    kernels.materialize_pending_heads()  # (a logit head that no loss consumed: its logits are still owed)
+    jobs = list(self.ctx.tail_jobs)
+    del self.ctx.tail_jobs[:]
+    values = [loss_dict[n] for n in names]
+    if jobs or any(getattr(v, '_er_partials', None) is not None for v in values):
+      # a fused head (builders/loss_builder.py): its loss arrives as per-workgroup partial sums, its dW / db as column-sum jobs
+      be.loss_tail(partials, 0.5 * eng.reg_lambda, vs.l2_partials if vs.any_l2 else None, values,
+                   [self.losses[n] for n in names], self.losses['regularization_loss'], self.losses['total_loss'], jobs=jobs)
+      return
     be.reg_total_loss(partials, 0.5 * eng.reg_lambda, vs.l2_partials if vs.any_l2 else None,
-                      [loss_dict[n].reshape(1) for n in names], [self.losses[n] for n in names],
+                      [v.reshape(1) for v in values], [self.losses[n] for n in names],
                       self.losses['regularization_loss'], self.losses['total_loss'])
 
   def train_step(self, batch=None):

@@ -136,6 +136,10 @@ class EasyRecModel(six.with_metaclass(_meta_type, object)):
   def begin_step(self):
     """Per-step state, emptied by the estimator before build_predict_graph (and once by the constructor)."""
     self._prediction_dict, self._loss_dict, self._backward_seeds = {}, {}, []
+    ctx = context._stack()[-1] if context._stack() else None
+    if ctx is not None and hasattr(ctx, 'heads'):
+      ctx.heads.clear()
+      del ctx.tail_jobs[:]
 
   @abstractmethod
   def build_predict_graph(self):

@@ -22,4 +22,4 @@ class MultiTower(RankModel):
       x = dnn.batch_norm(x, t.input + '_fea_bn', self._is_training)
       outs.append(self._dnn(x, t.dnn, t.input + '_dnn'))
     top = self._dnn(torch.cat(outs, dim=1), self._model_config.final_dnn, 'final_dnn')
-    return self._emit(dnn.dense(top, self._num_class, 'output'))
+    return self._emit(dnn.dense(top, self._num_class, 'output', head=True))

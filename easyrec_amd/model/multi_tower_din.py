@@ -66,6 +66,6 @@ class MultiTowerDIN(RankModel):
     all_fea = kernels.concat_cols(tower_fea_arr)
     final_dnn_layer = dnn.DNN(self._model_config.final_dnn, self._l2_reg, 'final_dnn', self._is_training)
     all_fea = final_dnn_layer(all_fea)
-    output = dnn.dense(all_fea, self._num_class, 'output')
+    output = dnn.dense(all_fea, self._num_class, 'output', head=True)
     self._add_to_prediction_dict(output)
     return self._prediction_dict

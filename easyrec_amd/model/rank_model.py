@@ -15,6 +15,7 @@ from collections import namedtuple
 
 import torch
 
+from easyrec_amd import kernels
 from easyrec_amd.builders import loss_builder
 from easyrec_amd.layers.dnn import dense
 from easyrec_amd.model.easy_rec_model import EasyRecModel
@@ -74,7 +75,7 @@ class RankModel(EasyRecModel):
     logits = self.backbone
     if int(logits.shape[-1]) != self._num_class:
       logging.info('add head logits layer for rank model')
-      logits = dense(logits, self._num_class, 'output')
+      logits = dense(logits, self._num_class, 'output', head=True)
     self._add_to_prediction_dict(logits)
     return self._prediction_dict
 
@@ -86,6 +87,11 @@ class RankModel(EasyRecModel):
       # while training, the fused loss kernel produces the probabilities; otherwise they are computed here
       probs = None if self._is_training else torch.sigmoid(column.detach())
       return {'logits' + suffix: column, 'probs' + suffix: probs}
+    # (a regression head reads its output right here or through a plain torch loss: a lazily computed logit head -
+    # layers/dnn.py dense(head=True) - is computed now)
+    pending = kernels.pending_head(column)
+    if pending is not None:
+      kernels.materialize_head(pending)
     if head is _SIGMOID_REGRESSION:
       column = torch.sigmoid(column)
     return {'y' + suffix: column}
@@ -104,7 +110,7 @@ class RankModel(EasyRecModel):
     head = _head_of(loss_type)
     pred = self._prediction_dict[head.loss_input + suffix]
     value, dpred = loss_builder.build(loss_type, self._labels[label_name], pred, loss_weight, num_class,
-                                      loss_scale=loss_scale, loss_param=loss_param)
+                                      loss_scale=loss_scale, loss_param=loss_param, fuse_head=len(self._losses) <= 1)
     self._backward_seeds.append((pred, dpred))
     # rank_model.py:236-250: a given loss_name stands as it is for the cross-entropy / L2 losses and gets the suffix for
     # the other binary loss types

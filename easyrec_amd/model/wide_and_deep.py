@@ -36,5 +36,5 @@ class WideAndDeep(RankModel):
     deep = self._dnn(deep_block, self._model_config.dnn, 'deep_feature')
     if len(self._model_config.final_dnn.hidden_units) > 0:
       top = self._dnn(kernels.concat_cols([wide, deep]), self._model_config.final_dnn, 'final_dnn')
-      return self._emit(dnn.dense(top, self._num_class, 'output', l2_reg=self._l2_reg))
+      return self._emit(dnn.dense(top, self._num_class, 'output', l2_reg=self._l2_reg, head=True))
     return self._emit(dnn.dense(deep, self._num_class, 'deep_out', l2_reg=self._l2_reg) + wide)

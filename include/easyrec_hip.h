@@ -537,6 +537,35 @@ int er_total_loss(const float* reg_emb, const float* reg_dense, const float* con
 int er_reg_total_loss(const float* emb_partials, int32_t n_partials, float emb_scale, const float* dense_partials,
                       int32_t n_dense, const float* const* losses_host, float* const* report_host, int32_t n_losses,
                       float* reg_out, float* total_out, er_stream_t stream);
+/* The binary head of a rank model in ONE launch (round 4).  Replaces the TF-op chain of the `output` projection and its
+ * loss - tf.layers.dense(units = 1) (model/deepfm.py:84-88, model/dcn.py:66, model/multi_tower.py, model/dlrm.py) ->
+ * tf.losses.sigmoid_cross_entropy (builders/loss_builder.py:35-39; no sample weights: the mean over the batch) - AND the
+ * gradient of both: logits[r] = x[r, :] . w + b[0]; probs = sigmoid(logits); dlogits[r] = loss_scale * (probs - labels) / B;
+ * dx[r, :] = dlogits[r] * w (dense [B, K]); loss = loss_scale * sum(loss_partials) / B over the ceil(B / 64) row tiles;
+ * wb_partials[tile][0..K) = sum over the tile's rows of x[r][c] * dlogits[r] (dW), [tile][K] = sum of dlogits (db) - summed
+ * into the gradient buffers by er_loss_tail's column-sum jobs.  When x is the activation output of a dense + BatchNorm +
+ * ReLU layer (src_z = that layer's pre-normalisation values incl. bias, src_mean / src_invstd its batch statistics, NULL
+ * for a layer without BatchNorm; src_act ER_ACT_*), bn_partials [tile][K][2] receives that layer's BatchNorm-backward
+ * column sums (sum g, sum g * xhat; g = dx masked by the ReLU) exactly as er_gemm_f32_bn_bwd leaves them.  K % 4 == 0,
+ * K <= 256; x, w, dx (and src_z) 16-byte aligned; probs / dlogits / b may be NULL.  Deterministic (fixed reduction trees). */
+int er_head_sigmoid_ce(const float* x, int32_t ldx, const float* w, const float* b, const float* labels, int32_t B, int32_t K,
+                       float loss_scale, float* logits, float* probs, float* dlogits, float* dx, float* loss_partials,
+                       float* wb_partials, const float* src_z, int32_t src_ld, const float* src_mean, const float* src_invstd,
+                       int32_t src_act, float* bn_partials, er_stream_t stream);
+/* er_reg_total_loss for steps whose head ran as er_head_sigmoid_ce: loss i may be given as loss_parts[i] > 0 partial sums
+ * (losses[i] points at them; its value loss_scales[i] * their sum / loss_divs[i] is also stored to loss_values[i][0] when that is
+ * non-NULL), and up to 4 column-sum jobs dst[j] += sum_p partial[p * ld + j] (j < n_cols) ride along (the head's dW / db, straight
+ * into the flat gradient buffer that the estimator's add_n of IndexedSlices-free dense gradients lives in).  HOST arrays. */
+typedef struct er_tail_job {
+  const float* partial;
+  float* dst;
+  int32_t n_parts, n_cols;
+  int32_t ld; /* floats between consecutive partial rows (>= n_cols) */
+} er_tail_job;
+int er_loss_tail(const float* emb_partials, int32_t n_partials, float emb_scale, const float* dense_partials, int32_t n_dense,
+                 const float* const* losses_host, float* const* report_host, const int32_t* loss_parts, const float* loss_scales,
+                 const float* loss_divs, float* const* loss_values_host, int32_t n_losses, const er_tail_job* jobs_host, int32_t n_jobs, float* reg_out,
+                 float* total_out, er_stream_t stream);
 /* partials[b] = sum over weights [256 b, 256 b + 256) of 0.5 * coef * w^2 (ceil(n / 256) floats); er_dense_opt_step_l2 =
  * er_dense_opt_step that also leaves these sums of the UPDATED weights (l2_partials may be NULL): the next step's
  * kernel-L2 term costs no pass over the weights. */

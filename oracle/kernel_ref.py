@@ -1014,6 +1014,53 @@ class RefBackend(object):
       total = total + src.reshape(1)
     total_out.copy_(total)
 
+  fused_head = True  # layers/dnn.py dense(head=True) + builders/loss_builder.py: the host logic runs on the stand-in too
+
+  def head_sigmoid_ce(self, x, w, b, labels, loss_scale, src=None, logits=None):
+    """easyrec_amd.kernels.HipBackend.head_sigmoid_ce restated with torch ops (per-64-row-tile partial sums like the kernel)."""
+    B, K = x.shape
+    xd, wd = x.detach().to(torch.float32), w.detach().reshape(K, 1)
+    z = xd @ wd
+    if b is not None:
+      z = z + b.detach().reshape(1, 1)
+    if logits is None:
+      logits = torch.empty(B, 1, dtype=torch.float32)
+    logits.copy_(z)
+    zf, y = z.reshape(-1), labels.to(torch.float32).reshape(-1)
+    ce = torch.clamp(zf, min=0) - zf * y + torch.log1p(torch.exp(-torch.abs(zf)))
+    p = torch.sigmoid(zf)
+    dz = loss_scale * (p - y) / torch.tensor(float(B))  # (sigmoid_ce's own expression, nz = B)
+    dx = dz.reshape(B, 1) * wd.reshape(1, K)
+    T = (B + 63) // 64
+    pad = T * 64 - B
+
+    def tiles(t):  # [B, C] -> per-tile column sums [T, C]
+      t2 = torch.cat([t, torch.zeros(pad, t.shape[1])], 0) if pad else t
+      return t2.reshape(T, 64, t.shape[1]).sum(dim=1)
+
+    out = {'logits': logits, 'probs': p, 'dlogits': dz, 'dx': dx, 'loss_partials': tiles(ce.reshape(B, 1)).reshape(T),
+           'wb_partials': torch.cat([tiles(xd * dz.reshape(B, 1)), tiles(dz.reshape(B, 1))], 1).contiguous(), 'bn_partials': None}
+    if src is not None:
+      g = dx.clone()
+      if src.act == ACT_RELU:
+        g = torch.where(xd > 0, g, torch.zeros_like(g))
+      gx = torch.zeros_like(g)
+      if src.mean is not None:
+        gx = g * ((src.z.detach() - src.mean.reshape(1, K)) * src.invstd.reshape(1, K))
+      out['bn_partials'] = torch.stack([tiles(g), tiles(gx)], dim=2).contiguous()
+    return out
+
+  def loss_tail(self, emb_partials, emb_scale, dense_partials, losses, reports, reg_out, total_out, jobs=()):
+    for partial, dst, n_cols in jobs:
+      dst.add_(partial[:, :n_cols].sum(dim=0))
+    scalars = []
+    for t in losses:
+      pl = getattr(t, '_er_partials', None)
+      if pl is not None:
+        t[0] = float(F32(pl[1]) * F32(pl[0].detach().numpy().astype(np.float64).sum()) / F32(pl[2]))
+      scalars.append(t.reshape(1))
+    self.reg_total_loss(emb_partials, emb_scale, dense_partials, scalars, reports, reg_out, total_out)
+
   def l2_partials(self, w, coef, partials):
     c, ww = coef.numpy().astype(np.float64), w.detach().numpy().astype(np.float64)
     t = np.zeros(partials.numel() * 256)

@@ -1581,3 +1581,59 @@ def test_cin_layers_against_einsum(hip, B, H0, D, sizes):
   for k in range(len(sizes)):
     assert close(wg[k], wr[k].grad), k
     assert close(bg[k], br[k].grad), k
+
+
+# ------------------------------------------------------------------------------------------- fused binary head
+@pytest.mark.parametrize('B,K,with_src,with_bn,bias', [(4096, 64, True, True, True), (300, 64, True, False, True),
+                                                      (130, 16, False, False, False), (130, 8, True, True, True), (1000, 256, True, True, True),
+                                                      (64, 128, False, False, True)])
+def test_head_sigmoid_ce_and_loss_tail(hip, ref, B, K, with_src, with_bn, bias):
+  """er_head_sigmoid_ce (dense(K -> 1) + sigmoid cross entropy + the projection's backward + the producing layer's
+  BatchNorm-backward column sums, one launch) and er_loss_tail (partial-sum losses + column-sum jobs) against the stand-in's
+  torch restatement: logits / probs / dlogits / dx 1e-5 relative, partial sums 1e-5 of their scale; ragged last tile."""
+  rng = np.random.default_rng(B + K)
+  ld = K + 8  # (a row stride wider than K: the head reads a column block in place)
+  xbuf = torch.from_numpy(rng.standard_normal((B, ld)).astype(np.float32))
+  z = torch.from_numpy(rng.standard_normal((B, K)).astype(np.float32))
+  mean = torch.from_numpy(rng.standard_normal(K).astype(np.float32) * 0.1)
+  invstd = torch.from_numpy((0.5 + rng.random(K)).astype(np.float32))
+  w = torch.from_numpy((rng.standard_normal((K, 1)) * 0.3).astype(np.float32))
+  b = torch.from_numpy(rng.standard_normal(1).astype(np.float32)) if bias else None
+  y = torch.from_numpy((rng.random(B) < 0.3).astype(np.float32))
+  scale = 0.7
+
+  def run(be, dev):
+    xd = xbuf.to(dev)
+    x = xd[:, :K]
+    src = None
+    if with_src:
+      src = kernels.BnSource(z.to(dev), None, x, mean.to(dev) if with_bn else None, invstd.to(dev) if with_bn else None,
+                             kernels.ACT_RELU)
+    out = be.head_sigmoid_ce(x, w.to(dev), None if b is None else b.to(dev), y.to(dev), scale, src=src)
+    loss = torch.zeros(1, device=dev)
+    loss._er_partials = (out['loss_partials'], scale, float(B))
+    wg = torch.full((K,), 0.25, device=dev)
+    bg = torch.full((1,), -0.5, device=dev)
+    reg, total, report = torch.zeros(1, device=dev), torch.zeros(1, device=dev), torch.zeros(1, device=dev)
+    other = torch.full((1,), 0.125, device=dev)
+    embp = torch.arange(7, dtype=torch.float32, device=dev)
+    be.loss_tail(embp, 0.5, None, [loss, other], [report, torch.zeros(1, device=dev)], reg, total,
+                 jobs=[(out['wb_partials'], wg, K), (out['wb_partials'][:, K:], bg, 1)])
+    if dev != 'cpu':
+      torch.cuda.synchronize()
+    res = {k: (v.cpu() if v is not None else None) for k, v in out.items()}
+    res.update(loss=loss.cpu(), wg=wg.cpu(), bg=bg.cpu(), reg=reg.cpu(), total=total.cpu(), report=report.cpu())
+    return res
+
+  got, exp = run(hip, DEV), run(ref, 'cpu')
+  for k in ('logits', 'probs', 'dlogits', 'dx'):
+    assert torch.allclose(got[k].reshape(-1), exp[k].reshape(-1), rtol=1e-5, atol=2e-6), k  # (a 64..256-term dot product in another order)
+  for k in ('loss_partials', 'wb_partials', 'bn_partials', 'wg', 'bg'):
+    if exp[k] is None:
+      assert got[k] is None
+      continue
+    s = float(exp[k].abs().max()) + 1e-12
+    assert float((got[k] - exp[k]).abs().max()) <= 1e-5 * s, (k, float((got[k] - exp[k]).abs().max()), s)
+  for k in ('loss', 'reg', 'total', 'report'):
+    assert abs(float(got[k]) - float(exp[k])) <= 2e-6 * max(1.0, abs(float(exp[k]))), (k, float(got[k]), float(exp[k]))
+  assert float(exp['reg']) == 0.5 * 21.0 and abs(float(exp['total']) - (10.5 + float(exp['loss']) + 0.125)) < 1e-5

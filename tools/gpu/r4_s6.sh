@@ -1,0 +1,4 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
+O=gpurun_out/r4s6; mkdir -p $O
+timeout 300 tools/micro/launch_floor 48 200 2>&1 | tee $O/launch_floor.txt | tail -12

@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <utility>
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
@@ -116,6 +117,89 @@ __global__ void k_lds(float* out) {
   if (out == nullptr) out[0] = sm[threadIdx.x];
 }
 
+// ---- shader clock: clock64() (s_memtime: shader cycles) against wall_clock64() (100 MHz) over a dependent ALU chain
+__global__ void k_clock(unsigned long long* out, int iters) {
+  const unsigned long long w0 = wall_clock64(), c0 = clock64();
+  float acc = static_cast<float>(threadIdx.x);
+  for (int i = 0; i < iters; ++i) acc = acc * 1.0001f + 0.5f;
+  const unsigned long long w1 = wall_clock64(), c1 = clock64();
+  if (threadIdx.x == 0) { out[blockIdx.x * 4] = w1 - w0; out[blockIdx.x * 4 + 1] = c1 - c0; out[blockIdx.x * 4 + 2] = static_cast<unsigned long long>(acc); }
+}
+
+// ---- loss-kernel shapes: which ingredient of a one-workgroup loss kernel (sigmoid_ce: 6-8 us) costs what
+template <int MATH, int REDUCE>
+__global__ void k_ce(const float* __restrict__ z, const float* __restrict__ y, int B, float* __restrict__ dz, float* __restrict__ probs,
+                     float* __restrict__ loss_part) {
+  __shared__ float red[16];
+  float acc = 0.f;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B; i += gridDim.x * blockDim.x) {
+    const float zi = z[i], yi = y[i];
+    float ce, p;
+    if (MATH) { ce = fmaxf(zi, 0.f) - zi * yi + log1pf(expf(-fabsf(zi))); p = 1.f / (1.f + expf(-zi)); }
+    else { ce = zi * yi; p = zi * 0.5f; }
+    acc += ce;
+    probs[i] = p;
+    dz[i] = (p - yi) * 0.001f;
+  }
+  if (REDUCE) {
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float r = 0.f;
+      for (int w = 0; w < static_cast<int>(blockDim.x >> 6); ++w) r += red[w];
+      loss_part[blockIdx.x] = r;
+    }
+  } else if (acc == 12345.f) {
+    loss_part[blockIdx.x] = acc;
+  }
+}
+
+// ---- cold instruction fetch: 48 DISTINCT kernels of ~4 KB / ~16 KB of straight-line code against ONE of them 48 times
+template <int ID, int N>
+__global__ void k_code(float* out, int n) {
+  float acc = static_cast<float>(threadIdx.x);
+#pragma unroll
+  for (int i = 0; i < N; ++i) acc = acc * 1.0001f + static_cast<float>((i * 7 + ID) & 1023);
+  out[(blockIdx.x * 256 + threadIdx.x) * n] = acc;  // (always stored: the chain cannot be sunk into a branch)
+}
+template <int ID, int N>
+void launch_code(hipStream_t st, float* buf) { hipLaunchKernelGGL((k_code<ID, N>), dim3(256), dim3(256), 0, st, buf, 1); }
+inline void launch_rmw(hipStream_t st, f32x4v* y, const f32x4v* x, int n4) { hipLaunchKernelGGL(k_rmw, dim3(2048), dim3(256), 0, st, y, x, n4); }
+template <int N, int... IDS>
+void launch_code_chain(hipStream_t st, float* buf, bool distinct, std::integer_sequence<int, IDS...>) {
+  if (distinct) { (launch_code<IDS, N>(st, buf), ...); }
+  else { for (size_t i = 0; i < sizeof...(IDS); ++i) launch_code<0, N>(st, buf); }
+}
+template <int N, int... IDS>
+void launch_code_chain_thrash(hipStream_t st, float* buf, f32x4v* y, const f32x4v* x, int n4, bool distinct, std::integer_sequence<int, IDS...>) {
+  if (distinct) { ((launch_rmw(st, y, x, n4), launch_code<IDS, N>(st, buf)), ...); }
+  else { for (size_t i = 0; i < sizeof...(IDS); ++i) { launch_rmw(st, y, x, n4); launch_code<0, N>(st, buf); } }
+}
+
+template <typename F>
+float time_graph(hipStream_t st, int replays, F&& body) {
+  hipGraph_t g; hipGraphExec_t ge;
+  body();
+  CK(hipStreamSynchronize(st));
+  CK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
+  body();
+  CK(hipStreamEndCapture(st, &g));
+  CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+  for (int i = 0; i < 5; ++i) CK(hipGraphLaunch(ge, st));
+  CK(hipStreamSynchronize(st));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  CK(hipEventRecord(e0, st));
+  for (int i = 0; i < replays; ++i) CK(hipGraphLaunch(ge, st));
+  CK(hipEventRecord(e1, st));
+  CK(hipStreamSynchronize(st));
+  float ms = 0.f;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
+  return ms * 1e3f / replays;
+}
+
 int main(int argc, char** argv) {
   const int chain = argc > 1 ? atoi(argv[1]) : 48;
   const int replays = argc > 2 ? atoi(argv[2]) : 200;
@@ -203,6 +287,61 @@ int main(int argc, char** argv) {
     CK(hipEventElapsedTime(&ms2, e0, e1));
     printf("%2d %-52s graph %7.3f us/launch   eager %7.3f us/launch\n", v, names[v], ms * 1e3 / (chain * replays), ms2 * 1e3 / (chain * 20));
     CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
+  }
+  // shader clock under three kinds of load
+  {
+    unsigned long long* ck;
+    CK(hipMalloc(&ck, 256 * 4 * 8));
+    auto report = [&](const char* what) {
+      hipLaunchKernelGGL(k_clock, dim3(1), dim3(64), 0, st, ck, 20000);
+      CK(hipStreamSynchronize(st));
+      unsigned long long h[4];
+      CK(hipMemcpy(h, ck, sizeof(h), hipMemcpyDeviceToHost));
+      printf("clock %-58s wall %6.1f us, clock64 %9llu ticks -> %7.1f MHz; %5.2f shader-clock-ticks per dependent mul+add\n", what, h[0] / 100.0, h[1],
+             h[1] / (h[0] / 100.0), static_cast<double>(h[1]) / 20000);
+    };
+    CK(hipStreamSynchronize(st));
+    report("(idle GPU)");
+    for (int i = 0; i < 2000; ++i) hipLaunchKernelGGL(k_empty, dim3(256), dim3(256), 0, st, buf);
+    report("(after 2000 empty kernels, ~3.4 ms)");
+    for (int i = 0; i < 3000; ++i) hipLaunchKernelGGL(k_rmw, dim3(2048), dim3(256), 0, st, reinterpret_cast<f32x4v*>(y), reinterpret_cast<const f32x4v*>(x), 5 * n / 4);
+    report("(after 3000 x 40 MB-traffic kernels, ~25 ms)");
+    for (int i = 0; i < 20000; ++i) hipLaunchKernelGGL(k_reduce1, dim3(1), dim3(256), 0, st, x, dn, dscale, buf);
+    report("(after 20000 one-workgroup kernels, ~60 ms)");
+  }
+  // loss-kernel shapes
+  {
+    struct V { const char* name; int grid, block, math, reduce; };
+    const V vs[] = {{"ce 1 x 1024, no math, no reduce", 1, 1024, 0, 0}, {"ce 1 x 1024, no math, reduce", 1, 1024, 0, 1},
+                    {"ce 1 x 1024, math, reduce", 1, 1024, 1, 1}, {"ce 1 x 256, math, reduce", 1, 256, 1, 1},
+                    {"ce 16 x 256, math, reduce (partials)", 16, 256, 1, 1}, {"ce 64 x 64, math, reduce (partials)", 64, 64, 1, 1},
+                    {"ce 16 x 256, no math, no reduce", 16, 256, 0, 0}};
+    for (const V& v : vs) {
+      auto one = [&] {
+        if (v.math && v.reduce) hipLaunchKernelGGL((k_ce<1, 1>), dim3(v.grid), dim3(v.block), 0, st, x, x + 4096, 4096, y, y + 4096, buf);
+        else if (v.reduce) hipLaunchKernelGGL((k_ce<0, 1>), dim3(v.grid), dim3(v.block), 0, st, x, x + 4096, 4096, y, y + 4096, buf);
+        else hipLaunchKernelGGL((k_ce<0, 0>), dim3(v.grid), dim3(v.block), 0, st, x, x + 4096, 4096, y, y + 4096, buf);
+      };
+      const float us = time_graph(st, replays, [&] { for (int i = 0; i < chain; ++i) one(); });
+      printf("%-44s graph %7.3f us/launch\n", v.name, us / chain);
+    }
+  }
+  // cold instruction fetch
+  {
+    auto seq = std::make_integer_sequence<int, 48>{};
+    f32x4v* y4 = reinterpret_cast<f32x4v*>(y); const f32x4v* x4 = reinterpret_cast<const f32x4v*>(x);
+    const float same_s = time_graph(st, replays, [&] { launch_code_chain<256>(st, buf, false, seq); });
+    const float dist_s = time_graph(st, replays, [&] { launch_code_chain<256>(st, buf, true, seq); });
+    const float same_l = time_graph(st, replays, [&] { launch_code_chain<1024>(st, buf, false, seq); });
+    const float dist_l = time_graph(st, replays, [&] { launch_code_chain<1024>(st, buf, true, seq); });
+    const float same_t = time_graph(st, replays / 4, [&] { launch_code_chain_thrash<256>(st, buf, y4, x4, 5 * n / 4, false, seq); });
+    const float dist_t = time_graph(st, replays / 4, [&] { launch_code_chain_thrash<256>(st, buf, y4, x4, 5 * n / 4, true, seq); });
+    const float same_tl = time_graph(st, replays / 4, [&] { launch_code_chain_thrash<1024>(st, buf, y4, x4, 5 * n / 4, false, seq); });
+    const float dist_tl = time_graph(st, replays / 4, [&] { launch_code_chain_thrash<1024>(st, buf, y4, x4, 5 * n / 4, true, seq); });
+    printf("code  ~4 KB straight-line kernel: ONE kernel x48 %7.3f us/launch | 48 DISTINCT kernels %7.3f us/launch\n", same_s / 48, dist_s / 48);
+    printf("code ~16 KB straight-line kernel: ONE kernel x48 %7.3f us/launch | 48 DISTINCT kernels %7.3f us/launch\n", same_l / 48, dist_l / 48);
+    printf("code  ~4 KB, a 40 MB-traffic kernel between launches (pair): ONE %7.3f us/pair | DISTINCT %7.3f us/pair\n", same_t / 48, dist_t / 48);
+    printf("code ~16 KB, a 40 MB-traffic kernel between launches (pair): ONE %7.3f us/pair | DISTINCT %7.3f us/pair\n", same_tl / 48, dist_tl / 48);
   }
   return 0;
 }
