@@ -10,6 +10,7 @@
 
 #include "er_common.h"
 #include "er_decay.h"
+#include "er_farmhash.h"
 
 namespace er {
 
@@ -1173,18 +1174,37 @@ l2_partials_kernel(const float* __restrict__ w, const float* __restrict__ coef, 
 
 
 
-// per-step scalars: out[:] = table[counter % n_slots][:]; counter += 1   (one block)
-// (+ blocks > 0, and block 0 after its own work: zero `zero_n` floats at `zero` - the flat gradient buffer of the dense
-// variables - so that the step's prologue is one launch instead of this one plus a fill)
-__global__ void hyper_select_kernel(const float* __restrict__ table, int64_t* __restrict__ counter, int n_slots,
+// per-step scalars: out[:] = table[counter % n_slots][:]; counter += 1   (block 0)
+// + the step's other input-independent front work, side by side in the same launch (each was a ~5 us launch of its own):
+//   blocks [0, zero_blocks)            zero `zero_n` floats at `zero` (the flat gradient buffer of the dense variables)
+//   blocks [.., + hash_blocks)         string_to_hash_bucket_fast of the batch's id strings (er_farmhash.h)
+// (the closed-form replay's per-launch table needs the step index, which block 0 is incrementing while the other blocks
+// run: it rides with the id sort instead, er_embedding.hip)
+struct PrologueHash {
+  const uint8_t* bytes;
+  const int64_t* offsets;
+  int64_t n, n_per_col;
+  const uint64_t* num_buckets;
+  int drop_empty;
+  int64_t* out;
+};
+__global__ void __launch_bounds__(256)
+hyper_select_kernel(const float* __restrict__ table, int64_t* __restrict__ counter, int n_slots,
                                     int floats_per_slot, float* __restrict__ out, float* __restrict__ hist,
                                     int64_t hist_capacity, int hist_index, float* __restrict__ zero, int64_t zero_n,
-                                    DecayTabDev tabs) {
-  if (zero) {
-    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
-    for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < zero_n; i += stride) zero[i] = 0.f;
+                                    DecayTabDev tabs, int zero_blocks, PrologueHash hs, int hash_blocks) {
+  const int bid = blockIdx.x;
+  if (bid >= zero_blocks) {  // hash
+    const int64_t stride = static_cast<int64_t>(hash_blocks) * blockDim.x;
+    for (int64_t i = static_cast<int64_t>(bid - zero_blocks) * blockDim.x + threadIdx.x; i < hs.n; i += stride)
+      hs.out[i] = hash_bucket_one(hs.bytes, hs.offsets, i, hs.n_per_col, hs.num_buckets, hs.drop_empty);
+    return;
   }
-  if (blockIdx.x != 0) return;
+  if (zero) {
+    const int64_t stride = static_cast<int64_t>(zero_blocks) * blockDim.x;
+    for (int64_t i = static_cast<int64_t>(bid) * blockDim.x + threadIdx.x; i < zero_n; i += stride) zero[i] = 0.f;
+  }
+  if (bid != 0) return;
   const int64_t c = *counter;
   const int64_t slot = c % n_slots;
   for (int i = threadIdx.x; i < floats_per_slot; i += blockDim.x) out[i] = table[slot * floats_per_slot + i];
@@ -1697,6 +1717,14 @@ int er_step_prologue(const float* table, int64_t* counter, int32_t n_slots, int3
 int er_step_prologue_decay(const float* table, int64_t* counter, int32_t n_slots, int32_t floats_per_slot, float* out,
                            float* history, int64_t history_capacity, int32_t history_index, float* zero,
                            int64_t zero_floats, er_decay_tables* decay_tables, er_stream_t stream) {
+  return er_step_prologue_hash(table, counter, n_slots, floats_per_slot, out, history, history_capacity, history_index, zero,
+                               zero_floats, decay_tables, nullptr, nullptr, 0, 1, nullptr, 0, nullptr, stream);
+}
+
+int er_step_prologue_hash(const float* table, int64_t* counter, int32_t n_slots, int32_t floats_per_slot, float* out,
+                          float* history, int64_t history_capacity, int32_t history_index, float* zero, int64_t zero_floats,
+                          er_decay_tables* decay_tables, const uint8_t* str_bytes, const int64_t* str_offsets, int64_t n_strings,
+                          int64_t n_per_col, const uint64_t* num_buckets, int drop_empty, int64_t* ids_out, er_stream_t stream) {
   ER_REQUIRE(table && counter && out && n_slots > 0 && floats_per_slot > 0, "er_step_prologue: bad arguments");
   ER_REQUIRE(!decay_tables || (decay_tables->hist == history && decay_tables->counter == counter &&
                                decay_tables->dev.capacity == history_capacity),
@@ -1706,11 +1734,17 @@ int er_step_prologue_decay(const float* table, int64_t* counter, int32_t n_slots
   ER_REQUIRE(!history || (history_index >= 0 && history_index < floats_per_slot && history_capacity > 0),
              "er_step_prologue: bad history arguments");
   ER_REQUIRE(zero_floats >= 0 && (zero || zero_floats == 0), "er_step_prologue: bad zero arguments");
+  ER_REQUIRE(n_strings >= 0 && (n_strings == 0 || (str_bytes && str_offsets && num_buckets && ids_out && n_per_col > 0)),
+             "er_step_prologue_hash: bad hash arguments");
   int64_t blocks = zero ? er::ceil_div(zero_floats, 256 * 8) : 1;
   if (blocks > 512) blocks = 512;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(er::hyper_select_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, er::as_stream(stream), table,
-                     counter, n_slots, floats_per_slot, out, history, history_capacity, history_index, zero, zero_floats, tabs);
+  int64_t hb = er::ceil_div(n_strings, 256);
+  if (hb > 4096) hb = 4096;
+  er::PrologueHash hs{str_bytes, str_offsets, n_strings, n_per_col > 0 ? n_per_col : 1, num_buckets, drop_empty, ids_out};
+  hipLaunchKernelGGL(er::hyper_select_kernel, dim3(static_cast<unsigned>(blocks + hb)), dim3(256), 0, er::as_stream(stream), table,
+                     counter, n_slots, floats_per_slot, out, history, history_capacity, history_index, zero, zero_floats, tabs,
+                     static_cast<int>(blocks), hs, static_cast<int>(hb));
   ER_LAUNCH_CHECK();
   return 0;
 }

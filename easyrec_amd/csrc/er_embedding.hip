@@ -26,6 +26,7 @@
 
 #include "er_common.h"
 #include "er_decay.h"
+#include "er_grad_finish.h"
 
 namespace er {
 
@@ -1043,6 +1044,447 @@ emb_bwd_fix_kernel(const uint32_t* __restrict__ skeys, int64_t n, int dim, int G
   fix_body<V>(blockIdx.x, skeys, n, dim, G, T, n_tiles, tab, opt_kind, hyper, ro, tile_first, tile_last);
 }
 
+// ------------------------------------------------------------------------------------------------
+// The fused single-GPU backward (er_emb_bwd_fused): the tile kernel with er_group_grad_finish folded in, + the fix kernel.
+//   * the finished output gradient is evaluated WHILE gathering (grad_finish_value: base + deferred terms + lambda * out) -
+//     the [B, sum(dim)] buffer is never rewritten and re-read;
+//   * runs that cross tile boundaries are combined by the fix kernel, as in the three-launch path (second launch);
+//   * lookups into ONE-ROW tables (the RawFeature projections: B entries, one key) do not go through the sort at all
+//     (emb_front_sort_kernel skips them): each is a weighted column sum of the finished gradient, reduced by kProjParts
+//     workgroups whose LAST arriver (one agent-scope ticket) combines the partials in a fixed order and applies the
+//     optimizer to the row.
+// Entry j of a group -> (lookup l, output row r) by a binary search over the lookups' entry offsets (dense-mode lookups:
+// entry i of a lookup is its row i); the per-entry pointer / scale arrays of the three-launch path are not read.
+// ------------------------------------------------------------------------------------------------
+constexpr int kProjParts = 16;
+constexpr int kOwnMaxLookups = 128;
+constexpr int kOwnMaxGG = 8;
+
+struct OwnLookup;
+struct OwnArgs {
+  const uint32_t* skeys;
+  const uint32_t* svals;
+  int64_t n;
+  const er_lookup_desc* descs;   // this group's lookups (out = the feature group's gradient buffer)
+  const int64_t* ent_base;
+  const OwnLookup* lookups;      // [n_lookups] gather records (device memory; built by er_emb_bwd_fused)
+  int cap_shift;                 // >= 0: every lookup holds 2^cap_shift entries (lookup of entry j = j >> cap_shift)
+  int n_lookups;
+  int dim, G, V, n_tiles;
+  RowUpdate tab;
+  float* tile_first;             // partial sums of the runs that cross tile boundaries (emb_bwd_fix_multi_kernel)
+  float* tile_last;
+  int n_proj;
+  const int32_t* proj_lookup;    // [n_proj] lookups into one-row tables
+  float* proj_partial;           // [n_proj][kProjParts][dim + 1] (last: number of valid entries)
+  uint32_t* proj_ticket;         // [n_proj] monotonic arrival counters
+};
+struct OwnMulti {
+  int n;
+  int start[kMaxMulti + 1];       // tile workgroups
+  int proj_start[kMaxMulti + 1];  // projection workgroups (after all tiles)
+  int opt_kind;
+  const er_opt_hyper* hyper;
+  unsigned long long* dbg;        // probe hook (er_debug_stamps): 16 wall-clock stamps per workgroup, or nullptr
+  int n_gg;
+  er_grad_group gg[kOwnMaxGG];    // (their term pointers change every step: by value; a workgroup copies them to LDS once -
+  OwnArgs a[kMaxMulti];           //  the gather indexes them per lane, which on a kernel argument would be a vector load
+};                                //  from the kernarg segment per access)
+
+struct OwnLookup {  // what the gather needs of a lookup: built on the host (er_emb_bwd_fused), copied to LDS per workgroup
+  const float* weights;
+  int32_t base;      // first entry
+  int32_t out_col;
+  int32_t combiner;
+  int8_t gg;         // which finish descriptor
+  uint8_t tmask;     // which of its terms cover the lookup's column block (a term covers a block entirely or not at all)
+  int16_t pad_;
+};
+
+// scale of a dense-mode lookup's single id (emb_bwd_build_kernel: w / den; den = sum w | sqrt(sum w^2) for mean | sqrtn)
+__device__ __forceinline__ float own_scale(const OwnLookup& L, int r) {
+  const float w = L.weights ? L.weights[r] : 1.f;
+  float den = 1.f;
+  if (L.combiner != ER_COMBINER_SUM) {
+    den = (L.combiner == ER_COMBINER_MEAN) ? w : sqrtf(w * w);
+    if (w == 0.f) den = 1.f;
+  }
+  return w / den;
+}
+
+__device__ __forceinline__ int own_find(const OwnLookup* __restrict__ L, int n, int j, int cap_shift) {
+  if (cap_shift >= 0) return j >> cap_shift;
+  int lo = 0, hi = n;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (L[mid].base <= j) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+template <int V>
+__device__ __forceinline__ Vec<V> own_ld(const float* p) {
+  Vec<V> v;
+  if (V == 4 && (reinterpret_cast<uintptr_t>(p) & 15) != 0) v.loadu(p); else v.load(p);
+  return v;
+}
+
+// V columns [col, col + V) of row b of the finished output gradient (grad_finish_value's arithmetic, component by
+// component in the same order): base + the terms of tmask + lambda * out; cb = the first column's offset inside the
+// lookup's block (= the FM term's d: the host checked that the block is one field of the term)
+template <int V>
+__device__ __forceinline__ Vec<V> own_finish(const er_grad_group& g, uint32_t tmask, int64_t b, int col, int cb) {
+  Vec<V> v;
+  if (g.has_base) v = own_ld<V>(g.dout + b * g.ld + col); else v.zero();
+  Vec<V> o;
+  o.zero();
+  const bool need_out = g.lambda != 0.f || (tmask & 0xF0u) != 0;  // (high nibble: an FM term is among them)
+  if (need_out) o = own_ld<V>(g.out + b * g.ld + col);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    if (!((tmask >> t) & 1u)) continue;
+    const er_grad_term& q = g.terms[t];
+    if (q.kind == ER_GRAD_TERM_ROWSUM) {
+      const float sgl = q.g[b * q.g_ld];
+      if constexpr (V == 4) { v.v.x = v.v.x + sgl; v.v.y = v.v.y + sgl; v.v.z = v.v.z + sgl; v.v.w = v.v.w + sgl; } else { v.v = v.v + sgl; }
+    } else {
+      const Vec<V> gf = own_ld<V>(q.g + b * q.g_ld + cb), sv = own_ld<V>(q.saved + b * q.dim + cb);
+      if constexpr (V == 4) {
+        v.v.x = v.v.x + gf.v.x * (sv.v.x - o.v.x); v.v.y = v.v.y + gf.v.y * (sv.v.y - o.v.y);
+        v.v.z = v.v.z + gf.v.z * (sv.v.z - o.v.z); v.v.w = v.v.w + gf.v.w * (sv.v.w - o.v.w);
+      } else {
+        v.v = v.v + gf.v * (sv.v - o.v);
+      }
+    }
+  }
+  if (g.lambda != 0.f) {
+    if constexpr (V == 4) {
+      v.v.x = v.v.x + g.lambda * o.v.x; v.v.y = v.v.y + g.lambda * o.v.y;
+      v.v.z = v.v.z + g.lambda * o.v.z; v.v.w = v.v.w + g.lambda * o.v.w;
+    } else {
+      v.v = v.v + g.lambda * o.v;
+    }
+  }
+  return v;
+}
+
+// gather + segmented scan of the T entries at [q, q + T) into vals (LDS); keys[0] = key before, keys[1..T] = the chunk,
+// keys[T + 1] = key after
+template <int V>
+__device__ __forceinline__ void own_chunk(int64_t q, const er_grad_group* __restrict__ ggs, const OwnArgs& a,
+                                          const OwnLookup* __restrict__ L, float* __restrict__ vals,
+                                          uint32_t* __restrict__ keys, int T, unsigned long long* dbg) {
+  constexpr int kTilePasses = tile_passes(V);
+  const int G = a.G, dim = a.dim;
+  const int epp = kBlock / G;
+  const int tid = threadIdx.x;
+  const int c = (tid % G) * V;
+  const bool col_ok = c < dim;
+  for (int i = tid; i < T + 2; i += kBlock) {
+    const int64_t p = q - 1 + i;
+    keys[i] = (p >= 0 && p < a.n) ? a.skeys[p] : kInvalidKey;
+  }
+  __syncthreads();
+  if (dbg && tid == 0) dbg[8] = wall_clock64();
+#pragma unroll
+  for (int ps = 0; ps < kTilePasses; ++ps) {
+    const int e = ps * epp + tid / G;
+    const int64_t p = q + e;
+    Vec<V> acc;
+    acc.zero();
+    if (col_ok && p < a.n && keys[e + 1] != kInvalidKey) {
+      const int j = static_cast<int>(a.svals[p]);
+      const OwnLookup lk = L[own_find(L, a.n_lookups, j, a.cap_shift)];
+      const int r = j - lk.base;
+      const float sc = own_scale(lk, r);
+      const Vec<V> g = own_finish<V>(ggs[lk.gg], lk.tmask, r, lk.out_col + c, c);
+      acc.add_scaled(g, sc);
+    }
+    if (col_ok) acc.store(vals + static_cast<size_t>(e) * dim + c);
+  }
+  if (dbg && tid == 0) dbg[9] = wall_clock64();
+  __syncthreads();
+  if (dbg && tid == 0) dbg[10] = wall_clock64();
+  for (int off = 1; off < T; off <<= 1) {
+    Vec<V> add[kTilePasses];
+    int any = 0;
+#pragma unroll
+    for (int ps = 0; ps < kTilePasses; ++ps) {
+      const int e = ps * epp + tid / G;
+      add[ps].zero();
+      if (col_ok && e >= off && keys[e + 1] != kInvalidKey && keys[e + 1 - off] == keys[e + 1]) {
+        add[ps].load(vals + static_cast<size_t>(e - off) * dim + c);
+        any = 1;
+      }
+    }
+    if (!__syncthreads_or(any)) break;
+#pragma unroll
+    for (int ps = 0; ps < kTilePasses; ++ps) {
+      const int e = ps * epp + tid / G;
+      if (col_ok && e >= off && keys[e + 1] != kInvalidKey && keys[e + 1 - off] == keys[e + 1]) {
+        Vec<V> cur;
+        cur.load(vals + static_cast<size_t>(e) * dim + c);
+        cur.add(add[ps]);
+        cur.store(vals + static_cast<size_t>(e) * dim + c);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <int V>
+__device__ __forceinline__ void own_tile_body(int bid, const OwnMulti& ma, const OwnArgs& a, float* __restrict__ smem) {
+  constexpr int kTilePasses = tile_passes(V);
+  const int G = a.G, dim = a.dim;
+  const int epp = kBlock / G;
+  const int T = kTilePasses * epp;
+  float* vals = smem;                                                                         // [T][dim]
+  uint32_t* keys = reinterpret_cast<uint32_t*>(smem + static_cast<size_t>(T) * dim);          // [T + 2]
+  OwnLookup* L = reinterpret_cast<OwnLookup*>(keys + T + 2 + ((T + 2) & 1));                   // [n_lookups] (8-byte aligned)
+  er_grad_group* ggs = reinterpret_cast<er_grad_group*>(L + a.n_lookups);                      // [n_gg]
+  const int tid = threadIdx.x;
+  const int sub = tid % G;
+  const int c = sub * V;
+  const bool col_ok = c < dim;
+  const int64_t t0 = static_cast<int64_t>(bid) * T;
+  unsigned long long* dbg = ma.dbg ? ma.dbg + static_cast<int64_t>(blockIdx.x) * 16 : nullptr;
+  if (dbg && tid == 0) dbg[0] = wall_clock64();
+  // the lookups' gather records (device memory, built by the host) and the finish descriptors (kernel arguments: copied by
+  // ONE wavefront, struct by struct with uniform indices - scalar loads; a per-lane index into a by-value argument would be
+  // a vector load from the kernarg segment, which is host memory: measured 140 us per launch)
+  {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(a.lookups);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(L);
+    for (int i = tid; i < a.n_lookups * static_cast<int>(sizeof(OwnLookup) / 4); i += kBlock) dst[i] = src[i];
+  }
+  if (tid < kWave)
+    for (int k = 0; k < ma.n_gg; ++k) ggs[k] = ma.gg[k];
+  const ReduceOut ro{0, nullptr, nullptr, nullptr, nullptr, 0};
+  if (dbg && tid == 0) dbg[2] = wall_clock64();
+  own_chunk<V>(t0, ggs, a, L, vals, keys, T, dbg);  // (its first barrier also orders the LDS set-up above before the gather)
+  if (dbg && tid == 0) dbg[3] = wall_clock64();
+  // run ends, as the three-launch path's tile kernel: a run inside the tile is finished here; a run that crosses a tile
+  // boundary leaves its partial in tile_first / tile_last for emb_bwd_fix_multi_kernel.  (A first version had the workgroup
+  // that holds a run's FIRST entry follow the run through the tiles behind it - no partials, no second launch - and lost:
+  // a tile's gather + scan is 6 us (dim 16) to 17 us (dim 1) of dependent round trips, and a Zipf-hot key's run spans four
+  // of them in series on one workgroup while the launch waits: 97 us against 27 + 12.)
+#pragma unroll
+  for (int ps = 0; ps < kTilePasses; ++ps) {
+    const int e = ps * epp + tid / G;
+    const int64_t p = t0 + e;
+    if (!col_ok || p >= a.n) continue;
+    const uint32_t key = keys[e + 1];
+    if (key == kInvalidKey) continue;
+    if (keys[e + 2] == key && e != T - 1) continue;           // not the last entry of its run in this tile
+    const bool from_prev = keys[0] == key;                    // sorted: then the run covers the tile up to e
+    const bool to_next = (e == T - 1) && keys[T + 1] == key;  // keys[T + 1] = first key of the next tile
+    const float* gs = vals + static_cast<size_t>(e) * dim + c;
+    if (!from_prev && !to_next) {
+      finish_run<V>(a.tab, ma.opt_kind, ma.hyper, ro, key, p, sub, c, dim, gs);
+    } else {
+      Vec<V> r;
+      r.load(gs);
+      if (from_prev) r.store(a.tile_first + static_cast<size_t>(bid) * dim + c);
+      if (to_next) r.store(a.tile_last + static_cast<size_t>(bid) * dim + c);
+    }
+  }
+  if (dbg && tid == 0) dbg[1] = wall_clock64();
+}
+
+// one-row tables: workgroup (projection pj, part k) sums its rows' scaled finished gradients; the last of the kProjParts
+// to arrive combines the partials (fixed order) and updates the row
+template <int V>
+__device__ __forceinline__ void own_proj_body(int local, const OwnMulti& ma, const OwnArgs& a, float* __restrict__ smem) {
+  const int pj = local / kProjParts, part = local % kProjParts;
+  const int G = a.G, dim = a.dim;
+  const int tid = threadIdx.x;
+  const int sub = tid % G, rl = tid / G, rpp = kBlock / G;
+  const int c = sub * V;
+  const bool col_ok = c < dim;
+  const int l = a.proj_lookup[pj];
+  const er_lookup_desc d = a.descs[l];
+  const OwnLookup lk = a.lookups[l];
+  // (uniform index made visibly uniform: the argument array is then read with scalar loads)
+  const er_grad_group& gg = ma.gg[__builtin_amdgcn_readfirstlane(static_cast<int>(lk.gg))];
+  const int rows_per_part = static_cast<int>(ceil_div(d.n_rows, kProjParts));
+  const int r0 = part * rows_per_part;
+  const int r1 = r0 + rows_per_part < d.n_rows ? r0 + rows_per_part : d.n_rows;
+  Vec<V> acc;
+  acc.zero();
+  float cnt = 0.f;
+  for (int r = r0 + rl; r < r1; r += rpp) {
+    const int64_t id = d.ids[r];
+    bool ok = id == 0;  // (rows == 1: the only valid id)
+    if (d.weights != nullptr && d.combiner != ER_COMBINER_SUM && !(d.weights[r] > 0.f)) ok = false;
+    if (!ok || !col_ok) continue;
+    const float sc = own_scale(lk, r);
+    const Vec<V> g = own_finish<V>(gg, lk.tmask, r, lk.out_col + c, c);
+    acc.add_scaled(g, sc);
+    cnt = cnt + 1.f;
+  }
+  // combine the row lanes of every column in a fixed order
+  float* s_acc = smem;                 // [rpp][dim]
+  float* s_cnt = smem + rpp * dim;     // [rpp]
+  if (col_ok) acc.store(s_acc + static_cast<size_t>(rl) * dim + c);
+  if (sub == 0) s_cnt[rl] = cnt;
+  __syncthreads();
+  // the partials cross workgroups INSIDE the launch.  A release fence here would write back the XCD L2's dirty lines - and
+  // the tile workgroups next door are dirtying megabytes of table rows.  Instead the partials are stored and loaded with
+  // system-scope atomics (write-through / cache-bypassing: MI355X_MICROARCH.md "valid forms"), the stores drained
+  // (s_waitcnt) before the arrival ticket, itself a relaxed agent-scope atomic.
+  float* mine = a.proj_partial + (static_cast<int64_t>(pj) * kProjParts + part) * (dim + 1);
+  if (tid < dim) {
+    float t = 0.f;
+    for (int q = 0; q < rpp; ++q) t = t + s_acc[static_cast<size_t>(q) * dim + tid];
+    __hip_atomic_store(mine + tid, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  if (tid == kBlock - 1) {
+    float t = 0.f;
+    for (int q = 0; q < rpp; ++q) t = t + s_cnt[q];
+    __hip_atomic_store(mine + dim, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores have reached memory
+  __syncthreads();                                     // ... and every wave's
+  __shared__ int s_last;
+  if (tid == 0) {
+    const uint32_t t = __hip_atomic_fetch_add(a.proj_ticket + pj, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = (t % kProjParts) == kProjParts - 1 ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  // every partial requested at once (one round trip), then combined from LDS in a fixed order
+  const float* all = a.proj_partial + static_cast<int64_t>(pj) * kProjParts * (dim + 1);
+  float* s_all = smem;  // [kProjParts][dim + 1] (the row-lane sums above are consumed)
+  for (int i = tid; i < kProjParts * (dim + 1); i += kBlock)
+    s_all[i] = __hip_atomic_load(all + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __syncthreads();
+  if (tid >= G || !col_ok) return;
+  float g[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) g[j] = 0.f;
+  float n_valid = 0.f;
+  for (int k = 0; k < kProjParts; ++k) {
+#pragma unroll
+    for (int j = 0; j < V; ++j) g[j] = g[j] + s_all[k * (dim + 1) + c + j];
+    n_valid = n_valid + s_all[k * (dim + 1) + dim];
+  }
+  if (n_valid == 0.f) return;  // no id of the batch read the row: TensorFlow's IndexedSlices has no entry for it
+  const ReduceOut ro{0, nullptr, nullptr, nullptr, nullptr, 0};
+  finish_run<V>(a.tab, ma.opt_kind, ma.hyper, ro, static_cast<uint32_t>(d.key_base), 0, sub, c, dim, g);
+}
+
+__global__ void __launch_bounds__(kBlock)
+emb_bwd_own_kernel(OwnMulti ma) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int bid = blockIdx.x;
+  if (bid < ma.start[ma.n]) {
+    int i = 0;
+    while (i + 1 < ma.n && bid >= ma.start[i + 1]) ++i;
+    const OwnArgs& a = ma.a[i];
+    if (a.V == 4) own_tile_body<4>(bid - ma.start[i], ma, a, smem);
+    else own_tile_body<1>(bid - ma.start[i], ma, a, smem);
+    return;
+  }
+  const int pb = bid - ma.start[ma.n];
+  int i = 0;
+  while (i + 1 < ma.n && pb >= ma.proj_start[i + 1]) ++i;
+  const OwnArgs& a = ma.a[i];
+  if (a.V == 4) own_proj_body<4>(pb - ma.proj_start[i], ma, a, smem);
+  else own_proj_body<1>(pb - ma.proj_start[i], ma, a, smem);
+}
+
+// The catch-up of a step's rows from the per-lookup lists of distinct keys the fused front's sort leaves (ukeys_seg:
+// lookup l's keys at [ent_base[l], ent_base[l] + seg_count[l])): catch_up_closed_body's arithmetic, one lane group per
+// potential key (those past their lookup's count leave at once), no cross-lookup scan and no route launch.  The last
+// workgroup of a group takes its one-row tables, which the fused front keeps out of the sort.
+struct CatchHeadsArgs {
+  const uint32_t* ukeys_seg;
+  const uint32_t* seg_count;
+  const int64_t* ent_base;
+  int n_lookups;
+  int64_t n;
+  RowUpdate tab;
+  DecayAux aux;
+  int dim, G, V;
+  const uint32_t* extra_keys;  // one-row tables' keys (or nullptr)
+  int n_extra;
+  int cap_shift;               // >= 0: every lookup holds 2^cap_shift entries
+};
+struct CatchHeadsMulti {
+  int n;
+  int start[kMaxMulti + 1];
+  const er_opt_hyper* hyper;
+  CatchHeadsArgs a[kMaxMulti];
+};
+
+template <int V>
+__device__ __forceinline__ void catch_up_row(const CatchHeadsArgs& a, uint32_t key, int c, int32_t t, float eps) {
+  const int32_t s_begin = a.tab.last_step[key] + 1;
+  if (s_begin >= t) return;
+  const int64_t off = static_cast<int64_t>(key) * a.dim + c;
+  float var[V], m[V], v[V];
+  ld_vec<V>(m, a.tab.m + off);
+  ld_vec<V>(v, a.tab.v + off);
+  bool live = false;
+#pragma unroll
+  for (int j = 0; j < V; ++j) live = live || (m[j] != 0.f) || (v[j] != 0.f);
+  if (live) {
+    ld_vec<V>(var, a.tab.var + off);
+    replay_closed<V>(var, m, v, a.aux, s_begin, t, eps);
+    st_vec<V>(a.tab.var + off, var);
+    st_vec<V>(a.tab.m + off, m);
+    st_vec<V>(a.tab.v + off, v);
+  }
+  if (c == 0) a.tab.last_step[key] = t - 1;
+}
+
+template <int V>
+__device__ __forceinline__ void catch_heads_body(int bid, const CatchHeadsArgs& a, const er_opt_hyper* __restrict__ hyper) {
+  __shared__ int s_base[kOwnMaxLookups + 1], s_cnt[kOwnMaxLookups + 1];
+  const int tid = threadIdx.x;
+  const int ppb = kBlock / a.G;  // potential keys per workgroup
+  const int c = (tid % a.G) * V;
+  const int64_t n_blocks = ceil_div(a.n, ppb);
+  if (bid >= n_blocks) {  // the group's one-row tables
+    const int h = tid / a.G;
+    if (h < a.n_extra && c < a.dim)
+      catch_up_row<V>(a, a.extra_keys[h], c, static_cast<int32_t>(*a.tab.step_counter - 1), pin_scalar(hyper->eps));
+    return;
+  }
+  // (the key is requested before anything else: the lookup search and the count check need no memory round trip after it)
+  const int64_t p = static_cast<int64_t>(bid) * ppb + tid / a.G;
+  const uint32_t key = p < a.n ? a.ukeys_seg[p] : kInvalidKey;
+  if (a.cap_shift >= 0) {  // (uniform) equal power-of-two capacities: no table, no barrier
+    if (p >= a.n || c >= a.dim) return;
+    const int l = static_cast<int>(p >> a.cap_shift);
+    if (p - (static_cast<int64_t>(l) << a.cap_shift) >= static_cast<int64_t>(a.seg_count[l])) return;
+  } else {
+    for (int i = tid; i <= a.n_lookups; i += kBlock) {
+      s_base[i] = static_cast<int>(a.ent_base[i]);
+      s_cnt[i] = i < a.n_lookups ? static_cast<int>(a.seg_count[i]) : 0;
+    }
+    __syncthreads();
+    if (p >= a.n || c >= a.dim) return;
+    int lo = 0, hi = a.n_lookups;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (s_base[mid] <= p) lo = mid; else hi = mid;
+    }
+    if (p - s_base[lo] >= s_cnt[lo]) return;
+  }
+  catch_up_row<V>(a, key, c, static_cast<int32_t>(*a.tab.step_counter - 1), pin_scalar(hyper->eps));
+}
+
+__global__ void __launch_bounds__(kBlock)
+emb_catch_up_heads_kernel(CatchHeadsMulti ma) {
+  int i = 0;
+  while (i + 1 < ma.n && static_cast<int>(blockIdx.x) >= ma.start[i + 1]) ++i;
+  const CatchHeadsArgs& a = ma.a[i];
+  const int bid = blockIdx.x - ma.start[i];
+  if (a.V == 4) catch_heads_body<4>(bid, a, ma.hyper);
+  else catch_heads_body<1>(bid, a, ma.hyper);
+}
+
 // Row-wise optimizer on ready-made row sums (er_emb_apply_unique): one lane group per de-duplicated key.
 template <int V>
 __global__ void __launch_bounds__(kBlock)
@@ -1146,32 +1588,35 @@ __device__ __forceinline__ void seg_cmpx(C& a, C& b, bool up) {
 // inside one lookup that order is (owner, local row), which is all the all-to-all needs; NARROW then packs
 // owner * shard_rows + local row, and with HEADS the kernel also counts the distinct keys per (lookup, owner)
 // (seg_count[lookup * 64 + owner]) for emb_route_seg_routed_kernel.
-template <int E, bool HEADS, bool NARROW>
-__global__ void __launch_bounds__(kSegSortMax / 8)
-emb_segment_sort_kernel(const uint32_t* __restrict__ keys_in, const int64_t* __restrict__ ent_base,
+// INLINE (the fused front of a single-GPU step, er_emb_front): the entries are built HERE from the lookups' ids (dense-mode
+// lookups only: entry i of lookup lk is its output row i) instead of being read from keys_in - emb_bwd_build_kernel's rule
+// for a valid id - and entries into ONE-ROW tables (the RawFeature projections: every valid id is row 0) sort as missing
+// when skip_one_row is set: the fused backward reduces those tables by columns (emb_bwd_own_kernel), not through the sort.
+template <int E, bool HEADS, bool NARROW, bool INLINE>
+__device__ __forceinline__ void seg_sort_body(int lk, const uint32_t* __restrict__ keys_in, const int64_t* __restrict__ ent_base,
                         const er_lookup_desc* __restrict__ descs, int P, Route rt, uint32_t* __restrict__ keys_out,
                         uint32_t* __restrict__ vals_out, uint32_t* __restrict__ flags_out,
-                        uint32_t* __restrict__ hidx_out, uint32_t* __restrict__ seg_count) {
+                        uint32_t* __restrict__ hidx_out, uint32_t* __restrict__ seg_count, int skip_one_row,
+                        unsigned long long* sk_raw, uint32_t* __restrict__ ukeys_seg = nullptr) {
   typedef typename std::conditional<NARROW, uint32_t, unsigned long long>::type C;
-  extern __shared__ __attribute__((aligned(16))) unsigned long long sk_raw[];  // [P] composites
   C* sk = reinterpret_cast<C*>(sk_raw);
   constexpr int L = E == 8 ? 3 : (E == 4 ? 2 : 1);
   static_assert(E == 2 || E == 4 || E == 8, "E");
   const int t = threadIdx.x;
   const int i0 = t * E;
-  const int64_t base = ent_base[blockIdx.x];
-  const int cnt = static_cast<int>(ent_base[blockIdx.x + 1] - base);
+  const int64_t base = ent_base[lk];
+  const int cnt = static_cast<int>(ent_base[lk + 1] - base);
   const int logP = __ffs(P) - 1;
   const bool routed = rt.local_base != nullptr;
   const uint32_t stride = static_cast<uint32_t>(rt.shard_stride);
   // NARROW: `rel` in [0, rows) enumerates the lookup's keys in key order; rel == rows is a missing id
   uint32_t key_base = 0u, rows = 0u, srows = 1u;
   if (NARROW) {
-    const er_lookup_desc& d = descs[blockIdx.x];
+    const er_lookup_desc& d = descs[lk];
     if (routed) {
       srows = static_cast<uint32_t>((d.rows + rt.world - 1) / rt.world);  // rows of one rank's shard of this table
       rows = srows * static_cast<uint32_t>(rt.world);
-      key_base = static_cast<uint32_t>(rt.local_base[blockIdx.x]);
+      key_base = static_cast<uint32_t>(rt.local_base[lk]);
     } else {
       rows = static_cast<uint32_t>(d.rows);
       key_base = static_cast<uint32_t>(d.key_base);
@@ -1193,6 +1638,19 @@ emb_segment_sort_kernel(const uint32_t* __restrict__ keys_in, const int64_t* __r
     const int i = i0 + e;
     if (i >= cnt) {
       x[e] = static_cast<C>(~0ull);
+    } else if (INLINE) {
+      const er_lookup_desc& d = descs[lk];
+      const int64_t id = d.ids[i];
+      bool ok = !(id < 0 || id >= d.rows);
+      if (d.weights != nullptr && d.combiner != ER_COMBINER_SUM && !(d.weights[i] > 0.f)) ok = false;
+      if (skip_one_row && d.rows == 1) ok = false;
+      if (NARROW) {
+        const uint32_t rel = ok ? static_cast<uint32_t>(id) : static_cast<uint32_t>(d.rows);
+        x[e] = static_cast<C>((rel << logP) | static_cast<uint32_t>(i));
+      } else {
+        const uint32_t key = ok ? static_cast<uint32_t>(d.key_base + id) : kInvalidKey;
+        x[e] = static_cast<C>((static_cast<unsigned long long>(key) << 32) | static_cast<unsigned>(base + i));
+      }
     } else if (NARROW) {
       const uint32_t key = keys_in[base + i];
       uint32_t rel = rows;
@@ -1309,11 +1767,14 @@ emb_segment_sort_kernel(const uint32_t* __restrict__ keys_in, const int64_t* __r
       if (i < cnt) {
         flags_out[base + i] = f[e];
         hidx_out[base + i] = run;
+        // (the fused front: the lookup's distinct keys, compact inside its own segment - er_emb_front's catch-up reads
+        // [base, base + seg_count[lookup]) of it, no cross-lookup scan and no launch for one)
+        if (ukeys_seg != nullptr && f[e]) ukeys_seg[base + run] = key_of(x[e]);
       }
       run += f[e];
     }
     if (!routed) {
-      if (t == 0) seg_count[blockIdx.x] = total;
+      if (t == 0) seg_count[lk] = total;
     } else {
       __shared__ uint32_t owner_cnt[64];
       if (t < 64) owner_cnt[t] = 0u;
@@ -1322,9 +1783,45 @@ emb_segment_sort_kernel(const uint32_t* __restrict__ keys_in, const int64_t* __r
       for (int e = 0; e < E; ++e)
         if (f[e]) atomicAdd(&owner_cnt[key_of(x[e]) / stride], 1u);  // integer: exact, order-independent
       __syncthreads();
-      if (t < 64) seg_count[blockIdx.x * 64 + t] = owner_cnt[t];
+      if (t < 64) seg_count[lk * 64 + t] = owner_cnt[t];
     }
   }
+}
+
+template <int E, bool HEADS, bool NARROW>
+__global__ void __launch_bounds__(kSegSortMax / 8)
+emb_segment_sort_kernel(const uint32_t* __restrict__ keys_in, const int64_t* __restrict__ ent_base,
+                        const er_lookup_desc* __restrict__ descs, int P, Route rt, uint32_t* __restrict__ keys_out,
+                        uint32_t* __restrict__ vals_out, uint32_t* __restrict__ flags_out,
+                        uint32_t* __restrict__ hidx_out, uint32_t* __restrict__ seg_count) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long sk_raw[];  // [P] composites
+  seg_sort_body<E, HEADS, NARROW, false>(blockIdx.x, keys_in, ent_base, descs, P, rt, keys_out, vals_out, flags_out, hidx_out,
+                                         seg_count, 0, sk_raw);
+}
+
+// The front of a single-GPU training step in ONE launch (er_emb_front): workgroup lk < n_lookups builds, sorts and
+// head-flags lookup lk's entries (seg_sort_body, INLINE); the workgroups behind them compute the closed-form replay's
+// per-launch table A for lag 1 (decay_tables_kernel's job: the step counter is stable here - the prologue that increments
+// it is an earlier launch - and the catch-up that reads A is a later one).
+template <int E, bool NARROW>
+__global__ void __launch_bounds__(kSegSortMax / 8)
+emb_front_sort_kernel(const int64_t* __restrict__ ent_base, const er_lookup_desc* __restrict__ descs, int n_lookups, int P,
+                      uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint32_t* __restrict__ flags_out,
+                      uint32_t* __restrict__ hidx_out, uint32_t* __restrict__ seg_count, int skip_one_row, DecayTabDev tabs,
+                      const float* __restrict__ hist, const int64_t* __restrict__ counter, uint32_t* __restrict__ ukeys_seg) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long sk_raw[];  // [P] composites
+  if (static_cast<int>(blockIdx.x) >= n_lookups) {
+    const int k = (static_cast<int>(blockIdx.x) - n_lookups) * static_cast<int>(blockDim.x >> 6) + static_cast<int>(threadIdx.x >> 6) + 1;
+    if (k > tabs.K) return;
+    const int64_t s_end = *counter - 1;  // lag 1: the rows are brought to the step before this one
+    const float mine = decay_sum_wave(tabs, hist, s_end - 1 - k, k);
+    const int lane = threadIdx.x & 63;
+    float* A = tabs.A + static_cast<int64_t>(kDecayKMax) * kDecayLd;  // (lag 1's table: decay_aux_for)
+    if (lane < kDecayLd) A[static_cast<int64_t>(k - 1) * kDecayLd + lane] = mine;
+    return;
+  }
+  seg_sort_body<E, true, NARROW, true>(blockIdx.x, nullptr, ent_base, descs, P, Route{1, 0, nullptr}, keys_out, vals_out,
+                                       flags_out, hidx_out, seg_count, skip_one_row, sk_raw, ukeys_seg);
 }
 
 // Routed counterpart of emb_route_seg_kernel.  The de-duplicated keys must come out grouped by owner (the
@@ -2010,6 +2507,16 @@ struct er_emb_group {
   size_t sort_temp_bytes = 0;
   void* scan_temp = nullptr;
   size_t scan_temp_bytes = 0;
+  // er_emb_front / er_emb_bwd_fused (the fused single-GPU step)
+  uint64_t front_epoch = ~0ull;   // sort_epoch of the last sort made by er_emb_front
+  bool front_skip = false;        // ... which kept the one-row tables' entries out of the sort
+  uint32_t* d_extra_keys = nullptr;  // keys of the one-row tables (always brought current by the fused catch-up)
+  int32_t* d_proj_lookup = nullptr;  // their lookup indices
+  int n_proj = -1;                   // -1: not collected yet
+  float* d_proj_partial = nullptr;
+  uint32_t* d_proj_ticket = nullptr;
+  void* d_own_lookups = nullptr;           // er::OwnLookup[n]: the fused backward's per-lookup gather records
+  std::vector<unsigned char> h_own_lookups;  // host shadow (re-uploaded when the finish descriptors' geometry changes)
 };
 
 namespace {
@@ -2196,7 +2703,8 @@ int er_emb_group_destroy(er_emb_group* g) {
   }
   void* ptrs[] = {g->d_descs, g->d_blk_start, g->d_ent_base, g->keys_in, g->keys_out, g->vals_in, g->vals_out,
                   g->ent_gptr, g->ent_scale, g->tile_first, g->tile_last, g->head_flags, g->head_index, g->sort_temp, g->scan_temp,
-                  g->d_local_base, g->seg_count, g->d_overflow};
+                  g->d_local_base, g->seg_count, g->d_overflow, g->d_extra_keys, g->d_proj_lookup, g->d_proj_partial,
+                  g->d_proj_ticket, g->d_own_lookups};
   for (void* q : ptrs) (void)hipFree(q);
   delete g;
   return 0;
@@ -2337,10 +2845,19 @@ static int emb_group_heads(er_emb_group* g, int32_t* n_unique, hipStream_t s) {
   return 0;
 }
 
+// a sort made by er_emb_front with skip_one_row leaves the one-row tables' entries out: only er_emb_bwd_fused may reduce it
+static int front_sort_guard(const er_emb_group* g, const char* who) {
+  const er_emb_group* src = g->src ? g->src : g;
+  ER_REQUIRE(!(src->front_skip && src->front_epoch == src->sort_epoch),
+             "%s: this step's sort was made by er_emb_front(skip_one_row = 1): reduce it with er_emb_bwd_fused", who);
+  return 0;
+}
+
 static int emb_group_run(er_emb_group* g, int opt_kind, const er_opt_hyper* hyper, int mode, uint32_t* out_keys,
                          float* out_grads, hipStream_t s, int out_ld = 0) {
   const int64_t N = group_entries(g);
   if (N == 0) return 0;
+  if (int rc = front_sort_guard(g, "er_emb_bwd_*")) return rc;
   const int T = g->tile_entries;
   const int n_tiles = static_cast<int>(er::ceil_div(N, T));
   er::RowUpdate tab{g->var, g->m, g->v, g->bitmap, g->last_step, g->step_counter};
@@ -2476,6 +2993,7 @@ static int emb_groups_run_multi(er_emb_group* const* groups, int n, int opt_kind
     g->sorted_valid = false;
     const int64_t N = group_entries(g);
     if (N == 0) continue;
+    if (int rc = front_sort_guard(g, "er_emb_bwd_update_multi")) return rc;
     const er_emb_group* src = g->src;
     er::RunArgs& a = ma.a[ma.n];
     a.skeys = src->keys_out; a.svals = src->vals_out; a.ent_gptr = g->ent_gptr; a.ent_scale = g->ent_scale;
@@ -2564,6 +3082,276 @@ static int launch_decay_tables(er_emb_group* const* groups, int n, int lag, hipS
   }
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// The fused single-GPU step (round 4): er_emb_front = build + sort + run heads (+ the closed-form replay's table) in ONE
+// launch per sort leader, then the catch-up straight from the heads; er_emb_bwd_fused = finish + reduce + row update in
+// ONE launch.  Returns 3 ("not eligible", er_last_error says why) when a group needs what only the general path offers.
+// ------------------------------------------------------------------------------------------------
+#define ER_ELIGIBLE(cond, ...)       \
+  do {                               \
+    if (!(cond)) {                   \
+      er::set_error(__VA_ARGS__);    \
+      return 3;                      \
+    }                                \
+  } while (0)
+
+// >= 0 when every lookup of the group holds the same power-of-two number of entries
+static int group_cap_shift(const er_emb_group* g) {
+  const int64_t cap = g->h_descs[0].offsets ? g->h_descs[0].max_nnz : g->h_descs[0].n_rows;
+  if (cap <= 0 || (cap & (cap - 1)) != 0) return -1;
+  for (int i = 1; i < g->n; ++i)
+    if ((g->h_descs[i].offsets ? g->h_descs[i].max_nnz : g->h_descs[i].n_rows) != cap) return -1;
+  int sh = 0;
+  while ((1LL << sh) < cap) ++sh;
+  return sh;
+}
+
+static int front_collect_one_row(er_emb_group* g) {
+  if (g->n_proj >= 0) return 0;
+  std::vector<uint32_t> keys;
+  std::vector<int32_t> idx;
+  for (int i = 0; i < g->n; ++i)
+    if (g->h_descs[i].rows == 1) {
+      keys.push_back(static_cast<uint32_t>(g->h_descs[i].key_base));
+      idx.push_back(i);
+    }
+  ER_REQUIRE(keys.size() <= 64, "er_emb_front: more than 64 one-row tables in a table group");
+  g->n_proj = static_cast<int>(keys.size());
+  if (g->n_proj > 0) {
+    ER_CHECK_HIP(hipMalloc(&g->d_extra_keys, sizeof(uint32_t) * keys.size()));
+    ER_CHECK_HIP(hipMalloc(&g->d_proj_lookup, sizeof(int32_t) * idx.size()));
+    ER_CHECK_HIP(hipMalloc(&g->d_proj_partial, sizeof(float) * keys.size() * er::kProjParts * (g->dim + 1)));
+    ER_CHECK_HIP(hipMalloc(&g->d_proj_ticket, sizeof(uint32_t) * keys.size()));
+    ER_CHECK_HIP(hipMemcpy(g->d_extra_keys, keys.data(), sizeof(uint32_t) * keys.size(), hipMemcpyHostToDevice));
+    ER_CHECK_HIP(hipMemcpy(g->d_proj_lookup, idx.data(), sizeof(int32_t) * idx.size(), hipMemcpyHostToDevice));
+    ER_CHECK_HIP(hipMemset(g->d_proj_ticket, 0, sizeof(uint32_t) * keys.size()));
+  }
+  return 0;
+}
+
+int er_emb_front(er_emb_group* const* groups, int n, int skip_one_row, const er_opt_hyper* hyper, er_stream_t stream) {
+  ER_REQUIRE(groups && n >= 1 && n <= er::kMaxMulti, "er_emb_front: bad arguments (1 <= n <= %d)", er::kMaxMulti);
+  hipStream_t s = er::as_stream(stream);
+  // eligibility first: nothing is launched for a set of groups the fused path does not cover
+  for (int i = 0; i < n; ++i) {
+    er_emb_group* g = groups[i];
+    ER_REQUIRE(g, "er_emb_front: null group %d", i);
+    ER_ELIGIBLE(g->d_local_base == nullptr && g->world == 1 && g->n_active < 0, "er_emb_front: group %d is routed / partly active", i);
+    ER_ELIGIBLE(!g->has_ragged && g->seg_sort_pow2 > 0, "er_emb_front: group %d has ragged lookups or no per-lookup sort", i);
+    ER_ELIGIBLE(!g->last_step || (g->tabs && g->G <= er::kWave), "er_emb_front: group %d replays its decay step by step", i);
+    ER_ELIGIBLE(g->n <= er::kOwnMaxLookups, "er_emb_front: group %d has more than %d lookups", i, er::kOwnMaxLookups);
+    if (g->last_step) ER_REQUIRE(hyper, "er_emb_front: the catch-up needs the step's er_opt_hyper");
+    if (int rc = front_collect_one_row(g)) return rc;
+  }
+  bool tables_done = false;
+  for (int i = 0; i < n; ++i) {
+    er_emb_group* g = groups[i];
+    er_emb_group* l = g->leader;
+    bool follows = false;
+    if (l && emb_group_same_keys(g, l))
+      for (int j = 0; j < i; ++j) follows = follows || groups[j] == l;
+    if (follows && l->front_epoch == l->sort_epoch && l->front_skip == (skip_one_row != 0)) {
+      g->src = l;
+      g->adopted_epoch = l->sort_epoch;
+      g->sorted_valid = true;
+      continue;
+    }
+    g->src = g;
+    ++g->sort_epoch;
+    const int P = g->seg_sort_pow2;
+    const bool with_tables = g->tabs != nullptr && !tables_done;
+    er::DecayTabDev tabs{};
+    if (with_tables) tabs = g->tabs->dev;
+    const int E = P > 4096 ? 8 : 4;
+    const int threads = P / E;
+    const int table_blocks = with_tables ? static_cast<int>(er::ceil_div(static_cast<int64_t>(tabs.K) * er::kWave, threads)) : 0;
+    const size_t lds = sizeof(unsigned long long) * static_cast<size_t>(P);
+#define ER_FRONT_SORT(EE, NRW)                                                                                           \
+  hipLaunchKernelGGL((er::emb_front_sort_kernel<EE, NRW>), dim3(g->n + table_blocks), dim3(threads), lds, s, g->d_ent_base, \
+                     g->d_descs, g->n, P, g->keys_out, g->vals_out, g->head_flags, g->head_index, g->seg_count,         \
+                     skip_one_row ? 1 : 0, tabs, with_tables ? g->tabs->hist : nullptr, with_tables ? g->tabs->counter : nullptr, \
+                     g->keys_in)
+    if (E == 8) { if (g->seg_narrow) ER_FRONT_SORT(8, true); else ER_FRONT_SORT(8, false); }
+    else { if (g->seg_narrow) ER_FRONT_SORT(4, true); else ER_FRONT_SORT(4, false); }
+#undef ER_FRONT_SORT
+    ER_LAUNCH_CHECK();
+    tables_done = tables_done || with_tables;
+    g->heads_epoch = g->sort_epoch;
+    g->front_epoch = g->sort_epoch;
+    g->front_skip = skip_one_row != 0;
+    g->sorted_valid = true;
+  }
+  // catch-up from the heads
+  er::CatchHeadsMulti cm;
+  cm.n = 0;
+  cm.start[0] = 0;
+  cm.hyper = hyper;
+  const er_decay_tables* first_tabs = nullptr;
+  for (int i = 0; i < n; ++i) {
+    er_emb_group* g = groups[i];
+    if (!g->last_step) continue;
+    if (!first_tabs) first_tabs = g->tabs;
+    ER_REQUIRE(g->tabs == first_tabs, "er_emb_front: the groups of one call must share their decay tables");
+    const er_emb_group* src = g->src;
+    er::CatchHeadsArgs& a = cm.a[cm.n];
+    a.ukeys_seg = src->keys_in;  // (the unsorted key array is free in the fused front: the sort builds its entries itself)
+    a.seg_count = src->seg_count; a.ent_base = src->d_ent_base; a.n_lookups = src->n; a.n = group_entries(g);
+    a.tab = er::RowUpdate{g->var, g->m, g->v, g->bitmap, g->last_step, g->step_counter};
+    a.aux = decay_aux_for(g, 1);
+    a.dim = g->dim; a.G = g->G; a.V = g->V;
+    a.extra_keys = skip_one_row ? g->d_extra_keys : nullptr;
+    a.n_extra = skip_one_row ? g->n_proj : 0;
+    a.cap_shift = group_cap_shift(src);
+    // (one lane group per sorted position; + one workgroup for the one-row tables: at most 64 of them, G <= 4 lanes each...)
+    ER_REQUIRE(a.n_extra * g->G <= er::kBlock, "er_emb_front: group %d: %d one-row tables of %d lanes exceed a workgroup", i, a.n_extra, g->G);
+    cm.start[cm.n + 1] = cm.start[cm.n] + static_cast<int>(er::ceil_div(a.n, er::kBlock / g->G)) + (a.n_extra > 0 ? 1 : 0);
+    ++cm.n;
+  }
+  if (cm.n > 0) {
+    ER_REQUIRE(tables_done, "er_emb_front: no sort leader carried the decay tables");
+    hipLaunchKernelGGL(er::emb_catch_up_heads_kernel, dim3(cm.start[cm.n]), dim3(er::kBlock), 0, s, cm);
+    ER_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+// probe hook: 16 wall-clock stamps (100 MHz) per workgroup of the next er_emb_bwd_fused launches into `p` (nullptr: off);
+// tools/own_probe.py reads them.  Not part of the product path.
+static unsigned long long* g_own_dbg = nullptr;
+int er_debug_stamps(unsigned long long* p) { g_own_dbg = p; return 0; }
+
+int er_emb_bwd_fused(er_emb_group* const* groups, int n, const er_grad_group* finish, int n_finish, int opt_kind,
+                     const er_opt_hyper* hyper, er_stream_t stream) {
+  ER_REQUIRE(groups && finish && hyper && n >= 1 && n <= er::kMaxMulti && n_finish >= 1 && n_finish <= er::kOwnMaxGG,
+             "er_emb_bwd_fused: bad arguments (1 <= n <= %d groups, 1 <= n_finish <= %d)", er::kMaxMulti, er::kOwnMaxGG);
+  ER_REQUIRE(opt_kind >= ER_OPT_SGD && opt_kind <= ER_OPT_ADAGRAD, "er_emb_bwd_fused: unknown optimizer %d", opt_kind);
+  hipStream_t s = er::as_stream(stream);
+  er::OwnMulti ma;
+  er::RunMulti fx;
+  fx.n = 0;
+  fx.start[0] = 0;
+  fx.opt_kind = opt_kind;
+  fx.hyper = hyper;
+  ma.n = 0;
+  ma.start[0] = 0;
+  ma.proj_start[0] = 0;
+  ma.opt_kind = opt_kind;
+  ma.hyper = hyper;
+  ma.n_gg = n_finish;
+  ma.dbg = g_own_dbg;
+  for (int k = 0; k < n_finish; ++k)
+    ER_REQUIRE(finish[k].dout && finish[k].out && finish[k].n_terms >= 0 && finish[k].n_terms <= 4,
+               "er_emb_bwd_fused: finish descriptor %d: bad arguments", k);
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(s, &cap);
+  size_t lds = 0;
+  for (int i = 0; i < n; ++i) {
+    er_emb_group* g = groups[i];
+    ER_REQUIRE(g, "er_emb_bwd_fused: null group %d", i);
+    const er_emb_group* src = g->src;
+    ER_REQUIRE(g->sorted_valid && src && src->front_epoch == src->sort_epoch,
+               "er_emb_bwd_fused: call er_emb_front for this step first (group %d)", i);
+    if (opt_kind == ER_OPT_ADAM || opt_kind == ER_OPT_LAZY_ADAM) ER_REQUIRE(g->m && g->v, "er_emb_bwd_fused: Adam needs m and v");
+    if (opt_kind == ER_OPT_ADAGRAD) ER_REQUIRE(g->v, "er_emb_bwd_fused: Adagrad needs the accumulator in v");
+    ER_REQUIRE(opt_kind != ER_OPT_ADAM || g->last_step, "er_emb_bwd_fused: ER_OPT_ADAM needs lazy dense decay (the sweep form: er_emb_bwd_update)");
+    // the lookups' gather records: which descriptor finishes each lookup's output block, and which of its terms cover it
+    std::vector<er::OwnLookup> recs(g->n);
+    for (int l = 0; l < g->n; ++l) {
+      const er_lookup_desc& d = g->h_descs[l];
+      int k_found = -1;
+      for (int k = 0; k < n_finish; ++k)
+        if (finish[k].dout == d.out && finish[k].ld == d.out_stride) k_found = k;
+      ER_REQUIRE(k_found >= 0, "er_emb_bwd_fused: group %d lookup %d: no finish descriptor for its gradient buffer", i, l);
+      const er_grad_group& fg = finish[k_found];
+      ER_REQUIRE(d.n_rows <= fg.batch && d.out_col + d.dim <= fg.width,
+                 "er_emb_bwd_fused: group %d lookup %d lies outside its gradient buffer", i, l);
+      unsigned mask = 0;
+      for (int t = 0; t < fg.n_terms; ++t) {
+        const er_grad_term& q = fg.terms[t];
+        const bool inside = d.out_col >= q.col0 && d.out_col + d.dim <= q.col0 + q.width;
+        const bool outside = d.out_col + d.dim <= q.col0 || d.out_col >= q.col0 + q.width;
+        ER_REQUIRE(inside || outside, "er_emb_bwd_fused: group %d lookup %d: a deferred term covers part of its columns", i, l);
+        if (!inside) continue;
+        if (q.kind == ER_GRAD_TERM_FM) {
+          ER_REQUIRE(q.dim == d.dim && (d.out_col - q.col0) % q.dim == 0,
+                     "er_emb_bwd_fused: group %d lookup %d is not one field of the FM term over its columns", i, l);
+          mask |= 0x10u << t;
+        }
+        mask |= 1u << t;
+      }
+      er::OwnLookup& r = recs[l];
+      std::memset(&r, 0, sizeof(r));
+      r.weights = d.weights;
+      r.base = static_cast<int32_t>(l == 0 ? 0 : 0);
+      r.out_col = d.out_col;
+      r.combiner = d.combiner;
+      r.gg = static_cast<int8_t>(k_found);
+      r.tmask = static_cast<uint8_t>(mask);
+    }
+    {  // entry offsets (dense-mode lookups: n_rows entries each)
+      int64_t base = 0;
+      for (int l = 0; l < g->n; ++l) {
+        recs[l].base = static_cast<int32_t>(base);
+        base += g->h_descs[l].offsets ? g->h_descs[l].max_nnz : g->h_descs[l].n_rows;
+      }
+    }
+    const size_t rec_bytes = sizeof(er::OwnLookup) * recs.size();
+    if (g->h_own_lookups.size() != rec_bytes || std::memcmp(g->h_own_lookups.data(), recs.data(), rec_bytes) != 0) {
+      ER_REQUIRE(cap == hipStreamCaptureStatusNone, "er_emb_bwd_fused: run one step eagerly before capturing (the plan is uploaded on first use)");
+      if (!g->d_own_lookups) ER_CHECK_HIP(hipMalloc(&g->d_own_lookups, sizeof(er::OwnLookup) * er::kOwnMaxLookups));
+      ER_CHECK_HIP(hipStreamSynchronize(s));  // (an earlier launch may still read the old records)
+      ER_CHECK_HIP(hipMemcpy(g->d_own_lookups, recs.data(), rec_bytes, hipMemcpyHostToDevice));
+      g->h_own_lookups.assign(reinterpret_cast<const unsigned char*>(recs.data()), reinterpret_cast<const unsigned char*>(recs.data()) + rec_bytes);
+    }
+    er::OwnArgs& a = ma.a[ma.n];
+    a.skeys = src->keys_out; a.svals = src->vals_out; a.n = group_entries(g);
+    a.descs = g->d_descs; a.ent_base = g->d_ent_base; a.lookups = static_cast<const er::OwnLookup*>(g->d_own_lookups);
+    a.n_lookups = g->n;
+    a.cap_shift = group_cap_shift(g);
+    a.dim = g->dim; a.G = g->G; a.V = g->V;
+    const int T = g->tile_entries;
+    a.n_tiles = static_cast<int>(er::ceil_div(a.n, T));
+    a.tab = er::RowUpdate{g->var, g->m, g->v, g->bitmap, g->last_step, g->step_counter};
+    a.tile_first = g->tile_first; a.tile_last = g->tile_last;
+    const bool proj = src->front_skip && g->n_proj > 0;
+    a.n_proj = proj ? g->n_proj : 0;
+    {  // the fix launch's arguments (emb_bwd_fix_multi_kernel: the three-launch path's kernel)
+      er::RunArgs& f = fx.a[fx.n];
+      f.skeys = src->keys_out; f.svals = src->vals_out; f.ent_gptr = nullptr; f.ent_scale = nullptr;
+      f.n = a.n; f.dim = g->dim; f.G = g->G; f.V = g->V; f.T = T; f.n_tiles = a.n_tiles;
+      f.tab = a.tab;
+      f.ro = er::ReduceOut{0, nullptr, nullptr, nullptr, nullptr, 0};
+      f.tile_first = g->tile_first; f.tile_last = g->tile_last;
+      const int fb = a.n_tiles > 1 ? static_cast<int>(er::ceil_div(static_cast<int64_t>(a.n_tiles) * g->G, er::kBlock)) : 0;
+      fx.start[fx.n + 1] = fx.start[fx.n] + fb;
+      ++fx.n;
+    }
+    a.proj_lookup = g->d_proj_lookup; a.proj_partial = g->d_proj_partial; a.proj_ticket = g->d_proj_ticket;
+    ma.start[ma.n + 1] = ma.start[ma.n] + a.n_tiles;
+    ma.proj_start[ma.n + 1] = ma.proj_start[ma.n] + a.n_proj * er::kProjParts;
+    size_t need = sizeof(float) * static_cast<size_t>(T) * g->dim + sizeof(uint32_t) * (T + 4) +
+                  sizeof(er::OwnLookup) * static_cast<size_t>(g->n) + sizeof(er_grad_group) * static_cast<size_t>(n_finish);
+    const size_t rpp = er::kBlock / g->G;
+    const size_t need_proj = sizeof(float) * (rpp * g->dim + rpp);
+    if (need_proj > need) need = need_proj;
+    if (need > lds) lds = need;
+    g->sorted_valid = false;
+    ++ma.n;
+  }
+  for (int k = 0; k < n_finish; ++k) ma.gg[k] = finish[k];
+  const int grid = ma.start[ma.n] + ma.proj_start[ma.n];
+  if (grid > 0) {
+    hipLaunchKernelGGL(er::emb_bwd_own_kernel, dim3(grid), dim3(er::kBlock), lds, s, ma);
+    ER_LAUNCH_CHECK();
+    if (fx.start[fx.n] > 0) {
+      hipLaunchKernelGGL(er::emb_bwd_fix_multi_kernel, dim3(fx.start[fx.n]), dim3(er::kBlock), 0, s, fx);
+      ER_LAUNCH_CHECK();
+    }
+  }
+  return 0;
+}
+#undef ER_ELIGIBLE
 
 int er_emb_catch_up(er_emb_group* g, const uint32_t* unique_keys, const int32_t* n_unique, const er_opt_hyper* hyper,
                     er_stream_t stream) {

@@ -6,6 +6,7 @@
 // Reference call sites: layers/fm.py:20-26, model/deepfm.py:62-63, model/dcn.py:32-45,
 // layers/keras/interaction.py:276-286, model/multi_tower_din.py:62-97, layers/mmoe.py:73-82.
 #include "er_common.h"
+#include "er_grad_finish.h"
 
 namespace er {
 
@@ -654,22 +655,7 @@ group_grad_finish_kernel(GradFinishMulti ma) {
   const int64_t b = idx / g.width;
   if (b >= g.batch) return;
   const int c = static_cast<int>(idx - b * g.width);
-  float* o = g.dout + b * g.ld + c;
-  float v = g.has_base ? *o : 0.f;
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    if (t >= g.n_terms) break;
-    const er_grad_term& q = g.terms[t];
-    if (c < q.col0 || c >= q.col0 + q.width) continue;
-    if (q.kind == ER_GRAD_TERM_ROWSUM) {
-      v = v + q.g[b * q.g_ld];
-    } else {  // ER_GRAD_TERM_FM
-      const int d = (c - q.col0) % q.dim;
-      v = v + q.g[b * q.g_ld + d] * (q.saved[b * q.dim + d] - g.out[b * g.ld + c]);
-    }
-  }
-  if (g.lambda != 0.f) v = v + g.lambda * g.out[b * g.ld + c];
-  *o = v;
+  g.dout[b * g.ld + c] = grad_finish_value(g, b, c);
 }
 
 // Several device-to-device copies in ONE launch (the parts of a device-resident batch that go into the step's static

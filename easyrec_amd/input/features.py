@@ -367,8 +367,17 @@ class DeviceFeatures(object):
     out['packed_has_strings'] = has_str
     return out
 
-  def transform(self):
-    """Device-side part of `_preprocess`: hash the packed id strings (K1)."""
+  def hash_job(self):
+    """hash_bucket_fast's arguments for the loaded batch's id strings, or None when the ids arrived hashed: the step
+    prologue runs the hash as part of its own launch (kernels.HipBackend.step_prologue) and transform(done=True) follows."""
+    if self._use_device_hash and self.hash_buckets is not None:
+      return (self.str_bytes, self.str_offsets, self.batch_size, self.hash_buckets, True, self.hash_ids)
+    return None
+
+  def transform(self, hashed=False):
+    """Device-side part of `_preprocess`: hash the packed id strings (K1).  hashed: the step prologue already did."""
+    if hashed:
+      return
     if self._use_device_hash and self.hash_buckets is not None:
       from easyrec_amd import kernels
       be = self._backend or kernels.hip()

@@ -1185,7 +1185,34 @@ class HipBackend(object):
   def group_grad_finish(self, groups):
     """groups: [(dout, out, lambda, has_base, [terms])], term = ('rowsum', g, col0, width) | ('fm', g, saved, col0,
     width, dim); g: [B] / [B, 1] / [B, dim] with unit inner stride.  One launch (er_group_grad_finish)."""
+    arr, _keep = self._grad_groups(groups)
+    self._ck(self.lib.er_group_grad_finish(arr, len(groups), _stream()), 'er_group_grad_finish')
+
+  # the fused single-GPU embedding step: er_emb_front (build + sort + heads [+ decay table] in one launch, catch-up from
+  # the heads) and er_emb_bwd_fused (finish + reduce + row update in one launch) - A/B switch
+  fused_emb = os.environ.get('EASYREC_AMD_FUSED_EMB', '1') != '0'
+
+  def emb_front(self, groups, hyper, skip_one_row):
+    """-> False when the groups need the general path (nothing launched)."""
+    n = len(groups)
+    gh = (ctypes.c_void_p * n)(*[g['handle'] for g in groups])
+    rc = self.lib.er_emb_front(gh, n, ctypes.c_int(int(bool(skip_one_row))), _p(hyper), _stream())
+    if rc == 3:
+      return False
+    self._ck(rc, 'er_emb_front')
+    return True
+
+  def emb_bwd_fused(self, groups, finish, opt_kind, hyper):
+    """finish: group_grad_finish's descriptors, one per feature-group gradient buffer the groups' lookups write."""
+    n = len(groups)
+    gh = (ctypes.c_void_p * n)(*[g['handle'] for g in groups])
+    arr, _keep = self._grad_groups(finish)
+    self._ck(self.lib.er_emb_bwd_fused(gh, n, arr, len(finish), ctypes.c_int(opt_kind), _p(hyper), _stream()),
+             'er_emb_bwd_fused')
+
+  def _grad_groups(self, groups):
     arr = (GradGroup * len(groups))()
+    keep = []
     for q, (dout, out, lam, has_base, terms) in zip(arr, groups):
       assert dout.shape == out.shape and dout.stride() == out.stride() and dout.stride(1) == 1 and len(terms) <= 4
       q.dout, q.out, q.ld = dout.data_ptr(), out.data_ptr(), dout.stride(0)
@@ -1198,8 +1225,9 @@ class HipBackend(object):
           t.kind, t.col0, t.width, t.dim = GRAD_TERM_ROWSUM, term[2], term[3], 1
         else:
           saved = _f32c(term[2])
+          keep.append(saved)
           t.kind, t.col0, t.width, t.dim, t.saved = GRAD_TERM_FM, term[3], term[4], term[5], saved.data_ptr()
-    self._ck(self.lib.er_group_grad_finish(arr, len(groups), _stream()), 'er_group_grad_finish')
+    return arr, keep
 
   def axpy2d(self, x, alpha, y, accumulate=True):
     """y (+)= alpha * x on 2-D views with unit inner stride."""
@@ -1648,17 +1676,27 @@ class HipBackend(object):
                                       ctypes.c_int64(cap), ctypes.c_int32(history_index), _stream()),
              'er_hyper_select')
 
-  def step_prologue(self, table, counter, out, history=None, zero=None, history_index=HYPER_LR_T, decay_tables=None):
+  def step_prologue(self, table, counter, out, history=None, zero=None, history_index=HYPER_LR_T, decay_tables=None,
+                    hash_job=None):
     """hyper_select + zeroing of `zero` (the flat gradient buffer) in one launch.  decay_tables (decay_tables_create):
-    the same launch appends the step's entry to the closed-form replay's per-step table."""
+    the same launch appends the step's entry to the closed-form replay's per-step table.  hash_job = (bytes, offsets,
+    n_per_col, num_buckets, drop_empty, out) (hash_bucket_fast's arguments): the batch's id strings are hashed by further
+    workgroups of the same launch."""
     n_slots = table.shape[0]
     cap = 0 if history is None else history.numel() // 2
     nz = 0 if zero is None else zero.numel()
     assert zero is None or (zero.dtype == torch.float32 and zero.is_contiguous())
-    self._ck(self.lib.er_step_prologue_decay(_p(table), _p(counter), n_slots, table[0].numel(), _p(out), _p(history),
-                                             ctypes.c_int64(cap), ctypes.c_int32(history_index), _p(zero),
-                                             ctypes.c_int64(nz), decay_tables['handle'] if decay_tables else None,
-                                             _stream()), 'er_step_prologue_decay')
+    hb = ho = hk = hout = None
+    hn, hpc, hdrop = 0, 1, 0
+    if hash_job is not None:
+      hb, ho, hpc, hk, hdrop, hout = hash_job
+      hn = ho.numel() - 1
+      assert hout.dtype == torch.int64 and hout.numel() >= hn
+    self._ck(self.lib.er_step_prologue_hash(_p(table), _p(counter), n_slots, table[0].numel(), _p(out), _p(history),
+                                            ctypes.c_int64(cap), ctypes.c_int32(history_index), _p(zero),
+                                            ctypes.c_int64(nz), decay_tables['handle'] if decay_tables else None,
+                                            _p(hb), _p(ho), ctypes.c_int64(hn), ctypes.c_int64(int(hpc)), _p(hk),
+                                            ctypes.c_int(int(hdrop)), _p(hout), _stream()), 'er_step_prologue_hash')
 
   # -- closed-form replay of TF-Adam's decay-only steps (csrc/er_decay.h)
   def decay_tables_create(self, lr_hist, step_counter, beta1, beta2):

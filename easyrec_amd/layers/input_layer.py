@@ -142,6 +142,11 @@ class EmbeddingEngine(object):
     self._window_pending = False  # launched on the second stream, not joined yet
     self._window_started = False  # this step's window has been launched (the row update must not launch it again)
     self._sort_leader = {}  # dim -> dim of the group whose per-step sort it reuses
+    # the fused single-GPU step (kernels.HipBackend.emb_front / emb_bwd_fused): decided per engine at the first step
+    # (None = not tried yet; False = these groups need the general path); the estimator clears `allow_fused` when
+    # something between lookup and row update needs the general path's buffers (gradient clipping by global norm)
+    self.allow_fused = True
+    self._fused = None
 
   # -- declaration (build pass)
   def declare_table(self, var_name, rows, dim, initializer=None, kv_capacity=None):
@@ -427,7 +432,9 @@ class EmbeddingEngine(object):
     self._join_window_flush()  # (a forward that no row update followed)
     if self.kv_jobs:
       self.translate_kv_ids()
-    if self.lazy_decay and not self.inference:
+    if self.lazy_decay and not self.inference and self._use_fused() and self._fused_front():
+      self._start_window_flush()
+    elif self.lazy_decay and not self.inference:
       # sort the step's ids once (reused by the backward), bring the rows it touches up to date, then look up
       grps, uks, nus = [], [], []
       for dim, grp in self.emb_groups.items():
@@ -523,8 +530,53 @@ class EmbeddingEngine(object):
       torch.cuda.current_stream().wait_stream(self._sweep_stream)
       self._sweep_pending = False
 
+  # -- the fused single-GPU step
+  def _use_fused(self):
+    be = kernels.hip()
+    return (self._fused is not False and self.allow_fused and getattr(be, 'fused_emb', False) and self.train_mode and
+            type(self) is EmbeddingEngine and not self.kv_jobs and len(self.emb_groups) <= 4 and
+            not self._sweep_pending and (not self.lazy_decay or self.flush_windows <= 0) and len(self.groups) <= 8 and
+            not any(st['bitmap'] is not None for st in self.storage.values()))
+
+  def _fused_front(self):
+    """er_emb_front over all table groups (leader first); remembers whether the groups are eligible."""
+    be = kernels.hip()
+    grps = list(self.emb_groups.values())
+    ok = be.emb_front(grps, self._clock[2] if self.lazy_decay else None, True)
+    if self._fused is None:
+      self._fused = bool(ok)
+      if not ok:
+        logging.info('easyrec_amd: the fused embedding step does not cover this model (%s): general path',
+                     getattr(be, 'last_error', lambda: '')())
+    else:
+      assert ok == self._fused
+    self._front_done = bool(ok)
+    return ok
+
+  def _finish_descs(self):
+    """group_grad_finish's descriptors for EVERY group buffer (a complete one: base only)."""
+    descs = []
+    for g in self.groups.values():
+      lam = g['reg'] if g['reg'] > 0 else 0.0
+      descs.append((g['dout'], g['out'], lam, g['got_grad'], g['terms']))
+    return descs
+
   def backward_update(self, opt_kind, hyper):
     be = kernels.hip()
+    # this step's front already ran fused (forward, lazy dense decay), or - optimizers without it - runs now
+    if getattr(self, '_front_done', False) or (not self.lazy_decay and self._use_fused() and self._fused_front()):
+      self._front_done = False
+      for g in self.groups.values():  # (more than 4 deferred terms on one buffer: finish the surplus into it first)
+        while len(g['terms']) > 4:
+          be.group_grad_finish([(g['dout'], g['out'], 0.0, g['got_grad'], g['terms'][:4])])
+          g['terms'], g['got_grad'] = g['terms'][4:], True
+      be.emb_bwd_fused(list(self.emb_groups.values()), self._finish_descs(), opt_kind, hyper)
+      for g in self.groups.values():
+        g['terms'] = []
+        g['got_grad'] = True
+      self._roll_flush(hyper)
+      self._decay_pending = True
+      return
     self.finish_group_grads()
     if opt_kind == kernels.OPT_ADAM and self._sweep_pending:
       # the sweep of the untouched rows is already in flight on the side stream; the touched rows

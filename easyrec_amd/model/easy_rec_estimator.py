@@ -49,6 +49,8 @@ class EasyRecEstimator(object):
     # on one box (tools/gpu_ab.sh) the two-branch graph is 0.609 ms against 0.550 sequential: like the sweep
     # overlap before it, concurrent kernels stretch the latency-bound ones more than they hide
     self.overlap_dense_update = os.environ.get('EASYREC_AMD_OVERLAP_DENSE', '0') != '0'
+    # the id hash as workgroups of the step prologue's launch (one launch less per step) - A/B switch
+    self.fused_front = os.environ.get('EASYREC_AMD_FUSED_FRONT', '1') != '0'
     self._side_stream = None
     # TF-exact Adam: True = run the dense-decay sweep of the untouched rows on a second stream (see
     # EmbeddingEngine.start_decay_sweep); False (default) = sequential sweep inside er_emb_bwd_update.
@@ -94,6 +96,8 @@ class EasyRecEstimator(object):
     # reduce -> norm -> apply instead of the fused reduce+apply (layers/input_layer.py backward_reduce).
     self.clip_norm = float(cfg.train_config.gradient_clipping_by_norm) \
         if cfg.train_config.gradient_clipping_by_norm > 0 else 0.0
+    if self.clip_norm > 0 or self.overlap_sweep:
+      self.engine.allow_fused = False  # (the norm sits between reduce and apply; the overlapped sweep marks rows first)
 
     labels = OrderedDict((name, self.features.label(name)) for name in self.schema.label_fields)
     with context.use(self.ctx):
@@ -243,9 +247,10 @@ class EasyRecEstimator(object):
     """Everything that runs on the GPU for one batch (graph-capturable)."""
     be = kernels.hip()
     # prologue, one launch: this step's optimizer scalars (device-side step counter) + the flat gradient buffer zeroed
+    hash_job = self.features.hash_job() if self.fused_front else None
     be.step_prologue(self.hyper_table, self.step_counter, self.hyper, history=self.lr_hist,
-                     zero=self.varstore.flat_grad_all, decay_tables=self.decay_tables)
-    self.features.transform()
+                     zero=self.varstore.flat_grad_all, decay_tables=self.decay_tables, hash_job=hash_job)
+    self.features.transform(hashed=hash_job is not None)
     if self.is_training and self.overlap_sweep and self.opt_emb.kind == kernels.OPT_ADAM:
       self.engine.start_decay_sweep(self.hyper[0])
     with context.use(self.ctx):

@@ -80,9 +80,10 @@ class EmbeddingParallelEstimator(EasyRecEstimator):
 
   # -- the step in phases: static device work (capturable) around the data-dependent exchanges
   def _phase_route(self):
+    hash_job = self.features.hash_job() if self.fused_front else None
     kernels.hip().step_prologue(self.hyper_table, self.step_counter, self.hyper, history=self.lr_hist,
-                                zero=self.varstore.flat_grad_all, decay_tables=self.decay_tables)
-    self.features.transform()
+                                zero=self.varstore.flat_grad_all, decay_tables=self.decay_tables, hash_job=hash_job)
+    self.features.transform(hashed=hash_job is not None)
     self.engine.route()
 
   def _phase_compute(self):

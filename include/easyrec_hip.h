@@ -325,6 +325,23 @@ typedef struct er_grad_group {
   er_grad_term terms[4];
 } er_grad_group;
 int er_group_grad_finish(const er_grad_group* groups_host, int n, er_stream_t stream);
+/* The fused single-GPU embedding step (round 4).  Both return 0, an error code, or 3 = "these groups need the general path"
+ * (er_last_error says why; nothing was launched).
+ *   er_emb_front: what er_emb_route + er_emb_catch_up_multi do for groups of dense-mode lookups (one id per output row)
+ *     that own their tables - entries built, sorted and run-head-flagged by ONE launch per sort leader (followers of a
+ *     shared sort adopt it), whose surplus workgroups also rebuild the closed-form replay's per-launch table; then ONE
+ *     launch brings the step's rows current straight from the run heads (no de-duplicated key list).  hyper may be NULL
+ *     for groups without lazy dense decay.  skip_one_row != 0: entries into one-row tables (RawFeature projections,
+ *     input/input.py:648-673: every valid id is row 0) stay out of the sort - then the step's gradients MUST be reduced
+ *     by er_emb_bwd_fused (the other reduce entry points refuse such a sort).
+ *   er_emb_bwd_fused: er_group_grad_finish + er_emb_bwd_update_multi in ONE launch: the finished output gradient
+ *     (finish[k]: the descriptors er_group_grad_finish takes, one per feature-group buffer the lookups write; each
+ *     lookup's `out` must be the dout of one of them) is evaluated while the sorted entries are gathered, a run of equal
+ *     keys is reduced by the workgroup that holds its first entry, and the one-row tables are reduced by columns.  The
+ *     gradient buffers themselves are left unfinished.  First use uploads a plan: call once outside stream capture. */
+int er_emb_front(er_emb_group* const* groups, int n, int skip_one_row, const er_opt_hyper* hyper, er_stream_t stream);
+int er_emb_bwd_fused(er_emb_group* const* groups, int n, const er_grad_group* finish_host, int n_finish, int opt_kind,
+                     const er_opt_hyper* hyper, er_stream_t stream);
 /* out[b, sum(widths[<p]) + j] = parts[p][b * lds[p] + j]: tf.concat(values, axis=1) of n <= 8 row-major blocks
  * (model/deepfm.py:75-83, model/multi_tower_din.py:96,117) in one launch.  parts / widths / lds: HOST arrays. */
 int er_concat_cols(const float* const* parts_host, const int32_t* widths_host, const int32_t* lds_host, int n,
@@ -581,6 +598,13 @@ int er_step_prologue(const float* table, int64_t* counter, int32_t n_slots, int3
 int er_step_prologue_decay(const float* table, int64_t* counter, int32_t n_slots, int32_t floats_per_slot, float* out,
                            float* history, int64_t history_capacity, int32_t history_index, float* zero,
                            int64_t zero_floats, er_decay_tables* decay_tables, er_stream_t stream);
+/* the same + string_to_hash_bucket_fast of the batch's id strings (er_hash_bucket_fast's arguments; n_strings == 0: none) as
+ * further workgroups of the SAME launch: the hash depends on nothing the prologue writes, and a launch of its own costs
+ * what a kernel boundary costs (feature_column_v2.py:3915-3921 issues it per column before the lookups). */
+int er_step_prologue_hash(const float* table, int64_t* counter, int32_t n_slots, int32_t floats_per_slot, float* out,
+                          float* history, int64_t history_capacity, int32_t history_index, float* zero, int64_t zero_floats,
+                          er_decay_tables* decay_tables, const uint8_t* str_bytes, const int64_t* str_offsets, int64_t n_strings,
+                          int64_t n_per_col, const uint64_t* num_buckets, int drop_empty, int64_t* ids_out, er_stream_t stream);
 /* out[0] = scale * sum of all n partials (deterministic single-block tree) */
 int er_reduce_sum(const float* partials, int32_t n, float scale, float* out, int accumulate,
                   er_stream_t stream);

@@ -523,6 +523,38 @@ class RefBackend(object):
     for g in groups:
       self.emb_bwd_update(g, opt_kind, hyper)
 
+  fused_emb = True  # layers/input_layer.py: the fused single-GPU step's host logic runs on the stand-in too
+
+  def emb_front(self, groups, hyper, skip_one_row):
+    """easyrec_amd.kernels.HipBackend.emb_front restated with the general entry points: route every group (a follower of
+    a shared sort after its leader), then bring the rows of the step current.  Eligibility as er_emb_front: dense-mode
+    lookups on their own tables, closed-form (or no) lazy decay."""
+    for g in groups:
+      if any(sp.offsets is not None for sp in g['specs']) or 'local_base' in g:
+        return False
+    uks, nus = [], []
+    for g in groups:
+      leader = g.get('sort_leader')
+      if leader is not None and any(leader is q for q in groups):
+        self.emb_route(g, None, None, None, None)
+        i = [k for k, q in enumerate(groups) if q is leader][0]
+        uks.append(uks[i])
+        nus.append(nus[i])
+      else:
+        uk = torch.zeros(max(g['num_entries'], 1), dtype=torch.int32)
+        nu = torch.zeros(1, dtype=torch.int32)
+        self.emb_route(g, uk, nu, None, None)
+        uks.append(uk)
+        nus.append(nu)
+    lazy = [(g, uk, nu) for g, uk, nu in zip(groups, uks, nus) if g.get('last_step') is not None]
+    if lazy:
+      self.emb_catch_up_multi([x[0] for x in lazy], [x[1] for x in lazy], [x[2] for x in lazy], hyper)
+    return True
+
+  def emb_bwd_fused(self, groups, finish, opt_kind, hyper):
+    self.group_grad_finish(finish)
+    self.emb_bwd_update_multi(groups, opt_kind, hyper)
+
   def emb_group_share_sort(self, group, leader):
     if not _same_lookup_keys(group, leader):
       return False
@@ -1080,10 +1112,14 @@ class RefBackend(object):
       total = F32(total + F32(src.reshape(-1)[0].item()))
     total_out[0] = float(total)
 
-  def step_prologue(self, table, counter, out, history=None, zero=None, history_index=HYPER_LR_T, decay_tables=None):
+  def step_prologue(self, table, counter, out, history=None, zero=None, history_index=HYPER_LR_T, decay_tables=None,
+                    hash_job=None):
     self.hyper_select(table, counter, out, history=history, history_index=history_index)
     if zero is not None:
       zero.zero_()
+    if hash_job is not None:
+      hb, ho, hpc, hk, hdrop, hout = hash_job
+      self.hash_bucket_fast(hb, ho, hpc, hk, hdrop, out=hout)
 
   def reduce_sum(self, partials, scale, out, accumulate=False):
     s = partials.to(torch.float64).sum().to(torch.float32) * scale

@@ -459,3 +459,52 @@ def test_fused_batchnorm_gemms_change_no_bit():
     assert losses == states[0][1]
     for k in states[0][0]:
       assert np.array_equal(st[k], states[0][0][k]), k
+
+
+@pytest.mark.parametrize('optimizer', ['adam', 'lazy_adam'])
+@pytest.mark.parametrize('buckets,B', [(1000, 256), (7, 2048), (300, 4096)])
+def test_fused_embedding_step_matches_the_general_path(optimizer, buckets, B):
+  """er_emb_front + er_emb_bwd_fused (build + sort + heads [+ decay table] in one launch, catch-up from the heads, finish +
+  reduce + row update in one launch, one-row tables reduced by columns) against er_emb_route + er_emb_catch_up_multi +
+  er_group_grad_finish + er_emb_bwd_update_multi from the same state: after the first step every table / slot / dense
+  variable to 1e-4 of its scale (the two paths add a run's gradients in different, fixed orders), the losses of 4 steps.  7 buckets
+  at B = 2048: runs of ~300 equal keys cross tile boundaries - the owner workgroup follows them."""
+  cfg = _cfg('deepfm_criteo_small.config')
+  for f in cfg.feature_config.features:
+    if f.HasField('hash_bucket_size') and f.hash_bucket_size > 0:
+      f.hash_bucket_size = buckets
+  if optimizer == 'lazy_adam':
+    oc = cfg.train_config.optimizer_config[0]
+    oc.lazy_adam_optimizer.learning_rate.CopyFrom(oc.adam_optimizer.learning_rate)
+  be = kernels.hip()
+  gen = SyntheticCriteo(cfg.data_config, list(cfg.feature_config.features), batch_size=B, seed=13)
+  batches = [gen.next_batch() for _ in range(4)]
+  first, losses = [], []
+  for fused in (False, True):
+    be.fused_emb = fused
+    try:
+      est = EasyRecEstimator(cfg, device=DEV, batch_size=B, seed=4).build()
+      ls = []
+      for i, b in enumerate(batches):
+        est.train_step(b)
+        ls.append(est.loss_values())
+        if i == 0:
+          first.append(est.state_dict(slots=True))
+      assert (est.engine._fused is True) == fused, est.engine._fused
+      losses.append(ls)
+    finally:
+      del be.fused_emb
+  # the first step from identical parameters: every table / slot / dense variable (later steps drift apart through Adam's
+  # normalisation of near-zero gradients, as any two fp32 summation orders do: the losses are held over all four)
+  sa, sb = first
+  assert set(sa) == set(sb)
+  worst = ('', 0.0)
+  for k in sa:
+    scale = float(np.max(np.abs(sa[k]))) + 1e-30
+    d = float(np.max(np.abs(sa[k] - sb[k]))) / scale
+    if d > worst[1]:
+      worst = (k, d)
+  assert worst[1] <= 1e-4, worst  # (a one-row table's gradient is a sum over the whole batch: 4096 terms in another order)
+  for step, (a, b) in enumerate(zip(*losses)):
+    for k in a:
+      assert abs(a[k] - b[k]) <= (1e-6 if step == 0 else 2e-4) * max(1.0, abs(a[k])), (step, k, a[k], b[k])

@@ -1,0 +1,4 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
+O=gpurun_out/r4s15; mkdir -p $O
+timeout 300 python tools/own_probe.py 2>&1 | tail -20 | tee $O/probe.txt
