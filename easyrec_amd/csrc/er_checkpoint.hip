@@ -177,4 +177,35 @@ int er_load_kv_embed(const char* ckpt_path, const char* var_name, int32_t task_i
   return 0;
 }
 
+
+// CRC-32C (Castagnoli, reflected polynomial 0x82F63B78) of n bytes, continuing from `crc` (0 to start): the checksum of
+// TensorFlow's tensor-bundle entries and table blocks (tensorflow/core/lib/hash/crc32c.h; the files a TF Saver writes for
+// the dense variables, reference model/easy_rec_model.py:219-351 restores from them) - easyrec_amd/utils/tensor_bundle.py.
+uint32_t er_crc32c(uint32_t crc, const void* data, int64_t n) {
+  static uint32_t table[8][256];
+  static bool ready = false;
+  if (!ready) {
+    for (uint32_t i = 0; i < 256; ++i) {
+      uint32_t c = i;
+      for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+      table[0][i] = c;
+    }
+    for (uint32_t i = 0; i < 256; ++i)
+      for (int t = 1; t < 8; ++t) table[t][i] = (table[t - 1][i] >> 8) ^ table[0][table[t - 1][i] & 0xFFu];
+    ready = true;
+  }
+  const unsigned char* p = static_cast<const unsigned char*>(data);
+  uint32_t c = ~crc;
+  while (n >= 8) {  // slicing-by-8
+    const uint32_t lo = c ^ (static_cast<uint32_t>(p[0]) | static_cast<uint32_t>(p[1]) << 8 | static_cast<uint32_t>(p[2]) << 16 |
+                             static_cast<uint32_t>(p[3]) << 24);
+    c = table[7][lo & 0xFFu] ^ table[6][(lo >> 8) & 0xFFu] ^ table[5][(lo >> 16) & 0xFFu] ^ table[4][lo >> 24] ^
+        table[3][p[4]] ^ table[2][p[5]] ^ table[1][p[6]] ^ table[0][p[7]];
+    p += 8;
+    n -= 8;
+  }
+  while (n-- > 0) c = table[0][(c ^ *p++) & 0xFFu] ^ (c >> 8);
+  return ~c;
+}
+
 }  // extern "C"

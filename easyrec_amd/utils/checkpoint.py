@@ -12,8 +12,10 @@ arena, whose row order is an accident of the run - and restored through er_load_
 115-163: keys with `key % world == rank`), re-inserted into the map (any arena order), values and slots scattered to
 the rows they got.
 
-Everything else - dense variables, their slots, the step - goes through the TF Saver in the reference (tensor-bundle
-files); that format is not written here: `<ckpt>.dense.npz` holds the same arrays under the same TF variable names.
+Everything else - dense variables, their slots, the step - goes through the TF Saver in the reference (model/
+easy_rec_model.py:219-351 restores them by variable name): tensor-bundle files `<ckpt>.index` + `<ckpt>.data-00000-of-00001`
+under the same TF variable names (`deep_feature/dnn_0/kernel`, `.../kernel/Adam`, `global_step`), written and read by
+utils/tensor_bundle.py, plus the `checkpoint` state file.  (Checkpoints of earlier rounds - `<ckpt>.dense.npz` - still load.)
 
 A checkpoint written by W workers loads on any other number (1 GPU <-> 8 GPUs): that is what the re-shard is for.
 """
@@ -23,6 +25,7 @@ import numpy as np
 import torch
 
 from easyrec_amd import kernels
+from easyrec_amd.utils import tensor_bundle
 
 _SLOT_NAMES = {  # estimator slot -> TF slot variable suffix, per optimizer kind
     kernels.OPT_ADAM: {'m': 'Adam', 'v': 'Adam_1'},
@@ -145,9 +148,10 @@ def save(est, ckpt_path):
     # the rows an uninterrupted one would
     for name, kv in getattr(engine, 'kv_tables', {}).items():
       dense[name + '/kv_meta'] = np.array([kv['seed'], kv['mean'], kv['stddev'], kv['capacity']], dtype=np.float64)
-      dense[name + '/kv_seed'] = np.asarray(int(kv['seed']), dtype=np.uint64)  # (float64 loses seeds >= 2^53)
+      dense[name + '/kv_seed'] = np.asarray(int(kv['seed']), dtype=np.int64)  # (float64 loses seeds >= 2^53)
     dense['global_step'] = np.asarray(int(est.global_step), dtype=np.int64)
-    np.savez(ckpt_path + '.dense.npz', **dense)
+    tensor_bundle.write_bundle(ckpt_path, dense)
+    tensor_bundle.write_checkpoint_state(ckpt_path)
 
 
 def restore(est, ckpt_path):
@@ -169,7 +173,13 @@ def restore(est, ckpt_path):
       if sv is not None:
         sv.copy_(torch.from_numpy(
             be.load_dense_embed(ckpt_path, embed_file_var_name(name + '/' + suffix), t_idx, t_num, dim, n_local)))
-  z = np.load(ckpt_path + '.dense.npz')
+  class _Arrays(dict):  # (np.load's interface: .files + item access)
+    files = property(lambda self: list(self.keys()))
+  if os.path.exists(ckpt_path + '.index'):
+    z = _Arrays(tensor_bundle.read_bundle(ckpt_path))
+  else:  # a checkpoint of rounds 2-3
+    z0 = np.load(ckpt_path + '.dense.npz')
+    z = _Arrays((k, z0[k]) for k in z0.files)
   for name, kv in getattr(engine, 'kv_tables', {}).items():
     if name + '/kv_meta' in z.files:
       meta = z[name + '/kv_meta']

@@ -998,6 +998,9 @@ int er_dot_interaction_bwd(const float* x, const float* g, int32_t B, int32_t F,
  *     with key mod task_num == task_index.  Call with out_keys = NULL to get the count in *n_keys, then with
  *     buffers of that capacity.  (The reference shuffles the result; here it is in file order.)
  * -------------------------------------------------------------------------------------------- */
+/* CRC-32C (Castagnoli) of n bytes continuing from crc (0 to start): TensorFlow's checksum for tensor-bundle entries and
+ * table blocks (tensorflow/core/lib/hash/crc32c.h) - the dense variables' checkpoint files (utils/tensor_bundle.py). Host. */
+uint32_t er_crc32c(uint32_t crc, const void* data, int64_t n);
 int er_save_dense_embed(const char* ckpt_path, const char* var_name, int32_t task_index, int32_t task_num,
                         const float* vals_host, int64_t rows, int32_t embed_dim);
 int er_load_dense_embed(const char* ckpt_path, const char* var_name, int32_t task_index, int32_t task_num,

@@ -226,3 +226,45 @@ def test_two_rank_checkpoint_restores_on_one_rank(ref_backend, built_lib, tmp_pa
   assert set(got) == set(want)
   for k in want:
     assert np.array_equal(got[k], want[k]), k
+
+
+def test_tensor_bundle_files(tmp_path, built_lib):
+  """utils/tensor_bundle.py: the dense variables' checkpoint in TensorFlow's tensor-bundle format.  Writer against reader;
+  the format's invariants a TF reader relies on (sorted unique keys with the header under "", footer magic, per-block and
+  per-tensor masked CRC-32C, BlockHandles); the CRC against its published known answers (RFC 3720 B.4); a table of more than
+  one data block; corruption is detected."""
+  import struct
+  from easyrec_amd.utils import tensor_bundle as tb
+  assert tb._crc32c(b'123456789') == 0xE3069283 and tb._crc32c(bytes(32)) == 0x8A9136AA and tb._crc32c(b'\xff' * 32) == 0x62A8AB43
+  assert tb._unmask(tb._mask(0x12345678)) == 0x12345678 and tb._mask(0) == 0xa282ead8
+  rng = np.random.default_rng(0)
+  tensors = {'deep_feature/dnn_0/kernel': rng.standard_normal((37, 16)).astype(np.float32),
+             'deep_feature/dnn_0/kernel/Adam': rng.standard_normal((37, 16)).astype(np.float32),
+             'deep_feature/dnn_0/bias': np.zeros(16, dtype=np.float32), 'global_step': np.asarray(12345, dtype=np.int64),
+             'empty': np.zeros((0, 4), dtype=np.float32), 'a/double': rng.standard_normal(3)}
+  for i in range(6000):  # enough index entries for more than one 256 KB data block
+    tensors['many/var_%05d/with_a_long_common_prefix_in_its_name_%s' % (i, 'x' * 60)] = np.asarray([i], dtype=np.int32)
+  prefix = os.path.join(str(tmp_path), 'model.ckpt-12345')
+  tb.write_bundle(prefix, tensors)
+  raw = open(prefix + '.index', 'rb').read()
+  assert struct.unpack('<Q', raw[-8:])[0] == 0xdb4775248b80fb57 and len(raw) > 2 * 256 * 1024  # (more than two data blocks)
+  items = tb._read_table(prefix + '.index')
+  keys = [k for k, _ in items]
+  assert keys[0] == b'' and keys == sorted(keys) and len(set(keys)) == len(keys) == len(tensors) + 1
+  assert items[0][1] == b'\x08\x01\x1a\x02\x08\x01'  # num_shards 1, (endianness LITTLE = default), version{producer 1}
+  assert os.path.getsize(tb.data_file(prefix)) == sum(v.nbytes for v in tensors.values())
+  got = tb.read_bundle(prefix)
+  assert set(got) == set(tensors)
+  for k, v in tensors.items():
+    assert got[k].dtype == v.dtype and got[k].shape == v.shape and np.array_equal(got[k], v), k
+  # a flipped data byte fails the tensor's CRC; a flipped index byte fails a block's
+  data = bytearray(open(tb.data_file(prefix), 'rb').read())
+  data[100] ^= 1
+  open(tb.data_file(prefix), 'wb').write(bytes(data))
+  with pytest.raises(ValueError, match='checksum'):
+    tb.read_bundle(prefix)
+  idx = bytearray(raw)
+  idx[1000] ^= 1
+  open(prefix + '.index', 'wb').write(bytes(idx))
+  with pytest.raises(ValueError, match='checksum'):
+    tb._read_table(prefix + '.index')
