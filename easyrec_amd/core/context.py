@@ -29,6 +29,8 @@ class ModelContext(object):
     # data pointer) and the column-sum jobs their fused launch leaves to the loss tail [(partial [P, ld], dst, n_cols)]
     self.heads = {}
     self.tail_jobs = []
+    # per step: one gradient buffer per activation tensor shared by its consumers' backward kernels (kernels.grad_slot)
+    self.grad_slots = {}
 
 
 @contextlib.contextmanager

@@ -253,6 +253,18 @@ __device__ __forceinline__ void bn_finalize_apply_body(const float* __restrict__
   const int cl = threadIdx.x % kColsPerBlock;
   const int rl = threadIdx.x / kColsPerBlock;
   const int c = bx * kColsPerBlock + cl;
+  // batch-sized layers (one row tile per workgroup): the tile's activations are requested BEFORE the partials are merged -
+  // the two round trips overlap instead of following each other (the kernel is a chain of dependent loads, not bytes)
+  constexpr int kPre = kApplyRows / kRowLanes;
+  float xpre[kPre];
+  const bool pre = tiles_per_block == 1 && c < N;
+  if (pre) {
+#pragma unroll
+    for (int k = 0; k < kPre; ++k) {
+      const int r = by * kApplyRows + rl + k * kRowLanes;
+      xpre[k] = (r < B) ? x[static_cast<int64_t>(r) * N + c] : 0.f;
+    }
+  }
   Welford t{0.f, 0.f, 0.f};
   if (c < N) {
     // groups of 8 partials: the 24 loads of a group are issued together, then merged in order
@@ -346,7 +358,7 @@ __device__ __forceinline__ void bn_finalize_apply_body(const float* __restrict__
 #pragma unroll
     for (int k = 0; k < kApplyRows / kRowLanes; ++k) {
       const int r = r0 + k * kRowLanes;
-      xv[k] = (r < B) ? x[static_cast<int64_t>(r) * N + c] : 0.f;
+      xv[k] = pre ? xpre[k] : ((r < B) ? x[static_cast<int64_t>(r) * N + c] : 0.f);
     }
 #pragma unroll
     for (int k = 0; k < kApplyRows / kRowLanes; ++k) {
@@ -433,6 +445,21 @@ __device__ __forceinline__ void bn_bwd_finalize_apply_body(const float* __restri
   const int cl = threadIdx.x % kColsPerBlock;
   const int rl = threadIdx.x / kColsPerBlock;
   const int c = bx * kColsPerBlock + cl;
+  // one row tile per workgroup: dy / x / y of the tile are requested before the partial sums are merged (see the forward)
+  constexpr int kPre = kApplyRows / kRowLanes;
+  float gpre[kPre], xpre[kPre], ypre[kPre];
+  const bool pre = tiles_per_block == 1 && c < N;
+  if (pre) {
+#pragma unroll
+    for (int k = 0; k < kPre; ++k) {
+      const int r = by * kApplyRows + rl + k * kRowLanes;
+      const int64_t i = static_cast<int64_t>(r) * N + c;
+      const bool ok = r < B;
+      gpre[k] = ok ? dy[static_cast<int64_t>(r) * dy_ld + c] : 0.f;
+      xpre[k] = (ok && (use_bn || !y)) ? x[i] : 0.f;
+      ypre[k] = (ok && act == ER_ACT_RELU && y) ? y[i] : 1.f;
+    }
+  }
   float a = 0.f, b = 0.f;
   if (c < N) {
 #pragma unroll 8
@@ -484,9 +511,9 @@ __device__ __forceinline__ void bn_bwd_finalize_apply_body(const float* __restri
       const int r = r0 + k * kRowLanes;
       const int64_t i = static_cast<int64_t>(r) * N + c;
       const bool ok = r < B;
-      gv[k] = ok ? dy[static_cast<int64_t>(r) * dy_ld + c] : 0.f;
-      xv[k] = (ok && (use_bn || !y)) ? x[i] : 0.f;
-      yv[k] = (ok && act == ER_ACT_RELU) ? (y ? y[i] : recomputed_y(xv[k] + bv, mu, is, ga, beta ? beta[c] : 0.f, use_bn)) : 1.f;
+      gv[k] = pre ? gpre[k] : (ok ? dy[static_cast<int64_t>(r) * dy_ld + c] : 0.f);
+      xv[k] = pre ? xpre[k] : ((ok && (use_bn || !y)) ? x[i] : 0.f);
+      yv[k] = (ok && act == ER_ACT_RELU) ? (y ? (pre ? ypre[k] : y[i]) : recomputed_y(xv[k] + bv, mu, is, ga, beta ? beta[c] : 0.f, use_bn)) : 1.f;
     }
 #pragma unroll
     for (int k = 0; k < kIter; ++k) {

@@ -815,6 +815,63 @@ cin_outer_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ xi,
   }
 }
 
+template <int V>
+__device__ __forceinline__ void ld_n(float (&r)[V], const float* p) {
+  if constexpr (V == 4) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w;
+  } else {
+    r[0] = p[0];
+  }
+}
+template <int V>
+__device__ __forceinline__ void st_n(float* p, const float (&r)[V]) {
+  if constexpr (V == 4) *reinterpret_cast<float4*>(p) = make_float4(r[0], r[1], r[2], r[3]); else p[0] = r[0];
+}
+
+// cross_v2_bwd with caller-provided destinations (round 4): dx0 and dx are ACCUMULATED into buffers the consumers of the
+// same tensors share - an embedding group's gradient buffer (row stride ld), or the tensor another gradient of x_l already
+// went to - so that autograd sums nothing (the 3-layer DCN-v2 backbone ran nine torch add kernels per step for these).
+// dx == nullptr: x IS x0 (the first cross layer): its gradient joins dx0's.  16-byte lanes when d and the strides allow.
+template <int V>
+__global__ void __launch_bounds__(kBlock)
+cross_v2_bwd_acc_kernel(const float* __restrict__ x0, const float* __restrict__ x, const float* __restrict__ u,
+                        const float* __restrict__ bias, float diag, const float* __restrict__ dout, int ldg, int B, int d,
+                        float* __restrict__ dx0, int ld0, int acc0, float* __restrict__ dx, int ldx, int accx,
+                        float* __restrict__ du) {
+  const int per_row = d / V;
+  const int64_t t = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (t >= static_cast<int64_t>(B) * per_row) return;
+  const int64_t r = t / per_row;
+  const int c = static_cast<int>(t - r * per_row) * V;
+  const int64_t i = r * d + c;
+  float x0v[V], xv[V], uv[V], gv[V], bv[V], o0[V], ox[V];
+  ld_n<V>(x0v, x0 + i);
+  ld_n<V>(uv, u + i);
+  ld_n<V>(gv, dout + r * ldg + c);
+  if (diag != 0.f) ld_n<V>(xv, x + i);
+  if (bias) ld_n<V>(bv, bias + c);
+  if (acc0) ld_n<V>(o0, dx0 + r * ld0 + c);
+  if (dx && accx) ld_n<V>(ox, dx + r * ldx + c);
+  float r0[V], rx[V], ru[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    float tt = uv[j] + (bias ? bv[j] : 0.f);
+    if (diag != 0.f) tt = tt + diag * xv[j];
+    const float g = gv[j];
+    const float a = g * tt;                                              // d out / d x0 (the Hadamard factor's side)
+    const float b = g + (diag != 0.f ? g * x0v[j] * diag : 0.f);         // d out / d x (residual + diagonal term)
+    ru[j] = g * x0v[j];
+    float v0 = acc0 ? (o0[j] + a) : a;
+    if (!dx) v0 = v0 + b;
+    r0[j] = v0;
+    rx[j] = (dx && accx) ? (ox[j] + b) : b;
+  }
+  st_n<V>(dx0 + r * ld0 + c, r0);
+  if (dx) st_n<V>(dx + r * ldx + c, rx);
+  st_n<V>(du + i, ru);
+}
+
 }  // namespace er
 
 extern "C" {
@@ -905,6 +962,26 @@ int er_cross_v2_epilogue_fwd(const float* x0, const float* x, const float* u, co
   const int64_t n = static_cast<int64_t>(B) * d;
   hipLaunchKernelGGL(er::cross_v2_fwd_kernel, dim3(er::blocks_for(n)), dim3(er::kBlock), 0, er::as_stream(stream), x0,
                      x, u, bias, diag_scale, n, d, out);
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
+int er_cross_v2_epilogue_bwd_acc(const float* x0, const float* x, const float* u, const float* bias, float diag_scale,
+                                 const float* dout, int32_t ld_dout, int32_t B, int32_t d, float* dx0, int32_t ld_dx0, int accumulate_dx0,
+                                 float* dx, int32_t ld_dx, int accumulate_dx, float* du, er_stream_t stream) {
+  ER_REQUIRE(x0 && x && u && dout && dx0 && du && B > 0 && d > 0 && ld_dx0 >= d && (!dx || ld_dx >= d) && ld_dout >= d,
+             "er_cross_v2_epilogue_bwd_acc: bad arguments");
+  const uintptr_t al = reinterpret_cast<uintptr_t>(x0) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(u) |
+                       reinterpret_cast<uintptr_t>(dout) | reinterpret_cast<uintptr_t>(dx0) | reinterpret_cast<uintptr_t>(dx) |
+                       reinterpret_cast<uintptr_t>(du) | reinterpret_cast<uintptr_t>(bias);
+  const bool vec = d % 4 == 0 && ld_dx0 % 4 == 0 && (!dx || ld_dx % 4 == 0) && ld_dout % 4 == 0 && (al & 15) == 0;
+  const int64_t n = static_cast<int64_t>(B) * (vec ? d / 4 : d);
+  if (vec)
+    hipLaunchKernelGGL(er::cross_v2_bwd_acc_kernel<4>, dim3(er::blocks_for(n)), dim3(er::kBlock), 0, er::as_stream(stream), x0, x,
+                       u, bias, diag_scale, dout, ld_dout, B, d, dx0, ld_dx0, accumulate_dx0, dx, ld_dx, accumulate_dx, du);
+  else
+    hipLaunchKernelGGL(er::cross_v2_bwd_acc_kernel<1>, dim3(er::blocks_for(n)), dim3(er::kBlock), 0, er::as_stream(stream), x0, x,
+                       u, bias, diag_scale, dout, ld_dout, B, d, dx0, ld_dx0, accumulate_dx0, dx, ld_dx, accumulate_dx, du);
   ER_LAUNCH_CHECK();
   return 0;
 }

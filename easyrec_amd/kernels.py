@@ -140,6 +140,32 @@ def grad_sink_of(x, col0=0, width=None):
   return sink
 
 
+def grad_slots_of_step():
+  """The step's gradient-slot table (kernels.grad_slot), or None: taken in a Function's FORWARD and kept on its ctx - the
+  backward may run on an autograd worker thread, where the thread-local model context is not set."""
+  from easyrec_amd.core import context
+  stack = context._stack()
+  return getattr(stack[-1], 'grad_slots', None) if (stack and _GRAD_SLOTS) else None
+
+
+_GRAD_SLOTS = os.environ.get('EASYREC_AMD_GRAD_SLOTS', '1') != '0'  # A/B switch
+
+
+def grad_slot(slots, x):
+  """One gradient buffer per activation tensor and step, shared by the backward kernels of ALL its consumers: the first to
+  ask gets (a fresh tensor, accumulate = False, first = True) and returns that tensor to autograd; the others get (the same
+  tensor, True, False), ADD into it inside their own kernels and return None - autograd then has one gradient for x and
+  launches no add kernel.  Valid because autograd runs the producer of x only after every consumer's backward.  Keyed by
+  storage start and shape; the table (grad_slots_of_step) is emptied by EasyRecModel.begin_step."""
+  key = (x.data_ptr(), tuple(x.shape))
+  t = slots.get(key)
+  if t is not None:
+    return t, True, False
+  t = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+  slots[key] = t
+  return t, False, True
+
+
 def bn_source_of(x):
   """The BnSource of x if x IS the untouched 2-D output of a fused dense + BatchNorm + activation layer."""
   src = getattr(x, '_er_bn_src', None)
@@ -1279,6 +1305,19 @@ class HipBackend(object):
         'er_cross_v2_epilogue_bwd')
     return dx0, dx, du
 
+  def cross_v2_bwd_acc(self, x0, x, u, bias, diag_scale, dout, dx0, acc0, dx, accx):
+    """er_cross_v2_epilogue_bwd_acc: dx0 / dx are 2-D destinations (unit inner stride; dx None: x is x0) written or, with
+    their flag, accumulated into.  Returns du."""
+    B, d = x0.shape
+    du = torch.empty_like(x0)
+    assert dx0.stride(1) == 1 and (dx is None or dx.stride(1) == 1)
+    assert dout.dim() == 2 and dout.stride(1) == 1 and dout.dtype == torch.float32
+    self._ck(self.lib.er_cross_v2_epilogue_bwd_acc(_p(x0), _p(x), _p(u), _p(bias), ctypes.c_float(diag_scale), _p(dout),
+                                                   ctypes.c_int32(dout.stride(0)), B, d, _p(dx0), ctypes.c_int32(dx0.stride(0)), int(bool(acc0)), _p(dx),
+                                                   ctypes.c_int32(dx.stride(0) if dx is not None else 0), int(bool(accx)),
+                                                   _p(du), _stream()), 'er_cross_v2_epilogue_bwd_acc')
+    return du
+
   # -- K8 DIN
   def din_concat_fwd(self, q, h):
     B, L, E = h.shape
@@ -1847,6 +1886,8 @@ class LinearFn(torch.autograd.Function):
     ctx.sink = be.wgrad_sink()
     ctx.src = src if (src is not None and x2 is x and not bf16 and src.fused and getattr(be, 'fused_bn_bwd', False)) else None
     ctx.gsink = sink if x2 is x else None
+    # (x's other consumers may share its gradient buffer: grad_slot)
+    ctx.slots = grad_slots_of_step() if (x2 is x and x.dim() == 2 and x.is_contiguous()) else None
     return y
 
   @staticmethod
@@ -1856,7 +1897,7 @@ class LinearFn(torch.autograd.Function):
     dy = dy if dy.stride(-1) == 1 and dy.dim() == 2 else dy.contiguous()
     dx = dw = db = None
     if ctx.needs_input_grad[0]:
-      dx = _dgrad(be, dy, w, ctx.src, ctx.bf16, ctx.gsink)
+      dx = _dgrad(be, dy, w, ctx.src, ctx.bf16, ctx.gsink, x, ctx.slots)
     if ctx.needs_input_grad[1]:
       dw = _wgrad(be, x, dy, ctx.w_grad, ctx.bf16, ctx.at, ctx.sink)
     if ctx.has_bias and ctx.needs_input_grad[2]:
@@ -1969,7 +2010,7 @@ def _wgrad(be, x, dz, w_grad, bf16, at, sink):
   return be.gemm(GEMM_TN, x, dz, bf16=bf16)
 
 
-def _dgrad(be, dz, w, src, bf16, sink=None):
+def _dgrad(be, dz, w, src, bf16, sink=None, x=None, slots=None):
   """dx = dz . W^T; when the input was the output of a fused dense + BatchNorm layer (src), the GEMM's epilogue also
   leaves that layer's BatchNorm-backward column sums in src.partial; when it was an embedding group output (sink),
   the GEMM accumulates straight into the group's gradient buffer and nothing is returned to autograd."""
@@ -1979,6 +2020,13 @@ def _dgrad(be, dz, w, src, bf16, sink=None):
     sink.done()
     return None
   if src is None:
+    slot = grad_slot(slots, x) if (x is not None and slots is not None) else None
+    if slot is not None and not slot[2]:
+      # another consumer of x already started its gradient (a cross layer's epilogue): this GEMM accumulates into it
+      be.gemm(GEMM_NT, dz, w, out=slot[0], accumulate=True, bf16=bf16)
+      return None
+    if slot is not None:
+      return be.gemm(GEMM_NT, dz, w, out=slot[0], bf16=bf16)
     return be.gemm(GEMM_NT, dz, w, bf16=bf16)
   M, N = dz.shape[0], w.shape[0]
   if src.exclusive and src.y is not None and src.grad_bufs is not None and getattr(be, 'gemm_fused_bn_ok', None) and \
@@ -2450,28 +2498,56 @@ class CrossV1Fn(torch.autograd.Function):
 
 
 class CrossV2EpilogueFn(torch.autograd.Function):
-  """reference layers/keras/interaction.py:276-286: x0 * (u + bias + diag*x) + x."""
+  """reference layers/keras/interaction.py:276-286: x0 * (u + bias + diag*x) + x.  The backward ADDS its gradients of x0
+  and x into the buffers their other consumers use (the embedding group's gradient buffer when x0 is a group output, else
+  the tensors' grad_slot): a stack of L cross layers sums nothing through autograd."""
 
   @staticmethod
-  def forward(ctx, x0, x, u, bias, diag_scale, bias_grad=None):
-    out = hip().cross_v2_fwd(x0.contiguous(), x.contiguous(), u.contiguous(), bias, diag_scale)
-    ctx.save_for_backward(x0, x, u, bias)
+  def forward(ctx, x0, x, u, bias, diag_scale, bias_grad=None, sink=None):
+    x0c, xc = x0.contiguous(), x.contiguous()
+    out = hip().cross_v2_fwd(x0c, xc, u.contiguous(), bias, diag_scale)
+    ctx.save_for_backward(x0c, xc, u, bias)
     ctx.diag = diag_scale
     ctx.bias_grad = bias_grad
+    ctx.same = x0c.data_ptr() == xc.data_ptr()
+    ctx.sink = sink if (sink is not None and x0c is x0) else None
+    # (a contiguous copy is another tensor: its consumers do not share a slot)
+    ctx.slots = grad_slots_of_step() if (x0c is x0 and xc is x) else None
     return out
 
   @staticmethod
   def backward(ctx, dout):
+    be = hip()
     x0, x, u, bias = ctx.saved_tensors
-    dx0, dx, du = hip().cross_v2_bwd(x0.contiguous(), x.contiguous(), u.contiguous(), bias, ctx.diag,
-                                     dout.contiguous())
+    d = x0.shape[1]
+    ret0 = retx = None
+    if not hasattr(be, 'cross_v2_bwd_acc') or ctx.slots is None:
+      dx0, dx, du = be.cross_v2_bwd(x0, x, u.contiguous(), bias, ctx.diag, dout.contiguous())
+      ret0, retx = dx0, dx
+    else:
+      # destination of d/dx0: the group's gradient buffer (a first deposit must cover it: here it does), else x0's slot
+      sink = ctx.sink
+      if sink is not None and sink.covers(0, d):
+        t0, acc0 = sink.target(0, d)
+      else:
+        sink = None
+        t0, acc0, first0 = grad_slot(ctx.slots, x0)
+        ret0 = t0 if first0 else None
+      tx = accx = None
+      if not ctx.same:
+        tx, accx, firstx = grad_slot(ctx.slots, x)
+        retx = tx if firstx else None
+      dg = dout if (dout.dim() == 2 and dout.stride(1) == 1) else dout.contiguous()  # (a column block of tf.concat's gradient: in place)
+      du = be.cross_v2_bwd_acc(x0, x, u.contiguous(), bias, ctx.diag, dg, t0, acc0, tx, accx)
+      if sink is not None:
+        sink.done()
     dbias = None
     if bias is not None:
       if ctx.bias_grad is not None:  # the column sums straight into the bias' slice of the flat gradient buffer
-        hip().colsum(du, out=ctx.bias_grad, accumulate=True)
+        be.colsum(du, out=ctx.bias_grad, accumulate=True)
       else:
-        dbias = hip().colsum(du)
-    return dx0, dx, du, dbias, None, None
+        dbias = be.colsum(du)
+    return ret0, retx, du, dbias, None, None, None
 
 
 class CINFn(torch.autograd.Function):

@@ -19,6 +19,8 @@ from collections import OrderedDict
 
 import torch
 
+from easyrec_amd import kernels
+
 from easyrec_amd.layers.keras.blocks import MLP
 from easyrec_amd.layers.utils import Parameter
 from easyrec_amd.utils.load_class import load_keras_layer
@@ -344,7 +346,7 @@ class Backbone(object):
     output = self._main_pkg(is_training, **kwargs)
     if self._top_mlp is not None:
       if isinstance(output, (list, tuple)):
-        output = torch.cat(list(output), dim=-1)
+        output = merge_inputs(list(output), msg='backbone output')
       output = self._top_mlp(output, training=is_training, **kwargs)
     return output
 
@@ -369,6 +371,8 @@ def merge_inputs(inputs, axis=-1, msg=''):
   if any(isinstance(x, list) for x in inputs):
     logging.warning('%s: try to merge inputs into list' % msg)
     return [e for x in inputs for e in (x if isinstance(x, list) else [x])]
+  if axis in (-1, 1) and all(torch.is_tensor(x) and x.dim() == 2 and x.dtype == torch.float32 for x in inputs) and len(inputs) <= 8:
+    return kernels.concat_cols(list(inputs))  # (one library launch; the backward hands out column views, no copies)
   return torch.cat(list(inputs), dim=axis)
 
 

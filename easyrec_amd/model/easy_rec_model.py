@@ -140,6 +140,7 @@ class EasyRecModel(six.with_metaclass(_meta_type, object)):
     if ctx is not None and hasattr(ctx, 'heads'):
       ctx.heads.clear()
       del ctx.tail_jobs[:]
+      ctx.grad_slots.clear()
 
   @abstractmethod
   def build_predict_graph(self):

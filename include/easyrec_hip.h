@@ -382,6 +382,14 @@ int er_cross_v2_epilogue_bwd(const float* x0, const float* x, const float* u, co
                              float diag_scale, const float* dout, int32_t B, int32_t d,
                              float* dx0, int accumulate_dx0, float* dx, float* du,
                              er_stream_t stream);
+/* the same with caller-provided destinations: dx0 (row stride ld_dx0) and dx (row stride ld_dx) are stored or, with their
+ * accumulate flag, ADDED to what the buffers hold - an embedding group's gradient buffer, the tensor another gradient of the
+ * same x_l went to - so that the sums autograd would run as separate add kernels happen here; dx == NULL: x is x0 (the first
+ * cross layer of layers/keras/interaction.py:276-286) and its gradient joins dx0's.  dout: row stride ld_dout (a column
+ * block of a wider gradient - tf.concat's backward - is read in place). */
+int er_cross_v2_epilogue_bwd_acc(const float* x0, const float* x, const float* u, const float* bias, float diag_scale,
+                                 const float* dout, int32_t ld_dout, int32_t B, int32_t d, float* dx0, int32_t ld_dx0,
+                                 int accumulate_dx0, float* dx, int32_t ld_dx, int accumulate_dx, float* du, er_stream_t stream);
 
 /* ---- K1b: hash-table ("KV") embedding tables: `ev_params` on a feature / model config ---------------------------
  * In the reference an embedding column with ev_params is backed by PAI-TF's get_embedding_variable

@@ -799,6 +799,21 @@ class RefBackend(object):
       t = t + diag_scale * x
     return x0 * t + x
 
+  def cross_v2_bwd_acc(self, x0, x, u, bias, diag_scale, dout, dx0, acc0, dx, accx):
+    g0, gx, du = self.cross_v2_bwd(x0, x, u, bias, diag_scale, dout)
+    if dx is None:
+      g0 = g0 + gx
+    if acc0:
+      dx0.add_(g0)
+    else:
+      dx0.copy_(g0)
+    if dx is not None:
+      if accx:
+        dx.add_(gx)
+      else:
+        dx.copy_(gx)
+    return du
+
   def cross_v2_bwd(self, x0, x, u, bias, diag_scale, dout):
     t = u if bias is None else u + bias
     if diag_scale != 0:
