@@ -1,6 +1,7 @@
 """Evaluation metrics on the hot path's predictions.
 
-Also: gAUC / session AUC (`SeparatedAUC`) and max F1 (`MaxF1`), host-side as in the reference (see below).
+Also: gAUC / session AUC (`SeparatedAUC` host-side as in the reference, `DeviceSeparatedAUC` the same numbers from device
+kernels: what evaluate() uses) and max F1 (`MaxF1`).
 
 AUC = `tf.metrics.auc(labels, predictions, num_thresholds=200)` as called by `RankModel.build_metric_graph`
 (reference easy_rec/python/model/rank_model.py:358-373; `eval_config.metrics_set { auc {} }`).  TensorFlow's
@@ -126,6 +127,50 @@ class SeparatedAUC(object):
     if not metrics:
       return 0.0
     return float(np.average(metrics, weights=weights).astype(np.float32))
+
+
+class DeviceSeparatedAUC(object):
+  """SeparatedAUC with the rows kept and reduced on the device: labels and predictions never leave it, the keys arrive
+  as one int64 per example (integer ids as they are, strings as a 64-bit digest - grouping only needs equality), and
+  result() is two device sorts + er_grouped_auc (kernels.py grouped_auc).  Same numbers as SeparatedAUC."""
+
+  def __init__(self, reduction='mean', device='cpu'):
+    assert reduction in SeparatedAUC.REDUCTIONS, 'reduction method must in mean | mean_by_sample_num | mean_by_positive_num'
+    self.reduction, self.device = reduction, torch.device(device)
+    self.reset()
+
+  def reset(self):
+    self._labels, self._preds, self._keys = [], [], []
+
+  @staticmethod
+  def key_codes(keys):
+    """One int64 per key: integers unchanged, anything else (the raw bytes of a string feature) by a 64-bit digest."""
+    if torch.is_tensor(keys):
+      return keys.reshape(-1).to(torch.int64)
+    keys = np.asarray(keys).reshape(-1)
+    if keys.dtype.kind in 'iu':
+      return torch.from_numpy(keys.astype(np.int64))
+    import hashlib
+    def digest(k):
+      raw = k if isinstance(k, bytes) else str(k).encode('utf-8')
+      return int.from_bytes(hashlib.blake2b(raw, digest_size=8).digest(), 'little', signed=True)
+    return torch.tensor([digest(k) for k in keys.tolist()], dtype=torch.int64)
+
+  def update(self, labels, predictions, keys):
+    labels = torch.as_tensor(labels).reshape(-1).to(self.device, torch.float32)
+    predictions = torch.as_tensor(predictions).detach().reshape(-1).to(self.device, torch.float32)
+    codes = self.key_codes(keys).to(self.device)
+    assert labels.numel() == predictions.numel() == codes.numel()
+    self._labels.append(labels.clone())
+    self._preds.append(predictions.clone())
+    self._keys.append(codes)
+
+  def result(self):
+    if not self._labels:
+      return 0.0
+    total, wsum, _ = kernels.hip().grouped_auc(torch.cat(self._keys), torch.cat(self._preds), torch.cat(self._labels),
+                                               SeparatedAUC.REDUCTIONS.index(self.reduction))
+    return float(np.float32(total / wsum)) if wsum > 0 else 0.0
 
 
 def gauc(reduction='mean'):

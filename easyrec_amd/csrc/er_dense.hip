@@ -1325,6 +1325,56 @@ auc_hist_kernel(const float* __restrict__ probs, const float* __restrict__ label
   atomicAdd(&counts[static_cast<size_t>(pos) * (T + 1) + lo], 1ull);
 }
 
+// ------------------------------------------------------------------------------------------------
+// K16b grouped AUC (gAUC / session AUC).  The rows arrive sorted by (key, prediction): thread i finds its key's
+// segment [gs, ge) and, inside it, the run [rs, re) of predictions equal to its own (binary searches), so its average
+// 1-based rank in the segment is (rs - gs + 1 + re - gs) / 2 - a half-integer, exact in a double, so the atomic sums
+// below do not depend on their order.  Accumulators live at the segment's first index.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+grouped_auc_rank_kernel(const int64_t* __restrict__ keys, const float* __restrict__ preds, const float* __restrict__ labels,
+                        int64_t n, double* __restrict__ pos_rank_sum, double* __restrict__ n_pos, double* __restrict__ n_all) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const int64_t key = keys[i];
+  int64_t lo = 0, hi = i;          // gs: first index with keys[idx] >= key
+  while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (keys[mid] < key) lo = mid + 1; else hi = mid; }
+  const int64_t gs = lo;
+  lo = i + 1; hi = n;              // ge: first index with keys[idx] > key
+  while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (keys[mid] <= key) lo = mid + 1; else hi = mid; }
+  const int64_t ge = lo;
+  if (i == gs) n_all[gs] = static_cast<double>(ge - gs);
+  if (labels[i] == 0.f) return;
+  const float p = preds[i];
+  lo = gs; hi = i;                 // rs: first index of the segment with preds[idx] >= p
+  while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (preds[mid] < p) lo = mid + 1; else hi = mid; }
+  const int64_t rs = lo;
+  lo = i + 1; hi = ge;             // re: first index of the segment with preds[idx] > p
+  while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (preds[mid] <= p) lo = mid + 1; else hi = mid; }
+  const int64_t re = lo;
+  atomicAdd(&pos_rank_sum[gs], 0.5 * static_cast<double>((rs - gs + 1) + (re - gs)));
+  atomicAdd(&n_pos[gs], 1.0);
+}
+
+// per segment: the Mann-Whitney AUC when both classes are present, weighted by the reduction
+// (0 'mean': 1, 1 'mean_by_sample_num': rows, 2 'mean_by_positive_num': positives; reference core/metrics.py:59-108);
+// out[0] += w * auc, out[1] += w, out[2] += 1
+__global__ void __launch_bounds__(kBlock)
+grouped_auc_reduce_kernel(const double* __restrict__ pos_rank_sum, const double* __restrict__ n_pos,
+                          const double* __restrict__ n_all, int64_t n, int reduction, double* __restrict__ out) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const double cnt = n_all[i];
+  if (cnt <= 0.0) return;
+  const double np = n_pos[i], nn = cnt - np;
+  if (np <= 0.0 || nn <= 0.0) return;  // (keys with one class are skipped, metrics.py:93-94)
+  const double auc = (pos_rank_sum[i] - np * (np + 1.0) * 0.5) / (np * nn);
+  const double w = reduction == 0 ? 1.0 : (reduction == 1 ? cnt : np);
+  atomicAdd(&out[0], w * auc);
+  atomicAdd(&out[1], w);
+  atomicAdd(&out[2], 1.0);
+}
+
 }  // namespace er
 
 extern "C" {
@@ -1882,6 +1932,21 @@ int er_auc_update(const float* probs, const float* labels, const float* weights,
   if (n == 0) return 0;
   hipLaunchKernelGGL(er::auc_hist_kernel, dim3(er::blocks_for(n)), dim3(er::kBlock), 0, er::as_stream(stream), probs, labels,
                      weights, n, thresholds, num_thresholds, reinterpret_cast<unsigned long long*>(counts));
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
+int er_grouped_auc(const int64_t* keys, const float* preds, const float* labels, int64_t n, int reduction, double* work,
+                   double* out, er_stream_t stream) {
+  ER_REQUIRE(n >= 0 && out && (n == 0 || (keys && preds && labels && work)) && reduction >= 0 && reduction <= 2,
+             "er_grouped_auc: bad arguments");
+  if (n == 0) return 0;
+  hipStream_t s = er::as_stream(stream);
+  hipLaunchKernelGGL(er::grouped_auc_rank_kernel, dim3(er::blocks_for(n)), dim3(er::kBlock), 0, s, keys, preds, labels, n, work,
+                     work + n, work + 2 * n);
+  ER_LAUNCH_CHECK();
+  hipLaunchKernelGGL(er::grouped_auc_reduce_kernel, dim3(er::blocks_for(n)), dim3(er::kBlock), 0, s, work, work + n, work + 2 * n,
+                     n, reduction, out);
   ER_LAUNCH_CHECK();
   return 0;
 }

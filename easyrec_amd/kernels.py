@@ -21,7 +21,9 @@ class KvJob(ctypes.Structure):
   _fields_ = [('ids', ctypes.c_void_p), ('n', ctypes.c_int64), ('map_keys', ctypes.c_void_p), ('map_rows', ctypes.c_void_p),
               ('map_slots', ctypes.c_int64), ('next_row', ctypes.c_void_p), ('var', ctypes.c_void_p), ('seed', ctypes.c_uint64),
               ('rows_out', ctypes.c_void_p), ('overflow', ctypes.c_void_p), ('capacity', ctypes.c_int32), ('dim', ctypes.c_int32),
-              ('init_mean', ctypes.c_float), ('init_stddev', ctypes.c_float), ('n_limit', ctypes.c_void_p)]
+              ('init_mean', ctypes.c_float), ('init_stddev', ctypes.c_float), ('n_limit', ctypes.c_void_p),
+              ('freq', ctypes.c_void_p), ('version', ctypes.c_void_p), ('n_keys', ctypes.c_void_p), ('step', ctypes.c_void_p),
+              ('filter_freq', ctypes.c_int32), ('reserved', ctypes.c_int32)]
 
 
 class CastDesc(ctypes.Structure):
@@ -1176,6 +1178,23 @@ class HipBackend(object):
     self._ck(self.lib.er_auc_update(_p(probs), _p(labels), _p(w), ctypes.c_int64(probs.numel()), _p(thresholds),
                                     ctypes.c_int32(thresholds.numel()), _p(counts), _stream()), 'er_auc_update')
 
+  def grouped_auc(self, keys, preds, labels, reduction):
+    """gAUC / session AUC of the accumulated rows (int64 keys, fp32 predictions, labels != 0 positive) -> (sum of
+    w * AUC over the keys with both classes, sum of w, number of such keys); the ordering by (key, prediction) is two
+    stable device sorts, the ranks and the reduction are er_grouped_auc (one host read at the end)."""
+    n = keys.numel()
+    preds, labels = _f32c(preds.reshape(-1)), _f32c(labels.reshape(-1))
+    assert preds.numel() == n and labels.numel() == n and keys.dtype == torch.int64
+    out = torch.zeros(3, dtype=torch.float64, device=keys.device)
+    if n:
+      by_pred = torch.sort(preds, stable=True).indices
+      order = by_pred[torch.sort(keys.reshape(-1)[by_pred], stable=True).indices]
+      k, p, y = keys.reshape(-1)[order].contiguous(), preds[order].contiguous(), labels[order].contiguous()
+      work = torch.zeros(3 * n, dtype=torch.float64, device=keys.device)
+      self._ck(self.lib.er_grouped_auc(_p(k), _p(p), _p(y), ctypes.c_int64(n), ctypes.c_int32(int(reduction)), _p(work), _p(out),
+                                       _stream()), 'er_grouped_auc')
+    return tuple(float(x) for x in out.cpu().tolist())
+
   def dot_interaction_fwd(self, x, F, D, self_interaction):
     """x [B, F*D] -> [B, P] pairwise dot products in the order of model/dlrm.py:51-57."""
     B = x.shape[0]
@@ -1354,28 +1373,46 @@ class HipBackend(object):
     return dscores, dhist
 
   # -- K1b hash-table (KV) embedding tables
-  def kv_create(self, var_rows, capacity, seed, init_mean, init_stddev):
-    """The map of one KV table whose arena is `var_rows` ([capacity, dim] view of the table group's storage)."""
+  def kv_create(self, var_rows, capacity, seed, init_mean, init_stddev, filter_freq=0, steps_to_live=0, step=None):
+    """The map of one KV table whose arena is `var_rows` ([capacity, dim] view of the table group's storage).
+    filter_freq > 1: keys get their row once seen that often (the map then tracks every id SEEN: 4x the slots);
+    steps_to_live > 0: every training lookup stamps the key with `step` (int64 device counter) for evict at save time."""
     dev = var_rows.device
+    filter_freq, steps_to_live = int(filter_freq), int(steps_to_live)
     slots = 1
-    while slots < 2 * int(capacity):
+    while slots < (8 if filter_freq > 1 else 2) * int(capacity):
       slots *= 2
-    return {'keys': torch.full((slots,), -1, dtype=torch.int64, device=dev),
-            'rows': torch.full((slots,), -1, dtype=torch.int32, device=dev),
-            'next_row': torch.zeros(1, dtype=torch.int32, device=dev),
-            'overflow': torch.zeros(1, dtype=torch.int32, device=dev),
-            'capacity': int(capacity), 'var': var_rows, 'dim': int(var_rows.shape[1]), 'seed': int(seed) & ((1 << 63) - 1),
-            'mean': float(init_mean), 'stddev': float(init_stddev)}
+    kv = {'keys': torch.full((slots,), -1, dtype=torch.int64, device=dev),
+          'rows': torch.full((slots,), -1, dtype=torch.int32, device=dev),
+          'next_row': torch.zeros(1, dtype=torch.int32, device=dev),
+          'overflow': torch.zeros(1, dtype=torch.int32, device=dev),
+          'capacity': int(capacity), 'var': var_rows, 'dim': int(var_rows.shape[1]), 'seed': int(seed) & ((1 << 63) - 1),
+          'mean': float(init_mean), 'stddev': float(init_stddev), 'filter_freq': filter_freq,
+          'steps_to_live': steps_to_live, 'freq': None, 'version': None, 'n_keys': None, 'step': None}
+    if filter_freq > 1:
+      kv['freq'] = torch.zeros(slots, dtype=torch.int32, device=dev)
+      kv['n_keys'] = torch.zeros(1, dtype=torch.int32, device=dev)
+    if steps_to_live > 0:
+      assert step is not None and step.dtype == torch.int64, 'steps_to_live needs the device step counter'
+      kv['version'] = torch.zeros(slots, dtype=torch.int32, device=dev)
+      kv['step'] = step
+    return kv
+
+  @staticmethod
+  def _kv_job(kv, ids, rows_out, limit=None):
+    opt = lambda t: 0 if t is None else t.data_ptr()
+    return KvJob(ids.data_ptr(), ids.numel(), kv['keys'].data_ptr(), kv['rows'].data_ptr(), kv['keys'].numel(),
+                 kv['next_row'].data_ptr(), kv['var'].data_ptr(), kv['seed'], rows_out.data_ptr(),
+                 kv['overflow'].data_ptr(), kv['capacity'], kv['dim'], kv['mean'], kv['stddev'], opt(limit),
+                 opt(kv['freq']), opt(kv['version']), opt(kv['n_keys']), opt(kv['step']), kv['filter_freq'], 0)
 
   def kv_translate(self, kv, ids, rows_out, insert):
-    """rows_out[i] = arena row of ids[i] (-1: no row); insert: unseen ids get a row (training)."""
+    """rows_out[i] = arena row of ids[i] (-1: no row); insert: a training lookup (unseen ids get a row, or - filtered
+    tables - a count)."""
     assert ids.dtype == torch.int64 and rows_out.dtype == torch.int64 and ids.is_contiguous() and rows_out.is_contiguous()
     assert ids.numel() == rows_out.numel()
-    self._ck(self.lib.er_kv_translate(_p(ids), ctypes.c_int64(ids.numel()), _p(kv['keys']), _p(kv['rows']),
-                                      ctypes.c_int64(kv['keys'].numel()), _p(kv['next_row']), ctypes.c_int32(kv['capacity']),
-                                      _p(kv['var']), ctypes.c_int32(kv['dim']), ctypes.c_uint64(kv['seed']),
-                                      ctypes.c_float(kv['mean']), ctypes.c_float(kv['stddev']), int(bool(insert)),
-                                      _p(rows_out), _p(kv['overflow']), _stream()), 'er_kv_translate')
+    job = self._kv_job(kv, ids, rows_out)
+    self._ck(self.lib.er_kv_translate_job(ctypes.byref(job), int(bool(insert)), _stream()), 'er_kv_translate_job')
 
   def kv_jobs_create(self, jobs):
     """jobs: [(kv, ids, rows_out[, n_limit])] -> the device-resident descriptor table of er_kv_translate_multi (built
@@ -1388,10 +1425,7 @@ class HipBackend(object):
       limit = job[3] if len(job) > 3 else None
       assert limit is None or (limit.dtype == torch.int32 and limit.numel() == 1)
       assert ids.dtype == torch.int64 and rows_out.dtype == torch.int64 and ids.is_contiguous() and rows_out.is_contiguous()
-      arr[i] = KvJob(ids.data_ptr(), ids.numel(), kv['keys'].data_ptr(), kv['rows'].data_ptr(), kv['keys'].numel(),
-                     kv['next_row'].data_ptr(), kv['var'].data_ptr(), kv['seed'], rows_out.data_ptr(),
-                     kv['overflow'].data_ptr(), kv['capacity'], kv['dim'], kv['mean'], kv['stddev'],
-                     0 if limit is None else limit.data_ptr())
+      arr[i] = self._kv_job(kv, ids, rows_out, limit)
       starts.append(starts[-1] + (ids.numel() + 255) // 256)
     dev = jobs[0][1].device
     table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
@@ -1416,6 +1450,44 @@ class HipBackend(object):
     keys, rows = keys[:n], rows[:n]
     order = torch.argsort(keys)
     return keys[order], rows[order].to(torch.int64)
+
+  def kv_export_all(self, kv):
+    """Every key the map holds, ascending: (keys, arena rows (-1: no row yet), freq, version) (host sync)."""
+    slots, dev = kv['keys'].numel(), kv['keys'].device
+    n_max = slots // 2 + 1
+    keys = torch.empty(n_max, dtype=torch.int64, device=dev)
+    rows, freq, version = (torch.empty(n_max, dtype=torch.int32, device=dev) for _ in range(3))
+    count = torch.zeros(1, dtype=torch.int32, device=dev)
+    opt = lambda t: None if t is None else _p(t)
+    self._ck(self.lib.er_kv_export_all(_p(kv['keys']), _p(kv['rows']), opt(kv['freq']), opt(kv['version']),
+                                       ctypes.c_int64(slots), _p(keys), _p(rows), _p(freq), _p(version), _p(count), _stream()),
+             'er_kv_export_all')
+    n = int(count.item())
+    order = torch.argsort(keys[:n])
+    return keys[:n][order], rows[:n][order].to(torch.int64), freq[:n][order], version[:n][order]
+
+  def kv_rebuild(self, kv, keys, rows, freq=None, version=None):
+    """Replace the map's content: distinct `keys` with their arena `rows` (-1: tracked, no row yet), counts and stamps.
+    The rows in use become 0 .. (number of rows >= 0) - 1: the caller has laid the arena out that way."""
+    dev = kv['keys'].device
+    keys = keys.to(dev, torch.int64).contiguous()
+    rows32 = rows.to(dev, torch.int32).contiguous()
+    kv['keys'].fill_(-1)
+    kv['rows'].fill_(-1)
+    opt = lambda t: None if t is None else _p(t)
+    if kv['freq'] is not None:
+      kv['freq'].zero_()
+      freq = None if freq is None else freq.to(dev, torch.int32).contiguous()
+    if kv['version'] is not None:
+      kv['version'].zero_()
+      version = None if version is None else version.to(dev, torch.int32).contiguous()
+    self._ck(self.lib.er_kv_rebuild(opt(keys), opt(rows32), opt(freq) if kv['freq'] is not None else None,
+                                    opt(version) if kv['version'] is not None else None, ctypes.c_int64(keys.numel()),
+                                    _p(kv['keys']), _p(kv['rows']), opt(kv['freq']), opt(kv['version']),
+                                    ctypes.c_int64(kv['keys'].numel()), _p(kv['overflow']), _stream()), 'er_kv_rebuild')
+    kv['next_row'].fill_(int((rows32 >= 0).sum().item()))
+    if kv['n_keys'] is not None:
+      kv['n_keys'].fill_(keys.numel())
 
   # -- K9b CIN (xDeepFM)
   def cin_outer_fwd(self, xi, strides, H, x0, z):

@@ -149,9 +149,11 @@ class EmbeddingEngine(object):
     self._fused = None
 
   # -- declaration (build pass)
-  def declare_table(self, var_name, rows, dim, initializer=None, kv_capacity=None):
+  def declare_table(self, var_name, rows, dim, initializer=None, kv_capacity=None, kv_filter_freq=0, kv_steps_to_live=0):
     """kv_capacity: a hash-table (`ev_params`) table - `rows` is then the capacity of its arena, ids are translated to
-    arena rows before every lookup (er_kv_translate) and rows are created on first sight."""
+    arena rows before every lookup (er_kv_translate) and rows are created on first sight - or, with kv_filter_freq > 1,
+    once the id has been seen that often; kv_steps_to_live > 0: ids not seen for that many steps are dropped when a
+    checkpoint is written (evict_stale)."""
     if kv_capacity is not None:
       rows = int(kv_capacity)
     if var_name in self.tables:
@@ -162,7 +164,7 @@ class EmbeddingEngine(object):
     base = self.dim_rows.get(dim, 0)
     self.dim_rows[dim] = base + rows
     t = {'name': var_name, 'rows': int(rows), 'dim': int(dim), 'key_base': base, 'init': initializer,
-         'kv': kv_capacity is not None}
+         'kv': kv_capacity is not None, 'kv_filter_freq': int(kv_filter_freq), 'kv_steps_to_live': int(kv_steps_to_live)}
     self.tables[var_name] = t
     return t
 
@@ -362,7 +364,10 @@ class EmbeddingEngine(object):
         # starts as zeros (a row that no id owns is never read)
         self.table_view(name).zero_()
         mean, std = self._init_mean_std(t)
-        self.kv_tables[name] = be.kv_create(self.table_view(name), t['rows'], _stable_seed(name, self.seed), mean, std)
+        assert t['kv_steps_to_live'] == 0 or self._clock is not None, 'steps_to_live needs the step clock (set_step_clock)'
+        self.kv_tables[name] = be.kv_create(self.table_view(name), t['rows'], _stable_seed(name, self.seed), mean, std,
+                                            filter_freq=t['kv_filter_freq'], steps_to_live=t['kv_steps_to_live'],
+                                            step=self._clock[0] if t['kv_steps_to_live'] > 0 else None)
       else:
         self.init_table_values(name, self.table_view(name))
     # lookup specs: regularised groups first so their sum-of-squares partials form a prefix
@@ -700,6 +705,45 @@ class EmbeddingEngine(object):
     self._decay_pending = True
 
   # -- host exchange
+  def _kv_filtered(self, name):
+    t = self.tables[name]
+    return t['kv_filter_freq'] > 1 or t['kv_steps_to_live'] > 0
+
+  def evict_stale(self, global_step):
+    """ev_params.steps_to_live (GlobalStepEvict): drop the ids whose last training lookup is more than steps_to_live
+    steps before `global_step` and compact the arena (var / slots / last_step rows move down, the freed rows are zeroed
+    like a fresh arena's).  Called when a checkpoint is written (utils/checkpoint.py save), as DeepRec evicts."""
+    be = kernels.hip()
+    evicted = {}
+    for name, kv in self.kv_tables.items():
+      stl = self.tables[name]['kv_steps_to_live']
+      if stl <= 0:
+        continue
+      self.flush_decay()
+      keys, rows, freq, version = be.kv_export_all(kv)
+      keep = (int(global_step) - version.to(torch.int64)) <= stl
+      if bool(keep.all()):
+        continue
+      evicted[name] = int((~keep).sum().item())
+      old_used = int(rows.max().item()) + 1   # (arena rows in use: 0 .. old_used - 1)
+      keys, rows, freq, version = keys[keep], rows[keep], freq[keep], version[keep]
+      has_row = rows >= 0
+      src = rows[has_row]
+      order = torch.argsort(src)               # arena order is kept: row i of the compacted arena = i-th surviving row
+      new_rows = torch.full_like(rows, -1)
+      new_rows[has_row.nonzero().view(-1)[order]] = torch.arange(src.numel(), dtype=rows.dtype, device=rows.device)
+      src = src[order].to(self.device)
+      n = src.numel()
+      t = self.tables[name]
+      views = [self.table_view(name)] + [v for v in (self.slot_view(name, 'm'), self.slot_view(name, 'v')) if v is not None]
+      # (lazy decay's last_step needs no move: after the flush above every row of the group carries the same stamp)
+      for v in views:
+        moved = v[src].clone()
+        v[:n] = moved
+        v[n:old_used].zero_()
+      be.kv_rebuild(kv, keys, new_rows, freq, version)
+    return evicted
+
   def state_dict(self, slots=False):
     out = OrderedDict()
     self.flush_decay()
@@ -709,9 +753,21 @@ class EmbeddingEngine(object):
       if self.tables[name]['kv']:
         # the materialised ids in ascending order and their rows (arena positions are run-dependent, keys are not)
         kv = self.kv_tables[name]
-        keys, rows = kernels.hip().kv_export(kv)
+        t = self.tables[name]
+        if self._kv_filtered(name):
+          seen, seen_rows, freq, version = kernels.hip().kv_export_all(kv)
+          has_row = seen_rows >= 0
+          keys, rows = seen[has_row], seen_rows[has_row]
+          # every id the table tracks (the counter filter's candidates included), its count (counting stops at
+          # filter_freq) and the step of its last training lookup
+          out[name + '/kv_seen_keys'] = seen.cpu().numpy().copy()
+          out[name + '/kv_freq'] = np.minimum(freq.cpu().numpy(), max(t['kv_filter_freq'], 1)).astype(np.int32)
+          out[name + '/kv_version'] = version.cpu().numpy().copy()
+        else:
+          keys, rows = kernels.hip().kv_export(kv)
         out[name + '/keys'] = keys.cpu().numpy().copy()
-        out[name + '/kv_meta'] = np.array([kv['seed'], kv['mean'], kv['stddev'], kv['capacity']], dtype=np.float64)
+        out[name + '/kv_meta'] = np.array([kv['seed'], kv['mean'], kv['stddev'], kv['capacity'], t['kv_filter_freq'],
+                                           t['kv_steps_to_live']], dtype=np.float64)
       pick = (lambda v: v) if rows is None else (lambda v: v[rows.to(v.device)])
       out[name] = pick(self.table_view(name).detach()).cpu().numpy().copy()
       if slots:
@@ -721,22 +777,51 @@ class EmbeddingEngine(object):
             out[name + '/' + s] = pick(sv.detach()).cpu().numpy().copy()
     return out
 
+  def load_kv_table(self, name, keys, values, slot_values, seen=None, freq=None, version=None):
+    """The hash-table table becomes exactly the saved one: saved id i (keys ascending) owns arena row i, the ids the
+    counter filter was still counting (`seen` minus `keys`) keep their counts, everything else is dropped.
+    values / slot_values[s]: [len(keys), dim] rows in the order of `keys`."""
+    kv = self.kv_tables[name]
+    keys = torch.from_numpy(np.ascontiguousarray(keys, dtype=np.int64))
+    n = keys.numel()
+    assert n <= kv['capacity'], 'hash-table embedding %s: %d saved ids, capacity %d' % (name, n, kv['capacity'])
+    assert n < 2 or bool((keys[1:] > keys[:-1]).all()), 'hash-table embedding %s: saved ids must be ascending' % name
+    rows = torch.arange(n, dtype=torch.int64)
+    if seen is not None and self._kv_filtered(name):
+      seen = torch.from_numpy(np.ascontiguousarray(seen, dtype=np.int64))
+      pos = torch.searchsorted(seen, keys)   # (both ascending; every saved id is among the seen ones)
+      assert bool((seen[pos.clamp(max=max(seen.numel() - 1, 0))] == keys).all()), name
+      rows = torch.full((seen.numel(),), -1, dtype=torch.int64)
+      rows[pos] = torch.arange(n, dtype=torch.int64)
+      freq = torch.from_numpy(np.ascontiguousarray(freq, dtype=np.int32))
+      version = torch.from_numpy(np.ascontiguousarray(version, dtype=np.int32))
+      keys = seen
+    else:
+      version = None
+      # (a checkpoint without the filter's state: a row means the id was admitted)
+      freq = torch.full((n,), self.tables[name]['kv_filter_freq'], dtype=torch.int32) \
+          if self.tables[name]['kv_filter_freq'] > 1 else None
+    kernels.hip().kv_rebuild(kv, keys, rows, freq, version)
+    self.check_kv_overflow()
+    view = self.table_view(name)
+    view.zero_()
+    view[:n] = torch.as_tensor(np.asarray(values, dtype=np.float32)).to(self.device)
+    for sl in ('m', 'v'):
+      sv = self.slot_view(name, sl)
+      if sv is not None:
+        sv.zero_()
+        if sl in slot_values:
+          sv[:n] = torch.as_tensor(np.asarray(slot_values[sl], dtype=np.float32)).to(self.device)
+
   def load_state_dict(self, state):
     for name in self.tables:
       if name not in state:
         continue
       values = torch.from_numpy(np.asarray(state[name], dtype=np.float32)).to(self.device)
       if self.tables[name]['kv']:
-        # re-create the rows of the saved ids (any arena order), then overwrite them with the saved values
-        keys = torch.from_numpy(np.asarray(state[name + '/keys'], dtype=np.int64)).to(self.device)
-        rows = torch.empty_like(keys)
-        kernels.hip().kv_translate(self.kv_tables[name], keys, rows, True)
-        self.check_kv_overflow()
-        self.table_view(name)[rows] = values
-        for s in ('m', 'v'):
-          sv = self.slot_view(name, s)
-          if sv is not None and (name + '/' + s) in state:
-            sv[rows] = torch.from_numpy(np.asarray(state[name + '/' + s], dtype=np.float32)).to(self.device)
+        slot_values = {sl: state[name + '/' + sl] for sl in ('m', 'v') if (name + '/' + sl) in state}
+        self.load_kv_table(name, state[name + '/keys'], values, slot_values, state.get(name + '/kv_seen_keys'),
+                           state.get(name + '/kv_freq'), state.get(name + '/kv_version'))
       else:
         self.table_view(name).copy_(values)
 
@@ -947,8 +1032,9 @@ def declare_lookup(eng, features, column, scope, gkey, col, n_out_rows, seq=Fals
     assert cat.kind == 'hash' and not seq and not column.shared_name, \
         'ev_params on %s: hash-table embeddings cover hashed IdFeatures and TagFeatures' % column.raw_name
     kv_capacity = int(ev.max_capacity) if ev.HasField('max_capacity') else int(os.environ.get('EASYREC_AMD_KV_CAPACITY', 1 << 22))
-    assert ev.filter_freq == 0 and ev.steps_to_live == 0, 'ev_params.filter_freq / steps_to_live are not supported'
-  eng.declare_table(table_name, rows, column.dimension, column.initializer, kv_capacity=kv_capacity)
+  eng.declare_table(table_name, rows, column.dimension, column.initializer, kv_capacity=kv_capacity,
+                    kv_filter_freq=int(ev.filter_freq) if ev is not None else 0,
+                    kv_steps_to_live=int(ev.steps_to_live) if ev is not None else 0)
   fname = column.raw_name
   schema = features.schema
   B = features.batch_size

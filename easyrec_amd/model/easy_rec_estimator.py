@@ -411,7 +411,7 @@ class EasyRecEstimator(object):
       if kind == 'auc':
         return metrics_lib.AUC(arg, self.device)
       if kind == 'grouped':
-        return metrics_lib.SeparatedAUC(arg[1])
+        return metrics_lib.DeviceSeparatedAUC(arg[1], self.device)
       return metrics_lib.MaxF1()
 
     acc = {}
@@ -429,7 +429,7 @@ class EasyRecEstimator(object):
             label = torch.trunc(label)
           if kind == 'auc':  # metrics_tf.auc(label, probs, num_thresholds): no weights (rank_model.py:362)
             m.update(label, pred['probs' + suf], None)
-          elif kind == 'grouped':  # host-side, as the reference's py_func
+          elif kind == 'grouped':  # labels / predictions stay on the device; only the key column comes from the host batch
             m.update(label, pred['probs' + suf], host_key_column(self.features.schema, batch, arg[0]))
           else:
             # max_f1 is fed the LOGITS (rank_model.py:424-427: `metrics_lib.max_f1(label, prediction_dict['logits'])`),

@@ -71,9 +71,20 @@ def _remove_stale_kv_parts(ckpt_path, var_name, world):
 
 
 def _save_kv_table(engine, ckpt_path, name, slots, rank, world=1):
-  """keys / rows of the ids that have a row, and the same rows of every slot (the slots share the table's keys)"""
+  """keys / rows of the ids that have a row, and the same rows of every slot (the slots share the table's keys).
+  -> the filter's state of an `ev_params { filter_freq / steps_to_live }` table (every id the table tracks, its count and
+  the step of its last lookup), which goes into the dense file."""
   kv = engine.kv_tables[name]
-  keys, rows = kernels.hip().kv_export(kv)
+  aux = {}
+  if engine._kv_filtered(name):
+    seen, seen_rows, freq, version = kernels.hip().kv_export_all(kv)
+    has_row = seen_rows >= 0
+    keys, rows = seen[has_row], seen_rows[has_row]
+    aux = {name + '/kv_seen_keys': seen.cpu().numpy().astype(np.int64),
+           name + '/kv_freq': np.minimum(freq.cpu().numpy(), max(engine.tables[name]['kv_filter_freq'], 1)).astype(np.int32),
+           name + '/kv_version': version.cpu().numpy().astype(np.int32)}
+  else:
+    keys, rows = kernels.hip().kv_export(kv)
   os.makedirs(ckpt_path + '-embedding', exist_ok=True)
   keys_np = keys.cpu().numpy().astype(np.int64)
   pairs = [(name, engine.table_view(name))] + [(name + '/' + suffix, engine.slot_view(name, s)) for s, suffix in slots.items()]
@@ -85,26 +96,28 @@ def _save_kv_table(engine, ckpt_path, name, slots, rank, world=1):
     view[rows.to(view.device)].detach().cpu().numpy().astype(np.float32).tofile(_kv_file(ckpt_path, fv, rank, 'val'))
     if rank == 0:
       _remove_stale_kv_parts(ckpt_path, fv, world)
+  return aux
 
 
-def _restore_kv_table(be, engine, ckpt_path, name, slots, rank, world):
-  kv = engine.kv_tables[name]
-  dev = engine.table_view(name).device
+def _restore_kv_table(be, engine, ckpt_path, name, slots, rank, world, aux):
+  """The table becomes the saved one (layers/input_layer.py load_kv_table); a slot's file carries the table's keys in its
+  own order."""
   dim = engine.table_view(name).shape[1]
-  pairs = [(name, engine.table_view(name))] + [(name + '/' + suffix, engine.slot_view(name, s)) for s, suffix in slots.items()]
-  for i, (var, view) in enumerate(pairs):
-    if view is None:
+  keys, vals = be.load_kv_embed(ckpt_path, embed_file_var_name(name), rank, world, dim)
+  keys = np.ascontiguousarray(keys, dtype=np.int64)
+  order = np.argsort(keys, kind='stable')
+  keys, vals = keys[order], np.ascontiguousarray(vals, dtype=np.float32)[order]
+  slot_values = {}
+  for s, suffix in slots.items():
+    if engine.slot_view(name, s) is None:
       continue
-    keys, vals = be.load_kv_embed(ckpt_path, embed_file_var_name(var), rank, world, dim)
-    keys_t = torch.from_numpy(np.ascontiguousarray(keys, dtype=np.int64)).to(dev)
-    rows = torch.empty_like(keys_t)
-    # the table's own file creates the rows; a slot's file finds them (its keys are the table's, in its own order)
-    kernels.hip().kv_translate(kv, keys_t, rows, i == 0)
-    if i == 0:
-      engine.check_kv_overflow()
-    else:
-      assert bool((rows >= 0).all()), 'checkpoint %s: slot file %s names ids the table file does not' % (ckpt_path, var)
-    view[rows] = torch.from_numpy(np.ascontiguousarray(vals, dtype=np.float32)).to(dev)
+    skeys, svals = be.load_kv_embed(ckpt_path, embed_file_var_name(name + '/' + suffix), rank, world, dim)
+    so = np.argsort(np.asarray(skeys, dtype=np.int64), kind='stable')
+    assert np.array_equal(np.asarray(skeys, dtype=np.int64)[so], keys), \
+        'checkpoint %s: slot file %s does not hold the table file\'s ids' % (ckpt_path, name + '/' + suffix)
+    slot_values[s] = np.ascontiguousarray(svals, dtype=np.float32)[so]
+  engine.load_kv_table(name, keys, vals, slot_values, aux.get(name + '/kv_seen_keys'), aux.get(name + '/kv_freq'),
+                       aux.get(name + '/kv_version'))
 
 
 def save(est, ckpt_path):
@@ -114,6 +127,9 @@ def save(est, ckpt_path):
   engine = est.engine
   rank, world = getattr(engine, 'rank', 0), getattr(engine, 'world', 1)
   engine.flush_decay()
+  if hasattr(engine, 'evict_stale'):
+    engine.evict_stale(est.global_step)  # ev_params.steps_to_live: eviction happens when a checkpoint is written
+  kv_aux = {}
   if est.device.type == 'cuda':
     torch.cuda.synchronize()
   # an overflowed fixed-capacity exchange voids the steps since: never persist tables it may have touched
@@ -126,7 +142,7 @@ def save(est, ckpt_path):
       continue
     t_idx, t_num = (rank, world) if is_shard else (0, 1)
     if engine.tables[name].get('kv'):
-      _save_kv_table(engine, ckpt_path, name, slots, t_idx, t_num)
+      kv_aux.update(_save_kv_table(engine, ckpt_path, name, slots, t_idx, t_num))
       continue
     be.save_dense_embed(ckpt_path, embed_file_var_name(name), t_idx, t_num, engine.table_view(name).cpu().numpy())
     for s, suffix in slots.items():
@@ -148,6 +164,7 @@ def save(est, ckpt_path):
     # the rows an uninterrupted one would
     for name, kv in getattr(engine, 'kv_tables', {}).items():
       dense[name + '/kv_meta'] = np.array([kv['seed'], kv['mean'], kv['stddev'], kv['capacity']], dtype=np.float64)
+      dense.update({k: v for k, v in kv_aux.items() if k.startswith(name + '/')})
       dense[name + '/kv_seed'] = np.asarray(int(kv['seed']), dtype=np.int64)  # (float64 loses seeds >= 2^53)
     dense['global_step'] = np.asarray(int(est.global_step), dtype=np.int64)
     tensor_bundle.write_bundle(ckpt_path, dense)
@@ -160,10 +177,17 @@ def restore(est, ckpt_path):
   engine = est.engine
   rank, world = getattr(engine, 'rank', 0), getattr(engine, 'world', 1)
   slots = _SLOT_NAMES[est.opt_emb.kind]
+  class _Arrays(dict):  # (np.load's interface: .files + item access)
+    files = property(lambda self: list(self.keys()))
+  if os.path.exists(ckpt_path + '.index'):
+    z = _Arrays(tensor_bundle.read_bundle(ckpt_path))
+  else:  # a checkpoint of rounds 2-3
+    z0 = np.load(ckpt_path + '.dense.npz')
+    z = _Arrays((k, z0[k]) for k in z0.files)
   for name, is_shard in _engine_tables(engine):
     t_idx, t_num = (rank, world) if is_shard else (0, 1)
     if engine.tables[name].get('kv'):
-      _restore_kv_table(be, engine, ckpt_path, name, slots, t_idx, t_num)
+      _restore_kv_table(be, engine, ckpt_path, name, slots, t_idx, t_num, z)
       continue
     view = engine.table_view(name)
     n_local, dim = view.shape
@@ -173,13 +197,6 @@ def restore(est, ckpt_path):
       if sv is not None:
         sv.copy_(torch.from_numpy(
             be.load_dense_embed(ckpt_path, embed_file_var_name(name + '/' + suffix), t_idx, t_num, dim, n_local)))
-  class _Arrays(dict):  # (np.load's interface: .files + item access)
-    files = property(lambda self: list(self.keys()))
-  if os.path.exists(ckpt_path + '.index'):
-    z = _Arrays(tensor_bundle.read_bundle(ckpt_path))
-  else:  # a checkpoint of rounds 2-3
-    z0 = np.load(ckpt_path + '.dense.npz')
-    z = _Arrays((k, z0[k]) for k in z0.files)
   for name, kv in getattr(engine, 'kv_tables', {}).items():
     if name + '/kv_meta' in z.files:
       meta = z[name + '/kv_meta']

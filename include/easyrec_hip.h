@@ -425,7 +425,31 @@ typedef struct {
   float init_mean, init_stddev;
   const int32_t* n_limit; /* NULL, or a device count: only the first min(n, *n_limit) ids are valid (a ragged id list
                              in a fixed-capacity buffer: the number of ids of this step) */
+  /* ev_params.filter_freq / steps_to_live (feature_config.proto:27-29; CounterFilter / steps_to_live of the embedding
+   * variable at feature_column_v2.py:3497-3512).  All NULL / 0: the plain table.
+   *   filter_freq > 1: freq int32[map_slots] (zeroed) counts a key's occurrences in training lookups; the key gets its
+   *     row in the launch in which the count reaches filter_freq and reads zeros (row -1, no update) until then; n_keys
+   *     int32[1] counts the occupied slots (keys without a row hold one: the overflow flag is raised past map_slots / 2).
+   *   version int32[map_slots] + step (device step counter): every training lookup stamps version[slot] = *step, which
+   *     the eviction at checkpoint time reads (er_kv_export_all -> er_kv_rebuild). */
+  int32_t* freq;
+  int32_t* version;
+  int32_t* n_keys;
+  const int64_t* step;
+  int32_t filter_freq;
+  int32_t reserved;
 } er_kv_job;
+/* one job handed over by value from the host (n_limit must be NULL) */
+int er_kv_translate_job(const er_kv_job* job, int insert, er_stream_t stream);
+/* every occupied slot with its state, rows -1 for keys that have no row yet; *count (zeroed by the caller) = records */
+int er_kv_export_all(const int64_t* map_keys, const int32_t* map_rows, const int32_t* map_freq, const int32_t* map_version,
+                     int64_t map_slots, int64_t* out_keys, int32_t* out_rows, int32_t* out_freq, int32_t* out_version,
+                     int32_t* count, er_stream_t stream);
+/* n (key, row, freq, version) records with distinct keys into a CLEARED map (map_keys = -1, map_rows = -1, freq /
+ * version = 0): what a checkpoint restore and the steps_to_live eviction (which compacts the arena) end with */
+int er_kv_rebuild(const int64_t* keys, const int32_t* rows, const int32_t* freq, const int32_t* version, int64_t n,
+                  int64_t* map_keys, int32_t* map_rows, int32_t* map_freq, int32_t* map_version, int64_t map_slots,
+                  int32_t* overflow, er_stream_t stream);
 int er_kv_translate_multi(const er_kv_job* jobs_dev, const int32_t* blk_start_dev, int n_jobs, int total_blocks, int insert,
                           er_stream_t stream);
 int er_kv_export(const int64_t* map_keys, const int32_t* map_rows, int64_t map_slots, int64_t* out_keys,
@@ -974,6 +998,14 @@ int er_emb_apply_unique(er_emb_group* g, const uint32_t* unique_keys, const floa
  * -------------------------------------------------------------------------------------------- */
 int er_auc_update(const float* probs, const float* labels, const float* weights, int64_t n,
                   const float* thresholds, int32_t num_thresholds, uint64_t* counts, er_stream_t stream);
+/* K16b grouped AUC: gAUC / session AUC (reference core/metrics.py:59-108 `_separated_auc_impl`, :260-297; the reference
+ * gathers (label, prediction, key) in a tf.py_func and averages sklearn's roc_auc_score per key on the host).
+ * keys / preds / labels: the n accumulated rows SORTED by (key, prediction) ascending; work: 3 * n doubles, zeroed;
+ * out: 3 doubles, zeroed: out[0] = sum over the keys with both classes of w * AUC(key), out[1] = sum of w, out[2] = the
+ * number of such keys; AUC(key) = the Mann-Whitney statistic with tied predictions at their average rank (what
+ * roc_auc_score returns); w by reduction: 0 'mean' 1, 1 'mean_by_sample_num' rows, 2 'mean_by_positive_num' positives. */
+int er_grouped_auc(const int64_t* keys, const float* preds, const float* labels, int64_t n, int reduction, double* work,
+                   double* out, er_stream_t stream);
 
 /* ----------------------------------------------------------------------------------------------
  * K15 DLRM dot interaction.  Replaces einsum('bne,bme->bnm') + the upper-triangle slicing / concat of

@@ -709,6 +709,24 @@ class RefBackend(object):
         into.copy_(val)
     return into
 
+  def grouped_auc(self, keys, preds, labels, reduction):
+    """er_grouped_auc restated: per key with both classes, the Mann-Whitney AUC with tied predictions at their average
+    rank; -> (sum of w * auc, sum of w, keys used)."""
+    keys, preds = keys.reshape(-1).numpy(), preds.reshape(-1).numpy().astype(np.float32)
+    pos = labels.reshape(-1).numpy() != 0
+    total = wsum = used = 0.0
+    for key in np.unique(keys):
+      sel = keys == key
+      p, y = preds[sel].astype(np.float64), pos[sel]
+      n_pos, n_neg = int(y.sum()), int((~y).sum())
+      if n_pos == 0 or n_neg == 0:
+        continue
+      ranks = np.array([((p < v).sum() + 1 + (p <= v).sum()) / 2.0 for v in p])
+      auc = (ranks[y].sum() - n_pos * (n_pos + 1) / 2.0) / (n_pos * float(n_neg))
+      w = (1.0, float(p.size), float(n_pos))[int(reduction)]
+      total, wsum, used = total + w * auc, wsum + w, used + 1
+    return total, wsum, used
+
   def auc_update(self, probs, labels, weights, thresholds, counts):
     """tf.metrics.auc's per-threshold `prediction > threshold` counts, as a histogram (core/metrics.py)."""
     p = probs.detach().reshape(-1).cpu().numpy().astype(np.float32)
@@ -874,41 +892,89 @@ class RefBackend(object):
     z = (((u[0] + u[1]) + (u[2] + u[3])) - np.float32(2.0)) * np.float32(1.7320508075688772)
     return (np.float32(mean) + np.float32(stddev) * z).astype(np.float32)
 
-  def kv_create(self, var_rows, capacity, seed, init_mean, init_stddev):
-    return {'map': {}, 'capacity': int(capacity), 'var': var_rows, 'dim': int(var_rows.shape[1]),
-            'seed': int(seed) & ((1 << 63) - 1), 'mean': float(init_mean), 'stddev': float(init_stddev),
-            'overflow': torch.zeros(1, dtype=torch.int32)}
+  def kv_create(self, var_rows, capacity, seed, init_mean, init_stddev, filter_freq=0, steps_to_live=0, step=None):
+    """map: key -> arena row (-1: tracked by the counter filter, no row yet); freq / version: key -> count / step."""
+    return {'map': {}, 'freq': {}, 'version': {}, 'n_rows': 0, 'capacity': int(capacity), 'var': var_rows,
+            'dim': int(var_rows.shape[1]), 'seed': int(seed) & ((1 << 63) - 1), 'mean': float(init_mean),
+            'stddev': float(init_stddev), 'overflow': torch.zeros(1, dtype=torch.int32), 'filter_freq': int(filter_freq),
+            'steps_to_live': int(steps_to_live), 'step': step}
 
-  def kv_translate(self, kv, ids, rows_out, insert):
-    out = []
+  def _kv_insert(self, kv, ids):
+    """A training lookup's insert launch (er_kv.hip kv_insert_one): every occurrence counts, a key gets its row when
+    its count reaches filter_freq (plain tables: on first sight)."""
+    counted = kv['filter_freq'] > 1
+    now = int(kv['step'].item()) if kv['step'] is not None else 0
     for k in ids.view(-1).tolist():
       if k < 0:
-        out.append(-1)
         continue
-      r = kv['map'].get(k)
-      if r is None and insert:
-        if len(kv['map']) >= kv['capacity']:
-          kv['overflow'][0] = 1  # (a full arena claims no further key: the id reads zeros, the flag is sticky)
-          r = -1
-        else:
-          r = len(kv['map'])
-          kv['var'].detach()[r] = torch.from_numpy(self.kv_init_value(kv['seed'], [k], kv['dim'], kv['mean'], kv['stddev'])[0])
-          kv['map'][k] = r
-      out.append(-1 if r is None else r)
+      known = k in kv['map']
+      if not known:
+        full = (len(kv['map']) >= 4 * kv['capacity']) if counted else (kv['n_rows'] >= kv['capacity'])
+        if full:
+          kv['overflow'][0] = 1  # (a full map claims no further key: the id reads zeros, the flag is sticky)
+          continue
+        kv['map'][k] = -1
+      if kv['steps_to_live'] > 0:
+        kv['version'][k] = now
+      create = not known
+      if counted:
+        create = False
+        if kv['freq'].get(k, 0) < kv['filter_freq']:
+          kv['freq'][k] = kv['freq'].get(k, 0) + 1
+          create = kv['freq'][k] == kv['filter_freq']
+      if create:
+        if kv['n_rows'] >= kv['capacity']:
+          kv['overflow'][0] = 1
+          continue
+        r = kv['n_rows']
+        kv['n_rows'] += 1
+        kv['var'].detach()[r] = torch.from_numpy(self.kv_init_value(kv['seed'], [k], kv['dim'], kv['mean'], kv['stddev'])[0])
+        kv['map'][k] = r
+
+  @staticmethod
+  def _kv_find(kv, ids, rows_out):
+    out = [-1 if k < 0 else kv['map'].get(k, -1) for k in ids.view(-1).tolist()]
     rows_out.view(-1).copy_(torch.tensor(out, dtype=torch.int64))
+
+  def kv_translate(self, kv, ids, rows_out, insert):
+    if insert:
+      self._kv_insert(kv, ids)
+    self._kv_find(kv, ids, rows_out)
 
   def kv_jobs_create(self, jobs):
     return {'jobs': jobs}
 
   def kv_translate_multi(self, handle, insert):
+    # (one insert launch over every job, then one find launch: er_kv_translate_multi)
+    spans = []
     for job in handle['jobs']:
       kv, ids, rows_out = job[:3]
       n = ids.numel() if len(job) < 4 or job[3] is None else min(ids.numel(), int(job[3].item()))
-      self.kv_translate(kv, ids.view(-1)[:n], rows_out.view(-1)[:n], insert)
+      spans.append((kv, ids.view(-1)[:n], rows_out.view(-1)[:n]))
+    if insert:
+      for kv, ids, _ in spans:
+        self._kv_insert(kv, ids)
+    for kv, ids, rows_out in spans:
+      self._kv_find(kv, ids, rows_out)
 
   def kv_export(self, kv):
     items = sorted((k, r) for k, r in kv['map'].items() if r >= 0)
     return (torch.tensor([k for k, _ in items], dtype=torch.int64), torch.tensor([r for _, r in items], dtype=torch.int64))
+
+  def kv_export_all(self, kv):
+    items = sorted(kv['map'].items())
+    keys = [k for k, _ in items]
+    return (torch.tensor(keys, dtype=torch.int64), torch.tensor([r for _, r in items], dtype=torch.int64),
+            torch.tensor([kv['freq'].get(k, 0) for k in keys], dtype=torch.int32),
+            torch.tensor([kv['version'].get(k, 0) for k in keys], dtype=torch.int32))
+
+  def kv_rebuild(self, kv, keys, rows, freq=None, version=None):
+    keys, rows = [int(k) for k in keys.view(-1).tolist()], [int(r) for r in rows.view(-1).tolist()]
+    assert len(set(keys)) == len(keys)
+    kv['map'] = dict(zip(keys, rows))
+    kv['n_rows'] = sum(1 for r in rows if r >= 0)
+    kv['freq'] = dict(zip(keys, freq.view(-1).tolist())) if (freq is not None and kv['filter_freq'] > 1) else {}
+    kv['version'] = dict(zip(keys, version.view(-1).tolist())) if (version is not None and kv['steps_to_live'] > 0) else {}
 
   # -- CIN (xDeepFM): strided views of the operands, plain torch arithmetic
   @staticmethod

@@ -121,13 +121,26 @@ class OracleTrainer(object):
     state = OrderedDict(state)
     for k in [k for k in state if k.endswith('/kv_meta')]:
       name = k[:-len('/kv_meta')]
-      seed, mean, std, cap = [float(x) for x in state.pop(k)]
+      meta = [float(x) for x in state.pop(k)]
+      seed, mean, std, cap = meta[:4]
+      # ev_params.filter_freq / steps_to_live (DeepRec's CounterFilter / GlobalStepEvict, restated from their documented
+      # behaviour in easyrec_amd/csrc/er_kv.hip's header): occurrences are counted per id, the id gets its row when the
+      # count reaches filter_freq; every training lookup stamps the id with the global step
+      filter_freq, steps_to_live = (int(meta[4]), int(meta[5])) if len(meta) >= 6 else (0, 0)
       keys = np.asarray(state.pop(name + '/keys'), dtype=np.int64)
       vals = np.asarray(state[name], dtype=np.float32)
       arena = np.zeros((int(cap), vals.shape[1]), dtype=np.float32)
       arena[:len(keys)] = vals
       state[name] = arena
-      self.kv[name] = {'map': {int(key): i for i, key in enumerate(keys)}, 'seed': int(seed), 'mean': mean, 'stddev': std}
+      kv = {'map': {int(key): i for i, key in enumerate(keys)}, 'n_rows': len(keys), 'seed': int(seed), 'mean': mean,
+            'stddev': std, 'filter_freq': filter_freq, 'steps_to_live': steps_to_live, 'freq': {}, 'version': {}}
+      if (name + '/kv_seen_keys') in state:
+        seen = np.asarray(state.pop(name + '/kv_seen_keys'), dtype=np.int64).tolist()
+        kv['freq'] = dict(zip(seen, np.asarray(state.pop(name + '/kv_freq')).tolist()))
+        kv['version'] = dict(zip(seen, np.asarray(state.pop(name + '/kv_version')).tolist()))
+        for key in seen:
+          kv['map'].setdefault(int(key), -1)
+      self.kv[name] = kv
     self.state = OrderedDict((k, np.array(v, dtype=np.float32)) for k, v in state.items())
     self.features = list(cfg.feature_configs) if cfg.feature_configs else list(cfg.feature_config.features)
     self.fc_by_name = OrderedDict((_fname(f), f) for f in self.features)
@@ -265,27 +278,63 @@ class OracleTrainer(object):
     mask[ids[ok]] = True
 
   def _kv_rows(self, name, ids):
-    """ids -> arena rows of a hash-table table (training: unseen ids get the next row, initialised from the generator)"""
+    """ids -> arena rows of a hash-table table in a training lookup: every occurrence counts, an id gets the next row
+    (initialised from the generator) on first sight or - filter_freq > 1 - in the lookup that brings its count to
+    filter_freq; ids without a row read zeros (-1) and take no update."""
     from oracle.kernel_ref import RefBackend
     kv, arena = self.kv[name], self.state[name]
-    out = np.full(len(ids), -1, dtype=np.int64)
-    for i, key in enumerate(np.asarray(ids, dtype=np.int64).tolist()):
+    ids = np.asarray(ids, dtype=np.int64).tolist()
+    counted = kv['filter_freq'] > 1
+    for key in ids:
       if key < 0:
         continue
-      r = kv['map'].get(key)
-      if r is None:
-        r = len(kv['map'])
+      known = key in kv['map']
+      if not known:
+        kv['map'][key] = -1
+      if kv['steps_to_live'] > 0:
+        kv['version'][key] = self.global_step + 1  # (the global step this training step ends with)
+      create = not known
+      if counted:
+        create = False
+        if kv['freq'].get(key, 0) < kv['filter_freq']:
+          kv['freq'][key] = kv['freq'].get(key, 0) + 1
+          create = kv['freq'][key] == kv['filter_freq']
+      if create:
+        r = kv['n_rows']
         assert r < arena.shape[0], 'oracle: hash-table %s is full' % name
+        kv['n_rows'] += 1
         arena[r] = RefBackend.kv_init_value(kv['seed'], [key], arena.shape[1], kv['mean'], kv['stddev'])[0]
+        for slot in ('/m', '/v'):  # (a row that an evicted id owned before: never the case here, rows are not reused)
+          assert (name + slot) not in self.slots or not self.slots[name + slot][r].any()
         kv['map'][key] = r
-      out[i] = r
-    return out
+    return np.array([-1 if key < 0 else kv['map'][key] for key in ids], dtype=np.int64)
+
+  def kv_evict(self, name):
+    """steps_to_live at checkpoint time: ids whose last training lookup is more than steps_to_live steps back are
+    dropped (their arena rows are simply never used again here).  -> the number of ids dropped."""
+    kv = self.kv[name]
+    if kv['steps_to_live'] <= 0:
+      return 0
+    stale = [k for k in kv['map'] if self.global_step - kv['version'].get(k, 0) > kv['steps_to_live']]
+    for k in stale:
+      del kv['map'][k]
+      kv['freq'].pop(k, None)
+      kv['version'].pop(k, None)
+    return len(stale)
 
   def kv_state(self, name, array=None):
-    """(ids ascending, their rows of `array` - default the table itself) of a hash-table table"""
-    items = sorted(self.kv[name]['map'].items())
+    """(ids ascending, their rows of `array` - default the table itself) of a hash-table table's ids that have a row"""
+    items = sorted((k, r) for k, r in self.kv[name]['map'].items() if r >= 0)
     src = self.state[name] if array is None else array
     return np.array([k for k, _ in items], dtype=np.int64), np.stack([src[r] for _, r in items]) if items else src[:0]
+
+  def kv_filter_state(self, name):
+    """(every tracked id ascending, min(count, filter_freq), last-lookup step)"""
+    kv = self.kv[name]
+    keys = sorted(kv['map'])
+    ff = max(kv['filter_freq'], 1)
+    return (np.array(keys, dtype=np.int64), np.array([min(kv['freq'].get(k, 0), ff) for k in keys], dtype=np.int32),
+            np.array([kv['version'].get(k, 0) for k in keys], dtype=np.int32))
 
   def _per_lookup(self, table):
     """When gradients are clipped: the table as THIS lookup sees it (an identity op whose gradient is kept), so that the

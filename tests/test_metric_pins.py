@@ -33,3 +33,41 @@ def test_max_f1_stream():
   for b in range(4):
     m.update(G['labels_%d' % b], G['preds_%d' % b])
     assert abs(m.result() - float(G['max_f1_after_%d' % b])) <= 1e-6, b
+
+
+def _device_stream(device):
+  """DeviceSeparatedAUC (what evaluate() uses: rows kept and reduced on the device, er_grouped_auc) on the reference's
+  own numbers: the four-batch stream with the three reductions, and string keys."""
+  from easyrec_amd.core.metrics import DeviceSeparatedAUC
+  for reduction in ('mean', 'mean_by_sample_num', 'mean_by_positive_num'):
+    m = DeviceSeparatedAUC(reduction, device)
+    for b in range(4):
+      m.update(G['labels_%d' % b], G['preds_%d' % b], G['keys_%d' % b])
+      assert abs(m.result() - float(G['gauc_%s_after_%d' % (reduction, b)])) <= 1e-6, (reduction, b)
+  m = DeviceSeparatedAUC('mean', device)
+  m.update(G['labels_0'], G['preds_0'], G['session_keys'])
+  assert abs(m.result() - float(G['session_auc'])) <= 1e-6
+  assert DeviceSeparatedAUC('mean', device).result() == 0.0
+
+
+def test_device_grouped_auc_on_the_stand_in_backend(ref_backend):
+  _device_stream('cpu')
+
+
+@pytest.mark.gpu
+def test_device_grouped_auc_on_the_gpu():
+  import torch
+  from easyrec_amd.core.metrics import DeviceSeparatedAUC, SeparatedAUC
+  _device_stream('cuda:0')
+  # a larger stream against the host implementation: 200k rows, 5000 users, rounded predictions (ties inside users)
+  rng = np.random.default_rng(11)
+  n = 200000
+  users = rng.integers(0, 5000, size=n) * 1000003 - 7
+  y = (rng.random(n) < 0.2).astype(np.float32)
+  p = np.round(np.clip(rng.normal(0.4 + 0.1 * y, 0.2), 0, 1), 2).astype(np.float32)
+  for reduction in SeparatedAUC.REDUCTIONS:
+    host, dev = SeparatedAUC(reduction), DeviceSeparatedAUC(reduction, 'cuda:0')
+    for lo in range(0, n, 50000):
+      host.update(y[lo:lo + 50000], p[lo:lo + 50000], users[lo:lo + 50000])
+      dev.update(torch.from_numpy(y[lo:lo + 50000]).cuda(), torch.from_numpy(p[lo:lo + 50000]).cuda(), users[lo:lo + 50000])
+    assert abs(host.result() - dev.result()) <= 1e-6, (reduction, host.result(), dev.result())

@@ -162,6 +162,15 @@ def test_multi_task_metrics_are_each_tower_s_own(ref_backend):
 
 
 def test_evaluate_with_grouped_metrics(ref_backend):
+  _evaluate_with_grouped_metrics('cpu')
+
+
+@pytest.mark.gpu
+def test_evaluate_with_grouped_metrics_on_the_gpu():
+  _evaluate_with_grouped_metrics('cuda:0')
+
+
+def _evaluate_with_grouped_metrics(device):
   """metrics_set { gauc } / { session_auc } / { max_f1 } through EasyRecEstimator.evaluate(): the key column is the
   RAW value of the named feature (its strings for a hashed id feature), as `feature_dict[uid_field]` in the
   reference; the result must equal the metric recomputed from the predictions by the reference's algorithm."""
@@ -175,7 +184,7 @@ def test_evaluate_with_grouped_metrics(ref_backend):
                     'metrics_set { session_auc { session_id_field: "C2" } } metrics_set { max_f1 {} }', cfg.eval_config)
   B = 64
   from easyrec_amd.input.criteo_synthetic import SyntheticCriteo
-  est = EasyRecEstimator(cfg, device='cpu', batch_size=B, seed=1).build()
+  est = EasyRecEstimator(cfg, device=device, batch_size=B, seed=1).build()
   gen = SyntheticCriteo(cfg.data_config, est.feature_configs, batch_size=B, seed=5)  # id features as raw strings
   batches = [gen.next_batch() for _ in range(4)]
   est.train_step(batches[0])
