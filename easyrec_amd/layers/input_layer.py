@@ -817,13 +817,13 @@ class EmbeddingEngine(object):
     for name in self.tables:
       if name not in state:
         continue
-      values = torch.from_numpy(np.asarray(state[name], dtype=np.float32)).to(self.device)
       if self.tables[name]['kv']:
+        values = state[name]
         slot_values = {sl: state[name + '/' + sl] for sl in ('m', 'v') if (name + '/' + sl) in state}
         self.load_kv_table(name, state[name + '/keys'], values, slot_values, state.get(name + '/kv_seen_keys'),
                            state.get(name + '/kv_freq'), state.get(name + '/kv_version'))
       else:
-        self.table_view(name).copy_(values)
+        self.table_view(name).copy_(torch.from_numpy(np.asarray(state[name], dtype=np.float32)).to(self.device))
 
 
 def _stable_seed(name, base):

@@ -244,11 +244,11 @@ def test_kv_filtered_translate_kernel():
   want = RefBackend.kv_init_value(77, keys[admitted].cpu().numpy(), dim, 0.0, 0.5)
   assert np.array_equal(var_d[rows[admitted]].cpu().numpy(), want)
   # rebuild from the exported records: the same lookups
-  probe = keys[torch.randperm(keys.numel(), generator=g)[:500].to(dev)]
-  before = torch.empty(500, dtype=torch.int64, device=dev)
+  probe = keys[torch.randperm(keys.numel(), generator=g)[:500].to(dev)].contiguous()
+  before = torch.empty(probe.numel(), dtype=torch.int64, device=dev)
   hip.kv_translate(kd, probe, before, False)
   hip.kv_rebuild(kd, keys, rows, freq, version)
-  after = torch.empty(500, dtype=torch.int64, device=dev)
+  after = torch.empty(probe.numel(), dtype=torch.int64, device=dev)
   hip.kv_translate(kd, probe, after, False)
   assert torch.equal(before, after) and int(kd['overflow'].item()) == 0
   again = hip.kv_export_all(kd)
