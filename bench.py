@@ -194,6 +194,12 @@ def embedding_bytes_per_step(est, batches):
     sweep = sum(st['total_rows'] * dim * 4 * 6 for dim, st in est.engine.storage.items())
   per = {k: v / max(n_steps, 1) for k, v in per.items()}
   per['emb_catch_up_multi_kernel'] = per['emb_catch_up_closed_kernel']
+  # the fused single-GPU embedding step (er_emb_front / er_emb_bwd_fused) does the same work under other names: the
+  # catch-up from the per-lookup key lists, the segmented reduction + row update with the gradient finish folded in,
+  # the sort with the entry build in front of it (the id hash itself runs inside the step prologue's launch)
+  per['emb_catch_up_heads_kernel'] = per['emb_catch_up_closed_kernel']
+  per['emb_bwd_own_kernel'] = per['emb_bwd_tile_multi_kernel']
+  per['emb_front_sort_kernel'] = per['emb_segment_sort_kernel']
   return lazy, sweep, per
 
 

@@ -13,7 +13,7 @@ compat/optimizers.py:285-345).  Here they are `torch.distributed` calls on devic
   exchange_counts   compact exchange only (more than 16 ranks): all-gather of a small [G, W] int32 matrix of
                     per-owner unique-key counts -> host-side send / recv split lists (one host synchronisation a step)
   all_to_all        compact exchange only: variable-split exchange of keys (int32), rows and gradient rows
-  all_gather_rows   checkpoint / test only: collect the shards of a table
+  all_gather_rows   checkpoint / test only: collect the shards of a table (all_gather_varlen: of a hash-table table)
 
 Messages are small at B=4096 (<= 1 MB per peer), i.e. latency-bound on xGMI's point-to-point links: what counts is
 how many collectives a step issues (4 for DeepFM), not their bytes.
@@ -44,6 +44,9 @@ class LocalComm(object):
     return t
 
   def all_gather_rows(self, t):
+    return [t]
+
+  def all_gather_varlen(self, t):
     return [t]
 
   def barrier(self):
@@ -90,6 +93,18 @@ class TorchDistComm(object):
     out = [torch.empty_like(t) for _ in range(self.world)]
     self.dist.all_gather(out, t.contiguous(), group=self.group)
     return out
+
+  def all_gather_varlen(self, t):
+    """checkpoint / test only: every rank's [n_r, ...] array (the n_r differ: hash-table shards)."""
+    n = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
+    sizes = [torch.empty_like(n) for _ in range(self.world)]
+    self.dist.all_gather(sizes, n, group=self.group)
+    sizes = [int(x.item()) for x in sizes]
+    pad = torch.zeros((max(sizes + [1]),) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    pad[:t.shape[0]] = t
+    out = [torch.empty_like(pad) for _ in range(self.world)]
+    self.dist.all_gather(out, pad, group=self.group)
+    return [o[:k] for o, k in zip(out, sizes)]
 
   def barrier(self):
     self.dist.barrier(group=self.group)

@@ -269,6 +269,59 @@ kv_rebuild_kernel(const int64_t* __restrict__ in_keys, const int32_t* __restrict
   atomicExch(overflow, 1);
 }
 
+// ---- embedding-parallel hash tables: the ids travel to their owners before the route ---------------------------------
+// Under the reference's embedding parallelism a hash-table column is an SOK DynamicVariable sharded by id % world
+// (compat/feature_column/feature_column.py:470-503, compat/dynamic_variable.py).  Here every rank owns the map and the
+// arena of the ids with id % world == rank; a step's ids go to their owners (fixed-capacity all-to-all), the owners
+// translate them (the insert / find launches above, counting filter and stamps included) and send the arena rows back,
+// and the requester turns (owner, arena row) into the VIRTUAL dense id arena_row * world + owner - which the ordinary
+// embedding-parallel route sends to the same owner (id % world) and local row (id / world).  Everything after this
+// pre-pass is the dense sharded path unchanged.
+//   bucket  : send[owner][job region] <- the job's ids of that owner in arrival order (slot[i] remembers where)
+//   unbucket: rows_out[i] = back[slot[i]] * world + owner, or -1
+__global__ void __launch_bounds__(kBlock)
+kv_bucket_clear_kernel(int64_t* __restrict__ send, int64_t send_n, int32_t* __restrict__ counts, int64_t counts_n) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < send_n; i += stride) send[i] = -1;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < counts_n; i += stride) counts[i] = 0;
+}
+
+__global__ void __launch_bounds__(kBlock)
+kv_bucket_kernel(const er_kv_route_job* __restrict__ jobs, const int32_t* __restrict__ blk_start, int n_jobs, int world,
+                 int64_t block_stride, int64_t* __restrict__ send, int32_t* __restrict__ counts) {
+  const int j = kv_job_of(blk_start, n_jobs, blockIdx.x);
+  const er_kv_route_job q = jobs[j];
+  const int64_t i = static_cast<int64_t>(blockIdx.x - blk_start[j]) * kBlock + threadIdx.x;
+  if (i >= q.n) return;
+  const int64_t n = q.n_limit ? (static_cast<int64_t>(*q.n_limit) < q.n ? static_cast<int64_t>(*q.n_limit) : q.n) : q.n;
+  const int64_t key = i < n ? q.ids[i] : -1;
+  if (key < 0) {
+    q.slot[i] = -1;
+    return;
+  }
+  const int owner = static_cast<int>(static_cast<uint64_t>(key) % static_cast<uint64_t>(world));
+  const int32_t s = atomicAdd(counts + static_cast<int64_t>(j) * world + owner, 1);  // (< q.n: the region holds the whole job)
+  const int64_t at = static_cast<int64_t>(owner) * block_stride + q.send_off + s;
+  send[at] = key;
+  q.slot[i] = static_cast<int32_t>(at);
+}
+
+__global__ void __launch_bounds__(kBlock)
+kv_unbucket_kernel(const er_kv_route_job* __restrict__ jobs, const int32_t* __restrict__ blk_start, int n_jobs, int world,
+                   int64_t block_stride, const int64_t* __restrict__ back) {
+  const int j = kv_job_of(blk_start, n_jobs, blockIdx.x);
+  const er_kv_route_job q = jobs[j];
+  const int64_t i = static_cast<int64_t>(blockIdx.x - blk_start[j]) * kBlock + threadIdx.x;
+  if (i >= q.n) return;
+  const int32_t at = q.slot[i];
+  int64_t v = -1;
+  if (at >= 0) {
+    const int64_t r = back[at];
+    if (r >= 0) v = r * world + at / block_stride;
+  }
+  q.rows_out[i] = v;
+}
+
 }  // namespace er
 
 extern "C" {
@@ -352,6 +405,31 @@ int er_kv_rebuild(const int64_t* keys, const int32_t* rows, const int32_t* freq,
   if (n == 0) return 0;
   hipLaunchKernelGGL(er::kv_rebuild_kernel, dim3(er::blocks_for(n)), dim3(er::kBlock), 0, er::as_stream(stream), keys, rows,
                      freq, version, n, map_keys, map_rows, map_freq, map_version, static_cast<uint64_t>(map_slots - 1), overflow);
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
+int er_kv_bucket(const er_kv_route_job* jobs_dev, const int32_t* blk_start_dev, int n_jobs, int total_blocks, int world,
+                 int64_t block_stride, int64_t* send, int32_t* counts, er_stream_t stream) {
+  ER_REQUIRE(jobs_dev && blk_start_dev && send && counts && n_jobs >= 1 && total_blocks >= 1 && world >= 1 && block_stride >= 1 &&
+                 block_stride * world < (1ll << 31),
+             "er_kv_bucket: bad arguments (the send buffer is addressed with 31 bits)");
+  hipStream_t s = er::as_stream(stream);
+  hipLaunchKernelGGL(er::kv_bucket_clear_kernel, dim3(256), dim3(er::kBlock), 0, s, send, block_stride * world, counts,
+                     static_cast<int64_t>(n_jobs) * world);
+  ER_LAUNCH_CHECK();
+  hipLaunchKernelGGL(er::kv_bucket_kernel, dim3(total_blocks), dim3(er::kBlock), 0, s, jobs_dev, blk_start_dev, n_jobs, world,
+                     block_stride, send, counts);
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
+int er_kv_unbucket(const er_kv_route_job* jobs_dev, const int32_t* blk_start_dev, int n_jobs, int total_blocks, int world,
+                   int64_t block_stride, const int64_t* back, er_stream_t stream) {
+  ER_REQUIRE(jobs_dev && blk_start_dev && back && n_jobs >= 1 && total_blocks >= 1 && world >= 1 && block_stride >= 1,
+             "er_kv_unbucket: bad arguments");
+  hipLaunchKernelGGL(er::kv_unbucket_kernel, dim3(total_blocks), dim3(er::kBlock), 0, er::as_stream(stream), jobs_dev,
+                     blk_start_dev, n_jobs, world, block_stride, back);
   ER_LAUNCH_CHECK();
   return 0;
 }

@@ -26,6 +26,12 @@ class KvJob(ctypes.Structure):
               ('filter_freq', ctypes.c_int32), ('reserved', ctypes.c_int32)]
 
 
+class KvRouteJob(ctypes.Structure):
+  """er_kv_route_job (include/easyrec_hip.h)"""
+  _fields_ = [('ids', ctypes.c_void_p), ('n', ctypes.c_int64), ('n_limit', ctypes.c_void_p), ('rows_out', ctypes.c_void_p),
+              ('slot', ctypes.c_void_p), ('send_off', ctypes.c_int64)]
+
+
 class CastDesc(ctypes.Structure):
   """er_cast_desc (include/easyrec_hip.h)"""
   _fields_ = [('src', ctypes.c_void_p), ('dst', ctypes.c_void_p), ('rows', ctypes.c_int64), ('cols', ctypes.c_int32),
@@ -1437,6 +1443,42 @@ class HipBackend(object):
       return
     self._ck(self.lib.er_kv_translate_multi(_p(handle['table']), _p(handle['blk_start']), handle['n'], handle['blocks'],
                                             int(bool(insert)), _stream()), 'er_kv_translate_multi')
+
+  def kv_route_create(self, jobs, world):
+    """Embedding-parallel hash tables: jobs [(ids, rows_out[, n_limit])] -> the buffers and descriptor table of
+    er_kv_bucket / er_kv_unbucket.  send / recv / owner_rows / back: int64 [world, C] with C = the jobs' id counts
+    summed (job j's region of every owner's block is [off_j, off_j + n_j): a job fits even if all its ids have one owner)."""
+    n = len(jobs)
+    dev = jobs[0][0].device
+    arr = (KvRouteJob * n)()
+    starts, offs, slots = [0], [0], []
+    for i, job in enumerate(jobs):
+      ids, rows_out = job[:2]
+      limit = job[2] if len(job) > 2 else None
+      assert ids.dtype == torch.int64 and rows_out.dtype == torch.int64 and ids.is_contiguous() and rows_out.is_contiguous()
+      assert ids.numel() == rows_out.numel() and (limit is None or (limit.dtype == torch.int32 and limit.numel() == 1))
+      slot = torch.full((ids.numel(),), -1, dtype=torch.int32, device=dev)
+      slots.append(slot)
+      arr[i] = KvRouteJob(ids.data_ptr(), ids.numel(), 0 if limit is None else limit.data_ptr(), rows_out.data_ptr(),
+                          slot.data_ptr(), offs[-1])
+      starts.append(starts[-1] + (ids.numel() + 255) // 256)
+      offs.append(offs[-1] + ids.numel())
+    C = max(offs[-1], 1)
+    buf = lambda: torch.full((world, C), -1, dtype=torch.int64, device=dev)
+    return {'table': torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev),
+            'blk_start': torch.tensor(starts, dtype=torch.int32, device=dev), 'n': n, 'blocks': starts[-1], 'world': int(world),
+            'C': C, 'offs': offs, 'slots': slots, 'jobs': jobs, 'send': buf(), 'recv': buf(), 'owner_rows': buf(), 'back': buf(),
+            'counts': torch.zeros(n * world, dtype=torch.int32, device=dev)}
+
+  def kv_bucket(self, h):
+    if h['blocks']:
+      self._ck(self.lib.er_kv_bucket(_p(h['table']), _p(h['blk_start']), h['n'], h['blocks'], h['world'], ctypes.c_int64(h['C']),
+                                     _p(h['send']), _p(h['counts']), _stream()), 'er_kv_bucket')
+
+  def kv_unbucket(self, h):
+    if h['blocks']:
+      self._ck(self.lib.er_kv_unbucket(_p(h['table']), _p(h['blk_start']), h['n'], h['blocks'], h['world'],
+                                       ctypes.c_int64(h['C']), _p(h['back']), _stream()), 'er_kv_unbucket')
 
   def kv_export(self, kv):
     """(keys ascending, arena rows) of the table's materialised ids (host sync)."""

@@ -54,15 +54,22 @@ class ShardedEmbeddingEngine(EmbeddingEngine):
   # -- storage
   def finalize(self, opt_kind):
     assert not self.finalized
-    assert not any(t.get('kv') for t in self.tables.values()), \
-        'hash-table (ev_params) embeddings are single-GPU only for now (the owner side would translate the received ids)'
     be = kernels.hip()
     W, rank, dev = self.world, self.rank, self.device
     # 1. placement of every table
     shard_rows, rep_rows = OrderedDict(), OrderedDict()
     for name, t in self.tables.items():
       dim = t['dim']
-      if self._is_replicated(t):
+      if t.get('kv'):
+        # a hash-table table: rank r owns the map and the arena of the ids with id % W == r (the reference: SOK's
+        # DynamicVariable, compat/feature_column/feature_column.py:470-503); its lookups carry the virtual dense ids
+        # arena_row * W + owner made by translate_kv_ids(), so from here on it is a sharded table of n_local * W rows
+        n_local = (t['rows'] + W - 1) // W
+        t['rows'] = n_local * W
+        base = shard_rows.get(dim, 0)
+        shard_rows[dim] = base + n_local
+        self.placement[name] = ('shard', dim, base, n_local)
+      elif self._is_replicated(t):
         base = rep_rows.get(dim, 0)
         rep_rows[dim] = base + t['rows']
         self.placement[name] = ('rep', dim, base, t['rows'])
@@ -79,7 +86,16 @@ class ShardedEmbeddingEngine(EmbeddingEngine):
       self.rep[dim] = {'st': self._alloc_storage(total, dim, opt_kind, force_bitmap=True)}
     for name, t in self.tables.items():
       kind, dim, base, n_local = self.placement[name]
-      if kind == 'rep':
+      if t.get('kv'):
+        arena = self.shard[dim]['st']['var'][base:base + n_local]
+        arena.zero_()  # rows are created on first sight (er_kv_translate: a pure function of seed, id and column)
+        mean, std = self._init_mean_std(t)
+        assert t['kv_steps_to_live'] == 0 or self._clock is not None, 'steps_to_live needs the step clock (set_step_clock)'
+        from easyrec_amd.layers.input_layer import _stable_seed
+        self.kv_tables[name] = be.kv_create(arena, n_local, _stable_seed(name, self.seed), mean, std,
+                                            filter_freq=t['kv_filter_freq'], steps_to_live=t['kv_steps_to_live'],
+                                            step=self._clock[0] if t['kv_steps_to_live'] > 0 else None)
+      elif kind == 'rep':
         self.init_table_values(name, self.rep[dim]['st']['var'][base:base + n_local])
       else:
         full = torch.empty(t['rows'], dim, dtype=torch.float32, device=dev)
@@ -267,6 +283,51 @@ class ShardedEmbeddingEngine(EmbeddingEngine):
   #    replayed as hipGraphs around the data-dependent exchanges (model/embedding_parallel.py):
   #      route()  [static]  -> exchange()  [host sync + all-to-alls] -> lookup() [static]
   #      reduce_local() [static] -> exchange_grads_and_update() [all-to-all, variable counts] -> apply_replicated() [static]
+  def translate_kv_ids(self):
+    """Hash-table lookups: this step's ids -> virtual dense ids (arena_row * world + owner).  The ids go to their
+    owners (id % world) in a fixed-capacity all-to-all, the owners translate what they receive in the single-GPU
+    engine's two launches - every occurrence of every rank counts towards filter_freq, unseen ids get a row while
+    training and read zeros otherwise - and the arena rows come back the same way."""
+    self.kv_bucket()
+    self.kv_exchange_ids()
+    self.kv_owner_translate()
+    self.kv_exchange_rows()
+    self.kv_unbucket()
+
+  # (the same in pieces: static device work around the two all-to-alls, for the estimator's phases / hipGraph segments)
+  def _kv_route(self):
+    be = kernels.hip()
+    if self._kv_handle is None:
+      route = be.kv_route_create([tuple(job[1:]) for job in self.kv_jobs], self.world)
+      # owner side: one translate job per (source rank, lookup) over the received block
+      owner_jobs = []
+      for src in range(self.world):
+        for j, job in enumerate(self.kv_jobs):
+          lo, hi = route['offs'][j], route['offs'][j + 1]
+          if hi > lo:
+            owner_jobs.append((self.kv_tables[job[0]], route['recv'][src, lo:hi], route['owner_rows'][src, lo:hi]))
+      self._kv_handle = (route, be.kv_jobs_create(owner_jobs) if owner_jobs else None)
+    return self._kv_handle
+
+  def kv_bucket(self):
+    kernels.hip().kv_bucket(self._kv_route()[0])
+
+  def kv_exchange_ids(self):
+    route = self._kv_route()[0]
+    self.comm.all_to_all_equal(route['send'].view(-1), route['recv'].view(-1))
+
+  def kv_owner_translate(self):
+    owner = self._kv_route()[1]
+    if owner is not None:
+      kernels.hip().kv_translate_multi(owner, self.train_mode and not self.inference)
+
+  def kv_exchange_rows(self):
+    route = self._kv_route()[0]
+    self.comm.all_to_all_equal(route['owner_rows'].view(-1), route['back'].view(-1))
+
+  def kv_unbucket(self):
+    kernels.hip().kv_unbucket(self._kv_route()[0])
+
   def route(self):
     be = kernels.hip()
     for gi, (dim, sh) in enumerate(self.shard.items()):
@@ -325,6 +386,7 @@ class ShardedEmbeddingEngine(EmbeddingEngine):
   def check_overflow(self):
     """Blocking: has any step so far routed more keys to one owner than the exchange's capacity (the flag is sticky)?"""
     be = kernels.hip()
+    self.check_kv_overflow()
     for dim, sh in self.shard.items():
       if sh['peer_cap'] and sh['leader'] is None and be.emb_route_overflow(sh['req']):
         raise RuntimeError('embedding-parallel: rank %d routed more than %d keys of dim %d to one owner; raise recv_slack'
@@ -390,6 +452,8 @@ class ShardedEmbeddingEngine(EmbeddingEngine):
     if version == self._ran_version:
       return
     self._join_window_flush()  # (a forward that no row update followed)
+    if self.kv_jobs:
+      self.translate_kv_ids()
     self.route()
     self.exchange()
     self.lookup()
@@ -490,10 +554,42 @@ class ShardedEmbeddingEngine(EmbeddingEngine):
       full[w::self.world] = p
     return full[:rows]
 
+  def _kv_state(self, name, out, slots):
+    """A hash-table table's entries of every rank, merged in key order (collective)."""
+    import numpy as np
+    be, kv, t = kernels.hip(), self.kv_tables[name], self.tables[name]
+    dev = self.device
+    if self._kv_filtered(name):
+      seen, seen_rows, freq, version = be.kv_export_all(kv)
+      has_row = seen_rows >= 0
+      keys, rows = seen[has_row], seen_rows[has_row]
+      gathered = [torch.cat(self.comm.all_gather_varlen(x.to(dev).contiguous())).cpu().numpy() for x in (seen, freq, version)]
+      order = np.argsort(gathered[0], kind='stable')
+      out[name + '/kv_seen_keys'] = gathered[0][order]
+      out[name + '/kv_freq'] = np.minimum(gathered[1][order], max(t['kv_filter_freq'], 1)).astype(np.int32)
+      out[name + '/kv_version'] = gathered[2][order]
+    else:
+      keys, rows = be.kv_export(kv)
+    all_keys = torch.cat(self.comm.all_gather_varlen(keys.to(dev).contiguous())).cpu().numpy()
+    order = np.argsort(all_keys, kind='stable')
+    out[name + '/keys'] = all_keys[order]
+    # (capacity: the whole table's, so that a single-process estimator - or the oracle - can hold the state)
+    out[name + '/kv_meta'] = np.array([kv['seed'], kv['mean'], kv['stddev'], kv['capacity'] * self.world, t['kv_filter_freq'],
+                                       t['kv_steps_to_live']], dtype=np.float64)
+    views = [('', self.table_view(name))] + ([('/' + sl, self.slot_view(name, sl)) for sl in ('m', 'v')] if slots else [])
+    for suffix, view in views:
+      if view is not None:
+        mine = view.detach()[rows.to(view.device)].contiguous()
+        out[name + suffix] = torch.cat(self.comm.all_gather_varlen(mine)).cpu().numpy()[order]
+
   def state_dict(self, slots=False):
     out = OrderedDict()
     self.flush_decay()
+    self.check_kv_overflow()
     for name in self.tables:
+      if self.tables[name].get('kv'):
+        self._kv_state(name, out, slots)
+        continue
       out[name] = self._gather_full(name, self.table_view(name)).cpu().numpy()
       if slots:
         for s in ('m', 'v'):
@@ -502,10 +598,28 @@ class ShardedEmbeddingEngine(EmbeddingEngine):
             out[name + '/' + s] = self._gather_full(name, sv).cpu().numpy()
     return out
 
+  def load_kv_table(self, name, keys, values, slot_values, seen=None, freq=None, version=None):
+    """This rank's share of the saved table: the ids with id % world == rank."""
+    import numpy as np
+    keys = np.asarray(keys, dtype=np.int64)
+    mine = (keys % self.world) == self.rank
+    pick = lambda a: None if a is None else np.asarray(a)[mine]
+    if seen is not None:
+      seen = np.asarray(seen, dtype=np.int64)
+      smine = (seen % self.world) == self.rank
+      seen, freq, version = seen[smine], np.asarray(freq)[smine], np.asarray(version)[smine]
+    super(ShardedEmbeddingEngine, self).load_kv_table(name, keys[mine], pick(values), {k: pick(v) for k, v in slot_values.items()},
+                                                      seen, freq, version)
+
   def load_state_dict(self, state):
     import numpy as np
     for name in self.tables:
       if name not in state:
+        continue
+      if self.tables[name].get('kv'):
+        slot_values = {sl: state[name + '/' + sl] for sl in ('m', 'v') if (name + '/' + sl) in state}
+        self.load_kv_table(name, state[name + '/keys'], state[name], slot_values, state.get(name + '/kv_seen_keys'),
+                           state.get(name + '/kv_freq'), state.get(name + '/kv_version'))
         continue
       kind, dim, base, n_local = self.placement[name]
       full = torch.from_numpy(np.asarray(state[name], dtype=np.float32)).to(self.device)

@@ -79,11 +79,26 @@ class EmbeddingParallelEstimator(EasyRecEstimator):
       self.comm.all_reduce_sum(self.varstore.flat_grad_all)
 
   # -- the step in phases: static device work (capturable) around the data-dependent exchanges
-  def _phase_route(self):
+  def _phase_prologue(self):
     hash_job = self.features.hash_job() if self.fused_front else None
     kernels.hip().step_prologue(self.hyper_table, self.step_counter, self.hyper, history=self.lr_hist,
                                 zero=self.varstore.flat_grad_all, decay_tables=self.decay_tables, hash_job=hash_job)
     self.features.transform(hashed=hash_job is not None)
+
+  def _phase_route(self):
+    self._phase_prologue()
+    self.engine.route()
+
+  # hash-table (ev_params) tables: the step's ids visit their owners before the route (two more all-to-alls)
+  def _phase_kv_bucket(self):
+    self._phase_prologue()
+    self.engine.kv_bucket()
+
+  def _phase_kv_owner(self):
+    self.engine.kv_owner_translate()
+
+  def _phase_kv_route(self):
+    self.engine.kv_unbucket()
     self.engine.route()
 
   def _phase_compute(self):
@@ -132,15 +147,21 @@ class EmbeddingParallelEstimator(EasyRecEstimator):
   def _phases(self):
     """[(static device work, the collectives that follow it)]: the static parts replay as hipGraphs."""
     eng = self.engine
+    after_route = eng.exchange_keys if eng.padded else eng.exchange
+    if eng.kv_jobs:
+      head = [(self._phase_kv_bucket, eng.kv_exchange_ids), (self._phase_kv_owner, eng.kv_exchange_rows),
+              (self._phase_kv_route, after_route)]
+    else:
+      head = [(self._phase_route, after_route)]
     if eng.padded:
       # fixed-capacity exchange: no host-side sizes anywhere, the host never waits for the device
-      seq = [(self._phase_route, eng.exchange_keys), (self._phase_owner_serve, eng.exchange_rows)]
+      seq = head + [(self._phase_owner_serve, eng.exchange_rows)]
       if self.is_training:
         seq += [(self._phase_compute, lambda: (self._sync_dense_grads(), eng.exchange_grads())), (self._phase_update, None)]
       else:
         seq += [(self._phase_compute, None)]
       return seq
-    seq = [(self._phase_route, eng.exchange)]  # host sync (split sizes) + all-to-all keys / rows
+    seq = list(head)  # host sync (split sizes) + all-to-all keys / rows
     if self.is_training:
       seq += [(self._phase_compute, self._compact_exchange_and_update), (self._phase_apply, None)]
     else:

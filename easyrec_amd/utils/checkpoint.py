@@ -63,7 +63,7 @@ def _remove_stale_kv_parts(ckpt_path, var_name, world):
   duplicate keys."""
   import glob
   import re
-  for ext in ('key', 'val'):
+  for ext in ('key', 'val', 'seen', 'freq', 'version'):
     for path in glob.glob(glob.escape('%s-embedding/%s-part-' % (ckpt_path, var_name)) + '*.' + ext):
       m = re.search(r'-part-(\d+)\.%s$' % ext, path)
       if m and int(m.group(1)) >= world:
@@ -71,21 +71,22 @@ def _remove_stale_kv_parts(ckpt_path, var_name, world):
 
 
 def _save_kv_table(engine, ckpt_path, name, slots, rank, world=1):
-  """keys / rows of the ids that have a row, and the same rows of every slot (the slots share the table's keys).
-  -> the filter's state of an `ev_params { filter_freq / steps_to_live }` table (every id the table tracks, its count and
-  the step of its last lookup), which goes into the dense file."""
+  """keys / rows of the ids that have a row, and the same rows of every slot (the slots share the table's keys).  An
+  `ev_params { filter_freq / steps_to_live }` table also writes its filter's state next to them: `.seen` (every id the
+  table tracks, int64), `.freq` (its count, int32) and `.version` (the step of its last lookup, int32)."""
   kv = engine.kv_tables[name]
-  aux = {}
+  os.makedirs(ckpt_path + '-embedding', exist_ok=True)
+  fv0 = embed_file_var_name(name)
   if engine._kv_filtered(name):
     seen, seen_rows, freq, version = kernels.hip().kv_export_all(kv)
     has_row = seen_rows >= 0
     keys, rows = seen[has_row], seen_rows[has_row]
-    aux = {name + '/kv_seen_keys': seen.cpu().numpy().astype(np.int64),
-           name + '/kv_freq': np.minimum(freq.cpu().numpy(), max(engine.tables[name]['kv_filter_freq'], 1)).astype(np.int32),
-           name + '/kv_version': version.cpu().numpy().astype(np.int32)}
+    seen.cpu().numpy().astype(np.int64).tofile(_kv_file(ckpt_path, fv0, rank, 'seen'))
+    np.minimum(freq.cpu().numpy(), max(engine.tables[name]['kv_filter_freq'], 1)).astype(np.int32).tofile(
+        _kv_file(ckpt_path, fv0, rank, 'freq'))
+    version.cpu().numpy().astype(np.int32).tofile(_kv_file(ckpt_path, fv0, rank, 'version'))
   else:
     keys, rows = kernels.hip().kv_export(kv)
-  os.makedirs(ckpt_path + '-embedding', exist_ok=True)
   keys_np = keys.cpu().numpy().astype(np.int64)
   pairs = [(name, engine.table_view(name))] + [(name + '/' + suffix, engine.slot_view(name, s)) for s, suffix in slots.items()]
   for var, view in pairs:
@@ -96,12 +97,30 @@ def _save_kv_table(engine, ckpt_path, name, slots, rank, world=1):
     view[rows.to(view.device)].detach().cpu().numpy().astype(np.float32).tofile(_kv_file(ckpt_path, fv, rank, 'val'))
     if rank == 0:
       _remove_stale_kv_parts(ckpt_path, fv, world)
-  return aux
 
 
-def _restore_kv_table(be, engine, ckpt_path, name, slots, rank, world, aux):
-  """The table becomes the saved one (layers/input_layer.py load_kv_table); a slot's file carries the table's keys in its
-  own order."""
+def _load_kv_filter_parts(ckpt_path, var_name, rank, world):
+  """The filter's state of the ids this rank owns (id % world == rank) out of every part found, ascending; None when
+  the checkpoint has none."""
+  import glob
+  seen, freq, version = [], [], []
+  for path in sorted(glob.glob(glob.escape('%s-embedding/%s-part-' % (ckpt_path, var_name)) + '*.seen')):
+    k = np.fromfile(path, dtype=np.int64)
+    mine = (k % world) == rank
+    seen.append(k[mine])
+    freq.append(np.fromfile(path[:-len('seen')] + 'freq', dtype=np.int32)[mine])
+    version.append(np.fromfile(path[:-len('seen')] + 'version', dtype=np.int32)[mine])
+  if not seen:
+    return None, None, None
+  seen, freq, version = np.concatenate(seen), np.concatenate(freq), np.concatenate(version)
+  order = np.argsort(seen, kind='stable')
+  return seen[order], freq[order], version[order]
+
+
+def _restore_kv_table(be, engine, ckpt_path, name, slots, rank, world):
+  """The table becomes the saved one (layers/input_layer.py load_kv_table): this rank's ids out of every part (the
+  loader keeps id % world == rank, ops/src/load_kv_embed.cc:100-130); a slot's file carries the table's keys in its own
+  order."""
   dim = engine.table_view(name).shape[1]
   keys, vals = be.load_kv_embed(ckpt_path, embed_file_var_name(name), rank, world, dim)
   keys = np.ascontiguousarray(keys, dtype=np.int64)
@@ -116,8 +135,10 @@ def _restore_kv_table(be, engine, ckpt_path, name, slots, rank, world, aux):
     assert np.array_equal(np.asarray(skeys, dtype=np.int64)[so], keys), \
         'checkpoint %s: slot file %s does not hold the table file\'s ids' % (ckpt_path, name + '/' + suffix)
     slot_values[s] = np.ascontiguousarray(svals, dtype=np.float32)[so]
-  engine.load_kv_table(name, keys, vals, slot_values, aux.get(name + '/kv_seen_keys'), aux.get(name + '/kv_freq'),
-                       aux.get(name + '/kv_version'))
+  seen, freq, version = _load_kv_filter_parts(ckpt_path, embed_file_var_name(name), rank, world)
+  # (EmbeddingEngine.load_kv_table, not the sharded override: the ids are already this rank's)
+  from easyrec_amd.layers.input_layer import EmbeddingEngine
+  EmbeddingEngine.load_kv_table(engine, name, keys, vals, slot_values, seen, freq, version)
 
 
 def save(est, ckpt_path):
@@ -129,7 +150,6 @@ def save(est, ckpt_path):
   engine.flush_decay()
   if hasattr(engine, 'evict_stale'):
     engine.evict_stale(est.global_step)  # ev_params.steps_to_live: eviction happens when a checkpoint is written
-  kv_aux = {}
   if est.device.type == 'cuda':
     torch.cuda.synchronize()
   # an overflowed fixed-capacity exchange voids the steps since: never persist tables it may have touched
@@ -142,7 +162,7 @@ def save(est, ckpt_path):
       continue
     t_idx, t_num = (rank, world) if is_shard else (0, 1)
     if engine.tables[name].get('kv'):
-      kv_aux.update(_save_kv_table(engine, ckpt_path, name, slots, t_idx, t_num))
+      _save_kv_table(engine, ckpt_path, name, slots, t_idx, t_num)
       continue
     be.save_dense_embed(ckpt_path, embed_file_var_name(name), t_idx, t_num, engine.table_view(name).cpu().numpy())
     for s, suffix in slots.items():
@@ -164,7 +184,6 @@ def save(est, ckpt_path):
     # the rows an uninterrupted one would
     for name, kv in getattr(engine, 'kv_tables', {}).items():
       dense[name + '/kv_meta'] = np.array([kv['seed'], kv['mean'], kv['stddev'], kv['capacity']], dtype=np.float64)
-      dense.update({k: v for k, v in kv_aux.items() if k.startswith(name + '/')})
       dense[name + '/kv_seed'] = np.asarray(int(kv['seed']), dtype=np.int64)  # (float64 loses seeds >= 2^53)
     dense['global_step'] = np.asarray(int(est.global_step), dtype=np.int64)
     tensor_bundle.write_bundle(ckpt_path, dense)
@@ -187,7 +206,7 @@ def restore(est, ckpt_path):
   for name, is_shard in _engine_tables(engine):
     t_idx, t_num = (rank, world) if is_shard else (0, 1)
     if engine.tables[name].get('kv'):
-      _restore_kv_table(be, engine, ckpt_path, name, slots, t_idx, t_num, z)
+      _restore_kv_table(be, engine, ckpt_path, name, slots, t_idx, t_num)
       continue
     view = engine.table_view(name)
     n_local, dim = view.shape

@@ -452,6 +452,26 @@ int er_kv_rebuild(const int64_t* keys, const int32_t* rows, const int32_t* freq,
                   int32_t* overflow, er_stream_t stream);
 int er_kv_translate_multi(const er_kv_job* jobs_dev, const int32_t* blk_start_dev, int n_jobs, int total_blocks, int insert,
                           er_stream_t stream);
+/* Embedding-parallel hash tables (the reference: SOK DynamicVariable sharded by id % world,
+ * compat/feature_column/feature_column.py:470-503).  Rank r owns the map and arena of the ids with id % world == r.
+ * Before the route of a step: er_kv_bucket sorts every job's ids by owner into send[world][block_stride] (job j's ids for
+ * an owner at [send_off_j, send_off_j + n_j) of that owner's block, -1 behind them; slot[i] = where id i went), an
+ * equal-split all-to-all moves the blocks, the owners run er_kv_translate_multi over what they received, a second
+ * all-to-all returns the arena rows, and er_kv_unbucket writes rows_out[i] = arena_row * world + owner (-1: no row) -
+ * a dense id that the ordinary embedding-parallel route (owner = id % world, local row = id / world) resolves to that
+ * arena row.  counts: int32[n_jobs * world] scratch.  jobs / blk_start: device arrays as in er_kv_translate_multi. */
+typedef struct {
+  const int64_t* ids;
+  int64_t n;
+  const int32_t* n_limit; /* NULL or the device count of valid ids (ragged lists) */
+  int64_t* rows_out;      /* [n] the virtual dense ids */
+  int32_t* slot;          /* [n] position in the send buffer, -1 for padding */
+  int64_t send_off;       /* this job's region inside an owner's block */
+} er_kv_route_job;
+int er_kv_bucket(const er_kv_route_job* jobs_dev, const int32_t* blk_start_dev, int n_jobs, int total_blocks, int world,
+                 int64_t block_stride, int64_t* send, int32_t* counts, er_stream_t stream);
+int er_kv_unbucket(const er_kv_route_job* jobs_dev, const int32_t* blk_start_dev, int n_jobs, int total_blocks, int world,
+                   int64_t block_stride, const int64_t* back, er_stream_t stream);
 int er_kv_export(const int64_t* map_keys, const int32_t* map_rows, int64_t map_slots, int64_t* out_keys,
                  int32_t* out_rows, int32_t* count, er_stream_t stream);
 /* ---- K9b: CIN, xDeepFM's compressed interaction network (reference layers/keras/interaction.py:370-409) ----

@@ -957,6 +957,40 @@ class RefBackend(object):
     for kv, ids, rows_out in spans:
       self._kv_find(kv, ids, rows_out)
 
+  def kv_route_create(self, jobs, world):
+    offs = [0]
+    for job in jobs:
+      offs.append(offs[-1] + job[0].numel())
+    C = max(offs[-1], 1)
+    buf = lambda: torch.full((world, C), -1, dtype=torch.int64)
+    return {'jobs': jobs, 'world': int(world), 'C': C, 'offs': offs, 'slots': [torch.full((j[0].numel(),), -1, dtype=torch.int64) for j in jobs],
+            'send': buf(), 'recv': buf(), 'owner_rows': buf(), 'back': buf()}
+
+  def kv_bucket(self, h):
+    W, C = h['world'], h['C']
+    h['send'].fill_(-1)
+    for j, job in enumerate(h['jobs']):
+      ids = job[0].view(-1)
+      n = ids.numel() if len(job) < 3 or job[2] is None else min(ids.numel(), int(job[2].item()))
+      counts = [0] * W
+      for i, key in enumerate(ids.tolist()):
+        if i >= n or key < 0:
+          h['slots'][j][i] = -1
+          continue
+        o = key % W
+        at = o * C + h['offs'][j] + counts[o]
+        counts[o] += 1
+        h['send'].view(-1)[at] = key
+        h['slots'][j][i] = at
+
+  def kv_unbucket(self, h):
+    W, C = h['world'], h['C']
+    back = h['back'].view(-1)
+    for j, job in enumerate(h['jobs']):
+      at = h['slots'][j]
+      r = back[at.clamp(min=0)]
+      job[1].view(-1).copy_(torch.where((at >= 0) & (r >= 0), r * W + at // C, torch.full_like(r, -1)))
+
   def kv_export(self, kv):
     items = sorted((k, r) for k, r in kv['map'].items() if r >= 0)
     return (torch.tensor([k for k, _ in items], dtype=torch.int64), torch.tensor([r for _, r in items], dtype=torch.int64))

@@ -285,7 +285,9 @@ class OracleTrainer(object):
     kv, arena = self.kv[name], self.state[name]
     ids = np.asarray(ids, dtype=np.int64).tolist()
     counted = kv['filter_freq'] > 1
-    for key in ids:
+    # (W workers: the owners see the ids of ALL workers before any row is read - train_step_world runs the workers'
+    #  lookups once in 'insert' mode, then forward / backward in 'find' mode)
+    for key in (ids if getattr(self, '_kv_mode', 'both') != 'find' else ()):
       if key < 0:
         continue
       known = key in kv['map']
@@ -307,7 +309,7 @@ class OracleTrainer(object):
         for slot in ('/m', '/v'):  # (a row that an evicted id owned before: never the case here, rows are not reused)
           assert (name + slot) not in self.slots or not self.slots[name + slot][r].any()
         kv['map'][key] = r
-    return np.array([-1 if key < 0 else kv['map'][key] for key in ids], dtype=np.int64)
+    return np.array([-1 if key < 0 else kv['map'].get(key, -1) for key in ids], dtype=np.int64)
 
   def kv_evict(self, name):
     """steps_to_live at checkpoint time: ids whose last training lookup is more than steps_to_live steps back are
@@ -1302,6 +1304,12 @@ class OracleTrainer(object):
     self.rank_moving = []
     clip_on = float(self.cfg.train_config.gradient_clipping_by_norm) > 0
     lookup_sq = {}  # W == 1: variable name -> sum over its lookups of the squared per-lookup gradient (shared tables)
+    if self.kv and W > 1:
+      self._kv_mode, self._track_lookups = 'insert', False
+      with torch.no_grad():
+        for batch in batches:
+          self.forward(batch)
+      self._kv_mode = 'find'
     for batch in batches:
       self._track_lookups, self._lookup_leaves = clip_on and W == 1, {}
       V, pred, losses = self.forward(batch)
@@ -1323,6 +1331,7 @@ class OracleTrainer(object):
       self.rank_moving.append({k: val.numpy().astype(np.float32) for k, val in self._moving.items()})
       losses_out.append({k: float(v.detach()) for k, v in losses.items()})
       self.last_pred = {k: v.detach().numpy() for k, v in pred.items()}
+    self._kv_mode = 'both'
     names = list(per_rank[0].keys())
     step = self.global_step
     # gradients after the multipliers (compat/optimizers.py:347-356); mean over the workers

@@ -94,5 +94,8 @@ class ThreadSimComm(object):
     self.sim.barrier.wait()
     return out
 
+  def all_gather_varlen(self, t):
+    return self.all_gather_rows(t)
+
   def barrier(self):
     self.sim.barrier.wait()

@@ -189,3 +189,140 @@ def test_evaluate_through_the_sharded_engine(ref_backend):
   est.train_step(batches[2])
   ra, rc = ref.loss_values(), est.loss_values()
   assert all(abs(ra[k] - rc[k]) <= 1e-6 * max(1.0, abs(ra[k])) for k in ra), (ra, rc)
+
+
+# ---- hash-table (ev_params) tables under embedding parallelism: the ids travel to their owners (id % world) --------
+def _kv_cfg(filtered):
+  from easyrec_amd.utils import config_util
+  cfg = config_util.get_configs_from_pipeline_file(os.path.join(ROOT, 'configs', 'deepfm_kv_criteo_small.config'))
+  if filtered:
+    by_name = {f.input_names[0]: f for f in cfg.feature_config.features}
+    by_name['C1'].ev_params.filter_freq = 2
+    by_name['C2'].ev_params.steps_to_live = 2
+  return cfg
+
+
+def _kv_compare(a, b, names, tol=1e-6):
+  for n in names:
+    for suffix in ('/keys', '/kv_seen_keys', '/kv_freq', '/kv_version'):
+      assert ((n + suffix) in a) == ((n + suffix) in b), (n, suffix)
+      if (n + suffix) in a:
+        assert np.array_equal(a[n + suffix], b[n + suffix]), (n, suffix)
+    for suffix in ('', '/m', '/v'):
+      d = float(np.abs(a[n + suffix] - b[n + suffix]).max()) if a[n + suffix].size else 0.0
+      assert d <= tol * max(float(np.abs(b[n + suffix]).max()) if b[n + suffix].size else 0.0, 1e-3), (n, suffix, d)
+
+
+@pytest.mark.parametrize('filtered', [False, True])
+def test_world1_sharded_kv_tables_equal_the_single_gpu_engine(ref_backend, filtered):
+  from easyrec_amd.input.criteo_synthetic import SyntheticCriteo
+  from easyrec_amd.model.easy_rec_estimator import EasyRecEstimator
+  from easyrec_amd.model.embedding_parallel import EmbeddingParallelEstimator
+  B = 32
+  cfg = _kv_cfg(filtered)
+  gen = SyntheticCriteo(cfg.data_config, list(cfg.feature_config.features), batch_size=B, seed=13)
+  batches = [gen.next_batch() for _ in range(3)]
+  ref = EasyRecEstimator(cfg, device='cpu', batch_size=B, seed=3).build()
+  est = EmbeddingParallelEstimator(cfg, device='cpu', batch_size=B, seed=3, rank=0, world=1, replicate_bytes=1024).build()
+  names = sorted(ref.engine.kv_tables)
+  assert names == sorted(est.engine.kv_tables) and all(est.engine.placement[n][0] == 'shard' for n in names)
+  for b in batches:
+    ref.train_step(b)
+    est.train_step(b)
+    ra, rc = ref.loss_values(), est.loss_values()
+    assert all(abs(ra[k] - rc[k]) <= 1e-6 * max(1.0, abs(ra[k])) for k in ra), (ra, rc)
+  _kv_compare(est.state_dict(slots=True), ref.state_dict(slots=True), names)
+  # evaluation creates no rows; a state loaded into a fresh sharded estimator continues alike
+  before = est.state_dict()
+  est.evaluate([SyntheticCriteo(cfg.data_config, list(cfg.feature_config.features), batch_size=B, seed=77).next_batch()])
+  assert all(np.array_equal(before[n + '/keys'], est.state_dict()[n + '/keys']) for n in names)
+  # (same seed: rows created after the load are drawn from the table's generator, whose seed derives from it)
+  twin = EmbeddingParallelEstimator(cfg, device='cpu', batch_size=B, seed=3, rank=0, world=1, replicate_bytes=1024).build()
+  twin.load_state_dict(est.state_dict(slots=True))
+  est.train_step(batches[0])
+  twin.train_step(batches[0])
+  a, c = est.loss_values(), twin.loss_values()
+  assert all(abs(a[k] - c[k]) <= 1e-6 * max(1.0, abs(a[k])) for k in a), (a, c)
+
+
+def _gloo_worker_kv(rank, world, port, B, steps, filtered, out_dir):
+  sys.path.insert(0, ROOT)
+  sys.path.insert(0, os.path.join(ROOT, 'tests'))
+  os.environ['MASTER_ADDR'] = '127.0.0.1'
+  os.environ['MASTER_PORT'] = str(port)
+  import pickle
+  import torch.distributed as dist
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  torch.set_num_threads(1)
+  from easyrec_amd import kernels
+  from oracle.kernel_ref import RefBackend
+  kernels._BACKEND = RefBackend()  # CPU stand-in for the HIP kernels (tests only)
+  from _multi_rank import rank_batches
+  from easyrec_amd.model.embedding_parallel import EmbeddingParallelEstimator
+  from test_embedding_parallel import _kv_cfg
+  cfg = _kv_cfg(filtered)
+  batches = rank_batches(cfg, list(cfg.feature_config.features), B, world, steps)
+  est = EmbeddingParallelEstimator(cfg, device='cpu', batch_size=B, seed=4, rank=rank, world=world,
+                                   replicate_bytes=1024).build()
+  init = est.state_dict()  # collective
+  losses, states = [], []
+  for step_batches in batches:
+    est.train_step(step_batches[rank])
+    losses.append(est.loss_values())
+    states.append(est.state_dict(slots=True))  # collective
+  owned = {n: int(kv_n) for n, kv_n in ((n, len(kv['map'])) for n, kv in est.engine.kv_tables.items())}
+  from easyrec_amd.utils import checkpoint
+  checkpoint.save(est, os.path.join(out_dir, 'model.ckpt-%d' % est.global_step))  # every rank its part files
+  states.append(est.state_dict(slots=True))  # (after the save: steps_to_live evicts when a checkpoint is written)
+  with open(os.path.join(out_dir, 'rank%d.pkl' % rank), 'wb') as f:
+    pickle.dump({'init': init, 'states': states, 'losses': losses, 'owned': owned}, f)
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('filtered', [False, True])
+def test_world2_gloo_kv_tables_match_the_w_worker_oracle(ref_backend, tmp_path, filtered):
+  """Two processes over gloo, each on its own batches, hash-table tables sharded by id % 2: the ids travel to their
+  owners and back (er_kv_bucket / translate / er_kv_unbucket around two all-to-alls), the owners count EVERY rank's
+  occurrences towards filter_freq.  Against the oracle's W-worker step after every step: per-rank losses, the ids that
+  have a row, the filter's counts and stamps, the rows and Adam's moments by id."""
+  import pickle
+  import torch.multiprocessing as mp
+  sys.path.insert(0, os.path.join(ROOT, 'tests'))
+  from _multi_rank import rank_batches
+  from oracle.model_oracle import OracleTrainer
+  B, world, steps = 24, 2, 2
+  port = 35500 + (os.getpid() % 2000) + (7 if filtered else 0)
+  mp.spawn(_gloo_worker_kv, args=(world, port, B, steps, filtered, str(tmp_path)), nprocs=world, join=True)
+  ranks = [pickle.load(open(os.path.join(str(tmp_path), 'rank%d.pkl' % r), 'rb')) for r in range(world)]
+  cfg = _kv_cfg(filtered)
+  batches = rank_batches(cfg, list(cfg.feature_config.features), B, world, steps)
+  orc = OracleTrainer(cfg, ranks[0]['init'], batch_size=B)
+  names = sorted(n for n in orc.kv)
+  assert len(names) == 8 and all(min(r['owned'][n] for r in ranks) > 0 for n in names), 'both ranks own ids of every table'
+  for step in range(steps):
+    exp = orc.train_step_world(batches[step])
+    for r in range(world):
+      for k, v in exp[r].items():
+        got = ranks[r]['losses'][step][k]
+        assert abs(got - v) <= 1e-4 * max(1.0, abs(v)), (step, r, k, got, v)
+    st = ranks[0]['states'][step]
+    for n in names:
+      keys, rows = orc.kv_state(n)
+      assert np.array_equal(st[n + '/keys'], keys), (step, n, st[n + '/keys'].size, keys.size)
+      assert np.array_equal(ranks[1]['states'][step][n + '/keys'], keys), 'state_dict gathers the same table on every rank'
+      _, m_rows = orc.kv_state(n, orc.slots[n + '/m'])
+      m_scale = float(np.abs(m_rows).max())
+      assert float(np.abs(st[n + '/m'] - m_rows).max()) <= 2e-4 * m_scale + 1e-9, (step, n)
+      if step == 0:  # (later: Adam's noise amplification on near-zero gradients, tests/test_kv_embedding.py)
+        assert float(np.abs(st[n] - rows).max()) <= 2e-4 * float(np.abs(rows).max()) + 1e-5, (step, n)
+      if (n + '/kv_seen_keys') in st:
+        seen, freq, version = orc.kv_filter_state(n)
+        assert np.array_equal(st[n + '/kv_seen_keys'], seen) and np.array_equal(st[n + '/kv_freq'], freq), (step, n)
+        assert np.array_equal(st[n + '/kv_version'], version), (step, n)
+  # the two ranks' checkpoint parts restored into ONE process: the same table (ids, rows, moments, filter state)
+  from easyrec_amd.model.easy_rec_estimator import EasyRecEstimator
+  from easyrec_amd.utils import checkpoint
+  single = EasyRecEstimator(cfg, device='cpu', batch_size=B, seed=11).build()
+  checkpoint.restore(single, os.path.join(str(tmp_path), 'model.ckpt-%d' % steps))
+  _kv_compare(single.state_dict(slots=True), ranks[0]['states'][-1], names, tol=0.0)

@@ -445,3 +445,85 @@ def test_lazy_decay_equals_sweep_through_two_sharded_ranks(monkeypatch, overlap)
 
     states[sweep] = sim.run(rank_fn)[0]
   _assert_lazy_equals_sweep(states[False], states[True])
+
+
+# ---- hash-table (ev_params) tables under embedding parallelism --------------------------------------------------------
+@pytest.mark.parametrize('W', [1, 2, 8])
+def test_kv_bucket_unbucket_kernels(W):
+  """er_kv_bucket / er_kv_unbucket: every id lands once in its owner's block (id % W) inside its job's region, padding
+  and the stale tail of a ragged list get no slot, and the way back writes arena_row * W + owner (or -1)."""
+  hip = kernels.hip()
+  g = torch.Generator().manual_seed(W)
+  jobs, limit = [], torch.tensor([700], dtype=torch.int32, device=DEV)
+  for j, n in enumerate((1000, 4096, 900)):
+    ids = torch.randint(0, 1 << 40, (n,), generator=g, dtype=torch.int64)
+    ids[::13] = -1
+    jobs.append((ids.to(DEV), torch.full((n,), -7, dtype=torch.int64, device=DEV)) + ((limit,) if j == 2 else ()))
+  h = hip.kv_route_create(jobs, W)
+  hip.kv_bucket(h)
+  torch.cuda.synchronize()
+  send, C = h['send'].cpu(), h['C']
+  for j, job in enumerate(jobs):
+    ids, slot = job[0].cpu(), h['slots'][j].cpu().to(torch.int64)
+    valid = ids >= 0
+    if j == 2:
+      valid &= torch.arange(ids.numel()) < 700
+    assert bool((slot[~valid] == -1).all()) and bool((slot[valid] >= 0).all())
+    at = slot[valid]
+    assert torch.equal(send.view(-1)[at], ids[valid]) and at.unique().numel() == at.numel()
+    assert torch.equal(at // C, ids[valid] % W)
+    off = at % C
+    assert bool((off >= h['offs'][j]).all()) and bool((off < h['offs'][j + 1]).all())
+  assert int((send >= 0).sum()) == sum(int((h['slots'][j] >= 0).sum()) for j in range(3))
+  # the owners' answer: row = (id >> 3) for even ids, none for odd ones
+  back = torch.where((send >= 0) & (send % 2 == 0), send >> 3, torch.full_like(send, -1))
+  h['back'].copy_(back.to(DEV))
+  hip.kv_unbucket(h)
+  torch.cuda.synchronize()
+  for j, job in enumerate(jobs):
+    ids, out = job[0].cpu(), job[1].cpu()
+    valid = (ids >= 0) & (ids % 2 == 0)
+    if j == 2:
+      valid &= torch.arange(ids.numel()) < 700
+    assert torch.equal(out[valid], (ids[valid] >> 3) * W + ids[valid] % W) and bool((out[~valid] == -1).all())
+
+
+@pytest.mark.parametrize('world', [1, 2])
+def test_sharded_kv_tables_with_the_same_batch_equal_single_gpu(world):
+  """Hash-table tables sharded by id % world (ids to their owners and back around the route): with the SAME batch on
+  every rank each row gets world * g / world, so the run follows the single-GPU engine - losses, the ids that have a
+  row, the rows."""
+  cfg = _cfg('deepfm_kv_criteo_small.config')
+  B, steps = 128, 2
+  ref = EasyRecEstimator(cfg, device=DEV, batch_size=B, seed=4).build()
+  gen = SyntheticCriteo(cfg.data_config, list(cfg.feature_config.features), batch_size=B, seed=9)
+  batches = [gen.next_batch() for _ in range(steps)]
+  ref_losses = []
+  for b in batches:
+    ref.train_step(b)
+    ref_losses.append(ref.loss_values())
+  ref_state = ref.state_dict(slots=True)
+  names = sorted(ref.engine.kv_tables)
+  sim = SimWorld(world)
+
+  def rank_fn(rank, comm):
+    torch.cuda.set_device(0)
+    est = EmbeddingParallelEstimator(cfg, device=DEV, batch_size=B, seed=4, rank=rank, world=world, comm=comm,
+                                     replicate_bytes=1024).build()
+    losses = []
+    for b in batches:
+      est.train_step(b)
+      losses.append(est.loss_values())
+    owned = {n: int(est.engine.kv_tables[n]['next_row'].item()) for n in names}
+    return est.state_dict(slots=True), losses, owned
+
+  results = sim.run(rank_fn)
+  for state, losses, owned in results:
+    for got, exp in zip(losses, ref_losses):
+      assert abs(got['total_loss'] - exp['total_loss']) <= 2e-4 * abs(exp['total_loss']), (got, exp)
+    for n in names:
+      assert np.array_equal(state[n + '/keys'], ref_state[n + '/keys']), n
+      assert world == 1 or 0 < owned[n] < state[n + '/keys'].size, (n, owned[n])
+      m_scale = float(np.abs(ref_state[n + '/m']).max())
+      assert float(np.abs(state[n + '/m'] - ref_state[n + '/m']).max()) <= 5e-3 * m_scale, n
+      assert float(np.abs(state[n] - ref_state[n]).max()) <= 4e-3, n
