@@ -120,6 +120,8 @@ struct GemmArgs {
   BnFused fu;         // fu.mode != 0: finish the BatchNorm in this launch (see BnFused)
   ATransform at;      // at.mean != nullptr: A is transformed while staged (kernels instantiated with A_TR)
   int tile_shape = 0; // gemm_f32_grouped_tnn_kernel: 2 * (128-row tile) + (128-column tile)
+  const float* row_bias = nullptr;  // [ceil(M / row_div)][N]: output row r also gets row_bias[r / row_div][col] (the
+  int row_div = 1;                  // per-example term of DIN's first attention layer, er_gemm_f32_rowbias); splits == 1
 };
 
 // Loads 4 consecutive elements along the CONTIGUOUS dimension of the operand tile.
@@ -665,6 +667,14 @@ __device__ __forceinline__ void gemm_f32_block(const GemmArgs& g, int bx, int bz
   // epilogue.  C/D map of the 32x32 tile: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
   const int col = n0 + wn * 32 + (lane & 31);
   const float bv = (g.bias && g.splits == 1 && col < g.N) ? g.bias[col] : 0.f;
+  if (g.row_bias != nullptr && col < g.N) {  // (uniform; before the statistics: they are those of the complete output)
+    const int khalf_rb = lane >> 5;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf_rb;
+      if (row < g.M) acc[r] += g.row_bias[static_cast<int64_t>(row / g.row_div) * g.N + col];
+    }
+  }
   if (g.col_stats)  // (host guarantees splits == 1) every thread takes part: it synchronises the workgroup
     tile_col_stats(acc, bv, m0 + wm * 32, g.M, col, g.N, wm, wn, lane, lds,
                    g.col_stats + static_cast<int64_t>(ty) * g.N * 3, g.fu.mode == 1 || g.fu.mode == 3);
@@ -1278,7 +1288,8 @@ int choose_splits(int M, int N, int K, int ktile) {
 template <bool BF16>
 int gemm_entry(int layout, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                const float* bias, int accumulate, float* col_stats, er_stream_t stream, const char* who,
-               const er::BnBwdEpi* bn = nullptr, const er::ATransform* at = nullptr, const er::BnFused* fu = nullptr) {
+               const er::BnBwdEpi* bn = nullptr, const er::ATransform* at = nullptr, const er::BnFused* fu = nullptr,
+               const float* row_bias = nullptr, int row_div = 1) {
   ER_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0, "%s: bad arguments", who);
   ER_REQUIRE(layout >= ER_GEMM_NN && layout <= ER_GEMM_TN, "%s: unknown layout %d", who, layout);
   const int min_lda = (layout == ER_GEMM_TN) ? M : K;
@@ -1294,7 +1305,8 @@ int gemm_entry(int layout, int M, int N, int K, const float* A, int lda, const f
   if (bn) a.bn = *bn;
   if (at) a.at = *at;
   if (fu) a.fu = *fu;
-  a.splits = (col_stats || bn) ? 1 : choose_splits(M, N, K, ktile);
+  a.row_bias = row_bias; a.row_div = row_div;
+  a.splits = (col_stats || bn || row_bias) ? 1 : choose_splits(M, N, K, ktile);
   ER_REQUIRE(!(col_stats && accumulate), "%s: column statistics need a plain (non-accumulating) output", who);
   a.k_per_split = static_cast<int>(er::ceil_div(er::ceil_div(K, a.splits), ktile)) * ktile;
   a.splits = static_cast<int>(er::ceil_div(K, a.k_per_split));
@@ -1629,6 +1641,14 @@ int er_gemm_f32_bn_bwd_z(int layout, int32_t M, int32_t N, int32_t K, const floa
 int er_gemm_f32(int layout, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B, int32_t ldb,
                 float* C, int32_t ldc, const float* bias, int accumulate, float* col_stats, er_stream_t stream) {
   return gemm_entry<false>(layout, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, col_stats, stream, "er_gemm_f32");
+}
+
+int er_gemm_f32_rowbias(int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B, int32_t ldb, float* C,
+                        int32_t ldc, const float* bias, const float* row_bias, int32_t row_div, float* col_stats,
+                        er_stream_t stream) {
+  ER_REQUIRE(row_bias && row_div >= 1, "er_gemm_f32_rowbias: row_bias / row_div missing");
+  return gemm_entry<false>(ER_GEMM_NN, M, N, K, A, lda, B, ldb, C, ldc, bias, 0, col_stats, stream, "er_gemm_f32_rowbias",
+                           nullptr, nullptr, nullptr, row_bias, row_div);
 }
 
 int er_gemm_bf16(int layout, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B, int32_t ldb,

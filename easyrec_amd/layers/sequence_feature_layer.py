@@ -34,10 +34,14 @@ def target_attention(dnn_config, deep_fea, name, l2_reg, is_training, need_key_f
       hist = dnn.dense(hist, E, 'sequence_fea_transform_layer_' + name)
   assert cur_id.shape[1] == E, 'DIN: key dim %d != history dim %d (set allow_key_transform)' % (cur_id.shape[1], E)
   hist = hist if hist.is_contiguous() else hist.contiguous()  # (a batch whose longest sequence is below max_seq_len)
-  din_net = kernels.DINConcatFn.apply(cur_id, hist)  # [B, L, 4E]
   din_layer = dnn.DNN(dnn_config, l2_reg, name, is_training, last_layer_no_activation=True,
                       last_layer_no_batch_norm=True)
-  scores = din_layer(din_net).reshape(B, L)
+  if din_layer.can_fold_din() and len(din_layer.hidden_units) > 1:
+    # the first layer is linear in [q, h, q - h, q * h]: folded, the [B, L, 4E] input is never built (dnn.din_first_layer)
+    scores = din_layer(None, din=(cur_id, hist)).reshape(B, L)
+  else:
+    din_net = kernels.DINConcatFn.apply(cur_id, hist)  # [B, L, 4E]
+    scores = din_layer(din_net).reshape(B, L)
   pooled = kernels.DINPoolFn.apply(scores, hist, seq_len, 1.0)  # softmax over where(t < len, score, -2^32 + 1)
   if not need_key_feature:
     return pooled

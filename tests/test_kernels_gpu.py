@@ -1637,3 +1637,45 @@ def test_head_sigmoid_ce_and_loss_tail(hip, ref, B, K, with_src, with_bn, bias):
   for k in ('loss', 'reg', 'total', 'report'):
     assert abs(float(got[k]) - float(exp[k])) <= 2e-6 * max(1.0, abs(float(exp[k]))), (k, float(got[k]), float(exp[k]))
   assert float(exp['reg']) == 0.5 * 21.0 and abs(float(exp['total']) - (10.5 + float(exp['loss']) + 0.125)) < 1e-5
+
+
+@pytest.mark.parametrize('B,L,E,H', [(64, 50, 32, 128), (37, 7, 12, 40), (256, 20, 8, 64)])
+def test_folded_din_first_layer_kernels(B, L, E, H):
+  """K8b: er_din_fold_w / er_din_pair_fwd / er_gemm_f32_rowbias (+ column statistics) / er_segment_rowsum /
+  er_din_pair_bwd / er_din_unfold_dw against torch, and the folded layer against dense(din_concat) (same sums in another
+  association: 1e-5 of the output's scale)."""
+  from oracle.kernel_ref import RefBackend
+  hip, ref = kernels.hip(), RefBackend()
+  g = torch.Generator().manual_seed(B + L)
+  q, h = torch.randn(B, E, generator=g), torch.randn(B, L, E, generator=g)
+  w, bias = torch.randn(4 * E, H, generator=g) * 0.1, torch.randn(H, generator=g)
+  qd, hd, wd, bd = q.to(DEV), h.to(DEV), w.to(DEV), bias.to(DEV)
+  wq, wp = hip.din_fold_w(wd)
+  rq, rp = ref.din_fold_w(w)
+  assert torch.equal(wq.cpu(), rq) and torch.equal(wp.cpu(), rp)
+  pair = hip.din_pair_fwd(qd, hd)
+  assert torch.equal(pair.cpu(), ref.din_pair_fwd(q, h))
+  rb = hip.gemm(kernels.GEMM_NN, qd, wq)
+  M = B * L
+  stats = torch.empty(hip.gemm_row_tiles(M) * H * 3, dtype=torch.float32, device=DEV)
+  z = hip.gemm(kernels.GEMM_NN, pair.reshape(M, 2 * E), wp, bias=bd, col_stats=stats, row_bias=rb, row_div=L)
+  want = (ref.din_concat_fwd(q, h).reshape(M, 4 * E).double() @ w.double() + bias.double()).float()
+  scale = float(want.abs().max())
+  assert float((z.cpu() - want).abs().max()) <= 1e-5 * scale
+  # the statistics are those of the complete output (row term included): mean of the per-tile means, weighted
+  st = stats.cpu().reshape(-1, H, 3)
+  mean = (st[:, :, 0] * st[:, :, 1]).sum(0) / st[:, :, 0].sum(0)
+  assert float((mean - want.double().mean(0).float()).abs().max()) <= 1e-4 * scale
+  dz = torch.randn(M, H, generator=g)
+  s = hip.segment_rowsum(dz.to(DEV), L)
+  assert float((s.cpu() - dz.reshape(B, L, H).sum(1)).abs().max()) <= 1e-5 * L ** 0.5 * 4
+  dpair = torch.randn(B, L, 2 * E, generator=g)
+  dq, dh = hip.din_pair_bwd(qd, hd, dpair.to(DEV))
+  rdq, rdh = ref.din_pair_bwd(q, h, dpair)
+  assert float((dq.cpu() - rdq).abs().max()) <= 1e-5 * float(rdq.abs().max()) and float((dh.cpu() - rdh).abs().max()) <= 1e-6 * float(rdh.abs().max()) + 1e-6
+  dwq, dwp = torch.randn(E, H, generator=g), torch.randn(2 * E, H, generator=g)
+  acc = torch.randn(4 * E, H, generator=g)
+  out = acc.clone().to(DEV)
+  hip.din_unfold_dw(dwq.to(DEV), dwp.to(DEV), out=out, accumulate=True)
+  assert float((out.cpu() - (acc + ref.din_unfold_dw(dwq, dwp))).abs().max()) <= 1e-6
+  assert torch.equal(hip.din_unfold_dw(dwq.to(DEV), dwp.to(DEV)).cpu(), ref.din_unfold_dw(dwq, dwp))
