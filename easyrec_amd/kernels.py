@@ -1641,13 +1641,19 @@ class HipBackend(object):
     nb = (ctypes.c_int64 * n)(*[s_.numel() * s_.element_size() for _, s_ in pairs])
     self._ck(self.lib.er_copy_multi(srcs, dsts, nb, n, _stream()), 'er_copy_multi')
 
+  concat_pitch = os.environ.get('EASYREC_AMD_CONCAT_PITCH', '1') != '0'  # A/B switch
+
   def concat_cols(self, parts):
     """torch.cat(parts, dim=1) of 2-D fp32 blocks (unit inner stride) as one library launch."""
     n = len(parts)
     B = parts[0].shape[0]
     for t in parts:
       assert t.dim() == 2 and t.shape[0] == B and t.stride(1) == 1 and t.dtype == torch.float32
-    out = torch.empty(B, sum(t.shape[1] for t in parts), dtype=torch.float32, device=parts[0].device)
+    # rows at a pitch that is a multiple of four floats (DeepFM's [wide | fm | deep] is 81 wide): the consumers' GEMMs
+    # then see a 16-byte aligned operand and take their branch-free 16-byte loads instead of the masked scalar path
+    width = sum(t.shape[1] for t in parts)
+    pitch = (width + 3) // 4 * 4 if self.concat_pitch else width
+    out = torch.empty(B, pitch, dtype=torch.float32, device=parts[0].device)[:, :width]
     for i in range(0, n, 8):  # (more than 8 parts: several launches into column blocks of `out`)
       chunk = parts[i:i + 8]
       col0 = sum(t.shape[1] for t in parts[:i])

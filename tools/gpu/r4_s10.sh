@@ -1,4 +1,5 @@
 #!/bin/bash
+# round 4, session 10: shader / memory clocks while the bench runs (is any of the step clock-limited?)
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 O=gpurun_out/r4s10; mkdir -p $O
 rocm-smi --showclocks 2>&1 | grep -iE "sclk|mclk|fclk" | head -5 | tee $O/clocks.txt

@@ -1,4 +1,5 @@
 #!/bin/bash
+# round 4, session 14: fused embedding step, second cut: A/B test + bench A/B with the embedding kernels listed
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 O=gpurun_out/r4s14; mkdir -p $O
 timeout 900 python -m pytest tests/test_deepfm_gpu.py -q -m gpu -x -k "fused_embedding" --timeout 300 2>&1 | tail -3 | tee $O/tests_fused.log

@@ -1,4 +1,5 @@
 #!/bin/bash
+# round 4, session 16: emb_bwd_own_kernel variants (run-following vs tile partials) inside the step
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 O=gpurun_out/r4s16; mkdir -p $O
 line() { python -c "

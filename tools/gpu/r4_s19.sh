@@ -1,4 +1,5 @@
 #!/bin/bash
+# round 4, session 19: gradient slots + library concat: aten op list, DCN / backbone model tests, same-box A/B
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 O=gpurun_out/r4s19; mkdir -p $O
 timeout 300 python tools/trace_step_ops.py configs/dcn_v2_criteo.config 4096 2>&1 | grep -v "^lib" | tee $O/dcnv2_aten_ops.txt | tail -8
