@@ -157,6 +157,7 @@ def grad_slots_of_step():
 
 
 _GRAD_SLOTS = os.environ.get('EASYREC_AMD_GRAD_SLOTS', '1') != '0'  # A/B switch
+_CAT_DGRAD = os.environ.get('EASYREC_AMD_CAT_DGRAD', '1') != '0'    # A/B switch: one input-gradient GEMM for the readers of a shared input
 
 
 def grad_slot(slots, x):
@@ -1361,12 +1362,16 @@ class HipBackend(object):
              'er_din_concat_fwd')
     return out
 
-  def din_concat_bwd(self, q, h, dout):
+  def din_concat_bwd(self, q, h, dout, dh=None, acc_h=False):
+    """dh given: the history's gradient buffer of the step (kernels.grad_slot); acc_h: add into it."""
     B, L, E = h.shape
     dq = torch.empty_like(q)
-    dh = torch.empty_like(h)
+    if dh is None:
+      assert not acc_h
+      dh = torch.empty_like(h)
+    assert dh.shape == h.shape and dh.is_contiguous()
     self._ck(
-        self.lib.er_din_concat_bwd(_p(q), _p(h), _p(_f32c(dout)), B, L, E, _p(dq), 0, _p(dh), 0, _stream()),
+        self.lib.er_din_concat_bwd(_p(q), _p(h), _p(_f32c(dout)), B, L, E, _p(dq), 0, _p(dh), int(bool(acc_h)), _stream()),
         'er_din_concat_bwd')
     return dq, dh
 
@@ -1425,13 +1430,16 @@ class HipBackend(object):
                                  _p(probs), _p(out), _stream()), 'er_din_pool_fwd')
     return out, probs
 
-  def din_pool_bwd(self, probs, hist, seq_len, dout, scale=1.0):
+  def din_pool_bwd(self, probs, hist, seq_len, dout, scale=1.0, dhist=None, acc_h=False):
     B, L, E = hist.shape
     dscores = torch.empty(B, L, dtype=torch.float32, device=hist.device)
-    dhist = torch.empty_like(hist)
+    if dhist is None:
+      assert not acc_h
+      dhist = torch.empty_like(hist)
+    assert dhist.shape == hist.shape and dhist.is_contiguous()
     self._ck(
         self.lib.er_din_pool_bwd(_p(probs), _p(hist), _p(seq_len), _p(_f32c(dout)), B, L, E,
-                                 ctypes.c_float(scale), _p(dscores), _p(dhist), 0, _stream()), 'er_din_pool_bwd')
+                                 ctypes.c_float(scale), _p(dscores), _p(dhist), int(bool(acc_h)), _stream()), 'er_din_pool_bwd')
     return dscores, dhist
 
   # -- K1b hash-table (KV) embedding tables
@@ -2390,7 +2398,19 @@ class GroupedLinearFn(torch.autograd.Function):
       if len(es) == 1 and ctx.gsinks[es[0]] is None:
         continue
       sink = ctx.gsinks[es[0]]
-      if sink is not None and sink.covers(0, ws[es[0]].shape[0]):  # an embedding group output: into its gradient buffer
+      to_sink = sink is not None and sink.covers(0, ws[es[0]].shape[0])  # an embedding group output: into its gradient buffer
+      if len(es) > 1 and _CAT_DGRAD and all(dzs[e].stride(1) == 1 for e in es):
+        # readers of ONE input (MMoE's first depth: every expert and gate reads the shared features): dx = sum_e dz_e W_e^T
+        # is ONE contraction over the layers' output columns laid side by side - the input-sized gradient is written once
+        # instead of being read and re-written by a GEMM per layer (8 x 36 MB at B = 8192), for two small concat launches
+        dz_cat = be.concat_cols([dzs[e] for e in es])
+        w_cat = be.concat_cols([ws[e].detach() for e in es])
+        if to_sink:
+          _dgrad(be, dz_cat, w_cat, None, False, sink)
+        else:
+          dxs[es[0]] = be.gemm(GEMM_NT, dz_cat, w_cat)
+        continue
+      if to_sink:
         for e in es:
           _dgrad(be, dzs[e], ws[e], None, False, sink)
         continue
@@ -2808,12 +2828,18 @@ class DINConcatFn(torch.autograd.Function):
   @staticmethod
   def forward(ctx, q, h):
     ctx.save_for_backward(q, h)
+    # (the history is also read by the pooling: both backward kernels write ONE gradient buffer - kernels.grad_slot)
+    ctx.slots = grad_slots_of_step() if h.is_contiguous() else None
     return hip().din_concat_fwd(q.contiguous(), h.contiguous())
 
   @staticmethod
   def backward(ctx, dout):
     q, h = ctx.saved_tensors
-    return hip().din_concat_bwd(q.contiguous(), h.contiguous(), dout.contiguous())
+    if ctx.slots is None:
+      return hip().din_concat_bwd(q.contiguous(), h.contiguous(), dout.contiguous())
+    buf, acc, first = grad_slot(ctx.slots, h)
+    dq, _ = hip().din_concat_bwd(q.contiguous(), h, dout.contiguous(), dh=buf, acc_h=acc)
+    return dq, (buf if first else None)
 
 
 class DINPairFn(torch.autograd.Function):
@@ -2862,13 +2888,18 @@ class DINPoolFn(torch.autograd.Function):
     out, probs = hip().din_pool_fwd(scores.contiguous(), hist.contiguous(), seq_len, scale)
     ctx.save_for_backward(probs, hist, seq_len)
     ctx.scale = scale
+    ctx.slots = grad_slots_of_step() if hist.is_contiguous() else None
     return out
 
   @staticmethod
   def backward(ctx, dout):
     probs, hist, seq_len = ctx.saved_tensors
-    dscores, dhist = hip().din_pool_bwd(probs, hist.contiguous(), seq_len, dout.contiguous(), ctx.scale)
-    return dscores, dhist, None, None
+    if ctx.slots is None:
+      dscores, dhist = hip().din_pool_bwd(probs, hist.contiguous(), seq_len, dout.contiguous(), ctx.scale)
+      return dscores, dhist, None, None
+    buf, acc, first = grad_slot(ctx.slots, hist)
+    dscores, _ = hip().din_pool_bwd(probs, hist, seq_len, dout.contiguous(), ctx.scale, dhist=buf, acc_h=acc)
+    return dscores, (buf if first else None), None, None
 
 
 class MMoEMixManyFn(torch.autograd.Function):

@@ -989,7 +989,7 @@ class InputLayer(object):
       views = list(flist) + list(all_seq_fea)
       for cfg, fea in zip(seq_cfgs, all_seq_fea):
         name_to_out['seq_fea/' + cfg.group_name] = fea
-      out = torch.cat([out] + list(all_seq_fea), dim=-1)
+      out = kernels.concat_cols([out] + list(all_seq_fea))
       flist = FeatureList(views)
     if is_dict:
       return out, flist, name_to_out

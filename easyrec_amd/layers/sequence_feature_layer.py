@@ -45,7 +45,7 @@ def target_attention(dnn_config, deep_fea, name, l2_reg, is_training, need_key_f
   pooled = kernels.DINPoolFn.apply(scores, hist, seq_len, 1.0)  # softmax over where(t < len, score, -2^32 + 1)
   if not need_key_feature:
     return pooled
-  return torch.cat([pooled, cur_id], dim=1)
+  return kernels.concat_cols([pooled, cur_id])
 
 
 class SequenceFeatureLayer(object):

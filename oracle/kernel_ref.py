@@ -847,12 +847,18 @@ class RefBackend(object):
     qq = q[:, None, :].expand(B, L, E)
     return torch.cat([qq, h, qq - h, qq * h], dim=-1)
 
-  def din_concat_bwd(self, q, h, dout):
+  def din_concat_bwd(self, q, h, dout, dh=None, acc_h=False):
     B, L, E = h.shape
     g0, g1, g2, g3 = dout[..., :E], dout[..., E:2 * E], dout[..., 2 * E:3 * E], dout[..., 3 * E:]
     qq = q[:, None, :]
     dq = (g0 + g2 + g3 * h).sum(dim=1)
-    dh = g1 - g2 + g3 * qq
+    r = g1 - g2 + g3 * qq
+    if dh is None:
+      return dq, r
+    if acc_h:
+      dh.add_(r)
+    else:
+      dh.copy_(r)
     return dq, dh
 
   din_fold = True
@@ -892,14 +898,20 @@ class RefBackend(object):
     p = torch.softmax(s, dim=1)
     return torch.bmm(p[:, None, :], hist)[:, 0, :], p
 
-  def din_pool_bwd(self, probs, hist, seq_len, dout, scale=1.0):
+  def din_pool_bwd(self, probs, hist, seq_len, dout, scale=1.0, dhist=None, acc_h=False):
     B, L, E = hist.shape
     dp = torch.bmm(hist, dout[:, :, None])[:, :, 0]
     ds = probs * (dp - (probs * dp).sum(dim=1, keepdim=True))
     mask = torch.arange(L)[None, :] < seq_len[:, None].to(torch.int64)
     ds = torch.where(mask, ds * scale, torch.zeros_like(ds))
     dh = probs[:, :, None] * dout[:, None, :]
-    return ds, dh
+    if dhist is None:
+      return ds, dh
+    if acc_h:
+      dhist.add_(dh)
+    else:
+      dhist.copy_(dh)
+    return ds, dhist
 
   # -- hash-table (KV) embedding tables: a python dict for the map, the same counter-based row initialiser in numpy
   @staticmethod
