@@ -2402,7 +2402,10 @@ class GroupedLinearFn(torch.autograd.Function):
       if len(es) > 1 and _CAT_DGRAD and all(dzs[e].stride(1) == 1 for e in es):
         # readers of ONE input (MMoE's first depth: every expert and gate reads the shared features): dx = sum_e dz_e W_e^T
         # is ONE contraction over the layers' output columns laid side by side - the input-sized gradient is written once
-        # instead of being read and re-written by a GEMM per layer (8 x 36 MB at B = 8192), for two small concat launches
+        # instead of being read and re-written by a GEMM per layer (8 x 36 MB at B = 8192), for two small concat launches.
+        # (The same for the weight gradients - x^T . [dz_1 | dz_2 | ...] as one TN GEMM outside the step's grouped launch,
+        # then added to the layers' gradient slices - measured SLOWER: 2.23 against 2.11 ms,
+        # profiles/r04_mmoe_cat_wgrad_ab.txt; the grouped launch's split-K scheduling is the better one.)
         dz_cat = be.concat_cols([dzs[e] for e in es])
         w_cat = be.concat_cols([ws[e].detach() for e in es])
         if to_sink:
