@@ -500,6 +500,8 @@ def steady_state(est, gen, n_steps):
       est.graph = saved_graph
     out['catch_up_ms_p50'] = float(np.percentile(cu, 50))
     out['catch_up_ms_p99'] = float(np.percentile(cu, 99))
+    out['catch_up_note'] = 'the general path\'s catch-up launches between HIP events, eager; a fused single-GPU step runs its ' \
+                           'catch-up as emb_catch_up_heads_kernel inside er_emb_front (roofline.kernels has its duration)' 
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     eng.flush_decay()

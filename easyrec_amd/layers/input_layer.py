@@ -538,7 +538,9 @@ class EmbeddingEngine(object):
   # -- the fused single-GPU step
   def _use_fused(self):
     be = kernels.hip()
+    # (bench.py's catch-up probe brackets the general path's catch-up launches with events: the fused front is one C call)
     return (self._fused is not False and self.allow_fused and getattr(be, 'fused_emb', False) and self.train_mode and
+            getattr(self, 'catch_up_probe', None) is None and
             type(self) is EmbeddingEngine and not self.kv_jobs and len(self.emb_groups) <= 4 and
             not self._sweep_pending and (not self.lazy_decay or self.flush_windows <= 0) and len(self.groups) <= 8 and
             not any(st['bitmap'] is not None for st in self.storage.values()))

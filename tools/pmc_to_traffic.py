@@ -1,4 +1,5 @@
-"""profiles/r03_pmc_by_kernel.json (tools/gpu_round3_pmc.sh: rocprofv3 --pmc passes over the eager DeepFM step) ->
+"""profiles/r04_pmc_by_kernel.json (tools/gpu/r4_final.sh; round 3: r03_pmc_by_kernel.json, tools/gpu_round3_pmc.sh: rocprofv3 --pmc
+passes over the eager DeepFM step) ->
 profiles/pmc_traffic.json `by_kernel`: HBM-side bytes per launch of every kernel of the step, which bench.py attaches to
 its `roofline.traffic`.  Correction as MI355X_MICROARCH.md prescribes and profiles/r02_pmc_embedding.md calibrated:
 FETCH_SIZE / WRITE_SIZE are KiB; a streaming kernel's 128-byte read requests are counted as 64 (fetch x 2); the random
@@ -10,7 +11,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, 'profiles', 'r03_pmc_by_kernel.json')
 res = json.load(open(src))['default']
-RANDOM_ROWS = ('emb_fwd_kernel', 'emb_bwd_tile', 'emb_catch_up', 'emb_bwd_fix', 'gather_rows', 'emb_flush', 'emb_owner_serve')
+RANDOM_ROWS = ('emb_fwd_kernel', 'emb_bwd_tile', 'emb_bwd_own', 'emb_catch_up', 'emb_bwd_fix', 'gather_rows', 'emb_flush', 'emb_owner_serve')
 by = {}
 for name, c in res.items():
   if 'er::' not in name or 'FETCH_SIZE' not in c or 'WRITE_SIZE' not in c:
@@ -27,7 +28,7 @@ for key, d in by.items():
   fetch, write = d['fetch_kib'] / d['launches'], d['write_kib'] / d['launches']
   out[key] = {'bytes_per_launch': (f * fetch + write) * 1024.0, 'fetch_factor': f, 'FETCH_SIZE_KiB': fetch,
               'WRITE_SIZE_KiB': write, 'launches_averaged': d['launches'],
-              'source': 'profiles/r03_pmc_by_kernel.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, eager step)'}
+              'source': '%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, eager step)' % os.path.relpath(src, ROOT)}
 p = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
 cur = json.load(open(p))
 cur['by_kernel'] = out
