@@ -14,11 +14,9 @@ namespace er {
 // FM
 // ------------------------------------------------------------------------------------------------
 template <int V>
-__global__ void __launch_bounds__(kBlock)
-fm_fwd_kernel(const float* __restrict__ x, int B, int F, int D, int x_stride, float* __restrict__ fm_out,
-              float* __restrict__ sum_out) {
+__device__ __forceinline__ void fm_fwd_body(int64_t idx, const float* __restrict__ x, int B, int F, int D, int x_stride,
+                                            float* __restrict__ fm_out, int fm_stride, float* __restrict__ sum_out) {
   const int lanes = D / V;
-  const int64_t idx = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
   const int64_t b = idx / lanes;
   const int c = static_cast<int>(idx % lanes) * V;
   if (b >= B) return;
@@ -40,9 +38,16 @@ fm_fwd_kernel(const float* __restrict__ x, int B, int F, int D, int x_stride, fl
   }
 #pragma unroll
   for (int i = 0; i < V; ++i) {
-    fm_out[b * D + c + i] = 0.5f * (s[i] * s[i] - q[i]);
+    fm_out[b * fm_stride + c + i] = 0.5f * (s[i] * s[i] - q[i]);
     sum_out[b * D + c + i] = s[i];
   }
+}
+
+template <int V>
+__global__ void __launch_bounds__(kBlock)
+fm_fwd_kernel(const float* __restrict__ x, int B, int F, int D, int x_stride, float* __restrict__ fm_out,
+              float* __restrict__ sum_out) {
+  fm_fwd_body<V>(static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x, x, B, F, D, x_stride, fm_out, D, sum_out);
 }
 
 template <int V>
@@ -65,10 +70,9 @@ fm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ S, const fl
   }
 }
 
-__global__ void __launch_bounds__(kBlock)
-rowsum_fwd_kernel(const float* __restrict__ x, int B, int n, int x_stride, float* __restrict__ out) {
+__device__ __forceinline__ void rowsum_fwd_body(int64_t idx, const float* __restrict__ x, int B, int n, int x_stride,
+                                                float* __restrict__ out, int out_stride) {
   // 4 lanes per row, then a 4-lane tree: keeps loads semi-coalesced for n ~ 39
-  const int64_t idx = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
   const int64_t b = idx >> 2;
   const int sub = static_cast<int>(idx & 3);
   float s = 0.f;
@@ -77,7 +81,34 @@ rowsum_fwd_kernel(const float* __restrict__ x, int B, int n, int x_stride, float
   }
   s += __shfl_xor(s, 1, 64);
   s += __shfl_xor(s, 2, 64);
-  if (b < B && sub == 0) out[b] = s;
+  if (b < B && sub == 0) out[b * out_stride] = s;
+}
+
+__global__ void __launch_bounds__(kBlock)
+rowsum_fwd_kernel(const float* __restrict__ x, int B, int n, int x_stride, float* __restrict__ out) {
+  rowsum_fwd_body(static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x, x, B, n, x_stride, out, 1);
+}
+
+// DeepFM's final-DNN input [sum(wide) | FM(fields) | deep] (reference model/deepfm.py:60-83: reduce_sum, layers/fm.py, concat)
+// in ONE launch: three workgroup ranges running the bodies of fm_fwd_kernel, rowsum_fwd_kernel and a copy - the same
+// arithmetic in the same order as the three separate launches.
+template <int V>
+__global__ void __launch_bounds__(kBlock)
+wide_fm_concat_kernel(const float* __restrict__ wide, int n_w, int ld_w, const float* __restrict__ fm_x, int F, int D, int ld_x,
+                      const float* __restrict__ deep, int n_d, int ld_d, int B, float* __restrict__ out, int ld_out,
+                      float* __restrict__ sum_out, int fm_blocks, int rs_blocks) {
+  const int bid = blockIdx.x;
+  if (bid < fm_blocks) {
+    fm_fwd_body<V>(static_cast<int64_t>(bid) * kBlock + threadIdx.x, fm_x, B, F, D, ld_x, out + 1, ld_out, sum_out);
+  } else if (bid < fm_blocks + rs_blocks) {
+    rowsum_fwd_body(static_cast<int64_t>(bid - fm_blocks) * kBlock + threadIdx.x, wide, B, n_w, ld_w, out, ld_out);
+  } else {
+    const int64_t i = static_cast<int64_t>(bid - fm_blocks - rs_blocks) * kBlock + threadIdx.x;
+    if (i >= static_cast<int64_t>(B) * n_d) return;
+    const int64_t b = i / n_d;
+    const int c = static_cast<int>(i % n_d);
+    out[b * ld_out + 1 + D + c] = deep[b * ld_d + c];
+  }
 }
 
 __global__ void __launch_bounds__(kBlock)
@@ -1048,6 +1079,28 @@ int er_fm_fwd(const float* x, int32_t B, int32_t F, int32_t D, int32_t x_stride,
   } else {
     hipLaunchKernelGGL(er::fm_fwd_kernel<1>, dim3(er::blocks_for(static_cast<int64_t>(B) * D)), dim3(er::kBlock), 0, s,
                        x, B, F, D, x_stride, fm_out, sum_out);
+  }
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
+int er_wide_fm_concat(const float* wide, int32_t n_w, int32_t ld_w, const float* fm_x, int32_t F, int32_t D, int32_t ld_x,
+                      const float* deep, int32_t n_d, int32_t ld_d, int32_t B, float* out, int32_t ld_out, float* sum_out,
+                      er_stream_t stream) {
+  ER_REQUIRE(wide && fm_x && deep && out && sum_out && B > 0 && n_w > 0 && F > 0 && D > 0 && n_d > 0 &&
+                 ld_out >= 1 + D + n_d && ld_w >= n_w && ld_x >= F * D && ld_d >= n_d,
+             "er_wide_fm_concat: bad arguments");
+  const bool vec = (D % 4 == 0) && (ld_x % 4 == 0) && ((reinterpret_cast<uintptr_t>(fm_x) & 15) == 0);
+  const int fm_blocks = er::blocks_for(static_cast<int64_t>(B) * (vec ? D / 4 : D));
+  const int rs_blocks = er::blocks_for(static_cast<int64_t>(B) * 4);
+  const int cp_blocks = er::blocks_for(static_cast<int64_t>(B) * n_d);
+  hipStream_t s = er::as_stream(stream);
+  if (vec) {
+    hipLaunchKernelGGL(er::wide_fm_concat_kernel<4>, dim3(fm_blocks + rs_blocks + cp_blocks), dim3(er::kBlock), 0, s, wide, n_w,
+                       ld_w, fm_x, F, D, ld_x, deep, n_d, ld_d, B, out, ld_out, sum_out, fm_blocks, rs_blocks);
+  } else {
+    hipLaunchKernelGGL(er::wide_fm_concat_kernel<1>, dim3(fm_blocks + rs_blocks + cp_blocks), dim3(er::kBlock), 0, s, wide, n_w,
+                       ld_w, fm_x, F, D, ld_x, deep, n_d, ld_d, B, out, ld_out, sum_out, fm_blocks, rs_blocks);
   }
   ER_LAUNCH_CHECK();
   return 0;

@@ -1236,6 +1236,19 @@ class HipBackend(object):
     self._ck(self.lib.er_rowsum_fwd(_p(x), B, n, x.stride(0), _p(out), _stream()), 'er_rowsum_fwd')
     return out
 
+  fused_wide_fm = os.environ.get('EASYREC_AMD_FUSED_WIDE_FM', '1') != '0'  # A/B switch
+
+  def wide_fm_concat(self, wide, fm_x, F, D, deep):
+    """[sum(wide) | FM(fm_x) | deep] at a 16-byte row pitch and the FM field sums ([B, D]) in one launch."""
+    B, n_w, n_d = wide.shape[0], wide.shape[1], deep.shape[1]
+    assert wide.stride(1) == 1 and fm_x.stride(1) == 1 and deep.stride(1) == 1 and fm_x.shape[1] >= F * D
+    width = 1 + D + n_d
+    out = torch.empty(B, (width + 3) // 4 * 4, dtype=torch.float32, device=wide.device)[:, :width]
+    S = torch.empty(B, D, dtype=torch.float32, device=wide.device)
+    self._ck(self.lib.er_wide_fm_concat(_p(wide), n_w, wide.stride(0), _p(fm_x), F, D, fm_x.stride(0), _p(deep), n_d,
+                                        deep.stride(0), B, _p(out), out.stride(0), _p(S), _stream()), 'er_wide_fm_concat')
+    return out, S
+
   def rowsum_bwd(self, g, n, into=None, accumulate=False):
     B = g.shape[0]
     dx = torch.empty(B, n, dtype=torch.float32, device=g.device) if into is None else into
@@ -2561,6 +2574,29 @@ class FMFn(torch.autograd.Function):
       full[:, :ctx.F * ctx.D] = dx
       dx = full
     return dx, None, None, None, None
+
+
+class WideFmConcatFn(torch.autograd.Function):
+  """DeepFM's [reduce_sum(wide) | FM(fields) | deep] (reference model/deepfm.py:60-83) as one launch; the wide and FM
+  blocks live in embedding group outputs, so their gradients are the deferred terms RowSumFn / FMFn would register
+  (finished with the group's gradient buffer), and `deep` gets its column block of the incoming gradient as a view."""
+
+  @staticmethod
+  def forward(ctx, wide, fm_x, deep, F, D, wide_sink, fm_sink, col0):
+    out, S = hip().wide_fm_concat(wide, fm_x, F, D, deep if deep.stride(-1) == 1 else deep.contiguous())
+    ctx.save_for_backward(S)
+    ctx.F, ctx.D, ctx.n_w = F, D, wide.shape[1]
+    ctx.wide_sink, ctx.fm_sink, ctx.col0 = wide_sink, fm_sink, col0
+    return out
+
+  @staticmethod
+  def backward(ctx, g):
+    S, = ctx.saved_tensors
+    D = ctx.D
+    g = g if g.stride(-1) == 1 else g.contiguous()
+    ctx.wide_sink.defer(('rowsum', g[:, 0:1], 0, ctx.n_w))
+    ctx.fm_sink.defer(('fm', g[:, 1:1 + D], S, ctx.col0, ctx.F * D, D))
+    return None, None, g[:, 1 + D:], None, None, None, None, None
 
 
 class ConcatFn(torch.autograd.Function):

@@ -14,6 +14,16 @@ class FM(object):
   def __init__(self, name='fm'):
     self._name = name
 
+  @staticmethod
+  def group_block(fm_fea):
+    """(x, F, D, sink, col0) when the fields are one uniform column block of an embedding group output, else None."""
+    blk = fm_fea.uniform_block() if hasattr(fm_fea, 'uniform_block') else None
+    if blk is None:
+      return None
+    base, col0, F, D = blk
+    x = base if (col0 == 0 and base.shape[1] == F * D) else base[:, col0:col0 + F * D]
+    return x, F, D, kernels.grad_sink_of(base), col0
+
   def __call__(self, fm_fea):
     blk = fm_fea.uniform_block() if hasattr(fm_fea, 'uniform_block') else None
     sink, col0 = None, 0

@@ -36,7 +36,23 @@ class DeepFM(RankModel):
     if self._num_class > 1 and self._wide_output_dim == self._num_class:
       raise AssertionError('multi-class wide output is outside the hot-path scope')
     own = self._model_config
-    wide = kernels.RowSumFn.apply(self._wide_features, kernels.grad_sink_of(self._wide_features))
+    # [reduce_sum(wide) | FM | deep] in one launch when both blocks are embedding group outputs of a training step
+    # (kernels.WideFmConcatFn); else the three separate ops
+    import torch
+    wide_sink = kernels.grad_sink_of(self._wide_features)
+    blk = fm.FM.group_block(self._fm_features)
+    fused = (len(own.final_dnn.hidden_units) > 0 and getattr(kernels.hip(), 'fused_wide_fm', False) and self._is_training and
+             torch.is_grad_enabled() and wide_sink is not None and blk is not None and blk[3] is not None and
+             self._wide_features.dim() == 2 and self._wide_features.stride(-1) == 1)
+    if fused:
+      deep = self._dnn(self._deep_features, own.dnn, 'deep_feature')
+      x, F, D, fm_sink, col0 = blk
+      joined = kernels.WideFmConcatFn.apply(self._wide_features, x, deep, F, D, wide_sink, fm_sink, col0)
+      self._fm_outputs = joined[:, 1:1 + D]
+      top = self._dnn(joined, own.final_dnn, 'final_dnn')
+      kernels.mark_single_consumer(top)  # read by the `output` projection alone
+      return self._emit(dnn.dense(top, self._num_class, 'output', l2_reg=self._l2_reg, head=True))
+    wide = kernels.RowSumFn.apply(self._wide_features, wide_sink)
     self._fm_outputs = pairwise = fm.FM(name='fm_feature')(self._fm_features)
     deep = self._dnn(self._deep_features, own.dnn, 'deep_feature')
     if len(own.final_dnn.hidden_units) > 0:

@@ -296,6 +296,12 @@ int er_copy_multi(const void* const* src_host, void* const* dst_host, const int6
 int er_fm_fwd(const float* x, int32_t B, int32_t F, int32_t D, int32_t x_stride, float* fm_out,
               float* sum_out, er_stream_t stream);
 /* dx[b,f,:] (+)= g[b,:] * (S[b,:] - x[b,f,:]).  accumulate != 0 adds into dx. */
+/* DeepFM's final-DNN input out = [sum over the n_w wide columns | FM over the F fields of width D | the n_d deep columns]
+ * ([B, 1 + D + n_d] at leading dimension ld_out; reference model/deepfm.py:60-83) in ONE launch - the arithmetic of
+ * er_rowsum_fwd, er_fm_fwd (sum_out [B, D] = the field sums its backward needs) and a copy, unchanged. */
+int er_wide_fm_concat(const float* wide, int32_t n_w, int32_t ld_w, const float* fm_x, int32_t F, int32_t D, int32_t ld_x,
+                      const float* deep, int32_t n_d, int32_t ld_d, int32_t B, float* out, int32_t ld_out, float* sum_out,
+                      er_stream_t stream);
 int er_fm_bwd(const float* x, const float* sum_saved, const float* g, int32_t B, int32_t F,
               int32_t D, int32_t x_stride, float* dx, int32_t dx_stride, int accumulate,
               er_stream_t stream);

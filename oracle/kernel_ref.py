@@ -771,6 +771,12 @@ class RefBackend(object):
   def concat_cols(self, parts):
     return torch.cat([t.detach() for t in parts], dim=1)
 
+  fused_wide_fm = True
+
+  def wide_fm_concat(self, wide, fm_x, F, D, deep):
+    fm, S = self.fm_fwd(fm_x, F, D)
+    return torch.cat([self.rowsum_fwd(wide, wide.shape[1]), fm, deep.detach()], dim=1), S
+
   def group_grad_finish(self, groups):
     for dout, out, lam, has_base, terms in groups:
       v = dout.detach().clone() if has_base else torch.zeros_like(dout)

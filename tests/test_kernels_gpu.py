@@ -1679,3 +1679,19 @@ def test_folded_din_first_layer_kernels(B, L, E, H):
   hip.din_unfold_dw(dwq.to(DEV), dwp.to(DEV), out=out, accumulate=True)
   assert float((out.cpu() - (acc + ref.din_unfold_dw(dwq, dwp))).abs().max()) <= 1e-6
   assert torch.equal(hip.din_unfold_dw(dwq.to(DEV), dwp.to(DEV)).cpu(), ref.din_unfold_dw(dwq, dwp))
+
+
+@pytest.mark.parametrize('B,n_w,F,D,n_d', [(4096, 39, 39, 16, 64), (100, 5, 7, 3, 9)])
+def test_wide_fm_concat_equals_the_three_launches(B, n_w, F, D, n_d):
+  """er_wide_fm_concat = er_rowsum_fwd + er_fm_fwd + the concat, bit for bit (the same bodies as workgroup ranges)."""
+  hip = kernels.hip()
+  g = torch.Generator().manual_seed(B)
+  wide_full = torch.randn(B, n_w + 3, generator=g).to(DEV)  # (a column block of a wider group output)
+  x_full = torch.randn(B, F * D + (4 if D % 4 == 0 else 1), generator=g).to(DEV)
+  deep = torch.randn(B, n_d, generator=g).to(DEV)
+  wide, x = wide_full[:, :n_w], x_full[:, :F * D]
+  out, S = hip.wide_fm_concat(wide, x, F, D, deep)
+  fm, S2 = hip.fm_fwd(x, F, D)
+  want = torch.cat([hip.rowsum_fwd(wide, n_w), fm, deep], dim=1)
+  assert out.shape == want.shape and out.stride(0) % 4 == 0
+  assert torch.equal(out, want) and torch.equal(S, S2)
