@@ -1,7 +1,8 @@
 """Evaluation metrics on the hot path's predictions.
 
 Also: gAUC / session AUC (`SeparatedAUC` host-side as in the reference, `DeviceSeparatedAUC` the same numbers from device
-kernels: what evaluate() uses) and max F1 (`MaxF1`).
+kernels: what evaluate() uses) and max F1 (`MaxF1` on the host, `DeviceMaxF1` from the AUC histogram kernel: what
+evaluate() uses).
 
 AUC = `tf.metrics.auc(labels, predictions, num_thresholds=200)` as called by `RankModel.build_metric_graph`
 (reference easy_rec/python/model/rank_model.py:358-373; `eval_config.metrics_set { auc {} }`).  TensorFlow's
@@ -179,6 +180,36 @@ def gauc(reduction='mean'):
 
 def session_auc(reduction='mean'):
   return SeparatedAUC(reduction)
+
+
+class DeviceMaxF1(object):
+  """MaxF1 with the streaming counts on the device: `prediction > threshold` against the same 200 thresholds is the
+  histogram er_auc_update already keeps (counts[label][number of thresholds below the prediction]); tp / fp / fn per
+  threshold are its suffix sums, finished on the host at result().  Same numbers as MaxF1."""
+
+  def __init__(self, num_thresholds=200, device='cpu'):
+    self.n = int(num_thresholds)
+    self.thresholds = torch.from_numpy(auc_thresholds(self.n)).to(device)
+    self.counts = torch.zeros(2, self.n + 1, dtype=torch.int64, device=device)
+
+  def reset(self):
+    self.counts.zero_()
+
+  def update(self, labels, predictions):
+    dev = self.counts.device
+    labels = torch.as_tensor(labels).reshape(-1).to(dev, torch.float32)
+    predictions = torch.as_tensor(predictions).detach().reshape(-1).to(dev, torch.float32)
+    kernels.hip().auc_update(predictions.contiguous(), labels.contiguous(), None, self.thresholds, self.counts)
+
+  def result(self):
+    counts = self.counts.cpu().numpy().astype(np.float64)
+    suffix = np.cumsum(counts[:, ::-1], axis=1)[:, ::-1]
+    tp, fp = suffix[1, 1:self.n + 1], suffix[0, 1:self.n + 1]   # prediction > thresholds[t]  <=>  bucket > t
+    fn = counts[1].sum() - tp
+    with np.errstate(divide='ignore', invalid='ignore'):
+      p = np.where(tp + fp > 0, tp / (tp + fp), 0.0)
+      r = np.where(tp + fn > 0, tp / (tp + fn), 0.0)
+    return float(np.max(2 * p * r / (p + r + 1e-12)))
 
 
 class MaxF1(object):

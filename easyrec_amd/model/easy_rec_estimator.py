@@ -412,7 +412,7 @@ class EasyRecEstimator(object):
         return metrics_lib.AUC(arg, self.device)
       if kind == 'grouped':
         return metrics_lib.DeviceSeparatedAUC(arg[1], self.device)
-      return metrics_lib.MaxF1()
+      return metrics_lib.DeviceMaxF1(200, self.device)
 
     acc = {}
     for suf, _ in heads:

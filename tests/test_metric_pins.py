@@ -54,6 +54,23 @@ def test_device_grouped_auc_on_the_stand_in_backend(ref_backend):
   _device_stream('cpu')
 
 
+def _device_max_f1(device):
+  from easyrec_amd.core.metrics import DeviceMaxF1
+  m = DeviceMaxF1(200, device)
+  for b in range(4):
+    m.update(G['labels_%d' % b], G['preds_%d' % b])
+    assert abs(m.result() - float(G['max_f1_after_%d' % b])) <= 1e-6, b
+
+
+def test_device_max_f1_on_the_stand_in_backend(ref_backend):
+  _device_max_f1('cpu')
+
+
+@pytest.mark.gpu
+def test_device_max_f1_on_the_gpu():
+  _device_max_f1('cuda:0')
+
+
 @pytest.mark.gpu
 def test_device_grouped_auc_on_the_gpu():
   import torch
