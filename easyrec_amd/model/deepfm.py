@@ -5,6 +5,8 @@ embeddings kept as [B, D]; deep = DNN(deep concat); final_dnn over concat[wide, 
 """
 import logging
 
+import torch
+
 from easyrec_amd import kernels
 from easyrec_amd.layers import dnn
 from easyrec_amd.layers import fm
@@ -38,7 +40,6 @@ class DeepFM(RankModel):
     own = self._model_config
     # [reduce_sum(wide) | FM | deep] in one launch when both blocks are embedding group outputs of a training step
     # (kernels.WideFmConcatFn); else the three separate ops
-    import torch
     wide_sink = kernels.grad_sink_of(self._wide_features)
     blk = fm.FM.group_block(self._fm_features)
     fused = (len(own.final_dnn.hidden_units) > 0 and getattr(kernels.hip(), 'fused_wide_fm', False) and self._is_training and
