@@ -1465,6 +1465,7 @@ class HipBackend(object):
     slots = 1
     while slots < (8 if filter_freq > 1 else 2) * int(capacity):
       slots *= 2
+    assert slots <= (1 << 31), 'hash-table embedding: %d map slots (the kernels count slots and rows in 32 bits)' % slots
     kv = {'keys': torch.full((slots,), -1, dtype=torch.int64, device=dev),
           'rows': torch.full((slots,), -1, dtype=torch.int32, device=dev),
           'next_row': torch.zeros(1, dtype=torch.int32, device=dev),
