@@ -88,3 +88,17 @@ def test_device_grouped_auc_on_the_gpu():
       host.update(y[lo:lo + 50000], p[lo:lo + 50000], users[lo:lo + 50000])
       dev.update(torch.from_numpy(y[lo:lo + 50000]).cuda(), torch.from_numpy(p[lo:lo + 50000]).cuda(), users[lo:lo + 50000])
     assert abs(host.result() - dev.result()) <= 1e-6, (reduction, host.result(), dev.result())
+
+
+def test_key_codes_are_consistent_across_batches_and_types():
+  """Grouping only needs equality: integer keys pass through, strings / bytes get a 64-bit digest that is the same in
+  every batch (so a user's rows meet across update() calls) and differs between different keys."""
+  import torch
+  from easyrec_amd.core.metrics import DeviceSeparatedAUC
+  ints = DeviceSeparatedAUC.key_codes(np.array([5, -3, 2 ** 40], dtype=np.int64))
+  assert ints.tolist() == [5, -3, 2 ** 40] and ints.dtype == torch.int64
+  a = DeviceSeparatedAUC.key_codes(np.array([b'u1', b'u2', b'u1', b''], dtype=object))
+  b = DeviceSeparatedAUC.key_codes(np.array(['u2', 'u1'], dtype=object))
+  assert a[0] == a[2] and a[0] != a[1] and a[3] not in (a[0], a[1])
+  assert b[0] == a[1] and b[1] == a[0], 'bytes and str of the same text are one key'
+  assert DeviceSeparatedAUC.key_codes(torch.tensor([[1, 2], [3, 4]])).tolist() == [1, 2, 3, 4]
