@@ -213,9 +213,10 @@ def _kv_compare(a, b, names, tol=1e-6):
       assert d <= tol * max(float(np.abs(b[n + suffix]).max()) if b[n + suffix].size else 0.0, 1e-3), (n, suffix, d)
 
 
-@pytest.mark.parametrize('filtered', [False, True])
-def test_world1_sharded_kv_tables_equal_the_single_gpu_engine(ref_backend, filtered):
+@pytest.mark.parametrize('filtered,padded', [(False, True), (True, True), (False, False)])
+def test_world1_sharded_kv_tables_equal_the_single_gpu_engine(ref_backend, filtered, padded, monkeypatch):
   from easyrec_amd.input.criteo_synthetic import SyntheticCriteo
+  monkeypatch.setenv('EASYREC_AMD_PADDED_EXCHANGE', '1' if padded else '0')  # (else the compact exchange)
   from easyrec_amd.model.easy_rec_estimator import EasyRecEstimator
   from easyrec_amd.model.embedding_parallel import EmbeddingParallelEstimator
   B = 32
@@ -226,6 +227,7 @@ def test_world1_sharded_kv_tables_equal_the_single_gpu_engine(ref_backend, filte
   est = EmbeddingParallelEstimator(cfg, device='cpu', batch_size=B, seed=3, rank=0, world=1, replicate_bytes=1024).build()
   names = sorted(ref.engine.kv_tables)
   assert names == sorted(est.engine.kv_tables) and all(est.engine.placement[n][0] == 'shard' for n in names)
+  assert est.engine.padded == padded
   for b in batches:
     ref.train_step(b)
     est.train_step(b)
