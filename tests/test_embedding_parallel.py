@@ -223,6 +223,7 @@ def test_world1_sharded_kv_tables_equal_the_single_gpu_engine(ref_backend, filte
   cfg = _kv_cfg(filtered)
   gen = SyntheticCriteo(cfg.data_config, list(cfg.feature_config.features), batch_size=B, seed=13)
   batches = [gen.next_batch() for _ in range(3)]
+  unseen = gen.next_batch()  # (one generator: building its Zipf tables is most of this test's time)
   ref = EasyRecEstimator(cfg, device='cpu', batch_size=B, seed=3).build()
   est = EmbeddingParallelEstimator(cfg, device='cpu', batch_size=B, seed=3, rank=0, world=1, replicate_bytes=1024).build()
   names = sorted(ref.engine.kv_tables)
@@ -236,7 +237,7 @@ def test_world1_sharded_kv_tables_equal_the_single_gpu_engine(ref_backend, filte
   _kv_compare(est.state_dict(slots=True), ref.state_dict(slots=True), names)
   # evaluation creates no rows; a state loaded into a fresh sharded estimator continues alike
   before = est.state_dict()
-  est.evaluate([SyntheticCriteo(cfg.data_config, list(cfg.feature_config.features), batch_size=B, seed=77).next_batch()])
+  est.evaluate([unseen])
   assert all(np.array_equal(before[n + '/keys'], est.state_dict()[n + '/keys']) for n in names)
   # (same seed: rows created after the load are drawn from the table's generator, whose seed derives from it)
   twin = EmbeddingParallelEstimator(cfg, device='cpu', batch_size=B, seed=3, rank=0, world=1, replicate_bytes=1024).build()
