@@ -22,6 +22,9 @@ def _hex8(values):
   return HEX[nib.astype(np.int64)]
 
 
+_ZIPF_CDF = {}  # vocabulary size -> cumulative Zipf(1.05) distribution
+
+
 class SyntheticCriteo(object):
 
   def __init__(self, data_config, feature_configs, batch_size=None, seed=20240607, mode='zipf',
@@ -39,7 +42,7 @@ class SyntheticCriteo(object):
     self.vocab = [10**(2 + (i % 6)) for i in range(self.n_hash)]
     # a fixed random permutation-ish mixing constant per feature so that vocab ids look like hashes
     self.mix = self.rng.integers(1, 2**31 - 1, size=self.n_hash, dtype=np.int64) | 1
-    self._zipf_cdf = {}
+    self._zipf_cdf = _ZIPF_CDF  # (shared by every generator of the process: the 10^7-entry table takes seconds to build)
 
   def _zipf(self, V, n):
     if V not in self._zipf_cdf:
