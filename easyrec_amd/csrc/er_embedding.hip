@@ -53,82 +53,6 @@ struct Acc4 {
 };
 
 // ------------------------------------------------------------------------------------------------
-// forward
-// ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock)
-emb_fwd_kernel(const er_lookup_desc* __restrict__ descs, const int32_t* __restrict__ blk_start, int n_lookups,
-               float* __restrict__ sumsq_partials) {
-  __shared__ float red[4];
-  const int l = find_lookup(blk_start, n_lookups, blockIdx.x);
-  const er_lookup_desc d = descs[l];
-  int V, G;
-  lane_geom(d.dim, V, G);
-  const int rows_per_block = kBlock / G;
-  const int r = (blockIdx.x - blk_start[l]) * rows_per_block + static_cast<int>(threadIdx.x) / G;
-  const int c = (static_cast<int>(threadIdx.x) % G) * V;
-  float ss = 0.f;
-  if (r < d.n_rows && c < d.dim) {
-    int64_t kb, ke;
-    if (d.offsets) {
-      kb = d.offsets[r];
-      ke = d.offsets[r + 1];
-    } else {
-      kb = r;
-      ke = r + 1;
-    }
-    const bool prune_nonpos = (d.weights != nullptr) && (d.combiner != ER_COMBINER_SUM);
-    Acc4 a{0.f, 0.f, 0.f, 0.f};
-    float wsum = 0.f, w2sum = 0.f;
-    for (int64_t k = kb; k < ke; ++k) {
-      const int64_t id = d.ids[k];
-      if (id < 0 || id >= d.rows) continue;
-      const float* row = d.table + id * (d.table_ld ? d.table_ld : d.dim) + c;
-      if (d.weights) {
-        const float w = d.weights[k];
-        if (prune_nonpos && !(w > 0.f)) continue;
-        if (V == 4) {
-          const float4 e = *reinterpret_cast<const float4*>(row);
-          a.x = a.x + e.x * w; a.y = a.y + e.y * w; a.z = a.z + e.z * w; a.w = a.w + e.w * w;
-        } else {
-          a.x = a.x + row[0] * w;
-        }
-        wsum = wsum + w;
-        w2sum = w2sum + w * w;
-      } else {
-        if (V == 4) {
-          const float4 e = *reinterpret_cast<const float4*>(row);
-          a.x = a.x + e.x; a.y = a.y + e.y; a.z = a.z + e.z; a.w = a.w + e.w;
-        } else {
-          a.x = a.x + row[0];
-        }
-        wsum = wsum + 1.f;
-        w2sum = w2sum + 1.f;
-      }
-    }
-    if (d.combiner != ER_COMBINER_SUM && wsum != 0.f) {
-      const float den = (d.combiner == ER_COMBINER_MEAN) ? wsum : sqrtf(w2sum);
-      a.x = a.x / den; a.y = a.y / den; a.z = a.z / den; a.w = a.w / den;
-    }
-    float* o = d.out + static_cast<int64_t>(r) * d.out_stride + d.out_col + c;
-    if (V == 4) {
-      if (((d.out_stride | d.out_col) & 3) == 0 && (reinterpret_cast<uintptr_t>(d.out) & 15) == 0) {
-        *reinterpret_cast<float4*>(o) = make_float4(a.x, a.y, a.z, a.w);
-      } else {
-        o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w;
-      }
-      ss = (a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w);
-    } else {
-      o[0] = a.x;
-      ss = a.x * a.x;
-    }
-  }
-  if (sumsq_partials) {
-    const float tot = block_sum_256(ss, red);
-    if (threadIdx.x == 0) sumsq_partials[blockIdx.x] = tot;
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
 // backward: entries, sort, reduce, apply
 // ------------------------------------------------------------------------------------------------
 // One thread per output row of one lookup: emits (key, grad pointer, scale) for every id of the row.
@@ -302,6 +226,14 @@ struct RowUpdate {
   // device step counter (== index of the current step + 1 once er_hyper_select has run)
   int32_t* last_step;
   const int64_t* step_counter;
+  // Row pitch (er_emb_group_set_row_pitch).  ld: floats between consecutive rows of var / m / v - dim for three plain
+  // [rows, dim] arrays; larger when a row's var | m | v (| last_step) lie side by side in ONE record, so that a
+  // touched row is one contiguous HBM access instead of three or four scattered ones.  ls_ld: int32 words between
+  // consecutive rows' last_step (1: an array of its own).
+  int64_t ld;
+  int64_t ls_ld;
+  __device__ __forceinline__ int64_t off(int64_t key, int c) const { return key * ld + c; }
+  __device__ __forceinline__ int32_t& ls(int64_t key) const { return last_step[key * ls_ld]; }
 };
 
 __device__ __forceinline__ float adam_elem(float& m, float& v, float var, float g, const er_opt_hyper& h) {
@@ -639,14 +571,14 @@ __device__ __forceinline__ void catch_up_body(int bid, const uint32_t* __restric
   int32_t s_begin = t;
   if (has) {
     const uint32_t key = ukeys[i];
-    s_begin = tab.last_step[key] + 1;  // (touched at step t-1, or never updated yet and current: nothing pending)
-    off = static_cast<int64_t>(key) * dim + c;
+    s_begin = tab.ls(key) + 1;  // (touched at step t-1, or never updated yet and current: nothing pending)
+    off = tab.off(key, c);
   }
   replay_block<V>(has, off, s_begin, t, tab, lr_hist, aux, hyper, smem);  // (synchronises first: every lane has read last_step)
   // The row is current up to step t-1 now.  This step's row update will set last_step = t; until then the record must
   // already say t-1, because the rolling flush of the step may run CONCURRENTLY (er_emb_flush_window with lag 1 on a
   // second stream) and has to find nothing pending on the rows the step touches.
-  if (has && c == 0 && s_begin < t) tab.last_step[ukeys[i]] = t - 1;
+  if (has && c == 0 && s_begin < t) tab.ls(ukeys[i]) = t - 1;
 }
 
 template <int V>
@@ -701,9 +633,9 @@ __device__ __forceinline__ void catch_up_closed_body(int bid, const CatchUpArgs&
   if (i >= a.capacity || i >= *a.n_unique || c >= a.dim) return;
   const int32_t t = static_cast<int32_t>(*a.tab.step_counter - 1);
   const uint32_t key = a.ukeys[i];
-  const int32_t s_begin = a.tab.last_step[key] + 1;
+  const int32_t s_begin = a.tab.ls(key) + 1;
   if (s_begin >= t) return;
-  const int64_t off = static_cast<int64_t>(key) * a.dim + c;
+  const int64_t off = a.tab.off(key, c);
   float var[V], m[V], v[V];
   ld_vec<V>(m, a.tab.m + off);
   ld_vec<V>(v, a.tab.v + off);
@@ -717,7 +649,7 @@ __device__ __forceinline__ void catch_up_closed_body(int bid, const CatchUpArgs&
     st_vec<V>(a.tab.m + off, m);
     st_vec<V>(a.tab.v + off, v);
   }
-  if (c == 0) a.tab.last_step[key] = t - 1;
+  if (c == 0) a.tab.ls(key) = t - 1;
 }
 
 __global__ void __launch_bounds__(kBlock)
@@ -752,9 +684,9 @@ emb_flush_decay_kernel(RowUpdate tab, int64_t total_rows, const float* __restric
   const int c = sub * V;
   if (row >= total_rows || c >= dim) return;
   const int32_t done = static_cast<int32_t>(*tab.step_counter);  // steps 0 .. done-1 have been executed
-  const int32_t last = tab.last_step[row];
+  const int32_t last = tab.ls(row);
   if (last + 1 < done) {
-    const int64_t off = row * dim + c;
+    const int64_t off = tab.off(row, c);
     float var[V], m[V], v[V];
     ld_vec<V>(var, tab.var + off);
     ld_vec<V>(m, tab.m + off);
@@ -796,9 +728,9 @@ __device__ __forceinline__ void flush_window_body(int bid, const RowUpdate& tab,
   const int64_t end = (w + 1) * chunk < total_rows ? (w + 1) * chunk : total_rows;
   const bool in_window = row < end;
   const bool has = in_window && c < dim;
-  const int32_t s_begin = in_window ? tab.last_step[row] + 1 : done;
-  replay_block<V>(has, row * dim + c, s_begin, done, tab, lr_hist, aux, hyper, smem);  // (synchronises first)
-  if (in_window && sub == 0 && s_begin < done) tab.last_step[row] = done - 1;
+  const int32_t s_begin = in_window ? tab.ls(row) + 1 : done;
+  replay_block<V>(has, tab.off(row, c), s_begin, done, tab, lr_hist, aux, hyper, smem);  // (synchronises first)
+  if (in_window && sub == 0 && s_begin < done) tab.ls(row) = done - 1;
 }
 
 struct FlushWindowArgs {
@@ -838,10 +770,151 @@ emb_flush_window_kernel(FlushWindowMulti ma) {
 
 // second pass of the flush (all lanes of a row must have read last_step before it changes)
 __global__ void __launch_bounds__(kBlock)
-emb_flush_mark_kernel(int32_t* __restrict__ last_step, int64_t total_rows, const int64_t* __restrict__ step_counter) {
+emb_flush_mark_kernel(int32_t* __restrict__ last_step, int64_t ls_ld, int64_t total_rows,
+                      const int64_t* __restrict__ step_counter) {
   const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
   const int32_t v = static_cast<int32_t>(*step_counter) - 1;
-  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < total_rows; i += stride) last_step[i] = v;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < total_rows; i += stride) last_step[i * ls_ld] = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward
+//
+// LAZY (er_emb_fwd_lazy, the fused single-GPU step): a lookup whose table group decays lazily (TF-exact Adam without the
+// sweep, closed-form replay) brings every row it reads current IN REGISTERS - the row's pending decay-only steps are
+// evaluated from its record (var, m, v, last_step: one contiguous access under er_emb_group_set_row_pitch) and only the
+// caught-up var enters the sum; nothing is written back.  The row update of the same step (finish_run) repeats the same
+// evaluation on the same bits before it applies the gradient, so the state a step leaves is exactly that of a
+// catch-up launch followed by lookup and update - without the launch and without writing and re-reading var, m, v.
+// ------------------------------------------------------------------------------------------------
+struct FwdLazy {
+  int n;                       // table groups with lazy decay (0: plain lookups only)
+  const int8_t* lookup_group;  // [n_lookups] index into tab / aux, or -1 (device memory)
+  const er_opt_hyper* hyper;
+  RowUpdate tab[kMaxMulti];
+  DecayAux aux[kMaxMulti];
+};
+
+template <int V>
+__device__ __forceinline__ void lazy_row(float (&var)[V], const RowUpdate& tab, const DecayAux& aux, int64_t key, int c,
+                                         int32_t t, float eps) {
+  const int64_t off = tab.off(key, c);
+  ld_vec<V>(var, tab.var + off);
+  const int32_t s_begin = tab.ls(key) + 1;
+  if (s_begin >= t) return;
+  float m[V], v[V];
+  ld_vec<V>(m, tab.m + off);
+  ld_vec<V>(v, tab.v + off);
+  bool live = false;
+#pragma unroll
+  for (int j = 0; j < V; ++j) live = live || (m[j] != 0.f) || (v[j] != 0.f);
+  if (live) replay_closed<V>(var, m, v, aux, s_begin, t, eps);
+}
+
+template <bool LAZY>
+__device__ __forceinline__ void fwd_body(const er_lookup_desc* __restrict__ descs, const int32_t* __restrict__ blk_start,
+                                         int n_lookups, float* __restrict__ sumsq_partials, const FwdLazy* lz) {
+  __shared__ float red[4];
+  const int l = find_lookup(blk_start, n_lookups, blockIdx.x);
+  const er_lookup_desc d = descs[l];
+  int V, G;
+  lane_geom(d.dim, V, G);
+  const int rows_per_block = kBlock / G;
+  const int r = (blockIdx.x - blk_start[l]) * rows_per_block + static_cast<int>(threadIdx.x) / G;
+  const int c = (static_cast<int>(threadIdx.x) % G) * V;
+  // (uniform over the workgroup: the group's records are read with scalar loads from the kernel arguments)
+  int gi = -1;
+  if (LAZY) gi = __builtin_amdgcn_readfirstlane(static_cast<int>(lz->lookup_group[l]));
+  int32_t t_now = 0;
+  float eps = 0.f;
+  if (LAZY && gi >= 0) {
+    t_now = static_cast<int32_t>(*lz->tab[gi].step_counter - 1);
+    eps = pin_scalar(lz->hyper->eps);
+  }
+  float ss = 0.f;
+  if (r < d.n_rows && c < d.dim) {
+    int64_t kb, ke;
+    if (d.offsets) {
+      kb = d.offsets[r];
+      ke = d.offsets[r + 1];
+    } else {
+      kb = r;
+      ke = r + 1;
+    }
+    const bool prune_nonpos = (d.weights != nullptr) && (d.combiner != ER_COMBINER_SUM);
+    Acc4 a{0.f, 0.f, 0.f, 0.f};
+    float wsum = 0.f, w2sum = 0.f;
+    for (int64_t k = kb; k < ke; ++k) {
+      const int64_t id = d.ids[k];
+      if (id < 0 || id >= d.rows) continue;
+      float w = 1.f;
+      if (d.weights) {
+        w = d.weights[k];
+        if (prune_nonpos && !(w > 0.f)) continue;
+      }
+      Acc4 e{0.f, 0.f, 0.f, 0.f};
+      if (LAZY && gi >= 0) {
+        if (V == 4) {
+          float q[4];
+          lazy_row<4>(q, lz->tab[gi], lz->aux[gi], d.key_base + id, c, t_now, eps);
+          e = Acc4{q[0], q[1], q[2], q[3]};
+        } else {
+          float q[1];
+          lazy_row<1>(q, lz->tab[gi], lz->aux[gi], d.key_base + id, c, t_now, eps);
+          e.x = q[0];
+        }
+      } else {
+        const float* row = d.table + id * (d.table_ld ? d.table_ld : d.dim) + c;
+        if (V == 4) {
+          const float4 q = *reinterpret_cast<const float4*>(row);
+          e = Acc4{q.x, q.y, q.z, q.w};
+        } else {
+          e.x = row[0];
+        }
+      }
+      if (d.weights) {
+        a.x = a.x + e.x * w; a.y = a.y + e.y * w; a.z = a.z + e.z * w; a.w = a.w + e.w * w;
+        wsum = wsum + w;
+        w2sum = w2sum + w * w;
+      } else {
+        a.x = a.x + e.x; a.y = a.y + e.y; a.z = a.z + e.z; a.w = a.w + e.w;
+        wsum = wsum + 1.f;
+        w2sum = w2sum + 1.f;
+      }
+    }
+    if (d.combiner != ER_COMBINER_SUM && wsum != 0.f) {
+      const float den = (d.combiner == ER_COMBINER_MEAN) ? wsum : sqrtf(w2sum);
+      a.x = a.x / den; a.y = a.y / den; a.z = a.z / den; a.w = a.w / den;
+    }
+    float* o = d.out + static_cast<int64_t>(r) * d.out_stride + d.out_col + c;
+    if (V == 4) {
+      if (((d.out_stride | d.out_col) & 3) == 0 && (reinterpret_cast<uintptr_t>(d.out) & 15) == 0) {
+        *reinterpret_cast<float4*>(o) = make_float4(a.x, a.y, a.z, a.w);
+      } else {
+        o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w;
+      }
+      ss = (a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w);
+    } else {
+      o[0] = a.x;
+      ss = a.x * a.x;
+    }
+  }
+  if (sumsq_partials) {
+    const float tot = block_sum_256(ss, red);
+    if (threadIdx.x == 0) sumsq_partials[blockIdx.x] = tot;
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+emb_fwd_kernel(const er_lookup_desc* __restrict__ descs, const int32_t* __restrict__ blk_start, int n_lookups,
+               float* __restrict__ sumsq_partials) {
+  fwd_body<false>(descs, blk_start, n_lookups, sumsq_partials, nullptr);
+}
+
+__global__ void __launch_bounds__(kBlock)
+emb_fwd_lazy_kernel(const er_lookup_desc* __restrict__ descs, const int32_t* __restrict__ blk_start, int n_lookups,
+                    float* __restrict__ sumsq_partials, FwdLazy lz) {
+  fwd_body<true>(descs, blk_start, n_lookups, sumsq_partials, &lz);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -867,10 +940,38 @@ struct ReduceOut {
   int ld;                        // mode 2: floats per row of out_grads (>= dim + 1)
 };
 
+// TF-exact Adam on a row whose pending decay-only steps have NOT been replayed by a catch-up launch (the fused step with
+// er_emb_fwd_lazy): the row's record is read once, caught up in registers (the evaluation the lookup made on the same
+// bits), stepped and written once.  The G lanes of the row sit in one wavefront: all read last_step before lane 0 of the
+// row stores it (finish_run).
+template <int V>
+__device__ __forceinline__ void update_row_lazy(const RowUpdate& t, const DecayAux& aux, const er_opt_hyper& h, int64_t key,
+                                                int c, const float* g) {
+  const int64_t off = t.off(key, c);
+  float var[V], m[V], v[V];
+  ld_vec<V>(var, t.var + off);
+  ld_vec<V>(m, t.m + off);
+  ld_vec<V>(v, t.v + off);
+  const int32_t now = static_cast<int32_t>(*t.step_counter - 1);
+  const int32_t s_begin = t.ls(key) + 1;
+  if (s_begin < now) {
+    bool live = false;
+#pragma unroll
+    for (int j = 0; j < V; ++j) live = live || (m[j] != 0.f) || (v[j] != 0.f);
+    if (live) replay_closed<V>(var, m, v, aux, s_begin, now, pin_scalar(h.eps));
+  }
+#pragma unroll
+  for (int i = 0; i < V; ++i) var[i] = adam_elem(m[i], v[i], var[i], g[i], h);
+  st_vec<V>(t.m + off, m);
+  st_vec<V>(t.v + off, v);
+  st_vec<V>(t.var + off, var);
+}
+
+// aux != nullptr: the rows of this step have not been caught up by a launch of their own (update_row_lazy)
 template <int V>
 __device__ __forceinline__ void finish_run(const RowUpdate& tab, int opt_kind, const er_opt_hyper* hyper,
                                            const ReduceOut& ro, uint32_t key, int64_t p, int sub, int c, int dim,
-                                           const float* gsum) {
+                                           const float* gsum, const DecayAux* aux = nullptr) {
   float g[V];
 #pragma unroll
   for (int i = 0; i < V; ++i) g[i] = gsum[i];
@@ -882,9 +983,10 @@ __device__ __forceinline__ void finish_run(const RowUpdate& tab, int opt_kind, c
 #pragma unroll
       for (int i = 0; i < V; ++i) g[i] = g[i] * h.clip_scale;
     }
-    update_row<V>(tab, opt_kind, h, static_cast<int64_t>(key) * dim + c, g);
+    if (aux != nullptr && opt_kind == ER_OPT_ADAM && tab.last_step != nullptr) update_row_lazy<V>(tab, *aux, h, key, c, g);
+    else update_row<V>(tab, opt_kind, h, tab.off(key, c), g);
     if (opt_kind == ER_OPT_ADAM && sub == 0) {
-      if (tab.last_step) tab.last_step[key] = static_cast<int32_t>(*tab.step_counter - 1);
+      if (tab.last_step) tab.ls(key) = static_cast<int32_t>(*tab.step_counter - 1);
       else atomicOr(&tab.bitmap[key >> 5], 1u << (key & 31));
     }
   } else if (ro.mode == 2) {
@@ -1007,7 +1109,8 @@ template <int V>
 __device__ __forceinline__ void fix_body(int bid, const uint32_t* __restrict__ skeys, int64_t n, int dim, int G, int T,
                                          int n_tiles, const RowUpdate& tab, int opt_kind,
                                          const er_opt_hyper* __restrict__ hyper, const ReduceOut& ro,
-                                         const float* __restrict__ tile_first, const float* __restrict__ tile_last) {
+                                         const float* __restrict__ tile_first, const float* __restrict__ tile_last,
+                                         const DecayAux* aux = nullptr) {
   const int64_t s = (static_cast<int64_t>(bid) * kBlock + threadIdx.x) / G;  // start tile candidate
   const int sub = static_cast<int>(threadIdx.x) % G;
   const int c = sub * V;
@@ -1033,7 +1136,7 @@ __device__ __forceinline__ void fix_body(int bid, const uint32_t* __restrict__ s
   }
   float g[V];
   if constexpr (V == 4) { g[0] = acc.v.x; g[1] = acc.v.y; g[2] = acc.v.z; g[3] = acc.v.w; } else { g[0] = acc.v; }
-  finish_run<V>(tab, opt_kind, hyper, ro, key, next0 - 1, sub, c, dim, g);
+  finish_run<V>(tab, opt_kind, hyper, ro, key, next0 - 1, sub, c, dim, g, aux);
 }
 
 template <int V>
@@ -1072,6 +1175,8 @@ struct OwnArgs {
   int n_lookups;
   int dim, G, V, n_tiles;
   RowUpdate tab;
+  DecayAux aux;                  // the closed-form replay's tables (lag 1) ...
+  int inline_catch_up;           // ... used when this step's rows were not caught up by a launch (er_emb_fwd_lazy)
   float* tile_first;             // partial sums of the runs that cross tile boundaries (emb_bwd_fix_multi_kernel)
   float* tile_last;
   int n_proj;
@@ -1280,7 +1385,7 @@ __device__ __forceinline__ void own_tile_body(int bid, const OwnMulti& ma, const
     const bool to_next = (e == T - 1) && keys[T + 1] == key;  // keys[T + 1] = first key of the next tile
     const float* gs = vals + static_cast<size_t>(e) * dim + c;
     if (!from_prev && !to_next) {
-      finish_run<V>(a.tab, ma.opt_kind, ma.hyper, ro, key, p, sub, c, dim, gs);
+      finish_run<V>(a.tab, ma.opt_kind, ma.hyper, ro, key, p, sub, c, dim, gs, a.inline_catch_up ? &a.aux : nullptr);
     } else {
       Vec<V> r;
       r.load(gs);
@@ -1370,7 +1475,8 @@ __device__ __forceinline__ void own_proj_body(int local, const OwnMulti& ma, con
   }
   if (n_valid == 0.f) return;  // no id of the batch read the row: TensorFlow's IndexedSlices has no entry for it
   const ReduceOut ro{0, nullptr, nullptr, nullptr, nullptr, 0};
-  finish_run<V>(a.tab, ma.opt_kind, ma.hyper, ro, static_cast<uint32_t>(d.key_base), 0, sub, c, dim, g);
+  finish_run<V>(a.tab, ma.opt_kind, ma.hyper, ro, static_cast<uint32_t>(d.key_base), 0, sub, c, dim, g,
+                a.inline_catch_up ? &a.aux : nullptr);
 }
 
 __global__ void __launch_bounds__(kBlock)
@@ -1419,9 +1525,9 @@ struct CatchHeadsMulti {
 
 template <int V>
 __device__ __forceinline__ void catch_up_row(const CatchHeadsArgs& a, uint32_t key, int c, int32_t t, float eps) {
-  const int32_t s_begin = a.tab.last_step[key] + 1;
+  const int32_t s_begin = a.tab.ls(key) + 1;
   if (s_begin >= t) return;
-  const int64_t off = static_cast<int64_t>(key) * a.dim + c;
+  const int64_t off = a.tab.off(key, c);
   float var[V], m[V], v[V];
   ld_vec<V>(m, a.tab.m + off);
   ld_vec<V>(v, a.tab.v + off);
@@ -1435,7 +1541,7 @@ __device__ __forceinline__ void catch_up_row(const CatchHeadsArgs& a, uint32_t k
     st_vec<V>(a.tab.m + off, m);
     st_vec<V>(a.tab.v + off, v);
   }
-  if (c == 0) a.tab.last_step[key] = t - 1;
+  if (c == 0) a.tab.ls(key) = t - 1;
 }
 
 template <int V>
@@ -1517,6 +1623,8 @@ struct RunArgs {
   ReduceOut ro;
   float* tile_first;
   float* tile_last;
+  DecayAux aux;         // (fix launch of the fused step: see OwnArgs)
+  int inline_catch_up;
 };
 struct RunMulti {
   int n;
@@ -1549,10 +1657,10 @@ emb_bwd_fix_multi_kernel(RunMulti ma) {
   const int bid = blockIdx.x - ma.start[i];
   if (a.V == 4)
     fix_body<4>(bid, a.skeys, a.n, a.dim, a.G, a.T, a.n_tiles, a.tab, ma.opt_kind, ma.hyper, a.ro, a.tile_first,
-                a.tile_last);
+                a.tile_last, a.inline_catch_up ? &a.aux : nullptr);
   else
     fix_body<1>(bid, a.skeys, a.n, a.dim, a.G, a.T, a.n_tiles, a.tab, ma.opt_kind, ma.hyper, a.ro, a.tile_first,
-                a.tile_last);
+                a.tile_last, a.inline_catch_up ? &a.aux : nullptr);
 }
 
 // Segmented sort: when every lookup of a group owns its own table (disjoint, increasing key ranges - the normal
@@ -2020,14 +2128,14 @@ __global__ void emb_owner_counts_kernel(const uint32_t* __restrict__ unique_keys
 // out[i, :] = table[keys[i] - key_sub, :]  (owner side of the lookup exchange)
 template <int V>
 __global__ void __launch_bounds__(kBlock)
-gather_rows_kernel(const float* __restrict__ table, const uint32_t* __restrict__ keys, int64_t n, int dim, int G,
-                   int64_t key_sub, int64_t table_rows, float* __restrict__ out) {
+gather_rows_kernel(const float* __restrict__ table, int64_t table_ld, const uint32_t* __restrict__ keys, int64_t n, int dim,
+                   int G, int64_t key_sub, int64_t table_rows, float* __restrict__ out) {
   const int64_t i = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) / G;
   const int c = (static_cast<int>(threadIdx.x) % G) * V;
   if (i >= n || c >= dim) return;
   const int64_t row = static_cast<int64_t>(keys[i]) - key_sub;
   Vec<V> e;
-  if (row >= 0 && row < table_rows) e.load(table + row * dim + c); else e.zero();
+  if (row >= 0 && row < table_rows) e.load(table + row * table_ld + c); else e.zero();
   e.store(out + i * dim + c);
 }
 
@@ -2160,12 +2268,12 @@ __device__ __forceinline__ void serve_body(int bid, const ServeArgs& a, const er
   if (p >= a.n || c >= a.dim || !a.flags[p]) return;
   const uint32_t key = a.skeys[p];
   if (key == kInvalidKey) return;
-  const int64_t off = static_cast<int64_t>(key) * a.dim + c;
+  const int64_t off = a.tab.off(key, c);
   float var[V];
   ld_vec<V>(var, a.tab.var + off);
   if (a.tab.last_step) {
     const int32_t t = static_cast<int32_t>(*a.tab.step_counter - 1);
-    const int32_t last = a.tab.last_step[key];
+    const int32_t last = a.tab.ls(key);
     if (last + 1 < t) {
       float m[V], v[V];
       ld_vec<V>(m, a.tab.m + off);
@@ -2182,7 +2290,7 @@ __device__ __forceinline__ void serve_body(int bid, const ServeArgs& a, const er
       }
       // current up to t-1 from here on (see catch_up_body: the rolling flush of the step may run next to the step).
       // The G lanes of the row sit in one wavefront (G <= 64, a power of two): all have read last_step above.
-      if (c == 0) a.tab.last_step[key] = t - 1;
+      if (c == 0) a.tab.ls(key) = t - 1;
     }
   }
   for (int64_t q = p; q < a.n && a.skeys[q] == key; ++q)
@@ -2347,6 +2455,35 @@ adam_decay_sweep_scalar_kernel(float* __restrict__ var, float* __restrict__ m, f
   }
 }
 
+// the same sweep over rows that lie at a pitch of ld floats (row records: er_emb_group_set_row_pitch); a lane owns V
+// consecutive columns of a row (V = 4 when dim and ld are multiples of 4)
+template <int V>
+__global__ void __launch_bounds__(kBlock)
+adam_decay_sweep_pitched_kernel(float* __restrict__ var, float* __restrict__ m, float* __restrict__ v,
+                                const uint32_t* __restrict__ bitmap, int64_t n_rows, int dim, int64_t ld,
+                                const er_opt_hyper* __restrict__ hyper) {
+  const er_opt_hyper h = *hyper;
+  const int upr = dim / V;  // lane units per row
+  const int64_t n_units = n_rows * upr;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n_units; i += stride) {
+    const int64_t row = i / upr;
+    const int c = static_cast<int>(i - row * upr) * V;
+    const uint32_t word = bitmap ? bitmap[row >> 5] : 0u;
+    if ((word >> (row & 31)) & 1u) continue;
+    const int64_t off = row * ld + c;
+    float a[V], b[V], cc[V];
+    ld_vec<V>(a, var + off);
+    ld_vec<V>(b, m + off);
+    ld_vec<V>(cc, v + off);
+#pragma unroll
+    for (int j = 0; j < V; ++j) decay_elem(a[j], b[j], cc[j], h);
+    st_vec<V>(var + off, a);
+    st_vec<V>(m + off, b);
+    st_vec<V>(v + off, cc);
+  }
+}
+
 // Replicated (small, data-parallel) tables of the embedding-parallel path: after the all-reduce of the dense
 // gradient buffer every rank applies the same update.  Row r of `dense` holds [grad (dim floats), count]; count > 0
 // means some rank had a gradient for the row.  Touched rows take the optimizer step on grad * grad_scale; under
@@ -2355,6 +2492,7 @@ adam_decay_sweep_scalar_kernel(float* __restrict__ var, float* __restrict__ m, f
 struct DenseApplyArgs {
   float *var, *m, *v;
   const float* dense;
+  int64_t tld;  // floats between consecutive rows of var / m / v (er_dense_apply_desc.table_ld, 0 = dim)
   int ld, dim, V, G;
   int64_t rows;
 };
@@ -2375,7 +2513,7 @@ __device__ __forceinline__ void dense_apply_body(int bid, const DenseApplyArgs& 
   if (row >= a.rows || c >= a.dim) return;
   const er_opt_hyper h = *hyper;
   const float* d = a.dense + row * a.ld;
-  const int64_t off = row * a.dim + c;
+  const int64_t off = row * a.tld + c;
   if (d[a.dim] > 0.f) {
     float g[V];
 #pragma unroll
@@ -2384,7 +2522,7 @@ __device__ __forceinline__ void dense_apply_body(int bid, const DenseApplyArgs& 
 #pragma unroll
       for (int i = 0; i < V; ++i) g[i] = g[i] * h.clip_scale;
     }
-    update_row<V>(RowUpdate{a.var, a.m, a.v, nullptr, nullptr, nullptr}, opt_kind, h, off, g);
+    update_row<V>(RowUpdate{a.var, a.m, a.v, nullptr, nullptr, nullptr, a.tld, 1}, opt_kind, h, off, g);
   } else if (opt_kind == ER_OPT_ADAM) {
     float var[V], m[V], v[V];
     ld_vec<V>(var, a.var + off);
@@ -2448,6 +2586,10 @@ struct er_emb_plan {
   int n_blocks = 0;
   er_lookup_desc* d_descs = nullptr;
   int32_t* d_blk_start = nullptr;
+  std::vector<er_lookup_desc> h_descs;
+  // er_emb_fwd_lazy: which table group (index into the call's group list) each lookup reads, -1: none of them
+  int8_t* d_lookup_group = nullptr;
+  std::vector<int8_t> h_lookup_group;
 };
 
 struct er_emb_group {
@@ -2491,6 +2633,8 @@ struct er_emb_group {
   std::vector<er_lookup_desc> h_descs;
   std::vector<int64_t> h_local_base;
   float *var = nullptr, *m = nullptr, *v = nullptr;
+  int64_t ld = 0;     // floats between consecutive rows of var / m / v (er_emb_group_set_row_pitch; dim by default)
+  int64_t ls_ld = 1;  // int32 words between consecutive rows' last_step
   uint32_t* bitmap = nullptr;
   int n_build_blocks = 0;
   er_lookup_desc* d_descs = nullptr;
@@ -2510,6 +2654,7 @@ struct er_emb_group {
   // er_emb_front / er_emb_bwd_fused (the fused single-GPU step)
   uint64_t front_epoch = ~0ull;   // sort_epoch of the last sort made by er_emb_front
   bool front_skip = false;        // ... which kept the one-row tables' entries out of the sort
+  bool front_deferred = false;    // ... and left the rows' catch-up to er_emb_fwd_lazy / er_emb_bwd_fused (in registers)
   uint32_t* d_extra_keys = nullptr;  // keys of the one-row tables (always brought current by the fused catch-up)
   int32_t* d_proj_lookup = nullptr;  // their lookup indices
   int n_proj = -1;                   // -1: not collected yet
@@ -2520,6 +2665,10 @@ struct er_emb_group {
 };
 
 namespace {
+
+er::RowUpdate tab_of(const er_emb_group* g) {
+  return er::RowUpdate{g->var, g->m, g->v, g->bitmap, g->last_step, g->step_counter, g->ld, g->ls_ld};
+}
 
 int validate_descs(const er_lookup_desc* descs, int n, const char* who) {
   for (int i = 0; i < n; ++i) {
@@ -2557,6 +2706,7 @@ int er_emb_plan_create(const er_lookup_desc* descs, int n, er_emb_plan** out) {
   ER_CHECK_HIP(hipMalloc(&p->d_blk_start, sizeof(int32_t) * (n + 1)));
   ER_CHECK_HIP(hipMemcpy(p->d_descs, descs, sizeof(er_lookup_desc) * n, hipMemcpyHostToDevice));
   ER_CHECK_HIP(hipMemcpy(p->d_blk_start, blk.data(), sizeof(int32_t) * (n + 1), hipMemcpyHostToDevice));
+  p->h_descs.assign(descs, descs + n);
   *out = p;
   return 0;
 }
@@ -2565,6 +2715,7 @@ int er_emb_plan_update(er_emb_plan* p, const er_lookup_desc* descs, int n) {
   ER_REQUIRE(p && descs && n == p->n, "er_emb_plan_update: lookup count changed");
   if (int rc = validate_descs(descs, n, "er_emb_plan_update")) return rc;
   ER_CHECK_HIP(hipMemcpy(p->d_descs, descs, sizeof(er_lookup_desc) * n, hipMemcpyHostToDevice));
+  p->h_descs.assign(descs, descs + n);
   return 0;
 }
 
@@ -2572,6 +2723,7 @@ int er_emb_plan_destroy(er_emb_plan* p) {
   if (!p) return 0;
   (void)hipFree(p->d_descs);
   (void)hipFree(p->d_blk_start);
+  (void)hipFree(p->d_lookup_group);
   delete p;
   return 0;
 }
@@ -2598,6 +2750,7 @@ int er_emb_group_create(const er_lookup_desc* descs, int n, int32_t dim, int64_t
   er::lane_geom(dim, g->V, g->G);
   g->total_rows = total_rows;
   g->var = var; g->m = m; g->v = v; g->bitmap = bitmap;
+  g->ld = dim;
   g->key_bits = 1;
   while ((1LL << g->key_bits) <= total_rows) ++g->key_bits;  // 2^bits > total_rows: invalid key sorts last
   std::vector<int32_t> blk(n + 1, 0);
@@ -2860,7 +3013,7 @@ static int emb_group_run(er_emb_group* g, int opt_kind, const er_opt_hyper* hype
   if (int rc = front_sort_guard(g, "er_emb_bwd_*")) return rc;
   const int T = g->tile_entries;
   const int n_tiles = static_cast<int>(er::ceil_div(N, T));
-  er::RowUpdate tab{g->var, g->m, g->v, g->bitmap, g->last_step, g->step_counter};
+  const er::RowUpdate tab = tab_of(g);
   const er_emb_group* src = g->src;  // whose sort this group reduces over (itself unless er_emb_group_share_sort)
   er::ReduceOut ro{mode, src->head_flags, src->head_index, out_keys, out_grads, out_ld};
   const size_t lds = sizeof(float) * static_cast<size_t>(T) * g->dim + sizeof(uint32_t) * (T + 2);
@@ -2903,11 +3056,28 @@ int er_config_set(const char* key, int64_t value) {
 
 int er_adam_decay_sweep(float* var, float* m, float* v, uint32_t* bitmap, int64_t total_rows, int32_t dim,
                         const er_opt_hyper* hyper, er_stream_t stream) {
-  ER_REQUIRE(var && m && v && hyper && total_rows > 0 && dim > 0, "er_adam_decay_sweep: bad arguments");
+  return er_adam_decay_sweep_ld(var, m, v, bitmap, total_rows, dim, dim, hyper, stream);
+}
+
+int er_adam_decay_sweep_ld(float* var, float* m, float* v, uint32_t* bitmap, int64_t total_rows, int32_t dim, int64_t ld,
+                           const er_opt_hyper* hyper, er_stream_t stream) {
+  ER_REQUIRE(var && m && v && hyper && total_rows > 0 && dim > 0 && ld >= dim, "er_adam_decay_sweep: bad arguments");
   hipStream_t s = er::as_stream(stream);
   constexpr int U = 4;
   const int max_blocks = 256 * g_sweep_blocks_per_cu;
-  if (dim % 4 == 0) {
+  if (ld != dim) {
+    const bool vec = dim % 4 == 0 && ld % 4 == 0 &&
+                     ((reinterpret_cast<uintptr_t>(var) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15) == 0;
+    const int64_t units = total_rows * (vec ? dim / 4 : dim);
+    int64_t blocks = er::ceil_div(units, er::kBlock);
+    if (blocks > max_blocks) blocks = max_blocks;
+    if (vec)
+      hipLaunchKernelGGL(er::adam_decay_sweep_pitched_kernel<4>, dim3(static_cast<int>(blocks)), dim3(er::kBlock), 0, s, var, m,
+                         v, bitmap, total_rows, dim, ld, hyper);
+    else
+      hipLaunchKernelGGL(er::adam_decay_sweep_pitched_kernel<1>, dim3(static_cast<int>(blocks)), dim3(er::kBlock), 0, s, var, m,
+                         v, bitmap, total_rows, dim, ld, hyper);
+  } else if (dim % 4 == 0) {
     const int64_t units = total_rows * (dim / 4);
     int64_t blocks = er::ceil_div(units, static_cast<int64_t>(er::kBlock) * U);
     if (blocks > max_blocks) blocks = max_blocks;
@@ -2951,7 +3121,7 @@ int er_emb_bwd_update(er_emb_group* g, int opt_kind, const er_opt_hyper* hyper, 
   g->sorted_valid = false;
   if (int rc = emb_group_run(g, opt_kind, hyper, 0, nullptr, nullptr, s)) return rc;
   if (opt_kind == ER_OPT_ADAM && !lazy_decay) {
-    if (int rc = er_adam_decay_sweep(g->var, g->m, g->v, g->bitmap, g->total_rows, g->dim, hyper, stream)) return rc;
+    if (int rc = er_adam_decay_sweep_ld(g->var, g->m, g->v, g->bitmap, g->total_rows, g->dim, g->ld, hyper, stream)) return rc;
     if (int rc = fill_u32(g->bitmap, 0u, er::ceil_div(g->total_rows, 32), s)) return rc;
   }
   return 0;
@@ -2999,7 +3169,9 @@ static int emb_groups_run_multi(er_emb_group* const* groups, int n, int opt_kind
     a.skeys = src->keys_out; a.svals = src->vals_out; a.ent_gptr = g->ent_gptr; a.ent_scale = g->ent_scale;
     a.n = N; a.dim = g->dim; a.G = g->G; a.V = g->V; a.T = g->tile_entries;
     a.n_tiles = static_cast<int>(er::ceil_div(N, a.T));
-    a.tab = er::RowUpdate{g->var, g->m, g->v, g->bitmap, g->last_step, g->step_counter};
+    a.tab = tab_of(g);
+    a.aux = er::DecayAux{};
+    a.inline_catch_up = 0;
     a.ro = dense ? er::ReduceOut{2, nullptr, nullptr, nullptr, dense[i], ld[i]}
                  : er::ReduceOut{0, src->head_flags, src->head_index, nullptr, nullptr, 0};
     a.tile_first = g->tile_first; a.tile_last = g->tile_last;
@@ -3023,7 +3195,7 @@ static int emb_groups_run_multi(er_emb_group* const* groups, int n, int opt_kind
   for (int i = 0; i < n && !dense; ++i) {  // TF-exact Adam with the streaming sweep: per group, as er_emb_bwd_update
     er_emb_group* g = groups[i];
     if (opt_kind == ER_OPT_ADAM && !g->last_step) {
-      if (int rc = er_adam_decay_sweep(g->var, g->m, g->v, g->bitmap, g->total_rows, g->dim, hyper, stream)) return rc;
+      if (int rc = er_adam_decay_sweep_ld(g->var, g->m, g->v, g->bitmap, g->total_rows, g->dim, g->ld, hyper, stream)) return rc;
       if (int rc = fill_u32(g->bitmap, 0u, er::ceil_div(g->total_rows, 32), s)) return rc;
     }
   }
@@ -3053,6 +3225,18 @@ int er_emb_group_enable_lazy_decay(er_emb_group* g, int32_t* last_step, const fl
   g->last_step = last_step;
   g->lr_hist = lr_t_history;
   g->step_counter = step_counter;
+  return 0;
+}
+
+int er_emb_group_set_row_pitch(er_emb_group* g, int64_t ld, int64_t last_step_ld) {
+  ER_REQUIRE(g && ld >= g->dim && last_step_ld >= 1, "er_emb_group_set_row_pitch: bad arguments (ld >= dim, last_step_ld >= 1)");
+  if (g->V == 4) {
+    ER_REQUIRE(ld % 4 == 0, "er_emb_group_set_row_pitch: ld %lld must be a multiple of 4 floats for 16-byte lanes", (long long)ld);
+    ER_REQUIRE(((reinterpret_cast<uintptr_t>(g->var) | reinterpret_cast<uintptr_t>(g->m) | reinterpret_cast<uintptr_t>(g->v)) & 15) == 0,
+               "er_emb_group_set_row_pitch: var / m / v must be 16-byte aligned");
+  }
+  g->ld = ld;
+  g->ls_ld = last_step_ld;
   return 0;
 }
 
@@ -3130,8 +3314,10 @@ static int front_collect_one_row(er_emb_group* g) {
   return 0;
 }
 
-int er_emb_front(er_emb_group* const* groups, int n, int skip_one_row, const er_opt_hyper* hyper, er_stream_t stream) {
+int er_emb_front(er_emb_group* const* groups, int n, int flags, const er_opt_hyper* hyper, er_stream_t stream) {
   ER_REQUIRE(groups && n >= 1 && n <= er::kMaxMulti, "er_emb_front: bad arguments (1 <= n <= %d)", er::kMaxMulti);
+  const int skip_one_row = flags & ER_FRONT_SKIP_ONE_ROW;
+  const bool defer = (flags & ER_FRONT_DEFER_CATCH_UP) != 0;
   hipStream_t s = er::as_stream(stream);
   // eligibility first: nothing is launched for a set of groups the fused path does not cover
   for (int i = 0; i < n; ++i) {
@@ -3182,6 +3368,12 @@ int er_emb_front(er_emb_group* const* groups, int n, int skip_one_row, const er_
     g->front_skip = skip_one_row != 0;
     g->sorted_valid = true;
   }
+  for (int i = 0; i < n; ++i) groups[i]->front_deferred = defer && groups[i]->last_step != nullptr;
+  if (defer) {  // the lookup (er_emb_fwd_lazy) and the row update (er_emb_bwd_fused) catch the rows up in registers
+    for (int i = 0; i < n; ++i)
+      if (groups[i]->last_step) ER_REQUIRE(tables_done, "er_emb_front: no sort leader carried the decay tables");
+    return 0;
+  }
   // catch-up from the heads
   er::CatchHeadsMulti cm;
   cm.n = 0;
@@ -3197,7 +3389,7 @@ int er_emb_front(er_emb_group* const* groups, int n, int skip_one_row, const er_
     er::CatchHeadsArgs& a = cm.a[cm.n];
     a.ukeys_seg = src->keys_in;  // (the unsorted key array is free in the fused front: the sort builds its entries itself)
     a.seg_count = src->seg_count; a.ent_base = src->d_ent_base; a.n_lookups = src->n; a.n = group_entries(g);
-    a.tab = er::RowUpdate{g->var, g->m, g->v, g->bitmap, g->last_step, g->step_counter};
+    a.tab = tab_of(g);
     a.aux = decay_aux_for(g, 1);
     a.dim = g->dim; a.G = g->G; a.V = g->V;
     a.extra_keys = skip_one_row ? g->d_extra_keys : nullptr;
@@ -3312,7 +3504,9 @@ int er_emb_bwd_fused(er_emb_group* const* groups, int n, const er_grad_group* fi
     a.dim = g->dim; a.G = g->G; a.V = g->V;
     const int T = g->tile_entries;
     a.n_tiles = static_cast<int>(er::ceil_div(a.n, T));
-    a.tab = er::RowUpdate{g->var, g->m, g->v, g->bitmap, g->last_step, g->step_counter};
+    a.tab = tab_of(g);
+    a.inline_catch_up = g->front_deferred ? 1 : 0;
+    a.aux = g->front_deferred ? decay_aux_for(g, 1) : er::DecayAux{};
     a.tile_first = g->tile_first; a.tile_last = g->tile_last;
     const bool proj = src->front_skip && g->n_proj > 0;
     a.n_proj = proj ? g->n_proj : 0;
@@ -3321,6 +3515,7 @@ int er_emb_bwd_fused(er_emb_group* const* groups, int n, const er_grad_group* fi
       f.skeys = src->keys_out; f.svals = src->vals_out; f.ent_gptr = nullptr; f.ent_scale = nullptr;
       f.n = a.n; f.dim = g->dim; f.G = g->G; f.V = g->V; f.T = T; f.n_tiles = a.n_tiles;
       f.tab = a.tab;
+      f.aux = a.aux; f.inline_catch_up = a.inline_catch_up;
       f.ro = er::ReduceOut{0, nullptr, nullptr, nullptr, nullptr, 0};
       f.tile_first = g->tile_first; f.tile_last = g->tile_last;
       const int fb = a.n_tiles > 1 ? static_cast<int>(er::ceil_div(static_cast<int64_t>(a.n_tiles) * g->G, er::kBlock)) : 0;
@@ -3337,6 +3532,7 @@ int er_emb_bwd_fused(er_emb_group* const* groups, int n, const er_grad_group* fi
     if (need_proj > need) need = need_proj;
     if (need > lds) lds = need;
     g->sorted_valid = false;
+    g->front_deferred = false;
     ++ma.n;
   }
   for (int k = 0; k < n_finish; ++k) ma.gg[k] = finish[k];
@@ -3353,6 +3549,57 @@ int er_emb_bwd_fused(er_emb_group* const* groups, int n, const er_grad_group* fi
 }
 #undef ER_ELIGIBLE
 
+int er_emb_fwd_lazy(er_emb_plan* p, er_emb_group* const* groups, int n, const er_opt_hyper* hyper, float* sumsq_partials,
+                    er_stream_t stream) {
+  ER_REQUIRE(p && groups && n >= 1 && n <= er::kMaxMulti, "er_emb_fwd_lazy: bad arguments (1 <= n <= %d)", er::kMaxMulti);
+  hipStream_t s = er::as_stream(stream);
+  er::FwdLazy lz;
+  lz.n = 0;
+  lz.hyper = hyper;
+  // which group a lookup reads: its table lies inside the group's var rows (and has the group's dim)
+  std::vector<int8_t> map(p->n, -1);
+  int slot_of[er::kMaxMulti];
+  for (int i = 0; i < n; ++i) {
+    er_emb_group* g = groups[i];
+    ER_REQUIRE(g, "er_emb_fwd_lazy: null group %d", i);
+    slot_of[i] = -1;
+    if (!g->last_step) continue;
+    ER_REQUIRE(hyper && g->tabs && g->G <= er::kWave && g->front_deferred,
+               "er_emb_fwd_lazy: group %d: call er_emb_front(ER_FRONT_DEFER_CATCH_UP) for this step first (closed-form replay only)", i);
+    slot_of[i] = lz.n;
+    lz.tab[lz.n] = tab_of(g);
+    lz.aux[lz.n] = decay_aux_for(g, 1);
+    ++lz.n;
+  }
+  for (int l = 0; l < p->n; ++l) {
+    const er_lookup_desc& d = p->h_descs[l];
+    for (int i = 0; i < n; ++i) {
+      const er_emb_group* g = groups[i];
+      if (slot_of[i] < 0 || d.dim != g->dim) continue;
+      const float* lo = g->var;
+      const float* hi = g->var + g->total_rows * g->ld;
+      if (d.table < lo || d.table >= hi) continue;
+      ER_REQUIRE(d.table == g->var + d.key_base * g->ld && (d.table_ld ? d.table_ld : d.dim) == g->ld,
+                 "er_emb_fwd_lazy: lookup %d does not address group %d's rows by its key_base / row pitch", l, i);
+      map[l] = static_cast<int8_t>(slot_of[i]);
+    }
+  }
+  if (map != p->h_lookup_group) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(s, &cap);
+    ER_REQUIRE(cap == hipStreamCaptureStatusNone, "er_emb_fwd_lazy: run one step eagerly before capturing (the plan is uploaded on first use)");
+    if (!p->d_lookup_group) ER_CHECK_HIP(hipMalloc(&p->d_lookup_group, sizeof(int8_t) * p->n));
+    ER_CHECK_HIP(hipStreamSynchronize(s));
+    ER_CHECK_HIP(hipMemcpy(p->d_lookup_group, map.data(), sizeof(int8_t) * p->n, hipMemcpyHostToDevice));
+    p->h_lookup_group = map;
+  }
+  lz.lookup_group = p->d_lookup_group;
+  hipLaunchKernelGGL(er::emb_fwd_lazy_kernel, dim3(p->n_blocks), dim3(er::kBlock), 0, s, p->d_descs, p->d_blk_start, p->n,
+                     sumsq_partials, lz);
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
 int er_emb_catch_up(er_emb_group* g, const uint32_t* unique_keys, const int32_t* n_unique, const er_opt_hyper* hyper,
                     er_stream_t stream) {
   ER_REQUIRE(g && unique_keys && n_unique && hyper, "er_emb_catch_up: null argument");
@@ -3360,7 +3607,7 @@ int er_emb_catch_up(er_emb_group* g, const uint32_t* unique_keys, const int32_t*
   if (g->tabs) return er_emb_catch_up_multi(&g, &unique_keys, &n_unique, 1, hyper, stream);
   const int64_t cap = group_entries(g);
   if (cap == 0) return 0;
-  er::RowUpdate tab{g->var, g->m, g->v, g->bitmap, g->last_step, g->step_counter};
+  const er::RowUpdate tab = tab_of(g);
   const int blocks = static_cast<int>(er::ceil_div(cap * g->G, er::kBlock));
   if (g->V == 4) {
     hipLaunchKernelGGL(er::emb_catch_up_kernel<4>, dim3(blocks), dim3(er::kBlock), 0, er::as_stream(stream), unique_keys,
@@ -3392,7 +3639,7 @@ int er_emb_catch_up_multi(er_emb_group* const* groups, const uint32_t* const* un
     closed = closed && g->tabs != nullptr && g->G <= er::kWave;
     er::CatchUpArgs& a = ma.a[ma.n];
     a.ukeys = unique_keys[i]; a.n_unique = n_unique[i]; a.capacity = cap;
-    a.tab = er::RowUpdate{g->var, g->m, g->v, g->bitmap, g->last_step, g->step_counter};
+    a.tab = tab_of(g);
     a.lr_hist = g->lr_hist; a.aux = decay_aux_for(g, 1); a.dim = g->dim; a.G = g->G; a.V = g->V;
     ma.start[ma.n + 1] = ma.start[ma.n] + static_cast<int>(er::ceil_div(cap * g->G, er::kBlock));
     ++ma.n;
@@ -3409,7 +3656,7 @@ int er_emb_flush_decay(er_emb_group* g, const er_opt_hyper* hyper, er_stream_t s
   ER_REQUIRE(g && hyper, "er_emb_flush_decay: null argument");
   ER_REQUIRE(g->last_step, "er_emb_flush_decay: call er_emb_group_enable_lazy_decay first");
   hipStream_t s = er::as_stream(stream);
-  er::RowUpdate tab{g->var, g->m, g->v, g->bitmap, g->last_step, g->step_counter};
+  const er::RowUpdate tab = tab_of(g);
   const int64_t blocks = er::ceil_div(g->total_rows * g->G, er::kBlock);
   ER_REQUIRE(blocks < 0x7FFFFFFFLL, "er_emb_flush_decay: table group too large for one launch");
   if (int rc = launch_decay_tables(&g, 1, 0, s)) return rc;
@@ -3421,7 +3668,7 @@ int er_emb_flush_decay(er_emb_group* g, const er_opt_hyper* hyper, er_stream_t s
                        g->total_rows, g->lr_hist, hyper, g->dim, g->G, g->aux);
   }
   ER_LAUNCH_CHECK();
-  hipLaunchKernelGGL(er::emb_flush_mark_kernel, dim3(1024), dim3(er::kBlock), 0, s, g->last_step, g->total_rows,
+  hipLaunchKernelGGL(er::emb_flush_mark_kernel, dim3(1024), dim3(er::kBlock), 0, s, g->last_step, g->ls_ld, g->total_rows,
                      g->step_counter);
   ER_LAUNCH_CHECK();
   return 0;
@@ -3535,7 +3782,7 @@ int er_emb_flush_window(er_emb_group* const* groups, int n, int32_t n_windows, i
     ER_REQUIRE(g && g->last_step, "er_emb_flush_window: call er_emb_group_enable_lazy_decay first (group %d)", i);
     ER_REQUIRE(g->G <= er::kWave, "er_emb_flush_window: a row must fit one wavefront");
     er::FlushWindowArgs& a = ma.a[ma.n];
-    a.tab = er::RowUpdate{g->var, g->m, g->v, g->bitmap, g->last_step, g->step_counter};
+    a.tab = tab_of(g);
     a.total_rows = g->total_rows;
     a.chunk = er::ceil_div(g->total_rows, n_windows);
     a.lr_hist = g->lr_hist; a.aux = decay_aux_for(g, lag); a.dim = g->dim; a.G = g->G; a.V = g->V;
@@ -3575,7 +3822,7 @@ int er_emb_mark_touched(er_emb_group* g, er_stream_t stream) {
 
 int er_emb_sweep_untouched(er_emb_group* g, const er_opt_hyper* hyper, er_stream_t stream) {
   ER_REQUIRE(g && hyper && g->bitmap && g->m && g->v, "er_emb_sweep_untouched: needs bitmap, m and v");
-  if (int rc = er_adam_decay_sweep(g->var, g->m, g->v, g->bitmap, g->total_rows, g->dim, hyper, stream)) return rc;
+  if (int rc = er_adam_decay_sweep_ld(g->var, g->m, g->v, g->bitmap, g->total_rows, g->dim, g->ld, hyper, stream)) return rc;
   return fill_u32(g->bitmap, 0u, er::ceil_div(g->total_rows, 32), er::as_stream(stream));
 }
 
@@ -3604,7 +3851,7 @@ int er_emb_apply_unique(er_emb_group* g, const uint32_t* unique_keys, const floa
   hipStream_t s = er::as_stream(stream);
   const int64_t cap = group_entries(g);
   if (cap > 0) {
-    er::RowUpdate tab{g->var, g->m, g->v, g->bitmap, g->last_step, g->step_counter};
+    const er::RowUpdate tab = tab_of(g);
     const int blocks = static_cast<int>(er::ceil_div(cap * g->G, er::kBlock));
     const int row_ld = ld ? ld : g->dim;
     if (g->V == 4) {
@@ -3618,7 +3865,7 @@ int er_emb_apply_unique(er_emb_group* g, const uint32_t* unique_keys, const floa
   }
   g->sorted_valid = false;  // (a sort left by this step's er_emb_route has served its purpose)
   if (opt_kind == ER_OPT_ADAM && !lazy_decay) {  // TF-exact Adam with the streaming sweep, as er_emb_bwd_update
-    if (int rc = er_adam_decay_sweep(g->var, g->m, g->v, g->bitmap, g->total_rows, g->dim, hyper, stream)) return rc;
+    if (int rc = er_adam_decay_sweep_ld(g->var, g->m, g->v, g->bitmap, g->total_rows, g->dim, g->ld, hyper, stream)) return rc;
     if (int rc = fill_u32(g->bitmap, 0u, er::ceil_div(g->total_rows, 32), s)) return rc;
   }
   return 0;
@@ -3780,17 +4027,22 @@ int er_emb_bwd_reduce_routed(er_emb_group* g, float* unique_grads, int32_t ld, e
 
 int er_gather_rows(const float* table, int64_t table_rows, int32_t dim, const uint32_t* keys, int64_t n,
                    int64_t key_sub, float* out, er_stream_t stream) {
-  ER_REQUIRE(table && keys && out && dim > 0 && n >= 0, "er_gather_rows: bad arguments");
+  return er_gather_rows_ld(table, dim, table_rows, dim, keys, n, key_sub, out, stream);
+}
+
+int er_gather_rows_ld(const float* table, int64_t table_ld, int64_t table_rows, int32_t dim, const uint32_t* keys, int64_t n,
+                      int64_t key_sub, float* out, er_stream_t stream) {
+  ER_REQUIRE(table && keys && out && dim > 0 && n >= 0 && table_ld >= dim, "er_gather_rows: bad arguments");
   if (n == 0) return 0;
   int V, G;
   er::lane_geom(dim, V, G);
   const int blocks = static_cast<int>(er::ceil_div(n * G, er::kBlock));
   if (V == 4) {
-    hipLaunchKernelGGL(er::gather_rows_kernel<4>, dim3(blocks), dim3(er::kBlock), 0, er::as_stream(stream), table, keys, n,
-                       dim, G, key_sub, table_rows, out);
+    hipLaunchKernelGGL(er::gather_rows_kernel<4>, dim3(blocks), dim3(er::kBlock), 0, er::as_stream(stream), table, table_ld, keys,
+                       n, dim, G, key_sub, table_rows, out);
   } else {
-    hipLaunchKernelGGL(er::gather_rows_kernel<1>, dim3(blocks), dim3(er::kBlock), 0, er::as_stream(stream), table, keys, n,
-                       dim, G, key_sub, table_rows, out);
+    hipLaunchKernelGGL(er::gather_rows_kernel<1>, dim3(blocks), dim3(er::kBlock), 0, er::as_stream(stream), table, table_ld, keys,
+                       n, dim, G, key_sub, table_rows, out);
   }
   ER_LAUNCH_CHECK();
   return 0;
@@ -3904,7 +4156,8 @@ int er_emb_owner_serve(er_emb_group* const* groups, float* const* rows_out, cons
     a.skeys = src->keys_out; a.svals = src->vals_out; a.flags = src->head_flags; a.n = N;
     // hyper == NULL: serve the rows as they are (inference after er_emb_flush_decay: nothing is pending and nothing
     // may be replayed, because no row update follows that would advance last_step)
-    a.tab = er::RowUpdate{g->var, g->m, g->v, g->bitmap, hyper ? g->last_step : nullptr, g->step_counter};
+    a.tab = tab_of(g);
+    if (!hyper) a.tab.last_step = nullptr;
     ER_REQUIRE(a.tab.last_step == nullptr || g->G <= er::kWave, "er_emb_owner_serve: a lazily decayed row must fit one wavefront");
     a.lr_hist = g->lr_hist; a.aux = decay_aux_for(g, 1); a.out = rows_out[i]; a.dim = g->dim; a.G = g->G; a.V = g->V;
     a.ld = ld && ld[i] ? ld[i] : g->dim;
@@ -3941,6 +4194,8 @@ int er_emb_dense_apply(const er_dense_apply_desc* descs, int n, int opt_kind, co
     if (d.rows == 0) continue;
     er::DenseApplyArgs& a = ma.a[ma.n];
     a.var = d.var; a.m = d.m; a.v = d.v; a.dense = d.dense; a.ld = d.ld; a.dim = d.dim; a.rows = d.rows;
+    a.tld = d.table_ld ? d.table_ld : d.dim;
+    ER_REQUIRE(a.tld >= d.dim, "er_emb_dense_apply: table %d: table_ld < dim", i);
     er::lane_geom(d.dim, a.V, a.G);
     ma.start[ma.n + 1] = ma.start[ma.n] + static_cast<int>(er::ceil_div(d.rows * a.G, er::kBlock));
     ++ma.n;

@@ -68,14 +68,14 @@ struct KvFilter {
 };
 
 __device__ __forceinline__ void kv_create_row(int64_t key, uint64_t pos, int32_t* rows, int32_t* next_row, int32_t capacity,
-                                              float* __restrict__ var, int dim, uint64_t seed, float mean, float stddev,
+                                              float* __restrict__ var, int dim, int ld, uint64_t seed, float mean, float stddev,
                                               int32_t* overflow) {
   const int32_t r = atomicAdd(next_row, 1);
   if (r >= capacity) {
     atomicExch(overflow, 1);  // the key stays without a row (find returns -1 for it: a zero embedding)
     return;
   }
-  float* dst = var + static_cast<int64_t>(r) * dim;
+  float* dst = var + static_cast<int64_t>(r) * ld;  // (ld: floats between rows - er_kv_job.table_ld)
   for (int c = 0; c < dim; ++c) dst[c] = kv_init_value(seed, key, c, mean, stddev);
   __hip_atomic_store(rows + pos, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -83,7 +83,7 @@ __device__ __forceinline__ void kv_create_row(int64_t key, uint64_t pos, int32_t
 // CounterFilter / version stamp: every occurrence of a key in a training lookup lands here once
 __device__ __forceinline__ void kv_insert_filtered(int64_t key, uint64_t pos, uint64_t mask, int64_t* keys, int32_t* rows,
                                                    int32_t* next_row, int32_t capacity, float* __restrict__ var, int dim,
-                                                   uint64_t seed, float mean, float stddev, int32_t* overflow,
+                                                   int ld, uint64_t seed, float mean, float stddev, int32_t* overflow,
                                                    const KvFilter& f) {
   const bool counted = f.filter_freq > 1;
   // a full map (filtered tables: slots in use, else rows in use) claims no further slot
@@ -109,7 +109,7 @@ __device__ __forceinline__ void kv_insert_filtered(int64_t key, uint64_t pos, ui
       if (__hip_atomic_load(f.freq + pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < f.filter_freq)
         create = atomicAdd(f.freq + pos, 1) + 1 == f.filter_freq;  // exactly one occurrence brings the count to the threshold
     }
-    if (create) kv_create_row(key, pos, rows, next_row, capacity, var, dim, seed, mean, stddev, overflow);
+    if (create) kv_create_row(key, pos, rows, next_row, capacity, var, dim, ld, seed, mean, stddev, overflow);
     return;
   }
   atomicExch(overflow, 1);
@@ -117,14 +117,14 @@ __device__ __forceinline__ void kv_insert_filtered(int64_t key, uint64_t pos, ui
 
 __device__ __forceinline__ void kv_insert_one(int64_t i, const int64_t* __restrict__ ids, int64_t n, int64_t* keys,
                                               int32_t* rows, uint64_t mask, int32_t* next_row, int32_t capacity,
-                                              float* __restrict__ var, int dim, uint64_t seed, float mean, float stddev,
-                                              int32_t* overflow, const KvFilter& flt) {
+                                              float* __restrict__ var, int dim, int ld, uint64_t seed, float mean,
+                                              float stddev, int32_t* overflow, const KvFilter& flt) {
   if (i >= n) return;
   const int64_t key = ids[i];
   if (key < 0) return;  // ('' / padding: no row)
   uint64_t pos = kv_home(key, mask);
   if (flt.filter_freq > 1 || flt.version) {
-    kv_insert_filtered(key, pos, mask, keys, rows, next_row, capacity, var, dim, seed, mean, stddev, overflow, flt);
+    kv_insert_filtered(key, pos, mask, keys, rows, next_row, capacity, var, dim, ld, seed, mean, stddev, overflow, flt);
     return;
   }
   // A full arena claims no further key slots: ids that have a row are found, new ones only raise the (sticky) overflow
@@ -145,7 +145,7 @@ __device__ __forceinline__ void kv_insert_one(int64_t i, const int64_t* __restri
                                               static_cast<unsigned long long>(kKvEmpty), static_cast<unsigned long long>(key));
     if (static_cast<int64_t>(prev) == key) return;  // present (or being created by its winner)
     if (static_cast<int64_t>(prev) == kKvEmpty) {    // this lane created the key
-      kv_create_row(key, pos, rows, next_row, capacity, var, dim, seed, mean, stddev, overflow);
+      kv_create_row(key, pos, rows, next_row, capacity, var, dim, ld, seed, mean, stddev, overflow);
       return;
     }
   }
@@ -154,10 +154,10 @@ __device__ __forceinline__ void kv_insert_one(int64_t i, const int64_t* __restri
 
 __global__ void __launch_bounds__(kBlock)
 kv_insert_kernel(const int64_t* __restrict__ ids, int64_t n, int64_t* keys, int32_t* rows, uint64_t mask,
-                 int32_t* next_row, int32_t capacity, float* __restrict__ var, int dim, uint64_t seed, float mean,
+                 int32_t* next_row, int32_t capacity, float* __restrict__ var, int dim, int ld, uint64_t seed, float mean,
                  float stddev, int32_t* overflow, KvFilter flt) {
   kv_insert_one(static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x, ids, n, keys, rows, mask, next_row, capacity, var,
-                dim, seed, mean, stddev, overflow, flt);
+                dim, ld, seed, mean, stddev, overflow, flt);
 }
 
 __device__ __forceinline__ void kv_find_one(int64_t i, const int64_t* __restrict__ ids, int64_t n,
@@ -203,7 +203,7 @@ kv_insert_multi_kernel(const er_kv_job* __restrict__ jobs, const int32_t* __rest
   const er_kv_job q = jobs[j];
   const int64_t n = q.n_limit ? (static_cast<int64_t>(*q.n_limit) < q.n ? static_cast<int64_t>(*q.n_limit) : q.n) : q.n;
   kv_insert_one(static_cast<int64_t>(blockIdx.x - blk_start[j]) * kBlock + threadIdx.x, q.ids, n, q.map_keys, q.map_rows,
-                static_cast<uint64_t>(q.map_slots - 1), q.next_row, q.capacity, q.var, q.dim, q.seed, q.init_mean,
+                static_cast<uint64_t>(q.map_slots - 1), q.next_row, q.capacity, q.var, q.dim, q.table_ld ? q.table_ld : q.dim, q.seed, q.init_mean,
                 q.init_stddev, q.overflow, KvFilter{q.freq, q.version, q.n_keys, q.step, q.filter_freq});
 }
 
@@ -338,7 +338,7 @@ int er_kv_translate(const int64_t* ids, int64_t n, int64_t* map_keys, int32_t* m
   const uint64_t mask = static_cast<uint64_t>(map_slots - 1);
   if (insert) {
     hipLaunchKernelGGL(er::kv_insert_kernel, dim3(er::blocks_for(n)), dim3(er::kBlock), 0, s, ids, n, map_keys, map_rows,
-                       mask, next_row, capacity, var, dim, seed, init_mean, init_stddev, overflow,
+                       mask, next_row, capacity, var, dim, dim, seed, init_mean, init_stddev, overflow,
                        er::KvFilter{nullptr, nullptr, nullptr, nullptr, 0});
     ER_LAUNCH_CHECK();
   }
@@ -374,7 +374,8 @@ int er_kv_translate_job(const er_kv_job* job, int insert, er_stream_t stream) {
   const uint64_t mask = static_cast<uint64_t>(job->map_slots - 1);
   if (insert) {
     hipLaunchKernelGGL(er::kv_insert_kernel, dim3(er::blocks_for(job->n)), dim3(er::kBlock), 0, s, job->ids, job->n,
-                       job->map_keys, job->map_rows, mask, job->next_row, job->capacity, job->var, job->dim, job->seed,
+                       job->map_keys, job->map_rows, mask, job->next_row, job->capacity, job->var, job->dim, job->table_ld ? job->table_ld : job->dim,
+                       job->seed,
                        job->init_mean, job->init_stddev, job->overflow,
                        er::KvFilter{job->freq, job->version, job->n_keys, job->step, job->filter_freq});
     ER_LAUNCH_CHECK();

@@ -23,7 +23,7 @@ class KvJob(ctypes.Structure):
               ('rows_out', ctypes.c_void_p), ('overflow', ctypes.c_void_p), ('capacity', ctypes.c_int32), ('dim', ctypes.c_int32),
               ('init_mean', ctypes.c_float), ('init_stddev', ctypes.c_float), ('n_limit', ctypes.c_void_p),
               ('freq', ctypes.c_void_p), ('version', ctypes.c_void_p), ('n_keys', ctypes.c_void_p), ('step', ctypes.c_void_p),
-              ('filter_freq', ctypes.c_int32), ('reserved', ctypes.c_int32)]
+              ('filter_freq', ctypes.c_int32), ('table_ld', ctypes.c_int32)]
 
 
 class KvRouteJob(ctypes.Structure):
@@ -160,12 +160,48 @@ _GRAD_SLOTS = os.environ.get('EASYREC_AMD_GRAD_SLOTS', '1') != '0'  # A/B switch
 _CAT_DGRAD = os.environ.get('EASYREC_AMD_CAT_DGRAD', '1') != '0'    # A/B switch: one input-gradient GEMM for the readers of a shared input
 
 
+class _SlotGateFn(torch.autograd.Function):
+  """Identity.  Every SLOT-AWARE consumer of an activation reads it through ONE gate per step (slot_gate), so the gate's
+  backward - which autograd runs only after all of THEM - is where their shared gradient buffer enters x's gradient."""
+
+  @staticmethod
+  def forward(ctx, x):
+    return x.view_as(x)
+
+  @staticmethod
+  def backward(ctx, g):
+    return g
+
+
+def slot_gate(x):
+  """The tensor a slot-aware Function (LinearFn, CrossV2EpilogueFn, DINConcatFn, DINPoolFn) must be APPLIED to instead of
+  x.  grad_slot lets those consumers accumulate their input gradients into one buffer that the first of them returns to
+  autograd.  If that buffer went to x directly, an ordinary consumer of x (a torch op, LinearBNActFn, ...) whose gradient
+  arrives between two slot consumers would make autograd sum out of place - buffer + other - and the later slot consumers
+  would add into a buffer nobody reads any more.  Behind the gate the buffer is the ONLY gradient autograd sees for the gate's
+  output, complete when the gate's backward hands it on to x, whatever else reads x and in whatever order."""
+  slots = grad_slots_of_step()
+  if slots is None or not torch.is_grad_enabled() or not x.requires_grad or x.dim() < 2:
+    return x
+  gates = slots.setdefault('gates', {})
+  key = (x.data_ptr(), tuple(x.shape), tuple(x.stride()))
+  ent = gates.get(key)
+  if ent is not None and (ent[0] is x or ent[1] is x):
+    return ent[1]
+  xg = _SlotGateFn.apply(x)
+  for attr in ('_er_bn_src', '_er_sink'):
+    if hasattr(x, attr):
+      setattr(xg, attr, getattr(x, attr))
+  gates[key] = (x, xg)
+  return xg
+
+
 def grad_slot(slots, x):
-  """One gradient buffer per activation tensor and step, shared by the backward kernels of ALL its consumers: the first to
-  ask gets (a fresh tensor, accumulate = False, first = True) and returns that tensor to autograd; the others get (the same
-  tensor, True, False), ADD into it inside their own kernels and return None - autograd then has one gradient for x and
-  launches no add kernel.  Valid because autograd runs the producer of x only after every consumer's backward.  Keyed by
-  storage start and shape; the table (grad_slots_of_step) is emptied by EasyRecModel.begin_step."""
+  """One gradient buffer per activation tensor and step, shared by the backward kernels of ALL its slot-aware consumers: the
+  first to ask gets (a fresh tensor, accumulate = False, first = True) and returns that tensor to autograd; the others get
+  (the same tensor, True, False), ADD into it inside their own kernels and return None - autograd then has one gradient for
+  x and launches no add kernel.  The consumers must have been applied to slot_gate(x): see there.  Keyed by storage start
+  and shape; the table (grad_slots_of_step) is emptied by EasyRecModel.begin_step."""
   key = (x.data_ptr(), tuple(x.shape))
   t = slots.get(key)
   if t is not None:
@@ -263,7 +299,7 @@ GRAD_TERM_ROWSUM, GRAD_TERM_FM = 0, 1
 
 class DenseApplyDesc(ctypes.Structure):  # = er_dense_apply_desc
   _fields_ = [('var', ctypes.c_void_p), ('m', ctypes.c_void_p), ('v', ctypes.c_void_p), ('dense', ctypes.c_void_p),
-              ('ld', ctypes.c_int32), ('dim', ctypes.c_int32), ('rows', ctypes.c_int64)]
+              ('ld', ctypes.c_int32), ('dim', ctypes.c_int32), ('rows', ctypes.c_int64), ('table_ld', ctypes.c_int64)]
 
 
 def same_lookup_keys(group, leader):
@@ -605,8 +641,23 @@ class HipBackend(object):
                                      ctypes.c_int64(total_rows), _p(var), _p(m), _p(v), _p(bitmap),
                                      ctypes.byref(grp)), 'er_emb_group_create')
     n_ent = self.lib.er_emb_group_num_entries(grp)
-    return {'handle': grp, 'specs': list(specs), 'dim': dim, 'total_rows': total_rows, 'var': var,
-            'm': m, 'v': v, 'bitmap': bitmap, 'num_entries': n_ent}
+    group = {'handle': grp, 'specs': list(specs), 'dim': dim, 'total_rows': total_rows, 'var': var,
+             'm': m, 'v': v, 'bitmap': bitmap, 'num_entries': n_ent, 'last_step': None}
+    self._set_row_pitch(group)
+    return group
+
+  def _set_row_pitch(self, group):
+    """var / m / v (and last_step) may be column blocks of ONE [rows, ld] record buffer (input_layer._alloc_storage):
+    the pitches are read off the tensors' strides."""
+    var, ls = group['var'], group.get('last_step')
+    ld = var.stride(0) if var.dim() == 2 else group['dim']
+    for t in (group['m'], group['v']):
+      assert t is None or (t.dim() == 2 and t.stride(0) == ld and t.stride(1) == 1), 'var / m / v must share one row pitch'
+    assert var.dim() != 2 or var.stride(1) == 1
+    ls_ld = 1 if ls is None else (ls.stride(0) if ls.numel() > 1 else 1)
+    if ld != group['dim'] or ls_ld != 1:
+      self._ck(self.lib.er_emb_group_set_row_pitch(group['handle'], ctypes.c_int64(ld), ctypes.c_int64(ls_ld)),
+               'er_emb_group_set_row_pitch')
 
   def emb_group_destroy(self, group):
     self.lib.er_emb_group_destroy(group['handle'])
@@ -1077,10 +1128,10 @@ class HipBackend(object):
                                                _stream()), 'er_emb_bwd_reduce_routed')
 
   def gather_rows(self, table, keys, n, key_sub, out):
-    assert keys.dtype == torch.int32 and table.dim() == 2 and table.is_contiguous()
-    self._ck(self.lib.er_gather_rows(_p(table), ctypes.c_int64(table.shape[0]), ctypes.c_int32(table.shape[1]),
-                                     _p(keys), ctypes.c_int64(int(n)), ctypes.c_int64(int(key_sub)), _p(out),
-                                     _stream()), 'er_gather_rows')
+    assert keys.dtype == torch.int32 and table.dim() == 2 and table.stride(1) == 1
+    self._ck(self.lib.er_gather_rows_ld(_p(table), ctypes.c_int64(table.stride(0)), ctypes.c_int64(table.shape[0]),
+                                        ctypes.c_int32(table.shape[1]), _p(keys), ctypes.c_int64(int(n)),
+                                        ctypes.c_int64(int(key_sub)), _p(out), _stream()), 'er_gather_rows_ld')
 
   def scatter_unique(self, keys, grads, n_unique, capacity, dim, dense):
     assert dense.dim() == 2 and dense.stride(1) == 1
@@ -1147,9 +1198,10 @@ class HipBackend(object):
     n = len(tables)
     descs = (DenseApplyDesc * n)()
     for i, (var, m, v, dense) in enumerate(tables):
-      assert var.is_contiguous() and dense.stride(1) == 1 and dense.shape[0] == var.shape[0]
+      assert var.stride(1) == 1 and dense.stride(1) == 1 and dense.shape[0] == var.shape[0]
+      assert all(t is None or t.stride() == var.stride() for t in (m, v))
       descs[i] = DenseApplyDesc(var.data_ptr(), None if m is None else m.data_ptr(), None if v is None else v.data_ptr(),
-                                dense.data_ptr(), dense.stride(0), var.shape[1], var.shape[0])
+                                dense.data_ptr(), dense.stride(0), var.shape[1], var.shape[0], var.stride(0))
     self._ck(self.lib.er_emb_dense_apply(descs, n, ctypes.c_int(opt_kind), _p(hyper), _stream()), 'er_emb_dense_apply')
 
   def emb_mark_touched(self, group):
@@ -1164,9 +1216,12 @@ class HipBackend(object):
     self._ck(self.lib.er_stream_copy(_p(src), _p(dst), ctypes.c_int64(nbytes), _stream()), 'er_stream_copy')
 
   def adam_decay_sweep(self, var, m, v, bitmap, total_rows, dim, hyper):
+    ld = var.stride(0) if var.dim() == 2 else dim
+    assert var.dim() != 2 or (m.stride() == var.stride() and v.stride() == var.stride() and var.stride(1) == 1)
     self._ck(
-        self.lib.er_adam_decay_sweep(_p(var), _p(m), _p(v), _p(bitmap), ctypes.c_int64(total_rows),
-                                     ctypes.c_int32(dim), _p(hyper), _stream()), 'er_adam_decay_sweep')
+        self.lib.er_adam_decay_sweep_ld(_p(var), _p(m), _p(v), _p(bitmap), ctypes.c_int64(total_rows),
+                                        ctypes.c_int32(dim), ctypes.c_int64(ld), _p(hyper), _stream()),
+        'er_adam_decay_sweep_ld')
 
   # -- K5 FM / wide
   def fm_fwd(self, x, F, D):
@@ -1267,15 +1322,26 @@ class HipBackend(object):
   # the heads) and er_emb_bwd_fused (finish + reduce + row update in one launch) - A/B switch
   fused_emb = os.environ.get('EASYREC_AMD_FUSED_EMB', '1') != '0'
 
-  def emb_front(self, groups, hyper, skip_one_row):
-    """-> False when the groups need the general path (nothing launched)."""
+  # the catch-up of lazy dense decay in registers (er_emb_fwd_lazy / er_emb_bwd_fused) instead of a launch of its own - A/B switch
+  defer_catch_up = os.environ.get('EASYREC_AMD_DEFER_CATCH_UP', '1') != '0'
+
+  def emb_front(self, groups, hyper, skip_one_row, defer=False):
+    """-> False when the groups need the general path (nothing launched).  defer: no catch-up launch - the step's lookup
+    must then be emb_fwd_lazy."""
     n = len(groups)
     gh = (ctypes.c_void_p * n)(*[g['handle'] for g in groups])
-    rc = self.lib.er_emb_front(gh, n, ctypes.c_int(int(bool(skip_one_row))), _p(hyper), _stream())
+    flags = (1 if skip_one_row else 0) | (2 if defer else 0)
+    rc = self.lib.er_emb_front(gh, n, ctypes.c_int(flags), _p(hyper), _stream())
     if rc == 3:
       return False
     self._ck(rc, 'er_emb_front')
     return True
+
+  def emb_fwd_lazy(self, plan, groups, hyper, sumsq_partials=None):
+    """emb_fwd whose lookups into the lazily decaying `groups` catch their rows up in registers (after emb_front(defer))."""
+    n = len(groups)
+    gh = (ctypes.c_void_p * n)(*[g['handle'] for g in groups])
+    self._ck(self.lib.er_emb_fwd_lazy(plan['handle'], gh, n, _p(hyper), _p(sumsq_partials), _stream()), 'er_emb_fwd_lazy')
 
   def emb_bwd_fused(self, groups, finish, opt_kind, hyper):
     """finish: group_grad_finish's descriptors, one per feature-group gradient buffer the groups' lookups write."""
@@ -1488,7 +1554,8 @@ class HipBackend(object):
     return KvJob(ids.data_ptr(), ids.numel(), kv['keys'].data_ptr(), kv['rows'].data_ptr(), kv['keys'].numel(),
                  kv['next_row'].data_ptr(), kv['var'].data_ptr(), kv['seed'], rows_out.data_ptr(),
                  kv['overflow'].data_ptr(), kv['capacity'], kv['dim'], kv['mean'], kv['stddev'], opt(limit),
-                 opt(kv['freq']), opt(kv['version']), opt(kv['n_keys']), opt(kv['step']), kv['filter_freq'], 0)
+                 opt(kv['freq']), opt(kv['version']), opt(kv['n_keys']), opt(kv['step']), kv['filter_freq'],
+                 kv['var'].stride(0) if kv['var'].stride(0) != kv['dim'] else 0)
 
   def kv_translate(self, kv, ids, rows_out, insert):
     """rows_out[i] = arena row of ids[i] (-1: no row); insert: a training lookup (unseen ids get a row, or - filtered
@@ -1972,6 +2039,7 @@ class HipBackend(object):
     if os.environ.get('EASYREC_AMD_ABSORB', '1') != '0':  # A/B switch: the absorbed regime of the replay
       self._ck(self.lib.er_emb_group_set_lr_max(group['handle'], _p(lr_hist[cap:])), 'er_emb_group_set_lr_max')
     group['last_step'], group['lr_hist'], group['step_counter'] = last_step, lr_hist, step_counter
+    self._set_row_pitch(group)
 
   def emb_flush_window(self, groups, n_windows, hyper, lag=0, max_blocks=0):
     """Rolling flush: this step's window (step mod n_windows) of up to 4 table groups, one launch.  lag 1: the

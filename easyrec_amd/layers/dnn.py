@@ -28,7 +28,7 @@ def _linear(x2, w, b, src=None, sink=None):
                               bias=None if b is None else b.detach(), bf16=bf16)
   wg = w.grad if (w.requires_grad and w.grad is not None) else None
   bg = b.grad if (b is not None and b.requires_grad and b.grad is not None) else None
-  return kernels.LinearFn.apply(x2, w, b, wg, bg, bf16, src, sink)
+  return kernels.LinearFn.apply(kernels.slot_gate(x2), w, b, wg, bg, bf16, src, sink)
 
 
 def dense(x, units, name, l2_reg=None, use_bias=True, kernel_initializer='glorot_uniform', head=False):

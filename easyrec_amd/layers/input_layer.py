@@ -109,6 +109,10 @@ class EmbeddingEngine(object):
     self.plan = None
     self.emb_groups = OrderedDict()  # dim -> C group handle
     self.storage = {}  # dim -> dict(var, m, v, bitmap)
+    # value of an optimizer slot on a row no update has touched: 0 for Adam's m / v; the estimator sets 'v' to Adagrad's
+    # initial_accumulator_value.  Rows of a hash-table arena that are freed (evict_stale) or not covered by a restored
+    # checkpoint (load_kv_table) go back to it - NOT to 0, or a resumed Adagrad run would take lr * sign(g) steps on new ids
+    self.slot_init = {'m': 0.0, 'v': 0.0}
     self._pending_tables = []
     self._anchor = torch.zeros(1, device=self.device, requires_grad=True)
     self.sumsq = None
@@ -220,7 +224,8 @@ class EmbeddingEngine(object):
     be = kernels.hip()
     dev = self.device
     lz = {
-        'last_step': torch.full((st['total_rows'],), -1, dtype=torch.int32, device=dev),
+        'last_step': st['last_step'] if st.get('last_step') is not None
+                     else torch.full((st['total_rows'],), -1, dtype=torch.int32, device=dev),
         'ukeys': torch.zeros(max(n_route, 1), dtype=torch.int32, device=dev),
         'n_unique': torch.zeros(1, dtype=torch.int32, device=dev),
     }
@@ -277,14 +282,50 @@ class EmbeddingEngine(object):
   def _lazy_states(self):
     return list(self._lazy.values())
 
+  @staticmethod
+  def record_floats(dim, n_slots, with_step):
+    """Floats per row record [var | slot ... | last_step | pad]: a power of two up to 16 floats, then whole 64-byte lines,
+    so that a record never straddles more lines than it needs (dim 16 + Adam + last_step: 49 -> 64 floats = 256 bytes;
+    dim 1: 4 floats = 16 bytes)."""
+    n = (1 + n_slots) * dim + (1 if with_step else 0)
+    if n <= 16:
+      p = 1
+      while p < n:
+        p *= 2
+      return max(p, 4 if dim % 4 == 0 else 1)
+    return (n + 15) // 16 * 16
+
   def _alloc_storage(self, total, dim, opt_kind, force_bitmap=False):
-    var = torch.empty(total, dim, dtype=torch.float32, device=self.device)
-    st = {'var': var, 'm': None, 'v': None, 'bitmap': None, 'total_rows': total}
-    if opt_kind in (kernels.OPT_ADAM, kernels.OPT_LAZY_ADAM):
-      st['m'] = torch.zeros_like(var)
-      st['v'] = torch.zeros_like(var)
-    elif opt_kind == kernels.OPT_ADAGRAD:
-      st['v'] = torch.zeros_like(var)
+    """The tables of one embedding dim.  Row records (the default): var, the optimizer slots and - under lazy dense
+    decay - the row's last_step lie side by side in ONE [total, ld] buffer, `var` / `m` / `v` / `last_step` being column
+    blocks of it, so a touched row is one contiguous HBM access per pass instead of three or four scattered ones
+    (er_emb_group_set_row_pitch).  TensorFlow keeps every slot in a variable of its own
+    (tf.train.AdamOptimizer._create_slots); state_dict / checkpoints convert at that boundary.  EASYREC_AMD_ROW_RECORDS=0:
+    plain [total, dim] arrays."""
+    adam = opt_kind in (kernels.OPT_ADAM, kernels.OPT_LAZY_ADAM)
+    n_slots = 2 if adam else (1 if opt_kind == kernels.OPT_ADAGRAD else 0)
+    with_step = bool(self.lazy_decay) and opt_kind == kernels.OPT_ADAM and not force_bitmap
+    st = {'var': None, 'm': None, 'v': None, 'bitmap': None, 'total_rows': total, 'last_step': None, 'rec': None}
+    if os.environ.get('EASYREC_AMD_ROW_RECORDS', '1') != '0' and n_slots > 0:
+      ld = self.record_floats(dim, n_slots, with_step)
+      rec = torch.zeros(total, ld, dtype=torch.float32, device=self.device)
+      st['rec'] = rec
+      st['var'] = rec[:, 0:dim]
+      if adam:
+        st['m'], st['v'] = rec[:, dim:2 * dim], rec[:, 2 * dim:3 * dim]
+      else:
+        st['v'] = rec[:, dim:2 * dim]
+      if with_step:
+        st['last_step'] = rec.view(torch.int32)[:, (1 + n_slots) * dim]
+        st['last_step'].fill_(-1)
+    else:
+      var = torch.empty(total, dim, dtype=torch.float32, device=self.device)
+      st['var'] = var
+      if adam:
+        st['m'] = torch.zeros_like(var)
+        st['v'] = torch.zeros_like(var)
+      elif opt_kind == kernels.OPT_ADAGRAD:
+        st['v'] = torch.zeros_like(var)
     if opt_kind == kernels.OPT_ADAM and (force_bitmap or not self.lazy_decay):
       st['bitmap'] = torch.zeros((total + 31) // 32, dtype=torch.int32, device=self.device)
     return st
@@ -326,6 +367,11 @@ class EmbeddingEngine(object):
   def init_table_values(self, name, view):
     """Fill `view` ([rows, dim]) with the initial values of table `name` (seeded per table name, so the
     single-GPU engine and every rank of the sharded engine draw the same table)."""
+    if not view.is_contiguous():  # a column block of the row records: draw into a plain array (the same values), then copy
+      tmp = torch.empty(view.shape, dtype=view.dtype, device=view.device)
+      self.init_table_values(name, tmp)
+      view.copy_(tmp)
+      return
     t = self.tables[name]
     init = t['init']
     gen = torch.Generator(device=self.device)
@@ -437,7 +483,9 @@ class EmbeddingEngine(object):
     self._join_window_flush()  # (a forward that no row update followed)
     if self.kv_jobs:
       self.translate_kv_ids()
+    lazy_lookup = False
     if self.lazy_decay and not self.inference and self._use_fused() and self._fused_front():
+      lazy_lookup = self._front_deferred
       self._start_window_flush()
     elif self.lazy_decay and not self.inference:
       # sort the step's ids once (reused by the backward), bring the rows it touches up to date, then look up
@@ -462,7 +510,10 @@ class EmbeddingEngine(object):
         probe[1].record()
       self._start_window_flush()
     if self.plan is not None:
-      be.emb_fwd(self.plan, self.sumsq if self.reg_lambda > 0 else None)
+      if lazy_lookup:
+        be.emb_fwd_lazy(self.plan, list(self.emb_groups.values()), self._clock[2], self.sumsq if self.reg_lambda > 0 else None)
+      else:
+        be.emb_fwd(self.plan, self.sumsq if self.reg_lambda > 0 else None)
     self._ran_version = version
 
   def group_tensor(self, gkey, requires_grad=True):
@@ -549,7 +600,11 @@ class EmbeddingEngine(object):
     """er_emb_front over all table groups (leader first); remembers whether the groups are eligible."""
     be = kernels.hip()
     grps = list(self.emb_groups.values())
-    ok = be.emb_front(grps, self._clock[2] if self.lazy_decay else None, True)
+    # lazy dense decay in closed form: no catch-up launch - the lookup and the row update evaluate a row's pending steps
+    # in registers (er_emb_fwd_lazy)
+    defer = bool(self.lazy_decay and getattr(be, 'defer_catch_up', False) and getattr(self, '_decay_tables', None) is not None)
+    ok = be.emb_front(grps, self._clock[2] if self.lazy_decay else None, True, defer=defer)
+    self._front_deferred = bool(ok and defer)
     if self._fused is None:
       self._fused = bool(ok)
       if not ok:
@@ -737,12 +792,13 @@ class EmbeddingEngine(object):
       src = src[order].to(self.device)
       n = src.numel()
       t = self.tables[name]
-      views = [self.table_view(name)] + [v for v in (self.slot_view(name, 'm'), self.slot_view(name, 'v')) if v is not None]
+      views = [(self.table_view(name), 0.0)] + [(self.slot_view(name, sl), self.slot_init[sl]) for sl in ('m', 'v')
+                                                if self.slot_view(name, sl) is not None]
       # (lazy decay's last_step needs no move: after the flush above every row of the group carries the same stamp)
-      for v in views:
+      for v, fresh in views:
         moved = v[src].clone()
         v[:n] = moved
-        v[n:old_used].zero_()
+        v[n:old_used].fill_(fresh)
       be.kv_rebuild(kv, keys, new_rows, freq, version)
     return evicted
 
@@ -811,7 +867,7 @@ class EmbeddingEngine(object):
     for sl in ('m', 'v'):
       sv = self.slot_view(name, sl)
       if sv is not None:
-        sv.zero_()
+        sv.fill_(self.slot_init[sl])
         if sl in slot_values:
           sv[:n] = torch.as_tensor(np.asarray(slot_values[sl], dtype=np.float32)).to(self.device)
 

@@ -46,6 +46,7 @@ class DIN(object):
       assert q_dim < E, 'the embedding size of target item is larger than the one of sequence'
     q_att = query if q_dim == E else torch.nn.functional.pad(query, (0, E - q_dim))
     keys = keys if keys.is_contiguous() else keys.contiguous()  # (a batch shorter than max_seq_len is a slice)
+    keys = kernels.slot_gate(keys)  # (DINConcatFn and DINPoolFn share the history's gradient buffer)
     din_all = kernels.DINConcatFn.apply(q_att, keys)  # [B, L, 4E]
     scores = self.din_layer(din_all, training=training).reshape(B, L)
     norm = self.config.attention_normalizer

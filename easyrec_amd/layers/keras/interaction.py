@@ -81,7 +81,8 @@ class Cross(object):
     if self._preactivation is not None:
       u = self._preactivation(u + bias if bias is not None else u)
       bias = None
-    return kernels.CrossV2EpilogueFn.apply(x0, x, u, bias, self._diag_scale, None if bias is None else bias.grad,
+    x0g = kernels.slot_gate(x0)
+    return kernels.CrossV2EpilogueFn.apply(x0g, x0g if x is x0 else kernels.slot_gate(x), u, bias, self._diag_scale, None if bias is None else bias.grad,
                                            kernels.grad_sink_of(x0))
 
 

@@ -34,6 +34,7 @@ def target_attention(dnn_config, deep_fea, name, l2_reg, is_training, need_key_f
       hist = dnn.dense(hist, E, 'sequence_fea_transform_layer_' + name)
   assert cur_id.shape[1] == E, 'DIN: key dim %d != history dim %d (set allow_key_transform)' % (cur_id.shape[1], E)
   hist = hist if hist.is_contiguous() else hist.contiguous()  # (a batch whose longest sequence is below max_seq_len)
+  hist = kernels.slot_gate(hist)  # (DINConcatFn and DINPoolFn share the history's gradient buffer)
   din_layer = dnn.DNN(dnn_config, l2_reg, name, is_training, last_layer_no_activation=True,
                       last_layer_no_batch_norm=True)
   if din_layer.can_fold_din() and len(din_layer.hidden_units) > 1:

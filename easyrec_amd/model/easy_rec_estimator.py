@@ -167,8 +167,10 @@ class EasyRecEstimator(object):
     self.ctx.building = False
     self.engine.finalize(self.opt_emb.kind)
     if self.opt_emb.kind == kernels.OPT_ADAGRAD:
+      # (also what a freed / never-owned arena row of a hash-table table goes back to: EmbeddingEngine.slot_init)
+      self.engine.slot_init['v'] = float(getattr(self.opt_emb, 'initial_accumulator_value', 0.1))
       for st in self.engine.storage.values():
-        st['v'].fill_(getattr(self.opt_emb, 'initial_accumulator_value', 0.1))
+        st['v'].fill_(self.engine.slot_init['v'])
     self.varstore.pack(self._extra_grad_floats())
     if self.ctx.dense_dtype == 'bf16' and self.device.type == 'cuda':
       self._bf16 = kernels.hip().bf16_enable(self.varstore)  # bf16 weight shadows for er_gemm_bf16_nt

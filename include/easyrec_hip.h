@@ -233,6 +233,16 @@ int er_emb_bwd_reduce(er_emb_group* group, uint32_t* unique_keys, float* unique_
  *     form for the concurrent launch - ~2 workgroups per CU leave the CUs' wave slots and LDS to the step. */
 int er_emb_group_enable_lazy_decay(er_emb_group* group, int32_t* last_step, const float* lr_t_history,
                                    const int64_t* step_counter);
+/* Row records.  By default var, m, v are three plain [total_rows, dim] arrays and last_step an int32 array of its own:
+ * every touched row costs three or four scattered HBM accesses per pass.  er_emb_group_set_row_pitch(group, ld,
+ * last_step_ld) tells the group that consecutive rows of var / m / v lie ld >= dim floats apart and consecutive rows'
+ * last_step last_step_ld int32 words apart - e.g. ONE record [var(dim) | m(dim) | v(dim) | last_step | pad] per row with
+ * var = rec, m = rec + dim, v = rec + 2 dim, last_step = (int32*)(rec + 3 dim), ld = last_step_ld = the record size: a
+ * touched row is then one contiguous, aligned access (TF keeps each slot in a variable of its own -
+ * tf.train.AdamOptimizer._create_slots; the layout is converted at the state_dict / checkpoint boundary only).  Call
+ * after er_emb_group_create (and again if the arrays move); lookups read such a table through er_lookup_desc.table_ld.
+ * 16-byte lanes (dim % 4 == 0) need ld % 4 == 0 and 16-byte aligned bases. */
+int er_emb_group_set_row_pitch(er_emb_group* group, int64_t ld, int64_t last_step_ld);
 int er_emb_group_set_lr_max(er_emb_group* group, const float* lr_max_history);
 int er_emb_flush_window(er_emb_group* const* groups_host, int n, int32_t n_windows, int32_t lag, int32_t max_blocks,
                         const er_opt_hyper* hyper,
@@ -277,6 +287,9 @@ int er_emb_sweep_untouched(er_emb_group* group, const er_opt_hyper* hyper, er_st
 int er_adam_decay_sweep(float* var, float* m, float* v, uint32_t* touched_bitmap,
                         int64_t total_rows, int32_t dim, const er_opt_hyper* hyper,
                         er_stream_t stream);
+/* the same sweep over rows at a pitch of ld >= dim floats (row records: er_emb_group_set_row_pitch) */
+int er_adam_decay_sweep_ld(float* var, float* m, float* v, uint32_t* touched_bitmap, int64_t total_rows, int32_t dim,
+                           int64_t ld, const er_opt_hyper* hyper, er_stream_t stream);
 /* Bandwidth probe: dst[0:bytes] = src[0:bytes] with the sweep's access pattern (16 B/lane, nontemporal,
  * grid-stride).  Moves exactly 2*bytes of HBM traffic: calibrates rocprofv3 FETCH_SIZE/WRITE_SIZE and
  * gives the achievable copy bandwidth quoted next to the 8 TB/s spec peak. */
@@ -345,7 +358,22 @@ int er_group_grad_finish(const er_grad_group* groups_host, int n, er_stream_t st
  *     lookup's `out` must be the dout of one of them) is evaluated while the sorted entries are gathered, a run of equal
  *     keys is reduced by the workgroup that holds its first entry, and the one-row tables are reduced by columns.  The
  *     gradient buffers themselves are left unfinished.  First use uploads a plan: call once outside stream capture. */
-int er_emb_front(er_emb_group* const* groups, int n, int skip_one_row, const er_opt_hyper* hyper, er_stream_t stream);
+#define ER_FRONT_SKIP_ONE_ROW 1    /* `flags` of er_emb_front: the skip_one_row mode above */
+#define ER_FRONT_DEFER_CATCH_UP 2 /* no catch-up launch: see er_emb_fwd_lazy */
+int er_emb_front(er_emb_group* const* groups, int n, int flags, const er_opt_hyper* hyper, er_stream_t stream);
+/* Round 5: the catch-up of TF-exact Adam's lazy dense decay (tf.train.AdamOptimizer._apply_sparse decays every row at
+ * every step, builders/optimizer_builder.py:61-66) WITHOUT a launch and without a write.  After
+ * er_emb_front(ER_FRONT_DEFER_CATCH_UP) the rows of the step still carry their pending decay-only steps;
+ * er_emb_fwd_lazy = er_emb_fwd in which a lookup into one of `groups` (lazy decay, closed-form replay) evaluates the
+ * pending steps of every row it reads in registers - from the row's record: var, m, v, last_step, one contiguous access
+ * under er_emb_group_set_row_pitch - and sums the caught-up values; nothing is stored.  er_emb_bwd_fused of the same
+ * step repeats the evaluation on the same bits right before it applies the row's gradient, so var / m / v / last_step
+ * after the step are exactly those of catch-up launch + lookup + update (compat/embedding_ops.py:37-162 for the lookup,
+ * compat/adam_s.py:185-213 for the row arithmetic), while a unique row costs one record read in the lookup and one
+ * read + one write in the update instead of the 13 scattered accesses of the three-launch form.  Lookups into tables of
+ * no listed group are plain er_emb_fwd lookups.  First use uploads a lookup -> group map: call once outside capture. */
+int er_emb_fwd_lazy(er_emb_plan* plan, er_emb_group* const* groups, int n, const er_opt_hyper* hyper,
+                    float* sumsq_partials, er_stream_t stream);
 int er_emb_bwd_fused(er_emb_group* const* groups, int n, const er_grad_group* finish_host, int n_finish, int opt_kind,
                      const er_opt_hyper* hyper, er_stream_t stream);
 /* out[b, sum(widths[<p]) + j] = parts[p][b * lds[p] + j]: tf.concat(values, axis=1) of n <= 8 row-major blocks
@@ -443,7 +471,8 @@ typedef struct {
   int32_t* n_keys;
   const int64_t* step;
   int32_t filter_freq;
-  int32_t reserved;
+  int32_t table_ld; /* floats between consecutive arena rows of var (0 = dim): the arena is a column block of the table
+                       group's row records (er_emb_group_set_row_pitch) */
 } er_kv_job;
 /* one job handed over by value from the host (n_limit must be NULL) */
 int er_kv_translate_job(const er_kv_job* job, int insert, er_stream_t stream);
@@ -925,6 +954,7 @@ typedef struct er_dense_apply_desc {
   int32_t ld;
   int32_t dim;
   int64_t rows;
+  int64_t table_ld;   /* floats between consecutive rows of var / m / v (0 = dim: plain [rows, dim] arrays) */
 } er_dense_apply_desc;
 int er_emb_group_set_routing(er_emb_group* group, int32_t world, int64_t shard_stride,
                              const int64_t* local_base_host);
@@ -955,6 +985,9 @@ int er_emb_route(er_emb_group* group, uint32_t* unique_keys, int32_t* n_unique,
 int er_emb_bwd_reduce_routed(er_emb_group* group, float* unique_grads, int32_t ld, er_stream_t stream);
 int er_gather_rows(const float* table, int64_t table_rows, int32_t dim, const uint32_t* keys, int64_t n,
                    int64_t key_sub, float* out, er_stream_t stream);
+/* ... from a table whose rows lie table_ld >= dim floats apart */
+int er_gather_rows_ld(const float* table, int64_t table_ld, int64_t table_rows, int32_t dim, const uint32_t* keys,
+                      int64_t n, int64_t key_sub, float* out, er_stream_t stream);
 int er_scatter_unique(const uint32_t* keys, const float* grads, const int32_t* n_unique,
                       int64_t capacity, int32_t dim, float* dense, int32_t dense_stride,
                       er_stream_t stream);

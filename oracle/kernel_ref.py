@@ -527,7 +527,17 @@ class RefBackend(object):
 
   fused_emb = True  # layers/input_layer.py: the fused single-GPU step's host logic runs on the stand-in too
 
-  def emb_front(self, groups, hyper, skip_one_row):
+  defer_catch_up = True
+
+  def emb_fwd_lazy(self, plan, groups, hyper, sumsq_partials=None):
+    """HipBackend.emb_fwd_lazy evaluates the pending decay of the rows it reads in registers and stores nothing; the
+    stand-in brings them current in place (what the row update of the same step does anyway), then looks up."""
+    lazy = [g for g in groups if g.get('last_step') is not None]
+    if lazy:
+      self.emb_catch_up_multi(lazy, [g['_front_keys'][0] for g in lazy], [g['_front_keys'][1] for g in lazy], hyper)
+    self.emb_fwd(plan, sumsq_partials)
+
+  def emb_front(self, groups, hyper, skip_one_row, defer=False):
     """easyrec_amd.kernels.HipBackend.emb_front restated with the general entry points: route every group (a follower of
     a shared sort after its leader), then bring the rows of the step current.  Eligibility as er_emb_front: dense-mode
     lookups on their own tables, closed-form (or no) lazy decay."""
@@ -548,8 +558,10 @@ class RefBackend(object):
         self.emb_route(g, uk, nu, None, None)
         uks.append(uk)
         nus.append(nu)
+    for g, uk, nu in zip(groups, uks, nus):
+      g['_front_keys'] = (uk, nu)
     lazy = [(g, uk, nu) for g, uk, nu in zip(groups, uks, nus) if g.get('last_step') is not None]
-    if lazy:
+    if lazy and not defer:
       self.emb_catch_up_multi([x[0] for x in lazy], [x[1] for x in lazy], [x[2] for x in lazy], hyper)
     return True
 

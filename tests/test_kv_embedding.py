@@ -309,3 +309,54 @@ def test_kv_tag_features_match_the_oracle_on_the_gpu():
   #  row over the three steps; the others put an example on a ReLU tie of an expert, whose pre-activations are not
   #  normalised - BatchNorm on the moving statistics, as the reference's MMoE - and a few rows then differ by O(lr))
   _run('cuda:0', config='mmoe_kv_taobao_small.config', n_kv=4, row_tol=2e-3, data_seed=16)
+
+
+def _adagrad_kv_config(tmp_path):
+  """deepfm_kv_criteo_small with an Adagrad embedding optimizer (initial_accumulator_value 0.2)"""
+  text = open(os.path.join(ROOT, 'configs', 'deepfm_kv_criteo_small.config')).read()
+  head = ('train_config {\n  optimizer_config {\n    adagrad_optimizer {\n      learning_rate {\n        '
+          'constant_learning_rate {\n          learning_rate: 0.05\n        }\n      }\n      '
+          'initial_accumulator_value: 0.2\n    }\n  }\n')
+  assert text.count('train_config {\n') == 1
+  path = os.path.join(str(tmp_path), 'deepfm_kv_adagrad.config')
+  with open(path, 'w') as f:
+    f.write(text.replace('train_config {\n', head))
+  return config_util.get_configs_from_pipeline_file(path)
+
+
+def _adagrad_restore_then_train(device, tmp_path):
+  """Round-4 advisor finding: a restore (and an eviction) reset the unused arena rows' Adagrad accumulator to 0 instead of
+  initial_accumulator_value, so ids created AFTER the restore took lr * sign(g) steps.  A restored twin must continue
+  exactly like the uninterrupted run - on a batch full of ids neither has seen."""
+  from easyrec_amd import kernels
+  from easyrec_amd.input.criteo_synthetic import SyntheticCriteo
+  from easyrec_amd.model.easy_rec_estimator import EasyRecEstimator
+  cfg = _adagrad_kv_config(tmp_path)
+  est = EasyRecEstimator(cfg, device=device, batch_size=64, seed=4).build()
+  assert est.opt_emb.kind == kernels.OPT_ADAGRAD and abs(est.engine.slot_init['v'] - 0.2) < 1e-7
+  gen = SyntheticCriteo(cfg.data_config, est.feature_configs, batch_size=64, seed=21)
+  for _ in range(2):
+    est.train_step(gen.next_batch())
+  twin = EasyRecEstimator(cfg, device=device, batch_size=64, seed=4).build()
+  twin.load_state_dict(est.state_dict(slots=True))
+  fresh = SyntheticCriteo(cfg.data_config, est.feature_configs, batch_size=64, seed=77).next_batch()  # new ids
+  est.train_step(fresh)
+  twin.train_step(fresh)
+  a, b = est.state_dict(slots=True), twin.state_dict(slots=True)
+  n_new = 0
+  for name in est.engine.kv_tables:
+    assert np.array_equal(a[name + '/keys'], b[name + '/keys']), name
+    assert np.array_equal(a[name + '/v'], b[name + '/v']), name   # the accumulators of old AND new ids
+    assert np.array_equal(a[name], b[name]), name
+    n_new += int((np.abs(a[name + '/v'] - 0.2).max(axis=1) > 0).sum())
+    assert float(a[name + '/v'].min()) >= 0.2 - 1e-7, name        # no accumulator started from 0
+  assert n_new > 50
+
+
+def test_adagrad_kv_restore_then_train_on_the_stand_in_backend(ref_backend, tmp_path):
+  _adagrad_restore_then_train('cpu', tmp_path)
+
+
+@pytest.mark.gpu
+def test_adagrad_kv_restore_then_train_on_the_gpu(tmp_path):
+  _adagrad_restore_then_train('cuda:0', tmp_path)
