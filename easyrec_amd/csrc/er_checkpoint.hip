@@ -182,18 +182,22 @@ int er_load_kv_embed(const char* ckpt_path, const char* var_name, int32_t task_i
 // TensorFlow's tensor-bundle entries and table blocks (tensorflow/core/lib/hash/crc32c.h; the files a TF Saver writes for
 // the dense variables, reference model/easy_rec_model.py:219-351 restores from them) - easyrec_amd/utils/tensor_bundle.py.
 uint32_t er_crc32c(uint32_t crc, const void* data, int64_t n) {
-  static uint32_t table[8][256];
-  static bool ready = false;
-  if (!ready) {
-    for (uint32_t i = 0; i < 256; ++i) {
-      uint32_t c = i;
-      for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
-      table[0][i] = c;
+  // (a function-local static with a constructor: initialised once, thread-safely, on first use - the first calls may come
+  // from two threads at once, e.g. an asynchronous checkpoint writer next to a reader)
+  struct Tables {
+    uint32_t t[8][256];
+    Tables() {
+      for (uint32_t i = 0; i < 256; ++i) {
+        uint32_t c = i;
+        for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+        t[0][i] = c;
+      }
+      for (uint32_t i = 0; i < 256; ++i)
+        for (int q = 1; q < 8; ++q) t[q][i] = (t[q - 1][i] >> 8) ^ t[0][t[q - 1][i] & 0xFFu];
     }
-    for (uint32_t i = 0; i < 256; ++i)
-      for (int t = 1; t < 8; ++t) table[t][i] = (table[t - 1][i] >> 8) ^ table[0][table[t - 1][i] & 0xFFu];
-    ready = true;
-  }
+  };
+  static const Tables tables;
+  const uint32_t (*table)[256] = tables.t;
   const unsigned char* p = static_cast<const unsigned char*>(data);
   uint32_t c = ~crc;
   while (n >= 8) {  // slicing-by-8

@@ -1641,7 +1641,9 @@ class HipBackend(object):
   def kv_export_all(self, kv):
     """Every key the map holds, ascending: (keys, arena rows (-1: no row yet), freq, version) (host sync)."""
     slots, dev = kv['keys'].numel(), kv['keys'].device
-    n_max = slots // 2 + 1
+    # (one record per map slot: a launch that crosses the load-factor threshold may claim more than slots / 2 of them while
+    # raising only the sticky overflow flag - the export must stay in bounds whatever the map holds)
+    n_max = slots
     keys = torch.empty(n_max, dtype=torch.int64, device=dev)
     rows, freq, version = (torch.empty(n_max, dtype=torch.int32, device=dev) for _ in range(3))
     count = torch.zeros(1, dtype=torch.int32, device=dev)

@@ -148,13 +148,14 @@ def save(est, ckpt_path):
   engine = est.engine
   rank, world = getattr(engine, 'rank', 0), getattr(engine, 'world', 1)
   engine.flush_decay()
-  if hasattr(engine, 'evict_stale'):
-    engine.evict_stale(est.global_step)  # ev_params.steps_to_live: eviction happens when a checkpoint is written
   if est.device.type == 'cuda':
     torch.cuda.synchronize()
-  # an overflowed fixed-capacity exchange voids the steps since: never persist tables it may have touched
+  # an overflowed fixed-capacity exchange or hash-table arena voids the steps since: never persist tables it may have
+  # touched - and never EXPORT an overflowed map (evict_stale -> er_kv_export_all sizes its buffers for a map within bounds)
   if hasattr(engine, 'check_overflow'):
     engine.check_overflow()
+  if hasattr(engine, 'evict_stale'):
+    engine.evict_stale(est.global_step)  # ev_params.steps_to_live: eviction happens when a checkpoint is written
   os.makedirs(os.path.dirname(os.path.abspath(ckpt_path)) or '.', exist_ok=True)
   slots = _SLOT_NAMES[est.opt_emb.kind]
   for name, is_shard in _engine_tables(engine):

@@ -248,7 +248,10 @@ def write_bundle(prefix, tensors):
   names = sorted(tensors, key=lambda s: s.encode('utf-8'))
   items = [(b'', _header_proto())]
   offset = 0
-  with open(data_file(prefix), 'wb') as f:
+  # (both files are written under temporary names and renamed when complete: a crash mid-save leaves the previous
+  # checkpoint of this prefix - or nothing - never a torn bundle)
+  tmp_data, tmp_index = data_file(prefix) + '.tmp', prefix + '.index.tmp'
+  with open(tmp_data, 'wb') as f:
     for name in names:
       a = np.asarray(tensors[name])
       a = a if a.ndim == 0 else np.ascontiguousarray(a)  # (ascontiguousarray would turn a scalar into shape [1])
@@ -258,7 +261,11 @@ def write_bundle(prefix, tensors):
       f.write(raw)
       items.append((name.encode('utf-8'), _entry_proto(_DT[a.dtype], a.shape, offset, len(raw), _mask(_crc32c(raw)))))
       offset += len(raw)
-  _write_table(prefix + '.index', items)
+    f.flush()
+    os.fsync(f.fileno())
+  _write_table(tmp_index, items)
+  os.replace(tmp_data, data_file(prefix))
+  os.replace(tmp_index, prefix + '.index')
 
 
 def read_bundle(prefix):
@@ -286,7 +293,26 @@ def read_bundle(prefix):
 
 
 def write_checkpoint_state(ckpt_path):
-  """The `checkpoint` text proto tf.train.latest_checkpoint reads (CheckpointState: model_checkpoint_path + history)."""
+  """The `checkpoint` text proto tf.train.latest_checkpoint reads (CheckpointState: model_checkpoint_path + the history
+  all_model_checkpoint_paths, oldest first, which tf.train.Saver keeps and which its max_to_keep clean-up walks).  Call it
+  AFTER the bundle files exist: written to a temporary file and renamed, so the state never names a checkpoint that is not
+  complete.  Earlier entries whose files are gone are dropped, as the Saver's own recovery does."""
   folder, name = os.path.split(os.path.abspath(ckpt_path))
-  with open(os.path.join(folder, 'checkpoint'), 'w') as f:
-    f.write('model_checkpoint_path: "%s"\nall_model_checkpoint_paths: "%s"\n' % (name, name))
+  path = os.path.join(folder, 'checkpoint')
+  history = []
+  if os.path.exists(path):
+    import re
+    for line in open(path):
+      m = re.match(r'\s*all_model_checkpoint_paths:\s*"(.*)"\s*$', line)
+      if m and m.group(1) != name and m.group(1) not in history:
+        old = m.group(1) if os.path.isabs(m.group(1)) else os.path.join(folder, m.group(1))
+        if os.path.exists(old + '.index'):
+          history.append(m.group(1))
+  history.append(name)
+  with open(path + '.tmp', 'w') as f:
+    f.write('model_checkpoint_path: "%s"\n' % name)
+    for h in history:
+      f.write('all_model_checkpoint_paths: "%s"\n' % h)
+    f.flush()
+    os.fsync(f.fileno())
+  os.replace(path + '.tmp', path)

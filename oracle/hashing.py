@@ -116,7 +116,7 @@ def _len16(u, v, mul):
 
 
 def fingerprint64_py(s):
-  """<= 32-byte branches of farmhashna::Hash64 in pure Python."""
+  """farmhashna::Hash64 (every length class) in pure Python."""
   if isinstance(s, str):
     s = s.encode('utf-8')
   n = len(s)
@@ -146,4 +146,67 @@ def fingerprint64_py(s):
     c = (f64(n - 8) * mul) & _M
     d = (f64(n - 16) * _K2) & _M
     return _len16((_rot((a + b) & _M, 43) + _rot(c, 30) + d) & _M, (a + _rot((b + _K2) & _M, 18) + c) & _M, mul)
-  raise NotImplementedError('pure-python transcription covers <= 32 bytes')
+  if n <= 64:  # farmhashna::HashLen33to64
+    mul = (_K2 + n * 2) & _M
+    a = (f64(0) * _K2) & _M
+    b = f64(8)
+    c = (f64(n - 8) * mul) & _M
+    d = (f64(n - 16) * _K2) & _M
+    y = (_rot((a + b) & _M, 43) + _rot(c, 30) + d) & _M
+    z = _len16(y, (a + _rot((b + _K2) & _M, 18) + c) & _M, mul)
+    e = (f64(16) * mul) & _M
+    f = f64(24)
+    g = ((y + f64(n - 32)) * mul) & _M
+    h = ((z + f64(n - 24)) * mul) & _M
+    return _len16((_rot((e + f) & _M, 43) + _rot(g, 30) + h) & _M, (e + _rot((f + a) & _M, 18) + g) & _M, mul)
+
+  # farmhashna::Hash64 for more than 64 bytes: 56 bytes of state (v, w, x, y, z) over 64-byte blocks, the LAST 64 bytes of
+  # the input (overlapping the final block) mixed in with a multiplier derived from the state
+  def weak32(o, a, b):  # WeakHashLen32WithSeeds over the 32 bytes at offset o
+    w_, x_, y_, z_ = f64(o), f64(o + 8), f64(o + 16), f64(o + 24)
+    a = (a + w_) & _M
+    b = _rot((b + a + z_) & _M, 21)
+    c = a
+    a = (a + x_ + y_) & _M
+    b = (b + _rot(a, 44)) & _M
+    return (a + z_) & _M, (b + c) & _M
+
+  def shift_mix(v):
+    return v ^ (v >> 47)
+
+  seed = 81
+  x = seed
+  y = (seed * _K1 + 113) & _M
+  z = (shift_mix((y * _K2 + 113) & _M) * _K2) & _M
+  v, w = (0, 0), (0, 0)
+  x = (x * _K2 + f64(0)) & _M
+  end = ((n - 1) // 64) * 64
+  last64 = end + ((n - 1) & 63) - 63
+  assert last64 == n - 64
+  o = 0
+  while True:
+    x = (_rot((x + y + v[0] + f64(o + 8)) & _M, 37) * _K1) & _M
+    y = (_rot((y + v[1] + f64(o + 48)) & _M, 42) * _K1) & _M
+    x ^= w[1]
+    y = (y + v[0] + f64(o + 40)) & _M
+    z = (_rot((z + w[0]) & _M, 33) * _K1) & _M
+    v = weak32(o, (v[1] * _K1) & _M, (x + w[0]) & _M)
+    w = weak32(o + 32, (z + w[1]) & _M, (y + f64(o + 16)) & _M)
+    z, x = x, z
+    o += 64
+    if o == end:
+      break
+  mul = (_K1 + ((z & 0xff) << 1)) & _M
+  o = last64
+  w = ((w[0] + ((n - 1) & 63)) & _M, w[1])
+  v = ((v[0] + w[0]) & _M, v[1])
+  w = ((w[0] + v[0]) & _M, w[1])
+  x = (_rot((x + y + v[0] + f64(o + 8)) & _M, 37) * mul) & _M
+  y = (_rot((y + v[1] + f64(o + 48)) & _M, 42) * mul) & _M
+  x ^= (w[1] * 9) & _M
+  y = (y + v[0] * 9 + f64(o + 40)) & _M
+  z = (_rot((z + w[0]) & _M, 33) * mul) & _M
+  v = weak32(o, (v[1] * mul) & _M, (x + w[0]) & _M)
+  w = weak32(o + 32, (z + w[1]) & _M, (y + f64(o + 16)) & _M)
+  z, x = x, z
+  return _len16((_len16(v[0], w[0], mul) + ((shift_mix(y) * _K0) & _M) + z) & _M, (_len16(v[1], w[1], mul) + x) & _M, mul)

@@ -268,3 +268,10 @@ def test_tensor_bundle_files(tmp_path, built_lib):
   open(prefix + '.index', 'wb').write(bytes(idx))
   with pytest.raises(ValueError, match='checksum'):
     tb._read_table(prefix + '.index')
+
+
+@pytest.mark.parametrize('optimizer', [None, 'lazy'])
+def test_written_files_read_back_through_the_reference_format_on_the_stand_in_backend(ref_backend, tmp_path, optimizer):
+  """the -m gpu test of tests/test_files_to_gpu.py (files a run writes against the reference's formats), host logic here"""
+  from test_files_to_gpu import written_files_check
+  written_files_check('cpu', tmp_path, optimizer)

@@ -260,3 +260,64 @@ def test_hash_table_tables_save_restore_continue_on_the_gpu(tmp_path):
   assert set(sa) == set(sb)
   for k in sa:
     assert np.array_equal(sa[k], sb[k]), k
+
+
+@pytest.mark.parametrize('optimizer', [None, 'lazy'])
+def test_what_a_gpu_run_writes_reads_back_through_the_reference_format(tmp_path, optimizer):
+  written_files_check(DEV, tmp_path, optimizer)
+
+
+def written_files_check(device, tmp_path, optimizer):
+  """f2, the other half: not save -> own restore, but the FILES a cuda:0 run writes against the reference's formats.
+  Every `embed-<var>-part-0.bin` (tables and their Adam slots) is read with the reference's re-shard logic
+  (`_load_embed`, compat/embedding_parallel_saver.py:140-168: tests/_ckpt_readers.ref_load_embed, held to the reference's
+  own function by tests/test_checkpoint_pins.py) - as the 1 worker that wrote it and as worker r of 3 - and must hold
+  exactly state_dict()'s rows; `<ckpt>.index` + `.data-00000-of-00001` are read by an independent tensor-bundle reader
+  (own table parser, the protobuf runtime, a pure-python CRC-32C: model/easy_rec_model.py:219-351 reads them with
+  tf.train.NewCheckpointReader) and must hold every dense variable, its Adam slots and global_step under their TF names."""
+  from _ckpt_readers import read_bundle, ref_load_embed
+  from test_embedding_parallel import _cfg_and_batches
+  from easyrec_amd.utils import checkpoint
+  B = 16
+  cfg, batches = _cfg_and_batches(B, 3, optimizer)
+  est = EasyRecEstimator(cfg, device=device, batch_size=B, seed=3).build()
+  _train(est, batches)
+  ckpt = os.path.join(str(tmp_path), 'model.ckpt-3')
+  checkpoint.save(est, ckpt)
+  state = est.state_dict(slots=True)
+  slot_names = {'m': 'Adam', 'v': 'Adam_1'}
+  folder = ckpt + '-embedding'
+  n_files = 0
+  for name, t in est.engine.tables.items():
+    for key, var in [(name, name)] + [(name + '/' + s, name + '/' + suffix) for s, suffix in slot_names.items()]:
+      want = state[key]
+      rows, dim = want.shape
+      fv = 'embed-' + (var + ':0').replace('/', '__')
+      path = os.path.join(folder, fv + '-part-0.bin')
+      assert os.path.getsize(path) == rows * dim * 4, path
+      n_files += 1
+      assert np.array_equal(ref_load_embed(folder, fv, dim, rows, 0, 1), want), key
+      n3 = (rows + 2) // 3
+      for r in range(3):  # the same file re-sharded for a world of 3, as a reference worker would load it
+        got = ref_load_embed(folder, fv, dim, n3, r, 3)
+        mine = want[r::3]
+        assert np.array_equal(got[:len(mine)], mine) and not got[len(mine):].any(), (key, r)
+  assert n_files == 3 * len(est.engine.tables) and n_files == len(os.listdir(folder))
+  bundle = read_bundle(ckpt)
+  assert int(bundle['global_step']) == 3 and bundle['global_step'].dtype == np.int64
+  dense = est.varstore.state_dict()
+  assert len(dense) > 10
+  for k, v in dense.items():
+    assert np.array_equal(bundle[k], np.asarray(v)), k
+  vs = est.varstore
+  n_slots = 0
+  for name in vs.trainable_names():
+    o, n = vs._offsets[name]
+    for s, suffix in slot_names.items():
+      want = vs.slots[s][o:o + n].view(vs._vars[name]['tensor'].shape).cpu().numpy()
+      assert np.array_equal(bundle[name + '/' + suffix], want), (name, suffix)
+      n_slots += 1
+  assert n_slots == 2 * len(vs.trainable_names()) and any(np.abs(bundle[k]).max() > 0 for k in bundle if k.endswith('/Adam_1'))
+  # TF variable names of the reference's graph (layers/dnn.py:57-79 under the model's scopes), not names of this package
+  assert any(k.endswith('/kernel') for k in bundle) and any(k.endswith('/bias') for k in bundle) and \
+      any(k.endswith('/moving_mean') or k.endswith('/moving_variance') for k in bundle), sorted(bundle)[:8]

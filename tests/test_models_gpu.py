@@ -126,7 +126,8 @@ def test_xdeepfm_backbone_matches_oracle():
 def test_dcn_v2_bf16_dense_tracks_the_fp32_oracle():
   """BASELINE config 3: bf16 MFMA for the dense contractions (operands rounded to bf16, fp32 accumulate),
   fp32 embeddings and master weights.  Against the fp32 oracle the loss must agree to bf16 resolution
-  (2^-8 relative per operand; tolerance 2e-2 on the loss, stated here) and training must progress."""
+  (2^-8 relative per operand, averaged over the batch and the contraction: tolerance 1e-3 on the loss, stated here - the
+  measured difference is ~5e-5, the 2e-2 of earlier rounds hid regressions) and training must progress."""
   cfg = _cfg('dcn_v2_criteo_small.config', lazy=True)
   B = 256
   est = EasyRecEstimator(cfg, device=DEV, batch_size=B, seed=7, dense_dtype='bf16').build()
@@ -135,7 +136,7 @@ def test_dcn_v2_bf16_dense_tracks_the_fp32_oracle():
   b = gen.next_batch()
   est.train_step(b)
   got, exp = est.loss_values(), orc.train_step(b)
-  assert abs(got['cross_entropy_loss'] - exp['cross_entropy_loss']) <= 2e-2 * exp['cross_entropy_loss'], (got, exp)
+  assert abs(got['cross_entropy_loss'] - exp['cross_entropy_loss']) <= 1e-3 * exp['cross_entropy_loss'], (got, exp)
   first = got['total_loss']
   for _ in range(20):
     est.train_step(b)
@@ -206,7 +207,7 @@ def test_full_size_models_train_and_replay_as_graph(name, B, dtype):
   assert np.isfinite(last) and last < first
 
 
-@pytest.mark.parametrize('name,dtype,tol', [('dcn_v2_criteo.config', 'f32', 1e-4), ('dcn_v2_criteo.config', 'bf16', 2e-2),
+@pytest.mark.parametrize('name,dtype,tol', [('dcn_v2_criteo.config', 'f32', 1e-4), ('dcn_v2_criteo.config', 'bf16', 1e-3),
                                             ('din_taobao_10m.config', 'f32', 1e-4),
                                             ('mmoe_taobao_4task_d64_25m.config', 'f32', 1e-4)])
 def test_full_size_parity_with_the_oracle(name, dtype, tol):

@@ -27,11 +27,17 @@ def test_tf_docs_example():
 
 
 def test_c_matches_python_transcription():
+  """Every length class of Fingerprint64 - 0-16, 17-32, 33-64 bytes and the 64-byte-block loop with each tail length
+  (65 ... 300: one to four blocks + every remainder) - through BOTH restatements (the C oracle and the Python
+  transcription, typed separately from the published algorithm); the inputs above 16 bytes have no external vector."""
   rng = np.random.default_rng(0)
-  for n in list(range(0, 33)):
-    for _ in range(20):
+  for n in list(range(0, 301)):
+    for _ in range(20 if n <= 32 else 6):
       s = bytes(rng.integers(0, 256, size=n, dtype=np.uint8))
-      assert hashing.fingerprint64(s) == hashing.fingerprint64_py(s)
+      assert hashing.fingerprint64(s) == hashing.fingerprint64_py(s), n
+  for n in (511, 512, 513, 1000, 4096):
+    s = bytes(rng.integers(0, 256, size=n, dtype=np.uint8))
+    assert hashing.fingerprint64(s) == hashing.fingerprint64_py(s), n
 
 
 def test_golden_file_matches():
