@@ -32,6 +32,12 @@ struct DecayTabDev {
   float* C;            // [capacity + 1][kDecayLd]
   int K;
   int64_t capacity;    // of the lr_t history
+  // The lag-1 table built one launch EARLY (er_decay_tables_set_prologue_build): lag[0] = the step counter as the last
+  // lookup launch saw it (= the s_end of the NEXT step's lag-1 consumers; er_emb_fwd_lazy / er_decay_tables_sync write it -
+  // a word no launch of the prologue writes, so the prologue's table workgroups can read it while workgroup 0 increments
+  // the counter itself), lag[1] = the s_end the lag-1 table was last built for (its consumers check it), lag[2] = sticky
+  // error: a consumer found the table built for another step (er_decay_tables_error).
+  int64_t* lag;
 };
 
 // T_n(t0, k), n < kDecayN, by one wavefront (fixed combination order); lane n of the result holds T_n.
@@ -59,6 +65,17 @@ __device__ __forceinline__ float decay_sum_wave(const DecayTabDev& t, const floa
   return mine;
 }
 
+// the workgroups of a launch that build A (lag 1) for s_end: wave `w` (0-based, over all of them) handles k = w + 1
+__device__ __forceinline__ void decay_build_lag1(const DecayTabDev& t, const float* __restrict__ hist, int64_t s_end, int w) {
+  const int k = w + 1;
+  if (k > t.K) return;
+  const float mine = decay_sum_wave(t, hist, s_end - 1 - k, k);
+  const int lane = threadIdx.x & 63;
+  float* A = t.A + static_cast<int64_t>(kDecayKMax) * kDecayLd;  // (lag 1's table: decay_aux_for)
+  if (lane < kDecayLd) A[static_cast<int64_t>(k - 1) * kDecayLd + lane] = mine;  // (lanes >= kDecayN hold 0)
+  if (k == 1 && lane == 0) t.lag[1] = s_end;
+}
+
 }  // namespace er
 
 struct er_decay_tables {
@@ -67,4 +84,5 @@ struct er_decay_tables {
   const int64_t* counter = nullptr;
   double ln_b1 = 0.0, ln_b2 = 0.0;
   float beta1 = 0.f, beta2 = 0.f;
+  bool prologue_build = false;  // er_decay_tables_set_prologue_build
 };

@@ -1221,6 +1221,10 @@ hyper_select_kernel(const float* __restrict__ table, int64_t* __restrict__ count
                                     int64_t hist_capacity, int hist_index, float* __restrict__ zero, int64_t zero_n,
                                     DecayTabDev tabs, int zero_blocks, PrologueHash hs, int hash_blocks) {
   const int bid = blockIdx.x;
+  if (bid >= zero_blocks + hash_blocks) {  // this step's lag-1 replay table, from the counter the last lookup launch left
+    decay_build_lag1(tabs, hist, tabs.lag[0], (bid - zero_blocks - hash_blocks) * static_cast<int>(blockDim.x >> 6) + static_cast<int>(threadIdx.x >> 6));
+    return;
+  }
   if (bid >= zero_blocks) {  // hash
     const int64_t stride = static_cast<int64_t>(hash_blocks) * blockDim.x;
     for (int64_t i = static_cast<int64_t>(bid - zero_blocks) * blockDim.x + threadIdx.x; i < hs.n; i += stride)
@@ -1819,7 +1823,9 @@ int er_step_prologue_hash(const float* table, int64_t* counter, int32_t n_slots,
   int64_t hb = er::ceil_div(n_strings, 256);
   if (hb > 4096) hb = 4096;
   er::PrologueHash hs{str_bytes, str_offsets, n_strings, n_per_col > 0 ? n_per_col : 1, num_buckets, drop_empty, ids_out};
-  hipLaunchKernelGGL(er::hyper_select_kernel, dim3(static_cast<unsigned>(blocks + hb)), dim3(256), 0, er::as_stream(stream), table,
+  // (one wavefront per k of the lag-1 table: er_decay_tables_set_prologue_build)
+  const int64_t tb = (decay_tables && decay_tables->prologue_build && history) ? er::ceil_div(static_cast<int64_t>(tabs.K) * 64, 256) : 0;
+  hipLaunchKernelGGL(er::hyper_select_kernel, dim3(static_cast<unsigned>(blocks + hb + tb)), dim3(256), 0, er::as_stream(stream), table,
                      counter, n_slots, floats_per_slot, out, history, history_capacity, history_index, zero, zero_floats, tabs,
                      static_cast<int>(blocks), hs, static_cast<int>(hb));
   ER_LAUNCH_CHECK();

@@ -662,6 +662,10 @@ emb_catch_up_closed_kernel(CatchUpMulti ma) {
   else catch_up_closed_body<1>(bid, a, ma.hyper);
 }
 
+__global__ void decay_lag_sync_kernel(int64_t* __restrict__ lag, const int64_t* __restrict__ counter) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) lag[0] = *counter;
+}
+
 // A[k-1][:] = T(s_end-1-k, k), k = 1..K, s_end = *counter - lag: one wavefront per k (er_decay.h)
 __global__ void __launch_bounds__(kBlock)
 decay_tables_kernel(DecayTabDev t, const float* __restrict__ hist, const int64_t* __restrict__ counter, int lag) {
@@ -791,6 +795,10 @@ struct FwdLazy {
   int n;                       // table groups with lazy decay (0: plain lookups only)
   const int8_t* lookup_group;  // [n_lookups] index into tab / aux, or -1 (device memory)
   const er_opt_hyper* hyper;
+  // the lag-1 replay table was built by the step prologue (er_decay_tables_set_prologue_build): the lookup launch checks
+  // that it was built for THIS step and leaves the counter for the next prologue (DecayTabDev.lag); else nullptr
+  int64_t* lag;
+  const int64_t* counter;
   RowUpdate tab[kMaxMulti];
   DecayAux aux[kMaxMulti];
 };
@@ -811,17 +819,23 @@ __device__ __forceinline__ void lazy_row(float (&var)[V], const RowUpdate& tab, 
   if (live) replay_closed<V>(var, m, v, aux, s_begin, t, eps);
 }
 
+// one block of kBlock lanes of the lookup launch: block `vb` of the plan, lane `vt` of it (a workgroup of the merged
+// sort + lookup launch holds several such blocks); returns the lane's share of the sum of squares of what it wrote
 template <bool LAZY>
-__device__ __forceinline__ void fwd_body(const er_lookup_desc* __restrict__ descs, const int32_t* __restrict__ blk_start,
-                                         int n_lookups, float* __restrict__ sumsq_partials, const FwdLazy* lz) {
-  __shared__ float red[4];
-  const int l = find_lookup(blk_start, n_lookups, blockIdx.x);
+__device__ __forceinline__ float fwd_rows(int vb, int vt, const er_lookup_desc* __restrict__ descs,
+                                          const int32_t* __restrict__ blk_start, int n_lookups, const FwdLazy* lz) {
+  const int l = find_lookup(blk_start, n_lookups, vb);
   const er_lookup_desc d = descs[l];
   int V, G;
   lane_geom(d.dim, V, G);
   const int rows_per_block = kBlock / G;
-  const int r = (blockIdx.x - blk_start[l]) * rows_per_block + static_cast<int>(threadIdx.x) / G;
-  const int c = (static_cast<int>(threadIdx.x) % G) * V;
+  const int r = (vb - blk_start[l]) * rows_per_block + vt / G;
+  const int c = (vt % G) * V;
+  if (LAZY && lz->lag != nullptr && vb == 0 && vt == 0) {
+    const int64_t cnt = *lz->counter;
+    if (lz->lag[1] != cnt - 1) lz->lag[2] = 1;  // the prologue built the table for another step: the step is void
+    lz->lag[0] = cnt;
+  }
   // (uniform over the workgroup: the group's records are read with scalar loads from the kernel arguments)
   int gi = -1;
   if (LAZY) gi = __builtin_amdgcn_readfirstlane(static_cast<int>(lz->lookup_group[l]));
@@ -899,6 +913,14 @@ __device__ __forceinline__ void fwd_body(const er_lookup_desc* __restrict__ desc
       ss = a.x * a.x;
     }
   }
+  return ss;
+}
+
+__global__ void __launch_bounds__(kBlock)
+emb_fwd_kernel(const er_lookup_desc* __restrict__ descs, const int32_t* __restrict__ blk_start, int n_lookups,
+               float* __restrict__ sumsq_partials) {
+  __shared__ float red[4];
+  const float ss = fwd_rows<false>(blockIdx.x, threadIdx.x, descs, blk_start, n_lookups, nullptr);
   if (sumsq_partials) {
     const float tot = block_sum_256(ss, red);
     if (threadIdx.x == 0) sumsq_partials[blockIdx.x] = tot;
@@ -906,15 +928,14 @@ __device__ __forceinline__ void fwd_body(const er_lookup_desc* __restrict__ desc
 }
 
 __global__ void __launch_bounds__(kBlock)
-emb_fwd_kernel(const er_lookup_desc* __restrict__ descs, const int32_t* __restrict__ blk_start, int n_lookups,
-               float* __restrict__ sumsq_partials) {
-  fwd_body<false>(descs, blk_start, n_lookups, sumsq_partials, nullptr);
-}
-
-__global__ void __launch_bounds__(kBlock)
 emb_fwd_lazy_kernel(const er_lookup_desc* __restrict__ descs, const int32_t* __restrict__ blk_start, int n_lookups,
                     float* __restrict__ sumsq_partials, FwdLazy lz) {
-  fwd_body<true>(descs, blk_start, n_lookups, sumsq_partials, &lz);
+  __shared__ float red[4];
+  const float ss = fwd_rows<true>(blockIdx.x, threadIdx.x, descs, blk_start, n_lookups, &lz);
+  if (sumsq_partials) {
+    const float tot = block_sum_256(ss, red);
+    if (threadIdx.x == 0) sumsq_partials[blockIdx.x] = tot;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -967,11 +988,13 @@ __device__ __forceinline__ void update_row_lazy(const RowUpdate& t, const DecayA
   st_vec<V>(t.var + off, var);
 }
 
-// aux != nullptr: the rows of this step have not been caught up by a launch of their own (update_row_lazy)
+// aux.A != nullptr: the rows of this step have not been caught up by a launch of their own (update_row_lazy).  (By
+// reference to the kernel-argument record, like tab: a POINTER to a by-value argument's field makes the compiler copy the
+// whole argument struct to scratch - 1 KB per lane, +10 us on the fix launch.)
 template <int V>
 __device__ __forceinline__ void finish_run(const RowUpdate& tab, int opt_kind, const er_opt_hyper* hyper,
                                            const ReduceOut& ro, uint32_t key, int64_t p, int sub, int c, int dim,
-                                           const float* gsum, const DecayAux* aux = nullptr) {
+                                           const float* gsum, const DecayAux& aux = DecayAux{}) {
   float g[V];
 #pragma unroll
   for (int i = 0; i < V; ++i) g[i] = gsum[i];
@@ -983,7 +1006,7 @@ __device__ __forceinline__ void finish_run(const RowUpdate& tab, int opt_kind, c
 #pragma unroll
       for (int i = 0; i < V; ++i) g[i] = g[i] * h.clip_scale;
     }
-    if (aux != nullptr && opt_kind == ER_OPT_ADAM && tab.last_step != nullptr) update_row_lazy<V>(tab, *aux, h, key, c, g);
+    if (aux.A != nullptr && opt_kind == ER_OPT_ADAM && tab.last_step != nullptr) update_row_lazy<V>(tab, aux, h, key, c, g);
     else update_row<V>(tab, opt_kind, h, tab.off(key, c), g);
     if (opt_kind == ER_OPT_ADAM && sub == 0) {
       if (tab.last_step) tab.ls(key) = static_cast<int32_t>(*tab.step_counter - 1);
@@ -1110,7 +1133,7 @@ __device__ __forceinline__ void fix_body(int bid, const uint32_t* __restrict__ s
                                          int n_tiles, const RowUpdate& tab, int opt_kind,
                                          const er_opt_hyper* __restrict__ hyper, const ReduceOut& ro,
                                          const float* __restrict__ tile_first, const float* __restrict__ tile_last,
-                                         const DecayAux* aux = nullptr) {
+                                         const DecayAux& aux = DecayAux{}) {
   const int64_t s = (static_cast<int64_t>(bid) * kBlock + threadIdx.x) / G;  // start tile candidate
   const int sub = static_cast<int>(threadIdx.x) % G;
   const int c = sub * V;
@@ -1175,10 +1198,20 @@ struct OwnArgs {
   int n_lookups;
   int dim, G, V, n_tiles;
   RowUpdate tab;
-  DecayAux aux;                  // the closed-form replay's tables (lag 1) ...
-  int inline_catch_up;           // ... used when this step's rows were not caught up by a launch (er_emb_fwd_lazy)
+  DecayAux aux;                  // A != nullptr: this step's rows were not caught up by a launch (er_emb_fwd_lazy) - the
+                                 // closed-form replay's tables (lag 1) for the row update to do it in registers
   float* tile_first;             // partial sums of the runs that cross tile boundaries (emb_bwd_fix_multi_kernel)
   float* tile_last;
+  // PAIRED follower (er_emb_bwd_fused): a dim-1 table group that shares this group's sort and keys (DeepFM / WideAndDeep: the
+  // wide weights of the ids the deep group embeds) rides on this group's tiles - lane 0 of every entry's lane group
+  // gathers, scans and applies the follower's scalar next to its own 4 columns, so the follower launches no tile
+  // workgroups of its own (they were the slow half of the launch: 256 scalar gathers + an 8-step scan per tile).
+  int pair;                      // 1: the fields below are set
+  RowUpdate ptab;
+  DecayAux paux;
+  const OwnLookup* plookups;
+  float* ptile_first;
+  float* ptile_last;
   int n_proj;
   const int32_t* proj_lookup;    // [n_proj] lookups into one-row tables
   float* proj_partial;           // [n_proj][kProjParts][dim + 1] (last: number of valid entries)
@@ -1189,6 +1222,8 @@ struct OwnMulti {
   int start[kMaxMulti + 1];       // tile workgroups
   int proj_start[kMaxMulti + 1];  // projection workgroups (after all tiles)
   int opt_kind;
+  int proj_first;                 // the one-row tables' workgroups (the longest dependent chain: partials -> ticket ->
+                                  // last arriver) take the FIRST block ids, so the chain runs under the tiles, not behind them
   const er_opt_hyper* hyper;
   unsigned long long* dbg;        // probe hook (er_debug_stamps): 16 wall-clock stamps per workgroup, or nullptr
   int n_gg;
@@ -1385,12 +1420,146 @@ __device__ __forceinline__ void own_tile_body(int bid, const OwnMulti& ma, const
     const bool to_next = (e == T - 1) && keys[T + 1] == key;  // keys[T + 1] = first key of the next tile
     const float* gs = vals + static_cast<size_t>(e) * dim + c;
     if (!from_prev && !to_next) {
-      finish_run<V>(a.tab, ma.opt_kind, ma.hyper, ro, key, p, sub, c, dim, gs, a.inline_catch_up ? &a.aux : nullptr);
+      finish_run<V>(a.tab, ma.opt_kind, ma.hyper, ro, key, p, sub, c, dim, gs, a.aux);
     } else {
       Vec<V> r;
       r.load(gs);
       if (from_prev) r.store(a.tile_first + static_cast<size_t>(bid) * dim + c);
       if (to_next) r.store(a.tile_last + static_cast<size_t>(bid) * dim + c);
+    }
+  }
+  if (dbg && tid == 0) dbg[1] = wall_clock64();
+}
+
+// own_tile_body<4> of a leader whose dim-1 follower is PAIRED with it (OwnArgs.pair): the tile's LDS rows are kPairLd floats
+// wide - the leader's dim columns, then the follower's scalar at column dim (rows stay 16-byte aligned) - and lane 0 of
+// every entry's lane group carries the scalar through gather, scan and run end.  Same arithmetic, entry order and scan tree
+// as the two groups' own tiles: the follower's bits are those of own_tile_body<1>.
+constexpr int kPairPad = 4;
+__device__ __forceinline__ void own_pair_tile_body(int bid, const OwnMulti& ma, const OwnArgs& a, float* __restrict__ smem) {
+  constexpr int V = 4;
+  constexpr int kTilePasses = tile_passes(V);
+  const int G = a.G, dim = a.dim;
+  const int ldv = dim + kPairPad;
+  const int epp = kBlock / G;
+  const int T = kTilePasses * epp;
+  float* vals = smem;                                                                         // [T][ldv]
+  uint32_t* keys = reinterpret_cast<uint32_t*>(smem + static_cast<size_t>(T) * ldv);          // [T + 2]
+  OwnLookup* L = reinterpret_cast<OwnLookup*>(keys + T + 2 + ((T + 2) & 1));                   // [n_lookups] leader
+  OwnLookup* Lw = L + a.n_lookups;                                                             // [n_lookups] follower
+  er_grad_group* ggs = reinterpret_cast<er_grad_group*>(Lw + a.n_lookups);                     // [n_gg]
+  const int tid = threadIdx.x;
+  const int sub = tid % G;
+  const int c = sub * V;
+  const bool col_ok = c < dim;
+  const int64_t t0 = static_cast<int64_t>(bid) * T;
+  unsigned long long* dbg = ma.dbg ? ma.dbg + static_cast<int64_t>(blockIdx.x) * 16 : nullptr;
+  if (dbg && tid == 0) dbg[0] = wall_clock64();
+  {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(a.lookups);
+    const uint32_t* srcw = reinterpret_cast<const uint32_t*>(a.plookups);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(L);
+    uint32_t* dstw = reinterpret_cast<uint32_t*>(Lw);
+    for (int i = tid; i < a.n_lookups * static_cast<int>(sizeof(OwnLookup) / 4); i += kBlock) {
+      dst[i] = src[i];
+      dstw[i] = srcw[i];
+    }
+  }
+  if (tid < kWave)
+    for (int k = 0; k < ma.n_gg; ++k) ggs[k] = ma.gg[k];
+  for (int i = tid; i < T + 2; i += kBlock) {
+    const int64_t p = t0 - 1 + i;
+    keys[i] = (p >= 0 && p < a.n) ? a.skeys[p] : kInvalidKey;
+  }
+  __syncthreads();
+  if (dbg && tid == 0) dbg[2] = wall_clock64();
+  // gather
+#pragma unroll
+  for (int ps = 0; ps < kTilePasses; ++ps) {
+    const int e = ps * epp + tid / G;
+    const int64_t p = t0 + e;
+    Vec<V> acc;
+    acc.zero();
+    float wacc = 0.f;
+    if (col_ok && p < a.n && keys[e + 1] != kInvalidKey) {
+      const int j = static_cast<int>(a.svals[p]);
+      const int li = own_find(L, a.n_lookups, j, a.cap_shift);
+      const OwnLookup lk = L[li];
+      const int r = j - lk.base;
+      const Vec<V> g = own_finish<V>(ggs[lk.gg], lk.tmask, r, lk.out_col + c, c);
+      acc.add_scaled(g, own_scale(lk, r));
+      if (sub == 0) {
+        const OwnLookup lw = Lw[li];
+        const Vec<1> gw = own_finish<1>(ggs[lw.gg], lw.tmask, r, lw.out_col, 0);
+        Vec<1> t;
+        t.zero();
+        t.add_scaled(gw, own_scale(lw, r));
+        wacc = t.v;
+      }
+    }
+    if (col_ok) acc.store(vals + static_cast<size_t>(e) * ldv + c);
+    if (sub == 0) vals[static_cast<size_t>(e) * ldv + dim] = wacc;
+  }
+  if (dbg && tid == 0) dbg[3] = wall_clock64();
+  __syncthreads();
+  if (dbg && tid == 0) dbg[4] = wall_clock64();
+  // segmented inclusive scan (own_chunk's tree; lane 0 of an entry also combines the follower's column)
+  for (int off = 1; off < T; off <<= 1) {
+    Vec<V> add[kTilePasses];
+    float wadd[kTilePasses];
+    int any = 0;
+#pragma unroll
+    for (int ps = 0; ps < kTilePasses; ++ps) {
+      const int e = ps * epp + tid / G;
+      add[ps].zero();
+      wadd[ps] = 0.f;
+      if (col_ok && e >= off && keys[e + 1] != kInvalidKey && keys[e + 1 - off] == keys[e + 1]) {
+        add[ps].load(vals + static_cast<size_t>(e - off) * ldv + c);
+        if (sub == 0) wadd[ps] = vals[static_cast<size_t>(e - off) * ldv + dim];
+        any = 1;
+      }
+    }
+    if (!__syncthreads_or(any)) break;
+#pragma unroll
+    for (int ps = 0; ps < kTilePasses; ++ps) {
+      const int e = ps * epp + tid / G;
+      if (col_ok && e >= off && keys[e + 1] != kInvalidKey && keys[e + 1 - off] == keys[e + 1]) {
+        Vec<V> cur;
+        cur.load(vals + static_cast<size_t>(e) * ldv + c);
+        cur.add(add[ps]);
+        cur.store(vals + static_cast<size_t>(e) * ldv + c);
+        if (sub == 0) vals[static_cast<size_t>(e) * ldv + dim] = vals[static_cast<size_t>(e) * ldv + dim] + wadd[ps];
+      }
+    }
+    __syncthreads();
+  }
+  // run ends
+  if (dbg && tid == 0) dbg[5] = wall_clock64();
+  const ReduceOut ro{0, nullptr, nullptr, nullptr, nullptr, 0};
+#pragma unroll
+  for (int ps = 0; ps < kTilePasses; ++ps) {
+    const int e = ps * epp + tid / G;
+    const int64_t p = t0 + e;
+    if (!col_ok || p >= a.n) continue;
+    const uint32_t key = keys[e + 1];
+    if (key == kInvalidKey) continue;
+    if (keys[e + 2] == key && e != T - 1) continue;
+    const bool from_prev = keys[0] == key;
+    const bool to_next = (e == T - 1) && keys[T + 1] == key;
+    const float* gs = vals + static_cast<size_t>(e) * ldv + c;
+    const float wsum = vals[static_cast<size_t>(e) * ldv + dim];
+    if (!from_prev && !to_next) {
+      finish_run<V>(a.tab, ma.opt_kind, ma.hyper, ro, key, p, sub, c, dim, gs, a.aux);
+      if (sub == 0) finish_run<1>(a.ptab, ma.opt_kind, ma.hyper, ro, key, p, 0, 0, 1, &wsum, a.paux);
+    } else {
+      Vec<V> r;
+      r.load(gs);
+      if (from_prev) r.store(a.tile_first + static_cast<size_t>(bid) * dim + c);
+      if (to_next) r.store(a.tile_last + static_cast<size_t>(bid) * dim + c);
+      if (sub == 0) {
+        if (from_prev) a.ptile_first[bid] = wsum;
+        if (to_next) a.ptile_last[bid] = wsum;
+      }
     }
   }
   if (dbg && tid == 0) dbg[1] = wall_clock64();
@@ -1406,6 +1575,8 @@ __device__ __forceinline__ void own_proj_body(int local, const OwnMulti& ma, con
   const int sub = tid % G, rl = tid / G, rpp = kBlock / G;
   const int c = sub * V;
   const bool col_ok = c < dim;
+  unsigned long long* dbg = ma.dbg ? ma.dbg + static_cast<int64_t>(blockIdx.x) * 16 : nullptr;
+  if (dbg && tid == 0) dbg[0] = wall_clock64();
   const int l = a.proj_lookup[pj];
   const er_lookup_desc d = a.descs[l];
   const OwnLookup lk = a.lookups[l];
@@ -1456,6 +1627,7 @@ __device__ __forceinline__ void own_proj_body(int local, const OwnMulti& ma, con
     s_last = (t % kProjParts) == kProjParts - 1 ? 1 : 0;
   }
   __syncthreads();
+  if (dbg && tid == 0) dbg[1] = wall_clock64();
   if (!s_last) return;
   // every partial requested at once (one round trip), then combined from LDS in a fixed order
   const float* all = a.proj_partial + static_cast<int64_t>(pj) * kProjParts * (dim + 1);
@@ -1475,19 +1647,24 @@ __device__ __forceinline__ void own_proj_body(int local, const OwnMulti& ma, con
   }
   if (n_valid == 0.f) return;  // no id of the batch read the row: TensorFlow's IndexedSlices has no entry for it
   const ReduceOut ro{0, nullptr, nullptr, nullptr, nullptr, 0};
-  finish_run<V>(a.tab, ma.opt_kind, ma.hyper, ro, static_cast<uint32_t>(d.key_base), 0, sub, c, dim, g,
-                a.inline_catch_up ? &a.aux : nullptr);
+  finish_run<V>(a.tab, ma.opt_kind, ma.hyper, ro, static_cast<uint32_t>(d.key_base), 0, sub, c, dim, g, a.aux);
+  if (dbg && tid == 0) dbg[1] = wall_clock64();
 }
 
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4)))
 emb_bwd_own_kernel(OwnMulti ma) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int bid = blockIdx.x;
+  int bid = blockIdx.x;
+  if (ma.proj_first) {  // grid = [one-row tables | tiles]
+    const int n_proj = ma.proj_start[ma.n];
+    bid = bid < n_proj ? bid + ma.start[ma.n] : bid - n_proj;
+  }
   if (bid < ma.start[ma.n]) {
     int i = 0;
     while (i + 1 < ma.n && bid >= ma.start[i + 1]) ++i;
     const OwnArgs& a = ma.a[i];
-    if (a.V == 4) own_tile_body<4>(bid - ma.start[i], ma, a, smem);
+    if (a.pair) own_pair_tile_body(bid - ma.start[i], ma, a, smem);
+    else if (a.V == 4) own_tile_body<4>(bid - ma.start[i], ma, a, smem);
     else own_tile_body<1>(bid - ma.start[i], ma, a, smem);
     return;
   }
@@ -1624,7 +1801,6 @@ struct RunArgs {
   float* tile_first;
   float* tile_last;
   DecayAux aux;         // (fix launch of the fused step: see OwnArgs)
-  int inline_catch_up;
 };
 struct RunMulti {
   int n;
@@ -1657,10 +1833,10 @@ emb_bwd_fix_multi_kernel(RunMulti ma) {
   const int bid = blockIdx.x - ma.start[i];
   if (a.V == 4)
     fix_body<4>(bid, a.skeys, a.n, a.dim, a.G, a.T, a.n_tiles, a.tab, ma.opt_kind, ma.hyper, a.ro, a.tile_first,
-                a.tile_last, a.inline_catch_up ? &a.aux : nullptr);
+                a.tile_last, a.aux);
   else
     fix_body<1>(bid, a.skeys, a.n, a.dim, a.G, a.T, a.n_tiles, a.tab, ma.opt_kind, ma.hyper, a.ro, a.tile_first,
-                a.tile_last, a.inline_catch_up ? &a.aux : nullptr);
+                a.tile_last, a.aux);
 }
 
 // Segmented sort: when every lookup of a group owns its own table (disjoint, increasing key ranges - the normal
@@ -1930,6 +2106,43 @@ emb_front_sort_kernel(const int64_t* __restrict__ ent_base, const er_lookup_desc
   }
   seg_sort_body<E, true, NARROW, true>(blockIdx.x, nullptr, ent_base, descs, P, Route{1, 0, nullptr}, keys_out, vals_out,
                                        flags_out, hidx_out, seg_count, skip_one_row, sk_raw, ukeys_seg);
+}
+
+// The sort of a single-GPU step and its LOOKUP in one launch (er_emb_front_fwd).  The lookup does not need the sort - it
+// reads the ids - and the sort keeps only n_lookups workgroups (one CU each) busy for ~20 us: the lookup's blocks, kBlock
+// lanes each, fill the rest of the chip meanwhile - blockDim / kBlock of them per workgroup behind the sort's.  Possible
+// once nothing in the launch produces what another part of it consumes: the lag-1 replay table the lazy lookup reads is
+// built one launch earlier, by the step prologue (er_decay_tables_set_prologue_build).
+template <int E, bool NARROW>
+__global__ void __launch_bounds__(kSegSortMax / 8)
+emb_front_fwd_kernel(const int64_t* __restrict__ ent_base, const er_lookup_desc* __restrict__ descs, int n_lookups, int P,
+                     uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint32_t* __restrict__ flags_out,
+                     uint32_t* __restrict__ hidx_out, uint32_t* __restrict__ seg_count, int skip_one_row,
+                     uint32_t* __restrict__ ukeys_seg, const er_lookup_desc* __restrict__ fwd_descs,
+                     const int32_t* __restrict__ fwd_blk_start, int fwd_lookups, int fwd_blocks,
+                     float* __restrict__ sumsq_partials, FwdLazy lz) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long sk_raw[];  // [P] composites (sort workgroups)
+  if (static_cast<int>(blockIdx.x) < n_lookups) {
+    seg_sort_body<E, true, NARROW, true>(blockIdx.x, nullptr, ent_base, descs, P, Route{1, 0, nullptr}, keys_out, vals_out,
+                                         flags_out, hidx_out, seg_count, skip_one_row, sk_raw, ukeys_seg);
+    return;
+  }
+  __shared__ float red[kSegSortMax / 8 / 64];
+  const int per_wg = static_cast<int>(blockDim.x) / kBlock;
+  const int vb = (static_cast<int>(blockIdx.x) - n_lookups) * per_wg + static_cast<int>(threadIdx.x) / kBlock;
+  const int vt = static_cast<int>(threadIdx.x) % kBlock;
+  float ss = 0.f;
+  if (vb < fwd_blocks) ss = fwd_rows<true>(vb, vt, fwd_descs, fwd_blk_start, fwd_lookups, &lz);
+  if (sumsq_partials) {  // block_sum_256 per kBlock lanes: wave sums, then (w0 + w1) + (w2 + w3)
+    ss = wave_sum(ss);
+    const int wid = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) red[wid] = ss;
+    __syncthreads();
+    if (vt == 0 && vb < fwd_blocks) {
+      const int w0 = (static_cast<int>(threadIdx.x) / kBlock) * 4;
+      sumsq_partials[vb] = (red[w0] + red[w0 + 1]) + (red[w0 + 2] + red[w0 + 3]);
+    }
+  }
 }
 
 // Routed counterpart of emb_route_seg_kernel.  The de-duplicated keys must come out grouped by owner (the
@@ -3042,12 +3255,28 @@ static int emb_group_run(er_emb_group* g, int opt_kind, const er_opt_hyper* hype
 // another stream it must leave wave slots free or those kernels queue behind the sweep's
 // long-running grid-stride blocks (measured).
 static int g_sweep_blocks_per_cu = 8;
+// er_emb_bwd_fused: a dim-1 follower's tiles ride on its leader's (own_pair_tile_body); 0 = every group launches its own tiles
+static int g_pair_tiles = 1;
+static int g_proj_first = 1;     // er_emb_bwd_fused: OwnMulti.proj_first
+static int g_front_sort_e8 = 0;  // 8 composites per thread in the front sort for P <= 4096 too (A/B)
 
 int er_config_set(const char* key, int64_t value) {
   ER_REQUIRE(key, "er_config_set: null key");
   if (strcmp(key, "sweep_blocks_per_cu") == 0) {
     ER_REQUIRE(value >= 1 && value <= 8, "er_config_set: sweep_blocks_per_cu must be in 1..8");
     g_sweep_blocks_per_cu = static_cast<int>(value);
+    return 0;
+  }
+  if (strcmp(key, "proj_first") == 0) {
+    g_proj_first = value != 0;
+    return 0;
+  }
+  if (strcmp(key, "front_sort_e8") == 0) {
+    g_front_sort_e8 = value != 0;
+    return 0;
+  }
+  if (strcmp(key, "pair_tiles") == 0) {
+    g_pair_tiles = value != 0;
     return 0;
   }
   ER_REQUIRE(false, "er_config_set: unknown key %s", key);
@@ -3171,7 +3400,6 @@ static int emb_groups_run_multi(er_emb_group* const* groups, int n, int opt_kind
     a.n_tiles = static_cast<int>(er::ceil_div(N, a.T));
     a.tab = tab_of(g);
     a.aux = er::DecayAux{};
-    a.inline_catch_up = 0;
     a.ro = dense ? er::ReduceOut{2, nullptr, nullptr, nullptr, dense[i], ld[i]}
                  : er::ReduceOut{0, src->head_flags, src->head_index, nullptr, nullptr, 0};
     a.tile_first = g->tile_first; a.tile_last = g->tile_last;
@@ -3314,11 +3542,22 @@ static int front_collect_one_row(er_emb_group* g) {
   return 0;
 }
 
-int er_emb_front(er_emb_group* const* groups, int n, int flags, const er_opt_hyper* hyper, er_stream_t stream) {
+// what er_emb_front_fwd hands to the front: the step's lookup, to ride on the last sort launch
+struct FrontFwd {
+  er_emb_plan* plan;
+  float* sumsq;
+  er::FwdLazy lz;
+  bool launched;
+};
+
+static int fwd_lazy_prepare(er_emb_plan* p, er_emb_group* const* groups, int n, const er_opt_hyper* hyper, hipStream_t s,
+                            er::FwdLazy* lz);
+
+static int emb_front_impl(er_emb_group* const* groups, int n, int flags, const er_opt_hyper* hyper, hipStream_t s,
+                          FrontFwd* ff) {
   ER_REQUIRE(groups && n >= 1 && n <= er::kMaxMulti, "er_emb_front: bad arguments (1 <= n <= %d)", er::kMaxMulti);
   const int skip_one_row = flags & ER_FRONT_SKIP_ONE_ROW;
   const bool defer = (flags & ER_FRONT_DEFER_CATCH_UP) != 0;
-  hipStream_t s = er::as_stream(stream);
   // eligibility first: nothing is launched for a set of groups the fused path does not cover
   for (int i = 0; i < n; ++i) {
     er_emb_group* g = groups[i];
@@ -3330,7 +3569,26 @@ int er_emb_front(er_emb_group* const* groups, int n, int flags, const er_opt_hyp
     if (g->last_step) ER_REQUIRE(hyper, "er_emb_front: the catch-up needs the step's er_opt_hyper");
     if (int rc = front_collect_one_row(g)) return rc;
   }
+  // the lag-1 replay table of this step was built by the step prologue (er_decay_tables_set_prologue_build)?
   bool tables_done = false;
+  for (int i = 0; i < n; ++i)
+    if (groups[i]->tabs && groups[i]->tabs->prologue_build) tables_done = true;
+  if (tables_done)
+    for (int i = 0; i < n; ++i)
+      ER_REQUIRE(!groups[i]->tabs || groups[i]->tabs->prologue_build, "er_emb_front: the groups of one call must share their decay tables");
+  // the fused lookup rides on the LAST sort launch of the call
+  int last_sort = -1;
+  if (ff) {
+    if (int rc = fwd_lazy_prepare(ff->plan, groups, n, hyper, s, &ff->lz)) return rc;
+    for (int i = 0; i < n; ++i) {
+      er_emb_group* g = groups[i];
+      er_emb_group* l = g->leader;
+      bool follows = false;
+      if (l && emb_group_same_keys(g, l))
+        for (int j = 0; j < i; ++j) follows = follows || groups[j] == l;
+      if (!follows) last_sort = i;
+    }
+  }
   for (int i = 0; i < n; ++i) {
     er_emb_group* g = groups[i];
     er_emb_group* l = g->leader;
@@ -3349,10 +3607,25 @@ int er_emb_front(er_emb_group* const* groups, int n, int flags, const er_opt_hyp
     const bool with_tables = g->tabs != nullptr && !tables_done;
     er::DecayTabDev tabs{};
     if (with_tables) tabs = g->tabs->dev;
-    const int E = P > 4096 ? 8 : 4;
+    const int E = (P > 4096 || g_front_sort_e8) ? 8 : 4;
     const int threads = P / E;
     const int table_blocks = with_tables ? static_cast<int>(er::ceil_div(static_cast<int64_t>(tabs.K) * er::kWave, threads)) : 0;
     const size_t lds = sizeof(unsigned long long) * static_cast<size_t>(P);
+    if (ff && i == last_sort && !with_tables && threads % er::kBlock == 0 && !ff->launched) {
+      // sort + lookup in one launch (emb_front_fwd_kernel): the lookup's blocks behind the sort's workgroups
+      er_emb_plan* pl = ff->plan;
+      const int per_wg = threads / er::kBlock;
+      const int fwd_wgs = static_cast<int>(er::ceil_div(pl->n_blocks, per_wg));
+#define ER_FRONT_FWD(EE, NRW)                                                                                             \
+  hipLaunchKernelGGL((er::emb_front_fwd_kernel<EE, NRW>), dim3(g->n + fwd_wgs), dim3(threads), lds, s, g->d_ent_base,      \
+                     g->d_descs, g->n, P, g->keys_out, g->vals_out, g->head_flags, g->head_index, g->seg_count,          \
+                     skip_one_row ? 1 : 0, g->keys_in, pl->d_descs, pl->d_blk_start, pl->n, pl->n_blocks, ff->sumsq, ff->lz)
+      if (E == 8) { if (g->seg_narrow) ER_FRONT_FWD(8, true); else ER_FRONT_FWD(8, false); }
+      else { if (g->seg_narrow) ER_FRONT_FWD(4, true); else ER_FRONT_FWD(4, false); }
+#undef ER_FRONT_FWD
+      ER_LAUNCH_CHECK();
+      ff->launched = true;
+    } else {
 #define ER_FRONT_SORT(EE, NRW)                                                                                           \
   hipLaunchKernelGGL((er::emb_front_sort_kernel<EE, NRW>), dim3(g->n + table_blocks), dim3(threads), lds, s, g->d_ent_base, \
                      g->d_descs, g->n, P, g->keys_out, g->vals_out, g->head_flags, g->head_index, g->seg_count,         \
@@ -3362,6 +3635,7 @@ int er_emb_front(er_emb_group* const* groups, int n, int flags, const er_opt_hyp
     else { if (g->seg_narrow) ER_FRONT_SORT(4, true); else ER_FRONT_SORT(4, false); }
 #undef ER_FRONT_SORT
     ER_LAUNCH_CHECK();
+    }
     tables_done = tables_done || with_tables;
     g->heads_epoch = g->sort_epoch;
     g->front_epoch = g->sort_epoch;
@@ -3408,6 +3682,10 @@ int er_emb_front(er_emb_group* const* groups, int n, int flags, const er_opt_hyp
   return 0;
 }
 
+int er_emb_front(er_emb_group* const* groups, int n, int flags, const er_opt_hyper* hyper, er_stream_t stream) {
+  return emb_front_impl(groups, n, flags, hyper, er::as_stream(stream), nullptr);
+}
+
 // probe hook: 16 wall-clock stamps (100 MHz) per workgroup of the next er_emb_bwd_fused launches into `p` (nullptr: off);
 // tools/own_probe.py reads them.  Not part of the product path.
 static unsigned long long* g_own_dbg = nullptr;
@@ -3429,6 +3707,7 @@ int er_emb_bwd_fused(er_emb_group* const* groups, int n, const er_grad_group* fi
   ma.start[0] = 0;
   ma.proj_start[0] = 0;
   ma.opt_kind = opt_kind;
+  ma.proj_first = g_proj_first;
   ma.hyper = hyper;
   ma.n_gg = n_finish;
   ma.dbg = g_own_dbg;
@@ -3505,9 +3784,26 @@ int er_emb_bwd_fused(er_emb_group* const* groups, int n, const er_grad_group* fi
     const int T = g->tile_entries;
     a.n_tiles = static_cast<int>(er::ceil_div(a.n, T));
     a.tab = tab_of(g);
-    a.inline_catch_up = g->front_deferred ? 1 : 0;
     a.aux = g->front_deferred ? decay_aux_for(g, 1) : er::DecayAux{};
     a.tile_first = g->tile_first; a.tile_last = g->tile_last;
+    a.pair = 0;
+    // a dim-1 follower of a 16-byte-lane leader of this call (same sort, same keys): its tiles ride on the leader's
+    bool rides = false;
+    if (g_pair_tiles && g->dim == 1 && g->src != g) {
+      for (int j = 0; j < i && !rides; ++j) {
+        er::OwnArgs& lead = ma.a[j];
+        if (groups[j] != g->src || lead.V != 4 || lead.pair || lead.n != a.n || lead.n_lookups != a.n_lookups ||
+            lead.cap_shift != a.cap_shift || lead.n_tiles != a.n_tiles || groups[j]->tile_entries != T)
+          continue;
+        lead.pair = 1;
+        lead.ptab = a.tab; lead.paux = a.aux; lead.plookups = a.lookups;
+        lead.ptile_first = g->tile_first; lead.ptile_last = g->tile_last;
+        const size_t need_pair = sizeof(float) * static_cast<size_t>(T) * (lead.dim + er::kPairPad) + sizeof(uint32_t) * (T + 4) +
+                                 2 * sizeof(er::OwnLookup) * static_cast<size_t>(g->n) + sizeof(er_grad_group) * static_cast<size_t>(n_finish);
+        if (need_pair > lds) lds = need_pair;
+        rides = true;
+      }
+    }
     const bool proj = src->front_skip && g->n_proj > 0;
     a.n_proj = proj ? g->n_proj : 0;
     {  // the fix launch's arguments (emb_bwd_fix_multi_kernel: the three-launch path's kernel)
@@ -3515,7 +3811,7 @@ int er_emb_bwd_fused(er_emb_group* const* groups, int n, const er_grad_group* fi
       f.skeys = src->keys_out; f.svals = src->vals_out; f.ent_gptr = nullptr; f.ent_scale = nullptr;
       f.n = a.n; f.dim = g->dim; f.G = g->G; f.V = g->V; f.T = T; f.n_tiles = a.n_tiles;
       f.tab = a.tab;
-      f.aux = a.aux; f.inline_catch_up = a.inline_catch_up;
+      f.aux = a.aux;
       f.ro = er::ReduceOut{0, nullptr, nullptr, nullptr, nullptr, 0};
       f.tile_first = g->tile_first; f.tile_last = g->tile_last;
       const int fb = a.n_tiles > 1 ? static_cast<int>(er::ceil_div(static_cast<int64_t>(a.n_tiles) * g->G, er::kBlock)) : 0;
@@ -3523,7 +3819,7 @@ int er_emb_bwd_fused(er_emb_group* const* groups, int n, const er_grad_group* fi
       ++fx.n;
     }
     a.proj_lookup = g->d_proj_lookup; a.proj_partial = g->d_proj_partial; a.proj_ticket = g->d_proj_ticket;
-    ma.start[ma.n + 1] = ma.start[ma.n] + a.n_tiles;
+    ma.start[ma.n + 1] = ma.start[ma.n] + (rides ? 0 : a.n_tiles);
     ma.proj_start[ma.n + 1] = ma.proj_start[ma.n] + a.n_proj * er::kProjParts;
     size_t need = sizeof(float) * static_cast<size_t>(T) * g->dim + sizeof(uint32_t) * (T + 4) +
                   sizeof(er::OwnLookup) * static_cast<size_t>(g->n) + sizeof(er_grad_group) * static_cast<size_t>(n_finish);
@@ -3549,13 +3845,16 @@ int er_emb_bwd_fused(er_emb_group* const* groups, int n, const er_grad_group* fi
 }
 #undef ER_ELIGIBLE
 
-int er_emb_fwd_lazy(er_emb_plan* p, er_emb_group* const* groups, int n, const er_opt_hyper* hyper, float* sumsq_partials,
-                    er_stream_t stream) {
+// the lazy lookup's arguments: which group every lookup of the plan reads (uploaded when it changes), the groups' records.
+// deferred_now: the groups are being deferred by the front of this very call (er_emb_front_fwd)
+static int fwd_lazy_prepare_impl(er_emb_plan* p, er_emb_group* const* groups, int n, const er_opt_hyper* hyper, hipStream_t s,
+                                 er::FwdLazy* out, bool deferred_now) {
   ER_REQUIRE(p && groups && n >= 1 && n <= er::kMaxMulti, "er_emb_fwd_lazy: bad arguments (1 <= n <= %d)", er::kMaxMulti);
-  hipStream_t s = er::as_stream(stream);
-  er::FwdLazy lz;
+  er::FwdLazy& lz = *out;
   lz.n = 0;
   lz.hyper = hyper;
+  lz.lag = nullptr;
+  lz.counter = nullptr;
   // which group a lookup reads: its table lies inside the group's var rows (and has the group's dim)
   std::vector<int8_t> map(p->n, -1);
   int slot_of[er::kMaxMulti];
@@ -3564,11 +3863,15 @@ int er_emb_fwd_lazy(er_emb_plan* p, er_emb_group* const* groups, int n, const er
     ER_REQUIRE(g, "er_emb_fwd_lazy: null group %d", i);
     slot_of[i] = -1;
     if (!g->last_step) continue;
-    ER_REQUIRE(hyper && g->tabs && g->G <= er::kWave && g->front_deferred,
+    ER_REQUIRE(hyper && g->tabs && g->G <= er::kWave && (g->front_deferred || deferred_now),
                "er_emb_fwd_lazy: group %d: call er_emb_front(ER_FRONT_DEFER_CATCH_UP) for this step first (closed-form replay only)", i);
     slot_of[i] = lz.n;
     lz.tab[lz.n] = tab_of(g);
     lz.aux[lz.n] = decay_aux_for(g, 1);
+    if (g->tabs->prologue_build) {  // (the lookup launch keeps the prologue's counter word and checks the table's stamp)
+      lz.lag = g->tabs->dev.lag;
+      lz.counter = g->tabs->counter;
+    }
     ++lz.n;
   }
   for (int l = 0; l < p->n; ++l) {
@@ -3594,9 +3897,39 @@ int er_emb_fwd_lazy(er_emb_plan* p, er_emb_group* const* groups, int n, const er
     p->h_lookup_group = map;
   }
   lz.lookup_group = p->d_lookup_group;
+  return 0;
+}
+
+static int fwd_lazy_prepare(er_emb_plan* p, er_emb_group* const* groups, int n, const er_opt_hyper* hyper, hipStream_t s,
+                            er::FwdLazy* lz) {
+  return fwd_lazy_prepare_impl(p, groups, n, hyper, s, lz, true);
+}
+
+int er_emb_fwd_lazy(er_emb_plan* p, er_emb_group* const* groups, int n, const er_opt_hyper* hyper, float* sumsq_partials,
+                    er_stream_t stream) {
+  hipStream_t s = er::as_stream(stream);
+  er::FwdLazy lz;
+  if (int rc = fwd_lazy_prepare_impl(p, groups, n, hyper, s, &lz, false)) return rc;
   hipLaunchKernelGGL(er::emb_fwd_lazy_kernel, dim3(p->n_blocks), dim3(er::kBlock), 0, s, p->d_descs, p->d_blk_start, p->n,
                      sumsq_partials, lz);
   ER_LAUNCH_CHECK();
+  return 0;
+}
+
+int er_emb_front_fwd(er_emb_group* const* groups, int n, int flags, er_emb_plan* plan, const er_opt_hyper* hyper,
+                     float* sumsq_partials, er_stream_t stream) {
+  ER_REQUIRE(plan && (flags & ER_FRONT_DEFER_CATCH_UP), "er_emb_front_fwd: needs a plan and ER_FRONT_DEFER_CATCH_UP");
+  hipStream_t s = er::as_stream(stream);
+  FrontFwd ff;
+  ff.plan = plan;
+  ff.sumsq = sumsq_partials;
+  ff.launched = false;
+  if (int rc = emb_front_impl(groups, n, flags, hyper, s, &ff)) return rc;
+  if (!ff.launched) {  // (no sort launch could carry it: the lookup as a launch of its own)
+    hipLaunchKernelGGL(er::emb_fwd_lazy_kernel, dim3(plan->n_blocks), dim3(er::kBlock), 0, s, plan->d_descs, plan->d_blk_start,
+                       plan->n, sumsq_partials, ff.lz);
+    ER_LAUNCH_CHECK();
+  }
   return 0;
 }
 
@@ -3705,7 +4038,7 @@ int er_decay_tables_supported(float beta1, float beta2) {
 int64_t er_decay_tables_bytes(int64_t history_capacity) {
   if (history_capacity <= 0) return -1;
   return static_cast<int64_t>(er::kDecayKMax) * er::kDecayLd * (sizeof(double) + 2 * sizeof(float)) +  // coef, A[lag 0 | 1]
-         (history_capacity + 1) * er::kDecayLd * static_cast<int64_t>(sizeof(float));
+         (history_capacity + 1) * er::kDecayLd * static_cast<int64_t>(sizeof(float)) + 64;  // + the lag words
 }
 
 int er_decay_tables_create(void* buffer, int64_t history_capacity, const float* lr_t_history, const int64_t* step_counter,
@@ -3729,6 +4062,8 @@ int er_decay_tables_create(void* buffer, int64_t history_capacity, const float* 
   t->dev.A = reinterpret_cast<float*>(base);  // two tables back to back: lag 0, lag 1 (er::decay_aux_for)
   base += 2 * static_cast<size_t>(er::kDecayKMax) * er::kDecayLd * sizeof(float);
   t->dev.C = reinterpret_cast<float*>(base);
+  base += (static_cast<size_t>(history_capacity) + 1) * er::kDecayLd * sizeof(float);
+  t->dev.lag = reinterpret_cast<int64_t*>(base);  // (8-byte aligned: every block before it is a multiple of 32 bytes)
   t->dev.K = K;
   t->dev.capacity = history_capacity;
   t->hist = lr_t_history;
@@ -3740,12 +4075,38 @@ int er_decay_tables_create(void* buffer, int64_t history_capacity, const float* 
   hipError_t e = hipMemcpy(buffer, coef.data(), coef.size() * sizeof(double), hipMemcpyHostToDevice);
   if (e == hipSuccess)
     e = hipMemset(t->dev.A, 0, (2 * static_cast<size_t>(er::kDecayKMax) + static_cast<size_t>(history_capacity) + 1) * er::kDecayLd * sizeof(float));
+  if (e == hipSuccess) {
+    const int64_t init[3] = {0, -1, 0};  // (lag[0] follows the counter from the first er_decay_tables_sync / lookup on)
+    e = hipMemcpy(t->dev.lag, init, sizeof(init), hipMemcpyHostToDevice);
+  }
+  if (e == hipSuccess) e = hipMemcpy(t->dev.lag, step_counter, sizeof(int64_t), hipMemcpyDeviceToDevice);
   if (e != hipSuccess) {
     delete t;
     er::set_error("er_decay_tables_create: %s", hipGetErrorString(e));
     return 1;
   }
   *out = t;
+  return 0;
+}
+
+int er_decay_tables_set_prologue_build(er_decay_tables* t, int on) {
+  ER_REQUIRE(t, "er_decay_tables_set_prologue_build: null tables");
+  t->prologue_build = on != 0;
+  return 0;
+}
+
+int er_decay_tables_sync(er_decay_tables* t, er_stream_t stream) {
+  ER_REQUIRE(t, "er_decay_tables_sync: null tables");
+  hipLaunchKernelGGL(er::decay_lag_sync_kernel, dim3(1), dim3(64), 0, er::as_stream(stream), t->dev.lag, t->counter);
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
+int er_decay_tables_error(er_decay_tables* t, int32_t* error_host) {
+  ER_REQUIRE(t && error_host, "er_decay_tables_error: null argument");
+  int64_t v = 0;
+  ER_CHECK_HIP(hipMemcpy(&v, t->dev.lag + 2, sizeof(v), hipMemcpyDeviceToHost));
+  *error_host = v != 0 ? 1 : 0;
   return 0;
 }
 

@@ -443,6 +443,11 @@ class HipBackend(object):
     self.lib.er_emb_group_num_entries.restype = ctypes.c_int64
     if self.lib.er_abi_version() != 1:
       raise RuntimeError('easyrec_amd: ABI version mismatch in %s' % LIB_PATH)
+    # A/B switches of the fused embedding step (er_config_set): paired tiles, one-row tables first, 8 composites per sort thread
+    for env, key, default in (('EASYREC_AMD_PAIR_TILES', b'pair_tiles', '1'), ('EASYREC_AMD_PROJ_FIRST', b'proj_first', '1'),
+                              ('EASYREC_AMD_SORT_E8', b'front_sort_e8', '0')):
+      if os.environ.get(env, default) != default:
+        self.lib.er_config_set(key, ctypes.c_int64(int(os.environ[env])))
 
   # -- measurement hook (bench.py): with `op_log` a list, every contraction appends (kernel name as rocprof prints it,
   # flops): one eager step gives the algorithmic work behind each GEMM kernel of the step's profile
@@ -1342,6 +1347,33 @@ class HipBackend(object):
     n = len(groups)
     gh = (ctypes.c_void_p * n)(*[g['handle'] for g in groups])
     self._ck(self.lib.er_emb_fwd_lazy(plan['handle'], gh, n, _p(hyper), _p(sumsq_partials), _stream()), 'er_emb_fwd_lazy')
+
+  def emb_front_fwd(self, groups, plan, hyper, skip_one_row, sumsq_partials=None):
+    """emb_front(defer=True) + emb_fwd_lazy in one call (one launch when the prologue builds the replay table).
+    -> False when the groups need the general path (nothing launched)."""
+    n = len(groups)
+    gh = (ctypes.c_void_p * n)(*[g['handle'] for g in groups])
+    rc = self.lib.er_emb_front_fwd(gh, n, ctypes.c_int((1 if skip_one_row else 0) | 2), plan['handle'], _p(hyper),
+                                   _p(sumsq_partials), _stream())
+    if rc == 3:
+      return False
+    self._ck(rc, 'er_emb_front_fwd')
+    return True
+
+  # the step's lag-1 replay table built by the prologue launch, so that sort and lookup share a launch - A/B switch
+  prologue_tables = os.environ.get('EASYREC_AMD_PROLOGUE_TABLES', '1') != '0'
+
+  def decay_tables_set_prologue_build(self, tabs, on):
+    self._ck(self.lib.er_decay_tables_set_prologue_build(tabs['handle'], int(bool(on))), 'er_decay_tables_set_prologue_build')
+    tabs['prologue_build'] = bool(on)
+
+  def decay_tables_sync(self, tabs):
+    self._ck(self.lib.er_decay_tables_sync(tabs['handle'], _stream()), 'er_decay_tables_sync')
+
+  def decay_tables_error(self, tabs):
+    flag = ctypes.c_int32(0)
+    self._ck(self.lib.er_decay_tables_error(tabs['handle'], ctypes.byref(flag)), 'er_decay_tables_error')
+    return bool(flag.value)
 
   def emb_bwd_fused(self, groups, finish, opt_kind, hyper):
     """finish: group_grad_finish's descriptors, one per feature-group gradient buffer the groups' lookups write."""

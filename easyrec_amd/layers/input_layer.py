@@ -216,8 +216,19 @@ class EmbeddingEngine(object):
     self._decay_tables = tabs
     if tabs is not None:
       self.flush_windows = 0
+    self._set_prologue_tables(tabs)
     for grp, _ in self._lazy_groups():
       kernels.hip().emb_group_set_decay_tables(grp, tabs)
+
+  def _set_prologue_tables(self, tabs):
+    """The step's lag-1 replay table from the prologue launch (er_decay_tables_set_prologue_build), so that the fused step's
+    sort and lookup are ONE launch (er_emb_front_fwd).  Only the single-GPU engine's fused step keeps the prologue's
+    counter word current by itself; forward() does it explicitly after any other kind of training lookup."""
+    be = kernels.hip()
+    self._prologue_tables = bool(tabs is not None and type(self) is EmbeddingEngine and getattr(be, 'prologue_tables', False) and
+                                 getattr(be, 'defer_catch_up', False) and hasattr(be, 'emb_front_fwd'))
+    if tabs is not None and hasattr(be, 'decay_tables_set_prologue_build'):
+      be.decay_tables_set_prologue_build(tabs, self._prologue_tables)
 
   def _enable_lazy_decay(self, dim, grp, st, n_route):
     """Per table group: the last-updated-step array and the buffers of er_emb_route (unique rows of a step)."""
@@ -245,6 +256,7 @@ class EmbeddingEngine(object):
       return
     self._clock = (self._clock[0], lr_hist, self._clock[2])
     self._decay_tables = decay_tables
+    self._set_prologue_tables(decay_tables)
     be = kernels.hip()
     for grp, lz in self._lazy_groups():
       be.emb_group_set_decay_tables(grp, None)
@@ -278,6 +290,8 @@ class EmbeddingEngine(object):
     for lz in self._lazy_states():
       lz['last_step'].fill_(int(step) - 1)
     self._decay_pending = False
+    if getattr(self, '_prologue_tables', False):  # (the step counter was set: the prologue's copy of it follows)
+      kernels.hip().decay_tables_sync(self._decay_tables)
 
   def _lazy_states(self):
     return list(self._lazy.values())
@@ -357,6 +371,9 @@ class EmbeddingEngine(object):
     the sharded engine adds its exchange capacity.  Called every OVERFLOW_CHECK_EVERY steps by the estimator, by
     evaluate(), state_dict() and checkpoint.save()."""
     self.check_kv_overflow()
+    if getattr(self, '_prologue_tables', False) and kernels.hip().decay_tables_error(self._decay_tables):
+      raise RuntimeError('lazy dense decay: a training lookup found the replay table built for another step (a training '
+                         'step ran its prologue without a lookup?): the steps since are void')
 
   def check_kv_overflow(self):
     for name, kv in self.kv_tables.items():
@@ -483,9 +500,11 @@ class EmbeddingEngine(object):
     self._join_window_flush()  # (a forward that no row update followed)
     if self.kv_jobs:
       self.translate_kv_ids()
-    lazy_lookup = False
-    if self.lazy_decay and not self.inference and self._use_fused() and self._fused_front():
+    lazy_lookup = looked_up = False
+    if self.lazy_decay and not self.inference and self._use_fused() and \
+        self._fused_front(with_lookup=getattr(self, '_prologue_tables', False) and self.plan is not None):
       lazy_lookup = self._front_deferred
+      looked_up = self._front_looked_up
       self._start_window_flush()
     elif self.lazy_decay and not self.inference:
       # sort the step's ids once (reused by the backward), bring the rows it touches up to date, then look up
@@ -509,7 +528,10 @@ class EmbeddingEngine(object):
       if probe is not None:
         probe[1].record()
       self._start_window_flush()
-    if self.plan is not None:
+    if getattr(self, '_prologue_tables', False) and self.train_mode and not self.inference and not lazy_lookup:
+      # a training lookup that is not the lazy one: the next prologue's table workgroups read the step from this word
+      be.decay_tables_sync(self._decay_tables)
+    if self.plan is not None and not looked_up:
       if lazy_lookup:
         be.emb_fwd_lazy(self.plan, list(self.emb_groups.values()), self._clock[2], self.sumsq if self.reg_lambda > 0 else None)
       else:
@@ -596,10 +618,20 @@ class EmbeddingEngine(object):
             not self._sweep_pending and (not self.lazy_decay or self.flush_windows <= 0) and len(self.groups) <= 8 and
             not any(st['bitmap'] is not None for st in self.storage.values()))
 
-  def _fused_front(self):
-    """er_emb_front over all table groups (leader first); remembers whether the groups are eligible."""
+  def _fused_front(self, with_lookup=False):
+    """er_emb_front over all table groups (leader first); remembers whether the groups are eligible.  with_lookup: the
+    step's lookup in the same call (er_emb_front_fwd: one launch with the sort)."""
     be = kernels.hip()
     grps = list(self.emb_groups.values())
+    self._front_looked_up = False
+    if with_lookup and self._fused is not False:
+      ok = be.emb_front_fwd(grps, self.plan, self._clock[2], True, self.sumsq if self.reg_lambda > 0 else None)
+      if self._fused is None:
+        self._fused = bool(ok)
+      else:
+        assert ok == self._fused
+      self._front_done = self._front_deferred = self._front_looked_up = bool(ok)
+      return ok
     # lazy dense decay in closed form: no catch-up launch - the lookup and the row update evaluate a row's pending steps
     # in registers (er_emb_fwd_lazy)
     defer = bool(self.lazy_decay and getattr(be, 'defer_catch_up', False) and getattr(self, '_decay_tables', None) is not None)

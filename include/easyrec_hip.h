@@ -273,6 +273,17 @@ int er_decay_tables_create(void* buffer, int64_t history_capacity, const float* 
                            const int64_t* step_counter, float beta1, float beta2, er_decay_tables** tables);
 int er_decay_tables_destroy(er_decay_tables* tables);
 int er_emb_group_set_decay_tables(er_emb_group* group, er_decay_tables* tables);
+/* The lag-1 table (what a training step's catch-up / lazy lookup / row update read) built ONE LAUNCH EARLY, by surplus
+ * workgroups of the step prologue (er_step_prologue_decay / _hash) instead of by the consumers' own front launch - which
+ * lets the step's sort and its lookup share one launch (er_emb_front_fwd).  The prologue increments the step counter in
+ * the same launch, so its table workgroups read the step from a word the LOOKUP launch of the previous step left
+ * (er_emb_fwd_lazy / er_emb_front_fwd write it; every consumer checks that the table it reads was built for its step and
+ * raises a sticky error otherwise).  The owner of the tables must keep that word current whenever a training step ran
+ * without such a lookup, or the counter was set: er_decay_tables_sync (stream-ordered: word = *step_counter).
+ * er_decay_tables_error: the sticky flag (host read: a sync). */
+int er_decay_tables_set_prologue_build(er_decay_tables* tables, int on);
+int er_decay_tables_sync(er_decay_tables* tables, er_stream_t stream);
+int er_decay_tables_error(er_decay_tables* tables, int32_t* error_host);
 /* TF-exact Adam with the sweep OVERLAPPED (two streams).  The rows a step touches are known as soon as
  * its ids are (before the forward): er_emb_mark_touched sets their bitmap bits; er_emb_sweep_untouched
  * then decays every other row (m*=beta1, v*=beta2, var-=lr_t*m/(sqrt(v)+eps): what
@@ -374,6 +385,12 @@ int er_emb_front(er_emb_group* const* groups, int n, int flags, const er_opt_hyp
  * no listed group are plain er_emb_fwd lookups.  First use uploads a lookup -> group map: call once outside capture. */
 int er_emb_fwd_lazy(er_emb_plan* plan, er_emb_group* const* groups, int n, const er_opt_hyper* hyper,
                     float* sumsq_partials, er_stream_t stream);
+/* er_emb_front(flags | ER_FRONT_DEFER_CATCH_UP) + er_emb_fwd_lazy as ONE call, and - when the lag-1 replay table is built by
+ * the prologue (er_decay_tables_set_prologue_build) - ONE launch: the lookup needs the ids, not the sort, and the sort keeps
+ * one workgroup per lookup (~20 us on 39 CUs for DeepFM-Criteo) busy, so the lookup's blocks run behind the sort's
+ * workgroups of the same grid.  Same results as the two calls. */
+int er_emb_front_fwd(er_emb_group* const* groups, int n, int flags, er_emb_plan* plan, const er_opt_hyper* hyper,
+                     float* sumsq_partials, er_stream_t stream);
 int er_emb_bwd_fused(er_emb_group* const* groups, int n, const er_grad_group* finish_host, int n_finish, int opt_kind,
                      const er_opt_hyper* hyper, er_stream_t stream);
 /* out[b, sum(widths[<p]) + j] = parts[p][b * lds[p] + j]: tf.concat(values, axis=1) of n <= 8 row-major blocks

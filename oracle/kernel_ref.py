@@ -537,6 +537,23 @@ class RefBackend(object):
       self.emb_catch_up_multi(lazy, [g['_front_keys'][0] for g in lazy], [g['_front_keys'][1] for g in lazy], hyper)
     self.emb_fwd(plan, sumsq_partials)
 
+  prologue_tables = True
+
+  def emb_front_fwd(self, groups, plan, hyper, skip_one_row, sumsq_partials=None):
+    if not self.emb_front(groups, hyper, skip_one_row, defer=True):
+      return False
+    self.emb_fwd_lazy(plan, groups, hyper, sumsq_partials)
+    return True
+
+  def decay_tables_set_prologue_build(self, tabs, on):
+    tabs['prologue_build'] = bool(on)
+
+  def decay_tables_sync(self, tabs):
+    tabs['lag'] = int(tabs['step_counter'].item())
+
+  def decay_tables_error(self, tabs):
+    return False
+
   def emb_front(self, groups, hyper, skip_one_row, defer=False):
     """easyrec_amd.kernels.HipBackend.emb_front restated with the general entry points: route every group (a follower of
     a shared sort after its leader), then bring the rows of the step current.  Eligibility as er_emb_front: dense-mode

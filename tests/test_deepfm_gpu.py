@@ -508,3 +508,76 @@ def test_fused_embedding_step_matches_the_general_path(optimizer, buckets, B):
   for step, (a, b) in enumerate(zip(*losses)):
     for k in a:
       assert abs(a[k] - b[k]) <= (1e-6 if step == 0 else 2e-4) * max(1.0, abs(a[k])), (step, k, a[k], b[k])
+
+
+def _run_variant(cfg, batches, B, defer, prologue, pair, e8=False, graph=False):
+  be = kernels.hip()
+  be.defer_catch_up, be.prologue_tables = defer, prologue
+  be.config_set('pair_tiles', int(pair))
+  be.config_set('front_sort_e8', int(e8))
+  try:
+    est = EasyRecEstimator(cfg, device=DEV, batch_size=B, seed=4).build()
+    losses = []
+    for i, b in enumerate(batches):
+      if graph and i == 2:
+        est.capture(warmup=0)
+      est.train_step(b)
+      losses.append(est.loss_values())
+    assert est.engine._fused is True
+    assert bool(getattr(est.engine, '_prologue_tables', False)) == bool(defer and prologue)
+    est.engine.check_overflow()  # (the replay table's stamp was right at every lookup)
+    return losses, est.state_dict(slots=True)
+  finally:
+    del be.defer_catch_up, be.prologue_tables
+    be.config_set('pair_tiles', 1)
+    be.config_set('front_sort_e8', 0)
+
+
+@pytest.mark.parametrize('buckets,B', [(1000, 256), (50, 2048)])
+def test_fused_step_variants_change_no_bit(buckets, B):
+  """Round 5's three changes to the fused single-GPU embedding step are re-arrangements of WHERE the same fp32 operations
+  run, not of the operations: (1) lazy dense decay caught up in registers by the lookup and again by the row update
+  (er_emb_fwd_lazy, update_row_lazy) instead of by a catch-up launch that stores the rows; (2) the dim-1 (wide) group's
+  tiles riding on the deep group's (own_pair_tile_body); (3) the lag-1 replay table built by the prologue and sort +
+  lookup in one launch (er_emb_front_fwd), eager and as a replayed hipGraph; (4) 8 composites per thread in the sort.
+  Eight steps over ids that recur after idle gaps (so rows ARE caught up): every loss, table, slot and dense variable
+  bit-identical to the round-4 arrangement."""
+  cfg = _cfg('deepfm_criteo_small.config')
+  for f in cfg.feature_config.features:
+    if f.HasField('hash_bucket_size') and f.hash_bucket_size > 0:
+      f.hash_bucket_size = buckets
+  gen = SyntheticCriteo(cfg.data_config, list(cfg.feature_config.features), batch_size=B, seed=13)
+  batches = [gen.next_batch() for _ in range(8)]
+  base_l, base_s = _run_variant(cfg, batches, B, defer=False, prologue=False, pair=False)
+  variants = {'in registers': dict(defer=True, prologue=False, pair=False),
+              'paired tiles': dict(defer=False, prologue=False, pair=True),
+              'one launch': dict(defer=True, prologue=True, pair=True),
+              'one launch, graph': dict(defer=True, prologue=True, pair=True, graph=True),
+              'one launch, e8': dict(defer=True, prologue=True, pair=True, e8=True)}
+  for name, kw in variants.items():
+    l, s = _run_variant(cfg, batches, B, **kw)
+    assert l == base_l, (name, [i for i, (a, b) in enumerate(zip(l, base_l)) if a != b])
+    assert set(s) == set(base_s)
+    for k in s:
+      assert np.array_equal(s[k], base_s[k]), (name, k)
+
+
+def test_a_replay_table_built_for_another_step_is_detected():
+  """The prologue builds the step's lag-1 replay table from the counter the LAST lookup launch left; a prologue that no
+  lookup followed leaves that word behind, the next prologue builds the table for the wrong step - and the next lookup
+  must notice (sticky error, raised where the other sticky device flags are polled) instead of training on it."""
+  cfg = _cfg('deepfm_criteo_small.config')
+  B = 256
+  est = EasyRecEstimator(cfg, device=DEV, batch_size=B, seed=4).build()
+  gen = SyntheticCriteo(cfg.data_config, est.feature_configs, batch_size=B, seed=3)
+  for _ in range(3):
+    est.train_step(gen.next_batch())
+  assert est.engine._prologue_tables
+  est.engine.check_overflow()
+  be = kernels.hip()
+  be.step_prologue(est.hyper_table, est.step_counter, est.hyper, history=est.lr_hist, zero=est.varstore.flat_grad_all,
+                   decay_tables=est.decay_tables)  # a step that stops after its prologue
+  est.global_step += 1
+  est.train_step(gen.next_batch())
+  with pytest.raises(RuntimeError, match='replay table'):
+    est.engine.check_overflow()

@@ -1,5 +1,7 @@
 #!/usr/bin/env python
-"""Probe: per-workgroup start / end stamps of emb_bwd_own_kernel inside one eager DeepFM step."""
+"""Probe: per-workgroup stamps of emb_bwd_own_kernel inside one eager DeepFM step (er_debug_stamps; 100 MHz wall clock).
+Round 5 layout of the launch: paired tiles (the dim-1 group rides on the dim-16 group's) first, then the one-row tables'
+column-reduction workgroups of both groups."""
 import ctypes, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -18,22 +20,30 @@ be.lib.er_debug_stamps(ctypes.c_void_p(buf.data_ptr()))
 est.train_step(bs[5]); torch.cuda.synchronize()
 be.lib.er_debug_stamps(None)
 full = buf.cpu().numpy().reshape(-1, 16)
-t = full[:, :2]
-used = t[:, 1] > 0
-t0 = t[used, 0].min()
-st, en = (t[:, 0] - t0) / 100.0, (t[:, 1] - t0) / 100.0
+used = full[:, 0] > 0
 idx = np.where(used)[0]
-print('workgroups stamped', used.sum(), 'span us', en[used].max())
-dur = en - st
-order = idx[np.argsort(-dur[idx])][:12]
-for i in order: print('wg %4d start %7.2f end %7.2f dur %7.2f' % (i, st[i], en[i], dur[i]))
-for lo, hi, name in ((0, 625, 'tiles D16'), (625, 1250, 'tiles D1'), (1250, 1666, 'proj')):
-  sel = [i for i in idx if lo <= i < hi]
-  if sel: print(name, 'n', len(sel), 'start min/max %.2f %.2f' % (st[sel].min(), st[sel].max()), 'end max %.2f' % en[sel].max(), 'dur mean %.2f max %.2f' % (dur[sel].mean(), dur[sel].max()))
-
-print('per-phase (us) for the slowest and some typical tile workgroups: setup | chunk | emit | follow (chunks) | total')
-for i in list(order[:6]) + [300, 400, 500, 620, 900, 1000, 1100, 1240]:
-  f = full[i]
-  if f[1] == 0 or f[2] == 0: continue
-  print('wg %4d: %6.2f | %6.2f | %6.2f | %6.2f (%d) | %6.2f   chunk: keys %.2f gather %.2f barrier %.2f scan %.2f' % (i, (f[2] - f[0]) / 100.0, (f[3] - f[2]) / 100.0, (f[4] - f[3]) / 100.0,
-        ((f[5] - f[4]) / 100.0) if f[5] else 0.0, f[6], (f[1] - f[0]) / 100.0, (f[8]-f[2])/100.0, (f[9]-f[8])/100.0, (f[10]-f[9])/100.0, (f[3]-f[10])/100.0))
+t0 = full[used, 0].min()
+st = (full[:, 0] - t0) / 100.0
+en = (np.where(full[:, 1] > 0, full[:, 1], full[:, 0]) - t0) / 100.0
+print('workgroups stamped', used.sum(), 'first start 0, last end %.2f us' % en[used].max())
+paired = os.environ.get('EASYREC_AMD_PAIR_TILES', '1') != '0'
+proj_first = os.environ.get('EASYREC_AMD_PROJ_FIRST', '1') != '0'
+n_tiles, n_proj = 624, 2 * 13 * 16
+t_lo = n_proj if proj_first else 0   # (stamps are indexed by the physical block id)
+p_lo = 0 if proj_first else (n_tiles if paired else 2 * n_tiles)
+ranges = ((t_lo, t_lo + n_tiles, 'tiles (paired)'),) if paired else \
+    ((t_lo, t_lo + n_tiles, 'tiles D16'), (t_lo + n_tiles, t_lo + 2 * n_tiles, 'tiles D1'))
+ranges += ((p_lo, p_lo + n_proj, 'one-row tables'),)
+for lo, hi, name in ranges:
+  sel = np.array([i for i in idx if lo <= i < hi])
+  if len(sel):
+    d = en[sel] - st[sel]
+    print('%-16s n %4d | start min %.2f p50 %.2f max %.2f | end p50 %.2f max %.2f | dur mean %.2f p50 %.2f max %.2f' % (
+        name, len(sel), st[sel].min(), np.median(st[sel]), st[sel].max(), np.median(en[sel]), en[sel].max(), d.mean(), np.median(d), d.max()))
+sel = np.array([i for i in idx if t_lo <= i < t_lo + n_tiles and full[i, 5] > 0])
+if len(sel):
+  f = full[sel].astype(np.float64)
+  ph = {'setup+keys': f[:, 2] - f[:, 0], 'gather': f[:, 3] - f[:, 2], 'barrier': f[:, 4] - f[:, 3], 'scan': f[:, 5] - f[:, 4], 'run ends': f[:, 1] - f[:, 5]}
+  print('paired tile phases (us): ' + ' | '.join('%s mean %.2f max %.2f' % (k, v.mean() / 100.0, v.max() / 100.0) for k, v in ph.items()))
+late = idx[np.argsort(-en[idx])][:10]
+print('last to finish:', ' '.join('wg%d[%.1f-%.1f]' % (i, st[i], en[i]) for i in late))
