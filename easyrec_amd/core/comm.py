@@ -10,6 +10,12 @@ compat/optimizers.py:285-345).  Here they are `torch.distributed` calls on devic
                     per route one for [count, keys], one for rows, one for row gradients
   all_reduce_sum    dense gradients with the replicated small tables' gradients behind them (scaled by 1 / W in the
                     optimizer kernels)
+  all_reduce_sum_async / wait
+                    the same, issued on a SECOND communicator as soon as the dense backward has finished and joined right
+                    before the optimizer kernels: it is in flight while the local gradient reduction runs and while the
+                    gradient all-to-all of the first communicator is on the wire (the reference's Horovod issues one
+                    all-reduce per dense gradient as backward produces it, compat/optimizers.py:315-331, overlapping
+                    them with the rest of backward the same way)
   exchange_counts   compact exchange only (more than 16 ranks): all-gather of a small [G, W] int32 matrix of
                     per-owner unique-key counts -> host-side send / recv split lists (one host synchronisation a step)
   all_to_all        compact exchange only: variable-split exchange of keys (int32), rows and gradient rows
@@ -43,6 +49,12 @@ class LocalComm(object):
   def all_reduce_sum(self, t):
     return t
 
+  def all_reduce_sum_async(self, t):
+    return None
+
+  def wait(self, handle):
+    pass
+
   def all_gather_rows(self, t):
     return [t]
 
@@ -56,13 +68,20 @@ class LocalComm(object):
 class TorchDistComm(object):
   """torch.distributed process group (nccl = RCCL on the MI355X node, gloo in the CPU tests)."""
 
-  def __init__(self, group=None):
+  def __init__(self, group=None, overlap_group=True):
     import torch.distributed as dist
     assert dist.is_initialized(), 'init_process_group first (bench.py / the launcher does it)'
     self.dist = dist
     self.group = group
     self.rank = dist.get_rank(group)
     self.world = dist.get_world_size(group)
+    # a second communicator over the same ranks (collective: every rank constructs its comm at the same point): RCCL
+    # serialises the collectives of ONE communicator on its stream, so the dense all-reduce that should overlap the
+    # gradient all-to-all needs its own
+    self.group2 = None
+    if overlap_group:
+      ranks = dist.get_process_group_ranks(group) if group is not None else None
+      self.group2 = dist.new_group(ranks=ranks)
 
   def exchange_counts(self, counts):
     """counts: int32 [G, W] on device: counts[g, w] = unique keys of dim-group g this rank sends to w.
@@ -88,6 +107,17 @@ class TorchDistComm(object):
   def all_reduce_sum(self, t):
     self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
     return t
+
+  def all_reduce_sum_async(self, t):
+    """-> handle for wait().  nccl (= RCCL): the collective runs on the second communicator's stream, ordered after the
+    work already queued on the current stream; wait() makes the CURRENT STREAM wait for it (the host does not block).
+    gloo (CPU tests): a background thread; wait() blocks the host."""
+    return self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group2 if self.group2 is not None else self.group,
+                                async_op=True)
+
+  def wait(self, handle):
+    if handle is not None:
+      handle.wait()
 
   def all_gather_rows(self, t):
     out = [torch.empty_like(t) for _ in range(self.world)]

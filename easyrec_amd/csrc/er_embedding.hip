@@ -3787,23 +3787,6 @@ int er_emb_bwd_fused(er_emb_group* const* groups, int n, const er_grad_group* fi
     a.aux = g->front_deferred ? decay_aux_for(g, 1) : er::DecayAux{};
     a.tile_first = g->tile_first; a.tile_last = g->tile_last;
     a.pair = 0;
-    // a dim-1 follower of a 16-byte-lane leader of this call (same sort, same keys): its tiles ride on the leader's
-    bool rides = false;
-    if (g_pair_tiles && g->dim == 1 && g->src != g) {
-      for (int j = 0; j < i && !rides; ++j) {
-        er::OwnArgs& lead = ma.a[j];
-        if (groups[j] != g->src || lead.V != 4 || lead.pair || lead.n != a.n || lead.n_lookups != a.n_lookups ||
-            lead.cap_shift != a.cap_shift || lead.n_tiles != a.n_tiles || groups[j]->tile_entries != T)
-          continue;
-        lead.pair = 1;
-        lead.ptab = a.tab; lead.paux = a.aux; lead.plookups = a.lookups;
-        lead.ptile_first = g->tile_first; lead.ptile_last = g->tile_last;
-        const size_t need_pair = sizeof(float) * static_cast<size_t>(T) * (lead.dim + er::kPairPad) + sizeof(uint32_t) * (T + 4) +
-                                 2 * sizeof(er::OwnLookup) * static_cast<size_t>(g->n) + sizeof(er_grad_group) * static_cast<size_t>(n_finish);
-        if (need_pair > lds) lds = need_pair;
-        rides = true;
-      }
-    }
     const bool proj = src->front_skip && g->n_proj > 0;
     a.n_proj = proj ? g->n_proj : 0;
     {  // the fix launch's arguments (emb_bwd_fix_multi_kernel: the three-launch path's kernel)
@@ -3819,8 +3802,6 @@ int er_emb_bwd_fused(er_emb_group* const* groups, int n, const er_grad_group* fi
       ++fx.n;
     }
     a.proj_lookup = g->d_proj_lookup; a.proj_partial = g->d_proj_partial; a.proj_ticket = g->d_proj_ticket;
-    ma.start[ma.n + 1] = ma.start[ma.n] + (rides ? 0 : a.n_tiles);
-    ma.proj_start[ma.n + 1] = ma.proj_start[ma.n] + a.n_proj * er::kProjParts;
     size_t need = sizeof(float) * static_cast<size_t>(T) * g->dim + sizeof(uint32_t) * (T + 4) +
                   sizeof(er::OwnLookup) * static_cast<size_t>(g->n) + sizeof(er_grad_group) * static_cast<size_t>(n_finish);
     const size_t rpp = er::kBlock / g->G;
@@ -3830,6 +3811,33 @@ int er_emb_bwd_fused(er_emb_group* const* groups, int n, const er_grad_group* fi
     g->sorted_valid = false;
     g->front_deferred = false;
     ++ma.n;
+  }
+  // A dim-1 group and a 16-byte-lane group of this call that reduce over ONE sort (either leads it) with the same entries:
+  // the dim-1 group's tiles ride on the other's (own_pair_tile_body) and are not launched.
+  bool rides[er::kMaxMulti] = {false, false, false, false};
+  for (int i = 0; i < ma.n && g_pair_tiles; ++i) {
+    if (groups[i]->dim != 1 || rides[i]) continue;
+    for (int j = 0; j < ma.n; ++j) {
+      er::OwnArgs& lead = ma.a[j];
+      const er::OwnArgs& w = ma.a[i];
+      if (j == i || lead.V != 4 || lead.pair || lead.skeys != w.skeys || lead.svals != w.svals || lead.n != w.n ||
+          lead.n_lookups != w.n_lookups || lead.cap_shift != w.cap_shift || lead.n_tiles != w.n_tiles ||
+          groups[j]->tile_entries != groups[i]->tile_entries || !emb_group_same_keys(groups[i], groups[j]))
+        continue;
+      lead.pair = 1;
+      lead.ptab = w.tab; lead.paux = w.aux; lead.plookups = w.lookups;
+      lead.ptile_first = w.tile_first; lead.ptile_last = w.tile_last;
+      const int T = groups[j]->tile_entries;
+      const size_t need_pair = sizeof(float) * static_cast<size_t>(T) * (lead.dim + er::kPairPad) + sizeof(uint32_t) * (T + 4) +
+                               2 * sizeof(er::OwnLookup) * static_cast<size_t>(lead.n_lookups) + sizeof(er_grad_group) * static_cast<size_t>(n_finish);
+      if (need_pair > lds) lds = need_pair;
+      rides[i] = true;
+      break;
+    }
+  }
+  for (int i = 0; i < ma.n; ++i) {
+    ma.start[i + 1] = ma.start[i] + (rides[i] ? 0 : ma.a[i].n_tiles);
+    ma.proj_start[i + 1] = ma.proj_start[i] + ma.a[i].n_proj * er::kProjParts;
   }
   for (int k = 0; k < n_finish; ++k) ma.gg[k] = finish[k];
   const int grid = ma.start[ma.n] + ma.proj_start[ma.n];

@@ -13,11 +13,18 @@ routed keys share one): an all-to-all of [count, keys] per owner, one of the row
 of all the route's dim groups side by side - all with equal, build-time split sizes, so there is NO host
 synchronisation in the step; + ONE all-reduce (dense gradients, with the replicated small tables' gradients
 behind them in the same buffer).  The static device work between the collectives (route | owner merge + serve |
-lookup+forward+backward+local reduce | owner update + replicated apply + dense optimizer) is captured as four
+lookup+forward+backward | local reduce | owner update + replicated apply + dense optimizer) is captured as five
 hipGraphs; the collectives are issued eagerly between them and the host runs ahead of the device.
+Overlap (round 5): the dense gradients are complete when the model's backward returns, long before the embedding
+gradients are reduced and exchanged - their all-reduce is issued there, asynchronously on a second communicator
+(core/comm.py all_reduce_sum_async), runs under the local reduction and next to the gradient all-to-all, and is joined
+right before the optimizer kernels; what the local reduction adds to the all-reduced buffer (the replicated small
+tables' gradients, the clipping norm's embedding share: the buffer's tail) follows in a second, small all-reduce.
 The compact exchange (variable split sizes through one host sync per step, three segments) remains for lookups
 the per-lookup routed sort does not cover.
 """
+import os
+
 import torch
 
 from easyrec_amd import kernels
@@ -40,6 +47,8 @@ class EmbeddingParallelEstimator(EasyRecEstimator):
     self.rank, self.world = rank, world
     self._engine_kwargs = dict(replicate_bytes=replicate_bytes, recv_slack=recv_slack)
     self._graphs = None
+    self._dense_work = None
+    self._overlap = os.environ.get('EASYREC_AMD_EP_OVERLAP', '1') != '0'  # A/B switch
     super(EmbeddingParallelEstimator, self).__init__(pipeline_config, device=device, batch_size=batch_size, seed=seed,
                                                      schema_kwargs=schema_kwargs, is_training=is_training,
                                                      overlap_sweep=False, dense_dtype=dense_dtype,
@@ -78,6 +87,24 @@ class EmbeddingParallelEstimator(EasyRecEstimator):
     if self.world > 1 or not isinstance(self.comm, LocalComm):
       self.comm.all_reduce_sum(self.varstore.flat_grad_all)
 
+  # -- overlap: the dense all-reduce in flight under the local reduction and the gradient all-to-all
+  @property
+  def overlap(self):
+    return self._overlap and (self.world > 1 or not isinstance(self.comm, LocalComm)) and hasattr(self.comm, 'all_reduce_sum_async')
+
+  def _start_dense_allreduce(self):
+    """right after the model's backward: every dense gradient is final (compat/optimizers.py:315-331 issues them one by one
+    as backward produces them); the buffer's tail is still being written by the local reduction"""
+    self._dense_work = self.comm.all_reduce_sum_async(self.varstore.flat_grad)
+
+  def _finish_exchanges(self):
+    tail = self.varstore.grad_tail
+    if tail.numel():  # replicated tables' gradients + the clipping norm's embedding share: complete only now
+      self.comm.all_reduce_sum(tail)
+    self.engine.exchange_grads()
+    self.comm.wait(self._dense_work)  # joined here: the optimizer kernels of the next segment read the summed gradients
+    self._dense_work = None
+
   # -- the step in phases: static device work (capturable) around the data-dependent exchanges
   def _phase_prologue(self):
     hash_job = self.features.hash_job() if self.fused_front else None
@@ -101,9 +128,9 @@ class EmbeddingParallelEstimator(EasyRecEstimator):
     self.engine.kv_unbucket()
     self.engine.route()
 
-  def _phase_compute(self):
-    """lookup -> forward -> losses -> backward -> local gradient reduction (no collective inside)."""
-    be = kernels.hip()
+  def _phase_compute(self, reduce=True):
+    """lookup -> forward -> losses -> backward [-> local gradient reduction] (no collective inside).  reduce=False: the
+    step overlaps the dense all-reduce with the local reduction, which is then a segment of its own (_phase_reduce)."""
     if self.is_training and not self.engine.inference:
       # the owned rows' rolling flush next to the lookup and the dense part (the owners' catch-up ran in an earlier
       # phase, their row update comes in a later one); fork and join inside this phase: one hipGraph holds both
@@ -117,10 +144,19 @@ class EmbeddingParallelEstimator(EasyRecEstimator):
       self._loss_tail(loss_dict)
       if self.is_training:
         self.model.backward()
-        self.engine.reduce_local()
-        if self.clip_norm > 0:
-          self.engine.local_gradsq(self._norm_slot, self._emb_gradsq_weight())
+        if reduce:
+          self._phase_reduce()
     self.engine._join_window_flush()
+
+  def _phase_forward_backward(self):
+    self._phase_compute(reduce=False)
+
+  def _phase_reduce(self):
+    """the embedding gradients of this rank's batch, de-duplicated per (owner, id) for the exchange (+ its share of the
+    clipping norm)"""
+    self.engine.reduce_local()
+    if self.clip_norm > 0:
+      self.engine.local_gradsq(self._norm_slot, self._emb_gradsq_weight())
 
   def _phase_apply(self):
     vs = self.varstore
@@ -156,7 +192,10 @@ class EmbeddingParallelEstimator(EasyRecEstimator):
     if eng.padded:
       # fixed-capacity exchange: no host-side sizes anywhere, the host never waits for the device
       seq = head + [(self._phase_owner_serve, eng.exchange_rows)]
-      if self.is_training:
+      if self.is_training and self.overlap:
+        seq += [(self._phase_forward_backward, self._start_dense_allreduce), (self._phase_reduce, self._finish_exchanges),
+                (self._phase_update, None)]
+      elif self.is_training:
         seq += [(self._phase_compute, lambda: (self._sync_dense_grads(), eng.exchange_grads())), (self._phase_update, None)]
       else:
         seq += [(self._phase_compute, None)]

@@ -88,6 +88,13 @@ class ThreadSimComm(object):
     self.sim.barrier.wait()
     return t
 
+  def all_reduce_sum_async(self, t):
+    self.all_reduce_sum(t)  # (threads on one device: nothing to overlap with)
+    return None
+
+  def wait(self, handle):
+    pass
+
   def all_gather_rows(self, t):
     allt = self._publish(t.contiguous())
     out = [x.clone() for x in allt]

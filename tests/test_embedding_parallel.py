@@ -133,14 +133,36 @@ def _gloo_worker_own_batches(rank, world, port, B, steps, lazy, clip, out_dir):
   est = EmbeddingParallelEstimator(cfg, device='cpu', batch_size=B, seed=4, rank=rank, world=world,
                                    replicate_bytes=1024).build()
   init = est.state_dict()  # collective: rank 0's copy seeds the oracle
+  # the order in which the step issues and joins its collectives (the overlap of the dense all-reduce, model/embedding_parallel.py)
+  events = []
+  comm = est.comm
+
+  def logged(name, fn, note=None):
+    def call(*a, **k):
+      events.append((name if note is None else note(*a, **k), 'issue'))
+      out = fn(*a, **k)
+      events.append((name if note is None else note(*a, **k), 'return'))
+      return out
+    return call
+
+  grad_bufs = {sh['ugrads_all'].data_ptr() for sh in est.engine.shard.values() if sh['leader'] is None}
+  comm.all_reduce_sum_async = logged('dense all-reduce (async)', comm.all_reduce_sum_async)
+  comm.wait = logged('dense all-reduce joined', comm.wait)
+  comm.all_reduce_sum = logged('tail all-reduce', comm.all_reduce_sum)
+  comm.all_to_all_equal = logged('all-to-all', comm.all_to_all_equal,
+                                 note=lambda send, recv: 'gradient all-to-all' if send.data_ptr() in grad_bufs else 'all-to-all')
+  assert est.overlap
   losses, norms = [], []
   for step_batches in batches:
+    events.append(('step', 'begin'))
     est.train_step(step_batches[rank])
     losses.append(est.loss_values())
     norms.append(float(est.grad_norm.item()))
+  for name in ('all_reduce_sum_async', 'wait', 'all_reduce_sum', 'all_to_all_equal'):
+    delattr(comm, name)  # (state_dict's collectives are not the step's)
   state = est.state_dict(slots=True)
   with open(os.path.join(out_dir, 'rank%d.pkl' % rank), 'wb') as f:
-    pickle.dump({'init': init if rank == 0 else None, 'state': state, 'losses': losses, 'norms': norms}, f)
+    pickle.dump({'init': init if rank == 0 else None, 'state': state, 'losses': losses, 'norms': norms, 'events': events}, f)
   dist.barrier()
   dist.destroy_process_group()
 
@@ -169,6 +191,22 @@ def test_world2_gloo_own_batches_match_the_w_worker_oracle(ref_backend, tmp_path
     exp_losses.append(orc.train_step_world(step_batches))
   results = [(r['state'], r['losses'], r['norms']) for r in ranks]
   check_against_oracle(results, orc, exp_losses, orc_first, orc_norm0, moving0, steps_checked=steps, clip=clip > 0)
+  # Overlap: in every step of every rank the dense all-reduce is ISSUED (asynchronously, second communicator) before the
+  # gradient all-to-all is issued and JOINED only after the all-to-all has returned - the two are in flight together, and
+  # with them the local reduction that runs between (it produces what the all-to-all sends).  The tail (replicated tables'
+  # gradients; with clipping the norm's share) is all-reduced after the local reduction, before the join.
+  for r in ranks:
+    ev = r['events']
+    starts = [i for i, e in enumerate(ev) if e == ('step', 'begin')] + [len(ev)]
+    assert len(starts) - 1 == steps
+    for a, b in zip(starts[:-1], starts[1:]):
+      step = ev[a:b]
+      issue = step.index(('dense all-reduce (async)', 'issue'))
+      a2a_issue, a2a_done = step.index(('gradient all-to-all', 'issue')), step.index(('gradient all-to-all', 'return'))
+      join = step.index(('dense all-reduce joined', 'issue'))
+      tail = step.index(('tail all-reduce', 'issue'))
+      assert issue < tail < a2a_issue < a2a_done < join, step
+      assert step.count(('dense all-reduce (async)', 'issue')) == 1 and step.count(('dense all-reduce joined', 'return')) == 1
 
 
 def test_evaluate_through_the_sharded_engine(ref_backend):
