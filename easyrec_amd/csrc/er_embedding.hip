@@ -1025,10 +1025,16 @@ __device__ __forceinline__ void finish_run(const RowUpdate& tab, int opt_kind, c
   }
 }
 
-// entries per lane of a tile: 4 for 16-byte lanes (dim 16: 64 entries per pass -> tiles of 256), 1 for scalar lanes
-// (dim 1: 256 entries per pass) - a tile is 256 sorted entries either way, and a group of 100 k entries spreads over
-// > 400 workgroups (the kernel is latency-bound: dependent random reads, so parallelism is what matters)
-__host__ __device__ constexpr int tile_passes(int V) { return V == 4 ? 4 : 1; }
+// entries per lane of a tile: 4 for 16-byte lanes (dim 16: 64 entries per pass -> tiles of 256), 2 for scalar lanes
+// (dim 1: 256 entries per pass -> tiles of 512).  The kernels are latency-bound (dependent random reads), so a group of
+// 100 k entries should spread over hundreds of workgroups - but in the fused own launch the dim-1 tiles of DeepFM are the
+// critical path (per-workgroup stamps: profiles/r05_own_launch_workgroup_stamps.txt) and 1,664 workgroups need two
+// rounds on the chip: 512-entry dim-1 tiles (two gathers in flight per lane) + 8 column-reduction parts per one-row
+// table fit it in one (own launch 35.7 -> 32.2 us; 1024-entry tiles: 33.4; profiles/r05_own_launch_knobs_ab_lines.txt)
+#ifndef ER_TILE_PASSES_V1
+#define ER_TILE_PASSES_V1 2
+#endif
+__host__ __device__ constexpr int tile_passes(int V) { return V == 4 ? 4 : ER_TILE_PASSES_V1; }
 
 template <int V>
 __device__ __forceinline__ void tile_body(int bid, float* __restrict__ smem, const uint32_t* __restrict__ skeys,
@@ -1182,7 +1188,10 @@ emb_bwd_fix_kernel(const uint32_t* __restrict__ skeys, int64_t n, int dim, int G
 // Entry j of a group -> (lookup l, output row r) by a binary search over the lookups' entry offsets (dense-mode lookups:
 // entry i of a lookup is its row i); the per-entry pointer / scale arrays of the three-launch path are not read.
 // ------------------------------------------------------------------------------------------------
-constexpr int kProjParts = 16;
+#ifndef ER_PROJ_PARTS
+#define ER_PROJ_PARTS 8
+#endif
+constexpr int kProjParts = ER_PROJ_PARTS;
 constexpr int kOwnMaxLookups = 128;
 constexpr int kOwnMaxGG = 8;
 
@@ -1202,16 +1211,6 @@ struct OwnArgs {
                                  // closed-form replay's tables (lag 1) for the row update to do it in registers
   float* tile_first;             // partial sums of the runs that cross tile boundaries (emb_bwd_fix_multi_kernel)
   float* tile_last;
-  // PAIRED follower (er_emb_bwd_fused): a dim-1 table group that shares this group's sort and keys (DeepFM / WideAndDeep: the
-  // wide weights of the ids the deep group embeds) rides on this group's tiles - lane 0 of every entry's lane group
-  // gathers, scans and applies the follower's scalar next to its own 4 columns, so the follower launches no tile
-  // workgroups of its own (they were the slow half of the launch: 256 scalar gathers + an 8-step scan per tile).
-  int pair;                      // 1: the fields below are set
-  RowUpdate ptab;
-  DecayAux paux;
-  const OwnLookup* plookups;
-  float* ptile_first;
-  float* ptile_last;
   int n_proj;
   const int32_t* proj_lookup;    // [n_proj] lookups into one-row tables
   float* proj_partial;           // [n_proj][kProjParts][dim + 1] (last: number of valid entries)
@@ -1222,8 +1221,6 @@ struct OwnMulti {
   int start[kMaxMulti + 1];       // tile workgroups
   int proj_start[kMaxMulti + 1];  // projection workgroups (after all tiles)
   int opt_kind;
-  int proj_first;                 // the one-row tables' workgroups (the longest dependent chain: partials -> ticket ->
-                                  // last arriver) take the FIRST block ids, so the chain runs under the tiles, not behind them
   const er_opt_hyper* hyper;
   unsigned long long* dbg;        // probe hook (er_debug_stamps): 16 wall-clock stamps per workgroup, or nullptr
   int n_gg;
@@ -1431,140 +1428,6 @@ __device__ __forceinline__ void own_tile_body(int bid, const OwnMulti& ma, const
   if (dbg && tid == 0) dbg[1] = wall_clock64();
 }
 
-// own_tile_body<4> of a leader whose dim-1 follower is PAIRED with it (OwnArgs.pair): the tile's LDS rows are kPairLd floats
-// wide - the leader's dim columns, then the follower's scalar at column dim (rows stay 16-byte aligned) - and lane 0 of
-// every entry's lane group carries the scalar through gather, scan and run end.  Same arithmetic, entry order and scan tree
-// as the two groups' own tiles: the follower's bits are those of own_tile_body<1>.
-constexpr int kPairPad = 4;
-__device__ __forceinline__ void own_pair_tile_body(int bid, const OwnMulti& ma, const OwnArgs& a, float* __restrict__ smem) {
-  constexpr int V = 4;
-  constexpr int kTilePasses = tile_passes(V);
-  const int G = a.G, dim = a.dim;
-  const int ldv = dim + kPairPad;
-  const int epp = kBlock / G;
-  const int T = kTilePasses * epp;
-  float* vals = smem;                                                                         // [T][ldv]
-  uint32_t* keys = reinterpret_cast<uint32_t*>(smem + static_cast<size_t>(T) * ldv);          // [T + 2]
-  OwnLookup* L = reinterpret_cast<OwnLookup*>(keys + T + 2 + ((T + 2) & 1));                   // [n_lookups] leader
-  OwnLookup* Lw = L + a.n_lookups;                                                             // [n_lookups] follower
-  er_grad_group* ggs = reinterpret_cast<er_grad_group*>(Lw + a.n_lookups);                     // [n_gg]
-  const int tid = threadIdx.x;
-  const int sub = tid % G;
-  const int c = sub * V;
-  const bool col_ok = c < dim;
-  const int64_t t0 = static_cast<int64_t>(bid) * T;
-  unsigned long long* dbg = ma.dbg ? ma.dbg + static_cast<int64_t>(blockIdx.x) * 16 : nullptr;
-  if (dbg && tid == 0) dbg[0] = wall_clock64();
-  {
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(a.lookups);
-    const uint32_t* srcw = reinterpret_cast<const uint32_t*>(a.plookups);
-    uint32_t* dst = reinterpret_cast<uint32_t*>(L);
-    uint32_t* dstw = reinterpret_cast<uint32_t*>(Lw);
-    for (int i = tid; i < a.n_lookups * static_cast<int>(sizeof(OwnLookup) / 4); i += kBlock) {
-      dst[i] = src[i];
-      dstw[i] = srcw[i];
-    }
-  }
-  if (tid < kWave)
-    for (int k = 0; k < ma.n_gg; ++k) ggs[k] = ma.gg[k];
-  for (int i = tid; i < T + 2; i += kBlock) {
-    const int64_t p = t0 - 1 + i;
-    keys[i] = (p >= 0 && p < a.n) ? a.skeys[p] : kInvalidKey;
-  }
-  __syncthreads();
-  if (dbg && tid == 0) dbg[2] = wall_clock64();
-  // gather
-#pragma unroll
-  for (int ps = 0; ps < kTilePasses; ++ps) {
-    const int e = ps * epp + tid / G;
-    const int64_t p = t0 + e;
-    Vec<V> acc;
-    acc.zero();
-    float wacc = 0.f;
-    if (col_ok && p < a.n && keys[e + 1] != kInvalidKey) {
-      const int j = static_cast<int>(a.svals[p]);
-      const int li = own_find(L, a.n_lookups, j, a.cap_shift);
-      const OwnLookup lk = L[li];
-      const int r = j - lk.base;
-      const Vec<V> g = own_finish<V>(ggs[lk.gg], lk.tmask, r, lk.out_col + c, c);
-      acc.add_scaled(g, own_scale(lk, r));
-      if (sub == 0) {
-        const OwnLookup lw = Lw[li];
-        const Vec<1> gw = own_finish<1>(ggs[lw.gg], lw.tmask, r, lw.out_col, 0);
-        Vec<1> t;
-        t.zero();
-        t.add_scaled(gw, own_scale(lw, r));
-        wacc = t.v;
-      }
-    }
-    if (col_ok) acc.store(vals + static_cast<size_t>(e) * ldv + c);
-    if (sub == 0) vals[static_cast<size_t>(e) * ldv + dim] = wacc;
-  }
-  if (dbg && tid == 0) dbg[3] = wall_clock64();
-  __syncthreads();
-  if (dbg && tid == 0) dbg[4] = wall_clock64();
-  // segmented inclusive scan (own_chunk's tree; lane 0 of an entry also combines the follower's column)
-  for (int off = 1; off < T; off <<= 1) {
-    Vec<V> add[kTilePasses];
-    float wadd[kTilePasses];
-    int any = 0;
-#pragma unroll
-    for (int ps = 0; ps < kTilePasses; ++ps) {
-      const int e = ps * epp + tid / G;
-      add[ps].zero();
-      wadd[ps] = 0.f;
-      if (col_ok && e >= off && keys[e + 1] != kInvalidKey && keys[e + 1 - off] == keys[e + 1]) {
-        add[ps].load(vals + static_cast<size_t>(e - off) * ldv + c);
-        if (sub == 0) wadd[ps] = vals[static_cast<size_t>(e - off) * ldv + dim];
-        any = 1;
-      }
-    }
-    if (!__syncthreads_or(any)) break;
-#pragma unroll
-    for (int ps = 0; ps < kTilePasses; ++ps) {
-      const int e = ps * epp + tid / G;
-      if (col_ok && e >= off && keys[e + 1] != kInvalidKey && keys[e + 1 - off] == keys[e + 1]) {
-        Vec<V> cur;
-        cur.load(vals + static_cast<size_t>(e) * ldv + c);
-        cur.add(add[ps]);
-        cur.store(vals + static_cast<size_t>(e) * ldv + c);
-        if (sub == 0) vals[static_cast<size_t>(e) * ldv + dim] = vals[static_cast<size_t>(e) * ldv + dim] + wadd[ps];
-      }
-    }
-    __syncthreads();
-  }
-  // run ends
-  if (dbg && tid == 0) dbg[5] = wall_clock64();
-  const ReduceOut ro{0, nullptr, nullptr, nullptr, nullptr, 0};
-#pragma unroll
-  for (int ps = 0; ps < kTilePasses; ++ps) {
-    const int e = ps * epp + tid / G;
-    const int64_t p = t0 + e;
-    if (!col_ok || p >= a.n) continue;
-    const uint32_t key = keys[e + 1];
-    if (key == kInvalidKey) continue;
-    if (keys[e + 2] == key && e != T - 1) continue;
-    const bool from_prev = keys[0] == key;
-    const bool to_next = (e == T - 1) && keys[T + 1] == key;
-    const float* gs = vals + static_cast<size_t>(e) * ldv + c;
-    const float wsum = vals[static_cast<size_t>(e) * ldv + dim];
-    if (!from_prev && !to_next) {
-      finish_run<V>(a.tab, ma.opt_kind, ma.hyper, ro, key, p, sub, c, dim, gs, a.aux);
-      if (sub == 0) finish_run<1>(a.ptab, ma.opt_kind, ma.hyper, ro, key, p, 0, 0, 1, &wsum, a.paux);
-    } else {
-      Vec<V> r;
-      r.load(gs);
-      if (from_prev) r.store(a.tile_first + static_cast<size_t>(bid) * dim + c);
-      if (to_next) r.store(a.tile_last + static_cast<size_t>(bid) * dim + c);
-      if (sub == 0) {
-        if (from_prev) a.ptile_first[bid] = wsum;
-        if (to_next) a.ptile_last[bid] = wsum;
-      }
-    }
-  }
-  if (dbg && tid == 0) dbg[1] = wall_clock64();
-}
-
 // one-row tables: workgroup (projection pj, part k) sums its rows' scaled finished gradients; the last of the kProjParts
 // to arrive combines the partials (fixed order) and updates the row
 template <int V>
@@ -1651,20 +1514,18 @@ __device__ __forceinline__ void own_proj_body(int local, const OwnMulti& ma, con
   if (dbg && tid == 0) dbg[1] = wall_clock64();
 }
 
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4)))
+#ifndef ER_OWN_WAVES
+#define ER_OWN_WAVES 4
+#endif
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(ER_OWN_WAVES)))
 emb_bwd_own_kernel(OwnMulti ma) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  int bid = blockIdx.x;
-  if (ma.proj_first) {  // grid = [one-row tables | tiles]
-    const int n_proj = ma.proj_start[ma.n];
-    bid = bid < n_proj ? bid + ma.start[ma.n] : bid - n_proj;
-  }
+  const int bid = blockIdx.x;
   if (bid < ma.start[ma.n]) {
     int i = 0;
     while (i + 1 < ma.n && bid >= ma.start[i + 1]) ++i;
     const OwnArgs& a = ma.a[i];
-    if (a.pair) own_pair_tile_body(bid - ma.start[i], ma, a, smem);
-    else if (a.V == 4) own_tile_body<4>(bid - ma.start[i], ma, a, smem);
+    if (a.V == 4) own_tile_body<4>(bid - ma.start[i], ma, a, smem);
     else own_tile_body<1>(bid - ma.start[i], ma, a, smem);
     return;
   }
@@ -3255,28 +3116,12 @@ static int emb_group_run(er_emb_group* g, int opt_kind, const er_opt_hyper* hype
 // another stream it must leave wave slots free or those kernels queue behind the sweep's
 // long-running grid-stride blocks (measured).
 static int g_sweep_blocks_per_cu = 8;
-// er_emb_bwd_fused: a dim-1 follower's tiles ride on its leader's (own_pair_tile_body); 0 = every group launches its own tiles
-static int g_pair_tiles = 1;
-static int g_proj_first = 1;     // er_emb_bwd_fused: OwnMulti.proj_first
-static int g_front_sort_e8 = 0;  // 8 composites per thread in the front sort for P <= 4096 too (A/B)
 
 int er_config_set(const char* key, int64_t value) {
   ER_REQUIRE(key, "er_config_set: null key");
   if (strcmp(key, "sweep_blocks_per_cu") == 0) {
     ER_REQUIRE(value >= 1 && value <= 8, "er_config_set: sweep_blocks_per_cu must be in 1..8");
     g_sweep_blocks_per_cu = static_cast<int>(value);
-    return 0;
-  }
-  if (strcmp(key, "proj_first") == 0) {
-    g_proj_first = value != 0;
-    return 0;
-  }
-  if (strcmp(key, "front_sort_e8") == 0) {
-    g_front_sort_e8 = value != 0;
-    return 0;
-  }
-  if (strcmp(key, "pair_tiles") == 0) {
-    g_pair_tiles = value != 0;
     return 0;
   }
   ER_REQUIRE(false, "er_config_set: unknown key %s", key);
@@ -3607,7 +3452,7 @@ static int emb_front_impl(er_emb_group* const* groups, int n, int flags, const e
     const bool with_tables = g->tabs != nullptr && !tables_done;
     er::DecayTabDev tabs{};
     if (with_tables) tabs = g->tabs->dev;
-    const int E = (P > 4096 || g_front_sort_e8) ? 8 : 4;
+    const int E = P > 4096 ? 8 : 4;
     const int threads = P / E;
     const int table_blocks = with_tables ? static_cast<int>(er::ceil_div(static_cast<int64_t>(tabs.K) * er::kWave, threads)) : 0;
     const size_t lds = sizeof(unsigned long long) * static_cast<size_t>(P);
@@ -3707,7 +3552,6 @@ int er_emb_bwd_fused(er_emb_group* const* groups, int n, const er_grad_group* fi
   ma.start[0] = 0;
   ma.proj_start[0] = 0;
   ma.opt_kind = opt_kind;
-  ma.proj_first = g_proj_first;
   ma.hyper = hyper;
   ma.n_gg = n_finish;
   ma.dbg = g_own_dbg;
@@ -3786,7 +3630,6 @@ int er_emb_bwd_fused(er_emb_group* const* groups, int n, const er_grad_group* fi
     a.tab = tab_of(g);
     a.aux = g->front_deferred ? decay_aux_for(g, 1) : er::DecayAux{};
     a.tile_first = g->tile_first; a.tile_last = g->tile_last;
-    a.pair = 0;
     const bool proj = src->front_skip && g->n_proj > 0;
     a.n_proj = proj ? g->n_proj : 0;
     {  // the fix launch's arguments (emb_bwd_fix_multi_kernel: the three-launch path's kernel)
@@ -3809,35 +3652,10 @@ int er_emb_bwd_fused(er_emb_group* const* groups, int n, const er_grad_group* fi
     if (need_proj > need) need = need_proj;
     if (need > lds) lds = need;
     g->sorted_valid = false;
+    ma.start[ma.n + 1] = ma.start[ma.n] + a.n_tiles;
+    ma.proj_start[ma.n + 1] = ma.proj_start[ma.n] + a.n_proj * er::kProjParts;
     g->front_deferred = false;
     ++ma.n;
-  }
-  // A dim-1 group and a 16-byte-lane group of this call that reduce over ONE sort (either leads it) with the same entries:
-  // the dim-1 group's tiles ride on the other's (own_pair_tile_body) and are not launched.
-  bool rides[er::kMaxMulti] = {false, false, false, false};
-  for (int i = 0; i < ma.n && g_pair_tiles; ++i) {
-    if (groups[i]->dim != 1 || rides[i]) continue;
-    for (int j = 0; j < ma.n; ++j) {
-      er::OwnArgs& lead = ma.a[j];
-      const er::OwnArgs& w = ma.a[i];
-      if (j == i || lead.V != 4 || lead.pair || lead.skeys != w.skeys || lead.svals != w.svals || lead.n != w.n ||
-          lead.n_lookups != w.n_lookups || lead.cap_shift != w.cap_shift || lead.n_tiles != w.n_tiles ||
-          groups[j]->tile_entries != groups[i]->tile_entries || !emb_group_same_keys(groups[i], groups[j]))
-        continue;
-      lead.pair = 1;
-      lead.ptab = w.tab; lead.paux = w.aux; lead.plookups = w.lookups;
-      lead.ptile_first = w.tile_first; lead.ptile_last = w.tile_last;
-      const int T = groups[j]->tile_entries;
-      const size_t need_pair = sizeof(float) * static_cast<size_t>(T) * (lead.dim + er::kPairPad) + sizeof(uint32_t) * (T + 4) +
-                               2 * sizeof(er::OwnLookup) * static_cast<size_t>(lead.n_lookups) + sizeof(er_grad_group) * static_cast<size_t>(n_finish);
-      if (need_pair > lds) lds = need_pair;
-      rides[i] = true;
-      break;
-    }
-  }
-  for (int i = 0; i < ma.n; ++i) {
-    ma.start[i + 1] = ma.start[i] + (rides[i] ? 0 : ma.a[i].n_tiles);
-    ma.proj_start[i + 1] = ma.proj_start[i] + ma.a[i].n_proj * er::kProjParts;
   }
   for (int k = 0; k < n_finish; ++k) ma.gg[k] = finish[k];
   const int grid = ma.start[ma.n] + ma.proj_start[ma.n];

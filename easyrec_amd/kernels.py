@@ -443,11 +443,6 @@ class HipBackend(object):
     self.lib.er_emb_group_num_entries.restype = ctypes.c_int64
     if self.lib.er_abi_version() != 1:
       raise RuntimeError('easyrec_amd: ABI version mismatch in %s' % LIB_PATH)
-    # A/B switches of the fused embedding step (er_config_set): paired tiles, one-row tables first, 8 composites per sort thread
-    for env, key, default in (('EASYREC_AMD_PAIR_TILES', b'pair_tiles', '1'), ('EASYREC_AMD_PROJ_FIRST', b'proj_first', '1'),
-                              ('EASYREC_AMD_SORT_E8', b'front_sort_e8', '0')):
-      if os.environ.get(env, default) != default:
-        self.lib.er_config_set(key, ctypes.c_int64(int(os.environ[env])))
 
   # -- measurement hook (bench.py): with `op_log` a list, every contraction appends (kernel name as rocprof prints it,
   # flops): one eager step gives the algorithmic work behind each GEMM kernel of the step's profile

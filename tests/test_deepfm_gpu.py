@@ -510,11 +510,9 @@ def test_fused_embedding_step_matches_the_general_path(optimizer, buckets, B):
       assert abs(a[k] - b[k]) <= (1e-6 if step == 0 else 2e-4) * max(1.0, abs(a[k])), (step, k, a[k], b[k])
 
 
-def _run_variant(cfg, batches, B, defer, prologue, pair, e8=False, graph=False):
+def _run_variant(cfg, batches, B, defer, prologue, graph=False):
   be = kernels.hip()
   be.defer_catch_up, be.prologue_tables = defer, prologue
-  be.config_set('pair_tiles', int(pair))
-  be.config_set('front_sort_e8', int(e8))
   try:
     est = EasyRecEstimator(cfg, device=DEV, batch_size=B, seed=4).build()
     losses = []
@@ -529,31 +527,26 @@ def _run_variant(cfg, batches, B, defer, prologue, pair, e8=False, graph=False):
     return losses, est.state_dict(slots=True)
   finally:
     del be.defer_catch_up, be.prologue_tables
-    be.config_set('pair_tiles', 1)
-    be.config_set('front_sort_e8', 0)
 
 
 @pytest.mark.parametrize('buckets,B', [(1000, 256), (50, 2048)])
 def test_fused_step_variants_change_no_bit(buckets, B):
-  """Round 5's three changes to the fused single-GPU embedding step are re-arrangements of WHERE the same fp32 operations
-  run, not of the operations: (1) lazy dense decay caught up in registers by the lookup and again by the row update
-  (er_emb_fwd_lazy, update_row_lazy) instead of by a catch-up launch that stores the rows; (2) the dim-1 (wide) group's
-  tiles riding on the deep group's (own_pair_tile_body); (3) the lag-1 replay table built by the prologue and sort +
-  lookup in one launch (er_emb_front_fwd), eager and as a replayed hipGraph; (4) 8 composites per thread in the sort.
-  Eight steps over ids that recur after idle gaps (so rows ARE caught up): every loss, table, slot and dense variable
-  bit-identical to the round-4 arrangement."""
+  """Round 5's changes to the fused single-GPU embedding step are re-arrangements of WHERE the same fp32 operations run, not
+  of the operations: (1) lazy dense decay caught up in registers by the lookup and again by the row update
+  (er_emb_fwd_lazy, update_row_lazy) instead of by a catch-up launch that stores the rows; (2) the lag-1 replay table
+  built by the prologue and sort + lookup in one launch (er_emb_front_fwd), eager and as a replayed hipGraph.  Eight steps
+  over ids that recur after idle gaps (so rows ARE caught up): every loss, table, slot and dense variable bit-identical
+  to the round-4 arrangement."""
   cfg = _cfg('deepfm_criteo_small.config')
   for f in cfg.feature_config.features:
     if f.HasField('hash_bucket_size') and f.hash_bucket_size > 0:
       f.hash_bucket_size = buckets
   gen = SyntheticCriteo(cfg.data_config, list(cfg.feature_config.features), batch_size=B, seed=13)
   batches = [gen.next_batch() for _ in range(8)]
-  base_l, base_s = _run_variant(cfg, batches, B, defer=False, prologue=False, pair=False)
-  variants = {'in registers': dict(defer=True, prologue=False, pair=False),
-              'paired tiles': dict(defer=False, prologue=False, pair=True),
-              'one launch': dict(defer=True, prologue=True, pair=True),
-              'one launch, graph': dict(defer=True, prologue=True, pair=True, graph=True),
-              'one launch, e8': dict(defer=True, prologue=True, pair=True, e8=True)}
+  base_l, base_s = _run_variant(cfg, batches, B, defer=False, prologue=False)
+  variants = {'in registers': dict(defer=True, prologue=False),
+              'one launch': dict(defer=True, prologue=True),
+              'one launch, graph': dict(defer=True, prologue=True, graph=True)}
   for name, kw in variants.items():
     l, s = _run_variant(cfg, batches, B, **kw)
     assert l == base_l, (name, [i for i, (a, b) in enumerate(zip(l, base_l)) if a != b])
