@@ -22,8 +22,6 @@
 #include <cstring>
 #include <vector>
 
-#include <rocprim/rocprim.hpp>
-
 #include "er_common.h"
 #include "er_decay.h"
 #include "er_grad_finish.h"
@@ -1029,8 +1027,9 @@ __device__ __forceinline__ void finish_run(const RowUpdate& tab, int opt_kind, c
 // (dim 1: 256 entries per pass -> tiles of 512).  The kernels are latency-bound (dependent random reads), so a group of
 // 100 k entries should spread over hundreds of workgroups - but in the fused own launch the dim-1 tiles of DeepFM are the
 // critical path (per-workgroup stamps: profiles/r05_own_launch_workgroup_stamps.txt) and 1,664 workgroups need two
-// rounds on the chip: 512-entry dim-1 tiles (two gathers in flight per lane) + 8 column-reduction parts per one-row
-// table fit it in one (own launch 35.7 -> 32.2 us; 1024-entry tiles: 33.4; profiles/r05_own_launch_knobs_ab_lines.txt)
+// rounds on the chip: 512-entry dim-1 tiles (two gathers in flight per lane) take the own launch from 35.7 to ~32.5 us
+// (1024-entry tiles: 33.4; 8 instead of 16 column-reduction parts per one-row table: no further gain, and a longer serial
+// sum per part; 5 waves per SIMD: none; profiles/r05_own_launch_knobs_ab_lines.txt)
 #ifndef ER_TILE_PASSES_V1
 #define ER_TILE_PASSES_V1 2
 #endif
@@ -1189,7 +1188,7 @@ emb_bwd_fix_kernel(const uint32_t* __restrict__ skeys, int64_t n, int dim, int G
 // entry i of a lookup is its row i); the per-entry pointer / scale arrays of the three-launch path are not read.
 // ------------------------------------------------------------------------------------------------
 #ifndef ER_PROJ_PARTS
-#define ER_PROJ_PARTS 8
+#define ER_PROJ_PARTS 16
 #endif
 constexpr int kProjParts = ER_PROJ_PARTS;
 constexpr int kOwnMaxLookups = 128;
@@ -1742,7 +1741,8 @@ __device__ __forceinline__ void seg_sort_body(int lk, const uint32_t* __restrict
                         const er_lookup_desc* __restrict__ descs, int P, Route rt, uint32_t* __restrict__ keys_out,
                         uint32_t* __restrict__ vals_out, uint32_t* __restrict__ flags_out,
                         uint32_t* __restrict__ hidx_out, uint32_t* __restrict__ seg_count, int skip_one_row,
-                        unsigned long long* sk_raw, uint32_t* __restrict__ ukeys_seg = nullptr) {
+                        unsigned long long* sk_raw, uint32_t* __restrict__ ukeys_seg = nullptr,
+                        int64_t n_limit = INT64_MAX) {  // (entries at positions >= n_limit do not exist: chunks of an owner group)
   typedef typename std::conditional<NARROW, uint32_t, unsigned long long>::type C;
   C* sk = reinterpret_cast<C*>(sk_raw);
   constexpr int L = E == 8 ? 3 : (E == 4 ? 2 : 1);
@@ -1750,7 +1750,8 @@ __device__ __forceinline__ void seg_sort_body(int lk, const uint32_t* __restrict
   const int t = threadIdx.x;
   const int i0 = t * E;
   const int64_t base = ent_base[lk];
-  const int cnt = static_cast<int>(ent_base[lk + 1] - base);
+  const int64_t end = ent_base[lk + 1] < n_limit ? ent_base[lk + 1] : n_limit;
+  const int cnt = end > base ? static_cast<int>(end - base) : 0;
   const int logP = __ffs(P) - 1;
   const bool routed = rt.local_base != nullptr;
   const uint32_t stride = static_cast<uint32_t>(rt.shard_stride);
@@ -2003,6 +2004,198 @@ emb_front_fwd_kernel(const int64_t* __restrict__ ent_base, const er_lookup_desc*
       const int w0 = (static_cast<int>(threadIdx.x) / kBlock) * 4;
       sumsq_partials[vb] = (red[w0] + red[w0 + 1]) + (red[w0 + 2] + red[w0 + 3]);
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The device-wide sort of a group whose lookups share a table or hold more than kSegSortMax entries (DIN's [B, L]
+// sequence lookups, MMoE's tag lists, dlrm_on_criteo_parquet_ep_v2-style shared tables): hand-written, no library.
+//   1. emb_chunk_sort_kernel: the entries in chunks of P <= kSegSortMax, one workgroup each, by the bitonic network of the
+//      per-lookup sort (64-bit composites key << 32 | entry: the order of a stable sort by key);
+//   2. emb_merge_pass_kernel, log2(chunks) times: adjacent sorted runs merged pairwise, one workgroup per kMergeTile
+//      outputs - two merge-path searches (where the tile's diagonals cut the two runs), the tile's inputs staged in LDS,
+//      then every lane finds its own kMergeVt outputs by a merge-path search in LDS and merges them serially;
+//   3. emb_head_scan_kernel / emb_head_offsets_kernel: run-head flags and their exclusive scan (the index of every
+//      entry's run among the distinct keys) in two levels - per tile, then one workgroup over the tile totals.
+// (rounds 1-4: rocPRIM's radix_sort_pairs + exclusive_scan, 18 launches and ~100 us per DIN / MMoE step.)
+// ------------------------------------------------------------------------------------------------
+template <int E>
+__global__ void __launch_bounds__(kSegSortMax / 8)
+emb_chunk_sort_kernel(const uint32_t* __restrict__ keys_in, const int64_t* __restrict__ chunk_base, int P, int64_t n,
+                      uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long sk_raw[];
+  seg_sort_body<E, false, false, false>(blockIdx.x, keys_in, chunk_base, nullptr, P, Route{1, 0, nullptr}, keys_out, vals_out,
+                                        nullptr, nullptr, nullptr, 0, sk_raw, nullptr, n);
+}
+
+// entries per chunk of the device-wide sort: 4 composites per thread (the 8-per-thread network that 8192-entry chunks
+// need ran 54 us for DIN's 25 chunks against ~20 us for 50 chunks of 4096 + one more 6 us merge pass)
+constexpr int kChunkSortMax = 4096;
+constexpr int kMergeVt = 8;                      // outputs per lane
+constexpr int kMergeTile = kBlock * kMergeVt;    // outputs per workgroup
+
+__device__ __forceinline__ unsigned long long merge_comp(const uint32_t* __restrict__ k, const uint32_t* __restrict__ v, int64_t i) {
+  return (static_cast<unsigned long long>(k[i]) << 32) | v[i];
+}
+
+// the number of elements the first `d` outputs of merge(A, B) take from A (composites are distinct: no ties)
+template <typename GetA, typename GetB>
+__device__ __forceinline__ int merge_path(int d, int na, int nb, GetA a_at, GetB b_at) {
+  int lo = d > nb ? d - nb : 0, hi = d < na ? d : na;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (a_at(mid) < b_at(d - 1 - mid)) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+__global__ void __launch_bounds__(kBlock)
+emb_merge_pass_kernel(const uint32_t* __restrict__ kin, const uint32_t* __restrict__ vin, int64_t n, int64_t run,
+                      uint32_t* __restrict__ kout, uint32_t* __restrict__ vout) {
+  __shared__ unsigned long long sm[kMergeTile];
+  __shared__ int s_lo[2], s_hi[2];
+  const int tid = threadIdx.x;
+  const int64_t o0 = static_cast<int64_t>(blockIdx.x) * kMergeTile;
+  const int64_t o1 = o0 + kMergeTile < n ? o0 + kMergeTile : n;
+  const int64_t pair0 = (o0 / (2 * run)) * (2 * run);           // start of this tile's pair of runs
+  const int64_t a_beg = pair0;
+  const int64_t a_end = a_beg + run < n ? a_beg + run : n;
+  const int64_t b_end = a_end + run < n ? a_end + run : n;
+  const int na = static_cast<int>(a_end - a_beg), nb = static_cast<int>(b_end - a_end);
+  // Where the tile's two diagonals cut the runs: the merge-path search over global memory, 128 probes per step and
+  // diagonal (one half of the workgroup each) - 3 steps for runs of 2^17 entries where a lane's binary search takes 17
+  // dependent round trips (12 -> ~6 us per pass).  The predicate A[a] < B[d - 1 - a] is true below the cut, false from it on.
+  {
+    constexpr int K = kBlock / 2;
+    const int half = tid / K, t = tid % K;
+    const int d = static_cast<int>((half == 0 ? o0 : o1) - pair0);
+    if (t == 0) {
+      s_lo[half] = d > nb ? d - nb : 0;
+      s_hi[half] = d < na ? d : na;
+    }
+    __syncthreads();
+    for (;;) {
+      const int lo = s_lo[half], hi = s_hi[half];
+      const int r = hi - lo;
+      if (!__syncthreads_or(r > 0)) break;  // (also: every lane has read lo / hi before anyone moves them)
+      if (r > 0) {
+        const int p = lo + static_cast<int>((static_cast<int64_t>(r) * (t + 1)) / (K + 1));  // in [lo, hi)
+        const bool below = merge_comp(kin, vin, a_beg + p) < merge_comp(kin, vin, a_end + (d - 1 - p));
+        if (below) atomicMax(&s_lo[half], p + 1); else atomicMin(&s_hi[half], p);
+      }
+      __syncthreads();
+    }
+  }
+  const int a0 = s_lo[0], a1 = s_lo[1];
+  const int b0 = static_cast<int>(o0 - pair0) - a0, b1 = static_cast<int>(o1 - pair0) - a1;
+  const int ta = a1 - a0, tb = b1 - b0;  // the tile's inputs: ta + tb == o1 - o0
+  for (int i = tid; i < ta; i += kBlock) sm[i] = merge_comp(kin, vin, a_beg + a0 + i);
+  for (int i = tid; i < tb; i += kBlock) sm[ta + i] = merge_comp(kin, vin, a_end + b0 + i);
+  __syncthreads();
+  const int total = ta + tb;
+  const int d = tid * kMergeVt < total ? tid * kMergeVt : total;
+  int ia = merge_path(d, ta, tb, [&](int i) { return sm[i]; }, [&](int i) { return sm[ta + i]; });
+  int ib = d - ia;
+#pragma unroll
+  for (int j = 0; j < kMergeVt; ++j) {
+    const int64_t o = o0 + d + j;
+    if (d + j >= total) break;
+    const bool take_a = ib >= tb || (ia < ta && sm[ia] < sm[ta + ib]);
+    const unsigned long long c = take_a ? sm[ia] : sm[ta + ib];
+    ia += take_a ? 1 : 0;
+    ib += take_a ? 0 : 1;
+    kout[o] = static_cast<uint32_t>(c >> 32);
+    vout[o] = static_cast<uint32_t>(c & 0xFFFFFFFFu);
+  }
+}
+
+// run-head flags of the sorted keys + their exclusive scan inside tiles of kMergeTile positions; tile_sum[t] = heads in tile t
+__global__ void __launch_bounds__(kBlock)
+emb_head_scan_kernel(const uint32_t* __restrict__ skeys, int64_t n, uint32_t* __restrict__ flags,
+                     uint32_t* __restrict__ head_index, uint32_t* __restrict__ tile_sum) {
+  __shared__ uint32_t wsum[kBlock / 64];
+  const int tid = threadIdx.x;
+  const int64_t p0 = static_cast<int64_t>(blockIdx.x) * kMergeTile + static_cast<int64_t>(tid) * kMergeVt;
+  uint32_t f[kMergeVt], c = 0;
+  uint32_t prev = (p0 > 0 && p0 <= n) ? skeys[p0 - 1] : kInvalidKey;
+#pragma unroll
+  for (int j = 0; j < kMergeVt; ++j) {
+    const int64_t p = p0 + j;
+    const uint32_t key = p < n ? skeys[p] : kInvalidKey;
+    f[j] = (p < n && key != kInvalidKey && (p == 0 || prev != key)) ? 1u : 0u;
+    c += f[j];
+    prev = key;
+  }
+  const int lane = tid & 63, wave = tid >> 6;
+  uint32_t inc = c;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t o = __shfl_up(inc, d, 64);
+    if (lane >= d) inc += o;
+  }
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  uint32_t before = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < kBlock / 64; ++w) {
+    const uint32_t ws = wsum[w];
+    if (w < wave) before += ws;
+    total += ws;
+  }
+  uint32_t run = before + inc - c;
+#pragma unroll
+  for (int j = 0; j < kMergeVt; ++j) {
+    const int64_t p = p0 + j;
+    if (p < n) {
+      flags[p] = f[j];
+      head_index[p] = run;
+    }
+    run += f[j];
+  }
+  if (tid == 0) tile_sum[blockIdx.x] = total;
+}
+
+// head_index += (heads of the tiles before); *n_unique = all heads.  Every workgroup scans the tile totals itself (a few
+// hundred words from L2) instead of waiting for a scan launch: two launches in all.
+__global__ void __launch_bounds__(kBlock)
+emb_head_offsets_kernel(const uint32_t* __restrict__ tile_sum, int n_tiles, int64_t n, uint32_t* __restrict__ head_index,
+                        int32_t* __restrict__ n_unique) {
+  __shared__ uint32_t red[kBlock / 64];
+  const int tid = threadIdx.x;
+  const int t = blockIdx.x;
+  uint32_t before = 0, all = 0;
+  for (int i = tid; i < n_tiles; i += kBlock) {
+    const uint32_t v = tile_sum[i];
+    all += v;
+    if (i < t) before += v;
+  }
+  // (two sums over the workgroup, integer: exact in any order)
+  uint32_t x = before;
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) x += __shfl_xor(x, d, 64);
+  if ((tid & 63) == 0) red[tid >> 6] = x;
+  __syncthreads();
+  uint32_t off = 0;
+#pragma unroll
+  for (int w = 0; w < kBlock / 64; ++w) off += red[w];
+  __syncthreads();
+  if (t == 0 && n_unique != nullptr) {
+    uint32_t y = all;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) y += __shfl_xor(y, d, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = y;
+    __syncthreads();
+    if (tid == 0) {
+      uint32_t tot = 0;
+      for (int w = 0; w < kBlock / 64; ++w) tot += red[w];
+      *n_unique = static_cast<int32_t>(tot);
+    }
+  }
+  if (off == 0) return;
+  const int64_t p0 = static_cast<int64_t>(t) * kMergeTile;
+  for (int i = tid; i < kMergeTile; i += kBlock) {
+    const int64_t p = p0 + i;
+    if (p < n) head_index[p] += off;
   }
 }
 
@@ -2721,10 +2914,10 @@ struct er_emb_group {
   float *tile_first = nullptr, *tile_last = nullptr;
   int tile_entries = 0;
   uint32_t *head_flags = nullptr, *head_index = nullptr;
-  void* sort_temp = nullptr;
-  size_t sort_temp_bytes = 0;
-  void* scan_temp = nullptr;
-  size_t scan_temp_bytes = 0;
+  // the hand-written device-wide sort (emb_chunk_sort_kernel + emb_merge_pass_kernel) and head scan
+  int chunk_pow2 = 0;                 // entries per sorted chunk (a power of two <= kSegSortMax)
+  int64_t* d_chunk_base = nullptr;    // [chunks + 1]
+  uint32_t* d_tile_sum = nullptr;     // [ceil(N / kMergeTile)] run heads per tile
   // er_emb_front / er_emb_bwd_fused (the fused single-GPU step)
   uint64_t front_epoch = ~0ull;   // sort_epoch of the last sort made by er_emb_front
   bool front_skip = false;        // ... which kept the one-row tables' entries out of the sort
@@ -2896,12 +3089,17 @@ int er_emb_group_create(const er_lookup_desc* descs, int n, int32_t dim, int64_t
   ER_CHECK_HIP(hipMalloc(&g->head_index, sizeof(uint32_t) * N));
   ER_CHECK_HIP(hipMalloc(&g->seg_count, sizeof(uint32_t) * (static_cast<size_t>(n) * 64 + 1)));  // [n][64 owners]
   ER_CHECK_HIP(hipMemset(g->keys_in, 0xFF, sizeof(uint32_t) * N));
-  ER_CHECK_HIP(rocprim::radix_sort_pairs(nullptr, g->sort_temp_bytes, g->keys_in, g->keys_out, g->vals_in, g->vals_out,
-                                         static_cast<size_t>(N), 0u, static_cast<unsigned>(g->key_bits)));
-  ER_CHECK_HIP(hipMalloc(&g->sort_temp, g->sort_temp_bytes > 0 ? g->sort_temp_bytes : 16));
-  ER_CHECK_HIP(rocprim::exclusive_scan(nullptr, g->scan_temp_bytes, g->head_flags, g->head_index, 0u,
-                                       static_cast<size_t>(N), rocprim::plus<uint32_t>()));
-  ER_CHECK_HIP(hipMalloc(&g->scan_temp, g->scan_temp_bytes > 0 ? g->scan_temp_bytes : 16));
+  {  // the device-wide sort's chunks (all but the last hold chunk_pow2 entries) and the head scan's tile totals
+    int p2 = er::kSegSortMin;
+    while (p2 < N && p2 < er::kChunkSortMax) p2 <<= 1;
+    g->chunk_pow2 = p2;
+    const int64_t chunks = er::ceil_div(N, p2);
+    std::vector<int64_t> cb(static_cast<size_t>(chunks) + 1);
+    for (int64_t c = 0; c <= chunks; ++c) cb[static_cast<size_t>(c)] = std::min<int64_t>(c * p2, N);
+    ER_CHECK_HIP(hipMalloc(&g->d_chunk_base, sizeof(int64_t) * cb.size()));
+    ER_CHECK_HIP(hipMemcpy(g->d_chunk_base, cb.data(), sizeof(int64_t) * cb.size(), hipMemcpyHostToDevice));
+    ER_CHECK_HIP(hipMalloc(&g->d_tile_sum, sizeof(uint32_t) * static_cast<size_t>(er::ceil_div(N, er::kMergeTile) + 1)));
+  }
   *out = g;
   return 0;
 }
@@ -2929,7 +3127,7 @@ int er_emb_group_destroy(er_emb_group* g) {
     f->src = f;
   }
   void* ptrs[] = {g->d_descs, g->d_blk_start, g->d_ent_base, g->keys_in, g->keys_out, g->vals_in, g->vals_out,
-                  g->ent_gptr, g->ent_scale, g->tile_first, g->tile_last, g->head_flags, g->head_index, g->sort_temp, g->scan_temp,
+                  g->ent_gptr, g->ent_scale, g->tile_first, g->tile_last, g->head_flags, g->head_index, g->d_chunk_base, g->d_tile_sum,
                   g->d_local_base, g->seg_count, g->d_overflow, g->d_extra_keys, g->d_proj_lookup, g->d_proj_partial,
                   g->d_proj_ticket, g->d_own_lookups};
   for (void* q : ptrs) (void)hipFree(q);
@@ -3017,6 +3215,38 @@ static int emb_group_adopt(er_emb_group* g, hipStream_t s, bool* adopted) {
   return 0;
 }
 
+// keys_in / vals_in (the built entries; N of them active) -> keys_out / vals_out in the order of a stable sort by key:
+// chunk sorts, then log2(chunks) merge passes that ping-pong between the two array pairs (the chunk sort writes the pair
+// from which an even number of passes ends in keys_out / vals_out; it may sort in place: a workgroup holds its whole
+// chunk in registers before it stores)
+static int emb_group_wide_sort(er_emb_group* g, int64_t N, hipStream_t s) {
+  const int P = g->chunk_pow2;
+  const int64_t chunks = er::ceil_div(N, P);
+  int passes = 0;
+  for (int64_t r = P; r < N; r <<= 1) ++passes;
+  uint32_t *ka = g->keys_out, *va = g->vals_out, *kb = g->keys_in, *vb = g->vals_in;
+  if (passes & 1) { std::swap(ka, kb); std::swap(va, vb); }
+  const size_t lds = sizeof(unsigned long long) * static_cast<size_t>(P);
+  // (d_chunk_base was built for n_entries; an owner group may hold fewer this step: the kernel bounds its last chunk by N)
+  if (P > 4096) {
+    hipLaunchKernelGGL((er::emb_chunk_sort_kernel<8>), dim3(static_cast<unsigned>(chunks)), dim3(P / 8), lds, s, g->keys_in,
+                       g->d_chunk_base, P, N, ka, va);
+  } else {
+    hipLaunchKernelGGL((er::emb_chunk_sort_kernel<4>), dim3(static_cast<unsigned>(chunks)), dim3(P / 4), lds, s, g->keys_in,
+                       g->d_chunk_base, P, N, ka, va);
+  }
+  ER_LAUNCH_CHECK();
+  const unsigned tiles = static_cast<unsigned>(er::ceil_div(N, er::kMergeTile));
+  for (int64_t run = P; run < N; run <<= 1) {
+    hipLaunchKernelGGL(er::emb_merge_pass_kernel, dim3(tiles), dim3(er::kBlock), 0, s, ka, va, N, run, kb, vb);
+    ER_LAUNCH_CHECK();
+    std::swap(ka, kb);
+    std::swap(va, vb);
+  }
+  ER_REQUIRE(ka == g->keys_out, "wide sort: pass parity");
+  return 0;
+}
+
 // build keys (routed) + stable sort.  Leaves keys_out/vals_out valid for this step.
 static bool emb_group_segmented(const er_emb_group* g) {
   if (g->n_active >= 0) return false;
@@ -3052,9 +3282,7 @@ static int emb_group_build_sort(er_emb_group* g, hipStream_t s, bool with_heads 
     ER_LAUNCH_CHECK();
     return 0;
   }
-  ER_CHECK_HIP(rocprim::radix_sort_pairs(g->sort_temp, g->sort_temp_bytes, g->keys_in, g->keys_out, g->vals_in,
-                                         g->vals_out, static_cast<size_t>(N), 0u, static_cast<unsigned>(g->key_bits), s));
-  return 0;
+  return emb_group_wide_sort(g, N, s);
 }
 
 static int emb_group_sort(er_emb_group* g, hipStream_t s) { return emb_group_build_sort(g, s); }
@@ -3062,12 +3290,12 @@ static int emb_group_sort(er_emb_group* g, hipStream_t s) { return emb_group_bui
 // head flags + exclusive scan + unique count over the sorted keys
 static int emb_group_heads(er_emb_group* g, int32_t* n_unique, hipStream_t s) {
   const int64_t N = group_entries(g);
-  hipLaunchKernelGGL(er::emb_head_flag_kernel, dim3(static_cast<int>(er::ceil_div(N, er::kBlock))), dim3(er::kBlock), 0,
-                     s, g->src->keys_out, N, g->head_flags);
+  const int tiles = static_cast<int>(er::ceil_div(N, er::kMergeTile));
+  hipLaunchKernelGGL(er::emb_head_scan_kernel, dim3(tiles), dim3(er::kBlock), 0, s, g->src->keys_out, N, g->head_flags,
+                     g->head_index, g->d_tile_sum);
   ER_LAUNCH_CHECK();
-  ER_CHECK_HIP(rocprim::exclusive_scan(g->scan_temp, g->scan_temp_bytes, g->head_flags, g->head_index, 0u,
-                                       static_cast<size_t>(N), rocprim::plus<uint32_t>(), s));
-  hipLaunchKernelGGL(er::emb_count_unique_kernel, dim3(1), dim3(64), 0, s, g->head_flags, g->head_index, N, n_unique);
+  hipLaunchKernelGGL(er::emb_head_offsets_kernel, dim3(tiles), dim3(er::kBlock), 0, s, g->d_tile_sum, tiles, N, g->head_index,
+                     n_unique);
   ER_LAUNCH_CHECK();
   return 0;
 }

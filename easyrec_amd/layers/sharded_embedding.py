@@ -372,6 +372,9 @@ class ShardedEmbeddingEngine(EmbeddingEngine):
   def exchange_grads(self):
     if self.rep and self.rep_flat_own:
       self.comm.all_reduce_sum(self.rep_flat)
+    self.exchange_row_grads()
+
+  def exchange_row_grads(self):
     for sh in self.shard.values():
       if sh['leader'] is None:
         self.comm.all_to_all_equal(sh['ugrads_all'], sh['recv_grads_all'])
@@ -460,6 +463,12 @@ class ShardedEmbeddingEngine(EmbeddingEngine):
     self._ran_version = version
 
   def reduce_local(self):
+    self.reduce_local_replicated()
+    self.reduce_local_sharded()
+
+  def reduce_local_replicated(self):
+    """first half of reduce_local: the group gradient buffers finished, the replicated tables' row sums in the dense buffer
+    that is all-reduced with the dense gradients - after it everything the dense all-reduce carries is final"""
     be = kernels.hip()
     self.finish_group_grads()
     if self.rep:
@@ -469,6 +478,10 @@ class ShardedEmbeddingEngine(EmbeddingEngine):
       reps = list(self.rep.values())
       for i in range(0, len(reps), 4):
         be.emb_bwd_reduce_dense([r['group'] for r in reps[i:i + 4]], [r['dense'] for r in reps[i:i + 4]])
+
+  def reduce_local_sharded(self):
+    """second half: this rank's gradients of the sharded tables' rows, de-duplicated per (owner, id) for the exchange"""
+    be = kernels.hip()
     for dim, sh in self.shard.items():
       be.emb_bwd_reduce_routed(sh['req'], sh['ugrads'])
 

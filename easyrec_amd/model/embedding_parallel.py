@@ -15,11 +15,13 @@ synchronisation in the step; + ONE all-reduce (dense gradients, with the replica
 behind them in the same buffer).  The static device work between the collectives (route | owner merge + serve |
 lookup+forward+backward | local reduce | owner update + replicated apply + dense optimizer) is captured as five
 hipGraphs; the collectives are issued eagerly between them and the host runs ahead of the device.
-Overlap (round 5): the dense gradients are complete when the model's backward returns, long before the embedding
-gradients are reduced and exchanged - their all-reduce is issued there, asynchronously on a second communicator
-(core/comm.py all_reduce_sum_async), runs under the local reduction and next to the gradient all-to-all, and is joined
-right before the optimizer kernels; what the local reduction adds to the all-reduced buffer (the replicated small
-tables' gradients, the clipping norm's embedding share: the buffer's tail) follows in a second, small all-reduce.
+Overlap (round 5, more than one rank, no gradient clipping): everything the all-reduce carries - the dense gradients
+and, behind them in the same buffer, the replicated small tables' row sums - is final once the model's backward has
+returned and the replicated half of the local reduction has run, long before the sharded tables' gradients are
+de-duplicated and exchanged.  The all-reduce is issued there, asynchronously on a second communicator (core/comm.py
+all_reduce_sum_async), runs under the sharded half of the local reduction and next to the gradient all-to-all, and is
+joined right before the optimizer kernels.  (With clipping by global norm the buffer's tail also carries this rank's share
+of the embedding gradients' norm, which only the sharded reduction produces: the step then keeps the serial order.)
 The compact exchange (variable split sizes through one host sync per step, three segments) remains for lookups
 the per-lookup routed sort does not cover.
 """
@@ -48,7 +50,7 @@ class EmbeddingParallelEstimator(EasyRecEstimator):
     self._engine_kwargs = dict(replicate_bytes=replicate_bytes, recv_slack=recv_slack)
     self._graphs = None
     self._dense_work = None
-    self._overlap = os.environ.get('EASYREC_AMD_EP_OVERLAP', '1') != '0'  # A/B switch
+    self._overlap = os.environ.get('EASYREC_AMD_EP_OVERLAP', 'auto')  # 'auto': more than one rank; '1' / '0': A/B switch
     super(EmbeddingParallelEstimator, self).__init__(pipeline_config, device=device, batch_size=batch_size, seed=seed,
                                                      schema_kwargs=schema_kwargs, is_training=is_training,
                                                      overlap_sweep=False, dense_dtype=dense_dtype,
@@ -90,18 +92,20 @@ class EmbeddingParallelEstimator(EasyRecEstimator):
   # -- overlap: the dense all-reduce in flight under the local reduction and the gradient all-to-all
   @property
   def overlap(self):
-    return self._overlap and (self.world > 1 or not isinstance(self.comm, LocalComm)) and hasattr(self.comm, 'all_reduce_sum_async')
+    """At world 1 there is nothing to overlap and the split costs a graph segment and the second communicator's stream
+    hand-over (`bench.py --force_ep --rccl`: 0.686 against 0.601 ms, profiles/r05_ep_world1_rccl_lines.txt): the switch
+    EASYREC_AMD_EP_OVERLAP=1 forces it on there (the tests do), =0 off everywhere."""
+    if self._overlap == '0' or self.clip_norm > 0 or not hasattr(self.comm, 'all_reduce_sum_async'):
+      return False
+    return self.world > 1 or (self._overlap == '1' and not isinstance(self.comm, LocalComm))
 
   def _start_dense_allreduce(self):
-    """right after the model's backward: every dense gradient is final (compat/optimizers.py:315-331 issues them one by one
-    as backward produces them); the buffer's tail is still being written by the local reduction"""
-    self._dense_work = self.comm.all_reduce_sum_async(self.varstore.flat_grad)
+    """right after the model's backward and the replicated tables' reduction: every gradient the buffer carries is final
+    (compat/optimizers.py:315-331 issues the dense ones one by one as backward produces them)"""
+    self._dense_work = self.comm.all_reduce_sum_async(self.varstore.flat_grad_all)
 
   def _finish_exchanges(self):
-    tail = self.varstore.grad_tail
-    if tail.numel():  # replicated tables' gradients + the clipping norm's embedding share: complete only now
-      self.comm.all_reduce_sum(tail)
-    self.engine.exchange_grads()
+    self.engine.exchange_row_grads()
     self.comm.wait(self._dense_work)  # joined here: the optimizer kernels of the next segment read the summed gradients
     self._dense_work = None
 
@@ -129,8 +133,9 @@ class EmbeddingParallelEstimator(EasyRecEstimator):
     self.engine.route()
 
   def _phase_compute(self, reduce=True):
-    """lookup -> forward -> losses -> backward [-> local gradient reduction] (no collective inside).  reduce=False: the
-    step overlaps the dense all-reduce with the local reduction, which is then a segment of its own (_phase_reduce)."""
+    """lookup -> forward -> losses -> backward -> local gradient reduction (no collective inside).  reduce=False: the step
+    overlaps the dense all-reduce with the SHARDED half of the local reduction, which is then a segment of its own
+    (_phase_reduce_sharded); this one ends with the replicated half."""
     if self.is_training and not self.engine.inference:
       # the owned rows' rolling flush next to the lookup and the dense part (the owners' catch-up ran in an earlier
       # phase, their row update comes in a later one); fork and join inside this phase: one hipGraph holds both
@@ -144,17 +149,18 @@ class EmbeddingParallelEstimator(EasyRecEstimator):
       self._loss_tail(loss_dict)
       if self.is_training:
         self.model.backward()
+        self.engine.reduce_local_replicated()
         if reduce:
-          self._phase_reduce()
+          self._phase_reduce_sharded()
     self.engine._join_window_flush()
 
   def _phase_forward_backward(self):
     self._phase_compute(reduce=False)
 
-  def _phase_reduce(self):
-    """the embedding gradients of this rank's batch, de-duplicated per (owner, id) for the exchange (+ its share of the
-    clipping norm)"""
-    self.engine.reduce_local()
+  def _phase_reduce_sharded(self):
+    """the gradients of the sharded tables' rows, de-duplicated per (owner, id) for the exchange (+ with clipping this
+    rank's share of the norm)"""
+    self.engine.reduce_local_sharded()
     if self.clip_norm > 0:
       self.engine.local_gradsq(self._norm_slot, self._emb_gradsq_weight())
 
@@ -193,7 +199,7 @@ class EmbeddingParallelEstimator(EasyRecEstimator):
       # fixed-capacity exchange: no host-side sizes anywhere, the host never waits for the device
       seq = head + [(self._phase_owner_serve, eng.exchange_rows)]
       if self.is_training and self.overlap:
-        seq += [(self._phase_forward_backward, self._start_dense_allreduce), (self._phase_reduce, self._finish_exchanges),
+        seq += [(self._phase_forward_backward, self._start_dense_allreduce), (self._phase_reduce_sharded, self._finish_exchanges),
                 (self._phase_update, None)]
       elif self.is_training:
         seq += [(self._phase_compute, lambda: (self._sync_dense_grads(), eng.exchange_grads())), (self._phase_update, None)]

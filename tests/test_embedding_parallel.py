@@ -148,10 +148,10 @@ def _gloo_worker_own_batches(rank, world, port, B, steps, lazy, clip, out_dir):
   grad_bufs = {sh['ugrads_all'].data_ptr() for sh in est.engine.shard.values() if sh['leader'] is None}
   comm.all_reduce_sum_async = logged('dense all-reduce (async)', comm.all_reduce_sum_async)
   comm.wait = logged('dense all-reduce joined', comm.wait)
-  comm.all_reduce_sum = logged('tail all-reduce', comm.all_reduce_sum)
+  comm.all_reduce_sum = logged('all-reduce', comm.all_reduce_sum)
   comm.all_to_all_equal = logged('all-to-all', comm.all_to_all_equal,
                                  note=lambda send, recv: 'gradient all-to-all' if send.data_ptr() in grad_bufs else 'all-to-all')
-  assert est.overlap
+  assert est.overlap == (clip == 0.0)  # (with clipping the buffer's tail needs the sharded reduction: serial order)
   losses, norms = [], []
   for step_batches in batches:
     events.append(('step', 'begin'))
@@ -191,22 +191,25 @@ def test_world2_gloo_own_batches_match_the_w_worker_oracle(ref_backend, tmp_path
     exp_losses.append(orc.train_step_world(step_batches))
   results = [(r['state'], r['losses'], r['norms']) for r in ranks]
   check_against_oracle(results, orc, exp_losses, orc_first, orc_norm0, moving0, steps_checked=steps, clip=clip > 0)
-  # Overlap: in every step of every rank the dense all-reduce is ISSUED (asynchronously, second communicator) before the
-  # gradient all-to-all is issued and JOINED only after the all-to-all has returned - the two are in flight together, and
-  # with them the local reduction that runs between (it produces what the all-to-all sends).  The tail (replicated tables'
-  # gradients; with clipping the norm's share) is all-reduced after the local reduction, before the join.
+  # Overlap (no clipping): in every step of every rank the ONE all-reduce (dense gradients + replicated tables' row sums) is
+  # ISSUED (asynchronously, second communicator) before the gradient all-to-all is issued and JOINED only after the
+  # all-to-all has returned - the two are in flight together, and with them the sharded half of the local reduction that
+  # runs between (it produces what the all-to-all sends).  No other all-reduce in the step.
   for r in ranks:
     ev = r['events']
     starts = [i for i, e in enumerate(ev) if e == ('step', 'begin')] + [len(ev)]
     assert len(starts) - 1 == steps
     for a, b in zip(starts[:-1], starts[1:]):
       step = ev[a:b]
+      if clip > 0:
+        assert ('dense all-reduce (async)', 'issue') not in step and step.count(('all-reduce', 'issue')) == 1
+        continue
       issue = step.index(('dense all-reduce (async)', 'issue'))
       a2a_issue, a2a_done = step.index(('gradient all-to-all', 'issue')), step.index(('gradient all-to-all', 'return'))
       join = step.index(('dense all-reduce joined', 'issue'))
-      tail = step.index(('tail all-reduce', 'issue'))
-      assert issue < tail < a2a_issue < a2a_done < join, step
+      assert issue < a2a_issue < a2a_done < join, step
       assert step.count(('dense all-reduce (async)', 'issue')) == 1 and step.count(('dense all-reduce joined', 'return')) == 1
+      assert ('all-reduce', 'issue') not in step
 
 
 def test_evaluate_through_the_sharded_engine(ref_backend):

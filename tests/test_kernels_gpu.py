@@ -888,11 +888,14 @@ def test_closed_form_decay_tracks_the_sweep(hip):
 
 
 @pytest.mark.parametrize('sizes', [(100, 4096, 5000, 8192, 257), (1, 2, 3), (4097,), (8192, 8192), (9000, 50),
-                                   (-3000000, 4096), (-600000, 8192, 77)])
+                                   (-3000000, 4096), (-600000, 8192, 77), (8193,), (16384, 1), (20000, 8192, 3),
+                                   (204800,), (70000, 9001, 130000)])
 def test_segmented_sort_sizes(hip, sizes):
-  """One table per lookup -> one workgroup sorts one lookup's entries (emb_segment_sort_kernel; the last case has
-  a lookup above its capacity and takes the global radix sort).  The de-duplicated keys must come out ascending
-  and every row's gradient must be the source-order sum of its entries."""
+  """One table per lookup -> one workgroup sorts one lookup's entries (emb_segment_sort_kernel); a lookup above 8192
+  entries takes the device-wide sort - hand-written since round 5: 8192-entry chunks sorted in LDS, then pairwise
+  merge-path passes (1 to 5 of them here, a ragged last chunk, DIN's 4096 x 50 sequence lookup) and the two-level head
+  scan.  The de-duplicated keys must come out ascending and every row's gradient must be the source-order sum of its
+  entries."""
   rng = np.random.default_rng(abs(sum(sizes)))
   dim = 4
   specs, base, exp_keys, exp = [], 0, [], []
@@ -927,6 +930,43 @@ def test_segmented_sort_sizes(hip, sizes):
   keys2, grads2, _ = hip.emb_bwd_reduce(g)
   torch.cuda.synchronize()
   assert torch.equal(grads[:len(exp_keys)], grads2[:len(exp_keys)])
+  hip.emb_group_destroy(g)
+
+
+@pytest.mark.parametrize('n_lookups,n,rows', [(26, 4096, 5000), (3, 300, 40), (7, 9000, 100000), (2, 5, 3)])
+def test_lookups_that_share_one_table_take_the_device_wide_sort(hip, n_lookups, n, rows):
+  """Several features on ONE table (the reference's own embedding-parallel Criteo config,
+  samples/model_config/dlrm_on_criteo_parquet_ep_v2.config; `embedding_name` sharing): the lookups' key ranges coincide, so
+  the group's order is not the concatenation of per-lookup sorts - chunk sort + merge passes over all entries.  A key's
+  gradient is the sum over every lookup that read it, in entry order."""
+  rng = np.random.default_rng(n_lookups * 1000 + n)
+  dim = 8
+  table = torch.zeros(rows, dim, device=DEV)
+  specs = []
+  acc = np.zeros((rows, dim), dtype=np.float64)
+  for li in range(n_lookups):
+    ids = rng.integers(-1, rows, size=n).astype(np.int64)
+    ids[: n // 4] = ids[0]
+    dout = (rng.standard_normal((n, dim)) * 0.01).astype(np.float32)
+    specs.append(kernels.LookupSpec(table=table, ids=torch.from_numpy(ids).to(DEV), offsets=None, weights=None,
+                                    out=torch.from_numpy(dout).to(DEV), out_col=0, rows=rows, key_base=0, dim=dim,
+                                    combiner=0, n_rows=n, max_nnz=n))
+    ok = ids >= 0
+    np.add.at(acc, ids[ok], dout[ok].astype(np.float64))
+  touched = np.zeros(rows, dtype=bool)
+  for sp in specs:
+    i = sp.ids.cpu().numpy()
+    touched[i[i >= 0]] = True
+  exp_keys = np.nonzero(touched)[0]
+  g = hip.emb_group_create(specs, dim, rows, table, None, None, None)
+  keys, grads, cnt = hip.emb_bwd_reduce(g)
+  torch.cuda.synchronize()
+  assert int(cnt.item()) == len(exp_keys)
+  assert np.array_equal(keys[:len(exp_keys)].cpu().numpy(), exp_keys)
+  assert np.allclose(grads[:len(exp_keys)].cpu().numpy(), acc[exp_keys], rtol=1e-5, atol=1e-7)
+  keys2, grads2, _ = hip.emb_bwd_reduce(g)  # deterministic: the same bits again
+  torch.cuda.synchronize()
+  assert torch.equal(grads[:len(exp_keys)], grads2[:len(exp_keys)]) and torch.equal(keys[:len(exp_keys)], keys2[:len(exp_keys)])
   hip.emb_group_destroy(g)
 
 
