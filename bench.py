@@ -200,6 +200,9 @@ def embedding_bytes_per_step(est, batches):
   per['emb_catch_up_heads_kernel'] = per['emb_catch_up_closed_kernel']
   per['emb_bwd_own_kernel'] = per['emb_bwd_tile_multi_kernel']
   per['emb_front_sort_kernel'] = per['emb_segment_sort_kernel']
+  # round 5: sort + lookup in one launch, the lookup reading whole row records (lazy decay evaluated in registers)
+  per['emb_front_fwd_kernel'] = per['emb_segment_sort_kernel'] + per['emb_fwd_kernel']
+  per['emb_fwd_lazy_kernel'] = per['emb_fwd_kernel']
   return lazy, sweep, per
 
 
@@ -478,9 +481,20 @@ def steady_state(est, gen, n_steps):
     evs[i + 1].record()
   torch.cuda.synchronize()
   ms = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(n_steps)])
+  p50 = float(np.percentile(ms, 50))
+  slow = np.nonzero(ms > 1.3 * p50)[0]
   out = {'steps': n_steps, 'distinct_batches': n_steps, 'batch_generation_s': gen_s,
-         'ms_per_step_mean': float(ms.mean()), 'ms_per_step_p50': float(np.percentile(ms, 50)),
+         'ms_per_step_mean': float(ms.mean()), 'ms_per_step_p50': p50,
          'ms_per_step_p99': float(np.percentile(ms, 99)), 'ms_per_step_last_256_mean': float(ms[-256:].mean()),
+         'ms_per_step_max': float(ms.max()),
+         # steps slower than 1.3 x the median, where they sit and what they cost in all: a tail that is a few isolated
+         # steps (the host refreshing the per-step scalar table every HYPER_SLOTS / 2 steps behind a stream
+         # synchronisation, a clock dip) reads differently from one that is a drift of every step
+         'slow_steps': {'count': int(slow.size), 'first_indices': [int(i) for i in slow[:12]],
+                        'excess_ms_total': float((ms[slow] - p50).sum()) if slow.size else 0.0,
+                        'mean_without_them': float(np.delete(ms, slow).mean()) if slow.size < ms.size else None,
+                        'hyper_table_refresh_every': int(getattr(est, 'HYPER_SLOTS', 0) // 2)},
+         'ms_per_step_quarters_mean': [float(q.mean()) for q in np.array_split(ms, 4)],
          'examples_per_s': float(est.batch_size / (ms.mean() * 1e-3))}
   eng = est.engine
   if getattr(eng, 'lazy_decay', False):
@@ -500,8 +514,8 @@ def steady_state(est, gen, n_steps):
       est.graph = saved_graph
     out['catch_up_ms_p50'] = float(np.percentile(cu, 50))
     out['catch_up_ms_p99'] = float(np.percentile(cu, 99))
-    out['catch_up_note'] = 'the general path\'s catch-up launches between HIP events, eager; a fused single-GPU step runs its ' \
-                           'catch-up as emb_catch_up_heads_kernel inside er_emb_front (roofline.kernels has its duration)' 
+    out['catch_up_note'] = 'the general path\'s catch-up launches between HIP events, eager; a fused single-GPU step has no ' \
+                           'catch-up launch since round 5 (the lookup and the row update evaluate a row\'s pending decay in registers)' 
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     eng.flush_decay()
@@ -729,6 +743,10 @@ def main():
     if args.steady_steps > 0 and not args.no_graph:
       try:
         out['steady_state'] = steady_state(est, dgen, args.steady_steps)
+        # (beside the headline: `value` is K timed steps over the resident ring; this is the mean over steady_steps
+        # further DISTINCT batches, host batch hand-over included)
+        out['ms_per_step_steady_mean'] = out['steady_state'].get('ms_per_step_mean')
+        out['value_steady'] = out['steady_state'].get('examples_per_s')
       except Exception as e:  # noqa: BLE001
         out['steady_state'] = {'error': str(e)[:300]}
     if not args.no_cpu_baseline:

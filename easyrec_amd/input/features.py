@@ -97,6 +97,11 @@ class FeatureSchema(object):
         self.tags[name] = {'cap': self.batch_size * max_tag_len, 'weighted': weighted, 'hash_buckets': hb}
       elif ft == FeatureConfig.SequenceFeature:
         hb = int(fc.hash_bucket_size) if fc.HasField('hash_bucket_size') and fc.hash_bucket_size > 0 else None
+        if fc.HasField('ev_params'):
+          # (the sequence's embedding column creates its variable like any other: feature_column_v2.py:3616-3640 ->
+          # _old_get_dense_tensor_internal -> :3478-3513 get_embedding_variable; the id is the hash into the whole range)
+          assert hb is not None, 'ev_params on %s: only hashed SequenceFeatures are hash-table backed here' % name
+          hb = MAX_HASH_BUCKET_SIZE
         ml = int(fc.max_seq_len) if fc.HasField('max_seq_len') and fc.max_seq_len > 0 else max_seq_len
         self.seqs[name] = {'max_len': ml, 'hash_buckets': hb}
         if fc.sub_feature_type == FeatureConfig.RawFeature:

@@ -286,7 +286,7 @@ class Input(object, metaclass=_meta_type):
           x = (x - np.float32(fc.min_val)) / np.float32(fc.max_val - fc.min_val)
         v = bucketize(x, self.schema.seqs[name]['bounds'])
       elif fc.HasField('hash_bucket_size') and fc.hash_bucket_size > 0:
-        v = self._hash_tokens(toks, int(fc.hash_bucket_size))
+        v = self._hash_tokens(toks, int(self.schema.seqs[name]['hash_buckets']))  # (ev_params: the whole int64 range)
       elif fc.vocab_list:
         vocab = {x: j for j, x in enumerate(fc.vocab_list)}
         v = np.array([vocab.get(t, 0) for t in toks], dtype=np.int64)

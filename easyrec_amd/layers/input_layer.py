@@ -1119,8 +1119,8 @@ def declare_lookup(eng, features, column, scope, gkey, col, n_out_rows, seq=Fals
   ev = getattr(column, 'ev_params', None)
   kv_capacity = None
   if ev is not None:
-    assert cat.kind == 'hash' and not seq and not column.shared_name, \
-        'ev_params on %s: hash-table embeddings cover hashed IdFeatures and TagFeatures' % column.raw_name
+    assert cat.kind == 'hash' and not column.shared_name, \
+        'ev_params on %s: hash-table embeddings cover hashed Id-, Tag- and SequenceFeatures with a table of their own' % column.raw_name
     kv_capacity = int(ev.max_capacity) if ev.HasField('max_capacity') else int(os.environ.get('EASYREC_AMD_KV_CAPACITY', 1 << 22))
   eng.declare_table(table_name, rows, column.dimension, column.initializer, kv_capacity=kv_capacity,
                     kv_filter_freq=int(ev.filter_freq) if ev is not None else 0,
@@ -1141,7 +1141,13 @@ def declare_lookup(eng, features, column, scope, gkey, col, n_out_rows, seq=Fals
   if seq:
     s = features.seqs[fname]
     L = s['ids'].shape[1]
-    eng.add_lookup(gkey, table_name, s['ids'].view(-1), None, None, col, 'sum', B * L, B * L, fname)
+    seq_ids = s['ids'].view(-1)
+    if kv_capacity is not None:
+      # every position of the [B, L] id buffer is translated each step (padding is -1: no row, a zero embedding)
+      rows_buf = torch.full_like(seq_ids, -1)
+      eng.kv_jobs.append((table_name, seq_ids, rows_buf))
+      seq_ids = rows_buf
+    eng.add_lookup(gkey, table_name, seq_ids, None, None, col, 'sum', B * L, B * L, fname)
     return
   if fname in schema.tags:
     t = features.tags[fname]

@@ -467,13 +467,13 @@ class OracleTrainer(object):
               keys.append(by_name[k])  # (present in the group: reused either way, seq_input_layer.py:66-79)
             else:
               fc = self.fc_by_name[k]
-              e = self._lookup_dense(V.get(self._column_var_name(group_name, fc, False)), self._categorical_ids(batch, fc, k))
+              e = self._id_lookup(V, self._column_var_name(group_name, fc, False), self._categorical_ids(batch, fc, k))
               if lam > 0:
                 self._reg = self._reg + lam * 0.5 * (e * e).sum()
               keys.append(e)
           for h in m.hist_seq:
             fc = self.fc_by_name[h]
-            e, lens = self._seq_lookup(V.get(self._column_var_name(group_name, fc, False)), batch, h)
+            e, lens = self._seq_lookup(V, self._column_var_name(group_name, fc, False), batch, h)
             hists.append(e)
             seq_len = lens if seq_len is None else seq_len
         hist = torch.cat(hists, dim=-1)
@@ -497,7 +497,13 @@ class OracleTrainer(object):
     hashed, raws, ints = self._cache
     return hashed[name] if name in hashed else ints[name]
 
-  def _seq_lookup(self, table, batch, name):
+  def _id_lookup(self, V, var_name, ids):
+    """one id per example into table `var_name` (hash-table tables: ids -> arena rows first, then the leaf)"""
+    if var_name in self.kv:  # (before V.get: new rows are written into the state the leaf is made from)
+      ids = self._kv_rows(var_name, ids)
+    return self._lookup_dense(V.get(var_name), ids)
+
+  def _seq_lookup(self, V, var_name, batch, name):
     """EmbeddingColumn._get_sequence_dense_tensor (feature_column_v2.py:3616-3640): [B, L, E] with L = the BATCH's
     longest sequence (the sparse tensor's dense shape; compat/feature_column/utils.py:30-54), zero rows for padding."""
     ids = np.asarray(batch['seq/%s/ids' % name])  # [B, max_seq_len], -1 padded
@@ -505,7 +511,10 @@ class OracleTrainer(object):
     L = max(1, int(lens.max())) if getattr(self, 'pad_to_batch_max', True) else ids.shape[1]
     ids = ids[:, :L]
     B = ids.shape[0]
-    return self._lookup_dense(table, ids.reshape(-1)).reshape(B, L, -1), lens
+    flat = ids.reshape(-1)
+    if var_name in self.kv:  # a hash-table (ev_params) sequence: ids -> arena rows (padding -> -1), before the leaf exists
+      flat = self._kv_rows(var_name, flat)
+    return self._lookup_dense(V.get(var_name), flat).reshape(B, L, -1), lens
 
   def seq_input_layer(self, V, batch, group_name):
     """layers/seq_input_layer.py:34-124: keys under variable_scope(group_name), history sequences keep the
@@ -517,12 +526,10 @@ class OracleTrainer(object):
     for m in grp.seq_att_map:
       for k in m.key:
         fc = self.fc_by_name[k]
-        table = V.get(self._column_var_name(group_name, fc, False))
-        keys.append(self._lookup_dense(table, self._categorical_ids(batch, fc, k)))
+        keys.append(self._id_lookup(V, self._column_var_name(group_name, fc, False), self._categorical_ids(batch, fc, k)))
       for h in m.hist_seq:
         fc = self.fc_by_name[h]
-        table = V.get(self._column_var_name(group_name, fc, False))
-        e, lens = self._seq_lookup(table, batch, h)
+        e, lens = self._seq_lookup(V, self._column_var_name(group_name, fc, False), batch, h)
         hists.append(e)
         if seq_len is None:
           seq_len = lens
@@ -914,8 +921,7 @@ class OracleTrainer(object):
     for n in g.feature_names:
       fc = self.fc_by_name[n]
       if fc.feature_type == fc.SequenceFeature:
-        table = V.get('input_layer/%s/embedding_weights' % n)
-        e, lens = self._seq_lookup(table, batch, n)
+        e, lens = self._seq_lookup(V, 'input_layer/%s/embedding_weights' % n, batch, n)
         if lam > 0:
           self._reg = self._reg + lam * 0.5 * (e * e).sum()
         seqs.append(e)

@@ -360,3 +360,61 @@ def test_adagrad_kv_restore_then_train_on_the_stand_in_backend(ref_backend, tmp_
 @pytest.mark.gpu
 def test_adagrad_kv_restore_then_train_on_the_gpu(tmp_path):
   _adagrad_restore_then_train('cuda:0', tmp_path)
+
+
+def _din_with_hash_table_sequences(device, steps=3, B=48):
+  """SequenceFeatures with `ev_params` (the last f4 leftover of round 4): the history sequences of MultiTowerDIN's attention
+  (`tag_brand_list`, `tag_category_list`) embedded from hash-table tables - the sequence column creates its variable like any
+  other (compat/feature_column/feature_column_v2.py:3616-3640 under :3478-3513), keyed by the hash into the whole int64
+  range; padding positions own no row.  Losses of every step, the materialised ids and every row against the oracle."""
+  from easyrec_amd.input.synthetic import SyntheticBatches
+  from easyrec_amd.model.easy_rec_estimator import EasyRecEstimator
+  from oracle.model_oracle import OracleTrainer
+  cfg = config_util.get_configs_from_pipeline_file(os.path.join(ROOT, 'configs', 'din_taobao_small.config'))
+  seqs = [f for f in cfg.feature_config.features if f.feature_type == f.SequenceFeature]
+  assert len(seqs) == 2
+  for f in seqs:
+    f.ev_params.max_capacity = 2048
+  est = EasyRecEstimator(cfg, device=device, batch_size=B, seed=4).build()
+  kv_names = sorted(est.engine.kv_tables)
+  assert len(kv_names) == 2 and all('tag_' in n for n in kv_names), kv_names
+  state0 = est.state_dict()
+  orc = OracleTrainer(cfg, state0, batch_size=B)
+  gen = SyntheticBatches(cfg.data_config, est.feature_configs, batch_size=B, seed=12)
+  for step in range(steps):
+    b = gen.next_batch()
+    est.train_step(b)
+    got, exp = est.loss_values(), orc.train_step(b)
+    for k in exp:
+      assert abs(got[k] - exp[k]) <= (1e-4 if step == 0 else 2e-3) * max(1.0, abs(exp[k])), (step, k, got[k], exp[k])
+  st = est.state_dict(slots=True)
+  for n in kv_names:
+    keys, rows = orc.kv_state(n)
+    assert np.array_equal(st[n + '/keys'], keys), n
+    assert keys.size > 20 and st[n].shape == rows.shape
+    _, m_rows = orc.kv_state(n, orc.slots[n + '/m'])
+    m_scale = float(np.abs(m_rows).max())
+    assert float(np.abs(st[n + '/m'] - m_rows).max()) <= 1e-3 * m_scale + 1e-9, n
+    assert float(np.abs(st[n] - rows).max()) <= 4e-3 * steps, n   # (a few lr-sized steps: Adam on near-zero gradients)
+  # evaluation creates no rows, and a restored twin continues like the original
+  n_before = {n: st[n + '/keys'].size for n in kv_names}
+  est.evaluate([SyntheticBatches(cfg.data_config, est.feature_configs, batch_size=B, seed=99).next_batch()])
+  after = est.state_dict()
+  assert all(after[n + '/keys'].size == n_before[n] for n in kv_names)
+  twin = EasyRecEstimator(cfg, device=device, batch_size=B, seed=4).build()
+  twin.load_state_dict(est.state_dict(slots=True))
+  twin.set_global_step(est.global_step)
+  b = gen.next_batch()
+  est.train_step(b)
+  twin.train_step(b)
+  a, c = est.loss_values(), twin.loss_values()
+  assert all(abs(a[k] - c[k]) <= 1e-6 * max(1.0, abs(a[k])) for k in a), (a, c)
+
+
+def test_hash_table_sequence_features_match_the_oracle_on_the_stand_in_backend(ref_backend):
+  _din_with_hash_table_sequences('cpu')
+
+
+@pytest.mark.gpu
+def test_hash_table_sequence_features_match_the_oracle_on_the_gpu():
+  _din_with_hash_table_sequences('cuda:0')
