@@ -119,9 +119,6 @@ struct GemmArgs {
   BnBwdEpi bn;        // bn.partial != nullptr: emit the BatchNorm-backward column sums of the output tile
   BnFused fu;         // fu.mode != 0: finish the BatchNorm in this launch (see BnFused)
   ATransform at;      // at.mean != nullptr: A is transformed while staged (kernels instantiated with A_TR)
-  int tile_shape = 0; // gemm_f32_grouped_tnn_kernel: 2 * (128-row tile) + (128-column tile)
-  const float* row_bias = nullptr;  // [ceil(M / row_div)][N]: output row r also gets row_bias[r / row_div][col] (the
-  int row_div = 1;                  // per-example term of DIN's first attention layer, er_gemm_f32_rowbias); splits == 1
 };
 
 // Loads 4 consecutive elements along the CONTIGUOUS dimension of the operand tile.
@@ -667,14 +664,6 @@ __device__ __forceinline__ void gemm_f32_block(const GemmArgs& g, int bx, int bz
   // epilogue.  C/D map of the 32x32 tile: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
   const int col = n0 + wn * 32 + (lane & 31);
   const float bv = (g.bias && g.splits == 1 && col < g.N) ? g.bias[col] : 0.f;
-  if (g.row_bias != nullptr && col < g.N) {  // (uniform; before the statistics: they are those of the complete output)
-    const int khalf_rb = lane >> 5;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf_rb;
-      if (row < g.M) acc[r] += g.row_bias[static_cast<int64_t>(row / g.row_div) * g.N + col];
-    }
-  }
   if (g.col_stats)  // (host guarantees splits == 1) every thread takes part: it synchronises the workgroup
     tile_col_stats(acc, bv, m0 + wm * 32, g.M, col, g.N, wm, wn, lane, lds,
                    g.col_stats + static_cast<int64_t>(ty) * g.N * 3, g.fu.mode == 1 || g.fu.mode == 3);
@@ -834,200 +823,6 @@ gemm_f32_grouped_tr_kernel(GroupedArgs ga) {
   while (p + 1 < ga.n && b >= ga.start[p + 1]) ++p;
   const int local = b - ga.start[p];
   gemm_f32_block<A_KC, B_KC, false, true>(ga.p[p], local % ga.tiles[p], local / ga.tiles[p], lds);
-}
-
-// ------------------------------------------------------------------------------------------------
-// TN in the operands' NATURAL layout.  The weight gradients dW = x^T . dz contract over the batch (K = 4,096 ... 204,800
-// rows) into a small M x N; both operands are k-major in HBM ([K][M], [K][N]), and so is the fragment of
-// v_mfma_f32_32x32x2f32: lane l supplies A[k = l >> 5][i = l & 31].  gemm_f32_block transposes both operands on their way
-// into its [mn][k] LDS tiles (4 dword stores per 16-byte load, and global loads that touch 16 rows x 64 B per wave
-// instruction); here a k-tile sits in LDS the way it sits in HBM - As[k][m], Bs[k][n], 16-byte loads along full rows,
-// 16-byte LDS stores - and a fragment is ONE ds_read_b32 per operand and MFMA (lanes 0-31: 32 consecutive floats of
-// row k, lanes 32-63: of the row its pair sits in; row stride = tile + 32 floats, so the halves use different banks).
-// Tile per problem: 128 or 64 along each of m and n (4 waves of (tile / 2) x (tile / 2): 2 x 2 ... 1 x 1 accumulators),
-// so that a 128 x 128 output reads x and dz exactly once per split.
-// Same contraction order per accumulator as gemm_f32_block (MFMA j of a 32-row k-tile takes rows j and 16 + j; a stage
-// here = 8 of the 16 MFMAs = rows {8 s + 0..7} and {16 + 8 s + 0..7}), same split-K workspace: the bits do not change.
-// ------------------------------------------------------------------------------------------------
-constexpr int kTnnRows = 16;                         // k rows per LDS stage
-constexpr int kTnnLdMax = 128 + 32;
-constexpr int kTnnLds = 2 * 2 * (kTnnRows * kTnnLdMax + 32);  // floats: [stage][A | B][16][160] (+ the half offset)
-
-template <int WM, int WN>
-__device__ __forceinline__ void gemm_f32_tnn_block(const GemmArgs& g, int bx, int bz, float* __restrict__ lds) {
-  constexpr int TM = 64 * WM, TN = 64 * WN;     // block tile
-  constexpr int LDA = TM + 32, LDB = TN + 32;   // LDS row strides
-  constexpr int UA = TM / 64, UB = TN / 64;     // 16-byte units per thread and stage
-  // rows 8-15 of a stage (the k of lanes 32-63) start 32 floats later than 8 row strides: 8 * LD is a multiple of 64 and
-  // lanes l, l + 32 of a fragment read would otherwise share a bank
-  constexpr int kOpA = kTnnRows * LDA + 32, kOpB = kTnnRows * LDB + 32;
-  constexpr int kStage = kOpA + kOpB;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  int tx, ty;
-  tile_coords(bx, static_cast<int>(ceil_div(g.N, TN)), static_cast<int>(ceil_div(g.M, TM)), tx, ty);
-  const int m0 = ty * TM, n0 = tx * TN;
-  const int kbeg = bz * g.k_per_split;
-  int kend = kbeg + g.k_per_split;
-  if (kend > g.K) kend = g.K;
-  const int S = 2 * ((kend - kbeg + BK32 - 1) / BK32);  // stages (two per 32-row k-tile)
-  const bool a_vec = (g.lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0);
-  const bool b_vec = (g.ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0);
-  f32x16 acc[WM][WN];
-#pragma unroll
-  for (int a = 0; a < WM; ++a)
-#pragma unroll
-    for (int b = 0; b < WN; ++b)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
-  // a wave whose whole tile lies outside the output (a 64 x 32 problem under a 64 x 64 tile: wn = 1) only stages
-  const bool live = (m0 + wm * 32 * WM < g.M) && (n0 + wn * 32 * WN < g.N);
-
-  // stage s, stage row sr -> global k (see the header: rows j and 16 + j of a 32-row tile pair up in MFMA j)
-  auto k_of = [&](int s, int sr) { return kbeg + (s >> 1) * BK32 + (s & 1) * 8 + (sr & 7) + 16 * (sr >> 3); };
-  const bool tile_full = (m0 + TM <= g.M) && (n0 + TN <= g.N);
-  // Branch-free 16-byte loads (both operands 16-byte aligned with ld % 4 == 0): coordinates outside the operand are
-  // clamped to a valid address and the values zeroed later, in stage() - a use of the loaded value here would wait for it
-  auto fetch_op = [&](const float* __restrict__ P, int ld, int mn0, int MN, int upr, int s, f32x4v* r, int U) {
-    const int mnpad = (MN + 3) & ~3;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      if (i >= U) break;
-      const int u = tid + i * kBlock;
-      int k = k_of(s, u / upr);
-      int mn = mn0 + (u % upr) * 4;
-      k = k < kend ? k : kend - 1;
-      mn = mn < mnpad - 4 ? mn : mnpad - 4;
-      r[i] = *reinterpret_cast<const f32x4v*>(P + static_cast<int64_t>(k) * ld + mn);
-    }
-  };
-  auto fetch_op_generic = [&](const float* __restrict__ P, int ld, int mn0, int MN, int upr, int s, f32x4v* r, int U) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      if (i >= U) break;
-      const int u = tid + i * kBlock;
-      const int k = k_of(s, u / upr);
-      const int mn = mn0 + (u % upr) * 4;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) r[i][j] = (k < kend && mn + j < MN) ? P[static_cast<int64_t>(k) * ld + mn + j] : 0.f;
-    }
-  };
-  auto fetch = [&](f32x4v (&ra)[2], f32x4v (&rb)[2], int s) {
-    s = s < S ? s : S - 1;  // (past the end: the same loads again, never staged)
-    fetch_op(g.A, g.lda, m0, g.M, TM / 4, s, ra, UA);
-    fetch_op(g.B, g.ldb, n0, g.N, TN / 4, s, rb, UB);
-  };
-  auto stage_op = [&](float* __restrict__ dst, int LD, const f32x4v* r, int mn0, int MN, int upr, int s, bool interior, int U) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      if (i >= U) break;
-      const int u = tid + i * kBlock;
-      const int sr = u / upr, c4 = (u % upr) * 4;
-      f32x4v v = r[i];
-      if (!interior) {
-        const int k = k_of(s, sr);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (!(k < kend && mn0 + c4 + j < MN)) v[j] = 0.f;
-      }
-      *reinterpret_cast<f32x4v*>(&dst[sr * LD + (sr >> 3) * 32 + c4]) = v;
-    }
-  };
-  auto stage = [&](int buf, const f32x4v (&ra)[2], const f32x4v (&rb)[2], int s, bool masked) {
-    if (s >= S) return;  // (uniform)
-    const bool interior = !masked || (tile_full && (kbeg + (s >> 1) * BK32 + BK32 <= kend));
-    float* As = lds + buf * kStage;
-    stage_op(As, LDA, ra, m0, g.M, TM / 4, s, interior, UA);
-    stage_op(As + kOpA, LDB, rb, n0, g.N, TN / 4, s, interior, UB);
-  };
-  const int khalf = lane >> 5, l31 = lane & 31;
-  auto compute = [&](int buf) {
-    if (!live) return;
-    const float* As = lds + buf * kStage + khalf * (8 * LDA + 32) + wm * 32 * WM + l31;
-    const float* Bs = lds + buf * kStage + kOpA + khalf * (8 * LDB + 32) + wn * 32 * WN + l31;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float a[WM], b[WN];
-#pragma unroll
-      for (int h = 0; h < WM; ++h) a[h] = As[j * LDA + h * 32];
-#pragma unroll
-      for (int c = 0; c < WN; ++c) b[c] = Bs[j * LDB + c * 32];
-#pragma unroll
-      for (int h = 0; h < WM; ++h)
-#pragma unroll
-        for (int c = 0; c < WN; ++c) acc[h][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[h], b[c], acc[h][c], 0, 0, 0);
-    }
-  };
-  // two register sets: the loads of stage s + 2 are issued before stage s is contracted, stage s + 1 goes to the other LDS
-  // buffer after it; one barrier per stage
-  f32x4v ra0[2], rb0[2], ra1[2], rb1[2];
-  if (a_vec && b_vec) {
-    auto step = [&](int buf, f32x4v (&fa_)[2], f32x4v (&fb_)[2], f32x4v (&sa)[2], f32x4v (&sb)[2], int s) {
-      fetch(fa_, fb_, s + 2);
-      __builtin_amdgcn_sched_barrier(0);
-      compute(buf);
-      __builtin_amdgcn_sched_barrier(0);
-      stage(buf ^ 1, sa, sb, s + 1, true);
-      __syncthreads();
-    };
-    fetch(ra0, rb0, 0);
-    fetch(ra1, rb1, 1);
-    stage(0, ra0, rb0, 0, true);
-    __syncthreads();
-    for (int s = 0; s < S; s += 2) {
-      step(0, ra0, rb0, ra1, rb1, s);
-      step(1, ra1, rb1, ra0, rb0, s + 1);
-    }
-  } else {
-    // unaligned operands (a [K x 1] gradient, a column block at an odd offset): masked scalar loads, a stage at a time
-    for (int s = 0; s < S; ++s) {
-      fetch_op_generic(g.A, g.lda, m0, g.M, TM / 4, s, ra0, UA);
-      fetch_op_generic(g.B, g.ldb, n0, g.N, TN / 4, s, rb0, UB);
-      stage(0, ra0, rb0, s, false);
-      __syncthreads();
-      compute(0);
-      __syncthreads();
-    }
-  }
-  if (!live) return;
-  float* Cz = g.C + (g.splits > 1 ? static_cast<int64_t>(bz) * g.M * g.N : 0);
-  const int ldc = g.splits > 1 ? g.N : g.ldc;
-#pragma unroll
-  for (int h = 0; h < WM; ++h)
-#pragma unroll
-    for (int c = 0; c < WN; ++c) {
-      const int col = n0 + wn * 32 * WN + c * 32 + l31;
-      if (col >= g.N) continue;
-      const float bv = (g.bias && g.splits == 1) ? g.bias[col] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 32 * WM + h * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-        if (row < g.M) {
-          float* p = Cz + static_cast<int64_t>(row) * ldc + col;
-          float v = acc[h][c][r] + bv;
-          if (g.accumulate && g.splits == 1) v = *p + v;
-          *p = v;
-        }
-      }
-    }
-}
-
-__global__ void __launch_bounds__(kBlock)
-gemm_f32_grouped_tnn_kernel(GroupedArgs ga) {
-  __shared__ __attribute__((aligned(16))) float lds[kTnnLds];
-  const int b = blockIdx.x;
-  int p = 0;
-  while (p + 1 < ga.n && b >= ga.start[p + 1]) ++p;
-  const int local = b - ga.start[p];
-  const GemmArgs& g = ga.p[p];
-  const int bx = local % ga.tiles[p], bz = local / ga.tiles[p];
-  switch (g.tile_shape) {  // (uniform over the workgroup)
-    case 3: gemm_f32_tnn_block<2, 2>(g, bx, bz, lds); break;
-    case 2: gemm_f32_tnn_block<2, 1>(g, bx, bz, lds); break;
-    case 1: gemm_f32_tnn_block<1, 2>(g, bx, bz, lds); break;
-    default: gemm_f32_tnn_block<1, 1>(g, bx, bz, lds); break;
-  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1288,8 +1083,7 @@ int choose_splits(int M, int N, int K, int ktile) {
 template <bool BF16>
 int gemm_entry(int layout, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                const float* bias, int accumulate, float* col_stats, er_stream_t stream, const char* who,
-               const er::BnBwdEpi* bn = nullptr, const er::ATransform* at = nullptr, const er::BnFused* fu = nullptr,
-               const float* row_bias = nullptr, int row_div = 1) {
+               const er::BnBwdEpi* bn = nullptr, const er::ATransform* at = nullptr, const er::BnFused* fu = nullptr) {
   ER_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0, "%s: bad arguments", who);
   ER_REQUIRE(layout >= ER_GEMM_NN && layout <= ER_GEMM_TN, "%s: unknown layout %d", who, layout);
   const int min_lda = (layout == ER_GEMM_TN) ? M : K;
@@ -1305,8 +1099,7 @@ int gemm_entry(int layout, int M, int N, int K, const float* A, int lda, const f
   if (bn) a.bn = *bn;
   if (at) a.at = *at;
   if (fu) a.fu = *fu;
-  a.row_bias = row_bias; a.row_div = row_div;
-  a.splits = (col_stats || bn || row_bias) ? 1 : choose_splits(M, N, K, ktile);
+  a.splits = (col_stats || bn) ? 1 : choose_splits(M, N, K, ktile);
   ER_REQUIRE(!(col_stats && accumulate), "%s: column statistics need a plain (non-accumulating) output", who);
   a.k_per_split = static_cast<int>(er::ceil_div(er::ceil_div(K, a.splits), ktile)) * ktile;
   a.splits = static_cast<int>(er::ceil_div(K, a.k_per_split));
@@ -1329,35 +1122,9 @@ int gemm_entry(int layout, int M, int N, int K, const float* A, int lda, const f
   return launch_gemm<BF16>(layout, a, s);
 }
 
-// Which TN problems of a grouped launch take the natural-layout kernel (gemm_f32_grouped_tnn_kernel).  ER_GEMM_TNN:
-// 0 = none (DEFAULT), 1 = the batch-long contractions into one or a few tiles (M, N <= 128: every operand byte is then
-// read once per split), 2 = every TN problem without an epilogue.
-// Measured on MI355X once the grids were exact (profiles/r03_wgrad_probe.md): no faster than gemm_f32_block on the
-// shapes it was built for (128 x 128 x 204,800: 117 us against 121 at 512 rows per split, 167 against 106 at 2,048) and
-// 20 - 30 % slower on the batch-8,192 problems (1152 x 256: 86 us against 71) - the transposing stores it avoids were
-// never what the launch waited for.  Kept as a tested (bit-identical) alternative, off.
-int g_tnn_mode = -1;  // (er_gemm_tn_natural_mode)
-int tnn_mode() {
-  if (g_tnn_mode < 0) {
-    const char* e = getenv("ER_GEMM_TNN");  // A/B switch
-    g_tnn_mode = e ? atoi(e) : 0;
-    if (g_tnn_mode < 0) g_tnn_mode = 0;
-  }
-  return g_tnn_mode;
-}
-
-bool tnn_fits(int layout, const er_gemm_problem& q) {
-  const int mode = tnn_mode();
-  if (mode <= 0 || layout != ER_GEMM_TN || q.a_mean || q.col_stats || q.bn_partial) return false;
-  if (mode >= 2) return true;
-  return q.M <= 128 && q.N <= 128 && q.K >= 2048;
-}
-
 int gemm_grouped_f32(int layout, const er_gemm_problem* pr, int n, er_stream_t stream, bool bf16 = false) {
   hipStream_t s = er::as_stream(stream);
   int64_t total_tiles = 0;
-  bool big[er::kMaxGroup];  // the problem takes the natural-layout TN kernel
-  int tm[er::kMaxGroup], tn[er::kMaxGroup];  // its tile
   for (int i = 0; i < n; ++i) {
     const er_gemm_problem& q = pr[i];
     ER_REQUIRE(q.A && q.B && q.C && q.M > 0 && q.N > 0 && q.K > 0, "er_gemm_grouped_f32: problem %d: bad arguments", i);
@@ -1366,11 +1133,7 @@ int gemm_grouped_f32(int layout, const er_gemm_problem* pr, int n, er_stream_t s
     ER_REQUIRE(q.lda >= min_lda && q.ldb >= min_ldb && q.ldc >= q.N,
                "er_gemm_grouped_f32: problem %d: leading dimension too small", i);
     ER_REQUIRE(!bf16 || !(q.a_mean || q.bn_partial), "er_gemm_grouped_bf16: problem %d: epilogues / transforms are fp32 only", i);
-    big[i] = !bf16 && tnn_fits(layout, q);
-    tm[i] = (big[i] && q.M > 64) ? 128 : 64;
-    tn[i] = (big[i] && q.N > 64) ? 128 : 64;
-    total_tiles += er::ceil_div(q.M, er::BM) * er::ceil_div(q.N, er::BN);  // (in 64 x 64 units whatever the kernel: the
-    // splits - and with them the bits - do not depend on which kernel takes a problem)
+    total_tiles += er::ceil_div(q.M, er::BM) * er::ceil_div(q.N, er::BN);
   }
   // k-splits: enough workgroups for ~2 per CU over the whole group (A/B: 512 beat 1024 and 2048), >= 4 k-tiles per split
   static const int64_t target_blocks = [] {  // (A/B knob)
@@ -1380,12 +1143,10 @@ int gemm_grouped_f32(int layout, const er_gemm_problem* pr, int n, er_stream_t s
   }();
   int64_t want = total_tiles >= target_blocks ? 1 : er::ceil_div(target_blocks, total_tiles);
   if (want > 64) want = 64;
-  er::GroupedArgs ga, gb;  // the problems of gemm_f32_block | of the natural-layout TN kernel
+  er::GroupedArgs ga;
   er::GroupedReduceArgs ra;
   ga.n = 0;
   ga.start[0] = 0;
-  gb.n = 0;
-  gb.start[0] = 0;
   er::GemmArgs* slot[er::kMaxGroup];  // where problem i's arguments live (the workspace base is patched in below)
   ra.n = 0;
   ra.start[0] = 0;
@@ -1393,7 +1154,7 @@ int gemm_grouped_f32(int layout, const er_gemm_problem* pr, int n, er_stream_t s
   bool any_tr = false, any_bn = false;
   for (int i = 0; i < n; ++i) {
     const er_gemm_problem& q = pr[i];
-    er::GroupedArgs& grp = big[i] ? gb : ga;
+    er::GroupedArgs& grp = ga;
     er::GemmArgs& a = grp.p[grp.n];
     slot[i] = &a;
     a = er::GemmArgs();
@@ -1438,8 +1199,7 @@ int gemm_grouped_f32(int layout, const er_gemm_problem* pr, int n, er_stream_t s
     if (sp < 1 || q.col_stats || q.bn_partial) sp = 1;
     a.k_per_split = static_cast<int>(er::ceil_div(er::ceil_div(q.K, sp), er::BK32)) * er::BK32;
     a.splits = static_cast<int>(er::ceil_div(q.K, a.k_per_split));
-    const int64_t tiles = er::ceil_div(q.M, tm[i]) * er::ceil_div(q.N, tn[i]);
-    a.tile_shape = 2 * (tm[i] == 128) + (tn[i] == 128);
+    const int64_t tiles = er::ceil_div(q.M, er::BM) * er::ceil_div(q.N, er::BN);
     grp.tiles[grp.n] = static_cast<int>(tiles);
     grp.start[grp.n + 1] = grp.start[grp.n] + grp.tiles[grp.n] * a.splits;
     ++grp.n;
@@ -1473,13 +1233,7 @@ int gemm_grouped_f32(int layout, const er_gemm_problem* pr, int n, er_stream_t s
     }
   }
   dim3 grid(static_cast<unsigned>(ga.start[ga.n])), block(er::kBlock);
-  if (gb.n > 0) {
-    hipLaunchKernelGGL(er::gemm_f32_grouped_tnn_kernel, dim3(static_cast<unsigned>(gb.start[gb.n])), block, 0, s, gb);
-    ER_LAUNCH_CHECK();
-  }
-  if (ga.n == 0) {
-    // (every problem took the natural-layout kernel)
-  } else if (bf16) {
+  if (bf16) {
     switch (layout) {
       case ER_GEMM_NN: hipLaunchKernelGGL((er::gemm_bf16_grouped_kernel<true, false>), grid, block, 0, s, ga); break;
       case ER_GEMM_NT: hipLaunchKernelGGL((er::gemm_bf16_grouped_kernel<true, true>), grid, block, 0, s, ga); break;
@@ -1527,12 +1281,6 @@ int er_gemm_reserve(int64_t floats) {
   if (int rc = ensure_counters()) return rc;  // (allocations are not capturable: both happen here)
   float* p;
   return ensure_ws(static_cast<size_t>(floats), &p);
-}
-
-int er_gemm_tn_natural_mode(int mode) {
-  const int prev = tnn_mode();
-  if (mode >= 0) g_tnn_mode = mode;
-  return prev;
 }
 
 int er_gemm_fused_bn_ok(int32_t M, int32_t N) { return fused_bn_fits(M, N) ? 1 : 0; }
@@ -1641,14 +1389,6 @@ int er_gemm_f32_bn_bwd_z(int layout, int32_t M, int32_t N, int32_t K, const floa
 int er_gemm_f32(int layout, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B, int32_t ldb,
                 float* C, int32_t ldc, const float* bias, int accumulate, float* col_stats, er_stream_t stream) {
   return gemm_entry<false>(layout, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, col_stats, stream, "er_gemm_f32");
-}
-
-int er_gemm_f32_rowbias(int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B, int32_t ldb, float* C,
-                        int32_t ldc, const float* bias, const float* row_bias, int32_t row_div, float* col_stats,
-                        er_stream_t stream) {
-  ER_REQUIRE(row_bias && row_div >= 1, "er_gemm_f32_rowbias: row_bias / row_div missing");
-  return gemm_entry<false>(ER_GEMM_NN, M, N, K, A, lda, B, ldb, C, ldc, bias, 0, col_stats, stream, "er_gemm_f32_rowbias",
-                           nullptr, nullptr, nullptr, row_bias, row_div);
 }
 
 int er_gemm_bf16(int layout, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B, int32_t ldb,

@@ -463,167 +463,6 @@ din_concat_bwd_fast_kernel(const float* __restrict__ q, const float* __restrict_
   }
 }
 
-// ---- DIN's first attention layer, folded (K8b) ---------------------------------------------------------------------
-// The layer is linear in its input [q, h, q - h, q * h] (4E columns), so with W = [W0; W1; W2; W3] (E rows each)
-//   z[b, t] = q_b (W0 + W2) + h_bt (W1 - W2) + (q_b * h_bt) W3 :
-// the first term is one [B, E] x [E, H] product per EXAMPLE (added to the rows of the example by the big GEMM's
-// epilogue: er_gemm_f32_rowbias), the rest a [B L, 2E] x [2E, H] contraction over the pair operand [h, q * h] - half
-// the concat's bytes and half its contraction length.
-__global__ void __launch_bounds__(kBlock)
-din_pair_fwd_kernel(const float* __restrict__ q, const float* __restrict__ h, int64_t n, int L, int E,
-                    float* __restrict__ out) {
-  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;  // (b, t, e)
-  if (i >= n) return;
-  const int e = static_cast<int>(i % E);
-  const int64_t bt = i / E;
-  const float hv = h[i], qv = q[(bt / L) * E + e];
-  out[bt * 2 * E + e] = hv;
-  out[bt * 2 * E + E + e] = qv * hv;
-}
-
-__global__ void __launch_bounds__(kBlock)
-din_pair_fwd_vec_kernel(const float* __restrict__ q, const float* __restrict__ h, int64_t n4, int L, int C,
-                        float* __restrict__ out) {
-  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;  // (b, t, c): 16-byte chunks
-  if (i >= n4) return;
-  const int c = static_cast<int>(i % C);
-  const int64_t bt = i / C;
-  const f32x4i hv = reinterpret_cast<const f32x4i*>(h)[i];
-  const f32x4i qv = reinterpret_cast<const f32x4i*>(q)[(bt / L) * C + c];
-  f32x4i p;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) p[j] = qv[j] * hv[j];
-  reinterpret_cast<f32x4i*>(out)[bt * 2 * C + c] = hv;
-  reinterpret_cast<f32x4i*>(out)[bt * 2 * C + C + c] = p;
-}
-
-// dh = g0 + g1 * q, dq = sum_t g1 * h from dout = [g0 | g1] ([B, L, 2E]); one wave per example, one pass
-__global__ void __launch_bounds__(kBlock)
-din_pair_bwd_fast_kernel(const float* __restrict__ q, const float* __restrict__ h, const float* __restrict__ dout, int B,
-                         int L, int E, float* __restrict__ dq, int acc_q, float* __restrict__ dh, int acc_h) {
-  const int lane = threadIdx.x & 63;
-  const int64_t b = static_cast<int64_t>(blockIdx.x) * (kBlock / 64) + (threadIdx.x >> 6);
-  if (b >= B) return;
-  const int C = E / 4, c = lane % C, r0 = lane / C, R = 64 / C;
-  const f32x4i qv = *reinterpret_cast<const f32x4i*>(q + b * E + c * 4);
-  const f32x4i* h4 = reinterpret_cast<const f32x4i*>(h + b * L * E);
-  const f32x4i* g4 = reinterpret_cast<const f32x4i*>(dout + b * L * 2 * E);
-  f32x4i* dh4 = dh ? reinterpret_cast<f32x4i*>(dh + b * L * E) : nullptr;
-  f32x4i s = {0.f, 0.f, 0.f, 0.f};
-  for (int t0 = 0; t0 < L; t0 += R) {
-    const int t = t0 + r0;
-    if (t < L) {
-      const f32x4i g0 = g4[(t * 2 + 0) * C + c], g1 = g4[(t * 2 + 1) * C + c];
-      const f32x4i hv = h4[t * C + c];
-      if (dh4) {
-        f32x4i o;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = g0[j] + g1[j] * qv[j];
-        if (acc_h) {
-          const f32x4i old = dh4[t * C + c];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) o[j] = old[j] + o[j];
-        }
-        dh4[t * C + c] = o;
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) s[j] = s[j] + g1[j] * hv[j];
-    }
-  }
-  if (dq) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) s[j] = row_lanes_sum(s[j], C);
-    if (r0 == 0) {
-      f32x4i* o = reinterpret_cast<f32x4i*>(dq + b * E + c * 4);
-      if (acc_q) {
-        const f32x4i old = *o;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) s[j] = old[j] + s[j];
-      }
-      *o = s;
-    }
-  }
-}
-
-// general shapes: a thread per (b, e) walks the L positions (t ascending)
-__global__ void __launch_bounds__(kBlock)
-din_pair_bwd_kernel(const float* __restrict__ q, const float* __restrict__ h, const float* __restrict__ dout, int B, int L,
-                    int E, float* __restrict__ dq, int acc_q, float* __restrict__ dh, int acc_h) {
-  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
-  if (i >= static_cast<int64_t>(B) * E) return;
-  const int e = static_cast<int>(i % E);
-  const int64_t b = i / E;
-  const float qv = q[i];
-  float s = 0.f;
-  for (int t = 0; t < L; ++t) {
-    const int64_t bt = b * L + t;
-    const float g0 = dout[bt * 2 * E + e], g1 = dout[bt * 2 * E + E + e];
-    if (dh) {
-      const float o = g0 + g1 * qv;
-      dh[bt * E + e] = acc_h ? dh[bt * E + e] + o : o;
-    }
-    s = s + g1 * h[bt * E + e];
-  }
-  if (dq) dq[i] = acc_q ? dq[i] + s : s;
-}
-
-// S[b, n] = sum over the L rows of example b of x[(b L + t), n] (t ascending): the gradient of a row-broadcast term
-__global__ void __launch_bounds__(kBlock)
-segment_rowsum_kernel(const float* __restrict__ x, int64_t B, int L, int N, float* __restrict__ out) {
-  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;  // (b, n)
-  if (i >= B * N) return;
-  const int n = static_cast<int>(i % N);
-  const int64_t b = i / N;
-  const float* p = x + b * L * N + n;
-  float s = 0.f;
-  for (int t = 0; t < L; ++t) s = s + p[static_cast<int64_t>(t) * N];
-  out[i] = s;
-}
-
-__global__ void __launch_bounds__(kBlock)
-segment_rowsum_vec_kernel(const float* __restrict__ x, int64_t B, int L, int N4, float* __restrict__ out) {
-  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;  // (b, 16-byte chunk)
-  if (i >= B * N4) return;
-  const int n = static_cast<int>(i % N4);
-  const int64_t b = i / N4;
-  const f32x4i* p = reinterpret_cast<const f32x4i*>(x) + b * L * N4 + n;
-  f32x4i s = {0.f, 0.f, 0.f, 0.f};
-  for (int t = 0; t < L; ++t) {
-    const f32x4i v = p[static_cast<int64_t>(t) * N4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) s[j] = s[j] + v[j];
-  }
-  reinterpret_cast<f32x4i*>(out)[i] = s;
-}
-
-// W [4E, H] -> Wq = W0 + W2 ([E, H]), Wp = [W1 - W2; W3] ([2E, H])
-__global__ void __launch_bounds__(kBlock)
-din_fold_w_kernel(const float* __restrict__ w, int E, int H, float* __restrict__ wq, float* __restrict__ wp) {
-  const int i = blockIdx.x * kBlock + threadIdx.x;  // (e, n)
-  if (i >= E * H) return;
-  const int EH = E * H;
-  const float w0 = w[i], w1 = w[EH + i], w2 = w[2 * EH + i], w3 = w[3 * EH + i];
-  wq[i] = w0 + w2;
-  wp[i] = w1 - w2;
-  wp[EH + i] = w3;
-}
-
-// the way back: dW0 = dWq, dW1 = dWp[:E], dW2 = dWq - dWp[:E], dW3 = dWp[E:]
-__global__ void __launch_bounds__(kBlock)
-din_unfold_dw_kernel(const float* __restrict__ dwq, const float* __restrict__ dwp, int E, int H, float* __restrict__ dw,
-                     int accumulate) {
-  const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= E * H) return;
-  const int EH = E * H;
-  const float a = dwq[i], b = dwp[i], c = dwp[EH + i];
-  const float v0 = a, v1 = b, v2 = a - b, v3 = c;
-  if (accumulate) {
-    dw[i] = dw[i] + v0; dw[EH + i] = dw[EH + i] + v1; dw[2 * EH + i] = dw[2 * EH + i] + v2; dw[3 * EH + i] = dw[3 * EH + i] + v3;
-  } else {
-    dw[i] = v0; dw[EH + i] = v1; dw[2 * EH + i] = v2; dw[3 * EH + i] = v3;
-  }
-}
-
 // one wave per example: masked softmax over L (any L, strided over lanes) then p @ hist
 __global__ void __launch_bounds__(kBlock)
 din_pool_fwd_kernel(const float* __restrict__ scores, const float* __restrict__ hist, const int32_t* __restrict__ len,
@@ -1240,64 +1079,6 @@ int er_din_concat_bwd(const float* query, const float* hist, const float* dout, 
                        dim3(er::kBlock), 0, s, hist, dout, B, L, E, dquery, acc_q);
     ER_LAUNCH_CHECK();
   }
-  return 0;
-}
-
-int er_din_pair_fwd(const float* query, const float* hist, int32_t B, int32_t L, int32_t E, float* out, er_stream_t stream) {
-  ER_REQUIRE(query && hist && out && B > 0 && L > 0 && E > 0, "er_din_pair_fwd: bad arguments");
-  const int64_t n = static_cast<int64_t>(B) * L * E;
-  if (E % 4 == 0 && ((reinterpret_cast<uintptr_t>(query) | reinterpret_cast<uintptr_t>(hist) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
-    hipLaunchKernelGGL(er::din_pair_fwd_vec_kernel, dim3(er::blocks_for(n / 4)), dim3(er::kBlock), 0, er::as_stream(stream),
-                       query, hist, n / 4, L, E / 4, out);
-  } else {
-    hipLaunchKernelGGL(er::din_pair_fwd_kernel, dim3(er::blocks_for(n)), dim3(er::kBlock), 0, er::as_stream(stream), query, hist,
-                       n, L, E, out);
-  }
-  ER_LAUNCH_CHECK();
-  return 0;
-}
-
-int er_din_pair_bwd(const float* query, const float* hist, const float* dout, int32_t B, int32_t L, int32_t E, float* dquery,
-                    int acc_q, float* dhist, int acc_h, er_stream_t stream) {
-  ER_REQUIRE(query && hist && dout && B > 0 && L > 0 && E > 0 && (dquery || dhist), "er_din_pair_bwd: bad arguments");
-  hipStream_t s = er::as_stream(stream);
-  if (er::din_fast_ok(L, E, query, hist, dout) && er::din_fast_ok(L, E, dquery, dhist)) {
-    hipLaunchKernelGGL(er::din_pair_bwd_fast_kernel, dim3(static_cast<int>(er::ceil_div(B, er::kBlock / 64))), dim3(er::kBlock),
-                       0, s, query, hist, dout, B, L, E, dquery, acc_q, dhist, acc_h);
-  } else {
-    hipLaunchKernelGGL(er::din_pair_bwd_kernel, dim3(er::blocks_for(static_cast<int64_t>(B) * E)), dim3(er::kBlock), 0, s,
-                       query, hist, dout, B, L, E, dquery, acc_q, dhist, acc_h);
-  }
-  ER_LAUNCH_CHECK();
-  return 0;
-}
-
-int er_segment_rowsum(const float* x, int64_t B, int32_t L, int32_t N, float* out, er_stream_t stream) {
-  ER_REQUIRE(x && out && B > 0 && L > 0 && N > 0, "er_segment_rowsum: bad arguments");
-  if (N % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
-    hipLaunchKernelGGL(er::segment_rowsum_vec_kernel, dim3(er::blocks_for(B * (N / 4))), dim3(er::kBlock), 0,
-                       er::as_stream(stream), x, B, L, N / 4, out);
-  } else {
-    hipLaunchKernelGGL(er::segment_rowsum_kernel, dim3(er::blocks_for(B * N)), dim3(er::kBlock), 0, er::as_stream(stream), x, B,
-                       L, N, out);
-  }
-  ER_LAUNCH_CHECK();
-  return 0;
-}
-
-int er_din_fold_w(const float* w, int32_t E, int32_t H, float* wq, float* wp, er_stream_t stream) {
-  ER_REQUIRE(w && wq && wp && E > 0 && H > 0, "er_din_fold_w: bad arguments");
-  hipLaunchKernelGGL(er::din_fold_w_kernel, dim3(er::blocks_for(static_cast<int64_t>(E) * H)), dim3(er::kBlock), 0,
-                     er::as_stream(stream), w, E, H, wq, wp);
-  ER_LAUNCH_CHECK();
-  return 0;
-}
-
-int er_din_unfold_dw(const float* dwq, const float* dwp, int32_t E, int32_t H, float* dw, int accumulate, er_stream_t stream) {
-  ER_REQUIRE(dwq && dwp && dw && E > 0 && H > 0, "er_din_unfold_dw: bad arguments");
-  hipLaunchKernelGGL(er::din_unfold_dw_kernel, dim3(er::blocks_for(static_cast<int64_t>(E) * H)), dim3(er::kBlock), 0,
-                     er::as_stream(stream), dwq, dwp, E, H, dw, accumulate);
-  ER_LAUNCH_CHECK();
   return 0;
 }
 

@@ -684,10 +684,6 @@ class HipBackend(object):
   def gemm_reserve(self, floats):
     self._ck(self.lib.er_gemm_reserve(ctypes.c_int64(int(floats))), 'er_gemm_reserve')
 
-  def gemm_tn_natural_mode(self, mode=-1):
-    """er_gemm_tn_natural_mode: which TN problems of gemm_grouped take the natural-layout kernel; returns the previous."""
-    return int(self.lib.er_gemm_tn_natural_mode(ctypes.c_int(int(mode))))
-
   def gemm_row_tiles(self, M):
     return int(self.lib.er_gemm_row_tiles(ctypes.c_int32(int(M))))
 
@@ -704,10 +700,9 @@ class HipBackend(object):
                                         _stream()), 'er_bn_apply_from_stats')
     return y, mean, invstd
 
-  def gemm(self, layout, a, b, out=None, bias=None, accumulate=False, bf16=False, col_stats=None, row_bias=None, row_div=1):
+  def gemm(self, layout, a, b, out=None, bias=None, accumulate=False, bf16=False, col_stats=None):
     """out (+)= op(a) . op(b) (+ bias).  2-D fp32 tensors with unit inner stride.
-    layout GEMM_NN: a[M,K] b[K,N]; GEMM_NT: a[M,K] b[N,K]; GEMM_TN: a[K,M] b[K,N].
-    row_bias [ceil(M / row_div), N] (NN, fp32): output row r also gets row_bias[r // row_div] (er_gemm_f32_rowbias)."""
+    layout GEMM_NN: a[M,K] b[K,N]; GEMM_NT: a[M,K] b[N,K]; GEMM_TN: a[K,M] b[K,N]."""
     assert a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1
     assert a.dtype == torch.float32 and b.dtype == torch.float32
     if layout == GEMM_NN:
@@ -721,15 +716,6 @@ class HipBackend(object):
       assert not accumulate
       out = torch.empty(M, N, dtype=torch.float32, device=a.device)
     assert out.shape == (M, N) and out.stride(1) == 1 and out.dtype == torch.float32
-    if row_bias is not None:
-      assert layout == GEMM_NN and not bf16 and not accumulate and row_bias.is_contiguous() and row_bias.dtype == torch.float32
-      assert row_bias.shape == ((M + row_div - 1) // row_div, N)
-      assert col_stats is None or col_stats.numel() >= self.gemm_row_tiles(M) * N * 3
-      self._log_gemm('gemm_f32_kernel', layout, M, N, K)
-      self._ck(self.lib.er_gemm_f32_rowbias(M, N, K, _p(a), ctypes.c_int32(a.stride(0)), _p(b), ctypes.c_int32(b.stride(0)),
-                                            _p(out), ctypes.c_int32(out.stride(0)), _p(bias), _p(row_bias),
-                                            ctypes.c_int32(int(row_div)), _p(col_stats), _stream()), 'er_gemm_f32_rowbias')
-      return out
     if bf16 and col_stats is None and self._gemm_bf16_fast(layout, a, b, out, bias, accumulate, M, N, K):
       return out
     self._log_gemm('gemm_bf16_kernel' if bf16 else 'gemm_f32_kernel', layout, M, N, K)
@@ -1035,14 +1021,9 @@ class HipBackend(object):
       else:
         (K, M), (K2, N) = a.shape, b.shape
       assert K == K2 and out.shape == (M, N)
-      if self.op_log is not None:  # (which of the two grouped kernels takes the problem: er_gemm.hip tnn_fits)
-        mode = self.gemm_tn_natural_mode()
-        natural = not bf16 and layout == GEMM_TN and at is None and stats is None and bn is None and \
-            (mode >= 2 or (mode == 1 and M <= 128 and N <= 128 and K >= 2048))
+      if self.op_log is not None:
         if bf16:
           self._log_gemm('gemm_bf16_grouped_kernel', layout, M, N, K)
-        elif natural:
-          self._log_gemm('gemm_f32_grouped_tnn_kernel', None, M, N, K)
         else:
           self._log_gemm('gemm_f32_grouped_tr_kernel' if at is not None else 'gemm_f32_grouped_kernel', layout, M, N, K)
       q.M, q.N, q.K = M, N, K
@@ -1480,52 +1461,6 @@ class HipBackend(object):
         self.lib.er_din_concat_bwd(_p(q), _p(h), _p(_f32c(dout)), B, L, E, _p(dq), 0, _p(dh), int(bool(acc_h)), _stream()),
         'er_din_concat_bwd')
     return dq, dh
-
-  # -- K8b: DIN's first attention layer, folded (include/easyrec_hip.h)
-  # OFF by default: measured slower on BASELINE config 4 (2.047 against 1.982 ms, same box, profiles/r04_din_folded_first_layer_ab.txt):
-  # the [204,800 x 128] layer is bound by the bytes of its output and of the BatchNorm passes over it, not by its
-  # contraction - halving K saves 28 us of input-gradient GEMM and costs the row term's epilogue loads, a row-sum pass
-  # over dz and a weight-gradient GEMM outside the step's grouped launch.  '1' switches it on (tested on both backends).
-  din_fold = os.environ.get('EASYREC_AMD_DIN_FOLD', '0') == '1'
-
-  def din_pair_fwd(self, q, h):
-    B, L, E = h.shape
-    out = torch.empty(B, L, 2 * E, dtype=torch.float32, device=h.device)
-    self._ck(self.lib.er_din_pair_fwd(_p(_f32c(q)), _p(_f32c(h)), B, L, E, _p(out), _stream()), 'er_din_pair_fwd')
-    return out
-
-  def din_pair_bwd(self, q, h, dout):
-    B, L, E = h.shape
-    dq, dh = torch.empty_like(q), torch.empty_like(h)
-    self._ck(self.lib.er_din_pair_bwd(_p(q), _p(h), _p(_f32c(dout)), B, L, E, _p(dq), 0, _p(dh), 0, _stream()), 'er_din_pair_bwd')
-    return dq, dh
-
-  def segment_rowsum(self, x, L):
-    """[B * L, N] -> [B, N]: sums over each example's L consecutive rows."""
-    assert x.dim() == 2 and x.is_contiguous() and x.shape[0] % L == 0
-    B, N = x.shape[0] // L, x.shape[1]
-    out = torch.empty(B, N, dtype=torch.float32, device=x.device)
-    self._ck(self.lib.er_segment_rowsum(_p(x), ctypes.c_int64(B), ctypes.c_int32(L), ctypes.c_int32(N), _p(out), _stream()),
-             'er_segment_rowsum')
-    return out
-
-  def din_fold_w(self, w):
-    E4, H = w.shape
-    E = E4 // 4
-    wq = torch.empty(E, H, dtype=torch.float32, device=w.device)
-    wp = torch.empty(2 * E, H, dtype=torch.float32, device=w.device)
-    self._ck(self.lib.er_din_fold_w(_p(_f32c(w)), E, H, _p(wq), _p(wp), _stream()), 'er_din_fold_w')
-    return wq, wp
-
-  def din_unfold_dw(self, dwq, dwp, out=None, accumulate=False):
-    E, H = dwq.shape
-    if out is None:
-      assert not accumulate
-      out = torch.empty(4 * E, H, dtype=torch.float32, device=dwq.device)
-    assert out.shape == (4 * E, H) and out.is_contiguous()
-    self._ck(self.lib.er_din_unfold_dw(_p(_f32c(dwq)), _p(_f32c(dwp)), E, H, _p(out), int(bool(accumulate)), _stream()),
-             'er_din_unfold_dw')
-    return out
 
   def din_pool_fwd(self, scores, hist, seq_len, scale=1.0):
     B, L, E = hist.shape
@@ -2345,27 +2280,17 @@ class LinearBNActFn(torch.autograd.Function):
 
   @staticmethod
   def forward(ctx, x, w, b, gamma, beta, moving_mean, moving_var, eps, momentum, act, bf16, grad_bufs, src=None,
-              sink=None, defer=False, row_bias=None, row_div=1):
+              sink=None, defer=False):
     """defer: do not write y - return z tagged as a DEFERRED output (BnSource.deferred); the caller guarantees that
-    every reader is a dense layer of this package (layers/dnn.py: the inner layers of a stack).
-    row_bias [M / row_div, N]: a term added to every group of row_div consecutive output rows before the statistics
-    (DIN's folded first attention layer); its gradient is the groups' row sums of dz."""
+    every reader is a dense layer of this package (layers/dnn.py: the inner layers of a stack)."""
     be = hip()
     x2 = x if x.stride(-1) == 1 else x.contiguous()
     M, N = x2.shape[0], w.shape[1]
     at = src if (src is not None and src.deferred) else None  # x holds a deferred layer's z: transformed by the GEMM
     assert at is None or (x2 is x and not bf16)
     defer = bool(defer) and not bf16 and getattr(be, 'deferred_bn', False)
-    assert row_bias is None or (not defer and at is None and not bf16)
-    ctx.row_div = int(row_div) if row_bias is not None else 0
     y = None
-    if row_bias is not None:
-      chunks = be.gemm_row_tiles(M)
-      stats = torch.empty(chunks * N * 3, dtype=torch.float32, device=x2.device)
-      z = be.gemm(GEMM_NN, x2, w, bias=b, col_stats=stats, row_bias=row_bias.contiguous(), row_div=int(row_div))
-      y, mean, invstd = be.bn_apply_from_stats(z, None, stats, chunks, gamma, beta, eps, momentum, moving_mean,
-                                               moving_var, act)
-    elif defer or at is not None:
+    if defer or at is not None:
       chunks = be.gemm_row_tiles(M)
       stats = torch.empty(chunks * N * 3, dtype=torch.float32, device=x2.device)
       if defer:
@@ -2425,14 +2350,12 @@ class LinearBNActFn(torch.autograd.Function):
         own.partial = None
       dz, _, dgamma, dbeta = be.bn_act_bwd(z, None, gamma, y, mean, invstd, dyc, 1, ctx.act, False, True,
                                            into=(None, gg, betag) if direct else None, partial=partial, beta=beta)
-    dx = dw = drb = None
+    dx = dw = None
     if ctx.needs_input_grad[0]:
       dx = _dgrad(be, dz, w, ctx.src, ctx.bf16, ctx.gsink)
     if ctx.needs_input_grad[1]:
       dw = _wgrad(be, x, dz, wg, ctx.bf16, ctx.at, ctx.sink)
-    if ctx.row_div and ctx.needs_input_grad[15]:
-      drb = be.segment_rowsum(dz if dz.is_contiguous() else dz.contiguous(), ctx.row_div)
-    return dx, dw, None, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None, drb, None
+    return dx, dw, None, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
 
 
 class GroupedLinearFn(torch.autograd.Function):
@@ -2977,44 +2900,6 @@ class DINConcatFn(torch.autograd.Function):
     buf, acc, first = grad_slot(ctx.slots, h)
     dq, _ = hip().din_concat_bwd(q.contiguous(), h, dout.contiguous(), dh=buf, acc_h=acc)
     return dq, (buf if first else None)
-
-
-class DINPairFn(torch.autograd.Function):
-  """[h, q * h]: the operand of DIN's folded first attention layer (include/easyrec_hip.h K8b)."""
-
-  @staticmethod
-  def forward(ctx, q, h):
-    q, h = q.contiguous(), h.contiguous()
-    ctx.save_for_backward(q, h)
-    return hip().din_pair_fwd(q, h)
-
-  @staticmethod
-  def backward(ctx, dout):
-    q, h = ctx.saved_tensors
-    return hip().din_pair_bwd(q, h, dout.contiguous())
-
-
-class DINFoldFn(torch.autograd.Function):
-  """W [4E, H] -> (Wq [E, H], Wp [2E, H]) of the folded first attention layer; the way back writes dW straight into
-  `w_grad` (W's slice of the flat gradient buffer) when there is one."""
-
-  @staticmethod
-  def forward(ctx, w, w_grad):
-    ctx.w_grad = w_grad
-    ctx.shape = tuple(w.shape)
-    return hip().din_fold_w(w.detach().contiguous())
-
-  @staticmethod
-  def backward(ctx, dwq, dwp):
-    be = hip()
-    E4, H = ctx.shape
-    dev = (dwq if dwq is not None else dwp).device
-    dwq = dwq.contiguous() if dwq is not None else torch.zeros(E4 // 4, H, device=dev)
-    dwp = dwp.contiguous() if dwp is not None else torch.zeros(E4 // 2, H, device=dev)
-    if ctx.w_grad is not None:
-      be.din_unfold_dw(dwq, dwp, out=ctx.w_grad, accumulate=True)
-      return None, None
-    return be.din_unfold_dw(dwq, dwp), None
 
 
 class DINPoolFn(torch.autograd.Function):

@@ -95,36 +95,6 @@ def dense_bn_act(x, units, name, l2_reg, use_bias, use_bn, act_relu, training, b
   return y.reshape(shape[:-1] + (units,))
 
 
-def din_first_layer(q, hist, units, name, l2_reg, act_relu, training):
-  """dense + BatchNorm(train) + activation over DIN's attention input [q, h, q - h, q * h] ([B, L, 4E]) WITHOUT building
-  it: the layer is linear in that input, so with kernel = [W0; W1; W2; W3]
-      z[b, t] = q_b (W0 + W2) + h_bt (W1 - W2) + (q_b * h_bt) W3
-  (reference model/multi_tower_din.py:62-80, layers/dnn.py:57-79; same variables: <name>/kernel [4E, units], /bias, /bn).
-  The first term is one small product per example, added to the example's rows in the big GEMM's epilogue
-  (er_gemm_f32_rowbias); the rest contracts [h, q * h] - half the bytes and half the contraction of the concat.
-  -> [B * L, units]."""
-  ctx = context.current()
-  vs = ctx.varstore
-  B, L, E = hist.shape
-  w = vs.get_variable(name + '/kernel', (4 * E, units), 'glorot_uniform', l2=l2_reg or 0.0)
-  b = vs.get_variable(name + '/bias', (units,), 'zeros')
-  bn = name + '/bn'
-  gamma = vs.get_variable(bn + '/gamma', (units,), 'ones')
-  beta = vs.get_variable(bn + '/beta', (units,), 'zeros')
-  mm = vs.get_variable(bn + '/moving_mean', (units,), 'zeros', trainable=False)
-  mv = vs.get_variable(bn + '/moving_variance', (units,), 'ones', trainable=False)
-  freeze = ctx.building and training
-  wq, wp = kernels.DINFoldFn.apply(w, w.grad if (w.requires_grad and w.grad is not None) else None)
-  per_example = kernels.LinearFn.apply(q.contiguous(), wq, None, None, None, False, None, None)   # [B, units]
-  pair = kernels.DINPairFn.apply(q, hist).reshape(B * L, 2 * E)
-  bufs = (None, gamma.grad, beta.grad) if (gamma.grad is not None and beta.grad is not None) else None
-  act = kernels.ACT_RELU if act_relu else kernels.ACT_NONE
-  y = kernels.LinearBNActFn.apply(pair, wp, b, gamma, beta, None if freeze else mm, None if freeze else mv, BN_EPSILON,
-                                  BN_MOMENTUM, act, False, bufs, None, None, False, per_example, L)
-  src = kernels.take_last_bn_source()
-  return kernels.tag_bn_source(y, src) if src is not None else y
-
-
 def _grad_bufs(b, gamma, beta):
   """(bias.grad, gamma.grad, beta.grad) when the variables are packed into the flat gradient buffer."""
   bufs = tuple(None if t is None else t.grad for t in (b, gamma, beta))
@@ -301,27 +271,13 @@ class DNN(object):
   def dropout_ratio(self):
     return self._config.dropout_ratio
 
-  def can_fold_din(self):
-    """The first layer can take DIN's (q, history) pair instead of the built [q, h, q - h, q * h] input: a training
-    step in fp32 whose first layer is dense -> BatchNorm -> (ReLU | activation applied separately), no dropout."""
-    ctx = context.current()
-    n = len(self.hidden_units)
-    return (getattr(kernels.hip(), 'din_fold', False) and self._is_training and torch.is_grad_enabled() and
-            ctx.is_training and getattr(ctx, 'dense_dtype', 'f32') != 'bf16' and n >= 1 and self.hidden_units[0] > 0 and
-            self._config.use_bn and (n > 1 or not self._last_layer_no_batch_norm))
-
-  def __call__(self, deep_fea, hidden_layer_feature_output=False, din=None):
-    """din = (query [B, E], history [B, L, E]): the input is DIN's [q, h, q - h, q * h] ([B, L, 4E]), never built - the
-    first layer runs folded (din_first_layer; the caller checked can_fold_din()); deep_fea is ignored."""
+  def __call__(self, deep_fea, hidden_layer_feature_output=False):
     hidden_units_len = len(self.hidden_units)
     if hidden_units_len == 1 and self.hidden_units[0] == 0:
       return deep_fea
     hidden_feature_dict = {}
     lead_shape = None
-    if din is not None:
-      assert not hidden_layer_feature_output
-      lead_shape = din[1].shape[:-1]
-    if din is None and deep_fea.dim() > 2 and not hidden_layer_feature_output:
+    if deep_fea.dim() > 2 and not hidden_layer_feature_output:
       # [B, L, d] inputs (DIN's attention MLP): the whole stack runs on the flattened [B * L, d] view - BatchNorm
       # normalises over every axis but the last either way - so that its inner layers can hand over deferred outputs
       lead_shape = deep_fea.shape[:-1]
@@ -335,11 +291,8 @@ class DNN(object):
       no_dropout = not (len(self.dropout_ratio) > 0 and self._is_training and self.dropout_ratio[i] > 0)
       defer = (i + 1 < hidden_units_len) and use_bn and (fuse_relu or not use_act or self.activation is None) and \
           no_dropout and not hidden_layer_feature_output
-      if i == 0 and din is not None:
-        deep_fea = din_first_layer(din[0], din[1], unit, layer, self._l2_reg, fuse_relu, self._is_training)
-      else:
-        deep_fea = dense_bn_act(deep_fea, unit, layer, self._l2_reg, True, use_bn, fuse_relu, self._is_training,
-                                defer=defer)
+      deep_fea = dense_bn_act(deep_fea, unit, layer, self._l2_reg, True, use_bn, fuse_relu, self._is_training,
+                              defer=defer)
       if i + 1 < hidden_units_len and not hidden_layer_feature_output:
         kernels.mark_single_consumer(deep_fea)  # (the next layer's GEMM is its only reader, unless replaced below)
       if use_act and not fuse_relu and self.activation is not None:

@@ -37,12 +37,10 @@ def target_attention(dnn_config, deep_fea, name, l2_reg, is_training, need_key_f
   hist = kernels.slot_gate(hist)  # (DINConcatFn and DINPoolFn share the history's gradient buffer)
   din_layer = dnn.DNN(dnn_config, l2_reg, name, is_training, last_layer_no_activation=True,
                       last_layer_no_batch_norm=True)
-  if din_layer.can_fold_din() and len(din_layer.hidden_units) > 1:
-    # the first layer is linear in [q, h, q - h, q * h]: folded, the [B, L, 4E] input is never built (dnn.din_first_layer)
-    scores = din_layer(None, din=(cur_id, hist)).reshape(B, L)
-  else:
-    din_net = kernels.DINConcatFn.apply(cur_id, hist)  # [B, L, 4E]
-    scores = din_layer(din_net).reshape(B, L)
+  # (the first attention layer folded over (q, h) - linear in [q, h, q - h, q * h], so the [B, L, 4E] input need not be
+  # built - was measured slower in round 4 and removed in round 5: profiles/r04_din_folded_first_layer_ab.txt)
+  din_net = kernels.DINConcatFn.apply(cur_id, hist)  # [B, L, 4E]
+  scores = din_layer(din_net).reshape(B, L)
   pooled = kernels.DINPoolFn.apply(scores, hist, seq_len, 1.0)  # softmax over where(t < len, score, -2^32 + 1)
   if not need_key_feature:
     return pooled

@@ -45,13 +45,11 @@ class EasyRecEstimator(object):
     self.device = torch.device(device)
     self.seed = seed
     self.is_training = is_training
-    # dense weight gradients + dense optimizer on a second stream alongside the embedding backward: OFF - measured
-    # on one box (tools/gpu_ab.sh) the two-branch graph is 0.609 ms against 0.550 sequential: like the sweep
-    # overlap before it, concurrent kernels stretch the latency-bound ones more than they hide
-    self.overlap_dense_update = os.environ.get('EASYREC_AMD_OVERLAP_DENSE', '0') != '0'
+    # (dense weight gradients + dense optimizer on a second stream alongside the embedding backward were measured in rounds
+    # 2 and 4 - 0.609 against 0.550 ms, 0.479 against 0.447 - and removed in round 5: concurrent kernels stretch the
+    # latency-bound ones more than they hide, profiles/r04_s1_lines_summary.txt)
     # the id hash as workgroups of the step prologue's launch (one launch less per step) - A/B switch
     self.fused_front = os.environ.get('EASYREC_AMD_FUSED_FRONT', '1') != '0'
-    self._side_stream = None
     # TF-exact Adam: True = run the dense-decay sweep of the untouched rows on a second stream (see
     # EmbeddingEngine.start_decay_sweep); False (default) = sequential sweep inside er_emb_bwd_update.
     # Measured on MI355X (profiles/r01_overlap_knob.txt): the overlapped step is SLOWER (3.8 ms vs
@@ -262,26 +260,7 @@ class EasyRecEstimator(object):
       self._loss_tail(loss_dict)
       if self.is_training:
         vs = self.varstore
-        if self.overlap_dense_update and self.device.type == 'cuda' and self.clip_norm <= 0:
-          # Two independent tails of the step: (a) the grouped weight-gradient GEMM + the dense optimizer, (b) the
-          # embedding backward (segmented reduction + row updates: chains of dependent random accesses that leave
-          # most CUs idle).  They run on two streams - parallel branches of the captured hipGraph.
-          self.model.backward(flush=False)
-          main = torch.cuda.current_stream()
-          if self._side_stream is None:
-            self._side_stream = torch.cuda.Stream(device=self.device)
-          side = self._side_stream
-          side.wait_stream(main)
-          with torch.cuda.stream(side):
-            keep = be.flush_wgrads()
-            self._sync_dense_grads()
-            be.dense_opt_step(vs.flat, vs.slots.get('m'), vs.slots.get('v'), vs.flat_grad,
-                              vs.l2coef if vs.any_l2 else None, self.opt_dense.kind, self.hyper[1],
-                              l2_partials=vs.l2_partials)
-          self.engine.backward_update(self.opt_emb.kind, self.hyper[0])
-          main.wait_stream(side)
-          del keep  # the queued operands stayed referenced until the streams joined
-        elif self.clip_norm > 0:
+        if self.clip_norm > 0:
           self.model.backward()
           self._sync_dense_grads()
           self._clipped_update()

@@ -559,19 +559,6 @@ int er_din_concat_fwd(const float* query, const float* hist, int32_t B, int32_t 
 int er_din_concat_bwd(const float* query, const float* hist, const float* dout, int32_t B,
                       int32_t L, int32_t E, float* dquery, int acc_q, float* dhist, int acc_h,
                       er_stream_t stream);
-/* K8b  DIN's first attention layer, folded.  The layer is linear in [q, h, q - h, q * h], so with W = [W0; W1; W2; W3]
- *   z[b, t] = q_b (W0 + W2) + h_bt (W1 - W2) + (q_b * h_bt) W3
- * - the same sums as dense(din_concat) (reference model/multi_tower_din.py:62-80) in another association: fp32 results
- * agree to rounding, not bit for bit.  er_din_fold_w: W [4E, H] -> Wq [E, H], Wp [2E, H]; er_din_pair_fwd: the pair
- * operand [h, q * h] ([B, L, 2E]); the contraction is er_gemm_f32_rowbias with row_bias = q Wq ([B, H]) and
- * row_div = L; backward: er_segment_rowsum (d row_bias = sum over an example's L rows of dz), er_din_pair_bwd
- * (dquery [B, E] (+)=, dhist [B, L, E] (+)= from d pair), er_din_unfold_dw (dWq, dWp -> dW (+)=). */
-int er_din_pair_fwd(const float* query, const float* hist, int32_t B, int32_t L, int32_t E, float* out, er_stream_t stream);
-int er_din_pair_bwd(const float* query, const float* hist, const float* dout, int32_t B, int32_t L, int32_t E, float* dquery,
-                    int acc_q, float* dhist, int acc_h, er_stream_t stream);
-int er_segment_rowsum(const float* x, int64_t B, int32_t L, int32_t N, float* out, er_stream_t stream);
-int er_din_fold_w(const float* w, int32_t E, int32_t H, float* wq, float* wp, er_stream_t stream);
-int er_din_unfold_dw(const float* dwq, const float* dwp, int32_t E, int32_t H, float* dw, int accumulate, er_stream_t stream);
 /* probs_out [B, L] saved for backward; out [B, E] */
 int er_din_pool_fwd(const float* scores, const float* hist, const int32_t* seq_len, int32_t B,
                     int32_t L, int32_t E, float scale, float* probs_out, float* out,
@@ -740,11 +727,6 @@ int er_mmoe_mix_bwd(const float* experts, const float* gates, const float* dout,
                     int32_t E, int32_t B, int32_t H, float* dexperts, float* dgate_logits,
                     er_stream_t stream);
 
-/* Which TN problems of er_gemm_grouped_f32 (the weight gradients dW = x^T . dz) run in the operands' natural k-major
- * layout (128- or 64-wide tiles, no transposition on the way into LDS; same bits as the default kernel): 0 none (default;
- * env ER_GEMM_TNN), 1 the batch-long contractions into M, N <= 128, 2 every TN problem without an epilogue.
- * mode < 0 only queries.  Returns the previous mode. */
-int er_gemm_tn_natural_mode(int mode);
 
 /* --------------------------------------------------------------------------------------------
  * K13 dense contractions on the matrix cores.  Replaces the MatMul of tf.layers.dense
@@ -892,11 +874,6 @@ int er_bn_act_bwd_z(const float* z, const float* bias, const float* gamma, const
 int er_gemm_f32(int layout, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B,
                 int32_t ldb, float* C, int32_t ldc, const float* bias, int accumulate, float* col_stats,
                 er_stream_t stream);
-/* NN fp32 GEMM whose output row r also receives row_bias[r / row_div][col] (row_bias: [ceil(M / row_div), N]) before the
- * column statistics are taken: a term that is constant over each group of row_div consecutive rows (K8b). */
-int er_gemm_f32_rowbias(int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B, int32_t ldb, float* C,
-                        int32_t ldc, const float* bias, const float* row_bias, int32_t row_div, float* col_stats,
-                        er_stream_t stream);
 int er_gemm_bf16(int layout, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B,
                  int32_t ldb, float* C, int32_t ldc, const float* bias, int accumulate, float* col_stats,
                  er_stream_t stream);

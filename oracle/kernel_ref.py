@@ -400,7 +400,7 @@ class RefBackend(object):
     # the statistics are recomputed from x: same values as the Welford merge up to rounding
     return self.bn_act_fwd(x, bias, gamma, beta, True, eps, momentum, moving_mean, moving_var, act)
 
-  def gemm(self, layout, a, b, out=None, bias=None, accumulate=False, bf16=False, col_stats=None, row_bias=None, row_div=1):
+  def gemm(self, layout, a, b, out=None, bias=None, accumulate=False, bf16=False, col_stats=None):
     def rnd(t):
       return t.to(torch.bfloat16).to(torch.float32) if bf16 else t
     A, Bm = rnd(a.detach()), rnd(b.detach())
@@ -410,8 +410,6 @@ class RefBackend(object):
       r = A @ Bm.t()
     else:
       r = A.t() @ Bm
-    if row_bias is not None:  # (er_gemm_f32_rowbias: before the bias, as the kernel's epilogue adds them)
-      r = r + row_bias.detach().repeat_interleave(int(row_div), dim=0)[:r.shape[0]]
     if bias is not None:
       r = r + bias.detach()
     if out is None:
@@ -895,35 +893,6 @@ class RefBackend(object):
     else:
       dh.copy_(r)
     return dq, dh
-
-  din_fold = True
-
-  def din_pair_fwd(self, q, h):
-    return torch.cat([h, q[:, None, :] * h], dim=-1)
-
-  def din_pair_bwd(self, q, h, dout):
-    E = h.shape[2]
-    g0, g1 = dout[..., :E], dout[..., E:]
-    return (g1 * h).sum(dim=1), g0 + g1 * q[:, None, :]
-
-  def segment_rowsum(self, x, L):
-    return x.reshape(-1, L, x.shape[1]).sum(dim=1)
-
-  def din_fold_w(self, w):
-    E = w.shape[0] // 4
-    w0, w1, w2, w3 = w[:E], w[E:2 * E], w[2 * E:3 * E], w[3 * E:]
-    return (w0 + w2).contiguous(), torch.cat([w1 - w2, w3], dim=0)
-
-  def din_unfold_dw(self, dwq, dwp, out=None, accumulate=False):
-    E = dwq.shape[0]
-    r = torch.cat([dwq, dwp[:E], dwq - dwp[:E], dwp[E:]], dim=0)
-    if out is None:
-      return r
-    if accumulate:
-      out.add_(r)
-    else:
-      out.copy_(r)
-    return out
 
   def din_pool_fwd(self, scores, hist, seq_len, scale=1.0):
     B, L, E = hist.shape

@@ -1148,48 +1148,6 @@ def test_gemm_grouped_bf16_matches_rounded_operands(hip):
     assert torch.equal(p[2], f)
 
 
-def test_natural_layout_weight_gradient_kernel_changes_no_bit(hip):
-  """gemm_f32_grouped_tnn_kernel (TN problems staged k-major, 128- / 64-wide tiles) against the default 64 x 64 kernel:
-  the same contraction order per accumulator and the same splits, so every output bit agrees - aligned and unaligned
-  operands, ragged edges, K that is no multiple of the k-tile, accumulate, column blocks of wider tensors."""
-  g = torch.Generator().manual_seed(17)
-  hip.gemm_reserve(1 << 23)
-  shapes = [(128, 128, 20480), (128, 64, 20480), (64, 32, 20480), (32, 1, 20480), (128, 128, 4100), (100, 36, 3001),
-            (624, 256, 4096), (81, 256, 4096), (129, 129, 131), (1, 1, 1), (64, 1, 4096), (320, 128, 20000),
-            (130, 72, 1000), (256, 192, 8192)]
-  probs, bases = [], []
-  for i, (M, N, K) in enumerate(shapes):
-    if i % 5 == 4:  # column blocks of wider tensors (aligned: offset 8; ld a multiple of 4)
-      wa, wb = torch.randn(K, M + 20, generator=g).to(DEV), torch.randn(K, N + 12, generator=g).to(DEV)
-      a, b = wa[:, 8:8 + M], wb[:, 8:8 + N]
-    elif i % 5 == 3:  # unaligned views
-      wa, wb = torch.randn(K, M + 5, generator=g).to(DEV), torch.randn(K, N + 3, generator=g).to(DEV)
-      a, b = wa[:, 1:1 + M], wb[:, 2:2 + N]
-    else:
-      a, b = torch.randn(K, M, generator=g).to(DEV), torch.randn(K, N, generator=g).to(DEV)
-    base = torch.randn(M, N, generator=g).to(DEV)
-    probs.append((a, b, base.clone(), None, i % 2 == 0))
-    bases.append(base)
-  prev = hip.gemm_tn_natural_mode()
-  try:
-    results = {}
-    for mode in (0, 1, 2):
-      hip.gemm_tn_natural_mode(mode)
-      for p, base in zip(probs, bases):
-        p[2].copy_(base)
-      hip.gemm_grouped(kernels.GEMM_TN, probs)
-      torch.cuda.synchronize()
-      results[mode] = [p[2].clone() for p in probs]
-  finally:
-    hip.gemm_tn_natural_mode(prev)
-  for i, (M, N, K) in enumerate(shapes):
-    ref = probs[i][0].double().t() @ probs[i][1].double() + (bases[i].double() if i % 2 == 0 else 0)
-    bound = (probs[i][0].double().abs().t() @ probs[i][1].double().abs()) * 1e-6 + 1e-5
-    assert ((results[0][i].double() - ref).abs() <= bound).all(), (i, M, N, K)
-    for mode in (1, 2):
-      assert torch.equal(results[mode][i], results[0][i]), (mode, i, M, N, K)
-
-
 def test_grouped_launch_epilogues_match_single_launches(hip):
   """What kernels.GroupedLinearFn relies on: problems of ONE grouped launch with their own epilogues - bias + per-row-tile
   column statistics forward (er_gemm_problem.col_stats), the BatchNorm-backward column sums of the producing layer on the
@@ -1677,48 +1635,6 @@ def test_head_sigmoid_ce_and_loss_tail(hip, ref, B, K, with_src, with_bn, bias):
   for k in ('loss', 'reg', 'total', 'report'):
     assert abs(float(got[k]) - float(exp[k])) <= 2e-6 * max(1.0, abs(float(exp[k]))), (k, float(got[k]), float(exp[k]))
   assert float(exp['reg']) == 0.5 * 21.0 and abs(float(exp['total']) - (10.5 + float(exp['loss']) + 0.125)) < 1e-5
-
-
-@pytest.mark.parametrize('B,L,E,H', [(64, 50, 32, 128), (37, 7, 12, 40), (256, 20, 8, 64)])
-def test_folded_din_first_layer_kernels(B, L, E, H):
-  """K8b: er_din_fold_w / er_din_pair_fwd / er_gemm_f32_rowbias (+ column statistics) / er_segment_rowsum /
-  er_din_pair_bwd / er_din_unfold_dw against torch, and the folded layer against dense(din_concat) (same sums in another
-  association: 1e-5 of the output's scale)."""
-  from oracle.kernel_ref import RefBackend
-  hip, ref = kernels.hip(), RefBackend()
-  g = torch.Generator().manual_seed(B + L)
-  q, h = torch.randn(B, E, generator=g), torch.randn(B, L, E, generator=g)
-  w, bias = torch.randn(4 * E, H, generator=g) * 0.1, torch.randn(H, generator=g)
-  qd, hd, wd, bd = q.to(DEV), h.to(DEV), w.to(DEV), bias.to(DEV)
-  wq, wp = hip.din_fold_w(wd)
-  rq, rp = ref.din_fold_w(w)
-  assert torch.equal(wq.cpu(), rq) and torch.equal(wp.cpu(), rp)
-  pair = hip.din_pair_fwd(qd, hd)
-  assert torch.equal(pair.cpu(), ref.din_pair_fwd(q, h))
-  rb = hip.gemm(kernels.GEMM_NN, qd, wq)
-  M = B * L
-  stats = torch.empty(hip.gemm_row_tiles(M) * H * 3, dtype=torch.float32, device=DEV)
-  z = hip.gemm(kernels.GEMM_NN, pair.reshape(M, 2 * E), wp, bias=bd, col_stats=stats, row_bias=rb, row_div=L)
-  want = (ref.din_concat_fwd(q, h).reshape(M, 4 * E).double() @ w.double() + bias.double()).float()
-  scale = float(want.abs().max())
-  assert float((z.cpu() - want).abs().max()) <= 1e-5 * scale
-  # the statistics are those of the complete output (row term included): mean of the per-tile means, weighted
-  st = stats.cpu().reshape(-1, H, 3)
-  mean = (st[:, :, 0] * st[:, :, 1]).sum(0) / st[:, :, 0].sum(0)
-  assert float((mean - want.double().mean(0).float()).abs().max()) <= 1e-4 * scale
-  dz = torch.randn(M, H, generator=g)
-  s = hip.segment_rowsum(dz.to(DEV), L)
-  assert float((s.cpu() - dz.reshape(B, L, H).sum(1)).abs().max()) <= 1e-5 * L ** 0.5 * 4
-  dpair = torch.randn(B, L, 2 * E, generator=g)
-  dq, dh = hip.din_pair_bwd(qd, hd, dpair.to(DEV))
-  rdq, rdh = ref.din_pair_bwd(q, h, dpair)
-  assert float((dq.cpu() - rdq).abs().max()) <= 1e-5 * float(rdq.abs().max()) and float((dh.cpu() - rdh).abs().max()) <= 1e-6 * float(rdh.abs().max()) + 1e-6
-  dwq, dwp = torch.randn(E, H, generator=g), torch.randn(2 * E, H, generator=g)
-  acc = torch.randn(4 * E, H, generator=g)
-  out = acc.clone().to(DEV)
-  hip.din_unfold_dw(dwq.to(DEV), dwp.to(DEV), out=out, accumulate=True)
-  assert float((out.cpu() - (acc + ref.din_unfold_dw(dwq, dwp))).abs().max()) <= 1e-6
-  assert torch.equal(hip.din_unfold_dw(dwq.to(DEV), dwp.to(DEV)).cpu(), ref.din_unfold_dw(dwq, dwp))
 
 
 @pytest.mark.parametrize('B,n_w,F,D,n_d', [(4096, 39, 39, 16, 64), (100, 5, 7, 3, 9)])

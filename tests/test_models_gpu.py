@@ -73,14 +73,6 @@ def test_multi_tower_din_matches_oracle(lazy):
   _first_steps(_cfg('din_taobao_small.config', lazy), 128, 22)
 
 
-def test_multi_tower_din_with_the_folded_first_attention_layer_matches_oracle(monkeypatch):
-  """EASYREC_AMD_DIN_FOLD=1 (layers/dnn.py din_first_layer: the attention MLP's first layer over (q, h) instead of the
-  built [q, h, q - h, q * h]; off by default - measured no faster) against the same oracle."""
-  from easyrec_amd import kernels
-  monkeypatch.setattr(type(kernels.hip()), 'din_fold', True)
-  _first_steps(_cfg('din_taobao_small.config', False), 128, 22)
-
-
 @pytest.mark.parametrize('name', ['wide_and_deep_criteo_small.config', 'wide_and_deep_nofinal_criteo_small.config',
                                   'fm_criteo_small.config', 'multi_tower_criteo_small.config',
                                   'dlrm_criteo_small.config', 'dlrm_itself_criteo_small.config',

@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Times the grouped TN launch (weight gradients dW = x^T . dz) on single problems - DIN's attention MLP (K = 204,800
-rows), MMoE's expert layers (K = 8,192) - with HIP events: default 64 x 64 kernel (mode 0) and natural-layout kernel
-(mode 2).  --only i --mode m: one shape, one mode (for rocprofv3 --pmc passes)."""
+rows), MMoE's expert layers (K = 8,192) - with HIP events.  --only i: one shape (for rocprofv3 --pmc passes).  (Round 3
+compared the default 64 x 64 kernel with a natural-layout TN kernel here: profiles/r03_wgrad_probe.md; that kernel was
+removed from the library in round 5.)"""
 import argparse
 import os
 import sys
@@ -13,7 +14,6 @@ from easyrec_amd import kernels  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument('--only', type=int, default=-1)
-ap.add_argument('--mode', type=int, default=-1)
 ap.add_argument('--iters', type=int, default=20)
 args = ap.parse_args()
 be = kernels.hip()
@@ -27,8 +27,7 @@ for si, (M, N, K) in enumerate(shapes):
   a, b = torch.randn(K, M, device=dev), torch.randn(K, N, device=dev)
   out = torch.zeros(M, N, device=dev)
   line = 'TN M=%5d N=%4d K=%6d ' % (M, N, K)
-  for mode in ((0, 2) if args.mode < 0 else (args.mode,)):
-    be.gemm_tn_natural_mode(mode)
+  for mode in (0,):
     for _ in range(3):
       be.gemm_grouped(kernels.GEMM_TN, [(a, b, out, None, False)])
     torch.cuda.synchronize()
