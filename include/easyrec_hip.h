@@ -813,6 +813,18 @@ int er_gemm_grouped_f32(int layout, const er_gemm_problem* problems_host, int n,
 /* ... with the operands rounded to bf16 while staged (er_gemm_bf16's arithmetic: v_mfma_f32_32x32x16_bf16, fp32
  * accumulation; the weight gradients of a bf16 step in one launch).  No A transform, no BatchNorm-backward epilogue. */
 int er_gemm_grouped_bf16(int layout, const er_gemm_problem* problems_host, int n, er_stream_t stream);
+/* How a grouped launch's grid is laid over the chip (host code, no device needed; the launch itself uses exactly these).
+ * A workgroup runs on XCD (block % 8) and every XCD has its own L2; all tiles of one k-split read the same rows of both
+ * operands.  er_gemm_grouped_layout: from the problems' tile and k-split counts, the XCD region - the first
+ * xsplits[p] = 8 * (splits[p] / 8) splits of problem p, dealt to the XCDs whole (XCD x: splits x, x + 8, ...; per-XCD
+ * offsets xstart[0..n]) - and the legacy region behind it (the remaining splits, offsets start[0..n]); by_xcd 0: legacy
+ * region only (the round-4 grid).  Returns the grid size (negative: error).  er_gemm_grouped_coords: what workgroup
+ * `block` of that grid computes - problem, tile (plain 1: the tile itself; 0: a slot of the XCD-aware tile order inside
+ * the problem) and k-split. */
+int er_gemm_grouped_layout(const int32_t* tiles, const int32_t* splits, int n, int by_xcd, int32_t* start, int32_t* xstart,
+                           int32_t* xsplits);
+int er_gemm_grouped_coords(const int32_t* tiles, const int32_t* start, const int32_t* xstart, const int32_t* xsplits, int n,
+                           int32_t block, int32_t* problem, int32_t* tile, int32_t* split, int32_t* plain);
 /* DEFERRED BatchNorm + activation (reference layers/dnn.py:57-79: dense -> batch_normalization -> relu per layer).
  * The reference materialises every intermediate; here a hidden layer of a stack writes only its pre-normalisation
  * values z (bias included) and its batch statistics, and every reader of its activation output y = act(BN(z)) -
