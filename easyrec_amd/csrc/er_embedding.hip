@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "er_common.h"
+#include "er_gemm_core.h"
 #include "er_decay.h"
 #include "er_grad_finish.h"
 
@@ -1516,10 +1517,7 @@ __device__ __forceinline__ void own_proj_body(int local, const OwnMulti& ma, con
 #ifndef ER_OWN_WAVES
 #define ER_OWN_WAVES 4
 #endif
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(ER_OWN_WAVES)))
-emb_bwd_own_kernel(OwnMulti ma) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int bid = blockIdx.x;
+__device__ __forceinline__ void own_block(int bid, const OwnMulti& ma, float* smem) {
   if (bid < ma.start[ma.n]) {
     int i = 0;
     while (i + 1 < ma.n && bid >= ma.start[i + 1]) ++i;
@@ -1534,6 +1532,32 @@ emb_bwd_own_kernel(OwnMulti ma) {
   const OwnArgs& a = ma.a[i];
   if (a.V == 4) own_proj_body<4>(pb - ma.proj_start[i], ma, a, smem);
   else own_proj_body<1>(pb - ma.proj_start[i], ma, a, smem);
+}
+
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(ER_OWN_WAVES)))
+emb_bwd_own_kernel(OwnMulti ma) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  own_block(blockIdx.x, ma, smem);
+}
+
+// The step's TAIL in one grid (er_emb_bwd_fused_wgrad): the weight gradients dW_l = x_l^T . dz_l of all dense layers (the
+// grouped TN launch of er_gemm_grouped_f32: workgroups [0, n_gemm), first in the grid so that its XCD region keeps
+// block % 8 = XCD) NEXT TO the embedding backward (gradient finish + tile reduce + row update: the workgroups behind
+// them).  The two are independent - both need only the last input-gradient GEMM - and bound by different things: the
+// contraction by the matrix cores and LDS of the ~2 workgroups per CU it launches, the row update by the latency of its
+// random row records at 4 workgroups per CU.  Back to back they took 39 + 32 us of a 367 us DeepFM step; the round-4
+// attempt to overlap them as two graph branches lost to launch-slot contention - one launch has no
+// second launch to contend with.  Same bodies, same arithmetic: bit-identical to the two launches.
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(ER_OWN_WAVES)))
+emb_bwd_own_wgrad_kernel(OwnMulti ma, GroupedArgs ga, int n_gemm) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // >= the GEMM's two operand stages
+  const int bid = blockIdx.x;
+  if (bid < n_gemm) {
+    const GroupedCoords c = grouped_coords(ga, bid);
+    gemm_f32_block<false, false>(ga.p[c.p], c.tile, c.split, smem, c.plain);
+    return;
+  }
+  own_block(bid - n_gemm, ma, smem);
 }
 
 // The catch-up of a step's rows from the per-lookup lists of distinct keys the fused front's sort leaves (ukeys_seg:
@@ -1685,18 +1709,31 @@ emb_bwd_tile_multi_kernel(RunMulti ma) {
                  a.tile_first, a.tile_last);
 }
 
-__global__ void __launch_bounds__(kBlock)
-emb_bwd_fix_multi_kernel(RunMulti ma) {
+__device__ __forceinline__ void fix_block(int b, const RunMulti& ma) {
   int i = 0;
-  while (i + 1 < ma.n && static_cast<int>(blockIdx.x) >= ma.start[i + 1]) ++i;
+  while (i + 1 < ma.n && b >= ma.start[i + 1]) ++i;
   const RunArgs& a = ma.a[i];
-  const int bid = blockIdx.x - ma.start[i];
+  const int bid = b - ma.start[i];
   if (a.V == 4)
     fix_body<4>(bid, a.skeys, a.n, a.dim, a.G, a.T, a.n_tiles, a.tab, ma.opt_kind, ma.hyper, a.ro, a.tile_first,
                 a.tile_last, a.aux);
   else
     fix_body<1>(bid, a.skeys, a.n, a.dim, a.G, a.T, a.n_tiles, a.tab, ma.opt_kind, ma.hyper, a.ro, a.tile_first,
                 a.tile_last, a.aux);
+}
+
+__global__ void __launch_bounds__(kBlock)
+emb_bwd_fix_multi_kernel(RunMulti ma) {
+  fix_block(blockIdx.x, ma);
+}
+
+// ... and the tail's second launch: the runs that cross tile boundaries (workgroups [0, n_fix)) next to the split-K
+// reduce of the weight gradients
+__global__ void __launch_bounds__(kBlock)
+emb_bwd_fix_reduce_kernel(RunMulti ma, GroupedReduceArgs ra, int n_fix) {
+  const int b = blockIdx.x;
+  if (b < n_fix) fix_block(b, ma);
+  else splitk_reduce_grouped_block<4>(ra, b - n_fix);
 }
 
 // Segmented sort: when every lookup of a group owns its own table (disjoint, increasing key ranges - the normal
@@ -3764,12 +3801,20 @@ int er_emb_front(er_emb_group* const* groups, int n, int flags, const er_opt_hyp
 static unsigned long long* g_own_dbg = nullptr;
 int er_debug_stamps(unsigned long long* p) { g_own_dbg = p; return 0; }
 
-int er_emb_bwd_fused(er_emb_group* const* groups, int n, const er_grad_group* finish, int n_finish, int opt_kind,
-                     const er_opt_hyper* hyper, er_stream_t stream) {
+static int emb_bwd_fused_impl(er_emb_group* const* groups, int n, const er_grad_group* finish, int n_finish, int opt_kind,
+                              const er_opt_hyper* hyper, const er_gemm_problem* wgrads, int n_wgrads, er_stream_t stream) {
   ER_REQUIRE(groups && finish && hyper && n >= 1 && n <= er::kMaxMulti && n_finish >= 1 && n_finish <= er::kOwnMaxGG,
              "er_emb_bwd_fused: bad arguments (1 <= n <= %d groups, 1 <= n_finish <= %d)", er::kMaxMulti, er::kOwnMaxGG);
   ER_REQUIRE(opt_kind >= ER_OPT_SGD && opt_kind <= ER_OPT_ADAGRAD, "er_emb_bwd_fused: unknown optimizer %d", opt_kind);
   hipStream_t s = er::as_stream(stream);
+  er::GroupedPlan plan;  // (n_wgrads > 0) the weight gradients' grouped launch: planned before any group state changes
+  if (n_wgrads > 0) {
+    ER_REQUIRE(wgrads && n_wgrads <= er::kMaxGroup, "er_emb_bwd_fused_wgrad: 1 <= n_wgrads <= %d", er::kMaxGroup);
+    for (int i = 0; i < n_wgrads; ++i)
+      ER_REQUIRE(!wgrads[i].a_mean && !wgrads[i].col_stats && !wgrads[i].bn_partial,
+                 "er_emb_bwd_fused_wgrad: problem %d: plain contractions only (no A transform, statistics or BatchNorm epilogue)", i);
+    if (int rc = er::plan_grouped(ER_GEMM_TN, wgrads, n_wgrads, false, &plan)) return rc;
+  }
   er::OwnMulti ma;
   er::RunMulti fx;
   fx.n = 0;
@@ -3887,6 +3932,20 @@ int er_emb_bwd_fused(er_emb_group* const* groups, int n, const er_grad_group* fi
   }
   for (int k = 0; k < n_finish; ++k) ma.gg[k] = finish[k];
   const int grid = ma.start[ma.n] + ma.proj_start[ma.n];
+  if (n_wgrads > 0) {
+    const int n_gemm = er::grouped_grid(plan.ga);
+    const size_t gemm_lds = sizeof(float) * 2 * 2 * er::kOpTile;
+    hipLaunchKernelGGL(er::emb_bwd_own_wgrad_kernel, dim3(n_gemm + grid), dim3(er::kBlock), lds > gemm_lds ? lds : gemm_lds, s,
+                       ma, plan.ga, n_gemm);
+    ER_LAUNCH_CHECK();
+    const int n_fix = grid > 0 ? fx.start[fx.n] : 0;
+    const int n_red = plan.ra.n > 0 ? plan.ra.start[plan.ra.n] : 0;
+    if (n_fix + n_red > 0) {
+      hipLaunchKernelGGL(er::emb_bwd_fix_reduce_kernel, dim3(n_fix + n_red), dim3(er::kBlock), 0, s, fx, plan.ra, n_fix);
+      ER_LAUNCH_CHECK();
+    }
+    return 0;
+  }
   if (grid > 0) {
     hipLaunchKernelGGL(er::emb_bwd_own_kernel, dim3(grid), dim3(er::kBlock), lds, s, ma);
     ER_LAUNCH_CHECK();
@@ -3896,6 +3955,17 @@ int er_emb_bwd_fused(er_emb_group* const* groups, int n, const er_grad_group* fi
     }
   }
   return 0;
+}
+
+int er_emb_bwd_fused(er_emb_group* const* groups, int n, const er_grad_group* finish, int n_finish, int opt_kind,
+                     const er_opt_hyper* hyper, er_stream_t stream) {
+  return emb_bwd_fused_impl(groups, n, finish, n_finish, opt_kind, hyper, nullptr, 0, stream);
+}
+
+int er_emb_bwd_fused_wgrad(er_emb_group* const* groups, int n, const er_grad_group* finish, int n_finish, int opt_kind,
+                           const er_opt_hyper* hyper, const er_gemm_problem* wgrads, int n_wgrads, er_stream_t stream) {
+  ER_REQUIRE(wgrads && n_wgrads >= 1, "er_emb_bwd_fused_wgrad: no weight-gradient problems (er_emb_bwd_fused)");
+  return emb_bwd_fused_impl(groups, n, finish, n_finish, opt_kind, hyper, wgrads, n_wgrads, stream);
 }
 #undef ER_ELIGIBLE
 

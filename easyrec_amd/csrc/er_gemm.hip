@@ -191,13 +191,7 @@ gemm_splitk_reduce_kernel(const float* __restrict__ ws, int64_t mn, int N, int s
 template <int VEC>
 __global__ void __launch_bounds__(kBlock)
 gemm_splitk_reduce_grouped_kernel(GroupedReduceArgs ra) {
-  const int b = blockIdx.x;
-  int p = 0;
-  while (p + 1 < ra.n && b >= ra.start[p + 1]) ++p;
-  const ReduceItem& r = ra.r[p];
-  const int64_t lane = static_cast<int64_t>(b - ra.start[p]) * kBlock + threadIdx.x;
-  if (VEC == 4 && r.vec) splitk_reduce_elems<4>(r.ws, r.mn, r.N, r.splits, r.bias, r.C, r.ldc, r.accumulate, lane * 4);
-  else splitk_reduce_elems<1>(r.ws, r.mn, r.N, r.splits, r.bias, r.C, r.ldc, r.accumulate, lane);
+  splitk_reduce_grouped_block<VEC>(ra, blockIdx.x);
 }
 
 }  // namespace er

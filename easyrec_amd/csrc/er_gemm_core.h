@@ -835,6 +835,16 @@ struct GroupedReduceArgs {
   ReduceItem r[kMaxGroup];
 };
 
+template <int VEC>
+__device__ __forceinline__ void splitk_reduce_grouped_block(const GroupedReduceArgs& ra, int b) {
+  int p = 0;
+  while (p + 1 < ra.n && b >= ra.start[p + 1]) ++p;
+  const ReduceItem& r = ra.r[p];
+  const int64_t lane = static_cast<int64_t>(b - ra.start[p]) * kBlock + threadIdx.x;
+  if (VEC == 4 && r.vec) splitk_reduce_elems<4>(r.ws, r.mn, r.N, r.splits, r.bias, r.C, r.ldc, r.accumulate, lane * 4);
+  else splitk_reduce_elems<1>(r.ws, r.mn, r.N, r.splits, r.bias, r.C, r.ldc, r.accumulate, lane);
+}
+
 // what er_gemm_grouped_f32 launches for one group of problems (er_gemm.hip); er_emb_bwd_fused_wgrad (er_embedding.hip)
 // launches the same records next to the embedding row update
 struct GroupedPlan {

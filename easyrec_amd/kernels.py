@@ -1002,6 +1002,14 @@ class HipBackend(object):
   def gemm_grouped(self, layout, problems, bf16=False):
     """problems: [(a, b, out, bias, accumulate)] fp32, one layout: ONE launch (+ one for the split-K reduces).
     bf16: operands rounded to bf16 while staged (er_gemm_grouped_bf16)."""
+    arr = self._gemm_problems(layout, problems, bf16)
+    if bf16:
+      self._ck(self.lib.er_gemm_grouped_bf16(ctypes.c_int(layout), arr, len(problems), _stream()), 'er_gemm_grouped_bf16')
+    else:
+      self._ck(self.lib.er_gemm_grouped_f32(ctypes.c_int(layout), arr, len(problems), _stream()), 'er_gemm_grouped_f32')
+
+  def _gemm_problems(self, layout, problems, bf16=False, log_as=None):
+    """The er_gemm_problem array of a grouped launch (log_as: the kernel the op log books the contractions under)."""
     arr = (GemmProblem * len(problems))()
     for q, pr in zip(arr, problems):
       a, b, out, bias, accumulate = pr[:5]
@@ -1022,7 +1030,9 @@ class HipBackend(object):
         (K, M), (K2, N) = a.shape, b.shape
       assert K == K2 and out.shape == (M, N)
       if self.op_log is not None:
-        if bf16:
+        if log_as is not None:
+          self._log_gemm(log_as, None, M, N, K)
+        elif bf16:
           self._log_gemm('gemm_bf16_grouped_kernel', layout, M, N, K)
         else:
           self._log_gemm('gemm_f32_grouped_tr_kernel' if at is not None else 'gemm_f32_grouped_kernel', layout, M, N, K)
@@ -1042,10 +1052,7 @@ class HipBackend(object):
         q.bn_mean, q.bn_invstd, q.bn_gamma, q.bn_beta = _ptr(src.mean), _ptr(src.invstd), _ptr(src.gamma), _ptr(src.beta)
         q.bn_ld, q.bn_use_bn, q.bn_act = src.z.stride(0), int(src.mean is not None), int(src.act)
         q.bn_partial = partial.data_ptr()
-    if bf16:
-      self._ck(self.lib.er_gemm_grouped_bf16(ctypes.c_int(layout), arr, len(problems), _stream()), 'er_gemm_grouped_bf16')
-    else:
-      self._ck(self.lib.er_gemm_grouped_f32(ctypes.c_int(layout), arr, len(problems), _stream()), 'er_gemm_grouped_f32')
+    return arr
 
   # weight gradients of a backward pass: queued by LinearFn / LinearBNActFn, contracted together by flush_wgrads()
   def wgrad_sink(self):
@@ -1064,14 +1071,28 @@ class HipBackend(object):
   def flush_wgrads(self):
     """Launch the queued weight gradients on the current stream.  Returns the queue: when that stream is not the one
     the operands were produced on, the caller keeps it alive until the streams have joined."""
-    sink = self.wgrad_sink()
-    q, sink.queue, sink.active = sink.queue, [], False
-    qb, sink.queue_bf16 = sink.queue_bf16, []
+    q, qb = self.take_wgrads()
     if q:
       self.gemm_grouped(GEMM_TN, q)
     if qb:
       self.gemm_grouped(GEMM_TN, qb, bf16=True)
     return q + qb
+
+  def take_wgrads(self):
+    """The queued weight gradients (fp32, bf16), NOT launched: the caller contracts them - the fused tail puts the fp32
+    ones into the embedding backward's grid (emb_bwd_fused(wgrads=...))."""
+    sink = self.wgrad_sink()
+    q, sink.queue, sink.active = sink.queue, [], False
+    qb, sink.queue_bf16 = sink.queue_bf16, []
+    return q, qb
+
+  # the step's tail in one grid (er_emb_bwd_fused_wgrad); A/B switch
+  fused_tail = os.environ.get('EASYREC_AMD_FUSED_TAIL', '1') != '0'
+
+  @staticmethod
+  def wgrads_fit_the_tail(q):
+    """plain fp32 contractions only (no deferred-BatchNorm operand), at most one grouped launch's worth"""
+    return 0 < len(q) <= 16 and all((len(pr) <= 5 or pr[5] is None) and len(pr) <= 6 for pr in q)
 
   # -- K12 embedding-parallel routing (include/easyrec_hip.h)
   def emb_group_set_routing(self, group, world, shard_stride, local_base):
@@ -1351,11 +1372,19 @@ class HipBackend(object):
     self._ck(self.lib.er_decay_tables_error(tabs['handle'], ctypes.byref(flag)), 'er_decay_tables_error')
     return bool(flag.value)
 
-  def emb_bwd_fused(self, groups, finish, opt_kind, hyper):
-    """finish: group_grad_finish's descriptors, one per feature-group gradient buffer the groups' lookups write."""
+  def emb_bwd_fused(self, groups, finish, opt_kind, hyper, wgrads=None):
+    """finish: group_grad_finish's descriptors, one per feature-group gradient buffer the groups' lookups write.
+    wgrads: the step's queued weight gradients (take_wgrads()'s fp32 list, wgrads_fit_the_tail) - contracted in the same
+    grid (er_emb_bwd_fused_wgrad)."""
     n = len(groups)
     gh = (ctypes.c_void_p * n)(*[g['handle'] for g in groups])
     arr, _keep = self._grad_groups(finish)
+    if wgrads:
+      pr = self._gemm_problems(GEMM_TN, wgrads, log_as='emb_bwd_own_wgrad_kernel')
+      self.tail_launches = getattr(self, 'tail_launches', 0) + 1  # (tests: the fused tail is what ran)
+      self._ck(self.lib.er_emb_bwd_fused_wgrad(gh, n, arr, len(finish), ctypes.c_int(opt_kind), _p(hyper), pr, len(wgrads),
+                                               _stream()), 'er_emb_bwd_fused_wgrad')
+      return
     self._ck(self.lib.er_emb_bwd_fused(gh, n, arr, len(finish), ctypes.c_int(opt_kind), _p(hyper), _stream()),
              'er_emb_bwd_fused')
 

@@ -655,7 +655,10 @@ class EmbeddingEngine(object):
       descs.append((g['dout'], g['out'], lam, g['got_grad'], g['terms']))
     return descs
 
-  def backward_update(self, opt_kind, hyper):
+  def backward_update(self, opt_kind, hyper, pending_wgrads=False):
+    """pending_wgrads: the dense layers' weight gradients of this backward pass are still queued (model.backward(flush=
+    False)): the fused step contracts them in the row update's grid (er_emb_bwd_fused_wgrad), every other path launches
+    them first."""
     be = kernels.hip()
     # this step's front already ran fused (forward, lazy dense decay), or - optimizers without it - runs now
     if getattr(self, '_front_done', False) or (not self.lazy_decay and self._use_fused() and self._fused_front()):
@@ -664,13 +667,24 @@ class EmbeddingEngine(object):
         while len(g['terms']) > 4:
           be.group_grad_finish([(g['dout'], g['out'], 0.0, g['got_grad'], g['terms'][:4])])
           g['terms'], g['got_grad'] = g['terms'][4:], True
-      be.emb_bwd_fused(list(self.emb_groups.values()), self._finish_descs(), opt_kind, hyper)
+      wgrads = None
+      if pending_wgrads:
+        q, qb = be.take_wgrads()
+        if qb:
+          be.gemm_grouped(kernels.GEMM_TN, qb, bf16=True)
+        if be.wgrads_fit_the_tail(q):
+          wgrads = q
+        elif q:
+          be.gemm_grouped(kernels.GEMM_TN, q)
+      be.emb_bwd_fused(list(self.emb_groups.values()), self._finish_descs(), opt_kind, hyper, wgrads=wgrads)
       for g in self.groups.values():
         g['terms'] = []
         g['got_grad'] = True
       self._roll_flush(hyper)
       self._decay_pending = True
       return
+    if pending_wgrads:
+      be.flush_wgrads()
     self.finish_group_grads()
     if opt_kind == kernels.OPT_ADAM and self._sweep_pending:
       # the sweep of the untouched rows is already in flight on the side stream; the touched rows

@@ -265,12 +265,24 @@ class EasyRecEstimator(object):
           self._sync_dense_grads()
           self._clipped_update()
         else:
-          self.model.backward()
+          # the step's tail: on one GPU the weight gradients stay queued and are contracted in the grid of the
+          # embedding row update (er_emb_bwd_fused_wgrad) - nothing between here and the dense optimizer reads them
+          tail = bool(getattr(be, 'fused_tail', False)) and self._tail_fusable()
+          self.model.backward(flush=not tail)
           self._sync_dense_grads()
-          self.engine.backward_update(self.opt_emb.kind, self.hyper[0])
+          if tail:
+            self.engine.backward_update(self.opt_emb.kind, self.hyper[0], pending_wgrads=True)
+          else:
+            self.engine.backward_update(self.opt_emb.kind, self.hyper[0])
           be.dense_opt_step(vs.flat, vs.slots.get('m'), vs.slots.get('v'), vs.flat_grad,
                             vs.l2coef if vs.any_l2 else None, self.opt_dense.kind, self.hyper[1],
                             l2_partials=vs.l2_partials)
+
+  def _tail_fusable(self):
+    """The queued weight gradients may wait for the embedding backward: one process (no dense all-reduce reads them
+    first) and the single-GPU engine, whose backward_update takes them."""
+    return type(self.engine) is EmbeddingEngine and type(self)._sync_dense_grads is EasyRecEstimator._sync_dense_grads \
+        and self._dense_grad_scale() == 1.0
 
   def _emb_gradsq_weight(self):
     """What the squared embedding row sums are multiplied by in the norm: grad_scale^2 (fp32, as the kernels apply it)."""

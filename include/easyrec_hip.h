@@ -825,6 +825,18 @@ int er_gemm_grouped_layout(const int32_t* tiles, const int32_t* splits, int n, i
                            int32_t* xsplits);
 int er_gemm_grouped_coords(const int32_t* tiles, const int32_t* start, const int32_t* xstart, const int32_t* xsplits, int n,
                            int32_t block, int32_t* problem, int32_t* tile, int32_t* split, int32_t* plain);
+/* The step's TAIL as two launches instead of four: er_emb_bwd_fused (above) with the weight gradients of the step's dense
+ * layers - `wgrads`: n_wgrads <= 16 plain ER_GEMM_TN problems dW_l (+)= x_l^T . dz_l, as er_gemm_grouped_f32 takes them
+ * (reference: the gradients tf.gradients builds for tf.layers.dense, layers/dnn.py:57-62, which the optimizer consumes
+ * beside the IndexedSlices of the embedding variables, compat/optimizers.py:285-345) - in the SAME grid: the
+ * contraction's workgroups first (its XCD region keeps block % 8), the embedding gradient finish + segmented reduce +
+ * row update behind them; then the cross-tile fix next to the split-K reduce.  The two halves depend only on the last
+ * input-gradient GEMM, not on each other, and are bound by different units (matrix cores / LDS against the latency of
+ * random row records).  Results are bit-identical to er_gemm_grouped_f32(ER_GEMM_TN, wgrads) followed by
+ * er_emb_bwd_fused: same bodies, same k-splits, same reduce order. */
+int er_emb_bwd_fused_wgrad(er_emb_group* const* groups, int n, const er_grad_group* finish_host, int n_finish, int opt_kind,
+                           const er_opt_hyper* hyper, const er_gemm_problem* wgrads_host, int n_wgrads,
+                           er_stream_t stream);
 /* DEFERRED BatchNorm + activation (reference layers/dnn.py:57-79: dense -> batch_normalization -> relu per layer).
  * The reference materialises every intermediate; here a hidden layer of a stack writes only its pre-normalisation
  * values z (bias included) and its batch statistics, and every reader of its activation output y = act(BN(z)) -

@@ -515,6 +515,15 @@ class RefBackend(object):
   def flush_wgrads(self):
     pass
 
+  fused_tail = True  # (the host logic of the fused tail runs on the stand-in too: nothing is ever queued here)
+
+  def take_wgrads(self):
+    return [], []
+
+  @staticmethod
+  def wgrads_fit_the_tail(q):
+    return False
+
   def emb_catch_up_multi(self, groups, unique_keys, n_unique, hyper):
     for g, uk, nu in zip(groups, unique_keys, n_unique):
       self.emb_catch_up(g, uk, nu, hyper)
@@ -580,7 +589,8 @@ class RefBackend(object):
       self.emb_catch_up_multi([x[0] for x in lazy], [x[1] for x in lazy], [x[2] for x in lazy], hyper)
     return True
 
-  def emb_bwd_fused(self, groups, finish, opt_kind, hyper):
+  def emb_bwd_fused(self, groups, finish, opt_kind, hyper, wgrads=None):
+    assert not wgrads
     self.group_grad_finish(finish)
     self.emb_bwd_update_multi(groups, opt_kind, hyper)
 

@@ -510,9 +510,10 @@ def test_fused_embedding_step_matches_the_general_path(optimizer, buckets, B):
       assert abs(a[k] - b[k]) <= (1e-6 if step == 0 else 2e-4) * max(1.0, abs(a[k])), (step, k, a[k], b[k])
 
 
-def _run_variant(cfg, batches, B, defer, prologue, graph=False):
+def _run_variant(cfg, batches, B, defer, prologue, graph=False, tail=False):
   be = kernels.hip()
-  be.defer_catch_up, be.prologue_tables = defer, prologue
+  be.defer_catch_up, be.prologue_tables, be.fused_tail = defer, prologue, tail
+  be.tail_launches = 0
   try:
     est = EasyRecEstimator(cfg, device=DEV, batch_size=B, seed=4).build()
     losses = []
@@ -524,9 +525,10 @@ def _run_variant(cfg, batches, B, defer, prologue, graph=False):
     assert est.engine._fused is True
     assert bool(getattr(est.engine, '_prologue_tables', False)) == bool(defer and prologue)
     est.engine.check_overflow()  # (the replay table's stamp was right at every lookup)
+    assert be.tail_launches == ((3 if graph else len(batches)) if tail else 0)  # (two eager steps + the capture, then replays)
     return losses, est.state_dict(slots=True)
   finally:
-    del be.defer_catch_up, be.prologue_tables
+    del be.defer_catch_up, be.prologue_tables, be.fused_tail
 
 
 @pytest.mark.parametrize('buckets,B', [(1000, 256), (50, 2048)])
@@ -534,9 +536,11 @@ def test_fused_step_variants_change_no_bit(buckets, B):
   """Round 5's changes to the fused single-GPU embedding step are re-arrangements of WHERE the same fp32 operations run, not
   of the operations: (1) lazy dense decay caught up in registers by the lookup and again by the row update
   (er_emb_fwd_lazy, update_row_lazy) instead of by a catch-up launch that stores the rows; (2) the lag-1 replay table
-  built by the prologue and sort + lookup in one launch (er_emb_front_fwd), eager and as a replayed hipGraph.  Eight steps
-  over ids that recur after idle gaps (so rows ARE caught up): every loss, table, slot and dense variable bit-identical
-  to the round-4 arrangement."""
+  built by the prologue and sort + lookup in one launch (er_emb_front_fwd), eager and as a replayed hipGraph; (3) the
+  step's tail - the dense layers' weight gradients in the grid of the embedding row update, the split-K reduce in the
+  grid of the cross-tile fix (er_emb_bwd_fused_wgrad) - instead of four launches.  Eight steps over ids that recur after
+  idle gaps (so rows ARE caught up): every loss, table, slot and dense variable bit-identical to the round-4
+  arrangement."""
   cfg = _cfg('deepfm_criteo_small.config')
   for f in cfg.feature_config.features:
     if f.HasField('hash_bucket_size') and f.hash_bucket_size > 0:
@@ -546,7 +550,10 @@ def test_fused_step_variants_change_no_bit(buckets, B):
   base_l, base_s = _run_variant(cfg, batches, B, defer=False, prologue=False)
   variants = {'in registers': dict(defer=True, prologue=False),
               'one launch': dict(defer=True, prologue=True),
-              'one launch, graph': dict(defer=True, prologue=True, graph=True)}
+              'one launch, graph': dict(defer=True, prologue=True, graph=True),
+              'tail in one grid': dict(defer=True, prologue=True, tail=True),
+              'tail in one grid, round-4 front': dict(defer=False, prologue=False, tail=True),
+              'tail in one grid, graph': dict(defer=True, prologue=True, graph=True, tail=True)}
   for name, kw in variants.items():
     l, s = _run_variant(cfg, batches, B, **kw)
     assert l == base_l, (name, [i for i, (a, b) in enumerate(zip(l, base_l)) if a != b])
