@@ -284,6 +284,9 @@ def time_gemm_kernel(est, launches):
 
 FAMILIES = (  # first match wins; names as rocprofv3 / the profiler print them
     ('decay replay', ('catch_up', 'flush_window', 'flush_decay', 'flush_mark', 'decay_tables', 'adam_decay_sweep')),
+    # the step's tail in one grid (er_emb_bwd_fused_wgrad): the dense layers' weight gradients NEXT TO the embedding row
+    # update, the split-K reduce next to the cross-tile fix - neither the GEMM family's nor the embedding family's alone
+    ('tail (weight gradients + embedding update)', ('emb_bwd_own_wgrad', 'emb_bwd_fix_reduce')),
     ('gemm', ('gemm_',)),
     ('batchnorm', ('er::bn_', 'dice', 'colsum')),
     ('embedding', ('er::emb_', 'hash_bucket', 'group_grad_finish', 'er::kv_', 'gather_rows', 'scatter_unique', 'rocprim')),
@@ -389,18 +392,61 @@ def step_roofline(est, per_kernel, flops, emb_bytes, pmc):
   out['kernels'] = [{'kernel': short_name(k), 'launches_per_step': v[0], 'us_per_step': v[1]}
                     for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1][1])[:14]]
   out['kernel_time_us_per_step'] = total
-  gemm_flops = sum(flops.values())
+  TAIL = 'tail (weight gradients + embedding update)'
+  tail_flops = sum(f for k, f in flops.items() if family_of(k) == TAIL)
+  gemm_flops = sum(f for k, f in flops.items() if family_of(k) == 'gemm')
   gemm_us = fams.get('gemm', [0, 0.0])[1]
+  if TAIL in fams:
+    out['tail'] = {'us_per_step': fams[TAIL][1], 'launches_per_step': fams[TAIL][0], 'gemm_flops_per_step': tail_flops,
+                   'note': 'two launches: [grouped weight-gradient GEMM | embedding gradient finish + segmented reduce + row '
+                           'update] and [split-K reduce | cross-tile fix], each pair in one grid; the GEMM family below '
+                           'excludes these flops and this time'}
   if gemm_flops > 0 and gemm_us > 0:
     out['gemm_family'] = {'flops_per_step': gemm_flops, 'us_per_step': gemm_us, 'TFLOPs': gemm_flops / (gemm_us * 1e-6) / 1e12,
                           'frac_of_mfma_peak': gemm_flops / (gemm_us * 1e-6) / 1e12 / peak_tf}
   if emb_bytes and emb_bytes.get('stage'):
-    stage_us = fams.get('embedding', [0, 0.0])[1] + fams.get('decay replay', [0, 0.0])[1]
+    stage_us = fams.get('embedding', [0, 0.0])[1] + fams.get('decay replay', [0, 0.0])[1] + fams.get(TAIL, [0, 0.0])[1]
     gbps = emb_bytes['stage'] / (stage_us * 1e-6) / 1e9
     out['embedding_stage'] = {'algorithmic_bytes_per_step': emb_bytes['stage'], 'us_per_step': stage_us, 'GBps': gbps,
                               'frac_of_hbm_peak': gbps / HBM_PEAK_GBS,
                               'note': 'hash + sort + catch-up + lookup + gradient finish + segmented reduction + row '
-                                      'update: the sum of those kernels\' durations INSIDE the replayed graph'}
+                                      'update: the sum of those kernels\' durations INSIDE the replayed graph'
+                                      + (' - the WHOLE duration of the tail launches is counted although the dense '
+                                         'layers\' weight gradients run in the same grids (a lower bound of the stage\'s '
+                                         'rate; embedding_stage_alone: the stage\'s own launches, tail unfused)'
+                                         if TAIL in fams else '')}
+  return out
+
+
+def tail_unfused(est, ring, emb_bytes, fused_per_kernel):
+  """The step with the tail as its four launches (grouped weight-gradient GEMM, split-K reduce, embedding backward, fix)
+  in a second replayed graph: what each half costs alone, and the embedding stage's rate from its own kernels."""
+  from easyrec_amd import kernels
+  be = kernels.hip()
+  saved = est.graph
+  be.fused_tail = False
+  try:
+    est.graph = None
+    est.capture(warmup=1)
+    per_kernel, _ = kernel_breakdown(est, ring)
+  finally:
+    del be.fused_tail
+    est.graph = saved
+  fams = {}
+  for name, (n, us) in per_kernel.items():
+    f = fams.setdefault(family_of(name), [0.0, 0.0])
+    f[0] += n
+    f[1] += us
+  total = sum(us for _, us in per_kernel.values())
+  pick = lambda pat: sum(us for k, (n, us) in per_kernel.items() if pat in k)  # noqa: E731
+  out = {'kernel_time_us_per_step': total,
+         'kernel_time_us_per_step_fused': sum(us for _, us in fused_per_kernel.values()),
+         'wgrad_gemm_us': pick('gemm_f32_grouped_kernel<false, false>'), 'splitk_reduce_us': pick('gemm_splitk_reduce_grouped'),
+         'emb_bwd_own_us': pick('emb_bwd_own_kernel'), 'emb_bwd_fix_us': pick('emb_bwd_fix_multi_kernel')}
+  if emb_bytes and emb_bytes.get('stage'):
+    stage_us = fams.get('embedding', [0, 0.0])[1] + fams.get('decay replay', [0, 0.0])[1]
+    gbps = emb_bytes['stage'] / (stage_us * 1e-6) / 1e9
+    out['embedding_stage_alone'] = {'us_per_step': stage_us, 'GBps': gbps, 'frac_of_hbm_peak': gbps / HBM_PEAK_GBS}
   return out
 
 
@@ -726,6 +772,10 @@ def main():
         if criteo:
           emb_bytes['stage'] = lazy_bytes
         out['roofline'] = step_roofline(est, per_kernel, flops, emb_bytes, pmc)
+        if 'tail' in out['roofline']:
+          # the embedding stage's OWN launches: the same step re-captured with the tail as four launches (bit-identical
+          # results, tests/test_deepfm_gpu.py::test_fused_step_variants_change_no_bit), after the timed region
+          out['roofline']['tail_unfused'] = tail_unfused(est, ring, emb_bytes, per_kernel)
       except Exception as e:  # noqa: BLE001
         out['roofline_error'] = str(e)[:300]
       try:  # cross-check of the profiler's durations: the largest GEMM launch alone, HIP events on the launch stream

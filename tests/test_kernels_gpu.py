@@ -1081,6 +1081,37 @@ def test_gemm_grouped_matches_single_launches(hip):
     assert torch.equal(p[2], f)
 
 
+@pytest.mark.parametrize('shapes', [
+    [(624, 256, 4096), (256, 128, 4096), (128, 64, 4096), (81, 256, 4096), (256, 128, 4096), (128, 64, 4096)],  # 8 splits each
+    [(130, 72, 30000), (64, 64, 30000)],   # 63 splits: 56 dealt to the XCDs whole + 7 in the legacy region
+    [(200, 40, 2048), (64, 200, 2304)],    # 16 / 18 splits
+])
+def test_gemm_grouped_splits_by_xcd(hip, shapes):
+  """A grouped weight-gradient launch whose problems get >= 8 k-splits: the XCD region of the grid (whole splits per XCD,
+  er_gemm_grouped_layout) computes every tile of every split - within the f32 bound of an fp64 matmul, accumulate
+  honoured - and the sum over splits is the fixed-order reduce's: bit-identical from launch to launch."""
+  g = torch.Generator().manual_seed(11)
+  hip.gemm_reserve(1 << 23)
+  probs, refs, bases = [], [], []
+  for (M, N, K) in shapes:
+    a, b = torch.randn(K, M, generator=g), torch.randn(K, N, generator=g)
+    base = torch.randn(M, N, generator=g)
+    probs.append((a.to(DEV), b.to(DEV), base.to(DEV), None, True))
+    refs.append(((a.double().t() @ b.double()), (a.double().abs().t() @ b.double().abs()) * 1e-6 + 1e-5))
+    bases.append(base)
+  hip.gemm_grouped(kernels.GEMM_TN, probs)
+  torch.cuda.synchronize()
+  first = [p[2].clone() for p in probs]
+  for (ref, bound), base, got in zip(refs, bases, first):
+    assert ((got.cpu().double() - (base.double() + ref)).abs() <= bound).all()
+  for p, base in zip(probs, bases):
+    p[2].copy_(base.to(DEV))
+  hip.gemm_grouped(kernels.GEMM_TN, probs)
+  torch.cuda.synchronize()
+  for p, f in zip(probs, first):
+    assert torch.equal(p[2], f)
+
+
 def test_sigmoid_ce_multi_matches_single_launches(hip):
   """er_sigmoid_ce_multi (the towers' losses of a multi-task model in one launch): head by head the bits of
   er_sigmoid_ce_fwd_bwd - with and without example weights, different batch sizes and scales, more heads than a launch."""
