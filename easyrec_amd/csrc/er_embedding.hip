@@ -3802,7 +3802,8 @@ static unsigned long long* g_own_dbg = nullptr;
 int er_debug_stamps(unsigned long long* p) { g_own_dbg = p; return 0; }
 
 static int emb_bwd_fused_impl(er_emb_group* const* groups, int n, const er_grad_group* finish, int n_finish, int opt_kind,
-                              const er_opt_hyper* hyper, const er_gemm_problem* wgrads, int n_wgrads, er_stream_t stream) {
+                              const er_opt_hyper* hyper, const er_gemm_problem* wgrads, int n_wgrads, int wgrad_blocks,
+                              er_stream_t stream) {
   ER_REQUIRE(groups && finish && hyper && n >= 1 && n <= er::kMaxMulti && n_finish >= 1 && n_finish <= er::kOwnMaxGG,
              "er_emb_bwd_fused: bad arguments (1 <= n <= %d groups, 1 <= n_finish <= %d)", er::kMaxMulti, er::kOwnMaxGG);
   ER_REQUIRE(opt_kind >= ER_OPT_SGD && opt_kind <= ER_OPT_ADAGRAD, "er_emb_bwd_fused: unknown optimizer %d", opt_kind);
@@ -3813,7 +3814,7 @@ static int emb_bwd_fused_impl(er_emb_group* const* groups, int n, const er_grad_
     for (int i = 0; i < n_wgrads; ++i)
       ER_REQUIRE(!wgrads[i].a_mean && !wgrads[i].col_stats && !wgrads[i].bn_partial,
                  "er_emb_bwd_fused_wgrad: problem %d: plain contractions only (no A transform, statistics or BatchNorm epilogue)", i);
-    if (int rc = er::plan_grouped(ER_GEMM_TN, wgrads, n_wgrads, false, &plan)) return rc;
+    if (int rc = er::plan_grouped(ER_GEMM_TN, wgrads, n_wgrads, false, &plan, wgrad_blocks)) return rc;
   }
   er::OwnMulti ma;
   er::RunMulti fx;
@@ -3959,13 +3960,14 @@ static int emb_bwd_fused_impl(er_emb_group* const* groups, int n, const er_grad_
 
 int er_emb_bwd_fused(er_emb_group* const* groups, int n, const er_grad_group* finish, int n_finish, int opt_kind,
                      const er_opt_hyper* hyper, er_stream_t stream) {
-  return emb_bwd_fused_impl(groups, n, finish, n_finish, opt_kind, hyper, nullptr, 0, stream);
+  return emb_bwd_fused_impl(groups, n, finish, n_finish, opt_kind, hyper, nullptr, 0, 0, stream);
 }
 
 int er_emb_bwd_fused_wgrad(er_emb_group* const* groups, int n, const er_grad_group* finish, int n_finish, int opt_kind,
-                           const er_opt_hyper* hyper, const er_gemm_problem* wgrads, int n_wgrads, er_stream_t stream) {
-  ER_REQUIRE(wgrads && n_wgrads >= 1, "er_emb_bwd_fused_wgrad: no weight-gradient problems (er_emb_bwd_fused)");
-  return emb_bwd_fused_impl(groups, n, finish, n_finish, opt_kind, hyper, wgrads, n_wgrads, stream);
+                           const er_opt_hyper* hyper, const er_gemm_problem* wgrads, int n_wgrads, int32_t wgrad_blocks,
+                           er_stream_t stream) {
+  ER_REQUIRE(wgrads && n_wgrads >= 1 && wgrad_blocks >= 0, "er_emb_bwd_fused_wgrad: no weight-gradient problems (er_emb_bwd_fused)");
+  return emb_bwd_fused_impl(groups, n, finish, n_finish, opt_kind, hyper, wgrads, n_wgrads, wgrad_blocks, stream);
 }
 #undef ER_ELIGIBLE
 

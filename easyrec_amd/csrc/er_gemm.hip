@@ -322,7 +322,7 @@ int gemm_entry(int layout, int M, int N, int K, const float* A, int lda, const f
 
 // The grouped launch's records for `n` (<= kMaxGroup) problems of one layout: k-splits, the XCD and legacy regions of the
 // grid (GroupedArgs), the split-K workspace (grown here: not capturable - er_gemm_reserve) and the reduce launch's items.
-int er::plan_grouped(int layout, const er_gemm_problem* pr, int n, bool bf16, er::GroupedPlan* plan) {
+int er::plan_grouped(int layout, const er_gemm_problem* pr, int n, bool bf16, er::GroupedPlan* plan, int64_t target_override) {
   er::GroupedArgs& ga = plan->ga;
   er::GroupedReduceArgs& ra = plan->ra;
   bool& any_tr = plan->any_tr;
@@ -344,7 +344,8 @@ int er::plan_grouped(int layout, const er_gemm_problem* pr, int n, bool bf16, er
     const int64_t v = e ? atoll(e) : 0;
     return v >= 1 ? v : 512;
   }();
-  int64_t want = total_tiles >= target_blocks ? 1 : er::ceil_div(target_blocks, total_tiles);
+  const int64_t target = target_override > 0 ? target_override : target_blocks;
+  int64_t want = total_tiles >= target ? 1 : er::ceil_div(target, total_tiles);
   // whole k-splits per XCD (GroupedArgs): 6 .. 8 wanted splits become 8, above that the next multiple of 8
   static const bool by_xcd = [] {  // (A/B knob)
     const char* e = getenv("ER_WGRAD_XCD");

@@ -865,7 +865,8 @@ inline void grouped_layout(const int* tiles, const int* splits, int n, int by_xc
 }
 inline int grouped_grid(const int* start, const int* xstart, int n) { return 8 * xstart[n] + start[n]; }
 inline int grouped_grid(const GroupedArgs& ga) { return grouped_grid(ga.start, ga.xstart, ga.n); }
-int plan_grouped(int layout, const er_gemm_problem* pr, int n, bool bf16, GroupedPlan* plan);
+// target_override > 0: the number of workgroups the k-splits aim at instead of the launch's own default (512)
+int plan_grouped(int layout, const er_gemm_problem* pr, int n, bool bf16, GroupedPlan* plan, int64_t target_override = 0);
 int launch_grouped_reduce(const GroupedReduceArgs& ra, hipStream_t s);
 
 }  // namespace er

@@ -1086,8 +1086,10 @@ class HipBackend(object):
     qb, sink.queue_bf16 = sink.queue_bf16, []
     return q, qb
 
-  # the step's tail in one grid (er_emb_bwd_fused_wgrad); A/B switch
+  # the step's tail in one grid (er_emb_bwd_fused_wgrad); A/B switch, and the workgroups its contraction's k-splits aim at
+  # (0: the stand-alone launch's 512 - bit-identical to the unfused tail; same-box 256 -> 54.5 us, 512 -> 60, 1024 -> 66)
   fused_tail = os.environ.get('EASYREC_AMD_FUSED_TAIL', '1') != '0'
+  tail_wgrad_blocks = int(os.environ.get('EASYREC_AMD_TAIL_BLOCKS', '256'))
 
   @staticmethod
   def wgrads_fit_the_tail(q):
@@ -1383,7 +1385,8 @@ class HipBackend(object):
       pr = self._gemm_problems(GEMM_TN, wgrads, log_as='emb_bwd_own_wgrad_kernel')
       self.tail_launches = getattr(self, 'tail_launches', 0) + 1  # (tests: the fused tail is what ran)
       self._ck(self.lib.er_emb_bwd_fused_wgrad(gh, n, arr, len(finish), ctypes.c_int(opt_kind), _p(hyper), pr, len(wgrads),
-                                               _stream()), 'er_emb_bwd_fused_wgrad')
+                                               ctypes.c_int32(int(self.tail_wgrad_blocks)), _stream()),
+               'er_emb_bwd_fused_wgrad')
       return
     self._ck(self.lib.er_emb_bwd_fused(gh, n, arr, len(finish), ctypes.c_int(opt_kind), _p(hyper), _stream()),
              'er_emb_bwd_fused')

@@ -832,11 +832,14 @@ int er_gemm_grouped_coords(const int32_t* tiles, const int32_t* start, const int
  * contraction's workgroups first (its XCD region keeps block % 8), the embedding gradient finish + segmented reduce +
  * row update behind them; then the cross-tile fix next to the split-K reduce.  The two halves depend only on the last
  * input-gradient GEMM, not on each other, and are bound by different units (matrix cores / LDS against the latency of
- * random row records).  Results are bit-identical to er_gemm_grouped_f32(ER_GEMM_TN, wgrads) followed by
- * er_emb_bwd_fused: same bodies, same k-splits, same reduce order. */
+ * random row records).  wgrad_blocks: the number of workgroups the contraction's k-splits aim at; 0 = the stand-alone
+ * launch's (512), and then the results are bit-identical to er_gemm_grouped_f32(ER_GEMM_TN, wgrads) followed by
+ * er_emb_bwd_fused: same bodies, same k-splits, same reduce order.  Fewer, longer contraction workgroups suit the shared
+ * grid better (they hold CU workgroup slots next to the row update's tiles for the whole launch): another split count
+ * sums the batch in another - equally fixed, launch-to-launch deterministic - order. */
 int er_emb_bwd_fused_wgrad(er_emb_group* const* groups, int n, const er_grad_group* finish_host, int n_finish, int opt_kind,
                            const er_opt_hyper* hyper, const er_gemm_problem* wgrads_host, int n_wgrads,
-                           er_stream_t stream);
+                           int32_t wgrad_blocks, er_stream_t stream);
 /* DEFERRED BatchNorm + activation (reference layers/dnn.py:57-79: dense -> batch_normalization -> relu per layer).
  * The reference materialises every intermediate; here a hidden layer of a stack writes only its pre-normalisation
  * values z (bias included) and its batch statistics, and every reader of its activation output y = act(BN(z)) -

@@ -513,6 +513,7 @@ def test_fused_embedding_step_matches_the_general_path(optimizer, buckets, B):
 def _run_variant(cfg, batches, B, defer, prologue, graph=False, tail=False):
   be = kernels.hip()
   be.defer_catch_up, be.prologue_tables, be.fused_tail = defer, prologue, tail
+  be.tail_wgrad_blocks = 0  # (the stand-alone launch's k-splits: the tail's default splits sum the batch in another order)
   be.tail_launches = 0
   try:
     est = EasyRecEstimator(cfg, device=DEV, batch_size=B, seed=4).build()
@@ -528,7 +529,7 @@ def _run_variant(cfg, batches, B, defer, prologue, graph=False, tail=False):
     assert be.tail_launches == ((3 if graph else len(batches)) if tail else 0)  # (two eager steps + the capture, then replays)
     return losses, est.state_dict(slots=True)
   finally:
-    del be.defer_catch_up, be.prologue_tables, be.fused_tail
+    del be.defer_catch_up, be.prologue_tables, be.fused_tail, be.tail_wgrad_blocks
 
 
 @pytest.mark.parametrize('buckets,B', [(1000, 256), (50, 2048)])
