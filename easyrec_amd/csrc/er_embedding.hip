@@ -1554,6 +1554,7 @@ emb_bwd_own_wgrad_kernel(OwnMulti ma, GroupedArgs ga, int n_gemm) {
   const int bid = blockIdx.x;
   if (bid < n_gemm) {
     const GroupedCoords c = grouped_coords(ga, bid);
+    if (c.split < 0) return;
     gemm_f32_block<false, false>(ga.p[c.p], c.tile, c.split, smem, c.plain);
     return;
   }

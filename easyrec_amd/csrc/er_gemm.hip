@@ -54,6 +54,7 @@ __global__ void __launch_bounds__(kBlock)
 gemm_f32_grouped_kernel(GroupedArgs ga) {
   __shared__ __attribute__((aligned(16))) float lds[2 * 2 * kOpTile];
   const GroupedCoords c = grouped_coords(ga, blockIdx.x);
+  if (c.split < 0) return;
   gemm_f32_block<A_KC, B_KC>(ga.p[c.p], c.tile, c.split, lds, c.plain);
 }
 
@@ -63,6 +64,7 @@ __global__ void __launch_bounds__(kBlock)
 gemm_f32_grouped_bn_bwd_kernel(GroupedArgs ga) {
   __shared__ __attribute__((aligned(16))) float lds[2 * 2 * kOpTile];
   const GroupedCoords c = grouped_coords(ga, blockIdx.x);
+  if (c.split < 0) return;
   gemm_f32_block<A_KC, B_KC, true>(ga.p[c.p], c.tile, c.split, lds, c.plain);
 }
 
@@ -71,6 +73,7 @@ __global__ void __launch_bounds__(kBlock)
 gemm_f32_grouped_tr_kernel(GroupedArgs ga) {
   __shared__ __attribute__((aligned(16))) float lds[kTrLds];
   const GroupedCoords c = grouped_coords(ga, blockIdx.x);
+  if (c.split < 0) return;
   gemm_f32_block<A_KC, B_KC, false, true>(ga.p[c.p], c.tile, c.split, lds, c.plain);
 }
 
@@ -175,6 +178,7 @@ gemm_bf16_grouped_kernel(GroupedArgs ga) {
   __shared__ __attribute__((aligned(16))) short As[BM * kBf16SH];
   __shared__ __attribute__((aligned(16))) short Bs[BN * kBf16SH];
   const GroupedCoords c = grouped_coords(ga, blockIdx.x);
+  if (c.split < 0) return;
   gemm_bf16_block<A_KC, B_KC>(ga.p[c.p], c.tile, c.split, As, Bs, c.plain);
 }
 
@@ -346,12 +350,12 @@ int er::plan_grouped(int layout, const er_gemm_problem* pr, int n, bool bf16, er
   }();
   const int64_t target = target_override > 0 ? target_override : target_blocks;
   int64_t want = total_tiles >= target ? 1 : er::ceil_div(target, total_tiles);
-  // whole k-splits per XCD (GroupedArgs): 6 .. 8 wanted splits become 8, above that the next multiple of 8
+  // whole k-splits per XCD (GroupedArgs): the wanted split count moves to the nearest of 4, 8, 16, 24, ...
   static const bool by_xcd = [] {  // (A/B knob)
     const char* e = getenv("ER_WGRAD_XCD");
     return !(e && e[0] == '0');
   }();
-  if (by_xcd && want >= 6) want = er::ceil_div(want, 8) * 8;
+  if (by_xcd && want >= 3) want = want <= 5 ? 4 : (want <= 11 ? 8 : ((want + 4) / 8) * 8);
   if (want > 64) want = 64;
   ga.n = 0;
   ga.start[0] = 0;
@@ -362,7 +366,7 @@ int er::plan_grouped(int layout, const er_gemm_problem* pr, int n, bool bf16, er
   size_t ws_floats = 0;
   any_tr = false;
   any_bn = false;
-  int n_splits[er::kMaxGroup];
+  int n_splits[er::kMaxGroup], xcd_ok[er::kMaxGroup];
   for (int i = 0; i < n; ++i) {
     const er_gemm_problem& q = pr[i];
     er::GroupedArgs& grp = ga;
@@ -413,6 +417,7 @@ int er::plan_grouped(int layout, const er_gemm_problem* pr, int n, bool bf16, er
     const int64_t tiles = er::ceil_div(q.M, er::BM) * er::ceil_div(q.N, er::BN);
     grp.tiles[grp.n] = static_cast<int>(tiles);
     n_splits[grp.n] = a.splits;
+    xcd_ok[grp.n] = (by_xcd && by_len <= want) ? 1 : 0;  // (a length-driven split count: legacy placement, GroupedArgs)
     ++grp.n;
     if (a.splits > 1) {
       const int64_t mn = static_cast<int64_t>(q.M) * q.N;
@@ -426,7 +431,7 @@ int er::plan_grouped(int layout, const er_gemm_problem* pr, int n, bool bf16, er
       ++ra.n;
     }
   }
-  er::grouped_layout(ga.tiles, n_splits, ga.n, by_xcd ? 1 : 0, ga.start, ga.xstart, ga.xsplits);
+  er::grouped_layout(ga.tiles, n_splits, ga.n, xcd_ok, ga.start, ga.xstart, ga.xsplits, ga.xper);
   if (ra.n > 0) {
     float* ws;
     if (int rc = ensure_ws(ws_floats, &ws)) return rc;
@@ -655,19 +660,20 @@ int er_gemm_grouped_bf16(int layout, const er_gemm_problem* problems, int n, er_
   return 0;
 }
 
-int er_gemm_grouped_layout(const int32_t* tiles, const int32_t* splits, int n, int by_xcd, int32_t* start, int32_t* xstart,
-                           int32_t* xsplits) {
-  if (!(tiles && splits && start && xstart && xsplits && n >= 1 && n <= er::kMaxGroup)) return -1;
-  er::grouped_layout(tiles, splits, n, by_xcd, start, xstart, xsplits);
+int er_gemm_grouped_layout(const int32_t* tiles, const int32_t* splits, int n, const int32_t* by_xcd, int32_t* start,
+                           int32_t* xstart, int32_t* xsplits, int32_t* xper) {
+  if (!(tiles && splits && start && xstart && xsplits && xper && n >= 1 && n <= er::kMaxGroup)) return -1;
+  er::grouped_layout(tiles, splits, n, by_xcd, start, xstart, xsplits, xper);
   return er::grouped_grid(start, xstart, n);
 }
 
-int er_gemm_grouped_coords(const int32_t* tiles, const int32_t* start, const int32_t* xstart, const int32_t* xsplits, int n,
-                           int32_t block, int32_t* problem, int32_t* tile, int32_t* split, int32_t* plain) {
-  ER_REQUIRE(tiles && start && xstart && xsplits && problem && tile && split && plain && n >= 1 && n <= er::kMaxGroup,
+int er_gemm_grouped_coords(const int32_t* tiles, const int32_t* start, const int32_t* xstart, const int32_t* xsplits,
+                           const int32_t* xper, int n, int32_t block, int32_t* problem, int32_t* tile, int32_t* split,
+                           int32_t* plain) {
+  ER_REQUIRE(tiles && start && xstart && xsplits && xper && problem && tile && split && plain && n >= 1 && n <= er::kMaxGroup,
              "er_gemm_grouped_coords: bad arguments");
   ER_REQUIRE(block >= 0 && block < er::grouped_grid(start, xstart, n), "er_gemm_grouped_coords: block %d outside the grid", block);
-  const er::GroupedCoords c = er::grouped_coords(start, tiles, xstart, xsplits, n, block);
+  const er::GroupedCoords c = er::grouped_coords(start, tiles, xstart, xsplits, xper, n, block);
   *problem = c.p; *tile = c.tile; *split = c.split; *plain = c.plain ? 1 : 0;
   return 0;
 }

@@ -746,12 +746,18 @@ __device__ __forceinline__ void gemm_f32_block(const GemmArgs& g, int bx, int bz
 //
 // Two regions.  XCD region, workgroups [0, 8 * xstart[n]): workgroup b runs on XCD b % 8 (MI355X_MICROARCH.md: observed
 // dispatch order, used for speed only - any placement gives the same result) and every XCD has its own L2.  The tiles
-// of ONE k-split all read the same rows of both operands, so a problem's first xsplits[p] (a multiple of 8) splits are
-// dealt to the XCDs whole: XCD x takes splits x, x + 8, ... and, inside its share j = b / 8 of the region, problem p's
-// workgroups [xstart[p], xstart[p + 1]) = its tiles of those splits, split-major.  With 8 splits per problem (DeepFM's
-// weight gradients at B = 4096) an XCD reads one eighth of the batch rows of every operand and nothing else: the
-// operands cross the HBM side once instead of once per XCD that holds one of the split's tiles (round 4: 121 MB of
-// counter traffic per launch against 39 MB of operands).
+// of ONE k-split all read the same rows of both operands, so splits are dealt to the XCDs whole; inside its share
+// j = b / 8 of the region, XCD x runs problem p's workgroups [xstart[p], xstart[p + 1]):
+//   xper[p] == 1 (splits >= 8): the first xsplits[p] = 8 * (splits / 8) splits - XCD x takes splits x, x + 8, ..., all
+//     their tiles, split-major;
+//   xper[p] == 2 | 4 (splits == 4 | 2): split x / xper on xper neighbouring XCDs, tile slot * xper + x % xper (a slot past
+//     the last tile idles: fewer than 8 workgroups per problem, not the surplus that aliased with the CU round robin).
+// With 8 (4) splits per problem - DeepFM's weight gradients at B = 4096, stand-alone (in the step's tail) - an XCD reads
+// one eighth (quarter) of the batch rows of every operand and nothing else: counter traffic 121 MB -> 47.5 MB per launch
+// = 1.0x operands + workspace (profiles/r05_s10_pmc_wgrad_by_xcd.txt).  The launch is NOT faster for it (39 us either
+// way: it never waited for HBM), and batch-long contractions (DIN's B x L = 204,800 rows, ~100 splits of 1 - 4 tiles)
+// got SLOWER (190 -> 245 us: every L2 holding a copy of the hot rows is 8x the L2 bandwidth of one), so the host places
+// by XCD only the problems whose splits are sized by the workgroup target, not by the contraction's length (plan_grouped).
 // Legacy region, after it: the remaining splits (xsplits[p] .. splits - 1) of problem p at [start[p], start[p + 1]):
 // tile slot = local % tiles (XCD-aware tile order inside the problem, tile_coords), k-split = local / tiles.
 constexpr int kMaxGroup = 16;
@@ -761,22 +767,26 @@ struct GroupedArgs {
   int tiles[kMaxGroup];
   int xstart[kMaxGroup + 1];
   int xsplits[kMaxGroup];
+  int xper[kMaxGroup];
   GemmArgs p[kMaxGroup];
 };
 struct GroupedCoords {
-  int p, tile, split;
-  bool plain;  // tile is the tile itself (XCD region), not a slot of tile_coords' order
+  int p, tile, split;  // split < 0: an idle workgroup
+  bool plain;          // tile is the tile itself (XCD region), not a slot of tile_coords' order
 };
 __host__ __device__ inline GroupedCoords grouped_coords(const int* __restrict__ start, const int* __restrict__ tiles,
                                                         const int* __restrict__ xstart, const int* __restrict__ xsplits,
-                                                        int n, int b) {
+                                                        const int* __restrict__ xper, int n, int b) {
   const int r1 = 8 * xstart[n];
   if (b < r1) {
     const int x = b & 7, j = b >> 3;
     int p = 0;
     while (p + 1 < n && j >= xstart[p + 1]) ++p;
     const int l = j - xstart[p];
-    return GroupedCoords{p, l % tiles[p], x + 8 * (l / tiles[p]), true};
+    const int xp = xper[p];
+    if (xp == 1) return GroupedCoords{p, l % tiles[p], x + 8 * (l / tiles[p]), true};
+    const int tile = l * xp + x % xp;
+    return GroupedCoords{p, tile, tile < tiles[p] ? x / xp : -1, true};
   }
   b -= r1;
   int p = 0;
@@ -785,7 +795,7 @@ __host__ __device__ inline GroupedCoords grouped_coords(const int* __restrict__ 
   return GroupedCoords{p, local % tiles[p], xsplits[p] + local / tiles[p], false};
 }
 __device__ __forceinline__ GroupedCoords grouped_coords(const GroupedArgs& ga, int b) {
-  return grouped_coords(ga.start, ga.tiles, ga.xstart, ga.xsplits, ga.n, b);
+  return grouped_coords(ga.start, ga.tiles, ga.xstart, ga.xsplits, ga.xper, ga.n, b);
 }
 
 // C[i, j] (+)= bias[j] + sum_s ws[s, i, j]   (split order fixed: deterministic).  VEC = 4: float4 per lane, the
@@ -852,14 +862,24 @@ struct GroupedPlan {
   GroupedReduceArgs ra;
   bool any_tr, any_bn;
 };
-// the two regions of a grouped grid from the problems' tile and k-split counts (GroupedArgs)
-inline void grouped_layout(const int* tiles, const int* splits, int n, int by_xcd, int* start, int* xstart, int* xsplits) {
+// the two regions of a grouped grid from the problems' tile and k-split counts (GroupedArgs); by_xcd[p] 0: problem p in
+// the legacy region only
+inline void grouped_layout(const int* tiles, const int* splits, int n, const int* by_xcd, int* start, int* xstart, int* xsplits,
+                           int* xper) {
   start[0] = 0;
   xstart[0] = 0;
   for (int p = 0; p < n; ++p) {
-    const int xs = by_xcd ? (splits[p] / 8) * 8 : 0;
+    int xs = 0, xp = 0, per_xcd = 0;
+    if (by_xcd && by_xcd[p]) {
+      if (splits[p] >= 8) {
+        xs = (splits[p] / 8) * 8; xp = 1; per_xcd = tiles[p] * (xs / 8);
+      } else if (splits[p] == 4 || splits[p] == 2) {
+        xs = splits[p]; xp = 8 / splits[p]; per_xcd = (tiles[p] + xp - 1) / xp;
+      }
+    }
     xsplits[p] = xs;
-    xstart[p + 1] = xstart[p] + tiles[p] * (xs / 8);
+    xper[p] = xp;
+    xstart[p + 1] = xstart[p] + per_xcd;
     start[p + 1] = start[p] + tiles[p] * (splits[p] - xs);
   }
 }

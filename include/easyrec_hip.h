@@ -815,16 +815,18 @@ int er_gemm_grouped_f32(int layout, const er_gemm_problem* problems_host, int n,
 int er_gemm_grouped_bf16(int layout, const er_gemm_problem* problems_host, int n, er_stream_t stream);
 /* How a grouped launch's grid is laid over the chip (host code, no device needed; the launch itself uses exactly these).
  * A workgroup runs on XCD (block % 8) and every XCD has its own L2; all tiles of one k-split read the same rows of both
- * operands.  er_gemm_grouped_layout: from the problems' tile and k-split counts, the XCD region - the first
- * xsplits[p] = 8 * (splits[p] / 8) splits of problem p, dealt to the XCDs whole (XCD x: splits x, x + 8, ...; per-XCD
- * offsets xstart[0..n]) - and the legacy region behind it (the remaining splits, offsets start[0..n]); by_xcd 0: legacy
- * region only (the round-4 grid).  Returns the grid size (negative: error).  er_gemm_grouped_coords: what workgroup
- * `block` of that grid computes - problem, tile (plain 1: the tile itself; 0: a slot of the XCD-aware tile order inside
- * the problem) and k-split. */
-int er_gemm_grouped_layout(const int32_t* tiles, const int32_t* splits, int n, int by_xcd, int32_t* start, int32_t* xstart,
-                           int32_t* xsplits);
-int er_gemm_grouped_coords(const int32_t* tiles, const int32_t* start, const int32_t* xstart, const int32_t* xsplits, int n,
-                           int32_t block, int32_t* problem, int32_t* tile, int32_t* split, int32_t* plain);
+ * operands.  er_gemm_grouped_layout: from the problems' tile and k-split counts, the XCD region - problems with
+ * by_xcd[p] != 0: with >= 8 splits the first xsplits[p] = 8 * (splits[p] / 8) of them, dealt to the XCDs whole (xper[p] = 1:
+ * XCD x takes splits x, x + 8, ...); with 4 or 2 splits every split on xper[p] = 2 or 4 neighbouring XCDs, its tiles dealt
+ * round robin among them (a slot past the last tile idles: split -1); per-XCD offsets xstart[0..n] - and the legacy region
+ * behind it (all other splits, offsets start[0..n]); by_xcd NULL: legacy region only (the round-4 grid).  Returns the grid
+ * size (negative: error).  er_gemm_grouped_coords: what workgroup `block` of that grid computes - problem, tile (plain 1:
+ * the tile itself; 0: a slot of the XCD-aware tile order inside the problem) and k-split. */
+int er_gemm_grouped_layout(const int32_t* tiles, const int32_t* splits, int n, const int32_t* by_xcd, int32_t* start,
+                           int32_t* xstart, int32_t* xsplits, int32_t* xper);
+int er_gemm_grouped_coords(const int32_t* tiles, const int32_t* start, const int32_t* xstart, const int32_t* xsplits,
+                           const int32_t* xper, int n, int32_t block, int32_t* problem, int32_t* tile, int32_t* split,
+                           int32_t* plain);
 /* The step's TAIL as two launches instead of four: er_emb_bwd_fused (above) with the weight gradients of the step's dense
  * layers - `wgrads`: n_wgrads <= 16 plain ER_GEMM_TN problems dW_l (+)= x_l^T . dz_l, as er_gemm_grouped_f32 takes them
  * (reference: the gradients tf.gradients builds for tf.layers.dense, layers/dnn.py:57-62, which the optimizer consumes
