@@ -286,7 +286,7 @@ FAMILIES = (  # first match wins; names as rocprofv3 / the profiler print them
     ('decay replay', ('catch_up', 'flush_window', 'flush_decay', 'flush_mark', 'decay_tables', 'adam_decay_sweep')),
     # the step's tail in one grid (er_emb_bwd_fused_wgrad): the dense layers' weight gradients NEXT TO the embedding row
     # update, the split-K reduce next to the cross-tile fix - neither the GEMM family's nor the embedding family's alone
-    ('tail (weight gradients + embedding update)', ('emb_bwd_own_wgrad', 'emb_bwd_fix_reduce')),
+    ('tail (weight gradients + embedding update)', ('emb_bwd_own_wgrad', 'emb_bwd_fix_reduce', 'emb_bwd_fix_opt')),
     ('gemm', ('gemm_',)),
     ('batchnorm', ('er::bn_', 'dice', 'colsum')),
     ('embedding', ('er::emb_', 'hash_bucket', 'group_grad_finish', 'er::kv_', 'gather_rows', 'scatter_unique', 'rocprim')),
@@ -399,8 +399,8 @@ def step_roofline(est, per_kernel, flops, emb_bytes, pmc):
   if TAIL in fams:
     out['tail'] = {'us_per_step': fams[TAIL][1], 'launches_per_step': fams[TAIL][0], 'gemm_flops_per_step': tail_flops,
                    'note': 'two launches: [grouped weight-gradient GEMM | embedding gradient finish + segmented reduce + row '
-                           'update] and [split-K reduce | cross-tile fix], each pair in one grid; the GEMM family below '
-                           'excludes these flops and this time'}
+                           'update | scalar loss tail] and [cross-tile fix | dense optimizer with the split-K reduce folded '
+                           'into its gradient read], each in one grid; the GEMM family below excludes these flops and this time'}
   if gemm_flops > 0 and gemm_us > 0:
     out['gemm_family'] = {'flops_per_step': gemm_flops, 'us_per_step': gemm_us, 'TFLOPs': gemm_flops / (gemm_us * 1e-6) / 1e12,
                           'frac_of_mfma_peak': gemm_flops / (gemm_us * 1e-6) / 1e12 / peak_tf}
@@ -442,7 +442,8 @@ def tail_unfused(est, ring, emb_bytes, fused_per_kernel):
   out = {'kernel_time_us_per_step': total,
          'kernel_time_us_per_step_fused': sum(us for _, us in fused_per_kernel.values()),
          'wgrad_gemm_us': pick('gemm_f32_grouped_kernel<false, false>'), 'splitk_reduce_us': pick('gemm_splitk_reduce_grouped'),
-         'emb_bwd_own_us': pick('emb_bwd_own_kernel'), 'emb_bwd_fix_us': pick('emb_bwd_fix_multi_kernel')}
+         'emb_bwd_own_us': pick('emb_bwd_own_kernel'), 'emb_bwd_fix_us': pick('emb_bwd_fix_multi_kernel'),
+         'loss_tail_us': pick('loss_tail_kernel'), 'dense_opt_us': pick('dense_opt_kernel')}
   if emb_bytes and emb_bytes.get('stage'):
     stage_us = fams.get('embedding', [0, 0.0])[1] + fams.get('decay replay', [0, 0.0])[1]
     gbps = emb_bytes['stage'] / (stage_us * 1e-6) / 1e9

@@ -9,6 +9,7 @@
 #include <mutex>
 
 #include "er_common.h"
+#include "er_dense_tail.h"
 #include "er_decay.h"
 #include "er_farmhash.h"
 
@@ -760,8 +761,7 @@ dice_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ alp
 // ------------------------------------------------------------------------------------------------
 // loss + scalar reductions (single block, fixed tree -> deterministic)
 // ------------------------------------------------------------------------------------------------
-// one workgroup of 1024 threads (16 waves): the batch is a few thousand logits; sums combine in a fixed order
-constexpr int kCeBlock = 1024;
+// (kCeBlock = 1024 threads, 16 waves: er_dense_tail.h) sums combine in a fixed order
 __device__ __forceinline__ float block_sum_1024(float v, float* smem16) {
   v = wave_sum(v);
   const int wid = threadIdx.x >> 6;
@@ -829,10 +829,6 @@ sigmoid_ce_multi_kernel(CeMultiArgs a) {
 // regularization_loss = reg_emb + reg_dense; total_loss = regularization_loss + sum_i losses[i]; copies of the
 // individual losses into their report slots: the estimator's add_n over the loss dict + REGULARIZATION_LOSSES
 // (model/easy_rec_estimator.py:166-184) as ONE launch instead of ~6 scalar add / copy kernels.
-struct LossPtrs {
-  const float* src[8];
-  float* dst[8];
-};
 __global__ void total_loss_kernel(const float* __restrict__ reg_emb, const float* __restrict__ reg_dense, LossPtrs lp,
                                   int n, float* __restrict__ reg_out, float* __restrict__ total_out) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -1028,86 +1024,11 @@ head_sigmoid_ce_kernel(HeadArgs a) {
   }
 }
 
-// The scalar tail of the loss (reg_total_loss_kernel) for steps whose head ran as er_head_sigmoid_ce: a task loss may
-// arrive as per-workgroup partial sums (loss = scale * sum of them, fixed order), and small column-sum jobs (the head's
-// dW / db partials: dst[j] += sum_p partial[p][j]) ride along, so that the head costs no launch of its own for them.
-constexpr int kTailJobs = 4;
-struct TailJob { const float* partial; float* dst; int n_parts, n_cols, ld; };
-struct LossTailArgs {
-  const float* emb_partials; int n_partials; float emb_scale;
-  const float* dense_partials; int n_dense;
-  LossPtrs lp; int n_losses;
-  int loss_parts[8];       // > 0: lp.src[i] holds that many partial sums ...
-  float loss_scale[8];     // ... and the loss is loss_scale[i] * their sum / loss_div[i] (sigmoid_ce_kernel's expression),
-  float loss_div[8];       //     also written back to loss_value[i]
-  float* loss_value[8];
-  float* reg_out; float* total_out;
-  int n_jobs; TailJob jobs[kTailJobs];
-};
-
+// (the loss tail's records and body: er_dense_tail.h - the fused tail of er_embedding.hip runs the same body)
 __global__ void __launch_bounds__(kCeBlock)
 loss_tail_kernel(LossTailArgs a) {
-  __shared__ float red[kCeBlock / 64];
-  __shared__ float s_loss[8];
-  // column-sum jobs: 16 part lanes x 64 columns per round (every partial's load is in flight at once: a thread per column
-  // walking its partials one after the other was a 20 us chain of dependent L2 round trips), lanes combined in a fixed order
-  __shared__ float s_job[16][64];
-  for (int j = 0; j < a.n_jobs; ++j) {
-    const TailJob& jb = a.jobs[j];
-    const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
-    for (int c0 = 0; c0 < jb.n_cols; c0 += 64) {
-      const int col = c0 + cl;
-      float s = 0.f;
-      if (col < jb.n_cols) {
-        float v[8];
-        for (int p0 = pl; p0 < jb.n_parts; p0 += 16 * 8) {
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const int p = p0 + u * 16;
-            v[u] = p < jb.n_parts ? jb.partial[static_cast<int64_t>(p) * jb.ld + col] : 0.f;
-          }
-#pragma unroll
-          for (int u = 0; u < 8; ++u) s = s + v[u];
-        }
-      }
-      s_job[pl][cl] = s;
-      __syncthreads();
-      if (pl == 0 && col < jb.n_cols) {
-        float t = 0.f;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) t = t + s_job[q][cl];
-        jb.dst[col] = jb.dst[col] + t;
-      }
-      __syncthreads();
-    }
-  }
-  for (int i = 0; i < a.n_losses; ++i) {
-    if (a.loss_parts[i] <= 0) continue;  // (uniform)
-    float v = 0.f;
-    for (int p = threadIdx.x; p < a.loss_parts[i]; p += kCeBlock) v = v + a.lp.src[i][p];
-    const float tot = block_sum_1024(v, red);
-    if (threadIdx.x == 0) {
-      const float l = a.loss_scale[i] * tot / a.loss_div[i];
-      s_loss[i] = l;
-      if (a.loss_value[i]) a.loss_value[i][0] = l;
-    }
-  }
-  float e = 0.f;
-  for (int i = threadIdx.x; i < a.n_partials; i += kCeBlock) e = e + a.emb_partials[i];
-  const float emb = block_sum_1024(e, red);
-  float b = 0.f;
-  for (int i = threadIdx.x; i < a.n_dense; i += kCeBlock) b = b + a.dense_partials[i];
-  const float dense = block_sum_1024(b, red);
-  if (threadIdx.x != 0) return;
-  const float reg = a.emb_scale * emb + dense;
-  a.reg_out[0] = reg;
-  float total = reg;
-  for (int i = 0; i < a.n_losses; ++i) {
-    const float v = a.loss_parts[i] > 0 ? s_loss[i] : a.lp.src[i][0];
-    if (a.lp.dst[i]) a.lp.dst[i][0] = v;
-    total = total + v;
-  }
-  a.total_out[0] = total;
+  __shared__ float lds[kLossTailLdsFloats];
+  loss_tail_body<kCeBlock>(a, lds);
 }
 
 __global__ void __launch_bounds__(kBlock)
@@ -1136,41 +1057,7 @@ l2_loss_partial_kernel(const float* __restrict__ w, const float* __restrict__ co
 // ------------------------------------------------------------------------------------------------
 // dense-variable optimizer over the flat buffer
 // ------------------------------------------------------------------------------------------------
-// one element of the dense optimizer; returns 0.5 * coef * w_new^2 (its share of the next step's kernel-L2 loss)
-__device__ __forceinline__ float dense_opt_elem(float* __restrict__ w, float* __restrict__ m, float* __restrict__ v,
-                                                const float* __restrict__ grad, const float* __restrict__ l2coef,
-                                                int64_t i, int opt_kind, const er_opt_hyper& h) {
-  float wi = w[i];
-  float g = grad[i] * h.grad_scale;
-  if (l2coef) {
-    const float c = l2coef[i];
-    if (c != 0.f) g = g + c * wi;
-  }
-  if (h.clip_scale != 0.f) g = g * h.clip_scale;  // clip_by_global_norm (er_clip_scale); 0 = no clipping
-  if (opt_kind == ER_OPT_ADAM || opt_kind == ER_OPT_LAZY_ADAM) {
-    // training_ops.apply_adam (dense): m += (g-m)*(1-b1); v += (g*g-v)*(1-b2); var -= m*alpha/(sqrt(v)+eps)
-    float mi = m[i], vi = v[i];
-    mi = mi + (g - mi) * h.one_minus_beta1;
-    vi = vi + (g * g - vi) * h.one_minus_beta2;
-    wi = wi - (mi * h.lr_t) / (sqrtf(vi) + h.eps);
-    m[i] = mi;
-    v[i] = vi;
-  } else if (opt_kind == ER_OPT_ADAGRAD) {
-    float vi = v[i] + g * g;
-    v[i] = vi;
-    wi = wi - (g * h.lr) / sqrtf(vi);
-  } else {
-    wi = wi - h.lr * g;
-  }
-  w[i] = wi;
-  float l2 = 0.f;
-  if (l2coef) {
-    const float c = l2coef[i];
-    if (c != 0.f) l2 = c * (0.5f * (wi * wi));
-  }
-  return l2;
-}
-
+// (dense_opt_elem: er_dense_tail.h)
 __global__ void __launch_bounds__(kBlock)
 dense_opt_kernel(float* __restrict__ w, float* __restrict__ m, float* __restrict__ v, const float* __restrict__ grad,
                  const float* __restrict__ l2coef, int64_t n, int opt_kind, const er_opt_hyper* __restrict__ hyper,
@@ -1380,6 +1267,46 @@ grouped_auc_reduce_kernel(const double* __restrict__ pos_rank_sum, const double*
 }
 
 }  // namespace er
+
+// er_loss_tail's / er_dense_opt_step_l2's argument checks and device records (also used by er_emb_bwd_fused_tail)
+int er::make_loss_tail_args(const er_loss_tail_job* job, er::LossTailArgs* out) {
+  ER_REQUIRE(job && out, "er_loss_tail: null job");
+  const er_loss_tail_job& q = *job;
+  ER_REQUIRE(q.reg_out && q.total_out && q.n_losses >= 0 && q.n_losses <= 8 && q.n_partials >= 0 && (q.emb_partials || q.n_partials == 0) &&
+                 q.n_dense >= 0 && (q.dense_partials || q.n_dense == 0) && q.n_jobs >= 0 && q.n_jobs <= er::kTailJobs && (q.jobs || q.n_jobs == 0) &&
+                 (q.losses || q.n_losses == 0),
+             "er_loss_tail: bad arguments (at most 8 losses, %d column-sum jobs)", er::kTailJobs);
+  er::LossTailArgs& a = *out;
+  a.emb_partials = q.emb_partials; a.n_partials = q.n_partials; a.emb_scale = q.emb_scale;
+  a.dense_partials = q.dense_partials; a.n_dense = q.n_dense; a.n_losses = q.n_losses;
+  for (int i = 0; i < 8; ++i) {
+    a.lp.src[i] = i < q.n_losses ? q.losses[i] : nullptr;
+    a.lp.dst[i] = (i < q.n_losses && q.report) ? q.report[i] : nullptr;
+    a.loss_parts[i] = (i < q.n_losses && q.loss_parts) ? q.loss_parts[i] : 0;
+    a.loss_scale[i] = (i < q.n_losses && q.loss_scales) ? q.loss_scales[i] : 1.f;
+    a.loss_div[i] = (i < q.n_losses && q.loss_divs) ? q.loss_divs[i] : 1.f;
+    a.loss_value[i] = (i < q.n_losses && q.loss_values) ? q.loss_values[i] : nullptr;
+    ER_REQUIRE(i >= q.n_losses || q.losses[i], "er_loss_tail: loss %d is null", i);
+  }
+  a.reg_out = q.reg_out; a.total_out = q.total_out; a.n_jobs = q.n_jobs;
+  for (int j = 0; j < q.n_jobs; ++j) {
+    ER_REQUIRE(q.jobs[j].partial && q.jobs[j].dst && q.jobs[j].n_parts > 0 && q.jobs[j].n_cols > 0 && q.jobs[j].ld >= q.jobs[j].n_cols,
+               "er_loss_tail: job %d: bad arguments", j);
+    a.jobs[j] = er::TailJob{q.jobs[j].partial, q.jobs[j].dst, q.jobs[j].n_parts, q.jobs[j].n_cols, q.jobs[j].ld};
+  }
+  return 0;
+}
+
+int er::make_dense_opt_args(const er_dense_opt_job* job, er::DenseOptArgs* out) {
+  ER_REQUIRE(job && out, "er_dense_opt_step: null job");
+  const er_dense_opt_job& q = *job;
+  ER_REQUIRE(q.w && q.grad && q.hyper && q.n > 0, "er_dense_opt_step: bad arguments");
+  ER_REQUIRE(q.opt_kind >= ER_OPT_SGD && q.opt_kind <= ER_OPT_ADAGRAD, "er_dense_opt_step: unknown optimizer %d", q.opt_kind);
+  if (q.opt_kind == ER_OPT_ADAM || q.opt_kind == ER_OPT_LAZY_ADAM) ER_REQUIRE(q.m && q.v, "er_dense_opt_step: Adam needs m, v");
+  if (q.opt_kind == ER_OPT_ADAGRAD) ER_REQUIRE(q.v, "er_dense_opt_step: Adagrad needs the accumulator in v");
+  *out = er::DenseOptArgs{q.w, q.m, q.v, q.grad, q.l2coef, q.n, q.opt_kind, q.hyper, q.l2_partials};
+  return 0;
+}
 
 extern "C" {
 
@@ -1882,27 +1809,14 @@ int er_loss_tail(const float* emb_partials, int32_t n_partials, float emb_scale,
                  const float* const* losses, float* const* report, const int32_t* loss_parts, const float* loss_scales,
                  const float* loss_divs, float* const* loss_values, int32_t n_losses, const er_tail_job* jobs, int32_t n_jobs, float* reg_out,
                  float* total_out, er_stream_t stream) {
-  ER_REQUIRE(reg_out && total_out && n_losses >= 0 && n_losses <= 8 && n_partials >= 0 && (emb_partials || n_partials == 0) &&
-                 n_dense >= 0 && (dense_partials || n_dense == 0) && n_jobs >= 0 && n_jobs <= er::kTailJobs && (jobs || n_jobs == 0),
-             "er_loss_tail: bad arguments (at most 8 losses, %d column-sum jobs)", er::kTailJobs);
+  er_loss_tail_job job;
+  job.emb_partials = emb_partials; job.n_partials = n_partials; job.emb_scale = emb_scale;
+  job.dense_partials = dense_partials; job.n_dense = n_dense;
+  job.losses = losses; job.report = report; job.loss_parts = loss_parts; job.loss_scales = loss_scales; job.loss_divs = loss_divs;
+  job.loss_values = loss_values; job.n_losses = n_losses; job.jobs = jobs; job.n_jobs = n_jobs;
+  job.reg_out = reg_out; job.total_out = total_out;
   er::LossTailArgs a;
-  a.emb_partials = emb_partials; a.n_partials = n_partials; a.emb_scale = emb_scale;
-  a.dense_partials = dense_partials; a.n_dense = n_dense; a.n_losses = n_losses;
-  for (int i = 0; i < 8; ++i) {
-    a.lp.src[i] = i < n_losses ? losses[i] : nullptr;
-    a.lp.dst[i] = (i < n_losses && report) ? report[i] : nullptr;
-    a.loss_parts[i] = (i < n_losses && loss_parts) ? loss_parts[i] : 0;
-    a.loss_scale[i] = (i < n_losses && loss_scales) ? loss_scales[i] : 1.f;
-    a.loss_div[i] = (i < n_losses && loss_divs) ? loss_divs[i] : 1.f;
-    a.loss_value[i] = (i < n_losses && loss_values) ? loss_values[i] : nullptr;
-    ER_REQUIRE(i >= n_losses || losses[i], "er_loss_tail: loss %d is null", i);
-  }
-  a.reg_out = reg_out; a.total_out = total_out; a.n_jobs = n_jobs;
-  for (int j = 0; j < n_jobs; ++j) {
-    ER_REQUIRE(jobs[j].partial && jobs[j].dst && jobs[j].n_parts > 0 && jobs[j].n_cols > 0 && jobs[j].ld >= jobs[j].n_cols,
-               "er_loss_tail: job %d: bad arguments", j);
-    a.jobs[j] = er::TailJob{jobs[j].partial, jobs[j].dst, jobs[j].n_parts, jobs[j].n_cols, jobs[j].ld};
-  }
+  if (int rc = er::make_loss_tail_args(&job, &a)) return rc;
   hipLaunchKernelGGL(er::loss_tail_kernel, dim3(1), dim3(er::kCeBlock), 0, er::as_stream(stream), a);
   ER_LAUNCH_CHECK();
   return 0;
@@ -1923,9 +1837,9 @@ int er_l2_partials(const float* w, const float* coef, int64_t n, float* partials
 
 int er_dense_opt_step_l2(float* w, float* m, float* v, const float* grad, const float* l2coef, int64_t n, int opt_kind,
                          const er_opt_hyper* hyper, float* l2_partials, er_stream_t stream) {
-  ER_REQUIRE(w && grad && hyper && n > 0, "er_dense_opt_step: bad arguments");
-  if (opt_kind == ER_OPT_ADAM || opt_kind == ER_OPT_LAZY_ADAM) ER_REQUIRE(m && v, "er_dense_opt_step: Adam needs m, v");
-  if (opt_kind == ER_OPT_ADAGRAD) ER_REQUIRE(v, "er_dense_opt_step: Adagrad needs the accumulator in v");
+  er_dense_opt_job job{w, m, v, const_cast<float*>(grad), l2coef, n, opt_kind, hyper, l2_partials};
+  er::DenseOptArgs chk;
+  if (int rc = er::make_dense_opt_args(&job, &chk)) return rc;
   hipLaunchKernelGGL(er::dense_opt_kernel, dim3(er::blocks_for(n)), dim3(er::kBlock), 0, er::as_stream(stream), w, m, v,
                      grad, l2coef, n, opt_kind, hyper, l2_partials);
   ER_LAUNCH_CHECK();

@@ -24,6 +24,7 @@
 
 #include "er_common.h"
 #include "er_gemm_core.h"
+#include "er_dense_tail.h"
 #include "er_decay.h"
 #include "er_grad_finish.h"
 
@@ -1548,8 +1549,10 @@ emb_bwd_own_kernel(OwnMulti ma) {
 // random row records at 4 workgroups per CU.  Back to back they took 39 + 32 us of a 367 us DeepFM step; the round-4
 // attempt to overlap them as two graph branches lost to launch-slot contention - one launch has no
 // second launch to contend with.  Same bodies, same arithmetic: bit-identical to the two launches.
+// n_own: the row update's workgroups; a workgroup behind them (er_emb_bwd_fused_tail with a loss-tail job) runs the step's
+// scalar loss tail (er_dense_tail.h: the 1024 lanes of er_loss_tail on 256 threads, same sums, same order).
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(ER_OWN_WAVES)))
-emb_bwd_own_wgrad_kernel(OwnMulti ma, GroupedArgs ga, int n_gemm) {
+emb_bwd_own_wgrad_kernel(OwnMulti ma, GroupedArgs ga, int n_gemm, int n_own, LossTailArgs lt) {
   extern __shared__ __attribute__((aligned(16))) float smem[];  // >= the GEMM's two operand stages
   const int bid = blockIdx.x;
   if (bid < n_gemm) {
@@ -1558,7 +1561,8 @@ emb_bwd_own_wgrad_kernel(OwnMulti ma, GroupedArgs ga, int n_gemm) {
     gemm_f32_block<false, false>(ga.p[c.p], c.tile, c.split, smem, c.plain);
     return;
   }
-  own_block(bid - n_gemm, ma, smem);
+  if (bid - n_gemm < n_own) own_block(bid - n_gemm, ma, smem);
+  else loss_tail_body<kBlock>(lt, smem);
 }
 
 // The catch-up of a step's rows from the per-lookup lists of distinct keys the fused front's sort leaves (ukeys_seg:
@@ -1735,6 +1739,15 @@ emb_bwd_fix_reduce_kernel(RunMulti ma, GroupedReduceArgs ra, int n_fix) {
   const int b = blockIdx.x;
   if (b < n_fix) fix_block(b, ma);
   else splitk_reduce_grouped_block<4>(ra, b - n_fix);
+}
+
+// ... or next to the dense optimizer, which finishes the k-split weight gradients while it reads them (dense_opt_block)
+__global__ void __launch_bounds__(kBlock)
+emb_bwd_fix_opt_kernel(RunMulti ma, GroupedReduceArgs ra, DenseOptArgs da, int n_fix) {
+  __shared__ float red[4];
+  const int b = blockIdx.x;
+  if (b < n_fix) fix_block(b, ma);
+  else dense_opt_block(da, ra, b - n_fix, red);
 }
 
 // Segmented sort: when every lookup of a group owns its own table (disjoint, increasing key ranges - the normal
@@ -3804,7 +3817,7 @@ int er_debug_stamps(unsigned long long* p) { g_own_dbg = p; return 0; }
 
 static int emb_bwd_fused_impl(er_emb_group* const* groups, int n, const er_grad_group* finish, int n_finish, int opt_kind,
                               const er_opt_hyper* hyper, const er_gemm_problem* wgrads, int n_wgrads, int wgrad_blocks,
-                              er_stream_t stream) {
+                              const er_loss_tail_job* loss_tail, const er_dense_opt_job* dense_opt, er_stream_t stream) {
   ER_REQUIRE(groups && finish && hyper && n >= 1 && n <= er::kMaxMulti && n_finish >= 1 && n_finish <= er::kOwnMaxGG,
              "er_emb_bwd_fused: bad arguments (1 <= n <= %d groups, 1 <= n_finish <= %d)", er::kMaxMulti, er::kOwnMaxGG);
   ER_REQUIRE(opt_kind >= ER_OPT_SGD && opt_kind <= ER_OPT_ADAGRAD, "er_emb_bwd_fused: unknown optimizer %d", opt_kind);
@@ -3816,6 +3829,23 @@ static int emb_bwd_fused_impl(er_emb_group* const* groups, int n, const er_grad_
       ER_REQUIRE(!wgrads[i].a_mean && !wgrads[i].col_stats && !wgrads[i].bn_partial,
                  "er_emb_bwd_fused_wgrad: problem %d: plain contractions only (no A transform, statistics or BatchNorm epilogue)", i);
     if (int rc = er::plan_grouped(ER_GEMM_TN, wgrads, n_wgrads, false, &plan, wgrad_blocks)) return rc;
+  }
+  er::LossTailArgs lt;
+  std::memset(&lt, 0, sizeof(lt));
+  er::DenseOptArgs da;
+  std::memset(&da, 0, sizeof(da));
+  if (loss_tail || dense_opt) ER_REQUIRE(n_wgrads > 0, "er_emb_bwd_fused_tail: the riders need the weight gradients' launch (n_wgrads > 0)");
+  if (loss_tail)
+    if (int rc = er::make_loss_tail_args(loss_tail, &lt)) return rc;
+  if (dense_opt) {
+    if (int rc = er::make_dense_opt_args(dense_opt, &da)) return rc;
+    for (int j = 0; j < plan.ra.n; ++j) {  // the k-split outputs the optimizer finishes while it reads them
+      const er::ReduceItem& r = plan.ra.r[j];
+      ER_REQUIRE(r.ldc == r.N && r.C >= da.grad && r.C + r.mn <= da.grad + da.n,
+                 "er_emb_bwd_fused_tail: weight gradient %d is not a contiguous block of dense_opt->grad", j);
+    }
+    for (int i = 0; i < n_wgrads; ++i)  // (an unsplit problem writes C itself: it only has to be finished before the optimizer)
+      ER_REQUIRE(wgrads[i].C, "er_emb_bwd_fused_tail: problem %d has no output", i);
   }
   er::OwnMulti ma;
   er::RunMulti fx;
@@ -3937,10 +3967,16 @@ static int emb_bwd_fused_impl(er_emb_group* const* groups, int n, const er_grad_
   if (n_wgrads > 0) {
     const int n_gemm = er::grouped_grid(plan.ga);
     const size_t gemm_lds = sizeof(float) * 2 * 2 * er::kOpTile;
-    hipLaunchKernelGGL(er::emb_bwd_own_wgrad_kernel, dim3(n_gemm + grid), dim3(er::kBlock), lds > gemm_lds ? lds : gemm_lds, s,
-                       ma, plan.ga, n_gemm);
+    hipLaunchKernelGGL(er::emb_bwd_own_wgrad_kernel, dim3(n_gemm + grid + (loss_tail ? 1 : 0)), dim3(er::kBlock),
+                       lds > gemm_lds ? lds : gemm_lds, s, ma, plan.ga, n_gemm, grid, lt);
     ER_LAUNCH_CHECK();
     const int n_fix = grid > 0 ? fx.start[fx.n] : 0;
+    if (dense_opt) {
+      const int n_opt = static_cast<int>(er::ceil_div(da.n, er::kBlock));
+      hipLaunchKernelGGL(er::emb_bwd_fix_opt_kernel, dim3(n_fix + n_opt), dim3(er::kBlock), 0, s, fx, plan.ra, da, n_fix);
+      ER_LAUNCH_CHECK();
+      return 0;
+    }
     const int n_red = plan.ra.n > 0 ? plan.ra.start[plan.ra.n] : 0;
     if (n_fix + n_red > 0) {
       hipLaunchKernelGGL(er::emb_bwd_fix_reduce_kernel, dim3(n_fix + n_red), dim3(er::kBlock), 0, s, fx, plan.ra, n_fix);
@@ -3961,14 +3997,21 @@ static int emb_bwd_fused_impl(er_emb_group* const* groups, int n, const er_grad_
 
 int er_emb_bwd_fused(er_emb_group* const* groups, int n, const er_grad_group* finish, int n_finish, int opt_kind,
                      const er_opt_hyper* hyper, er_stream_t stream) {
-  return emb_bwd_fused_impl(groups, n, finish, n_finish, opt_kind, hyper, nullptr, 0, 0, stream);
+  return emb_bwd_fused_impl(groups, n, finish, n_finish, opt_kind, hyper, nullptr, 0, 0, nullptr, nullptr, stream);
 }
 
 int er_emb_bwd_fused_wgrad(er_emb_group* const* groups, int n, const er_grad_group* finish, int n_finish, int opt_kind,
                            const er_opt_hyper* hyper, const er_gemm_problem* wgrads, int n_wgrads, int32_t wgrad_blocks,
                            er_stream_t stream) {
   ER_REQUIRE(wgrads && n_wgrads >= 1 && wgrad_blocks >= 0, "er_emb_bwd_fused_wgrad: no weight-gradient problems (er_emb_bwd_fused)");
-  return emb_bwd_fused_impl(groups, n, finish, n_finish, opt_kind, hyper, wgrads, n_wgrads, wgrad_blocks, stream);
+  return emb_bwd_fused_impl(groups, n, finish, n_finish, opt_kind, hyper, wgrads, n_wgrads, wgrad_blocks, nullptr, nullptr, stream);
+}
+
+int er_emb_bwd_fused_tail(er_emb_group* const* groups, int n, const er_grad_group* finish, int n_finish, int opt_kind,
+                          const er_opt_hyper* hyper, const er_gemm_problem* wgrads, int n_wgrads, int32_t wgrad_blocks,
+                          const er_loss_tail_job* loss_tail, const er_dense_opt_job* dense_opt, er_stream_t stream) {
+  ER_REQUIRE(wgrads && n_wgrads >= 1 && wgrad_blocks >= 0, "er_emb_bwd_fused_tail: no weight-gradient problems (er_emb_bwd_fused)");
+  return emb_bwd_fused_impl(groups, n, finish, n_finish, opt_kind, hyper, wgrads, n_wgrads, wgrad_blocks, loss_tail, dense_opt, stream);
 }
 #undef ER_ELIGIBLE
 

@@ -283,6 +283,21 @@ class TailJob(ctypes.Structure):  # = er_tail_job
               ('ld', ctypes.c_int32)]
 
 
+class LossTailJob(ctypes.Structure):  # = er_loss_tail_job
+  _fields_ = [('emb_partials', ctypes.c_void_p), ('n_partials', ctypes.c_int32), ('emb_scale', ctypes.c_float),
+              ('dense_partials', ctypes.c_void_p), ('n_dense', ctypes.c_int32),
+              ('losses', ctypes.c_void_p), ('report', ctypes.c_void_p), ('loss_parts', ctypes.c_void_p),
+              ('loss_scales', ctypes.c_void_p), ('loss_divs', ctypes.c_void_p), ('loss_values', ctypes.c_void_p),
+              ('n_losses', ctypes.c_int32), ('jobs', ctypes.c_void_p), ('n_jobs', ctypes.c_int32),
+              ('reg_out', ctypes.c_void_p), ('total_out', ctypes.c_void_p)]
+
+
+class DenseOptJob(ctypes.Structure):  # = er_dense_opt_job
+  _fields_ = [('w', ctypes.c_void_p), ('m', ctypes.c_void_p), ('v', ctypes.c_void_p), ('grad', ctypes.c_void_p),
+              ('l2coef', ctypes.c_void_p), ('n', ctypes.c_int64), ('opt_kind', ctypes.c_int32), ('hyper', ctypes.c_void_p),
+              ('l2_partials', ctypes.c_void_p)]
+
+
 class GradTerm(ctypes.Structure):  # = er_grad_term
   _fields_ = [('kind', ctypes.c_int32), ('col0', ctypes.c_int32), ('width', ctypes.c_int32), ('dim', ctypes.c_int32),
               ('g', ctypes.c_void_p), ('g_ld', ctypes.c_int32), ('pad_', ctypes.c_int32), ('saved', ctypes.c_void_p)]
@@ -1374,22 +1389,45 @@ class HipBackend(object):
     self._ck(self.lib.er_decay_tables_error(tabs['handle'], ctypes.byref(flag)), 'er_decay_tables_error')
     return bool(flag.value)
 
-  def emb_bwd_fused(self, groups, finish, opt_kind, hyper, wgrads=None):
+  def emb_bwd_fused(self, groups, finish, opt_kind, hyper, wgrads=None, dense_opt=None):
     """finish: group_grad_finish's descriptors, one per feature-group gradient buffer the groups' lookups write.
     wgrads: the step's queued weight gradients (take_wgrads()'s fp32 list, wgrads_fit_the_tail) - contracted in the same
-    grid (er_emb_bwd_fused_wgrad)."""
+    grid (er_emb_bwd_fused_tail), a deferred loss tail (loss_tail(defer=True)) as one more workgroup of it; dense_opt:
+    dense_opt_step's arguments (w, m, v, grad, l2coef, opt_kind, hyper, l2_partials) - the dense optimizer behind the
+    cross-tile fix, finishing the k-split weight gradients while it reads them (dense_opt_fits_the_tail).  Returns True
+    when the optimizer ran here."""
     n = len(groups)
     gh = (ctypes.c_void_p * n)(*[g['handle'] for g in groups])
     arr, _keep = self._grad_groups(finish)
     if wgrads:
       pr = self._gemm_problems(GEMM_TN, wgrads, log_as='emb_bwd_own_wgrad_kernel')
       self.tail_launches = getattr(self, 'tail_launches', 0) + 1  # (tests: the fused tail is what ran)
-      self._ck(self.lib.er_emb_bwd_fused_wgrad(gh, n, arr, len(finish), ctypes.c_int(opt_kind), _p(hyper), pr, len(wgrads),
-                                               ctypes.c_int32(int(self.tail_wgrad_blocks)), _stream()),
-               'er_emb_bwd_fused_wgrad')
-      return
+      lt = getattr(self, '_deferred_loss_tail', None)
+      self._deferred_loss_tail = None
+      oj = None
+      if dense_opt is not None:
+        w, m, v, grad, l2coef, kind, hyp, l2p = dense_opt
+        oj = DenseOptJob(_ptr(w), _ptr(m), _ptr(v), _ptr(grad), _ptr(l2coef), w.numel(), int(kind), _ptr(hyp), _ptr(l2p))
+      self._ck(self.lib.er_emb_bwd_fused_tail(gh, n, arr, len(finish), ctypes.c_int(opt_kind), _p(hyper), pr, len(wgrads),
+                                              ctypes.c_int32(int(self.tail_wgrad_blocks)),
+                                              ctypes.byref(lt[0]) if lt is not None else None,
+                                              ctypes.byref(oj) if oj is not None else None, _stream()),
+               'er_emb_bwd_fused_tail')
+      return oj is not None
     self._ck(self.lib.er_emb_bwd_fused(gh, n, arr, len(finish), ctypes.c_int(opt_kind), _p(hyper), _stream()),
              'er_emb_bwd_fused')
+    return False
+
+  # the riders of the fused tail (er_emb_bwd_fused_tail); A/B switch
+  tail_riders = os.environ.get('EASYREC_AMD_TAIL_RIDERS', '1') != '0'
+
+  def dense_opt_fits_the_tail(self, wgrads, w, grad):
+    """every queued weight gradient is a contiguous block of the flat gradient buffer (the optimizer finishes the k-split
+    ones while it reads them), fp32 masters without bf16 shadows to refresh"""
+    if self._bf16_state_of(w) is not None:
+      return False
+    lo, hi = grad.data_ptr(), grad.data_ptr() + 4 * grad.numel()
+    return all(pr[2].is_contiguous() and lo <= pr[2].data_ptr() and pr[2].data_ptr() + 4 * pr[2].numel() <= hi for pr in wgrads)
 
   def _grad_groups(self, groups):
     arr = (GradGroup * len(groups))()
@@ -1904,9 +1942,11 @@ class HipBackend(object):
                                          _p(out['bn_partials']), _stream()), 'er_head_sigmoid_ce')
     return out
 
-  def loss_tail(self, emb_partials, emb_scale, dense_partials, losses, reports, reg_out, total_out, jobs=()):
+  def loss_tail(self, emb_partials, emb_scale, dense_partials, losses, reports, reg_out, total_out, jobs=(), defer=False):
     """reg_total_loss whose task losses may be PartialLoss records (per-workgroup partial sums left by head_sigmoid_ce)
-    and which also runs small column-sum jobs [(partial [P, ld], dst [n_cols], n_cols)]: dst[j] += sum_p partial[p, j]."""
+    and which also runs small column-sum jobs [(partial [P, ld], dst [n_cols], n_cols)]: dst[j] += sum_p partial[p, j].
+    defer: not launched now - the step's fused tail runs it as one workgroup of its first launch (emb_bwd_fused(tail=...));
+    whoever does not get that far calls flush_loss_tail() before anything reads the losses or the gradient buffer."""
     n = len(losses)
     assert n <= 8 and len(jobs) <= 4
     src = (ctypes.c_void_p * max(n, 1))()
@@ -1927,9 +1967,35 @@ class HipBackend(object):
       q.partial, q.dst, q.n_parts, q.n_cols, q.ld = partial.data_ptr(), d.data_ptr(), partial.shape[0], int(n_cols), partial.stride(0)
     n_part = 0 if emb_partials is None else emb_partials.numel()
     n_dense = 0 if dense_partials is None else dense_partials.numel()
+    if defer:
+      assert getattr(self, '_deferred_loss_tail', None) is None, 'the previous deferred loss tail was never run'
+      vp = ctypes.c_void_p
+      job = LossTailJob(_ptr(emb_partials), n_part, float(emb_scale), _ptr(dense_partials), n_dense,
+                        ctypes.cast(src, vp), ctypes.cast(dst, vp), ctypes.cast(parts, vp), ctypes.cast(scales, vp),
+                        ctypes.cast(divs, vp), ctypes.cast(values, vp), n, ctypes.cast(arr, vp), len(jobs),
+                        _ptr(reg_out), _ptr(total_out))
+      # (the record points into the ctypes arrays and the tensors: both stay alive with it)
+      self._deferred_loss_tail = (job, (src, dst, parts, scales, divs, values, arr, emb_partials, dense_partials, list(losses),
+                                        list(reports), reg_out, total_out, list(jobs)))
+      return
     self._ck(self.lib.er_loss_tail(_p(emb_partials), ctypes.c_int32(n_part), ctypes.c_float(emb_scale), _p(dense_partials),
                                    ctypes.c_int32(n_dense), src, dst, parts, scales, divs, values, ctypes.c_int32(n), arr,
                                    ctypes.c_int32(len(jobs)), _p(reg_out), _p(total_out), _stream()), 'er_loss_tail')
+
+  def flush_loss_tail(self):
+    """Run a deferred loss tail on its own (a step whose tail did not take it)."""
+    pending = getattr(self, '_deferred_loss_tail', None)
+    if pending is None:
+      return
+    self._deferred_loss_tail = None
+    j = pending[0]
+    I32, F32, VP = ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_void_p)
+    self._ck(self.lib.er_loss_tail(ctypes.c_void_p(j.emb_partials), ctypes.c_int32(j.n_partials), ctypes.c_float(j.emb_scale),
+                                   ctypes.c_void_p(j.dense_partials), ctypes.c_int32(j.n_dense), ctypes.cast(j.losses, VP),
+                                   ctypes.cast(j.report, VP), ctypes.cast(j.loss_parts, I32), ctypes.cast(j.loss_scales, F32),
+                                   ctypes.cast(j.loss_divs, F32), ctypes.cast(j.loss_values, VP), ctypes.c_int32(j.n_losses),
+                                   ctypes.cast(j.jobs, ctypes.POINTER(TailJob)), ctypes.c_int32(j.n_jobs),
+                                   ctypes.c_void_p(j.reg_out), ctypes.c_void_p(j.total_out), _stream()), 'er_loss_tail')
 
   def l2_partials(self, w, coef, partials):
     """partials[b] = sum over weights [256 b, 256 b + 256) of 0.5 * coef * w^2 (what dense_opt_step(l2_partials=) keeps

@@ -655,10 +655,11 @@ class EmbeddingEngine(object):
       descs.append((g['dout'], g['out'], lam, g['got_grad'], g['terms']))
     return descs
 
-  def backward_update(self, opt_kind, hyper, pending_wgrads=False):
+  def backward_update(self, opt_kind, hyper, pending_wgrads=False, dense_opt=None):
     """pending_wgrads: the dense layers' weight gradients of this backward pass are still queued (model.backward(flush=
-    False)): the fused step contracts them in the row update's grid (er_emb_bwd_fused_wgrad), every other path launches
-    them first."""
+    False)): the fused step contracts them in the row update's grid (er_emb_bwd_fused_tail), every other path launches
+    them first.  dense_opt: be.dense_opt_step's arguments - the fused tail may run the dense optimizer too; returns True
+    when it did."""
     be = kernels.hip()
     # this step's front already ran fused (forward, lazy dense decay), or - optimizers without it - runs now
     if getattr(self, '_front_done', False) or (not self.lazy_decay and self._use_fused() and self._fused_front()):
@@ -676,15 +677,22 @@ class EmbeddingEngine(object):
           wgrads = q
         elif q:
           be.gemm_grouped(kernels.GEMM_TN, q)
-      be.emb_bwd_fused(list(self.emb_groups.values()), self._finish_descs(), opt_kind, hyper, wgrads=wgrads)
+      if wgrads is None:
+        be.flush_loss_tail()  # (a deferred loss tail rides with the weight gradients' grid only)
+      if dense_opt is not None and not (wgrads is not None and getattr(be, 'tail_riders', False) and
+                                        be.dense_opt_fits_the_tail(wgrads, dense_opt[0], dense_opt[3])):
+        dense_opt = None
+      ran_opt = be.emb_bwd_fused(list(self.emb_groups.values()), self._finish_descs(), opt_kind, hyper, wgrads=wgrads,
+                                 dense_opt=dense_opt)
       for g in self.groups.values():
         g['terms'] = []
         g['got_grad'] = True
       self._roll_flush(hyper)
       self._decay_pending = True
-      return
+      return bool(ran_opt)
     if pending_wgrads:
       be.flush_wgrads()
+    be.flush_loss_tail()
     self.finish_group_grads()
     if opt_kind == kernels.OPT_ADAM and self._sweep_pending:
       # the sweep of the untouched rows is already in flight on the side stream; the touched rows
@@ -697,6 +705,7 @@ class EmbeddingEngine(object):
     self.join_decay_sweep()
     self._roll_flush(hyper)
     self._decay_pending = True
+    return False
 
   def _roll_flush(self, hyper):
     """After the step's row updates: this step's window of every lazily decaying table group (one launch per 4) - or,

@@ -257,7 +257,12 @@ class EasyRecEstimator(object):
       self.model.begin_step()
       self.model.build_predict_graph()
       loss_dict = self.model.build_loss_graph()
-      self._loss_tail(loss_dict)
+      # the step's tail (single GPU, no clipping): the weight gradients stay queued and are contracted in the grid of the
+      # embedding row update, the scalar loss tail rides in that grid and the dense optimizer in the next one
+      # (er_emb_bwd_fused_tail) - nothing between here and the end of the step reads what they write
+      tail = self.is_training and self.clip_norm <= 0 and bool(getattr(be, 'fused_tail', False)) and self._tail_fusable()
+      riders = tail and bool(getattr(be, 'tail_riders', False))
+      self._loss_tail(loss_dict, defer=riders)
       if self.is_training:
         vs = self.varstore
         if self.clip_norm > 0:
@@ -265,18 +270,20 @@ class EasyRecEstimator(object):
           self._sync_dense_grads()
           self._clipped_update()
         else:
-          # the step's tail: on one GPU the weight gradients stay queued and are contracted in the grid of the
-          # embedding row update (er_emb_bwd_fused_wgrad) - nothing between here and the dense optimizer reads them
-          tail = bool(getattr(be, 'fused_tail', False)) and self._tail_fusable()
           self.model.backward(flush=not tail)
           self._sync_dense_grads()
+          opt = (vs.flat, vs.slots.get('m'), vs.slots.get('v'), vs.flat_grad, vs.l2coef if vs.any_l2 else None,
+                 self.opt_dense.kind, self.hyper[1], vs.l2_partials)
+          done = False
           if tail:
-            self.engine.backward_update(self.opt_emb.kind, self.hyper[0], pending_wgrads=True)
+            done = self.engine.backward_update(self.opt_emb.kind, self.hyper[0], pending_wgrads=True,
+                                               dense_opt=opt if riders else None)
           else:
             self.engine.backward_update(self.opt_emb.kind, self.hyper[0])
-          be.dense_opt_step(vs.flat, vs.slots.get('m'), vs.slots.get('v'), vs.flat_grad,
-                            vs.l2coef if vs.any_l2 else None, self.opt_dense.kind, self.hyper[1],
-                            l2_partials=vs.l2_partials)
+          if riders:
+            be.flush_loss_tail()  # (a tail that did not take it)
+          if not done:
+            be.dense_opt_step(*opt[:7], l2_partials=opt[7])
 
   def _tail_fusable(self):
     """The queued weight gradients may wait for the embedding backward: one process (no dense all-reduce reads them
@@ -301,7 +308,7 @@ class EasyRecEstimator(object):
     be.dense_opt_step(vs.flat, vs.slots.get('m'), vs.slots.get('v'), vs.flat_grad, l2, self.opt_dense.kind, self.hyper[1],
                       l2_partials=vs.l2_partials)
 
-  def _loss_tail(self, loss_dict):
+  def _loss_tail(self, loss_dict, defer=False):
     """regularization_loss = embedding-output L2 + kernel L2, total_loss = that + the task losses (estimator :166-184);
     one launch."""
     be, eng, vs = kernels.hip(), self.engine, self.varstore
@@ -317,7 +324,8 @@ class EasyRecEstimator(object):
     if jobs or any(getattr(v, '_er_partials', None) is not None for v in values):
       # a fused head (builders/loss_builder.py): its loss arrives as per-workgroup partial sums, its dW / db as column-sum jobs
       be.loss_tail(partials, 0.5 * eng.reg_lambda, vs.l2_partials if vs.any_l2 else None, values,
-                   [self.losses[n] for n in names], self.losses['regularization_loss'], self.losses['total_loss'], jobs=jobs)
+                   [self.losses[n] for n in names], self.losses['regularization_loss'], self.losses['total_loss'], jobs=jobs,
+                   defer=defer)
       return
     be.reg_total_loss(partials, 0.5 * eng.reg_lambda, vs.l2_partials if vs.any_l2 else None,
                       [v.reshape(1) for v in values], [self.losses[n] for n in names],

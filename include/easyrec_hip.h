@@ -693,6 +693,20 @@ int er_loss_tail(const float* emb_partials, int32_t n_partials, float emb_scale,
 int er_l2_partials(const float* w, const float* coef, int64_t n, float* partials, er_stream_t stream);
 int er_dense_opt_step_l2(float* w, float* m, float* v, const float* grad, const float* l2coef, int64_t n,
                          int opt_kind, const er_opt_hyper* hyper, float* l2_partials, er_stream_t stream);
+/* er_loss_tail's and er_dense_opt_step_l2's arguments as records (HOST structs, the arrays inside HOST arrays as there):
+ * what er_emb_bwd_fused_tail (below) takes to run the two inside the step's tail launches. */
+typedef struct er_loss_tail_job {
+  const float* emb_partials; int32_t n_partials; float emb_scale;
+  const float* dense_partials; int32_t n_dense;
+  const float* const* losses; float* const* report; const int32_t* loss_parts; const float* loss_scales;
+  const float* loss_divs; float* const* loss_values; int32_t n_losses;
+  const er_tail_job* jobs; int32_t n_jobs;
+  float* reg_out; float* total_out;
+} er_loss_tail_job;
+typedef struct er_dense_opt_job {
+  float* w; float* m; float* v; float* grad; const float* l2coef; int64_t n; int32_t opt_kind; const er_opt_hyper* hyper;
+  float* l2_partials;
+} er_dense_opt_job;
 /* er_hyper_select that also zeroes zero_floats floats at `zero` (the dense variables' flat gradient buffer): the
  * step's prologue as one launch. */
 int er_step_prologue(const float* table, int64_t* counter, int32_t n_slots, int32_t floats_per_slot, float* out,
@@ -842,6 +856,20 @@ int er_gemm_grouped_coords(const int32_t* tiles, const int32_t* start, const int
 int er_emb_bwd_fused_wgrad(er_emb_group* const* groups, int n, const er_grad_group* finish_host, int n_finish, int opt_kind,
                            const er_opt_hyper* hyper, const er_gemm_problem* wgrads_host, int n_wgrads,
                            int32_t wgrad_blocks, er_stream_t stream);
+/* ... and with the rest of the step's tail riding in the same two launches (either job may be NULL):
+ *   loss_tail: er_loss_tail (the add_n over the loss dict + REGULARIZATION_LOSSES, model/easy_rec_estimator.py:166-184,
+ *     and the head's dW / db column sums) as ONE more workgroup of the first launch - it reads what the forward pass left
+ *     and is read by nothing before the optimizer, so it needs no launch between them;
+ *   dense_opt: er_dense_opt_step_l2 over the flat dense variables (builders/optimizer_builder.py:33-97 applied to the dense
+ *     half of the two-optimizer split, model/easy_rec_estimator.py:120-160) as the workgroups behind the cross-tile fix of
+ *     the second launch, with the split-K reduce folded into its gradient read: an element of a k-split weight gradient
+ *     (every wgrads[i].C must lie inside dense_opt->grad with ldc == N) is summed from the workspace - er_gemm's reduce
+ *     order, split by split - stored to grad[] and applied at once.
+ * Bit-identical to er_loss_tail, er_gemm_grouped_f32 (at the same wgrad_blocks), er_emb_bwd_fused and
+ * er_dense_opt_step_l2 one after the other: six launches become two. */
+int er_emb_bwd_fused_tail(er_emb_group* const* groups, int n, const er_grad_group* finish_host, int n_finish, int opt_kind,
+                          const er_opt_hyper* hyper, const er_gemm_problem* wgrads_host, int n_wgrads, int32_t wgrad_blocks,
+                          const er_loss_tail_job* loss_tail, const er_dense_opt_job* dense_opt, er_stream_t stream);
 /* DEFERRED BatchNorm + activation (reference layers/dnn.py:57-79: dense -> batch_normalization -> relu per layer).
  * The reference materialises every intermediate; here a hidden layer of a stack writes only its pre-normalisation
  * values z (bias included) and its batch statistics, and every reader of its activation output y = act(BN(z)) -

@@ -520,6 +520,14 @@ class RefBackend(object):
   def take_wgrads(self):
     return [], []
 
+  tail_riders = True
+
+  def flush_loss_tail(self):
+    pass  # (loss_tail(defer=True) runs at once here)
+
+  def dense_opt_fits_the_tail(self, wgrads, w, grad):
+    return False
+
   @staticmethod
   def wgrads_fit_the_tail(q):
     return False
@@ -589,8 +597,8 @@ class RefBackend(object):
       self.emb_catch_up_multi([x[0] for x in lazy], [x[1] for x in lazy], [x[2] for x in lazy], hyper)
     return True
 
-  def emb_bwd_fused(self, groups, finish, opt_kind, hyper, wgrads=None):
-    assert not wgrads
+  def emb_bwd_fused(self, groups, finish, opt_kind, hyper, wgrads=None, dense_opt=None):
+    assert not wgrads and dense_opt is None
     self.group_grad_finish(finish)
     self.emb_bwd_update_multi(groups, opt_kind, hyper)
 
@@ -1254,7 +1262,7 @@ class RefBackend(object):
       out['bn_partials'] = torch.stack([tiles(g), tiles(gx)], dim=2).contiguous()
     return out
 
-  def loss_tail(self, emb_partials, emb_scale, dense_partials, losses, reports, reg_out, total_out, jobs=()):
+  def loss_tail(self, emb_partials, emb_scale, dense_partials, losses, reports, reg_out, total_out, jobs=(), defer=False):
     for partial, dst, n_cols in jobs:
       dst.add_(partial[:, :n_cols].sum(dim=0))
     scalars = []

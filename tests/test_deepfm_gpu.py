@@ -510,9 +510,9 @@ def test_fused_embedding_step_matches_the_general_path(optimizer, buckets, B):
       assert abs(a[k] - b[k]) <= (1e-6 if step == 0 else 2e-4) * max(1.0, abs(a[k])), (step, k, a[k], b[k])
 
 
-def _run_variant(cfg, batches, B, defer, prologue, graph=False, tail=False):
+def _run_variant(cfg, batches, B, defer, prologue, graph=False, tail=False, riders=False):
   be = kernels.hip()
-  be.defer_catch_up, be.prologue_tables, be.fused_tail = defer, prologue, tail
+  be.defer_catch_up, be.prologue_tables, be.fused_tail, be.tail_riders = defer, prologue, tail, riders
   be.tail_wgrad_blocks = 0  # (the stand-alone launch's k-splits: the tail's default splits sum the batch in another order)
   be.tail_launches = 0
   try:
@@ -529,7 +529,7 @@ def _run_variant(cfg, batches, B, defer, prologue, graph=False, tail=False):
     assert be.tail_launches == ((3 if graph else len(batches)) if tail else 0)  # (two eager steps + the capture, then replays)
     return losses, est.state_dict(slots=True)
   finally:
-    del be.defer_catch_up, be.prologue_tables, be.fused_tail, be.tail_wgrad_blocks
+    del be.defer_catch_up, be.prologue_tables, be.fused_tail, be.tail_wgrad_blocks, be.tail_riders
 
 
 @pytest.mark.parametrize('buckets,B', [(1000, 256), (50, 2048)])
@@ -539,7 +539,9 @@ def test_fused_step_variants_change_no_bit(buckets, B):
   (er_emb_fwd_lazy, update_row_lazy) instead of by a catch-up launch that stores the rows; (2) the lag-1 replay table
   built by the prologue and sort + lookup in one launch (er_emb_front_fwd), eager and as a replayed hipGraph; (3) the
   step's tail - the dense layers' weight gradients in the grid of the embedding row update, the split-K reduce in the
-  grid of the cross-tile fix (er_emb_bwd_fused_wgrad) - instead of four launches.  Eight steps over ids that recur after
+  grid of the cross-tile fix (er_emb_bwd_fused_wgrad) - instead of four launches; (4) the tail's riders - the scalar loss
+  tail as one more workgroup of that grid, the dense optimizer behind the fix with the split-K reduce folded into its
+  gradient read (er_emb_bwd_fused_tail): six launches as two.  Eight steps over ids that recur after
   idle gaps (so rows ARE caught up): every loss, table, slot and dense variable bit-identical to the round-4
   arrangement."""
   cfg = _cfg('deepfm_criteo_small.config')
@@ -554,7 +556,10 @@ def test_fused_step_variants_change_no_bit(buckets, B):
               'one launch, graph': dict(defer=True, prologue=True, graph=True),
               'tail in one grid': dict(defer=True, prologue=True, tail=True),
               'tail in one grid, round-4 front': dict(defer=False, prologue=False, tail=True),
-              'tail in one grid, graph': dict(defer=True, prologue=True, graph=True, tail=True)}
+              'tail in one grid, graph': dict(defer=True, prologue=True, graph=True, tail=True),
+              'tail with its riders': dict(defer=True, prologue=True, tail=True, riders=True),
+              'tail with its riders, round-4 front': dict(defer=False, prologue=False, tail=True, riders=True),
+              'tail with its riders, graph': dict(defer=True, prologue=True, graph=True, tail=True, riders=True)}
   for name, kw in variants.items():
     l, s = _run_variant(cfg, batches, B, **kw)
     assert l == base_l, (name, [i for i, (a, b) in enumerate(zip(l, base_l)) if a != b])
