@@ -296,7 +296,10 @@ int gemm_entry(int layout, int M, int N, int K, const float* A, int lda, const f
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
   a.accumulate = accumulate;
   a.col_stats = col_stats;
-  if (bn) a.bn = *bn;
+  if (bn) {
+    a.bn = *bn;
+    if (a.bn.n_src == 0) { a.bn.col0 = 0; a.bn.n_src = N; }
+  }
   if (at) a.at = *at;
   if (fu) a.fu = *fu;
   a.splits = (col_stats || bn) ? 1 : choose_splits(M, N, K, ktile);
@@ -384,6 +387,7 @@ int er::plan_grouped(int layout, const er_gemm_problem* pr, int n, bool bf16, er
       a.bn.z = q.bn_z; a.bn.zbias = q.bn_zbias; a.bn.y = q.bn_y; a.bn.mean = q.bn_mean; a.bn.invstd = q.bn_invstd;
       a.bn.gamma = q.bn_gamma; a.bn.beta = q.bn_beta; a.bn.ld = q.bn_ld; a.bn.use_bn = q.bn_use_bn; a.bn.act = q.bn_act;
       a.bn.partial = q.bn_partial;
+      a.bn.col0 = 0; a.bn.n_src = q.N;
       any_bn = true;
     }
     if (q.a_mean) {
@@ -565,6 +569,7 @@ int er_gemm_f32_bn_bwd_apply(int layout, int32_t M, int32_t N, int32_t K, const 
   a.k_per_split = static_cast<int>(er::ceil_div(K, er::BK32)) * er::BK32;
   a.bn.z = z; a.bn.zbias = z_bias; a.bn.y = y; a.bn.mean = save_mean; a.bn.invstd = save_invstd;
   a.bn.ld = ld_zy; a.bn.use_bn = use_bn; a.bn.act = act; a.bn.partial = partial;
+  a.bn.col0 = 0; a.bn.n_src = N;
   a.fu.mode = 2;
   a.fu.gamma = gamma; a.fu.dgamma = dgamma; a.fu.dbeta = dbeta; a.fu.dbias = dbias; a.fu.accumulate = accumulate;
   a.fu.counters = g_bn_counters;
@@ -638,6 +643,20 @@ int er_gemm_f32_bn_bwd(int layout, int32_t M, int32_t N, int32_t K, const float*
   e.z = z; e.zbias = z_bias; e.y = y; e.mean = save_mean; e.invstd = save_invstd;
   e.ld = ld_zy; e.use_bn = use_bn; e.act = act; e.partial = partial;
   return gemm_entry<false>(layout, M, N, K, A, lda, B, ldb, C, ldc, nullptr, 0, nullptr, stream, "er_gemm_f32_bn_bwd", &e);
+}
+
+int er_gemm_f32_bn_bwd_cols(int layout, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B,
+                            int32_t ldb, float* C, int32_t ldc, const float* z, const float* z_bias, const float* y,
+                            const float* save_mean, const float* save_invstd, int32_t ld_zy, int use_bn, int act,
+                            float* partial, int32_t col0, int32_t n_src, er_stream_t stream) {
+  ER_REQUIRE(z && y && partial && col0 >= 0 && n_src >= 1 && col0 + n_src <= N && ld_zy >= n_src,
+             "er_gemm_f32_bn_bwd_cols: bad epilogue arguments (source columns [%d, %d) of %d outputs)", col0, col0 + n_src, N);
+  ER_REQUIRE(!use_bn || (save_mean && save_invstd), "er_gemm_f32_bn_bwd_cols: BatchNorm statistics missing");
+  er::BnBwdEpi e;
+  e.z = z; e.zbias = z_bias; e.y = y; e.mean = save_mean; e.invstd = save_invstd;
+  e.ld = ld_zy; e.use_bn = use_bn; e.act = act; e.partial = partial;
+  e.col0 = col0; e.n_src = n_src;
+  return gemm_entry<false>(layout, M, N, K, A, lda, B, ldb, C, ldc, nullptr, 0, nullptr, stream, "er_gemm_f32_bn_bwd_cols", &e);
 }
 
 int er_gemm_grouped_f32(int layout, const er_gemm_problem* problems, int n, er_stream_t stream) {

@@ -25,7 +25,11 @@ struct BnBwdEpi {
   const float* mean = nullptr;
   const float* invstd = nullptr;
   int ld = 0, use_bn = 0, act = 0;
-  float* partial = nullptr;       // [row tiles][N][2]
+  float* partial = nullptr;       // [row tiles][n_src][2]
+  // The producing layer's output may be a COLUMN BLOCK of this GEMM's output position: output column c belongs to source
+  // column c - col0 when 0 <= c - col0 < n_src (DeepFM: the deep tower's 64 columns inside d[sum(wide) | FM | deep],
+  // model/deepfm.py:75-83); z / y / mean / invstd / gamma / beta / zbias / partial are the SOURCE layer's, n_src wide.
+  int col0 = 0, n_src = 0;        // n_src == 0: the whole output (n_src = N, set by the host)
   // y == nullptr (the producing layer's activation output was never materialised: ATransform below): the ReLU mask is
   // recomputed from z with the producing layer's affine parameters
   const float* gamma = nullptr;
@@ -226,7 +230,8 @@ __device__ __forceinline__ void tile_bn_bwd_partial(const f32x16& acc, const BnB
                                                     int wn, int lane, float* lds, int ty, bool coherent = false) {
   const int khalf = lane >> 5;
   float sg = 0.f, sgx = 0.f;
-  if (col < N) {
+  const bool col_ok = col >= 0 && col < N;  // (col, N: the SOURCE column and width - BnBwdEpi.col0)
+  if (col_ok) {
     const float bv = e.zbias ? e.zbias[col] : 0.f;
     const float mu = e.use_bn ? e.mean[col] : 0.f;
     const float is = e.use_bn ? e.invstd[col] : 0.f;
@@ -252,7 +257,7 @@ __device__ __forceinline__ void tile_bn_bwd_partial(const f32x16& acc, const BnB
   float* slot = lds + (wn * 32 + (lane & 31)) * 2;
   if (wm == 1 && khalf == 0) { slot[0] = a; slot[1] = ax; }
   __syncthreads();
-  if (wm == 0 && khalf == 0 && col < N) {
+  if (wm == 0 && khalf == 0 && col_ok) {
     float* p = e.partial + (static_cast<int64_t>(ty) * N + col) * 2;
     if (coherent) { st_agent(p, a + slot[0]); st_agent(p + 1, ax + slot[1]); }
     else { p[0] = a + slot[0]; p[1] = ax + slot[1]; }
@@ -522,8 +527,8 @@ __device__ __forceinline__ void gemm_f32_block(const GemmArgs& g, int bx, int bz
   const int T = (kend - kbeg + BK32 - 1) / BK32;
   float py[16], pz[16];
   if (BN_EPI && g.bn.partial != nullptr) {  // (a grouped launch may mix problems with and without the epilogue)
-    int c = n0 + wn * 32 + (lane & 31);
-    c = c < g.N ? c : g.N - 1;
+    int c = n0 + wn * 32 + (lane & 31) - g.bn.col0;  // (source column, clamped: a lane outside the block loads what it ignores)
+    c = c < 0 ? 0 : (c < g.bn.n_src ? c : g.bn.n_src - 1);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -676,7 +681,8 @@ __device__ __forceinline__ void gemm_f32_block(const GemmArgs& g, int bx, int bz
     }
   }
   if (BN_EPI && g.bn.partial != nullptr)
-    tile_bn_bwd_partial(acc, g.bn, py, pz, m0 + wm * 32, g.M, col, g.N, wm, wn, lane, lds, ty, g.fu.mode == 2);
+    tile_bn_bwd_partial(acc, g.bn, py, pz, m0 + wm * 32, g.M, col < g.N ? col - g.bn.col0 : -1, g.bn.n_src, wm, wn, lane, lds, ty,
+                        g.fu.mode == 2);
   if (g.fu.mode == 1 || g.fu.mode == 2) {  // (uniform over the grid; host guarantees splits == 1 and a co-resident grid)
     const int gy = static_cast<int>(ceil_div(g.M, BM));
     tile_column_barrier(g.fu.counters + 2 * tx, static_cast<unsigned>(gy));

@@ -124,6 +124,35 @@ class BnSource(object):
     return self.y is None
 
 
+class BnColsView(object):
+  """`src`'s layer output as the column block [col0, col0 + width) of a wider tensor (DeepFM's [sum(wide) | FM | deep]):
+  the consumer's dgrad GEMM emits that layer's BatchNorm-backward column sums from those columns of its output
+  (HipBackend.gemm_bn_bwd(col0=...))."""
+  __slots__ = ('src', 'col0', 'ref')
+  deferred, fused, exclusive = False, True, False  # (what LinearBNActFn.forward asks of a BnSource)
+
+  def __init__(self, src, col0, ref):
+    self.src, self.col0, self.ref = src, int(col0), ref
+
+
+def tag_bn_cols(joined, part, col0):
+  """`joined[:, col0:col0 + part.shape[1]]` is a copy of `part`, the output of a fused dense + BatchNorm layer."""
+  src = bn_source_of(part)
+  if src is not None and src.y is not None and src.fused and not src.exclusive:
+    joined._er_bn_cols = BnColsView(src, col0, joined)
+  return joined
+
+
+def bn_cols_of(x):
+  """The BnColsView of x if x IS the untouched tensor tag_bn_cols marked (dense + BatchNorm layers take it as `src`)."""
+  if not getattr(hip(), 'bn_cols_epilogue', False):
+    return None
+  v = getattr(x, '_er_bn_cols', None)
+  if v is None or x.dim() != 2 or x.data_ptr() != v.ref.data_ptr() or x.shape != v.ref.shape or x.stride() != v.ref.stride():
+    return None
+  return v
+
+
 def mark_single_consumer(y):
   """Promise that the NEXT dense layer is the only reader of y (the output of a fused dense + BatchNorm layer): its
   dgrad GEMM may then finish this layer's BatchNorm backward in its epilogue and hand dz, not dy, to autograd."""
@@ -855,9 +884,14 @@ class HipBackend(object):
         int(bool(accumulate)), _stream()), 'er_gemm_f32_bn_bwd_apply')
     return out
 
-  def gemm_bn_bwd(self, layout, a, b, src, partial):
+  # the BatchNorm-backward column sums of a layer whose output is a column block of the consumer's input (DeepFM's deep
+  # tower inside [sum(wide) | FM | deep]) from the consumer's dgrad epilogue (er_gemm_f32_bn_bwd_cols); A/B switch
+  bn_cols_epilogue = os.environ.get('EASYREC_AMD_BN_COLS_EPILOGUE', '1') != '0'
+
+  def gemm_bn_bwd(self, layout, a, b, src, partial, col0=None):
     """dgrad GEMM whose epilogue also emits the BatchNorm-backward column sums of the layer described by `src`
-    (a BnSource: the producer of this GEMM's input) into partial [row tiles][N][2]."""
+    (a BnSource: the producer of this GEMM's input) into partial [row tiles][N][2].  col0: that layer produced the
+    columns [col0, col0 + its width) of this GEMM's input only."""
     assert a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1
     if layout == GEMM_NN:
       (M, K), (K2, N) = a.shape, b.shape
@@ -865,6 +899,19 @@ class HipBackend(object):
       (M, K), (N, K2) = a.shape, b.shape
     else:
       (K, M), (K2, N) = a.shape, b.shape
+    if col0 is not None:
+      n_src = src.y.shape[1]
+      assert K == K2 and src.z.shape == (M, n_src) and src.y.stride() == src.z.stride() and 0 <= col0 and col0 + n_src <= N
+      assert partial.numel() >= self.gemm_row_tiles(M) * n_src * 2
+      self._log_gemm('gemm_f32_bn_bwd_kernel', layout, M, N, K)
+      out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+      self._ck(self.lib.er_gemm_f32_bn_bwd_cols(ctypes.c_int(layout), M, N, K, _p(a), ctypes.c_int32(a.stride(0)), _p(b),
+                                                ctypes.c_int32(b.stride(0)), _p(out), ctypes.c_int32(out.stride(0)),
+                                                _p(src.z), _p(src.zbias), _p(src.y), _p(src.mean), _p(src.invstd),
+                                                ctypes.c_int32(src.y.stride(0)), int(src.mean is not None), int(src.act),
+                                                _p(partial), ctypes.c_int32(int(col0)), ctypes.c_int32(n_src), _stream()),
+               'er_gemm_f32_bn_bwd_cols')
+      return out
     assert K == K2 and src.z.shape == (M, N) and (src.y is None or (src.y.shape == (M, N) and src.y.stride() == src.z.stride()))
     assert partial.numel() >= self.gemm_row_tiles(M) * N * 2
     self._log_gemm('gemm_f32_bn_bwd_kernel', layout, M, N, K)
@@ -1420,6 +1467,8 @@ class HipBackend(object):
 
   # the riders of the fused tail (er_emb_bwd_fused_tail); A/B switch
   tail_riders = os.environ.get('EASYREC_AMD_TAIL_RIDERS', '1') != '0'
+  # the embedding backward's table groups narrowest first (layers/input_layer.py backward_update); A/B switch
+  own_long_first = os.environ.get('EASYREC_AMD_OWN_LONG_FIRST', '0') != '0'
 
   def dense_opt_fits_the_tail(self, wgrads, w, grad):
     """every queued weight gradient is a contiguous block of the flat gradient buffer (the optimizer finishes the k-split
@@ -2357,6 +2406,15 @@ def _dgrad(be, dz, w, src, bf16, sink=None, x=None, slots=None):
       return be.gemm(GEMM_NT, dz, w, out=slot[0], bf16=bf16)
     return be.gemm(GEMM_NT, dz, w, bf16=bf16)
   M, N = dz.shape[0], w.shape[0]
+  if isinstance(src, BnColsView):
+    inner = src.src
+    if bf16 or be._mask_from_z(inner.mean is not None, inner.act, inner.gamma, inner.beta):
+      return be.gemm(GEMM_NT, dz, w, bf16=bf16)
+    n_src = inner.y.shape[1]
+    partial = torch.empty(be.gemm_row_tiles(M) * n_src * 2, dtype=torch.float32, device=dz.device)
+    dx = be.gemm_bn_bwd(GEMM_NT, dz, w, inner, partial, col0=src.col0)
+    inner.partial, inner.dx_ptr = partial, dx.data_ptr() + 4 * src.col0  # (what the block's view of dx starts at)
+    return dx
   if src.exclusive and src.y is not None and src.grad_bufs is not None and getattr(be, 'gemm_fused_bn_ok', None) and \
       be.gemm_fused_bn_ok(M, N):
     # this GEMM is the only reader of the producing layer's output: finish that layer's BatchNorm backward here

@@ -80,7 +80,8 @@ def dense_bn_act(x, units, name, l2_reg, use_bias, use_bn, act_relu, training, b
     bf16 = getattr(ctx, 'dense_dtype', 'f32') == 'bf16'
     y = kernels.LinearBNActFn.apply(x if x.dim() == 2 else x.reshape(-1, in_dim), w, b, gamma, beta,
                                     None if freeze else mm, None if freeze else mv, BN_EPSILON, BN_MOMENTUM, act, bf16,
-                                    bufs, kernels.bn_source_of(x), kernels.grad_sink_of(x), bool(defer) and x.dim() == 2)
+                                    bufs, kernels.bn_source_of(x) or kernels.bn_cols_of(x), kernels.grad_sink_of(x),
+                                    bool(defer) and x.dim() == 2)
     src = kernels.take_last_bn_source()
     y = y.reshape(shape[:-1] + (units,))
     return kernels.tag_bn_source(y, src) if src is not None else y

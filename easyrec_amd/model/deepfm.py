@@ -49,6 +49,7 @@ class DeepFM(RankModel):
       deep = self._dnn(self._deep_features, own.dnn, 'deep_feature')
       x, F, D, fm_sink, col0 = blk
       joined = kernels.WideFmConcatFn.apply(self._wide_features, x, deep, F, D, wide_sink, fm_sink, col0)
+      kernels.tag_bn_cols(joined, deep, 1 + D)  # (the deep tower's last BatchNorm backward: sums from final_dnn's dgrad)
       self._fm_outputs = joined[:, 1:1 + D]
       top = self._dnn(joined, own.final_dnn, 'final_dnn')
       kernels.mark_single_consumer(top)  # read by the `output` projection alone

@@ -773,6 +773,15 @@ int er_gemm_f32_bn_bwd(int layout, int32_t M, int32_t N, int32_t K, const float*
                        int32_t ldb, float* C, int32_t ldc, const float* z, const float* z_bias, const float* y,
                        const float* save_mean, const float* save_invstd, int32_t ld_zy, int use_bn, int act,
                        float* partial, er_stream_t stream);
+/* ... when the layer below produced only a COLUMN BLOCK of what C is the gradient of: output columns [col0, col0 + n_src)
+ * of C are the gradient of that layer's n_src activations (z, y, statistics: its own, n_src wide; partial [tiles][n_src]
+ * [2]), the other columns carry no epilogue.  DeepFM's final DNN reads [reduce_sum(wide) | FM | deep] (reference
+ * model/deepfm.py:75-83): the input gradient of its first layer holds the deep tower's 64 columns at col0 = 1 + D, and
+ * the tower's last BatchNorm backward needs no column-sum pass of its own (one launch less per step). */
+int er_gemm_f32_bn_bwd_cols(int layout, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B,
+                            int32_t ldb, float* C, int32_t ldc, const float* z, const float* z_bias, const float* y,
+                            const float* save_mean, const float* save_invstd, int32_t ld_zy, int use_bn, int act,
+                            float* partial, int32_t col0, int32_t n_src, er_stream_t stream);
 /* dense + BatchNorm(train) + activation of one DNN layer in ONE launch (reference layers/dnn.py:57-79: MatMul, BiasAdd,
  * FusedBatchNorm / moments, Relu): the GEMM's workgroups publish per-row-tile column statistics (col_stats scratch,
  * er_gemm_row_tiles(M) * N * 3 floats), meet at a barrier per column of tiles, finalise the statistics (same order

@@ -1384,6 +1384,43 @@ def test_dgrad_gemm_emits_batchnorm_backward_sums(hip, B, N, K, act):
     assert float((a - b).abs().max()) <= 2e-5 * scale, (what, float((a - b).abs().max()), scale)
 
 
+@pytest.mark.parametrize('B,N,K,col0,n_src', [(4096, 81, 256, 17, 64), (300, 150, 33, 70, 80), (130, 64, 64, 0, 64),
+                                              (1000, 81, 256, 80, 1), (64, 200, 16, 3, 130)])
+@pytest.mark.parametrize('act', [kernels.ACT_RELU, kernels.ACT_NONE])
+def test_dgrad_gemm_emits_the_sums_of_a_column_block(hip, B, N, K, col0, n_src, act):
+  """er_gemm_f32_bn_bwd_cols: the layer below produced columns [col0, col0 + n_src) of the GEMM's output position only
+  (DeepFM: the deep tower inside [sum(wide) | FM | deep]).  The output is the plain GEMM's, bit for bit; the partials are,
+  bit for bit, those of er_gemm_f32_bn_bwd over that block alone (the same accumulators, rows and order)."""
+  g = torch.Generator().manual_seed(B + N + K + col0 + act)
+  z = torch.randn(B, n_src, generator=g).to(DEV)
+  gamma = (torch.rand(n_src, generator=g) + 0.5).to(DEV)
+  beta = (torch.randn(n_src, generator=g) * 0.1).to(DEV)
+  mm, mv = torch.zeros(n_src, device=DEV), torch.ones(n_src, device=DEV)
+  y, mean, invstd = hip.bn_act_fwd(z, None, gamma, beta, 1, 1e-3, 0.99, mm, mv, act)
+  dz_next = (torch.randn(B, K, generator=g) * 0.1).to(DEV)
+  w = torch.randn(N, K, generator=g).to(DEV)
+  src = kernels.BnSource(z, None, y, mean, invstd, act)
+  tiles = hip.gemm_row_tiles(B)
+  part_c = torch.full((tiles * n_src * 2,), float('nan'), device=DEV)
+  dy = hip.gemm_bn_bwd(kernels.GEMM_NT, dz_next, w, src, part_c, col0=col0)
+  assert torch.equal(dy, hip.gemm(kernels.GEMM_NT, dz_next, w))
+  part_b = torch.full((tiles * n_src * 2,), float('nan'), device=DEV)
+  dy_b = hip.gemm_bn_bwd(kernels.GEMM_NT, dz_next, w[col0:col0 + n_src].contiguous(), src, part_b)
+  torch.cuda.synchronize()
+  assert torch.equal(dy_b, dy[:, col0:col0 + n_src])
+  assert not torch.isnan(part_c).any() and torch.equal(part_c, part_b)
+  # ... and they finish the block's BatchNorm backward from the strided view of dy, as the model does
+  ref = hip.bn_act_bwd(z, None, gamma, y, mean, invstd, dy[:, col0:col0 + n_src], 1, act, False, True)
+  got = hip.bn_act_bwd(z, None, gamma, y, mean, invstd, dy[:, col0:col0 + n_src], 1, act, False, True, partial=part_c)
+  torch.cuda.synchronize()
+  for a, b, what in zip(got, ref, ('dz', 'dbias', 'dgamma', 'dbeta')):
+    if a is None:
+      assert b is None
+      continue
+    scale = float(b.abs().max()) + 1e-12
+    assert float((a - b).abs().max()) <= 2e-5 * scale, (what, float((a - b).abs().max()), scale)
+
+
 @pytest.mark.parametrize('B,dims', [(300, (16, 1)), (5000, (4,)), (7, (8,))])
 def test_route_outputs_of_the_segmented_path(hip, ref, B, dims):
   """er_emb_route without routing tables (one table per lookup -> fused sort + heads + route launches): the
