@@ -1436,14 +1436,22 @@ int er_bn_act_bwd_from_partials(const float* x, const float* bias, const float* 
                                 const float* save_mean, const float* save_invstd, const float* dy, int32_t B, int32_t N,
                                 int use_bn, int act, const float* partial, int32_t chunks, float* dx, float* dbias,
                                 float* dgamma, float* dbeta, int accumulate, er_stream_t stream) {
-  ER_REQUIRE(x && y && dy && dx && partial && B > 0 && N > 0 && chunks > 0, "er_bn_act_bwd_from_partials: bad arguments");
+  return er_bn_act_bwd_from_partials_ld(x, bias, gamma, y, save_mean, save_invstd, dy, N, B, N, use_bn, act, partial, chunks, dx,
+                                        dbias, dgamma, dbeta, accumulate, stream);
+}
+
+int er_bn_act_bwd_from_partials_ld(const float* x, const float* bias, const float* gamma, const float* y,
+                                   const float* save_mean, const float* save_invstd, const float* dy, int32_t dy_ld, int32_t B,
+                                   int32_t N, int use_bn, int act, const float* partial, int32_t chunks, float* dx, float* dbias,
+                                   float* dgamma, float* dbeta, int accumulate, er_stream_t stream) {
+  ER_REQUIRE(x && y && dy && dx && partial && B > 0 && N > 0 && chunks > 0 && dy_ld >= N, "er_bn_act_bwd_from_partials: bad arguments");
   std::unique_lock<std::mutex> merge_lock(er::g_merge_mu, std::defer_lock);
   if (int rc = merge_bwd_partials(&partial, &chunks, N, er::as_stream(stream), &merge_lock)) return rc;
   const int tpb = er::apply_tiles_per_block(B);
   dim3 grid2(static_cast<unsigned>(er::ceil_div(N, er::kColsPerBlock)),
              static_cast<unsigned>(er::ceil_div(B, er::kApplyRows * tpb)));
   hipLaunchKernelGGL(er::bn_bwd_finalize_apply_kernel, grid2, dim3(er::kBlock), 0, er::as_stream(stream), partial, x, bias,
-                     gamma, y, save_mean, save_invstd, dy, B, N, chunks, use_bn, act, accumulate, dx, dbias, dgamma, dbeta, N, tpb);
+                     gamma, y, save_mean, save_invstd, dy, B, N, chunks, use_bn, act, accumulate, dx, dbias, dgamma, dbeta, dy_ld, tpb);
   ER_LAUNCH_CHECK();
   return 0;
 }

@@ -1870,10 +1870,10 @@ class HipBackend(object):
                                     _p(dgamma), _p(dbeta), int(acc), _stream()), 'er_bn_act_bwd_ld')
     elif partial is not None:
       self._ck(
-          self.lib.er_bn_act_bwd_from_partials(_p(x), _p(bias), _p(gamma), _p(y), _p(mean), _p(invstd), _p(_f32c(dy)),
-                                               B, N, int(use_bn), int(act), _p(partial),
-                                               ctypes.c_int32(self.gemm_row_tiles(B)), _p(dx), _p(dbias), _p(dgamma),
-                                               _p(dbeta), int(acc), _stream()), 'er_bn_act_bwd_from_partials')
+          self.lib.er_bn_act_bwd_from_partials_ld(_p(x), _p(bias), _p(gamma), _p(y), _p(mean), _p(invstd), _p(dy),
+                                                  ctypes.c_int32(dy.stride(0)), B, N, int(use_bn), int(act), _p(partial),
+                                                  ctypes.c_int32(self.gemm_row_tiles(B)), _p(dx), _p(dbias), _p(dgamma),
+                                                  _p(dbeta), int(acc), _stream()), 'er_bn_act_bwd_from_partials_ld')
     else:
       self._ck(
           self.lib.er_bn_act_bwd(_p(x), _p(bias), _p(gamma), _p(y), _p(mean), _p(invstd), _p(_f32c(dy)), B, N,

@@ -613,6 +613,12 @@ int er_bn_act_bwd_from_partials(const float* x, const float* bias, const float* 
                                 int32_t B, int32_t N, int use_bn, int act, const float* partial,
                                 int32_t chunks, float* dx, float* dbias, float* dgamma, float* dbeta,
                                 int accumulate, er_stream_t stream);
+/* ... with dy a column block of a wider gradient (dy_ld floats between its rows: er_gemm_f32_bn_bwd_cols' output) */
+int er_bn_act_bwd_from_partials_ld(const float* x, const float* bias, const float* gamma, const float* y,
+                                   const float* save_mean, const float* save_invstd, const float* dy, int32_t dy_ld,
+                                   int32_t B, int32_t N, int use_bn, int act, const float* partial, int32_t chunks,
+                                   float* dx, float* dbias, float* dgamma, float* dbeta, int accumulate,
+                                   er_stream_t stream);
 /* out[j] = sum_i x[i, j]  (bias gradients, partial reductions); er_colsum_acc: out[j] += ... when accumulate
  * (straight into the variable's slice of the flat gradient buffer) */
 int er_colsum_acc(const float* x, int32_t rows, int32_t cols, int32_t x_stride, float* out, int accumulate,
