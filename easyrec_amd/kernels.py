@@ -1467,8 +1467,6 @@ class HipBackend(object):
 
   # the riders of the fused tail (er_emb_bwd_fused_tail); A/B switch
   tail_riders = os.environ.get('EASYREC_AMD_TAIL_RIDERS', '1') != '0'
-  # the embedding backward's table groups narrowest first (layers/input_layer.py backward_update); A/B switch
-  own_long_first = os.environ.get('EASYREC_AMD_OWN_LONG_FIRST', '0') != '0'
 
   def dense_opt_fits_the_tail(self, wgrads, w, grad):
     """every queued weight gradient is a contiguous block of the flat gradient buffer (the optimizer finishes the k-split

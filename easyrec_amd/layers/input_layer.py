@@ -682,13 +682,9 @@ class EmbeddingEngine(object):
       if dense_opt is not None and not (wgrads is not None and getattr(be, 'tail_riders', False) and
                                         be.dense_opt_fits_the_tail(wgrads, dense_opt[0], dense_opt[3])):
         dense_opt = None
-      grps = list(self.emb_groups.values())
-      if getattr(be, 'own_long_first', False):
-        # the row update's grid is dealt in order: the narrow groups' tiles are its long ones (512 scalar gathers and a
-        # scan each, ~20 us against ~9 for a dim-16 tile) - first in the grid they start at once instead of behind two
-        # rounds of short tiles (the groups are independent: any order gives the same bits)
-        grps = [self.emb_groups[d] for d in sorted(self.emb_groups)]
-      ran_opt = be.emb_bwd_fused(grps, self._finish_descs(), opt_kind, hyper, wgrads=wgrads, dense_opt=dense_opt)
+      # (the narrow groups' long tiles FIRST in the grid: measured, no change - profiles/r05_s14_*)
+      ran_opt = be.emb_bwd_fused(list(self.emb_groups.values()), self._finish_descs(), opt_kind, hyper, wgrads=wgrads,
+                                 dense_opt=dense_opt)
       for g in self.groups.values():
         g['terms'] = []
         g['got_grad'] = True

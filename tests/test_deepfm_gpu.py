@@ -575,33 +575,31 @@ def test_fused_step_variants_change_no_bit(buckets, B):
 def test_deep_tower_sums_from_the_final_dnn_dgrad():
   """DeepFM's deep tower ends in [sum(wide) | FM | deep]; its last BatchNorm backward takes its column sums from the
   epilogue of the final DNN's first input-gradient GEMM (er_gemm_f32_bn_bwd_cols) instead of a pass of its own: one launch
-  less, the same step up to the order of a column's 4096-term sums."""
+  less, the same gradients up to the order of a column's 2048-term sums (one step from identical parameters: the losses are
+  equal, every dense gradient within 1e-5 of the buffer's scale)."""
   cfg = _cfg('deepfm_criteo_small.config')
   B = 2048
   gen = SyntheticCriteo(cfg.data_config, list(cfg.feature_config.features), batch_size=B, seed=21)
-  batches = [gen.next_batch() for _ in range(2)]
+  batch = gen.next_batch()
   be = kernels.hip()
-  states, losses, launches = [], [], []
+  grads, losses, launches = [], [], []
   for on in (False, True):
     be.bn_cols_epilogue = on
     try:
       est = EasyRecEstimator(cfg, device=DEV, batch_size=B, seed=4).build()
-      est.train_step(batches[0])
       be.op_log = []
-      est.train_step(batches[1])
+      est.train_step(batch)
       launches.append(sum(1 for name, _ in be.op_log if 'gemm_f32_bn_bwd_kernel' in name))
       be.op_log = None
       losses.append(est.loss_values())
-      states.append(est.state_dict(slots=True))
+      grads.append(est.varstore.flat_grad.detach().cpu().numpy().copy())
     finally:
       be.op_log = None
       del be.bn_cols_epilogue
   assert launches[1] == launches[0] + 1  # (the final DNN's first dgrad now carries the epilogue)
-  for k in losses[0]:
-    assert abs(losses[0][k] - losses[1][k]) <= 2e-5 * max(1.0, abs(losses[0][k])), (k, losses[0][k], losses[1][k])
-  for k in states[0]:
-    scale = float(np.max(np.abs(states[0][k]))) + 1e-30
-    assert float(np.max(np.abs(states[0][k] - states[1][k]))) <= 1e-4 * scale, k
+  assert losses[0] == losses[1]
+  scale = float(np.max(np.abs(grads[0])))
+  assert scale > 0 and float(np.max(np.abs(grads[0] - grads[1]))) <= 1e-5 * scale
 
 
 def test_a_replay_table_built_for_another_step_is_detected():
