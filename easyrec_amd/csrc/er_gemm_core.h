@@ -11,9 +11,6 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef short bf16x4 __attribute__((ext_vector_type(4)));
 
-#ifndef ER_GEMM_PREFETCH
-#define ER_GEMM_PREFETCH 2  // k-tiles of global loads in flight per thread behind the one being contracted (2 | 4)
-#endif
 constexpr int BM = 64, BN = 64;
 constexpr int BK32 = 32;   // k-tile of the f32 kernel
 constexpr int BK16 = 32;   // k-tile of the bf16 kernel (two 32x32x16 steps)
@@ -606,6 +603,10 @@ __device__ __forceinline__ void gemm_f32_block(const GemmArgs& g, int bx, int bz
     // other LDS stage.  A global load has almost two k-tiles of matrix work to arrive.  Two steps per loop
     // iteration so that each register set keeps its registers; an odd k-tile count is rounded up with an
     // all-zero tile (masked in stage_tile).
+    // (FOUR register sets - the loads of k-tiles t + 1 .. t + 4 in flight, every load of a K <= 128 contraction issued
+    // before its first MFMA - were built and measured in round 5: bit-identical, 96 - 135 VGPRs instead of 64 - 100, and
+    // SLOWER on every config - DeepFM 0.3287 -> 0.3343 ms, DCN-v2 0.785 -> 0.802, DIN 1.833 -> 1.892, MMoE 2.094 -> 2.173:
+    // global latency is not what the k loop waits for; profiles/r05_s15_gemm_prefetch_depth_ab_lines.txt)
     // Fragments are read a quarter of the k-tile at a time, right before their four MFMAs, and the compiler places the
     // instructions (no scheduling fences): against "every fragment first, fences around the MFMA groups" the bare core
     // (tools/micro/gemm_core.hip, variants 9 -> 1) gains 10 % on 8192 x 1152 x 256, 7 % on 8192 x 256 x 1152.
@@ -628,48 +629,6 @@ __device__ __forceinline__ void gemm_f32_block(const GemmArgs& g, int bx, int bz
       }
       __syncthreads();
     };
-#if ER_GEMM_PREFETCH == 4
-    // FOUR register sets: the loads of k-tiles t + 1 .. t + 4 are in flight while tile t is contracted.  With one wave per
-    // SIMD (a 256-workgroup forward GEMM has nothing else to switch to) two tiles of matrix work - ~1 us - did not cover
-    // an operand that the previous launch has just written (the lookup's output, a BatchNorm's y); and a contraction of
-    // <= 4 k-tiles (K <= 128: the narrow layers and their input gradients) now has every load in flight before its first
-    // MFMA.  Same k order, same bits.  Tiles past the end: the loads stay (clamped, identical every iteration: the
-    // compiler counts vmcnt exactly), the matrix work and the staging are skipped (uniform branch).
-    f32x4v ra2[2], rb2[2], ra3[2], rb3[2];
-    auto step4 = [&](int buf, f32x4v (&fa_)[2], f32x4v (&fb_)[2], f32x4v (&sa)[2], f32x4v (&sb)[2], int t) {
-      const float* base = lds + buf * 2 * kOpTile;
-      fetch(fa_, fb_, t + 4);
-      if (t < T) {
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-          const f32x4v a = *reinterpret_cast<const f32x4v*>(base + fa + 4 * q);
-          const f32x4v b = *reinterpret_cast<const f32x4v*>(base + fb + 4 * q);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[i], acc, 0, 0, 0);
-        }
-        if (t + 1 < T) stage(buf ^ 1, sa, sb, t + 1);
-        {
-          const f32x4v a = *reinterpret_cast<const f32x4v*>(base + fa + 12);
-          const f32x4v b = *reinterpret_cast<const f32x4v*>(base + fb + 12);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[i], acc, 0, 0, 0);
-        }
-        __syncthreads();
-      }
-    };
-    fetch(ra0, rb0, 0);
-    fetch(ra1, rb1, 1);
-    fetch(ra2, rb2, 2);
-    fetch(ra3, rb3, 3);
-    stage(0, ra0, rb0, 0);
-    __syncthreads();
-    for (int t = 0; t < T; t += 4) {
-      step4(0, ra0, rb0, ra1, rb1, t);
-      step4(1, ra1, rb1, ra2, rb2, t + 1);
-      step4(0, ra2, rb2, ra3, rb3, t + 2);
-      step4(1, ra3, rb3, ra0, rb0, t + 3);
-    }
-#else
     fetch(ra0, rb0, 0);
     fetch(ra1, rb1, 1);
     stage(0, ra0, rb0, 0);
@@ -678,7 +637,6 @@ __device__ __forceinline__ void gemm_f32_block(const GemmArgs& g, int bx, int bz
       step(0, ra0, rb0, ra1, rb1, t);
       step(1, ra1, rb1, ra0, rb0, t + 1);
     }
-#endif
   } else {
     // unaligned operands (e.g. lda = 81): masked scalar loads, one k-tile at a time
     f32x4v ra[2], rb[2];
