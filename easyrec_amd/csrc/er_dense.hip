@@ -379,17 +379,10 @@ bn_finalize_apply_kernel(const float* __restrict__ partial, const float* __restr
 }
 
 
-__device__ __forceinline__ float recomputed_y(float z, float mu, float is, float ga, float be, int use_bn) {
-  if (!use_bn) return z;
-  const float v = (z - mu) * is;
-  return v * ga + be;
-}
-
 // backward partials: p[(chunk*N + c)*2 + {0,1}] = (sum g, sum g*xhat), g = dy * act'(y)
 __device__ __forceinline__ void bn_bwd_partial_body(const float* __restrict__ x, const float* __restrict__ bias, const float* __restrict__ y,
                       const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ dy,
-                      int B, int N, int chunks, int use_bn, int act, float* __restrict__ partial, int dy_ld,
-                      const float* __restrict__ gamma, const float* __restrict__ beta, int bx, int by) {
+                      int B, int N, int chunks, int use_bn, int act, float* __restrict__ partial, int dy_ld, int bx, int by) {
   __shared__ float sm[2][kRowLanes][kColsPerBlock];
   const int cl = threadIdx.x % kColsPerBlock;
   const int rl = threadIdx.x / kColsPerBlock;
@@ -403,12 +396,10 @@ __device__ __forceinline__ void bn_bwd_partial_body(const float* __restrict__ x,
     const float bv = bias ? bias[c] : 0.f;
     const float mu = use_bn ? mean[c] : 0.f;
     const float is = use_bn ? invstd[c] : 0.f;
-    const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
     for (int r = r0 + rl; r < r1; r += kRowLanes) {
       const int64_t i = static_cast<int64_t>(r) * N + c;
       float g = dy[static_cast<int64_t>(r) * dy_ld + c];
-      // (y == nullptr: never written - recomputed from x with bn_finalize_apply_kernel's operation sequence)
-      if (act == ER_ACT_RELU && !((y ? y[i] : recomputed_y(x[i] + bv, mu, is, ga, be, use_bn)) > 0.f)) g = 0.f;
+      if (act == ER_ACT_RELU && !(y[i] > 0.f)) g = 0.f;
       sg = sg + g;
       if (use_bn) sgx = sgx + g * ((x[i] + bv - mu) * is);
     }
@@ -426,9 +417,8 @@ __device__ __forceinline__ void bn_bwd_partial_body(const float* __restrict__ x,
 __global__ void __launch_bounds__(kBlock)
 bn_bwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ bias, const float* __restrict__ y,
                       const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ dy,
-                      int B, int N, int chunks, int use_bn, int act, float* __restrict__ partial, int dy_ld,
-                      const float* __restrict__ gamma = nullptr, const float* __restrict__ beta = nullptr) {
-  bn_bwd_partial_body(x, bias, y, mean, invstd, dy, B, N, chunks, use_bn, act, partial, dy_ld, gamma, beta, static_cast<int>(blockIdx.x), static_cast<int>(blockIdx.y));
+                      int B, int N, int chunks, int use_bn, int act, float* __restrict__ partial, int dy_ld) {
+  bn_bwd_partial_body(x, bias, y, mean, invstd, dy, B, N, chunks, use_bn, act, partial, dy_ld, static_cast<int>(blockIdx.x), static_cast<int>(blockIdx.y));
 }
 
 
@@ -440,7 +430,7 @@ __device__ __forceinline__ void bn_bwd_finalize_apply_body(const float* __restri
                              const float* __restrict__ invstd, const float* __restrict__ dy, int B, int N,
                              int chunks, int use_bn, int act, int accumulate, float* __restrict__ dx,
                              float* __restrict__ dbias, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                             int dy_ld, int tiles_per_block, const float* __restrict__ beta, int bx, int by) {
+                             int dy_ld, int tiles_per_block, int bx, int by) {
   __shared__ float sm[2][kRowLanes][kColsPerBlock];
   __shared__ float s_g[kColsPerBlock], s_gx[kColsPerBlock];
   const int cl = threadIdx.x % kColsPerBlock;
@@ -457,8 +447,8 @@ __device__ __forceinline__ void bn_bwd_finalize_apply_body(const float* __restri
       const int64_t i = static_cast<int64_t>(r) * N + c;
       const bool ok = r < B;
       gpre[k] = ok ? dy[static_cast<int64_t>(r) * dy_ld + c] : 0.f;
-      xpre[k] = (ok && (use_bn || !y)) ? x[i] : 0.f;
-      ypre[k] = (ok && act == ER_ACT_RELU && y) ? y[i] : 1.f;
+      xpre[k] = (ok && use_bn) ? x[i] : 0.f;
+      ypre[k] = (ok && act == ER_ACT_RELU) ? y[i] : 1.f;
     }
   }
   float a = 0.f, b = 0.f;
@@ -513,8 +503,8 @@ __device__ __forceinline__ void bn_bwd_finalize_apply_body(const float* __restri
       const int64_t i = static_cast<int64_t>(r) * N + c;
       const bool ok = r < B;
       gv[k] = pre ? gpre[k] : (ok ? dy[static_cast<int64_t>(r) * dy_ld + c] : 0.f);
-      xv[k] = pre ? xpre[k] : ((ok && (use_bn || !y)) ? x[i] : 0.f);
-      yv[k] = (ok && act == ER_ACT_RELU) ? (y ? (pre ? ypre[k] : y[i]) : recomputed_y(xv[k] + bv, mu, is, ga, beta ? beta[c] : 0.f, use_bn)) : 1.f;
+      xv[k] = pre ? xpre[k] : ((ok && use_bn) ? x[i] : 0.f);
+      yv[k] = (ok && act == ER_ACT_RELU) ? (pre ? ypre[k] : y[i]) : 1.f;
     }
 #pragma unroll
     for (int k = 0; k < kIter; ++k) {
@@ -539,8 +529,8 @@ bn_bwd_finalize_apply_kernel(const float* __restrict__ partial, const float* __r
                              const float* __restrict__ invstd, const float* __restrict__ dy, int B, int N,
                              int chunks, int use_bn, int act, int accumulate, float* __restrict__ dx,
                              float* __restrict__ dbias, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                             int dy_ld, int tiles_per_block, const float* __restrict__ beta = nullptr) {
-  bn_bwd_finalize_apply_body(partial, x, bias, gamma, y, mean, invstd, dy, B, N, chunks, use_bn, act, accumulate, dx, dbias, dgamma, dbeta, dy_ld, tiles_per_block, beta, static_cast<int>(blockIdx.x), static_cast<int>(blockIdx.y));
+                             int dy_ld, int tiles_per_block) {
+  bn_bwd_finalize_apply_body(partial, x, bias, gamma, y, mean, invstd, dy, B, N, chunks, use_bn, act, accumulate, dx, dbias, dgamma, dbeta, dy_ld, tiles_per_block, static_cast<int>(blockIdx.x), static_cast<int>(blockIdx.y));
 }
 
 
@@ -601,7 +591,7 @@ bn_bwd_partial_multi_kernel(BnMultiArgs a) {
   const BnItem& d = a.d[i];
   const int local = blockIdx.x - a.start[i];
   bn_bwd_partial_body(d.x, d.bias, d.yin, d.save_mean, d.save_invstd, d.dy, d.B, d.N, d.chunks, d.mode, d.act, d.scratch,
-                      d.dy_ld, d.gamma, d.beta, local % d.gx, local / d.gx);
+                      d.dy_ld, local % d.gx, local / d.gx);
 }
 
 __global__ void __launch_bounds__(kBlock)
@@ -610,7 +600,7 @@ bn_bwd_finalize_apply_multi_kernel(BnMultiArgs a) {
   const BnItem& d = a.d[i];
   const int local = blockIdx.x - a.start[i];
   bn_bwd_finalize_apply_body(d.partial, d.x, d.bias, d.gamma, d.yin, d.save_mean, d.save_invstd, d.dy, d.B, d.N, d.chunks,
-                             d.mode, d.act, d.accumulate, d.dx, d.dbias, d.dgamma, d.dbeta, d.dy_ld, d.tpb, d.beta,
+                             d.mode, d.act, d.accumulate, d.dx, d.dbias, d.dgamma, d.dbeta, d.dy_ld, d.tpb,
                              local % d.gx, local / d.gx);
 }
 
@@ -1452,37 +1442,6 @@ int er_bn_act_bwd_from_partials_ld(const float* x, const float* bias, const floa
              static_cast<unsigned>(er::ceil_div(B, er::kApplyRows * tpb)));
   hipLaunchKernelGGL(er::bn_bwd_finalize_apply_kernel, grid2, dim3(er::kBlock), 0, er::as_stream(stream), partial, x, bias,
                      gamma, y, save_mean, save_invstd, dy, B, N, chunks, use_bn, act, accumulate, dx, dbias, dgamma, dbeta, dy_ld, tpb);
-  ER_LAUNCH_CHECK();
-  return 0;
-}
-
-int er_bn_act_bwd_z(const float* z, const float* bias, const float* gamma, const float* beta, const float* save_mean,
-                    const float* save_invstd, const float* dy, int32_t dy_ld, int32_t B, int32_t N, int use_bn, int act,
-                    const float* partial, int32_t chunks, float* dx, float* dbias, float* dgamma, float* dbeta,
-                    int accumulate, er_stream_t stream) {
-  ER_REQUIRE(z && dy && dx && B > 0 && N > 0 && dy_ld >= N && (!partial || chunks > 0), "er_bn_act_bwd_z: bad arguments");
-  ER_REQUIRE(!use_bn || (save_mean && save_invstd), "er_bn_act_bwd_z: BatchNorm statistics missing");
-  hipStream_t s = er::as_stream(stream);
-  std::unique_lock<std::mutex> scratch_lock(er::g_scratch_mu, std::defer_lock);
-  if (!partial) {
-    chunks = er::choose_chunks(B, N);
-    scratch_lock.lock();
-    float* scratch;
-    if (er::get_scratch(static_cast<size_t>(chunks) * N * 2, &scratch)) return 1;
-    dim3 grid(static_cast<unsigned>(er::ceil_div(N, er::kColsPerBlock)), static_cast<unsigned>(chunks));
-    hipLaunchKernelGGL(er::bn_bwd_partial_kernel, grid, dim3(er::kBlock), 0, s, z, bias, static_cast<const float*>(nullptr),
-                       save_mean, save_invstd, dy, B, N, chunks, use_bn, act, scratch, dy_ld, gamma, beta);
-    ER_LAUNCH_CHECK();
-    partial = scratch;
-  }
-  std::unique_lock<std::mutex> merge_lock(er::g_merge_mu, std::defer_lock);
-  if (int rc = merge_bwd_partials(&partial, &chunks, N, s, &merge_lock)) return rc;
-  const int tpb = er::apply_tiles_per_block(B);
-  dim3 grid2(static_cast<unsigned>(er::ceil_div(N, er::kColsPerBlock)),
-             static_cast<unsigned>(er::ceil_div(B, er::kApplyRows * tpb)));
-  hipLaunchKernelGGL(er::bn_bwd_finalize_apply_kernel, grid2, dim3(er::kBlock), 0, s, partial, z, bias, gamma,
-                     static_cast<const float*>(nullptr), save_mean, save_invstd, dy, B, N, chunks, use_bn, act, accumulate,
-                     dx, dbias, dgamma, dbeta, dy_ld, tpb, beta);
   ER_LAUNCH_CHECK();
   return 0;
 }

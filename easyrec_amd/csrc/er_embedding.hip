@@ -3826,8 +3826,8 @@ static int emb_bwd_fused_impl(er_emb_group* const* groups, int n, const er_grad_
   if (n_wgrads > 0) {
     ER_REQUIRE(wgrads && n_wgrads <= er::kMaxGroup, "er_emb_bwd_fused_wgrad: 1 <= n_wgrads <= %d", er::kMaxGroup);
     for (int i = 0; i < n_wgrads; ++i)
-      ER_REQUIRE(!wgrads[i].a_mean && !wgrads[i].col_stats && !wgrads[i].bn_partial,
-                 "er_emb_bwd_fused_wgrad: problem %d: plain contractions only (no A transform, statistics or BatchNorm epilogue)", i);
+      ER_REQUIRE(!wgrads[i].col_stats && !wgrads[i].bn_partial,
+                 "er_emb_bwd_fused_wgrad: problem %d: plain contractions only (no column statistics or BatchNorm epilogue)", i);
     if (int rc = er::plan_grouped(ER_GEMM_TN, wgrads, n_wgrads, false, &plan, wgrad_blocks)) return rc;
   }
   er::LossTailArgs lt;

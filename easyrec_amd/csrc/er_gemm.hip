@@ -39,16 +39,6 @@ gemm_f32_bn_bwd_kernel(GemmArgs g) {
   gemm_f32_block<A_KC, B_KC, true>(g, blockIdx.x, 0, lds);
 }
 
-// the same with the A transform: the LDS parameter table behind the operand stages
-constexpr int kTrLds = 2 * 2 * kOpTile + 4 * kTrMaxK;
-template <bool A_KC, bool B_KC>
-__global__ void __launch_bounds__(kBlock)
-gemm_f32_tr_kernel(GemmArgs g) {
-  __shared__ __attribute__((aligned(16))) float lds[kTrLds];
-  gemm_f32_block<A_KC, B_KC, false, true>(g, blockIdx.x, blockIdx.z, lds);
-}
-
-
 template <bool A_KC, bool B_KC>
 __global__ void __launch_bounds__(kBlock)
 gemm_f32_grouped_kernel(GroupedArgs ga) {
@@ -66,15 +56,6 @@ gemm_f32_grouped_bn_bwd_kernel(GroupedArgs ga) {
   const GroupedCoords c = grouped_coords(ga, blockIdx.x);
   if (c.split < 0) return;
   gemm_f32_block<A_KC, B_KC, true>(ga.p[c.p], c.tile, c.split, lds, c.plain);
-}
-
-template <bool A_KC, bool B_KC>
-__global__ void __launch_bounds__(kBlock)
-gemm_f32_grouped_tr_kernel(GroupedArgs ga) {
-  __shared__ __attribute__((aligned(16))) float lds[kTrLds];
-  const GroupedCoords c = grouped_coords(ga, blockIdx.x);
-  if (c.split < 0) return;
-  gemm_f32_block<A_KC, B_KC, false, true>(ga.p[c.p], c.tile, c.split, lds, c.plain);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -218,32 +199,6 @@ int ensure_ws(size_t floats, float** out) {
   return 0;
 }
 
-// barrier words of the fused-BatchNorm epilogues: [kMaxColTiles][2], zero between launches
-constexpr int kMaxColTiles = 256;
-unsigned* g_bn_counters = nullptr;
-int g_num_cus = 0;
-
-int ensure_counters() {
-  if (!g_bn_counters) {
-    ER_CHECK_HIP(hipMalloc(&g_bn_counters, sizeof(unsigned) * 2 * kMaxColTiles));
-    ER_CHECK_HIP(hipMemset(g_bn_counters, 0, sizeof(unsigned) * 2 * kMaxColTiles));
-    int dev = 0;
-    hipDeviceProp_t prop;
-    ER_CHECK_HIP(hipGetDevice(&dev));
-    ER_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
-    g_num_cus = prop.multiProcessorCount;
-  }
-  return 0;
-}
-
-// The barrier needs every workgroup of the grid resident at once: 36 KB of LDS and 256 threads per workgroup leave
-// room for at least 2 per CU; stay at that.
-bool fused_bn_fits(int M, int N) {
-  if (!g_bn_counters || g_num_cus <= 0) return false;
-  const int64_t gx = er::ceil_div(N, er::BN), gy = er::ceil_div(M, er::BM);
-  return gx <= kMaxColTiles && gx * gy <= 2LL * g_num_cus;
-}
-
 template <bool BF16>
 int launch_gemm(int layout, er::GemmArgs& a, hipStream_t s) {
   const int64_t n_tiles = er::ceil_div(a.N, er::BN) * er::ceil_div(a.M, er::BM);
@@ -260,8 +215,6 @@ int launch_gemm(int layout, er::GemmArgs& a, hipStream_t s) {
     ER_LAUNCH_GEMM(er::gemm_bf16_kernel)
   } else if (a.bn.partial) {
     ER_LAUNCH_GEMM(er::gemm_f32_bn_bwd_kernel)
-  } else if (a.at.mean) {
-    ER_LAUNCH_GEMM(er::gemm_f32_tr_kernel)
   } else {
     ER_LAUNCH_GEMM(er::gemm_f32_kernel)
   }
@@ -283,7 +236,7 @@ int choose_splits(int M, int N, int K, int ktile) {
 template <bool BF16>
 int gemm_entry(int layout, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                const float* bias, int accumulate, float* col_stats, er_stream_t stream, const char* who,
-               const er::BnBwdEpi* bn = nullptr, const er::ATransform* at = nullptr, const er::BnFused* fu = nullptr) {
+               const er::BnBwdEpi* bn = nullptr) {
   ER_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0, "%s: bad arguments", who);
   ER_REQUIRE(layout >= ER_GEMM_NN && layout <= ER_GEMM_TN, "%s: unknown layout %d", who, layout);
   const int min_lda = (layout == ER_GEMM_TN) ? M : K;
@@ -300,8 +253,6 @@ int gemm_entry(int layout, int M, int N, int K, const float* A, int lda, const f
     a.bn = *bn;
     if (a.bn.n_src == 0) { a.bn.col0 = 0; a.bn.n_src = N; }
   }
-  if (at) a.at = *at;
-  if (fu) a.fu = *fu;
   a.splits = (col_stats || bn) ? 1 : choose_splits(M, N, K, ktile);
   ER_REQUIRE(!(col_stats && accumulate), "%s: column statistics need a plain (non-accumulating) output", who);
   a.k_per_split = static_cast<int>(er::ceil_div(er::ceil_div(K, a.splits), ktile)) * ktile;
@@ -332,7 +283,6 @@ int gemm_entry(int layout, int M, int N, int K, const float* A, int lda, const f
 int er::plan_grouped(int layout, const er_gemm_problem* pr, int n, bool bf16, er::GroupedPlan* plan, int64_t target_override) {
   er::GroupedArgs& ga = plan->ga;
   er::GroupedReduceArgs& ra = plan->ra;
-  bool& any_tr = plan->any_tr;
   bool& any_bn = plan->any_bn;
   int64_t total_tiles = 0;
   for (int i = 0; i < n; ++i) {
@@ -342,7 +292,7 @@ int er::plan_grouped(int layout, const er_gemm_problem* pr, int n, bool bf16, er
     const int min_ldb = (layout == ER_GEMM_NT) ? q.K : q.N;
     ER_REQUIRE(q.lda >= min_lda && q.ldb >= min_ldb && q.ldc >= q.N,
                "er_gemm_grouped_f32: problem %d: leading dimension too small", i);
-    ER_REQUIRE(!bf16 || !(q.a_mean || q.bn_partial), "er_gemm_grouped_bf16: problem %d: epilogues / transforms are fp32 only", i);
+    ER_REQUIRE(!bf16 || !q.bn_partial, "er_gemm_grouped_bf16: problem %d: the BatchNorm-backward epilogue is fp32 only", i);
     total_tiles += er::ceil_div(q.M, er::BM) * er::ceil_div(q.N, er::BN);
   }
   // k-splits: enough workgroups for ~2 per CU over the whole group (A/B: 512 beat 1024 and 2048), >= 4 k-tiles per split
@@ -367,7 +317,6 @@ int er::plan_grouped(int layout, const er_gemm_problem* pr, int n, bool bf16, er
   ra.n = 0;
   ra.start[0] = 0;
   size_t ws_floats = 0;
-  any_tr = false;
   any_bn = false;
   int n_splits[er::kMaxGroup], xcd_ok[er::kMaxGroup];
   for (int i = 0; i < n; ++i) {
@@ -382,20 +331,13 @@ int er::plan_grouped(int layout, const er_gemm_problem* pr, int n, bool bf16, er
     a.col_stats = q.col_stats;
     ER_REQUIRE(!(q.col_stats && q.accumulate), "er_gemm_grouped_f32: problem %d: column statistics need a plain output", i);
     if (q.bn_partial) {
-      ER_REQUIRE(q.bn_z && q.bn_ld >= q.N && !q.accumulate && (!q.bn_use_bn || (q.bn_mean && q.bn_invstd)),
+      ER_REQUIRE(q.bn_z && q.bn_y && q.bn_ld >= q.N && !q.accumulate && (!q.bn_use_bn || (q.bn_mean && q.bn_invstd)),
                  "er_gemm_grouped_f32: problem %d: bad BatchNorm-backward epilogue arguments", i);
       a.bn.z = q.bn_z; a.bn.zbias = q.bn_zbias; a.bn.y = q.bn_y; a.bn.mean = q.bn_mean; a.bn.invstd = q.bn_invstd;
-      a.bn.gamma = q.bn_gamma; a.bn.beta = q.bn_beta; a.bn.ld = q.bn_ld; a.bn.use_bn = q.bn_use_bn; a.bn.act = q.bn_act;
+      a.bn.ld = q.bn_ld; a.bn.use_bn = q.bn_use_bn; a.bn.act = q.bn_act;
       a.bn.partial = q.bn_partial;
       a.bn.col0 = 0; a.bn.n_src = q.N;
       any_bn = true;
-    }
-    if (q.a_mean) {
-      ER_REQUIRE(q.a_invstd, "er_gemm_grouped_f32: problem %d: A transform without invstd", i);
-      ER_REQUIRE(layout == ER_GEMM_TN || q.K <= er::kTrMaxK - 64,
-                 "er_gemm_grouped_f32: problem %d: A transform over K = %d features (limit %d)", i, q.K, er::kTrMaxK - 64);
-      a.at.mean = q.a_mean; a.at.invstd = q.a_invstd; a.at.gamma = q.a_gamma; a.at.beta = q.a_beta; a.at.act = q.a_act;
-      any_tr = true;
     }
     int64_t sp = want;
     // a long contraction (DIN's attention MLP contracts over B x L = 204,800 rows into an 80-column output) gets
@@ -472,7 +414,7 @@ int gemm_grouped_f32(int layout, const er_gemm_problem* pr, int n, er_stream_t s
   er::GroupedPlan plan;
   if (int rc = er::plan_grouped(layout, pr, n, bf16, &plan)) return rc;
   const er::GroupedArgs& ga = plan.ga;
-  const bool any_tr = plan.any_tr, any_bn = plan.any_bn;
+  const bool any_bn = plan.any_bn;
   dim3 grid(static_cast<unsigned>(er::grouped_grid(ga))), block(er::kBlock);
   if (bf16) {
     switch (layout) {
@@ -482,18 +424,10 @@ int gemm_grouped_f32(int layout, const er_gemm_problem* pr, int n, er_stream_t s
       default: er::set_error("er_gemm_grouped_bf16: unknown layout %d", layout); return 2;
     }
   } else if (any_bn) {
-    ER_REQUIRE(!any_tr, "er_gemm_grouped_f32: the A transform and the BatchNorm-backward epilogue in one launch");
     switch (layout) {
       case ER_GEMM_NN: hipLaunchKernelGGL((er::gemm_f32_grouped_bn_bwd_kernel<true, false>), grid, block, 0, s, ga); break;
       case ER_GEMM_NT: hipLaunchKernelGGL((er::gemm_f32_grouped_bn_bwd_kernel<true, true>), grid, block, 0, s, ga); break;
       case ER_GEMM_TN: hipLaunchKernelGGL((er::gemm_f32_grouped_bn_bwd_kernel<false, false>), grid, block, 0, s, ga); break;
-      default: er::set_error("er_gemm_grouped_f32: unknown layout %d", layout); return 2;
-    }
-  } else if (any_tr) {
-    switch (layout) {
-      case ER_GEMM_NN: hipLaunchKernelGGL((er::gemm_f32_grouped_tr_kernel<true, false>), grid, block, 0, s, ga); break;
-      case ER_GEMM_NT: hipLaunchKernelGGL((er::gemm_f32_grouped_tr_kernel<true, true>), grid, block, 0, s, ga); break;
-      case ER_GEMM_TN: hipLaunchKernelGGL((er::gemm_f32_grouped_tr_kernel<false, false>), grid, block, 0, s, ga); break;
       default: er::set_error("er_gemm_grouped_f32: unknown layout %d", layout); return 2;
     }
   } else {
@@ -514,113 +448,8 @@ extern "C" {
 
 int er_gemm_reserve(int64_t floats) {
   ER_REQUIRE(floats >= 0, "er_gemm_reserve: negative size");
-  if (int rc = ensure_counters()) return rc;  // (allocations are not capturable: both happen here)
   float* p;
   return ensure_ws(static_cast<size_t>(floats), &p);
-}
-
-int er_gemm_fused_bn_ok(int32_t M, int32_t N) { return fused_bn_fits(M, N) ? 1 : 0; }
-
-int er_gemm_f32_bn_fwd(int layout, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B,
-                       int32_t ldb, float* Z, int32_t ldz, const float* bias, float* col_stats, const float* gamma,
-                       const float* beta, float eps, float momentum, float* moving_mean, float* moving_var, int act,
-                       float* Y, int32_t ldy, float* save_mean, float* save_invstd, er_stream_t stream) {
-  ER_REQUIRE(A && B && Z && Y && col_stats && save_mean && save_invstd && ldy >= N, "er_gemm_f32_bn_fwd: bad arguments");
-  ER_REQUIRE(fused_bn_fits(M, N), "er_gemm_f32_bn_fwd: %d x %d outputs do not fit one co-resident grid (er_gemm_fused_bn_ok); "
-             "call er_gemm_reserve first", M, N);
-  ER_REQUIRE(layout >= ER_GEMM_NN && layout <= ER_GEMM_TN, "er_gemm_f32_bn_fwd: unknown layout %d", layout);
-  const int min_lda = (layout == ER_GEMM_TN) ? M : K;
-  const int min_ldb = (layout == ER_GEMM_NT) ? K : N;
-  ER_REQUIRE(lda >= min_lda && ldb >= min_ldb && ldz >= N, "er_gemm_f32_bn_fwd: leading dimension too small");
-  er::GemmArgs a;
-  a.A = A; a.B = B; a.C = Z; a.bias = bias;
-  a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldz;
-  a.accumulate = 0;
-  a.col_stats = col_stats;
-  a.splits = 1;
-  a.k_per_split = static_cast<int>(er::ceil_div(K, er::BK32)) * er::BK32;
-  a.fu.mode = 1;
-  a.fu.gamma = gamma; a.fu.beta = beta; a.fu.eps = eps; a.fu.momentum = momentum;
-  a.fu.moving_mean = moving_mean; a.fu.moving_var = moving_var;
-  a.fu.save_mean = save_mean; a.fu.save_invstd = save_invstd;
-  a.fu.y = Y; a.fu.ldy = ldy; a.fu.act = act;
-  a.fu.counters = g_bn_counters;
-  return launch_gemm<false>(layout, a, er::as_stream(stream));
-}
-
-int er_gemm_f32_bn_bwd_apply(int layout, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B,
-                             int32_t ldb, float* DZ, int32_t ldc, const float* z, const float* z_bias, const float* y,
-                             const float* save_mean, const float* save_invstd, int32_t ld_zy, int use_bn, int act,
-                             const float* gamma, float* partial, float* dgamma, float* dbeta, float* dbias,
-                             int accumulate, er_stream_t stream) {
-  ER_REQUIRE(A && B && DZ && z && y && partial && ld_zy >= N && ldc >= N, "er_gemm_f32_bn_bwd_apply: bad arguments");
-  ER_REQUIRE(!use_bn || (save_mean && save_invstd), "er_gemm_f32_bn_bwd_apply: BatchNorm statistics missing");
-  ER_REQUIRE(fused_bn_fits(M, N), "er_gemm_f32_bn_bwd_apply: %d x %d outputs do not fit one co-resident grid", M, N);
-  ER_REQUIRE(layout >= ER_GEMM_NN && layout <= ER_GEMM_TN, "er_gemm_f32_bn_bwd_apply: unknown layout %d", layout);
-  const int min_lda = (layout == ER_GEMM_TN) ? M : K;
-  const int min_ldb = (layout == ER_GEMM_NT) ? K : N;
-  ER_REQUIRE(lda >= min_lda && ldb >= min_ldb, "er_gemm_f32_bn_bwd_apply: leading dimension too small");
-  er::GemmArgs a;
-  a.A = A; a.B = B; a.C = DZ; a.bias = nullptr;
-  a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
-  a.accumulate = 0;
-  a.col_stats = nullptr;
-  a.splits = 1;
-  a.k_per_split = static_cast<int>(er::ceil_div(K, er::BK32)) * er::BK32;
-  a.bn.z = z; a.bn.zbias = z_bias; a.bn.y = y; a.bn.mean = save_mean; a.bn.invstd = save_invstd;
-  a.bn.ld = ld_zy; a.bn.use_bn = use_bn; a.bn.act = act; a.bn.partial = partial;
-  a.bn.col0 = 0; a.bn.n_src = N;
-  a.fu.mode = 2;
-  a.fu.gamma = gamma; a.fu.dgamma = dgamma; a.fu.dbeta = dbeta; a.fu.dbias = dbias; a.fu.accumulate = accumulate;
-  a.fu.counters = g_bn_counters;
-  return launch_gemm<false>(layout, a, er::as_stream(stream));
-}
-
-int er_gemm_f32_deferred(int layout, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const er_a_transform* at,
-                         const float* B, int32_t ldb, float* C, int32_t ldc, const float* bias, int accumulate,
-                         float* col_stats, const er_bn_finalize* fin, er_stream_t stream) {
-  ER_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0, "er_gemm_f32_deferred: bad arguments");
-  ER_REQUIRE(layout >= ER_GEMM_NN && layout <= ER_GEMM_TN, "er_gemm_f32_deferred: unknown layout %d", layout);
-  const int min_lda = (layout == ER_GEMM_TN) ? M : K;
-  const int min_ldb = (layout == ER_GEMM_NT) ? K : N;
-  ER_REQUIRE(lda >= min_lda && ldb >= min_ldb && ldc >= N, "er_gemm_f32_deferred: leading dimension too small");
-  ER_REQUIRE(!fin || (col_stats && fin->save_mean && fin->save_invstd && fin->counters && !accumulate),
-             "er_gemm_f32_deferred: finalising the statistics needs col_stats, save_mean, save_invstd, counters and a plain output");
-  ER_REQUIRE(!fin || er::ceil_div(N, er::BN) <= fin->n_counters / 2,
-             "er_gemm_f32_deferred: %d column tiles need %d counter words", static_cast<int>(er::ceil_div(N, er::BN)),
-             static_cast<int>(2 * er::ceil_div(N, er::BN)));
-  er::ATransform tr;
-  if (at && at->mean) {
-    ER_REQUIRE(at->invstd, "er_gemm_f32_deferred: A transform without invstd");
-    ER_REQUIRE(layout != ER_GEMM_NT, "er_gemm_f32_deferred: the A transform is defined for [batch, features] operands (NN, TN)");
-    ER_REQUIRE(layout == ER_GEMM_TN || K <= er::kTrMaxK - 64, "er_gemm_f32_deferred: A transform over K = %d features (limit %d)",
-               K, er::kTrMaxK - 64);
-    tr.mean = at->mean; tr.invstd = at->invstd; tr.gamma = at->gamma; tr.beta = at->beta; tr.act = at->act;
-  }
-  er::BnFused fu;
-  if (fin) {
-    fu.mode = 3;
-    fu.eps = fin->eps; fu.momentum = fin->momentum;
-    fu.moving_mean = fin->moving_mean; fu.moving_var = fin->moving_var;
-    fu.save_mean = fin->save_mean; fu.save_invstd = fin->save_invstd;
-    fu.counters = reinterpret_cast<unsigned*>(fin->counters);
-  }
-  // (the k-split of a plain contraction - hence its summation order - is er_gemm_f32's)
-  return gemm_entry<false>(layout, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, col_stats, stream, "er_gemm_f32_deferred",
-                           nullptr, tr.mean ? &tr : nullptr, fin ? &fu : nullptr);
-}
-
-int er_gemm_f32_bn_bwd_z(int layout, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B,
-                         int32_t ldb, float* C, int32_t ldc, const float* z, const float* z_bias, const float* gamma,
-                         const float* beta, const float* save_mean, const float* save_invstd, int32_t ld_z, int use_bn,
-                         int act, float* partial, er_stream_t stream) {
-  ER_REQUIRE(z && partial && ld_z >= N, "er_gemm_f32_bn_bwd_z: bad epilogue arguments");
-  ER_REQUIRE(!use_bn || (save_mean && save_invstd), "er_gemm_f32_bn_bwd_z: BatchNorm statistics missing");
-  er::BnBwdEpi e;
-  e.z = z; e.zbias = z_bias; e.y = nullptr; e.mean = save_mean; e.invstd = save_invstd;
-  e.gamma = gamma; e.beta = beta;
-  e.ld = ld_z; e.use_bn = use_bn; e.act = act; e.partial = partial;
-  return gemm_entry<false>(layout, M, N, K, A, lda, B, ldb, C, ldc, nullptr, 0, nullptr, stream, "er_gemm_f32_bn_bwd_z", &e);
 }
 
 int er_gemm_f32(int layout, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B, int32_t ldb,

@@ -30,64 +30,6 @@ struct BnBwdEpi {
   // column c - col0 when 0 <= c - col0 < n_src (DeepFM: the deep tower's 64 columns inside d[sum(wide) | FM | deep],
   // model/deepfm.py:75-83); z / y / mean / invstd / gamma / beta / zbias / partial are the SOURCE layer's, n_src wide.
   int col0 = 0, n_src = 0;        // n_src == 0: the whole output (n_src = N, set by the host)
-  // y == nullptr (the producing layer's activation output was never materialised: ATransform below): the ReLU mask is
-  // recomputed from z with the producing layer's affine parameters
-  const float* gamma = nullptr;
-  const float* beta = nullptr;
-};
-
-// y of a dense + BatchNorm + activation layer from its pre-normalisation value: the operation sequence of
-// bn_finalize_apply_kernel (er_dense.hip), so a recomputed y has the bits of a materialised one
-__device__ __forceinline__ float bn_act_value(float z, float mu, float is, float ga, float be, int use_bn, int act) {
-  float v = z;
-  if (use_bn) {
-    v = (z - mu) * is;
-    v = v * ga + be;
-  }
-  if (act == ER_ACT_RELU) v = v > 0.f ? v : 0.f;
-  return v;
-}
-
-// Operand A as the output of a dense + BatchNorm(train) + activation layer that was NEVER WRITTEN: A points at that
-// layer's pre-normalisation values z (bias included) and the staging applies bn_act_value with the layer's batch
-// statistics and affine parameters per FEATURE - A is [batch, features] row-major both as the forward operand (NN:
-// features = k) and as the weight-gradient operand (TN: features = m), so a staging unit's 4 contiguous elements are 4
-// consecutive features either way.  Saves the separate normalise + activate pass and the write + re-reads of y.
-struct ATransform {
-  const float* mean = nullptr;  // nullptr: A is used as it is
-  const float* invstd = nullptr;
-  const float* gamma = nullptr;  // nullptr: 1
-  const float* beta = nullptr;   // nullptr: 0
-  int act = 0;
-};
-constexpr int kTrMaxK = 1024;  // forward operand: the whole feature axis (= K) sits in the LDS parameter table
-
-// BatchNorm fused INTO the epilogue (forward: normalise + activation; backward: the dz of the producing layer) needs
-// the column statistics of ALL row tiles before any output can be written: the workgroups of one column of tiles meet
-// at a barrier (arrive counter + spin; the whole grid is co-resident: er_gemm_fused_bn_ok), each then finalises the
-// statistics of its 64 columns redundantly - in exactly the order bn_finalize_apply_kernel /
-// bn_bwd_finalize_apply_kernel use, so the results are bit-identical to the two-launch form - and transforms its
-// accumulator tile in registers.  One launch per dense + BatchNorm + ReLU layer instead of two, and no second pass over
-// the layer's output.
-struct BnFused {
-  int mode = 0;                    // 0: off; 1: forward (needs col_stats); 2: backward (needs bn.partial);
-                                   // 3: forward statistics only, WITHOUT a barrier: the workgroup that is last to add
-                                   //    its partial to a column of tiles (arrival counter) finalises mean / invstd /
-                                   //    moving statistics of those 64 columns; nobody waits, z is written as usual
-  const float* gamma = nullptr;
-  const float* beta = nullptr;     // forward
-  float eps = 0.f, momentum = 0.f;
-  float* moving_mean = nullptr;    // forward, may be nullptr (build pass)
-  float* moving_var = nullptr;
-  float* save_mean = nullptr;      // forward: [N] outputs
-  float* save_invstd = nullptr;
-  float* y = nullptr;              // forward: activation output [M][ldy]
-  int ldy = 0, act = 0;
-  float* dgamma = nullptr;         // backward: parameter gradients (accumulated when accumulate != 0), may be nullptr
-  float* dbeta = nullptr;
-  float* dbias = nullptr;          // backward without BatchNorm: the bias gradient
-  int accumulate = 0;
-  unsigned* counters = nullptr;    // [column tiles][2], all zero between launches (the barrier resets itself)
 };
 
 struct GemmArgs {
@@ -102,8 +44,6 @@ struct GemmArgs {
   int splits;
   float* col_stats;   // nullptr, or [gridDim.y][N][3] Welford (count, mean, M2) of the output columns per row tile
   BnBwdEpi bn;        // bn.partial != nullptr: emit the BatchNorm-backward column sums of the output tile
-  BnFused fu;         // fu.mode != 0: finish the BatchNorm in this launch (see BnFused)
-  ATransform at;      // at.mean != nullptr: A is transformed while staged (kernels instantiated with A_TR)
 };
 
 // Loads 4 consecutive elements along the CONTIGUOUS dimension of the operand tile.
@@ -165,17 +105,6 @@ __device__ __forceinline__ void tile_coords(int i, int gx, int gy, int& tx, int&
   ty = t / gx;
 }
 
-// Values that cross workgroups INSIDE a launch (the per-row-tile partials of the fused epilogues) are stored and
-// loaded as relaxed agent-scope atomics: on gfx950 these go through to the memory side (sc1) instead of sitting in
-// the issuing XCD's L2, so no cache-wide writeback / invalidate (a release / acquire FENCE at agent scope costs about
-// as much as the kernel boundary the fusion is meant to save - measured: 27 us per fused launch with fences).
-__device__ __forceinline__ void st_agent(float* p, float v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ float ld_agent(const float* p) {
-  return __hip_atomic_load(const_cast<float*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 // Per-row-tile column statistics of the OUTPUT (value = acc + bias), for a following BatchNorm: removes the
 // separate statistics pass over the GEMM output.  A lane holds 16 rows of one column; lanes l and l^32 hold the
 // other 16 rows; the two waves with wm = 0 / 1 cover the tile's 64 rows.  Welford/Chan merges in a fixed order.
@@ -191,8 +120,7 @@ __device__ __forceinline__ void chan_merge(float& n, float& mean, float& m2, flo
 
 __device__ __forceinline__ void tile_col_stats(const f32x16& acc, float bv, int row_base, int M, int col, int N, int wm,
                                                int wn, int lane, float* lds /* >= 2*32*3 floats */,
-                                               float* __restrict__ out_tile /* [N][3] of this row tile */,
-                                               bool coherent = false /* read by other workgroups of THIS launch */) {
+                                               float* __restrict__ out_tile /* [N][3] of this row tile */) {
   const int khalf = lane >> 5;
   float n = 0.f, s = 0.f;
 #pragma unroll
@@ -218,8 +146,7 @@ __device__ __forceinline__ void tile_col_stats(const f32x16& acc, float bv, int 
   if (wm == 0 && khalf == 0 && col < N) {
     chan_merge(an, am, a2, slot[0], slot[1], slot[2]);
     float* o = out_tile + static_cast<int64_t>(col) * 3;
-    if (coherent) { st_agent(o, an); st_agent(o + 1, am); st_agent(o + 2, a2); }
-    else { o[0] = an; o[1] = am; o[2] = a2; }
+    o[0] = an; o[1] = am; o[2] = a2;
   }
 }
 
@@ -227,7 +154,7 @@ __device__ __forceinline__ void tile_col_stats(const f32x16& acc, float bv, int 
 // register order, then the lane pair (l, l ^ 32), then the two waves that share the columns.
 __device__ __forceinline__ void tile_bn_bwd_partial(const f32x16& acc, const BnBwdEpi& e, const float (&py)[16],
                                                     const float (&pz)[16], int row_base, int M, int col, int N, int wm,
-                                                    int wn, int lane, float* lds, int ty, bool coherent = false) {
+                                                    int wn, int lane, float* lds, int ty) {
   const int khalf = lane >> 5;
   float sg = 0.f, sgx = 0.f;
   const bool col_ok = col >= 0 && col < N;  // (col, N: the SOURCE column and width - BnBwdEpi.col0)
@@ -235,16 +162,12 @@ __device__ __forceinline__ void tile_bn_bwd_partial(const f32x16& acc, const BnB
     const float bv = e.zbias ? e.zbias[col] : 0.f;
     const float mu = e.use_bn ? e.mean[col] : 0.f;
     const float is = e.use_bn ? e.invstd[col] : 0.f;
-    const float ga = e.gamma ? e.gamma[col] : 1.f, be = e.beta ? e.beta[col] : 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = row_base + (r & 3) + 8 * (r >> 2) + 4 * khalf;
       if (row < M) {
         float g = acc[r];
-        if (e.act == ER_ACT_RELU) {
-          const float yv = e.y ? py[r] : bn_act_value(pz[r] + bv, mu, is, ga, be, e.use_bn, ER_ACT_NONE);
-          if (!(yv > 0.f)) g = 0.f;
-        }
+        if (e.act == ER_ACT_RELU && !(py[r] > 0.f)) g = 0.f;
         sg = sg + g;
         if (e.use_bn) sgx = sgx + g * ((pz[r] + bv - mu) * is);
       }
@@ -259,131 +182,9 @@ __device__ __forceinline__ void tile_bn_bwd_partial(const f32x16& acc, const BnB
   __syncthreads();
   if (wm == 0 && khalf == 0 && col_ok) {
     float* p = e.partial + (static_cast<int64_t>(ty) * N + col) * 2;
-    if (coherent) { st_agent(p, a + slot[0]); st_agent(p + 1, ax + slot[1]); }
-    else { p[0] = a + slot[0]; p[1] = ax + slot[1]; }
+    p[0] = a + slot[0];
+    p[1] = ax + slot[1];
   }
-}
-
-// Barrier among the `n` workgroups that share a column of tiles.  c[0]: arrivals, c[1]: departures; the last workgroup
-// to leave zeroes both (every other one has left the spin by then), so the words are zero again for the next launch.
-// No fences: the data the barrier orders is written with st_agent and read with ld_agent only; a writer waits for
-// its stores to be acknowledged (s_waitcnt vmcnt(0): stores count in vmcnt on gfx9) before the workgroup's arrival
-// is counted, a reader issues its loads after the spin has seen every arrival (in-order issue + the barrier).
-__device__ __forceinline__ void tile_column_barrier(unsigned* c, unsigned n) {
-  __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) expcnt(0) lgkmcnt(0): this wave's partial stores have completed
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // (bounded: ~50 ms.  The host only launches a co-resident grid; should that ever not hold, the launch produces wrong
-    // statistics - which the tests catch - instead of hanging the device)
-    for (unsigned spins = 0; __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n && spins < (1u << 21); ++spins)
-      __builtin_amdgcn_s_sleep(1);
-    const unsigned gone = __hip_atomic_fetch_add(c + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (gone == n - 1) {  // everyone has left the spin: zero the words for the next launch
-      __hip_atomic_store(c + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-  __syncthreads();
-}
-
-// Forward: finalise the statistics of the tile's 64 columns from the per-row-tile Welford partials (thread (cl, rl)
-// merges row tiles rl, rl + 4, ... in ascending order, eight loads in flight; then ((0 + 1) + (2 + 3)): the order of
-// bn_finalize_apply_kernel), leave mean / invstd in LDS; the ty == 0 workgroup records them and moves the moving
-// statistics.  lds: >= 256 + 768 + 128 floats.
-__device__ __forceinline__ void fused_bn_fwd_finalize(const GemmArgs& g, int n0, int ty, int gy, float* lds,
-                                                      float*& s_mu, float*& s_is) {
-  float* sm = lds + 256;  // [4][64][3]
-  s_mu = lds + 256 + 768;
-  s_is = s_mu + 64;
-  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int c = n0 + cl;
-  float tn = 0.f, tm = 0.f, t2 = 0.f;
-  if (c < g.N) {
-    for (int k0 = rl; k0 < gy; k0 += 32) {
-      float w[8][3];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int k = k0 + j * 4;
-        if (k < gy) {
-          const float* p = g.col_stats + (static_cast<int64_t>(k) * g.N + c) * 3;
-          w[j][0] = ld_agent(p); w[j][1] = ld_agent(p + 1); w[j][2] = ld_agent(p + 2);
-        } else {
-          w[j][0] = 0.f; w[j][1] = 0.f; w[j][2] = 0.f;
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) chan_merge(tn, tm, t2, w[j][0], w[j][1], w[j][2]);
-    }
-  }
-  float* mine = sm + (rl * 64 + cl) * 3;
-  mine[0] = tn; mine[1] = tm; mine[2] = t2;
-  __syncthreads();
-  if (rl == 0 && c < g.N) {
-    const float* q0 = sm + (0 * 64 + cl) * 3;
-    const float* q1 = sm + (1 * 64 + cl) * 3;
-    const float* q2 = sm + (2 * 64 + cl) * 3;
-    const float* q3 = sm + (3 * 64 + cl) * 3;
-    float an = q0[0], am = q0[1], a2 = q0[2];
-    chan_merge(an, am, a2, q1[0], q1[1], q1[2]);
-    float bn = q2[0], bm = q2[1], b2 = q2[2];
-    chan_merge(bn, bm, b2, q3[0], q3[1], q3[2]);
-    chan_merge(an, am, a2, bn, bm, b2);
-    const float mean = am;
-    const float var = a2 / static_cast<float>(g.M);  // biased, as tf.nn.moments
-    const float inv = 1.f / sqrtf(var + g.fu.eps);
-    s_mu[cl] = mean;
-    s_is[cl] = inv;
-    if (ty == 0) {
-      g.fu.save_mean[c] = mean;
-      g.fu.save_invstd[c] = inv;
-      if (g.fu.moving_mean) {
-        const float om = 1.f - g.fu.momentum;
-        g.fu.moving_mean[c] = g.fu.moving_mean[c] - (g.fu.moving_mean[c] - mean) * om;
-        g.fu.moving_var[c] = g.fu.moving_var[c] - (g.fu.moving_var[c] - var) * om;
-      }
-    }
-  }
-  __syncthreads();
-}
-
-// Backward: the two column sums (sum g, sum g * xhat) of the tile's 64 columns from the per-row-tile partials, in the
-// order of bn_bwd_finalize_apply_kernel; the ty == 0 workgroup writes / accumulates the parameter gradients.
-__device__ __forceinline__ void fused_bn_bwd_finalize(const GemmArgs& g, int n0, int ty, int gy, float* lds,
-                                                      float*& s_g, float*& s_gx) {
-  float* sm = lds + 256;  // [2][4][64]
-  s_g = lds + 256 + 512;
-  s_gx = s_g + 64;
-  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int c = n0 + cl;
-  float a = 0.f, b = 0.f;
-  if (c < g.N) {
-#pragma unroll 8
-    for (int k = rl; k < gy; k += 4) {
-      const float* p = g.bn.partial + (static_cast<int64_t>(k) * g.N + c) * 2;
-      a = a + ld_agent(p);
-      b = b + ld_agent(p + 1);
-    }
-  }
-  sm[rl * 64 + cl] = a;
-  sm[256 + rl * 64 + cl] = b;
-  __syncthreads();
-  if (rl == 0 && c < g.N) {
-    a = (sm[cl] + sm[64 + cl]) + (sm[128 + cl] + sm[192 + cl]);
-    b = (sm[256 + cl] + sm[256 + 64 + cl]) + (sm[256 + 128 + cl] + sm[256 + 192 + cl]);
-    s_g[cl] = a;
-    s_gx[cl] = b;
-    if (ty == 0) {
-      const int acc = g.fu.accumulate;
-      if (g.bn.use_bn) {
-        if (g.fu.dbeta) g.fu.dbeta[c] = acc ? g.fu.dbeta[c] + a : a;
-        if (g.fu.dgamma) g.fu.dgamma[c] = acc ? g.fu.dgamma[c] + b : b;
-      } else if (g.fu.dbias) {
-        g.fu.dbias[c] = acc ? g.fu.dbias[c] + a : a;
-      }
-    }
-  }
-  __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -473,26 +274,14 @@ __device__ __forceinline__ void fetch_tile_generic(const float* __restrict__ P, 
   }
 }
 
-// tr (LDS, A_TR only): [4][kTrMaxK] = mean | invstd | gamma | beta, indexed by the absolute k (KC) or by the feature's
-// offset inside the tile (non-KC); tr_off = what to add to the unit's own coordinate to get that index
 template <bool KC>
 __device__ __forceinline__ void stage_tile(float* __restrict__ S, int tid, const f32x4v (&r)[2], bool interior, int mn0,
-                                           int MN, int k0, int kend, const float* __restrict__ tr = nullptr,
-                                           int tr_off = 0, int tr_act = 0) {
+                                           int MN, int k0, int kend) {
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     int row, k;
     unit_pos<KC>(tid, i, row, k);
     f32x4v v = r[i];
-    if (tr != nullptr) {
-      const int f = (KC ? k : row) + tr_off;  // (a multiple of 4)
-      const f32x4v mu = *reinterpret_cast<const f32x4v*>(tr + f);
-      const f32x4v is = *reinterpret_cast<const f32x4v*>(tr + kTrMaxK + f);
-      const f32x4v ga = *reinterpret_cast<const f32x4v*>(tr + 2 * kTrMaxK + f);
-      const f32x4v be = *reinterpret_cast<const f32x4v*>(tr + 3 * kTrMaxK + f);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = bn_act_value(v[j], mu[j], is[j], ga[j], be[j], 1, tr_act);
-    }
     if (!interior) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -512,7 +301,7 @@ __device__ __forceinline__ void stage_tile(float* __restrict__ S, int tid, const
 // bx: index of the workgroup among the problem's (8-rounded) tiles, bz: its k-split.  BN_EPI: with the BnBwdEpi
 // epilogue - the y / z values of the lane's 16 output positions are requested BEFORE the k loop so that their
 // latency hides behind it (32 more VGPRs: a separate instantiation).
-template <bool A_KC, bool B_KC, bool BN_EPI = false, bool A_TR = false>
+template <bool A_KC, bool B_KC, bool BN_EPI = false>
 __device__ __forceinline__ void gemm_f32_block(const GemmArgs& g, int bx, int bz, float* __restrict__ lds,
                                                bool plain_tiles = false) {
   const int tid = threadIdx.x;
@@ -534,30 +323,10 @@ __device__ __forceinline__ void gemm_f32_block(const GemmArgs& g, int bx, int bz
       int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
       row = row < g.M ? row : g.M - 1;
       const int64_t i = static_cast<int64_t>(row) * g.bn.ld + c;
-      py[r] = g.bn.y ? g.bn.y[i] : 0.f;
+      py[r] = g.bn.y[i];
       pz[r] = g.bn.z[i];
     }
   }
-  // A_TR: the parameter table of the A transform, behind the operand stages
-  const float* tr = nullptr;
-  if (A_TR && g.at.mean != nullptr) {
-    float* t = lds + 2 * 2 * kOpTile;
-    const int n_feat = A_KC ? ((g.K + 3) & ~3) : BM;
-    const int f0 = A_KC ? 0 : m0;
-    const int f_end = A_KC ? g.K : g.M;
-    for (int i = tid; i < n_feat; i += kBlock) {
-      const int f = f0 + i;
-      const bool ok = f < f_end;
-      t[i] = ok ? g.at.mean[f] : 0.f;
-      t[kTrMaxK + i] = ok ? g.at.invstd[f] : 0.f;
-      t[2 * kTrMaxK + i] = (ok && g.at.gamma) ? g.at.gamma[f] : 1.f;
-      t[3 * kTrMaxK + i] = (ok && g.at.beta) ? g.at.beta[f] : 0.f;
-    }
-    tr = t;  // (visible after the __syncthreads() that precedes the first use of a staged tile ... and the first stage
-             // itself reads it: synchronise here)
-    __syncthreads();
-  }
-  const int tr_act = g.at.act;
   const bool a_vec = (g.lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0);
   const bool b_vec = (g.ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0);
   const bool rows_full = (m0 + BM <= g.M) && (n0 + BN <= g.N);
@@ -594,7 +363,7 @@ __device__ __forceinline__ void gemm_f32_block(const GemmArgs& g, int bx, int bz
     auto stage = [&](int buf, const f32x4v (&ra)[2], const f32x4v (&rb)[2], int t) {
       const int k0 = kbeg + t * BK32;  // unclamped: a tile past the end is masked to zero
       const bool interior = rows_full && (k0 + BK32 <= kend);
-      stage_tile<A_KC>(lds + buf * 2 * kOpTile, tid, ra, interior, m0, g.M, k0, kend, tr, A_KC ? k0 : 0, tr_act);
+      stage_tile<A_KC>(lds + buf * 2 * kOpTile, tid, ra, interior, m0, g.M, k0, kend);
       stage_tile<B_KC>(lds + buf * 2 * kOpTile + kOpTile, tid, rb, interior, n0, g.N, k0, kend);
     };
     // One step = one k-tile: read its fragments from LDS stage `buf`, issue the global loads of k-tile t + 2 into
@@ -644,8 +413,7 @@ __device__ __forceinline__ void gemm_f32_block(const GemmArgs& g, int bx, int bz
       const int k0 = kbeg + t * BK32;
       fetch_tile_generic<A_KC>(g.A, g.lda, m0, g.M, k0, kend, tid, ra);
       fetch_tile_generic<B_KC>(g.B, g.ldb, n0, g.N, k0, kend, tid, rb);
-      stage_tile<A_KC>(lds, tid, ra, tr == nullptr, m0, g.M, k0, kend, tr, A_KC ? k0 : 0, tr_act);  // (a transformed
-      // out-of-range element is not zero: masked again after the transform)
+      stage_tile<A_KC>(lds, tid, ra, true, m0, g.M, k0, kend);
       stage_tile<B_KC>(lds + kOpTile, tid, rb, true, n0, g.N, k0, kend);
       __syncthreads();
       f32x4v a[4], b[4];
@@ -659,83 +427,9 @@ __device__ __forceinline__ void gemm_f32_block(const GemmArgs& g, int bx, int bz
   const float bv = (g.bias && g.splits == 1 && col < g.N) ? g.bias[col] : 0.f;
   if (g.col_stats)  // (host guarantees splits == 1) every thread takes part: it synchronises the workgroup
     tile_col_stats(acc, bv, m0 + wm * 32, g.M, col, g.N, wm, wn, lane, lds,
-                   g.col_stats + static_cast<int64_t>(ty) * g.N * 3, g.fu.mode == 1 || g.fu.mode == 3);
-  if (g.fu.mode == 3) {
-    // No barrier: a workgroup adds itself to its column's arrival counter once its partial is at the memory side
-    // (st_agent + s_waitcnt, as in tile_column_barrier); the one that completes the count - whichever it is - merges
-    // all partials of the 64 columns in bn_finalize_apply_kernel's fixed order and writes mean / invstd / the moving
-    // statistics.  The consumer of those is the NEXT launch.
-    const int gy = static_cast<int>(ceil_div(g.M, BM));
-    __builtin_amdgcn_s_waitcnt(0);
-    __syncthreads();
-    unsigned* flag = reinterpret_cast<unsigned*>(lds);
-    if (tid == 0) {
-      unsigned* c = g.fu.counters + 2 * tx;
-      const unsigned before = __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const bool last = before + 1u == static_cast<unsigned>(gy);
-      if (last) __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // zero again for the next launch
-      *flag = last ? 1u : 0u;
-    }
-    __syncthreads();
-    const bool last = *flag != 0u;
-    __syncthreads();
-    if (last) {
-      float *s_mu, *s_is;
-      fused_bn_fwd_finalize(g, n0, 0, gy, lds, s_mu, s_is);
-    }
-  }
+                   g.col_stats + static_cast<int64_t>(ty) * g.N * 3);
   if (BN_EPI && g.bn.partial != nullptr)
-    tile_bn_bwd_partial(acc, g.bn, py, pz, m0 + wm * 32, g.M, col < g.N ? col - g.bn.col0 : -1, g.bn.n_src, wm, wn, lane, lds, ty,
-                        g.fu.mode == 2);
-  if (g.fu.mode == 1 || g.fu.mode == 2) {  // (uniform over the grid; host guarantees splits == 1 and a co-resident grid)
-    const int gy = static_cast<int>(ceil_div(g.M, BM));
-    tile_column_barrier(g.fu.counters + 2 * tx, static_cast<unsigned>(gy));
-    const int cl = wn * 32 + (lane & 31);
-    if (g.fu.mode == 1) {
-      float *s_mu, *s_is;
-      fused_bn_fwd_finalize(g, n0, ty, gy, lds, s_mu, s_is);
-      if (col >= g.N) return;
-      const float mu = s_mu[cl], is = s_is[cl];
-      const float ga = g.fu.gamma ? g.fu.gamma[col] : 1.f, be = g.fu.beta ? g.fu.beta[col] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-        if (row < g.M) {
-          const float z = acc[r] + bv;
-          g.C[static_cast<int64_t>(row) * g.ldc + col] = z;
-          float v = (z - mu) * is;
-          v = v * ga + be;
-          if (g.fu.act == ER_ACT_RELU) v = v > 0.f ? v : 0.f;
-          g.fu.y[static_cast<int64_t>(row) * g.fu.ldy + col] = v;
-        }
-      }
-      return;
-    }
-    if (BN_EPI) {  // mode 2: dz of the producing layer instead of dy
-      float *s_g, *s_gx;
-      fused_bn_bwd_finalize(g, n0, ty, gy, lds, s_g, s_gx);
-      if (col >= g.N) return;
-      const float sg = s_g[cl], sgx = s_gx[cl];
-      const float zb = g.bn.zbias ? g.bn.zbias[col] : 0.f;
-      const float mu = g.bn.use_bn ? g.bn.mean[col] : 0.f, is = g.bn.use_bn ? g.bn.invstd[col] : 0.f;
-      const float ga = g.fu.gamma ? g.fu.gamma[col] : 1.f;
-      const float invB = 1.f / static_cast<float>(g.M);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-        if (row < g.M) {
-          float gr = acc[r];
-          if (g.bn.act == ER_ACT_RELU && !(py[r] > 0.f)) gr = 0.f;
-          if (g.bn.use_bn) {
-            const float xh = (pz[r] + zb - mu) * is;
-            gr = ga * is * (gr - sg * invB - xh * (sgx * invB));
-          }
-          g.C[static_cast<int64_t>(row) * g.ldc + col] = gr;
-        }
-      }
-      return;
-    }
-  }
+    tile_bn_bwd_partial(acc, g.bn, py, pz, m0 + wm * 32, g.M, col < g.N ? col - g.bn.col0 : -1, g.bn.n_src, wm, wn, lane, lds, ty);
   if (col >= g.N) return;
   float* Cz = g.C + (g.splits > 1 ? static_cast<int64_t>(bz) * g.M * g.N : 0);
   const int ldc = g.splits > 1 ? g.N : g.ldc;
@@ -870,7 +564,7 @@ __device__ __forceinline__ void splitk_reduce_grouped_block(const GroupedReduceA
 struct GroupedPlan {
   GroupedArgs ga;
   GroupedReduceArgs ra;
-  bool any_tr, any_bn;
+  bool any_bn;
 };
 // the two regions of a grouped grid from the problems' tile and k-split counts (GroupedArgs); by_xcd[p] 0: problem p in
 // the legacy region only

@@ -93,35 +93,25 @@ class WgradSink(object):
     self.queue = []
     self.queue_bf16 = []  # (a bf16 step's weight gradients: er_gemm_grouped_bf16)
 
-  def put(self, x, dy, out, bf16, at=None):
-    """at: the BnSource of a DEFERRED producer of x (x holds its pre-normalisation values: the GEMM transforms them)"""
-    if not self.active or (bf16 and at is not None):
+  def put(self, x, dy, out, bf16):
+    if not self.active:
       return False
-    (self.queue_bf16 if bf16 else self.queue).append((x, dy, out, None, True, at))
+    (self.queue_bf16 if bf16 else self.queue).append((x, dy, out, None, True))
     return True
 
 
 class BnSource(object):
   """What the dgrad GEMM of a consumer needs in order to emit, in its epilogue, the BatchNorm-backward column sums
-  of the layer that produced its input (HipBackend.gemm_bn_bwd): that layer's z, y and batch statistics - or, when the
-  consumer is the ONLY reader of y (`exclusive`, set by the layer stacks for their inner layers), to finish that
-  layer's BatchNorm backward itself (HipBackend.gemm_bn_bwd_apply): then also gamma and the gradient buffers."""
-  __slots__ = ('z', 'zbias', 'y', 'mean', 'invstd', 'act', 'partial', 'dx_ptr', 'gamma', 'grad_bufs', 'exclusive',
-               'dz_ptr', 'beta', 'fused')
+  of the layer that produced its input (HipBackend.gemm_bn_bwd): that layer's z, y and batch statistics."""
+  __slots__ = ('z', 'zbias', 'y', 'mean', 'invstd', 'act', 'partial', 'dx_ptr', 'gamma', 'grad_bufs', 'beta', 'fused')
 
   def __init__(self, z, zbias, y, mean, invstd, act, gamma=None, grad_bufs=None, beta=None, fused=True):
+    assert y is not None
     self.z, self.zbias, self.y, self.mean, self.invstd, self.act = z, zbias, y, mean, invstd, act
     self.partial, self.dx_ptr = None, 0
     self.gamma, self.grad_bufs = gamma, grad_bufs  # grad_bufs = (gamma.grad, beta.grad) slices of the flat buffer
-    self.exclusive, self.dz_ptr = False, 0
-    # DEFERRED layer (y is None): the activation output was never written; the tensor handed to the next layer holds z and
-    # every reader applies act(BN(z)) itself (include/easyrec_hip.h er_a_transform) - which needs beta as well.
     # fused: the consumer's dgrad GEMM may emit this layer's BatchNorm-backward column sums (HipBackend.fused_bn_bwd)
     self.beta, self.fused = beta, fused
-
-  @property
-  def deferred(self):
-    return self.y is None
 
 
 class BnColsView(object):
@@ -129,7 +119,7 @@ class BnColsView(object):
   the consumer's dgrad GEMM emits that layer's BatchNorm-backward column sums from those columns of its output
   (HipBackend.gemm_bn_bwd(col0=...))."""
   __slots__ = ('src', 'col0', 'ref')
-  deferred, fused, exclusive = False, True, False  # (what LinearBNActFn.forward asks of a BnSource)
+  fused = True  # (what LinearBNActFn.forward asks of a BnSource)
 
   def __init__(self, src, col0, ref):
     self.src, self.col0, self.ref = src, int(col0), ref
@@ -138,7 +128,7 @@ class BnColsView(object):
 def tag_bn_cols(joined, part, col0):
   """`joined[:, col0:col0 + part.shape[1]]` is a copy of `part`, the output of a fused dense + BatchNorm layer."""
   src = bn_source_of(part)
-  if src is not None and src.y is not None and src.fused and not src.exclusive:
+  if src is not None and src.fused:
     joined._er_bn_cols = BnColsView(src, col0, joined)
   return joined
 
@@ -151,15 +141,6 @@ def bn_cols_of(x):
   if v is None or x.dim() != 2 or x.data_ptr() != v.ref.data_ptr() or x.shape != v.ref.shape or x.stride() != v.ref.stride():
     return None
   return v
-
-
-def mark_single_consumer(y):
-  """Promise that the NEXT dense layer is the only reader of y (the output of a fused dense + BatchNorm layer): its
-  dgrad GEMM may then finish this layer's BatchNorm backward in its epilogue and hand dz, not dy, to autograd."""
-  src = bn_source_of(y)
-  if src is not None:
-    src.exclusive = True
-  return y
 
 
 def tag_bn_source(y, src):
@@ -245,46 +226,20 @@ def bn_source_of(x):
   src = getattr(x, '_er_bn_src', None)
   if src is None:
     return None
-  ref = src.y if src.y is not None else src.z
+  ref = src.y
   if x.dim() != 2 or x.data_ptr() != ref.data_ptr() or x.shape != ref.shape or x.stride() != ref.stride():
-    assert src.y is not None, 'easyrec_amd: a view of a deferred dense + BatchNorm output reached a layer (it holds ' \
-        'pre-normalisation values: only the untouched tensor may be consumed)'
     return None
   return src
-
-
-class ATransform(ctypes.Structure):  # = er_a_transform
-  _fields_ = [('mean', ctypes.c_void_p), ('invstd', ctypes.c_void_p), ('gamma', ctypes.c_void_p), ('beta', ctypes.c_void_p),
-              ('act', ctypes.c_int32)]
-
-
-class BnFinalize(ctypes.Structure):  # = er_bn_finalize
-  _fields_ = [('save_mean', ctypes.c_void_p), ('save_invstd', ctypes.c_void_p), ('moving_mean', ctypes.c_void_p),
-              ('moving_var', ctypes.c_void_p), ('eps', ctypes.c_float), ('momentum', ctypes.c_float),
-              ('counters', ctypes.c_void_p), ('n_counters', ctypes.c_int32)]
-
-
-def _ptr(t):
-  return None if t is None else t.data_ptr()
-
-
-def _a_transform(at):
-  """er_a_transform of a deferred BnSource (or None)"""
-  if at is None:
-    return None
-  return ATransform(_ptr(at.mean), _ptr(at.invstd), _ptr(at.gamma), _ptr(at.beta), int(at.act))
 
 
 class GemmProblem(ctypes.Structure):  # = er_gemm_problem
   _fields_ = [('M', ctypes.c_int32), ('N', ctypes.c_int32), ('K', ctypes.c_int32), ('A', ctypes.c_void_p),
               ('lda', ctypes.c_int32), ('B', ctypes.c_void_p), ('ldb', ctypes.c_int32), ('C', ctypes.c_void_p),
               ('ldc', ctypes.c_int32), ('bias', ctypes.c_void_p), ('accumulate', ctypes.c_int32),
-              ('a_mean', ctypes.c_void_p), ('a_invstd', ctypes.c_void_p), ('a_gamma', ctypes.c_void_p),
-              ('a_beta', ctypes.c_void_p), ('a_act', ctypes.c_int32), ('col_stats', ctypes.c_void_p),
+              ('col_stats', ctypes.c_void_p),
               ('bn_z', ctypes.c_void_p), ('bn_zbias', ctypes.c_void_p), ('bn_y', ctypes.c_void_p),
-              ('bn_mean', ctypes.c_void_p), ('bn_invstd', ctypes.c_void_p), ('bn_gamma', ctypes.c_void_p),
-              ('bn_beta', ctypes.c_void_p), ('bn_ld', ctypes.c_int32), ('bn_use_bn', ctypes.c_int32),
-              ('bn_act', ctypes.c_int32), ('bn_partial', ctypes.c_void_p)]
+              ('bn_mean', ctypes.c_void_p), ('bn_invstd', ctypes.c_void_p), ('bn_ld', ctypes.c_int32),
+              ('bn_use_bn', ctypes.c_int32), ('bn_act', ctypes.c_int32), ('bn_partial', ctypes.c_void_p)]
 
 
 class BnLayer(ctypes.Structure):  # = er_bn_layer
@@ -833,57 +788,6 @@ class HipBackend(object):
 
   # er_gemm_f32_bn_bwd / er_bn_act_bwd_from_partials are used (A/B switch: EASYREC_AMD_FUSED_BN_BWD=0)
   fused_bn_bwd = os.environ.get('EASYREC_AMD_FUSED_BN_BWD', '1') != '0'
-  # BatchNorm finished INSIDE the GEMM launch (er_gemm_f32_bn_fwd / er_gemm_f32_bn_bwd_apply): bit-identical, 10 launches
-  # fewer per DeepFM step - and SLOWER: the barrier among a column's row tiles crosses XCDs, i.e. goes through
-  # memory-side atomics at ~2 us a hop (stats out, arrive, spin, partials back in), which costs what the kernel
-  # boundary it replaces costs.  Same box, 300 steps: 0.592 / 0.597 ms fused vs 0.561 / 0.565 two-launch (with
-  # agent-scope fences instead of sc1 atomics: 0.788).  OFF by default; kept as an A/B switch and for its tests.
-  fused_bn_gemm = os.environ.get('EASYREC_AMD_FUSED_BN_GEMM', '0') != '0'
-
-  def gemm_fused_bn_ok(self, M, N):
-    return self.fused_bn_gemm and bool(self.lib.er_gemm_fused_bn_ok(ctypes.c_int32(int(M)), ctypes.c_int32(int(N))))
-
-  def gemm_bn_fwd(self, x, w, b, gamma, beta, eps, momentum, moving_mean, moving_var, act, y_out=None):
-    """One launch: z = x . w (+ b), batch statistics, y = act(BatchNorm(z)).  Returns (z, y, mean, invstd).
-    y_out: a [M, N] view (unit inner stride) to write y into, e.g. a column block of a wider buffer."""
-    (M, K), (K2, N) = x.shape, w.shape
-    assert K == K2 and x.stride(1) == 1 and w.stride(1) == 1
-    dev = x.device
-    z = torch.empty(M, N, dtype=torch.float32, device=dev)
-    y = torch.empty(M, N, dtype=torch.float32, device=dev) if y_out is None else y_out
-    assert y.shape == (M, N) and y.stride(1) == 1
-    stats = torch.empty(self.gemm_row_tiles(M) * N * 3, dtype=torch.float32, device=dev)
-    mean = torch.empty(N, dtype=torch.float32, device=dev)
-    invstd = torch.empty(N, dtype=torch.float32, device=dev)
-    self._ck(self.lib.er_gemm_f32_bn_fwd(ctypes.c_int(GEMM_NN), M, N, K, _p(x), ctypes.c_int32(x.stride(0)), _p(w),
-                                         ctypes.c_int32(w.stride(0)), _p(z), ctypes.c_int32(z.stride(0)), _p(b), _p(stats),
-                                         _p(gamma), _p(beta), ctypes.c_float(eps), ctypes.c_float(momentum),
-                                         _p(moving_mean), _p(moving_var), int(act), _p(y), ctypes.c_int32(y.stride(0)),
-                                         _p(mean), _p(invstd), _stream()), 'er_gemm_f32_bn_fwd')
-    return z, y, mean, invstd
-
-  def gemm_bn_bwd_apply(self, layout, a, b, src, accumulate=True):
-    """dgrad GEMM whose epilogue finishes the BatchNorm / activation backward of the layer described by `src`: returns
-    dz of THAT layer; its gamma / beta gradients go to src.grad_bufs."""
-    if layout == GEMM_NN:
-      (M, K), (K2, N) = a.shape, b.shape
-    elif layout == GEMM_NT:
-      (M, K), (N, K2) = a.shape, b.shape
-    else:
-      (K, M), (K2, N) = a.shape, b.shape
-    assert K == K2 and src.y.shape == (M, N) and src.z.shape == (M, N) and src.y.stride() == src.z.stride()
-    use_bn = src.mean is not None
-    self._log_gemm('gemm_f32_bn_bwd_apply_kernel', layout, M, N, K)
-    dg, dbt = src.grad_bufs if src.grad_bufs is not None else (None, None)
-    partial = torch.empty(self.gemm_row_tiles(M) * N * 2, dtype=torch.float32, device=a.device)
-    out = torch.empty(M, N, dtype=torch.float32, device=a.device)
-    self._ck(self.lib.er_gemm_f32_bn_bwd_apply(
-        ctypes.c_int(layout), M, N, K, _p(a), ctypes.c_int32(a.stride(0)), _p(b), ctypes.c_int32(b.stride(0)), _p(out),
-        ctypes.c_int32(out.stride(0)), _p(src.z), _p(src.zbias), _p(src.y), _p(src.mean), _p(src.invstd),
-        ctypes.c_int32(src.y.stride(0)), int(use_bn), int(src.act), _p(src.gamma), _p(partial), _p(dg), _p(dbt), None,
-        int(bool(accumulate)), _stream()), 'er_gemm_f32_bn_bwd_apply')
-    return out
-
   # the BatchNorm-backward column sums of a layer whose output is a column block of the consumer's input (DeepFM's deep
   # tower inside [sum(wide) | FM | deep]) from the consumer's dgrad epilogue (er_gemm_f32_bn_bwd_cols); A/B switch
   bn_cols_epilogue = os.environ.get('EASYREC_AMD_BN_COLS_EPILOGUE', '1') != '0'
@@ -912,18 +816,11 @@ class HipBackend(object):
                                                 _p(partial), ctypes.c_int32(int(col0)), ctypes.c_int32(n_src), _stream()),
                'er_gemm_f32_bn_bwd_cols')
       return out
-    assert K == K2 and src.z.shape == (M, N) and (src.y is None or (src.y.shape == (M, N) and src.y.stride() == src.z.stride()))
+    assert K == K2 and src.z.shape == (M, N) and src.y.shape == (M, N) and src.y.stride() == src.z.stride()
     assert partial.numel() >= self.gemm_row_tiles(M) * N * 2
     self._log_gemm('gemm_f32_bn_bwd_kernel', layout, M, N, K)
     out = torch.empty(M, N, dtype=torch.float32, device=a.device)
     use_bn = src.mean is not None
-    if src.y is None or self._mask_from_z(use_bn, src.act, src.gamma, src.beta):  # the ReLU mask is recomputed from z
-      self._ck(self.lib.er_gemm_f32_bn_bwd_z(ctypes.c_int(layout), M, N, K, _p(a), ctypes.c_int32(a.stride(0)), _p(b),
-                                             ctypes.c_int32(b.stride(0)), _p(out), ctypes.c_int32(out.stride(0)),
-                                             _p(src.z), _p(src.zbias), _p(src.gamma), _p(src.beta), _p(src.mean),
-                                             _p(src.invstd), ctypes.c_int32(src.z.stride(0)), int(use_bn), int(src.act),
-                                             _p(partial), _stream()), 'er_gemm_f32_bn_bwd_z')
-      return out
     self._ck(self.lib.er_gemm_f32_bn_bwd(ctypes.c_int(layout), M, N, K, _p(a), ctypes.c_int32(a.stride(0)), _p(b),
                                          ctypes.c_int32(b.stride(0)), _p(out), ctypes.c_int32(out.stride(0)),
                                          _p(src.z), _p(src.zbias), _p(src.y), _p(src.mean), _p(src.invstd),
@@ -938,16 +835,6 @@ class HipBackend(object):
   # er_bn_bwd_multi)
   grouped_bn = os.environ.get('EASYREC_AMD_GROUPED_BN', '1') != '0'  # A/B switch
   BN_MULTI_MAX_ROWS = 8192  # (taller layers reduce their partial sums in a merge launch of their own: single launches)
-
-  # BatchNorm + ReLU layers: the backward kernels can recompute the ReLU mask from z (one multiply-add chain, the forward's
-  # own operation sequence: the same bits as y > 0, tests) instead of reading y - a quarter of their traffic.  OFF:
-  # measured no faster (same box, BatchNorm family per step: MMoE 500 us against 504, DeepFM 91.5 against 90.0) and slower
-  # on DIN's tall layers (591 against 557) - these kernels wait on their dependent round trips, not on bytes.
-  recompute_relu_mask = os.environ.get('EASYREC_AMD_BN_RECOMPUTE_MASK', '0') != '0'  # A/B switch
-
-  def _mask_from_z(self, use_bn, act, gamma, beta):
-    return self.recompute_relu_mask and int(use_bn) != BN_NONE and int(act) == ACT_RELU and gamma is not None and \
-        beta is not None
 
   def bn_fwd_multi(self, layers):
     """layers: [dict(x, bias, gamma, beta, moving_mean, moving_var, col_stats, use_bn, act, eps, momentum)] -> [(y, mean,
@@ -998,7 +885,7 @@ class HipBackend(object):
       q.x, q.bias, q.gamma, q.beta = x.data_ptr(), _ptr(l.get('bias')), _ptr(l.get('gamma')), _ptr(l.get('beta'))
       q.B, q.N, q.use_bn, q.act = B, N, int(l['use_bn']), int(l['act'])
       q.save_mean, q.save_invstd = _ptr(l.get('mean')), _ptr(l.get('invstd'))
-      q.y_in = None if self._mask_from_z(l['use_bn'], l['act'], l.get('gamma'), l.get('beta')) else _ptr(l['y'])
+      q.y_in = _ptr(l['y'])
       q.dy, q.dy_ld = dy.data_ptr(), dy.stride(0)
       if partial is not None:
         q.partial, q.chunks = partial.data_ptr(), self.gemm_row_tiles(B)
@@ -1007,59 +894,6 @@ class HipBackend(object):
       outs.append((dx, None, None, None) if into is not None else (dx, dbias, dgamma, dbeta))
     self._ck(self.lib.er_bn_bwd_multi(arr, len(layers), _stream()), 'er_bn_bwd_multi')
     return outs
-
-  # -- deferred BatchNorm + activation (include/easyrec_hip.h er_a_transform / er_bn_finalize)
-  # OFF by default - built, bit-identical to the materialised form (tests), and SLOWER on MI355X at these sizes: what the
-  # deferred form removes is one normalise + activate launch per hidden layer (7.8 us for a batch-sized layer), what it
-  # adds is the statistics' finalisation inside the GEMM launch - partial stores, an arrival counter and the last
-  # workgroup's loads all cross XCDs through memory-side (sc1) accesses at ~2 us a hop, the same wall the in-GEMM barrier
-  # of fused_bn_gemm hit - plus a parameter-table prologue in every reader: DeepFM-Criteo 0.524 ms deferred against 0.488
-  # (GEMM family 282 us against 222, BatchNorm 69 against 95); DIN 10 M 3.21 ms against 2.66 (one workgroup merging the
-  # 3,200 row-tile partials of a [B x L]-row layer is a 50 us serial tail).  profiles/r03_deferred_bn.md.
-  deferred_bn = os.environ.get('EASYREC_AMD_DEFER_BN', '0') != '0'  # A/B switch
-
-  def _bn_counters(self, device):
-    """arrival counters of er_bn_finalize: one zero-initialised buffer per calling thread and device (the launches of one
-    thread are stream-ordered; the simulated ranks of the tests are threads)"""
-    bufs = getattr(_bn_tls, 'counters', None)
-    if bufs is None:
-      bufs = _bn_tls.counters = {}
-    key = str(device)
-    if key not in bufs:
-      bufs[key] = torch.zeros(512, dtype=torch.int32, device=device)
-    return bufs[key]
-
-  def gemm_deferred(self, layout, a, b, at=None, out=None, bias=None, accumulate=False, col_stats=None, fin=None):
-    """gemm() with the A operand transformed while staged (at: the BnSource of a deferred layer whose z `a` holds) and /
-    or the output's batch statistics finalised by the launch (fin = (save_mean, save_invstd, moving_mean, moving_var, eps,
-    momentum); needs col_stats)."""
-    assert a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1
-    assert a.dtype == torch.float32 and b.dtype == torch.float32
-    if layout == GEMM_NN:
-      (M, K), (K2, N) = a.shape, b.shape
-    elif layout == GEMM_NT:
-      (M, K), (N, K2) = a.shape, b.shape
-    else:
-      (K, M), (K2, N) = a.shape, b.shape
-    assert K == K2, 'gemm: inner dimensions %d vs %d' % (K, K2)
-    if out is None:
-      assert not accumulate
-      out = torch.empty(M, N, dtype=torch.float32, device=a.device)
-    assert out.shape == (M, N) and out.stride(1) == 1 and out.dtype == torch.float32
-    self._log_gemm('gemm_f32_tr_kernel' if at is not None else 'gemm_f32_kernel', layout, M, N, K)
-    tr = _a_transform(at)
-    fz = None
-    if fin is not None:
-      mean, invstd, mm, mv, eps, momentum = fin
-      assert col_stats is not None and col_stats.numel() >= self.gemm_row_tiles(M) * N * 3
-      cnt = self._bn_counters(a.device)
-      fz = BnFinalize(_ptr(mean), _ptr(invstd), _ptr(mm), _ptr(mv), float(eps), float(momentum), cnt.data_ptr(), cnt.numel())
-    self._ck(self.lib.er_gemm_f32_deferred(ctypes.c_int(layout), M, N, K, _p(a), ctypes.c_int32(a.stride(0)),
-                                           ctypes.byref(tr) if tr is not None else None, _p(b), ctypes.c_int32(b.stride(0)),
-                                           _p(out), ctypes.c_int32(out.stride(0)), _p(bias), int(bool(accumulate)),
-                                           _p(col_stats), ctypes.byref(fz) if fz is not None else None, _stream()),
-             'er_gemm_f32_deferred')
-    return out
 
   def gemm_grouped(self, layout, problems, bf16=False):
     """problems: [(a, b, out, bias, accumulate)] fp32, one layout: ONE launch (+ one for the split-K reduces).
@@ -1075,13 +909,8 @@ class HipBackend(object):
     arr = (GemmProblem * len(problems))()
     for q, pr in zip(arr, problems):
       a, b, out, bias, accumulate = pr[:5]
-      at = pr[5] if len(pr) > 5 else None
-      stats = pr[6] if len(pr) > 6 else None
-      bn = pr[7] if len(pr) > 7 else None  # (BnSource of the layer that produced this problem's output position, partial)
-      if at is not None:
-        assert layout != GEMM_NT and at.deferred
-        q.a_mean, q.a_invstd, q.a_gamma, q.a_beta, q.a_act = _ptr(at.mean), _ptr(at.invstd), _ptr(at.gamma), \
-            _ptr(at.beta), int(at.act)
+      stats = pr[5] if len(pr) > 5 else None
+      bn = pr[6] if len(pr) > 6 else None  # (BnSource of the layer that produced this problem's output position, partial)
       assert a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1 and out.stride(1) == 1
       assert a.dtype == torch.float32 and b.dtype == torch.float32 and out.dtype == torch.float32
       if layout == GEMM_NN:
@@ -1097,7 +926,7 @@ class HipBackend(object):
         elif bf16:
           self._log_gemm('gemm_bf16_grouped_kernel', layout, M, N, K)
         else:
-          self._log_gemm('gemm_f32_grouped_tr_kernel' if at is not None else 'gemm_f32_grouped_kernel', layout, M, N, K)
+          self._log_gemm('gemm_f32_grouped_kernel', layout, M, N, K)
       q.M, q.N, q.K = M, N, K
       q.A, q.lda, q.B, q.ldb = a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0)
       q.C, q.ldc = out.data_ptr(), out.stride(0)
@@ -1110,8 +939,8 @@ class HipBackend(object):
         src, partial = bn
         assert src.z.shape == (M, N) and partial.numel() >= self.gemm_row_tiles(M) * N * 2 and not accumulate
         q.bn_z, q.bn_zbias = _ptr(src.z), _ptr(src.zbias)
-        q.bn_y = None if self._mask_from_z(src.mean is not None, src.act, src.gamma, src.beta) else _ptr(src.y)
-        q.bn_mean, q.bn_invstd, q.bn_gamma, q.bn_beta = _ptr(src.mean), _ptr(src.invstd), _ptr(src.gamma), _ptr(src.beta)
+        q.bn_y = _ptr(src.y)
+        q.bn_mean, q.bn_invstd = _ptr(src.mean), _ptr(src.invstd)
         q.bn_ld, q.bn_use_bn, q.bn_act = src.z.stride(0), int(src.mean is not None), int(src.act)
         q.bn_partial = partial.data_ptr()
     return arr
@@ -1155,8 +984,8 @@ class HipBackend(object):
 
   @staticmethod
   def wgrads_fit_the_tail(q):
-    """plain fp32 contractions only (no deferred-BatchNorm operand), at most one grouped launch's worth"""
-    return 0 < len(q) <= 16 and all((len(pr) <= 5 or pr[5] is None) and len(pr) <= 6 for pr in q)
+    """plain fp32 contractions only, at most one grouped launch's worth"""
+    return 0 < len(q) <= 16 and all(len(pr) <= 5 for pr in q)
 
   # -- K12 embedding-parallel routing (include/easyrec_hip.h)
   def emb_group_set_routing(self, group, world, shard_stride, local_base):
@@ -1839,8 +1668,7 @@ class HipBackend(object):
                  partial=None, beta=None):
     """into = (dbias_buf, dgamma_buf, dbeta_buf) (each may be None): accumulate the parameter gradients
     into those buffers (slices of the flat gradient buffer) instead of returning new tensors.
-    partial: column sums [gemm_row_tiles(B)][N][2] already produced by gemm_bn_bwd (skips that pass).
-    y None (a deferred layer: never written): the activation's mask is recomputed from x with gamma / beta."""
+    partial: column sums [gemm_row_tiles(B)][N][2] already produced by gemm_bn_bwd (skips that pass)."""
     B, N = x.shape
     dx = torch.empty_like(x)
     dev = x.device
@@ -1852,16 +1680,7 @@ class HipBackend(object):
       dgamma = torch.empty(N, dtype=torch.float32, device=dev) if need_affine else None
       dbeta = torch.empty(N, dtype=torch.float32, device=dev) if need_affine else None
     assert dy.dim() == 2 and dy.stride(1) == 1 and dy.dtype == torch.float32
-    if y is not None and self._mask_from_z(use_bn, act, gamma, beta):
-      y = None
-    if y is None:
-      dyl = dy if partial is None else _f32c(dy)
-      self._ck(
-          self.lib.er_bn_act_bwd_z(_p(x), _p(bias), _p(gamma), _p(beta), _p(mean), _p(invstd), _p(dyl),
-                                   ctypes.c_int32(dyl.stride(0)), B, N, int(use_bn), int(act), _p(partial),
-                                   ctypes.c_int32(self.gemm_row_tiles(B) if partial is not None else 0), _p(dx),
-                                   _p(dbias), _p(dgamma), _p(dbeta), int(acc), _stream()), 'er_bn_act_bwd_z')
-    elif partial is None and dy.stride(0) != N:  # a column block of a wider gradient (ConcatFn's backward): read in place
+    if partial is None and dy.stride(0) != N:  # a column block of a wider gradient (ConcatFn's backward): read in place
       self._ck(
           self.lib.er_bn_act_bwd_ld(_p(x), _p(bias), _p(gamma), _p(y), _p(mean), _p(invstd), _p(dy),
                                     ctypes.c_int32(dy.stride(0)), B, N, int(use_bn), int(act), _p(dx), _p(dbias),
@@ -2249,15 +2068,10 @@ class LinearFn(torch.autograd.Function):
   def forward(ctx, x, w, b, w_grad, b_grad, bf16, src=None, sink=None):
     be = hip()
     x2 = x if x.stride(-1) == 1 else x.contiguous()
-    at = src if (src is not None and src.deferred) else None  # x holds a deferred layer's z: transformed by the GEMM
-    assert at is None or (x2 is x and not bf16)
-    if at is not None:
-      y = be.gemm_deferred(GEMM_NN, x2, w, at=at, bias=b)
-    else:
-      y = be.gemm(GEMM_NN, x2, w, bias=b, bf16=bf16)
+    y = be.gemm(GEMM_NN, x2, w, bias=b, bf16=bf16)
     ctx.save_for_backward(x2, w)
     ctx.has_bias = b is not None
-    ctx.w_grad, ctx.b_grad, ctx.bf16, ctx.at = w_grad, b_grad, bf16, at
+    ctx.w_grad, ctx.b_grad, ctx.bf16 = w_grad, b_grad, bf16
     ctx.sink = be.wgrad_sink()
     ctx.src = src if (src is not None and x2 is x and not bf16 and src.fused and getattr(be, 'fused_bn_bwd', False)) else None
     ctx.gsink = sink if x2 is x else None
@@ -2274,7 +2088,7 @@ class LinearFn(torch.autograd.Function):
     if ctx.needs_input_grad[0]:
       dx = _dgrad(be, dy, w, ctx.src, ctx.bf16, ctx.gsink, x, ctx.slots)
     if ctx.needs_input_grad[1]:
-      dw = _wgrad(be, x, dy, ctx.w_grad, ctx.bf16, ctx.at, ctx.sink)
+      dw = _wgrad(be, x, dy, ctx.w_grad, ctx.bf16, ctx.sink)
     if ctx.has_bias and ctx.needs_input_grad[2]:
       if ctx.b_grad is not None:
         be.colsum(dy, out=ctx.b_grad, accumulate=True)  # straight into the flat gradient buffer
@@ -2361,7 +2175,7 @@ class HeadFn(torch.autograd.Function):
     if ctx.needs_input_grad[0]:
       dx = _dgrad(be, dy, w, st.src, st.bf16, None)
     if ctx.needs_input_grad[1]:
-      dw = _wgrad(be, x, dy, st.w_grad, st.bf16, None, ctx.sink)
+      dw = _wgrad(be, x, dy, st.w_grad, st.bf16, ctx.sink)
     if ctx.has_bias and ctx.needs_input_grad[2]:
       if st.b_grad is not None:
         be.colsum(dy, out=st.b_grad, accumulate=True)
@@ -2370,18 +2184,13 @@ class HeadFn(torch.autograd.Function):
     return dx, dw, db, None, None, None, None, None
 
 
-def _wgrad(be, x, dz, w_grad, bf16, at, sink):
+def _wgrad(be, x, dz, w_grad, bf16, sink):
   """dW = x^T . dz: queued for the grouped launch (accumulating into w_grad, a slice of the flat gradient buffer), else
-  launched here; `at`: x holds a deferred layer's z and is transformed while staged.  Returns dW only without w_grad."""
+  launched here.  Returns dW only without w_grad."""
   if w_grad is not None:
-    if not sink.put(x, dz, w_grad, bf16, at):
-      if at is not None:
-        be.gemm_deferred(GEMM_TN, x, dz, at=at, out=w_grad, accumulate=True)
-      else:
-        be.gemm(GEMM_TN, x, dz, out=w_grad, accumulate=True, bf16=bf16)
+    if not sink.put(x, dz, w_grad, bf16):
+      be.gemm(GEMM_TN, x, dz, out=w_grad, accumulate=True, bf16=bf16)
     return None
-  if at is not None:
-    return be.gemm_deferred(GEMM_TN, x, dz, at=at)
   return be.gemm(GEMM_TN, x, dz, bf16=bf16)
 
 
@@ -2406,18 +2215,12 @@ def _dgrad(be, dz, w, src, bf16, sink=None, x=None, slots=None):
   M, N = dz.shape[0], w.shape[0]
   if isinstance(src, BnColsView):
     inner = src.src
-    if bf16 or be._mask_from_z(inner.mean is not None, inner.act, inner.gamma, inner.beta):
+    if bf16:
       return be.gemm(GEMM_NT, dz, w, bf16=bf16)
     n_src = inner.y.shape[1]
     partial = torch.empty(be.gemm_row_tiles(M) * n_src * 2, dtype=torch.float32, device=dz.device)
     dx = be.gemm_bn_bwd(GEMM_NT, dz, w, inner, partial, col0=src.col0)
     inner.partial, inner.dx_ptr = partial, dx.data_ptr() + 4 * src.col0  # (what the block's view of dx starts at)
-    return dx
-  if src.exclusive and src.y is not None and src.grad_bufs is not None and getattr(be, 'gemm_fused_bn_ok', None) and \
-      be.gemm_fused_bn_ok(M, N):
-    # this GEMM is the only reader of the producing layer's output: finish that layer's BatchNorm backward here
-    dx = be.gemm_bn_bwd_apply(GEMM_NT, dz, w, src)
-    src.dz_ptr = dx.data_ptr()
     return dx
   partial = torch.empty(be.gemm_row_tiles(M) * N * 2, dtype=torch.float32, device=dz.device)
   dx = be.gemm_bn_bwd(GEMM_NT, dz, w, src, partial)
@@ -2434,50 +2237,26 @@ class LinearBNActFn(torch.autograd.Function):
 
   @staticmethod
   def forward(ctx, x, w, b, gamma, beta, moving_mean, moving_var, eps, momentum, act, bf16, grad_bufs, src=None,
-              sink=None, defer=False):
-    """defer: do not write y - return z tagged as a DEFERRED output (BnSource.deferred); the caller guarantees that
-    every reader is a dense layer of this package (layers/dnn.py: the inner layers of a stack)."""
+              sink=None):
     be = hip()
     x2 = x if x.stride(-1) == 1 else x.contiguous()
     M, N = x2.shape[0], w.shape[1]
-    at = src if (src is not None and src.deferred) else None  # x holds a deferred layer's z: transformed by the GEMM
-    assert at is None or (x2 is x and not bf16)
-    defer = bool(defer) and not bf16 and getattr(be, 'deferred_bn', False)
-    y = None
-    if defer or at is not None:
-      chunks = be.gemm_row_tiles(M)
-      stats = torch.empty(chunks * N * 3, dtype=torch.float32, device=x2.device)
-      if defer:
-        # ONE launch: GEMM (+ the producer's BatchNorm / ReLU on its A operand) + bias + column statistics, finalised by
-        # the last workgroup of each column of tiles; y is never written
-        mean = torch.empty(N, dtype=torch.float32, device=x2.device)
-        invstd = torch.empty(N, dtype=torch.float32, device=x2.device)
-        z = be.gemm_deferred(GEMM_NN, x2, w, at=at, bias=b, col_stats=stats,
-                             fin=(mean, invstd, moving_mean, moving_var, eps, momentum))
-      else:
-        z = be.gemm_deferred(GEMM_NN, x2, w, at=at, bias=b, col_stats=stats)
-        y, mean, invstd = be.bn_apply_from_stats(z, None, stats, chunks, gamma, beta, eps, momentum, moving_mean,
-                                                 moving_var, act)
-    elif not bf16 and getattr(be, 'gemm_fused_bn_ok', None) and be.gemm_fused_bn_ok(M, N):
-      # ONE launch: GEMM, statistics, barrier, normalise + activation from registers
-      z, y, mean, invstd = be.gemm_bn_fwd(x2, w, b, gamma, beta, eps, momentum, moving_mean, moving_var, act)
-    else:
-      chunks = be.gemm_row_tiles(M)
-      stats = torch.empty(chunks * N * 3, dtype=torch.float32, device=x2.device)
-      z = be.gemm(GEMM_NN, x2, w, bias=b, bf16=bf16, col_stats=stats)
-      y, mean, invstd = be.bn_apply_from_stats(z, None, stats, chunks, gamma, beta, eps, momentum, moving_mean,
-                                               moving_var, act)
+    chunks = be.gemm_row_tiles(M)
+    stats = torch.empty(chunks * N * 3, dtype=torch.float32, device=x2.device)
+    z = be.gemm(GEMM_NN, x2, w, bias=b, bf16=bf16, col_stats=stats)
+    y, mean, invstd = be.bn_apply_from_stats(z, None, stats, chunks, gamma, beta, eps, momentum, moving_mean,
+                                             moving_var, act)
     ctx.save_for_backward(x2, w, gamma, beta, z, y, mean, invstd)
-    ctx.act, ctx.bf16, ctx.grad_bufs, ctx.at = act, bf16, grad_bufs, at
+    ctx.act, ctx.bf16, ctx.grad_bufs = act, bf16, grad_bufs
     ctx.sink = be.wgrad_sink()
     fused = not bf16 and getattr(be, 'fused_bn_bwd', False)
     ctx.src = src if (src is not None and x2 is x and fused and src.fused) else None
     ctx.gsink = sink if x2 is x else None
     gb = None if grad_bufs is None else (grad_bufs[1], grad_bufs[2])
     # (z already carries the bias)
-    ctx.own = BnSource(z, None, y, mean, invstd, act, gamma, gb, beta=beta, fused=fused) if (fused or defer) else None
+    ctx.own = BnSource(z, None, y, mean, invstd, act, gamma, gb, beta=beta, fused=fused) if fused else None
     _bn_tls.last = ctx.own
-    return z if defer else y
+    return y
 
   @staticmethod
   def backward(ctx, dy):
@@ -2489,27 +2268,19 @@ class LinearBNActFn(torch.autograd.Function):
     dyc = dy if (dy.dim() == 2 and dy.stride(1) == 1) else dy.contiguous()
     own, partial = ctx.own, None
     dgamma = dbeta = None
-    if own is not None and own.dz_ptr:
-      # the (single) consumer's dgrad GEMM finished this layer's BatchNorm backward: what arrives is dz
-      if dyc.data_ptr() != own.dz_ptr:
-        raise RuntimeError('easyrec_amd: the output of a fused dense + BatchNorm layer marked single-consumer '
-                           '(kernels.mark_single_consumer) reached a second consumer; set EASYREC_AMD_FUSED_BN_GEMM=0')
-      own.dz_ptr = 0
-      dz = dyc
-    else:
-      if own is not None:
-        # the consumer's dgrad GEMM already reduced the column sums, provided dy is exactly its output
-        if own.partial is not None and dyc.data_ptr() == own.dx_ptr:
-          partial = own.partial
-        own.partial = None
-      dz, _, dgamma, dbeta = be.bn_act_bwd(z, None, gamma, y, mean, invstd, dyc, 1, ctx.act, False, True,
-                                           into=(None, gg, betag) if direct else None, partial=partial, beta=beta)
+    if own is not None:
+      # the consumer's dgrad GEMM already reduced the column sums, provided dy is exactly its output
+      if own.partial is not None and dyc.data_ptr() == own.dx_ptr:
+        partial = own.partial
+      own.partial = None
+    dz, _, dgamma, dbeta = be.bn_act_bwd(z, None, gamma, y, mean, invstd, dyc, 1, ctx.act, False, True,
+                                         into=(None, gg, betag) if direct else None, partial=partial, beta=beta)
     dx = dw = None
     if ctx.needs_input_grad[0]:
       dx = _dgrad(be, dz, w, ctx.src, ctx.bf16, ctx.gsink)
     if ctx.needs_input_grad[1]:
-      dw = _wgrad(be, x, dz, wg, ctx.bf16, ctx.at, ctx.sink)
-    return dx, dw, None, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
+      dw = _wgrad(be, x, dz, wg, ctx.bf16, ctx.sink)
+    return dx, dw, None, dgamma, dbeta, None, None, None, None, None, None, None, None, None
 
 
 class GroupedLinearFn(torch.autograd.Function):
@@ -2531,7 +2302,7 @@ class GroupedLinearFn(torch.autograd.Function):
     # srcs[e]: the BnSource of x_e when it IS the output of a dense + BatchNorm(train) layer: the input-gradient launch
     # then also emits that layer's BatchNorm-backward column sums (er_gemm_problem.bn_*)
     fused = getattr(be, 'fused_bn_bwd', False)
-    ctx.srcs = [sc if (fused and sc is not None and sc.fused and not sc.deferred and x.stride(-1) == 1) else None
+    ctx.srcs = [sc if (fused and sc is not None and sc.fused and x.stride(-1) == 1) else None
                 for sc, x in zip(srcs, xs)]
     xs = [x if x.stride(-1) == 1 else x.contiguous() for x in xs]
     zs, stats, problems = [], [], []
@@ -2541,7 +2312,7 @@ class GroupedLinearFn(torch.autograd.Function):
       st = torch.empty(be.gemm_row_tiles(M) * N * 3, dtype=torch.float32, device=z.device) if stats_mask[e] else None
       zs.append(z)
       stats.append(st if st is not None else torch.empty(0, device=z.device))
-      problems.append((xs[e], ws[e].detach(), z, None if bs[e] is None else bs[e].detach(), False, None, st))
+      problems.append((xs[e], ws[e].detach(), z, None if bs[e] is None else bs[e].detach(), False, st))
     be.gemm_grouped(GEMM_NN, problems)
     ctx.save_for_backward(*xs, *ws)
     ctx.E, ctx.bs = E, bs
@@ -2579,7 +2350,7 @@ class GroupedLinearFn(torch.autograd.Function):
         else:
           M, N = dxs[e].shape
           partial = torch.empty(be.gemm_row_tiles(M) * N * 2, dtype=torch.float32, device=dxs[e].device)
-          problems.append((dzs[e], ws[e], dxs[e], None, False, None, None, (src, partial)))
+          problems.append((dzs[e], ws[e], dxs[e], None, False, None, (src, partial)))
           src.partial, src.dx_ptr = partial, dxs[e].data_ptr()
       be.gemm_grouped(GEMM_NT, problems)
     for es in by_input.values():
@@ -2614,7 +2385,7 @@ class GroupedLinearFn(torch.autograd.Function):
       if dzs[e] is None:
         continue
       if ctx.needs_input_grad[4 + E + e]:
-        dws[e] = _wgrad(be, xs[e], dzs[e], ctx.wgrads[e], False, None, ctx.sink)
+        dws[e] = _wgrad(be, xs[e], dzs[e], ctx.wgrads[e], False, ctx.sink)
       b = ctx.bs[e]
       # (a layer whose output feeds BatchNorm on batch statistics - stats_mask - has a bias gradient of exactly zero)
       if b is not None and not ctx.stats_mask[e] and ctx.needs_input_grad[4 + 2 * E + e]:

@@ -53,10 +53,8 @@ def dense(x, units, name, l2_reg=None, use_bias=True, kernel_initializer='glorot
 
 
 def dense_bn_act(x, units, name, l2_reg, use_bias, use_bn, act_relu, training, bn_name=None,
-                 kernel_initializer='glorot_uniform', defer=False):
-  """GEMM followed by the fused bias + BatchNorm(train) + ReLU kernel.  defer: the caller promises that the ONLY reader of
-  the result is the next dense layer of this module - the layer then writes its pre-normalisation values only and the
-  reader's GEMMs apply BatchNorm + ReLU while staging them (kernels.LinearBNActFn; include/easyrec_hip.h er_a_transform)."""
+                 kernel_initializer='glorot_uniform'):
+  """GEMM followed by the fused bias + BatchNorm(train) + ReLU kernel."""
   ctx = context.current()
   vs = ctx.varstore
   in_dim = x.shape[-1]
@@ -80,8 +78,7 @@ def dense_bn_act(x, units, name, l2_reg, use_bias, use_bn, act_relu, training, b
     bf16 = getattr(ctx, 'dense_dtype', 'f32') == 'bf16'
     y = kernels.LinearBNActFn.apply(x if x.dim() == 2 else x.reshape(-1, in_dim), w, b, gamma, beta,
                                     None if freeze else mm, None if freeze else mv, BN_EPSILON, BN_MOMENTUM, act, bf16,
-                                    bufs, kernels.bn_source_of(x) or kernels.bn_cols_of(x), kernels.grad_sink_of(x),
-                                    bool(defer) and x.dim() == 2)
+                                    bufs, kernels.bn_source_of(x) or kernels.bn_cols_of(x), kernels.grad_sink_of(x))
     src = kernels.take_last_bn_source()
     y = y.reshape(shape[:-1] + (units,))
     return kernels.tag_bn_source(y, src) if src is not None else y
@@ -280,7 +277,7 @@ class DNN(object):
     lead_shape = None
     if deep_fea.dim() > 2 and not hidden_layer_feature_output:
       # [B, L, d] inputs (DIN's attention MLP): the whole stack runs on the flattened [B * L, d] view - BatchNorm
-      # normalises over every axis but the last either way - so that its inner layers can hand over deferred outputs
+      # normalises over every axis but the last either way
       lead_shape = deep_fea.shape[:-1]
       deep_fea = deep_fea.reshape(-1, deep_fea.shape[-1])
     for i, unit in enumerate(self.hidden_units):
@@ -288,14 +285,7 @@ class DNN(object):
       use_bn = self._config.use_bn and ((i + 1 < hidden_units_len) or not self._last_layer_no_batch_norm)
       use_act = (i + 1 < hidden_units_len) or not self._last_layer_no_activation
       fuse_relu = use_act and is_relu(self._act_string)
-      # an inner layer whose output only the next layer's GEMMs read: nothing but dense -> BatchNorm -> (ReLU) in between
-      no_dropout = not (len(self.dropout_ratio) > 0 and self._is_training and self.dropout_ratio[i] > 0)
-      defer = (i + 1 < hidden_units_len) and use_bn and (fuse_relu or not use_act or self.activation is None) and \
-          no_dropout and not hidden_layer_feature_output
-      deep_fea = dense_bn_act(deep_fea, unit, layer, self._l2_reg, True, use_bn, fuse_relu, self._is_training,
-                              defer=defer)
-      if i + 1 < hidden_units_len and not hidden_layer_feature_output:
-        kernels.mark_single_consumer(deep_fea)  # (the next layer's GEMM is its only reader, unless replaced below)
+      deep_fea = dense_bn_act(deep_fea, unit, layer, self._l2_reg, True, use_bn, fuse_relu, self._is_training)
       if use_act and not fuse_relu and self.activation is not None:
         deep_fea = self.activation(deep_fea, name='%s/dnn_%d/act' % (self._name, i))
       if len(self.dropout_ratio) > 0 and self._is_training:

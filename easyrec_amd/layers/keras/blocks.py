@@ -60,7 +60,6 @@ class MLP(object):
     for i, u in enumerate(self.units[:-1]):
       x = self._layer(x, i, u, self.use_bn, self.activation, self.use_bias,
                       self.dropout_rate[i] if i < nd else 0.0, training)
-      kernels.mark_single_consumer(x)  # the next layer's GEMM is the only reader of an inner layer's output
     x = self._layer(x, n, self.units[-1], self.use_final_bn, self.final_activation, self.use_final_bias,
                     self.dropout_rate[n] if nd > n else 0.0, training)
     if self.add_to_outputs and 'prediction_dict' in kwargs:

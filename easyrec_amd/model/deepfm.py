@@ -52,14 +52,12 @@ class DeepFM(RankModel):
       kernels.tag_bn_cols(joined, deep, 1 + D)  # (the deep tower's last BatchNorm backward: sums from final_dnn's dgrad)
       self._fm_outputs = joined[:, 1:1 + D]
       top = self._dnn(joined, own.final_dnn, 'final_dnn')
-      kernels.mark_single_consumer(top)  # read by the `output` projection alone
       return self._emit(dnn.dense(top, self._num_class, 'output', l2_reg=self._l2_reg, head=True))
     wide = kernels.RowSumFn.apply(self._wide_features, wide_sink)
     self._fm_outputs = pairwise = fm.FM(name='fm_feature')(self._fm_features)
     deep = self._dnn(self._deep_features, own.dnn, 'deep_feature')
     if len(own.final_dnn.hidden_units) > 0:
       top = self._dnn(kernels.concat_cols([wide, pairwise, deep]), own.final_dnn, 'final_dnn')
-      kernels.mark_single_consumer(top)  # read by the `output` projection alone
       return self._emit(dnn.dense(top, self._num_class, 'output', l2_reg=self._l2_reg, head=True))
     # without a final_dnn the three parts ARE logits and add up (deepfm.py:90-105)
     deep_logit = dnn.dense(deep, self._num_class, 'deep_logits', l2_reg=self._l2_reg)

@@ -788,27 +788,6 @@ int er_gemm_f32_bn_bwd_cols(int layout, int32_t M, int32_t N, int32_t K, const f
                             int32_t ldb, float* C, int32_t ldc, const float* z, const float* z_bias, const float* y,
                             const float* save_mean, const float* save_invstd, int32_t ld_zy, int use_bn, int act,
                             float* partial, int32_t col0, int32_t n_src, er_stream_t stream);
-/* dense + BatchNorm(train) + activation of one DNN layer in ONE launch (reference layers/dnn.py:57-79: MatMul, BiasAdd,
- * FusedBatchNorm / moments, Relu): the GEMM's workgroups publish per-row-tile column statistics (col_stats scratch,
- * er_gemm_row_tiles(M) * N * 3 floats), meet at a barrier per column of tiles, finalise the statistics (same order
- * as er_bn_apply_from_stats: bit-identical results) and write Z = A.B + bias (kept for the backward) and
- * Y = act(gamma * (Z - mean) * invstd + beta) from registers; save_mean / save_invstd [N] and the moving statistics
- * (NULL: untouched) as er_bn_act_fwd.  The grid must be co-resident: er_gemm_fused_bn_ok(M, N) != 0 (after
- * er_gemm_reserve), else use er_gemm_f32 + er_bn_apply_from_stats.
- * er_gemm_f32_bn_bwd_apply: the dgrad GEMM DY = A.B (as er_gemm_f32_bn_bwd) that goes on, after the same kind of
- * barrier, to the BatchNorm / activation backward of the layer that produced its output's forward value (z, y, mean,
- * invstd, gamma): DZ is written instead of DY, dgamma / dbeta (or dbias without BatchNorm; any may be NULL) are
- * written or accumulated.  Replaces er_gemm_f32_bn_bwd + er_bn_act_bwd_from_partials, bit-identically. */
-int er_gemm_fused_bn_ok(int32_t M, int32_t N);
-int er_gemm_f32_bn_fwd(int layout, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B,
-                       int32_t ldb, float* Z, int32_t ldz, const float* bias, float* col_stats, const float* gamma,
-                       const float* beta, float eps, float momentum, float* moving_mean, float* moving_var, int act,
-                       float* Y, int32_t ldy, float* save_mean, float* save_invstd, er_stream_t stream);
-int er_gemm_f32_bn_bwd_apply(int layout, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B,
-                             int32_t ldb, float* DZ, int32_t ldc, const float* z, const float* z_bias, const float* y,
-                             const float* save_mean, const float* save_invstd, int32_t ld_zy, int use_bn, int act,
-                             const float* gamma, float* partial, float* dgamma, float* dbeta, float* dbias,
-                             int accumulate, er_stream_t stream);
 /* Grouped launch: n independent fp32 problems of ONE layout in one grid (+ one grid for their split-K reduces).
  * The use: the weight gradients dW_l = x_l^T . dz_l of every dense layer of a step (reference: the MatMul
  * gradients TF schedules for layers/dnn.py:57-62, one per layer) - each a small M x N with K = batch - queued
@@ -822,19 +801,15 @@ typedef struct er_gemm_problem {
   float* C; int32_t ldc;
   const float* bias;
   int32_t accumulate;
-  /* a_mean != NULL: A is the never-written output of a dense + BatchNorm + activation layer (er_a_transform below) */
-  const float* a_mean; const float* a_invstd; const float* a_gamma; const float* a_beta;
-  int32_t a_act;
   /* col_stats != NULL: per-row-tile Welford statistics of this problem's output columns, as er_gemm_f32's col_stats
    * ([er_gemm_row_tiles(M)][N][3]; the problem is then not k-split and must not accumulate): the same-depth layers of
    * parallel stacks (MMoE's experts, the task towers: layers/mmoe.py:62-83, model/multi_task_model.py:33-100) run as ONE
    * launch and still feed their BatchNorms */
   float* col_stats;
-  /* bn_partial != NULL: the epilogue of er_gemm_f32_bn_bwd(_z) for this problem - the BatchNorm-backward column sums of
-   * the layer that produced the problem's OUTPUT position (z, y (NULL: recomputed from z with gamma / beta), statistics,
-   * leading dimension of z / y, partial [er_gemm_row_tiles(M)][N][2]); not k-split, no accumulate */
+  /* bn_partial != NULL: the epilogue of er_gemm_f32_bn_bwd for this problem - the BatchNorm-backward column sums of the
+   * layer that produced the problem's OUTPUT position (z, y, statistics, leading dimension of z / y, partial
+   * [er_gemm_row_tiles(M)][N][2]); not k-split, no accumulate */
   const float* bn_z; const float* bn_zbias; const float* bn_y; const float* bn_mean; const float* bn_invstd;
-  const float* bn_gamma; const float* bn_beta;
   int32_t bn_ld, bn_use_bn, bn_act;
   float* bn_partial;
 } er_gemm_problem;
@@ -885,40 +860,6 @@ int er_emb_bwd_fused_wgrad(er_emb_group* const* groups, int n, const er_grad_gro
 int er_emb_bwd_fused_tail(er_emb_group* const* groups, int n, const er_grad_group* finish_host, int n_finish, int opt_kind,
                           const er_opt_hyper* hyper, const er_gemm_problem* wgrads_host, int n_wgrads, int32_t wgrad_blocks,
                           const er_loss_tail_job* loss_tail, const er_dense_opt_job* dense_opt, er_stream_t stream);
-/* DEFERRED BatchNorm + activation (reference layers/dnn.py:57-79: dense -> batch_normalization -> relu per layer).
- * The reference materialises every intermediate; here a hidden layer of a stack writes only its pre-normalisation
- * values z (bias included) and its batch statistics, and every reader of its activation output y = act(BN(z)) -
- * the next layer's forward GEMM, the next layer's weight-gradient GEMM, the ReLU mask of its own backward - applies
- *     y = act(((z - mean[f]) * invstd[f]) * gamma[f] + beta[f])
- * itself (the operation sequence of er_bn_apply_from_stats: a recomputed y has the bits of a materialised one):
- *   er_a_transform: operand A ([batch, features] row-major: layouts NN and TN) is transformed while the GEMM stages
- *     it into LDS (parameter table of the features in LDS; NN: K <= 960).  mean == NULL: A as it is.
- *   er_bn_finalize: the GEMM emits per-row-tile column statistics of its output (col_stats: [er_gemm_row_tiles(M)][N]
- *     [3]) and the workgroup that is LAST to deliver a partial for a column of tiles (arrival counter, no barrier, no
- *     spinning) merges them in er_bn_apply_from_stats' order into save_mean / save_invstd and moves the moving
- *     statistics (NULL: not touched).  counters: device int32 [n_counters >= 2 * ceil(N / 64)], zero before the first
- *     launch; every launch leaves them zero.  One buffer per stream (launches of one stream are ordered).
- *   er_gemm_f32_deferred: C (+)= op(A') . op(B) (+ bias) with either or both (`at`, `fin` may be NULL).
- *   er_gemm_f32_bn_bwd_z: er_gemm_f32_bn_bwd for a producing layer whose y was never written: the mask is recomputed
- *     from z, z_bias, the statistics and gamma / beta.
- *   er_bn_act_bwd_z: er_bn_act_bwd(_ld / _from_partials) likewise (partial NULL: the column sums are computed first). */
-typedef struct er_a_transform {
-  const float* mean; const float* invstd; const float* gamma; const float* beta;
-  int32_t act;
-} er_a_transform;
-typedef struct er_bn_finalize {
-  float* save_mean; float* save_invstd; float* moving_mean; float* moving_var;
-  float eps, momentum;
-  int32_t* counters; int32_t n_counters;
-} er_bn_finalize;
-int er_gemm_f32_deferred(int layout, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda,
-                         const er_a_transform* at, const float* B, int32_t ldb, float* C, int32_t ldc,
-                         const float* bias, int accumulate, float* col_stats, const er_bn_finalize* fin,
-                         er_stream_t stream);
-int er_gemm_f32_bn_bwd_z(int layout, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B,
-                         int32_t ldb, float* C, int32_t ldc, const float* z, const float* z_bias, const float* gamma,
-                         const float* beta, const float* save_mean, const float* save_invstd, int32_t ld_z, int use_bn,
-                         int act, float* partial, er_stream_t stream);
 /* The bias / BatchNorm / activation kernels of SEVERAL layer outputs in one launch (forward) or two (backward: column
  * sums, then finalize + apply): the same-depth layers of parallel stacks - MMoE's experts and task towers
  * (layers/mmoe.py:62-83, model/multi_task_model.py:33-100) - each own launches of a few microseconds otherwise.  Same
@@ -939,10 +880,6 @@ typedef struct er_bn_layer {
 } er_bn_layer;
 int er_bn_fwd_multi(const er_bn_layer* layers_host, int n, er_stream_t stream);
 int er_bn_bwd_multi(const er_bn_layer* layers_host, int n, er_stream_t stream);
-int er_bn_act_bwd_z(const float* z, const float* bias, const float* gamma, const float* beta, const float* save_mean,
-                    const float* save_invstd, const float* dy, int32_t dy_ld, int32_t B, int32_t N, int use_bn, int act,
-                    const float* partial, int32_t chunks, float* dx, float* dbias, float* dgamma, float* dbeta,
-                    int accumulate, er_stream_t stream);
 int er_gemm_f32(int layout, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B,
                 int32_t ldb, float* C, int32_t ldc, const float* bias, int accumulate, float* col_stats,
                 er_stream_t stream);

@@ -437,34 +437,7 @@ class RefBackend(object):
   def gemm_grouped(self, layout, problems, bf16=False):
     for pr in problems:
       a, b, out, bias, accumulate = pr[:5]
-      at = pr[5] if len(pr) > 5 else None
-      A = self._deferred_value(at, a) if at is not None else a
-      self.gemm(layout, A, b, out=out, bias=bias, accumulate=accumulate, bf16=bf16)  # (column statistics: recomputed by bn_apply_from_stats)
-
-  # -- deferred BatchNorm + activation (include/easyrec_hip.h er_a_transform / er_bn_finalize): the stand-in applies the
-  # producer's normalisation to the operand, then contracts; statistics straight from the output
-  deferred_bn = True  # (on for the stand-in: the host logic of the deferred path stays covered by the CPU tests)
-
-  @staticmethod
-  def _deferred_value(at, a):
-    y = (a.detach() - at.mean) * at.invstd
-    y = y * (at.gamma.detach() if at.gamma is not None else 1.0) + (at.beta.detach() if at.beta is not None else 0.0)
-    return torch.relu(y) if at.act == ACT_RELU else y
-
-  def gemm_deferred(self, layout, a, b, at=None, out=None, bias=None, accumulate=False, col_stats=None, fin=None):
-    A = self._deferred_value(at, a) if at is not None else a
-    r = self.gemm(layout, A, b, out=out, bias=bias, accumulate=accumulate)
-    if fin is not None:
-      mean, invstd, mm, mv, eps, momentum = fin
-      z = r.detach()
-      mu = z.mean(dim=0)
-      var = ((z - mu)**2).mean(dim=0)  # tf.nn.moments: biased
-      mean.copy_(mu)
-      invstd.copy_(1.0 / torch.sqrt(var + eps))
-      if mm is not None:
-        mm.sub_((mm - mu) * (1.0 - momentum))
-        mv.sub_((mv - var) * (1.0 - momentum))
-    return r
+      self.gemm(layout, a, b, out=out, bias=bias, accumulate=accumulate, bf16=bf16)  # (column statistics: recomputed by bn_apply_from_stats)
 
   # -- embedding-parallel routing (reference compat/feature_column/feature_column.py:248-357:
   #    owner = id % world, local row = id // world)
@@ -1137,12 +1110,6 @@ class RefBackend(object):
   def bn_act_bwd(self, x, bias, gamma, y, mean, invstd, dy, use_bn, act, need_bias, need_affine, into=None,
                  partial=None, beta=None):
     assert partial is None  # only the HIP backend fuses the column sums into the dgrad GEMM
-    if y is None:  # a deferred layer: its activation output was never written
-      z = x if bias is None else x + bias
-      y = z
-      if use_bn:
-        y = (z - mean) * invstd
-        y = y * (gamma.detach() if gamma is not None else 1.0) + (beta.detach() if beta is not None else 0.0)
     res = self._bn_act_bwd(x, bias, gamma, y, mean, invstd, dy, use_bn, act, need_bias, need_affine)
     if into is None:
       return res

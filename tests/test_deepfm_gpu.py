@@ -391,76 +391,6 @@ def test_evaluate_does_not_disturb_training(monkeypatch, exact):
     _assert_closed_tracks_sweep(sb, sa, tol_q50=1e-6)
 
 
-@pytest.mark.parametrize('config,B', [('deepfm_criteo_small.config', 512), ('din_taobao_small.config', 64)])
-def test_deferred_batchnorm_changes_no_bit_model_level(config, B):
-  """The DEFERRED step (hidden layers of every DNN stack write z only: kernels.HipBackend.deferred_bn, an A/B switch that
-  is off by default - measured slower, see its comment) against the same step with every activation output materialised: losses and every variable / slot bit for bit, eager and as a replayed graph
-  (DeepFM: two towers of batch-sized layers; MultiTowerDIN: the attention MLP over [B, L] positions)."""
-  cfg = _cfg(config)
-  be = kernels.hip()
-  if 'criteo' in config:
-    gen = SyntheticCriteo(cfg.data_config, list(cfg.feature_config.features), batch_size=B, seed=6)
-  else:
-    from easyrec_amd.input.synthetic import SyntheticBatches
-    gen = SyntheticBatches(cfg.data_config, list(cfg.feature_config.features), batch_size=B, seed=6)
-  batches = [gen.next_batch() for _ in range(5)]
-  states = []
-  saved = be.deferred_bn
-  try:
-    for deferred, graph in ((False, False), (True, False), (True, True)):
-      be.deferred_bn = deferred
-      est = EasyRecEstimator(cfg, device=DEV, batch_size=B, seed=2).build()
-      est.features.load(batches[0])
-      if graph:
-        est.capture(warmup=1)
-      else:
-        est.train_step()
-      losses = []
-      for bt in batches[1:]:
-        est.train_step(bt)
-        losses.append(est.loss_values())
-      states.append((est.state_dict(slots=True), losses))
-  finally:
-    be.deferred_bn = saved
-  for st, losses in states[1:]:
-    assert losses == states[0][1]
-    for k in states[0][0]:
-      assert np.array_equal(st[k], states[0][0][k]), k
-
-
-def test_fused_batchnorm_gemms_change_no_bit():
-  """The whole DeepFM step with BatchNorm finished inside the GEMM launches (forward normalise + ReLU, backward dz of
-  the producing layer) against the two-launch forms: states and losses bit for bit, eager and as a replayed graph."""
-  cfg = _cfg('deepfm_criteo_small.config')
-  B = 512
-  be = kernels.hip()
-  gen = SyntheticCriteo(cfg.data_config, list(cfg.feature_config.features), batch_size=B, seed=6)
-  batches = [gen.next_batch() for _ in range(5)]
-  states = []
-  saved = be.fused_bn_gemm
-  try:
-    for fused, graph in ((False, False), (True, False), (True, True)):
-      be.fused_bn_gemm = fused
-      est = EasyRecEstimator(cfg, device=DEV, batch_size=B, seed=2).build()
-      assert be.gemm_fused_bn_ok(B, 256) == fused
-      est.features.load(batches[0])
-      if graph:
-        est.capture(warmup=1)
-      else:
-        est.train_step()
-      losses = []
-      for bt in batches[1:]:
-        est.train_step(bt)
-        losses.append(est.loss_values())
-      states.append((est.state_dict(slots=True), losses))
-  finally:
-    be.fused_bn_gemm = saved
-  for st, losses in states[1:]:
-    assert losses == states[0][1]
-    for k in states[0][0]:
-      assert np.array_equal(st[k], states[0][0][k]), k
-
-
 @pytest.mark.parametrize('optimizer', ['adam', 'lazy_adam'])
 @pytest.mark.parametrize('buckets,B', [(1000, 256), (7, 2048), (300, 4096)])
 def test_fused_embedding_step_matches_the_general_path(optimizer, buckets, B):

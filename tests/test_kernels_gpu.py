@@ -629,120 +629,6 @@ def test_gemm_epilogue_statistics_feed_batchnorm(hip, M, N, K, bf16):
   assert torch.allclose(mv.cpu().double(), 0.99 + 0.01 * var, rtol=1e-4, atol=1e-6)
 
 
-@pytest.mark.parametrize('M,N,K', [(4096, 256, 624), (4096, 128, 256), (4096, 64, 128), (1000, 70, 33), (8192, 256, 81)])
-def test_batchnorm_fused_into_the_gemm_launch(hip, M, N, K):
-  """er_gemm_f32_bn_fwd / er_gemm_f32_bn_bwd_apply (statistics, a barrier among the row tiles of a column of tiles,
-  BatchNorm from registers - ONE launch) against the two-launch forms they replace: every output bit for bit,
-  repeated launches included (the barrier words reset themselves)."""
-  hip.gemm_reserve(1 << 20)
-  assert hip.lib.er_gemm_fused_bn_ok(M, N) == 1  # (the path is off by default: kernels.HipBackend.fused_bn_gemm)
-  g = torch.Generator().manual_seed(M + N + K)
-  x, w = torch.randn(M, K, generator=g).to(DEV), (torch.randn(K, N, generator=g) * 0.1).to(DEV)
-  bias, gamma, beta = torch.randn(N, generator=g).to(DEV), (torch.rand(N, generator=g) + 0.5).to(DEV), torch.randn(N, generator=g).to(DEV)
-  chunks = hip.gemm_row_tiles(M)
-  for rep in range(3):
-    mm_a, mv_a = torch.zeros(N, device=DEV), torch.ones(N, device=DEV)
-    mm_b, mv_b = torch.zeros(N, device=DEV), torch.ones(N, device=DEV)
-    stats = torch.zeros(chunks * N * 3, device=DEV)
-    z_a = hip.gemm(kernels.GEMM_NN, x, w, bias=bias, col_stats=stats)
-    y_a, mean_a, inv_a = hip.bn_apply_from_stats(z_a, None, stats, chunks, gamma, beta, 1e-3, 0.99, mm_a, mv_a, kernels.ACT_RELU)
-    z_b, y_b, mean_b, inv_b = hip.gemm_bn_fwd(x, w, bias, gamma, beta, 1e-3, 0.99, mm_b, mv_b, kernels.ACT_RELU)
-    torch.cuda.synchronize()
-    for a, b, what in ((z_a, z_b, 'z'), (y_a, y_b, 'y'), (mean_a, mean_b, 'mean'), (inv_a, inv_b, 'invstd'),
-                       (mm_a, mm_b, 'moving_mean'), (mv_a, mv_b, 'moving_variance')):
-      assert torch.equal(a, b), (rep, what)
-  # backward: the dgrad GEMM of a consumer layer [M, N] <- dz_next [M, K2] . w_next^T [K2, N] finishing THIS layer's BatchNorm
-  K2 = 96
-  dz_next = (torch.randn(M, K2, generator=g) * 0.01).to(DEV)
-  w_next = (torch.randn(N, K2, generator=g) * 0.1).to(DEV)
-  src = kernels.BnSource(z_b, None, y_b, mean_b, inv_b, kernels.ACT_RELU, gamma, None)
-  for rep in range(2):
-    dg_a, db_a = torch.full((N,), 0.25, device=DEV), torch.full((N,), -0.5, device=DEV)
-    dg_b, db_b = dg_a.clone(), db_a.clone()
-    partial = torch.zeros(chunks * N * 2, device=DEV)
-    dy = hip.gemm_bn_bwd(kernels.GEMM_NT, dz_next, w_next, src, partial)
-    dz_a, _, _, _ = hip.bn_act_bwd(z_b, None, gamma, y_b, mean_b, inv_b, dy, 1, kernels.ACT_RELU, False, True,
-                                   into=(None, dg_a, db_a), partial=partial)
-    src.grad_bufs = (dg_b, db_b)
-    dz_b = hip.gemm_bn_bwd_apply(kernels.GEMM_NT, dz_next, w_next, src)
-    torch.cuda.synchronize()
-    assert torch.equal(dz_a, dz_b), rep
-    assert torch.equal(dg_a, dg_b) and torch.equal(db_a, db_b), rep
-
-
-@pytest.mark.parametrize('M,N,K,N2', [(4096, 256, 624, 128), (4096, 128, 256, 64), (1000, 70, 33, 40), (8192, 64, 81, 1),
-                                      (20000, 40, 24, 32)])
-def test_deferred_batchnorm_changes_no_bit(hip, M, N, K, N2):
-  """A hidden dense + BatchNorm + ReLU layer WITHOUT its activation output (er_gemm_f32_deferred: statistics finalised
-  by the last workgroup of a column of tiles; the readers transform z while staging it) against the materialised form
-  (er_gemm_f32 + er_bn_apply_from_stats, then plain GEMMs over y), bit for bit:
-    forward of the next layer  y . W2          (NN, A transformed; also with its own statistics finalised)
-    weight gradient            y^T . dz2       (TN, A transformed; single launch and grouped with split-K)
-    dgrad + BatchNorm sums     dz2 . W2^T      (er_gemm_f32_bn_bwd_z: mask recomputed from z)
-    the layer's own backward   er_bn_act_bwd_z (with and without the column sums handed over)
-  repeated (the arrival counters reset themselves)."""
-  g = torch.Generator().manual_seed(M + N + K)
-  x, w = torch.randn(M, K, generator=g).to(DEV), (torch.randn(K, N, generator=g) * 0.1).to(DEV)
-  bias, gamma, beta = torch.randn(N, generator=g).to(DEV), (torch.rand(N, generator=g) + 0.5).to(DEV), torch.randn(N, generator=g).to(DEV)
-  w2 = (torch.randn(N, N2, generator=g) * 0.1).to(DEV)
-  b2 = torch.randn(N2, generator=g).to(DEV)
-  dz2 = (torch.randn(M, N2, generator=g) * 0.01).to(DEV)
-  chunks = hip.gemm_row_tiles(M)
-  for rep in range(3):
-    mm_a, mv_a = torch.zeros(N, device=DEV), torch.ones(N, device=DEV)
-    mm_b, mv_b = torch.zeros(N, device=DEV), torch.ones(N, device=DEV)
-    stats = torch.zeros(chunks * N * 3, device=DEV)
-    z_a = hip.gemm(kernels.GEMM_NN, x, w, bias=bias, col_stats=stats)
-    y_a, mean_a, inv_a = hip.bn_apply_from_stats(z_a, None, stats, chunks, gamma, beta, 1e-3, 0.99, mm_a, mv_a, kernels.ACT_RELU)
-    stats_b = torch.zeros(chunks * N * 3, device=DEV)
-    mean_b, inv_b = torch.empty(N, device=DEV), torch.empty(N, device=DEV)
-    z_b = hip.gemm_deferred(kernels.GEMM_NN, x, w, bias=bias, col_stats=stats_b, fin=(mean_b, inv_b, mm_b, mv_b, 1e-3, 0.99))
-    torch.cuda.synchronize()
-    tall = chunks > 256  # (the materialised form merges more than 256 row-tile partials in slices: another fixed order)
-    for a, b, what in ((z_a, z_b, 'z'), (mean_a, mean_b, 'mean'), (inv_a, inv_b, 'invstd'), (mm_a, mm_b, 'moving_mean'),
-                       (mv_a, mv_b, 'moving_variance')):
-      if tall and what != 'z':
-        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6), (rep, what)
-      else:
-        assert torch.equal(a, b), (rep, what)
-    if tall:  # everything below is compared bit for bit: give both forms the same statistics
-      mean_b.copy_(mean_a)
-      inv_b.copy_(inv_a)
-    src = kernels.BnSource(z_b, None, None, mean_b, inv_b, kernels.ACT_RELU, gamma, None, beta=beta)
-    assert src.deferred
-    # next layer forward, plain and with its own statistics
-    o_a = hip.gemm(kernels.GEMM_NN, y_a, w2, bias=b2)
-    o_b = hip.gemm_deferred(kernels.GEMM_NN, z_b, w2, at=src, bias=b2)
-    st2_a, st2_b = torch.zeros(chunks * N2 * 3, device=DEV), torch.zeros(chunks * N2 * 3, device=DEV)
-    m2, i2 = torch.empty(N2, device=DEV), torch.empty(N2, device=DEV)
-    p_a = hip.gemm(kernels.GEMM_NN, y_a, w2, bias=b2, col_stats=st2_a)
-    p_b = hip.gemm_deferred(kernels.GEMM_NN, z_b, w2, at=src, bias=b2, col_stats=st2_b, fin=(m2, i2, None, None, 1e-3, 0.99))
-    # weight gradient: single launch, and grouped (split-K over the batch)
-    dw_a = hip.gemm(kernels.GEMM_TN, y_a, dz2)
-    dw_b = hip.gemm_deferred(kernels.GEMM_TN, z_b, dz2, at=src)
-    gw_a, gw_b = torch.full((N, N2), 0.5, device=DEV), torch.full((N, N2), 0.5, device=DEV)
-    hip.gemm_grouped(kernels.GEMM_TN, [(y_a, dz2, gw_a, None, True)])
-    hip.gemm_grouped(kernels.GEMM_TN, [(z_b, dz2, gw_b, None, True, src)])
-    # dgrad with the BatchNorm-backward column sums of the producing layer, then that layer's own backward
-    src_a = kernels.BnSource(z_a, None, y_a, mean_a, inv_a, kernels.ACT_RELU, gamma, None)
-    part_a, part_b = torch.zeros(chunks * N * 2, device=DEV), torch.zeros(chunks * N * 2, device=DEV)
-    dy_a = hip.gemm_bn_bwd(kernels.GEMM_NT, dz2, w2, src_a, part_a)
-    dy_b = hip.gemm_bn_bwd(kernels.GEMM_NT, dz2, w2, src, part_b)
-    r_a = hip.bn_act_bwd(z_a, None, gamma, y_a, mean_a, inv_a, dy_a, 1, kernels.ACT_RELU, False, True, partial=part_a)
-    r_b = hip.bn_act_bwd(z_b, None, gamma, None, mean_b, inv_b, dy_b, 1, kernels.ACT_RELU, False, True, partial=part_b, beta=beta)
-    q_a = hip.bn_act_bwd(z_a, None, gamma, y_a, mean_a, inv_a, dy_a, 1, kernels.ACT_RELU, False, True)
-    q_b = hip.bn_act_bwd(z_b, None, gamma, None, mean_b, inv_b, dy_b, 1, kernels.ACT_RELU, False, True, beta=beta)
-    torch.cuda.synchronize()
-    for a, b, what in ((o_a, o_b, 'next forward'), (p_a, p_b, 'next forward + statistics'), (st2_a, st2_b, 'next statistics'),
-                       (dw_a, dw_b, 'dW'), (gw_a, gw_b, 'grouped dW'), (dy_a, dy_b, 'dgrad'), (part_a, part_b, 'column sums'),
-                       (r_a[0], r_b[0], 'dz from partials'), (r_a[2], r_b[2], 'dgamma'), (r_a[3], r_b[3], 'dbeta'),
-                       (q_a[0], q_b[0], 'dz'), (q_a[2], q_b[2], 'dgamma (own sums)')):
-      assert torch.equal(a, b), (rep, what, float((a - b).abs().max()))
-    zr = p_b.cpu().double()
-    assert torch.allclose(m2.cpu().double(), zr.mean(dim=0), rtol=1e-5, atol=1e-5)
-    assert torch.allclose(i2.cpu().double(), 1.0 / torch.sqrt(zr.var(dim=0, unbiased=False) + 1e-3), rtol=1e-5, atol=1e-6)
-
-
 def test_lazy_dense_decay_equals_the_sweep(hip):
   """TF-exact Adam two ways over 1300 steps on one table: (A) the streaming sweep of every row every step,
   (B) lazy dense decay (er_emb_route -> er_emb_catch_up -> touched-row update, er_emb_flush_decay at the end).
@@ -1197,7 +1083,7 @@ def test_grouped_launch_epilogues_match_single_launches(hip):
     single_st.append(st)
   zs = [torch.empty_like(z) for z in single_z]
   sts = [torch.zeros_like(st) if st is not None else None for st in single_st]
-  hip.gemm_grouped(kernels.GEMM_NN, [(x, w, z, b, False, None, st) for x, w, z, b, st in zip(xs, ws, zs, bs, sts)])
+  hip.gemm_grouped(kernels.GEMM_NN, [(x, w, z, b, False, st) for x, w, z, b, st in zip(xs, ws, zs, bs, sts)])
   torch.cuda.synchronize()
   for i in range(len(shapes)):
     assert torch.equal(zs[i], single_z[i]), i
@@ -1226,53 +1112,13 @@ def test_grouped_launch_epilogues_match_single_launches(hip):
       single_part.append(None)
   dxs = [torch.empty_like(d) for d in single_dx]
   parts = [torch.zeros_like(p) if p is not None else None for p in single_part]
-  hip.gemm_grouped(kernels.GEMM_NT, [(dzs[i], ws[i], dxs[i], None, False) + ((None, None, (srcs[i], parts[i])) if srcs[i] is not None else ())
+  hip.gemm_grouped(kernels.GEMM_NT, [(dzs[i], ws[i], dxs[i], None, False) + ((None, (srcs[i], parts[i])) if srcs[i] is not None else ())
                                      for i in range(len(shapes))])
   torch.cuda.synchronize()
   for i in range(len(shapes)):
     assert torch.equal(dxs[i], single_dx[i]), i
     if parts[i] is not None:
       assert torch.equal(parts[i], single_part[i]), i
-
-
-@pytest.mark.parametrize('B,N', [(4096, 256), (300, 70), (20000, 40)])
-@pytest.mark.parametrize('mode', [kernels.BN_BATCH, kernels.BN_FROZEN])
-def test_relu_mask_recomputed_from_z_changes_no_bit(hip, B, N, mode):
-  """BatchNorm + ReLU backward with the mask recomputed from z (HipBackend.recompute_relu_mask: y is not read) against
-  the kernels reading y: the forward's operation sequence gives the forward's bits, so every gradient bit agrees - the
-  two-pass kernels, the sums from a dgrad GEMM's epilogue, and the multi-layer launch."""
-  g = torch.Generator().manual_seed(B + N + mode)
-  z = torch.randn(B, N, generator=g).to(DEV)
-  bias = torch.randn(N, generator=g).to(DEV) if mode == kernels.BN_FROZEN else None
-  gamma, beta = (torch.rand(N, generator=g) + 0.5).to(DEV), (torch.randn(N, generator=g) * 0.1).to(DEV)
-  mm, mv = (torch.randn(N, generator=g) * 0.1).to(DEV), (torch.rand(N, generator=g) + 0.5).to(DEV)
-  y, mean, invstd = hip.bn_act_fwd(z, bias, gamma, beta, mode, 1e-3, 0.99, mm, mv, kernels.ACT_RELU)
-  dy = (torch.randn(B, N, generator=g) * 0.1).to(DEV)
-  dzn, wn = (torch.randn(B, 24, generator=g) * 0.1).to(DEV), torch.randn(N, 24, generator=g).to(DEV)
-  prev = hip.recompute_relu_mask
-  res = {}
-  try:
-    for on in (True, False):
-      hip.recompute_relu_mask = on
-      a = hip.bn_act_bwd(z, bias, gamma, y, mean, invstd, dy, mode, kernels.ACT_RELU, bias is not None, True, beta=beta)
-      out = list(a)
-      if mode == kernels.BN_BATCH:
-        part = torch.empty(hip.gemm_row_tiles(B) * N * 2, device=DEV)
-        src = kernels.BnSource(z, None, y, mean, invstd, kernels.ACT_RELU, gamma, None, beta=beta)
-        dy2 = hip.gemm_bn_bwd(kernels.GEMM_NT, dzn, wn, src, part)
-        out += [dy2, part] + list(hip.bn_act_bwd(z, None, gamma, y, mean, invstd, dy2, mode, kernels.ACT_RELU, False, True,
-                                                 partial=part, beta=beta))
-      if B <= hip.BN_MULTI_MAX_ROWS:
-        out += list(hip.bn_bwd_multi([dict(x=z, bias=bias, gamma=gamma, beta=beta, y=y, mean=mean, invstd=invstd, dy=dy,
-                                            use_bn=mode, act=kernels.ACT_RELU)] * 2)[1])
-      res[on] = out
-  finally:
-    hip.recompute_relu_mask = prev
-  torch.cuda.synchronize()
-  for i, (a, b_) in enumerate(zip(res[True], res[False])):
-    assert (a is None) == (b_ is None), i
-    if a is not None:
-      assert torch.equal(a, b_), i
 
 
 def test_multi_layer_batchnorm_launches_match_single_launches(hip):

@@ -55,8 +55,7 @@ def main():
   be = kernels.hip()
   for name in dir(be):
     fn = getattr(be, name)
-    if callable(fn) and not name.startswith('_') and name not in ('wgrad_sink', 'gemm_row_tiles', 'gemm_fused_bn_ok',
-                                                                  'require_device', 'device_info'):
+    if callable(fn) and not name.startswith('_') and name not in ('wgrad_sink', 'gemm_row_tiles', 'require_device', 'device_info'):
       def wrap(fn=fn, name=name):
         def inner(*a, **k):
           LOG.append(('lib', name, _site()))
