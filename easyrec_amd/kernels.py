@@ -232,6 +232,10 @@ def bn_source_of(x):
   return src
 
 
+def _ptr(t):
+  return None if t is None else t.data_ptr()
+
+
 class GemmProblem(ctypes.Structure):  # = er_gemm_problem
   _fields_ = [('M', ctypes.c_int32), ('N', ctypes.c_int32), ('K', ctypes.c_int32), ('A', ctypes.c_void_p),
               ('lda', ctypes.c_int32), ('B', ctypes.c_void_p), ('ldb', ctypes.c_int32), ('C', ctypes.c_void_p),
