@@ -386,7 +386,11 @@ def _din_with_hash_table_sequences(device, steps=3, B=48):
     est.train_step(b)
     got, exp = est.loss_values(), orc.train_step(b)
     for k in exp:
-      assert abs(got[k] - exp[k]) <= (1e-4 if step == 0 else 2e-3) * max(1.0, abs(exp[k])), (step, k, got[k], exp[k])
+      # (step 0 from identical parameters: the 1e-4 bar.  After two Adam steps this 48-row BatchNorm model amplifies any
+      # difference in fp32 summation order - with hash-table AND with dense sequence tables alike: over seeds the GPU step
+      # and the oracle differ by 1e-7 .. 5e-3 at step 2, profiles/r05_s19_din_small_chaos_probe.txt, tools/dbg_kv_seq_gpu.py)
+      assert abs(got[k] - exp[k]) <= (1e-4 if step == 0 else (2e-3 if step == 1 else 1e-2)) * max(1.0, abs(exp[k])), \
+          (step, k, got[k], exp[k])
   st = est.state_dict(slots=True)
   for n in kv_names:
     keys, rows = orc.kv_state(n)
