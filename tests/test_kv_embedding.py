@@ -421,4 +421,7 @@ def test_hash_table_sequence_features_match_the_oracle_on_the_stand_in_backend(r
 
 @pytest.mark.gpu
 def test_hash_table_sequence_features_match_the_oracle_on_the_gpu():
-  _din_with_hash_table_sequences('cuda:0')
+  # two steps: from the third on this 48-row BatchNorm model amplifies the GPU's and the oracle's different fp32 summation
+  # orders until single rows' Adam moments differ by tens of percent - with dense sequence tables just as with hash-table
+  # ones (profiles/r05_s19_din_small_chaos_probe.txt); the first two steps agree to 1e-7 / 5e-6 over every seed tried
+  _din_with_hash_table_sequences('cuda:0', steps=2)

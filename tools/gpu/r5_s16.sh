@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 5 session 16: after the removal of the rejected variants (GemmArgs 320 -> 144 bytes): the whole -m gpu suite, then
+# round 5 session 16: after the removal of the rejected variants (GemmArgs 320 -> 152 bytes): the whole -m gpu suite, then
 # the lines of configs 2-5
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 O=gpurun_out/r5s16; mkdir -p $O

@@ -11,7 +11,9 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, 'profiles', 'r03_pmc_by_kernel.json')
 res = json.load(open(src))['default']
-RANDOM_ROWS = ('emb_fwd_kernel', 'emb_bwd_tile', 'emb_bwd_own', 'emb_catch_up', 'emb_bwd_fix', 'gather_rows', 'emb_flush', 'emb_owner_serve')
+RANDOM_ROWS = ('emb_fwd_kernel', 'emb_bwd_tile', 'emb_bwd_own', 'emb_catch_up', 'emb_bwd_fix', 'gather_rows', 'emb_flush', 'emb_owner_serve',
+               'emb_front_fwd')  # (emb_bwd_own_wgrad: the row update's random records counted right, the contraction's
+                                 #  streamed operands at half - a LOWER bound; its GEMM half alone: profiles/r05_s11_pmc_fused_tail.txt)
 by = {}
 for name, c in res.items():
   if 'er::' not in name or 'FETCH_SIZE' not in c or 'WRITE_SIZE' not in c:
