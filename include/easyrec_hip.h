@@ -393,6 +393,9 @@ int er_emb_front_fwd(er_emb_group* const* groups, int n, int flags, er_emb_plan*
                      float* sumsq_partials, er_stream_t stream);
 int er_emb_bwd_fused(er_emb_group* const* groups, int n, const er_grad_group* finish_host, int n_finish, int opt_kind,
                      const er_opt_hyper* hyper, er_stream_t stream);
+/* Probe hook (tools/own_probe.py): the next er_emb_bwd_fused* launches leave 16 wall-clock stamps (100 MHz) per workgroup
+ * of the embedding backward in `stamps` (device memory, 16 * grid uint64); NULL: off. */
+int er_debug_stamps(unsigned long long* stamps);
 /* out[b, sum(widths[<p]) + j] = parts[p][b * lds[p] + j]: tf.concat(values, axis=1) of n <= 8 row-major blocks
  * (model/deepfm.py:75-83, model/multi_tower_din.py:96,117) in one launch.  parts / widths / lds: HOST arrays. */
 int er_concat_cols(const float* const* parts_host, const int32_t* widths_host, const int32_t* lds_host, int n,
