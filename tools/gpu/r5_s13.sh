@@ -1,3 +1,6 @@
+#!/bin/bash
+# round 5 session 13: test_fused_embedding_step_matches_the_general_path bisected over the session's switches (the tail's
+# k-split count is what moved the step-3 loss), then the rest of the DeepFM GPU tests
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 O=gpurun_out/r5s13; mkdir -p $O
 T="tests/test_deepfm_gpu.py::test_fused_embedding_step_matches_the_general_path"
