@@ -1852,6 +1852,11 @@ class HipBackend(object):
                                    ctypes.c_int32(n_dense), src, dst, parts, scales, divs, values, ctypes.c_int32(n), arr,
                                    ctypes.c_int32(len(jobs)), _p(reg_out), _p(total_out), _stream()), 'er_loss_tail')
 
+  def discard_loss_tail(self):
+    """Forget a deferred loss tail nobody ran (the step that queued it raised before its tail): called at the start of
+    every step."""
+    self._deferred_loss_tail = None
+
   def flush_loss_tail(self):
     """Run a deferred loss tail on its own (a step whose tail did not take it)."""
     pending = getattr(self, '_deferred_loss_tail', None)

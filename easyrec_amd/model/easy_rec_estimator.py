@@ -262,6 +262,8 @@ class EasyRecEstimator(object):
   def _device_step(self):
     """Everything that runs on the GPU for one batch (graph-capturable)."""
     be = kernels.hip()
+    if hasattr(be, 'discard_loss_tail'):
+      be.discard_loss_tail()  # (a step that raised between its loss tail and its tail launch must not poison this one)
     # prologue, one launch: this step's optimizer scalars (device-side step counter) + the flat gradient buffer zeroed
     hash_job = self.features.hash_job() if self.fused_front else None
     be.step_prologue(self.hyper_table, self.step_counter, self.hyper, history=self.lr_hist,
