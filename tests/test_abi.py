@@ -53,3 +53,52 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
   monkeypatch.setattr(kernels, 'LIB_PATH', str(tmp_path / 'nope.so'))
   with pytest.raises(RuntimeError, match='no CPU fallback'):
     kernels.HipBackend()
+
+
+MIRRORS = {  # ctypes class in easyrec_amd/kernels.py -> the C struct it mirrors
+    'LookupDesc': 'er_lookup_desc', 'KvJob': 'er_kv_job', 'KvRouteJob': 'er_kv_route_job', 'CastDesc': 'er_cast_desc',
+    'GemmProblem': 'er_gemm_problem', 'BnLayer': 'er_bn_layer', 'CeHead': 'er_ce_head', 'TailJob': 'er_tail_job',
+    'LossTailJob': 'er_loss_tail_job', 'DenseOptJob': 'er_dense_opt_job', 'GradTerm': 'er_grad_term',
+    'GradGroup': 'er_grad_group', 'DenseApplyDesc': 'er_dense_apply_desc',
+}
+
+
+RENAMED = {('GradGroup', 'lam'): 'lambda'}  # (a Python keyword on the C side)
+
+
+def test_every_ctypes_mirror_has_the_size_and_field_offsets_of_its_c_struct(tmp_path):
+  """The host side hands the library arrays of records: a ctypes mirror that drifts from include/easyrec_hip.h (a field
+  dropped on one side only) would corrupt every call silently.  The header is compiled as C (gcc) into a probe that prints
+  sizeof and every field's offsetof; the mirrors must agree field by field, in order."""
+  import shutil
+  import subprocess
+  from easyrec_amd import kernels
+  if shutil.which('gcc') is None:
+    import pytest
+    pytest.skip('no gcc')
+  lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "easyrec_hip.h"', 'int main(void) {']
+  for cls_name, c_name in MIRRORS.items():
+    cls = getattr(kernels, cls_name)
+    lines.append('  printf("%s size %%zu\\n", sizeof(%s));' % (c_name, c_name))
+    for field in cls._fields_:
+      fname = field[0]
+      if fname.endswith('_') and fname.startswith('pad'):
+        continue
+      lines.append('  printf("%s %s %%zu\\n", offsetof(%s, %s));' % (c_name, fname, c_name, RENAMED.get((cls_name, fname), fname)))
+  lines += ['  return 0;', '}']
+  src = tmp_path / 'probe.c'
+  src.write_text('\n'.join(lines))
+  exe = tmp_path / 'probe'
+  subprocess.run(['gcc', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)], check=True)
+  out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+  got = {}
+  for ln in out.splitlines():
+    c_name, key, val = ln.split()
+    got[(c_name, key)] = int(val)
+  for cls_name, c_name in MIRRORS.items():
+    cls = getattr(kernels, cls_name)
+    assert ctypes.sizeof(cls) == got[(c_name, 'size')], (cls_name, ctypes.sizeof(cls), got[(c_name, 'size')])
+    for field in cls._fields_:
+      fname = field[0]
+      if (c_name, fname) in got:
+        assert getattr(cls, fname).offset == got[(c_name, fname)], (cls_name, fname)
