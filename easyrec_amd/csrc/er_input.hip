@@ -10,10 +10,261 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <unistd.h>
+#include <vector>
 
 #include "er_common.h"
 
+namespace {
+
+// Host worker threads that outlive a call: creating and joining a thread costs 20 - 50 us on a plain Linux host and
+// 0.3 - 0.5 ms inside a sandboxed container - per thread and per 4096-line batch that is the whole gain.  One job at a
+// time (callers are serialised); the pool is never destroyed (no destructor races at exit) and is rebuilt after a fork
+// (a child process has none of the parent's threads).
+class HostPool {
+ public:
+  static HostPool* get() {
+    static std::mutex mu;
+    static HostPool* pool = nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!pool || pool->pid_ != getpid()) pool = new HostPool();  // (the old one is leaked on purpose)
+    return pool;
+  }
+  // fn(0 .. n - 1), fn(0) on the calling thread
+  void run(int n, const std::function<void(int)>& fn) {
+    std::lock_guard<std::mutex> serial(run_mu_);
+    if (n <= 1) {
+      fn(0);
+      return;
+    }
+    {
+      std::unique_lock<std::mutex> lock(mu_);
+      while (static_cast<int>(workers_.size()) < n - 1) workers_.emplace_back([this] { loop(); });
+      fn_ = &fn;
+      n_ = n;
+      next_ = 1;
+      pending_ = n - 1;
+      ++epoch_;
+    }
+    cv_.notify_all();
+    fn(0);
+    std::unique_lock<std::mutex> lock(mu_);
+    done_cv_.wait(lock, [this] { return pending_ == 0; });
+    fn_ = nullptr;
+  }
+
+ private:
+  HostPool() : pid_(getpid()) {}
+  void loop() {
+    uint64_t seen = 0;
+    std::unique_lock<std::mutex> lock(mu_);
+    for (;;) {
+      cv_.wait(lock, [&] { return epoch_ != seen; });
+      seen = epoch_;
+      while (fn_ && next_ < n_) {
+        const int i = next_++;
+        const std::function<void(int)>* fn = fn_;
+        lock.unlock();
+        (*fn)(i);
+        lock.lock();
+        if (--pending_ == 0) done_cv_.notify_one();
+      }
+    }
+  }
+  pid_t pid_;
+  std::mutex mu_, run_mu_;
+  std::condition_variable cv_, done_cv_;
+  std::vector<std::thread> workers_;
+  const std::function<void(int)>* fn_ = nullptr;
+  int n_ = 0, next_ = 0, pending_ = 0;
+  uint64_t epoch_ = 0;
+};
+
+// A decimal integer as strtoll reads it when nothing unusual is in the cell: [+-] 1 - 18 digits.  Anything else (spaces,
+// 19+ digits, other characters) is left to strtoll itself - the results and the error behaviour stay its.
+inline bool parse_int_fast(const uint8_t* p, int64_t len, int64_t* out) {
+  int64_t i = 0;
+  bool neg = false;
+  if (p[0] == '-' || p[0] == '+') {
+    neg = p[0] == '-';
+    i = 1;
+  }
+  if (i == len || len - i > 18) return false;
+  uint64_t v = 0;
+  for (; i < len; ++i) {
+    const unsigned d = static_cast<unsigned>(p[i]) - '0';
+    if (d > 9) return false;
+    v = v * 10 + d;
+  }
+  *out = neg ? -static_cast<int64_t>(v) : static_cast<int64_t>(v);
+  return true;
+}
+
+// [+-] digits [. digits] with at most 15 significant digits and at most 22 fraction digits: mantissa and 10^k are both
+// exact doubles, so ONE IEEE division is the correctly rounded value - what glibc's strtod returns (Clinger's fast path).
+// Exponents, inf / nan, hex floats, longer mantissas: strtod.
+inline bool parse_double_fast(const uint8_t* p, int64_t len, double* out) {
+  static const double kPow10[23] = {1e0,  1e1,  1e2,  1e3,  1e4,  1e5,  1e6,  1e7,  1e8,  1e9,  1e10, 1e11,
+                                    1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+  int64_t i = 0;
+  bool neg = false;
+  if (p[0] == '-' || p[0] == '+') {
+    neg = p[0] == '-';
+    i = 1;
+  }
+  uint64_t m = 0;
+  int digits = 0, frac = 0, sig = 0;
+  bool seen_dot = false;
+  for (; i < len; ++i) {
+    const uint8_t c = p[i];
+    if (c == '.') {
+      if (seen_dot) return false;
+      seen_dot = true;
+      continue;
+    }
+    const unsigned d = static_cast<unsigned>(c) - '0';
+    if (d > 9) return false;
+    ++digits;
+    if (m != 0 || d != 0) ++sig;
+    if (sig > 15) return false;
+    m = m * 10 + d;
+    if (seen_dot) ++frac;
+  }
+  if (digits == 0 || frac > 22) return false;
+  const double v = static_cast<double>(m) / kPow10[frac];
+  *out = neg ? -v : v;
+  return true;
+}
+
+struct CsvLine { int64_t b, e; };  // [b, e): the line without its "\n" / "\r\n"
+
+// rows [r0, r1) of `lines` into the column-major outputs; the first failure (if any) as (row, message)
+void decode_rows(const uint8_t* text, const CsvLine* lines, int64_t r0, int64_t r1, uint8_t sep, int32_t n_fields,
+                 const int32_t* kinds, int64_t out_stride, int64_t* int_out, double* flt_out, uint8_t* empty_out,
+                 int64_t* str_begin, int32_t* str_len, int64_t* bad_row, std::string* bad_msg) {
+  char num[64], msg[256];
+  for (int64_t row = r0; row < r1; ++row) {
+    int64_t b = lines[row].b;
+    const int64_t eol = lines[row].e;
+    for (int32_t f = 0; f < n_fields; ++f) {
+      const uint8_t* hit = b < eol ? static_cast<const uint8_t*>(memchr(text + b, sep, static_cast<size_t>(eol - b))) : nullptr;
+      const int64_t e = hit ? hit - text : eol;
+      if (!(f + 1 < n_fields ? e < eol : e == eol)) {
+        snprintf(msg, sizeof(msg), "er_decode_csv_host: line %lld has %s than %d fields", (long long)row,
+                 f + 1 < n_fields ? "fewer" : "more", n_fields);
+        *bad_row = row;
+        *bad_msg = msg;
+        return;
+      }
+      const int64_t o = static_cast<int64_t>(f) * out_stride + row;
+      const int64_t len = e - b;
+      empty_out[o] = len == 0;
+      str_begin[o] = b;
+      str_len[o] = static_cast<int32_t>(len);
+      int_out[o] = 0;
+      flt_out[o] = 0.0;
+      if (len > 0 && kinds[f] != 0) {
+        bool ok = false;
+        if (kinds[f] == 1) {
+          ok = parse_int_fast(text + b, len, &int_out[o]);
+          if (ok) flt_out[o] = static_cast<double>(int_out[o]);
+        } else {
+          ok = parse_double_fast(text + b, len, &flt_out[o]);
+        }
+        if (!ok) {  // the general path: strtoll / strtod on a terminated copy
+          if (len >= static_cast<int64_t>(sizeof(num))) {
+            snprintf(msg, sizeof(msg), "er_decode_csv_host: line %lld field %d: number too long", (long long)row, f);
+            *bad_row = row;
+            *bad_msg = msg;
+            return;
+          }
+          memcpy(num, text + b, static_cast<size_t>(len));
+          num[len] = 0;
+          char* endp = nullptr;
+          errno = 0;
+          if (kinds[f] == 1) {
+            int_out[o] = strtoll(num, &endp, 10);
+            flt_out[o] = static_cast<double>(int_out[o]);
+          } else {
+            flt_out[o] = strtod(num, &endp);
+          }
+          if (!(endp == num + len && errno == 0)) {
+            snprintf(msg, sizeof(msg), "er_decode_csv_host: line %lld field %d: '%s' is not a number", (long long)row, f, num);
+            *bad_row = row;
+            *bad_msg = msg;
+            return;
+          }
+        }
+      }
+      b = e + 1;
+    }
+  }
+}
+
+}  // namespace
+
 extern "C" {
+
+// er_decode_csv_host on `n_threads` host threads (<= 0: one per hardware thread, at most 16; a thread takes at least 256
+// rows).  out_stride (>= max_rows): elements between consecutive fields of the column-major outputs - NOT a power of two
+// where it matters: a row's 40 fields x 5 arrays at a 4096-element pitch all map to the same cache sets (one 4096-line
+// batch: 3.2 ms at pitch 4096, 2.4 at 4100 on one thread; 0.9 against 0.7 on eight).  One pass finds the lines (memchr: a few GB/s), the threads parse disjoint row ranges into the same column-major
+// outputs; numbers take an inline fast path (a plain decimal integer; a decimal of <= 15 significant digits = one exact
+// division, the value glibc's strtod returns) and strtoll / strtod otherwise.  Results and errors: er_decode_csv_host's.
+int er_decode_csv_host_mt(const uint8_t* text, int64_t n_bytes, uint8_t sep, int32_t n_fields, const int32_t* kinds,
+                          int64_t max_rows, int64_t out_stride, int64_t* int_out, double* flt_out, uint8_t* empty_out,
+                          int64_t* str_begin, int32_t* str_len, int64_t* n_rows_out, int64_t* consumed_out, int32_t n_threads) {
+  ER_REQUIRE(text && kinds && int_out && flt_out && empty_out && str_begin && str_len && n_rows_out && consumed_out &&
+                 n_bytes >= 0 && n_fields > 0 && max_rows >= 0 && out_stride >= max_rows && sep != '\n' && sep != '\r',
+             "er_decode_csv_host: bad arguments");
+  std::vector<CsvLine> lines;
+  lines.reserve(static_cast<size_t>(max_rows < (1 << 20) ? max_rows : (1 << 20)));
+  int64_t pos = 0;
+  while (pos < n_bytes && static_cast<int64_t>(lines.size()) < max_rows) {
+    const uint8_t* nl = static_cast<const uint8_t*>(memchr(text + pos, '\n', static_cast<size_t>(n_bytes - pos)));
+    if (!nl) break;  // an unterminated last line is left to the caller (it may continue in the next chunk)
+    int64_t eol = nl - text;
+    const int64_t next = eol + 1;
+    if (eol > pos && text[eol - 1] == '\r') --eol;
+    if (eol > pos) lines.push_back(CsvLine{pos, eol});  // (a blank line is skipped)
+    pos = next;
+  }
+  const int64_t rows = static_cast<int64_t>(lines.size());
+  int T = n_threads;
+  if (T <= 0) {
+    T = static_cast<int>(std::thread::hardware_concurrency());
+    if (T > 16) T = 16;
+  }
+  if (T > rows / 256) T = static_cast<int>(rows / 256);
+  if (T < 1) T = 1;
+  std::vector<int64_t> bad_row(static_cast<size_t>(T), -1);
+  std::vector<std::string> bad_msg(static_cast<size_t>(T));
+  const int64_t per = (rows + T - 1) / T;
+  auto work = [&](int t) {
+    const int64_t r0 = t * per, r1 = (r0 + per < rows) ? r0 + per : rows;
+    if (r0 < r1)
+      decode_rows(text, lines.data(), r0, r1, sep, n_fields, kinds, out_stride, int_out, flt_out, empty_out, str_begin, str_len,
+                  &bad_row[t], &bad_msg[t]);
+  };
+  if (T == 1) {
+    work(0);
+  } else {
+    HostPool::get()->run(T, work);
+  }
+  for (int t = 0; t < T; ++t)  // the ranges ascend: the first thread with a failure holds the smallest row
+    if (bad_row[t] >= 0) {
+      er::set_error("%s", bad_msg[t].c_str());
+      return 2;
+    }
+  *n_rows_out = rows;
+  *consumed_out = pos;
+  return 0;
+}
 
 int er_decode_csv_host(const uint8_t* text, int64_t n_bytes, uint8_t sep, int32_t n_fields, const int32_t* kinds,
                        int64_t max_rows, int64_t* int_out, double* flt_out, uint8_t* empty_out, int64_t* str_begin,
@@ -79,7 +330,7 @@ int er_pack_cells_host(const uint8_t* text, const int64_t* begin, const int32_t*
                        int64_t* out_offsets) {
   ER_REQUIRE(text && begin && length && out_offsets && n >= 0, "er_pack_cells_host: bad arguments");
   int64_t o = 0;
-  for (int64_t i = 0; i < n; ++i) {
+  for (int64_t i = 0; i < n; ++i) {  // (the copies on the host pool: measured no faster - 0.85 against 0.75 ms for 26 x 4096 cells)
     out_offsets[i] = o;
     if (length[i] > 0) {
       ER_REQUIRE(out_bytes, "er_pack_cells_host: null output");

@@ -27,6 +27,9 @@ class CSVInput(Input):
     self._line_no = 0  # data lines seen so far (line sharding runs over the concatenation of the files)
     import os
     self.native_decode = os.environ.get('EASYREC_AMD_NATIVE_CSV', '1') != '0'  # else the line-by-line Python path
+    # host threads of the native decoder (0: one per hardware thread, at most 16; 1: the single-pass decoder)
+    self.decode_threads = int(os.environ.get('EASYREC_AMD_CSV_THREADS', '0'))
+    self._decode_buffers = {}
 
   @staticmethod
   def _split_quoted(line, sep):
@@ -137,7 +140,7 @@ class CSVInput(Input):
       default = get_type_defaults(t, self._input_field_defaults[f])
       if t == DatasetConfig.STRING:
         if miss.any() and default not in ('', b''):
-          col = PackedCol(text, begin[f, :n], length[f, :n])
+          col = PackedCol(text, begin[f, :n].copy(), length[f, :n].copy())
           cols[name] = [default if miss[i] else col[i] for i in range(n)]
         else:
           cols[name] = PackedCol(text, begin[f, :n].copy(), length[f, :n].copy())
@@ -184,7 +187,10 @@ class CSVInput(Input):
       pos = 0
       while pos < len(text):
         want = B - (len(next(iter(carry.values()))) if carry else 0)
-        n, used, ints, flts, empty, begin, length = be.decode_csv_host(text[pos:], sep, kinds, want)
+        # (the decoded arrays are consumed - copied or turned into new arrays - by _columns_from_decoded before the next
+        # call: they are reused across the batches of this reader)
+        n, used, ints, flts, empty, begin, length = be.decode_csv_host(text[pos:], sep, kinds, want,
+                                                                       threads=self.decode_threads, out=self._decode_buffers)
         if n == 0:
           break
         chunk = text[pos:]

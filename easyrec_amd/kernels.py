@@ -511,17 +511,29 @@ class HipBackend(object):
     return keys, vals
 
   # -- K1 hashing
-  def decode_csv_host(self, text, sep, kinds, max_rows):
-    """CSVInput's decode step on the host (er_decode_csv_host).  text: uint8 array; kinds: 0 string / 1 int / 2 float
-    per field.  Returns (n_rows, consumed bytes, ints [F, max_rows], floats, empty mask, str_begin, str_len)."""
+  def decode_csv_host(self, text, sep, kinds, max_rows, threads=0, out=None):
+    """CSVInput's decode step on the host.  text: uint8 array; kinds: 0 string / 1 int / 2 float per field.  threads: 0 =
+    one per hardware thread (at most 16), n > 1 = that many (er_decode_csv_host_mt); 1 = the single-pass form
+    (er_decode_csv_host).  out: a dict the five output arrays are kept in between calls of the same shape (for a reader
+    that is done with a batch's arrays before it decodes the next: fresh 1.3 MB arrays are page-faulted in on every call).
+    Returns (n_rows, consumed bytes, ints [F, max_rows], floats, empty mask, str_begin, str_len)."""
     text = np.ascontiguousarray(text, dtype=np.uint8)
     kinds = np.ascontiguousarray(kinds, dtype=np.int32)
     F = len(kinds)
-    ints = np.empty((F, max_rows), dtype=np.int64)
-    flts = np.empty((F, max_rows), dtype=np.float64)
-    empty = np.empty((F, max_rows), dtype=np.uint8)
-    begin = np.empty((F, max_rows), dtype=np.int64)
-    length = np.empty((F, max_rows), dtype=np.int32)
+    # (the threaded decoder writes its column-major outputs at a pitch that is not a power of two: a row's F fields x 5
+    # arrays at a 4096-element pitch share their cache sets; the arrays handed back are [F, max_rows] views)
+    pitch = max_rows if int(threads) == 1 else max_rows + 24
+    key = (F, int(max_rows), int(pitch))
+    if out is not None and out.get('key') == key:
+      ints, flts, empty, begin, length = out['arrays']
+    else:
+      ints = np.empty((F, pitch), dtype=np.int64)[:, :max_rows]
+      flts = np.empty((F, pitch), dtype=np.float64)[:, :max_rows]
+      empty = np.empty((F, pitch), dtype=np.uint8)[:, :max_rows]
+      begin = np.empty((F, pitch), dtype=np.int64)[:, :max_rows]
+      length = np.empty((F, pitch), dtype=np.int32)[:, :max_rows]
+      if out is not None:
+        out['key'], out['arrays'] = key, (ints, flts, empty, begin, length)
     n_rows, consumed = ctypes.c_int64(0), ctypes.c_int64(0)
     sep_b = sep.encode('utf-8') if isinstance(sep, str) else bytes(sep)
     assert len(sep_b) == 1, 'separator must be one byte: %r' % sep
@@ -531,10 +543,16 @@ class HipBackend(object):
 
     def ptr(a):
       return a.ctypes.data_as(ctypes.c_void_p)
-    self._ck(self.lib.er_decode_csv_host(ptr(text), ctypes.c_int64(text.size), ctypes.c_uint8(sep_b[0]), ctypes.c_int32(F),
-                                         ptr(kinds), ctypes.c_int64(int(max_rows)), ptr(ints), ptr(flts), ptr(empty),
-                                         ptr(begin), ptr(length), ctypes.byref(n_rows), ctypes.byref(consumed)),
-             'er_decode_csv_host')
+    if int(threads) == 1:
+      self._ck(self.lib.er_decode_csv_host(ptr(text), ctypes.c_int64(text.size), ctypes.c_uint8(sep_b[0]), ctypes.c_int32(F),
+                                           ptr(kinds), ctypes.c_int64(int(max_rows)), ptr(ints), ptr(flts), ptr(empty),
+                                           ptr(begin), ptr(length), ctypes.byref(n_rows), ctypes.byref(consumed)),
+               'er_decode_csv_host')
+    else:
+      self._ck(self.lib.er_decode_csv_host_mt(ptr(text), ctypes.c_int64(text.size), ctypes.c_uint8(sep_b[0]), ctypes.c_int32(F),
+                                              ptr(kinds), ctypes.c_int64(int(max_rows)), ctypes.c_int64(int(pitch)), ptr(ints),
+                                              ptr(flts), ptr(empty), ptr(begin), ptr(length), ctypes.byref(n_rows),
+                                              ctypes.byref(consumed), ctypes.c_int32(int(threads))), 'er_decode_csv_host_mt')
     return n_rows.value, consumed.value, ints, flts, empty, begin, length
 
   def pack_cells_host(self, text, begin, length):

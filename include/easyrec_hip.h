@@ -78,6 +78,18 @@ int er_decode_csv_host(const uint8_t* text_host, int64_t n_bytes, uint8_t separa
                        const int32_t* kinds_host, int64_t max_rows, int64_t* int_out, double* flt_out,
                        uint8_t* empty_out, int64_t* str_begin, int32_t* str_len, int64_t* n_rows_out,
                        int64_t* consumed_out);
+/* ... on n_threads host threads (<= 0: one per hardware thread, at most 16; at least 256 rows per thread): one pass finds
+ * the lines, the threads parse disjoint row ranges into the same outputs; plain decimal cells take an inline fast path
+ * (integers; decimals of <= 15 significant digits as ONE exact division - the correctly rounded value, i.e. strtod's),
+ * everything else strtoll / strtod.  Same results, same errors (the failing line with the smallest index is reported).
+ * out_stride (>= max_rows): elements between consecutive fields of the outputs - give it a pitch that is not a power of
+ * two (a row's fields at a 4096-element pitch all fall into the same cache sets).
+ * tf.decode_csv under tf.data's parallel map (input/csv_input.py:33-76, input/input.py:1057-1110) is the reference's
+ * form of the same thing. */
+int er_decode_csv_host_mt(const uint8_t* text, int64_t n_bytes, uint8_t sep, int32_t n_fields, const int32_t* kinds,
+                          int64_t max_rows, int64_t out_stride, int64_t* int_out, double* flt_out, uint8_t* empty_out,
+                          int64_t* str_begin, int32_t* str_len, int64_t* n_rows_out, int64_t* consumed_out,
+                          int32_t n_threads);
 /* The string cells of a decoded batch (any order, e.g. feature-major) -> packed bytes + offsets[n + 1], the input of
  * er_hash_bucket_fast(_host).  out_bytes holds sum(length) bytes. */
 int er_pack_cells_host(const uint8_t* text_host, const int64_t* begin, const int32_t* length, int64_t n,

@@ -252,7 +252,7 @@ class RefBackend(object):
   def hash_bucket_fast_host(self, bytes_np, offsets_np, n_per_col, num_buckets, drop_empty):
     return hashing.hash_bucket_fast(bytes_np, offsets_np, n_per_col, num_buckets, drop_empty)
 
-  def decode_csv_host(self, text, sep, kinds, max_rows):
+  def decode_csv_host(self, text, sep, kinds, max_rows, threads=0, out=None):
     """Line by line in Python (what tf.decode_csv does per record, input/csv_input.py:33-76)."""
     raw = np.ascontiguousarray(text, dtype=np.uint8).tobytes()
     sep_b = sep.encode('utf-8') if isinstance(sep, str) else bytes(sep)

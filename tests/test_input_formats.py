@@ -227,6 +227,79 @@ def test_native_csv_decode_equals_the_line_by_line_path(tmp_path, built_lib, dro
       assert np.array_equal(np.asarray(a[k]), np.asarray(b[k])), k
 
 
+def _random_cells(rng, kind):
+  """what a cell of a numeric / string column may hold: plain and signed decimals, long mantissas, exponents, leading
+  zeros and dots (the fast path's edges and what it must hand to strtoll / strtod), empty cells"""
+  if kind == 0:
+    return rng.choice(['', 'abc', '%08x' % rng.integers(0, 2**32), 'x' * int(rng.integers(1, 40))])
+  if kind == 1:
+    return rng.choice(['', '0', '-0', '+7', '%d' % rng.integers(-10**6, 10**6), '%d' % rng.integers(-2**62, 2**62),
+                       '000123', '999999999999999999', '-999999999999999999', '1234567890123456789'])
+  return rng.choice(['', '0', '-0.0', '.5', '5.', '+.25', '%.6f' % rng.normal(), '%d' % rng.integers(-500, 500), '1e2', '-3.5E-3',
+                     '123456789012345', '1234567890123456', '0.1234567890123456789', '%.15g' % rng.normal(),
+                     '%.17g' % rng.normal(), '0000.5000', '3.', 'inf', '1' + '0' * 25, '0.' + '0' * 23 + '1'])
+
+
+@pytest.mark.parametrize('threads', [0, 2, 5])
+@pytest.mark.parametrize('seed', [0, 1, 2])
+def test_threaded_csv_decode_equals_the_single_pass_decoder(built_lib, threads, seed):
+  """er_decode_csv_host_mt (lines found in one pass, row ranges parsed by host threads, inline fast paths for plain
+  decimals) against er_decode_csv_host (one thread, strtoll / strtod on every cell): every output array bit for bit -
+  doubles compared as bit patterns -, the row count, the consumed bytes; CRLF, blank lines, an unterminated last line,
+  max_rows below and above the number of lines.  Host code: no device needed."""
+  from easyrec_amd import kernels
+  be = kernels.HipBackend.__new__(kernels.HipBackend)  # (host entry points only: no device is touched)
+  import ctypes
+  be.lib = ctypes.CDLL(built_lib)
+  be.lib.er_last_error.restype = ctypes.c_char_p
+  rng = np.random.default_rng(seed)
+  kinds = [int(k) for k in rng.integers(0, 3, size=9)]
+  n_lines = 1500
+  rows = []
+  for i in range(n_lines):
+    rows.append('\t'.join(str(_random_cells(rng, k)) for k in kinds))
+    if rng.random() < 0.03:
+      rows.append('')  # blank line
+  eol = '\r\n' if seed == 1 else '\n'
+  body = eol.join(rows) + (eol if seed != 2 else '')  # seed 2: the last line is not terminated
+  # (a line made of empty cells only is not blank: it has separators)
+  text = np.frombuffer(body.encode('utf-8'), dtype=np.uint8)
+  n_terminated = sum(1 for r in (rows if seed != 2 else rows[:-1]) if r != '')
+  for max_rows in (100, 700, 5000):
+    one = be.decode_csv_host(text, '\t', kinds, max_rows, threads=1)
+    many = be.decode_csv_host(text, '\t', kinds, max_rows, threads=threads)
+    n = one[0]
+    assert n == many[0] == min(max_rows, n_terminated) and one[1] == many[1]
+    for a, b, what in zip(one[2:], many[2:], ('ints', 'floats', 'empty', 'begin', 'length')):
+      a, b = a[:, :n], b[:, :n]
+      if what == 'floats':
+        a, b = a.view(np.int64), b.view(np.int64)
+      assert np.array_equal(a, b), (what, max_rows)
+
+
+def test_threaded_csv_decode_reports_the_first_bad_line(built_lib):
+  """a line with too few fields / a cell that is not a number: the same error, naming the SMALLEST failing line, whatever
+  thread met it"""
+  from easyrec_amd import kernels
+  import ctypes
+  be = kernels.HipBackend.__new__(kernels.HipBackend)
+  be.lib = ctypes.CDLL(built_lib)
+  be.lib.er_last_error.restype = ctypes.c_char_p
+  good = '1\t2.5\tabc'
+  for bad, what in (('1\t2.5', 'fewer than 3 fields'), ('1\t2.5\tabc\tx', 'more than 3 fields'), ('1\tzz\tabc', "'zz' is not a number")):
+    rows = [good] * 2000
+    rows[1500] = bad
+    rows[700] = bad
+    text = np.frombuffer(('\n'.join(rows) + '\n').encode('utf-8'), dtype=np.uint8)
+    msgs = []
+    for threads in (1, 4):
+      with pytest.raises(RuntimeError) as e:
+        be.decode_csv_host(text, '\t', [1, 2, 0], 4096, threads=threads)
+      msgs.append(str(e.value).split('failed')[-1])
+    assert 'line 700' in msgs[0] and what in msgs[0]
+    assert msgs[0].split(':', 1)[-1].strip() == msgs[1].split(':', 1)[-1].strip()
+
+
 @pytest.mark.parametrize('file_shard', [False, True])
 def test_csv_workers_read_disjoint_parts_of_the_data(tmp_path, built_lib, file_shard, monkeypatch):
   """One process per GPU: worker r of W takes line k of the data set when k % W == r (reference

@@ -27,8 +27,9 @@ with tempfile.NamedTemporaryFile('w', suffix='.tsv', delete=False) as f:
     f.write('\t'.join(['%d' % (i % 2)] + fl + c) + '\n')
   path = f.name
 kernels.hip()  # load the library once (host entry points only)
-for native in ('1', '0'):
+for native, threads in (('1', '0'), ('1', '1'), ('0', '1')):
   os.environ['EASYREC_AMD_NATIVE_CSV'] = native
+  os.environ['EASYREC_AMD_CSV_THREADS'] = threads
   for host_hash in (False, True):
     best = 0.0
     for _ in range(3):
@@ -36,6 +37,18 @@ for native in ('1', '0'):
       t0 = time.perf_counter()
       nb = sum(1 for _ in inp.batches())
       best = max(best, nb * B / (time.perf_counter() - t0))
-    print('native decode %s, ids hashed on the %s: %.0f examples/s (best of 3, one core)' %
-          ('on ' if native == '1' else 'off', 'host  ' if host_hash else 'device', best))
+    print('native decode %s (%s), ids hashed on the %s: %.0f examples/s (best of 3)' %
+          ('on ' if native == '1' else 'off', ('%d host threads' % min(os.cpu_count() or 1, 16)) if threads == '0' and native == '1'
+           else 'one thread', 'host  ' if host_hash else 'device', best))
+# the decode call alone, per 4096-line batch
+text = np.frombuffer(open(path, 'rb').read(), dtype=np.uint8)
+kinds = [1] + [2] * 13 + [0] * 26
+be = kernels.hip()
+for threads in (1, 2, 4, 8, 0):
+  t0 = time.perf_counter()
+  reps = 20
+  for _ in range(reps):
+    be.decode_csv_host(text, '\t', kinds, B, threads=threads)
+  dt = (time.perf_counter() - t0) / reps
+  print('decode of one %d-line batch, threads=%d: %.2f ms = %.2f M lines/s' % (B, threads, dt * 1e3, B / dt / 1e6))
 os.unlink(path)
