@@ -66,6 +66,14 @@ class PackedCol(object):
       yield self[i]
 
 
+class IntCol(object):
+  """An integer input column of a hashed IdFeature: hashed as its values' decimal strings (`_as_string`, input.py:356-376)."""
+  __slots__ = ('values',)
+
+  def __init__(self, values):
+    self.values = np.ascontiguousarray(values, dtype=np.int64)
+
+
 def pack_columns(cols):
   """[PackedCol ...] over ONE text buffer -> (uint8 bytes, int64 offsets) of all their cells, column after column
   (er_pack_cells_host: one pass of memcpy instead of a Python loop over every cell)."""
@@ -328,8 +336,14 @@ class Input(object, metaclass=_meta_type):
         col = columns[fc.input_names[0]]
         if name in sch.hash_single:
           ftype = self.field_type(fc.input_names[0])
-          hash_strings[sch.hash_single[name]['col']] = as_string(col, ftype, fc.precision) \
-              if ftype != DatasetConfig.STRING else col
+          if ftype not in (DatasetConfig.FLOAT, DatasetConfig.DOUBLE) and isinstance(col, np.ndarray) and col.dtype.kind in 'iu':
+            # an integer array (the Criteo binary format's categories, whatever type the data_config declares for the
+            # field: a string field fed integers is hashed as str(int) too): its decimal strings are written by one
+            # native pass below (IntCol), not as 4096 Python strings per feature
+            hash_strings[sch.hash_single[name]['col']] = IntCol(col)
+          else:
+            hash_strings[sch.hash_single[name]['col']] = as_string(col, ftype, fc.precision) \
+                if ftype != DatasetConfig.STRING else col
         else:
           c = sch.int_single[name]['col']
           if fc.vocab_list:
@@ -371,9 +385,14 @@ class Input(object, metaclass=_meta_type):
     if hash_strings:
       if all(isinstance(s, PackedCol) for s in hash_strings) and len({id(s.buf) for s in hash_strings}) == 1:
         data, offsets = pack_columns(hash_strings)  # cells of the decoded text batch: no per-cell Python work
+      elif all(isinstance(s, IntCol) for s in hash_strings):
+        from easyrec_amd import kernels
+        data, offsets = kernels.hip().pack_int_decimal_host(np.concatenate([s.values for s in hash_strings]))
       else:
         flat = []
         for s in hash_strings:
+          if isinstance(s, IntCol):
+            s = [str(int(v)) for v in s.values]
           flat.extend(s if s is not None else [''] * B)
         data, offsets = pack_strings(flat)
       if self._hash_on_host:

@@ -570,6 +570,18 @@ class HipBackend(object):
                                          ptr(out), ptr(offsets)), 'er_pack_cells_host')
     return out[:int(offsets[-1])], offsets
 
+  def pack_int_decimal_host(self, values):
+    """int64 array -> (packed uint8 bytes, int64 offsets[n + 1]) of the values' decimal strings (str(int))."""
+    values = np.ascontiguousarray(values, dtype=np.int64).reshape(-1)
+    n = values.size
+    out = np.empty(max(20 * n, 1), dtype=np.uint8)
+    offsets = np.empty(n + 1, dtype=np.int64)
+
+    def ptr(a):
+      return a.ctypes.data_as(ctypes.c_void_p)
+    self._ck(self.lib.er_pack_int_decimal_host(ptr(values), ctypes.c_int64(n), ptr(out), ptr(offsets)), 'er_pack_int_decimal_host')
+    return out[:int(offsets[-1])], offsets
+
   def sparse_cross_hashed_host(self, bytes_np, offsets_np, n_rows, n_cols, num_buckets, hash_key=None):
     """ComboFeature through crossed_column: column-major strings -> int64 [n_rows] bucket ids ('' is a value too)."""
     bytes_np = np.ascontiguousarray(bytes_np, dtype=np.uint8)

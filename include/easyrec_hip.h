@@ -94,6 +94,11 @@ int er_decode_csv_host_mt(const uint8_t* text, int64_t n_bytes, uint8_t sep, int
  * er_hash_bucket_fast(_host).  out_bytes holds sum(length) bytes. */
 int er_pack_cells_host(const uint8_t* text_host, const int64_t* begin, const int32_t* length, int64_t n,
                        uint8_t* out_bytes, int64_t* out_offsets);
+/* n int64 values as decimal strings (Python's str(int): the reference's `_as_string` of an integer column,
+ * input/input.py:356-376), packed like er_pack_cells_host's output - hashed IdFeatures fed from integer columns (the
+ * Criteo binary format's uint32 categories, input/criteo_input.py:75-85) without a Python object per value.  out_bytes:
+ * 20 bytes per value. */
+int er_pack_int_decimal_host(const int64_t* values, int64_t n, uint8_t* out_bytes, int64_t* out_offsets);
 /* ComboFeature through `crossed_column` (reference feature_column/feature_column.py:434-445 ->
  * CrossedColumn._transform_feature, compat/feature_column/feature_column_v2.py:4527-4560 -> TF's
  * sparse_cross_hashed): one string per (column, row), column-major (string i = c * n_rows + r);

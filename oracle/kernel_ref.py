@@ -289,6 +289,12 @@ class RefBackend(object):
     np.cumsum([len(c) for c in cells], out=offsets[1:])
     return np.frombuffer(b''.join(cells), dtype=np.uint8) if offsets[-1] else np.zeros(0, dtype=np.uint8), offsets
 
+  def pack_int_decimal_host(self, values):
+    enc = [str(int(v)).encode('ascii') for v in np.asarray(values).reshape(-1)]
+    offsets = np.zeros(len(enc) + 1, dtype=np.int64)
+    np.cumsum([len(e) for e in enc], out=offsets[1:])
+    return np.frombuffer(b''.join(enc), dtype=np.uint8) if enc else np.zeros(0, dtype=np.uint8), offsets
+
   def sparse_cross_hashed_host(self, bytes_np, offsets_np, n_rows, n_cols, num_buckets, hash_key=None):
     key = hashing.DEFAULT_CROSS_HASH_KEY if hash_key is None else hash_key
     return hashing.sparse_cross_hashed_columns(bytes_np, offsets_np, n_rows, n_cols, num_buckets, key)

@@ -300,6 +300,28 @@ def test_threaded_csv_decode_reports_the_first_bad_line(built_lib):
     assert msgs[0].split(':', 1)[-1].strip() == msgs[1].split(':', 1)[-1].strip()
 
 
+def test_integer_columns_are_hashed_as_their_decimal_strings_by_one_native_pass(built_lib):
+  """er_pack_int_decimal_host: the packed decimal strings of an int64 array are Python's str(int) of every value (the
+  reference's `_as_string` of an integer column, input.py:356-376) - digits two at a time, 32-bit arithmetic once they
+  fit: the boundaries of both, negative values, the int64 extremes."""
+  import ctypes
+  from easyrec_amd import kernels
+  be = kernels.HipBackend.__new__(kernels.HipBackend)
+  be.lib = ctypes.CDLL(built_lib)
+  be.lib.er_last_error.restype = ctypes.c_char_p
+  rng = np.random.default_rng(3)
+  edge = [0, -1, 9, 10, 99, 100, 101, 999, 1000, 2**32 - 1, 2**32, 2**32 + 1, 4294967295000, 10**18, -10**18, 2**63 - 1, -2**63]
+  vals = np.concatenate([rng.integers(0, 2**32, size=5000), rng.integers(-2**63, 2**63 - 1, size=2000, dtype=np.int64),
+                         np.array(edge, dtype=np.int64)]).astype(np.int64)
+  data, offs = be.pack_int_decimal_host(vals)
+  raw = data.tobytes()
+  assert offs[0] == 0 and offs[-1] == len(raw)
+  for i, v in enumerate(vals):
+    assert raw[offs[i]:offs[i + 1]] == str(int(v)).encode('ascii'), (i, int(v))
+  empty, eo = be.pack_int_decimal_host(np.zeros(0, dtype=np.int64))
+  assert empty.size == 0 and list(eo) == [0]
+
+
 @pytest.mark.parametrize('file_shard', [False, True])
 def test_csv_workers_read_disjoint_parts_of_the_data(tmp_path, built_lib, file_shard, monkeypatch):
   """One process per GPU: worker r of W takes line k of the data set when k % W == r (reference

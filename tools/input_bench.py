@@ -1,0 +1,45 @@
+#!/usr/bin/env python
+"""Host-side input rates of the packed formats on the Criteo layout, next to the CSV reader's
+(tools/csv_bench.py): CriteoInput over the three flat binary files of a part, ParquetInput over packed row groups.  What
+is timed is everything the host does per batch up to the packed arrays the device buffers take (no GPU needed).
+usage: python tools/input_bench.py [rows]"""
+import os
+import sys
+import tempfile
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import logging  # noqa: E402
+
+import numpy as np  # noqa: E402
+
+logging.disable(logging.WARNING)
+from easyrec_amd import kernels  # noqa: E402
+from easyrec_amd.utils import config_util  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+B = 4096
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 64 * B
+rng = np.random.default_rng(0)
+kernels.hip()
+tmp = tempfile.mkdtemp()
+
+# -- Criteo binary
+from easyrec_amd.input.criteo_input import CriteoInput  # noqa: E402
+
+cfg = config_util.get_configs_from_pipeline_file(os.path.join(ROOT, 'configs', 'deepfm_criteo_small.config'))
+rng.integers(0, 2, size=n, dtype=np.int32).tofile(os.path.join(tmp, 'p0_label.bin'))
+rng.random((n, 13), dtype=np.float32).tofile(os.path.join(tmp, 'p0_dense.bin'))
+rng.integers(0, 2**32, size=(n, 26), dtype=np.uint32).tofile(os.path.join(tmp, 'p0_category.bin'))
+try:
+  best = 0.0
+  for _ in range(3):
+    inp = CriteoInput(cfg.data_config, list(cfg.feature_config.features),
+                      {'label_path': [os.path.join(tmp, 'p0_label.bin')], 'dense_path': [os.path.join(tmp, 'p0_dense.bin')],
+                       'category_path': [os.path.join(tmp, 'p0_category.bin')]}, batch_size=B)
+    t0 = time.perf_counter()
+    nb = sum(1 for _ in inp.batches())
+    best = max(best, nb * B / (time.perf_counter() - t0))
+  print('Criteo binary (memory-mapped parts -> packed batch): %.2f M examples/s (best of 3, %d batches)' % (best / 1e6, nb))
+except Exception as e:  # noqa: BLE001
+  print('Criteo binary: not run (%s)' % str(e)[:200])
