@@ -342,6 +342,46 @@ int er_pack_cells_host(const uint8_t* text, const int64_t* begin, const int32_t*
   return 0;
 }
 
+// The cells (begin, length) of a text buffer split into tokens - what tf.string_split / tf.strings.split do to a TagFeature's
+// or a SequenceFeature's column (reference input/input.py:488-530, 680-690) - as (begin, length) views of the same buffer
+// plus row offsets [n + 1]: the ragged layout the lookup kernels take, with no per-row Python work.
+//   keep_empty 0 (tf.string_split, tags): EVERY byte of `seps` is a delimiter, empty tokens are skipped, an empty cell has
+//     no token;
+//   keep_empty 1 (tf.strings.split with a one-byte separator, sequences): empty tokens stay, an empty cell is ONE empty
+//     token; at most max_tokens per cell are kept (max_seq_len truncation; <= 0: all).
+// tok_begin / tok_len hold `capacity` entries (sum(length) + n always suffices).  Returns 0 and the token count in
+// row_offsets[n].
+int er_split_cells_host(const uint8_t* text, const int64_t* begin, const int32_t* length, int64_t n, const uint8_t* seps,
+                        int32_t n_seps, int32_t keep_empty, int32_t max_tokens, int64_t* tok_begin, int32_t* tok_len,
+                        int64_t capacity, int64_t* row_offsets) {
+  ER_REQUIRE(begin && length && seps && tok_begin && tok_len && row_offsets && n >= 0 && n_seps >= 1 && capacity >= 0 &&
+                 (n == 0 || text) && (!keep_empty || n_seps == 1),
+             "er_split_cells_host: bad arguments");
+  bool is_sep[256];
+  memset(is_sep, 0, sizeof(is_sep));
+  for (int32_t k = 0; k < n_seps; ++k) is_sep[seps[k]] = true;
+  int64_t t = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    row_offsets[i] = t;
+    const int64_t b = begin[i], e = b + length[i];
+    int64_t kept = 0, tb = b;
+    for (int64_t p = b; p <= e; ++p) {
+      if (p < e && !is_sep[text[p]]) continue;
+      const int64_t len = p - tb;  // a token ends at a delimiter or at the end of the cell
+      if ((keep_empty || len > 0) && (max_tokens <= 0 || kept < max_tokens)) {
+        ER_REQUIRE(t < capacity, "er_split_cells_host: more than %lld tokens", (long long)capacity);
+        tok_begin[t] = tb;
+        tok_len[t] = static_cast<int32_t>(len);
+        ++t;
+        ++kept;
+      }
+      tb = p + 1;
+    }
+  }
+  row_offsets[n] = t;
+  return 0;
+}
+
 // n int64 values as decimal strings ("-12", "0", "4294967295": Python's str(int), the reference's `_as_string` of an
 // integer column, input/input.py:356-376) packed like er_pack_cells_host's output: what er_hash_bucket_fast(_host) takes
 // for hashed IdFeatures fed from integer columns (the Criteo binary format's uint32 categories,

@@ -11,6 +11,7 @@ feature types on the hot path:
 This is plumbing around the hot path (it runs in data-loader threads on the host); only the id
 hashing is done by the library (`er_hash_bucket_fast_host` here, or on device from packed bytes).
 """
+import os
 import re
 from collections import OrderedDict
 
@@ -72,6 +73,15 @@ class IntCol(object):
 
   def __init__(self, values):
     self.values = np.ascontiguousarray(values, dtype=np.int64)
+
+
+def as_cells(col):
+  """Any string column -> (text buffer uint8, begin int64 [n], length int32 [n]): a PackedCol as it is, a list of str /
+  bytes packed once (per cell, not per token)."""
+  if isinstance(col, PackedCol):
+    return col.buf, col.begin, col.length
+  data, offsets = pack_strings(col)
+  return data, offsets[:-1].copy(), np.diff(offsets).astype(np.int32)
 
 
 def pack_columns(cols):
@@ -177,9 +187,34 @@ class Input(object, metaclass=_meta_type):
     data, offsets = pack_strings(tokens)
     return kernels.hip().hash_bucket_fast_host(data, offsets, max(len(tokens), 1), [buckets], False)
 
+  # TagFeature / SequenceFeature columns split by one native pass (er_split_cells_host) instead of a Python loop over the
+  # rows: hashed features with ASCII separators (the Taobao layouts); everything else keeps the per-row code below
+  native_split = os.environ.get('EASYREC_AMD_NATIVE_SPLIT', '1') != '0'
+
+  def _native_split_ok(self, fc, col):
+    from easyrec_amd import kernels
+    be = kernels.hip()
+    sep = fc.separator
+    return (self.native_split and hasattr(be, 'split_cells_host') and fc.HasField('hash_bucket_size') and
+            fc.hash_bucket_size > 0 and len(sep) >= 1 and all(ord(c) < 128 for c in sep) and
+            (isinstance(col, PackedCol) or all(isinstance(s, (str, bytes)) for s in col)))
+
   def _parse_tag(self, fc, columns, out, name):
     B = self._batch_size
     col = columns[fc.input_names[0]]
+    if len(fc.input_names) == 1 and not fc.HasField('kv_separator') and self._native_split_ok(fc, col):
+      from easyrec_amd import kernels
+      be = kernels.hip()
+      text, begin, length = as_cells(col)
+      tb, tl, offs = be.split_cells_host(text, begin, length, fc.separator, keep_empty=False)
+      if len(tb):
+        data, offsets = be.pack_cells_host(text, tb, tl)
+        ids = be.hash_bucket_fast_host(data, offsets, len(tb), [int(fc.hash_bucket_size)], False)
+      else:
+        ids = np.zeros(0, dtype=np.int64)
+      out['tag/%s/ids' % name] = ids
+      out['tag/%s/offsets' % name] = offs.astype(np.int32)
+      return
     toks, offs, wts = [], np.zeros(B + 1, dtype=np.int32), []
     for i, s in enumerate(col):
       parts = self._split_charset(s, fc.separator)
@@ -273,6 +308,21 @@ class Input(object, metaclass=_meta_type):
     col = columns[fc.input_names[0]]
     ids = np.full((B, L), -1, dtype=np.int64)
     lens = np.zeros(B, dtype=np.int32)
+    if 'bounds' not in self.schema.seqs[name] and len(fc.separator) == 1 and self._native_split_ok(fc, col):
+      # tf.strings.split on the one-byte separator: empty tokens stay, an empty cell is one empty token, max_seq_len cut
+      from easyrec_amd import kernels
+      be = kernels.hip()
+      text, begin, length = as_cells(col)
+      tb, tl, offs = be.split_cells_host(text, begin, length, fc.separator, keep_empty=True, max_tokens=L)
+      if len(tb):
+        data, offsets = be.pack_cells_host(text, tb, tl)
+        v = be.hash_bucket_fast_host(data, offsets, len(tb), [int(self.schema.seqs[name]['hash_buckets'])], False)
+        lens[:] = np.diff(offs).astype(np.int32)
+        rows = np.repeat(np.arange(B, dtype=np.int64), lens)
+        ids[rows, np.arange(len(tb), dtype=np.int64) - offs[:-1][rows]] = v
+      out['seq/%s/ids' % name] = ids
+      out['seq/%s/len' % name] = lens
+      return
     for i, s in enumerate(col):
       if isinstance(s, bytes):
         s = s.decode('utf-8')

@@ -570,6 +570,27 @@ class HipBackend(object):
                                          ptr(out), ptr(offsets)), 'er_pack_cells_host')
     return out[:int(offsets[-1])], offsets
 
+  def split_cells_host(self, text, begin, length, seps, keep_empty=False, max_tokens=0):
+    """Cells (begin, length) of `text` split on the bytes of `seps` -> (tok_begin int64 [T], tok_len int32 [T],
+    row_offsets int64 [n + 1]) (er_split_cells_host)."""
+    text = np.ascontiguousarray(text, dtype=np.uint8)
+    begin = np.ascontiguousarray(begin, dtype=np.int64)
+    length = np.ascontiguousarray(length, dtype=np.int32)
+    n = len(begin)
+    cap = int(length.sum(dtype=np.int64)) + n + 1
+    tb, tl = np.empty(cap, dtype=np.int64), np.empty(cap, dtype=np.int32)
+    offs = np.empty(n + 1, dtype=np.int64)
+    sb = np.frombuffer(seps if isinstance(seps, bytes) else seps.encode('utf-8'), dtype=np.uint8)
+
+    def ptr(a):
+      return a.ctypes.data_as(ctypes.c_void_p)
+    self._ck(self.lib.er_split_cells_host(ptr(text) if text.size else ptr(tb), ptr(begin), ptr(length), ctypes.c_int64(n), ptr(sb),
+                                          ctypes.c_int32(len(sb)), ctypes.c_int32(int(bool(keep_empty))),
+                                          ctypes.c_int32(int(max_tokens)), ptr(tb), ptr(tl), ctypes.c_int64(cap), ptr(offs)),
+             'er_split_cells_host')
+    T = int(offs[-1])
+    return tb[:T], tl[:T], offs
+
   def pack_int_decimal_host(self, values):
     """int64 array -> (packed uint8 bytes, int64 offsets[n + 1]) of the values' decimal strings (str(int))."""
     values = np.ascontiguousarray(values, dtype=np.int64).reshape(-1)

@@ -99,6 +99,15 @@ int er_pack_cells_host(const uint8_t* text_host, const int64_t* begin, const int
  * Criteo binary format's uint32 categories, input/criteo_input.py:75-85) without a Python object per value.  out_bytes:
  * 20 bytes per value. */
 int er_pack_int_decimal_host(const int64_t* values, int64_t n, uint8_t* out_bytes, int64_t* out_offsets);
+/* The cells (begin, length) of a text buffer split into tokens as (begin, length) views of the same buffer + row offsets
+ * [n + 1] - what tf.string_split / tf.strings.split do to a TagFeature's or SequenceFeature's column (reference
+ * input/input.py:488-530, 680-690), in the ragged layout the lookup kernels take.  keep_empty 0 (tags): every byte of
+ * `seps` is a delimiter, empty tokens are skipped; keep_empty 1 (sequences, one-byte separator): empty tokens stay, an
+ * empty cell is one empty token, at most max_tokens per cell (<= 0: all).  tok_begin / tok_len: `capacity` entries
+ * (sum(length) + n always suffices); the token count is left in row_offsets[n]. */
+int er_split_cells_host(const uint8_t* text, const int64_t* begin, const int32_t* length, int64_t n, const uint8_t* seps,
+                        int32_t n_seps, int32_t keep_empty, int32_t max_tokens, int64_t* tok_begin, int32_t* tok_len,
+                        int64_t capacity, int64_t* row_offsets);
 /* ComboFeature through `crossed_column` (reference feature_column/feature_column.py:434-445 ->
  * CrossedColumn._transform_feature, compat/feature_column/feature_column_v2.py:4527-4560 -> TF's
  * sparse_cross_hashed): one string per (column, row), column-major (string i = c * n_rows + r);

@@ -322,6 +322,73 @@ def test_integer_columns_are_hashed_as_their_decimal_strings_by_one_native_pass(
   assert empty.size == 0 and list(eo) == [0]
 
 
+@pytest.mark.parametrize('config', ['mmoe_taobao_small.config', 'din_taobao_small.config'])
+@pytest.mark.parametrize('packed', [False, True])
+def test_native_tag_and_sequence_split_equals_the_per_row_path(built_lib, config, packed, monkeypatch):
+  """er_split_cells_host (TagFeature: tf.string_split, every separator byte a delimiter, empty tokens skipped;
+  SequenceFeature: tf.strings.split, empty tokens kept, an empty cell = one empty token, max_seq_len cut) + ONE hash call
+  per feature against the per-row Python code: every array of the batch dict, for list-of-str columns and for PackedCol
+  views of a text buffer; empty cells, leading / trailing / doubled separators, multi-byte UTF-8 tokens, sequences longer
+  than max_seq_len.  Host code only."""
+  from easyrec_amd import kernels
+  from easyrec_amd.input.input import Input, PackedCol, pack_strings
+  from easyrec_amd.input.synthetic import SyntheticBatches
+  from easyrec_amd.protos.feature_config_pb2 import FeatureConfig
+  monkeypatch.setattr(kernels, '_BACKEND', None)
+  be = kernels.HipBackend.__new__(kernels.HipBackend)  # (host entry points only: no device is touched)
+  import ctypes
+  be.lib = ctypes.CDLL(built_lib)
+  be.lib.er_last_error.restype = ctypes.c_char_p
+  monkeypatch.setattr(kernels, '_BACKEND', be)
+  cfg = config_util.get_configs_from_pipeline_file(os.path.join(ROOT, 'configs', config))
+  feats = list(cfg.feature_config.features)
+  B = 64
+  inp = Input(cfg.data_config, feats, batch_size=B, hash_on_host=True)
+  rng = np.random.default_rng(5)
+  words = ['a', 'bb', '1234', 'x' * 20, 'é', '日本', '0', '']
+  split_feats = [f for f in feats if f.feature_type in (FeatureConfig.TagFeature, FeatureConfig.SequenceFeature)]
+  assert split_feats
+
+  def cell(sep, n_max):
+    k = int(rng.integers(0, n_max))
+    toks = [str(rng.choice(words)) for _ in range(k)]
+    c = sep.join(toks)
+    r = rng.random()
+    return sep + c if r < 0.1 else c + sep if r < 0.2 else c.replace(sep, sep + sep, 1) if r < 0.3 else c
+
+  gen = SyntheticBatches(cfg.data_config, feats, batch_size=B, seed=3)
+  cols = {k: list(v) if not isinstance(v, np.ndarray) else v for k, v in gen.raw_columns().items()} \
+      if hasattr(gen, 'raw_columns') else None
+  if cols is None:  # build the columns by hand: every input field a plausible value, the split columns the edge cases
+    cols = {}
+    for f in cfg.data_config.input_fields:
+      cols[f.input_name] = ['%d' % rng.integers(0, 50) for _ in range(B)]
+  for f in split_feats:
+    n_max = 70 if f.feature_type == FeatureConfig.SequenceFeature else 6
+    cols[f.input_names[0]] = [cell(f.separator or '|', n_max) for _ in range(B)]
+    cols[f.input_names[0]][0] = ''
+  if packed:  # the columns as PackedCol views of one text buffer, as the native CSV decoder hands them over
+    for f in split_feats:
+      data, offs = pack_strings(cols[f.input_names[0]])
+      cols[f.input_names[0]] = PackedCol(data, offs[:-1].copy(), np.diff(offs).astype(np.int32))
+  outs, calls = [], []
+  real_split = be.split_cells_host
+  be.split_cells_host = lambda *a, **kw: (calls.append(1), real_split(*a, **kw))[1]
+  for native in (True, False):
+    inp.native_split = native
+    outs.append(inp.preprocess({k: v for k, v in cols.items()}))
+    if native:
+      assert len(calls) == len(split_feats)  # (every tag / sequence column took the native pass)
+  assert len(calls) == len(split_feats)
+  a, b = outs
+  assert set(a) == set(b)
+  checked = 0
+  for k in a:
+    assert np.array_equal(np.asarray(a[k]), np.asarray(b[k])), k
+    checked += k.startswith('tag/') or k.startswith('seq/')
+  assert checked >= 2 * len(split_feats)
+
+
 @pytest.mark.parametrize('file_shard', [False, True])
 def test_csv_workers_read_disjoint_parts_of_the_data(tmp_path, built_lib, file_shard, monkeypatch):
   """One process per GPU: worker r of W takes line k of the data set when k % W == r (reference

@@ -43,3 +43,38 @@ try:
   print('Criteo binary (memory-mapped parts -> packed batch): %.2f M examples/s (best of 3, %d batches)' % (best / 1e6, nb))
 except Exception as e:  # noqa: BLE001
   print('Criteo binary: not run (%s)' % str(e)[:200])
+
+# -- CSV with TagFeature / SequenceFeature columns (the Taobao layouts of BASELINE configs 4-5): the per-row Python split
+#    against er_split_cells_host + one hash call per feature
+from easyrec_amd.input.csv_input import CSVInput  # noqa: E402
+from easyrec_amd.protos.feature_config_pb2 import FeatureConfig  # noqa: E402
+
+for config in ('din_taobao_small.config', 'mmoe_taobao_small.config'):
+  cfg = config_util.get_configs_from_pipeline_file(os.path.join(ROOT, 'configs', config))
+  feats = list(cfg.feature_config.features)
+  sep = cfg.data_config.separator
+  split = {f.input_names[0]: (f.separator or '|', 50 if f.feature_type == FeatureConfig.SequenceFeature else 4)
+           for f in feats if f.feature_type in (FeatureConfig.TagFeature, FeatureConfig.SequenceFeature)}
+  rows = 16 * 1024
+  path = os.path.join(tmp, config + '.csv')
+  with open(path, 'w') as f:
+    for i in range(rows):
+      cells = []
+      for fld in cfg.data_config.input_fields:
+        if fld.input_name in split:
+          s, k = split[fld.input_name]
+          cells.append(s.join('%d' % rng.integers(0, 100000) for _ in range(int(rng.integers(1, k + 1)))))
+        else:
+          cells.append('%d' % rng.integers(0, 2 if fld.input_name in cfg.data_config.label_fields else 1000))
+      f.write(sep.join(cells) + '\n')
+  for native in ('1', '0'):
+    os.environ['EASYREC_AMD_NATIVE_SPLIT'] = native
+    best = 0.0
+    for _ in range(2):
+      inp = CSVInput(cfg.data_config, feats, path, batch_size=1024, hash_on_host=True)
+      inp.native_split = native == '1'
+      t0 = time.perf_counter()
+      nb = sum(1 for _ in inp.batches(num_epochs=1))
+      best = max(best, nb * 1024 / (time.perf_counter() - t0))
+    print('%s as CSV (%d tag / sequence columns), %s split: %.0f examples/s' %
+          (config, len(split), 'native  ' if native == '1' else 'per-row', best))
