@@ -78,3 +78,29 @@ for config in ('din_taobao_small.config', 'mmoe_taobao_small.config'):
       best = max(best, nb * 1024 / (time.perf_counter() - t0))
     print('%s as CSV (%d tag / sequence columns), %s split: %.0f examples/s' %
           (config, len(split), 'native  ' if native == '1' else 'per-row', best))
+
+# -- packed Parquet (the reference's embedding-parallel format): scalar id columns, one ragged id list, dense columns
+try:
+  import pyarrow as pa
+  import pyarrow.parquet as pq
+  from easyrec_amd.input.parquet_input import ParquetInput
+  cfg = config_util.get_configs_from_pipeline_file(os.path.join(ROOT, 'configs', 'deepfm_parquet_small.config'))
+  rows = 64 * 4096
+  lens = rng.integers(0, 5, size=rows)
+  offs = np.zeros(rows + 1, dtype=np.int32)
+  offs[1:] = np.cumsum(lens)
+  t1 = pa.ListArray.from_arrays(pa.array(offs), pa.array(rng.integers(0, 10**9, size=int(offs[-1])).astype(np.int64)))
+  table = pa.table({'label': rng.integers(0, 2, size=rows).astype(np.int32), 's1': rng.integers(0, 10**12, size=rows).astype(np.int64),
+                    's2': rng.integers(0, 1000, size=rows).astype(np.int64), 't1': t1,
+                    'd1': rng.standard_normal(rows).astype(np.float32), 'd2': (rng.random(rows) * 100).astype(np.float32)})
+  path = os.path.join(tmp, 'part-0.parquet')
+  pq.write_table(table, path, row_group_size=4 * 4096)
+  best = 0.0
+  for _ in range(3):
+    inp = ParquetInput(cfg.data_config, list(cfg.feature_config.features), path, batch_size=4096)
+    t0 = time.perf_counter()
+    nb = sum(1 for _ in inp.batches(num_epochs=1))
+    best = max(best, nb * 4096 / (time.perf_counter() - t0))
+  print('packed Parquet (deepfm_parquet_small layout, %d batches of 4096): %.2f M examples/s (best of 3)' % (nb, best / 1e6))
+except Exception as e:  # noqa: BLE001
+  print('packed Parquet: not run (%s)' % str(e)[:300])
