@@ -31,6 +31,8 @@ class ModelContext(object):
     self.tail_jobs = []
     # per step: one gradient buffer per activation tensor shared by its consumers' backward kernels (kernels.grad_slot)
     self.grad_slots = {}
+    # dense_dtype 'bf16' on the GPU: the kernels.Bf16Shadows of the model (weight shadows + the step's bf16 operand copies)
+    self.bf16_state = None
 
 
 @contextlib.contextmanager

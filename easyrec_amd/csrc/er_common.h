@@ -38,6 +38,15 @@ inline hipStream_t as_stream(er_stream_t s) { return reinterpret_cast<hipStream_
 
 __host__ __device__ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// fp32 -> bf16 bits, round to nearest even (NaN stays NaN): what every bf16 copy in the library holds
+__host__ __device__ inline uint16_t f32_to_bf16_bits(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return static_cast<uint16_t>((u >> 16) | 0x40u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return static_cast<uint16_t>(u >> 16);
+}
+
 // Cross-lane moves inside a 16-lane row by DPP (a VALU modifier: a few cycles) instead of ds_bpermute (an LDS-unit
 // instruction: ~100+ cycles of latency per dependent step - a 6-step __shfl_xor butterfly measured ~0.3 us per wave sum,
 // tools/micro/lib_chain.cpp).  quad_perm [1,0,3,2] / [2,3,0,1] ARE the xor-1 / xor-2 exchanges; after them the four lanes

@@ -248,7 +248,9 @@ __device__ __forceinline__ void bn_finalize_apply_body(const float* __restrict__
                          const float* __restrict__ gamma, const float* __restrict__ beta, int B, int N, int chunks,
                          float eps, float momentum, float* __restrict__ moving_mean, float* __restrict__ moving_var,
                          int act, float* __restrict__ y, float* __restrict__ save_mean,
-                         float* __restrict__ save_invstd, int tiles_per_block, int bx, int by) {
+                         float* __restrict__ save_invstd, int tiles_per_block, int bx, int by,
+                         uint16_t* __restrict__ yb = nullptr, int ldyb = 0) {
+  // yb: a bf16 copy of y (row stride ldyb) for the contraction that reads it next (dense_dtype 'bf16': no cast launch)
   __shared__ Welford sm[kRowLanes][kColsPerBlock];
   __shared__ float s_mean[kColsPerBlock], s_inv[kColsPerBlock];
   const int cl = threadIdx.x % kColsPerBlock;
@@ -340,6 +342,10 @@ __device__ __forceinline__ void bn_finalize_apply_body(const float* __restrict__
 #pragma unroll
           for (int j = 0; j < 4; ++j) out[j] = bn_act_one(xv[u][j], bv[j], mu[j], is[j], ga[j], be[j], act);
           *reinterpret_cast<f32x4d*>(y + static_cast<int64_t>(r) * N + c4) = out;
+          if (yb) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) yb[static_cast<int64_t>(r) * ldyb + c4 + j] = f32_to_bf16_bits(out[j]);
+          }
         }
       }
     }
@@ -364,7 +370,11 @@ __device__ __forceinline__ void bn_finalize_apply_body(const float* __restrict__
 #pragma unroll
     for (int k = 0; k < kApplyRows / kRowLanes; ++k) {
       const int r = r0 + k * kRowLanes;
-      if (r < B) y[static_cast<int64_t>(r) * N + c] = bn_act_one(xv[k], bv, mu, is, ga, be, act);
+      if (r < B) {
+        const float o = bn_act_one(xv[k], bv, mu, is, ga, be, act);
+        y[static_cast<int64_t>(r) * N + c] = o;
+        if (yb) yb[static_cast<int64_t>(r) * ldyb + c] = f32_to_bf16_bits(o);
+      }
     }
   }
 }
@@ -374,8 +384,8 @@ bn_finalize_apply_kernel(const float* __restrict__ partial, const float* __restr
                          const float* __restrict__ gamma, const float* __restrict__ beta, int B, int N, int chunks,
                          float eps, float momentum, float* __restrict__ moving_mean, float* __restrict__ moving_var,
                          int act, float* __restrict__ y, float* __restrict__ save_mean,
-                         float* __restrict__ save_invstd, int tiles_per_block) {
-  bn_finalize_apply_body(partial, x, bias, gamma, beta, B, N, chunks, eps, momentum, moving_mean, moving_var, act, y, save_mean, save_invstd, tiles_per_block, static_cast<int>(blockIdx.x), static_cast<int>(blockIdx.y));
+                         float* __restrict__ save_invstd, int tiles_per_block, uint16_t* __restrict__ yb, int ldyb) {
+  bn_finalize_apply_body(partial, x, bias, gamma, beta, B, N, chunks, eps, momentum, moving_mean, moving_var, act, y, save_mean, save_invstd, tiles_per_block, static_cast<int>(blockIdx.x), static_cast<int>(blockIdx.y), yb, ldyb);
 }
 
 
@@ -430,7 +440,9 @@ __device__ __forceinline__ void bn_bwd_finalize_apply_body(const float* __restri
                              const float* __restrict__ invstd, const float* __restrict__ dy, int B, int N,
                              int chunks, int use_bn, int act, int accumulate, float* __restrict__ dx,
                              float* __restrict__ dbias, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                             int dy_ld, int tiles_per_block, int bx, int by) {
+                             int dy_ld, int tiles_per_block, int bx, int by, uint16_t* __restrict__ dxb = nullptr,
+                             int lddxb = 0) {
+  // dxb: a bf16 copy of dx (row stride lddxb) for the input-gradient contraction that reads it next
   __shared__ float sm[2][kRowLanes][kColsPerBlock];
   __shared__ float s_g[kColsPerBlock], s_gx[kColsPerBlock];
   const int cl = threadIdx.x % kColsPerBlock;
@@ -517,6 +529,7 @@ __device__ __forceinline__ void bn_bwd_finalize_apply_body(const float* __restri
           g = (use_bn == ER_BN_FROZEN) ? ga * is * g : ga * is * (g - sg * invB - xh * (sgx * invB));
         }
         dx[static_cast<int64_t>(r) * N + c] = g;
+        if (dxb) dxb[static_cast<int64_t>(r) * lddxb + c] = f32_to_bf16_bits(g);
       }
     }
   }
@@ -529,8 +542,8 @@ bn_bwd_finalize_apply_kernel(const float* __restrict__ partial, const float* __r
                              const float* __restrict__ invstd, const float* __restrict__ dy, int B, int N,
                              int chunks, int use_bn, int act, int accumulate, float* __restrict__ dx,
                              float* __restrict__ dbias, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                             int dy_ld, int tiles_per_block) {
-  bn_bwd_finalize_apply_body(partial, x, bias, gamma, y, mean, invstd, dy, B, N, chunks, use_bn, act, accumulate, dx, dbias, dgamma, dbeta, dy_ld, tiles_per_block, static_cast<int>(blockIdx.x), static_cast<int>(blockIdx.y));
+                             int dy_ld, int tiles_per_block, uint16_t* __restrict__ dxb, int lddxb) {
+  bn_bwd_finalize_apply_body(partial, x, bias, gamma, y, mean, invstd, dy, B, N, chunks, use_bn, act, accumulate, dx, dbias, dgamma, dbeta, dy_ld, tiles_per_block, static_cast<int>(blockIdx.x), static_cast<int>(blockIdx.y), dxb, lddxb);
 }
 
 
@@ -636,6 +649,28 @@ colsum_finalize_kernel(const float* __restrict__ partial, int cols, int chunks, 
   for (int k = lane; k < chunks; k += 64) a = a + partial[static_cast<int64_t>(k) * cols + c];
   a = wave_sum(a);
   if (lane == 0) out[c] = accumulate ? out[c] + a : a;
+}
+
+// dst[j] (+)= sum_p partial[p * ld + j] for several jobs in one launch (er_colsum_partials_multi): one wave per column,
+// colsum_finalize_kernel's order (lane k sums partials k, k + 64, ..; then the wave butterfly)
+constexpr int kMaxColsumJobs = 16;
+struct ColsumJobs {
+  int n;
+  int start[kMaxColsumJobs + 1];  // workgroups [start[i], start[i + 1]) own job i (4 columns per workgroup)
+  er_tail_job j[kMaxColsumJobs];
+};
+__global__ void __launch_bounds__(kBlock)
+colsum_partials_multi_kernel(ColsumJobs a, int accumulate) {
+  int i = 0;
+  while (i + 1 < a.n && static_cast<int>(blockIdx.x) >= a.start[i + 1]) ++i;
+  const er_tail_job& q = a.j[i];
+  const int lane = threadIdx.x & 63;
+  const int c = (static_cast<int>(blockIdx.x) - a.start[i]) * (kBlock / 64) + (threadIdx.x >> 6);
+  if (c >= q.n_cols) return;
+  float s = 0.f;
+  for (int k = lane; k < q.n_parts; k += 64) s = s + q.partial[static_cast<int64_t>(k) * q.ld + c];
+  s = wave_sum(s);
+  if (lane == 0) q.dst[c] = accumulate ? q.dst[c] + s : s;
 }
 
 // few columns (the bias gradient of a narrow head: dy [B, 1]): one workgroup per column, one launch
@@ -1343,7 +1378,15 @@ int er_bn_apply_from_stats(const float* x, const float* bias, const float* col_s
                            const float* gamma, const float* beta, int32_t B, int32_t N, float eps, float momentum,
                            float* moving_mean, float* moving_var, int act, float* y, float* save_mean,
                            float* save_invstd, er_stream_t stream) {
-  ER_REQUIRE(x && y && col_stats && save_mean && save_invstd && B > 0 && N > 0 && chunks > 0,
+  return er_bn_apply_from_stats_b16(x, bias, col_stats, chunks, gamma, beta, B, N, eps, momentum, moving_mean, moving_var, act, y,
+                                    save_mean, save_invstd, nullptr, 0, stream);
+}
+
+int er_bn_apply_from_stats_b16(const float* x, const float* bias, const float* col_stats, int32_t chunks,
+                               const float* gamma, const float* beta, int32_t B, int32_t N, float eps, float momentum,
+                               float* moving_mean, float* moving_var, int act, float* y, float* save_mean,
+                               float* save_invstd, uint16_t* y_bf16, int32_t ld_bf16, er_stream_t stream) {
+  ER_REQUIRE(x && y && col_stats && save_mean && save_invstd && B > 0 && N > 0 && chunks > 0 && (!y_bf16 || ld_bf16 >= N),
              "er_bn_apply_from_stats: bad arguments");
   std::unique_lock<std::mutex> merge_lock(er::g_merge_mu, std::defer_lock);
   if (chunks > er::kInlineChunks && static_cast<size_t>(N) * 3 * er::kMergeSlices <= er::kMergedFloats) {
@@ -1363,7 +1406,8 @@ int er_bn_apply_from_stats(const float* x, const float* bias, const float* col_s
   dim3 grid(static_cast<unsigned>(er::ceil_div(N, er::kColsPerBlock)),
             static_cast<unsigned>(er::ceil_div(B, er::kApplyRows * tpb)));
   hipLaunchKernelGGL(er::bn_finalize_apply_kernel, grid, dim3(er::kBlock), 0, er::as_stream(stream), col_stats, x, bias,
-                     gamma, beta, B, N, chunks, eps, momentum, moving_mean, moving_var, act, y, save_mean, save_invstd, tpb);
+                     gamma, beta, B, N, chunks, eps, momentum, moving_mean, moving_var, act, y, save_mean, save_invstd, tpb,
+                     y_bf16, ld_bf16);
   ER_LAUNCH_CHECK();
   return 0;
 }
@@ -1399,7 +1443,15 @@ int er_bn_act_bwd(const float* x, const float* bias, const float* gamma, const f
 int er_bn_act_bwd_ld(const float* x, const float* bias, const float* gamma, const float* y, const float* save_mean,
                      const float* save_invstd, const float* dy, int32_t dy_ld, int32_t B, int32_t N, int use_bn, int act,
                      float* dx, float* dbias, float* dgamma, float* dbeta, int accumulate, er_stream_t stream) {
-  ER_REQUIRE(x && y && dy && dx && B > 0 && N > 0 && dy_ld >= N, "er_bn_act_bwd: bad arguments");
+  return er_bn_act_bwd_ld_b16(x, bias, gamma, y, save_mean, save_invstd, dy, dy_ld, B, N, use_bn, act, dx, dbias, dgamma, dbeta,
+                              accumulate, nullptr, 0, stream);
+}
+
+int er_bn_act_bwd_ld_b16(const float* x, const float* bias, const float* gamma, const float* y, const float* save_mean,
+                         const float* save_invstd, const float* dy, int32_t dy_ld, int32_t B, int32_t N, int use_bn, int act,
+                         float* dx, float* dbias, float* dgamma, float* dbeta, int accumulate, uint16_t* dx_bf16,
+                         int32_t ld_bf16, er_stream_t stream) {
+  ER_REQUIRE(x && y && dy && dx && B > 0 && N > 0 && dy_ld >= N && (!dx_bf16 || ld_bf16 >= N), "er_bn_act_bwd: bad arguments");
   hipStream_t s = er::as_stream(stream);
   const int chunks = er::choose_chunks(B, N);
   std::lock_guard<std::mutex> lock(er::g_scratch_mu);
@@ -1417,7 +1469,8 @@ int er_bn_act_bwd_ld(const float* x, const float* bias, const float* gamma, cons
   dim3 grid2(static_cast<unsigned>(er::ceil_div(N, er::kColsPerBlock)),
              static_cast<unsigned>(er::ceil_div(B, er::kApplyRows * tpb)));
   hipLaunchKernelGGL(er::bn_bwd_finalize_apply_kernel, grid2, dim3(er::kBlock), 0, s, partial, x, bias, gamma, y,
-                     save_mean, save_invstd, dy, B, N, n_partial, use_bn, act, accumulate, dx, dbias, dgamma, dbeta, dy_ld, tpb);
+                     save_mean, save_invstd, dy, B, N, n_partial, use_bn, act, accumulate, dx, dbias, dgamma, dbeta, dy_ld, tpb,
+                     dx_bf16, ld_bf16);
   ER_LAUNCH_CHECK();
   return 0;
 }
@@ -1434,14 +1487,25 @@ int er_bn_act_bwd_from_partials_ld(const float* x, const float* bias, const floa
                                    const float* save_mean, const float* save_invstd, const float* dy, int32_t dy_ld, int32_t B,
                                    int32_t N, int use_bn, int act, const float* partial, int32_t chunks, float* dx, float* dbias,
                                    float* dgamma, float* dbeta, int accumulate, er_stream_t stream) {
-  ER_REQUIRE(x && y && dy && dx && partial && B > 0 && N > 0 && chunks > 0 && dy_ld >= N, "er_bn_act_bwd_from_partials: bad arguments");
+  return er_bn_act_bwd_from_partials_ld_b16(x, bias, gamma, y, save_mean, save_invstd, dy, dy_ld, B, N, use_bn, act, partial, chunks,
+                                            dx, dbias, dgamma, dbeta, accumulate, nullptr, 0, stream);
+}
+
+int er_bn_act_bwd_from_partials_ld_b16(const float* x, const float* bias, const float* gamma, const float* y,
+                                       const float* save_mean, const float* save_invstd, const float* dy, int32_t dy_ld, int32_t B,
+                                       int32_t N, int use_bn, int act, const float* partial, int32_t chunks, float* dx,
+                                       float* dbias, float* dgamma, float* dbeta, int accumulate, uint16_t* dx_bf16,
+                                       int32_t ld_bf16, er_stream_t stream) {
+  ER_REQUIRE(x && y && dy && dx && partial && B > 0 && N > 0 && chunks > 0 && dy_ld >= N && (!dx_bf16 || ld_bf16 >= N),
+             "er_bn_act_bwd_from_partials: bad arguments");
   std::unique_lock<std::mutex> merge_lock(er::g_merge_mu, std::defer_lock);
   if (int rc = merge_bwd_partials(&partial, &chunks, N, er::as_stream(stream), &merge_lock)) return rc;
   const int tpb = er::apply_tiles_per_block(B);
   dim3 grid2(static_cast<unsigned>(er::ceil_div(N, er::kColsPerBlock)),
              static_cast<unsigned>(er::ceil_div(B, er::kApplyRows * tpb)));
   hipLaunchKernelGGL(er::bn_bwd_finalize_apply_kernel, grid2, dim3(er::kBlock), 0, er::as_stream(stream), partial, x, bias,
-                     gamma, y, save_mean, save_invstd, dy, B, N, chunks, use_bn, act, accumulate, dx, dbias, dgamma, dbeta, dy_ld, tpb);
+                     gamma, y, save_mean, save_invstd, dy, B, N, chunks, use_bn, act, accumulate, dx, dbias, dgamma, dbeta, dy_ld, tpb,
+                     dx_bf16, ld_bf16);
   ER_LAUNCH_CHECK();
   return 0;
 }
@@ -1564,6 +1628,26 @@ int er_colsum_acc(const float* x, int32_t rows, int32_t cols, int32_t x_stride, 
   hipLaunchKernelGGL(er::colsum_finalize_kernel, dim3(er::blocks_for(static_cast<int64_t>(cols) * 64)), dim3(er::kBlock), 0, s, scratch, cols,
                      chunks, out, accumulate);
   ER_LAUNCH_CHECK();
+  return 0;
+}
+
+int er_colsum_partials_multi(const er_tail_job* jobs, int32_t n_jobs, int accumulate, er_stream_t stream) {
+  ER_REQUIRE(jobs && n_jobs >= 1, "er_colsum_partials_multi: bad arguments");
+  for (int base = 0; base < n_jobs; base += er::kMaxColsumJobs) {
+    er::ColsumJobs a;
+    a.n = 0;
+    a.start[0] = 0;
+    for (int i = base; i < n_jobs && i < base + er::kMaxColsumJobs; ++i) {
+      const er_tail_job& q = jobs[i];
+      ER_REQUIRE(q.partial && q.dst && q.n_parts > 0 && q.n_cols > 0 && q.ld >= q.n_cols, "er_colsum_partials_multi: job %d: bad descriptor", i);
+      a.j[a.n] = q;
+      a.start[a.n + 1] = a.start[a.n] + static_cast<int>(er::ceil_div(q.n_cols, er::kBlock / 64));
+      ++a.n;
+    }
+    hipLaunchKernelGGL(er::colsum_partials_multi_kernel, dim3(static_cast<unsigned>(a.start[a.n])), dim3(er::kBlock), 0,
+                       er::as_stream(stream), a, accumulate);
+    ER_LAUNCH_CHECK();
+  }
   return 0;
 }
 

@@ -39,6 +39,14 @@ gemm_f32_bn_bwd_kernel(GemmArgs g) {
   gemm_f32_block<A_KC, B_KC, true>(g, blockIdx.x, 0, lds);
 }
 
+// ... with the DCN-v2 cross layer's elementwise part in the epilogue (er_gemm_f32_cross)
+template <bool A_KC, bool B_KC, int XEPI>
+__global__ void __launch_bounds__(kBlock)
+gemm_f32_cross_kernel(GemmArgs g, er_gemm_epilogue xe) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * 2 * kOpTile];
+  gemm_f32_block<A_KC, B_KC, false, XEPI>(g, blockIdx.x, 0, lds, false, &xe);
+}
+
 template <bool A_KC, bool B_KC>
 __global__ void __launch_bounds__(kBlock)
 gemm_f32_grouped_kernel(GroupedArgs ga) {
@@ -486,6 +494,47 @@ int er_gemm_f32_bn_bwd_cols(int layout, int32_t M, int32_t N, int32_t K, const f
   e.ld = ld_zy; e.use_bn = use_bn; e.act = act; e.partial = partial;
   e.col0 = col0; e.n_src = n_src;
   return gemm_entry<false>(layout, M, N, K, A, lda, B, ldb, C, ldc, nullptr, 0, nullptr, stream, "er_gemm_f32_bn_bwd_cols", &e);
+}
+
+int er_gemm_f32_cross(int layout, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B, int32_t ldb,
+                      float* C, int32_t ldc, const float* bias, int accumulate, const er_gemm_epilogue* epi,
+                      er_stream_t stream) {
+  ER_REQUIRE(A && B && C && epi && M > 0 && N > 0 && K > 0, "er_gemm_f32_cross: bad arguments");
+  ER_REQUIRE(layout == ER_GEMM_NN || layout == ER_GEMM_NT, "er_gemm_f32_cross: layout %d (NN forward, NT backward)", layout);
+  ER_REQUIRE(lda >= K && ldb >= (layout == ER_GEMM_NT ? K : N) && ldc >= N, "er_gemm_f32_cross: leading dimension too small");
+  er_gemm_epilogue e = *epi;
+  if (e.kind == ER_EPI_CROSS_FWD) {
+    ER_REQUIRE(e.x0 && e.xl && e.ld_x0 >= N && e.ld_xl >= N && (!e.u || e.ld_u >= N) && !accumulate,
+               "er_gemm_f32_cross: bad forward epilogue arguments");
+  } else if (e.kind == ER_EPI_CROSS_BWD) {
+    ER_REQUIRE(e.dout && e.ld_dout >= N && (e.diag == 0.f || (e.du_in && e.ld_du_in >= N)),
+               "er_gemm_f32_cross: bad backward epilogue arguments (dout / du_in)");
+    ER_REQUIRE(!e.prev_u || (e.x0 && e.dx0 && e.ld_x0 >= N && e.ld_prev_u >= N && e.ld_dx0 >= N &&
+                             (!e.du_out || e.ld_du_out >= N) && (!e.du_out_bf16 || e.ld_du_out_bf16 >= N) &&
+                             (e.diag == 0.f || (e.xl && e.ld_xl >= N))),
+               "er_gemm_f32_cross: bad backward epilogue arguments (the lower layer's part)");
+  } else {
+    ER_REQUIRE(false, "er_gemm_f32_cross: epilogue kind %d", e.kind);
+  }
+  er::GemmArgs a;
+  a.A = A; a.B = B; a.C = C; a.bias = bias;
+  a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
+  a.accumulate = accumulate;
+  a.col_stats = nullptr;
+  a.splits = 1;
+  a.k_per_split = static_cast<int>(er::ceil_div(K, er::BK32)) * er::BK32;
+  const int64_t n_tiles = er::ceil_div(N, er::BN) * er::ceil_div(M, er::BM);
+  dim3 grid(static_cast<unsigned>(n_tiles)), block(er::kBlock);
+  hipStream_t s = er::as_stream(stream);
+  if (e.kind == ER_EPI_CROSS_FWD) {
+    if (layout == ER_GEMM_NN) hipLaunchKernelGGL((er::gemm_f32_cross_kernel<true, false, ER_EPI_CROSS_FWD>), grid, block, 0, s, a, e);
+    else hipLaunchKernelGGL((er::gemm_f32_cross_kernel<true, true, ER_EPI_CROSS_FWD>), grid, block, 0, s, a, e);
+  } else {
+    if (layout == ER_GEMM_NN) hipLaunchKernelGGL((er::gemm_f32_cross_kernel<true, false, ER_EPI_CROSS_BWD>), grid, block, 0, s, a, e);
+    else hipLaunchKernelGGL((er::gemm_f32_cross_kernel<true, true, ER_EPI_CROSS_BWD>), grid, block, 0, s, a, e);
+  }
+  ER_LAUNCH_CHECK();
+  return 0;
 }
 
 int er_gemm_grouped_f32(int layout, const er_gemm_problem* problems, int n, er_stream_t stream) {

@@ -47,6 +47,7 @@ struct NtArgs {
   int lda, ldb, ldc, ldcb;
   int accumulate;       // C += (fp32 output only)
   int debug;            // (micro-benchmarks only) 1: no epilogue stores, 2: no k-loop, 4: XCD-grouped tile order
+  er_gemm_epilogue e;   // what the epilogue does besides + bias / C += (EPI template parameter = e.kind)
 };
 
 __device__ __forceinline__ uint16_t f32_to_bf16(float f) {
@@ -59,7 +60,7 @@ __device__ __forceinline__ uint16_t f32_to_bf16(float f) {
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
-template <int STAGES>
+template <int STAGES, int EPI>
 __global__ void __launch_bounds__(kNtThreads)
 gemm_bf16_nt_kernel(NtArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // [STAGES][A tile | Bt tile]
@@ -225,7 +226,9 @@ gemm_bf16_nt_kernel(NtArgs g) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (same wave reads what it wrote: no workgroup barrier needed)
   const int c4 = (lane & 15) * 4;
   const int col = n0 + wc * 64 + c4;
-  const int row_base = m0 + wr * 64 + (lane >> 4);
+  const int rsub = lane >> 4;
+  const int row0 = m0 + wr * 64;
+  const int row_base = row0 + rsub;
   const bool vec = (g.N % 4 == 0) && (!g.C || ((g.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.C) & 15) == 0))) &&
                    (!g.Cb || ((g.ldcb % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.Cb) & 7) == 0)));
   float bv[4] = {0.f, 0.f, 0.f, 0.f};
@@ -234,42 +237,244 @@ gemm_bf16_nt_kernel(NtArgs g) {
     for (int q = 0; q < 4; ++q)
       if (col + q < g.N) bv[q] = g.bias[col + q];
   }
-  if (col >= g.N) return;
-  if (vec) {  // (col + 3 < N follows from N % 4 == 0)
+  if (col >= g.N) return;  // (lanes l, l ^ 16, l ^ 32 share their columns: the exchanges below stay among live lanes)
+  auto staged = [&](int it) { return *reinterpret_cast<const f32x4*>(&stage[(it * 4 + rsub) * kLd + c4]); };
+  auto store_out = [&](int row, f32x4 v) {
+    if (g.C) {
+      f32x4* c = reinterpret_cast<f32x4*>(g.C + static_cast<int64_t>(row) * g.ldc + col);
+      if (g.accumulate) {
+        const f32x4 old = *c;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] += old[q];
+      }
+      *c = v;
+    }
+    if (g.Cb) {
+      ushort4 h;
+      h.x = f32_to_bf16(v[0]); h.y = f32_to_bf16(v[1]); h.z = f32_to_bf16(v[2]); h.w = f32_to_bf16(v[3]);
+      *reinterpret_cast<ushort4*>(g.Cb + static_cast<int64_t>(row) * g.ldcb + col) = h;
+    }
+  };
+  // sum over the four lanes (rsub = 0 .. 3) that hold the other rows of this lane's columns; the same bits in all four
+  auto rows_sum = [&](float v) {
+    v = v + __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+  };
+  const er_gemm_epilogue& e = g.e;
+  const int tile64 = row0 / 64;             // the 64-row tile (er_gemm_row_tiles) this wave's block is
+  const bool tile_live = row0 < g.M;
+  if (EPI == ER_EPI_PLAIN) {
+    if (vec) {  // (col + 3 < N follows from N % 4 == 0)
+#pragma unroll 4
+      for (int it = 0; it < 16; ++it) {
+        const int row = row_base + it * 4;
+        if (row >= g.M) break;
+        f32x4 v = staged(it);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] += bv[q];
+        store_out(row, v);
+      }
+    } else {
+      for (int it = 0; it < 16; ++it) {
+        const int row = row_base + it * 4;
+        if (row >= g.M) break;
+        for (int q = 0; q < 4 && col + q < g.N; ++q) {
+          float v = stage[(it * 4 + rsub) * kLd + c4 + q] + bv[q];
+          if (g.C) {
+            float* c = g.C + static_cast<int64_t>(row) * g.ldc + col + q;
+            if (g.accumulate) v += *c;
+            *c = v;
+          }
+          if (g.Cb) g.Cb[static_cast<int64_t>(row) * g.ldcb + col + q] = f32_to_bf16(v);
+        }
+      }
+    }
+  } else if (EPI == ER_EPI_STATS) {
+    // Welford triple of the wave's 64 rows per column: two passes over the staged block (mean, then M2 about it)
+    const int nvalid = g.M - row0 < 64 ? (g.M - row0 > 0 ? g.M - row0 : 0) : 64;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
     for (int it = 0; it < 16; ++it) {
       const int row = row_base + it * 4;
-      if (row >= g.M) break;
-      f32x4 v = *reinterpret_cast<const f32x4*>(&stage[(it * 4 + (lane >> 4)) * kLd + c4]);
+      if (row < g.M) {
+        f32x4 v = staged(it);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) v[q] += bv[q];
-      if (g.C) {
-        f32x4* c = reinterpret_cast<f32x4*>(g.C + static_cast<int64_t>(row) * g.ldc + col);
-        if (g.accumulate) {
-          const f32x4 old = *c;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] += old[q];
-        }
-        *c = v;
-      }
-      if (g.Cb) {
-        ushort4 h;
-        h.x = f32_to_bf16(v[0]); h.y = f32_to_bf16(v[1]); h.z = f32_to_bf16(v[2]); h.w = f32_to_bf16(v[3]);
-        *reinterpret_cast<ushort4*>(g.Cb + static_cast<int64_t>(row) * g.ldcb + col) = h;
+        for (int q = 0; q < 4; ++q) { v[q] += bv[q]; s[q] += v[q]; }
+        store_out(row, v);
       }
     }
-  } else {
+    float mean[4], m2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) mean[q] = nvalid > 0 ? rows_sum(s[q]) / static_cast<float>(nvalid) : 0.f;
+#pragma unroll 4
     for (int it = 0; it < 16; ++it) {
       const int row = row_base + it * 4;
-      if (row >= g.M) break;
-      for (int q = 0; q < 4 && col + q < g.N; ++q) {
-        float v = stage[(it * 4 + (lane >> 4)) * kLd + c4 + q] + bv[q];
-        if (g.C) {
-          float* c = g.C + static_cast<int64_t>(row) * g.ldc + col + q;
-          if (g.accumulate) v += *c;
-          *c = v;
+      if (row < g.M) {
+        const f32x4 v = staged(it);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const float d = (v[q] + bv[q]) - mean[q]; m2[q] += d * d; }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) m2[q] = rows_sum(m2[q]);
+    if (rsub == 0 && tile_live) {
+      float* o = e.col_stats + (static_cast<int64_t>(tile64) * g.N + col) * 3;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { o[q * 3 + 0] = static_cast<float>(nvalid); o[q * 3 + 1] = mean[q]; o[q * 3 + 2] = m2[q]; }
+    }
+  } else if (EPI == ER_EPI_BN_BWD) {
+    // (sum g, sum g * xhat) of the wave's 64 rows per source column; z / y of 8 rows in flight per lane
+    const int cs = col - e.bn_col0;
+    const bool in_block = cs >= 0 && cs < e.bn_n_src;
+    float sg[4] = {0.f, 0.f, 0.f, 0.f}, sgx[4] = {0.f, 0.f, 0.f, 0.f};
+    float zb[4] = {0.f, 0.f, 0.f, 0.f}, mu[4] = {0.f, 0.f, 0.f, 0.f}, is[4] = {0.f, 0.f, 0.f, 0.f};
+    if (in_block) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (e.bn_zbias) zb[q] = e.bn_zbias[cs + q];
+        if (e.bn_use_bn) { mu[q] = e.bn_mean[cs + q]; is[q] = e.bn_invstd[cs + q]; }
+      }
+    }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      f32x4 yv[8], zv[8];
+      if (in_block) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          int row = row_base + (half * 8 + k) * 4;
+          row = row < g.M ? row : g.M - 1;
+          const int64_t i = static_cast<int64_t>(row) * e.bn_ld + cs;
+          yv[k] = *reinterpret_cast<const f32x4*>(e.bn_y + i);
+          zv[k] = *reinterpret_cast<const f32x4*>(e.bn_z + i);
         }
-        if (g.Cb) g.Cb[static_cast<int64_t>(row) * g.ldcb + col + q] = f32_to_bf16(v);
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int it = half * 8 + k;
+        const int row = row_base + it * 4;
+        if (row < g.M) {
+          f32x4 v = staged(it);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] += bv[q];
+          store_out(row, v);
+          if (in_block) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              float gq = v[q];
+              if (e.bn_act == ER_ACT_RELU && !(yv[k][q] > 0.f)) gq = 0.f;
+              sg[q] = sg[q] + gq;
+              if (e.bn_use_bn) sgx[q] = sgx[q] + gq * ((zv[k][q] + zb[q] - mu[q]) * is[q]);
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { sg[q] = rows_sum(sg[q]); sgx[q] = rows_sum(sgx[q]); }
+    if (rsub == 0 && in_block && tile_live) {
+      float* o = e.bn_partial + (static_cast<int64_t>(tile64) * e.bn_n_src + cs) * 2;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { o[q * 2] = sg[q]; o[q * 2 + 1] = sgx[q]; }
+    }
+  } else if (EPI == ER_EPI_CROSS_FWD) {
+    // x_{l+1} = x0 * (acc + b + diag * x_l) + x_l (reference layers/keras/interaction.py:276-286); u keeps acc
+    const bool with_diag = e.diag != 0.f;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      f32x4 x0v[8], xlv[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        int row = row_base + (half * 8 + k) * 4;
+        row = row < g.M ? row : g.M - 1;
+        x0v[k] = *reinterpret_cast<const f32x4*>(e.x0 + static_cast<int64_t>(row) * e.ld_x0 + col);
+        xlv[k] = *reinterpret_cast<const f32x4*>(e.xl + static_cast<int64_t>(row) * e.ld_xl + col);
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int it = half * 8 + k;
+        const int row = row_base + it * 4;
+        if (row < g.M) {
+          const f32x4 a = staged(it);
+          if (e.u) *reinterpret_cast<f32x4*>(e.u + static_cast<int64_t>(row) * e.ld_u + col) = a;
+          f32x4 o;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float t = a[q] + bv[q];
+            if (with_diag) t = t + e.diag * xlv[k][q];
+            o[q] = x0v[k][q] * t + xlv[k][q];
+          }
+          store_out(row, o);
+        }
+      }
+    }
+  } else if (EPI == ER_EPI_CROSS_BWD) {
+    // v = acc + dout + diag * du_in: the whole gradient of x_{l-1}; the lower cross layer's elementwise backward on it
+    const bool with_diag = e.diag != 0.f;
+    const bool prev = e.prev_u != nullptr;
+    float pb[4] = {0.f, 0.f, 0.f, 0.f}, cs4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (prev && e.prev_bias) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) pb[q] = e.prev_bias[col + q];
+    }
+#pragma unroll
+    for (int part = 0; part < 4; ++part) {
+      f32x4 gv[4], dv[4], x0v[4], uv[4], xlv[4], o0[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        int row = row_base + (part * 4 + k) * 4;
+        row = row < g.M ? row : g.M - 1;
+        const int64_t r = row;
+        gv[k] = *reinterpret_cast<const f32x4*>(e.dout + r * e.ld_dout + col);
+        if (with_diag) dv[k] = *reinterpret_cast<const f32x4*>(e.du_in + r * e.ld_du_in + col);
+        if (prev) {
+          x0v[k] = *reinterpret_cast<const f32x4*>(e.x0 + r * e.ld_x0 + col);
+          uv[k] = *reinterpret_cast<const f32x4*>(e.prev_u + r * e.ld_prev_u + col);
+          if (with_diag) xlv[k] = *reinterpret_cast<const f32x4*>(e.xl + r * e.ld_xl + col);
+          if (e.accumulate_dx0) o0[k] = *reinterpret_cast<const f32x4*>(e.dx0 + r * e.ld_dx0 + col);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int it = part * 4 + k;
+        const int row = row_base + it * 4;
+        if (row < g.M) {
+          f32x4 v = staged(it);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            v[q] = v[q] + bv[q] + gv[k][q];
+            if (with_diag) v[q] = v[q] + e.diag * dv[k][q];
+          }
+          store_out(row, v);
+          if (prev) {
+            f32x4 du, d0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              du[q] = v[q] * x0v[k][q];
+              float t = uv[k][q] + pb[q];
+              if (with_diag) t = t + e.diag * xlv[k][q];
+              const float a = v[q] * t;
+              d0[q] = e.accumulate_dx0 ? o0[k][q] + a : a;
+              cs4[q] = cs4[q] + du[q];
+            }
+            const int64_t r = row;
+            *reinterpret_cast<f32x4*>(e.dx0 + r * e.ld_dx0 + col) = d0;
+            if (e.du_out) *reinterpret_cast<f32x4*>(e.du_out + r * e.ld_du_out + col) = du;
+            if (e.du_out_bf16) {
+              ushort4 h;
+              h.x = f32_to_bf16(du[0]); h.y = f32_to_bf16(du[1]); h.z = f32_to_bf16(du[2]); h.w = f32_to_bf16(du[3]);
+              *reinterpret_cast<ushort4*>(e.du_out_bf16 + r * e.ld_du_out_bf16 + col) = h;
+            }
+          }
+        }
+      }
+    }
+    if (prev && e.partial) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) cs4[q] = rows_sum(cs4[q]);
+      if (rsub == 0 && tile_live) {
+        float* o = e.partial + static_cast<int64_t>(tile64) * g.N + col;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = cs4[q];
       }
     }
   }
@@ -352,16 +557,23 @@ extern "C" {
 int er_gemm_bf16_nt_prepare(void) {
   if (int rc = ensure_zero()) return rc;
   if (!g_nt_attr_set) {
-    ER_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&er::gemm_bf16_nt_kernel<kNtStages>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, kNtStages * er::kNtStageBytes));
+#define ER_NT_ATTR(EPI)                                                                                         \
+  ER_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&er::gemm_bf16_nt_kernel<kNtStages, EPI>),     \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, kNtStages * er::kNtStageBytes))
+    ER_NT_ATTR(ER_EPI_PLAIN);
+    ER_NT_ATTR(ER_EPI_STATS);
+    ER_NT_ATTR(ER_EPI_BN_BWD);
+    ER_NT_ATTR(ER_EPI_CROSS_FWD);
+    ER_NT_ATTR(ER_EPI_CROSS_BWD);
+#undef ER_NT_ATTR
     g_nt_attr_set = true;
   }
   return 0;
 }
 
-int er_gemm_bf16_nt(int32_t M, int32_t N, int32_t K, const uint16_t* A, int32_t lda, const uint16_t* Bt, int32_t ldb,
-                    float* C, int32_t ldc, uint16_t* C_bf16, int32_t ldc_bf16, const float* bias, int accumulate,
-                    er_stream_t stream) {
+int er_gemm_bf16_nt_epi(int32_t M, int32_t N, int32_t K, const uint16_t* A, int32_t lda, const uint16_t* Bt, int32_t ldb,
+                        float* C, int32_t ldc, uint16_t* C_bf16, int32_t ldc_bf16, const float* bias, int accumulate,
+                        const er_gemm_epilogue* epi, er_stream_t stream) {
   ER_REQUIRE(A && Bt && (C || C_bf16) && M > 0 && N > 0 && K > 0, "er_gemm_bf16_nt: bad arguments");
   ER_REQUIRE(K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && lda >= K && ldb >= K,
              "er_gemm_bf16_nt: K and the leading dimensions must be multiples of 8 bf16 (16-byte chunks)");
@@ -375,16 +587,73 @@ int er_gemm_bf16_nt(int32_t M, int32_t N, int32_t K, const uint16_t* A, int32_t 
   er::NtArgs a;
   a.A = A; a.Bt = Bt; a.zero = g_zero16; a.C = C; a.Cb = C_bf16; a.bias = bias;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldcb = ldc_bf16; a.accumulate = accumulate;
+  memset(&a.e, 0, sizeof(a.e));
+  const int kind = epi ? epi->kind : ER_EPI_PLAIN;
+  if (kind != ER_EPI_PLAIN) {
+    a.e = *epi;
+    er_gemm_epilogue& e = a.e;
+    auto al16 = [](const void* p, int ld) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && ld % 4 == 0; };
+    ER_REQUIRE(N % 4 == 0 && (!C || al16(C, ldc)) && (!C_bf16 || ((reinterpret_cast<uintptr_t>(C_bf16) & 7) == 0 && ldc_bf16 % 4 == 0)),
+               "er_gemm_bf16_nt_epi: an epilogue needs N %% 4 == 0 and aligned output rows");
+    ER_REQUIRE(!bias || (reinterpret_cast<uintptr_t>(bias) & 3) == 0, "er_gemm_bf16_nt_epi: bias");
+    switch (kind) {
+      case ER_EPI_STATS:
+        ER_REQUIRE(e.col_stats && !accumulate, "er_gemm_bf16_nt_epi: STATS needs col_stats and a plain output");
+        break;
+      case ER_EPI_BN_BWD:
+        if (e.bn_n_src == 0) { e.bn_col0 = 0; e.bn_n_src = N; }
+        ER_REQUIRE(e.bn_z && e.bn_y && e.bn_partial && e.bn_col0 >= 0 && e.bn_col0 % 4 == 0 && e.bn_n_src % 4 == 0 &&
+                       e.bn_col0 + e.bn_n_src <= N && e.bn_ld >= e.bn_n_src && al16(e.bn_z, e.bn_ld) && al16(e.bn_y, e.bn_ld) &&
+                       (!e.bn_use_bn || (e.bn_mean && e.bn_invstd)),
+                   "er_gemm_bf16_nt_epi: bad BatchNorm-backward epilogue arguments");
+        break;
+      case ER_EPI_CROSS_FWD:
+        ER_REQUIRE(e.x0 && e.xl && e.ld_x0 >= N && e.ld_xl >= N && al16(e.x0, e.ld_x0) && al16(e.xl, e.ld_xl) &&
+                       (!e.u || (e.ld_u >= N && al16(e.u, e.ld_u))) && !accumulate,
+                   "er_gemm_bf16_nt_epi: bad cross-forward epilogue arguments");
+        break;
+      case ER_EPI_CROSS_BWD:
+        ER_REQUIRE(e.dout && e.ld_dout >= N && al16(e.dout, e.ld_dout) &&
+                       (e.diag == 0.f || (e.du_in && e.ld_du_in >= N && al16(e.du_in, e.ld_du_in))),
+                   "er_gemm_bf16_nt_epi: bad cross-backward epilogue arguments (dout / du_in)");
+        if (e.prev_u) {
+          ER_REQUIRE(e.x0 && e.dx0 && e.ld_x0 >= N && e.ld_prev_u >= N && e.ld_dx0 >= N && al16(e.x0, e.ld_x0) &&
+                         al16(e.prev_u, e.ld_prev_u) && al16(e.dx0, e.ld_dx0) &&
+                         (!e.du_out || (e.ld_du_out >= N && al16(e.du_out, e.ld_du_out))) &&
+                         (!e.du_out_bf16 || (e.ld_du_out_bf16 >= N && e.ld_du_out_bf16 % 4 == 0 &&
+                                             (reinterpret_cast<uintptr_t>(e.du_out_bf16) & 7) == 0)) &&
+                         (e.diag == 0.f || (e.xl && e.ld_xl >= N && al16(e.xl, e.ld_xl))) &&
+                         (!e.prev_bias || (reinterpret_cast<uintptr_t>(e.prev_bias) & 3) == 0),
+                     "er_gemm_bf16_nt_epi: bad cross-backward epilogue arguments (the lower layer's part)");
+        }
+        break;
+      default:
+        ER_REQUIRE(false, "er_gemm_bf16_nt_epi: unknown epilogue kind %d", kind);
+    }
+  }
   static const int debug_flags = [] {  // (micro-benchmarks: tools/gemm_bf16_bench.py)
     const char* dbg = getenv("ER_NT_DEBUG");
     return dbg ? atoi(dbg) : 0;
   }();
   a.debug = debug_flags;
   dim3 grid(static_cast<unsigned>(er::ceil_div(N, er::kNtN)), static_cast<unsigned>(er::ceil_div(M, er::kNtM)));
-  hipLaunchKernelGGL((er::gemm_bf16_nt_kernel<kNtStages>), grid, dim3(er::kNtThreads), kNtStages * er::kNtStageBytes,
-                     er::as_stream(stream), a);
+  const size_t lds = kNtStages * er::kNtStageBytes;
+  hipStream_t s = er::as_stream(stream);
+  switch (kind) {
+    case ER_EPI_STATS: hipLaunchKernelGGL((er::gemm_bf16_nt_kernel<kNtStages, ER_EPI_STATS>), grid, dim3(er::kNtThreads), lds, s, a); break;
+    case ER_EPI_BN_BWD: hipLaunchKernelGGL((er::gemm_bf16_nt_kernel<kNtStages, ER_EPI_BN_BWD>), grid, dim3(er::kNtThreads), lds, s, a); break;
+    case ER_EPI_CROSS_FWD: hipLaunchKernelGGL((er::gemm_bf16_nt_kernel<kNtStages, ER_EPI_CROSS_FWD>), grid, dim3(er::kNtThreads), lds, s, a); break;
+    case ER_EPI_CROSS_BWD: hipLaunchKernelGGL((er::gemm_bf16_nt_kernel<kNtStages, ER_EPI_CROSS_BWD>), grid, dim3(er::kNtThreads), lds, s, a); break;
+    default: hipLaunchKernelGGL((er::gemm_bf16_nt_kernel<kNtStages, ER_EPI_PLAIN>), grid, dim3(er::kNtThreads), lds, s, a); break;
+  }
   ER_LAUNCH_CHECK();
   return 0;
+}
+
+int er_gemm_bf16_nt(int32_t M, int32_t N, int32_t K, const uint16_t* A, int32_t lda, const uint16_t* Bt, int32_t ldb,
+                    float* C, int32_t ldc, uint16_t* C_bf16, int32_t ldc_bf16, const float* bias, int accumulate,
+                    er_stream_t stream) {
+  return er_gemm_bf16_nt_epi(M, N, K, A, lda, Bt, ldb, C, ldc, C_bf16, ldc_bf16, bias, accumulate, nullptr, stream);
 }
 
 int er_cast_bf16(const er_cast_desc* descs_host, int n, er_stream_t stream) {

@@ -301,9 +301,12 @@ __device__ __forceinline__ void stage_tile(float* __restrict__ S, int tid, const
 // bx: index of the workgroup among the problem's (8-rounded) tiles, bz: its k-split.  BN_EPI: with the BnBwdEpi
 // epilogue - the y / z values of the lane's 16 output positions are requested BEFORE the k loop so that their
 // latency hides behind it (32 more VGPRs: a separate instantiation).
-template <bool A_KC, bool B_KC, bool BN_EPI = false>
+// XEPI: ER_EPI_CROSS_FWD / ER_EPI_CROSS_BWD with the record *xe (er_gemm_f32_cross: the DCN-v2 cross layer's elementwise
+// part inside its contraction, reference layers/keras/interaction.py:276-286) - like BN_EPI, what the epilogue reads at the
+// lane's 16 output positions is requested before the k loop.
+template <bool A_KC, bool B_KC, bool BN_EPI = false, int XEPI = 0>
 __device__ __forceinline__ void gemm_f32_block(const GemmArgs& g, int bx, int bz, float* __restrict__ lds,
-                                               bool plain_tiles = false) {
+                                               bool plain_tiles = false, const er_gemm_epilogue* xe = nullptr) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -325,6 +328,33 @@ __device__ __forceinline__ void gemm_f32_block(const GemmArgs& g, int bx, int bz
       const int64_t i = static_cast<int64_t>(row) * g.bn.ld + c;
       py[r] = g.bn.y[i];
       pz[r] = g.bn.z[i];
+    }
+  }
+  // cross epilogues: x0 / x_l (forward), dout / du_in and the lower layer's x0 / u / x_l / dx0 (backward) of the 16 positions
+  float qa[XEPI ? 16 : 1], qb[XEPI ? 16 : 1], qc[XEPI == ER_EPI_CROSS_BWD ? 16 : 1], qd[XEPI == ER_EPI_CROSS_BWD ? 16 : 1],
+      qe[XEPI == ER_EPI_CROSS_BWD ? 16 : 1], qf[XEPI == ER_EPI_CROSS_BWD ? 16 : 1];
+  if (XEPI) {
+    int c = n0 + wn * 32 + (lane & 31);
+    c = c < g.N ? c : g.N - 1;
+    const bool with_diag = xe->diag != 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      row = row < g.M ? row : g.M - 1;
+      const int64_t rr = row;
+      if (XEPI == ER_EPI_CROSS_FWD) {
+        qa[r] = xe->x0[rr * xe->ld_x0 + c];
+        qb[r] = xe->xl[rr * xe->ld_xl + c];
+      } else {
+        qa[r] = xe->dout[rr * xe->ld_dout + c];
+        qb[r] = with_diag ? xe->du_in[rr * xe->ld_du_in + c] : 0.f;
+        if (xe->prev_u) {
+          qc[r] = xe->x0[rr * xe->ld_x0 + c];
+          qd[r] = xe->prev_u[rr * xe->ld_prev_u + c];
+          qe[r] = with_diag ? xe->xl[rr * xe->ld_xl + c] : 0.f;
+          qf[r] = xe->accumulate_dx0 ? xe->dx0[rr * xe->ld_dx0 + c] : 0.f;
+        }
+      }
     }
   }
   const bool a_vec = (g.lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0);
@@ -430,6 +460,63 @@ __device__ __forceinline__ void gemm_f32_block(const GemmArgs& g, int bx, int bz
                    g.col_stats + static_cast<int64_t>(ty) * g.N * 3);
   if (BN_EPI && g.bn.partial != nullptr)
     tile_bn_bwd_partial(acc, g.bn, py, pz, m0 + wm * 32, g.M, col < g.N ? col - g.bn.col0 : -1, g.bn.n_src, wm, wn, lane, lds, ty);
+  if (XEPI == ER_EPI_CROSS_FWD) {
+    // x_{l+1} = x0 * (acc + b + diag * x_l) + x_l, in cross_v2_fwd_kernel's order; u keeps acc
+    if (col >= g.N) return;
+    const bool with_diag = xe->diag != 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+      if (row < g.M) {
+        const int64_t rr = row;
+        if (xe->u) xe->u[rr * xe->ld_u + col] = acc[r];
+        float t = acc[r] + bv;
+        if (with_diag) t = t + xe->diag * qb[r];
+        g.C[rr * g.ldc + col] = qa[r] * t + qb[r];
+      }
+    }
+    return;
+  }
+  if (XEPI == ER_EPI_CROSS_BWD) {
+    // v = acc + dout + diag * du_in = the whole gradient of x_{l-1}; C (+)= v; the lower cross layer's elementwise backward
+    const bool with_diag = xe->diag != 0.f;
+    const bool prev = xe->prev_u != nullptr;
+    const float pb = (prev && xe->prev_bias && col < g.N) ? xe->prev_bias[col] : 0.f;
+    float cs = 0.f;
+    if (col < g.N) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+        if (row < g.M) {
+          const int64_t rr = row;
+          float v = acc[r] + bv + qa[r];
+          if (with_diag) v = v + xe->diag * qb[r];
+          float* p = g.C + rr * g.ldc + col;
+          *p = g.accumulate ? *p + v : v;
+          if (prev) {
+            const float du = v * qc[r];
+            float t = qd[r] + pb;
+            if (with_diag) t = t + xe->diag * qe[r];
+            const float a = v * t;
+            xe->dx0[rr * xe->ld_dx0 + col] = xe->accumulate_dx0 ? qf[r] + a : a;
+            if (xe->du_out) xe->du_out[rr * xe->ld_du_out + col] = du;
+            if (xe->du_out_bf16) xe->du_out_bf16[rr * xe->ld_du_out_bf16 + col] = static_cast<uint16_t>(f32_to_bf16_rne(du));
+            cs = cs + du;
+          }
+        }
+      }
+    }
+    if (prev && xe->partial) {  // (uniform) per-tile column sums of du_out: lane pair, then the two waves sharing the columns
+      const float o = __shfl_xor(cs, 32, 64);
+      const float a = (khalf ? o : cs) + (khalf ? cs : o);
+      __syncthreads();  // LDS operand tiles are dead
+      float* slot = lds + (wn * 32 + (lane & 31));
+      if (wm == 1 && khalf == 0) slot[0] = a;
+      __syncthreads();
+      if (wm == 0 && khalf == 0 && col < g.N) xe->partial[static_cast<int64_t>(ty) * g.N + col] = a + slot[0];
+    }
+    return;
+  }
   if (col >= g.N) return;
   float* Cz = g.C + (g.splits > 1 ? static_cast<int64_t>(bz) * g.M * g.N : 0);
   const int ldc = g.splits > 1 ? g.N : g.ldc;

@@ -735,6 +735,8 @@ struct ConcatArgs {
   float* out;
   const float* src[8];
   int ld[8], col0[8 + 1];
+  uint16_t* out_bf16;  // a bf16 copy of out (row stride ld_bf16; the padding columns up to it are zeroed) or nullptr
+  int ld_bf16;
 };
 
 __global__ void __launch_bounds__(kBlock)
@@ -746,7 +748,66 @@ concat_cols_kernel(ConcatArgs a) {
   const int c = static_cast<int>(idx - b * width);
   int p = 0;
   while (p + 1 < a.n && c >= a.col0[p + 1]) ++p;
-  a.out[b * a.out_ld + c] = a.src[p][b * a.ld[p] + (c - a.col0[p])];
+  const float v = a.src[p][b * a.ld[p] + (c - a.col0[p])];
+  a.out[b * a.out_ld + c] = v;
+  if (a.out_bf16) {
+    a.out_bf16[b * a.ld_bf16 + c] = f32_to_bf16_bits(v);
+    if (c == 0) for (int j = width; j < a.ld_bf16; ++j) a.out_bf16[b * a.ld_bf16 + j] = 0;
+  }
+}
+
+// The elementwise backward of the TOP cross layer of a stack (its dout comes from outside the stack) by 64 x 64 tiles, with
+// what the fused chain needs of it: du = dout * x0 (fp32 for the weight gradient, bf16 for the bf16 contraction), dx0 (+)=
+// dout * (u + bias + diag * x), per-tile column sums of du (the bias gradient: er_colsum_partials_multi).  dout's own
+// contribution to the gradient of x is added by the layer's input-gradient contraction (ER_EPI_CROSS_BWD).
+__global__ void __launch_bounds__(kBlock)
+cross_v2_bwd_top_kernel(const float* __restrict__ x0, const float* __restrict__ x, const float* __restrict__ u,
+                        const float* __restrict__ bias, float diag, const float* __restrict__ dout, int ldg, int B, int d,
+                        float* __restrict__ dx0, int ld0, int acc0, float* __restrict__ du, uint16_t* __restrict__ dub,
+                        int lddub, float* __restrict__ partial) {
+  __shared__ float sm[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  const int r0 = blockIdx.y * 64;
+  float cs = 0.f;
+  if (c < d) {
+    const float bv = bias ? bias[c] : 0.f;
+    float gv[16], x0v[16], uv[16], xv[16], ov[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      int r = r0 + rl + 4 * k;
+      r = r < B ? r : B - 1;
+      const int64_t i = static_cast<int64_t>(r) * d + c;
+      gv[k] = dout[static_cast<int64_t>(r) * ldg + c];
+      x0v[k] = x0[i];
+      uv[k] = u[i];
+      xv[k] = diag != 0.f ? x[i] : 0.f;
+      ov[k] = acc0 ? dx0[static_cast<int64_t>(r) * ld0 + c] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int r = r0 + rl + 4 * k;
+      if (r < B) {
+        float tt = uv[k] + bv;
+        if (diag != 0.f) tt = tt + diag * xv[k];
+        const float a = gv[k] * tt;
+        const float w = gv[k] * x0v[k];
+        dx0[static_cast<int64_t>(r) * ld0 + c] = acc0 ? ov[k] + a : a;
+        du[static_cast<int64_t>(r) * d + c] = w;
+        if (dub) dub[static_cast<int64_t>(r) * lddub + c] = f32_to_bf16_bits(w);
+        cs = cs + w;
+      }
+    }
+  }
+  if (dub && c >= d && c < lddub) {  // (the k-tail of the bf16 copy reads zeros)
+    for (int k = 0; k < 16; ++k) {
+      const int r = r0 + rl + 4 * k;
+      if (r < B) dub[static_cast<int64_t>(r) * lddub + c] = 0;
+    }
+  }
+  sm[rl][cl] = cs;
+  __syncthreads();
+  if (rl == 0 && c < d && partial) partial[static_cast<int64_t>(blockIdx.y) * d + c] = (sm[0][cl] + sm[1][cl]) + (sm[2][cl] + sm[3][cl]);
 }
 
 
@@ -1266,18 +1327,36 @@ int er_copy_multi(const void* const* src, void* const* dst, const int64_t* bytes
   return 0;
 }
 
+int er_cross_v2_bwd_top(const float* x0, const float* x, const float* u, const float* bias, float diag_scale, const float* dout,
+                        int32_t ld_dout, int32_t B, int32_t d, float* dx0, int32_t ld_dx0, int accumulate_dx0, float* du,
+                        uint16_t* du_bf16, int32_t ld_du_bf16, float* partial, er_stream_t stream) {
+  ER_REQUIRE(x0 && u && dout && dx0 && du && B > 0 && d > 0 && ld_dout >= d && ld_dx0 >= d && (diag_scale == 0.f || x) &&
+                 (!du_bf16 || ld_du_bf16 >= d),
+             "er_cross_v2_bwd_top: bad arguments");
+  dim3 grid(static_cast<unsigned>(er::ceil_div(du_bf16 ? ld_du_bf16 : d, 64)), static_cast<unsigned>(er::ceil_div(B, 64)));
+  hipLaunchKernelGGL(er::cross_v2_bwd_top_kernel, grid, dim3(er::kBlock), 0, er::as_stream(stream), x0, x, u, bias, diag_scale,
+                     dout, ld_dout, B, d, dx0, ld_dx0, accumulate_dx0, du, du_bf16, ld_du_bf16, partial);
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
 int er_concat_cols(const float* const* parts, const int32_t* widths, const int32_t* lds, int n, int32_t batch, float* out,
                    int32_t out_ld, er_stream_t stream) {
+  return er_concat_cols_b16(parts, widths, lds, n, batch, out, out_ld, nullptr, 0, stream);
+}
+
+int er_concat_cols_b16(const float* const* parts, const int32_t* widths, const int32_t* lds, int n, int32_t batch, float* out,
+                       int32_t out_ld, uint16_t* out_bf16, int32_t ld_bf16, er_stream_t stream) {
   ER_REQUIRE(parts && widths && lds && out && n >= 1 && n <= 8 && batch > 0, "er_concat_cols: bad arguments (n <= 8)");
   er::ConcatArgs a;
-  a.n = n; a.batch = batch; a.out_ld = out_ld; a.out = out;
+  a.n = n; a.batch = batch; a.out_ld = out_ld; a.out = out; a.out_bf16 = out_bf16; a.ld_bf16 = ld_bf16;
   a.col0[0] = 0;
   for (int i = 0; i < n; ++i) {
     ER_REQUIRE(parts[i] && widths[i] > 0 && lds[i] >= widths[i], "er_concat_cols: part %d: bad descriptor", i);
     a.src[i] = parts[i]; a.ld[i] = lds[i];
     a.col0[i + 1] = a.col0[i] + widths[i];
   }
-  ER_REQUIRE(out_ld >= a.col0[n], "er_concat_cols: out_ld too small");
+  ER_REQUIRE(out_ld >= a.col0[n] && (!out_bf16 || ld_bf16 >= a.col0[n]), "er_concat_cols: out_ld too small");
   hipLaunchKernelGGL(er::concat_cols_kernel, dim3(er::blocks_for(static_cast<int64_t>(batch) * a.col0[n])), dim3(er::kBlock), 0,
                      er::as_stream(stream), a);
   ER_LAUNCH_CHECK();

@@ -49,6 +49,23 @@ BN_NONE, BN_BATCH, BN_FROZEN = 0, 1, 2  # er_bn_act_fwd / _bwd use_bn (include/e
 GEMM_NN, GEMM_NT, GEMM_TN = 0, 1, 2
 
 
+class GemmEpilogue(ctypes.Structure):  # = er_gemm_epilogue
+  _fields_ = [('kind', ctypes.c_int32), ('diag', ctypes.c_float), ('col_stats', ctypes.c_void_p),
+              ('bn_z', ctypes.c_void_p), ('bn_zbias', ctypes.c_void_p), ('bn_y', ctypes.c_void_p), ('bn_mean', ctypes.c_void_p),
+              ('bn_invstd', ctypes.c_void_p), ('bn_partial', ctypes.c_void_p),
+              ('bn_ld', ctypes.c_int32), ('bn_use_bn', ctypes.c_int32), ('bn_act', ctypes.c_int32), ('bn_col0', ctypes.c_int32),
+              ('bn_n_src', ctypes.c_int32),
+              ('ld_x0', ctypes.c_int32), ('ld_xl', ctypes.c_int32), ('ld_u', ctypes.c_int32), ('ld_dout', ctypes.c_int32),
+              ('ld_du_in', ctypes.c_int32), ('ld_prev_u', ctypes.c_int32), ('ld_dx0', ctypes.c_int32),
+              ('ld_du_out', ctypes.c_int32), ('ld_du_out_bf16', ctypes.c_int32), ('accumulate_dx0', ctypes.c_int32),
+              ('x0', ctypes.c_void_p), ('xl', ctypes.c_void_p), ('u', ctypes.c_void_p), ('dout', ctypes.c_void_p),
+              ('du_in', ctypes.c_void_p), ('prev_u', ctypes.c_void_p), ('prev_bias', ctypes.c_void_p), ('dx0', ctypes.c_void_p),
+              ('du_out', ctypes.c_void_p), ('du_out_bf16', ctypes.c_void_p), ('partial', ctypes.c_void_p)]
+
+
+EPI_PLAIN, EPI_STATS, EPI_BN_BWD, EPI_CROSS_FWD, EPI_CROSS_BWD = 0, 1, 2, 3, 4
+
+
 class LookupDesc(ctypes.Structure):
   """Mirror of `er_lookup_desc` (include/easyrec_hip.h)."""
   _fields_ = [
@@ -92,6 +109,9 @@ class WgradSink(object):
     self.active = False
     self.queue = []
     self.queue_bf16 = []  # (a bf16 step's weight gradients: er_gemm_grouped_bf16)
+    # bias gradients left as per-row-tile column sums by the fused cross backward [(partial [T, ld], dst [n], n)]:
+    # finished by ONE launch when the backward pass is over (HipBackend.take_wgrads -> colsum_partials_multi)
+    self.colsum_jobs = []
 
   def put(self, x, dy, out, bf16):
     if not self.active:
@@ -388,6 +408,31 @@ class Bf16Shadows(object):
     self.device = flat.device
     self.weights = {}  # data_ptr -> (master view [K, N], plain, t)
     self.seen_version = getattr(varstore, 'version', 0)
+    # per step (begin_step): bf16 copies of fp32 activations / gradients that their PRODUCER wrote beside the fp32 tensor
+    # (BatchNorm apply, the cross epilogue, concat, the BatchNorm backward: register) or that an earlier contraction of
+    # the forward pass cast (act(cache=True)): (data_ptr, shape, stride) -> (the fp32 tensor, kept alive so that its
+    # address cannot be handed out again within the step; its bf16 copy)
+    self.copies = {}
+
+  def begin_step(self):
+    self.copies = {}
+
+  @staticmethod
+  def _key(x):
+    return (x.data_ptr(), tuple(x.shape), tuple(x.stride()))
+
+  def register(self, x, xb):
+    self.copies[self._key(x)] = (x, xb)
+
+  def new_copy(self, x):
+    """An empty bf16 buffer [rows, pad8(cols)] for a producer to fill beside the fp32 matrix x (the padding columns are
+    read as the k-tail of a contraction: zeroed here when there are any), registered as x's copy."""
+    rows, cols = x.shape
+    pc = self.pad8(cols)
+    xb = torch.empty(rows, pc, dtype=torch.bfloat16, device=x.device) if pc == cols else \
+        torch.zeros(rows, pc, dtype=torch.bfloat16, device=x.device)
+    self.register(x, xb)
+    return xb
 
   @staticmethod
   def pad8(n):
@@ -422,12 +467,20 @@ class Bf16Shadows(object):
     if self.weights:
       self.be.cast_bf16(self._descs(self.weights.values()))
 
-  def act(self, x, transpose=False):
-    """A bf16 copy of the fp32 matrix x ([rows, pad8(cols)], or its transpose [cols, pad8(rows)])."""
+  def act(self, x, transpose=False, cache=False):
+    """A bf16 copy of the fp32 matrix x ([rows, pad8(cols)], or its transpose [cols, pad8(rows)]): the one its producer
+    registered, else a cast launch.  cache: x will not change any more within the step (a forward activation) - later
+    contractions reuse this cast."""
+    if not transpose:
+      e = self.copies.get(self._key(x))
+      if e is not None:
+        return e[1]
     rows, cols = x.shape
     dst = torch.empty((cols, self.pad8(rows)) if transpose else (rows, self.pad8(cols)), dtype=torch.bfloat16,
                       device=x.device)
     self.be.cast_bf16([(x, dst, transpose)])
+    if cache and not transpose:
+      self.register(x, dst)
     return dst
 
 
@@ -741,17 +794,21 @@ class HipBackend(object):
   def gemm_row_tiles(self, M):
     return int(self.lib.er_gemm_row_tiles(ctypes.c_int32(int(M))))
 
-  def bn_apply_from_stats(self, x, bias, col_stats, chunks, gamma, beta, eps, momentum, moving_mean, moving_var, act):
-    """BatchNorm(train) + activation from ready-made column statistics (er_gemm's epilogue)."""
+  def bn_apply_from_stats(self, x, bias, col_stats, chunks, gamma, beta, eps, momentum, moving_mean, moving_var, act,
+                          bf16_state=None):
+    """BatchNorm(train) + activation from ready-made column statistics (er_gemm's epilogue).  bf16_state (a Bf16Shadows):
+    the launch also writes y's bf16 copy, registered there for the contraction that reads y next."""
     B, N = x.shape
     y = torch.empty_like(x)
     mean = torch.empty(N, dtype=torch.float32, device=x.device)
     invstd = torch.empty(N, dtype=torch.float32, device=x.device)
+    yb = bf16_state.new_copy(y) if bf16_state is not None else None
     self._ck(
-        self.lib.er_bn_apply_from_stats(_p(_f32c(x)), _p(bias), _p(col_stats), ctypes.c_int32(int(chunks)), _p(gamma),
-                                        _p(beta), B, N, ctypes.c_float(eps), ctypes.c_float(momentum),
-                                        _p(moving_mean), _p(moving_var), int(act), _p(y), _p(mean), _p(invstd),
-                                        _stream()), 'er_bn_apply_from_stats')
+        self.lib.er_bn_apply_from_stats_b16(_p(_f32c(x)), _p(bias), _p(col_stats), ctypes.c_int32(int(chunks)), _p(gamma),
+                                            _p(beta), B, N, ctypes.c_float(eps), ctypes.c_float(momentum),
+                                            _p(moving_mean), _p(moving_var), int(act), _p(y), _p(mean), _p(invstd),
+                                            _p(yb), ctypes.c_int32(0 if yb is None else yb.stride(0)),
+                                            _stream()), 'er_bn_apply_from_stats')
     return y, mean, invstd
 
   def gemm(self, layout, a, b, out=None, bias=None, accumulate=False, bf16=False, col_stats=None):
@@ -770,7 +827,7 @@ class HipBackend(object):
       assert not accumulate
       out = torch.empty(M, N, dtype=torch.float32, device=a.device)
     assert out.shape == (M, N) and out.stride(1) == 1 and out.dtype == torch.float32
-    if bf16 and col_stats is None and self._gemm_bf16_fast(layout, a, b, out, bias, accumulate, M, N, K):
+    if bf16 and self._gemm_bf16_fast(layout, a, b, out, bias, accumulate, M, N, K, col_stats=col_stats):
       return out
     self._log_gemm('gemm_bf16_kernel' if bf16 else 'gemm_f32_kernel', layout, M, N, K)
     fn = self.lib.er_gemm_bf16 if bf16 else self.lib.er_gemm_f32
@@ -783,6 +840,10 @@ class HipBackend(object):
 
   # -- bf16 operands in HBM (dense_dtype 'bf16'): er_gemm_bf16_nt
   bf16_nt = os.environ.get('EASYREC_AMD_BF16_NT', '1') != '0'  # A/B switch: '0' = er_gemm_bf16 (converts while staging)
+
+  # the producers of a bf16 step write their consumers' bf16 operands and the bf16 contractions carry the BatchNorm /
+  # cross epilogues (er_gemm_bf16_nt_epi); A/B switch: '0' = round 5's arrangement (cast launches, fp32-only epilogues)
+  bf16_epilogues = os.environ.get('EASYREC_AMD_BF16_EPILOGUES', '1') != '0'
 
   def bf16_enable(self, varstore):
     """Called by the estimator (dense_dtype 'bf16') once the dense variables are packed; outside graph capture."""
@@ -812,33 +873,46 @@ class HipBackend(object):
       arr[i] = CastDesc(src.data_ptr(), dst.data_ptr(), rows, cols, src.stride(0), dst.stride(0), 1 if tr else 0)
     self._ck(self.lib.er_cast_bf16(arr, n, _stream()), 'er_cast_bf16')
 
-  def gemm_bf16_nt(self, a, bt, M, N, K, out=None, out_bf16=None, bias=None, accumulate=False):
+  def gemm_bf16_nt(self, a, bt, M, N, K, out=None, out_bf16=None, bias=None, accumulate=False, epi=None):
     """out[M, N] (+)= a[M, K] . bt[N, K]^T (+ bias): bf16 operands with leading dimensions that are multiples of 8,
-    fp32 accumulate; out fp32 and / or out_bf16."""
+    fp32 accumulate; out fp32 and / or out_bf16.  epi: a GemmEpilogue record (er_gemm_bf16_nt_epi)."""
     assert a.dtype == torch.bfloat16 and bt.dtype == torch.bfloat16 and a.stride(1) == 1 and bt.stride(1) == 1
     assert a.shape[0] >= M and bt.shape[0] >= N
     Kp = (K + 7) // 8 * 8  # (the k-tail up to the padded width reads zeros: Bf16Shadows pads with zeros)
     assert a.stride(0) >= Kp and bt.stride(0) >= Kp and a.stride(0) % 8 == 0 and bt.stride(0) % 8 == 0
-    self._log_gemm('gemm_bf16_nt_kernel', None, M, N, K)
-    self._ck(self.lib.er_gemm_bf16_nt(M, N, Kp, ctypes.c_void_p(a.data_ptr()), ctypes.c_int32(a.stride(0)),
-                                      ctypes.c_void_p(bt.data_ptr()), ctypes.c_int32(bt.stride(0)), _p(out),
-                                      ctypes.c_int32(0 if out is None else out.stride(0)),
-                                      ctypes.c_void_p(0 if out_bf16 is None else out_bf16.data_ptr()),
-                                      ctypes.c_int32(0 if out_bf16 is None else out_bf16.stride(0)), _p(bias),
-                                      int(bool(accumulate)), _stream()), 'er_gemm_bf16_nt')
+    kind = 0 if epi is None else int(epi.kind)
+    self._log_gemm('gemm_bf16_nt_kernel<4, %d>' % kind, None, M, N, K)
+    self._ck(self.lib.er_gemm_bf16_nt_epi(M, N, Kp, ctypes.c_void_p(a.data_ptr()), ctypes.c_int32(a.stride(0)),
+                                          ctypes.c_void_p(bt.data_ptr()), ctypes.c_int32(bt.stride(0)), _p(out),
+                                          ctypes.c_int32(0 if out is None else out.stride(0)),
+                                          ctypes.c_void_p(0 if out_bf16 is None else out_bf16.data_ptr()),
+                                          ctypes.c_int32(0 if out_bf16 is None else out_bf16.stride(0)), _p(bias),
+                                          int(bool(accumulate)), None if epi is None else ctypes.byref(epi), _stream()),
+             'er_gemm_bf16_nt')
     return out
 
-  def _gemm_bf16_fast(self, layout, a, b, out, bias, accumulate, M, N, K):
+  @staticmethod
+  def _nt_rows_ok(*ts):
+    """The epilogues of er_gemm_bf16_nt_epi read / write fp32 rows in 16-byte pieces."""
+    return all(t is None or (t.data_ptr() % 16 == 0 and t.stride(0) % 4 == 0 and t.stride(1) == 1) for t in ts)
+
+  def _gemm_bf16_fast(self, layout, a, b, out, bias, accumulate, M, N, K, col_stats=None):
     """The bf16 contraction through er_gemm_bf16_nt when one operand is a weight of a bf16-enabled store (forward
-    x . W, input gradient dy . W^T); False = not applicable."""
+    x . W, input gradient dy . W^T); False = not applicable.  col_stats: the following BatchNorm's per-row-tile column
+    statistics from the epilogue (ER_EPI_STATS)."""
     if not self.bf16_nt or layout == GEMM_TN:
       return False
     st = self._bf16_state_of(b)
     if st is None:
       return False
+    epi = None
+    if col_stats is not None:
+      if N % 4 != 0 or accumulate or not self._nt_rows_ok(out):
+        return False
+      epi = GemmEpilogue(kind=EPI_STATS, col_stats=col_stats.data_ptr())
     w, plain, t = st.weight(b)
-    a16 = st.act(a)
-    self.gemm_bf16_nt(a16, t if layout == GEMM_NN else plain, M, N, K, out=out, bias=bias, accumulate=accumulate)
+    a16 = st.act(a, cache=(layout == GEMM_NN))
+    self.gemm_bf16_nt(a16, t if layout == GEMM_NN else plain, M, N, K, out=out, bias=bias, accumulate=accumulate, epi=epi)
     return True
 
   # er_gemm_f32_bn_bwd / er_bn_act_bwd_from_partials are used (A/B switch: EASYREC_AMD_FUSED_BN_BWD=0)
@@ -847,10 +921,11 @@ class HipBackend(object):
   # tower inside [sum(wide) | FM | deep]) from the consumer's dgrad epilogue (er_gemm_f32_bn_bwd_cols); A/B switch
   bn_cols_epilogue = os.environ.get('EASYREC_AMD_BN_COLS_EPILOGUE', '1') != '0'
 
-  def gemm_bn_bwd(self, layout, a, b, src, partial, col0=None):
+  def gemm_bn_bwd(self, layout, a, b, src, partial, col0=None, bf16=False):
     """dgrad GEMM whose epilogue also emits the BatchNorm-backward column sums of the layer described by `src`
     (a BnSource: the producer of this GEMM's input) into partial [row tiles][N][2].  col0: that layer produced the
-    columns [col0, col0 + its width) of this GEMM's input only."""
+    columns [col0, col0 + its width) of this GEMM's input only.  bf16: through er_gemm_bf16_nt_epi (ER_EPI_BN_BWD) when
+    b is a weight of a bf16-enabled store; None = not applicable there."""
     assert a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1
     if layout == GEMM_NN:
       (M, K), (K2, N) = a.shape, b.shape
@@ -858,6 +933,21 @@ class HipBackend(object):
       (M, K), (N, K2) = a.shape, b.shape
     else:
       (K, M), (K2, N) = a.shape, b.shape
+    if bf16:
+      st = self._bf16_state_of(b) if (self.bf16_nt and layout == GEMM_NT) else None
+      n_src = src.y.shape[1]
+      c0 = 0 if col0 is None else int(col0)
+      if st is None or N % 4 or n_src % 4 or c0 % 4 or not self._nt_rows_ok(src.z, src.y) or src.y.stride() != src.z.stride():
+        return None
+      assert K == K2 and src.z.shape == (M, n_src) and c0 + n_src <= N and partial.numel() >= self.gemm_row_tiles(M) * n_src * 2
+      out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+      epi = GemmEpilogue(kind=EPI_BN_BWD, bn_z=src.z.data_ptr(), bn_zbias=_ptr(src.zbias), bn_y=src.y.data_ptr(),
+                         bn_mean=_ptr(src.mean), bn_invstd=_ptr(src.invstd), bn_partial=partial.data_ptr(),
+                         bn_ld=src.y.stride(0), bn_use_bn=int(src.mean is not None), bn_act=int(src.act), bn_col0=c0,
+                         bn_n_src=n_src)
+      w, plain, t = st.weight(b)
+      self.gemm_bf16_nt(st.act(a), plain, M, N, K, out=out, epi=epi)
+      return out
     if col0 is not None:
       n_src = src.y.shape[1]
       assert K == K2 and src.z.shape == (M, n_src) and src.y.stride() == src.z.stride() and 0 <= col0 and col0 + n_src <= N
@@ -1030,7 +1120,26 @@ class HipBackend(object):
     sink = self.wgrad_sink()
     q, sink.queue, sink.active = sink.queue, [], False
     qb, sink.queue_bf16 = sink.queue_bf16, []
+    jobs, sink.colsum_jobs = sink.colsum_jobs, []
+    if jobs:
+      self.colsum_partials_multi(jobs)
     return q, qb
+
+  def queue_colsum(self, sink, partial, dst, n_cols):
+    """dst[j] += sum_p partial[p, j] once the backward pass is over (one launch for all queued jobs), or now."""
+    if sink is not None and sink.active:
+      sink.colsum_jobs.append((partial, dst, n_cols))
+    else:
+      self.colsum_partials_multi([(partial, dst, n_cols)])
+
+  def colsum_partials_multi(self, jobs, accumulate=True):
+    """jobs: [(partial [P, ld], dst [n_cols], n_cols)]: dst[j] (+)= sum_p partial[p, j], all jobs in one launch."""
+    arr = (TailJob * len(jobs))()
+    for q, (partial, d, n_cols) in zip(arr, jobs):
+      assert partial.dim() == 2 and partial.stride(1) == 1 and d.is_contiguous() and d.numel() == n_cols
+      q.partial, q.dst, q.n_parts, q.n_cols, q.ld = partial.data_ptr(), d.data_ptr(), partial.shape[0], int(n_cols), partial.stride(0)
+    self._ck(self.lib.er_colsum_partials_multi(arr, ctypes.c_int32(len(jobs)), int(bool(accumulate)), _stream()),
+             'er_colsum_partials_multi')
 
   # the step's tail in one grid (er_emb_bwd_fused_wgrad); A/B switch, and the workgroups its contraction's k-splits aim at
   # (0: the stand-alone launch's 512 - bit-identical to the unfused tail; same-box 256 -> 54.5 us, 512 -> 60, 1024 -> 66)
@@ -1429,6 +1538,97 @@ class HipBackend(object):
         'er_cross_v2_epilogue_bwd')
     return dx0, dx, du
 
+  # The DCN-v2 cross layer as ONE launch forward and one or two backward (north_star: "DCN-cross ... as fused HIP kernels";
+  # reference layers/keras/interaction.py:249-286): the elementwise part rides in the epilogue of the layer's contraction
+  # (er_gemm_f32_cross / er_gemm_bf16_nt_epi).  A/B switch: '0' = GEMM + er_cross_v2_epilogue_* launches.
+  fused_cross = os.environ.get('EASYREC_AMD_FUSED_CROSS', '1') != '0'
+
+  def _cross_b16(self, w, bf16, *rows):
+    """The Bf16Shadows a bf16 cross contraction over weight w runs on (None: the fp32 kernel), or False: bf16 was asked
+    for but er_gemm_bf16_nt_epi does not take these operands (the caller uses the unfused launches)."""
+    if not bf16:
+      return None
+    st = self._bf16_state_of(w) if (self.bf16_nt and self.bf16_epilogues) else None
+    if st is None or w.shape[0] % 4 or w.shape[1] % 4 or not self._nt_rows_ok(*rows):
+      return False
+    return st
+
+  def cross_fwd_fused(self, x0, x, w, bias, diag, bf16):
+    """(out, u) = (x0 * (x . w + bias + diag * x) + x, x . w) in one launch; None: not applicable."""
+    B, d = x.shape
+    if w.shape != (d, d) or x0.shape != x.shape or x0.stride(1) != 1 or x.stride(1) != 1:
+      return None
+    out = torch.empty(B, d, dtype=torch.float32, device=x.device)
+    u = torch.empty(B, d, dtype=torch.float32, device=x.device)
+    st = self._cross_b16(w, bf16, x0, x, out, u)
+    if st is False:
+      return None
+    epi = GemmEpilogue(kind=EPI_CROSS_FWD, diag=float(diag), x0=x0.data_ptr(), xl=x.data_ptr(), u=u.data_ptr(),
+                       ld_x0=x0.stride(0), ld_xl=x.stride(0), ld_u=u.stride(0))
+    if st is not None:
+      _, plain, t = st.weight(w)
+      self.gemm_bf16_nt(st.act(x, cache=True), t, B, d, d, out=out, out_bf16=st.new_copy(out), bias=bias, epi=epi)
+    else:
+      self._log_gemm('gemm_f32_cross_kernel<true, false, 3>', None, B, d, d)
+      self._ck(self.lib.er_gemm_f32_cross(ctypes.c_int(GEMM_NN), B, d, d, _p(x), ctypes.c_int32(x.stride(0)), _p(w),
+                                          ctypes.c_int32(w.stride(0)), _p(out), ctypes.c_int32(out.stride(0)), _p(bias), 0,
+                                          ctypes.byref(epi), _stream()), 'er_gemm_f32_cross')
+    return out, u
+
+  def cross_bwd_top(self, x0, x, u, bias, diag, dout, dx0, acc0, bf16, w):
+    """The elementwise backward of a cross layer whose dout comes from outside the stack: du = dout * x0 (and its bf16 copy
+    in a bf16 step), dx0 (+)= dout * (u + bias + diag * x), partial [row tiles, d] = per-tile column sums of du."""
+    B, d = x0.shape
+    du = torch.empty(B, d, dtype=torch.float32, device=x0.device)
+    partial = torch.empty(self.gemm_row_tiles(B), d, dtype=torch.float32, device=x0.device)
+    st = self._cross_b16(w, bf16, du) if bf16 else None
+    dub = None
+    if st:
+      dub = torch.empty(B, st.pad8(d), dtype=torch.bfloat16, device=x0.device)  # (the kernel zeroes the k-tail columns)
+      st.register(du, dub)
+    self._ck(self.lib.er_cross_v2_bwd_top(_p(x0), _p(x), _p(u), _p(bias), ctypes.c_float(diag), _p(dout),
+                                          ctypes.c_int32(dout.stride(0)), B, d, _p(dx0), ctypes.c_int32(dx0.stride(0)),
+                                          int(bool(acc0)), _p(du), _p(dub), ctypes.c_int32(0 if dub is None else dub.stride(0)),
+                                          _p(partial), _stream()), 'er_cross_v2_bwd_top')
+    return du, partial
+
+  def cross_dgrad_fused(self, du, w, dout, diag, bf16, dst, acc, prev=None):
+    """dst (+)= du . w^T + dout + diag * du - the whole gradient of the layer's input x_{l-1} - in one launch; with prev =
+    dict(x0, u, bias, xl, dx0, acc0) (x_{l-1} is the output of the cross layer below) the same launch runs that layer's
+    elementwise backward on it: returns (du_prev, partial_prev) (its du = dst * x0 and the per-tile column sums), else
+    (None, None).  False: not applicable (bf16 operands the epilogue does not take)."""
+    B, d = du.shape
+    st = self._cross_b16(w, bf16, du, dout, dst, *( [prev['x0'], prev['u'], prev['dx0']] if prev else []))
+    if st is False:
+      return False
+    epi = GemmEpilogue(kind=EPI_CROSS_BWD, diag=float(diag), dout=dout.data_ptr(), ld_dout=dout.stride(0))
+    if diag != 0:
+      epi.du_in, epi.ld_du_in = du.data_ptr(), du.stride(0)
+    du_prev = partial = None
+    if prev is not None:
+      du_prev = torch.empty(B, d, dtype=torch.float32, device=du.device)
+      partial = torch.empty(self.gemm_row_tiles(B), d, dtype=torch.float32, device=du.device)
+      epi.x0, epi.ld_x0 = prev['x0'].data_ptr(), prev['x0'].stride(0)
+      epi.prev_u, epi.ld_prev_u = prev['u'].data_ptr(), prev['u'].stride(0)
+      epi.prev_bias = _ptr(prev['bias'])
+      if diag != 0:
+        epi.xl, epi.ld_xl = prev['xl'].data_ptr(), prev['xl'].stride(0)
+      epi.dx0, epi.ld_dx0, epi.accumulate_dx0 = prev['dx0'].data_ptr(), prev['dx0'].stride(0), int(bool(prev['acc0']))
+      epi.du_out, epi.ld_du_out = du_prev.data_ptr(), du_prev.stride(0)
+      epi.partial = partial.data_ptr()
+      if st is not None:
+        dpb = st.new_copy(du_prev)
+        epi.du_out_bf16, epi.ld_du_out_bf16 = dpb.data_ptr(), dpb.stride(0)
+    if st is not None:
+      _, plain, t = st.weight(w)
+      self.gemm_bf16_nt(st.act(du), plain, B, d, d, out=dst, accumulate=acc, epi=epi)
+    else:
+      self._log_gemm('gemm_f32_cross_kernel<true, true, 4>', None, B, d, d)
+      self._ck(self.lib.er_gemm_f32_cross(ctypes.c_int(GEMM_NT), B, d, d, _p(du), ctypes.c_int32(du.stride(0)), _p(w),
+                                          ctypes.c_int32(w.stride(0)), _p(dst), ctypes.c_int32(dst.stride(0)), None,
+                                          int(bool(acc)), ctypes.byref(epi), _stream()), 'er_gemm_f32_cross')
+    return du_prev, partial
+
   def cross_v2_bwd_acc(self, x0, x, u, bias, diag_scale, dout, dx0, acc0, dx, accx):
     """er_cross_v2_epilogue_bwd_acc: dx0 / dx are 2-D destinations (unit inner stride; dx None: x is x0) written or, with
     their flag, accumulated into.  Returns du."""
@@ -1697,8 +1897,9 @@ class HipBackend(object):
 
   concat_pitch = os.environ.get('EASYREC_AMD_CONCAT_PITCH', '1') != '0'  # A/B switch
 
-  def concat_cols(self, parts):
-    """torch.cat(parts, dim=1) of 2-D fp32 blocks (unit inner stride) as one library launch."""
+  def concat_cols(self, parts, bf16_state=None):
+    """torch.cat(parts, dim=1) of 2-D fp32 blocks (unit inner stride) as one library launch.  bf16_state (a Bf16Shadows):
+    the launch also writes the bf16 copy the next contraction reads, registered there."""
     n = len(parts)
     B = parts[0].shape[0]
     for t in parts:
@@ -1708,6 +1909,10 @@ class HipBackend(object):
     width = sum(t.shape[1] for t in parts)
     pitch = (width + 3) // 4 * 4 if self.concat_pitch else width
     out = torch.empty(B, pitch, dtype=torch.float32, device=parts[0].device)[:, :width]
+    outb = None
+    if bf16_state is not None and n <= 8:
+      outb = torch.empty(B, bf16_state.pad8(width), dtype=torch.bfloat16, device=out.device)  # (k-tail zeroed by the kernel)
+      bf16_state.register(out, outb)
     for i in range(0, n, 8):  # (more than 8 parts: several launches into column blocks of `out`)
       chunk = parts[i:i + 8]
       col0 = sum(t.shape[1] for t in parts[:i])
@@ -1715,18 +1920,22 @@ class HipBackend(object):
       pp = (ctypes.c_void_p * len(chunk))(*[t.data_ptr() for t in chunk])
       ww = (ctypes.c_int32 * len(chunk))(*[t.shape[1] for t in chunk])
       ll = (ctypes.c_int32 * len(chunk))(*[t.stride(0) for t in chunk])
-      self._ck(self.lib.er_concat_cols(pp, ww, ll, len(chunk), B, _p(dst), ctypes.c_int32(out.stride(0)), _stream()),
+      self._ck(self.lib.er_concat_cols_b16(pp, ww, ll, len(chunk), B, _p(dst), ctypes.c_int32(out.stride(0)), _p(outb),
+                                           ctypes.c_int32(0 if outb is None else outb.stride(0)), _stream()),
                'er_concat_cols')
     return out
 
   def bn_act_bwd(self, x, bias, gamma, y, mean, invstd, dy, use_bn, act, need_bias, need_affine, into=None,
-                 partial=None, beta=None):
+                 partial=None, beta=None, bf16_state=None):
     """into = (dbias_buf, dgamma_buf, dbeta_buf) (each may be None): accumulate the parameter gradients
     into those buffers (slices of the flat gradient buffer) instead of returning new tensors.
-    partial: column sums [gemm_row_tiles(B)][N][2] already produced by gemm_bn_bwd (skips that pass)."""
+    partial: column sums [gemm_row_tiles(B)][N][2] already produced by gemm_bn_bwd (skips that pass).
+    bf16_state (a Bf16Shadows): the launch also writes dx's bf16 copy, registered there for the input-gradient contraction."""
     B, N = x.shape
     dx = torch.empty_like(x)
     dev = x.device
+    dxb = bf16_state.new_copy(dx) if bf16_state is not None else None
+    ldb = ctypes.c_int32(0 if dxb is None else dxb.stride(0))
     acc = into is not None
     if acc:
       dbias, dgamma, dbeta = into
@@ -1735,22 +1944,18 @@ class HipBackend(object):
       dgamma = torch.empty(N, dtype=torch.float32, device=dev) if need_affine else None
       dbeta = torch.empty(N, dtype=torch.float32, device=dev) if need_affine else None
     assert dy.dim() == 2 and dy.stride(1) == 1 and dy.dtype == torch.float32
-    if partial is None and dy.stride(0) != N:  # a column block of a wider gradient (ConcatFn's backward): read in place
+    if partial is not None:
       self._ck(
-          self.lib.er_bn_act_bwd_ld(_p(x), _p(bias), _p(gamma), _p(y), _p(mean), _p(invstd), _p(dy),
-                                    ctypes.c_int32(dy.stride(0)), B, N, int(use_bn), int(act), _p(dx), _p(dbias),
-                                    _p(dgamma), _p(dbeta), int(acc), _stream()), 'er_bn_act_bwd_ld')
-    elif partial is not None:
+          self.lib.er_bn_act_bwd_from_partials_ld_b16(_p(x), _p(bias), _p(gamma), _p(y), _p(mean), _p(invstd), _p(dy),
+                                                      ctypes.c_int32(dy.stride(0)), B, N, int(use_bn), int(act), _p(partial),
+                                                      ctypes.c_int32(self.gemm_row_tiles(B)), _p(dx), _p(dbias), _p(dgamma),
+                                                      _p(dbeta), int(acc), _p(dxb), ldb, _stream()),
+          'er_bn_act_bwd_from_partials_ld')
+    else:  # (dy may be a column block of a wider gradient - ConcatFn's backward -: read in place)
       self._ck(
-          self.lib.er_bn_act_bwd_from_partials_ld(_p(x), _p(bias), _p(gamma), _p(y), _p(mean), _p(invstd), _p(dy),
-                                                  ctypes.c_int32(dy.stride(0)), B, N, int(use_bn), int(act), _p(partial),
-                                                  ctypes.c_int32(self.gemm_row_tiles(B)), _p(dx), _p(dbias), _p(dgamma),
-                                                  _p(dbeta), int(acc), _stream()), 'er_bn_act_bwd_from_partials_ld')
-    else:
-      self._ck(
-          self.lib.er_bn_act_bwd(_p(x), _p(bias), _p(gamma), _p(y), _p(mean), _p(invstd), _p(_f32c(dy)), B, N,
-                                 int(use_bn), int(act), _p(dx), _p(dbias), _p(dgamma), _p(dbeta), int(acc),
-                                 _stream()), 'er_bn_act_bwd')
+          self.lib.er_bn_act_bwd_ld_b16(_p(x), _p(bias), _p(gamma), _p(y), _p(mean), _p(invstd), _p(dy),
+                                        ctypes.c_int32(dy.stride(0)), B, N, int(use_bn), int(act), _p(dx), _p(dbias),
+                                        _p(dgamma), _p(dbeta), int(acc), _p(dxb), ldb, _stream()), 'er_bn_act_bwd_ld')
     if acc:
       return dx, None, None, None
     return dx, dbias, dgamma, dbeta
@@ -2133,7 +2338,7 @@ class LinearFn(torch.autograd.Function):
     ctx.has_bias = b is not None
     ctx.w_grad, ctx.b_grad, ctx.bf16 = w_grad, b_grad, bf16
     ctx.sink = be.wgrad_sink()
-    ctx.src = src if (src is not None and x2 is x and not bf16 and src.fused and getattr(be, 'fused_bn_bwd', False)) else None
+    ctx.src = src if (src is not None and x2 is x and _bn_bwd_fusable(be, bf16) and src.fused) else None
     ctx.gsink = sink if x2 is x else None
     # (x's other consumers may share its gradient buffer: grad_slot)
     ctx.slots = grad_slots_of_step() if (x2 is x and x.dim() == 2 and x.is_contiguous()) else None
@@ -2209,7 +2414,7 @@ class HeadFn(torch.autograd.Function):
     x2 = x if x.stride(-1) == 1 else x.contiguous()
     logits = torch.empty(x2.shape[0], 1, dtype=torch.float32, device=x2.device)
     be = hip()
-    fused = src is not None and x2 is x and not bf16 and src.fused and getattr(be, 'fused_bn_bwd', False)
+    fused = src is not None and x2 is x and not bf16 and src.fused and getattr(be, 'fused_bn_bwd', False)  # (the head launch is fp32)
     # (the state keeps a DETACHED alias of the logits: they are written after this forward returned, outside autograd's view)
     st = HeadState(x2, w.detach(), None if b is None else b.detach(), w_grad, b_grad, src if fused else None, logits.detach(), bf16)
     heads[logits.data_ptr()] = st
@@ -2244,6 +2449,14 @@ class HeadFn(torch.autograd.Function):
     return dx, dw, db, None, None, None, None, None
 
 
+def _bn_bwd_fusable(be, bf16):
+  """May a consumer's input-gradient contraction emit the producer's BatchNorm-backward column sums?  fp32: er_gemm_f32_bn_bwd;
+  bf16: the same epilogue of er_gemm_bf16_nt_epi (bf16 operands in HBM)."""
+  if not getattr(be, 'fused_bn_bwd', False):
+    return False
+  return (not bf16) or bool(getattr(be, 'bf16_nt', False) and getattr(be, 'bf16_epilogues', False))
+
+
 def _wgrad(be, x, dz, w_grad, bf16, sink):
   """dW = x^T . dz: queued for the grouped launch (accumulating into w_grad, a slice of the flat gradient buffer), else
   launched here.  Returns dW only without w_grad."""
@@ -2275,15 +2488,17 @@ def _dgrad(be, dz, w, src, bf16, sink=None, x=None, slots=None):
   M, N = dz.shape[0], w.shape[0]
   if isinstance(src, BnColsView):
     inner = src.src
-    if bf16:
-      return be.gemm(GEMM_NT, dz, w, bf16=bf16)
     n_src = inner.y.shape[1]
     partial = torch.empty(be.gemm_row_tiles(M) * n_src * 2, dtype=torch.float32, device=dz.device)
-    dx = be.gemm_bn_bwd(GEMM_NT, dz, w, inner, partial, col0=src.col0)
+    dx = be.gemm_bn_bwd(GEMM_NT, dz, w, inner, partial, col0=src.col0, **({'bf16': True} if bf16 else {}))
+    if dx is None:  # (bf16: shapes the epilogue does not take)
+      return be.gemm(GEMM_NT, dz, w, bf16=bf16)
     inner.partial, inner.dx_ptr = partial, dx.data_ptr() + 4 * src.col0  # (what the block's view of dx starts at)
     return dx
   partial = torch.empty(be.gemm_row_tiles(M) * N * 2, dtype=torch.float32, device=dz.device)
-  dx = be.gemm_bn_bwd(GEMM_NT, dz, w, src, partial)
+  dx = be.gemm_bn_bwd(GEMM_NT, dz, w, src, partial, **({'bf16': True} if bf16 else {}))
+  if dx is None:
+    return be.gemm(GEMM_NT, dz, w, bf16=bf16)
   src.partial, src.dx_ptr = partial, dx.data_ptr()
   return dx
 
@@ -2304,12 +2519,14 @@ class LinearBNActFn(torch.autograd.Function):
     chunks = be.gemm_row_tiles(M)
     stats = torch.empty(chunks * N * 3, dtype=torch.float32, device=x2.device)
     z = be.gemm(GEMM_NN, x2, w, bias=b, bf16=bf16, col_stats=stats)
+    # (bf16: the BatchNorm launch writes the bf16 copy the next contraction reads; its backward the one the dgrad reads)
+    ctx.b16 = be._bf16_state_of(w) if (bf16 and getattr(be, 'bf16_nt', False) and getattr(be, 'bf16_epilogues', False)) else None
     y, mean, invstd = be.bn_apply_from_stats(z, None, stats, chunks, gamma, beta, eps, momentum, moving_mean,
-                                             moving_var, act)
+                                             moving_var, act, **({'bf16_state': ctx.b16} if ctx.b16 is not None else {}))
     ctx.save_for_backward(x2, w, gamma, beta, z, y, mean, invstd)
     ctx.act, ctx.bf16, ctx.grad_bufs = act, bf16, grad_bufs
     ctx.sink = be.wgrad_sink()
-    fused = not bf16 and getattr(be, 'fused_bn_bwd', False)
+    fused = _bn_bwd_fusable(be, bf16)
     ctx.src = src if (src is not None and x2 is x and fused and src.fused) else None
     ctx.gsink = sink if x2 is x else None
     gb = None if grad_bufs is None else (grad_bufs[1], grad_bufs[2])
@@ -2334,7 +2551,8 @@ class LinearBNActFn(torch.autograd.Function):
         partial = own.partial
       own.partial = None
     dz, _, dgamma, dbeta = be.bn_act_bwd(z, None, gamma, y, mean, invstd, dyc, 1, ctx.act, False, True,
-                                         into=(None, gg, betag) if direct else None, partial=partial, beta=beta)
+                                         into=(None, gg, betag) if direct else None, partial=partial, beta=beta,
+                                         **({'bf16_state': ctx.b16} if (ctx.b16 is not None and ctx.needs_input_grad[0]) else {}))
     dx = dw = None
     if ctx.needs_input_grad[0]:
       dx = _dgrad(be, dz, w, ctx.src, ctx.bf16, ctx.gsink)
@@ -2613,7 +2831,10 @@ class ConcatFn(torch.autograd.Function):
   @staticmethod
   def forward(ctx, *parts):
     ctx.widths = [int(t.shape[1]) for t in parts]
-    return hip().concat_cols([t if t.stride(-1) == 1 else t.contiguous() for t in parts])
+    be = hip()
+    st = _bf16_step_state(be)
+    ps = [t if t.stride(-1) == 1 else t.contiguous() for t in parts]
+    return be.concat_cols(ps, bf16_state=st) if st is not None else be.concat_cols(ps)
 
   @staticmethod
   def backward(ctx, g):
@@ -2622,6 +2843,18 @@ class ConcatFn(torch.autograd.Function):
       out.append(g[:, c:c + w])
       c += w
     return tuple(out)
+
+
+def _bf16_step_state(be):
+  """The Bf16Shadows of the model being run when its dense part is bf16 with producer-written operands, else None."""
+  if not (getattr(be, 'bf16_nt', False) and getattr(be, 'bf16_epilogues', False)):
+    return None
+  from easyrec_amd.core import context
+  stack = context._stack()
+  ctx = stack[-1] if stack else None
+  if ctx is None or getattr(ctx, 'dense_dtype', 'f32') != 'bf16':
+    return None
+  return getattr(ctx, 'bf16_state', None)
 
 
 def concat_cols(parts):
@@ -2801,6 +3034,116 @@ class CrossV2EpilogueFn(torch.autograd.Function):
       else:
         dbias = be.colsum(du)
     return ret0, retx, du, dbias, None, None, None
+
+
+class CrossSrc(object):
+  """What the input-gradient contraction of the cross layer ABOVE needs in order to run THIS layer's elementwise backward in
+  its epilogue (HipBackend.cross_dgrad_fused(prev=...)), and what it leaves behind for this layer's backward."""
+  __slots__ = ('x0', 'x', 'u', 'bias', 'diag', 'bias_grad', 'out', 'sink', 'slots', 'wsink', 'done', 'dout_ptr', 'du', 'ret0')
+
+  def __init__(self, x0, x, u, bias, diag, bias_grad, out, sink, slots, wsink):
+    self.x0, self.x, self.u, self.bias, self.diag, self.bias_grad, self.out = x0, x, u, bias, diag, bias_grad, out
+    self.sink, self.slots, self.wsink = sink, slots, wsink
+    self.done, self.dout_ptr, self.du, self.ret0 = False, 0, None, None
+
+  def dx0_target(self):
+    """(tensor, accumulate, what to hand autograd for x0 - the slot tensor on its first use - or None, the sink to mark)"""
+    d = self.x0.shape[1]
+    sink = self.sink
+    if sink is not None and sink.covers(0, d):
+      t0, acc0 = sink.target(0, d)
+      return t0, acc0, None, sink
+    t0, acc0, first0 = grad_slot(self.slots, self.x0)
+    return t0, acc0, (t0 if first0 else None), None
+
+
+_cross_tls = threading.local()
+
+
+def take_last_cross_source():
+  src, _cross_tls.last = getattr(_cross_tls, 'last', None), None
+  return src
+
+
+def cross_source_of(x):
+  """The CrossSrc of x if x IS the untouched output of a fused cross layer."""
+  src = getattr(x, '_er_cross_src', None)
+  if src is None or x.dim() != 2 or x.data_ptr() != src.out.data_ptr() or x.shape != src.out.shape or x.stride() != src.out.stride():
+    return None
+  return src
+
+
+class CrossLayerFn(torch.autograd.Function):
+  """One full-rank DCN-v2 cross layer x_{l+1} = x0 * (x_l . W + b + diag * x_l) + x_l (reference layers/keras/interaction.py:
+  249-286) as ONE launch forward - the contraction with the elementwise part in its epilogue - and, in a stack, ONE launch
+  per layer backward: the input-gradient contraction du_l . W^T adds dout_l in its epilogue (the whole gradient of x_{l-1})
+  and runs the elementwise backward of the layer below on it (du_{l-1}, d/dx0, the bias gradient's per-tile column sums);
+  only the top layer of a stack, whose dout comes from outside, needs its own elementwise launch.  Weight gradients join the
+  step's grouped launch; the bias gradients are finished by one launch for all layers (HipBackend.queue_colsum).  d/dx0 goes
+  into the embedding group's gradient buffer (sink) or x0's gradient slot."""
+
+  @staticmethod
+  def forward(ctx, x0, x, w, bias, diag, w_grad, b_grad, sink, bf16, prev):
+    be = hip()
+    out, u = be.cross_fwd_fused(x0, x, w, bias, diag, bf16)
+    ctx.save_for_backward(x0, x, u, w, bias)
+    ctx.diag, ctx.bf16, ctx.w_grad = diag, bf16, w_grad
+    ctx.same = x0.data_ptr() == x.data_ptr()
+    ctx.prev = prev
+    ctx.src = CrossSrc(x0, x, u, bias, diag, b_grad, out, sink, grad_slots_of_step(), be.wgrad_sink())
+    _cross_tls.last = ctx.src
+    return out
+
+  @staticmethod
+  def backward(ctx, dout):
+    be = hip()
+    x0, x, u, w, bias = ctx.saved_tensors
+    src, prev = ctx.src, ctx.prev
+    dg = dout if (dout.dim() == 2 and dout.stride(1) == 1) else dout.contiguous()
+    ret0 = None
+    # 1. this layer's elementwise backward - already done by the contraction of the layer above?
+    if src.done and dg.data_ptr() == src.dout_ptr:
+      du = src.du
+    else:
+      t0, acc0, r0, sk = src.dx0_target()
+      du, partial = be.cross_bwd_top(x0, x, u, bias, ctx.diag, dg, t0, acc0, ctx.bf16, w)
+      if sk is not None:
+        sk.done()
+      ret0 = r0
+      if bias is not None:
+        be.queue_colsum(src.wsink, partial, src.bias_grad, bias.numel())
+    src.done, src.du = False, None
+    # 2. the input-gradient contraction; its epilogue completes the gradient of x_{l-1} and runs the layer below
+    retx = None
+    if ctx.same:  # x_{l-1} is x0: the gradient joins d/dx0
+      t0, acc0, r0, sk = src.dx0_target()
+      assert acc0, 'the elementwise backward deposits into d/dx0 first'
+      res = be.cross_dgrad_fused(du, w, dg, ctx.diag, ctx.bf16, t0, True)
+      assert res is not False
+      if sk is not None:
+        sk.done()
+      ret0 = ret0 if ret0 is not None else r0
+    else:
+      retx = torch.empty_like(x)
+      pv = None
+      if prev is not None:
+        p0, pacc0, pr0, psk = prev.dx0_target()
+        pv = dict(x0=prev.x0, u=prev.u, bias=prev.bias, xl=prev.x, dx0=p0, acc0=pacc0)
+      res = be.cross_dgrad_fused(du, w, dg, ctx.diag, ctx.bf16, retx, False, prev=pv)
+      assert res is not False
+      if prev is not None:
+        du_prev, partial_prev = res
+        if psk is not None:
+          psk.done()
+        ret0 = ret0 if ret0 is not None else pr0
+        if prev.bias is not None:
+          be.queue_colsum(prev.wsink, partial_prev, prev.bias_grad, prev.bias.numel())
+        prev.done, prev.dout_ptr, prev.du = True, retx.data_ptr(), du_prev
+    # 3. the weight gradient x_{l-1}^T . du joins the step's grouped launch
+    dw = None
+    if ctx.needs_input_grad[2]:
+      dw = _wgrad(be, x, du, ctx.w_grad, ctx.bf16, src.wsink)
+    return ret0, retx, dw, None, None, None, None, None, None, None
 
 
 class CINFn(torch.autograd.Function):

@@ -72,6 +72,9 @@ class Cross(object):
     bias = vs.get_variable(self.name + '/dense/bias', (d,), self._bias_initializer) if self._use_bias else None
     if self._projection_dim is None:
       w = vs.get_variable(self.name + '/dense/kernel', (d, d), self._kernel_initializer)
+      fused = self._fused(x0, x, w, bias)
+      if fused is not None:
+        return fused
       u = dnn._linear(x, w, None)
     else:
       r = int(self._projection_dim)
@@ -84,6 +87,28 @@ class Cross(object):
     x0g = kernels.slot_gate(x0)
     return kernels.CrossV2EpilogueFn.apply(x0g, x0g if x is x0 else kernels.slot_gate(x), u, bias, self._diag_scale, None if bias is None else bias.grad,
                                            kernels.grad_sink_of(x0))
+
+
+  def _fused(self, x0, x, w, bias):
+    """The whole layer as one launch forward / one per layer backward (kernels.CrossLayerFn), or None: the general form
+    (low rank, a preactivation, evaluation, operands the fused contraction does not take)."""
+    ctx = context.current()
+    be = kernels.hip()
+    if not (getattr(be, 'fused_cross', False) and self._preactivation is None and torch.is_grad_enabled() and
+            ctx.is_training and not ctx.building and x0.dim() == 2 and x.dim() == 2 and x0.is_contiguous() and
+            x.is_contiguous() and kernels.grad_slots_of_step() is not None and w.grad is not None and
+            (bias is None or bias.grad is not None)):
+      return None
+    bf16 = getattr(ctx, 'dense_dtype', 'f32') == 'bf16'
+    if bf16 and be._cross_b16(w, True, x0, x) is False:
+      return None
+    same = x is x0
+    x0g = kernels.slot_gate(x0)
+    prev = None if same else kernels.cross_source_of(x)
+    out = kernels.CrossLayerFn.apply(x0g, x0g if same else x, w, bias, self._diag_scale, w.grad,
+                                     None if bias is None else bias.grad, kernels.grad_sink_of(x0), bf16, prev)
+    out._er_cross_src = kernels.take_last_cross_source()
+    return out
 
 
 class CIN(object):

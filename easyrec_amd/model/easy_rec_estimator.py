@@ -172,6 +172,7 @@ class EasyRecEstimator(object):
     self.varstore.pack(self._extra_grad_floats())
     if self.ctx.dense_dtype == 'bf16' and self.device.type == 'cuda':
       self._bf16 = kernels.hip().bf16_enable(self.varstore)  # bf16 weight shadows for er_gemm_bf16_nt
+      self.ctx.bf16_state = self._bf16  # (+ the step's registry of producer-written bf16 operands: kernels.Bf16Shadows)
     self._after_pack()
     if self.opt_dense.kind in (kernels.OPT_ADAM, kernels.OPT_LAZY_ADAM):
       self.varstore.slot('m')

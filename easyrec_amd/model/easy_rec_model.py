@@ -141,6 +141,8 @@ class EasyRecModel(six.with_metaclass(_meta_type, object)):
       ctx.heads.clear()
       del ctx.tail_jobs[:]
       ctx.grad_slots.clear()
+      if getattr(ctx, 'bf16_state', None) is not None:
+        ctx.bf16_state.begin_step()
 
   @abstractmethod
   def build_predict_graph(self):

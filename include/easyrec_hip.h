@@ -424,6 +424,10 @@ int er_emb_bwd_fused(er_emb_group* const* groups, int n, const er_grad_group* fi
 int er_debug_stamps(unsigned long long* stamps);
 /* out[b, sum(widths[<p]) + j] = parts[p][b * lds[p] + j]: tf.concat(values, axis=1) of n <= 8 row-major blocks
  * (model/deepfm.py:75-83, model/multi_tower_din.py:96,117) in one launch.  parts / widths / lds: HOST arrays. */
+/* ... er_concat_cols_b16: also a bf16 copy of out (row stride ld_bf16 >= the joined width; the columns past it zeroed): the
+ * operand of the bf16 contraction that reads the concatenation next (dense_dtype 'bf16'). */
+int er_concat_cols_b16(const float* const* parts_host, const int32_t* widths_host, const int32_t* lds_host, int n,
+                       int32_t batch, float* out, int32_t out_ld, uint16_t* out_bf16, int32_t ld_bf16, er_stream_t stream);
 int er_concat_cols(const float* const* parts_host, const int32_t* widths_host, const int32_t* lds_host, int n,
                    int32_t batch, float* out, int32_t out_ld, er_stream_t stream);
 /* y[i] (+)= alpha * x[i]  over a strided 2-D view (used for the embedding L2 gradient
@@ -467,6 +471,13 @@ int er_cross_v2_epilogue_bwd(const float* x0, const float* x, const float* u, co
  * same x_l went to - so that the sums autograd would run as separate add kernels happen here; dx == NULL: x is x0 (the first
  * cross layer of layers/keras/interaction.py:276-286) and its gradient joins dx0's.  dout: row stride ld_dout (a column
  * block of a wider gradient - tf.concat's backward - is read in place). */
+/* The elementwise backward of the TOP layer of a cross stack whose input gradients run through er_gemm_f32_cross /
+ * er_gemm_bf16_nt_epi (ER_EPI_CROSS_BWD): du = dout * x0 (fp32, and bf16 with row stride ld_du_bf16 when du_bf16 != NULL),
+ * dx0 (+)= dout * (u + bias + diag * x), partial [er_gemm_row_tiles(B)][d] = per 64-row tile column sums of du (NULL: not
+ * wanted).  It leaves dout's own term of d/dx to the contraction's epilogue. */
+int er_cross_v2_bwd_top(const float* x0, const float* x, const float* u, const float* bias, float diag_scale, const float* dout,
+                        int32_t ld_dout, int32_t B, int32_t d, float* dx0, int32_t ld_dx0, int accumulate_dx0, float* du,
+                        uint16_t* du_bf16, int32_t ld_du_bf16, float* partial, er_stream_t stream);
 int er_cross_v2_epilogue_bwd_acc(const float* x0, const float* x, const float* u, const float* bias, float diag_scale,
                                  const float* dout, int32_t ld_dout, int32_t B, int32_t d, float* dx0, int32_t ld_dx0,
                                  int accumulate_dx0, float* dx, int32_t ld_dx, int accumulate_dx, float* du, er_stream_t stream);
@@ -623,6 +634,22 @@ int er_bn_apply_from_stats(const float* x, const float* bias, const float* col_s
                            const float* gamma, const float* beta, int32_t B, int32_t N, float eps,
                            float momentum, float* moving_mean, float* moving_var, int act, float* y,
                            float* save_mean, float* save_invstd, er_stream_t stream);
+/* ... that also writes y_bf16 [B][ld_bf16] (NULL: no), the bf16 copy the next bf16 contraction reads (dense_dtype 'bf16':
+ * the producer writes its consumer's operand - no cast launch); er_bn_act_bwd_ld_b16 / er_bn_act_bwd_from_partials_ld_b16
+ * likewise leave dx_bf16 for the input-gradient contraction. */
+int er_bn_apply_from_stats_b16(const float* x, const float* bias, const float* col_stats, int32_t chunks,
+                               const float* gamma, const float* beta, int32_t B, int32_t N, float eps,
+                               float momentum, float* moving_mean, float* moving_var, int act, float* y,
+                               float* save_mean, float* save_invstd, uint16_t* y_bf16, int32_t ld_bf16, er_stream_t stream);
+int er_bn_act_bwd_ld_b16(const float* x, const float* bias, const float* gamma, const float* y,
+                         const float* save_mean, const float* save_invstd, const float* dy, int32_t dy_ld,
+                         int32_t B, int32_t N, int use_bn, int act, float* dx, float* dbias, float* dgamma,
+                         float* dbeta, int accumulate, uint16_t* dx_bf16, int32_t ld_bf16, er_stream_t stream);
+int er_bn_act_bwd_from_partials_ld_b16(const float* x, const float* bias, const float* gamma, const float* y,
+                                       const float* save_mean, const float* save_invstd, const float* dy, int32_t dy_ld,
+                                       int32_t B, int32_t N, int use_bn, int act, const float* partial, int32_t chunks,
+                                       float* dx, float* dbias, float* dgamma, float* dbeta, int accumulate,
+                                       uint16_t* dx_bf16, int32_t ld_bf16, er_stream_t stream);
 /* dx [B,N]; dbias/dgamma/dbeta [N] (NULL to skip): overwritten, or += when accumulate != 0 (they then
  * point into the flat gradient buffer).  y is the forward output (relu mask); x the forward input. */
 int er_bn_act_bwd(const float* x, const float* bias, const float* gamma, const float* y,
@@ -938,6 +965,50 @@ int er_gemm_bf16_nt_prepare(void);
 int er_gemm_bf16_nt(int32_t M, int32_t N, int32_t K, const uint16_t* A, int32_t lda, const uint16_t* Bt, int32_t ldb,
                     float* C, int32_t ldc, uint16_t* C_bf16, int32_t ldc_bf16, const float* bias, int accumulate,
                     er_stream_t stream);
+/* What a contraction's epilogue does with its accumulators besides + bias / C += (a HOST record; er_gemm_bf16_nt_epi,
+ * er_gemm_f32_cross).  The fusions north_star names for the DCN-v2 cross layer (reference layers/keras/interaction.py:
+ * 249-286: x_{l+1} = x0 * (W x_l + b + diag * x_l) + x_l) and for the dense + BatchNorm layers of layers/dnn.py:57-79:
+ *   ER_EPI_STATS     col_stats [er_gemm_row_tiles(M)][N][3]: per 64-row tile the Welford triple (count, mean, M2) of the
+ *                    output columns (value = acc + bias), as er_gemm_f32's col_stats: the following BatchNorm's batch
+ *                    statistics without a pass over C (er_bn_apply_from_stats consumes them).
+ *   ER_EPI_BN_BWD    the output is the gradient dy of the activations y = act(BN(z + zbias)) of the layer below: per 64-row
+ *                    tile the column sums (sum g, sum g * xhat), g = dy masked by the activation, into bn_partial
+ *                    [tiles][bn_n_src][2] (er_gemm_f32_bn_bwd(_cols)' epilogue; output columns [bn_col0, bn_col0 +
+ *                    bn_n_src) belong to that layer; bn_n_src 0: all N).
+ *   ER_EPI_CROSS_FWD C / C_bf16 = x0 * (acc + bias + diag * xl) + xl with x0, xl fp32 [M][ld]; u (optional) keeps
+ *                    acc (the W x_l product without the bias: what the backward's d/dx0 needs).  One launch per cross
+ *                    layer where the reference issues MatMul, BiasAdd, Mul, Mul, Add.
+ *   ER_EPI_CROSS_BWD the contraction is du_l . W_l^T of cross layer l (du_l = dout_l * x0): v = acc + dout + diag * du_in
+ *                    is the whole gradient of x_{l-1}; C (+)= v.  With prev_u != NULL (x_{l-1} is itself the output of a
+ *                    cross layer) the elementwise backward of THAT layer happens here too: du_out / du_out_bf16 = v * x0,
+ *                    dx0 (+)= v * (prev_u + prev_bias + diag * xl), partial [er_gemm_row_tiles(M)][N] = per-tile column
+ *                    sums of du_out (the lower layer's bias gradient: er_colsum_partials_multi finishes them). */
+enum { ER_EPI_PLAIN = 0, ER_EPI_STATS = 1, ER_EPI_BN_BWD = 2, ER_EPI_CROSS_FWD = 3, ER_EPI_CROSS_BWD = 4 };
+typedef struct er_gemm_epilogue {
+  int32_t kind;
+  float diag;
+  float* col_stats;
+  const float* bn_z; const float* bn_zbias; const float* bn_y; const float* bn_mean; const float* bn_invstd;
+  float* bn_partial;
+  int32_t bn_ld, bn_use_bn, bn_act, bn_col0, bn_n_src;
+  int32_t ld_x0, ld_xl, ld_u, ld_dout, ld_du_in, ld_prev_u, ld_dx0, ld_du_out, ld_du_out_bf16, accumulate_dx0;
+  const float* x0; const float* xl; float* u;
+  const float* dout; const float* du_in; const float* prev_u; const float* prev_bias;
+  float* dx0; float* du_out; uint16_t* du_out_bf16; float* partial;
+} er_gemm_epilogue;
+/* er_gemm_bf16_nt with an epilogue record (epi NULL or kind ER_EPI_PLAIN: er_gemm_bf16_nt).  Epilogues other than PLAIN
+ * need N % 4 == 0 and 16-byte aligned rows of every fp32 matrix they touch (8-byte for bf16). */
+int er_gemm_bf16_nt_epi(int32_t M, int32_t N, int32_t K, const uint16_t* A, int32_t lda, const uint16_t* Bt, int32_t ldb,
+                        float* C, int32_t ldc, uint16_t* C_bf16, int32_t ldc_bf16, const float* bias, int accumulate,
+                        const er_gemm_epilogue* epi, er_stream_t stream);
+/* The fp32 contraction (er_gemm_f32's kernel, no k-split) with the ER_EPI_CROSS_FWD / ER_EPI_CROSS_BWD epilogue: the
+ * values the epilogue needs at a lane's 16 output positions are requested before the k loop. */
+int er_gemm_f32_cross(int layout, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B, int32_t ldb,
+                      float* C, int32_t ldc, const float* bias, int accumulate, const er_gemm_epilogue* epi,
+                      er_stream_t stream);
+/* dst[j] (+)= sum_p partial[p * ld + j] for up to 16 jobs in ONE launch (er_tail_job records, HOST array): the bias
+ * gradients of a stack of cross layers from the per-tile column sums their fused backward left. */
+int er_colsum_partials_multi(const er_tail_job* jobs_host, int32_t n_jobs, int accumulate, er_stream_t stream);
 int er_cast_bf16(const er_cast_desc* descs_host, int n, er_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------

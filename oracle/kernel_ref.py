@@ -849,6 +849,46 @@ class RefBackend(object):
       t = t + diag_scale * x
     return x0 * t + x
 
+  # the fused cross layer of the HIP backend (kernels.CrossLayerFn): same results from the separate steps
+  fused_cross = True
+
+  def _cross_b16(self, w, bf16, *rows):
+    return None
+
+  def cross_fwd_fused(self, x0, x, w, bias, diag, bf16):
+    u = self.gemm(0, x, w, bf16=bf16)
+    return self.cross_v2_fwd(x0, x, u, bias, diag), u
+
+  def cross_bwd_top(self, x0, x, u, bias, diag, dout, dx0, acc0, bf16, w):
+    g0, _, du = self.cross_v2_bwd(x0, x, u, bias, diag, dout)
+    if acc0:
+      dx0.add_(g0)
+    else:
+      dx0.copy_(g0)
+    return du, du.sum(dim=0, keepdim=True)
+
+  def cross_dgrad_fused(self, du, w, dout, diag, bf16, dst, acc, prev=None):
+    v = self.gemm(1, du, w, bf16=bf16) + dout
+    if diag != 0:
+      v = v + diag * du
+    if acc:
+      dst.add_(v)
+    else:
+      dst.copy_(v)
+    if prev is None:
+      return None, None
+    return self.cross_bwd_top(prev['x0'], prev['xl'], prev['u'], prev['bias'], diag, v, prev['dx0'], prev['acc0'], bf16, w)
+
+  def queue_colsum(self, sink, partial, dst, n_cols):
+    dst.add_(partial.sum(dim=0))
+
+  def colsum_partials_multi(self, jobs, accumulate=True):
+    for partial, dst, n_cols in jobs:
+      if accumulate:
+        dst.add_(partial.sum(dim=0))
+      else:
+        dst.copy_(partial.sum(dim=0))
+
   def cross_v2_bwd_acc(self, x0, x, u, bias, diag_scale, dout, dx0, acc0, dx, accx):
     g0, gx, du = self.cross_v2_bwd(x0, x, u, bias, diag_scale, dout)
     if dx is None:

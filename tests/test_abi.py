@@ -56,7 +56,7 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
 
 
 MIRRORS = {  # ctypes class in easyrec_amd/kernels.py -> the C struct it mirrors
-    'LookupDesc': 'er_lookup_desc', 'KvJob': 'er_kv_job', 'KvRouteJob': 'er_kv_route_job', 'CastDesc': 'er_cast_desc',
+    'GemmEpilogue': 'er_gemm_epilogue', 'LookupDesc': 'er_lookup_desc', 'KvJob': 'er_kv_job', 'KvRouteJob': 'er_kv_route_job', 'CastDesc': 'er_cast_desc',
     'GemmProblem': 'er_gemm_problem', 'BnLayer': 'er_bn_layer', 'CeHead': 'er_ce_head', 'TailJob': 'er_tail_job',
     'LossTailJob': 'er_loss_tail_job', 'DenseOptJob': 'er_dense_opt_job', 'GradTerm': 'er_grad_term',
     'GradGroup': 'er_grad_group', 'DenseApplyDesc': 'er_dense_apply_desc',
