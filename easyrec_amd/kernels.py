@@ -113,10 +113,17 @@ class WgradSink(object):
     # finished by ONE launch when the backward pass is over (HipBackend.take_wgrads -> colsum_partials_multi)
     self.colsum_jobs = []
 
+  # a bf16 step's weight gradients dW = x^T . dz contract over the BATCH: their operands are k-strided in HBM, which the bf16
+  # kernel with operands in HBM (er_gemm_bf16_nt) does not take, and er_gemm_grouped_bf16 rounds fp32 operands while staging
+  # them (122 us per DCN-v2 step for what the fp32 launch inside the step's fused tail does in the shadow of the embedding
+  # update).  Default: the fp32 contraction of the fp32 activations / gradients the step holds anyway - the weight
+  # gradient is then the one quantity of a bf16 step computed at HIGHER precision; '0' = er_gemm_grouped_bf16.
+  bf16_wgrad_f32 = os.environ.get('EASYREC_AMD_BF16_WGRAD_F32', '1') != '0'
+
   def put(self, x, dy, out, bf16):
     if not self.active:
       return False
-    (self.queue_bf16 if bf16 else self.queue).append((x, dy, out, None, True))
+    (self.queue_bf16 if (bf16 and not self.bf16_wgrad_f32) else self.queue).append((x, dy, out, None, True))
     return True
 
 
@@ -196,6 +203,9 @@ class _SlotGateFn(torch.autograd.Function):
 
   @staticmethod
   def forward(ctx, x):
+    # (when every consumer deposited its gradient elsewhere - an embedding group's GradSink - nothing arrives here: without
+    # this autograd would materialise a zero tensor and the group would add it to its buffer: a fill + an axpy2d for nothing)
+    ctx.set_materialize_grads(False)
     return x.view_as(x)
 
   @staticmethod
@@ -1453,6 +1463,10 @@ class HipBackend(object):
                                               ctypes.byref(lt[0]) if lt is not None else None,
                                               ctypes.byref(oj) if oj is not None else None, _stream()),
                'er_emb_bwd_fused_tail')
+      if oj is not None:
+        st = self._bf16_state_of(dense_opt[0])
+        if st is not None:
+          st.refresh()  # (a bf16 step whose dense optimizer ran in the tail: the weights' bf16 shadows follow the masters)
       return oj is not None
     self._ck(self.lib.er_emb_bwd_fused(gh, n, arr, len(finish), ctypes.c_int(opt_kind), _p(hyper), _stream()),
              'er_emb_bwd_fused')
@@ -2414,7 +2428,8 @@ class HeadFn(torch.autograd.Function):
     x2 = x if x.stride(-1) == 1 else x.contiguous()
     logits = torch.empty(x2.shape[0], 1, dtype=torch.float32, device=x2.device)
     be = hip()
-    fused = src is not None and x2 is x and not bf16 and src.fused and getattr(be, 'fused_bn_bwd', False)  # (the head launch is fp32)
+    # (the head launch itself is fp32 arithmetic on fp32 activations, whatever the dense dtype)
+    fused = src is not None and x2 is x and src.fused and _bn_bwd_fusable(be, bf16)
     # (the state keeps a DETACHED alias of the logits: they are written after this forward returned, outside autograd's view)
     st = HeadState(x2, w.detach(), None if b is None else b.detach(), w_grad, b_grad, src if fused else None, logits.detach(), bf16)
     heads[logits.data_ptr()] = st
@@ -2863,7 +2878,17 @@ def concat_cols(parts):
   if len(parts) == 1:
     return parts[0]
   if any(t.requires_grad for t in parts) and torch.is_grad_enabled():
-    return ConcatFn.apply(*parts)
+    out = ConcatFn.apply(*parts)
+    # a part that is the output of a fused dense + BatchNorm layer (DCN-v2's deep tower beside the cross stack): the
+    # consumer's input-gradient contraction emits that layer's BatchNorm-backward sums from its column block
+    c = 0
+    for t in parts:
+      src = bn_source_of(t)
+      if src is not None and src.fused:
+        tag_bn_cols(out, t, c)
+        break
+      c += int(t.shape[1])
+    return out
   return hip().concat_cols([t if t.stride(-1) == 1 else t.contiguous() for t in parts])
 
 

@@ -1352,6 +1352,10 @@ class OracleTrainer(object):
         g = (g * F32(self.emb_mult)).astype(np.float32)
       grads[name] = g
     self.last_grads = OrderedDict((n, g.copy()) for n, g in grads.items())
+    # test hook (tests/test_chaos_bars.py): a model of ANOTHER fp32 summation order - callable (name, g) -> g' applied to
+    # every gradient before the optimizer sees it; None in every other use
+    if getattr(self, 'grad_noise', None) is not None:
+      grads = OrderedDict((n, self.grad_noise(n, g).astype(np.float32)) for n, g in grads.items())
     # clip_by_global_norm (:365-376, 453-481): norm = sqrt(2 * sum of tf.nn.l2_loss(g)); a table's IndexedSlices carry
     # one row per distinct id of a lookup, so (one lookup per table) the dense gradient has the same sum of squares; with
     # sharded tables the rows of different workers stay separate rows of `values` (each divided by W), their l2 sums are
