@@ -575,7 +575,9 @@ def steady_state(est, gen, n_steps):
 
 def parity_full_size(cfg, est, ring, host_batches, batch_size, n_steps):
   """The GPU path and the CPU oracle from the SAME full-size training state (weights, Adam slots, step), the same
-  batches: relative loss differences over n_steps steps (north_star: 1e-4)."""
+  batches: relative loss differences over n_steps steps.  Tolerance: north_star's 1e-4 for fp32; with bf16 dense
+  contractions (operands carry 8 significant bits; north_star states no bar for them) 1e-3 against the fp32 oracle, the bar
+  tests/test_models_gpu.py holds the bf16 step to."""
   from oracle.model_oracle import OracleTrainer
   state = est.state_dict(slots=True)
   weights = {k: v for k, v in state.items() if not (k.endswith('/m') or k.endswith('/v'))}
@@ -590,7 +592,8 @@ def parity_full_size(cfg, est, ring, host_batches, batch_size, n_steps):
     d = max(abs(got[n] - exp[n]) / max(abs(exp[n]), 1e-3) for n in exp)
     per_step.append({'gpu_total_loss': got['total_loss'], 'oracle_total_loss': exp['total_loss'], 'max_rel_diff': d})
     worst = max(worst, d)
-  return {'max_rel_loss_diff': worst, 'steps': n_steps, 'tolerance': 1e-4, 'ok': bool(worst <= 1e-4),
+  tol = 1e-3 if getattr(est.ctx, 'dense_dtype', 'f32') == 'bf16' else 1e-4
+  return {'max_rel_loss_diff': worst, 'steps': n_steps, 'tolerance': tol, 'ok': bool(worst <= tol),
           'per_step': per_step, 'from_global_step': int(est.global_step - n_steps)}, orc
 
 

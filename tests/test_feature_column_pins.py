@@ -63,3 +63,15 @@ def test_parser_builds_what_the_reference_parser_builds(tag):
     assert [by_id[id(c)] for c in plain] == want['plain'] and [by_id[id(c)] for c in seqs] == want['sequence'], gname
   for name, n in case['vocab_size'].items():
     assert parser.get_feature_vocab_size(name) == n, (name, parser.get_feature_vocab_size(name), n)
+
+
+def test_every_small_fixture_config_has_a_pinned_case():
+  """A config added under configs/ without re-running tests/golden/make_feature_column_vectors.py (where /root/reference
+  exists) would be a fixture the reference's parser never saw: every `*_small.config` must have its case (the full-size twins
+  differ only in table sizes and are not cases of their own)."""
+  import glob
+  root = os.path.dirname(HERE)
+  names = sorted(os.path.basename(p)[:-len('.config')] for p in glob.glob(os.path.join(root, 'configs', '*_small.config')))
+  assert names, 'no fixture configs found'
+  missing = [n for n in names if n not in CASES]
+  assert not missing, 'configs without a feature-column case (regenerate the fixture): %s' % missing
