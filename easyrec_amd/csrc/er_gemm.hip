@@ -47,6 +47,30 @@ gemm_f32_cross_kernel(GemmArgs g, er_gemm_epilogue xe) {
   gemm_f32_block<A_KC, B_KC, false, XEPI>(g, blockIdx.x, 0, lds, false, &xe);
 }
 
+// DIN's first attention layer on the generated [q, h, q - h, q * h] operand (DinGen): forward / weight gradient (DIN = 1),
+// input gradient reduced to dh and dq partials in the epilogue (DIN = 2)
+template <bool A_KC, bool B_KC, int DIN>
+__global__ void __launch_bounds__(kBlock)
+gemm_f32_din_kernel(GemmArgs g, DinGen d) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * 2 * kOpTile];
+  gemm_f32_block<A_KC, B_KC, false, 0, DIN>(g, blockIdx.x, blockIdx.z, lds, false, nullptr, &d);
+}
+
+// dq[b][j] = sum over the row tiles that hold rows of example b of its slot's partial (tile order: fixed)
+__global__ void __launch_bounds__(kBlock)
+din_dq_finish_kernel(const float* __restrict__ partial, int B, int L, int E, int slots, int64_t M, float* __restrict__ dq, int lddq) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i >= static_cast<int64_t>(B) * E) return;
+  const int b = static_cast<int>(i / E), j = static_cast<int>(i % E);
+  const int64_t r0 = static_cast<int64_t>(b) * L, r1 = r0 + L - 1;
+  float s = 0.f;
+  for (int64_t ty = r0 / BM; ty <= r1 / BM; ++ty) {
+    const int slot = b - static_cast<int>((ty * BM) / L);
+    s = s + partial[(ty * slots + slot) * E + j];
+  }
+  dq[static_cast<int64_t>(b) * lddq + j] = s;
+}
+
 template <bool A_KC, bool B_KC>
 __global__ void __launch_bounds__(kBlock)
 gemm_f32_grouped_kernel(GroupedArgs ga) {
@@ -533,6 +557,117 @@ int er_gemm_f32_cross(int layout, int32_t M, int32_t N, int32_t K, const float* 
     if (layout == ER_GEMM_NN) hipLaunchKernelGGL((er::gemm_f32_cross_kernel<true, false, ER_EPI_CROSS_BWD>), grid, block, 0, s, a, e);
     else hipLaunchKernelGGL((er::gemm_f32_cross_kernel<true, true, ER_EPI_CROSS_BWD>), grid, block, 0, s, a, e);
   }
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
+namespace {
+int din_gen(const char* who, const float* q, int32_t ldq, const float* h, int32_t ldh, int32_t B, int32_t L, int32_t E,
+            er::DinGen* d) {
+  ER_REQUIRE(q && h && B > 0 && L > 0 && E > 0 && E % 4 == 0 && ldq >= E && ldh >= E && ldq % 4 == 0 && ldh % 4 == 0 &&
+                 ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(h)) & 15) == 0,
+             "%s: q [B][ldq] / h [B * L][ldh] must be 16-byte aligned rows, E a multiple of 4", who);
+  ER_REQUIRE(static_cast<int64_t>(B) * L < (1LL << 31) / (L > 0 ? L : 1) * L && static_cast<int64_t>(B) * L < (1LL << 32) / L,
+             "%s: B * L too large for the row / L shortcut", who);
+  *d = er::DinGen();
+  d->q = q; d->h = h; d->ldq = ldq; d->ldh = ldh; d->L = L; d->E = E;
+  d->inv_L = static_cast<uint32_t>(((1ULL << 32) + L - 1) / L);
+  if (L == 1) d->inv_L = 0xFFFFFFFFu;  // (2^32 does not fit: row * (2^32 - 1) >> 32 == row - 1 for row >= 1 - handled below)
+  return 0;
+}
+}  // namespace
+
+int er_din_gemm_fwd(const float* q, int32_t ldq, const float* h, int32_t ldh, int32_t B, int32_t L, int32_t E, const float* W,
+                    int32_t ldw, int32_t N, const float* bias, float* z, int32_t ldz, float* col_stats, er_stream_t stream) {
+  er::DinGen d;
+  if (int rc = din_gen("er_din_gemm_fwd", q, ldq, h, ldh, B, L, E, &d)) return rc;
+  ER_REQUIRE(L >= 2, "er_din_gemm_fwd: L >= 2");
+  ER_REQUIRE(W && z && N > 0 && ldw >= N && ldz >= N && ldw % 4 == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0,
+             "er_din_gemm_fwd: W [4E][ldw] must have 16-byte aligned rows");
+  er::GemmArgs a;
+  a.A = nullptr; a.B = W; a.C = z; a.bias = bias;
+  a.M = B * L; a.N = N; a.K = 4 * E; a.lda = 4 * E; a.ldb = ldw; a.ldc = ldz;
+  a.accumulate = 0; a.col_stats = col_stats; a.splits = 1;
+  a.k_per_split = static_cast<int>(er::ceil_div(a.K, er::BK32)) * er::BK32;
+  const int64_t n_tiles = er::ceil_div(a.N, er::BN) * er::ceil_div(a.M, er::BM);
+  hipLaunchKernelGGL((er::gemm_f32_din_kernel<true, false, 1>), dim3(static_cast<unsigned>(n_tiles)), dim3(er::kBlock), 0,
+                     er::as_stream(stream), a, d);
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
+int er_din_gemm_wgrad(const float* q, int32_t ldq, const float* h, int32_t ldh, int32_t B, int32_t L, int32_t E, const float* dz,
+                      int32_t lddz, int32_t N, float* dW, int32_t lddw, int accumulate, er_stream_t stream) {
+  er::DinGen d;
+  if (int rc = din_gen("er_din_gemm_wgrad", q, ldq, h, ldh, B, L, E, &d)) return rc;
+  ER_REQUIRE(L >= 2, "er_din_gemm_wgrad: L >= 2");
+  ER_REQUIRE(dz && dW && N > 0 && lddz >= N && lddw >= N && lddz % 4 == 0 && (reinterpret_cast<uintptr_t>(dz) & 15) == 0,
+             "er_din_gemm_wgrad: dz [B * L][lddz] must have 16-byte aligned rows");
+  hipStream_t s = er::as_stream(stream);
+  er::GemmArgs a;
+  a.A = nullptr; a.B = dz; a.bias = nullptr;
+  a.M = 4 * E; a.N = N; a.K = B * L; a.lda = 4 * E; a.ldb = lddz; a.ldc = lddw;
+  a.accumulate = accumulate; a.col_stats = nullptr;
+  // a batch-long contraction into a small output: k-splits of at most 2048 rows (er_gemm_grouped_f32's rule)
+  int64_t splits = er::ceil_div(a.K, 2048);
+  const int64_t max_by_k = a.K / (4 * er::BK32);
+  if (splits > 128) splits = 128;
+  if (splits > max_by_k) splits = max_by_k;
+  if (splits < 1) splits = 1;
+  a.k_per_split = static_cast<int>(er::ceil_div(er::ceil_div(a.K, splits), er::BK32)) * er::BK32;
+  a.splits = static_cast<int>(er::ceil_div(a.K, a.k_per_split));
+  const int64_t n_tiles = er::ceil_div(a.N, er::BN) * er::ceil_div(a.M, er::BM);
+  dim3 grid(static_cast<unsigned>(n_tiles), 1, static_cast<unsigned>(a.splits));
+  if (a.splits > 1) {
+    float* ws;
+    if (int rc = ensure_ws(static_cast<size_t>(a.splits) * a.M * a.N, &ws)) return rc;
+    a.C = ws;
+    hipLaunchKernelGGL((er::gemm_f32_din_kernel<false, false, 1>), grid, dim3(er::kBlock), 0, s, a, d);
+    ER_LAUNCH_CHECK();
+    const int64_t mn = static_cast<int64_t>(a.M) * a.N;
+    if (N % 4 == 0 && lddw % 4 == 0 && (reinterpret_cast<uintptr_t>(dW) & 15) == 0) {
+      hipLaunchKernelGGL(er::gemm_splitk_reduce_kernel<4>, dim3(static_cast<unsigned>(er::ceil_div(mn / 4, er::kBlock))),
+                         dim3(er::kBlock), 0, s, ws, mn, N, a.splits, static_cast<const float*>(nullptr), dW, lddw, accumulate);
+    } else {
+      hipLaunchKernelGGL(er::gemm_splitk_reduce_kernel<1>, dim3(static_cast<unsigned>(er::ceil_div(mn, er::kBlock))),
+                         dim3(er::kBlock), 0, s, ws, mn, N, a.splits, static_cast<const float*>(nullptr), dW, lddw, accumulate);
+    }
+  } else {
+    a.C = dW;
+    hipLaunchKernelGGL((er::gemm_f32_din_kernel<false, false, 1>), grid, dim3(er::kBlock), 0, s, a, d);
+  }
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
+int64_t er_din_dq_partial_floats(int32_t B, int32_t L, int32_t E) {
+  if (B <= 0 || L <= 0 || E <= 0) return -1;
+  return er::ceil_div(static_cast<int64_t>(B) * L, er::BM) * ((er::BM - 1) / L + 2) * E;
+}
+
+int er_din_gemm_dgrad(const float* dz, int32_t lddz, int32_t N, const float* W, int32_t ldw, const float* q, int32_t ldq,
+                      const float* h, int32_t ldh, int32_t B, int32_t L, int32_t E, float* dq, int32_t lddq, float* dh,
+                      int32_t lddh, int accumulate_dh, float* dq_partial, er_stream_t stream) {
+  er::DinGen d;
+  if (int rc = din_gen("er_din_gemm_dgrad", q, ldq, h, ldh, B, L, E, &d)) return rc;
+  ER_REQUIRE(L >= 2 && E % 16 == 0, "er_din_gemm_dgrad: E must be a multiple of 16 (one 64-column tile holds the four segments of 16 positions), L >= 2");
+  ER_REQUIRE(dz && W && dq && dh && dq_partial && N > 0 && lddz >= N && ldw >= N && lddq >= E && lddh >= E && lddz % 4 == 0 &&
+                 ldw % 4 == 0 && ((reinterpret_cast<uintptr_t>(dz) | reinterpret_cast<uintptr_t>(W)) & 15) == 0,
+             "er_din_gemm_dgrad: dz [B * L][lddz] / W [4E][ldw] must have 16-byte aligned rows");
+  d.dh = dh; d.lddh = lddh; d.accumulate_dh = accumulate_dh;
+  d.dq_partial = dq_partial;
+  d.slots = (er::BM - 1) / L + 2;
+  hipStream_t s = er::as_stream(stream);
+  er::GemmArgs a;
+  a.A = dz; a.B = W; a.C = nullptr; a.bias = nullptr;
+  a.M = B * L; a.N = 4 * E; a.K = N; a.lda = lddz; a.ldb = ldw; a.ldc = 4 * E;
+  a.accumulate = 0; a.col_stats = nullptr; a.splits = 1;
+  a.k_per_split = static_cast<int>(er::ceil_div(a.K, er::BK32)) * er::BK32;
+  const int64_t n_tiles = er::ceil_div(a.N, er::BN) * er::ceil_div(a.M, er::BM);
+  hipLaunchKernelGGL((er::gemm_f32_din_kernel<true, true, 2>), dim3(static_cast<unsigned>(n_tiles)), dim3(er::kBlock), 0, s, a, d);
+  ER_LAUNCH_CHECK();
+  hipLaunchKernelGGL(er::din_dq_finish_kernel, dim3(static_cast<unsigned>(er::ceil_div(static_cast<int64_t>(B) * E, er::kBlock))),
+                     dim3(er::kBlock), 0, s, dq_partial, B, L, E, d.slots, static_cast<int64_t>(B) * L, dq, lddq);
   ER_LAUNCH_CHECK();
   return 0;
 }

@@ -298,15 +298,99 @@ __device__ __forceinline__ void stage_tile(float* __restrict__ S, int tid, const
   }
 }
 
+// DIN's attention input [q, h, q - h, q * h] ([B * L, 4E], reference model/multi_tower_din.py:62-80) as a GENERATED operand:
+// the contraction reads q [B, E] and h [B * L, E] and forms the 4E columns while staging, so the block never exists in HBM.
+//   forward  (NN): z1 = [q, h, q - h, q * h] . W1           A_KC: 4 consecutive concat columns of one row per unit
+//   wgrad    (TN): dW1 = [q, h, q - h, q * h]^T . dz1        !A_KC: 4 consecutive concat columns of one row per unit too
+// and, for the input gradient dcat = dz1 . W1^T (NT), an epilogue that reduces the four column segments of dcat to dh and
+// to per-tile partial sums of dq (DinBwd) - with W1's rows permuted so that one 64-column tile holds all four segments of 16
+// embedding positions.
+struct DinGen {
+  const float* q;   // [B][ldq]
+  const float* h;   // [B * L][ldh]
+  int ldq, ldh, L, E;
+  uint32_t inv_L;   // ceil(2^32 / L): row / L = (row * inv_L) >> 32 for row < 2^32 / L
+  // input-gradient epilogue (DinBwd)
+  float* dh;        // [B * L][lddh]: dh (+)= d1 - d2 + q * d3
+  int lddh, accumulate_dh;
+  float* dq_partial;  // [row tiles][slots][E]: per 64-row tile and example slot, sum over the tile's rows of d0 + d2 + h * d3
+  int slots;          // (63 / L) + 2: the examples a 64-row tile can touch
+};
+__device__ __forceinline__ int din_div_L(const DinGen& d, int row) {
+  return static_cast<int>((static_cast<uint64_t>(static_cast<uint32_t>(row)) * d.inv_L) >> 32);
+}
+// the generated 4 consecutive concat columns [c, c + 4) of a row from its q / h pieces (c % 4 == 0, E % 4 == 0: one segment)
+__device__ __forceinline__ f32x4v din_combine(int seg, const f32x4v& qv, const f32x4v& hv) {
+  f32x4v v;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] = seg == 0 ? qv[j] : (seg == 1 ? hv[j] : (seg == 2 ? qv[j] - hv[j] : qv[j] * hv[j]));
+  return v;
+}
+// loads of a thread's 2 units of the GENERATED A tile (clamped like fetch_tile; the values are combined at staging)
+template <bool KC>
+__device__ __forceinline__ void fetch_din(const DinGen& d, int mn0, int MN, int k0, int kend, int K, int tid,
+                                          f32x4v (&rh)[2], f32x4v (&rq)[2]) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int row, k;
+    unit_pos<KC>(tid, i, row, k);
+    int mn = mn0 + row;
+    k += k0;
+    int r, c;  // the unit's row of the block and its first concat column
+    if (KC) {  // NN: mn = row of the block, k = concat column
+      r = mn < MN ? mn : MN - 1;
+      c = k < K - 4 ? k : K - 4;
+    } else {   // TN: mn = concat column, k = row of the block
+      c = mn < MN - 4 ? mn : MN - 4;
+      r = k < kend ? k : kend - 1;
+    }
+    const int j = c % d.E;
+    const int b = din_div_L(d, r);
+    rq[i] = *reinterpret_cast<const f32x4v*>(d.q + static_cast<int64_t>(b) * d.ldq + j);
+    rh[i] = *reinterpret_cast<const f32x4v*>(d.h + static_cast<int64_t>(r) * d.ldh + j);
+  }
+}
+template <bool KC>
+__device__ __forceinline__ void combine_din(const DinGen& d, int mn0, int MN, int k0, int K, int tid, f32x4v (&rh)[2],
+                                            const f32x4v (&rq)[2]) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int row, k;
+    unit_pos<KC>(tid, i, row, k);
+    int c;
+    if (KC) { c = k0 + k; c = c < K - 4 ? c : K - 4; }
+    else { c = mn0 + row; c = c < MN - 4 ? c : MN - 4; }
+    rh[i] = din_combine(c / d.E, rq[i], rh[i]);
+  }
+}
+// B rows of the input-gradient contraction in the permuted order: tile column c' of column tile tx is concat column
+// (c' / 16) * E + tx * 16 + c' % 16 (all four segments of 16 embedding positions in one 64-column tile)
+__device__ __forceinline__ void fetch_tile_din_perm(const float* __restrict__ P, int ld, int tx, int E, int k0, int kend, int K,
+                                                    int tid, f32x4v (&r)[2]) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int row, k;
+    unit_pos<true>(tid, i, row, k);
+    const int n = (row >> 4) * E + tx * 16 + (row & 15);
+    k += k0;
+    const int kpad = (K + 3) & ~3;
+    k = k < kpad - 4 ? k : kpad - 4;
+    r[i] = *reinterpret_cast<const f32x4v*>(P + static_cast<int64_t>(n) * ld + k);
+  }
+}
+
 // bx: index of the workgroup among the problem's (8-rounded) tiles, bz: its k-split.  BN_EPI: with the BnBwdEpi
 // epilogue - the y / z values of the lane's 16 output positions are requested BEFORE the k loop so that their
 // latency hides behind it (32 more VGPRs: a separate instantiation).
 // XEPI: ER_EPI_CROSS_FWD / ER_EPI_CROSS_BWD with the record *xe (er_gemm_f32_cross: the DCN-v2 cross layer's elementwise
 // part inside its contraction, reference layers/keras/interaction.py:276-286) - like BN_EPI, what the epilogue reads at the
 // lane's 16 output positions is requested before the k loop.
-template <bool A_KC, bool B_KC, bool BN_EPI = false, int XEPI = 0>
+// DIN: 1 = the A operand is DinGen's generated block (forward NN, weight gradient TN); 2 = the input-gradient contraction
+// (NT) with permuted B rows and the epilogue that reduces dcat to dh / dq partials (nothing is stored to C).
+template <bool A_KC, bool B_KC, bool BN_EPI = false, int XEPI = 0, int DIN = 0>
 __device__ __forceinline__ void gemm_f32_block(const GemmArgs& g, int bx, int bz, float* __restrict__ lds,
-                                               bool plain_tiles = false, const er_gemm_epilogue* xe = nullptr) {
+                                               bool plain_tiles = false, const er_gemm_epilogue* xe = nullptr,
+                                               const DinGen* dg = nullptr) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -381,18 +465,22 @@ __device__ __forceinline__ void gemm_f32_block(const GemmArgs& g, int bx, int bz
     }
   };
 
-  if (a_vec && b_vec) {
+  if (DIN || (a_vec && b_vec)) {  // (the DIN variants are launched on aligned operands only: host check)
     f32x4v ra0[2], rb0[2], ra1[2], rb1[2];
+    f32x4v rq0[2], rq1[2];  // (DIN == 1: the q pieces of the generated A units; ra holds the h pieces until staging)
     // k-tile indices past the end are clamped to the last tile: the loop body has the same loads every
     // iteration (the compiler can then wait for exactly the older register set), the duplicate tile is never used
-    auto fetch = [&](f32x4v (&ra)[2], f32x4v (&rb)[2], int t) {
+    auto fetch = [&](f32x4v (&ra)[2], f32x4v (&rb)[2], f32x4v (&rq)[2], int t) {
       const int k0 = kbeg + (t < T ? t : T - 1) * BK32;
-      fetch_tile<A_KC>(g.A, g.lda, m0, g.M, k0, kend, g.K, tid, ra);
-      fetch_tile<B_KC>(g.B, g.ldb, n0, g.N, k0, kend, g.K, tid, rb);
+      if (DIN == 1) fetch_din<A_KC>(*dg, m0, g.M, k0, kend, g.K, tid, ra, rq);
+      else fetch_tile<A_KC>(g.A, g.lda, m0, g.M, k0, kend, g.K, tid, ra);
+      if (DIN == 2) fetch_tile_din_perm(g.B, g.ldb, tx, dg->E, k0, kend, g.K, tid, rb);
+      else fetch_tile<B_KC>(g.B, g.ldb, n0, g.N, k0, kend, g.K, tid, rb);
     };
-    auto stage = [&](int buf, const f32x4v (&ra)[2], const f32x4v (&rb)[2], int t) {
+    auto stage = [&](int buf, f32x4v (&ra)[2], const f32x4v (&rb)[2], const f32x4v (&rq)[2], int t) {
       const int k0 = kbeg + t * BK32;  // unclamped: a tile past the end is masked to zero
       const bool interior = rows_full && (k0 + BK32 <= kend);
+      if (DIN == 1) combine_din<A_KC>(*dg, m0, g.M, kbeg + (t < T ? t : T - 1) * BK32, g.K, tid, ra, rq);
       stage_tile<A_KC>(lds + buf * 2 * kOpTile, tid, ra, interior, m0, g.M, k0, kend);
       stage_tile<B_KC>(lds + buf * 2 * kOpTile + kOpTile, tid, rb, interior, n0, g.N, k0, kend);
     };
@@ -409,9 +497,10 @@ __device__ __forceinline__ void gemm_f32_block(const GemmArgs& g, int bx, int bz
     // Fragments are read a quarter of the k-tile at a time, right before their four MFMAs, and the compiler places the
     // instructions (no scheduling fences): against "every fragment first, fences around the MFMA groups" the bare core
     // (tools/micro/gemm_core.hip, variants 9 -> 1) gains 10 % on 8192 x 1152 x 256, 7 % on 8192 x 256 x 1152.
-    auto step = [&](int buf, f32x4v (&fa_)[2], f32x4v (&fb_)[2], f32x4v (&sa)[2], f32x4v (&sb)[2], int t) {
+    auto step = [&](int buf, f32x4v (&fa_)[2], f32x4v (&fb_)[2], f32x4v (&fq_)[2], f32x4v (&sa)[2], f32x4v (&sb)[2],
+                    f32x4v (&sq)[2], int t) {
       const float* base = lds + buf * 2 * kOpTile;
-      fetch(fa_, fb_, t + 2);
+      fetch(fa_, fb_, fq_, t + 2);
 #pragma unroll
       for (int q = 0; q < 3; ++q) {
         const f32x4v a = *reinterpret_cast<const f32x4v*>(base + fa + 4 * q);
@@ -419,7 +508,7 @@ __device__ __forceinline__ void gemm_f32_block(const GemmArgs& g, int bx, int bz
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[i], acc, 0, 0, 0);
       }
-      stage(buf ^ 1, sa, sb, t + 1);
+      stage(buf ^ 1, sa, sb, sq, t + 1);
       {
         const f32x4v a = *reinterpret_cast<const f32x4v*>(base + fa + 12);
         const f32x4v b = *reinterpret_cast<const f32x4v*>(base + fb + 12);
@@ -428,13 +517,13 @@ __device__ __forceinline__ void gemm_f32_block(const GemmArgs& g, int bx, int bz
       }
       __syncthreads();
     };
-    fetch(ra0, rb0, 0);
-    fetch(ra1, rb1, 1);
-    stage(0, ra0, rb0, 0);
+    fetch(ra0, rb0, rq0, 0);
+    fetch(ra1, rb1, rq1, 1);
+    stage(0, ra0, rb0, rq0, 0);
     __syncthreads();
     for (int t = 0; t < T; t += 2) {
-      step(0, ra0, rb0, ra1, rb1, t);
-      step(1, ra1, rb1, ra0, rb0, t + 1);
+      step(0, ra0, rb0, rq0, ra1, rb1, rq1, t);
+      step(1, ra1, rb1, rq1, ra0, rb0, rq0, t + 1);
     }
   } else {
     // unaligned operands (e.g. lda = 81): masked scalar loads, one k-tile at a time
@@ -460,6 +549,53 @@ __device__ __forceinline__ void gemm_f32_block(const GemmArgs& g, int bx, int bz
                    g.col_stats + static_cast<int64_t>(ty) * g.N * 3);
   if (BN_EPI && g.bn.partial != nullptr)
     tile_bn_bwd_partial(acc, g.bn, py, pz, m0 + wm * 32, g.M, col < g.N ? col - g.bn.col0 : -1, g.bn.n_src, wm, wn, lane, lds, ty);
+  if (DIN == 2) {
+    // dcat tile (64 rows x [seg0 | seg1 | seg2 | seg3] of 16 embedding positions) -> LDS -> dh and the dq partials
+    const DinGen& d = *dg;
+    constexpr int kD = 65;
+    float* D = lds;                 // [64][65]
+    float* Es = lds + 64 * kD;      // [64][16]
+    __syncthreads();                // LDS operand tiles are dead
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int rl = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+      D[rl * kD + wn * 32 + (lane & 31)] = acc[r];
+    }
+    __syncthreads();
+    const int j = tid & 15, rg = tid >> 4;
+    const int J = tx * 16 + j;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rl = rg * 4 + i;
+      const int row = m0 + rl;
+      float e = 0.f;
+      if (row < g.M) {
+        const int b = din_div_L(d, row);
+        const float qv = d.q[static_cast<int64_t>(b) * d.ldq + J];
+        const float hv = d.h[static_cast<int64_t>(row) * d.ldh + J];
+        const float d0 = D[rl * kD + j], d1 = D[rl * kD + 16 + j], d2 = D[rl * kD + 32 + j], d3 = D[rl * kD + 48 + j];
+        const float gh = (d1 - d2) + qv * d3;
+        float* p = d.dh + static_cast<int64_t>(row) * d.lddh + J;
+        *p = d.accumulate_dh ? *p + gh : gh;
+        e = (d0 + d2) + hv * d3;
+      }
+      Es[rl * 16 + j] = e;
+    }
+    __syncthreads();
+    const int b0 = din_div_L(d, m0);
+    for (int u = tid; u < d.slots * 16; u += kBlock) {
+      const int slot = u >> 4, jj = u & 15;
+      const int b = b0 + slot;
+      int lo = b * d.L, hi = lo + d.L;
+      lo = lo > m0 ? lo : m0;
+      hi = hi < m0 + BM ? hi : m0 + BM;
+      hi = hi < g.M ? hi : g.M;
+      float sum = 0.f;
+      for (int row = lo; row < hi; ++row) sum = sum + Es[(row - m0) * 16 + jj];
+      d.dq_partial[(static_cast<int64_t>(ty) * d.slots + slot) * d.E + tx * 16 + jj] = sum;
+    }
+    return;
+  }
   if (XEPI == ER_EPI_CROSS_FWD) {
     // x_{l+1} = x0 * (acc + b + diag * x_l) + x_l, in cross_v2_fwd_kernel's order; u keeps acc
     if (col >= g.N) return;

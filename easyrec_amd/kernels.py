@@ -1677,6 +1677,61 @@ class HipBackend(object):
         'er_din_concat_bwd')
     return dq, dh
 
+  # DIN's first attention layer on the GENERATED [q, h, q - h, q * h] operand (er_din_gemm_*): the [B, L, 4E] block exists
+  # neither forward nor backward.  A/B switch: '0' = er_din_concat + the ordinary contractions.
+  din_fused = os.environ.get('EASYREC_AMD_DIN_FUSED', '1') != '0'
+
+  @staticmethod
+  def din_gemm_ok(q, h, w):
+    """q [B, E], h [B, L, E] contiguous fp32, w [4E, N]: shapes er_din_gemm_* take (E % 16 == 0, 16-byte aligned rows)."""
+    if h.dim() != 3 or q.dim() != 2:
+      return False
+    B, L, E = h.shape
+    return (E % 16 == 0 and L >= 2 and q.shape == (B, E) and q.is_contiguous() and h.is_contiguous() and w.shape[0] == 4 * E and
+            w.stride(1) == 1 and w.stride(0) % 4 == 0 and q.data_ptr() % 16 == 0 and h.data_ptr() % 16 == 0 and
+            w.data_ptr() % 16 == 0 and B * L * L < 2 ** 32)
+
+  def din_gemm_fwd(self, q, h, w, bias, col_stats=None):
+    """z [B * L, N] = [q, h, q - h, q * h] . w (+ bias) without building the block; col_stats as gemm()'s."""
+    B, L, E = h.shape
+    N = w.shape[1]
+    z = torch.empty(B * L, N, dtype=torch.float32, device=h.device)
+    self._log_gemm('gemm_f32_din_kernel<true, false, 1>', None, B * L, N, 4 * E)
+    self._ck(self.lib.er_din_gemm_fwd(_p(q), ctypes.c_int32(q.stride(0)), _p(h), ctypes.c_int32(E), B, L, E, _p(w),
+                                      ctypes.c_int32(w.stride(0)), N, _p(bias), _p(z), ctypes.c_int32(N), _p(col_stats),
+                                      _stream()), 'er_din_gemm_fwd')
+    return z
+
+  def din_gemm_wgrad(self, q, h, dz, out, accumulate=True):
+    """out [4E, N] (+)= [q, h, q - h, q * h]^T . dz"""
+    B, L, E = h.shape
+    N = dz.shape[1]
+    assert dz.shape[0] == B * L and dz.stride(1) == 1 and out.shape == (4 * E, N) and out.stride(1) == 1
+    self._log_gemm('gemm_f32_din_kernel<false, false, 1>', None, 4 * E, N, B * L)
+    self._ck(self.lib.er_din_gemm_wgrad(_p(q), ctypes.c_int32(q.stride(0)), _p(h), ctypes.c_int32(E), B, L, E, _p(dz),
+                                        ctypes.c_int32(dz.stride(0)), N, _p(out), ctypes.c_int32(out.stride(0)),
+                                        int(bool(accumulate)), _stream()), 'er_din_gemm_wgrad')
+    return out
+
+  def din_gemm_dgrad(self, dz, w, q, h, dh=None, acc_h=False):
+    """(dq [B, E], dh [B, L, E]) from dz [B * L, N] and w [4E, N] without building dcat = dz . w^T; dh given: the history's
+    gradient buffer of the step (kernels.grad_slot), acc_h: add into it."""
+    B, L, E = h.shape
+    N = dz.shape[1]
+    dq = torch.empty(B, E, dtype=torch.float32, device=h.device)
+    if dh is None:
+      assert not acc_h
+      dh = torch.empty_like(h)
+    assert dh.shape == h.shape and dh.is_contiguous()
+    self.lib.er_din_dq_partial_floats.restype = ctypes.c_int64
+    n_part = int(self.lib.er_din_dq_partial_floats(B, L, E))
+    partial = torch.empty(n_part, dtype=torch.float32, device=h.device)
+    self._log_gemm('gemm_f32_din_kernel<true, true, 2>', None, B * L, 4 * E, N)
+    self._ck(self.lib.er_din_gemm_dgrad(_p(dz), ctypes.c_int32(dz.stride(0)), N, _p(w), ctypes.c_int32(w.stride(0)), _p(q),
+                                        ctypes.c_int32(q.stride(0)), _p(h), ctypes.c_int32(E), B, L, E, _p(dq), ctypes.c_int32(E),
+                                        _p(dh), ctypes.c_int32(E), int(bool(acc_h)), _p(partial), _stream()), 'er_din_gemm_dgrad')
+    return dq, dh
+
   def din_pool_fwd(self, scores, hist, seq_len, scale=1.0):
     B, L, E = hist.shape
     probs = torch.empty(B, L, dtype=torch.float32, device=hist.device)
@@ -3253,6 +3308,61 @@ class DINConcatFn(torch.autograd.Function):
     buf, acc, first = grad_slot(ctx.slots, h)
     dq, _ = hip().din_concat_bwd(q.contiguous(), h, dout.contiguous(), dh=buf, acc_h=acc)
     return dq, (buf if first else None)
+
+
+class DINFirstLayerFn(torch.autograd.Function):
+  """dense (+ bias) -> BatchNorm(train) -> activation over DIN's attention input [q, h, q - h, q * h] ([B, L, 4E], reference
+  model/multi_tower_din.py:62-80 feeding layers/dnn.py:57-79) WITHOUT building it, forward or backward: the contraction
+  generates the block from (q, h) while staging (er_din_gemm_fwd), the weight gradient likewise (er_din_gemm_wgrad), and the
+  input-gradient contraction reduces the block's gradient to dq / dh in its epilogue (er_din_gemm_dgrad).  Same variables
+  and arithmetic as LinearBNActFn over DINConcatFn's output; the history's gradient lands in its gradient slot."""
+
+  @staticmethod
+  def forward(ctx, q, h, w, b, gamma, beta, moving_mean, moving_var, eps, momentum, act, grad_bufs):
+    be = hip()
+    B, L, E = h.shape
+    N = w.shape[1]
+    chunks = be.gemm_row_tiles(B * L)
+    stats = torch.empty(chunks * N * 3, dtype=torch.float32, device=h.device)
+    z = be.din_gemm_fwd(q, h, w, b, col_stats=stats)
+    y, mean, invstd = be.bn_apply_from_stats(z, None, stats, chunks, gamma, beta, eps, momentum, moving_mean, moving_var, act)
+    ctx.save_for_backward(q, h, w, gamma, beta, z, y, mean, invstd)
+    ctx.act, ctx.grad_bufs = act, grad_bufs
+    ctx.slots = grad_slots_of_step()
+    fused = getattr(be, 'fused_bn_bwd', False)
+    gb = None if grad_bufs is None else (grad_bufs[1], grad_bufs[2])
+    ctx.own = BnSource(z, None, y, mean, invstd, act, gamma, gb, beta=beta, fused=fused) if fused else None
+    _bn_tls.last = ctx.own
+    return y
+
+  @staticmethod
+  def backward(ctx, dy):
+    be = hip()
+    q, h, w, gamma, beta, z, y, mean, invstd = ctx.saved_tensors
+    wg, gg, betag = ctx.grad_bufs if ctx.grad_bufs is not None else (None, None, None)
+    direct = gg is not None and betag is not None
+    dyc = dy if (dy.dim() == 2 and dy.stride(1) == 1) else dy.contiguous()
+    own, partial = ctx.own, None
+    if own is not None:
+      if own.partial is not None and dyc.data_ptr() == own.dx_ptr:
+        partial = own.partial
+      own.partial = None
+    dz, _, dgamma, dbeta = be.bn_act_bwd(z, None, gamma, y, mean, invstd, dyc, 1, ctx.act, False, True,
+                                         into=(None, gg, betag) if direct else None, partial=partial, beta=beta)
+    dq = dh = dw = None
+    if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+      if ctx.slots is not None:
+        buf, acc, first = grad_slot(ctx.slots, h)
+        dq, _ = be.din_gemm_dgrad(dz, w, q, h, dh=buf, acc_h=acc)
+        dh = buf if first else None
+      else:
+        dq, dh = be.din_gemm_dgrad(dz, w, q, h)
+    if ctx.needs_input_grad[2]:
+      if wg is not None:
+        be.din_gemm_wgrad(q, h, dz, wg, accumulate=True)
+      else:
+        dw = be.din_gemm_wgrad(q, h, dz, torch.empty_like(w), accumulate=False)
+    return dq, dh, dw, None, dgamma, dbeta, None, None, None, None, None, None
 
 
 class DINPoolFn(torch.autograd.Function):

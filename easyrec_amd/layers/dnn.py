@@ -93,6 +93,47 @@ def dense_bn_act(x, units, name, l2_reg, use_bias, use_bn, act_relu, training, b
   return y.reshape(shape[:-1] + (units,))
 
 
+def din_first_layer(q, hist, units, name, l2_reg, act_relu, training):
+  """dense + BatchNorm(train) + activation over DIN's attention input [q, h, q - h, q * h] ([B, L, 4E]) WITHOUT building it
+  (kernels.DINFirstLayerFn; reference model/multi_tower_din.py:62-80, layers/dnn.py:57-79; the same variables: <name>/kernel
+  [4E, units], /bias, /bn).  -> [B * L, units]."""
+  ctx = context.current()
+  vs = ctx.varstore
+  B, L, E = hist.shape
+  w = vs.get_variable(name + '/kernel', (4 * E, units), 'glorot_uniform', l2=l2_reg or 0.0)
+  b = vs.get_variable(name + '/bias', (units,), 'zeros')
+  bn = name + '/bn'
+  gamma = vs.get_variable(bn + '/gamma', (units,), 'ones')
+  beta = vs.get_variable(bn + '/beta', (units,), 'zeros')
+  mm = vs.get_variable(bn + '/moving_mean', (units,), 'zeros', trainable=False)
+  mv = vs.get_variable(bn + '/moving_variance', (units,), 'ones', trainable=False)
+  freeze = ctx.building and training
+  bufs = (w.grad, gamma.grad, beta.grad) if (w.grad is not None and gamma.grad is not None and beta.grad is not None) else None
+  act = kernels.ACT_RELU if act_relu else kernels.ACT_NONE
+  y = kernels.DINFirstLayerFn.apply(q, hist, w, b, gamma, beta, None if freeze else mm, None if freeze else mv, BN_EPSILON,
+                                    BN_MOMENTUM, act, bufs)
+  src = kernels.take_last_bn_source()
+  return kernels.tag_bn_source(y, src) if src is not None else y
+
+
+def din_first_layer_ok(din_layer, q, hist):
+  """May the attention DNN's first layer take (q, history) instead of the built [q, h, q - h, q * h] input?  A training step
+  in fp32 whose first layer is dense -> BatchNorm -> ReLU (or no activation), no dropout, on shapes er_din_gemm_* take."""
+  ctx = context.current()
+  be = kernels.hip()
+  n = len(din_layer.hidden_units)
+  if not (getattr(be, 'din_fused', False) and din_layer._is_training and torch.is_grad_enabled() and ctx.is_training and
+          not ctx.building and getattr(ctx, 'dense_dtype', 'f32') == 'f32' and n > 1 and din_layer.hidden_units[0] > 0 and
+          din_layer._config.use_bn and (is_relu(din_layer._act_string) or din_layer.activation is None) and
+          not (len(din_layer.dropout_ratio) > 0 and din_layer.dropout_ratio[0] > 0)):
+    return False
+  vs = ctx.varstore
+  E = hist.shape[-1]
+  w = vs.get_variable('%s/dnn_0/kernel' % din_layer._name, (4 * E, din_layer.hidden_units[0]), 'glorot_uniform',
+                      l2=din_layer._l2_reg or 0.0)
+  return w.grad is not None and be.din_gemm_ok(q, hist, w)
+
+
 def _grad_bufs(b, gamma, beta):
   """(bias.grad, gamma.grad, beta.grad) when the variables are packed into the flat gradient buffer."""
   bufs = tuple(None if t is None else t.grad for t in (b, gamma, beta))
@@ -269,13 +310,19 @@ class DNN(object):
   def dropout_ratio(self):
     return self._config.dropout_ratio
 
-  def __call__(self, deep_fea, hidden_layer_feature_output=False):
+  def __call__(self, deep_fea, hidden_layer_feature_output=False, din=None):
+    """din = (query [B, E], history [B, L, E]): the input is DIN's [q, h, q - h, q * h] ([B, L, 4E]), never built - the first
+    layer generates it inside its contractions (din_first_layer; the caller checked din_first_layer_ok); deep_fea is
+    ignored."""
     hidden_units_len = len(self.hidden_units)
     if hidden_units_len == 1 and self.hidden_units[0] == 0:
       return deep_fea
     hidden_feature_dict = {}
     lead_shape = None
-    if deep_fea.dim() > 2 and not hidden_layer_feature_output:
+    if din is not None:
+      assert not hidden_layer_feature_output
+      lead_shape = din[1].shape[:-1]
+    if din is None and deep_fea.dim() > 2 and not hidden_layer_feature_output:
       # [B, L, d] inputs (DIN's attention MLP): the whole stack runs on the flattened [B * L, d] view - BatchNorm
       # normalises over every axis but the last either way
       lead_shape = deep_fea.shape[:-1]
@@ -285,7 +332,10 @@ class DNN(object):
       use_bn = self._config.use_bn and ((i + 1 < hidden_units_len) or not self._last_layer_no_batch_norm)
       use_act = (i + 1 < hidden_units_len) or not self._last_layer_no_activation
       fuse_relu = use_act and is_relu(self._act_string)
-      deep_fea = dense_bn_act(deep_fea, unit, layer, self._l2_reg, True, use_bn, fuse_relu, self._is_training)
+      if i == 0 and din is not None:
+        deep_fea = din_first_layer(din[0], din[1], unit, layer, self._l2_reg, fuse_relu, self._is_training)
+      else:
+        deep_fea = dense_bn_act(deep_fea, unit, layer, self._l2_reg, True, use_bn, fuse_relu, self._is_training)
       if use_act and not fuse_relu and self.activation is not None:
         deep_fea = self.activation(deep_fea, name='%s/dnn_%d/act' % (self._name, i))
       if len(self.dropout_ratio) > 0 and self._is_training:

@@ -37,10 +37,14 @@ def target_attention(dnn_config, deep_fea, name, l2_reg, is_training, need_key_f
   hist = kernels.slot_gate(hist)  # (DINConcatFn and DINPoolFn share the history's gradient buffer)
   din_layer = dnn.DNN(dnn_config, l2_reg, name, is_training, last_layer_no_activation=True,
                       last_layer_no_batch_norm=True)
-  # (the first attention layer folded over (q, h) - linear in [q, h, q - h, q * h], so the [B, L, 4E] input need not be
-  # built - was measured slower in round 4 and removed in round 5: profiles/r04_din_folded_first_layer_ab.txt)
-  din_net = kernels.DINConcatFn.apply(cur_id, hist)  # [B, L, 4E]
-  scores = din_layer(din_net).reshape(B, L)
+  if dnn.din_first_layer_ok(din_layer, cur_id, hist):
+    # the [B, L, 4E] attention input is never built: the first layer's contractions generate [q, h, q - h, q * h] from
+    # (q, h) while staging and reduce its gradient to dq / dh in their epilogue (kernels.DINFirstLayerFn, round 6; the
+    # ALGEBRAIC fold of round 4 - a different thing - was measured slower and removed: profiles/r04_din_folded_first_layer_ab.txt)
+    scores = din_layer(None, din=(cur_id, hist)).reshape(B, L)
+  else:
+    din_net = kernels.DINConcatFn.apply(cur_id, hist)  # [B, L, 4E]
+    scores = din_layer(din_net).reshape(B, L)
   pooled = kernels.DINPoolFn.apply(scores, hist, seq_len, 1.0)  # softmax over where(t < len, score, -2^32 + 1)
   if not need_key_feature:
     return pooled

@@ -1006,6 +1006,25 @@ int er_gemm_bf16_nt_epi(int32_t M, int32_t N, int32_t K, const uint16_t* A, int3
 int er_gemm_f32_cross(int layout, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B, int32_t ldb,
                       float* C, int32_t ldc, const float* bias, int accumulate, const er_gemm_epilogue* epi,
                       er_stream_t stream);
+/* DIN's first attention layer WITHOUT the [B, L, 4E] block (north_star: "DIN-attention as fused HIP kernels"; reference
+ * model/multi_tower_din.py:62-80 builds tf.concat([q, h, q - h, q * h], axis=-1) and feeds it to the attention DNN,
+ * layers/dnn.py:57-79): the three contractions of the layer take q [B][ldq] and h [B * L][ldh] (E columns each) and form
+ * the 4E concat columns while staging (forward, weight gradient), or reduce the gradient of the block to dh and dq in
+ * the epilogue (input gradient) - the block exists neither forward nor backward.  fp32 MFMA, 16-byte aligned rows, E % 4 == 0.
+ *   er_din_gemm_fwd    z [B * L][N] = [q, h, q - h, q * h] . W [4E][N] (+ bias); col_stats as er_gemm_f32's
+ *   er_din_gemm_wgrad  dW [4E][N] (+)= [q, h, q - h, q * h]^T . dz [B * L][N]   (k-splits of <= 2048 rows + fixed-order reduce)
+ *   er_din_gemm_dgrad  with dcat = dz . W^T ([B * L][4E], never stored; W's rows visited in an order that puts the four
+ *                      segments of 16 embedding positions into one 64-column tile, E % 16 == 0):
+ *                      dh [B * L][E] (+)= dcat1 - dcat2 + q * dcat3;  dq [B][E] = sum_l (dcat0 + dcat2 + h * dcat3), summed
+ *                      per 64-row tile into dq_partial (er_din_dq_partial_floats(B, L, E) floats) and finished in tile order. */
+int er_din_gemm_fwd(const float* q, int32_t ldq, const float* h, int32_t ldh, int32_t B, int32_t L, int32_t E, const float* W,
+                    int32_t ldw, int32_t N, const float* bias, float* z, int32_t ldz, float* col_stats, er_stream_t stream);
+int er_din_gemm_wgrad(const float* q, int32_t ldq, const float* h, int32_t ldh, int32_t B, int32_t L, int32_t E, const float* dz,
+                      int32_t lddz, int32_t N, float* dW, int32_t lddw, int accumulate, er_stream_t stream);
+int64_t er_din_dq_partial_floats(int32_t B, int32_t L, int32_t E);
+int er_din_gemm_dgrad(const float* dz, int32_t lddz, int32_t N, const float* W, int32_t ldw, const float* q, int32_t ldq,
+                      const float* h, int32_t ldh, int32_t B, int32_t L, int32_t E, float* dq, int32_t lddq, float* dh,
+                      int32_t lddh, int accumulate_dh, float* dq_partial, er_stream_t stream);
 /* dst[j] (+)= sum_p partial[p * ld + j] for up to 16 jobs in ONE launch (er_tail_job records, HOST array): the bias
  * gradients of a stack of cross layers from the per-tile column sums their fused backward left. */
 int er_colsum_partials_multi(const er_tail_job* jobs_host, int32_t n_jobs, int accumulate, er_stream_t stream);

@@ -912,6 +912,26 @@ class RefBackend(object):
     return dout * t, dx, dout * x0
 
   # -- DIN
+  # the first attention layer on the generated operand (kernels.DINFirstLayerFn): same results through the built block
+  din_fused = True
+
+  @staticmethod
+  def din_gemm_ok(q, h, w):
+    return h.dim() == 3 and q.dim() == 2 and h.shape[-1] % 16 == 0 and h.shape[1] >= 2
+
+  def din_gemm_fwd(self, q, h, w, bias, col_stats=None):
+    B, L, E = h.shape
+    return self.gemm(0, self.din_concat_fwd(q, h).reshape(B * L, 4 * E), w, bias=bias)
+
+  def din_gemm_wgrad(self, q, h, dz, out, accumulate=True):
+    B, L, E = h.shape
+    return self.gemm(2, self.din_concat_fwd(q, h).reshape(B * L, 4 * E), dz, out=out, accumulate=accumulate)
+
+  def din_gemm_dgrad(self, dz, w, q, h, dh=None, acc_h=False):
+    B, L, E = h.shape
+    dcat = self.gemm(1, dz, w).reshape(B, L, 4 * E)
+    return self.din_concat_bwd(q, h, dcat, dh=dh, acc_h=acc_h)
+
   def din_concat_fwd(self, q, h):
     B, L, E = h.shape
     qq = q[:, None, :].expand(B, L, E)

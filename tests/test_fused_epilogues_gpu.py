@@ -310,3 +310,72 @@ def test_dcn_v2_step_fused_cross_equals_the_separate_launches(hip, dtype, monkey
   assert abs(f1 - f0) <= ltol * abs(f0), (f1, f0)
   assert float((m1 - m0).abs().max()) <= mtol * float(m0.abs().max()), float((m1 - m0).abs().max())
   assert abs(s1 - s0) <= stol * abs(s0), (s1, s0)
+
+
+@pytest.mark.parametrize('B,L,E,N', [(4096, 50, 32, 128), (64, 12, 32, 128), (37, 7, 16, 72), (5, 3, 48, 64), (130, 50, 32, 36)])
+def test_din_first_layer_contractions_generate_the_attention_input(hip, B, L, E, N):
+  """er_din_gemm_fwd / _wgrad / _dgrad against the ordinary contractions over the BUILT [q, h, q - h, q * h] block
+  (er_din_concat_fwd / _bwd around er_gemm_f32; reference model/multi_tower_din.py:62-80).  Forward: the same kernel body
+  over the same operand values in the same k order -> bit-identical z and column statistics.  Weight gradient: another
+  k-split, 2e-5 of the gradient's scale.  Input gradient: dh elementwise from the same accumulators (2e-6), dq summed per
+  tile then per example instead of by one wave per example (2e-5)."""
+  g = torch.Generator().manual_seed(B + L + E + N)
+  q = torch.randn(B, E, generator=g).to(DEV)
+  h = torch.randn(B, L, E, generator=g).to(DEV)
+  w = (torch.randn(4 * E, N, generator=g) * 0.1).to(DEV)
+  b = torch.randn(N, generator=g).to(DEV)
+  cat = hip.din_concat_fwd(q, h).reshape(B * L, 4 * E)
+  T = hip.gemm_row_tiles(B * L)
+  st_ref = torch.empty(T * N * 3, device=DEV)
+  z_ref = hip.gemm(kernels.GEMM_NN, cat, w, bias=b, col_stats=st_ref)
+  st = torch.full((T * N * 3,), float('nan'), device=DEV)
+  z = hip.din_gemm_fwd(q, h, w, b, col_stats=st)
+  torch.cuda.synchronize()
+  assert torch.equal(z, z_ref) and torch.equal(st, st_ref)
+  dz = (torch.randn(B * L, N, generator=g) * 0.1).to(DEV)
+  dw_ref = hip.gemm(kernels.GEMM_TN, cat, dz)
+  base = torch.randn(4 * E, N, generator=g).to(DEV)
+  dw = base.clone()
+  hip.din_gemm_wgrad(q, h, dz, dw, accumulate=True)
+  torch.cuda.synchronize()
+  scale = float(dw_ref.abs().max())
+  assert float((dw - base - dw_ref).abs().max()) <= 2e-5 * scale
+  dcat = hip.gemm(kernels.GEMM_NT, dz, w).reshape(B, L, 4 * E)
+  dq_ref, dh_ref = hip.din_concat_bwd(q, h, dcat)
+  hbase = torch.randn(B, L, E, generator=g).to(DEV)
+  dh = hbase.clone()
+  dq, _ = hip.din_gemm_dgrad(dz, w, q, h, dh=dh, acc_h=True)
+  dq2, dh2 = hip.din_gemm_dgrad(dz, w, q, h)
+  torch.cuda.synchronize()
+  assert float((dh2 - dh_ref).abs().max()) <= 2e-6 * float(dh_ref.abs().max())
+  assert float((dh - hbase - dh_ref).abs().max()) <= 1e-5 * float(dh_ref.abs().max())
+  assert torch.equal(dq, dq2)
+  assert float((dq - dq_ref).abs().max()) <= 2e-5 * float(dq_ref.abs().max())
+
+
+def test_din_step_with_the_generated_attention_input_equals_the_built_one(hip, monkeypatch):
+  """MultiTowerDIN (configs/din_taobao_small.config) with the first attention layer on the generated operand and with the
+  built [B, L, 4E] block: the first step's loss is identical (bit-identical forward), the first Adam moments within 2e-5 of
+  the largest, the second step's loss within 1e-4."""
+  import os
+  from easyrec_amd.input.synthetic import SyntheticBatches
+  from easyrec_amd.model.easy_rec_estimator import EasyRecEstimator
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  cfg = os.path.join(root, 'configs', 'din_taobao_small.config')
+
+  def run(fused):
+    monkeypatch.setattr(kernels.HipBackend, 'din_fused', fused)
+    est = EasyRecEstimator(cfg, device=DEV, batch_size=256, seed=3).build()
+    gen = SyntheticBatches(est.pipeline_config.data_config, est.feature_configs, batch_size=256, seed=11)
+    n0 = len([1 for _ in ()])
+    first = float(est.train_step(gen.next_batch())['total_loss'])
+    torch.cuda.synchronize()
+    m = est.varstore.slots['m'].clone()
+    second = float(est.train_step(gen.next_batch())['total_loss'])
+    return first, second, m
+
+  f1, s1, m1 = run(True)
+  f0, s0, m0 = run(False)
+  assert f1 == f0, (f1, f0)
+  assert float((m1 - m0).abs().max()) <= 2e-5 * float(m0.abs().max()), float((m1 - m0).abs().max())
+  assert abs(s1 - s0) <= 1e-4 * abs(s0), (s1, s0)
