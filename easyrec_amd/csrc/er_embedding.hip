@@ -1714,6 +1714,38 @@ emb_bwd_tile_multi_kernel(RunMulti ma) {
                  a.tile_first, a.tile_last);
 }
 
+__device__ __forceinline__ void tile_multi_block(int b, const RunMulti& ma, float* smem) {
+  int i = 0;
+  while (i + 1 < ma.n && b >= ma.start[i + 1]) ++i;
+  const RunArgs& a = ma.a[i];
+  const int bid = b - ma.start[i];
+  if (a.V == 4)
+    tile_body<4>(bid, smem, a.skeys, a.svals, a.ent_gptr, a.ent_scale, a.n, a.dim, a.G, a.tab, ma.opt_kind, ma.hyper, a.ro,
+                 a.tile_first, a.tile_last);
+  else
+    tile_body<1>(bid, smem, a.skeys, a.svals, a.ent_gptr, a.ent_scale, a.n, a.dim, a.G, a.tab, ma.opt_kind, ma.hyper, a.ro,
+                 a.tile_first, a.tile_last);
+}
+
+// The embedding-parallel requester's tail of the compute segment in ONE grid (er_emb_reduce_local_tail): the step's weight
+// gradients (grouped TN contraction, workgroups [0, n_gemm)), the local gradient reductions of every table group - the
+// replicated groups' dense row sums and the sharded groups' per-(owner, id) sums, emb_bwd_tile_multi_kernel's bodies - behind
+// them, and the scalar loss tail as one more workgroup: the arrangement of the single-GPU step's fused tail
+// (emb_bwd_own_wgrad_kernel) for the step that the 1/2/4/8-GPU metric runs.  Same bodies, same bits as the launches apart.
+__global__ void __launch_bounds__(kBlock)
+emb_reduce_local_wgrad_kernel(RunMulti ma, GroupedArgs ga, int n_gemm, int n_tile, LossTailArgs lt) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int bid = blockIdx.x;
+  if (bid < n_gemm) {
+    const GroupedCoords c = grouped_coords(ga, bid);
+    if (c.split < 0) return;
+    gemm_f32_block<false, false>(ga.p[c.p], c.tile, c.split, smem, c.plain);
+    return;
+  }
+  if (bid - n_gemm < n_tile) tile_multi_block(bid - n_gemm, ma, smem);
+  else loss_tail_body<kBlock>(lt, smem);
+}
+
 __device__ __forceinline__ void fix_block(int b, const RunMulti& ma) {
   int i = 0;
   while (i + 1 < ma.n && b >= ma.start[i + 1]) ++i;
@@ -4545,6 +4577,92 @@ int er_emb_route(er_emb_group* g, uint32_t* unique_keys, int32_t* n_unique, int6
     ER_LAUNCH_CHECK();
   }
   g->sorted_valid = true;
+  return 0;
+}
+
+int er_emb_reduce_local_tail(er_emb_group* const* groups, const int32_t* modes, float* const* outs, const int32_t* ld, int n,
+                             const er_gemm_problem* wgrads, int n_wgrads, int32_t wgrad_blocks,
+                             const er_loss_tail_job* loss_tail, er_stream_t stream) {
+  ER_REQUIRE(groups && modes && outs && ld && n >= 1 && n <= er::kMaxMulti, "er_emb_reduce_local_tail: bad arguments (1 <= n <= %d)",
+             er::kMaxMulti);
+  ER_REQUIRE(n_wgrads >= 0 && n_wgrads <= er::kMaxGroup && (n_wgrads == 0 || wgrads) && wgrad_blocks >= 0,
+             "er_emb_reduce_local_tail: 0 <= n_wgrads <= %d", er::kMaxGroup);
+  ER_REQUIRE(!loss_tail || n_wgrads > 0, "er_emb_reduce_local_tail: the loss tail rides with the weight gradients' grid");
+  hipStream_t s = er::as_stream(stream);
+  er::GroupedPlan plan;
+  plan.ra.n = 0;
+  if (n_wgrads > 0) {
+    for (int i = 0; i < n_wgrads; ++i)
+      ER_REQUIRE(!wgrads[i].col_stats && !wgrads[i].bn_partial, "er_emb_reduce_local_tail: problem %d: plain contractions only", i);
+    if (int rc = er::plan_grouped(ER_GEMM_TN, wgrads, n_wgrads, false, &plan, wgrad_blocks)) return rc;
+  }
+  er::LossTailArgs lt;
+  std::memset(&lt, 0, sizeof(lt));
+  if (loss_tail)
+    if (int rc = er::make_loss_tail_args(loss_tail, &lt)) return rc;
+  er::RunMulti ma;
+  ma.n = 0;
+  ma.start[0] = 0;
+  ma.opt_kind = ER_OPT_SGD;
+  ma.hyper = nullptr;
+  int fix_start[er::kMaxMulti + 1] = {0};
+  size_t lds = 0;
+  for (int i = 0; i < n; ++i) {
+    er_emb_group* g = groups[i];
+    ER_REQUIRE(g && outs[i] && (modes[i] == 1 || modes[i] == 2), "er_emb_reduce_local_tail: group %d: null argument or mode %d", i,
+               g ? modes[i] : -1);
+    if (modes[i] == 1) {  // sharded: this step's er_emb_route left the routed sort (er_emb_bwd_reduce_routed)
+      ER_REQUIRE(ld[i] == 0 || ld[i] >= g->dim, "er_emb_reduce_local_tail: group %d: ld < dim", i);
+      ER_REQUIRE(g->sorted_valid, "er_emb_reduce_local_tail: group %d: call er_emb_route for this step first", i);
+    } else {              // replicated: sort now unless a leader's sort is adopted (er_emb_bwd_reduce_dense)
+      ER_REQUIRE(ld[i] > g->dim, "er_emb_reduce_local_tail: group %d: dense buffer needs ld > dim", i);
+      if (!g->sorted_valid) {
+        bool adopted = false;
+        if (g->leader)
+          if (int rc = emb_group_adopt(g, s, &adopted)) return rc;
+        if (!adopted)
+          if (int rc = emb_group_sort(g, s)) return rc;
+      }
+      g->sorted_valid = false;
+    }
+    const int64_t N = group_entries(g);
+    if (N == 0) continue;
+    if (int rc = front_sort_guard(g, "er_emb_reduce_local_tail")) return rc;
+    const er_emb_group* src = g->src;
+    er::RunArgs& a = ma.a[ma.n];
+    a.skeys = src->keys_out; a.svals = src->vals_out; a.ent_gptr = g->ent_gptr; a.ent_scale = g->ent_scale;
+    a.n = N; a.dim = g->dim; a.G = g->G; a.V = g->V; a.T = g->tile_entries;
+    a.n_tiles = static_cast<int>(er::ceil_div(N, a.T));
+    a.tab = tab_of(g);
+    a.aux = er::DecayAux{};
+    a.ro = modes[i] == 2 ? er::ReduceOut{2, nullptr, nullptr, nullptr, outs[i], ld[i]}
+                         : er::ReduceOut{1, src->head_flags, src->head_index, nullptr, outs[i], ld[i]};
+    a.tile_first = g->tile_first; a.tile_last = g->tile_last;
+    ma.start[ma.n + 1] = ma.start[ma.n] + a.n_tiles;
+    const int fb = a.n_tiles > 1 ? static_cast<int>(er::ceil_div(static_cast<int64_t>(a.n_tiles) * g->G, er::kBlock)) : 0;
+    fix_start[ma.n + 1] = fix_start[ma.n] + fb;
+    const size_t need = sizeof(float) * static_cast<size_t>(a.T) * g->dim + sizeof(uint32_t) * (a.T + 2);
+    if (need > lds) lds = need;
+    ++ma.n;
+  }
+  const int n_tile = ma.n > 0 ? ma.start[ma.n] : 0;
+  const int n_fix = ma.n > 0 ? fix_start[ma.n] : 0;
+  if (n_wgrads > 0) {
+    const int n_gemm = er::grouped_grid(plan.ga);
+    const size_t gemm_lds = sizeof(float) * 2 * 2 * er::kOpTile;
+    hipLaunchKernelGGL(er::emb_reduce_local_wgrad_kernel, dim3(n_gemm + n_tile + (loss_tail ? 1 : 0)), dim3(er::kBlock),
+                       lds > gemm_lds ? lds : gemm_lds, s, ma, plan.ga, n_gemm, n_tile, lt);
+    ER_LAUNCH_CHECK();
+  } else if (n_tile > 0) {
+    hipLaunchKernelGGL(er::emb_bwd_tile_multi_kernel, dim3(n_tile), dim3(er::kBlock), lds, s, ma);
+    ER_LAUNCH_CHECK();
+  }
+  for (int i = 0; i <= ma.n; ++i) ma.start[i] = fix_start[i];
+  const int n_red = plan.ra.n > 0 ? plan.ra.start[plan.ra.n] : 0;
+  if (n_fix + n_red > 0) {
+    hipLaunchKernelGGL(er::emb_bwd_fix_reduce_kernel, dim3(n_fix + n_red), dim3(er::kBlock), 0, s, ma, plan.ra, n_fix);
+    ER_LAUNCH_CHECK();
+  }
   return 0;
 }
 

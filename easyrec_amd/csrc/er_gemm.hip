@@ -572,6 +572,7 @@ int din_gen(const char* who, const float* q, int32_t ldq, const float* h, int32_
   *d = er::DinGen();
   d->q = q; d->h = h; d->ldq = ldq; d->ldh = ldh; d->L = L; d->E = E;
   d->inv_L = static_cast<uint32_t>(((1ULL << 32) + L - 1) / L);
+  d->inv_E = static_cast<uint32_t>(((1ULL << 32) + E - 1) / E);
   if (L == 1) d->inv_L = 0xFFFFFFFFu;  // (2^32 does not fit: row * (2^32 - 1) >> 32 == row - 1 for row >= 1 - handled below)
   return 0;
 }
@@ -608,10 +609,18 @@ int er_din_gemm_wgrad(const float* q, int32_t ldq, const float* h, int32_t ldh, 
   a.A = nullptr; a.B = dz; a.bias = nullptr;
   a.M = 4 * E; a.N = N; a.K = B * L; a.lda = 4 * E; a.ldb = lddz; a.ldc = lddw;
   a.accumulate = accumulate; a.col_stats = nullptr;
-  // a batch-long contraction into a small output: k-splits of at most 2048 rows (er_gemm_grouped_f32's rule)
-  int64_t splits = er::ceil_div(a.K, 2048);
-  const int64_t max_by_k = a.K / (4 * er::BK32);
-  if (splits > 128) splits = 128;
+  // a batch-long contraction into a small output, alone in its launch: enough k-splits for ~4 workgroups per CU (the
+  // launch's 4 - 8 output tiles x 100 splits of 2048 rows - er_gemm_grouped_f32's rule - left 112 of 256 CUs with one
+  // workgroup and 144 with two: 92.7 us against ~55 us for the same problem inside a grouped launch)
+  static const int64_t din_wgrad_blocks = [] {  // (A/B knob)
+    const char* e = getenv("ER_DIN_WGRAD_BLOCKS");
+    const int64_t v = e ? atoll(e) : 0;
+    return v >= 1 ? v : 1024;
+  }();
+  const int64_t out_tiles = er::ceil_div(a.N, er::BN) * er::ceil_div(a.M, er::BM);
+  int64_t splits = er::ceil_div(din_wgrad_blocks, out_tiles);
+  const int64_t max_by_k = a.K / (8 * er::BK32);
+  if (splits > 256) splits = 256;
   if (splits > max_by_k) splits = max_by_k;
   if (splits < 1) splits = 1;
   a.k_per_split = static_cast<int>(er::ceil_div(er::ceil_div(a.K, splits), er::BK32)) * er::BK32;

@@ -1196,6 +1196,34 @@ class HipBackend(object):
     self._ck(self.lib.er_emb_bwd_reduce_routed(group['handle'], _p(unique_grads), ctypes.c_int32(unique_grads.stride(0)),
                                                _stream()), 'er_emb_bwd_reduce_routed')
 
+  # the embedding-parallel requester's local reductions + the step's weight gradients + the loss tail as two launches
+  # (er_emb_reduce_local_tail); A/B switch: '0' = one launch per reduction kind and dim group, the grouped wgrad launch apart
+  ep_merged_reduce = os.environ.get('EASYREC_AMD_EP_MERGED_REDUCE', '1') != '0'
+
+  def emb_reduce_local_tail(self, routed, dense, wgrads=None):
+    """routed: [(sharded requester group, unique_grads [slots, >= dim])], dense: [(replicated group, dense [rows, dim + 1])]
+    (at most 4 together): their local gradient reductions in ONE tile launch + ONE fix launch; wgrads: take_wgrads()'s fp32
+    list (wgrads_fit_the_tail) contracted in the same grid, with a deferred loss tail (loss_tail(defer=True)) as one more
+    workgroup of it."""
+    items = [(g, 1, t) for g, t in routed] + [(g, 2, t) for g, t in dense]
+    n = len(items)
+    assert 1 <= n <= 4
+    for _, _, t in items:
+      assert t.dim() == 2 and t.stride(1) == 1 and t.dtype == torch.float32
+    gh = (ctypes.c_void_p * n)(*[g['handle'] for g, _, _ in items])
+    modes = (ctypes.c_int32 * n)(*[m for _, m, _ in items])
+    outs = (ctypes.c_void_p * n)(*[t.data_ptr() for _, _, t in items])
+    ld = (ctypes.c_int32 * n)(*[t.stride(0) for _, _, t in items])
+    pr, lt = None, None
+    if wgrads:
+      pr = self._gemm_problems(GEMM_TN, wgrads, log_as='emb_reduce_local_wgrad_kernel')
+      lt = getattr(self, '_deferred_loss_tail', None)
+      self._deferred_loss_tail = None
+    self._ck(self.lib.er_emb_reduce_local_tail(gh, modes, outs, ld, n, pr, len(wgrads) if wgrads else 0,
+                                               ctypes.c_int32(int(self.tail_wgrad_blocks) if wgrads else 0),
+                                               ctypes.byref(lt[0]) if lt is not None else None, _stream()),
+             'er_emb_reduce_local_tail')
+
   def gather_rows(self, table, keys, n, key_sub, out):
     assert keys.dtype == torch.int32 and table.dim() == 2 and table.stride(1) == 1
     self._ck(self.lib.er_gather_rows_ld(_p(table), ctypes.c_int64(table.stride(0)), ctypes.c_int64(table.shape[0]),

@@ -466,6 +466,39 @@ class ShardedEmbeddingEngine(EmbeddingEngine):
     self.reduce_local_replicated()
     self.reduce_local_sharded()
 
+  def reduce_local_tail(self, pending_wgrads=False):
+    """reduce_local() with every reduction in ONE tile launch + ONE fix launch (er_emb_reduce_local_tail) and, with
+    pending_wgrads (model.backward(flush=False)), the step's queued weight gradients contracted in the same grid, a
+    deferred loss tail riding along - the single-GPU step's fused tail for the requester of the embedding-parallel step.
+    Falls back to the launches apart when there are more than 4 table groups or the weight gradients do not fit."""
+    be = kernels.hip()
+    self.finish_group_grads()
+    if self.rep and self.rep_flat_own:
+      self.rep_flat.zero_()
+    routed = [(sh['req'], sh['ugrads']) for sh in self.shard.values()]
+    dense = [(r['group'], r['dense']) for r in self.rep.values()]
+    wgrads = None
+    if pending_wgrads:
+      q, qb = be.take_wgrads()
+      if qb:
+        be.gemm_grouped(kernels.GEMM_TN, qb, bf16=True)
+      if be.wgrads_fit_the_tail(q):
+        wgrads = q
+      elif q:
+        be.gemm_grouped(kernels.GEMM_TN, q)
+    if wgrads is None:
+      be.flush_loss_tail()  # (a deferred loss tail rides with the weight gradients' grid only)
+    if 1 <= len(routed) + len(dense) <= 4:
+      be.emb_reduce_local_tail(routed, dense, wgrads=wgrads)
+      return
+    if wgrads:
+      be.gemm_grouped(kernels.GEMM_TN, wgrads)
+      be.flush_loss_tail()
+    reps = list(self.rep.values())
+    for i in range(0, len(reps), 4):
+      be.emb_bwd_reduce_dense([r['group'] for r in reps[i:i + 4]], [r['dense'] for r in reps[i:i + 4]])
+    self.reduce_local_sharded()
+
   def reduce_local_replicated(self):
     """first half of reduce_local: the group gradient buffers finished, the replicated tables' row sums in the dense buffer
     that is all-reduced with the dense gradients - after it everything the dense all-reduce carries is final"""

@@ -157,6 +157,45 @@ class EmbeddingParallelEstimator(EasyRecEstimator):
   def _phase_forward_backward(self):
     self._phase_compute(reduce=False)
 
+  # -- round 6: the requester's tail merged (er_emb_reduce_local_tail): weight gradients + every local reduction + the loss
+  # tail as two launches at the end of the compute segment; the dense all-reduce (asynchronous where the communicator has a
+  # second one) and the gradient all-to-all are issued back to back behind it and overlap EACH OTHER
+  @property
+  def merged_reduce(self):
+    be = kernels.hip()
+    return bool(getattr(be, 'ep_merged_reduce', False)) and self.engine.padded and self.is_training
+
+  def _phase_compute_merged(self):
+    if not self.engine.inference:
+      self.engine._start_window_flush()
+    self.engine.lookup()
+    self.engine._ran_version = self.features.version
+    be = kernels.hip()
+    with context.use(self.ctx):
+      self.model.begin_step()
+      self.model.build_predict_graph()
+      loss_dict = self.model.build_loss_graph()
+      riders = bool(getattr(be, 'tail_riders', False)) and bool(getattr(be, 'fused_tail', False))
+      self._loss_tail(loss_dict, defer=riders)
+      self.model.backward(flush=False)
+      self.engine.reduce_local_tail(pending_wgrads=True)
+      if riders:
+        be.flush_loss_tail()  # (a tail that did not take it)
+      if self.clip_norm > 0:
+        self.engine.local_gradsq(self._norm_slot, self._emb_gradsq_weight())
+    self.engine._join_window_flush()
+
+  def _collectives_after_compute(self):
+    # (at world 1 there is nothing to overlap and the second communicator's stream hand-over only costs: the serial order,
+    # unless EASYREC_AMD_EP_OVERLAP=1 forces the asynchronous form - the collective-order test does)
+    if self.clip_norm <= 0 and hasattr(self.comm, 'all_reduce_sum_async') and \
+        ((self._overlap == 'auto' and self.world > 1) or (self._overlap == '1' and not isinstance(self.comm, LocalComm))):
+      self._start_dense_allreduce()
+      self._finish_exchanges()
+    else:
+      self._sync_dense_grads()
+      self.engine.exchange_grads()
+
   def _phase_reduce_sharded(self):
     """the gradients of the sharded tables' rows, de-duplicated per (owner, id) for the exchange (+ with clipping this
     rank's share of the norm)"""
@@ -198,7 +237,9 @@ class EmbeddingParallelEstimator(EasyRecEstimator):
     if eng.padded:
       # fixed-capacity exchange: no host-side sizes anywhere, the host never waits for the device
       seq = head + [(self._phase_owner_serve, eng.exchange_rows)]
-      if self.is_training and self.overlap:
+      if self.merged_reduce:
+        seq += [(self._phase_compute_merged, self._collectives_after_compute), (self._phase_update, None)]
+      elif self.is_training and self.overlap:
         seq += [(self._phase_forward_backward, self._start_dense_allreduce), (self._phase_reduce_sharded, self._finish_exchanges),
                 (self._phase_update, None)]
       elif self.is_training:

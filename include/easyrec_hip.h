@@ -899,6 +899,18 @@ int er_gemm_grouped_coords(const int32_t* tiles, const int32_t* start, const int
  * er_emb_bwd_fused: same bodies, same k-splits, same reduce order.  Fewer, longer contraction workgroups suit the shared
  * grid better (they hold CU workgroup slots next to the row update's tiles for the whole launch): another split count
  * sums the batch in another - equally fixed, launch-to-launch deterministic - order. */
+/* The embedding-parallel REQUESTER's tail of the compute segment as two launches (reference
+ * compat/feature_column/feature_column.py:248-357 backward + compat/optimizers.py:285-345: the IndexedSlices of the local
+ * lookups are de-duplicated before hvd.alltoall returns them to the owners, next to the dense gradients' all-reduce): the
+ * local gradient reductions of up to 4 table groups - modes[i] 1: a sharded group's per-(owner, id) sums into outs[i]
+ * (er_emb_bwd_reduce_routed; this step's er_emb_route ran), 2: a replicated group's dense row sums [rows][ld] with the count
+ * in column dim (er_emb_bwd_reduce_dense) - in ONE tile grid, with the step's weight gradients (wgrads: n_wgrads <= 16 plain
+ * ER_GEMM_TN problems, as er_emb_bwd_fused_tail takes them; 0: none) contracted in the same grid and the loss tail
+ * (er_loss_tail's job, may be NULL) as one more workgroup; then the cross-tile fix beside the split-K reduce.  Same bodies
+ * as the launches apart: bit-identical results at the same wgrad_blocks (0: er_gemm_grouped_f32's own k-splits). */
+int er_emb_reduce_local_tail(er_emb_group* const* groups, const int32_t* modes_host, float* const* outs_host,
+                             const int32_t* ld_host, int n, const er_gemm_problem* wgrads_host, int n_wgrads,
+                             int32_t wgrad_blocks, const er_loss_tail_job* loss_tail, er_stream_t stream);
 int er_emb_bwd_fused_wgrad(er_emb_group* const* groups, int n, const er_grad_group* finish_host, int n_finish, int opt_kind,
                            const er_opt_hyper* hyper, const er_gemm_problem* wgrads_host, int n_wgrads,
                            int32_t wgrad_blocks, er_stream_t stream);

@@ -679,6 +679,15 @@ class RefBackend(object):
       ok = spec.ids[:n] >= 0  # (padding of the fixed-capacity exchange)
       out[:n][ok] = g['var'].detach()[spec.key_base + spec.ids[:n][ok]]
 
+  ep_merged_reduce = True  # (the host logic of the merged requester tail runs on the stand-in too)
+
+  def emb_reduce_local_tail(self, routed, dense, wgrads=None):
+    assert not wgrads  # (never queued here)
+    if dense:
+      self.emb_bwd_reduce_dense([g for g, _ in dense], [d for _, d in dense])
+    for g, t in routed:
+      self.emb_bwd_reduce_routed(g, t)
+
   def emb_bwd_reduce_dense(self, groups, dense):
     for g, d in zip(groups, dense):  # the two-step form: de-duplicated rows, then the scatter
       keys, grads, n_unique = self.emb_bwd_reduce(g)

@@ -392,14 +392,21 @@ def _din_with_hash_table_sequences(device, steps=3, B=48):
       # any difference in fp32 summation order; the bars are tests/_bars.py's, each at most ten times what a one-ulp
       # perturbation of the oracle's own gradients produces at that step - measured by tests/test_chaos_bars.py on the CPU)
       assert abs(got[k] - exp[k]) <= _bars.bar('din_taobao_small', step) * max(1.0, abs(exp[k])), (step, k, got[k], exp[k])
+    if step == min(steps, 2) - 1:
+      # Adam's first moments row by row after the SECOND step: from the third on single rows' moments of this model differ by
+      # tens of percent between two fp32 summation orders (the loss bar above is what the chaos envelope allows there)
+      st2 = est.state_dict(slots=True)
+      for n in kv_names:
+        keys2, _ = orc.kv_state(n)
+        assert np.array_equal(st2[n + '/keys'], keys2), n
+        _, m_rows = orc.kv_state(n, orc.slots[n + '/m'])
+        m_scale = float(np.abs(m_rows).max())
+        assert float(np.abs(st2[n + '/m'] - m_rows).max()) <= 1e-3 * m_scale + 1e-9, n
   st = est.state_dict(slots=True)
   for n in kv_names:
     keys, rows = orc.kv_state(n)
     assert np.array_equal(st[n + '/keys'], keys), n
     assert keys.size > 20 and st[n].shape == rows.shape
-    _, m_rows = orc.kv_state(n, orc.slots[n + '/m'])
-    m_scale = float(np.abs(m_rows).max())
-    assert float(np.abs(st[n + '/m'] - m_rows).max()) <= 1e-3 * m_scale + 1e-9, n
     assert float(np.abs(st[n] - rows).max()) <= 4e-3 * steps, n   # (a few lr-sized steps: Adam on near-zero gradients)
   # evaluation creates no rows, and a restored twin continues like the original
   n_before = {n: st[n + '/keys'].size for n in kv_names}

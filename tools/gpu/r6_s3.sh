@@ -4,7 +4,7 @@
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 O=gpurun_out/r6s3; mkdir -p $O
 timeout 900 python -m pytest tests/test_fused_epilogues_gpu.py -q --timeout 300 -x -k "din" 2>&1 | tail -15 | tee $O/tests_new.txt
-timeout 900 python -m pytest tests/test_models_gpu.py tests/test_kv_embedding.py tests/test_deepfm_gpu.py -q --timeout 300 -k "din or DIN or hash_table_sequence or trajectory or neighbouring" 2>&1 | tail -8 | tee $O/tests_models.txt
+timeout 900 python -m pytest tests/test_models_gpu.py tests/test_kv_embedding.py tests/test_deepfm_gpu.py -q --timeout 300 -m gpu -k "din or DIN or hash_table_sequence or trajectory or neighbouring" 2>&1 | tail -8 | tee $O/tests_models.txt
 line() { name=$1; shift; ( timeout 600 python bench.py "$@" ) > $O/$name.out 2>&1; echo "$name exit $?"; grep '^{' $O/$name.out | tail -1 >> $O/bench_lines.jsonl; grep '^{' $O/$name.out | tail -1 | python -c "
 import sys,json
 d=json.loads(sys.stdin.read()); r=d.get('roofline') or {}; p=d.get('parity_full_size') or {}
