@@ -54,6 +54,10 @@ def parse_args():
   ap.add_argument('--steady_steps', type=int, default=2048,
                   help='N=1: after the timed region, this many further steps over as many DISTINCT device-generated '
                        'batches (realistic idle lengths for the lazy dense decay); 0 = skip')
+  ap.add_argument('--from_file', default='', choices=['', 'csv', 'criteo'],
+                  help='N=1, Criteo-shaped configs: after the device-resident measurement, train from FILES written to a temp '
+                       'directory - Input -> pack (prefetch thread) -> train_step - and report the end-to-end examples/s as an '
+                       'extra key (never the headline value)')
   ap.add_argument('--parity_steps', type=int, default=2,
                   help='N=1: steps of the full-size GPU-vs-oracle loss comparison (0 = skip; needs the CPU baseline)')
   return ap.parse_args()
@@ -286,7 +290,9 @@ FAMILIES = (  # first match wins; names as rocprofv3 / the profiler print them
     ('decay replay', ('catch_up', 'flush_window', 'flush_decay', 'flush_mark', 'decay_tables', 'adam_decay_sweep')),
     # the step's tail in one grid (er_emb_bwd_fused_wgrad): the dense layers' weight gradients NEXT TO the embedding row
     # update, the split-K reduce next to the cross-tile fix - neither the GEMM family's nor the embedding family's alone
-    ('tail (weight gradients + embedding update)', ('emb_bwd_own_wgrad', 'emb_bwd_fix_reduce', 'emb_bwd_fix_opt')),
+    ('tail (weight gradients + embedding update)', ('emb_bwd_own_wgrad', 'emb_bwd_fix_reduce', 'emb_bwd_fix_opt',
+                                                     'emb_reduce_local_wgrad')),
+    ('collectives (RCCL)', ('rccl', 'nccl')),
     ('gemm', ('gemm_',)),
     ('batchnorm', ('er::bn_', 'dice', 'colsum')),
     ('embedding', ('er::emb_', 'hash_bucket', 'group_grad_finish', 'er::kv_', 'gather_rows', 'scatter_unique', 'rocprim')),
@@ -573,6 +579,81 @@ def steady_state(est, gen, n_steps):
   return out
 
 
+def gpu_clocks():
+  """What `rocm-smi --showclocks` says right after the timed region (boxes of this pool differ by up to 20 % on the same
+  tree: the clocks beside every number tell box variance from a regression)."""
+  import re
+  import subprocess
+  try:
+    txt = subprocess.run(['rocm-smi', '--showclocks'], capture_output=True, text=True, timeout=20).stdout
+    out = {}
+    for line in txt.splitlines():
+      m = re.search(r'GPU\[(\d+)\]\s*:\s*(\w+) clock level:\s*\d+:?\s*\(?(\d+)\s*Mhz\)?', line, flags=re.I)
+      if m and m.group(1) == '0':
+        out[m.group(2).lower() + '_mhz'] = int(m.group(3))
+    return out or {'raw': txt.strip()[-400:]}
+  except Exception as e:  # noqa: BLE001
+    return {'error': str(e)[:120]}
+
+
+def from_file_rate(cfg, est, kind, B, n_batches=48, steps=96):
+  """End to end from files: `Input -> pack (background thread, input/prefetch.py) -> train_step` over a Criteo-layout
+  file set written to a temp directory (reference input/csv_input.py:33-76, input/criteo_binary_reader.py) - what the device
+  step sustains when the host feeds it, beside the device-resident headline."""
+  import shutil
+  import tempfile
+  from easyrec_amd.input.prefetch import Prefetcher
+  tmp = tempfile.mkdtemp(prefix='er_bench_')
+  rng = np.random.default_rng(7)
+  n = n_batches * B
+  try:
+    feats = list(cfg.feature_config.features) or list(cfg.feature_configs)
+    if kind == 'csv':
+      from easyrec_amd.input.input import Input
+      path = os.path.join(tmp, 'train.tsv')
+      vocab = np.array(['%08x' % v for v in rng.integers(0, 2 ** 32, size=200000)])
+      ints = rng.integers(0, 1000, size=(n, 13)).astype(str)
+      cats = vocab[np.minimum((rng.pareto(1.05, size=(n, 26))).astype(np.int64), len(vocab) - 1)]
+      labels = (rng.random(n) < 0.25).astype(np.int64).astype(str)
+      sep = cfg.data_config.separator or '\t'
+      with open(path, 'w') as f:
+        for i in range(n):
+          f.write(sep.join([labels[i]] + list(ints[i]) + list(cats[i])) + '\n')
+      inp = Input.create(cfg.data_config, feats, path, batch_size=B, hash_on_host=False)
+    else:
+      from easyrec_amd.input.criteo_input import CriteoInput
+      (rng.random(n) < 0.25).astype(np.int32).tofile(os.path.join(tmp, 'p0_label.bin'))
+      rng.random((n, 13), dtype=np.float32).tofile(os.path.join(tmp, 'p0_dense.bin'))
+      rng.integers(0, 2 ** 32, size=(n, 26), dtype=np.uint32).tofile(os.path.join(tmp, 'p0_category.bin'))
+      inp = CriteoInput(cfg.data_config, feats,
+                        {'label_path': [os.path.join(tmp, 'p0_label.bin')], 'dense_path': [os.path.join(tmp, 'p0_dense.bin')],
+                         'category_path': [os.path.join(tmp, 'p0_category.bin')]}, batch_size=B)
+    epochs = (steps + 16) // n_batches + 2
+    it = Prefetcher(inp.batches(num_epochs=epochs, drop_remainder=True) if kind == 'csv' else
+                    (b for _ in range(epochs) for b in inp.batches()), depth=4, transform=est.features.pack)
+    k, t0 = 0, None
+    for b in it:
+      if b['labels'].shape[0] != B if isinstance(b, dict) and 'labels' in b else False:
+        continue
+      if k == 16:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+      est.train_step(b)
+      k += 1
+      if k == 16 + steps:
+        break
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    it.close()
+    done = k - 16
+    return {'format': kind, 'examples_per_s': done * B / dt, 'ms_per_step': dt / done * 1e3, 'steps': done,
+            'host_threads': os.cpu_count(), 'file_batches': n_batches,
+            'note': 'Input -> pack in one background thread (depth 4) -> one packed host-to-device copy + the replayed step; '
+                    'the device-resident rate is `value`'}
+  finally:
+    shutil.rmtree(tmp, ignore_errors=True)
+
+
 def parity_full_size(cfg, est, ring, host_batches, batch_size, n_steps):
   """The GPU path and the CPU oracle from the SAME full-size training state (weights, Adam slots, step), the same
   batches: relative loss differences over n_steps steps.  Tolerance: north_star's 1e-4 for fp32; with bf16 dense
@@ -739,6 +820,7 @@ def main():
       },
       'final_loss': losses.get('total_loss'),
       'device': kernels.hip().device_info(),
+      'clocks': gpu_clocks(),
   }
   if world == 1 and not ep:
     lazy_bytes, sweep_bytes, per_kernel_bytes = embedding_bytes_per_step(est, host_ring) if criteo else (0.0, 0.0, {})
@@ -819,6 +901,19 @@ def main():
       except Exception as e:  # noqa: BLE001
         out['cpu_baseline'] = {'value': None, 'unit': 'examples/s', 'cores': 0, 'kind': 'port',
                                'sample': 'failed: %s' % str(e)[:200]}
+  if world == 1 and not ep and args.from_file and criteo:
+    try:
+      out['from_file'] = from_file_rate(cfg, est, args.from_file, B)
+    except Exception as e:  # noqa: BLE001
+      out['from_file'] = {'format': args.from_file, 'error': str(e)[:300]}
+  if world == 1 and ep and not args.no_graph:
+    # the embedding-parallel step at W = 1 (--force_ep): the same per-kernel / per-family table as the single-GPU line,
+    # collectives as a family of their own (rank 0 alone may run extra steps only at world 1)
+    try:
+      per_kernel, flops = kernel_breakdown(est, ring)
+      out['roofline'] = step_roofline(est, per_kernel, flops, {}, None)
+    except Exception as e:  # noqa: BLE001
+      out['roofline_error'] = str(e)[:300]
   if 'roofline' not in out and not getattr(est, 'dense_sweep', False):
     # embedding-parallel runs (N > 1, --force_ep): the dense part is the same per rank; time the same GEMM on rank 0
     try:

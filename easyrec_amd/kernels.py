@@ -1217,7 +1217,7 @@ class HipBackend(object):
     pr, lt = None, None
     if wgrads:
       pr = self._gemm_problems(GEMM_TN, wgrads, log_as='emb_reduce_local_wgrad_kernel')
-      lt = getattr(self, '_deferred_loss_tail', None)
+      lt = self._deferred_loss_tail
       self._deferred_loss_tail = None
     self._ck(self.lib.er_emb_reduce_local_tail(gh, modes, outs, ld, n, pr, len(wgrads) if wgrads else 0,
                                                ctypes.c_int32(int(self.tail_wgrad_blocks) if wgrads else 0),
@@ -1480,7 +1480,7 @@ class HipBackend(object):
     if wgrads:
       pr = self._gemm_problems(GEMM_TN, wgrads, log_as='emb_bwd_own_wgrad_kernel')
       self.tail_launches = getattr(self, 'tail_launches', 0) + 1  # (tests: the fused tail is what ran)
-      lt = getattr(self, '_deferred_loss_tail', None)
+      lt = self._deferred_loss_tail
       self._deferred_loss_tail = None
       oj = None
       if dense_opt is not None:
@@ -2191,7 +2191,7 @@ class HipBackend(object):
     n_part = 0 if emb_partials is None else emb_partials.numel()
     n_dense = 0 if dense_partials is None else dense_partials.numel()
     if defer:
-      assert getattr(self, '_deferred_loss_tail', None) is None, 'the previous deferred loss tail was never run'
+      assert self._deferred_loss_tail is None, 'the previous deferred loss tail was never run'
       vp = ctypes.c_void_p
       job = LossTailJob(_ptr(emb_partials), n_part, float(emb_scale), _ptr(dense_partials), n_dense,
                         ctypes.cast(src, vp), ctypes.cast(dst, vp), ctypes.cast(parts, vp), ctypes.cast(scales, vp),
@@ -2205,6 +2205,17 @@ class HipBackend(object):
                                    ctypes.c_int32(n_dense), src, dst, parts, scales, divs, values, ctypes.c_int32(n), arr,
                                    ctypes.c_int32(len(jobs)), _p(reg_out), _p(total_out), _stream()), 'er_loss_tail')
 
+  # the deferred loss tail is per THREAD: the embedding-parallel tests run their ranks as threads over this one backend
+  _tail_tls = threading.local()
+
+  @property
+  def _deferred_loss_tail(self):
+    return getattr(HipBackend._tail_tls, 'pending', None)
+
+  @_deferred_loss_tail.setter
+  def _deferred_loss_tail(self, value):
+    HipBackend._tail_tls.pending = value
+
   def discard_loss_tail(self):
     """Forget a deferred loss tail nobody ran (the step that queued it raised before its tail): called at the start of
     every step."""
@@ -2212,7 +2223,7 @@ class HipBackend(object):
 
   def flush_loss_tail(self):
     """Run a deferred loss tail on its own (a step whose tail did not take it)."""
-    pending = getattr(self, '_deferred_loss_tail', None)
+    pending = self._deferred_loss_tail
     if pending is None:
       return
     self._deferred_loss_tail = None

@@ -527,3 +527,40 @@ def test_sharded_kv_tables_with_the_same_batch_equal_single_gpu(world):
       m_scale = float(np.abs(ref_state[n + '/m']).max())
       assert float(np.abs(state[n + '/m'] - ref_state[n + '/m']).max()) <= 5e-3 * m_scale, n
       assert float(np.abs(state[n] - ref_state[n]).max()) <= 4e-3, n
+
+
+@pytest.mark.parametrize('world', [1, 2, 4])
+def test_merged_requester_tail_changes_no_bit(world, monkeypatch):
+  """The embedding-parallel step with the requester's tail merged (er_emb_reduce_local_tail: weight gradients + every local
+  reduction + loss tail in two launches, round 6) against the launches apart (one per reduction kind and dim group, the
+  grouped weight-gradient launch and the loss tail on their own), W = 1, 2, 4 ranks as threads on different batches: with
+  the contraction's k-splits those of the stand-alone grouped launch (tail_wgrad_blocks = 0) every loss, table, slot and
+  dense variable is bit-identical over three steps - same bodies, same order."""
+  cfg = _cfg('deepfm_criteo_small.config')
+  B, steps = 128, 3
+  gens = [SyntheticCriteo(cfg.data_config, list(cfg.feature_config.features), batch_size=B, seed=20 + r) for r in range(world)]
+  batches = [[g.next_batch() for _ in range(steps)] for g in gens]
+  monkeypatch.setattr(kernels.HipBackend, 'tail_wgrad_blocks', 0)
+
+  def run(merged):
+    monkeypatch.setattr(kernels.HipBackend, 'ep_merged_reduce', merged)
+    sim = SimWorld(world)
+
+    def rank_fn(rank, comm):
+      torch.cuda.set_device(0)
+      est = EmbeddingParallelEstimator(cfg, device=DEV, batch_size=B, seed=4, rank=rank, world=world, comm=comm,
+                                       replicate_bytes=1024).build()
+      assert est.merged_reduce == merged
+      losses = []
+      for b in batches[rank]:
+        est.train_step(b)
+        losses.append(est.loss_values())
+      return est.state_dict(slots=True), losses
+
+    return sim.run(rank_fn)
+
+  a, b = run(True), run(False)
+  for (sa, la), (sb, lb) in zip(a, b):
+    assert la == lb, (la, lb)
+    for k in sb:
+      assert np.array_equal(sa[k], sb[k]), k
