@@ -24,6 +24,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+COMPACT_ORACLE_ABOVE_BYTES = 48 * 2 ** 30  # tables + Adam slots beyond this: parity_full_size fetches rows by id
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s achievable by a float4 copy
 
 
@@ -58,6 +59,9 @@ def parse_args():
                   help='N=1, Criteo-shaped configs: after the device-resident measurement, train from FILES written to a temp '
                        'directory - Input -> pack (prefetch thread) -> train_step - and report the end-to-end examples/s as an '
                        'extra key (never the headline value)')
+  ap.add_argument('--parity_only', action='store_true',
+                  help='with --no_cpu_baseline: still run the full-size GPU-vs-oracle parity check (the 200 M-row config: the '
+                       'oracle then holds only the rows the parity batches read - no CPU timing is possible on that state)')
   ap.add_argument('--parity_steps', type=int, default=2,
                   help='N=1: steps of the full-size GPU-vs-oracle loss comparison (0 = skip; needs the CPU baseline)')
   return ap.parse_args()
@@ -660,9 +664,19 @@ def parity_full_size(cfg, est, ring, host_batches, batch_size, n_steps):
   contractions (operands carry 8 significant bits; north_star states no bar for them) 1e-3 against the fp32 oracle, the bar
   tests/test_models_gpu.py holds the bf16 step to."""
   from oracle.model_oracle import OracleTrainer
-  state = est.state_dict(slots=True)
+  tables = {n: (t['rows'], t['dim']) for n, t in est.engine.tables.items() if not t.get('kv')}
+  table_bytes = sum(r * d * 4 for r, d in tables.values())
+  compact = None
+  if table_bytes * 3 > COMPACT_ORACLE_ABOVE_BYTES:
+    # tables (+ Adam's two slots) too large for a host copy - BASELINE config 5 at its stated 200 M rows x 64 is 153 GB: the
+    # oracle runs over the rows the parity batches read, fetched by id.  Exactly the full oracle's losses (a row no lookup
+    # reads influences nothing; TF-Adam's every-row decay acts row by row): tests/test_compact_oracle.py
+    dense_only = {k: v for k, v in est.varstore.state_dict().items()}
+    compact = OracleTrainer(cfg, dense_only, batch_size=batch_size).probe_ids(
+        [host_batches[k % len(host_batches)] for k in range(n_steps)], tables)
+  state = est.state_dict(slots=True, rows_of=compact)
   weights = {k: v for k, v in state.items() if not (k.endswith('/m') or k.endswith('/v'))}
-  orc = OracleTrainer(cfg, weights, batch_size=batch_size)
+  orc = OracleTrainer(cfg, weights, batch_size=batch_size, compact_ids=compact)
   orc.resume(est.global_step, {k: v for k, v in state.items() if k.endswith('/m') or k.endswith('/v')})
   del state, weights
   worst, per_step = 0.0, []
@@ -675,6 +689,9 @@ def parity_full_size(cfg, est, ring, host_batches, batch_size, n_steps):
     worst = max(worst, d)
   tol = 1e-3 if getattr(est.ctx, 'dense_dtype', 'f32') == 'bf16' else 1e-4
   return {'max_rel_loss_diff': worst, 'steps': n_steps, 'tolerance': tol, 'ok': bool(worst <= tol),
+          'oracle_tables': 'full' if compact is None else
+          'compact: the %d rows (of %d) the parity batches read, fetched by id' % (sum(len(v) for v in compact.values()),
+                                                                                  sum(r for r, _ in tables.values())),
           'per_step': per_step, 'from_global_step': int(est.global_step - n_steps)}, orc
 
 
@@ -885,6 +902,11 @@ def main():
         out['value_steady'] = out['steady_state'].get('examples_per_s')
       except Exception as e:  # noqa: BLE001
         out['steady_state'] = {'error': str(e)[:300]}
+    if args.no_cpu_baseline and args.parity_steps > 0 and args.parity_only:
+      try:
+        out['parity_full_size'], _ = parity_full_size(cfg, est, host_ring, host_batches, B, args.parity_steps)
+      except Exception as e:  # noqa: BLE001
+        out['parity_full_size'] = {'error': str(e)[:300]}
     if not args.no_cpu_baseline:
       orc = None
       torch.set_num_threads(min(os.cpu_count() or 1, 64))

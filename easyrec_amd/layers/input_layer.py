@@ -858,12 +858,16 @@ class EmbeddingEngine(object):
       be.kv_rebuild(kv, keys, new_rows, freq, version)
     return evicted
 
-  def state_dict(self, slots=False):
+  def state_dict(self, slots=False, rows_of=None):
+    """rows_of: {table name: int64 ids}: only those rows of the named (dense) tables - and of their slots - are copied to
+    the host, in the order given (a 200 M-row table's state is 153 GB; a parity check needs the rows its batches read)."""
     out = OrderedDict()
     self.flush_decay()
     self.check_kv_overflow()
     for name in self.tables:
       rows = None
+      if rows_of is not None and name in rows_of and not self.tables[name]['kv']:
+        rows = torch.as_tensor(rows_of[name], dtype=torch.int64)
       if self.tables[name]['kv']:
         # the materialised ids in ascending order and their rows (arena positions are run-dependent, keys are not)
         kv = self.kv_tables[name]

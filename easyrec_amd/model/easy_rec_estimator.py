@@ -483,9 +483,9 @@ class EasyRecEstimator(object):
     return g
 
   # -- host exchange (parity tests / checkpoints)
-  def state_dict(self, slots=False):
+  def state_dict(self, slots=False, rows_of=None):
     sd = self.varstore.state_dict()
-    sd.update(self.engine.state_dict(slots=slots))
+    sd.update(self.engine.state_dict(slots=slots, rows_of=rows_of) if rows_of is not None else self.engine.state_dict(slots=slots))
     if slots:
       for name in self.varstore.trainable_names():
         o, n = self.varstore._offsets[name]

@@ -89,13 +89,23 @@ def _fname(fc):
 class Vars(object):
   """name -> torch leaf (requires_grad) created from the numpy state on first use."""
 
-  def __init__(self, state, dtype):
+  def __init__(self, state, dtype, compact=None, probe=None):
     self.state = state
     self.dtype = dtype
     self.used = OrderedDict()
     self.l2 = {}
+    # compact: {table name: ascending ids} - state[name] holds ONLY those rows of the table, lookups map ids to positions
+    # (OracleTrainer(compact_ids=...)); probe: {table name: (rows, dim)} - tables stand in as one zero row and the lookups
+    # record the ids they see (OracleTrainer.probe_ids)
+    self.compact = compact or {}
+    self.probe = probe
 
   def get(self, name, l2=0.0, trainable=True):
+    if name not in self.used and self.probe is not None and name in self.probe:
+      t = torch.zeros(1, int(self.probe[name][1]), dtype=self.dtype)
+      t._probe_name = name
+      self.used[name] = t
+      self.l2[name] = l2
     if name not in self.used:
       if name not in self.state:
         raise KeyError('oracle: variable %r not found in the product state (have e.g. %s)' %
@@ -103,6 +113,8 @@ class Vars(object):
       t = torch.tensor(self.state[name], dtype=self.dtype)
       if trainable:
         t.requires_grad_(True)
+      if name in self.compact:
+        t._compact_ids = self.compact[name]
       self.used[name] = t
       self.l2[name] = l2
     return self.used[name]
@@ -110,10 +122,17 @@ class Vars(object):
 
 class OracleTrainer(object):
 
-  def __init__(self, cfg, state, batch_size, dtype=torch.float32):
+  def __init__(self, cfg, state, batch_size, dtype=torch.float32, compact_ids=None):
+    """compact_ids: {embedding table name: ascending int64 ids}: `state[name]` (and the slots handed to resume()) hold
+    ONLY those rows - every id the batches of this trainer's life will look up must be among them.  Rows that no lookup
+    reads cannot influence a loss, and TF-Adam's every-row decay acts on each row independently, so the losses and the
+    listed rows are exactly those of the full tables: what makes the 200 M-row table of BASELINE config 5 (51 GB, 153 GB
+    with Adam's slots) checkable on a host (bench.py parity_full_size, tests/test_compact_oracle.py)."""
     self.cfg = cfg
     self.B = batch_size
     self.dtype = dtype
+    self.compact_ids = {k: np.asarray(v, dtype=np.int64) for k, v in (compact_ids or {}).items()}
+    self._probe = None
     # hash-table (ev_params) tables arrive as (ids ascending, rows, meta): kept here as a dense arena of `capacity` rows
     # + an id -> row dict; rows are created on first sight from the same counter-based generator as the product
     # (oracle/kernel_ref.py kv_init_value), so a row's value does not depend on which arena position it gets
@@ -350,8 +369,29 @@ class OracleTrainer(object):
     self._lookup_leaves.setdefault(id(table), []).append(t)
     return t
 
+  def _table_ids(self, table, ids):
+    """ids as positions of `table`: unchanged for a full table; for a compact one (Vars.compact) the position of each id
+    in its ascending id list (an id that is not listed is a caller error); a probe table records them and reads row 0."""
+    ids = np.asarray(ids)
+    name = getattr(table, '_probe_name', None)
+    if name is not None:
+      rows = int(self._probe[name][0])
+      ok = (ids >= 0) & (ids < rows)
+      self._probe_seen.setdefault(name, []).append(np.unique(ids[ok]).astype(np.int64))
+      return np.where(ok, 0, -1).astype(np.int64)
+    listed = getattr(table, '_compact_ids', None)
+    if listed is None:
+      return ids
+    pos = np.searchsorted(listed, ids)
+    posc = np.minimum(pos, len(listed) - 1)
+    hit = (ids >= 0) & (listed[posc] == ids)
+    assert bool(np.all(hit | (ids < 0) | (ids >= int(getattr(table, '_full_rows', 1 << 62))))), \
+        'compact oracle: a looked-up id is not among compact_ids'
+    return np.where(hit, posc, -1).astype(np.int64)
+
   def _lookup_dense(self, table, ids, weights=None):
     """One id per example; id < 0 -> zero row; optional weight multiplies the row (combiner sum)."""
+    ids = self._table_ids(table, ids)
     self._touch(table, ids)
     table = self._per_lookup(table)
     idt = torch.as_tensor(np.asarray(ids), dtype=torch.int64)
@@ -363,7 +403,7 @@ class OracleTrainer(object):
 
   def _lookup_ragged(self, table, ids, offsets, weights, combiner):
     rows = []
-    ids = np.asarray(ids)
+    ids = self._table_ids(table, np.asarray(ids))
     self._touch(table, ids[int(offsets[0]):int(offsets[self.B])])
     table = self._per_lookup(table)
     for r in range(self.B):
@@ -1173,8 +1213,21 @@ class OracleTrainer(object):
     return out
 
   # ------------------------------------------------------------------ one step
+  def probe_ids(self, batches, table_shapes):
+    """{table name: ascending ids} the lookups of `batches` read: the forward pass with every embedding table of
+    table_shapes {name: (rows, dim)} standing in as ONE zero row and the lookups recording what they are asked for.  What
+    bench.py needs to fetch only those rows of a table too large for the host (compact_ids)."""
+    self._probe, self._probe_seen = dict(table_shapes), {}
+    try:
+      with torch.no_grad():
+        for b in batches:
+          self.forward(b)
+    finally:
+      self._probe = None
+    return {k: np.unique(np.concatenate(v)) for k, v in self._probe_seen.items()}
+
   def forward(self, batch):
-    V = Vars(self.state, self.dtype)
+    V = Vars(self.state, self.dtype, compact=self.compact_ids, probe=self._probe)
     self._reg = torch.zeros((), dtype=self.dtype)
     self._moving = {}
     self._touched = {}
