@@ -633,16 +633,48 @@ def from_file_rate(cfg, est, kind, B, n_batches=48, steps=96):
                         {'label_path': [os.path.join(tmp, 'p0_label.bin')], 'dense_path': [os.path.join(tmp, 'p0_dense.bin')],
                          'category_path': [os.path.join(tmp, 'p0_category.bin')]}, batch_size=B)
     epochs = (steps + 16) // n_batches + 2
-    it = Prefetcher(inp.batches(num_epochs=epochs, drop_remainder=True) if kind == 'csv' else
-                    (b for _ in range(epochs) for b in inp.batches()), depth=4, transform=est.features.pack)
+    # where the time goes, per batch: the producer thread's read + decode (`input_ms`) and pack (`pack_ms`), the consumer's
+    # wait for the producer (`wait_ms`) and its host time inside train_step (`step_host_ms`: copy + graph launch)
+    stage = {'input': 0.0, 'pack': 0.0, 'wait': 0.0, 'step_host': 0.0, 'n_in': 0}
+
+    def timed_source(src):
+      src = iter(src)
+      while True:
+        t = time.perf_counter()
+        try:
+          b = next(src)
+        except StopIteration:
+          return
+        stage['input'] += time.perf_counter() - t
+        stage['n_in'] += 1
+        yield b
+
+    def timed_pack(b):
+      t = time.perf_counter()
+      out = est.features.pack(b)
+      stage['pack'] += time.perf_counter() - t
+      return out
+
+    it = Prefetcher(timed_source(inp.batches(num_epochs=epochs, drop_remainder=True) if kind == 'csv' else
+                                 (b for _ in range(epochs) for b in inp.batches())), depth=4, transform=timed_pack)
     k, t0 = 0, None
-    for b in it:
+    while True:
+      tw = time.perf_counter()
+      try:
+        b = next(it)
+      except StopIteration:
+        break
+      if k >= 16:
+        stage['wait'] += time.perf_counter() - tw
       if b['labels'].shape[0] != B if isinstance(b, dict) and 'labels' in b else False:
         continue
       if k == 16:
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+      ts = time.perf_counter()
       est.train_step(b)
+      if k >= 16:
+        stage['step_host'] += time.perf_counter() - ts
       k += 1
       if k == 16 + steps:
         break
@@ -652,6 +684,10 @@ def from_file_rate(cfg, est, kind, B, n_batches=48, steps=96):
     done = k - 16
     return {'format': kind, 'examples_per_s': done * B / dt, 'ms_per_step': dt / done * 1e3, 'steps': done,
             'host_threads': os.cpu_count(), 'file_batches': n_batches,
+            'stage_ms_per_batch': {'input': stage['input'] / max(stage['n_in'], 1) * 1e3,
+                                   'pack': stage['pack'] / max(stage['n_in'], 1) * 1e3,
+                                   'consumer_wait': stage['wait'] / max(done, 1) * 1e3,
+                                   'train_step_host': stage['step_host'] / max(done, 1) * 1e3},
             'note': 'Input -> pack in one background thread (depth 4) -> one packed host-to-device copy + the replayed step; '
                     'the device-resident rate is `value`'}
   finally:

@@ -181,7 +181,7 @@ inline int apply_tiles_per_block(int B) {  // (workgroups in flight ~ constant)
   static const int mid = [] {  // (A/B knob: row tiles per workgroup for 8192 <= B <= 32768)
     const char* e = getenv("ER_BN_TILES_MID");
     const int v = e ? atoi(e) : 0;
-    return v >= 1 ? v : 2;
+    return v >= 1 ? v : 4;  // (round 6, under the pooled merge: MMoE 25 M 2.042 ms at 2, 1.998 at 4, 1.993 at 8)
   }();
   return B > 32768 ? 16 : (B >= 8192 ? mid : 1);
 }
@@ -262,32 +262,57 @@ __device__ __forceinline__ void bn_finalize_apply_body(const float* __restrict__
   float xpre[kPre];
   const bool pre = tiles_per_block == 1 && c < N;
   if (pre) {
+    // branch-free (rows past the end read the last row and are never stored): loads inside per-row branches are waited
+    // for inside them
 #pragma unroll
     for (int k = 0; k < kPre; ++k) {
-      const int r = by * kApplyRows + rl + k * kRowLanes;
-      xpre[k] = (r < B) ? x[static_cast<int64_t>(r) * N + c] : 0.f;
+      int r = by * kApplyRows + rl + k * kRowLanes;
+      r = r < B ? r : B - 1;
+      xpre[k] = x[static_cast<int64_t>(r) * N + c];
     }
   }
-  Welford t{0.f, 0.f, 0.f};
+  // The partials (n_i, mean_i, M2_i) of a lane group are pooled around a pivot p (the group's first mean) without a division
+  // per partial:  S0 = sum n_i, S1 = sum n_i (mean_i - p), S2 = sum M2_i + n_i (mean_i - p)^2;
+  //               mean = p + S1 / S0, M2 = S2 - S1^2 / S0
+  // (exact algebra of the pooled variance; the chunk means lie within a chunk-mean standard error of p, so the subtraction
+  // cancels ~1/64 of S2).  Chan's pairwise update - two IEEE divisions per partial - cost 800 VALU instructions per wave on a
+  // B = 4096 layer, twice that at B = 8192, in EVERY 16-row workgroup (profiles/r06_s6_sq_counters_by_kernel.json).
+  // Fixed order: lane group rl pools partials rl, rl + 4, ...; the four groups are merged (Chan) as (0 + 1) + (2 + 3).
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, pivot = 0.f;
+  constexpr int kGroup = 16;
   if (c < N) {
-    // groups of 8 partials: the 24 loads of a group are issued together, then merged in order
-    for (int k0 = rl; k0 < chunks; k0 += 8 * kRowLanes) {
-      Welford w8[8];
+    // groups of 16 partials (a B = 4096 layer's 64 row tiles: ONE round trip per lane): the 48 loads of a group are issued together, then pooled in order
+    for (int k0 = rl; k0 < chunks; k0 += kGroup * kRowLanes) {
+      Welford w8[kGroup];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
+      for (int j = 0; j < kGroup; ++j) {
+        // branch-free: a partial past the end is loaded from the last one's address and its count / M2 zeroed afterwards
+        // (an `if (k < chunks)` around the load made the compiler wait for every load inside its branch: 16 dependent
+        // L2 round trips per lane on a B = 4096 layer - s_waitcnt vmcnt(0) behind each global_load_dwordx3 in the ISA)
         const int k = k0 + j * kRowLanes;
-        if (k < chunks) {
-          const float* p = partial + (static_cast<int64_t>(k) * N + c) * 3;
-          w8[j] = Welford{p[0], p[1], p[2]};
-        } else {
-          w8[j] = Welford{0.f, 0.f, 0.f};
-        }
+        const int kc = k < chunks ? k : chunks - 1;
+        const float* p = partial + (static_cast<int64_t>(kc) * N + c) * 3;
+        w8[j] = Welford{p[0], p[1], p[2]};
       }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) t = wf_merge(t, w8[j]);
+      for (int j = 0; j < kGroup; ++j) {
+        if (k0 + j * kRowLanes >= chunks) { w8[j].n = 0.f; w8[j].m2 = 0.f; }
+      }
+      if (k0 == rl) pivot = w8[0].mean;
+#pragma unroll
+      for (int j = 0; j < kGroup; ++j) {
+        const float d = w8[j].mean - pivot;
+        const float nd = w8[j].n * d;
+        s0 = s0 + w8[j].n;
+        s1 = s1 + nd;
+        s2 = s2 + (w8[j].m2 + nd * d);
+      }
     }
   }
-  sm[rl][cl] = t;
+  {
+    const float shift = s0 > 0.f ? s1 / s0 : 0.f;
+    sm[rl][cl] = Welford{s0, pivot + shift, fmaxf(s2 - s1 * shift, 0.f)};
+  }
   __syncthreads();
   if (rl == 0 && c < N) {
     const Welford w = wf_merge(wf_merge(sm[0][cl], sm[1][cl]), wf_merge(sm[2][cl], sm[3][cl]));

@@ -282,13 +282,17 @@ class DeviceFeatures(object):
         if src.numel():
           dev_pairs.append((dst.view(-1)[:src.numel()], src.reshape(-1)))
         return
-      if src.device != dst.device and src.device.type == 'cpu' and non_blocking:
+      if src.device != dst.device and src.device.type == 'cpu' and non_blocking and not src.is_pinned():
         src = src.pin_memory() if torch.cuda.is_available() else src
       dst.view(-1)[:src.numel()].copy_(src.reshape(-1), non_blocking=non_blocking)
 
     if 'packed' in batch:  # pack(): one copy for labels, raw values, ids and strings
       src = batch['packed']
       put(self.arena, src)
+      if batch.get('packed_slot') is not None and self.device.type == 'cuda':  # pack()'s ring: the slot is free once copied
+        ev = torch.cuda.Event()
+        ev.record()
+        self._pin_ring['events'][batch['packed_slot']] = ev
       self._use_device_hash = bool(batch['packed_has_strings'])
     put(self.labels, batch.get('labels'))
     put(self.raw_block, batch.get('raw'))
@@ -348,7 +352,28 @@ class DeviceFeatures(object):
     has_str = 'str_bytes' in batch
     last = 'str_bytes' if has_str else 'hash_ids'
     end = self._layout[last][0] + self._layout[last][1]
-    img = np.zeros(end, dtype=np.uint8)
+    used = end  # bytes of the image that carry the batch (the string section is cut at its last byte)
+    if has_str:
+      sb = batch['str_bytes']
+      used = self._layout['str_bytes'][0] + int(sb.numel() if torch.is_tensor(sb) else sb.size)
+    slot = None
+    if device is None and self.device.type == 'cuda':
+      # a ring of page-locked images: load() copies straight from them (no pin_memory() allocation + copy per step on the
+      # consumer's side: 2.5 - 13 ms of host time per train_step, profiles/r06_s9_from_file_stages.txt) and records an
+      # event; a slot is refilled only after its copy has left
+      ring = self.__dict__.setdefault('_pin_ring', {'bufs': [], 'events': [], 'next': 0})
+      cap = self._layout['str_bytes'][0] + self._layout['str_bytes'][1]
+      if not ring['bufs']:
+        ring['bufs'] = [torch.empty(cap, dtype=torch.uint8).pin_memory() for _ in range(8)]
+        ring['events'] = [None] * 8
+      slot = ring['next']
+      ring['next'] = (slot + 1) % len(ring['bufs'])
+      if ring['events'][slot] is not None:
+        ring['events'][slot].synchronize()
+      img = ring['bufs'][slot].numpy()
+      img[:self._layout['str_offsets'][0]] = 0
+    else:
+      img = np.zeros(end, dtype=np.uint8)
     out = {}
     for key, val in batch.items():
       name = self._PACKED_KEYS.get(key)
@@ -367,8 +392,12 @@ class DeviceFeatures(object):
     if not has_str and 'hash_ids' not in batch:
       o, nbytes, _, _ = self._layout['hash_ids']
       img[o:o + nbytes] = 0xFF  # -1: missing
-    t = torch.from_numpy(img)
-    out['packed'] = t.to(device) if device is not None else t
+    if slot is not None:
+      out['packed'] = self._pin_ring['bufs'][slot][:used]
+      out['packed_slot'] = slot
+    else:
+      t = torch.from_numpy(img[:used])
+      out['packed'] = t.to(device) if device is not None else t
     out['packed_has_strings'] = has_str
     return out
 

@@ -435,13 +435,18 @@ def test_fused_embedding_step_matches_the_general_path(optimizer, buckets, B):
   # normalisation of near-zero gradients, as any two fp32 summation orders do: the losses are held over all four)
   sa, sb = first
   assert set(sa) == set(sb)
+  # (a one-row table's gradient g is a sum over the whole batch: 4096 terms in another order.  Its relative difference is
+  # held to 1e-4 through the first moment m = (1 - beta1) g; the second moment of the first step is v = (1 - beta2) g^2,
+  # whose relative difference is twice g's: 2e-4)
   worst = ('', 0.0)
   for k in sa:
     scale = float(np.max(np.abs(sa[k]))) + 1e-30
     d = float(np.max(np.abs(sa[k] - sb[k]))) / scale
+    if k.endswith('/v'):
+      d = d / 2.0
     if d > worst[1]:
       worst = (k, d)
-  assert worst[1] <= 1e-4, worst  # (a one-row table's gradient is a sum over the whole batch: 4096 terms in another order)
+  assert worst[1] <= 1e-4, worst
   for step, (a, b) in enumerate(zip(*losses)):
     for k in a:
       assert abs(a[k] - b[k]) <= (1e-6 if step == 0 else 2e-4) * max(1.0, abs(a[k])), (step, k, a[k], b[k])
