@@ -261,6 +261,8 @@ __device__ __forceinline__ void bn_finalize_apply_body(const float* __restrict__
   constexpr int kPre = kApplyRows / kRowLanes;
   float xpre[kPre];
   const bool pre = tiles_per_block == 1 && c < N;
+  // (requesting the column's bias / gamma / beta here too, instead of behind the merge's barrier, measured SLOWER: BatchNorm
+  // family 64.0 -> 65.5 us on DeepFM, 439 -> 455 on MMoE, profiles/r06_s11_bn_coefficients_first_rejected_ab_lines.txt)
   if (pre) {
     // branch-free (rows past the end read the last row and are never stored): loads inside per-row branches are waited
     // for inside them
@@ -490,6 +492,9 @@ __device__ __forceinline__ void bn_bwd_finalize_apply_body(const float* __restri
   }
   float a = 0.f, b = 0.f;
   if (c < N) {
+    // (16 partials per trip with clamped addresses, as in the forward, measured no faster on DeepFM and SLOWER on the taller
+    // layers - MMoE's BatchNorm family 439 -> 452 us, profiles/r06_s12_bn_bwd_fm_batched_loads_ab_lines.txt: these two adds
+    // per partial never waited the way the forward's Chan merge did)
 #pragma unroll 8
     for (int k = rl; k < chunks; k += kRowLanes) {
       const float* p = partial + (static_cast<int64_t>(k) * N + c) * 2;

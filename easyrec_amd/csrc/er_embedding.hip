@@ -806,16 +806,13 @@ struct FwdLazy {
 template <int V>
 __device__ __forceinline__ void lazy_row(float (&var)[V], const RowUpdate& tab, const DecayAux& aux, int64_t key, int c,
                                          int32_t t, float eps) {
-  // var, m, v and last_step of the row requested together (one record under er_emb_group_set_row_pitch): with TF-Adam's
-  // every-row decay a row read this step has pending steps unless it was also read in the step before, so asking for m / v
-  // only after last_step had arrived was a second dependent HBM round trip for nearly every row
   const int64_t off = tab.off(key, c);
-  float m[V], v[V];
   ld_vec<V>(var, tab.var + off);
-  ld_vec<V>(m, tab.m + off);
-  ld_vec<V>(v, tab.v + off);
   const int32_t s_begin = tab.ls(key) + 1;
   if (s_begin >= t) return;
+  float m[V], v[V];
+  ld_vec<V>(m, tab.m + off);
+  ld_vec<V>(v, tab.v + off);
   bool live = false;
 #pragma unroll
   for (int j = 0; j < V; ++j) live = live || (m[j] != 0.f) || (v[j] != 0.f);
@@ -1150,14 +1147,11 @@ __device__ __forceinline__ void fix_body(int bid, const uint32_t* __restrict__ s
   if (s >= n_tiles || c >= dim) return;
   const int64_t next0 = (s + 1) * T;
   if (next0 >= n) return;                       // last tile: nothing to cross into
-  // (the three keys and the tile's partial sum are requested together: one round trip before the decision, not three)
   const uint32_t key = skeys[next0 - 1];
-  const uint32_t key_next = skeys[next0];
-  const uint32_t key_before = skeys[s > 0 ? s * T - 1 : 0];
+  if (key == kInvalidKey || skeys[next0] != key) return;  // the tile's last run ends with the tile
+  if (s > 0 && skeys[s * T - 1] == key) return;            // the run came from an earlier tile: not its owner
   Vec<V> acc;
   acc.load(tile_last + s * dim + c);
-  if (key == kInvalidKey || key_next != key) return;  // the tile's last run ends with the tile
-  if (s > 0 && key_before == key) return;             // the run came from an earlier tile: not its owner
   for (int64_t m = s + 1; m < n_tiles; ++m) {
     const int64_t mnext = (m + 1) * T;
     Vec<V> part;
@@ -1246,15 +1240,6 @@ struct OwnLookup {  // what the gather needs of a lookup: built on the host (er_
 };
 
 // scale of a dense-mode lookup's single id (emb_bwd_build_kernel: w / den; den = sum w | sqrt(sum w^2) for mean | sqrtn)
-__device__ __forceinline__ float own_scale_of(const OwnLookup& L, float w_loaded) {  // w_loaded: weights[r] when there are weights
-  const float w = L.weights ? w_loaded : 1.f;
-  float den = 1.f;
-  if (L.combiner != ER_COMBINER_SUM) {
-    den = (L.combiner == ER_COMBINER_MEAN) ? w : sqrtf(w * w);
-    if (w == 0.f) den = 1.f;
-  }
-  return w / den;
-}
 __device__ __forceinline__ float own_scale(const OwnLookup& L, int r) {
   const float w = L.weights ? L.weights[r] : 1.f;
   float den = 1.f;
@@ -1321,83 +1306,6 @@ __device__ __forceinline__ Vec<V> own_finish(const er_grad_group& g, uint32_t tm
   return v;
 }
 
-// own_finish with every load outside a branch: a piece that is absent (no base gradient, no FM term, ...) is read from
-// `safe` (any valid 16 bytes) and dropped by a select, the arithmetic and its order are own_finish's.  With the loads inside
-// `if (has_base)` / `if (need_out)` / per-term branches the compiler waited for each one inside its branch
-// (s_waitcnt vmcnt(0) behind the global_load in the ISA): per gathered entry a chain of 4 - 5 dependent random HBM round
-// trips, and the tile's passes one after the other - what emb_bwd_own spent its 32 us on at 1.2 TB/s.  Terms 2 and 3 (no
-// model of this repo has them on a lookup) keep the branches: two terms' pieces are what fits in registers for 4 passes.
-typedef float f32x4a4 __attribute__((ext_vector_type(4), aligned(4)));
-template <int V>
-__device__ __forceinline__ Vec<V> own_ld_any(const float* p) {
-  Vec<V> v;
-  if constexpr (V == 4) {
-    const f32x4a4 t = *reinterpret_cast<const f32x4a4*>(p);
-    v.v = make_float4(t.x, t.y, t.z, t.w);
-  } else {
-    v.v = p[0];
-  }
-  return v;
-}
-template <int V>
-struct OwnPieces {
-  Vec<V> base, o, gf[2], sv[2];
-  float sgl[2];
-};
-template <int V>
-__device__ __forceinline__ void own_finish_issue(const er_grad_group& g, uint32_t tmask, int64_t b, int col, int cb,
-                                                 const float* safe, OwnPieces<V>& pc) {
-  const bool need_out = g.lambda != 0.f || (tmask & 0xF0u) != 0;
-  pc.base = own_ld_any<V>(g.has_base ? g.dout + b * g.ld + col : safe);
-  pc.o = own_ld_any<V>(need_out ? g.out + b * g.ld + col : safe);
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const er_grad_term& q = g.terms[t];
-    const bool on = ((tmask >> t) & 1u) != 0;
-    const bool fm = on && q.kind != ER_GRAD_TERM_ROWSUM;
-    const bool rs = on && q.kind == ER_GRAD_TERM_ROWSUM;
-    pc.sgl[t] = *(rs ? q.g + b * q.g_ld : safe);
-    pc.gf[t] = own_ld_any<V>(fm ? q.g + b * q.g_ld + cb : safe);
-    pc.sv[t] = own_ld_any<V>(fm ? q.saved + b * q.dim + cb : safe);
-  }
-}
-template <int V>
-__device__ __forceinline__ Vec<V> own_finish_combine(const er_grad_group& g, uint32_t tmask, int64_t b, int cb,
-                                                     const OwnPieces<V>& pc) {
-  const bool need_out = g.lambda != 0.f || (tmask & 0xF0u) != 0;
-  Vec<V> v = pc.base, o = pc.o;
-  if (!g.has_base) v.zero();
-  if (!need_out) o.zero();
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    if (!((tmask >> t) & 1u)) continue;
-    const er_grad_term& q = g.terms[t];
-    if (q.kind == ER_GRAD_TERM_ROWSUM) {
-      const float sgl = t < 2 ? pc.sgl[t < 2 ? t : 0] : q.g[b * q.g_ld];
-      if constexpr (V == 4) { v.v.x = v.v.x + sgl; v.v.y = v.v.y + sgl; v.v.z = v.v.z + sgl; v.v.w = v.v.w + sgl; } else { v.v = v.v + sgl; }
-    } else {
-      Vec<V> gf, sv;
-      if (t < 2) { gf = pc.gf[t < 2 ? t : 0]; sv = pc.sv[t < 2 ? t : 0]; }
-      else { gf = own_ld<V>(q.g + b * q.g_ld + cb); sv = own_ld<V>(q.saved + b * q.dim + cb); }
-      if constexpr (V == 4) {
-        v.v.x = v.v.x + gf.v.x * (sv.v.x - o.v.x); v.v.y = v.v.y + gf.v.y * (sv.v.y - o.v.y);
-        v.v.z = v.v.z + gf.v.z * (sv.v.z - o.v.z); v.v.w = v.v.w + gf.v.w * (sv.v.w - o.v.w);
-      } else {
-        v.v = v.v + gf.v * (sv.v - o.v);
-      }
-    }
-  }
-  if (g.lambda != 0.f) {
-    if constexpr (V == 4) {
-      v.v.x = v.v.x + g.lambda * o.v.x; v.v.y = v.v.y + g.lambda * o.v.y;
-      v.v.z = v.v.z + g.lambda * o.v.z; v.v.w = v.v.w + g.lambda * o.v.w;
-    } else {
-      v.v = v.v + g.lambda * o.v;
-    }
-  }
-  return v;
-}
-
 // gather + segmented scan of the T entries at [q, q + T) into vals (LDS); keys[0] = key before, keys[1..T] = the chunk,
 // keys[T + 1] = key after
 template <int V>
@@ -1416,47 +1324,21 @@ __device__ __forceinline__ void own_chunk(int64_t q, const er_grad_group* __rest
   }
   __syncthreads();
   if (dbg && tid == 0) dbg[8] = wall_clock64();
-  // The passes of the tile in three sweeps, every load outside a branch: the entry indices of all passes, then every piece
-  // of every pass's finished gradient (own_finish_issue), then the arithmetic.  A lane that holds no entry (past the end, a
-  // missing id, a padding column) reads what a valid neighbour reads - svals is a permutation of the entries, so any
-  // position < n names an existing output row - and drops it.
-  const float* safe = reinterpret_cast<const float*>(a.skeys);
-  const int cc = col_ok ? c : 0;
-  int jv[kTilePasses];
 #pragma unroll
   for (int ps = 0; ps < kTilePasses; ++ps) {
-    const int64_t p = q + ps * epp + tid / G;
-    jv[ps] = static_cast<int>(a.svals[p < a.n ? p : a.n - 1]);
-  }
-  // (two passes' pieces at a time: all four take 30 more registers than the launch's 4 waves per SIMD leave)
-  constexpr int kHalf = kTilePasses >= 2 ? 2 : 1;
-#pragma unroll
-  for (int h0 = 0; h0 < kTilePasses; h0 += kHalf) {
-    OwnPieces<V> pc[kHalf];
-    float wv[kHalf];
-    int lki[kHalf];
-#pragma unroll
-    for (int u = 0; u < kHalf; ++u) {
-      lki[u] = own_find(L, a.n_lookups, jv[h0 + u], a.cap_shift);
-      const OwnLookup& lk = L[lki[u]];
-      const int r = jv[h0 + u] - lk.base;
-      wv[u] = *(lk.weights ? lk.weights + r : safe);
-      own_finish_issue<V>(ggs[lk.gg], lk.tmask, r, lk.out_col + cc, cc, safe, pc[u]);
-    }
-#pragma unroll
-    for (int u = 0; u < kHalf; ++u) {
-      const int e = (h0 + u) * epp + tid / G;
-      const int64_t p = q + e;
-      const OwnLookup& lk = L[lki[u]];
-      const int r = jv[h0 + u] - lk.base;
-      const float sc = own_scale_of(lk, wv[u]);
-      const Vec<V> g = own_finish_combine<V>(ggs[lk.gg], lk.tmask, r, cc, pc[u]);
-      Vec<V> acc;
-      acc.zero();
+    const int e = ps * epp + tid / G;
+    const int64_t p = q + e;
+    Vec<V> acc;
+    acc.zero();
+    if (col_ok && p < a.n && keys[e + 1] != kInvalidKey) {
+      const int j = static_cast<int>(a.svals[p]);
+      const OwnLookup lk = L[own_find(L, a.n_lookups, j, a.cap_shift)];
+      const int r = j - lk.base;
+      const float sc = own_scale(lk, r);
+      const Vec<V> g = own_finish<V>(ggs[lk.gg], lk.tmask, r, lk.out_col + c, c);
       acc.add_scaled(g, sc);
-      if (!(p < a.n && keys[e + 1] != kInvalidKey)) acc.zero();
-      if (col_ok) acc.store(vals + static_cast<size_t>(e) * dim + c);
     }
+    if (col_ok) acc.store(vals + static_cast<size_t>(e) * dim + c);
   }
   if (dbg && tid == 0) dbg[9] = wall_clock64();
   __syncthreads();
@@ -1570,46 +1452,15 @@ __device__ __forceinline__ void own_proj_body(int local, const OwnMulti& ma, con
   Vec<V> acc;
   acc.zero();
   float cnt = 0.f;
-  // Four of the lane's rows per trip, every load outside a branch (own_finish_issue): the ids and weights of the four, then
-  // the gradient pieces two rows at a time, added in row order as before.  (One row per trip with the loads inside
-  // `if (ok)` was 4 - 5 dependent round trips per row: ~20 in a row for a [4096, 16] projection's part.)
-  const float* safe = a.proj_partial;  // (any valid 16 bytes; what is read from it is dropped)
-  const int cc = col_ok ? c : 0;
-  constexpr int kIt = 4;
-  for (int rb = r0 + rl; rb < r1; rb += kIt * rpp) {
-    int64_t idv[kIt];
-    float dwv[kIt], lwv[kIt];
-#pragma unroll
-    for (int u = 0; u < kIt; ++u) {
-      const int r = rb + u * rpp;
-      const int rc = r < r1 ? r : r1 - 1;
-      idv[u] = d.ids[rc];
-      dwv[u] = *(d.weights ? d.weights + rc : safe);
-      lwv[u] = *(lk.weights ? lk.weights + rc : safe);
-    }
-#pragma unroll
-    for (int h = 0; h < kIt; h += 2) {
-      OwnPieces<V> pc[2];
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int r = rb + (h + u) * rpp;
-        const int rc = r < r1 ? r : r1 - 1;
-        own_finish_issue<V>(gg, lk.tmask, rc, lk.out_col + cc, cc, safe, pc[u]);
-      }
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int r = rb + (h + u) * rpp;
-        const int rc = r < r1 ? r : r1 - 1;
-        bool ok = r < r1 && col_ok && idv[h + u] == 0;  // (rows == 1: the only valid id)
-        if (d.weights != nullptr && d.combiner != ER_COMBINER_SUM && !(dwv[h + u] > 0.f)) ok = false;
-        const float sc = own_scale_of(lk, lwv[h + u]);
-        const Vec<V> g = own_finish_combine<V>(gg, lk.tmask, rc, cc, pc[u]);
-        if (ok) {
-          acc.add_scaled(g, sc);
-          cnt = cnt + 1.f;
-        }
-      }
-    }
+  for (int r = r0 + rl; r < r1; r += rpp) {
+    const int64_t id = d.ids[r];
+    bool ok = id == 0;  // (rows == 1: the only valid id)
+    if (d.weights != nullptr && d.combiner != ER_COMBINER_SUM && !(d.weights[r] > 0.f)) ok = false;
+    if (!ok || !col_ok) continue;
+    const float sc = own_scale(lk, r);
+    const Vec<V> g = own_finish<V>(gg, lk.tmask, r, lk.out_col + c, c);
+    acc.add_scaled(g, sc);
+    cnt = cnt + 1.f;
   }
   // combine the row lanes of every column in a fixed order
   float* s_acc = smem;                 // [rpp][dim]
