@@ -546,6 +546,12 @@ __device__ __forceinline__ void gemm_f32_block(const GemmArgs& g, int bx, int bz
     // before its first MFMA - were built and measured in round 5: bit-identical, 96 - 135 VGPRs instead of 64 - 100, and
     // SLOWER on every config - DeepFM 0.3287 -> 0.3343 ms, DCN-v2 0.785 -> 0.802, DIN 1.833 -> 1.892, MMoE 2.094 -> 2.173:
     // global latency is not what the k loop waits for; profiles/r05_s15_gemm_prefetch_depth_ab_lines.txt)
+    // (EIGHT-wave workgroups whose second four waves contract the second half of the k-tiles of the same tile, the halves
+    // added through LDS - two waves per SIMD for launches of at most one workgroup per compute unit - were built and
+    // measured in round 6: 624 -> 256 at B = 4096 20.4 -> 19.8 us, but 256 -> 128 10.8 -> 11.1, 128 -> 64 7.9 -> 8.5 and
+    // the input-gradient launches 7.7 -> 9.6 / 8.4 -> 9.6: DeepFM 0.3015 -> 0.3072 ms.  These launches are ~5 us of
+    // prologue + epilogue + drain and 0.73 us per k-tile; halving the k-tiles per wave buys less than the second barrier
+    // population and the LDS add cost.  profiles/r06_s13_gemm_ksplit_pair_rejected_*.txt)
     // Fragments are read a quarter of the k-tile at a time, right before their four MFMAs, and the compiler places the
     // instructions (no scheduling fences): against "every fragment first, fences around the MFMA groups" the bare core
     // (tools/micro/gemm_core.hip, variants 9 -> 1) gains 10 % on 8192 x 1152 x 256, 7 % on 8192 x 256 x 1152.
