@@ -433,12 +433,30 @@ __device__ __forceinline__ void bn_bwd_partial_body(const float* __restrict__ x,
     const float bv = bias ? bias[c] : 0.f;
     const float mu = use_bn ? mean[c] : 0.f;
     const float is = use_bn ? invstd[c] : 0.f;
-    for (int r = r0 + rl; r < r1; r += kRowLanes) {
-      const int64_t i = static_cast<int64_t>(r) * N + c;
-      float g = dy[static_cast<int64_t>(r) * dy_ld + c];
-      if (act == ER_ACT_RELU && !(y[i] > 0.f)) g = 0.f;
-      sg = sg + g;
-      if (use_bn) sgx = sgx + g * ((x[i] + bv - mu) * is);
+    // 8 of the lane's rows per trip (a row past the chunk's end reads the last one and is skipped), summed in row order: the
+    // one-row-per-trip loop was a chain of rows_per_chunk / 4 dependent round trips with three loads in flight
+    const float* xs = use_bn ? x : dy;  // (absent operands read dy: valid addresses, values dropped)
+    const float* ys = act == ER_ACT_RELU ? y : dy;
+    const int64_t xs_ld = use_bn ? N : dy_ld, ys_ld = act == ER_ACT_RELU ? N : dy_ld;
+    constexpr int kRows = 8;
+    for (int rb = r0 + rl; rb < r1; rb += kRows * kRowLanes) {
+      float gv[kRows], yv[kRows], xv[kRows];
+#pragma unroll
+      for (int u = 0; u < kRows; ++u) {
+        const int r = rb + u * kRowLanes < r1 ? rb + u * kRowLanes : r1 - 1;
+        gv[u] = dy[static_cast<int64_t>(r) * dy_ld + c];
+        yv[u] = ys[static_cast<int64_t>(r) * ys_ld + c];
+        xv[u] = xs[static_cast<int64_t>(r) * xs_ld + c];
+      }
+#pragma unroll
+      for (int u = 0; u < kRows; ++u) {
+        if (rb + u * kRowLanes < r1) {
+          float g = gv[u];
+          if (act == ER_ACT_RELU && !(yv[u] > 0.f)) g = 0.f;
+          sg = sg + g;
+          if (use_bn) sgx = sgx + g * ((xv[u] + bv - mu) * is);
+        }
+      }
     }
   }
   sm[0][rl][cl] = sg;

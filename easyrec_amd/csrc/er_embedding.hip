@@ -2030,11 +2030,19 @@ __device__ __forceinline__ void seg_sort_body(int lk, const uint32_t* __restrict
       }
     }
   }
+  // every sorted composite's key (and, routed, its owner) once: the routed form costs two integer divisions per call, and
+  // the stores, the head flags, the distinct-key list and the per-owner counts below each asked for it again
+  uint32_t kk[E], ow[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    kk[e] = key_of(x[e]);
+    ow[e] = routed ? kk[e] / stride : 0u;
+  }
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     const int i = i0 + e;
     if (i < cnt) {
-      keys_out[base + i] = key_of(x[e]);
+      keys_out[base + i] = kk[e];
       vals_out[base + i] = NARROW ? static_cast<uint32_t>(base) + (static_cast<uint32_t>(x[e]) & static_cast<uint32_t>(P - 1))
                                   : static_cast<uint32_t>(static_cast<unsigned long long>(x[e]) & 0xFFFFFFFFu);
     }
@@ -2044,13 +2052,13 @@ __device__ __forceinline__ void seg_sort_body(int lk, const uint32_t* __restrict
     uint32_t* k32 = reinterpret_cast<uint32_t*>(sk_raw);  // [P] sorted keys, to look one position back
     __syncthreads();                                      // every thread has taken its composites out of sk
 #pragma unroll
-    for (int e = 0; e < E; ++e) k32[i0 + e] = key_of(x[e]);
+    for (int e = 0; e < E; ++e) k32[i0 + e] = kk[e];
     __syncthreads();
     uint32_t prev = i0 > 0 ? k32[i0 - 1] : kInvalidKey;
     uint32_t f[E], c = 0;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-      const uint32_t key = key_of(x[e]);
+      const uint32_t key = kk[e];
       f[e] = (key != kInvalidKey && (i0 + e == 0 || prev != key)) ? 1u : 0u;
       c += f[e];
       prev = key;
@@ -2080,7 +2088,7 @@ __device__ __forceinline__ void seg_sort_body(int lk, const uint32_t* __restrict
         hidx_out[base + i] = run;
         // (the fused front: the lookup's distinct keys, compact inside its own segment - er_emb_front's catch-up reads
         // [base, base + seg_count[lookup]) of it, no cross-lookup scan and no launch for one)
-        if (ukeys_seg != nullptr && f[e]) ukeys_seg[base + run] = key_of(x[e]);
+        if (ukeys_seg != nullptr && f[e]) ukeys_seg[base + run] = kk[e];
       }
       run += f[e];
     }
@@ -2092,7 +2100,7 @@ __device__ __forceinline__ void seg_sort_body(int lk, const uint32_t* __restrict
       __syncthreads();
 #pragma unroll
       for (int e = 0; e < E; ++e)
-        if (f[e]) atomicAdd(&owner_cnt[key_of(x[e]) / stride], 1u);  // integer: exact, order-independent
+        if (f[e]) atomicAdd(&owner_cnt[ow[e]], 1u);  // integer: exact, order-independent
       __syncthreads();
       if (t < 64) seg_count[lk * 64 + t] = owner_cnt[t];
     }

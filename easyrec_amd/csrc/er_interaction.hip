@@ -775,6 +775,51 @@ concat_cols_kernel(ConcatArgs a) {
   }
 }
 
+// the same copy for 16-byte aligned blocks (every col0, ld, out_ld a multiple of 4 floats; the host checks): one wave per
+// kConcatRows rows, a lane moves 16 bytes per row and column chunk with the rows' loads in flight together - no 64-bit
+// division per element, and the block a column belongs to is found once per column chunk with unrolled selects (a per-lane
+// index into the by-value argument arrays would copy them to scratch).  MMoE's [8192, 1040] concat: 29 us at 2.3 TB/s before.
+constexpr int kConcatRows = 4;
+__global__ void __launch_bounds__(kBlock)
+concat_cols_vec_kernel(ConcatArgs a) {
+  const int width = a.col0[a.n];
+  const int lane = threadIdx.x & 63;
+  const int64_t r0 = (static_cast<int64_t>(blockIdx.x) * (kBlock / 64) + (threadIdx.x >> 6)) * kConcatRows;
+  if (r0 >= a.batch) return;
+  for (int c = lane * 4; c < width; c += 64 * 4) {
+    const float* src = a.src[0];
+    int ld = a.ld[0], c0 = 0;
+#pragma unroll
+    for (int q = 1; q < 8; ++q) {
+      if (q < a.n && c >= a.col0[q]) { src = a.src[q]; ld = a.ld[q]; c0 = a.col0[q]; }
+    }
+    float4 v[kConcatRows];
+#pragma unroll
+    for (int u = 0; u < kConcatRows; ++u) {
+      const int64_t r = r0 + u < a.batch ? r0 + u : a.batch - 1;
+      v[u] = *reinterpret_cast<const float4*>(src + r * ld + (c - c0));
+    }
+#pragma unroll
+    for (int u = 0; u < kConcatRows; ++u) {
+      const int64_t r = r0 + u;
+      if (r < a.batch) {
+        *reinterpret_cast<float4*>(a.out + r * a.out_ld + c) = v[u];
+        if (a.out_bf16) {
+          uint16_t* ob = a.out_bf16 + r * a.ld_bf16 + c;
+          ob[0] = f32_to_bf16_bits(v[u].x); ob[1] = f32_to_bf16_bits(v[u].y);
+          ob[2] = f32_to_bf16_bits(v[u].z); ob[3] = f32_to_bf16_bits(v[u].w);
+        }
+      }
+    }
+  }
+  if (a.out_bf16 && lane == 0) {
+#pragma unroll
+    for (int u = 0; u < kConcatRows; ++u)
+      if (r0 + u < a.batch)
+        for (int j = width; j < a.ld_bf16; ++j) a.out_bf16[(r0 + u) * a.ld_bf16 + j] = 0;
+  }
+}
+
 // The elementwise backward of the TOP cross layer of a stack (its dout comes from outside the stack) by 64 x 64 tiles, with
 // what the fused chain needs of it: du = dout * x0 (fp32 for the weight gradient, bf16 for the bf16 contraction), dx0 (+)=
 // dout * (u + bias + diag * x), per-tile column sums of du (the bias gradient: er_colsum_partials_multi).  dout's own
@@ -1376,8 +1421,17 @@ int er_concat_cols_b16(const float* const* parts, const int32_t* widths, const i
     a.col0[i + 1] = a.col0[i] + widths[i];
   }
   ER_REQUIRE(out_ld >= a.col0[n] && (!out_bf16 || ld_bf16 >= a.col0[n]), "er_concat_cols: out_ld too small");
-  hipLaunchKernelGGL(er::concat_cols_kernel, dim3(er::blocks_for(static_cast<int64_t>(batch) * a.col0[n])), dim3(er::kBlock), 0,
-                     er::as_stream(stream), a);
+  bool vec = out_ld % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && a.col0[n] % 4 == 0;
+  for (int i = 0; i < n; ++i)
+    vec = vec && a.col0[i] % 4 == 0 && lds[i] % 4 == 0 && (reinterpret_cast<uintptr_t>(parts[i]) & 15) == 0;
+  if (vec) {
+    const int64_t waves = er::ceil_div(static_cast<int64_t>(batch), er::kConcatRows);
+    hipLaunchKernelGGL(er::concat_cols_vec_kernel, dim3(static_cast<unsigned>(er::ceil_div(waves, er::kBlock / 64))),
+                       dim3(er::kBlock), 0, er::as_stream(stream), a);
+  } else {
+    hipLaunchKernelGGL(er::concat_cols_kernel, dim3(er::blocks_for(static_cast<int64_t>(batch) * a.col0[n])), dim3(er::kBlock), 0,
+                       er::as_stream(stream), a);
+  }
   ER_LAUNCH_CHECK();
   return 0;
 }

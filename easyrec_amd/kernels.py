@@ -180,7 +180,7 @@ def grad_sink_of(x, col0=0, width=None):
   """The GradSink of x if x IS a group output of the embedding engine (layers/input_layer.py) and a deposit into
   columns [col0, col0 + width) is allowed now, else None."""
   sink = getattr(x, '_er_sink', None)
-  if sink is None or x.dim() != 2 or os.environ.get('EASYREC_AMD_GRAD_SINK', '1') == '0':  # A/B switch
+  if sink is None or x.dim() != 2:
     return None
   return sink
 
@@ -849,7 +849,7 @@ class HipBackend(object):
     return out
 
   # -- bf16 operands in HBM (dense_dtype 'bf16'): er_gemm_bf16_nt
-  bf16_nt = os.environ.get('EASYREC_AMD_BF16_NT', '1') != '0'  # A/B switch: '0' = er_gemm_bf16 (converts while staging)
+  bf16_nt = True  # (False: er_gemm_bf16, which converts fp32 operands while staging - round 1's form, kept for tests)
 
   # the producers of a bf16 step write their consumers' bf16 operands and the bf16 contractions carry the BatchNorm /
   # cross epilogues (er_gemm_bf16_nt_epi); A/B switch: '0' = round 5's arrangement (cast launches, fp32-only epilogues)
@@ -925,8 +925,8 @@ class HipBackend(object):
     self.gemm_bf16_nt(a16, t if layout == GEMM_NN else plain, M, N, K, out=out, bias=bias, accumulate=accumulate, epi=epi)
     return True
 
-  # er_gemm_f32_bn_bwd / er_bn_act_bwd_from_partials are used (A/B switch: EASYREC_AMD_FUSED_BN_BWD=0)
-  fused_bn_bwd = os.environ.get('EASYREC_AMD_FUSED_BN_BWD', '1') != '0'
+  # er_gemm_f32_bn_bwd / er_bn_act_bwd_from_partials are used
+  fused_bn_bwd = True
   # the BatchNorm-backward column sums of a layer whose output is a column block of the consumer's input (DeepFM's deep
   # tower inside [sum(wide) | FM | deep]) from the consumer's dgrad epilogue (er_gemm_f32_bn_bwd_cols); A/B switch
   bn_cols_epilogue = os.environ.get('EASYREC_AMD_BN_COLS_EPILOGUE', '1') != '0'
@@ -984,11 +984,11 @@ class HipBackend(object):
     return out
 
   # the same-depth layers of parallel stacks (MMoE's experts, task towers) as one grouped launch: layers/dnn.py run_parallel
-  grouped_stacks = os.environ.get('EASYREC_AMD_GROUPED_STACKS', '1') != '0'  # A/B switch
+  grouped_stacks = True
 
   # the bias / BatchNorm / activation launches of those layers as one launch forward, two backward (er_bn_fwd_multi /
   # er_bn_bwd_multi)
-  grouped_bn = os.environ.get('EASYREC_AMD_GROUPED_BN', '1') != '0'  # A/B switch
+  grouped_bn = True
   BN_MULTI_MAX_ROWS = 8192  # (taller layers reduce their partial sums in a merge launch of their own: single launches)
 
   def bn_fwd_multi(self, layers):
@@ -1112,7 +1112,7 @@ class HipBackend(object):
   def defer_wgrads(self):
     sink = self.wgrad_sink()
     assert not sink.queue and not sink.queue_bf16, 'flush_wgrads() was not called for the previous backward pass'
-    sink.active = os.environ.get('EASYREC_AMD_GROUPED_WGRAD', '1') != '0'  # A/B switch
+    sink.active = True
 
   def flush_wgrads(self):
     """Launch the queued weight gradients on the current stream.  Returns the queue: when that stream is not the one
@@ -2337,7 +2337,7 @@ class HipBackend(object):
     self._ck(self.lib.er_emb_group_enable_lazy_decay(group['handle'], _p(last_step), _p(lr_hist), _p(step_counter)),
              'er_emb_group_enable_lazy_decay')
     cap = lr_hist.numel() // 2
-    if os.environ.get('EASYREC_AMD_ABSORB', '1') != '0':  # A/B switch: the absorbed regime of the replay
+    if True:  # (the absorbed regime of the replay)
       self._ck(self.lib.er_emb_group_set_lr_max(group['handle'], _p(lr_hist[cap:])), 'er_emb_group_set_lr_max')
     group['last_step'], group['lr_hist'], group['step_counter'] = last_step, lr_hist, step_counter
     self._set_row_pitch(group)

@@ -131,7 +131,7 @@ class EmbeddingEngine(object):
     self.inference = False
     # rolling flush: every step one window of every table group is brought current, so no row is ever more than
     # this many steps behind (er_emb_flush_window); 0 = off (rows wait for their next touch or a full flush)
-    self.flush_windows = int(os.environ.get('EASYREC_AMD_FLUSH_WINDOWS', '64'))
+    self.flush_windows = 64
     # '1': the window's launch runs on a second stream, concurrently with the step (lag 1: see er_emb_flush_window), joined
     # after the step's row update; default: after the row update on the main stream (lag 0).  Measured on DeepFM-Criteo
     # (profiles/r02_overlap_flush.md): no gain - the steady-state step is bound by the SUM of its kernels' durations
@@ -519,7 +519,7 @@ class EmbeddingEngine(object):
         grps.append(grp)
         uks.append(lz['ukeys'])
         nus.append(lz['n_unique'])
-      step = 4 if os.environ.get('EASYREC_AMD_MULTI', '1') != '0' else 1  # A/B switch
+      step = 4
       probe = getattr(self, 'catch_up_probe', None)  # bench.py: (start event, end event) around the catch-up launches
       if probe is not None:
         probe[0].record()
@@ -700,7 +700,7 @@ class EmbeddingEngine(object):
       # get the same per-row arithmetic as TF's sparse apply (== the lazy row update)
       opt_kind = kernels.OPT_LAZY_ADAM
     grps = list(self.emb_groups.values())
-    step = 4 if os.environ.get('EASYREC_AMD_MULTI', '1') != '0' else 1
+    step = 4
     for i in range(0, len(grps), step):  # one tile launch + one fix launch for (up to 4) table groups
       be.emb_bwd_update_multi(grps[i:i + step], opt_kind, hyper)
     self.join_decay_sweep()

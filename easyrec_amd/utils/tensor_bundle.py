@@ -248,8 +248,11 @@ def write_bundle(prefix, tensors):
   names = sorted(tensors, key=lambda s: s.encode('utf-8'))
   items = [(b'', _header_proto())]
   offset = 0
-  # (both files are written under temporary names and renamed when complete: a crash mid-save leaves the previous
-  # checkpoint of this prefix - or nothing - never a torn bundle)
+  # (both files are written under temporary names, flushed to disk and renamed when complete - the data file first, the
+  # index last.  A crash before the renames leaves the previous bundle of this prefix untouched; a crash BETWEEN the two
+  # renames while re-saving an existing prefix leaves new data under the old index, which read_bundle's per-tensor CRCs
+  # reject - that bundle is then lost.  EmbeddingCheckpoint saves under a fresh step-numbered prefix and publishes it with
+  # the atomically renamed `checkpoint` state file, so only a re-save of the same step is exposed to that window.)
   tmp_data, tmp_index = data_file(prefix) + '.tmp', prefix + '.index.tmp'
   with open(tmp_data, 'wb') as f:
     for name in names:
@@ -264,8 +267,18 @@ def write_bundle(prefix, tensors):
     f.flush()
     os.fsync(f.fileno())
   _write_table(tmp_index, items)
+  with open(tmp_index, 'rb') as f:
+    os.fsync(f.fileno())
   os.replace(tmp_data, data_file(prefix))
   os.replace(tmp_index, prefix + '.index')
+  try:  # the renames themselves: the directory entry
+    dfd = os.open(os.path.dirname(os.path.abspath(prefix)) or '.', os.O_RDONLY)
+    try:
+      os.fsync(dfd)
+    finally:
+      os.close(dfd)
+  except OSError:
+    pass
 
 
 def read_bundle(prefix):

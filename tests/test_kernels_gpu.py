@@ -1551,6 +1551,23 @@ def test_head_sigmoid_ce_and_loss_tail(hip, ref, B, K, with_src, with_bn, bias):
   assert float(exp['reg']) == 0.5 * 21.0 and abs(float(exp['total']) - (10.5 + float(exp['loss']) + 0.125)) < 1e-5
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,widths', [(4096, (624, 256)), (8192, (256, 256, 256, 256, 16)), (130, (81, 64)), (7, (4, 8, 12)),
+                                      (1, (128,) * 8)])
+def test_concat_cols_equals_torch_cat(B, widths):
+  """er_concat_cols (reference tf.concat(axis=1), model/deepfm.py:75-83): the 16-byte-lane form for aligned blocks and the
+  per-element form otherwise are both exactly torch.cat; parts may be column views of wider buffers."""
+  hip = kernels.hip()
+  g = torch.Generator().manual_seed(B + len(widths))
+  parts = []
+  for k, w in enumerate(widths):
+    buf = torch.randn(B, w + 4 * (k % 2), generator=g).to(DEV)
+    parts.append(buf[:, :w])
+  out = hip.concat_cols(parts)
+  assert torch.equal(out, torch.cat(parts, dim=1))
+
+
+
 @pytest.mark.parametrize('B,n_w,F,D,n_d', [(4096, 39, 39, 16, 64), (100, 5, 7, 3, 9)])
 def test_wide_fm_concat_equals_the_three_launches(B, n_w, F, D, n_d):
   """er_wide_fm_concat = er_rowsum_fwd + er_fm_fwd + the concat, bit for bit (the same bodies as workgroup ranges)."""
