@@ -68,7 +68,12 @@ class LocalComm(object):
 class TorchDistComm(object):
   """torch.distributed process group (nccl = RCCL on the MI355X node, gloo in the CPU tests)."""
 
-  def __init__(self, group=None, overlap_group=True):
+  def __init__(self, group=None, overlap_group=None):
+    """overlap_group: create the second communicator (None: only where the asynchronous all-reduce can be used - more than
+    one rank, or EASYREC_AMD_EP_OVERLAP=1 - and not with EASYREC_AMD_EP_OVERLAP=0).  torch.distributed.new_group is
+    collective over the DEFAULT process group: every rank of it - not only the members of `group` - must construct its
+    TorchDistComm at the same point when the second communicator is created."""
+    import os
     import torch.distributed as dist
     assert dist.is_initialized(), 'init_process_group first (bench.py / the launcher does it)'
     self.dist = dist
@@ -79,6 +84,9 @@ class TorchDistComm(object):
     # serialises the collectives of ONE communicator on its stream, so the dense all-reduce that should overlap the
     # gradient all-to-all needs its own
     self.group2 = None
+    if overlap_group is None:
+      sw = os.environ.get('EASYREC_AMD_EP_OVERLAP', 'auto')
+      overlap_group = sw == '1' or (sw != '0' and self.world > 1)
     if overlap_group:
       ranks = dist.get_process_group_ranks(group) if group is not None else None
       self.group2 = dist.new_group(ranks=ranks)

@@ -12,6 +12,7 @@
 #include <cstring>
 #include <condition_variable>
 #include <functional>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -29,11 +30,21 @@ namespace {
 class HostPool {
  public:
   static HostPool* get() {
-    static std::mutex mu;
-    static HostPool* pool = nullptr;
-    std::lock_guard<std::mutex> lock(mu);
-    if (!pool || pool->pid_ != getpid()) pool = new HostPool();  // (the old one is leaked on purpose)
-    return pool;
+    // lock-free (a mutex here could be inherited LOCKED by a child forked while another thread held it): the pool of this
+    // process, replaced after a fork - the parent's worker threads do not exist in the child; the old object is leaked on
+    // purpose
+    static std::atomic<HostPool*> pool{nullptr};
+    HostPool* p = pool.load(std::memory_order_acquire);
+    if (!p || p->pid_ != getpid()) {
+      HostPool* fresh = new HostPool();
+      if (pool.compare_exchange_strong(p, fresh, std::memory_order_acq_rel)) {
+        p = fresh;
+      } else {
+        delete fresh;  // (another thread of this process installed one first; p holds it)
+        if (p->pid_ != getpid()) p = pool.load(std::memory_order_acquire);
+      }
+    }
+    return p;
   }
   // fn(0 .. n - 1), fn(0) on the calling thread
   void run(int n, const std::function<void(int)>& fn) {
@@ -210,7 +221,7 @@ void decode_rows(const uint8_t* text, const CsvLine* lines, int64_t r0, int64_t 
 
 extern "C" {
 
-// er_decode_csv_host on `n_threads` host threads (<= 0: one per hardware thread, at most 16; a thread takes at least 256
+// er_decode_csv_host on `n_threads` host threads (<= 0: one per hardware thread, at most 8; a thread takes at least 256
 // rows).  out_stride (>= max_rows): elements between consecutive fields of the column-major outputs - NOT a power of two
 // where it matters: a row's 40 fields x 5 arrays at a 4096-element pitch all map to the same cache sets (one 4096-line
 // batch: 3.2 ms at pitch 4096, 2.4 at 4100 on one thread; 0.9 against 0.7 on eight).  One pass finds the lines (memchr: a few GB/s), the threads parse disjoint row ranges into the same column-major
@@ -237,8 +248,10 @@ int er_decode_csv_host_mt(const uint8_t* text, int64_t n_bytes, uint8_t sep, int
   const int64_t rows = static_cast<int64_t>(lines.size());
   int T = n_threads;
   if (T <= 0) {
+    // (at most 8: the decode of a 4096-line batch stops scaling there, several reader threads of one process serialise on
+    // the pool, and a multi-process loader would otherwise put 16 workers per reader on the host)
     T = static_cast<int>(std::thread::hardware_concurrency());
-    if (T > 16) T = 16;
+    if (T > 8) T = 8;
   }
   if (T > rows / 256) T = static_cast<int>(rows / 256);
   if (T < 1) T = 1;

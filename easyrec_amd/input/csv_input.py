@@ -27,7 +27,7 @@ class CSVInput(Input):
     self._line_no = 0  # data lines seen so far (line sharding runs over the concatenation of the files)
     import os
     self.native_decode = os.environ.get('EASYREC_AMD_NATIVE_CSV', '1') != '0'  # else the line-by-line Python path
-    # host threads of the native decoder (0: one per hardware thread, at most 16; 1: the single-pass decoder)
+    # host threads of the native decoder (0: one per hardware thread, at most 8; 1: the single-pass decoder)
     self.decode_threads = int(os.environ.get('EASYREC_AMD_CSV_THREADS', '0'))
     self._decode_buffers = {}
 

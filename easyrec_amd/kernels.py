@@ -228,6 +228,13 @@ def slot_gate(x):
   ent = gates.get(key)
   if ent is not None and (ent[0] is x or ent[1] is x):
     return ent[1]
+  if ent is not None and x._base is not None and ent[0]._base is x._base and ent[0]._version == x._version and \
+      ent[0].dtype == x.dtype:
+    # another VIEW OBJECT of the same activation with the same geometry (dense() on a 3-D input reshapes it on every call):
+    # its consumers must share the first view's gate - grad_slot keys the shared buffer by storage start and shape, and two
+    # gates over one buffer would let the first hand it to autograd while the second's consumers are still adding into it.
+    # The gradient reaches the common base through the first view's node: the same values.
+    return ent[1]
   xg = _SlotGateFn.apply(x)
   for attr in ('_er_bn_src', '_er_sink'):
     if hasattr(x, attr):
@@ -576,7 +583,7 @@ class HipBackend(object):
   # -- K1 hashing
   def decode_csv_host(self, text, sep, kinds, max_rows, threads=0, out=None):
     """CSVInput's decode step on the host.  text: uint8 array; kinds: 0 string / 1 int / 2 float per field.  threads: 0 =
-    one per hardware thread (at most 16), n > 1 = that many (er_decode_csv_host_mt); 1 = the single-pass form
+    one per hardware thread (at most 8), n > 1 = that many (er_decode_csv_host_mt); 1 = the single-pass form
     (er_decode_csv_host).  out: a dict the five output arrays are kept in between calls of the same shape (for a reader
     that is done with a batch's arrays before it decodes the next: fresh 1.3 MB arrays are page-faulted in on every call).
     Returns (n_rows, consumed bytes, ints [F, max_rows], floats, empty mask, str_begin, str_len)."""

@@ -322,6 +322,10 @@ class EmbeddingEngine(object):
     st = {'var': None, 'm': None, 'v': None, 'bitmap': None, 'total_rows': total, 'last_step': None, 'rec': None}
     if os.environ.get('EASYREC_AMD_ROW_RECORDS', '1') != '0' and n_slots > 0:
       ld = self.record_floats(dim, n_slots, with_step)
+      plain = (1 + n_slots) * dim + (1 if with_step else 0)
+      if total * ld * 4 >= (1 << 30):  # (what the padding to whole 64-byte lines costs, where it matters)
+        logging.info('easyrec_amd: %d rows of dim %d as %d-float records: %.1f GB (%.1f GB unpadded; EASYREC_AMD_ROW_RECORDS=0 '
+                     'for plain arrays)', total, dim, ld, total * ld * 4 / 2 ** 30, total * plain * 4 / 2 ** 30)
       rec = torch.zeros(total, ld, dtype=torch.float32, device=self.device)
       st['rec'] = rec
       st['var'] = rec[:, 0:dim]

@@ -78,7 +78,7 @@ int er_decode_csv_host(const uint8_t* text_host, int64_t n_bytes, uint8_t separa
                        const int32_t* kinds_host, int64_t max_rows, int64_t* int_out, double* flt_out,
                        uint8_t* empty_out, int64_t* str_begin, int32_t* str_len, int64_t* n_rows_out,
                        int64_t* consumed_out);
-/* ... on n_threads host threads (<= 0: one per hardware thread, at most 16; at least 256 rows per thread): one pass finds
+/* ... on n_threads host threads (<= 0: one per hardware thread, at most 8; at least 256 rows per thread): one pass finds
  * the lines, the threads parse disjoint row ranges into the same outputs; plain decimal cells take an inline fast path
  * (integers; decimals of <= 15 significant digits as ONE exact division - the correctly rounded value, i.e. strtod's),
  * everything else strtoll / strtod.  Same results, same errors (the failing line with the smallest index is reported).

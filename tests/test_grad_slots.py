@@ -58,3 +58,29 @@ def test_slot_consumers_alone_still_share_one_buffer(ref_backend, monkeypatch):
     assert len([k for k in ctx.grad_slots if k != 'gates']) == 1  # one slot for the three consumers
   exp = sum(2.0 * (x.detach() @ w.detach()) @ w.detach().t() for w in ws)
   assert len(seen) == 1 and torch.allclose(seen[0], exp, rtol=1e-5, atol=1e-5)
+
+
+def test_two_view_objects_of_one_activation_share_one_gate(ref_backend, monkeypatch):
+  """dense() on a 3-D input reshapes it on every call: two view OBJECTS with the same storage start, shape and strides.  Their
+  slot consumers share ONE gradient buffer (grad_slot keys on storage start and shape), so they must share ONE gate too -
+  with a gate per view object the first consumer hands the buffer to autograd through its own gate while the second is
+  still adding into it (round-5 advisor finding).  Gradient: that of plain autograd."""
+  torch.manual_seed(5)
+  base = torch.randn(4, 3, 6)
+  ws = {k: torch.randn(6, 5, requires_grad=True) for k in ('w1', 'w2')}
+
+  def run(slots_on):
+    monkeypatch.setattr(kernels, '_GRAD_SLOTS', slots_on)
+    x3 = (base.clone().requires_grad_() * 1.0)
+    vs = VarStore('cpu')
+    ctx = context.ModelContext(vs, None, is_training=True)
+    with context.use(ctx):
+      a, b = x3.reshape(-1, 6), x3.reshape(-1, 6)  # two view objects
+      if slots_on:
+        ga, gb = kernels.slot_gate(a), kernels.slot_gate(b)
+        assert ga is gb
+      loss = dnn._linear(a, ws['w1'], None).pow(2).sum() + dnn._linear(b, ws['w2'], None).pow(2).sum()
+      (g,) = torch.autograd.grad(loss, x3)
+    return g
+
+  assert torch.allclose(run(True), run(False), rtol=1e-6, atol=1e-6)
