@@ -696,11 +696,34 @@ struct GradFinishMulti {
   er_grad_group g[8];
 };
 
+// a group without deferred terms on 16-byte aligned rows (the general path's usual case: base + lambda * out): 4 columns per
+// lane, a 32-bit division per lane instead of a 64-bit one per element (DIN / MMoE: 29 us per step for this launch at 3 TB/s)
+__host__ __device__ inline bool grad_finish_vec(const er_grad_group& g) {
+  return g.n_terms == 0 && g.width % 4 == 0 && g.ld % 4 == 0 &&
+         ((reinterpret_cast<uintptr_t>(g.dout) | reinterpret_cast<uintptr_t>(g.out)) & 15) == 0 &&
+         static_cast<int64_t>(g.batch) * (g.width / 4) < (1ll << 31);
+}
+
 __global__ void __launch_bounds__(kBlock)
 group_grad_finish_kernel(GradFinishMulti ma) {
   int i = 0;
   while (i + 1 < ma.n && static_cast<int>(blockIdx.x) >= ma.start[i + 1]) ++i;
   const er_grad_group& g = ma.g[i];
+  if (grad_finish_vec(g)) {  // (uniform over the workgroup)
+    const uint32_t w4 = static_cast<uint32_t>(g.width / 4);
+    const uint32_t id4 = (blockIdx.x - static_cast<uint32_t>(ma.start[i])) * kBlock + threadIdx.x;
+    const uint32_t b = id4 / w4;
+    if (b >= static_cast<uint32_t>(g.batch)) return;
+    const int64_t at = static_cast<int64_t>(b) * g.ld + static_cast<int64_t>(id4 - b * w4) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g.has_base) v = *reinterpret_cast<const float4*>(g.dout + at);
+    if (g.lambda != 0.f) {  // grad_finish_value's arithmetic per component
+      const float4 o = *reinterpret_cast<const float4*>(g.out + at);
+      v.x = v.x + g.lambda * o.x; v.y = v.y + g.lambda * o.y; v.z = v.z + g.lambda * o.z; v.w = v.w + g.lambda * o.w;
+    }
+    *reinterpret_cast<float4*>(g.dout + at) = v;
+    return;
+  }
   const int64_t idx = (static_cast<int64_t>(blockIdx.x) - ma.start[i]) * kBlock + threadIdx.x;
   const int64_t b = idx / g.width;
   if (b >= g.batch) return;
@@ -1359,7 +1382,9 @@ int er_group_grad_finish(const er_grad_group* groups, int n, er_stream_t stream)
                         (g.terms[t].kind == ER_GRAD_TERM_FM && g.terms[t].saved && g.terms[t].dim > 0)),
                    "er_group_grad_finish: group %d term %d: bad descriptor", i0 + i, t);
       ma.g[i] = g;
-      ma.start[i + 1] = ma.start[i] + static_cast<int>(er::ceil_div(static_cast<int64_t>(g.batch) * g.width, er::kBlock));
+      const int64_t lanes = er::grad_finish_vec(g) ? static_cast<int64_t>(g.batch) * (g.width / 4)
+                                                   : static_cast<int64_t>(g.batch) * g.width;
+      ma.start[i + 1] = ma.start[i] + static_cast<int>(er::ceil_div(lanes, er::kBlock));
     }
     hipLaunchKernelGGL(er::group_grad_finish_kernel, dim3(static_cast<unsigned>(ma.start[ma.n])), dim3(er::kBlock), 0,
                        er::as_stream(stream), ma);

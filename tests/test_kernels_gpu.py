@@ -1552,6 +1552,27 @@ def test_head_sigmoid_ce_and_loss_tail(hip, ref, B, K, with_src, with_bn, bias):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('B,width,ld,has_base,lam', [(4096, 624, 624, True, 5e-5), (8192, 1040, 1040, True, 1e-4),
+                                                     (130, 81, 84, True, 5e-5), (64, 32, 36, False, 0.25),
+                                                     (64, 32, 32, True, 0.0), (7, 12, 12, False, 0.0)])
+def test_group_grad_finish_base_plus_lambda_out(B, width, ld, has_base, lam):
+  """er_group_grad_finish without deferred terms - dout = [dout] + lambda * out (the embedding-output L2 of
+  layers/input_layer.py:369-375) - on 16-byte aligned rows (the 4-columns-per-lane form) and on others (per element)."""
+  hip = kernels.hip()
+  g = torch.Generator().manual_seed(B + width)
+  dbuf = torch.randn(B, ld, generator=g).to(DEV)
+  obuf = torch.randn(B, ld, generator=g).to(DEV)
+  dout, out = dbuf[:, :width], obuf[:, :width]
+  exp = (dout.clone() if has_base else torch.zeros_like(dout))
+  if lam != 0.0:
+    exp = exp + lam * out
+  pad_before = dbuf[:, width:].clone()
+  hip.group_grad_finish([(dout, out, lam, has_base, [])])
+  assert torch.equal(dout, exp)
+  assert torch.equal(dbuf[:, width:], pad_before)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('B,widths', [(4096, (624, 256)), (8192, (256, 256, 256, 256, 16)), (130, (81, 64)), (7, (4, 8, 12)),
                                       (1, (128,) * 8)])
 def test_concat_cols_equals_torch_cat(B, widths):
