@@ -12,6 +12,7 @@
 #include "er_dense_tail.h"
 #include "er_decay.h"
 #include "er_farmhash.h"
+#include "er_fm_bodies.h"
 
 namespace er {
 
@@ -249,8 +250,9 @@ __device__ __forceinline__ void bn_finalize_apply_body(const float* __restrict__
                          float eps, float momentum, float* __restrict__ moving_mean, float* __restrict__ moving_var,
                          int act, float* __restrict__ y, float* __restrict__ save_mean,
                          float* __restrict__ save_invstd, int tiles_per_block, int bx, int by,
-                         uint16_t* __restrict__ yb = nullptr, int ldyb = 0) {
+                         uint16_t* __restrict__ yb = nullptr, int ldyb = 0, float* __restrict__ y2 = nullptr, int ldy2 = 0) {
   // yb: a bf16 copy of y (row stride ldyb) for the contraction that reads it next (dense_dtype 'bf16': no cast launch)
+  // y2: a second fp32 copy of y at row stride ldy2 - the layer's column block of a concat (er_bn_apply_wide_fm)
   __shared__ Welford sm[kRowLanes][kColsPerBlock];
   __shared__ float s_mean[kColsPerBlock], s_inv[kColsPerBlock];
   const int cl = threadIdx.x % kColsPerBlock;
@@ -369,6 +371,10 @@ __device__ __forceinline__ void bn_finalize_apply_body(const float* __restrict__
 #pragma unroll
           for (int j = 0; j < 4; ++j) out[j] = bn_act_one(xv[u][j], bv[j], mu[j], is[j], ga[j], be[j], act);
           *reinterpret_cast<f32x4d*>(y + static_cast<int64_t>(r) * N + c4) = out;
+          if (y2) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) y2[static_cast<int64_t>(r) * ldy2 + c4 + j] = out[j];
+          }
           if (yb) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) yb[static_cast<int64_t>(r) * ldyb + c4 + j] = f32_to_bf16_bits(out[j]);
@@ -400,6 +406,7 @@ __device__ __forceinline__ void bn_finalize_apply_body(const float* __restrict__
       if (r < B) {
         const float o = bn_act_one(xv[k], bv, mu, is, ga, be, act);
         y[static_cast<int64_t>(r) * N + c] = o;
+        if (y2) y2[static_cast<int64_t>(r) * ldy2 + c] = o;
         if (yb) yb[static_cast<int64_t>(r) * ldyb + c] = f32_to_bf16_bits(o);
       }
     }
@@ -415,6 +422,38 @@ bn_finalize_apply_kernel(const float* __restrict__ partial, const float* __restr
   bn_finalize_apply_body(partial, x, bias, gamma, beta, B, N, chunks, eps, momentum, moving_mean, moving_var, act, y, save_mean, save_invstd, tiles_per_block, static_cast<int>(blockIdx.x), static_cast<int>(blockIdx.y), yb, ldyb);
 }
 
+
+// The LAST BatchNorm finalize + apply of DeepFM's deep tower together with what joins its output (reference
+// model/deepfm.py:60-83): workgroups [0, bn_blocks) run bn_finalize_apply_body and store the activations twice - as the
+// layer's own output y and as the column block [1 + D, 1 + D + N) of out = [sum(wide) | FM | deep] - the workgroups behind
+// them the FM and wide row-sum bodies of er_wide_fm_concat, which depend on the embeddings only.  One launch for two
+// (the concat launch and the 1.45 us boundary in front of it), the same arithmetic in the same order.
+struct WideFmArgs {
+  const float* wide; int n_w, ld_w;
+  const float* fm_x; int F, D, ld_x;
+  float* out; int ld_out;
+  float* sum_out;
+  int fm_blocks;
+};
+template <int V>
+__global__ void __launch_bounds__(kBlock)
+bn_apply_wide_fm_kernel(const float* __restrict__ partial, const float* __restrict__ x, const float* __restrict__ bias,
+                        const float* __restrict__ gamma, const float* __restrict__ beta, int B, int N, int chunks,
+                        float eps, float momentum, float* __restrict__ moving_mean, float* __restrict__ moving_var,
+                        int act, float* __restrict__ y, float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                        int tiles_per_block, int gx, int bn_blocks, WideFmArgs w) {
+  const int bid = blockIdx.x;
+  if (bid < bn_blocks) {
+    bn_finalize_apply_body(partial, x, bias, gamma, beta, B, N, chunks, eps, momentum, moving_mean, moving_var, act, y,
+                           save_mean, save_invstd, tiles_per_block, bid % gx, bid / gx, nullptr, 0, w.out + 1 + w.D, w.ld_out);
+  } else if (bid < bn_blocks + w.fm_blocks) {
+    fm_fwd_body<V>(static_cast<int64_t>(bid - bn_blocks) * kBlock + threadIdx.x, w.fm_x, B, w.F, w.D, w.ld_x, w.out + 1,
+                   w.ld_out, w.sum_out);
+  } else {
+    rowsum_fwd_body(static_cast<int64_t>(bid - bn_blocks - w.fm_blocks) * kBlock + threadIdx.x, w.wide, B, w.n_w, w.ld_w,
+                    w.out, w.ld_out);
+  }
+}
 
 // backward partials: p[(chunk*N + c)*2 + {0,1}] = (sum g, sum g*xhat), g = dy * act'(y)
 __device__ __forceinline__ void bn_bwd_partial_body(const float* __restrict__ x, const float* __restrict__ bias, const float* __restrict__ y,
@@ -1428,6 +1467,38 @@ int er_bn_apply_from_stats(const float* x, const float* bias, const float* col_s
                            float* save_invstd, er_stream_t stream) {
   return er_bn_apply_from_stats_b16(x, bias, col_stats, chunks, gamma, beta, B, N, eps, momentum, moving_mean, moving_var, act, y,
                                     save_mean, save_invstd, nullptr, 0, stream);
+}
+
+int er_bn_apply_wide_fm(const float* x, const float* col_stats, int32_t chunks, const float* gamma, const float* beta,
+                        int32_t B, int32_t N, float eps, float momentum, float* moving_mean, float* moving_var, int act,
+                        float* y, float* save_mean, float* save_invstd, const float* wide, int32_t n_w, int32_t ld_w,
+                        const float* fm_x, int32_t F, int32_t D, int32_t ld_x, float* out, int32_t ld_out, float* sum_out,
+                        er_stream_t stream) {
+  ER_REQUIRE(x && y && col_stats && save_mean && save_invstd && B > 0 && N > 0 && chunks > 0 && wide && fm_x && out &&
+                 sum_out && n_w > 0 && F > 0 && D > 0 && ld_out >= 1 + D + N && ld_w >= n_w && ld_x >= F * D,
+             "er_bn_apply_wide_fm: bad arguments");
+  if (chunks > er::kInlineChunks) {
+    er::set_error("er_bn_apply_wide_fm: %d row tiles need the merge launch: use er_bn_apply_from_stats + er_wide_fm_concat", chunks);
+    return 3;
+  }
+  const int tpb = er::apply_tiles_per_block(B);
+  const int gx = static_cast<int>(er::ceil_div(N, er::kColsPerBlock));
+  const int bn_blocks = gx * static_cast<int>(er::ceil_div(B, er::kApplyRows * tpb));
+  const bool vec = (D % 4 == 0) && (ld_x % 4 == 0) && ((reinterpret_cast<uintptr_t>(fm_x) & 15) == 0);
+  er::WideFmArgs w{wide, n_w, ld_w, fm_x, F, D, ld_x, out, ld_out, sum_out, er::blocks_for(static_cast<int64_t>(B) * (vec ? D / 4 : D))};
+  const int rs_blocks = er::blocks_for(static_cast<int64_t>(B) * 4);
+  dim3 grid(static_cast<unsigned>(bn_blocks + w.fm_blocks + rs_blocks));
+  if (vec) {
+    hipLaunchKernelGGL(er::bn_apply_wide_fm_kernel<4>, grid, dim3(er::kBlock), 0, er::as_stream(stream), col_stats, x, nullptr,
+                       gamma, beta, B, N, chunks, eps, momentum, moving_mean, moving_var, act, y, save_mean, save_invstd, tpb, gx,
+                       bn_blocks, w);
+  } else {
+    hipLaunchKernelGGL(er::bn_apply_wide_fm_kernel<1>, grid, dim3(er::kBlock), 0, er::as_stream(stream), col_stats, x, nullptr,
+                       gamma, beta, B, N, chunks, eps, momentum, moving_mean, moving_var, act, y, save_mean, save_invstd, tpb, gx,
+                       bn_blocks, w);
+  }
+  ER_LAUNCH_CHECK();
+  return 0;
 }
 
 int er_bn_apply_from_stats_b16(const float* x, const float* bias, const float* col_stats, int32_t chunks,

@@ -130,7 +130,7 @@ class WgradSink(object):
 class BnSource(object):
   """What the dgrad GEMM of a consumer needs in order to emit, in its epilogue, the BatchNorm-backward column sums
   of the layer that produced its input (HipBackend.gemm_bn_bwd): that layer's z, y and batch statistics."""
-  __slots__ = ('z', 'zbias', 'y', 'mean', 'invstd', 'act', 'partial', 'dx_ptr', 'gamma', 'grad_bufs', 'beta', 'fused')
+  __slots__ = ('z', 'zbias', 'y', 'mean', 'invstd', 'act', 'partial', 'dx_ptr', 'gamma', 'grad_bufs', 'beta', 'fused', 'pending')
 
   def __init__(self, z, zbias, y, mean, invstd, act, gamma=None, grad_bufs=None, beta=None, fused=True):
     assert y is not None
@@ -139,6 +139,10 @@ class BnSource(object):
     self.gamma, self.grad_bufs = gamma, grad_bufs  # grad_bufs = (gamma.grad, beta.grad) slices of the flat buffer
     # fused: the consumer's dgrad GEMM may emit this layer's BatchNorm-backward column sums (HipBackend.fused_bn_bwd)
     self.beta, self.fused = beta, fused
+    # pending: the layer's BatchNorm finalize + apply has NOT been launched yet (LinearBNActFn(defer_apply=True)): y, mean,
+    # invstd are unwritten until the ONE consumer the model promised runs it (WideFmConcatFn: er_bn_apply_wide_fm) or
+    # finish_pending_bn does; holds the arguments of HipBackend.bn_apply_from_stats
+    self.pending = None
 
 
 class BnColsView(object):
@@ -1408,6 +1412,40 @@ class HipBackend(object):
                                         deep.stride(0), B, _p(out), out.stride(0), _p(S), _stream()), 'er_wide_fm_concat')
     return out, S
 
+  def bn_apply_wide_fm(self, pend, wide, fm_x, F, D):
+    """er_bn_apply_wide_fm: the deferred BatchNorm finalize + apply `pend` (LinearBNActFn(defer_apply=True)) and
+    [sum(wide) | FM(fm_x) | y] in ONE launch -> (out, S) as wide_fm_concat, or None when the library wants the two launches."""
+    z, y = pend['z'], pend['y']
+    B, N = z.shape
+    n_w = wide.shape[1]
+    assert wide.stride(1) == 1 and fm_x.stride(1) == 1 and fm_x.shape[1] >= F * D and z.is_contiguous() and y.is_contiguous()
+    width = 1 + D + N
+    out = torch.empty(B, (width + 3) // 4 * 4, dtype=torch.float32, device=wide.device)[:, :width]
+    S = torch.empty(B, D, dtype=torch.float32, device=wide.device)
+    rc = self.lib.er_bn_apply_wide_fm(_p(z), _p(pend['stats']), ctypes.c_int32(int(pend['chunks'])), _p(pend['gamma']),
+                                      _p(pend['beta']), B, N, ctypes.c_float(pend['eps']), ctypes.c_float(pend['momentum']),
+                                      _p(pend['moving_mean']), _p(pend['moving_var']), int(pend['act']), _p(y),
+                                      _p(pend['mean']), _p(pend['invstd']), _p(wide), n_w, wide.stride(0), _p(fm_x), F, D,
+                                      fm_x.stride(0), _p(out), out.stride(0), _p(S), _stream())
+    if rc == 3:
+      return None
+    self._ck(rc, 'er_bn_apply_wide_fm')
+    return out, S
+
+  def bn_apply_pending(self, pend):
+    """the deferred BatchNorm finalize + apply as the launch of its own it would have been"""
+    z = pend['z']
+    B, N = z.shape
+    self._ck(self.lib.er_bn_apply_from_stats_b16(_p(z), None, _p(pend['stats']), ctypes.c_int32(int(pend['chunks'])),
+                                                 _p(pend['gamma']), _p(pend['beta']), B, N, ctypes.c_float(pend['eps']),
+                                                 ctypes.c_float(pend['momentum']), _p(pend['moving_mean']),
+                                                 _p(pend['moving_var']), int(pend['act']), _p(pend['y']), _p(pend['mean']),
+                                                 _p(pend['invstd']), None, ctypes.c_int32(0), _stream()),
+             'er_bn_apply_from_stats')
+
+  # the last BatchNorm apply of DeepFM's deep tower inside the [sum(wide) | FM | deep] launch (er_bn_apply_wide_fm) - A/B switch
+  defer_bn_apply = os.environ.get('EASYREC_AMD_DEFER_BN_APPLY', '1') != '0'
+
   def rowsum_bwd(self, g, n, into=None, accumulate=False):
     B = g.shape[0]
     dx = torch.empty(B, n, dtype=torch.float32, device=g.device) if into is None else into
@@ -2628,7 +2666,7 @@ class LinearBNActFn(torch.autograd.Function):
 
   @staticmethod
   def forward(ctx, x, w, b, gamma, beta, moving_mean, moving_var, eps, momentum, act, bf16, grad_bufs, src=None,
-              sink=None):
+              sink=None, defer_apply=False):
     be = hip()
     x2 = x if x.stride(-1) == 1 else x.contiguous()
     M, N = x2.shape[0], w.shape[1]
@@ -2637,8 +2675,18 @@ class LinearBNActFn(torch.autograd.Function):
     z = be.gemm(GEMM_NN, x2, w, bias=b, bf16=bf16, col_stats=stats)
     # (bf16: the BatchNorm launch writes the bf16 copy the next contraction reads; its backward the one the dgrad reads)
     ctx.b16 = be._bf16_state_of(w) if (bf16 and getattr(be, 'bf16_nt', False) and getattr(be, 'bf16_epilogues', False)) else None
-    y, mean, invstd = be.bn_apply_from_stats(z, None, stats, chunks, gamma, beta, eps, momentum, moving_mean,
-                                             moving_var, act, **({'bf16_state': ctx.b16} if ctx.b16 is not None else {}))
+    # defer_apply: the caller's NEXT op on y is the one consumer that runs this layer's BatchNorm finalize + apply inside its
+    # own launch (DeepFM: WideFmConcatFn).  Until then y / mean / invstd are unwritten buffers.
+    pend = None
+    if defer_apply and not bf16 and _bn_bwd_fusable(be, bf16) and getattr(be, 'defer_bn_apply', False) and z.is_contiguous():
+      y = torch.empty_like(z)
+      mean = torch.empty(N, dtype=torch.float32, device=z.device)
+      invstd = torch.empty(N, dtype=torch.float32, device=z.device)
+      pend = dict(z=z, stats=stats, chunks=chunks, gamma=gamma.detach(), beta=beta.detach(), eps=eps, momentum=momentum,
+                  moving_mean=moving_mean, moving_var=moving_var, act=act, y=y, mean=mean, invstd=invstd)
+    else:
+      y, mean, invstd = be.bn_apply_from_stats(z, None, stats, chunks, gamma, beta, eps, momentum, moving_mean,
+                                               moving_var, act, **({'bf16_state': ctx.b16} if ctx.b16 is not None else {}))
     ctx.save_for_backward(x2, w, gamma, beta, z, y, mean, invstd)
     ctx.act, ctx.bf16, ctx.grad_bufs = act, bf16, grad_bufs
     ctx.sink = be.wgrad_sink()
@@ -2648,6 +2696,8 @@ class LinearBNActFn(torch.autograd.Function):
     gb = None if grad_bufs is None else (grad_bufs[1], grad_bufs[2])
     # (z already carries the bias)
     ctx.own = BnSource(z, None, y, mean, invstd, act, gamma, gb, beta=beta, fused=fused) if fused else None
+    if pend is not None:
+      ctx.own.pending = pend
     _bn_tls.last = ctx.own
     return y
 
@@ -2655,6 +2705,7 @@ class LinearBNActFn(torch.autograd.Function):
   def backward(ctx, dy):
     be = hip()
     x, w, gamma, beta, z, y, mean, invstd = ctx.saved_tensors
+    assert ctx.own is None or ctx.own.pending is None, 'a deferred BatchNorm apply was never run (kernels.finish_pending_bn)'
     wg, gg, betag = ctx.grad_bufs if ctx.grad_bufs is not None else (None, None, None)
     direct = gg is not None and betag is not None
     # (a column block of a wider gradient - ConcatFn's backward - is read in place by the BatchNorm backward)
@@ -2674,7 +2725,16 @@ class LinearBNActFn(torch.autograd.Function):
       dx = _dgrad(be, dz, w, ctx.src, ctx.bf16, ctx.gsink)
     if ctx.needs_input_grad[1]:
       dw = _wgrad(be, x, dz, wg, ctx.bf16, ctx.sink)
-    return dx, dw, None, dgamma, dbeta, None, None, None, None, None, None, None, None, None
+    return dx, dw, None, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
+
+
+def finish_pending_bn(t):
+  """Run the deferred BatchNorm finalize + apply behind tensor t (LinearBNActFn(defer_apply=True)) as a launch of its own, if
+  it is still pending: what a consumer that cannot fold it calls before it reads t."""
+  src = bn_source_of(t)
+  if src is not None and src.pending is not None:
+    hip().bn_apply_pending(src.pending)
+    src.pending = None
 
 
 class GroupedLinearFn(torch.autograd.Function):
@@ -2923,7 +2983,16 @@ class WideFmConcatFn(torch.autograd.Function):
 
   @staticmethod
   def forward(ctx, wide, fm_x, deep, F, D, wide_sink, fm_sink, col0):
-    out, S = hip().wide_fm_concat(wide, fm_x, F, D, deep if deep.stride(-1) == 1 else deep.contiguous())
+    be = hip()
+    src = bn_source_of(deep)
+    res = None
+    if src is not None and src.pending is not None:
+      # the deep tower's last BatchNorm finalize + apply rides in this launch (er_bn_apply_wide_fm)
+      res = be.bn_apply_wide_fm(src.pending, wide, fm_x, F, D)
+      if res is None:
+        be.bn_apply_pending(src.pending)
+      src.pending = None
+    out, S = res if res is not None else be.wide_fm_concat(wide, fm_x, F, D, deep if deep.stride(-1) == 1 else deep.contiguous())
     ctx.save_for_backward(S)
     ctx.F, ctx.D, ctx.n_w = F, D, wide.shape[1]
     ctx.wide_sink, ctx.fm_sink, ctx.col0 = wide_sink, fm_sink, col0

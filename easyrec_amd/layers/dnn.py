@@ -53,8 +53,10 @@ def dense(x, units, name, l2_reg=None, use_bias=True, kernel_initializer='glorot
 
 
 def dense_bn_act(x, units, name, l2_reg, use_bias, use_bn, act_relu, training, bn_name=None,
-                 kernel_initializer='glorot_uniform'):
-  """GEMM followed by the fused bias + BatchNorm(train) + ReLU kernel."""
+                 kernel_initializer='glorot_uniform', defer_apply=False):
+  """GEMM followed by the fused bias + BatchNorm(train) + ReLU kernel.  defer_apply: the caller hands the result straight to
+  the ONE op that runs the BatchNorm finalize + apply inside its own launch (kernels.WideFmConcatFn); anything else must
+  call kernels.finish_pending_bn on it first."""
   ctx = context.current()
   vs = ctx.varstore
   in_dim = x.shape[-1]
@@ -78,7 +80,8 @@ def dense_bn_act(x, units, name, l2_reg, use_bias, use_bn, act_relu, training, b
     bf16 = getattr(ctx, 'dense_dtype', 'f32') == 'bf16'
     y = kernels.LinearBNActFn.apply(x if x.dim() == 2 else x.reshape(-1, in_dim), w, b, gamma, beta,
                                     None if freeze else mm, None if freeze else mv, BN_EPSILON, BN_MOMENTUM, act, bf16,
-                                    bufs, kernels.bn_source_of(x) or kernels.bn_cols_of(x), kernels.grad_sink_of(x))
+                                    bufs, kernels.bn_source_of(x) or kernels.bn_cols_of(x), kernels.grad_sink_of(x),
+                                    bool(defer_apply) and x.dim() == 2)
     src = kernels.take_last_bn_source()
     y = y.reshape(shape[:-1] + (units,))
     return kernels.tag_bn_source(y, src) if src is not None else y
@@ -310,7 +313,7 @@ class DNN(object):
   def dropout_ratio(self):
     return self._config.dropout_ratio
 
-  def __call__(self, deep_fea, hidden_layer_feature_output=False, din=None):
+  def __call__(self, deep_fea, hidden_layer_feature_output=False, din=None, defer_last_apply=False):
     """din = (query [B, E], history [B, L, E]): the input is DIN's [q, h, q - h, q * h] ([B, L, 4E]), never built - the first
     layer generates it inside its contractions (din_first_layer; the caller checked din_first_layer_ok); deep_fea is
     ignored."""
@@ -335,7 +338,12 @@ class DNN(object):
       if i == 0 and din is not None:
         deep_fea = din_first_layer(din[0], din[1], unit, layer, self._l2_reg, fuse_relu, self._is_training)
       else:
-        deep_fea = dense_bn_act(deep_fea, unit, layer, self._l2_reg, True, use_bn, fuse_relu, self._is_training)
+        last = i + 1 == hidden_units_len
+        # (defer_last_apply: see dense_bn_act - only when nothing below touches the layer's output again)
+        defer = bool(defer_last_apply and last and use_bn and (fuse_relu or not use_act) and not hidden_layer_feature_output and
+                     lead_shape is None and not (len(self.dropout_ratio) > 0 and self._is_training and self.dropout_ratio[i] > 0))
+        deep_fea = dense_bn_act(deep_fea, unit, layer, self._l2_reg, True, use_bn, fuse_relu, self._is_training,
+                                defer_apply=defer)
       if use_act and not fuse_relu and self.activation is not None:
         deep_fea = self.activation(deep_fea, name='%s/dnn_%d/act' % (self._name, i))
       if len(self.dropout_ratio) > 0 and self._is_training:

@@ -46,9 +46,11 @@ class DeepFM(RankModel):
              torch.is_grad_enabled() and wide_sink is not None and blk is not None and blk[3] is not None and
              self._wide_features.dim() == 2 and self._wide_features.stride(-1) == 1)
     if fused:
-      deep = self._dnn(self._deep_features, own.dnn, 'deep_feature')
+      # (the tower's last BatchNorm finalize + apply is left to the concat launch: kernels.LinearBNActFn(defer_apply))
+      deep = self._dnn(self._deep_features, own.dnn, 'deep_feature', defer_last_apply=True)
       x, F, D, fm_sink, col0 = blk
       joined = kernels.WideFmConcatFn.apply(self._wide_features, x, deep, F, D, wide_sink, fm_sink, col0)
+      kernels.finish_pending_bn(deep)  # (a no-op: WideFmConcatFn ran it)
       kernels.tag_bn_cols(joined, deep, 1 + D)  # (the deep tower's last BatchNorm backward: sums from final_dnn's dgrad)
       self._fm_outputs = joined[:, 1:1 + D]
       top = self._dnn(joined, own.final_dnn, 'final_dnn')

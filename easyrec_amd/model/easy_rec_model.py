@@ -71,10 +71,10 @@ class EasyRecModel(six.with_metaclass(_meta_type, object)):
     """(concatenated output, per-feature outputs) of a feature group, through the input layer"""
     return self._input_layer(self._feature_dict, name)
 
-  def _dnn(self, x, config, name):
+  def _dnn(self, x, config, name, defer_last_apply=False):
     """a layers/dnn.py DNN with this model's kernel regulariser and training flag"""
     from easyrec_amd.layers import dnn
-    return dnn.DNN(config, self._l2_reg, name, self._is_training)(x)
+    return dnn.DNN(config, self._l2_reg, name, self._is_training)(x, defer_last_apply=defer_last_apply)
 
   def _emit(self, output):
     self._add_to_prediction_dict(output)

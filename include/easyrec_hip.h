@@ -352,6 +352,17 @@ int er_fm_fwd(const float* x, int32_t B, int32_t F, int32_t D, int32_t x_stride,
 int er_wide_fm_concat(const float* wide, int32_t n_w, int32_t ld_w, const float* fm_x, int32_t F, int32_t D, int32_t ld_x,
                       const float* deep, int32_t n_d, int32_t ld_d, int32_t B, float* out, int32_t ld_out, float* sum_out,
                       er_stream_t stream);
+/* er_wide_fm_concat with the BatchNorm finalize + apply of the layer that PRODUCES the deep block (the last layer of
+ * DeepFM's deep tower: er_gemm_f32's column statistics -> er_bn_apply_from_stats, reference layers/dnn.py:63-79) in the same
+ * launch: y [B, N] = act(BN(x)) is stored as the layer's output AND as columns [1 + D, 1 + D + N) of out; save_mean /
+ * save_invstd / the moving statistics as er_bn_apply_from_stats leaves them.  The FM and row-sum workgroups need the
+ * embeddings only and run beside the BatchNorm's.  Returns 3 (nothing launched) when the statistics need the merge launch
+ * (more than 256 row tiles).  Same arithmetic, same order as the two launches. */
+int er_bn_apply_wide_fm(const float* x, const float* col_stats, int32_t chunks, const float* gamma, const float* beta,
+                        int32_t B, int32_t N, float eps, float momentum, float* moving_mean, float* moving_var, int act,
+                        float* y, float* save_mean, float* save_invstd, const float* wide, int32_t n_w, int32_t ld_w,
+                        const float* fm_x, int32_t F, int32_t D, int32_t ld_x, float* out, int32_t ld_out, float* sum_out,
+                        er_stream_t stream);
 int er_fm_bwd(const float* x, const float* sum_saved, const float* g, int32_t B, int32_t F,
               int32_t D, int32_t x_stride, float* dx, int32_t dx_stride, int accumulate,
               er_stream_t stream);

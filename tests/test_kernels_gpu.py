@@ -1603,3 +1603,36 @@ def test_wide_fm_concat_equals_the_three_launches(B, n_w, F, D, n_d):
   want = torch.cat([hip.rowsum_fwd(wide, n_w), fm, deep], dim=1)
   assert out.shape == want.shape and out.stride(0) % 4 == 0
   assert torch.equal(out, want) and torch.equal(S, S2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,K,N,n_w,F,D', [(4096, 128, 64, 39, 39, 16), (8192, 64, 128, 5, 7, 8), (100, 32, 20, 5, 7, 3)])
+def test_bn_apply_wide_fm_equals_the_two_launches(B, K, N, n_w, F, D):
+  """er_bn_apply_wide_fm (the deep tower's last BatchNorm finalize + apply inside DeepFM's [sum(wide) | FM | deep] launch) =
+  er_bn_apply_from_stats followed by er_wide_fm_concat, bit for bit: activations, saved statistics, moving statistics, the
+  concat and the FM field sums."""
+  hip = kernels.hip()
+  g = torch.Generator().manual_seed(B + N)
+  x = torch.randn(B, K, generator=g).to(DEV)
+  w = (torch.randn(K, N, generator=g) * 0.3).to(DEV)
+  bias = torch.randn(N, generator=g).to(DEV)
+  gamma = (torch.rand(N, generator=g) + 0.5).to(DEV)
+  beta = torch.randn(N, generator=g).to(DEV)
+  wide_full = torch.randn(B, n_w + 3, generator=g).to(DEV)
+  x_full = torch.randn(B, F * D + (4 if D % 4 == 0 else 1), generator=g).to(DEV)
+  wide, fx = wide_full[:, :n_w], x_full[:, :F * D]
+  chunks = hip.gemm_row_tiles(B)
+  stats = torch.empty(chunks * N * 3, device=DEV)
+  z = hip.gemm(kernels.GEMM_NN, x, w, bias=bias, col_stats=stats)
+  mm1, mv1 = torch.zeros(N, device=DEV), torch.ones(N, device=DEV)
+  y1, mean1, inv1 = hip.bn_apply_from_stats(z, None, stats, chunks, gamma, beta, 1e-3, 0.99, mm1, mv1, kernels.ACT_RELU)
+  out1, S1 = hip.wide_fm_concat(wide, fx, F, D, y1)
+  mm2, mv2 = torch.zeros(N, device=DEV), torch.ones(N, device=DEV)
+  pend = dict(z=z, stats=stats, chunks=chunks, gamma=gamma, beta=beta, eps=1e-3, momentum=0.99, moving_mean=mm2, moving_var=mv2,
+              act=kernels.ACT_RELU, y=torch.empty_like(z), mean=torch.empty(N, device=DEV), invstd=torch.empty(N, device=DEV))
+  res = hip.bn_apply_wide_fm(pend, wide, fx, F, D)
+  assert res is not None
+  out2, S2 = res
+  assert torch.equal(pend['y'], y1) and torch.equal(pend['mean'], mean1) and torch.equal(pend['invstd'], inv1)
+  assert torch.equal(mm2, mm1) and torch.equal(mv2, mv1)
+  assert out2.shape == out1.shape and torch.equal(out2, out1) and torch.equal(S2, S1)
