@@ -810,7 +810,10 @@ def main():
   if not args.no_graph:
     try:
       est.capture(warmup=3)
-      graph_note = 'hipGraph segments + eager all-to-alls' if ep else 'hipGraph replay'
+      graph_note = 'hipGraph replay'
+      if ep:
+        graph_note = ('one hipGraph (collectives inside)' if getattr(est, '_whole_graph', None) is not None
+                      else 'hipGraph segments + eager all-to-alls')
     except Exception as e:  # noqa: BLE001  (multi-GPU only: keep the run alive, say so in the output)
       if not ep:
         raise

@@ -49,6 +49,7 @@ class EmbeddingParallelEstimator(EasyRecEstimator):
     self.rank, self.world = rank, world
     self._engine_kwargs = dict(replicate_bytes=replicate_bytes, recv_slack=recv_slack)
     self._graphs = None
+    self._whole_graph = None
     self._dense_work = None
     self._overlap = os.environ.get('EASYREC_AMD_EP_OVERLAP', 'auto')  # 'auto': more than one rank; '1' / '0': A/B switch
     super(EmbeddingParallelEstimator, self).__init__(pipeline_config, device=device, batch_size=batch_size, seed=seed,
@@ -256,6 +257,9 @@ class EmbeddingParallelEstimator(EasyRecEstimator):
 
   def _device_step(self):
     g = self._graphs
+    if g is not None and self._whole_graph is not None:
+      self._whole_graph.replay()  # (static work AND collectives: capture(whole=True))
+      return
     for i, (static, collectives) in enumerate(self._phases()):
       if g is None:
         static()
@@ -290,10 +294,22 @@ class EmbeddingParallelEstimator(EasyRecEstimator):
     self.engine.check_overflow()
     return super(EmbeddingParallelEstimator, self).state_dict(slots=slots)
 
-  def capture(self, warmup=3):
-    """Capture the three static segments of the step as hipGraphs (the all-to-alls between them have
-    data-dependent split sizes and stay eager).  Runs `warmup` eager steps on the loaded batch first."""
-    assert self._built and self._graphs is None
+  def whole_graph_default(self):
+    """May capture() put the collectives INSIDE the graph?  Only the fixed-capacity exchange (nothing in it waits for the
+    host), and by default only where it has been run on hardware: one rank (local copies, or a world-1 RCCL process group:
+    `bench.py --force_ep --rccl`, where every eager collective between two graph segments costs 25-35 us of idle device);
+    EASYREC_AMD_EP_WHOLE_GRAPH=1 asks for it on more ranks (RCCL collectives are capturable: the kernels' plans become
+    persistent), =0 switches it off."""
+    sw = os.environ.get('EASYREC_AMD_EP_WHOLE_GRAPH', 'auto')
+    if sw == '0' or not self.engine.padded or torch.device(self.device).type != 'cuda':
+      return False
+    return sw == '1' or self.world == 1
+
+  def capture(self, warmup=3, whole=None):
+    """Capture the step as hipGraphs: the static segments between the collectives (which then stay eager), or -
+    whole=True, default whole_graph_default() - ONE graph of static work and collectives.  A whole-step capture that
+    fails falls back to the segments.  Runs `warmup` eager steps on the loaded batch first."""
+    assert self._built and self._graphs is None and self._whole_graph is None
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(s):
@@ -301,6 +317,25 @@ class EmbeddingParallelEstimator(EasyRecEstimator):
         self.train_step()
     torch.cuda.current_stream().wait_stream(s)
     torch.cuda.synchronize()
+    if whole is None:
+      whole = self.whole_graph_default()
+    if whole:
+      try:
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode='thread_local'):
+          for phase, collectives in self._phases():
+            phase()
+            if collectives is not None:
+              collectives()
+        self._whole_graph = g
+        self._graphs = [g]
+        return self._graphs
+      except Exception as e:  # noqa: BLE001  (a communicator that cannot be captured: the segments below)
+        import logging
+        logging.warning('easyrec_amd: whole-step hipGraph capture failed (%s); capturing the static segments', str(e)[:200])
+        self._whole_graph = None
+        self._dense_work = None
+        torch.cuda.synchronize()
     pool = torch.cuda.graph_pool_handle()
     graphs = []
     for phase, _ in self._phases():

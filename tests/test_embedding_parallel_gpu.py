@@ -160,9 +160,10 @@ def test_sharded_ranks_with_the_same_batch_equal_single_gpu(world, lazy, padded,
       assert np.array_equal(results[0][0][k], results[-1][0][k]), k
 
 
-def test_graph_segments_equal_eager_embedding_parallel_step():
-  """The EP step replayed as three hipGraph segments (+ eager exchanges) must give the same bits as the
-  all-eager EP step (every kernel on the path is deterministic)."""
+@pytest.mark.parametrize('whole', [False, True])
+def test_graph_segments_equal_eager_embedding_parallel_step(whole):
+  """The EP step replayed as hipGraph segments (+ eager exchanges), or as ONE hipGraph with the exchanges inside
+  (capture(whole=True)), must give the same bits as the all-eager EP step (every kernel on the path is deterministic)."""
   from easyrec_amd.core.comm import LocalComm
   cfg = _cfg('deepfm_criteo_small.config')
   B = 256
@@ -174,7 +175,8 @@ def test_graph_segments_equal_eager_embedding_parallel_step():
     e.features.load(batches[0])
   for _ in range(3):
     ests[0].train_step()
-  ests[1].capture(warmup=3)
+  graphs = ests[1].capture(warmup=3, whole=whole)
+  assert (ests[1]._whole_graph is not None) == whole and len(graphs) == (1 if whole else len(ests[1]._phases()))
   for b in batches[1:]:
     for e in ests:
       e.train_step(b)
