@@ -85,4 +85,7 @@ struct er_decay_tables {
   double ln_b1 = 0.0, ln_b2 = 0.0;
   float beta1 = 0.f, beta2 = 0.f;
   bool prologue_build = false;  // er_decay_tables_set_prologue_build
+  // the lag-1 table of THIS step was already built by a rider of an earlier launch on the same stream
+  // (er_emb_owner_ids_merge): the next er_emb_owner_serve consumes the note instead of launching decay_tables_kernel
+  bool lag1_built = false;
 };

@@ -2680,6 +2680,93 @@ emb_owner_merge_padded_kernel(const uint32_t* __restrict__ keys_in, const uint32
   flags[pos] = first ? 1u : 0u;
 }
 
+// The owner's side between the key exchange and the serve launch as ONE launch (er_emb_owner_ids_merge): emb_owner_ids_kernel,
+// the entry build of the owner group and of the groups that share its sort (build_body) and emb_owner_merge_padded_kernel were
+// three launches of n_runs * cap threads each, one chained to the next only through arrays every thread can derive for ANY
+// position from the received keys themselves: the key of a received slot p is what the build writes for it - key_base + id,
+// or the invalid key for an id outside the table - so the merge's binary searches read the RECEIVED runs and no thread waits
+// for another workgroup's build.  Workgroups behind the n_main of the merge build the closed-form replay's lag-1 table for
+// the serve launch that follows (decay_tables_kernel's body, one wavefront per k).  Same arithmetic per entry: every array
+// this launch leaves is bit for bit what the three (four) launches leave.
+__global__ void __launch_bounds__(kBlock)
+emb_owner_ids_merge_kernel(const uint32_t* recv, const int32_t* counts, int n_runs, int cap, int hdr, int64_t key_sub,
+                           int64_t* ids, int32_t* counts_out, BuildMulti bm, int n_main, uint32_t* __restrict__ keys_out,
+                           uint32_t* __restrict__ vals_out, uint32_t* __restrict__ flags, DecayTabDev tabs,
+                           const float* __restrict__ hist, const int64_t* __restrict__ counter) {
+  if (static_cast<int>(blockIdx.x) >= n_main) {
+    const int k = static_cast<int>(((blockIdx.x - n_main) * kBlock + threadIdx.x) >> 6) + 1;
+    if (k > tabs.K) return;
+    const int64_t s_end = *counter - 1;  // lag 1 (decay_tables_kernel)
+    const float mine = decay_sum_wave(tabs, hist, s_end - 1 - k, k);
+    const int lane = threadIdx.x & 63;
+    float* A = tabs.A + static_cast<int64_t>(kDecayKMax) * kDecayLd;
+    if (lane < kDecayLd) A[static_cast<int64_t>(k - 1) * kDecayLd + lane] = mine;
+    return;
+  }
+  const int i = static_cast<int>(blockIdx.x) * kBlock + threadIdx.x;
+  const bool live = i < n_runs * cap;
+  const int own = live ? i / cap : 0;
+  const int j = i - own * cap;
+  const int stride = cap + hdr;
+  // (q and the run counts are wave-uniform: scalar loads)
+  auto run_count = [&](int q) { return hdr ? static_cast<int>(recv[static_cast<int64_t>(q) * stride]) : counts[q]; };
+  // emb_owner_ids_kernel
+  int64_t my_id = -1;
+  if (live) {
+    const uint32_t* run = recv + static_cast<int64_t>(own) * stride;
+    const int cnt = run_count(own);
+    my_id = j < cnt ? static_cast<int64_t>(run[hdr + j]) - key_sub : -1;
+    ids[i] = my_id;
+    if (j == 0 && counts_out) counts_out[own] = cnt;
+  }
+  // the entry build of the group and of its followers (their lookups read ids[] - this thread's own store)
+  for (int g = 0; g < bm.n; ++g) {
+    const BuildArgs& a = bm.a[g];
+    build_body(blockIdx.x, a.descs, a.blk_start, a.ent_base, a.n_lookups, a.rt, a.n_active, a.keys, a.vals, a.ent_gptr,
+               a.ent_scale);
+  }
+  if (!live) return;
+  // emb_owner_merge_padded_kernel on keys derived from the received runs
+  const er_lookup_desc d0 = bm.a[0].descs[0];
+  auto key_of_id = [&](int64_t id) {
+    return (id < 0 || id >= d0.rows) ? kInvalidKey : static_cast<uint32_t>(d0.key_base + id);
+  };
+  auto key_at = [&](int q, int jj) {  // the key the build leaves at slot q * cap + jj (jj < that run's count)
+    return key_of_id(static_cast<int64_t>(recv[static_cast<int64_t>(q) * stride + hdr + jj]) - key_sub);
+  };
+  uint32_t pos = 0;
+  bool first = true;
+  const uint32_t k = key_of_id(my_id);
+  const bool valid = j < min(run_count(own), cap);
+  if (valid) {
+    for (int q = 0; q < n_runs; ++q) {
+      const int e = min(run_count(q), cap);
+      int lo = 0, hi = e;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (key_at(q, mid) < k) lo = mid + 1; else hi = mid;
+      }
+      pos += static_cast<uint32_t>(lo);
+      if (q < own && lo < e && key_at(q, lo) == k) {
+        ++pos;
+        first = false;
+      }
+    }
+  } else {
+    int n_valid = 0, pad_before = 0;
+    for (int q = 0; q < n_runs; ++q) {
+      const int c = min(run_count(q), cap);
+      n_valid += c;
+      if (q < own) pad_before += cap - c;
+    }
+    pos = static_cast<uint32_t>(n_valid + pad_before + (j - min(run_count(own), cap)));
+    first = false;
+  }
+  keys_out[pos] = valid ? k : kInvalidKey;
+  vals_out[pos] = static_cast<uint32_t>(i);  // (= vals_in[i]: a dense-mode lookup's entry index)
+  flags[pos] = first ? 1u : 0u;
+}
+
 // Serve the received keys: one lane group per sorted position that heads a run brings the row up to date (lazy
 // dense decay of TF-exact Adam: the catch-up of catch_up_body) and writes it to the reply slot of EVERY entry of
 // the run (at most one per requester), so each distinct row is read once.
@@ -2976,13 +3063,36 @@ __device__ __forceinline__ void dense_apply_body(int bid, const DenseApplyArgs& 
   }
 }
 
+__device__ __forceinline__ void dense_apply_block(int b, const DenseApplyMulti& ma) {
+  int i = 0;
+  while (i + 1 < ma.n && b >= ma.start[i + 1]) ++i;
+  const DenseApplyArgs& a = ma.a[i];
+  if (a.V == 4) dense_apply_body<4>(b - ma.start[i], a, ma.opt_kind, ma.hyper);
+  else dense_apply_body<1>(b - ma.start[i], a, ma.opt_kind, ma.hyper);
+}
+
 __global__ void __launch_bounds__(kBlock)
 emb_dense_apply_kernel(DenseApplyMulti ma) {
-  int i = 0;
-  while (i + 1 < ma.n && static_cast<int>(blockIdx.x) >= ma.start[i + 1]) ++i;
-  const DenseApplyArgs& a = ma.a[i];
-  if (a.V == 4) dense_apply_body<4>(blockIdx.x - ma.start[i], a, ma.opt_kind, ma.hyper);
-  else dense_apply_body<1>(blockIdx.x - ma.start[i], a, ma.opt_kind, ma.hyper);
+  dense_apply_block(blockIdx.x, ma);
+}
+
+// The end of an embedding-parallel step as ONE launch (er_emb_owner_update_tail): the owner update's cross-tile fix
+// (workgroups [0, n_fix)), the replicated tables' apply ([n_fix, n_fix + n_apply)) and the dense optimizer behind them -
+// three launches that depend on nothing of each other (owned rows | replicated tables | dense variables), each at the
+// 4-5 us floor of a launch.  Same bodies: bit-identical to the launches apart.
+__global__ void __launch_bounds__(kBlock)
+emb_bwd_fix_apply_opt_kernel(RunMulti fx, DenseApplyMulti am, DenseOptArgs da, int n_fix, int n_apply) {
+  __shared__ float red[4];
+  const int b = blockIdx.x;
+  if (b < n_fix) {
+    fix_block(b, fx);
+  } else if (b < n_fix + n_apply) {
+    dense_apply_block(b - n_fix, am);
+  } else {
+    GroupedReduceArgs none;
+    none.n = 0;  // (no k-split weight gradient is finished here: the requester's tail did that before the all-reduce)
+    dense_opt_block(da, none, b - n_fix - n_apply, red);
+  }
 }
 
 // Word fill used instead of hipMemsetAsync: inside a captured hipGraph a memset NODE was observed to lose its
@@ -3325,14 +3435,35 @@ static bool emb_group_same_keys(const er_emb_group* g, const er_emb_group* l);
 
 // Entry arrays (keys, gradient pointers, scales) of g - and, in the same launch, of the groups that share its sort
 // (they are about to adopt it: er_emb_group_share_sort).
+static int emb_group_build_prepare(er_emb_group* g, hipStream_t s, er::BuildMulti* out, er_emb_group** gs);
+
 static int emb_group_build(er_emb_group* g, hipStream_t s) {
   const int64_t N = group_entries(g);
   if (N == 0) return 0;
-  er_emb_group* gs[er::kMaxMulti] = {g};
+  er_emb_group* gs[er::kMaxMulti];
+  er::BuildMulti ma;
+  if (int rc = emb_group_build_prepare(g, s, &ma, gs)) return rc;
+  const int n = ma.n;
+  if (n == 1) {
+    hipLaunchKernelGGL(er::emb_bwd_build_kernel, dim3(g->n_build_blocks), dim3(er::kBlock), 0, s, ma.a[0].descs,
+                       ma.a[0].blk_start, ma.a[0].ent_base, ma.a[0].n_lookups, ma.a[0].rt, ma.a[0].n_active, ma.a[0].keys,
+                       ma.a[0].vals, ma.a[0].ent_gptr, ma.a[0].ent_scale);
+  } else {
+    hipLaunchKernelGGL(er::emb_bwd_build_multi_kernel, dim3(ma.start[n]), dim3(er::kBlock), 0, s, ma);
+  }
+  ER_LAUNCH_CHECK();
+  for (int i = 1; i < n; ++i) gs[i]->built_epoch = g->sort_epoch + 1;  // the sort that follows bumps the epoch
+  return 0;
+}
+
+// the build launch's record for g and the groups that share its sort (gs: the groups, g first); ragged groups' key fills
+// are launched here
+static int emb_group_build_prepare(er_emb_group* g, hipStream_t s, er::BuildMulti* out, er_emb_group** gs) {
+  gs[0] = g;
   int n = 1;
   for (er_emb_group* f : g->followers)
     if (n < er::kMaxMulti && group_entries(f) > 0 && emb_group_same_keys(f, g)) gs[n++] = f;
-  er::BuildMulti ma;
+  er::BuildMulti& ma = *out;
   ma.n = n;
   ma.start[0] = 0;
   for (int i = 0; i < n; ++i) {
@@ -3344,15 +3475,6 @@ static int emb_group_build(er_emb_group* g, hipStream_t s) {
                             q->n_active >= 0 ? q->n_active : INT64_MAX, q->keys_in, q->vals_in, q->ent_gptr, q->ent_scale};
     ma.start[i + 1] = ma.start[i] + q->n_build_blocks;
   }
-  if (n == 1) {
-    hipLaunchKernelGGL(er::emb_bwd_build_kernel, dim3(g->n_build_blocks), dim3(er::kBlock), 0, s, ma.a[0].descs,
-                       ma.a[0].blk_start, ma.a[0].ent_base, ma.a[0].n_lookups, ma.a[0].rt, ma.a[0].n_active, ma.a[0].keys,
-                       ma.a[0].vals, ma.a[0].ent_gptr, ma.a[0].ent_scale);
-  } else {
-    hipLaunchKernelGGL(er::emb_bwd_build_multi_kernel, dim3(ma.start[n]), dim3(er::kBlock), 0, s, ma);
-  }
-  ER_LAUNCH_CHECK();
-  for (int i = 1; i < n; ++i) gs[i]->built_epoch = g->sort_epoch + 1;  // the sort that follows bumps the epoch
   return 0;
 }
 
@@ -3605,7 +3727,8 @@ int er_emb_bwd_update(er_emb_group* g, int opt_kind, const er_opt_hyper* hyper, 
 // The reduce kernels of up to kMaxMulti groups side by side in one launch.  dense == nullptr: apply the optimizer
 // (er_emb_bwd_update_multi); else: the row sums go to dense[i][key * ld[i] ...] (er_emb_bwd_reduce_dense).
 static int emb_groups_run_multi(er_emb_group* const* groups, int n, int opt_kind, const er_opt_hyper* hyper,
-                                float* const* dense, const int32_t* ld, er_stream_t stream) {
+                                float* const* dense, const int32_t* ld, er_stream_t stream,
+                                const er::DenseApplyMulti* rider_apply = nullptr, const er::DenseOptArgs* rider_opt = nullptr) {
   hipStream_t s = er::as_stream(stream);
   er::RunMulti ma;
   ma.n = 0;
@@ -3660,11 +3783,22 @@ static int emb_groups_run_multi(er_emb_group* const* groups, int n, int opt_kind
   if (ma.n > 0) {
     hipLaunchKernelGGL(er::emb_bwd_tile_multi_kernel, dim3(ma.start[ma.n]), dim3(er::kBlock), lds, s, ma);
     ER_LAUNCH_CHECK();
-    if (any_fix) {
-      for (int i = 0; i <= ma.n; ++i) ma.start[i] = fix_start[i];
-      hipLaunchKernelGGL(er::emb_bwd_fix_multi_kernel, dim3(ma.start[ma.n]), dim3(er::kBlock), 0, s, ma);
-      ER_LAUNCH_CHECK();
-    }
+  }
+  if (rider_opt) {  // (er_emb_owner_update_tail) the fix launch also carries the replicated tables' apply and the dense optimizer
+    for (int i = 0; i <= ma.n; ++i) ma.start[i] = fix_start[i];
+    const int n_fix = (ma.n > 0 && any_fix) ? ma.start[ma.n] : 0;
+    const int n_apply = (rider_apply && rider_apply->n > 0) ? rider_apply->start[rider_apply->n] : 0;
+    const int n_opt = static_cast<int>(er::ceil_div(rider_opt->n, er::kBlock));
+    er::DenseApplyMulti am;
+    if (n_apply > 0) am = *rider_apply;
+    else am.n = 0;
+    hipLaunchKernelGGL(er::emb_bwd_fix_apply_opt_kernel, dim3(n_fix + n_apply + n_opt), dim3(er::kBlock), 0, s, ma, am,
+                       *rider_opt, n_fix, n_apply);
+    ER_LAUNCH_CHECK();
+  } else if (ma.n > 0 && any_fix) {
+    for (int i = 0; i <= ma.n; ++i) ma.start[i] = fix_start[i];
+    hipLaunchKernelGGL(er::emb_bwd_fix_multi_kernel, dim3(ma.start[ma.n]), dim3(er::kBlock), 0, s, ma);
+    ER_LAUNCH_CHECK();
   }
   for (int i = 0; i < n && !dense; ++i) {  // TF-exact Adam with the streaming sweep: per group, as er_emb_bwd_update
     er_emb_group* g = groups[i];
@@ -3734,6 +3868,10 @@ static int launch_decay_tables(er_emb_group* const* groups, int n, int lag, hipS
     for (int j = 0; j < n_done; ++j) seen = seen || done[j] == t;
     if (seen) continue;
     if (n_done < er::kMaxMulti) done[n_done++] = t;
+    if (lag == 1 && t->lag1_built) {  // (a rider of an earlier launch of this step built it: er_emb_owner_ids_merge)
+      const_cast<er_decay_tables*>(t)->lag1_built = false;
+      continue;
+    }
     const int blocks = static_cast<int>(er::ceil_div(static_cast<int64_t>(t->dev.K) * er::kWave, er::kBlock));
     hipLaunchKernelGGL(er::decay_tables_kernel, dim3(blocks), dim3(er::kBlock), 0, s, t->dev, t->hist, t->counter, lag);
     ER_LAUNCH_CHECK();
@@ -4849,6 +4987,48 @@ int er_emb_owner_ids(const uint32_t* recv_keys, const int32_t* counts, int n_run
   return 0;
 }
 
+int er_emb_owner_ids_merge(er_emb_group* g, const uint32_t* recv_keys, const int32_t* counts, int n_runs, int64_t peer_cap,
+                           int64_t key_sub, int64_t* ids, int32_t* counts_out, int build_lag1_tables, er_stream_t stream) {
+  ER_REQUIRE(g && recv_keys && ids && (counts || counts_out) && n_runs >= 1 && peer_cap > 0 &&
+                 n_runs * (peer_cap + 1) < 0x7FFFFFFFLL,
+             "er_emb_owner_ids_merge: bad arguments");
+  ER_REQUIRE(g->n == 1 && !g->has_ragged && !g->d_local_base && !g->leader && g->n_active < 0,
+             "er_emb_owner_ids_merge: needs a group of ONE dense-mode lookup, all rows active, following no group");
+  ER_REQUIRE(g->n_entries == n_runs * peer_cap, "er_emb_owner_ids_merge: the group holds %lld rows, not %d x %lld",
+             (long long)g->n_entries, n_runs, (long long)peer_cap);
+  ER_REQUIRE(g->h_descs[0].ids == ids && !g->h_descs[0].offsets && !g->h_descs[0].weights,
+             "er_emb_owner_ids_merge: the group's lookup must read `ids` (dense mode, unweighted)");
+  hipStream_t s = er::as_stream(stream);
+  er_emb_group* gs[er::kMaxMulti];
+  er::BuildMulti bm;
+  if (int rc = emb_group_build_prepare(g, s, &bm, gs)) return rc;
+  const int n_main = static_cast<int>(er::ceil_div(g->n_entries, er::kBlock));
+  for (int i = 0; i < bm.n; ++i)
+    ER_REQUIRE(gs[i]->n_build_blocks == n_main && !gs[i]->has_ragged,
+               "er_emb_owner_ids_merge: group %d of the shared sort does not have the leader's entries", i);
+  for (int i = 1; i < bm.n; ++i) gs[i]->built_epoch = g->sort_epoch + 1;
+  g->src = g;
+  ++g->sort_epoch;
+  er::DecayTabDev tabs{};
+  const float* hist = nullptr;
+  const int64_t* counter = nullptr;
+  int n_tab = 0;
+  if (build_lag1_tables && g->tabs) {
+    tabs = g->tabs->dev;
+    hist = g->tabs->hist;
+    counter = g->tabs->counter;
+    n_tab = static_cast<int>(er::ceil_div(static_cast<int64_t>(tabs.K) * er::kWave, er::kBlock));
+    g->tabs->lag1_built = true;  // (consumed by the er_emb_owner_serve that follows on this stream)
+  }
+  hipLaunchKernelGGL(er::emb_owner_ids_merge_kernel, dim3(static_cast<unsigned>(n_main + n_tab)), dim3(er::kBlock), 0, s,
+                     recv_keys, counts, n_runs, static_cast<int>(peer_cap), counts ? 0 : 1, key_sub, ids, counts_out, bm, n_main,
+                     g->keys_out, g->vals_out, g->head_flags, tabs, hist, counter);
+  ER_LAUNCH_CHECK();
+  g->merged_epoch = g->sort_epoch;
+  g->sorted_valid = true;
+  return 0;
+}
+
 int er_emb_owner_merge_padded(er_emb_group* g, const int32_t* counts, int n_runs, int64_t peer_cap, er_stream_t stream) {
   ER_REQUIRE(g && counts && n_runs >= 1 && peer_cap > 0, "er_emb_owner_merge_padded: bad arguments");
   ER_REQUIRE(g->n == 1 && !g->has_ragged && !g->d_local_base && !g->leader && g->n_active < 0,
@@ -4908,18 +5088,22 @@ int er_emb_owner_serve(er_emb_group* const* groups, float* const* rows_out, cons
   if (ma.n == 0) return 0;
   if (hyper) {  // (serve_body brings the rows to step *counter - 1)
     if (int rc = launch_decay_tables(groups, n, 1, s)) return rc;
+  } else {
+    for (int i = 0; i < n; ++i)
+      if (groups[i] && groups[i]->tabs) groups[i]->tabs->lag1_built = false;
   }
   hipLaunchKernelGGL(er::emb_owner_serve_kernel, dim3(ma.start[ma.n]), dim3(er::kBlock), 0, s, ma);
   ER_LAUNCH_CHECK();
   return 0;
 }
 
-int er_emb_dense_apply(const er_dense_apply_desc* descs, int n, int opt_kind, const er_opt_hyper* hyper,
-                       er_stream_t stream) {
+// er_emb_dense_apply's argument checks and launch record
+static int make_dense_apply_multi(const er_dense_apply_desc* descs, int n, int opt_kind, const er_opt_hyper* hyper,
+                                  er::DenseApplyMulti* out) {
   ER_REQUIRE(descs && hyper && n >= 1 && n <= er::kMaxMulti, "er_emb_dense_apply: bad arguments (1 <= n <= %d)",
              er::kMaxMulti);
   ER_REQUIRE(opt_kind >= ER_OPT_SGD && opt_kind <= ER_OPT_ADAGRAD, "er_emb_dense_apply: unknown optimizer %d", opt_kind);
-  er::DenseApplyMulti ma;
+  er::DenseApplyMulti& ma = *out;
   ma.n = 0;
   ma.start[0] = 0;
   ma.opt_kind = opt_kind;
@@ -4939,10 +5123,34 @@ int er_emb_dense_apply(const er_dense_apply_desc* descs, int n, int opt_kind, co
     ma.start[ma.n + 1] = ma.start[ma.n] + static_cast<int>(er::ceil_div(d.rows * a.G, er::kBlock));
     ++ma.n;
   }
+  return 0;
+}
+
+int er_emb_dense_apply(const er_dense_apply_desc* descs, int n, int opt_kind, const er_opt_hyper* hyper,
+                       er_stream_t stream) {
+  er::DenseApplyMulti ma;
+  if (int rc = make_dense_apply_multi(descs, n, opt_kind, hyper, &ma)) return rc;
   if (ma.n == 0) return 0;
   hipLaunchKernelGGL(er::emb_dense_apply_kernel, dim3(ma.start[ma.n]), dim3(er::kBlock), 0, er::as_stream(stream), ma);
   ER_LAUNCH_CHECK();
   return 0;
+}
+
+int er_emb_owner_update_tail(er_emb_group* const* groups, int n, int opt_kind, const er_opt_hyper* hyper,
+                             const er_dense_apply_desc* descs, int n_apply, const er_dense_opt_job* dense_opt,
+                             er_stream_t stream) {
+  ER_REQUIRE(groups && hyper && dense_opt && n >= 1 && n <= er::kMaxMulti && n_apply >= 0 && n_apply <= er::kMaxMulti &&
+                 (n_apply == 0 || descs),
+             "er_emb_owner_update_tail: bad arguments (1 <= n <= %d groups, <= %d replicated tables, a dense optimizer job)",
+             er::kMaxMulti, er::kMaxMulti);
+  ER_REQUIRE(opt_kind >= ER_OPT_SGD && opt_kind <= ER_OPT_ADAGRAD, "er_emb_owner_update_tail: unknown optimizer %d", opt_kind);
+  er::DenseApplyMulti am;
+  am.n = 0;
+  if (n_apply > 0)
+    if (int rc = make_dense_apply_multi(descs, n_apply, opt_kind, hyper, &am)) return rc;
+  er::DenseOptArgs da;
+  if (int rc = er::make_dense_opt_args(dense_opt, &da)) return rc;
+  return emb_groups_run_multi(groups, n, opt_kind, hyper, nullptr, nullptr, stream, &am, &da);
 }
 
 int er_scatter_unique(const uint32_t* keys, const float* grads, const int32_t* n_unique, int64_t capacity, int32_t dim,

@@ -1274,6 +1274,18 @@ class HipBackend(object):
                                        ctypes.c_int64(int(peer_cap)), ctypes.c_int64(int(key_sub)), _p(ids), _p(counts_out),
                                        _stream()), 'er_emb_owner_ids')
 
+  # owner ids + entry build + merge (+ the serve launch's lag-1 replay table) as one launch - A/B switch
+  ep_owner_fused = os.environ.get('EASYREC_AMD_EP_OWNER_FUSED', '1') != '0'
+
+  def emb_owner_ids_merge(self, group, recv_keys, n_runs, peer_cap, key_sub, ids, counts_out, build_tables):
+    """er_emb_owner_ids_merge: emb_owner_ids (runs with their count in front) + emb_owner_merge_padded in one launch."""
+    assert recv_keys.dtype == torch.int32 and ids.dtype == torch.int64 and counts_out.dtype == torch.int32
+    assert recv_keys.numel() >= n_runs * (peer_cap + 1) and ids.numel() >= n_runs * peer_cap and counts_out.numel() >= n_runs
+    self._ck(self.lib.er_emb_owner_ids_merge(group['handle'], _p(recv_keys), None, ctypes.c_int(n_runs),
+                                             ctypes.c_int64(int(peer_cap)), ctypes.c_int64(int(key_sub)), _p(ids),
+                                             _p(counts_out), ctypes.c_int(1 if build_tables else 0), _stream()),
+             'er_emb_owner_ids_merge')
+
   def emb_owner_merge_padded(self, group, counts, n_runs, peer_cap):
     assert counts.dtype == torch.int32 and counts.numel() >= n_runs
     self._ck(self.lib.er_emb_owner_merge_padded(group['handle'], _p(counts), ctypes.c_int(n_runs),
@@ -2414,6 +2426,28 @@ class HipBackend(object):
     gh = (ctypes.c_void_p * n)(*[g['handle'] for g in groups])
     self._ck(self.lib.er_emb_bwd_update_multi(gh, n, ctypes.c_int(opt_kind), _p(hyper), _stream()),
              'er_emb_bwd_update_multi')
+
+  # the end of an embedding-parallel step - owner fix | replicated apply | dense optimizer - as one launch - A/B switch
+  ep_update_tail = os.environ.get('EASYREC_AMD_EP_UPDATE_TAIL', '1') != '0'
+
+  def emb_owner_update_tail(self, groups, opt_kind, hyper, tables, dense_opt):
+    """er_emb_owner_update_tail: emb_bwd_update_multi(groups) whose fix launch also carries emb_dense_apply(tables) and
+    dense_opt_step(*dense_opt) (dense_opt = (w, m, v, grad, l2coef, kind, hyper, l2_partials)); <= 4 groups, <= 4 tables."""
+    n, nt = len(groups), len(tables)
+    gh = (ctypes.c_void_p * n)(*[g['handle'] for g in groups])
+    descs = (DenseApplyDesc * max(nt, 1))()
+    for i, (var, m, v, dense) in enumerate(tables):
+      assert var.stride(1) == 1 and dense.stride(1) == 1 and dense.shape[0] == var.shape[0]
+      assert all(t is None or t.stride() == var.stride() for t in (m, v))
+      descs[i] = DenseApplyDesc(var.data_ptr(), None if m is None else m.data_ptr(), None if v is None else v.data_ptr(),
+                                dense.data_ptr(), dense.stride(0), var.shape[1], var.shape[0], var.stride(0))
+    w, m, v, grad, l2coef, kind, hyp, l2p = dense_opt
+    oj = DenseOptJob(_ptr(w), _ptr(m), _ptr(v), _ptr(grad), _ptr(l2coef), w.numel(), int(kind), _ptr(hyp), _ptr(l2p))
+    self._ck(self.lib.er_emb_owner_update_tail(gh, n, ctypes.c_int(opt_kind), _p(hyper), descs if nt else None, nt,
+                                               ctypes.byref(oj), _stream()), 'er_emb_owner_update_tail')
+    st = self._bf16_state_of(w)
+    if st is not None:
+      st.refresh()  # the weights' bf16 shadows follow the masters (one launch)
 
   def emb_flush_decay(self, group, hyper):
     self._ck(self.lib.er_emb_flush_decay(group['handle'], _p(hyper), _stream()), 'er_emb_flush_decay')

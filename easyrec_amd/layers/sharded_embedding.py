@@ -355,12 +355,17 @@ class ShardedEmbeddingEngine(EmbeddingEngine):
     """Received keys -> local rows, merged order, caught-up rows written to the reply buffers (static launches)."""
     be, W = kernels.hip(), self.world
     shs = list(self.shard.values())
-    for sh in shs:
-      if sh['leader'] is None:
-        be.emb_owner_ids(sh['recv_keys'], None, W, sh['peer_cap'], self.rank * sh['stride'], sh['recv_ids'], sh['recv_cnt'])
-        be.emb_owner_merge_padded(sh['owner'], sh['recv_cnt'], W, sh['peer_cap'])
     # (inference: the rows were flushed by begin_inference(); serving them must not replay anything)
     hyper = self._clock[2] if (any(sh['lazy'] is not None for sh in shs) and not self.inference) else None
+    fused = getattr(be, 'ep_owner_fused', False)
+    for sh in shs:
+      if sh['leader'] is None:
+        if fused:  # one launch; it also builds the lag-1 replay table the serve launch below reads
+          be.emb_owner_ids_merge(sh['owner'], sh['recv_keys'], W, sh['peer_cap'], self.rank * sh['stride'], sh['recv_ids'],
+                                 sh['recv_cnt'], hyper is not None and len(shs) <= 4)
+        else:
+          be.emb_owner_ids(sh['recv_keys'], None, W, sh['peer_cap'], self.rank * sh['stride'], sh['recv_ids'], sh['recv_cnt'])
+          be.emb_owner_merge_padded(sh['owner'], sh['recv_cnt'], W, sh['peer_cap'])
     for i in range(0, len(shs), 4):
       be.emb_owner_serve([sh['owner'] for sh in shs[i:i + 4]], [sh['rows_out'] for sh in shs[i:i + 4]], hyper)
 

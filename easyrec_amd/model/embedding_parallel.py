@@ -217,7 +217,18 @@ class EmbeddingParallelEstimator(EasyRecEstimator):
   def _phase_update(self):
     if self.clip_norm > 0:
       self._clip_from_reduced()
-    self.engine.owner_update(self.opt_emb.kind, self.hyper[0])
+    be, eng, vs = kernels.hip(), self.engine, self.varstore
+    owners = [sh['owner'] for sh in eng.shard.values()]
+    if getattr(be, 'ep_update_tail', False) and 1 <= len(owners) <= 4 and len(eng.rep) <= 4:
+      # the owners' row update; its second launch also carries the replicated tables' apply and the dense optimizer
+      # (er_emb_owner_update_tail: same bodies, bit-identical to owner_update + _phase_apply)
+      tables = [(r['st']['var'], r['st']['m'], r['st']['v'], r['dense']) for r in eng.rep.values()]
+      be.emb_owner_update_tail(owners, self.opt_emb.kind, self.hyper[0], tables,
+                               (vs.flat, vs.slots.get('m'), vs.slots.get('v'), vs.flat_grad,
+                                vs.l2coef if vs.any_l2 else None, self.opt_dense.kind, self.hyper[1], vs.l2_partials))
+      eng._roll_flush(self.hyper[0])
+      return
+    eng.owner_update(self.opt_emb.kind, self.hyper[0])
     self._phase_apply()
 
   def _compact_exchange_and_update(self):

@@ -1170,12 +1170,30 @@ int er_emb_owner_ids(const uint32_t* recv_keys, const int32_t* counts, int n_run
                      int64_t* ids, int32_t* counts_out, er_stream_t stream);
 int er_emb_owner_merge_padded(er_emb_group* group, const int32_t* counts, int n_runs, int64_t peer_cap,
                               er_stream_t stream);
+/* er_emb_owner_ids + er_emb_owner_merge_padded (with the entry build in front of it) as ONE launch: the key of any received
+ * slot follows from the received runs themselves, so the merge's searches read those and nothing waits for another
+ * workgroup's build; every array the three launches leave (ids, counts_out, the groups' entry arrays, the merged keys / entry
+ * indices / head flags) is left bit for bit.  The group's one lookup must read `ids`.  build_lag1_tables != 0: workgroups
+ * behind the merge's build the closed-form replay's lag-1 table, and the er_emb_owner_serve that follows on the stream does
+ * not launch its own build. */
+int er_emb_owner_ids_merge(er_emb_group* group, const uint32_t* recv_keys, const int32_t* counts, int n_runs,
+                           int64_t peer_cap, int64_t key_sub, int64_t* ids, int32_t* counts_out, int build_lag1_tables,
+                           er_stream_t stream);
 int er_emb_owner_serve(er_emb_group* const* groups_host, float* const* rows_out_host, const int32_t* ld_host,
                        int n, const er_opt_hyper* hyper, er_stream_t stream);
 int er_emb_bwd_reduce_dense(er_emb_group* const* groups_host, float* const* dense_host, const int32_t* ld_host,
                             int n, er_stream_t stream);
 int er_emb_dense_apply(const er_dense_apply_desc* descs_host, int n, int opt_kind, const er_opt_hyper* hyper,
                        er_stream_t stream);
+/* The end of an embedding-parallel step as TWO launches: er_emb_bwd_update_multi(groups) - the owners' row update (reference
+ * compat/optimizers.py:285-345: the optimizer applied to the summed IndexedSlices an owner received) - whose second launch
+ * (the cross-tile fix) also carries er_emb_dense_apply(descs, n_apply) - the replicated tables after the all-reduce - and
+ * er_dense_opt_step_l2(*dense_opt) - the dense variables - as further workgroup ranges: owned rows, replicated tables and
+ * dense variables are disjoint, the bodies are the three launches' own, every bit of the result is theirs.  n_apply may be
+ * 0; both row optimizers take (opt_kind, hyper), the dense one what its job says. */
+int er_emb_owner_update_tail(er_emb_group* const* groups_host, int n, int opt_kind, const er_opt_hyper* hyper,
+                             const er_dense_apply_desc* descs_host, int n_apply, const er_dense_opt_job* dense_opt,
+                             er_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
  * Dense-variable optimizer: one launch over the flat parameter buffer.  Replaces ApplyAdam /

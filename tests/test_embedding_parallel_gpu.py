@@ -566,3 +566,96 @@ def test_merged_requester_tail_changes_no_bit(world, monkeypatch):
     assert la == lb, (la, lb)
     for k in sb:
       assert np.array_equal(sa[k], sb[k]), k
+
+
+@pytest.mark.parametrize('switch', ['ep_update_tail', 'ep_owner_fused'])
+@pytest.mark.parametrize('world,config', [(1, 'deepfm_criteo_small.config'), (2, 'deepfm_criteo_small.config'),
+                                          (4, 'deepfm_criteo_small.config'), (2, 'mmoe_taobao_small.config')])
+def test_merged_owner_launches_change_no_bit(world, config, switch, monkeypatch):
+  """ep_update_tail: the end of the embedding-parallel step as two launches (er_emb_owner_update_tail: the owners' row update
+  whose cross-tile fix launch also carries the replicated tables' apply and the dense optimizer) against the four launches
+  apart (er_emb_bwd_update_multi, er_emb_dense_apply, er_dense_opt_step_l2).  ep_owner_fused: owner ids + entry build + merge
+  + the serve launch's lag-1 replay table as one launch (er_emb_owner_ids_merge) against the four apart.  Ranks as threads
+  on different batches, every loss, table, slot and dense variable bit-identical over three steps."""
+  cfg = _cfg(config)
+  B, steps = 128, 3
+  if 'criteo' in config:
+    gens = [SyntheticCriteo(cfg.data_config, list(cfg.feature_config.features), batch_size=B, seed=30 + r) for r in range(world)]
+  else:
+    from easyrec_amd.input.synthetic import SyntheticBatches
+    from easyrec_amd.utils import config_util
+    fcs = config_util.get_compatible_feature_configs(cfg)
+    gens = [SyntheticBatches(cfg.data_config, fcs, batch_size=B, seed=30 + r) for r in range(world)]
+  batches = [[g.next_batch() for _ in range(steps)] for g in gens]
+
+  def run(merged):
+    monkeypatch.setattr(kernels.HipBackend, switch, merged)
+    sim = SimWorld(world)
+
+    def rank_fn(rank, comm):
+      torch.cuda.set_device(0)
+      est = EmbeddingParallelEstimator(cfg, device=DEV, batch_size=B, seed=4, rank=rank, world=world, comm=comm,
+                                       replicate_bytes=1024).build()
+      losses = []
+      for b in batches[rank]:
+        est.train_step(b)
+        losses.append(est.loss_values())
+      return est.state_dict(slots=True), losses
+
+    return sim.run(rank_fn)
+
+  a, b = run(True), run(False)
+  for (sa, la), (sb, lb) in zip(a, b):
+    assert la == lb, (la, lb)
+    for k in sb:
+      assert np.array_equal(sa[k], sb[k]), k
+
+
+@pytest.mark.parametrize('counts', [[700], [300, 0, 450, 1, 0], [64, 64, 64, 64], [2000, 1500, 1800, 1700, 1600, 1900, 1400, 1300]])
+def test_owner_ids_merge_equals_the_launches_apart(counts):
+  """er_emb_owner_ids_merge (owner ids + entry build + merge in one launch, the merge searching the RECEIVED runs) against
+  er_emb_owner_ids + er_emb_owner_merge_padded on twin owner groups: runs of different lengths (empty, one key, filled to
+  the capacity), keys shared between runs, one id outside the table - the ids, the counts, the rows the serve launch
+  replies and the table after an SGD row update are bit-identical."""
+  hip = kernels.hip()
+  rng = np.random.default_rng(sum(counts))
+  W, dim, stride = len(counts), 16, 5000
+  C = max(counts)
+  me = W // 2
+  recv = np.zeros((W, C + 1), dtype=np.int64)
+  for q, c in enumerate(counts):
+    ks = np.sort(rng.choice(stride, size=c, replace=False)) + me * stride
+    recv[q, 0] = c
+    recv[q, 1:1 + c] = ks
+    recv[q, 1 + c:] = rng.integers(0, 1 << 20, size=C - c)  # (stale padding)
+  if counts[0] > 2:
+    recv[0, counts[0]] = me * stride + stride + 3  # an id past the table: its entry carries the invalid key
+  recv_t = torch.from_numpy(recv.astype(np.int32).reshape(-1)).to(DEV)
+  table = torch.from_numpy(rng.standard_normal((stride, dim)).astype(np.float32)).to(DEV)
+  rgrads = torch.from_numpy(rng.standard_normal((W * C, dim)).astype(np.float32)).to(DEV)
+  hyper = torch.zeros(16, dtype=torch.float32)
+  hyper[kernels.HYPER_LR], hyper[kernels.HYPER_GSCALE] = 0.1, 1.0
+  hyper = hyper.to(DEV)
+  res = []
+  for fused in (False, True):
+    rids = torch.zeros(W * C, dtype=torch.int64, device=DEV)
+    rcnt = torch.zeros(W, dtype=torch.int32, device=DEV)
+    var = table.clone()
+    ospec = kernels.LookupSpec(table=var, ids=rids, offsets=None, weights=None, out=rgrads, out_col=0, rows=stride, key_base=0,
+                               dim=dim, combiner=0, n_rows=W * C, max_nnz=W * C)
+    og = hip.emb_group_create([ospec], dim, stride, var, None, None, None)
+    if fused:
+      hip.emb_owner_ids_merge(og, recv_t, W, C, me * stride, rids, rcnt, False)
+    else:
+      hip.emb_owner_ids(recv_t, None, W, C, me * stride, rids, rcnt)
+      hip.emb_owner_merge_padded(og, rcnt, W, C)
+    rows_out = torch.full((W * C, dim), 7.0, device=DEV)
+    hip.emb_owner_serve([og], [rows_out], None)
+    hip.emb_bwd_update(og, kernels.OPT_SGD, hyper)
+    torch.cuda.synchronize()
+    res.append((rids.cpu().numpy(), rcnt.cpu().numpy(), rows_out.cpu().numpy(), var.cpu().numpy()))
+    hip.emb_group_destroy(og)
+  assert np.array_equal(res[0][1], counts)
+  for a, b, what in zip(res[0], res[1], ('ids', 'counts', 'served rows', 'table after the update')):
+    assert np.array_equal(a, b), what
+  assert not np.array_equal(res[0][3], table.cpu().numpy())
