@@ -1636,3 +1636,54 @@ def test_bn_apply_wide_fm_equals_the_two_launches(B, K, N, n_w, F, D):
   assert torch.equal(pend['y'], y1) and torch.equal(pend['mean'], mean1) and torch.equal(pend['invstd'], inv1)
   assert torch.equal(mm2, mm1) and torch.equal(mv2, mv1)
   assert out2.shape == out1.shape and torch.equal(out2, out1) and torch.equal(S2, S1)
+
+
+def _misaligned(t):
+  """a copy of t whose base address is 4 bytes past a 16-byte boundary (the library then takes its generic fetch path)"""
+  buf = torch.empty(t.numel() + 5, dtype=t.dtype, device=t.device)
+  off = 1 + ((4 - (buf.data_ptr() // 4) % 4) % 4)
+  assert (buf.data_ptr() + 4 * off) % 16 == 4
+  out = buf[off:off + t.numel()].view(t.shape)
+  out.copy_(t)
+  return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('M,K,N,ldk', [(4096, 256, 128, 256), (4096, 128, 64, 128), (4096, 81, 256, 84), (100, 64, 37, 64),
+                                      (1000, 224, 200, 224), (333, 32, 64, 40)])
+def test_panel_gemm_equals_the_tile_loop_bit_for_bit(M, K, N, ldk):
+  """The panel form of short contractions (gemm_f32_panel_kernel: K <= 256, B's panel staged once, A's fragments straight to
+  registers, one barrier) against the library's k-tile loop, which an operand 4 bytes off a 16-byte boundary selects: the
+  forward contraction with bias and BatchNorm column statistics (NN) and the input-gradient contraction with the
+  BatchNorm-backward column sums in its epilogue (NT) - same fragments, same order, every output bit-identical."""
+  hip = kernels.hip()
+  g = torch.Generator().manual_seed(M + K + N)
+  xbuf = torch.randn(M, ldk, generator=g).to(DEV)  # (K of its ldk columns: the padding must not be read as operand)
+  xbuf[:, K:] = float('nan')
+  x = xbuf[:, :K]
+  w = (torch.randn(K, N, generator=g) * 0.2).to(DEV)
+  bias = torch.randn(N, generator=g).to(DEV)
+  chunks = hip.gemm_row_tiles(M)
+  s1, s2 = torch.zeros(chunks * N * 3, device=DEV), torch.zeros(chunks * N * 3, device=DEV)
+  if N % 4 == 0:
+    z1 = hip.gemm(kernels.GEMM_NN, x, w, bias=bias, col_stats=s1)
+    z2 = hip.gemm(kernels.GEMM_NN, x, _misaligned(w), bias=bias, col_stats=s2)
+    assert torch.equal(z1, z2) and torch.equal(s1, s2)
+    ref = x.double() @ w.double() + bias.double()
+    assert float((z1.double() - ref).abs().max()) < 1e-4 * max(1.0, float(ref.abs().max()))
+  # input gradient: dx = dz . w^T (NT, contraction over N) with the BatchNorm-backward sums of x's producer
+  if N <= 256 and N % 4 == 0 and K % 4 == 0:
+    dz = torch.randn(M, N, generator=g).to(DEV)
+    zsrc = torch.randn(M, K, generator=g).to(DEV)
+    ysrc = torch.relu(zsrc + 0.1)
+    mean, inv = torch.randn(K, generator=g).to(DEV) * 0.1, (torch.rand(K, generator=g) + 0.5).to(DEV)
+    wk = w.contiguous()
+    outs = []
+    for wt in (wk, _misaligned(wk)):
+      src = kernels.BnSource(zsrc, None, ysrc, mean, inv, kernels.ACT_RELU)
+      part = torch.zeros(chunks * K * 2, device=DEV)
+      dx = hip.gemm_bn_bwd(kernels.GEMM_NT, dz, wt, src, part)
+      outs.append((dx, part))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    ref = dz.double() @ wk.double().t()
+    assert float((outs[0][0].double() - ref).abs().max()) < 1e-4 * max(1.0, float(ref.abs().max()))
