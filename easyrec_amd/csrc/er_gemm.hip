@@ -39,15 +39,6 @@ gemm_f32_bn_bwd_kernel(GemmArgs g) {
   gemm_f32_block<A_KC, B_KC, true>(g, blockIdx.x, 0, lds);
 }
 
-// short contractions (K <= 32 * PANEL, NN / NT): B's panel staged once, A's fragments straight to registers, one barrier
-// (gemm_f32_block, PANEL); PANEL operand tiles of dynamic LDS
-template <bool B_KC, bool BN_EPI, int PANEL>
-__global__ void __launch_bounds__(kBlock)
-gemm_f32_panel_kernel(GemmArgs g) {
-  extern __shared__ __attribute__((aligned(16))) float panel_lds[];
-  gemm_f32_block<true, B_KC, BN_EPI, 0, 0, PANEL>(g, blockIdx.x, 0, panel_lds);
-}
-
 // ... with the DCN-v2 cross layer's elementwise part in the epilogue (er_gemm_f32_cross)
 template <bool A_KC, bool B_KC, int XEPI>
 __global__ void __launch_bounds__(kBlock)
@@ -240,25 +231,6 @@ int ensure_ws(size_t floats, float** out) {
   return 0;
 }
 
-// the panel form of short contractions (gemm_f32_panel_kernel) - A/B knob
-bool panel_enabled() {
-  static const bool on = [] {
-    const char* e = getenv("ER_GEMM_PANEL");
-    return !(e && e[0] == '0');
-  }();
-  return on;
-}
-// ... for launches of at most this many output tiles: the form keeps 130 - 260 registers and 37 - 74 KB of LDS per workgroup,
-// ONE workgroup per compute unit - what a launch of <= 256 tiles has anyway; a larger one wants its workgroups co-resident
-int64_t panel_max_tiles() {
-  static const int64_t v = [] {
-    const char* e = getenv("ER_GEMM_PANEL_TILES");
-    const int64_t x = e ? atoll(e) : 0;
-    return x >= 1 ? x : 256;
-  }();
-  return v;
-}
-
 template <bool BF16>
 int launch_gemm(int layout, er::GemmArgs& a, hipStream_t s) {
   const int64_t n_tiles = er::ceil_div(a.N, er::BN) * er::ceil_div(a.M, er::BM);
@@ -270,33 +242,6 @@ int launch_gemm(int layout, er::GemmArgs& a, hipStream_t s) {
     case ER_GEMM_NT: hipLaunchKernelGGL((KERNEL<true, true>), grid, block, 0, s, a); break;   \
     case ER_GEMM_TN: hipLaunchKernelGGL((KERNEL<false, false>), grid, block, 0, s, a); break; \
     default: er::set_error("er_gemm: unknown layout %d", layout); return 2;     \
-  }
-  if (!BF16 && layout != ER_GEMM_TN && a.splits == 1 && a.K <= 8 * er::BK32 && panel_enabled() && n_tiles <= panel_max_tiles() &&
-      a.lda % 4 == 0 && a.ldb % 4 == 0 && ((reinterpret_cast<uintptr_t>(a.A) | reinterpret_cast<uintptr_t>(a.B)) & 15) == 0) {
-    // a short contraction: the panel form (gemm_f32_block, PANEL) - same bits as the pipelined loop
-    const bool kc = layout == ER_GEMM_NT, bn = a.bn.partial != nullptr;
-    const int panel = a.K <= 4 * er::BK32 ? 4 : 8;
-    const size_t lds = sizeof(float) * static_cast<size_t>(panel) * er::kOpTile;
-#define ER_LAUNCH_PANEL(B_KC, BN, P)                                                                                  \
-  {                                                                                                                   \
-    static bool sized = false; /* (> 64 KB of LDS per workgroup needs the attribute; set once, before any capture) */   \
-    if (!sized) {                                                                                                     \
-      ER_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&er::gemm_f32_panel_kernel<B_KC, BN, P>),         \
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));           \
-      sized = true;                                                                                                   \
-    }                                                                                                                 \
-    hipLaunchKernelGGL((er::gemm_f32_panel_kernel<B_KC, BN, P>), grid, block, lds, s, a);                            \
-  }
-    if (panel == 4) {
-      if (kc) { if (bn) ER_LAUNCH_PANEL(true, true, 4) else ER_LAUNCH_PANEL(true, false, 4) }
-      else { if (bn) ER_LAUNCH_PANEL(false, true, 4) else ER_LAUNCH_PANEL(false, false, 4) }
-    } else {
-      if (kc) { if (bn) ER_LAUNCH_PANEL(true, true, 8) else ER_LAUNCH_PANEL(true, false, 8) }
-      else { if (bn) ER_LAUNCH_PANEL(false, true, 8) else ER_LAUNCH_PANEL(false, false, 8) }
-    }
-#undef ER_LAUNCH_PANEL
-    ER_LAUNCH_CHECK();
-    return 0;
   }
   if (BF16) {
     ER_LAUNCH_GEMM(er::gemm_bf16_kernel)

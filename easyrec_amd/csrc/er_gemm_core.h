@@ -437,13 +437,7 @@ __device__ __forceinline__ void fetch_tile_din_perm(const float* __restrict__ P,
 // lane's 16 output positions is requested before the k loop.
 // DIN: 1 = the A operand is DinGen's generated block (forward NN, weight gradient TN); 2 = the input-gradient contraction
 // (NT) with permuted B rows and the epilogue that reduces dcat to dh / dq partials (nothing is stored to C).
-// PANEL (4 | 8): the whole contraction has at most PANEL k-tiles (K <= 32 * PANEL, one split, A's k contiguous, aligned
-// operands): B's panel - every k-tile of the tile's 64 columns - is staged into PANEL LDS stages ONCE, a lane's A fragments
-// (16 consecutive k of ONE row per k-tile: four 16-byte loads) go straight from memory to registers, one barrier, then the
-// MFMAs run from registers and ds_read_b128 alone: no per-k-tile barrier, no staging inside the contraction.  Every load
-// of the launch is in flight before the first MFMA.  Same fragments, same order of the 16 steps per k-tile: the result is
-// the pipelined loop's bit for bit.  `lds` must hold PANEL operand tiles.
-template <bool A_KC, bool B_KC, bool BN_EPI = false, int XEPI = 0, int DIN = 0, int PANEL = 0>
+template <bool A_KC, bool B_KC, bool BN_EPI = false, int XEPI = 0, int DIN = 0>
 __device__ __forceinline__ void gemm_f32_block(const GemmArgs& g, int bx, int bz, float* __restrict__ lds,
                                                bool plain_tiles = false, const er_gemm_epilogue* xe = nullptr,
                                                const DinGen* dg = nullptr) {
@@ -521,72 +515,7 @@ __device__ __forceinline__ void gemm_f32_block(const GemmArgs& g, int bx, int bz
     }
   };
 
-  if constexpr (PANEL > 0) {
-    static_assert(A_KC && XEPI == 0 && DIN == 0, "PANEL: NN / NT without the cross / DIN forms");
-    f32x4v rb[PANEL][2];
-    f32x4v af[PANEL][4];
-#pragma unroll
-    for (int t = 0; t < PANEL; ++t)
-      if (t < T) fetch_tile<B_KC>(g.B, g.ldb, n0, g.N, kbeg + t * BK32, kend, g.K, tid, rb[t]);
-    {
-      int arow = m0 + wm * 32 + (lane & 31);
-      arow = arow < g.M ? arow : g.M - 1;  // (a row past the end computes what the epilogue ignores)
-      const float* ap = g.A + static_cast<int64_t>(arow) * g.lda;
-      const int kpad = (g.K + 3) & ~3;
-#pragma unroll
-      for (int t = 0; t < PANEL; ++t) {
-        if (t < T) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            int k = kbeg + t * BK32 + khalf * 16 + 4 * q;
-            k = k < kpad - 4 ? k : kpad - 4;
-            af[t][q] = *reinterpret_cast<const f32x4v*>(ap + k);
-          }
-        }
-      }
-    }
-#pragma unroll
-    for (int t = 0; t < PANEL; ++t) {
-      if (t < T) {
-        const int k0 = kbeg + t * BK32;
-        stage_tile<B_KC>(lds + t * kOpTile, tid, rb[t], (n0 + BN <= g.N) && (k0 + BK32 <= kend), n0, g.N, k0, kend);
-      }
-    }
-    if (kbeg + T * BK32 > kend) {  // (uniform) the last k-tile is partial: A's positions past the end contract as zeros
-      const int t = T - 1;
-#pragma unroll
-      for (int tt = 0; tt < PANEL; ++tt) {
-        if (tt == t) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int k = kbeg + tt * BK32 + khalf * 16 + 4 * q;
-            const int kpad = (g.K + 3) & ~3;
-            const int kc = k < kpad - 4 ? k : kpad - 4;  // (what the load read: positions kc .. kc + 3)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              // fragment slot j stands for position k + j; the clamped load delivered position kc + j
-              const float v = (k + j < kend && kc == k) ? af[tt][q][j] : 0.f;
-              af[tt][q][j] = v;
-            }
-          }
-        }
-      }
-    }
-    __syncthreads();
-    const int fbp = (wn * 32 + (lane & 31)) * SK + khalf * 16;
-#pragma unroll
-    for (int t = 0; t < PANEL; ++t) {
-      if (t < T) {
-        const float* base = lds + t * kOpTile;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const f32x4v b = *reinterpret_cast<const f32x4v*>(base + fbp + 4 * q);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[t][q][i], b[i], acc, 0, 0, 0);
-        }
-      }
-    }
-  } else if (DIN || (a_vec && b_vec)) {  // (the DIN variants are launched on aligned operands only: host check)
+  if (DIN || (a_vec && b_vec)) {  // (the DIN variants are launched on aligned operands only: host check)
     f32x4v ra0[2], rb0[2], ra1[2], rb1[2];
     f32x4v rq0[2], rq1[2];  // (DIN == 1: the q pieces of the generated A units; ra holds the h pieces until staging)
     DinPre dpre;
@@ -617,6 +546,10 @@ __device__ __forceinline__ void gemm_f32_block(const GemmArgs& g, int bx, int bz
     // before its first MFMA - were built and measured in round 5: bit-identical, 96 - 135 VGPRs instead of 64 - 100, and
     // SLOWER on every config - DeepFM 0.3287 -> 0.3343 ms, DCN-v2 0.785 -> 0.802, DIN 1.833 -> 1.892, MMoE 2.094 -> 2.173:
     // global latency is not what the k loop waits for; profiles/r05_s15_gemm_prefetch_depth_ab_lines.txt)
+    // (the PANEL form of short contractions - K <= 256: B's whole panel staged once, A's fragments straight from memory to
+    // registers, one barrier, every load in flight before the first MFMA - was built and measured in round 6: bit-identical,
+    // 130 - 260 VGPRs and 37 - 74 KB of LDS, and SLOWER: DeepFM 0.2984 -> 0.3195 ms (forward 69.5 -> 77.9 us, BatchNorm-backward
+    // dgrads 40.8 -> 50.8), DCN-v2 0.709 -> 0.717, DIN 1.719 -> 1.726, MMoE level; profiles/r06_s23_panel_gemm_ab_lines.txt)
     // (EIGHT-wave workgroups whose second four waves contract the second half of the k-tiles of the same tile, the halves
     // added through LDS - two waves per SIMD for launches of at most one workgroup per compute unit - were built and
     // measured in round 6: 624 -> 256 at B = 4096 20.4 -> 19.8 us, but 256 -> 128 10.8 -> 11.1, 128 -> 64 7.9 -> 8.5 and

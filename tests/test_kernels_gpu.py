@@ -1651,11 +1651,11 @@ def _misaligned(t):
 @pytest.mark.gpu
 @pytest.mark.parametrize('M,K,N,ldk', [(4096, 256, 128, 256), (4096, 128, 64, 128), (4096, 81, 256, 84), (100, 64, 37, 64),
                                       (1000, 224, 200, 224), (333, 32, 64, 40)])
-def test_panel_gemm_equals_the_tile_loop_bit_for_bit(M, K, N, ldk):
-  """The panel form of short contractions (gemm_f32_panel_kernel: K <= 256, B's panel staged once, A's fragments straight to
-  registers, one barrier) against the library's k-tile loop, which an operand 4 bytes off a 16-byte boundary selects: the
-  forward contraction with bias and BatchNorm column statistics (NN) and the input-gradient contraction with the
-  BatchNorm-backward column sums in its epilogue (NT) - same fragments, same order, every output bit-identical."""
+def test_vector_fetch_gemm_equals_the_generic_fetch_bit_for_bit(M, K, N, ldk):
+  """The contraction's 16-byte fetch path (aligned operands) against its generic fetch path, which an operand 4 bytes off
+  a 16-byte boundary selects: the forward contraction with bias and BatchNorm column statistics (NN) and the input-gradient
+  contraction with the BatchNorm-backward column sums in its epilogue (NT) - same fragments, same order, every output
+  bit-identical.  (Written for round 6's panel form of short contractions, which was measured slower and removed.)"""
   hip = kernels.hip()
   g = torch.Generator().manual_seed(M + K + N)
   xbuf = torch.randn(M, ldk, generator=g).to(DEV)  # (K of its ldk columns: the padding must not be read as operand)
