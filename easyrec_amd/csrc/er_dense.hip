@@ -250,7 +250,9 @@ __device__ __forceinline__ void bn_finalize_apply_body(const float* __restrict__
                          float eps, float momentum, float* __restrict__ moving_mean, float* __restrict__ moving_var,
                          int act, float* __restrict__ y, float* __restrict__ save_mean,
                          float* __restrict__ save_invstd, int tiles_per_block, int bx, int by,
-                         uint16_t* __restrict__ yb = nullptr, int ldyb = 0, float* __restrict__ y2 = nullptr, int ldy2 = 0) {
+                         uint16_t* __restrict__ yb = nullptr, int ldyb = 0, float* __restrict__ y2 = nullptr, int ldy2 = 0,
+                         bool apply = true) {
+  // apply == false (bn_finalize_stats_kernel): the statistics only - mean / invstd / moving statistics; x and y are not touched
   // yb: a bf16 copy of y (row stride ldyb) for the contraction that reads it next (dense_dtype 'bf16': no cast launch)
   // y2: a second fp32 copy of y at row stride ldy2 - the layer's column block of a concat (er_bn_apply_wide_fm)
   __shared__ Welford sm[kRowLanes][kColsPerBlock];
@@ -262,7 +264,7 @@ __device__ __forceinline__ void bn_finalize_apply_body(const float* __restrict__
   // the two round trips overlap instead of following each other (the kernel is a chain of dependent loads, not bytes)
   constexpr int kPre = kApplyRows / kRowLanes;
   float xpre[kPre];
-  const bool pre = tiles_per_block == 1 && c < N;
+  const bool pre = apply && tiles_per_block == 1 && c < N;
   // (requesting the column's bias / gamma / beta here too, instead of behind the merge's barrier, measured SLOWER: BatchNorm
   // family 64.0 -> 65.5 us on DeepFM, 439 -> 455 on MMoE, profiles/r06_s11_bn_coefficients_first_rejected_ab_lines.txt)
   if (pre) {
@@ -336,6 +338,7 @@ __device__ __forceinline__ void bn_finalize_apply_body(const float* __restrict__
     }
   }
   __syncthreads();
+  if (!apply) return;
   if (tiles_per_block >= 4 && N % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0) {
     // tall activations (DIN's [B x L]-row layers: 16 row tiles per workgroup): 16-byte lanes - 16 column lanes x 16 row
     // lanes, one load per lane and tile, four tiles in flight.  Measured (profiles/r03_bn_lanes.md): 250 -> 210 us per DIN
@@ -420,6 +423,16 @@ bn_finalize_apply_kernel(const float* __restrict__ partial, const float* __restr
                          int act, float* __restrict__ y, float* __restrict__ save_mean,
                          float* __restrict__ save_invstd, int tiles_per_block, uint16_t* __restrict__ yb, int ldyb) {
   bn_finalize_apply_body(partial, x, bias, gamma, beta, B, N, chunks, eps, momentum, moving_mean, moving_var, act, y, save_mean, save_invstd, tiles_per_block, static_cast<int>(blockIdx.x), static_cast<int>(blockIdx.y), yb, ldyb);
+}
+
+// the finalize half alone (er_bn_finalize_from_stats): the layer's apply runs inside the NEXT contraction's staging
+// (er_gemm_f32_bn_a); same merge, same order, same bits as bn_finalize_apply_kernel's first phase
+__global__ void __launch_bounds__(kBlock)
+bn_finalize_stats_kernel(const float* __restrict__ partial, int B, int N, int chunks, float eps, float momentum,
+                   float* __restrict__ moving_mean, float* __restrict__ moving_var, float* __restrict__ save_mean,
+                   float* __restrict__ save_invstd) {
+  bn_finalize_apply_body(partial, nullptr, nullptr, nullptr, nullptr, B, N, chunks, eps, momentum, moving_mean, moving_var, 0,
+                         nullptr, save_mean, save_invstd, 1, static_cast<int>(blockIdx.x), 0, nullptr, 0, nullptr, 0, false);
 }
 
 
@@ -585,6 +598,48 @@ __device__ __forceinline__ void bn_bwd_finalize_apply_body(const float* __restri
     }
   }
   __syncthreads();
+  if (!pre && N <= kColsPerBlock / 2 && (N & (N - 1)) == 0) {
+    // a NARROW tall layer (DIN's attention MLP ends 64 -> 32 -> 1 over B x L rows): with one lane per column, 64 columns per
+    // workgroup, only N of every 64 lanes had work - the [204800, 1] layer's pass took 23.7 us for 2.4 MB.  The elementwise
+    // half is remapped: kBlock / N row lanes, every lane busy, four rows in flight per lane; same formula, same bits.
+    const int c2 = threadIdx.x & (N - 1);
+    const int rstep = kBlock / N;
+    const int row_lo = by * tiles_per_block * kApplyRows;
+    int row_hi = row_lo + tiles_per_block * kApplyRows;
+    row_hi = row_hi < B ? row_hi : B;
+    const float sg2 = s_g[c2], sgx2 = s_gx[c2];
+    const float bv2 = bias ? bias[c2] : 0.f;
+    const float mu2 = use_bn ? mean[c2] : 0.f, is2 = use_bn ? invstd[c2] : 0.f;
+    const float ga2 = gamma ? gamma[c2] : 1.f;
+    const float invB2 = 1.f / static_cast<float>(B);
+    for (int r0 = row_lo + threadIdx.x / N; r0 < row_hi; r0 += 4 * rstep) {
+      float gv[4], yv[4], xv[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        int r = r0 + k * rstep;
+        r = r < row_hi ? r : row_hi - 1;  // (clamped, never stored: a load inside a branch is waited for inside it)
+        const int64_t i = static_cast<int64_t>(r) * N + c2;
+        gv[k] = dy[static_cast<int64_t>(r) * dy_ld + c2];
+        xv[k] = use_bn ? x[i] : 0.f;
+        yv[k] = act == ER_ACT_RELU ? y[i] : 1.f;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int r = r0 + k * rstep;
+        if (r < row_hi) {
+          float g = gv[k];
+          if (act == ER_ACT_RELU && !(yv[k] > 0.f)) g = 0.f;
+          if (use_bn) {
+            const float xh = (xv[k] + bv2 - mu2) * is2;
+            g = (use_bn == ER_BN_FROZEN) ? ga2 * is2 * g : ga2 * is2 * (g - sg2 * invB2 - xh * (sgx2 * invB2));
+          }
+          dx[static_cast<int64_t>(r) * N + c2] = g;
+          if (dxb) dxb[static_cast<int64_t>(r) * lddxb + c2] = f32_to_bf16_bits(g);
+        }
+      }
+    }
+    return;
+  }
   if (c >= N) return;
   const float sg = s_g[cl], sgx = s_gx[cl];
   const float bv = bias ? bias[c] : 0.f;
@@ -779,6 +834,37 @@ colsum_narrow_kernel(const float* __restrict__ x, int rows, int cols, int x_stri
   for (; r < rows; r += kBlock) a = a + x[static_cast<int64_t>(r) * x_stride + c];
   const float s = block_sum_256(a, red);
   if (threadIdx.x == 0) out[c] = accumulate ? out[c] + s : s;
+}
+
+// ... of several narrow matrices in ONE launch (er_colsum_narrow_multi: the bias gradients of a multi-task model's tower
+// heads and gates, reference model/mmoe.py:56-68 - one 4 us launch each before): workgroup b sums column b - start[j] of job j
+constexpr int kMaxNarrowJobs = 16;
+struct NarrowJobs {
+  int n;
+  int start[kMaxNarrowJobs + 1];
+  er_colsum_job j[kMaxNarrowJobs];
+};
+__global__ void __launch_bounds__(kBlock)
+colsum_narrow_multi_kernel(NarrowJobs a, int accumulate) {
+  __shared__ float red[4];
+  int i = 0;
+  while (i + 1 < a.n && static_cast<int>(blockIdx.x) >= a.start[i + 1]) ++i;
+  const er_colsum_job& q = a.j[i];
+  const float* __restrict__ x = q.x;
+  const int rows = q.rows, x_stride = q.x_stride;
+  const int c = blockIdx.x - a.start[i];
+  float s = 0.f;
+  int r = threadIdx.x;
+  for (; r + 7 * kBlock < rows; r += 8 * kBlock) {  // (colsum_narrow_kernel's loop: the same order, the same bits)
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = x[static_cast<int64_t>(r + j * kBlock) * x_stride + c];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s = s + v[j];
+  }
+  for (; r < rows; r += kBlock) s = s + x[static_cast<int64_t>(r) * x_stride + c];
+  const float t = block_sum_256(s, red);
+  if (threadIdx.x == 0) q.out[c] = accumulate ? q.out[c] + t : t;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1531,6 +1617,31 @@ int er_bn_apply_from_stats_b16(const float* x, const float* bias, const float* c
   return 0;
 }
 
+int er_bn_finalize_from_stats(const float* col_stats, int32_t chunks, int32_t B, int32_t N, float eps, float momentum,
+                              float* moving_mean, float* moving_var, float* save_mean, float* save_invstd,
+                              er_stream_t stream) {
+  ER_REQUIRE(col_stats && save_mean && save_invstd && B > 0 && N > 0 && chunks > 0, "er_bn_finalize_from_stats: bad arguments");
+  std::unique_lock<std::mutex> merge_lock(er::g_merge_mu, std::defer_lock);
+  if (chunks > er::kInlineChunks && static_cast<size_t>(N) * 3 * er::kMergeSlices <= er::kMergedFloats) {
+    float* merged;
+    if (er::get_merged(&merged)) return 1;
+    merge_lock.lock();  // (held until the consumer below is launched)
+    const int per_slice = static_cast<int>(er::ceil_div(chunks, er::kMergeSlices));
+    const int slices = static_cast<int>(er::ceil_div(chunks, per_slice));
+    hipLaunchKernelGGL(er::bn_stats_merge_kernel,
+                       dim3(static_cast<unsigned>(er::ceil_div(N, er::kColsPerBlock)), static_cast<unsigned>(slices)),
+                       dim3(er::kBlock), 0, er::as_stream(stream), col_stats, N, chunks, per_slice, merged);
+    ER_LAUNCH_CHECK();
+    col_stats = merged;
+    chunks = slices;
+  }
+  hipLaunchKernelGGL(er::bn_finalize_stats_kernel, dim3(static_cast<unsigned>(er::ceil_div(N, er::kColsPerBlock))), dim3(er::kBlock), 0,
+                     er::as_stream(stream), col_stats, B, N, chunks, eps, momentum, moving_mean, moving_var, save_mean,
+                     save_invstd);
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
 
 namespace {
 // > kInlineChunks partial sums per column: merged into kMergeSlices records first (the lock stays held until the
@@ -1747,6 +1858,27 @@ int er_colsum_acc(const float* x, int32_t rows, int32_t cols, int32_t x_stride, 
   hipLaunchKernelGGL(er::colsum_finalize_kernel, dim3(er::blocks_for(static_cast<int64_t>(cols) * 64)), dim3(er::kBlock), 0, s, scratch, cols,
                      chunks, out, accumulate);
   ER_LAUNCH_CHECK();
+  return 0;
+}
+
+int er_colsum_narrow_multi(const er_colsum_job* jobs, int32_t n_jobs, int accumulate, er_stream_t stream) {
+  ER_REQUIRE(jobs && n_jobs >= 1, "er_colsum_narrow_multi: bad arguments");
+  for (int base = 0; base < n_jobs; base += er::kMaxNarrowJobs) {
+    er::NarrowJobs a;
+    a.n = 0;
+    a.start[0] = 0;
+    for (int i = base; i < n_jobs && i < base + er::kMaxNarrowJobs; ++i) {
+      const er_colsum_job& q = jobs[i];
+      ER_REQUIRE(q.x && q.out && q.rows > 0 && q.cols > 0 && q.cols <= 64 && q.x_stride >= q.cols,
+                 "er_colsum_narrow_multi: job %d: bad descriptor", i);
+      a.j[a.n] = q;
+      a.start[a.n + 1] = a.start[a.n] + q.cols;
+      ++a.n;
+    }
+    hipLaunchKernelGGL(er::colsum_narrow_multi_kernel, dim3(static_cast<unsigned>(a.start[a.n])), dim3(er::kBlock), 0,
+                       er::as_stream(stream), a, accumulate);
+    ER_LAUNCH_CHECK();
+  }
   return 0;
 }
 

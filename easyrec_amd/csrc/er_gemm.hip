@@ -56,6 +56,16 @@ gemm_f32_din_kernel(GemmArgs g, DinGen d) {
   gemm_f32_block<A_KC, B_KC, false, 0, DIN>(g, blockIdx.x, blockIdx.z, lds, false, nullptr, &d);
 }
 
+// the A operand is a BatchNorm'd layer's z, normalised + activated while staging (BnA; er_gemm_f32_bn_a)
+__global__ void __launch_bounds__(kBlock)
+gemm_f32_bna_kernel(GemmArgs g, BnA b) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * 2 * kOpTile];
+  __shared__ __attribute__((aligned(16))) float coef[4 * kBnAMaxK];
+  bna_load_coef(b, g.K, coef);
+  __syncthreads();
+  gemm_f32_block<true, false, false, 0, 3>(g, blockIdx.x, 0, lds, false, nullptr, nullptr, &b, coef);
+}
+
 // dq[b][j] = sum over the row tiles that hold rows of example b of its slot's partial (tile order: fixed)
 __global__ void __launch_bounds__(kBlock)
 din_dq_finish_kernel(const float* __restrict__ partial, int B, int L, int E, int slots, int64_t M, float* __restrict__ dq, int lddq) {
@@ -557,6 +567,29 @@ int er_gemm_f32_cross(int layout, int32_t M, int32_t N, int32_t K, const float* 
     if (layout == ER_GEMM_NN) hipLaunchKernelGGL((er::gemm_f32_cross_kernel<true, false, ER_EPI_CROSS_BWD>), grid, block, 0, s, a, e);
     else hipLaunchKernelGGL((er::gemm_f32_cross_kernel<true, true, ER_EPI_CROSS_BWD>), grid, block, 0, s, a, e);
   }
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
+int er_gemm_f32_bn_a(int32_t M, int32_t N, int32_t K, const float* z, int32_t ldz, const float* mean, const float* invstd,
+                     const float* gamma, const float* beta, int act, float* y, int32_t ldy, const float* W, int32_t ldw, float* C,
+                     int32_t ldc, const float* bias, float* col_stats, er_stream_t stream) {
+  ER_REQUIRE(z && mean && invstd && W && C && M > 0 && N > 0 && K > 0, "er_gemm_f32_bn_a: bad arguments");
+  ER_REQUIRE(K % 4 == 0 && K <= er::kBnAMaxK, "er_gemm_f32_bn_a: K = %d (a multiple of 4, at most %d)", K, er::kBnAMaxK);
+  ER_REQUIRE(ldz >= K && ldw >= N && ldc >= N && (!y || ldy >= K), "er_gemm_f32_bn_a: leading dimension too small");
+  ER_REQUIRE(ldz % 4 == 0 && (!y || ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(y)) & 15) == 0,
+             "er_gemm_f32_bn_a: z / y must be 16-byte aligned with leading dimensions that are multiples of 4");
+  ER_REQUIRE(act == ER_ACT_NONE || act == ER_ACT_RELU, "er_gemm_f32_bn_a: activation %d", act);
+  er::GemmArgs a;
+  a.A = z; a.B = W; a.C = C; a.bias = bias;
+  a.M = M; a.N = N; a.K = K; a.lda = ldz; a.ldb = ldw; a.ldc = ldc;
+  a.accumulate = 0;
+  a.col_stats = col_stats;
+  a.splits = 1;
+  a.k_per_split = static_cast<int>(er::ceil_div(K, er::BK32)) * er::BK32;
+  er::BnA b{mean, invstd, gamma, beta, act, y, ldy};
+  const int64_t n_tiles = er::ceil_div(N, er::BN) * er::ceil_div(M, er::BM);
+  hipLaunchKernelGGL(er::gemm_f32_bna_kernel, dim3(static_cast<unsigned>(n_tiles)), dim3(er::kBlock), 0, er::as_stream(stream), a, b);
   ER_LAUNCH_CHECK();
   return 0;
 }

@@ -429,6 +429,54 @@ __device__ __forceinline__ void fetch_tile_din_perm(const float* __restrict__ P,
   }
 }
 
+// The A operand as the PRODUCING layer's pre-normalisation values z with that layer's BatchNorm + activation applied while
+// staging (er_gemm_f32_bn_a; reference layers/dnn.py:57-79: dense -> batch_normalization -> relu, then the next dense): a
+// tall layer's activations y = act(((z - mean) * invstd) * gamma + beta) are then never read back from HBM by a launch of
+// their own - the column tile tx == 0 of every row tile stores them (the backward reads y) while it stages them.  The
+// arithmetic is bn_act_one's (er_dense.hip), operation by operation: the same bits as bn_finalize_apply_kernel writes.
+struct BnA {
+  const float* mean;    // [K] of the producing layer (er_bn_finalize_from_stats)
+  const float* invstd;  // [K]
+  const float* gamma;   // [K] or nullptr (ones)
+  const float* beta;    // [K] or nullptr (zeros)
+  int act;
+  float* y;             // [M][ldy] or nullptr
+  int ldy;
+};
+constexpr int kBnAMaxK = 256;  // coefficient table in LDS: [k][mean, invstd, gamma, beta]
+__device__ __forceinline__ void bna_load_coef(const BnA& b, int K, float* __restrict__ coef) {
+  for (int k = threadIdx.x; k < ((K + 3) & ~3); k += kBlock) {
+    const bool in = k < K;
+    f32x4v c = {in ? b.mean[k] : 0.f, in ? b.invstd[k] : 0.f, (in && b.gamma) ? b.gamma[k] : 1.f, (in && b.beta) ? b.beta[k] : 0.f};
+    *reinterpret_cast<f32x4v*>(coef + 4 * k) = c;
+  }
+}
+// a thread's 2 units (4 consecutive k of one row each, the same k offset) of the fetched z tile -> y; stored when `store`
+__device__ __forceinline__ void bna_apply(const BnA& b, const float* __restrict__ coef, int tid, int m0, int M, int k0, int K,
+                                          bool store, f32x4v (&r)[2]) {
+  int kk = k0 + (tid & 7) * 4;
+  const int kpad = (K + 3) & ~3;
+  kk = kk < kpad - 4 ? kk : kpad - 4;  // (what fetch_tile read)
+  f32x4v c[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) c[j] = *reinterpret_cast<const f32x4v*>(coef + 4 * (kk + j));
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    f32x4v v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float t = (r[i][j] - c[j][0]) * c[j][1];
+      t = t * c[j][2] + c[j][3];
+      if (b.act == ER_ACT_RELU) t = t > 0.f ? t : 0.f;
+      v[j] = t;
+    }
+    r[i] = v;
+    const int row = m0 + ((tid + i * kBlock) >> 3);
+    if (store && row < M && k0 + (tid & 7) * 4 < K)
+      *reinterpret_cast<f32x4v*>(b.y + static_cast<int64_t>(row) * b.ldy + kk) = v;
+  }
+}
+
 // bx: index of the workgroup among the problem's (8-rounded) tiles, bz: its k-split.  BN_EPI: with the BnBwdEpi
 // epilogue - the y / z values of the lane's 16 output positions are requested BEFORE the k loop so that their
 // latency hides behind it (32 more VGPRs: a separate instantiation).
@@ -436,11 +484,13 @@ __device__ __forceinline__ void fetch_tile_din_perm(const float* __restrict__ P,
 // part inside its contraction, reference layers/keras/interaction.py:276-286) - like BN_EPI, what the epilogue reads at the
 // lane's 16 output positions is requested before the k loop.
 // DIN: 1 = the A operand is DinGen's generated block (forward NN, weight gradient TN); 2 = the input-gradient contraction
-// (NT) with permuted B rows and the epilogue that reduces dcat to dh / dq partials (nothing is stored to C).
+// (NT) with permuted B rows and the epilogue that reduces dcat to dh / dq partials (nothing is stored to C); 3 = the A
+// operand is a BatchNorm'd layer's z, normalised while staging (BnA *ba, its coefficient table `coef` in LDS; NN, K % 4 == 0).
 template <bool A_KC, bool B_KC, bool BN_EPI = false, int XEPI = 0, int DIN = 0>
 __device__ __forceinline__ void gemm_f32_block(const GemmArgs& g, int bx, int bz, float* __restrict__ lds,
                                                bool plain_tiles = false, const er_gemm_epilogue* xe = nullptr,
-                                               const DinGen* dg = nullptr) {
+                                               const DinGen* dg = nullptr, const BnA* ba = nullptr,
+                                               const float* __restrict__ coef = nullptr) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -527,12 +577,14 @@ __device__ __forceinline__ void gemm_f32_block(const GemmArgs& g, int bx, int bz
       if (DIN == 1) fetch_din<A_KC>(*dg, dpre, k0, kend, g.K, ra, rq);
       else fetch_tile<A_KC>(g.A, g.lda, m0, g.M, k0, kend, g.K, tid, ra);
       if (DIN == 2) fetch_tile_din_perm(g.B, g.ldb, tx, dg->E, k0, kend, g.K, tid, rb);
+      else if (DIN == 3 && !b_vec) fetch_tile_generic<B_KC>(g.B, g.ldb, n0, g.N, k0, kend, tid, rb);  // (e.g. a [K, 1] weight)
       else fetch_tile<B_KC>(g.B, g.ldb, n0, g.N, k0, kend, g.K, tid, rb);
     };
     auto stage = [&](int buf, f32x4v (&ra)[2], const f32x4v (&rb)[2], const f32x4v (&rq)[2], int t) {
       const int k0 = kbeg + t * BK32;  // unclamped: a tile past the end is masked to zero
       const bool interior = rows_full && (k0 + BK32 <= kend);
       if (DIN == 1) combine_din<A_KC>(*dg, dpre, kbeg + (t < T ? t : T - 1) * BK32, g.K, ra, rq);
+      if (DIN == 3) bna_apply(*ba, coef, tid, m0, g.M, kbeg + (t < T ? t : T - 1) * BK32, g.K, tx == 0 && t < T && ba->y != nullptr, ra);
       stage_tile<A_KC>(lds + buf * 2 * kOpTile, tid, ra, interior, m0, g.M, k0, kend);
       stage_tile<B_KC>(lds + buf * 2 * kOpTile + kOpTile, tid, rb, interior, n0, g.N, k0, kend);
     };

@@ -312,6 +312,11 @@ class TailJob(ctypes.Structure):  # = er_tail_job
               ('ld', ctypes.c_int32)]
 
 
+class ColsumJob(ctypes.Structure):  # = er_colsum_job
+  _fields_ = [('x', ctypes.c_void_p), ('rows', ctypes.c_int32), ('cols', ctypes.c_int32), ('x_stride', ctypes.c_int32),
+              ('out', ctypes.c_void_p)]
+
+
 class LossTailJob(ctypes.Structure):  # = er_loss_tail_job
   _fields_ = [('emb_partials', ctypes.c_void_p), ('n_partials', ctypes.c_int32), ('emb_scale', ctypes.c_float),
               ('dense_partials', ctypes.c_void_p), ('n_dense', ctypes.c_int32),
@@ -1153,6 +1158,21 @@ class HipBackend(object):
     else:
       self.colsum_partials_multi([(partial, dst, n_cols)])
 
+  @staticmethod
+  def colsum_is_narrow(x):
+    """er_colsum_acc would take its one-workgroup-per-column form for x"""
+    return x.dim() == 2 and x.shape[1] <= 8 and x.shape[0] * x.shape[1] <= (1 << 17) and x.stride(1) == 1
+
+  def colsum_narrow_multi(self, jobs, accumulate=True):
+    """jobs: [(x [rows, cols <= 8], out [cols])]: out[j] (+)= sum_i x[i, j], all jobs in ONE launch (column by column the
+    sums of colsum())."""
+    arr = (ColsumJob * len(jobs))()
+    for q, (x, out) in zip(arr, jobs):
+      assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == torch.float32 and out.is_contiguous() and out.numel() == x.shape[1]
+      q.x, q.rows, q.cols, q.x_stride, q.out = x.data_ptr(), x.shape[0], x.shape[1], x.stride(0), out.data_ptr()
+    self._ck(self.lib.er_colsum_narrow_multi(arr, ctypes.c_int32(len(jobs)), int(bool(accumulate)), _stream()),
+             'er_colsum_narrow_multi')
+
   def colsum_partials_multi(self, jobs, accumulate=True):
     """jobs: [(partial [P, ld], dst [n_cols], n_cols)]: dst[j] (+)= sum_p partial[p, j], all jobs in one launch."""
     arr = (TailJob * len(jobs))()
@@ -1457,6 +1477,39 @@ class HipBackend(object):
 
   # the last BatchNorm apply of DeepFM's deep tower inside the [sum(wide) | FM | deep] launch (er_bn_apply_wide_fm) - A/B switch
   defer_bn_apply = os.environ.get('EASYREC_AMD_DEFER_BN_APPLY', '1') != '0'
+
+  # a TALL layer's BatchNorm apply inside the NEXT contraction's staging (er_bn_finalize_from_stats + er_gemm_f32_bn_a): the
+  # [B * L, units] activations of DIN's attention MLP are not read back by an apply launch of their own - A/B switch
+  bn_in_staging = os.environ.get('EASYREC_AMD_BN_IN_STAGING', '1') != '0'
+  BN_IN_STAGING_MIN_ROWS = 256 * 64 + 1  # (layers whose column statistics take the merge launch: more than 256 row tiles)
+
+  def bn_a_ok(self, pend, w):
+    """May the deferred BatchNorm apply `pend` run inside the staging of the contraction with w [K, N]?"""
+    z, y = pend['z'], pend['y']
+    K = z.shape[1]
+    return (K % 4 == 0 and K <= 256 and z.is_contiguous() and y.is_contiguous() and w.dim() == 2 and w.stride(1) == 1 and
+            (z.data_ptr() | y.data_ptr()) % 16 == 0)
+
+  def gemm_bn_a(self, pend, w, bias, col_stats=None):
+    """out [M, N] = act(BatchNorm(z)) . w (+ bias) for the deferred BatchNorm apply `pend` (LinearBNActFn(defer_apply=True)):
+    the statistics are finalized by a launch of their own, the apply runs while the contraction stages its A tiles and leaves
+    pend['y'] behind for the backward pass.  The same bits as bn_apply_pending + gemm."""
+    z, y = pend['z'], pend['y']
+    M, K = z.shape
+    N = w.shape[1]
+    self._ck(self.lib.er_bn_finalize_from_stats(_p(pend['stats']), ctypes.c_int32(int(pend['chunks'])), M, K,
+                                                ctypes.c_float(pend['eps']), ctypes.c_float(pend['momentum']),
+                                                _p(pend['moving_mean']), _p(pend['moving_var']), _p(pend['mean']),
+                                                _p(pend['invstd']), _stream()), 'er_bn_finalize_from_stats')
+    out = torch.empty(M, N, dtype=torch.float32, device=z.device)
+    if col_stats is not None:
+      assert col_stats.numel() >= self.gemm_row_tiles(M) * N * 3 and col_stats.dtype == torch.float32
+    self._log_gemm('gemm_f32_bna_kernel', None, M, N, K)
+    self._ck(self.lib.er_gemm_f32_bn_a(M, N, K, _p(z), ctypes.c_int32(z.stride(0)), _p(pend['mean']), _p(pend['invstd']),
+                                       _p(pend['gamma']), _p(pend['beta']), int(pend['act']), _p(y),
+                                       ctypes.c_int32(y.stride(0)), _p(w), ctypes.c_int32(w.stride(0)), _p(out),
+                                       ctypes.c_int32(out.stride(0)), _p(bias), _p(col_stats), _stream()), 'er_gemm_f32_bn_a')
+    return out
 
   def rowsum_bwd(self, g, n, into=None, accumulate=False):
     B = g.shape[0]
@@ -2509,6 +2562,21 @@ def hip():
 # autograd glue: dense activations flow through torch.autograd; each Function is one fused kernel
 # forward and one backward.
 # ---------------------------------------------------------------------------------------------
+def _take_pending_bn(be, x, src, w, bf16):
+  """x may be the output of a layer whose BatchNorm apply was deferred to its consumer (LinearBNActFn / DINFirstLayerFn with
+  defer_apply): -> the pending record when the apply can run inside the staging of the contraction x . w
+  (HipBackend.gemm_bn_a), else None - after running the apply as the launch of its own it would have been."""
+  pin = src.pending if isinstance(src, BnSource) else None
+  if pin is None:
+    return None
+  src.pending = None
+  if x.dim() == 2 and x.stride(-1) == 1 and not bf16 and getattr(be, 'bn_in_staging', False) and \
+      pin['y'].data_ptr() == x.data_ptr() and pin['y'].shape == x.shape and be.bn_a_ok(pin, w):
+    return pin
+  be.bn_apply_pending(pin)
+  return None
+
+
 class LinearFn(torch.autograd.Function):
   """y = x . W (+ b): tf.layers.dense without activation (reference layers/dnn.py:57-62).  Forward and both
   gradients are hand-written MFMA GEMMs (er_gemm_*).  The weight/bias gradients are accumulated straight
@@ -2519,8 +2587,9 @@ class LinearFn(torch.autograd.Function):
   @staticmethod
   def forward(ctx, x, w, b, w_grad, b_grad, bf16, src=None, sink=None):
     be = hip()
+    pin = _take_pending_bn(be, x, src, w, bf16)
     x2 = x if x.stride(-1) == 1 else x.contiguous()
-    y = be.gemm(GEMM_NN, x2, w, bias=b, bf16=bf16)
+    y = be.gemm_bn_a(pin, w, b) if pin is not None else be.gemm(GEMM_NN, x2, w, bias=b, bf16=bf16)
     ctx.save_for_backward(x2, w)
     ctx.has_bias = b is not None
     ctx.w_grad, ctx.b_grad, ctx.bf16 = w_grad, b_grad, bf16
@@ -2702,17 +2771,23 @@ class LinearBNActFn(torch.autograd.Function):
   def forward(ctx, x, w, b, gamma, beta, moving_mean, moving_var, eps, momentum, act, bf16, grad_bufs, src=None,
               sink=None, defer_apply=False):
     be = hip()
+    pin = _take_pending_bn(be, x, src, w, bf16)
     x2 = x if x.stride(-1) == 1 else x.contiguous()
     M, N = x2.shape[0], w.shape[1]
     chunks = be.gemm_row_tiles(M)
     stats = torch.empty(chunks * N * 3, dtype=torch.float32, device=x2.device)
-    z = be.gemm(GEMM_NN, x2, w, bias=b, bf16=bf16, col_stats=stats)
+    if pin is not None:
+      z = be.gemm_bn_a(pin, w, b, col_stats=stats)
+    else:
+      z = be.gemm(GEMM_NN, x2, w, bias=b, bf16=bf16, col_stats=stats)
     # (bf16: the BatchNorm launch writes the bf16 copy the next contraction reads; its backward the one the dgrad reads)
     ctx.b16 = be._bf16_state_of(w) if (bf16 and getattr(be, 'bf16_nt', False) and getattr(be, 'bf16_epilogues', False)) else None
     # defer_apply: the caller's NEXT op on y is the one consumer that runs this layer's BatchNorm finalize + apply inside its
     # own launch (DeepFM: WideFmConcatFn).  Until then y / mean / invstd are unwritten buffers.
     pend = None
-    if defer_apply and not bf16 and _bn_bwd_fusable(be, bf16) and getattr(be, 'defer_bn_apply', False) and z.is_contiguous():
+    # (defer_apply == 'staging': the consumer is the next layer's LinearBNActFn - a tall layer, HipBackend.bn_in_staging)
+    if defer_apply and not bf16 and _bn_bwd_fusable(be, bf16) and z.is_contiguous() and \
+        getattr(be, 'bn_in_staging' if defer_apply == 'staging' else 'defer_bn_apply', False):
       y = torch.empty_like(z)
       mean = torch.empty(N, dtype=torch.float32, device=z.device)
       invstd = torch.empty(N, dtype=torch.float32, device=z.device)
@@ -2869,6 +2944,7 @@ class GroupedLinearFn(torch.autograd.Function):
         be.gemm(GEMM_NT, dzs[e], ws[e], out=acc, accumulate=j > 0)
       dxs[es[0]] = acc
     dws, dbs = [None] * E, [None] * E
+    narrow = []  # the bias gradients of narrow layers (tower heads [B, 1], gates [B, experts]): ONE launch for all of them
     for e in range(E):
       if dzs[e] is None:
         continue
@@ -2878,9 +2954,16 @@ class GroupedLinearFn(torch.autograd.Function):
       # (a layer whose output feeds BatchNorm on batch statistics - stats_mask - has a bias gradient of exactly zero)
       if b is not None and not ctx.stats_mask[e] and ctx.needs_input_grad[4 + 2 * E + e]:
         if b.grad is not None:
-          be.colsum(dzs[e], out=b.grad, accumulate=True)
+          if hasattr(be, 'colsum_narrow_multi') and be.colsum_is_narrow(dzs[e]) and b.grad.is_contiguous():
+            narrow.append((dzs[e], b.grad))
+          else:
+            be.colsum(dzs[e], out=b.grad, accumulate=True)
         else:
           dbs[e] = be.colsum(dzs[e])
+    if len(narrow) == 1:
+      be.colsum(narrow[0][0], out=narrow[0][1], accumulate=True)
+    elif narrow:
+      be.colsum_narrow_multi(narrow, accumulate=True)
     return (None, None, None, None) + tuple(dxs) + tuple(dws) + tuple(dbs)
 
 
@@ -3467,20 +3550,31 @@ class DINFirstLayerFn(torch.autograd.Function):
   and arithmetic as LinearBNActFn over DINConcatFn's output; the history's gradient lands in its gradient slot."""
 
   @staticmethod
-  def forward(ctx, q, h, w, b, gamma, beta, moving_mean, moving_var, eps, momentum, act, grad_bufs):
+  def forward(ctx, q, h, w, b, gamma, beta, moving_mean, moving_var, eps, momentum, act, grad_bufs, defer_apply=False):
     be = hip()
     B, L, E = h.shape
     N = w.shape[1]
     chunks = be.gemm_row_tiles(B * L)
     stats = torch.empty(chunks * N * 3, dtype=torch.float32, device=h.device)
     z = be.din_gemm_fwd(q, h, w, b, col_stats=stats)
-    y, mean, invstd = be.bn_apply_from_stats(z, None, stats, chunks, gamma, beta, eps, momentum, moving_mean, moving_var, act)
+    fused = getattr(be, 'fused_bn_bwd', False)
+    pend = None
+    if defer_apply and fused and getattr(be, 'bn_in_staging', False):
+      # the next layer's contraction applies this BatchNorm while it stages its A tiles (LinearBNActFn, HipBackend.gemm_bn_a)
+      y = torch.empty_like(z)
+      mean = torch.empty(N, dtype=torch.float32, device=z.device)
+      invstd = torch.empty(N, dtype=torch.float32, device=z.device)
+      pend = dict(z=z, stats=stats, chunks=chunks, gamma=gamma.detach(), beta=beta.detach(), eps=eps, momentum=momentum,
+                  moving_mean=moving_mean, moving_var=moving_var, act=act, y=y, mean=mean, invstd=invstd)
+    else:
+      y, mean, invstd = be.bn_apply_from_stats(z, None, stats, chunks, gamma, beta, eps, momentum, moving_mean, moving_var, act)
     ctx.save_for_backward(q, h, w, gamma, beta, z, y, mean, invstd)
     ctx.act, ctx.grad_bufs = act, grad_bufs
     ctx.slots = grad_slots_of_step()
-    fused = getattr(be, 'fused_bn_bwd', False)
     gb = None if grad_bufs is None else (grad_bufs[1], grad_bufs[2])
     ctx.own = BnSource(z, None, y, mean, invstd, act, gamma, gb, beta=beta, fused=fused) if fused else None
+    if pend is not None:
+      ctx.own.pending = pend
     _bn_tls.last = ctx.own
     return y
 
@@ -3488,6 +3582,7 @@ class DINFirstLayerFn(torch.autograd.Function):
   def backward(ctx, dy):
     be = hip()
     q, h, w, gamma, beta, z, y, mean, invstd = ctx.saved_tensors
+    assert ctx.own is None or ctx.own.pending is None, 'a deferred BatchNorm apply was never run (kernels.finish_pending_bn)'
     wg, gg, betag = ctx.grad_bufs if ctx.grad_bufs is not None else (None, None, None)
     direct = gg is not None and betag is not None
     dyc = dy if (dy.dim() == 2 and dy.stride(1) == 1) else dy.contiguous()
@@ -3511,7 +3606,7 @@ class DINFirstLayerFn(torch.autograd.Function):
         be.din_gemm_wgrad(q, h, dz, wg, accumulate=True)
       else:
         dw = be.din_gemm_wgrad(q, h, dz, torch.empty_like(w), accumulate=False)
-    return dq, dh, dw, None, dgamma, dbeta, None, None, None, None, None, None
+    return dq, dh, dw, None, dgamma, dbeta, None, None, None, None, None, None, None
 
 
 class DINPoolFn(torch.autograd.Function):

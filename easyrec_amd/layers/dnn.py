@@ -24,6 +24,7 @@ def _linear(x2, w, b, src=None, sink=None):
   ctx = context.current()
   bf16 = getattr(ctx, 'dense_dtype', 'f32') == 'bf16'
   if not torch.is_grad_enabled() or not ctx.is_training:
+    kernels.finish_pending_bn(x2)
     return kernels.hip().gemm(kernels.GEMM_NN, x2 if x2.stride(-1) == 1 else x2.contiguous(), w.detach(),
                               bias=None if b is None else b.detach(), bf16=bf16)
   wg = w.grad if (w.requires_grad and w.grad is not None) else None
@@ -81,22 +82,23 @@ def dense_bn_act(x, units, name, l2_reg, use_bias, use_bn, act_relu, training, b
     y = kernels.LinearBNActFn.apply(x if x.dim() == 2 else x.reshape(-1, in_dim), w, b, gamma, beta,
                                     None if freeze else mm, None if freeze else mv, BN_EPSILON, BN_MOMENTUM, act, bf16,
                                     bufs, kernels.bn_source_of(x) or kernels.bn_cols_of(x), kernels.grad_sink_of(x),
-                                    bool(defer_apply) and x.dim() == 2)
+                                    defer_apply if (defer_apply and x.dim() == 2) else False)
     src = kernels.take_last_bn_source()
     y = y.reshape(shape[:-1] + (units,))
     return kernels.tag_bn_source(y, src) if src is not None else y
   # no BatchNorm, or BatchNorm on the moving statistics (evaluation; in training the experts of the reference's MMoE /
   # DBMTL, whose MMOE layer is built without is_training): plain GEMM, then ONE bias + normalise + activation launch
   if x.dim() == 2:
-    z = _linear(x, w, None, kernels.bn_source_of(x), kernels.grad_sink_of(x))
+    z = _linear(x, w, None, kernels.bn_source_of(x), kernels.grad_sink_of(x))  # (a pending BatchNorm apply behind x: LinearFn)
   else:
+    kernels.finish_pending_bn(x)
     z = _linear(x.reshape(-1, in_dim), w, None)
   y = kernels.BNActFn.apply(z, b, gamma, beta, None if freeze else mm, None if freeze else mv, use_bn,
                             BN_EPSILON, BN_MOMENTUM, act, training, _grad_bufs(b, gamma, beta))
   return y.reshape(shape[:-1] + (units,))
 
 
-def din_first_layer(q, hist, units, name, l2_reg, act_relu, training):
+def din_first_layer(q, hist, units, name, l2_reg, act_relu, training, defer_apply=False):
   """dense + BatchNorm(train) + activation over DIN's attention input [q, h, q - h, q * h] ([B, L, 4E]) WITHOUT building it
   (kernels.DINFirstLayerFn; reference model/multi_tower_din.py:62-80, layers/dnn.py:57-79; the same variables: <name>/kernel
   [4E, units], /bias, /bn).  -> [B * L, units]."""
@@ -114,7 +116,7 @@ def din_first_layer(q, hist, units, name, l2_reg, act_relu, training):
   bufs = (w.grad, gamma.grad, beta.grad) if (w.grad is not None and gamma.grad is not None and beta.grad is not None) else None
   act = kernels.ACT_RELU if act_relu else kernels.ACT_NONE
   y = kernels.DINFirstLayerFn.apply(q, hist, w, b, gamma, beta, None if freeze else mm, None if freeze else mv, BN_EPSILON,
-                                    BN_MOMENTUM, act, bufs)
+                                    BN_MOMENTUM, act, bufs, bool(defer_apply))
   src = kernels.take_last_bn_source()
   return kernels.tag_bn_source(y, src) if src is not None else y
 
@@ -335,13 +337,25 @@ class DNN(object):
       use_bn = self._config.use_bn and ((i + 1 < hidden_units_len) or not self._last_layer_no_batch_norm)
       use_act = (i + 1 < hidden_units_len) or not self._last_layer_no_activation
       fuse_relu = use_act and is_relu(self._act_string)
+      last = i + 1 == hidden_units_len
+      no_drop = not (len(self.dropout_ratio) > 0 and self._is_training and self.dropout_ratio[i] > 0)
+      # a TALL layer (DIN's attention MLP over B x L rows) hands its BatchNorm apply to the NEXT layer's contraction, which
+      # runs it while staging (kernels.LinearBNActFn / LinearFn -> HipBackend.gemm_bn_a): when nothing between the two reads
+      # the activations
+      rows = (din[1].shape[0] * din[1].shape[1]) if (i == 0 and din is not None) else \
+          (deep_fea.shape[0] if deep_fea.dim() == 2 else 0)
+      to_next = bool(not last and use_bn and self._is_training and torch.is_grad_enabled() and self._config.use_bn and
+                     (fuse_relu or not use_act or self.activation is None) and no_drop and not hidden_layer_feature_output and
+                     getattr(kernels.hip(), 'bn_in_staging', False) and rows >= kernels.hip().BN_IN_STAGING_MIN_ROWS and
+                     getattr(context.current(), 'dense_dtype', 'f32') == 'f32' and context.current().is_training)
       if i == 0 and din is not None:
-        deep_fea = din_first_layer(din[0], din[1], unit, layer, self._l2_reg, fuse_relu, self._is_training)
+        deep_fea = din_first_layer(din[0], din[1], unit, layer, self._l2_reg, fuse_relu, self._is_training, defer_apply=to_next)
       else:
-        last = i + 1 == hidden_units_len
         # (defer_last_apply: see dense_bn_act - only when nothing below touches the layer's output again)
         defer = bool(defer_last_apply and last and use_bn and (fuse_relu or not use_act) and not hidden_layer_feature_output and
-                     lead_shape is None and not (len(self.dropout_ratio) > 0 and self._is_training and self.dropout_ratio[i] > 0))
+                     lead_shape is None and no_drop)
+        if to_next:
+          defer = 'staging'
         deep_fea = dense_bn_act(deep_fea, unit, layer, self._l2_reg, True, use_bn, fuse_relu, self._is_training,
                                 defer_apply=defer)
       if use_act and not fuse_relu and self.activation is not None:

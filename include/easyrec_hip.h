@@ -652,6 +652,13 @@ int er_bn_apply_from_stats_b16(const float* x, const float* bias, const float* c
                                const float* gamma, const float* beta, int32_t B, int32_t N, float eps,
                                float momentum, float* moving_mean, float* moving_var, int act, float* y,
                                float* save_mean, float* save_invstd, uint16_t* y_bf16, int32_t ld_bf16, er_stream_t stream);
+/* The FINALIZE half of er_bn_apply_from_stats alone: the column statistics are merged (in the same order, to the same bits)
+ * into save_mean / save_invstd and the moving statistics; nothing is normalised.  For a TALL layer (DIN's attention MLP over
+ * B x L rows, reference model/multi_tower_din.py:62-80 -> layers/dnn.py:57-79) whose apply runs inside the next
+ * contraction's staging: er_gemm_f32_bn_a. */
+int er_bn_finalize_from_stats(const float* col_stats, int32_t chunks, int32_t B, int32_t N, float eps, float momentum,
+                              float* moving_mean, float* moving_var, float* save_mean, float* save_invstd,
+                              er_stream_t stream);
 int er_bn_act_bwd_ld_b16(const float* x, const float* bias, const float* gamma, const float* y,
                          const float* save_mean, const float* save_invstd, const float* dy, int32_t dy_ld,
                          int32_t B, int32_t N, int use_bn, int act, float* dx, float* dbias, float* dgamma,
@@ -1029,6 +1036,15 @@ int er_gemm_bf16_nt_epi(int32_t M, int32_t N, int32_t K, const uint16_t* A, int3
 int er_gemm_f32_cross(int layout, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B, int32_t ldb,
                       float* C, int32_t ldc, const float* bias, int accumulate, const er_gemm_epilogue* epi,
                       er_stream_t stream);
+/* C [M][N] = act(BatchNorm(z)) . W [K][N] (+ bias), col_stats as er_gemm_f32's: the A operand is the PRODUCING layer's
+ * pre-normalisation output z [M][ldz] (K columns) and its normalisation + activation - ((z - mean) * invstd) * gamma + beta,
+ * ReLU: reference layers/dnn.py:62-79 (tf.layers.batch_normalization, then the activation, then the next tf.layers.dense) -
+ * is applied while the tile is staged, operation by operation as er_bn_apply_from_stats applies it; y [M][ldy] (NULL: not
+ * kept) receives the activations, written once per row tile, for the backward pass.  mean / invstd: er_bn_finalize_from_stats.
+ * K % 4 == 0, K <= 256, 16-byte aligned rows of z / y (W: any alignment, e.g. a [K, 1] projection). */
+int er_gemm_f32_bn_a(int32_t M, int32_t N, int32_t K, const float* z, int32_t ldz, const float* mean, const float* invstd,
+                     const float* gamma, const float* beta, int act, float* y, int32_t ldy, const float* W, int32_t ldw, float* C,
+                     int32_t ldc, const float* bias, float* col_stats, er_stream_t stream);
 /* DIN's first attention layer WITHOUT the [B, L, 4E] block (north_star: "DIN-attention as fused HIP kernels"; reference
  * model/multi_tower_din.py:62-80 builds tf.concat([q, h, q - h, q * h], axis=-1) and feeds it to the attention DNN,
  * layers/dnn.py:57-79): the three contractions of the layer take q [B][ldq] and h [B * L][ldh] (E columns each) and form
@@ -1048,6 +1064,16 @@ int64_t er_din_dq_partial_floats(int32_t B, int32_t L, int32_t E);
 int er_din_gemm_dgrad(const float* dz, int32_t lddz, int32_t N, const float* W, int32_t ldw, const float* q, int32_t ldq,
                       const float* h, int32_t ldh, int32_t B, int32_t L, int32_t E, float* dq, int32_t lddq, float* dh,
                       int32_t lddh, int accumulate_dh, float* dq_partial, er_stream_t stream);
+/* out[j] (+)= sum_i x[i * x_stride + j] of SEVERAL narrow matrices (cols <= 64; meant for cols <= 8) in ONE launch: the bias
+ * gradients of a multi-task model's tower heads and gates (reference model/mmoe.py:56-68, model/multi_task_model.py:33-100 -
+ * tf.layers.dense per tower; each was an er_colsum_acc launch).  Column by column the same sums, in the same order, as
+ * er_colsum_acc's narrow form.  jobs: HOST array. */
+typedef struct er_colsum_job {
+  const float* x;
+  int32_t rows, cols, x_stride;
+  float* out;
+} er_colsum_job;
+int er_colsum_narrow_multi(const er_colsum_job* jobs_host, int32_t n_jobs, int accumulate, er_stream_t stream);
 /* dst[j] (+)= sum_p partial[p * ld + j] for up to 16 jobs in ONE launch (er_tail_job records, HOST array): the bias
  * gradients of a stack of cross layers from the per-tile column sums their fused backward left. */
 int er_colsum_partials_multi(const er_tail_job* jobs_host, int32_t n_jobs, int accumulate, er_stream_t stream);

@@ -59,7 +59,7 @@ MIRRORS = {  # ctypes class in easyrec_amd/kernels.py -> the C struct it mirrors
     'GemmEpilogue': 'er_gemm_epilogue', 'LookupDesc': 'er_lookup_desc', 'KvJob': 'er_kv_job', 'KvRouteJob': 'er_kv_route_job', 'CastDesc': 'er_cast_desc',
     'GemmProblem': 'er_gemm_problem', 'BnLayer': 'er_bn_layer', 'CeHead': 'er_ce_head', 'TailJob': 'er_tail_job',
     'LossTailJob': 'er_loss_tail_job', 'DenseOptJob': 'er_dense_opt_job', 'GradTerm': 'er_grad_term',
-    'GradGroup': 'er_grad_group', 'DenseApplyDesc': 'er_dense_apply_desc',
+    'GradGroup': 'er_grad_group', 'DenseApplyDesc': 'er_dense_apply_desc', 'ColsumJob': 'er_colsum_job',
 }
 
 

@@ -379,3 +379,44 @@ def test_din_step_with_the_generated_attention_input_equals_the_built_one(hip, m
   assert f1 == f0, (f1, f0)
   assert float((m1 - m0).abs().max()) <= 2e-5 * float(m0.abs().max()), float((m1 - m0).abs().max())
   assert abs(s1 - s0) <= 1e-4 * abs(s0), (s1, s0)
+
+
+def test_din_step_with_the_tall_batchnorm_applies_in_the_next_contraction_is_bit_identical(hip, monkeypatch):
+  """MultiTowerDIN (configs/din_taobao_small.config at B = 2048, L = 12: 24,576 attention rows, more than the 16,384 above which
+  column statistics take the merge launch) with the attention MLP's BatchNorm applies inside the next layer's contraction
+  (HipBackend.bn_in_staging: er_bn_finalize_from_stats + er_gemm_f32_bn_a) and as launches of their own: the same arithmetic
+  in the same order - losses of two steps and the first Adam moments bit-identical."""
+  import os
+  from easyrec_amd.input.synthetic import SyntheticBatches
+  from easyrec_amd.model.easy_rec_estimator import EasyRecEstimator
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  cfg = os.path.join(root, 'configs', 'din_taobao_small.config')
+  calls = []
+  real = kernels.HipBackend.gemm_bn_a
+
+  def counted(self, *a, **k):
+    calls.append(1)
+    return real(self, *a, **k)
+
+  monkeypatch.setattr(kernels.HipBackend, 'gemm_bn_a', counted)
+
+  def run(on):
+    monkeypatch.setattr(kernels.HipBackend, 'bn_in_staging', on)
+    est = EasyRecEstimator(cfg, device=DEV, batch_size=2048, seed=3).build()
+    gen = SyntheticBatches(est.pipeline_config.data_config, est.feature_configs, batch_size=2048, seed=11)
+    first = float(est.train_step(gen.next_batch())['total_loss'])
+    torch.cuda.synchronize()
+    m = est.varstore.slots['m'].clone()
+    mv = {k: np.array(v) for k, v in est.varstore.state_dict().items() if 'moving_' in k}
+    second = float(est.train_step(gen.next_batch())['total_loss'])
+    return first, second, m, mv
+
+  f1, s1, m1, mv1 = run(True)
+  n_on = len(calls)
+  f0, s0, m0, mv0 = run(False)
+  assert n_on >= 2 and len(calls) == n_on, (n_on, len(calls))  # (the staging form ran, and only when switched on)
+  assert f1 == f0 and s1 == s0, (f1, f0, s1, s0)
+  assert torch.equal(m1, m0)
+  assert len(mv0) > 0
+  for k in mv0:
+    assert np.array_equal(mv1[k], mv0[k]), k

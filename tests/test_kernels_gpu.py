@@ -1638,6 +1638,71 @@ def test_bn_apply_wide_fm_equals_the_two_launches(B, K, N, n_w, F, D):
   assert out2.shape == out1.shape and torch.equal(out2, out1) and torch.equal(S2, S1)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('M,K0,K,N,act', [(204800, 128, 128, 64, 'relu'), (20000, 64, 64, 32, 'relu'), (16500, 48, 36, 128, 'none'),
+                                         (777, 32, 256, 200, 'relu'), (4096, 40, 8, 4, 'relu'), (204800, 64, 32, 1, 'relu'), (5000, 16, 12, 3, 'none')])
+def test_gemm_with_the_batchnorm_apply_in_its_staging_equals_the_two_launches(M, K0, K, N, act):
+  """er_bn_finalize_from_stats + er_gemm_f32_bn_a (a tall layer's BatchNorm finalize as a launch of its own, its apply inside the
+  NEXT layer's contraction while the A tiles are staged; reference layers/dnn.py:57-79) = er_bn_apply_from_stats followed by
+  er_gemm_f32, bit for bit: the activations left behind for the backward, saved and moving statistics, the contraction's
+  output and its column statistics.  (M > 16384: the statistics take the merge launch first, as in DIN's attention MLP.)"""
+  hip = kernels.hip()
+  a = kernels.ACT_RELU if act == 'relu' else kernels.ACT_NONE
+  g = torch.Generator().manual_seed(M + K + N)
+  x = torch.randn(M, K0, generator=g).to(DEV)
+  w0 = (torch.randn(K0, K, generator=g) * 0.3).to(DEV)
+  b0 = torch.randn(K, generator=g).to(DEV)
+  gamma = (torch.rand(K, generator=g) + 0.5).to(DEV)
+  beta = torch.randn(K, generator=g).to(DEV)
+  w1 = (torch.randn(K, N, generator=g) * 0.2).to(DEV)
+  b1 = torch.randn(N, generator=g).to(DEV)
+  chunks = hip.gemm_row_tiles(M)
+  stats = torch.empty(chunks * K * 3, device=DEV)
+  z = hip.gemm(kernels.GEMM_NN, x, w0, bias=b0, col_stats=stats)
+  mm1, mv1 = torch.zeros(K, device=DEV), torch.ones(K, device=DEV)
+  y1, mean1, inv1 = hip.bn_apply_from_stats(z, None, stats, chunks, gamma, beta, 1e-3, 0.99, mm1, mv1, a)
+  s1 = torch.zeros(chunks * N * 3, device=DEV)
+  out1 = hip.gemm(kernels.GEMM_NN, y1, w1, bias=b1, col_stats=s1)
+  mm2, mv2 = torch.zeros(K, device=DEV), torch.ones(K, device=DEV)
+  pend = dict(z=z, stats=stats, chunks=chunks, gamma=gamma, beta=beta, eps=1e-3, momentum=0.99, moving_mean=mm2, moving_var=mv2,
+              act=a, y=torch.full_like(z, float('nan')), mean=torch.empty(K, device=DEV), invstd=torch.empty(K, device=DEV))
+  assert hip.bn_a_ok(pend, w1)
+  s2 = torch.zeros(chunks * N * 3, device=DEV)
+  out2 = hip.gemm_bn_a(pend, w1, b1, col_stats=s2)
+  torch.cuda.synchronize()
+  assert torch.equal(pend['mean'], mean1) and torch.equal(pend['invstd'], inv1)
+  assert torch.equal(mm2, mm1) and torch.equal(mv2, mv1)
+  assert torch.equal(pend['y'], y1)
+  assert torch.equal(out2, out1) and torch.equal(s2, s1)
+
+
+@pytest.mark.gpu
+def test_narrow_column_sums_of_several_matrices_in_one_launch_equal_the_single_launches():
+  """er_colsum_narrow_multi (the bias gradients of a multi-task model's tower heads [B, 1] and gates [B, experts] in ONE
+  launch) = er_colsum_acc per matrix, bit for bit, accumulating and overwriting; column blocks of wider tensors included."""
+  hip = kernels.hip()
+  g = torch.Generator().manual_seed(5)
+  shapes = [(8192, 1), (8192, 1), (8192, 4), (8192, 8), (5000, 3), (1, 2), (300, 1)] + [(777, 2)] * 12  # (> 16 jobs: two launches)
+  xs = []
+  for rows, cols in shapes:
+    full = torch.randn(rows, cols + 3, generator=g).to(DEV)
+    xs.append(full[:, 1:1 + cols])
+  for acc in (True, False):
+    base = [torch.randn(x.shape[1], generator=g).to(DEV) for x in xs]
+    want = [b.clone() for b in base]
+    for x, w in zip(xs, want):
+      assert hip.colsum_is_narrow(x)
+      hip.colsum(x, out=w, accumulate=acc)
+    got = [b.clone() for b in base]
+    hip.colsum_narrow_multi(list(zip(xs, got)), accumulate=acc)
+    torch.cuda.synchronize()
+    for a, b, x in zip(got, want, xs):
+      assert torch.equal(a, b)
+      assert torch.allclose(a - (0 if not acc else base[0] * 0), a)  # (finite)
+    ref = xs[2].double().sum(0)
+    assert float(((got[2].double() - (base[2].double() if acc else 0)) - ref).abs().max()) < 1e-3
+
+
 def _misaligned(t):
   """a copy of t whose base address is 4 bytes past a 16-byte boundary (the library then takes its generic fetch path)"""
   buf = torch.empty(t.numel() + 5, dtype=t.dtype, device=t.device)
