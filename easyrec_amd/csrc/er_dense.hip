@@ -471,7 +471,11 @@ bn_apply_wide_fm_kernel(const float* __restrict__ partial, const float* __restri
 // backward partials: p[(chunk*N + c)*2 + {0,1}] = (sum g, sum g*xhat), g = dy * act'(y)
 __device__ __forceinline__ void bn_bwd_partial_body(const float* __restrict__ x, const float* __restrict__ bias, const float* __restrict__ y,
                       const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ dy,
-                      int B, int N, int chunks, int use_bn, int act, float* __restrict__ partial, int dy_ld, int bx, int by) {
+                      int B, int N, int chunks, int use_bn, int act, float* __restrict__ partial, int dy_ld, int bx, int by,
+                      const float* __restrict__ gamma = nullptr, float* __restrict__ dx = nullptr) {
+  // dx != nullptr (use_bn == ER_BN_FROZEN only): on the moving statistics dx = gamma * invstd * g depends on no column sum,
+  // so this pass - which holds g already - writes it, and the finalize launch that follows only merges the sums into the
+  // parameter gradients (er_bn_bwd_multi: the experts of a multi-task model, one pass over dy / y / z instead of two)
   __shared__ float sm[2][kRowLanes][kColsPerBlock];
   const int cl = threadIdx.x % kColsPerBlock;
   const int rl = threadIdx.x / kColsPerBlock;
@@ -491,6 +495,7 @@ __device__ __forceinline__ void bn_bwd_partial_body(const float* __restrict__ x,
     const float* ys = act == ER_ACT_RELU ? y : dy;
     const int64_t xs_ld = use_bn ? N : dy_ld, ys_ld = act == ER_ACT_RELU ? N : dy_ld;
     constexpr int kRows = 8;
+    const float ga = (dx && gamma) ? gamma[c] : 1.f;
     for (int rb = r0 + rl; rb < r1; rb += kRows * kRowLanes) {
       float gv[kRows], yv[kRows], xv[kRows];
 #pragma unroll
@@ -507,6 +512,7 @@ __device__ __forceinline__ void bn_bwd_partial_body(const float* __restrict__ x,
           if (act == ER_ACT_RELU && !(yv[u] > 0.f)) g = 0.f;
           sg = sg + g;
           if (use_bn) sgx = sgx + g * ((xv[u] + bv - mu) * is);
+          if (dx) dx[static_cast<int64_t>(rb + u * kRowLanes) * N + c] = ga * is * g;  // (bn_bwd_finalize_apply_body's frozen form)
         }
       }
     }
@@ -538,7 +544,8 @@ __device__ __forceinline__ void bn_bwd_finalize_apply_body(const float* __restri
                              int chunks, int use_bn, int act, int accumulate, float* __restrict__ dx,
                              float* __restrict__ dbias, float* __restrict__ dgamma, float* __restrict__ dbeta,
                              int dy_ld, int tiles_per_block, int bx, int by, uint16_t* __restrict__ dxb = nullptr,
-                             int lddxb = 0) {
+                             int lddxb = 0, bool apply = true) {
+  // apply == false: the parameter gradients only (row block 0) - dx was written by bn_bwd_partial_body (frozen statistics)
   // dxb: a bf16 copy of dx (row stride lddxb) for the input-gradient contraction that reads it next
   __shared__ float sm[2][kRowLanes][kColsPerBlock];
   __shared__ float s_g[kColsPerBlock], s_gx[kColsPerBlock];
@@ -548,7 +555,7 @@ __device__ __forceinline__ void bn_bwd_finalize_apply_body(const float* __restri
   // one row tile per workgroup: dy / x / y of the tile are requested before the partial sums are merged (see the forward)
   constexpr int kPre = kApplyRows / kRowLanes;
   float gpre[kPre], xpre[kPre], ypre[kPre];
-  const bool pre = tiles_per_block == 1 && c < N;
+  const bool pre = apply && tiles_per_block == 1 && c < N;
   if (pre) {
 #pragma unroll
     for (int k = 0; k < kPre; ++k) {
@@ -598,6 +605,7 @@ __device__ __forceinline__ void bn_bwd_finalize_apply_body(const float* __restri
     }
   }
   __syncthreads();
+  if (!apply) return;
   if (!pre && N <= kColsPerBlock / 2 && (N & (N - 1)) == 0) {
     // a NARROW tall layer (DIN's attention MLP ends 64 -> 32 -> 1 over B x L rows): with one lane per column, 64 columns per
     // workgroup, only N of every 64 lanes had work - the [204800, 1] layer's pass took 23.7 us for 2.4 MB.  The elementwise
@@ -706,6 +714,7 @@ struct BnItem {
   float* scratch;         // backward phase 1 output (when the sums are computed here)
   int B, N, chunks, mode, act, dy_ld, accumulate, tpb, gx;
   float eps, momentum;
+  int dx_in_partial;      // backward, frozen statistics: phase 1 writes dx, phase 2 (one row block) the parameter gradients only
 };
 struct BnMultiArgs {
   int n;
@@ -746,7 +755,7 @@ bn_bwd_partial_multi_kernel(BnMultiArgs a) {
   const BnItem& d = a.d[i];
   const int local = blockIdx.x - a.start[i];
   bn_bwd_partial_body(d.x, d.bias, d.yin, d.save_mean, d.save_invstd, d.dy, d.B, d.N, d.chunks, d.mode, d.act, d.scratch,
-                      d.dy_ld, local % d.gx, local / d.gx);
+                      d.dy_ld, local % d.gx, local / d.gx, d.gamma, d.dx_in_partial ? d.dx : nullptr);
 }
 
 __global__ void __launch_bounds__(kBlock)
@@ -756,7 +765,7 @@ bn_bwd_finalize_apply_multi_kernel(BnMultiArgs a) {
   const int local = blockIdx.x - a.start[i];
   bn_bwd_finalize_apply_body(d.partial, d.x, d.bias, d.gamma, d.yin, d.save_mean, d.save_invstd, d.dy, d.B, d.N, d.chunks,
                              d.mode, d.act, d.accumulate, d.dx, d.dbias, d.dgamma, d.dbeta, d.dy_ld, d.tpb,
-                             local % d.gx, local / d.gx);
+                             local % d.gx, local / d.gx, nullptr, 0, !d.dx_in_partial);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1779,6 +1788,14 @@ int er_bn_fwd_multi(const er_bn_layer* layers, int n, er_stream_t stream) {
   return 0;
 }
 
+static bool frozen_one_pass() {  // (A/B knob: '0' = column sums, then finalize + apply - two passes over dy / y / z)
+  static const bool on = [] {
+    const char* e = getenv("ER_BN_FROZEN_ONE_PASS");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+
 int er_bn_bwd_multi(const er_bn_layer* layers, int n, er_stream_t stream) {
   ER_REQUIRE(layers && n >= 1, "er_bn_bwd_multi: bad arguments");
   hipStream_t s = er::as_stream(stream);
@@ -1816,12 +1833,13 @@ int er_bn_bwd_multi(const er_bn_layer* layers, int n, er_stream_t stream) {
         d.scratch = scratch + off;
         d.partial = d.scratch;
         off += static_cast<size_t>(d.chunks) * q.N * 2;
+        d.dx_in_partial = (q.use_bn == ER_BN_FROZEN && frozen_one_pass()) ? 1 : 0;
         p1.d[p1.n] = d;
         p1.start[p1.n + 1] = p1.start[p1.n] + d.gx * d.chunks;
         ++p1.n;
       }
       p2.d[p2.n] = d;
-      p2.start[p2.n + 1] = p2.start[p2.n] + d.gx * static_cast<int>(er::ceil_div(q.B, er::kApplyRows * d.tpb));
+      p2.start[p2.n + 1] = p2.start[p2.n] + d.gx * (d.dx_in_partial ? 1 : static_cast<int>(er::ceil_div(q.B, er::kApplyRows * d.tpb)));
       ++p2.n;
     }
     if (p1.n > 0) {

@@ -66,6 +66,86 @@ gemm_f32_bna_kernel(GemmArgs g, BnA b) {
   gemm_f32_block<true, false, false, 0, 3>(g, blockIdx.x, 0, lds, false, nullptr, nullptr, &b, coef);
 }
 
+// A TALL projection onto 1 - 4 columns (DIN's attention score layer: [B x L, 32] -> [B x L, 1], reference
+// model/multi_tower_din.py:80-84 - the last tf.layers.dense of the attention DNN): 64-column MFMA tiles did 1/64 useful work
+// and took the generic fetch path ([K, 1] is not 16-byte addressable): 20.7 us for 26 MB.  Here lpr lanes share a row
+// (16 bytes of it each per trip: a wave reads whole contiguous rows), each lane accumulates its k's in order, the lanes'
+// partial sums are added by a fixed butterfly.  b.mean != nullptr: the row is the producing layer's z and its BatchNorm +
+// activation is applied on the way (BnA; y kept for the backward) - bn_act_one's arithmetic.
+template <int NC>
+__global__ void __launch_bounds__(kBlock)
+gemv_bna_kernel(const float* __restrict__ x, int ldx, int M, int K, BnA b, const float* __restrict__ W, int ldw,
+                const float* __restrict__ bias, float* __restrict__ C, int ldc, int lpr) {
+  constexpr int R = 4;  // rows per thread, their loads in flight together
+  const int rpb = kBlock / lpr;
+  const int lr = threadIdx.x % lpr;
+  const int r0 = (static_cast<int>(blockIdx.x) * R) * rpb + threadIdx.x / lpr;
+  const bool bn = b.mean != nullptr;
+  float acc[R][NC];
+#pragma unroll
+  for (int u = 0; u < R; ++u)
+#pragma unroll
+    for (int n = 0; n < NC; ++n) acc[u][n] = 0.f;
+  for (int c = lr; c < K / 4; c += lpr) {
+    const int k = 4 * c;
+    f32x4v xv[R];
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+      int row = r0 + u * rpb;
+      row = row < M ? row : M - 1;  // (clamped, never stored)
+      xv[u] = *reinterpret_cast<const f32x4v*>(x + static_cast<int64_t>(row) * ldx + k);
+    }
+    float w[4][NC];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int n = 0; n < NC; ++n) w[j][n] = W[static_cast<int64_t>(k + j) * ldw + n];
+    float mu[4], is[4], ga[4], be[4];
+    if (bn) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        mu[j] = b.mean[k + j];
+        is[j] = b.invstd[k + j];
+        ga[j] = b.gamma ? b.gamma[k + j] : 1.f;
+        be[j] = b.beta ? b.beta[k + j] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+      f32x4v v = xv[u];
+      if (bn) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float t = (v[j] - mu[j]) * is[j];
+          t = t * ga[j] + be[j];
+          if (b.act == ER_ACT_RELU) t = t > 0.f ? t : 0.f;
+          v[j] = t;
+        }
+        const int row = r0 + u * rpb;
+        if (b.y && row < M) *reinterpret_cast<f32x4v*>(b.y + static_cast<int64_t>(row) * b.ldy + k) = v;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int n = 0; n < NC; ++n) acc[u][n] = acc[u][n] + v[j] * w[j][n];
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < R; ++u) {
+#pragma unroll
+    for (int n = 0; n < NC; ++n) {
+      float a = acc[u][n];
+      for (int m = 1; m < lpr; m <<= 1) a = a + __shfl_xor(a, m, 64);
+      acc[u][n] = a;
+    }
+    const int row = r0 + u * rpb;
+    if (lr == 0 && row < M) {
+#pragma unroll
+      for (int n = 0; n < NC; ++n) C[static_cast<int64_t>(row) * ldc + n] = acc[u][n] + (bias ? bias[n] : 0.f);
+    }
+  }
+}
+
 // dq[b][j] = sum over the row tiles that hold rows of example b of its slot's partial (tile order: fixed)
 __global__ void __launch_bounds__(kBlock)
 din_dq_finish_kernel(const float* __restrict__ partial, int B, int L, int E, int slots, int64_t M, float* __restrict__ dq, int lddq) {
@@ -88,6 +168,16 @@ gemm_f32_grouped_kernel(GroupedArgs ga) {
   const GroupedCoords c = grouped_coords(ga, blockIdx.x);
   if (c.split < 0) return;
   gemm_f32_block<A_KC, B_KC>(ga.p[c.p], c.tile, c.split, lds, c.plain);
+}
+
+// ... forward (NN) with bias + BatchNorm on the moving statistics + activation in the epilogue of the problems that ask for
+// it (GemmArgs.fz_y): the experts of a multi-task model write z and y from one launch
+__global__ void __launch_bounds__(kBlock)
+gemm_f32_grouped_fz_kernel(GroupedArgs ga) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * 2 * kOpTile];
+  const GroupedCoords c = grouped_coords(ga, blockIdx.x);
+  if (c.split < 0) return;
+  gemm_f32_block<true, false, false, kEpiFrozenBn>(ga.p[c.p], c.tile, c.split, lds, c.plain);
 }
 
 // ... with the BatchNorm-backward column sums of each problem's producing layer in the epilogue (BnBwdEpi per problem)
@@ -326,6 +416,7 @@ int er::plan_grouped(int layout, const er_gemm_problem* pr, int n, bool bf16, er
   er::GroupedArgs& ga = plan->ga;
   er::GroupedReduceArgs& ra = plan->ra;
   bool& any_bn = plan->any_bn;
+  bool& any_fz = plan->any_fz;
   int64_t total_tiles = 0;
   for (int i = 0; i < n; ++i) {
     const er_gemm_problem& q = pr[i];
@@ -360,6 +451,7 @@ int er::plan_grouped(int layout, const er_gemm_problem* pr, int n, bool bf16, er
   ra.start[0] = 0;
   size_t ws_floats = 0;
   any_bn = false;
+  any_fz = false;
   int n_splits[er::kMaxGroup], xcd_ok[er::kMaxGroup];
   for (int i = 0; i < n; ++i) {
     const er_gemm_problem& q = pr[i];
@@ -381,6 +473,15 @@ int er::plan_grouped(int layout, const er_gemm_problem* pr, int n, bool bf16, er
       a.bn.col0 = 0; a.bn.n_src = q.N;
       any_bn = true;
     }
+    if (q.fz_y) {
+      ER_REQUIRE(layout == ER_GEMM_NN && !q.bn_partial && !q.col_stats && !q.accumulate && q.fz_mean && q.fz_var && q.fz_save &&
+                     (q.fz_act == ER_ACT_NONE || q.fz_act == ER_ACT_RELU),
+                 "er_gemm_grouped_f32: problem %d: bad frozen-BatchNorm epilogue arguments", i);
+      a.bn.zbias = q.fz_bias; a.bn.z = q.fz_gamma; a.bn.y = q.fz_beta; a.bn.mean = q.fz_mean; a.bn.invstd = q.fz_var;
+      a.bn.act = q.fz_act;
+      a.fz_y = q.fz_y; a.fz_save = q.fz_save; a.fz_eps = q.fz_eps;
+      any_fz = true;
+    }
     int64_t sp = want;
     // a long contraction (DIN's attention MLP contracts over B x L = 204,800 rows into an 80-column output) gets
     // splits of at most 2048 rows whatever the group's tile count asks for: 13 splits of 15,753 rows took 0.52 ms
@@ -399,7 +500,7 @@ int er::plan_grouped(int layout, const er_gemm_problem* pr, int n, bool bf16, er
     if (sp > max_splits) sp = max_splits;
     const int64_t max_by_k = q.K / (4 * er::BK32);
     if (sp > max_by_k) sp = max_by_k;
-    if (sp < 1 || q.col_stats || q.bn_partial) sp = 1;
+    if (sp < 1 || q.col_stats || q.bn_partial || q.fz_y) sp = 1;
     a.k_per_split = static_cast<int>(er::ceil_div(er::ceil_div(q.K, sp), er::BK32)) * er::BK32;
     a.splits = static_cast<int>(er::ceil_div(q.K, a.k_per_split));
     const int64_t tiles = er::ceil_div(q.M, er::BM) * er::ceil_div(q.N, er::BN);
@@ -458,7 +559,10 @@ int gemm_grouped_f32(int layout, const er_gemm_problem* pr, int n, er_stream_t s
   const er::GroupedArgs& ga = plan.ga;
   const bool any_bn = plan.any_bn;
   dim3 grid(static_cast<unsigned>(er::grouped_grid(ga))), block(er::kBlock);
-  if (bf16) {
+  ER_REQUIRE(!plan.any_fz || (!bf16 && !any_bn && layout == ER_GEMM_NN), "er_gemm_grouped: the frozen-BatchNorm epilogue is fp32 NN only");
+  if (plan.any_fz) {
+    hipLaunchKernelGGL(er::gemm_f32_grouped_fz_kernel, grid, block, 0, s, ga);
+  } else if (bf16) {
     switch (layout) {
       case ER_GEMM_NN: hipLaunchKernelGGL((er::gemm_bf16_grouped_kernel<true, false>), grid, block, 0, s, ga); break;
       case ER_GEMM_NT: hipLaunchKernelGGL((er::gemm_bf16_grouped_kernel<true, true>), grid, block, 0, s, ga); break;
@@ -590,6 +694,31 @@ int er_gemm_f32_bn_a(int32_t M, int32_t N, int32_t K, const float* z, int32_t ld
   er::BnA b{mean, invstd, gamma, beta, act, y, ldy};
   const int64_t n_tiles = er::ceil_div(N, er::BN) * er::ceil_div(M, er::BM);
   hipLaunchKernelGGL(er::gemm_f32_bna_kernel, dim3(static_cast<unsigned>(n_tiles)), dim3(er::kBlock), 0, er::as_stream(stream), a, b);
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
+int er_gemv_f32_bn_a(int32_t M, int32_t N, int32_t K, const float* x, int32_t ldx, const float* mean, const float* invstd,
+                     const float* gamma, const float* beta, int act, float* y, int32_t ldy, const float* W, int32_t ldw, float* C,
+                     int32_t ldc, const float* bias, er_stream_t stream) {
+  ER_REQUIRE(x && W && C && M > 0 && N >= 1 && N <= 4 && K > 0, "er_gemv_f32_bn_a: bad arguments (1 <= N <= 4)");
+  ER_REQUIRE(K % 4 == 0 && ldx >= K && ldx % 4 == 0 && ldw >= N && ldc >= N && (reinterpret_cast<uintptr_t>(x) & 15) == 0,
+             "er_gemv_f32_bn_a: K and ldx multiples of 4, x 16-byte aligned");
+  ER_REQUIRE(!mean || (invstd && (!y || (ldy >= K && ldy % 4 == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0))),
+             "er_gemv_f32_bn_a: bad BatchNorm arguments");
+  ER_REQUIRE(act == ER_ACT_NONE || act == ER_ACT_RELU, "er_gemv_f32_bn_a: activation %d", act);
+  int lpr = 1;
+  while (lpr * 2 <= 8 && lpr * 2 <= K / 4) lpr *= 2;
+  er::BnA b{mean, invstd, gamma, beta, act, y, ldy};
+  const int rows_per_block = (er::kBlock / lpr) * 4;
+  dim3 grid(static_cast<unsigned>(er::ceil_div(M, rows_per_block))), block(er::kBlock);
+  hipStream_t s = er::as_stream(stream);
+  switch (N) {
+    case 1: hipLaunchKernelGGL(er::gemv_bna_kernel<1>, grid, block, 0, s, x, ldx, M, K, b, W, ldw, bias, C, ldc, lpr); break;
+    case 2: hipLaunchKernelGGL(er::gemv_bna_kernel<2>, grid, block, 0, s, x, ldx, M, K, b, W, ldw, bias, C, ldc, lpr); break;
+    case 3: hipLaunchKernelGGL(er::gemv_bna_kernel<3>, grid, block, 0, s, x, ldx, M, K, b, W, ldw, bias, C, ldc, lpr); break;
+    default: hipLaunchKernelGGL(er::gemv_bna_kernel<4>, grid, block, 0, s, x, ldx, M, K, b, W, ldw, bias, C, ldc, lpr); break;
+  }
   ER_LAUNCH_CHECK();
   return 0;
 }

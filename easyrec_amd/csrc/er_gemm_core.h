@@ -44,7 +44,17 @@ struct GemmArgs {
   int splits;
   float* col_stats;   // nullptr, or [gridDim.y][N][3] Welford (count, mean, M2) of the output columns per row tile
   BnBwdEpi bn;        // bn.partial != nullptr: emit the BatchNorm-backward column sums of the output tile
+  // fz_y != nullptr (kernels instantiated with XEPI == kEpiFrozenBn, forward launches: bn is free there): the output ALSO goes
+  // through bias + BatchNorm on the MOVING statistics + activation in the epilogue (the experts of the reference's MMoE /
+  // DBMTL, layers/mmoe.py:62-83: batch_normalization(training=False) inside the training graph) - C keeps the contraction z,
+  // fz_y [M][ldc] gets y = act((((z + bias) - mean) * invstd) * gamma + beta), bn_frozen_apply_body's arithmetic with
+  //   bn.zbias = bias, bn.z = gamma, bn.y = beta, bn.mean = moving_mean, bn.invstd = moving VARIANCE, bn.act = activation;
+  // row tile 0 writes fz_save[0 .. N) = mean, fz_save[N .. 2N) = 1 / sqrt(var + fz_eps) for the backward.
+  float* fz_y = nullptr;
+  float* fz_save = nullptr;
+  float fz_eps = 0.f;
 };
+constexpr int kEpiFrozenBn = 7;  // (an XEPI value beside ER_EPI_CROSS_FWD / _BWD)
 
 // Loads 4 consecutive elements along the CONTIGUOUS dimension of the operand tile.
 //   K_CONTIG : elements (mn, k..k+3);  else: elements (mn..mn+3, k)
@@ -517,7 +527,7 @@ __device__ __forceinline__ void gemm_f32_block(const GemmArgs& g, int bx, int bz
   // cross epilogues: x0 / x_l (forward), dout / du_in and the lower layer's x0 / u / x_l / dx0 (backward) of the 16 positions
   float qa[XEPI ? 16 : 1], qb[XEPI ? 16 : 1], qc[XEPI == ER_EPI_CROSS_BWD ? 16 : 1], qd[XEPI == ER_EPI_CROSS_BWD ? 16 : 1],
       qe[XEPI == ER_EPI_CROSS_BWD ? 16 : 1], qf[XEPI == ER_EPI_CROSS_BWD ? 16 : 1];
-  if (XEPI) {
+  if (XEPI && XEPI != kEpiFrozenBn) {
     int c = n0 + wn * 32 + (lane & 31);
     c = c < g.N ? c : g.N - 1;
     const bool with_diag = xe->diag != 0.f;
@@ -768,6 +778,29 @@ __device__ __forceinline__ void gemm_f32_block(const GemmArgs& g, int bx, int bz
     return;
   }
   if (col >= g.N) return;
+  if (XEPI == kEpiFrozenBn && g.fz_y != nullptr) {  // (a grouped launch may mix problems with and without it; host: splits == 1)
+    const float fb = g.bn.zbias ? g.bn.zbias[col] : 0.f;
+    const float mu = g.bn.mean[col];
+    const float is = 1.f / sqrtf(g.bn.invstd[col] + g.fz_eps);
+    const float ga = g.bn.z ? g.bn.z[col] : 1.f, be = g.bn.y ? g.bn.y[col] : 0.f;
+    if (ty == 0 && wm == 0 && khalf == 0) {
+      g.fz_save[col] = mu;
+      g.fz_save[g.N + col] = is;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+      if (row < g.M) {
+        const float zv = acc[r] + bv;
+        g.C[static_cast<int64_t>(row) * g.ldc + col] = zv;
+        float v = ((zv + fb) - mu) * is;
+        v = v * ga + be;
+        if (g.bn.act == ER_ACT_RELU) v = v > 0.f ? v : 0.f;
+        g.fz_y[static_cast<int64_t>(row) * g.ldc + col] = v;
+      }
+    }
+    return;
+  }
   float* Cz = g.C + (g.splits > 1 ? static_cast<int64_t>(bz) * g.M * g.N : 0);
   const int ldc = g.splits > 1 ? g.N : g.ldc;
   if (g.accumulate && g.splits == 1) {
@@ -914,6 +947,7 @@ struct GroupedPlan {
   GroupedArgs ga;
   GroupedReduceArgs ra;
   bool any_bn;
+  bool any_fz;  // a problem with the frozen-BatchNorm forward epilogue (GemmArgs.fz_y)
 };
 // the two regions of a grouped grid from the problems' tile and k-split counts (GroupedArgs); by_xcd[p] 0: problem p in
 // the legacy region only

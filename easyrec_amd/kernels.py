@@ -284,7 +284,10 @@ class GemmProblem(ctypes.Structure):  # = er_gemm_problem
               ('col_stats', ctypes.c_void_p),
               ('bn_z', ctypes.c_void_p), ('bn_zbias', ctypes.c_void_p), ('bn_y', ctypes.c_void_p),
               ('bn_mean', ctypes.c_void_p), ('bn_invstd', ctypes.c_void_p), ('bn_ld', ctypes.c_int32),
-              ('bn_use_bn', ctypes.c_int32), ('bn_act', ctypes.c_int32), ('bn_partial', ctypes.c_void_p)]
+              ('bn_use_bn', ctypes.c_int32), ('bn_act', ctypes.c_int32), ('bn_partial', ctypes.c_void_p),
+              ('fz_bias', ctypes.c_void_p), ('fz_gamma', ctypes.c_void_p), ('fz_beta', ctypes.c_void_p),
+              ('fz_mean', ctypes.c_void_p), ('fz_var', ctypes.c_void_p), ('fz_eps', ctypes.c_float), ('fz_act', ctypes.c_int32),
+              ('fz_y', ctypes.c_void_p), ('fz_save', ctypes.c_void_p)]
 
 
 class BnLayer(ctypes.Structure):  # = er_bn_layer
@@ -855,6 +858,8 @@ class HipBackend(object):
     assert out.shape == (M, N) and out.stride(1) == 1 and out.dtype == torch.float32
     if bf16 and self._gemm_bf16_fast(layout, a, b, out, bias, accumulate, M, N, K, col_stats=col_stats):
       return out
+    if layout == GEMM_NN and not bf16 and not accumulate and col_stats is None and self.gemv_ok(a, M, N, K):
+      return self._gemv(a, None, b, bias, out)
     self._log_gemm('gemm_bf16_kernel' if bf16 else 'gemm_f32_kernel', layout, M, N, K)
     fn = self.lib.er_gemm_bf16 if bf16 else self.lib.er_gemm_f32
     if col_stats is not None:
@@ -1114,6 +1119,16 @@ class HipBackend(object):
         q.bn_mean, q.bn_invstd = _ptr(src.mean), _ptr(src.invstd)
         q.bn_ld, q.bn_use_bn, q.bn_act = src.z.stride(0), int(src.mean is not None), int(src.act)
         q.bn_partial = partial.data_ptr()
+      fz = pr[7] if len(pr) > 7 else None  # (the frozen-BatchNorm forward epilogue: er_gemm_problem.fz_*)
+      if fz is not None:
+        assert layout == GEMM_NN and not bf16 and stats is None and bn is None and not accumulate
+        y, save = fz['y'], fz['save']
+        assert y.shape == (M, N) and y.stride(0) == out.stride(0) and y.stride(1) == 1 and save.is_contiguous() and \
+            save.numel() == 2 * N
+        q.fz_bias, q.fz_gamma, q.fz_beta = _ptr(fz.get('bias')), _ptr(fz.get('gamma')), _ptr(fz.get('beta'))
+        q.fz_mean, q.fz_var = fz['moving_mean'].data_ptr(), fz['moving_var'].data_ptr()
+        q.fz_eps, q.fz_act = float(fz['eps']), int(fz['act'])
+        q.fz_y, q.fz_save = y.data_ptr(), save.data_ptr()
     return arr
 
   # weight gradients of a backward pass: queued by LinearFn / LinearBNActFn, contracted together by flush_wgrads()
@@ -1490,6 +1505,35 @@ class HipBackend(object):
     return (K % 4 == 0 and K <= 256 and z.is_contiguous() and y.is_contiguous() and w.dim() == 2 and w.stride(1) == 1 and
             (z.data_ptr() | y.data_ptr()) % 16 == 0)
 
+  # the bias + frozen BatchNorm + activation of a multi-task model's expert layers inside the grouped contraction's epilogue
+  # (er_gemm_problem.fz_*: one launch writes z and y; the depth's BatchNorm launch disappears) - A/B switch
+  frozen_bn_epilogue = os.environ.get('EASYREC_AMD_FROZEN_BN_EPILOGUE', '1') != '0'
+
+  # tall projections onto <= 4 columns (DIN's attention scores [B x L, 32] -> [B x L, 1]) by er_gemv_f32_bn_a - A/B switch
+  tall_gemv = os.environ.get('EASYREC_AMD_TALL_GEMV', '1') != '0'
+
+  def gemv_ok(self, x, M, N, K):
+    return (self.tall_gemv and N <= 4 and M >= self.BN_IN_STAGING_MIN_ROWS and K % 4 == 0 and x.stride(1) == 1 and
+            x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0)
+
+  def _gemv(self, x, pend, w, bias, out=None):
+    """out [M, N <= 4] = x . w (+ bias), or act(BatchNorm(z)) . w for a deferred apply `pend` (x = its z; statistics already
+    finalized)"""
+    M, K = x.shape
+    N = w.shape[1]
+    if out is None:
+      out = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    if self.op_log is not None:
+      self.op_log.append(('er::gemv_bna_kernel<%d>' % N, 2.0 * M * N * K))
+    bn = pend is not None
+    y = pend['y'] if bn else None
+    self._ck(self.lib.er_gemv_f32_bn_a(M, N, K, _p(x), ctypes.c_int32(x.stride(0)), _p(pend['mean']) if bn else None,
+                                       _p(pend['invstd']) if bn else None, _p(pend['gamma']) if bn else None,
+                                       _p(pend['beta']) if bn else None, int(pend['act']) if bn else 0, _p(y),
+                                       ctypes.c_int32(y.stride(0) if bn else 0), _p(w), ctypes.c_int32(w.stride(0)), _p(out),
+                                       ctypes.c_int32(out.stride(0)), _p(bias), _stream()), 'er_gemv_f32_bn_a')
+    return out
+
   def gemm_bn_a(self, pend, w, bias, col_stats=None):
     """out [M, N] = act(BatchNorm(z)) . w (+ bias) for the deferred BatchNorm apply `pend` (LinearBNActFn(defer_apply=True)):
     the statistics are finalized by a launch of their own, the apply runs while the contraction stages its A tiles and leaves
@@ -1501,6 +1545,8 @@ class HipBackend(object):
                                                 ctypes.c_float(pend['eps']), ctypes.c_float(pend['momentum']),
                                                 _p(pend['moving_mean']), _p(pend['moving_var']), _p(pend['mean']),
                                                 _p(pend['invstd']), _stream()), 'er_bn_finalize_from_stats')
+    if col_stats is None and self.gemv_ok(z, M, N, K):
+      return self._gemv(z, pend, w, bias)
     out = torch.empty(M, N, dtype=torch.float32, device=z.device)
     if col_stats is not None:
       assert col_stats.numel() >= self.gemm_row_tiles(M) * N * 3 and col_stats.dtype == torch.float32
@@ -2861,6 +2907,10 @@ class GroupedLinearFn(torch.autograd.Function):
   def forward(ctx, E, stats_mask, sinks, srcs, *args):
     be = hip()
     xs, ws, bs = args[:E], args[E:2 * E], args[2 * E:3 * E]
+    # fzs[e]: None, or dict(bias, gamma, beta, moving_mean, moving_var, eps, act) - layer e's output also goes through the frozen
+    # BatchNorm + activation in the launch's epilogue; the outputs then carry (y_e, save_e = [mean | invstd]) behind the statistics
+    fzs = args[3 * E] if len(args) > 3 * E else None
+    ctx.has_fzs = len(args) > 3 * E
     ctx.gsinks = [sk if (sk is not None and x.stride(-1) == 1) else None for sk, x in zip(sinks, xs)]
     # srcs[e]: the BnSource of x_e when it IS the output of a dense + BatchNorm(train) layer: the input-gradient launch
     # then also emits that layer's BatchNorm-backward column sums (er_gemm_problem.bn_*)
@@ -2868,14 +2918,21 @@ class GroupedLinearFn(torch.autograd.Function):
     ctx.srcs = [sc if (fused and sc is not None and sc.fused and x.stride(-1) == 1) else None
                 for sc, x in zip(srcs, xs)]
     xs = [x if x.stride(-1) == 1 else x.contiguous() for x in xs]
-    zs, stats, problems = [], [], []
+    zs, stats, problems, pre = [], [], [], []
     for e in range(E):
       M, N = xs[e].shape[0], ws[e].shape[1]
       z = torch.empty(M, N, dtype=torch.float32, device=xs[e].device)
       st = torch.empty(be.gemm_row_tiles(M) * N * 3, dtype=torch.float32, device=z.device) if stats_mask[e] else None
       zs.append(z)
       stats.append(st if st is not None else torch.empty(0, device=z.device))
-      problems.append((xs[e], ws[e].detach(), z, None if bs[e] is None else bs[e].detach(), False, st))
+      fz = None
+      if fzs is not None and fzs[e] is not None:
+        assert bs[e] is None and st is None
+        fz = dict(fzs[e], y=torch.empty_like(z), save=torch.empty(2, N, dtype=torch.float32, device=z.device))
+        pre += [fz['y'], fz['save']]
+      elif fzs is not None:
+        pre += [torch.empty(0, device=z.device), torch.empty(0, device=z.device)]
+      problems.append((xs[e], ws[e].detach(), z, None if bs[e] is None else bs[e].detach(), False, st, None, fz))
     be.gemm_grouped(GEMM_NN, problems)
     ctx.save_for_backward(*xs, *ws)
     ctx.E, ctx.bs = E, bs
@@ -2883,8 +2940,8 @@ class GroupedLinearFn(torch.autograd.Function):
     ctx.stats_mask = tuple(stats_mask)
     ctx.set_materialize_grads(False)  # (the statistics outputs get no gradient: no zero tensors to be filled for them)
     ctx.sink = be.wgrad_sink()
-    ctx.mark_non_differentiable(*stats)
-    return tuple(zs) + tuple(stats)
+    ctx.mark_non_differentiable(*stats, *pre)
+    return tuple(zs) + tuple(stats) + tuple(pre)
 
   @staticmethod
   def backward(ctx, *grads):
@@ -2964,7 +3021,7 @@ class GroupedLinearFn(torch.autograd.Function):
       be.colsum(narrow[0][0], out=narrow[0][1], accumulate=True)
     elif narrow:
       be.colsum_narrow_multi(narrow, accumulate=True)
-    return (None, None, None, None) + tuple(dxs) + tuple(dws) + tuple(dbs)
+    return (None, None, None, None) + tuple(dxs) + tuple(dws) + tuple(dbs) + ((None,) if ctx.has_fzs else ())
 
 
 class BNFromStatsFn(torch.autograd.Function):
@@ -3014,12 +3071,25 @@ class GroupedBNActFn(torch.autograd.Function):
   def forward(ctx, E, cfgs, *args):
     be = hip()
     zs, stats, biases, gammas, betas = (args[i * E:(i + 1) * E] for i in range(5))
-    layers = []
+    # pres[e] = (y, save [2, N]): layer e was already applied by its contraction's epilogue (GroupedLinearFn, fzs) - only its
+    # backward is this Function's
+    pres = args[5 * E:6 * E] if len(args) >= 6 * E else (None,) * E
+    layers, todo = [], []
     for e in range(E):
       mode, act, mm, mv, eps, momentum, _ = cfgs[e]
+      if pres[e] is not None:
+        continue
+      todo.append(e)
       layers.append(dict(x=zs[e], bias=biases[e], gamma=gammas[e], beta=betas[e], moving_mean=mm, moving_var=mv,
                          col_stats=stats[e], use_bn=mode, act=act, eps=eps, momentum=momentum))
-    outs = be.bn_fwd_multi(layers)
+    done = be.bn_fwd_multi(layers) if layers else []
+    outs = [None] * E
+    for e, o in zip(todo, done):
+      outs[e] = o
+    for e in range(E):
+      if pres[e] is not None:
+        y, save = pres[e]
+        outs[e] = (y.detach(), save[0], save[1])  # (a new tensor object over the same memory: this Function's output)
     fused = getattr(be, 'fused_bn_bwd', False)
     ctx.owns, saved = [], []
     for e in range(E):
@@ -3034,6 +3104,7 @@ class GroupedBNActFn(torch.autograd.Function):
       saved += [zs[e], biases[e], gammas[e], betas[e], y, mean, invstd]
     ctx.save_for_backward(*saved)
     ctx.E, ctx.cfgs = E, cfgs
+    ctx.n_extra = len(args) - 5 * E
     _bn_tls.last = ctx.owns if any(o is not None for o in ctx.owns) else None  # (the caller tags the outputs)
     return tuple(o[0] for o in outs)
 
@@ -3063,7 +3134,8 @@ class GroupedBNActFn(torch.autograd.Function):
     outs = be.bn_bwd_multi(layers)
     dzs = tuple(o[0] for o in outs)
     none = (None,) * E
-    return (None, None) + dzs + none + tuple(o[1] for o in outs) + tuple(o[2] for o in outs) + tuple(o[3] for o in outs)
+    return (None, None) + dzs + none + tuple(o[1] for o in outs) + tuple(o[2] for o in outs) + tuple(o[3] for o in outs) + \
+        (None,) * ctx.n_extra
 
 
 class FMFn(torch.autograd.Function):

@@ -237,11 +237,29 @@ def run_parallel(stacks, inputs, extra_dense=()):
     train_bn = [m is not None and bool(m[0]) and m[2] for m in metas]  # batch statistics: from the GEMM's epilogue
     sinks = tuple(kernels.grad_sink_of(x) for x in xs)
     srcs = tuple(kernels.bn_source_of(x) for x in xs)
-    out = kernels.GroupedLinearFn.apply(E, tuple(train_bn), sinks, srcs, *xs, *ws, *bs)
-    zs, stats = out[:E], out[E:]
     be = kernels.hip()
     lay = [e for e, m in enumerate(metas) if m is not None]
-    if getattr(be, 'grouped_bn', False) and len(lay) > 1 and all(zs[e].shape[0] <= be.BN_MULTI_MAX_ROWS for e in lay):
+    multi_bn = getattr(be, 'grouped_bn', False) and len(lay) > 1 and all(xs[e].shape[0] <= be.BN_MULTI_MAX_ROWS for e in lay)
+    # layers on the MOVING statistics (the experts of the reference's MMoE: batch_normalization(training=False) in training):
+    # bias + normalise + activate inside the contraction's epilogue - the launch writes z and y (er_gemm_problem.fz_*)
+    fzs = None
+    if multi_bn and getattr(be, 'frozen_bn_epilogue', False) and not ctx.building:
+      fzs = [None] * E
+      for e in lay:
+        use_bn, relu, training, gamma, beta, mm, mv, bias = metas[e]
+        if use_bn and not training and not train_bn[e] and bs[e] is None:
+          fzs[e] = dict(bias=bias.detach(), gamma=gamma.detach(), beta=beta.detach(), moving_mean=mm, moving_var=mv,
+                        eps=BN_EPSILON, act=kernels.ACT_RELU if relu else kernels.ACT_NONE)
+      if not any(f is not None for f in fzs):
+        fzs = None
+    if fzs is not None:
+      out = kernels.GroupedLinearFn.apply(E, tuple(train_bn), sinks, srcs, *xs, *ws, *bs, fzs)
+      pres = [(out[2 * E + 2 * e], out[2 * E + 2 * e + 1]) if fzs[e] is not None else None for e in range(E)]
+    else:
+      out = kernels.GroupedLinearFn.apply(E, tuple(train_bn), sinks, srcs, *xs, *ws, *bs)
+      pres = None
+    zs, stats = out[:E], out[E:2 * E]
+    if multi_bn:
       # the bias / BatchNorm / activation kernels of the depth as one launch (kernels.GroupedBNActFn)
       cfgs, a_b, a_g, a_be = [], [], [], []
       for e in lay:
@@ -257,8 +275,9 @@ def run_parallel(stacks, inputs, extra_dense=()):
         a_b.append(eb)
         a_g.append(gamma)
         a_be.append(beta)
+      extra = [pres[e] for e in lay] if pres is not None else []
       ys = kernels.GroupedBNActFn.apply(len(lay), tuple(cfgs), *[zs[e] for e in lay],
-                                        *[stats[e] if train_bn[e] else None for e in lay], *a_b, *a_g, *a_be)
+                                        *[stats[e] if train_bn[e] else None for e in lay], *a_b, *a_g, *a_be, *extra)
       owns = kernels.take_last_bn_source() or [None] * len(lay)
       for e in range(E):
         if metas[e] is None:

@@ -886,6 +886,15 @@ typedef struct er_gemm_problem {
   const float* bn_z; const float* bn_zbias; const float* bn_y; const float* bn_mean; const float* bn_invstd;
   int32_t bn_ld, bn_use_bn, bn_act;
   float* bn_partial;
+  /* fz_y != NULL (layout NN, fp32; no col_stats / bn_partial / accumulate): the problem's output ALSO goes through
+   * bias + BatchNorm on the MOVING statistics + activation in the epilogue - the experts of the reference's MMoE / DBMTL
+   * (layers/mmoe.py:62-83 builds them with batch_normalization(training=False) inside the training graph; layers/dnn.py:57-79):
+   * C keeps z = A . B, fz_y [M][ldc] receives y = act((((z + fz_bias) - fz_mean) * (1 / sqrt(fz_var + fz_eps))) * fz_gamma +
+   * fz_beta) - er_bn_act_fwd's frozen arithmetic, operation by operation - and fz_save [2][N] the mean and 1 / sqrt(var + eps)
+   * the backward reads.  fz_bias / fz_gamma / fz_beta may be NULL (0 / 1 / 0). */
+  const float* fz_bias; const float* fz_gamma; const float* fz_beta; const float* fz_mean; const float* fz_var;
+  float fz_eps; int32_t fz_act;
+  float* fz_y; float* fz_save;
 } er_gemm_problem;
 int er_gemm_grouped_f32(int layout, const er_gemm_problem* problems_host, int n, er_stream_t stream);
 /* ... with the operands rounded to bf16 while staged (er_gemm_bf16's arithmetic: v_mfma_f32_32x32x16_bf16, fp32
@@ -1045,6 +1054,13 @@ int er_gemm_f32_cross(int layout, int32_t M, int32_t N, int32_t K, const float* 
 int er_gemm_f32_bn_a(int32_t M, int32_t N, int32_t K, const float* z, int32_t ldz, const float* mean, const float* invstd,
                      const float* gamma, const float* beta, int act, float* y, int32_t ldy, const float* W, int32_t ldw, float* C,
                      int32_t ldc, const float* bias, float* col_stats, er_stream_t stream);
+/* C [M][N] = op(x) . W [K][N] (+ bias) for a TALL projection onto N <= 4 columns (DIN's attention score layer [B x L, 32] ->
+ * [B x L, 1]: reference model/multi_tower_din.py:80-84, the last tf.layers.dense of the attention DNN, layers/dnn.py:57-62):
+ * rows are read whole, 16 bytes per lane, no 64-column MFMA tile.  op(x) = x (mean == NULL), or the producing layer's
+ * BatchNorm + activation of x = z as in er_gemm_f32_bn_a (y [M][ldy] keeps the activations, NULL: not kept).  K % 4 == 0. */
+int er_gemv_f32_bn_a(int32_t M, int32_t N, int32_t K, const float* x, int32_t ldx, const float* mean, const float* invstd,
+                     const float* gamma, const float* beta, int act, float* y, int32_t ldy, const float* W, int32_t ldw, float* C,
+                     int32_t ldc, const float* bias, er_stream_t stream);
 /* DIN's first attention layer WITHOUT the [B, L, 4E] block (north_star: "DIN-attention as fused HIP kernels"; reference
  * model/multi_tower_din.py:62-80 builds tf.concat([q, h, q - h, q * h], axis=-1) and feeds it to the attention DNN,
  * layers/dnn.py:57-79): the three contractions of the layer take q [B][ldq] and h [B * L][ldh] (E columns each) and form

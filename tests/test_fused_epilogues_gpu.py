@@ -420,3 +420,78 @@ def test_din_step_with_the_tall_batchnorm_applies_in_the_next_contraction_is_bit
   assert len(mv0) > 0
   for k in mv0:
     assert np.array_equal(mv1[k], mv0[k]), k
+
+
+@pytest.mark.parametrize('M,K,Ns', [(8192, 1152, (256, 256, 4)), (4096, 64, (192, 128, 64, 20)), (100, 36, (37, 64)), (8192, 256, (192,) * 4)])
+def test_grouped_contraction_with_the_frozen_batchnorm_in_its_epilogue_equals_the_two_launches(hip, M, K, Ns):
+  """er_gemm_grouped_f32 with er_gemm_problem.fz_* (bias + BatchNorm on the moving statistics + activation in the epilogue of
+  the problems that ask for it; the experts of the reference's MMoE, layers/mmoe.py:62-83 -> layers/dnn.py:57-79) against the
+  grouped contraction followed by the frozen BatchNorm launch: z, y, saved mean / invstd bit for bit; a problem of the same
+  launch without the epilogue (a gate) is the plain contraction."""
+  g = torch.Generator().manual_seed(M + K + sum(Ns))
+  x = torch.randn(M, K, generator=g).to(DEV)
+  ws = [(torch.randn(K, n, generator=g) * 0.1).to(DEV) for n in Ns]
+  plain = len(Ns) - 1  # the last problem has no epilogue (and a GEMM bias)
+  pb = torch.randn(Ns[-1], generator=g).to(DEV)
+  P = []
+  for n in Ns[:-1]:
+    P.append(dict(bias=torch.randn(n, generator=g).to(DEV), gamma=(torch.rand(n, generator=g) + 0.5).to(DEV),
+                  beta=torch.randn(n, generator=g).to(DEV), moving_mean=(torch.randn(n, generator=g) * 0.2).to(DEV),
+                  moving_var=(torch.rand(n, generator=g) + 0.3).to(DEV), eps=1e-3, act=kernels.ACT_RELU))
+  # apart
+  z1 = [torch.empty(M, n, device=DEV) for n in Ns]
+  hip.gemm_grouped(kernels.GEMM_NN, [(x, ws[e], z1[e], pb if e == plain else None, False) for e in range(len(Ns))])
+  outs = hip.bn_fwd_multi([dict(x=z1[e], bias=P[e]['bias'], gamma=P[e]['gamma'], beta=P[e]['beta'], moving_mean=P[e]['moving_mean'],
+                                moving_var=P[e]['moving_var'], col_stats=None, use_bn=kernels.BN_FROZEN, act=P[e]['act'], eps=1e-3,
+                                momentum=0.99) for e in range(plain)])
+  # one launch
+  z2 = [torch.full((M, n), float('nan'), device=DEV) for n in Ns]
+  fz = [dict(P[e], y=torch.full((M, Ns[e]), float('nan'), device=DEV), save=torch.empty(2, Ns[e], device=DEV)) for e in range(plain)]
+  hip.gemm_grouped(kernels.GEMM_NN, [(x, ws[e], z2[e], pb if e == plain else None, False, None, None, fz[e] if e < plain else None)
+                                     for e in range(len(Ns))])
+  torch.cuda.synchronize()
+  for e in range(len(Ns)):
+    assert torch.equal(z2[e], z1[e]), e
+  for e in range(plain):
+    y, mean, invstd = outs[e]
+    assert torch.equal(fz[e]['y'], y), e
+    assert torch.equal(fz[e]['save'][0], mean) and torch.equal(fz[e]['save'][1], invstd), e
+
+
+@pytest.mark.parametrize('name', ['mmoe_taobao_small.config', 'dbmtl_mmoe_taobao_small.config'])
+def test_multi_task_step_with_the_frozen_batchnorm_in_the_contractions_epilogue_is_bit_identical(hip, monkeypatch, name):
+  """MMoE / DBMTL-over-MMoE with the experts' bias + frozen BatchNorm + ReLU inside the grouped contraction's epilogue
+  (HipBackend.frozen_bn_epilogue) and as the depth's BatchNorm launch: losses of two steps and the first Adam moments
+  bit-identical."""
+  import os
+  from easyrec_amd.input.synthetic import SyntheticBatches
+  from easyrec_amd.model.easy_rec_estimator import EasyRecEstimator
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  cfg = os.path.join(root, 'configs', name)
+  seen = []
+  real = kernels.HipBackend._gemm_problems
+
+  def spy(self, layout, problems, *a, **k):
+    seen.append(sum(1 for pr in problems if len(pr) > 7 and pr[7] is not None))
+    return real(self, layout, problems, *a, **k)
+
+  monkeypatch.setattr(kernels.HipBackend, '_gemm_problems', spy)
+
+  def run(on):
+    monkeypatch.setattr(kernels.HipBackend, 'frozen_bn_epilogue', on)
+    # (B = 4096: every forward problem of the grouped launches is one k-split either way - at B = 512 the launch WITHOUT the
+    # epilogue splits the experts' contractions over k, another summation order)
+    est = EasyRecEstimator(cfg, device=DEV, batch_size=4096, seed=3).build()
+    gen = SyntheticBatches(est.pipeline_config.data_config, est.feature_configs, batch_size=4096, seed=11)
+    first = float(est.train_step(gen.next_batch())['total_loss'])
+    torch.cuda.synchronize()
+    m = est.varstore.slots['m'].clone()
+    second = float(est.train_step(gen.next_batch())['total_loss'])
+    return first, second, m
+
+  f1, s1, m1 = run(True)
+  n_on = sum(seen)
+  f0, s0, m0 = run(False)
+  assert n_on > 0 and sum(seen) == n_on, (n_on, sum(seen))  # (the epilogue form ran, and only when switched on)
+  assert f1 == f0 and s1 == s0, (f1, f0, s1, s0)
+  assert torch.equal(m1, m0)

@@ -1703,6 +1703,50 @@ def test_narrow_column_sums_of_several_matrices_in_one_launch_equal_the_single_l
     assert float(((got[2].double() - (base[2].double() if acc else 0)) - ref).abs().max()) < 1e-3
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('M,K,N', [(204800, 32, 1), (20000, 64, 4), (16500, 8, 2), (17000, 12, 3), (30000, 256, 1), (16385, 4, 1)])
+def test_tall_narrow_projection_and_its_batchnorm_in_staging_form(M, K, N):
+  """er_gemv_f32_bn_a - a tall projection onto <= 4 columns (DIN's attention scores, reference model/multi_tower_din.py:80-84)
+  without MFMA tiles - against a float64 product (1e-5 of the output's scale: another summation order than the tile kernel's),
+  and its form with the producing layer's BatchNorm apply on the way against apply-then-project through the same kernel, bit
+  for bit (activations, statistics, moving statistics, output)."""
+  hip = kernels.hip()
+  g = torch.Generator().manual_seed(M + K + N)
+  xbuf = torch.randn(M, K + 4, generator=g).to(DEV)
+  x = xbuf[:, :K]  # (a column block: row pitch K + 4)
+  w = (torch.randn(K, N, generator=g) * 0.3).to(DEV)
+  bias = torch.randn(N, generator=g).to(DEV)
+  assert hip.gemv_ok(x, M, N, K)
+  out = hip.gemm(kernels.GEMM_NN, x, w, bias=bias)
+  ref = x.double() @ w.double() + bias.double()
+  assert float((out.double() - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))
+  # the same columns through the MFMA tiles (col_stats asked for): the two kernels agree to rounding
+  st = torch.zeros(hip.gemm_row_tiles(M) * N * 3, device=DEV)
+  out_t = hip.gemm(kernels.GEMM_NN, x, w, bias=bias, col_stats=st)
+  assert float((out - out_t).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))
+  # BatchNorm of the producing layer applied on the way
+  gamma = (torch.rand(K, generator=g) + 0.5).to(DEV)
+  beta = torch.randn(K, generator=g).to(DEV)
+  z = x.contiguous()
+  chunks = hip.gemm_row_tiles(M)
+  stats = torch.empty(chunks * K * 3, device=DEV)
+  # column statistics of z as a GEMM epilogue would have written them: z = z . I
+  z2 = hip.gemm(kernels.GEMM_NN, z, torch.eye(K, device=DEV), col_stats=stats)
+  assert torch.equal(z2, z)
+  mm1, mv1 = torch.zeros(K, device=DEV), torch.ones(K, device=DEV)
+  y1, mean1, inv1 = hip.bn_apply_from_stats(z, None, stats, chunks, gamma, beta, 1e-3, 0.99, mm1, mv1, kernels.ACT_RELU)
+  out1 = hip.gemm(kernels.GEMM_NN, y1, w, bias=bias)
+  mm2, mv2 = torch.zeros(K, device=DEV), torch.ones(K, device=DEV)
+  pend = dict(z=z, stats=stats, chunks=chunks, gamma=gamma, beta=beta, eps=1e-3, momentum=0.99, moving_mean=mm2, moving_var=mv2,
+              act=kernels.ACT_RELU, y=torch.full_like(z, float('nan')), mean=torch.empty(K, device=DEV),
+              invstd=torch.empty(K, device=DEV))
+  assert hip.bn_a_ok(pend, w)
+  out2 = hip.gemm_bn_a(pend, w, bias)
+  torch.cuda.synchronize()
+  assert torch.equal(pend['mean'], mean1) and torch.equal(pend['invstd'], inv1) and torch.equal(mm2, mm1) and torch.equal(mv2, mv1)
+  assert torch.equal(pend['y'], y1) and torch.equal(out2, out1)
+
+
 def _misaligned(t):
   """a copy of t whose base address is 4 bytes past a 16-byte boundary (the library then takes its generic fetch path)"""
   buf = torch.empty(t.numel() + 5, dtype=t.dtype, device=t.device)
