@@ -153,6 +153,10 @@ def test_grouped_batchnorm_launches_change_no_bit_model_level(name):
   B = 256
   states = []
   prev = kernels.HipBackend.grouped_bn
+  prev_fz = kernels.HipBackend.frozen_bn_epilogue
+  # (the frozen-BatchNorm epilogue of the grouped contraction rides on the grouped form and keeps its problems in one k-split -
+  # another summation order at this batch size; it has its own bit-identity test in test_fused_epilogues_gpu.py)
+  kernels.HipBackend.frozen_bn_epilogue = False
   try:
     for on in (True, False):
       kernels.HipBackend.grouped_bn = on
@@ -163,6 +167,7 @@ def test_grouped_batchnorm_launches_change_no_bit_model_level(name):
       states.append((est.state_dict(slots=True), est.loss_values()))
   finally:
     kernels.HipBackend.grouped_bn = prev
+    kernels.HipBackend.frozen_bn_epilogue = prev_fz
   (sa, la), (sb, lb) = states
   assert la == lb
   for k in sb:
