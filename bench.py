@@ -297,7 +297,7 @@ FAMILIES = (  # first match wins; names as rocprofv3 / the profiler print them
     ('tail (weight gradients + embedding update)', ('emb_bwd_own_wgrad', 'emb_bwd_fix_reduce', 'emb_bwd_fix_opt',
                                                      'emb_reduce_local_wgrad')),
     ('collectives (RCCL)', ('rccl', 'nccl')),
-    ('gemm', ('gemm_', 'gemv_')),
+    ('gemm', ('gemm_', 'gemv_', 'wgrad_narrow')),
     ('batchnorm', ('er::bn_', 'dice', 'colsum')),
     ('embedding', ('er::emb_', 'hash_bucket', 'group_grad_finish', 'er::kv_', 'gather_rows', 'scatter_unique', 'rocprim')),
     ('interaction', ('fm_', 'cross_', 'din_', 'mmoe_', 'cin_', 'dot_interaction', 'rowsum', 'concat_cols', 'cast_bf16')),

@@ -146,6 +146,94 @@ gemv_bna_kernel(const float* __restrict__ x, int ldx, int M, int K, BnA b, const
   }
 }
 
+// The weight gradient of a TALL projection onto 1 - 4 columns, dW [K][N] = x^T . dz over rows >> K (DIN's attention score
+// layer: x [B x L, 32], dz [B x L, 1]): in the grouped launch this problem had a [rows, 1] operand no 16-byte load can take, so
+// its ~100 k-splits of 64 k-tiles each ran the one-tile-at-a-time generic loop and the whole launch waited for them.  Here a
+// workgroup owns a chunk of rows; lpr lanes share a row (16 bytes of x each), every lane keeps the products of ITS k's with
+// the row's dz in registers, the lanes that hold the same k's are added through LDS in a fixed order -> partial [chunk][K][N];
+// er_colsum_partials_multi-style reduction over the chunks follows (wgrad_narrow_reduce_kernel).
+template <int NC>
+__global__ void __launch_bounds__(kBlock)
+wgrad_narrow_partial_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dz, int lddz, int rows, int K,
+                            int rows_per_chunk, int lpr, float* __restrict__ partial) {
+  constexpr int R = 4;  // rows per lane and trip, their loads in flight together
+  __shared__ float sm[kBlock * 4 * NC];
+  const int rpb = kBlock / lpr;            // row lanes
+  const int lr = threadIdx.x % lpr, rl = threadIdx.x / lpr;
+  const int r_lo = static_cast<int>(blockIdx.x) * rows_per_chunk;
+  int r_hi = r_lo + rows_per_chunk;
+  r_hi = r_hi < rows ? r_hi : rows;
+  for (int c0 = 0; c0 < K / 4; c0 += lpr) {  // (K / 4 > lpr: the k groups in rounds)
+    const int c = c0 + lr;
+    const bool live = c < K / 4;
+    const int k = 4 * (live ? c : 0);
+    float acc[4][NC];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int n = 0; n < NC; ++n) acc[j][n] = 0.f;
+    for (int r0 = r_lo + rl; r0 < r_hi; r0 += R * rpb) {
+      f32x4v xv[R];
+      float dv[R][NC];
+#pragma unroll
+      for (int u = 0; u < R; ++u) {
+        int r = r0 + u * rpb;
+        r = r < r_hi ? r : r_hi - 1;  // (clamped; its products are dropped below)
+        xv[u] = *reinterpret_cast<const f32x4v*>(x + static_cast<int64_t>(r) * ldx + k);
+#pragma unroll
+        for (int n = 0; n < NC; ++n) dv[u][n] = dz[static_cast<int64_t>(r) * lddz + n];
+      }
+#pragma unroll
+      for (int u = 0; u < R; ++u) {
+        if (r0 + u * rpb < r_hi) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int n = 0; n < NC; ++n) acc[j][n] = acc[j][n] + xv[u][j] * dv[u][n];
+        }
+      }
+    }
+    __syncthreads();  // (the previous round's readers are done)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int n = 0; n < NC; ++n) sm[(rl * lpr + lr) * 4 * NC + j * NC + n] = acc[j][n];
+    __syncthreads();
+    // element e = (lr', j, n) of this round: the row lanes' values added in row-lane order
+    for (int e = threadIdx.x; e < lpr * 4 * NC; e += kBlock) {
+      const int l2 = e / (4 * NC), jn = e % (4 * NC);
+      const int c2 = c0 + l2;
+      if (c2 < K / 4) {
+        float t = 0.f;
+        for (int q = 0; q < rpb; ++q) t = t + sm[(q * lpr + l2) * 4 * NC + jn];
+        const int kk = 4 * c2 + jn / NC, n = jn % NC;
+        partial[(static_cast<int64_t>(blockIdx.x) * K + kk) * NC + n] = t;
+      }
+    }
+  }
+}
+
+// dW[e] (+)= sum over the chunks of partial[chunk][e]: one workgroup per element, lane t adds chunks t, t + 256, ..., then a
+// fixed tree over the lanes (a serial loop over ~512 chunks per element was a 90 us chain of dependent loads)
+__global__ void __launch_bounds__(kBlock)
+wgrad_narrow_reduce_kernel(const float* __restrict__ partial, int chunks, int KN, int N, float* __restrict__ dW, int lddw,
+                           int accumulate) {
+  __shared__ float sm[kBlock];
+  const int e = static_cast<int>(blockIdx.x);
+  float t = 0.f;
+  for (int c = threadIdx.x; c < chunks; c += kBlock) t = t + partial[static_cast<int64_t>(c) * KN + e];
+  sm[threadIdx.x] = t;
+  __syncthreads();
+  for (int w = kBlock / 2; w >= 1; w >>= 1) {
+    if (static_cast<int>(threadIdx.x) < w) sm[threadIdx.x] = sm[threadIdx.x] + sm[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    float* p = dW + static_cast<int64_t>(e / N) * lddw + e % N;
+    *p = accumulate ? *p + sm[0] : sm[0];
+  }
+}
+
 // dq[b][j] = sum over the row tiles that hold rows of example b of its slot's partial (tile order: fixed)
 __global__ void __launch_bounds__(kBlock)
 din_dq_finish_kernel(const float* __restrict__ partial, int B, int L, int E, int slots, int64_t M, float* __restrict__ dq, int lddq) {
@@ -719,6 +807,36 @@ int er_gemv_f32_bn_a(int32_t M, int32_t N, int32_t K, const float* x, int32_t ld
     case 3: hipLaunchKernelGGL(er::gemv_bna_kernel<3>, grid, block, 0, s, x, ldx, M, K, b, W, ldw, bias, C, ldc, lpr); break;
     default: hipLaunchKernelGGL(er::gemv_bna_kernel<4>, grid, block, 0, s, x, ldx, M, K, b, W, ldw, bias, C, ldc, lpr); break;
   }
+  ER_LAUNCH_CHECK();
+  return 0;
+}
+
+int er_wgrad_tall_narrow(int32_t rows, int32_t K, int32_t N, const float* x, int32_t ldx, const float* dz, int32_t lddz,
+                         float* dW, int32_t lddw, int accumulate, float* scratch, int64_t scratch_floats, er_stream_t stream) {
+  ER_REQUIRE(x && dz && dW && scratch && rows > 0 && K > 0 && N >= 1 && N <= 4, "er_wgrad_tall_narrow: bad arguments (1 <= N <= 4)");
+  ER_REQUIRE(K % 4 == 0 && ldx >= K && ldx % 4 == 0 && lddz >= N && lddw >= N && (reinterpret_cast<uintptr_t>(x) & 15) == 0,
+             "er_wgrad_tall_narrow: K and ldx multiples of 4, x 16-byte aligned");
+  int lpr = 1;
+  while (lpr * 2 <= 8 && lpr * 2 <= K / 4) lpr *= 2;
+  // ~2 workgroups per compute unit, whole trips of (row lanes x 4 rows) per chunk
+  const int trip = (er::kBlock / lpr) * 4;
+  int64_t rpc = er::ceil_div(rows, 512);
+  rpc = er::ceil_div(rpc, trip) * trip;
+  const int chunks = static_cast<int>(er::ceil_div(rows, rpc));
+  ER_REQUIRE(static_cast<int64_t>(chunks) * K * N <= scratch_floats, "er_wgrad_tall_narrow: scratch of %lld floats, need %lld",
+             (long long)scratch_floats, (long long)chunks * K * N);
+  hipStream_t s = er::as_stream(stream);
+  dim3 grid(static_cast<unsigned>(chunks)), block(er::kBlock);
+  const int irpc = static_cast<int>(rpc);
+  switch (N) {
+    case 1: hipLaunchKernelGGL(er::wgrad_narrow_partial_kernel<1>, grid, block, 0, s, x, ldx, dz, lddz, rows, K, irpc, lpr, scratch); break;
+    case 2: hipLaunchKernelGGL(er::wgrad_narrow_partial_kernel<2>, grid, block, 0, s, x, ldx, dz, lddz, rows, K, irpc, lpr, scratch); break;
+    case 3: hipLaunchKernelGGL(er::wgrad_narrow_partial_kernel<3>, grid, block, 0, s, x, ldx, dz, lddz, rows, K, irpc, lpr, scratch); break;
+    default: hipLaunchKernelGGL(er::wgrad_narrow_partial_kernel<4>, grid, block, 0, s, x, ldx, dz, lddz, rows, K, irpc, lpr, scratch); break;
+  }
+  ER_LAUNCH_CHECK();
+  hipLaunchKernelGGL(er::wgrad_narrow_reduce_kernel, dim3(static_cast<unsigned>(K * N)), block, 0, s, scratch, chunks, K * N, N,
+                     dW, lddw, accumulate);
   ER_LAUNCH_CHECK();
   return 0;
 }

@@ -1534,6 +1534,25 @@ class HipBackend(object):
                                        ctypes.c_int32(out.stride(0)), _p(bias), _stream()), 'er_gemv_f32_bn_a')
     return out
 
+  def wgrad_tall_narrow_ok(self, x, dz):
+    return (self.tall_gemv and x.dim() == 2 and dz.dim() == 2 and dz.shape[1] <= 4 and x.shape[0] >= self.BN_IN_STAGING_MIN_ROWS and
+            x.shape[1] % 4 == 0 and x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and dz.stride(1) == 1 and
+            x.dtype == torch.float32 and dz.dtype == torch.float32)
+
+  def wgrad_tall_narrow(self, x, dz, out, accumulate=True):
+    """out [K, N <= 4] (+)= x^T . dz for a tall x [rows, K] (er_wgrad_tall_narrow: the weight gradient of DIN's attention score
+    projection, which stalled the grouped weight-gradient launch on its [rows, 1] operand)"""
+    rows, K = x.shape
+    N = dz.shape[1]
+    assert out.shape == (K, N) and out.stride(1) == 1 and dz.shape[0] == rows
+    scratch = torch.empty(513 * K * N, dtype=torch.float32, device=x.device)
+    if self.op_log is not None:
+      self.op_log.append(('er::wgrad_narrow_partial_kernel<%d>' % N, 2.0 * rows * N * K))
+    self._ck(self.lib.er_wgrad_tall_narrow(rows, K, N, _p(x), ctypes.c_int32(x.stride(0)), _p(dz), ctypes.c_int32(dz.stride(0)),
+                                           _p(out), ctypes.c_int32(out.stride(0)), int(bool(accumulate)), _p(scratch),
+                                           ctypes.c_int64(scratch.numel()), _stream()), 'er_wgrad_tall_narrow')
+    return out
+
   def gemm_bn_a(self, pend, w, bias, col_stats=None):
     """out [M, N] = act(BatchNorm(z)) . w (+ bias) for the deferred BatchNorm apply `pend` (LinearBNActFn(defer_apply=True)):
     the statistics are finalized by a launch of their own, the apply runs while the contraction stages its A tiles and leaves
@@ -2764,7 +2783,9 @@ def _wgrad(be, x, dz, w_grad, bf16, sink):
   """dW = x^T . dz: queued for the grouped launch (accumulating into w_grad, a slice of the flat gradient buffer), else
   launched here.  Returns dW only without w_grad."""
   if w_grad is not None:
-    if not sink.put(x, dz, w_grad, bf16):
+    if not bf16 and hasattr(be, 'wgrad_tall_narrow_ok') and be.wgrad_tall_narrow_ok(x, dz) and w_grad.stride(-1) == 1:
+      be.wgrad_tall_narrow(x, dz, w_grad, accumulate=True)  # (a [rows, 1] operand would stall the grouped launch: see there)
+    elif not sink.put(x, dz, w_grad, bf16):
       be.gemm(GEMM_TN, x, dz, out=w_grad, accumulate=True, bf16=bf16)
     return None
   return be.gemm(GEMM_TN, x, dz, bf16=bf16)

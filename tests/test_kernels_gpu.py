@@ -1747,6 +1747,34 @@ def test_tall_narrow_projection_and_its_batchnorm_in_staging_form(M, K, N):
   assert torch.equal(pend['y'], y1) and torch.equal(out2, out1)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('rows,K,N', [(204800, 32, 1), (20000, 64, 4), (16500, 8, 2), (17000, 12, 3), (30000, 256, 1), (16385, 4, 1)])
+def test_weight_gradient_of_a_tall_narrow_projection(rows, K, N):
+  """er_wgrad_tall_narrow: dW [K, N <= 4] (+)= x^T . dz over >> K rows (DIN's attention score layer) against a float64 product
+  (2e-5 of the gradient's scale), overwriting and accumulating into a column block; run twice: the same bits."""
+  hip = kernels.hip()
+  g = torch.Generator().manual_seed(rows + K + N)
+  xbuf = torch.randn(rows, K + 4, generator=g).to(DEV)
+  x = xbuf[:, :K]
+  dzbuf = (torch.randn(rows, N + 2, generator=g) * 0.1).to(DEV)
+  dz = dzbuf[:, 1:1 + N]
+  assert hip.wgrad_tall_narrow_ok(x, dz)
+  ref = x.double().t() @ dz.double()
+  scale = max(1e-6, float(ref.abs().max()))
+  out = torch.full((K, N), float('nan'), device=DEV)
+  hip.wgrad_tall_narrow(x, dz, out, accumulate=False)
+  assert float((out.double() - ref).abs().max()) <= 2e-5 * scale
+  wide = torch.randn(K, N + 5, generator=g).to(DEV)
+  base = wide.clone()
+  hip.wgrad_tall_narrow(x, dz, wide[:, 2:2 + N], accumulate=True)
+  assert torch.equal(wide[:, :2], base[:, :2]) and torch.equal(wide[:, 2 + N:], base[:, 2 + N:])
+  assert float(((wide[:, 2:2 + N] - base[:, 2:2 + N]).double() - ref).abs().max()) <= 2e-5 * scale + 1e-6
+  out2 = torch.empty(K, N, device=DEV)
+  hip.wgrad_tall_narrow(x, dz, out2, accumulate=False)
+  torch.cuda.synchronize()
+  assert torch.equal(out, out2)
+
+
 def _misaligned(t):
   """a copy of t whose base address is 4 bytes past a 16-byte boundary (the library then takes its generic fetch path)"""
   buf = torch.empty(t.numel() + 5, dtype=t.dtype, device=t.device)
