@@ -64,5 +64,9 @@ echo mmoe25m | tee -a $O/lines_summary.txt; run mmoe25m --config configs/mmoe_ta
 echo mmoe200m_compact_parity | tee -a $O/lines_summary.txt; run mmoe200m --config configs/mmoe_taobao_4task_d64_200m.config --no_cpu_baseline --parity_only --steady_steps 0 --precondition 64
 echo uniform | tee -a $O/lines_summary.txt; run uniform --ids uniform --no_cpu_baseline --steady_steps 256
 echo ep1_rccl | tee -a $O/lines_summary.txt; run ep1_rccl --force_ep --rccl --no_cpu_baseline --steady_steps 0
+for cfg in din_taobao_10m mmoe_taobao_4task_d64_25m; do
+  timeout 600 rocprofv3 --kernel-trace --output-format rocpd -d $O/proft_$cfg -o trace -- python bench.py --config configs/$cfg.config --steps 100 --warmup 20 --no_cpu_baseline --steady_steps 0 --parity_steps 0 --precondition 32 > $O/proft_$cfg.log 2>&1
+  DB=$(find $O/proft_$cfg -name "*.db" | head -1); python tools/rocpd_timeline.py $DB 60 > $O/${cfg}_step_timeline.txt 2>&1; tail -1 $O/${cfg}_step_timeline.txt | cut -c1-160; rm -rf $O/proft_$cfg
+done
 timeout 2400 python -m pytest tests -q --timeout 900 -m gpu 2>&1 | tail -12 | tee $O/tests_full.txt
 ls $O; du -sh $O
