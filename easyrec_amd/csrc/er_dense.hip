@@ -1815,7 +1815,10 @@ int er_bn_bwd_multi(const er_bn_layer* layers, int n, er_stream_t stream) {
     size_t off = 0;
     for (int i = base; i < base + m; ++i) {
       const er_bn_layer& q = layers[i];
-      ER_REQUIRE(q.x && q.dy && q.dx && q.B > 0 && q.N > 0 && q.dy_ld >= q.N, "er_bn_bwd_multi: layer %d: bad arguments", i);
+      // (dx == NULL with ready-made partial sums: the parameter gradients only - dx was written by the contraction that
+      // produced dy, er_gemm_problem.bn_dz_out)
+      ER_REQUIRE(q.x && q.dy && (q.dx || (q.partial && q.use_bn == ER_BN_FROZEN)) && q.B > 0 && q.N > 0 && q.dy_ld >= q.N,
+                 "er_bn_bwd_multi: layer %d: bad arguments", i);
       ER_REQUIRE(!q.use_bn || (q.save_mean && q.save_invstd), "er_bn_bwd_multi: layer %d: BatchNorm statistics missing", i);
       er::BnItem d = er::BnItem();
       d.x = q.x; d.bias = q.bias; d.gamma = q.gamma; d.beta = q.beta; d.yin = q.y_in; d.save_mean = q.save_mean;
@@ -1827,6 +1830,7 @@ int er_bn_bwd_multi(const er_bn_layer* layers, int n, er_stream_t stream) {
         ER_REQUIRE(q.chunks > 0 && q.chunks <= er::kInlineChunks, "er_bn_bwd_multi: layer %d: at most %d partials", i,
                    er::kInlineChunks);
         d.partial = q.partial; d.chunks = q.chunks;
+        d.dx_in_partial = q.dx ? 0 : 1;
       } else {
         d.chunks = er::choose_chunks(q.B, q.N);
         ER_REQUIRE(d.chunks <= er::kInlineChunks, "er_bn_bwd_multi: layer %d: too tall for the grouped form", i);

@@ -559,6 +559,11 @@ int er::plan_grouped(int layout, const er_gemm_problem* pr, int n, bool bf16, er
       a.bn.ld = q.bn_ld; a.bn.use_bn = q.bn_use_bn; a.bn.act = q.bn_act;
       a.bn.partial = q.bn_partial;
       a.bn.col0 = 0; a.bn.n_src = q.N;
+      if (q.bn_dz_out) {
+        ER_REQUIRE(q.bn_use_bn && q.bn_invstd, "er_gemm_grouped_f32: problem %d: bn_dz_out needs the layer's statistics", i);
+        a.bn.gamma = q.bn_gamma;
+        a.bn.dz_out = 1;
+      }
       any_bn = true;
     }
     if (q.fz_y) {

@@ -30,6 +30,12 @@ struct BnBwdEpi {
   // column c - col0 when 0 <= c - col0 < n_src (DeepFM: the deep tower's 64 columns inside d[sum(wide) | FM | deep],
   // model/deepfm.py:75-83); z / y / mean / invstd / gamma / beta / zbias / partial are the SOURCE layer's, n_src wide.
   int col0 = 0, n_src = 0;        // n_src == 0: the whole output (n_src = N, set by the host)
+  // dz_out != 0 (the producing layer normalises with the MOVING statistics - the experts of a multi-task model; col0 == 0,
+  // n_src == N): its whole backward is elementwise, dz = gamma * invstd * g with g the activation-masked accumulator, so the
+  // launch stores THAT instead of the accumulator and the layer's own backward pass disappears (its parameter gradients
+  // come from `partial`)
+  const float* gamma = nullptr;
+  int dz_out = 0;
 };
 
 struct GemmArgs {
@@ -671,8 +677,24 @@ __device__ __forceinline__ void gemm_f32_block(const GemmArgs& g, int bx, int bz
   if (g.col_stats)  // (host guarantees splits == 1) every thread takes part: it synchronises the workgroup
     tile_col_stats(acc, bv, m0 + wm * 32, g.M, col, g.N, wm, wn, lane, lds,
                    g.col_stats + static_cast<int64_t>(ty) * g.N * 3);
-  if (BN_EPI && g.bn.partial != nullptr)
+  if (BN_EPI && g.bn.partial != nullptr) {
     tile_bn_bwd_partial(acc, g.bn, py, pz, m0 + wm * 32, g.M, col < g.N ? col - g.bn.col0 : -1, g.bn.n_src, wm, wn, lane, lds, ty);
+    if (g.bn.dz_out) {  // (uniform per problem; host: col0 == 0, n_src == N, one k-split, no accumulate)
+      if (col >= g.N) return;
+      const float ga = g.bn.gamma ? g.bn.gamma[col] : 1.f;
+      const float is = g.bn.invstd[col];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+        if (row < g.M) {
+          float gg = acc[r] + bv;
+          if (g.bn.act == ER_ACT_RELU && !(py[r] > 0.f)) gg = 0.f;
+          g.C[static_cast<int64_t>(row) * g.ldc + col] = ga * is * gg;  // (bn_bwd_finalize_apply_body's frozen form)
+        }
+      }
+      return;
+    }
+  }
   if (DIN == 2) {
     // dcat tile (64 rows x [seg0 | seg1 | seg2 | seg3] of 16 embedding positions) -> LDS -> dh and the dq partials
     const DinGen& d = *dg;

@@ -130,7 +130,8 @@ class WgradSink(object):
 class BnSource(object):
   """What the dgrad GEMM of a consumer needs in order to emit, in its epilogue, the BatchNorm-backward column sums
   of the layer that produced its input (HipBackend.gemm_bn_bwd): that layer's z, y and batch statistics."""
-  __slots__ = ('z', 'zbias', 'y', 'mean', 'invstd', 'act', 'partial', 'dx_ptr', 'gamma', 'grad_bufs', 'beta', 'fused', 'pending')
+  __slots__ = ('z', 'zbias', 'y', 'mean', 'invstd', 'act', 'partial', 'dx_ptr', 'gamma', 'grad_bufs', 'beta', 'fused', 'pending',
+               'frozen', 'dz_done')
 
   def __init__(self, z, zbias, y, mean, invstd, act, gamma=None, grad_bufs=None, beta=None, fused=True):
     assert y is not None
@@ -143,6 +144,9 @@ class BnSource(object):
     # invstd are unwritten until the ONE consumer the model promised runs it (WideFmConcatFn: er_bn_apply_wide_fm) or
     # finish_pending_bn does; holds the arguments of HipBackend.bn_apply_from_stats
     self.pending = None
+    # frozen: the layer normalises with the MOVING statistics (its backward is elementwise); dz_done: the contraction that
+    # produced this layer's dy has already turned it into dz (er_gemm_problem.bn_dz_out, GroupedLinearFn.backward)
+    self.frozen, self.dz_done = False, False
 
 
 class BnColsView(object):
@@ -287,7 +291,7 @@ class GemmProblem(ctypes.Structure):  # = er_gemm_problem
               ('bn_use_bn', ctypes.c_int32), ('bn_act', ctypes.c_int32), ('bn_partial', ctypes.c_void_p),
               ('fz_bias', ctypes.c_void_p), ('fz_gamma', ctypes.c_void_p), ('fz_beta', ctypes.c_void_p),
               ('fz_mean', ctypes.c_void_p), ('fz_var', ctypes.c_void_p), ('fz_eps', ctypes.c_float), ('fz_act', ctypes.c_int32),
-              ('fz_y', ctypes.c_void_p), ('fz_save', ctypes.c_void_p)]
+              ('fz_y', ctypes.c_void_p), ('fz_save', ctypes.c_void_p), ('bn_gamma', ctypes.c_void_p), ('bn_dz_out', ctypes.c_int32)]
 
 
 class BnLayer(ctypes.Structure):  # = er_bn_layer
@@ -1047,7 +1051,8 @@ class HipBackend(object):
       B, N = x.shape
       assert dy.dim() == 2 and dy.stride(1) == 1 and dy.dtype == torch.float32 and B <= self.BN_MULTI_MAX_ROWS
       dev = x.device
-      dx = torch.empty_like(x)
+      dx_done = bool(l.get('dx_done'))  # (dy already holds dx: the contraction that produced it ran the elementwise backward)
+      dx = dy if dx_done else torch.empty_like(x)
       into = l.get('into')
       if into is not None:
         dbias, dgamma, dbeta = into
@@ -1065,7 +1070,8 @@ class HipBackend(object):
       q.dy, q.dy_ld = dy.data_ptr(), dy.stride(0)
       if partial is not None:
         q.partial, q.chunks = partial.data_ptr(), self.gemm_row_tiles(B)
-      q.dx, q.dbias, q.dgamma, q.dbeta = dx.data_ptr(), _ptr(dbias), _ptr(dgamma), _ptr(dbeta)
+      assert not dx_done or (partial is not None and int(l['use_bn']) == BN_FROZEN)
+      q.dx, q.dbias, q.dgamma, q.dbeta = (None if dx_done else dx.data_ptr()), _ptr(dbias), _ptr(dgamma), _ptr(dbeta)
       q.accumulate = int(into is not None)
       outs.append((dx, None, None, None) if into is not None else (dx, dbias, dgamma, dbeta))
     self._ck(self.lib.er_bn_bwd_multi(arr, len(layers), _stream()), 'er_bn_bwd_multi')
@@ -1112,7 +1118,10 @@ class HipBackend(object):
         assert stats.dtype == torch.float32 and stats.numel() >= self.gemm_row_tiles(M) * N * 3 and not accumulate
         q.col_stats = stats.data_ptr()
       if bn is not None:
-        src, partial = bn
+        src, partial = bn[:2]
+        if len(bn) > 2 and bn[2]:  # (the layer's elementwise backward in this launch's epilogue: frozen statistics only)
+          assert src.frozen and layout == GEMM_NT
+          q.bn_gamma, q.bn_dz_out = _ptr(src.gamma), 1
         assert src.z.shape == (M, N) and partial.numel() >= self.gemm_row_tiles(M) * N * 2 and not accumulate
         q.bn_z, q.bn_zbias = _ptr(src.z), _ptr(src.zbias)
         q.bn_y = _ptr(src.y)
@@ -1508,6 +1517,10 @@ class HipBackend(object):
   # the bias + frozen BatchNorm + activation of a multi-task model's expert layers inside the grouped contraction's epilogue
   # (er_gemm_problem.fz_*: one launch writes z and y; the depth's BatchNorm launch disappears) - A/B switch
   frozen_bn_epilogue = os.environ.get('EASYREC_AMD_FROZEN_BN_EPILOGUE', '1') != '0'
+
+  # ... and their elementwise backward (dz = gamma * invstd * masked dy) in the epilogue of the input-gradient contraction of
+  # the layer ABOVE (er_gemm_problem.bn_dz_out): the experts' BatchNorm-backward passes of all but the last depth disappear
+  frozen_dz_epilogue = os.environ.get('EASYREC_AMD_FROZEN_DZ_EPILOGUE', '1') != '0'
 
   # tall projections onto <= 4 columns (DIN's attention scores [B x L, 32] -> [B x L, 1]) by er_gemv_f32_bn_a - A/B switch
   tall_gemv = os.environ.get('EASYREC_AMD_TALL_GEMV', '1') != '0'
@@ -2991,8 +3004,12 @@ class GroupedLinearFn(torch.autograd.Function):
         else:
           M, N = dxs[e].shape
           partial = torch.empty(be.gemm_row_tiles(M) * N * 2, dtype=torch.float32, device=dxs[e].device)
-          problems.append((dzs[e], ws[e], dxs[e], None, False, None, (src, partial)))
+          # (a layer on the moving statistics: the launch also runs its elementwise backward - dxs[e] leaves as dz)
+          dz_out = bool(getattr(src, 'frozen', False) and getattr(be, 'frozen_dz_epilogue', False) and not src.dz_done)
+          problems.append((dzs[e], ws[e], dxs[e], None, False, None, (src, partial, dz_out)))
           src.partial, src.dx_ptr = partial, dxs[e].data_ptr()
+          if dz_out:
+            src.dz_done = True
       be.gemm_grouped(GEMM_NT, problems)
     for es in by_input.values():
       if len(es) == 1 and ctx.gsinks[es[0]] is None:
@@ -3121,6 +3138,11 @@ class GroupedBNActFn(torch.autograd.Function):
       if fused and mode == BN_BATCH:
         own = BnSource(zs[e], None, y, mean, invstd, act, gammas[e], None if gb is None else (gb[1], gb[2]), beta=betas[e],
                        fused=True)
+      elif fused and mode == BN_FROZEN and getattr(be, 'frozen_dz_epilogue', False) and gammas[e] is not None:
+        # (z is the bare contraction: the bias enters through zbias)
+        own = BnSource(zs[e], None if biases[e] is None else biases[e].detach(), y, mean, invstd, act, gammas[e].detach(), None,
+                       beta=betas[e], fused=True)
+        own.frozen = True
       ctx.owns.append(own)
       saved += [zs[e], biases[e], gammas[e], betas[e], y, mean, invstd]
     ctx.save_for_backward(*saved)
@@ -3139,19 +3161,22 @@ class GroupedBNActFn(torch.autograd.Function):
       z, bias, gamma, beta, y, mean, invstd = saved[7 * e:7 * e + 7]
       mode, act, gb = ctx.cfgs[e][0], ctx.cfgs[e][1], ctx.cfgs[e][6]
       dy = dys[e] if (dys[e].dim() == 2 and dys[e].stride(1) == 1) else dys[e].contiguous()
-      own, partial = ctx.owns[e], None
+      own, partial, dx_done = ctx.owns[e], None, False
       if own is not None:
         # the consumer's input-gradient launch already reduced the column sums, provided dy is exactly its output
-        if own.partial is not None and dy.data_ptr() == own.dx_ptr:
+        if own.partial is not None and dy.data_ptr() == own.dx_ptr and dy.stride(0) == dy.shape[1]:
           partial = own.partial
-        own.partial = None
+          dx_done = own.dz_done  # (... and, on frozen statistics, turned dy into dz: only the parameter gradients are left)
+        else:
+          assert not own.dz_done, 'a contraction wrote dz for a frozen BatchNorm layer whose backward received another tensor'
+        own.partial, own.dz_done = None, False
       into = None
       if gb is not None:
         bg, gg, betag = gb
         if (bias is None or bg is not None) and (gamma is None or (gg is not None and betag is not None)):
           into = (bg if bias is not None else None, gg, betag)
       layers.append(dict(x=z, bias=bias, gamma=gamma, beta=beta, y=y, mean=mean, invstd=invstd, dy=dy, use_bn=mode, act=act,
-                         partial=partial, into=into))
+                         partial=partial, into=into, dx_done=dx_done))
     outs = be.bn_bwd_multi(layers)
     dzs = tuple(o[0] for o in outs)
     none = (None,) * E

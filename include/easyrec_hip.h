@@ -895,6 +895,11 @@ typedef struct er_gemm_problem {
   const float* fz_bias; const float* fz_gamma; const float* fz_beta; const float* fz_mean; const float* fz_var;
   float fz_eps; int32_t fz_act;
   float* fz_y; float* fz_save;
+  /* bn_dz_out != 0 (with bn_partial; the producing layer normalises with the MOVING statistics): the launch stores
+   * dz = bn_gamma * bn_invstd * g - g the accumulator masked by the layer's activation - instead of the accumulator: the
+   * layer's whole elementwise backward (er_bn_act_bwd's frozen form) in the epilogue of the contraction that produces its dy;
+   * its parameter gradients follow from bn_partial (er_bn_bwd_multi with dx == NULL) */
+  const float* bn_gamma; int32_t bn_dz_out;
 } er_gemm_problem;
 int er_gemm_grouped_f32(int layout, const er_gemm_problem* problems_host, int n, er_stream_t stream);
 /* ... with the operands rounded to bf16 while staged (er_gemm_bf16's arithmetic: v_mfma_f32_32x32x16_bf16, fp32

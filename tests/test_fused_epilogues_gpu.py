@@ -495,3 +495,86 @@ def test_multi_task_step_with_the_frozen_batchnorm_in_the_contractions_epilogue_
   assert n_on > 0 and sum(seen) == n_on, (n_on, sum(seen))  # (the epilogue form ran, and only when switched on)
   assert f1 == f0 and s1 == s0, (f1, f0, s1, s0)
   assert torch.equal(m1, m0)
+
+
+@pytest.mark.parametrize('M,K,Ns', [(8192, 192, (256, 256)), (4096, 64, (128, 192, 33)), (100, 36, (37, 64))])
+def test_input_gradient_contraction_runs_the_frozen_batchnorm_backward_in_its_epilogue(hip, M, K, Ns):
+  """er_gemm_grouped_f32 (NT) with er_gemm_problem.bn_dz_out: dy = dz_next . W^T of a layer that normalises with the MOVING
+  statistics leaves the launch as dz = gamma * invstd * (dy masked by the ReLU) - bit for bit what er_bn_bwd_multi's frozen
+  form makes of the plain contraction's output - together with the column sums; the parameter gradients that
+  er_bn_bwd_multi(dx = None) derives from those sums agree with the two-pass form to 2e-5 of their scale (another summation
+  order: per 64-row tile instead of per row chunk)."""
+  g = torch.Generator().manual_seed(M + K + sum(Ns))
+  L = []
+  for n in Ns:
+    z = torch.randn(M, n, generator=g).to(DEV)
+    bias = torch.randn(n, generator=g).to(DEV)
+    gamma = (torch.rand(n, generator=g) + 0.5).to(DEV)
+    beta = (torch.randn(n, generator=g) * 0.2).to(DEV)
+    mm, mv = (torch.randn(n, generator=g) * 0.2).to(DEV), (torch.rand(n, generator=g) + 0.3).to(DEV)
+    y, mean, invstd = hip.bn_act_fwd(z, bias, gamma, beta, kernels.BN_FROZEN, 1e-3, 0.99, mm, mv, kernels.ACT_RELU)
+    dzn = (torch.randn(M, K, generator=g) * 0.1).to(DEV)
+    w = torch.randn(n, K, generator=g).to(DEV)
+    L.append(dict(z=z, bias=bias, gamma=gamma, beta=beta, y=y, mean=mean, invstd=invstd, dzn=dzn, w=w))
+  # apart: plain contraction, then the frozen backward (column sums + apply)
+  dy1 = [torch.empty(M, n, device=DEV) for n in Ns]
+  hip.gemm_grouped(kernels.GEMM_NT, [(l['dzn'], l['w'], dy1[i], None, False) for i, l in enumerate(L)])
+  ref = hip.bn_bwd_multi([dict(x=l['z'], bias=l['bias'], gamma=l['gamma'], beta=l['beta'], y=l['y'], mean=l['mean'],
+                               invstd=l['invstd'], dy=dy1[i], use_bn=kernels.BN_FROZEN, act=kernels.ACT_RELU, partial=None, into=None)
+                          for i, l in enumerate(L)])
+  # one launch + the parameter gradients from its sums
+  dy2 = [torch.full((M, n), float('nan'), device=DEV) for n in Ns]
+  parts = [torch.empty(hip.gemm_row_tiles(M) * n * 2, device=DEV) for n in Ns]
+  srcs = []
+  for l in L:
+    src = kernels.BnSource(l['z'], l['bias'], l['y'], l['mean'], l['invstd'], kernels.ACT_RELU, l['gamma'], None, beta=l['beta'], fused=True)
+    src.frozen = True
+    srcs.append(src)
+  hip.gemm_grouped(kernels.GEMM_NT, [(l['dzn'], l['w'], dy2[i], None, False, None, (srcs[i], parts[i], True)) for i, l in enumerate(L)])
+  got = hip.bn_bwd_multi([dict(x=l['z'], bias=l['bias'], gamma=l['gamma'], beta=l['beta'], y=l['y'], mean=l['mean'],
+                               invstd=l['invstd'], dy=dy2[i], use_bn=kernels.BN_FROZEN, act=kernels.ACT_RELU, partial=parts[i], into=None,
+                               dx_done=True) for i, l in enumerate(L)])
+  torch.cuda.synchronize()
+  for i in range(len(Ns)):
+    assert torch.equal(dy2[i], ref[i][0]), i                 # dz, bit for bit
+    assert got[i][0].data_ptr() == dy2[i].data_ptr()
+    for a, b in zip(got[i][1:], ref[i][1:]):                 # dbias, dgamma, dbeta
+      assert float((a - b).abs().max()) <= 2e-5 * max(1e-6, float(b.abs().max())), i
+
+
+def test_multi_task_step_with_the_frozen_batchnorm_backward_in_the_input_gradient_epilogue(hip, monkeypatch):
+  """MMoE (configs/mmoe_taobao_small.config, B = 4096) with the experts' elementwise BatchNorm backward inside the epilogue of
+  the input-gradient contraction of the layer above (HipBackend.frozen_dz_epilogue) and as the depth's BatchNorm-backward
+  launches: the first step's loss identical (same forward), the first Adam moments within 2e-5 of the largest, the second
+  step's loss within 1e-4."""
+  import os
+  from easyrec_amd.input.synthetic import SyntheticBatches
+  from easyrec_amd.model.easy_rec_estimator import EasyRecEstimator
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  cfg = os.path.join(root, 'configs', 'mmoe_taobao_small.config')
+  seen = []
+  real = kernels.HipBackend._gemm_problems
+
+  def spy(self, layout, problems, *a, **k):
+    seen.append(sum(1 for pr in problems if len(pr) > 6 and pr[6] is not None and len(pr[6]) > 2 and pr[6][2]))
+    return real(self, layout, problems, *a, **k)
+
+  monkeypatch.setattr(kernels.HipBackend, '_gemm_problems', spy)
+
+  def run(on):
+    monkeypatch.setattr(kernels.HipBackend, 'frozen_dz_epilogue', on)
+    est = EasyRecEstimator(cfg, device=DEV, batch_size=4096, seed=3).build()
+    gen = SyntheticBatches(est.pipeline_config.data_config, est.feature_configs, batch_size=4096, seed=11)
+    first = float(est.train_step(gen.next_batch())['total_loss'])
+    torch.cuda.synchronize()
+    m = est.varstore.slots['m'].clone()
+    second = float(est.train_step(gen.next_batch())['total_loss'])
+    return first, second, m
+
+  f1, s1, m1 = run(True)
+  n_on = sum(seen)
+  f0, s0, m0 = run(False)
+  assert n_on > 0 and sum(seen) == n_on, (n_on, sum(seen))
+  assert f1 == f0, (f1, f0)
+  assert float((m1 - m0).abs().max()) <= 2e-5 * float(m0.abs().max()), float((m1 - m0).abs().max())
+  assert abs(s1 - s0) <= 1e-4 * abs(s0), (s1, s0)

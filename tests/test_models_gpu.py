@@ -153,10 +153,12 @@ def test_grouped_batchnorm_launches_change_no_bit_model_level(name):
   B = 256
   states = []
   prev = kernels.HipBackend.grouped_bn
-  prev_fz = kernels.HipBackend.frozen_bn_epilogue
-  # (the frozen-BatchNorm epilogue of the grouped contraction rides on the grouped form and keeps its problems in one k-split -
-  # another summation order at this batch size; it has its own bit-identity test in test_fused_epilogues_gpu.py)
+  prev_fz, prev_dz = kernels.HipBackend.frozen_bn_epilogue, kernels.HipBackend.frozen_dz_epilogue
+  # (the frozen-BatchNorm epilogues of the grouped contractions ride on the grouped form: the forward one keeps its problems in
+  # one k-split, the backward one sums the parameter gradients per 64-row tile - other summation orders; they have their own
+  # tests in test_fused_epilogues_gpu.py)
   kernels.HipBackend.frozen_bn_epilogue = False
+  kernels.HipBackend.frozen_dz_epilogue = False
   try:
     for on in (True, False):
       kernels.HipBackend.grouped_bn = on
@@ -168,6 +170,7 @@ def test_grouped_batchnorm_launches_change_no_bit_model_level(name):
   finally:
     kernels.HipBackend.grouped_bn = prev
     kernels.HipBackend.frozen_bn_epilogue = prev_fz
+    kernels.HipBackend.frozen_dz_epilogue = prev_dz
   (sa, la), (sb, lb) = states
   assert la == lb
   for k in sb:
