@@ -88,6 +88,12 @@ def dense_bn_act(x, units, name, l2_reg, use_bias, use_bn, act_relu, training, b
     return kernels.tag_bn_source(y, src) if src is not None else y
   # no BatchNorm, or BatchNorm on the moving statistics (evaluation; in training the experts of the reference's MMoE /
   # DBMTL, whose MMOE layer is built without is_training): plain GEMM, then ONE bias + normalise + activation launch
+  be = kernels.hip()
+  if x.dim() == 2 and not use_bn and act == kernels.ACT_NONE and b is not None and torch.is_grad_enabled() and ctx.is_training and \
+      getattr(be, 'tall_gemv', False) and x.shape[0] >= be.BN_IN_STAGING_MIN_ROWS:
+    # a TALL plain projection (DIN's attention scores over B x L rows): the bias in the contraction's epilogue and its gradient
+    # as a column sum, instead of a bias launch forward and three (column sums, merge, copy) backward
+    return _linear(x, w, b, kernels.bn_source_of(x), kernels.grad_sink_of(x)).reshape(shape[:-1] + (units,))
   if x.dim() == 2:
     z = _linear(x, w, None, kernels.bn_source_of(x), kernels.grad_sink_of(x))  # (a pending BatchNorm apply behind x: LinearFn)
   else:
