@@ -2262,10 +2262,29 @@ emb_merge_pass_kernel(const uint32_t* __restrict__ kin, const uint32_t* __restri
   const int a0 = s_lo[0], a1 = s_lo[1];
   const int b0 = static_cast<int>(o0 - pair0) - a0, b1 = static_cast<int>(o1 - pair0) - a1;
   const int ta = a1 - a0, tb = b1 - b0;  // the tile's inputs: ta + tb == o1 - o0
-  for (int i = tid; i < ta; i += kBlock) sm[i] = merge_comp(kin, vin, a_beg + a0 + i);
-  for (int i = tid; i < tb; i += kBlock) sm[ta + i] = merge_comp(kin, vin, a_end + b0 + i);
-  __syncthreads();
   const int total = ta + tb;
+  {
+    // the tile's kMergeVt inputs per lane requested TOGETHER (slot i of the LDS tile comes from A below ta, from B behind it;
+    // a slot past the end reads the last input and is not stored): the two loops `for (i = tid; i < ta; i += kBlock)` this
+    // replaces had data-dependent trip counts, were not unrolled, and waited for each iteration's two loads before the next -
+    // up to nine dependent round trips per pass and workgroup, seven passes per DIN / MMoE step
+    uint32_t kv[kMergeVt], vv[kMergeVt];
+#pragma unroll
+    for (int j = 0; j < kMergeVt; ++j) {
+      int i = tid + j * kBlock;
+      i = i < total ? i : total - 1;
+      i = i < 0 ? 0 : i;
+      const int64_t at = i < ta ? a_beg + a0 + i : a_end + b0 + (i - ta);
+      kv[j] = kin[at];
+      vv[j] = vin[at];
+    }
+#pragma unroll
+    for (int j = 0; j < kMergeVt; ++j) {
+      const int i = tid + j * kBlock;
+      if (i < total) sm[i] = (static_cast<unsigned long long>(kv[j]) << 32) | vv[j];
+    }
+  }
+  __syncthreads();
   const int d = tid * kMergeVt < total ? tid * kMergeVt : total;
   int ia = merge_path(d, ta, tb, [&](int i) { return sm[i]; }, [&](int i) { return sm[ta + i]; });
   int ib = d - ia;
