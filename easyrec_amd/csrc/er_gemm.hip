@@ -155,7 +155,7 @@ gemv_bna_kernel(const float* __restrict__ x, int ldx, int M, int K, BnA b, const
 template <int NC>
 __global__ void __launch_bounds__(kBlock)
 wgrad_narrow_partial_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dz, int lddz, int rows, int K,
-                            int rows_per_chunk, int lpr, float* __restrict__ partial) {
+                            int rows_per_chunk, int lpr, float* __restrict__ partial, int with_bias) {
   constexpr int R = 4;  // rows per lane and trip, their loads in flight together
   __shared__ float sm[kBlock * 4 * NC];
   const int rpb = kBlock / lpr;            // row lanes
@@ -207,9 +207,45 @@ wgrad_narrow_partial_kernel(const float* __restrict__ x, int ldx, const float* _
         float t = 0.f;
         for (int q = 0; q < rpb; ++q) t = t + sm[(q * lpr + l2) * 4 * NC + jn];
         const int kk = 4 * c2 + jn / NC, n = jn % NC;
-        partial[(static_cast<int64_t>(blockIdx.x) * K + kk) * NC + n] = t;
+        partial[(static_cast<int64_t>(blockIdx.x) * (K + with_bias) + kk) * NC + n] = t;
       }
     }
+  }
+  if (with_bias) {
+    // row K of the chunk's record: the column sums of dz over the chunk (the bias gradient of the projection): every thread
+    // its rows (stride kBlock, four in flight), then the threads in order
+    float bs[NC];
+#pragma unroll
+    for (int n = 0; n < NC; ++n) bs[n] = 0.f;
+    for (int r0 = r_lo + threadIdx.x; r0 < r_hi; r0 += R * kBlock) {
+      float dv[R][NC];
+#pragma unroll
+      for (int u = 0; u < R; ++u) {
+        int r = r0 + u * kBlock;
+        r = r < r_hi ? r : r_hi - 1;
+#pragma unroll
+        for (int n = 0; n < NC; ++n) dv[u][n] = dz[static_cast<int64_t>(r) * lddz + n];
+      }
+#pragma unroll
+      for (int u = 0; u < R; ++u) {
+        if (r0 + u * kBlock < r_hi) {
+#pragma unroll
+          for (int n = 0; n < NC; ++n) bs[n] = bs[n] + dv[u][n];
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < NC; ++n) sm[threadIdx.x * NC + n] = bs[n];
+    __syncthreads();
+    for (int w = kBlock / 2; w >= 1; w >>= 1) {
+      if (static_cast<int>(threadIdx.x) < w) {
+#pragma unroll
+        for (int n = 0; n < NC; ++n) sm[threadIdx.x * NC + n] = sm[threadIdx.x * NC + n] + sm[(threadIdx.x + w) * NC + n];
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x < NC) partial[(static_cast<int64_t>(blockIdx.x) * (K + 1) + K) * NC + threadIdx.x] = sm[threadIdx.x];
   }
 }
 
@@ -217,11 +253,12 @@ wgrad_narrow_partial_kernel(const float* __restrict__ x, int ldx, const float* _
 // fixed tree over the lanes (a serial loop over ~512 chunks per element was a 90 us chain of dependent loads)
 __global__ void __launch_bounds__(kBlock)
 wgrad_narrow_reduce_kernel(const float* __restrict__ partial, int chunks, int KN, int N, float* __restrict__ dW, int lddw,
-                           int accumulate) {
+                           int accumulate, float* __restrict__ dbias, int stride) {
+  // (stride: floats per chunk record = KN, + N when the records carry the bias row; elements >= KN go to dbias)
   __shared__ float sm[kBlock];
   const int e = static_cast<int>(blockIdx.x);
   float t = 0.f;
-  for (int c = threadIdx.x; c < chunks; c += kBlock) t = t + partial[static_cast<int64_t>(c) * KN + e];
+  for (int c = threadIdx.x; c < chunks; c += kBlock) t = t + partial[static_cast<int64_t>(c) * stride + e];
   sm[threadIdx.x] = t;
   __syncthreads();
   for (int w = kBlock / 2; w >= 1; w >>= 1) {
@@ -229,7 +266,7 @@ wgrad_narrow_reduce_kernel(const float* __restrict__ partial, int chunks, int KN
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    float* p = dW + static_cast<int64_t>(e / N) * lddw + e % N;
+    float* p = e < KN ? dW + static_cast<int64_t>(e / N) * lddw + e % N : dbias + (e - KN);
     *p = accumulate ? *p + sm[0] : sm[0];
   }
 }
@@ -817,7 +854,8 @@ int er_gemv_f32_bn_a(int32_t M, int32_t N, int32_t K, const float* x, int32_t ld
 }
 
 int er_wgrad_tall_narrow(int32_t rows, int32_t K, int32_t N, const float* x, int32_t ldx, const float* dz, int32_t lddz,
-                         float* dW, int32_t lddw, int accumulate, float* scratch, int64_t scratch_floats, er_stream_t stream) {
+                         float* dW, int32_t lddw, float* dbias, int accumulate, float* scratch, int64_t scratch_floats,
+                         er_stream_t stream) {
   ER_REQUIRE(x && dz && dW && scratch && rows > 0 && K > 0 && N >= 1 && N <= 4, "er_wgrad_tall_narrow: bad arguments (1 <= N <= 4)");
   ER_REQUIRE(K % 4 == 0 && ldx >= K && ldx % 4 == 0 && lddz >= N && lddw >= N && (reinterpret_cast<uintptr_t>(x) & 15) == 0,
              "er_wgrad_tall_narrow: K and ldx multiples of 4, x 16-byte aligned");
@@ -828,20 +866,21 @@ int er_wgrad_tall_narrow(int32_t rows, int32_t K, int32_t N, const float* x, int
   int64_t rpc = er::ceil_div(rows, 512);
   rpc = er::ceil_div(rpc, trip) * trip;
   const int chunks = static_cast<int>(er::ceil_div(rows, rpc));
-  ER_REQUIRE(static_cast<int64_t>(chunks) * K * N <= scratch_floats, "er_wgrad_tall_narrow: scratch of %lld floats, need %lld",
-             (long long)scratch_floats, (long long)chunks * K * N);
+  const int wb = dbias ? 1 : 0;
+  ER_REQUIRE(static_cast<int64_t>(chunks) * (K + wb) * N <= scratch_floats, "er_wgrad_tall_narrow: scratch of %lld floats, need %lld",
+             (long long)scratch_floats, (long long)chunks * (K + wb) * N);
   hipStream_t s = er::as_stream(stream);
   dim3 grid(static_cast<unsigned>(chunks)), block(er::kBlock);
   const int irpc = static_cast<int>(rpc);
   switch (N) {
-    case 1: hipLaunchKernelGGL(er::wgrad_narrow_partial_kernel<1>, grid, block, 0, s, x, ldx, dz, lddz, rows, K, irpc, lpr, scratch); break;
-    case 2: hipLaunchKernelGGL(er::wgrad_narrow_partial_kernel<2>, grid, block, 0, s, x, ldx, dz, lddz, rows, K, irpc, lpr, scratch); break;
-    case 3: hipLaunchKernelGGL(er::wgrad_narrow_partial_kernel<3>, grid, block, 0, s, x, ldx, dz, lddz, rows, K, irpc, lpr, scratch); break;
-    default: hipLaunchKernelGGL(er::wgrad_narrow_partial_kernel<4>, grid, block, 0, s, x, ldx, dz, lddz, rows, K, irpc, lpr, scratch); break;
+    case 1: hipLaunchKernelGGL(er::wgrad_narrow_partial_kernel<1>, grid, block, 0, s, x, ldx, dz, lddz, rows, K, irpc, lpr, scratch, wb); break;
+    case 2: hipLaunchKernelGGL(er::wgrad_narrow_partial_kernel<2>, grid, block, 0, s, x, ldx, dz, lddz, rows, K, irpc, lpr, scratch, wb); break;
+    case 3: hipLaunchKernelGGL(er::wgrad_narrow_partial_kernel<3>, grid, block, 0, s, x, ldx, dz, lddz, rows, K, irpc, lpr, scratch, wb); break;
+    default: hipLaunchKernelGGL(er::wgrad_narrow_partial_kernel<4>, grid, block, 0, s, x, ldx, dz, lddz, rows, K, irpc, lpr, scratch, wb); break;
   }
   ER_LAUNCH_CHECK();
-  hipLaunchKernelGGL(er::wgrad_narrow_reduce_kernel, dim3(static_cast<unsigned>(K * N)), block, 0, s, scratch, chunks, K * N, N,
-                     dW, lddw, accumulate);
+  hipLaunchKernelGGL(er::wgrad_narrow_reduce_kernel, dim3(static_cast<unsigned>((K + wb) * N)), block, 0, s, scratch, chunks, K * N, N,
+                     dW, lddw, accumulate, dbias, (K + wb) * N);
   ER_LAUNCH_CHECK();
   return 0;
 }

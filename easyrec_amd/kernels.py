@@ -1552,17 +1552,18 @@ class HipBackend(object):
             x.shape[1] % 4 == 0 and x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and dz.stride(1) == 1 and
             x.dtype == torch.float32 and dz.dtype == torch.float32)
 
-  def wgrad_tall_narrow(self, x, dz, out, accumulate=True):
+  def wgrad_tall_narrow(self, x, dz, out, accumulate=True, bias_grad=None):
     """out [K, N <= 4] (+)= x^T . dz for a tall x [rows, K] (er_wgrad_tall_narrow: the weight gradient of DIN's attention score
     projection, which stalled the grouped weight-gradient launch on its [rows, 1] operand)"""
     rows, K = x.shape
     N = dz.shape[1]
     assert out.shape == (K, N) and out.stride(1) == 1 and dz.shape[0] == rows
-    scratch = torch.empty(513 * K * N, dtype=torch.float32, device=x.device)
+    assert bias_grad is None or (bias_grad.is_contiguous() and bias_grad.numel() == N)
+    scratch = torch.empty(513 * (K + 1) * N, dtype=torch.float32, device=x.device)
     if self.op_log is not None:
       self.op_log.append(('er::wgrad_narrow_partial_kernel<%d>' % N, 2.0 * rows * N * K))
     self._ck(self.lib.er_wgrad_tall_narrow(rows, K, N, _p(x), ctypes.c_int32(x.stride(0)), _p(dz), ctypes.c_int32(dz.stride(0)),
-                                           _p(out), ctypes.c_int32(out.stride(0)), int(bool(accumulate)), _p(scratch),
+                                           _p(out), ctypes.c_int32(out.stride(0)), _p(bias_grad), int(bool(accumulate)), _p(scratch),
                                            ctypes.c_int64(scratch.numel()), _stream()), 'er_wgrad_tall_narrow')
     return out
 
@@ -2686,9 +2687,17 @@ class LinearFn(torch.autograd.Function):
     dx = dw = db = None
     if ctx.needs_input_grad[0]:
       dx = _dgrad(be, dy, w, ctx.src, ctx.bf16, ctx.gsink, x, ctx.slots)
+    with_bias = False
     if ctx.needs_input_grad[1]:
-      dw = _wgrad(be, x, dy, ctx.w_grad, ctx.bf16, ctx.sink)
-    if ctx.has_bias and ctx.needs_input_grad[2]:
+      # (a tall projection onto <= 4 columns: weight AND bias gradient from one pass over dy - HipBackend.wgrad_tall_narrow)
+      with_bias = bool(ctx.has_bias and ctx.needs_input_grad[2] and ctx.b_grad is not None and ctx.w_grad is not None and
+                       not ctx.bf16 and hasattr(be, 'wgrad_tall_narrow_ok') and be.wgrad_tall_narrow_ok(x, dy) and
+                       ctx.w_grad.stride(-1) == 1 and ctx.b_grad.is_contiguous())
+      if with_bias:
+        be.wgrad_tall_narrow(x, dy, ctx.w_grad, accumulate=True, bias_grad=ctx.b_grad)
+      else:
+        dw = _wgrad(be, x, dy, ctx.w_grad, ctx.bf16, ctx.sink)
+    if ctx.has_bias and ctx.needs_input_grad[2] and not with_bias:
       if ctx.b_grad is not None:
         be.colsum(dy, out=ctx.b_grad, accumulate=True)  # straight into the flat gradient buffer
       else:

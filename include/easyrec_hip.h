@@ -1068,9 +1068,11 @@ int er_gemv_f32_bn_a(int32_t M, int32_t N, int32_t K, const float* x, int32_t ld
                      int32_t ldc, const float* bias, er_stream_t stream);
 /* The weight gradient of such a projection: dW [K][N <= 4] (+)= x^T . dz, x [rows][ldx] (K columns), dz [rows][lddz] (the
  * MatMul gradient TF schedules for that tf.layers.dense, reference layers/dnn.py:57-62) - rows in ~512 chunks, per-chunk sums
- * in a fixed lane order, then the chunks in order.  scratch: at least 513 * K * N floats, the caller's (stream-ordered). */
+ * in a fixed lane order, then the chunks in order; dbias [N] (NULL: no) (+)= the column sums of dz (the BiasAdd gradient), from
+ * the same pass.  scratch: at least 513 * (K + 1) * N floats, the caller's (stream-ordered). */
 int er_wgrad_tall_narrow(int32_t rows, int32_t K, int32_t N, const float* x, int32_t ldx, const float* dz, int32_t lddz,
-                         float* dW, int32_t lddw, int accumulate, float* scratch, int64_t scratch_floats, er_stream_t stream);
+                         float* dW, int32_t lddw, float* dbias, int accumulate, float* scratch, int64_t scratch_floats,
+                         er_stream_t stream);
 /* DIN's first attention layer WITHOUT the [B, L, 4E] block (north_star: "DIN-attention as fused HIP kernels"; reference
  * model/multi_tower_din.py:62-80 builds tf.concat([q, h, q - h, q * h], axis=-1) and feeds it to the attention DNN,
  * layers/dnn.py:57-79): the three contractions of the layer take q [B][ldq] and h [B * L][ldh] (E columns each) and form

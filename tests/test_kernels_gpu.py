@@ -1773,6 +1773,18 @@ def test_weight_gradient_of_a_tall_narrow_projection(rows, K, N):
   hip.wgrad_tall_narrow(x, dz, out2, accumulate=False)
   torch.cuda.synchronize()
   assert torch.equal(out, out2)
+  # ... with the bias gradient (the column sums of dz) from the same pass
+  out3, db = torch.empty(K, N, device=DEV), torch.full((N,), 0.5, device=DEV)
+  hip.wgrad_tall_narrow(x, dz, out3, accumulate=False, bias_grad=db)
+  torch.cuda.synchronize()
+  assert torch.equal(out3, out)
+  bref = dz.double().sum(0)
+  assert float((db.double() - bref).abs().max()) <= 2e-5 * max(1e-6, float(bref.abs().max()), float(dz.abs().sum(0).max()) * 1e-2)
+  db2 = torch.full((N,), 0.5, device=DEV)
+  out4 = out.clone()
+  hip.wgrad_tall_narrow(x, dz, out4, accumulate=True, bias_grad=db2)
+  torch.cuda.synchronize()
+  assert float(((db2 - 0.5).double() - bref).abs().max()) <= 2e-5 * max(1e-6, float(bref.abs().max()), float(dz.abs().sum(0).max()) * 1e-2) + 1e-6
 
 
 def _misaligned(t):
