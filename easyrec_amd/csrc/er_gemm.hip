@@ -315,6 +315,15 @@ gemm_f32_grouped_bn_bwd_kernel(GroupedArgs ga) {
   gemm_f32_block<A_KC, B_KC, true>(ga.p[c.p], c.tile, c.split, lds, c.plain);
 }
 
+// ... input gradients (NT) of which some also store the producing layer's dz (BnBwdEpi.dz_out: frozen statistics)
+__global__ void __launch_bounds__(kBlock)
+gemm_f32_grouped_bn_bwd_dz_kernel(GroupedArgs ga) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * 2 * kOpTile];
+  const GroupedCoords c = grouped_coords(ga, blockIdx.x);
+  if (c.split < 0) return;
+  gemm_f32_block<true, true, true, kEpiFrozenDz>(ga.p[c.p], c.tile, c.split, lds, c.plain);
+}
+
 // ------------------------------------------------------------------------------------------------
 // bf16 inputs (rounded from fp32 while staging), fp32 accumulate.  LDS: As[m][k], Bs[n][k] in bf16, row
 // stride 40 halves (80 B): the 16-byte fragment reads of a 16-lane group hit 16 distinct bank quads.
@@ -577,6 +586,8 @@ int er::plan_grouped(int layout, const er_gemm_problem* pr, int n, bool bf16, er
   size_t ws_floats = 0;
   any_bn = false;
   any_fz = false;
+  plan->any_dz = false;
+  bool& any_dz = plan->any_dz;
   int n_splits[er::kMaxGroup], xcd_ok[er::kMaxGroup];
   for (int i = 0; i < n; ++i) {
     const er_gemm_problem& q = pr[i];
@@ -598,8 +609,10 @@ int er::plan_grouped(int layout, const er_gemm_problem* pr, int n, bool bf16, er
       a.bn.col0 = 0; a.bn.n_src = q.N;
       if (q.bn_dz_out) {
         ER_REQUIRE(q.bn_use_bn && q.bn_invstd, "er_gemm_grouped_f32: problem %d: bn_dz_out needs the layer's statistics", i);
+        ER_REQUIRE(layout == ER_GEMM_NT, "er_gemm_grouped_f32: problem %d: bn_dz_out is an input-gradient (NT) epilogue", i);
         a.bn.gamma = q.bn_gamma;
         a.bn.dz_out = 1;
+        any_dz = true;
       }
       any_bn = true;
     }
@@ -690,6 +703,7 @@ int gemm_grouped_f32(int layout, const er_gemm_problem* pr, int n, er_stream_t s
   const bool any_bn = plan.any_bn;
   dim3 grid(static_cast<unsigned>(er::grouped_grid(ga))), block(er::kBlock);
   ER_REQUIRE(!plan.any_fz || (!bf16 && !any_bn && layout == ER_GEMM_NN), "er_gemm_grouped: the frozen-BatchNorm epilogue is fp32 NN only");
+  ER_REQUIRE(!plan.any_dz || !bf16, "er_gemm_grouped: bn_dz_out is fp32 only");
   if (plan.any_fz) {
     hipLaunchKernelGGL(er::gemm_f32_grouped_fz_kernel, grid, block, 0, s, ga);
   } else if (bf16) {
@@ -699,6 +713,9 @@ int gemm_grouped_f32(int layout, const er_gemm_problem* pr, int n, er_stream_t s
       case ER_GEMM_TN: hipLaunchKernelGGL((er::gemm_bf16_grouped_kernel<false, false>), grid, block, 0, s, ga); break;
       default: er::set_error("er_gemm_grouped_bf16: unknown layout %d", layout); return 2;
     }
+  } else if (plan.any_dz) {
+    ER_REQUIRE(!bf16 && layout == ER_GEMM_NT, "er_gemm_grouped: bn_dz_out is fp32 NT only");
+    hipLaunchKernelGGL(er::gemm_f32_grouped_bn_bwd_dz_kernel, grid, block, 0, s, ga);
   } else if (any_bn) {
     switch (layout) {
       case ER_GEMM_NN: hipLaunchKernelGGL((er::gemm_f32_grouped_bn_bwd_kernel<true, false>), grid, block, 0, s, ga); break;

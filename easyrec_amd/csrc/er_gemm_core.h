@@ -61,6 +61,9 @@ struct GemmArgs {
   float fz_eps = 0.f;
 };
 constexpr int kEpiFrozenBn = 7;  // (an XEPI value beside ER_EPI_CROSS_FWD / _BWD)
+constexpr int kEpiFrozenDz = 8;  // (with BN_EPI: BnBwdEpi.dz_out is honoured - its own instantiation: inside the plain BN_EPI
+                                 //  kernels the extra branch kept y's 16 values alive past the column sums and cost DeepFM's five
+                                 //  input-gradient launches 40.8 -> 47.5 us)
 
 // Loads 4 consecutive elements along the CONTIGUOUS dimension of the operand tile.
 //   K_CONTIG : elements (mn, k..k+3);  else: elements (mn..mn+3, k)
@@ -533,7 +536,7 @@ __device__ __forceinline__ void gemm_f32_block(const GemmArgs& g, int bx, int bz
   // cross epilogues: x0 / x_l (forward), dout / du_in and the lower layer's x0 / u / x_l / dx0 (backward) of the 16 positions
   float qa[XEPI ? 16 : 1], qb[XEPI ? 16 : 1], qc[XEPI == ER_EPI_CROSS_BWD ? 16 : 1], qd[XEPI == ER_EPI_CROSS_BWD ? 16 : 1],
       qe[XEPI == ER_EPI_CROSS_BWD ? 16 : 1], qf[XEPI == ER_EPI_CROSS_BWD ? 16 : 1];
-  if (XEPI && XEPI != kEpiFrozenBn) {
+  if (XEPI && XEPI != kEpiFrozenBn && XEPI != kEpiFrozenDz) {
     int c = n0 + wn * 32 + (lane & 31);
     c = c < g.N ? c : g.N - 1;
     const bool with_diag = xe->diag != 0.f;
@@ -679,7 +682,7 @@ __device__ __forceinline__ void gemm_f32_block(const GemmArgs& g, int bx, int bz
                    g.col_stats + static_cast<int64_t>(ty) * g.N * 3);
   if (BN_EPI && g.bn.partial != nullptr) {
     tile_bn_bwd_partial(acc, g.bn, py, pz, m0 + wm * 32, g.M, col < g.N ? col - g.bn.col0 : -1, g.bn.n_src, wm, wn, lane, lds, ty);
-    if (g.bn.dz_out) {  // (uniform per problem; host: col0 == 0, n_src == N, one k-split, no accumulate)
+    if (XEPI == kEpiFrozenDz && g.bn.dz_out) {  // (uniform per problem; host: col0 == 0, n_src == N, one k-split, no accumulate)
       if (col >= g.N) return;
       const float ga = g.bn.gamma ? g.bn.gamma[col] : 1.f;
       const float is = g.bn.invstd[col];
@@ -971,6 +974,7 @@ struct GroupedPlan {
   GroupedReduceArgs ra;
   bool any_bn;
   bool any_fz;  // a problem with the frozen-BatchNorm forward epilogue (GemmArgs.fz_y)
+  bool any_dz;  // a problem whose BatchNorm-backward epilogue also stores dz (BnBwdEpi.dz_out)
 };
 // the two regions of a grouped grid from the problems' tile and k-split counts (GroupedArgs); by_xcd[p] 0: problem p in
 // the legacy region only
